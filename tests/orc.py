@@ -1,0 +1,259 @@
+"""ctypes wrapper around oracle/liblis_oracle.so (the CPU checker).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liblis_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "liblis_ref.so")
+
+I = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+D = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+ci, cd = C.c_int, C.c_double
+
+
+class Result(C.Structure):
+    _fields_ = [("iter", ci), ("retcode", ci), ("resid", cd)]
+
+
+def build():
+    """(Re)build the oracle and, when /root/reference is present, oracle/_ref."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "-j8"], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    src = os.path.join(ORACLE_DIR, "lis_oracle.c")
+    if (not os.path.exists(ORACLE_SO)
+            or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src)):
+        build()
+    L = C.CDLL(ORACLE_SO)
+    P = C.c_void_p
+    sig = {
+        "orc_gen_poisson1d": (ci, [ci, ci, ci, I, I, D]),
+        "orc_gen_poisson3d": (ci, [ci, ci, ci, ci, ci, ci, I, I, D]),
+        "orc_spmv_csr": (None, [ci, I, I, D, D, D]),
+        "orc_spmv_csc": (None, [ci, ci, I, I, D, D, D]),
+        "orc_spmv_ell": (None, [ci, ci, I, D, D, D]),
+        "orc_spmv_dia": (None, [ci, ci, ci, I, D, D, D]),
+        "orc_spmv_jad": (None, [ci, ci, ci, I, I, I, D, D, D]),
+        "orc_spmv_bsr": (None, [ci, ci, ci, ci, I, I, D, D, D]),
+        "orc_ell_maxnzr": (ci, [ci, I]),
+        "orc_csr2ell": (None, [ci, I, I, D, ci, I, D]),
+        "orc_csr2csc": (None, [ci, ci, I, I, D, I, I, D]),
+        "orc_csr2dia": (ci, [ci, ci, I, I, D, P, P]),
+        "orc_csr2jad": (None, [ci, I, I, D, ci, I, I, I, D]),
+        "orc_csr2bsr": (ci, [ci, I, I, D, ci, ci, I, P, P]),
+        "orc_csr_diagonal": (None, [ci, I, I, D, D]),
+        "orc_dot": (cd, [ci, D, D]),
+        "orc_nrm2": (cd, [ci, D]),
+        "orc_nrm1": (cd, [ci, D]),
+        "orc_axpy": (None, [ci, cd, D, D]),
+        "orc_xpay": (None, [ci, D, cd, D]),
+        "orc_axpyz": (None, [ci, cd, D, D, D]),
+        "orc_scale": (None, [ci, cd, D]),
+        "orc_pmul": (None, [ci, D, D, D]),
+        "orc_reciprocal": (None, [ci, D]),
+        "orc_cg": (Result, [ci, I, I, D, D, D, ci, cd, ci, ci, P]),
+        "orc_bicgstab": (Result, [ci, I, I, D, D, D, ci, cd, ci, ci, P]),
+        "orc_gmres": (Result, [ci, I, I, D, D, D, ci, cd, ci, ci, ci, P]),
+    }
+    for k, (r, a) in sig.items():
+        f = getattr(L, k)
+        f.restype, f.argtypes = r, a
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------- generators
+def poisson1d(gn, is_=0, ie=None):
+    ie = gn if ie is None else ie
+    n = ie - is_
+    ptr = np.zeros(n + 1, np.int32)
+    idx = np.zeros(3 * n, np.int32)
+    val = np.zeros(3 * n, np.float64)
+    nnz = lib().orc_gen_poisson1d(gn, is_, ie, ptr, idx, val)
+    return ptr, idx[:nnz].copy(), val[:nnz].copy()
+
+
+def poisson3d(l, m, n, sort_cols=False, is_=0, ie=None):
+    gn = l * m * n
+    ie = gn if ie is None else ie
+    rows = ie - is_
+    ptr = np.zeros(rows + 1, np.int32)
+    idx = np.zeros(7 * rows, np.int32)
+    val = np.zeros(7 * rows, np.float64)
+    nnz = lib().orc_gen_poisson3d(l, m, n, is_, ie, int(sort_cols), ptr, idx, val)
+    return ptr, idx[:nnz].copy(), val[:nnz].copy()
+
+
+def random_csr(n, avg_nnz, seed, ncols=None, sort_cols=False, empty_rows=True, long_row=None):
+    """Irregular CSR with distinct columns per row, values in [-1,1).  Test input, no reference analogue."""
+    rng = np.random.default_rng(seed)
+    ncols = n if ncols is None else ncols
+    lens = rng.poisson(avg_nnz, n).astype(np.int64)
+    lens = np.minimum(lens, ncols)
+    if empty_rows and n > 4:
+        lens[rng.integers(0, n, max(1, n // 16))] = 0
+    if long_row is not None and n > 0:
+        lens[rng.integers(0, n)] = min(long_row, ncols)
+    ptr = np.zeros(n + 1, np.int32)
+    ptr[1:] = np.cumsum(lens)
+    idx = np.empty(int(ptr[-1]), np.int32)
+    for r in range(n):
+        k = int(lens[r])
+        if k:
+            cols = rng.choice(ncols, k, replace=False).astype(np.int32)
+            if sort_cols:
+                cols.sort()
+            idx[ptr[r]:ptr[r + 1]] = cols
+    val = rng.uniform(-1, 1, int(ptr[-1]))
+    return ptr, idx, val
+
+
+# ---------------------------------------------------------------- spmv
+def spmv_csr(ptr, idx, val, x):
+    n = len(ptr) - 1
+    y = np.empty(n)
+    lib().orc_spmv_csr(n, ptr, idx, val, x, y)
+    return y
+
+
+def spmv_csc(n, np_, ptr, idx, val, x):
+    y = np.empty(n)
+    lib().orc_spmv_csc(n, np_, ptr, idx, val, x, y)
+    return y
+
+
+def spmv_ell(n, maxnzr, idx, val, x):
+    y = np.empty(n)
+    lib().orc_spmv_ell(n, maxnzr, idx, val, x, y)
+    return y
+
+
+def spmv_dia(n, nnd, off, val, x, nchunks=1):
+    y = np.empty(n)
+    lib().orc_spmv_dia(n, nnd, nchunks, off, val, x, y)
+    return y
+
+
+def spmv_jad(n, maxnzr, perm, ptr, idx, val, x, nchunks=1):
+    y = np.empty(n)
+    lib().orc_spmv_jad(n, maxnzr, nchunks, perm, ptr, idx, val, x, y)
+    return y
+
+
+def spmv_bsr(n, nr, bnr, bnc, bptr, bidx, val, x):
+    y = np.zeros(nr * bnr)
+    xx = np.zeros(max(len(x), (int(bidx.max()) + 1) * bnc if len(bidx) else 0))
+    xx[:len(x)] = x
+    lib().orc_spmv_bsr(n, nr, bnr, bnc, bptr, bidx, val, xx, y)
+    return y[:n].copy()
+
+
+# ---------------------------------------------------------------- conversions
+def csr2ell(ptr, idx, val):
+    n = len(ptr) - 1
+    mx = lib().orc_ell_maxnzr(n, ptr)
+    eidx = np.empty(mx * n, np.int32)
+    eval_ = np.empty(mx * n)
+    lib().orc_csr2ell(n, ptr, idx, val, mx, eidx, eval_)
+    return mx, eidx, eval_
+
+
+def csr2csc(ptr, idx, val, np_=None):
+    n = len(ptr) - 1
+    np_ = n if np_ is None else np_
+    cptr = np.empty(np_ + 1, np.int32)
+    cidx = np.empty(len(idx), np.int32)
+    cval = np.empty(len(idx))
+    lib().orc_csr2csc(n, np_, ptr, idx, val, cptr, cidx, cval)
+    return cptr, cidx, cval
+
+
+def sort_rows(ptr, idx, val):
+    idx = idx.copy()
+    val = val.copy()
+    for r in range(len(ptr) - 1):
+        s, e = ptr[r], ptr[r + 1]
+        o = np.argsort(idx[s:e], kind="stable")
+        idx[s:e] = idx[s:e][o]
+        val[s:e] = val[s:e][o]
+    return idx, val
+
+
+def csr2dia(ptr, idx, val):
+    """Input rows must be column-sorted (the reference sorts its input in place first)."""
+    n = len(ptr) - 1
+    nnz = len(idx)
+    nnd = lib().orc_csr2dia(n, nnz, ptr, idx, val, None, None)
+    off = np.empty(nnd, np.int32)
+    dval = np.empty(nnd * n)
+    lib().orc_csr2dia(n, nnz, ptr, idx, val, _p(off), _p(dval))
+    return nnd, off, dval
+
+
+def csr2jad(ptr, idx, val):
+    n = len(ptr) - 1
+    mx = lib().orc_ell_maxnzr(n, ptr)
+    perm = np.empty(n, np.int32)
+    jptr = np.empty(mx + 1, np.int32)
+    jidx = np.empty(len(idx), np.int32)
+    jval = np.empty(len(idx))
+    lib().orc_csr2jad(n, ptr, idx, val, mx, perm, jptr, jidx, jval)
+    return mx, perm, jptr, jidx, jval
+
+
+def csr2bsr(ptr, idx, val, bnr=2, bnc=2):
+    n = len(ptr) - 1
+    nr = 1 + (n - 1) // bnr
+    bptr = np.empty(nr + 1, np.int32)
+    bnnz = lib().orc_csr2bsr(n, ptr, idx, val, bnr, bnc, bptr, None, None)
+    bidx = np.empty(bnnz, np.int32)
+    bval = np.empty(bnnz * bnr * bnc)
+    lib().orc_csr2bsr(n, ptr, idx, val, bnr, bnc, bptr, _p(bidx), _p(bval))
+    return nr, bptr, bidx, bval
+
+
+def csr_diagonal(ptr, idx, val):
+    n = len(ptr) - 1
+    d = np.empty(n)
+    lib().orc_csr_diagonal(n, ptr, idx, val, d)
+    return d
+
+
+# ---------------------------------------------------------------- solvers
+def _solve(fn, ptr, idx, val, b, x0, precon, tol, maxiter, extra):
+    n = len(ptr) - 1
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
+    rh = np.zeros(maxiter + 2)
+    pre = {"none": 0, "jacobi": 1}[precon]
+    args = [n, ptr, idx, val, np.ascontiguousarray(b), x, pre, float(tol), int(maxiter)]
+    args += extra + [int(x0 is None), _p(rh)]
+    res = fn(*args)
+    return x, res.iter, res.retcode, res.resid, rh
+
+
+def cg(ptr, idx, val, b, x0=None, precon="none", tol=1e-12, maxiter=1000):
+    return _solve(lib().orc_cg, ptr, idx, val, b, x0, precon, tol, maxiter, [])
+
+
+def bicgstab(ptr, idx, val, b, x0=None, precon="none", tol=1e-12, maxiter=1000):
+    return _solve(lib().orc_bicgstab, ptr, idx, val, b, x0, precon, tol, maxiter, [])
+
+
+def gmres(ptr, idx, val, b, x0=None, precon="none", tol=1e-12, maxiter=1000, restart=40):
+    return _solve(lib().orc_gmres, ptr, idx, val, b, x0, precon, tol, maxiter, [int(restart)])

@@ -1,0 +1,139 @@
+/*
+ * liship.h -- kernel-level C ABI of the MI355X (gfx950) hot path: plain device pointers and sizes.
+ *
+ * This is the layer a Lis maintainer binds from C: each entry point replaces one
+ * OpenMP hot loop of the reference (anishida/lis 2.1.11; citations are file:line under /root/reference).
+ * Everything here is hand-written HIP; there is no CPU fallback -- a call on a machine without a
+ * gfx950 device fails with a HIP error code.
+ *
+ * Conventions
+ *   - all array arguments are DEVICE pointers (hipMalloc'd), int32 indices, f64 scalars
+ *     (LIS_INT / LIS_SCALAR of the reference's default build, include/lis.h:446,461);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous;
+ *   - return value: 0 on success, otherwise the hipError_t of the failing runtime call, or
+ *     LISHIP_ERR_ARG (-1) for an argument the kernel cannot serve;
+ *   - arithmetic: one rounded multiply and one rounded add per term (no FMA contraction), rows summed
+ *     strictly in stored order starting from +0.0 -- bit-identical to the reference's CPU loops.
+ */
+#ifndef LISHIP_H
+#define LISHIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LISHIP_ERR_ARG (-1)
+
+/* ------------------------------------------------------------------ device / memory utilities */
+int  liship_device_count(int *count);
+int  liship_set_device(int device);
+int  liship_get_device(int *device);
+int  liship_device_name(char *buf, int buflen);           /* e.g. "gfx950:sramecc+:xnack-" */
+int  liship_malloc(void **dptr, size_t bytes);
+int  liship_free(void *dptr);
+int  liship_memset(void *dptr, int byte, size_t bytes, void *stream);
+int  liship_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int  liship_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int  liship_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int  liship_stream_create(void **stream);
+int  liship_stream_destroy(void *stream);
+int  liship_stream_synchronize(void *stream);
+int  liship_device_synchronize(void);
+/* HIP-event stopwatch on `stream`: start/stop bracket a region, elapsed_ms reads it after stop+sync */
+int  liship_timer_create(void **timer);
+int  liship_timer_destroy(void *timer);
+int  liship_timer_start(void *timer, void *stream);
+int  liship_timer_stop(void *timer, void *stream);
+int  liship_timer_elapsed_ms(void *timer, float *ms);
+const char *liship_error_string(int code);
+
+/* ------------------------------------------------------------------ CSR SpMV
+ * replaces lis_matvec_csr, src/matvec/lis_matvec_csr.c:90-110 (unsplit branch):
+ *     y[i] = sum_{j=ptr[i]}^{ptr[i+1]-1} value[j] * x[index[j]]      (in stored order)
+ *
+ * A plan is the nnz-balanced row split of one matrix (merge-path coordinates row+nnz, whole rows per
+ * workgroup); it depends only on ptr[] and is built once per matrix on the device. */
+typedef struct liship_csr_plan_s *liship_csr_plan_t;
+int  liship_csr_plan_create(liship_csr_plan_t *plan, int n, const int *ptr, void *stream);
+int  liship_csr_plan_destroy(liship_csr_plan_t plan);
+int  liship_csr_plan_info(liship_csr_plan_t plan, int *n, long long *nnz, int *nblocks);
+int  liship_spmv_csr_f64(liship_csr_plan_t plan, const int *ptr, const int *index,
+                         const double *value, const double *x, double *y, void *stream);
+/* same product restricted to rows [row_begin,row_end) (used to overlap the halo exchange) */
+int  liship_spmv_csr_rows_f64(liship_csr_plan_t plan, int row_begin, int row_end, const int *ptr,
+                              const int *index, const double *value, const double *x, double *y,
+                              void *stream);
+/* tuning knobs for experiments (bench/profiling only): variant 0 = default */
+int  liship_spmv_csr_set_variant(int variant);
+
+/* ------------------------------------------------------------------ other formats
+ * ELL   lis_matvec_ell  src/matvec/lis_matvec_ell.c:113-128   value/index column-major [maxnzr][n]
+ * DIA   lis_matvec_dia  src/matvec/lis_matvec_dia.c:148-172   ONE-chunk layout value[d*n+i], offsets index[nnd]
+ * JAD   lis_matvec_jad  src/matvec/lis_matvec_jad.c:170-196   ONE-chunk layout, y[perm[i]] = w[i]
+ * BSR   lis_matvec_bsr* src/matvec/lis_matvec_bsr.c:57-858    column-major bnr x bnc blocks; like the
+ *       reference it writes all nr*bnr rows, so y needs nr*bnr entries and x nc*bnc (the `pad`)
+ * DIA   ncols = number of readable x entries (n, or np with ghost columns: lis_matvec_dia.c:158-162)
+ * (CSC  lis_matvec_csc  src/matvec/lis_matvec_csc.c:128-144 is served by the CSR kernel on the
+ *  column-ordered transpose the host layer builds at upload) */
+int  liship_spmv_ell_f64(int n, int maxnzr, const int *index, const double *value,
+                         const double *x, double *y, void *stream);
+int  liship_spmv_dia_f64(int n, int ncols, int nnd, const int *offsets, const double *value,
+                         const double *x, double *y, void *stream);
+int  liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int *ptr, const int *index,
+                         const double *value, const double *x, double *y, void *stream);
+int  liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, const int *bindex,
+                         const double *value, const double *x, double *y, void *stream);
+
+/* ------------------------------------------------------------------ vector kernels
+ * element-wise: src/vector/lis_vector_opv.c (axpy :174, xpay :214, axpyz :253, scale :285, pmul :325,
+ * pdiv :365, set_all :397, abs :428, reciprocal :458, shift :520); copy is a device memcpy. */
+int  liship_axpy_f64 (int n, double alpha, const double *x, double *y, void *stream);       /* y += a*x    */
+int  liship_xpay_f64 (int n, const double *x, double alpha, double *y, void *stream);       /* y = x + a*y */
+int  liship_axpyz_f64(int n, double alpha, const double *x, const double *y, double *z, void *stream);
+int  liship_scale_f64(int n, double alpha, double *x, void *stream);
+int  liship_scale_to_f64(int n, double alpha, const double *x, double *y, void *stream);    /* y = a*x (lis_solver_gmres.c:290-296) */
+int  liship_pmul_f64 (int n, const double *x, const double *y, double *z, void *stream);
+int  liship_pdiv_f64 (int n, const double *x, const double *y, double *z, void *stream);
+int  liship_set_all_f64(int n, double alpha, double *x, void *stream);
+int  liship_abs_f64  (int n, double *x, void *stream);
+int  liship_reciprocal_f64(int n, double *x, void *stream);
+int  liship_shift_f64(int n, double sigma, double *x, void *stream);
+/* two-stage reductions (wavefront shuffle + LDS, then one fixed-order pass over the partials):
+ * src/vector/lis_vector_ops.c dot :58-127, nrm2 :210-271, nrm1 :278-342, sum :418-478.
+ * `result` is a DEVICE pointer to `count` doubles, `work` a device scratch of liship_reduce_work_bytes().
+ * *_partial variants leave the un-rooted local sum (for a cross-GPU all-reduce before sqrt). */
+size_t liship_reduce_work_bytes(void);
+int  liship_dot_f64 (int n, const double *x, const double *y, double *result, void *work, void *stream);
+int  liship_nrm2_f64(int n, const double *x, double *result, void *work, void *stream);
+int  liship_sumsq_f64(int n, const double *x, double *result, void *work, void *stream);
+int  liship_nrm1_f64(int n, const double *x, double *result, void *work, void *stream);
+int  liship_sum_f64 (int n, const double *x, double *result, void *work, void *stream);
+/* result[0] = <x,y>, result[1] = <x,x> in one pass (BiCGSTAB's <t,s>,<t,t>, lis_solver_bicgstab.c:267-268) */
+int  liship_dot2_f64(int n, const double *x, const double *y, double *result, void *work, void *stream);
+
+/* ------------------------------------------------------------------ matrix helpers on device */
+/* d[i] = first value[j] with index[j]==i in row i, else 0: lis_matrix_get_diagonal_csr,
+ * src/matrix/lis_matrix_csr.c:547-558 */
+int  liship_csr_diagonal_f64(int n, const int *ptr, const int *index, const double *value,
+                             double *d, void *stream);
+/* halo pack: ws[i] = x[export_index[i]]  (lis_send_recv, src/matrix/lis_matrix_mpi.c:904-916) */
+int  liship_gather_f64(int count, const int *export_index, const double *x, double *ws, void *stream);
+
+/* ------------------------------------------------------------------ synthetic inputs
+ * Rows [is,ie) of the 3-D 7-pt Poisson matrix on an l x m x n grid, generated directly in HBM with the
+ * entry order of test/test3.c:114-127 (sorted!=0: ascending column as test/spmvtest3.c:192-195).
+ * Columns are LOCAL: owned column g -> g-is, ghost columns -> (ie-is) + rank in ascending global order,
+ * exactly as lis_matrix_g2l_csr numbers them (src/matrix/lis_matrix_mpi.c:274-306).
+ * ptr has ie-is+1 entries; index/value must hold liship_poisson3d_nnz() entries. */
+long long liship_poisson3d_nnz(int l, int m, int n, int is, int ie);
+int  liship_poisson3d_csr(int l, int m, int n, int is, int ie, int sorted,
+                          int *ptr, int *index, double *value, void *stream);
+/* b = A*1 for those rows without forming A (test/test3.c:150): 6 minus the number of neighbours */
+int  liship_poisson3d_rhs(int l, int m, int n, int is, int ie, double *b, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,191 @@
+// runtime.hip -- device/memory/stream/timer utilities of the kernel-level C ABI (liship.h) and the
+// device-side generator of the synthetic 3-D Poisson inputs.
+#include "common.hpp"
+#include "liship.h"
+#include <string.h>
+
+extern "C" int liship_device_count(int *count) { HIP_TRY(hipGetDeviceCount(count)); return 0; }
+extern "C" int liship_set_device(int device) { HIP_TRY(hipSetDevice(device)); return 0; }
+extern "C" int liship_get_device(int *device) { HIP_TRY(hipGetDevice(device)); return 0; }
+
+extern "C" int liship_device_name(char *buf, int buflen)
+{
+    if (!buf || buflen < 1) return LISHIP_ERR_ARG;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    strncpy(buf, prop.gcnArchName, (size_t)buflen - 1);
+    buf[buflen - 1] = 0;
+    return 0;
+}
+
+extern "C" int liship_malloc(void **dptr, size_t bytes) { HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16)); return 0; }
+extern "C" int liship_free(void *dptr) { if (dptr) HIP_TRY(hipFree(dptr)); return 0; }
+extern "C" int liship_memset(void *dptr, int byte, size_t bytes, void *stream)
+{ if (bytes) HIP_TRY(hipMemsetAsync(dptr, byte, bytes, as_stream(stream))); return 0; }
+extern "C" int liship_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{ if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream))); return 0; }
+extern "C" int liship_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{ if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream))); return 0; }
+extern "C" int liship_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{ if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream))); return 0; }
+extern "C" int liship_stream_create(void **stream)
+{ hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = s; return 0; }
+extern "C" int liship_stream_destroy(void *stream) { if (stream) HIP_TRY(hipStreamDestroy(as_stream(stream))); return 0; }
+extern "C" int liship_stream_synchronize(void *stream) { HIP_TRY(hipStreamSynchronize(as_stream(stream))); return 0; }
+extern "C" int liship_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return 0; }
+
+struct liship_timer { hipEvent_t a, b; };
+extern "C" int liship_timer_create(void **timer)
+{
+    liship_timer *t = new liship_timer();
+    hipError_t e = hipEventCreate(&t->a);
+    if (e == hipSuccess) e = hipEventCreate(&t->b);
+    if (e != hipSuccess) { delete t; return (int)e; }
+    *timer = t;
+    return 0;
+}
+extern "C" int liship_timer_destroy(void *timer)
+{
+    liship_timer *t = static_cast<liship_timer *>(timer);
+    if (!t) return 0;
+    (void)hipEventDestroy(t->a); (void)hipEventDestroy(t->b);
+    delete t;
+    return 0;
+}
+extern "C" int liship_timer_start(void *timer, void *stream)
+{ HIP_TRY(hipEventRecord(static_cast<liship_timer *>(timer)->a, as_stream(stream))); return 0; }
+extern "C" int liship_timer_stop(void *timer, void *stream)
+{ HIP_TRY(hipEventRecord(static_cast<liship_timer *>(timer)->b, as_stream(stream))); return 0; }
+extern "C" int liship_timer_elapsed_ms(void *timer, float *ms)
+{
+    liship_timer *t = static_cast<liship_timer *>(timer);
+    HIP_TRY(hipEventSynchronize(t->b));
+    HIP_TRY(hipEventElapsedTime(ms, t->a, t->b));
+    return 0;
+}
+extern "C" const char *liship_error_string(int code)
+{
+    if (code == 0) return "success";
+    if (code == LISHIP_ERR_ARG) return "liship: invalid argument";
+    return hipGetErrorString((hipError_t)code);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3-D 7-point Poisson rows [is,ie) generated in place (no host matrix, no PCIe).  Row g = i*m*n + j*n + k
+// has -1 for each in-range neighbour and +6 on the diagonal; entry order as test/test3.c:114-127
+// (-mn,+mn,-n,+n,-1,+1,diag) or ascending column (test/spmvtest3.c:192-195).
+namespace {
+
+struct Grid { int l, m, n; long long mn; };
+
+// number of matrix entries in global rows [0,g): 7g minus the neighbours cut off by the six faces
+__host__ __device__ inline long long entries_before(const Grid &G, long long g)
+{
+    const long long mn = G.mn, nn = G.n;
+    const long long planes = g / mn, rem = g % mn;
+    long long cut = 0;
+    cut += (g < mn ? g : mn);                                           // i == 0     : no -mn
+    cut += (g > (long long)(G.l - 1) * mn ? g - (long long)(G.l - 1) * mn : 0);   // i == l-1   : no +mn
+    cut += planes * nn + (rem < nn ? rem : nn);                         // j == 0     : no -n
+    cut += planes * nn + (rem > (long long)(G.m - 1) * nn ? rem - (long long)(G.m - 1) * nn : 0); // j == m-1
+    cut += (g + nn - 1) / nn;                                           // k == 0     : no -1
+    cut += g / nn;                                                      // k == n-1   : no +1
+    return 7 * g - cut;
+}
+
+__global__ __launch_bounds__(256)
+void poisson3d_kernel(Grid G, int is, int ie, int sorted, int nlow,
+                      int *__restrict__ ptr, int *__restrict__ idx, double *__restrict__ val)
+{
+    const int nloc = ie - is;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r > nloc) return;
+    const long long g = (long long)is + r;
+    const long long base = entries_before(G, is);
+    const int start = (int)(entries_before(G, g) - base);
+    ptr[r] = start;
+    if (r == nloc) return;
+    const int mn = (int)G.mn;
+    const int i = (int)(g / mn), rem = (int)(g % mn), j = rem / G.n, k = rem % G.n;
+    // neighbour offsets in the requested order; 0 marks the diagonal
+    int offs[7];
+    if (sorted) { offs[0] = -mn; offs[1] = -G.n; offs[2] = -1; offs[3] = 0; offs[4] = 1; offs[5] = G.n; offs[6] = mn; }
+    else        { offs[0] = -mn; offs[1] = mn; offs[2] = -G.n; offs[3] = G.n; offs[4] = -1; offs[5] = 1; offs[6] = 0; }
+    int w = start;
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int o = offs[t];
+        bool present;
+        if (o == -mn) present = i > 0;
+        else if (o == mn) present = i < G.l - 1;
+        else if (o == -G.n) present = j > 0;
+        else if (o == G.n) present = j < G.m - 1;
+        else if (o == -1) present = k > 0;
+        else if (o == 1) present = k < G.n - 1;
+        else present = true;
+        if (!present) continue;
+        const long long c = g + o;
+        int lc;
+        if (c >= is && c < ie) lc = (int)(c - is);
+        else if (c < is)       lc = nloc + (int)(c - ((long long)is - mn));     // lower ghost plane
+        else                   lc = nloc + nlow + (int)(c - ie);                 // upper ghost plane
+        idx[w] = lc;
+        val[w] = (o == 0) ? 6.0 : -1.0;
+        w++;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void poisson3d_rhs_kernel(Grid G, int is, int ie, double *__restrict__ b)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= ie - is) return;
+    const long long g = (long long)is + r;
+    const int mn = (int)G.mn;
+    const int i = (int)(g / mn), rem = (int)(g % mn), j = rem / G.n, k = rem % G.n;
+    const int nb = (i > 0) + (i < G.l - 1) + (j > 0) + (j < G.m - 1) + (k > 0) + (k < G.n - 1);
+    b[r] = 6.0 - (double)nb;
+}
+
+bool slab_ok(int l, int m, int n, int is, int ie)
+{
+    if (l < 1 || m < 1 || n < 1) return false;
+    const long long mn = (long long)m * n, gn = mn * l;
+    if (gn > 0x7fffffffLL || is < 0 || ie < is || ie > gn) return false;
+    // ghost numbering above assumes whole planes per slab unless the slab is the whole grid
+    if ((is % mn) != 0 || (ie % mn) != 0) return false;
+    return true;
+}
+
+} // namespace
+
+extern "C" long long liship_poisson3d_nnz(int l, int m, int n, int is, int ie)
+{
+    if (!slab_ok(l, m, n, is, ie)) return -1;
+    Grid G{l, m, n, (long long)m * n};
+    return entries_before(G, ie) - entries_before(G, is);
+}
+
+extern "C" int liship_poisson3d_csr(int l, int m, int n, int is, int ie, int sorted,
+                                    int *ptr, int *index, double *value, void *stream)
+{
+    if (!slab_ok(l, m, n, is, ie)) return LISHIP_ERR_ARG;
+    Grid G{l, m, n, (long long)m * n};
+    if (entries_before(G, ie) - entries_before(G, is) > 0x7fffffffLL) return LISHIP_ERR_ARG;
+    const int nloc = ie - is, nlow = is > 0 ? (int)G.mn : 0;
+    poisson3d_kernel<<<(nloc + 1 + 255) / 256, 256, 0, as_stream(stream)>>>(G, is, ie, sorted, nlow, ptr, index, value);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int liship_poisson3d_rhs(int l, int m, int n, int is, int ie, double *b, void *stream)
+{
+    if (!slab_ok(l, m, n, is, ie)) return LISHIP_ERR_ARG;
+    if (ie == is) return 0;
+    Grid G{l, m, n, (long long)m * n};
+    poisson3d_rhs_kernel<<<(ie - is + 255) / 256, 256, 0, as_stream(stream)>>>(G, is, ie, b);
+    LAUNCH_CHECK();
+    return 0;
+}

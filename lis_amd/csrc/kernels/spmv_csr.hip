@@ -1,0 +1,496 @@
+// spmv_csr.hip -- CSR sparse matrix-vector product for gfx950 (MI355X), f64 values / i32 indices.
+//
+// Replaces the OpenMP loop of lis_matvec_csr (reference src/matvec/lis_matvec_csr.c:90-110).
+// HBM-bound (12 B per non-zero + 20 B per row, 0.135 flop/B): no MFMA, everything below is about
+// keeping ~6 TB/s of coalesced streams in flight and making the x[] gather cheap for the L1/TA.
+//
+//   * Row split balanced on merge-path coordinates.  Row block b owns the whole rows r whose coordinate
+//     key(r) = r + ptr[r] falls in [b*WORK, (b+1)*WORK).  The split blk[b] = {row, ptr[row]} is built
+//     once per matrix on the device (csr_plan_kernel: one binary search per block), costs 8 B per
+//     ~1400 items, and one 16 B scalar load hands a workgroup its row range AND non-zero range.
+//     Boundaries are pulled down to multiples of 16 rows when that is cheap, so every workgroup
+//     writes whole 128 B lines of y.
+//   * Default kernel ("row gather"): the raw value[]/index[] slice of the block goes global -> LDS
+//     with 16 B-per-lane LDS-DMA (global_load_lds_dwordx4 nt: no VGPR round trip, no ds_write); then
+//     lane r walks ITS row in LDS, gathers x[] itself and forms the row sum in registers, strictly
+//     in stored order from +0.0 with one rounded multiply and one rounded add per term -- the
+//     reference's rounding sequence, so y is bit-identical to lis_matvec_csr.
+//     Consecutive lanes own consecutive rows: for banded / stencil matrices the j-th gather of a
+//     wavefront touches 4-8 contiguous cache lines instead of ~20 when lanes own consecutive
+//     non-zeros; the gather was the dominant cost once the streams ran at speed.
+//   * y is written with non-temporal stores (a plain 8 B/row store stream next to the read streams
+//     costs 20 % of the bandwidth on this chip, tools/ubench_write.hip).
+//   * Fallback kernel ("products"): lanes own consecutive non-zeros, products value*x are parked in
+//     LDS and summed per row in order.  Serves unaligned user arrays and rows longer than the LDS
+//     stage (continued pass by pass by the lane that owns them, still in order).
+// No __shfl tree is used for the row sums on purpose: a tree changes the association order and would
+// break bit parity with the reference; the reductions that ARE trees live in vector_ops.hip.
+#include "common.hpp"
+#include "liship.h"
+
+namespace {
+
+// BLOCK threads per workgroup, WORK merge-path items (rows + non-zeros) per row block.
+struct Geometry { int block, work; };
+constexpr Geometry kGeom[] = {
+    {192, 1408},   // 0: default -- 176 stencil rows per block, 18.5 KB LDS, 8 workgroups per CU
+    {256, 2048},   // 1
+    {128,  896},   // 2
+    {192, 1536},   // 3
+    {256, 1536},   // 4
+    {512, 4096},   // 5
+    { 64,  512},   // 6: one wavefront per workgroup
+};
+constexpr int kNumGeom = sizeof(kGeom) / sizeof(kGeom[0]);
+constexpr int ROW_ALIGN = 16;    // rows per 128 B line of y / x
+constexpr int SLACK = 128;       // extra items a block may take to start on an aligned row
+constexpr int BATCH = 4;         // products kernel: independent load pairs in flight per lane
+
+// Experiment knob (liship_spmv_csr_set_variant); 0 is the shipped configuration.
+//   bit0  XCD-run block order (each XCD walks runs of consecutive row blocks; measured slower: the x
+//         lines neighbours share then all hit ONE L2 -- DESIGN.md 5)         bits16-23 run length
+//   bit1  products kernel with scalar loads     bit2  products kernel with vector loads
+//   bits4-7 geometry id and bit24 "no row alignment": read at plan creation
+//   bit8  ablation: skip the x gather  (WRONG results, timing only)
+//   bit10 register staging instead of LDS-DMA   bits11-12 gather unroll U: 0 auto, 1: 4, 2: 7, 3: 8
+int g_variant = 0;
+
+struct Blk { int r0, k0, r1, k1; };
+
+__global__ void csr_plan_kernel(int n, const int *__restrict__ ptr, int nblocks, int WORK, int align,
+                                v2i32 *__restrict__ blk)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nblocks) return;
+    const long long target = (long long)b * WORK;
+    int lo = 0, hi = n;                       // first row r in [0,n] with r + ptr[r] >= target
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if ((long long)mid + ptr[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    if (align && lo < n) {
+        const int al = lo & ~(ROW_ALIGN - 1);
+        if (al < lo && (lo - al) + (ptr[lo] - ptr[al]) <= SLACK) lo = al;
+    }
+    v2i32 e; e.x = lo; e.y = ptr[lo];
+    blk[b] = e;
+}
+
+__device__ __forceinline__ Blk load_blk(const v2i32 *__restrict__ blk, int b)
+{
+    const v2i32 lo = blk[b], hi = blk[b + 1];
+    return Blk{lo.x, lo.y, hi.x, hi.y};
+}
+
+// workgroup id -> row block.  Round-robin (identity) spreads neighbouring row blocks over the 8 XCDs.
+template <bool XRUN>
+__device__ __forceinline__ int block_of_workgroup(int nb, int run)
+{
+    if (!XRUN) return blockIdx.x;
+    const int xcd = blockIdx.x % NUM_XCD, slot = blockIdx.x / NUM_XCD;
+    const int lb = ((slot / run) * NUM_XCD + xcd) * run + slot % run;
+    return lb < nb ? lb : -1;
+}
+
+__device__ __forceinline__ bool clip_rows(Blk &B, const int *__restrict__ ptr, int row_begin, int row_end)
+{
+    if (B.r0 < row_begin) { B.r0 = row_begin; if (B.r0 < B.r1) B.k0 = ptr[B.r0]; }     // partial launches only
+    if (B.r1 > row_end)   { B.r1 = row_end;   if (B.r0 < B.r1) B.k1 = ptr[B.r1]; }
+    return B.r0 < B.r1;
+}
+
+// ------------------------------------------------------------------------------ products kernel
+// products for non-zeros [kbeg,kend) -> prod[k - ka]; ka is kbeg rounded down to even
+template <int BLOCK, bool VEC, bool NOGATHER>
+__device__ __forceinline__ void stage_products(double *prod, const int *__restrict__ idx,
+                                               const double *__restrict__ val,
+                                               const double *__restrict__ x,
+                                               int kbeg, int kend, int ka)
+{
+    if (VEC) {
+        const int npairs = (kend - ka) >> 1;
+        for (int base = 0; base < npairs; base += BATCH * BLOCK) {
+            v2f64 v[BATCH];
+            v2i32 c[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                const int p = base + u * BLOCK + (int)threadIdx.x;
+                if (p < npairs) {
+                    const int k = ka + 2 * p;
+                    v[u] = load_stream(reinterpret_cast<const v2f64 *>(val + k));
+                    c[u] = load_stream(reinterpret_cast<const v2i32 *>(idx + k));
+                }
+            }
+            v2f64 xv[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {       // all gathers in flight before the first use
+                const int p = base + u * BLOCK + (int)threadIdx.x;
+                if (p < npairs) {
+                    if (NOGATHER) { xv[u].x = (double)c[u].x; xv[u].y = (double)c[u].y; }
+                    else { xv[u].x = x[c[u].x]; xv[u].y = x[c[u].y]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                const int p = base + u * BLOCK + (int)threadIdx.x;
+                if (p < npairs) {
+                    v2f64 pr;
+                    pr.x = v[u].x * xv[u].x;
+                    pr.y = v[u].y * xv[u].y;
+                    *reinterpret_cast<v2f64 *>(prod + 2 * p) = pr;
+                }
+            }
+        }
+        if (((kend - ka) & 1) && threadIdx.x == BLOCK - 1) {
+            const int k = kend - 1;
+            prod[k - ka] = val[k] * x[idx[k]];
+        }
+    } else {
+        for (int k = kbeg + (int)threadIdx.x; k < kend; k += BLOCK)
+            prod[k - ka] = load_stream(val + k) * x[load_stream(idx + k)];
+    }
+}
+
+// sum of p[0..lim) in order, from +0.0; absent terms are +0.0, which leaves the sum bit-unchanged
+__device__ __forceinline__ double ordered_sum(const double *p, int lim)
+{
+    double acc = 0.0;
+    for (int j = 0; j < lim; j += 4) {
+        const double d0 = p[j];
+        const double d1 = (j + 1 < lim) ? p[j + 1] : 0.0;
+        const double d2 = (j + 2 < lim) ? p[j + 2] : 0.0;
+        const double d3 = (j + 3 < lim) ? p[j + 3] : 0.0;
+        acc += d0; acc += d1; acc += d2; acc += d3;
+    }
+    return acc;
+}
+
+// one whole row block of any shape (many empty rows, rows longer than the LDS stage).
+// Invariant from the plan: every row but the last ends inside the first pass of CAP products.
+template <int BLOCK, int CAP, bool VEC, bool NOGATHER>
+__device__ __forceinline__ void block_by_products(double *prod, const int *__restrict__ ptr,
+                                                  const int *__restrict__ idx, const double *__restrict__ val,
+                                                  const double *__restrict__ x, double *__restrict__ y,
+                                                  const Blk B)
+{
+    const int r0 = B.r0, r1 = B.r1, k0 = B.k0, k1 = B.k1;
+    const int ka = k0 & ~1;
+    const int kfirst = min(k1, k0 + CAP);      // end of the first pass
+
+    // this lane's first row extent: issued before the streaming loads so it is back by the sums
+    const int rmine = r0 + (int)threadIdx.x;
+    int s_first = 0, e_first = 0;
+    if (rmine < r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; }
+
+    stage_products<BLOCK, VEC, NOGATHER>(prod, idx, val, x, k0, kfirst, ka);
+    __syncthreads();
+
+    double carry = 0.0;
+    for (int r = rmine; r < r1; r += BLOCK) {
+        int s = s_first, e = e_first;
+        if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
+        const double acc = ordered_sum(prod + (s - ka), min(e, kfirst) - s);
+        if (e <= kfirst) store_stream(y + r, acc); else carry = acc;   // only the block's last row can overflow
+    }
+
+    if (k1 > kfirst) {                                          // uniform: finish the long last row
+        const int rl = r1 - 1;
+        const int owner = (rl - r0) % BLOCK;
+        int base = kfirst;
+        while (base < k1) {
+            const int kend = min(base + CAP, k1);
+            const int ka2 = base & ~1;
+            __syncthreads();
+            stage_products<BLOCK, VEC, NOGATHER>(prod, idx, val, x, base, kend, ka2);
+            __syncthreads();
+            if ((int)threadIdx.x == owner)
+                for (int k = base; k < kend; k++) carry += prod[k - ka2];
+            base = kend;
+        }
+        if ((int)threadIdx.x == owner) store_stream(y + rl, carry);
+    }
+}
+
+template <int BLOCK, int WORK, bool XRUN, bool VEC, bool NOGATHER>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
+                              const double *__restrict__ val, const double *__restrict__ x,
+                              double *__restrict__ y, const v2i32 *__restrict__ blk,
+                              int bfirst, int nb, int row_begin, int row_end, int run)
+{
+    constexpr int CAP = WORK + SLACK;
+    __shared__ double prod[CAP + 8];
+    const int lb = block_of_workgroup<XRUN>(nb, run);
+    if (lb < 0) return;
+    Blk B = load_blk(blk, bfirst + lb);
+    if (!clip_rows(B, ptr, row_begin, row_end)) return;
+    block_by_products<BLOCK, CAP, VEC, NOGATHER>(prod, ptr, idx, val, x, y, B);
+}
+
+// ------------------------------------------------------------------------------ row-gather kernel
+template <int BLOCK, int WORK, int U, bool XRUN, bool DMA, bool NOGATHER>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
+                               const double *__restrict__ val, const double *__restrict__ x,
+                               double *__restrict__ y, const v2i32 *__restrict__ blk,
+                               int bfirst, int nb, int row_begin, int row_end, int nnz_total, int run)
+{
+    constexpr int CAP = WORK + SLACK;
+    // + one wavefront of slack: the LDS-DMA form always lands whole 1 KiB wave slices
+    __shared__ __attribute__((aligned(16))) double valL[CAP + 8 + 2 * WAVE];
+    __shared__ __attribute__((aligned(16))) int idxL[CAP + 8 + 4 * WAVE];
+
+    const int lb = block_of_workgroup<XRUN>(nb, run);
+    if (lb < 0) return;
+    Blk B = load_blk(blk, bfirst + lb);
+    if (!clip_rows(B, ptr, row_begin, row_end)) return;
+
+    const int ka = B.k0 & ~3;                       // 16 B aligned start for both streams
+    const int nq = (B.k1 - ka + 3) >> 2;            // quads of 4 non-zeros
+    if ((B.k1 - ka) > CAP || ka + 4 * nq > nnz_total) {     // long row / tail of the arrays
+        block_by_products<BLOCK, CAP, true, NOGATHER>(valL, ptr, idx, val, x, y, B);
+        return;
+    }
+
+    const int rmine = B.r0 + (int)threadIdx.x;
+    int s_first = 0, e_first = 0;
+    if (rmine < B.r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; }
+
+    // linear copies of both slices, every load instruction fully coalesced (16 B per lane, 1 KiB per wave)
+    const int np = 2 * nq;                          // pairs of values
+    if (DMA) {
+        // global -> LDS directly: each wave lands 64 x 16 B at a wave-uniform LDS base; lanes past the
+        // end re-read the last valid 16 B (their LDS slot is never used)
+        const int wbase = (int)threadIdx.x & ~(WAVE - 1), lane = (int)threadIdx.x & (WAVE - 1);
+        for (int p0 = wbase; p0 < np; p0 += BLOCK) {
+            const int p = min(p0 + lane, np - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+        }
+        for (int q0 = wbase; q0 < nq; q0 += BLOCK) {
+            const int q = min(q0 + lane, nq - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v4i32 *>(idx + ka) + q),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v4i32 *>(idxL) + q0), 16, 0, 2);
+        }
+    } else {
+        for (int p0 = 0; p0 < np; p0 += 4 * BLOCK) {
+            v2f64 v[4]; v4i32 c[2];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int p = p0 + u * BLOCK + (int)threadIdx.x;
+                if (p < np) v[u] = load_stream(reinterpret_cast<const v2f64 *>(val + ka) + p);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int q = (p0 >> 1) + u * BLOCK + (int)threadIdx.x;
+                if (q < nq) c[u] = load_stream(reinterpret_cast<const v4i32 *>(idx + ka) + q);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int p = p0 + u * BLOCK + (int)threadIdx.x;
+                if (p < np) reinterpret_cast<v2f64 *>(valL)[p] = v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int q = (p0 >> 1) + u * BLOCK + (int)threadIdx.x;
+                if (q < nq) reinterpret_cast<v4i32 *>(idxL)[q] = c[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int r = rmine; r < B.r1; r += BLOCK) {
+        int s = s_first, e = e_first;
+        if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
+        const int len = e - s;
+        const int off = s - ka;
+        double acc = 0.0;
+        for (int j0 = 0; j0 < len; j0 += U) {
+            int cc[U]; double vv[U], xx[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = min(j0 + u, len - 1);         // clamped: repeats the row's last entry
+                cc[u] = idxL[off + j];
+                vv[u] = valL[off + j];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) xx[u] = NOGATHER ? (double)cc[u] : x[cc[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double t = vv[u] * xx[u];
+                acc += (j0 + u < len) ? t : 0.0;            // +0.0 terms leave the sum bit-unchanged
+            }
+        }
+        store_stream(y + r, acc);
+    }
+}
+
+} // namespace
+
+struct liship_csr_plan_s {
+    int n;
+    long long nnz;
+    int nblocks;
+    int geom;            // index into kGeom the split was built for
+    int unroll;          // gather unroll U chosen from the mean row length
+    v2i32 *blk;          // device, nblocks + 1 entries {row, ptr[row]}
+    v2i32 *blk_host;     // host copy (row-range launches)
+};
+
+extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
+
+extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *ptr, void *stream)
+{
+    if (!out || n < 0 || (n > 0 && !ptr)) return LISHIP_ERR_ARG;
+    hipStream_t st = as_stream(stream);
+    int nnz = 0;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(&nnz, ptr + n, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    liship_csr_plan_s *p = new liship_csr_plan_s();
+    p->n = n;
+    p->nnz = nnz;
+    const long long items = (long long)n + nnz;
+    p->geom = (g_variant >> 4) & 15;
+    if (p->geom >= kNumGeom) p->geom = 0;
+    const double mean_len = n > 0 ? (double)nnz / n : 0.0;
+    p->unroll = mean_len <= 4.0 ? 4 : (mean_len <= 7.0 ? 7 : 8);
+    const int WORK = kGeom[p->geom].work;
+    p->nblocks = (int)((items + WORK - 1) / WORK);
+    p->blk = nullptr;
+    p->blk_host = nullptr;
+    if (p->nblocks > 0) {
+        const size_t bytes = (size_t)(p->nblocks + 1) * sizeof(v2i32);
+        hipError_t e = hipMalloc(&p->blk, bytes);
+        if (e != hipSuccess) { delete p; return (int)e; }
+        const int threads = 256, grid = (p->nblocks + 1 + threads - 1) / threads;
+        csr_plan_kernel<<<grid, threads, 0, st>>>(n, ptr, p->nblocks, WORK, (g_variant & 0x1000000) ? 0 : 1, p->blk);
+        e = hipGetLastError();
+        p->blk_host = (v2i32 *)malloc(bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->blk_host, p->blk, bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)hipFree(p->blk); free(p->blk_host); delete p; return (int)e; }
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
+{
+    if (!p) return 0;
+    int rc = 0;
+    if (p->blk) rc = (int)hipFree(p->blk);
+    free(p->blk_host);
+    delete p;
+    return rc;
+}
+
+extern "C" int liship_csr_plan_info(liship_csr_plan_t p, int *n, long long *nnz, int *nblocks)
+{
+    if (!p) return LISHIP_ERR_ARG;
+    if (n) *n = p->n;
+    if (nnz) *nnz = p->nnz;
+    if (nblocks) *nblocks = p->nblocks;
+    return 0;
+}
+
+namespace {
+
+struct LaunchArgs {
+    const int *ptr, *idx; const double *val, *x; double *y; const v2i32 *blk;
+    int bfirst, nb, rb, re, nnz;
+    hipStream_t st;
+};
+
+inline int xcd_run() { int c = (g_variant >> 16) & 0xff; return c ? c : 16; }
+
+template <int G, int U, bool XRUN, bool DMA, bool NOGATHER>
+void launch_rowgather(int grid, const LaunchArgs &a)
+{
+    constexpr Geometry g = kGeom[G];
+    spmv_csr_rowgather_kernel<g.block, g.work, U, XRUN, DMA, NOGATHER>
+        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, xcd_run());
+}
+
+template <int G, bool XRUN, bool VEC, bool NOGATHER>
+void launch_products(int grid, const LaunchArgs &a)
+{
+    constexpr Geometry g = kGeom[G];
+    spmv_csr_products_kernel<g.block, g.work, XRUN, VEC, NOGATHER>
+        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, xcd_run());
+}
+
+template <int G>
+void launch_geom(const LaunchArgs &a, int unroll)
+{
+    const bool nogather = (g_variant & 0x100) != 0;
+    const bool xrun = (g_variant & 1) && a.nb >= 4 * NUM_XCD;
+    const int span = NUM_XCD * xcd_run();
+    const int grid = xrun ? ((a.nb + span - 1) / span) * span : a.nb;
+    const bool val16 = aligned16(a.val), idx16 = aligned16(a.idx);
+    const bool idx8 = (reinterpret_cast<uintptr_t>(a.idx) & 7u) == 0;
+    const bool products = (g_variant & 6) != 0 || !(val16 && idx16);
+    if (products) {
+        const bool vec = !(g_variant & 2) && val16 && idx8;
+        if (nogather)  launch_products<G, false, true, true>(a.nb, a);
+        else if (xrun) { if (vec) launch_products<G, true, true, false>(grid, a); else launch_products<G, true, false, false>(grid, a); }
+        else           { if (vec) launch_products<G, false, true, false>(grid, a); else launch_products<G, false, false, false>(grid, a); }
+        return;
+    }
+    const int usel = (g_variant >> 11) & 3;
+    const int U = usel == 1 ? 4 : usel == 2 ? 7 : usel == 3 ? 8 : unroll;
+    const bool dma = !(g_variant & 0x400);
+    if (nogather)  { launch_rowgather<G, 8, false, true, true>(a.nb, a); return; }
+    if (xrun)      { launch_rowgather<G, 8, true, true, false>(grid, a); return; }
+    if (!dma)      { launch_rowgather<G, 8, false, false, false>(grid, a); return; }
+    if (U == 4)      launch_rowgather<G, 4, false, true, false>(grid, a);
+    else if (U == 7) launch_rowgather<G, 7, false, true, false>(grid, a);
+    else             launch_rowgather<G, 8, false, true, false>(grid, a);
+}
+
+int launch_csr(liship_csr_plan_t p, const LaunchArgs &a)
+{
+    if (a.nb <= 0) return 0;
+    switch (p->geom) {
+        case 0: launch_geom<0>(a, p->unroll); break;
+        case 1: launch_geom<1>(a, p->unroll); break;
+        case 2: launch_geom<2>(a, p->unroll); break;
+        case 3: launch_geom<3>(a, p->unroll); break;
+        case 4: launch_geom<4>(a, p->unroll); break;
+        case 5: launch_geom<5>(a, p->unroll); break;
+        case 6: launch_geom<6>(a, p->unroll); break;
+        default: return LISHIP_ERR_ARG;
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+} // namespace
+
+extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const int *idx,
+                                   const double *val, const double *x, double *y, void *stream)
+{
+    if (!p) return LISHIP_ERR_ARG;
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream)};
+    return launch_csr(p, a);
+}
+
+extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int row_end, const int *ptr,
+                                        const int *idx, const double *val, const double *x, double *y,
+                                        void *stream)
+{
+    if (!p || row_begin < 0 || row_end > p->n) return LISHIP_ERR_ARG;
+    if (row_begin >= row_end || p->nblocks == 0) return 0;
+    // row blocks whose interval [blk[b].row, blk[b+1].row) intersects [row_begin,row_end)
+    const v2i32 *br = p->blk_host;
+    int lo = 0, hi = p->nblocks;                 // first b with br[b+1].row > row_begin
+    while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid + 1].x > row_begin) hi = mid; else lo = mid + 1; }
+    const int bfirst = lo;
+    lo = bfirst; hi = p->nblocks;                // first b with br[b].row >= row_end
+    while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream)};
+    return launch_csr(p, a);
+}

@@ -1,0 +1,307 @@
+"""Parity of the hand-written HIP kernels (kernel-level C ABI, include/liship.h) against the CPU oracle.
+
+Bit-exact for every SpMV format and every element-wise kernel (same rounding sequence as the
+reference's loops); reductions are compared at 1e-14 relative (tree order differs from the reference's
+left-to-right order -- tolerance stated here, SURVEY 7 "hard parts").
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import lis_amd
+from lis_amd import DeviceArray as DA, check
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "lis_ref_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = lis_amd.load()
+    assert lis_amd.gpu_available(), "no HIP device: the product path has no CPU fallback"
+    return lib
+
+
+def dev_csr_spmv(lib, ptr, idx, val, x, variant=0, rows=None):
+    n = len(ptr) - 1
+    dptr, didx, dval = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64)
+    dx = DA.from_host(x, np.float64)
+    dy = DA.from_host(np.full(n, np.nan), np.float64)
+    plan = C.c_void_p()
+    lib.liship_spmv_csr_set_variant(variant)          # geometry bits are read at plan creation
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    if rows is None:
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+    else:
+        check(lib.liship_spmv_csr_rows_f64(plan, rows[0], rows[1], dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+    lib.liship_spmv_csr_set_variant(0)
+    y = dy.to_host()
+    check(lib.liship_csr_plan_destroy(plan))
+    return y
+
+
+CSR_CASES = {
+    "p1d_10000": lambda: orc.poisson1d(10000),
+    "p3d_16": lambda: orc.poisson3d(16, 16, 16),
+    "p3d_20x17x13_sorted": lambda: orc.poisson3d(20, 17, 13, sort_cols=True),
+    "p3d_64": lambda: orc.poisson3d(64, 64, 64),
+    "rand_5000": lambda: orc.random_csr(5000, 11, seed=1),
+    "rand_long_rows": lambda: orc.random_csr(300, 40, seed=2, ncols=9000, long_row=7001),
+    "rand_wide_77": lambda: orc.random_csr(4000, 77, seed=3, ncols=4000, empty_rows=False),
+    "mostly_empty": lambda: orc.random_csr(20000, 0.05, seed=4),
+    "single_row": lambda: orc.random_csr(1, 5, seed=5, ncols=64, empty_rows=False),
+}
+
+
+# liship_spmv_csr_set_variant bits (lis_amd/csrc/kernels/spmv_csr.hip): 0 = shipped row-gather kernel with LDS-DMA;
+# 0x1 XCD-run order; 0x2 / 0x4 products kernel (scalar / vector loads); 0x?0 geometry; 0x400 register staging;
+# 0x800 / 0x1000 / 0x1800 gather unroll 4 / 7 / 8; 0x1000000 unaligned row blocks
+VARIANTS = [0x0, 0x1, 0x040001, 0x2, 0x4, 0x5, 0x10, 0x14, 0x20, 0x30, 0x40, 0x50, 0x54, 0x60, 0x62,
+            0x400, 0x800, 0x1000, 0x1800, 0x1000000, 0x1000004]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("name", list(CSR_CASES))
+def test_spmv_csr_bit_exact(lib, name, variant):
+    ptr, idx, val = CSR_CASES[name]()
+    ncols = max(len(ptr) - 1, int(idx.max()) + 1 if len(idx) else 1)
+    x = np.random.default_rng(3).uniform(-1, 1, ncols)
+    y = dev_csr_spmv(lib, ptr, idx, val, x, variant)
+    assert np.array_equal(y, orc.spmv_csr(ptr, idx, val, x)), name
+
+
+def test_spmv_csr_empty_matrix_and_zero_rows(lib):
+    ptr = np.zeros(1001, np.int32)
+    y = dev_csr_spmv(lib, ptr, np.zeros(0, np.int32), np.zeros(0), np.ones(1000))
+    assert np.array_equal(y, np.zeros(1000))
+
+
+def test_spmv_csr_special_values(lib):
+    # signed zeros, infinities and NaN propagate exactly as in the reference loop
+    ptr, idx, val = orc.random_csr(500, 6, seed=8)
+    x = np.random.default_rng(1).uniform(-1, 1, 500)
+    x[::7] = 0.0
+    x[3::11] = -0.0
+    val[::13] = -0.0
+    x[50] = np.inf
+    x[60] = np.nan
+    y = dev_csr_spmv(lib, ptr, idx, val, x)
+    ref = orc.spmv_csr(ptr, idx, val, x)
+    assert np.array_equal(y.view(np.uint64), ref.view(np.uint64))
+
+
+def test_spmv_csr_row_range(lib):
+    ptr, idx, val = orc.poisson3d(12, 12, 12)
+    n = len(ptr) - 1
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    ref = orc.spmv_csr(ptr, idx, val, x)
+    for rb, re in [(0, 144), (144, n - 144), (n - 144, n), (7, 9), (100, 100)]:
+        y = dev_csr_spmv(lib, ptr, idx, val, x, rows=(rb, re))
+        assert np.array_equal(y[rb:re], ref[rb:re])
+        assert np.all(np.isnan(y[:rb])) and np.all(np.isnan(y[re:]))
+
+
+@pytest.mark.parametrize("name", ["p1d100", "p3d_6x5x4", "p3d_8s", "irr150"])
+def test_golden_all_formats(lib, name):
+    """Every format against the vectors the reference itself produced (tests/golden)."""
+    ptr, idx, val, x = (G[f"{name}/{k}"] for k in ("ptr", "idx", "val", "x"))
+    n = len(ptr) - 1
+    assert np.array_equal(dev_csr_spmv(lib, ptr, idx, val, x), G[f"{name}/y_csr"])
+    dx = DA.from_host(x)
+    dy = DA.zeros(n + 8, np.float64)
+
+    def run(fn, *args):
+        check(lib.liship_memset(dy.ptr, 0xFF, dy.nbytes, None))
+        check(fn(*args, dx.ptr, dy.ptr, None))
+        return dy.to_host(n)
+
+    g = lambda k: G[f"{name}/{k}"]
+    eidx, ev = DA.from_host(g("ell/index")), DA.from_host(g("ell/value"))
+    assert np.array_equal(run(lib.liship_spmv_ell_f64, n, int(g("ell/maxnzr")[0]), eidx.ptr, ev.ptr), g("y_ell"))
+    off, dv = DA.from_host(g("dia/index")), DA.from_host(g("dia/value"))
+    assert np.array_equal(run(lib.liship_spmv_dia_f64, n, n, int(g("dia/nnd")[0]), off.ptr, dv.ptr), g("y_dia"))
+    perm, jp, ji, jv = (DA.from_host(g(f"jad/{k}")) for k in ("row", "ptr", "index", "value"))
+    assert np.array_equal(run(lib.liship_spmv_jad_f64, n, int(g("jad/maxnzr")[0]), perm.ptr, jp.ptr, ji.ptr, jv.ptr), g("y_jad"))
+    bp, bi, bv = (DA.from_host(g(f"bsr/{k}")) for k in ("bptr", "bindex", "value"))
+    xpad = np.zeros(n + 8)
+    xpad[:n] = x
+    dx = DA.from_host(xpad)
+    assert np.array_equal(run(lib.liship_spmv_bsr_f64, int(g("bsr/nr")[0]), 2, 2, bp.ptr, bi.ptr, bv.ptr), g("y_bsr"))
+    # CSC: the device keeps the column-ordered transpose as CSR; its row sums are the reference's CSC sums
+    cptr, cidx, cval = g("csc/ptr"), g("csc/index"), g("csc/value")
+    order = np.lexsort((np.repeat(np.arange(n), np.diff(cptr)), cidx))    # stable by row, column ascending
+    tptr = np.zeros(n + 1, np.int32)
+    np.add.at(tptr, cidx + 1, 1)
+    tptr = np.cumsum(tptr).astype(np.int32)
+    tidx = np.repeat(np.arange(n, dtype=np.int32), np.diff(cptr))[order]
+    assert np.array_equal(dev_csr_spmv(lib, tptr, tidx, cval[order], x), g("y_csc"))
+
+
+@pytest.mark.parametrize("fmt", ["ell", "dia", "jad", "bsr"])
+@pytest.mark.parametrize("case", ["p3d_20x17x13_sorted", "rand_5000"])
+def test_formats_vs_oracle(lib, fmt, case):
+    ptr, idx, val = CSR_CASES[case]()
+    n = len(ptr) - 1
+    x = np.random.default_rng(9).uniform(-1, 1, n + 8)
+    x[n:] = 0.0
+    dx, dy = DA.from_host(x), DA.zeros(n + 8, np.float64)
+    if fmt == "ell":
+        mx, eidx, ev = orc.csr2ell(ptr, idx, val)
+        a, b = DA.from_host(eidx), DA.from_host(ev)
+        check(lib.liship_spmv_ell_f64(n, mx, a.ptr, b.ptr, dx.ptr, dy.ptr, None))
+        ref = orc.spmv_ell(n, mx, eidx, ev, x[:n].copy())
+    elif fmt == "dia":
+        if case.startswith("rand"):
+            pytest.skip("DIA of an irregular matrix is dense")
+        sidx, sval = orc.sort_rows(ptr, idx, val)
+        nnd, off, dv = orc.csr2dia(ptr, sidx, sval)
+        a, b = DA.from_host(off), DA.from_host(dv)
+        check(lib.liship_spmv_dia_f64(n, n, nnd, a.ptr, b.ptr, dx.ptr, dy.ptr, None))
+        ref = orc.spmv_dia(n, nnd, off, dv, x[:n].copy())
+    elif fmt == "jad":
+        mx, perm, jptr, jidx, jv = orc.csr2jad(ptr, idx, val)
+        a, b, c, d = DA.from_host(perm), DA.from_host(jptr), DA.from_host(jidx), DA.from_host(jv)
+        check(lib.liship_spmv_jad_f64(n, mx, a.ptr, b.ptr, c.ptr, d.ptr, dx.ptr, dy.ptr, None))
+        ref = orc.spmv_jad(n, mx, perm, jptr, jidx, jv, x[:n].copy())
+    else:
+        nr, bptr, bidx, bv = orc.csr2bsr(ptr, idx, val, 3, 2)
+        a, b, c = DA.from_host(bptr), DA.from_host(bidx), DA.from_host(bv)
+        check(lib.liship_spmv_bsr_f64(nr, 3, 2, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
+        ref = orc.spmv_bsr(n, nr, 3, 2, bptr, bidx, bv, x[:n].copy())
+    assert np.array_equal(dy.to_host(n), ref)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 1000, 4097, 1 << 20, (1 << 20) + 3])
+def test_elementwise_bit_exact(lib, n):
+    rng = np.random.default_rng(n)
+    x, y, z = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(0.5, 2, n)
+    a = 0.37120000000000003
+    O = orc.lib()
+    dx, dy, dz = DA.from_host(x), DA.from_host(y), DA.from_host(z)
+    yy = y.copy(); O.orc_axpy(n, a, x, yy)
+    check(lib.liship_axpy_f64(n, a, dx.ptr, dy.ptr, None)); assert np.array_equal(dy.to_host(), yy)
+    O.orc_xpay(n, x, a, yy)
+    check(lib.liship_xpay_f64(n, dx.ptr, a, dy.ptr, None)); assert np.array_equal(dy.to_host(), yy)
+    zz = np.empty(n); O.orc_axpyz(n, a, x, yy, zz)
+    check(lib.liship_axpyz_f64(n, a, dx.ptr, dy.ptr, dz.ptr, None)); assert np.array_equal(dz.to_host(), zz)
+    O.orc_scale(n, a, zz)
+    check(lib.liship_scale_f64(n, a, dz.ptr, None)); assert np.array_equal(dz.to_host(), zz)
+    O.orc_pmul(n, x, yy, zz)
+    check(lib.liship_pmul_f64(n, dx.ptr, dy.ptr, dz.ptr, None)); assert np.array_equal(dz.to_host(), zz)
+    dz.upload(z); zz = z.copy(); O.orc_reciprocal(n, zz)
+    check(lib.liship_reciprocal_f64(n, dz.ptr, None)); assert np.array_equal(dz.to_host(), zz)
+    check(lib.liship_pdiv_f64(n, dx.ptr, dz.ptr, dy.ptr, None)); assert np.array_equal(dy.to_host(), x / zz)
+    check(lib.liship_scale_to_f64(n, a, dx.ptr, dy.ptr, None)); assert np.array_equal(dy.to_host(), a * x)
+    check(lib.liship_set_all_f64(n, a, dy.ptr, None)); assert np.array_equal(dy.to_host(), np.full(n, a))
+    check(lib.liship_abs_f64(n, dx.ptr, None)); assert np.array_equal(dx.to_host(), np.abs(x))
+    check(lib.liship_shift_f64(n, a, dx.ptr, None)); assert np.array_equal(dx.to_host(), np.abs(x) - a)
+
+
+def test_elementwise_unaligned_views(lib):
+    n = 1001
+    x, y = np.arange(n + 1, dtype=np.float64), np.ones(n + 1)
+    dx, dy = DA.from_host(x), DA.from_host(y)
+    check(lib.liship_axpy_f64(n, 2.0, dx.ptr + 8, dy.ptr + 8, None))     # 8-byte aligned only
+    out = dy.to_host()
+    assert out[0] == 1.0 and np.array_equal(out[1:], 1.0 + 2.0 * x[1:])
+
+
+@pytest.mark.parametrize("n", [1, 2, 65, 1000, 4097, 1 << 20, (1 << 22) + 5])
+def test_reductions(lib, n):
+    rng = np.random.default_rng(n + 1)
+    x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    dx, dy = DA.from_host(x), DA.from_host(y)
+    work = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64)
+    res = DA.zeros(2, np.float64)
+    O = orc.lib()
+    scale = np.sqrt(n)
+
+    def close(a, b, ref_mag):
+        return abs(a - b) <= 1e-14 * max(ref_mag, 1e-300) * max(1.0, np.log2(n + 1))
+
+    check(lib.liship_dot_f64(n, dx.ptr, dy.ptr, res.ptr, work.ptr, None))
+    assert close(res.to_host()[0], O.orc_dot(n, x, y), np.abs(x * y).sum())
+    check(lib.liship_nrm2_f64(n, dx.ptr, res.ptr, work.ptr, None))
+    assert close(res.to_host()[0], O.orc_nrm2(n, x), O.orc_nrm2(n, x))
+    check(lib.liship_sumsq_f64(n, dx.ptr, res.ptr, work.ptr, None))
+    assert close(res.to_host()[0], O.orc_nrm2(n, x) ** 2, np.dot(x, x))
+    check(lib.liship_nrm1_f64(n, dx.ptr, res.ptr, work.ptr, None))
+    assert close(res.to_host()[0], O.orc_nrm1(n, x), O.orc_nrm1(n, x))
+    check(lib.liship_sum_f64(n, dx.ptr, res.ptr, work.ptr, None))
+    assert close(res.to_host()[0], x.sum(), np.abs(x).sum())
+    check(lib.liship_dot2_f64(n, dx.ptr, dy.ptr, res.ptr, work.ptr, None))
+    r = res.to_host()
+    assert close(r[0], O.orc_dot(n, x, y), np.abs(x * y).sum()) and close(r[1], np.dot(x, x), np.dot(x, x))
+    # run-to-run reproducibility (fixed reduction tree)
+    check(lib.liship_dot_f64(n, dx.ptr, dy.ptr, res.ptr, work.ptr, None)); a = res.to_host()[0]
+    check(lib.liship_dot_f64(n, dx.ptr, dy.ptr, res.ptr, work.ptr, None)); assert a == res.to_host()[0]
+    del scale
+
+
+def test_diagonal_and_gather(lib):
+    ptr, idx, val = orc.random_csr(3000, 9, seed=12)
+    n = 3000
+    a, b, c = DA.from_host(ptr), DA.from_host(idx), DA.from_host(val)
+    d = DA.zeros(n, np.float64)
+    check(lib.liship_csr_diagonal_f64(n, a.ptr, b.ptr, c.ptr, d.ptr, None))
+    assert np.array_equal(d.to_host(), orc.csr_diagonal(ptr, idx, val))
+    sel = np.random.default_rng(0).integers(0, n, 777).astype(np.int32)
+    x = np.random.default_rng(1).uniform(-1, 1, n)
+    dsel, dx, out = DA.from_host(sel), DA.from_host(x), DA.zeros(777, np.float64)
+    check(lib.liship_gather_f64(777, dsel.ptr, dx.ptr, out.ptr, None))
+    assert np.array_equal(out.to_host(), x[sel])
+
+
+@pytest.mark.parametrize("grid,slab,sorted_", [((8, 6, 5), None, 0), ((8, 6, 5), None, 1),
+                                               ((8, 6, 5), (2, 5), 0), ((8, 6, 5), (0, 3), 1),
+                                               ((8, 6, 5), (5, 8), 0), ((1, 1, 7), None, 0)])
+def test_device_poisson_generator(lib, grid, slab, sorted_):
+    """Device-generated rows == oracle generator + the reference's ghost renumbering (lis_matrix_mpi.c:274-306)."""
+    l, m, n = grid
+    mn = m * n
+    is_, ie = (0, l * mn) if slab is None else (slab[0] * mn, slab[1] * mn)
+    nloc = ie - is_
+    ptr, idx, val = orc.poisson3d(l, m, n, sort_cols=bool(sorted_), is_=is_, ie=ie)
+    ghosts = np.unique(idx[(idx < is_) | (idx >= ie)])
+    lidx = idx.copy()
+    own = (idx >= is_) & (idx < ie)
+    lidx[own] = idx[own] - is_
+    lidx[~own] = nloc + np.searchsorted(ghosts, idx[~own])
+    nnz = lib.liship_poisson3d_nnz(l, m, n, is_, ie)
+    assert nnz == len(idx)
+    dptr, didx, dval = DA.zeros(nloc + 1, np.int32), DA.zeros(nnz, np.int32), DA.zeros(nnz, np.float64)
+    check(lib.liship_poisson3d_csr(l, m, n, is_, ie, sorted_, dptr.ptr, didx.ptr, dval.ptr, None))
+    assert np.array_equal(dptr.to_host(), ptr)
+    assert np.array_equal(didx.to_host(), lidx)
+    assert np.array_equal(dval.to_host(), val)
+    b = DA.zeros(nloc, np.float64)
+    check(lib.liship_poisson3d_rhs(l, m, n, is_, ie, b.ptr, None))
+    full_ptr, full_idx, full_val = orc.poisson3d(l, m, n)
+    assert np.array_equal(b.to_host(), orc.spmv_csr(full_ptr, full_idx, full_val, np.ones(l * mn))[is_:ie])
+
+
+def test_large_poisson_properties(lib):
+    """Full-size property check without a CPU pass: ||A*1||_2^2 = 6(N-2)^2 + 48(N-2) + 72 (spmvtest3)."""
+    N = 256
+    n = N ** 3
+    nnz = lib.liship_poisson3d_nnz(N, N, N, 0, n)
+    assert nnz == 7 * n - 6 * N * N
+    dptr, didx, dval = DA(n + 1, np.int32), DA(nnz, np.int32), DA(nnz, np.float64)
+    check(lib.liship_poisson3d_csr(N, N, N, 0, n, 0, dptr.ptr, didx.ptr, dval.ptr, None))
+    x, y, b = DA(n, np.float64), DA(n, np.float64), DA(n, np.float64)
+    check(lib.liship_set_all_f64(n, 1.0, x.ptr, None))
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None))
+    work, res = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
+    check(lib.liship_sumsq_f64(n, y.ptr, res.ptr, work.ptr, None))
+    assert res.to_host()[0] == 6.0 * (N - 2) ** 2 + 48.0 * (N - 2) + 72.0     # small integers: exact
+    # y == b (= A*1 in closed form) everywhere: y - b == 0
+    check(lib.liship_poisson3d_rhs(N, N, N, 0, n, b.ptr, None))
+    check(lib.liship_axpy_f64(n, -1.0, b.ptr, y.ptr, None))
+    check(lib.liship_nrm1_f64(n, y.ptr, res.ptr, work.ptr, None))
+    assert res.to_host()[0] == 0.0
+    check(lib.liship_csr_plan_destroy(plan))

@@ -1,0 +1,86 @@
+/*
+ * lis_amd.h -- extensions of liblis_amd.so beyond the Lis API: where the data lives, and multi-GPU.
+ *
+ * Lis objects expose raw host arrays (v->value[], A->ptr[] ...) that callers read and write directly
+ * (test/spmvtest1.c:215, src/solver/lis_solver_gmres.c:203).  The kernels run on HBM copies.  Two
+ * residency policies decide who is authoritative:
+ *
+ *   LIS_AMD_COHERENT (default)  every public call treats the HOST arrays of its inputs as the truth
+ *       (uploads them) and leaves its outputs valid on the host (downloads them).  Any program written
+ *       for Lis works unchanged; stand-alone lis_matvec / lis_vector_* calls pay PCIe transfers.
+ *       lis_solve() uploads b (and x) once, iterates entirely in HBM and downloads x once.
+ *   LIS_AMD_RESIDENT            objects live in HBM; validity of each side is tracked by the library.
+ *       API writers (lis_vector_set_value(s), set_all ...) and readers (get_value(s), gather) stay
+ *       correct; code that pokes v->value[] directly must bracket it with
+ *       lis_amd_vector_sync_host() (before reading) / lis_amd_vector_host_modified() (after writing).
+ */
+#ifndef LIS_AMD_H
+#define LIS_AMD_H
+
+#include "lis.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIS_AMD_COHERENT 0
+#define LIS_AMD_RESIDENT 1
+
+LIS_INT lis_amd_set_residency(LIS_INT mode);
+LIS_INT lis_amd_get_residency(void);
+
+/* vectors */
+LIS_INT lis_amd_vector_sync_host(LIS_VECTOR v);        /* make v->value[] current (D2H if needed)        */
+LIS_INT lis_amd_vector_host_modified(LIS_VECTOR v);    /* v->value[] was written directly: HBM copy stale */
+LIS_INT lis_amd_vector_device_ptr(LIS_VECTOR v, LIS_SCALAR **dptr);  /* current HBM copy (uploads if needed) */
+LIS_INT lis_amd_vector_device_modified(LIS_VECTOR v);  /* HBM copy was written by foreign kernels          */
+
+/* matrices */
+LIS_INT lis_amd_matrix_upload(LIS_MATRIX A);           /* build the HBM copy now (otherwise on first use) */
+LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A);    /* host arrays changed: drop the HBM copy          */
+/* adopt CSR arrays that already live in HBM (no host copy exists; A must be sized and unassembled).
+ * ptr has n+1 entries, columns are local (0..np-1, ghosts >= n).  The arrays are freed with the matrix. */
+LIS_INT lis_amd_matrix_set_csr_device(LIS_INT nnz, LIS_INT np, LIS_INT *dptr, LIS_INT *dindex,
+                                      LIS_SCALAR *dvalue, LIS_MATRIX A);
+/* 3-D 7-pt Poisson on an l x m x n grid (test/test3.c:114-127; sorted!=0: test/spmvtest3.c:192-195),
+ * generated in HBM for this rank's rows; A must be created + set_size'd with global size l*m*n.
+ * In a multi-GPU job the halo tables are derived in closed form (whole planes per rank). */
+LIS_INT lis_amd_matrix_poisson3d(LIS_MATRIX A, LIS_INT l, LIS_INT m, LIS_INT n, LIS_INT sorted);
+/* b = A*1 for that matrix in closed form (test/test3.c:150) */
+LIS_INT lis_amd_vector_poisson3d_rhs(LIS_VECTOR b, LIS_INT l, LIS_INT m, LIS_INT n);
+
+/* stream all library work is queued on (hipStream_t as void*), and a full device sync */
+void   *lis_amd_stream(void);
+LIS_INT lis_amd_synchronize(void);
+
+/* ---- multi-GPU: one process per GPU, row-block partition (LIS_GET_ISIE), RCCL over xGMI ------------
+ * Replaces the MPI layer of the reference (src/matrix/lis_matrix_mpi.c): halo = packed export rows
+ * exchanged with grouped ncclSend/ncclRecv straight into x[n..np), reductions = all-gather of the
+ * per-rank partial sums folded in rank order (deterministic).
+ *
+ * Bootstrap: rank 0 calls lis_amd_comm_get_unique_id(), the launcher broadcasts the 128 bytes (any
+ * channel: torch.distributed/gloo in bench.py, a file, MPI), every rank calls lis_amd_comm_init_rccl().
+ * lis_amd_comm_init_callbacks() installs host-memory collectives instead (CPU tests with gloo). */
+#define LIS_AMD_UNIQUE_ID_BYTES 128
+LIS_INT lis_amd_comm_get_unique_id(void *id128);
+LIS_INT lis_amd_comm_init_rccl(const void *id128, LIS_INT rank, LIS_INT nprocs, LIS_INT device);
+typedef struct {
+    /* recv[r*count .. (r+1)*count) <- send of rank r, for all r (host memory) */
+    int (*allgather)(void *ctx, const void *send, void *recv, size_t bytes_per_rank);
+    /* exchange with every neighbour: send sendbuf[sptr[i]..sptr[i+1]) doubles to rank neib[i], receive
+     * recvbuf[rptr[i]..rptr[i+1]) from it (host memory) */
+    int (*neighbor_exchange)(void *ctx, int nneib, const int *neib, const double *sendbuf, const int *sptr,
+                             double *recvbuf, const int *rptr);
+    void *ctx;
+} lis_amd_comm_callbacks;
+LIS_INT lis_amd_comm_init_callbacks(const lis_amd_comm_callbacks *cb, LIS_INT rank, LIS_INT nprocs);
+/* the reference's lis_send_recv on a HOST array x[np] through the callback communicator (tests of the tables) */
+LIS_INT lis_amd_halo_exchange_host(LIS_MATRIX A, LIS_SCALAR x[]);
+LIS_INT lis_amd_comm_finalize(void);
+LIS_INT lis_amd_comm_rank(void);
+LIS_INT lis_amd_comm_size(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,408 @@
+/*
+ * lis_device.c -- HBM copies of Lis objects and the dispatch of the hot path onto the HIP kernels.
+ *
+ * Data layout in HBM (all f64 / i32):
+ *   vectors   one buffer of np + pad (+ slack) doubles; owned entries [0,n), ghost entries [n,np)
+ *   CSR       ptr[n+1], index[nnz], value[nnz] + the merge-path row split (liship_csr_plan_t)
+ *   CSC       kept as the column-ordered transpose, i.e. CSR whose rows list their entries by ascending
+ *             column: the reference's serial CSC loop (src/matvec/lis_matvec_csc.c:128-144) adds the
+ *             terms of output row i in exactly that order
+ *   ELL/DIA   column-major [maxnzr|nnd][n];  JAD  perm/ptr/index/value (one chunk);  BSR  bptr/bindex/value
+ */
+#include <stdio.h>
+#include "lis_internal.h"
+
+/* ------------------------------------------------------------------ runtime */
+LIS_INT lisd_init(void)
+{
+	if (lisg.device_ready) return LIS_SUCCESS;
+	int count = 0;
+	int rc = liship_device_count(&count);
+	if (rc != 0 || count < 1) {
+		fprintf(stderr, "liblis_amd: no HIP device available (%s) -- this library has no CPU fallback\n",
+		        rc ? liship_error_string(rc) : "device count is 0");
+		return LIS_ERR_NOT_IMPLEMENTED;
+	}
+	if (lisg.comm_kind != 1) {           /* the RCCL bootstrap already chose the device */
+		const char *env = getenv("LIS_AMD_DEVICE");
+		lisg.device = env ? atoi(env) : 0;
+		if (lisg.device < 0 || lisg.device >= count) lisg.device = 0;
+	}
+	HIPCHK(liship_set_device(lisg.device));
+	HIPCHK(liship_stream_create(&lisg.stream));
+	HIPCHK(liship_malloc(&lisg.reduce_work, liship_reduce_work_bytes()));
+	HIPCHK(liship_malloc((void **)&lisg.reduce_out, 4 * sizeof(double)));
+	lisg.device_ready = 1;
+	return LIS_SUCCESS;
+}
+
+void *lis_amd_stream(void) { return lisd_init() == LIS_SUCCESS ? lisg.stream : NULL; }
+
+LIS_INT lis_amd_synchronize(void)
+{
+	LISCHK(lisd_init());
+	HIPCHK(liship_device_synchronize());
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_amd_set_residency(LIS_INT mode)
+{
+	if (mode != LIS_AMD_COHERENT && mode != LIS_AMD_RESIDENT) return LISI_ERR(LIS_ERR_ILL_ARG, "unknown residency mode %D\n", mode);
+	lisg.residency = mode;
+	return LIS_SUCCESS;
+}
+LIS_INT lis_amd_get_residency(void) { return lisg.residency; }
+
+/* ------------------------------------------------------------------ vectors */
+static size_t vec_len(LIS_VECTOR v) { return (size_t)(v->np + v->pad); }
+
+LIS_INT lisd_vec_reserve(LIS_VECTOR v, size_t doubles)
+{
+	lisd_vec *d = VDEV(v);
+	LISCHK(lisd_init());
+	if (d->d && d->cap >= doubles) return LIS_SUCCESS;
+	const size_t cap = doubles + 16;                      /* slack: BSR kernels read/write whole blocks */
+	void *nd = NULL;
+	HIPCHK(liship_malloc(&nd, cap * sizeof(double)));
+	HIPCHK(liship_memset(nd, 0, cap * sizeof(double), lisg.stream));
+	if (d->d) {
+		if (d->dev_valid) HIPCHK(liship_memcpy_d2d(nd, d->d, d->cap * sizeof(double), lisg.stream));
+		HIPCHK(liship_stream_synchronize(lisg.stream));
+		HIPCHK(liship_free(d->d));
+	}
+	d->d = (double *)nd;
+	d->cap = cap;
+	return LIS_SUCCESS;
+}
+
+/* host -> HBM when the host side is the truth (always in COHERENT mode) */
+LIS_INT lisd_vec_in(LIS_VECTOR v, double **out)
+{
+	lisd_vec *d = VDEV(v);
+	LISCHK(lisd_vec_reserve(v, vec_len(v)));
+	const int host_is_truth = (lisg.residency == LIS_AMD_COHERENT) ? (d->host_valid || !d->dev_valid) : !d->dev_valid;
+	if (host_is_truth && v->value) {
+		size_t len = d->hlen < d->cap ? d->hlen : d->cap;
+		HIPCHK(liship_memcpy_h2d(d->d, v->value, len * sizeof(double), lisg.stream));
+		d->dev_valid = 1;
+		if (lisg.residency == LIS_AMD_COHERENT) d->host_valid = 1;
+	}
+	*out = d->d;
+	return LIS_SUCCESS;
+}
+
+LIS_INT lisd_vec_out(LIS_VECTOR v, double **out)
+{
+	LISCHK(lisd_vec_reserve(v, vec_len(v)));
+	*out = VDEV(v)->d;
+	return LIS_SUCCESS;
+}
+
+LIS_INT lisd_vec_done(LIS_VECTOR v)
+{
+	lisd_vec *d = VDEV(v);
+	d->dev_valid = 1;
+	d->host_valid = 0;
+	if (lisg.residency == LIS_AMD_COHERENT) return lisd_vec_to_host(v);
+	return LIS_SUCCESS;
+}
+
+LIS_INT lisd_vec_to_host(LIS_VECTOR v)
+{
+	lisd_vec *d = VDEV(v);
+	if (d->host_valid || !d->dev_valid || !d->d || !v->value) { d->host_valid = 1; return LIS_SUCCESS; }
+	size_t len = d->hlen < d->cap ? d->hlen : d->cap;
+	HIPCHK(liship_memcpy_d2h(v->value, d->d, len * sizeof(double), lisg.stream));
+	HIPCHK(liship_stream_synchronize(lisg.stream));
+	d->host_valid = 1;
+	return LIS_SUCCESS;
+}
+
+void lisd_vec_free(LIS_VECTOR v)
+{
+	lisd_vec *d = VDEV(v);
+	if (d->d) { (void)liship_free(d->d); d->d = NULL; d->cap = 0; }
+	d->dev_valid = 0;
+}
+
+LIS_INT lis_amd_vector_sync_host(LIS_VECTOR v) { return lisd_vec_to_host(v); }
+LIS_INT lis_amd_vector_host_modified(LIS_VECTOR v) { VDEV(v)->host_valid = 1; VDEV(v)->dev_valid = 0; return LIS_SUCCESS; }
+LIS_INT lis_amd_vector_device_modified(LIS_VECTOR v) { VDEV(v)->host_valid = 0; VDEV(v)->dev_valid = 1; return LIS_SUCCESS; }
+LIS_INT lis_amd_vector_device_ptr(LIS_VECTOR v, LIS_SCALAR **dptr) { return lisd_vec_in(v, dptr); }
+
+/* ------------------------------------------------------------------ matrices */
+static LIS_INT up_i(int **dst, const int *src, size_t count)
+{
+	void *p = NULL;
+	HIPCHK(liship_malloc(&p, (count + 4) * sizeof(int)));          /* +4: 16 B slack for vector loads */
+	if (count) HIPCHK(liship_memcpy_h2d(p, src, count * sizeof(int), lisg.stream));
+	*dst = (int *)p;
+	return LIS_SUCCESS;
+}
+static LIS_INT up_d(double **dst, const double *src, size_t count)
+{
+	void *p = NULL;
+	HIPCHK(liship_malloc(&p, (count + 2) * sizeof(double)));
+	if (count) HIPCHK(liship_memcpy_h2d(p, src, count * sizeof(double), lisg.stream));
+	*dst = (double *)p;
+	return LIS_SUCCESS;
+}
+
+/* rows of the local matrix that reference no ghost column, as one maximal run [b,e) */
+static void find_inner_rows(LIS_MATRIX A, int *b, int *e)
+{
+	const int n = A->n;
+	int best_b = 0, best_e = 0, run_b = 0;
+	if (A->matrix_type != LIS_MATRIX_CSR || !A->ptr || A->np == n) { *b = 0; *e = n; return; }
+	for (int r = 0; r <= n; r++) {
+		int ghost = 1;
+		if (r < n) {
+			ghost = 0;
+			for (int k = A->ptr[r]; k < A->ptr[r + 1]; k++) if (A->index[k] >= n) { ghost = 1; break; }
+		}
+		if (ghost) {
+			if (r - run_b > best_e - best_b) { best_b = run_b; best_e = r; }
+			run_b = r + 1;
+		}
+	}
+	*b = best_b; *e = best_e;
+}
+
+static LIS_INT upload_csc_as_csr(LIS_MATRIX A, lisd_mat *d)
+{
+	const int n = A->n, np = A->np, nnz = A->nnz;
+	int *tptr = (int *)calloc((size_t)n + 2, sizeof(int));
+	int *tidx = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+	double *tval = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+	if (!tptr || !tidx || !tval) { free(tptr); free(tidx); free(tval); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "csc transpose\n"); }
+	for (int k = 0; k < nnz; k++) tptr[A->index[k] + 1]++;
+	for (int r = 0; r < n; r++) tptr[r + 1] += tptr[r];
+	int *fill = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+	memcpy(fill, tptr, sizeof(int) * (size_t)n);
+	for (int c = 0; c < np; c++)                    /* columns ascending: the reference's summation order */
+		for (int k = A->ptr[c]; k < A->ptr[c + 1]; k++) {
+			const int dst = fill[A->index[k]]++;
+			tidx[dst] = c; tval[dst] = A->value[k];
+		}
+	free(fill);
+	LIS_INT err = up_i(&d->ptr, tptr, (size_t)n + 1);
+	if (!err) err = up_i(&d->index, tidx, (size_t)nnz);
+	if (!err) err = up_d(&d->value, tval, (size_t)nnz);
+	if (!err) { int rc = liship_stream_synchronize(lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
+	free(tptr); free(tidx); free(tval);
+	return err;
+}
+
+LIS_INT lisd_mat_ready(LIS_MATRIX A)
+{
+	lisd_mat *d = MDEV(A);
+	if (d->ready) return LIS_SUCCESS;
+	LISCHK(lisd_init());
+	if (A->status < LIS_MATRIX_CSR) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is not assembled\n");
+	if (A->is_splited) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "split (D/L/U) matrices are not served\n");
+	d->n = A->n; d->np = A->np; d->nnz = A->nnz;
+	d->type = A->matrix_type;
+	const size_t n = (size_t)A->n;
+	switch (A->matrix_type) {
+	case LIS_MATRIX_CSR:
+		LISCHK(up_i(&d->ptr, A->ptr, n + 1));
+		LISCHK(up_i(&d->index, A->index, (size_t)A->nnz));
+		LISCHK(up_d(&d->value, A->value, (size_t)A->nnz));
+		HIPCHK(liship_csr_plan_create(&d->plan, A->n, d->ptr, lisg.stream));
+		break;
+	case LIS_MATRIX_CSC:
+		LISCHK(upload_csc_as_csr(A, d));
+		d->type = LIS_MATRIX_CSR;
+		HIPCHK(liship_csr_plan_create(&d->plan, A->n, d->ptr, lisg.stream));
+		break;
+	case LIS_MATRIX_ELL:
+		d->maxnzr = A->maxnzr;
+		LISCHK(up_i(&d->index, A->index, n * (size_t)A->maxnzr));
+		LISCHK(up_d(&d->value, A->value, n * (size_t)A->maxnzr));
+		break;
+	case LIS_MATRIX_DIA:
+		d->nnd = A->nnd;
+		LISCHK(up_i(&d->index, A->index, (size_t)A->nnd));
+		LISCHK(up_d(&d->value, A->value, n * (size_t)A->nnd));
+		break;
+	case LIS_MATRIX_JAD:
+		d->maxnzr = A->maxnzr;
+		LISCHK(up_i(&d->row, A->row, n));
+		LISCHK(up_i(&d->ptr, A->ptr, (size_t)A->maxnzr + 1));
+		LISCHK(up_i(&d->index, A->index, (size_t)A->nnz));
+		LISCHK(up_d(&d->value, A->value, (size_t)A->nnz));
+		break;
+	case LIS_MATRIX_BSR:
+		d->nr = A->nr; d->nc = A->nc; d->bnr = A->bnr; d->bnc = A->bnc;
+		LISCHK(up_i(&d->bptr, A->bptr, (size_t)A->nr + 1));
+		LISCHK(up_i(&d->bindex, A->bindex, (size_t)A->bnnz));
+		LISCHK(up_d(&d->value, A->value, (size_t)A->bnnz * (size_t)A->bnr * (size_t)A->bnc));
+		break;
+	default:
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "storage format %D is not served by liblis_amd\n", A->matrix_type);
+	}
+	HIPCHK(liship_stream_synchronize(lisg.stream));
+	find_inner_rows(A, &d->inner_begin, &d->inner_end);
+	d->ready = 1;
+	return LIS_SUCCESS;
+}
+
+void lisd_mat_free(LIS_MATRIX A)
+{
+	lisd_mat *d = MDEV(A);
+	if (d->plan) (void)liship_csr_plan_destroy(d->plan);
+	(void)liship_free(d->ptr); (void)liship_free(d->index); (void)liship_free(d->row);
+	(void)liship_free(d->bptr); (void)liship_free(d->bindex); (void)liship_free(d->value);
+	(void)liship_free(d->export_index); (void)liship_free(d->ws);
+	(void)liship_free(d->sx); (void)liship_free(d->sy);
+	memset(d, 0, sizeof(*d));
+}
+
+LIS_INT lis_amd_matrix_upload(LIS_MATRIX A) { return lisd_mat_ready(A); }
+LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A)
+{
+	if (MDEV(A)->device_only) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix lives in HBM only\n");
+	lisd_mat_free(A);
+	return LIS_SUCCESS;
+}
+
+/* y = A x on device pointers.  In a multi-GPU job the ghost part of x is filled first; the rows that do
+ * not touch ghosts are issued before the exchange completes (same stream ordering via RCCL). */
+LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
+{
+	lisd_mat *d = MDEV(A);
+	LISCHK(lisd_mat_ready(A));
+	if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
+	switch (d->type) {
+	case LIS_MATRIX_CSR:
+		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));
+		break;
+	case LIS_MATRIX_ELL:
+		HIPCHK(liship_spmv_ell_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, lisg.stream));
+		break;
+	case LIS_MATRIX_DIA:
+		HIPCHK(liship_spmv_dia_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, lisg.stream));
+		break;
+	case LIS_MATRIX_JAD:
+		HIPCHK(liship_spmv_jad_f64(d->n, d->maxnzr, d->row, d->ptr, d->index, d->value, dx, dy, lisg.stream));
+		break;
+	case LIS_MATRIX_BSR:
+		HIPCHK(liship_spmv_bsr_f64(d->nr, d->bnr, d->bnc, d->bptr, d->bindex, d->value, dx, dy, lisg.stream));
+		break;
+	default:
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "storage format %D is not served by liblis_amd\n", d->type);
+	}
+	return LIS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ reductions -> host scalars */
+LIS_INT lisd_fetch(int count, double *out)
+{
+	HIPCHK(liship_memcpy_d2h(lisg.host_out, lisg.reduce_out, (size_t)count * sizeof(double), lisg.stream));
+	HIPCHK(liship_stream_synchronize(lisg.stream));
+	for (int i = 0; i < count; i++) out[i] = lisg.host_out[i];
+	if (lisg.nprocs > 1) LISCHK(lisc_fold(count, out));
+	return LIS_SUCCESS;
+}
+
+LIS_INT lisd_dot(int n, const double *dx, const double *dy, double *out)
+{
+	HIPCHK(liship_dot_f64(n, dx, dy, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+	return lisd_fetch(1, out);
+}
+
+LIS_INT lisd_nrm2(int n, const double *dx, double *out)
+{
+	/* the root is taken after the cross-rank fold (ref lis_vector_ops.c:263-264) */
+	HIPCHK(liship_sumsq_f64(n, dx, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+	LISCHK(lisd_fetch(1, out));
+	*out = sqrt(*out);
+	return LIS_SUCCESS;
+}
+
+LIS_INT lisd_nrm1(int n, const double *dx, double *out)
+{
+	HIPCHK(liship_nrm1_f64(n, dx, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+	return lisd_fetch(1, out);
+}
+
+LIS_INT lisd_dot2(int n, const double *dx, const double *dy, double *out2)
+{
+	HIPCHK(liship_dot2_f64(n, dx, dy, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+	return lisd_fetch(2, out2);
+}
+
+/* ------------------------------------------------------------------ matrices born in HBM */
+LIS_INT lis_amd_matrix_set_csr_device(LIS_INT nnz, LIS_INT np, LIS_INT *dptr, LIS_INT *dindex,
+                                      LIS_SCALAR *dvalue, LIS_MATRIX A)
+{
+	if (!lisi_is_registered(A)) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is undefined\n");
+	if (A->status != LIS_MATRIX_NULL) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A must be sized and not yet assembled\n");
+	if (np < A->n) return LISI_ERR(LIS_ERR_ILL_ARG, "np(=%D) is smaller than n(=%D)\n", np, A->n);
+	LISCHK(lisd_init());
+	lisd_mat *d = MDEV(A);
+	d->device_only = 1;
+	d->type = LIS_MATRIX_CSR;
+	d->n = A->n; d->np = np; d->nnz = nnz;
+	d->ptr = dptr; d->index = dindex; d->value = dvalue;
+	HIPCHK(liship_csr_plan_create(&d->plan, A->n, d->ptr, lisg.stream));
+	d->inner_begin = 0; d->inner_end = A->n;
+	d->ready = 1;
+	A->nnz = nnz; A->np = np;
+	A->is_copy = LIS_FALSE;
+	A->matrix_type = LIS_MATRIX_CSR;
+	A->status = LIS_MATRIX_CSR;                /* assembled: there is nothing left to do on the host */
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_amd_matrix_poisson3d(LIS_MATRIX A, LIS_INT l, LIS_INT m, LIS_INT n, LIS_INT sorted)
+{
+	if (!lisi_is_registered(A)) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is undefined\n");
+	if (A->status != LIS_MATRIX_NULL) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A must be sized and not yet assembled\n");
+	const long long mn = (long long)m * n, gn = mn * l;
+	if (gn != A->gn) return LISI_ERR(LIS_ERR_ILL_ARG, "grid %D x %D x %D does not match the global size\n", l, m, n);
+	const long long nnz = liship_poisson3d_nnz(l, m, n, A->is, A->ie);
+	if (nnz < 0) return LISI_ERR(LIS_ERR_ILL_ARG, "rows [%D,%D) are not whole grid planes of %D rows\n", A->is, A->ie, (LIS_INT)mn);
+	LISCHK(lisd_init());
+	const LIS_INT nloc = A->n, nlow = A->is > 0 ? (LIS_INT)mn : 0, nup = A->ie < gn ? (LIS_INT)mn : 0;
+	int *dptr = NULL, *didx = NULL; double *dval = NULL;
+	HIPCHK(liship_malloc((void **)&dptr, sizeof(int) * ((size_t)nloc + 1 + 4)));
+	HIPCHK(liship_malloc((void **)&didx, sizeof(int) * ((size_t)nnz + 4)));
+	HIPCHK(liship_malloc((void **)&dval, sizeof(double) * ((size_t)nnz + 2)));
+	HIPCHK(liship_poisson3d_csr(l, m, n, A->is, A->ie, sorted, dptr, didx, dval, lisg.stream));
+	LISCHK(lis_amd_matrix_set_csr_device((LIS_INT)nnz, nloc + nlow + nup, dptr, didx, dval, A));
+	if (A->nprocs > 1) {
+		/* halo tables in closed form: one plane to/from the rank below and above (ghosts ascending: low first) */
+		const LIS_INT ns = nlow + nup;
+		A->l2g_map = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(ns > 0 ? ns : 1));
+		for (LIS_INT i = 0; i < nlow; i++) A->l2g_map[i] = A->is - (LIS_INT)mn + i;
+		for (LIS_INT i = 0; i < nup; i++) A->l2g_map[nlow + i] = A->ie + i;
+		LIS_COMMTABLE t = (LIS_COMMTABLE)calloc(1, sizeof(struct LIS_COMMTABLE_STRUCT));
+		const LIS_INT nb = (nlow ? 1 : 0) + (nup ? 1 : 0);
+		t->neibpe = (LIS_INT *)malloc(sizeof(LIS_INT) * 2);
+		t->import_ptr = (LIS_INT *)calloc(3, sizeof(LIS_INT)); t->export_ptr = (LIS_INT *)calloc(3, sizeof(LIS_INT));
+		t->import_index = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(ns > 0 ? ns : 1));
+		t->export_index = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(ns > 0 ? ns : 1));
+		LIS_INT q = 0;
+		if (nlow) { t->neibpe[q] = A->my_rank - 1; t->import_ptr[q + 1] = t->import_ptr[q] + nlow; t->export_ptr[q + 1] = t->export_ptr[q] + nlow;
+			for (LIS_INT i = 0; i < nlow; i++) t->export_index[t->export_ptr[q] + i] = i; q++; }
+		if (nup)  { t->neibpe[q] = A->my_rank + 1; t->import_ptr[q + 1] = t->import_ptr[q] + nup;  t->export_ptr[q + 1] = t->export_ptr[q] + nup;
+			for (LIS_INT i = 0; i < nup; i++) t->export_index[t->export_ptr[q] + i] = nloc - (LIS_INT)mn + i; q++; }
+		for (LIS_INT i = 0; i < ns; i++) t->import_index[i] = nloc + i;
+		t->comm = A->comm; t->neibpetot = nb; t->imnnz = ns; t->exnnz = ns; t->wssize = ns; t->wrsize = ns;
+		t->ws = (LIS_SCALAR *)malloc(sizeof(LIS_SCALAR) * (size_t)(ns > 0 ? ns : 1));
+		t->wr = (LIS_SCALAR *)malloc(sizeof(LIS_SCALAR) * (size_t)(ns > 0 ? ns : 1));
+		A->commtable = t;
+		A->is_comm = LIS_TRUE;
+		MDEV(A)->inner_begin = nlow; MDEV(A)->inner_end = nloc - nup;
+	}
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_amd_vector_poisson3d_rhs(LIS_VECTOR b, LIS_INT l, LIS_INT m, LIS_INT n)
+{
+	double *db;
+	LISCHK(lisd_vec_out(b, &db));
+	HIPCHK(liship_poisson3d_rhs(l, m, n, b->is, b->ie, db, lisg.stream));
+	return lisd_vec_done(b);
+}

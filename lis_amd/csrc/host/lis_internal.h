@@ -1,0 +1,138 @@
+/*
+ * lis_internal.h -- private side of liblis_amd.so's host layer (C).
+ *
+ * Public Lis objects are allocated as a larger private struct whose first member is the public,
+ * ABI-identical struct from include/lis.h; the tail carries the HBM copy and its validity flags.
+ */
+#ifndef LIS_AMD_INTERNAL_H
+#define LIS_AMD_INTERNAL_H
+
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "lis.h"
+#include "lis_amd.h"
+#include "liship.h"
+
+/* ---- error reporting: "file(line) : func : error CODE :message" (reference src/system/lis_error.c:161) */
+LIS_INT lisi_error(const char *file, const char *func, int line, LIS_INT code, const char *fmt, ...);
+#define LISI_ERR(code, ...) (lisi_error(__FILE__, __func__, __LINE__, (code), __VA_ARGS__), (code))
+/* a failing HIP call is fatal for the operation: no CPU fallback exists */
+LIS_INT lisi_hip_error(const char *file, const char *func, int line, int hipcode);
+#define HIPCHK(expr) do { int rc__ = (expr); if (rc__ != 0) return lisi_hip_error(__FILE__, __func__, __LINE__, rc__); } while (0)
+#define LISCHK(expr) do { LIS_INT e__ = (expr); if (e__ != LIS_SUCCESS) return e__; } while (0)
+
+/* ---- object registry (lis_is_malloc on handles, leak-free lis_finalize) */
+#define LISI_KIND_VECTOR 1
+#define LISI_KIND_MATRIX 2
+#define LISI_KIND_SOLVER 3
+#define LISI_KIND_PRECON 4
+void lisi_register(void *obj, int kind);
+void lisi_unregister(void *obj);
+int  lisi_is_registered(void *obj);
+
+/* ---- vectors ------------------------------------------------------------------------------------ */
+typedef struct {
+	double *d;          /* HBM buffer (NULL until first device use) */
+	size_t  cap;        /* doubles allocated in HBM */
+	size_t  hlen;       /* doubles allocated on the host (value[]) */
+	int     host_valid; /* value[] holds the current data */
+	int     dev_valid;  /* d[] holds the current data */
+} lisd_vec;
+
+typedef struct {
+	struct LIS_VECTOR_STRUCT pub;
+	lisd_vec dev;
+} lisi_vector;
+#define VDEV(v) (&((lisi_vector *)(v))->dev)
+
+/* ---- matrices ----------------------------------------------------------------------------------- */
+typedef struct {
+	int ready;                 /* HBM copy is built */
+	int device_only;           /* arrays were adopted from the caller; no host copy exists */
+	int type;                  /* kernel family actually used (CSC is served as transposed CSR) */
+	int n, np, nnz;
+	int maxnzr, nnd, nr, nc, bnr, bnc;
+	int *ptr, *index, *row, *bptr, *bindex;
+	double *value;
+	liship_csr_plan_t plan;
+	/* halo (multi-GPU) */
+	int halo_ready;
+	int *export_index;         /* device copy of commtable->export_index */
+	double *ws;                /* packed send buffer in HBM */
+	int inner_begin, inner_end;/* maximal run of rows without ghost columns: overlappable with the halo */
+	/* scratch for the raw-array entry points lis_matvec_<fmt>(A, x[], y[]) */
+	double *sx, *sy; size_t scap;
+} lisd_mat;
+
+typedef struct {
+	struct LIS_MATRIX_STRUCT pub;
+	lisd_mat dev;
+} lisi_matrix;
+#define MDEV(A) (&((lisi_matrix *)(A))->dev)
+
+/* ---- global runtime state ------------------------------------------------------------------------ */
+typedef struct {
+	int initialized;
+	int residency;
+	int device_ready;
+	int device;
+	void *stream;
+	void *reduce_work;         /* HBM scratch of the two-stage reductions */
+	double *reduce_out;        /* HBM: up to 4 results */
+	double *gather_out;        /* HBM: nprocs * 4 doubles (cross-rank fold) */
+	double host_out[4];
+	/* communicator */
+	int rank, nprocs;
+	int comm_kind;             /* 0 none, 1 rccl, 2 callbacks */
+	void *nccl_comm;
+	lis_amd_comm_callbacks cb;
+} lisi_globals;
+extern lisi_globals lisg;
+
+/* ---- device runtime (lis_device.c) */
+LIS_INT lisd_init(void);                                     /* lazy; fails loudly without a GPU */
+LIS_INT lisd_vec_in(LIS_VECTOR v, double **d);                /* device pointer holding current data (input) */
+LIS_INT lisd_vec_out(LIS_VECTOR v, double **d);               /* device pointer to be fully overwritten (n entries) */
+LIS_INT lisd_vec_done(LIS_VECTOR v);                          /* after a kernel wrote v on the device */
+LIS_INT lisd_vec_reserve(LIS_VECTOR v, size_t doubles);       /* grow the HBM buffer (keeps data) */
+LIS_INT lisd_vec_to_host(LIS_VECTOR v);
+void    lisd_vec_free(LIS_VECTOR v);
+LIS_INT lisd_mat_ready(LIS_MATRIX A);
+void    lisd_mat_free(LIS_MATRIX A);
+LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy);      /* y = A x on device pointers (halo included) */
+LIS_INT lisd_fetch(int count, double *out);                   /* reduce_out[0..count) -> host, cross-rank fold */
+LIS_INT lisd_dot(int n, const double *dx, const double *dy, double *out);
+LIS_INT lisd_nrm2(int n, const double *dx, double *out);
+LIS_INT lisd_nrm1(int n, const double *dx, double *out);
+LIS_INT lisd_dot2(int n, const double *dx, const double *dy, double *out2);
+
+/* ---- communicator (lis_comm.c) */
+LIS_INT lisc_ranges_create(LIS_Comm comm, LIS_INT *local_n, LIS_INT *global_n, LIS_INT **ranges,
+                           LIS_INT *is, LIS_INT *ie, LIS_INT *nprocs, LIS_INT *my_rank);
+LIS_INT lisc_matrix_g2l(LIS_MATRIX A);                        /* global -> local columns, ghosts appended */
+LIS_INT lisc_commtable_create(LIS_MATRIX A);
+void    lisc_commtable_destroy(LIS_COMMTABLE t);
+LIS_INT lisc_halo_device(LIS_MATRIX A, double *dx);           /* fill dx[n..np) from the neighbours */
+LIS_INT lisc_fold(int count, double *host_inout);             /* sum over ranks, rank order */
+LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes);
+
+/* ---- matrix internals shared between files */
+LIS_INT lisi_matrix_check(LIS_MATRIX A, int level);
+#define LISI_CHECK_NULL 0
+#define LISI_CHECK_SIZE 1
+#define LISI_CHECK_ASSEMBLED 2
+#define LISI_CHECK_NOT_ASSEMBLED 3
+LIS_INT lisi_matrix_storage_destroy(LIS_MATRIX A);
+LIS_INT lisi_matrix_copy_header(LIS_MATRIX src, LIS_MATRIX dst);
+void    lisi_sort_row(LIS_INT lo, LIS_INT hi, LIS_INT *idx, LIS_SCALAR *val);
+LIS_INT lisi_convert_csr_to(LIS_MATRIX Ain, LIS_MATRIX Aout);  /* Aout->matrix_type selects the target */
+LIS_INT lisi_convert_to_csr(LIS_MATRIX Ain, LIS_MATRIX Aout);
+LIS_INT lisi_matrix_deep_copy(LIS_MATRIX Ain, LIS_MATRIX Aout);
+
+/* args (lis_initialize / lis_solver_set_option share the tokenizer) */
+int lisi_tokenize(const char *text, char ***tokens);
+void lisi_tokens_free(char **tokens, int n);
+extern int lisi_cmd_argc; extern char **lisi_cmd_argv;
+
+#endif

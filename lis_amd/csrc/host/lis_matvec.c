@@ -1,0 +1,61 @@
+/*
+ * lis_matvec.c -- y = A x through the Lis entry points, executed by the HIP kernels.
+ *
+ *   lis_matvec(A, X, Y)               reference src/matvec/lis_matvec.c:55-187: switch on A->matrix_type,
+ *                                     halo exchange first in a multi-rank job (LIS_MATVEC_SENDRECV,
+ *                                     include/lis_matvec.h:31-44), unknown format -> LIS_ERR_NOT_IMPLEMENTED
+ *   lis_matvec_<fmt>(A, x[], y[])     reference include/lis_matvec.h:91-181: raw HOST arrays.  They cannot
+ *                                     report errors (void), so a failing device call aborts loudly.
+ */
+#include <stdio.h>
+#include "lis_internal.h"
+
+LIS_INT lis_matvec(LIS_MATRIX A, LIS_VECTOR X, LIS_VECTOR Y)
+{
+	switch (A->matrix_type) {
+	case LIS_MATRIX_CSR: case LIS_MATRIX_CSC: case LIS_MATRIX_ELL:
+	case LIS_MATRIX_DIA: case LIS_MATRIX_JAD: case LIS_MATRIX_BSR:
+		break;
+	default:
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "storage format %D is not served by liblis_amd\n", A->matrix_type);
+	}
+	LISCHK(lisd_mat_ready(A));
+	/* like the reference, grow X to hold the ghost (and block padding) entries of A */
+	if (A->np + A->pad > X->np + X->pad) { X->np = A->np; X->pad = A->pad; }
+	double *dx, *dy;
+	size_t need_x = (size_t)(A->np + A->pad), need_y = (size_t)(A->n + A->pad);
+	if (A->matrix_type == LIS_MATRIX_BSR) { need_x = (size_t)A->nc * A->bnc; need_y = (size_t)A->nr * A->bnr; }
+	LISCHK(lisd_vec_reserve(X, need_x));
+	LISCHK(lisd_vec_reserve(Y, need_y));
+	LISCHK(lisd_vec_in(X, &dx));
+	LISCHK(lisd_vec_out(Y, &dy));
+	LISCHK(lisd_spmv(A, dx, dy));
+	return lisd_vec_done(Y);
+}
+
+static void raw_matvec(LIS_MATRIX A, LIS_INT fmt, LIS_SCALAR x[], LIS_SCALAR y[])
+{
+	lisd_mat *d = MDEV(A);
+	LIS_INT err = (A->matrix_type == fmt) ? lisd_mat_ready(A) : LIS_ERR_ILL_ARG;
+	const size_t nx = (size_t)A->np + (size_t)A->pad + 16 + (fmt == LIS_MATRIX_BSR ? (size_t)A->nc * A->bnc : 0);
+	if (!err && d->scap < nx) {
+		(void)liship_free(d->sx); (void)liship_free(d->sy);
+		d->sx = d->sy = NULL; d->scap = 0;
+		if (liship_malloc((void **)&d->sx, nx * sizeof(double)) || liship_malloc((void **)&d->sy, nx * sizeof(double))) err = LIS_ERR_OUT_OF_MEMORY;
+		else { d->scap = nx; (void)liship_memset(d->sx, 0, nx * sizeof(double), lisg.stream); }
+	}
+	if (!err && liship_memcpy_h2d(d->sx, x, sizeof(double) * (size_t)(lisg.nprocs > 1 ? A->n : A->np), lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+	if (!err) err = lisd_spmv(A, d->sx, d->sy);
+	if (!err && (liship_memcpy_d2h(y, d->sy, sizeof(double) * (size_t)A->n, lisg.stream) || liship_stream_synchronize(lisg.stream))) err = LIS_ERR_NOT_IMPLEMENTED;
+	if (err) {
+		fprintf(stderr, "liblis_amd: lis_matvec_<fmt>(A, x[], y[]) failed (code %d) and has no error channel -- aborting\n", (int)err);
+		abort();
+	}
+}
+
+void lis_matvec_csr(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A, LIS_MATRIX_CSR, x, y); }
+void lis_matvec_csc(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A, LIS_MATRIX_CSC, x, y); }
+void lis_matvec_ell(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A, LIS_MATRIX_ELL, x, y); }
+void lis_matvec_dia(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A, LIS_MATRIX_DIA, x, y); }
+void lis_matvec_jad(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A, LIS_MATRIX_JAD, x, y); }
+void lis_matvec_bsr(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A, LIS_MATRIX_BSR, x, y); }

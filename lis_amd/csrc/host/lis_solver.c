@@ -1,0 +1,642 @@
+/*
+ * lis_solver.c -- lis_solve() and the three Krylov loops of the hot path, iterating entirely in HBM.
+ *
+ * Orchestration follows the reference (src/solver/lis_solver.c: lis_solve :367, lis_solve_kernel :441,
+ * initial residual :957, defaults :242-284, option table :175-197); the recurrences are the reference's
+ *   CG        src/solver/lis_solver_cg.c:129-235
+ *   BiCGSTAB  src/solver/lis_solver_bicgstab.c:137-315
+ *   GMRES(m)  src/solver/lis_solver_gmres.c:135-342
+ * with every vector operation in the same order and with the same element-wise arithmetic, executed by
+ * the HIP kernels; only the association order inside dot / nrm2 differs (fixed tree instead of the
+ * reference's thread-count dependent left-to-right sum).  Work vectors are raw HBM buffers:
+ * b and x cross PCIe once on entry, x once on exit.  Scalars (alpha, beta, rho, Givens rotations, the
+ * Hessenberg matrix) stay on the host exactly as in the reference.
+ */
+#include <ctype.h>
+#include <stdio.h>
+#include "lis_internal.h"
+
+static const char *solver_keys[] = {"cg", "bicg", "cgs", "bicgstab", "bicgstabl", "gpbicg", "tfqmr", "orthomin", "gmres",
+	"jacobi", "gs", "sor", "bicgsafe", "cr", "bicr", "crs", "bicrstab", "gpbicr", "bicrsafe", "fgmres", "idrs", "idr1",
+	"minres", "cocg", "cocr"};
+static const char *solver_names[] = {"", "CG", "BiCG", "CGS", "BiCGSTAB", "BiCGSTAB(l)", "GPBiCG", "TFQMR", "Orthomin", "GMRES",
+	"Jacobi", "Gauss-Seidel", "SOR", "BiCGSafe", "CR", "BiCR", "CRS", "BiCRSTAB", "GPBiCR", "BiCRSafe", "FGMRES", "IDR(s)",
+	"IDR(1)", "MINRES", "COCG", "COCR"};
+static const char *precon_keys[] = {"none", "jacobi", "ilu", "ssor", "hybrid", "is", "sainv", "saamg", "iluc", "ilut", "bjacobi"};
+static const char *precon_names[] = {"none", "Jacobi", "ILU", "SSOR", "Hybrid", "I+S", "SAINV", "SAAMG", "Crout ILU", "ILUT", "Block Jacobi"};
+static const char *storage_keys[] = {"csr", "csc", "msr", "dia", "ell", "jad", "bsr", "bsc", "vbr", "coo", "dns"};
+static const char *storage_names[] = {"CSR", "CSC", "MSR", "DIA", "ELL", "JAD", "BSR", "BSC", "VBR", "COO", "DNS"};
+static const char *print_keys[] = {"none", "mem", "out", "all"};
+static const char *scale_keys[] = {"none", "jacobi", "symm_diag"};
+static const char *bool_keys[] = {"false", "true"};
+static const char *precision_keys[] = {"double", "quad", "switch"};
+static const char *conv_keys[] = {"nrm2_r", "nrm2_b", "nrm1_b"};
+static const char *retcode_names[] = {"LIS_SUCCESS", "LIS_ILL_OPTION", "LIS_BREAKDOWN", "LIS_OUT_OF_MEMORY", "LIS_MAXITER", "LIS_NOT_IMPLEMENTED", "LIS_ERR_FILE_IO"};
+#define COUNT(a) ((int)(sizeof(a) / sizeof((a)[0])))
+
+/* ------------------------------------------------------------------ solver object */
+static void solver_defaults(LIS_SOLVER s)
+{	/* ref lis_solver.c:221-290 */
+	memset(s, 0, sizeof(*s));
+	LIS_INT *o = s->options; LIS_SCALAR *p = s->params;
+	o[LIS_OPTIONS_SOLVER] = LIS_SOLVER_BICG;   o[LIS_OPTIONS_PRECON] = LIS_PRECON_TYPE_NONE;
+	o[LIS_OPTIONS_OUTPUT] = LIS_FALSE;         o[LIS_OPTIONS_MAXITER] = 1000;
+	o[LIS_OPTIONS_RESTART] = 40;               o[LIS_OPTIONS_ELL] = 2;
+	o[LIS_OPTIONS_SCALE] = LIS_SCALE_NONE;     o[LIS_OPTIONS_FILL] = 0;
+	o[LIS_OPTIONS_M] = 3;                      o[LIS_OPTIONS_PSOLVER] = LIS_SOLVER_SOR;
+	o[LIS_OPTIONS_PMAXITER] = 25;              o[LIS_OPTIONS_PRESTART] = 40;
+	o[LIS_OPTIONS_PELL] = 2;                   o[LIS_OPTIONS_PPRECON] = LIS_PRECON_TYPE_NONE;
+	o[LIS_OPTIONS_ISLEVEL] = 1;                o[LIS_OPTIONS_INITGUESS_ZEROS] = LIS_TRUE;
+	o[LIS_OPTIONS_ADDS] = LIS_FALSE;           o[LIS_OPTIONS_ADDS_ITER] = 1;
+	o[LIS_OPTIONS_PRECISION] = LIS_PRECISION_DOUBLE; o[LIS_OPTIONS_USE_AT] = LIS_FALSE;
+	o[LIS_OPTIONS_SWITCH_MAXITER] = -1;        o[LIS_OPTIONS_SAAMG_UNSYM] = LIS_FALSE;
+	o[LIS_OPTIONS_STORAGE] = 0;                o[LIS_OPTIONS_STORAGE_BLOCK] = 2;
+	o[LIS_OPTIONS_CONV_COND] = 0;              o[LIS_OPTIONS_INIT_SHADOW_RESID] = LIS_RESID;
+	o[LIS_OPTIONS_IDRS_RESTART] = 2;
+	p[LIS_PARAMS_RESID - LIS_OPTIONS_LEN] = 1.0e-12;       p[LIS_PARAMS_RESID_WEIGHT - LIS_OPTIONS_LEN] = 1.0;
+	p[LIS_PARAMS_OMEGA - LIS_OPTIONS_LEN] = 1.9;           p[LIS_PARAMS_SSOR_OMEGA - LIS_OPTIONS_LEN] = 1.0;
+	p[LIS_PARAMS_RELAX - LIS_OPTIONS_LEN] = 1.0;           p[LIS_PARAMS_DROP - LIS_OPTIONS_LEN] = 0.05;
+	p[LIS_PARAMS_ALPHA - LIS_OPTIONS_LEN] = 1.0;           p[LIS_PARAMS_TAU - LIS_OPTIONS_LEN] = 0.05;
+	p[LIS_PARAMS_SIGMA - LIS_OPTIONS_LEN] = 2.0;           p[LIS_PARAMS_GAMMA - LIS_OPTIONS_LEN] = 1.0;
+	p[LIS_PARAMS_PRESID - LIS_OPTIONS_LEN] = 1.0e-3;       p[LIS_PARAMS_POMEGA - LIS_OPTIONS_LEN] = 1.5;
+	p[LIS_PARAMS_SWITCH_RESID - LIS_OPTIONS_LEN] = 1.0e-12; p[LIS_PARAMS_RATE - LIS_OPTIONS_LEN] = 5.0;
+	p[LIS_PARAMS_SAAMG_THETA - LIS_OPTIONS_LEN] = 0.05;
+	s->precision = LIS_PRECISION_DOUBLE;
+}
+
+LIS_INT lis_solver_create(LIS_SOLVER *solver)
+{
+	*solver = (LIS_SOLVER)malloc(sizeof(struct LIS_SOLVER_STRUCT));
+	if (!*solver) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)sizeof(struct LIS_SOLVER_STRUCT));
+	solver_defaults(*solver);
+	lisi_register(*solver, LISI_KIND_SOLVER);
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_solver_destroy(LIS_SOLVER solver)
+{
+	if (solver && lisi_is_registered(solver)) {
+		if (solver->d) lis_vector_destroy(solver->d);
+		free(solver->rhistory);
+		lisi_unregister(solver);
+		free(solver);
+	}
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_solver_set_matrix(LIS_MATRIX A, LIS_SOLVER solver) { solver->A = A; return LIS_SUCCESS; }
+LIS_INT lis_solver_get_iter(LIS_SOLVER s, LIS_INT *iter) { *iter = s->iter; return LIS_SUCCESS; }
+LIS_INT lis_solver_get_iterex(LIS_SOLVER s, LIS_INT *iter, LIS_INT *d, LIS_INT *q)
+{ *iter = s->iter; *d = s->iter2; *q = s->iter - s->iter2; return LIS_SUCCESS; }
+LIS_INT lis_solver_get_time(LIS_SOLVER s, double *t) { *t = s->time; return LIS_SUCCESS; }
+LIS_INT lis_solver_get_timeex(LIS_SOLVER s, double *time, double *itime, double *ptime, double *pc, double *pi)
+{
+	*time = s->time;
+	if (itime) *itime = s->itime;
+	if (ptime) *ptime = s->ptime;
+	if (pc) *pc = s->p_c_time;
+	if (pi) *pi = s->p_i_time;
+	return LIS_SUCCESS;
+}
+LIS_INT lis_solver_get_residualnorm(LIS_SOLVER s, LIS_REAL *r) { *r = s->resid; return LIS_SUCCESS; }
+LIS_INT lis_solver_get_solver(LIS_SOLVER s, LIS_INT *n) { *n = s->options[LIS_OPTIONS_SOLVER]; return LIS_SUCCESS; }
+LIS_INT lis_solver_get_precon(LIS_SOLVER s, LIS_INT *p) { *p = s->options[LIS_OPTIONS_PRECON]; return LIS_SUCCESS; }
+LIS_INT lis_solver_get_status(LIS_SOLVER s, LIS_INT *st) { *st = s->retcode; return LIS_SUCCESS; }
+
+LIS_INT lis_solver_get_rhistory(LIS_SOLVER s, LIS_VECTOR v)
+{	/* ref lis_solver.c:1715-1740 */
+	LIS_INT count = s->iter + 1;
+	if (s->retcode != LIS_SUCCESS) count--;
+	if (count > v->n) count = v->n;
+	LISCHK(lisd_vec_to_host(v));
+	for (LIS_INT i = 0; i < count; i++) v->value[i] = s->rhistory[i];
+	lis_amd_vector_host_modified(v);
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_solver_output_rhistory(LIS_SOLVER s, char *filename)
+{	/* ref src/system/lis_output.c:586-640: one %e per line, entries 0..iter */
+	if (!s->rhistory) return LISI_ERR(LIS_ERR_ILL_ARG, "residual history is empty\n");
+	if (lisg.rank != 0) return LIS_SUCCESS;
+	FILE *f = fopen(filename, "w");
+	if (!f) return LISI_ERR(LIS_ERR_FILE_IO, "cannot open file %s\n", filename);
+	LIS_INT count = s->iter + 1;
+	if (s->retcode != LIS_SUCCESS) count--;
+	for (LIS_INT i = 0; i < count; i++) fprintf(f, "%e\n", s->rhistory[i]);
+	fclose(f);
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_solver_get_solvername(LIS_INT solver, char *name)
+{
+	if (solver < 1 || solver > LIS_SOLVER_LEN) return LIS_FAILS;
+	strcpy(name, solver_names[solver]);
+	return LIS_SUCCESS;
+}
+LIS_INT lis_solver_get_preconname(LIS_INT precon_type, char *name)
+{
+	if (precon_type < 0 || precon_type > LIS_PRECON_TYPE_LEN - 2) return LIS_FAILS;
+	strcpy(name, precon_names[precon_type]);
+	return LIS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ options */
+static LIS_INT pick(const char *val, const char **keys, int nkeys, int base, LIS_INT *slot, const char *what)
+{
+	if (val[0] >= '0' && val[0] <= '9') { *slot = atoi(val); return LIS_SUCCESS; }
+	for (int i = 0; i < nkeys; i++) if (strcmp(val, keys[i]) == 0) { *slot = i + base; return LIS_SUCCESS; }
+	return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter %s is not correct\n", what);
+}
+
+static LIS_INT set_one(const char *name, const char *val, LIS_SOLVER s)
+{
+	static const struct { const char *name; int slot; } table[] = {   /* ref lis_solver.c:175-197 */
+		{"-maxiter", LIS_OPTIONS_MAXITER}, {"-tol", LIS_PARAMS_RESID}, {"-print", LIS_OPTIONS_OUTPUT}, {"-scale", LIS_OPTIONS_SCALE},
+		{"-ssor_omega", LIS_PARAMS_SSOR_OMEGA}, {"-ilu_fill", LIS_OPTIONS_FILL}, {"-ilu_relax", LIS_PARAMS_RELAX},
+		{"-is_alpha", LIS_PARAMS_ALPHA}, {"-is_level", LIS_OPTIONS_ISLEVEL}, {"-is_m", LIS_OPTIONS_M},
+		{"-hybrid_maxiter", LIS_OPTIONS_PMAXITER}, {"-hybrid_ell", LIS_OPTIONS_PELL}, {"-hybrid_restart", LIS_OPTIONS_PRESTART},
+		{"-hybrid_tol", LIS_PARAMS_PRESID}, {"-hybrid_omega", LIS_PARAMS_POMEGA}, {"-hybrid_i", LIS_OPTIONS_PSOLVER},
+		{"-sainv_drop", LIS_PARAMS_DROP}, {"-ric2s_tau", LIS_PARAMS_TAU}, {"-ric2s_sigma", LIS_PARAMS_SIGMA}, {"-ric2s_gamma", LIS_PARAMS_GAMMA},
+		{"-restart", LIS_OPTIONS_RESTART}, {"-ell", LIS_OPTIONS_ELL}, {"-omega", LIS_PARAMS_OMEGA}, {"-i", LIS_OPTIONS_SOLVER},
+		{"-p", LIS_OPTIONS_PRECON}, {"-hybrid_p", LIS_OPTIONS_PPRECON}, {"-initx_zeros", LIS_OPTIONS_INITGUESS_ZEROS},
+		{"-adds", LIS_OPTIONS_ADDS}, {"-adds_iter", LIS_OPTIONS_ADDS_ITER}, {"-f", LIS_OPTIONS_PRECISION}, {"-use_at", LIS_OPTIONS_USE_AT},
+		{"-switch_tol", LIS_PARAMS_SWITCH_RESID}, {"-switch_maxiter", LIS_OPTIONS_SWITCH_MAXITER}, {"-saamg_unsym", LIS_OPTIONS_SAAMG_UNSYM},
+		{"-iluc_drop", LIS_PARAMS_DROP}, {"-iluc_gamma", LIS_PARAMS_GAMMA}, {"-iluc_rate", LIS_PARAMS_RATE},
+		{"-storage", LIS_OPTIONS_STORAGE}, {"-storage_block", LIS_OPTIONS_STORAGE_BLOCK}, {"-conv_cond", LIS_OPTIONS_CONV_COND},
+		{"-tol_w", LIS_PARAMS_RESID_WEIGHT}, {"-saamg_theta", LIS_PARAMS_SAAMG_THETA}, {"-irestart", LIS_OPTIONS_IDRS_RESTART},
+	};
+	for (int i = 0; i < COUNT(table); i++) {
+		if (strcmp(name, table[i].name) != 0) continue;
+		const int slot = table[i].slot;
+		LIS_INT *o = s->options;
+		switch (slot) {
+		case LIS_OPTIONS_SOLVER:  return pick(val, solver_keys, COUNT(solver_keys), 1, &o[slot], "LIS_OPTIONS_SOLVER");
+		case LIS_OPTIONS_PSOLVER: return pick(val, solver_keys, COUNT(solver_keys), 1, &o[slot], "LIS_OPTIONS_PSOLVER");
+		case LIS_OPTIONS_PRECON:  return pick(val, precon_keys, COUNT(precon_keys), 0, &o[slot], "LIS_OPTIONS_PRECON");
+		case LIS_OPTIONS_PPRECON: return pick(val, precon_keys, COUNT(precon_keys), 0, &o[slot], "LIS_OPTIONS_PPRECON");
+		case LIS_OPTIONS_SCALE:   return pick(val, scale_keys, COUNT(scale_keys), 0, &o[slot], "LIS_OPTIONS_SCALE");
+		case LIS_OPTIONS_OUTPUT:  return pick(val, print_keys, COUNT(print_keys), 0, &o[slot], "LIS_OPTIONS_OUTPUT");
+		case LIS_OPTIONS_STORAGE: return pick(val, storage_keys, COUNT(storage_keys), 1, &o[slot], "LIS_OPTIONS_STORAGE");
+		case LIS_OPTIONS_CONV_COND: return pick(val, conv_keys, COUNT(conv_keys), 0, &o[slot], "LIS_OPTIONS_CONV_COND");
+		case LIS_OPTIONS_PRECISION: return pick(val, precision_keys, COUNT(precision_keys), 0, &o[slot], "LIS_OPTIONS_PRECISION");
+		case LIS_OPTIONS_INITGUESS_ZEROS: case LIS_OPTIONS_ADDS: case LIS_OPTIONS_USE_AT: case LIS_OPTIONS_SAAMG_UNSYM:
+			return pick(val, bool_keys, COUNT(bool_keys), 0, &o[slot], "true/false");
+		default:
+			if (slot < LIS_OPTIONS_LEN) o[slot] = atoi(val);
+			else s->params[slot - LIS_OPTIONS_LEN] = strtod(val, NULL);
+			return LIS_SUCCESS;
+		}
+	}
+	return LIS_SUCCESS;      /* unknown options are ignored, as in the reference */
+}
+
+static LIS_INT set_from_tokens(char **tok, int n, LIS_SOLVER s)
+{
+	for (int i = 0; i + 1 < n; i++) {
+		if (tok[i][0] != '-' || (tok[i][1] >= '0' && tok[i][1] <= '9')) continue;
+		char name[64], val[256];
+		size_t k;
+		for (k = 0; tok[i][k] && k + 1 < sizeof(name); k++) name[k] = (char)tolower((unsigned char)tok[i][k]);
+		name[k] = 0;
+		for (k = 0; tok[i + 1][k] && k + 1 < sizeof(val); k++) val[k] = (char)tolower((unsigned char)tok[i + 1][k]);
+		val[k] = 0;
+		LIS_INT err = set_one(name, val, s);
+		if (err) { s->retcode = err; return err; }
+	}
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_solver_set_option(char *text, LIS_SOLVER solver)
+{
+	char **tok;
+	int n = lisi_tokenize(text, &tok);
+	LIS_INT err = set_from_tokens(tok, n, solver);
+	lisi_tokens_free(tok, n);
+	return err;
+}
+
+LIS_INT lis_solver_set_optionC(LIS_SOLVER solver)
+{	/* options given on the command line captured by lis_initialize (ref lis_solver.c:1095) */
+	return set_from_tokens(lisi_cmd_argv, lisi_cmd_argc, solver);
+}
+
+/* ------------------------------------------------------------------ preconditioner (none, Jacobi) */
+LIS_INT lis_precon_create(LIS_SOLVER solver, LIS_PRECON *precon)
+{
+	const LIS_INT type = solver->options[LIS_OPTIONS_PRECON];
+	*precon = NULL;
+	if (type != LIS_PRECON_TYPE_NONE && type != LIS_PRECON_TYPE_JACOBI)
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "preconditioner %D is not served by liblis_amd (none, jacobi)\n", type);
+	LIS_PRECON p = (LIS_PRECON)calloc(1, sizeof(struct LIS_PRECON_STRUCT));
+	if (!p) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)sizeof(struct LIS_PRECON_STRUCT));
+	p->precon_type = type;
+	lisi_register(p, LISI_KIND_PRECON);
+	if (type == LIS_PRECON_TYPE_JACOBI) {      /* D = 1 / diag(A): ref lis_precon_jacobi.c:61-85 */
+		LIS_INT err = lis_vector_duplicate(solver->A, &p->D);
+		if (!err) err = lis_matrix_get_diagonal(solver->A, p->D);
+		if (!err) err = lis_vector_reciprocal(p->D);
+		if (err) { lis_precon_destroy(p); return err; }
+	}
+	*precon = p;
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_precon_destroy(LIS_PRECON precon)
+{
+	if (precon && lisi_is_registered(precon)) {
+		if (precon->D) lis_vector_destroy(precon->D);
+		lisi_unregister(precon);
+		free(precon);
+	}
+	return LIS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ the device-side solve context */
+typedef struct {
+	LIS_SOLVER s;
+	LIS_MATRIX A;
+	int n;
+	size_t len;              /* doubles per work vector: np + pad + slack (ghost slots for the halo) */
+	double *b, *x;           /* HBM */
+	double *dinv;            /* Jacobi 1/diag in HBM, NULL for none */
+	double **work; int nwork;
+	double bnrm, tol;
+	int output, maxiter;
+} ctx_t;
+
+static LIS_INT work_alloc(ctx_t *c, int count)
+{
+	c->work = (double **)calloc((size_t)count, sizeof(double *));
+	c->nwork = count;
+	for (int i = 0; i < count; i++) {
+		HIPCHK(liship_malloc((void **)&c->work[i], c->len * sizeof(double)));
+		HIPCHK(liship_memset(c->work[i], 0, c->len * sizeof(double), lisg.stream));
+	}
+	return LIS_SUCCESS;
+}
+static void work_free(ctx_t *c)
+{
+	for (int i = 0; i < c->nwork; i++) (void)liship_free(c->work[i]);
+	free(c->work); c->work = NULL; c->nwork = 0;
+}
+
+#define K(call) HIPCHK(call)
+static LIS_INT d_copy(ctx_t *c, const double *src, double *dst) { K(liship_memcpy_d2d(dst, src, sizeof(double) * (size_t)c->n, lisg.stream)); return LIS_SUCCESS; }
+static LIS_INT d_psolve(ctx_t *c, const double *r, double *z)
+{	/* none: copy (lis_precon.c:365-384); Jacobi: z = r .* dinv (lis_precon_jacobi.c:121-124) */
+	if (c->dinv) { K(liship_pmul_f64(c->n, r, c->dinv, z, lisg.stream)); return LIS_SUCCESS; }
+	return d_copy(c, r, z);
+}
+static LIS_INT d_matvec(ctx_t *c, double *x, double *y) { return lisd_spmv(c->A, x, y); }
+static LIS_INT d_resid(ctx_t *c, const double *r, double *nrm)
+{	/* lis_solver_get_residual_nrm2_r (lis_solver.c:1792) / _nrm1_b (:1804) */
+	if (c->s->options[LIS_OPTIONS_CONV_COND] == LIS_CONV_COND_NRM1_B) return lisd_nrm1(c->n, r, nrm);
+	LISCHK(lisd_nrm2(c->n, r, nrm));
+	*nrm = *nrm * c->bnrm;
+	return LIS_SUCCESS;
+}
+static void note(ctx_t *c, LIS_INT iter, double nrm)
+{
+	if (!c->output) return;
+	if (c->output & LIS_PRINT_MEM) c->s->rhistory[iter] = nrm;
+	if (c->output & LIS_PRINT_OUT) lis_printf(LIS_COMM_WORLD, "iteration: %5d  relative residual = %e\n", (int)iter, nrm);
+}
+
+/* r = b - A x (or b when x0 = 0), scaling 1/||r||, early exit when already converged: lis_solver.c:957-1091.
+ * returns 1 when the caller must stop (converged), 0 to iterate, <0 on error (-err) */
+static int initial_residual(ctx_t *c, double *r)
+{
+	LIS_SOLVER s = c->s;
+	const int conv = s->options[LIS_OPTIONS_CONV_COND];
+	const double tol = s->params[LIS_PARAMS_RESID - LIS_OPTIONS_LEN], tol_w = s->params[LIS_PARAMS_RESID_WEIGHT - LIS_OPTIONS_LEN];
+	LIS_INT err = 0;
+	if (!s->options[LIS_OPTIONS_INITGUESS_ZEROS]) {
+		err = d_matvec(c, c->x, r);
+		if (!err && liship_xpay_f64(c->n, c->b, -1.0, r, lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+	} else err = d_copy(c, c->b, r);
+	if (err) return -(int)err;
+	double nrm = 0.0, bn = 0.0;
+	switch (conv) {
+	case LIS_CONV_COND_NRM2_R: err = lisd_nrm2(c->n, r, &nrm); bn = nrm; s->tol = tol; break;
+	case LIS_CONV_COND_NRM2_B: err = lisd_nrm2(c->n, r, &nrm); if (!err) err = lisd_nrm2(c->n, c->b, &bn); s->tol = tol; break;
+	default:                   err = lisd_nrm1(c->n, r, &nrm); if (!err) err = lisd_nrm1(c->n, c->b, &bn); s->tol = bn * tol_w + tol; break;
+	}
+	if (err) return -(int)err;
+	s->tol_switch = s->params[LIS_PARAMS_SWITCH_RESID - LIS_OPTIONS_LEN];
+	bn = (bn == 0.0) ? 1.0 : 1.0 / bn;
+	s->bnrm = bn; c->bnrm = bn; c->tol = s->tol;
+	nrm = nrm * bn;
+	if (nrm <= fabs(tol)) { s->retcode = LIS_SUCCESS; s->iter = 1; s->resid = nrm; return 1; }
+	return 0;
+}
+
+#define TRY(expr) do { LIS_INT e__ = (expr); if (e__) { err = e__; goto done; } } while (0)
+#define KTRY(call) do { int rc__ = (call); if (rc__) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc__); goto done; } } while (0)
+
+static LIS_INT run_cg(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter;
+	const int n = c->n;
+	TRY(work_alloc(c, 4));
+	double *z = c->work[0], *q = c->work[1], *r = c->work[2], *p = c->work[3];
+	double alpha, beta, rho, rho_old = 1.0, dot_pq, nrm2 = 0.0;
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	KTRY(liship_set_all_f64(n, 0.0, p, lisg.stream));
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		TRY(d_psolve(c, r, z));
+		TRY(lisd_dot(n, r, z, &rho));
+		beta = rho / rho_old;
+		KTRY(liship_xpay_f64(n, z, beta, p, lisg.stream));
+		TRY(d_matvec(c, p, q));
+		TRY(lisd_dot(n, p, q, &dot_pq));
+		if (dot_pq == 0.0) { s->retcode = LIS_BREAKDOWN; s->iter = iter; s->resid = nrm2; err = LIS_BREAKDOWN; goto done; }
+		alpha = rho / dot_pq;
+		KTRY(liship_axpy_f64(n, alpha, p, c->x, lisg.stream));
+		KTRY(liship_axpy_f64(n, -alpha, q, r, lisg.stream));
+		TRY(d_resid(c, r, &nrm2));
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) { s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done; }
+		rho_old = rho;
+	}
+	s->retcode = LIS_MAXITER; s->iter = iter; s->resid = nrm2; err = LIS_MAXITER;
+done:
+	work_free(c);
+	return err;
+}
+
+static LIS_INT run_bicgstab(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter;
+	const int n = c->n;
+	TRY(work_alloc(c, 7));
+	double *rtld = c->work[0], *r = c->work[1], *t = c->work[2], *p = c->work[3], *v = c->work[4],
+	       *phat = c->work[5], *shat = c->work[6];
+	double *sv = r;                                    /* s aliases r: lis_solver_bicgstab.c:160-161 */
+	double alpha = 1.0, omega = 1.0, rho_old = 1.0, rho, beta, nrm2 = 0.0, d1, d2[2];
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	TRY(d_copy(c, r, rtld));                           /* shadow residual = r0 (lis_solver.c:1862) */
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		TRY(lisd_dot(n, rtld, r, &rho));
+		if (rho == 0.0) { s->retcode = LIS_BREAKDOWN; s->iter = iter; s->resid = nrm2; err = LIS_BREAKDOWN; goto done; }
+		if (iter == 1) TRY(d_copy(c, r, p));
+		else {
+			beta = (rho / rho_old) * (alpha / omega);
+			KTRY(liship_axpy_f64(n, -omega, v, p, lisg.stream));
+			KTRY(liship_xpay_f64(n, r, beta, p, lisg.stream));
+		}
+		TRY(d_psolve(c, p, phat));
+		TRY(d_matvec(c, phat, v));
+		TRY(lisd_dot(n, rtld, v, &d1));
+		alpha = rho / d1;
+		KTRY(liship_axpy_f64(n, -alpha, v, r, lisg.stream));
+		TRY(d_resid(c, sv, &nrm2));
+		if (nrm2 <= c->tol) {
+			note(c, iter, nrm2);
+			KTRY(liship_axpy_f64(n, alpha, phat, c->x, lisg.stream));
+			s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done;
+		}
+		TRY(d_psolve(c, sv, shat));
+		TRY(d_matvec(c, shat, t));
+		TRY(lisd_dot2(n, t, sv, d2));                   /* <t,s> and <t,t> in one pass (:267-268) */
+		omega = d2[0] / d2[1];
+		KTRY(liship_axpy_f64(n, alpha, phat, c->x, lisg.stream));
+		KTRY(liship_axpy_f64(n, omega, shat, c->x, lisg.stream));
+		KTRY(liship_axpy_f64(n, -omega, t, r, lisg.stream));
+		TRY(d_resid(c, r, &nrm2));
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) { s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done; }
+		if (omega == 0.0) { s->retcode = LIS_BREAKDOWN; s->iter = iter; s->resid = nrm2; err = LIS_BREAKDOWN; goto done; }
+		rho_old = rho;
+	}
+	s->retcode = LIS_MAXITER; s->iter = iter; s->resid = nrm2; err = LIS_MAXITER;
+done:
+	work_free(c);
+	return err;
+}
+
+static LIS_INT run_gmres(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0;
+	const int n = c->n, m = s->options[LIS_OPTIONS_RESTART], ld = m + 1;
+	const int CS = (m + 1) * ld, SN = (m + 2) * ld;
+	double *h = (double *)calloc((size_t)(ld + 1) * (size_t)(ld + 2), sizeof(double));   /* Hessenberg + rotations, host */
+	double *g = (double *)calloc((size_t)ld + 1, sizeof(double));                      /* the reference's vector s */
+	double nrm2 = 0.0, rnorm, t;
+	int iter = 0;
+	if (!h || !g) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", ld); goto done; }
+	TRY(work_alloc(c, m + 3));
+	double *r = c->work[0], *z = c->work[1], **v = &c->work[2];
+	int st = initial_residual(c, v[0]);                /* :193 leaves the unpreconditioned residual in v0 */
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	while (iter < c->maxiter) {
+		TRY(lisd_nrm2(n, v[0], &rnorm));
+		KTRY(liship_scale_f64(n, 1.0 / rnorm, v[0], lisg.stream));
+		for (int j = 0; j <= m; j++) g[j] = 0.0;
+		g[0] = rnorm;
+		int i = 0, ii = 0, i1 = 0;
+		do {
+			iter++; i++;
+			ii = i - 1; i1 = i;
+			double *hc = h + (size_t)ii * ld;
+			TRY(d_psolve(c, v[ii], z));
+			TRY(d_matvec(c, z, v[i1]));
+			for (int k = 0; k < i; k++) {                  /* modified Gram-Schmidt */
+				TRY(lisd_dot(n, v[i1], v[k], &t));
+				hc[k] = t;
+				KTRY(liship_axpy_f64(n, -t, v[k], v[i1], lisg.stream));
+			}
+			TRY(lisd_nrm2(n, v[i1], &t));
+			hc[i1] = t;
+			KTRY(liship_scale_f64(n, 1.0 / t, v[i1], lisg.stream));
+			for (int k = 1; k <= ii; k++) {                /* apply the previous rotations */
+				const int jj = k - 1;
+				const double tt = hc[jj];
+				double aa = h[jj + CS] * tt;  aa += h[jj + SN] * hc[k];
+				double bb = -h[jj + SN] * tt; bb += h[jj + CS] * hc[k];
+				hc[jj] = aa; hc[k] = bb;
+			}
+			double aa = hc[ii], bb = hc[i1];
+			const double a2 = aa * aa, b2 = bb * bb;
+			double rr = sqrt(a2 + b2);
+			if (rr == 0.0) rr = 1.0e-17;
+			h[ii + CS] = aa / rr;
+			h[ii + SN] = bb / rr;
+			g[i1] = -h[ii + SN] * g[ii];
+			g[ii] =  h[ii + CS] * g[ii];
+			aa  = h[ii + CS] * hc[ii];
+			aa += h[ii + SN] * hc[i1];
+			hc[ii] = aa;
+			nrm2 = fabs(g[i1]) * c->bnrm;
+			note(c, iter, nrm2);
+			if (c->tol >= nrm2) break;
+		} while (i < m && iter < c->maxiter);
+
+		g[ii] = g[ii] / h[ii + (size_t)ii * ld];           /* back substitution */
+		for (int k = 1; k <= ii; k++) {
+			const int jj = ii - k;
+			double tt = g[jj];
+			for (int j = jj + 1; j <= ii; j++) tt -= h[jj + (size_t)j * ld] * g[j];
+			g[jj] = tt / h[jj + (size_t)jj * ld];
+		}
+		KTRY(liship_scale_to_f64(n, g[0], v[0], z, lisg.stream));     /* z = y0 v0  (:290-296) */
+		for (int j = 1; j <= ii; j++) KTRY(liship_axpy_f64(n, g[j], v[j], z, lisg.stream));
+		TRY(d_psolve(c, z, r));
+		KTRY(liship_axpy_f64(n, 1.0, r, c->x, lisg.stream));
+		if (c->tol >= nrm2) { s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done; }
+		for (int j = 1; j <= i; j++) {
+			const int jj = i1 - j + 1;
+			g[jj - 1] = -h[jj - 1 + SN] * g[jj];
+			g[jj]     =  h[jj - 1 + CS] * g[jj];
+		}
+		for (int j = 0; j <= i1; j++) {
+			double tt = g[j];
+			if (j == 0) tt = tt - 1.0;
+			KTRY(liship_axpy_f64(n, tt, v[j], v[0], lisg.stream));
+		}
+	}
+	s->retcode = LIS_MAXITER; s->iter = iter + 1; s->resid = nrm2; err = LIS_MAXITER;
+done:
+	work_free(c);
+	free(h); free(g);
+	return err;
+}
+
+/* ------------------------------------------------------------------ lis_solve */
+LIS_INT lis_solve(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER solver)
+{
+	LIS_PRECON precon;
+	solver->A = A;
+	if (solver->options[LIS_OPTIONS_PRECON] < 0 || solver->options[LIS_OPTIONS_PRECON] > LIS_PRECONNAME_MAX)
+		return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_PRECON is %D (Set between 0 to %D)\n", solver->options[LIS_OPTIONS_PRECON], LIS_PRECONNAME_MAX);
+	LIS_INT err = lis_precon_create(solver, &precon);
+	if (err) { solver->retcode = err; return err; }
+	err = lis_solve_kernel(A, b, x, solver, precon);
+	lis_precon_destroy(precon);
+	if (err) { solver->retcode = err; return err; }
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER solver, LIS_PRECON precon)
+{
+	const LIS_INT nsolver = solver->options[LIS_OPTIONS_SOLVER], maxiter = solver->options[LIS_OPTIONS_MAXITER];
+	const LIS_INT output = solver->options[LIS_OPTIONS_OUTPUT], storage = solver->options[LIS_OPTIONS_STORAGE];
+	const LIS_INT conv = solver->options[LIS_OPTIONS_CONV_COND];
+	const double tol = solver->params[LIS_PARAMS_RESID - LIS_OPTIONS_LEN];
+	LIS_MATRIX Awork = A, Aconv = NULL;
+	LIS_INT err = 0;
+	ctx_t c;
+	memset(&c, 0, sizeof(c));
+
+	/* parameter checks, ref :482-537 */
+	if (nsolver < 1 || nsolver > LIS_SOLVER_LEN) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_SOLVER is %D (Set between 1 to %D)\n", nsolver, LIS_SOLVER_LEN);
+	if (nsolver != LIS_SOLVER_CG && nsolver != LIS_SOLVER_BICGSTAB && nsolver != LIS_SOLVER_GMRES)
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s is not served by liblis_amd (cg, bicgstab, gmres)\n", solver_names[nsolver]);
+	if (maxiter < 0) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_MAXITER(=%D) is less than 0\n", maxiter);
+	if (conv > 0 && nsolver == LIS_SOLVER_GMRES) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
+	if (solver->options[LIS_OPTIONS_PRECISION] != LIS_PRECISION_DOUBLE) return LISI_ERR(LIS_ERR_ILL_ARG, "Quad precision is not enabled\n");
+	if (solver->options[LIS_OPTIONS_SCALE] != LIS_SCALE_NONE) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "-scale is not served by liblis_amd\n");
+	if (nsolver == LIS_SOLVER_GMRES && solver->options[LIS_OPTIONS_RESTART] < 0)
+		return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_RESTART(=%D) is less than 0\n", solver->options[LIS_OPTIONS_RESTART]);
+	if (A->n != b->n || A->n != x->n) return LISI_ERR(LIS_ERR_ILL_ARG, "sizes of A, b and x do not match\n");
+
+	solver->A = A; solver->b = b;
+	solver->precision = LIS_PRECISION_DOUBLE;
+	free(solver->rhistory);
+	solver->rhistory = (LIS_REAL *)malloc(sizeof(LIS_REAL) * (size_t)(maxiter + 2));
+	if (!solver->rhistory) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", maxiter + 2);
+	solver->rhistory[0] = 1.0;
+	solver->ptime = 0.0;
+
+	double t_itime = lis_wtime();
+	/* -storage: iterate on a converted copy (ref lis_matrix_convert_self, lis_matrix_ops.c:326) */
+	if (storage && storage != A->matrix_type) {
+		err = lis_matrix_duplicate(A, &Aconv);
+		if (!err) err = lis_matrix_set_type(Aconv, storage);
+		if (!err && storage == LIS_MATRIX_BSR) err = lis_matrix_set_blocksize(Aconv, solver->options[LIS_OPTIONS_STORAGE_BLOCK], solver->options[LIS_OPTIONS_STORAGE_BLOCK], NULL, NULL);
+		if (!err) err = lis_matrix_convert(A, Aconv);
+		if (err) { if (Aconv) lis_matrix_destroy(Aconv); solver->retcode = err; return err; }
+		Awork = Aconv;
+	}
+
+	if (output) {
+		lis_printf(LIS_COMM_WORLD, "initial vector x      : %s\n", solver->options[LIS_OPTIONS_INITGUESS_ZEROS] ? "all components set to 0" : "user defined");
+		lis_printf(LIS_COMM_WORLD, "precision             : double\n");
+		lis_printf(LIS_COMM_WORLD, "linear solver         : %s\n", solver_names[nsolver]);
+		lis_printf(LIS_COMM_WORLD, "preconditioner        : %s\n", precon_names[precon->precon_type]);
+		if (conv == LIS_CONV_COND_NRM2_R) lis_printf(LIS_COMM_WORLD, "convergence condition : ||b-Ax||_2 <= %6.1e * ||b-Ax_0||_2\n", tol);
+		if (Awork->matrix_type == LIS_MATRIX_BSR) lis_printf(LIS_COMM_WORLD, "matrix storage format : %s(%D x %D)\n", storage_names[Awork->matrix_type - 1], Awork->bnr, Awork->bnc);
+		else lis_printf(LIS_COMM_WORLD, "matrix storage format : %s\n", storage_names[Awork->matrix_type - 1]);
+	}
+
+	c.s = solver; c.A = Awork; c.n = A->n;
+	c.output = output; c.maxiter = maxiter;
+	if ((err = lisd_mat_ready(Awork))) goto out;
+	{
+		size_t len = (size_t)(Awork->np + Awork->pad) + 16;
+		if (Awork->matrix_type == LIS_MATRIX_BSR) {
+			const size_t a = (size_t)Awork->nc * Awork->bnc + 16, bb = (size_t)Awork->nr * Awork->bnr + 16;
+			if (a > len) len = a;
+			if (bb > len) len = bb;
+		}
+		c.len = len;
+	}
+	/* b: once over PCIe (or already resident); x: a private HBM iterate "xx" (ref :545-592), zero or copy of x */
+	{
+		double *db, *dx0;
+		if ((err = lisd_vec_in(b, &db))) goto out;
+		c.b = db;
+		int rc = liship_malloc((void **)&c.x, c.len * sizeof(double));
+		if (!rc) rc = liship_memset(c.x, 0, c.len * sizeof(double), lisg.stream);
+		if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
+		if (!solver->options[LIS_OPTIONS_INITGUESS_ZEROS]) {
+			if ((err = lisd_vec_in(x, &dx0))) goto out;
+			if ((rc = liship_memcpy_d2d(c.x, dx0, sizeof(double) * (size_t)A->n, lisg.stream))) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
+		}
+	}
+	if (precon && precon->precon_type == LIS_PRECON_TYPE_JACOBI) {
+		if ((err = lisd_vec_in(precon->D, &c.dinv))) goto out;
+	}
+	solver->x = NULL; solver->xx = x; solver->precon = precon;
+
+	switch (nsolver) {
+	case LIS_SOLVER_CG:       err = run_cg(&c); break;
+	case LIS_SOLVER_BICGSTAB: err = run_bicgstab(&c); break;
+	default:                  err = run_gmres(&c); break;
+	}
+	const LIS_INT solver_code = err;
+	if (err == LIS_MAXITER || err == LIS_BREAKDOWN) err = 0;    /* reported through retcode only (ref :874,952) */
+	else if (err) goto out;
+	solver->retcode = solver_code;
+
+	/* xx -> x (ref :890) */
+	{
+		double *dx;
+		if ((err = lisd_vec_out(x, &dx))) goto out;
+		int rc = liship_memcpy_d2d(dx, c.x, sizeof(double) * (size_t)A->n, lisg.stream);
+		if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
+		if ((err = lisd_vec_done(x))) goto out;
+	}
+	{
+		int rc = liship_stream_synchronize(lisg.stream);
+		if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
+	}
+	t_itime = lis_wtime() - t_itime;
+	solver->itime = t_itime; solver->p_i_time = 0.0; solver->p_c_time = 0.0; solver->ptime = 0.0;
+	solver->time = t_itime;
+	solver->iter2 = solver->iter;
+	if (output) {
+		if (solver_code) lis_printf(LIS_COMM_WORLD, "linear solver status  : %s(code=%D)\n\n", retcode_names[solver_code], solver_code);
+		else lis_printf(LIS_COMM_WORLD, "linear solver status  : normal end\n\n");
+	}
+out:
+	if (c.x) (void)liship_free(c.x);
+	if (Aconv) lis_matrix_destroy(Aconv);
+	solver->precon = NULL;
+	if (err) solver->retcode = err;
+	return err;
+}

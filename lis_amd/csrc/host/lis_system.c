@@ -1,0 +1,242 @@
+/*
+ * lis_system.c -- process-level services of the Lis API: init/finalize, allocation, errors, timers.
+ *
+ * Mirrors the caller-visible behaviour of the reference's src/system (lis_init.c:121-247,
+ * lis_memory.c, lis_error.c:161-191, lis_time.c); none of it is on the hot path.
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <sys/time.h>
+#include "lis_internal.h"
+
+lisi_globals lisg = {0};
+int lisi_cmd_argc = 0;
+char **lisi_cmd_argv = NULL;
+
+/* ------------------------------------------------------------------ registry of live handles */
+typedef struct { void *obj; int kind; } reg_entry;
+static reg_entry *reg_tab = NULL;
+static size_t reg_cap = 0, reg_len = 0;     /* open addressing, tombstone = (void*)1 */
+
+static size_t reg_hash(const void *p, size_t cap) { return (((size_t)p) >> 4) * 0x9E3779B97F4A7C15ULL % cap; }
+
+static void reg_grow(void)
+{
+	size_t ncap = reg_cap ? reg_cap * 2 : 256;
+	reg_entry *nt = (reg_entry *)calloc(ncap, sizeof(reg_entry));
+	for (size_t i = 0; i < reg_cap; i++) {
+		if (reg_tab[i].obj && reg_tab[i].obj != (void *)1) {
+			size_t h = reg_hash(reg_tab[i].obj, ncap);
+			while (nt[h].obj) h = (h + 1) % ncap;
+			nt[h] = reg_tab[i];
+		}
+	}
+	free(reg_tab);
+	reg_tab = nt; reg_cap = ncap;
+}
+
+void lisi_register(void *obj, int kind)
+{
+	if ((reg_len + 1) * 2 > reg_cap) reg_grow();
+	size_t h = reg_hash(obj, reg_cap);
+	while (reg_tab[h].obj && reg_tab[h].obj != (void *)1) h = (h + 1) % reg_cap;
+	reg_tab[h].obj = obj; reg_tab[h].kind = kind;
+	reg_len++;
+}
+
+static reg_entry *reg_find(void *obj)
+{
+	if (!reg_cap || !obj) return NULL;
+	size_t h = reg_hash(obj, reg_cap);
+	for (size_t probes = 0; probes < reg_cap && reg_tab[h].obj; probes++, h = (h + 1) % reg_cap)
+		if (reg_tab[h].obj == obj) return &reg_tab[h];
+	return NULL;
+}
+
+void lisi_unregister(void *obj) { reg_entry *e = reg_find(obj); if (e) { e->obj = (void *)1; } }
+int  lisi_is_registered(void *obj) { return reg_find(obj) != NULL; }
+
+/* ------------------------------------------------------------------ allocation (ref:1037-1042)
+ * The reference keeps a list of every block so that lis_free_all can sweep at finalize; callers may
+ * also hand malloc'ed arrays to lis_matrix_set_* and have lis_free fall back to free().  Plain
+ * malloc/free gives the same observable behaviour. */
+void *lis_malloc(size_t size, char *tag) { (void)tag; return malloc(size ? size : 1); }
+void *lis_calloc(size_t size, char *tag) { (void)tag; return calloc(size ? size : 1, 1); }
+void *lis_realloc(void *p, size_t size) { return realloc(p, size ? size : 1); }
+void  lis_free(void *p) { free(p); }
+void  lis_free2(LIS_INT n, ...)
+{
+	va_list ap;
+	va_start(ap, n);
+	for (LIS_INT i = 0; i < n; i++) { void *p = va_arg(ap, void *); if (p) free(p); }
+	va_end(ap);
+}
+LIS_INT lis_is_malloc(void *p) { return lisi_is_registered(p) ? LIS_TRUE : LIS_FALSE; }
+
+/* ------------------------------------------------------------------ printing and errors */
+static const char *err_name(LIS_INT code)
+{
+	static const char *names[] = {"ILL_ARG", "BREAKDOWN", "OUT_OF_MEMORY", "MAXITER", "NOT_IMPLEMENTED", "FILE_IO_ERROR"};
+	return (code >= 1 && code <= 6) ? names[code - 1] : "UNKNOWN";
+}
+
+/* the reference's format strings use %D for LIS_INT (lis_error.c:124) */
+static void vprint_lis(FILE *f, const char *fmt, va_list ap)
+{
+	char buf[2048];
+	size_t w = 0;
+	for (const char *p = fmt; *p && w + 2 < sizeof(buf); p++) {
+		if (p[0] == '%' && p[1] == 'D') { buf[w++] = '%'; buf[w++] = 'd'; p++; }
+		else buf[w++] = *p;
+	}
+	buf[w] = 0;
+	vfprintf(f, buf, ap);
+}
+
+LIS_INT lis_printf(LIS_Comm comm, const char *mess, ...)
+{
+	(void)comm;
+	if (lisg.rank != 0) return LIS_SUCCESS;
+	va_list ap;
+	va_start(ap, mess);
+	vprint_lis(stdout, mess, ap);
+	va_end(ap);
+	return LIS_SUCCESS;
+}
+
+LIS_INT lisi_error(const char *file, const char *func, int line, LIS_INT code, const char *fmt, ...)
+{
+	if (lisg.rank != 0) return LIS_SUCCESS;
+	const char *base = strrchr(file, '/');
+	printf("%s(%d) : %s : error %s :", base ? base + 1 : file, line, func, err_name(code));
+	if (fmt) { va_list ap; va_start(ap, fmt); vprint_lis(stdout, fmt, ap); va_end(ap); }
+	fflush(stdout);
+	return LIS_SUCCESS;
+}
+
+LIS_INT lisi_hip_error(const char *file, const char *func, int line, int hipcode)
+{
+	const char *base = strrchr(file, '/');
+	fprintf(stderr, "%s(%d) : %s : HIP error %d (%s) -- liblis_amd has no CPU fallback\n",
+	        base ? base + 1 : file, line, func, hipcode, liship_error_string(hipcode));
+	return hipcode == 2 /* hipErrorOutOfMemory */ ? LIS_ERR_OUT_OF_MEMORY : LIS_ERR_NOT_IMPLEMENTED;
+}
+
+void CHKERR(LIS_INT err)
+{
+	if (err) { lis_finalize(); exit((int)err); }
+}
+
+double lis_wtime(void)
+{
+	struct timeval tv;
+	gettimeofday(&tv, NULL);
+	return (double)tv.tv_sec + (double)tv.tv_usec * 1.0e-6;
+}
+
+/* ------------------------------------------------------------------ argument tokens */
+int lisi_tokenize(const char *text, char ***tokens)
+{
+	int n = 0, cap = 16;
+	char **t = (char **)malloc(sizeof(char *) * cap);
+	const char *p = text;
+	while (p && *p) {
+		while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r') p++;
+		if (!*p) break;
+		const char *q = p;
+		while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') q++;
+		if (n == cap) { cap *= 2; t = (char **)realloc(t, sizeof(char *) * cap); }
+		t[n] = (char *)malloc((size_t)(q - p) + 1);
+		memcpy(t[n], p, (size_t)(q - p));
+		t[n][q - p] = 0;
+		n++;
+		p = q;
+	}
+	*tokens = t;
+	return n;
+}
+
+void lisi_tokens_free(char **tokens, int n)
+{
+	for (int i = 0; i < n; i++) free(tokens[i]);
+	free(tokens);
+}
+
+/* ------------------------------------------------------------------ init / finalize */
+LIS_INT lis_initialize(int *argc, char **argv[])
+{
+	/* the command line is kept for lis_solver_set_optionC (ref lis_init.c:148, lis_solver.c:1095).
+	 * -omp_num_threads is accepted and ignored: the parallelism here is the GPU's. */
+	if (lisi_cmd_argv) { lisi_tokens_free(lisi_cmd_argv, lisi_cmd_argc); lisi_cmd_argv = NULL; lisi_cmd_argc = 0; }
+	if (argc && argv && *argc > 0 && *argv) {
+		lisi_cmd_argc = *argc;
+		lisi_cmd_argv = (char **)malloc(sizeof(char *) * (size_t)*argc);
+		for (int i = 0; i < *argc; i++) {
+			const char *s = (*argv)[i] ? (*argv)[i] : "";
+			lisi_cmd_argv[i] = (char *)malloc(strlen(s) + 1);
+			strcpy(lisi_cmd_argv[i], s);
+		}
+		for (int i = 1; i < *argc; i++) {
+			if (strncmp(lisi_cmd_argv[i], "-ver", 4) == 0) { lis_printf(LIS_COMM_WORLD, "Lis Version %s (lis_amd, gfx950)\n", LIS_VERSION); CHKERR(1); }
+			if (strncmp(lisi_cmd_argv[i], "-help", 5) == 0) CHKERR(1);
+		}
+	}
+	if (!lisg.initialized) {
+		lisg.initialized = 1;
+		if (lisg.nprocs == 0) { lisg.nprocs = 1; lisg.rank = 0; }
+		const char *r = getenv("LIS_AMD_RESIDENCY");
+		if (r && (strcmp(r, "resident") == 0 || strcmp(r, "1") == 0)) lisg.residency = LIS_AMD_RESIDENT;
+	}
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_finalize(void)
+{
+	if (lisi_cmd_argv) { lisi_tokens_free(lisi_cmd_argv, lisi_cmd_argc); lisi_cmd_argv = NULL; lisi_cmd_argc = 0; }
+	lisg.initialized = 0;
+	return LIS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ sorting helpers
+ * ascending sort of i1[is..ie] carrying d1 (ref src/system/lis_sort.c:90-118).  Drivers call it on rows
+ * with distinct columns, where any correct sort gives the reference's order. */
+void lis_sort_id(LIS_INT is, LIS_INT ie, LIS_INT *i1, LIS_SCALAR *d1)
+{
+	if (ie > is) lisi_sort_row(is, ie + 1, i1, d1);
+}
+
+void lisi_sort_row(LIS_INT lo, LIS_INT hi, LIS_INT *idx, LIS_SCALAR *val)
+{
+	/* [lo,hi): insertion sort for short rows, heap sort otherwise (no recursion, O(n log n) worst case) */
+	LIS_INT len = hi - lo;
+	if (len < 2) return;
+	LIS_INT *k = idx + lo;
+	LIS_SCALAR *v = val + lo;
+	if (len <= 24) {
+		for (LIS_INT a = 1; a < len; a++) {
+			LIS_INT ck = k[a]; LIS_SCALAR cv = v[a]; LIS_INT b = a - 1;
+			while (b >= 0 && k[b] > ck) { k[b + 1] = k[b]; v[b + 1] = v[b]; b--; }
+			k[b + 1] = ck; v[b + 1] = cv;
+		}
+		return;
+	}
+	for (LIS_INT start = len / 2 - 1, end = len;;) {
+		LIS_INT root;
+		if (start >= 0) root = start--;
+		else {
+			if (--end <= 0) break;
+			LIS_INT tk = k[0]; k[0] = k[end]; k[end] = tk;
+			LIS_SCALAR tv = v[0]; v[0] = v[end]; v[end] = tv;
+			root = 0;
+		}
+		for (;;) {
+			LIS_INT child = 2 * root + 1;
+			if (child >= end) break;
+			if (child + 1 < end && k[child + 1] > k[child]) child++;
+			if (k[root] >= k[child]) break;
+			LIS_INT tk = k[root]; k[root] = k[child]; k[child] = tk;
+			LIS_SCALAR tv = v[root]; v[root] = v[child]; v[child] = tv;
+			root = child;
+		}
+	}
+}

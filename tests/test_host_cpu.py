@@ -1,0 +1,281 @@
+"""Host-side logic of liblis_amd.so that needs no GPU: ABI, exported symbols, object state machine,
+storage-format conversions (bit-exact index work), option parser, error convention, and the loud
+failure of every compute entry point when no HIP device exists."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import lis_amd
+import lisdrv
+import orc
+from lis_amd import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "lis_ref_golden.npz"))
+HAVE_GPU = lis_amd.gpu_available()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = lis_amd.load()
+    assert lib.initialize([]) == 0
+    return lib
+
+
+# ---------------------------------------------------------------------------------------------- ABI
+def _declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b((?:lis|liship|CHKERR)\w*)\s*\(", txt)
+    return sorted({n for n in names if not n.isupper() or n == "CHKERR"} - {"lis_amd_comm_callbacks"})
+
+
+@pytest.mark.parametrize("header", ["lis.h", "lis_amd.h", "liship.h"])
+def test_every_declared_symbol_is_exported(header):
+    dll = C.CDLL(lis_amd.LIB_PATH)
+    missing = [n for n in _declared_functions(header) if not hasattr(dll, n)]
+    assert not missing, missing
+
+
+LAYOUT_PROBE = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "lis.h"
+#define F(S, f) printf(#S "." #f " %zu\n", offsetof(struct S, f))
+int main(void) {
+  printf("sizeof.vector %zu\nsizeof.matrix %zu\nsizeof.solver %zu\nsizeof.precon %zu\nsizeof.commtable %zu\n",
+    sizeof(struct LIS_VECTOR_STRUCT), sizeof(struct LIS_MATRIX_STRUCT), sizeof(struct LIS_SOLVER_STRUCT),
+    sizeof(struct LIS_PRECON_STRUCT), sizeof(struct LIS_COMMTABLE_STRUCT));
+  F(LIS_VECTOR_STRUCT, n); F(LIS_VECTOR_STRUCT, np); F(LIS_VECTOR_STRUCT, ranges); F(LIS_VECTOR_STRUCT, value); F(LIS_VECTOR_STRUCT, intvalue);
+  F(LIS_MATRIX_STRUCT, n); F(LIS_MATRIX_STRUCT, matrix_type); F(LIS_MATRIX_STRUCT, nnz); F(LIS_MATRIX_STRUCT, maxnzr);
+  F(LIS_MATRIX_STRUCT, ptr); F(LIS_MATRIX_STRUCT, row); F(LIS_MATRIX_STRUCT, index); F(LIS_MATRIX_STRUCT, bptr);
+  F(LIS_MATRIX_STRUCT, value); F(LIS_MATRIX_STRUCT, work); F(LIS_MATRIX_STRUCT, L); F(LIS_MATRIX_STRUCT, is_block);
+  F(LIS_MATRIX_STRUCT, conv_bnr); F(LIS_MATRIX_STRUCT, options); F(LIS_MATRIX_STRUCT, w_annz); F(LIS_MATRIX_STRUCT, l2g_map);
+  F(LIS_MATRIX_STRUCT, commtable);
+  F(LIS_SOLVER_STRUCT, rhistory); F(LIS_SOLVER_STRUCT, options); F(LIS_SOLVER_STRUCT, params); F(LIS_SOLVER_STRUCT, retcode);
+  F(LIS_SOLVER_STRUCT, iter); F(LIS_SOLVER_STRUCT, resid); F(LIS_SOLVER_STRUCT, time); F(LIS_SOLVER_STRUCT, bnrm); F(LIS_SOLVER_STRUCT, setup);
+  F(LIS_PRECON_STRUCT, D); F(LIS_PRECON_STRUCT, commtable);
+  F(LIS_COMMTABLE_STRUCT, neibpe); F(LIS_COMMTABLE_STRUCT, export_index); F(LIS_COMMTABLE_STRUCT, wr);
+  printf("const %d %d %d %d %d %d\n", LIS_MATRIX_DECIDING_SIZE, LIS_MATRIX_NULL, LIS_OPTIONS_LEN, LIS_PARAMS_RESID, LIS_ERR_NOT_IMPLEMENTED, LIS_MATRIX_BSR);
+  return 0;
+}
+"""
+
+
+def _probe(include_dir, tmp_path, tag):
+    src = tmp_path / f"probe_{tag}.c"
+    src.write_text(LAYOUT_PROBE)
+    exe = tmp_path / f"probe_{tag}"
+    subprocess.run(["gcc", "-I", include_dir, str(src), "-o", str(exe)], check=True)
+    return subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+
+
+def test_struct_layout_is_the_reference_abi(tmp_path):
+    ours = _probe(os.path.join(ROOT, "include"), tmp_path, "ours")
+    golden = open(os.path.join(ROOT, "tests", "golden", "lis_abi_layout.txt")).read()
+    assert ours == golden                                     # produced from the reference header (see below)
+    ref_inc = "/root/reference/include"
+    if os.path.exists(os.path.join(ref_inc, "lis.h")):        # dev container: re-derive from the reference itself
+        assert _probe(ref_inc, tmp_path, "ref") == ours
+
+
+def test_ctypes_mirror_matches_c_layout(tmp_path):
+    ours = dict(line.rsplit(" ", 1) for line in _probe(os.path.join(ROOT, "include"), tmp_path, "o2").splitlines()
+                if not line.startswith("const"))
+    assert C.sizeof(capi.Vector) == int(ours["sizeof.vector"])
+    assert C.sizeof(capi.Matrix) == int(ours["sizeof.matrix"])
+    assert C.sizeof(capi.Solver) == int(ours["sizeof.solver"])
+    assert capi.Matrix.commtable.offset == int(ours["LIS_MATRIX_STRUCT.commtable"])
+    assert capi.Solver.resid.offset == int(ours["LIS_SOLVER_STRUCT.resid"])
+
+
+# ---------------------------------------------------------------------------------------------- state machine
+def test_matrix_state_machine_and_errors(lib):
+    A = capi.PM()
+    assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
+    a = A.contents
+    assert (a.status, a.matrix_type, a.is_destroy, a.conv_bnr, a.label) == (-256, 1, 1, 2, 1)
+    assert lib.lis_matrix_set_size(A, 5, 3) == capi.LIS_ERR_ILL_ARG           # local > global
+    assert lib.lis_matrix_set_size(A, -1, 0) == capi.LIS_ERR_ILL_ARG
+    assert lib.lis_matrix_set_size(A, 0, 0) == capi.LIS_ERR_ILL_ARG
+    assert lib.lis_matrix_assemble(A) == capi.LIS_ERR_ILL_ARG                  # size undefined
+    assert lib.lis_matrix_set_size(A, 0, 4) == 0
+    assert (a.status, a.n, a.gn, a.np, a.is_, a.ie) == (-257, 4, 4, 4, 0, 4)
+    assert lib.lis_matrix_assemble(A) == capi.LIS_ERR_ILL_ARG                  # type undefined
+    assert lib.lis_matrix_set_type(A, 99) == capi.LIS_ERR_ILL_ARG
+    ptr, idx, val = orc.poisson1d(4)
+    p, i, v = capi.P_INT(), capi.P_INT(), capi.P_DBL()
+    assert lib.lis_matrix_malloc_csr(4, len(idx), C.byref(p), C.byref(i), C.byref(v)) == 0
+    C.memmove(p, ptr.ctypes.data, ptr.nbytes); C.memmove(i, idx.ctypes.data, idx.nbytes); C.memmove(v, val.ctypes.data, val.nbytes)
+    assert lib.lis_matrix_set_csr(len(idx), p, i, v, A) == 0
+    assert (a.status, a.nnz, a.is_copy) == (-1, len(idx), 0)
+    # quirk of the reference: set_<fmt> on a matrix that is not in state NULL succeeds without adopting
+    assert lib.lis_matrix_set_csr(1, None, None, None, A) == 0 and a.nnz == len(idx)
+    assert lib.lis_matrix_assemble(A) == 0
+    assert (a.status, a.matrix_type) == (1, 1)
+    assert lib.lis_matrix_set_type(A, capi.LIS_MATRIX_ELL) == capi.LIS_ERR_ILL_ARG   # already assembled
+    n, gn, nnz, t = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert lib.lis_matrix_get_size(A, C.byref(n), C.byref(gn)) == 0 and (n.value, gn.value) == (4, 4)
+    assert lib.lis_matrix_get_nnz(A, C.byref(nnz)) == 0 and nnz.value == len(idx)
+    assert lib.lis_matrix_get_type(A, C.byref(t)) == 0 and t.value == 1
+    v1 = capi.PV()
+    assert lib.lis_vector_duplicate(C.cast(A, C.c_void_p), C.byref(v1)) == 0
+    vc = v1.contents
+    assert (vc.label, vc.status, vc.n, vc.np, vc.gn) == (0, 1, 4, 4, 4)
+    assert lib.lis_vector_set_value(capi.LIS_INS_VALUE, 7, 1.0, v1) == capi.LIS_ERR_ILL_ARG
+    assert lib.lis_vector_set_value(capi.LIS_INS_VALUE, 2, 1.5, v1) == 0
+    assert lib.lis_vector_set_value(capi.LIS_ADD_VALUE, 2, 1.0, v1) == 0
+    out = C.c_double()
+    assert lib.lis_vector_get_value(v1, 2, C.byref(out)) == 0 and out.value == 2.5
+    assert vc.value[2] == 2.5
+    buf = (C.c_double * 4)()
+    assert lib.lis_vector_get_values(v1, 1, 4, buf) == capi.LIS_ERR_ILL_ARG     # runs past the end
+    assert lib.lis_vector_get_values(v1, 1, 3, buf) == 0 and list(buf)[:3] == [0.0, 2.5, 0.0]
+    assert lib.lis_matrix_destroy(A) == 0 and lib.lis_vector_destroy(v1) == 0
+    assert lib.lis_matrix_destroy(A) == 0                                       # destroying twice is harmless
+
+
+def test_set_value_assembly(lib):
+    """lis_matrix_set_value -> assemble (test/test4.c): rows in insertion order, duplicates combined."""
+    A = capi.PM()
+    lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A))
+    lib.lis_matrix_set_size(A, 0, 6)
+    for i in range(6):
+        if i > 0:
+            lib.lis_matrix_set_value(capi.LIS_INS_VALUE, i, i - 1, -1.0, A)
+        if i < 5:
+            lib.lis_matrix_set_value(capi.LIS_INS_VALUE, i, i + 1, -1.0, A)
+        lib.lis_matrix_set_value(capi.LIS_INS_VALUE, i, i, 1.0, A)
+        lib.lis_matrix_set_value(capi.LIS_ADD_VALUE, i, i, 1.0, A)
+    assert A.contents.status == 0
+    assert lib.lis_matrix_assemble(A) == 0
+    arrs = lisdrv.matrix_arrays(A)
+    ptr, idx, val = orc.poisson1d(6)
+    assert np.array_equal(arrs["ptr"], ptr) and np.array_equal(arrs["index"], idx) and np.array_equal(arrs["value"], val)
+    lib.lis_matrix_destroy(A)
+
+
+# ---------------------------------------------------------------------------------------------- conversions
+def _check_arrays(fmt, got, want):
+    keys = {"csc": ["ptr", "index", "value"], "ell": ["maxnzr", "index", "value"], "dia": ["nnd", "index", "value"],
+            "jad": ["maxnzr", "row", "ptr", "index", "value"], "bsr": ["nr", "nc", "bnnz", "pad", "bptr", "bindex", "value"]}[fmt]
+    for k in keys:
+        w = want[k]
+        g = got[k]
+        assert np.array_equal(np.atleast_1d(g), np.atleast_1d(w)), (fmt, k)
+
+
+@pytest.mark.parametrize("name", ["p1d100", "p3d_6x5x4", "p3d_8s", "irr150"])
+@pytest.mark.parametrize("fmt", ["csc", "ell", "dia", "jad", "bsr"])
+def test_convert_against_golden(lib, name, fmt):
+    """lis_matrix_convert produces the arrays the reference produced (tests/golden), bit for bit."""
+    ptr, idx, val = (G[f"{name}/{k}"] for k in ("ptr", "idx", "val"))
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    B = lisdrv.convert(lib, A, fmt)
+    got = lisdrv.matrix_arrays(B)
+    want = {k.split("/")[-1]: G[k] for k in G.files if k.startswith(f"{name}/{fmt}/")}
+    _check_arrays(fmt, got, want)
+    assert B.contents.status == capi.FORMAT_ID[fmt] and B.contents.matrix_type == capi.FORMAT_ID[fmt]
+    lib.lis_matrix_destroy(A); lib.lis_matrix_destroy(B)
+
+
+CASES = {"rand257": lambda: orc.random_csr(257, 9, seed=1), "rand_long": lambda: orc.random_csr(64, 5, seed=2, long_row=60),
+         "p3d_7x6x5": lambda: orc.poisson3d(7, 6, 5), "p3d_9_sorted": lambda: orc.poisson3d(9, 9, 9, sort_cols=True)}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("fmt,bs", [("csc", 0), ("ell", 0), ("dia", 0), ("jad", 0), ("bsr", 2), ("bsr", 3)])
+def test_convert_against_reference(lib, reflib, case, fmt, bs):
+    ptr, idx, val = CASES[case]()
+    out = []
+    for L in (lib, reflib):
+        A = lisdrv.make_csr(L, ptr, idx, val)
+        B = lisdrv.convert(L, A, fmt, bs or 2, bs or 2)
+        out.append(lisdrv.matrix_arrays(B))
+        L.lis_matrix_destroy(A); L.lis_matrix_destroy(B)
+    _check_arrays(fmt, out[0], out[1])
+
+
+@pytest.mark.parametrize("fmt", ["csc", "ell", "dia", "jad", "bsr"])
+def test_round_trip_to_csr(lib, fmt):
+    """X -> CSR gives back the matrix (entries by ascending column, explicit zeros of ELL/DIA/BSR dropped)."""
+    ptr, idx, val = orc.random_csr(120, 6, seed=5, sort_cols=True)
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    B = lisdrv.convert(lib, A, fmt)
+    Cm = lisdrv.convert(lib, B, "csr")
+    got = lisdrv.matrix_arrays(Cm)
+    x = np.random.default_rng(0).uniform(-1, 1, 120)
+    sidx, sval = orc.sort_rows(got["ptr"], got["index"], got["value"])
+    assert np.array_equal(got["ptr"], ptr) and np.array_equal(sidx, idx) and np.array_equal(sval, val)
+    assert np.array_equal(orc.spmv_csr(got["ptr"], sidx, sval, x), orc.spmv_csr(ptr, idx, val, x))
+    for M in (A, B, Cm):
+        lib.lis_matrix_destroy(M)
+
+
+def test_diagonal_host_formats(lib):
+    if HAVE_GPU:
+        pytest.skip("covered on the device path by the gpu tests")
+    ptr, idx, val = orc.random_csr(90, 7, seed=6)
+    d = orc.csr_diagonal(ptr, idx, val)
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    for fmt in ("csr", "csc", "ell", "jad", "bsr"):
+        B = A if fmt == "csr" else lisdrv.convert(lib, A, fmt)
+        v = lisdrv.new_vector(lib, B)
+        assert lib.lis_matrix_get_diagonal(B, v) == 0
+        assert np.array_equal(np.ctypeslib.as_array(v.contents.value, shape=(90,)), d), fmt
+        lib.lis_vector_destroy(v)
+
+
+# ---------------------------------------------------------------------------------------------- solver object
+def test_solver_defaults_and_options(lib):
+    S = capi.PS()
+    assert lib.lis_solver_create(C.byref(S)) == 0
+    s = S.contents
+    assert (s.options[0], s.options[1], s.options[2], s.options[4], s.options[15]) == (2, 0, 1000, 40, 1)   # BiCG, none, 1000, 40, zeros
+    assert s.params[0] == 1e-12
+    assert lib.lis_solver_set_option(b"-i cg -p jacobi -tol 1.0e-10 -maxiter 77 -print mem -restart 30 -storage ell -initx_zeros false", S) == 0
+    assert (s.options[0], s.options[1], s.options[2], s.options[3], s.options[4], s.options[22], s.options[15]) == (1, 1, 77, 1, 30, 5, 0)
+    assert s.params[0] == 1e-10
+    assert lib.lis_solver_set_option(b"-i 9 -p 0 -conv_cond nrm1_b", S) == 0 and (s.options[0], s.options[1], s.options[24]) == (9, 0, 2)
+    assert lib.lis_solver_set_option(b"-i nosuchsolver", S) == capi.LIS_ERR_ILL_ARG
+    name = C.create_string_buffer(64)
+    assert lib.lis_solver_get_solvername(4, name) == 0 and name.value == b"BiCGSTAB"
+    assert lib.lis_solver_get_preconname(1, name) == 0 and name.value == b"Jacobi"
+    assert lib.lis_solver_destroy(S) == 0
+
+
+def test_unserved_paths_say_so(lib):
+    ptr, idx, val = orc.poisson1d(10)
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    b, x = lisdrv.new_vector(lib, A, np.ones(10)), lisdrv.new_vector(lib, A)
+    for opts, code in ((b"-i bicg", 5), (b"-i cg -p ilu", 5), (b"-i cg -f quad", 1), (b"-i cg -maxiter -3", 1)):
+        S = capi.PS()
+        lib.lis_solver_create(C.byref(S))
+        assert lib.lis_solver_set_option(opts, S) == 0
+        assert lib.lis_solve(A, b, x, S) == code, opts
+        lib.lis_solver_destroy(S)
+    B = capi.PM()
+    lib.lis_matrix_duplicate(A, C.byref(B))
+    lib.lis_matrix_set_type(B, 3)                                   # MSR: in the enum, not served
+    assert lib.lis_matrix_convert(A, B) == capi.LIS_ERR_NOT_IMPLEMENTED
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="needs a box WITHOUT a GPU")
+def test_compute_fails_loudly_without_gpu(lib, capfd):
+    """No CPU fallback: every compute entry point reports an error instead of silently computing on the host."""
+    ptr, idx, val = orc.poisson1d(10)
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    x, y = lisdrv.new_vector(lib, A, np.ones(10)), lisdrv.new_vector(lib, A)
+    out = C.c_double()
+    assert lib.lis_matvec(A, x, y) != 0
+    assert lib.lis_vector_dot(x, y, C.byref(out)) != 0
+    assert lib.lis_vector_axpy(1.0, x, y) != 0
+    S = capi.PS()
+    lib.lis_solver_create(C.byref(S))
+    lib.lis_solver_set_option(b"-i cg", S)
+    assert lib.lis_solve(A, x, y, S) != 0
+    assert "no CPU fallback" in capfd.readouterr().err

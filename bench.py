@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py -- the hot path's headline metric on N MI355X GPUs of one node.
+
+    python bench.py [--gpus 1] [--steps 50] [--warmup 5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json): the 3-D 7-point Poisson matrix on a 512^3 grid in CSR (test/test3.c entry order,
+f64 values, i32 indices), generated directly in HBM; a "step" is one y = A*x through lis_matvec() of
+liblis_amd.so (x = 1, as test/spmvtest3.c).  With N > 1 the matrix is row-block partitioned over the ranks
+(LIS_GET_ISIE: 512/N grid planes each, STRONG scaling: the global problem is fixed) and every step does the
+halo exchange over RCCL (ncclSend/ncclRecv of one plane per neighbour) before the local product.
+Reported: value = global SpMV GFLOP/s = 2*nnz*K / t (reference convention, test/spmvtest1.c:225), the
+roofline fraction of the dominant kernel from HIP events on the library's stream, CG+Jacobi and BiCGSTAB
+iterations/s on the same matrix, and the reference's own OpenMP CPU path timed on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=512, help="cubic grid edge (BASELINE: 512)")
+    ap.add_argument("--solver-iters", type=int, default=60, help="Krylov iterations timed for the it/s figures")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solvers", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    # torch first: liblis_amd.so then binds the HIP / RCCL runtime torch already loaded (one runtime per process),
+    # so torch.cuda.synchronize() and the library see the same device context.  torch is plumbing only.
+    torch = dist = None
+    try:
+        import torch
+        import torch.distributed as dist
+    except Exception:                                    # single-GPU runs do not need it
+        if world > 1:
+            raise
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only; data plane is RCCL
+    import numpy as np
+    import lis_amd
+    from lis_amd import _capi as capi, check
+    lib = lis_amd.load()
+    dll = lib.dll
+    if world == 1:
+        os.environ.setdefault("LIS_AMD_DEVICE", str(local_rank))
+    assert lib.initialize([]) == 0
+    if world > 1:
+        uid = [None]
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            assert dll.lis_amd_comm_get_unique_id(buf) == 0
+            uid[0] = bytes(buf)
+        dist.broadcast_object_list(uid, src=0)
+        assert dll.lis_amd_comm_init_rccl(uid[0], rank, world, local_rank) == 0
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    dll.lis_amd_set_residency(1)                          # objects live in HBM; nothing crosses PCIe in the timed region
+    dll.lis_amd_stream.restype = C.c_void_p
+
+    def sync():
+        assert dll.lis_amd_synchronize() == 0
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    N = args.grid
+    n_global = N ** 3
+    if N % world:
+        sys.exit(f"grid edge {N} is not divisible by {world} ranks (whole planes per rank)")
+    A = capi.PM()
+    assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
+    assert lib.lis_matrix_set_size(A, 0, n_global) == 0
+    dll.lis_amd_matrix_poisson3d.argtypes = [capi.PM, C.c_int, C.c_int, C.c_int, C.c_int]
+    assert dll.lis_amd_matrix_poisson3d(A, N, N, N, 0) == 0
+    n_local, nnz_local = A.contents.n, A.contents.nnz
+    nnz_global = 7 * n_global - 6 * N * N
+
+    def vec():
+        v = capi.PV()
+        assert lib.lis_vector_duplicate(C.cast(A, C.c_void_p), C.byref(v)) == 0
+        return v
+    x, y, b = vec(), vec(), vec()
+    assert lib.lis_vector_set_all(1.0, x) == 0
+
+    # ---- timed region: W warm-up steps, then exactly K steps between barrier + device sync on both sides
+    for _ in range(args.warmup):
+        assert lib.lis_matvec(A, x, y) == 0
+    stream = dll.lis_amd_stream()
+    timer = C.c_void_p()
+    check(lib.liship_timer_create(C.byref(timer)))
+    sync(); barrier()
+    t0 = time.perf_counter()
+    check(lib.liship_timer_start(timer, stream))
+    for _ in range(args.steps):
+        assert lib.lis_matvec(A, x, y) == 0
+    check(lib.liship_timer_stop(timer, stream))
+    sync(); barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = C.c_float()
+    check(lib.liship_timer_elapsed_ms(timer, C.byref(ev_ms)))
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    ms_per_step = dt / args.steps * 1e3
+    gflops = 2.0 * nnz_global * args.steps / dt / 1e9
+
+    # result check outside the timed region: ||A*1||_2^2 = 6(N-2)^2 + 48(N-2) + 72 exactly (spmvtest3)
+    nrm = C.c_double()
+    assert lib.lis_vector_nrm2(y, C.byref(nrm)) == 0
+    expect = (6.0 * (N - 2) ** 2 + 48.0 * (N - 2) + 72.0) ** 0.5
+    if abs(nrm.value - expect) > 1e-12 * expect:
+        sys.exit(f"rank {rank}: ||A*1||_2 = {nrm.value!r}, expected {expect!r}")
+
+    # ---- roofline of the dominant kernel (CSR SpMV): algorithmic bytes per launch / HIP-event time per launch
+    alg_bytes = 12 * nnz_local + 20 * n_local + 4        # 12 B per non-zero + 20 B per row
+    kernel_ms = ev_ms.value / args.steps
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None                                          # PMC bytes per launch, from the committed rocprofv3 run of this command
+    tf = os.path.join(ROOT, "profiles", "r01_spmv512_traffic.json")
+    if N == 512 and world == 1 and os.path.exists(tf):
+        traffic = json.load(open(tf))["hbm_traffic_bytes_per_launch"]
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "spmv_csr_rowgather_kernel", "kernel_ms": round(kernel_ms, 4),
+                "alg_bytes_per_launch": alg_bytes, "per_gpu": True}
+
+    # ---- Krylov iterations/s on the same matrix (b = A*1, x0 = 0), whole job
+    solvers = {}
+    if not args.no_solvers:
+        dll.lis_amd_vector_poisson3d_rhs.argtypes = [capi.PV, C.c_int, C.c_int, C.c_int]
+        assert dll.lis_amd_vector_poisson3d_rhs(b, N, N, N) == 0
+        for key, opts in (("cg_jacobi", "-i cg -p jacobi"), ("bicgstab_none", "-i bicgstab -p none")):
+            S = capi.PS()
+            assert lib.lis_solver_create(C.byref(S)) == 0
+            assert lib.lis_solver_set_option(f"{opts} -tol 1e-12 -maxiter {args.solver_iters}".encode(), S) == 0
+            assert lib.lis_solve(A, b, y, S) == 0        # warm-up pass (allocations, first launches)
+            sync(); barrier()
+            t1 = time.perf_counter()
+            assert lib.lis_solve(A, b, y, S) == 0
+            sync(); barrier()
+            el = time.perf_counter() - t1
+            iters = min(S.contents.iter, args.solver_iters)
+            if world > 1:
+                tt = torch.tensor([el], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt[0])
+            solvers[key] = {"iters_per_sec": round(iters / el, 2), "iters_timed": iters,
+                            "rel_residual_after": S.contents.resid}
+            lib.lis_solver_destroy(S)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(np)
+
+    if rank == 0:
+        out = {
+            "metric": "SpMV GFLOP/s, CSR, 3-D 7-pt Poisson n=512^3" if N == 512 else f"SpMV GFLOP/s, CSR, 3-D 7-pt Poisson n={N}^3",
+            "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3-D 7-point Poisson {N}^3, CSR f64/i32, y=A*x via lis_matvec (x=1), test3.c entry order",
+                       "n": n_global, "nnz": nnz_global, "parallelism": f"row-block x{world}" + (" + RCCL halo" if world > 1 else "")},
+            "roofline": roofline,
+            "hbm_roofline_pct_whole_job": round(100.0 * (12 * nnz_global + 20 * n_global) / (ms_per_step * 1e-3) / 1e9
+                                                / (HBM_PEAK_GBS * world), 2),
+            "krylov": solvers,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dll.lis_amd_comm_finalize()
+        dist.destroy_process_group()
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def cpu_baseline(np):
+    """The reference's OpenMP CSR SpMV (oracle/_ref = Lis 2.1.11 compiled from its own sources) on this box's host
+    cores, on a bounded sample: 256^3 rows of the same stencil (1/8 of the 512^3 workload), 10 products.
+    Falls back to the oracle's scalar C port when oracle/_ref is not in the snapshot."""
+    import lisdrv
+    import orc
+    Nc, reps = 256, 10
+    cores = usable_cores()
+    try:
+        ptr, idx, val = orc.poisson3d(Nc, Nc, Nc)
+        n = Nc ** 3
+        if os.path.exists(orc.REF_SO):
+            ref = lisdrv.open_lib(orc.REF_SO, threads=cores)
+            A = lisdrv.make_csr(ref, ptr, idx, val)
+            vx, vy = lisdrv.new_vector(ref, A, np.ones(n)), lisdrv.new_vector(ref, A)
+            ref.lis_matvec(A, vx, vy)                     # thread-team start-up and first touch excluded
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ref.lis_matvec(A, vx, vy)
+            el = time.perf_counter() - t0
+            kind, used = "reference", cores
+        else:
+            x = np.ones(n)
+            orc.spmv_csr(ptr, idx, val, x)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                orc.spmv_csr(ptr, idx, val, x)
+            el = time.perf_counter() - t0
+            kind, used = "port", 1
+        return {"value": round(2.0 * len(idx) * reps / el / 1e9, 3), "unit": "GFLOP/s", "cores": used, "kind": kind,
+                "sample": f"{reps} CSR SpMV on the {Nc}^3 stencil matrix (1/8 of the workload's rows), lis_matvec of Lis 2.1.11 with OpenMP"
+                if kind == "reference" else f"{reps} CSR SpMV on the {Nc}^3 stencil matrix, scalar C port (oracle/lis_oracle.c)"}
+    except Exception as e:                                 # the baseline must never sink the bench line
+        return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+
+if __name__ == "__main__":
+    main()

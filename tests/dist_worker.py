@@ -1,0 +1,222 @@
+"""One rank of a multi-process test of the distributed layer (row-block partition, ghost renumbering, halo
+tables, halo exchange, cross-rank folds).  Launched by tests/test_distributed.py with RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT in the environment; collectives go through torch.distributed (gloo) installed
+into the library as host-memory callbacks (lis_amd_comm_init_callbacks).
+
+    python tests/dist_worker.py host     # CPU only: tables + host halo exchange + local products by the oracle
+    python tests/dist_worker.py device   # GPU box: lis_matvec / lis_solve on every rank's HBM slice
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import lis_amd  # noqa: E402
+import lisdrv  # noqa: E402
+import orc  # noqa: E402
+from lis_amd import _capi as capi  # noqa: E402
+
+ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                       C.POINTER(C.c_double), C.POINTER(C.c_int))
+
+
+class Callbacks(C.Structure):
+    _fields_ = [("allgather", ALLGATHER), ("neighbor_exchange", EXCHANGE), ("ctx", C.c_void_p)]
+
+
+def make_callbacks(world):
+    def allgather(ctx, send, recv, nbytes):
+        src = torch.from_numpy(np.frombuffer(C.string_at(send, nbytes), dtype=np.uint8).copy())
+        outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(outs, src)
+        flat = torch.cat(outs).numpy()
+        C.memmove(recv, flat.ctypes.data, nbytes * world)
+        return 0
+
+    def exchange(ctx, nneib, neib, sendbuf, sptr, recvbuf, rptr):
+        reqs, recvs = [], []
+        for i in range(nneib):
+            sc, rc = sptr[i + 1] - sptr[i], rptr[i + 1] - rptr[i]
+            if sc > 0:
+                t = torch.from_numpy(np.ctypeslib.as_array(sendbuf, shape=(sptr[nneib],))[sptr[i]:sptr[i + 1]].copy())
+                reqs.append(dist.isend(t, dst=neib[i]))
+            if rc > 0:
+                t = torch.empty(rc, dtype=torch.float64)
+                recvs.append((t, rptr[i]))
+                reqs.append(dist.irecv(t, src=neib[i]))
+        for r in reqs:
+            r.wait()
+        for t, off in recvs:
+            arr = t.numpy()
+            C.memmove(C.addressof(recvbuf.contents) + 8 * off, arr.ctypes.data, 8 * arr.size)
+        return 0
+
+    cb = Callbacks(ALLGATHER(allgather), EXCHANGE(exchange), None)
+    return cb
+
+
+def isie(rank, world, n):
+    q, r = divmod(n, world)
+    if rank < r:
+        return (q + 1) * rank, (q + 1) * rank + q + 1
+    return q * rank + r, q * rank + r + q
+
+
+def local_rows(ptr, idx, val, is_, ie):
+    p = (ptr[is_:ie + 1] - ptr[is_]).astype(np.int32)
+    return p, idx[ptr[is_]:ptr[ie]].copy(), val[ptr[is_]:ptr[ie]].copy()
+
+
+def main():
+    mode = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = lis_amd.load()
+    cb = make_callbacks(world)
+    lib.dll.lis_amd_comm_init_callbacks.argtypes = [C.POINTER(Callbacks), C.c_int, C.c_int]
+    assert lib.dll.lis_amd_comm_init_callbacks(C.byref(cb), rank, world) == 0
+    assert lib.initialize([]) == 0
+    assert lib.dll.lis_amd_comm_rank() == rank and lib.dll.lis_amd_comm_size() == world
+    lib.dll.lis_amd_halo_exchange_host.argtypes = [capi.PM, capi.P_DBL]
+
+    cases = {
+        "poisson_unaligned": orc.poisson3d(5, 4, 3),                  # 60 rows: slabs cut through planes
+        "poisson_planes": orc.poisson3d(2 * world, 5, 4),
+        "irregular": orc.random_csr(211, 7, seed=3),                  # far-away ghosts, empty rows
+        "block_diagonal": (np.arange(41, dtype=np.int32), np.arange(40, dtype=np.int32), np.full(40, 2.0)),  # no ghosts at all
+    }
+    for name, (ptr, idx, val) in cases.items():
+        gn = len(ptr) - 1
+        is_, ie = isie(rank, world, gn)
+        n = ie - is_
+        lp, li, lv = local_rows(ptr, idx, val, is_, ie)
+        A = lisdrv.make_csr(lib, lp, li, lv, n=0, gn=gn)             # set_size(A, 0, gn): LIS_GET_ISIE split
+        a = A.contents
+        assert (a.n, a.gn, a.is_, a.ie, a.nprocs, a.my_rank) == (n, gn, is_, ie, world, rank), name
+        if world > 1:
+            assert list(a.ranges[:world + 1]) == [isie(r, world, gn)[0] for r in range(world)] + [gn]
+
+        # ghost renumbering: owned g -> g - is, ghosts -> n + rank among the sorted distinct ghost columns
+        ghosts = np.unique(li[(li < is_) | (li >= ie)])
+        assert a.np == n + len(ghosts), name
+        want = np.where((li >= is_) & (li < ie), li - is_, n + np.searchsorted(ghosts, li)).astype(np.int32)
+        got = lisdrv.matrix_arrays(A)
+        assert np.array_equal(got["index"], want), name
+        if len(ghosts):
+            assert np.array_equal(np.ctypeslib.as_array(a.l2g_map, shape=(len(ghosts),)), ghosts), name
+
+        # halo tables: neighbours ascending, import slots contiguous per owner, exports = what the peer imports
+        t = a.commtable.contents
+        nb = t.neibpetot
+        neib = list(t.neibpe[:nb])
+        assert neib == sorted(neib) and rank not in neib
+        owners = np.searchsorted(np.array([isie(r, world, gn)[1] for r in range(world)]), ghosts, side="right")
+        assert t.imnnz == len(ghosts)
+        for i, p in enumerate(neib):
+            assert t.import_ptr[i + 1] - t.import_ptr[i] == int(np.sum(owners == p)), name
+        assert list(t.import_index[:t.imnnz]) == list(range(n, n + len(ghosts)))
+        all_ghosts = [None] * world
+        dist.all_gather_object(all_ghosts, ghosts)
+        for i, p in enumerate(neib):
+            mine = all_ghosts[p][(all_ghosts[p] >= is_) & (all_ghosts[p] < ie)] - is_
+            assert list(t.export_index[t.export_ptr[i]:t.export_ptr[i + 1]]) == list(mine), name
+
+        # halo exchange + local product == the rows of the global product, bit for bit
+        xg = np.random.default_rng(17).uniform(-1, 1, gn)
+        xl = np.zeros(a.np)
+        xl[:n] = xg[is_:ie]
+        assert lib.dll.lis_amd_halo_exchange_host(A, xl.ctypes.data_as(capi.P_DBL)) == 0
+        assert np.array_equal(xl[n:], xg[ghosts]), name
+        yg = orc.spmv_csr(ptr, idx, val, xg)
+        assert np.array_equal(orc.spmv_csr(got["ptr"], got["index"], got["value"], xl), yg[is_:ie]), name
+
+        # vectors of the partition: ranges, gather, infinity norm (host-side collectives)
+        v = lisdrv.new_vector(lib, A, None)
+        assert (v.contents.n, v.contents.np, v.contents.gn, v.contents.is_) == (n, a.np, gn, is_)
+        for i in range(n):
+            assert lib.lis_vector_set_value(capi.LIS_INS_VALUE, is_ + i, float(xg[is_ + i]), v) == 0    # global indices
+        assert lib.lis_vector_set_value(capi.LIS_INS_VALUE, (ie) % gn if world > 1 else gn, 1.0, v) == capi.LIS_ERR_ILL_ARG
+        full = np.zeros(gn)
+        assert lib.lis_vector_gather(v, full.ctypes.data_as(capi.P_DBL)) == 0
+        assert np.array_equal(full, xg), name
+        out = C.c_double()
+        assert lib.lis_vector_nrmi(v, C.byref(out)) == 0 and out.value == np.abs(xg).max()
+
+        if mode == "device":
+            device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn)
+        lib.lis_vector_destroy(v)
+        lib.lis_matrix_destroy(A)
+
+    if mode == "device":
+        device_poisson_generator(lib, rank, world)
+    dist.barrier()
+    print(f"rank {rank}/{world} {mode} OK", flush=True)
+    dist.destroy_process_group()
+
+
+def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
+    """Every rank drives its HBM slice: lis_matvec with the halo exchange, global reductions, lis_solve."""
+    n = ie - is_
+    vx, vy = lisdrv.new_vector(lib, A, None), lisdrv.new_vector(lib, A, None)
+    assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(xg[is_:ie]).ctypes.data_as(capi.P_DBL), vx) == 0
+    assert lib.lis_matvec(A, vx, vy) == 0
+    y = np.empty(n)
+    assert lib.lis_vector_get_values(vy, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
+    assert np.array_equal(y, yg[is_:ie]), name                        # distributed SpMV: bit-identical rows
+    out = C.c_double()
+    assert lib.lis_vector_dot(vx, vy, C.byref(out)) == 0
+    assert abs(out.value - float(np.dot(xg, yg))) <= 1e-13 * float(np.abs(xg * yg).sum()), name
+    assert lib.lis_vector_nrm2(vy, C.byref(out)) == 0 and abs(out.value - np.linalg.norm(yg)) <= 1e-13 * np.linalg.norm(yg)
+    if name.startswith("poisson"):
+        bg = orc.spmv_csr(ptr, idx, val, np.ones(gn))
+        vb, vs = lisdrv.new_vector(lib, A, None), lisdrv.new_vector(lib, A, None)
+        assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(bg[is_:ie]).ctypes.data_as(capi.P_DBL), vb) == 0
+        for solver, precon, ref in (("cg", "jacobi", orc.cg), ("bicgstab", "none", orc.bicgstab), ("gmres", "none", orc.gmres)):
+            S = capi.PS()
+            lib.lis_solver_create(C.byref(S))
+            lib.lis_solver_set_option(f"-i {solver} -p {precon} -tol 1e-12 -maxiter 500 -restart 20".encode(), S)
+            assert lib.lis_solve(A, vb, vs, S) == 0
+            xs = np.empty(n)
+            assert lib.lis_vector_get_values(vs, is_, n, xs.ctypes.data_as(capi.P_DBL)) == 0
+            kw = {"restart": 20} if solver == "gmres" else {}
+            xo, it, rc, resid, _ = ref(ptr, idx, val, bg, precon=precon, maxiter=500, **kw)
+            assert S.contents.retcode == 0 and S.contents.resid <= 1e-12, (name, solver)
+            if solver == "cg":
+                assert S.contents.iter == it, (name, solver, S.contents.iter, it)
+            else:
+                assert abs(S.contents.iter - it) <= max(3, it // 10), (name, solver, S.contents.iter, it)
+            assert np.allclose(xs, xo[is_:ie], rtol=0, atol=1e-9), (name, solver)
+            lib.lis_solver_destroy(S)
+
+
+def device_poisson_generator(lib, rank, world):
+    """lis_amd_matrix_poisson3d: HBM-generated slab + closed-form halo tables == the host path on the same rows."""
+    l, m, n = 3 * world, 6, 5
+    gn = l * m * n
+    A = capi.PM()
+    assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
+    assert lib.lis_matrix_set_size(A, 0, gn) == 0
+    lib.dll.lis_amd_matrix_poisson3d.argtypes = [capi.PM, C.c_int, C.c_int, C.c_int, C.c_int]
+    assert lib.dll.lis_amd_matrix_poisson3d(A, l, m, n, 0) == 0
+    is_, ie = A.contents.is_, A.contents.ie
+    ptr, idx, val = orc.poisson3d(l, m, n)
+    xg = np.random.default_rng(5).uniform(-1, 1, gn)
+    yg = orc.spmv_csr(ptr, idx, val, xg)
+    vx, vy = lisdrv.new_vector(lib, A, None), lisdrv.new_vector(lib, A, None)
+    nl = ie - is_
+    assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, nl, np.ascontiguousarray(xg[is_:ie]).ctypes.data_as(capi.P_DBL), vx) == 0
+    assert lib.lis_matvec(A, vx, vy) == 0
+    y = np.empty(nl)
+    assert lib.lis_vector_get_values(vy, is_, nl, y.ctypes.data_as(capi.P_DBL)) == 0
+    assert np.array_equal(y, yg[is_:ie])
+
+
+if __name__ == "__main__":
+    main()

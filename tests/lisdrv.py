@@ -34,11 +34,13 @@ def _arr(ptr, count, dtype):
 
 
 def make_csr(lib, ptr, idx, val, n=None, gn=0):
-    """gn=0: serial call pattern set_size(A, n, 0) -> n local == global."""
-    n = len(ptr) - 1 if n is None else n
+    """Rows given by ptr.  gn=0: set_size(A, rows, 0) (local size given); gn>0 with n=0: set_size(A, 0, gn), the
+    drivers' call pattern, where the library splits the global rows over the ranks (LIS_GET_ISIE)."""
+    rows = len(ptr) - 1
     A = capi.PM()
     assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
-    assert lib.lis_matrix_set_size(A, n, gn) == 0
+    assert lib.lis_matrix_set_size(A, rows if n is None else n, gn) == 0
+    n = rows
     p, i, v = capi.P_INT(), capi.P_INT(), capi.P_DBL()
     nnz = int(ptr[-1])
     assert lib.lis_matrix_malloc_csr(n, max(nnz, 1), C.byref(p), C.byref(i), C.byref(v)) == 0

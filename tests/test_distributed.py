@@ -1,0 +1,51 @@
+"""The N>1 path with world_size 2 and 3 over gloo: partition, ghost renumbering, halo tables, halo exchange and
+cross-rank folds (tests/dist_worker.py).  `host` mode runs anywhere; `device` mode runs the same ranks on
+one GPU (each rank drives its HBM slice; the halo takes the host-callback route instead of RCCL)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _launch(mode, world, timeout=600):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", LIS_AMD_DEVICE="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {rank}/{world} {mode} OK" in out, f"rank {rank}:\n{out[-3000:]}"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partition_tables_and_halo_on_cpu(world):
+    _launch("host", world)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_spmv_and_solvers_on_one_gpu(world):
+    _launch("device", world)

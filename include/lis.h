@@ -139,6 +139,11 @@ typedef LIS_INT      LIS_Comm;         /* ref:485 */
 #define LIS_SOLVER_COCG 24
 #define LIS_SOLVER_COCR 25
 
+#define LIS_FMT_AUTO 0                /* ref:55-64 (served by lis_output_vector: PLAIN, MM) */
+#define LIS_FMT_PLAIN 1
+#define LIS_FMT_MM 2
+#define LIS_FMT_LIS 3
+
 #define LIS_INS_VALUE 0               /* ref:207-209 */
 #define LIS_ADD_VALUE 1
 #define LIS_SUB_VALUE 2
@@ -510,6 +515,7 @@ LIS_INT lis_precon_destroy(LIS_PRECON precon);
 LIS_INT lis_solver_get_solvername(LIS_INT solver, char *solvername);
 LIS_INT lis_solver_get_preconname(LIS_INT precon_type, char *preconname);
 LIS_INT lis_solver_output_rhistory(LIS_SOLVER solver, char *filename);  /* ref:1022, src/system/lis_output.c:586 */
+LIS_INT lis_output_vector(LIS_VECTOR v, LIS_INT format, char *filename); /* ref:1021, src/system/lis_output.c:146 (drivers write x with it) */
 
 /* ---- utilities, ref:1030-1045 (src/system) ----------------------------------------------------- */
 LIS_INT lis_initialize(int *argc, char **argv[]);
@@ -524,6 +530,10 @@ void    lis_free2(LIS_INT n, ...);
 LIS_INT lis_is_malloc(void *p);
 LIS_INT lis_printf(LIS_Comm comm, const char *mess, ...);
 void    lis_sort_id(LIS_INT is, LIS_INT ie, LIS_INT *i1, LIS_SCALAR *d1);  /* src/system/lis_sort.c:90; test/spmvtest3.c:194 */
+
+/* the reference's drivers bracket main() with these (ref:286-292); trace output is a _DEBUG build feature */
+#define LIS_DEBUG_FUNC_IN
+#define LIS_DEBUG_FUNC_OUT
 
 /* static row split every reference kernel and the rank partition use, ref:1067-1078 */
 #define LIS_GET_ISIE(id,nprocs,n,is,ie) \

@@ -176,6 +176,8 @@ _PROTOS = {
     "lis_solver_set_option": (LIS_INT, [C.c_char_p, PS]),
     "lis_solver_set_optionC": (LIS_INT, [PS]),
     "lis_solve": (LIS_INT, [PM, PV, PV, PS]),
+    "lis_output_vector": (LIS_INT, [PV, LIS_INT, C.c_char_p]),
+    "lis_solver_output_rhistory": (LIS_INT, [PS, C.c_char_p]),
     "lis_solver_get_solvername": (LIS_INT, [LIS_INT, C.c_char_p]),
     "lis_solver_get_preconname": (LIS_INT, [LIS_INT, C.c_char_p]),
     # memory (lis.h:1037-1042)

@@ -1,0 +1,65 @@
+"""The reference's own test drivers (test/spmvtest1.c, spmvtest3.c, test3.c, test4.c), compiled UNCHANGED against
+this repo's include/ and linked to liblis_amd.so (oracle/Makefile target `drivers`; binaries travel under
+oracle/_ref/drivers/), run on the GPU next to the same drivers linked to the reference library.
+What the drivers print is the only correctness signal the reference has: 2-norms, iteration counts,
+relative residuals."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+DRV = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "drivers")
+
+
+def run(name, *args):
+    exe = os.path.join(DRV, name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (needs /root/reference at build time)")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    return subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=600, env=env, check=True).stdout
+
+
+def norms(out):
+    return {int(m.group(1)): m.group(2) for m in re.finditer(r"matrix_type =\s*(\d+) .*2-norm = (\S+)", out)}
+
+
+@pytest.mark.parametrize("driver,args", [("spmvtest1", (10000, 20)), ("spmvtest3", (24, 20, 16, 5))])
+def test_spmvtest_prints_the_reference_norms(driver, args):
+    for fmt in (1, 2, 4, 5, 6, 7):                          # CSR CSC DIA ELL JAD BSR
+        got = norms(run(driver + "_amd", *args, fmt))
+        want = norms(run(driver + "_ref", *args, fmt))
+        assert got == want and fmt in got, (driver, fmt, got, want)
+    if driver == "spmvtest1":
+        assert got[7] == "1.414214e+00"                     # sqrt(2): SURVEY 8c
+
+
+@pytest.mark.parametrize("opts", ["-i cg -p jacobi", "-i cg -p none", "-i bicgstab -p none", "-i gmres -restart 30 -p none",
+                                  "-i cg -p jacobi -storage ell", "-i cg -p jacobi -storage bsr"])
+def test_test3_solver_driver(tmp_path, opts):
+    outs = {}
+    for tag in ("amd", "ref"):
+        sol, rh = tmp_path / f"sol_{tag}.txt", tmp_path / f"rh_{tag}.txt"
+        out = run(f"test3_{tag}", 16, 16, 16, 1, sol, rh, *opts.split())
+        it = int(re.search(r"number of iterations = (\d+)", out).group(1))
+        res = float(re.search(r"relative residual\s*= (\S+)", out).group(1))
+        xs = [float(line.split()[1]) for line in open(sol).read().splitlines()[2:]]
+        hist = [float(v) for v in open(rh).read().split()]
+        outs[tag] = (it, res, xs, hist)
+    (it_a, res_a, x_a, h_a), (it_r, res_r, x_r, h_r) = outs["amd"], outs["ref"]
+    if "-i cg" in opts:
+        assert it_a == it_r
+    else:
+        assert abs(it_a - it_r) <= max(3, it_r // 10)
+    assert res_a <= 1e-12 and res_r <= 1e-12
+    assert len(x_a) == len(x_r) == 16 ** 3 and max(abs(a - b) for a, b in zip(x_a, x_r)) <= 1e-9
+    assert abs(h_a[1] - h_r[1]) <= 1e-9 * h_r[1] and len(h_a) == it_a + 1
+
+
+def test_test4_set_value_assembly():
+    # the driver's default solver is BiCG (not on the served path): pick CG on its command line (lis_solver_set_optionC)
+    a, r = run("test4_amd", "-i", "cg"), run("test4_ref", "-i", "cg")
+    grab = lambda s: re.findall(r"^\s*(\d+)\s+(\S+)$", s, flags=re.M)
+    assert re.search(r"number of iterations = (\d+)", a).group(1) == re.search(r"number of iterations = (\d+)", r).group(1)
+    assert grab(a) == grab(r) and len(grab(a)) == 12        # the 12 solution components, as printed

@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=512, help="cubic grid edge (BASELINE: 512)")
     ap.add_argument("--solver-iters", type=int, default=60, help="Krylov iterations timed for the it/s figures")
+    ap.add_argument("--preroll", type=int, default=600,
+                    help="untimed clock-ramp steps before the W warm-up steps: a fresh box's first process measured "
+                         "7 %% slower for its first ~second of kernels (DESIGN.md 5); same count on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solvers", action="store_true")
     return ap.parse_args()
@@ -112,6 +115,10 @@ def main():
     x, y, b = vec(), vec(), vec()
     assert lib.lis_vector_set_all(1.0, x) == 0
 
+    # ---- untimed clock ramp (power state of an idle box), then the contract's W warm-up steps
+    for _ in range(args.preroll):
+        assert lib.lis_matvec(A, x, y) == 0
+    sync()
     # ---- timed region: W warm-up steps, then exactly K steps between barrier + device sync on both sides
     for _ in range(args.warmup):
         assert lib.lis_matvec(A, x, y) == 0

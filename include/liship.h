@@ -61,6 +61,13 @@ int  liship_csr_plan_destroy(liship_csr_plan_t plan);
 int  liship_csr_plan_info(liship_csr_plan_t plan, int *n, long long *nnz, int *nblocks);
 int  liship_spmv_csr_f64(liship_csr_plan_t plan, const int *ptr, const int *index,
                          const double *value, const double *x, double *y, void *stream);
+/* the product with a fused reduction epilogue: result[0] = sum_r w[r]*y[r] (w may be x: CG's <p,Ap>,
+ * lis_solver_cg.c:185-188), result[1] = sum_r y[r]^2 when want_sumsq (BiCGSTAB's <t,s>,<t,t>,
+ * lis_solver_bicgstab.c:262-268).  y is bit-identical to liship_spmv_csr_f64; saves a 16 B/row pass.
+ * Returns LISHIP_ERR_ARG when it cannot serve the call (then use the plain product + liship_dot_f64). */
+int  liship_spmv_csr_dot_f64(liship_csr_plan_t plan, const int *ptr, const int *index, const double *value,
+                             const double *x, double *y, const double *w, int want_sumsq,
+                             double *result, void *work, void *stream);
 /* same product restricted to rows [row_begin,row_end) (used to overlap the halo exchange) */
 int  liship_spmv_csr_rows_f64(liship_csr_plan_t plan, int row_begin, int row_end, const int *ptr,
                               const int *index, const double *value, const double *x, double *y,
@@ -100,6 +107,10 @@ int  liship_set_all_f64(int n, double alpha, double *x, void *stream);
 int  liship_abs_f64  (int n, double *x, void *stream);
 int  liship_reciprocal_f64(int n, double *x, void *stream);
 int  liship_shift_f64(int n, double sigma, double *x, void *stream);
+/* fused forms: the SAME per-element expressions in the SAME order as the calls they replace (bit-identical),
+ * one pass over HBM instead of two or three */
+int  liship_axpy2_f64(int n, double a, const double *x, double b, const double *w, double *y, void *stream);       /* y += a*x; y += b*w   (lis_solver_bicgstab.c:272-273) */
+int  liship_axpy_xpay_f64(int n, double a, const double *x, const double *w, double b, double *y, void *stream);   /* y += a*x; y = w + b*y (lis_solver_bicgstab.c:212-213) */
 /* two-stage reductions (wavefront shuffle + LDS, then one fixed-order pass over the partials):
  * src/vector/lis_vector_ops.c dot :58-127, nrm2 :210-271, nrm1 :278-342, sum :418-478.
  * `result` is a DEVICE pointer to `count` doubles, `work` a device scratch of liship_reduce_work_bytes().
@@ -110,6 +121,20 @@ int  liship_nrm2_f64(int n, const double *x, double *result, void *work, void *s
 int  liship_sumsq_f64(int n, const double *x, double *result, void *work, void *stream);
 int  liship_nrm1_f64(int n, const double *x, double *result, void *work, void *stream);
 int  liship_sum_f64 (int n, const double *x, double *result, void *work, void *stream);
+/* x += alpha*p; r += (-alpha)*q; result[0] = sum r^2   (lis_solver_cg.c:199-205: two axpys + the residual norm) */
+int  liship_cg_update_f64(int n, double alpha, const double *p, const double *q, double *x, double *r,
+                          double *result, void *work, void *stream);
+/* the same with the Jacobi solve of the next iteration folded in: z = r.*dinv is formed per element (not
+ * stored) and result = {sum r^2, sum r*z}   (lis_solver_cg.c:199-205 + :176-180 of the next iteration) */
+int  liship_cg_update_jacobi_f64(int n, double alpha, const double *p, const double *q, const double *dinv,
+                                 double *x, double *r, double *result, void *work, void *stream);
+/* z = x.*d ; y = z + a*y   (Jacobi solve lis_precon_jacobi.c:121-124 + lis_vector_xpay, lis_solver_cg.c:183) */
+int  liship_pmul_xpay_f64(int n, const double *x, const double *d, double a, double *y, void *stream);
+/* y += a*x; result[0] = sum y^2            (lis_solver_bicgstab.c:233-236) */
+int  liship_axpy_sumsq_f64(int n, double a, const double *x, double *y, double *result, void *work, void *stream);
+/* y += a*x; result = {sum y^2, sum v*y}    (lis_solver_bicgstab.c:276-279 + :190 of the next iteration) */
+int  liship_axpy_sumsq_dot_f64(int n, double a, const double *x, double *y, const double *v, double *result,
+                               void *work, void *stream);
 /* result[0] = <x,y>, result[1] = <x,x> in one pass (BiCGSTAB's <t,s>,<t,t>, lis_solver_bicgstab.c:267-268) */
 int  liship_dot2_f64(int n, const double *x, const double *y, double *result, void *work, void *stream);
 

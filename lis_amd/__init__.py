@@ -45,6 +45,7 @@ _LISHIP = {
     "liship_csr_plan_destroy": (_ci, [_vp]),
     "liship_csr_plan_info": (_ci, [_vp, C.POINTER(_ci), C.POINTER(C.c_longlong), C.POINTER(_ci)]),
     "liship_spmv_csr_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_spmv_csr_dot_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "liship_spmv_csr_rows_f64": (_ci, [_vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_spmv_csr_set_variant": (_ci, [_ci]),
     "liship_spmv_ell_f64": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp]),
@@ -62,6 +63,13 @@ _LISHIP = {
     "liship_abs_f64": (_ci, [_ci, _vp, _vp]),
     "liship_reciprocal_f64": (_ci, [_ci, _vp, _vp]),
     "liship_shift_f64": (_ci, [_ci, _cd, _vp, _vp]),
+    "liship_axpy2_f64": (_ci, [_ci, _cd, _vp, _cd, _vp, _vp, _vp]),
+    "liship_axpy_xpay_f64": (_ci, [_ci, _cd, _vp, _vp, _cd, _vp, _vp]),
+    "liship_cg_update_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_cg_update_jacobi_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_pmul_xpay_f64": (_ci, [_ci, _vp, _vp, _cd, _vp, _vp]),
+    "liship_axpy_sumsq_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp]),
+    "liship_axpy_sumsq_dot_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_reduce_work_bytes": (_sz, []),
     "liship_dot_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp]),
     "liship_nrm2_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),

@@ -296,6 +296,25 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 }
 
 /* ------------------------------------------------------------------ reductions -> host scalars */
+/* y = A x with <w,y> (and <y,y>) formed in the product's epilogue when the kernel can (CSR row-gather);
+ * otherwise the product followed by one reduction pass.  The sums land in lisg.reduce_out[0..1]. */
+LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq)
+{
+	lisd_mat *d = MDEV(A);
+	LISCHK(lisd_mat_ready(A));
+	if (d->type == LIS_MATRIX_CSR && !lisg.no_fusion) {
+		if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
+		int rc = liship_spmv_csr_dot_f64(d->plan, d->ptr, d->index, d->value, dx, dy, dw, want_sumsq,
+		                                 lisg.reduce_out, lisg.reduce_work, lisg.stream);
+		if (rc == 0) return LIS_SUCCESS;
+		if (rc != LISHIP_ERR_ARG) HIPCHK(rc);
+		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));
+	} else LISCHK(lisd_spmv(A, dx, dy));
+	if (want_sumsq) HIPCHK(liship_dot2_f64(d->n, dy, dw, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+	else HIPCHK(liship_dot_f64(d->n, dw, dy, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+	return LIS_SUCCESS;
+}
+
 LIS_INT lisd_fetch(int count, double *out)
 {
 	HIPCHK(liship_memcpy_d2h(lisg.host_out, lisg.reduce_out, (size_t)count * sizeof(double), lisg.stream));

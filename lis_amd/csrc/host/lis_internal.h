@@ -75,6 +75,7 @@ typedef struct {
 typedef struct {
 	int initialized;
 	int residency;
+	int no_fusion;             /* LIS_AMD_NO_FUSION=1: Krylov loops call the separate kernels (A/B measurements) */
 	int device_ready;
 	int device;
 	void *stream;
@@ -101,6 +102,7 @@ void    lisd_vec_free(LIS_VECTOR v);
 LIS_INT lisd_mat_ready(LIS_MATRIX A);
 void    lisd_mat_free(LIS_MATRIX A);
 LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy);      /* y = A x on device pointers (halo included) */
+LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq); /* sums -> reduce_out */
 LIS_INT lisd_fetch(int count, double *out);                   /* reduce_out[0..count) -> host, cross-rank fold */
 LIS_INT lisd_dot(int n, const double *dx, const double *dy, double *out);
 LIS_INT lisd_nrm2(int n, const double *dx, double *out);

@@ -353,7 +353,66 @@ static int initial_residual(ctx_t *c, double *r)
 #define TRY(expr) do { LIS_INT e__ = (expr); if (e__) { err = e__; goto done; } } while (0)
 #define KTRY(call) do { int rc__ = (call); if (rc__) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc__); goto done; } } while (0)
 
+/* residual norm from a sum of squares the fused kernels already produced (lis_solver.c:1792); the
+ * 1-norm criterion (:1804) has no fused form and takes its own pass */
+static LIS_INT resid_from_sumsq(ctx_t *c, const double *r, double sumsq, double *nrm)
+{
+	if (c->s->options[LIS_OPTIONS_CONV_COND] == LIS_CONV_COND_NRM1_B) return lisd_nrm1(c->n, r, nrm);
+	*nrm = sqrt(sumsq) * c->bnrm;
+	return LIS_SUCCESS;
+}
+
+/* Preconditioned CG, lis_solver_cg.c:176-215, the reference's operation order per element with the
+ * passes over HBM fused:
+ *   p = M^-1 r + beta p              one pass   (the solve is a copy or r.*dinv, folded into the xpay)
+ *   q = A p ; <p,q>                  the product, the dot in its epilogue
+ *   x += alpha p ; r -= alpha q ; ||r|| ; rho' = <r, M^-1 r>     one pass
+ * rho' is the next iteration's rho (the reference computes it at :180 from the same r).
+ * LIS_AMD_NO_FUSION=1 runs the one-kernel-per-reference-call loop instead. */
+static LIS_INT run_cg_unfused(ctx_t *c);
 static LIS_INT run_cg(ctx_t *c)
+{
+	if (lisg.no_fusion) return run_cg_unfused(c);
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter;
+	const int n = c->n;
+	TRY(work_alloc(c, 3));
+	double *q = c->work[0], *r = c->work[1], *p = c->work[2];
+	double alpha, beta, rho, rho_old = 1.0, dot_pq, nrm2 = 0.0, sums[2];
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	/* rho of the first iteration; z lives in q for this one pass */
+	if (c->dinv) { KTRY(liship_pmul_f64(n, r, c->dinv, q, lisg.stream)); TRY(lisd_dot(n, r, q, &rho)); }
+	else TRY(lisd_dot(n, r, r, &rho));
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		beta = rho / rho_old;
+		if (c->dinv) KTRY(liship_pmul_xpay_f64(n, r, c->dinv, beta, p, lisg.stream));
+		else         KTRY(liship_xpay_f64(n, r, beta, p, lisg.stream));
+		TRY(lisd_spmv_dot_launch(c->A, p, q, p, 0));
+		TRY(lisd_fetch(1, &dot_pq));
+		if (dot_pq == 0.0) { s->retcode = LIS_BREAKDOWN; s->iter = iter; s->resid = nrm2; err = LIS_BREAKDOWN; goto done; }
+		alpha = rho / dot_pq;
+		if (c->dinv) {
+			KTRY(liship_cg_update_jacobi_f64(n, alpha, p, q, c->dinv, c->x, r, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+			TRY(lisd_fetch(2, sums));
+		} else {
+			KTRY(liship_cg_update_f64(n, alpha, p, q, c->x, r, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+			TRY(lisd_fetch(1, sums));
+			sums[1] = sums[0];
+		}
+		TRY(resid_from_sumsq(c, r, sums[0], &nrm2));
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) { s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done; }
+		rho_old = rho;
+		rho = sums[1];
+	}
+	s->retcode = LIS_MAXITER; s->iter = iter; s->resid = nrm2; err = LIS_MAXITER;
+done:
+	work_free(c);
+	return err;
+}
+
+static LIS_INT run_cg_unfused(ctx_t *c)
 {
 	LIS_SOLVER s = c->s;
 	LIS_INT err = 0, iter;
@@ -386,7 +445,70 @@ done:
 	return err;
 }
 
+/* BiCGSTAB, lis_solver_bicgstab.c:186-290, same treatment:
+ *   p = r + beta (p - omega v)                      one pass
+ *   v = A M^-1 p ; <rtld,v>                         product + epilogue (M^-1 p aliases p without a preconditioner)
+ *   s = r - alpha v ; ||s||                         one pass
+ *   t = A M^-1 s ; <t,s>, <t,t>                     product + epilogue
+ *   x += alpha phat + omega shat                    one pass
+ *   r = s - omega t ; ||r|| ; rho' = <rtld,r>       one pass (rho' is :190 of the next iteration) */
+static LIS_INT run_bicgstab_unfused(ctx_t *c);
 static LIS_INT run_bicgstab(ctx_t *c)
+{
+	if (lisg.no_fusion) return run_bicgstab_unfused(c);
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter;
+	const int n = c->n;
+	const int pre = c->dinv != NULL;
+	TRY(work_alloc(c, pre ? 7 : 5));
+	double *rtld = c->work[0], *r = c->work[1], *t = c->work[2], *p = c->work[3], *v = c->work[4];
+	double *phat = pre ? c->work[5] : p, *shat = pre ? c->work[6] : r;
+	double *sv = r;                                    /* s aliases r: lis_solver_bicgstab.c:160-161 */
+	double alpha = 1.0, omega = 1.0, rho_old = 1.0, rho, beta, nrm2 = 0.0, d1, d2[2], sums[2];
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	TRY(d_copy(c, r, rtld));                           /* shadow residual = r0 (lis_solver.c:1862) */
+	TRY(lisd_dot(n, rtld, r, &rho));
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		if (rho == 0.0) { s->retcode = LIS_BREAKDOWN; s->iter = iter; s->resid = nrm2; err = LIS_BREAKDOWN; goto done; }
+		if (iter == 1) TRY(d_copy(c, r, p));
+		else {
+			beta = (rho / rho_old) * (alpha / omega);
+			KTRY(liship_axpy_xpay_f64(n, -omega, v, r, beta, p, lisg.stream));
+		}
+		if (pre) KTRY(liship_pmul_f64(n, p, c->dinv, phat, lisg.stream));
+		TRY(lisd_spmv_dot_launch(c->A, phat, v, rtld, 0));
+		TRY(lisd_fetch(1, &d1));
+		alpha = rho / d1;
+		KTRY(liship_axpy_sumsq_f64(n, -alpha, v, r, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+		TRY(lisd_fetch(1, sums));
+		TRY(resid_from_sumsq(c, sv, sums[0], &nrm2));
+		if (nrm2 <= c->tol) {
+			note(c, iter, nrm2);
+			KTRY(liship_axpy_f64(n, alpha, phat, c->x, lisg.stream));
+			s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done;
+		}
+		if (pre) KTRY(liship_pmul_f64(n, sv, c->dinv, shat, lisg.stream));
+		TRY(lisd_spmv_dot_launch(c->A, shat, t, sv, 1));
+		TRY(lisd_fetch(2, d2));                         /* <t,s>, <t,t> (:267-268) */
+		omega = d2[0] / d2[1];
+		KTRY(liship_axpy2_f64(n, alpha, phat, omega, shat, c->x, lisg.stream));
+		KTRY(liship_axpy_sumsq_dot_f64(n, -omega, t, r, rtld, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+		TRY(lisd_fetch(2, sums));
+		TRY(resid_from_sumsq(c, r, sums[0], &nrm2));
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) { s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done; }
+		if (omega == 0.0) { s->retcode = LIS_BREAKDOWN; s->iter = iter; s->resid = nrm2; err = LIS_BREAKDOWN; goto done; }
+		rho_old = rho;
+		rho = sums[1];
+	}
+	s->retcode = LIS_MAXITER; s->iter = iter; s->resid = nrm2; err = LIS_MAXITER;
+done:
+	work_free(c);
+	return err;
+}
+
+static LIS_INT run_bicgstab_unfused(ctx_t *c)
 {
 	LIS_SOLVER s = c->s;
 	LIS_INT err = 0, iter;

@@ -186,6 +186,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		if (lisg.nprocs == 0) { lisg.nprocs = 1; lisg.rank = 0; }
 		const char *r = getenv("LIS_AMD_RESIDENCY");
 		if (r && (strcmp(r, "resident") == 0 || strcmp(r, "1") == 0)) lisg.residency = LIS_AMD_RESIDENT;
+		r = getenv("LIS_AMD_NO_FUSION");
+		lisg.no_fusion = (r && r[0] == '1');
 	}
 	return LIS_SUCCESS;
 }

@@ -61,3 +61,6 @@ __device__ __forceinline__ double block_sum(double v, double *scratch)
 }
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// vector_ops.hip: fold `count` per-workgroup partials per result (layout partial[k*stride + i]) into result[k]
+int liship_internal_fold(int count, int nres, int stride, double *partial, double *spare, double *result, void *stream);

@@ -165,13 +165,25 @@ __device__ __forceinline__ double ordered_sum(const double *p, int lim)
     return acc;
 }
 
+// fused reduction epilogue: DOT = 0 none, 1: sum_r w[r]*y[r], 2: also sum_r y[r]^2 (lane-local partial sums)
+template <int DOT>
+struct RowDots {
+    const double *w;
+    double c0, c1;
+    __device__ __forceinline__ void add(int r, double yr)
+    {
+        if (DOT >= 1) c0 += w[r] * yr;
+        if (DOT >= 2) c1 += yr * yr;
+    }
+};
+
 // one whole row block of any shape (many empty rows, rows longer than the LDS stage).
 // Invariant from the plan: every row but the last ends inside the first pass of CAP products.
-template <int BLOCK, int CAP, bool VEC, bool NOGATHER>
+template <int BLOCK, int CAP, bool VEC, bool NOGATHER, int DOT = 0>
 __device__ __forceinline__ void block_by_products(double *prod, const int *__restrict__ ptr,
                                                   const int *__restrict__ idx, const double *__restrict__ val,
                                                   const double *__restrict__ x, double *__restrict__ y,
-                                                  const Blk B)
+                                                  const Blk B, RowDots<DOT> &dots)
 {
     const int r0 = B.r0, r1 = B.r1, k0 = B.k0, k1 = B.k1;
     const int ka = k0 & ~1;
@@ -190,7 +202,7 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
         int s = s_first, e = e_first;
         if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
         const double acc = ordered_sum(prod + (s - ka), min(e, kfirst) - s);
-        if (e <= kfirst) store_stream(y + r, acc); else carry = acc;   // only the block's last row can overflow
+        if (e <= kfirst) { store_stream(y + r, acc); dots.add(r, acc); } else carry = acc;   // only the block's last row can overflow
     }
 
     if (k1 > kfirst) {                                          // uniform: finish the long last row
@@ -207,7 +219,20 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
                 for (int k = base; k < kend; k++) carry += prod[k - ka2];
             base = kend;
         }
-        if ((int)threadIdx.x == owner) store_stream(y + rl, carry);
+        if ((int)threadIdx.x == owner) { store_stream(y + rl, carry); dots.add(rl, carry); }
+    }
+}
+
+// lane partials -> one value per workgroup (fixed order: wave butterfly, then waves in order), written by lane 0
+template <int BLOCK, int DOT>
+__device__ __forceinline__ void publish_dots(const RowDots<DOT> &dots, double *scratch, double *partial, int slot, int stride)
+{
+    if (DOT == 0) return;
+    const double t0 = block_sum<BLOCK / WAVE>(dots.c0, scratch);
+    if (threadIdx.x == 0) partial[slot] = t0;
+    if (DOT >= 2) {
+        const double t1 = block_sum<BLOCK / WAVE>(dots.c1, scratch);
+        if (threadIdx.x == 0) partial[stride + slot] = t1;
     }
 }
 
@@ -224,17 +249,21 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
     if (lb < 0) return;
     Blk B = load_blk(blk, bfirst + lb);
     if (!clip_rows(B, ptr, row_begin, row_end)) return;
-    block_by_products<BLOCK, CAP, VEC, NOGATHER>(prod, ptr, idx, val, x, y, B);
+    RowDots<0> none{nullptr, 0.0, 0.0};
+    block_by_products<BLOCK, CAP, VEC, NOGATHER, 0>(prod, ptr, idx, val, x, y, B, none);
 }
 
 // ------------------------------------------------------------------------------ row-gather kernel
-template <int BLOCK, int WORK, int U, bool XRUN, bool DMA, bool NOGATHER>
+template <int BLOCK, int WORK, int U, bool XRUN, bool DMA, bool NOGATHER, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                                const double *__restrict__ val, const double *__restrict__ x,
                                double *__restrict__ y, const v2i32 *__restrict__ blk,
-                               int bfirst, int nb, int row_begin, int row_end, int nnz_total, int run)
+                               int bfirst, int nb, int row_begin, int row_end, int nnz_total, int run,
+                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr)
 {
+    __shared__ double dot_scratch[BLOCK / WAVE];
+    RowDots<DOT> dots{wdot, 0.0, 0.0};
     constexpr int CAP = WORK + SLACK;
     // + one wavefront of slack: the LDS-DMA form always lands whole 1 KiB wave slices
     __shared__ __attribute__((aligned(16))) double valL[CAP + 8 + 2 * WAVE];
@@ -243,12 +272,17 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     const int lb = block_of_workgroup<XRUN>(nb, run);
     if (lb < 0) return;
     Blk B = load_blk(blk, bfirst + lb);
-    if (!clip_rows(B, ptr, row_begin, row_end)) return;
+    if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
+        return;
+    }
 
     const int ka = B.k0 & ~3;                       // 16 B aligned start for both streams
     const int nq = (B.k1 - ka + 3) >> 2;            // quads of 4 non-zeros
     if ((B.k1 - ka) > CAP || ka + 4 * nq > nnz_total) {     // long row / tail of the arrays
-        block_by_products<BLOCK, CAP, true, NOGATHER>(valL, ptr, idx, val, x, y, B);
+        block_by_products<BLOCK, CAP, true, NOGATHER, DOT>(valL, ptr, idx, val, x, y, B, dots);
+        __syncthreads();
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
         return;
     }
 
@@ -324,7 +358,9 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
             }
         }
         store_stream(y + r, acc);
+        dots.add(r, acc);
     }
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
 }
 
 } // namespace
@@ -451,6 +487,16 @@ void launch_geom(const LaunchArgs &a, int unroll)
     else             launch_rowgather<G, 8, false, true, false>(grid, a);
 }
 
+template <int G, int DOT>
+void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, double *partial)
+{
+    constexpr Geometry g = kGeom[G];
+#define GO(UU) spmv_csr_rowgather_kernel<g.block, g.work, UU, false, true, false, DOT><<<a.nb, g.block, 0, a.st>>>( \
+        a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, 16, w, partial)
+    if (unroll == 4) GO(4); else if (unroll == 7) GO(7); else GO(8);
+#undef GO
+}
+
 int launch_csr(liship_csr_plan_t p, const LaunchArgs &a)
 {
     if (a.nb <= 0) return 0;
@@ -476,6 +522,26 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
     if (!p) return LISHIP_ERR_ARG;
     LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream)};
     return launch_csr(p, a);
+}
+
+// y = A x and, in the same pass, result[0] = sum_r w[r]*y[r] (w may be x), result[1] = sum_r y[r]^2 if want_sumsq.
+// `work` is the reduction scratch (liship_reduce_work_bytes).  LISHIP_ERR_ARG when the fused form cannot
+// serve the call (unaligned arrays, more row blocks than scratch slots, non-default geometry): use the plain
+// product + liship_dot_f64 then.
+extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val,
+                                       const double *x, double *y, const double *w, int want_sumsq,
+                                       double *result, void *work, void *stream)
+{
+    if (!p || !w || !result || !work) return LISHIP_ERR_ARG;
+    const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
+    if (p->geom != 0 || g_variant != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream)};
+    if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
+    if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial);
+    else            launch_rowgather_dot<0, 1>(a, p->unroll, w, partial);
+    LAUNCH_CHECK();
+    return liship_internal_fold(p->nblocks, want_sumsq ? 2 : 1, p->nblocks, partial, spare, result, stream);
 }
 
 extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int row_end, const int *ptr,

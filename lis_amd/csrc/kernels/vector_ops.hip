@@ -2,13 +2,19 @@
 //
 // Element-wise kernels restate src/vector/lis_vector_opv.c of the reference one expression each, with
 // one rounded multiply + one rounded add (no FMA contraction: compiled with -ffp-contract=off), so
-// their results are bit-identical to the CPU loops.  They stream 16 B per lane per access.
+// their results are bit-identical to the CPU loops.  Fused forms (two axpys in one pass, the BiCGSTAB
+// direction update, update + norm + dot) apply the SAME expressions in the SAME order per element --
+// fusing removes passes over HBM, not roundings.
 //
-// Reductions (src/vector/lis_vector_ops.c) are two-stage: every lane accumulates a grid-strided
-// slice, a wavefront butterfly (__shfl_xor) + LDS folds the workgroup, and a second one-workgroup
-// kernel folds the REDUCE_GRID partials in a fixed order.  The grid is a constant, so a result is
-// reproducible run to run and independent of the launch; it is NOT the reference's left-to-right
-// order (which itself changes with OMP_NUM_THREADS, SURVEY 7 "hard parts").
+// Launch shape (measured, tools/ubench_axpy.hip, 1 GiB vectors): one-shot grid, 4 independent 16 B
+// accesses per lane per array issued before the first use, non-temporal stores always, non-temporal
+// loads once the vectors are larger than the 256 MiB Infinity Cache: 4.8 -> 6.1 TB/s for axpy.
+//
+// Reductions (src/vector/lis_vector_ops.c) are trees: every lane accumulates its slice, a wavefront
+// butterfly (__shfl_xor) + LDS folds the workgroup, the per-workgroup partials are folded by further
+// one-shot passes until one workgroup finishes.  The tree depends only on n, so a result is
+// reproducible run to run; it is NOT the reference's left-to-right order (which itself changes with
+// OMP_NUM_THREADS, SURVEY 7 "hard parts").
 #include "common.hpp"
 #include "liship.h"
 
@@ -16,172 +22,293 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int NW = BLOCK / WAVE;
-constexpr int EW_MAX_GRID = 256 * 16;        // element-wise: <= 16 workgroups per CU, grid-stride beyond
-constexpr int REDUCE_GRID = 2048;            // partials per reduction (8 workgroups per CU)
-constexpr int MAX_RESULTS = 2;               // dot2 produces two sums
+constexpr int U = 4;                               // 16 B accesses per lane per array
+constexpr int PAIRS_PER_BLOCK = BLOCK * U;         // 2048 doubles per workgroup
+constexpr long long NT_LOAD_ELEMS = 32LL << 20;    // vectors beyond 256 MiB: stream past the caches
+constexpr size_t MAX_PARTIALS = (1u << 20) + 4096; // level-1 partials of a 2^31-element vector (+ level 2)
 
-inline int ew_grid(long long work_items)
+inline int blocks_for(long long npairs) { return (int)((npairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK); }
+
+template <bool NT> __device__ __forceinline__ v2f64 ld2(const double *p, long long pair)
 {
-    long long g = (work_items + BLOCK - 1) / BLOCK;
-    if (g < 1) g = 1;
-    if (g > EW_MAX_GRID) g = EW_MAX_GRID;
-    return (int)g;
+    const v2f64 *q = reinterpret_cast<const v2f64 *>(p) + pair;
+    return NT ? __builtin_nontemporal_load(q) : *q;
+}
+__device__ __forceinline__ void st2(double *p, long long pair, v2f64 v)
+{
+    __builtin_nontemporal_store(v, reinterpret_cast<v2f64 *>(p) + pair);
 }
 
-// ---- element-wise -------------------------------------------------------------------------
-// F: functor called per element with (i, index) access to arrays hidden in the functor itself.
-// Vector body works on aligned pairs; a scalar tail / unaligned fallback covers the rest.
-template <typename F>
-__global__ __launch_bounds__(BLOCK) void ew_kernel(int n, bool vec, F f)
+// ---- element-wise ---------------------------------------------------------------------------------
+enum EwOp { EW_AXPY, EW_XPAY, EW_AXPYZ, EW_SCALE_TO, EW_PMUL, EW_PDIV, EW_SET, EW_ABS, EW_RECIP, EW_SHIFT,
+            EW_AXPY2, EW_PUPDATE, EW_PMUL_XPAY };
+
+// x = in0, y = in1, w = in2; the expressions are the reference's (file:line in liship.h)
+template <int OP>
+__device__ __forceinline__ double ew_apply(double a, double b, double x, double y, double w)
 {
-    const int tid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
-    if (vec) {
-        const int npairs = n >> 1;
-        for (int p = tid; p < npairs; p += stride) f.pair(p);
-        if ((n & 1) && tid == 0) f.one(n - 1);
-    } else {
-        for (int i = tid; i < n; i += stride) f.one(i);
+    switch (OP) {
+    case EW_AXPY:     return y + a * x;              // y[i] += alpha * x[i]
+    case EW_XPAY:     return x + a * y;              // y[i] = x[i] + alpha * y[i]
+    case EW_AXPYZ:    return a * x + y;              // z[i] = alpha * x[i] + y[i]
+    case EW_SCALE_TO: return a * x;
+    case EW_PMUL:     return x * y;
+    case EW_PDIV:     return x / y;
+    case EW_SET:      return a;
+    case EW_ABS:      return fabs(x);
+    case EW_RECIP:    return 1.0 / x;
+    case EW_SHIFT:    return x - a;
+    case EW_AXPY2:    { double t = y + a * x; return t + b * w; }        // y += a*x ; y += b*w
+    case EW_PUPDATE:  { double t = y + a * x; return w + b * t; }        // y += a*x ; y = w + b*y
+    case EW_PMUL_XPAY: { double z = x * w; return z + a * y; }          // z = x.*w ; y = z + a*y
+    }
+    return 0.0;
+}
+
+template <int OP> struct EwArity { static constexpr int value =
+    (OP == EW_SET) ? 0 : (OP == EW_SCALE_TO || OP == EW_ABS || OP == EW_RECIP || OP == EW_SHIFT) ? 1 :
+    (OP == EW_AXPY2 || OP == EW_PUPDATE || OP == EW_PMUL_XPAY) ? 3 : 2; };
+
+template <int OP, bool NT, bool VEC>
+__global__ __launch_bounds__(BLOCK)
+void ew_kernel(int n, double a, double b, const double *in0, const double *in1, const double *in2, double *out)
+{
+    constexpr int NIN = EwArity<OP>::value;
+    if (VEC) {
+        const long long npairs = n >> 1;
+        const long long base = (long long)blockIdx.x * PAIRS_PER_BLOCK + threadIdx.x;
+        v2f64 x[U], y[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long p = base + u * BLOCK;
+            if (p < npairs) {
+                if (NIN >= 1) x[u] = ld2<NT>(in0, p);
+                if (NIN >= 2) y[u] = ld2<NT>(in1, p);
+                if (NIN >= 3) w[u] = ld2<NT>(in2, p);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long p = base + u * BLOCK;
+            if (p < npairs) {
+                v2f64 r;
+                r.x = ew_apply<OP>(a, b, NIN >= 1 ? x[u].x : 0.0, NIN >= 2 ? y[u].x : 0.0, NIN >= 3 ? w[u].x : 0.0);
+                r.y = ew_apply<OP>(a, b, NIN >= 1 ? x[u].y : 0.0, NIN >= 2 ? y[u].y : 0.0, NIN >= 3 ? w[u].y : 0.0);
+                st2(out, p, r);
+            }
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const int i = n - 1;
+            out[i] = ew_apply<OP>(a, b, NIN >= 1 ? in0[i] : 0.0, NIN >= 2 ? in1[i] : 0.0, NIN >= 3 ? in2[i] : 0.0);
+        }
+    } else {                                     // arrays that are only 8 B aligned
+        const long long i0 = (long long)blockIdx.x * (2 * PAIRS_PER_BLOCK) + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 2 * U; u++) {
+            const long long i = i0 + u * BLOCK;
+            if (i < n) out[i] = ew_apply<OP>(a, b, NIN >= 1 ? in0[i] : 0.0, NIN >= 2 ? in1[i] : 0.0, NIN >= 3 ? in2[i] : 0.0);
+        }
     }
 }
 
-#define V2(p) (reinterpret_cast<v2f64 *>(p))
-#define CV2(p) (reinterpret_cast<const v2f64 *>(p))
-
-struct AxpyF {   // y += a*x
-    double a; const double *x; double *y;
-    __device__ void one(int i) const { y[i] += a * x[i]; }
-    __device__ void pair(int p) const { v2f64 xv = CV2(x)[p], yv = V2(y)[p]; yv.x += a * xv.x; yv.y += a * xv.y; V2(y)[p] = yv; }
-};
-struct XpayF {   // y = x + a*y
-    double a; const double *x; double *y;
-    __device__ void one(int i) const { y[i] = x[i] + a * y[i]; }
-    __device__ void pair(int p) const { v2f64 xv = CV2(x)[p], yv = V2(y)[p]; yv.x = xv.x + a * yv.x; yv.y = xv.y + a * yv.y; V2(y)[p] = yv; }
-};
-struct AxpyzF {  // z = a*x + y
-    double a; const double *x; const double *y; double *z;
-    __device__ void one(int i) const { z[i] = a * x[i] + y[i]; }
-    __device__ void pair(int p) const { v2f64 xv = CV2(x)[p], yv = CV2(y)[p], zv; zv.x = a * xv.x + yv.x; zv.y = a * xv.y + yv.y; V2(z)[p] = zv; }
-};
-struct ScaleToF { // y = a*x
-    double a; const double *x; double *y;
-    __device__ void one(int i) const { y[i] = a * x[i]; }
-    __device__ void pair(int p) const { v2f64 xv = CV2(x)[p], yv; yv.x = a * xv.x; yv.y = a * xv.y; V2(y)[p] = yv; }
-};
-struct PmulF {   // z = x*y
-    const double *x; const double *y; double *z;
-    __device__ void one(int i) const { z[i] = x[i] * y[i]; }
-    __device__ void pair(int p) const { v2f64 xv = CV2(x)[p], yv = CV2(y)[p], zv; zv.x = xv.x * yv.x; zv.y = xv.y * yv.y; V2(z)[p] = zv; }
-};
-struct PdivF {   // z = x/y
-    const double *x; const double *y; double *z;
-    __device__ void one(int i) const { z[i] = x[i] / y[i]; }
-    __device__ void pair(int p) const { v2f64 xv = CV2(x)[p], yv = CV2(y)[p], zv; zv.x = xv.x / yv.x; zv.y = xv.y / yv.y; V2(z)[p] = zv; }
-};
-struct SetAllF {
-    double a; double *x;
-    __device__ void one(int i) const { x[i] = a; }
-    __device__ void pair(int p) const { v2f64 v; v.x = a; v.y = a; V2(x)[p] = v; }
-};
-struct AbsF {
-    double *x;
-    __device__ void one(int i) const { x[i] = fabs(x[i]); }
-    __device__ void pair(int p) const { v2f64 v = V2(x)[p]; v.x = fabs(v.x); v.y = fabs(v.y); V2(x)[p] = v; }
-};
-struct RecipF {
-    double *x;
-    __device__ void one(int i) const { x[i] = 1.0 / x[i]; }
-    __device__ void pair(int p) const { v2f64 v = V2(x)[p]; v.x = 1.0 / v.x; v.y = 1.0 / v.y; V2(x)[p] = v; }
-};
-struct ShiftF {  // x = x - sigma
-    double s; double *x;
-    __device__ void one(int i) const { x[i] = x[i] - s; }
-    __device__ void pair(int p) const { v2f64 v = V2(x)[p]; v.x = v.x - s; v.y = v.y - s; V2(x)[p] = v; }
-};
-
-template <typename F>
-int run_ew(int n, bool vec, F f, void *stream)
+template <int OP>
+int run_ew(int n, double a, double b, const double *in0, const double *in1, const double *in2, double *out, void *stream)
 {
     if (n < 0) return LISHIP_ERR_ARG;
     if (n == 0) return 0;
-    ew_kernel<F><<<ew_grid(vec ? (n + 1) / 2 : n), BLOCK, 0, as_stream(stream)>>>(n, vec, f);
-    LAUNCH_CHECK();
-    return 0;
-}
-
-// ---- reductions -----------------------------------------------------------------------------
-enum RedOp { RED_DOT = 0, RED_SUMSQ = 1, RED_ABS = 2, RED_SUM = 3, RED_DOT2 = 4 };
-
-template <int OP>
-__device__ __forceinline__ void red_term(double xv, double yv, double &a0, double &a1)
-{
-    if (OP == RED_DOT)   a0 += xv * yv;
-    if (OP == RED_SUMSQ) a0 += xv * xv;
-    if (OP == RED_ABS)   a0 += fabs(xv);
-    if (OP == RED_SUM)   a0 += xv;
-    if (OP == RED_DOT2) { a0 += xv * yv; a1 += xv * xv; }
-}
-
-template <int OP>
-__global__ __launch_bounds__(BLOCK)
-void reduce_stage1(int n, bool vec, const double *__restrict__ x, const double *__restrict__ y,
-                   double *__restrict__ partial)
-{
-    __shared__ double scratch[NW];
-    constexpr bool TWO_IN = (OP == RED_DOT || OP == RED_DOT2);
-    const int tid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
-    double a0 = 0.0, a1 = 0.0;
-    if (vec) {
-        const int npairs = n >> 1;
-        for (int p = tid; p < npairs; p += stride) {
-            const v2f64 xv = CV2(x)[p];
-            v2f64 yv = xv;
-            if (TWO_IN) yv = CV2(y)[p];
-            red_term<OP>(xv.x, yv.x, a0, a1);
-            red_term<OP>(xv.y, yv.y, a0, a1);
-        }
-        if ((n & 1) && tid == 0) red_term<OP>(x[n - 1], TWO_IN ? y[n - 1] : 0.0, a0, a1);
-    } else {
-        for (int i = tid; i < n; i += stride) red_term<OP>(x[i], TWO_IN ? y[i] : 0.0, a0, a1);
-    }
-    const double s0 = block_sum<NW>(a0, scratch);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s0;
-    if (OP == RED_DOT2) {
-        const double s1 = block_sum<NW>(a1, scratch);
-        if (threadIdx.x == 0) partial[REDUCE_GRID + blockIdx.x] = s1;
-    }
-}
-
-// one workgroup: result[k] = fold(partial[k*REDUCE_GRID .. +count)), optional sqrt
-__global__ __launch_bounds__(BLOCK)
-void reduce_stage2(int count, int nresults, bool root, const double *__restrict__ partial,
-                   double *__restrict__ result)
-{
-    __shared__ double scratch[NW];
-    for (int k = 0; k < nresults; k++) {
-        double a = 0.0;
-        for (int i = threadIdx.x; i < count; i += BLOCK) a += partial[k * REDUCE_GRID + i];
-        const double s = block_sum<NW>(a, scratch);
-        if (threadIdx.x == 0) result[k] = root ? sqrt(s) : s;
-    }
-}
-
-template <int OP>
-int run_reduce(int n, const double *x, const double *y, double *result, void *work, bool root, void *stream)
-{
-    if (n < 0 || !result || !work) return LISHIP_ERR_ARG;
-    constexpr bool TWO_IN = (OP == RED_DOT || OP == RED_DOT2);
-    const bool vec = aligned16(x) && (!TWO_IN || aligned16(y));
-    long long items = vec ? (n + 1) / 2 : n;
-    int grid = (int)((items + BLOCK - 1) / BLOCK);
-    if (grid < 1) grid = 1;
-    if (grid > REDUCE_GRID) grid = REDUCE_GRID;
-    double *partial = static_cast<double *>(work);
+    constexpr int NIN = EwArity<OP>::value;
+    const bool vec = aligned16(out) && (NIN < 1 || aligned16(in0)) && (NIN < 2 || aligned16(in1)) && (NIN < 3 || aligned16(in2));
+    const int grid = blocks_for(vec ? (n + 1) / 2 : ((long long)n + 1) / 2);
     hipStream_t st = as_stream(stream);
-    reduce_stage1<OP><<<grid, BLOCK, 0, st>>>(n, vec, x, y, partial);
-    LAUNCH_CHECK();
-    reduce_stage2<<<1, BLOCK, 0, st>>>(grid, OP == RED_DOT2 ? 2 : 1, root, partial, result);
+    if (!vec)                       ew_kernel<OP, false, false><<<grid, BLOCK, 0, st>>>(n, a, b, in0, in1, in2, out);
+    else if (n > NT_LOAD_ELEMS)     ew_kernel<OP, true, true><<<grid, BLOCK, 0, st>>>(n, a, b, in0, in1, in2, out);
+    else                            ew_kernel<OP, false, true><<<grid, BLOCK, 0, st>>>(n, a, b, in0, in1, in2, out);
     LAUNCH_CHECK();
     return 0;
+}
+
+// ---- reductions -------------------------------------------------------------------------------------
+// level 1: partial[k*stride + block] for k < NRES; levels >= 2 sum partial arrays the same way
+enum RedOp { RED_DOT, RED_SUMSQ, RED_ABS, RED_SUM, RED_DOT2,
+             RED_CG_UPDATE,     // x += a*p; r += (-a)*q; result {sum r^2}
+             RED_CG_UPDATE_JAC, // same + z = r.*dinv (not stored); results {sum r^2, sum r*z}
+             RED_AXPY_NRM2,     // y += a*x; result {sum y^2}
+             RED_AXPY_NRM2_DOT  // y += a*x; results {sum y^2, sum w*y}
+};
+template <int OP> struct RedResults { static constexpr int value =
+    (OP == RED_DOT2 || OP == RED_AXPY_NRM2_DOT || OP == RED_CG_UPDATE_JAC) ? 2 : 1; };
+
+struct RedArgs {
+    int n;
+    double a;
+    const double *x, *y, *w, *d, *e; // inputs (meaning per OP)
+    double *ox, *oy;                 // in-place outputs of the fused forms
+};
+
+template <int OP, bool NT, bool VEC>
+__global__ __launch_bounds__(BLOCK)
+void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool root)
+{
+    __shared__ double scratch[NW];
+    constexpr int NRES = RedResults<OP>::value;
+    double s0 = 0.0, s1 = 0.0;
+    const int n = A.n;
+    auto term = [&](double x, double y, double w, double d, double e, double &ox, double &oy) {
+        if (OP == RED_DOT)   s0 += x * y;
+        if (OP == RED_SUMSQ) s0 += x * x;
+        if (OP == RED_ABS)   s0 += fabs(x);
+        if (OP == RED_SUM)   s0 += x;
+        if (OP == RED_DOT2) { s0 += x * y; s1 += x * x; }
+        if (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC) {   // x: p, y: q, w: x-iterate, d: residual r, e: 1/diag
+            ox = w + A.a * x;               // x += alpha*p
+            oy = d + (-A.a) * y;            // r += (-alpha)*q
+            s0 += oy * oy;
+            if (OP == RED_CG_UPDATE_JAC) { const double z = oy * e; s1 += oy * z; }   // z = r.*dinv ; <r,z>
+        }
+        if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT) {
+            oy = y + A.a * x;               // y += a*x
+            s0 += oy * oy;
+            if (OP == RED_AXPY_NRM2_DOT) s1 += w * oy;
+        }
+        (void)e;
+    };
+    constexpr bool IS_CG = (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC);
+    constexpr bool HAS_Y = (OP == RED_DOT || OP == RED_DOT2 || IS_CG || OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT);
+    constexpr bool HAS_W = (IS_CG || OP == RED_AXPY_NRM2_DOT);
+    constexpr bool HAS_D = IS_CG;
+    constexpr bool HAS_E = (OP == RED_CG_UPDATE_JAC);
+    if (VEC) {
+        const long long npairs = n >> 1;
+        const long long base = (long long)blockIdx.x * PAIRS_PER_BLOCK + threadIdx.x;
+        v2f64 x[U], y[U], w[U], d[U], e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long p = base + u * BLOCK;
+            if (p < npairs) {
+                x[u] = ld2<NT>(A.x, p);
+                if (HAS_Y) y[u] = ld2<NT>(A.y, p);
+                if (HAS_W) w[u] = ld2<NT>(A.w, p);
+                if (HAS_D) d[u] = ld2<NT>(A.d, p);
+                if (HAS_E) e[u] = ld2<NT>(A.e, p);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long p = base + u * BLOCK;
+            if (p < npairs) {
+                double ox0 = 0.0, oy0 = 0.0, ox1 = 0.0, oy1 = 0.0;
+                term(x[u].x, HAS_Y ? y[u].x : 0.0, HAS_W ? w[u].x : 0.0, HAS_D ? d[u].x : 0.0, HAS_E ? e[u].x : 0.0, ox0, oy0);
+                term(x[u].y, HAS_Y ? y[u].y : 0.0, HAS_W ? w[u].y : 0.0, HAS_D ? d[u].y : 0.0, HAS_E ? e[u].y : 0.0, ox1, oy1);
+                v2f64 ox, oy;
+                ox.x = ox0; ox.y = ox1; oy.x = oy0; oy.y = oy1;
+                if (IS_CG) { st2(A.ox, p, ox); st2(A.oy, p, oy); }
+                if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT) st2(A.oy, p, oy);
+            }
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const int i = n - 1;
+            double ox, oy;
+            term(A.x[i], HAS_Y ? A.y[i] : 0.0, HAS_W ? A.w[i] : 0.0, HAS_D ? A.d[i] : 0.0, HAS_E ? A.e[i] : 0.0, ox, oy);
+            if (IS_CG) { A.ox[i] = ox; A.oy[i] = oy; }
+            if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT) A.oy[i] = oy;
+        }
+    } else {
+        const long long i0 = (long long)blockIdx.x * (2 * PAIRS_PER_BLOCK) + threadIdx.x;
+        for (int u = 0; u < 2 * U; u++) {
+            const long long i = i0 + u * BLOCK;
+            if (i < n) {
+                double ox, oy;
+                term(A.x[i], HAS_Y ? A.y[i] : 0.0, HAS_W ? A.w[i] : 0.0, HAS_D ? A.d[i] : 0.0, HAS_E ? A.e[i] : 0.0, ox, oy);
+                if (IS_CG) { A.ox[i] = ox; A.oy[i] = oy; }
+                if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT) A.oy[i] = oy;
+            }
+        }
+    }
+    const double t0 = block_sum<NW>(s0, scratch);       // root only when this block IS the whole reduction
+    if (threadIdx.x == 0) partial[blockIdx.x] = root ? sqrt(t0) : t0;
+    if (NRES == 2) {
+        const double t1 = block_sum<NW>(s1, scratch);
+        if (threadIdx.x == 0) partial[stride + blockIdx.x] = t1;
+    }
+}
+
+// levels >= 2: out[k*ostride + block] = sum of in[k*istride + block*2048 ...), finally one block
+__global__ __launch_bounds__(BLOCK)
+void reduce_fold(int count, int nres, int istride, int ostride, const double *__restrict__ in, double *__restrict__ out,
+                 bool root)
+{
+    __shared__ double scratch[NW];
+    for (int k = 0; k < nres; k++) {
+        const double *src = in + (size_t)k * istride;
+        double s = 0.0;
+        const long long i0 = (long long)blockIdx.x * (2 * PAIRS_PER_BLOCK) + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 2 * U; u++) {
+            const long long i = i0 + u * BLOCK;
+            if (i < count) s += src[i];
+        }
+        const double t = block_sum<NW>(s, scratch);
+        if (threadIdx.x == 0) out[(size_t)k * ostride + blockIdx.x] = root ? sqrt(t) : t;
+    }
+}
+
+__global__ void finish_kernel(int nres, int stride, bool root, const double *__restrict__ in, double *__restrict__ result)
+{
+    if (threadIdx.x < nres) { const double s = in[(size_t)threadIdx.x * stride]; result[threadIdx.x] = root ? sqrt(s) : s; }
+}
+
+// fold `count` partials per result (layout partial[k*stride + i]) down to result[k]; scratch2 lives behind them
+int fold_partials(int count, int nres, int stride, double *partial, double *spare, double *result, bool root, hipStream_t st)
+{
+    const double *cur = partial;
+    int cstride = stride;
+    double *bufs[2] = {spare, partial};
+    int which = 0;
+    while (count > 1) {
+        const int blocks = (count + 2 * PAIRS_PER_BLOCK - 1) / (2 * PAIRS_PER_BLOCK);
+        if (blocks == 1) {                          // last level: straight into result[k]
+            reduce_fold<<<1, BLOCK, 0, st>>>(count, nres, cstride, 1, cur, result, root);
+            LAUNCH_CHECK();
+            return 0;
+        }
+        double *dst = bufs[which];
+        reduce_fold<<<blocks, BLOCK, 0, st>>>(count, nres, cstride, blocks, cur, dst, false);
+        LAUNCH_CHECK();
+        cur = dst; cstride = blocks; count = blocks;
+        which ^= 1;
+    }
+    finish_kernel<<<1, 64, 0, st>>>(nres, cstride, root, cur, result);    // a single partial (SpMV epilogue of one block)
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <int OP>
+int run_reduce(RedArgs A, double *result, void *work, bool root, void *stream)
+{
+    if (A.n < 0 || !result || !work) return LISHIP_ERR_ARG;
+    constexpr int NRES = RedResults<OP>::value;
+    const int n = A.n;
+    bool vec = aligned16(A.x);
+    if (A.y) vec = vec && aligned16(A.y);
+    if (A.w) vec = vec && aligned16(A.w);
+    if (A.d) vec = vec && aligned16(A.d);
+    if (A.e) vec = vec && aligned16(A.e);
+    if (A.ox) vec = vec && aligned16(A.ox);
+    if (A.oy) vec = vec && aligned16(A.oy);
+    int grid = blocks_for(vec ? (n + 1) / 2 : ((long long)n + 1) / 2);
+    if (grid < 1) grid = 1;
+    double *partial = static_cast<double *>(work);
+    double *spare = partial + 2 * MAX_PARTIALS;              // second half of the scratch
+    hipStream_t st = as_stream(stream);
+    const bool single = (grid == 1);                         // one block: it writes result[k] itself
+    double *dst = single ? result : partial;
+    const bool r1 = single && root;
+    if (!vec)                   reduce_level1<OP, false, false><<<grid, BLOCK, 0, st>>>(A, grid, dst, r1);
+    else if (n > NT_LOAD_ELEMS) reduce_level1<OP, true, true><<<grid, BLOCK, 0, st>>>(A, grid, dst, r1);
+    else                        reduce_level1<OP, false, true><<<grid, BLOCK, 0, st>>>(A, grid, dst, r1);
+    LAUNCH_CHECK();
+    if (single) return 0;
+    return fold_partials(grid, NRES, grid, partial, spare, result, root, st);
 }
 
 __global__ __launch_bounds__(BLOCK)
@@ -206,49 +333,82 @@ void csr_diagonal_kernel(int n, const int *__restrict__ ptr, const int *__restri
 
 } // namespace
 
-extern "C" size_t liship_reduce_work_bytes(void) { return sizeof(double) * REDUCE_GRID * MAX_RESULTS; }
+// scratch: two ping-pong partial areas, each big enough for two results of a 2^31-element vector
+extern "C" size_t liship_reduce_work_bytes(void) { return sizeof(double) * 2 * MAX_PARTIALS * 2; }
+
+// used by spmv_csr.hip's fused dot epilogue
+int liship_internal_fold(int count, int nres, int stride, double *partial, double *spare, double *result, void *stream)
+{ return fold_partials(count, nres, stride, partial, spare, result, false, as_stream(stream)); }
 
 extern "C" int liship_axpy_f64(int n, double a, const double *x, double *y, void *s)
-{ return run_ew(n, aligned16(x) && aligned16(y), AxpyF{a, x, y}, s); }
+{ return run_ew<EW_AXPY>(n, a, 0.0, x, y, nullptr, y, s); }
 extern "C" int liship_xpay_f64(int n, const double *x, double a, double *y, void *s)
-{ return run_ew(n, aligned16(x) && aligned16(y), XpayF{a, x, y}, s); }
+{ return run_ew<EW_XPAY>(n, a, 0.0, x, y, nullptr, y, s); }
 extern "C" int liship_axpyz_f64(int n, double a, const double *x, const double *y, double *z, void *s)
-{ return run_ew(n, aligned16(x) && aligned16(y) && aligned16(z), AxpyzF{a, x, y, z}, s); }
+{ return run_ew<EW_AXPYZ>(n, a, 0.0, x, y, nullptr, z, s); }
 extern "C" int liship_scale_f64(int n, double a, double *x, void *s)
-{ return run_ew(n, aligned16(x), ScaleToF{a, x, x}, s); }
+{ return run_ew<EW_SCALE_TO>(n, a, 0.0, x, nullptr, nullptr, x, s); }
 extern "C" int liship_scale_to_f64(int n, double a, const double *x, double *y, void *s)
-{ return run_ew(n, aligned16(x) && aligned16(y), ScaleToF{a, x, y}, s); }
+{ return run_ew<EW_SCALE_TO>(n, a, 0.0, x, nullptr, nullptr, y, s); }
 extern "C" int liship_pmul_f64(int n, const double *x, const double *y, double *z, void *s)
-{ return run_ew(n, aligned16(x) && aligned16(y) && aligned16(z), PmulF{x, y, z}, s); }
+{ return run_ew<EW_PMUL>(n, 0.0, 0.0, x, y, nullptr, z, s); }
 extern "C" int liship_pdiv_f64(int n, const double *x, const double *y, double *z, void *s)
-{ return run_ew(n, aligned16(x) && aligned16(y) && aligned16(z), PdivF{x, y, z}, s); }
+{ return run_ew<EW_PDIV>(n, 0.0, 0.0, x, y, nullptr, z, s); }
 extern "C" int liship_set_all_f64(int n, double a, double *x, void *s)
-{ return run_ew(n, aligned16(x), SetAllF{a, x}, s); }
+{ return run_ew<EW_SET>(n, a, 0.0, nullptr, nullptr, nullptr, x, s); }
 extern "C" int liship_abs_f64(int n, double *x, void *s)
-{ return run_ew(n, aligned16(x), AbsF{x}, s); }
+{ return run_ew<EW_ABS>(n, 0.0, 0.0, x, nullptr, nullptr, x, s); }
 extern "C" int liship_reciprocal_f64(int n, double *x, void *s)
-{ return run_ew(n, aligned16(x), RecipF{x}, s); }
+{ return run_ew<EW_RECIP>(n, 0.0, 0.0, x, nullptr, nullptr, x, s); }
 extern "C" int liship_shift_f64(int n, double sigma, double *x, void *s)
-{ return run_ew(n, aligned16(x), ShiftF{sigma, x}, s); }
+{ return run_ew<EW_SHIFT>(n, sigma, 0.0, x, nullptr, nullptr, x, s); }
+extern "C" int liship_axpy2_f64(int n, double a, const double *x, double b, const double *w, double *y, void *s)
+{ return run_ew<EW_AXPY2>(n, a, b, x, y, w, y, s); }
+extern "C" int liship_axpy_xpay_f64(int n, double a, const double *x, const double *w, double b, double *y, void *s)
+{ return run_ew<EW_PUPDATE>(n, a, b, x, y, w, y, s); }
 
 extern "C" int liship_dot_f64(int n, const double *x, const double *y, double *r, void *w, void *s)
-{ return run_reduce<RED_DOT>(n, x, y, r, w, false, s); }
+{ RedArgs A{n, 0.0, x, y, nullptr, nullptr, nullptr, nullptr, nullptr}; return run_reduce<RED_DOT>(A, r, w, false, s); }
 extern "C" int liship_nrm2_f64(int n, const double *x, double *r, void *w, void *s)
-{ return run_reduce<RED_SUMSQ>(n, x, nullptr, r, w, true, s); }
+{ RedArgs A{n, 0.0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; return run_reduce<RED_SUMSQ>(A, r, w, true, s); }
 extern "C" int liship_sumsq_f64(int n, const double *x, double *r, void *w, void *s)
-{ return run_reduce<RED_SUMSQ>(n, x, nullptr, r, w, false, s); }
+{ RedArgs A{n, 0.0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; return run_reduce<RED_SUMSQ>(A, r, w, false, s); }
 extern "C" int liship_nrm1_f64(int n, const double *x, double *r, void *w, void *s)
-{ return run_reduce<RED_ABS>(n, x, nullptr, r, w, false, s); }
+{ RedArgs A{n, 0.0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; return run_reduce<RED_ABS>(A, r, w, false, s); }
 extern "C" int liship_sum_f64(int n, const double *x, double *r, void *w, void *s)
-{ return run_reduce<RED_SUM>(n, x, nullptr, r, w, false, s); }
+{ RedArgs A{n, 0.0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; return run_reduce<RED_SUM>(A, r, w, false, s); }
 extern "C" int liship_dot2_f64(int n, const double *x, const double *y, double *r, void *w, void *s)
-{ return run_reduce<RED_DOT2>(n, x, y, r, w, false, s); }
+{ RedArgs A{n, 0.0, x, y, nullptr, nullptr, nullptr, nullptr, nullptr}; return run_reduce<RED_DOT2>(A, r, w, false, s); }
+
+// x += alpha*p ; r -= alpha*q ; result = {sum r^2}  (the two axpys + nrm2 of a CG iteration in one pass)
+extern "C" int liship_cg_update_f64(int n, double alpha, const double *p, const double *q, double *x, double *r,
+                                    double *result, void *w, void *s)
+{
+    RedArgs A{n, alpha, p, q, x, r, nullptr, x, r};
+    return run_reduce<RED_CG_UPDATE>(A, result, w, false, s);
+}
+extern "C" int liship_cg_update_jacobi_f64(int n, double alpha, const double *p, const double *q, const double *dinv,
+                                           double *x, double *r, double *result, void *w, void *s)
+{
+    RedArgs A{n, alpha, p, q, x, r, dinv, x, r};
+    return run_reduce<RED_CG_UPDATE_JAC>(A, result, w, false, s);
+}
+extern "C" int liship_pmul_xpay_f64(int n, const double *x, const double *d, double a, double *y, void *s)
+{ return run_ew<EW_PMUL_XPAY>(n, a, 0.0, x, y, d, y, s); }
+// y += a*x ; result = {sum y^2}
+extern "C" int liship_axpy_sumsq_f64(int n, double a, const double *x, double *y, double *result, void *w, void *s)
+{ RedArgs A{n, a, x, y, nullptr, nullptr, nullptr, nullptr, y}; return run_reduce<RED_AXPY_NRM2>(A, result, w, false, s); }
+// y += a*x ; result = {sum y^2, sum v*y}
+extern "C" int liship_axpy_sumsq_dot_f64(int n, double a, const double *x, double *y, const double *v, double *result, void *w, void *s)
+{ RedArgs A{n, a, x, y, v, nullptr, nullptr, nullptr, y}; return run_reduce<RED_AXPY_NRM2_DOT>(A, result, w, false, s); }
 
 extern "C" int liship_gather_f64(int count, const int *index, const double *x, double *out, void *s)
 {
     if (count < 0) return LISHIP_ERR_ARG;
     if (count == 0) return 0;
-    gather_kernel<<<ew_grid(count), BLOCK, 0, as_stream(s)>>>(count, index, x, out);
+    int grid = (count + BLOCK - 1) / BLOCK;
+    if (grid > 4096) grid = 4096;
+    gather_kernel<<<grid, BLOCK, 0, as_stream(s)>>>(count, index, x, out);
     LAUNCH_CHECK();
     return 0;
 }

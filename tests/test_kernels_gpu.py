@@ -305,3 +305,82 @@ def test_large_poisson_properties(lib):
     check(lib.liship_nrm1_f64(n, y.ptr, res.ptr, work.ptr, None))
     assert res.to_host()[0] == 0.0
     check(lib.liship_csr_plan_destroy(plan))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 1000, 4097, (1 << 21) + 3])
+def test_fused_vector_kernels_bit_exact(lib, n):
+    """Fused forms must give the bits of the separate reference calls they replace (same expressions, same order)."""
+    rng = np.random.default_rng(n + 7)
+    x, y, w, r = (rng.uniform(-1, 1, n) for _ in range(4))
+    a, b = 0.37120000000000003, -1.25
+    O = orc.lib()
+    work, res = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
+    dx, dy, dw, dr = DA.from_host(x), DA.from_host(y), DA.from_host(w), DA.from_host(r)
+    # y += a*x ; y += b*w
+    yy = y.copy(); O.orc_axpy(n, a, x, yy); O.orc_axpy(n, b, w, yy)
+    check(lib.liship_axpy2_f64(n, a, dx.ptr, b, dw.ptr, dy.ptr, None)); assert np.array_equal(dy.to_host(), yy)
+    # y += a*x ; y = w + b*y
+    O.orc_axpy(n, a, x, yy); O.orc_xpay(n, w, b, yy)
+    check(lib.liship_axpy_xpay_f64(n, a, dx.ptr, dw.ptr, b, dy.ptr, None)); assert np.array_equal(dy.to_host(), yy)
+    # CG update: xi += a*p ; r += (-a)*q ; sum r^2
+    xi, rr = w.copy(), r.copy()
+    O.orc_axpy(n, a, x, xi); O.orc_axpy(n, -a, y, rr)
+    dy.upload(y)
+    check(lib.liship_cg_update_f64(n, a, dx.ptr, dy.ptr, dw.ptr, dr.ptr, res.ptr, work.ptr, None))
+    assert np.array_equal(dw.to_host(), xi) and np.array_equal(dr.to_host(), rr)
+    assert abs(res.to_host()[0] - np.dot(rr, rr)) <= 1e-14 * np.dot(rr, rr) * max(1.0, np.log2(n + 1))
+    # y += a*x ; sum y^2 (; sum v*y)
+    yy = y.copy(); O.orc_axpy(n, a, x, yy)
+    check(lib.liship_axpy_sumsq_f64(n, a, dx.ptr, dy.ptr, res.ptr, work.ptr, None))
+    assert np.array_equal(dy.to_host(), yy) and abs(res.to_host()[0] - np.dot(yy, yy)) <= 1e-14 * np.dot(yy, yy) * max(1.0, np.log2(n + 1))
+    O.orc_axpy(n, a, x, yy)
+    check(lib.liship_axpy_sumsq_dot_f64(n, a, dx.ptr, dy.ptr, dr.ptr, res.ptr, work.ptr, None))
+    out = res.to_host()
+    assert np.array_equal(dy.to_host(), yy)
+    assert abs(out[0] - np.dot(yy, yy)) <= 1e-14 * np.dot(yy, yy) * max(1.0, np.log2(n + 1))
+    assert abs(out[1] - np.dot(rr, yy)) <= 1e-14 * np.abs(rr * yy).sum() * max(1.0, np.log2(n + 1))
+    # Jacobi forms: z = x.*d ; y = z + b*y      and      CG update + <r, r.*dinv>
+    dinv = rng.uniform(0.1, 2.0, n)
+    dd = DA.from_host(dinv)
+    z = np.empty(n); O.orc_pmul(n, x, dinv, z); O.orc_xpay(n, z, b, yy)
+    check(lib.liship_pmul_xpay_f64(n, dx.ptr, dd.ptr, b, dy.ptr, None)); assert np.array_equal(dy.to_host(), yy)
+    xi, rr = w.copy(), r.copy()
+    O.orc_axpy(n, a, x, xi); O.orc_axpy(n, -a, y, rr); O.orc_pmul(n, rr, dinv, z)
+    dy.upload(y); dw.upload(w); dr.upload(r)
+    check(lib.liship_cg_update_jacobi_f64(n, a, dx.ptr, dy.ptr, dd.ptr, dw.ptr, dr.ptr, res.ptr, work.ptr, None))
+    out = res.to_host()
+    assert np.array_equal(dw.to_host(), xi) and np.array_equal(dr.to_host(), rr)
+    assert abs(out[0] - np.dot(rr, rr)) <= 1e-14 * np.dot(rr, rr) * max(1.0, np.log2(n + 1))
+    assert abs(out[1] - np.dot(rr, z)) <= 1e-14 * np.abs(rr * z).sum() * max(1.0, np.log2(n + 1))
+
+
+@pytest.mark.parametrize("name", list(CSR_CASES))
+@pytest.mark.parametrize("want_sumsq", [0, 1])
+def test_spmv_csr_fused_dot(lib, name, want_sumsq):
+    """y of the fused form is bit-identical to the plain product; the fused sums agree with the separate
+    reduction kernels to 1e-13 relative (different but fixed tree order) and repeat bit for bit."""
+    ptr, idx, val = CSR_CASES[name]()
+    n = len(ptr) - 1
+    ncols = max(n, int(idx.max()) + 1 if len(idx) else 1)
+    rng = np.random.default_rng(11)
+    x, w = rng.uniform(-1, 1, ncols), rng.uniform(-1, 1, n)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64)
+    dx, dw = DA.from_host(x, np.float64), DA.from_host(w, np.float64)
+    dy = DA.from_host(np.full(n, np.nan), np.float64)
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    res = DA.from_host(np.full(2, np.nan), np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    got = []
+    for _ in range(2):
+        check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, want_sumsq,
+                                          res.ptr, work.ptr, None))
+        got.append(res.to_host())
+        assert np.array_equal(dy.to_host(), yref)
+    check(lib.liship_csr_plan_destroy(plan))
+    assert np.array_equal(got[0][:1 + want_sumsq], got[1][:1 + want_sumsq])
+    scale = np.abs(w * yref).sum() + 1e-300
+    assert abs(got[0][0] - np.dot(w, yref)) <= 1e-13 * scale
+    if want_sumsq:
+        assert abs(got[0][1] - np.dot(yref, yref)) <= 1e-13 * np.dot(yref, yref) + 1e-300

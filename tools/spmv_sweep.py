@@ -52,6 +52,14 @@ def main():
                       f"{gbs:.0f} GB/s  {gbs/80:.1f}% of 8 TB/s", flush=True)
                 lib.liship_csr_plan_destroy(plan)
             lib.liship_spmv_csr_set_variant(0)
+            plan = C.c_void_p()
+            check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+            fw, fr = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
+            for sq in (0, 1):
+                ms = timed(lib, lambda: check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr,
+                                                                          x.ptr, sq, fr.ptr, fw.ptr, None)))
+                print(f"N={N} sorted={sorted_} fused dot (sumsq={sq}): {ms:.4f} ms  ({(bytes_alg + 8 * n) / ms / 1e6:.0f} GB/s incl. w)", flush=True)
+            lib.liship_csr_plan_destroy(plan)
         # streaming yardsticks on the same box: copy (16 B/elem) and dot (16 B/elem), axpy (24 B/elem)
         ms = timed(lib, lambda: check(lib.liship_memcpy_d2d(y.ptr, x.ptr, 8 * n, None)))
         print(f"N={N} d2d copy: {ms:.4f} ms {16*n/ms/1e6:.0f} GB/s")

@@ -139,10 +139,18 @@ typedef LIS_INT      LIS_Comm;         /* ref:485 */
 #define LIS_SOLVER_COCG 24
 #define LIS_SOLVER_COCR 25
 
-#define LIS_FMT_AUTO 0                /* ref:55-64 (served by lis_output_vector: PLAIN, MM) */
+#define LIS_FMT_AUTO 0                /* ref:55-64; served: PLAIN/MM/LIS(ascii) vectors, MM/MMB matrices */
 #define LIS_FMT_PLAIN 1
 #define LIS_FMT_MM 2
 #define LIS_FMT_LIS 3
+#define LIS_FMT_LIS_ASCII 3
+#define LIS_FMT_LIS_BINARY 4
+#define LIS_FMT_FREE 5
+#define LIS_FMT_ITBL 6
+#define LIS_FMT_HB 7
+#define LIS_FMT_MMB 8
+#define LIS_BINARY_BIG 0              /* ref:66-67 */
+#define LIS_BINARY_LITTLE 1
 
 #define LIS_INS_VALUE 0               /* ref:207-209 */
 #define LIS_ADD_VALUE 1
@@ -515,7 +523,18 @@ LIS_INT lis_precon_destroy(LIS_PRECON precon);
 LIS_INT lis_solver_get_solvername(LIS_INT solver, char *solvername);
 LIS_INT lis_solver_get_preconname(LIS_INT precon_type, char *preconname);
 LIS_INT lis_solver_output_rhistory(LIS_SOLVER solver, char *filename);  /* ref:1022, src/system/lis_output.c:586 */
-LIS_INT lis_output_vector(LIS_VECTOR v, LIS_INT format, char *filename); /* ref:1021, src/system/lis_output.c:146 (drivers write x with it) */
+/* ---- file I/O, ref:1019-1024 (src/system/lis_input.c, lis_input_mm.c, lis_output.c, lis_output_mm.c) ----
+ * Matrix Market coordinate real general|symmetric, with Lis's size-line extension "nr nc nnz isb isx [isbin]"
+ * (right-hand side / initial guess appended, optional binary records).  The reader fixes the in-row entry
+ * order (file order, mirrored entry first) and with it the bits of every SpMV on the matrix.
+ * `array` (dense) files are read straight into CSR (non-zero values, columns ascending), which is what the
+ * reference's DNS -> CSR conversion yields.  Not served: Harwell-Boeing files -> LIS_ERR_NOT_IMPLEMENTED. */
+LIS_INT lis_input(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, char *filename);      /* lis_input.c:67 */
+LIS_INT lis_input_matrix(LIS_MATRIX A, char *filename);                          /* lis_input.c:174 */
+LIS_INT lis_input_vector(LIS_VECTOR v, char *filename);                          /* lis_input.c:188 (MM, Lis ascii, plain) */
+LIS_INT lis_output(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_INT mode, char *path); /* lis_output.c:63 (MM, MMB) */
+LIS_INT lis_output_matrix(LIS_MATRIX A, LIS_INT mode, char *path);               /* lis_output.c:101 */
+LIS_INT lis_output_vector(LIS_VECTOR v, LIS_INT format, char *filename);         /* lis_output.c:146 (PLAIN, MM, LIS) */
 
 /* ---- utilities, ref:1030-1045 (src/system) ----------------------------------------------------- */
 LIS_INT lis_initialize(int *argc, char **argv[]);

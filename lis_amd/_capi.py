@@ -177,6 +177,11 @@ _PROTOS = {
     "lis_solver_set_optionC": (LIS_INT, [PS]),
     "lis_solve": (LIS_INT, [PM, PV, PV, PS]),
     "lis_output_vector": (LIS_INT, [PV, LIS_INT, C.c_char_p]),
+    "lis_input": (LIS_INT, [PM, PV, PV, C.c_char_p]),
+    "lis_input_matrix": (LIS_INT, [PM, C.c_char_p]),
+    "lis_input_vector": (LIS_INT, [PV, C.c_char_p]),
+    "lis_output": (LIS_INT, [PM, PV, PV, LIS_INT, C.c_char_p]),
+    "lis_output_matrix": (LIS_INT, [PM, LIS_INT, C.c_char_p]),
     "lis_solver_output_rhistory": (LIS_INT, [PS, C.c_char_p]),
     "lis_solver_get_solvername": (LIS_INT, [LIS_INT, C.c_char_p]),
     "lis_solver_get_preconname": (LIS_INT, [LIS_INT, C.c_char_p]),

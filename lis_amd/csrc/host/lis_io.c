@@ -1,0 +1,521 @@
+/*
+ * lis_io.c -- the data formats either side of the hot path: Matrix Market (+ Lis's extensions) in,
+ * Matrix Market / plain / Lis-ASCII out.
+ *
+ * Behaviour follows the reference reader src/system/lis_input.c:67-171 (format sniffing),
+ * lis_input_mm.c:62-146 (dispatch, conversion to the requested storage type), :326-411 (banner),
+ * :413-458 (size line "nr nc nnz [isb isx [isbin]]"), :699-1069 (coordinate -> CSR) and :148-324
+ * (the optional right-hand side / initial guess appended to the matrix file).  What fixes the BITS
+ * of every later SpMV is the in-row entry order the reader produces:
+ *     row r receives its entries in FILE order; for `symmetric` files the mirrored entry (c,r) of
+ *     an off-diagonal line "r c v" is appended to row c BEFORE (r,c) is appended to row r.
+ * The implementation is not the reference's two fgets/sscanf passes: the file is slurped once, every
+ * line is parsed once (hand-rolled integer scan + strtod, which rounds like sscanf("%lg")) into
+ * triplets, and a counting sort places them.  Every rank reads the whole file and keeps rows
+ * [is,ie) with global column numbers, as the reference's MPI build does.
+ */
+#include <stdio.h>
+#include <ctype.h>
+#include <errno.h>
+#include "lis_internal.h"
+
+#define MM_BANNER "%%MatrixMarket"
+
+typedef struct { char *buf; size_t len, pos; } slurp_t;
+
+static LIS_INT slurp_file(const char *path, slurp_t *s)
+{
+	memset(s, 0, sizeof(*s));
+	FILE *f = fopen(path, "rb");
+	if (!f) return LISI_ERR(LIS_ERR_FILE_IO, "cannot open file %s\n", path);
+	size_t cap = 1 << 16, len = 0;
+	if (fseek(f, 0, SEEK_END) == 0) { long sz = ftell(f); if (sz > 0) cap = (size_t)sz + 1; rewind(f); }
+	char *buf = (char *)malloc(cap + 1);
+	if (!buf) { fclose(f); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)cap); }
+	for (;;) {
+		if (len == cap) {
+			cap *= 2;
+			char *nb = (char *)realloc(buf, cap + 1);
+			if (!nb) { free(buf); fclose(f); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)cap); }
+			buf = nb;
+		}
+		size_t got = fread(buf + len, 1, cap - len, f);
+		if (got == 0) break;
+		len += got;
+	}
+	fclose(f);
+	buf[len] = '\0';
+	s->buf = buf; s->len = len; s->pos = 0;
+	return LIS_SUCCESS;
+}
+
+/* next text line [*b,*e) without its newline; the byte at *e is overwritten with NUL. 0 at end of file */
+static int next_line(slurp_t *s, char **b, char **e)
+{
+	if (s->pos >= s->len) return 0;
+	char *p = s->buf + s->pos;
+	char *nl = (char *)memchr(p, '\n', s->len - s->pos);
+	char *end = nl ? nl : s->buf + s->len;
+	s->pos = (size_t)(end - s->buf) + (nl ? 1 : 0);
+	*end = '\0';
+	*b = p; *e = end;
+	return 1;
+}
+
+static int scan_int(char **pp, long *out)
+{	/* "%d": blanks, optional sign, digits */
+	char *p = *pp;
+	while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f') p++;
+	int neg = 0;
+	if (*p == '+' || *p == '-') { neg = (*p == '-'); p++; }
+	if (*p < '0' || *p > '9') return 0;
+	long v = 0;
+	while (*p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); p++; }
+	*out = neg ? -v : v;
+	*pp = p;
+	return 1;
+}
+
+static int scan_double(char **pp, double *out)
+{	/* "%lg" */
+	char *end;
+	double v = strtod(*pp, &end);
+	if (end == *pp) return 0;
+	*out = v; *pp = end;
+	return 1;
+}
+
+static void lower(char *p) { for (; *p; p++) *p = (char)tolower((unsigned char)*p); }
+
+/* ------------------------------------------------------------------ Matrix Market banner + size line */
+typedef struct { int coordinate, symmetric; LIS_INT nr, nc, nnz, isb, isx, isbin; } mm_head;
+
+static LIS_INT mm_banner(slurp_t *s, const char *object, mm_head *h)
+{	/* ref lis_input_mm.c:326-411 */
+	char *b, *e;
+	if (!next_line(s, &b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+	char banner[64] = "", mtx[64] = "", fmt[64] = "", dtype[64] = "", dstruct[64] = "";
+	sscanf(b, "%63s %63s %63s %63s %63s", banner, mtx, fmt, dtype, dstruct);
+	lower(mtx); lower(fmt); lower(dtype); lower(dstruct);
+	if (strncmp(banner, MM_BANNER, strlen(MM_BANNER)) != 0 || strncmp(mtx, object, strlen(object)) != 0)
+		return LISI_ERR(LIS_ERR_FILE_IO, "Not Matrix Market banner\n");
+	if (strncmp(fmt, "coordinate", 10) == 0) h->coordinate = 1;
+	else if (strncmp(fmt, "array", 5) == 0) h->coordinate = 0;
+	else return LISI_ERR(LIS_ERR_FILE_IO, "Not Matrix Market format\n");
+	if (strncmp(dtype, "real", 4) != 0) return LISI_ERR(LIS_ERR_FILE_IO, "Not real\n");
+	if (strncmp(dstruct, "general", 7) == 0) h->symmetric = 0;
+	else if (strncmp(dstruct, "symmetric", 9) == 0) h->symmetric = 1;
+	else return LISI_ERR(LIS_ERR_FILE_IO, "Not general or symmetric\n");
+	return LIS_SUCCESS;
+}
+
+static LIS_INT mm_skip_comments(slurp_t *s, char **b)
+{
+	char *e;
+	do {
+		if (!next_line(s, b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+	} while ((*b)[0] == '%');
+	return LIS_SUCCESS;
+}
+
+static LIS_INT mm_size(slurp_t *s, mm_head *h)
+{	/* ref lis_input_mm.c:413-458 */
+	char *b;
+	LISCHK(mm_skip_comments(s, &b));
+	int nr = 0, nc = 0, nnz = 0, isb = 0, isx = 0, isbin = 0;
+	int got = sscanf(b, "%d %d %d %d %d %d", &nr, &nc, &nnz, &isb, &isx, &isbin);
+	if (got < 2) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+	if (got == 2) { nnz = nr * nc; isb = isx = isbin = 0; }
+	else if (got == 3) { isb = isx = isbin = 0; }
+	else if (got == 4) { isx = isbin = 0; }
+	else if (got == 5) { isbin = 0; }
+	if (nr != nc) return LISI_ERR(LIS_ERR_FILE_IO, "matrix is not square\n");
+	h->nr = nr; h->nc = nc; h->nnz = nnz; h->isb = isb; h->isx = isx; h->isbin = isbin;
+	return LIS_SUCCESS;
+}
+
+/* binary extension records (ref include/lis_io.h:104-115), host byte order unless isbin says otherwise */
+typedef struct { int i; int j; double value; } mm_matrec;
+typedef struct { int i; double value; } mm_vecrec;
+static void bswap4(void *p) { unsigned char *c = (unsigned char *)p, t; t = c[0]; c[0] = c[3]; c[3] = t; t = c[1]; c[1] = c[2]; c[2] = t; }
+static void bswap8(void *p) { unsigned char *c = (unsigned char *)p, t; for (int i = 0; i < 4; i++) { t = c[i]; c[i] = c[7 - i]; c[7 - i] = t; } }
+static int host_little(void) { int one = 1; return *(char *)&one; }
+
+/* in-file vector section: gn records "idx value" (ref lis_input_mm.c:148-324) */
+static LIS_INT mm_read_vec(slurp_t *s, const mm_head *h, LIS_MATRIX A, LIS_VECTOR v)
+{
+	const int swap = h->isbin && (host_little() != (h->isbin - 1));
+	LISCHK(lis_vector_set_size(v, A->n, 0));
+	for (LIS_INT i = 0; i < A->gn; i++) {
+		long idx; double val;
+		if (h->isbin) {
+			if (s->pos + sizeof(mm_vecrec) > s->len) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+			mm_vecrec r; memcpy(&r, s->buf + s->pos, sizeof(r)); s->pos += sizeof(r);
+			if (swap) { bswap4(&r.i); bswap8(&r.value); }
+			idx = r.i; val = r.value;
+		} else {
+			char *b, *e;
+			if (!next_line(s, &b, &e) || !scan_int(&b, &idx) || !scan_double(&b, &val))
+				return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+		}
+		idx--;
+		if (idx >= A->is && idx < A->ie) v->value[idx - A->is] = val;
+	}
+	lis_amd_vector_host_modified(v);
+	return LIS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ coordinate file -> CSR rows [is,ie) */
+static LIS_INT mm_read_csr(slurp_t *s, const mm_head *h, LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x)
+{
+	LISCHK(lis_matrix_set_size(A, 0, h->nr));
+	if (A->my_rank == 0) { printf("matrix size = %d x %d (%d nonzero entries)\n\n", h->nr, h->nc, h->nnz); fflush(stdout); }
+	const LIS_INT n = A->n, is = A->is, ie = A->ie, nnz = h->nnz;
+	const int swap = h->isbin && (host_little() != (h->isbin - 1));
+	LIS_INT err = LIS_SUCCESS;
+	int *ri = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+	int *ci = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+	double *va = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+	LIS_INT *ptr = (LIS_INT *)calloc((size_t)n + 1, sizeof(LIS_INT));
+	LIS_INT *fill = NULL, *index = NULL;
+	LIS_SCALAR *value = NULL;
+	if (!ri || !ci || !va || !ptr) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", nnz); goto fail; }
+
+	for (LIS_INT k = 0; k < nnz; k++) {
+		long r, c; double v;
+		if (h->isbin) {
+			if (s->pos + sizeof(mm_matrec) > s->len) { err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n"); goto fail; }
+			mm_matrec rec; memcpy(&rec, s->buf + s->pos, sizeof(rec)); s->pos += sizeof(rec);
+			if (swap) { bswap4(&rec.i); bswap4(&rec.j); bswap8(&rec.value); }
+			r = rec.i; c = rec.j; v = rec.value;
+		} else {
+			char *lb, *le;
+			if (!next_line(s, &lb, &le) || !scan_int(&lb, &r) || !scan_int(&lb, &c) || !scan_double(&lb, &v)) {
+				err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n"); goto fail;
+			}
+		}
+		r--; c--;
+		ri[k] = (int)r; ci[k] = (int)c; va[k] = v;
+		if (h->symmetric && r != c && c >= is && c < ie) ptr[c - is + 1]++;
+		if (r >= is && r < ie) ptr[r - is + 1]++;
+	}
+	for (LIS_INT i = 0; i < n; i++) ptr[i + 1] += ptr[i];
+	const LIS_INT lnnz = ptr[n];
+	index = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(lnnz > 0 ? lnnz : 1));
+	value = (LIS_SCALAR *)malloc(sizeof(LIS_SCALAR) * (size_t)(lnnz > 0 ? lnnz : 1));
+	fill = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(n > 0 ? n : 1));
+	if (!index || !value || !fill) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", lnnz); goto fail; }
+	memcpy(fill, ptr, sizeof(LIS_INT) * (size_t)n);
+	for (LIS_INT k = 0; k < nnz; k++) {
+		const int r = ri[k], c = ci[k];
+		if (h->symmetric && r != c && c >= is && c < ie) { const LIS_INT at = fill[c - is]++; index[at] = r; value[at] = va[k]; }
+		if (r >= is && r < ie) { const LIS_INT at = fill[r - is]++; index[at] = c; value[at] = va[k]; }
+	}
+	free(ri); free(ci); free(va); free(fill);
+	ri = ci = NULL; va = NULL; fill = NULL;
+
+	err = lis_matrix_set_csr(lnnz, ptr, index, value, A);
+	if (err) goto fail;
+	ptr = NULL; index = NULL; value = NULL;          /* adopted */
+	LISCHK(lis_matrix_assemble(A));
+	if (b != NULL && x != NULL) {
+		if (h->isb) LISCHK(mm_read_vec(s, h, A, b));
+		if (h->isx) LISCHK(mm_read_vec(s, h, A, x));
+	}
+	return LIS_SUCCESS;
+fail:
+	free(ri); free(ci); free(va); free(fill); free(ptr); free(index); free(value);
+	return err;
+}
+
+/* `array` files: nr*nc values, one per line, column-major (ref lis_input_mm.c:462-697), held by the reference as
+ * LIS_MATRIX_DNS and converted to the requested type through CSR keeping value != 0, columns ascending
+ * (lis_matrix_dns.c:823-915).  DNS itself is not a served format, so the CSR is built directly. */
+static LIS_INT mm_read_dense(slurp_t *s, const mm_head *h, LIS_MATRIX A)
+{
+	if (h->isbin) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "binary Matrix Market array input is not implemented\n");
+	LISCHK(lis_matrix_set_size(A, 0, h->nr));
+	if (A->my_rank == 0) { printf("matrix size = %d x %d (%d nonzero entries)\n\n", h->nr, h->nc, h->nr * h->nc); fflush(stdout); }
+	const LIS_INT n = A->n, gn = h->nr, is = A->is;
+	LIS_INT err = LIS_SUCCESS;
+	double *dense = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * (size_t)gn);
+	LIS_INT *ptr = (LIS_INT *)calloc((size_t)n + 1, sizeof(LIS_INT)), *index = NULL;
+	LIS_SCALAR *value = NULL;
+	if (!dense || !ptr) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", gn); goto fail; }
+	for (LIS_INT j = 0; j < gn; j++) {
+		for (LIS_INT i = 0; i < gn; i++) {
+			char *b, *e; double v;
+			if (!next_line(s, &b, &e) || !scan_double(&b, &v)) { err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n"); goto fail; }
+			if (i >= is && i < is + n) { dense[(size_t)(i - is) * gn + j] = v; if (v != 0.0) ptr[i - is + 1]++; }
+		}
+	}
+	for (LIS_INT i = 0; i < n; i++) ptr[i + 1] += ptr[i];
+	index = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(ptr[n] > 0 ? ptr[n] : 1));
+	value = (LIS_SCALAR *)malloc(sizeof(LIS_SCALAR) * (size_t)(ptr[n] > 0 ? ptr[n] : 1));
+	if (!index || !value) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", ptr[n]); goto fail; }
+	for (LIS_INT i = 0, k = 0; i < n; i++)
+		for (LIS_INT j = 0; j < gn; j++)
+			if (dense[(size_t)i * gn + j] != 0.0) { index[k] = j; value[k] = dense[(size_t)i * gn + j]; k++; }
+	free(dense); dense = NULL;
+	err = lis_matrix_set_csr(ptr[n], ptr, index, value, A);
+	if (err) goto fail;
+	return lis_matrix_assemble(A);
+fail:
+	free(dense); free(ptr); free(index); free(value);
+	return err;
+}
+
+/* storage type requested with lis_matrix_set_type before the read: convert in place (ref lis_input_mm.c:82-107) */
+LIS_INT lisi_matrix_retype(LIS_MATRIX A, LIS_INT want)
+{
+	if (want == A->matrix_type) return LIS_SUCCESS;
+	LIS_MATRIX B;
+	LISCHK(lis_matrix_duplicate(A, &B));
+	LISCHK(lis_matrix_set_type(B, want));
+	LIS_INT err = lis_matrix_convert(A, B);
+	if (err) { lis_matrix_destroy(B); return err; }
+	lisi_matrix_storage_destroy(A);
+	lisi_matrix_copy_header(B, A);
+	lisi_unregister(B);
+	free(B);
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_input(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, char *filename)
+{
+	if (!lisi_is_registered(A)) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is undefined\n");
+	if (A->status != LIS_MATRIX_DECIDING_SIZE && A->status != LIS_MATRIX_NULL)
+		return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is already assembled\n");
+	if (b != NULL && x != NULL) {
+		if (!lisi_is_registered(b) || !lis_vector_is_null(b)) return LISI_ERR(LIS_ERR_ILL_ARG, "vector b is not null\n");
+		if (!lisi_is_registered(x) || !lis_vector_is_null(x)) return LISI_ERR(LIS_ERR_ILL_ARG, "vector x is not null\n");
+	}
+	if (filename == NULL) return LISI_ERR(LIS_ERR_ILL_ARG, "filname is NULL\n");
+	slurp_t s;
+	LISCHK(slurp_file(filename, &s));
+	LIS_INT err;
+	if (s.len == 0) { free(s.buf); return LIS_ERR_FILE_IO; }
+	if (strncmp(s.buf, MM_BANNER, strlen(MM_BANNER)) != 0) {
+		/* anything else is taken for Harwell-Boeing by the reference (lis_input.c:122-125, lis_input_hb.c) */
+		free(s.buf);
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "Harwell-Boeing input is not served by liblis_amd\n");
+	}
+	const LIS_INT want = A->matrix_type;
+	mm_head h;
+	memset(&h, 0, sizeof(h));
+	err = mm_banner(&s, "matrix", &h);
+	if (!err) err = mm_size(&s, &h);
+	if (!err && !h.coordinate && want == LIS_MATRIX_DNS)
+		err = LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "dense storage (LIS_MATRIX_DNS) is not served by liblis_amd\n");
+	if (!err) err = h.coordinate ? mm_read_csr(&s, &h, A, b, x) : mm_read_dense(&s, &h, A);
+	free(s.buf);
+	if (err) return err;
+	return lisi_matrix_retype(A, want);
+}
+
+LIS_INT lis_input_matrix(LIS_MATRIX A, char *filename) { return lis_input(A, NULL, NULL, filename); }
+
+/* ------------------------------------------------------------------ vectors in */
+static LIS_INT vector_mm(slurp_t *s, LIS_VECTOR v)
+{	/* ref lis_input.c:247-389 */
+	mm_head h;
+	LISCHK(mm_banner(s, "vector", &h));
+	if (h.symmetric) return LISI_ERR(LIS_ERR_FILE_IO, "Not general\n");
+	char *b;
+	LISCHK(mm_skip_comments(s, &b));
+	int n;
+	if (sscanf(b, "%d", &n) != 1) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+	LISCHK(lis_vector_set_size(v, 0, n));
+	for (LIS_INT i = 0; i < n; i++) {
+		char *e; long idx; double val;
+		if (!next_line(s, &b, &e) || !scan_int(&b, &idx) || !scan_double(&b, &val))
+			return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+		idx--;
+		if (idx >= v->is && idx < v->ie) v->value[idx - v->is] = val;
+	}
+	return LIS_SUCCESS;
+}
+
+static LIS_INT vector_plain(slurp_t *s, LIS_VECTOR v)
+{	/* ref lis_input.c:391-438: count the leading numbers of the file, then one number per line */
+	LIS_INT n = 0;
+	char *p = s->buf;
+	for (;;) { double t; if (!scan_double(&p, &t)) break; n++; }
+	LISCHK(lis_vector_set_size(v, 0, n));
+	for (LIS_INT i = 0; i < n; i++) {
+		char *b, *e; double val;
+		if (!next_line(s, &b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+		if (i >= v->is && i < v->ie) {
+			if (!scan_double(&b, &val)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+			v->value[i - v->is] = val;
+		}
+	}
+	return LIS_SUCCESS;
+}
+
+static LIS_INT vector_lis_ascii(slurp_t *s, LIS_VECTOR v)
+{	/* ref lis_input.c:440-588: "#LIS A vec" / nprocs / "# pe n" / values */
+	char *b, *e;
+	if (!next_line(s, &b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+	char banner[16] = "", mode[16] = "", kind[16] = "";
+	if (e - b > 10) b[10] = '\0';
+	sscanf(b, "%15s %15s %15s", banner, mode, kind);
+	if (strncmp(banner, "#LIS", 4) != 0) return LISI_ERR(LIS_ERR_FILE_IO, "not lis file format\n");
+	if (mode[0] == 'B' || mode[0] == 'L') return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "binary Lis vector files are not implemented\n");
+	if (strncmp(kind, "vec", 3) != 0) return LISI_ERR(LIS_ERR_FILE_IO, "not lis file format\n");
+	int np_file;
+	if (!next_line(s, &b, &e) || sscanf(b, "%d", &np_file) != 1) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+	if (np_file != lisg.nprocs)
+		return LISI_ERR(LIS_ERR_FILE_IO, "The number of PE=(%D) is different (in file PE=%D)\n", (LIS_INT)lisg.nprocs, (LIS_INT)np_file);
+	int pe = -1, n = 0;
+	do {
+		if (!next_line(s, &b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+		if (b[0] == '#') { char c; if (sscanf(b, "%c %d %d", &c, &pe, &n) != 3) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n"); }
+	} while (pe != lisg.rank);
+	LISCHK(lis_vector_set_size(v, 0, n));
+	char *p = s->buf + s->pos;
+	for (LIS_INT i = 0; i < n; i++) {
+		double val;
+		if (!scan_double(&p, &val)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+		v->value[i] = val;
+	}
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_input_vector(LIS_VECTOR v, char *filename)
+{	/* ref lis_input.c:188-245 */
+	if (!lisi_is_registered(v)) return LISI_ERR(LIS_ERR_ILL_ARG, "vector v is undefined\n");
+	if (filename == NULL) return LISI_ERR(LIS_ERR_ILL_ARG, "filname is NULL\n");
+	slurp_t s;
+	LISCHK(slurp_file(filename, &s));
+	if (s.len == 0) { free(s.buf); return LIS_ERR_FILE_IO; }
+	LIS_INT err;
+	if (strncmp(s.buf, MM_BANNER, strlen(MM_BANNER)) == 0) err = vector_mm(&s, v);
+	else if (strncmp(s.buf, "#LIS", 4) == 0) err = vector_lis_ascii(&s, v);
+	else err = vector_plain(&s, v);
+	free(s.buf);
+	if (!err) lis_amd_vector_host_modified(v);
+	return err;
+}
+
+/* ------------------------------------------------------------------ out */
+/* ranks take turns in rank order; the token exchange keeps them in step (ref: the pe loops + MPI_Allreduce of
+ * lis_output.c:196-246, lis_output_mm.c:85-222) */
+static void turn(int nprocs)
+{
+	if (nprocs > 1) {
+		double tok = 0.0, *all = (double *)malloc(sizeof(double) * (size_t)nprocs);
+		lisc_allgather_host(&tok, all, sizeof(double));
+		free(all);
+	}
+}
+
+static void put_vec_mm(FILE *f, LIS_VECTOR v, int binary)
+{	/* ref lis_output_mm.c:225-324 ("%d %28.20e"; integer vectors "%d %28d") */
+	for (LIS_INT i = 0; i < v->n; i++) {
+		if (binary) { mm_vecrec r; memset(&r, 0, sizeof(r)); r.i = v->is + i + 1; r.value = v->value[i]; fwrite(&r, sizeof(r), 1, f); }
+		else if (v->intvalue) fprintf(f, "%d %28d\n", v->is + i + 1, (int)v->value[i]);
+		else fprintf(f, "%d %28.20e\n", v->is + i + 1, (double)v->value[i]);
+	}
+}
+
+/* CSR (or CSC: same arrays, indices swapped) + optional b, x into one extended Matrix Market file */
+static LIS_INT output_mm_to(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_INT format, const char *path)
+{	/* ref lis_output_mm.c:327-741 */
+	const int binary = (format == LIS_FMT_MMB);
+	const int isb = (b && !lis_vector_is_null(b)), isx = (x && !lis_vector_is_null(x));
+	if (isb) LISCHK(lisd_vec_to_host(b));
+	if (isx) LISCHK(lisd_vec_to_host(x));
+	double nnz_local = (double)A->nnz, nnz_total = nnz_local;
+	if (A->nprocs > 1) {
+		double *all = (double *)malloc(sizeof(double) * (size_t)A->nprocs);
+		LISCHK(lisc_allgather_host(&nnz_local, all, sizeof(double)));
+		nnz_total = 0.0;
+		for (int p = 0; p < A->nprocs; p++) nnz_total += all[p];
+		free(all);
+	}
+	LIS_INT err = LIS_SUCCESS;
+	for (int phase = 0; phase < 3; phase++) {          /* matrix entries, then b, then x: each in rank order */
+		if (phase == 1 && !isb) continue;
+		if (phase == 2 && !isx) continue;
+		for (int pe = 0; pe < A->nprocs; pe++) {
+			turn(A->nprocs);
+			if (pe != A->my_rank) continue;
+			FILE *f = fopen(path, (phase == 0 && pe == 0) ? (binary ? "wb" : "w") : (binary ? "ab" : "a"));
+			if (!f) { err = LISI_ERR(LIS_ERR_FILE_IO, "cannot open file %s\n", path); continue; }
+			if (phase == 0 && pe == 0) {
+				fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n");
+				if (binary) fprintf(f, "%d %d %d %d %d %d\n", A->gn, A->gn, (int)nnz_total, isb, isx, host_little() + 1);
+				else if (!isb && !isx) fprintf(f, "%d %d %d\n", A->gn, A->gn, (int)nnz_total);
+				else fprintf(f, "%d %d %d %d %d\n", A->gn, A->gn, (int)nnz_total, isb, isx);
+			}
+			if (phase == 0) {
+				const int csc = (A->matrix_type == LIS_MATRIX_CSC);
+				for (LIS_INT i = 0; i < A->n; i++) {
+					for (LIS_INT j = A->ptr[i]; j < A->ptr[i + 1]; j++) {
+						LIS_INT jj = A->index[j];
+						if (A->l2g_map && jj >= A->n) jj = A->l2g_map[jj - A->n]; else jj += A->is;
+						const int r = csc ? jj + 1 : A->is + i + 1, c = csc ? A->is + i + 1 : jj + 1;
+						if (binary) { mm_matrec rec; rec.i = r; rec.j = c; rec.value = A->value[j]; fwrite(&rec, sizeof(rec), 1, f); }
+						else fprintf(f, "%d %d %28.20e\n", r, c, (double)A->value[j]);
+					}
+				}
+			} else put_vec_mm(f, phase == 1 ? b : x, binary);
+			fclose(f);
+		}
+	}
+	return err;
+}
+
+LIS_INT lis_output(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_INT format, char *path)
+{	/* ref lis_output.c:63-97 */
+	LISCHK(lisi_matrix_check(A, LISI_CHECK_ASSEMBLED));
+	if (format != LIS_FMT_MM && format != LIS_FMT_MMB) return LIS_SUCCESS;
+	if (MDEV(A)->device_only) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A lives in HBM only (lis_amd_matrix_set_csr_device): nothing to write\n");
+	if (A->matrix_type == LIS_MATRIX_CSR) return output_mm_to(A, b, x, format, path);
+	LIS_MATRIX B;
+	LISCHK(lis_matrix_duplicate(A, &B));
+	LISCHK(lis_matrix_set_type(B, LIS_MATRIX_CSR));
+	LIS_INT err = lis_matrix_convert(A, B);
+	if (!err) err = output_mm_to(B, b, x, format, path);
+	lis_matrix_destroy(B);
+	return err;
+}
+
+LIS_INT lis_output_matrix(LIS_MATRIX A, LIS_INT format, char *path) { return lis_output(A, NULL, NULL, format, path); }
+
+LIS_INT lis_output_vector(LIS_VECTOR v, LIS_INT format, char *filename)
+{	/* ref lis_output.c:146-583: PLAIN one "%28.20e" per line; MM "vector coordinate real general" + gn + "i v";
+	 * LIS "#LIS A vec" / nprocs / "# pe n" / three "%28.20e " per line */
+	if (!lisi_is_registered(v)) return LISI_ERR(LIS_ERR_ILL_ARG, "vector v is undefined\n");
+	if (lis_vector_is_null(v)) return LISI_ERR(LIS_ERR_ILL_ARG, "vector v is null\n");
+	if (format != LIS_FMT_PLAIN && format != LIS_FMT_MM && format != LIS_FMT_LIS) return LISI_ERR(LIS_ERR_ILL_ARG, "ill format option\n");
+	LISCHK(lisd_vec_to_host(v));
+	LIS_INT err = LIS_SUCCESS;
+	for (LIS_INT pe = 0; pe < v->nprocs; pe++) {
+		turn(v->nprocs);
+		if (pe != v->my_rank) continue;
+		FILE *f = fopen(filename, pe == 0 ? "w" : "a");
+		if (!f) { err = LISI_ERR(LIS_ERR_FILE_IO, "cannot open file %s\n", filename); continue; }
+		if (pe == 0 && format == LIS_FMT_MM)
+			fprintf(f, "%%%%MatrixMarket vector coordinate %s general\n%d\n", v->intvalue ? "integer" : "real", v->gn);
+		if (pe == 0 && format == LIS_FMT_LIS) fprintf(f, "#LIS A vec\n%d\n", v->nprocs);
+		if (format == LIS_FMT_MM) put_vec_mm(f, v, 0);
+		else if (format == LIS_FMT_PLAIN) {
+			for (LIS_INT i = 0; i < v->n; i++) {
+				if (v->intvalue) fprintf(f, "%28d\n", (int)v->value[i]);
+				else fprintf(f, "%28.20e\n", (double)v->value[i]);
+			}
+		} else {
+			fprintf(f, "# %d %d\n", (int)pe, v->n);
+			for (LIS_INT i = 0; i < v->n; i++) {
+				if (v->intvalue) fprintf(f, "%28d ", (int)v->value[i]);
+				else fprintf(f, "%28.20e ", (double)v->value[i]);
+				if ((i + 1) % 3 == 0) fprintf(f, "\n");
+			}
+			if (v->n % 3 != 0) fprintf(f, "\n");
+		}
+		fclose(f);
+	}
+	return err;
+}

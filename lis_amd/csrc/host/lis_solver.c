@@ -127,26 +127,6 @@ LIS_INT lis_solver_output_rhistory(LIS_SOLVER s, char *filename)
 	return LIS_SUCCESS;
 }
 
-LIS_INT lis_output_vector(LIS_VECTOR v, LIS_INT format, char *filename)
-{	/* ref src/system/lis_output.c:146-440: PLAIN = one %28.20e per line; MM = "vector coordinate real general" */
-	if (!lisi_is_registered(v)) return LISI_ERR(LIS_ERR_ILL_ARG, "vector v is undefined\n");
-	if (format != LIS_FMT_PLAIN && format != LIS_FMT_MM) return LISI_ERR(LIS_ERR_ILL_ARG, "ill format option\n");
-	LISCHK(lisd_vec_to_host(v));
-	for (LIS_INT pe = 0; pe < v->nprocs; pe++) {              /* ranks append their slices in order */
-		if (v->nprocs > 1) { double tok = 0.0, *all = (double *)malloc(sizeof(double) * (size_t)v->nprocs); lisc_allgather_host(&tok, all, sizeof(double)); free(all); }
-		if (pe != v->my_rank) continue;
-		FILE *f = fopen(filename, pe == 0 ? "w" : "a");
-		if (!f) return LISI_ERR(LIS_ERR_FILE_IO, "cannot open file %s\n", filename);
-		if (pe == 0 && format == LIS_FMT_MM) fprintf(f, "%%%%MatrixMarket vector coordinate real general\n%d\n", v->gn);
-		for (LIS_INT i = 0; i < v->n; i++) {
-			if (format == LIS_FMT_MM) fprintf(f, "%d %28.20e\n", i + v->is + 1, v->value[i]);
-			else fprintf(f, "%28.20e\n", v->value[i]);
-		}
-		fclose(f);
-	}
-	return LIS_SUCCESS;
-}
-
 LIS_INT lis_solver_get_solvername(LIS_INT solver, char *name)
 {
 	if (solver < 1 || solver > LIS_SOLVER_LEN) return LIS_FAILS;

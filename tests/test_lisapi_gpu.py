@@ -264,3 +264,43 @@ def test_device_born_poisson_and_full_size_cg(lib):
         finally:
             lib.dll.lis_amd_set_residency(0)
         lib.lis_matrix_destroy(A)
+
+
+# ------------------------------------------------------------------ Matrix Market inputs (north_star)
+GM = np.load(os.path.join(os.path.dirname(__file__), "golden", "mm_golden.npz"))
+MM_DIR = os.path.join(os.path.dirname(__file__), "golden", "mm")
+MM_SOLVES = sorted({tuple(k.split("/")[1:3]) for k in GM.files if k.startswith("solve/")})
+
+
+def _read_mm(lib, name):
+    A, b, x = capi.PM(), capi.PV(), capi.PV()
+    assert lib.lis_matrix_create(0, C.byref(A)) == 0
+    assert lib.lis_vector_create(0, C.byref(b)) == 0 and lib.lis_vector_create(0, C.byref(x)) == 0
+    assert lib.lis_input(A, b, x, os.path.join(MM_DIR, name).encode()) == 0
+    return A, b, x
+
+
+@pytest.mark.parametrize("name", sorted(k[:-2] for k in GM.files if k.endswith(".mtx/y")))
+def test_matrix_market_spmv_bit_exact(lib, name):
+    """lis_input -> lis_matvec on the GPU gives the bits of the reference reading the same file."""
+    A, b, x = _read_mm(lib, name)
+    n = A.contents.n
+    x0 = np.cos(np.arange(n) * 0.37) + 1.5
+    assert np.array_equal(lisdrv.matvec(lib, A, x0), GM[f"{name}/y"])
+
+
+@pytest.mark.parametrize("name,opts", MM_SOLVES)
+def test_matrix_market_solves_match_reference(lib, name, opts):
+    A, b, x = _read_mm(lib, name)
+    n = A.contents.n
+    key = f"solve/{name}/{opts}"
+    bb = GM[key + "/b"]
+    x0 = None if lib.lis_vector_is_null(x) else lisdrv.get_vector(lib, x, n)
+    out = lisdrv.solve(lib, A, bb, opts + " -tol 1e-12 -maxiter 1000 -print mem" + ("" if x0 is None else " -initx_zeros false"), x0=x0)
+    it_ref, st_ref = (int(v) for v in GM[key + "/iter_status"])
+    assert out["err"] == 0 and out["status"] == st_ref == 0
+    assert out["iter"] == it_ref, (out["iter"], it_ref)          # bit-exact iteration counts on these inputs, all three solvers
+    assert out["resid"] <= 1e-12
+    assert np.allclose(out["x"], GM[key + "/x"], rtol=0, atol=1e-10)
+    k = min(it_ref, 6)
+    assert np.allclose(out["rhistory"][1:k + 1], GM[key + "/rhistory"][1:k + 1], rtol=1e-8, atol=0)

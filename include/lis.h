@@ -429,6 +429,14 @@ void lis_matvec_ell(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);   /* src/matv
 void lis_matvec_dia(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);   /* src/matvec/lis_matvec_dia.c:50 */
 void lis_matvec_jad(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);   /* src/matvec/lis_matvec_jad.c:51 */
 void lis_matvec_bsr(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);   /* src/matvec/lis_matvec_bsr.c:57 */
+/* y = A^T x (A^H; real build).  The reference scatters; here A^T is kept as a second CSR whose rows list the
+ * contributions in the reference's scatter order, so the result has the reference's bits (1 thread). */
+void lis_matvech_csr(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);  /* src/matvec/lis_matvec_csr.c:113 */
+void lis_matvech_csc(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);  /* src/matvec/lis_matvec_csc.c:148 */
+void lis_matvech_ell(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);  /* src/matvec/lis_matvec_ell.c:133 */
+void lis_matvech_dia(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);  /* src/matvec/lis_matvec_dia.c:177 */
+void lis_matvech_jad(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);  /* src/matvec/lis_matvec_jad.c:484 */
+void lis_matvech_bsr(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);  /* src/matvec/lis_matvec_bsr.c:860 */
 
 /* ---- vectors, ref:824-859 (src/vector/lis_vector.c, lis_vector_ops.c, lis_vector_opv.c) ---------- */
 LIS_INT lis_vector_create(LIS_Comm comm, LIS_VECTOR *vec);
@@ -500,6 +508,7 @@ LIS_INT lis_matrix_set_dia(LIS_INT nnd, LIS_INT *index, LIS_SCALAR *value, LIS_M
 
 /* ---- matrix-vector product, ref:920 (src/matvec/lis_matvec.c:55) ------------------------------- */
 LIS_INT lis_matvec(LIS_MATRIX A, LIS_VECTOR x, LIS_VECTOR y);
+LIS_INT lis_matvech(LIS_MATRIX A, LIS_VECTOR x, LIS_VECTOR y);        /* ref:921, src/matvec/lis_matvec.c:191 (BiCG's A^H p~) */
 
 /* ---- linear solvers, ref:961-984 (src/solver/lis_solver.c, _cg.c, _bicgstab.c, _gmres.c) ---------- */
 LIS_INT lis_solver_create(LIS_SOLVER *solver);

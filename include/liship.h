@@ -145,6 +145,8 @@ int  liship_csr_diagonal_f64(int n, const int *ptr, const int *index, const doub
                              double *d, void *stream);
 /* halo pack: ws[i] = x[export_index[i]]  (lis_send_recv, src/matrix/lis_matrix_mpi.c:904-916) */
 int  liship_gather_f64(int count, const int *export_index, const double *x, double *ws, void *stream);
+/* reverse halo: y[export_index[i]] += wr[i], indices unique within one call  (lis_reduce, lis_matrix_mpi.c:988-996) */
+int  liship_scatter_add_f64(int count, const int *export_index, const double *wr, double *y, void *stream);
 
 /* ------------------------------------------------------------------ synthetic inputs
  * Rows [is,ie) of the 3-D 7-pt Poisson matrix on an l x m x n grid, generated directly in HBM with the

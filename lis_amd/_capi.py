@@ -161,6 +161,7 @@ _PROTOS = {
     "lis_matrix_set_dia": (LIS_INT, [LIS_INT, P_INT, P_DBL, PM]),
     # matvec (lis.h:920)
     "lis_matvec": (LIS_INT, [PM, PV, PV]),
+    "lis_matvech": (LIS_INT, [PM, PV, PV]),
     # solvers (lis.h:961-984)
     "lis_solver_create": (LIS_INT, [C.POINTER(PS)]),
     "lis_solver_destroy": (LIS_INT, [PS]),

@@ -325,6 +325,40 @@ LIS_INT lisc_halo_device(LIS_MATRIX A, double *dx)
 	return LISI_ERR(LIS_ERR_ILL_ARG, "halo exchange without a communicator\n");
 }
 
+/* the reverse exchange of lis_reduce (ref lis_matrix_mpi.c:959-1000): every rank sends the ghost part of y to
+ * the ghosts' owners, which add what they receive to their own rows, neighbour by neighbour in table order
+ * (one scatter-add launch per neighbour: rows are unique within a neighbour's list, not across lists) */
+LIS_INT lisc_reduce_device(LIS_MATRIX A, double *dy)
+{
+	LIS_COMMTABLE t = A->commtable;
+	lisd_mat *d = MDEV(A);
+	if (!t || t->neibpetot == 0) return LIS_SUCCESS;
+	LISCHK(halo_tables_ready(A));
+	const LIS_INT n = A->n, pad = t->pad;
+	if (!d->wr) HIPCHK(liship_malloc((void **)&d->wr, sizeof(double) * (size_t)(t->exnnz > 0 ? t->exnnz : 1)));
+	if (lisg.comm_kind == 1) {
+		NCCLCHK(rccl.GroupStart());
+		for (LIS_INT i = 0; i < t->neibpetot; i++) {
+			const LIS_INT peer = t->neibpe[i];
+			const LIS_INT sc = t->import_ptr[i + 1] - t->import_ptr[i], rc = t->export_ptr[i + 1] - t->export_ptr[i];
+			if (sc > 0) NCCLCHK(rccl.Send(dy + n + pad + t->import_ptr[i], (size_t)sc, NCCL_DOUBLE, peer, lisg.nccl_comm, lisg.stream));
+			if (rc > 0) NCCLCHK(rccl.Recv(d->wr + t->export_ptr[i], (size_t)rc, NCCL_DOUBLE, peer, lisg.nccl_comm, lisg.stream));
+		}
+		NCCLCHK(rccl.GroupEnd());
+	} else if (lisg.comm_kind == 2) {           /* host round trip (tests / bring-up only) */
+		if (t->imnnz > 0) HIPCHK(liship_memcpy_d2h(t->wr, dy + n + pad, sizeof(double) * (size_t)t->imnnz, lisg.stream));
+		HIPCHK(liship_stream_synchronize(lisg.stream));
+		if (lisg.cb.neighbor_exchange(lisg.cb.ctx, t->neibpetot, t->neibpe, t->wr, t->import_ptr, t->ws, t->export_ptr))
+			return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "neighbor_exchange callback failed\n");
+		if (t->exnnz > 0) HIPCHK(liship_memcpy_h2d(d->wr, t->ws, sizeof(double) * (size_t)t->exnnz, lisg.stream));
+	} else return LISI_ERR(LIS_ERR_ILL_ARG, "reduce without a communicator\n");
+	for (LIS_INT i = 0; i < t->neibpetot; i++) {
+		const LIS_INT rc = t->export_ptr[i + 1] - t->export_ptr[i];
+		if (rc > 0) HIPCHK(liship_scatter_add_f64(rc, d->export_index + t->export_ptr[i], d->wr + t->export_ptr[i], dy, lisg.stream));
+	}
+	return LIS_SUCCESS;
+}
+
 /* host-array variant of the same exchange (the reference's lis_send_recv on x[]), used by CPU tests of the
  * tables: x has np entries, ghosts are filled in place */
 LIS_INT lis_amd_halo_exchange_host(LIS_MATRIX A, LIS_SCALAR x[])

@@ -251,6 +251,8 @@ void lisd_mat_free(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
 	if (d->plan) (void)liship_csr_plan_destroy(d->plan);
+	if (d->t_plan) (void)liship_csr_plan_destroy(d->t_plan);
+	(void)liship_free(d->t_ptr); (void)liship_free(d->t_index); (void)liship_free(d->t_value); (void)liship_free(d->wr);
 	(void)liship_free(d->ptr); (void)liship_free(d->index); (void)liship_free(d->row);
 	(void)liship_free(d->bptr); (void)liship_free(d->bindex); (void)liship_free(d->value);
 	(void)liship_free(d->export_index); (void)liship_free(d->ws);

@@ -56,6 +56,12 @@ typedef struct {
 	int *ptr, *index, *row, *bptr, *bindex;
 	double *value;
 	liship_csr_plan_t plan;
+	/* A^T as a CSR in the reference's scatter order (lis_matvech.c), built on the first lis_matvech */
+	int t_ready, t_rows, t_nnz;
+	int *t_ptr, *t_index;
+	double *t_value;
+	liship_csr_plan_t t_plan;
+	double *wr;                /* received ghost contributions (reverse halo) */
 	/* halo (multi-GPU) */
 	int halo_ready;
 	int *export_index;         /* device copy of commtable->export_index */
@@ -101,6 +107,8 @@ LIS_INT lisd_vec_to_host(LIS_VECTOR v);
 void    lisd_vec_free(LIS_VECTOR v);
 LIS_INT lisd_mat_ready(LIS_MATRIX A);
 void    lisd_mat_free(LIS_MATRIX A);
+LIS_INT lisd_mat_ready_t(LIS_MATRIX A);                       /* build / upload the transposed operator */
+LIS_INT lisd_spmv_t(LIS_MATRIX A, double *dx, double *dy);    /* y[0..np) = A^T x, ghost rows reduced to owners */
 LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy);      /* y = A x on device pointers (halo included) */
 LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq); /* sums -> reduce_out */
 LIS_INT lisd_fetch(int count, double *out);                   /* reduce_out[0..count) -> host, cross-rank fold */
@@ -116,6 +124,7 @@ LIS_INT lisc_ranges_create(LIS_Comm comm, LIS_INT *local_n, LIS_INT *global_n, L
 LIS_INT lisc_matrix_g2l(LIS_MATRIX A);                        /* global -> local columns, ghosts appended */
 LIS_INT lisc_commtable_create(LIS_MATRIX A);
 void    lisc_commtable_destroy(LIS_COMMTABLE t);
+LIS_INT lisc_reduce_device(LIS_MATRIX A, double *dy);         /* dy[export rows] += neighbours' dy[n..np) */
 LIS_INT lisc_halo_device(LIS_MATRIX A, double *dx);           /* fill dx[n..np) from the neighbours */
 LIS_INT lisc_fold(int count, double *host_inout);             /* sum over ranks, rank order */
 LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes);

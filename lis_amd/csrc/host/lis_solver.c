@@ -540,6 +540,59 @@ done:
 	return err;
 }
 
+/* BiCG, lis_solver_bicg.c:135-268 -- Lis's default solver (lis_solver.c:242).  The dual recurrence needs A^T:
+ * lisd_spmv_t (lis_matvech.c) serves it from a transposed CSR in the reference's scatter order.
+ *   p = M^-1 r + beta p ; p~ = M^-1 r~ + beta p~          one pass each (solve folded into the xpay)
+ *   q = A p ; <p~,q>                                       product + epilogue
+ *   q~ = A^T p~                                            product
+ *   x += alpha p ; r -= alpha q ; ||r||                    one pass
+ *   r~ -= alpha q~ ; rho' = <r~, M^-1 r>                   one pass (rho' is :187 of the next iteration) */
+static LIS_INT run_bicg(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter;
+	const int n = c->n;
+	TRY(work_alloc(c, 7));
+	double *r = c->work[0], *rtld = c->work[1], *q = c->work[2], *qtld = c->work[3], *p = c->work[4], *ptld = c->work[5];
+	double *z = c->work[6];                            /* M^-1 r, only kept for the Jacobi dot */
+	double alpha, beta, rho, rho_old = 1.0, d1, nrm2 = 0.0, sums[2];
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	TRY(d_copy(c, r, rtld));                           /* shadow residual = r0 (lis_solver.c:1862) */
+	if (c->dinv) { KTRY(liship_pmul_f64(n, r, c->dinv, z, lisg.stream)); TRY(lisd_dot(n, rtld, z, &rho)); }
+	else TRY(lisd_dot(n, rtld, r, &rho));
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		if (rho == 0.0) { s->retcode = LIS_BREAKDOWN; s->iter = iter; s->resid = nrm2; err = LIS_BREAKDOWN; goto done; }
+		beta = rho / rho_old;
+		if (c->dinv) {
+			KTRY(liship_pmul_xpay_f64(n, r, c->dinv, beta, p, lisg.stream));
+			KTRY(liship_pmul_xpay_f64(n, rtld, c->dinv, beta, ptld, lisg.stream));
+		} else {
+			KTRY(liship_xpay_f64(n, r, beta, p, lisg.stream));
+			KTRY(liship_xpay_f64(n, rtld, beta, ptld, lisg.stream));
+		}
+		TRY(lisd_spmv_dot_launch(c->A, p, q, ptld, 0));
+		TRY(lisd_fetch(1, &d1));
+		TRY(lisd_spmv_t(c->A, ptld, qtld));
+		if (d1 == 0.0) { s->retcode = LIS_BREAKDOWN; s->iter = iter; s->resid = nrm2; err = LIS_BREAKDOWN; goto done; }
+		alpha = rho / d1;
+		KTRY(liship_cg_update_f64(n, alpha, p, q, c->x, r, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+		TRY(lisd_fetch(1, sums));
+		TRY(resid_from_sumsq(c, r, sums[0], &nrm2));
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) { s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done; }
+		if (c->dinv) KTRY(liship_pmul_f64(n, r, c->dinv, z, lisg.stream));
+		KTRY(liship_axpy_sumsq_dot_f64(n, -alpha, qtld, rtld, c->dinv ? z : r, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+		TRY(lisd_fetch(2, sums));
+		rho_old = rho;
+		rho = sums[1];
+	}
+	s->retcode = LIS_MAXITER; s->iter = iter; s->resid = nrm2; err = LIS_MAXITER;
+done:
+	work_free(c);
+	return err;
+}
+
 static LIS_INT run_gmres(ctx_t *c)
 {
 	LIS_SOLVER s = c->s;
@@ -656,8 +709,8 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 
 	/* parameter checks, ref :482-537 */
 	if (nsolver < 1 || nsolver > LIS_SOLVER_LEN) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_SOLVER is %D (Set between 1 to %D)\n", nsolver, LIS_SOLVER_LEN);
-	if (nsolver != LIS_SOLVER_CG && nsolver != LIS_SOLVER_BICGSTAB && nsolver != LIS_SOLVER_GMRES)
-		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s is not served by liblis_amd (cg, bicgstab, gmres)\n", solver_names[nsolver]);
+	if (nsolver != LIS_SOLVER_CG && nsolver != LIS_SOLVER_BICG && nsolver != LIS_SOLVER_BICGSTAB && nsolver != LIS_SOLVER_GMRES)
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s is not served by liblis_amd (cg, bicg, bicgstab, gmres)\n", solver_names[nsolver]);
 	if (maxiter < 0) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_MAXITER(=%D) is less than 0\n", maxiter);
 	if (conv > 0 && nsolver == LIS_SOLVER_GMRES) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
 	if (solver->options[LIS_OPTIONS_PRECISION] != LIS_PRECISION_DOUBLE) return LISI_ERR(LIS_ERR_ILL_ARG, "Quad precision is not enabled\n");
@@ -727,6 +780,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 
 	switch (nsolver) {
 	case LIS_SOLVER_CG:       err = run_cg(&c); break;
+	case LIS_SOLVER_BICG:     err = run_bicg(&c); break;
 	case LIS_SOLVER_BICGSTAB: err = run_bicgstab(&c); break;
 	default:                  err = run_gmres(&c); break;
 	}

@@ -320,6 +320,14 @@ void gather_kernel(int count, const int *__restrict__ index, const double *__res
 }
 
 __global__ __launch_bounds__(BLOCK)
+void scatter_add_kernel(int count, const int *__restrict__ index, const double *__restrict__ src,
+                        double *__restrict__ y)
+{
+    const int stride = gridDim.x * BLOCK;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) y[index[i]] += src[i];   // indices unique
+}
+
+__global__ __launch_bounds__(BLOCK)
 void csr_diagonal_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ idx,
                          const double *__restrict__ val, double *__restrict__ d)
 {
@@ -409,6 +417,17 @@ extern "C" int liship_gather_f64(int count, const int *index, const double *x, d
     int grid = (count + BLOCK - 1) / BLOCK;
     if (grid > 4096) grid = 4096;
     gather_kernel<<<grid, BLOCK, 0, as_stream(s)>>>(count, index, x, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int liship_scatter_add_f64(int count, const int *index, const double *src, double *y, void *s)
+{
+    if (count < 0) return LISHIP_ERR_ARG;
+    if (count == 0) return 0;
+    int grid = (count + BLOCK - 1) / BLOCK;
+    if (grid > 4096) grid = 4096;
+    scatter_add_kernel<<<grid, BLOCK, 0, as_stream(s)>>>(count, index, src, y);
     LAUNCH_CHECK();
     return 0;
 }

@@ -94,6 +94,75 @@ void orc_spmv_ell(int n, int maxnzr, const int *idx, const double *val,
     }
 }
 
+/* ---- y = A^T x (lis_matvech_<fmt>), the reference's scatter loops at one thread.  The OpenMP build scatters
+ * into a zeroed per-thread buffer w and stores y[i] = 0.0 + w[i]; with one thread that is the same value as the
+ * sequential sums below (w starts +0.0 and can never become -0.0). */
+void orc_spmvh_csr(int n, int np, const int *ptr, const int *idx, const double *val,
+                   const double *x, double *y)
+{   /* lis_matvec_csr.c:213-250 */
+    for (int c = 0; c < np; c++) y[c] = 0.0;
+    for (int r = 0; r < n; r++) {
+        const double t = x[r];
+        for (int k = ptr[r]; k < ptr[r + 1]; k++) y[idx[k]] += val[k] * t;
+    }
+}
+
+void orc_spmvh_csc(int np, const int *ptr, const int *idx, const double *val,
+                   const double *x, double *y)
+{   /* lis_matvec_csc.c:176-190: row sums over the stored columns */
+    for (int c = 0; c < np; c++) {
+        double t = 0.0;
+        for (int k = ptr[c]; k < ptr[c + 1]; k++) t += val[k] * x[idx[k]];
+        y[c] = t;
+    }
+}
+
+void orc_spmvh_ell(int n, int np, int maxnzr, const int *idx, const double *val,
+                   const double *x, double *y)
+{   /* lis_matvec_ell.c:181-215: jagged column by jagged column, padding entries included */
+    for (int c = 0; c < np; c++) y[c] = 0.0;
+    for (int j = 0; j < maxnzr; j++) {
+        const size_t base = (size_t)j * (size_t)n;
+        for (int r = 0; r < n; r++) y[idx[base + r]] += val[base + r] * x[r];
+    }
+}
+
+void orc_spmvh_dia(int n, int np, int nnd, const int *off, const double *val,
+                   const double *x, double *y)
+{   /* lis_matvec_dia.c:262-310 with one chunk: diagonal by diagonal */
+    for (int c = 0; c < np; c++) y[c] = 0.0;
+    for (int d = 0; d < nnd; d++) {
+        const int jj = off[d];
+        const int lo = jj < 0 ? -jj : 0, hi = (n - jj) < n ? (n - jj) : n;
+        for (int r = lo; r < hi; r++) y[jj + r] += val[(size_t)d * (size_t)n + r] * x[r];
+    }
+}
+
+void orc_spmvh_jad(int n, int np, int maxnzr, const int *perm, const int *ptr, const int *idx,
+                   const double *val, const double *x, double *y)
+{   /* lis_matvec_jad.c:545-580 */
+    (void)n;
+    for (int c = 0; c < np; c++) y[c] = 0.0;
+    for (int j = 0; j < maxnzr; j++) {
+        int k = 0;
+        for (int i = ptr[j]; i < ptr[j + 1]; i++, k++) y[idx[i]] += val[i] * x[perm[k]];
+    }
+}
+
+void orc_spmvh_bsr(int nr, int bnr, int bnc, const int *bptr, const int *bidx, const double *val,
+                   const double *x, double *y, int ylen)
+{   /* lis_matvec_bsr.c:935-957: x and y are the padded vectors (nr*bnr / nc*bnc entries) */
+    for (int c = 0; c < ylen; c++) y[c] = 0.0;
+    const int bs = bnr * bnc;
+    for (int bi = 0; bi < nr; bi++)
+        for (int bc = bptr[bi]; bc < bptr[bi + 1]; bc++) {
+            const int bj = bidx[bc] * bnc;
+            size_t k = (size_t)bc * bs;
+            for (int j = 0; j < bnc; j++)
+                for (int i = 0; i < bnr; i++, k++) y[bj + j] += val[k] * x[bi * bnr + i];
+        }
+}
+
 static void chunk_range(int id, int nchunks, int n, int *lo, int *hi)
 {   /* static row split used by every reference kernel: LIS_GET_ISIE, include/lis.h:1067-1078 */
     int q = n / nchunks, rem = n % nchunks;
@@ -481,6 +550,49 @@ orc_result orc_bicgstab(int n, const int *ptr, const int *idx, const double *val
     out.retcode = 4; out.iter = it; out.resid = nrm;
 done:
     free(rt); free(r); free(t); free(p); free(v); free(ph); free(sh); sys_close(&S);
+    return out;
+}
+
+/* lis_bicg, lis_solver_bicg.c:135-268: the dual recurrences with A^T (real build: conj is the identity);
+ * z/ztld double as q/qtld (work[2], work[3], :160-165) */
+orc_result orc_bicg(int n, const int *ptr, const int *idx, const double *val,
+                    const double *b, double *x, int precon, double tol, int maxiter,
+                    int init_zero, double *rhistory)
+{
+    orc_result out = {0, 0, 0.0};
+    orc_sys S; sys_open(&S, n, ptr, idx, val, precon);
+    double *r = vec_new(n), *rt = vec_new(n), *z = vec_new(n), *zt = vec_new(n), *p = vec_new(n), *pt = vec_new(n);
+    double *q = z, *qt = zt;
+    double bnrm, nrm = 0.0, rho_old = 1.0;
+    if (rhistory) rhistory[0] = 1.0;
+    if (init_zero) memset(x, 0, (size_t)n * sizeof(double));
+    if (initial_residual(&S, b, x, init_zero, r, tol, &bnrm, &out)) goto done;
+    memcpy(rt, r, (size_t)n * sizeof(double));
+    int it;
+    for (it = 1; it <= maxiter; it++) {
+        sys_psolve(&S, r, z);
+        sys_psolve(&S, rt, zt);                      /* M^-H = M^-1 for none / Jacobi (lis_precon_jacobi.c:188-191) */
+        const double rho = orc_dot(n, rt, z);
+        if (rho == 0.0) { out.retcode = 2; out.iter = it; out.resid = nrm; goto done; }
+        const double beta = rho / rho_old;
+        orc_xpay(n, z, beta, p);
+        sys_matvec(&S, p, q);
+        orc_xpay(n, zt, beta, pt);
+        orc_spmvh_csr(n, n, S.ptr, S.idx, S.val, pt, qt);
+        const double d = orc_dot(n, pt, q);
+        if (d == 0.0) { out.retcode = 2; out.iter = it; out.resid = nrm; goto done; }
+        const double alpha = rho / d;
+        orc_axpy(n, alpha, p, x);
+        orc_axpy(n, -alpha, q, r);
+        nrm = orc_nrm2(n, r) * bnrm;
+        if (rhistory) rhistory[it] = nrm;
+        if (tol >= nrm) { out.retcode = 0; out.iter = it; out.resid = nrm; goto done; }
+        orc_axpy(n, -alpha, qt, rt);
+        rho_old = rho;
+    }
+    out.retcode = 4; out.iter = it; out.resid = nrm;
+done:
+    free(r); free(rt); free(z); free(zt); free(p); free(pt); sys_close(&S);
     return out;
 }
 

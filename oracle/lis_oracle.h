@@ -52,6 +52,20 @@ void orc_spmv_jad(int n, int maxnzr, int nchunks, const int *perm, const int *pt
 void orc_spmv_bsr(int n, int nr, int bnr, int bnc, const int *bptr, const int *bidx,
                   const double *val, const double *x, double *y);
 
+/* ---- y = A^T x: lis_matvech_<fmt>, scatter order of the reference at one thread ------------ */
+void orc_spmvh_csr(int n, int np, const int *ptr, const int *idx, const double *val,
+                   const double *x, double *y);                      /* lis_matvec_csr.c:213-250 */
+void orc_spmvh_csc(int np, const int *ptr, const int *idx, const double *val,
+                   const double *x, double *y);                      /* lis_matvec_csc.c:176-190 */
+void orc_spmvh_ell(int n, int np, int maxnzr, const int *idx, const double *val,
+                   const double *x, double *y);                      /* lis_matvec_ell.c:181-215 */
+void orc_spmvh_dia(int n, int np, int nnd, const int *off, const double *val,
+                   const double *x, double *y);                      /* lis_matvec_dia.c:262-310 */
+void orc_spmvh_jad(int n, int np, int maxnzr, const int *perm, const int *ptr, const int *idx,
+                   const double *val, const double *x, double *y);   /* lis_matvec_jad.c:545-580 */
+void orc_spmvh_bsr(int nr, int bnr, int bnc, const int *bptr, const int *bidx, const double *val,
+                   const double *x, double *y, int ylen);            /* lis_matvec_bsr.c:935-957 */
+
 /* ---- CSR -> other formats (layouts the reference defines; 1-thread semantics) -------------- */
 int  orc_ell_maxnzr(int n, const int *ptr);
 /* src/matrix/lis_matrix_ell.c:1018-1043 */
@@ -109,6 +123,9 @@ orc_result orc_bicgstab(int n, const int *ptr, const int *idx, const double *val
                         const double *b, double *x, int precon, double tol, int maxiter,
                         int init_zero, double *rhistory);
 /* src/solver/lis_solver_gmres.c:135-342 */
+orc_result orc_bicg(int n, const int *ptr, const int *idx, const double *val,
+                    const double *b, double *x, int precon, double tol, int maxiter,
+                    int init_zero, double *rhistory);               /* lis_solver_bicg.c:135-268 */
 orc_result orc_gmres(int n, const int *ptr, const int *idx, const double *val,
                      const double *b, double *x, int precon, double tol, int maxiter,
                      int restart, int init_zero, double *rhistory);

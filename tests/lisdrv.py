@@ -96,6 +96,18 @@ def matvec(lib, A, x):
     return y
 
 
+def matvech(lib, A, x):
+    """y = A^T x through lis_matvech (ref src/matvec/lis_matvec.c:191)."""
+    vx = new_vector(lib, A, x)
+    vy = new_vector(lib, A)
+    err = lib.lis_matvech(A, vx, vy)
+    assert err == 0, err
+    y = get_vector(lib, vy, A.contents.n)
+    lib.lis_vector_destroy(vx)
+    lib.lis_vector_destroy(vy)
+    return y
+
+
 def matrix_arrays(A):
     """Host arrays of an assembled matrix, by format (layouts: SURVEY 8a rows a5-a11)."""
     a = A.contents

@@ -47,6 +47,12 @@ def lib():
         "orc_spmv_dia": (None, [ci, ci, ci, I, D, D, D]),
         "orc_spmv_jad": (None, [ci, ci, ci, I, I, I, D, D, D]),
         "orc_spmv_bsr": (None, [ci, ci, ci, ci, I, I, D, D, D]),
+        "orc_spmvh_csr": (None, [ci, ci, I, I, D, D, D]),
+        "orc_spmvh_csc": (None, [ci, I, I, D, D, D]),
+        "orc_spmvh_ell": (None, [ci, ci, ci, I, D, D, D]),
+        "orc_spmvh_dia": (None, [ci, ci, ci, I, D, D, D]),
+        "orc_spmvh_jad": (None, [ci, ci, ci, I, I, I, D, D, D]),
+        "orc_spmvh_bsr": (None, [ci, ci, ci, I, I, D, D, D, ci]),
         "orc_ell_maxnzr": (ci, [ci, I]),
         "orc_csr2ell": (None, [ci, I, I, D, ci, I, D]),
         "orc_csr2csc": (None, [ci, ci, I, I, D, I, I, D]),
@@ -64,6 +70,7 @@ def lib():
         "orc_pmul": (None, [ci, D, D, D]),
         "orc_reciprocal": (None, [ci, D]),
         "orc_cg": (Result, [ci, I, I, D, D, D, ci, cd, ci, ci, P]),
+        "orc_bicg": (Result, [ci, I, I, D, D, D, ci, cd, ci, ci, P]),
         "orc_bicgstab": (Result, [ci, I, I, D, D, D, ci, cd, ci, ci, P]),
         "orc_gmres": (Result, [ci, I, I, D, D, D, ci, cd, ci, ci, ci, P]),
     }
@@ -164,6 +171,47 @@ def spmv_bsr(n, nr, bnr, bnc, bptr, bidx, val, x):
     return y[:n].copy()
 
 
+def spmvh_csr(ptr, idx, val, x, np_=None):
+    n = len(ptr) - 1
+    np_ = n if np_ is None else np_
+    y = np.empty(np_)
+    lib().orc_spmvh_csr(n, np_, ptr, idx, val, x, y)
+    return y
+
+
+def spmvh_csc(np_, ptr, idx, val, x):
+    y = np.empty(np_)
+    lib().orc_spmvh_csc(np_, ptr, idx, val, x, y)
+    return y
+
+
+def spmvh_ell(n, maxnzr, idx, val, x):
+    y = np.empty(n)
+    lib().orc_spmvh_ell(n, n, maxnzr, idx, val, x, y)
+    return y
+
+
+def spmvh_dia(n, nnd, off, val, x):
+    y = np.empty(n)
+    lib().orc_spmvh_dia(n, n, nnd, off, val, x, y)
+    return y
+
+
+def spmvh_jad(n, maxnzr, perm, ptr, idx, val, x):
+    y = np.empty(n)
+    lib().orc_spmvh_jad(n, n, maxnzr, perm, ptr, idx, val, x, y)
+    return y
+
+
+def spmvh_bsr(n, nr, bnr, bnc, bptr, bidx, val, x):
+    ylen = max(nr * bnr, (int(bidx.max()) + 1) * bnc if len(bidx) else 0)
+    y = np.zeros(ylen)
+    xx = np.zeros(nr * bnr)
+    xx[:n] = x[:n]
+    lib().orc_spmvh_bsr(nr, bnr, bnc, bptr, bidx, val, xx, y, ylen)
+    return y[:n].copy()
+
+
 # ---------------------------------------------------------------- conversions
 def csr2ell(ptr, idx, val):
     n = len(ptr) - 1
@@ -249,6 +297,10 @@ def _solve(fn, ptr, idx, val, b, x0, precon, tol, maxiter, extra):
 
 def cg(ptr, idx, val, b, x0=None, precon="none", tol=1e-12, maxiter=1000):
     return _solve(lib().orc_cg, ptr, idx, val, b, x0, precon, tol, maxiter, [])
+
+
+def bicg(ptr, idx, val, b, x0=None, precon="none", tol=1e-12, maxiter=1000):
+    return _solve(lib().orc_bicg, ptr, idx, val, b, x0, precon, tol, maxiter, [])
 
 
 def bicgstab(ptr, idx, val, b, x0=None, precon="none", tol=1e-12, maxiter=1000):

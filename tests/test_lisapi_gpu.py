@@ -304,3 +304,104 @@ def test_matrix_market_solves_match_reference(lib, name, opts):
     assert np.allclose(out["x"], GM[key + "/x"], rtol=0, atol=1e-10)
     k = min(it_ref, 6)
     assert np.allclose(out["rhistory"][1:k + 1], GM[key + "/rhistory"][1:k + 1], rtol=1e-8, atol=0)
+
+
+# ------------------------------------------------------------------ A^T x and BiCG
+def oracle_t(fmt, ptr, idx, val, x, bs=2):
+    """lis_matvech of the reference for this storage format (scatter order differs per format)."""
+    n = len(ptr) - 1
+    if fmt == "csr":
+        return orc.spmvh_csr(ptr, idx, val, x)
+    if fmt == "csc":
+        return orc.spmvh_csc(n, *orc.csr2csc(ptr, idx, val), x)
+    if fmt == "ell":
+        mx, eidx, ev = orc.csr2ell(ptr, idx, val)
+        return orc.spmvh_ell(n, mx, eidx, ev, x)
+    if fmt == "dia":
+        sidx, sval = orc.sort_rows(ptr, idx, val)
+        nnd, off, dv = orc.csr2dia(ptr, sidx, sval)
+        return orc.spmvh_dia(n, nnd, off, dv, x)
+    if fmt == "jad":
+        mx, perm, jptr, jidx, jval = orc.csr2jad(ptr, idx, val)
+        return orc.spmvh_jad(n, mx, perm, jptr, jidx, jval, x)
+    nr, bptr, bidx, bval = orc.csr2bsr(ptr, idx, val, bs, bs)
+    return orc.spmvh_bsr(n, nr, bs, bs, bptr, bidx, bval, x)
+
+
+@pytest.mark.parametrize("fmt,bs", [("csr", 0), ("csc", 0), ("ell", 0), ("dia", 0), ("jad", 0), ("bsr", 2), ("bsr", 3)])
+@pytest.mark.parametrize("case", ["rand_3001", "p3d_21x14x11", "rand_long"])
+def test_lis_matvech_bit_exact(lib, fmt, bs, case):
+    if case == "rand_3001":
+        ptr, idx, val = orc.random_csr(3001, 9, seed=4)
+    elif case == "p3d_21x14x11":
+        ptr, idx, val = orc.poisson3d(21, 14, 11, sort_cols=True)
+    else:
+        ptr, idx, val = orc.random_csr(400, 30, seed=5, long_row=390)
+    if fmt == "dia" and case != "p3d_21x14x11":
+        pytest.skip("DIA of a random matrix is a dense band: covered by the stencil case")
+    n = len(ptr) - 1
+    x = np.random.default_rng(12).uniform(-1, 1, n)
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    B = A if fmt == "csr" else lisdrv.convert(lib, A, fmt, bs or 2, bs or 2)
+    y = lisdrv.matvech(lib, B, x)
+    assert np.array_equal(y, oracle_t(fmt, ptr, idx, val, x, bs or 2)), (fmt, case)
+    # the forward product still works next to the cached transpose
+    assert np.array_equal(lisdrv.matvec(lib, B, x), oracle_for(fmt, ptr, idx, val, x, bs or 2))
+
+
+def test_raw_matvech_entry_point(lib):
+    ptr, idx, val = orc.random_csr(777, 6, seed=8)
+    n = 777
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    y = np.full(n, np.nan)
+    lib.dll.lis_matvech_csr(A, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(y, orc.spmvh_csr(ptr, idx, val, x))
+
+
+def _nonsym_dominant(n, seed):
+    """random non-symmetric pattern, stray diagonal entries moved off the diagonal (lis_matrix_get_diagonal takes the
+    FIRST entry with index == row), a dominant diagonal appended to every row"""
+    ptr, idx, val = orc.random_csr(n, 6, seed=seed, empty_rows=False)
+    nptr = (ptr + np.arange(n + 1)).astype(np.int32)
+    nidx, nval = np.empty(len(idx) + n, np.int32), np.empty(len(idx) + n)
+    for r in range(n):
+        s, e = ptr[r], ptr[r + 1]
+        vals = val[s:e]
+        nidx[nptr[r]:nptr[r + 1] - 1], nval[nptr[r]:nptr[r + 1] - 1] = np.where(idx[s:e] == r, (r + 1) % n, idx[s:e]), vals
+        nidx[nptr[r + 1] - 1], nval[nptr[r + 1] - 1] = r, np.abs(vals).sum() + 1.0
+    return nptr, nidx, nval
+
+
+@pytest.mark.parametrize("precon", ["none", "jacobi"])
+@pytest.mark.parametrize("case", ["p3d_9", "nonsym_500"])
+def test_bicg_matches_oracle(lib, precon, case):
+    """BiCG (Lis's default solver) against the oracle restatement of lis_solver_bicg.c: same iteration count,
+    residual <= 1e-12, solution within 1e-9, early residual history within 1e-8 relative."""
+    ptr, idx, val = orc.poisson3d(9, 9, 9) if case == "p3d_9" else _nonsym_dominant(500, 31)
+    n = len(ptr) - 1
+    b = orc.spmv_csr(ptr, idx, val, np.ones(n))
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    out = lisdrv.solve(lib, A, b, f"-i bicg -p {precon} -tol 1e-12 -maxiter 1000 -print mem")
+    x, it, rc, resid, rh = orc.bicg(ptr, idx, val, b, precon=precon, tol=1e-12, maxiter=1000)
+    assert out["err"] == 0 and out["status"] == rc == 0
+    assert out["iter"] == it, (out["iter"], it)
+    assert out["resid"] <= 1e-12
+    assert np.allclose(out["x"], x, rtol=0, atol=1e-9)
+    k = min(it, 8)
+    assert np.allclose(out["rhistory"][1:k + 1], rh[1:k + 1], rtol=1e-8, atol=0)
+    # a run cut short reports LIS_MAXITER in the status, iter = maxiter + 1, like the reference (lis_solver_bicg.c:262-265)
+    out = lisdrv.solve(lib, A, b, f"-i bicg -p {precon} -maxiter 3 -print mem")
+    x3, it3, rc3, _, rh3 = orc.bicg(ptr, idx, val, b, precon=precon, maxiter=3)
+    assert (out["err"], out["status"], out["iter"]) == (0, rc3, it3) == (0, capi.LIS_MAXITER, 4)
+    assert np.allclose(out["rhistory"][1:4], rh3[1:4], rtol=1e-10, atol=0) and np.allclose(out["x"], x3, rtol=1e-10, atol=1e-13)
+
+
+def test_default_solver_is_bicg_on_reference_fixture(lib):
+    """test/test.sh of the reference: `test1 testmat.mtx 0` with default options = BiCG, 15 iterations."""
+    A, b, x = _read_mm(lib, "testmat.mtx")
+    n = A.contents.n
+    bb = lisdrv.get_vector(lib, b, n)
+    out = lisdrv.solve(lib, A, bb, "-print mem")
+    assert out["err"] == 0 and out["status"] == 0 and out["iter"] == 15
+    assert np.allclose(out["x"], np.ones(n), rtol=0, atol=1e-12)

@@ -87,6 +87,40 @@ def test_convert_and_spmv(reflib, name, csr, fmt):
     reflib.lis_matrix_destroy(B)
 
 
+@pytest.mark.parametrize("name,csr", CASES, ids=IDS)
+@pytest.mark.parametrize("fmt", ["csr", "csc", "ell", "dia", "jad", "bsr"])
+def test_transposed_spmv(reflib, name, csr, fmt):
+    """lis_matvech of the reference (1 thread) == the oracle's scatter restatement, every format."""
+    ptr, idx, val = csr
+    n = len(ptr) - 1
+    x = _x(n, seed=9)
+    A = lisdrv.make_csr(reflib, ptr, idx, val)
+    B = A if fmt == "csr" else lisdrv.convert(reflib, A, fmt)
+    y_ref = lisdrv.matvech(reflib, B, x)
+    if fmt == "csr":
+        y = orc.spmvh_csr(ptr, idx, val, x)
+    elif fmt == "csc":
+        cptr, cidx, cval = orc.csr2csc(ptr, idx, val)
+        y = orc.spmvh_csc(n, cptr, cidx, cval, x)
+    elif fmt == "ell":
+        mx, eidx, eval_ = orc.csr2ell(ptr, idx, val)
+        y = orc.spmvh_ell(n, mx, eidx, eval_, x)
+    elif fmt == "dia":
+        sidx, sval = orc.sort_rows(ptr, idx, val)
+        nnd, off, dval = orc.csr2dia(ptr, sidx, sval)
+        y = orc.spmvh_dia(n, nnd, off, dval, x)
+    elif fmt == "jad":
+        mx, perm, jptr, jidx, jval = orc.csr2jad(ptr, idx, val)
+        y = orc.spmvh_jad(n, mx, perm, jptr, jidx, jval, x)
+    else:
+        nr, bptr, bidx, bval = orc.csr2bsr(ptr, idx, val, 2, 2)
+        y = orc.spmvh_bsr(n, nr, 2, 2, bptr, bidx, bval, x)
+    assert np.array_equal(y, y_ref), fmt
+    if B is not A:
+        reflib.lis_matrix_destroy(B)
+    reflib.lis_matrix_destroy(A)
+
+
 @pytest.mark.parametrize("bnr,bnc", [(1, 1), (2, 3), (3, 2), (4, 4), (3, 3)])
 def test_bsr_blocks(reflib, bnr, bnc):
     ptr, idx, val = orc.random_csr(120, 7, seed=11)
@@ -145,6 +179,7 @@ SOLVER_CASES = [
     ("cg", "jacobi", (8, 8, 8)), ("cg", "none", (6, 7, 5)),
     ("bicgstab", "none", (8, 8, 8)), ("bicgstab", "jacobi", (5, 6, 7)),
     ("gmres", "none", (8, 8, 8)), ("gmres", "jacobi", (6, 6, 6)),
+    ("bicg", "none", (8, 8, 8)), ("bicg", "jacobi", (5, 6, 7)),
 ]
 
 
@@ -189,7 +224,7 @@ def test_solver_nonsymmetric_and_maxiter(reflib):
         nval[nptr[r + 1] - 1] = dense_diag[r]
     b = orc.spmv_csr(nptr, nidx, nval, np.ones(n))
     A = lisdrv.make_csr(reflib, nptr, nidx, nval)
-    for solver, extra, o in (("bicgstab", {}, ""), ("gmres", {"restart": 5}, " -restart 5")):
+    for solver, extra, o in (("bicgstab", {}, ""), ("gmres", {"restart": 5}, " -restart 5"), ("bicg", {}, "")):
         for maxiter in (3, 400):
             ref = lisdrv.solve(reflib, A, b, f"-i {solver} -p none -maxiter {maxiter} -print mem" + o)
             x, it, rc, resid, rh = getattr(orc, solver)(nptr, nidx, nval, b, maxiter=maxiter, **extra)

@@ -63,3 +63,40 @@ def test_test4_set_value_assembly():
     grab = lambda s: re.findall(r"^\s*(\d+)\s+(\S+)$", s, flags=re.M)
     assert re.search(r"number of iterations = (\d+)", a).group(1) == re.search(r"number of iterations = (\d+)", r).group(1)
     assert grab(a) == grab(r) and len(grab(a)) == 12        # the 12 solution components, as printed
+
+
+MM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mm")
+
+
+@pytest.mark.parametrize("opts", ["", "-i bicg -p jacobi", "-i cg", "-i bicgstab", "-i gmres", "-storage ell", "-storage jad -i bicg"])
+def test_test1_matrix_market_driver(tmp_path, opts):
+    """test/test.sh: `test1 testmat.mtx 0 sol rhist` -- Matrix Market in (b appended), default solver BiCG,
+    solution out in MM vector format.  Same printed iteration count as the reference binary, same solution."""
+    outs = {}
+    for tag in ("amd", "ref"):
+        sol, rh = tmp_path / f"sol_{tag}.mtx", tmp_path / f"rh_{tag}.txt"
+        out = run(f"test1_{tag}", os.path.join(MM, "testmat.mtx"), 0, sol, rh, *opts.split())
+        m = re.search(r"(\S+): number of iterations = (\d+)", out)
+        res = float(re.search(r"relative residual\s*= (\S+)", out).group(1))
+        lines = open(sol).read().splitlines()
+        assert lines[0] == "%%MatrixMarket vector coordinate real general" and lines[1] == "100"
+        outs[tag] = (m.group(1), int(m.group(2)), res, [float(l.split()[1]) for l in lines[2:]], "matrix size = 100 x 100 (460 nonzero entries)" in out)
+    a, r = outs["amd"], outs["ref"]
+    assert a[0] == r[0] and a[1] == r[1], (a[:2], r[:2])       # solver name and iteration count as printed
+    if not opts:
+        assert a[0] == "BiCG" and a[1] == 15                     # SURVEY 8c known answer
+    assert a[2] <= 1e-12 and a[4] and r[4]
+    assert max(abs(x - y) for x, y in zip(a[3], r[3])) <= 1e-12
+
+
+def test_test1_rhs_modes_and_vector_file(tmp_path):
+    """rhs_setting 1 (b = 1), 2 (b = A*1) and a file name (lis_input_vector), on a file without an appended b."""
+    for rhs in ("1", "2", os.path.join(MM, "testvec0.mtx")):
+        res = {}
+        for tag in ("amd", "ref"):
+            sol, rh = tmp_path / f"s_{tag}.mtx", tmp_path / f"r_{tag}.txt"
+            out = run(f"test1_{tag}", os.path.join(MM, "testmat0.mtx"), rhs, sol, rh, "-i", "bicg")
+            res[tag] = (int(re.search(r"number of iterations = (\d+)", out).group(1)),
+                        [float(l.split()[1]) for l in open(sol).read().splitlines()[2:]])
+        assert res["amd"][0] == res["ref"][0], rhs
+        assert max(abs(x - y) for x, y in zip(*[res[t][1] for t in ("amd", "ref")])) <= 1e-11

@@ -13,51 +13,94 @@ namespace {
 
 constexpr int BLOCK = 256;
 
+// ELL: lane owns ROWS consecutive rows (2 when n is even: 16 B value / 8 B index loads), UNROLL jagged columns
+// in flight before the first use; column-major storage makes every load of a wavefront contiguous.
+template <int ROWS, int UNROLL>
 __global__ __launch_bounds__(BLOCK)
 void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const double *__restrict__ val,
                      const double *__restrict__ x, double *__restrict__ y)
 {
-    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    const int r = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
     if (r >= n) return;
-    double acc = 0.0;
-    int j = 0;
-    for (; j + 4 <= maxnzr; j += 4) {            // four independent (value,index,x) chains in flight
-        double v[4]; int c[4];
+    double acc[ROWS];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const size_t k = (size_t)(j + u) * (size_t)n + (size_t)r;
-            v[u] = load_stream(val + k);
-            c[u] = load_stream(idx + k);
+    for (int i = 0; i < ROWS; i++) acc[i] = 0.0;
+    for (int j0 = 0; j0 < maxnzr; j0 += UNROLL) {
+        double v[UNROLL][ROWS], xv[UNROLL][ROWS];
+        int c[UNROLL][ROWS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int j = min(j0 + u, maxnzr - 1);          // clamped: the tail repeats the last column, masked below
+            const size_t k = (size_t)j * (size_t)n + (size_t)r;
+            if (ROWS == 2) {
+                const v2f64 vv = load_stream(reinterpret_cast<const v2f64 *>(val + k));
+                const v2i32 cc = load_stream(reinterpret_cast<const v2i32 *>(idx + k));
+                v[u][0] = vv.x; v[u][ROWS - 1] = vv.y; c[u][0] = cc.x; c[u][ROWS - 1] = cc.y;
+            } else { v[u][0] = load_stream(val + k); c[u][0] = load_stream(idx + k); }
         }
-        double xv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) xv[u] = x[c[u]];
+        for (int u = 0; u < UNROLL; u++)
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc += v[u] * xv[u];
+            for (int i = 0; i < ROWS; i++) xv[u][i] = x[c[u][i]];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                const double t = v[u][i] * xv[u][i];
+                acc[i] += (j0 + u < maxnzr) ? t : 0.0;      // +0.0 leaves the sum's bits unchanged
+            }
     }
-    for (; j < maxnzr; j++) {
-        const size_t k = (size_t)j * (size_t)n + (size_t)r;
-        acc += load_stream(val + k) * x[load_stream(idx + k)];
-    }
-    y[r] = acc;
+    if (ROWS == 2) { v2f64 o; o.x = acc[0]; o.y = acc[ROWS - 1]; store_stream(reinterpret_cast<v2f64 *>(y + r), o); }
+    else store_stream(y + r, acc[0]);
 }
 
+// DIA: same shape; a diagonal's offset is wave-uniform (scalar load), x[r + off] is contiguous across the wavefront.
+// The reference skips the part of a diagonal that falls outside the matrix (lis_matvec_dia.c:152-158): masked here.
+template <int ROWS, int UNROLL>
 __global__ __launch_bounds__(BLOCK)
 void spmv_dia_kernel(int n, int ncols, int nnd, const int *__restrict__ off,
                      const double *__restrict__ val, const double *__restrict__ x,
                      double *__restrict__ y)
 {
-    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    const int r = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
     if (r >= n) return;
-    double acc = 0.0;
-    for (int d = 0; d < nnd; d++) {
-        const int c = r + off[d];                 // off[d] is wave-uniform -> scalar load
-        if (c >= 0 && c < ncols)
-            acc += load_stream(val + (size_t)d * (size_t)n + (size_t)r) * x[c];
+    double acc[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; i++) acc[i] = 0.0;
+    for (int d0 = 0; d0 < nnd; d0 += UNROLL) {
+        double v[UNROLL][ROWS], xv[UNROLL][ROWS];
+        bool ok[UNROLL][ROWS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int d = min(d0 + u, nnd - 1);
+            const size_t k = (size_t)d * (size_t)n + (size_t)r;
+            if (ROWS == 2) {
+                const v2f64 vv = load_stream(reinterpret_cast<const v2f64 *>(val + k));
+                v[u][0] = vv.x; v[u][ROWS - 1] = vv.y;
+            } else v[u][0] = load_stream(val + k);
+            const int o = off[d];
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                const int c = r + i + o;
+                ok[u][i] = (d0 + u < nnd) && c >= 0 && c < ncols;
+                xv[u][i] = x[ok[u][i] ? c : r];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                const double t = v[u][i] * xv[u][i];
+                acc[i] += ok[u][i] ? t : 0.0;
+            }
     }
-    y[r] = acc;
+    if (ROWS == 2) { v2f64 o; o.x = acc[0]; o.y = acc[ROWS - 1]; store_stream(reinterpret_cast<v2f64 *>(y + r), o); }
+    else store_stream(y + r, acc[0]);
 }
 
+// JAD: lane owns one slot of the length-sorted order; UNROLL jagged diagonals in flight.  Diagonals only get
+// shorter, so a lane past the end of diagonal j is past the end of all later ones (masked, not branched).
+template <int UNROLL>
 __global__ __launch_bounds__(BLOCK)
 void spmv_jad_kernel(int n, int maxnzr, const int *__restrict__ perm, const int *__restrict__ ptr,
                      const int *__restrict__ idx, const double *__restrict__ val,
@@ -65,14 +108,31 @@ void spmv_jad_kernel(int n, int maxnzr, const int *__restrict__ perm, const int 
 {
     const int s = blockIdx.x * BLOCK + threadIdx.x;   // slot in the length-sorted order
     if (s >= n) return;
+    const int row = perm[s];
     double acc = 0.0;
-    for (int j = 0; j < maxnzr; j++) {
-        const int b = ptr[j], len = ptr[j + 1] - b;   // wave-uniform
-        if (s >= len) break;                          // jagged diagonals only get shorter
-        const int k = b + s;
-        acc += load_stream(val + k) * x[load_stream(idx + k)];
+    for (int j0 = 0; j0 < maxnzr; j0 += UNROLL) {
+        double v[UNROLL], xv[UNROLL];
+        int c[UNROLL];
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int j = min(j0 + u, maxnzr - 1);
+            const int b = ptr[j], len = ptr[j + 1] - b;   // wave-uniform
+            ok[u] = (j0 + u < maxnzr) && s < len;
+            const int k = ok[u] ? b + s : 0;
+            v[u] = load_stream(val + k);
+            c[u] = load_stream(idx + k);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const double t = v[u] * xv[u];
+            acc += ok[u] ? t : 0.0;
+        }
+        if (!ok[UNROLL - 1]) break;
     }
-    y[perm[s]] = acc;
+    y[row] = acc;
 }
 
 // one lane per scalar row: blocks of the block row in stored order, block columns ascending --
@@ -94,6 +154,61 @@ void spmv_bsr_kernel(int nrows, int bnr, int bnc, const int *__restrict__ bptr,
     y[r] = acc;
 }
 
+// BSR, square blocks up to 4x4: a workgroup owns BLOCK/BNR block rows.  Phase 1: lane = one block COLUMN
+// (BNR contiguous values -> fully coalesced 8*BNR B loads, one x value), the BNR rounded products go to LDS.
+// Phase 2: lane = one scalar row, sums its products block by block, column by column -- the order of
+// lis_matvec_bsr.c:120-148 -- with the running sum kept in a register across LDS passes for long block rows.
+template <int BNR, int BNC>
+__global__ __launch_bounds__(BLOCK)
+void spmv_bsr_tile_kernel(int nr, const int *__restrict__ bptr, const int *__restrict__ bidx,
+                          const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+{
+    constexpr int BS = BNR * BNC;
+    constexpr int BRW = BLOCK / BNR;                 // block rows per workgroup
+    constexpr int CHUNK = 4096 / BS;                 // blocks per LDS pass (32 KB of products)
+    __shared__ __attribute__((aligned(16))) double prod[CHUNK * BS];
+    const int br0 = blockIdx.x * BRW;
+    const int br1 = min(br0 + BRW, nr);
+    const int bb = bptr[br0], be = bptr[br1];
+    const int L = threadIdx.x;
+    const int mybr = br0 + L / BNR, myi = L % BNR;
+    const bool rowlane = (L < BRW * BNR) && mybr < br1;
+    int rs = 0, re = 0;
+    if (rowlane) { rs = bptr[mybr]; re = bptr[mybr + 1]; }
+    double acc = 0.0;
+    for (int cb = bb; cb < be; cb += CHUNK) {
+        const int nblk = min(CHUNK, be - cb);
+        for (int t = L; t < nblk * BNC; t += BLOCK) {
+            const int b = cb + t / BNC, j = t % BNC;
+            const double *src = val + (size_t)b * BS + (size_t)j * BNR;
+            const double xj = x[(size_t)bidx[b] * BNC + j];
+            double *dst = prod + (size_t)t * BNR;
+            if (BNR == 2 || BNR == 4) {
+#pragma unroll
+                for (int i = 0; i < BNR; i += 2) {
+                    const v2f64 v = load_stream(reinterpret_cast<const v2f64 *>(src + i));
+                    v2f64 o; o.x = v.x * xj; o.y = v.y * xj;
+                    *reinterpret_cast<v2f64 *>(dst + i) = o;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < BNR; i++) dst[i] = load_stream(src + i) * xj;
+            }
+        }
+        __syncthreads();
+        if (rowlane) {
+            const int s = max(rs, cb), e = min(re, cb + nblk);
+            for (int b = s; b < e; b++) {
+                const double *pp = prod + (size_t)(b - cb) * BS + myi;
+#pragma unroll
+                for (int j = 0; j < BNC; j++) acc += pp[j * BNR];
+            }
+        }
+        __syncthreads();
+    }
+    if (rowlane) store_stream(y + (size_t)mybr * BNR + myi, acc);
+}
+
 inline int grid_for(int n) { return (n + BLOCK - 1) / BLOCK; }
 
 } // namespace
@@ -103,7 +218,11 @@ extern "C" int liship_spmv_ell_f64(int n, int maxnzr, const int *idx, const doub
 {
     if (n < 0 || maxnzr < 0) return LISHIP_ERR_ARG;
     if (n == 0) return 0;
-    spmv_ell_kernel<<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y);
+    if (maxnzr == 0) { HIP_TRY(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n, as_stream(stream))); return 0; }
+    if ((n & 1) == 0 && aligned16(val) && aligned16(y) && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0)
+        spmv_ell_kernel<2, 8><<<grid_for(n / 2), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y);
+    else
+        spmv_ell_kernel<1, 8><<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y);
     LAUNCH_CHECK();
     return 0;
 }
@@ -113,7 +232,11 @@ extern "C" int liship_spmv_dia_f64(int n, int ncols, int nnd, const int *off, co
 {
     if (n < 0 || nnd < 0 || ncols < n) return LISHIP_ERR_ARG;
     if (n == 0) return 0;
-    spmv_dia_kernel<<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y);
+    if (nnd == 0) { HIP_TRY(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n, as_stream(stream))); return 0; }
+    if ((n & 1) == 0 && aligned16(val) && aligned16(y))
+        spmv_dia_kernel<2, 8><<<grid_for(n / 2), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y);
+    else
+        spmv_dia_kernel<1, 8><<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y);
     LAUNCH_CHECK();
     return 0;
 }
@@ -123,7 +246,8 @@ extern "C" int liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int
 {
     if (n < 0 || maxnzr < 0) return LISHIP_ERR_ARG;
     if (n == 0) return 0;
-    spmv_jad_kernel<<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, perm, ptr, idx, val, x, y);
+    if (maxnzr == 0) { HIP_TRY(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n, as_stream(stream))); return 0; }
+    spmv_jad_kernel<8><<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, perm, ptr, idx, val, x, y);
     LAUNCH_CHECK();
     return 0;
 }
@@ -135,7 +259,17 @@ extern "C" int liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, co
     if (nr == 0) return 0;
     const long long rows = (long long)nr * bnr;
     if (rows > 0x7fffffffLL) return LISHIP_ERR_ARG;
-    spmv_bsr_kernel<<<grid_for((int)rows), BLOCK, 0, as_stream(stream)>>>((int)rows, bnr, bnc, bptr, bidx, val, x, y);
+    hipStream_t st = as_stream(stream);
+    if (bnr == bnc && bnr <= 4 && aligned16(val)) {
+        const int brw = BLOCK / bnr, grid = (nr + brw - 1) / brw;
+        switch (bnr) {
+        case 1: spmv_bsr_tile_kernel<1, 1><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
+        case 2: spmv_bsr_tile_kernel<2, 2><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
+        case 3: spmv_bsr_tile_kernel<3, 3><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
+        default: spmv_bsr_tile_kernel<4, 4><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
+        }
+    } else
+        spmv_bsr_kernel<<<grid_for((int)rows), BLOCK, 0, st>>>((int)rows, bnr, bnc, bptr, bidx, val, x, y);
     LAUNCH_CHECK();
     return 0;
 }

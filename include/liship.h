@@ -135,6 +135,18 @@ int  liship_axpy_sumsq_f64(int n, double a, const double *x, double *y, double *
 /* y += a*x; result = {sum y^2, sum v*y}    (lis_solver_bicgstab.c:276-279 + :190 of the next iteration) */
 int  liship_axpy_sumsq_dot_f64(int n, double a, const double *x, double *y, const double *v, double *result,
                                void *work, void *stream);
+/* one modified Gram-Schmidt step of GMRES (lis_solver_gmres.c:219-227) with the coefficient read from HBM:
+ * w += (-*hprev)*vprev, then result[0] = <w,vnext>, or sum w^2 when vnext is NULL.  hprev is a previous
+ * result[], so a Hessenberg column needs no host synchronisation between its steps. */
+int  liship_mgs_step_f64(int n, const double *hprev, const double *vprev, double *w, const double *vnext,
+                         double *result, void *work, void *stream);
+/* x *= 1/sqrt(*sumsq) with sumsq in HBM  (lis_vector_nrm2 + lis_vector_scale, lis_solver_gmres.c:229-232) */
+int  liship_scale_inv_norm_f64(int n, const double *sumsq, double *x, void *stream);
+/* z = c0*v0, z += c1*v1, ... (accumulate = 0) or z += c0*v0, ... (accumulate = 1), element by element in that
+ * order: the bits of lis_vector_scale/axpy chains (lis_solver_gmres.c:290-296, :323-329) in one pass over z.
+ * vs[] and coef[] are HOST arrays (passed by value to the kernel); a v that aliases z reads the running value. */
+int  liship_lincomb_f64(int n, int count, const double *const *vs, const double *coef, int accumulate,
+                        double *z, void *stream);
 /* result[0] = <x,y>, result[1] = <x,x> in one pass (BiCGSTAB's <t,s>,<t,t>, lis_solver_bicgstab.c:267-268) */
 int  liship_dot2_f64(int n, const double *x, const double *y, double *result, void *work, void *stream);
 

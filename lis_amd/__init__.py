@@ -70,6 +70,9 @@ _LISHIP = {
     "liship_pmul_xpay_f64": (_ci, [_ci, _vp, _vp, _cd, _vp, _vp]),
     "liship_axpy_sumsq_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp]),
     "liship_axpy_sumsq_dot_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_mgs_step_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_scale_inv_norm_f64": (_ci, [_ci, _vp, _vp, _vp]),
+    "liship_lincomb_f64": (_ci, [_ci, _ci, _vp, _vp, _ci, _vp, _vp]),
     "liship_reduce_work_bytes": (_sz, []),
     "liship_dot_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp]),
     "liship_nrm2_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),

@@ -602,10 +602,14 @@ static LIS_INT run_gmres(ctx_t *c)
 	double *h = (double *)calloc((size_t)(ld + 1) * (size_t)(ld + 2), sizeof(double));   /* Hessenberg + rotations, host */
 	double *g = (double *)calloc((size_t)ld + 1, sizeof(double));                      /* the reference's vector s */
 	double nrm2 = 0.0, rnorm, t;
+	double *hdev = NULL;
 	int iter = 0;
 	if (!h || !g) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", ld); goto done; }
 	TRY(work_alloc(c, m + 3));
 	double *r = c->work[0], *z = c->work[1], **v = &c->work[2];
+	/* device-chained Gram-Schmidt needs the cross-rank fold on the device too: single-rank jobs only for now */
+	const int chained = !lisg.no_fusion && lisg.nprocs == 1;
+	if (chained) KTRY(liship_malloc((void **)&hdev, sizeof(double) * (size_t)(m + 4)));
 	int st = initial_residual(c, v[0]);                /* :193 leaves the unpreconditioned residual in v0 */
 	if (st) { err = st < 0 ? -st : 0; goto done; }
 	while (iter < c->maxiter) {
@@ -620,14 +624,27 @@ static LIS_INT run_gmres(ctx_t *c)
 			double *hc = h + (size_t)ii * ld;
 			TRY(d_psolve(c, v[ii], z));
 			TRY(d_matvec(c, z, v[i1]));
-			for (int k = 0; k < i; k++) {                  /* modified Gram-Schmidt */
-				TRY(lisd_dot(n, v[i1], v[k], &t));
-				hc[k] = t;
-				KTRY(liship_axpy_f64(n, -t, v[k], v[i1], lisg.stream));
+			if (chained) {
+				/* modified Gram-Schmidt with the coefficients kept in HBM: step k reads h[k-1] from the previous
+				 * step's reduction, so the whole column costs ONE host synchronisation instead of i+1 */
+				KTRY(liship_dot_f64(n, v[i1], v[0], hdev, lisg.reduce_work, lisg.stream));
+				for (int k = 1; k < i; k++)
+					KTRY(liship_mgs_step_f64(n, hdev + k - 1, v[k - 1], v[i1], v[k], hdev + k, lisg.reduce_work, lisg.stream));
+				KTRY(liship_mgs_step_f64(n, hdev + i - 1, v[i - 1], v[i1], NULL, hdev + i, lisg.reduce_work, lisg.stream));
+				KTRY(liship_scale_inv_norm_f64(n, hdev + i, v[i1], lisg.stream));
+				KTRY(liship_memcpy_d2h(hc, hdev, sizeof(double) * (size_t)(i + 1), lisg.stream));
+				KTRY(liship_stream_synchronize(lisg.stream));
+				hc[i1] = sqrt(hc[i1]);
+			} else {
+				for (int k = 0; k < i; k++) {                  /* modified Gram-Schmidt */
+					TRY(lisd_dot(n, v[i1], v[k], &t));
+					hc[k] = t;
+					KTRY(liship_axpy_f64(n, -t, v[k], v[i1], lisg.stream));
+				}
+				TRY(lisd_nrm2(n, v[i1], &t));
+				hc[i1] = t;
+				KTRY(liship_scale_f64(n, 1.0 / t, v[i1], lisg.stream));
 			}
-			TRY(lisd_nrm2(n, v[i1], &t));
-			hc[i1] = t;
-			KTRY(liship_scale_f64(n, 1.0 / t, v[i1], lisg.stream));
 			for (int k = 1; k <= ii; k++) {                /* apply the previous rotations */
 				const int jj = k - 1;
 				const double tt = hc[jj];
@@ -658,8 +675,11 @@ static LIS_INT run_gmres(ctx_t *c)
 			for (int j = jj + 1; j <= ii; j++) tt -= h[jj + (size_t)j * ld] * g[j];
 			g[jj] = tt / h[jj + (size_t)jj * ld];
 		}
-		KTRY(liship_scale_to_f64(n, g[0], v[0], z, lisg.stream));     /* z = y0 v0  (:290-296) */
-		for (int j = 1; j <= ii; j++) KTRY(liship_axpy_f64(n, g[j], v[j], z, lisg.stream));
+		if (!lisg.no_fusion) KTRY(liship_lincomb_f64(n, ii + 1, (const double *const *)v, g, 0, z, lisg.stream));   /* z = sum y_j v_j, one pass */
+		else {
+			KTRY(liship_scale_to_f64(n, g[0], v[0], z, lisg.stream));     /* z = y0 v0  (:290-296) */
+			for (int j = 1; j <= ii; j++) KTRY(liship_axpy_f64(n, g[j], v[j], z, lisg.stream));
+		}
 		TRY(d_psolve(c, z, r));
 		KTRY(liship_axpy_f64(n, 1.0, r, c->x, lisg.stream));
 		if (c->tol >= nrm2) { s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done; }
@@ -668,7 +688,10 @@ static LIS_INT run_gmres(ctx_t *c)
 			g[jj - 1] = -h[jj - 1 + SN] * g[jj];
 			g[jj]     =  h[jj - 1 + CS] * g[jj];
 		}
-		for (int j = 0; j <= i1; j++) {
+		if (!lisg.no_fusion) {                               /* v0 += (g0-1) v0 + sum g_j v_j  (:323-329), one pass */
+			g[0] = g[0] - 1.0;
+			KTRY(liship_lincomb_f64(n, i1 + 1, (const double *const *)v, g, 1, v[0], lisg.stream));
+		} else for (int j = 0; j <= i1; j++) {
 			double tt = g[j];
 			if (j == 0) tt = tt - 1.0;
 			KTRY(liship_axpy_f64(n, tt, v[j], v[0], lisg.stream));
@@ -677,6 +700,7 @@ static LIS_INT run_gmres(ctx_t *c)
 	s->retcode = LIS_MAXITER; s->iter = iter + 1; s->resid = nrm2; err = LIS_MAXITER;
 done:
 	work_free(c);
+	(void)liship_free(hdev);
 	free(h); free(g);
 	return err;
 }

@@ -41,7 +41,7 @@ __device__ __forceinline__ void st2(double *p, long long pair, v2f64 v)
 
 // ---- element-wise ---------------------------------------------------------------------------------
 enum EwOp { EW_AXPY, EW_XPAY, EW_AXPYZ, EW_SCALE_TO, EW_PMUL, EW_PDIV, EW_SET, EW_ABS, EW_RECIP, EW_SHIFT,
-            EW_AXPY2, EW_PUPDATE, EW_PMUL_XPAY };
+            EW_AXPY2, EW_PUPDATE, EW_PMUL_XPAY, EW_SCALE_DEV };
 
 // x = in0, y = in1, w = in2; the expressions are the reference's (file:line in liship.h)
 template <int OP>
@@ -61,12 +61,13 @@ __device__ __forceinline__ double ew_apply(double a, double b, double x, double 
     case EW_AXPY2:    { double t = y + a * x; return t + b * w; }        // y += a*x ; y += b*w
     case EW_PUPDATE:  { double t = y + a * x; return w + b * t; }        // y += a*x ; y = w + b*y
     case EW_PMUL_XPAY: { double z = x * w; return z + a * y; }          // z = x.*w ; y = z + a*y
+    case EW_SCALE_DEV: return a * x;             // a = 1/sqrt(*device scalar), formed once per lane
     }
     return 0.0;
 }
 
 template <int OP> struct EwArity { static constexpr int value =
-    (OP == EW_SET) ? 0 : (OP == EW_SCALE_TO || OP == EW_ABS || OP == EW_RECIP || OP == EW_SHIFT) ? 1 :
+    (OP == EW_SET) ? 0 : (OP == EW_SCALE_TO || OP == EW_ABS || OP == EW_RECIP || OP == EW_SHIFT || OP == EW_SCALE_DEV) ? 1 :
     (OP == EW_AXPY2 || OP == EW_PUPDATE || OP == EW_PMUL_XPAY) ? 3 : 2; };
 
 template <int OP, bool NT, bool VEC>
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(BLOCK)
 void ew_kernel(int n, double a, double b, const double *in0, const double *in1, const double *in2, double *out)
 {
     constexpr int NIN = EwArity<OP>::value;
+    if (OP == EW_SCALE_DEV) a = 1.0 / sqrt(in1[0]);     // in1: device scalar (a sum of squares), lis_solver_gmres.c:229-232
     if (VEC) {
         const long long npairs = n >> 1;
         const long long base = (long long)blockIdx.x * PAIRS_PER_BLOCK + threadIdx.x;
@@ -133,7 +135,9 @@ enum RedOp { RED_DOT, RED_SUMSQ, RED_ABS, RED_SUM, RED_DOT2,
              RED_CG_UPDATE,     // x += a*p; r += (-a)*q; result {sum r^2}
              RED_CG_UPDATE_JAC, // same + z = r.*dinv (not stored); results {sum r^2, sum r*z}
              RED_AXPY_NRM2,     // y += a*x; result {sum y^2}
-             RED_AXPY_NRM2_DOT  // y += a*x; results {sum y^2, sum w*y}
+             RED_AXPY_NRM2_DOT, // y += a*x; results {sum y^2, sum w*y}
+             RED_AXPYD_DOT,     // y += (-*sp)*x; result {sum y*w}      (one modified Gram-Schmidt step)
+             RED_AXPYD_SUMSQ    // y += (-*sp)*x; result {sum y^2}      (the last one)
 };
 template <int OP> struct RedResults { static constexpr int value =
     (OP == RED_DOT2 || OP == RED_AXPY_NRM2_DOT || OP == RED_CG_UPDATE_JAC) ? 2 : 1; };
@@ -143,6 +147,7 @@ struct RedArgs {
     double a;
     const double *x, *y, *w, *d, *e; // inputs (meaning per OP)
     double *ox, *oy;                 // in-place outputs of the fused forms
+    const double *sp;                // device scalar of the *D ops (last: the other initialisers leave it NULL)
 };
 
 template <int OP, bool NT, bool VEC>
@@ -153,6 +158,7 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
     constexpr int NRES = RedResults<OP>::value;
     double s0 = 0.0, s1 = 0.0;
     const int n = A.n;
+    const double adev = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) ? -A.sp[0] : 0.0;
     auto term = [&](double x, double y, double w, double d, double e, double &ox, double &oy) {
         if (OP == RED_DOT)   s0 += x * y;
         if (OP == RED_SUMSQ) s0 += x * x;
@@ -170,11 +176,16 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
             s0 += oy * oy;
             if (OP == RED_AXPY_NRM2_DOT) s1 += w * oy;
         }
+        if (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) {
+            oy = y + adev * x;              // y += (-h)*x, h read from HBM: no host round trip between steps
+            if (OP == RED_AXPYD_DOT) s0 += oy * w; else s0 += oy * oy;
+        }
         (void)e;
     };
     constexpr bool IS_CG = (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC);
-    constexpr bool HAS_Y = (OP == RED_DOT || OP == RED_DOT2 || IS_CG || OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT);
-    constexpr bool HAS_W = (IS_CG || OP == RED_AXPY_NRM2_DOT);
+    constexpr bool IS_AXD = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ);
+    constexpr bool HAS_Y = (OP == RED_DOT || OP == RED_DOT2 || IS_CG || OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || IS_AXD);
+    constexpr bool HAS_W = (IS_CG || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPYD_DOT);
     constexpr bool HAS_D = IS_CG;
     constexpr bool HAS_E = (OP == RED_CG_UPDATE_JAC);
     if (VEC) {
@@ -202,7 +213,7 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
                 v2f64 ox, oy;
                 ox.x = ox0; ox.y = ox1; oy.x = oy0; oy.y = oy1;
                 if (IS_CG) { st2(A.ox, p, ox); st2(A.oy, p, oy); }
-                if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT) st2(A.oy, p, oy);
+                if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || IS_AXD) st2(A.oy, p, oy);
             }
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -210,7 +221,7 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
             double ox, oy;
             term(A.x[i], HAS_Y ? A.y[i] : 0.0, HAS_W ? A.w[i] : 0.0, HAS_D ? A.d[i] : 0.0, HAS_E ? A.e[i] : 0.0, ox, oy);
             if (IS_CG) { A.ox[i] = ox; A.oy[i] = oy; }
-            if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT) A.oy[i] = oy;
+            if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || IS_AXD) A.oy[i] = oy;
         }
     } else {
         const long long i0 = (long long)blockIdx.x * (2 * PAIRS_PER_BLOCK) + threadIdx.x;
@@ -220,7 +231,7 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
                 double ox, oy;
                 term(A.x[i], HAS_Y ? A.y[i] : 0.0, HAS_W ? A.w[i] : 0.0, HAS_D ? A.d[i] : 0.0, HAS_E ? A.e[i] : 0.0, ox, oy);
                 if (IS_CG) { A.ox[i] = ox; A.oy[i] = oy; }
-                if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT) A.oy[i] = oy;
+                if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || IS_AXD) A.oy[i] = oy;
             }
         }
     }
@@ -409,6 +420,63 @@ extern "C" int liship_axpy_sumsq_f64(int n, double a, const double *x, double *y
 // y += a*x ; result = {sum y^2, sum v*y}
 extern "C" int liship_axpy_sumsq_dot_f64(int n, double a, const double *x, double *y, const double *v, double *result, void *w, void *s)
 { RedArgs A{n, a, x, y, v, nullptr, nullptr, nullptr, y}; return run_reduce<RED_AXPY_NRM2_DOT>(A, result, w, false, s); }
+
+// modified Gram-Schmidt on the device: w += (-*hprev) * vprev, then result[0] = <w, vnext> (vnext != NULL) or
+// sum w^2 (vnext == NULL).  hprev lives in HBM (the previous step's result), so a column of the Hessenberg is
+// formed without a host synchronisation between steps.
+extern "C" int liship_mgs_step_f64(int n, const double *hprev, const double *vprev, double *wv, const double *vnext,
+                                   double *result, void *w, void *s)
+{
+    if (!hprev || !vprev) return LISHIP_ERR_ARG;
+    RedArgs A{n, 0.0, vprev, wv, vnext, nullptr, nullptr, nullptr, wv, hprev};
+    if (vnext) return run_reduce<RED_AXPYD_DOT>(A, result, w, false, s);
+    return run_reduce<RED_AXPYD_SUMSQ>(A, result, w, false, s);
+}
+// x *= 1/sqrt(*sumsq), sumsq in HBM  (lis_vector_nrm2 + lis_vector_scale, lis_solver_gmres.c:229-232)
+extern "C" int liship_scale_inv_norm_f64(int n, const double *sumsq, double *x, void *s)
+{ return run_ew<EW_SCALE_DEV>(n, 0.0, 0.0, x, sumsq, nullptr, x, s); }
+
+namespace {
+constexpr int LINCOMB_MAX = 48;
+struct LinComb { int n, count, accumulate; const double *v[LINCOMB_MAX]; double c[LINCOMB_MAX]; };
+
+// accumulate == 0: z = c0*v0; z += c1*v1; ...      (lis_vector_scale + axpys, lis_solver_gmres.c:290-296)
+// accumulate == 1: z += c0*v0; z += c1*v1; ...     (v0 may be z itself: the residual update :323-329)
+__global__ __launch_bounds__(BLOCK)
+void lincomb_kernel(LinComb L, double *__restrict__ z)
+{
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= L.n) return;
+    double t;
+    int j = 0;
+    if (L.accumulate) t = z[i];
+    else { t = L.c[0] * L.v[0][i]; j = 1; }
+    for (; j < L.count; j++) {
+        const double vj = (L.v[j] == z) ? t : L.v[j][i];   // aliasing z means "the running value"
+        t = t + L.c[j] * vj;
+    }
+    z[i] = t;
+}
+}
+
+extern "C" int liship_lincomb_f64(int n, int count, const double *const *vs, const double *coef, int accumulate,
+                                  double *z, void *s)
+{
+    if (n < 0 || count < 0 || !z) return LISHIP_ERR_ARG;
+    if (n == 0) return 0;
+    int done = 0;
+    if (count == 0 && !accumulate) { HIP_TRY(hipMemsetAsync(z, 0, sizeof(double) * (size_t)n, as_stream(s))); return 0; }
+    while (done < count) {
+        LinComb L;
+        L.n = n; L.accumulate = (done > 0) ? 1 : accumulate;
+        L.count = (count - done < LINCOMB_MAX) ? count - done : LINCOMB_MAX;
+        for (int j = 0; j < L.count; j++) { L.v[j] = vs[done + j]; L.c[j] = coef[done + j]; }
+        lincomb_kernel<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, as_stream(s)>>>(L, z);
+        LAUNCH_CHECK();
+        done += L.count;
+    }
+    return 0;
+}
 
 extern "C" int liship_gather_f64(int count, const int *index, const double *x, double *out, void *s)
 {

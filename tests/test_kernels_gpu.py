@@ -384,3 +384,48 @@ def test_spmv_csr_fused_dot(lib, name, want_sumsq):
     assert abs(got[0][0] - np.dot(w, yref)) <= 1e-13 * scale
     if want_sumsq:
         assert abs(got[0][1] - np.dot(yref, yref)) <= 1e-13 * np.dot(yref, yref) + 1e-300
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 1000, 4097, (1 << 20) + 3])
+def test_gmres_device_chained_kernels(lib, n):
+    """The GMRES building blocks that keep their scalars in HBM give the bits of the reference's call sequence
+    (lis_vector_axpy / scale chains, lis_solver_gmres.c:219-232, :290-296, :323-329)."""
+    rng = np.random.default_rng(n + 11)
+    O = orc.lib()
+    w, vp, vn = (rng.uniform(-1, 1, n) for _ in range(3))
+    h = 0.43219876
+    work = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64)
+    dh, res = DA.from_host(np.array([h, 0.0])), DA.zeros(2, np.float64)
+    dw, dvp, dvn = DA.from_host(w), DA.from_host(vp), DA.from_host(vn)
+    # one Gram-Schmidt step: w += (-h) vp ; <w, vn>
+    ww = w.copy(); O.orc_axpy(n, -h, vp, ww)
+    check(lib.liship_mgs_step_f64(n, dh.ptr, dvp.ptr, dw.ptr, dvn.ptr, res.ptr, work.ptr, None))
+    assert np.array_equal(dw.to_host(), ww)
+    assert abs(res.to_host()[0] - np.dot(ww, vn)) <= 1e-14 * np.abs(ww * vn).sum() * max(1.0, np.log2(n + 1))
+    # the last step: w += (-h) vp ; sum w^2, then w *= 1/sqrt(sum) with the sum read from HBM
+    O.orc_axpy(n, -h, vp, ww)
+    check(lib.liship_mgs_step_f64(n, dh.ptr, dvp.ptr, dw.ptr, None, res.ptr, work.ptr, None))
+    ss = res.to_host()[0]
+    assert np.array_equal(dw.to_host(), ww) and abs(ss - np.dot(ww, ww)) <= 1e-14 * np.dot(ww, ww) * max(1.0, np.log2(n + 1))
+    check(lib.liship_scale_inv_norm_f64(n, res.ptr, dw.ptr, None))
+    O.orc_scale(n, 1.0 / np.sqrt(ss), ww)
+    assert np.array_equal(dw.to_host(), ww)
+    # linear combinations in the reference's order
+    m = 5
+    V = [rng.uniform(-1, 1, n) for _ in range(m)]
+    coef = rng.uniform(-2, 2, m)
+    dV = [DA.from_host(v) for v in V]
+    ptrs = (C.c_void_p * m)(*[d.ptr for d in dV])
+    dz = DA.from_host(np.full(n, np.nan))
+    check(lib.liship_lincomb_f64(n, m, ptrs, coef.ctypes.data, 0, dz.ptr, None))
+    z = np.zeros(n); O.orc_axpy(n, coef[0], V[0], z); z = coef[0] * V[0]
+    for j in range(1, m):
+        O.orc_axpy(n, coef[j], V[j], z)
+    assert np.array_equal(dz.to_host(), z)
+    # accumulate form with the first vector aliasing the destination: v0 += c0*v0 + c1*v1 + ...
+    ptrs2 = (C.c_void_p * m)(*([dV[0].ptr] + [d.ptr for d in dV[1:]]))
+    check(lib.liship_lincomb_f64(n, m, ptrs2, coef.ctypes.data, 1, dV[0].ptr, None))
+    z = V[0].copy(); O.orc_axpy(n, coef[0], V[0].copy(), z)
+    for j in range(1, m):
+        O.orc_axpy(n, coef[j], V[j], z)
+    assert np.array_equal(dV[0].to_host(), z)

@@ -151,16 +151,26 @@ __device__ __forceinline__ void stage_products(double *prod, const int *__restri
     }
 }
 
-// sum of p[0..lim) in order, from +0.0; absent terms are +0.0, which leaves the sum bit-unchanged
-__device__ __forceinline__ double ordered_sum(const double *p, int lim)
+// acc + p[0] + p[1] + ... + p[lim-1], strictly left to right (the reference's rounding sequence).  The adds form
+// one dependent chain, so the LDS reads are issued 16 at a time ahead of it; absent terms are +0.0, which leaves
+// the sum bit-unchanged (a sum that starts at +0.0 never becomes -0.0).
+__device__ __forceinline__ double ordered_sum(double acc, const double *p, int lim)
 {
-    double acc = 0.0;
-    for (int j = 0; j < lim; j += 4) {
-        const double d0 = p[j];
-        const double d1 = (j + 1 < lim) ? p[j + 1] : 0.0;
-        const double d2 = (j + 2 < lim) ? p[j + 2] : 0.0;
-        const double d3 = (j + 3 < lim) ? p[j + 3] : 0.0;
-        acc += d0; acc += d1; acc += d2; acc += d3;
+    constexpr int W = 16;
+    int j = 0;
+    for (; j + W <= lim; j += W) {
+        double d[W];
+#pragma unroll
+        for (int u = 0; u < W; u++) d[u] = p[j + u];
+#pragma unroll
+        for (int u = 0; u < W; u++) acc += d[u];
+    }
+    if (j < lim) {
+        double d[W];
+#pragma unroll
+        for (int u = 0; u < W; u++) d[u] = (j + u < lim) ? p[j + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < W; u++) acc += d[u];
     }
     return acc;
 }
@@ -201,7 +211,7 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
     for (int r = rmine; r < r1; r += BLOCK) {
         int s = s_first, e = e_first;
         if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
-        const double acc = ordered_sum(prod + (s - ka), min(e, kfirst) - s);
+        const double acc = ordered_sum(0.0, prod + (s - ka), min(e, kfirst) - s);
         if (e <= kfirst) { store_stream(y + r, acc); dots.add(r, acc); } else carry = acc;   // only the block's last row can overflow
     }
 
@@ -215,8 +225,7 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
             __syncthreads();
             stage_products<BLOCK, VEC, NOGATHER>(prod, idx, val, x, base, kend, ka2);
             __syncthreads();
-            if ((int)threadIdx.x == owner)
-                for (int k = base; k < kend; k++) carry += prod[k - ka2];
+            if ((int)threadIdx.x == owner) carry = ordered_sum(carry, prod + (base - ka2), kend - base);
             base = kend;
         }
         if ((int)threadIdx.x == owner) { store_stream(y + rl, carry); dots.add(rl, carry); }
@@ -236,21 +245,28 @@ __device__ __forceinline__ void publish_dots(const RowDots<DOT> &dots, double *s
     }
 }
 
-template <int BLOCK, int WORK, bool XRUN, bool VEC, bool NOGATHER>
+template <int BLOCK, int WORK, bool XRUN, bool VEC, bool NOGATHER, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                               const double *__restrict__ val, const double *__restrict__ x,
                               double *__restrict__ y, const v2i32 *__restrict__ blk,
-                              int bfirst, int nb, int row_begin, int row_end, int run)
+                              int bfirst, int nb, int row_begin, int row_end, int run,
+                              const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr)
 {
     constexpr int CAP = WORK + SLACK;
     __shared__ double prod[CAP + 8];
+    __shared__ double dot_scratch[BLOCK / WAVE];
+    RowDots<DOT> dots{wdot, 0.0, 0.0};
     const int lb = block_of_workgroup<XRUN>(nb, run);
     if (lb < 0) return;
     Blk B = load_blk(blk, bfirst + lb);
-    if (!clip_rows(B, ptr, row_begin, row_end)) return;
-    RowDots<0> none{nullptr, 0.0, 0.0};
-    block_by_products<BLOCK, CAP, VEC, NOGATHER, 0>(prod, ptr, idx, val, x, y, B, none);
+    if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
+        return;
+    }
+    block_by_products<BLOCK, CAP, VEC, NOGATHER, DOT>(prod, ptr, idx, val, x, y, B, dots);
+    __syncthreads();
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
 }
 
 // ------------------------------------------------------------------------------ row-gather kernel
@@ -371,6 +387,7 @@ struct liship_csr_plan_s {
     int nblocks;
     int geom;            // index into kGeom the split was built for
     int unroll;          // gather unroll U chosen from the mean row length
+    int products;        // long rows on average: the products kernel (lanes own non-zeros) instead of row-gather
     v2i32 *blk;          // device, nblocks + 1 entries {row, ptr[row]}
     v2i32 *blk_host;     // host copy (row-range launches)
 };
@@ -394,6 +411,10 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     if (p->geom >= kNumGeom) p->geom = 0;
     const double mean_len = n > 0 ? (double)nnz / n : 0.0;
     p->unroll = mean_len <= 4.0 ? 4 : (mean_len <= 7.0 ? 7 : 8);
+    // lane-per-row keeps 176 lanes busy on 7-entry rows but only 17 on 80-entry rows: from ~14 entries per row on,
+    // lanes own non-zeros instead (measured crossover, tools/rowlen_sweep.py)
+    p->products = (g_variant == 0 && mean_len >= 14.0) ? 1 : 0;
+    if (p->products) p->geom = 1;
     const int WORK = kGeom[p->geom].work;
     p->nblocks = (int)((items + WORK - 1) / WORK);
     p->blk = nullptr;
@@ -460,7 +481,7 @@ void launch_products(int grid, const LaunchArgs &a)
 }
 
 template <int G>
-void launch_geom(const LaunchArgs &a, int unroll)
+void launch_geom(const LaunchArgs &a, int unroll, bool plan_products)
 {
     const bool nogather = (g_variant & 0x100) != 0;
     const bool xrun = (g_variant & 1) && a.nb >= 4 * NUM_XCD;
@@ -468,7 +489,7 @@ void launch_geom(const LaunchArgs &a, int unroll)
     const int grid = xrun ? ((a.nb + span - 1) / span) * span : a.nb;
     const bool val16 = aligned16(a.val), idx16 = aligned16(a.idx);
     const bool idx8 = (reinterpret_cast<uintptr_t>(a.idx) & 7u) == 0;
-    const bool products = (g_variant & 6) != 0 || !(val16 && idx16);
+    const bool products = plan_products || (g_variant & 6) != 0 || !(val16 && idx16);
     if (products) {
         const bool vec = !(g_variant & 2) && val16 && idx8;
         if (nogather)  launch_products<G, false, true, true>(a.nb, a);
@@ -497,17 +518,25 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
 #undef GO
 }
 
+template <int G, int DOT>
+void launch_products_dot(const LaunchArgs &a, const double *w, double *partial)
+{
+    constexpr Geometry g = kGeom[G];
+    spmv_csr_products_kernel<g.block, g.work, false, true, false, DOT>
+        <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial);
+}
+
 int launch_csr(liship_csr_plan_t p, const LaunchArgs &a)
 {
     if (a.nb <= 0) return 0;
     switch (p->geom) {
-        case 0: launch_geom<0>(a, p->unroll); break;
-        case 1: launch_geom<1>(a, p->unroll); break;
-        case 2: launch_geom<2>(a, p->unroll); break;
-        case 3: launch_geom<3>(a, p->unroll); break;
-        case 4: launch_geom<4>(a, p->unroll); break;
-        case 5: launch_geom<5>(a, p->unroll); break;
-        case 6: launch_geom<6>(a, p->unroll); break;
+        case 0: launch_geom<0>(a, p->unroll, p->products != 0); break;
+        case 1: launch_geom<1>(a, p->unroll, p->products != 0); break;
+        case 2: launch_geom<2>(a, p->unroll, p->products != 0); break;
+        case 3: launch_geom<3>(a, p->unroll, p->products != 0); break;
+        case 4: launch_geom<4>(a, p->unroll, p->products != 0); break;
+        case 5: launch_geom<5>(a, p->unroll, p->products != 0); break;
+        case 6: launch_geom<6>(a, p->unroll, p->products != 0); break;
         default: return LISHIP_ERR_ARG;
     }
     LAUNCH_CHECK();
@@ -534,12 +563,14 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
 {
     if (!p || !w || !result || !work) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
-    if (p->geom != 0 || g_variant != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    if (g_variant != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
     LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream)};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
-    if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial);
-    else            launch_rowgather_dot<0, 1>(a, p->unroll, w, partial);
+    if (p->products) {              // geometry 1
+        if (want_sumsq) launch_products_dot<1, 2>(a, w, partial); else launch_products_dot<1, 1>(a, w, partial);
+    } else if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial);
+    else                   launch_rowgather_dot<0, 1>(a, p->unroll, w, partial);
     LAUNCH_CHECK();
     return liship_internal_fold(p->nblocks, want_sumsq ? 2 : 1, p->nblocks, partial, spare, result, stream);
 }

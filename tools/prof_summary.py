@@ -20,12 +20,12 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         agg = defaultdict(lambda: [0.0, 0])
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                key = (row.get("Kernel_Name", "")[:70], row.get("Counter_Name"))
+                key = (row.get("Kernel_Name", "")[:110], row.get("Counter_Name"))
                 agg[key][0] += float(row.get("Counter_Value", 0))
                 agg[key][1] += 1
         lines.append("== PMC: " + os.path.relpath(f, out))
         for (k, c), (v, cnt) in sorted(agg.items()):
-            lines.append(f"{k:70s} {c:28s} per-launch={v/cnt:.6g} launches={cnt}")
+            lines.append(f"{k:110s} {c:28s} per-launch={v/cnt:.6g} launches={cnt}")
 txt = "\n".join(lines)
 open(os.path.join(out, "summary.txt"), "w").write(txt + "\n")
 print(txt)

@@ -42,6 +42,11 @@ int  liship_stream_destroy(void *stream);
 int  liship_stream_synchronize(void *stream);
 int  liship_device_synchronize(void);
 /* HIP-event stopwatch on `stream`: start/stop bracket a region, elapsed_ms reads it after stop+sync */
+/* stream-ordering events: record on one stream, make another stream wait (no host involvement) */
+int  liship_event_create(void **event);
+int  liship_event_destroy(void *event);
+int  liship_event_record(void *event, void *stream);
+int  liship_stream_wait_event(void *stream, void *event);
 int  liship_timer_create(void **timer);
 int  liship_timer_destroy(void *timer);
 int  liship_timer_start(void *timer, void *stream);

@@ -35,6 +35,10 @@ _LISHIP = {
     "liship_stream_destroy": (_ci, [_vp]),
     "liship_stream_synchronize": (_ci, [_vp]),
     "liship_device_synchronize": (_ci, []),
+    "liship_event_create": (_ci, [_pvp]),
+    "liship_event_destroy": (_ci, [_vp]),
+    "liship_event_record": (_ci, [_vp, _vp]),
+    "liship_stream_wait_event": (_ci, [_vp, _vp]),
     "liship_timer_create": (_ci, [_pvp]),
     "liship_timer_destroy": (_ci, [_vp]),
     "liship_timer_start": (_ci, [_vp, _vp]),

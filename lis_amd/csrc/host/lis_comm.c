@@ -102,6 +102,11 @@ LIS_INT lis_amd_comm_init_callbacks(const lis_amd_comm_callbacks *cb, LIS_INT ra
 LIS_INT lis_amd_comm_finalize(void)
 {
 	if (lisg.comm_kind == 1 && lisg.nccl_comm) { (void)liship_device_synchronize(); (void)rccl.CommDestroy(lisg.nccl_comm); }
+	if (lisg.comm_stream) {
+		(void)liship_event_destroy(lisg.ev_packed); (void)liship_event_destroy(lisg.ev_landed);
+		(void)liship_stream_destroy(lisg.comm_stream);
+		lisg.comm_stream = lisg.ev_packed = lisg.ev_landed = NULL;
+	}
 	if (lisg.gather_out) { (void)liship_free(lisg.gather_out); lisg.gather_out = NULL; }
 	lisg.nccl_comm = NULL; lisg.comm_kind = 0; lisg.rank = 0; lisg.nprocs = 1;
 	return LIS_SUCCESS;
@@ -315,6 +320,56 @@ LIS_INT lisc_halo_device(LIS_MATRIX A, double *dx)
 		return LIS_SUCCESS;
 	}
 	if (lisg.comm_kind == 2) {                  /* host round trip (tests / bring-up only) */
+		if (t->exnnz > 0) HIPCHK(liship_memcpy_d2h(t->ws, d->ws, sizeof(double) * (size_t)t->exnnz, lisg.stream));
+		HIPCHK(liship_stream_synchronize(lisg.stream));
+		if (lisg.cb.neighbor_exchange(lisg.cb.ctx, t->neibpetot, t->neibpe, t->ws, t->export_ptr, t->wr, t->import_ptr))
+			return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "neighbor_exchange callback failed\n");
+		if (t->imnnz > 0) HIPCHK(liship_memcpy_h2d(dx + n + pad, t->wr, sizeof(double) * (size_t)t->imnnz, lisg.stream));
+		return LIS_SUCCESS;
+	}
+	return LISI_ERR(LIS_ERR_ILL_ARG, "halo exchange without a communicator\n");
+}
+
+/* the same exchange split in two so the rows that reference no ghost column run while the planes travel:
+ *   begin: pack on the compute stream; RCCL send/recv on the second stream once the pack is done
+ *   end:   the compute stream waits for the landing (stream-side wait, the host does not block)
+ * With the callback backend (tests) `begin` only packs and `end` does the host round trip. */
+LIS_INT lisc_halo_begin(LIS_MATRIX A, double *dx)
+{
+	LIS_COMMTABLE t = A->commtable;
+	lisd_mat *d = MDEV(A);
+	if (!t || t->neibpetot == 0) return LIS_SUCCESS;
+	LISCHK(halo_tables_ready(A));
+	const LIS_INT n = A->n, pad = t->pad;
+	if (t->exnnz > 0) HIPCHK(liship_gather_f64(t->exnnz, d->export_index, dx, d->ws, lisg.stream));
+	if (lisg.comm_kind != 1) return LIS_SUCCESS;
+	if (!lisg.comm_stream) {
+		HIPCHK(liship_stream_create(&lisg.comm_stream));
+		HIPCHK(liship_event_create(&lisg.ev_packed));
+		HIPCHK(liship_event_create(&lisg.ev_landed));
+	}
+	HIPCHK(liship_event_record(lisg.ev_packed, lisg.stream));
+	HIPCHK(liship_stream_wait_event(lisg.comm_stream, lisg.ev_packed));
+	NCCLCHK(rccl.GroupStart());
+	for (LIS_INT i = 0; i < t->neibpetot; i++) {
+		const LIS_INT peer = t->neibpe[i];
+		const LIS_INT sc = t->export_ptr[i + 1] - t->export_ptr[i], rc = t->import_ptr[i + 1] - t->import_ptr[i];
+		if (sc > 0) NCCLCHK(rccl.Send(d->ws + t->export_ptr[i], (size_t)sc, NCCL_DOUBLE, peer, lisg.nccl_comm, lisg.comm_stream));
+		if (rc > 0) NCCLCHK(rccl.Recv(dx + n + pad + t->import_ptr[i], (size_t)rc, NCCL_DOUBLE, peer, lisg.nccl_comm, lisg.comm_stream));
+	}
+	NCCLCHK(rccl.GroupEnd());
+	HIPCHK(liship_event_record(lisg.ev_landed, lisg.comm_stream));
+	return LIS_SUCCESS;
+}
+
+LIS_INT lisc_halo_end(LIS_MATRIX A, double *dx)
+{
+	LIS_COMMTABLE t = A->commtable;
+	lisd_mat *d = MDEV(A);
+	if (!t || t->neibpetot == 0) return LIS_SUCCESS;
+	if (lisg.comm_kind == 1) { HIPCHK(liship_stream_wait_event(lisg.stream, lisg.ev_landed)); return LIS_SUCCESS; }
+	if (lisg.comm_kind == 2) {
+		const LIS_INT n = A->n, pad = t->pad;
 		if (t->exnnz > 0) HIPCHK(liship_memcpy_d2h(t->ws, d->ws, sizeof(double) * (size_t)t->exnnz, lisg.stream));
 		HIPCHK(liship_stream_synchronize(lisg.stream));
 		if (lisg.cb.neighbor_exchange(lisg.cb.ctx, t->neibpetot, t->neibpe, t->ws, t->export_ptr, t->wr, t->import_ptr))

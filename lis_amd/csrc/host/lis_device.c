@@ -274,6 +274,19 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 {
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_mat_ready(A));
+	if (lisg.nprocs > 1 && A->commtable && d->type == LIS_MATRIX_CSR && !lisg.no_overlap &&
+	    d->inner_end - d->inner_begin >= d->n / 2) {
+		/* rows [inner_begin, inner_end) reference no ghost column: they run while the halo is in flight; the
+		 * boundary rows follow once the ghosts have landed (same kernel, same bits: rows are independent) */
+		LISCHK(lisc_halo_begin(A, dx));
+		HIPCHK(liship_spmv_csr_rows_f64(d->plan, d->inner_begin, d->inner_end, d->ptr, d->index, d->value, dx, dy, lisg.stream));
+		LISCHK(lisc_halo_end(A, dx));
+		if (d->inner_begin > 0)
+			HIPCHK(liship_spmv_csr_rows_f64(d->plan, 0, d->inner_begin, d->ptr, d->index, d->value, dx, dy, lisg.stream));
+		if (d->inner_end < d->n)
+			HIPCHK(liship_spmv_csr_rows_f64(d->plan, d->inner_end, d->n, d->ptr, d->index, d->value, dx, dy, lisg.stream));
+		return LIS_SUCCESS;
+	}
 	if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
 	switch (d->type) {
 	case LIS_MATRIX_CSR:

@@ -93,6 +93,9 @@ typedef struct {
 	int rank, nprocs;
 	int comm_kind;             /* 0 none, 1 rccl, 2 callbacks */
 	void *nccl_comm;
+	void *comm_stream;         /* second HIP stream: halo send/recv overlapped with the interior rows */
+	void *ev_packed, *ev_landed;
+	int no_overlap;            /* LIS_AMD_NO_OVERLAP=1: exchange first, then the whole product (A/B measurements) */
 	lis_amd_comm_callbacks cb;
 } lisi_globals;
 extern lisi_globals lisg;
@@ -125,6 +128,8 @@ LIS_INT lisc_matrix_g2l(LIS_MATRIX A);                        /* global -> local
 LIS_INT lisc_commtable_create(LIS_MATRIX A);
 void    lisc_commtable_destroy(LIS_COMMTABLE t);
 LIS_INT lisc_reduce_device(LIS_MATRIX A, double *dy);         /* dy[export rows] += neighbours' dy[n..np) */
+LIS_INT lisc_halo_begin(LIS_MATRIX A, double *dx);            /* pack + start the exchange (second stream) */
+LIS_INT lisc_halo_end(LIS_MATRIX A, double *dx);              /* ghosts of dx are valid for work queued after this */
 LIS_INT lisc_halo_device(LIS_MATRIX A, double *dx);           /* fill dx[n..np) from the neighbours */
 LIS_INT lisc_fold(int count, double *host_inout);             /* sum over ranks, rank order */
 LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes);

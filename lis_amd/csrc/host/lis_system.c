@@ -188,6 +188,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		if (r && (strcmp(r, "resident") == 0 || strcmp(r, "1") == 0)) lisg.residency = LIS_AMD_RESIDENT;
 		r = getenv("LIS_AMD_NO_FUSION");
 		lisg.no_fusion = (r && r[0] == '1');
+		r = getenv("LIS_AMD_NO_OVERLAP");
+		lisg.no_overlap = (r && r[0] == '1');
 	}
 	return LIS_SUCCESS;
 }

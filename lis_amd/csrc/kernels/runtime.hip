@@ -36,6 +36,18 @@ extern "C" int liship_stream_destroy(void *stream) { if (stream) HIP_TRY(hipStre
 extern "C" int liship_stream_synchronize(void *stream) { HIP_TRY(hipStreamSynchronize(as_stream(stream))); return 0; }
 extern "C" int liship_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return 0; }
 
+// stream-ordering events (halo exchange on a second stream overlapped with the interior rows of the product)
+extern "C" int liship_event_create(void **ev)
+{
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = e;
+    return 0;
+}
+extern "C" int liship_event_destroy(void *ev) { if (ev) HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(ev))); return 0; }
+extern "C" int liship_event_record(void *ev, void *stream) { HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(ev), as_stream(stream))); return 0; }
+extern "C" int liship_stream_wait_event(void *stream, void *ev) { HIP_TRY(hipStreamWaitEvent(as_stream(stream), static_cast<hipEvent_t>(ev), 0)); return 0; }
+
 struct liship_timer { hipEvent_t a, b; };
 extern "C" int liship_timer_create(void **timer)
 {

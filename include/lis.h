@@ -488,6 +488,7 @@ LIS_INT lis_matrix_set_type(LIS_MATRIX A, LIS_INT matrix_type);
 LIS_INT lis_matrix_get_type(LIS_MATRIX A, LIS_INT *matrix_type);
 LIS_INT lis_matrix_set_value(LIS_INT flag, LIS_INT i, LIS_INT j, LIS_SCALAR value, LIS_MATRIX A);
 LIS_INT lis_matrix_get_diagonal(LIS_MATRIX A, LIS_VECTOR d);
+LIS_INT lis_matrix_scale(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_INT action);   /* ref:882, src/matrix/lis_matrix_ops.c:579 (-scale) */
 LIS_INT lis_matrix_convert(LIS_MATRIX Ain, LIS_MATRIX Aout);
 LIS_INT lis_matrix_copy(LIS_MATRIX Ain, LIS_MATRIX Aout);
 LIS_INT lis_matrix_set_blocksize(LIS_MATRIX A, LIS_INT bnr, LIS_INT bnc, LIS_INT row[], LIS_INT col[]);

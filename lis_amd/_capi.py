@@ -162,6 +162,7 @@ _PROTOS = {
     # matvec (lis.h:920)
     "lis_matvec": (LIS_INT, [PM, PV, PV]),
     "lis_matvech": (LIS_INT, [PM, PV, PV]),
+    "lis_matrix_scale": (LIS_INT, [PM, PV, PV, LIS_INT]),
     # solvers (lis.h:961-984)
     "lis_solver_create": (LIS_INT, [C.POINTER(PS)]),
     "lis_solver_destroy": (LIS_INT, [PS]),

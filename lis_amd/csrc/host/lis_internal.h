@@ -121,7 +121,7 @@ LIS_INT lisd_nrm1(int n, const double *dx, double *out);
 LIS_INT lisd_dot2(int n, const double *dx, const double *dy, double *out2);
 
 /* ---- communicator (lis_comm.c) */
-LIS_INT lisi_matrix_retype(LIS_MATRIX A, LIS_INT want);       /* convert an assembled matrix in place (lis_io.c) */
+LIS_INT lisi_matrix_retype(LIS_MATRIX A, LIS_INT want, LIS_INT block);       /* convert an assembled matrix in place (lis_io.c) */
 LIS_INT lisc_ranges_create(LIS_Comm comm, LIS_INT *local_n, LIS_INT *global_n, LIS_INT **ranges,
                            LIS_INT *is, LIS_INT *ie, LIS_INT *nprocs, LIS_INT *my_rank);
 LIS_INT lisc_matrix_g2l(LIS_MATRIX A);                        /* global -> local columns, ghosts appended */

@@ -266,11 +266,12 @@ fail:
 }
 
 /* storage type requested with lis_matrix_set_type before the read: convert in place (ref lis_input_mm.c:82-107) */
-LIS_INT lisi_matrix_retype(LIS_MATRIX A, LIS_INT want)
+LIS_INT lisi_matrix_retype(LIS_MATRIX A, LIS_INT want, LIS_INT block)
 {
 	if (want == A->matrix_type) return LIS_SUCCESS;
 	LIS_MATRIX B;
 	LISCHK(lis_matrix_duplicate(A, &B));
+	if (block > 0) LISCHK(lis_matrix_set_blocksize(B, block, block, NULL, NULL));
 	LISCHK(lis_matrix_set_type(B, want));
 	LIS_INT err = lis_matrix_convert(A, B);
 	if (err) { lis_matrix_destroy(B); return err; }
@@ -310,7 +311,7 @@ LIS_INT lis_input(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, char *filename)
 	if (!err) err = h.coordinate ? mm_read_csr(&s, &h, A, b, x) : mm_read_dense(&s, &h, A);
 	free(s.buf);
 	if (err) return err;
-	return lisi_matrix_retype(A, want);
+	return lisi_matrix_retype(A, want, 0);
 }
 
 LIS_INT lis_input_matrix(LIS_MATRIX A, char *filename) { return lis_input(A, NULL, NULL, filename); }

@@ -307,7 +307,7 @@ LIS_INT lis_matrix_assemble(LIS_MATRIX A)
 		LISCHK(assemble_rows_to_csr(A));
 		A->status = LIS_MATRIX_CSR; A->matrix_type = LIS_MATRIX_CSR;
 		if (lisg.nprocs > 1) { LISCHK(lisc_matrix_g2l(A)); LISCHK(lisc_commtable_create(A)); A->is_comm = LIS_TRUE; }
-		return lisi_matrix_retype(A, want);   /* ref lis_matrix.c:630-643: convert in place to the requested type */
+		return lisi_matrix_retype(A, want, 0);   /* ref lis_matrix.c:630-643: convert in place to the requested type */
 	}
 	if (A->status < 0 && A->n > 0) {
 		A->status = -A->status;

@@ -726,7 +726,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	const LIS_INT output = solver->options[LIS_OPTIONS_OUTPUT], storage = solver->options[LIS_OPTIONS_STORAGE];
 	const LIS_INT conv = solver->options[LIS_OPTIONS_CONV_COND];
 	const double tol = solver->params[LIS_PARAMS_RESID - LIS_OPTIONS_LEN];
-	LIS_MATRIX Awork = A, Aconv = NULL;
+	LIS_MATRIX Awork = A;
 	LIS_INT err = 0;
 	ctx_t c;
 	memset(&c, 0, sizeof(c));
@@ -738,7 +738,9 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	if (maxiter < 0) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_MAXITER(=%D) is less than 0\n", maxiter);
 	if (conv > 0 && nsolver == LIS_SOLVER_GMRES) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
 	if (solver->options[LIS_OPTIONS_PRECISION] != LIS_PRECISION_DOUBLE) return LISI_ERR(LIS_ERR_ILL_ARG, "Quad precision is not enabled\n");
-	if (solver->options[LIS_OPTIONS_SCALE] != LIS_SCALE_NONE) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "-scale is not served by liblis_amd\n");
+	LIS_INT scale = solver->options[LIS_OPTIONS_SCALE];
+	if (scale && storage == LIS_MATRIX_BSR && scale == LIS_SCALE_JACOBI)
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "block-diagonal scaling of BSR storage (-scale jacobi -storage bsr) is not served by liblis_amd\n");
 	if (nsolver == LIS_SOLVER_GMRES && solver->options[LIS_OPTIONS_RESTART] < 0)
 		return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_RESTART(=%D) is less than 0\n", solver->options[LIS_OPTIONS_RESTART]);
 	if (A->n != b->n || A->n != x->n) return LISI_ERR(LIS_ERR_ILL_ARG, "sizes of A, b and x do not match\n");
@@ -751,15 +753,26 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	solver->rhistory[0] = 1.0;
 	solver->ptime = 0.0;
 
+	/* -scale: A and b are scaled in place and stay scaled, CG turns jacobi into symm_diag (ref :686-724).  The
+	 * Jacobi preconditioner was built from the UNSCALED matrix by lis_solve before this point, as in the reference. */
+	if (scale) {
+		if (!solver->d) { err = lis_vector_duplicate(A, &solver->d); if (err) { solver->retcode = err; return err; } }
+		if (scale == LIS_SCALE_JACOBI && nsolver == LIS_SOLVER_CG) scale = LIS_SCALE_SYMM_DIAG;
+		if (!A->is_scaled) err = lis_matrix_scale(A, b, solver->d, scale);
+		else if (!b->is_scaled) {
+			err = lisd_vec_to_host(b);
+			if (!err) err = lisd_vec_to_host(solver->d);
+			if (!err) { for (LIS_INT i = 0; i < A->n; i++) b->value[i] = b->value[i] * solver->d->value[i]; lis_amd_vector_host_modified(b); }
+		}
+		if (err) { solver->retcode = err; return err; }
+	}
+
 	double t_itime = lis_wtime();
-	/* -storage: iterate on a converted copy (ref lis_matrix_convert_self, lis_matrix_ops.c:326) */
+	/* -storage: the caller's matrix itself is converted and stays converted (ref lis_matrix_convert_self,
+	 * lis_matrix_ops.c:326-372) */
 	if (storage && storage != A->matrix_type) {
-		err = lis_matrix_duplicate(A, &Aconv);
-		if (!err) err = lis_matrix_set_type(Aconv, storage);
-		if (!err && storage == LIS_MATRIX_BSR) err = lis_matrix_set_blocksize(Aconv, solver->options[LIS_OPTIONS_STORAGE_BLOCK], solver->options[LIS_OPTIONS_STORAGE_BLOCK], NULL, NULL);
-		if (!err) err = lis_matrix_convert(A, Aconv);
-		if (err) { if (Aconv) lis_matrix_destroy(Aconv); solver->retcode = err; return err; }
-		Awork = Aconv;
+		err = lisi_matrix_retype(A, storage, storage == LIS_MATRIX_BSR ? solver->options[LIS_OPTIONS_STORAGE_BLOCK] : 0);
+		if (err) { solver->retcode = err; return err; }
 	}
 
 	if (output) {
@@ -817,7 +830,12 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	{
 		double *dx;
 		if ((err = lisd_vec_out(x, &dx))) goto out;
-		int rc = liship_memcpy_d2d(dx, c.x, sizeof(double) * (size_t)A->n, lisg.stream);
+		int rc;
+		if (scale == LIS_SCALE_SYMM_DIAG) {             /* x = xx .* d  (ref :876-885) */
+			double *dd;
+			if ((err = lisd_vec_in(solver->d, &dd))) goto out;
+			rc = liship_pmul_f64(A->n, c.x, dd, dx, lisg.stream);
+		} else rc = liship_memcpy_d2d(dx, c.x, sizeof(double) * (size_t)A->n, lisg.stream);
 		if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
 		if ((err = lisd_vec_done(x))) goto out;
 	}
@@ -835,7 +853,6 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	}
 out:
 	if (c.x) (void)liship_free(c.x);
-	if (Aconv) lis_matrix_destroy(Aconv);
 	solver->precon = NULL;
 	if (err) solver->retcode = err;
 	return err;

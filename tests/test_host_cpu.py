@@ -279,3 +279,24 @@ def test_compute_fails_loudly_without_gpu(lib, capfd):
     lib.lis_solver_set_option(b"-i cg", S)
     assert lib.lis_solve(A, x, y, S) != 0
     assert "no CPU fallback" in capfd.readouterr().err
+
+
+# ------------------------------------------------------------------ -scale: host arithmetic, no GPU
+GS = np.load(os.path.join(ROOT, "tests", "golden", "scale_golden.npz"))
+
+
+@pytest.mark.parametrize("action", [1, 2])
+@pytest.mark.parametrize("fmt", ["csr", "csc", "ell", "dia", "jad", "bsr"])
+def test_matrix_scale_matches_reference_bits(lib, fmt, action):
+    """lis_matrix_scale: scaled values, b and d are the reference's bits, including its per-format association
+    of the two symmetric factors (lis_matrix_csr.c:687 vs lis_matrix_ell.c:821)."""
+    ptr, idx, val, b = (GS[k] for k in ("ptr", "idx", "val", "b"))
+    n = len(ptr) - 1
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    B = A if fmt == "csr" else lisdrv.convert(lib, A, fmt)
+    vb, vd = lisdrv.new_vector(lib, B, b), lisdrv.new_vector(lib, B)
+    assert lib.lis_matrix_scale(B, vb, vd, action) == 0
+    assert B.contents.is_scaled == 1 and vb.contents.is_scaled == 1
+    assert np.array_equal(lisdrv.matrix_arrays(B)["value"], GS[f"scale{action}/{fmt}/value"])
+    assert np.array_equal(np.ctypeslib.as_array(vb.contents.value, shape=(n,)), GS[f"scale{action}/{fmt}/b"])
+    assert np.array_equal(np.ctypeslib.as_array(vd.contents.value, shape=(n,)), GS[f"scale{action}/{fmt}/d"])

@@ -251,87 +251,7 @@ LIS_INT lis_precon_destroy(LIS_PRECON precon)
 	return LIS_SUCCESS;
 }
 
-/* ------------------------------------------------------------------ the device-side solve context */
-typedef struct {
-	LIS_SOLVER s;
-	LIS_MATRIX A;
-	int n;
-	size_t len;              /* doubles per work vector: np + pad + slack (ghost slots for the halo) */
-	double *b, *x;           /* HBM */
-	double *dinv;            /* Jacobi 1/diag in HBM, NULL for none */
-	double **work; int nwork;
-	double bnrm, tol;
-	int output, maxiter;
-} ctx_t;
-
-static LIS_INT work_alloc(ctx_t *c, int count)
-{
-	c->work = (double **)calloc((size_t)count, sizeof(double *));
-	c->nwork = count;
-	for (int i = 0; i < count; i++) {
-		HIPCHK(liship_malloc((void **)&c->work[i], c->len * sizeof(double)));
-		HIPCHK(liship_memset(c->work[i], 0, c->len * sizeof(double), lisg.stream));
-	}
-	return LIS_SUCCESS;
-}
-static void work_free(ctx_t *c)
-{
-	for (int i = 0; i < c->nwork; i++) (void)liship_free(c->work[i]);
-	free(c->work); c->work = NULL; c->nwork = 0;
-}
-
-#define K(call) HIPCHK(call)
-static LIS_INT d_copy(ctx_t *c, const double *src, double *dst) { K(liship_memcpy_d2d(dst, src, sizeof(double) * (size_t)c->n, lisg.stream)); return LIS_SUCCESS; }
-static LIS_INT d_psolve(ctx_t *c, const double *r, double *z)
-{	/* none: copy (lis_precon.c:365-384); Jacobi: z = r .* dinv (lis_precon_jacobi.c:121-124) */
-	if (c->dinv) { K(liship_pmul_f64(c->n, r, c->dinv, z, lisg.stream)); return LIS_SUCCESS; }
-	return d_copy(c, r, z);
-}
-static LIS_INT d_matvec(ctx_t *c, double *x, double *y) { return lisd_spmv(c->A, x, y); }
-static LIS_INT d_resid(ctx_t *c, const double *r, double *nrm)
-{	/* lis_solver_get_residual_nrm2_r (lis_solver.c:1792) / _nrm1_b (:1804) */
-	if (c->s->options[LIS_OPTIONS_CONV_COND] == LIS_CONV_COND_NRM1_B) return lisd_nrm1(c->n, r, nrm);
-	LISCHK(lisd_nrm2(c->n, r, nrm));
-	*nrm = *nrm * c->bnrm;
-	return LIS_SUCCESS;
-}
-static void note(ctx_t *c, LIS_INT iter, double nrm)
-{
-	if (!c->output) return;
-	if (c->output & LIS_PRINT_MEM) c->s->rhistory[iter] = nrm;
-	if (c->output & LIS_PRINT_OUT) lis_printf(LIS_COMM_WORLD, "iteration: %5d  relative residual = %e\n", (int)iter, nrm);
-}
-
-/* r = b - A x (or b when x0 = 0), scaling 1/||r||, early exit when already converged: lis_solver.c:957-1091.
- * returns 1 when the caller must stop (converged), 0 to iterate, <0 on error (-err) */
-static int initial_residual(ctx_t *c, double *r)
-{
-	LIS_SOLVER s = c->s;
-	const int conv = s->options[LIS_OPTIONS_CONV_COND];
-	const double tol = s->params[LIS_PARAMS_RESID - LIS_OPTIONS_LEN], tol_w = s->params[LIS_PARAMS_RESID_WEIGHT - LIS_OPTIONS_LEN];
-	LIS_INT err = 0;
-	if (!s->options[LIS_OPTIONS_INITGUESS_ZEROS]) {
-		err = d_matvec(c, c->x, r);
-		if (!err && liship_xpay_f64(c->n, c->b, -1.0, r, lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
-	} else err = d_copy(c, c->b, r);
-	if (err) return -(int)err;
-	double nrm = 0.0, bn = 0.0;
-	switch (conv) {
-	case LIS_CONV_COND_NRM2_R: err = lisd_nrm2(c->n, r, &nrm); bn = nrm; s->tol = tol; break;
-	case LIS_CONV_COND_NRM2_B: err = lisd_nrm2(c->n, r, &nrm); if (!err) err = lisd_nrm2(c->n, c->b, &bn); s->tol = tol; break;
-	default:                   err = lisd_nrm1(c->n, r, &nrm); if (!err) err = lisd_nrm1(c->n, c->b, &bn); s->tol = bn * tol_w + tol; break;
-	}
-	if (err) return -(int)err;
-	s->tol_switch = s->params[LIS_PARAMS_SWITCH_RESID - LIS_OPTIONS_LEN];
-	bn = (bn == 0.0) ? 1.0 : 1.0 / bn;
-	s->bnrm = bn; c->bnrm = bn; c->tol = s->tol;
-	nrm = nrm * bn;
-	if (nrm <= fabs(tol)) { s->retcode = LIS_SUCCESS; s->iter = 1; s->resid = nrm; return 1; }
-	return 0;
-}
-
-#define TRY(expr) do { LIS_INT e__ = (expr); if (e__) { err = e__; goto done; } } while (0)
-#define KTRY(call) do { int rc__ = (call); if (rc__) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc__); goto done; } } while (0)
+#include "lis_krylov.h"
 
 /* residual norm from a sum of squares the fused kernels already produced (lis_solver.c:1792); the
  * 1-norm criterion (:1804) has no fused form and takes its own pass */
@@ -733,15 +653,21 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 
 	/* parameter checks, ref :482-537 */
 	if (nsolver < 1 || nsolver > LIS_SOLVER_LEN) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_SOLVER is %D (Set between 1 to %D)\n", nsolver, LIS_SOLVER_LEN);
-	if (nsolver != LIS_SOLVER_CG && nsolver != LIS_SOLVER_BICG && nsolver != LIS_SOLVER_BICGSTAB && nsolver != LIS_SOLVER_GMRES)
-		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s is not served by liblis_amd (cg, bicg, bicgstab, gmres)\n", solver_names[nsolver]);
+	switch (nsolver) {
+	case LIS_SOLVER_CG: case LIS_SOLVER_BICG: case LIS_SOLVER_BICGSTAB: case LIS_SOLVER_GMRES:
+	case LIS_SOLVER_CGS: case LIS_SOLVER_CR: case LIS_SOLVER_GPBICG: case LIS_SOLVER_TFQMR: case LIS_SOLVER_BICGSAFE:
+	case LIS_SOLVER_ORTHOMIN:
+		break;
+	default:
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s is not served by liblis_amd (cg, bicg, cgs, bicgstab, gpbicg, tfqmr, orthomin, gmres, bicgsafe, cr)\n", solver_names[nsolver]);
+	}
 	if (maxiter < 0) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_MAXITER(=%D) is less than 0\n", maxiter);
-	if (conv > 0 && nsolver == LIS_SOLVER_GMRES) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
+	if (conv > 0 && (nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_TFQMR)) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
 	if (solver->options[LIS_OPTIONS_PRECISION] != LIS_PRECISION_DOUBLE) return LISI_ERR(LIS_ERR_ILL_ARG, "Quad precision is not enabled\n");
 	LIS_INT scale = solver->options[LIS_OPTIONS_SCALE];
 	if (scale && storage == LIS_MATRIX_BSR && scale == LIS_SCALE_JACOBI)
 		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "block-diagonal scaling of BSR storage (-scale jacobi -storage bsr) is not served by liblis_amd\n");
-	if (nsolver == LIS_SOLVER_GMRES && solver->options[LIS_OPTIONS_RESTART] < 0)
+	if ((nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_ORTHOMIN) && solver->options[LIS_OPTIONS_RESTART] < 0)
 		return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_RESTART(=%D) is less than 0\n", solver->options[LIS_OPTIONS_RESTART]);
 	if (A->n != b->n || A->n != x->n) return LISI_ERR(LIS_ERR_ILL_ARG, "sizes of A, b and x do not match\n");
 
@@ -819,6 +745,12 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	case LIS_SOLVER_CG:       err = run_cg(&c); break;
 	case LIS_SOLVER_BICG:     err = run_bicg(&c); break;
 	case LIS_SOLVER_BICGSTAB: err = run_bicgstab(&c); break;
+	case LIS_SOLVER_CGS:      err = lisk_cgs(&c); break;
+	case LIS_SOLVER_CR:       err = lisk_cr(&c); break;
+	case LIS_SOLVER_GPBICG:   err = lisk_gpbicg(&c); break;
+	case LIS_SOLVER_TFQMR:    err = lisk_tfqmr(&c); break;
+	case LIS_SOLVER_BICGSAFE: err = lisk_bicgsafe(&c); break;
+	case LIS_SOLVER_ORTHOMIN: err = lisk_orthomin(&c); break;
 	default:                  err = run_gmres(&c); break;
 	}
 	const LIS_INT solver_code = err;

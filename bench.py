@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--preroll", type=int, default=600,
                     help="untimed clock-ramp steps before the W warm-up steps: a fresh box's first process measured "
                          "7 %% slower for its first ~second of kernels (DESIGN.md 5); same count on every rank")
+    ap.add_argument("--comm", choices=["rccl", "callbacks"], default="rccl",
+                    help="callbacks: collectives through torch.distributed/gloo host callbacks -- bring-up of the N>1 "
+                         "path with several ranks on ONE GPU (RCCL refuses that); never a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solvers", action="store_true")
     return ap.parse_args()
@@ -74,7 +77,13 @@ def main():
     if world == 1:
         os.environ.setdefault("LIS_AMD_DEVICE", str(local_rank))
     assert lib.initialize([]) == 0
-    if world > 1:
+    if world > 1 and args.comm == "callbacks":
+        from lis_amd._hostcomm import make_callbacks
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        os.environ["LIS_AMD_DEVICE"] = str(local_rank)
+        cb = make_callbacks(world)
+        assert dll.lis_amd_comm_init_callbacks(C.byref(cb), rank, world) == 0
+    elif world > 1:
         uid = [None]
         if rank == 0:
             buf = (C.c_char * 128)()
@@ -197,7 +206,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"3-D 7-point Poisson {N}^3, CSR f64/i32, y=A*x via lis_matvec (x=1), test3.c entry order",
-                       "n": n_global, "nnz": nnz_global, "parallelism": f"row-block x{world}" + (" + RCCL halo" if world > 1 else "")},
+                       "n": n_global, "nnz": nnz_global, "parallelism": f"row-block x{world}" + ((" + RCCL halo" if args.comm == "rccl" else " + gloo-callback halo (bring-up, not a measurement)") if world > 1 else "")},
             "roofline": roofline,
             "hbm_roofline_pct_whole_job": round(100.0 * (12 * nnz_global + 20 * n_global) / (ms_per_step * 1e-3) / 1e9
                                                 / (HBM_PEAK_GBS * world), 2),

@@ -22,44 +22,7 @@ import lisdrv  # noqa: E402
 import orc  # noqa: E402
 from lis_amd import _capi as capi  # noqa: E402
 
-ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
-EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
-                       C.POINTER(C.c_double), C.POINTER(C.c_int))
-
-
-class Callbacks(C.Structure):
-    _fields_ = [("allgather", ALLGATHER), ("neighbor_exchange", EXCHANGE), ("ctx", C.c_void_p)]
-
-
-def make_callbacks(world):
-    def allgather(ctx, send, recv, nbytes):
-        src = torch.from_numpy(np.frombuffer(C.string_at(send, nbytes), dtype=np.uint8).copy())
-        outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
-        dist.all_gather(outs, src)
-        flat = torch.cat(outs).numpy()
-        C.memmove(recv, flat.ctypes.data, nbytes * world)
-        return 0
-
-    def exchange(ctx, nneib, neib, sendbuf, sptr, recvbuf, rptr):
-        reqs, recvs = [], []
-        for i in range(nneib):
-            sc, rc = sptr[i + 1] - sptr[i], rptr[i + 1] - rptr[i]
-            if sc > 0:
-                t = torch.from_numpy(np.ctypeslib.as_array(sendbuf, shape=(sptr[nneib],))[sptr[i]:sptr[i + 1]].copy())
-                reqs.append(dist.isend(t, dst=neib[i]))
-            if rc > 0:
-                t = torch.empty(rc, dtype=torch.float64)
-                recvs.append((t, rptr[i]))
-                reqs.append(dist.irecv(t, src=neib[i]))
-        for r in reqs:
-            r.wait()
-        for t, off in recvs:
-            arr = t.numpy()
-            C.memmove(C.addressof(recvbuf.contents) + 8 * off, arr.ctypes.data, 8 * arr.size)
-        return 0
-
-    cb = Callbacks(ALLGATHER(allgather), EXCHANGE(exchange), None)
-    return cb
+from lis_amd._hostcomm import Callbacks, make_callbacks  # noqa: E402,F401
 
 
 def isie(rank, world, n):

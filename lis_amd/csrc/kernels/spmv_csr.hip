@@ -44,7 +44,6 @@ constexpr Geometry kGeom[] = {
 constexpr int kNumGeom = sizeof(kGeom) / sizeof(kGeom[0]);
 constexpr int ROW_ALIGN = 16;    // rows per 128 B line of y / x
 constexpr int SLACK = 128;       // extra items a block may take to start on an aligned row
-constexpr int BATCH = 4;         // products kernel: independent load pairs in flight per lane
 
 // Experiment knob (liship_spmv_csr_set_variant); 0 is the shipped configuration.
 //   bit0  XCD-run block order (each XCD walks runs of consecutive row blocks; measured slower: the x
@@ -101,13 +100,16 @@ __device__ __forceinline__ bool clip_rows(Blk &B, const int *__restrict__ ptr, i
 
 // ------------------------------------------------------------------------------ products kernel
 // products for non-zeros [kbeg,kend) -> prod[k - ka]; ka is kbeg rounded down to even
-template <int BLOCK, bool VEC, bool NOGATHER>
+// VEC: 0 = scalar loads; 2 / 4 = 16 B value + 8 B index loads with that many independent pairs in flight per lane
+// (4 for rows of 14-24 entries, 2 beyond: measured on banded and FEM patterns, tools/rowlen_sweep.py, irregular_sweep.py)
+template <int BLOCK, int VEC, bool NOGATHER>
 __device__ __forceinline__ void stage_products(double *prod, const int *__restrict__ idx,
                                                const double *__restrict__ val,
                                                const double *__restrict__ x,
                                                int kbeg, int kend, int ka)
 {
     if (VEC) {
+        constexpr int BATCH = VEC ? VEC : 1;
         const int npairs = (kend - ka) >> 1;
         for (int base = 0; base < npairs; base += BATCH * BLOCK) {
             v2f64 v[BATCH];
@@ -189,7 +191,7 @@ struct RowDots {
 
 // one whole row block of any shape (many empty rows, rows longer than the LDS stage).
 // Invariant from the plan: every row but the last ends inside the first pass of CAP products.
-template <int BLOCK, int CAP, bool VEC, bool NOGATHER, int DOT = 0>
+template <int BLOCK, int CAP, int VEC, bool NOGATHER, int DOT = 0>
 __device__ __forceinline__ void block_by_products(double *prod, const int *__restrict__ ptr,
                                                   const int *__restrict__ idx, const double *__restrict__ val,
                                                   const double *__restrict__ x, double *__restrict__ y,
@@ -245,7 +247,7 @@ __device__ __forceinline__ void publish_dots(const RowDots<DOT> &dots, double *s
     }
 }
 
-template <int BLOCK, int WORK, bool XRUN, bool VEC, bool NOGATHER, int DOT = 0>
+template <int BLOCK, int WORK, bool XRUN, int VEC, bool NOGATHER, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                               const double *__restrict__ val, const double *__restrict__ x,
@@ -296,7 +298,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     const int ka = B.k0 & ~3;                       // 16 B aligned start for both streams
     const int nq = (B.k1 - ka + 3) >> 2;            // quads of 4 non-zeros
     if ((B.k1 - ka) > CAP || ka + 4 * nq > nnz_total) {     // long row / tail of the arrays
-        block_by_products<BLOCK, CAP, true, NOGATHER, DOT>(valL, ptr, idx, val, x, y, B, dots);
+        block_by_products<BLOCK, CAP, 4, NOGATHER, DOT>(valL, ptr, idx, val, x, y, B, dots);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
         return;
@@ -388,6 +390,7 @@ struct liship_csr_plan_s {
     int geom;            // index into kGeom the split was built for
     int unroll;          // gather unroll U chosen from the mean row length
     int products;        // long rows on average: the products kernel (lanes own non-zeros) instead of row-gather
+    int batch;           // its independent load pairs in flight per lane (2 or 4)
     v2i32 *blk;          // device, nblocks + 1 entries {row, ptr[row]}
     v2i32 *blk_host;     // host copy (row-range launches)
 };
@@ -415,6 +418,9 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     // lanes own non-zeros instead (measured crossover, tools/rowlen_sweep.py)
     p->products = (g_variant == 0 && mean_len >= 14.0) ? 1 : 0;
     if (p->products) p->geom = 1;
+    p->batch = mean_len >= 24.0 ? 2 : 4;
+    if (g_variant & 0x4000000) p->batch = 4;              // experiment knobs
+    if (g_variant & 0x8000000) p->batch = 2;
     const int WORK = kGeom[p->geom].work;
     p->nblocks = (int)((items + WORK - 1) / WORK);
     p->blk = nullptr;
@@ -472,7 +478,7 @@ void launch_rowgather(int grid, const LaunchArgs &a)
         <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, xcd_run());
 }
 
-template <int G, bool XRUN, bool VEC, bool NOGATHER>
+template <int G, bool XRUN, int VEC, bool NOGATHER>
 void launch_products(int grid, const LaunchArgs &a)
 {
     constexpr Geometry g = kGeom[G];
@@ -481,7 +487,7 @@ void launch_products(int grid, const LaunchArgs &a)
 }
 
 template <int G>
-void launch_geom(const LaunchArgs &a, int unroll, bool plan_products)
+void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
 {
     const bool nogather = (g_variant & 0x100) != 0;
     const bool xrun = (g_variant & 1) && a.nb >= 4 * NUM_XCD;
@@ -492,9 +498,11 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products)
     const bool products = plan_products || (g_variant & 6) != 0 || !(val16 && idx16);
     if (products) {
         const bool vec = !(g_variant & 2) && val16 && idx8;
-        if (nogather)  launch_products<G, false, true, true>(a.nb, a);
-        else if (xrun) { if (vec) launch_products<G, true, true, false>(grid, a); else launch_products<G, true, false, false>(grid, a); }
-        else           { if (vec) launch_products<G, false, true, false>(grid, a); else launch_products<G, false, false, false>(grid, a); }
+        if (nogather)  launch_products<G, false, 4, true>(a.nb, a);
+        else if (xrun) { if (vec) launch_products<G, true, 4, false>(grid, a); else launch_products<G, true, 0, false>(grid, a); }
+        else if (!vec) launch_products<G, false, 0, false>(grid, a);
+        else if (batch == 2) launch_products<G, false, 2, false>(grid, a);
+        else           launch_products<G, false, 4, false>(grid, a);
         return;
     }
     const int usel = (g_variant >> 11) & 3;
@@ -519,24 +527,28 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
 }
 
 template <int G, int DOT>
-void launch_products_dot(const LaunchArgs &a, const double *w, double *partial)
+void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double *partial)
 {
     constexpr Geometry g = kGeom[G];
-    spmv_csr_products_kernel<g.block, g.work, false, true, false, DOT>
-        <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial);
+    if (batch == 2)
+        spmv_csr_products_kernel<g.block, g.work, false, 2, false, DOT>
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial);
+    else
+        spmv_csr_products_kernel<g.block, g.work, false, 4, false, DOT>
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial);
 }
 
 int launch_csr(liship_csr_plan_t p, const LaunchArgs &a)
 {
     if (a.nb <= 0) return 0;
     switch (p->geom) {
-        case 0: launch_geom<0>(a, p->unroll, p->products != 0); break;
-        case 1: launch_geom<1>(a, p->unroll, p->products != 0); break;
-        case 2: launch_geom<2>(a, p->unroll, p->products != 0); break;
-        case 3: launch_geom<3>(a, p->unroll, p->products != 0); break;
-        case 4: launch_geom<4>(a, p->unroll, p->products != 0); break;
-        case 5: launch_geom<5>(a, p->unroll, p->products != 0); break;
-        case 6: launch_geom<6>(a, p->unroll, p->products != 0); break;
+        case 0: launch_geom<0>(a, p->unroll, p->products != 0, p->batch); break;
+        case 1: launch_geom<1>(a, p->unroll, p->products != 0, p->batch); break;
+        case 2: launch_geom<2>(a, p->unroll, p->products != 0, p->batch); break;
+        case 3: launch_geom<3>(a, p->unroll, p->products != 0, p->batch); break;
+        case 4: launch_geom<4>(a, p->unroll, p->products != 0, p->batch); break;
+        case 5: launch_geom<5>(a, p->unroll, p->products != 0, p->batch); break;
+        case 6: launch_geom<6>(a, p->unroll, p->products != 0, p->batch); break;
         default: return LISHIP_ERR_ARG;
     }
     LAUNCH_CHECK();
@@ -568,7 +580,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream)};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (p->products) {              // geometry 1
-        if (want_sumsq) launch_products_dot<1, 2>(a, w, partial); else launch_products_dot<1, 1>(a, w, partial);
+        if (want_sumsq) launch_products_dot<1, 2>(a, p->batch, w, partial); else launch_products_dot<1, 1>(a, p->batch, w, partial);
     } else if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial);
     else                   launch_rowgather_dot<0, 1>(a, p->unroll, w, partial);
     LAUNCH_CHECK();

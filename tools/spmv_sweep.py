@@ -14,7 +14,7 @@ import lis_amd  # noqa: E402
 from lis_amd import DeviceArray as DA, check  # noqa: E402
 
 
-def timed(lib, fn, iters=20, warm=3):
+def timed(lib, fn, iters=30, warm=25):
     t = C.c_void_p()
     check(lib.liship_timer_create(C.byref(t)))
     for _ in range(warm):

@@ -97,5 +97,12 @@ LIS_INT lisk_gpbicg(ctx_t *c);
 LIS_INT lisk_tfqmr(ctx_t *c);
 LIS_INT lisk_bicgsafe(ctx_t *c);
 LIS_INT lisk_orthomin(ctx_t *c);
+LIS_INT lisk_gpbicr(ctx_t *c);
+LIS_INT lisk_bicr(ctx_t *c);
+LIS_INT lisk_crs(ctx_t *c);
+LIS_INT lisk_bicrstab(ctx_t *c);
+LIS_INT lisk_bicrsafe(ctx_t *c);
+LIS_INT lisk_fgmres(ctx_t *c);
+LIS_INT lisk_minres(ctx_t *c);
 
 #endif

@@ -656,18 +656,19 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	switch (nsolver) {
 	case LIS_SOLVER_CG: case LIS_SOLVER_BICG: case LIS_SOLVER_BICGSTAB: case LIS_SOLVER_GMRES:
 	case LIS_SOLVER_CGS: case LIS_SOLVER_CR: case LIS_SOLVER_GPBICG: case LIS_SOLVER_TFQMR: case LIS_SOLVER_BICGSAFE:
-	case LIS_SOLVER_ORTHOMIN:
+	case LIS_SOLVER_ORTHOMIN: case LIS_SOLVER_BICR: case LIS_SOLVER_CRS: case LIS_SOLVER_BICRSTAB: case LIS_SOLVER_GPBICR:
+	case LIS_SOLVER_BICRSAFE: case LIS_SOLVER_FGMRES: case LIS_SOLVER_MINRES: case LIS_SOLVER_COCG: case LIS_SOLVER_COCR:
 		break;
-	default:
-		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s is not served by liblis_amd (cg, bicg, cgs, bicgstab, gpbicg, tfqmr, orthomin, gmres, bicgsafe, cr)\n", solver_names[nsolver]);
+	default:      /* BiCGSTAB(l), IDR(s), IDR(1) and the stationary Jacobi / Gauss-Seidel / SOR iterations */
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s is not served by liblis_amd\n", solver_names[nsolver]);
 	}
 	if (maxiter < 0) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_MAXITER(=%D) is less than 0\n", maxiter);
-	if (conv > 0 && (nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_TFQMR)) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
+	if (conv > 0 && (nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_TFQMR || nsolver == LIS_SOLVER_FGMRES || nsolver == LIS_SOLVER_MINRES)) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
 	if (solver->options[LIS_OPTIONS_PRECISION] != LIS_PRECISION_DOUBLE) return LISI_ERR(LIS_ERR_ILL_ARG, "Quad precision is not enabled\n");
 	LIS_INT scale = solver->options[LIS_OPTIONS_SCALE];
 	if (scale && storage == LIS_MATRIX_BSR && scale == LIS_SCALE_JACOBI)
 		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "block-diagonal scaling of BSR storage (-scale jacobi -storage bsr) is not served by liblis_amd\n");
-	if ((nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_ORTHOMIN) && solver->options[LIS_OPTIONS_RESTART] < 0)
+	if ((nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_ORTHOMIN || nsolver == LIS_SOLVER_FGMRES) && solver->options[LIS_OPTIONS_RESTART] < 0)
 		return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_RESTART(=%D) is less than 0\n", solver->options[LIS_OPTIONS_RESTART]);
 	if (A->n != b->n || A->n != x->n) return LISI_ERR(LIS_ERR_ILL_ARG, "sizes of A, b and x do not match\n");
 
@@ -751,6 +752,15 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	case LIS_SOLVER_TFQMR:    err = lisk_tfqmr(&c); break;
 	case LIS_SOLVER_BICGSAFE: err = lisk_bicgsafe(&c); break;
 	case LIS_SOLVER_ORTHOMIN: err = lisk_orthomin(&c); break;
+	case LIS_SOLVER_BICR:     err = lisk_bicr(&c); break;
+	case LIS_SOLVER_CRS:      err = lisk_crs(&c); break;
+	case LIS_SOLVER_BICRSTAB: err = lisk_bicrstab(&c); break;
+	case LIS_SOLVER_GPBICR:   err = lisk_gpbicr(&c); break;
+	case LIS_SOLVER_BICRSAFE: err = lisk_bicrsafe(&c); break;
+	case LIS_SOLVER_FGMRES:   err = lisk_fgmres(&c); break;
+	case LIS_SOLVER_MINRES:   err = lisk_minres(&c); break;
+	case LIS_SOLVER_COCG:     err = run_cg(&c); break;          /* real build: lis_cocg is lis_cg's arithmetic (lis_solver_cg.c:632-739) */
+	case LIS_SOLVER_COCR:     err = lisk_cr(&c); break;         /* and lis_cocr is lis_cr's (:1155-1274) */
 	default:                  err = run_gmres(&c); break;
 	}
 	const LIS_INT solver_code = err;

@@ -6,9 +6,15 @@
  * (element-wise results are bit-identical, reductions are the deterministic trees of vector_ops.hip), so the
  * recurrences see the same numbers as the CPU path up to the reduction order.  No pass fusion here: these are
  * coverage, CG / BiCG / BiCGSTAB / GMRES in lis_solver.c are the tuned ones.
- *   CGS       src/solver/lis_solver_cgs.c:128-262        CR         lis_solver_cg.c:681-795
- *   GPBiCG    lis_solver_gpbicg.c:145-351                TFQMR      lis_solver_qmr.c:113-300
- *   BiCGSafe  lis_solver_bicgsafe.c:145-326              Orthomin   lis_solver_orthomin.c:124-252
+ *   CGS       src/solver/lis_solver_cgs.c:134-276        CR         lis_solver_cg.c:821-940
+ *   GPBiCG    lis_solver_gpbicg.c:145-351                TFQMR      lis_solver_qmr.c:113-299
+ *   BiCGSafe  lis_solver_bicgsafe.c:145-322              Orthomin   lis_solver_orthomin.c:124-250
+ * and the conjugate-residual family + the rest that needs no new kernel:
+ *   BiCR      lis_solver_bicg.c:788-926 (uses A^T)       CRS        lis_solver_cgs.c:805-938
+ *   BiCRSTAB  lis_solver_bicgstab.c:951-1098             GPBiCR     lis_solver_gpbicg.c:1349-1556
+ *   BiCRSafe  lis_solver_bicgsafe.c:1048-1227            FGMRES(m)  lis_solver_gmres.c:1128-1303
+ *   MINRES    lis_solver_minres.c:121-258                COCG/COCR  lis_solver_cg.c:632-739, :1155-1274 (real build:
+ *                                                                   the arithmetic of CG / CR)
  */
 #include "lis_krylov.h"
 
@@ -31,7 +37,7 @@ LIS_INT lisk_cgs(ctx_t *c)
 	double nrm2 = 0.0, rho, rho_old = 1.0, alpha, beta, d1;
 	TRY(work_alloc(c, 7));
 	double *rtld = c->work[0], *r = c->work[1], *p = c->work[2], *phat = c->work[3], *q = c->work[4],
-	       *qhat = c->work[5], *u = c->work[5], *uhat = c->work[6], *vhat = c->work[6];      /* aliases as :147-153 */
+	       *qhat = c->work[5], *u = c->work[5], *uhat = c->work[6], *vhat = c->work[6];      /* aliases as in the reference */
 	int st = initial_residual(c, r);
 	if (st) { err = st < 0 ? -st : 0; goto done; }
 	COPY(r, rtld);
@@ -110,7 +116,13 @@ static void qsi_eta(int first, const double *t, double *qsi, double *eta)
 	*eta = (t[4] * t[2] - t[3] * t[1]) / tmp;
 }
 
-LIS_INT lisk_gpbicg(ctx_t *c)
+static LIS_INT gpbi(ctx_t *c, int cr);
+LIS_INT lisk_gpbicg(ctx_t *c) { return gpbi(c, 0); }
+LIS_INT lisk_gpbicr(ctx_t *c) { return gpbi(c, 1); }
+
+/* GPBiCG, and GPBiCR (cr): the same recurrences with the shadow residual A^T r0 and the dots taken against the
+ * preconditioned vectors (lis_solver_gpbicg.c:1349-1556) */
+static LIS_INT gpbi(ctx_t *c, int cr)
 {
 	LIS_SOLVER s = c->s;
 	LIS_INT err = 0, iter = 0;
@@ -122,13 +134,13 @@ LIS_INT lisk_gpbicg(ctx_t *c)
 	       *z = c->work[12], *mt_old = c->work[13];
 	int st = initial_residual(c, r);
 	if (st) { err = st < 0 ? -st : 0; goto done; }
-	COPY(r, rtld);
+	if (cr) { COPY(r, p); TRY(lisd_spmv_t(c->A, p, rtld)); } else COPY(r, rtld);
 	PSOLVE(r, p);
-	DOT(rtld, r, &rho_old);
+	DOT(rtld, cr ? p : r, &rho_old);
 	for (iter = 1; iter <= c->maxiter; iter++) {
 		MATVEC(p, ap);
 		PSOLVE(ap, map);
-		DOT(rtld, ap, &t5[0]);
+		DOT(rtld, cr ? map : ap, &t5[0]);
 		if (t5[0] == 0.0) FINISH(LIS_BREAKDOWN);
 		alpha = rho_old / t5[0];
 		AXPYZ(-1.0, w, ap, y);                /* y = t - r + alpha (ap - w) */
@@ -160,7 +172,7 @@ LIS_INT lisk_gpbicg(ctx_t *c)
 		note(c, iter, nrm2);
 		if (c->tol >= nrm2) FINISH(LIS_SUCCESS);
 		PSOLVE(r, mr);
-		DOT(rtld, r, &rho);
+		DOT(rtld, cr ? mr : r, &rho);
 		if (rho == 0.0) FINISH(LIS_BREAKDOWN);
 		beta = (rho / rho_old) * (alpha / qsi);
 		AXPYZ(beta, ap, amt, w);              /* w = amt + beta ap */
@@ -338,5 +350,347 @@ LIS_INT lisk_orthomin(ctx_t *c)
 done:
 	work_free(c);
 	free(dotsave);
+	return err;
+}
+
+LIS_INT lisk_bicr(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter = 0;
+	const int n = c->n;
+	double nrm2 = 0.0, rho, rho_old, alpha, beta, d1;
+	TRY(work_alloc(c, 10));
+	double *r = c->work[0], *rtld = c->work[1], *z = c->work[2], *ztld = c->work[3], *p = c->work[4], *ptld = c->work[5],
+	       *ap = c->work[6], *az = c->work[7], *map = c->work[8], *aptld = c->work[9];
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	COPY(r, rtld);
+	PSOLVE(r, z);
+	PSOLVE(rtld, ztld);                           /* M^-H = M^-1 for none / Jacobi */
+	COPY(z, p);
+	COPY(ztld, ptld);
+	MATVEC(z, ap);
+	DOT(ztld, ap, &rho_old);
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		TRY(lisd_spmv_t(c->A, ptld, aptld));
+		PSOLVE(ap, map);
+		DOT(aptld, map, &d1);
+		if (d1 == 0.0) FINISH(LIS_BREAKDOWN);
+		alpha = rho_old / d1;
+		AXPY(alpha, p, c->x);
+		AXPY(-alpha, ap, r);
+		RESID(r, &nrm2);
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) FINISH(LIS_SUCCESS);
+		AXPY(-alpha, aptld, rtld);
+		AXPY(-alpha, map, z);
+		PSOLVE(rtld, ztld);
+		MATVEC(z, az);
+		DOT(ztld, az, &rho);
+		if (rho == 0.0) FINISH(LIS_BREAKDOWN);
+		beta = rho / rho_old;
+		XPAY(z, beta, p);
+		XPAY(ztld, beta, ptld);
+		XPAY(az, beta, ap);
+		rho_old = rho;
+	}
+	FINISH(LIS_MAXITER);
+done:
+	work_free(c);
+	return err;
+}
+
+LIS_INT lisk_crs(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter = 0;
+	const int n = c->n;
+	double nrm2 = 0.0, rho, rho_old = 1.0, alpha, beta, d1;
+	TRY(work_alloc(c, 6));
+	double *r = c->work[0], *rtld = c->work[1], *p = c->work[2], *z = c->work[3], *u = c->work[3], *uq = c->work[3],
+	       *q = c->work[4], *ap = c->work[4], *map = c->work[5], *auq = c->work[5];           /* aliases as in the reference */
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	COPY(r, p);
+	TRY(lisd_spmv_t(c->A, p, rtld));              /* shadow residual A^T r0 */
+	KTRY(liship_set_all_f64(n, 0.0, q, lisg.stream));
+	KTRY(liship_set_all_f64(n, 0.0, p, lisg.stream));
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		PSOLVE(r, z);
+		DOT(rtld, z, &rho);
+		if (rho == 0.0) FINISH(LIS_BREAKDOWN);
+		beta = rho / rho_old;
+		AXPYZ(beta, q, z, u);
+		XPAY(q, beta, p);
+		XPAY(u, beta, p);
+		MATVEC(p, ap);
+		PSOLVE(ap, map);
+		DOT(rtld, map, &d1);
+		if (d1 == 0.0) FINISH(LIS_BREAKDOWN);
+		alpha = rho / d1;
+		AXPYZ(-alpha, map, u, q);
+		AXPYZ(1.0, u, q, uq);
+		MATVEC(uq, auq);
+		AXPY(alpha, uq, c->x);
+		AXPY(-alpha, auq, r);
+		RESID(r, &nrm2);
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) FINISH(LIS_SUCCESS);
+		rho_old = rho;
+	}
+	FINISH(LIS_MAXITER);
+done:
+	work_free(c);
+	return err;
+}
+
+LIS_INT lisk_bicrstab(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter = 0;
+	const int n = c->n;
+	double nrm2 = 0.0, rho, rho_old, alpha, beta, omega, d1, d2;
+	TRY(work_alloc(c, 9));
+	double *rtld = c->work[0], *r = c->work[1], *sv = c->work[2], *ms = c->work[3], *ams = c->work[4], *p = c->work[5],
+	       *ap = c->work[6], *map = c->work[7], *z = c->work[8];
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	COPY(r, p);
+	TRY(lisd_spmv_t(c->A, p, rtld));
+	PSOLVE(r, z);
+	COPY(z, p);
+	DOT(rtld, z, &rho_old);
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		MATVEC(p, ap);
+		PSOLVE(ap, map);
+		DOT(rtld, map, &d1);
+		alpha = rho_old / d1;
+		AXPYZ(-alpha, ap, r, sv);
+		RESID(sv, &nrm2);
+		if (nrm2 <= c->tol) {
+			note(c, iter, nrm2);
+			AXPY(alpha, p, c->x);
+			FINISH(LIS_SUCCESS);
+		}
+		AXPYZ(-alpha, map, z, ms);
+		MATVEC(ms, ams);
+		DOT(ams, sv, &d1);
+		DOT(ams, ams, &d2);
+		omega = d1 / d2;
+		AXPY(alpha, p, c->x);
+		AXPY(omega, ms, c->x);
+		AXPYZ(-omega, ams, sv, r);
+		RESID(r, &nrm2);
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) FINISH(LIS_SUCCESS);
+		PSOLVE(r, z);
+		DOT(rtld, z, &rho);
+		if (rho == 0.0) FINISH(LIS_BREAKDOWN);
+		beta = (rho / rho_old) * (alpha / omega);
+		AXPY(-omega, map, p);
+		XPAY(z, beta, p);
+		rho_old = rho;
+	}
+	FINISH(LIS_MAXITER);
+done:
+	work_free(c);
+	return err;
+}
+
+LIS_INT lisk_bicrsafe(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter = 0;
+	const int n = c->n;
+	double nrm2 = 0.0, rho, rho_old, alpha, beta = 0.0, qsi, eta, t5[5];
+	TRY(work_alloc(c, 13));
+	double *rtld = c->work[0], *r = c->work[1], *mr = c->work[2], *amr = c->work[3], *p = c->work[4], *ap = c->work[5],
+	       *map = c->work[6], *my = c->work[7], *y = c->work[8], *u = c->work[9], *z = c->work[10], *au = c->work[11],
+	       *artld = c->work[12];
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	COPY(r, rtld);
+	TRY(lisd_spmv_t(c->A, rtld, artld));
+	PSOLVE(r, mr);
+	MATVEC(mr, amr);
+	DOT(rtld, amr, &rho_old);
+	COPY(amr, ap);
+	COPY(mr, p);
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		PSOLVE(ap, map);
+		DOT(artld, map, &t5[0]);
+		alpha = rho_old / t5[0];
+		DOT(y, y, &t5[0]); DOT(amr, r, &t5[1]); DOT(y, r, &t5[2]); DOT(amr, y, &t5[3]); DOT(amr, amr, &t5[4]);
+		qsi_eta(iter == 1, t5, &qsi, &eta);
+		SCALE(eta * beta, u);                 /* u = qsi map + eta (my + beta u) */
+		AXPY(qsi, map, u);
+		AXPY(eta, my, u);
+		MATVEC(u, au);
+		SCALE(eta, z);
+		AXPY(qsi, mr, z);
+		AXPY(-alpha, u, z);
+		SCALE(eta, y);
+		AXPY(qsi, amr, y);
+		AXPY(-alpha, au, y);
+		PSOLVE(y, my);
+		AXPY(alpha, p, c->x);
+		AXPY(1.0, z, c->x);
+		AXPY(-alpha, ap, r);
+		AXPY(-1.0, y, r);
+		RESID(r, &nrm2);
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) FINISH(LIS_SUCCESS);
+		AXPY(-alpha, map, mr);
+		AXPY(-1.0, my, mr);
+		MATVEC(mr, amr);
+		DOT(rtld, amr, &rho);
+		if (rho == 0.0) FINISH(LIS_BREAKDOWN);
+		beta = (rho / rho_old) * (alpha / qsi);
+		AXPY(-1.0, u, p);
+		XPAY(mr, beta, p);
+		AXPY(-1.0, au, ap);
+		XPAY(amr, beta, ap);
+		rho_old = rho;
+	}
+	FINISH(LIS_MAXITER);
+done:
+	work_free(c);
+	return err;
+}
+
+/* flexible GMRES: the preconditioned basis z[] is kept, so the update is x += sum y_j z_j.  Its convergence test
+ * compares the ABSOLUTE residual |s[i+1]| with the tolerance (lis_solver_gmres.c:1128-1303, no bnrm factor): kept. */
+LIS_INT lisk_fgmres(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter = 0;
+	const int n = c->n, m = s->options[LIS_OPTIONS_RESTART], ld = m + 1;
+	const int CS = (m + 1) * ld, SN = (m + 2) * ld;
+	double *h = (double *)calloc((size_t)(ld + 1) * (size_t)(ld + 2), sizeof(double));
+	double *g = (double *)calloc((size_t)ld + 2, sizeof(double));
+	double nrm2 = 0.0, rnorm, bnrm2, t;
+	int ii = 0;
+	if (!h || !g) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", ld); goto done; }
+	TRY(work_alloc(c, 2 * m + 3));
+	double **z = &c->work[0], **v = &c->work[m + 1];
+	int st = initial_residual(c, v[0]);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	bnrm2 = c->bnrm;
+	rnorm = 1.0 / bnrm2;
+	while (iter < c->maxiter) {
+		SCALE(bnrm2, v[0]);
+		for (int j = 0; j <= m + 1; j++) g[j] = 0.0;
+		g[0] = rnorm;
+		int i = 0;
+		do {
+			iter++; i++;
+			ii = i - 1;
+			const int i1 = i;
+			double *hc = h + (size_t)ii * ld;
+			PSOLVE(v[ii], z[ii]);
+			MATVEC(z[ii], v[i1]);
+			for (int k = 0; k < i; k++) {
+				DOT(v[i1], v[k], &t);
+				hc[k] = t;
+				AXPY(-t, v[k], v[i1]);
+			}
+			TRY(lisd_nrm2(n, v[i1], &t));
+			hc[i1] = t;
+			SCALE(1.0 / t, v[i1]);
+			for (int k = 1; k <= ii; k++) {
+				const int jj = k - 1;
+				const double tt = hc[jj];
+				double aa = h[jj + CS] * tt;  aa += h[jj + SN] * hc[k];
+				double bb = -h[jj + SN] * tt; bb += h[jj + CS] * hc[k];
+				hc[jj] = aa; hc[k] = bb;
+			}
+			double aa = hc[ii], bb = hc[i1];
+			double rr = sqrt(aa * aa + bb * bb);
+			if (rr == 0.0) rr = 1.0e-17;
+			h[ii + CS] = aa / rr;
+			h[ii + SN] = bb / rr;
+			g[i1] = -h[ii + SN] * g[ii];
+			g[ii] =  h[ii + CS] * g[ii];
+			aa  = h[ii + CS] * hc[ii];
+			aa += h[ii + SN] * hc[i1];
+			hc[ii] = aa;
+			nrm2 = fabs(g[i1]);
+			note(c, iter, nrm2);
+			if (c->tol >= nrm2) break;
+		} while (i < m && iter < c->maxiter);
+		g[ii] = g[ii] / h[ii + (size_t)ii * ld];
+		for (int k = 1; k <= ii; k++) {
+			const int jj = ii - k;
+			double tt = g[jj];
+			for (int j = jj + 1; j <= ii; j++) tt -= h[jj + (size_t)j * ld] * g[j];
+			g[jj] = tt / h[jj + (size_t)jj * ld];
+		}
+		for (int j = 0; j <= ii; j++) AXPY(g[j], z[j], c->x);
+		if (c->tol >= nrm2) FINISH(LIS_SUCCESS);
+		MATVEC(c->x, v[0]);
+		XPAY(c->b, -1.0, v[0]);
+		TRY(lisd_nrm2(n, v[0], &rnorm));
+		bnrm2 = 1.0 / rnorm;
+	}
+	s->retcode = LIS_MAXITER; s->iter = iter + 1; s->resid = nrm2; err = LIS_MAXITER;
+done:
+	work_free(c);
+	free(h); free(g);
+	return err;
+}
+
+/* MINRES keeps its own residual bookkeeping: r0 = M^-1 (b - A x) always formed with a product, relative norm
+ * r_euc / r0_euc against the raw -tol parameter (lis_solver_minres.c:121-258) */
+LIS_INT lisk_minres(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter = 0;
+	const int n = c->n;
+	const double tol = s->params[LIS_PARAMS_RESID - LIS_OPTIONS_LEN];
+	double nrm2, alpha, beta2, beta3, gamma1 = 1.0, gamma2 = 1.0, gamma3, delta, eta, sigma1 = 0.0, sigma2 = 0.0, sigma3,
+	       rho1, rho2, rho3, r0_euc, r_euc;
+	TRY(work_alloc(c, 7));
+	double *v1 = c->work[0], *v2 = c->work[1], *v3 = c->work[2], *v4 = c->work[3], *w0 = c->work[4], *w1 = c->work[5], *w2 = c->work[6];
+	MATVEC(c->x, v2);
+	XPAY(c->b, -1.0, v2);
+	PSOLVE(v2, v3);
+	COPY(v3, v2);
+	TRY(lisd_nrm2(n, v2, &r_euc));
+	eta = beta2 = r0_euc = r_euc;
+	nrm2 = r_euc / r0_euc;
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		SCALE(1.0 / beta2, v2);
+		MATVEC(v2, v3);
+		PSOLVE(v3, v4);
+		DOT(v2, v4, &alpha);
+		AXPY(-alpha, v2, v4);
+		AXPY(-beta2, v1, v4);
+		TRY(lisd_nrm2(n, v4, &beta3));
+		delta = gamma2 * alpha - gamma1 * sigma2 * beta2;
+		rho1 = sqrt(delta * delta + beta3 * beta3);
+		rho2 = sigma2 * alpha + gamma1 * gamma2 * beta2;
+		rho3 = sigma1 * beta2;
+		gamma3 = delta / rho1;
+		sigma3 = beta3 / rho1;
+		AXPYZ(-rho3, w0, v2, w2);
+		AXPY(-rho2, w1, w2);
+		SCALE(1.0 / rho1, w2);
+		AXPY(gamma3 * eta, w2, c->x);
+		r_euc *= fabs(sigma3);
+		nrm2 = r_euc / r0_euc;
+		note(c, iter, nrm2);
+		if (nrm2 <= tol) FINISH(LIS_SUCCESS);
+		eta *= -sigma3;
+		COPY(v2, v1);
+		COPY(v4, v2);
+		COPY(w1, w0);
+		COPY(w2, w1);
+		beta2 = beta3;
+		gamma1 = gamma2; gamma2 = gamma3;
+		sigma1 = sigma2; sigma2 = sigma3;
+	}
+	FINISH(LIS_MAXITER);
+done:
+	work_free(c);
 	return err;
 }

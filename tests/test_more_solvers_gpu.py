@@ -1,4 +1,5 @@
-"""The other Krylov solvers of Lis (CGS, CR, GPBiCG, TFQMR, BiCGSafe, Orthomin) on the GPU against
+"""The other Krylov solvers of Lis (CGS, CR, GPBiCG, TFQMR, BiCGSafe, Orthomin, BiCR, CRS, BiCRSTAB,
+GPBiCR, BiCRSafe, FGMRES, MINRES, COCG, COCR) on the GPU against
 what the reference itself produced for the same systems (tests/golden/solvers_golden.npz, make_golden_solvers.py).
 
 Element-wise arithmetic is bit-identical; the reductions are trees, so a recurrence can part from the reference's
@@ -46,7 +47,9 @@ def test_solver_matches_reference(lib, case):
     it_ref, st_ref = (int(v) for v in G[case + "/iter_status"])
     assert out["err"] == 0 and out["status"] == st_ref
     if st_ref == 0:
-        if mat == "p3d":
+        # FGMRES(5) on the Poisson case stops at 9.9976e-13 against a tolerance of 1e-12 in the reference: a 0.02 % margin
+        # that any change of reduction order flips by one iteration -- it gets the loose bar
+        if mat == "p3d" and solver != "fgmres":
             assert out["iter"] == it_ref, (case, out["iter"], it_ref)
         else:
             assert abs(out["iter"] - it_ref) <= max(3, it_ref // 10), (case, out["iter"], it_ref)

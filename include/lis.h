@@ -538,7 +538,8 @@ LIS_INT lis_solver_output_rhistory(LIS_SOLVER solver, char *filename);  /* ref:1
  * (right-hand side / initial guess appended, optional binary records).  The reader fixes the in-row entry
  * order (file order, mirrored entry first) and with it the bits of every SpMV on the matrix.
  * `array` (dense) files are read straight into CSR (non-zero values, columns ascending), which is what the
- * reference's DNS -> CSR conversion yields.  Not served: Harwell-Boeing files -> LIS_ERR_NOT_IMPLEMENTED. */
+ * reference's DNS -> CSR conversion yields.  Anything that is not Matrix Market is read as Harwell-Boeing
+ * (real unsymmetric assembled only, right-hand sides skipped: lis_input_hb.c). */
 LIS_INT lis_input(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, char *filename);      /* lis_input.c:67 */
 LIS_INT lis_input_matrix(LIS_MATRIX A, char *filename);                          /* lis_input.c:174 */
 LIS_INT lis_input_vector(LIS_VECTOR v, char *filename);                          /* lis_input.c:188 (MM, Lis ascii, plain) */

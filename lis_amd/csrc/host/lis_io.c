@@ -265,6 +265,106 @@ fail:
 	return err;
 }
 
+/* ------------------------------------------------------------------ Harwell-Boeing (RUA only, like the reference)
+ * lis_input_hb.c:120-463: header lines 1-4 (+5 when right-hand sides are present; they are skipped), fixed-width
+ * integer / real fields as described by the Fortran formats of line 4, column pointers / row indices / values =
+ * a CSC matrix, converted to CSR unless CSC was requested. */
+static int hb_format(const char *field, int size, int *count, int *width)
+{	/* "(10I8)" -> 10, 8; "(4E20.12)" / "(1P,4D20.12)"-free forms -> 4, 20 (lis_input_hb.c:100-137) */
+	char tmp[64];
+	if (size > 63) size = 63;
+	memcpy(tmp, field, (size_t)size); tmp[size] = '\0';
+	lower(tmp);
+	char *p = strchr(tmp, '(');
+	*count = 0; *width = 0;
+	if (!p) return 1;
+	char *sfmt = p + 1, *q = strchr(sfmt, ')');
+	if (q) *q = '\0';
+	char *k = strchr(sfmt, 'i');
+	if (!k) {
+		k = strchr(sfmt, 'e');
+		if (!k) k = strchr(sfmt, 'd');
+		if (!k) return 0;
+		char *dot = strchr(sfmt, '.');
+		if (dot) *dot = '\0';
+	}
+	*k = '\0';
+	*count = atoi(sfmt);
+	*width = atoi(k + 1);
+	return 1;
+}
+
+static LIS_INT hb_read(slurp_t *s, LIS_MATRIX A)
+{
+	char *b, *e;
+	const LIS_INT want = A->matrix_type;
+	if (!next_line(s, &b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");          /* line 1: title, key */
+	if (!next_line(s, &b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");          /* line 2: card counts */
+	int totcrd = 0, ptrcrd = 0, indcrd = 0, valcrd = 0, rhscrd = 0;
+	if (sscanf(b, "%14d%14d%14d%14d%14d", &totcrd, &ptrcrd, &indcrd, &valcrd, &rhscrd) < 4) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+	if (!next_line(s, &b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");          /* line 3: type, sizes */
+	char mtx[64] = "";
+	int nrow = 0, ncol = 0, nnzero = 0, neltvl = 0;
+	if (sscanf(b, "%63s %d %d %d %d", mtx, &nrow, &ncol, &nnzero, &neltvl) != 5) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+	lower(mtx);
+	if (mtx[0] != 'r') return LISI_ERR(LIS_ERR_FILE_IO, "Not real\n");
+	if (mtx[1] != 'u') return LISI_ERR(LIS_ERR_FILE_IO, "Not unsymmetric\n");
+	if (mtx[2] != 'a') return LISI_ERR(LIS_ERR_FILE_IO, "Not assembled\n");
+	if (nrow != ncol) return LISI_ERR(LIS_ERR_FILE_IO, "matrix is not square\n");
+	if (lisg.rank == 0) { printf("matrix size = %d x %d (%d nonzero entries)\n\n", nrow, ncol, nnzero); fflush(stdout); }
+	if (!next_line(s, &b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");          /* line 4: formats */
+	char fmt[96];
+	memset(fmt, ' ', sizeof(fmt));
+	memcpy(fmt, b, (size_t)((e - b) < 95 ? (e - b) : 95));
+	int iptr, wptr, iind, wind, ival, wval, irhs, wrhs;
+	if (!hb_format(fmt, 16, &iptr, &wptr) || !hb_format(fmt + 16, 16, &iind, &wind) || !hb_format(fmt + 32, 20, &ival, &wval))
+		return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+	(void)hb_format(fmt + 52, 20, &irhs, &wrhs);
+	if (rhscrd != 0 && !next_line(s, &b, &e)) return LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");   /* line 5 */
+	if (lisg.nprocs > 1) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "Harwell-Boeing input is single-process only\n");
+	LISCHK(lis_matrix_set_size(A, 0, nrow));
+	const LIS_INT n = A->n;
+	LIS_INT *ptr = (LIS_INT *)malloc(sizeof(LIS_INT) * ((size_t)n + 1));
+	LIS_INT *index = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(nnzero > 0 ? nnzero : 1));
+	LIS_SCALAR *value = (LIS_SCALAR *)malloc(sizeof(LIS_SCALAR) * (size_t)(nnzero > 0 ? nnzero : 1));
+	LIS_INT err = LIS_SUCCESS;
+	if (!ptr || !index || !value) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", nnzero); goto fail; }
+	char dat[128];
+	for (int pass = 0; pass < 3 && !err; pass++) {
+		const int cards = pass == 0 ? ptrcrd : pass == 1 ? indcrd : valcrd;
+		const int per = pass == 0 ? iptr : pass == 1 ? iind : ival, wd = pass == 0 ? wptr : pass == 1 ? wind : wval;
+		const LIS_INT total = pass == 0 ? n + 1 : nnzero;
+		LIS_INT k = 0;
+		if (wd <= 0 || wd > 120) { err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n"); break; }
+		for (int i = 0; i < cards; i++) {
+			if (!next_line(s, &b, &e)) { err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n"); break; }
+			char *p = b;
+			for (int j = 0; j < per && k < total; j++) {
+				int w = 0;
+				while (w < wd && p + w < e) { dat[w] = p[w]; w++; }       /* a short last field is what strncpy would copy */
+				dat[w] = '\0';
+				if (pass == 0) ptr[k] = atoi(dat) - 1;
+				else if (pass == 1) index[k] = atoi(dat) - 1;
+				else value[k] = atof(dat);
+				p += wd;
+				if (p > e) p = e;
+				k++;
+			}
+		}
+	}
+	if (err) goto fail;
+	err = lis_matrix_set_csc(nnzero, ptr, index, value, A);
+	if (err) goto fail;
+	ptr = NULL; index = NULL; value = NULL;
+	LISCHK(lis_matrix_assemble(A));
+	if (want != LIS_MATRIX_CSC) LISCHK(lisi_matrix_retype(A, LIS_MATRIX_CSR, 0));
+	if (want != LIS_MATRIX_CSR && want != LIS_MATRIX_CSC) LISCHK(lisi_matrix_retype(A, want, 0));
+	return LIS_SUCCESS;
+fail:
+	free(ptr); free(index); free(value);
+	return err;
+}
+
 /* storage type requested with lis_matrix_set_type before the read: convert in place (ref lis_input_mm.c:82-107) */
 LIS_INT lisi_matrix_retype(LIS_MATRIX A, LIS_INT want, LIS_INT block)
 {
@@ -297,9 +397,10 @@ LIS_INT lis_input(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, char *filename)
 	LIS_INT err;
 	if (s.len == 0) { free(s.buf); return LIS_ERR_FILE_IO; }
 	if (strncmp(s.buf, MM_BANNER, strlen(MM_BANNER)) != 0) {
-		/* anything else is taken for Harwell-Boeing by the reference (lis_input.c:122-125, lis_input_hb.c) */
+		/* anything else is taken for Harwell-Boeing by the reference (lis_input.c:122-125) */
+		err = hb_read(&s, A);
 		free(s.buf);
-		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "Harwell-Boeing input is not served by liblis_amd\n");
+		return err;
 	}
 	const LIS_INT want = A->matrix_type;
 	mm_head h;

@@ -87,6 +87,16 @@ def test_writers_match_reference_bytes(lib, name, tmp_path, capfd):
     destroy(lib, A, b, x)
 
 
+def test_harwell_boeing_requested_as_csc(lib, capfd):
+    """an .rua file holds CSC arrays: asking for CSC keeps them as read (lis_input_hb.c:447-462)"""
+    err, A, b, x = read_with(lib, os.path.join(MM, "gen_hb.rua"), want=capi.LIS_MATRIX_CSC)
+    assert err == 0 and A.contents.matrix_type == capi.LIS_MATRIX_CSC
+    arrs = lisdrv.matrix_arrays(A)
+    assert arrs["nnz"] == 202 and arrs["ptr"][1] == 4 and np.array_equal(arrs["ptr"][:4], [0, 4, 10, 13])
+    capfd.readouterr()
+    destroy(lib, A, b, x)
+
+
 def test_roundtrips_text_and_binary(lib, tmp_path, capfd):
     """write -> read gives the same arrays back, for the text and the binary (MMB) form, with b and x."""
     err, A, b, x = read_with(lib, os.path.join(MM, "gen_symmetric_bx.mtx"))
@@ -157,15 +167,15 @@ def test_error_paths(lib, tmp_path, capfd):
     B = capi.PM()
     lib.lis_matrix_create(0, C.byref(B))
     assert lib.lis_input_matrix(B, str(p).encode()) == 6                                  # truncated file
-    p = tmp_path / "hb.rua"
-    p.write_text("1Title                                                                  Key\n")
+    p = tmp_path / "hb.rua"                              # anything that is not Matrix Market is parsed as Harwell-Boeing
+    p.write_text("%-72s%-8s\n%14d%14d%14d%14d\n%-14s%14d%14d%14d%14d\n" % ("title", "KEY", 3, 1, 1, 1, "RSA", 2, 2, 2, 0))
     Cm = capi.PM()
     lib.lis_matrix_create(0, C.byref(Cm))
-    assert lib.lis_input_matrix(Cm, str(p).encode()) == 5                                 # HB: not served, said loudly
+    assert lib.lis_input_matrix(Cm, str(p).encode()) == 6                                 # "Not unsymmetric" (RUA only)
     assert lib.lis_input_matrix(A, None) == 1
     cap = capfd.readouterr()
     err = cap.out + cap.err                              # diagnostics go where the reference's lis_error sends them
-    assert "not square" in err and "Not real" in err and "Harwell-Boeing" in err
+    assert "not square" in err and "Not real" in err and "Not unsymmetric" in err
     for m in (A, B, Cm):
         lib.lis_matrix_destroy(m)
 

@@ -487,6 +487,8 @@ LIS_INT lis_matrix_get_nnz(LIS_MATRIX A, LIS_INT *nnz);
 LIS_INT lis_matrix_set_type(LIS_MATRIX A, LIS_INT matrix_type);
 LIS_INT lis_matrix_get_type(LIS_MATRIX A, LIS_INT *matrix_type);
 LIS_INT lis_matrix_set_value(LIS_INT flag, LIS_INT i, LIS_INT j, LIS_SCALAR value, LIS_MATRIX A);
+LIS_INT lis_matrix_set_values(LIS_INT flag, LIS_INT n, LIS_SCALAR value[], LIS_MATRIX A);   /* ref:878, lis_matrix.c:808 (dense block) */
+LIS_INT lis_matrix_malloc(LIS_MATRIX A, LIS_INT nnz_row, LIS_INT nnz[]);                  /* ref:880, lis_matrix.c:592 (row capacity hint) */
 LIS_INT lis_matrix_get_diagonal(LIS_MATRIX A, LIS_VECTOR d);
 LIS_INT lis_matrix_scale(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_INT action);   /* ref:882, src/matrix/lis_matrix_ops.c:579 (-scale) */
 LIS_INT lis_matrix_convert(LIS_MATRIX Ain, LIS_MATRIX Aout);

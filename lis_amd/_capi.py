@@ -163,6 +163,8 @@ _PROTOS = {
     "lis_matvec": (LIS_INT, [PM, PV, PV]),
     "lis_matvech": (LIS_INT, [PM, PV, PV]),
     "lis_matrix_scale": (LIS_INT, [PM, PV, PV, LIS_INT]),
+    "lis_matrix_set_values": (LIS_INT, [LIS_INT, LIS_INT, P_DBL, PM]),
+    "lis_matrix_malloc": (LIS_INT, [PM, LIS_INT, C.POINTER(LIS_INT)]),
     # solvers (lis.h:961-984)
     "lis_solver_create": (LIS_INT, [C.POINTER(PS)]),
     "lis_solver_destroy": (LIS_INT, [PS]),

@@ -270,12 +270,33 @@ LIS_INT lis_matrix_set_value(LIS_INT flag, LIS_INT i, LIS_INT j, LIS_SCALAR valu
 			return LIS_SUCCESS;
 		}
 	if (r->len == r->cap) {
-		r->cap = r->cap ? 2 * r->cap : A->w_annz;
+		r->cap = r->cap ? 2 * r->cap : (A->w_nnz && A->w_nnz[i - A->is] > 0 ? A->w_nnz[i - A->is] : A->w_annz);
 		r->col = (LIS_INT *)realloc(r->col, sizeof(LIS_INT) * (size_t)r->cap);
 		r->val = (LIS_SCALAR *)realloc(r->val, sizeof(LIS_SCALAR) * (size_t)r->cap);
 		if (!r->col || !r->val) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", r->cap);
 	}
 	r->col[r->len] = j; r->val[r->len] = value; r->len++;
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_matrix_set_values(LIS_INT flag, LIS_INT n, LIS_SCALAR value[], LIS_MATRIX A)
+{	/* a dense n x n block, row-major, through lis_matrix_set_value; errors of the single calls are dropped as in the
+	 * reference (lis_matrix.c:808-822) */
+	for (LIS_INT i = 0; i < n; i++)
+		for (LIS_INT j = 0; j < n; j++) (void)lis_matrix_set_value(flag, i, j, value[(size_t)i * n + j], A);
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_matrix_malloc(LIS_MATRIX A, LIS_INT nnz_row, LIS_INT nnz[])
+{	/* expected entries per row for the element-wise assembly (lis_matrix.c:592-625): a capacity hint here */
+	LISCHK(lisi_matrix_check(A, LISI_CHECK_NOT_ASSEMBLED));
+	const LIS_INT n = A->n;
+	if (!A->w_nnz) {
+		A->w_nnz = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(n > 0 ? n : 1));
+		if (!A->w_nnz) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", n);
+	}
+	if (nnz == NULL) { A->w_annz = nnz_row > 0 ? nnz_row : 1; for (LIS_INT k = 0; k < n; k++) A->w_nnz[k] = nnz_row; }
+	else for (LIS_INT k = 0; k < n; k++) A->w_nnz[k] = nnz[k];
 	return LIS_SUCCESS;
 }
 
@@ -384,7 +405,7 @@ LIS_INT lisi_matrix_storage_destroy(LIS_MATRIX A)
 /* move every field of src into dst (dst keeps its address); src is left hollow for free() */
 LIS_INT lisi_matrix_copy_header(LIS_MATRIX src, LIS_MATRIX dst)
 {
-	free(dst->ranges); free(dst->l2g_map);
+	free(dst->ranges); free(dst->l2g_map); free(dst->w_nnz);
 	if (dst->commtable) lisc_commtable_destroy(dst->commtable);
 	memcpy(dst, src, sizeof(struct LIS_MATRIX_STRUCT));
 	*MDEV(dst) = *MDEV(src);
@@ -408,6 +429,7 @@ LIS_INT lis_matrix_destroy(LIS_MATRIX A)
 {
 	if (A && lisi_is_registered(A)) {
 		lisi_matrix_storage_destroy(A);
+		free(A->w_nnz);
 		free(A->l2g_map);
 		if (A->commtable) lisc_commtable_destroy(A->commtable);
 		free(A->ranges);

@@ -300,3 +300,19 @@ def test_matrix_scale_matches_reference_bits(lib, fmt, action):
     assert np.array_equal(lisdrv.matrix_arrays(B)["value"], GS[f"scale{action}/{fmt}/value"])
     assert np.array_equal(np.ctypeslib.as_array(vb.contents.value, shape=(n,)), GS[f"scale{action}/{fmt}/b"])
     assert np.array_equal(np.ctypeslib.as_array(vd.contents.value, shape=(n,)), GS[f"scale{action}/{fmt}/d"])
+
+
+def test_set_values_block_and_row_hints(lib):
+    """lis_matrix_malloc (capacity hint) + lis_matrix_set_values (dense row-major block) -> the CSR the same
+    lis_matrix_set_value calls give (reference lis_matrix.c:592-625, :808-822)."""
+    n = 4
+    dense = np.arange(1.0, n * n + 1).reshape(n, n)
+    A = capi.PM()
+    assert lib.lis_matrix_create(0, C.byref(A)) == 0 and lib.lis_matrix_set_size(A, 0, n) == 0
+    assert lib.lis_matrix_malloc(A, 4, None) == 0
+    assert lib.lis_matrix_set_values(capi.LIS_INS_VALUE, n, dense.ravel().ctypes.data_as(capi.P_DBL), A) == 0
+    assert lib.lis_matrix_set_type(A, capi.LIS_MATRIX_CSR) == 0 and lib.lis_matrix_assemble(A) == 0
+    arrs = lisdrv.matrix_arrays(A)
+    assert np.array_equal(arrs["ptr"], np.arange(0, n * n + 1, n))
+    assert np.array_equal(arrs["index"], np.tile(np.arange(n), n)) and np.array_equal(arrs["value"], dense.ravel())
+    lib.lis_matrix_destroy(A)

@@ -178,21 +178,34 @@ void spmv_bsr_tile_kernel(int nr, const int *__restrict__ bptr, const int *__res
     double acc = 0.0;
     for (int cb = bb; cb < be; cb += CHUNK) {
         const int nblk = min(CHUNK, be - cb);
-        for (int t = L; t < nblk * BNC; t += BLOCK) {
-            const int b = cb + t / BNC, j = t % BNC;
-            const double *src = val + (size_t)b * BS + (size_t)j * BNR;
-            const double xj = x[(size_t)bidx[b] * BNC + j];
-            double *dst = prod + (size_t)t * BNR;
-            if (BNR == 2 || BNR == 4) {
+        constexpr int UB = 4;                            // block columns in flight per lane
+        for (int t0 = L; t0 < nblk * BNC; t0 += UB * BLOCK) {
+            double v[UB][BNR], xj[UB];
 #pragma unroll
-                for (int i = 0; i < BNR; i += 2) {
-                    const v2f64 v = load_stream(reinterpret_cast<const v2f64 *>(src + i));
-                    v2f64 o; o.x = v.x * xj; o.y = v.y * xj;
-                    *reinterpret_cast<v2f64 *>(dst + i) = o;
+            for (int u = 0; u < UB; u++) {
+                const int t = min(t0 + u * BLOCK, nblk * BNC - 1);      // clamped: the tail repeats the last column
+                const int b = cb + t / BNC, j = t % BNC;
+                const double *src = val + (size_t)b * BS + (size_t)j * BNR;
+                if (BNR == 2 || BNR == 4) {
+#pragma unroll
+                    for (int i = 0; i < BNR; i += 2) {
+                        const v2f64 vv = load_stream(reinterpret_cast<const v2f64 *>(src + i));
+                        v[u][i] = vv.x; v[u][i + 1 < BNR ? i + 1 : i] = vv.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < BNR; i++) v[u][i] = load_stream(src + i);
                 }
-            } else {
+                xj[u] = x[(size_t)bidx[b] * BNC + j];
+            }
 #pragma unroll
-                for (int i = 0; i < BNR; i++) dst[i] = load_stream(src + i) * xj;
+            for (int u = 0; u < UB; u++) {
+                const int t = t0 + u * BLOCK;
+                if (t < nblk * BNC) {
+                    double *dst = prod + (size_t)t * BNR;
+#pragma unroll
+                    for (int i = 0; i < BNR; i++) dst[i] = v[u][i] * xj[u];
+                }
             }
         }
         __syncthreads();

@@ -176,7 +176,9 @@ def main():
     if not args.no_solvers:
         dll.lis_amd_vector_poisson3d_rhs.argtypes = [capi.PV, C.c_int, C.c_int, C.c_int]
         assert dll.lis_amd_vector_poisson3d_rhs(b, N, N, N) == 0
-        for key, opts in (("cg_jacobi", "-i cg -p jacobi"), ("bicgstab_none", "-i bicgstab -p none")):
+        for key, opts in (("cg_jacobi", "-i cg -p jacobi"), ("bicgstab_none", "-i bicgstab -p none"),
+                          ("bicg_none", "-i bicg -p none"),            # Lis's default solver: needs A^T (built in HBM on first use)
+                          ("gmres30_none", "-i gmres -restart 30 -p none")):
             S = capi.PS()
             assert lib.lis_solver_create(C.byref(S)) == 0
             assert lib.lis_solver_set_option(f"{opts} -tol 1e-12 -maxiter {args.solver_iters}".encode(), S) == 0

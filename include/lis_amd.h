@@ -51,6 +51,7 @@ LIS_INT lis_amd_vector_poisson3d_rhs(LIS_VECTOR b, LIS_INT l, LIS_INT m, LIS_INT
 
 /* stream all library work is queued on (hipStream_t as void*), and a full device sync */
 void   *lis_amd_stream(void);
+LIS_INT lis_amd_trim(void);                            /* give the solver work-vector pool back to the driver */
 LIS_INT lis_amd_synchronize(void);
 
 /* ---- multi-GPU: one process per GPU, row-block partition (LIS_GET_ISIE), RCCL over xGMI ------------

@@ -162,6 +162,11 @@ int  liship_csr_diagonal_f64(int n, const int *ptr, const int *index, const doub
                              double *d, void *stream);
 /* halo pack: ws[i] = x[export_index[i]]  (lis_send_recv, src/matrix/lis_matrix_mpi.c:904-916) */
 int  liship_gather_f64(int count, const int *export_index, const double *x, double *ws, void *stream);
+/* A^T of a CSR matrix in HBM, each transposed row listing its entries in the order of their positions in the
+ * source arrays -- the order lis_matvech_csr's scatter adds them (lis_matvec_csr.c:213-250).  tptr: ncols+1 ints,
+ * tindex / tvalue: nnz entries, work: ncols + nnz ints.  Setup-time (once per matrix). */
+int  liship_csr_transpose_f64(int nrows, int ncols, int nnz, const int *ptr, const int *index, const double *value,
+                              int *tptr, int *tindex, double *tvalue, int *work, void *stream);
 /* reverse halo: y[export_index[i]] += wr[i], indices unique within one call  (lis_reduce, lis_matrix_mpi.c:988-996) */
 int  liship_scatter_add_f64(int count, const int *export_index, const double *wr, double *y, void *stream);
 

@@ -85,6 +85,7 @@ _LISHIP = {
     "liship_sum_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_dot2_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp]),
     "liship_csr_diagonal_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp]),
+    "liship_csr_transpose_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_gather_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_scatter_add_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_poisson3d_nnz": (C.c_longlong, [_ci, _ci, _ci, _ci, _ci]),

@@ -36,6 +36,39 @@ LIS_INT lisd_init(void)
 	return LIS_SUCCESS;
 }
 
+/* ------------------------------------------------------------------ work-vector pool
+ * A Krylov solve needs 4 ... restart+3 vectors of the matrix size; hipMalloc/hipFree of tens of GiB cost more
+ * than the iterations of a short solve (GMRES(30) at 512^3: 33 GiB, ~1 s).  Buffers released by a solve are
+ * kept and handed to the next one that asks for the same size; lis_amd_trim() / lis_finalize() / an allocation
+ * failure anywhere give them back to the driver. */
+#define POOL_SLOTS 160
+static struct { void *p; size_t bytes; } pool[POOL_SLOTS];
+
+LIS_INT lisd_pool_get(size_t bytes, void **out)
+{
+	for (int i = 0; i < POOL_SLOTS; i++)
+		if (pool[i].p && pool[i].bytes == bytes) { *out = pool[i].p; pool[i].p = NULL; return LIS_SUCCESS; }
+	int rc = liship_malloc(out, bytes);
+	if (rc) { lis_amd_trim(); rc = liship_malloc(out, bytes); }
+	HIPCHK(rc);
+	return LIS_SUCCESS;
+}
+
+void lisd_pool_put(void *p, size_t bytes)
+{
+	if (!p) return;
+	for (int i = 0; i < POOL_SLOTS; i++)
+		if (!pool[i].p) { pool[i].p = p; pool[i].bytes = bytes; return; }
+	(void)liship_free(p);
+}
+
+LIS_INT lis_amd_trim(void)
+{
+	for (int i = 0; i < POOL_SLOTS; i++)
+		if (pool[i].p) { (void)liship_free(pool[i].p); pool[i].p = NULL; pool[i].bytes = 0; }
+	return LIS_SUCCESS;
+}
+
 void *lis_amd_stream(void) { return lisd_init() == LIS_SUCCESS ? lisg.stream : NULL; }
 
 LIS_INT lis_amd_synchronize(void)

@@ -110,6 +110,8 @@ LIS_INT lisd_vec_to_host(LIS_VECTOR v);
 void    lisd_vec_free(LIS_VECTOR v);
 LIS_INT lisd_mat_ready(LIS_MATRIX A);
 void    lisd_mat_free(LIS_MATRIX A);
+LIS_INT lisd_pool_get(size_t bytes, void **out);              /* HBM buffer of exactly `bytes`, reused across solves */
+void    lisd_pool_put(void *p, size_t bytes);
 LIS_INT lisd_mat_ready_t(LIS_MATRIX A);                       /* build / upload the transposed operator */
 LIS_INT lisd_spmv_t(LIS_MATRIX A, double *dx, double *dy);    /* y[0..np) = A^T x, ghost rows reduced to owners */
 LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy);      /* y = A x on device pointers (halo included) */

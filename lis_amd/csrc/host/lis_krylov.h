@@ -26,14 +26,14 @@ static inline LIS_INT work_alloc(ctx_t *c, int count)
 	c->work = (double **)calloc((size_t)count, sizeof(double *));
 	c->nwork = count;
 	for (int i = 0; i < count; i++) {
-		HIPCHK(liship_malloc((void **)&c->work[i], c->len * sizeof(double)));
+		LISCHK(lisd_pool_get(c->len * sizeof(double), (void **)&c->work[i]));
 		HIPCHK(liship_memset(c->work[i], 0, c->len * sizeof(double), lisg.stream));
 	}
 	return LIS_SUCCESS;
 }
 static inline void work_free(ctx_t *c)
 {
-	for (int i = 0; i < c->nwork; i++) (void)liship_free(c->work[i]);
+	for (int i = 0; i < c->nwork; i++) lisd_pool_put(c->work[i], c->len * sizeof(double));
 	free(c->work); c->work = NULL; c->nwork = 0;
 }
 

@@ -91,6 +91,18 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 		LISCHK(upload((void **)&d->t_ptr, A->ptr, sizeof(int) * ((size_t)np + 1)));
 		LISCHK(upload((void **)&d->t_index, A->index, sizeof(int) * (size_t)A->nnz));
 		LISCHK(upload((void **)&d->t_value, A->value, sizeof(double) * (size_t)A->nnz));
+	} else if (type == LIS_MATRIX_CSR && d->type == LIS_MATRIX_CSR) {
+		/* CSR: the HBM copy is transposed in HBM (transpose.hip): no host pass, works for matrices born on the device */
+		int *work = NULL;
+		d->t_nnz = d->nnz;
+		HIPCHK(liship_malloc((void **)&d->t_ptr, sizeof(int) * ((size_t)np + 1) + 16));
+		HIPCHK(liship_malloc((void **)&d->t_index, sizeof(int) * (size_t)d->nnz + 16));
+		HIPCHK(liship_malloc((void **)&d->t_value, sizeof(double) * (size_t)d->nnz + 16));
+		HIPCHK(liship_malloc((void **)&work, sizeof(int) * ((size_t)np + (size_t)d->nnz) + 16));
+		int rc = liship_csr_transpose_f64(n, np, d->nnz, d->ptr, d->index, d->value, d->t_ptr, d->t_index, d->t_value, work, lisg.stream);
+		if (!rc) rc = liship_stream_synchronize(lisg.stream);
+		(void)liship_free(work);
+		HIPCHK(rc);
 	} else {
 		const LIS_INT *ptr = A->ptr, *index = A->index;
 		const double *value = A->value;

@@ -729,8 +729,8 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		double *db, *dx0;
 		if ((err = lisd_vec_in(b, &db))) goto out;
 		c.b = db;
-		int rc = liship_malloc((void **)&c.x, c.len * sizeof(double));
-		if (!rc) rc = liship_memset(c.x, 0, c.len * sizeof(double), lisg.stream);
+		if ((err = lisd_pool_get(c.len * sizeof(double), (void **)&c.x))) goto out;
+		int rc = liship_memset(c.x, 0, c.len * sizeof(double), lisg.stream);
 		if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
 		if (!solver->options[LIS_OPTIONS_INITGUESS_ZEROS]) {
 			if ((err = lisd_vec_in(x, &dx0))) goto out;
@@ -794,7 +794,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		else lis_printf(LIS_COMM_WORLD, "linear solver status  : normal end\n\n");
 	}
 out:
-	if (c.x) (void)liship_free(c.x);
+	if (c.x) lisd_pool_put(c.x, c.len * sizeof(double));
 	solver->precon = NULL;
 	if (err) solver->retcode = err;
 	return err;

@@ -198,6 +198,7 @@ LIS_INT lis_finalize(void)
 {
 	if (lisi_cmd_argv) { lisi_tokens_free(lisi_cmd_argv, lisi_cmd_argc); lisi_cmd_argv = NULL; lisi_cmd_argc = 0; }
 	lisg.initialized = 0;
+	(void)lis_amd_trim();
 	return LIS_SUCCESS;
 }
 

@@ -1,0 +1,163 @@
+// transpose.hip -- A^T of a CSR matrix, built in HBM, in the order lis_matvech_csr needs.
+//
+// lis_matvech_csr (reference src/matvec/lis_matvec_csr.c:213-250) scatters y[col] += a * x[row] while it walks
+// the matrix row by row, so the contributions to y[c] arrive ordered by their position k in the CSR arrays.
+// The transposed operator used by lis_matvech.c must list them in that order.  Three steps, no sort library:
+//   1. count entries per column (integer atomics: order-free), exclusive scan -> tptr
+//   2. scatter every entry's POSITION k into its column's segment in whatever order the atomics grant
+//   3. one lane per column sorts its segment of positions ascending (positions are unique, so the result does
+//      not depend on step 2's order), then fills index = row_of(k) (binary search in ptr) and value = value[k]
+// Setup-time code: runs once per matrix, not on the hot path.
+#include "common.hpp"
+#include "liship.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+__global__ __launch_bounds__(BLOCK)
+void count_columns(int n, const int *__restrict__ ptr, const int *__restrict__ idx, int *__restrict__ count)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    for (int k = ptr[r]; k < ptr[r + 1]; k++) atomicAdd(&count[idx[k]], 1);
+}
+
+// exclusive scan of count[0..m) into out[0..m] in three passes: sums of 4096-element tiles, a single workgroup
+// scanning the tile sums, tiles scanned locally with their offset
+constexpr int TILE = 4096;
+
+__global__ __launch_bounds__(BLOCK)
+void tile_sums(int m, const int *__restrict__ count, long long *__restrict__ sums)
+{
+    __shared__ long long part[BLOCK];
+    const long long base = (long long)blockIdx.x * TILE;
+    long long s = 0;
+    for (int i = threadIdx.x; i < TILE; i += BLOCK) if (base + i < m) s += count[base + i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = BLOCK / 2; w > 0; w >>= 1) { if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0];
+}
+
+__global__ __launch_bounds__(1024)
+void scan_tile_sums(int ntiles, long long *__restrict__ sums)      // in place: sums[t] = sum of tiles before t
+{
+    __shared__ long long part[1024];
+    const int t = threadIdx.x, T = blockDim.x;
+    const int per = (ntiles + T - 1) / T;
+    const int lo = min(ntiles, t * per), hi = min(ntiles, lo + per);
+    long long s = 0;
+    for (int i = lo; i < hi; i++) s += sums[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) { long long run = 0; for (int i = 0; i < T; i++) { const long long v = part[i]; part[i] = run; run += v; } }
+    __syncthreads();
+    long long run = part[t];
+    for (int i = lo; i < hi; i++) { const long long v = sums[i]; sums[i] = run; run += v; }
+}
+
+__global__ __launch_bounds__(BLOCK)
+void scan_tiles(int m, const int *__restrict__ count, const long long *__restrict__ sums, int *__restrict__ out)
+{
+    __shared__ long long part[BLOCK];
+    constexpr int PER = TILE / BLOCK;                 // consecutive elements per lane
+    const long long base = (long long)blockIdx.x * TILE + (long long)threadIdx.x * PER;
+    long long s = 0;
+    for (int i = 0; i < PER; i++) if (base + i < m) s += count[base + i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long run = sums[blockIdx.x]; for (int i = 0; i < BLOCK; i++) { const long long v = part[i]; part[i] = run; run += v; } }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (int i = 0; i < PER; i++) if (base + i < m) { out[base + i] = (int)run; run += count[base + i]; }
+    if (base <= m && m < base + PER) out[m] = (int)run;              // the total, by the lane whose range holds m
+    if (m % TILE == 0 && blockIdx.x == gridDim.x - 1 && threadIdx.x == BLOCK - 1) out[m] = (int)run;
+}
+
+__global__ __launch_bounds__(BLOCK)
+void scatter_positions(int n, const int *__restrict__ ptr, const int *__restrict__ idx,
+                       const int *__restrict__ tptr, int *__restrict__ fill, int *__restrict__ pos)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    for (int k = ptr[r]; k < ptr[r + 1]; k++) {
+        const int c = idx[k];
+        pos[tptr[c] + atomicAdd(&fill[c], 1)] = k;
+    }
+}
+
+__device__ void sift_down(int *a, int start, int end)
+{
+    int root = start;
+    while (2 * root + 1 <= end) {
+        int child = 2 * root + 1;
+        if (child + 1 <= end && a[child] < a[child + 1]) child++;
+        if (a[root] >= a[child]) return;
+        const int t = a[root]; a[root] = a[child]; a[child] = t;
+        root = child;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK)
+void order_and_fill(int ncols, int nrows, const int *__restrict__ ptr, const double *__restrict__ val,
+                    const int *__restrict__ tptr, int *__restrict__ pos, int *__restrict__ tidx,
+                    double *__restrict__ tval)
+{
+    const int c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= ncols) return;
+    int *a = pos + tptr[c];
+    const int len = tptr[c + 1] - tptr[c];
+    if (len <= 32) {                                 // insertion sort
+        for (int i = 1; i < len; i++) {
+            const int v = a[i];
+            int j = i - 1;
+            while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; j--; }
+            a[j + 1] = v;
+        }
+    } else {                                         // heap sort, in place
+        for (int s = (len - 2) / 2; s >= 0; s--) sift_down(a, s, len - 1);
+        for (int e = len - 1; e > 0; e--) { const int t = a[e]; a[e] = a[0]; a[0] = t; sift_down(a, 0, e - 1); }
+    }
+    for (int i = 0; i < len; i++) {
+        const int k = a[i];
+        int lo = 0, hi = nrows;                      // last row r with ptr[r] <= k
+        while (hi - lo > 1) { const int mid = lo + ((hi - lo) >> 1); if (ptr[mid] <= k) lo = mid; else hi = mid; }
+        tidx[tptr[c] + i] = lo;
+        tval[tptr[c] + i] = val[k];
+    }
+}
+
+} // namespace
+
+// tptr: ncols + 1 ints, tidx / tval: nnz entries; work: (ncols + nnz) ints of scratch.  All device pointers.
+extern "C" int liship_csr_transpose_f64(int nrows, int ncols, int nnz, const int *ptr, const int *idx, const double *val,
+                                        int *tptr, int *tidx, double *tval, int *work, void *stream)
+{
+    if (nrows < 0 || ncols < 0 || nnz < 0) return LISHIP_ERR_ARG;
+    hipStream_t st = as_stream(stream);
+    int *count = work, *pos = work + ncols;
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * (size_t)(ncols > 0 ? ncols : 1), st));
+    if (nrows > 0) count_columns<<<(nrows + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(nrows, ptr, idx, count);
+    LAUNCH_CHECK();
+    {
+        const int ntiles = (ncols + TILE - 1) / TILE;
+        long long *sums = nullptr;
+        HIP_TRY(hipMalloc(&sums, sizeof(long long) * (size_t)(ntiles > 0 ? ntiles : 1)));
+        if (ntiles > 0) {
+            tile_sums<<<ntiles, BLOCK, 0, st>>>(ncols, count, sums);
+            scan_tile_sums<<<1, 1024, 0, st>>>(ntiles, sums);
+            scan_tiles<<<ntiles, BLOCK, 0, st>>>(ncols, count, sums, tptr);
+        } else HIP_TRY(hipMemsetAsync(tptr, 0, sizeof(int), st));
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(sums);
+        if (e != hipSuccess) return (int)e;
+    }
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * (size_t)(ncols > 0 ? ncols : 1), st));
+    if (nrows > 0) scatter_positions<<<(nrows + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(nrows, ptr, idx, tptr, count, pos);
+    LAUNCH_CHECK();
+    if (ncols > 0) order_and_fill<<<(ncols + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(ncols, nrows, ptr, val, tptr, pos, tidx, tval);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -429,3 +429,24 @@ def test_gmres_device_chained_kernels(lib, n):
     for j in range(1, m):
         O.orc_axpy(n, coef[j], V[j], z)
     assert np.array_equal(dV[0].to_host(), z)
+
+
+@pytest.mark.parametrize("name", ["p3d_16", "rand_5000", "rand_long_rows", "mostly_empty", "single_row", "rand_wide_77"])
+def test_csr_transpose_in_scatter_order(lib, name):
+    """A^T built in HBM lists every transposed row's entries by their position in the source arrays (the order of
+    lis_matvech_csr's scatter): arrays equal to a stable host transposition, whatever the atomics did."""
+    ptr, idx, val = CSR_CASES[name]()
+    n = len(ptr) - 1
+    ncols = max(n, int(idx.max()) + 1 if len(idx) else 1)
+    nnz = len(idx)
+    order = np.argsort(idx, kind="stable")                      # positions grouped by column, ascending inside
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(ptr))
+    tptr_ref = np.zeros(ncols + 1, np.int32)
+    np.cumsum(np.bincount(idx, minlength=ncols), out=tptr_ref[1:])
+    dptr, didx, dval = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64)
+    tptr, tidx, tval = DA(ncols + 1, np.int32), DA(max(nnz, 1), np.int32), DA(max(nnz, 1), np.float64)
+    work = DA(ncols + nnz + 4, np.int32)
+    for _ in range(2):
+        check(lib.liship_csr_transpose_f64(n, ncols, nnz, dptr.ptr, didx.ptr, dval.ptr, tptr.ptr, tidx.ptr, tval.ptr, work.ptr, None))
+        assert np.array_equal(tptr.to_host(), tptr_ref)
+        assert np.array_equal(tidx.to_host(nnz), rows[order]) and np.array_equal(tval.to_host(nnz), val[order])

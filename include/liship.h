@@ -149,7 +149,8 @@ int  liship_mgs_step_f64(int n, const double *hprev, const double *vprev, double
 int  liship_scale_inv_norm_f64(int n, const double *sumsq, double *x, void *stream);
 /* z = c0*v0, z += c1*v1, ... (accumulate = 0) or z += c0*v0, ... (accumulate = 1), element by element in that
  * order: the bits of lis_vector_scale/axpy chains (lis_solver_gmres.c:290-296, :323-329) in one pass over z.
- * vs[] and coef[] are HOST arrays (passed by value to the kernel); a v that aliases z reads the running value. */
+ * vs[] and coef[] are HOST arrays (passed by value to the kernel); a v that aliases z reads z as it was on entry.
+ * More than 48 vectors are processed in chunks: only the first chunk may then alias z. */
 int  liship_lincomb_f64(int n, int count, const double *const *vs, const double *coef, int accumulate,
                         double *z, void *stream);
 /* result[0] = <x,y>, result[1] = <x,x> in one pass (BiCGSTAB's <t,s>,<t,t>, lis_solver_bicgstab.c:267-268) */

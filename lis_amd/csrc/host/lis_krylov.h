@@ -104,5 +104,6 @@ LIS_INT lisk_bicrstab(ctx_t *c);
 LIS_INT lisk_bicrsafe(ctx_t *c);
 LIS_INT lisk_fgmres(ctx_t *c);
 LIS_INT lisk_minres(ctx_t *c);
+LIS_INT lisk_idrs(ctx_t *c);
 
 #endif

@@ -694,3 +694,193 @@ done:
 	work_free(c);
 	return err;
 }
+
+/* ------------------------------------------------------------------ IDR(s), lis_solver_idrs.c:523-783
+ * The shadow space P is filled from MT19937 (init_by_array {0x123,0x234,0x345,0x456}, genrand_real1) exactly as the
+ * reference does (:578-585), so the same P -- and with it the same iteration history -- comes out.  The generator
+ * below is the published algorithm of Matsumoto & Nishimura (the reference bundles their mt19937ar.c). */
+typedef struct { unsigned long mt[624]; int mti; } mt19937;
+
+static void mt_seed(mt19937 *g, unsigned long s)
+{
+	g->mt[0] = s & 0xffffffffUL;
+	for (g->mti = 1; g->mti < 624; g->mti++)
+		g->mt[g->mti] = (1812433253UL * (g->mt[g->mti - 1] ^ (g->mt[g->mti - 1] >> 30)) + (unsigned long)g->mti) & 0xffffffffUL;
+}
+
+static void mt_seed_array(mt19937 *g, const unsigned long *key, int len)
+{
+	int i = 1, j = 0, k = 624 > len ? 624 : len;
+	mt_seed(g, 19650218UL);
+	for (; k; k--) {
+		g->mt[i] = ((g->mt[i] ^ ((g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) * 1664525UL)) + key[j] + (unsigned long)j) & 0xffffffffUL;
+		i++; j++;
+		if (i >= 624) { g->mt[0] = g->mt[623]; i = 1; }
+		if (j >= len) j = 0;
+	}
+	for (k = 623; k; k--) {
+		g->mt[i] = ((g->mt[i] ^ ((g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) * 1566083941UL)) - (unsigned long)i) & 0xffffffffUL;
+		i++;
+		if (i >= 624) { g->mt[0] = g->mt[623]; i = 1; }
+	}
+	g->mt[0] = 0x80000000UL;
+}
+
+static unsigned long mt_next(mt19937 *g)
+{
+	static const unsigned long mag[2] = {0x0UL, 0x9908b0dfUL};
+	unsigned long y;
+	if (g->mti >= 624) {
+		int kk;
+		for (kk = 0; kk < 624 - 397; kk++) {
+			y = (g->mt[kk] & 0x80000000UL) | (g->mt[kk + 1] & 0x7fffffffUL);
+			g->mt[kk] = g->mt[kk + 397] ^ (y >> 1) ^ mag[y & 1UL];
+		}
+		for (; kk < 623; kk++) {
+			y = (g->mt[kk] & 0x80000000UL) | (g->mt[kk + 1] & 0x7fffffffUL);
+			g->mt[kk] = g->mt[kk + (397 - 624)] ^ (y >> 1) ^ mag[y & 1UL];
+		}
+		y = (g->mt[623] & 0x80000000UL) | (g->mt[0] & 0x7fffffffUL);
+		g->mt[623] = g->mt[396] ^ (y >> 1) ^ mag[y & 1UL];
+		g->mti = 0;
+	}
+	y = g->mt[g->mti++];
+	y ^= (y >> 11);
+	y ^= (y << 7) & 0x9d2c5680UL;
+	y ^= (y << 15) & 0xefc60000UL;
+	y ^= (y >> 18);
+	return y & 0xffffffffUL;
+}
+
+/* x = M \ m for the s x s system of IDR(s) (column-major, lis_array_solve, src/array/lis_array.c): the reference's
+ * LU without pivoting with reciprocal pivots, special-cased for s = 1, 2 with its own operation order */
+static void small_solve(int n, const double *a, const double *b, double *x, double *w)
+{
+	for (int i = 0; i < n * n; i++) w[i] = a[i];
+	if (n == 1) { x[0] = b[0] / w[0]; return; }
+	if (n == 2) {
+		w[0] = 1.0 / w[0];
+		w[1] *= w[0];
+		w[3] -= w[1] * w[2];
+		w[3] = 1.0 / w[3];
+		x[0] = b[0];
+		x[1] = b[1] - w[1] * x[0];
+		x[1] *= w[3];
+		x[0] -= w[2] * x[1];
+		x[0] *= w[0];
+		return;
+	}
+	for (int k = 0; k < n; k++) {
+		w[k + k * n] = 1.0 / w[k + k * n];
+		for (int i = k + 1; i < n; i++) {
+			const double t = w[i + k * n] * w[k + k * n];
+			for (int j = k + 1; j < n; j++) w[i + j * n] -= t * w[k + j * n];
+			w[i + k * n] = t;
+		}
+	}
+	for (int i = 0; i < n; i++) {
+		x[i] = b[i];
+		for (int j = 0; j < i; j++) x[i] -= w[i + j * n] * x[j];
+	}
+	for (int i = n - 1; i >= 0; i--) {
+		for (int j = i + 1; j < n; j++) x[i] -= w[i + j * n] * x[j];
+		x[i] *= w[i + i * n];
+	}
+}
+
+LIS_INT lisk_idrs(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter = 0;
+	const int n = c->n, sd = s->options[LIS_OPTIONS_IDRS_RESTART];
+	double nrm2 = 0.0, om = 0.0, h;
+	double *m = NULL, *cf = NULL, *M = NULL, *MM = NULL, *hostP = NULL, *coef = NULL;
+	const double **vs = NULL;
+	if (sd < 1 || sd > 40) { err = LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_IDRS_RESTART(=%D) must be in [1,40]\n", (LIS_INT)sd); goto done; }
+	if (lisg.nprocs > 1) { err = LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "IDR(s) is single-process only in liblis_amd\n"); goto done; }
+	m = (double *)calloc((size_t)sd, sizeof(double)); cf = (double *)calloc((size_t)sd, sizeof(double));
+	M = (double *)calloc((size_t)sd * sd, sizeof(double)); MM = (double *)calloc((size_t)sd * sd, sizeof(double));
+	coef = (double *)calloc((size_t)sd + 1, sizeof(double)); vs = (const double **)calloc((size_t)sd + 1, sizeof(double *));
+	hostP = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+	if (!m || !cf || !M || !MM || !coef || !vs || !hostP) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)sd); goto done; }
+	TRY(work_alloc(c, 4 + 3 * sd));
+	double *r = c->work[0], *t = c->work[1], *v = c->work[2], *av = c->work[3];
+	double **dX = &c->work[4], **P = &c->work[4 + sd], **dR = &c->work[4 + 2 * sd];
+	int st = initial_residual(c, r);
+	if (st) { err = st < 0 ? -st : 0; goto done; }
+	{
+		mt19937 g;
+		const unsigned long key[4] = {0x123, 0x234, 0x345, 0x456};
+		mt_seed_array(&g, key, 4);
+		for (int k = 0; k < sd; k++) {
+			for (int i = 0; i < n; i++) hostP[i] = (double)mt_next(&g) * (1.0 / 4294967295.0);
+			KTRY(liship_memcpy_h2d(P[k], hostP, sizeof(double) * (size_t)n, lisg.stream));
+			KTRY(liship_stream_synchronize(lisg.stream));
+		}
+	}
+	for (int j = 0; j < sd; j++) {                    /* lis_idrs_orth (:202-220): modified Gram-Schmidt on P */
+		double rn, d;
+		TRY(lisd_nrm2(n, P[j], &rn));
+		SCALE(1.0 / rn, P[j]);
+		for (int i = j + 1; i < sd; i++) { DOT(P[j], P[i], &d); AXPY(-d, P[j], P[i]); }
+	}
+	for (int k = 0; k < sd; k++) {                    /* s minimal-residual start-up steps */
+		PSOLVE(r, dX[k]);
+		MATVEC(dX[k], dR[k]);
+		DOT(dR[k], dR[k], &h);
+		DOT(dR[k], r, &om);
+		om = om / h;
+		SCALE(om, dX[k]);
+		SCALE(-om, dR[k]);
+		AXPY(1.0, dX[k], c->x);
+		AXPY(1.0, dR[k], r);
+		RESID(r, &nrm2);
+		iter = k + 1;
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) FINISH(LIS_SUCCESS);
+		for (int i = 0; i < sd; i++) DOT(P[i], dR[k], &M[k * sd + i]);
+	}
+	iter = sd;
+	int oldest = 0;
+	for (int i = 0; i < sd; i++) DOT(P[i], r, &m[i]);
+	while (iter <= c->maxiter) {
+		small_solve(sd, M, m, cf, MM);
+		COPY(r, v);
+		for (int j = 0; j < sd; j++) AXPY(-cf[j], dR[j], v);
+		PSOLVE(v, av);
+		for (int j = 0; j < sd; j++) { coef[j + 1] = -cf[j]; }
+		if ((iter % (sd + 1)) == sd) {
+			MATVEC(av, t);
+			DOT(t, t, &h);
+			DOT(t, v, &om);
+			om = om / h;
+			coef[0] = om;  vs[0] = av; for (int j = 0; j < sd; j++) vs[j + 1] = dX[j];     /* dX[oldest] = om av - sum c_j dX_j */
+			KTRY(liship_lincomb_f64(n, sd + 1, vs, coef, 0, dX[oldest], lisg.stream));
+			coef[0] = -om; vs[0] = t;  for (int j = 0; j < sd; j++) vs[j + 1] = dR[j];     /* dR[oldest] = -om t - sum c_j dR_j */
+			KTRY(liship_lincomb_f64(n, sd + 1, vs, coef, 0, dR[oldest], lisg.stream));
+		} else {
+			coef[0] = om;  vs[0] = av; for (int j = 0; j < sd; j++) vs[j + 1] = dX[j];
+			KTRY(liship_lincomb_f64(n, sd + 1, vs, coef, 0, dX[oldest], lisg.stream));
+			MATVEC(dX[oldest], dR[oldest]);
+			SCALE(-1.0, dR[oldest]);
+		}
+		AXPY(1.0, dR[oldest], r);
+		AXPY(1.0, dX[oldest], c->x);
+		iter++;
+		RESID(r, &nrm2);
+		note(c, iter, nrm2);
+		if (c->tol >= nrm2) FINISH(LIS_SUCCESS);
+		for (int i = 0; i < sd; i++) {
+			DOT(P[i], dR[oldest], &h);
+			m[i] += h;
+			M[oldest * sd + i] = h;
+		}
+		oldest++;
+		if (oldest == sd) oldest = 0;
+	}
+	FINISH(LIS_MAXITER);
+done:
+	work_free(c);
+	free(m); free(cf); free(M); free(MM); free(coef); free((void *)vs); free(hostP);
+	return err;
+}

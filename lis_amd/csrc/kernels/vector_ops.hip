@@ -438,21 +438,23 @@ extern "C" int liship_scale_inv_norm_f64(int n, const double *sumsq, double *x, 
 
 namespace {
 constexpr int LINCOMB_MAX = 48;
-struct LinComb { int n, count, accumulate; const double *v[LINCOMB_MAX]; double c[LINCOMB_MAX]; };
+struct LinComb { int n, count, accumulate, aliased; const double *v[LINCOMB_MAX]; double c[LINCOMB_MAX]; };
 
 // accumulate == 0: z = c0*v0; z += c1*v1; ...      (lis_vector_scale + axpys, lis_solver_gmres.c:290-296)
-// accumulate == 1: z += c0*v0; z += c1*v1; ...     (v0 may be z itself: the residual update :323-329)
+// accumulate == 1: z += c0*v0; z += c1*v1; ...     (a v may be z itself -- it then reads z as it was on entry:
+//                 the residual update :323-329, the IDR(s) direction updates lis_solver_idrs.c:660-700)
 __global__ __launch_bounds__(BLOCK)
 void lincomb_kernel(LinComb L, double *__restrict__ z)
 {
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= L.n) return;
+    const double z0 = (L.accumulate || L.aliased) ? z[i] : 0.0;    // a v that aliases z reads z as it was on entry
     double t;
     int j = 0;
-    if (L.accumulate) t = z[i];
-    else { t = L.c[0] * L.v[0][i]; j = 1; }
+    if (L.accumulate) t = z0;
+    else { t = L.c[0] * ((L.v[0] == z) ? z0 : L.v[0][i]); j = 1; }
     for (; j < L.count; j++) {
-        const double vj = (L.v[j] == z) ? t : L.v[j][i];   // aliasing z means "the running value"
+        const double vj = (L.v[j] == z) ? z0 : L.v[j][i];
         t = t + L.c[j] * vj;
     }
     z[i] = t;
@@ -470,7 +472,8 @@ extern "C" int liship_lincomb_f64(int n, int count, const double *const *vs, con
         LinComb L;
         L.n = n; L.accumulate = (done > 0) ? 1 : accumulate;
         L.count = (count - done < LINCOMB_MAX) ? count - done : LINCOMB_MAX;
-        for (int j = 0; j < L.count; j++) { L.v[j] = vs[done + j]; L.c[j] = coef[done + j]; }
+        L.aliased = 0;
+        for (int j = 0; j < L.count; j++) { L.v[j] = vs[done + j]; L.c[j] = coef[done + j]; if (L.v[j] == z) L.aliased = 1; }
         lincomb_kernel<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, as_stream(s)>>>(L, z);
         LAUNCH_CHECK();
         done += L.count;

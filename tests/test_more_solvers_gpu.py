@@ -1,5 +1,5 @@
 """The other Krylov solvers of Lis (CGS, CR, GPBiCG, TFQMR, BiCGSafe, Orthomin, BiCR, CRS, BiCRSTAB,
-GPBiCR, BiCRSafe, FGMRES, MINRES, COCG, COCR) on the GPU against
+GPBiCR, BiCRSafe, FGMRES, MINRES, COCG, COCR, IDR(s)) on the GPU against
 what the reference itself produced for the same systems (tests/golden/solvers_golden.npz, make_golden_solvers.py).
 
 Element-wise arithmetic is bit-identical; the reductions are trees, so a recurrence can part from the reference's
@@ -37,7 +37,7 @@ def lib():
 
 @pytest.mark.parametrize("case", CASES)
 def test_solver_matches_reference(lib, case):
-    solver, precon, mat = case.split("_")
+    solver, precon, mat = case.split("_")          # "idrs4" = IDR(s) with -irestart 4
     ptr, idx, val = orc.poisson3d(8, 7, 6) if mat == "p3d" else nonsym_matrix(n=120, seed=9)
     n = len(ptr) - 1
     b = orc.spmv_csr(ptr, idx, val, np.ones(n))
@@ -52,7 +52,10 @@ def test_solver_matches_reference(lib, case):
         if mat == "p3d" and solver != "fgmres":
             assert out["iter"] == it_ref, (case, out["iter"], it_ref)
         else:
-            assert abs(out["iter"] - it_ref) <= max(3, it_ref // 10), (case, out["iter"], it_ref)
+            # IDR(s) without a preconditioner on the non-symmetric matrix wanders for 100+ iterations before it drops;
+            # where it drops moves by 15-20 % with the reduction order (same first residuals, same P): 25 % bar there
+            slack = it_ref // 4 if solver.startswith("idrs") else it_ref // 10
+            assert abs(out["iter"] - it_ref) <= max(3, slack), (case, out["iter"], it_ref)
         assert out["resid"] <= 1e-12
         assert np.allclose(out["x"], G[case + "/x"], rtol=0, atol=1e-8)
     else:
@@ -67,5 +70,5 @@ def test_solver_matches_reference(lib, case):
 def test_unserved_solver_says_so(lib):
     ptr, idx, val = orc.poisson1d(10)
     A = lisdrv.make_csr(lib, ptr, idx, val)
-    out = lisdrv.solve(lib, A, np.ones(10), "-i idrs")
+    out = lisdrv.solve(lib, A, np.ones(10), "-i bicgstabl")
     assert out["err"] == capi.LIS_ERR_NOT_IMPLEMENTED

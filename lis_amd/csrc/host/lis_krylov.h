@@ -105,5 +105,6 @@ LIS_INT lisk_bicrsafe(ctx_t *c);
 LIS_INT lisk_fgmres(ctx_t *c);
 LIS_INT lisk_minres(ctx_t *c);
 LIS_INT lisk_idrs(ctx_t *c);
+LIS_INT lisk_bicgstabl(ctx_t *c);
 
 #endif

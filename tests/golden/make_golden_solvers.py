@@ -1,5 +1,5 @@
 """Golden results of the reference for the solvers of lis_solver_more.c (CGS, CR, GPBiCG, TFQMR, BiCGSafe, Orthomin, BiCR, CRS,
-BiCRSTAB, GPBiCR, BiCRSafe, FGMRES, MINRES, COCG, COCR, IDR(s)).
+BiCRSTAB, GPBiCR, BiCRSafe, FGMRES, MINRES, COCG, COCR, IDR(s), BiCGSTAB(l)).
 
 Dev container only: oracle/_ref (Lis 2.1.11 from /root/reference/src, 1 OpenMP thread) through lis_solve; stores the
 iteration count, status, residual history and solution per case.
@@ -22,7 +22,7 @@ from make_golden_scale import test_matrix  # noqa: E402
 
 CASES = []
 for solver in ("cgs", "cr", "gpbicg", "tfqmr", "bicgsafe", "orthomin",
-               "bicr", "crs", "bicrstab", "gpbicr", "bicrsafe", "fgmres", "minres", "cocg", "cocr", "idrs", "idrs4"):
+               "bicr", "crs", "bicrstab", "gpbicr", "bicrsafe", "fgmres", "minres", "cocg", "cocr", "idrs", "idrs4", "bicgstabl", "bicgstabl4"):
     for precon in ("none", "jacobi"):
         for mat in ("p3d", "nonsym"):
             if solver in ("cr", "minres", "cocg", "cocr") and mat == "nonsym":
@@ -46,6 +46,8 @@ def main():
         opts = f"-i {solver.rstrip('4')} -p {precon} -tol 1e-12 -maxiter 400 -print mem" + (" -restart 5" if solver in ("orthomin", "fgmres") else "")
         if solver == "idrs4":
             opts += " -irestart 4"
+        if solver == "bicgstabl4":
+            opts += " -ell 4"
         res = lisdrv.solve(ref, A, b, opts)
         key = f"{solver}_{precon}_{mat}"
         out[key + "/iter_status"] = np.array([res["iter"], res["status"]])

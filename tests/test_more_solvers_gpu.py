@@ -1,5 +1,5 @@
 """The other Krylov solvers of Lis (CGS, CR, GPBiCG, TFQMR, BiCGSafe, Orthomin, BiCR, CRS, BiCRSTAB,
-GPBiCR, BiCRSafe, FGMRES, MINRES, COCG, COCR, IDR(s)) on the GPU against
+GPBiCR, BiCRSafe, FGMRES, MINRES, COCG, COCR, IDR(s), BiCGSTAB(l)) on the GPU against
 what the reference itself produced for the same systems (tests/golden/solvers_golden.npz, make_golden_solvers.py).
 
 Element-wise arithmetic is bit-identical; the reductions are trees, so a recurrence can part from the reference's
@@ -37,7 +37,7 @@ def lib():
 
 @pytest.mark.parametrize("case", CASES)
 def test_solver_matches_reference(lib, case):
-    solver, precon, mat = case.split("_")          # "idrs4" = IDR(s) with -irestart 4
+    solver, precon, mat = case.split("_")          # "idrs4" = IDR(s) with -irestart 4, "bicgstabl4" = BiCGSTAB(l) with -ell 4
     ptr, idx, val = orc.poisson3d(8, 7, 6) if mat == "p3d" else nonsym_matrix(n=120, seed=9)
     n = len(ptr) - 1
     b = orc.spmv_csr(ptr, idx, val, np.ones(n))
@@ -70,5 +70,5 @@ def test_solver_matches_reference(lib, case):
 def test_unserved_solver_says_so(lib):
     ptr, idx, val = orc.poisson1d(10)
     A = lisdrv.make_csr(lib, ptr, idx, val)
-    out = lisdrv.solve(lib, A, np.ones(10), "-i bicgstabl")
+    out = lisdrv.solve(lib, A, np.ones(10), "-i idr1")
     assert out["err"] == capi.LIS_ERR_NOT_IMPLEMENTED

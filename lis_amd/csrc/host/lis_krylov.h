@@ -55,7 +55,7 @@ static inline LIS_INT d_resid(ctx_t *c, const double *r, double *nrm)
 static inline void note(ctx_t *c, LIS_INT iter, double nrm)
 {
 	if (!c->output) return;
-	if (c->output & LIS_PRINT_MEM) c->s->rhistory[iter] = nrm;
+	if ((c->output & LIS_PRINT_MEM) && iter <= c->maxiter + 1) c->s->rhistory[iter] = nrm;   /* maxiter + 2 slots (IDR(1) can step past) */
 	if (c->output & LIS_PRINT_OUT) lis_printf(LIS_COMM_WORLD, "iteration: %5d  relative residual = %e\n", (int)iter, nrm);
 }
 

@@ -658,9 +658,9 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	case LIS_SOLVER_CGS: case LIS_SOLVER_CR: case LIS_SOLVER_GPBICG: case LIS_SOLVER_TFQMR: case LIS_SOLVER_BICGSAFE:
 	case LIS_SOLVER_ORTHOMIN: case LIS_SOLVER_BICR: case LIS_SOLVER_CRS: case LIS_SOLVER_BICRSTAB: case LIS_SOLVER_GPBICR:
 	case LIS_SOLVER_BICRSAFE: case LIS_SOLVER_FGMRES: case LIS_SOLVER_MINRES: case LIS_SOLVER_COCG: case LIS_SOLVER_COCR:
-	case LIS_SOLVER_IDRS: case LIS_SOLVER_BICGSTABL:
+	case LIS_SOLVER_IDRS: case LIS_SOLVER_BICGSTABL: case LIS_SOLVER_IDR1:
 		break;
-	default:      /* IDR(1) and the stationary Jacobi / Gauss-Seidel / SOR iterations */
+	default:      /* the stationary Jacobi / Gauss-Seidel / SOR iterations */
 		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s is not served by liblis_amd\n", solver_names[nsolver]);
 	}
 	if (maxiter < 0) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_MAXITER(=%D) is less than 0\n", maxiter);
@@ -760,7 +760,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	case LIS_SOLVER_BICRSAFE: err = lisk_bicrsafe(&c); break;
 	case LIS_SOLVER_FGMRES:   err = lisk_fgmres(&c); break;
 	case LIS_SOLVER_MINRES:   err = lisk_minres(&c); break;
-	case LIS_SOLVER_IDRS:     err = lisk_idrs(&c); break;
+	case LIS_SOLVER_IDRS: case LIS_SOLVER_IDR1: err = lisk_idrs(&c); break;
 	case LIS_SOLVER_BICGSTABL: err = lisk_bicgstabl(&c); break;
 	case LIS_SOLVER_COCG:     err = run_cg(&c); break;          /* real build: lis_cocg is lis_cg's arithmetic (lis_solver_cg.c:632-739) */
 	case LIS_SOLVER_COCR:     err = lisk_cr(&c); break;         /* and lis_cocr is lis_cr's (:1155-1274) */

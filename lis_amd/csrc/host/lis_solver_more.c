@@ -792,7 +792,8 @@ LIS_INT lisk_idrs(ctx_t *c)
 {
 	LIS_SOLVER s = c->s;
 	LIS_INT err = 0, iter = 0;
-	const int n = c->n, sd = s->options[LIS_OPTIONS_IDRS_RESTART];
+	/* IDR(1) (lis_idr1, lis_solver_idrs.c:222-520) is the same recurrence with s = 1 written out */
+	const int n = c->n, sd = (s->options[LIS_OPTIONS_SOLVER] == LIS_SOLVER_IDR1) ? 1 : s->options[LIS_OPTIONS_IDRS_RESTART];
 	double nrm2 = 0.0, om = 0.0, h;
 	double *m = NULL, *cf = NULL, *M = NULL, *MM = NULL, *hostP = NULL, *coef = NULL;
 	const double **vs = NULL;
@@ -843,7 +844,9 @@ LIS_INT lisk_idrs(ctx_t *c)
 	iter = sd;
 	int oldest = 0;
 	for (int i = 0; i < sd; i++) DOT(P[i], r, &m[i]);
-	while (iter <= c->maxiter) {
+	/* lis_idr1 runs its two kinds of step back to back and tests maxiter once per pair (:320-510) */
+	const int idr1 = (s->options[LIS_OPTIONS_SOLVER] == LIS_SOLVER_IDR1);
+	while (iter <= c->maxiter || (idr1 && iter % 2 == 0)) {
 		small_solve(sd, M, m, cf, MM);
 		COPY(r, v);
 		for (int j = 0; j < sd; j++) AXPY(-cf[j], dR[j], v);

@@ -54,7 +54,7 @@ def test_solver_matches_reference(lib, case):
         else:
             # IDR(s) without a preconditioner on the non-symmetric matrix wanders for 100+ iterations before it drops;
             # where it drops moves by 15-20 % with the reduction order (same first residuals, same P): 25 % bar there
-            slack = it_ref // 4 if solver.startswith("idrs") else it_ref // 10
+            slack = it_ref // 4 if solver.startswith("idr") else it_ref // 10
             assert abs(out["iter"] - it_ref) <= max(3, slack), (case, out["iter"], it_ref)
         assert out["resid"] <= 1e-12
         assert np.allclose(out["x"], G[case + "/x"], rtol=0, atol=1e-8)
@@ -63,12 +63,13 @@ def test_solver_matches_reference(lib, case):
     k = min(out["iter"], it_ref, 5)
     assert np.allclose(out["rhistory"][1:k + 1], G[case + "/rhistory"][1:k + 1], rtol=1e-8, atol=0), case
     cut = lisdrv.solve(lib, A, b, opts.replace("-maxiter 400", "-maxiter 3"))
-    assert [cut["iter"], cut["status"]] == [int(v) for v in G[case + "/cut_iter_status"]] == [4, capi.LIS_MAXITER]
+    assert [cut["iter"], cut["status"]] == [int(v) for v in G[case + "/cut_iter_status"]]       # 4 (IDR(1): 5), LIS_MAXITER
+    assert cut["status"] == capi.LIS_MAXITER
     assert np.allclose(cut["x"], G[case + "/cut_x"], rtol=1e-9, atol=1e-12)
 
 
 def test_unserved_solver_says_so(lib):
     ptr, idx, val = orc.poisson1d(10)
     A = lisdrv.make_csr(lib, ptr, idx, val)
-    out = lisdrv.solve(lib, A, np.ones(10), "-i idr1")
+    out = lisdrv.solve(lib, A, np.ones(10), "-i sor")
     assert out["err"] == capi.LIS_ERR_NOT_IMPLEMENTED

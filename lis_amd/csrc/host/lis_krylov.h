@@ -106,5 +106,6 @@ LIS_INT lisk_fgmres(ctx_t *c);
 LIS_INT lisk_minres(ctx_t *c);
 LIS_INT lisk_idrs(ctx_t *c);
 LIS_INT lisk_bicgstabl(ctx_t *c);
+LIS_INT lisk_jacobi(ctx_t *c);
 
 #endif

@@ -658,13 +658,13 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	case LIS_SOLVER_CGS: case LIS_SOLVER_CR: case LIS_SOLVER_GPBICG: case LIS_SOLVER_TFQMR: case LIS_SOLVER_BICGSAFE:
 	case LIS_SOLVER_ORTHOMIN: case LIS_SOLVER_BICR: case LIS_SOLVER_CRS: case LIS_SOLVER_BICRSTAB: case LIS_SOLVER_GPBICR:
 	case LIS_SOLVER_BICRSAFE: case LIS_SOLVER_FGMRES: case LIS_SOLVER_MINRES: case LIS_SOLVER_COCG: case LIS_SOLVER_COCR:
-	case LIS_SOLVER_IDRS: case LIS_SOLVER_BICGSTABL: case LIS_SOLVER_IDR1:
+	case LIS_SOLVER_IDRS: case LIS_SOLVER_BICGSTABL: case LIS_SOLVER_IDR1: case LIS_SOLVER_JACOBI:
 		break;
-	default:      /* the stationary Jacobi / Gauss-Seidel / SOR iterations */
+	default:      /* Gauss-Seidel / SOR: sparse triangular solves, a different kernel family */
 		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s is not served by liblis_amd\n", solver_names[nsolver]);
 	}
 	if (maxiter < 0) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_MAXITER(=%D) is less than 0\n", maxiter);
-	if (conv > 0 && (nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_TFQMR || nsolver == LIS_SOLVER_FGMRES || nsolver == LIS_SOLVER_MINRES)) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
+	if (conv > 0 && (nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_TFQMR || nsolver == LIS_SOLVER_FGMRES || nsolver == LIS_SOLVER_MINRES || nsolver == LIS_SOLVER_JACOBI)) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
 	if (solver->options[LIS_OPTIONS_PRECISION] != LIS_PRECISION_DOUBLE) return LISI_ERR(LIS_ERR_ILL_ARG, "Quad precision is not enabled\n");
 	LIS_INT scale = solver->options[LIS_OPTIONS_SCALE];
 	if (scale && storage == LIS_MATRIX_BSR && scale == LIS_SCALE_JACOBI)
@@ -762,6 +762,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	case LIS_SOLVER_MINRES:   err = lisk_minres(&c); break;
 	case LIS_SOLVER_IDRS: case LIS_SOLVER_IDR1: err = lisk_idrs(&c); break;
 	case LIS_SOLVER_BICGSTABL: err = lisk_bicgstabl(&c); break;
+	case LIS_SOLVER_JACOBI:   err = lisk_jacobi(&c); break;
 	case LIS_SOLVER_COCG:     err = run_cg(&c); break;          /* real build: lis_cocg is lis_cg's arithmetic (lis_solver_cg.c:632-739) */
 	case LIS_SOLVER_COCR:     err = lisk_cr(&c); break;         /* and lis_cocr is lis_cr's (:1155-1274) */
 	default:                  err = run_gmres(&c); break;

@@ -984,3 +984,40 @@ done:
 	free(tau);
 	return err;
 }
+
+/* the stationary Jacobi iteration as a solver, lis_solver_jacobi.c:104-190 (-p none; with a preconditioner the
+ * reference first rescales the system, lis_solver.c:639-656: not served).  x += D^-1 (b - A x), residual relative
+ * to ||b||, against the raw -tol parameter. */
+LIS_INT lisk_jacobi(ctx_t *c)
+{
+	LIS_SOLVER s = c->s;
+	LIS_INT err = 0, iter = 0;
+	const int n = c->n;
+	const double tol = s->params[LIS_PARAMS_RESID - LIS_OPTIONS_LEN];
+	double nrm2 = 0.0, bnrm2;
+	lisd_mat *dm = MDEV(c->A);
+	if (c->dinv) { err = LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "the Jacobi solver with a preconditioner (system rescaling) is not served by liblis_amd\n"); goto done; }
+	if (dm->type != LIS_MATRIX_CSR) { err = LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "the Jacobi solver is served for CSR / CSC storage only\n"); goto done; }
+	TRY(work_alloc(c, 4));
+	double *r = c->work[0], *t = c->work[1], *sx = c->work[2], *d = c->work[3];
+	TRY(lisd_nrm2(n, c->b, &bnrm2));
+	bnrm2 = 1.0 / bnrm2;
+	KTRY(liship_csr_diagonal_f64(n, dm->ptr, dm->index, dm->value, d, lisg.stream));
+	KTRY(liship_reciprocal_f64(n, d, lisg.stream));
+	for (iter = 1; iter <= c->maxiter; iter++) {
+		PSOLVE(c->x, sx);
+		MATVEC(sx, t);
+		AXPYZ(-1.0, t, c->b, r);
+		TRY(lisd_nrm2(n, r, &nrm2));
+		KTRY(liship_pmul_f64(n, r, d, r, lisg.stream));
+		AXPY(1.0, r, c->x);
+		nrm2 = nrm2 * bnrm2;
+		note(c, iter, nrm2);
+		if (tol >= nrm2) { PSOLVE(c->x, sx); COPY(sx, c->x); FINISH(LIS_SUCCESS); }
+	}
+	PSOLVE(c->x, sx); COPY(sx, c->x);
+	FINISH(LIS_MAXITER);
+done:
+	work_free(c);
+	return err;
+}

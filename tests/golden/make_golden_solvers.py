@@ -22,11 +22,13 @@ from make_golden_scale import test_matrix  # noqa: E402
 
 CASES = []
 for solver in ("cgs", "cr", "gpbicg", "tfqmr", "bicgsafe", "orthomin",
-               "bicr", "crs", "bicrstab", "gpbicr", "bicrsafe", "fgmres", "minres", "cocg", "cocr", "idrs", "idrs4", "bicgstabl", "bicgstabl4", "idr1"):
+               "bicr", "crs", "bicrstab", "gpbicr", "bicrsafe", "fgmres", "minres", "cocg", "cocr", "idrs", "idrs4", "bicgstabl", "bicgstabl4", "idr1", "jacobi"):
     for precon in ("none", "jacobi"):
         for mat in ("p3d", "nonsym"):
             if solver in ("cr", "minres", "cocg", "cocr") and mat == "nonsym":
                 continue                                   # symmetric systems only
+            if solver == "jacobi" and precon != "none":
+                continue                                   # the stationary solver is served without a preconditioner
             CASES.append((solver, precon, mat))
 
 

@@ -71,5 +71,5 @@ def test_solver_matches_reference(lib, case):
 def test_unserved_solver_says_so(lib):
     ptr, idx, val = orc.poisson1d(10)
     A = lisdrv.make_csr(lib, ptr, idx, val)
-    out = lisdrv.solve(lib, A, np.ones(10), "-i sor")
+    out = lisdrv.solve(lib, A, np.ones(10), "-i sor")                  # Gauss-Seidel / SOR: not served, said loudly
     assert out["err"] == capi.LIS_ERR_NOT_IMPLEMENTED

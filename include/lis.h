@@ -5,9 +5,11 @@
  * convention and -- for the structs -- the byte layout of anishida/lis 2.1.11 (reference
  * include/lis.h; the line each item mirrors is cited as "ref:NNN").  A program written against the
  * reference header compiles against this one and links against liblis_amd.so instead of liblis.
- * Only the slice on the hot path is provided; anything else is absent, and the
- * two storage formats / solvers that exist in the enumerations but are not served return
- * LIS_ERR_NOT_IMPLEMENTED at run time exactly where the reference would dispatch to them.
+ * Only the slice on the hot path and the rows next to it are provided (six storage
+ * formats, A x and A^T x, the Krylov solvers, none/Jacobi preconditioning, scaling, Matrix Market / Harwell-Boeing
+ * files); anything else is absent, and what exists in the enumerations but is not served (MSR/BSC/VBR/COO/DNS
+ * storage, Gauss-Seidel / SOR, the ILU-family preconditioners) returns LIS_ERR_NOT_IMPLEMENTED at run time
+ * exactly where the reference would dispatch to it.
  *
  * Default build of the reference is assumed: LIS_INT = int (ref:461), LIS_SCALAR = LIS_REAL = double
  * (ref:446-447), no MPI (LIS_Comm = LIS_INT, ref:485), no quad precision.
@@ -263,7 +265,8 @@ typedef struct LIS_VECTOR_STRUCT *LIS_VECTOR;
 
 #define LIS_MATRIX_OPTION_LEN 10
 
-/* ref:569-589 (split parts; never populated here: lis_matrix_split is out of scope) */
+/* ref:569-589 (split parts; never populated here: lis_matrix_split is internal to the reference and only reached
+ * through the SSOR / ILU-family preconditioners, which are not served) */
 struct LIS_MATRIX_CORE_STRUCT
 {
 	LIS_INT nnz, ndz, bnr, bnc, nr, nc, bnnz, nnd, maxnzr;

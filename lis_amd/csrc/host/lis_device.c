@@ -365,6 +365,8 @@ LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double 
 
 LIS_INT lisd_fetch(int count, double *out)
 {
+	if (lisg.nprocs > 1 && lisg.comm_kind == 1)        /* RCCL gathers the partials straight from HBM: one sync, not two */
+		return lisc_fold(count, out);
 	HIPCHK(liship_memcpy_d2h(lisg.host_out, lisg.reduce_out, (size_t)count * sizeof(double), lisg.stream));
 	HIPCHK(liship_stream_synchronize(lisg.stream));
 	for (int i = 0; i < count; i++) out[i] = lisg.host_out[i];

@@ -80,6 +80,11 @@ int  liship_spmv_csr_rows_f64(liship_csr_plan_t plan, int row_begin, int row_end
 /* tuning knobs for experiments (bench/profiling only): variant 0 = default */
 int  liship_spmv_csr_set_variant(int variant);
 
+/* ELL / DIA products with the reduction epilogue of liship_spmv_csr_dot_f64 (same contract and fallback rule) */
+int  liship_spmv_ell_dot_f64(int n, int maxnzr, const int *index, const double *value, const double *x, double *y,
+                             const double *w, int want_sumsq, double *result, void *work, void *stream);
+int  liship_spmv_dia_dot_f64(int n, int ncols, int nnd, const int *offsets, const double *value, const double *x, double *y,
+                             const double *w, int want_sumsq, double *result, void *work, void *stream);
 /* ------------------------------------------------------------------ other formats
  * ELL   lis_matvec_ell  src/matvec/lis_matvec_ell.c:113-128   value/index column-major [maxnzr][n]
  * DIA   lis_matvec_dia  src/matvec/lis_matvec_dia.c:148-172   ONE-chunk layout value[d*n+i], offsets index[nnd]

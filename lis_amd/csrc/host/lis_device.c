@@ -357,6 +357,15 @@ LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double 
 		if (rc == 0) return LIS_SUCCESS;
 		if (rc != LISHIP_ERR_ARG) HIPCHK(rc);
 		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));
+	} else if ((d->type == LIS_MATRIX_ELL || d->type == LIS_MATRIX_DIA) && !lisg.no_fusion) {
+		if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
+		int rc = (d->type == LIS_MATRIX_ELL)
+			? liship_spmv_ell_dot_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, dw, want_sumsq, lisg.reduce_out, lisg.reduce_work, lisg.stream)
+			: liship_spmv_dia_dot_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, dw, want_sumsq, lisg.reduce_out, lisg.reduce_work, lisg.stream);
+		if (rc == 0) return LIS_SUCCESS;
+		if (rc != LISHIP_ERR_ARG) HIPCHK(rc);
+		if (d->type == LIS_MATRIX_ELL) HIPCHK(liship_spmv_ell_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, lisg.stream));
+		else HIPCHK(liship_spmv_dia_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, lisg.stream));
 	} else LISCHK(lisd_spmv(A, dx, dy));
 	if (want_sumsq) HIPCHK(liship_dot2_f64(d->n, dy, dw, lisg.reduce_out, lisg.reduce_work, lisg.stream));
 	else HIPCHK(liship_dot_f64(d->n, dw, dy, lisg.reduce_out, lisg.reduce_work, lisg.stream));

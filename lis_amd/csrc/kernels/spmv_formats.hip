@@ -15,14 +15,31 @@ constexpr int BLOCK = 256;
 
 // ELL: lane owns ROWS consecutive rows (2 when n is even: 16 B value / 8 B index loads), UNROLL jagged columns
 // in flight before the first use; column-major storage makes every load of a wavefront contiguous.
-template <int ROWS, int UNROLL>
+// lane partials of the fused reductions <w,y> (DOT >= 1) and <y,y> (DOT == 2) -> one value per workgroup
+template <int DOT>
+__device__ __forceinline__ void publish(double c0, double c1, double *__restrict__ partial, int stride)
+{
+    __shared__ double scratch[BLOCK / WAVE];
+    if (DOT == 0) return;
+    const double t0 = block_sum<BLOCK / WAVE>(c0, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t0;
+    if (DOT == 2) {
+        const double t1 = block_sum<BLOCK / WAVE>(c1, scratch);
+        if (threadIdx.x == 0) partial[stride + blockIdx.x] = t1;
+    }
+}
+
+template <int ROWS, int UNROLL, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const double *__restrict__ val,
-                     const double *__restrict__ x, double *__restrict__ y)
+                     const double *__restrict__ x, double *__restrict__ y,
+                     const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr)
 {
-    const int r = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
-    if (r >= n) return;
-    double acc[ROWS];
+    const int r0 = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
+    const bool active = r0 < n;
+    if (!DOT && !active) return;
+    const int r = active ? r0 : 0;                  // idle lanes of the last workgroup shadow row 0 (fused form: they
+    double acc[ROWS];                               // must reach the workgroup reduction)
 #pragma unroll
     for (int i = 0; i < ROWS; i++) acc[i] = 0.0;
     for (int j0 = 0; j0 < maxnzr; j0 += UNROLL) {
@@ -50,20 +67,30 @@ void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const doubl
                 acc[i] += (j0 + u < maxnzr) ? t : 0.0;      // +0.0 leaves the sum's bits unchanged
             }
     }
-    if (ROWS == 2) { v2f64 o; o.x = acc[0]; o.y = acc[ROWS - 1]; store_stream(reinterpret_cast<v2f64 *>(y + r), o); }
-    else store_stream(y + r, acc[0]);
+    double c0 = 0.0, c1 = 0.0;
+    if (active) {
+        if (ROWS == 2) { v2f64 o; o.x = acc[0]; o.y = acc[ROWS - 1]; store_stream(reinterpret_cast<v2f64 *>(y + r), o); }
+        else store_stream(y + r, acc[0]);
+        if (DOT) {
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) { c0 += wdot[r + i] * acc[i]; if (DOT == 2) c1 += acc[i] * acc[i]; }
+        }
+    }
+    publish<DOT>(c0, c1, partial, gridDim.x);
 }
 
 // DIA: same shape; a diagonal's offset is wave-uniform (scalar load), x[r + off] is contiguous across the wavefront.
 // The reference skips the part of a diagonal that falls outside the matrix (lis_matvec_dia.c:152-158): masked here.
-template <int ROWS, int UNROLL>
+template <int ROWS, int UNROLL, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_dia_kernel(int n, int ncols, int nnd, const int *__restrict__ off,
                      const double *__restrict__ val, const double *__restrict__ x,
-                     double *__restrict__ y)
+                     double *__restrict__ y, const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr)
 {
-    const int r = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
-    if (r >= n) return;
+    const int r0 = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
+    const bool active = r0 < n;
+    if (!DOT && !active) return;
+    const int r = active ? r0 : 0;
     double acc[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; i++) acc[i] = 0.0;
@@ -94,8 +121,16 @@ void spmv_dia_kernel(int n, int ncols, int nnd, const int *__restrict__ off,
                 acc[i] += ok[u][i] ? t : 0.0;
             }
     }
-    if (ROWS == 2) { v2f64 o; o.x = acc[0]; o.y = acc[ROWS - 1]; store_stream(reinterpret_cast<v2f64 *>(y + r), o); }
-    else store_stream(y + r, acc[0]);
+    double c0 = 0.0, c1 = 0.0;
+    if (active) {
+        if (ROWS == 2) { v2f64 o; o.x = acc[0]; o.y = acc[ROWS - 1]; store_stream(reinterpret_cast<v2f64 *>(y + r), o); }
+        else store_stream(y + r, acc[0]);
+        if (DOT) {
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) { c0 += wdot[r + i] * acc[i]; if (DOT == 2) c1 += acc[i] * acc[i]; }
+        }
+    }
+    publish<DOT>(c0, c1, partial, gridDim.x);
 }
 
 // JAD: lane owns one slot of the length-sorted order; UNROLL jagged diagonals in flight.  Diagonals only get
@@ -252,6 +287,38 @@ extern "C" int liship_spmv_dia_f64(int n, int ncols, int nnd, const int *off, co
         spmv_dia_kernel<1, 8><<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y);
     LAUNCH_CHECK();
     return 0;
+}
+
+// ELL / DIA products with the reduction epilogue of liship_spmv_csr_dot_f64 (same contract: LISHIP_ERR_ARG when the
+// fused form cannot serve the call -- odd n, unaligned arrays -- and the caller then uses product + dot)
+extern "C" int liship_spmv_ell_dot_f64(int n, int maxnzr, const int *idx, const double *val, const double *x, double *y,
+                                       const double *w, int want_sumsq, double *result, void *work, void *stream)
+{
+    if (n <= 0 || maxnzr <= 0 || !w || !result || !work) return LISHIP_ERR_ARG;
+    if ((n & 1) || !aligned16(val) || !aligned16(y) || (reinterpret_cast<uintptr_t>(idx) & 7u)) return LISHIP_ERR_ARG;
+    const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
+    const int grid = grid_for(n / 2);
+    if ((size_t)grid > slots) return LISHIP_ERR_ARG;
+    double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
+    if (want_sumsq) spmv_ell_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial);
+    else            spmv_ell_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial);
+    LAUNCH_CHECK();
+    return liship_internal_fold(grid, want_sumsq ? 2 : 1, grid, partial, spare, result, stream);
+}
+
+extern "C" int liship_spmv_dia_dot_f64(int n, int ncols, int nnd, const int *off, const double *val, const double *x, double *y,
+                                       const double *w, int want_sumsq, double *result, void *work, void *stream)
+{
+    if (n <= 0 || nnd <= 0 || ncols < n || !w || !result || !work) return LISHIP_ERR_ARG;
+    if ((n & 1) || !aligned16(val) || !aligned16(y)) return LISHIP_ERR_ARG;
+    const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
+    const int grid = grid_for(n / 2);
+    if ((size_t)grid > slots) return LISHIP_ERR_ARG;
+    double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
+    if (want_sumsq) spmv_dia_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial);
+    else            spmv_dia_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial);
+    LAUNCH_CHECK();
+    return liship_internal_fold(grid, want_sumsq ? 2 : 1, grid, partial, spare, result, stream);
 }
 
 extern "C" int liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int *ptr, const int *idx,

@@ -450,3 +450,39 @@ def test_csr_transpose_in_scatter_order(lib, name):
         check(lib.liship_csr_transpose_f64(n, ncols, nnz, dptr.ptr, didx.ptr, dval.ptr, tptr.ptr, tidx.ptr, tval.ptr, work.ptr, None))
         assert np.array_equal(tptr.to_host(), tptr_ref)
         assert np.array_equal(tidx.to_host(nnz), rows[order]) and np.array_equal(tval.to_host(nnz), val[order])
+
+
+@pytest.mark.parametrize("fmt", ["ell", "dia"])
+@pytest.mark.parametrize("want_sumsq", [0, 1])
+@pytest.mark.parametrize("grid", [(20, 17, 14), (8, 8, 8), (33, 5, 2)])
+def test_ell_dia_fused_dot(lib, fmt, want_sumsq, grid):
+    """ELL / DIA products with the reduction epilogue: y bit-identical to the plain product, sums as the separate
+    reductions (1e-13 relative), repeatable bit for bit"""
+    ptr, idx, val = orc.poisson3d(*grid, sort_cols=True)
+    n = len(ptr) - 1
+    rng = np.random.default_rng(5)
+    x, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    dx, dw, dy = DA.from_host(x), DA.from_host(w), DA.from_host(np.full(n, np.nan))
+    work, res = DA(lib.liship_reduce_work_bytes() // 8, np.float64), DA.from_host(np.full(2, np.nan))
+    if fmt == "ell":
+        mx, eidx, ev = orc.csr2ell(ptr, idx, val)
+        di, dv = DA.from_host(eidx, np.int32), DA.from_host(ev)
+        yref = orc.spmv_ell(n, mx, eidx, ev, x)
+        call = lambda: lib.liship_spmv_ell_dot_f64(n, mx, di.ptr, dv.ptr, dx.ptr, dy.ptr, dw.ptr, want_sumsq, res.ptr, work.ptr, None)
+    else:
+        nnd, off, dval = orc.csr2dia(ptr, idx, val)
+        di, dv = DA.from_host(off, np.int32), DA.from_host(dval)
+        yref = orc.spmv_dia(n, nnd, off, dval, x)
+        call = lambda: lib.liship_spmv_dia_dot_f64(n, n, nnd, di.ptr, dv.ptr, dx.ptr, dy.ptr, dw.ptr, want_sumsq, res.ptr, work.ptr, None)
+    rc = call()
+    if n % 2:
+        assert rc == -1                                        # odd n: the caller falls back to product + dot
+        return
+    check(rc)
+    first = res.to_host()
+    assert np.array_equal(dy.to_host(), yref)
+    check(call())
+    assert np.array_equal(res.to_host()[:1 + want_sumsq], first[:1 + want_sumsq])
+    assert abs(first[0] - np.dot(w, yref)) <= 1e-13 * np.abs(w * yref).sum()
+    if want_sumsq:
+        assert abs(first[1] - np.dot(yref, yref)) <= 1e-13 * np.dot(yref, yref)

@@ -42,6 +42,9 @@ int  liship_stream_destroy(void *stream);
 int  liship_stream_synchronize(void *stream);
 int  liship_device_synchronize(void);
 /* HIP-event stopwatch on `stream`: start/stop bracket a region, elapsed_ms reads it after stop+sync */
+/* page-locked host memory for the scalar read-backs */
+int  liship_malloc_host(void **ptr, size_t bytes);
+int  liship_free_host(void *ptr);
 /* stream-ordering events: record on one stream, make another stream wait (no host involvement) */
 int  liship_event_create(void **event);
 int  liship_event_destroy(void *event);

@@ -35,6 +35,8 @@ _LISHIP = {
     "liship_stream_destroy": (_ci, [_vp]),
     "liship_stream_synchronize": (_ci, [_vp]),
     "liship_device_synchronize": (_ci, []),
+    "liship_malloc_host": (_ci, [_pvp, _sz]),
+    "liship_free_host": (_ci, [_vp]),
     "liship_event_create": (_ci, [_pvp]),
     "liship_event_destroy": (_ci, [_vp]),
     "liship_event_record": (_ci, [_vp, _vp]),

@@ -137,8 +137,9 @@ LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes)
 LIS_INT lisc_fold(int count, double *inout)
 {
 	if (lisg.nprocs <= 1) return LIS_SUCCESS;
-	double all[4 * 64];
+	double stack_all[4 * 64], *all = stack_all;
 	if (count > 4 || lisg.nprocs > 64) return LISI_ERR(LIS_ERR_ILL_ARG, "fold of %D values over %D ranks\n", count, lisg.nprocs);
+	if (lisg.comm_kind == 1 && lisg.host_out) all = lisg.host_out;       /* page-locked landing zone */
 	if (lisg.comm_kind == 1) {
 		/* reduce_out already holds the partials in HBM: gather them device-side, one small D2H */
 		NCCLCHK(rccl.AllGather(lisg.reduce_out, lisg.gather_out, (size_t)count, NCCL_DOUBLE, lisg.nccl_comm, lisg.stream));

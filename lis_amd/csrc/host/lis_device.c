@@ -32,6 +32,7 @@ LIS_INT lisd_init(void)
 	HIPCHK(liship_stream_create(&lisg.stream));
 	HIPCHK(liship_malloc(&lisg.reduce_work, liship_reduce_work_bytes()));
 	HIPCHK(liship_malloc((void **)&lisg.reduce_out, 4 * sizeof(double)));
+	HIPCHK(liship_malloc_host((void **)&lisg.host_out, 4 * 64 * sizeof(double)));
 	lisg.device_ready = 1;
 	return LIS_SUCCESS;
 }

@@ -88,7 +88,7 @@ typedef struct {
 	void *reduce_work;         /* HBM scratch of the two-stage reductions */
 	double *reduce_out;        /* HBM: up to 4 results */
 	double *gather_out;        /* HBM: nprocs * 4 doubles (cross-rank fold) */
-	double host_out[4];
+	double *host_out;          /* page-locked: 4 results, and up to 4 x 64 gathered partials */
 	/* communicator */
 	int rank, nprocs;
 	int comm_kind;             /* 0 none, 1 rccl, 2 callbacks */

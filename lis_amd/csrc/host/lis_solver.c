@@ -552,8 +552,14 @@ static LIS_INT run_gmres(ctx_t *c)
 					KTRY(liship_mgs_step_f64(n, hdev + k - 1, v[k - 1], v[i1], v[k], hdev + k, lisg.reduce_work, lisg.stream));
 				KTRY(liship_mgs_step_f64(n, hdev + i - 1, v[i - 1], v[i1], NULL, hdev + i, lisg.reduce_work, lisg.stream));
 				KTRY(liship_scale_inv_norm_f64(n, hdev + i, v[i1], lisg.stream));
-				KTRY(liship_memcpy_d2h(hc, hdev, sizeof(double) * (size_t)(i + 1), lisg.stream));
-				KTRY(liship_stream_synchronize(lisg.stream));
+				if (i + 1 <= 256) {                        /* through the page-locked landing zone */
+					KTRY(liship_memcpy_d2h(lisg.host_out, hdev, sizeof(double) * (size_t)(i + 1), lisg.stream));
+					KTRY(liship_stream_synchronize(lisg.stream));
+					memcpy(hc, lisg.host_out, sizeof(double) * (size_t)(i + 1));
+				} else {
+					KTRY(liship_memcpy_d2h(hc, hdev, sizeof(double) * (size_t)(i + 1), lisg.stream));
+					KTRY(liship_stream_synchronize(lisg.stream));
+				}
 				hc[i1] = sqrt(hc[i1]);
 			} else {
 				for (int k = 0; k < i; k++) {                  /* modified Gram-Schmidt */

@@ -36,6 +36,11 @@ extern "C" int liship_stream_destroy(void *stream) { if (stream) HIP_TRY(hipStre
 extern "C" int liship_stream_synchronize(void *stream) { HIP_TRY(hipStreamSynchronize(as_stream(stream))); return 0; }
 extern "C" int liship_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return 0; }
 
+// page-locked host memory: the 8-32 B results of the reductions come back through it (a D2H into pageable memory
+// is staged by the runtime and costs 10-20 us more per host synchronisation)
+extern "C" int liship_malloc_host(void **p, size_t bytes) { HIP_TRY(hipHostMalloc(p, bytes, hipHostMallocDefault)); return 0; }
+extern "C" int liship_free_host(void *p) { if (p) HIP_TRY(hipHostFree(p)); return 0; }
+
 // stream-ordering events (halo exchange on a second stream overlapped with the interior rows of the product)
 extern "C" int liship_event_create(void **ev)
 {

@@ -1,0 +1,14 @@
+import sys, time, ctypes as C
+sys.path[:0]=['.','tests']
+import numpy as np, lis_amd, lisdrv, orc
+lib=lis_amd.load(); lib.initialize([])
+N=256; n=N**3
+ptr,idx,val=orc.poisson3d(N,N,N)
+A=lisdrv.make_csr(lib,ptr,idx,val)
+vx,vy=lisdrv.new_vector(lib,A,np.ones(n)),lisdrv.new_vector(lib,A)
+lib.dll.lis_amd_set_residency(0)
+for _ in range(3): lib.lis_matvec(A,vx,vy)
+t=time.perf_counter()
+for _ in range(10): lib.lis_matvec(A,vx,vy)
+el=(time.perf_counter()-t)/10
+print(f"COHERENT lis_matvec 256^3: {el*1e3:.2f} ms/call = {2*len(idx)/el/1e9:.1f} GFLOP/s (x up + y down over PCIe: {2*8*n/el/1e9:.1f} GB/s)")

@@ -120,7 +120,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    mode = os.RTLD_NOW | os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0)
+    mode = os.RTLD_NOW | os.RTLD_LOCAL
+    if not os.environ.get("LIS_AMD_NO_DEEPBIND"):          # sanitizer runs need it off
+        mode |= getattr(os, "RTLD_DEEPBIND", 0)
     lib = _capi.LisLib(LIB_PATH, mode=mode)
     lib.liship_missing = []
     for name, (res, args) in _LISHIP.items():

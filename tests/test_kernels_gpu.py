@@ -486,3 +486,70 @@ def test_ell_dia_fused_dot(lib, fmt, want_sumsq, grid):
     assert abs(first[0] - np.dot(w, yref)) <= 1e-13 * np.abs(w * yref).sum()
     if want_sumsq:
         assert abs(first[1] - np.dot(yref, yref)) <= 1e-13 * np.dot(yref, yref)
+
+
+def test_full_size_512_properties(lib):
+    """BASELINE's full size (512^3 rows, 938 M non-zeros) through size-independent properties, no CPU pass:
+    A*1 equals the closed form everywhere (exact: small integers), the row-range launches and the fused-dot form
+    write the bits of the plain launch, <A x, y> == <x, A y> to rounding (A is symmetric), linearity in x."""
+    N = 512
+    n = N ** 3
+    nnz = lib.liship_poisson3d_nnz(N, N, N, 0, n)
+    assert nnz == 7 * n - 6 * N * N == 937951232
+    dptr, didx, dval = DA(n + 1, np.int32), DA(nnz, np.int32), DA(nnz, np.float64)
+    check(lib.liship_poisson3d_csr(N, N, N, 0, n, 0, dptr.ptr, didx.ptr, dval.ptr, None))
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    work, res = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
+    x, y, y2, b = (DA(n, np.float64) for _ in range(4))
+
+    def spmv(src, dst):
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, src.ptr, dst.ptr, None))
+
+    def nrm1(v):
+        check(lib.liship_nrm1_f64(n, v.ptr, res.ptr, work.ptr, None))
+        return res.to_host()[0]
+
+    def dot(u, v):
+        check(lib.liship_dot_f64(n, u.ptr, v.ptr, res.ptr, work.ptr, None))
+        return res.to_host()[0]
+
+    # A*1: closed form, exact
+    check(lib.liship_set_all_f64(n, 1.0, x.ptr, None))
+    spmv(x, y)
+    check(lib.liship_sumsq_f64(n, y.ptr, res.ptr, work.ptr, None))
+    assert res.to_host()[0] == 6.0 * (N - 2) ** 2 + 48.0 * (N - 2) + 72.0
+    check(lib.liship_poisson3d_rhs(N, N, N, 0, n, b.ptr, None))
+    check(lib.liship_axpy_f64(n, -1.0, b.ptr, y.ptr, None))
+    assert nrm1(y) == 0.0
+    # a non-trivial x: x_i = frac(i * golden ratio) - 0.5, built in pieces to keep the host footprint small
+    chunk = 1 << 24
+    for s in range(0, n, chunk):
+        part = np.modf(np.arange(s, min(n, s + chunk), dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+        check(lib.liship_memcpy_h2d(x.ptr + 8 * s, part.ctypes.data, part.nbytes, None))
+        check(lib.liship_device_synchronize())
+    spmv(x, y)
+    # row-range launches (the multi-GPU overlap path) write the same bits
+    check(lib.liship_memset(y2.ptr, 0xff, 8 * n, None))
+    for lo, hi in ((0, 262144), (262144, n - 300000), (n - 300000, n)):
+        check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y2.ptr, None))
+    check(lib.liship_axpy_f64(n, -1.0, y.ptr, y2.ptr, None))
+    assert nrm1(y2) == 0.0
+    # the fused-dot form: same y, and its <x,y> agrees with the separate reduction
+    check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y2.ptr, x.ptr, 1, res.ptr, work.ptr, None))
+    fused = res.to_host().copy()
+    xAx = dot(x, y)
+    assert abs(fused[0] - xAx) <= 1e-12 * abs(xAx)
+    check(lib.liship_sumsq_f64(n, y.ptr, res.ptr, work.ptr, None))
+    assert abs(fused[1] - res.to_host()[0]) <= 1e-12 * fused[1]
+    check(lib.liship_axpy_f64(n, -1.0, y.ptr, y2.ptr, None))
+    assert nrm1(y2) == 0.0
+    # symmetry: <A x, b> == <x, A b>  (b = A*1 as the second vector), and linearity: A(2x) == 2 A x exactly
+    spmv(b, y2)
+    lhs, rhs = dot(y, b), dot(x, y2)
+    assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), 1.0)
+    check(lib.liship_scale_f64(n, 2.0, x.ptr, None))
+    spmv(x, y2)
+    check(lib.liship_axpy_f64(n, -2.0, y.ptr, y2.ptr, None))
+    assert nrm1(y2) == 0.0
+    check(lib.liship_csr_plan_destroy(plan))

@@ -444,3 +444,44 @@ def test_solve_with_scaling_matches_reference(lib, name):
     assert np.array_equal(lisdrv.matrix_arrays(A)["value"], GSC[f"solve/{name}/A_value_after"])   # A stays scaled
     # the in-place -storage conversion rebuilds the header and loses the flag, in the reference too (checked live)
     assert A.contents.is_scaled == (0 if "-storage" in opts else 1)
+
+
+def test_config3_full_size_bicgstab_512(lib):
+    """BASELINE config 3 on one GPU: the 512^3 system (938 M non-zeros) solved by BiCGSTAB to 1e-12 through lis_solve
+    on the HBM-generated matrix; checked by the residual the library reports, the TRUE residual recomputed with
+    lis_matvec, and the known solution (b = A*1).  The reference needs hours for this on a CPU: no count to compare."""
+    N = 512
+    n = N ** 3
+    A = capi.PM()
+    assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
+    assert lib.lis_matrix_set_size(A, 0, n) == 0
+    fn = lib.dll.lis_amd_matrix_poisson3d
+    fn.argtypes = [capi.PM, C.c_int, C.c_int, C.c_int, C.c_int]
+    assert fn(A, N, N, N, 0) == 0
+    lib.dll.lis_amd_set_residency(1)
+    try:
+        b, x, r = (lisdrv.new_vector(lib, A) for _ in range(3))
+        rhs = lib.dll.lis_amd_vector_poisson3d_rhs
+        rhs.argtypes = [capi.PV, C.c_int, C.c_int, C.c_int]
+        assert rhs(b, N, N, N) == 0
+        S = capi.PS()
+        lib.lis_solver_create(C.byref(S))
+        lib.lis_solver_set_option(b"-i bicgstab -p none -tol 1e-12 -maxiter 10000", S)
+        assert lib.lis_solve(A, b, x, S) == 0
+        assert S.contents.retcode == 0 and S.contents.resid <= 1e-12 and 100 < S.contents.iter < 10000
+        bn, rn, en = C.c_double(), C.c_double(), C.c_double()
+        assert lib.lis_matvec(A, x, r) == 0 and lib.lis_vector_xpay(b, -1.0, r) == 0          # r = b - A x
+        lib.lis_vector_nrm2(b, C.byref(bn)); lib.lis_vector_nrm2(r, C.byref(rn))
+        assert rn.value / bn.value <= 1e-11
+        one = lisdrv.new_vector(lib, A)
+        lib.lis_vector_set_all(1.0, one)
+        lib.lis_vector_axpy(-1.0, one, x)
+        lib.lis_vector_nrm2(x, C.byref(en))
+        assert en.value / np.sqrt(n) <= 1e-8
+        lib.lis_solver_destroy(S)
+        for v in (b, x, r, one):
+            lib.lis_vector_destroy(v)
+    finally:
+        lib.dll.lis_amd_set_residency(0)
+        lib.dll.lis_amd_trim()
+    lib.lis_matrix_destroy(A)

@@ -1,6 +1,6 @@
 """BASELINE config 5: the same 3-D 7-point Poisson matrix in every storage format, through the Lis API.
 
-    python tools/format_sweep.py [N] [--solve]      # cubic grid edge, default 256
+    python tests/perf/format_sweep.py [N] [--solve]      # cubic grid edge, default 256
 Per format: lis_matvec ms (HIP events on the library's stream), GFLOP/s on the TRUE non-zeros, algorithmic GB/s
 (SURVEY 8d byte counts) and, with --solve, CG+Jacobi iterations and it/s.  y is checked against the CSR result
 (bit equality where the reference's summation order is the same) and ||A*1||_2 against the closed form."""
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import lis_amd  # noqa: E402
 import lisdrv   # noqa: E402

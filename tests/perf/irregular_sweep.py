@@ -5,7 +5,7 @@ SuiteSparse Queen_4147 cannot be fetched here (no network), so two synthetic mat
          rows shorter) -- the sparsity class of Queen_4147 (3-D structural FEM); symmetric, diagonally dominant
   zipf   row lengths drawn from a heavy-tailed law (1 .. 200 000 per row), random columns: the load-balance stress
          for the merge-path row split
-    python tools/irregular_sweep.py [G] [--gmres-iters K]
+    python tests/perf/irregular_sweep.py [G] [--gmres-iters K]
 Prints SpMV ms / GFLOP/s / algorithmic GB/s (12*nnz + 20*n bytes) with y checked bit for bit against the CPU oracle,
 and GMRES(30) iterations per second through lis_solve."""
 import ctypes as C
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import lis_amd  # noqa: E402
 import lisdrv   # noqa: E402

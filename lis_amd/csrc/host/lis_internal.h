@@ -110,6 +110,8 @@ LIS_INT lisd_vec_to_host(LIS_VECTOR v);
 void    lisd_vec_free(LIS_VECTOR v);
 LIS_INT lisd_mat_ready(LIS_MATRIX A);
 void    lisd_mat_free(LIS_MATRIX A);
+LIS_INT lisd_init_quiet(void);                               /* lisd_init without the diagnostic when no device exists */
+void    lisd_mat_eager(LIS_MATRIX A);                         /* resident mode: upload at assemble / convert time */
 LIS_INT lisd_pool_get(size_t bytes, void **out);              /* HBM buffer of exactly `bytes`, reused across solves */
 void    lisd_pool_put(void *p, size_t bytes);
 LIS_INT lisd_mat_ready_t(LIS_MATRIX A);                       /* build / upload the transposed operator */

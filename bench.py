@@ -77,20 +77,38 @@ def main():
     if world == 1:
         os.environ.setdefault("LIS_AMD_DEVICE", str(local_rank))
     assert lib.initialize([]) == 0
-    if world > 1 and args.comm == "callbacks":
+    comm_used = args.comm
+    if world > 1 and args.comm == "rccl":
+        # RCCL communicator: rank 0's unique id travels over the gloo control plane.  If ANY rank fails to join,
+        # every rank drops to the callback backend so that the job still reports (marked as such in `config`).
+        uid = [None]
+        ok = int(torch.cuda.is_available() and local_rank < torch.cuda.device_count())   # a rank without its own GPU
+        flag = torch.tensor([ok], dtype=torch.int32)                                      # must not leave the others
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                                       # waiting inside ncclCommInitRank
+        ok = int(flag[0])
+        if rank == 0 and ok:
+            buf = (C.c_char * 128)()
+            if dll.lis_amd_comm_get_unique_id(buf) == 0:
+                uid[0] = bytes(buf)
+        dist.broadcast_object_list(uid, src=0)
+        if ok and uid[0] is not None:
+            ok = int(dll.lis_amd_comm_init_rccl(uid[0], rank, world, local_rank) == 0)
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            if rank == 0:
+                print("bench.py: RCCL communicator could not be formed on every rank -- falling back to host callbacks",
+                      file=sys.stderr, flush=True)
+            dll.lis_amd_comm_finalize()
+            comm_used = "callbacks"
+    if world > 1 and comm_used == "callbacks":
         from lis_amd._hostcomm import make_callbacks
         local_rank = local_rank % max(1, torch.cuda.device_count())
         os.environ["LIS_AMD_DEVICE"] = str(local_rank)
         cb = make_callbacks(world)
         assert dll.lis_amd_comm_init_callbacks(C.byref(cb), rank, world) == 0
-    elif world > 1:
-        uid = [None]
-        if rank == 0:
-            buf = (C.c_char * 128)()
-            assert dll.lis_amd_comm_get_unique_id(buf) == 0
-            uid[0] = bytes(buf)
-        dist.broadcast_object_list(uid, src=0)
-        assert dll.lis_amd_comm_init_rccl(uid[0], rank, world, local_rank) == 0
     if torch is not None and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     dll.lis_amd_set_residency(1)                          # objects live in HBM; nothing crosses PCIe in the timed region
@@ -208,7 +226,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"3-D 7-point Poisson {N}^3, CSR f64/i32, y=A*x via lis_matvec (x=1), test3.c entry order",
-                       "n": n_global, "nnz": nnz_global, "parallelism": f"row-block x{world}" + ((" + RCCL halo" if args.comm == "rccl" else " + gloo-callback halo (bring-up, not a measurement)") if world > 1 else "")},
+                       "n": n_global, "nnz": nnz_global, "parallelism": f"row-block x{world}" + ((" + RCCL halo" if comm_used == "rccl" else " + gloo-callback halo (bring-up, not a measurement)") if world > 1 else "")},
             "roofline": roofline,
             "hbm_roofline_pct_whole_job": round(100.0 * (12 * nnz_global + 20 * n_global) / (ms_per_step * 1e-3) / 1e9
                                                 / (HBM_PEAK_GBS * world), 2),

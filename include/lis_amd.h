@@ -29,6 +29,15 @@ extern "C" {
 LIS_INT lis_amd_set_residency(LIS_INT mode);
 LIS_INT lis_amd_get_residency(void);
 
+/* How the CG / BiCGSTAB loops run (all three produce identical bits; the choice is for A/B measurements):
+ *   DEVICE  scalars live in HBM, iterations are enqueued in batches, one read-back per batch (default)
+ *   HOST    fused passes, every scalar read back as it is formed          (env LIS_AMD_HOST_SCALARS=1)
+ *   UNFUSED one kernel per reference call                                 (env LIS_AMD_NO_FUSION=1)  */
+#define LIS_AMD_LOOP_DEVICE  0
+#define LIS_AMD_LOOP_HOST    1
+#define LIS_AMD_LOOP_UNFUSED 2
+LIS_INT lis_amd_set_loop_mode(LIS_INT mode);
+
 /* vectors */
 LIS_INT lis_amd_vector_sync_host(LIS_VECTOR v);        /* make v->value[] current (D2H if needed)        */
 LIS_INT lis_amd_vector_host_modified(LIS_VECTOR v);    /* v->value[] was written directly: HBM copy stale */

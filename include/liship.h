@@ -155,6 +155,61 @@ int  liship_mgs_step_f64(int n, const double *hprev, const double *vprev, double
                          double *result, void *work, void *stream);
 /* x *= 1/sqrt(*sumsq) with sumsq in HBM  (lis_vector_nrm2 + lis_vector_scale, lis_solver_gmres.c:229-232) */
 int  liship_scale_inv_norm_f64(int n, const double *sumsq, double *x, void *stream);
+
+/* ------------------------------------------------------------------ device-driven Krylov loops
+ * The scalars of CG / BiCGSTAB (rho, alpha, beta, omega, the residual norm, the iteration count and the
+ * convergence flag) can live in HBM: a block of LISHIP_KS_LEN doubles the host fills once.  The `_dev` forms of
+ * the vector kernels read their coefficient(s) from that block at kernel start, reductions leave their sums in
+ * it, and liship_krylov_step() -- one lane -- applies the reference's scalar statements between them
+ * (lis_solver_cg.c:176-215, lis_solver_bicgstab.c:186-290) with the same IEEE operations the host loop would
+ * use.  While a guard flag is installed (liship_krylov_guard), every vector / reduction / fused-product kernel
+ * launched returns immediately if *flag != 0, so the host may enqueue a batch of iterations, read the block
+ * back once, and find x, r and the iteration count exactly as the one-synchronisation-per-scalar loop leaves
+ * them. */
+enum {
+	LISHIP_KS_RHO = 0, LISHIP_KS_RHO_OLD, LISHIP_KS_ALPHA, LISHIP_KS_NALPHA, LISHIP_KS_BETA, LISHIP_KS_OMEGA,
+	LISHIP_KS_NOMEGA, LISHIP_KS_DOT0, LISHIP_KS_DOT1, LISHIP_KS_SUM0, LISHIP_KS_SUM1, LISHIP_KS_NRM2,
+	LISHIP_KS_BNRM,          /* factor of the convergence test: 1/||b|| or 1/||r0|| (lis_solver.c:1792-1812) */
+	LISHIP_KS_TOL,
+	LISHIP_KS_ITER,          /* iterations completed (a double holding an integer) */
+	LISHIP_KS_DONE,          /* 0 while iterating; the guard flag */
+	LISHIP_KS_STATUS,        /* 0 running, 1 converged, 2 breakdown */
+	LISHIP_KS_NOT_HALF,      /* BiCGSTAB: 0 only between the half-step convergence and its x update (every step re-arms it) */
+	LISHIP_KS_NHIST,         /* residual-history entries written (a breakdown ends an iteration without one) */
+	LISHIP_KS_LEN = 32
+};
+enum {
+	LISHIP_STEP_CG_ALPHA = 1,     /* after <p,q>:            breakdown test, alpha = rho / <p,q>                */
+	LISHIP_STEP_CG_RESID,         /* after the update pass:  ||r||, history, convergence, rho <- <r,r>, beta    */
+	LISHIP_STEP_CG_RESID_PRE,     /* same with rho <- <r,z> (second sum)                                        */
+	LISHIP_STEP_BICGSTAB_ALPHA,   /* after <rtld,v>: rho == 0 breakdown test, alpha = rho / <rtld,v>            */
+	LISHIP_STEP_BICGSTAB_HALF,    /* after ||s||: convergence at the half step (lowers NOT_HALF for the x update)*/
+	LISHIP_STEP_BICGSTAB_OMEGA,   /* after <t,s>,<t,t>: omega = <t,s>/<t,t>                                     */
+	LISHIP_STEP_BICGSTAB_RESID    /* after the r update: ||r||, history, convergence, omega breakdown, rho', beta */
+};
+/* install (flag != NULL) or remove (NULL) the guard for the launches that follow */
+int  liship_krylov_guard(const double *flag);
+/* one scalar step on `state`; rhistory (device, may be NULL) receives the residual norm of each completed
+ * iteration at [iter].  In a multi-rank job `gathered` holds nranks x count per-rank sums (rank-major), which are
+ * added in rank order into the slots the step reads, before it runs; NULL otherwise. */
+int  liship_krylov_step(int step, double *state, double *rhistory, const double *gathered, int nranks, void *stream);
+/* single-rank jobs: announce the step BEFORE launching the reduction whose sums it reads; it then runs in that
+ * reduction's last kernel instead of a launch of its own.  liship_krylov_chain_flush runs a step that was announced
+ * but found no reduction to ride in (call it after the reduction; a no-op otherwise). */
+int  liship_krylov_chain(int step, double *state, double *rhistory);
+int  liship_krylov_chain_flush(void *stream);
+/* y = x + (*pa)*y;  y = x.*d + (*pa)*y;  y += (*pa)*x;  y += (*pa)*x, then y += (*pb)*w;  y += (*pa)*x, then y = w + (*pb)*y */
+int  liship_xpay_dev_f64(int n, const double *x, const double *pa, double *y, void *stream);
+int  liship_pmul_xpay_dev_f64(int n, const double *x, const double *d, const double *pa, double *y, void *stream);
+int  liship_axpy_dev_f64(int n, const double *pa, const double *x, double *y, void *stream);
+int  liship_axpy2_dev_f64(int n, const double *pa, const double *x, const double *pb, const double *w, double *y, void *stream);
+int  liship_axpy_xpay_dev_f64(int n, const double *pa, const double *x, const double *w, const double *pb, double *y, void *stream);
+/* the fused update passes with the coefficient in HBM (dinv may be NULL for liship_cg_update_dev_f64) */
+int  liship_cg_update_dev_f64(int n, const double *palpha, const double *p, const double *q, const double *dinv,
+                              double *x, double *r, double *result, void *work, void *stream);
+int  liship_axpy_sumsq_dev_f64(int n, const double *pa, const double *x, double *y, double *result, void *work, void *stream);
+int  liship_axpy_sumsq_dot_dev_f64(int n, const double *pa, const double *x, double *y, const double *v, double *result,
+                                   void *work, void *stream);
 /* z = c0*v0, z += c1*v1, ... (accumulate = 0) or z += c0*v0, ... (accumulate = 1), element by element in that
  * order: the bits of lis_vector_scale/axpy chains (lis_solver_gmres.c:290-296, :323-329) in one pass over z.
  * vs[] and coef[] are HOST arrays (passed by value to the kernel); a v that aliases z reads z as it was on entry.

@@ -103,6 +103,14 @@ LIS_INT lis_amd_set_residency(LIS_INT mode)
 }
 LIS_INT lis_amd_get_residency(void) { return lisg.residency; }
 
+LIS_INT lis_amd_set_loop_mode(LIS_INT mode)
+{
+	if (mode < LIS_AMD_LOOP_DEVICE || mode > LIS_AMD_LOOP_UNFUSED) return LISI_ERR(LIS_ERR_ILL_ARG, "unknown loop mode %D\n", mode);
+	lisg.host_scalars = (mode == LIS_AMD_LOOP_HOST);
+	lisg.no_fusion = (mode == LIS_AMD_LOOP_UNFUSED);
+	return LIS_SUCCESS;
+}
+
 /* ------------------------------------------------------------------ vectors */
 static size_t vec_len(LIS_VECTOR v) { return (size_t)(v->np + v->pad); }
 
@@ -365,27 +373,32 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
  * otherwise the product followed by one reduction pass.  The sums land in lisg.reduce_out[0..1]. */
 LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq)
 {
+	return lisd_spmv_dot_launch_to(A, dx, dy, dw, want_sumsq, lisg.reduce_out);
+}
+
+LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq, double *result)
+{
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_mat_ready(A));
 	if (d->type == LIS_MATRIX_CSR && !lisg.no_fusion) {
 		if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
 		int rc = liship_spmv_csr_dot_f64(d->plan, d->ptr, d->index, d->value, dx, dy, dw, want_sumsq,
-		                                 lisg.reduce_out, lisg.reduce_work, lisg.stream);
+		                                 result, lisg.reduce_work, lisg.stream);
 		if (rc == 0) return LIS_SUCCESS;
 		if (rc != LISHIP_ERR_ARG) HIPCHK(rc);
 		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));
 	} else if ((d->type == LIS_MATRIX_ELL || d->type == LIS_MATRIX_DIA) && !lisg.no_fusion) {
 		if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
 		int rc = (d->type == LIS_MATRIX_ELL)
-			? liship_spmv_ell_dot_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, dw, want_sumsq, lisg.reduce_out, lisg.reduce_work, lisg.stream)
-			: liship_spmv_dia_dot_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, dw, want_sumsq, lisg.reduce_out, lisg.reduce_work, lisg.stream);
+			? liship_spmv_ell_dot_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, dw, want_sumsq, result, lisg.reduce_work, lisg.stream)
+			: liship_spmv_dia_dot_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, dw, want_sumsq, result, lisg.reduce_work, lisg.stream);
 		if (rc == 0) return LIS_SUCCESS;
 		if (rc != LISHIP_ERR_ARG) HIPCHK(rc);
 		if (d->type == LIS_MATRIX_ELL) HIPCHK(liship_spmv_ell_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, lisg.stream));
 		else HIPCHK(liship_spmv_dia_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, lisg.stream));
 	} else LISCHK(lisd_spmv(A, dx, dy));
-	if (want_sumsq) HIPCHK(liship_dot2_f64(d->n, dy, dw, lisg.reduce_out, lisg.reduce_work, lisg.stream));
-	else HIPCHK(liship_dot_f64(d->n, dw, dy, lisg.reduce_out, lisg.reduce_work, lisg.stream));
+	if (want_sumsq) HIPCHK(liship_dot2_f64(d->n, dy, dw, result, lisg.reduce_work, lisg.stream));
+	else HIPCHK(liship_dot_f64(d->n, dw, dy, result, lisg.reduce_work, lisg.stream));
 	return LIS_SUCCESS;
 }
 

@@ -95,6 +95,7 @@ typedef struct {
 	void *nccl_comm;
 	void *comm_stream;         /* second HIP stream: halo send/recv overlapped with the interior rows */
 	void *ev_packed, *ev_landed;
+	int host_scalars;          /* LIS_AMD_HOST_SCALARS=1: CG / BiCGSTAB read every scalar back (A/B against the device-driven loops) */
 	int no_overlap;            /* LIS_AMD_NO_OVERLAP=1: exchange first, then the whole product (A/B measurements) */
 	lis_amd_comm_callbacks cb;
 } lisi_globals;
@@ -118,6 +119,7 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A);                       /* build / upload 
 LIS_INT lisd_spmv_t(LIS_MATRIX A, double *dx, double *dy);    /* y[0..np) = A^T x, ghost rows reduced to owners */
 LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy);      /* y = A x on device pointers (halo included) */
 LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq); /* sums -> reduce_out */
+LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq, double *result); /* sums -> result (HBM) */
 LIS_INT lisd_fetch(int count, double *out);                   /* reduce_out[0..count) -> host, cross-rank fold */
 LIS_INT lisd_dot(int n, const double *dx, const double *dy, double *out);
 LIS_INT lisd_nrm2(int n, const double *dx, double *out);
@@ -135,6 +137,7 @@ LIS_INT lisc_reduce_device(LIS_MATRIX A, double *dy);         /* dy[export rows]
 LIS_INT lisc_halo_begin(LIS_MATRIX A, double *dx);            /* pack + start the exchange (second stream) */
 LIS_INT lisc_halo_end(LIS_MATRIX A, double *dx);              /* ghosts of dx are valid for work queued after this */
 LIS_INT lisc_halo_device(LIS_MATRIX A, double *dx);           /* fill dx[n..np) from the neighbours */
+LIS_INT lisc_gather_device(const double *src, int count);    /* RCCL only: every rank's src[0..count) -> lisg.gather_out, rank-major, on the stream */
 LIS_INT lisc_fold(int count, double *host_inout);             /* sum over ranks, rank order */
 LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes);
 

@@ -262,6 +262,194 @@ static LIS_INT resid_from_sumsq(ctx_t *c, const double *r, double sumsq, double 
 	return LIS_SUCCESS;
 }
 
+/* ------------------------------------------------------------------ device-driven loops (include/liship.h)
+ * The loops above wait for the host after every reduction (2 round trips per CG iteration, 4 per BiCGSTAB
+ * iteration): short next to a 512^3 product, a tenth of a 256^3 iteration, most of a small one, and in a
+ * multi-rank job each of them also stalls the neighbours.  Here the scalars stay in HBM: the host enqueues
+ * LISD_BATCH whole iterations, every kernel of which is a no-op once the convergence flag is up, then reads the
+ * state block back once.  Same kernels, same per-element expressions, same IEEE scalar operations in the same
+ * order -- iteration counts, x and the residual history are bit-identical to the host-scalar loops
+ * (tests/test_device_loops_gpu.py runs both), which stay selectable with LIS_AMD_HOST_SCALARS=1.
+ * Not used for -conv_cond nrm1_b (needs a second reduction of another kind) or with the callback communicator
+ * (its fold is a host function). */
+#define LISD_BATCH 16
+static int device_scalars_ok(const ctx_t *c)
+{
+	if (lisg.host_scalars) return 0;
+	if (c->s->options[LIS_OPTIONS_CONV_COND] == LIS_CONV_COND_NRM1_B) return 0;
+	if (lisg.nprocs > 1 && lisg.comm_kind != 1) return 0;
+	return 1;
+}
+
+typedef struct {
+	double *st, *rh;           /* HBM: state block, residual history (NULL unless asked for) */
+	size_t bytes;              /* of the pooled allocation holding both */
+	double host[LISHIP_KS_LEN];
+	LIS_INT printed;           /* history entries already passed to note() */
+} dev_loop;
+
+static LIS_INT dev_loop_begin(ctx_t *c, dev_loop *L, const double *init)
+{
+	const size_t hist = c->output ? (size_t)c->maxiter + 2 : 0;
+	L->bytes = sizeof(double) * (LISHIP_KS_LEN + hist);
+	L->printed = 0;
+	LISCHK(lisd_pool_get(L->bytes, (void **)&L->st));
+	L->rh = hist ? L->st + LISHIP_KS_LEN : NULL;
+	HIPCHK(liship_memset(L->st, 0, L->bytes, lisg.stream));
+	memcpy(L->host, init, sizeof(L->host));
+	HIPCHK(liship_memcpy_h2d(L->st, L->host, sizeof(L->host), lisg.stream));
+	HIPCHK(liship_stream_synchronize(lisg.stream));
+	return LIS_SUCCESS;
+}
+
+/* The scalar step that consumes a reduction's sums st[slot..slot+count).  Single-rank job: announced before the
+ * reduction is launched, it runs inside the reduction's last kernel (dev_step then only catches the case where it
+ * found none to ride in).  RCCL job: the sums are gathered from all ranks first, then the step runs on its own. */
+static LIS_INT dev_announce(dev_loop *L, int step)
+{
+	if (lisg.comm_kind != 1) HIPCHK(liship_krylov_chain(step, L->st, L->rh));
+	return LIS_SUCCESS;
+}
+static LIS_INT dev_step(dev_loop *L, int step, int slot, int count)
+{
+	if (lisg.comm_kind != 1) { HIPCHK(liship_krylov_chain_flush(lisg.stream)); return LIS_SUCCESS; }
+	LISCHK(lisc_gather_device(L->st + slot, count));
+	HIPCHK(liship_krylov_step(step, L->st, L->rh, lisg.gather_out, lisg.nprocs, lisg.stream));
+	return LIS_SUCCESS;
+}
+
+/* one read-back per batch: the state block, and the new history entries when the caller wants them */
+static LIS_INT dev_loop_sync(ctx_t *c, dev_loop *L)
+{
+	HIPCHK(liship_memcpy_d2h(lisg.host_out, L->st, sizeof(L->host), lisg.stream));
+	HIPCHK(liship_stream_synchronize(lisg.stream));
+	memcpy(L->host, lisg.host_out, sizeof(L->host));
+	if (L->rh) {
+		LIS_INT upto = (LIS_INT)L->host[LISHIP_KS_NHIST];
+		if (upto > c->maxiter + 1) upto = c->maxiter + 1;
+		if (upto > L->printed) {
+			const size_t cnt = (size_t)(upto - L->printed);
+			double *tmp = (double *)malloc(sizeof(double) * cnt);
+			if (!tmp) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)cnt);
+			int rc = liship_memcpy_d2h(tmp, L->rh + L->printed + 1, sizeof(double) * cnt, lisg.stream);
+			if (!rc) rc = liship_stream_synchronize(lisg.stream);
+			if (rc) { free(tmp); HIPCHK(rc); }
+			for (size_t i = 0; i < cnt; i++) note(c, L->printed + 1 + (LIS_INT)i, tmp[i]);
+			free(tmp);
+			L->printed = upto;
+		}
+	}
+	return LIS_SUCCESS;
+}
+
+static LIS_INT dev_loop_finish(ctx_t *c, dev_loop *L, LIS_INT err)
+{
+	LIS_SOLVER s = c->s;
+	(void)liship_krylov_guard(NULL);
+	if (!err) {
+		s->resid = L->host[LISHIP_KS_NRM2];
+		if (L->host[LISHIP_KS_STATUS] == 1.0) { s->retcode = LIS_SUCCESS; s->iter = (LIS_INT)L->host[LISHIP_KS_ITER]; }
+		else if (L->host[LISHIP_KS_STATUS] == 2.0) { s->retcode = LIS_BREAKDOWN; s->iter = (LIS_INT)L->host[LISHIP_KS_ITER]; err = LIS_BREAKDOWN; }
+		else { s->retcode = LIS_MAXITER; s->iter = c->maxiter + 1; err = LIS_MAXITER; }
+	}
+	if (L->st) { (void)liship_stream_synchronize(lisg.stream); lisd_pool_put(L->st, L->bytes); L->st = NULL; }
+	return err;
+}
+
+static LIS_INT run_cg_device(ctx_t *c)
+{
+	LIS_INT err = 0;
+	const int n = c->n;
+	dev_loop L = {0};
+	TRY(work_alloc(c, 3));
+	double *q = c->work[0], *r = c->work[1], *p = c->work[2];
+	double rho, init[LISHIP_KS_LEN] = {0};
+	int st0 = initial_residual(c, r);
+	if (st0) { work_free(c); return st0 < 0 ? -st0 : 0; }
+	if (c->dinv) { KTRY(liship_pmul_f64(n, r, c->dinv, q, lisg.stream)); TRY(lisd_dot(n, r, q, &rho)); }
+	else TRY(lisd_dot(n, r, r, &rho));
+	init[LISHIP_KS_RHO] = rho; init[LISHIP_KS_RHO_OLD] = 1.0; init[LISHIP_KS_BETA] = rho / 1.0;
+	init[LISHIP_KS_BNRM] = c->bnrm; init[LISHIP_KS_TOL] = c->tol; init[LISHIP_KS_NOT_HALF] = 1.0;
+	TRY(dev_loop_begin(c, &L, init));
+	double *st = L.st;
+	KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
+	for (LIS_INT queued = 0; queued < c->maxiter && L.host[LISHIP_KS_DONE] == 0.0; ) {
+		const LIS_INT batch = (c->maxiter - queued < LISD_BATCH) ? c->maxiter - queued : LISD_BATCH;
+		for (LIS_INT k = 0; k < batch; k++) {
+			if (c->dinv) KTRY(liship_pmul_xpay_dev_f64(n, r, c->dinv, st + LISHIP_KS_BETA, p, lisg.stream));
+			else         KTRY(liship_xpay_dev_f64(n, r, st + LISHIP_KS_BETA, p, lisg.stream));
+			TRY(dev_announce(&L, LISHIP_STEP_CG_ALPHA));
+			TRY(lisd_spmv_dot_launch_to(c->A, p, q, p, 0, st + LISHIP_KS_DOT0));
+			TRY(dev_step(&L, LISHIP_STEP_CG_ALPHA, LISHIP_KS_DOT0, 1));
+			TRY(dev_announce(&L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID));
+			KTRY(liship_cg_update_dev_f64(n, st + LISHIP_KS_ALPHA, p, q, c->dinv, c->x, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			TRY(dev_step(&L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID, LISHIP_KS_SUM0, c->dinv ? 2 : 1));
+		}
+		queued += batch;
+		TRY(dev_loop_sync(c, &L));
+	}
+done:
+	err = dev_loop_finish(c, &L, err);
+	work_free(c);
+	return err;
+}
+
+static LIS_INT run_bicgstab_device(ctx_t *c)
+{
+	LIS_INT err = 0;
+	const int n = c->n;
+	const int pre = c->dinv != NULL;
+	dev_loop L = {0};
+	TRY(work_alloc(c, pre ? 7 : 5));
+	double *rtld = c->work[0], *r = c->work[1], *t = c->work[2], *p = c->work[3], *v = c->work[4];
+	double *phat = pre ? c->work[5] : p, *shat = pre ? c->work[6] : r;
+	double *sv = r;                                    /* s aliases r: lis_solver_bicgstab.c:160-161 */
+	double rho, init[LISHIP_KS_LEN] = {0};
+	int st0 = initial_residual(c, r);
+	if (st0) { work_free(c); return st0 < 0 ? -st0 : 0; }
+	TRY(d_copy(c, r, rtld));
+	TRY(lisd_dot(n, rtld, r, &rho));
+	init[LISHIP_KS_RHO] = rho; init[LISHIP_KS_RHO_OLD] = 1.0;
+	init[LISHIP_KS_ALPHA] = 1.0; init[LISHIP_KS_NALPHA] = -1.0; init[LISHIP_KS_OMEGA] = 1.0; init[LISHIP_KS_NOMEGA] = -1.0;
+	init[LISHIP_KS_BNRM] = c->bnrm; init[LISHIP_KS_TOL] = c->tol; init[LISHIP_KS_NOT_HALF] = 1.0;
+	TRY(dev_loop_begin(c, &L, init));
+	double *st = L.st;
+	for (LIS_INT queued = 0; queued < c->maxiter && L.host[LISHIP_KS_DONE] == 0.0; ) {
+		const LIS_INT batch = (c->maxiter - queued < LISD_BATCH) ? c->maxiter - queued : LISD_BATCH;
+		for (LIS_INT k = 0; k < batch; k++) {
+			KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
+			if (queued + k == 0) TRY(d_copy(c, r, p));
+			else KTRY(liship_axpy_xpay_dev_f64(n, st + LISHIP_KS_NOMEGA, v, r, st + LISHIP_KS_BETA, p, lisg.stream));
+			if (pre) KTRY(liship_pmul_f64(n, p, c->dinv, phat, lisg.stream));
+			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_ALPHA));
+			TRY(lisd_spmv_dot_launch_to(c->A, phat, v, rtld, 0, st + LISHIP_KS_DOT0));
+			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_ALPHA, LISHIP_KS_DOT0, 1));
+			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_HALF));
+			KTRY(liship_axpy_sumsq_dev_f64(n, st + LISHIP_KS_NALPHA, v, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_HALF, LISHIP_KS_SUM0, 1));
+			/* converged at the half step: x += alpha*phat (:240-258), and only then -- NOT_HALF is 0 from that
+			 * step until the next one */
+			KTRY(liship_krylov_guard(st + LISHIP_KS_NOT_HALF));
+			KTRY(liship_axpy_dev_f64(n, st + LISHIP_KS_ALPHA, phat, c->x, lisg.stream));
+			KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
+			if (pre) KTRY(liship_pmul_f64(n, sv, c->dinv, shat, lisg.stream));
+			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_OMEGA));
+			TRY(lisd_spmv_dot_launch_to(c->A, shat, t, sv, 1, st + LISHIP_KS_DOT0));
+			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_OMEGA, LISHIP_KS_DOT0, 2));
+			KTRY(liship_axpy2_dev_f64(n, st + LISHIP_KS_ALPHA, phat, st + LISHIP_KS_OMEGA, shat, c->x, lisg.stream));
+			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_RESID));
+			KTRY(liship_axpy_sumsq_dot_dev_f64(n, st + LISHIP_KS_NOMEGA, t, r, rtld, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_RESID, LISHIP_KS_SUM0, 2));
+		}
+		queued += batch;
+		TRY(dev_loop_sync(c, &L));
+	}
+done:
+	err = dev_loop_finish(c, &L, err);
+	work_free(c);
+	return err;
+}
+
 /* Preconditioned CG, lis_solver_cg.c:176-215, the reference's operation order per element with the
  * passes over HBM fused:
  *   p = M^-1 r + beta p              one pass   (the solve is a copy or r.*dinv, folded into the xpay)
@@ -270,9 +458,11 @@ static LIS_INT resid_from_sumsq(ctx_t *c, const double *r, double sumsq, double 
  * rho' is the next iteration's rho (the reference computes it at :180 from the same r).
  * LIS_AMD_NO_FUSION=1 runs the one-kernel-per-reference-call loop instead. */
 static LIS_INT run_cg_unfused(ctx_t *c);
+static LIS_INT run_cg_device(ctx_t *c);
 static LIS_INT run_cg(ctx_t *c)
 {
 	if (lisg.no_fusion) return run_cg_unfused(c);
+	if (device_scalars_ok(c)) return run_cg_device(c);
 	LIS_SOLVER s = c->s;
 	LIS_INT err = 0, iter;
 	const int n = c->n;
@@ -353,9 +543,11 @@ done:
  *   x += alpha phat + omega shat                    one pass
  *   r = s - omega t ; ||r|| ; rho' = <rtld,r>       one pass (rho' is :190 of the next iteration) */
 static LIS_INT run_bicgstab_unfused(ctx_t *c);
+static LIS_INT run_bicgstab_device(ctx_t *c);
 static LIS_INT run_bicgstab(ctx_t *c)
 {
 	if (lisg.no_fusion) return run_bicgstab_unfused(c);
+	if (device_scalars_ok(c)) return run_bicgstab_device(c);
 	LIS_SOLVER s = c->s;
 	LIS_INT err = 0, iter;
 	const int n = c->n;
@@ -682,7 +874,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	solver->A = A; solver->b = b;
 	solver->precision = LIS_PRECISION_DOUBLE;
 	free(solver->rhistory);
-	solver->rhistory = (LIS_REAL *)malloc(sizeof(LIS_REAL) * (size_t)(maxiter + 2));
+	solver->rhistory = (LIS_REAL *)calloc((size_t)(maxiter + 2), sizeof(LIS_REAL));   /* zeroed: an iteration that breaks down before its residual is formed leaves 0, not heap contents */
 	if (!solver->rhistory) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", maxiter + 2);
 	solver->rhistory[0] = 1.0;
 	solver->ptime = 0.0;

@@ -64,3 +64,5 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 
 // vector_ops.hip: fold `count` per-workgroup partials per result (layout partial[k*stride + i]) into result[k]
 int liship_internal_fold(int count, int nres, int stride, double *partial, double *spare, double *result, void *stream);
+// vector_ops.hip: the guard flag installed by liship_krylov_guard (NULL when none)
+const double *liship_internal_guard(void);

@@ -253,8 +253,10 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
                               const double *__restrict__ val, const double *__restrict__ x,
                               double *__restrict__ y, const v2i32 *__restrict__ blk,
                               int bfirst, int nb, int row_begin, int row_end, int run,
-                              const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr)
+                              const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                              const double *__restrict__ guard = nullptr)
 {
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     constexpr int CAP = WORK + SLACK;
     __shared__ double prod[CAP + 8];
     __shared__ double dot_scratch[BLOCK / WAVE];
@@ -278,8 +280,10 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
                                const double *__restrict__ val, const double *__restrict__ x,
                                double *__restrict__ y, const v2i32 *__restrict__ blk,
                                int bfirst, int nb, int row_begin, int row_end, int nnz_total, int run,
-                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr)
+                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                               const double *__restrict__ guard = nullptr)
 {
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     __shared__ double dot_scratch[BLOCK / WAVE];
     RowDots<DOT> dots{wdot, 0.0, 0.0};
     constexpr int CAP = WORK + SLACK;
@@ -521,7 +525,7 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
 {
     constexpr Geometry g = kGeom[G];
 #define GO(UU) spmv_csr_rowgather_kernel<g.block, g.work, UU, false, true, false, DOT><<<a.nb, g.block, 0, a.st>>>( \
-        a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, 16, w, partial)
+        a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, 16, w, partial, liship_internal_guard())
     if (unroll == 4) GO(4); else if (unroll == 7) GO(7); else GO(8);
 #undef GO
 }
@@ -532,10 +536,10 @@ void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double
     constexpr Geometry g = kGeom[G];
     if (batch == 2)
         spmv_csr_products_kernel<g.block, g.work, false, 2, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial);
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial, liship_internal_guard());
     else
         spmv_csr_products_kernel<g.block, g.work, false, 4, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial);
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial, liship_internal_guard());
 }
 
 int launch_csr(liship_csr_plan_t p, const LaunchArgs &a)

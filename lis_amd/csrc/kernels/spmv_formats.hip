@@ -33,8 +33,10 @@ template <int ROWS, int UNROLL, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const double *__restrict__ val,
                      const double *__restrict__ x, double *__restrict__ y,
-                     const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr)
+                     const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                     const double *__restrict__ guard = nullptr)
 {
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const int r0 = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
     const bool active = r0 < n;
     if (!DOT && !active) return;
@@ -85,8 +87,10 @@ template <int ROWS, int UNROLL, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_dia_kernel(int n, int ncols, int nnd, const int *__restrict__ off,
                      const double *__restrict__ val, const double *__restrict__ x,
-                     double *__restrict__ y, const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr)
+                     double *__restrict__ y, const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                     const double *__restrict__ guard = nullptr)
 {
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const int r0 = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
     const bool active = r0 < n;
     if (!DOT && !active) return;
@@ -300,8 +304,8 @@ extern "C" int liship_spmv_ell_dot_f64(int n, int maxnzr, const int *idx, const 
     const int grid = grid_for(n / 2);
     if ((size_t)grid > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    if (want_sumsq) spmv_ell_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial);
-    else            spmv_ell_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial);
+    if (want_sumsq) spmv_ell_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial, liship_internal_guard());
+    else            spmv_ell_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial, liship_internal_guard());
     LAUNCH_CHECK();
     return liship_internal_fold(grid, want_sumsq ? 2 : 1, grid, partial, spare, result, stream);
 }
@@ -315,8 +319,8 @@ extern "C" int liship_spmv_dia_dot_f64(int n, int ncols, int nnd, const int *off
     const int grid = grid_for(n / 2);
     if ((size_t)grid > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    if (want_sumsq) spmv_dia_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial);
-    else            spmv_dia_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial);
+    if (want_sumsq) spmv_dia_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial, liship_internal_guard());
+    else            spmv_dia_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial, liship_internal_guard());
     LAUNCH_CHECK();
     return liship_internal_fold(grid, want_sumsq ? 2 : 1, grid, partial, spare, result, stream);
 }

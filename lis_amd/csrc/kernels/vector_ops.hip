@@ -39,6 +39,15 @@ __device__ __forceinline__ void st2(double *p, long long pair, v2f64 v)
     __builtin_nontemporal_store(v, reinterpret_cast<v2f64 *>(p) + pair);
 }
 
+// ---- device-driven Krylov loops ----------------------------------------------------------------------
+// A solver that keeps its scalars in HBM (liship.h "krylov state") enqueues many iterations without a host
+// round trip.  Two things make that safe: (1) coefficients can be read from HBM at kernel start (Dev::pa/pb),
+// (2) every kernel launched while a guard is installed returns at once when *guard != 0 -- the state's DONE
+// flag, raised by the scalar step that detects convergence -- so the iterations queued behind the converged
+// one change nothing.
+struct Dev { const double *pa, *pb, *skip; };
+const double *g_guard = nullptr;
+
 // ---- element-wise ---------------------------------------------------------------------------------
 enum EwOp { EW_AXPY, EW_XPAY, EW_AXPYZ, EW_SCALE_TO, EW_PMUL, EW_PDIV, EW_SET, EW_ABS, EW_RECIP, EW_SHIFT,
             EW_AXPY2, EW_PUPDATE, EW_PMUL_XPAY, EW_SCALE_DEV };
@@ -72,9 +81,12 @@ template <int OP> struct EwArity { static constexpr int value =
 
 template <int OP, bool NT, bool VEC>
 __global__ __launch_bounds__(BLOCK)
-void ew_kernel(int n, double a, double b, const double *in0, const double *in1, const double *in2, double *out)
+void ew_kernel(int n, double a, double b, const double *in0, const double *in1, const double *in2, double *out, Dev D)
 {
     constexpr int NIN = EwArity<OP>::value;
+    if (D.skip && D.skip[0] != 0.0) return;
+    if (D.pa) a = D.pa[0];
+    if (D.pb) b = D.pb[0];
     if (OP == EW_SCALE_DEV) a = 1.0 / sqrt(in1[0]);     // in1: device scalar (a sum of squares), lis_solver_gmres.c:229-232
     if (VEC) {
         const long long npairs = n >> 1;
@@ -114,7 +126,8 @@ void ew_kernel(int n, double a, double b, const double *in0, const double *in1, 
 }
 
 template <int OP>
-int run_ew(int n, double a, double b, const double *in0, const double *in1, const double *in2, double *out, void *stream)
+int run_ew(int n, double a, double b, const double *in0, const double *in1, const double *in2, double *out, void *stream,
+           const double *pa = nullptr, const double *pb = nullptr)
 {
     if (n < 0) return LISHIP_ERR_ARG;
     if (n == 0) return 0;
@@ -122,9 +135,10 @@ int run_ew(int n, double a, double b, const double *in0, const double *in1, cons
     const bool vec = aligned16(out) && (NIN < 1 || aligned16(in0)) && (NIN < 2 || aligned16(in1)) && (NIN < 3 || aligned16(in2));
     const int grid = blocks_for(vec ? (n + 1) / 2 : ((long long)n + 1) / 2);
     hipStream_t st = as_stream(stream);
-    if (!vec)                       ew_kernel<OP, false, false><<<grid, BLOCK, 0, st>>>(n, a, b, in0, in1, in2, out);
-    else if (n > NT_LOAD_ELEMS)     ew_kernel<OP, true, true><<<grid, BLOCK, 0, st>>>(n, a, b, in0, in1, in2, out);
-    else                            ew_kernel<OP, false, true><<<grid, BLOCK, 0, st>>>(n, a, b, in0, in1, in2, out);
+    const Dev D{pa, pb, g_guard};
+    if (!vec)                       ew_kernel<OP, false, false><<<grid, BLOCK, 0, st>>>(n, a, b, in0, in1, in2, out, D);
+    else if (n > NT_LOAD_ELEMS)     ew_kernel<OP, true, true><<<grid, BLOCK, 0, st>>>(n, a, b, in0, in1, in2, out, D);
+    else                            ew_kernel<OP, false, true><<<grid, BLOCK, 0, st>>>(n, a, b, in0, in1, in2, out, D);
     LAUNCH_CHECK();
     return 0;
 }
@@ -148,6 +162,8 @@ struct RedArgs {
     const double *x, *y, *w, *d, *e; // inputs (meaning per OP)
     double *ox, *oy;                 // in-place outputs of the fused forms
     const double *sp;                // device scalar of the *D ops (last: the other initialisers leave it NULL)
+    const double *pa;                // coefficient `a` read from HBM when set (device-driven loops)
+    const double *skip;              // guard flag (filled by run_reduce)
 };
 
 template <int OP, bool NT, bool VEC>
@@ -158,6 +174,8 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
     constexpr int NRES = RedResults<OP>::value;
     double s0 = 0.0, s1 = 0.0;
     const int n = A.n;
+    if (A.skip && A.skip[0] != 0.0) return;
+    if (A.pa) A.a = A.pa[0];
     const double adev = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) ? -A.sp[0] : 0.0;
     auto term = [&](double x, double y, double w, double d, double e, double &ox, double &oy) {
         if (OP == RED_DOT)   s0 += x * y;
@@ -243,6 +261,96 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
     }
 }
 
+// One lane: the scalar statements between the vector passes, on the state block in HBM.  Every operation is the
+// IEEE double operation the host loop performs (no contraction; sqrt and / are correctly rounded on gfx950).
+__device__ void krylov_step_device(int step, double *st, double *rhist, const double *gathered, int nranks)
+{
+    st[LISHIP_KS_NOT_HALF] = 1.0;                    // (re-)armed by every step; only BICGSTAB_HALF may lower it
+    if (st[LISHIP_KS_DONE] != 0.0) return;
+    if (gathered) {                                  // cross-rank fold, rank order (lis_vector_ops.c:119,263)
+        int slot = LISHIP_KS_DOT0, count = 1;
+        switch (step) {
+        case LISHIP_STEP_CG_RESID:        slot = LISHIP_KS_SUM0; break;
+        case LISHIP_STEP_CG_RESID_PRE:    slot = LISHIP_KS_SUM0; count = 2; break;
+        case LISHIP_STEP_BICGSTAB_HALF:   slot = LISHIP_KS_SUM0; break;
+        case LISHIP_STEP_BICGSTAB_OMEGA:  count = 2; break;
+        case LISHIP_STEP_BICGSTAB_RESID:  slot = LISHIP_KS_SUM0; count = 2; break;
+        default: break;
+        }
+        for (int k = 0; k < count; k++) {
+            double s = 0.0;
+            for (int r = 0; r < nranks; r++) s += gathered[r * count + k];
+            st[slot + k] = s;
+        }
+    }
+    auto finish_iteration = [&](double nrm2) {
+        const double iter = st[LISHIP_KS_ITER] + 1.0;
+        st[LISHIP_KS_ITER] = iter;
+        st[LISHIP_KS_NRM2] = nrm2;
+        st[LISHIP_KS_NHIST] = iter;
+        if (rhist) rhist[(long long)iter] = nrm2;
+    };
+    auto stop = [&](double status) { st[LISHIP_KS_STATUS] = status; st[LISHIP_KS_DONE] = 1.0; };
+    switch (step) {
+    case LISHIP_STEP_CG_ALPHA: {                      // lis_solver_cg.c:193-204
+        const double dot_pq = st[LISHIP_KS_DOT0];
+        if (dot_pq == 0.0) { st[LISHIP_KS_ITER] += 1.0; stop(2.0); return; }
+        const double alpha = st[LISHIP_KS_RHO] / dot_pq;
+        st[LISHIP_KS_ALPHA] = alpha; st[LISHIP_KS_NALPHA] = -alpha;
+        return;
+    }
+    case LISHIP_STEP_CG_RESID:
+    case LISHIP_STEP_CG_RESID_PRE: {                  // :207-215, then :180-184 of the next iteration
+        const double nrm2 = sqrt(st[LISHIP_KS_SUM0]) * st[LISHIP_KS_BNRM];
+        finish_iteration(nrm2);
+        if (st[LISHIP_KS_TOL] >= nrm2) { stop(1.0); return; }
+        const double rho_old = st[LISHIP_KS_RHO];
+        const double rho = st[step == LISHIP_STEP_CG_RESID_PRE ? LISHIP_KS_SUM1 : LISHIP_KS_SUM0];
+        st[LISHIP_KS_RHO_OLD] = rho_old; st[LISHIP_KS_RHO] = rho;
+        st[LISHIP_KS_BETA] = rho / rho_old;
+        return;
+    }
+    case LISHIP_STEP_BICGSTAB_ALPHA: {                // :190-196 (the test of rho precedes everything the iteration
+        const double rho = st[LISHIP_KS_RHO];         // changes in x and r), :226-230
+        if (rho == 0.0) { st[LISHIP_KS_ITER] += 1.0; stop(2.0); return; }
+        const double alpha = rho / st[LISHIP_KS_DOT0];
+        st[LISHIP_KS_ALPHA] = alpha; st[LISHIP_KS_NALPHA] = -alpha;
+        return;
+    }
+    case LISHIP_STEP_BICGSTAB_HALF: {                 // :236-258
+        const double nrm2 = sqrt(st[LISHIP_KS_SUM0]) * st[LISHIP_KS_BNRM];
+        if (nrm2 <= st[LISHIP_KS_TOL]) { finish_iteration(nrm2); st[LISHIP_KS_NOT_HALF] = 0.0; stop(1.0); }
+        else st[LISHIP_KS_NRM2] = nrm2;
+        return;
+    }
+    case LISHIP_STEP_BICGSTAB_OMEGA: {                // :267-269
+        const double omega = st[LISHIP_KS_DOT0] / st[LISHIP_KS_DOT1];
+        st[LISHIP_KS_OMEGA] = omega; st[LISHIP_KS_NOMEGA] = -omega;
+        return;
+    }
+    case LISHIP_STEP_BICGSTAB_RESID: {                // :279-303
+        const double nrm2 = sqrt(st[LISHIP_KS_SUM0]) * st[LISHIP_KS_BNRM];
+        finish_iteration(nrm2);
+        if (st[LISHIP_KS_TOL] >= nrm2) { stop(1.0); return; }
+        if (st[LISHIP_KS_OMEGA] == 0.0) { stop(2.0); return; }
+        const double rho_old = st[LISHIP_KS_RHO], rho = st[LISHIP_KS_SUM1];
+        st[LISHIP_KS_RHO_OLD] = rho_old; st[LISHIP_KS_RHO] = rho;
+        st[LISHIP_KS_BETA] = (rho / rho_old) * (st[LISHIP_KS_ALPHA] / st[LISHIP_KS_OMEGA]);   // :212 of the next iteration
+        return;
+    }
+    default: return;
+    }
+}
+
+__global__ void krylov_step_kernel(int step, double *st, double *rhist, const double *gathered, int nranks)
+{ krylov_step_device(step, st, rhist, gathered, nranks); }
+
+// a scalar step announced with liship_krylov_chain rides in the last kernel of the next reduction (single-rank
+// jobs: nothing has to be gathered between the fold and the step), saving a launch per reduction
+struct Chain { int step; double *st, *rh; };
+Chain g_chain{0, nullptr, nullptr};
+inline Chain take_chain() { Chain c = g_chain; g_chain.step = 0; return c; }
+
 // levels >= 2: out[k*ostride + block] = sum of in[k*istride + block*2048 ...), finally one block
 __global__ __launch_bounds__(BLOCK)
 void reduce_fold(int count, int nres, int istride, int ostride, const double *__restrict__ in, double *__restrict__ out,
@@ -266,7 +374,7 @@ void reduce_fold(int count, int nres, int istride, int ostride, const double *__
 // last level in one launch: a single 1024-lane workgroup sums up to 2^14 partials per result (lane-strided, then the
 // fixed wave/LDS tree), (16 per lane: beyond that a second level of 256-lane workgroups is faster)
 __global__ __launch_bounds__(1024)
-void reduce_final(int count, int nres, int istride, const double *__restrict__ in, double *__restrict__ result, bool root)
+void reduce_final(int count, int nres, int istride, const double *__restrict__ in, double *result, bool root, Chain chain)
 {
     __shared__ double scratch[1024 / WAVE];
     for (int k = 0; k < nres; k++) {
@@ -276,11 +384,15 @@ void reduce_final(int count, int nres, int istride, const double *__restrict__ i
         const double t = block_sum<1024 / WAVE>(s, scratch);
         if (threadIdx.x == 0) result[k] = root ? sqrt(t) : t;
     }
+    if (chain.step && threadIdx.x == 0) krylov_step_device(chain.step, chain.st, chain.rh, nullptr, 0);
 }
 
-__global__ void finish_kernel(int nres, int stride, bool root, const double *__restrict__ in, double *__restrict__ result)
+__global__ void finish_kernel(int nres, int stride, bool root, const double *__restrict__ in, double *result, Chain chain)
 {
-    if (threadIdx.x < nres) { const double s = in[(size_t)threadIdx.x * stride]; result[threadIdx.x] = root ? sqrt(s) : s; }
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < nres; k++) { const double s = in[(size_t)k * stride]; result[k] = root ? sqrt(s) : s; }
+        if (chain.step) krylov_step_device(chain.step, chain.st, chain.rh, nullptr, 0);
+    }
 }
 
 // fold `count` partials per result (layout partial[k*stride + i]) down to result[k]; scratch2 lives behind them
@@ -292,7 +404,7 @@ int fold_partials(int count, int nres, int stride, double *partial, double *spar
     int which = 0;
     while (count > 1) {
         if (count <= (1 << 14)) {                   // last level: one workgroup, straight into result[k]
-            reduce_final<<<1, 1024, 0, st>>>(count, nres, cstride, cur, result, root);
+            reduce_final<<<1, 1024, 0, st>>>(count, nres, cstride, cur, result, root, take_chain());
             LAUNCH_CHECK();
             return 0;
         }
@@ -308,7 +420,7 @@ int fold_partials(int count, int nres, int stride, double *partial, double *spar
         cur = dst; cstride = blocks; count = blocks;
         which ^= 1;
     }
-    finish_kernel<<<1, 64, 0, st>>>(nres, cstride, root, cur, result);    // a single partial (SpMV epilogue of one block)
+    finish_kernel<<<1, 64, 0, st>>>(nres, cstride, root, cur, result, take_chain());    // a single partial (SpMV epilogue of one block)
     LAUNCH_CHECK();
     return 0;
 }
@@ -331,6 +443,7 @@ int run_reduce(RedArgs A, double *result, void *work, bool root, void *stream)
     double *partial = static_cast<double *>(work);
     double *spare = partial + 2 * MAX_PARTIALS;              // second half of the scratch
     hipStream_t st = as_stream(stream);
+    A.skip = g_guard;
     const bool single = (grid == 1);                         // one block: it writes result[k] itself
     double *dst = single ? result : partial;
     const bool r1 = single && root;
@@ -338,7 +451,11 @@ int run_reduce(RedArgs A, double *result, void *work, bool root, void *stream)
     else if (n > NT_LOAD_ELEMS) reduce_level1<OP, true, true><<<grid, BLOCK, 0, st>>>(A, grid, dst, r1);
     else                        reduce_level1<OP, false, true><<<grid, BLOCK, 0, st>>>(A, grid, dst, r1);
     LAUNCH_CHECK();
-    if (single) return 0;
+    if (single) {                                            // no fold to ride in: the announced step gets its own launch
+        const Chain c = take_chain();
+        if (c.step) { krylov_step_kernel<<<1, 1, 0, st>>>(c.step, c.st, c.rh, nullptr, 0); LAUNCH_CHECK(); }
+        return 0;
+    }
     return fold_partials(grid, NRES, grid, partial, spare, result, root, st);
 }
 
@@ -455,6 +572,62 @@ extern "C" int liship_mgs_step_f64(int n, const double *hprev, const double *vpr
 // x *= 1/sqrt(*sumsq), sumsq in HBM  (lis_vector_nrm2 + lis_vector_scale, lis_solver_gmres.c:229-232)
 extern "C" int liship_scale_inv_norm_f64(int n, const double *sumsq, double *x, void *s)
 { return run_ew<EW_SCALE_DEV>(n, 0.0, 0.0, x, sumsq, nullptr, x, s); }
+
+// ---- device-driven Krylov loops: coefficient-from-HBM forms and the scalar steps (liship.h) --------------
+extern "C" int liship_krylov_guard(const double *flag) { g_guard = flag; return 0; }
+const double *liship_internal_guard(void) { return g_guard; }      // for the fused-product launches (spmv_*.hip)
+
+extern "C" int liship_xpay_dev_f64(int n, const double *x, const double *pa, double *y, void *s)
+{ return pa ? run_ew<EW_XPAY>(n, 0.0, 0.0, x, y, nullptr, y, s, pa) : LISHIP_ERR_ARG; }
+extern "C" int liship_pmul_xpay_dev_f64(int n, const double *x, const double *d, const double *pa, double *y, void *s)
+{ return pa ? run_ew<EW_PMUL_XPAY>(n, 0.0, 0.0, x, y, d, y, s, pa) : LISHIP_ERR_ARG; }
+extern "C" int liship_axpy_dev_f64(int n, const double *pa, const double *x, double *y, void *s)
+{ return pa ? run_ew<EW_AXPY>(n, 0.0, 0.0, x, y, nullptr, y, s, pa) : LISHIP_ERR_ARG; }
+extern "C" int liship_axpy2_dev_f64(int n, const double *pa, const double *x, const double *pb, const double *w, double *y, void *s)
+{ return (pa && pb) ? run_ew<EW_AXPY2>(n, 0.0, 0.0, x, y, w, y, s, pa, pb) : LISHIP_ERR_ARG; }
+extern "C" int liship_axpy_xpay_dev_f64(int n, const double *pa, const double *x, const double *w, const double *pb, double *y, void *s)
+{ return (pa && pb) ? run_ew<EW_PUPDATE>(n, 0.0, 0.0, x, y, w, y, s, pa, pb) : LISHIP_ERR_ARG; }
+extern "C" int liship_cg_update_dev_f64(int n, const double *palpha, const double *p, const double *q, const double *dinv,
+                                        double *x, double *r, double *result, void *w, void *s)
+{
+    if (!palpha) return LISHIP_ERR_ARG;
+    RedArgs A{n, 0.0, p, q, x, r, dinv, x, r, nullptr, palpha};
+    return dinv ? run_reduce<RED_CG_UPDATE_JAC>(A, result, w, false, s) : run_reduce<RED_CG_UPDATE>(A, result, w, false, s);
+}
+extern "C" int liship_axpy_sumsq_dev_f64(int n, const double *pa, const double *x, double *y, double *result, void *w, void *s)
+{
+    if (!pa) return LISHIP_ERR_ARG;
+    RedArgs A{n, 0.0, x, y, nullptr, nullptr, nullptr, nullptr, y, nullptr, pa};
+    return run_reduce<RED_AXPY_NRM2>(A, result, w, false, s);
+}
+extern "C" int liship_axpy_sumsq_dot_dev_f64(int n, const double *pa, const double *x, double *y, const double *v,
+                                             double *result, void *w, void *s)
+{
+    if (!pa) return LISHIP_ERR_ARG;
+    RedArgs A{n, 0.0, x, y, v, nullptr, nullptr, nullptr, y, nullptr, pa};
+    return run_reduce<RED_AXPY_NRM2_DOT>(A, result, w, false, s);
+}
+
+extern "C" int liship_krylov_chain(int step, double *state, double *rhistory)
+{
+    if (!state || step < LISHIP_STEP_CG_ALPHA || step > LISHIP_STEP_BICGSTAB_RESID) return LISHIP_ERR_ARG;
+    g_chain = Chain{step, state, rhistory};
+    return 0;
+}
+// the announced step did not find a reduction to ride in (a product without the fused epilogue, ...): run it alone
+extern "C" int liship_krylov_chain_flush(void *stream)
+{
+    const Chain c = take_chain();
+    if (c.step) { krylov_step_kernel<<<1, 1, 0, as_stream(stream)>>>(c.step, c.st, c.rh, nullptr, 0); LAUNCH_CHECK(); }
+    return 0;
+}
+extern "C" int liship_krylov_step(int step, double *state, double *rhistory, const double *gathered, int nranks, void *stream)
+{
+    if (!state || step < LISHIP_STEP_CG_ALPHA || step > LISHIP_STEP_BICGSTAB_RESID) return LISHIP_ERR_ARG;
+    krylov_step_kernel<<<1, 1, 0, as_stream(stream)>>>(step, state, rhistory, gathered, gathered ? nranks : 0);
+    LAUNCH_CHECK();
+    return 0;
+}
 
 namespace {
 constexpr int LINCOMB_MAX = 48;

@@ -137,7 +137,6 @@ LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes)
  * rank order (liship_krylov_step) -- no host synchronisation */
 LIS_INT lisc_gather_device(const double *src, int count)
 {
-	if (lisg.nprocs <= 1) return LIS_SUCCESS;
 	if (lisg.comm_kind != 1 || count > 4) return LISI_ERR(LIS_ERR_ILL_ARG, "device gather needs the RCCL communicator\n");
 	NCCLCHK(rccl.AllGather(src, lisg.gather_out, (size_t)count, NCCL_DOUBLE, lisg.nccl_comm, lisg.stream));
 	return LIS_SUCCESS;

@@ -197,6 +197,9 @@ int  liship_krylov_step(int step, double *state, double *rhistory, const double 
  * reduction's last kernel instead of a launch of its own.  liship_krylov_chain_flush runs a step that was announced
  * but found no reduction to ride in (call it after the reduction; a no-op otherwise). */
 int  liship_krylov_chain(int step, double *state, double *rhistory);
+/* out[k] = sum over ranks r (in rank order, from 0.0) of gathered[r*count + k]: the device half of the cross-rank
+ * fold that MPI_Allreduce does in the reference (lis_vector_ops.c:119,263), count <= 64 */
+int  liship_rank_fold_f64(int count, const double *gathered, int nranks, double *out, void *stream);
 int  liship_krylov_chain_flush(void *stream);
 /* y = x + (*pa)*y;  y = x.*d + (*pa)*y;  y += (*pa)*x;  y += (*pa)*x, then y += (*pb)*w;  y += (*pa)*x, then y = w + (*pb)*y */
 int  liship_xpay_dev_f64(int n, const double *x, const double *pa, double *y, void *stream);

@@ -705,6 +705,15 @@ done:
 	return err;
 }
 
+/* RCCL job: replace this rank's sums in HBM by the sums over all ranks, without leaving the stream */
+static LIS_INT globalize(double *slot, int count)
+{
+	if (lisg.comm_kind != 1) return LIS_SUCCESS;
+	LISCHK(lisc_gather_device(slot, count));
+	HIPCHK(liship_rank_fold_f64(count, lisg.gather_out, lisg.nprocs, slot, lisg.stream));
+	return LIS_SUCCESS;
+}
+
 static LIS_INT run_gmres(ctx_t *c)
 {
 	LIS_SOLVER s = c->s;
@@ -719,8 +728,9 @@ static LIS_INT run_gmres(ctx_t *c)
 	if (!h || !g) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", ld); goto done; }
 	TRY(work_alloc(c, m + 3));
 	double *r = c->work[0], *z = c->work[1], **v = &c->work[2];
-	/* device-chained Gram-Schmidt needs the cross-rank fold on the device too: single-rank jobs only for now */
-	const int chained = !lisg.no_fusion && lisg.nprocs == 1;
+	/* device-chained Gram-Schmidt: in an RCCL job each coefficient is made global on the device as well
+	 * (all-gather + rank-order fold); the callback communicator folds on the host, so it takes the other branch */
+	const int chained = !lisg.no_fusion && (lisg.nprocs == 1 || lisg.comm_kind == 1);
 	if (chained) KTRY(liship_malloc((void **)&hdev, sizeof(double) * (size_t)(m + 4)));
 	int st = initial_residual(c, v[0]);                /* :193 leaves the unpreconditioned residual in v0 */
 	if (st) { err = st < 0 ? -st : 0; goto done; }
@@ -740,9 +750,13 @@ static LIS_INT run_gmres(ctx_t *c)
 				/* modified Gram-Schmidt with the coefficients kept in HBM: step k reads h[k-1] from the previous
 				 * step's reduction, so the whole column costs ONE host synchronisation instead of i+1 */
 				KTRY(liship_dot_f64(n, v[i1], v[0], hdev, lisg.reduce_work, lisg.stream));
-				for (int k = 1; k < i; k++)
+				TRY(globalize(hdev, 1));
+				for (int k = 1; k < i; k++) {
 					KTRY(liship_mgs_step_f64(n, hdev + k - 1, v[k - 1], v[i1], v[k], hdev + k, lisg.reduce_work, lisg.stream));
+					TRY(globalize(hdev + k, 1));
+				}
 				KTRY(liship_mgs_step_f64(n, hdev + i - 1, v[i - 1], v[i1], NULL, hdev + i, lisg.reduce_work, lisg.stream));
+				TRY(globalize(hdev + i, 1));
 				KTRY(liship_scale_inv_norm_f64(n, hdev + i, v[i1], lisg.stream));
 				if (i + 1 <= 256) {                        /* through the page-locked landing zone */
 					KTRY(liship_memcpy_d2h(lisg.host_out, hdev, sizeof(double) * (size_t)(i + 1), lisg.stream));

@@ -608,6 +608,24 @@ extern "C" int liship_axpy_sumsq_dot_dev_f64(int n, const double *pa, const doub
     return run_reduce<RED_AXPY_NRM2_DOT>(A, result, w, false, s);
 }
 
+namespace {
+__global__ void rank_fold_kernel(int count, const double *__restrict__ gathered, int nranks, double *__restrict__ out)
+{
+    const int k = threadIdx.x;
+    if (k >= count) return;
+    double s = 0.0;
+    for (int r = 0; r < nranks; r++) s += gathered[r * count + k];
+    out[k] = s;
+}
+} // namespace
+extern "C" int liship_rank_fold_f64(int count, const double *gathered, int nranks, double *out, void *stream)
+{
+    if (count < 1 || count > 64 || nranks < 1 || !gathered || !out) return LISHIP_ERR_ARG;
+    rank_fold_kernel<<<1, 64, 0, as_stream(stream)>>>(count, gathered, nranks, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int liship_krylov_chain(int step, double *state, double *rhistory)
 {
     if (!state || step < LISHIP_STEP_CG_ALPHA || step > LISHIP_STEP_BICGSTAB_RESID) return LISHIP_ERR_ARG;

@@ -161,7 +161,7 @@ int  liship_scale_inv_norm_f64(int n, const double *sumsq, double *x, void *stre
  * convergence flag) can live in HBM: a block of LISHIP_KS_LEN doubles the host fills once.  The `_dev` forms of
  * the vector kernels read their coefficient(s) from that block at kernel start, reductions leave their sums in
  * it, and liship_krylov_step() -- one lane -- applies the reference's scalar statements between them
- * (lis_solver_cg.c:176-215, lis_solver_bicgstab.c:186-290) with the same IEEE operations the host loop would
+ * (lis_solver_cg.c:176-215, lis_solver_bicgstab.c:186-290, lis_solver_bicg.c:176-262) with the same IEEE operations the host loop would
  * use.  While a guard flag is installed (liship_krylov_guard), every vector / reduction / fused-product kernel
  * launched returns immediately if *flag != 0, so the host may enqueue a batch of iterations, read the block
  * back once, and find x, r and the iteration count exactly as the one-synchronisation-per-scalar loop leaves
@@ -185,7 +185,10 @@ enum {
 	LISHIP_STEP_BICGSTAB_ALPHA,   /* after <rtld,v>: rho == 0 breakdown test, alpha = rho / <rtld,v>            */
 	LISHIP_STEP_BICGSTAB_HALF,    /* after ||s||: convergence at the half step (lowers NOT_HALF for the x update)*/
 	LISHIP_STEP_BICGSTAB_OMEGA,   /* after <t,s>,<t,t>: omega = <t,s>/<t,t>                                     */
-	LISHIP_STEP_BICGSTAB_RESID    /* after the r update: ||r||, history, convergence, omega breakdown, rho', beta */
+	LISHIP_STEP_BICGSTAB_RESID,   /* after the r update: ||r||, history, convergence, omega breakdown, rho', beta */
+	LISHIP_STEP_BICG_ALPHA,       /* after <p~,q>: rho == 0 and <p~,q> == 0 breakdown tests, alpha              */
+	LISHIP_STEP_BICG_RESID,       /* after the x,r update: ||r||, history, convergence                          */
+	LISHIP_STEP_BICG_RHO          /* after the r~ update: rho <- <r~, M^-1 r>, beta                             */
 };
 /* install (flag != NULL) or remove (NULL) the guard for the launches that follow */
 int  liship_krylov_guard(const double *flag);

@@ -659,8 +659,10 @@ done:
  *   q~ = A^T p~                                            product
  *   x += alpha p ; r -= alpha q ; ||r||                    one pass
  *   r~ -= alpha q~ ; rho' = <r~, M^-1 r>                   one pass (rho' is :187 of the next iteration) */
+static LIS_INT run_bicg_device(ctx_t *c);
 static LIS_INT run_bicg(ctx_t *c)
 {
+	if (!lisg.no_fusion && device_scalars_ok(c)) return run_bicg_device(c);
 	LIS_SOLVER s = c->s;
 	LIS_INT err = 0, iter;
 	const int n = c->n;
@@ -701,6 +703,56 @@ static LIS_INT run_bicg(ctx_t *c)
 	}
 	s->retcode = LIS_MAXITER; s->iter = iter; s->resid = nrm2; err = LIS_MAXITER;
 done:
+	work_free(c);
+	return err;
+}
+
+static LIS_INT run_bicg_device(ctx_t *c)
+{
+	LIS_INT err = 0;
+	const int n = c->n;
+	dev_loop L = {0};
+	TRY(work_alloc(c, 7));
+	double *r = c->work[0], *rtld = c->work[1], *q = c->work[2], *qtld = c->work[3], *p = c->work[4], *ptld = c->work[5];
+	double *z = c->work[6];
+	double rho, init[LISHIP_KS_LEN] = {0};
+	int st0 = initial_residual(c, r);
+	if (st0) { work_free(c); return st0 < 0 ? -st0 : 0; }
+	TRY(d_copy(c, r, rtld));
+	if (c->dinv) { KTRY(liship_pmul_f64(n, r, c->dinv, z, lisg.stream)); TRY(lisd_dot(n, rtld, z, &rho)); }
+	else TRY(lisd_dot(n, rtld, r, &rho));
+	init[LISHIP_KS_RHO] = rho; init[LISHIP_KS_RHO_OLD] = 1.0; init[LISHIP_KS_BETA] = rho / 1.0;
+	init[LISHIP_KS_BNRM] = c->bnrm; init[LISHIP_KS_TOL] = c->tol; init[LISHIP_KS_NOT_HALF] = 1.0;
+	TRY(dev_loop_begin(c, &L, init));
+	double *st = L.st;
+	KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
+	for (LIS_INT queued = 0; queued < c->maxiter && L.host[LISHIP_KS_DONE] == 0.0; ) {
+		const LIS_INT batch = (c->maxiter - queued < LISD_BATCH) ? c->maxiter - queued : LISD_BATCH;
+		for (LIS_INT k = 0; k < batch; k++) {
+			if (c->dinv) {
+				KTRY(liship_pmul_xpay_dev_f64(n, r, c->dinv, st + LISHIP_KS_BETA, p, lisg.stream));
+				KTRY(liship_pmul_xpay_dev_f64(n, rtld, c->dinv, st + LISHIP_KS_BETA, ptld, lisg.stream));
+			} else {
+				KTRY(liship_xpay_dev_f64(n, r, st + LISHIP_KS_BETA, p, lisg.stream));
+				KTRY(liship_xpay_dev_f64(n, rtld, st + LISHIP_KS_BETA, ptld, lisg.stream));
+			}
+			TRY(dev_announce(&L, LISHIP_STEP_BICG_ALPHA));
+			TRY(lisd_spmv_dot_launch_to(c->A, p, q, ptld, 0, st + LISHIP_KS_DOT0));
+			TRY(dev_step(&L, LISHIP_STEP_BICG_ALPHA, LISHIP_KS_DOT0, 1));
+			TRY(lisd_spmv_t(c->A, ptld, qtld));           /* recomputed from scratch each time: harmless behind a raised flag */
+			TRY(dev_announce(&L, LISHIP_STEP_BICG_RESID));
+			KTRY(liship_cg_update_dev_f64(n, st + LISHIP_KS_ALPHA, p, q, NULL, c->x, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			TRY(dev_step(&L, LISHIP_STEP_BICG_RESID, LISHIP_KS_SUM0, 1));
+			if (c->dinv) KTRY(liship_pmul_f64(n, r, c->dinv, z, lisg.stream));
+			TRY(dev_announce(&L, LISHIP_STEP_BICG_RHO));
+			KTRY(liship_axpy_sumsq_dot_dev_f64(n, st + LISHIP_KS_NALPHA, qtld, rtld, c->dinv ? z : r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			TRY(dev_step(&L, LISHIP_STEP_BICG_RHO, LISHIP_KS_SUM0, 2));
+		}
+		queued += batch;
+		TRY(dev_loop_sync(c, &L));
+	}
+done:
+	err = dev_loop_finish(c, &L, err);
 	work_free(c);
 	return err;
 }

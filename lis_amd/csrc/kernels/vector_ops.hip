@@ -275,6 +275,8 @@ __device__ void krylov_step_device(int step, double *st, double *rhist, const do
         case LISHIP_STEP_BICGSTAB_HALF:   slot = LISHIP_KS_SUM0; break;
         case LISHIP_STEP_BICGSTAB_OMEGA:  count = 2; break;
         case LISHIP_STEP_BICGSTAB_RESID:  slot = LISHIP_KS_SUM0; count = 2; break;
+        case LISHIP_STEP_BICG_RESID:      slot = LISHIP_KS_SUM0; break;
+        case LISHIP_STEP_BICG_RHO:        slot = LISHIP_KS_SUM0; count = 2; break;
         default: break;
         }
         for (int k = 0; k < count; k++) {
@@ -336,6 +338,25 @@ __device__ void krylov_step_device(int step, double *st, double *rhist, const do
         const double rho_old = st[LISHIP_KS_RHO], rho = st[LISHIP_KS_SUM1];
         st[LISHIP_KS_RHO_OLD] = rho_old; st[LISHIP_KS_RHO] = rho;
         st[LISHIP_KS_BETA] = (rho / rho_old) * (st[LISHIP_KS_ALPHA] / st[LISHIP_KS_OMEGA]);   // :212 of the next iteration
+        return;
+    }
+    case LISHIP_STEP_BICG_ALPHA: {                    // lis_solver_bicg.c:187-195, :226-238
+        const double rho = st[LISHIP_KS_RHO], d1 = st[LISHIP_KS_DOT0];
+        if (rho == 0.0 || d1 == 0.0) { st[LISHIP_KS_ITER] += 1.0; stop(2.0); return; }
+        const double alpha = rho / d1;
+        st[LISHIP_KS_ALPHA] = alpha; st[LISHIP_KS_NALPHA] = -alpha;
+        return;
+    }
+    case LISHIP_STEP_BICG_RESID: {                    // :244-256
+        const double nrm2 = sqrt(st[LISHIP_KS_SUM0]) * st[LISHIP_KS_BNRM];
+        finish_iteration(nrm2);
+        if (st[LISHIP_KS_TOL] >= nrm2) stop(1.0);
+        return;
+    }
+    case LISHIP_STEP_BICG_RHO: {                      // :258-260, then :180-197 of the next iteration
+        const double rho_old = st[LISHIP_KS_RHO], rho = st[LISHIP_KS_SUM1];
+        st[LISHIP_KS_RHO_OLD] = rho_old; st[LISHIP_KS_RHO] = rho;
+        st[LISHIP_KS_BETA] = rho / rho_old;
         return;
     }
     default: return;
@@ -628,7 +649,7 @@ extern "C" int liship_rank_fold_f64(int count, const double *gathered, int nrank
 
 extern "C" int liship_krylov_chain(int step, double *state, double *rhistory)
 {
-    if (!state || step < LISHIP_STEP_CG_ALPHA || step > LISHIP_STEP_BICGSTAB_RESID) return LISHIP_ERR_ARG;
+    if (!state || step < LISHIP_STEP_CG_ALPHA || step > LISHIP_STEP_BICG_RHO) return LISHIP_ERR_ARG;
     g_chain = Chain{step, state, rhistory};
     return 0;
 }
@@ -641,7 +662,7 @@ extern "C" int liship_krylov_chain_flush(void *stream)
 }
 extern "C" int liship_krylov_step(int step, double *state, double *rhistory, const double *gathered, int nranks, void *stream)
 {
-    if (!state || step < LISHIP_STEP_CG_ALPHA || step > LISHIP_STEP_BICGSTAB_RESID) return LISHIP_ERR_ARG;
+    if (!state || step < LISHIP_STEP_CG_ALPHA || step > LISHIP_STEP_BICG_RHO) return LISHIP_ERR_ARG;
     krylov_step_kernel<<<1, 1, 0, as_stream(stream)>>>(step, state, rhistory, gathered, gathered ? nranks : 0);
     LAUNCH_CHECK();
     return 0;

@@ -1,4 +1,4 @@
-"""Device-driven CG / BiCGSTAB (scalars in HBM, iterations enqueued in batches, one read-back per batch) must leave
+"""Device-driven CG / BiCGSTAB / BiCG (scalars in HBM, iterations enqueued in batches, one read-back per batch) must leave
 exactly what the host-scalar loops leave: iteration count, status, residual, every residual-history entry and
 every bit of x (the unfused loops group their reductions differently and are compared by the golden-vector tests instead) --
 whatever the position of the converged iteration inside a batch of 16, for every way a loop
@@ -58,7 +58,7 @@ def same(outs):
     return a
 
 
-@pytest.mark.parametrize("solver", ["cg", "bicgstab"])
+@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg"])
 @pytest.mark.parametrize("precon", ["none", "jacobi"])
 @pytest.mark.parametrize("fmt", ["csr", "ell", "dia", "jad"])
 def test_bits_match_host_loops(lib, solver, precon, fmt):
@@ -69,7 +69,7 @@ def test_bits_match_host_loops(lib, solver, precon, fmt):
     assert a["status"] == 0 and a["iter"] > 16
 
 
-@pytest.mark.parametrize("solver", ["cg", "bicgstab"])
+@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg"])
 @pytest.mark.parametrize("maxiter", [0, 1, 5, 15, 16, 17, 31, 32, 33])
 def test_maxiter_at_every_batch_position(lib, solver, maxiter):
     ptr, idx, val = orc.poisson3d(14, 13, 9)
@@ -78,10 +78,10 @@ def test_maxiter_at_every_batch_position(lib, solver, maxiter):
     assert a["status"] != 0 and a["iter"] == maxiter + 1
 
 
-@pytest.mark.parametrize("solver", ["cg", "bicgstab"])
+@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg"])
 @pytest.mark.parametrize("tol", ["1e-1", "1e-2", "1e-3", "1e-4", "1e-5", "1e-6", "1e-7", "1e-8", "1e-9", "1e-10", "1e-11"])
 def test_converged_iteration_anywhere_in_a_batch(lib, solver, tol):
-    ptr, idx, val = nonsym(11) if solver == "bicgstab" else orc.poisson3d(20, 9, 8)
+    ptr, idx, val = orc.poisson3d(20, 9, 8) if solver == "cg" else nonsym(11)
     b = np.random.default_rng(5).uniform(-1, 1, len(ptr) - 1)
     x0 = np.random.default_rng(6).uniform(-1, 1, len(ptr) - 1)
     a = same(run_modes(lib, ptr, idx, val, b, f"-i {solver} -p none -tol {tol} -maxiter 500 -print mem -initx_zeros false",
@@ -93,7 +93,7 @@ def test_converged_iteration_anywhere_in_a_batch(lib, solver, tol):
 def test_convergence_conditions(lib, cond):
     ptr, idx, val = nonsym(2)
     b = np.random.default_rng(7).uniform(-1, 1, len(ptr) - 1)
-    for solver in ("cg", "bicgstab"):
+    for solver in ("cg", "bicgstab", "bicg"):
         if solver == "cg":
             p, i, v = orc.poisson3d(11, 10, 9)
             bb = b[: len(p) - 1]
@@ -122,6 +122,8 @@ def test_breakdowns(lib):
     b = np.ones(n)
     # CG on A = 0: <p,q> == 0 in the first iteration (lis_solver_cg.c:196-202)
     a = same(run_modes(lib, ptr, idx, np.zeros(n), b, "-i cg -p none -print mem"))
+    assert a["status"] != 0 and a["iter"] == 1
+    a = same(run_modes(lib, ptr, idx, np.zeros(n), b, "-i bicg -p none -print mem"))     # <p~,q> == 0 (lis_solver_bicg.c:228-236)
     assert a["status"] != 0 and a["iter"] == 1
     # BiCGSTAB on a rotation-like operator: <rtld, r> hits zero (:190-196) or omega does
     sw = idx.reshape(-1, 2)[:, ::-1].reshape(-1).astype(np.int32)           # swaps neighbours: A^2 = I, <r, A r> small

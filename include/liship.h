@@ -80,6 +80,15 @@ int  liship_spmv_csr_dot_f64(liship_csr_plan_t plan, const int *ptr, const int *
 int  liship_spmv_csr_rows_f64(liship_csr_plan_t plan, int row_begin, int row_end, const int *ptr,
                               const int *index, const double *value, const double *x, double *y,
                               void *stream);
+/* The fused-reduction product of liship_spmv_csr_dot_f64 in parts: rows [row_begin,row_end) now, their per-row-block
+ * partial sums parked in `work` from slot_base on (*slots_used of them); after the last part
+ * liship_spmv_csr_dot_finish_f64 folds all parked partials into result[0..1].  A multi-rank job uses it to run the rows
+ * that reference no ghost column while the halo travels (LIS_MATVEC_SENDRECV, include/lis_matvec.h:31-44, serialises
+ * the two in the reference). */
+int  liship_spmv_csr_rows_dot_f64(liship_csr_plan_t plan, int row_begin, int row_end, const int *ptr, const int *index,
+                                  const double *value, const double *x, double *y, const double *w, int want_sumsq,
+                                  void *work, int slot_base, int *slots_used, void *stream);
+int  liship_spmv_csr_dot_finish_f64(int slots_used, int want_sumsq, double *result, void *work, void *stream);
 /* tuning knobs for experiments (bench/profiling only): variant 0 = default */
 int  liship_spmv_csr_set_variant(int variant);
 

@@ -380,7 +380,33 @@ LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const doub
 {
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_mat_ready(A));
-	if (d->type == LIS_MATRIX_CSR && !lisg.no_fusion) {
+	if (d->type == LIS_MATRIX_CSR && !lisg.no_fusion && lisg.nprocs > 1 && A->commtable && !lisg.no_overlap &&
+	    d->inner_end - d->inner_begin >= d->n / 2) {
+		/* as lisd_spmv: interior rows while the halo travels, boundary rows after it; every part parks its
+		 * per-block partial sums, one fold at the end */
+		int used = 0, total = 0;
+		LISCHK(lisc_halo_begin(A, dx));
+		int rc = liship_spmv_csr_rows_dot_f64(d->plan, d->inner_begin, d->inner_end, d->ptr, d->index, d->value, dx, dy, dw,
+		                                      want_sumsq, lisg.reduce_work, 0, &used, lisg.stream);
+		LISCHK(lisc_halo_end(A, dx));
+		if (rc == 0) {
+			total = used;
+			if (d->inner_begin > 0) {
+				HIPCHK(liship_spmv_csr_rows_dot_f64(d->plan, 0, d->inner_begin, d->ptr, d->index, d->value, dx, dy, dw,
+				                                    want_sumsq, lisg.reduce_work, total, &used, lisg.stream));
+				total += used;
+			}
+			if (d->inner_end < d->n) {
+				HIPCHK(liship_spmv_csr_rows_dot_f64(d->plan, d->inner_end, d->n, d->ptr, d->index, d->value, dx, dy, dw,
+				                                    want_sumsq, lisg.reduce_work, total, &used, lisg.stream));
+				total += used;
+			}
+			HIPCHK(liship_spmv_csr_dot_finish_f64(total, want_sumsq, result, lisg.reduce_work, lisg.stream));
+			return LIS_SUCCESS;
+		}
+		if (rc != LISHIP_ERR_ARG) HIPCHK(rc);
+		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));   /* the ghosts are in */
+	} else if (d->type == LIS_MATRIX_CSR && !lisg.no_fusion) {
 		if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
 		int rc = liship_spmv_csr_dot_f64(d->plan, d->ptr, d->index, d->value, dx, dy, dw, want_sumsq,
 		                                 result, lisg.reduce_work, lisg.stream);

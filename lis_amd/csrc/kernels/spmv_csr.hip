@@ -254,7 +254,7 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
                               double *__restrict__ y, const v2i32 *__restrict__ blk,
                               int bfirst, int nb, int row_begin, int row_end, int run,
                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                              const double *__restrict__ guard = nullptr)
+                              const double *__restrict__ guard = nullptr, int pstride = 0)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     constexpr int CAP = WORK + SLACK;
@@ -265,12 +265,12 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
     if (lb < 0) return;
     Blk B = load_blk(blk, bfirst + lb);
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
-        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
     }
     block_by_products<BLOCK, CAP, VEC, NOGATHER, DOT>(prod, ptr, idx, val, x, y, B, dots);
     __syncthreads();
-    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
 // ------------------------------------------------------------------------------ row-gather kernel
@@ -281,7 +281,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
                                double *__restrict__ y, const v2i32 *__restrict__ blk,
                                int bfirst, int nb, int row_begin, int row_end, int nnz_total, int run,
                                const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                               const double *__restrict__ guard = nullptr)
+                               const double *__restrict__ guard = nullptr, int pstride = 0)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     __shared__ double dot_scratch[BLOCK / WAVE];
@@ -295,7 +295,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     if (lb < 0) return;
     Blk B = load_blk(blk, bfirst + lb);
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
-        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
     }
 
@@ -304,7 +304,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     if ((B.k1 - ka) > CAP || ka + 4 * nq > nnz_total) {     // long row / tail of the arrays
         block_by_products<BLOCK, CAP, 4, NOGATHER, DOT>(valL, ptr, idx, val, x, y, B, dots);
         __syncthreads();
-        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
     }
 
@@ -382,7 +382,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
         store_stream(y + r, acc);
         dots.add(r, acc);
     }
-    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, nb);
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
 } // namespace
@@ -521,25 +521,25 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
 }
 
 template <int G, int DOT>
-void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, double *partial)
+void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
 #define GO(UU) spmv_csr_rowgather_kernel<g.block, g.work, UU, false, true, false, DOT><<<a.nb, g.block, 0, a.st>>>( \
-        a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, 16, w, partial, liship_internal_guard())
+        a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, 16, w, partial, liship_internal_guard(), pstride)
     if (unroll == 4) GO(4); else if (unroll == 7) GO(7); else GO(8);
 #undef GO
 }
 
 template <int G, int DOT>
-void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double *partial)
+void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
     if (batch == 2)
         spmv_csr_products_kernel<g.block, g.work, false, 2, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial, liship_internal_guard());
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial, liship_internal_guard(), pstride);
     else
         spmv_csr_products_kernel<g.block, g.work, false, 4, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial, liship_internal_guard());
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial, liship_internal_guard(), pstride);
 }
 
 int launch_csr(liship_csr_plan_t p, const LaunchArgs &a)
@@ -606,4 +606,49 @@ extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int 
     while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
     LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream)};
     return launch_csr(p, a);
+}
+
+// The fused-reduction product in parts (a multi-rank job runs the rows that reference no ghost column while the
+// halo is in flight, the boundary rows after it): each part leaves one partial per row block it launched at
+// work[slot_base ...) (second result `slots` further), liship_spmv_csr_dot_finish_f64 folds all of them.  The sum
+// order is a function of the parts' row ranges only.  LISHIP_ERR_ARG as for liship_spmv_csr_dot_f64, or when the
+// slots run out.
+extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, int row_end, const int *ptr, const int *idx,
+                                            const double *val, const double *x, double *y, const double *w, int want_sumsq,
+                                            void *work, int slot_base, int *slots_used, void *stream)
+{
+    if (!p || !w || !work || !slots_used || row_begin < 0 || row_end > p->n || slot_base < 0) return LISHIP_ERR_ARG;
+    const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
+    if (g_variant != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    *slots_used = 0;
+    if (row_begin >= row_end || p->nblocks == 0) return 0;
+    const v2i32 *br = p->blk_host;
+    int lo = 0, hi = p->nblocks;                 // first b with br[b+1].row > row_begin
+    while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid + 1].x > row_begin) hi = mid; else lo = mid + 1; }
+    const int bfirst = lo;
+    lo = bfirst; hi = p->nblocks;                // first b with br[b].row >= row_end
+    while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
+    const int nb = lo - bfirst;
+    if (nb <= 0) return 0;
+    if ((size_t)slot_base + (size_t)nb > slots) return LISHIP_ERR_ARG;
+    double *partial = static_cast<double *>(work) + slot_base;
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream)};
+    const int ps = (int)slots;
+    if (p->products) {
+        if (want_sumsq) launch_products_dot<1, 2>(a, p->batch, w, partial, ps); else launch_products_dot<1, 1>(a, p->batch, w, partial, ps);
+    } else if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial, ps);
+    else                   launch_rowgather_dot<0, 1>(a, p->unroll, w, partial, ps);
+    LAUNCH_CHECK();
+    *slots_used = nb;
+    return 0;
+}
+
+extern "C" int liship_spmv_csr_dot_finish_f64(int slots_used, int want_sumsq, double *result, void *work, void *stream)
+{
+    if (!result || !work || slots_used < 0) return LISHIP_ERR_ARG;
+    const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
+    if ((size_t)slots_used > slots) return LISHIP_ERR_ARG;
+    if (slots_used == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, as_stream(stream))); return 0; }
+    double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
+    return liship_internal_fold(slots_used, want_sumsq ? 2 : 1, (int)slots, partial, spare, result, stream);
 }

@@ -386,6 +386,44 @@ def test_spmv_csr_fused_dot(lib, name, want_sumsq):
         assert abs(got[0][1] - np.dot(yref, yref)) <= 1e-13 * np.dot(yref, yref) + 1e-300
 
 
+@pytest.mark.parametrize("name", ["p3d_64", "rand_5000", "rand_long_rows", "rand_wide_77", "mostly_empty"])
+@pytest.mark.parametrize("want_sumsq", [0, 1])
+@pytest.mark.parametrize("cuts", [(0.0, 1.0), (0.1, 0.9), (0.0, 0.6), (0.37, 1.0), (0.5, 0.5)])
+def test_spmv_csr_fused_dot_in_parts(lib, name, want_sumsq, cuts):
+    """interior rows, then the two boundary ranges, one fold: y bit-identical to the plain product, the sums as the
+    one-launch fused form to 1e-13 (another grouping of the same terms), repeatable bit for bit"""
+    ptr, idx, val = CSR_CASES[name]()
+    n = len(ptr) - 1
+    ncols = max(n, int(idx.max()) + 1 if len(idx) else 1)
+    rng = np.random.default_rng(12)
+    x, w = rng.uniform(-1, 1, ncols), rng.uniform(-1, 1, n)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64)
+    dx, dw = DA.from_host(x, np.float64), DA.from_host(w, np.float64)
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    res = DA.from_host(np.full(2, np.nan), np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    lo, hi = int(cuts[0] * n), int(cuts[1] * n)
+    got = []
+    for _ in range(2):
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        total, used = 0, C.c_int()
+        for a, b in ((lo, hi), (0, lo), (hi, n)):
+            check(lib.liship_spmv_csr_rows_dot_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, want_sumsq,
+                                                   work.ptr, total, C.byref(used), None))
+            total += used.value
+        check(lib.liship_spmv_csr_dot_finish_f64(total, want_sumsq, res.ptr, work.ptr, None))
+        got.append(res.to_host())
+        assert np.array_equal(dy.to_host(), yref)
+    check(lib.liship_csr_plan_destroy(plan))
+    assert np.array_equal(got[0][:1 + want_sumsq], got[1][:1 + want_sumsq])
+    scale = np.abs(w * yref).sum() + 1e-300
+    assert abs(got[0][0] - np.dot(w, yref)) <= 1e-13 * scale
+    if want_sumsq:
+        assert abs(got[0][1] - np.dot(yref, yref)) <= 1e-13 * np.dot(yref, yref) + 1e-300
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 1000, 4097, (1 << 20) + 3])
 def test_gmres_device_chained_kernels(lib, n):
     """The GMRES building blocks that keep their scalars in HBM give the bits of the reference's call sequence

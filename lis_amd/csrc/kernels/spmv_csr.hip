@@ -187,6 +187,13 @@ struct RowDots {
         if (DOT >= 1) c0 += w[r] * yr;
         if (DOT >= 2) c1 += yr * yr;
     }
+    // the same with w[r] already in a register (loaded before the row's gathers, so that its latency hides behind them)
+    __device__ __forceinline__ double fetch(int r) const { return DOT >= 1 ? w[r] : 0.0; }
+    __device__ __forceinline__ void add_loaded(double wr, double yr)
+    {
+        if (DOT >= 1) c0 += wr * yr;
+        if (DOT >= 2) c1 += yr * yr;
+    }
 };
 
 // one whole row block of any shape (many empty rows, rows longer than the LDS stage).
@@ -362,6 +369,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
         if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
         const int len = e - s;
         const int off = s - ka;
+        const double wr = dots.fetch(r);
         double acc = 0.0;
         for (int j0 = 0; j0 < len; j0 += U) {
             int cc[U]; double vv[U], xx[U];
@@ -380,7 +388,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
             }
         }
         store_stream(y + r, acc);
-        dots.add(r, acc);
+        dots.add_loaded(wr, acc);
     }
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }

@@ -137,41 +137,55 @@ void spmv_dia_kernel(int n, int ncols, int nnd, const int *__restrict__ off,
     publish<DOT>(c0, c1, partial, gridDim.x);
 }
 
-// JAD: lane owns one slot of the length-sorted order; UNROLL jagged diagonals in flight.  Diagonals only get
-// shorter, so a lane past the end of diagonal j is past the end of all later ones (masked, not branched).
-template <int UNROLL>
+// JAD: a lane owns TWO adjacent slots of the length-sorted order (their entries are adjacent in every jagged
+// diagonal: one 16 B value load + one 8 B index load when the diagonal starts on an even element), UNROLL jagged
+// diagonals in flight.  Diagonals only get shorter, so a slot past the end of diagonal j is past the end of all
+// later ones (masked, not branched).  y leaves through nt stores (perm is the identity on runs of equal-length rows).
+template <int UNROLL, bool VEC>
 __global__ __launch_bounds__(BLOCK)
 void spmv_jad_kernel(int n, int maxnzr, const int *__restrict__ perm, const int *__restrict__ ptr,
                      const int *__restrict__ idx, const double *__restrict__ val,
                      const double *__restrict__ x, double *__restrict__ y)
 {
-    const int s = blockIdx.x * BLOCK + threadIdx.x;   // slot in the length-sorted order
+    const int s = (blockIdx.x * BLOCK + threadIdx.x) * 2;   // first of the lane's two slots
     if (s >= n) return;
-    const int row = perm[s];
-    double acc = 0.0;
+    const bool two = s + 1 < n;
+    const int row0 = perm[s], row1 = two ? perm[s + 1] : 0;
+    double acc0 = 0.0, acc1 = 0.0;
     for (int j0 = 0; j0 < maxnzr; j0 += UNROLL) {
-        double v[UNROLL], xv[UNROLL];
-        int c[UNROLL];
-        bool ok[UNROLL];
+        double v0[UNROLL], v1[UNROLL], x0[UNROLL], x1[UNROLL];
+        int c0[UNROLL], c1[UNROLL];
+        bool ok0[UNROLL], ok1[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const int j = min(j0 + u, maxnzr - 1);
             const int b = ptr[j], len = ptr[j + 1] - b;   // wave-uniform
-            ok[u] = (j0 + u < maxnzr) && s < len;
-            const int k = ok[u] ? b + s : 0;
-            v[u] = load_stream(val + k);
-            c[u] = load_stream(idx + k);
+            const bool live = j0 + u < maxnzr;
+            ok0[u] = live && s < len;
+            ok1[u] = live && two && s + 1 < len;
+            const int k = ok0[u] ? b + s : 0;
+            if (VEC && ok1[u] && (k & 1) == 0) {                // both slots, 16 B aligned (k even <=> b even: wave-uniform but for the tail)
+                const v2f64 vv = load_stream(reinterpret_cast<const v2f64 *>(val + k));
+                const v2i32 cc = load_stream(reinterpret_cast<const v2i32 *>(idx + k));
+                v0[u] = vv.x; v1[u] = vv.y; c0[u] = cc.x; c1[u] = cc.y;
+            } else {
+                v0[u] = load_stream(val + k); c0[u] = load_stream(idx + k);
+                const int k1 = ok1[u] ? k + 1 : k;
+                v1[u] = load_stream(val + k1); c1[u] = load_stream(idx + k1);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) xv[u] = x[c[u]];
+        for (int u = 0; u < UNROLL; u++) { x0[u] = x[c0[u]]; x1[u] = x[c1[u]]; }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            const double t = v[u] * xv[u];
-            acc += ok[u] ? t : 0.0;
+            const double t0 = v0[u] * x0[u], t1 = v1[u] * x1[u];
+            acc0 += ok0[u] ? t0 : 0.0;                    // +0.0 terms leave the sum bit-unchanged
+            acc1 += ok1[u] ? t1 : 0.0;
         }
-        if (!ok[UNROLL - 1]) break;
+        if (!ok0[UNROLL - 1]) break;
     }
-    y[row] = acc;
+    store_stream(y + row0, acc0);
+    if (two) store_stream(y + row1, acc1);
 }
 
 // one lane per scalar row: blocks of the block row in stored order, block columns ascending --
@@ -261,6 +275,67 @@ void spmv_bsr_tile_kernel(int nr, const int *__restrict__ bptr, const int *__res
     if (rowlane) store_stream(y + (size_t)mybr * BNR + myi, acc);
 }
 
+// BSR 2x2 (Lis's default block size): phase 1 with a lane per BLOCK -- two 16 B value loads, ONE 16 B gather of
+// the x pair, the four rounded products to LDS as two 16 B stores; phase 2 as above (lane = scalar row, products
+// added block by block, column by column: lis_matvec_bsr.c:120-148).
+__global__ __launch_bounds__(BLOCK)
+void spmv_bsr22_kernel(int nr, const int *__restrict__ bptr, const int *__restrict__ bidx,
+                       const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+{
+    constexpr int BRW = BLOCK / 2;                   // block rows per workgroup
+    constexpr int CHUNK = 1024;                      // blocks per LDS pass (32 KB of products)
+    __shared__ __attribute__((aligned(16))) double prod[CHUNK * 4];
+    const int br0 = blockIdx.x * BRW;
+    const int br1 = min(br0 + BRW, nr);
+    const int bb = bptr[br0], be = bptr[br1];
+    const int L = threadIdx.x;
+    const int mybr = br0 + (L >> 1), myi = L & 1;
+    const bool rowlane = mybr < br1;
+    int rs = 0, re = 0;
+    if (rowlane) { rs = bptr[mybr]; re = bptr[mybr + 1]; }
+    double acc = 0.0;
+    for (int cb = bb; cb < be; cb += CHUNK) {
+        const int nblk = min(CHUNK, be - cb);
+        constexpr int UB = 4;                        // blocks in flight per lane
+        for (int t0 = L; t0 < nblk; t0 += UB * BLOCK) {
+            v2f64 a0[UB], a1[UB], xv[UB];
+            int c[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int b = cb + min(t0 + u * BLOCK, nblk - 1);       // clamped: the tail repeats the last block
+                const v2f64 *src = reinterpret_cast<const v2f64 *>(val + (size_t)b * 4);
+                a0[u] = load_stream(src);            // column 0: a00 a10
+                a1[u] = load_stream(src + 1);        // column 1: a01 a11
+                c[u] = load_stream(bidx + b);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; u++) xv[u] = *reinterpret_cast<const v2f64 *>(x + (size_t)c[u] * 2);
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int t = t0 + u * BLOCK;
+                if (t < nblk) {
+                    v2f64 p0, p1;
+                    p0.x = a0[u].x * xv[u].x; p0.y = a0[u].y * xv[u].x;
+                    p1.x = a1[u].x * xv[u].y; p1.y = a1[u].y * xv[u].y;
+                    reinterpret_cast<v2f64 *>(prod)[2 * t] = p0;
+                    reinterpret_cast<v2f64 *>(prod)[2 * t + 1] = p1;
+                }
+            }
+        }
+        __syncthreads();
+        if (rowlane) {
+            const int s = max(rs, cb), e = min(re, cb + nblk);
+            for (int b = s; b < e; b++) {
+                const double *pp = prod + (size_t)(b - cb) * 4 + myi;
+                acc += pp[0];
+                acc += pp[2];
+            }
+        }
+        __syncthreads();
+    }
+    if (rowlane) store_stream(y + (size_t)mybr * 2 + myi, acc);
+}
+
 inline int grid_for(int n) { return (n + BLOCK - 1) / BLOCK; }
 
 } // namespace
@@ -331,7 +406,10 @@ extern "C" int liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int
     if (n < 0 || maxnzr < 0) return LISHIP_ERR_ARG;
     if (n == 0) return 0;
     if (maxnzr == 0) { HIP_TRY(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n, as_stream(stream))); return 0; }
-    spmv_jad_kernel<8><<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, perm, ptr, idx, val, x, y);
+    if (aligned16(val) && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0)
+        spmv_jad_kernel<8, true><<<grid_for((n + 1) / 2), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, perm, ptr, idx, val, x, y);
+    else
+        spmv_jad_kernel<8, false><<<grid_for((n + 1) / 2), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, perm, ptr, idx, val, x, y);
     LAUNCH_CHECK();
     return 0;
 }
@@ -348,7 +426,10 @@ extern "C" int liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, co
         const int brw = BLOCK / bnr, grid = (nr + brw - 1) / brw;
         switch (bnr) {
         case 1: spmv_bsr_tile_kernel<1, 1><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
-        case 2: spmv_bsr_tile_kernel<2, 2><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
+        case 2:
+            if (aligned16(x)) spmv_bsr22_kernel<<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
+            else              spmv_bsr_tile_kernel<2, 2><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
+            break;
         case 3: spmv_bsr_tile_kernel<3, 3><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
         default: spmv_bsr_tile_kernel<4, 4><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
         }

@@ -336,6 +336,75 @@ void spmv_bsr22_kernel(int nr, const int *__restrict__ bptr, const int *__restri
     if (rowlane) store_stream(y + (size_t)mybr * 2 + myi, acc);
 }
 
+// BSR 2x2 the way the CSR row-gather kernel works: one wavefront per workgroup owns 64 block rows, stages the raw
+// value (32 B) and index (4 B) slices of their blocks in LDS with direct global->LDS loads (every instruction a
+// fully coalesced 1 KiB), then a lane walks ITS block row in stored order: per block two 16 B LDS reads, one 16 B
+// gather of the x pair and the four multiply-adds of lis_matvec_bsr.c:120-148 in their order (t0 += a00 x0;
+// t1 += a10 x0; t0 += a01 x1; t1 += a11 x1).  Both rows of a block row live in one lane, y leaves as 16 B nt stores.
+// Block rows longer than the stage are walked in passes with the running sums kept in registers.
+constexpr int BSR_LANES = 64, BSR_CAP = 512;
+template <int U>
+__global__ __launch_bounds__(BSR_LANES)
+void spmv_bsr22_rows_kernel(int nr, const int *__restrict__ bptr, const int *__restrict__ bidx,
+                            const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+{
+    __shared__ __attribute__((aligned(16))) double valL[(BSR_CAP + 4) * 4 + 2 * WAVE];
+    __shared__ __attribute__((aligned(16))) int idxL[BSR_CAP + 4 + 4 * WAVE];
+    const int lane = threadIdx.x;
+    const int br0 = blockIdx.x * BSR_LANES, br1 = min(br0 + BSR_LANES, nr);
+    const int bb = bptr[br0], be = bptr[br1], nblk_total = bptr[nr];
+    const int mybr = br0 + lane;
+    const bool live = mybr < br1;
+    int rs = 0, re = 0;
+    if (live) { rs = bptr[mybr]; re = bptr[mybr + 1]; }
+    double t0 = 0.0, t1 = 0.0;
+    for (int cb = bb; cb < be; cb += BSR_CAP) {
+        const int ka = cb & ~3;                          // 16 B aligned start of the index slice
+        const int cend = min(cb + BSR_CAP, be);
+        const int cnt = cend - ka;                       // staged blocks [ka, cend)
+        const int np = 2 * cnt;                          // 16 B pieces of the value slice
+        for (int p0 = 0; p0 < np; p0 += WAVE) {
+            const int p = min(p0 + lane, np - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + (size_t)ka * 4) + p),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+        }
+        const int nq = (cnt + 3) >> 2;
+        if (ka + 4 * nq <= nblk_total) {
+            for (int q0 = 0; q0 < nq; q0 += WAVE) {
+                const int q = min(q0 + lane, nq - 1);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v4i32 *>(bidx + ka) + q),
+                    (__attribute__((address_space(3))) void *)(reinterpret_cast<v4i32 *>(idxL) + q0), 16, 0, 2);
+            }
+        } else {                                         // the last few indices of the array: no 16 B reads past its end
+            for (int i = lane; i < cnt; i += WAVE) idxL[i] = bidx[ka + i];
+        }
+        __syncthreads();
+        const int s = max(rs, cb), e = min(re, cend);
+        for (int b0 = s; b0 < e; b0 += U) {
+            v2f64 a0[U], a1[U], xv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int o = min(b0 + u, e - 1) - ka;    // clamped: repeats the row's last block
+                a0[u] = reinterpret_cast<const v2f64 *>(valL)[2 * o];
+                a1[u] = reinterpret_cast<const v2f64 *>(valL)[2 * o + 1];
+                xv[u] = *reinterpret_cast<const v2f64 *>(x + (size_t)idxL[o] * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool ok = b0 + u < e;               // +0.0 terms leave the sums bit-unchanged
+                const double p00 = a0[u].x * xv[u].x, p10 = a0[u].y * xv[u].x;
+                const double p01 = a1[u].x * xv[u].y, p11 = a1[u].y * xv[u].y;
+                t0 += ok ? p00 : 0.0; t1 += ok ? p10 : 0.0;
+                t0 += ok ? p01 : 0.0; t1 += ok ? p11 : 0.0;
+            }
+        }
+        __syncthreads();
+    }
+    if (live) { v2f64 out; out.x = t0; out.y = t1; store_stream(reinterpret_cast<v2f64 *>(y + (size_t)mybr * 2), out); }
+}
+
 inline int grid_for(int n) { return (n + BLOCK - 1) / BLOCK; }
 
 } // namespace
@@ -427,7 +496,9 @@ extern "C" int liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, co
         switch (bnr) {
         case 1: spmv_bsr_tile_kernel<1, 1><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
         case 2:
-            if (aligned16(x)) spmv_bsr22_kernel<<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
+            if (aligned16(x) && aligned16(y) && aligned16(bidx))
+                spmv_bsr22_rows_kernel<4><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
+            else if (aligned16(x)) spmv_bsr22_kernel<<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             else              spmv_bsr_tile_kernel<2, 2><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             break;
         case 3: spmv_bsr_tile_kernel<3, 3><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;

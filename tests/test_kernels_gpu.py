@@ -174,6 +174,39 @@ def test_formats_vs_oracle(lib, fmt, case):
     assert np.array_equal(dy.to_host(n), ref)
 
 
+BSR22_CASES = {
+    "stencil": lambda: orc.poisson3d(23, 18, 14),
+    "one_block_row": lambda: orc.random_csr(2, 2, seed=7, empty_rows=False),
+    "63_rows": lambda: orc.random_csr(63, 6, seed=8),
+    "129_rows_odd": lambda: orc.random_csr(129, 9, seed=9),                       # odd n: the last block row is padded
+    "long_rows": lambda: orc.random_csr(9000, 3, seed=2, long_row=7001),         # a block row of > 512 blocks: several LDS passes
+    "mostly_empty": lambda: orc.random_csr(20000, 0.05, seed=4),
+    "wide": lambda: orc.random_csr(4000, 77, seed=3, ncols=4000, empty_rows=False),
+}
+
+
+@pytest.mark.parametrize("name", list(BSR22_CASES))
+@pytest.mark.parametrize("bs", [1, 2, 3, 4])
+def test_spmv_bsr_square_blocks(lib, name, bs):
+    """square blocks 1..4 (2x2 takes the wavefront-per-64-block-rows kernel with LDS-DMA staging): bit-identical to
+    lis_matvec_bsr's order on ragged, empty, very long and tail block rows"""
+    ptr, idx, val = BSR22_CASES[name]()
+    n = len(ptr) - 1
+    ncols = max(n, int(idx.max()) + 1 if len(idx) else 1)
+    pad = (-ncols) % bs
+    x = np.random.default_rng(21).uniform(-1, 1, ncols + pad + bs)
+    nr, bptr, bidx, bv = orc.csr2bsr(ptr, idx, val, bs, bs)
+    nc = int(bidx.max()) + 1 if len(bidx) else 1
+    xx = np.zeros(max(len(x), nc * bs))
+    xx[:len(x)] = x
+    a, b, c = DA.from_host(bptr), DA.from_host(bidx if len(bidx) else np.zeros(1, np.int32)), DA.from_host(bv if len(bv) else np.zeros(1))
+    dx, dy = DA.from_host(xx), DA.from_host(np.full(nr * bs, np.nan))
+    for _ in range(2):
+        check(lib.liship_spmv_bsr_f64(nr, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
+        ref = orc.spmv_bsr(n, nr, bs, bs, bptr, bidx, bv, xx)
+        assert np.array_equal(dy.to_host(n), ref)
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 1000, 4097, 1 << 20, (1 << 20) + 3])
 def test_elementwise_bit_exact(lib, n):
     rng = np.random.default_rng(n)

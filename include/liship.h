@@ -114,6 +114,10 @@ int  liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int *ptr, con
                          const double *value, const double *x, double *y, void *stream);
 int  liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, const int *bindex,
                          const double *value, const double *x, double *y, void *stream);
+/* the same with the number of stored blocks given (bnnz < 0: unknown), which lets the library choose between a lane
+ * per block row (short block rows) and a lane per block (long ones) */
+int  liship_spmv_bsr_nnz_f64(int nr, int bnnz, int bnr, int bnc, const int *bptr, const int *bindex,
+                             const double *value, const double *x, double *y, void *stream);
 
 /* ------------------------------------------------------------------ vector kernels
  * element-wise: src/vector/lis_vector_opv.c (axpy :174, xpay :214, axpyz :253, scale :285, pmul :325,

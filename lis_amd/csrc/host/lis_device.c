@@ -360,7 +360,7 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 		HIPCHK(liship_spmv_jad_f64(d->n, d->maxnzr, d->row, d->ptr, d->index, d->value, dx, dy, lisg.stream));
 		break;
 	case LIS_MATRIX_BSR:
-		HIPCHK(liship_spmv_bsr_f64(d->nr, d->bnr, d->bnc, d->bptr, d->bindex, d->value, dx, dy, lisg.stream));
+		HIPCHK(liship_spmv_bsr_nnz_f64(d->nr, A->bnnz, d->bnr, d->bnc, d->bptr, d->bindex, d->value, dx, dy, lisg.stream));
 		break;
 	default:
 		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "storage format %D is not served by liblis_amd\n", d->type);

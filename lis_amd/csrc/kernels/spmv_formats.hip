@@ -336,20 +336,22 @@ void spmv_bsr22_kernel(int nr, const int *__restrict__ bptr, const int *__restri
     if (rowlane) store_stream(y + (size_t)mybr * 2 + myi, acc);
 }
 
-// BSR 2x2 the way the CSR row-gather kernel works: one wavefront per workgroup owns 64 block rows, stages the raw
-// value (32 B) and index (4 B) slices of their blocks in LDS with direct global->LDS loads (every instruction a
-// fully coalesced 1 KiB), then a lane walks ITS block row in stored order: per block two 16 B LDS reads, one 16 B
-// gather of the x pair and the four multiply-adds of lis_matvec_bsr.c:120-148 in their order (t0 += a00 x0;
-// t1 += a10 x0; t0 += a01 x1; t1 += a11 x1).  Both rows of a block row live in one lane, y leaves as 16 B nt stores.
+// Square BSR blocks (2x2 is Lis's default, 3x3 / 4x4 the usual FEM choices) the way the CSR row-gather kernel works:
+// one wavefront per workgroup owns 64 block rows, stages the raw value (8 BS^2 B) and index (4 B) slices of their
+// blocks in LDS with direct global->LDS loads (every instruction a fully coalesced 1 KiB), then a lane walks ITS
+// block row in stored order: per block BS^2 values from LDS, ONE gather of the BS x values and the multiply-adds of
+// lis_matvec_bsr.c:120-148 in their order (column by column inside a block: t_i += a_ij x_j for i = 0..BS-1, then
+// the next j).  All BS rows of a block row live in one lane, y leaves as 16 B nt stores where BS is even.
 // Block rows longer than the stage are walked in passes with the running sums kept in registers.
-constexpr int BSR_LANES = 64, BSR_CAP = 512;
-template <int U>
+constexpr int BSR_LANES = 64;
+template <int BS, int CAP, int U>
 __global__ __launch_bounds__(BSR_LANES)
-void spmv_bsr22_rows_kernel(int nr, const int *__restrict__ bptr, const int *__restrict__ bidx,
-                            const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+void spmv_bsr_rows_kernel(int nr, const int *__restrict__ bptr, const int *__restrict__ bidx,
+                          const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
 {
-    __shared__ __attribute__((aligned(16))) double valL[(BSR_CAP + 4) * 4 + 2 * WAVE];
-    __shared__ __attribute__((aligned(16))) int idxL[BSR_CAP + 4 + 4 * WAVE];
+    constexpr int BB = BS * BS;
+    __shared__ __attribute__((aligned(16))) double valL[(CAP + 4) * BB + 2 * WAVE];
+    __shared__ __attribute__((aligned(16))) int idxL[CAP + 4 + 4 * WAVE];
     const int lane = threadIdx.x;
     const int br0 = blockIdx.x * BSR_LANES, br1 = min(br0 + BSR_LANES, nr);
     const int bb = bptr[br0], be = bptr[br1], nblk_total = bptr[nr];
@@ -357,18 +359,24 @@ void spmv_bsr22_rows_kernel(int nr, const int *__restrict__ bptr, const int *__r
     const bool live = mybr < br1;
     int rs = 0, re = 0;
     if (live) { rs = bptr[mybr]; re = bptr[mybr + 1]; }
-    double t0 = 0.0, t1 = 0.0;
-    for (int cb = bb; cb < be; cb += BSR_CAP) {
-        const int ka = cb & ~3;                          // 16 B aligned start of the index slice
-        const int cend = min(cb + BSR_CAP, be);
+    double t[BS];
+#pragma unroll
+    for (int i = 0; i < BS; i++) t[i] = 0.0;
+    for (int cb = bb; cb < be; cb += CAP) {
+        const int ka = cb & ~3;                          // 16 B aligned start of both slices (4 | ka: 32 BS^2 B and 16 B)
+        const int cend = min(cb + CAP, be);
         const int cnt = cend - ka;                       // staged blocks [ka, cend)
-        const int np = 2 * cnt;                          // 16 B pieces of the value slice
-        for (int p0 = 0; p0 < np; p0 += WAVE) {
-            const int p = min(p0 + lane, np - 1);
+        const int np = (cnt * BB + 1) >> 1;              // 16 B pieces of the value slice (ka * BB is even)
+        // odd BS: the last piece of the array's last block would read 8 B past its end -- that value goes alone
+        const bool tail = (long long)ka * BB + 2LL * np > (long long)nblk_total * BB;
+        const int npd = tail ? (cnt * BB) >> 1 : np;
+        for (int p0 = 0; p0 < npd; p0 += WAVE) {
+            const int p = min(p0 + lane, npd - 1);
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + (size_t)ka * 4) + p),
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + (size_t)ka * BB) + p),
                 (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
         }
+        if (tail && lane == 0) valL[cnt * BB - 1] = val[(size_t)(ka + cnt) * BB - 1];
         const int nq = (cnt + 3) >> 2;
         if (ka + 4 * nq <= nblk_total) {
             for (int q0 = 0; q0 < nq; q0 += WAVE) {
@@ -383,26 +391,56 @@ void spmv_bsr22_rows_kernel(int nr, const int *__restrict__ bptr, const int *__r
         __syncthreads();
         const int s = max(rs, cb), e = min(re, cend);
         for (int b0 = s; b0 < e; b0 += U) {
-            v2f64 a0[U], a1[U], xv[U];
+            double a[U][BB], xv[U][BS];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int o = min(b0 + u, e - 1) - ka;    // clamped: repeats the row's last block
-                a0[u] = reinterpret_cast<const v2f64 *>(valL)[2 * o];
-                a1[u] = reinterpret_cast<const v2f64 *>(valL)[2 * o + 1];
-                xv[u] = *reinterpret_cast<const v2f64 *>(x + (size_t)idxL[o] * 2);
+                if (BB % 2 == 0) {
+#pragma unroll
+                    for (int q = 0; q < BB / 2; q++) {
+                        const v2f64 vv = reinterpret_cast<const v2f64 *>(valL)[(o * BB) / 2 + q];
+                        a[u][2 * q] = vv.x; a[u][2 * q + 1 < BB ? 2 * q + 1 : 2 * q] = vv.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < BB; q++) a[u][q] = valL[o * BB + q];
+                }
+                const double *xp = x + (size_t)idxL[o] * BS;
+                if (BS % 2 == 0) {
+#pragma unroll
+                    for (int q = 0; q < BS / 2; q++) {
+                        const v2f64 vv = reinterpret_cast<const v2f64 *>(xp)[q];
+                        xv[u][2 * q] = vv.x; xv[u][2 * q + 1 < BS ? 2 * q + 1 : 2 * q] = vv.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < BS; q++) xv[u][q] = xp[q];
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const bool ok = b0 + u < e;               // +0.0 terms leave the sums bit-unchanged
-                const double p00 = a0[u].x * xv[u].x, p10 = a0[u].y * xv[u].x;
-                const double p01 = a1[u].x * xv[u].y, p11 = a1[u].y * xv[u].y;
-                t0 += ok ? p00 : 0.0; t1 += ok ? p10 : 0.0;
-                t0 += ok ? p01 : 0.0; t1 += ok ? p11 : 0.0;
+#pragma unroll
+                for (int j = 0; j < BS; j++)
+#pragma unroll
+                    for (int i = 0; i < BS; i++) {
+                        const double pr = a[u][i + j * BS] * xv[u][j];
+                        t[i] += ok ? pr : 0.0;
+                    }
             }
         }
         __syncthreads();
     }
-    if (live) { v2f64 out; out.x = t0; out.y = t1; store_stream(reinterpret_cast<v2f64 *>(y + (size_t)mybr * 2), out); }
+    if (live) {
+        double *yp = y + (size_t)mybr * BS;
+        if (BS % 2 == 0) {
+#pragma unroll
+            for (int q = 0; q < BS / 2; q++) { v2f64 out; out.x = t[2 * q]; out.y = t[2 * q + 1 < BS ? 2 * q + 1 : 2 * q]; store_stream(reinterpret_cast<v2f64 *>(yp) + q, out); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BS; i++) store_stream(yp + i, t[i]);
+        }
+    }
 }
 
 inline int grid_for(int n) { return (n + BLOCK - 1) / BLOCK; }
@@ -485,24 +523,39 @@ extern "C" int liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int
 
 extern "C" int liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, const int *bidx,
                                    const double *val, const double *x, double *y, void *stream)
+{ return liship_spmv_bsr_nnz_f64(nr, -1, bnr, bnc, bptr, bidx, val, x, y, stream); }
+
+// the same with the number of stored blocks known (the host layer knows it): block rows that are short on average
+// take the lane-per-block-row kernel, long ones keep the lane-per-block(-column) kernels (as CSR's two kernels)
+extern "C" int liship_spmv_bsr_nnz_f64(int nr, int bnnz, int bnr, int bnc, const int *bptr, const int *bidx,
+                                       const double *val, const double *x, double *y, void *stream)
 {
     if (nr < 0 || bnr < 1 || bnc < 1) return LISHIP_ERR_ARG;
     if (nr == 0) return 0;
     const long long rows = (long long)nr * bnr;
     if (rows > 0x7fffffffLL) return LISHIP_ERR_ARG;
     hipStream_t st = as_stream(stream);
+    const double mean = bnnz >= 0 ? (double)bnnz / nr : 0.0;            // stored blocks per block row
     if (bnr == bnc && bnr <= 4 && aligned16(val)) {
         const int brw = BLOCK / bnr, grid = (nr + brw - 1) / brw;
         switch (bnr) {
         case 1: spmv_bsr_tile_kernel<1, 1><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
         case 2:
-            if (aligned16(x) && aligned16(y) && aligned16(bidx))
-                spmv_bsr22_rows_kernel<4><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
+            if (aligned16(x) && aligned16(y) && aligned16(bidx) && (bnnz < 0 || mean <= 12.0))
+                spmv_bsr_rows_kernel<2, 512, 4><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
             else if (aligned16(x)) spmv_bsr22_kernel<<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             else              spmv_bsr_tile_kernel<2, 2><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             break;
-        case 3: spmv_bsr_tile_kernel<3, 3><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
-        default: spmv_bsr_tile_kernel<4, 4><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
+        case 3:
+            if (aligned16(bidx) && bnnz >= 0 && mean <= 16.0) spmv_bsr_rows_kernel<3, 256, 3><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
+            else                 spmv_bsr_tile_kernel<3, 3><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
+            break;
+        default:
+            if (aligned16(x) && aligned16(y) && aligned16(bidx) && bnnz >= 0 && mean <= 12.0)
+                spmv_bsr_rows_kernel<4, 160, 2><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
+            else
+                spmv_bsr_tile_kernel<4, 4><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
+            break;
         }
     } else
         spmv_bsr_kernel<<<grid_for((int)rows), BLOCK, 0, st>>>((int)rows, bnr, bnc, bptr, bidx, val, x, y);

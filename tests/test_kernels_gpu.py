@@ -201,10 +201,13 @@ def test_spmv_bsr_square_blocks(lib, name, bs):
     xx[:len(x)] = x
     a, b, c = DA.from_host(bptr), DA.from_host(bidx if len(bidx) else np.zeros(1, np.int32)), DA.from_host(bv if len(bv) else np.zeros(1))
     dx, dy = DA.from_host(xx), DA.from_host(np.full(nr * bs, np.nan))
-    for _ in range(2):
-        check(lib.liship_spmv_bsr_f64(nr, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
-        ref = orc.spmv_bsr(n, nr, bs, bs, bptr, bidx, bv, xx)
-        assert np.array_equal(dy.to_host(n), ref)
+    ref = orc.spmv_bsr(n, nr, bs, bs, bptr, bidx, bv, xx)
+    for known in (-1, len(bidx), 0):                      # 0: "short block rows" claimed for any matrix -> the lane-per-block-row kernel
+        dy = DA.from_host(np.full(nr * bs, np.nan))
+        check(lib.liship_spmv_bsr_nnz_f64(nr, known, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host(n), ref), known
+    check(lib.liship_spmv_bsr_f64(nr, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
+    assert np.array_equal(dy.to_host(n), ref)
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 1000, 4097, 1 << 20, (1 << 20) + 3])

@@ -211,7 +211,8 @@ static void find_inner_rows(LIS_MATRIX A, int *b, int *e)
 {
 	const int n = A->n;
 	int best_b = 0, best_e = 0, run_b = 0;
-	if (A->matrix_type != LIS_MATRIX_CSR || !A->ptr || A->np == n) { *b = 0; *e = n; return; }
+	if (A->np == n) { *b = 0; *e = n; return; }                       /* no ghost columns at all */
+	if (A->matrix_type != LIS_MATRIX_CSR || !A->ptr) { *b = 0; *e = 0; return; }   /* other host layouts: no overlap, exchange first */
 	for (int r = 0; r <= n; r++) {
 		int ghost = 1;
 		if (r < n) {
@@ -251,6 +252,41 @@ static LIS_INT upload_csc_as_csr(LIS_MATRIX A, lisd_mat *d)
 	return err;
 }
 
+/* A JAD matrix is laid out in HBM row by row, in the ORIGINAL row order: row perm[s] gets the s-th entry of every
+ * jagged diagonal that is long enough, diagonal by diagonal -- the order in which lis_matvec_jad adds them to
+ * y[perm[s]] starting from 0 (lis_matvec_jad.c:57-75), so the CSR kernel forms the same sums bit for bit.  The
+ * jagged layout is what a vector CPU wants; on MI355X it costs a permuted y and maxnzr separate streams per lane
+ * (68 % of the roofline, spmv_jad_kernel, kept for the kernel-level API), the row layout runs at the CSR rate. */
+static LIS_INT upload_jad_as_csr(LIS_MATRIX A, lisd_mat *d)
+{
+	const int n = A->n, nnz = A->nnz, maxnzr = A->maxnzr;
+	int *cptr = (int *)calloc((size_t)n + 2, sizeof(int));
+	int *cidx = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+	double *cval = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+	int *fill = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+	if (!cptr || !cidx || !cval || !fill) { free(cptr); free(cidx); free(cval); free(fill); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "jad re-layout\n"); }
+	for (int j = 0; j < maxnzr; j++) {
+		const int len = A->ptr[j + 1] - A->ptr[j];
+		for (int s = 0; s < len; s++) cptr[A->row[s] + 1]++;
+	}
+	for (int r = 0; r < n; r++) cptr[r + 1] += cptr[r];
+	memcpy(fill, cptr, sizeof(int) * (size_t)n);
+	for (int j = 0; j < maxnzr; j++) {                /* diagonals ascending: each row receives its entries in summation order */
+		const int b = A->ptr[j], len = A->ptr[j + 1] - b;
+		for (int s = 0; s < len; s++) {
+			const int dst = fill[A->row[s]]++;
+			cidx[dst] = A->index[b + s]; cval[dst] = A->value[b + s];
+		}
+	}
+	free(fill);
+	LIS_INT err = up_i(&d->ptr, cptr, (size_t)n + 1);
+	if (!err) err = up_i(&d->index, cidx, (size_t)nnz);
+	if (!err) err = up_d(&d->value, cval, (size_t)nnz);
+	if (!err) { int rc = liship_stream_synchronize(lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
+	free(cptr); free(cidx); free(cval);
+	return err;
+}
+
 LIS_INT lisd_mat_ready(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
@@ -284,11 +320,9 @@ LIS_INT lisd_mat_ready(LIS_MATRIX A)
 		LISCHK(up_d(&d->value, A->value, n * (size_t)A->nnd));
 		break;
 	case LIS_MATRIX_JAD:
-		d->maxnzr = A->maxnzr;
-		LISCHK(up_i(&d->row, A->row, n));
-		LISCHK(up_i(&d->ptr, A->ptr, (size_t)A->maxnzr + 1));
-		LISCHK(up_i(&d->index, A->index, (size_t)A->nnz));
-		LISCHK(up_d(&d->value, A->value, (size_t)A->nnz));
+		LISCHK(upload_jad_as_csr(A, d));
+		d->type = LIS_MATRIX_CSR;
+		HIPCHK(liship_csr_plan_create(&d->plan, A->n, d->ptr, lisg.stream));
 		break;
 	case LIS_MATRIX_BSR:
 		d->nr = A->nr; d->nc = A->nc; d->bnr = A->bnr; d->bnc = A->bnc;

@@ -182,7 +182,10 @@ static LIS_INT csr2bsr(LIS_MATRIX A, LIS_MATRIX B)
 #undef BOFF
 	free(slot); free(seen);
 	err = lis_matrix_set_bsr(bnr, bnc, bnnz, bptr, bindex, value, B);
-	if (!err) B->pad_comm = pad;
+	if (!err) {                                                  /* ref lis_matrix_bsr.c:539-548 */
+		B->pad_comm = pad;
+		if (B->commtable) B->commtable->pad = pad;               /* the halo of a BSR matrix lands behind the front padding */
+	}
 	return finish(B, err);
 fail:
 	free(bptr); free(bindex); free(value); free(slot); free(seen);
@@ -295,6 +298,8 @@ LIS_INT lisi_convert_to_csr(LIS_MATRIX A, LIS_MATRIX B)
 	}
 	free(count);
 	if (err) return err;
+	B->pad = 0; B->pad_comm = 0;                                 /* ref lis_matrix_bsr.c:673-683: a CSR matrix has no padding, */
+	if (B->commtable) B->commtable->pad = 0;                     /* whatever the (duplicated) tables of the BSR source said    */
 	return finish(B, lis_matrix_set_csr(c.nnz, c.ptr, c.index, c.value, B));
 }
 

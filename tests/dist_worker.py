@@ -100,6 +100,21 @@ def main():
         yg = orc.spmv_csr(ptr, idx, val, xg)
         assert np.array_equal(orc.spmv_csr(got["ptr"], got["index"], got["value"], xl), yg[is_:ie]), name
 
+        # BSR of the local block: ghost columns start on a fresh block column (lis_matrix_bsr.c:425-428), i.e. they are
+        # shifted by pad = (bnc - n % bnc) % bnc, and the halo lands at x[n + pad ...) (commtable->pad)
+        for bs in (2, 3):
+            B = lisdrv.convert(lib, A, "bsr", bs, bs)
+            g = lisdrv.matrix_arrays(B)
+            pad = (bs - n % bs) % bs
+            assert g["pad"] == pad + ((bs - len(ghosts) % bs) % bs if len(ghosts) else 0), (name, bs, g["pad"], pad)   # front + back padding (:97-102)
+            xb = np.zeros(max(g["nc"] * bs, a.np + pad))
+            xb[:n] = xg[is_:ie]
+            xb[n + pad:n + pad + len(ghosts)] = xg[ghosts]
+            yb = orc.spmv_bsr(n, g["nr"], bs, bs, g["bptr"], g["bindex"], g["value"], xb)
+            sc = orc.spmv_csr(ptr, idx, np.abs(val), np.abs(xg))[is_:ie] + 1e-300
+            assert np.all(np.abs(yb - yg[is_:ie]) <= 1e-13 * sc), (name, bs)
+            lib.lis_matrix_destroy(B)
+
         # vectors of the partition: ranges, gather, infinity norm (host-side collectives)
         v = lisdrv.new_vector(lib, A, None)
         assert (v.contents.n, v.contents.np, v.contents.gn, v.contents.is_) == (n, a.np, gn, is_)
@@ -144,6 +159,21 @@ def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
     assert lib.lis_vector_get_values(vy, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
     scale = orc.spmvh_csr(ptr, idx, np.abs(val), np.abs(xg))[is_:ie] + 1e-300
     assert np.all(np.abs(y - yt[is_:ie]) <= 1e-13 * scale), name
+    # the same product from every other storage format of the local block (ghost columns included): same rows to
+    # 1e-13 relative (CSC / BSR / DIA add a row's terms in another order), every format behind the halo exchange
+    scale_y = orc.spmv_csr(ptr, idx, np.abs(val), np.abs(xg))[is_:ie] + 1e-300
+    for fmt in ("csc", "ell", "jad", "bsr", "dia"):
+        if fmt == "dia" and not name.startswith("poisson"):
+            continue
+        B = lisdrv.convert(lib, A, fmt)
+        vb2, vy2 = lisdrv.new_vector(lib, B, None), lisdrv.new_vector(lib, B, None)
+        assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(xg[is_:ie]).ctypes.data_as(capi.P_DBL), vb2) == 0
+        assert lib.lis_matvec(B, vb2, vy2) == 0, (name, fmt)
+        assert lib.lis_vector_get_values(vy2, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
+        assert np.all(np.abs(y - yg[is_:ie]) <= 1e-13 * scale_y), (name, fmt)
+        if fmt in ("ell", "jad"):
+            assert np.array_equal(y, yg[is_:ie]), (name, fmt)
+        lib.lis_vector_destroy(vb2); lib.lis_vector_destroy(vy2); lib.lis_matrix_destroy(B)
     if name.startswith("poisson"):
         bg = orc.spmv_csr(ptr, idx, val, np.ones(gn))
         vb, vs = lisdrv.new_vector(lib, A, None), lisdrv.new_vector(lib, A, None)

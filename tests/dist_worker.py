@@ -195,6 +195,24 @@ def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
                 assert abs(S.contents.iter - it) <= max(3, it // 10), (name, solver, S.contents.iter, it)
             assert np.allclose(xs, xo[is_:ie], rtol=0, atol=1e-9), (name, solver)
             lib.lis_solver_destroy(S)
+        # the solvers on the other storage formats of the same partition (BiCG also needs their A^T with the reverse halo)
+        xo, it, _, _, _ = orc.cg(ptr, idx, val, bg, precon="jacobi", maxiter=500)
+        for fmt in ("ell", "jad", "bsr", "csc", "dia"):
+            B = lisdrv.convert(lib, A, fmt)
+            for opts in ("-i cg -p jacobi", "-i bicg -p none", "-i bicgstab -p jacobi"):
+                vb2, vs2 = lisdrv.new_vector(lib, B, None), lisdrv.new_vector(lib, B, None)
+                assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(bg[is_:ie]).ctypes.data_as(capi.P_DBL), vb2) == 0
+                S = capi.PS()
+                lib.lis_solver_create(C.byref(S))
+                lib.lis_solver_set_option(f"{opts} -tol 1e-12 -maxiter 500".encode(), S)
+                assert lib.lis_solve(B, vb2, vs2, S) == 0, (name, fmt, opts)
+                xs = np.empty(n)
+                assert lib.lis_vector_get_values(vs2, is_, n, xs.ctypes.data_as(capi.P_DBL)) == 0
+                assert S.contents.retcode == 0 and S.contents.resid <= 1e-12, (name, fmt, opts, S.contents.retcode, S.contents.resid)
+                assert abs(S.contents.iter - it) <= max(3, it // 4) or "bicgstab" in opts, (name, fmt, opts, S.contents.iter, it)
+                assert np.allclose(xs, xo[is_:ie], rtol=0, atol=1e-9), (name, fmt, opts)
+                lib.lis_solver_destroy(S); lib.lis_vector_destroy(vb2); lib.lis_vector_destroy(vs2)
+            lib.lis_matrix_destroy(B)
 
 
 def device_poisson_generator(lib, rank, world):

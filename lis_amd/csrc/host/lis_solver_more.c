@@ -798,7 +798,8 @@ LIS_INT lisk_idrs(ctx_t *c)
 	double *m = NULL, *cf = NULL, *M = NULL, *MM = NULL, *hostP = NULL, *coef = NULL;
 	const double **vs = NULL;
 	if (sd < 1 || sd > 40) { err = LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_IDRS_RESTART(=%D) must be in [1,40]\n", (LIS_INT)sd); goto done; }
-	if (lisg.nprocs > 1) { err = LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "IDR(s) is single-process only in liblis_amd\n"); goto done; }
+	/* multi-rank jobs: like the reference under MPI (:578-584), every rank seeds the generator identically and fills
+	 * its own n local entries of each shadow vector */
 	m = (double *)calloc((size_t)sd, sizeof(double)); cf = (double *)calloc((size_t)sd, sizeof(double));
 	M = (double *)calloc((size_t)sd * sd, sizeof(double)); MM = (double *)calloc((size_t)sd * sd, sizeof(double));
 	coef = (double *)calloc((size_t)sd + 1, sizeof(double)); vs = (const double **)calloc((size_t)sd + 1, sizeof(double *));

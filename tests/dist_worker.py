@@ -213,6 +213,33 @@ def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
                 assert np.allclose(xs, xo[is_:ie], rtol=0, atol=1e-9), (name, fmt, opts)
                 lib.lis_solver_destroy(S); lib.lis_vector_destroy(vb2); lib.lis_vector_destroy(vs2)
             lib.lis_matrix_destroy(B)
+        # the other short-recurrence solvers share the collective vector kernels: spot-check a few per family
+        for opts in ("-i cgs", "-i cr", "-i gpbicg", "-i tfqmr", "-i bicgsafe", "-i orthomin -restart 10", "-i bicr", "-i crs",
+                     "-i bicrstab", "-i fgmres -restart 20", "-i minres", "-i idrs -irestart 2", "-i bicgstabl -ell 2", "-i jacobi"):
+            vs2 = lisdrv.new_vector(lib, A, None)
+            S = capi.PS()
+            lib.lis_solver_create(C.byref(S))
+            lib.lis_solver_set_option(f"{opts} -p none -tol 1e-11 -maxiter 3000".encode(), S)
+            assert lib.lis_solve(A, vb, vs2, S) == 0, (name, opts)
+            xs = np.empty(n)
+            assert lib.lis_vector_get_values(vs2, is_, n, xs.ctypes.data_as(capi.P_DBL)) == 0
+            assert S.contents.retcode == 0, (name, opts, S.contents.retcode, S.contents.iter, S.contents.resid)
+            assert np.allclose(xs, xo[is_:ie], rtol=0, atol=1e-7), (name, opts, np.abs(xs - xo[is_:ie]).max())
+            lib.lis_solver_destroy(S); lib.lis_vector_destroy(vs2)
+        # -scale in a distributed job: symm_diag needs the diagonal of the ghost columns (one halo of d)
+        for scale, opts in (("symm_diag", "-i cg -p none"), ("jacobi", "-i bicgstab -p none")):
+            B = lisdrv.convert(lib, A, "csr")                       # scaling rewrites the matrix: work on a copy
+            vb2, vs2 = lisdrv.new_vector(lib, B, None), lisdrv.new_vector(lib, B, None)
+            assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(bg[is_:ie]).ctypes.data_as(capi.P_DBL), vb2) == 0
+            S = capi.PS()
+            lib.lis_solver_create(C.byref(S))
+            lib.lis_solver_set_option(f"{opts} -scale {scale} -tol 1e-12 -maxiter 500".encode(), S)
+            assert lib.lis_solve(B, vb2, vs2, S) == 0, (name, scale)
+            xs = np.empty(n)
+            assert lib.lis_vector_get_values(vs2, is_, n, xs.ctypes.data_as(capi.P_DBL)) == 0
+            assert S.contents.retcode == 0, (name, scale, S.contents.retcode)
+            assert np.allclose(xs, xo[is_:ie], rtol=0, atol=1e-8), (name, scale, np.abs(xs - xo[is_:ie]).max())
+            lib.lis_solver_destroy(S); lib.lis_vector_destroy(vb2); lib.lis_vector_destroy(vs2); lib.lis_matrix_destroy(B)
 
 
 def device_poisson_generator(lib, rank, world):

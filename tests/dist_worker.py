@@ -132,11 +132,64 @@ def main():
         lib.lis_vector_destroy(v)
         lib.lis_matrix_destroy(A)
 
+    io_checks(lib, rank, world)
     if mode == "device":
         device_poisson_generator(lib, rank, world)
     dist.barrier()
     print(f"rank {rank}/{world} {mode} OK", flush=True)
     dist.destroy_process_group()
+
+
+def io_checks(lib, rank, world):
+    """Matrix Market in a multi-rank job (lis_input_mm.c: every rank reads the file and keeps its rows; the writers take
+    turns in rank order): local rows / vectors equal the slices of the single-process golden arrays, and the files the
+    ranks write together are the bytes one process writes."""
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    G = np.load(os.path.join(here, "golden", "mm_golden.npz"))
+    path = [None]
+    if rank == 0:
+        path[0] = tempfile.mkdtemp(prefix="lis_dist_io_")
+    dist.broadcast_object_list(path, src=0)
+    for fname in ("gen_general_b.mtx", "gen_symmetric_bx.mtx", "gen_binary_bx.mtx", "testmat.mtx", "gen_general_shuffled.mtx"):
+        A, b, x = capi.PM(), capi.PV(), capi.PV()
+        assert lib.lis_matrix_create(0, C.byref(A)) == 0
+        assert lib.lis_vector_create(0, C.byref(b)) == 0 and lib.lis_vector_create(0, C.byref(x)) == 0
+        assert lib.lis_input(A, b, x, os.path.join(here, "golden", "mm", fname).encode()) == 0, fname
+        a = A.contents
+        gptr, gidx, gval = G[f"{fname}/ptr"], G[f"{fname}/index"], G[f"{fname}/value"]
+        gn = len(gptr) - 1
+        is_, ie = isie(rank, world, gn)
+        assert (a.n, a.gn, a.is_, a.ie) == (ie - is_, gn, is_, ie), fname
+        got = lisdrv.matrix_arrays(A)
+        l2g = np.ctypeslib.as_array(a.l2g_map, shape=(a.np - a.n,)) if a.np > a.n else np.zeros(0, np.int32)
+        cols = np.where(got["index"] < a.n, got["index"] + is_, l2g[np.maximum(got["index"] - a.n, 0)] if len(l2g) else 0)
+        lo, hi = gptr[is_], gptr[ie]
+        assert np.array_equal(got["ptr"], gptr[is_:ie + 1] - lo), fname
+        assert np.array_equal(cols, gidx[lo:hi]) and np.array_equal(got["value"], gval[lo:hi]), fname
+        for tag, v in (("b", b), ("x", x)):
+            if f"{fname}/{tag}" in G.files:
+                vals = np.empty(ie - is_)
+                assert lib.lis_vector_get_values(v, is_, ie - is_, vals.ctypes.data_as(capi.P_DBL)) == 0
+                assert np.array_equal(vals, G[f"{fname}/{tag}"][is_:ie]), (fname, tag)
+        out = os.path.join(path[0], f"{fname}.out")
+        assert lib.lis_output_matrix(A, 2, out.encode()) == 0
+        dist.barrier()
+        if rank == 0:
+            assert np.array_equal(np.frombuffer(open(out, "rb").read(), np.uint8), G[f"{fname}/out_matrix"]), fname
+        dist.barrier()
+        if f"{fname}/b" in G.files:
+            for fmt, tag in ((1, "plain"), (2, "mm")):
+                assert lib.lis_output_vector(b, fmt, out.encode()) == 0
+                dist.barrier()
+                if rank == 0:
+                    assert np.array_equal(np.frombuffer(open(out, "rb").read(), np.uint8), G[f"{fname}/out_b_{tag}"]), (fname, tag)
+                dist.barrier()
+        lib.lis_matrix_destroy(A); lib.lis_vector_destroy(b); lib.lis_vector_destroy(x)
+    dist.barrier()
+    if rank == 0:
+        import shutil
+        shutil.rmtree(path[0], ignore_errors=True)
 
 
 def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):

@@ -211,7 +211,7 @@ int  liship_krylov_guard(const double *flag);
 int  liship_krylov_step(int step, double *state, double *rhistory, const double *gathered, int nranks, void *stream);
 /* single-rank jobs: announce the step BEFORE launching the reduction whose sums it reads; it then runs in that
  * reduction's last kernel instead of a launch of its own.  liship_krylov_chain_flush runs a step that was announced
- * but found no reduction to ride in (call it after the reduction; a no-op otherwise). */
+ * but found no reduction to ride in (call it after the reduction; a no-op otherwise); step 0 withdraws an announced step. */
 int  liship_krylov_chain(int step, double *state, double *rhistory);
 /* out[k] = sum over ranks r (in rank order, from 0.0) of gathered[r*count + k]: the device half of the cross-rank
  * fold that MPI_Allreduce does in the reference (lis_vector_ops.c:119,263), count <= 64 */

@@ -346,6 +346,7 @@ static LIS_INT dev_loop_finish(ctx_t *c, dev_loop *L, LIS_INT err)
 {
 	LIS_SOLVER s = c->s;
 	(void)liship_krylov_guard(NULL);
+	(void)liship_krylov_chain(0, NULL, NULL);      /* an error may have left a step announced */
 	if (!err) {
 		s->resid = L->host[LISHIP_KS_NRM2];
 		if (L->host[LISHIP_KS_STATUS] == 1.0) { s->retcode = LIS_SUCCESS; s->iter = (LIS_INT)L->host[LISHIP_KS_ITER]; }

@@ -649,6 +649,7 @@ extern "C" int liship_rank_fold_f64(int count, const double *gathered, int nrank
 
 extern "C" int liship_krylov_chain(int step, double *state, double *rhistory)
 {
+    if (step == 0) { g_chain = Chain{0, nullptr, nullptr}; return 0; }      // withdraw an announced step (error unwinding)
     if (!state || step < LISHIP_STEP_CG_ALPHA || step > LISHIP_STEP_BICG_RHO) return LISHIP_ERR_ARG;
     g_chain = Chain{step, state, rhistory};
     return 0;

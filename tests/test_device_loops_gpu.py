@@ -60,7 +60,7 @@ def same(outs):
 
 @pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg"])
 @pytest.mark.parametrize("precon", ["none", "jacobi"])
-@pytest.mark.parametrize("fmt", ["csr", "ell", "dia", "jad"])
+@pytest.mark.parametrize("fmt", ["csr", "ell", "dia", "jad", "bsr", "csc"])
 def test_bits_match_host_loops(lib, solver, precon, fmt):
     ptr, idx, val = orc.poisson3d(17, 12, 10, sort_cols=(fmt == "dia"))
     n = len(ptr) - 1

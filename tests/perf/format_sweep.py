@@ -37,7 +37,8 @@ def main():
     want = np.sqrt(6 * (N - 2) ** 2 + 12 * (N - 2) * 4 + 8 * 9.0)
     y_csr = None
     bytes_alg = {"csr": 12 * nnz + 20 * n + 4, "csc": 12 * nnz + 20 * n + 4, "ell": 12 * 7 * n + 16 * n, "dia": 8 * 7 * n + 16 * n,
-                 "jad": 12 * nnz + 20 * n + 4,      # served from a row-ordered HBM layout: CSR's bytes "bsr": None}
+                 "jad": 12 * nnz + 20 * n + 4,      # served from a row-ordered HBM layout: CSR's bytes
+                 "bsr": None}
     for fmt in ("csr", "ell", "dia", "jad", "bsr", "csc"):
         t0 = time.time()
         B = A if fmt == "csr" else lisdrv.convert(lib, A, fmt)

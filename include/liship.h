@@ -118,6 +118,11 @@ int  liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, const int *b
  * per block row (short block rows) and a lane per block (long ones) */
 int  liship_spmv_bsr_nnz_f64(int nr, int bnnz, int bnr, int bnc, const int *bptr, const int *bindex,
                              const double *value, const double *x, double *y, void *stream);
+/* BSR product with the reduction epilogue (the contract of liship_spmv_csr_dot_f64): square blocks 2..4 and short block
+ * rows; n = number of scalar rows (rows of the last block row beyond it are padding and stay out of the sums) */
+int  liship_spmv_bsr_dot_f64(int nr, int n, int bnnz, int bs, const int *bptr, const int *bindex, const double *value,
+                             const double *x, double *y, const double *w, int want_sumsq, double *result,
+                             void *work, void *stream);
 
 /* ------------------------------------------------------------------ vector kernels
  * element-wise: src/vector/lis_vector_opv.c (axpy :174, xpay :214, axpyz :253, scale :285, pmul :325,

@@ -456,6 +456,13 @@ LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const doub
 		if (rc != LISHIP_ERR_ARG) HIPCHK(rc);
 		if (d->type == LIS_MATRIX_ELL) HIPCHK(liship_spmv_ell_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, lisg.stream));
 		else HIPCHK(liship_spmv_dia_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, lisg.stream));
+	} else if (d->type == LIS_MATRIX_BSR && d->bnr == d->bnc && !lisg.no_fusion) {
+		if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
+		int rc = liship_spmv_bsr_dot_f64(d->nr, d->n, A->bnnz, d->bnr, d->bptr, d->bindex, d->value, dx, dy, dw, want_sumsq,
+		                                 result, lisg.reduce_work, lisg.stream);
+		if (rc == 0) return LIS_SUCCESS;
+		if (rc != LISHIP_ERR_ARG) HIPCHK(rc);
+		HIPCHK(liship_spmv_bsr_nnz_f64(d->nr, A->bnnz, d->bnr, d->bnc, d->bptr, d->bindex, d->value, dx, dy, lisg.stream));
 	} else LISCHK(lisd_spmv(A, dx, dy));
 	if (want_sumsq) HIPCHK(liship_dot2_f64(d->n, dy, dw, result, lisg.reduce_work, lisg.stream));
 	else HIPCHK(liship_dot_f64(d->n, dw, dy, result, lisg.reduce_work, lisg.stream));

@@ -344,11 +344,14 @@ void spmv_bsr22_kernel(int nr, const int *__restrict__ bptr, const int *__restri
 // the next j).  All BS rows of a block row live in one lane, y leaves as 16 B nt stores where BS is even.
 // Block rows longer than the stage are walked in passes with the running sums kept in registers.
 constexpr int BSR_LANES = 64;
-template <int BS, int CAP, int U>
+template <int BS, int CAP, int U, int DOT = 0>
 __global__ __launch_bounds__(BSR_LANES)
 void spmv_bsr_rows_kernel(int nr, const int *__restrict__ bptr, const int *__restrict__ bidx,
-                          const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+                          const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+                          int n = 0, const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                          const double *__restrict__ guard = nullptr)
 {
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     constexpr int BB = BS * BS;
     __shared__ __attribute__((aligned(16))) double valL[(CAP + 4) * BB + 2 * WAVE];
     __shared__ __attribute__((aligned(16))) int idxL[CAP + 4 + 4 * WAVE];
@@ -359,9 +362,13 @@ void spmv_bsr_rows_kernel(int nr, const int *__restrict__ bptr, const int *__res
     const bool live = mybr < br1;
     int rs = 0, re = 0;
     if (live) { rs = bptr[mybr]; re = bptr[mybr + 1]; }
-    double t[BS];
+    double t[BS], wv[BS];
 #pragma unroll
-    for (int i = 0; i < BS; i++) t[i] = 0.0;
+    for (int i = 0; i < BS; i++) {
+        t[i] = 0.0;
+        const int r = mybr * BS + i;                     // w is fetched before the blocks: its latency hides behind them
+        wv[i] = (DOT != 0 && live && r < n) ? wdot[r] : 0.0;
+    }
     for (int cb = bb; cb < be; cb += CAP) {
         const int ka = cb & ~3;                          // 16 B aligned start of both slices (4 | ka: 32 BS^2 B and 16 B)
         const int cend = min(cb + CAP, be);
@@ -440,6 +447,18 @@ void spmv_bsr_rows_kernel(int nr, const int *__restrict__ bptr, const int *__res
 #pragma unroll
             for (int i = 0; i < BS; i++) store_stream(yp + i, t[i]);
         }
+    }
+    if (DOT != 0) {                                      // <w,y> (and <y,y>): one partial per workgroup = per wavefront, no LDS
+        double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < BS; i++) {
+            const bool in = live && mybr * BS + i < n;   // rows of the padding do not exist
+            c0 += in ? wv[i] * t[i] : 0.0;
+            if (DOT == 2) c1 += in ? t[i] * t[i] : 0.0;
+        }
+        c0 = wave_sum(c0);
+        if (lane == 0) partial[blockIdx.x] = c0;
+        if (DOT == 2) { c1 = wave_sum(c1); if (lane == 0) partial[gridDim.x + blockIdx.x] = c1; }
     }
 }
 
@@ -524,6 +543,33 @@ extern "C" int liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int
 extern "C" int liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, const int *bidx,
                                    const double *val, const double *x, double *y, void *stream)
 { return liship_spmv_bsr_nnz_f64(nr, -1, bnr, bnc, bptr, bidx, val, x, y, stream); }
+
+// y = A x with result[0] = <w,y> (result[1] = <y,y> if want_sumsq) in the product's pass, for the square block sizes
+// and block-row lengths the lane-per-block-row kernel serves; LISHIP_ERR_ARG otherwise (the caller then runs the
+// product and the reduction separately) -- the contract of liship_spmv_csr_dot_f64
+extern "C" int liship_spmv_bsr_dot_f64(int nr, int n, int bnnz, int bs, const int *bptr, const int *bidx, const double *val,
+                                       const double *x, double *y, const double *w, int want_sumsq, double *result,
+                                       void *work, void *stream)
+{
+    if (nr <= 0 || n <= 0 || bnnz < 0 || !w || !result || !work) return LISHIP_ERR_ARG;
+    if (!aligned16(val) || !aligned16(x) || !aligned16(y) || !aligned16(bidx)) return LISHIP_ERR_ARG;
+    const double mean = (double)bnnz / nr;
+    const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
+    const int grid = (nr + BSR_LANES - 1) / BSR_LANES;
+    if ((size_t)grid > slots) return LISHIP_ERR_ARG;
+    double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
+    hipStream_t st = as_stream(stream);
+    const double *guard = liship_internal_guard();
+#define GO(BS, CAP, U) do { if (want_sumsq) spmv_bsr_rows_kernel<BS, CAP, U, 2><<<grid, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y, n, w, partial, guard); \
+                            else            spmv_bsr_rows_kernel<BS, CAP, U, 1><<<grid, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y, n, w, partial, guard); } while (0)
+    if (bs == 2 && mean <= 12.0) GO(2, 512, 4);
+    else if (bs == 3 && mean <= 16.0) GO(3, 256, 3);
+    else if (bs == 4 && mean <= 12.0) GO(4, 160, 2);
+    else return LISHIP_ERR_ARG;
+#undef GO
+    LAUNCH_CHECK();
+    return liship_internal_fold(grid, want_sumsq ? 2 : 1, grid, partial, spare, result, stream);
+}
 
 // the same with the number of stored blocks known (the host layer knows it): block rows that are short on average
 // take the lane-per-block-row kernel, long ones keep the lane-per-block(-column) kernels (as CSR's two kernels)

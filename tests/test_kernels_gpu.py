@@ -208,6 +208,25 @@ def test_spmv_bsr_square_blocks(lib, name, bs):
         assert np.array_equal(dy.to_host(n), ref), known
     check(lib.liship_spmv_bsr_f64(nr, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
     assert np.array_equal(dy.to_host(n), ref)
+    # the product with the reduction epilogue: same y, sums as numpy to 1e-13, repeatable; refuses what it does not serve
+    w = np.random.default_rng(22).uniform(-1, 1, nr * bs)
+    dw, work, res = DA.from_host(w), DA(lib.liship_reduce_work_bytes() // 8, np.float64), DA.from_host(np.full(2, np.nan))
+    for want_sumsq in (0, 1):
+        got = []
+        for _ in range(2):
+            dy = DA.from_host(np.full(nr * bs, np.nan))
+            rc = lib.liship_spmv_bsr_dot_f64(nr, n, len(bidx), bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, dw.ptr, want_sumsq,
+                                             res.ptr, work.ptr, None)
+            if rc != 0:
+                assert rc == -1 and (bs == 1 or len(bidx) / nr > 12)
+                break
+            assert np.array_equal(dy.to_host(n), ref)
+            got.append(res.to_host())
+        if got:
+            assert np.array_equal(got[0][:1 + want_sumsq], got[1][:1 + want_sumsq])
+            assert abs(got[0][0] - np.dot(w[:n], ref)) <= 1e-13 * (np.abs(w[:n] * ref).sum() + 1e-300)
+            if want_sumsq:
+                assert abs(got[0][1] - np.dot(ref, ref)) <= 1e-13 * np.dot(ref, ref) + 1e-300
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 1000, 4097, 1 << 20, (1 << 20) + 3])

@@ -65,6 +65,15 @@ const char *liship_error_string(int code);
  * workgroup); it depends only on ptr[] and is built once per matrix on the device. */
 typedef struct liship_csr_plan_s *liship_csr_plan_t;
 int  liship_csr_plan_create(liship_csr_plan_t *plan, int n, const int *ptr, void *stream);
+/* Index coding (setup-time, optional, never an error when the matrix does not qualify): if the entries of the matrix sit
+ * on at most 255 distinct diagonals -- every structured-grid discretisation -- the plan keeps ONE byte per non-zero
+ * (the position of column - row in a sorted dictionary) and the row-gather kernel streams 9 B per non-zero instead
+ * of 12.  Same terms in the same order: results are bit-identical.  The index array must stay valid (long rows, array
+ * tails and row-range launches may still read it).  liship_csr_plan_coded: dictionary size, 0 if not coded.
+ * liship_spmv_csr_set_index_codes(0) makes every product ignore the codes (A/B measurements). */
+int  liship_csr_plan_encode_indices(liship_csr_plan_t plan, const int *ptr, const int *index, void *stream);
+int  liship_csr_plan_coded(liship_csr_plan_t plan);
+int  liship_spmv_csr_set_index_codes(int on);
 int  liship_csr_plan_destroy(liship_csr_plan_t plan);
 int  liship_csr_plan_info(liship_csr_plan_t plan, int *n, long long *nnz, int *nblocks);
 int  liship_spmv_csr_f64(liship_csr_plan_t plan, const int *ptr, const int *index,

@@ -52,6 +52,9 @@ _LISHIP = {
     "liship_csr_plan_info": (_ci, [_vp, C.POINTER(_ci), C.POINTER(C.c_longlong), C.POINTER(_ci)]),
     "liship_spmv_csr_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_spmv_csr_dot_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
+    "liship_csr_plan_encode_indices": (_ci, [_vp, _vp, _vp, _vp]),
+    "liship_csr_plan_coded": (_ci, [_vp]),
+    "liship_spmv_csr_set_index_codes": (_ci, [_ci]),
     "liship_spmv_csr_rows_f64": (_ci, [_vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_spmv_csr_rows_dot_f64": (_ci, [_vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp]),
     "liship_spmv_csr_dot_finish_f64": (_ci, [_ci, _ci, _vp, _vp, _vp]),

@@ -207,6 +207,15 @@ static LIS_INT up_d(double **dst, const double *src, size_t count)
 }
 
 /* rows of the local matrix that reference no ghost column, as one maximal run [b,e) */
+/* the row split of a CSR-ordered HBM matrix and, where its columns allow it, the one-byte column codes
+ * (liship.h "index coding"; LIS_AMD_NO_INDEX_CODES=1 keeps the 4 B indices for A/B measurements) */
+LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex)
+{
+	HIPCHK(liship_csr_plan_create(plan, n, dptr, lisg.stream));
+	if (!lisg.no_index_codes) HIPCHK(liship_csr_plan_encode_indices(*plan, dptr, dindex, lisg.stream));
+	return LIS_SUCCESS;
+}
+
 static void find_inner_rows(LIS_MATRIX A, int *b, int *e)
 {
 	const int n = A->n;
@@ -302,12 +311,12 @@ LIS_INT lisd_mat_ready(LIS_MATRIX A)
 		LISCHK(up_i(&d->ptr, A->ptr, n + 1));
 		LISCHK(up_i(&d->index, A->index, (size_t)A->nnz));
 		LISCHK(up_d(&d->value, A->value, (size_t)A->nnz));
-		HIPCHK(liship_csr_plan_create(&d->plan, A->n, d->ptr, lisg.stream));
+		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index));
 		break;
 	case LIS_MATRIX_CSC:
 		LISCHK(upload_csc_as_csr(A, d));
 		d->type = LIS_MATRIX_CSR;
-		HIPCHK(liship_csr_plan_create(&d->plan, A->n, d->ptr, lisg.stream));
+		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index));
 		break;
 	case LIS_MATRIX_ELL:
 		d->maxnzr = A->maxnzr;
@@ -322,7 +331,7 @@ LIS_INT lisd_mat_ready(LIS_MATRIX A)
 	case LIS_MATRIX_JAD:
 		LISCHK(upload_jad_as_csr(A, d));
 		d->type = LIS_MATRIX_CSR;
-		HIPCHK(liship_csr_plan_create(&d->plan, A->n, d->ptr, lisg.stream));
+		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index));
 		break;
 	case LIS_MATRIX_BSR:
 		d->nr = A->nr; d->nc = A->nc; d->bnr = A->bnr; d->bnc = A->bnc;
@@ -520,7 +529,7 @@ LIS_INT lis_amd_matrix_set_csr_device(LIS_INT nnz, LIS_INT np, LIS_INT *dptr, LI
 	d->type = LIS_MATRIX_CSR;
 	d->n = A->n; d->np = np; d->nnz = nnz;
 	d->ptr = dptr; d->index = dindex; d->value = dvalue;
-	HIPCHK(liship_csr_plan_create(&d->plan, A->n, d->ptr, lisg.stream));
+	LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index));
 	d->inner_begin = 0; d->inner_end = A->n;
 	d->ready = 1;
 	A->nnz = nnz; A->np = np;

@@ -95,6 +95,7 @@ typedef struct {
 	void *nccl_comm;
 	void *comm_stream;         /* second HIP stream: halo send/recv overlapped with the interior rows */
 	void *ev_packed, *ev_landed;
+	int no_index_codes;        /* LIS_AMD_NO_INDEX_CODES=1: CSR products keep reading the 4 B column indices (A/B measurements) */
 	int host_scalars;          /* LIS_AMD_HOST_SCALARS=1: CG / BiCGSTAB read every scalar back (A/B against the device-driven loops) */
 	int no_overlap;            /* LIS_AMD_NO_OVERLAP=1: exchange first, then the whole product (A/B measurements) */
 	lis_amd_comm_callbacks cb;
@@ -118,6 +119,7 @@ void    lisd_pool_put(void *p, size_t bytes);
 LIS_INT lisd_mat_ready_t(LIS_MATRIX A);                       /* build / upload the transposed operator */
 LIS_INT lisd_spmv_t(LIS_MATRIX A, double *dx, double *dy);    /* y[0..np) = A^T x, ghost rows reduced to owners */
 LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy);      /* y = A x on device pointers (halo included) */
+LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex);   /* row split + index codes */
 LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq); /* sums -> reduce_out */
 LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq, double *result); /* sums -> result (HBM) */
 LIS_INT lisd_fetch(int count, double *out);                   /* reduce_out[0..count) -> host, cross-rank fold */

@@ -147,7 +147,7 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 		free(hptr); free(hidx); free(hval);
 		if (err) return err;
 	}
-	HIPCHK(liship_csr_plan_create(&d->t_plan, d->t_rows, d->t_ptr, lisg.stream));
+	LISCHK(lisd_csr_plan(&d->t_plan, d->t_rows, d->t_ptr, d->t_index));
 	HIPCHK(liship_stream_synchronize(lisg.stream));
 	d->t_ready = 1;
 	return LIS_SUCCESS;

@@ -192,6 +192,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_fusion = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_OVERLAP");
 		lisg.no_overlap = (r && r[0] == '1');
+		r = getenv("LIS_AMD_NO_INDEX_CODES");
+		lisg.no_index_codes = (r && r[0] == '1');
 		r = getenv("LIS_AMD_HOST_SCALARS");
 		lisg.host_scalars = (r && r[0] == '1');
 	}

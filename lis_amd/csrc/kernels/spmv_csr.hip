@@ -53,6 +53,7 @@ constexpr int SLACK = 128;       // extra items a block may take to start on an 
 //   bit8  ablation: skip the x gather  (WRONG results, timing only)
 //   bit10 register staging instead of LDS-DMA   bits11-12 gather unroll U: 0 auto, 1: 4, 2: 7, 3: 8
 int g_variant = 0;
+int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps every product on the 4 B indices
 
 struct Blk { int r0, k0, r1, k1; };
 
@@ -393,6 +394,137 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
+// ------------------------------------------------------------------------------ row-gather kernel, coded indices
+// A matrix whose entries sit on at most 255 distinct diagonals (every structured-grid discretisation: the 7-point
+// stencil has 7) does not need 4 B per column index: the plan stores ONE byte per non-zero, the position of
+// (column - row) in a sorted dictionary of the offsets that occur (csr_collect_offsets / csr_encode below), and this
+// kernel streams 9 B per non-zero instead of 12.  Same rows, same terms, same order as the kernel above (the column
+// is rebuilt as row + dict[code]), so the sums are bit-identical; the index array itself stays in HBM for the
+// paths that want it (long rows, array tails, transposition).
+template <int BLOCK, int WORK, int U, int DOT = 0>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
+                           const double *__restrict__ val, const unsigned char *__restrict__ codes,
+                           const int *__restrict__ dict, const double *__restrict__ x,
+                           double *__restrict__ y, const v2i32 *__restrict__ blk,
+                           int bfirst, int nb, int row_begin, int row_end, int nnz_total,
+                           const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                           const double *__restrict__ guard = nullptr, int pstride = 0)
+{
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    __shared__ double dot_scratch[BLOCK / WAVE];
+    RowDots<DOT> dots{wdot, 0.0, 0.0};
+    constexpr int CAP = WORK + SLACK + 16;          // + the 16-entry alignment of the code slice
+    __shared__ __attribute__((aligned(16))) double valL[CAP + 8 + 2 * WAVE];
+    __shared__ __attribute__((aligned(16))) unsigned char codeL[CAP + 16 + 16 * WAVE];
+    __shared__ int dictL[256];
+
+    const int lb = blockIdx.x;
+    Blk B = load_blk(blk, bfirst + lb);
+    if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+        return;
+    }
+    const int ka = B.k0 & ~15;                      // 16 B aligned start of the code slice (128 B for the values)
+    const int cnt = B.k1 - ka;
+    const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
+    const int nc = (cnt + 15) >> 4;                 // 16 B pieces of the code slice (the code array is padded)
+    if (cnt > CAP || ka + 2 * np > nnz_total) {     // long row / last value of the array
+        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots);
+        __syncthreads();
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+        return;
+    }
+    for (int i = threadIdx.x; i < 256; i += BLOCK) dictL[i] = dict[i];
+    const int rmine = B.r0 + (int)threadIdx.x;
+    int s_first = 0, e_first = 0;
+    if (rmine < B.r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; }
+    {
+        const int wbase = (int)threadIdx.x & ~(WAVE - 1), lane = (int)threadIdx.x & (WAVE - 1);
+        for (int p0 = wbase; p0 < np; p0 += BLOCK) {
+            const int p = min(p0 + lane, np - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+        }
+        for (int q0 = wbase; q0 < nc; q0 += BLOCK) {
+            const int q = min(q0 + lane, nc - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v4i32 *>(codes + ka) + q),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v4i32 *>(codeL) + q0), 16, 0, 2);
+        }
+    }
+    __syncthreads();
+
+    for (int r = rmine; r < B.r1; r += BLOCK) {
+        int s = s_first, e = e_first;
+        if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
+        const int len = e - s;
+        const int off = s - ka;
+        const double wr = dots.fetch(r);
+        double acc = 0.0;
+        for (int j0 = 0; j0 < len; j0 += U) {
+            int cc[U]; double vv[U], xx[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = min(j0 + u, len - 1);         // clamped: repeats the row's last entry
+                cc[u] = r + dictL[codeL[off + j]];
+                vv[u] = valL[off + j];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) xx[u] = x[cc[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double t = vv[u] * xx[u];
+                acc += (j0 + u < len) ? t : 0.0;            // +0.0 terms leave the sum bit-unchanged
+            }
+        }
+        store_stream(y + r, acc);
+        dots.add_loaded(wr, acc);
+    }
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+}
+
+// plan time: the set of (column - row) offsets, in a small open-addressing table; gives up beyond 255
+constexpr int OFFSET_TABLE = 1024, OFFSET_EMPTY = -2147483647 - 1;
+__global__ void csr_collect_offsets(int n, const int *__restrict__ ptr, const int *__restrict__ idx,
+                                    int *__restrict__ table, int *__restrict__ count)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || count[0] > 255) return;
+    for (int k = ptr[r]; k < ptr[r + 1]; k++) {
+        const int off = idx[k] - r;
+        unsigned h = ((unsigned)off * 2654435761u) >> 22;        // 10 bits
+        for (int probe = 0; probe < OFFSET_TABLE; probe++) {
+            const int v = table[h];
+            if (v == off) break;
+            if (v == OFFSET_EMPTY) {
+                const int old = atomicCAS(&table[h], OFFSET_EMPTY, off);
+                if (old == OFFSET_EMPTY) { atomicAdd(count, 1); break; }
+                if (old == off) break;
+            }
+            h = (h + 1) & (OFFSET_TABLE - 1);
+            if (count[0] > 255) return;
+        }
+    }
+}
+
+__global__ void csr_encode(int n, const int *__restrict__ ptr, const int *__restrict__ idx, const int *__restrict__ dict,
+                           int ndict, unsigned char *__restrict__ codes)
+{
+    __shared__ int d[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) d[i] = dict[i];
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    for (int k = ptr[r]; k < ptr[r + 1]; k++) {
+        const int off = idx[k] - r;
+        int lo = 0, hi = ndict - 1;                 // sorted ascending: the offset is there
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (d[mid] < off) lo = mid + 1; else hi = mid; }
+        codes[k] = (unsigned char)lo;
+    }
+}
+
 } // namespace
 
 struct liship_csr_plan_s {
@@ -405,9 +537,35 @@ struct liship_csr_plan_s {
     int batch;           // its independent load pairs in flight per lane (2 or 4)
     v2i32 *blk;          // device, nblocks + 1 entries {row, ptr[row]}
     v2i32 *blk_host;     // host copy (row-range launches)
+    unsigned char *codes; // device, one byte per non-zero (+ padding): position of (column - row) in dict; NULL = not coded
+    int *dict;           // device, 256 sorted offsets (the tail repeats the last one)
+    int ndict;
 };
 
 extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
+extern "C" int liship_spmv_csr_set_index_codes(int on) { g_index_codes = on ? 1 : 0; return 0; }
+
+// the merge-path row split for the plan's geometry (device + host copy); replaces an existing one
+static int build_split(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
+{
+    if (p->blk) { (void)hipFree(p->blk); p->blk = nullptr; }
+    free(p->blk_host); p->blk_host = nullptr;
+    const long long items = (long long)p->n + p->nnz;
+    const int WORK = kGeom[p->geom].work;
+    p->nblocks = (int)((items + WORK - 1) / WORK);
+    if (p->nblocks <= 0) return 0;
+    const size_t bytes = (size_t)(p->nblocks + 1) * sizeof(v2i32);
+    hipError_t e = hipMalloc(&p->blk, bytes);
+    if (e != hipSuccess) return (int)e;
+    const int threads = 256, grid = (p->nblocks + 1 + threads - 1) / threads;
+    csr_plan_kernel<<<grid, threads, 0, st>>>(p->n, ptr, p->nblocks, WORK, (g_variant & 0x1000000) ? 0 : 1, p->blk);
+    e = hipGetLastError();
+    p->blk_host = (v2i32 *)malloc(bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->blk_host, p->blk, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(p->blk); p->blk = nullptr; free(p->blk_host); p->blk_host = nullptr; return (int)e; }
+    return 0;
+}
 
 extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *ptr, void *stream)
 {
@@ -421,7 +579,6 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     liship_csr_plan_s *p = new liship_csr_plan_s();
     p->n = n;
     p->nnz = nnz;
-    const long long items = (long long)n + nnz;
     p->geom = (g_variant >> 4) & 15;
     if (p->geom >= kNumGeom) p->geom = 0;
     const double mean_len = n > 0 ? (double)nnz / n : 0.0;
@@ -433,22 +590,11 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->batch = mean_len >= 24.0 ? 2 : 4;
     if (g_variant & 0x4000000) p->batch = 4;              // experiment knobs
     if (g_variant & 0x8000000) p->batch = 2;
-    const int WORK = kGeom[p->geom].work;
-    p->nblocks = (int)((items + WORK - 1) / WORK);
     p->blk = nullptr;
     p->blk_host = nullptr;
-    if (p->nblocks > 0) {
-        const size_t bytes = (size_t)(p->nblocks + 1) * sizeof(v2i32);
-        hipError_t e = hipMalloc(&p->blk, bytes);
-        if (e != hipSuccess) { delete p; return (int)e; }
-        const int threads = 256, grid = (p->nblocks + 1 + threads - 1) / threads;
-        csr_plan_kernel<<<grid, threads, 0, st>>>(n, ptr, p->nblocks, WORK, (g_variant & 0x1000000) ? 0 : 1, p->blk);
-        e = hipGetLastError();
-        p->blk_host = (v2i32 *)malloc(bytes);
-        if (e == hipSuccess) e = hipMemcpyAsync(p->blk_host, p->blk, bytes, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { (void)hipFree(p->blk); free(p->blk_host); delete p; return (int)e; }
-    }
+    p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
+    const int rc = build_split(p, ptr, st);
+    if (rc) { delete p; return rc; }
     *out = p;
     return 0;
 }
@@ -458,6 +604,8 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (!p) return 0;
     int rc = 0;
     if (p->blk) rc = (int)hipFree(p->blk);
+    if (p->codes) (void)hipFree(p->codes);
+    if (p->dict) (void)hipFree(p->dict);
     free(p->blk_host);
     delete p;
     return rc;
@@ -472,13 +620,68 @@ extern "C" int liship_csr_plan_info(liship_csr_plan_t p, int *n, long long *nnz,
     return 0;
 }
 
+// One byte per column index where the matrix allows it (see spmv_csr_coded_kernel): at most 255 distinct
+// (column - row) offsets, short rows on average (the row-gather kernel), 16 B aligned arrays.  Setup-time: two passes
+// over ptr / index.  Not an error when the matrix does not qualify -- the plan then keeps using the index array.
+extern "C" int liship_csr_plan_encode_indices(liship_csr_plan_t p, const int *ptr, const int *idx, void *stream)
+{
+    if (!p || (p->n > 0 && (!ptr || !idx))) return LISHIP_ERR_ARG;
+    if (p->codes || p->products || p->n == 0 || p->nnz == 0 || !aligned16(idx)) return 0;
+    hipStream_t st = as_stream(stream);
+    int *table = nullptr;                            // OFFSET_TABLE slots + the counter
+    HIP_TRY(hipMalloc(&table, sizeof(int) * (OFFSET_TABLE + 1)));
+    int host[OFFSET_TABLE + 1];
+    for (int i = 0; i < OFFSET_TABLE; i++) host[i] = OFFSET_EMPTY;
+    host[OFFSET_TABLE] = 0;
+    hipError_t e = hipMemcpyAsync(table, host, sizeof(host), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        csr_collect_offsets<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, idx, table, table + OFFSET_TABLE);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, table, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(table);
+    if (e != hipSuccess) return (int)e;
+    if (host[OFFSET_TABLE] > 255) return 0;          // too many diagonals: stay with 4 B indices
+    int dict[256], nd = 0;
+    for (int i = 0; i < OFFSET_TABLE; i++) if (host[i] != OFFSET_EMPTY && nd < 256) dict[nd++] = host[i];
+    if (nd == 0 || nd > 255) return 0;
+    for (int i = 1; i < nd; i++) { const int v = dict[i]; int j = i - 1; while (j >= 0 && dict[j] > v) { dict[j + 1] = dict[j]; j--; } dict[j + 1] = v; }
+    for (int i = nd; i < 256; i++) dict[i] = dict[nd - 1];
+    const size_t cbytes = ((size_t)p->nnz + 15) / 16 * 16 + 16 * WAVE;       // whole 16 B pieces, one wave slice of slack
+    e = hipMalloc(&p->dict, sizeof(dict));
+    if (e == hipSuccess) e = hipMalloc(&p->codes, cbytes);
+    if (e == hipSuccess) e = hipMemsetAsync(p->codes, 0, cbytes, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->dict, dict, sizeof(dict), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        csr_encode<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, idx, p->dict, nd, p->codes);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        if (p->codes) (void)hipFree(p->codes);
+        if (p->dict) (void)hipFree(p->dict);
+        p->codes = nullptr; p->dict = nullptr;
+        return (int)e;
+    }
+    p->ndict = nd;
+    // 9 B per item instead of 12: the coded kernel runs best on 256-lane workgroups of 2048 items (tools/coded_sweep.py)
+    if (p->geom == 0 && g_variant == 0) { p->geom = 1; return build_split(p, ptr, st); }
+    return 0;
+}
+// number of dictionary entries when the plan's indices are coded, 0 otherwise
+extern "C" int liship_csr_plan_coded(liship_csr_plan_t p) { return (p && p->codes) ? p->ndict : 0; }
+
 namespace {
 
 struct LaunchArgs {
     const int *ptr, *idx; const double *val, *x; double *y; const v2i32 *blk;
     int bfirst, nb, rb, re, nnz;
     hipStream_t st;
+    const unsigned char *codes = nullptr;   // one-byte column codes + their dictionary, when the plan has them
+    const int *dict = nullptr;
 };
+
 
 inline int xcd_run() { int c = (g_variant >> 16) & 0xff; return c ? c : 16; }
 
@@ -520,6 +723,14 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     const int usel = (g_variant >> 11) & 3;
     const int U = usel == 1 ? 4 : usel == 2 ? 7 : usel == 3 ? 8 : unroll;
     const bool dma = !(g_variant & 0x400);
+    if (a.codes && (g_variant & ~0xF0) == 0) {       // one-byte column codes (the plan found <= 255 diagonals)
+        constexpr Geometry g = kGeom[G];
+#define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, 0><<<a.nb, g.block, 0, a.st>>>( \
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz)
+        if (U == 4) GO(4); else if (U == 7) GO(7); else GO(8);
+#undef GO
+        return;
+    }
     if (nogather)  { launch_rowgather<G, 8, false, true, true>(a.nb, a); return; }
     if (xrun)      { launch_rowgather<G, 8, true, true, false>(grid, a); return; }
     if (!dma)      { launch_rowgather<G, 8, false, false, false>(grid, a); return; }
@@ -532,6 +743,13 @@ template <int G, int DOT>
 void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
+    if (a.codes) {
+#define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, DOT><<<a.nb, g.block, 0, a.st>>>( \
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, w, partial, liship_internal_guard(), pstride)
+        if (unroll == 4) GO(4); else if (unroll == 7) GO(7); else GO(8);
+#undef GO
+        return;
+    }
 #define GO(UU) spmv_csr_rowgather_kernel<g.block, g.work, UU, false, true, false, DOT><<<a.nb, g.block, 0, a.st>>>( \
         a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, 16, w, partial, liship_internal_guard(), pstride)
     if (unroll == 4) GO(4); else if (unroll == 7) GO(7); else GO(8);
@@ -573,7 +791,7 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
                                    const double *val, const double *x, double *y, void *stream)
 {
     if (!p) return LISHIP_ERR_ARG;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream)};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict};
     return launch_csr(p, a);
 }
 
@@ -589,12 +807,13 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if (g_variant != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream)};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (p->products) {              // geometry 1
         if (want_sumsq) launch_products_dot<1, 2>(a, p->batch, w, partial); else launch_products_dot<1, 1>(a, p->batch, w, partial);
-    } else if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial);
-    else                   launch_rowgather_dot<0, 1>(a, p->unroll, w, partial);
+    } else if (p->geom == 1) { if (want_sumsq) launch_rowgather_dot<1, 2>(a, p->unroll, w, partial); else launch_rowgather_dot<1, 1>(a, p->unroll, w, partial); }
+    else if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial);
+    else                 launch_rowgather_dot<0, 1>(a, p->unroll, w, partial);
     LAUNCH_CHECK();
     return liship_internal_fold(p->nblocks, want_sumsq ? 2 : 1, p->nblocks, partial, spare, result, stream);
 }
@@ -612,7 +831,7 @@ extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int 
     const int bfirst = lo;
     lo = bfirst; hi = p->nblocks;                // first b with br[b].row >= row_end
     while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream)};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict};
     return launch_csr(p, a);
 }
 
@@ -640,12 +859,13 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if (nb <= 0) return 0;
     if ((size_t)slot_base + (size_t)nb > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work) + slot_base;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream)};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict};
     const int ps = (int)slots;
     if (p->products) {
         if (want_sumsq) launch_products_dot<1, 2>(a, p->batch, w, partial, ps); else launch_products_dot<1, 1>(a, p->batch, w, partial, ps);
-    } else if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial, ps);
-    else                   launch_rowgather_dot<0, 1>(a, p->unroll, w, partial, ps);
+    } else if (p->geom == 1) { if (want_sumsq) launch_rowgather_dot<1, 2>(a, p->unroll, w, partial, ps); else launch_rowgather_dot<1, 1>(a, p->unroll, w, partial, ps); }
+    else if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial, ps);
+    else                 launch_rowgather_dot<0, 1>(a, p->unroll, w, partial, ps);
     LAUNCH_CHECK();
     *slots_used = nb;
     return 0;

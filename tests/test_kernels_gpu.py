@@ -174,6 +174,108 @@ def test_formats_vs_oracle(lib, fmt, case):
     assert np.array_equal(dy.to_host(n), ref)
 
 
+def banded(n, offsets, seed, ncols=None):
+    """rows with one entry on each of the given diagonals that falls inside the matrix, in the given (unsorted) order"""
+    rng = np.random.default_rng(seed)
+    ncols = ncols or n
+    rows, cols = [], []
+    for r in range(n):
+        for o in offsets:
+            if 0 <= r + o < ncols:
+                rows.append(r); cols.append(r + o)
+    ptr = np.zeros(n + 1, np.int32)
+    np.add.at(ptr, np.asarray(rows) + 1, 1)
+    return np.cumsum(ptr).astype(np.int32), np.asarray(cols, np.int32), rng.uniform(-1, 1, len(cols))
+
+
+def cyclic_diagonals(n, count, seed):
+    """two entries per row: the main diagonal and one of `count - 1` other diagonals, chosen cyclically"""
+    rng = np.random.default_rng(seed)
+    others = [5 * k + 1 if k % 2 else -(5 * k + 2) for k in range(count - 1)]
+    ptr, cols = [0], []
+    for r in range(n):
+        o = others[r % len(others)]
+        cols += [r] + ([r + o] if 0 <= r + o < n else [])
+        ptr.append(len(cols))
+    return np.asarray(ptr, np.int32), np.asarray(cols, np.int32), rng.uniform(-1, 1, len(cols))
+
+
+CODED_CASES = {
+    "p1d_10000": (lambda: orc.poisson1d(10000), 3),
+    "p3d_20x17x13": (lambda: orc.poisson3d(20, 17, 13), 7),
+    "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
+    "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
+    "diagonals_255": (lambda: cyclic_diagonals(6000, 255, 2), 255),
+    "diagonals_300": (lambda: cyclic_diagonals(6000, 300, 3), 0),                           # too many diagonals
+    "band_ghost_columns": (lambda: banded(4000, [-2, 0, 5, 3000, 4100], 4, ncols=8200), 5),      # columns beyond n
+    "rand_5000": (lambda: orc.random_csr(5000, 11, seed=1), 0),                              # thousands of offsets
+    "mostly_empty": (lambda: orc.random_csr(20000, 0.05, seed=4), None),
+    "single_row": (lambda: orc.random_csr(1, 5, seed=5, ncols=64, empty_rows=False), None),
+    "wide_77": (lambda: orc.random_csr(4000, 77, seed=3, ncols=4000, empty_rows=False), 0),     # products kernel: never coded
+}
+
+
+@pytest.mark.parametrize("name", list(CODED_CASES))
+def test_spmv_csr_index_codes(lib, name):
+    """one-byte column codes: the plan codes exactly the matrices with <= 255 diagonals, and with the codes every form
+    of the product (plain, reduction epilogue, row ranges, parts) returns the bits of the 4 B-index kernel"""
+    make, want = CODED_CASES[name]
+    ptr, idx, val = make()
+    n = len(ptr) - 1
+    ncols = max(n, int(idx.max()) + 1 if len(idx) else 1)
+    rng = np.random.default_rng(31)
+    x, w = rng.uniform(-1, 1, ncols), rng.uniform(-1, 1, n)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval = DA.from_host(ptr, np.int32), DA.from_host(idx if len(idx) else np.zeros(1, np.int32), np.int32), \
+        DA.from_host(val if len(val) else np.zeros(1), np.float64)
+    dx, dw = DA.from_host(x, np.float64), DA.from_host(w, np.float64)
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    coded = lib.liship_csr_plan_coded(plan)
+    if want is not None:
+        assert coded == want, (coded, want)
+    results = {}
+    for on in (1, 0):
+        lib.liship_spmv_csr_set_index_codes(on)
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host(), yref), on
+        out = []
+        for sq in (0, 1):
+            res = DA.from_host(np.full(2, np.nan), np.float64)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            rc = lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, sq, res.ptr, work.ptr, None)
+            if rc == 0:
+                assert np.array_equal(dy.to_host(), yref), (on, sq)
+                out.append(res.to_host()[:1 + sq].copy())
+        lo, hi = n // 5, n - n // 7
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        for a, b in ((lo, hi), (0, lo), (hi, n)):
+            check(lib.liship_spmv_csr_rows_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host(), yref), on
+        total, used = 0, C.c_int()
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        ok = True
+        for a, b in ((lo, hi), (0, lo), (hi, n)):
+            rc = lib.liship_spmv_csr_rows_dot_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, 1,
+                                                  work.ptr, total, C.byref(used), None)
+            ok = ok and rc == 0
+            total += used.value
+        if ok:
+            res = DA.from_host(np.full(2, np.nan), np.float64)
+            check(lib.liship_spmv_csr_dot_finish_f64(total, 1, res.ptr, work.ptr, None))
+            assert np.array_equal(dy.to_host(), yref), on
+            out.append(res.to_host().copy())
+        results[on] = out
+    lib.liship_spmv_csr_set_index_codes(1)
+    check(lib.liship_csr_plan_destroy(plan))
+    assert len(results[0]) == len(results[1])
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b)                        # same partial sums, same fold: the reductions agree to the bit too
+
+
 BSR22_CASES = {
     "stencil": lambda: orc.poisson3d(23, 18, 14),
     "one_block_row": lambda: orc.random_csr(2, 2, seed=7, empty_rows=False),

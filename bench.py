@@ -184,10 +184,18 @@ def main():
     tf = os.path.join(ROOT, "profiles", "r01_spmv512_traffic.json")
     if N == 512 and world == 1 and os.path.exists(tf):
         traffic = json.load(open(tf))["hbm_traffic_bytes_per_launch"]
+    # One-byte column codes (the stencil sits on 7 diagonals): the kernel then streams 9 B per non-zero, not
+    # the 12 B the contract's algorithmic count prices -- `achieved` / `frac` stay on the contract's bytes, the bytes the
+    # kernel is actually asked to move and the fraction of the roofline THEY reach are reported beside them.
+    dll.lis_amd_matrix_index_codes.argtypes = [capi.PM]
+    coded = int(dll.lis_amd_matrix_index_codes(A))
+    moved = (9 if coded else 12) * nnz_local + 20 * n_local + 4
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "spmv_csr_rowgather_kernel", "kernel_ms": round(kernel_ms, 4),
-                "alg_bytes_per_launch": alg_bytes, "per_gpu": True}
+                "kernel": "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel", "kernel_ms": round(kernel_ms, 4),
+                "alg_bytes_per_launch": alg_bytes, "per_gpu": True,
+                "index_codes": coded, "stored_bytes_per_launch": moved,
+                "frac_of_stored_bytes": round(moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---- Krylov iterations/s on the same matrix (b = A*1, x0 = 0), whole job
     solvers = {}

@@ -362,6 +362,11 @@ void lisd_mat_free(LIS_MATRIX A)
 }
 
 LIS_INT lis_amd_matrix_upload(LIS_MATRIX A) { return lisd_mat_ready(A); }
+LIS_INT lis_amd_matrix_index_codes(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return MDEV(A)->plan ? liship_csr_plan_coded(MDEV(A)->plan) : 0;
+}
 LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A)
 {
 	if (MDEV(A)->device_only) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix lives in HBM only\n");

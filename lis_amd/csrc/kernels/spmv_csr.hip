@@ -401,7 +401,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
 // kernel streams 9 B per non-zero instead of 12.  Same rows, same terms, same order as the kernel above (the column
 // is rebuilt as row + dict[code]), so the sums are bit-identical; the index array itself stays in HBM for the
 // paths that want it (long rows, array tails, transposition).
-template <int BLOCK, int WORK, int U, int DOT = 0>
+template <int BLOCK, int WORK, int U, int DOT = 0, bool NOGATHER = false, bool XRUN = false>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                            const double *__restrict__ val, const unsigned char *__restrict__ codes,
@@ -409,7 +409,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
                            double *__restrict__ y, const v2i32 *__restrict__ blk,
                            int bfirst, int nb, int row_begin, int row_end, int nnz_total,
                            const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                           const double *__restrict__ guard = nullptr, int pstride = 0)
+                           const double *__restrict__ guard = nullptr, int pstride = 0, int run = 16)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     __shared__ double dot_scratch[BLOCK / WAVE];
@@ -419,7 +419,8 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     __shared__ __attribute__((aligned(16))) unsigned char codeL[CAP + 16 + 16 * WAVE];
     __shared__ int dictL[256];
 
-    const int lb = blockIdx.x;
+    const int lb = block_of_workgroup<XRUN>(nb, run);
+    if (lb < 0) return;
     Blk B = load_blk(blk, bfirst + lb);
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
@@ -472,7 +473,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
                 vv[u] = valL[off + j];
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) xx[u] = x[cc[u]];
+            for (int u = 0; u < U; u++) xx[u] = NOGATHER ? (double)cc[u] : x[cc[u]];   // NOGATHER: ablation, wrong results
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const double t = vv[u] * xx[u];
@@ -723,6 +724,19 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     const int usel = (g_variant >> 11) & 3;
     const int U = usel == 1 ? 4 : usel == 2 ? 7 : usel == 3 ? 8 : unroll;
     const bool dma = !(g_variant & 0x400);
+    if (a.codes && (g_variant & ~0xFF00F0) == 0x1 && a.nb >= 4 * NUM_XCD) {   // experiment: XCD-run block order for the coded kernel
+        constexpr Geometry g = kGeom[G];
+        const int sp = NUM_XCD * xcd_run(), gr = ((a.nb + sp - 1) / sp) * sp;
+        spmv_csr_coded_kernel<g.block, g.work, 7, 0, false, true><<<gr, g.block, 0, a.st>>>(
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, nullptr, nullptr, nullptr, 0, xcd_run());
+        return;
+    }
+    if (a.codes && (g_variant & ~0xF0) == 0x100) {   // ablation: coded kernel without the x gather (timing only)
+        constexpr Geometry g = kGeom[G];
+        spmv_csr_coded_kernel<g.block, g.work, 7, 0, true><<<a.nb, g.block, 0, a.st>>>(
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz);
+        return;
+    }
     if (a.codes && (g_variant & ~0xF0) == 0) {       // one-byte column codes (the plan found <= 255 diagonals)
         constexpr Geometry g = kGeom[G];
 #define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, 0><<<a.nb, g.block, 0, a.st>>>( \

@@ -584,9 +584,11 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     if (p->geom >= kNumGeom) p->geom = 0;
     const double mean_len = n > 0 ? (double)nnz / n : 0.0;
     p->unroll = mean_len <= 4.0 ? 4 : (mean_len <= 7.0 ? 7 : 8);
-    // lane-per-row keeps 176 lanes busy on 7-entry rows but only 17 on 80-entry rows: from ~14 entries per row on,
-    // lanes own non-zeros instead (measured crossover, tools/rowlen_sweep.py)
-    p->products = (g_variant == 0 && mean_len >= 14.0) ? 1 : 0;
+    // lane-per-row keeps 176 lanes busy on 7-entry rows but only 17 on 80-entry rows: from 22 entries per row on,
+    // lanes own non-zeros instead (measured crossover with U = 8, tools/rowlen_sweep.py: the row-gather kernel wins up to
+    // 20 entries per row, ties at 22-24, loses from 27 on).  With coded indices (liship_csr_plan_encode_indices) the
+    // row-gather kernel stays ahead up to 29 entries per row and the plan switches back to it.
+    p->products = (g_variant == 0 && mean_len >= 22.0) ? 1 : 0;
     if (p->products) p->geom = 1;
     p->batch = mean_len >= 24.0 ? 2 : 4;
     if (g_variant & 0x4000000) p->batch = 4;              // experiment knobs
@@ -627,7 +629,9 @@ extern "C" int liship_csr_plan_info(liship_csr_plan_t p, int *n, long long *nnz,
 extern "C" int liship_csr_plan_encode_indices(liship_csr_plan_t p, const int *ptr, const int *idx, void *stream)
 {
     if (!p || (p->n > 0 && (!ptr || !idx))) return LISHIP_ERR_ARG;
-    if (p->codes || p->products || p->n == 0 || p->nnz == 0 || !aligned16(idx)) return 0;
+    const double mean_len = (double)p->nnz / (p->n > 0 ? p->n : 1);
+    if (p->codes || p->n == 0 || p->nnz == 0 || !aligned16(idx) || (g_variant != 0 && p->products)) return 0;
+    if (p->products && mean_len >= 30.0) return 0;   // long rows: the products kernel, which reads the 4 B indices
     hipStream_t st = as_stream(stream);
     int *table = nullptr;                            // OFFSET_TABLE slots + the counter
     HIP_TRY(hipMalloc(&table, sizeof(int) * (OFFSET_TABLE + 1)));
@@ -666,8 +670,9 @@ extern "C" int liship_csr_plan_encode_indices(liship_csr_plan_t p, const int *pt
         return (int)e;
     }
     p->ndict = nd;
-    // 9 B per item instead of 12: the coded kernel runs best on 256-lane workgroups of 2048 items (tools/coded_sweep.py)
-    if (p->geom == 0 && g_variant == 0) { p->geom = 1; return build_split(p, ptr, st); }
+    // 9 B per item instead of 12: the coded kernel runs best on 256-lane workgroups of 2048 items (tools/coded_sweep.py),
+    // and up to 29 entries per row it beats the products kernel the plan had chosen for 22+
+    if (g_variant == 0 && (p->geom == 0 || p->products)) { p->geom = 1; p->products = 0; return build_split(p, ptr, st); }
     return 0;
 }
 // number of dictionary entries when the plan's indices are coded, 0 otherwise
@@ -737,7 +742,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz);
         return;
     }
-    if (a.codes && (g_variant & ~0xF0) == 0) {       // one-byte column codes (the plan found <= 255 diagonals)
+    if (a.codes && (g_variant & ~0x18F0) == 0) {     // one-byte column codes (the plan found <= 255 diagonals)
         constexpr Geometry g = kGeom[G];
 #define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, 0><<<a.nb, g.block, 0, a.st>>>( \
             a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz)

@@ -798,11 +798,12 @@ static LIS_INT run_gmres(ctx_t *c)
 			ii = i - 1; i1 = i;
 			double *hc = h + (size_t)ii * ld;
 			TRY(d_psolve(c, v[ii], z));
-			TRY(d_matvec(c, z, v[i1]));
+			if (!chained) TRY(d_matvec(c, z, v[i1]));
 			if (chained) {
 				/* modified Gram-Schmidt with the coefficients kept in HBM: step k reads h[k-1] from the previous
-				 * step's reduction, so the whole column costs ONE host synchronisation instead of i+1 */
-				KTRY(liship_dot_f64(n, v[i1], v[0], hdev, lisg.reduce_work, lisg.stream));
+				 * step's reduction, so the whole column costs ONE host synchronisation instead of i+1; the first
+				 * coefficient <A z, v0> is formed in the product's own pass */
+				TRY(lisd_spmv_dot_launch_to(c->A, z, v[i1], v[0], 0, hdev));
 				TRY(globalize(hdev, 1));
 				for (int k = 1; k < i; k++) {
 					KTRY(liship_mgs_step_f64(n, hdev + k - 1, v[k - 1], v[i1], v[k], hdev + k, lisg.reduce_work, lisg.stream));

@@ -1,4 +1,4 @@
-"""Device-driven CG / BiCGSTAB / BiCG (scalars in HBM, iterations enqueued in batches, one read-back per batch) must leave
+"""Device-driven CG / BiCGSTAB / BiCG / GMRES(m) (scalars in HBM, iterations enqueued in batches, one read-back per batch) must leave
 exactly what the host-scalar loops leave: iteration count, status, residual, every residual-history entry and
 every bit of x (the unfused loops group their reductions differently and are compared by the golden-vector tests instead) --
 whatever the position of the converged iteration inside a batch of 16, for every way a loop
@@ -58,7 +58,7 @@ def same(outs):
     return a
 
 
-@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg"])
+@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg", "gmres -restart 7", "gmres -restart 30"])
 @pytest.mark.parametrize("precon", ["none", "jacobi"])
 @pytest.mark.parametrize("fmt", ["csr", "ell", "dia", "jad", "bsr", "csc"])
 def test_bits_match_host_loops(lib, solver, precon, fmt):
@@ -69,7 +69,7 @@ def test_bits_match_host_loops(lib, solver, precon, fmt):
     assert a["status"] == 0 and a["iter"] > 16
 
 
-@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg"])
+@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg", "gmres -restart 6", "gmres"])
 @pytest.mark.parametrize("maxiter", [0, 1, 5, 15, 16, 17, 31, 32, 33])
 def test_maxiter_at_every_batch_position(lib, solver, maxiter):
     ptr, idx, val = orc.poisson3d(14, 13, 9)
@@ -78,7 +78,7 @@ def test_maxiter_at_every_batch_position(lib, solver, maxiter):
     assert a["status"] != 0 and a["iter"] == maxiter + 1
 
 
-@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg"])
+@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg", "gmres -restart 5", "gmres -restart 40"])
 @pytest.mark.parametrize("tol", ["1e-1", "1e-2", "1e-3", "1e-4", "1e-5", "1e-6", "1e-7", "1e-8", "1e-9", "1e-10", "1e-11"])
 def test_converged_iteration_anywhere_in_a_batch(lib, solver, tol):
     ptr, idx, val = orc.poisson3d(20, 9, 8) if solver == "cg" else nonsym(11)
@@ -93,7 +93,7 @@ def test_converged_iteration_anywhere_in_a_batch(lib, solver, tol):
 def test_convergence_conditions(lib, cond):
     ptr, idx, val = nonsym(2)
     b = np.random.default_rng(7).uniform(-1, 1, len(ptr) - 1)
-    for solver in ("cg", "bicgstab", "bicg"):
+    for solver in ("cg", "bicgstab", "bicg", "gmres -restart 9"):
         if solver == "cg":
             p, i, v = orc.poisson3d(11, 10, 9)
             bb = b[: len(p) - 1]

@@ -473,7 +473,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
                 vv[u] = valL[off + j];
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) xx[u] = NOGATHER ? (double)cc[u] : x[cc[u]];   // NOGATHER: ablation, wrong results
+            for (int u = 0; u < U; u++) xx[u] = NOGATHER ? x[cc[u] & 4095] : x[cc[u]];   // NOGATHER: ablation (all gathers hit one 32 KiB window), wrong results
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const double t = vv[u] * xx[u];

@@ -205,6 +205,9 @@ CODED_CASES = {
     "p3d_20x17x13": (lambda: orc.poisson3d(20, 17, 13), 7),
     "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
     "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
+    "p3d_40_sorted": (lambda: orc.poisson3d(40, 40, 40, sort_cols=True), 7),                # several row blocks
+    "p3d_odd_33x7x5": (lambda: orc.poisson3d(33, 7, 5), 7),                                 # odd number of columns
+    "band_neighbours": (lambda: banded(9000, [-3, -2, -1, 0, 1, 2, 700, 701, -4000], 6), 9),
     "diagonals_255": (lambda: cyclic_diagonals(6000, 255, 2), 255),
     "diagonals_300": (lambda: cyclic_diagonals(6000, 300, 3), 0),                           # too many diagonals
     "band_ghost_columns": (lambda: banded(4000, [-2, 0, 5, 3000, 4100], 4, ncols=8200), 5),      # columns beyond n

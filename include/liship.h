@@ -104,6 +104,14 @@ int  liship_spmv_csr_set_variant(int variant);
 /* ELL / DIA products with the reduction epilogue of liship_spmv_csr_dot_f64 (same contract and fallback rule) */
 int  liship_spmv_ell_dot_f64(int n, int maxnzr, const int *index, const double *value, const double *x, double *y,
                              const double *w, int want_sumsq, double *result, void *work, void *stream);
+/* ELL index coding (as liship_csr_plan_encode_indices): *codes / *dict are allocated on the device when the n*maxnzr
+ * slots (padding included) sit on <= 255 diagonals and n is even, else stay NULL; free them with liship_free.
+ * liship_spmv_ell_coded_f64: the ELL product from value + codes (9 B per slot), want_sumsq < 0 for the plain product,
+ * 0 / 1 for the reduction epilogue of liship_spmv_ell_dot_f64; bit-identical to the 4 B-index kernels. */
+int  liship_ell_encode_indices(int n, int maxnzr, const int *index, unsigned char **codes, int **dict, int *ndict, void *stream);
+int  liship_spmv_ell_coded_f64(int n, int maxnzr, const unsigned char *codes, const int *dict, const double *value,
+                               const double *x, double *y, const double *w, int want_sumsq, double *result,
+                               void *work, void *stream);
 int  liship_spmv_dia_dot_f64(int n, int ncols, int nnd, const int *offsets, const double *value, const double *x, double *y,
                              const double *w, int want_sumsq, double *result, void *work, void *stream);
 /* ------------------------------------------------------------------ other formats

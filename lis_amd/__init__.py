@@ -65,6 +65,8 @@ _LISHIP = {
     "liship_spmv_dia_dot_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "liship_spmv_jad_f64": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_spmv_bsr_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_ell_encode_indices": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "liship_spmv_ell_coded_f64": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "liship_spmv_bsr_dot_f64": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "liship_spmv_bsr_nnz_f64": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_axpy_f64": (_ci, [_ci, _cd, _vp, _vp, _vp]),

@@ -322,6 +322,10 @@ LIS_INT lisd_mat_ready(LIS_MATRIX A)
 		d->maxnzr = A->maxnzr;
 		LISCHK(up_i(&d->index, A->index, n * (size_t)A->maxnzr));
 		LISCHK(up_d(&d->value, A->value, n * (size_t)A->maxnzr));
+		if (!lisg.no_index_codes) {
+			int nd = 0;
+			HIPCHK(liship_ell_encode_indices(A->n, A->maxnzr, d->index, &d->ell_codes, &d->ell_dict, &nd, lisg.stream));
+		}
 		break;
 	case LIS_MATRIX_DIA:
 		d->nnd = A->nnd;
@@ -354,6 +358,7 @@ void lisd_mat_free(LIS_MATRIX A)
 	if (d->plan) (void)liship_csr_plan_destroy(d->plan);
 	if (d->t_plan) (void)liship_csr_plan_destroy(d->t_plan);
 	(void)liship_free(d->t_ptr); (void)liship_free(d->t_index); (void)liship_free(d->t_value); (void)liship_free(d->wr);
+	(void)liship_free(d->ell_codes); (void)liship_free(d->ell_dict);
 	(void)liship_free(d->ptr); (void)liship_free(d->index); (void)liship_free(d->row);
 	(void)liship_free(d->bptr); (void)liship_free(d->bindex); (void)liship_free(d->value);
 	(void)liship_free(d->export_index); (void)liship_free(d->ws);
@@ -399,6 +404,11 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));
 		break;
 	case LIS_MATRIX_ELL:
+		if (d->ell_codes) {
+			int rc = liship_spmv_ell_coded_f64(d->n, d->maxnzr, d->ell_codes, d->ell_dict, d->value, dx, dy, NULL, -1, NULL, NULL, lisg.stream);
+			if (rc == 0) break;
+			if (rc != LISHIP_ERR_ARG) HIPCHK(rc);
+		}
 		HIPCHK(liship_spmv_ell_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, lisg.stream));
 		break;
 	case LIS_MATRIX_DIA:
@@ -463,7 +473,9 @@ LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const doub
 		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));
 	} else if ((d->type == LIS_MATRIX_ELL || d->type == LIS_MATRIX_DIA) && !lisg.no_fusion) {
 		if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
-		int rc = (d->type == LIS_MATRIX_ELL)
+		int rc = (d->type == LIS_MATRIX_ELL && d->ell_codes)
+			? liship_spmv_ell_coded_f64(d->n, d->maxnzr, d->ell_codes, d->ell_dict, d->value, dx, dy, dw, want_sumsq ? 1 : 0, result, lisg.reduce_work, lisg.stream)
+			: (d->type == LIS_MATRIX_ELL)
 			? liship_spmv_ell_dot_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, dw, want_sumsq, result, lisg.reduce_work, lisg.stream)
 			: liship_spmv_dia_dot_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, dw, want_sumsq, result, lisg.reduce_work, lisg.stream);
 		if (rc == 0) return LIS_SUCCESS;

@@ -56,6 +56,8 @@ typedef struct {
 	int *ptr, *index, *row, *bptr, *bindex;
 	double *value;
 	liship_csr_plan_t plan;
+	unsigned char *ell_codes;  /* ELL: one-byte column codes + dictionary when the matrix allows it (liship_ell_encode_indices) */
+	int *ell_dict;
 	/* A^T as a CSR in the reference's scatter order (lis_matvech.c), built on the first lis_matvech */
 	int t_ready, t_rows, t_nnz;
 	int *t_ptr, *t_index;

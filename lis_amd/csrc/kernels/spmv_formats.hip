@@ -29,14 +29,22 @@ __device__ __forceinline__ void publish(double c0, double c1, double *__restrict
     }
 }
 
-template <int ROWS, int UNROLL, int DOT = 0>
+// CODED: one byte per column index (position of column - row in a sorted dictionary of <= 255 offsets, as for CSR:
+// liship_ell_encode_indices), 9 B per slot instead of 12; same lanes, same rows, same order -> same bits.
+template <int ROWS, int UNROLL, int DOT = 0, bool CODED = false>
 __global__ __launch_bounds__(BLOCK)
 void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const double *__restrict__ val,
                      const double *__restrict__ x, double *__restrict__ y,
                      const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                     const double *__restrict__ guard = nullptr)
+                     const double *__restrict__ guard = nullptr,
+                     const unsigned char *__restrict__ codes = nullptr, const int *__restrict__ dict = nullptr)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    __shared__ int dictL[CODED ? 256 : 1];
+    if (CODED) {
+        for (int i = threadIdx.x; i < 256; i += BLOCK) dictL[i] = dict[i];
+        __syncthreads();
+    }
     const int r0 = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
     const bool active = r0 < n;
     if (!DOT && !active) return;
@@ -53,8 +61,14 @@ void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const doubl
             const size_t k = (size_t)j * (size_t)n + (size_t)r;
             if (ROWS == 2) {
                 const v2f64 vv = load_stream(reinterpret_cast<const v2f64 *>(val + k));
-                const v2i32 cc = load_stream(reinterpret_cast<const v2i32 *>(idx + k));
-                v[u][0] = vv.x; v[u][ROWS - 1] = vv.y; c[u][0] = cc.x; c[u][ROWS - 1] = cc.y;
+                v[u][0] = vv.x; v[u][ROWS - 1] = vv.y;
+                if (CODED) {
+                    const unsigned short two = load_stream(reinterpret_cast<const unsigned short *>(codes + k));
+                    c[u][0] = r + dictL[two & 255]; c[u][ROWS - 1] = r + 1 + dictL[two >> 8];
+                } else {
+                    const v2i32 cc = load_stream(reinterpret_cast<const v2i32 *>(idx + k));
+                    c[u][0] = cc.x; c[u][ROWS - 1] = cc.y;
+                }
             } else { v[u][0] = load_stream(val + k); c[u][0] = load_stream(idx + k); }
         }
 #pragma unroll
@@ -492,6 +506,102 @@ extern "C" int liship_spmv_dia_f64(int n, int ncols, int nnd, const int *off, co
         spmv_dia_kernel<1, 8><<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y);
     LAUNCH_CHECK();
     return 0;
+}
+
+// ---- ELL index coding (see spmv_csr.hip "coded indices"): the offsets column - row of all n*maxnzr slots, padding
+// slots included (they point at their own row: offset 0)
+namespace {
+constexpr int ELL_TABLE = 1024, ELL_EMPTY = -2147483647 - 1;
+__global__ void ell_collect_offsets(int n, long long slots, const int *__restrict__ idx, int *__restrict__ table, int *__restrict__ count)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= slots || count[0] > 255) return;
+    const int off = idx[k] - (int)(k % n);
+    unsigned h = ((unsigned)off * 2654435761u) >> 22;
+    for (int probe = 0; probe < ELL_TABLE; probe++) {
+        const int v = table[h];
+        if (v == off) return;
+        if (v == ELL_EMPTY) {
+            const int old = atomicCAS(&table[h], ELL_EMPTY, off);
+            if (old == ELL_EMPTY) { atomicAdd(count, 1); return; }
+            if (old == off) return;
+        }
+        h = (h + 1) & (ELL_TABLE - 1);
+        if (count[0] > 255) return;
+    }
+}
+__global__ void ell_encode(int n, long long slots, const int *__restrict__ idx, const int *__restrict__ dict, int ndict,
+                           unsigned char *__restrict__ codes)
+{
+    __shared__ int d[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) d[i] = dict[i];
+    __syncthreads();
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= slots) return;
+    const int off = idx[k] - (int)(k % n);
+    int lo = 0, hi = ndict - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (d[mid] < off) lo = mid + 1; else hi = mid; }
+    codes[k] = (unsigned char)lo;
+}
+} // namespace
+
+// *codes (n*maxnzr bytes) and *dict (256 ints) are allocated on the device when the matrix qualifies (<= 255 distinct
+// offsets, even n, 16 B aligned arrays), else left NULL; the caller frees them with liship_free.  Setup-time.
+extern "C" int liship_ell_encode_indices(int n, int maxnzr, const int *idx, unsigned char **codes, int **dict, int *ndict, void *stream)
+{
+    if (!codes || !dict || !ndict || n < 0 || maxnzr < 0) return LISHIP_ERR_ARG;
+    *codes = nullptr; *dict = nullptr; *ndict = 0;
+    if (n == 0 || maxnzr == 0 || (n & 1) || !idx) return 0;
+    hipStream_t st = as_stream(stream);
+    const long long slots = (long long)n * maxnzr;
+    int *table = nullptr, host[ELL_TABLE + 1];
+    HIP_TRY(hipMalloc(&table, sizeof(host)));
+    for (int i = 0; i < ELL_TABLE; i++) host[i] = ELL_EMPTY;
+    host[ELL_TABLE] = 0;
+    hipError_t e = hipMemcpyAsync(table, host, sizeof(host), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) { ell_collect_offsets<<<(unsigned)((slots + 255) / 256), 256, 0, st>>>(n, slots, idx, table, table + ELL_TABLE); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, table, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(table);
+    if (e != hipSuccess) return (int)e;
+    if (host[ELL_TABLE] > 255) return 0;
+    int d[256], nd = 0;
+    for (int i = 0; i < ELL_TABLE; i++) if (host[i] != ELL_EMPTY && nd < 256) d[nd++] = host[i];
+    if (nd == 0 || nd > 255) return 0;
+    for (int i = 1; i < nd; i++) { const int v = d[i]; int j = i - 1; while (j >= 0 && d[j] > v) { d[j + 1] = d[j]; j--; } d[j + 1] = v; }
+    for (int i = nd; i < 256; i++) d[i] = d[nd - 1];
+    e = hipMalloc(dict, sizeof(d));
+    if (e == hipSuccess) e = hipMalloc(codes, (size_t)slots + 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(*dict, d, sizeof(d), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) { ell_encode<<<(unsigned)((slots + 255) / 256), 256, 0, st>>>(n, slots, idx, *dict, nd, *codes); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { if (*codes) (void)hipFree(*codes); if (*dict) (void)hipFree(*dict); *codes = nullptr; *dict = nullptr; return (int)e; }
+    *ndict = nd;
+    return 0;
+}
+
+// y = A x from the coded form; want_sumsq < 0: no reduction, else the epilogue of liship_spmv_ell_dot_f64
+extern "C" int liship_spmv_ell_coded_f64(int n, int maxnzr, const unsigned char *codes, const int *dict, const double *val,
+                                         const double *x, double *y, const double *w, int want_sumsq, double *result,
+                                         void *work, void *stream)
+{
+    if (n <= 0 || maxnzr <= 0 || !codes || !dict) return LISHIP_ERR_ARG;
+    if ((n & 1) || !aligned16(val) || !aligned16(y) || (reinterpret_cast<uintptr_t>(codes) & 1u)) return LISHIP_ERR_ARG;
+    const int grid = grid_for(n / 2);
+    hipStream_t st = as_stream(stream);
+    if (want_sumsq < 0) {
+        spmv_ell_kernel<2, 8, 0, true><<<grid, BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, nullptr, nullptr, nullptr, codes, dict);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (!w || !result || !work) return LISHIP_ERR_ARG;
+    const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
+    if ((size_t)grid > slots) return LISHIP_ERR_ARG;
+    double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
+    if (want_sumsq) spmv_ell_kernel<2, 8, 2, true><<<grid, BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, w, partial, liship_internal_guard(), codes, dict);
+    else            spmv_ell_kernel<2, 8, 1, true><<<grid, BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, w, partial, liship_internal_guard(), codes, dict);
+    LAUNCH_CHECK();
+    return liship_internal_fold(grid, want_sumsq ? 2 : 1, grid, partial, spare, result, stream);
 }
 
 // ELL / DIA products with the reduction epilogue of liship_spmv_csr_dot_f64 (same contract: LISHIP_ERR_ARG when the

@@ -650,6 +650,49 @@ def test_csr_transpose_in_scatter_order(lib, name):
         assert np.array_equal(tidx.to_host(nnz), rows[order]) and np.array_equal(tval.to_host(nnz), val[order])
 
 
+ELL_CODED_CASES = {
+    "p3d_20x17x14": (lambda: orc.poisson3d(20, 17, 14, sort_cols=True), True),
+    "p3d_8": (lambda: orc.poisson3d(8, 8, 8), True),
+    "p3d_odd_33x5x3": (lambda: orc.poisson3d(33, 5, 3), False),                 # odd n: not coded
+    "band": (lambda: banded(6000, [-900, -2, -1, 0, 1, 2, 40, 900], 8), True),
+    "random": (lambda: orc.random_csr(3000, 9, seed=6, empty_rows=False), False),   # too many diagonals
+}
+
+
+@pytest.mark.parametrize("name", list(ELL_CODED_CASES))
+def test_spmv_ell_index_codes(lib, name):
+    """ELL with one-byte column codes: coded exactly when it can be, and then the plain product and both reduction
+    epilogues return the bits of the 4 B-index kernels (y AND sums: same lanes, same rows, same order)"""
+    make, want = ELL_CODED_CASES[name]
+    ptr, idx, val = make()
+    n = len(ptr) - 1
+    mx, eidx, ev = orc.csr2ell(ptr, idx, val)
+    rng = np.random.default_rng(41)
+    x, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    yref = orc.spmv_ell(n, mx, eidx, ev, x)
+    di, dv, dx, dw = DA.from_host(eidx, np.int32), DA.from_host(ev), DA.from_host(x), DA.from_host(w)
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    codes, dic, nd = C.c_void_p(), C.c_void_p(), C.c_int()
+    check(lib.liship_ell_encode_indices(n, mx, di.ptr, C.byref(codes), C.byref(dic), C.byref(nd), None))
+    assert bool(codes.value) == want, (nd.value, want)
+    if not codes.value:
+        return
+    offsets = set((eidx.reshape(mx, n) - np.arange(n)[None, :]).ravel().tolist())
+    assert nd.value == len(offsets)
+    dy = DA.from_host(np.full(n, np.nan))
+    check(lib.liship_spmv_ell_coded_f64(n, mx, codes, dic, dv.ptr, dx.ptr, dy.ptr, None, -1, None, None, None))
+    assert np.array_equal(dy.to_host(), yref)
+    for sq in (0, 1):
+        r1, r2 = DA.from_host(np.full(2, np.nan)), DA.from_host(np.full(2, np.nan))
+        dy = DA.from_host(np.full(n, np.nan))
+        check(lib.liship_spmv_ell_coded_f64(n, mx, codes, dic, dv.ptr, dx.ptr, dy.ptr, dw.ptr, sq, r1.ptr, work.ptr, None))
+        assert np.array_equal(dy.to_host(), yref)
+        check(lib.liship_spmv_ell_dot_f64(n, mx, di.ptr, dv.ptr, dx.ptr, dy.ptr, dw.ptr, sq, r2.ptr, work.ptr, None))
+        assert np.array_equal(r1.to_host()[:1 + sq], r2.to_host()[:1 + sq])
+    check(lib.liship_free(codes))
+    check(lib.liship_free(dic))
+
+
 @pytest.mark.parametrize("fmt", ["ell", "dia"])
 @pytest.mark.parametrize("want_sumsq", [0, 1])
 @pytest.mark.parametrize("grid", [(20, 17, 14), (8, 8, 8), (33, 5, 2)])

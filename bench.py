@@ -264,12 +264,20 @@ def usable_cores():
 
 def cpu_baseline(np):
     """The reference's OpenMP CSR SpMV (oracle/_ref = Lis 2.1.11 compiled from its own sources) on this box's host
-    cores, on a bounded sample: 256^3 rows of the same stencil (1/8 of the 512^3 workload), 10 products.
+    cores, on a bounded sample: 256^3 rows of the same stencil (1/8 of the 512^3 workload), 40 products.
     Falls back to the oracle's scalar C port when oracle/_ref is not in the snapshot."""
     import lisdrv
     import orc
-    Nc, reps = 256, 10
+    Nc, reps = 256, 40
     cores = usable_cores()
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     try:
         ptr, idx, val = orc.poisson3d(Nc, Nc, Nc)
         n = Nc ** 3
@@ -291,7 +299,7 @@ def cpu_baseline(np):
                 orc.spmv_csr(ptr, idx, val, x)
             el = time.perf_counter() - t0
             kind, used = "port", 1
-        return {"value": round(2.0 * len(idx) * reps / el / 1e9, 3), "unit": "GFLOP/s", "cores": used, "kind": kind,
+        return {"value": round(2.0 * len(idx) * reps / el / 1e9, 3), "unit": "GFLOP/s", "cores": used, "kind": kind, "cpu_model": model,
                 "sample": f"{reps} CSR SpMV on the {Nc}^3 stencil matrix (1/8 of the workload's rows), lis_matvec of Lis 2.1.11 with OpenMP"
                 if kind == "reference" else f"{reps} CSR SpMV on the {Nc}^3 stencil matrix, scalar C port (oracle/lis_oracle.c)"}
     except Exception as e:                                 # the baseline must never sink the bench line

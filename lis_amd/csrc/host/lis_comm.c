@@ -85,7 +85,7 @@ LIS_INT lis_amd_comm_init_rccl(const void *id128, LIS_INT rank, LIS_INT nprocs, 
 	NCCLCHK(rccl.CommInitRank(&c, nprocs, id, rank));
 	lisg.nccl_comm = c;
 	lisg.rank = rank; lisg.nprocs = nprocs;
-	HIPCHK(liship_malloc((void **)&lisg.gather_out, sizeof(double) * 4 * (size_t)nprocs));
+	HIPCHK(lisd_malloc((void **)&lisg.gather_out, sizeof(double) * 4 * (size_t)nprocs));
 	return LIS_SUCCESS;
 }
 
@@ -122,7 +122,7 @@ LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes)
 	if (lisg.comm_kind == 2) return lisg.cb.allgather(lisg.cb.ctx, send, recv, bytes) ? LIS_ERR_NOT_IMPLEMENTED : LIS_SUCCESS;
 	if (lisg.comm_kind == 1) {                  /* setup-time only: stage through HBM */
 		void *ds = NULL, *dr = NULL;
-		HIPCHK(liship_malloc(&ds, bytes)); HIPCHK(liship_malloc(&dr, bytes * (size_t)lisg.nprocs));
+		HIPCHK(lisd_malloc(&ds, bytes)); HIPCHK(lisd_malloc(&dr, bytes * (size_t)lisg.nprocs));
 		HIPCHK(liship_memcpy_h2d(ds, send, bytes, lisg.stream));
 		NCCLCHK(rccl.AllGather(ds, dr, bytes, NCCL_INT8, lisg.nccl_comm, lisg.stream));
 		HIPCHK(liship_memcpy_d2h(recv, dr, bytes * (size_t)lisg.nprocs, lisg.stream));
@@ -301,9 +301,9 @@ static LIS_INT halo_tables_ready(LIS_MATRIX A)
 	if (d->halo_ready) return LIS_SUCCESS;
 	LIS_COMMTABLE t = A->commtable;
 	if (t->exnnz > 0) {
-		HIPCHK(liship_malloc((void **)&d->export_index, sizeof(int) * (size_t)t->exnnz));
+		HIPCHK(lisd_malloc((void **)&d->export_index, sizeof(int) * (size_t)t->exnnz));
 		HIPCHK(liship_memcpy_h2d(d->export_index, t->export_index, sizeof(int) * (size_t)t->exnnz, lisg.stream));
-		HIPCHK(liship_malloc((void **)&d->ws, sizeof(double) * (size_t)t->exnnz));
+		HIPCHK(lisd_malloc((void **)&d->ws, sizeof(double) * (size_t)t->exnnz));
 		HIPCHK(liship_stream_synchronize(lisg.stream));
 	}
 	d->halo_ready = 1;
@@ -400,7 +400,7 @@ LIS_INT lisc_reduce_device(LIS_MATRIX A, double *dy)
 	if (!t || t->neibpetot == 0) return LIS_SUCCESS;
 	LISCHK(halo_tables_ready(A));
 	const LIS_INT n = A->n, pad = t->pad;
-	if (!d->wr) HIPCHK(liship_malloc((void **)&d->wr, sizeof(double) * (size_t)(t->exnnz > 0 ? t->exnnz : 1)));
+	if (!d->wr) HIPCHK(lisd_malloc((void **)&d->wr, sizeof(double) * (size_t)(t->exnnz > 0 ? t->exnnz : 1)));
 	if (lisg.comm_kind == 1) {
 		NCCLCHK(rccl.GroupStart());
 		for (LIS_INT i = 0; i < t->neibpetot; i++) {

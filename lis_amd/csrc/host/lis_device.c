@@ -45,8 +45,8 @@ LIS_INT lisd_init(void)
 	}
 	HIPCHK(liship_set_device(lisg.device));
 	HIPCHK(liship_stream_create(&lisg.stream));
-	HIPCHK(liship_malloc(&lisg.reduce_work, liship_reduce_work_bytes()));
-	HIPCHK(liship_malloc((void **)&lisg.reduce_out, 4 * sizeof(double)));
+	HIPCHK(lisd_malloc(&lisg.reduce_work, liship_reduce_work_bytes()));
+	HIPCHK(lisd_malloc((void **)&lisg.reduce_out, 4 * sizeof(double)));
 	HIPCHK(liship_malloc_host((void **)&lisg.host_out, 4 * 64 * sizeof(double)));
 	lisg.device_ready = 1;
 	return LIS_SUCCESS;
@@ -60,13 +60,20 @@ LIS_INT lisd_init(void)
 #define POOL_SLOTS 160
 static struct { void *p; size_t bytes; } pool[POOL_SLOTS];
 
+/* every HBM allocation of the host layer: when the driver is out of memory the pooled work vectors (up to 33 GiB
+ * after a GMRES(30) solve at 512^3) go back to it and the request is tried once more.  Returns the HIP code. */
+int lisd_malloc(void **out, size_t bytes)
+{
+	int rc = liship_malloc(out, bytes);
+	if (rc && lis_amd_trim_count() > 0) rc = liship_malloc(out, bytes);
+	return rc;
+}
+
 LIS_INT lisd_pool_get(size_t bytes, void **out)
 {
 	for (int i = 0; i < POOL_SLOTS; i++)
 		if (pool[i].p && pool[i].bytes == bytes) { *out = pool[i].p; pool[i].p = NULL; return LIS_SUCCESS; }
-	int rc = liship_malloc(out, bytes);
-	if (rc) { lis_amd_trim(); rc = liship_malloc(out, bytes); }
-	HIPCHK(rc);
+	HIPCHK(lisd_malloc(out, bytes));
 	return LIS_SUCCESS;
 }
 
@@ -78,12 +85,15 @@ void lisd_pool_put(void *p, size_t bytes)
 	(void)liship_free(p);
 }
 
-LIS_INT lis_amd_trim(void)
+/* gives the pooled buffers back; returns how many there were */
+int lis_amd_trim_count(void)
 {
+	int freed = 0;
 	for (int i = 0; i < POOL_SLOTS; i++)
-		if (pool[i].p) { (void)liship_free(pool[i].p); pool[i].p = NULL; pool[i].bytes = 0; }
-	return LIS_SUCCESS;
+		if (pool[i].p) { (void)liship_free(pool[i].p); pool[i].p = NULL; pool[i].bytes = 0; freed++; }
+	return freed;
 }
+LIS_INT lis_amd_trim(void) { (void)lis_amd_trim_count(); return LIS_SUCCESS; }
 
 void *lis_amd_stream(void) { return lisd_init() == LIS_SUCCESS ? lisg.stream : NULL; }
 
@@ -121,7 +131,7 @@ LIS_INT lisd_vec_reserve(LIS_VECTOR v, size_t doubles)
 	if (d->d && d->cap >= doubles) return LIS_SUCCESS;
 	const size_t cap = doubles + 16;                      /* slack: BSR kernels read/write whole blocks */
 	void *nd = NULL;
-	HIPCHK(liship_malloc(&nd, cap * sizeof(double)));
+	HIPCHK(lisd_malloc(&nd, cap * sizeof(double)));
 	HIPCHK(liship_memset(nd, 0, cap * sizeof(double), lisg.stream));
 	if (d->d) {
 		if (d->dev_valid) HIPCHK(liship_memcpy_d2d(nd, d->d, d->cap * sizeof(double), lisg.stream));
@@ -192,7 +202,7 @@ LIS_INT lis_amd_vector_device_ptr(LIS_VECTOR v, LIS_SCALAR **dptr) { return lisd
 static LIS_INT up_i(int **dst, const int *src, size_t count)
 {
 	void *p = NULL;
-	HIPCHK(liship_malloc(&p, (count + 4) * sizeof(int)));          /* +4: 16 B slack for vector loads */
+	HIPCHK(lisd_malloc(&p, (count + 4) * sizeof(int)));          /* +4: 16 B slack for vector loads */
 	if (count) HIPCHK(liship_memcpy_h2d(p, src, count * sizeof(int), lisg.stream));
 	*dst = (int *)p;
 	return LIS_SUCCESS;
@@ -200,7 +210,7 @@ static LIS_INT up_i(int **dst, const int *src, size_t count)
 static LIS_INT up_d(double **dst, const double *src, size_t count)
 {
 	void *p = NULL;
-	HIPCHK(liship_malloc(&p, (count + 2) * sizeof(double)));
+	HIPCHK(lisd_malloc(&p, (count + 2) * sizeof(double)));
 	if (count) HIPCHK(liship_memcpy_h2d(p, src, count * sizeof(double), lisg.stream));
 	*dst = (double *)p;
 	return LIS_SUCCESS;
@@ -211,8 +221,15 @@ static LIS_INT up_d(double **dst, const double *src, size_t count)
  * (liship.h "index coding"; LIS_AMD_NO_INDEX_CODES=1 keeps the 4 B indices for A/B measurements) */
 LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex)
 {
-	HIPCHK(liship_csr_plan_create(plan, n, dptr, lisg.stream));
-	if (!lisg.no_index_codes) HIPCHK(liship_csr_plan_encode_indices(*plan, dptr, dindex, lisg.stream));
+	int rc = liship_csr_plan_create(plan, n, dptr, lisg.stream);
+	if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_create(plan, n, dptr, lisg.stream);   /* the plan allocates in the kernel layer */
+	HIPCHK(rc);
+	if (!lisg.no_index_codes) {
+		/* the codes are an optimisation: a matrix that cannot have them (out of memory included) keeps its 4 B indices */
+		rc = liship_csr_plan_encode_indices(*plan, dptr, dindex, lisg.stream);
+		if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_encode_indices(*plan, dptr, dindex, lisg.stream);
+		if (rc && rc != 2 /* hipErrorOutOfMemory */) HIPCHK(rc);
+	}
 	return LIS_SUCCESS;
 }
 
@@ -296,10 +313,18 @@ static LIS_INT upload_jad_as_csr(LIS_MATRIX A, lisd_mat *d)
 	return err;
 }
 
+static LIS_INT mat_upload(LIS_MATRIX A);
 LIS_INT lisd_mat_ready(LIS_MATRIX A)
 {
+	if (MDEV(A)->ready) return LIS_SUCCESS;
+	const LIS_INT err = mat_upload(A);
+	if (err) lisd_mat_free(A);      /* a half-made HBM copy (arrays up, plan failed ...) must not be uploaded over by the next call */
+	return err;
+}
+
+static LIS_INT mat_upload(LIS_MATRIX A)
+{
 	lisd_mat *d = MDEV(A);
-	if (d->ready) return LIS_SUCCESS;
 	LISCHK(lisd_init());
 	if (A->status < LIS_MATRIX_CSR) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is not assembled\n");
 	if (A->is_splited) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "split (D/L/U) matrices are not served\n");
@@ -323,8 +348,10 @@ LIS_INT lisd_mat_ready(LIS_MATRIX A)
 		LISCHK(up_i(&d->index, A->index, n * (size_t)A->maxnzr));
 		LISCHK(up_d(&d->value, A->value, n * (size_t)A->maxnzr));
 		if (!lisg.no_index_codes) {
-			int nd = 0;
-			HIPCHK(liship_ell_encode_indices(A->n, A->maxnzr, d->index, &d->ell_codes, &d->ell_dict, &nd, lisg.stream));
+			int nd = 0;      /* an optimisation: when it cannot be had (out of memory included) the 4 B indices serve */
+			int rc = liship_ell_encode_indices(A->n, A->maxnzr, d->index, &d->ell_codes, &d->ell_dict, &nd, lisg.stream);
+			if (rc) { (void)liship_free(d->ell_codes); (void)liship_free(d->ell_dict); d->ell_codes = NULL; d->ell_dict = NULL; }
+			if (rc && rc != 2 /* hipErrorOutOfMemory */) HIPCHK(rc);
 		}
 		break;
 	case LIS_MATRIX_DIA:
@@ -438,7 +465,15 @@ LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const doub
 {
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_mat_ready(A));
+	int nblocks = 0;
+	if (d->type == LIS_MATRIX_CSR && d->plan) (void)liship_csr_plan_info(d->plan, NULL, NULL, &nblocks);
+	/* the three parts launch at most nblocks + 2 row blocks (each cut splits one): all of them must find a slot for
+	 * their partial sums BEFORE the first part is launched -- otherwise the plain overlapped product + one dot pass */
+	const int slots_ok = (size_t)nblocks + 2 <= liship_reduce_work_bytes() / sizeof(double) / 4;
 	if (d->type == LIS_MATRIX_CSR && !lisg.no_fusion && lisg.nprocs > 1 && A->commtable && !lisg.no_overlap &&
+	    d->inner_end - d->inner_begin >= d->n / 2 && !slots_ok) {
+		LISCHK(lisd_spmv(A, dx, dy));
+	} else if (d->type == LIS_MATRIX_CSR && !lisg.no_fusion && lisg.nprocs > 1 && A->commtable && !lisg.no_overlap &&
 	    d->inner_end - d->inner_begin >= d->n / 2) {
 		/* as lisd_spmv: interior rows while the halo travels, boundary rows after it; every part parks its
 		 * per-block partial sums, one fold at the end */
@@ -567,9 +602,9 @@ LIS_INT lis_amd_matrix_poisson3d(LIS_MATRIX A, LIS_INT l, LIS_INT m, LIS_INT n, 
 	LISCHK(lisd_init());
 	const LIS_INT nloc = A->n, nlow = A->is > 0 ? (LIS_INT)mn : 0, nup = A->ie < gn ? (LIS_INT)mn : 0;
 	int *dptr = NULL, *didx = NULL; double *dval = NULL;
-	HIPCHK(liship_malloc((void **)&dptr, sizeof(int) * ((size_t)nloc + 1 + 4)));
-	HIPCHK(liship_malloc((void **)&didx, sizeof(int) * ((size_t)nnz + 4)));
-	HIPCHK(liship_malloc((void **)&dval, sizeof(double) * ((size_t)nnz + 2)));
+	HIPCHK(lisd_malloc((void **)&dptr, sizeof(int) * ((size_t)nloc + 1 + 4)));
+	HIPCHK(lisd_malloc((void **)&didx, sizeof(int) * ((size_t)nnz + 4)));
+	HIPCHK(lisd_malloc((void **)&dval, sizeof(double) * ((size_t)nnz + 2)));
 	HIPCHK(liship_poisson3d_csr(l, m, n, A->is, A->ie, sorted, dptr, didx, dval, lisg.stream));
 	LISCHK(lis_amd_matrix_set_csr_device((LIS_INT)nnz, nloc + nlow + nup, dptr, didx, dval, A));
 	if (A->nprocs > 1) {

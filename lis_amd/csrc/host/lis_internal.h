@@ -118,6 +118,8 @@ LIS_INT lisd_init_quiet(void);                               /* lisd_init withou
 void    lisd_mat_eager(LIS_MATRIX A);                         /* resident mode: upload at assemble / convert time */
 LIS_INT lisd_pool_get(size_t bytes, void **out);              /* HBM buffer of exactly `bytes`, reused across solves */
 void    lisd_pool_put(void *p, size_t bytes);
+int     lisd_malloc(void **out, size_t bytes);                /* liship_malloc that hands the pool back and retries when HBM is full; HIP code */
+int     lis_amd_trim_count(void);                             /* lis_amd_trim(), returning the number of buffers released */
 LIS_INT lisd_mat_ready_t(LIS_MATRIX A);                       /* build / upload the transposed operator */
 LIS_INT lisd_spmv_t(LIS_MATRIX A, double *dx, double *dy);    /* y[0..np) = A^T x, ghost rows reduced to owners */
 LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy);      /* y = A x on device pointers (halo included) */

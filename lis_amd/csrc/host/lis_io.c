@@ -195,6 +195,9 @@ static LIS_INT mm_read_csr(slurp_t *s, const mm_head *h, LIS_MATRIX A, LIS_VECTO
 			}
 		}
 		r--; c--;
+		/* an index outside the matrix would become an x gather index of the HIP kernels (a GPU fault that takes the
+		 * context with it); the reference does not check either, but its out-of-bounds read stays in one process */
+		if (r < 0 || r >= h->nr || c < 0 || c >= h->nr) { err = LISI_ERR(LIS_ERR_FILE_IO, "entry %D: index (%D,%D) is outside the matrix\n", k + 1, (LIS_INT)(r + 1), (LIS_INT)(c + 1)); goto fail; }
 		ri[k] = (int)r; ci[k] = (int)c; va[k] = v;
 		if (h->symmetric && r != c && c >= is && c < ie) ptr[c - is + 1]++;
 		if (r >= is && r < ie) ptr[r - is + 1]++;
@@ -351,7 +354,13 @@ static LIS_INT hb_read(slurp_t *s, LIS_MATRIX A)
 				k++;
 			}
 		}
+		if (!err && k != total) err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error: section %D holds %D of %D fields\n", (LIS_INT)pass, k, total);
 	}
+	if (err) goto fail;
+	/* column pointers monotone and closed, row indices inside the matrix: they become device addresses */
+	if (ptr[0] != 0 || ptr[n] != nnzero) err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error: column pointers do not span the entries\n");
+	for (LIS_INT j = 0; j < n && !err; j++) if (ptr[j + 1] < ptr[j]) err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error: column pointers decrease\n");
+	for (LIS_INT k = 0; k < nnzero && !err; k++) if (index[k] < 0 || index[k] >= n) err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error: row index %D is outside the matrix\n", index[k] + 1);
 	if (err) goto fail;
 	err = lis_matrix_set_csc(nnzero, ptr, index, value, A);
 	if (err) goto fail;

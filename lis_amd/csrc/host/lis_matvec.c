@@ -41,7 +41,7 @@ static void raw_matvec(LIS_MATRIX A, LIS_INT fmt, LIS_SCALAR x[], LIS_SCALAR y[]
 	if (!err && d->scap < nx) {
 		(void)liship_free(d->sx); (void)liship_free(d->sy);
 		d->sx = d->sy = NULL; d->scap = 0;
-		if (liship_malloc((void **)&d->sx, nx * sizeof(double)) || liship_malloc((void **)&d->sy, nx * sizeof(double))) err = LIS_ERR_OUT_OF_MEMORY;
+		if (lisd_malloc((void **)&d->sx, nx * sizeof(double)) || lisd_malloc((void **)&d->sy, nx * sizeof(double))) err = LIS_ERR_OUT_OF_MEMORY;
 		else { d->scap = nx; (void)liship_memset(d->sx, 0, nx * sizeof(double), lisg.stream); }
 	}
 	if (!err && liship_memcpy_h2d(d->sx, x, sizeof(double) * (size_t)(lisg.nprocs > 1 ? A->n : A->np), lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;

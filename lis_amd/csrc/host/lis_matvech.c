@@ -74,7 +74,7 @@ static void walk(LIS_INT type, LIS_MATRIX A, const LIS_INT *ptr, const LIS_INT *
 
 static LIS_INT upload(void **dst, const void *src, size_t bytes)
 {
-	HIPCHK(liship_malloc(dst, bytes + 16));
+	HIPCHK(lisd_malloc(dst, bytes + 16));
 	if (bytes) HIPCHK(liship_memcpy_h2d(*dst, src, bytes, lisg.stream));
 	return LIS_SUCCESS;
 }
@@ -95,10 +95,10 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 		/* CSR: the HBM copy is transposed in HBM (transpose.hip): no host pass, works for matrices born on the device */
 		int *work = NULL;
 		d->t_nnz = d->nnz;
-		HIPCHK(liship_malloc((void **)&d->t_ptr, sizeof(int) * ((size_t)np + 1) + 16));
-		HIPCHK(liship_malloc((void **)&d->t_index, sizeof(int) * (size_t)d->nnz + 16));
-		HIPCHK(liship_malloc((void **)&d->t_value, sizeof(double) * (size_t)d->nnz + 16));
-		HIPCHK(liship_malloc((void **)&work, sizeof(int) * ((size_t)np + (size_t)d->nnz) + 16));
+		HIPCHK(lisd_malloc((void **)&d->t_ptr, sizeof(int) * ((size_t)np + 1) + 16));
+		HIPCHK(lisd_malloc((void **)&d->t_index, sizeof(int) * (size_t)d->nnz + 16));
+		HIPCHK(lisd_malloc((void **)&d->t_value, sizeof(double) * (size_t)d->nnz + 16));
+		HIPCHK(lisd_malloc((void **)&work, sizeof(int) * ((size_t)np + (size_t)d->nnz) + 16));
 		int rc = liship_csr_transpose_f64(n, np, d->nnz, d->ptr, d->index, d->value, d->t_ptr, d->t_index, d->t_value, work, lisg.stream);
 		if (!rc) rc = liship_stream_synchronize(lisg.stream);
 		(void)liship_free(work);
@@ -197,7 +197,7 @@ static void raw_matvech(LIS_MATRIX A, LIS_INT fmt, LIS_SCALAR x[], LIS_SCALAR y[
 	if (!err && d->scap < nx) {
 		(void)liship_free(d->sx); (void)liship_free(d->sy);
 		d->sx = d->sy = NULL; d->scap = 0;
-		if (liship_malloc((void **)&d->sx, nx * sizeof(double)) || liship_malloc((void **)&d->sy, nx * sizeof(double))) err = LIS_ERR_OUT_OF_MEMORY;
+		if (lisd_malloc((void **)&d->sx, nx * sizeof(double)) || lisd_malloc((void **)&d->sy, nx * sizeof(double))) err = LIS_ERR_OUT_OF_MEMORY;
 		else { d->scap = nx; (void)liship_memset(d->sx, 0, nx * sizeof(double), lisg.stream); }
 	}
 	if (!err && liship_memcpy_h2d(d->sx, x, sizeof(double) * (size_t)A->n, lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;

@@ -784,7 +784,7 @@ static LIS_INT run_gmres(ctx_t *c)
 	/* device-chained Gram-Schmidt: in an RCCL job each coefficient is made global on the device as well
 	 * (all-gather + rank-order fold); the callback communicator folds on the host, so it takes the other branch */
 	const int chained = !lisg.no_fusion && (lisg.nprocs == 1 || lisg.comm_kind == 1);
-	if (chained) KTRY(liship_malloc((void **)&hdev, sizeof(double) * (size_t)(m + 4)));
+	if (chained) KTRY(lisd_malloc((void **)&hdev, sizeof(double) * (size_t)(m + 4)));
 	int st = initial_residual(c, v[0]);                /* :193 leaves the unpreconditioned residual in v0 */
 	if (st) { err = st < 0 ? -st : 0; goto done; }
 	while (iter < c->maxiter) {

@@ -16,13 +16,16 @@ char **lisi_cmd_argv = NULL;
 /* ------------------------------------------------------------------ registry of live handles */
 typedef struct { void *obj; int kind; } reg_entry;
 static reg_entry *reg_tab = NULL;
-static size_t reg_cap = 0, reg_len = 0;     /* open addressing, tombstone = (void*)1 */
+static size_t reg_cap = 0, reg_live = 0, reg_used = 0;   /* open addressing, tombstone = (void*)1; used = live + tombstones */
 
 static size_t reg_hash(const void *p, size_t cap) { return (((size_t)p) >> 4) * 0x9E3779B97F4A7C15ULL % cap; }
 
-static void reg_grow(void)
+/* rebuild the table from its live entries: twice the size when they fill half of it, the same size when it is the
+ * tombstones of a long create/destroy history that do (the table follows the LIVE count, not the total ever made) */
+static void reg_rehash(void)
 {
-	size_t ncap = reg_cap ? reg_cap * 2 : 256;
+	size_t ncap = reg_cap ? reg_cap : 256;
+	while ((reg_live + 1) * 2 > ncap) ncap *= 2;
 	reg_entry *nt = (reg_entry *)calloc(ncap, sizeof(reg_entry));
 	for (size_t i = 0; i < reg_cap; i++) {
 		if (reg_tab[i].obj && reg_tab[i].obj != (void *)1) {
@@ -32,28 +35,30 @@ static void reg_grow(void)
 		}
 	}
 	free(reg_tab);
-	reg_tab = nt; reg_cap = ncap;
+	reg_tab = nt; reg_cap = ncap; reg_used = reg_live;
 }
 
 void lisi_register(void *obj, int kind)
 {
-	if ((reg_len + 1) * 2 > reg_cap) reg_grow();
+	if ((reg_used + 1) * 2 > reg_cap) reg_rehash();
 	size_t h = reg_hash(obj, reg_cap);
 	while (reg_tab[h].obj && reg_tab[h].obj != (void *)1) h = (h + 1) % reg_cap;
+	if (!reg_tab[h].obj) reg_used++;           /* a reused tombstone was counted already */
 	reg_tab[h].obj = obj; reg_tab[h].kind = kind;
-	reg_len++;
+	reg_live++;
 }
 
 static reg_entry *reg_find(void *obj)
 {
-	if (!reg_cap || !obj) return NULL;
+	if (!reg_cap || !obj || obj == (void *)1) return NULL;
 	size_t h = reg_hash(obj, reg_cap);
 	for (size_t probes = 0; probes < reg_cap && reg_tab[h].obj; probes++, h = (h + 1) % reg_cap)
 		if (reg_tab[h].obj == obj) return &reg_tab[h];
 	return NULL;
 }
 
-void lisi_unregister(void *obj) { reg_entry *e = reg_find(obj); if (e) { e->obj = (void *)1; } }
+void lisi_unregister(void *obj) { reg_entry *e = reg_find(obj); if (e) { e->obj = (void *)1; reg_live--; } }
+size_t lisi_registry_slots(void) { return reg_cap; }          /* tests: the table must not grow with the create/destroy count */
 int  lisi_is_registered(void *obj) { return reg_find(obj) != NULL; }
 
 /* ------------------------------------------------------------------ allocation (ref:1037-1042)

@@ -20,7 +20,12 @@ extern "C" int liship_device_name(char *buf, int buflen)
     return 0;
 }
 
-extern "C" int liship_malloc(void **dptr, size_t bytes) { HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16)); return 0; }
+extern "C" int liship_malloc(void **dptr, size_t bytes)
+{
+    const hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) { (void)hipGetLastError(); *dptr = nullptr; }   // the caller may retry: do not leave the code for the next launch check
+    return (int)e;
+}
 extern "C" int liship_free(void *dptr) { if (dptr) HIP_TRY(hipFree(dptr)); return 0; }
 extern "C" int liship_memset(void *dptr, int byte, size_t bytes, void *stream)
 { if (bytes) HIP_TRY(hipMemsetAsync(dptr, byte, bytes, as_stream(stream))); return 0; }

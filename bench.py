@@ -11,8 +11,10 @@ liblis_amd.so (x = 1, as test/spmvtest3.c).  With N > 1 the matrix is row-block 
 (LIS_GET_ISIE: 512/N grid planes each, STRONG scaling: the global problem is fixed) and every step does the
 halo exchange over RCCL (ncclSend/ncclRecv of one plane per neighbour) before the local product.
 Reported: value = global SpMV GFLOP/s = 2*nnz*K / t (reference convention, test/spmvtest1.c:225), the
-roofline fraction of the dominant kernel from HIP events on the library's stream, CG+Jacobi and BiCGSTAB
-iterations/s on the same matrix, and the reference's own OpenMP CPU path timed on this box's host cores.
+roofline fraction of the dominant kernel from HIP events on the library's stream, Krylov iterations/s on the
+same matrix as the reference defines them -- iter / itime of lis_solver_get_timeex (src/solver/lis_solver.c:
+902-908) over --solver-iters iterations -- each with its own roofline, and the reference's own
+OpenMP CPU path timed on this box's host cores.
 """
 import argparse
 import ctypes as C
@@ -35,7 +37,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=512, help="cubic grid edge (BASELINE: 512)")
-    ap.add_argument("--solver-iters", type=int, default=60, help="Krylov iterations timed for the it/s figures")
+    ap.add_argument("--solver-iters", type=int, default=500,
+                    help="Krylov iterations timed for the it/s figures (maxiter of the timed solve; none of the solvers "
+                         "converges earlier at 512^3: CG needs 1504)")
     ap.add_argument("--preroll", type=int, default=600,
                     help="untimed clock-ramp steps before the W warm-up steps: a fresh box's first process measured "
                          "7 %% slower for its first ~second of kernels (DESIGN.md 5); same count on every rank")
@@ -180,10 +184,20 @@ def main():
     alg_bytes = 12 * nnz_local + 20 * n_local + 4        # 12 B per non-zero + 20 B per row
     kernel_ms = ev_ms.value / args.steps
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None                                          # PMC bytes per launch, from the committed rocprofv3 run of this command
-    tf = os.path.join(ROOT, "profiles", "r01_spmv512_traffic.json")
-    if N == 512 and world == 1 and os.path.exists(tf):
-        traffic = json.load(open(tf))["hbm_traffic_bytes_per_launch"]
+    # PMC traffic of the same command (rocprofv3 --pmc passes cannot run inside this process): the newest committed summary,
+    # made by tools/prof.sh + tools/traffic_json.py.  Bytes are counted at the L2 <-> fabric boundary by request size
+    # (TCC_EA0_RDREQ_{32B,64B,128B}, TCC_EA0_WRREQ_{,64B}), so reads served by the 256 MB Infinity Cache are included.
+    traffic, traffic_detail = None, None
+    if N == 512 and world == 1:
+        for tf in ("r02_spmv512_traffic.json", "r01_spmv512_traffic.json"):
+            tf = os.path.join(ROOT, "profiles", tf)
+            if os.path.exists(tf):
+                tj = json.load(open(tf))
+                traffic = tj.get("fabric_bytes_per_launch", tj.get("hbm_traffic_bytes_per_launch"))
+                traffic_detail = {k: tj[k] for k in ("source", "kernel", "level", "read_bytes_per_launch", "write_bytes_per_launch",
+                                                     "x_bytes_per_launch", "x_refetch_factor", "fabric_rate_GBs", "note") if k in tj}
+                traffic_detail["file"] = os.path.relpath(tf, ROOT)
+                break
     # One-byte column codes (the stencil sits on 7 diagonals): the kernel then streams 9 B per non-zero, not
     # the 12 B the contract's algorithmic count prices -- `achieved` / `frac` stay on the contract's bytes, the bytes the
     # kernel is actually asked to move and the fraction of the roofline THEY reach are reported beside them.
@@ -191,13 +205,35 @@ def main():
     coded = int(dll.lis_amd_matrix_index_codes(A))
     moved = (9 if coded else 12) * nnz_local + 20 * n_local + 4
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
                 "kernel": "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel", "kernel_ms": round(kernel_ms, 4),
                 "alg_bytes_per_launch": alg_bytes, "per_gpu": True,
                 "index_codes": coded, "stored_bytes_per_launch": moved,
                 "frac_of_stored_bytes": round(moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
-    # ---- Krylov iterations/s on the same matrix (b = A*1, x0 = 0), whole job
+    # ---- N > 1: what the exchange costs by itself, and the product with the overlap switched off (A/B)
+    multi = None
+    if world > 1:
+        dll.lis_amd_halo_exchange.argtypes = [capi.PM, capi.PV]
+
+        def timed(fn, reps):
+            sync(); barrier()
+            t = time.perf_counter()
+            for _ in range(reps):
+                assert fn() == 0
+            sync(); barrier()
+            el = time.perf_counter() - t
+            tt = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt[0]) / reps * 1e3
+        halo_ms = timed(lambda: dll.lis_amd_halo_exchange(A, x), args.steps)
+        dll.lis_amd_set_overlap(0)
+        serial_ms = timed(lambda: lib.lis_matvec(A, x, y), args.steps)
+        dll.lis_amd_set_overlap(1)
+        multi = {"halo_ms_per_step": round(halo_ms, 4), "ms_per_step_no_overlap": round(serial_ms, 4),
+                 "ms_per_step_overlap": round(ms_per_step, 4)}
+
+    # ---- Krylov iterations/s on the same matrix (b = A*1, x0 = 0), whole job: iter / itime as the reference splits it
     solvers = {}
     if not args.no_solvers:
         dll.lis_amd_vector_poisson3d_rhs.argtypes = [capi.PV, C.c_int, C.c_int, C.c_int]
@@ -207,20 +243,35 @@ def main():
                           ("gmres30_none", "-i gmres -restart 30 -p none")):
             S = capi.PS()
             assert lib.lis_solver_create(C.byref(S)) == 0
-            assert lib.lis_solver_set_option(f"{opts} -tol 1e-12 -maxiter {args.solver_iters}".encode(), S) == 0
-            assert lib.lis_solve(A, b, y, S) == 0        # warm-up pass (allocations, first launches)
+            # warm-up pass: work-vector pool, A^T, first launches -- the one-off costs the reference pays in its own setup
+            assert lib.lis_solver_set_option(f"{opts} -tol 1e-12 -maxiter 20".encode(), S) == 0
+            assert lib.lis_solve(A, b, y, S) == 0
+            assert lib.lis_solver_set_option(f"-maxiter {args.solver_iters}".encode(), S) == 0
             sync(); barrier()
             t1 = time.perf_counter()
             assert lib.lis_solve(A, b, y, S) == 0
             sync(); barrier()
-            el = time.perf_counter() - t1
+            wall = time.perf_counter() - t1
+            tm = [C.c_double() for _ in range(5)]           # time, itime, ptime, p_c_time, p_i_time
+            assert lib.lis_solver_get_timeex(S, *[C.byref(t) for t in tm]) == 0
+            itime = tm[1].value
             iters = min(S.contents.iter, args.solver_iters)
             if world > 1:
-                tt = torch.tensor([el], dtype=torch.float64)
+                tt = torch.tensor([itime, wall], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                el = float(tt[0])
-            solvers[key] = {"iters_per_sec": round(iters / el, 2), "iters_timed": iters,
-                            "rel_residual_after": S.contents.resid}
+                itime, wall = float(tt[0]), float(tt[1])
+            loop_b, contract_b = krylov_bytes(key, iters, n_local, nnz_local, coded)
+            sec_per_iter = itime / max(1, iters)
+            solvers[key] = {
+                "iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 4),
+                "lis_solve_wall_s": round(wall, 4), "rel_residual_after": S.contents.resid,
+                # per GPU: bytes one iteration's passes are asked to stream (fused loops, coded indices: DESIGN.md 6)
+                # and the bytes of the reference's unfused operator sequence over the same time
+                "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_gpu": True,
+                             "loop_bytes_per_iter": loop_b, "achieved": round(loop_b / sec_per_iter / 1e9, 1),
+                             "frac": round(loop_b / sec_per_iter / 1e9 / HBM_PEAK_GBS, 4),
+                             "contract_bytes_per_iter": contract_b,
+                             "frac_of_contract_bytes": round(contract_b / sec_per_iter / 1e9 / HBM_PEAK_GBS, 4)}}
             lib.lis_solver_destroy(S)
 
     cpu = None
@@ -238,13 +289,58 @@ def main():
             "roofline": roofline,
             "hbm_roofline_pct_whole_job": round(100.0 * (12 * nnz_global + 20 * n_global) / (ms_per_step * 1e-3) / 1e9
                                                 / (HBM_PEAK_GBS * world), 2),
+            "preroll": args.preroll,          # untimed clock-ramp launches before the W warm-up steps (a cold process: +7 %)
+            "degraded": bool(world > 1 and comm_used != "rccl"),   # True: the RCCL communicator could not be formed, NOT a measurement
+            "rccl_ranks": world if (world > 1 and comm_used == "rccl" and int(dll.lis_amd_comm_kind()) == 1) else (0 if world > 1 else None),
+            "multi_gpu": multi,
             "krylov": solvers,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    degraded = world > 1 and comm_used != "rccl" and args.comm == "rccl"
     if world > 1:
         dll.lis_amd_comm_finalize()
         dist.destroy_process_group()
+    if degraded:
+        sys.exit(3)                   # the line above says "degraded": true; a driver that only looks at the exit code sees it too
+
+
+def krylov_bytes(key, iters, n, nnz, coded):
+    """Bytes per iteration and per GPU: (what the passes of the fused device loops are asked to stream, what the
+    reference's unfused operator sequence moves by SURVEY 8d's count).  n / nnz are the local rows / non-zeros.
+    Product: S = (9 coded | 12) B per non-zero + 20 B per row (ptr, y, compulsory x); contract B = 12 nnz + 20 n.
+    Vector passes: every array a pass reads or writes counts 8 B per row once."""
+    S = (9 if coded else 12) * nnz + 20 * n
+    B = 12 * nnz + 20 * n
+    if key == "cg_jacobi":
+        # p = dinv.*r + beta p (+ the deferred x += alpha p: r dinv p x | p x) ; q = A p with <p,q> (w = p: no extra stream) ;
+        # r -= alpha q, ||r||^2, <r, dinv.*r> (q r dinv | r)
+        return S + CG_VECTOR_BYTES_PER_ROW * n, B + 136 * n
+    if key == "bicgstab_none":
+        # p-update 32 ; v = A p + <rtld,v> (+8: rtld) ; s = r - alpha v, ||s|| 24 ; t = A s + <t,s>,<t,t> ; x += alpha p + omega s 32 ;
+        # r = s - omega t, ||r||, <rtld,r> 32
+        return 2 * S + 128 * n, 2 * B + 248 * n
+    if key == "bicg_none":
+        # two direction updates 24 + 24 ; q = A p + <p~,q> (+8: p~) ; q~ = A^T p~ ; x,r update 48 ; r~ update + rho 32
+        # reference: 2 products, 2 copies (psolve none), 2 dots, 2 xpays, 3 axpys, nrm2 (lis_solver_bicg.c:176-262) = 192 n
+        return 2 * S + 136 * n, 2 * B + 192 * n
+    if key == "gmres30_none":
+        m, loop, contract, done = 30, 0, 0, 0
+        while done < iters:
+            steps = min(m, iters - done)
+            loop += 24 * n                                  # ||v0||, v0 /= ||v0||
+            for i in range(1, steps + 1):
+                # w = A v_{i-1} + <w,v0> (+8), i-1 chained Gram-Schmidt steps (vprev w vnext | w), the last one with ||w||^2, w /= ||w||
+                loop += S + 8 * n + 32 * n * (i - 1) + 24 * n + 16 * n
+                contract += B + 40 * n * i + 40 * n         # SURVEY 8d: B_spmv + 40 n i + 40 n
+            loop += 8 * n * (steps + 1) + 24 * n + 8 * n * (steps + 2)     # z = sum y_j v_j ; x += z ; v0 += sum g_j v_j
+            contract += 16 * n + 24 * n * (steps - 1) + 24 * n + 24 * n * (steps + 1)
+            done += steps
+        return loop // max(1, iters), contract // max(1, iters)
+    raise KeyError(key)
+
+
+CG_VECTOR_BYTES_PER_ROW = 88      # 32 (direction update) + 56 (x, r update with both sums); 80 once x += alpha p is deferred
 
 
 def usable_cores():

@@ -92,6 +92,11 @@ LIS_INT lis_amd_halo_exchange_host(LIS_MATRIX A, LIS_SCALAR x[]);
 LIS_INT lis_amd_comm_finalize(void);
 LIS_INT lis_amd_comm_rank(void);
 LIS_INT lis_amd_comm_size(void);
+LIS_INT lis_amd_comm_kind(void);                       /* 0: no communicator, 1: RCCL, 2: host callbacks */
+/* halo exchange overlapped with the interior rows of a product (default on; env LIS_AMD_NO_OVERLAP=1): for A/B runs */
+LIS_INT lis_amd_set_overlap(LIS_INT on);
+/* one halo exchange of x's ghost entries in HBM, by itself (what a product does before its boundary rows) */
+LIS_INT lis_amd_halo_exchange(LIS_MATRIX A, LIS_VECTOR x);
 
 #ifdef __cplusplus
 }

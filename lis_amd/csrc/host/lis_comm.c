@@ -113,6 +113,17 @@ LIS_INT lis_amd_comm_finalize(void)
 }
 
 LIS_INT lis_amd_comm_rank(void) { return lisg.rank; }
+LIS_INT lis_amd_comm_kind(void) { return lisg.comm_kind; }
+LIS_INT lis_amd_set_overlap(LIS_INT on) { lisg.no_overlap = on ? 0 : 1; return LIS_SUCCESS; }
+/* the halo exchange of one product on its own (pack, send/recv, ghosts landed), for timing it apart from the rows */
+LIS_INT lis_amd_halo_exchange(LIS_MATRIX A, LIS_VECTOR x)
+{
+	double *dx;
+	LISCHK(lisd_mat_ready(A));
+	LISCHK(lisd_vec_in(x, &dx));
+	if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
+	return LIS_SUCCESS;
+}
 LIS_INT lis_amd_comm_size(void) { return lisg.nprocs ? lisg.nprocs : 1; }
 
 /* every rank contributes `bytes`; recv holds nprocs*bytes in rank order (host memory) */

@@ -797,13 +797,15 @@ static LIS_INT run_gmres(ctx_t *c)
 			iter++; i++;
 			ii = i - 1; i1 = i;
 			double *hc = h + (size_t)ii * ld;
-			TRY(d_psolve(c, v[ii], z));
-			if (!chained) TRY(d_matvec(c, z, v[i1]));
+			/* M^-1 v: without a preconditioner the reference copies (lis_precon.c:365-384); the product reads v itself */
+			double *zin = z;
+			if (c->dinv || lisg.no_fusion) TRY(d_psolve(c, v[ii], z)); else zin = v[ii];
+			if (!chained) TRY(d_matvec(c, zin, v[i1]));
 			if (chained) {
 				/* modified Gram-Schmidt with the coefficients kept in HBM: step k reads h[k-1] from the previous
 				 * step's reduction, so the whole column costs ONE host synchronisation instead of i+1; the first
 				 * coefficient <A z, v0> is formed in the product's own pass */
-				TRY(lisd_spmv_dot_launch_to(c->A, z, v[i1], v[0], 0, hdev));
+				TRY(lisd_spmv_dot_launch_to(c->A, zin, v[i1], v[0], 0, hdev));
 				TRY(globalize(hdev, 1));
 				for (int k = 1; k < i; k++) {
 					KTRY(liship_mgs_step_f64(n, hdev + k - 1, v[k - 1], v[i1], v[k], hdev + k, lisg.reduce_work, lisg.stream));
@@ -866,8 +868,10 @@ static LIS_INT run_gmres(ctx_t *c)
 			KTRY(liship_scale_to_f64(n, g[0], v[0], z, lisg.stream));     /* z = y0 v0  (:290-296) */
 			for (int j = 1; j <= ii; j++) KTRY(liship_axpy_f64(n, g[j], v[j], z, lisg.stream));
 		}
-		TRY(d_psolve(c, z, r));
-		KTRY(liship_axpy_f64(n, 1.0, r, c->x, lisg.stream));
+		if (c->dinv || lisg.no_fusion) {
+			TRY(d_psolve(c, z, r));
+			KTRY(liship_axpy_f64(n, 1.0, r, c->x, lisg.stream));
+		} else KTRY(liship_axpy_f64(n, 1.0, z, c->x, lisg.stream));      /* the copy of psolve_none left out: same addend */
 		if (c->tol >= nrm2) { s->retcode = LIS_SUCCESS; s->iter = iter; s->resid = nrm2; goto done; }
 		for (int j = 1; j <= i; j++) {
 			const int jj = i1 - j + 1;

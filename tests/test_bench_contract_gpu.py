@@ -31,5 +31,10 @@ def test_bench_line_has_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
-    for name in ("cg_jacobi", "bicgstab_none", "gmres30_none"):
-        assert d["krylov"][name]["iters_per_sec"] > 0
+    assert d["preroll"] == 5 and d["degraded"] is False and d["rccl_ranks"] is None
+    for name in ("cg_jacobi", "bicgstab_none", "bicg_none", "gmres30_none"):
+        k = d["krylov"][name]
+        assert k["iters_per_sec"] > 0 and 0 < k["itime_s"] <= k["lis_solve_wall_s"] + 1e-3
+        assert abs(k["iters_per_sec"] - k["iters_timed"] / k["itime_s"]) < 0.01 * k["iters_per_sec"]     # iter / itime (lis_solver.c:902-908)
+        kr = k["roofline"]
+        assert 0 < kr["frac"] <= 1.0 and kr["loop_bytes_per_iter"] <= kr["contract_bytes_per_iter"]

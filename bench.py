@@ -194,8 +194,8 @@ def main():
             if os.path.exists(tf):
                 tj = json.load(open(tf))
                 traffic = tj.get("fabric_bytes_per_launch", tj.get("hbm_traffic_bytes_per_launch"))
-                traffic_detail = {k: tj[k] for k in ("source", "kernel", "level", "read_bytes_per_launch", "write_bytes_per_launch",
-                                                     "x_bytes_per_launch", "x_refetch_factor", "fabric_rate_GBs", "note") if k in tj}
+                traffic_detail = {k: tj[k] for k in ("source", "kernel", "level", "avg_kernel_ns", "read_bytes_per_launch", "write_bytes_per_launch",
+                                                     "x_bytes_per_launch", "x_refetch_factor", "fabric_rate_GBs", "hbm_bytes_bounds", "note") if k in tj}
                 traffic_detail["file"] = os.path.relpath(tf, ROOT)
                 break
     # One-byte column codes (the stencil sits on 7 diagonals): the kernel then streams 9 B per non-zero, not
@@ -263,7 +263,7 @@ def main():
             loop_b, contract_b = krylov_bytes(key, iters, n_local, nnz_local, coded)
             sec_per_iter = itime / max(1, iters)
             solvers[key] = {
-                "iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 4),
+                "iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6),
                 "lis_solve_wall_s": round(wall, 4), "rel_residual_after": S.contents.resid,
                 # per GPU: bytes one iteration's passes are asked to stream (fused loops, coded indices: DESIGN.md 6)
                 # and the bytes of the reference's unfused operator sequence over the same time

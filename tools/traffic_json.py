@@ -72,5 +72,13 @@ if rd is not None:
     if avg_ns and wr is not None:
         out["fabric_rate_GBs"] = round((rd + wr) / avg_ns, 1)
         out["traffic_over_stored"] = round((rd + wr) / out["stored_bytes_per_launch"], 4)
+        cap = 8.0e12 * avg_ns * 1e-9
+        out["hbm_bytes_bounds"] = [out["stored_bytes_per_launch"], int(min(rd + wr, cap))]
+        out["note"] = ("exact bytes at the L2 <-> fabric boundary (requests counted by size; 2 x FETCH_SIZE agrees within 0.3 %). "
+                       "They include re-reads of x that the Infinity Cache serves, which is how the rate at this boundary can pass the "
+                       "8 TB/s of HBM itself: the HBM bytes lie between the compulsory stored bytes and min(fabric bytes, 8 TB/s x kernel "
+                       "time) = hbm_bytes_bounds.  value / code / ptr streams are read once (nt loads): everything else on the read side "
+                       "is x, fetched x_refetch_factor times across the fabric (the 8 XCD L2s each fetch their own copy of a line: the "
+                       "+-n neighbours of a row block run on other XCDs, the +-mn ones 128 blocks later on the same one).")
 json.dump(out, open(a.out, "w"), indent=1)
 print(json.dumps(out, indent=1))

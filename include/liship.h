@@ -74,6 +74,20 @@ int  liship_csr_plan_create(liship_csr_plan_t *plan, int n, const int *ptr, void
 int  liship_csr_plan_encode_indices(liship_csr_plan_t plan, const int *ptr, const int *index, void *stream);
 int  liship_csr_plan_coded(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_index_codes(int on);
+/* Block-local columns (setup-time, optional, never an error when the matrix does not qualify): for matrices with long rows
+ * (the plan's products kernel) whose row blocks address few distinct columns -- several unknowns per node, wide bands --
+ * the plan keeps per row block the sorted list of its distinct columns and per non-zero a 2 B position in that list; the
+ * kernel then gathers x once per distinct column into LDS and forms the products from LDS (10 B + 4 B x distinct/entries
+ * per non-zero instead of 12, a fraction of the gathers).  Same terms in the same order: bit-identical.  The index array
+ * must stay valid.  liship_csr_plan_localized: total length of the lists, 0 if the plan has none.
+ * liship_spmv_csr_set_local_columns(0) makes every product ignore them (A/B measurements). */
+int  liship_csr_plan_localize_columns(liship_csr_plan_t plan, const int *ptr, const int *index, void *stream);
+long long liship_csr_plan_localized(liship_csr_plan_t plan);
+int  liship_spmv_csr_set_local_columns(int on);
+/* Opt-in, off by default, NOT bit-identical to the reference: the part of a row beyond the LDS stage (~2100 entries) is added
+ * by a workgroup-wide tree per pass instead of one left-to-right chain (a 200 000-entry row is otherwise a 200 000-long
+ * dependent add chain, by the parity contract).  Deterministic; rows that fit the stage keep the reference's bits. */
+int  liship_spmv_csr_set_long_row_tree(int on);
 int  liship_csr_plan_destroy(liship_csr_plan_t plan);
 int  liship_csr_plan_info(liship_csr_plan_t plan, int *n, long long *nnz, int *nblocks);
 int  liship_spmv_csr_f64(liship_csr_plan_t plan, const int *ptr, const int *index,

@@ -48,6 +48,7 @@ LIS_INT lisd_init(void)
 	HIPCHK(lisd_malloc(&lisg.reduce_work, liship_reduce_work_bytes()));
 	HIPCHK(lisd_malloc((void **)&lisg.reduce_out, 4 * sizeof(double)));
 	HIPCHK(liship_malloc_host((void **)&lisg.host_out, 4 * 64 * sizeof(double)));
+	if (lisg.long_row_tree) HIPCHK(liship_spmv_csr_set_long_row_tree(1));
 	lisg.device_ready = 1;
 	return LIS_SUCCESS;
 }
@@ -229,6 +230,11 @@ LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int
 		rc = liship_csr_plan_encode_indices(*plan, dptr, dindex, lisg.stream);
 		if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_encode_indices(*plan, dptr, dindex, lisg.stream);
 		if (rc && rc != 2 /* hipErrorOutOfMemory */) HIPCHK(rc);
+	}
+	if (!lisg.no_local_columns && !liship_csr_plan_coded(*plan)) {      /* long rows: block-local columns where they pay */
+		rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
+		if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
+		if (rc && rc != 2) HIPCHK(rc);
 	}
 	return LIS_SUCCESS;
 }

@@ -42,6 +42,7 @@ constexpr Geometry kGeom[] = {
     { 64,  512},   // 6: one wavefront per workgroup
 };
 constexpr int kNumGeom = sizeof(kGeom) / sizeof(kGeom[0]);
+constexpr int LOCAL_GEOM = 5;    // block-local columns (spmv_csr_local_kernel): 512 lanes / 4096 items, 2 distinct columns per lane
 constexpr int ROW_ALIGN = 16;    // rows per 128 B line of y / x
 constexpr int SLACK = 128;       // extra items a block may take to start on an aligned row
 
@@ -54,6 +55,9 @@ constexpr int SLACK = 128;       // extra items a block may take to start on an 
 //   bit10 register staging instead of LDS-DMA   bits11-12 gather unroll U: 0 auto, 1: 4, 2: 7, 3: 8
 int g_variant = 0;
 int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps every product on the 4 B indices
+int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps the products kernel on the 4 B indices
+
+__device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
 
 struct Blk { int r0, k0, r1, k1; };
 
@@ -100,7 +104,16 @@ __device__ __forceinline__ bool clip_rows(Blk &B, const int *__restrict__ ptr, i
 }
 
 // ------------------------------------------------------------------------------ products kernel
-// products for non-zeros [kbeg,kend) -> prod[k - ka]; ka is kbeg rounded down to even
+// The products of a row block are parked in LDS at GUARD + their position in the block, and the lane that owns row i adds
+// its products strictly in order.  Read at the same step, the j-th products of all rows sit L slots apart for rows of L
+// entries: L = 80 puts every second row on the same bank (a 25-way conflict per read).  ordered_sum therefore lets lane i
+// start `skew` steps late -- step t reads the term t - skew -- with skew chosen so that (row start - skew) mod 32 = 17 i mod 32:
+// at every step the lanes of a wavefront then read 32 different banks, whatever the row lengths.  Steps outside the row add
+// +0.0; GUARD slots in front of the stage keep the early reads of the first rows inside the array.
+constexpr int GUARD = 32;
+__device__ __forceinline__ int row_skew(int start, int i) { return (start - 17 * i) & 31; }
+
+// products for non-zeros [kbeg,kend) -> prod[GUARD + k - ka]; ka is kbeg rounded down to even
 // VEC: 0 = scalar loads; 2 / 4 = 16 B value + 8 B index loads with that many independent pairs in flight per lane
 // (4 for rows of 14-24 entries, 2 beyond: measured on banded and FEM patterns, tools/rowlen_sweep.py, irregular_sweep.py)
 template <int BLOCK, int VEC, bool NOGATHER>
@@ -140,26 +153,44 @@ __device__ __forceinline__ void stage_products(double *prod, const int *__restri
                     v2f64 pr;
                     pr.x = v[u].x * xv[u].x;
                     pr.y = v[u].y * xv[u].y;
-                    *reinterpret_cast<v2f64 *>(prod + 2 * p) = pr;
+                    *reinterpret_cast<v2f64 *>(prod + GUARD + 2 * p) = pr;
                 }
             }
         }
         if (((kend - ka) & 1) && threadIdx.x == BLOCK - 1) {
             const int k = kend - 1;
-            prod[k - ka] = val[k] * x[idx[k]];
+            prod[GUARD + k - ka] = val[k] * x[idx[k]];
         }
     } else {
         for (int k = kbeg + (int)threadIdx.x; k < kend; k += BLOCK)
-            prod[k - ka] = load_stream(val + k) * x[load_stream(idx + k)];
+            prod[GUARD + k - ka] = load_stream(val + k) * x[load_stream(idx + k)];
     }
 }
 
-// acc + p[0] + p[1] + ... + p[lim-1], strictly left to right (the reference's rounding sequence).  The adds form
-// one dependent chain, so the LDS reads are issued 16 at a time ahead of it; absent terms are +0.0, which leaves
-// the sum bit-unchanged (a sum that starts at +0.0 never becomes -0.0).
-__device__ __forceinline__ double ordered_sum(double acc, const double *p, int lim)
+// acc + q[0] + q[1] + ... + q[lim-1] with q[j] = buf[GUARD + first + j], strictly left to right (the reference's rounding
+// sequence), term j read at step j + skew.  The adds form one dependent chain, so the LDS reads are issued 16 at a time ahead
+// of it; absent terms are +0.0, which leaves the sum bit-unchanged (a sum that starts at +0.0 never becomes -0.0).
+__device__ __forceinline__ double ordered_sum(double acc, const double *buf, int first, int lim, int skew = 0)
 {
     constexpr int W = 16;
+    const double *p = buf + GUARD + first - skew;       // p[t] = term t - skew
+    const int total = lim + skew;
+    for (int t = 0; t < total; t += W) {
+        double d[W];
+#pragma unroll
+        for (int u = 0; u < W; u++) d[u] = p[t + u];     // at most 15 slots past the row: inside the stage's slack
+#pragma unroll
+        for (int u = 0; u < W; u++) acc += ((unsigned)(t + u - skew) < (unsigned)lim) ? d[u] : 0.0;
+    }
+    return acc;
+}
+
+// the same without a skew, for the passes that continue a row longer than the stage (one lane, 10^5 terms: no selects
+// in the whole batches)
+__device__ __forceinline__ double ordered_sum_plain(double acc, const double *buf, int first, int lim)
+{
+    constexpr int W = 16;
+    const double *p = buf + GUARD + first;
     int j = 0;
     for (; j + W <= lim; j += W) {
         double d[W];
@@ -221,21 +252,42 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
     for (int r = rmine; r < r1; r += BLOCK) {
         int s = s_first, e = e_first;
         if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
-        const double acc = ordered_sum(0.0, prod + (s - ka), min(e, kfirst) - s);
+        const double acc = ordered_sum(0.0, prod, s - ka, min(e, kfirst) - s, row_skew(s - ka, (int)threadIdx.x));
         if (e <= kfirst) { store_stream(y + r, acc); dots.add(r, acc); } else carry = acc;   // only the block's last row can overflow
     }
 
     if (k1 > kfirst) {                                          // uniform: finish the long last row
         const int rl = r1 - 1;
         const int owner = (rl - r0) % BLOCK;
+        const bool tree = d_long_row_tree != 0;                 // opt-in (liship_spmv_csr_set_long_row_tree): NOT the reference's bits
+        __shared__ double tree_scratch[BLOCK / WAVE];
         int base = kfirst;
+        if (tree) {
+            // every lane adds the products it reaches with stride BLOCK (8 loads and gathers in flight, nothing staged), the
+            // workgroup folds the lane sums (butterfly, then the wavefronts in order): a fixed order, but not left to right --
+            // a 200 000-entry row costs ~100 rounds of memory latency instead of a 200 000-long dependent add chain
+            double part = 0.0;
+            for (int k = kfirst + (int)threadIdx.x; k < k1; k += 8 * BLOCK) {
+                double v[8], xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int kk = min(k + u * BLOCK, k1 - 1); v[u] = load_stream(val + kk); xv[u] = x[load_stream(idx + kk)]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) part += (k + u * BLOCK < k1) ? v[u] * xv[u] : 0.0;
+            }
+            __syncthreads();
+            const double tot = block_sum<BLOCK / WAVE>(part, tree_scratch);
+            if (threadIdx.x == 0) tree_scratch[0] = tot;
+            __syncthreads();
+            if ((int)threadIdx.x == owner) carry += tree_scratch[0];
+            base = k1;
+        }
         while (base < k1) {
             const int kend = min(base + CAP, k1);
             const int ka2 = base & ~1;
             __syncthreads();
             stage_products<BLOCK, VEC, NOGATHER>(prod, idx, val, x, base, kend, ka2);
             __syncthreads();
-            if ((int)threadIdx.x == owner) carry = ordered_sum(carry, prod + (base - ka2), kend - base);
+            if ((int)threadIdx.x == owner) carry = ordered_sum_plain(carry, prod, base - ka2, kend - base);
             base = kend;
         }
         if ((int)threadIdx.x == owner) { store_stream(y + rl, carry); dots.add(rl, carry); }
@@ -266,7 +318,7 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     constexpr int CAP = WORK + SLACK;
-    __shared__ double prod[CAP + 8];
+    __shared__ double prod[(GUARD + CAP + 8 + 16)];
     __shared__ double dot_scratch[BLOCK / WAVE];
     RowDots<DOT> dots{wdot, 0.0, 0.0};
     const int lb = block_of_workgroup<XRUN>(nb, run);
@@ -296,7 +348,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     RowDots<DOT> dots{wdot, 0.0, 0.0};
     constexpr int CAP = WORK + SLACK;
     // + one wavefront of slack: the LDS-DMA form always lands whole 1 KiB wave slices
-    __shared__ __attribute__((aligned(16))) double valL[CAP + 8 + 2 * WAVE];
+    __shared__ __attribute__((aligned(16))) double valL[(GUARD + CAP + 8 + 16) + 2 * WAVE];    // also the padded product stage of block_by_products
     __shared__ __attribute__((aligned(16))) int idxL[CAP + 8 + 4 * WAVE];
 
     const int lb = block_of_workgroup<XRUN>(nb, run);
@@ -394,6 +446,176 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
+// ------------------------------------------------------------------------------ products kernel, block-local columns
+// Long rows are bound by the x gather, not by the streams (profiles/r02_csr_kernel_experiments.txt: without the gather
+// the products kernel runs at 80 % of the roofline, with it at 62 %).  But the entries of one row block address few
+// DISTINCT columns when rows are long: the three rows of a finite-element node share all their columns, neighbouring
+// rows most of them -- 2048 entries of the 81-per-row pattern touch ~270 columns.  So the plan can keep, per row block,
+// the sorted list of its distinct columns (dcol, 4 B each) and per non-zero a 2 B position in that list (lcol,
+// liship_csr_plan_localize_columns), and this kernel
+//   * loads the block's list and gathers x ONCE per distinct column into LDS (4 per lane, sorted columns: neighbouring
+//     lanes hit the same lines), while the value / position slices arrive by LDS-DMA,
+//   * forms every product from LDS alone (all lanes, consecutive entries),
+//   * adds the products of a row strictly left to right, one lane per row, as block_by_products does.
+// 10 B + 4 B x (distinct / entries) per non-zero instead of 12, an eighth of the gathers; same terms in the same
+// order, so y is bit-identical.  Row blocks the plan left out (a row longer than the stage, more than 4 x BLOCK
+// distinct columns) have an empty list and take block_by_products on the 4 B indices.
+template <int BLOCK, int WORK, int DOT = 0, int NDPL = 2>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
+                           const unsigned short *__restrict__ lcol, const int *__restrict__ dcol,
+                           const int *__restrict__ doff, const double *__restrict__ x, double *__restrict__ y,
+                           const v2i32 *__restrict__ blk, int bfirst, int nb, int row_begin, int row_end, int nnz_total,
+                           const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                           const double *__restrict__ guard = nullptr, int pstride = 0)
+{
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    constexpr int CAP = WORK + SLACK + 8;           // + the 8-entry alignment of the position slice
+    constexpr int NDMAX = NDPL * BLOCK;             // distinct columns a block may list: NDPL per lane (2 or 4)
+    __shared__ double dot_scratch[BLOCK / WAVE];
+    __shared__ __attribute__((aligned(16))) double valL[(GUARD + CAP + 8 + 16) + 2 * WAVE];
+    __shared__ __attribute__((aligned(16))) unsigned short lcL[CAP + 8 + 8 * WAVE];
+    __shared__ __attribute__((aligned(16))) double xL[NDMAX];
+    RowDots<DOT> dots{wdot, 0.0, 0.0};
+
+    const int lb = blockIdx.x;
+    Blk B = load_blk(blk, bfirst + lb);
+    const int d0 = doff[bfirst + lb], nd = doff[bfirst + lb + 1] - d0;      // the plan's block, whatever the row range of this launch
+    if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+        return;
+    }
+    const int ka = B.k0 & ~7;                       // 16 B aligned start of the position slice (64 B for the values)
+    const int cnt = B.k1 - ka;
+    const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
+    const int nl = (cnt + 7) >> 3;                  // 16 B pieces of the position slice (the array is padded)
+    if (nd == 0 || cnt > CAP || ka + 2 * np > nnz_total) {  // block without a list / last value of the array
+        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots);
+        __syncthreads();
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+        return;
+    }
+    // the block's distinct columns: the first memory operation, so that the gathers can leave while the slices stream in
+    const int j4 = NDPL * (int)threadIdx.x;
+    v4i32 dc = {0, 0, 0, 0};
+    if (j4 < nd) {                                  // lists are padded to whole 16 B pieces
+        if (NDPL == 4) dc = *reinterpret_cast<const v4i32 *>(dcol + d0 + j4);
+        else { const v2i32 h = *reinterpret_cast<const v2i32 *>(dcol + d0 + j4); dc.x = h.x; dc.y = h.y; }
+    }
+    {
+        const int wbase = (int)threadIdx.x & ~(WAVE - 1), lane = (int)threadIdx.x & (WAVE - 1);
+        for (int p0 = wbase; p0 < np; p0 += BLOCK) {
+            const int p = min(p0 + lane, np - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL + GUARD) + p0), 16, 0, 2);
+        }
+        for (int q0 = wbase; q0 < nl; q0 += BLOCK) {
+            const int q = min(q0 + lane, nl - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v4i32 *>(lcol + ka) + q),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v4i32 *>(lcL) + q0), 16, 0, 2);
+        }
+    }
+    // rows stay with consecutive lanes of as few wavefronts as possible: dealing them to all wavefronts was tried and multiplies
+    // the LDS instructions of the serial sums by the number of wavefronts (each then issues the whole chain for a few lanes)
+    const int rmine = B.r0 + (int)threadIdx.x;
+    int s_first = 0, e_first = 0;
+    if (rmine < B.r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; }
+    if (j4 < nd) {
+        v2f64 a, b;
+        a.x = x[dc.x]; a.y = x[dc.y];
+        if (NDPL == 4) { b.x = x[dc.z]; b.y = x[dc.w]; }
+        *reinterpret_cast<v2f64 *>(xL + j4) = a;
+        if (NDPL == 4) *reinterpret_cast<v2f64 *>(xL + j4 + 2) = b;
+    }
+    __syncthreads();
+
+    // products in place, from LDS alone: entry e of the stage by lane e % BLOCK, 8 in flight per lane
+    for (int e0 = (B.k0 - ka) + (int)threadIdx.x; e0 < cnt; e0 += 8 * BLOCK) {
+        double vv[8], xv[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) { const int e = min(e0 + g * BLOCK, cnt - 1); vv[g] = valL[GUARD + e]; xv[g] = xL[lcL[e]]; }
+#pragma unroll
+        for (int g = 0; g < 8; g++) { const int e = e0 + g * BLOCK; if (e < cnt) valL[GUARD + e] = vv[g] * xv[g]; }
+    }
+    __syncthreads();
+
+    for (int r = rmine; r < B.r1; r += BLOCK) {
+        int s = s_first, e = e_first;
+        if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
+        const double wr = dots.fetch(r);
+        const double acc = ordered_sum(0.0, valL, s - ka, e - s, row_skew(s - ka, (int)threadIdx.x));
+        store_stream(y + r, acc);
+        dots.add_loaded(wr, acc);
+    }
+    if (DOT != 0) __syncthreads();
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+}
+
+// plan time, one workgroup per row block: sort the block's column indices (bitonic, in LDS), keep the distinct ones.
+// PASS 0 counts them (nd[b]; 0 = no list: empty block, a row longer than the stage, more than ndmax columns);
+// PASS 1 writes the list at dcol[doff[b]...) (padded to a multiple of 4 with its last entry) and, per non-zero, the
+// position of its column in the list.
+template <int BLOCK, int PASS, int LOCAL_SORT>
+__global__ __launch_bounds__(BLOCK)
+void csr_local_build(const v2i32 *__restrict__ blk, const int *__restrict__ idx, int cap, int ndmax,
+                     int *__restrict__ nd_out, const int *__restrict__ doff, int *__restrict__ dcol,
+                     unsigned short *__restrict__ lcol)
+{
+    __shared__ int keys[LOCAL_SORT];
+    __shared__ int dist[LOCAL_SORT / 2 + 256];
+    __shared__ int wsum[BLOCK / WAVE];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int k0 = blk[b].y, k1 = blk[b + 1].y, cnt = k1 - k0;
+    if (cnt <= 0 || cnt > cap || cnt > LOCAL_SORT / 2 + 256) { if (PASS == 0 && t == 0) nd_out[b] = 0; return; }
+    if (PASS == 1 && doff[b + 1] == doff[b]) return;
+    for (int i = t; i < LOCAL_SORT; i += BLOCK) keys[i] = i < cnt ? idx[k0 + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= LOCAL_SORT; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < LOCAL_SORT; i += BLOCK) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int a = keys[i], c = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { keys[i] = c; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // distinct heads among the first cnt sorted keys: each thread owns LOCAL_SORT / BLOCK consecutive ones
+    constexpr int PER = LOCAL_SORT / BLOCK;
+    int mine = 0;
+    for (int u = 0; u < PER; u++) {
+        const int i = t * PER + u;
+        if (i < cnt && (i == 0 || keys[i] != keys[i - 1])) mine++;
+    }
+    int incl = mine;                                 // inclusive scan over the workgroup: wave scan, then the wave totals
+    const int lane = t & (WAVE - 1), w = t / WAVE;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const int v = __shfl_up(incl, off, WAVE); if (lane >= off) incl += v; }
+    if (lane == WAVE - 1) wsum[w] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int q = 0; q < BLOCK / WAVE; q++) { if (q < w) base += wsum[q]; total += wsum[q]; }
+    if (PASS == 0) { if (t == 0) nd_out[b] = total <= ndmax ? total : 0; return; }
+    int pos = base + incl - mine;
+    for (int u = 0; u < PER; u++) {
+        const int i = t * PER + u;
+        if (i < cnt && (i == 0 || keys[i] != keys[i - 1])) dist[pos++] = keys[i];
+    }
+    __syncthreads();
+    const int nd = total, d0 = doff[b], padded = doff[b + 1] - d0;
+    for (int j = t; j < padded; j += BLOCK) dcol[d0 + j] = dist[j < nd ? j : nd - 1];
+    for (int i = t; i < cnt; i += BLOCK) {
+        const int c = idx[k0 + i];
+        int lo = 0, hi = nd - 1;                     // the column is in the list
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (dist[mid] < c) lo = mid + 1; else hi = mid; }
+        lcol[k0 + i] = (unsigned short)lo;
+    }
+}
+
 // ------------------------------------------------------------------------------ row-gather kernel, coded indices
 // A matrix whose entries sit on at most 255 distinct diagonals (every structured-grid discretisation: the 7-point
 // stencil has 7) does not need 4 B per column index: the plan stores ONE byte per non-zero, the position of
@@ -415,7 +637,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     __shared__ double dot_scratch[BLOCK / WAVE];
     RowDots<DOT> dots{wdot, 0.0, 0.0};
     constexpr int CAP = WORK + SLACK + 16;          // + the 16-entry alignment of the code slice
-    __shared__ __attribute__((aligned(16))) double valL[CAP + 8 + 2 * WAVE];
+    __shared__ __attribute__((aligned(16))) double valL[(GUARD + CAP + 8 + 16) + 2 * WAVE];    // also the padded product stage of block_by_products
     __shared__ __attribute__((aligned(16))) unsigned char codeL[CAP + 16 + 16 * WAVE];
     __shared__ int dictL[256];
 
@@ -541,10 +763,23 @@ struct liship_csr_plan_s {
     unsigned char *codes; // device, one byte per non-zero (+ padding): position of (column - row) in dict; NULL = not coded
     int *dict;           // device, 256 sorted offsets (the tail repeats the last one)
     int ndict;
+    unsigned short *lcol; // device, one 2 B position per non-zero into its row block's list of distinct columns; NULL = none
+    int *dcol;           // device, the lists (each padded to a multiple of 4 entries)
+    int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
+    long long ndcol;     // entries of dcol
 };
 
 extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
 extern "C" int liship_spmv_csr_set_index_codes(int on) { g_index_codes = on ? 1 : 0; return 0; }
+// Opt-in, off by default: the part of a row that does not fit the LDS stage (beyond ~2100 entries) is added by a workgroup-wide
+// tree per pass instead of one strictly ordered chain.  Deterministic, but NOT bit-identical to the reference's left-to-right
+// sum (differences of a few ulp of the row's magnitude); for heavy-tailed matrices where a single row is 10^5 entries long.
+extern "C" int liship_spmv_csr_set_long_row_tree(int on)
+{
+    const int v = on ? 1 : 0;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(d_long_row_tree), &v, sizeof(int)));
+    return 0;
+}
 
 // the merge-path row split for the plan's geometry (device + host copy); replaces an existing one
 static int build_split(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
@@ -596,6 +831,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->blk = nullptr;
     p->blk_host = nullptr;
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
+    p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -609,6 +845,9 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->blk) rc = (int)hipFree(p->blk);
     if (p->codes) (void)hipFree(p->codes);
     if (p->dict) (void)hipFree(p->dict);
+    if (p->lcol) (void)hipFree(p->lcol);
+    if (p->dcol) (void)hipFree(p->dcol);
+    if (p->doff) (void)hipFree(p->doff);
     free(p->blk_host);
     delete p;
     return rc;
@@ -678,6 +917,70 @@ extern "C" int liship_csr_plan_encode_indices(liship_csr_plan_t p, const int *pt
 // number of dictionary entries when the plan's indices are coded, 0 otherwise
 extern "C" int liship_csr_plan_coded(liship_csr_plan_t p) { return (p && p->codes) ? p->ndict : 0; }
 
+// Block-local columns for the products kernel (see spmv_csr_local_kernel): setup-time, optional, never an error when the
+// matrix does not qualify.  Kept when the lists cover >= 90 % of the non-zeros and hold at most half as many columns as
+// the blocks hold entries -- below that the 2 B + 4 B of a once-used column cost more than its 4 B index.
+extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *ptr, const int *idx, void *stream)
+{
+    if (!p || (p->n > 0 && (!ptr || !idx))) return LISHIP_ERR_ARG;
+    if (p->lcol || p->codes || !p->products || p->nblocks <= 0 || p->nnz <= 0 || g_variant != 0 || !aligned16(idx)) return 0;
+    hipStream_t st = as_stream(stream);
+    constexpr Geometry g = kGeom[LOCAL_GEOM];
+    constexpr int CAPL = g.work + SLACK, NDMAX = 2 * g.block;
+    const int geom_before = p->geom;
+    if (p->geom != LOCAL_GEOM) { p->geom = LOCAL_GEOM; const int rc = build_split(p, ptr, st); if (rc) return rc; }
+    const int nb = p->nblocks;
+    int *nd_dev = nullptr;
+    HIP_TRY(hipMalloc(&nd_dev, sizeof(int) * (size_t)(nb + 1)));
+    csr_local_build<256, 0, 8192><<<nb, 256, 0, st>>>(p->blk, idx, CAPL, NDMAX, nd_dev, nullptr, nullptr, nullptr);
+    hipError_t e = hipGetLastError();
+    int *off = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(off, nd_dev, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipFree(nd_dev); free(off);
+        if (geom_before != LOCAL_GEOM) { p->geom = geom_before; (void)build_split(p, ptr, st); }
+        return (int)e;
+    }
+    long long listed = 0, covered = 0, run = 0;
+    for (int b = 0; b < nb; b++) {
+        const int nd = off[b];
+        off[b] = (int)run;
+        if (nd > 0) { listed += nd; covered += p->blk_host[b + 1].y - p->blk_host[b].y; run += (nd + 3) & ~3; }
+    }
+    off[nb] = (int)run;
+    if (run > 0x7fffffffLL || covered * 10 < p->nnz * 9 || listed * 2 > covered) {      // not worth it: back to the products kernel's own split
+        (void)hipFree(nd_dev); free(off);
+        if (geom_before != LOCAL_GEOM) { p->geom = geom_before; return build_split(p, ptr, st); }
+        return 0;
+    }
+    const size_t lbytes = ((size_t)p->nnz + 7) / 8 * 16 + 16 * WAVE;          // whole 16 B pieces, one wave slice of slack
+    e = hipMalloc(&p->dcol, sizeof(int) * (size_t)(run + 4));
+    if (e == hipSuccess) e = hipMalloc(&p->lcol, lbytes);
+    if (e == hipSuccess) e = hipMemsetAsync(p->lcol, 0, lbytes, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nd_dev, off, sizeof(int) * (size_t)(nb + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        csr_local_build<256, 1, 8192><<<nb, 256, 0, st>>>(p->blk, idx, CAPL, NDMAX, nullptr, nd_dev, p->dcol, p->lcol);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    free(off);
+    if (e != hipSuccess) {
+        if (p->dcol) (void)hipFree(p->dcol);
+        if (p->lcol) (void)hipFree(p->lcol);
+        (void)hipFree(nd_dev);
+        p->dcol = nullptr; p->lcol = nullptr;
+        if (geom_before != LOCAL_GEOM) { p->geom = geom_before; (void)build_split(p, ptr, st); }
+        return (int)e;
+    }
+    p->doff = nd_dev;
+    p->ndcol = run;
+    return 0;
+}
+// entries of the distinct-column lists when the plan keeps block-local columns, 0 otherwise
+extern "C" long long liship_csr_plan_localized(liship_csr_plan_t p) { return (p && p->lcol) ? p->ndcol : 0; }
+extern "C" int liship_spmv_csr_set_local_columns(int on) { g_local_cols = on ? 1 : 0; return 0; }
+
 namespace {
 
 struct LaunchArgs {
@@ -686,6 +989,8 @@ struct LaunchArgs {
     hipStream_t st;
     const unsigned char *codes = nullptr;   // one-byte column codes + their dictionary, when the plan has them
     const int *dict = nullptr;
+    const unsigned short *lcol = nullptr;   // block-local columns (positions, lists, list offsets), when the plan has them
+    const int *dcol = nullptr, *doff = nullptr;
 };
 
 
@@ -717,6 +1022,12 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     const bool val16 = aligned16(a.val), idx16 = aligned16(a.idx);
     const bool idx8 = (reinterpret_cast<uintptr_t>(a.idx) & 7u) == 0;
     const bool products = plan_products || (g_variant & 6) != 0 || !(val16 && idx16);
+    if (a.lcol && plan_products && G == LOCAL_GEOM && g_variant == 0 && val16) {     // long rows, few distinct columns per row block
+        constexpr Geometry g = kGeom[LOCAL_GEOM];
+        spmv_csr_local_kernel<g.block, g.work><<<a.nb, g.block, 0, a.st>>>(
+            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz);
+        return;
+    }
     if (products) {
         const bool vec = !(g_variant & 2) && val16 && idx8;
         if (nogather)  launch_products<G, false, 4, true>(a.nb, a);
@@ -779,6 +1090,11 @@ template <int G, int DOT>
 void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
+    if (a.lcol && G == LOCAL_GEOM) {
+        spmv_csr_local_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
+            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, w, partial, liship_internal_guard(), pstride);
+        return;
+    }
     if (batch == 2)
         spmv_csr_products_kernel<g.block, g.work, false, 2, false, DOT>
             <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial, liship_internal_guard(), pstride);
@@ -810,7 +1126,7 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
                                    const double *val, const double *x, double *y, void *stream)
 {
     if (!p) return LISHIP_ERR_ARG;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff};
     return launch_csr(p, a);
 }
 
@@ -826,9 +1142,11 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if (g_variant != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
-    if (p->products) {              // geometry 1
+    if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
+        if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);
+    } else if (p->products) {       // geometry 1
         if (want_sumsq) launch_products_dot<1, 2>(a, p->batch, w, partial); else launch_products_dot<1, 1>(a, p->batch, w, partial);
     } else if (p->geom == 1) { if (want_sumsq) launch_rowgather_dot<1, 2>(a, p->unroll, w, partial); else launch_rowgather_dot<1, 1>(a, p->unroll, w, partial); }
     else if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial);
@@ -850,7 +1168,7 @@ extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int 
     const int bfirst = lo;
     lo = bfirst; hi = p->nblocks;                // first b with br[b].row >= row_end
     while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff};
     return launch_csr(p, a);
 }
 
@@ -878,9 +1196,11 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if (nb <= 0) return 0;
     if ((size_t)slot_base + (size_t)nb > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work) + slot_base;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff};
     const int ps = (int)slots;
-    if (p->products) {
+    if (p->products && p->geom == LOCAL_GEOM) {
+        if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial, ps);
+    } else if (p->products) {
         if (want_sumsq) launch_products_dot<1, 2>(a, p->batch, w, partial, ps); else launch_products_dot<1, 1>(a, p->batch, w, partial, ps);
     } else if (p->geom == 1) { if (want_sumsq) launch_rowgather_dot<1, 2>(a, p->unroll, w, partial, ps); else launch_rowgather_dot<1, 1>(a, p->unroll, w, partial, ps); }
     else if (want_sumsq) launch_rowgather_dot<0, 2>(a, p->unroll, w, partial, ps);

@@ -132,6 +132,48 @@ def random_csr(n, avg_nnz, seed, ncols=None, sort_cols=False, empty_rows=True, l
 
 
 # ---------------------------------------------------------------- spmv
+
+def fem3(G, dofs=3):
+    """BASELINE config 4 stand-in (SuiteSparse Queen_4147's sparsity class, 3-D structural FEM): `dofs` unknowns per node
+    of a G^3 grid, 27-node connectivity -- dofs x dofs blocks, up to 27 * dofs entries per row (boundary rows shorter);
+    symmetric, strictly diagonally dominant.  Returns ptr (int32), idx (int32), val, n."""
+    nodes = G ** 3
+    z, y, x = np.meshgrid(np.arange(G), np.arange(G), np.arange(G), indexing="ij")
+    z, y, x = z.ravel(), y.ravel(), x.ravel()
+    offs = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    masks = [((z + dz >= 0) & (z + dz < G) & (y + dy >= 0) & (y + dy < G) & (x + dx >= 0) & (x + dx < G)) for dz, dy, dx in offs]
+    cnt = np.zeros(nodes, np.int64)
+    pos = []
+    for m in masks:
+        pos.append(cnt.copy())
+        cnt += m
+    rowlen = np.repeat(dofs * cnt, dofs)
+    ptr = np.zeros(dofs * nodes + 1, np.int64)
+    np.cumsum(rowlen, out=ptr[1:])
+    nnz = int(ptr[-1])
+    idx = np.empty(nnz, np.int32)
+    val = np.empty(nnz)
+    for k, ((dz, dy, dx), m) in enumerate(zip(offs, masks)):
+        p = np.nonzero(m)[0]
+        q = p + (dz * G + dy) * G + dx
+        dist = abs(dz) + abs(dy) + abs(dx)
+        for d in range(dofs):
+            base = ptr[dofs * p + d] + dofs * pos[k][p]
+            for e in range(dofs):
+                idx[base + e] = dofs * q + e
+                if dist == 0:
+                    val[base + e] = 0.0 if d == e else -0.125          # diagonal filled below
+                else:
+                    val[base + e] = -(1.0 if d == e else 0.25) / dist
+    n = dofs * nodes
+    rowsum = np.add.reduceat(np.abs(val), ptr[:-1])                    # diagonal = 1 + sum of |off-diagonal| of the row
+    self_k = offs.index((0, 0, 0))
+    p = np.arange(nodes)
+    for d in range(dofs):
+        at = ptr[dofs * p + d] + dofs * pos[self_k][p] + d
+        val[at] = rowsum[dofs * p + d] + 1.0
+    return ptr.astype(np.int32), idx, val, n
+
 def spmv_csr(ptr, idx, val, x):
     n = len(ptr) - 1
     y = np.empty(n)

@@ -23,46 +23,7 @@ import orc      # noqa: E402
 from lis_amd import _capi as capi, check  # noqa: E402
 
 
-def fem3(G):
-    nodes = G ** 3
-    z, y, x = np.meshgrid(np.arange(G), np.arange(G), np.arange(G), indexing="ij")
-    z, y, x = z.ravel(), y.ravel(), x.ravel()
-    offs = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
-    masks = [((z + dz >= 0) & (z + dz < G) & (y + dy >= 0) & (y + dy < G) & (x + dx >= 0) & (x + dx < G)) for dz, dy, dx in offs]
-    cnt = np.zeros(nodes, np.int64)
-    pos = []
-    for m in masks:
-        pos.append(cnt.copy())
-        cnt += m
-    rowlen = np.repeat(3 * cnt, 3)
-    ptr = np.zeros(3 * nodes + 1, np.int64)
-    np.cumsum(rowlen, out=ptr[1:])
-    nnz = int(ptr[-1])
-    idx = np.empty(nnz, np.int32)
-    val = np.empty(nnz)
-    for k, ((dz, dy, dx), m) in enumerate(zip(offs, masks)):
-        p = np.nonzero(m)[0]
-        q = p + (dz * G + dy) * G + dx
-        dist = abs(dz) + abs(dy) + abs(dx)
-        for d in range(3):
-            base = ptr[3 * p + d] + 3 * pos[k][p]
-            for e in range(3):
-                idx[base + e] = 3 * q + e
-                if dist == 0:
-                    val[base + e] = 0.0 if d != e else 0.0      # diagonal filled below
-                    if d != e:
-                        val[base + e] = -0.125
-                else:
-                    val[base + e] = -(1.0 if d == e else 0.25) / dist
-    n = 3 * nodes
-    # diagonal = 1 + sum of |off-diagonal| of the row: strictly dominant, symmetric
-    rowsum = np.add.reduceat(np.abs(val), ptr[:-1])
-    self_k = offs.index((0, 0, 0))
-    p = np.arange(nodes)
-    for d in range(3):
-        at = ptr[3 * p + d] + 3 * pos[self_k][p] + d
-        val[at] = rowsum[3 * p + d] + 1.0
-    return ptr.astype(np.int32), idx, val, n
+fem3 = orc.fem3
 
 
 def zipf(n, seed=3):
@@ -101,7 +62,10 @@ def main():
     dll = lib.dll
     dll.lis_amd_stream.restype = C.c_void_p
     variants = [int(v, 0) for v in os.environ.get("SWEEP_VARIANTS", "0").split(",")]
-    for name, gen in (("fem3", lambda: fem3(G)), ("zipf", lambda: zipf(2_000_000))):
+    only = os.environ.get("IRREG_ONLY")                # "fem3" / "zipf": one of the two (profiling runs)
+    for name, gen in (("fem3", lambda: fem3(G)[:4]), ("zipf", lambda: zipf(2_000_000))):
+        if only and name != only:
+            continue
         t0 = time.time()
         ptr, idx, val, n = gen()
         nnz = len(idx)

@@ -279,6 +279,139 @@ def test_spmv_csr_index_codes(lib, name):
         assert np.array_equal(a, b)                        # same partial sums, same fold: the reductions agree to the bit too
 
 
+def stack_rows(parts):
+    """row-wise concatenation of CSR matrices (ptr, idx, val) over one column space"""
+    ptr, idx, val = [np.zeros(1, np.int64)], [], []
+    for p, i, v in parts:
+        ptr.append(np.asarray(p[1:], np.int64) + ptr[-1][-1])
+        idx.append(i); val.append(v)
+    return np.concatenate(ptr).astype(np.int32), np.concatenate(idx).astype(np.int32), np.concatenate(val)
+
+
+def _fem(G, dofs=3):
+    return orc.fem3(G, dofs)[:3]
+
+
+def _fem_with_strangers(kind):
+    """an FEM pattern with other rows in between: blocks the plan must leave on the 4 B indices"""
+    ptr, idx, val = _fem(10)
+    n = len(ptr) - 1
+    if kind == "long_row":                       # one row longer than the LDS stage, in the middle
+        extra = orc.random_csr(1, 5000, seed=8, ncols=n, empty_rows=False)
+    else:                                        # 60 rows of 70 random columns: more than 1024 distinct columns per row block
+        extra = orc.random_csr(60, 70, seed=9, ncols=n, empty_rows=False)
+    half = n // 2
+    top = (ptr[:half + 1], idx[:ptr[half]], val[:ptr[half]])
+    bot = (ptr[half:] - ptr[half], idx[ptr[half]:], val[ptr[half]:])
+    return stack_rows([top, extra, bot])
+
+
+LOCAL_CASES = {       # name: (matrix, plan keeps block-local columns?)
+    "fem3_12": (lambda: _fem(12), True),
+    "fem2_14": (lambda: _fem(14, 2), True),                       # 54 per row, 2 x 2 blocks
+    "fem3_ghost_columns": (lambda: (lambda p, i, v: (p, (i + (i % 7 == 0) * (len(p) - 1)).astype(np.int32), v))(*_fem(9)), True),
+    "band_60": (lambda: banded(20000, list(range(-30, 30)), 2), True),
+    "fem3_long_row": (lambda: _fem_with_strangers("long_row"), True),
+    "fem3_random_rows": (lambda: _fem_with_strangers("random"), True),
+    "wide_77_random": (lambda: orc.random_csr(4000, 77, seed=3, ncols=4000, empty_rows=False), False),    # every column distinct
+    "p3d_30": (lambda: orc.poisson3d(30, 30, 30), False),            # short rows: not the products kernel
+}
+
+
+@pytest.mark.parametrize("name", list(LOCAL_CASES))
+def test_spmv_csr_local_columns(lib, name):
+    """block-local columns (long rows, few distinct columns per row block): the plan keeps them for exactly the matrices
+    that qualify, and with them every form of the product returns the bits of the 4 B-index kernels and of the oracle"""
+    make, want = LOCAL_CASES[name]
+    ptr, idx, val = make()
+    n = len(ptr) - 1
+    ncols = max(n, int(idx.max()) + 1)
+    rng = np.random.default_rng(37)
+    x, w = rng.uniform(-1, 1, ncols), rng.uniform(-1, 1, n)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64)
+    dx, dw = DA.from_host(x, np.float64), DA.from_host(w, np.float64)
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_localize_columns(plan, dptr.ptr, didx.ptr, None))
+    listed = lib.liship_csr_plan_localized(plan)
+    assert (listed > 0) == want, listed
+    if want:
+        assert listed * 2 <= len(idx)                      # the lists are worth their bytes
+    results = {}
+    for on in (1, 0):
+        lib.liship_spmv_csr_set_local_columns(on)
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host(), yref), on
+        out = []
+        for sq in (0, 1):
+            res = DA.from_host(np.full(2, np.nan), np.float64)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            rc = lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, sq, res.ptr, work.ptr, None)
+            if rc == 0:
+                assert np.array_equal(dy.to_host(), yref), (on, sq)
+                out.append(res.to_host()[:1 + sq].copy())
+        lo, hi = n // 5 + 1, n - n // 7
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        for a, b in ((lo, hi), (0, lo), (hi, n)):
+            check(lib.liship_spmv_csr_rows_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host(), yref), on
+        total, used = 0, C.c_int()
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        ok = True
+        for a, b in ((lo, hi), (0, lo), (hi, n)):
+            rc = lib.liship_spmv_csr_rows_dot_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, 1,
+                                                  work.ptr, total, C.byref(used), None)
+            ok = ok and rc == 0
+            total += used.value
+        if ok:
+            res = DA.from_host(np.full(2, np.nan), np.float64)
+            check(lib.liship_spmv_csr_dot_finish_f64(total, 1, res.ptr, work.ptr, None))
+            assert np.array_equal(dy.to_host(), yref), on
+            out.append(res.to_host().copy())
+        results[on] = out
+    lib.liship_spmv_csr_set_local_columns(1)
+    check(lib.liship_csr_plan_destroy(plan))
+    assert len(results[0]) == len(results[1])
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b)                        # same partial sums, same fold: the reductions agree to the bit too
+
+
+def test_spmv_csr_long_row_tree_is_opt_in(lib):
+    """rows longer than the LDS stage: left-to-right by default (the oracle's bits); with the opt-in tree the same value to
+    rounding, reproducibly -- and rows that fit the stage keep their bits either way"""
+    rng = np.random.default_rng(12)
+    base = orc.random_csr(3000, 9, seed=12, ncols=3000)
+    half = 1500
+    long_ptr = np.array([0, 60000], np.int32)                     # one row of 60 000 entries (columns repeat)
+    long_row = (long_ptr, rng.integers(0, 3000, 60000).astype(np.int32), rng.uniform(-1, 1, 60000))
+    top = (base[0][:half + 1], base[1][:base[0][half]], base[2][:base[0][half]])
+    bot = (base[0][half:] - base[0][half], base[1][base[0][half]:], base[2][base[0][half]:])
+    ptr, idx, val = stack_rows([top, long_row, bot])
+    n = len(ptr) - 1
+    x = np.random.default_rng(5).uniform(-1, 1, 3000)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval, dx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    out = []
+    for tree in (0, 1, 1):
+        check(lib.liship_spmv_csr_set_long_row_tree(tree))
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        out.append(dy.to_host())
+    check(lib.liship_spmv_csr_set_long_row_tree(0))
+    check(lib.liship_csr_plan_destroy(plan))
+    assert np.array_equal(out[0], yref)
+    assert np.array_equal(out[1], out[2])
+    short = np.diff(ptr) <= 2000
+    assert np.array_equal(out[1][short], yref[short])
+    scale = np.abs(val[ptr[1500]:ptr[1501]] * x[idx[ptr[1500]:ptr[1501]]]).sum()
+    assert abs(out[1][1500] - yref[1500]) <= 1e-13 * scale            # a different association of 60 000 terms
+
+
 BSR22_CASES = {
     "stencil": lambda: orc.poisson3d(23, 18, 14),
     "one_block_row": lambda: orc.random_csr(2, 2, seed=7, empty_rows=False),

@@ -32,8 +32,12 @@ def main():
             check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
             if os.environ.get("SWEEP_CODES"):
                 check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+            if os.environ.get("SWEEP_LOCAL"):
+                check(lib.liship_csr_plan_localize_columns(plan, dptr.ptr, didx.ptr, None))
             ms = timed(lib, lambda: check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None)))
-            out.append(f"{v:#x}{'c%d' % lib.liship_csr_plan_coded(plan) if lib.liship_csr_plan_coded(plan) else ''}: {ms:.4f} ms {b / ms / 1e6:.0f} GB/s")
+            tag = ('c%d' % lib.liship_csr_plan_coded(plan) if lib.liship_csr_plan_coded(plan) else '') + \
+                  ('L%.2f' % (lib.liship_csr_plan_localized(plan) / (n * L)) if lib.liship_csr_plan_localized(plan) else '')
+            out.append(f"{v:#x}{tag}: {ms:.4f} ms {b / ms / 1e6:.0f} GB/s")
             lib.liship_csr_plan_destroy(plan)
         lib.liship_spmv_csr_set_variant(0)
         print(f"L={L} n={n}: " + " | ".join(out), flush=True)

@@ -340,7 +340,7 @@ def krylov_bytes(key, iters, n, nnz, coded):
     raise KeyError(key)
 
 
-CG_VECTOR_BYTES_PER_ROW = 88      # 32 (direction update) + 56 (x, r update with both sums); 80 once x += alpha p is deferred
+CG_VECTOR_BYTES_PER_ROW = 80      # 48 (x += alpha_prev p, p = dinv.*r + beta p: r dinv p x | p x) + 32 (r -= alpha q with both sums: q r dinv | r)
 
 
 def usable_cores():

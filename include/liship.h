@@ -259,6 +259,17 @@ int  liship_pmul_xpay_dev_f64(int n, const double *x, const double *d, const dou
 int  liship_axpy_dev_f64(int n, const double *pa, const double *x, double *y, void *stream);
 int  liship_axpy2_dev_f64(int n, const double *pa, const double *x, const double *pb, const double *w, double *y, void *stream);
 int  liship_axpy_xpay_dev_f64(int n, const double *pa, const double *x, const double *w, const double *pb, double *y, void *stream);
+/* CG with the x update deferred into the NEXT iteration's direction update, which reads p anyway (lis_solver_cg.c:199, then
+ * :176-183): x += (*palpha)*p on the old p, then p = r.*dinv + (*pbeta)*p (dinv NULL: p = r + (*pbeta)*p).  Each element sees
+ * the reference's operations in the reference's order -- the bits of x and p are those of the undeferred loop -- while an
+ * iteration moves 80 instead of 88 B of vectors per row.  palpha NULL: first iteration, x is not touched.  The caller owes
+ * the last x += alpha*p after the loop (liship_axpy_dev_f64). */
+int  liship_cg_direction_dev_f64(int n, const double *palpha, const double *pbeta, const double *r, const double *dinv,
+                                 double *p, double *x, void *stream);
+/* r += (*pna)*q (pna holds -alpha) ; result = {sum r^2, sum r*(r.*dinv)} : the residual half of liship_cg_update_jacobi_f64
+ * (without a preconditioner liship_axpy_sumsq_dev_f64 serves) */
+int  liship_cg_residual_jacobi_dev_f64(int n, const double *pna, const double *q, const double *dinv, double *r,
+                                       double *result, void *work, void *stream);
 /* the fused update passes with the coefficient in HBM (dinv may be NULL for liship_cg_update_dev_f64) */
 int  liship_cg_update_dev_f64(int n, const double *palpha, const double *p, const double *q, const double *dinv,
                               double *x, double *r, double *result, void *work, void *stream);

@@ -377,17 +377,24 @@ static LIS_INT run_cg_device(ctx_t *c)
 	for (LIS_INT queued = 0; queued < c->maxiter && L.host[LISHIP_KS_DONE] == 0.0; ) {
 		const LIS_INT batch = (c->maxiter - queued < LISD_BATCH) ? c->maxiter - queued : LISD_BATCH;
 		for (LIS_INT k = 0; k < batch; k++) {
-			if (c->dinv) KTRY(liship_pmul_xpay_dev_f64(n, r, c->dinv, st + LISHIP_KS_BETA, p, lisg.stream));
-			else         KTRY(liship_xpay_dev_f64(n, r, st + LISHIP_KS_BETA, p, lisg.stream));
+			/* x += alpha p of the PREVIOUS iteration rides in this pass, which reads p anyway (none before the first) */
+			KTRY(liship_cg_direction_dev_f64(n, queued + k ? st + LISHIP_KS_ALPHA : NULL, st + LISHIP_KS_BETA, r, c->dinv, p, c->x, lisg.stream));
 			TRY(dev_announce(&L, LISHIP_STEP_CG_ALPHA));
 			TRY(lisd_spmv_dot_launch_to(c->A, p, q, p, 0, st + LISHIP_KS_DOT0));
 			TRY(dev_step(&L, LISHIP_STEP_CG_ALPHA, LISHIP_KS_DOT0, 1));
 			TRY(dev_announce(&L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID));
-			KTRY(liship_cg_update_dev_f64(n, st + LISHIP_KS_ALPHA, p, q, c->dinv, c->x, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			if (c->dinv) KTRY(liship_cg_residual_jacobi_dev_f64(n, st + LISHIP_KS_NALPHA, q, c->dinv, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			else         KTRY(liship_axpy_sumsq_dev_f64(n, st + LISHIP_KS_NALPHA, q, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
 			TRY(dev_step(&L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID, LISHIP_KS_SUM0, c->dinv ? 2 : 1));
 		}
 		queued += batch;
 		TRY(dev_loop_sync(c, &L));
+	}
+	/* the x update of the last iteration that formed an alpha: owed unless the loop ended on <p,q> = 0 (the reference
+	 * leaves before its axpy then, lis_solver_cg.c:193-197) -- the kernels queued behind a raised flag touched neither p nor alpha */
+	if (c->maxiter > 0 && L.host[LISHIP_KS_STATUS] != 2.0) {
+		KTRY(liship_krylov_guard(NULL));
+		KTRY(liship_axpy_dev_f64(n, st + LISHIP_KS_ALPHA, p, c->x, lisg.stream));
 	}
 done:
 	err = dev_loop_finish(c, &L, err);

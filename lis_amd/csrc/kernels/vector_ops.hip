@@ -143,6 +143,84 @@ int run_ew(int n, double a, double b, const double *in0, const double *in1, cons
     return 0;
 }
 
+// CG's direction update with the PREVIOUS iteration's x update folded in (device-driven loop): x += alpha*p on the old p, then
+// p = M^-1 r + beta*p -- lis_solver_cg.c:199 (axpy) and :176-183 (psolve none / Jacobi, xpay), each with its own rounding
+// sequence.  p is read once for both (the pass that updates x in the reference's position reads it a second time).
+template <bool NT, bool VEC, bool JAC, bool XUP>
+__global__ __launch_bounds__(BLOCK)
+void cg_direction_kernel(int n, const double *__restrict__ palpha, const double *__restrict__ pbeta, const double *__restrict__ r,
+                         const double *__restrict__ dinv, double *p, double *x, const double *skip)
+{
+    if (skip && skip[0] != 0.0) return;
+    const double alpha = XUP ? palpha[0] : 0.0, beta = pbeta[0];
+    auto one = [&](double rv, double dv, double pv, double xv, double &po, double &xo) {
+        if (XUP) xo = xv + alpha * pv;                   // x[i] += alpha * p[i]
+        const double z = JAC ? rv * dv : rv;             // z = M^-1 r
+        po = z + beta * pv;                              // p[i] = z[i] + beta * p[i]
+    };
+    if (VEC) {
+        const long long npairs = n >> 1;
+        const long long base = (long long)blockIdx.x * PAIRS_PER_BLOCK + threadIdx.x;
+        v2f64 rv[U], dv[U], pv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long q = base + u * BLOCK;
+            if (q < npairs) {
+                rv[u] = ld2<NT>(r, q); pv[u] = ld2<NT>(p, q);
+                if (JAC) dv[u] = ld2<NT>(dinv, q);
+                if (XUP) xv[u] = ld2<NT>(x, q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long q = base + u * BLOCK;
+            if (q < npairs) {
+                double p0 = 0.0, p1 = 0.0, x0 = 0.0, x1 = 0.0;
+                one(rv[u].x, JAC ? dv[u].x : 0.0, pv[u].x, XUP ? xv[u].x : 0.0, p0, x0);
+                one(rv[u].y, JAC ? dv[u].y : 0.0, pv[u].y, XUP ? xv[u].y : 0.0, p1, x1);
+                v2f64 po, xo;
+                po.x = p0; po.y = p1; xo.x = x0; xo.y = x1;
+                st2(p, q, po);
+                if (XUP) st2(x, q, xo);
+            }
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const int i = n - 1;
+            double po, xo;
+            one(r[i], JAC ? dinv[i] : 0.0, p[i], XUP ? x[i] : 0.0, po, xo);
+            p[i] = po;
+            if (XUP) x[i] = xo;
+        }
+    } else {
+        const long long i0 = (long long)blockIdx.x * (2 * PAIRS_PER_BLOCK) + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 2 * U; u++) {
+            const long long i = i0 + u * BLOCK;
+            if (i < n) {
+                double po, xo;
+                one(r[i], JAC ? dinv[i] : 0.0, p[i], XUP ? x[i] : 0.0, po, xo);
+                p[i] = po;
+                if (XUP) x[i] = xo;
+            }
+        }
+    }
+}
+
+template <bool JAC, bool XUP>
+int run_cg_direction(int n, const double *palpha, const double *pbeta, const double *r, const double *dinv, double *p, double *x, void *stream)
+{
+    if (n < 0 || !pbeta || !r || !p || (XUP && (!palpha || !x)) || (JAC && !dinv)) return LISHIP_ERR_ARG;
+    if (n == 0) return 0;
+    const bool vec = aligned16(r) && aligned16(p) && (!JAC || aligned16(dinv)) && (!XUP || aligned16(x));
+    const int grid = blocks_for(((long long)n + 1) / 2);
+    hipStream_t st = as_stream(stream);
+    if (!vec)                   cg_direction_kernel<false, false, JAC, XUP><<<grid, BLOCK, 0, st>>>(n, palpha, pbeta, r, dinv, p, x, g_guard);
+    else if (n > NT_LOAD_ELEMS) cg_direction_kernel<true, true, JAC, XUP><<<grid, BLOCK, 0, st>>>(n, palpha, pbeta, r, dinv, p, x, g_guard);
+    else                        cg_direction_kernel<false, true, JAC, XUP><<<grid, BLOCK, 0, st>>>(n, palpha, pbeta, r, dinv, p, x, g_guard);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- reductions -------------------------------------------------------------------------------------
 // level 1: partial[k*stride + block] for k < NRES; levels >= 2 sum partial arrays the same way
 enum RedOp { RED_DOT, RED_SUMSQ, RED_ABS, RED_SUM, RED_DOT2,
@@ -150,11 +228,12 @@ enum RedOp { RED_DOT, RED_SUMSQ, RED_ABS, RED_SUM, RED_DOT2,
              RED_CG_UPDATE_JAC, // same + z = r.*dinv (not stored); results {sum r^2, sum r*z}
              RED_AXPY_NRM2,     // y += a*x; result {sum y^2}
              RED_AXPY_NRM2_DOT, // y += a*x; results {sum y^2, sum w*y}
+             RED_AXPY_NRM2_JAC, // y += a*x; z = y.*e (not stored); results {sum y^2, sum y*z}
              RED_AXPYD_DOT,     // y += (-*sp)*x; result {sum y*w}      (one modified Gram-Schmidt step)
              RED_AXPYD_SUMSQ    // y += (-*sp)*x; result {sum y^2}      (the last one)
 };
 template <int OP> struct RedResults { static constexpr int value =
-    (OP == RED_DOT2 || OP == RED_AXPY_NRM2_DOT || OP == RED_CG_UPDATE_JAC) ? 2 : 1; };
+    (OP == RED_DOT2 || OP == RED_AXPY_NRM2_DOT || OP == RED_CG_UPDATE_JAC || OP == RED_AXPY_NRM2_JAC) ? 2 : 1; };
 
 struct RedArgs {
     int n;
@@ -189,10 +268,11 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
             s0 += oy * oy;
             if (OP == RED_CG_UPDATE_JAC) { const double z = oy * e; s1 += oy * z; }   // z = r.*dinv ; <r,z>
         }
-        if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT) {
+        if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC) {
             oy = y + A.a * x;               // y += a*x
             s0 += oy * oy;
             if (OP == RED_AXPY_NRM2_DOT) s1 += w * oy;
+            if (OP == RED_AXPY_NRM2_JAC) { const double z = oy * e; s1 += oy * z; }   // z = r.*dinv ; <r,z>
         }
         if (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) {
             oy = y + adev * x;              // y += (-h)*x, h read from HBM: no host round trip between steps
@@ -202,10 +282,11 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
     };
     constexpr bool IS_CG = (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC);
     constexpr bool IS_AXD = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ);
-    constexpr bool HAS_Y = (OP == RED_DOT || OP == RED_DOT2 || IS_CG || OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || IS_AXD);
+    constexpr bool IS_AXN = (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC);
+    constexpr bool HAS_Y = (OP == RED_DOT || OP == RED_DOT2 || IS_CG || IS_AXN || IS_AXD);
     constexpr bool HAS_W = (IS_CG || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPYD_DOT);
     constexpr bool HAS_D = IS_CG;
-    constexpr bool HAS_E = (OP == RED_CG_UPDATE_JAC);
+    constexpr bool HAS_E = (OP == RED_CG_UPDATE_JAC || OP == RED_AXPY_NRM2_JAC);
     if (VEC) {
         const long long npairs = n >> 1;
         const long long base = (long long)blockIdx.x * PAIRS_PER_BLOCK + threadIdx.x;
@@ -231,7 +312,7 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
                 v2f64 ox, oy;
                 ox.x = ox0; ox.y = ox1; oy.x = oy0; oy.y = oy1;
                 if (IS_CG) { st2(A.ox, p, ox); st2(A.oy, p, oy); }
-                if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || IS_AXD) st2(A.oy, p, oy);
+                if (IS_AXN || IS_AXD) st2(A.oy, p, oy);
             }
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -239,7 +320,7 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
             double ox, oy;
             term(A.x[i], HAS_Y ? A.y[i] : 0.0, HAS_W ? A.w[i] : 0.0, HAS_D ? A.d[i] : 0.0, HAS_E ? A.e[i] : 0.0, ox, oy);
             if (IS_CG) { A.ox[i] = ox; A.oy[i] = oy; }
-            if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || IS_AXD) A.oy[i] = oy;
+            if (IS_AXN || IS_AXD) A.oy[i] = oy;
         }
     } else {
         const long long i0 = (long long)blockIdx.x * (2 * PAIRS_PER_BLOCK) + threadIdx.x;
@@ -249,7 +330,7 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
                 double ox, oy;
                 term(A.x[i], HAS_Y ? A.y[i] : 0.0, HAS_W ? A.w[i] : 0.0, HAS_D ? A.d[i] : 0.0, HAS_E ? A.e[i] : 0.0, ox, oy);
                 if (IS_CG) { A.ox[i] = ox; A.oy[i] = oy; }
-                if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || IS_AXD) A.oy[i] = oy;
+                if (IS_AXN || IS_AXD) A.oy[i] = oy;
             }
         }
     }
@@ -614,6 +695,22 @@ extern "C" int liship_cg_update_dev_f64(int n, const double *palpha, const doubl
     if (!palpha) return LISHIP_ERR_ARG;
     RedArgs A{n, 0.0, p, q, x, r, dinv, x, r, nullptr, palpha};
     return dinv ? run_reduce<RED_CG_UPDATE_JAC>(A, result, w, false, s) : run_reduce<RED_CG_UPDATE>(A, result, w, false, s);
+}
+// device-driven CG with the x update deferred into the next direction update (80 B instead of 88 B of vector traffic per row
+// and iteration): palpha NULL = first iteration, x untouched; dinv NULL = no preconditioner
+extern "C" int liship_cg_direction_dev_f64(int n, const double *palpha, const double *pbeta, const double *r, const double *dinv,
+                                           double *p, double *x, void *s)
+{
+    if (dinv) return palpha ? run_cg_direction<true, true>(n, palpha, pbeta, r, dinv, p, x, s) : run_cg_direction<true, false>(n, palpha, pbeta, r, dinv, p, x, s);
+    return palpha ? run_cg_direction<false, true>(n, palpha, pbeta, r, dinv, p, x, s) : run_cg_direction<false, false>(n, palpha, pbeta, r, dinv, p, x, s);
+}
+// r += (*pna)*q ; result = {sum r^2, sum r*(r.*dinv)}   (the residual half of liship_cg_update_jacobi_f64; pna holds -alpha)
+extern "C" int liship_cg_residual_jacobi_dev_f64(int n, const double *pna, const double *q, const double *dinv, double *r,
+                                                 double *result, void *w, void *s)
+{
+    if (!pna || !dinv) return LISHIP_ERR_ARG;
+    RedArgs A{n, 0.0, q, r, nullptr, nullptr, dinv, nullptr, r, nullptr, pna};
+    return run_reduce<RED_AXPY_NRM2_JAC>(A, result, w, false, s);
 }
 extern "C" int liship_axpy_sumsq_dev_f64(int n, const double *pa, const double *x, double *y, double *result, void *w, void *s)
 {

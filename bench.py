@@ -317,9 +317,9 @@ def krylov_bytes(key, iters, n, nnz, coded):
         # r -= alpha q, ||r||^2, <r, dinv.*r> (q r dinv | r)
         return S + CG_VECTOR_BYTES_PER_ROW * n, B + 136 * n
     if key == "bicgstab_none":
-        # p-update 32 ; v = A p + <rtld,v> (+8: rtld) ; s = r - alpha v, ||s|| 24 ; t = A s + <t,s>,<t,t> ; x += alpha p + omega s 32 ;
-        # r = s - omega t, ||r||, <rtld,r> 32
-        return 2 * S + 128 * n, 2 * B + 248 * n
+        # p-update 32 ; v = A p + <rtld,v> (+8: rtld) ; s = r - alpha v, ||s|| 24 ; t = A s + <t,s>,<t,t> ;
+        # x += alpha p + omega s, r = s - omega t, ||r||, <rtld,r> in one pass 56 (t s rtld p x | x r)
+        return 2 * S + 120 * n, 2 * B + 248 * n
     if key == "bicg_none":
         # two direction updates 24 + 24 ; q = A p + <p~,q> (+8: p~) ; q~ = A^T p~ ; x,r update 48 ; r~ update + rho 32
         # reference: 2 products, 2 copies (psolve none), 2 dots, 2 xpays, 3 axpys, nrm2 (lis_solver_bicg.c:176-262) = 192 n

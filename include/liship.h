@@ -270,6 +270,11 @@ int  liship_cg_direction_dev_f64(int n, const double *palpha, const double *pbet
  * (without a preconditioner liship_axpy_sumsq_dev_f64 serves) */
 int  liship_cg_residual_jacobi_dev_f64(int n, const double *pna, const double *q, const double *dinv, double *r,
                                        double *result, void *work, void *stream);
+/* BiCGSTAB without a preconditioner (shat is s itself): x += (*palpha)*phat, x += (*pomega)*s, r = s + (*pnomega)*t, result =
+ * {sum r^2, sum rtld*r} -- lis_solver_bicgstab.c:272-279 and :190 of the next iteration in ONE pass (s is read once for the
+ * iterate and the residual: 56 instead of 64 B per row); s is the content of r[] on entry */
+int  liship_bicgstab_end_dev_f64(int n, const double *palpha, const double *pomega, const double *pnomega, const double *phat,
+                                 const double *t, const double *rtld, double *x, double *r, double *result, void *work, void *stream);
 /* the fused update passes with the coefficient in HBM (dinv may be NULL for liship_cg_update_dev_f64) */
 int  liship_cg_update_dev_f64(int n, const double *palpha, const double *p, const double *q, const double *dinv,
                               double *x, double *r, double *result, void *work, void *stream);

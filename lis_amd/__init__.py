@@ -89,6 +89,7 @@ _LISHIP = {
     "liship_cg_update_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_cg_update_jacobi_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_pmul_xpay_f64": (_ci, [_ci, _vp, _vp, _cd, _vp, _vp]),
+    "liship_bicgstab_end_dev_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_cg_direction_dev_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_cg_residual_jacobi_dev_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_axpy_sumsq_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp]),

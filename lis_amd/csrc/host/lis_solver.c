@@ -444,9 +444,12 @@ static LIS_INT run_bicgstab_device(ctx_t *c)
 			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_OMEGA));
 			TRY(lisd_spmv_dot_launch_to(c->A, shat, t, sv, 1, st + LISHIP_KS_DOT0));
 			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_OMEGA, LISHIP_KS_DOT0, 2));
-			KTRY(liship_axpy2_dev_f64(n, st + LISHIP_KS_ALPHA, phat, st + LISHIP_KS_OMEGA, shat, c->x, lisg.stream));
+			if (pre) KTRY(liship_axpy2_dev_f64(n, st + LISHIP_KS_ALPHA, phat, st + LISHIP_KS_OMEGA, shat, c->x, lisg.stream));
 			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_RESID));
-			KTRY(liship_axpy_sumsq_dot_dev_f64(n, st + LISHIP_KS_NOMEGA, t, r, rtld, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			if (pre) KTRY(liship_axpy_sumsq_dot_dev_f64(n, st + LISHIP_KS_NOMEGA, t, r, rtld, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			else     /* shat is s itself: the iterate and the residual in one pass (s read once) */
+				KTRY(liship_bicgstab_end_dev_f64(n, st + LISHIP_KS_ALPHA, st + LISHIP_KS_OMEGA, st + LISHIP_KS_NOMEGA, phat, t, rtld, c->x, r,
+				                                 st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
 			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_RESID, LISHIP_KS_SUM0, 2));
 		}
 		queued += batch;

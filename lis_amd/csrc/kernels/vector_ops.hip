@@ -229,11 +229,12 @@ enum RedOp { RED_DOT, RED_SUMSQ, RED_ABS, RED_SUM, RED_DOT2,
              RED_AXPY_NRM2,     // y += a*x; result {sum y^2}
              RED_AXPY_NRM2_DOT, // y += a*x; results {sum y^2, sum w*y}
              RED_AXPY_NRM2_JAC, // y += a*x; z = y.*e (not stored); results {sum y^2, sum y*z}
+             RED_BICGSTAB_END,  // e += (*pb)*d; e += (*pc)*y; y += a*x; results {sum y^2, sum w*y}   (x-iterate and residual of BiCGSTAB)
              RED_AXPYD_DOT,     // y += (-*sp)*x; result {sum y*w}      (one modified Gram-Schmidt step)
              RED_AXPYD_SUMSQ    // y += (-*sp)*x; result {sum y^2}      (the last one)
 };
 template <int OP> struct RedResults { static constexpr int value =
-    (OP == RED_DOT2 || OP == RED_AXPY_NRM2_DOT || OP == RED_CG_UPDATE_JAC || OP == RED_AXPY_NRM2_JAC) ? 2 : 1; };
+    (OP == RED_DOT2 || OP == RED_AXPY_NRM2_DOT || OP == RED_CG_UPDATE_JAC || OP == RED_AXPY_NRM2_JAC || OP == RED_BICGSTAB_END) ? 2 : 1; };
 
 struct RedArgs {
     int n;
@@ -243,6 +244,7 @@ struct RedArgs {
     const double *sp;                // device scalar of the *D ops (last: the other initialisers leave it NULL)
     const double *pa;                // coefficient `a` read from HBM when set (device-driven loops)
     const double *skip;              // guard flag (filled by run_reduce)
+    const double *pb, *pc;           // further device coefficients (RED_BICGSTAB_END: alpha, omega)
 };
 
 template <int OP, bool NT, bool VEC>
@@ -256,6 +258,7 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
     if (A.skip && A.skip[0] != 0.0) return;
     if (A.pa) A.a = A.pa[0];
     const double adev = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) ? -A.sp[0] : 0.0;
+    const double cb = OP == RED_BICGSTAB_END ? A.pb[0] : 0.0, cc = OP == RED_BICGSTAB_END ? A.pc[0] : 0.0;
     auto term = [&](double x, double y, double w, double d, double e, double &ox, double &oy) {
         if (OP == RED_DOT)   s0 += x * y;
         if (OP == RED_SUMSQ) s0 += x * x;
@@ -274,19 +277,26 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
             if (OP == RED_AXPY_NRM2_DOT) s1 += w * oy;
             if (OP == RED_AXPY_NRM2_JAC) { const double z = oy * e; s1 += oy * z; }   // z = r.*dinv ; <r,z>
         }
+        if (OP == RED_BICGSTAB_END) {       // x: t, y: s (becomes r), w: rtld, d: phat, e: the iterate; shat aliases s (no preconditioner)
+            const double t1 = e + cb * d;   // x += alpha*phat     (lis_solver_bicgstab.c:272)
+            ox = t1 + cc * y;               // x += omega*shat     (:273)
+            oy = y + A.a * x;               // r += (-omega)*t     (:276)
+            s0 += oy * oy;
+            s1 += w * oy;
+        }
         if (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) {
             oy = y + adev * x;              // y += (-h)*x, h read from HBM: no host round trip between steps
             if (OP == RED_AXPYD_DOT) s0 += oy * w; else s0 += oy * oy;
         }
         (void)e;
     };
-    constexpr bool IS_CG = (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC);
+    constexpr bool IS_CG = (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC || OP == RED_BICGSTAB_END);     // five inputs, two outputs
     constexpr bool IS_AXD = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ);
     constexpr bool IS_AXN = (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC);
     constexpr bool HAS_Y = (OP == RED_DOT || OP == RED_DOT2 || IS_CG || IS_AXN || IS_AXD);
     constexpr bool HAS_W = (IS_CG || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPYD_DOT);
     constexpr bool HAS_D = IS_CG;
-    constexpr bool HAS_E = (OP == RED_CG_UPDATE_JAC || OP == RED_AXPY_NRM2_JAC);
+    constexpr bool HAS_E = (OP == RED_CG_UPDATE_JAC || OP == RED_AXPY_NRM2_JAC || OP == RED_BICGSTAB_END);
     if (VEC) {
         const long long npairs = n >> 1;
         const long long base = (long long)blockIdx.x * PAIRS_PER_BLOCK + threadIdx.x;
@@ -711,6 +721,15 @@ extern "C" int liship_cg_residual_jacobi_dev_f64(int n, const double *pna, const
     if (!pna || !dinv) return LISHIP_ERR_ARG;
     RedArgs A{n, 0.0, q, r, nullptr, nullptr, dinv, nullptr, r, nullptr, pna};
     return run_reduce<RED_AXPY_NRM2_JAC>(A, result, w, false, s);
+}
+// BiCGSTAB without a preconditioner: x += (*palpha)*phat + (*pomega)*s ; r = s + (*pnomega)*t ; result = {sum r^2, sum rtld*r}
+// (s is the residual array before the pass, r after it): liship_axpy2_dev_f64 + liship_axpy_sumsq_dot_dev_f64 in one pass
+extern "C" int liship_bicgstab_end_dev_f64(int n, const double *palpha, const double *pomega, const double *pnomega, const double *phat,
+                                           const double *t, const double *rtld, double *x, double *r, double *result, void *w, void *s)
+{
+    if (!palpha || !pomega || !pnomega) return LISHIP_ERR_ARG;
+    RedArgs A{n, 0.0, t, r, rtld, phat, x, x, r, nullptr, pnomega, nullptr, palpha, pomega};
+    return run_reduce<RED_BICGSTAB_END>(A, result, w, false, s);
 }
 extern "C" int liship_axpy_sumsq_dev_f64(int n, const double *pa, const double *x, double *y, double *result, void *w, void *s)
 {

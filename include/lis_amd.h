@@ -46,10 +46,13 @@ LIS_INT lis_amd_vector_device_modified(LIS_VECTOR v);  /* HBM copy was written b
 
 /* matrices */
 LIS_INT lis_amd_matrix_upload(LIS_MATRIX A);           /* build the HBM copy now (otherwise on first use) */
-LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A);
+LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A);   /* host arrays changed: drop the HBM copy */
 /* number of entries of the column-offset dictionary when the HBM copy of A carries one-byte column codes (liship.h
  * "index coding": matrices on <= 255 diagonals), 0 when it reads the 4 B indices; uploads A if needed */
-LIS_INT lis_amd_matrix_index_codes(LIS_MATRIX A);    /* host arrays changed: drop the HBM copy          */
+LIS_INT lis_amd_matrix_index_codes(LIS_MATRIX A);
+/* total length of the per-row-block lists of distinct columns when the HBM copy of A carries block-local columns (liship.h:
+ * long rows that share their columns), 0 when it does not; uploads A if needed */
+LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A);
 /* adopt CSR arrays that already live in HBM (no host copy exists; A must be sized and unassembled).
  * ptr has n+1 entries, columns are local (0..np-1, ghosts >= n).  The arrays are freed with the matrix. */
 LIS_INT lis_amd_matrix_set_csr_device(LIS_INT nnz, LIS_INT np, LIS_INT *dptr, LIS_INT *dindex,

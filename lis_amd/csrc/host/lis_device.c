@@ -405,6 +405,12 @@ LIS_INT lis_amd_matrix_index_codes(LIS_MATRIX A)
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	return MDEV(A)->plan ? liship_csr_plan_coded(MDEV(A)->plan) : 0;
 }
+LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	const long long listed = MDEV(A)->plan ? liship_csr_plan_localized(MDEV(A)->plan) : 0;
+	return listed > 0x7fffffffLL ? 0x7fffffff : (LIS_INT)listed;
+}
 LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A)
 {
 	if (MDEV(A)->device_only) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix lives in HBM only\n");

@@ -1,0 +1,75 @@
+"""Golden results of the reference for BASELINE config 4's class: irregular CSR with long rows, GMRES(30) and friends.
+
+SuiteSparse Queen_4147 itself is neither in the reference tree nor fetchable here; two generated matrices stand in
+(tests/orc.py, deterministic numpy code, fingerprinted below so that a drift of the generators is noticed):
+  fem3_22   orc.fem3(22): 3 unknowns per node of a 22^3 grid, 27-node connectivity -- 31 944 rows, 2.4 M non-zeros,
+            up to 81 per row, symmetric, diagonally dominant (the block-local-columns kernel serves it)
+  tail      orc.heavy_tail(30000): Pareto row lengths 1 .. 9000 (mean ~25, rows longer than the LDS stage), random
+            columns, non-symmetric, diagonally dominant (the products kernel and its long-row passes serve it)
+Dev container only: oracle/_ref (Lis 2.1.11 from /root/reference/src, 1 OpenMP thread) through lis_matvec / lis_solve, with
+b = A * x_true as test/test1.c builds it in rhs mode 2 (test1.c:138-139), but with x_true = cos(0.01 i) + 1.25 instead of 1: the
+rows of fem3 sum to 1, so b = A*1 = 1 would be solved in one iteration.  Stored per case: iteration count,
+status, final relative residual, the first residual-history entries, and a checksum of y = A*x.
+    python tests/golden/make_golden_irregular.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+import lisdrv  # noqa: E402
+import orc     # noqa: E402
+
+SOLVES = {
+    "fem3_22": ("-i gmres -restart 30 -p none", "-i gmres -restart 30 -p jacobi", "-i bicgstab -p none", "-i cg -p jacobi", "-i bicg -p none"),
+    "tail": ("-i gmres -restart 30 -p none", "-i gmres -restart 30 -p jacobi", "-i bicgstab -p jacobi", "-i bicg -p jacobi"),
+}
+
+
+def matrices():
+    ptr, idx, val, _ = orc.fem3(22)
+    yield "fem3_22", ptr, idx, val
+    yield ("tail",) + orc.heavy_tail(30000)
+
+
+def fingerprint(ptr, idx, val):
+    h = hashlib.sha256()
+    for a in (np.ascontiguousarray(ptr, np.int32), np.ascontiguousarray(idx, np.int32), np.ascontiguousarray(val, np.float64)):
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def main():
+    orc.build()
+    ref = lisdrv.open_lib(orc.REF_SO, threads=1)
+    out = {"_source": "Lis 2.1.11 compiled from /root/reference by oracle/Makefile, 1 OpenMP thread, b = A*(cos(0.01 i) + 1.25), x0 = 0, tol 1e-12 "
+                      "(tests/golden/make_golden_irregular.py)"}
+    for name, ptr, idx, val in matrices():
+        n = len(ptr) - 1
+        A = lisdrv.make_csr(ref, ptr, idx, val)
+        x = np.cos(np.arange(n) * 0.01) + 1.25
+        vx, vy = lisdrv.new_vector(ref, A, x), lisdrv.new_vector(ref, A)
+        assert ref.lis_matvec(A, vx, vy) == 0
+        y = lisdrv.get_vector(ref, vy, n)
+        assert np.array_equal(y, orc.spmv_csr(ptr, idx, val, x))          # the oracle restates the reference's product
+        b = y                                                             # = A * x_true
+        lens = np.diff(ptr)
+        case = {"n": n, "nnz": int(len(idx)), "max_row": int(lens.max()), "sha256": fingerprint(ptr, idx, val),
+                "y_sha256": hashlib.sha256(y.tobytes()).hexdigest(), "solves": {}}
+        for opts in SOLVES[name]:
+            res = lisdrv.solve(ref, A, b, opts + " -tol 1e-12 -maxiter 2000 -print mem")
+            case["solves"][opts] = {"iter": int(res["iter"]), "status": int(res["status"]), "resid": float(res["resid"]),
+                                    "rhistory_head": [float(v) for v in res["rhistory"][:6]]}
+            print(name, opts, res["iter"], res["status"], res["resid"])
+        out[name] = case
+    json.dump(out, open(os.path.join(HERE, "irregular_golden.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,23 @@ def fem3(G, dofs=3):
         val[at] = rowsum[dofs * p + d] + 1.0
     return ptr.astype(np.int32), idx, val, n
 
+
+def heavy_tail(n, seed=3, cap=9000):
+    """Heavy-tailed row lengths (Pareto, 1 .. cap: some rows longer than the kernels' LDS stage), random columns (repeats
+    allowed), values in [-1,1) with the diagonal entry -- stored first -- raised to 1 + the row's absolute sum: non-symmetric,
+    strictly diagonally dominant.  The load-balance stress of BASELINE config 4's class.  Returns ptr, idx, val."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum((rng.pareto(1.3, n) * 8 + 2).astype(np.int64), cap)
+    ptr = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    nnz = int(ptr[-1])
+    idx = rng.integers(0, n, nnz, dtype=np.int32)
+    val = rng.uniform(-1, 1, nnz)
+    idx[ptr[:-1]] = np.arange(n, dtype=np.int32)                       # first entry of every row: the diagonal
+    val[ptr[:-1]] = 0.0
+    val[ptr[:-1]] = np.add.reduceat(np.abs(val), ptr[:-1]) + 1.0
+    return ptr.astype(np.int32), idx, val
+
 def spmv_csr(ptr, idx, val, x):
     n = len(ptr) - 1
     y = np.empty(n)

@@ -78,3 +78,40 @@ def test_known_iteration_counts_32cubed():
     assert [it, resid] == list(G["known/bicgstab_none_32/iter_resid"])      # 75 at 1 thread
     _, it, rc, resid, _ = orc.gmres(ptr, idx, val, b, maxiter=1000, restart=30)
     assert [it, resid] == list(G["known/gmres30_none_32/iter_resid"])       # 276
+
+
+# ---------------------------------------------------------------- BASELINE config 4's class (irregular, long rows)
+import hashlib  # noqa: E402
+import json     # noqa: E402
+
+IRR = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "irregular_golden.json")))
+
+
+def _irr_matrix(name):
+    return orc.fem3(22)[:3] if name == "fem3_22" else orc.heavy_tail(30000)
+
+
+@pytest.mark.parametrize("name", ["fem3_22", "tail"])
+def test_irregular_fixture_oracle_product_and_counts(name):
+    """the generators still produce the matrices the fixture was made from, and the oracle reproduces what the reference
+    returned for them: the bits of y = A*x and -- same arithmetic at one thread -- the exact iteration counts"""
+    ptr, idx, val = _irr_matrix(name)
+    g = IRR[name]
+    h = hashlib.sha256()
+    for a in (ptr.astype(np.int32), idx.astype(np.int32), val):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == g["sha256"], "orc.fem3 / orc.heavy_tail drifted from tests/golden/irregular_golden.json"
+    n = len(ptr) - 1
+    x = np.cos(np.arange(n) * 0.01) + 1.25
+    y = orc.spmv_csr(ptr, idx, val, x)
+    assert hashlib.sha256(y.tobytes()).hexdigest() == g["y_sha256"]
+    for opts, want in g["solves"].items():
+        if want["iter"] > 200:
+            continue                                      # the 1225-iteration GMRES run stays with the generator script
+        tok = opts.split()
+        solver, precon = tok[1], tok[tok.index("-p") + 1]
+        kw = {"restart": 30} if solver == "gmres" else {}
+        _, it, rc, resid, rh = getattr(orc, solver)(ptr, idx, val, y, precon=precon, tol=1e-12, maxiter=2000, **kw)
+        assert (it, rc) == (want["iter"], want["status"]), opts
+        assert resid == want["resid"], opts
+        assert list(rh[:6]) == want["rhistory_head"], opts

@@ -316,3 +316,24 @@ def test_set_values_block_and_row_hints(lib):
     assert np.array_equal(arrs["ptr"], np.arange(0, n * n + 1, n))
     assert np.array_equal(arrs["index"], np.tile(np.arange(n), n)) and np.array_equal(arrs["value"], dense.ravel())
     lib.lis_matrix_destroy(A)
+
+
+def test_handle_registry_follows_the_live_count(lib):
+    """a long create / destroy history (every lis_solve registers a preconditioner) must not grow the handle table"""
+    dll = lib.dll
+    dll.lisi_registry_slots.restype = C.c_size_t
+    keep = []
+    for _ in range(100):
+        v = capi.PV()
+        assert lib.lis_vector_create(0, C.byref(v)) == 0
+        keep.append(v)
+    before = dll.lisi_registry_slots()
+    for _ in range(20000):
+        v = capi.PV()
+        assert lib.lis_vector_create(0, C.byref(v)) == 0
+        assert lib.lis_vector_set_size(v, 4, 0) == 0
+        assert lib.lis_vector_destroy(v) == 0
+    assert dll.lisi_registry_slots() <= max(before, 1024)
+    for v in keep:                                       # the survivors are still known
+        assert lib.lis_vector_set_size(v, 3, 0) == 0
+        assert lib.lis_vector_destroy(v) == 0

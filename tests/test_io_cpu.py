@@ -180,6 +180,42 @@ def test_error_paths(lib, tmp_path, capfd):
         lib.lis_matrix_destroy(m)
 
 
+def test_indices_outside_the_matrix_are_refused(lib, tmp_path, capfd):
+    """an out-of-range row / column would become a gather index of the HIP kernels: the readers fail with LIS_ERR_FILE_IO"""
+    cases = {
+        "col.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n2 4 5.0\n",
+        "row.mtx": "%%MatrixMarket matrix coordinate real symmetric\n3 3 2\n1 1 1.0\n7 2 5.0\n",
+        "zero.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 2\n0 1 1.0\n2 2 5.0\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / name
+        p.write_text(text)
+        A = capi.PM()
+        lib.lis_matrix_create(0, C.byref(A))
+        assert lib.lis_input_matrix(A, str(p).encode()) == 6, name
+        lib.lis_matrix_destroy(A)
+    # Harwell-Boeing: a generated file with one row index pushed out of range, and one that ends before its last card
+    good = open(os.path.join(MM, "gen_hb.rua")).read().splitlines()
+    head = good[:4]
+    ptrcrd, indcrd = int(good[1][14:28]), int(good[1][28:42])
+    bad = list(good)
+    first_ind = 4 + ptrcrd
+    bad[first_ind] = "%8d" % 99999 + bad[first_ind][8:]
+    p = tmp_path / "badrow.rua"
+    p.write_text("\n".join(bad) + "\n")
+    A = capi.PM()
+    lib.lis_matrix_create(0, C.byref(A))
+    assert lib.lis_input_matrix(A, str(p).encode()) == 6
+    lib.lis_matrix_destroy(A)
+    p = tmp_path / "short.rua"
+    p.write_text("\n".join(good[:4 + ptrcrd + indcrd]) + "\n")           # no value cards at all
+    A = capi.PM()
+    lib.lis_matrix_create(0, C.byref(A))
+    assert lib.lis_input_matrix(A, str(p).encode()) == 6
+    lib.lis_matrix_destroy(A)
+    capfd.readouterr()
+
+
 def test_live_against_reference_on_random_files(lib, reflib, tmp_path, capfd):
     """Dev container only: random general / symmetric files, the reference and this library read the same bytes."""
     rng = np.random.default_rng(7)

@@ -265,8 +265,7 @@ typedef struct LIS_VECTOR_STRUCT *LIS_VECTOR;
 
 #define LIS_MATRIX_OPTION_LEN 10
 
-/* ref:569-589 (split parts; never populated here: lis_matrix_split is internal to the reference and only reached
- * through the SSOR / ILU-family preconditioners, which are not served) */
+/* ref:569-589: the strictly lower / upper part of a split matrix (lis_matrix_split), in the layout of the matrix's own format */
 struct LIS_MATRIX_CORE_STRUCT
 {
 	LIS_INT nnz, ndz, bnr, bnc, nr, nc, bnnz, nnd, maxnzr;
@@ -495,6 +494,10 @@ LIS_INT lis_matrix_malloc(LIS_MATRIX A, LIS_INT nnz_row, LIS_INT nnz[]);        
 LIS_INT lis_matrix_get_diagonal(LIS_MATRIX A, LIS_VECTOR d);
 LIS_INT lis_matrix_scale(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_INT action);   /* ref:882, src/matrix/lis_matrix_ops.c:579 (-scale) */
 LIS_INT lis_matrix_convert(LIS_MATRIX Ain, LIS_MATRIX Aout);
+/* A = L + D + U in A->L / A->D / A->U (is_splited): lis_matvec then adds D x first, the L entries, the U entries.  The
+ * reference keeps these two in its internal header (src/matrix lis_matrix.h; lis_matrix_ops.c:860, :1052) */
+LIS_INT lis_matrix_split(LIS_MATRIX A);
+LIS_INT lis_matrix_merge(LIS_MATRIX A);
 LIS_INT lis_matrix_copy(LIS_MATRIX Ain, LIS_MATRIX Aout);
 LIS_INT lis_matrix_set_blocksize(LIS_MATRIX A, LIS_INT bnr, LIS_INT bnc, LIS_INT row[], LIS_INT col[]);
 LIS_INT lis_matrix_unset(LIS_MATRIX A);

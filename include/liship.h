@@ -90,6 +90,11 @@ int  liship_spmv_csr_set_local_columns(int on);
 int  liship_spmv_csr_set_long_row_tree(int on);
 int  liship_csr_plan_destroy(liship_csr_plan_t plan);
 int  liship_csr_plan_info(liship_csr_plan_t plan, int *n, long long *nnz, int *nblocks);
+/* Rows that START with their first product instead of being added to 0.0: the reference's split products compute
+ * t0 = D[i]*x[i]; t0 += (L row); t0 += (U row)  (lis_matvec_csr.c:64-89 and the is_splited branches of the other formats).
+ * With the flag on, every product of this plan starts its row sums at -0.0, which reproduces that sequence bit for bit
+ * (signed zeros included) on rows laid out as [D, L entries, U entries]. */
+int  liship_csr_plan_set_first_term_initialises(liship_csr_plan_t plan, int on);
 int  liship_spmv_csr_f64(liship_csr_plan_t plan, const int *ptr, const int *index,
                          const double *value, const double *x, double *y, void *stream);
 /* the product with a fused reduction epilogue: result[0] = sum_r w[r]*y[r] (w may be x: CG's <p,Ap>,

@@ -49,6 +49,7 @@ _LISHIP = {
     "liship_error_string": (C.c_char_p, [_ci]),
     "liship_csr_plan_create": (_ci, [_pvp, _ci, _vp, _vp]),
     "liship_csr_plan_destroy": (_ci, [_vp]),
+    "liship_csr_plan_set_first_term_initialises": (_ci, [_vp, _ci]),
     "liship_csr_plan_info": (_ci, [_vp, C.POINTER(_ci), C.POINTER(C.c_longlong), C.POINTER(_ci)]),
     "liship_spmv_csr_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_spmv_csr_dot_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),

@@ -49,6 +49,20 @@ class CommTable(C.Structure):
     ]
 
 
+class MatrixCore(C.Structure):
+    """LIS_MATRIX_CORE_STRUCT (lis.h:569-589): the L / U part of a split matrix."""
+    _fields_ = [(k, LIS_INT) for k in ("nnz", "ndz", "bnr", "bnc", "nr", "nc", "bnnz", "nnd", "maxnzr")] + \
+               [(k, P_INT) for k in ("ptr", "row", "col", "index", "bptr", "bindex")] + [("value", P_DBL), ("work", P_DBL)]
+
+
+class MatrixDiag(C.Structure):
+    """LIS_MATRIX_DIAG_STRUCT (lis.h:591-619)."""
+    _fields_ = [(k, LIS_INT) for k in ("label", "status", "precision", "gn", "n", "np", "pad", "origin", "is_copy", "is_destroy",
+                                       "is_scaled", "my_rank", "nprocs", "comm", "is_", "ie")] + \
+               [("ranges", P_INT), ("value", P_DBL), ("work", P_DBL), ("bn", LIS_INT), ("nr", LIS_INT), ("bns", P_INT), ("ptr", P_INT),
+                ("v_value", C.c_void_p)]
+
+
 class Matrix(C.Structure):
     _fields_ = _Header._fields_ + [
         ("matrix_type", LIS_INT), ("nnz", LIS_INT), ("ndz", LIS_INT), ("bnr", LIS_INT),
@@ -56,7 +70,7 @@ class Matrix(C.Structure):
         ("nnd", LIS_INT), ("maxnzr", LIS_INT),
         ("ptr", P_INT), ("row", P_INT), ("col", P_INT), ("index", P_INT),
         ("bptr", P_INT), ("bindex", P_INT), ("value", P_DBL), ("work", P_DBL),
-        ("L", C.c_void_p), ("U", C.c_void_p), ("D", C.c_void_p), ("WD", C.c_void_p),
+        ("L", C.POINTER(MatrixCore)), ("U", C.POINTER(MatrixCore)), ("D", C.POINTER(MatrixDiag)), ("WD", C.c_void_p),
         ("is_block", LIS_INT), ("pad_comm", LIS_INT), ("is_pmat", LIS_INT),
         ("is_sorted", LIS_INT), ("is_splited", LIS_INT), ("is_save", LIS_INT),
         ("is_comm", LIS_INT), ("is_fallocated", LIS_INT), ("use_wd", LIS_INT),
@@ -145,6 +159,8 @@ _PROTOS = {
     "lis_matrix_set_value": (LIS_INT, [LIS_INT, LIS_INT, LIS_INT, LIS_SCALAR, PM]),
     "lis_matrix_get_diagonal": (LIS_INT, [PM, PV]),
     "lis_matrix_convert": (LIS_INT, [PM, PM]),
+    "lis_matrix_split": (LIS_INT, [PM]),
+    "lis_matrix_merge": (LIS_INT, [PM]),
     "lis_matrix_copy": (LIS_INT, [PM, PM]),
     "lis_matrix_set_blocksize": (LIS_INT, [PM, LIS_INT, LIS_INT, P_INT, P_INT]),
     "lis_matrix_malloc_csr": (LIS_INT, [LIS_INT, LIS_INT, C.POINTER(P_INT), C.POINTER(P_INT), C.POINTER(P_DBL)]),

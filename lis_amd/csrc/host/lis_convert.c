@@ -96,7 +96,7 @@ fail:
 /* descending sort of key[] carrying tag[] with the reference's own partition scheme (middle pivot parked at
  * the end, strict Hoare scans; src/system/lis_sort.c:249-276): it is unstable, and the JAD permutation of
  * equal-length rows is whatever this exact scheme leaves -- parity of A->row needs the same scheme */
-static void sort_desc_pairs(LIS_INT lo, LIS_INT hi, LIS_INT *key, LIS_INT *tag)
+void lisi_sortr_ii(LIS_INT lo, LIS_INT hi, LIS_INT *key, LIS_INT *tag)
 {
 	while (lo < hi) {
 		const LIS_INT mid = (lo + hi) / 2, pv = key[mid];
@@ -113,7 +113,7 @@ static void sort_desc_pairs(LIS_INT lo, LIS_INT hi, LIS_INT *key, LIS_INT *tag)
 				a++; b--;
 			}
 		}
-		sort_desc_pairs(lo, b, key, tag);
+		lisi_sortr_ii(lo, b, key, tag);
 		lo = a;
 	}
 }
@@ -127,7 +127,7 @@ static LIS_INT csr2jad(LIS_MATRIX A, LIS_MATRIX B)
 	NEW(perm, LIS_INT, n); NEW(ptr, LIS_INT, maxnzr + 1); NEW(index, LIS_INT, nnz); NEW(value, LIS_SCALAR, nnz);
 	memset(ptr, 0, sizeof(LIS_INT) * (size_t)(maxnzr + 1));
 	for (LIS_INT i = 0; i < n; i++) { perm[i] = i; for (LIS_INT j = 0; j < len[i]; j++) ptr[j + 1]++; }
-	sort_desc_pairs(0, n - 1, len, perm);
+	lisi_sortr_ii(0, n - 1, len, perm);
 	for (LIS_INT j = 0; j < maxnzr; j++) ptr[j + 1] += ptr[j];
 	for (LIS_INT s = 0; s < n; s++) {                          /* jagged diagonal j holds the j-th entry of every row long enough */
 		const LIS_INT src = A->ptr[perm[s]], cnt = A->ptr[perm[s] + 1] - src;

@@ -25,7 +25,7 @@ LIS_INT lisd_init_quiet(void)
 
 void lisd_mat_eager(LIS_MATRIX A)
 {
-	if (lisg.residency == LIS_AMD_RESIDENT && lisg.device_ready && A->status >= LIS_MATRIX_CSR && !A->is_splited) (void)lisd_mat_ready(A);
+	if (lisg.residency == LIS_AMD_RESIDENT && lisg.device_ready && A->status >= LIS_MATRIX_CSR) (void)lisd_mat_ready(A);
 }
 
 LIS_INT lisd_init(void)
@@ -319,6 +319,49 @@ static LIS_INT upload_jad_as_csr(LIS_MATRIX A, lisd_mat *d)
 	return err;
 }
 
+/* A split matrix (lis_split.c) lives in HBM as CSR rows that list the terms of a row in the order the reference's is_splited
+ * branch adds them -- D x first -- and the kernels start the sum at -0.0, which makes the first product the initial value
+ * (t0 = D[i]*x[i]; t0 += ...: lis_matvec_csr.c:70-87) bit for bit, signed zeros included.  JAD is not one chain:
+ * (D x + sum over L) + sum over U with both partial sums started at 0 (lis_matvec_jad.c:60-140) -- two products, then two
+ * element-wise passes (lisd_spmv). */
+static LIS_INT upload_rows(lisd_mat *d, LIS_INT rows, LIS_INT *ptr, LIS_INT *idx, LIS_SCALAR *val, int **dptr, int **didx, double **dval, liship_csr_plan_t *plan, int from_zero)
+{
+	const LIS_INT nnz = ptr[rows];
+	LIS_INT err = up_i(dptr, ptr, (size_t)rows + 1);
+	if (!err) err = up_i(didx, idx, (size_t)nnz);
+	if (!err) err = up_d(dval, val, (size_t)nnz);
+	if (!err) { int rc = liship_stream_synchronize(lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
+	free(ptr); free(idx); free(val);
+	if (err) return err;
+	LISCHK(lisd_csr_plan(plan, rows, *dptr, *didx));
+	if (!from_zero) HIPCHK(liship_csr_plan_set_first_term_initialises(*plan, 1));
+	(void)d;
+	return LIS_SUCCESS;
+}
+
+static LIS_INT upload_split(LIS_MATRIX A, lisd_mat *d)
+{
+	LIS_INT *ptr, *idx; LIS_SCALAR *val;
+	if (A->matrix_type == LIS_MATRIX_JAD) {
+		LISCHK(lisi_split_jad_part(A, 0, &ptr, &idx, &val));
+		LISCHK(upload_rows(d, A->n, ptr, idx, val, &d->ptr, &d->index, &d->value, &d->plan, 1));
+		LISCHK(lisi_split_jad_part(A, 1, &ptr, &idx, &val));
+		LISCHK(upload_rows(d, A->n, ptr, idx, val, &d->u_ptr, &d->u_index, &d->u_value, &d->u_plan, 1));
+		LISCHK(up_d(&d->dsplit, A->D->value, (size_t)A->n));
+		HIPCHK(lisd_malloc((void **)&d->jw, ((size_t)A->n + 16) * sizeof(double)));
+		d->type = LIS_MATRIX_CSR;
+		d->split_jad = 1;
+		return LIS_SUCCESS;
+	}
+	LIS_INT rows; int from_zero;
+	LISCHK(lisi_split_rows(A, &rows, &ptr, &idx, &val, &from_zero));
+	d->nnz = ptr[rows];
+	LISCHK(upload_rows(d, rows, ptr, idx, val, &d->ptr, &d->index, &d->value, &d->plan, from_zero));
+	d->type = LIS_MATRIX_CSR;
+	d->n = rows;                          /* BSR: nr*bnr rows, the padding rows included (the vectors carry the pad) */
+	return LIS_SUCCESS;
+}
+
 static LIS_INT mat_upload(LIS_MATRIX A);
 LIS_INT lisd_mat_ready(LIS_MATRIX A)
 {
@@ -333,10 +376,17 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_init());
 	if (A->status < LIS_MATRIX_CSR) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is not assembled\n");
-	if (A->is_splited) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "split (D/L/U) matrices are not served\n");
 	d->n = A->n; d->np = A->np; d->nnz = A->nnz;
 	d->type = A->matrix_type;
 	const size_t n = (size_t)A->n;
+	if (A->is_splited && !(A->matrix_type == LIS_MATRIX_BSR && A->bnr != A->bnc)) {
+		LISCHK(upload_split(A, d));
+		HIPCHK(liship_stream_synchronize(lisg.stream));
+		find_inner_rows(A, &d->inner_begin, &d->inner_end);
+		if (A->np != A->n) { d->inner_begin = 0; d->inner_end = 0; }     /* ghost columns: exchange first, no overlap */
+		d->ready = 1;
+		return LIS_SUCCESS;
+	}
 	switch (A->matrix_type) {
 	case LIS_MATRIX_CSR:
 		LISCHK(up_i(&d->ptr, A->ptr, n + 1));
@@ -389,6 +439,8 @@ void lisd_mat_free(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
 	if (d->plan) (void)liship_csr_plan_destroy(d->plan);
+	if (d->u_plan) (void)liship_csr_plan_destroy(d->u_plan);
+	(void)liship_free(d->u_ptr); (void)liship_free(d->u_index); (void)liship_free(d->u_value); (void)liship_free(d->dsplit); (void)liship_free(d->jw);
 	if (d->t_plan) (void)liship_csr_plan_destroy(d->t_plan);
 	(void)liship_free(d->t_ptr); (void)liship_free(d->t_index); (void)liship_free(d->t_value); (void)liship_free(d->wr);
 	(void)liship_free(d->ell_codes); (void)liship_free(d->ell_dict);
@@ -438,6 +490,15 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 		return LIS_SUCCESS;
 	}
 	if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
+	if (d->split_jad) {
+		/* y = (D x + L x) + U x, the two sparse sums each formed from 0 on their own: w = L x; w = D.*x + 1*w (exact: 1*w is w);
+		 * y = U x; y += 1*w (a + b and b + a are the same double) */
+		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, d->jw, lisg.stream));
+		HIPCHK(liship_pmul_xpay_f64(d->n, d->dsplit, dx, 1.0, d->jw, lisg.stream));
+		HIPCHK(liship_spmv_csr_f64(d->u_plan, d->u_ptr, d->u_index, d->u_value, dx, dy, lisg.stream));
+		HIPCHK(liship_axpy_f64(d->n, 1.0, d->jw, dy, lisg.stream));
+		return LIS_SUCCESS;
+	}
 	switch (d->type) {
 	case LIS_MATRIX_CSR:
 		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));
@@ -478,6 +539,12 @@ LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const doub
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_mat_ready(A));
 	int nblocks = 0;
+	if (d->split_jad) {
+		LISCHK(lisd_spmv(A, dx, dy));
+		if (want_sumsq) HIPCHK(liship_dot2_f64(d->n, dy, dw, result, lisg.reduce_work, lisg.stream));
+		else HIPCHK(liship_dot_f64(d->n, dw, dy, result, lisg.reduce_work, lisg.stream));
+		return LIS_SUCCESS;
+	}
 	if (d->type == LIS_MATRIX_CSR && d->plan) (void)liship_csr_plan_info(d->plan, NULL, NULL, &nblocks);
 	/* the three parts launch at most nblocks + 2 row blocks (each cut splits one): all of them must find a slot for
 	 * their partial sums BEFORE the first part is launched -- otherwise the plain overlapped product + one dot pass */

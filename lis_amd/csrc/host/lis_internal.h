@@ -71,6 +71,11 @@ typedef struct {
 	int inner_begin, inner_end;/* maximal run of rows without ghost columns: overlappable with the halo */
 	/* scratch for the raw-array entry points lis_matvec_<fmt>(A, x[], y[]) */
 	double *sx, *sy; size_t scap;
+	/* split JAD matrix (lis_split.c): d->ptr/index/value/plan hold L, these hold U, the diagonal and a work vector */
+	int split_jad;
+	int *u_ptr, *u_index;
+	double *u_value, *dsplit, *jw;
+	liship_csr_plan_t u_plan;
 } lisd_mat;
 
 typedef struct {
@@ -151,6 +156,12 @@ LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes);
 
 /* ---- matrix internals shared between files */
 LIS_INT lisi_matrix_check(LIS_MATRIX A, int level);
+/* ---- split form (lis_split.c) */
+void    lisi_sortr_ii(LIS_INT lo, LIS_INT hi, LIS_INT *key, LIS_INT *tag);    /* the reference's descending quicksort (lis_convert.c) */
+void    lisi_matrix_dlu_destroy(LIS_MATRIX A);
+LIS_INT lisi_split_rows(LIS_MATRIX A, LIS_INT *rows, LIS_INT **ptr, LIS_INT **idx, LIS_SCALAR **val, int *from_zero);
+LIS_INT lisi_matrix_bscale_bsr(LIS_MATRIX A, LIS_VECTOR B);                  /* -scale jacobi -storage bsr (lis_scale.c) */
+LIS_INT lisi_split_jad_part(LIS_MATRIX A, int upper, LIS_INT **ptr, LIS_INT **idx, LIS_SCALAR **val);
 #define LISI_CHECK_NULL 0
 #define LISI_CHECK_SIZE 1
 #define LISI_CHECK_ASSEMBLED 2

@@ -397,6 +397,7 @@ LIS_INT lis_matrix_duplicate(LIS_MATRIX Ain, LIS_MATRIX *Aout)
 LIS_INT lisi_matrix_storage_destroy(LIS_MATRIX A)
 {
 	lisd_mat_free(A);
+	lisi_matrix_dlu_destroy(A);
 	asm_free(A);
 	if (A->is_destroy) {
 		free(A->ptr); free(A->row); free(A->col); free(A->index);
@@ -462,6 +463,15 @@ LIS_INT lis_matrix_get_diagonal(LIS_MATRIX A, LIS_VECTOR D)
 	const LIS_INT n = A->n;
 	LIS_SCALAR *out = D->value;
 	for (LIS_INT i = 0; i < n; i++) out[i] = 0.0;
+	if (A->is_splited) {                /* the split form holds the diagonal itself (ref lis_matrix_csr.c:532-545, lis_matrix_bsr.c get_diagonal) */
+		if (A->matrix_type == LIS_MATRIX_BSR) {
+			const size_t bs = (size_t)A->bnr * A->bnc;
+			for (LIS_INT br = 0; br < A->nr; br++)
+				for (LIS_INT j = 0; j < A->bnr && br * A->bnr + j < n; j++) out[br * A->bnr + j] = A->D->value[bs * br + (size_t)j * A->bnr + j];
+		} else memcpy(out, A->D->value, sizeof(LIS_SCALAR) * (size_t)n);
+		lis_amd_vector_host_modified(D);
+		return LIS_SUCCESS;
+	}
 	switch (A->matrix_type) {
 	case LIS_MATRIX_CSR:
 		for (LIS_INT i = 0; i < n; i++)

@@ -82,6 +82,7 @@ static LIS_INT upload(void **dst, const void *src, size_t bytes)
 LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
+	if (A->is_splited) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "A^T x of a split (D/L/U) matrix is not served\n");     /* another summation order again (lis_matvec_csr.c:124-160) */
 	if (d->t_ready) return LIS_SUCCESS;
 	LISCHK(lisd_mat_ready(A));
 	const LIS_INT type = A->matrix_type, n = A->n, np = A->np;

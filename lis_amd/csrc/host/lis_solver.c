@@ -947,8 +947,6 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	if (conv > 0 && (nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_TFQMR || nsolver == LIS_SOLVER_FGMRES || nsolver == LIS_SOLVER_MINRES || nsolver == LIS_SOLVER_JACOBI)) return LISI_ERR(LIS_ERR_ILL_ARG, "Option conv_cond is not implemented for solver %s\n", solver_names[nsolver]);
 	if (solver->options[LIS_OPTIONS_PRECISION] != LIS_PRECISION_DOUBLE) return LISI_ERR(LIS_ERR_ILL_ARG, "Quad precision is not enabled\n");
 	LIS_INT scale = solver->options[LIS_OPTIONS_SCALE];
-	if (scale && storage == LIS_MATRIX_BSR && scale == LIS_SCALE_JACOBI)
-		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "block-diagonal scaling of BSR storage (-scale jacobi -storage bsr) is not served by liblis_amd\n");
 	if ((nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_ORTHOMIN || nsolver == LIS_SOLVER_FGMRES) && solver->options[LIS_OPTIONS_RESTART] < 0)
 		return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_RESTART(=%D) is less than 0\n", solver->options[LIS_OPTIONS_RESTART]);
 	if (A->n != b->n || A->n != x->n) return LISI_ERR(LIS_ERR_ILL_ARG, "sizes of A, b and x do not match\n");
@@ -963,6 +961,14 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 
 	/* -scale: A and b are scaled in place and stay scaled, CG turns jacobi into symm_diag (ref :686-724).  The
 	 * Jacobi preconditioner was built from the UNSCALED matrix by lis_solve before this point, as in the reference. */
+	if (scale && storage == LIS_MATRIX_BSR && scale == LIS_SCALE_JACOBI) {
+		/* block-diagonal scaling: A becomes BSR, is split and multiplied by the inverse diagonal blocks, b likewise; the
+		 * iterations then run on the split product (ref :659-690) */
+		if (A->matrix_type != LIS_MATRIX_BSR) err = lisi_matrix_retype(A, LIS_MATRIX_BSR, solver->options[LIS_OPTIONS_STORAGE_BLOCK]);
+		if (!err) err = lisi_matrix_bscale_bsr(A, b);
+		if (err) { solver->retcode = err; return err; }
+		scale = 0;
+	}
 	if (scale) {
 		if (!solver->d) { err = lis_vector_duplicate(A, &solver->d); if (err) { solver->retcode = err; return err; } }
 		if (scale == LIS_SCALE_JACOBI && nsolver == LIS_SOLVER_CG) scale = LIS_SCALE_SYMM_DIAG;

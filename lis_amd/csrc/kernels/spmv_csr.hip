@@ -60,6 +60,10 @@ int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps t
 __device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
 
 struct Blk { int r0, k0, r1, k1; };
+// the row range of a launch and the value every row sum starts from: +0.0 as the reference's `t0 = 0.0`, or -0.0 for the
+// split form, where the reference starts at the first product (`t0 = D[i]*x[i]`, lis_matvec_csr.c:70) -- (-0.0) + p is p
+// for every p, signed zeros included.  Masked-out terms are added as -0.0, which leaves any sum unchanged.
+struct Rows { int rb, re; double acc0; };
 
 __global__ void csr_plan_kernel(int n, const int *__restrict__ ptr, int nblocks, int WORK, int align,
                                 v2i32 *__restrict__ blk)
@@ -169,7 +173,7 @@ __device__ __forceinline__ void stage_products(double *prod, const int *__restri
 
 // acc + q[0] + q[1] + ... + q[lim-1] with q[j] = buf[GUARD + first + j], strictly left to right (the reference's rounding
 // sequence), term j read at step j + skew.  The adds form one dependent chain, so the LDS reads are issued 16 at a time ahead
-// of it; absent terms are +0.0, which leaves the sum bit-unchanged (a sum that starts at +0.0 never becomes -0.0).
+// of it; absent terms are -0.0, which leaves every sum bit-unchanged (x + (-0.0) is x for all x, both zeros included).
 __device__ __forceinline__ double ordered_sum(double acc, const double *buf, int first, int lim, int skew = 0)
 {
     constexpr int W = 16;
@@ -180,7 +184,7 @@ __device__ __forceinline__ double ordered_sum(double acc, const double *buf, int
 #pragma unroll
         for (int u = 0; u < W; u++) d[u] = p[t + u];     // at most 15 slots past the row: inside the stage's slack
 #pragma unroll
-        for (int u = 0; u < W; u++) acc += ((unsigned)(t + u - skew) < (unsigned)lim) ? d[u] : 0.0;
+        for (int u = 0; u < W; u++) acc += ((unsigned)(t + u - skew) < (unsigned)lim) ? d[u] : -0.0;
     }
     return acc;
 }
@@ -202,7 +206,7 @@ __device__ __forceinline__ double ordered_sum_plain(double acc, const double *bu
     if (j < lim) {
         double d[W];
 #pragma unroll
-        for (int u = 0; u < W; u++) d[u] = (j + u < lim) ? p[j + u] : 0.0;
+        for (int u = 0; u < W; u++) d[u] = (j + u < lim) ? p[j + u] : -0.0;
 #pragma unroll
         for (int u = 0; u < W; u++) acc += d[u];
     }
@@ -234,7 +238,7 @@ template <int BLOCK, int CAP, int VEC, bool NOGATHER, int DOT = 0>
 __device__ __forceinline__ void block_by_products(double *prod, const int *__restrict__ ptr,
                                                   const int *__restrict__ idx, const double *__restrict__ val,
                                                   const double *__restrict__ x, double *__restrict__ y,
-                                                  const Blk B, RowDots<DOT> &dots)
+                                                  const Blk B, RowDots<DOT> &dots, const double acc0 = 0.0)
 {
     const int r0 = B.r0, r1 = B.r1, k0 = B.k0, k1 = B.k1;
     const int ka = k0 & ~1;
@@ -252,7 +256,7 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
     for (int r = rmine; r < r1; r += BLOCK) {
         int s = s_first, e = e_first;
         if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
-        const double acc = ordered_sum(0.0, prod, s - ka, min(e, kfirst) - s, row_skew(s - ka, (int)threadIdx.x));
+        const double acc = ordered_sum(acc0, prod, s - ka, min(e, kfirst) - s, row_skew(s - ka, (int)threadIdx.x));
         if (e <= kfirst) { store_stream(y + r, acc); dots.add(r, acc); } else carry = acc;   // only the block's last row can overflow
     }
 
@@ -312,11 +316,13 @@ __global__ __launch_bounds__(BLOCK)
 void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                               const double *__restrict__ val, const double *__restrict__ x,
                               double *__restrict__ y, const v2i32 *__restrict__ blk,
-                              int bfirst, int nb, int row_begin, int row_end, int run,
+                              int bfirst, int nb, Rows RW, int run,
                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                               const double *__restrict__ guard = nullptr, int pstride = 0)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    const int row_begin = RW.rb, row_end = RW.re;
+    const double acc0 = RW.acc0;
     constexpr int CAP = WORK + SLACK;
     __shared__ double prod[(GUARD + CAP + 8 + 16)];
     __shared__ double dot_scratch[BLOCK / WAVE];
@@ -328,7 +334,7 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
     }
-    block_by_products<BLOCK, CAP, VEC, NOGATHER, DOT>(prod, ptr, idx, val, x, y, B, dots);
+    block_by_products<BLOCK, CAP, VEC, NOGATHER, DOT>(prod, ptr, idx, val, x, y, B, dots, acc0);
     __syncthreads();
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
@@ -339,11 +345,13 @@ __global__ __launch_bounds__(BLOCK)
 void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                                const double *__restrict__ val, const double *__restrict__ x,
                                double *__restrict__ y, const v2i32 *__restrict__ blk,
-                               int bfirst, int nb, int row_begin, int row_end, int nnz_total, int run,
+                               int bfirst, int nb, Rows RW, int nnz_total, int run,
                                const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                                const double *__restrict__ guard = nullptr, int pstride = 0)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    const int row_begin = RW.rb, row_end = RW.re;
+    const double acc0 = RW.acc0;
     __shared__ double dot_scratch[BLOCK / WAVE];
     RowDots<DOT> dots{wdot, 0.0, 0.0};
     constexpr int CAP = WORK + SLACK;
@@ -362,7 +370,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     const int ka = B.k0 & ~3;                       // 16 B aligned start for both streams
     const int nq = (B.k1 - ka + 3) >> 2;            // quads of 4 non-zeros
     if ((B.k1 - ka) > CAP || ka + 4 * nq > nnz_total) {     // long row / tail of the arrays
-        block_by_products<BLOCK, CAP, 4, NOGATHER, DOT>(valL, ptr, idx, val, x, y, B, dots);
+        block_by_products<BLOCK, CAP, 4, NOGATHER, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
@@ -423,7 +431,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
         const int len = e - s;
         const int off = s - ka;
         const double wr = dots.fetch(r);
-        double acc = 0.0;
+        double acc = acc0;
         for (int j0 = 0; j0 < len; j0 += U) {
             int cc[U]; double vv[U], xx[U];
 #pragma unroll
@@ -437,7 +445,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const double t = vv[u] * xx[u];
-                acc += (j0 + u < len) ? t : 0.0;            // +0.0 terms leave the sum bit-unchanged
+                acc += (j0 + u < len) ? t : -0.0;           // -0.0 terms leave any sum bit-unchanged
             }
         }
         store_stream(y + r, acc);
@@ -465,11 +473,13 @@ __global__ __launch_bounds__(BLOCK)
 void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
                            const unsigned short *__restrict__ lcol, const int *__restrict__ dcol,
                            const int *__restrict__ doff, const double *__restrict__ x, double *__restrict__ y,
-                           const v2i32 *__restrict__ blk, int bfirst, int nb, int row_begin, int row_end, int nnz_total,
+                           const v2i32 *__restrict__ blk, int bfirst, int nb, Rows RW, int nnz_total,
                            const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                            const double *__restrict__ guard = nullptr, int pstride = 0)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    const int row_begin = RW.rb, row_end = RW.re;
+    const double acc0 = RW.acc0;
     constexpr int CAP = WORK + SLACK + 8;           // + the 8-entry alignment of the position slice
     constexpr int NDMAX = NDPL * BLOCK;             // distinct columns a block may list: NDPL per lane (2 or 4)
     __shared__ double dot_scratch[BLOCK / WAVE];
@@ -490,7 +500,7 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
     const int nl = (cnt + 7) >> 3;                  // 16 B pieces of the position slice (the array is padded)
     if (nd == 0 || cnt > CAP || ka + 2 * np > nnz_total) {  // block without a list / last value of the array
-        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots);
+        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
@@ -545,7 +555,7 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
         int s = s_first, e = e_first;
         if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
         const double wr = dots.fetch(r);
-        const double acc = ordered_sum(0.0, valL, s - ka, e - s, row_skew(s - ka, (int)threadIdx.x));
+        const double acc = ordered_sum(acc0, valL, s - ka, e - s, row_skew(s - ka, (int)threadIdx.x));
         store_stream(y + r, acc);
         dots.add_loaded(wr, acc);
     }
@@ -629,11 +639,13 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
                            const double *__restrict__ val, const unsigned char *__restrict__ codes,
                            const int *__restrict__ dict, const double *__restrict__ x,
                            double *__restrict__ y, const v2i32 *__restrict__ blk,
-                           int bfirst, int nb, int row_begin, int row_end, int nnz_total,
+                           int bfirst, int nb, Rows RW, int nnz_total,
                            const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                            const double *__restrict__ guard = nullptr, int pstride = 0, int run = 16)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    const int row_begin = RW.rb, row_end = RW.re;
+    const double acc0 = RW.acc0;
     __shared__ double dot_scratch[BLOCK / WAVE];
     RowDots<DOT> dots{wdot, 0.0, 0.0};
     constexpr int CAP = WORK + SLACK + 16;          // + the 16-entry alignment of the code slice
@@ -653,7 +665,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
     const int nc = (cnt + 15) >> 4;                 // 16 B pieces of the code slice (the code array is padded)
     if (cnt > CAP || ka + 2 * np > nnz_total) {     // long row / last value of the array
-        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots);
+        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
@@ -685,7 +697,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
         const int len = e - s;
         const int off = s - ka;
         const double wr = dots.fetch(r);
-        double acc = 0.0;
+        double acc = acc0;
         for (int j0 = 0; j0 < len; j0 += U) {
             int cc[U]; double vv[U], xx[U];
 #pragma unroll
@@ -699,7 +711,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const double t = vv[u] * xx[u];
-                acc += (j0 + u < len) ? t : 0.0;            // +0.0 terms leave the sum bit-unchanged
+                acc += (j0 + u < len) ? t : -0.0;           // -0.0 terms leave any sum bit-unchanged
             }
         }
         store_stream(y + r, acc);
@@ -767,6 +779,7 @@ struct liship_csr_plan_s {
     int *dcol;           // device, the lists (each padded to a multiple of 4 entries)
     int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
     long long ndcol;     // entries of dcol
+    int first_term;      // row sums start at the first product instead of at +0.0 (split matrices)
 };
 
 extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
@@ -832,6 +845,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->blk_host = nullptr;
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0;
+    p->first_term = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -851,6 +865,15 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     free(p->blk_host);
     delete p;
     return rc;
+}
+
+// the rows of this matrix are chains that START with their first product (the split form D x + L x + U x of the reference,
+// lis_matvec_csr.c:64-89) instead of being added to 0.0: same kernels, the running sum starts at -0.0
+extern "C" int liship_csr_plan_set_first_term_initialises(liship_csr_plan_t p, int on)
+{
+    if (!p) return LISHIP_ERR_ARG;
+    p->first_term = on ? 1 : 0;
+    return 0;
 }
 
 extern "C" int liship_csr_plan_info(liship_csr_plan_t p, int *n, long long *nnz, int *nblocks)
@@ -991,6 +1014,7 @@ struct LaunchArgs {
     const int *dict = nullptr;
     const unsigned short *lcol = nullptr;   // block-local columns (positions, lists, list offsets), when the plan has them
     const int *dcol = nullptr, *doff = nullptr;
+    double acc0 = 0.0;                      // what a row sum starts from (Rows)
 };
 
 
@@ -1001,7 +1025,7 @@ void launch_rowgather(int grid, const LaunchArgs &a)
 {
     constexpr Geometry g = kGeom[G];
     spmv_csr_rowgather_kernel<g.block, g.work, U, XRUN, DMA, NOGATHER>
-        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, xcd_run());
+        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, xcd_run());
 }
 
 template <int G, bool XRUN, int VEC, bool NOGATHER>
@@ -1009,7 +1033,7 @@ void launch_products(int grid, const LaunchArgs &a)
 {
     constexpr Geometry g = kGeom[G];
     spmv_csr_products_kernel<g.block, g.work, XRUN, VEC, NOGATHER>
-        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, xcd_run());
+        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, xcd_run());
 }
 
 template <int G>
@@ -1025,7 +1049,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     if (a.lcol && plan_products && G == LOCAL_GEOM && g_variant == 0 && val16) {     // long rows, few distinct columns per row block
         constexpr Geometry g = kGeom[LOCAL_GEOM];
         spmv_csr_local_kernel<g.block, g.work><<<a.nb, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz);
+            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
     if (products) {
@@ -1044,19 +1068,19 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
         constexpr Geometry g = kGeom[G];
         const int sp = NUM_XCD * xcd_run(), gr = ((a.nb + sp - 1) / sp) * sp;
         spmv_csr_coded_kernel<g.block, g.work, 7, 0, false, true><<<gr, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, nullptr, nullptr, nullptr, 0, xcd_run());
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, nullptr, nullptr, nullptr, 0, xcd_run());
         return;
     }
     if (a.codes && (g_variant & ~0xF0) == 0x100) {   // ablation: coded kernel without the x gather (timing only)
         constexpr Geometry g = kGeom[G];
         spmv_csr_coded_kernel<g.block, g.work, 7, 0, true><<<a.nb, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz);
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
     if (a.codes && (g_variant & ~0x18F0) == 0) {     // one-byte column codes (the plan found <= 255 diagonals)
         constexpr Geometry g = kGeom[G];
 #define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, 0><<<a.nb, g.block, 0, a.st>>>( \
-            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz)
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz)
         if (U == 4) GO(4); else if (U == 7) GO(7); else GO(8);
 #undef GO
         return;
@@ -1075,13 +1099,13 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
     constexpr Geometry g = kGeom[G];
     if (a.codes) {
 #define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, DOT><<<a.nb, g.block, 0, a.st>>>( \
-            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, w, partial, liship_internal_guard(), pstride)
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride)
         if (unroll == 4) GO(4); else if (unroll == 7) GO(7); else GO(8);
 #undef GO
         return;
     }
 #define GO(UU) spmv_csr_rowgather_kernel<g.block, g.work, UU, false, true, false, DOT><<<a.nb, g.block, 0, a.st>>>( \
-        a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, 16, w, partial, liship_internal_guard(), pstride)
+        a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, 16, w, partial, liship_internal_guard(), pstride)
     if (unroll == 4) GO(4); else if (unroll == 7) GO(7); else GO(8);
 #undef GO
 }
@@ -1092,15 +1116,15 @@ void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double
     constexpr Geometry g = kGeom[G];
     if (a.lcol && G == LOCAL_GEOM) {
         spmv_csr_local_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, a.nnz, w, partial, liship_internal_guard(), pstride);
+            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride);
         return;
     }
     if (batch == 2)
         spmv_csr_products_kernel<g.block, g.work, false, 2, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial, liship_internal_guard(), pstride);
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, 16, w, partial, liship_internal_guard(), pstride);
     else
         spmv_csr_products_kernel<g.block, g.work, false, 4, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, a.rb, a.re, 16, w, partial, liship_internal_guard(), pstride);
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, 16, w, partial, liship_internal_guard(), pstride);
 }
 
 int launch_csr(liship_csr_plan_t p, const LaunchArgs &a)
@@ -1126,7 +1150,7 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
                                    const double *val, const double *x, double *y, void *stream)
 {
     if (!p) return LISHIP_ERR_ARG;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0};
     return launch_csr(p, a);
 }
 
@@ -1142,7 +1166,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if (g_variant != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);
@@ -1168,7 +1192,7 @@ extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int 
     const int bfirst = lo;
     lo = bfirst; hi = p->nblocks;                // first b with br[b].row >= row_end
     while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0};
     return launch_csr(p, a);
 }
 
@@ -1196,7 +1220,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if (nb <= 0) return 0;
     if ((size_t)slot_base + (size_t)nb > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work) + slot_base;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0};
     const int ps = (int)slots;
     if (p->products && p->geom == LOCAL_GEOM) {
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial, ps);

@@ -161,3 +161,30 @@ def solve(lib, A, b, options, x0=None):
     lib.lis_vector_destroy(vb)
     lib.lis_vector_destroy(vx)
     return out
+
+
+def split_arrays(A):
+    """L / U / D of a split matrix as numpy arrays, by storage format (layouts: src/matrix/lis_matrix_<fmt>.c split routines)."""
+    a = A.contents
+    assert a.is_splited
+    t, n, np_ = a.matrix_type, a.n, a.np
+    out = {}
+    for tag, core in (("L", a.L.contents), ("U", a.U.contents)):
+        if t in (capi.LIS_MATRIX_CSR, capi.LIS_MATRIX_CSC):
+            lines = n if t == capi.LIS_MATRIX_CSR else np_
+            out[tag] = dict(nnz=core.nnz, ptr=_arr(core.ptr, lines + 1, np.int32), index=_arr(core.index, core.nnz, np.int32),
+                            value=_arr(core.value, core.nnz, np.float64))
+        elif t == capi.LIS_MATRIX_ELL:
+            out[tag] = dict(maxnzr=core.maxnzr, index=_arr(core.index, core.maxnzr * n, np.int32), value=_arr(core.value, core.maxnzr * n, np.float64))
+        elif t == capi.LIS_MATRIX_DIA:
+            out[tag] = dict(nnd=core.nnd, index=_arr(core.index, core.nnd, np.int32), value=_arr(core.value, core.nnd * n, np.float64))
+        elif t == capi.LIS_MATRIX_JAD:
+            out[tag] = dict(nnz=core.nnz, maxnzr=core.maxnzr, row=_arr(core.row, n, np.int32), ptr=_arr(core.ptr, core.maxnzr + 1, np.int32),
+                            index=_arr(core.index, core.nnz, np.int32), value=_arr(core.value, core.nnz, np.float64))
+        elif t == capi.LIS_MATRIX_BSR:
+            bs = core.bnr * core.bnc
+            out[tag] = dict(bnnz=core.bnnz, bptr=_arr(core.bptr, core.nr + 1, np.int32), bindex=_arr(core.bindex, core.bnnz, np.int32),
+                            value=_arr(core.value, core.bnnz * bs, np.float64))
+    dcount = a.nr * a.bnr * a.bnc if t == capi.LIS_MATRIX_BSR else n
+    out["D"] = _arr(a.D.contents.value, dcount, np.float64)
+    return out

@@ -368,3 +368,119 @@ def bicgstab(ptr, idx, val, b, x0=None, precon="none", tol=1e-12, maxiter=1000):
 
 def gmres(ptr, idx, val, b, x0=None, precon="none", tol=1e-12, maxiter=1000, restart=40):
     return _solve(lib().orc_gmres, ptr, idx, val, b, x0, precon, tol, maxiter, [int(restart)])
+
+
+# ---------------------------------------------------------------- split form A = L + D + U
+# Test infrastructure in plain Python / numpy (small cases): which terms the reference's is_splited branches add to a row, in
+# which order, restated from src/matvec/lis_matvec_<fmt>.c and src/matrix/lis_matrix_<fmt>.c (split routines).  Pinned against
+# the reference itself by tests/golden/make_golden_split.py -> tests/golden/split_golden.npz.
+def _chain(first_from_zero, terms):
+    """t = first product (or 0.0 + first product), then t += each further product, one rounding per operation"""
+    t = 0.0 if first_from_zero else None
+    for v, xv in terms:
+        p = float(v) * float(xv)
+        t = p if t is None else t + p
+    return t
+
+
+def split_csr(ptr, idx, val):
+    """lis_matrix_split_csr (lis_matrix_csr.c:765): per row the entries left / right of the diagonal, D = the last entry on it"""
+    n = len(ptr) - 1
+    L, U, D = [[] for _ in range(n)], [[] for _ in range(n)], np.zeros(n)
+    for r in range(n):
+        for k in range(ptr[r], ptr[r + 1]):
+            (L[r] if idx[k] < r else U[r] if idx[k] > r else []).append((idx[k], val[k]))
+            if idx[k] == r:
+                D[r] = val[k]
+    return L, U, D
+
+
+def spmv_split_csr(ptr, idx, val, x):
+    """lis_matvec_csr.c:64-89"""
+    L, U, D = split_csr(ptr, idx, val)
+    return np.array([_chain(False, [(D[r], x[r])] + [(v, x[c]) for c, v in L[r]] + [(v, x[c]) for c, v in U[r]]) for r in range(len(D))])
+
+
+def spmv_split_csc(n, cptr, cidx, cval, x):
+    """lis_matrix_split_csc (lis_matrix_csc.c:493) + lis_matvec_csc.c:65-90: y = D x, then column by column its "L" entries
+    (row index < column) and its "U" entries (row index > column), scattered into y"""
+    D = np.zeros(n)
+    terms = [[] for _ in range(n)]
+    for c in range(len(cptr) - 1):
+        lo = [(cidx[k], cval[k]) for k in range(cptr[c], cptr[c + 1]) if cidx[k] < c]
+        up = [(cidx[k], cval[k]) for k in range(cptr[c], cptr[c + 1]) if cidx[k] > c]
+        for k in range(cptr[c], cptr[c + 1]):
+            if cidx[k] == c:
+                D[c] = cval[k]
+        for r, v in lo + up:
+            terms[r].append((v, x[c]))
+    return np.array([_chain(False, [(D[r], x[r])] + terms[r]) for r in range(n)])
+
+
+def spmv_split_ell(n, maxnzr, eidx, eval_, x):
+    """lis_matrix_split_ell (lis_matrix_ell.c:324) + lis_matvec_ell.c:56-87: L / U are ELL arrays padded to their own widths
+    with (value 0, column = row); D takes a diagonal entry only when its value is not 0"""
+    rows_l, rows_u, D = [], [], np.zeros(n)
+    for r in range(n):
+        ent = [(eidx[j * n + r], eval_[j * n + r]) for j in range(maxnzr)]
+        rows_l.append([(c, v) for c, v in ent if c < r])
+        rows_u.append([(c, v) for c, v in ent if c > r])
+        for c, v in ent:
+            if c == r and v != 0.0:
+                D[r] = v
+    lmax, umax = max((len(t) for t in rows_l), default=0), max((len(t) for t in rows_u), default=0)
+    y = []
+    for r in range(n):
+        lo = rows_l[r] + [(r, 0.0)] * (lmax - len(rows_l[r]))
+        up = rows_u[r] + [(r, 0.0)] * (umax - len(rows_u[r]))
+        y.append(_chain(False, [(D[r], x[r])] + [(v, x[c]) for c, v in lo] + [(v, x[c]) for c, v in up]))
+    return np.array(y)
+
+
+def spmv_split_dia(n, nnd, off, dval, x):
+    """lis_matrix_split_dia (lis_matrix_dia.c:782) + lis_matvec_dia.c:56-123: whole diagonals move to L (offset < 0), U (> 0), D"""
+    y = []
+    for r in range(n):
+        d0 = [dval[d * n + r] for d in range(nnd) if off[d] == 0]
+        terms = [(d0[-1] if d0 else 0.0, x[r])]
+        for sign in (-1, 1):
+            terms += [(dval[d * n + r], x[r + off[d]]) for d in range(nnd) if off[d] * sign > 0 and 0 <= r + off[d] < n]
+        y.append(_chain(False, terms))
+    return np.array(y)
+
+
+def spmv_split_bsr(n, nr, bnr, bnc, bptr, bidx, bval, x):
+    """lis_matrix_split_bsr (lis_matrix_bsr.c:1131, square blocks) + lis_matvec_bsr_NxN (lis_matvec_bsr.c:159 / :293 / :453 / :644):
+    the block row of D column by column -- the first product starts the sum --, then the L blocks, then the U blocks; blocks
+    larger than 4 x 4 take the generic routine (:70-118), which starts every sum at 0.0"""
+    assert bnr == bnc
+    bs = bnr * bnc
+    xp = np.concatenate([x, np.zeros(nr * bnr + bnc - len(x))])
+    y = np.zeros(nr * bnr)
+    for bi in range(nr):
+        blocks = [(bidx[k], bval[k * bs:(k + 1) * bs]) for k in range(bptr[bi], bptr[bi + 1])]
+        dblk = np.zeros(bs)
+        for c, v in blocks:
+            if c == bi:
+                dblk = v
+        order = [(bi, dblk)] + [(c, v) for c, v in blocks if c < bi] + [(c, v) for c, v in blocks if c > bi]
+        for ii in range(bnr):
+            terms = [(v[j * bnr + ii], xp[c * bnc + j]) for c, v in order for j in range(bnc)]
+            y[bi * bnr + ii] = _chain(bnr > 4, terms)
+    return y[:n]
+
+
+def spmv_split_jad(n, maxnzr, perm, jptr, jidx, jval, x):
+    """lis_matvec_jad.c:60-140: y = D x; w = sum over the L entries (from 0, jagged-diagonal order); y[row] += w; the same for U.
+    The jagged order of a row's L (U) entries is their order in A's jagged diagonals (lis_matrix_split_jad keeps it)."""
+    lo, up, D = [[] for _ in range(n)], [[] for _ in range(n)], np.zeros(n)
+    for j in range(maxnzr):
+        for s, k in enumerate(range(jptr[j], jptr[j + 1])):
+            r = perm[s]
+            if jidx[k] < r:
+                lo[r].append((jval[k], x[jidx[k]]))
+            elif jidx[k] > r:
+                up[r].append((jval[k], x[jidx[k]]))
+            else:
+                D[r] = jval[k]
+    return np.array([(float(D[r]) * float(x[r]) + _chain(True, lo[r])) + _chain(True, up[r]) for r in range(n)])

@@ -8,6 +8,9 @@
  * csr2csc lis_matrix_csc.c:904-1087; dispatcher lis_matrix_ops.c:128-322.
  */
 #include "lis_internal.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define NEW(p, T, count) do { (p) = (T *)malloc(sizeof(T) * (size_t)((count) > 0 ? (count) : 1)); \
 	if (!(p)) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)(count)); goto fail; } } while (0)
@@ -25,15 +28,22 @@ static LIS_INT csr2ell(LIS_MATRIX A, LIS_MATRIX B)
 {
 	const LIS_INT n = A->n;
 	LIS_INT err = 0, maxnzr = 0, *index = NULL; LIS_SCALAR *value = NULL;
+	#pragma omp parallel for reduction(max : maxnzr)
 	for (LIS_INT i = 0; i < n; i++) if (A->ptr[i + 1] - A->ptr[i] > maxnzr) maxnzr = A->ptr[i + 1] - A->ptr[i];
 	NEW(index, LIS_INT, (size_t)n * maxnzr); NEW(value, LIS_SCALAR, (size_t)n * maxnzr);
-	for (LIS_INT j = 0; j < maxnzr; j++)                       /* padding: value 0 on the row's own column */
-		for (LIS_INT i = 0; i < n; i++) { value[(size_t)j * n + i] = 0.0; index[(size_t)j * n + i] = i; }
-	for (LIS_INT i = 0; i < n; i++)
-		for (LIS_INT k = A->ptr[i], j = 0; k < A->ptr[i + 1]; k++, j++) {
-			value[(size_t)j * n + i] = A->value[k];
-			index[(size_t)j * n + i] = A->index[k];
-		}
+	/* slot j of every row, rows in chunks: each thread writes whole cache lines of the column-major arrays;
+	 * padding: value 0 on the row's own column */
+	#pragma omp parallel for schedule(static)
+	for (LIS_INT c = 0; c < (n + 1023) / 1024; c++) {
+		const LIS_INT i0 = c * 1024, i1 = i0 + 1024 < n ? i0 + 1024 : n;
+		for (LIS_INT j = 0; j < maxnzr; j++)
+			for (LIS_INT i = i0; i < i1; i++) {
+				const LIS_INT k = A->ptr[i] + j;
+				const int have = k < A->ptr[i + 1];
+				value[(size_t)j * n + i] = have ? A->value[k] : 0.0;
+				index[(size_t)j * n + i] = have ? A->index[k] : i;
+			}
+	}
 	return finish(B, lis_matrix_set_ell(maxnzr, index, value, B));
 fail:
 	free(index); free(value);
@@ -46,14 +56,30 @@ static LIS_INT csr2csc(LIS_MATRIX A, LIS_MATRIX B)
 	LIS_INT err = 0, *ptr = NULL, *index = NULL, *fill = NULL; LIS_SCALAR *value = NULL;
 	NEW(ptr, LIS_INT, np + 1); NEW(index, LIS_INT, nnz); NEW(value, LIS_SCALAR, nnz); NEW(fill, LIS_INT, np + 1);
 	memset(fill, 0, sizeof(LIS_INT) * (size_t)(np + 1));
-	for (LIS_INT k = 0; k < nnz; k++) fill[A->index[k]]++;
+	/* a counting sort by column that keeps the rows ascending inside each column.  Threads own column RANGES and each walks
+	 * all rows in order, taking the entries of its columns: no shared counters, the same arrays as the serial sweep */
+	int nth = 1;
+	#ifdef _OPENMP
+	nth = omp_get_max_threads();
+	if (nth > 32) nth = 32;
+	if ((long long)nnz < 4000000) nth = 1;
+	#endif
+	#pragma omp parallel for schedule(static, 1) num_threads(nth)
+	for (int t = 0; t < nth; t++) {
+		const LIS_INT c0 = (LIS_INT)((long long)np * t / nth), c1 = (LIS_INT)((long long)np * (t + 1) / nth);
+		for (LIS_INT k = 0; k < nnz; k++) { const LIS_INT c = A->index[k]; if (c >= c0 && c < c1) fill[c]++; }
+	}
 	ptr[0] = 0;
 	for (LIS_INT c = 0; c < np; c++) { ptr[c + 1] = ptr[c] + fill[c]; fill[c] = ptr[c]; }
-	for (LIS_INT i = 0; i < n; i++)                           /* rows ascending inside each column */
-		for (LIS_INT k = A->ptr[i]; k < A->ptr[i + 1]; k++) {
-			const LIS_INT dst = fill[A->index[k]]++;
-			value[dst] = A->value[k]; index[dst] = i;
-		}
+	#pragma omp parallel for schedule(static, 1) num_threads(nth)
+	for (int t = 0; t < nth; t++) {
+		const LIS_INT c0 = (LIS_INT)((long long)np * t / nth), c1 = (LIS_INT)((long long)np * (t + 1) / nth);
+		for (LIS_INT i = 0; i < n; i++)                       /* rows ascending inside each column */
+			for (LIS_INT k = A->ptr[i]; k < A->ptr[i + 1]; k++) {
+				const LIS_INT c = A->index[k];
+				if (c >= c0 && c < c1) { const LIS_INT dst = fill[c]++; value[dst] = A->value[k]; index[dst] = i; }
+			}
+	}
 	free(fill);
 	return finish(B, lis_matrix_set_csc(nnz, ptr, index, value, B));
 fail:
@@ -61,35 +87,37 @@ fail:
 	return err;
 }
 
-static int cmp_int(const void *a, const void *b) { LIS_INT x = *(const LIS_INT *)a, y = *(const LIS_INT *)b; return (x > y) - (x < y); }
-
 static LIS_INT csr2dia(LIS_MATRIX A, LIS_MATRIX B)
 {
-	const LIS_INT n = A->n, nnz = A->nnz;
-	LIS_INT err = 0, nnd = 0, *off = NULL, *index = NULL; LIS_SCALAR *value = NULL;
+	const LIS_INT n = A->n, np = A->np;
+	LIS_INT err = 0, nnd = 0, *index = NULL, *slot = NULL; LIS_SCALAR *value = NULL;
+	unsigned char *used = NULL;
 	/* like the reference (lis_matrix_dia.c:1217) the INPUT rows are put in ascending column order first */
+	#pragma omp parallel for schedule(dynamic, 4096)
 	for (LIS_INT i = 0; i < n; i++) lisi_sort_row(A->ptr[i], A->ptr[i + 1], A->index, A->value);
 	A->is_sorted = LIS_TRUE;
 	if (MDEV(A)->ready) lisd_mat_free(A);                     /* its HBM copy had the old order */
-	NEW(off, LIS_INT, nnz);
-	for (LIS_INT i = 0; i < n; i++) for (LIS_INT k = A->ptr[i]; k < A->ptr[i + 1]; k++) off[k] = A->index[k] - i;
-	qsort(off, (size_t)nnz, sizeof(LIS_INT), cmp_int);
-	for (LIS_INT k = 0; k < nnz; k++) if (k == 0 || off[k] != off[k - 1]) off[nnd++] = off[k];
-	NEW(index, LIS_INT, nnd); NEW(value, LIS_SCALAR, (size_t)n * nnd);
-	memcpy(index, off, sizeof(LIS_INT) * (size_t)nnd);
-	memset(value, 0, sizeof(LIS_SCALAR) * (size_t)n * (size_t)nnd);
-	for (LIS_INT i = 0; i < n; i++) {
-		LIS_INT d = 0;
-		for (LIS_INT k = A->ptr[i]; k < A->ptr[i + 1]; k++) {
-			const LIS_INT o = A->index[k] - i;
-			while (index[d] != o) d++;
-			value[(size_t)d * n + i] = A->value[k];
-		}
+	/* the diagonals that occur, ascending: one flag per possible offset -(n-1) .. np-1 instead of a sort of all offsets */
+	const size_t span = (size_t)n + (size_t)np;
+	used = (unsigned char *)calloc(span ? span : 1, 1);
+	if (!used) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)span); goto fail; }
+	#pragma omp parallel for schedule(static)
+	for (LIS_INT i = 0; i < n; i++) for (LIS_INT k = A->ptr[i]; k < A->ptr[i + 1]; k++) used[(size_t)(A->index[k] - i + n)] = 1;   /* racing writers store the same 1 */
+	for (size_t o = 0; o < span; o++) nnd += used[o];
+	NEW(index, LIS_INT, nnd); NEW(value, LIS_SCALAR, (size_t)n * nnd); NEW(slot, LIS_INT, span);
+	nnd = 0;
+	for (size_t o = 0; o < span; o++) if (used[o]) { slot[o] = nnd; index[nnd++] = (LIS_INT)((long long)o - n); }
+	#pragma omp parallel for schedule(static)
+	for (LIS_INT c = 0; c < (n + 1023) / 1024; c++) {
+		const LIS_INT i0 = c * 1024, i1 = i0 + 1024 < n ? i0 + 1024 : n;
+		for (LIS_INT d = 0; d < nnd; d++) memset(value + (size_t)d * n + i0, 0, sizeof(LIS_SCALAR) * (size_t)(i1 - i0));
+		for (LIS_INT i = i0; i < i1; i++)
+			for (LIS_INT k = A->ptr[i]; k < A->ptr[i + 1]; k++) value[(size_t)slot[(size_t)(A->index[k] - i + n)] * n + i] = A->value[k];
 	}
-	free(off);
+	free(used); free(slot);
 	return finish(B, lis_matrix_set_dia(nnd, index, value, B));
 fail:
-	free(off); free(index); free(value);
+	free(used); free(slot); free(index); free(value);
 	return err;
 }
 
@@ -126,9 +154,17 @@ static LIS_INT csr2jad(LIS_MATRIX A, LIS_MATRIX B)
 	for (LIS_INT i = 0; i < n; i++) { len[i] = A->ptr[i + 1] - A->ptr[i]; if (len[i] > maxnzr) maxnzr = len[i]; }
 	NEW(perm, LIS_INT, n); NEW(ptr, LIS_INT, maxnzr + 1); NEW(index, LIS_INT, nnz); NEW(value, LIS_SCALAR, nnz);
 	memset(ptr, 0, sizeof(LIS_INT) * (size_t)(maxnzr + 1));
-	for (LIS_INT i = 0; i < n; i++) { perm[i] = i; for (LIS_INT j = 0; j < len[i]; j++) ptr[j + 1]++; }
+	{	/* ptr[j+1] = rows with more than j entries: a histogram of the lengths, summed from the top */
+		LIS_INT *hist = (LIS_INT *)calloc((size_t)maxnzr + 2, sizeof(LIS_INT));
+		if (!hist) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", maxnzr); goto fail; }
+		for (LIS_INT i = 0; i < n; i++) { perm[i] = i; hist[len[i]]++; }
+		LIS_INT longer = 0;
+		for (LIS_INT j = maxnzr; j >= 1; j--) { longer += hist[j]; ptr[j] = longer; }
+		free(hist);
+	}
 	lisi_sortr_ii(0, n - 1, len, perm);
 	for (LIS_INT j = 0; j < maxnzr; j++) ptr[j + 1] += ptr[j];
+	#pragma omp parallel for schedule(static)
 	for (LIS_INT s = 0; s < n; s++) {                          /* jagged diagonal j holds the j-th entry of every row long enough */
 		const LIS_INT src = A->ptr[perm[s]], cnt = A->ptr[perm[s] + 1] - src;
 		for (LIS_INT j = 0; j < cnt; j++) { value[ptr[j] + s] = A->value[src + j]; index[ptr[j] + s] = A->index[src + j]; }
@@ -146,37 +182,54 @@ static LIS_INT csr2bsr(LIS_MATRIX A, LIS_MATRIX B)
 	const LIS_INT nr = 1 + (n - 1) / bnr, pad = (bnc - n % bnc) % bnc;
 	const LIS_INT nc = (n == np) ? 1 + (n - 1) / bnc : 2 + (n - 1) / bnc + (pad + np - n - 1) / bnc;
 	LIS_INT err = 0, *bptr = NULL, *bindex = NULL, *slot = NULL, *seen = NULL; LIS_SCALAR *value = NULL;
-	NEW(bptr, LIS_INT, nr + 1); NEW(slot, LIS_INT, nc); NEW(seen, LIS_INT, nc);
-	memset(slot, 0, sizeof(LIS_INT) * (size_t)nc);
+	NEW(bptr, LIS_INT, nr + 1);
+	(void)nc;
 #define BCOL(c) (((c) < n ? (c) : (c) + pad) / bnc)             /* ghost columns start on a fresh block (ref :425-428) */
 #define BOFF(c) (((c) < n ? (c) : (c) + pad) % bnc)
+	/* Block rows are independent.  The distinct block columns of one block row, in first-seen order, are few (a stencil: 7-14):
+	 * a short list searched linearly from its end (neighbouring entries repeat the last block) replaces a table over all nc. */
+	enum { LOCAL = 512 };
 	bptr[0] = 0;
+	#pragma omp parallel for schedule(dynamic, 1024)
 	for (LIS_INT br = 0; br < nr; br++) {                       /* pass 1: distinct block columns per block row */
-		LIS_INT nseen = 0;
+		LIS_INT list[LOCAL], nseen = 0, *big = NULL, cap = LOCAL;
+		LIS_INT *cur = list;
 		for (LIS_INT ii = 0; ii < bnr && br * bnr + ii < n; ii++)
 			for (LIS_INT k = A->ptr[br * bnr + ii]; k < A->ptr[br * bnr + ii + 1]; k++) {
 				const LIS_INT bc = BCOL(A->index[k]);
-				if (!slot[bc]) { slot[bc] = 1; seen[nseen++] = bc; }
+				LIS_INT s = nseen - 1;
+				while (s >= 0 && cur[s] != bc) s--;
+				if (s < 0) {
+					if (nseen == cap) {                             /* a very wide block row: the list moves to the heap */
+						LIS_INT *nb = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)cap * 2);
+						memcpy(nb, cur, sizeof(LIS_INT) * (size_t)cap);
+						free(big); big = nb; cur = nb; cap *= 2;
+					}
+					cur[nseen++] = bc;
+				}
 			}
-		for (LIS_INT s = 0; s < nseen; s++) slot[seen[s]] = 0;
-		bptr[br + 1] = bptr[br] + nseen;
+		free(big);
+		bptr[br + 1] = nseen;
 	}
+	for (LIS_INT br = 0; br < nr; br++) bptr[br + 1] += bptr[br];
 	const LIS_INT bnnz = bptr[nr];
 	NEW(bindex, LIS_INT, bnnz); NEW(value, LIS_SCALAR, (size_t)bnnz * bs);
+	#pragma omp parallel for schedule(dynamic, 1024)
 	for (LIS_INT br = 0; br < nr; br++) {                       /* pass 2: blocks in first-seen order, column-major inside */
-		LIS_INT next = bptr[br];
+		const LIS_INT first = bptr[br];
+		LIS_INT next = first;
 		for (LIS_INT ii = 0; ii < bnr && br * bnr + ii < n; ii++)
 			for (LIS_INT k = A->ptr[br * bnr + ii]; k < A->ptr[br * bnr + ii + 1]; k++) {
 				const LIS_INT bc = BCOL(A->index[k]), jc = BOFF(A->index[k]);
-				if (!slot[bc]) {
-					slot[bc] = next + 1;
-					bindex[next] = bc;
-					for (LIS_INT z = 0; z < bs; z++) value[(size_t)next * bs + z] = 0.0;
-					next++;
+				LIS_INT s = next - 1;
+				while (s >= first && bindex[s] != bc) s--;
+				if (s < first) {
+					s = next++;
+					bindex[s] = bc;
+					for (LIS_INT z = 0; z < bs; z++) value[(size_t)s * bs + z] = 0.0;
 				}
-				value[(size_t)(slot[bc] - 1) * bs + (size_t)jc * bnr + ii] = A->value[k];
+				value[(size_t)s * bs + (size_t)jc * bnr + ii] = A->value[k];
 			}
-		for (LIS_INT b = bptr[br]; b < bptr[br + 1]; b++) slot[bindex[b]] = 0;
 	}
 #undef BCOL
 #undef BOFF

@@ -28,12 +28,12 @@ static LIS_INT csr2ell(LIS_MATRIX A, LIS_MATRIX B)
 {
 	const LIS_INT n = A->n;
 	LIS_INT err = 0, maxnzr = 0, *index = NULL; LIS_SCALAR *value = NULL;
-	#pragma omp parallel for reduction(max : maxnzr)
+	#pragma omp parallel for reduction(max : maxnzr) num_threads(lisi_host_threads())
 	for (LIS_INT i = 0; i < n; i++) if (A->ptr[i + 1] - A->ptr[i] > maxnzr) maxnzr = A->ptr[i + 1] - A->ptr[i];
 	NEW(index, LIS_INT, (size_t)n * maxnzr); NEW(value, LIS_SCALAR, (size_t)n * maxnzr);
 	/* slot j of every row, rows in chunks: each thread writes whole cache lines of the column-major arrays;
 	 * padding: value 0 on the row's own column */
-	#pragma omp parallel for schedule(static)
+	#pragma omp parallel for schedule(static) num_threads(lisi_host_threads())
 	for (LIS_INT c = 0; c < (n + 1023) / 1024; c++) {
 		const LIS_INT i0 = c * 1024, i1 = i0 + 1024 < n ? i0 + 1024 : n;
 		for (LIS_INT j = 0; j < maxnzr; j++)
@@ -60,8 +60,7 @@ static LIS_INT csr2csc(LIS_MATRIX A, LIS_MATRIX B)
 	 * all rows in order, taking the entries of its columns: no shared counters, the same arrays as the serial sweep */
 	int nth = 1;
 	#ifdef _OPENMP
-	nth = omp_get_max_threads();
-	if (nth > 32) nth = 32;
+	nth = lisi_host_threads();
 	if ((long long)nnz < 4000000) nth = 1;
 	#endif
 	#pragma omp parallel for schedule(static, 1) num_threads(nth)
@@ -93,7 +92,7 @@ static LIS_INT csr2dia(LIS_MATRIX A, LIS_MATRIX B)
 	LIS_INT err = 0, nnd = 0, *index = NULL, *slot = NULL; LIS_SCALAR *value = NULL;
 	unsigned char *used = NULL;
 	/* like the reference (lis_matrix_dia.c:1217) the INPUT rows are put in ascending column order first */
-	#pragma omp parallel for schedule(dynamic, 4096)
+	#pragma omp parallel for schedule(dynamic, 4096) num_threads(lisi_host_threads())
 	for (LIS_INT i = 0; i < n; i++) lisi_sort_row(A->ptr[i], A->ptr[i + 1], A->index, A->value);
 	A->is_sorted = LIS_TRUE;
 	if (MDEV(A)->ready) lisd_mat_free(A);                     /* its HBM copy had the old order */
@@ -101,13 +100,19 @@ static LIS_INT csr2dia(LIS_MATRIX A, LIS_MATRIX B)
 	const size_t span = (size_t)n + (size_t)np;
 	used = (unsigned char *)calloc(span ? span : 1, 1);
 	if (!used) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)span); goto fail; }
-	#pragma omp parallel for schedule(static)
-	for (LIS_INT i = 0; i < n; i++) for (LIS_INT k = A->ptr[i]; k < A->ptr[i + 1]; k++) used[(size_t)(A->index[k] - i + n)] = 1;   /* racing writers store the same 1 */
+	#pragma omp parallel for schedule(static) num_threads(lisi_host_threads())
+	for (LIS_INT i = 0; i < n; i++)
+		for (LIS_INT k = A->ptr[i]; k < A->ptr[i + 1]; k++) {
+			/* test first: a stencil has a handful of offsets, and 16 threads storing into the same cache line 10^8 times
+			 * (measured: 0.4 s at 160^3) is what the test avoids; racing writers store the same 1 */
+			const size_t o = (size_t)(A->index[k] - i + n);
+			if (!used[o]) used[o] = 1;
+		}
 	for (size_t o = 0; o < span; o++) nnd += used[o];
 	NEW(index, LIS_INT, nnd); NEW(value, LIS_SCALAR, (size_t)n * nnd); NEW(slot, LIS_INT, span);
 	nnd = 0;
 	for (size_t o = 0; o < span; o++) if (used[o]) { slot[o] = nnd; index[nnd++] = (LIS_INT)((long long)o - n); }
-	#pragma omp parallel for schedule(static)
+	#pragma omp parallel for schedule(static) num_threads(lisi_host_threads())
 	for (LIS_INT c = 0; c < (n + 1023) / 1024; c++) {
 		const LIS_INT i0 = c * 1024, i1 = i0 + 1024 < n ? i0 + 1024 : n;
 		for (LIS_INT d = 0; d < nnd; d++) memset(value + (size_t)d * n + i0, 0, sizeof(LIS_SCALAR) * (size_t)(i1 - i0));
@@ -164,7 +169,7 @@ static LIS_INT csr2jad(LIS_MATRIX A, LIS_MATRIX B)
 	}
 	lisi_sortr_ii(0, n - 1, len, perm);
 	for (LIS_INT j = 0; j < maxnzr; j++) ptr[j + 1] += ptr[j];
-	#pragma omp parallel for schedule(static)
+	#pragma omp parallel for schedule(static) num_threads(lisi_host_threads())
 	for (LIS_INT s = 0; s < n; s++) {                          /* jagged diagonal j holds the j-th entry of every row long enough */
 		const LIS_INT src = A->ptr[perm[s]], cnt = A->ptr[perm[s] + 1] - src;
 		for (LIS_INT j = 0; j < cnt; j++) { value[ptr[j] + s] = A->value[src + j]; index[ptr[j] + s] = A->index[src + j]; }
@@ -190,7 +195,7 @@ static LIS_INT csr2bsr(LIS_MATRIX A, LIS_MATRIX B)
 	 * a short list searched linearly from its end (neighbouring entries repeat the last block) replaces a table over all nc. */
 	enum { LOCAL = 512 };
 	bptr[0] = 0;
-	#pragma omp parallel for schedule(dynamic, 1024)
+	#pragma omp parallel for schedule(dynamic, 1024) num_threads(lisi_host_threads())
 	for (LIS_INT br = 0; br < nr; br++) {                       /* pass 1: distinct block columns per block row */
 		LIS_INT list[LOCAL], nseen = 0, *big = NULL, cap = LOCAL;
 		LIS_INT *cur = list;
@@ -214,7 +219,7 @@ static LIS_INT csr2bsr(LIS_MATRIX A, LIS_MATRIX B)
 	for (LIS_INT br = 0; br < nr; br++) bptr[br + 1] += bptr[br];
 	const LIS_INT bnnz = bptr[nr];
 	NEW(bindex, LIS_INT, bnnz); NEW(value, LIS_SCALAR, (size_t)bnnz * bs);
-	#pragma omp parallel for schedule(dynamic, 1024)
+	#pragma omp parallel for schedule(dynamic, 1024) num_threads(lisi_host_threads())
 	for (LIS_INT br = 0; br < nr; br++) {                       /* pass 2: blocks in first-seen order, column-major inside */
 		const LIS_INT first = bptr[br];
 		LIS_INT next = first;

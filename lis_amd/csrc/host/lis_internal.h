@@ -156,6 +156,7 @@ LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes);
 
 /* ---- matrix internals shared between files */
 LIS_INT lisi_matrix_check(LIS_MATRIX A, int level);
+int     lisi_host_threads(void);      /* threads the host-side conversions may use: affinity mask capped by the cgroup CPU quota, at most 32 */
 /* ---- split form (lis_split.c) */
 void    lisi_sortr_ii(LIS_INT lo, LIS_INT hi, LIS_INT *key, LIS_INT *tag);    /* the reference's descending quicksort (lis_convert.c) */
 void    lisi_matrix_dlu_destroy(LIS_MATRIX A);

@@ -4,6 +4,7 @@
  * Mirrors the caller-visible behaviour of the reference's src/system (lis_init.c:121-247,
  * lis_memory.c, lis_error.c:161-191, lis_time.c); none of it is on the hot path.
  */
+#define _GNU_SOURCE
 #include <stdarg.h>
 #include <stdio.h>
 #include <sys/time.h>
@@ -60,6 +61,37 @@ static reg_entry *reg_find(void *obj)
 void lisi_unregister(void *obj) { reg_entry *e = reg_find(obj); if (e) { e->obj = (void *)1; reg_live--; } }
 size_t lisi_registry_slots(void) { return reg_cap; }          /* tests: the table must not grow with the create/destroy count */
 int  lisi_is_registered(void *obj) { return reg_find(obj) != NULL; }
+
+/* ------------------------------------------------------------------ host threads for the one-off conversions (lis_convert.c)
+ * A container sees every core of the machine but may only run a quota of them: a team of 128 threads on a 16-core quota is
+ * throttled to a crawl (measured: csr2dia at 256^3 11 s instead of 0.5 s).  Affinity mask, capped by cpu.max, capped at 32;
+ * LIS_AMD_HOST_THREADS overrides. */
+#include <sched.h>
+int lisi_host_threads(void)
+{
+	static int cached = 0;
+	if (cached) return cached;
+	int n = 1;
+	const char *env = getenv("LIS_AMD_HOST_THREADS");
+	if (env && atoi(env) > 0) n = atoi(env);
+	else {
+		cpu_set_t set;
+		if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+		FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+		if (f) {
+			char quota[64]; long period = 0;
+			if (fscanf(f, "%63s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+				const long q = atol(quota) / period;
+				if (q >= 1 && q < n) n = (int)q;
+			}
+			fclose(f);
+		}
+		if (n > 32) n = 32;
+	}
+	if (n < 1) n = 1;
+	cached = n;
+	return n;
+}
 
 /* ------------------------------------------------------------------ allocation (ref:1037-1042)
  * The reference keeps a list of every block so that lis_free_all can sweep at finalize; callers may

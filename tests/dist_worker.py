@@ -5,6 +5,8 @@ into the library as host-memory callbacks (lis_amd_comm_init_callbacks).
 
     python tests/dist_worker.py host     # CPU only: tables + host halo exchange + local products by the oracle
     python tests/dist_worker.py device   # GPU box: lis_matvec / lis_solve on every rank's HBM slice
+    python tests/dist_worker.py rccl     # >= WORLD_SIZE GPUs: the same checks with an RCCL communicator, one GPU per rank --
+                                         # grouped ncclSend/ncclRecv halos, ncclAllGather + rank-order folds, the overlap stream
 """
 import ctypes as C
 import os
@@ -42,9 +44,23 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = lis_amd.load()
-    cb = make_callbacks(world)
-    lib.dll.lis_amd_comm_init_callbacks.argtypes = [C.POINTER(Callbacks), C.c_int, C.c_int]
-    assert lib.dll.lis_amd_comm_init_callbacks(C.byref(cb), rank, world) == 0
+    if mode == "rccl":
+        # rank 0's unique id travels over the gloo control plane; the data plane of everything below is RCCL over xGMI
+        uid = [None]
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            assert lib.dll.lis_amd_comm_get_unique_id(buf) == 0
+            uid[0] = bytes(buf)
+        dist.broadcast_object_list(uid, src=0)
+        assert lib.dll.lis_amd_comm_init_rccl(uid[0], rank, world, int(os.environ.get("LOCAL_RANK", rank))) == 0
+        assert lib.dll.lis_amd_comm_kind() == 1
+        mode = "device"
+        tag = "rccl"
+    else:
+        tag = mode
+        cb = make_callbacks(world)
+        lib.dll.lis_amd_comm_init_callbacks.argtypes = [C.POINTER(Callbacks), C.c_int, C.c_int]
+        assert lib.dll.lis_amd_comm_init_callbacks(C.byref(cb), rank, world) == 0
     assert lib.initialize([]) == 0
     assert lib.dll.lis_amd_comm_rank() == rank and lib.dll.lis_amd_comm_size() == world
     lib.dll.lis_amd_halo_exchange_host.argtypes = [capi.PM, capi.P_DBL]
@@ -95,8 +111,11 @@ def main():
         xg = np.random.default_rng(17).uniform(-1, 1, gn)
         xl = np.zeros(a.np)
         xl[:n] = xg[is_:ie]
-        assert lib.dll.lis_amd_halo_exchange_host(A, xl.ctypes.data_as(capi.P_DBL)) == 0
-        assert np.array_equal(xl[n:], xg[ghosts]), name
+        if tag == "rccl":
+            xl[n:] = xg[ghosts]                                        # the host-array exchange belongs to the callback communicator
+        else:
+            assert lib.dll.lis_amd_halo_exchange_host(A, xl.ctypes.data_as(capi.P_DBL)) == 0
+            assert np.array_equal(xl[n:], xg[ghosts]), name
         yg = orc.spmv_csr(ptr, idx, val, xg)
         assert np.array_equal(orc.spmv_csr(got["ptr"], got["index"], got["value"], xl), yg[is_:ie]), name
 
@@ -136,7 +155,9 @@ def main():
     if mode == "device":
         device_poisson_generator(lib, rank, world)
     dist.barrier()
-    print(f"rank {rank}/{world} {mode} OK", flush=True)
+    if tag == "rccl":
+        assert lib.dll.lis_amd_comm_finalize() == 0
+    print(f"rank {rank}/{world} {tag} OK", flush=True)
     dist.destroy_process_group()
 
 

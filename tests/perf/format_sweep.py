@@ -67,7 +67,7 @@ def main():
         if fmt == "bsr":
             b = 8 * B.contents.bnnz * 4 + 4 * B.contents.bnnz + 4 * (B.contents.nr + 1) + 16 * n
         line = (f"{fmt}: {ms:.4f} ms  {2 * nnz / ms / 1e6:.1f} GFLOP/s  {b / ms / 1e6:.0f} GB/s alg ({b / ms / 1e6 / 80:.1f}% of 8 TB/s)"
-                f"  ||A*1||={nrm:.6e} (want {want:.6e})  y==y_csr:{same}  convert {tconv:.1f}s")
+                f"  ||A*1||={nrm:.6e} (want {want:.6e})  y==y_csr:{same}  convert {tconv:.3f}s")
         if solve:
             bb = lisdrv.new_vector(lib, B)
             assert lib.lis_matvec(B, vx, bb) == 0

@@ -24,7 +24,8 @@ def _launch(mode, world, timeout=600):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", LIS_AMD_DEVICE="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   LIS_AMD_DEVICE=str(rank) if mode == "rccl" else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -49,3 +50,22 @@ def test_partition_tables_and_halo_on_cpu(world):
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_spmv_and_solvers_on_one_gpu(world):
     _launch("device", world)
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_over_rccl_one_gpu_per_rank(world):
+    """The real N > 1 data path: an RCCL communicator with one GPU per rank (grouped ncclSend/ncclRecv halos on the second stream,
+    ncclAllGather + rank-order folds, device-driven loops across ranks).  Every product slice must carry the bits of the
+    single-process product, every solve the counts of the callback run.  Needs `world` GPUs: skipped on a one-GPU box."""
+    if _gpu_count() < world:
+        pytest.skip(f"needs {world} GPUs, {_gpu_count()} visible")
+    _launch("rccl", world)

@@ -203,12 +203,14 @@ def main():
     # kernel is actually asked to move and the fraction of the roofline THEY reach are reported beside them.
     dll.lis_amd_matrix_index_codes.argtypes = [capi.PM]
     coded = int(dll.lis_amd_matrix_index_codes(A))
-    moved = (9 if coded else 12) * nnz_local + 20 * n_local + 4
+    dll.lis_amd_matrix_row_patterns.argtypes = [capi.PM]
+    patterns = int(dll.lis_amd_matrix_row_patterns(A))     # > 0: one byte per ROW (pattern) + a 2 B row start instead of 1 B per non-zero + 4 B
+    moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
-                "kernel": "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel", "kernel_ms": round(kernel_ms, 4),
+                "kernel": "spmv_csr_pattern_kernel" if patterns else "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel", "kernel_ms": round(kernel_ms, 4),
                 "alg_bytes_per_launch": alg_bytes, "per_gpu": True,
-                "index_codes": coded, "stored_bytes_per_launch": moved,
+                "index_codes": coded, "row_patterns": patterns, "stored_bytes_per_launch": moved,
                 "frac_of_stored_bytes": round(moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---- N > 1: what the exchange costs by itself, and the product with the overlap switched off (A/B)
@@ -260,7 +262,7 @@ def main():
                 tt = torch.tensor([itime, wall], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 itime, wall = float(tt[0]), float(tt[1])
-            loop_b, contract_b = krylov_bytes(key, iters, n_local, nnz_local, coded)
+            loop_b, contract_b = krylov_bytes(key, iters, n_local, nnz_local, coded, patterns)
             sec_per_iter = itime / max(1, iters)
             solvers[key] = {
                 "iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6),
@@ -305,12 +307,20 @@ def main():
         sys.exit(3)                   # the line above says "degraded": true; a driver that only looks at the exit code sees it too
 
 
-def krylov_bytes(key, iters, n, nnz, coded):
+def spmv_stored_bytes(n, nnz, coded, patterns):
+    """bytes one product is asked to stream: values + column information + row starts + y + the compulsory x"""
+    if patterns:
+        return 8 * nnz + (1 + 2 + 8 + 8) * n + 4           # one pattern byte and a 2 B block-relative start per row
+    return (9 if coded else 12) * nnz + 20 * n + 4
+
+
+def krylov_bytes(key, iters, n, nnz, coded, patterns=0):
     """Bytes per iteration and per GPU: (what the passes of the fused device loops are asked to stream, what the
     reference's unfused operator sequence moves by SURVEY 8d's count).  n / nnz are the local rows / non-zeros.
-    Product: S = (9 coded | 12) B per non-zero + 20 B per row (ptr, y, compulsory x); contract B = 12 nnz + 20 n.
+    Product: S = (9 coded | 12) B per non-zero + 20 B per row (ptr, y, compulsory x), or 8 B per non-zero + 19 B per row with row
+    patterns; contract B = 12 nnz + 20 n.
     Vector passes: every array a pass reads or writes counts 8 B per row once."""
-    S = (9 if coded else 12) * nnz + 20 * n
+    S = spmv_stored_bytes(n, nnz, coded, patterns) - 4
     B = 12 * nnz + 20 * n
     if key == "cg_jacobi":
         # p = dinv.*r + beta p (+ the deferred x += alpha p: r dinv p x | p x) ; q = A p with <p,q> (w = p: no extra stream) ;

@@ -50,6 +50,9 @@ LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A);   /* host arrays changed: dr
 /* number of entries of the column-offset dictionary when the HBM copy of A carries one-byte column codes (liship.h
  * "index coding": matrices on <= 255 diagonals), 0 when it reads the 4 B indices; uploads A if needed */
 LIS_INT lis_amd_matrix_index_codes(LIS_MATRIX A);
+/* number of row patterns when the HBM copy of A keeps ONE byte per row (liship.h "row patterns": the rows of a coded matrix
+ * follow <= 255 offset sequences), 0 otherwise; uploads A if needed */
+LIS_INT lis_amd_matrix_row_patterns(LIS_MATRIX A);
 /* total length of the per-row-block lists of distinct columns when the HBM copy of A carries block-local columns (liship.h:
  * long rows that share their columns), 0 when it does not; uploads A if needed */
 LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A);

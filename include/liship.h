@@ -73,6 +73,14 @@ int  liship_csr_plan_create(liship_csr_plan_t *plan, int n, const int *ptr, void
  * liship_spmv_csr_set_index_codes(0) makes every product ignore the codes (A/B measurements). */
 int  liship_csr_plan_encode_indices(liship_csr_plan_t plan, const int *ptr, const int *index, void *stream);
 int  liship_csr_plan_coded(liship_csr_plan_t plan);
+/* Row patterns (setup-time, optional, after liship_csr_plan_encode_indices; never an error when the matrix does not qualify):
+ * when the rows of a coded matrix follow at most 255 distinct (length, offset sequence) patterns -- a 7-point stencil has 27 --
+ * the plan keeps ONE byte per row (its pattern) and a 2 B row start relative to the row block instead of one byte per
+ * non-zero and the 4 B row pointer: 75 instead of 83 B per stencil row.  Same terms in the same order: bit-identical.
+ * liship_csr_plan_row_patterns: number of patterns, 0 if none.  liship_spmv_csr_set_row_patterns(0): A/B switch. */
+int  liship_csr_plan_encode_row_patterns(liship_csr_plan_t plan, const int *ptr, void *stream);
+int  liship_csr_plan_row_patterns(liship_csr_plan_t plan);
+int  liship_spmv_csr_set_row_patterns(int on);
 int  liship_spmv_csr_set_index_codes(int on);
 /* Block-local columns (setup-time, optional, never an error when the matrix does not qualify): for matrices with long rows
  * (the plan's products kernel) whose row blocks address few distinct columns -- several unknowns per node, wide bands --

@@ -55,6 +55,9 @@ _LISHIP = {
     "liship_spmv_csr_dot_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "liship_csr_plan_encode_indices": (_ci, [_vp, _vp, _vp, _vp]),
     "liship_csr_plan_coded": (_ci, [_vp]),
+    "liship_csr_plan_encode_row_patterns": (_ci, [_vp, _vp, _vp]),
+    "liship_csr_plan_row_patterns": (_ci, [_vp]),
+    "liship_spmv_csr_set_row_patterns": (_ci, [_ci]),
     "liship_csr_plan_localize_columns": (_ci, [_vp, _vp, _vp, _vp]),
     "liship_csr_plan_localized": (C.c_longlong, [_vp]),
     "liship_spmv_csr_set_local_columns": (_ci, [_ci]),

@@ -230,6 +230,10 @@ LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int
 		rc = liship_csr_plan_encode_indices(*plan, dptr, dindex, lisg.stream);
 		if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_encode_indices(*plan, dptr, dindex, lisg.stream);
 		if (rc && rc != 2 /* hipErrorOutOfMemory */) HIPCHK(rc);
+		if (!rc && !lisg.no_row_patterns && liship_csr_plan_coded(*plan)) {       /* whole rows that repeat: one byte per row */
+			rc = liship_csr_plan_encode_row_patterns(*plan, dptr, lisg.stream);
+			if (rc && rc != 2) HIPCHK(rc);
+		}
 	}
 	if (!lisg.no_local_columns && !liship_csr_plan_coded(*plan)) {      /* long rows: block-local columns where they pay */
 		rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
@@ -456,6 +460,11 @@ LIS_INT lis_amd_matrix_index_codes(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	return MDEV(A)->plan ? liship_csr_plan_coded(MDEV(A)->plan) : 0;
+}
+LIS_INT lis_amd_matrix_row_patterns(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return MDEV(A)->plan ? liship_csr_plan_row_patterns(MDEV(A)->plan) : 0;
 }
 LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A)
 {

@@ -103,6 +103,7 @@ typedef struct {
 	void *comm_stream;         /* second HIP stream: halo send/recv overlapped with the interior rows */
 	void *ev_packed, *ev_landed;
 	int long_row_tree;         /* LIS_AMD_LONG_ROW_TREE=1: rows longer than the LDS stage are added by a tree per pass (not bit-parity; opt-in) */
+	int no_row_patterns;       /* LIS_AMD_NO_ROW_PATTERNS=1: coded CSR matrices keep one byte per non-zero instead of one per row (A/B measurements) */
 	int no_local_columns;      /* LIS_AMD_NO_LOCAL_COLUMNS=1: long-row CSR products keep the 4 B column indices (A/B measurements) */
 	int no_index_codes;        /* LIS_AMD_NO_INDEX_CODES=1: CSR products keep reading the 4 B column indices (A/B measurements) */
 	int host_scalars;          /* LIS_AMD_HOST_SCALARS=1: CG / BiCGSTAB read every scalar back (A/B against the device-driven loops) */

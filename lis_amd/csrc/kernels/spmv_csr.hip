@@ -25,6 +25,8 @@
 //     stage (continued pass by pass by the lane that owns them, still in order).
 // No __shfl tree is used for the row sums on purpose: a tree changes the association order and would
 // break bit parity with the reference; the reductions that ARE trees live in vector_ops.hip.
+#include <string.h>
+#include <stdlib.h>
 #include "common.hpp"
 #include "liship.h"
 
@@ -55,6 +57,7 @@ constexpr int SLACK = 128;       // extra items a block may take to start on an 
 //   bit10 register staging instead of LDS-DMA   bits11-12 gather unroll U: 0 auto, 1: 4, 2: 7, 3: 8
 int g_variant = 0;
 int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps every product on the 4 B indices
+int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
 int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps the products kernel on the 4 B indices
 
 __device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
@@ -720,6 +723,157 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
+// ------------------------------------------------------------------------------ row-gather kernel, row patterns
+// A structured-grid matrix repeats not only its offsets but whole ROWS of them: every interior row of the 7-point stencil is
+// the same sequence of 7 offsets, the boundary rows are 26 more sequences.  When the rows of a coded matrix follow at most 255
+// such patterns (liship_csr_plan_encode_row_patterns) the plan keeps ONE byte per ROW -- the pattern, which gives the row's
+// length and its offsets from a small table in LDS -- and a 2 B start of the row relative to its row block, instead of one byte
+// per non-zero and a 4 B row pointer: the 7-point stencil streams 75 B per row (56 values, 1 pattern, 2 start, 8 y, 8 x)
+// instead of 83.  Same rows, same terms, same order as the two kernels above: bit-identical.
+constexpr int PAT_TABLE = 1024 + 256 + 2;           // ints of LDS for the table: npat + 1 prefix entries, then the offsets
+template <int BLOCK, int WORK, int U, int DOT = 0>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
+                             const unsigned char *__restrict__ rowpat, const unsigned short *__restrict__ rowrel,
+                             const int *__restrict__ ptab, int tablen, int npat1,
+                             const double *__restrict__ x, double *__restrict__ y, const v2i32 *__restrict__ blk,
+                             int bfirst, int nb, Rows RW, int nnz_total,
+                             const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                             const double *__restrict__ guard = nullptr, int pstride = 0)
+{
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    const int row_begin = RW.rb, row_end = RW.re;
+    const double acc0 = RW.acc0;
+    __shared__ double dot_scratch[BLOCK / WAVE];
+    RowDots<DOT> dots{wdot, 0.0, 0.0};
+    constexpr int CAP = WORK + SLACK + 2;
+    __shared__ __attribute__((aligned(16))) double valL[(GUARD + CAP + 8 + 16) + 2 * WAVE];    // also the product stage of block_by_products
+    __shared__ int ptabL[PAT_TABLE];
+
+    const int lb = blockIdx.x;
+    Blk B = load_blk(blk, bfirst + lb);
+    const int kplan = B.k0;                         // the row starts are relative to the PLAN's block, whatever this launch clips
+    if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+        return;
+    }
+    const int ka = B.k0 & ~1;                       // 16 B aligned start of the value slice
+    const int cnt = B.k1 - ka;
+    const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
+    if (cnt > CAP || ka + 2 * np > nnz_total) {     // long row / last value of the array
+        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
+        __syncthreads();
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+        return;
+    }
+    for (int i = threadIdx.x; i < tablen; i += BLOCK) ptabL[i] = ptab[i];
+    const int rmine = B.r0 + (int)threadIdx.x;
+    int p_first = 0, s_first = 0;
+    if (rmine < B.r1) { p_first = rowpat[rmine]; s_first = kplan + rowrel[rmine]; }
+    {
+        const int wbase = (int)threadIdx.x & ~(WAVE - 1), lane = (int)threadIdx.x & (WAVE - 1);
+        for (int p0 = wbase; p0 < np; p0 += BLOCK) {
+            const int p = min(p0 + lane, np - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+        }
+    }
+    __syncthreads();
+
+    for (int r = rmine; r < B.r1; r += BLOCK) {
+        int pat = p_first, s = s_first;
+        if (r != rmine) { pat = rowpat[r]; s = kplan + rowrel[r]; }
+        const int ps = ptabL[pat], len = ptabL[pat + 1] - ps;
+        const int *po = ptabL + npat1 + ps;
+        const int off = s - ka;
+        const double wr = dots.fetch(r);
+        double acc = acc0;
+        for (int j0 = 0; j0 < len; j0 += U) {
+            int cc[U]; double vv[U], xx[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = min(j0 + u, len - 1);         // clamped: repeats the row's last entry
+                cc[u] = r + po[j];
+                vv[u] = valL[off + j];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) xx[u] = x[cc[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double t = vv[u] * xx[u];
+                acc += (j0 + u < len) ? t : -0.0;           // -0.0 terms leave any sum bit-unchanged
+            }
+        }
+        store_stream(y + r, acc);
+        dots.add_loaded(wr, acc);
+    }
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+}
+
+// plan time: one 64-bit hash per row over (length, code sequence); the distinct ones in an open-addressing table together with the
+// smallest row that has them; gives up beyond 255
+constexpr int PAT_SLOTS = 1024, PAT_MAXLEN = 64;
+__device__ __forceinline__ unsigned long long row_hash(const unsigned char *codes, int s, int e)
+{
+    unsigned long long h = 1469598103934665603ull ^ (unsigned long long)(e - s);
+    for (int k = s; k < e; k++) { h ^= codes[k]; h *= 1099511628211ull; }
+    return h | 1ull;                                 // 0 marks an empty slot
+}
+__global__ void csr_collect_patterns(int n, const int *__restrict__ ptr, const unsigned char *__restrict__ codes,
+                                     unsigned long long *__restrict__ keys, int *__restrict__ rep, int *__restrict__ count)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || count[0] > 255) return;
+    const int s = ptr[r], e = ptr[r + 1];
+    if (e - s > PAT_MAXLEN) { atomicAdd(count, 1000); return; }
+    const unsigned long long h = row_hash(codes, s, e);
+    unsigned slot = (unsigned)(h >> 40) & (PAT_SLOTS - 1);
+    for (int probe = 0; probe < PAT_SLOTS; probe++) {
+        unsigned long long v = keys[slot];
+        if (v == 0ull) {
+            v = atomicCAS(&keys[slot], 0ull, h);
+            if (v == 0ull) { atomicAdd(count, 1); v = h; }
+        }
+        if (v == h) { if (r < rep[slot]) atomicMin(&rep[slot], r); return; }    // the test keeps 10^8 rows off the same few words
+        slot = (slot + 1) & (PAT_SLOTS - 1);
+        if (count[0] > 255) return;
+    }
+}
+// the code sequences of the representative rows: out[p * PAT_MAXLEN + j]
+__global__ void csr_fetch_patterns(int npat, const int *__restrict__ rep, const int *__restrict__ ptr,
+                                   const unsigned char *__restrict__ codes, int *__restrict__ len, unsigned char *__restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npat) return;
+    const int s = ptr[rep[p]], e = ptr[rep[p] + 1];
+    len[p] = e - s;
+    for (int k = s; k < e && k - s < PAT_MAXLEN; k++) out[p * PAT_MAXLEN + (k - s)] = codes[k];
+}
+// one workgroup per row block: pattern number (position of the row's hash in the sorted list, sequence verified) and the row's
+// start relative to the block; *bad counts rows that match no pattern (hash collision: the plan then stays with the codes)
+__global__ void csr_encode_patterns(const v2i32 *__restrict__ blk, const int *__restrict__ ptr, const unsigned char *__restrict__ codes,
+                                    int npat, const unsigned long long *__restrict__ hashes, const int *__restrict__ plen,
+                                    const unsigned char *__restrict__ pcodes, unsigned char *__restrict__ rowpat,
+                                    unsigned short *__restrict__ rowrel, int *__restrict__ bad)
+{
+    __shared__ unsigned long long hL[256];
+    for (int i = threadIdx.x; i < npat; i += blockDim.x) hL[i] = hashes[i];
+    __syncthreads();
+    const int b = blockIdx.x, r0 = blk[b].x, k0 = blk[b].y, r1 = blk[b + 1].x;
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += blockDim.x) {
+        const int s = ptr[r], e = ptr[r + 1];
+        const unsigned long long h = row_hash(codes, s, e);
+        int lo = 0, hi = npat - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (hL[mid] < h) lo = mid + 1; else hi = mid; }
+        bool ok = hL[lo] == h && plen[lo] == e - s && s - k0 < 65536;
+        for (int k = s; ok && k < e; k++) ok = pcodes[lo * PAT_MAXLEN + (k - s)] == codes[k];
+        if (!ok) atomicAdd(bad, 1);
+        rowpat[r] = (unsigned char)lo;
+        rowrel[r] = (unsigned short)(s - k0);
+    }
+}
+
 // plan time: the set of (column - row) offsets, in a small open-addressing table; gives up beyond 255
 constexpr int OFFSET_TABLE = 1024, OFFSET_EMPTY = -2147483647 - 1;
 __global__ void csr_collect_offsets(int n, const int *__restrict__ ptr, const int *__restrict__ idx,
@@ -780,6 +934,10 @@ struct liship_csr_plan_s {
     int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
     long long ndcol;     // entries of dcol
     int first_term;      // row sums start at the first product instead of at +0.0 (split matrices)
+    unsigned char *rowpat; // device, one byte per row: its pattern (length + offset sequence); NULL = none
+    unsigned short *rowrel; // device, 2 B per row: its first non-zero relative to its row block
+    int *ptab;           // device: npat + 1 prefix entries, then the offsets of all patterns
+    int ptab_len, npat;
 };
 
 extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
@@ -846,6 +1004,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0;
     p->first_term = 0;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -859,6 +1018,9 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->blk) rc = (int)hipFree(p->blk);
     if (p->codes) (void)hipFree(p->codes);
     if (p->dict) (void)hipFree(p->dict);
+    if (p->rowpat) (void)hipFree(p->rowpat);
+    if (p->rowrel) (void)hipFree(p->rowrel);
+    if (p->ptab) (void)hipFree(p->ptab);
     if (p->lcol) (void)hipFree(p->lcol);
     if (p->dcol) (void)hipFree(p->dcol);
     if (p->doff) (void)hipFree(p->doff);
@@ -940,6 +1102,91 @@ extern "C" int liship_csr_plan_encode_indices(liship_csr_plan_t p, const int *pt
 // number of dictionary entries when the plan's indices are coded, 0 otherwise
 extern "C" int liship_csr_plan_coded(liship_csr_plan_t p) { return (p && p->codes) ? p->ndict : 0; }
 
+// Row patterns on top of the column codes (see spmv_csr_pattern_kernel): setup-time, optional, never an error when the matrix
+// does not qualify (not coded, a row longer than 64, more than 255 patterns, more than 1024 offsets over all patterns).
+// Must follow liship_csr_plan_encode_indices, whose final row split it encodes the row starts against.
+extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const int *ptr, void *stream)
+{
+    if (!p || (p->n > 0 && !ptr)) return LISHIP_ERR_ARG;
+    if (!p->codes || p->rowpat || p->products || p->nblocks <= 0 || g_variant != 0) return 0;
+    hipStream_t st = as_stream(stream);
+    struct Table { unsigned long long keys[PAT_SLOTS]; int rep[PAT_SLOTS]; int count; };
+    Table *host = (Table *)malloc(sizeof(Table));
+    Table *dev = nullptr;
+    if (!host) return LISHIP_ERR_ARG;
+    hipError_t e = hipMalloc(&dev, sizeof(Table));
+    if (e != hipSuccess) { free(host); return (int)e; }
+    memset(host, 0, sizeof(Table));
+    for (int i = 0; i < PAT_SLOTS; i++) host->rep[i] = 0x7fffffff;
+    e = hipMemcpyAsync(dev, host, sizeof(Table), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        csr_collect_patterns<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, p->codes, dev->keys, dev->rep, &dev->count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(Table), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dev);
+    if (e != hipSuccess) { free(host); return (int)e; }
+    if (host->count > 255 || host->count <= 0) { free(host); return 0; }
+    // the patterns, sorted by hash (what csr_encode_patterns searches)
+    int npat = 0, order[256];
+    for (int i = 0; i < PAT_SLOTS; i++) if (host->keys[i] != 0ull && npat < 256) order[npat++] = i;
+    for (int i = 1; i < npat; i++) { const int v = order[i]; int j = i - 1; while (j >= 0 && host->keys[order[j]] > host->keys[v]) { order[j + 1] = order[j]; j--; } order[j + 1] = v; }
+    unsigned long long hashes[256]; int reps[256], plen[256];
+    for (int i = 0; i < npat; i++) { hashes[i] = host->keys[order[i]]; reps[i] = host->rep[order[i]]; }
+    free(host);
+    unsigned long long *d_hash = nullptr; int *d_rep = nullptr, *d_len = nullptr, *d_bad = nullptr; unsigned char *d_pc = nullptr;
+    unsigned char *pcodes = (unsigned char *)calloc((size_t)npat * PAT_MAXLEN, 1);
+    int rc = 0, bad = 0, dict[256];
+#define PT(expr) do { if (rc == 0) { hipError_t e__ = (expr); if (e__ != hipSuccess) rc = (int)e__; } } while (0)
+    PT(hipMalloc(&d_hash, sizeof(hashes))); PT(hipMalloc(&d_rep, sizeof(reps))); PT(hipMalloc(&d_len, sizeof(plen)));
+    PT(hipMalloc(&d_bad, sizeof(int))); PT(hipMalloc(&d_pc, (size_t)npat * PAT_MAXLEN));
+    PT(hipMemcpyAsync(d_hash, hashes, sizeof(unsigned long long) * npat, hipMemcpyHostToDevice, st));
+    PT(hipMemcpyAsync(d_rep, reps, sizeof(int) * npat, hipMemcpyHostToDevice, st));
+    PT(hipMemsetAsync(d_bad, 0, sizeof(int), st));
+    PT(hipMemsetAsync(d_pc, 0, (size_t)npat * PAT_MAXLEN, st));
+    if (rc == 0) { csr_fetch_patterns<<<1, 256, 0, st>>>(npat, d_rep, ptr, p->codes, d_len, d_pc); PT(hipGetLastError()); }
+    PT(hipMemcpyAsync(plen, d_len, sizeof(int) * npat, hipMemcpyDeviceToHost, st));
+    PT(hipMemcpyAsync(pcodes, d_pc, (size_t)npat * PAT_MAXLEN, hipMemcpyDeviceToHost, st));
+    PT(hipMemcpyAsync(dict, p->dict, sizeof(dict), hipMemcpyDeviceToHost, st));
+    PT(hipStreamSynchronize(st));
+    int total = 0;
+    for (int i = 0; i < npat && rc == 0; i++) total += plen[i];
+    const bool fits = rc == 0 && total <= 1024 && npat + 1 + total <= PAT_TABLE;
+    int *tab = nullptr;
+    if (fits) {
+        tab = (int *)malloc(sizeof(int) * (size_t)(npat + 1 + total));
+        int at = 0;
+        for (int i = 0; i < npat; i++) { tab[i] = at; for (int j = 0; j < plen[i]; j++) tab[npat + 1 + at + j] = dict[pcodes[i * PAT_MAXLEN + j]]; at += plen[i]; }
+        tab[npat] = at;
+        PT(hipMalloc(&p->ptab, sizeof(int) * (size_t)(npat + 1 + total)));
+        PT(hipMalloc(&p->rowpat, (size_t)p->n + 64));
+        PT(hipMalloc(&p->rowrel, sizeof(unsigned short) * ((size_t)p->n + 64)));
+        PT(hipMemcpyAsync(p->ptab, tab, sizeof(int) * (size_t)(npat + 1 + total), hipMemcpyHostToDevice, st));
+        if (rc == 0) {
+            csr_encode_patterns<<<p->nblocks, 256, 0, st>>>(p->blk, ptr, p->codes, npat, d_hash, d_len, d_pc, p->rowpat, p->rowrel, d_bad);
+            PT(hipGetLastError());
+        }
+        PT(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+        PT(hipStreamSynchronize(st));
+    }
+#undef PT
+    (void)hipFree(d_hash); (void)hipFree(d_rep); (void)hipFree(d_len); (void)hipFree(d_bad); (void)hipFree(d_pc);
+    free(pcodes); free(tab);
+    if (rc != 0 || !fits || bad != 0) {             // not this matrix (or two patterns with one hash): the codes serve
+        if (p->ptab) (void)hipFree(p->ptab);
+        if (p->rowpat) (void)hipFree(p->rowpat);
+        if (p->rowrel) (void)hipFree(p->rowrel);
+        p->ptab = nullptr; p->rowpat = nullptr; p->rowrel = nullptr;
+        return rc;
+    }
+    p->npat = npat; p->ptab_len = npat + 1 + total;
+    return 0;
+}
+// number of row patterns when the plan keeps one byte per row, 0 otherwise
+extern "C" int liship_csr_plan_row_patterns(liship_csr_plan_t p) { return (p && p->rowpat) ? p->npat : 0; }
+extern "C" int liship_spmv_csr_set_row_patterns(int on) { g_row_patterns = on ? 1 : 0; return 0; }
+
 // Block-local columns for the products kernel (see spmv_csr_local_kernel): setup-time, optional, never an error when the
 // matrix does not qualify.  Kept when the lists cover >= 90 % of the non-zeros and hold at most half as many columns as
 // the blocks hold entries -- below that the 2 B + 4 B of a once-used column cost more than its 4 B index.
@@ -1015,6 +1262,9 @@ struct LaunchArgs {
     const unsigned short *lcol = nullptr;   // block-local columns (positions, lists, list offsets), when the plan has them
     const int *dcol = nullptr, *doff = nullptr;
     double acc0 = 0.0;                      // what a row sum starts from (Rows)
+    const unsigned char *rowpat = nullptr;  // row patterns (pattern per row, relative row starts, table), when the plan has them
+    const unsigned short *rowrel = nullptr;
+    const int *ptab = nullptr; int ptab_len = 0, npat1 = 0;
 };
 
 
@@ -1077,6 +1327,14 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
+    if (a.rowpat && g_variant == 0) {                // one byte per ROW (the plan found <= 255 row patterns)
+        constexpr Geometry g = kGeom[G];
+#define GOP(UU) spmv_csr_pattern_kernel<g.block, g.work, UU, 0><<<a.nb, g.block, 0, a.st>>>( \
+            a.ptr, a.idx, a.val, a.rowpat, a.rowrel, a.ptab, a.ptab_len, a.npat1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz)
+        if (U == 4) GOP(4); else if (U == 7) GOP(7); else GOP(8);
+#undef GOP
+        return;
+    }
     if (a.codes && (g_variant & ~0x18F0) == 0) {     // one-byte column codes (the plan found <= 255 diagonals)
         constexpr Geometry g = kGeom[G];
 #define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, 0><<<a.nb, g.block, 0, a.st>>>( \
@@ -1097,6 +1355,14 @@ template <int G, int DOT>
 void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
+    if (a.rowpat) {
+#define GOP(UU) spmv_csr_pattern_kernel<g.block, g.work, UU, DOT><<<a.nb, g.block, 0, a.st>>>( \
+            a.ptr, a.idx, a.val, a.rowpat, a.rowrel, a.ptab, a.ptab_len, a.npat1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, \
+            w, partial, liship_internal_guard(), pstride)
+        if (unroll == 4) GOP(4); else if (unroll == 7) GOP(7); else GOP(8);
+#undef GOP
+        return;
+    }
     if (a.codes) {
 #define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, DOT><<<a.nb, g.block, 0, a.st>>>( \
             a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride)
@@ -1150,7 +1416,7 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
                                    const double *val, const double *x, double *y, void *stream)
 {
     if (!p) return LISHIP_ERR_ARG;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1};
     return launch_csr(p, a);
 }
 
@@ -1166,7 +1432,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if (g_variant != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);
@@ -1192,7 +1458,7 @@ extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int 
     const int bfirst = lo;
     lo = bfirst; hi = p->nblocks;                // first b with br[b].row >= row_end
     while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1};
     return launch_csr(p, a);
 }
 
@@ -1220,7 +1486,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if (nb <= 0) return 0;
     if ((size_t)slot_base + (size_t)nb > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work) + slot_base;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1};
     const int ps = (int)slots;
     if (p->products && p->geom == LOCAL_GEOM) {
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial, ps);

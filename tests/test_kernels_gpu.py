@@ -200,6 +200,9 @@ def cyclic_diagonals(n, count, seed):
     return np.asarray(ptr, np.int32), np.asarray(cols, np.int32), rng.uniform(-1, 1, len(cols))
 
 
+# row patterns the plan must find on top of the codes: 3 for the 1-D stencil (first row, interior, last row), 27 for the 3-D one
+ROW_PATTERNS = {"p1d_10000": 3, "p3d_20x17x13": 27, "p3d_64_sorted": 27, "p3d_40_sorted": 27, "p3d_odd_33x7x5": 27, "diagonals_255": 255,
+                "diagonals_300": 0, "rand_5000": 0, "wide_77": 0}        # diagonals_255: 254 two-entry rows + the rows whose second entry falls outside
 CODED_CASES = {
     "p1d_10000": (lambda: orc.poisson1d(10000), 3),
     "p3d_20x17x13": (lambda: orc.poisson3d(20, 17, 13), 7),
@@ -239,9 +242,15 @@ def test_spmv_csr_index_codes(lib, name):
     coded = lib.liship_csr_plan_coded(plan)
     if want is not None:
         assert coded == want, (coded, want)
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    npat = lib.liship_csr_plan_row_patterns(plan)
+    assert npat == 0 or coded > 0
+    if name in ROW_PATTERNS:
+        assert npat == ROW_PATTERNS[name], npat
     results = {}
-    for on in (1, 0):
-        lib.liship_spmv_csr_set_index_codes(on)
+    for on in (2, 1, 0):                       # 2: one byte per row (patterns), 1: one byte per non-zero (codes), 0: 4 B indices
+        lib.liship_spmv_csr_set_index_codes(1 if on else 0)
+        lib.liship_spmv_csr_set_row_patterns(1 if on == 2 else 0)
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
         assert np.array_equal(dy.to_host(), yref), on
@@ -273,10 +282,11 @@ def test_spmv_csr_index_codes(lib, name):
             out.append(res.to_host().copy())
         results[on] = out
     lib.liship_spmv_csr_set_index_codes(1)
+    lib.liship_spmv_csr_set_row_patterns(1)
     check(lib.liship_csr_plan_destroy(plan))
-    assert len(results[0]) == len(results[1])
-    for a, b in zip(results[0], results[1]):
-        assert np.array_equal(a, b)                        # same partial sums, same fold: the reductions agree to the bit too
+    assert len(results[0]) == len(results[1]) == len(results[2])
+    for a, b, c in zip(results[0], results[1], results[2]):
+        assert np.array_equal(a, b) and np.array_equal(a, c)    # same partial sums, same fold: the reductions agree to the bit too
 
 
 def stack_rows(parts):

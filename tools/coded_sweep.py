@@ -19,8 +19,8 @@ x, y = DA(n, np.float64), DA(n, np.float64)
 check(lib.liship_poisson3d_csr(N, N, N, 0, n, 0, dptr.ptr, didx.ptr, dval.ptr, None))
 check(lib.liship_set_all_f64(n, 1.0, x.ptr, None))
 bytes_alg = 12 * nnz + 20 * n + 4
-for geom in (1, 4):
-    for extra in (0, 0x100, 0x020001, 0x040001, 0x100001, 0x400001, 0x800001):                         # 0x100: ablation without the x gather (wrong results, timing only)
+for geom in (1,):
+    for extra in (0, 0x100, 0x020001, 0x030001, 0x040001, 0x080001, 0x100001, 0x400001, 0):                         # 0x100: ablation without the x gather (wrong results, timing only)
         variant = (geom << 4)
         lib.liship_spmv_csr_set_variant(variant)
         plan = C.c_void_p()

@@ -20,6 +20,7 @@ ap.add_argument("dir"); ap.add_argument("kernel"); ap.add_argument("out")
 ap.add_argument("--n", type=int, default=512 ** 3)
 ap.add_argument("--nnz", type=int, default=7 * 512 ** 3 - 6 * 512 * 512)
 ap.add_argument("--coded", type=int, default=1)
+ap.add_argument("--patterns", type=int, default=0, help="row patterns: 8 B per non-zero + 3 B per row of matrix streams")
 ap.add_argument("--command", default="python bench.py --steps 20 --warmup 3 --preroll 100 --no-cpu-baseline")
 a = ap.parse_args()
 
@@ -50,6 +51,8 @@ if g("TCC_EA0_WRREQ_sum") is not None:
     wr = 64 * w64 + 32 * (g("TCC_EA0_WRREQ_sum") - w64)
 n, nnz = a.n, a.nnz
 stream_rd = (9 if a.coded else 12) * nnz + 4 * (n + 1)           # value + code/index + ptr, each read once
+if a.patterns:
+    stream_rd = 8 * nnz + 3 * n                                   # value + one pattern byte and a 2 B start per row
 out = {
     "source": f"rocprofv3 --kernel-trace --pmc <group> -- {a.command} (separate passes per counter group, tools/prof.sh), summarised by tools/traffic_json.py",
     "kernel": a.kernel, "launches": launches, "avg_kernel_ns": avg_ns,
@@ -62,7 +65,7 @@ out = {
     "dram_read_bytes_32B_granular": 32 * g("TCC_EA0_RDREQ_DRAM_32B_sum") if g("TCC_EA0_RDREQ_DRAM_32B_sum") is not None else None,
     "dram_write_bytes_32B_granular": 32 * g("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum") if g("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum") is not None else None,
     "algorithmic_bytes_per_launch": 12 * nnz + 20 * n + 4,
-    "stored_bytes_per_launch": (9 if a.coded else 12) * nnz + 20 * n + 4,
+    "stored_bytes_per_launch": (8 * nnz + 19 * n + 4) if a.patterns else ((9 if a.coded else 12) * nnz + 20 * n + 4),
     "stream_read_bytes_per_launch": stream_rd,
 }
 if rd is not None:
@@ -77,7 +80,7 @@ if rd is not None:
         out["note"] = ("exact bytes at the L2 <-> fabric boundary (requests counted by size; 2 x FETCH_SIZE agrees within 0.3 %). "
                        "They include re-reads of x that the Infinity Cache serves, which is how the rate at this boundary can pass the "
                        "8 TB/s of HBM itself: the HBM bytes lie between the compulsory stored bytes and min(fabric bytes, 8 TB/s x kernel "
-                       "time) = hbm_bytes_bounds.  value / code / ptr streams are read once (nt loads): everything else on the read side "
+                       "time) = hbm_bytes_bounds.  the matrix streams (values, codes or row patterns, row starts) are read once (nt loads): everything else on the read side "
                        "is x, fetched x_refetch_factor times across the fabric (the 8 XCD L2s each fetch their own copy of a line: the "
                        "+-n neighbours of a row block run on other XCDs, the +-mn ones 128 blocks later on the same one).")
 json.dump(out, open(a.out, "w"), indent=1)

@@ -310,14 +310,14 @@ def main():
 def spmv_stored_bytes(n, nnz, coded, patterns):
     """bytes one product is asked to stream: values + column information + row starts + y + the compulsory x"""
     if patterns:
-        return 8 * nnz + (1 + 2 + 8 + 8) * n + 4           # one pattern byte and a 2 B block-relative start per row
+        return 8 * nnz + (1 + 8 + 8) * n + 4               # one pattern byte per row (row starts: a scan of the pattern lengths)
     return (9 if coded else 12) * nnz + 20 * n + 4
 
 
 def krylov_bytes(key, iters, n, nnz, coded, patterns=0):
     """Bytes per iteration and per GPU: (what the passes of the fused device loops are asked to stream, what the
     reference's unfused operator sequence moves by SURVEY 8d's count).  n / nnz are the local rows / non-zeros.
-    Product: S = (9 coded | 12) B per non-zero + 20 B per row (ptr, y, compulsory x), or 8 B per non-zero + 19 B per row with row
+    Product: S = (9 coded | 12) B per non-zero + 20 B per row (ptr, y, compulsory x), or 8 B per non-zero + 17 B per row with row
     patterns; contract B = 12 nnz + 20 n.
     Vector passes: every array a pass reads or writes counts 8 B per row once."""
     S = spmv_stored_bytes(n, nnz, coded, patterns) - 4

@@ -727,9 +727,9 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
 // A structured-grid matrix repeats not only its offsets but whole ROWS of them: every interior row of the 7-point stencil is
 // the same sequence of 7 offsets, the boundary rows are 26 more sequences.  When the rows of a coded matrix follow at most 255
 // such patterns (liship_csr_plan_encode_row_patterns) the plan keeps ONE byte per ROW -- the pattern, which gives the row's
-// length and its offsets from a small table in LDS -- and a 2 B start of the row relative to its row block, instead of one byte
-// per non-zero and a 4 B row pointer: the 7-point stencil streams 75 B per row (56 values, 1 pattern, 2 start, 8 y, 8 x)
-// instead of 83.  Same rows, same terms, same order as the two kernels above: bit-identical.
+// length and its offsets from a small table in LDS -- instead of one byte per non-zero and a 4 B row pointer; the rows' starts
+// are the running sum of the pattern lengths within the row block (a 2 B start per row is kept for blocks of more than BLOCK
+// rows): the 7-point stencil streams 73 B per row (56 values, 1 pattern, 8 y, 8 x) instead of 83.  Same rows, same terms, same order as the two kernels above: bit-identical.
 constexpr int PAT_TABLE = 1024 + 256 + 2;           // ints of LDS for the table: npat + 1 prefix entries, then the offsets
 template <int BLOCK, int WORK, int U, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
@@ -752,7 +752,7 @@ void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict_
 
     const int lb = blockIdx.x;
     Blk B = load_blk(blk, bfirst + lb);
-    const int kplan = B.k0;                         // the row starts are relative to the PLAN's block, whatever this launch clips
+    const int kplan = B.k0, rplan0 = B.r0, rplan1 = B.r1;   // the PLAN's block, whatever this launch clips
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
@@ -769,7 +769,13 @@ void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict_
     for (int i = threadIdx.x; i < tablen; i += BLOCK) ptabL[i] = ptab[i];
     const int rmine = B.r0 + (int)threadIdx.x;
     int p_first = 0, s_first = 0;
-    if (rmine < B.r1) { p_first = rowpat[rmine]; s_first = kplan + rowrel[rmine]; }
+    // Row starts without reading them: when the plan's block has at most BLOCK rows, lane t takes the pattern of the block's t-th
+    // row, and the rows' starts are the running sum of the pattern lengths (wavefront scan + the wavefront totals through
+    // LDS).  Larger blocks (very short rows) and launches clipped at the front read the 2 B starts.
+    const bool scan = (rplan1 - rplan0) <= BLOCK && B.r0 == rplan0;      // (a launch clipped at its front reads the starts too)
+    __shared__ int wtot[BLOCK / WAVE];
+    if (scan) { if (rplan0 + (int)threadIdx.x < rplan1) p_first = rowpat[rplan0 + (int)threadIdx.x]; }
+    else if (rmine < B.r1) { p_first = rowpat[rmine]; s_first = kplan + rowrel[rmine]; }
     {
         const int wbase = (int)threadIdx.x & ~(WAVE - 1), lane = (int)threadIdx.x & (WAVE - 1);
         for (int p0 = wbase; p0 < np; p0 += BLOCK) {
@@ -780,6 +786,18 @@ void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict_
         }
     }
     __syncthreads();
+    if (scan) {                                       // uniform
+        const int lane = (int)threadIdx.x & (WAVE - 1), w = (int)threadIdx.x / WAVE;
+        const int mylen = (rplan0 + (int)threadIdx.x < rplan1) ? ptabL[p_first + 1] - ptabL[p_first] : 0;
+        int incl = mylen;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) { const int v = __shfl_up(incl, o, WAVE); if (lane >= o) incl += v; }
+        if (lane == WAVE - 1) wtot[w] = incl;
+        __syncthreads();
+        int base = kplan;
+        for (int q = 0; q < w; q++) base += wtot[q];
+        s_first = base + incl - mylen;
+    }
 
     for (int r = rmine; r < B.r1; r += BLOCK) {
         int pat = p_first, s = s_first;
@@ -787,7 +805,11 @@ void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict_
         const int ps = ptabL[pat], len = ptabL[pat + 1] - ps;
         const int *po = ptabL + npat1 + ps;
         const int off = s - ka;
-        const double wr = dots.fetch(r);
+        // <w,y> with w = x (CG's <p,Ap>, BiCGSTAB's <t,s>): w[r] is the x the row gathers for its diagonal entry anyway -- one
+        // vector-memory instruction less per row; a row without a diagonal entry loads it after all
+        const bool w_is_x = DOT >= 1 && wdot == x;
+        double wr = w_is_x ? 0.0 : dots.fetch(r);
+        bool have_w = !w_is_x;
         double acc = acc0;
         for (int j0 = 0; j0 < len; j0 += U) {
             int cc[U]; double vv[U], xx[U];
@@ -803,8 +825,10 @@ void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict_
             for (int u = 0; u < U; u++) {
                 const double t = vv[u] * xx[u];
                 acc += (j0 + u < len) ? t : -0.0;           // -0.0 terms leave any sum bit-unchanged
+                if (DOT >= 1 && w_is_x && cc[u] == r) { wr = xx[u]; have_w = true; }
             }
         }
+        if (DOT >= 1 && !have_w) wr = wdot[r];
         store_stream(y + r, acc);
         dots.add_loaded(wr, acc);
     }

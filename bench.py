@@ -205,10 +205,12 @@ def main():
     coded = int(dll.lis_amd_matrix_index_codes(A))
     dll.lis_amd_matrix_row_patterns.argtypes = [capi.PM]
     patterns = int(dll.lis_amd_matrix_row_patterns(A))     # > 0: one byte per ROW (pattern) + a 2 B row start instead of 1 B per non-zero + 4 B
+    dll.lis_amd_matrix_pattern_records.argtypes = [capi.PM]
+    records = int(dll.lis_amd_matrix_pattern_records(A))   # 1: patterns of <= 7 offsets kept as 32 B records (gathers ahead of the value slice)
     moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
-                "kernel": "spmv_csr_pattern_kernel" if patterns else "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel", "kernel_ms": round(kernel_ms, 4),
+                "kernel": "spmv_csr_pattern7_kernel" if patterns and records else "spmv_csr_pattern_kernel" if patterns else "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel", "kernel_ms": round(kernel_ms, 4),
                 "alg_bytes_per_launch": alg_bytes, "per_gpu": True,
                 "index_codes": coded, "row_patterns": patterns, "stored_bytes_per_launch": moved,
                 "frac_of_stored_bytes": round(moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}

@@ -53,6 +53,9 @@ LIS_INT lis_amd_matrix_index_codes(LIS_MATRIX A);
 /* number of row patterns when the HBM copy of A keeps ONE byte per row (liship.h "row patterns": the rows of a coded matrix
  * follow <= 255 offset sequences), 0 otherwise; uploads A if needed */
 LIS_INT lis_amd_matrix_row_patterns(LIS_MATRIX A);
+/* 1 when those patterns are also kept as 32 B records (1..7 offsets each: the 7-point stencil) and the products use the
+ * kernel that issues its x gathers ahead of the value slice, 0 otherwise; uploads A if needed */
+LIS_INT lis_amd_matrix_pattern_records(LIS_MATRIX A);
 /* total length of the per-row-block lists of distinct columns when the HBM copy of A carries block-local columns (liship.h:
  * long rows that share their columns), 0 when it does not; uploads A if needed */
 LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A);

@@ -77,9 +77,12 @@ int  liship_csr_plan_coded(liship_csr_plan_t plan);
  * when the rows of a coded matrix follow at most 255 distinct (length, offset sequence) patterns -- a 7-point stencil has 27 --
  * the plan keeps ONE byte per row (its pattern) and a 2 B row start relative to the row block instead of one byte per
  * non-zero and the 4 B row pointer: 75 instead of 83 B per stencil row.  Same terms in the same order: bit-identical.
- * liship_csr_plan_row_patterns: number of patterns, 0 if none.  liship_spmv_csr_set_row_patterns(0): A/B switch. */
+ * liship_csr_plan_row_patterns: number of patterns, 0 if none.  liship_spmv_csr_set_row_patterns(0): A/B switch.
+ * When every pattern has 1..7 offsets (and there are at most 64, n < 2^29) the plan also keeps them as 32 B records and the
+ * products run through the kernel that issues its x gathers ahead of the value slice: liship_csr_plan_pattern_records = 1. */
 int  liship_csr_plan_encode_row_patterns(liship_csr_plan_t plan, const int *ptr, void *stream);
 int  liship_csr_plan_row_patterns(liship_csr_plan_t plan);
+int  liship_csr_plan_pattern_records(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_row_patterns(int on);
 int  liship_spmv_csr_set_index_codes(int on);
 /* Block-local columns (setup-time, optional, never an error when the matrix does not qualify): for matrices with long rows

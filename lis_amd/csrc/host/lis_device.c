@@ -466,6 +466,11 @@ LIS_INT lis_amd_matrix_row_patterns(LIS_MATRIX A)
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	return MDEV(A)->plan ? liship_csr_plan_row_patterns(MDEV(A)->plan) : 0;
 }
+LIS_INT lis_amd_matrix_pattern_records(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return MDEV(A)->plan ? liship_csr_plan_pattern_records(MDEV(A)->plan) : 0;
+}
 LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;

@@ -25,6 +25,7 @@
 //     stage (continued pass by pass by the lane that owns them, still in order).
 // No __shfl tree is used for the row sums on purpose: a tree changes the association order and would
 // break bit parity with the reference; the reductions that ARE trees live in vector_ops.hip.
+#include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
 #include "common.hpp"
@@ -55,6 +56,7 @@ constexpr int SLACK = 128;       // extra items a block may take to start on an 
 //   bits4-7 geometry id and bit24 "no row alignment": read at plan creation
 //   bit8  ablation: skip the x gather  (WRONG results, timing only)
 //   bit10 register staging instead of LDS-DMA   bits11-12 gather unroll U: 0 auto, 1: 4, 2: 7, 3: 8
+//   bit13 (0x2000) row patterns through the general kernel (table in LDS) even when the plan has 32 B records
 int g_variant = 0;
 int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps every product on the 4 B indices
 int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
@@ -835,6 +837,173 @@ void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict_
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
+// inclusive sum over the 64 lanes by data-parallel primitives: 4 shifts inside the rows of 16, then lane 15 of each row into
+// the next row, then lane 31 into the upper half -- 6 adds, no LDS traffic.  All lanes must be active.
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// The same for matrices whose patterns have at most 7 offsets and no empty row (the 7-point stencil): a pattern is then ONE 32 B
+// record -- the 7 column offsets in bytes (the tail repeats the last one) and the length -- and nothing of the row phase depends
+// on LDS contents: a lane knows its columns from (row, pattern) alone and issues its x gathers BEFORE the value slice has
+// landed.  With the codes the columns came out of the streamed slice and the gathers could only start behind it.
+// The vector-memory counter counts IN ORDER: a wait for any load younger than the slice is a wait for the whole slice.  Hence
+// the order here: the pattern bytes are loaded first (older than the slice: the wait for them leaves the slice in flight), the
+// records come by SCALAR loads (their own counter; one load per distinct pattern in the wavefront, nearly always one), then the
+// gathers leave, and the one barrier that ends the scan of the row lengths is the first wait behind the slice.
+// The row phase is instruction-bound once everything overlaps (ablations in profiles/r02_csr_kernel_experiments.txt: with every
+// load hitting a cache and no value stream it alone takes 0.70 ms at 512^3), so it is kept short: 32-bit byte offsets on a
+// scalar base (one add per gather), unpredicated gathers, a 6-instruction scan of the lengths, and a wavefront whose rows all
+// have 7 entries adds its products without selects.  Same terms, same order: bit-identical to every other CSR kernel.
+// (Persistent workgroups that prefetch the next block's extents and pattern bytes were tried on top of this and were 10-30 %
+// slower at every grid size -- DESIGN.md 5.)
+constexpr int PAT7_MAX = 64;       // patterns the plan accepts for this kernel (more: the general pattern kernel)
+template <int BLOCK, int WORK, int DOT = 0>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_pattern7_kernel(const int *__restrict__ ptr, const double *__restrict__ val,
+                              const unsigned char *__restrict__ rowpat, const unsigned short *__restrict__ rowrel,
+                              const v4i32 *__restrict__ ptab8,
+                              const double *__restrict__ x, double *__restrict__ y, const v2i32 *__restrict__ blk,
+                              int bfirst, int nb, Rows RW, int nnz_total,
+                              const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                              const double *__restrict__ guard = nullptr, int pstride = 0)
+{
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    const int row_begin = RW.rb, row_end = RW.re;
+    const double acc0 = RW.acc0;
+    __shared__ double dot_scratch[BLOCK / WAVE];
+    __shared__ int wtot[BLOCK / WAVE];
+    constexpr int CAP = WORK + SLACK + 2;
+    __shared__ __attribute__((aligned(16))) double valL[(GUARD + CAP + 8 + 16) + 2 * WAVE];
+    RowDots<DOT> dots{wdot, 0.0, 0.0};
+    const int tid = (int)threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const bool w_is_x = DOT >= 1 && wdot == x;
+
+    const int lb = blockIdx.x;
+    Blk B = load_blk(blk, bfirst + lb);
+    const int kplan = B.k0, rplan0 = B.r0, rplan1 = B.r1;   // the PLAN's block, whatever this launch clips
+    if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
+        publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+        return;
+    }
+    const bool scan = (rplan1 - rplan0) <= BLOCK && B.r0 == rplan0;      // row starts = running sum of the lengths (see the kernel above)
+    const int rmine = B.r0 + tid;
+    const bool mine = rmine < B.r1;
+    // 1. the pattern bytes (and, for a front-clipped block or one of more than BLOCK rows, the stored row starts): the oldest
+    //    loads, unconditional (clamped index) so that no select or branch needs their value before the records do
+    const int prow = scan ? rplan0 + tid : rmine;
+    const bool planrow = scan ? prow < rplan1 : mine;
+    // (issued by hand: the compiler would wait for this byte with vmcnt(0), i.e. for the whole slice issued behind it; the
+    //  counter retires in order, so "at most NIT younger operations outstanding" is all the byte needs -- step 3)
+    int pat;
+    asm volatile("global_load_ubyte %0, %1, off" : "=v"(pat) : "v"(rowpat + min(prow, (scan ? rplan1 : B.r1) - 1)) : "memory");
+    int s_first = scan ? 0 : kplan + (int)rowrel[min(rmine, B.r1 - 1)];
+    // 2. the value slice, by a FIXED number of LDS-DMA instructions (the compiler can then wait for the pattern bytes with the
+    //    slice still in flight): rows of 1..7 entries put at most 7/8 of a block's WORK + SLACK + 8 items into values; lanes
+    //    past the slice re-read its last piece into stage slots nobody reads.  Only the matrix's very last value needs care:
+    //    the 16 B piece that holds it would end past the array.
+    const int ka = B.k0 & ~1;                       // 16 B aligned start of the value slice
+    const int cnt = B.k1 - ka;
+    const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
+    const int tailv = (ka + 2 * np > nnz_total) ? 1 : 0;
+    constexpr int MAXNNZ = (WORK + SLACK + 8) * 7 / 8 + 2, NIT = ((MAXNNZ + 1) / 2 + BLOCK - 1) / BLOCK;
+    {
+        static_assert(2 * NIT * BLOCK <= (GUARD + CAP + 8 + 16) + 2 * WAVE, "value stage too small");
+        const int npd = np - tailv, wbase = tid & ~(WAVE - 1);
+        const v2f64 *src = reinterpret_cast<const v2f64 *>(npd > 0 ? val + ka : val);
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int p0 = wbase + it * BLOCK;
+            const int p = max(min(p0 + lane, npd - 1), 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + p),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+        }
+    }
+    // 3. the records: one pair of scalar loads per distinct pattern among the wavefront's lanes
+    int o[7] = {0, 0, 0, 0, 0, 0, 0}, len = 0;
+    {
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pat) : "n"(NIT) : "memory");       // the pattern byte is in; the slice stays in flight
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(planrow);
+        while (todo != 0) {                                               // uniform
+            int pw = __builtin_amdgcn_readlane(pat, (int)__builtin_ctzll(todo));
+            asm volatile("" : "+s"(pw));                                  // (opaque: keeps the record address scalar)
+            v4i32 a = ptab8[2 * pw], b = ptab8[2 * pw + 1];               // uniform address: scalar loads
+            asm volatile("" : "+s"(a.x), "+s"(a.y), "+s"(a.z), "+s"(a.w), "+s"(b.x), "+s"(b.y), "+s"(b.z), "+s"(b.w));       // (and stay so)
+            const bool hit = planrow && pat == pw;
+            if (hit) { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; len = b.w; }
+            todo &= ~__builtin_amdgcn_ballot_w64(hit);
+        }
+    }
+    // 4. the gathers: behind nothing but the record
+    double xx[7], wr = 0.0;
+    const unsigned rb8 = (unsigned)rmine * 8u;            // byte offsets in 32 bits (the plan checks n < 2^29): scalar base + one add per gather
+    if (mine) {
+        if (DOT >= 1 && !w_is_x) wr = wdot[rmine];
+#pragma unroll
+        for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)o[u]));
+    }
+    double tail_value = 0.0;
+    if (tailv && tid == 0) tail_value = val[B.k1 - 1];
+    if (scan) {                                       // uniform
+        const int incl = wave_inclusive_scan(len);
+        if (lane == WAVE - 1) wtot[wv] = incl;
+        __syncthreads();                              // the wavefront totals, the value slice, the gathers
+        int base = kplan;
+#pragma unroll
+        for (int q = 0; q < BLOCK / WAVE - 1; q++) base += q < wv ? wtot[q] : 0;
+        s_first = base + incl - len;
+    } else __syncthreads();
+    if (tailv) {                                      // uniform; behind the slice (whose clamped lanes land on this slot too)
+        if (tid == 0) valL[cnt - 1] = tail_value;
+        __syncthreads();
+    }
+    const bool full = __builtin_amdgcn_ballot_w64(mine && len != 7) == 0;       // wavefront-uniform: no row here is shorter than 7
+    if (mine) {
+        const double *vp = valL + (s_first - ka);
+        double acc = acc0;
+        if (full) {
+#pragma unroll
+            for (int u = 0; u < 7; u++) acc += vp[u] * xx[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const double t = vp[min(u, len - 1)] * xx[u];
+                acc += (u < len) ? t : -0.0;            // -0.0 terms leave any sum bit-unchanged
+            }
+        }
+        if (DOT >= 1 && w_is_x) {                     // w is x: the diagonal's gather has it (else the load below)
+            bool have_w = false;
+#pragma unroll
+            for (int u = 0; u < 7; u++) if (u < len && o[u] == 0) { wr = xx[u]; have_w = true; }
+            if (!have_w) wr = wdot[rmine];
+        }
+        store_stream(reinterpret_cast<double *>(reinterpret_cast<char *>(y) + rb8), acc);
+        dots.add_loaded(wr, acc);
+    }
+    for (int r = rmine + BLOCK; r < B.r1; r += BLOCK) {        // blocks of more than BLOCK rows (very short rows): the later rows
+        const int pt = rowpat[r], s = kplan + rowrel[r];
+        const v4i32 a = ptab8[2 * pt], b = ptab8[2 * pt + 1];
+        const int oo[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z}, ln = b.w, off = s - ka;
+        const double wvl = dots.fetch(r);
+        double xv[7], acc = acc0;
+#pragma unroll
+        for (int u = 0; u < 7; u++) xv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned)r * 8u + (unsigned)oo[u]));
+#pragma unroll
+        for (int u = 0; u < 7; u++) { const double t = valL[off + min(u, ln - 1)] * xv[u]; acc += (u < ln) ? t : -0.0; }
+        store_stream(y + r, acc);
+        dots.add_loaded(wvl, acc);
+    }
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+}
+
 // plan time: one 64-bit hash per row over (length, code sequence); the distinct ones in an open-addressing table together with the
 // smallest row that has them; gives up beyond 255
 constexpr int PAT_SLOTS = 1024, PAT_MAXLEN = 64;
@@ -962,6 +1131,7 @@ struct liship_csr_plan_s {
     unsigned short *rowrel; // device, 2 B per row: its first non-zero relative to its row block
     int *ptab;           // device: npat + 1 prefix entries, then the offsets of all patterns
     int ptab_len, npat;
+    v4i32 *ptab8;        // device: when no pattern has more than 7 offsets, one 32 B record per pattern (7 offsets, length); else NULL
 };
 
 extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
@@ -1028,7 +1198,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -1045,6 +1215,7 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->rowpat) (void)hipFree(p->rowpat);
     if (p->rowrel) (void)hipFree(p->rowrel);
     if (p->ptab) (void)hipFree(p->ptab);
+    if (p->ptab8) (void)hipFree(p->ptab8);
     if (p->lcol) (void)hipFree(p->lcol);
     if (p->dcol) (void)hipFree(p->dcol);
     if (p->doff) (void)hipFree(p->doff);
@@ -1187,6 +1358,22 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
         PT(hipMalloc(&p->rowpat, (size_t)p->n + 64));
         PT(hipMalloc(&p->rowrel, sizeof(unsigned short) * ((size_t)p->n + 64)));
         PT(hipMemcpyAsync(p->ptab, tab, sizeof(int) * (size_t)(npat + 1 + total), hipMemcpyHostToDevice, st));
+        int maxlen = 0;
+        for (int i = 0; i < npat; i++) if (plen[i] > maxlen) maxlen = plen[i];
+        int minlen = 1 << 30;
+        for (int i = 0; i < npat; i++) if (plen[i] < minlen) minlen = plen[i];
+        int maxoff = 0;                             // the kernel addresses x by 32-bit byte offsets: row + offset < 2^29
+        for (int t = 0; t < total; t++) if (tab[npat + 1 + t] > maxoff) maxoff = tab[npat + 1 + t];
+        if (maxlen <= 7 && minlen >= 1 && npat <= PAT7_MAX && (long long)p->n + maxoff < (1ll << 29)) {
+            // one 32 B record per pattern: the 7 column offsets IN BYTES (the tail repeats the last: always a column of the row), the length
+            int rec[PAT7_MAX * 8];
+            for (int i = 0; i < npat; i++) {
+                for (int j = 0; j < 7; j++) rec[8 * i + j] = 8 * tab[npat + 1 + tab[i] + (j < plen[i] ? j : plen[i] - 1)];
+                rec[8 * i + 7] = plen[i];
+            }
+            PT(hipMalloc(&p->ptab8, sizeof(int) * 8 * (size_t)npat));
+            PT(hipMemcpyAsync(p->ptab8, rec, sizeof(int) * 8 * (size_t)npat, hipMemcpyHostToDevice, st));
+        }
         if (rc == 0) {
             csr_encode_patterns<<<p->nblocks, 256, 0, st>>>(p->blk, ptr, p->codes, npat, d_hash, d_len, d_pc, p->rowpat, p->rowrel, d_bad);
             PT(hipGetLastError());
@@ -1201,7 +1388,8 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
         if (p->ptab) (void)hipFree(p->ptab);
         if (p->rowpat) (void)hipFree(p->rowpat);
         if (p->rowrel) (void)hipFree(p->rowrel);
-        p->ptab = nullptr; p->rowpat = nullptr; p->rowrel = nullptr;
+        if (p->ptab8) (void)hipFree(p->ptab8);
+        p->ptab = nullptr; p->rowpat = nullptr; p->rowrel = nullptr; p->ptab8 = nullptr;
         return rc;
     }
     p->npat = npat; p->ptab_len = npat + 1 + total;
@@ -1209,6 +1397,8 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
 }
 // number of row patterns when the plan keeps one byte per row, 0 otherwise
 extern "C" int liship_csr_plan_row_patterns(liship_csr_plan_t p) { return (p && p->rowpat) ? p->npat : 0; }
+// 1 when every pattern has 1..7 offsets and the plan also keeps them as 32 B records (spmv_csr_pattern7_kernel), else 0
+extern "C" int liship_csr_plan_pattern_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8) ? 1 : 0; }
 extern "C" int liship_spmv_csr_set_row_patterns(int on) { g_row_patterns = on ? 1 : 0; return 0; }
 
 // Block-local columns for the products kernel (see spmv_csr_local_kernel): setup-time, optional, never an error when the
@@ -1289,6 +1479,7 @@ struct LaunchArgs {
     const unsigned char *rowpat = nullptr;  // row patterns (pattern per row, relative row starts, table), when the plan has them
     const unsigned short *rowrel = nullptr;
     const int *ptab = nullptr; int ptab_len = 0, npat1 = 0;
+    const v4i32 *ptab8 = nullptr;
 };
 
 
@@ -1351,7 +1542,13 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
-    if (a.rowpat && g_variant == 0) {                // one byte per ROW (the plan found <= 255 row patterns)
+    if (a.rowpat && a.ptab8 && g_variant == 0) {      // patterns of at most 7 offsets: gathers ahead of the slice
+        constexpr Geometry g = kGeom[G];
+        spmv_csr_pattern7_kernel<g.block, g.work, 0><<<a.nb, g.block, 0, a.st>>>(
+            a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
+        return;
+    }
+    if (a.rowpat && (g_variant & ~0x2000) == 0) {    // one byte per ROW (the plan found <= 255 row patterns); 0x2000: experiment, table in LDS even for short patterns
         constexpr Geometry g = kGeom[G];
 #define GOP(UU) spmv_csr_pattern_kernel<g.block, g.work, UU, 0><<<a.nb, g.block, 0, a.st>>>( \
             a.ptr, a.idx, a.val, a.rowpat, a.rowrel, a.ptab, a.ptab_len, a.npat1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz)
@@ -1379,6 +1576,12 @@ template <int G, int DOT>
 void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
+    if (a.rowpat && a.ptab8 && !(g_variant & 0x2000)) {
+        spmv_csr_pattern7_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
+            a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz,
+            w, partial, liship_internal_guard(), pstride);
+        return;
+    }
     if (a.rowpat) {
 #define GOP(UU) spmv_csr_pattern_kernel<g.block, g.work, UU, DOT><<<a.nb, g.block, 0, a.st>>>( \
             a.ptr, a.idx, a.val, a.rowpat, a.rowrel, a.ptab, a.ptab_len, a.npat1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, \
@@ -1440,7 +1643,7 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
                                    const double *val, const double *x, double *y, void *stream)
 {
     if (!p) return LISHIP_ERR_ARG;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8};
     return launch_csr(p, a);
 }
 
@@ -1454,9 +1657,9 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
 {
     if (!p || !w || !result || !work) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
-    if (g_variant != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    if ((g_variant & ~0x2000) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);
@@ -1482,7 +1685,7 @@ extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int 
     const int bfirst = lo;
     lo = bfirst; hi = p->nblocks;                // first b with br[b].row >= row_end
     while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8};
     return launch_csr(p, a);
 }
 
@@ -1497,7 +1700,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
 {
     if (!p || !w || !work || !slots_used || row_begin < 0 || row_end > p->n || slot_base < 0) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
-    if (g_variant != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    if ((g_variant & ~0x2000) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     *slots_used = 0;
     if (row_begin >= row_end || p->nblocks == 0) return 0;
     const v2i32 *br = p->blk_host;
@@ -1510,7 +1713,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if (nb <= 0) return 0;
     if ((size_t)slot_base + (size_t)nb > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work) + slot_base;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8};
     const int ps = (int)slots;
     if (p->products && p->geom == LOCAL_GEOM) {
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial, ps);

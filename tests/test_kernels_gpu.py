@@ -202,10 +202,30 @@ def cyclic_diagonals(n, count, seed):
 
 # row patterns the plan must find on top of the codes: 3 for the 1-D stencil (first row, interior, last row), 27 for the 3-D one
 ROW_PATTERNS = {"p1d_10000": 3, "p3d_20x17x13": 27, "p3d_64_sorted": 27, "p3d_40_sorted": 27, "p3d_odd_33x7x5": 27, "diagonals_255": 255,
-                "diagonals_300": 0, "rand_5000": 0, "wide_77": 0}        # diagonals_255: 254 two-entry rows + the rows whose second entry falls outside
+                "diagonals_300": 0, "rand_5000": 0, "wide_77": 0,        # diagonals_255: 254 two-entry rows + the rows whose second entry falls outside
+                "p1d_9999": 3, "p3d_holes": 27}            # p3d_holes: the empty row is one more pattern, a corner row that lost its entries one fewer
+# ... and whether it also keeps them as 32 B records (1..7 offsets per pattern, at most 64 patterns: spmv_csr_pattern7_kernel)
+PATTERN_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
+                   "diagonals_255": 0, "p3d_holes": 0, "band_9_unsorted": 0, "rand_5000": 0}
+
+
+def poisson3d_with_empty_rows(nx, ny, nz, every):
+    """the 3-D stencil with every `every`-th row emptied: one more pattern (length 0), which the 32 B records do not take"""
+    ptr, idx, val = orc.poisson3d(nx, ny, nz)
+    n = len(ptr) - 1
+    keep = np.ones(len(idx), bool)
+    for r in range(0, n, every):
+        keep[ptr[r]:ptr[r + 1]] = False
+    cnt = np.diff(ptr)
+    cnt[::every] = 0
+    return np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), idx[keep], val[keep]
+
+
 CODED_CASES = {
     "p1d_10000": (lambda: orc.poisson1d(10000), 3),
+    "p1d_9999": (lambda: orc.poisson1d(9999), 3),                                           # odd number of values: the last one has no 16 B piece
     "p3d_20x17x13": (lambda: orc.poisson3d(20, 17, 13), 7),
+    "p3d_holes": (lambda: poisson3d_with_empty_rows(24, 20, 16, 37), 7),
     "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
     "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
     "p3d_40_sorted": (lambda: orc.poisson3d(40, 40, 40, sort_cols=True), 7),                # several row blocks
@@ -247,10 +267,13 @@ def test_spmv_csr_index_codes(lib, name):
     assert npat == 0 or coded > 0
     if name in ROW_PATTERNS:
         assert npat == ROW_PATTERNS[name], npat
+    if name in PATTERN_RECORDS:
+        assert lib.liship_csr_plan_pattern_records(plan) == PATTERN_RECORDS[name]
     results = {}
-    for on in (2, 1, 0):                       # 2: one byte per row (patterns), 1: one byte per non-zero (codes), 0: 4 B indices
-        lib.liship_spmv_csr_set_index_codes(1 if on else 0)
-        lib.liship_spmv_csr_set_row_patterns(1 if on == 2 else 0)
+    for on in (3, 2, 1, 0):                    # 2: one byte per row (patterns; 3: through the general pattern kernel even when the plan
+        lib.liship_spmv_csr_set_index_codes(1 if on else 0)         # has 32 B records), 1: one byte per non-zero (codes), 0: 4 B indices
+        lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)
+        lib.liship_spmv_csr_set_variant(0x2000 if on == 3 else 0)
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
         assert np.array_equal(dy.to_host(), yref), on
@@ -262,6 +285,13 @@ def test_spmv_csr_index_codes(lib, name):
             if rc == 0:
                 assert np.array_equal(dy.to_host(), yref), (on, sq)
                 out.append(res.to_host()[:1 + sq].copy())
+        if ncols == n:                          # (x, A x): the kernels take x_r from the diagonal's gather when the row has one
+            res = DA.from_host(np.full(2, np.nan), np.float64)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            rc = lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dx.ptr, 1, res.ptr, work.ptr, None)
+            if rc == 0:
+                assert np.array_equal(dy.to_host(), yref), on
+                out.append(res.to_host().copy())
         lo, hi = n // 5, n - n // 7
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         for a, b in ((lo, hi), (0, lo), (hi, n)):
@@ -283,10 +313,11 @@ def test_spmv_csr_index_codes(lib, name):
         results[on] = out
     lib.liship_spmv_csr_set_index_codes(1)
     lib.liship_spmv_csr_set_row_patterns(1)
+    lib.liship_spmv_csr_set_variant(0)
     check(lib.liship_csr_plan_destroy(plan))
-    assert len(results[0]) == len(results[1]) == len(results[2])
-    for a, b, c in zip(results[0], results[1], results[2]):
-        assert np.array_equal(a, b) and np.array_equal(a, c)    # same partial sums, same fold: the reductions agree to the bit too
+    assert len(results[0]) == len(results[1]) == len(results[2]) == len(results[3])
+    for a, b, c, d in zip(results[0], results[1], results[2], results[3]):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)    # same partial sums, same fold: the reductions agree to the bit too
 
 
 def stack_rows(parts):

@@ -56,6 +56,12 @@ LIS_INT lis_amd_matrix_row_patterns(LIS_MATRIX A);
 /* 1 when those patterns are also kept as 32 B records (1..7 offsets each: the 7-point stencil) and the products use the
  * kernel that issues its x gathers ahead of the value slice, 0 otherwise; uploads A if needed */
 LIS_INT lis_amd_matrix_pattern_records(LIS_MATRIX A);
+/* 1 when the rows of each pattern also carry the same values (a constant-coefficient stencil) and the HBM copy keeps them in
+ * the pattern records -- the products then read ONE byte per row of matrix data, neither values nor indices (liship.h "value
+ * records"; LIS_AMD_NO_VALUE_RECORDS=1 switches them off) -- 0 otherwise; uploads A if needed.  Like every other part of the HBM
+ * copy they follow the host arrays only through lis_amd_matrix_host_modified(); the arrays of a matrix adopted with
+ * lis_amd_matrix_set_csr_device() must not be rewritten in place once a product has run. */
+LIS_INT lis_amd_matrix_value_records(LIS_MATRIX A);
 /* total length of the per-row-block lists of distinct columns when the HBM copy of A carries block-local columns (liship.h:
  * long rows that share their columns), 0 when it does not; uploads A if needed */
 LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A);

@@ -83,6 +83,15 @@ int  liship_csr_plan_coded(liship_csr_plan_t plan);
 int  liship_csr_plan_encode_row_patterns(liship_csr_plan_t plan, const int *ptr, void *stream);
 int  liship_csr_plan_row_patterns(liship_csr_plan_t plan);
 int  liship_csr_plan_pattern_records(liship_csr_plan_t plan);
+/* Value records (setup-time, optional, after liship_csr_plan_encode_row_patterns; never an error when the matrix does not
+ * qualify): when the plan has 32 B pattern records and every row of a pattern carries the same values bit for bit -- a
+ * constant-coefficient stencil -- the 7 values join the 7 offsets in the record and the products read neither the value nor
+ * the index array: one byte per row (the idea of CSR-VI, value indexing, applied to whole rows).  Same products in the same
+ * order: bit-identical.  The value array must not change afterwards (a new plan is needed if it does).
+ * liship_csr_plan_value_records: 1 if the plan has them.  liship_spmv_csr_set_row_values(0): A/B switch (stream the values). */
+int  liship_csr_plan_encode_row_values(liship_csr_plan_t plan, const int *ptr, const double *value, void *stream);
+int  liship_csr_plan_value_records(liship_csr_plan_t plan);
+int  liship_spmv_csr_set_row_values(int on);
 int  liship_spmv_csr_set_row_patterns(int on);
 int  liship_spmv_csr_set_index_codes(int on);
 /* Block-local columns (setup-time, optional, never an error when the matrix does not qualify): for matrices with long rows

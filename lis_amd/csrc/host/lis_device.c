@@ -220,7 +220,7 @@ static LIS_INT up_d(double **dst, const double *src, size_t count)
 /* rows of the local matrix that reference no ghost column, as one maximal run [b,e) */
 /* the row split of a CSR-ordered HBM matrix and, where its columns allow it, the one-byte column codes
  * (liship.h "index coding"; LIS_AMD_NO_INDEX_CODES=1 keeps the 4 B indices for A/B measurements) */
-LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex)
+LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue)
 {
 	int rc = liship_csr_plan_create(plan, n, dptr, lisg.stream);
 	if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_create(plan, n, dptr, lisg.stream);   /* the plan allocates in the kernel layer */
@@ -233,6 +233,10 @@ LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int
 		if (!rc && !lisg.no_row_patterns && liship_csr_plan_coded(*plan)) {       /* whole rows that repeat: one byte per row */
 			rc = liship_csr_plan_encode_row_patterns(*plan, dptr, lisg.stream);
 			if (rc && rc != 2) HIPCHK(rc);
+			if (!rc && !lisg.no_value_records && dvalue) {        /* ... and carry the same values: nothing left to stream */
+				rc = liship_csr_plan_encode_row_values(*plan, dptr, dvalue, lisg.stream);
+				if (rc && rc != 2) HIPCHK(rc);
+			}
 		}
 	}
 	if (!lisg.no_local_columns && !liship_csr_plan_coded(*plan)) {      /* long rows: block-local columns where they pay */
@@ -337,7 +341,7 @@ static LIS_INT upload_rows(lisd_mat *d, LIS_INT rows, LIS_INT *ptr, LIS_INT *idx
 	if (!err) { int rc = liship_stream_synchronize(lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
 	free(ptr); free(idx); free(val);
 	if (err) return err;
-	LISCHK(lisd_csr_plan(plan, rows, *dptr, *didx));
+	LISCHK(lisd_csr_plan(plan, rows, *dptr, *didx, *dval));
 	if (!from_zero) HIPCHK(liship_csr_plan_set_first_term_initialises(*plan, 1));
 	(void)d;
 	return LIS_SUCCESS;
@@ -396,12 +400,12 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 		LISCHK(up_i(&d->ptr, A->ptr, n + 1));
 		LISCHK(up_i(&d->index, A->index, (size_t)A->nnz));
 		LISCHK(up_d(&d->value, A->value, (size_t)A->nnz));
-		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index));
+		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index, d->value));
 		break;
 	case LIS_MATRIX_CSC:
 		LISCHK(upload_csc_as_csr(A, d));
 		d->type = LIS_MATRIX_CSR;
-		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index));
+		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index, d->value));
 		break;
 	case LIS_MATRIX_ELL:
 		d->maxnzr = A->maxnzr;
@@ -422,7 +426,7 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 	case LIS_MATRIX_JAD:
 		LISCHK(upload_jad_as_csr(A, d));
 		d->type = LIS_MATRIX_CSR;
-		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index));
+		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index, d->value));
 		break;
 	case LIS_MATRIX_BSR:
 		d->nr = A->nr; d->nc = A->nc; d->bnr = A->bnr; d->bnc = A->bnc;
@@ -470,6 +474,11 @@ LIS_INT lis_amd_matrix_pattern_records(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	return MDEV(A)->plan ? liship_csr_plan_pattern_records(MDEV(A)->plan) : 0;
+}
+LIS_INT lis_amd_matrix_value_records(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return MDEV(A)->plan ? liship_csr_plan_value_records(MDEV(A)->plan) : 0;
 }
 LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A)
 {
@@ -674,7 +683,7 @@ LIS_INT lis_amd_matrix_set_csr_device(LIS_INT nnz, LIS_INT np, LIS_INT *dptr, LI
 	d->type = LIS_MATRIX_CSR;
 	d->n = A->n; d->np = np; d->nnz = nnz;
 	d->ptr = dptr; d->index = dindex; d->value = dvalue;
-	LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index));
+	LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index, d->value));
 	d->inner_begin = 0; d->inner_end = A->n;
 	d->ready = 1;
 	A->nnz = nnz; A->np = np;

@@ -60,6 +60,7 @@ constexpr int SLACK = 128;       // extra items a block may take to start on an 
 int g_variant = 0;
 int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps every product on the 4 B indices
 int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
+int g_row_values = 1;            // liship_spmv_csr_set_row_values: 0 keeps streaming the values of matrices that have value records
 int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps the products kernel on the 4 B indices
 
 __device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
@@ -1004,6 +1005,107 @@ void spmv_csr_pattern7_kernel(const int *__restrict__ ptr, const double *__restr
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
+// Value records (CSR-VI in the literature: a matrix that holds few distinct values is stored by reference to them; here by whole
+// rows): when every row of a pattern also carries the same VALUES -- a constant-coefficient stencil: the 27 patterns of the 7-point
+// Laplacian are 27 (offsets, values) rows -- the plan keeps the 7 values beside the 7 offsets (96 B per pattern, checked bit for
+// bit against every row at plan time) and the product needs neither the value nor the index stream: ONE byte per row.
+// What is left per row is the pattern byte, 7 gathers of x and the store of y -- no value stage, no block geometry beyond
+// the row blocks that keep the fused dots' partial slots where the other kernels put them.  The records sit in LDS (6 KB at
+// most, loaded per workgroup while the pattern bytes are in flight); a lane reads its offsets, issues its gathers, and reads
+// the values only when it adds.  Same products (the record holds the row's values bit for bit), same order: bit-identical.
+// Measured on the way (512^3, profiles/r02_csr_kernel_experiments.txt): one block per workgroup with the record fetched by
+// scalar loads 0.89-0.93 ms, of which 0.54 ms remain when every gather hits a cache and nothing is stored -- a chain of
+// dependent round trips plus the cost of starting half a million short-lived workgroups; two blocks per workgroup 0.85 ms,
+// four the same; XCD-contiguous block orders +-1 %.  256^3 (x within the Infinity Cache): 0.078 ms.
+template <int BLOCK, int K, int DOT = 0>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_valuerec_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, int npat,
+                              const double *__restrict__ x, double *__restrict__ y, const v2i32 *__restrict__ blk,
+                              int bfirst, int nb, Rows RW,
+                              const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                              const double *__restrict__ guard = nullptr, int pstride = 0)
+{
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
+    const double acc0 = RW.acc0;
+    __shared__ double dot_scratch[BLOCK / WAVE];
+    __shared__ __attribute__((aligned(16))) v4i32 recL[6 * PAT7_MAX];     // 96 B per pattern: 7 byte offsets + length, 7 values
+    const int tid = (int)threadIdx.x;
+    for (int t = tid; t < 6 * npat; t += BLOCK) recL[t] = rec[t];
+    // a workgroup takes K consecutive row blocks at once, K rows per lane: with nothing to stream the kernel is a chain of
+    // dependent round trips (extents -> pattern byte -> x -> y) plus the cost of starting a wavefront, and rows in flight per
+    // wavefront are what hides both.  Each block keeps its own partial slot for the fused dots.
+    const int lb0 = blockIdx.x * K;
+    int r[K], r1[K], pat[K];
+#pragma unroll
+    for (int h = 0; h < K; h++) {
+        const Blk B = lb0 + h < nb ? load_blk(blk, bfirst + lb0 + h) : Blk{0, 0, 0, 0};
+        r[h] = max(B.r0, RW.rb) + tid; r1[h] = min(B.r1, RW.re);    // only the rows matter here
+    }
+#pragma unroll
+    for (int h = 0; h < K; h++) pat[h] = r[h] < r1[h] ? (int)rowpat[r[h]] : -1;
+    __syncthreads();                                                   // the records are in LDS (and the pattern bytes in)
+    RowDots<DOT> dots[K];
+    double xx[K][7], wr[K];
+    int len[K];
+#pragma unroll
+    for (int h = 0; h < K; h++) {                                      // all gathers first: 7 K per lane in flight
+        dots[h] = RowDots<DOT>{wdot, 0.0, 0.0};
+        len[h] = 0; wr[h] = 0.0;
+        if (pat[h] >= 0) {
+            const v4i32 a = recL[6 * pat[h]], b = recL[6 * pat[h] + 1];
+            const int o[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+            len[h] = b.w;
+            const unsigned rb8 = (unsigned)r[h] * 8u;   // 32-bit byte offsets on a scalar base (the plan checks n + max offset < 2^29)
+            if (DOT >= 1) wr[h] = wdot[r[h]];           // (w = x in CG: the line the diagonal's gather fetches anyway)
+#pragma unroll
+            for (int u = 0; u < 7; u++) xx[h][u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)o[u]));
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < K; h++) {                                      // then the sums, the values read from LDS only now
+        const bool full = __builtin_amdgcn_ballot_w64(pat[h] >= 0 && len[h] != 7) == 0;     // wavefront-uniform: no row here is shorter than 7
+        if (pat[h] >= 0) {
+            const v2f64 *q = reinterpret_cast<const v2f64 *>(recL + 6 * pat[h] + 2);
+            const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const double v[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
+            double acc = acc0;
+            if (full) {
+#pragma unroll
+                for (int u = 0; u < 7; u++) acc += v[u] * xx[h][u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 7; u++) { const double t = v[u] * xx[h][u]; acc += (u < len[h]) ? t : -0.0; }   // -0.0 terms leave any sum bit-unchanged
+            }
+            store_stream(reinterpret_cast<double *>(reinterpret_cast<char *>(y) + (unsigned)r[h] * 8u), acc);
+            dots[h].add_loaded(wr[h], acc);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < K; h++) {                                      // blocks of more than BLOCK rows (very short rows): the later rows
+        for (int rr = r[h] + BLOCK; rr < r1[h]; rr += BLOCK) {
+            const int pt = rowpat[rr];
+            const v4i32 a = recL[6 * pt], b = recL[6 * pt + 1];
+            const v2f64 *q = reinterpret_cast<const v2f64 *>(recL + 6 * pt + 2);
+            const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const int o[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z}, ln = b.w;
+            const double v[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
+            const double wv = dots[h].fetch(rr);
+            double xv[7], acc = acc0;
+#pragma unroll
+            for (int u = 0; u < 7; u++) xv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned)rr * 8u + (unsigned)o[u]));
+#pragma unroll
+            for (int u = 0; u < 7; u++) { const double t = v[u] * xv[u]; acc += (u < ln) ? t : -0.0; }
+            store_stream(y + rr, acc);
+            dots[h].add_loaded(wv, acc);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < K; h++) {
+        if (lb0 + h < nb) publish_dots<BLOCK, DOT>(dots[h], dot_scratch, partial, lb0 + h, pstride ? pstride : nb);
+        if (DOT != 0 && h + 1 < K) __syncthreads();
+    }
+}
+
 // plan time: one 64-bit hash per row over (length, code sequence); the distinct ones in an open-addressing table together with the
 // smallest row that has them; gives up beyond 255
 constexpr int PAT_SLOTS = 1024, PAT_MAXLEN = 64;
@@ -1107,6 +1209,27 @@ __global__ void csr_encode(int n, const int *__restrict__ ptr, const int *__rest
     }
 }
 
+// value records: the values of each pattern's representative row ...
+__global__ void csr_fetch_values(int npat, const int *__restrict__ rep, const int *__restrict__ ptr, const double *__restrict__ val,
+                                 double *__restrict__ vrec)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npat) return;
+    const int s = ptr[rep[p]], e = ptr[rep[p] + 1];
+    for (int j = 0; j < 8; j++) vrec[8 * p + j] = (s + j < e && j < 7) ? val[s + j] : 0.0;
+}
+// ... and the check that EVERY row carries its pattern's values, bit for bit
+__global__ void csr_check_values(int n, const int *__restrict__ ptr, const double *__restrict__ val,
+                                 const unsigned char *__restrict__ rowpat, const double *__restrict__ vrec, int *__restrict__ bad)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || bad[0] != 0) return;
+    const int s = ptr[r], e = ptr[r + 1], p = rowpat[r];
+    bool ok = e - s <= 7;
+    for (int k = s; ok && k < e; k++) ok = __double_as_longlong(val[k]) == __double_as_longlong(vrec[8 * p + (k - s)]);
+    if (!ok) atomicAdd(bad, 1);
+}
+
 } // namespace
 
 struct liship_csr_plan_s {
@@ -1132,6 +1255,8 @@ struct liship_csr_plan_s {
     int *ptab;           // device: npat + 1 prefix entries, then the offsets of all patterns
     int ptab_len, npat;
     v4i32 *ptab8;        // device: when no pattern has more than 7 offsets, one 32 B record per pattern (7 offsets, length); else NULL
+    int prep[64];        // with ptab8: a row that carries each pattern (PAT7_MAX entries)
+    v4i32 *vrec;         // device: with ptab8, when every row of a pattern carries the same values, 96 B per pattern (the 32 B record + 7 values); else NULL
 };
 
 extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
@@ -1198,7 +1323,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->vrec = nullptr;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -1216,6 +1341,7 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->rowrel) (void)hipFree(p->rowrel);
     if (p->ptab) (void)hipFree(p->ptab);
     if (p->ptab8) (void)hipFree(p->ptab8);
+    if (p->vrec) (void)hipFree(p->vrec);
     if (p->lcol) (void)hipFree(p->lcol);
     if (p->dcol) (void)hipFree(p->dcol);
     if (p->doff) (void)hipFree(p->doff);
@@ -1373,6 +1499,7 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
             }
             PT(hipMalloc(&p->ptab8, sizeof(int) * 8 * (size_t)npat));
             PT(hipMemcpyAsync(p->ptab8, rec, sizeof(int) * 8 * (size_t)npat, hipMemcpyHostToDevice, st));
+            for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
         }
         if (rc == 0) {
             csr_encode_patterns<<<p->nblocks, 256, 0, st>>>(p->blk, ptr, p->codes, npat, d_hash, d_len, d_pc, p->rowpat, p->rowrel, d_bad);
@@ -1400,6 +1527,46 @@ extern "C" int liship_csr_plan_row_patterns(liship_csr_plan_t p) { return (p && 
 // 1 when every pattern has 1..7 offsets and the plan also keeps them as 32 B records (spmv_csr_pattern7_kernel), else 0
 extern "C" int liship_csr_plan_pattern_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8) ? 1 : 0; }
 extern "C" int liship_spmv_csr_set_row_patterns(int on) { g_row_patterns = on ? 1 : 0; return 0; }
+
+// Value records on top of the pattern records (see spmv_csr_valuerec_kernel): setup-time, optional, never an error when the matrix
+// does not qualify (no 32 B records, or two rows of one pattern with different values).  One pass over ptr / value.
+extern "C" int liship_csr_plan_encode_row_values(liship_csr_plan_t p, const int *ptr, const double *val, void *stream)
+{
+    if (!p || (p->n > 0 && (!ptr || !val))) return LISHIP_ERR_ARG;
+    if (!p->rowpat || !p->ptab8 || p->vrec || p->npat <= 0 || p->npat > PAT7_MAX || g_variant != 0) return 0;
+    hipStream_t st = as_stream(stream);
+    int *d_rep = nullptr, *d_bad = nullptr, bad = 1, rc = 0;
+    double *vr = nullptr;
+#define PT(expr) do { if (rc == 0) { hipError_t e__ = (expr); if (e__ != hipSuccess) rc = (int)e__; } } while (0)
+    PT(hipMalloc(&d_rep, sizeof(int) * (size_t)p->npat)); PT(hipMalloc(&d_bad, sizeof(int)));
+    PT(hipMalloc(&vr, sizeof(double) * 8 * (size_t)p->npat));
+    PT(hipMemcpyAsync(d_rep, p->prep, sizeof(int) * (size_t)p->npat, hipMemcpyHostToDevice, st));
+    PT(hipMemsetAsync(d_bad, 0, sizeof(int), st));
+    if (rc == 0) { csr_fetch_values<<<1, 64, 0, st>>>(p->npat, d_rep, ptr, val, vr); PT(hipGetLastError()); }
+    if (rc == 0) { csr_check_values<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, val, p->rowpat, vr, d_bad); PT(hipGetLastError()); }
+    PT(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    PT(hipStreamSynchronize(st));
+#undef PT
+    (void)hipFree(d_rep); (void)hipFree(d_bad);
+    double hv[PAT7_MAX * 8];
+    int hr[PAT7_MAX * 8];
+    if (rc == 0 && bad == 0) {                       // the combined records: 32 B (offsets, length) + 64 B (values) per pattern
+        hipError_t e = hipMemcpy(hv, vr, sizeof(double) * 8 * (size_t)p->npat, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hr, p->ptab8, sizeof(int) * 8 * (size_t)p->npat, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = (int)e;
+    }
+    if (vr) (void)hipFree(vr);
+    if (rc != 0 || bad != 0) return rc;
+    unsigned char img[PAT7_MAX * 96];
+    for (int i = 0; i < p->npat; i++) { memcpy(img + 96 * i, hr + 8 * i, 32); memcpy(img + 96 * i + 32, hv + 8 * i, 64); }
+    hipError_t e = hipMalloc(&p->vrec, 96 * (size_t)p->npat);
+    if (e == hipSuccess) e = hipMemcpy(p->vrec, img, 96 * (size_t)p->npat, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { if (p->vrec) (void)hipFree(p->vrec); p->vrec = nullptr; return (int)e; }
+    return 0;
+}
+// 1 when the plan keeps the rows' values in the pattern records (the products then read neither values nor indices), else 0
+extern "C" int liship_csr_plan_value_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8 && p->vrec) ? 1 : 0; }
+extern "C" int liship_spmv_csr_set_row_values(int on) { g_row_values = on ? 1 : 0; return 0; }
 
 // Block-local columns for the products kernel (see spmv_csr_local_kernel): setup-time, optional, never an error when the
 // matrix does not qualify.  Kept when the lists cover >= 90 % of the non-zeros and hold at most half as many columns as
@@ -1480,6 +1647,7 @@ struct LaunchArgs {
     const unsigned short *rowrel = nullptr;
     const int *ptab = nullptr; int ptab_len = 0, npat1 = 0;
     const v4i32 *ptab8 = nullptr;
+    const v4i32 *vrec = nullptr;            // value records (with ptab8), when the plan has them and they are switched on
 };
 
 
@@ -1542,6 +1710,12 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
+    if (a.rowpat && a.ptab8 && a.vrec && g_variant == 0) {            // the rows' values ride in the pattern records: one byte per row
+        constexpr Geometry g = kGeom[G];
+        spmv_csr_valuerec_kernel<g.block, 2, 0><<<(a.nb + 1) / 2, g.block, 0, a.st>>>(
+            a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0});
+        return;
+    }
     if (a.rowpat && a.ptab8 && g_variant == 0) {      // patterns of at most 7 offsets: gathers ahead of the slice
         constexpr Geometry g = kGeom[G];
         spmv_csr_pattern7_kernel<g.block, g.work, 0><<<a.nb, g.block, 0, a.st>>>(
@@ -1576,6 +1750,12 @@ template <int G, int DOT>
 void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
+    if (a.rowpat && a.ptab8 && a.vrec && !(g_variant & 0x2000)) {
+        spmv_csr_valuerec_kernel<g.block, 2, DOT><<<(a.nb + 1) / 2, g.block, 0, a.st>>>(
+            a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
+            w, partial, liship_internal_guard(), pstride);
+        return;
+    }
     if (a.rowpat && a.ptab8 && !(g_variant & 0x2000)) {
         spmv_csr_pattern7_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz,
@@ -1643,7 +1823,7 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
                                    const double *val, const double *x, double *y, void *stream)
 {
     if (!p) return LISHIP_ERR_ARG;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr};
     return launch_csr(p, a);
 }
 
@@ -1659,7 +1839,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x2000) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);
@@ -1685,7 +1865,7 @@ extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int 
     const int bfirst = lo;
     lo = bfirst; hi = p->nblocks;                // first b with br[b].row >= row_end
     while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr};
     return launch_csr(p, a);
 }
 
@@ -1713,7 +1893,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if (nb <= 0) return 0;
     if ((size_t)slot_base + (size_t)nb > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work) + slot_base;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr};
     const int ps = (int)slots;
     if (p->products && p->geom == LOCAL_GEOM) {
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial, ps);

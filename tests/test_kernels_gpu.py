@@ -203,10 +203,19 @@ def cyclic_diagonals(n, count, seed):
 # row patterns the plan must find on top of the codes: 3 for the 1-D stencil (first row, interior, last row), 27 for the 3-D one
 ROW_PATTERNS = {"p1d_10000": 3, "p3d_20x17x13": 27, "p3d_64_sorted": 27, "p3d_40_sorted": 27, "p3d_odd_33x7x5": 27, "diagonals_255": 255,
                 "diagonals_300": 0, "rand_5000": 0, "wide_77": 0,        # diagonals_255: 254 two-entry rows + the rows whose second entry falls outside
-                "p1d_9999": 3, "p3d_holes": 27}            # p3d_holes: the empty row is one more pattern, a corner row that lost its entries one fewer
+                "p1d_9999": 3, "p3d_holes": 27, "p3d_varcoef": 27}            # p3d_holes: the empty row is one more pattern, a corner row that lost its entries one fewer
 # ... and whether it also keeps them as 32 B records (1..7 offsets per pattern, at most 64 patterns: spmv_csr_pattern7_kernel)
+# ... and whether every row of a pattern also carries the same values (then the records hold them: spmv_csr_valuerec_kernel)
+VALUE_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
+                 "p3d_varcoef": 0, "p3d_holes": 0, "diagonals_255": 0, "band_9_unsorted": 0}
 PATTERN_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
-                   "diagonals_255": 0, "p3d_holes": 0, "band_9_unsorted": 0, "rand_5000": 0}
+                   "diagonals_255": 0, "p3d_holes": 0, "band_9_unsorted": 0, "rand_5000": 0, "p3d_varcoef": 1}
+
+
+def poisson3d_variable_coefficients(nx, ny, nz, seed):
+    """the 3-D stencil's pattern with random values: pattern records, but no value records"""
+    ptr, idx, val = orc.poisson3d(nx, ny, nz)
+    return ptr, idx, np.random.default_rng(seed).uniform(-1, 1, len(val))
 
 
 def poisson3d_with_empty_rows(nx, ny, nz, every):
@@ -226,6 +235,7 @@ CODED_CASES = {
     "p1d_9999": (lambda: orc.poisson1d(9999), 3),                                           # odd number of values: the last one has no 16 B piece
     "p3d_20x17x13": (lambda: orc.poisson3d(20, 17, 13), 7),
     "p3d_holes": (lambda: poisson3d_with_empty_rows(24, 20, 16, 37), 7),
+    "p3d_varcoef": (lambda: poisson3d_variable_coefficients(24, 20, 16, 5), 7),
     "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
     "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
     "p3d_40_sorted": (lambda: orc.poisson3d(40, 40, 40, sort_cols=True), 7),                # several row blocks
@@ -269,10 +279,15 @@ def test_spmv_csr_index_codes(lib, name):
         assert npat == ROW_PATTERNS[name], npat
     if name in PATTERN_RECORDS:
         assert lib.liship_csr_plan_pattern_records(plan) == PATTERN_RECORDS[name]
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    if name in VALUE_RECORDS:
+        assert lib.liship_csr_plan_value_records(plan) == VALUE_RECORDS[name]
+    assert lib.liship_csr_plan_value_records(plan) <= lib.liship_csr_plan_pattern_records(plan)
     results = {}
-    for on in (3, 2, 1, 0):                    # 2: one byte per row (patterns; 3: through the general pattern kernel even when the plan
-        lib.liship_spmv_csr_set_index_codes(1 if on else 0)         # has 32 B records), 1: one byte per non-zero (codes), 0: 4 B indices
-        lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)
+    for on in (4, 3, 2, 1, 0):                 # 4: values in the pattern records too (nothing streamed), 2: one byte per row (patterns;
+        lib.liship_spmv_csr_set_index_codes(1 if on else 0)         # 3: through the general pattern kernel even when the plan has
+        lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)   # 32 B records), 1: one byte per non-zero (codes), 0: 4 B indices
+        lib.liship_spmv_csr_set_row_values(1 if on == 4 else 0)
         lib.liship_spmv_csr_set_variant(0x2000 if on == 3 else 0)
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
@@ -314,10 +329,11 @@ def test_spmv_csr_index_codes(lib, name):
     lib.liship_spmv_csr_set_index_codes(1)
     lib.liship_spmv_csr_set_row_patterns(1)
     lib.liship_spmv_csr_set_variant(0)
+    lib.liship_spmv_csr_set_row_values(1)
     check(lib.liship_csr_plan_destroy(plan))
-    assert len(results[0]) == len(results[1]) == len(results[2]) == len(results[3])
-    for a, b, c, d in zip(results[0], results[1], results[2], results[3]):
-        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)    # same partial sums, same fold: the reductions agree to the bit too
+    assert len(results[0]) == len(results[1]) == len(results[2]) == len(results[3]) == len(results[4])
+    for a, b, c, d, e in zip(results[0], results[1], results[2], results[3], results[4]):    # same partial sums, same fold: the reductions agree to the bit too
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e)
 
 
 def stack_rows(parts):

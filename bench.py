@@ -306,7 +306,8 @@ def main():
                 tt = torch.tensor([itime, wall], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 itime, wall = float(tt[0]), float(tt[1])
-            loop_b, contract_b = krylov_bytes(key, iters, n_local, nnz_local, coded, patterns, values)
+            uniform = int(dll.lis_amd_last_solve_uniform_jacobi())      # CG + Jacobi on a constant diagonal: 1/diag rides as a scalar
+            loop_b, contract_b = krylov_bytes(key, iters, n_local, nnz_local, coded, patterns, values, uniform)
             sec_per_iter = itime / max(1, iters)
             solvers[key] = {
                 "iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6),
@@ -332,7 +333,7 @@ def main():
                 tt = torch.tensor([itime], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 itime = float(tt[0])
-            loop_b, _ = krylov_bytes("cg_jacobi", iters, n_local, nnz_local, coded, patterns, 0)
+            loop_b, _ = krylov_bytes("cg_jacobi", iters, n_local, nnz_local, coded, patterns, 0, int(dll.lis_amd_last_solve_uniform_jacobi()))
             streamed["cg_jacobi"] = {"iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6),
                                      "loop_bytes_per_iter": loop_b, "frac": round(loop_b / (itime / max(1, iters)) / 1e9 / HBM_PEAK_GBS, 4)}
             lib.lis_solver_destroy(S)
@@ -379,7 +380,7 @@ def spmv_stored_bytes(n, nnz, coded, patterns, values=0):
     return (9 if coded else 12) * nnz + 20 * n + 4
 
 
-def krylov_bytes(key, iters, n, nnz, coded, patterns=0, values=0):
+def krylov_bytes(key, iters, n, nnz, coded, patterns=0, values=0, uniform_jacobi=0):
     """Bytes per iteration and per GPU: (what the passes of the fused device loops are asked to stream, what the
     reference's unfused operator sequence moves by SURVEY 8d's count).  n / nnz are the local rows / non-zeros.
     Product: S = (9 coded | 12) B per non-zero + 20 B per row (ptr, y, compulsory x), or 8 B per non-zero + 17 B per row with row
@@ -390,7 +391,8 @@ def krylov_bytes(key, iters, n, nnz, coded, patterns=0, values=0):
     if key == "cg_jacobi":
         # p = dinv.*r + beta p (+ the deferred x += alpha p: r dinv p x | p x) ; q = A p with <p,q> (w = p: no extra stream) ;
         # r -= alpha q, ||r||^2, <r, dinv.*r> (q r dinv | r)
-        return S + CG_VECTOR_BYTES_PER_ROW * n, B + 136 * n
+        # (a constant diagonal: dinv is one double, neither pass reads the array: 16 B per row fewer)
+        return S + (CG_VECTOR_BYTES_PER_ROW - (16 if uniform_jacobi else 0)) * n, B + 136 * n
     if key == "bicgstab_none":
         # p-update 32 ; v = A p + <rtld,v> (+8: rtld) ; s = r - alpha v, ||s|| 24 ; t = A s + <t,s>,<t,t> ;
         # x += alpha p + omega s, r = s - omega t, ||r||, <rtld,r> in one pass 56 (t s rtld p x | x r)

@@ -37,6 +37,9 @@ LIS_INT lis_amd_get_residency(void);
 #define LIS_AMD_LOOP_HOST    1
 #define LIS_AMD_LOOP_UNFUSED 2
 LIS_INT lis_amd_set_loop_mode(LIS_INT mode);
+/* 1 when the last lis_solve ran CG + Jacobi on a matrix with a constant diagonal and its fused passes took 1/diag as one double
+ * instead of reading the array (bit-identical; LIS_AMD_NO_UNIFORM_JACOBI=1 switches it off), else 0 */
+LIS_INT lis_amd_last_solve_uniform_jacobi(void);
 
 /* vectors */
 LIS_INT lis_amd_vector_sync_host(LIS_VECTOR v);        /* make v->value[] current (D2H if needed)        */

@@ -295,6 +295,15 @@ int  liship_cg_direction_dev_f64(int n, const double *palpha, const double *pbet
  * (without a preconditioner liship_axpy_sumsq_dev_f64 serves) */
 int  liship_cg_residual_jacobi_dev_f64(int n, const double *pna, const double *q, const double *dinv, double *r,
                                        double *result, void *work, void *stream);
+/* The two passes for a Jacobi preconditioner with a UNIFORM diagonal: every dinv[i] is the double dc (the caller has made sure:
+ * liship_count_ne_f64 returned 0), so r[i]*dc is r[i]*dinv[i] in every bit and the array is not read -- 64 instead of 80 B of
+ * vectors per row and iteration. */
+int  liship_cg_direction_uniform_dev_f64(int n, const double *palpha, const double *pbeta, const double *r, double dc,
+                                         double *p, double *x, void *stream);
+int  liship_cg_residual_jacobi_uniform_dev_f64(int n, const double *pna, const double *q, double dc, double *r,
+                                               double *result, void *work, void *stream);
+/* result[0] = how many x[i] differ from `a` in any bit (a reduction like the others: work as for liship_dot_f64) */
+int  liship_count_ne_f64(int n, const double *x, double a, double *result, void *work, void *stream);
 /* BiCGSTAB without a preconditioner (shat is s itself): x += (*palpha)*phat, x += (*pomega)*s, r = s + (*pnomega)*t, result =
  * {sum r^2, sum rtld*r} -- lis_solver_bicgstab.c:272-279 and :190 of the next iteration in ONE pass (s is read once for the
  * iterate and the residual: 56 instead of 64 B per row); s is the content of r[] on entry */

@@ -100,6 +100,9 @@ _LISHIP = {
     "liship_bicgstab_end_dev_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_cg_direction_dev_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_cg_residual_jacobi_dev_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_cg_direction_uniform_dev_f64": (_ci, [_ci, _vp, _vp, _vp, _cd, _vp, _vp, _vp]),
+    "liship_cg_residual_jacobi_uniform_dev_f64": (_ci, [_ci, _vp, _vp, _cd, _vp, _vp, _vp, _vp]),
+    "liship_count_ne_f64": (_ci, [_ci, _vp, _cd, _vp, _vp, _vp]),
     "liship_axpy_sumsq_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp]),
     "liship_axpy_sumsq_dot_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_mgs_step_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

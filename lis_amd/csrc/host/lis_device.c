@@ -114,6 +114,8 @@ LIS_INT lis_amd_set_residency(LIS_INT mode)
 }
 LIS_INT lis_amd_get_residency(void) { return lisg.residency; }
 
+LIS_INT lis_amd_last_solve_uniform_jacobi(void) { return lisg.last_uniform_jacobi; }
+
 LIS_INT lis_amd_set_loop_mode(LIS_INT mode)
 {
 	if (mode < LIS_AMD_LOOP_DEVICE || mode > LIS_AMD_LOOP_UNFUSED) return LISI_ERR(LIS_ERR_ILL_ARG, "unknown loop mode %D\n", mode);

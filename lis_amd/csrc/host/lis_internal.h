@@ -105,6 +105,8 @@ typedef struct {
 	int long_row_tree;         /* LIS_AMD_LONG_ROW_TREE=1: rows longer than the LDS stage are added by a tree per pass (not bit-parity; opt-in) */
 	int no_value_records;      /* LIS_AMD_NO_VALUE_RECORDS=1: matrices whose rows repeat with their values keep streaming the values (A/B measurements) */
 	int no_row_patterns;       /* LIS_AMD_NO_ROW_PATTERNS=1: coded CSR matrices keep one byte per non-zero instead of one per row (A/B measurements) */
+	int last_uniform_jacobi;   /* the last lis_solve ran CG + Jacobi with 1/diag as one double (lis_amd_last_solve_uniform_jacobi) */
+	int no_uniform_jacobi;     /* LIS_AMD_NO_UNIFORM_JACOBI=1: CG + Jacobi reads 1/diag even when the diagonal is constant (A/B measurements) */
 	int no_local_columns;      /* LIS_AMD_NO_LOCAL_COLUMNS=1: long-row CSR products keep the 4 B column indices (A/B measurements) */
 	int no_index_codes;        /* LIS_AMD_NO_INDEX_CODES=1: CSR products keep reading the 4 B column indices (A/B measurements) */
 	int host_scalars;          /* LIS_AMD_HOST_SCALARS=1: CG / BiCGSTAB read every scalar back (A/B against the device-driven loops) */

@@ -16,6 +16,7 @@ typedef struct {
 	size_t len;              /* doubles per work vector: np + pad + slack (ghost slots for the halo) */
 	double *b, *x;           /* HBM */
 	double *dinv;            /* Jacobi 1/diag in HBM, NULL for none */
+	int duniform; double dconst;   /* every dinv[i] is the double dconst (a constant diagonal): the fused CG passes take the scalar */
 	double **work; int nwork;
 	double bnrm, tol;
 	int output, maxiter;

@@ -378,12 +378,14 @@ static LIS_INT run_cg_device(ctx_t *c)
 		const LIS_INT batch = (c->maxiter - queued < LISD_BATCH) ? c->maxiter - queued : LISD_BATCH;
 		for (LIS_INT k = 0; k < batch; k++) {
 			/* x += alpha p of the PREVIOUS iteration rides in this pass, which reads p anyway (none before the first) */
-			KTRY(liship_cg_direction_dev_f64(n, queued + k ? st + LISHIP_KS_ALPHA : NULL, st + LISHIP_KS_BETA, r, c->dinv, p, c->x, lisg.stream));
+			if (c->duniform) KTRY(liship_cg_direction_uniform_dev_f64(n, queued + k ? st + LISHIP_KS_ALPHA : NULL, st + LISHIP_KS_BETA, r, c->dconst, p, c->x, lisg.stream));
+			else KTRY(liship_cg_direction_dev_f64(n, queued + k ? st + LISHIP_KS_ALPHA : NULL, st + LISHIP_KS_BETA, r, c->dinv, p, c->x, lisg.stream));
 			TRY(dev_announce(&L, LISHIP_STEP_CG_ALPHA));
 			TRY(lisd_spmv_dot_launch_to(c->A, p, q, p, 0, st + LISHIP_KS_DOT0));
 			TRY(dev_step(&L, LISHIP_STEP_CG_ALPHA, LISHIP_KS_DOT0, 1));
 			TRY(dev_announce(&L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID));
-			if (c->dinv) KTRY(liship_cg_residual_jacobi_dev_f64(n, st + LISHIP_KS_NALPHA, q, c->dinv, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			if (c->duniform) KTRY(liship_cg_residual_jacobi_uniform_dev_f64(n, st + LISHIP_KS_NALPHA, q, c->dconst, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+			else if (c->dinv) KTRY(liship_cg_residual_jacobi_dev_f64(n, st + LISHIP_KS_NALPHA, q, c->dinv, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
 			else         KTRY(liship_axpy_sumsq_dev_f64(n, st + LISHIP_KS_NALPHA, q, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
 			TRY(dev_step(&L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID, LISHIP_KS_SUM0, c->dinv ? 2 : 1));
 		}
@@ -1024,8 +1026,21 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 			if ((rc = liship_memcpy_d2d(c.x, dx0, sizeof(double) * (size_t)A->n, lisg.stream))) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
 		}
 	}
+	lisg.last_uniform_jacobi = 0;
 	if (precon && precon->precon_type == LIS_PRECON_TYPE_JACOBI) {
 		if ((err = lisd_vec_in(precon->D, &c.dinv))) goto out;
+		if (nsolver == LIS_SOLVER_CG && !lisg.no_uniform_jacobi && A->n > 0) {
+			/* a constant diagonal (constant-coefficient stencils): z = r.*dinv is r*dinv[0] in every bit, and the fused CG passes
+			 * need not read the array -- one counting pass per solve decides (all ranks: the count is folded like any sum) */
+			double d0 = 0.0, differ = 1.0;
+			int rc = liship_memcpy_d2h(&d0, c.dinv, sizeof(double), lisg.stream);
+			if (!rc) rc = liship_stream_synchronize(lisg.stream);
+			if (!rc) rc = liship_count_ne_f64(A->n, c.dinv, d0, lisg.reduce_out, lisg.reduce_work, lisg.stream);
+			if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
+			if ((err = lisd_fetch(1, &differ))) goto out;
+			if (differ == 0.0) { c.duniform = 1; c.dconst = d0; }
+			lisg.last_uniform_jacobi = c.duniform;
+		}
 	}
 	solver->x = NULL; solver->xx = x; solver->precon = precon;
 

@@ -146,16 +146,18 @@ int run_ew(int n, double a, double b, const double *in0, const double *in1, cons
 // CG's direction update with the PREVIOUS iteration's x update folded in (device-driven loop): x += alpha*p on the old p, then
 // p = M^-1 r + beta*p -- lis_solver_cg.c:199 (axpy) and :176-183 (psolve none / Jacobi, xpay), each with its own rounding
 // sequence.  p is read once for both (the pass that updates x in the reference's position reads it a second time).
-template <bool NT, bool VEC, bool JAC, bool XUP>
+// JAC: 0 no preconditioner, 1 Jacobi (z = r.*dinv), 2 Jacobi with a UNIFORM diagonal (every dinv[i] is the same double dc, so
+// z = r*dc is the same product and the array is not read)
+template <bool NT, bool VEC, int JAC, bool XUP>
 __global__ __launch_bounds__(BLOCK)
 void cg_direction_kernel(int n, const double *__restrict__ palpha, const double *__restrict__ pbeta, const double *__restrict__ r,
-                         const double *__restrict__ dinv, double *p, double *x, const double *skip)
+                         const double *__restrict__ dinv, double dc, double *p, double *x, const double *skip)
 {
     if (skip && skip[0] != 0.0) return;
     const double alpha = XUP ? palpha[0] : 0.0, beta = pbeta[0];
     auto one = [&](double rv, double dv, double pv, double xv, double &po, double &xo) {
         if (XUP) xo = xv + alpha * pv;                   // x[i] += alpha * p[i]
-        const double z = JAC ? rv * dv : rv;             // z = M^-1 r
+        const double z = JAC == 1 ? rv * dv : JAC == 2 ? rv * dc : rv;       // z = M^-1 r
         po = z + beta * pv;                              // p[i] = z[i] + beta * p[i]
     };
     if (VEC) {
@@ -167,7 +169,7 @@ void cg_direction_kernel(int n, const double *__restrict__ palpha, const double 
             const long long q = base + u * BLOCK;
             if (q < npairs) {
                 rv[u] = ld2<NT>(r, q); pv[u] = ld2<NT>(p, q);
-                if (JAC) dv[u] = ld2<NT>(dinv, q);
+                if (JAC == 1) dv[u] = ld2<NT>(dinv, q);
                 if (XUP) xv[u] = ld2<NT>(x, q);
             }
         }
@@ -176,8 +178,8 @@ void cg_direction_kernel(int n, const double *__restrict__ palpha, const double 
             const long long q = base + u * BLOCK;
             if (q < npairs) {
                 double p0 = 0.0, p1 = 0.0, x0 = 0.0, x1 = 0.0;
-                one(rv[u].x, JAC ? dv[u].x : 0.0, pv[u].x, XUP ? xv[u].x : 0.0, p0, x0);
-                one(rv[u].y, JAC ? dv[u].y : 0.0, pv[u].y, XUP ? xv[u].y : 0.0, p1, x1);
+                one(rv[u].x, JAC == 1 ? dv[u].x : 0.0, pv[u].x, XUP ? xv[u].x : 0.0, p0, x0);
+                one(rv[u].y, JAC == 1 ? dv[u].y : 0.0, pv[u].y, XUP ? xv[u].y : 0.0, p1, x1);
                 v2f64 po, xo;
                 po.x = p0; po.y = p1; xo.x = x0; xo.y = x1;
                 st2(p, q, po);
@@ -187,7 +189,7 @@ void cg_direction_kernel(int n, const double *__restrict__ palpha, const double 
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const int i = n - 1;
             double po, xo;
-            one(r[i], JAC ? dinv[i] : 0.0, p[i], XUP ? x[i] : 0.0, po, xo);
+            one(r[i], JAC == 1 ? dinv[i] : 0.0, p[i], XUP ? x[i] : 0.0, po, xo);
             p[i] = po;
             if (XUP) x[i] = xo;
         }
@@ -198,7 +200,7 @@ void cg_direction_kernel(int n, const double *__restrict__ palpha, const double 
             const long long i = i0 + u * BLOCK;
             if (i < n) {
                 double po, xo;
-                one(r[i], JAC ? dinv[i] : 0.0, p[i], XUP ? x[i] : 0.0, po, xo);
+                one(r[i], JAC == 1 ? dinv[i] : 0.0, p[i], XUP ? x[i] : 0.0, po, xo);
                 p[i] = po;
                 if (XUP) x[i] = xo;
             }
@@ -206,17 +208,17 @@ void cg_direction_kernel(int n, const double *__restrict__ palpha, const double 
     }
 }
 
-template <bool JAC, bool XUP>
-int run_cg_direction(int n, const double *palpha, const double *pbeta, const double *r, const double *dinv, double *p, double *x, void *stream)
+template <int JAC, bool XUP>
+int run_cg_direction(int n, const double *palpha, const double *pbeta, const double *r, const double *dinv, double dc, double *p, double *x, void *stream)
 {
-    if (n < 0 || !pbeta || !r || !p || (XUP && (!palpha || !x)) || (JAC && !dinv)) return LISHIP_ERR_ARG;
+    if (n < 0 || !pbeta || !r || !p || (XUP && (!palpha || !x)) || (JAC == 1 && !dinv)) return LISHIP_ERR_ARG;
     if (n == 0) return 0;
-    const bool vec = aligned16(r) && aligned16(p) && (!JAC || aligned16(dinv)) && (!XUP || aligned16(x));
+    const bool vec = aligned16(r) && aligned16(p) && (JAC != 1 || aligned16(dinv)) && (!XUP || aligned16(x));
     const int grid = blocks_for(((long long)n + 1) / 2);
     hipStream_t st = as_stream(stream);
-    if (!vec)                   cg_direction_kernel<false, false, JAC, XUP><<<grid, BLOCK, 0, st>>>(n, palpha, pbeta, r, dinv, p, x, g_guard);
-    else if (n > NT_LOAD_ELEMS) cg_direction_kernel<true, true, JAC, XUP><<<grid, BLOCK, 0, st>>>(n, palpha, pbeta, r, dinv, p, x, g_guard);
-    else                        cg_direction_kernel<false, true, JAC, XUP><<<grid, BLOCK, 0, st>>>(n, palpha, pbeta, r, dinv, p, x, g_guard);
+    if (!vec)                   cg_direction_kernel<false, false, JAC, XUP><<<grid, BLOCK, 0, st>>>(n, palpha, pbeta, r, dinv, dc, p, x, g_guard);
+    else if (n > NT_LOAD_ELEMS) cg_direction_kernel<true, true, JAC, XUP><<<grid, BLOCK, 0, st>>>(n, palpha, pbeta, r, dinv, dc, p, x, g_guard);
+    else                        cg_direction_kernel<false, true, JAC, XUP><<<grid, BLOCK, 0, st>>>(n, palpha, pbeta, r, dinv, dc, p, x, g_guard);
     LAUNCH_CHECK();
     return 0;
 }
@@ -229,12 +231,14 @@ enum RedOp { RED_DOT, RED_SUMSQ, RED_ABS, RED_SUM, RED_DOT2,
              RED_AXPY_NRM2,     // y += a*x; result {sum y^2}
              RED_AXPY_NRM2_DOT, // y += a*x; results {sum y^2, sum w*y}
              RED_AXPY_NRM2_JAC, // y += a*x; z = y.*e (not stored); results {sum y^2, sum y*z}
+             RED_AXPY_NRM2_JACU,// the same with every e[i] equal to the double c (e is not read)
+             RED_COUNT_NE,      // result {number of x[i] whose bits differ from a's}
              RED_BICGSTAB_END,  // e += (*pb)*d; e += (*pc)*y; y += a*x; results {sum y^2, sum w*y}   (x-iterate and residual of BiCGSTAB)
              RED_AXPYD_DOT,     // y += (-*sp)*x; result {sum y*w}      (one modified Gram-Schmidt step)
              RED_AXPYD_SUMSQ    // y += (-*sp)*x; result {sum y^2}      (the last one)
 };
 template <int OP> struct RedResults { static constexpr int value =
-    (OP == RED_DOT2 || OP == RED_AXPY_NRM2_DOT || OP == RED_CG_UPDATE_JAC || OP == RED_AXPY_NRM2_JAC || OP == RED_BICGSTAB_END) ? 2 : 1; };
+    (OP == RED_DOT2 || OP == RED_AXPY_NRM2_DOT || OP == RED_CG_UPDATE_JAC || OP == RED_AXPY_NRM2_JAC || OP == RED_AXPY_NRM2_JACU || OP == RED_BICGSTAB_END) ? 2 : 1; };
 
 struct RedArgs {
     int n;
@@ -245,6 +249,7 @@ struct RedArgs {
     const double *pa;                // coefficient `a` read from HBM when set (device-driven loops)
     const double *skip;              // guard flag (filled by run_reduce)
     const double *pb, *pc;           // further device coefficients (RED_BICGSTAB_END: alpha, omega)
+    double c;                        // RED_AXPY_NRM2_JACU: the uniform 1/diag
 };
 
 template <int OP, bool NT, bool VEC>
@@ -271,11 +276,13 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
             s0 += oy * oy;
             if (OP == RED_CG_UPDATE_JAC) { const double z = oy * e; s1 += oy * z; }   // z = r.*dinv ; <r,z>
         }
-        if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC) {
+        if (OP == RED_COUNT_NE) s0 += (__double_as_longlong(x) != __double_as_longlong(A.a)) ? 1.0 : 0.0;
+        if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC || OP == RED_AXPY_NRM2_JACU) {
             oy = y + A.a * x;               // y += a*x
             s0 += oy * oy;
             if (OP == RED_AXPY_NRM2_DOT) s1 += w * oy;
             if (OP == RED_AXPY_NRM2_JAC) { const double z = oy * e; s1 += oy * z; }   // z = r.*dinv ; <r,z>
+            if (OP == RED_AXPY_NRM2_JACU) { const double z = oy * A.c; s1 += oy * z; } // the same, dinv uniform
         }
         if (OP == RED_BICGSTAB_END) {       // x: t, y: s (becomes r), w: rtld, d: phat, e: the iterate; shat aliases s (no preconditioner)
             const double t1 = e + cb * d;   // x += alpha*phat     (lis_solver_bicgstab.c:272)
@@ -292,7 +299,7 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
     };
     constexpr bool IS_CG = (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC || OP == RED_BICGSTAB_END);     // five inputs, two outputs
     constexpr bool IS_AXD = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ);
-    constexpr bool IS_AXN = (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC);
+    constexpr bool IS_AXN = (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC || OP == RED_AXPY_NRM2_JACU);
     constexpr bool HAS_Y = (OP == RED_DOT || OP == RED_DOT2 || IS_CG || IS_AXN || IS_AXD);
     constexpr bool HAS_W = (IS_CG || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPYD_DOT);
     constexpr bool HAS_D = IS_CG;
@@ -711,8 +718,14 @@ extern "C" int liship_cg_update_dev_f64(int n, const double *palpha, const doubl
 extern "C" int liship_cg_direction_dev_f64(int n, const double *palpha, const double *pbeta, const double *r, const double *dinv,
                                            double *p, double *x, void *s)
 {
-    if (dinv) return palpha ? run_cg_direction<true, true>(n, palpha, pbeta, r, dinv, p, x, s) : run_cg_direction<true, false>(n, palpha, pbeta, r, dinv, p, x, s);
-    return palpha ? run_cg_direction<false, true>(n, palpha, pbeta, r, dinv, p, x, s) : run_cg_direction<false, false>(n, palpha, pbeta, r, dinv, p, x, s);
+    if (dinv) return palpha ? run_cg_direction<1, true>(n, palpha, pbeta, r, dinv, 0.0, p, x, s) : run_cg_direction<1, false>(n, palpha, pbeta, r, dinv, 0.0, p, x, s);
+    return palpha ? run_cg_direction<0, true>(n, palpha, pbeta, r, dinv, 0.0, p, x, s) : run_cg_direction<0, false>(n, palpha, pbeta, r, dinv, 0.0, p, x, s);
+}
+// the same for a Jacobi preconditioner whose diagonal is uniform: every dinv[i] is the double dc (the caller has checked: liship_count_ne_f64)
+extern "C" int liship_cg_direction_uniform_dev_f64(int n, const double *palpha, const double *pbeta, const double *r, double dc,
+                                                   double *p, double *x, void *s)
+{
+    return palpha ? run_cg_direction<2, true>(n, palpha, pbeta, r, nullptr, dc, p, x, s) : run_cg_direction<2, false>(n, palpha, pbeta, r, nullptr, dc, p, x, s);
 }
 // r += (*pna)*q ; result = {sum r^2, sum r*(r.*dinv)}   (the residual half of liship_cg_update_jacobi_f64; pna holds -alpha)
 extern "C" int liship_cg_residual_jacobi_dev_f64(int n, const double *pna, const double *q, const double *dinv, double *r,
@@ -721,6 +734,21 @@ extern "C" int liship_cg_residual_jacobi_dev_f64(int n, const double *pna, const
     if (!pna || !dinv) return LISHIP_ERR_ARG;
     RedArgs A{n, 0.0, q, r, nullptr, nullptr, dinv, nullptr, r, nullptr, pna};
     return run_reduce<RED_AXPY_NRM2_JAC>(A, result, w, false, s);
+}
+// the same when every dinv[i] is the double dc
+extern "C" int liship_cg_residual_jacobi_uniform_dev_f64(int n, const double *pna, const double *q, double dc, double *r,
+                                                         double *result, void *w, void *s)
+{
+    if (!pna) return LISHIP_ERR_ARG;
+    RedArgs A{n, 0.0, q, r, nullptr, nullptr, nullptr, nullptr, r, nullptr, pna};
+    A.c = dc;
+    return run_reduce<RED_AXPY_NRM2_JACU>(A, result, w, false, s);
+}
+// result[0] = number of x[i] that differ from `a` in any bit (0: the vector is uniform)
+extern "C" int liship_count_ne_f64(int n, const double *x, double a, double *result, void *w, void *s)
+{
+    RedArgs A{n, a, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return run_reduce<RED_COUNT_NE>(A, result, w, false, s);
 }
 // BiCGSTAB without a preconditioner: x += (*palpha)*phat + (*pomega)*s ; r = s + (*pnomega)*t ; result = {sum r^2, sum rtld*r}
 // (s is the residual array before the pass, r after it): liship_axpy2_dev_f64 + liship_axpy_sumsq_dot_dev_f64 in one pass

@@ -146,3 +146,22 @@ def test_print_out_lines_are_the_same(lib, capfd):
         libc.fflush(None)                               # the library prints through C stdio
         texts.append(capfd.readouterr().out)
     assert texts[0] == texts[1] and "relative residual" in texts[0]
+
+
+def test_cg_jacobi_uniform_and_varying_diagonal(lib):
+    """CG + Jacobi in the device-driven loop takes 1/diag as ONE double when the diagonal is constant (the 7-point stencil: 6) and
+    reads the array when it is not; either way the host-scalar loop, which always reads the array, must leave the same bits"""
+    ptr, idx, val = orc.poisson3d(15, 14, 9)
+    n = len(ptr) - 1
+    b = np.random.default_rng(8).uniform(-1, 1, n)
+    a = same(run_modes(lib, ptr, idx, val, b, "-i cg -p jacobi -tol 1e-12 -maxiter 400 -print mem"))
+    assert a["status"] == 0
+    val = val.copy()
+    rows = np.repeat(np.arange(n), np.diff(ptr))
+    val[idx == rows] += np.random.default_rng(9).uniform(0.0, 2.0, n)          # still symmetric positive definite
+    a = same(run_modes(lib, ptr, idx, val, b, "-i cg -p jacobi -tol 1e-12 -maxiter 400 -print mem"))
+    assert a["status"] == 0
+    val[idx == rows] = 6.0
+    val[ptr[n // 2] + int(np.flatnonzero(idx[ptr[n // 2]:ptr[n // 2 + 1]] == n // 2)[0])] = np.nextafter(6.0, 7.0)   # one ulp in one row
+    a = same(run_modes(lib, ptr, idx, val, b, "-i cg -p jacobi -tol 1e-12 -maxiter 400 -print mem"))
+    assert a["status"] == 0

@@ -984,3 +984,46 @@ def test_full_size_512_properties(lib):
     check(lib.liship_axpy_f64(n, -2.0, y.ptr, y2.ptr, None))
     assert nrm1(y2) == 0.0
     check(lib.liship_csr_plan_destroy(plan))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 1000, 1 << 20, (1 << 20) + 1])
+def test_uniform_jacobi_passes(lib, n):
+    """the CG passes that take 1/diag as one double give the bits of the passes that read an array holding that double everywhere,
+    and liship_count_ne_f64 counts the elements that differ from it in any bit (-0.0 against 0.0 included)"""
+    rng = np.random.default_rng(n)
+    dc = 1.0 / 6.0
+    r, p, x, q = (rng.uniform(-1, 1, n) for _ in range(4))
+    scal = DA.from_host(np.array([0.37, -0.81, 0.59]), np.float64)          # alpha, beta, -alpha
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    dinv = DA.from_host(np.full(n, dc), np.float64)
+    res = DA.from_host(np.full(2, np.nan), np.float64)
+    check(lib.liship_count_ne_f64(n, dinv.ptr, dc, res.ptr, work.ptr, None))
+    assert res.to_host()[0] == 0.0
+    bumped = np.full(n, dc)
+    bumped[n // 2] = np.nextafter(dc, 1.0)
+    if n > 2:
+        bumped[0] = -dc
+    dbump, dzero = DA.from_host(bumped, np.float64), DA.from_host(np.full(n, -0.0), np.float64)
+    check(lib.liship_count_ne_f64(n, dbump.ptr, dc, res.ptr, work.ptr, None))
+    assert res.to_host()[0] == (2.0 if n > 2 else 1.0)
+    check(lib.liship_count_ne_f64(n, dzero.ptr, 0.0, res.ptr, work.ptr, None))
+    assert res.to_host()[0] == float(n)
+    outs = []
+    for uniform in (0, 1):
+        dr, dp, dx, dq = (DA.from_host(v, np.float64) for v in (r, p, x, q))
+        ss = scal.ptr
+        for first in (1, 0):                     # the first iteration's form (no x update), then the general one
+            pa = None if first else ss
+            if uniform:
+                check(lib.liship_cg_direction_uniform_dev_f64(n, pa, ss + 8, dr.ptr, dc, dp.ptr, dx.ptr, None))
+            else:
+                check(lib.liship_cg_direction_dev_f64(n, pa, ss + 8, dr.ptr, dinv.ptr, dp.ptr, dx.ptr, None))
+        res = DA.from_host(np.full(2, np.nan), np.float64)
+        if uniform:
+            check(lib.liship_cg_residual_jacobi_uniform_dev_f64(n, ss + 16, dq.ptr, dc, dr.ptr, res.ptr, work.ptr, None))
+        else:
+            check(lib.liship_cg_residual_jacobi_dev_f64(n, ss + 16, dq.ptr, dinv.ptr, dr.ptr, res.ptr, work.ptr, None))
+        outs.append((dp.to_host(), dx.to_host(), dr.to_host(), res.to_host()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(outs[0][1], x) and not np.array_equal(outs[0][2], r)       # the passes did run

@@ -1027,7 +1027,7 @@ void spmv_csr_valuerec_kernel(const unsigned char *__restrict__ rowpat, const v4
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const double acc0 = RW.acc0;
-    __shared__ double dot_scratch[BLOCK / WAVE];
+    __shared__ double dot_scratch[2 * K * (BLOCK / WAVE)];
     __shared__ __attribute__((aligned(16))) v4i32 recL[6 * PAT7_MAX];     // 96 B per pattern: 7 byte offsets + length, 7 values
     const int tid = (int)threadIdx.x;
     for (int t = tid; t < 6 * npat; t += BLOCK) recL[t] = rec[t];
@@ -1099,10 +1099,20 @@ void spmv_csr_valuerec_kernel(const unsigned char *__restrict__ rowpat, const v4
             dots[h].add_loaded(wv, acc);
         }
     }
+    if (DOT != 0) {                                   // the K blocks' partials behind ONE barrier; per block the order of publish_dots:
+        const int lane = tid & (WAVE - 1), w = tid / WAVE, stride = pstride ? pstride : nb;      // wave butterfly, then the waves in order
 #pragma unroll
-    for (int h = 0; h < K; h++) {
-        if (lb0 + h < nb) publish_dots<BLOCK, DOT>(dots[h], dot_scratch, partial, lb0 + h, pstride ? pstride : nb);
-        if (DOT != 0 && h + 1 < K) __syncthreads();
+        for (int h = 0; h < K; h++) {
+            const double s0 = wave_sum(dots[h].c0), s1 = DOT >= 2 ? wave_sum(dots[h].c1) : 0.0;
+            if (lane == 0) { dot_scratch[(2 * h) * (BLOCK / WAVE) + w] = s0; if (DOT >= 2) dot_scratch[(2 * h + 1) * (BLOCK / WAVE) + w] = s1; }
+        }
+        __syncthreads();
+        if (tid < 2 * K && lb0 + tid / 2 < nb && (DOT >= 2 || (tid & 1) == 0)) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < BLOCK / WAVE; i++) t += dot_scratch[tid * (BLOCK / WAVE) + i];
+            partial[(size_t)(tid & 1) * stride + lb0 + tid / 2] = t;
+        }
     }
 }
 

@@ -329,6 +329,83 @@ static LIS_INT upload_jad_as_csr(LIS_MATRIX A, lisd_mat *d)
 	return err;
 }
 
+/* ELL and DIA matrices with constant coefficients.  Both formats add the terms of a row in a fixed order from 0 -- ELL its maxnzr
+ * slots, padding included (value 0, index i: lis_matvec_ell.c:113-128), DIA its diagonals in ascending order over the rows where
+ * i + offset stays inside the matrix, explicit zeros included (lis_matvec_dia.c:148-172) -- so a CSR layout that lists exactly
+ * those terms, zeros and all, in that order, gives the CSR kernel the same sums bit for bit (0 * x[i] is kept: it is NaN when x[i]
+ * is not finite, as in the reference).  The layout pays when the plan then finds value records (liship.h): a constant-coefficient
+ * stencil in ELL or DIA streams 100 or 72 B per row, its row form one byte per row.  A cheap screen (few distinct values among the
+ * first entries) keeps every other matrix away from the attempt; when the plan finds no value records the row form is dropped and
+ * the native arrays are uploaded as before.  *taken says which. */
+static int few_distinct_values(const double *v, size_t count)
+{
+	unsigned long long seen[8];
+	int ns = 0;
+	const size_t lim = count < 65536 ? count : 65536;
+	for (size_t k = 0; k < lim; k++) {
+		unsigned long long b;
+		memcpy(&b, v + k, 8);
+		int j = 0;
+		while (j < ns && seen[j] != b) j++;
+		if (j == ns) { if (ns == 8) return 0; seen[ns++] = b; }
+	}
+	return 1;
+}
+
+static LIS_INT try_row_form(LIS_MATRIX A, lisd_mat *d, int *taken)
+{
+	*taken = 0;
+	const int n = A->n;
+	if (lisg.no_value_records || lisg.no_row_patterns || lisg.no_index_codes || n <= 0) return LIS_SUCCESS;
+	const int width = A->matrix_type == LIS_MATRIX_ELL ? A->maxnzr : A->nnd;
+	if (width < 1 || width > 7 || (long long)n * width >= 0x7fffffffLL) return LIS_SUCCESS;     /* value records hold 7 entries per row */
+	if (!few_distinct_values(A->value, (size_t)n * (size_t)width)) return LIS_SUCCESS;
+	int *cptr = (int *)malloc(sizeof(int) * ((size_t)n + 1));
+	if (!cptr) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "row form\n");
+	const int T = lisi_host_threads();
+	const long long ncols = A->np;
+	if (A->matrix_type == LIS_MATRIX_ELL) {
+		for (int i = 0; i <= n; i++) cptr[i] = i * width;
+	} else {
+		cptr[0] = 0;
+		for (int i = 0; i < n; i++) {                 /* the diagonals that reach row i: 0 <= i + offset < np (lis_matvec_dia.c:154-160) */
+			int c = 0;
+			for (int k = 0; k < width; k++) { const long long j = (long long)i + A->index[k]; c += (j >= 0 && j < ncols); }
+			cptr[i + 1] = cptr[i] + c;
+		}
+	}
+	const size_t nnz = (size_t)cptr[n];
+	int *cidx = (int *)malloc(sizeof(int) * (nnz ? nnz : 1));
+	double *cval = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+	if (!cidx || !cval) { free(cptr); free(cidx); free(cval); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "row form\n"); }
+	if (A->matrix_type == LIS_MATRIX_ELL) {
+#pragma omp parallel for num_threads(T) schedule(static)
+		for (int i = 0; i < n; i++)
+			for (int j = 0; j < width; j++) { cidx[(size_t)i * width + j] = A->index[(size_t)j * n + i]; cval[(size_t)i * width + j] = A->value[(size_t)j * n + i]; }
+	} else {
+#pragma omp parallel for num_threads(T) schedule(static)
+		for (int i = 0; i < n; i++) {
+			int at = cptr[i];
+			for (int k = 0; k < width; k++) {
+				const long long j = (long long)i + A->index[k];
+				if (j >= 0 && j < ncols) { cidx[at] = (int)j; cval[at] = A->value[(size_t)k * n + i]; at++; }
+			}
+		}
+	}
+	LIS_INT err = up_i(&d->ptr, cptr, (size_t)n + 1);
+	if (!err) err = up_i(&d->index, cidx, nnz);
+	if (!err) err = up_d(&d->value, cval, nnz);
+	if (!err) { int rc = liship_stream_synchronize(lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
+	free(cptr); free(cidx); free(cval);
+	if (!err) err = lisd_csr_plan(&d->plan, n, d->ptr, d->index, d->value);
+	if (!err && liship_csr_plan_value_records(d->plan)) { *taken = 1; d->type = LIS_MATRIX_CSR; d->nnz = (LIS_INT)nnz; return LIS_SUCCESS; }
+	if (d->plan) { (void)liship_csr_plan_destroy(d->plan); d->plan = NULL; }          /* not this matrix: the native layout */
+	(void)liship_free(d->ptr); (void)liship_free(d->index); (void)liship_free(d->value);
+	d->ptr = NULL; d->index = NULL; d->value = NULL;
+	if (err == LIS_ERR_OUT_OF_MEMORY) err = LIS_SUCCESS;   /* an optimisation: out of memory on the way is not an error */
+	return err;
+}
+
 /* A split matrix (lis_split.c) lives in HBM as CSR rows that list the terms of a row in the order the reference's is_splited
  * branch adds them -- D x first -- and the kernels start the sum at -0.0, which makes the first product the initial value
  * (t0 = D[i]*x[i]; t0 += ...: lis_matvec_csr.c:70-87) bit for bit, signed zeros included.  JAD is not one chain:
@@ -411,6 +488,7 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 		break;
 	case LIS_MATRIX_ELL:
 		d->maxnzr = A->maxnzr;
+		{ int taken = 0; LISCHK(try_row_form(A, d, &taken)); if (taken) break; }
 		LISCHK(up_i(&d->index, A->index, n * (size_t)A->maxnzr));
 		LISCHK(up_d(&d->value, A->value, n * (size_t)A->maxnzr));
 		if (!lisg.no_index_codes) {
@@ -422,6 +500,7 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 		break;
 	case LIS_MATRIX_DIA:
 		d->nnd = A->nnd;
+		{ int taken = 0; LISCHK(try_row_form(A, d, &taken)); if (taken) break; }
 		LISCHK(up_i(&d->index, A->index, (size_t)A->nnd));
 		LISCHK(up_d(&d->value, A->value, n * (size_t)A->nnd));
 		break;

@@ -1240,6 +1240,65 @@ __global__ void csr_check_values(int n, const int *__restrict__ ptr, const doubl
     if (!ok) atomicAdd(bad, 1);
 }
 
+// Refinement: rows of one offset pattern that carry DIFFERENT values (a Dirichlet row stored with the interior row's sparsity, the
+// explicit zeros of a DIA matrix) split the pattern.  One hash per row over (pattern, value bits), the distinct ones with their
+// smallest row in the open-addressing table of the offset patterns' collector; gives up beyond 255.
+__device__ __forceinline__ unsigned long long value_row_hash(int pat, const double *val, int s, int e)
+{
+    unsigned long long h = 1469598103934665603ull ^ (unsigned long long)(pat + 1);
+    for (int k = s; k < e; k++) { h ^= (unsigned long long)__double_as_longlong(val[k]); h *= 1099511628211ull; h ^= h >> 29; }
+    return h | 1ull;
+}
+__global__ void csr_collect_value_patterns(int n, const int *__restrict__ ptr, const double *__restrict__ val,
+                                           const unsigned char *__restrict__ rowpat, unsigned long long *__restrict__ keys,
+                                           int *__restrict__ rep, int *__restrict__ count)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || count[0] > 255) return;
+    const unsigned long long h = value_row_hash(rowpat[r], val, ptr[r], ptr[r + 1]);
+    unsigned slot = (unsigned)(h >> 40) & (PAT_SLOTS - 1);
+    for (int probe = 0; probe < PAT_SLOTS; probe++) {
+        unsigned long long v = keys[slot];
+        if (v == 0ull) {
+            v = atomicCAS(&keys[slot], 0ull, h);
+            if (v == 0ull) { atomicAdd(count, 1); v = h; }
+        }
+        if (v == h) { if (r < rep[slot]) atomicMin(&rep[slot], r); return; }
+        slot = (slot + 1) & (PAT_SLOTS - 1);
+        if (count[0] > 255) return;
+    }
+}
+// per refined pattern: the offset pattern of its representative row and that row's values
+__global__ void csr_fetch_value_patterns(int npat, const int *__restrict__ rep, const int *__restrict__ ptr, const double *__restrict__ val,
+                                         const unsigned char *__restrict__ rowpat, int *__restrict__ oldpat, double *__restrict__ vrec)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npat) return;
+    const int s = ptr[rep[p]], e = ptr[rep[p] + 1];
+    oldpat[p] = rowpat[rep[p]];
+    for (int j = 0; j < 8; j++) vrec[8 * p + j] = (s + j < e && j < 7) ? val[s + j] : 0.0;
+}
+// every row -> its refined pattern (position of its hash in the sorted list; offset pattern and values verified)
+__global__ void csr_encode_value_patterns(int n, const int *__restrict__ ptr, const double *__restrict__ val,
+                                          const unsigned char *__restrict__ rowpat, int npat, const unsigned long long *__restrict__ hashes,
+                                          const int *__restrict__ oldpat, const double *__restrict__ vrec,
+                                          unsigned char *__restrict__ out, int *__restrict__ bad)
+{
+    __shared__ unsigned long long hL[256];
+    for (int i = threadIdx.x; i < npat; i += blockDim.x) hL[i] = hashes[i];
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int s = ptr[r], e = ptr[r + 1], op = rowpat[r];
+    const unsigned long long h = value_row_hash(op, val, s, e);
+    int lo = 0, hi = npat - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (hL[mid] < h) lo = mid + 1; else hi = mid; }
+    bool ok = hL[lo] == h && oldpat[lo] == op && e - s <= 7;
+    for (int k = s; ok && k < e; k++) ok = __double_as_longlong(val[k]) == __double_as_longlong(vrec[8 * lo + (k - s)]);
+    if (!ok) atomicAdd(bad, 1);
+    out[r] = (unsigned char)lo;
+}
+
 } // namespace
 
 struct liship_csr_plan_s {
@@ -1538,6 +1597,87 @@ extern "C" int liship_csr_plan_row_patterns(liship_csr_plan_t p) { return (p && 
 extern "C" int liship_csr_plan_pattern_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8) ? 1 : 0; }
 extern "C" int liship_spmv_csr_set_row_patterns(int on) { g_row_patterns = on ? 1 : 0; return 0; }
 
+// the 96 B records (32 B offsets + length, 64 B values) of npat patterns -> p->vrec
+static int install_value_records(liship_csr_plan_s *p, int npat, const int *rec32, const double *val8)
+{
+    unsigned char img[PAT7_MAX * 96];
+    for (int i = 0; i < npat; i++) { memcpy(img + 96 * i, rec32 + 8 * i, 32); memcpy(img + 96 * i + 32, val8 + 8 * i, 64); }
+    hipError_t e = hipMalloc(&p->vrec, 96 * (size_t)npat);
+    if (e == hipSuccess) e = hipMemcpy(p->vrec, img, 96 * (size_t)npat, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { if (p->vrec) (void)hipFree(p->vrec); p->vrec = nullptr; return (int)e; }
+    return 0;
+}
+
+// Split the offset patterns by the values their rows carry (see csr_collect_value_patterns).  On success the plan's pattern
+// bytes, pattern table, 32 B records and value records are all replaced by the refined set (more patterns, some with the same
+// offsets), so that every kernel that reads the pattern bytes keeps working; otherwise nothing changes.  old32: the 32 B records
+// of the current patterns (host).
+static int refine_patterns_by_values(liship_csr_plan_s *p, const int *ptr, const double *val, const int *old32, hipStream_t st)
+{
+    struct Table { unsigned long long keys[PAT_SLOTS]; int rep[PAT_SLOTS]; int count; };
+    Table *host = (Table *)malloc(sizeof(Table)), *dev = nullptr;
+    if (!host) return 0;
+    memset(host, 0, sizeof(Table));
+    for (int i = 0; i < PAT_SLOTS; i++) host->rep[i] = 0x7fffffff;
+    int rc = 0;
+#define PT(expr) do { if (rc == 0) { hipError_t e__ = (expr); if (e__ != hipSuccess) rc = (int)e__; } } while (0)
+    PT(hipMalloc(&dev, sizeof(Table)));
+    PT(hipMemcpyAsync(dev, host, sizeof(Table), hipMemcpyHostToDevice, st));
+    if (rc == 0) { csr_collect_value_patterns<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, val, p->rowpat, dev->keys, dev->rep, &dev->count); PT(hipGetLastError()); }
+    PT(hipMemcpyAsync(host, dev, sizeof(Table), hipMemcpyDeviceToHost, st));
+    PT(hipStreamSynchronize(st));
+    if (dev) (void)hipFree(dev);
+    if (rc != 0 || host->count <= 0 || host->count > PAT7_MAX) { free(host); return rc; }
+    int npat = 0, order[PAT7_MAX];
+    for (int i = 0; i < PAT_SLOTS && npat < PAT7_MAX; i++) if (host->keys[i] != 0ull) order[npat++] = i;
+    for (int i = 1; i < npat; i++) { const int v = order[i]; int j = i - 1; while (j >= 0 && host->keys[order[j]] > host->keys[v]) { order[j + 1] = order[j]; j--; } order[j + 1] = v; }
+    unsigned long long hashes[PAT7_MAX]; int reps[PAT7_MAX], oldpat[PAT7_MAX], bad = 1;
+    double hv[PAT7_MAX * 8];
+    for (int i = 0; i < npat; i++) { hashes[i] = host->keys[order[i]]; reps[i] = host->rep[order[i]]; }
+    free(host);
+    unsigned long long *d_hash = nullptr; int *d_rep = nullptr, *d_old = nullptr, *d_bad = nullptr; double *d_v = nullptr; unsigned char *newpat = nullptr;
+    PT(hipMalloc(&d_hash, sizeof(hashes))); PT(hipMalloc(&d_rep, sizeof(reps))); PT(hipMalloc(&d_old, sizeof(oldpat)));
+    PT(hipMalloc(&d_bad, sizeof(int))); PT(hipMalloc(&d_v, sizeof(hv))); PT(hipMalloc(&newpat, (size_t)p->n + 64));
+    PT(hipMemcpyAsync(d_hash, hashes, sizeof(unsigned long long) * npat, hipMemcpyHostToDevice, st));
+    PT(hipMemcpyAsync(d_rep, reps, sizeof(int) * npat, hipMemcpyHostToDevice, st));
+    PT(hipMemsetAsync(d_bad, 0, sizeof(int), st));
+    if (rc == 0) { csr_fetch_value_patterns<<<1, 64, 0, st>>>(npat, d_rep, ptr, val, p->rowpat, d_old, d_v); PT(hipGetLastError()); }
+    if (rc == 0) {
+        csr_encode_value_patterns<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, val, p->rowpat, npat, d_hash, d_old, d_v, newpat, d_bad);
+        PT(hipGetLastError());
+    }
+    PT(hipMemcpyAsync(oldpat, d_old, sizeof(int) * npat, hipMemcpyDeviceToHost, st));
+    PT(hipMemcpyAsync(hv, d_v, sizeof(double) * 8 * npat, hipMemcpyDeviceToHost, st));
+    PT(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    PT(hipStreamSynchronize(st));
+    (void)hipFree(d_hash); (void)hipFree(d_rep); (void)hipFree(d_old); (void)hipFree(d_bad); (void)hipFree(d_v);
+    // the refined tables: pattern i has the offsets of offset pattern oldpat[i]
+    int rec[PAT7_MAX * 8], tab[PAT7_MAX + 1 + PAT7_MAX * 7], total = 0, *d_tab = nullptr; v4i32 *d_rec = nullptr;
+    if (rc == 0 && bad == 0) {
+        for (int i = 0; i < npat; i++) {
+            memcpy(rec + 8 * i, old32 + 8 * oldpat[i], 32);
+            tab[i] = total;
+            total += rec[8 * i + 7];
+        }
+        tab[npat] = total;
+        int at = npat + 1;
+        for (int i = 0; i < npat; i++) for (int j = 0; j < rec[8 * i + 7]; j++) tab[at++] = rec[8 * i + j] / 8;     // the general table holds element offsets
+        PT(hipMalloc(&d_tab, sizeof(int) * (size_t)(npat + 1 + total)));
+        PT(hipMalloc(&d_rec, sizeof(int) * 8 * (size_t)npat));
+        PT(hipMemcpy(d_tab, tab, sizeof(int) * (size_t)(npat + 1 + total), hipMemcpyHostToDevice));
+        PT(hipMemcpy(d_rec, rec, sizeof(int) * 8 * (size_t)npat, hipMemcpyHostToDevice));
+    }
+#undef PT
+    if (rc != 0 || bad != 0) { if (newpat) (void)hipFree(newpat); if (d_tab) (void)hipFree(d_tab); if (d_rec) (void)hipFree(d_rec); return rc; }
+    rc = install_value_records(p, npat, rec, hv);
+    if (rc != 0) { (void)hipFree(newpat); (void)hipFree(d_tab); (void)hipFree(d_rec); return rc; }
+    (void)hipFree(p->rowpat); (void)hipFree(p->ptab); (void)hipFree(p->ptab8);
+    p->rowpat = newpat; p->ptab = d_tab; p->ptab8 = d_rec;
+    p->npat = npat; p->ptab_len = npat + 1 + total;
+    for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
+    return 0;
+}
+
 // Value records on top of the pattern records (see spmv_csr_valuerec_kernel): setup-time, optional, never an error when the matrix
 // does not qualify (no 32 B records, or two rows of one pattern with different values).  One pass over ptr / value.
 extern "C" int liship_csr_plan_encode_row_values(liship_csr_plan_t p, const int *ptr, const double *val, void *stream)
@@ -1560,19 +1700,15 @@ extern "C" int liship_csr_plan_encode_row_values(liship_csr_plan_t p, const int 
     (void)hipFree(d_rep); (void)hipFree(d_bad);
     double hv[PAT7_MAX * 8];
     int hr[PAT7_MAX * 8];
-    if (rc == 0 && bad == 0) {                       // the combined records: 32 B (offsets, length) + 64 B (values) per pattern
+    if (rc == 0) {
         hipError_t e = hipMemcpy(hv, vr, sizeof(double) * 8 * (size_t)p->npat, hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(hr, p->ptab8, sizeof(int) * 8 * (size_t)p->npat, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = (int)e;
     }
     if (vr) (void)hipFree(vr);
-    if (rc != 0 || bad != 0) return rc;
-    unsigned char img[PAT7_MAX * 96];
-    for (int i = 0; i < p->npat; i++) { memcpy(img + 96 * i, hr + 8 * i, 32); memcpy(img + 96 * i + 32, hv + 8 * i, 64); }
-    hipError_t e = hipMalloc(&p->vrec, 96 * (size_t)p->npat);
-    if (e == hipSuccess) e = hipMemcpy(p->vrec, img, 96 * (size_t)p->npat, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { if (p->vrec) (void)hipFree(p->vrec); p->vrec = nullptr; return (int)e; }
-    return 0;
+    if (rc != 0) return rc;
+    if (bad != 0) return refine_patterns_by_values(p, ptr, val, hr, st);     // rows of one offset pattern with different values
+    return install_value_records(p, p->npat, hr, hv);
 }
 // 1 when the plan keeps the rows' values in the pattern records (the products then read neither values nor indices), else 0
 extern "C" int liship_csr_plan_value_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8 && p->vrec) ? 1 : 0; }

@@ -203,19 +203,32 @@ def cyclic_diagonals(n, count, seed):
 # row patterns the plan must find on top of the codes: 3 for the 1-D stencil (first row, interior, last row), 27 for the 3-D one
 ROW_PATTERNS = {"p1d_10000": 3, "p3d_20x17x13": 27, "p3d_64_sorted": 27, "p3d_40_sorted": 27, "p3d_odd_33x7x5": 27, "diagonals_255": 255,
                 "diagonals_300": 0, "rand_5000": 0, "wide_77": 0,        # diagonals_255: 254 two-entry rows + the rows whose second entry falls outside
-                "p1d_9999": 3, "p3d_holes": 27, "p3d_varcoef": 27}            # p3d_holes: the empty row is one more pattern, a corner row that lost its entries one fewer
+                "p1d_9999": 3, "p3d_holes": 27, "p3d_varcoef": 27, "p3d_dirichlet": 27}            # p3d_holes: the empty row is one more pattern, a corner row that lost its entries one fewer
 # ... and whether it also keeps them as 32 B records (1..7 offsets per pattern, at most 64 patterns: spmv_csr_pattern7_kernel)
 # ... and whether every row of a pattern also carries the same values (then the records hold them: spmv_csr_valuerec_kernel)
 VALUE_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
-                 "p3d_varcoef": 0, "p3d_holes": 0, "diagonals_255": 0, "band_9_unsorted": 0}
+                 "p3d_varcoef": 0, "p3d_holes": 0, "diagonals_255": 0, "band_9_unsorted": 0,
+                 "p3d_dirichlet": 1}         # ... after the offset patterns were split by the values their rows carry
 PATTERN_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
-                   "diagonals_255": 0, "p3d_holes": 0, "band_9_unsorted": 0, "rand_5000": 0, "p3d_varcoef": 1}
+                   "diagonals_255": 0, "p3d_holes": 0, "band_9_unsorted": 0, "rand_5000": 0, "p3d_varcoef": 1, "p3d_dirichlet": 1}
 
 
 def poisson3d_variable_coefficients(nx, ny, nz, seed):
     """the 3-D stencil's pattern with random values: pattern records, but no value records"""
     ptr, idx, val = orc.poisson3d(nx, ny, nz)
     return ptr, idx, np.random.default_rng(seed).uniform(-1, 1, len(val))
+
+
+def poisson3d_with_dirichlet_rows(nx, ny, nz, every):
+    """the 3-D stencil where every `every`-th row is an identity row stored with the stencil's sparsity (1 on the diagonal, explicit
+    zeros beside it) -- how boundary conditions are often imposed: the same offset patterns, two value sets for some of them"""
+    ptr, idx, val = orc.poisson3d(nx, ny, nz)
+    val = val.copy()
+    n = len(ptr) - 1
+    for r in range(0, n, every):
+        seg = slice(ptr[r], ptr[r + 1])
+        val[seg] = np.where(idx[seg] == r, 1.0, 0.0)
+    return ptr, idx, val
 
 
 def poisson3d_with_empty_rows(nx, ny, nz, every):
@@ -236,6 +249,7 @@ CODED_CASES = {
     "p3d_20x17x13": (lambda: orc.poisson3d(20, 17, 13), 7),
     "p3d_holes": (lambda: poisson3d_with_empty_rows(24, 20, 16, 37), 7),
     "p3d_varcoef": (lambda: poisson3d_variable_coefficients(24, 20, 16, 5), 7),
+    "p3d_dirichlet": (lambda: poisson3d_with_dirichlet_rows(24, 20, 16, 11), 7),
     "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
     "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
     "p3d_40_sorted": (lambda: orc.poisson3d(40, 40, 40, sort_cols=True), 7),                # several row blocks

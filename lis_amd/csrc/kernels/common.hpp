@@ -35,11 +35,42 @@ __device__ __forceinline__ T load_stream(const T *p) { return __builtin_nontempo
 template <typename T>
 __device__ __forceinline__ void store_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
 
-// sum across the 64 lanes of a wavefront, fixed butterfly order (result valid in every lane)
+// the value of lane (i ^ off) in lane i, for off = 8, 4, 2, 1, by data-parallel-primitive moves inside a row of 16 lanes (no LDS
+// permute): row_ror:8 IS i ^ 8; i ^ 4 is lane i + 4 for the banks of 4 lanes {0, 2} and lane i - 4 for the banks {1, 3};
+// i ^ 2 and i ^ 1 are quad permutes.  All lanes must be active.
+template <int OFF>
+__device__ __forceinline__ double lane_xor_in_row(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (OFF == 8) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false);          // row_ror:8
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false);
+    } else if (OFF == 4) {
+        int l2 = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0x5, false);      // row_shl:4 into banks 0 and 2: lane i + 4
+        int h2 = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0x5, false);
+        lo = __builtin_amdgcn_update_dpp(l2, lo, 0x114, 0xf, 0xa, false);         // row_shr:4 into banks 1 and 3: lane i - 4
+        hi = __builtin_amdgcn_update_dpp(h2, hi, 0x114, 0xf, 0xa, false);
+    } else if (OFF == 2) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4e, 0xf, 0xf, false);           // quad_perm:[2,3,0,1]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4e, 0xf, 0xf, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xb1, 0xf, 0xf, false);           // quad_perm:[1,0,3,2]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xb1, 0xf, 0xf, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// sum across the 64 lanes of a wavefront, fixed butterfly order: partners 32, 16, 8, 4, 2, 1 lanes away, in that order (result
+// valid in every lane).  The first two steps cross the rows of 16 lanes (LDS permute); the last four stay inside a row and use
+// DPP moves of the SAME partner lanes -- the sum is the same in every bit (tests/golden/reduction_bits.json pins it).
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    v += __shfl_xor(v, 32, WAVE);
+    v += __shfl_xor(v, 16, WAVE);
+    v += lane_xor_in_row<8>(v);
+    v += lane_xor_in_row<4>(v);
+    v += lane_xor_in_row<2>(v);
+    v += lane_xor_in_row<1>(v);
     return v;
 }
 

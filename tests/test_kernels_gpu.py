@@ -1041,3 +1041,21 @@ def test_uniform_jacobi_passes(lib, n):
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
     assert not np.array_equal(outs[0][1], x) and not np.array_equal(outs[0][2], r)       # the passes did run
+
+
+def test_reduction_order_is_pinned(lib):
+    """tests/golden/reduction_bits.json (made on an MI355X by this library: make_golden_reduction_bits.py) holds the bits of dot,
+    sum of squares, the two-result dot and the reduction epilogue of the CSR product on seeded inputs.  The order of these
+    reductions -- wavefront butterfly, wavefronts of a workgroup in order, tree fold over the partials -- is part of what the
+    Krylov iteration counts hang on: a kernel change that is meant to keep it must reproduce every bit."""
+    import importlib.util
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden_reduction_bits", os.path.join(here, "golden", "make_golden_reduction_bits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "golden", "reduction_bits.json")))
+    got = mod.measure(lib)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k] == want[k], k

@@ -437,11 +437,12 @@ def usable_cores():
 
 def cpu_baseline(np):
     """The reference's OpenMP CSR SpMV (oracle/_ref = Lis 2.1.11 compiled from its own sources) on this box's host
-    cores, on a bounded sample: 256^3 rows of the same stencil (1/8 of the 512^3 workload), 40 products.
+    cores, on a bounded sample: 256^3 rows of the same stencil (1/8 of the 512^3 workload), 600 products (about 5 s of CPU work)
+    and 40 iterations of its CG + Jacobi on the same matrix (iter / itime, as for the GPU).
     Falls back to the oracle's scalar C port when oracle/_ref is not in the snapshot."""
     import lisdrv
     import orc
-    Nc, reps = 256, 40
+    Nc, reps = 256, 600
     cores = usable_cores()
     model = "unknown"
     try:
@@ -464,6 +465,12 @@ def cpu_baseline(np):
                 ref.lis_matvec(A, vx, vy)
             el = time.perf_counter() - t0
             kind, used = "reference", cores
+            try:                                          # the reference's own CG + Jacobi, iterations per second by its own clock
+                b = orc.spmv_csr(ptr, idx, val, np.ones(n))
+                out = lisdrv.solve(ref, A, b, "-i cg -p jacobi -tol 1e-30 -maxiter 40")
+                cg = round(min(out["iter"], 40) / out["itime"], 2) if out.get("itime") else None
+            except Exception:
+                cg = None
         else:
             x = np.ones(n)
             orc.spmv_csr(ptr, idx, val, x)
@@ -471,9 +478,10 @@ def cpu_baseline(np):
             for _ in range(reps):
                 orc.spmv_csr(ptr, idx, val, x)
             el = time.perf_counter() - t0
-            kind, used = "port", 1
+            kind, used, cg = "port", 1, None
         return {"value": round(2.0 * len(idx) * reps / el / 1e9, 3), "unit": "GFLOP/s", "cores": used, "kind": kind, "cpu_model": model,
-                "sample": f"{reps} CSR SpMV on the {Nc}^3 stencil matrix (1/8 of the workload's rows), lis_matvec of Lis 2.1.11 with OpenMP"
+                "cg_jacobi_iters_per_sec": cg,
+                "sample": f"{reps} CSR SpMV on the {Nc}^3 stencil matrix (1/8 of the workload's rows), lis_matvec of Lis 2.1.11 with OpenMP; cg_jacobi_iters_per_sec: 40 iterations of its lis_solve on the same matrix (256^3: 1/8 of the rows per iteration)"
                 if kind == "reference" else f"{reps} CSR SpMV on the {Nc}^3 stencil matrix, scalar C port (oracle/lis_oracle.c)"}
     except Exception as e:                                 # the baseline must never sink the bench line
         return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}

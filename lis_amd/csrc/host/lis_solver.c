@@ -1029,11 +1029,11 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	lisg.last_uniform_jacobi = 0;
 	if (precon && precon->precon_type == LIS_PRECON_TYPE_JACOBI) {
 		if ((err = lisd_vec_in(precon->D, &c.dinv))) goto out;
-		if (nsolver == LIS_SOLVER_CG && !lisg.no_uniform_jacobi && A->n > 0) {
+		if (nsolver == LIS_SOLVER_CG && !lisg.no_uniform_jacobi) {        /* (every rank: the count below is a collective) */
 			/* a constant diagonal (constant-coefficient stencils): z = r.*dinv is r*dinv[0] in every bit, and the fused CG passes
 			 * need not read the array -- one counting pass per solve decides (all ranks: the count is folded like any sum) */
 			double d0 = 0.0, differ = 1.0;
-			int rc = liship_memcpy_d2h(&d0, c.dinv, sizeof(double), lisg.stream);
+			int rc = A->n > 0 ? liship_memcpy_d2h(&d0, c.dinv, sizeof(double), lisg.stream) : 0;
 			if (!rc) rc = liship_stream_synchronize(lisg.stream);
 			if (!rc) rc = liship_count_ne_f64(A->n, c.dinv, d0, lisg.reduce_out, lisg.reduce_work, lisg.stream);
 			if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }

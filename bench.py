@@ -212,7 +212,8 @@ def main():
     moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, values)     # records hold them, neither values nor indices are streamed
 
     def kernel_name(v):
-        return ("spmv_csr_valuerec_kernel" if patterns and records and v else "spmv_csr_pattern7_kernel" if patterns and records else
+        pair = n_local * 8 > (256 << 20)                  # x beyond the Infinity Cache: the two-rows-per-lane form of the plain product
+        return (("spmv_csr_valuerec_pair_kernel" if pair else "spmv_csr_valuerec_kernel") if patterns and records and v else "spmv_csr_pattern7_kernel" if patterns and records else
                 "spmv_csr_pattern_kernel" if patterns else "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,

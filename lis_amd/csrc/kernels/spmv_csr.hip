@@ -57,6 +57,7 @@ constexpr int SLACK = 128;       // extra items a block may take to start on an 
 //   bit8  ablation: skip the x gather  (WRONG results, timing only)
 //   bit10 register staging instead of LDS-DMA   bits11-12 gather unroll U: 0 auto, 1: 4, 2: 7, 3: 8
 //   bit13 (0x2000) row patterns through the general kernel (table in LDS) even when the plan has 32 B records
+//   bit14 (0x4000) value records: the two-rows-per-lane kernel whatever the size (tests; by default only beyond 256 MB of x)
 int g_variant = 0;
 int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps every product on the 4 B indices
 int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
@@ -1038,8 +1039,13 @@ void spmv_csr_valuerec_kernel(const unsigned char *__restrict__ rowpat, const v4
     int r[K], r1[K], pat[K];
 #pragma unroll
     for (int h = 0; h < K; h++) {
-        const Blk B = lb0 + h < nb ? load_blk(blk, bfirst + lb0 + h) : Blk{0, 0, 0, 0};
-        r[h] = max(B.r0, RW.rb) + tid; r1[h] = min(B.r1, RW.re);    // only the rows matter here
+        if (DOT == 0) {                                 // the plain product owes nobody a partial per row block: chunks of BLOCK rows by
+            const long long c0 = (long long)RW.rb + (long long)(lb0 + h) * BLOCK;          // arithmetic, one dependent load fewer
+            r[h] = (int)min(c0, (long long)RW.re) + tid; r1[h] = (int)min(c0 + BLOCK, (long long)RW.re);
+        } else {
+            const Blk B = lb0 + h < nb ? load_blk(blk, bfirst + lb0 + h) : Blk{0, 0, 0, 0};
+            r[h] = max(B.r0, RW.rb) + tid; r1[h] = min(B.r1, RW.re);    // only the rows matter here
+        }
     }
 #pragma unroll
     for (int h = 0; h < K; h++) pat[h] = r[h] < r1[h] ? (int)rowpat[r[h]] : -1;
@@ -1112,6 +1118,84 @@ void spmv_csr_valuerec_kernel(const unsigned char *__restrict__ rowpat, const v4
 #pragma unroll
             for (int i = 0; i < BLOCK / WAVE; i++) t += dot_scratch[tid * (BLOCK / WAVE) + i];
             partial[(size_t)(tid & 1) * stride + lb0 + tid / 2] = t;
+        }
+    }
+}
+
+// The plain product with value records, two rows per lane.  The counters say what binds the kernel above (profiles/
+// r02_valuerec_kernel_pmc.txt): 19 vector-memory instructions per wavefront, each of which the texture addresser takes apart
+// in 16 quads of lanes whatever it hits -- 62 % of the kernel's cycles, TA busy 84 % -- while VALU is busy 20 % of the time and
+// the x traffic is not felt at all.  An 8 B access per lane uses half of what a quad can carry.  So a lane takes the rows 2p and
+// 2p + 1: when they share their pattern (all but two pairs per grid line) x[r + o] and x[r + 1 + o] are ONE 16 B load, y[r],
+// y[r + 1] one 16 B store, the two pattern bytes one 2 B load: half the instructions per row.  A pair with two patterns (or a
+// last row without a partner) takes the rows one after the other.  Same products, same order per row: bit-identical.
+template <int BLOCK, int K>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_valuerec_pair_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, int npat,
+                                   const double *__restrict__ x, double *__restrict__ y, Rows RW)
+{
+    const double acc0 = RW.acc0;
+    __shared__ __attribute__((aligned(16))) v4i32 recL[6 * PAT7_MAX];     // 96 B per pattern: 7 byte offsets + length, 7 values
+    const int tid = (int)threadIdx.x;
+    for (int t = tid; t < 6 * npat; t += BLOCK) recL[t] = rec[t];
+    int ra[K], pa[K], pb[K];
+#pragma unroll
+    for (int h = 0; h < K; h++) {                         // pair (ra, ra + 1); pb < 0: no second row
+        const long long c0 = (long long)RW.rb + ((long long)blockIdx.x * K + h) * (2 * BLOCK) + 2 * tid;
+        ra[h] = (int)min(c0, (long long)RW.re);
+        pa[h] = pb[h] = -1;
+        if (ra[h] + 1 < RW.re) {
+            if ((ra[h] & 1) == 0) { const unsigned two = *reinterpret_cast<const unsigned short *>(rowpat + ra[h]); pa[h] = (int)(two & 255u); pb[h] = (int)(two >> 8); }
+            else { pa[h] = rowpat[ra[h]]; pb[h] = rowpat[ra[h] + 1]; }
+        } else if (ra[h] < RW.re) pa[h] = rowpat[ra[h]];
+    }
+    __syncthreads();                                      // the records are in LDS
+    v2f64 xx[K][7];
+#pragma unroll
+    for (int h = 0; h < K; h++) {                         // the paired gathers first: 7 K 16 B loads per lane in flight
+        if (pa[h] >= 0 && pa[h] == pb[h]) {
+            const v4i32 a = recL[6 * pa[h]], b = recL[6 * pa[h] + 1];
+            const int o[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+            const unsigned rb8 = (unsigned)ra[h] * 8u;
+#pragma unroll
+            for (int u = 0; u < 7; u++) xx[h][u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)o[u]));
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < K; h++) {
+        if (pa[h] >= 0 && pa[h] == pb[h]) {
+            const v4i32 b = recL[6 * pa[h] + 1];
+            const v2f64 *q = reinterpret_cast<const v2f64 *>(recL + 6 * pa[h] + 2);
+            const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const double v[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
+            const int len = b.w;
+            double s0 = acc0, s1 = acc0;
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const double t0 = v[u] * xx[h][u].x, t1 = v[u] * xx[h][u].y;
+                s0 += (u < len) ? t0 : -0.0;              // -0.0 terms leave any sum bit-unchanged
+                s1 += (u < len) ? t1 : -0.0;
+            }
+            v2f64 out; out.x = s0; out.y = s1;
+            if ((ra[h] & 1) == 0) store_stream(reinterpret_cast<v2f64 *>(y + ra[h]), out);
+            else { store_stream(y + ra[h], s0); store_stream(y + ra[h] + 1, s1); }
+        } else {
+#pragma unroll
+            for (int w = 0; w < 2; w++) {                 // two patterns in the pair, or a single last row: one row at a time
+                const int pt = w ? pb[h] : pa[h], r = ra[h] + w;
+                if (pt < 0) continue;
+                const v4i32 a = recL[6 * pt], b = recL[6 * pt + 1];
+                const v2f64 *q = reinterpret_cast<const v2f64 *>(recL + 6 * pt + 2);
+                const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const int o[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z}, len = b.w;
+                const double v[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
+                double xv[7], acc = acc0;
+#pragma unroll
+                for (int u = 0; u < 7; u++) xv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned)r * 8u + (unsigned)o[u]));
+#pragma unroll
+                for (int u = 0; u < 7; u++) { const double t = v[u] * xv[u]; acc += (u < len) ? t : -0.0; }
+                store_stream(y + r, acc);
+            }
         }
     }
 }
@@ -1856,10 +1940,17 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
-    if (a.rowpat && a.ptab8 && a.vrec && g_variant == 0) {            // the rows' values ride in the pattern records: one byte per row
+    if (a.rowpat && a.ptab8 && a.vrec && (g_variant & ~0x4000) == 0) {            // the rows' values ride in the pattern records: one byte per row
         constexpr Geometry g = kGeom[G];
-        spmv_csr_valuerec_kernel<g.block, 2, 0><<<(a.nb + 1) / 2, g.block, 0, a.st>>>(
-            a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0});
+        const int chunks = (a.re - a.rb + g.block - 1) / g.block;       // rows [rb, re) in chunks of one workgroup's lanes, two per workgroup
+        // beyond the Infinity Cache (256 MB of x) the two-rows-per-lane form wins (16 B requests: 320^3 +4 %, 448^3 +13 %, 512^3 +7 %);
+        // below it x stays cache-resident from product to product and the one-row form is 15 % faster (tools/valuerec_probe.py)
+        const bool pairs = (g_variant & 0x4000) || (long long)(a.re - a.rb) * 8 > (256ll << 20);
+        if (chunks > 0 && pairs)
+            spmv_csr_valuerec_pair_kernel<g.block, 1><<<(chunks + 1) / 2, g.block, 0, a.st>>>(a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0});
+        else if (chunks > 0)
+            spmv_csr_valuerec_kernel<g.block, 2, 0><<<(chunks + 1) / 2, g.block, 0, a.st>>>(
+                a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, chunks, Rows{a.rb, a.re, a.acc0});
         return;
     }
     if (a.rowpat && a.ptab8 && g_variant == 0) {      // patterns of at most 7 offsets: gathers ahead of the slice
@@ -1983,7 +2074,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
 {
     if (!p || !w || !result || !work) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
-    if ((g_variant & ~0x2000) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    if ((g_variant & ~0x6000) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
     LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
@@ -2026,7 +2117,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
 {
     if (!p || !w || !work || !slots_used || row_begin < 0 || row_end > p->n || slot_base < 0) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
-    if ((g_variant & ~0x2000) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    if ((g_variant & ~0x6000) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     *slots_used = 0;
     if (row_begin >= row_end || p->nblocks == 0) return 0;
     const v2i32 *br = p->blk_host;

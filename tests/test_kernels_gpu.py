@@ -298,11 +298,11 @@ def test_spmv_csr_index_codes(lib, name):
         assert lib.liship_csr_plan_value_records(plan) == VALUE_RECORDS[name]
     assert lib.liship_csr_plan_value_records(plan) <= lib.liship_csr_plan_pattern_records(plan)
     results = {}
-    for on in (4, 3, 2, 1, 0):                 # 4: values in the pattern records too (nothing streamed), 2: one byte per row (patterns;
-        lib.liship_spmv_csr_set_index_codes(1 if on else 0)         # 3: through the general pattern kernel even when the plan has
-        lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)   # 32 B records), 1: one byte per non-zero (codes), 0: 4 B indices
-        lib.liship_spmv_csr_set_row_values(1 if on == 4 else 0)
-        lib.liship_spmv_csr_set_variant(0x2000 if on == 3 else 0)
+    for on in (5, 4, 3, 2, 1, 0):              # 4: values in the pattern records too (nothing streamed; 5: the plain product two rows per
+        lib.liship_spmv_csr_set_index_codes(1 if on else 0)         # lane, the form for x beyond the Infinity Cache), 2: one byte per row
+        lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)   # (patterns; 3: through the general pattern kernel even when the plan has
+        lib.liship_spmv_csr_set_row_values(1 if on >= 4 else 0)     # 32 B records), 1: one byte per non-zero (codes), 0: 4 B indices
+        lib.liship_spmv_csr_set_variant(0x2000 if on == 3 else 0x4000 if on == 5 else 0)
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
         assert np.array_equal(dy.to_host(), yref), on
@@ -345,9 +345,9 @@ def test_spmv_csr_index_codes(lib, name):
     lib.liship_spmv_csr_set_variant(0)
     lib.liship_spmv_csr_set_row_values(1)
     check(lib.liship_csr_plan_destroy(plan))
-    assert len(results[0]) == len(results[1]) == len(results[2]) == len(results[3]) == len(results[4])
-    for a, b, c, d, e in zip(results[0], results[1], results[2], results[3], results[4]):    # same partial sums, same fold: the reductions agree to the bit too
-        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e)
+    assert len({len(results[k]) for k in range(6)}) == 1
+    for parts in zip(*(results[k] for k in range(6))):     # same partial sums, same fold: the reductions agree to the bit too
+        assert all(np.array_equal(parts[0], q) for q in parts[1:])
 
 
 def stack_rows(parts):

@@ -1059,3 +1059,87 @@ def test_reduction_order_is_pinned(lib):
     assert sorted(got) == sorted(want)
     for k in want:
         assert got[k] == want[k], k
+
+
+def _structured_random(seed):
+    """a random matrix of the structured kind the plan's coders look for: rows drawn from a few (offset subset, value set)
+    templates, with knobs for everything that switches a coder on or off -- the number of diagonals and templates, empty rows,
+    rows longer than 7, values from a palette / per template / fully random, columns beyond n"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 3, 17, 64, 255, 256, 257, 1000, 2500, 4099, 9000]))
+    nd = int(rng.integers(1, 10))
+    offs = np.unique(np.concatenate([[0], rng.integers(-min(n, 300), min(n, 300) + 1, nd - 1)])) if nd > 1 else np.array([0])
+    ncols = n + (int(rng.integers(1, 50)) if rng.random() < 0.3 else 0)
+    ntemp = int(rng.integers(1, 7))
+    temps = []
+    for _ in range(ntemp):
+        keep = rng.random(len(offs)) < rng.choice([0.5, 0.8, 1.0])
+        if rng.random() < 0.15:
+            keep[:] = False                                 # an empty-row template
+        mode = rng.choice(["palette", "template", "random"])
+        vals = rng.choice([-1.0, 6.0, 0.0, 0.25, -0.0], len(offs)) if mode == "palette" else rng.uniform(-2, 2, len(offs))
+        temps.append((keep, vals, mode))
+    which = rng.integers(0, ntemp, n) if rng.random() < 0.5 else np.minimum(np.arange(n) * ntemp // max(n, 1), ntemp - 1)
+    ptr, idx, val = [0], [], []
+    for r in range(n):
+        keep, vals, mode = temps[which[r]]
+        for k, o in enumerate(offs):
+            c = r + int(o)
+            if keep[k] and 0 <= c < ncols:
+                idx.append(c)
+                val.append(rng.uniform(-2, 2) if mode == "random" else vals[k])
+        ptr.append(len(idx))
+    return np.array(ptr, np.int32), np.array(idx, np.int32), np.array(val, np.float64), ncols
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_plan_coders_on_random_structured_matrices(lib, seed):
+    """whatever the plan decides to keep -- codes, row patterns, 32 B records, value records (refined or not) -- every form of the
+    product and of the fused dots must give the bits of the 4 B-index kernel, which must give the oracle's"""
+    ptr, idx, val, ncols = _structured_random(seed)
+    n = len(ptr) - 1
+    rng = np.random.default_rng(1000 + seed)
+    x, w = rng.uniform(-1, 1, ncols), rng.uniform(-1, 1, n)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr = DA.from_host(ptr, np.int32)
+    didx = DA.from_host(idx if len(idx) else np.zeros(1, np.int32), np.int32)
+    dval = DA.from_host(val if len(val) else np.zeros(1), np.float64)
+    dx, dw = DA.from_host(x, np.float64), DA.from_host(w, np.float64)
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    state = (lib.liship_csr_plan_coded(plan), lib.liship_csr_plan_row_patterns(plan), lib.liship_csr_plan_pattern_records(plan),
+             lib.liship_csr_plan_value_records(plan))
+    assert state[3] <= state[2] <= (1 if state[1] else 0) <= (1 if state[0] else 0), state
+    dots = []
+    try:
+        for codes, pats, vals_on, variant in ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0x2000), (1, 1, 0, 0), (1, 1, 1, 0), (1, 1, 1, 0x4000)):
+            lib.liship_spmv_csr_set_index_codes(codes)
+            lib.liship_spmv_csr_set_row_patterns(pats)
+            lib.liship_spmv_csr_set_row_values(vals_on)
+            lib.liship_spmv_csr_set_variant(variant)
+            dy = DA.from_host(np.full(max(n, 1), np.nan), np.float64)
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host()[:n], yref), (state, codes, pats, vals_on, variant)
+            lo, hi = n // 3, n - n // 4
+            dy = DA.from_host(np.full(max(n, 1), np.nan), np.float64)
+            for a, b in ((lo, hi), (0, lo), (hi, n)):
+                check(lib.liship_spmv_csr_rows_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host()[:n], yref), (state, "rows", codes, pats, vals_on, variant)
+            res = DA.from_host(np.full(2, np.nan), np.float64)
+            dy = DA.from_host(np.full(max(n, 1), np.nan), np.float64)
+            rc = lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, 1, res.ptr, work.ptr, None)
+            if rc == 0:
+                assert np.array_equal(dy.to_host()[:n], yref)
+                dots.append(res.to_host().copy())
+    finally:
+        lib.liship_spmv_csr_set_index_codes(1)
+        lib.liship_spmv_csr_set_row_patterns(1)
+        lib.liship_spmv_csr_set_row_values(1)
+        lib.liship_spmv_csr_set_variant(0)
+        check(lib.liship_csr_plan_destroy(plan))
+    for d in dots[1:]:
+        assert np.array_equal(d, dots[0]), state

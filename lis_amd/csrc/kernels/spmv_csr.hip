@@ -1026,8 +1026,8 @@ void spmv_csr_valuerec_kernel(const unsigned char *__restrict__ rowpat, const v4
                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                               const double *__restrict__ guard = nullptr, int pstride = 0)
 {
-    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
-    const double acc0 = RW.acc0;
+    const double stop = (DOT != 0 && guard != nullptr) ? guard[0] : 0.0;      // device-driven Krylov loop already converged? (looked at
+    const double acc0 = RW.acc0;                                              // behind the record fill: not a step of the chain)
     __shared__ double dot_scratch[2 * K * (BLOCK / WAVE)];
     __shared__ __attribute__((aligned(16))) v4i32 recL[6 * PAT7_MAX];     // 96 B per pattern: 7 byte offsets + length, 7 values
     const int tid = (int)threadIdx.x;
@@ -1050,6 +1050,7 @@ void spmv_csr_valuerec_kernel(const unsigned char *__restrict__ rowpat, const v4
 #pragma unroll
     for (int h = 0; h < K; h++) pat[h] = r[h] < r1[h] ? (int)rowpat[r[h]] : -1;
     __syncthreads();                                                   // the records are in LDS (and the pattern bytes in)
+    if (DOT != 0 && stop != 0.0) return;                               // (uniform; nothing has been written)
     RowDots<DOT> dots[K];
     double xx[K][7], wr[K];
     int len[K];
@@ -1196,6 +1197,113 @@ void spmv_csr_valuerec_pair_kernel(const unsigned char *__restrict__ rowpat, con
                 for (int u = 0; u < 7; u++) { const double t = v[u] * xv[u]; acc += (u < len) ? t : -0.0; }
                 store_stream(y + r, acc);
             }
+        }
+    }
+}
+
+// The fused-dot forms two rows per lane.  The partial of a row block is DEFINED by the one-row kernels: lane t of the block's
+// 256 holds sum_k w*y over its rows r0 + t + 256 k, a wavefront adds its 64 lanes by the butterfly 32, 16, 8, 4, 2, 1, lane 0
+// adds the four wavefronts in order.  Here lane p of a block's 128 holds the "virtual lanes" 2p and 2p + 1 in two accumulators,
+// and the same tree is walked on them: the butterfly steps 32 .. 2 pair virtual lanes of equal parity 16 .. 1 physical lanes
+// apart (each accumulator by itself, inside a half wavefront of 32), the last step adds the lane's two accumulators (a + b is
+// b + a), and a half wavefront is a virtual wavefront.  Every addition has the operands it has in the one-row kernels: the
+// partials -- and with them every dot, every iteration count -- are bit-identical (tests/golden/reduction_bits.json and the
+// A/B forms of test_spmv_csr_index_codes pin it).  A workgroup of 256 lanes takes two row blocks.
+template <int BLOCK, int DOT>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_valuerec_pair_dot_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, int npat,
+                                       const double *__restrict__ x, double *__restrict__ y, const v2i32 *__restrict__ blk,
+                                       int bfirst, int nb, Rows RW,
+                                       const double *__restrict__ wdot, double *__restrict__ partial,
+                                       const double *__restrict__ guard, int pstride)
+{
+    static_assert(BLOCK == 256, "two row blocks of 128 lane pairs");
+    const double stop = guard != nullptr ? guard[0] : 0.0;          // device-driven Krylov loop already converged? (looked at behind the
+    const double acc0 = RW.acc0;                                    // record fill: the flag's round trip is not a step of the chain)
+    __shared__ double scratch[2][2][4];                   // [block of the workgroup][result][virtual wavefront]
+    __shared__ __attribute__((aligned(16))) v4i32 recL[6 * PAT7_MAX];
+    const int tid = (int)threadIdx.x;
+    for (int t = tid; t < 6 * npat; t += BLOCK) recL[t] = rec[t];
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 7), p = tid & 127;        // wavefronts 0, 1: the first block; 2, 3: the second
+    const int lb = blockIdx.x * 2 + h;
+    const Blk B = lb < nb ? load_blk(blk, bfirst + lb) : Blk{0, 0, 0, 0};
+    const int r0 = max(B.r0, RW.rb), r1 = min(B.r1, RW.re);
+    __syncthreads();                                      // the records are in LDS
+    if (stop != 0.0) return;                              // (uniform; nothing has been written)
+    double c0[2] = {0.0, 0.0}, c1[2] = {0.0, 0.0};
+    for (int base = r0; base < r1; base += 256) {         // (uniform per wavefront) virtual lane t holds the rows base + t
+        const int ra = base + 2 * p;
+        int pa = -1, pb = -1;
+        if (ra + 1 < r1) {
+            if ((ra & 1) == 0) { const unsigned two = *reinterpret_cast<const unsigned short *>(rowpat + ra); pa = (int)(two & 255u); pb = (int)(two >> 8); }
+            else { pa = rowpat[ra]; pb = rowpat[ra + 1]; }
+        } else if (ra < r1) pa = rowpat[ra];
+        if (pa >= 0 && pa == pb) {
+            const v4i32 a = recL[6 * pa], b = recL[6 * pa + 1];
+            const int o[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z}, len = b.w;
+            const unsigned rb8 = (unsigned)ra * 8u;
+            v2f64 xx[7], ww;
+            if ((ra & 1) == 0) ww = *reinterpret_cast<const v2f64 *>(wdot + ra); else { ww.x = wdot[ra]; ww.y = wdot[ra + 1]; }
+#pragma unroll
+            for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)o[u]));
+            const v2f64 *q = reinterpret_cast<const v2f64 *>(recL + 6 * pa + 2);
+            const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const double v[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
+            double s0 = acc0, s1 = acc0;
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const double t0 = v[u] * xx[u].x, t1 = v[u] * xx[u].y;
+                s0 += (u < len) ? t0 : -0.0;              // -0.0 terms leave any sum bit-unchanged
+                s1 += (u < len) ? t1 : -0.0;
+            }
+            v2f64 out; out.x = s0; out.y = s1;
+            if ((ra & 1) == 0) store_stream(reinterpret_cast<v2f64 *>(y + ra), out);
+            else { store_stream(y + ra, s0); store_stream(y + ra + 1, s1); }
+            c0[0] += ww.x * s0; c0[1] += ww.y * s1;
+            if (DOT >= 2) { c1[0] += s0 * s0; c1[1] += s1 * s1; }
+        } else {
+#pragma unroll
+            for (int w = 0; w < 2; w++) {                 // two patterns in the pair, or a single last row: one row at a time
+                const int pt = w ? pb : pa, r = ra + w;
+                if (pt < 0) continue;
+                const v4i32 a = recL[6 * pt], b = recL[6 * pt + 1];
+                const v2f64 *q = reinterpret_cast<const v2f64 *>(recL + 6 * pt + 2);
+                const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const int o[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z}, len = b.w;
+                const double v[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
+                const double wr = wdot[r];
+                double xv[7], acc = acc0;
+#pragma unroll
+                for (int u = 0; u < 7; u++) xv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned)r * 8u + (unsigned)o[u]));
+#pragma unroll
+                for (int u = 0; u < 7; u++) { const double t = v[u] * xv[u]; acc += (u < len) ? t : -0.0; }
+                store_stream(y + r, acc);
+                c0[w] += wr * acc;
+                if (DOT >= 2) c1[w] += acc * acc;
+            }
+        }
+    }
+    // the one-row kernels' tree on the virtual lanes (see above)
+    const int vw = p >> 5;                                // virtual wavefront of this lane's two virtual lanes
+#pragma unroll
+    for (int res = 0; res < (DOT >= 2 ? 2 : 1); res++) {
+        double e = res ? c1[0] : c0[0], f = res ? c1[1] : c0[1];
+        e += __shfl_xor(e, 16, WAVE); f += __shfl_xor(f, 16, WAVE);
+        e += lane_xor_in_row<8>(e);   f += lane_xor_in_row<8>(f);
+        e += lane_xor_in_row<4>(e);   f += lane_xor_in_row<4>(f);
+        e += lane_xor_in_row<2>(e);   f += lane_xor_in_row<2>(f);
+        e += lane_xor_in_row<1>(e);   f += lane_xor_in_row<1>(f);
+        const double t = e + f;
+        if ((p & 31) == 0) scratch[h][res][vw] = t;
+    }
+    __syncthreads();
+    if (tid < 4) {                                        // thread = (block of the workgroup, result)
+        const int hh = tid >> 1, res = tid & 1, slot = blockIdx.x * 2 + hh, stride = pstride ? pstride : nb;
+        if (slot < nb && (res == 0 || DOT >= 2)) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) t += scratch[hh][res][i];
+            partial[(size_t)res * stride + slot] = t;
         }
     }
 }
@@ -1987,6 +2095,13 @@ template <int G, int DOT>
 void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
+    if (a.rowpat && a.ptab8 && a.vrec && !(g_variant & 0x2000) && g.block == 256 &&
+        ((g_variant & 0x4000) || (long long)(a.re - a.rb) * 8 > (256ll << 20))) {          // two rows per lane beyond the Infinity Cache (see launch_geom)
+        spmv_csr_valuerec_pair_dot_kernel<256, DOT><<<(a.nb + 1) / 2, 256, 0, a.st>>>(
+            a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
+            w, partial, liship_internal_guard(), pstride);
+        return;
+    }
     if (a.rowpat && a.ptab8 && a.vrec && !(g_variant & 0x2000)) {
         spmv_csr_valuerec_kernel<g.block, 2, DOT><<<(a.nb + 1) / 2, g.block, 0, a.st>>>(
             a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},

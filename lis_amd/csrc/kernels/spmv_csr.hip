@@ -292,14 +292,48 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
             if ((int)threadIdx.x == owner) carry += tree_scratch[0];
             base = k1;
         }
-        while (base < k1) {
-            const int kend = min(base + CAP, k1);
-            const int ka2 = base & ~1;
+        if (BLOCK == WAVE) {                                    // a single wavefront has nobody to stage for it
+            while (base < k1) {
+                const int kend = min(base + CAP, k1);
+                const int ka2 = base & ~1;
+                __syncthreads();
+                stage_products<BLOCK, VEC, NOGATHER>(prod, idx, val, x, base, kend, ka2);
+                __syncthreads();
+                if ((int)threadIdx.x == owner) carry = ordered_sum_plain(carry, prod, base - ka2, kend - base);
+                base = kend;
+            }
+        } else if (base < k1) {
+            // The rest of the long row, strictly in order: ONE lane owns the chain of additions, and nothing can shorten it but
+            // keeping that lane fed.  The stage is used as two halves: while the owner adds the products of one half, the lanes
+            // of the OTHER wavefronts form the products of the next half (4 loads and gathers in flight each), so a pass costs
+            // the longer of the two instead of their sum, and the owner's wavefront never waits for memory.
+            constexpr int H = (CAP / 2) & ~15;                  // products per half
+            const int ownerwave = owner / WAVE;
+            constexpr int helpers = BLOCK > WAVE ? BLOCK - WAVE : 1;   // lanes of the other wavefronts
+            const int hl = ((int)threadIdx.x / WAVE < ownerwave) ? (int)threadIdx.x : (int)threadIdx.x - WAVE;   // index among them
+            const bool helper = (int)threadIdx.x / WAVE != ownerwave;
+            auto stage_half = [&](int half, int kb, int ke) {   // prod[GUARD + half * H + (k - kb)] = value[k] * x[index[k]]
+                double *dst = prod + GUARD + half * H;
+                for (int k = kb + hl; k < ke; k += 4 * helpers) {
+                    double v[4], xv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int kk = min(k + u * helpers, ke - 1); v[u] = load_stream(val + kk); xv[u] = NOGATHER ? 1.0 : x[load_stream(idx + kk)]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (k + u * helpers < ke) dst[k + u * helpers - kb] = v[u] * xv[u];
+                }
+            };
+            __syncthreads();                                    // the first pass's sums have read the stage
+            int half = 0;
+            if (helper) stage_half(0, base, min(base + H, k1));
             __syncthreads();
-            stage_products<BLOCK, VEC, NOGATHER>(prod, idx, val, x, base, kend, ka2);
-            __syncthreads();
-            if ((int)threadIdx.x == owner) carry = ordered_sum_plain(carry, prod, base - ka2, kend - base);
-            base = kend;
+            while (base < k1) {
+                const int kend = min(base + H, k1);
+                if (helper) { if (kend < k1) stage_half(half ^ 1, kend, min(kend + H, k1)); }
+                else if ((int)threadIdx.x == owner) carry = ordered_sum_plain(carry, prod, half * H, kend - base);
+                __syncthreads();
+                base = kend;
+                half ^= 1;
+            }
         }
         if ((int)threadIdx.x == owner) { store_stream(y + rl, carry); dots.add(rl, carry); }
     }
@@ -325,7 +359,7 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
                               double *__restrict__ y, const v2i32 *__restrict__ blk,
                               int bfirst, int nb, Rows RW, int run,
                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                              const double *__restrict__ guard = nullptr, int pstride = 0)
+                              const double *__restrict__ guard = nullptr, int pstride = 0, const int *__restrict__ order = nullptr)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const int row_begin = RW.rb, row_end = RW.re;
@@ -334,7 +368,9 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
     __shared__ double prod[(GUARD + CAP + 8 + 16)];
     __shared__ double dot_scratch[BLOCK / WAVE];
     RowDots<DOT> dots{wdot, 0.0, 0.0};
-    const int lb = block_of_workgroup<XRUN>(nb, run);
+    // order: the plan's launch order when some row blocks hold a row far longer than the stage -- those first, so that their
+    // chains of additions (one lane, strictly in order) run beside the rest of the matrix instead of behind it
+    const int lb = order ? order[blockIdx.x] : block_of_workgroup<XRUN>(nb, run);
     if (lb < 0) return;
     Blk B = load_blk(blk, bfirst + lb);
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
@@ -1511,6 +1547,7 @@ struct liship_csr_plan_s {
     int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
     long long ndcol;     // entries of dcol
     int first_term;      // row sums start at the first product instead of at +0.0 (split matrices)
+    int *order;          // device, nblocks entries or NULL: launch order of the products kernel (blocks with a very long row first)
     unsigned char *rowpat; // device, one byte per row: its pattern (length + offset sequence); NULL = none
     unsigned short *rowrel; // device, 2 B per row: its first non-zero relative to its row block
     int *ptab;           // device: npat + 1 prefix entries, then the offsets of all patterns
@@ -1551,6 +1588,30 @@ static int build_split(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
     if (e == hipSuccess) e = hipMemcpyAsync(p->blk_host, p->blk, bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { (void)hipFree(p->blk); p->blk = nullptr; free(p->blk_host); p->blk_host = nullptr; return (int)e; }
+    if (p->order) { (void)hipFree(p->order); p->order = nullptr; }
+    if (p->products && p->nblocks > 1) {             // blocks whose last row overflows the stage by far: launched first (products kernel)
+        const int heavy_from = 4 * (WORK + SLACK);
+        int nheavy = 0;
+        for (int b = 0; b < p->nblocks; b++) nheavy += (p->blk_host[b + 1].y - p->blk_host[b].y > heavy_from);
+        if (nheavy > 0 && nheavy < p->nblocks) {
+            int *ord = (int *)malloc(sizeof(int) * (size_t)p->nblocks);
+            if (ord) {
+                int at = 0;
+                for (int b = 0; b < p->nblocks; b++) if (p->blk_host[b + 1].y - p->blk_host[b].y > heavy_from) ord[at++] = b;
+                for (int i = 1; i < nheavy; i++) {       // the longest first
+                    const int v = ord[i]; int j = i - 1;
+                    auto len = [&](int b) { return p->blk_host[b + 1].y - p->blk_host[b].y; };
+                    while (j >= 0 && len(ord[j]) < len(v)) { ord[j + 1] = ord[j]; j--; }
+                    ord[j + 1] = v;
+                }
+                for (int b = 0; b < p->nblocks; b++) if (!(p->blk_host[b + 1].y - p->blk_host[b].y > heavy_from)) ord[at++] = b;
+                if (hipMalloc(&p->order, sizeof(int) * (size_t)p->nblocks) == hipSuccess) {
+                    if (hipMemcpy(p->order, ord, sizeof(int) * (size_t)p->nblocks, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p->order); p->order = nullptr; }
+                } else { p->order = nullptr; (void)hipGetLastError(); }
+                free(ord);
+            }
+        }
+    }
     return 0;
 }
 
@@ -1584,7 +1645,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->vrec = nullptr;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->vrec = nullptr; p->order = nullptr;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -1603,6 +1664,7 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->ptab) (void)hipFree(p->ptab);
     if (p->ptab8) (void)hipFree(p->ptab8);
     if (p->vrec) (void)hipFree(p->vrec);
+    if (p->order) (void)hipFree(p->order);
     if (p->lcol) (void)hipFree(p->lcol);
     if (p->dcol) (void)hipFree(p->dcol);
     if (p->doff) (void)hipFree(p->doff);
@@ -1986,6 +2048,7 @@ struct LaunchArgs {
     const int *ptab = nullptr; int ptab_len = 0, npat1 = 0;
     const v4i32 *ptab8 = nullptr;
     const v4i32 *vrec = nullptr;            // value records (with ptab8), when the plan has them and they are switched on
+    const int *order = nullptr;             // launch order of the products kernel (whole-matrix launches of a plan that has one)
 };
 
 
@@ -2004,7 +2067,8 @@ void launch_products(int grid, const LaunchArgs &a)
 {
     constexpr Geometry g = kGeom[G];
     spmv_csr_products_kernel<g.block, g.work, XRUN, VEC, NOGATHER>
-        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, xcd_run());
+        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, xcd_run(),
+                                     nullptr, nullptr, nullptr, 0, XRUN ? nullptr : a.order);
 }
 
 template <int G>
@@ -2146,10 +2210,10 @@ void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double
     }
     if (batch == 2)
         spmv_csr_products_kernel<g.block, g.work, false, 2, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, 16, w, partial, liship_internal_guard(), pstride);
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, 16, w, partial, liship_internal_guard(), pstride, a.order);
     else
         spmv_csr_products_kernel<g.block, g.work, false, 4, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, 16, w, partial, liship_internal_guard(), pstride);
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, 16, w, partial, liship_internal_guard(), pstride, a.order);
 }
 
 int launch_csr(liship_csr_plan_t p, const LaunchArgs &a)
@@ -2175,7 +2239,7 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
                                    const double *val, const double *x, double *y, void *stream)
 {
     if (!p) return LISHIP_ERR_ARG;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order};
     return launch_csr(p, a);
 }
 
@@ -2191,7 +2255,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x6000) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);

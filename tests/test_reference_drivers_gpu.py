@@ -104,12 +104,15 @@ def test_test1_rhs_modes_and_vector_file(tmp_path):
 
 def test_unchanged_driver_in_resident_mode_times_real_work():
     """LIS_AMD_RESIDENCY=resident lets the UNCHANGED spmvtest3 binary time products instead of PCIe copies: same 2-norm,
-    a rate above the coherent run's and below what 8 TB/s allows (lis_wtime drains the queue, so the driver's clock
-    brackets the work, not just its launches)."""
+    a rate above the coherent run's and below anything a real product could reach (lis_wtime drains the queue, so the driver's
+    clock brackets the work, not just its launches)."""
     rate = {}
     for mode in ("coherent", "resident"):
         out = run("spmvtest3_amd", 160, 160, 160, 50, 1, env_extra={"LIS_AMD_RESIDENCY": mode})
         m = re.search(r"computation = (\S+) sec, (\S+) MFLOPS, 2-norm = (\S+)", out)
         rate[mode] = (float(m.group(2)), m.group(3))
     assert rate["coherent"][1] == rate["resident"][1]
-    assert rate["coherent"][0] < rate["resident"][0] < 1.1e6          # 1077 GFLOP/s is the HBM roofline of this product
+    # above the coherent run's, and not absurd: the product streams one byte per row here (value records: ~3000 GFLOP/s at this
+    # size), so the 1077 GFLOP/s that 8 TB/s allows on the contract's bytes is no bound any more -- 6000 would mean the clock
+    # bracketed launches, not work
+    assert rate["coherent"][0] < rate["resident"][0] < 6.0e6

@@ -1092,7 +1092,7 @@ def _structured_random(seed):
     return np.array(ptr, np.int32), np.array(idx, np.int32), np.array(val, np.float64), ncols
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LIS_AMD_FUZZ_SEEDS", "60"))))      # more seeds: LIS_AMD_FUZZ_SEEDS=1000
 def test_plan_coders_on_random_structured_matrices(lib, seed):
     """whatever the plan decides to keep -- codes, row patterns, 32 B records, value records (refined or not) -- every form of the
     product and of the fused dots must give the bits of the 4 B-index kernel, which must give the oracle's"""

@@ -14,7 +14,7 @@ from lis_amd import DeviceArray as DA, check  # noqa: E402
 
 src = open(os.path.join(ROOT, "tests", "test_kernels_gpu.py")).read()
 ns = {"np": np}
-exec(src[src.index("def _structured_random(seed):"):src.index('@pytest.mark.parametrize("seed", range(60))')], ns)
+exec(src[src.index("def _structured_random(seed):"):src.index('@pytest.mark.parametrize("seed", range(int(os.environ')], ns)
 lib = lis_amd.load()
 census = collections.Counter()
 for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):

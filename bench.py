@@ -209,6 +209,10 @@ def main():
     records = int(dll.lis_amd_matrix_pattern_records(A))   # 1: patterns of <= 7 offsets kept as 32 B records (gathers ahead of the value slice)
     dll.lis_amd_matrix_value_records.argtypes = [capi.PM]
     values = int(dll.lis_amd_matrix_value_records(A))      # 1: the rows of a pattern share their values too (constant coefficients): the
+    if world > 1:                                          # (one answer for the whole job: the second measurement below is collective)
+        vv = torch.tensor([values], dtype=torch.int32)
+        dist.all_reduce(vv, op=dist.ReduceOp.MIN)
+        values = int(vv[0])
     moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, values)     # records hold them, neither values nor indices are streamed
 
     def kernel_name(v):

@@ -1,4 +1,5 @@
-"""The reference's own test drivers (test/spmvtest1.c, spmvtest3.c, test3.c, test4.c), compiled UNCHANGED against
+"""The reference's own test drivers (test/spmvtest1.c, spmvtest2.c, spmvtest2b.c, spmvtest3.c, spmvtest3b.c, spmvtest5.c, test1.c,
+test2.c, test3.c, test3b.c, test3c.c, test4.c, test5.c), compiled UNCHANGED against
 this repo's include/ and linked to liblis_amd.so (oracle/Makefile target `drivers`; binaries travel under
 oracle/_ref/drivers/), run on the GPU next to the same drivers linked to the reference library.
 What the drivers print is the only correctness signal the reference has: 2-norms, iteration counts,
@@ -116,3 +117,58 @@ def test_unchanged_driver_in_resident_mode_times_real_work():
     # size), so the 1077 GFLOP/s that 8 TB/s allows on the contract's bytes is no bound any more -- 6000 would mean the clock
     # bracketed launches, not work
     assert rate["coherent"][0] < rate["resident"][0] < 6.0e6
+
+
+# ------------------------------------------------------------------ more of the reference's drivers, unchanged
+def _solve_report(out):
+    it = re.search(r"number of iterations = (\d+)", out)
+    res = re.search(r"relative residual\s*= (\S+)", out)
+    st = re.search(r"linear solver status\s*: (.*)", out)
+    return (int(it.group(1)) if it else None, float(res.group(1)) if res else None, st.group(1).strip() if st else None)
+
+
+@pytest.mark.parametrize("driver,args", [("spmvtest2", (60, 50, 5)), ("spmvtest2b", (60, 50, 5)), ("spmvtest3b", (14, 12, 10, 5))])
+def test_more_spmvtest_drivers_print_the_reference_norms(driver, args):
+    """spmvtest2 (2-D 5-point), spmvtest2b (2-D 9-point), spmvtest3b (3-D 27-point): the norms the reference prints, format by format"""
+    for fmt in (1, 2, 4, 5, 6, 7):                          # CSR CSC DIA ELL JAD BSR
+        got = norms(run(driver + "_amd", *args, fmt))
+        want = norms(run(driver + "_ref", *args, fmt))
+        assert got == want and fmt in got, (driver, fmt, got, want)
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 4, 5, 6, 7])
+def test_spmvtest5_matrix_market_product(fmt):
+    mtx = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mm", "testmat.mtx")
+    got = norms(run("spmvtest5_amd", mtx, fmt, 5))
+    want = norms(run("spmvtest5_ref", mtx, fmt, 5))
+    assert got == want and fmt in got, (fmt, got, want)
+
+
+@pytest.mark.parametrize("driver,args,opts", [
+    ("test2", (24, 20, 1), "-i cg -p jacobi"), ("test2", (24, 20, 1), "-i bicgstab -p none"), ("test2", (24, 20, 5), "-i cg -p none"),
+    # test3b presets "-p ssor -adds true" (Gauss-Seidel-type preconditioners and additive Schwarz are out of scope: SURVEY 2)
+    ("test3b", (10, 9, 8, 1), "-i cg -p jacobi -adds false"), ("test3b", (10, 9, 8, 1), "-i gmres -restart 20 -p none -adds false"),
+    ("test5", (200, 2.0), "-i bicgstab -p none"), ("test5", (200, 0.5), "-i gmres -restart 30 -p jacobi")])
+def test_more_solver_drivers(tmp_path, driver, args, opts):
+    """test2 (2-D Poisson), test3b (3-D 27-point), test5 (the non-symmetric Toeplitz system of test.sh): status, iteration
+    count (exact for CG, the usual slack where the reference's own count moves with its thread count) and residual"""
+    rep = {}
+    for tag in ("amd", "ref"):
+        files = (tmp_path / f"sol_{tag}.txt", tmp_path / f"rh_{tag}.txt") if driver != "test5" else ()
+        rep[tag] = _solve_report(run(f"{driver}_{tag}", *args, *files, *opts.split()))
+    (it_a, res_a, st_a), (it_r, res_r, st_r) = rep["amd"], rep["ref"]
+    assert st_a == st_r, rep
+    if "-i cg" in opts:
+        assert it_a == it_r, rep
+    else:
+        assert abs(it_a - it_r) <= max(3, it_r // 10), rep
+    if st_r == "normal end":
+        assert res_a <= 1e-12 and res_r <= 1e-12
+
+
+def test_test3c_time_stepping_driver():
+    """test3c: one matrix, `step` solves in a row with the previous solution as the right-hand side's source"""
+    got = run("test3c_amd", 10, 9, 8, 4, "-i", "cg")
+    want = run("test3c_ref", 10, 9, 8, 4, "-i", "cg")
+    its = [re.findall(r"number of iterations = (\d+)", o) for o in (got, want)]
+    assert its[0] == its[1] and len(its[0]) >= 1

@@ -59,7 +59,7 @@ LIS_INT lis_amd_matrix_row_patterns(LIS_MATRIX A);
 /* 1 when those patterns are also kept as 32 B records (1..7 offsets each: the 7-point stencil) and the products use the
  * kernel that issues its x gathers ahead of the value slice, 0 otherwise; uploads A if needed */
 LIS_INT lis_amd_matrix_pattern_records(LIS_MATRIX A);
-/* 1 when the rows of each pattern also carry the same values (a constant-coefficient stencil) and the HBM copy keeps them in
+/* 1 (2: rows of 8..32 entries, the wide form) when the rows of each pattern also carry the same values (a constant-coefficient stencil) and the HBM copy keeps them in
  * the pattern records -- the products then read ONE byte per row of matrix data, neither values nor indices (liship.h "value
  * records"; LIS_AMD_NO_VALUE_RECORDS=1 switches them off) -- 0 otherwise; uploads A if needed.  Like every other part of the HBM
  * copy they follow the host arrays only through lis_amd_matrix_host_modified(); the arrays of a matrix adopted with

@@ -88,7 +88,11 @@ int  liship_csr_plan_pattern_records(liship_csr_plan_t plan);
  * constant-coefficient stencil -- the 7 values join the 7 offsets in the record and the products read neither the value nor
  * the index array: one byte per row (the idea of CSR-VI, value indexing, applied to whole rows).  Same products in the same
  * order: bit-identical.  The value array must not change afterwards (a new plan is needed if it does).
- * liship_csr_plan_value_records: 1 if the plan has them.  liship_spmv_csr_set_row_values(0): A/B switch (stream the values). */
+ * Rows of one offset pattern that carry different values (a Dirichlet row stored with the interior row's sparsity) split the pattern.
+ * Patterns of 8..32 offsets (no 32 B records: the 9-point stencil in 2-D, the 19- and 27-point ones in 3-D) get WIDE records when
+ * there are at most 48 of them (400 B per pattern; no splitting by values there).
+ * liship_csr_plan_value_records: 1 if the plan has them, 2 for the wide form.  liship_spmv_csr_set_row_values(0): A/B switch
+ * (stream the values). */
 int  liship_csr_plan_encode_row_values(liship_csr_plan_t plan, const int *ptr, const double *value, void *stream);
 int  liship_csr_plan_value_records(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_row_values(int on);

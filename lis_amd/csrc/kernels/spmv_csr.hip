@@ -1344,6 +1344,66 @@ void spmv_csr_valuerec_pair_dot_kernel(const unsigned char *__restrict__ rowpat,
     }
 }
 
+// Value records for longer rows (up to 32 entries: the 9-point stencil in 2-D, the 19- and 27-point ones in 3-D, whose 27 row
+// patterns carry their values when the coefficients are constant).  One row per lane; the records -- 144 B of byte offsets and
+// the length, 256 B of values per pattern -- sit in LDS; a row is walked in chunks of 8 entries: offsets, 8 gathers in flight,
+// values, 8 additions in order (terms beyond the row's length add -0.0).  Same products in the same order: bit-identical.
+constexpr int PATW_MAX = 48, PATW_LEN = 32, PATW_OFF = 36;             // patterns, entries per pattern, ints per offset record
+template <int BLOCK, int DOT = 0>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_valuerecw_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, int npat,
+                               const double *__restrict__ x, double *__restrict__ y, const v2i32 *__restrict__ blk,
+                               int bfirst, int nb, Rows RW,
+                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                               const double *__restrict__ guard = nullptr, int pstride = 0)
+{
+    const double stop = (DOT != 0 && guard != nullptr) ? guard[0] : 0.0;
+    const double acc0 = RW.acc0;
+    __shared__ double dot_scratch[BLOCK / WAVE];
+    __shared__ __attribute__((aligned(16))) int offL[PATW_MAX * PATW_OFF];
+    __shared__ __attribute__((aligned(16))) double valL[PATW_MAX * PATW_LEN];
+    const int tid = (int)threadIdx.x;
+    {   // the image: npat x 144 B of offsets, then npat x 256 B of values
+        const v4i32 *src = rec;
+        for (int t = tid; t < npat * (PATW_OFF / 4); t += BLOCK) reinterpret_cast<v4i32 *>(offL)[t] = src[t];
+        src += npat * (PATW_OFF / 4);
+        for (int t = tid; t < npat * (PATW_LEN / 2); t += BLOCK) reinterpret_cast<v4i32 *>(valL)[t] = src[t];
+    }
+    RowDots<DOT> dots{wdot, 0.0, 0.0};
+    const int lb = blockIdx.x;
+    const Blk B = load_blk(blk, bfirst + lb);
+    const int r0 = max(B.r0, RW.rb), r1 = min(B.r1, RW.re);
+    __syncthreads();                                      // the records are in LDS
+    if (DOT != 0 && stop != 0.0) return;                  // device-driven Krylov loop already converged (uniform; nothing written)
+    for (int r = r0 + tid; __builtin_amdgcn_ballot_w64(r < r1) != 0; r += BLOCK) {      // wavefront-uniform trip count
+        const bool mine = r < r1;
+        const int pat = mine ? (int)rowpat[r] : 0;
+        const int len = mine ? offL[pat * PATW_OFF + PATW_LEN] : 0;
+        const unsigned rb8 = (unsigned)r * 8u;            // 32-bit byte offsets on a scalar base (the plan checks n + max offset < 2^29)
+        double wr = 0.0, acc = acc0;
+        if (DOT >= 1 && mine) wr = wdot[r];
+        for (int c = 0; __builtin_amdgcn_ballot_w64(c < len) != 0; c += 8) {            // (uniform) 8 entries at a time
+            if (c < len) {
+                const v4i32 oa = *reinterpret_cast<const v4i32 *>(offL + pat * PATW_OFF + c), ob = *reinterpret_cast<const v4i32 *>(offL + pat * PATW_OFF + c + 4);
+                const int o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+                double xx[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) xx[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)o[u]));
+                const v2f64 *q = reinterpret_cast<const v2f64 *>(valL + pat * PATW_LEN + c);
+                const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const double v[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const double t = v[u] * xx[u]; acc += (c + u < len) ? t : -0.0; }     // -0.0 terms leave any sum bit-unchanged
+            }
+        }
+        if (mine) {
+            store_stream(reinterpret_cast<double *>(reinterpret_cast<char *>(y) + rb8), acc);
+            dots.add_loaded(wr, acc);
+        }
+    }
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+}
+
 // plan time: one 64-bit hash per row over (length, code sequence); the distinct ones in an open-addressing table together with the
 // smallest row that has them; gives up beyond 255
 constexpr int PAT_SLOTS = 1024, PAT_MAXLEN = 64;
@@ -1449,22 +1509,23 @@ __global__ void csr_encode(int n, const int *__restrict__ ptr, const int *__rest
 
 // value records: the values of each pattern's representative row ...
 __global__ void csr_fetch_values(int npat, const int *__restrict__ rep, const int *__restrict__ ptr, const double *__restrict__ val,
-                                 double *__restrict__ vrec)
+                                 double *__restrict__ vrec, int stride = 8, int cap = 7)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npat) return;
     const int s = ptr[rep[p]], e = ptr[rep[p] + 1];
-    for (int j = 0; j < 8; j++) vrec[8 * p + j] = (s + j < e && j < 7) ? val[s + j] : 0.0;
+    for (int j = 0; j < stride; j++) vrec[stride * p + j] = (s + j < e && j < cap) ? val[s + j] : 0.0;
 }
 // ... and the check that EVERY row carries its pattern's values, bit for bit
 __global__ void csr_check_values(int n, const int *__restrict__ ptr, const double *__restrict__ val,
-                                 const unsigned char *__restrict__ rowpat, const double *__restrict__ vrec, int *__restrict__ bad)
+                                 const unsigned char *__restrict__ rowpat, const double *__restrict__ vrec, int *__restrict__ bad,
+                                 int stride = 8, int cap = 7)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n || bad[0] != 0) return;
     const int s = ptr[r], e = ptr[r + 1], p = rowpat[r];
-    bool ok = e - s <= 7;
-    for (int k = s; ok && k < e; k++) ok = __double_as_longlong(val[k]) == __double_as_longlong(vrec[8 * p + (k - s)]);
+    bool ok = e - s <= cap;
+    for (int k = s; ok && k < e; k++) ok = __double_as_longlong(val[k]) == __double_as_longlong(vrec[stride * p + (k - s)]);
     if (!ok) atomicAdd(bad, 1);
 }
 
@@ -1547,13 +1608,14 @@ struct liship_csr_plan_s {
     int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
     long long ndcol;     // entries of dcol
     int first_term;      // row sums start at the first product instead of at +0.0 (split matrices)
+    v4i32 *vrecw;        // device: WIDE value records for patterns of up to 32 entries (no ptab8): per pattern 144 B of byte offsets + length, 256 B of values; else NULL
     int *order;          // device, nblocks entries or NULL: launch order of the products kernel (blocks with a very long row first)
     unsigned char *rowpat; // device, one byte per row: its pattern (length + offset sequence); NULL = none
     unsigned short *rowrel; // device, 2 B per row: its first non-zero relative to its row block
     int *ptab;           // device: npat + 1 prefix entries, then the offsets of all patterns
     int ptab_len, npat;
     v4i32 *ptab8;        // device: when no pattern has more than 7 offsets, one 32 B record per pattern (7 offsets, length); else NULL
-    int prep[64];        // with ptab8: a row that carries each pattern (PAT7_MAX entries)
+    int prep[256];       // a row that carries each pattern
     v4i32 *vrec;         // device: with ptab8, when every row of a pattern carries the same values, 96 B per pattern (the 32 B record + 7 values); else NULL
 };
 
@@ -1645,7 +1707,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->vrec = nullptr; p->order = nullptr;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -1665,6 +1727,7 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->ptab8) (void)hipFree(p->ptab8);
     if (p->vrec) (void)hipFree(p->vrec);
     if (p->order) (void)hipFree(p->order);
+    if (p->vrecw) (void)hipFree(p->vrecw);
     if (p->lcol) (void)hipFree(p->lcol);
     if (p->dcol) (void)hipFree(p->dcol);
     if (p->doff) (void)hipFree(p->doff);
@@ -1843,6 +1906,7 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
         return rc;
     }
     p->npat = npat; p->ptab_len = npat + 1 + total;
+    for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
     return 0;
 }
 // number of row patterns when the plan keeps one byte per row, 0 otherwise
@@ -1934,9 +1998,54 @@ static int refine_patterns_by_values(liship_csr_plan_s *p, const int *ptr, const
 
 // Value records on top of the pattern records (see spmv_csr_valuerec_kernel): setup-time, optional, never an error when the matrix
 // does not qualify (no 32 B records, or two rows of one pattern with different values).  One pass over ptr / value.
+// the same for patterns of up to 32 entries (no 32 B records): offsets from the plan's pattern table, values from one row per pattern,
+// every row checked; the image is npat x 144 B (32 byte offsets, the tail repeating the last one; the length; padding) followed by
+// npat x 256 B (32 values, the tail 0).  No refinement here: rows of one offset pattern with different values keep the values streamed.
+static int encode_wide_value_records(liship_csr_plan_s *p, const int *ptr, const double *val, hipStream_t st)
+{
+    if (p->npat <= 0 || p->npat > PATW_MAX || p->ptab_len <= p->npat) return 0;
+    const int npat = p->npat;
+    int *tab = (int *)malloc(sizeof(int) * (size_t)p->ptab_len);
+    if (!tab) return 0;
+    int rc = 0, bad = 1;
+#define PT(expr) do { if (rc == 0) { hipError_t e__ = (expr); if (e__ != hipSuccess) rc = (int)e__; } } while (0)
+    PT(hipMemcpy(tab, p->ptab, sizeof(int) * (size_t)p->ptab_len, hipMemcpyDeviceToHost));
+    int maxlen = 0, minlen = 1 << 30, maxoff = 0;
+    for (int i = 0; i < npat && rc == 0; i++) { const int l = tab[i + 1] - tab[i]; if (l > maxlen) maxlen = l; if (l < minlen) minlen = l; }
+    for (int t = npat + 1; t < p->ptab_len && rc == 0; t++) if (tab[t] > maxoff) maxoff = tab[t];
+    if (rc != 0 || maxlen > PATW_LEN || minlen < 1 || (long long)p->n + maxoff >= (1ll << 29)) { free(tab); return rc; }
+    int *d_rep = nullptr, *d_bad = nullptr; double *vr = nullptr;
+    PT(hipMalloc(&d_rep, sizeof(int) * (size_t)npat)); PT(hipMalloc(&d_bad, sizeof(int))); PT(hipMalloc(&vr, sizeof(double) * PATW_LEN * (size_t)npat));
+    PT(hipMemcpyAsync(d_rep, p->prep, sizeof(int) * (size_t)npat, hipMemcpyHostToDevice, st));
+    PT(hipMemsetAsync(d_bad, 0, sizeof(int), st));
+    if (rc == 0) { csr_fetch_values<<<1, 64, 0, st>>>(npat, d_rep, ptr, val, vr, PATW_LEN, PATW_LEN); PT(hipGetLastError()); }
+    if (rc == 0) { csr_check_values<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, val, p->rowpat, vr, d_bad, PATW_LEN, PATW_LEN); PT(hipGetLastError()); }
+    PT(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    PT(hipStreamSynchronize(st));
+    const size_t obytes = sizeof(int) * PATW_OFF * (size_t)npat, vbytes = sizeof(double) * PATW_LEN * (size_t)npat;
+    unsigned char *img = (unsigned char *)calloc(1, obytes + vbytes);
+    if (rc == 0 && bad == 0 && img) {
+        int *off = (int *)img;
+        for (int i = 0; i < npat; i++) {
+            const int l = tab[i + 1] - tab[i];
+            for (int j = 0; j < PATW_LEN; j++) off[PATW_OFF * i + j] = 8 * tab[npat + 1 + tab[i] + (j < l ? j : l - 1)];
+            off[PATW_OFF * i + PATW_LEN] = l;
+        }
+        PT(hipMemcpy(img + obytes, vr, vbytes, hipMemcpyDeviceToHost));
+        PT(hipMalloc(&p->vrecw, obytes + vbytes));
+        PT(hipMemcpy(p->vrecw, img, obytes + vbytes, hipMemcpyHostToDevice));
+        if (rc != 0 && p->vrecw) { (void)hipFree(p->vrecw); p->vrecw = nullptr; }
+    }
+#undef PT
+    (void)hipFree(d_rep); (void)hipFree(d_bad); (void)hipFree(vr);
+    free(img); free(tab);
+    return rc;
+}
+
 extern "C" int liship_csr_plan_encode_row_values(liship_csr_plan_t p, const int *ptr, const double *val, void *stream)
 {
     if (!p || (p->n > 0 && (!ptr || !val))) return LISHIP_ERR_ARG;
+    if (p->rowpat && !p->ptab8 && !p->vrecw && !p->vrec && g_variant == 0) return encode_wide_value_records(p, ptr, val, as_stream(stream));
     if (!p->rowpat || !p->ptab8 || p->vrec || p->npat <= 0 || p->npat > PAT7_MAX || g_variant != 0) return 0;
     hipStream_t st = as_stream(stream);
     int *d_rep = nullptr, *d_bad = nullptr, bad = 1, rc = 0;
@@ -1964,8 +2073,9 @@ extern "C" int liship_csr_plan_encode_row_values(liship_csr_plan_t p, const int 
     if (bad != 0) return refine_patterns_by_values(p, ptr, val, hr, st);     // rows of one offset pattern with different values
     return install_value_records(p, p->npat, hr, hv);
 }
-// 1 when the plan keeps the rows' values in the pattern records (the products then read neither values nor indices), else 0
-extern "C" int liship_csr_plan_value_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8 && p->vrec) ? 1 : 0; }
+// 1 (2: wide records) when the plan keeps the rows' values in the pattern records (the products then read neither values nor indices), else 0
+extern "C" int liship_csr_plan_value_records(liship_csr_plan_t p)
+{ return (p && p->rowpat && p->ptab8 && p->vrec) ? 1 : (p && p->rowpat && p->vrecw) ? 2 : 0; }        // 2: the wide records (rows of up to 32 entries)
 extern "C" int liship_spmv_csr_set_row_values(int on) { g_row_values = on ? 1 : 0; return 0; }
 
 // Block-local columns for the products kernel (see spmv_csr_local_kernel): setup-time, optional, never an error when the
@@ -2049,6 +2159,7 @@ struct LaunchArgs {
     const v4i32 *ptab8 = nullptr;
     const v4i32 *vrec = nullptr;            // value records (with ptab8), when the plan has them and they are switched on
     const int *order = nullptr;             // launch order of the products kernel (whole-matrix launches of a plan that has one)
+    const v4i32 *vrecw = nullptr;           // wide value records (rows of up to 32 entries), when the plan has them and they are switched on
 };
 
 
@@ -2125,6 +2236,12 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
                 a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, chunks, Rows{a.rb, a.re, a.acc0});
         return;
     }
+    if (a.rowpat && a.vrecw && g_variant == 0) {      // the rows' values ride in WIDE records (rows of up to 32 entries): one byte per row
+        constexpr Geometry g = kGeom[G];
+        spmv_csr_valuerecw_kernel<g.block, 0><<<a.nb, g.block, 0, a.st>>>(
+            a.rowpat, a.vrecw, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0});
+        return;
+    }
     if (a.rowpat && a.ptab8 && g_variant == 0) {      // patterns of at most 7 offsets: gathers ahead of the slice
         constexpr Geometry g = kGeom[G];
         spmv_csr_pattern7_kernel<g.block, g.work, 0><<<a.nb, g.block, 0, a.st>>>(
@@ -2175,6 +2292,12 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
     if (a.rowpat && a.ptab8 && !(g_variant & 0x2000)) {
         spmv_csr_pattern7_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz,
+            w, partial, liship_internal_guard(), pstride);
+        return;
+    }
+    if (a.rowpat && a.vrecw && !(g_variant & 0x2000)) {
+        spmv_csr_valuerecw_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(
+            a.rowpat, a.vrecw, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
             w, partial, liship_internal_guard(), pstride);
         return;
     }
@@ -2239,7 +2362,7 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
                                    const double *val, const double *x, double *y, void *stream)
 {
     if (!p) return LISHIP_ERR_ARG;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order, g_row_values ? p->vrecw : nullptr};
     return launch_csr(p, a);
 }
 
@@ -2255,7 +2378,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x6000) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order, g_row_values ? p->vrecw : nullptr};
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);
@@ -2281,7 +2404,7 @@ extern "C" int liship_spmv_csr_rows_f64(liship_csr_plan_t p, int row_begin, int 
     const int bfirst = lo;
     lo = bfirst; hi = p->nblocks;                // first b with br[b].row >= row_end
     while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid].x >= row_end) hi = mid; else lo = mid + 1; }
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, lo - bfirst, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, nullptr, g_row_values ? p->vrecw : nullptr};
     return launch_csr(p, a);
 }
 
@@ -2309,7 +2432,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if (nb <= 0) return 0;
     if ((size_t)slot_base + (size_t)nb > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work) + slot_base;
-    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr};
+    LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, nullptr, g_row_values ? p->vrecw : nullptr};
     const int ps = (int)slots;
     if (p->products && p->geom == LOCAL_GEOM) {
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial, ps);

@@ -203,20 +203,47 @@ def cyclic_diagonals(n, count, seed):
 # row patterns the plan must find on top of the codes: 3 for the 1-D stencil (first row, interior, last row), 27 for the 3-D one
 ROW_PATTERNS = {"p1d_10000": 3, "p3d_20x17x13": 27, "p3d_64_sorted": 27, "p3d_40_sorted": 27, "p3d_odd_33x7x5": 27, "diagonals_255": 255,
                 "diagonals_300": 0, "rand_5000": 0, "wide_77": 0,        # diagonals_255: 254 two-entry rows + the rows whose second entry falls outside
-                "p1d_9999": 3, "p3d_holes": 27, "p3d_varcoef": 27, "p3d_dirichlet": 27}            # p3d_holes: the empty row is one more pattern, a corner row that lost its entries one fewer
+                "p1d_9999": 3, "p3d_holes": 27, "p3d_varcoef": 27, "p3d_dirichlet": 27, "box27_18x15x13": 27, "box9_70x50": 9}            # p3d_holes: the empty row is one more pattern, a corner row that lost its entries one fewer
 # ... and whether it also keeps them as 32 B records (1..7 offsets per pattern, at most 64 patterns: spmv_csr_pattern7_kernel)
 # ... and whether every row of a pattern also carries the same values (then the records hold them: spmv_csr_valuerec_kernel)
 VALUE_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
                  "p3d_varcoef": 0, "p3d_holes": 0, "diagonals_255": 0, "band_9_unsorted": 0,
-                 "p3d_dirichlet": 1}         # ... after the offset patterns were split by the values their rows carry
+                 "p3d_dirichlet": 1,         # ... after the offset patterns were split by the values their rows carry
+                 "box27_18x15x13": 2, "box9_70x50": 2}
 PATTERN_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
-                   "diagonals_255": 0, "p3d_holes": 0, "band_9_unsorted": 0, "rand_5000": 0, "p3d_varcoef": 1, "p3d_dirichlet": 1}
+                   "diagonals_255": 0, "p3d_holes": 0, "band_9_unsorted": 0, "rand_5000": 0, "p3d_varcoef": 1, "p3d_dirichlet": 1,
+                   "box27_18x15x13": 0, "box9_70x50": 0}
 
 
 def poisson3d_variable_coefficients(nx, ny, nz, seed):
     """the 3-D stencil's pattern with random values: pattern records, but no value records"""
     ptr, idx, val = orc.poisson3d(nx, ny, nz)
     return ptr, idx, np.random.default_rng(seed).uniform(-1, 1, len(val))
+
+
+def stencil_box(dims, centre=None):
+    """the full box stencil on a grid (9 points in 2-D, 27 in 3-D), constant coefficients: -1 on the neighbours, their count on the
+    diagonal, Dirichlet truncation; sorted columns.  What the reference's spmvtest2b / spmvtest3b drivers generate."""
+    dims = tuple(dims)
+    n = int(np.prod(dims))
+    grids = np.meshgrid(*[np.arange(d) for d in dims], indexing="ij")
+    co = [g.ravel() for g in grids]
+    strides = [int(np.prod(dims[k + 1:])) for k in range(len(dims))]
+    rows, cols, vals = [], [], []
+    import itertools
+    for d in itertools.product((-1, 0, 1), repeat=len(dims)):
+        m = np.ones(n, bool)
+        for k, dk in enumerate(d):
+            m &= (co[k] + dk >= 0) & (co[k] + dk < dims[k])
+        r = np.nonzero(m)[0]
+        rows.append(r)
+        cols.append(r + sum(dk * st for dk, st in zip(d, strides)))
+        vals.append(np.full(len(r), float(3 ** len(dims) - 1) if centre is None and not any(d) else (centre if not any(d) else -1.0)))
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    order = np.lexsort((cols, rows))
+    ptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=ptr[1:])
+    return ptr.astype(np.int32), cols[order].astype(np.int32), vals[order]
 
 
 def poisson3d_with_dirichlet_rows(nx, ny, nz, every):
@@ -250,6 +277,8 @@ CODED_CASES = {
     "p3d_holes": (lambda: poisson3d_with_empty_rows(24, 20, 16, 37), 7),
     "p3d_varcoef": (lambda: poisson3d_variable_coefficients(24, 20, 16, 5), 7),
     "p3d_dirichlet": (lambda: poisson3d_with_dirichlet_rows(24, 20, 16, 11), 7),
+    "box27_18x15x13": (lambda: stencil_box((18, 15, 13)), 27),                                  # rows of up to 27 entries: the wide value records
+    "box9_70x50": (lambda: stencil_box((70, 50)), 9),
     "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
     "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
     "p3d_40_sorted": (lambda: orc.poisson3d(40, 40, 40, sort_cols=True), 7),                # several row blocks
@@ -296,7 +325,7 @@ def test_spmv_csr_index_codes(lib, name):
     check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
     if name in VALUE_RECORDS:
         assert lib.liship_csr_plan_value_records(plan) == VALUE_RECORDS[name]
-    assert lib.liship_csr_plan_value_records(plan) <= lib.liship_csr_plan_pattern_records(plan)
+    assert lib.liship_csr_plan_value_records(plan) in (0, 2) or lib.liship_csr_plan_pattern_records(plan) == 1     # 2: the wide records
     results = {}
     for on in (5, 4, 3, 2, 1, 0):              # 4: values in the pattern records too (nothing streamed; 5: the plain product two rows per
         lib.liship_spmv_csr_set_index_codes(1 if on else 0)         # lane, the form for x beyond the Infinity Cache), 2: one byte per row
@@ -1113,7 +1142,7 @@ def test_plan_coders_on_random_structured_matrices(lib, seed):
     check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
     state = (lib.liship_csr_plan_coded(plan), lib.liship_csr_plan_row_patterns(plan), lib.liship_csr_plan_pattern_records(plan),
              lib.liship_csr_plan_value_records(plan))
-    assert state[3] <= state[2] <= (1 if state[1] else 0) <= (1 if state[0] else 0), state
+    assert (state[3] == 1) <= state[2] <= (1 if state[1] else 0) <= (1 if state[0] else 0) and (state[3] != 2 or (state[1] and not state[2])), state
     dots = []
     try:
         for codes, pats, vals_on, variant in ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0x2000), (1, 1, 0, 0), (1, 1, 1, 0), (1, 1, 1, 0x4000)):

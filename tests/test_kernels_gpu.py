@@ -1096,8 +1096,9 @@ def _structured_random(seed):
     rows longer than 7, values from a palette / per template / fully random, columns beyond n"""
     rng = np.random.default_rng(seed)
     n = int(rng.choice([1, 2, 3, 17, 64, 255, 256, 257, 1000, 2500, 4099, 9000]))
-    nd = int(rng.integers(1, 10))
-    offs = np.unique(np.concatenate([[0], rng.integers(-min(n, 300), min(n, 300) + 1, nd - 1)])) if nd > 1 else np.array([0])
+    nd = int(rng.integers(1, 10)) if rng.random() < 0.7 else int(rng.integers(10, 30))      # up to 7: the 32 B records; 8..32: the wide ones
+    reach = min(n, 300) if rng.random() < 0.7 else min(n, 12)                               # a narrow band keeps the boundary patterns few
+    offs = np.unique(np.concatenate([[0], rng.integers(-reach, reach + 1, nd - 1)])) if nd > 1 else np.array([0])
     ncols = n + (int(rng.integers(1, 50)) if rng.random() < 0.3 else 0)
     ntemp = int(rng.integers(1, 7))
     temps = []

@@ -358,7 +358,7 @@ static LIS_INT try_row_form(LIS_MATRIX A, lisd_mat *d, int *taken)
 	const int n = A->n;
 	if (lisg.no_value_records || lisg.no_row_patterns || lisg.no_index_codes || n <= 0) return LIS_SUCCESS;
 	const int width = A->matrix_type == LIS_MATRIX_ELL ? A->maxnzr : A->nnd;
-	if (width < 1 || width > 7 || (long long)n * width >= 0x7fffffffLL) return LIS_SUCCESS;     /* value records hold 7 entries per row */
+	if (width < 1 || width > 32 || (long long)n * width >= 0x7fffffffLL) return LIS_SUCCESS;    /* value records hold up to 32 entries per row */
 	if (!few_distinct_values(A->value, (size_t)n * (size_t)width)) return LIS_SUCCESS;
 	int *cptr = (int *)malloc(sizeof(int) * ((size_t)n + 1));
 	if (!cptr) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "row form\n");

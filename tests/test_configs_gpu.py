@@ -144,6 +144,28 @@ def test_config5_256_cubed_cg_jacobi_in_ell_and_dia(lib, fmt):
     lib.lis_matrix_destroy(A)
 
 
+def test_ell_row_form_of_the_27_point_stencil(lib):
+    """rows of 27 entries: the ELL row form meets the WIDE value records (DIA does not: its explicit zeros give rows of one offset
+    pattern different values, which only the 7-entry records split -- it keeps its native kernel, with the same bits)"""
+    from test_kernels_gpu import stencil_box
+    ptr, idx, val = stencil_box((11, 9, 8))
+    n = len(ptr) - 1
+    fn = lib.dll.lis_amd_matrix_value_records
+    fn.argtypes = [capi.PM]
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    x[[1, n // 3]] = [np.nan, np.inf]
+    for fmt, want_records in (("ell", 2), ("dia", 0)):
+        A = lisdrv.make_csr(lib, ptr, idx, val)
+        B = lisdrv.convert(lib, A, fmt)
+        arrs = lisdrv.matrix_arrays(B)
+        want = (orc.spmv_ell(n, B.contents.maxnzr, arrs["index"], arrs["value"], x) if fmt == "ell"
+                else orc.spmv_dia(n, B.contents.nnd, arrs["index"], arrs["value"], x))
+        got = lisdrv.matvec(lib, B, x)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+        assert fn(B) == want_records
+        lib.lis_matrix_destroy(B)
+
+
 @pytest.mark.parametrize("fmt", ["ell", "dia"])
 def test_ell_and_dia_row_form_for_constant_coefficients(lib, fmt):
     """An ELL / DIA matrix with constant coefficients lives in HBM as CSR rows that list the format's terms -- padding and explicit

@@ -90,7 +90,7 @@ int  liship_csr_plan_pattern_records(liship_csr_plan_t plan);
  * order: bit-identical.  The value array must not change afterwards (a new plan is needed if it does).
  * Rows of one offset pattern that carry different values (a Dirichlet row stored with the interior row's sparsity) split the pattern.
  * Patterns of 8..32 offsets (no 32 B records: the 9-point stencil in 2-D, the 19- and 27-point ones in 3-D) get WIDE records when
- * there are at most 48 of them (400 B per pattern; no splitting by values there).
+ * there are at most 48 of them after the same splitting (400 B per pattern).
  * liship_csr_plan_value_records: 1 if the plan has them, 2 for the wide form.  liship_spmv_csr_set_row_values(0): A/B switch
  * (stream the values). */
 int  liship_csr_plan_encode_row_values(liship_csr_plan_t plan, const int *ptr, const double *value, void *stream);

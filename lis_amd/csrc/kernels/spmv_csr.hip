@@ -1559,19 +1559,20 @@ __global__ void csr_collect_value_patterns(int n, const int *__restrict__ ptr, c
 }
 // per refined pattern: the offset pattern of its representative row and that row's values
 __global__ void csr_fetch_value_patterns(int npat, const int *__restrict__ rep, const int *__restrict__ ptr, const double *__restrict__ val,
-                                         const unsigned char *__restrict__ rowpat, int *__restrict__ oldpat, double *__restrict__ vrec)
+                                         const unsigned char *__restrict__ rowpat, int *__restrict__ oldpat, double *__restrict__ vrec,
+                                         int stride = 8, int cap = 7)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npat) return;
     const int s = ptr[rep[p]], e = ptr[rep[p] + 1];
     oldpat[p] = rowpat[rep[p]];
-    for (int j = 0; j < 8; j++) vrec[8 * p + j] = (s + j < e && j < 7) ? val[s + j] : 0.0;
+    for (int j = 0; j < stride; j++) vrec[stride * p + j] = (s + j < e && j < cap) ? val[s + j] : 0.0;
 }
 // every row -> its refined pattern (position of its hash in the sorted list; offset pattern and values verified)
 __global__ void csr_encode_value_patterns(int n, const int *__restrict__ ptr, const double *__restrict__ val,
                                           const unsigned char *__restrict__ rowpat, int npat, const unsigned long long *__restrict__ hashes,
                                           const int *__restrict__ oldpat, const double *__restrict__ vrec,
-                                          unsigned char *__restrict__ out, int *__restrict__ bad)
+                                          unsigned char *__restrict__ out, int *__restrict__ bad, int stride = 8, int cap = 7)
 {
     __shared__ unsigned long long hL[256];
     for (int i = threadIdx.x; i < npat; i += blockDim.x) hL[i] = hashes[i];
@@ -1582,8 +1583,8 @@ __global__ void csr_encode_value_patterns(int n, const int *__restrict__ ptr, co
     const unsigned long long h = value_row_hash(op, val, s, e);
     int lo = 0, hi = npat - 1;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (hL[mid] < h) lo = mid + 1; else hi = mid; }
-    bool ok = hL[lo] == h && oldpat[lo] == op && e - s <= 7;
-    for (int k = s; ok && k < e; k++) ok = __double_as_longlong(val[k]) == __double_as_longlong(vrec[8 * lo + (k - s)]);
+    bool ok = hL[lo] == h && oldpat[lo] == op && e - s <= cap;
+    for (int k = s; ok && k < e; k++) ok = __double_as_longlong(val[k]) == __double_as_longlong(vrec[stride * lo + (k - s)]);
     if (!ok) atomicAdd(bad, 1);
     out[r] = (unsigned char)lo;
 }
@@ -2000,7 +2001,7 @@ static int refine_patterns_by_values(liship_csr_plan_s *p, const int *ptr, const
 // does not qualify (no 32 B records, or two rows of one pattern with different values).  One pass over ptr / value.
 // the same for patterns of up to 32 entries (no 32 B records): offsets from the plan's pattern table, values from one row per pattern,
 // every row checked; the image is npat x 144 B (32 byte offsets, the tail repeating the last one; the length; padding) followed by
-// npat x 256 B (32 values, the tail 0).  No refinement here: rows of one offset pattern with different values keep the values streamed.
+// npat x 256 B (32 values, the tail 0).  Rows of one offset pattern with different values split the pattern (up to 48 in all).
 static int encode_wide_value_records(liship_csr_plan_s *p, const int *ptr, const double *val, hipStream_t st)
 {
     if (p->npat <= 0 || p->npat > PATW_MAX || p->ptab_len <= p->npat) return 0;
@@ -2022,23 +2023,95 @@ static int encode_wide_value_records(liship_csr_plan_s *p, const int *ptr, const
     if (rc == 0) { csr_check_values<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, val, p->rowpat, vr, d_bad, PATW_LEN, PATW_LEN); PT(hipGetLastError()); }
     PT(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
     PT(hipStreamSynchronize(st));
-    const size_t obytes = sizeof(int) * PATW_OFF * (size_t)npat, vbytes = sizeof(double) * PATW_LEN * (size_t)npat;
+    // rows of one offset pattern with different values: split the patterns by (pattern, values), as for the 7-entry records
+    int np2 = npat, *oldpat = nullptr, *ntab = nullptr, ntab_len = 0, reps2[PATW_MAX];
+    unsigned char *newpat = nullptr;
+    double *vr2 = nullptr;                               // device: the refined patterns' values
+    if (rc == 0 && bad != 0) {
+        struct Table { unsigned long long keys[PAT_SLOTS]; int rep[PAT_SLOTS]; int count; };
+        Table *host = (Table *)calloc(1, sizeof(Table)), *dev = nullptr;
+        if (host) {
+            for (int i = 0; i < PAT_SLOTS; i++) host->rep[i] = 0x7fffffff;
+            PT(hipMalloc(&dev, sizeof(Table)));
+            PT(hipMemcpyAsync(dev, host, sizeof(Table), hipMemcpyHostToDevice, st));
+            if (rc == 0) { csr_collect_value_patterns<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, val, p->rowpat, dev->keys, dev->rep, &dev->count); PT(hipGetLastError()); }
+            PT(hipMemcpyAsync(host, dev, sizeof(Table), hipMemcpyDeviceToHost, st));
+            PT(hipStreamSynchronize(st));
+            if (dev) (void)hipFree(dev);
+            if (rc == 0 && host->count > 0 && host->count <= PATW_MAX) {
+                int order[PATW_MAX];
+                np2 = 0;
+                for (int i = 0; i < PAT_SLOTS && np2 < PATW_MAX; i++) if (host->keys[i] != 0ull) order[np2++] = i;
+                for (int i = 1; i < np2; i++) { const int v = order[i]; int j = i - 1; while (j >= 0 && host->keys[order[j]] > host->keys[v]) { order[j + 1] = order[j]; j--; } order[j + 1] = v; }
+                unsigned long long hashes[PATW_MAX];
+                for (int i = 0; i < np2; i++) { hashes[i] = host->keys[order[i]]; reps2[i] = host->rep[order[i]]; }
+                unsigned long long *d_hash = nullptr; int *d_rep2 = nullptr, *d_old = nullptr;
+                oldpat = (int *)malloc(sizeof(int) * PATW_MAX);
+                PT(hipMalloc(&d_hash, sizeof(hashes))); PT(hipMalloc(&d_rep2, sizeof(int) * PATW_MAX)); PT(hipMalloc(&d_old, sizeof(int) * PATW_MAX));
+                PT(hipMalloc(&vr2, sizeof(double) * PATW_LEN * PATW_MAX)); PT(hipMalloc(&newpat, (size_t)p->n + 64));
+                PT(hipMemcpyAsync(d_hash, hashes, sizeof(unsigned long long) * np2, hipMemcpyHostToDevice, st));
+                PT(hipMemcpyAsync(d_rep2, reps2, sizeof(int) * np2, hipMemcpyHostToDevice, st));
+                PT(hipMemsetAsync(d_bad, 0, sizeof(int), st));
+                if (rc == 0) { csr_fetch_value_patterns<<<1, 64, 0, st>>>(np2, d_rep2, ptr, val, p->rowpat, d_old, vr2, PATW_LEN, PATW_LEN); PT(hipGetLastError()); }
+                if (rc == 0) {
+                    csr_encode_value_patterns<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, val, p->rowpat, np2, d_hash, d_old, vr2, newpat, d_bad, PATW_LEN, PATW_LEN);
+                    PT(hipGetLastError());
+                }
+                if (oldpat) PT(hipMemcpyAsync(oldpat, d_old, sizeof(int) * np2, hipMemcpyDeviceToHost, st));
+                PT(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+                PT(hipStreamSynchronize(st));
+                (void)hipFree(d_hash); (void)hipFree(d_rep2); (void)hipFree(d_old);
+                if (rc == 0 && bad == 0 && oldpat) {         // the general pattern table of the refined set (prefix, then element offsets)
+                    int total = 0;
+                    for (int i = 0; i < np2; i++) total += tab[oldpat[i] + 1] - tab[oldpat[i]];
+                    ntab_len = np2 + 1 + total;
+                    ntab = ntab_len <= PAT_TABLE ? (int *)malloc(sizeof(int) * (size_t)ntab_len) : nullptr;     // (the general pattern kernel keeps the table in LDS)
+                    if (ntab) {
+                        int at = 0;
+                        for (int i = 0; i < np2; i++) {
+                            const int l = tab[oldpat[i] + 1] - tab[oldpat[i]];
+                            ntab[i] = at;
+                            for (int j = 0; j < l; j++) ntab[np2 + 1 + at + j] = tab[npat + 1 + tab[oldpat[i]] + j];
+                            at += l;
+                        }
+                        ntab[np2] = at;
+                    } else bad = 1;
+                } else bad = 1;
+            }
+            free(host);
+        }
+    }
+    const int *T = ntab ? ntab : tab;                    // the table the records are built from, and its pattern count
+    const int NP = ntab ? np2 : npat;
+    const size_t obytes = sizeof(int) * PATW_OFF * (size_t)NP, vbytes = sizeof(double) * PATW_LEN * (size_t)NP;
     unsigned char *img = (unsigned char *)calloc(1, obytes + vbytes);
     if (rc == 0 && bad == 0 && img) {
         int *off = (int *)img;
-        for (int i = 0; i < npat; i++) {
-            const int l = tab[i + 1] - tab[i];
-            for (int j = 0; j < PATW_LEN; j++) off[PATW_OFF * i + j] = 8 * tab[npat + 1 + tab[i] + (j < l ? j : l - 1)];
+        for (int i = 0; i < NP; i++) {
+            const int l = T[i + 1] - T[i];
+            for (int j = 0; j < PATW_LEN; j++) off[PATW_OFF * i + j] = 8 * T[NP + 1 + T[i] + (j < l ? j : l - 1)];
             off[PATW_OFF * i + PATW_LEN] = l;
         }
-        PT(hipMemcpy(img + obytes, vr, vbytes, hipMemcpyDeviceToHost));
+        PT(hipMemcpy(img + obytes, ntab ? vr2 : vr, vbytes, hipMemcpyDeviceToHost));
         PT(hipMalloc(&p->vrecw, obytes + vbytes));
         PT(hipMemcpy(p->vrecw, img, obytes + vbytes, hipMemcpyHostToDevice));
-        if (rc != 0 && p->vrecw) { (void)hipFree(p->vrecw); p->vrecw = nullptr; }
+        int *d_tab = nullptr;
+        if (ntab) {                                      // the refined pattern bytes and table replace the plan's
+            PT(hipMalloc(&d_tab, sizeof(int) * (size_t)ntab_len));
+            PT(hipMemcpy(d_tab, ntab, sizeof(int) * (size_t)ntab_len, hipMemcpyHostToDevice));
+        }
+        if (rc != 0) { if (p->vrecw) (void)hipFree(p->vrecw); p->vrecw = nullptr; if (d_tab) (void)hipFree(d_tab); }
+        else if (ntab) {
+            (void)hipFree(p->rowpat); (void)hipFree(p->ptab);
+            p->rowpat = newpat; newpat = nullptr; p->ptab = d_tab; p->npat = np2; p->ptab_len = ntab_len;
+            for (int i = 0; i < np2; i++) p->prep[i] = reps2[i];
+        }
     }
 #undef PT
     (void)hipFree(d_rep); (void)hipFree(d_bad); (void)hipFree(vr);
-    free(img); free(tab);
+    if (vr2) (void)hipFree(vr2);
+    if (newpat) (void)hipFree(newpat);
+    free(img); free(tab); free(ntab); free(oldpat);
     return rc;
 }
 

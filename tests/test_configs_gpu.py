@@ -144,9 +144,9 @@ def test_config5_256_cubed_cg_jacobi_in_ell_and_dia(lib, fmt):
     lib.lis_matrix_destroy(A)
 
 
-def test_ell_row_form_of_the_27_point_stencil(lib):
-    """rows of 27 entries: the ELL row form meets the WIDE value records (DIA does not: its explicit zeros give rows of one offset
-    pattern different values, which only the 7-entry records split -- it keeps its native kernel, with the same bits)"""
+def test_ell_and_dia_row_form_of_the_27_point_stencil(lib):
+    """rows of 27 entries: the ELL and DIA row forms meet the WIDE value records (DIA's explicit zeros give rows of one offset
+    pattern different values: the patterns are split by them)"""
     from test_kernels_gpu import stencil_box
     ptr, idx, val = stencil_box((11, 9, 8))
     n = len(ptr) - 1
@@ -154,7 +154,7 @@ def test_ell_row_form_of_the_27_point_stencil(lib):
     fn.argtypes = [capi.PM]
     x = np.random.default_rng(3).uniform(-1, 1, n)
     x[[1, n // 3]] = [np.nan, np.inf]
-    for fmt, want_records in (("ell", 2), ("dia", 0)):
+    for fmt, want_records in (("ell", 2), ("dia", 2)):
         A = lisdrv.make_csr(lib, ptr, idx, val)
         B = lisdrv.convert(lib, A, fmt)
         arrs = lisdrv.matrix_arrays(B)

@@ -209,7 +209,7 @@ ROW_PATTERNS = {"p1d_10000": 3, "p3d_20x17x13": 27, "p3d_64_sorted": 27, "p3d_40
 VALUE_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
                  "p3d_varcoef": 0, "p3d_holes": 0, "diagonals_255": 0, "band_9_unsorted": 0,
                  "p3d_dirichlet": 1,         # ... after the offset patterns were split by the values their rows carry
-                 "box27_18x15x13": 2, "box9_70x50": 2}
+                 "box27_18x15x13": 2, "box9_70x50": 2, "box27_dirichlet": 2}
 PATTERN_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
                    "diagonals_255": 0, "p3d_holes": 0, "band_9_unsorted": 0, "rand_5000": 0, "p3d_varcoef": 1, "p3d_dirichlet": 1,
                    "box27_18x15x13": 0, "box9_70x50": 0}
@@ -246,6 +246,16 @@ def stencil_box(dims, centre=None):
     return ptr.astype(np.int32), cols[order].astype(np.int32), vals[order]
 
 
+def box27_with_dirichlet_rows(dims, every):
+    """the 27-point stencil with identity rows stored on the stencil's sparsity (1 on the diagonal, explicit zeros beside it)"""
+    ptr, idx, val = stencil_box(dims)
+    val = val.copy()
+    for r in range(0, len(ptr) - 1, every):
+        seg = slice(ptr[r], ptr[r + 1])
+        val[seg] = np.where(idx[seg] == r, 1.0, 0.0)
+    return ptr, idx, val
+
+
 def poisson3d_with_dirichlet_rows(nx, ny, nz, every):
     """the 3-D stencil where every `every`-th row is an identity row stored with the stencil's sparsity (1 on the diagonal, explicit
     zeros beside it) -- how boundary conditions are often imposed: the same offset patterns, two value sets for some of them"""
@@ -279,6 +289,7 @@ CODED_CASES = {
     "p3d_dirichlet": (lambda: poisson3d_with_dirichlet_rows(24, 20, 16, 11), 7),
     "box27_18x15x13": (lambda: stencil_box((18, 15, 13)), 27),                                  # rows of up to 27 entries: the wide value records
     "box9_70x50": (lambda: stencil_box((70, 50)), 9),
+    "box27_dirichlet": (lambda: box27_with_dirichlet_rows((16, 13, 11), 7), 27),              # wide records after the split by values
     "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
     "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
     "p3d_40_sorted": (lambda: orc.poisson3d(40, 40, 40, sort_cols=True), 7),                # several row blocks

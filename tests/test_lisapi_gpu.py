@@ -5,6 +5,7 @@ lis_matvec, lis_solve.  SpMV and element-wise results must be bit-identical to t
 results follow north_star: CG iteration counts exact, relative residual within 1e-12, solutions close.
 """
 import ctypes as C
+import json
 import os
 
 import numpy as np
@@ -127,6 +128,7 @@ def _true_residual(ptr, idx, val, b, x):
 
 
 SOLVES = sorted({k.split("/")[1] for k in G.files if k.startswith("solve/")})
+SPREAD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "iteration_spread.json")))
 
 
 @pytest.mark.parametrize("name", SOLVES)
@@ -145,8 +147,11 @@ def test_lis_solve_against_golden(lib, name):
     if solver == "cg":
         assert out["iter"] == it_ref                       # north_star: bit-exact iteration counts (CG is reduction-order stable)
     else:
-        # BiCGSTAB / GMRES counts move with the reduction order in the reference itself (1/2/4/8 threads: SURVEY 8c)
-        assert abs(out["iter"] - it_ref) <= max(3, it_ref // 10)
+        # BiCGSTAB / GMRES counts move with the reduction order in the reference itself: tests/golden/iteration_spread.json holds its
+        # counts at 1 .. 8 OpenMP threads (make_golden_spread.py) -- each a different grouping of the dots' partial sums, which is all
+        # that separates this library's tree reductions from the 1-thread reference.  The count must lie inside that spread (+- 1).
+        spread = SPREAD["counts"][name]
+        assert min(spread) - 1 <= out["iter"] <= max(spread) + 1, (name, out["iter"], spread)
     assert out["resid"] <= 1e-12
     assert _true_residual(ptr, idx, val, b, out["x"]) <= 1e-11
     assert np.allclose(out["x"], G[f"solve/{name}/x"], rtol=0, atol=1e-9)

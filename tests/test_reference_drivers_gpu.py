@@ -52,7 +52,7 @@ def test_test3_solver_driver(tmp_path, opts):
     if "-i cg" in opts:
         assert it_a == it_r
     else:
-        assert abs(it_a - it_r) <= max(3, it_r // 10)
+        assert abs(it_a - it_r) <= 2                         # (the reference itself moves by 1 between thread counts: tests/golden/iteration_spread.json)
     assert res_a <= 1e-12 and res_r <= 1e-12
     assert len(x_a) == len(x_r) == 16 ** 3 and max(abs(a - b) for a, b in zip(x_a, x_r)) <= 1e-9
     assert abs(h_a[1] - h_r[1]) <= 1e-9 * h_r[1] and len(h_a) == it_a + 1
@@ -151,7 +151,7 @@ def test_spmvtest5_matrix_market_product(fmt):
     ("test5", (200, 2.0), "-i bicgstab -p none"), ("test5", (200, 0.5), "-i gmres -restart 30 -p jacobi")])
 def test_more_solver_drivers(tmp_path, driver, args, opts):
     """test2 (2-D Poisson), test3b (3-D 27-point), test5 (the non-symmetric Toeplitz system of test.sh): status, iteration
-    count (exact for CG, the usual slack where the reference's own count moves with its thread count) and residual"""
+    count (exact for CG, within 2 where the reference's own count moves with its thread count) and residual"""
     rep = {}
     for tag in ("amd", "ref"):
         files = (tmp_path / f"sol_{tag}.txt", tmp_path / f"rh_{tag}.txt") if driver != "test5" else ()
@@ -161,7 +161,7 @@ def test_more_solver_drivers(tmp_path, driver, args, opts):
     if "-i cg" in opts:
         assert it_a == it_r, rep
     else:
-        assert abs(it_a - it_r) <= max(3, it_r // 10), rep
+        assert abs(it_a - it_r) <= 2, rep
     if st_r == "normal end":
         assert res_a <= 1e-12 and res_r <= 1e-12
 

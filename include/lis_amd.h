@@ -40,6 +40,12 @@ LIS_INT lis_amd_set_loop_mode(LIS_INT mode);
 /* 1 when the last lis_solve ran CG + Jacobi on a matrix with a constant diagonal and its fused passes took 1/diag as one double
  * instead of reading the array (bit-identical; LIS_AMD_NO_UNIFORM_JACOBI=1 switches it off), else 0 */
 LIS_INT lis_amd_last_solve_uniform_jacobi(void);
+/* hipGraph replay of the device-driven Krylov batches (opt-in, environment LIS_AMD_GRAPHS=1): from the second full batch on
+ * a single-rank solve replays one captured batch instead of launching its kernels.  Results do not depend on it (same
+ * kernels, arguments and order); measured it does not pay on this hardware -- a small system's iteration is bound by the
+ * GPU's ~4.5 us per dependent kernel, not by the host's launch rate (profiles/r02_graph_sweep.txt). */
+LIS_INT lis_amd_set_graphs(LIS_INT on);
+LIS_INT lis_amd_last_solve_graph_replays(void);        /* batches of the last lis_solve that ran as a graph replay */
 
 /* vectors */
 LIS_INT lis_amd_vector_sync_host(LIS_VECTOR v);        /* make v->value[] current (D2H if needed)        */

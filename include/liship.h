@@ -41,6 +41,14 @@ int  liship_stream_create(void **stream);
 int  liship_stream_destroy(void *stream);
 int  liship_stream_synchronize(void *stream);
 int  liship_device_synchronize(void);
+/* hipGraph capture of whatever is enqueued on `stream` between begin and end (the Krylov loops replay a batch of
+ * iterations this way when the system is small enough to be launch bound -- the reference has no counterpart: its
+ * loops are host code, src/solver/lis_solver_cg.c:176-215).  capture_end always ends the capture; with exec == NULL the
+ * recording is dropped.  A failed capture leaves the stream usable for plain launches. */
+int  liship_graph_capture_begin(void *stream);
+int  liship_graph_capture_end(void *stream, void **exec);
+int  liship_graph_launch(void *exec, void *stream);
+int  liship_graph_destroy(void *exec);
 /* HIP-event stopwatch on `stream`: start/stop bracket a region, elapsed_ms reads it after stop+sync */
 /* page-locked host memory for the scalar read-backs */
 int  liship_malloc_host(void **ptr, size_t bytes);

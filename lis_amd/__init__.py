@@ -35,6 +35,10 @@ _LISHIP = {
     "liship_stream_destroy": (_ci, [_vp]),
     "liship_stream_synchronize": (_ci, [_vp]),
     "liship_device_synchronize": (_ci, []),
+    "liship_graph_capture_begin": (_ci, [_vp]),
+    "liship_graph_capture_end": (_ci, [_vp, _pvp]),
+    "liship_graph_launch": (_ci, [_vp, _vp]),
+    "liship_graph_destroy": (_ci, [_vp]),
     "liship_malloc_host": (_ci, [_pvp, _sz]),
     "liship_free_host": (_ci, [_vp]),
     "liship_event_create": (_ci, [_pvp]),

@@ -116,6 +116,8 @@ LIS_INT lis_amd_get_residency(void) { return lisg.residency; }
 
 LIS_INT lis_amd_last_solve_uniform_jacobi(void) { return lisg.last_uniform_jacobi; }
 
+LIS_INT lis_amd_set_graphs(LIS_INT on) { lisg.graphs = (on != 0); return LIS_SUCCESS; }
+LIS_INT lis_amd_last_solve_graph_replays(void) { return lisg.last_graph_replays; }
 LIS_INT lis_amd_set_loop_mode(LIS_INT mode)
 {
 	if (mode < LIS_AMD_LOOP_DEVICE || mode > LIS_AMD_LOOP_UNFUSED) return LISI_ERR(LIS_ERR_ILL_ARG, "unknown loop mode %D\n", mode);

@@ -106,6 +106,8 @@ typedef struct {
 	int no_value_records;      /* LIS_AMD_NO_VALUE_RECORDS=1: matrices whose rows repeat with their values keep streaming the values (A/B measurements) */
 	int no_row_patterns;       /* LIS_AMD_NO_ROW_PATTERNS=1: coded CSR matrices keep one byte per non-zero instead of one per row (A/B measurements) */
 	int last_uniform_jacobi;   /* the last lis_solve ran CG + Jacobi with 1/diag as one double (lis_amd_last_solve_uniform_jacobi) */
+	int graphs;                /* LIS_AMD_GRAPHS=1: single-rank device-driven loops replay a hipGraph of one batch (opt-in: measured, no gain) */
+	int last_graph_replays;    /* batches of the last lis_solve that were graph replays (lis_amd_last_solve_graph_replays) */
 	int no_uniform_jacobi;     /* LIS_AMD_NO_UNIFORM_JACOBI=1: CG + Jacobi reads 1/diag even when the diagonal is constant (A/B measurements) */
 	int no_local_columns;      /* LIS_AMD_NO_LOCAL_COLUMNS=1: long-row CSR products keep the 4 B column indices (A/B measurements) */
 	int no_index_codes;        /* LIS_AMD_NO_INDEX_CODES=1: CSR products keep reading the 4 B column indices (A/B measurements) */

@@ -342,6 +342,43 @@ static LIS_INT dev_loop_sync(ctx_t *c, dev_loop *L)
 	return LIS_SUCCESS;
 }
 
+/* The batches of a device-driven loop.  `enqueue` puts `batch` whole iterations on the stream (the first one is
+ * iteration queued + 1).  With LIS_AMD_GRAPHS=1 a single-rank solve replays a hipGraph of one batch from the second full
+ * batch on (every argument of every kernel is the same from batch to batch -- the scalars live in the state block -- and
+ * a batch behind a raised convergence flag is as harmless replayed as enqueued).  Opt-in because it does not pay here:
+ * 32^3 and 64^3 run the same 44 000 CG iterations/s (5 dependent kernels in 22.5 us), so the floor is the GPU's
+ * dispatch of a dependent kernel, not the host's launch rate, and the replay is 0-5 % SLOWER from 32^3 to 320^3
+ * (profiles/r02_graph_sweep.txt). */
+typedef LIS_INT (*dev_batch_fn)(ctx_t *c, dev_loop *L, void *vars, LIS_INT queued, LIS_INT batch);
+static LIS_INT dev_loop_run(ctx_t *c, dev_loop *L, dev_batch_fn enqueue, void *vars)
+{
+	LIS_INT err = 0;
+	void *gexec = NULL;
+	int graphs = lisg.graphs && lisg.nprocs == 1;
+	for (LIS_INT queued = 0; queued < c->maxiter && L->host[LISHIP_KS_DONE] == 0.0; ) {
+		const LIS_INT batch = (c->maxiter - queued < LISD_BATCH) ? c->maxiter - queued : LISD_BATCH;
+		int replayed = 0;
+		if (graphs && queued > 0 && batch == LISD_BATCH) {
+			if (!gexec) {
+				int rc = liship_graph_capture_begin(lisg.stream);
+				if (rc == 0) {
+					const LIS_INT e = enqueue(c, L, vars, queued, batch);
+					rc = liship_graph_capture_end(lisg.stream, e ? NULL : &gexec);
+					if (e || rc) { (void)liship_krylov_chain(0, NULL, NULL); gexec = NULL; }
+				}
+				if (!gexec) graphs = 0;                    /* not capturable here: plain launches from now on */
+			}
+			if (gexec) { KTRY(liship_graph_launch(gexec, lisg.stream)); replayed = 1; lisg.last_graph_replays++; }
+		}
+		if (!replayed) TRY(enqueue(c, L, vars, queued, batch));
+		queued += batch;
+		TRY(dev_loop_sync(c, L));
+	}
+done:
+	(void)liship_graph_destroy(gexec);
+	return err;
+}
+
 static LIS_INT dev_loop_finish(ctx_t *c, dev_loop *L, LIS_INT err)
 {
 	LIS_SOLVER s = c->s;
@@ -354,6 +391,30 @@ static LIS_INT dev_loop_finish(ctx_t *c, dev_loop *L, LIS_INT err)
 		else { s->retcode = LIS_MAXITER; s->iter = c->maxiter + 1; err = LIS_MAXITER; }
 	}
 	if (L->st) { (void)liship_stream_synchronize(lisg.stream); lisd_pool_put(L->st, L->bytes); L->st = NULL; }
+	return err;
+}
+
+typedef struct { double *q, *r, *p; } cg_vars;
+static LIS_INT cg_batch(ctx_t *c, dev_loop *L, void *vars, LIS_INT queued, LIS_INT batch)
+{
+	LIS_INT err = 0;
+	const int n = c->n;
+	const cg_vars *v = (const cg_vars *)vars;
+	double *q = v->q, *r = v->r, *p = v->p, *st = L->st;
+	for (LIS_INT k = 0; k < batch; k++) {
+		/* x += alpha p of the PREVIOUS iteration rides in this pass, which reads p anyway (none before the first) */
+		if (c->duniform) KTRY(liship_cg_direction_uniform_dev_f64(n, queued + k ? st + LISHIP_KS_ALPHA : NULL, st + LISHIP_KS_BETA, r, c->dconst, p, c->x, lisg.stream));
+		else KTRY(liship_cg_direction_dev_f64(n, queued + k ? st + LISHIP_KS_ALPHA : NULL, st + LISHIP_KS_BETA, r, c->dinv, p, c->x, lisg.stream));
+		TRY(dev_announce(L, LISHIP_STEP_CG_ALPHA));
+		TRY(lisd_spmv_dot_launch_to(c->A, p, q, p, 0, st + LISHIP_KS_DOT0));
+		TRY(dev_step(L, LISHIP_STEP_CG_ALPHA, LISHIP_KS_DOT0, 1));
+		TRY(dev_announce(L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID));
+		if (c->duniform) KTRY(liship_cg_residual_jacobi_uniform_dev_f64(n, st + LISHIP_KS_NALPHA, q, c->dconst, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+		else if (c->dinv) KTRY(liship_cg_residual_jacobi_dev_f64(n, st + LISHIP_KS_NALPHA, q, c->dinv, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+		else         KTRY(liship_axpy_sumsq_dev_f64(n, st + LISHIP_KS_NALPHA, q, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+		TRY(dev_step(L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID, LISHIP_KS_SUM0, c->dinv ? 2 : 1));
+	}
+done:
 	return err;
 }
 
@@ -374,24 +435,8 @@ static LIS_INT run_cg_device(ctx_t *c)
 	TRY(dev_loop_begin(c, &L, init));
 	double *st = L.st;
 	KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
-	for (LIS_INT queued = 0; queued < c->maxiter && L.host[LISHIP_KS_DONE] == 0.0; ) {
-		const LIS_INT batch = (c->maxiter - queued < LISD_BATCH) ? c->maxiter - queued : LISD_BATCH;
-		for (LIS_INT k = 0; k < batch; k++) {
-			/* x += alpha p of the PREVIOUS iteration rides in this pass, which reads p anyway (none before the first) */
-			if (c->duniform) KTRY(liship_cg_direction_uniform_dev_f64(n, queued + k ? st + LISHIP_KS_ALPHA : NULL, st + LISHIP_KS_BETA, r, c->dconst, p, c->x, lisg.stream));
-			else KTRY(liship_cg_direction_dev_f64(n, queued + k ? st + LISHIP_KS_ALPHA : NULL, st + LISHIP_KS_BETA, r, c->dinv, p, c->x, lisg.stream));
-			TRY(dev_announce(&L, LISHIP_STEP_CG_ALPHA));
-			TRY(lisd_spmv_dot_launch_to(c->A, p, q, p, 0, st + LISHIP_KS_DOT0));
-			TRY(dev_step(&L, LISHIP_STEP_CG_ALPHA, LISHIP_KS_DOT0, 1));
-			TRY(dev_announce(&L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID));
-			if (c->duniform) KTRY(liship_cg_residual_jacobi_uniform_dev_f64(n, st + LISHIP_KS_NALPHA, q, c->dconst, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
-			else if (c->dinv) KTRY(liship_cg_residual_jacobi_dev_f64(n, st + LISHIP_KS_NALPHA, q, c->dinv, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
-			else         KTRY(liship_axpy_sumsq_dev_f64(n, st + LISHIP_KS_NALPHA, q, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
-			TRY(dev_step(&L, c->dinv ? LISHIP_STEP_CG_RESID_PRE : LISHIP_STEP_CG_RESID, LISHIP_KS_SUM0, c->dinv ? 2 : 1));
-		}
-		queued += batch;
-		TRY(dev_loop_sync(c, &L));
-	}
+	cg_vars vars = { q, r, p };
+	TRY(dev_loop_run(c, &L, cg_batch, &vars));
 	/* the x update of the last iteration that formed an alpha: owed unless the loop ended on <p,q> = 0 (the reference
 	 * leaves before its axpy then, lis_solver_cg.c:193-197) -- the kernels queued behind a raised flag touched neither p nor alpha */
 	if (c->maxiter > 0 && L.host[LISHIP_KS_STATUS] != 2.0) {
@@ -404,6 +449,47 @@ done:
 	return err;
 }
 
+typedef struct { double *rtld, *r, *t, *p, *v, *phat, *shat; int pre; } bicgstab_vars;
+static LIS_INT bicgstab_batch(ctx_t *c, dev_loop *L, void *vars, LIS_INT queued, LIS_INT batch)
+{
+	LIS_INT err = 0;
+	const int n = c->n;
+	const bicgstab_vars *w = (const bicgstab_vars *)vars;
+	double *rtld = w->rtld, *r = w->r, *t = w->t, *p = w->p, *v = w->v, *phat = w->phat, *shat = w->shat, *st = L->st;
+	double *sv = r;                                    /* s aliases r: lis_solver_bicgstab.c:160-161 */
+	const int pre = w->pre;
+	for (LIS_INT k = 0; k < batch; k++) {
+		KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
+		if (queued + k == 0) TRY(d_copy(c, r, p));
+		else KTRY(liship_axpy_xpay_dev_f64(n, st + LISHIP_KS_NOMEGA, v, r, st + LISHIP_KS_BETA, p, lisg.stream));
+		if (pre) KTRY(liship_pmul_f64(n, p, c->dinv, phat, lisg.stream));
+		TRY(dev_announce(L, LISHIP_STEP_BICGSTAB_ALPHA));
+		TRY(lisd_spmv_dot_launch_to(c->A, phat, v, rtld, 0, st + LISHIP_KS_DOT0));
+		TRY(dev_step(L, LISHIP_STEP_BICGSTAB_ALPHA, LISHIP_KS_DOT0, 1));
+		TRY(dev_announce(L, LISHIP_STEP_BICGSTAB_HALF));
+		KTRY(liship_axpy_sumsq_dev_f64(n, st + LISHIP_KS_NALPHA, v, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+		TRY(dev_step(L, LISHIP_STEP_BICGSTAB_HALF, LISHIP_KS_SUM0, 1));
+		/* converged at the half step: x += alpha*phat (:240-258), and only then -- NOT_HALF is 0 from that
+		 * step until the next one */
+		KTRY(liship_krylov_guard(st + LISHIP_KS_NOT_HALF));
+		KTRY(liship_axpy_dev_f64(n, st + LISHIP_KS_ALPHA, phat, c->x, lisg.stream));
+		KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
+		if (pre) KTRY(liship_pmul_f64(n, sv, c->dinv, shat, lisg.stream));
+		TRY(dev_announce(L, LISHIP_STEP_BICGSTAB_OMEGA));
+		TRY(lisd_spmv_dot_launch_to(c->A, shat, t, sv, 1, st + LISHIP_KS_DOT0));
+		TRY(dev_step(L, LISHIP_STEP_BICGSTAB_OMEGA, LISHIP_KS_DOT0, 2));
+		if (pre) KTRY(liship_axpy2_dev_f64(n, st + LISHIP_KS_ALPHA, phat, st + LISHIP_KS_OMEGA, shat, c->x, lisg.stream));
+		TRY(dev_announce(L, LISHIP_STEP_BICGSTAB_RESID));
+		if (pre) KTRY(liship_axpy_sumsq_dot_dev_f64(n, st + LISHIP_KS_NOMEGA, t, r, rtld, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+		else     /* shat is s itself: the iterate and the residual in one pass (s read once) */
+			KTRY(liship_bicgstab_end_dev_f64(n, st + LISHIP_KS_ALPHA, st + LISHIP_KS_OMEGA, st + LISHIP_KS_NOMEGA, phat, t, rtld, c->x, r,
+			                                 st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+		TRY(dev_step(L, LISHIP_STEP_BICGSTAB_RESID, LISHIP_KS_SUM0, 2));
+	}
+done:
+	return err;
+}
+
 static LIS_INT run_bicgstab_device(ctx_t *c)
 {
 	LIS_INT err = 0;
@@ -413,7 +499,6 @@ static LIS_INT run_bicgstab_device(ctx_t *c)
 	TRY(work_alloc(c, pre ? 7 : 5));
 	double *rtld = c->work[0], *r = c->work[1], *t = c->work[2], *p = c->work[3], *v = c->work[4];
 	double *phat = pre ? c->work[5] : p, *shat = pre ? c->work[6] : r;
-	double *sv = r;                                    /* s aliases r: lis_solver_bicgstab.c:160-161 */
 	double rho, init[LISHIP_KS_LEN] = {0};
 	int st0 = initial_residual(c, r);
 	if (st0) { work_free(c); return st0 < 0 ? -st0 : 0; }
@@ -423,40 +508,8 @@ static LIS_INT run_bicgstab_device(ctx_t *c)
 	init[LISHIP_KS_ALPHA] = 1.0; init[LISHIP_KS_NALPHA] = -1.0; init[LISHIP_KS_OMEGA] = 1.0; init[LISHIP_KS_NOMEGA] = -1.0;
 	init[LISHIP_KS_BNRM] = c->bnrm; init[LISHIP_KS_TOL] = c->tol; init[LISHIP_KS_NOT_HALF] = 1.0;
 	TRY(dev_loop_begin(c, &L, init));
-	double *st = L.st;
-	for (LIS_INT queued = 0; queued < c->maxiter && L.host[LISHIP_KS_DONE] == 0.0; ) {
-		const LIS_INT batch = (c->maxiter - queued < LISD_BATCH) ? c->maxiter - queued : LISD_BATCH;
-		for (LIS_INT k = 0; k < batch; k++) {
-			KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
-			if (queued + k == 0) TRY(d_copy(c, r, p));
-			else KTRY(liship_axpy_xpay_dev_f64(n, st + LISHIP_KS_NOMEGA, v, r, st + LISHIP_KS_BETA, p, lisg.stream));
-			if (pre) KTRY(liship_pmul_f64(n, p, c->dinv, phat, lisg.stream));
-			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_ALPHA));
-			TRY(lisd_spmv_dot_launch_to(c->A, phat, v, rtld, 0, st + LISHIP_KS_DOT0));
-			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_ALPHA, LISHIP_KS_DOT0, 1));
-			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_HALF));
-			KTRY(liship_axpy_sumsq_dev_f64(n, st + LISHIP_KS_NALPHA, v, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
-			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_HALF, LISHIP_KS_SUM0, 1));
-			/* converged at the half step: x += alpha*phat (:240-258), and only then -- NOT_HALF is 0 from that
-			 * step until the next one */
-			KTRY(liship_krylov_guard(st + LISHIP_KS_NOT_HALF));
-			KTRY(liship_axpy_dev_f64(n, st + LISHIP_KS_ALPHA, phat, c->x, lisg.stream));
-			KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
-			if (pre) KTRY(liship_pmul_f64(n, sv, c->dinv, shat, lisg.stream));
-			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_OMEGA));
-			TRY(lisd_spmv_dot_launch_to(c->A, shat, t, sv, 1, st + LISHIP_KS_DOT0));
-			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_OMEGA, LISHIP_KS_DOT0, 2));
-			if (pre) KTRY(liship_axpy2_dev_f64(n, st + LISHIP_KS_ALPHA, phat, st + LISHIP_KS_OMEGA, shat, c->x, lisg.stream));
-			TRY(dev_announce(&L, LISHIP_STEP_BICGSTAB_RESID));
-			if (pre) KTRY(liship_axpy_sumsq_dot_dev_f64(n, st + LISHIP_KS_NOMEGA, t, r, rtld, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
-			else     /* shat is s itself: the iterate and the residual in one pass (s read once) */
-				KTRY(liship_bicgstab_end_dev_f64(n, st + LISHIP_KS_ALPHA, st + LISHIP_KS_OMEGA, st + LISHIP_KS_NOMEGA, phat, t, rtld, c->x, r,
-				                                 st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
-			TRY(dev_step(&L, LISHIP_STEP_BICGSTAB_RESID, LISHIP_KS_SUM0, 2));
-		}
-		queued += batch;
-		TRY(dev_loop_sync(c, &L));
-	}
+	bicgstab_vars vars = { rtld, r, t, p, v, phat, shat, pre };
+	TRY(dev_loop_run(c, &L, bicgstab_batch, &vars));
 done:
 	err = dev_loop_finish(c, &L, err);
 	work_free(c);
@@ -720,6 +773,38 @@ done:
 	return err;
 }
 
+typedef struct { double *r, *rtld, *q, *qtld, *p, *ptld, *z; } bicg_vars;
+static LIS_INT bicg_batch(ctx_t *c, dev_loop *L, void *vars, LIS_INT queued, LIS_INT batch)
+{
+	LIS_INT err = 0;
+	const int n = c->n;
+	const bicg_vars *w = (const bicg_vars *)vars;
+	double *r = w->r, *rtld = w->rtld, *q = w->q, *qtld = w->qtld, *p = w->p, *ptld = w->ptld, *z = w->z, *st = L->st;
+	(void)queued;
+	for (LIS_INT k = 0; k < batch; k++) {
+		if (c->dinv) {
+			KTRY(liship_pmul_xpay_dev_f64(n, r, c->dinv, st + LISHIP_KS_BETA, p, lisg.stream));
+			KTRY(liship_pmul_xpay_dev_f64(n, rtld, c->dinv, st + LISHIP_KS_BETA, ptld, lisg.stream));
+		} else {
+			KTRY(liship_xpay_dev_f64(n, r, st + LISHIP_KS_BETA, p, lisg.stream));
+			KTRY(liship_xpay_dev_f64(n, rtld, st + LISHIP_KS_BETA, ptld, lisg.stream));
+		}
+		TRY(dev_announce(L, LISHIP_STEP_BICG_ALPHA));
+		TRY(lisd_spmv_dot_launch_to(c->A, p, q, ptld, 0, st + LISHIP_KS_DOT0));
+		TRY(dev_step(L, LISHIP_STEP_BICG_ALPHA, LISHIP_KS_DOT0, 1));
+		TRY(lisd_spmv_t(c->A, ptld, qtld));           /* recomputed from scratch each time: harmless behind a raised flag */
+		TRY(dev_announce(L, LISHIP_STEP_BICG_RESID));
+		KTRY(liship_cg_update_dev_f64(n, st + LISHIP_KS_ALPHA, p, q, NULL, c->x, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+		TRY(dev_step(L, LISHIP_STEP_BICG_RESID, LISHIP_KS_SUM0, 1));
+		if (c->dinv) KTRY(liship_pmul_f64(n, r, c->dinv, z, lisg.stream));
+		TRY(dev_announce(L, LISHIP_STEP_BICG_RHO));
+		KTRY(liship_axpy_sumsq_dot_dev_f64(n, st + LISHIP_KS_NALPHA, qtld, rtld, c->dinv ? z : r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
+		TRY(dev_step(L, LISHIP_STEP_BICG_RHO, LISHIP_KS_SUM0, 2));
+	}
+done:
+	return err;
+}
+
 static LIS_INT run_bicg_device(ctx_t *c)
 {
 	LIS_INT err = 0;
@@ -737,33 +822,9 @@ static LIS_INT run_bicg_device(ctx_t *c)
 	init[LISHIP_KS_RHO] = rho; init[LISHIP_KS_RHO_OLD] = 1.0; init[LISHIP_KS_BETA] = rho / 1.0;
 	init[LISHIP_KS_BNRM] = c->bnrm; init[LISHIP_KS_TOL] = c->tol; init[LISHIP_KS_NOT_HALF] = 1.0;
 	TRY(dev_loop_begin(c, &L, init));
-	double *st = L.st;
-	KTRY(liship_krylov_guard(st + LISHIP_KS_DONE));
-	for (LIS_INT queued = 0; queued < c->maxiter && L.host[LISHIP_KS_DONE] == 0.0; ) {
-		const LIS_INT batch = (c->maxiter - queued < LISD_BATCH) ? c->maxiter - queued : LISD_BATCH;
-		for (LIS_INT k = 0; k < batch; k++) {
-			if (c->dinv) {
-				KTRY(liship_pmul_xpay_dev_f64(n, r, c->dinv, st + LISHIP_KS_BETA, p, lisg.stream));
-				KTRY(liship_pmul_xpay_dev_f64(n, rtld, c->dinv, st + LISHIP_KS_BETA, ptld, lisg.stream));
-			} else {
-				KTRY(liship_xpay_dev_f64(n, r, st + LISHIP_KS_BETA, p, lisg.stream));
-				KTRY(liship_xpay_dev_f64(n, rtld, st + LISHIP_KS_BETA, ptld, lisg.stream));
-			}
-			TRY(dev_announce(&L, LISHIP_STEP_BICG_ALPHA));
-			TRY(lisd_spmv_dot_launch_to(c->A, p, q, ptld, 0, st + LISHIP_KS_DOT0));
-			TRY(dev_step(&L, LISHIP_STEP_BICG_ALPHA, LISHIP_KS_DOT0, 1));
-			TRY(lisd_spmv_t(c->A, ptld, qtld));           /* recomputed from scratch each time: harmless behind a raised flag */
-			TRY(dev_announce(&L, LISHIP_STEP_BICG_RESID));
-			KTRY(liship_cg_update_dev_f64(n, st + LISHIP_KS_ALPHA, p, q, NULL, c->x, r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
-			TRY(dev_step(&L, LISHIP_STEP_BICG_RESID, LISHIP_KS_SUM0, 1));
-			if (c->dinv) KTRY(liship_pmul_f64(n, r, c->dinv, z, lisg.stream));
-			TRY(dev_announce(&L, LISHIP_STEP_BICG_RHO));
-			KTRY(liship_axpy_sumsq_dot_dev_f64(n, st + LISHIP_KS_NALPHA, qtld, rtld, c->dinv ? z : r, st + LISHIP_KS_SUM0, lisg.reduce_work, lisg.stream));
-			TRY(dev_step(&L, LISHIP_STEP_BICG_RHO, LISHIP_KS_SUM0, 2));
-		}
-		queued += batch;
-		TRY(dev_loop_sync(c, &L));
-	}
+	KTRY(liship_krylov_guard(L.st + LISHIP_KS_DONE));
+	bicg_vars vars = { r, rtld, q, qtld, p, ptld, z };
+	TRY(dev_loop_run(c, &L, bicg_batch, &vars));
 done:
 	err = dev_loop_finish(c, &L, err);
 	work_free(c);
@@ -1027,6 +1088,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		}
 	}
 	lisg.last_uniform_jacobi = 0;
+	lisg.last_graph_replays = 0;
 	if (precon && precon->precon_type == LIS_PRECON_TYPE_JACOBI) {
 		if ((err = lisd_vec_in(precon->D, &c.dinv))) goto out;
 		if (nsolver == LIS_SOLVER_CG && !lisg.no_uniform_jacobi) {        /* (every rank: the count below is a collective) */

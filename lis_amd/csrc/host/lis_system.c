@@ -241,6 +241,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_local_columns = (r && r[0] == '1');
 		r = getenv("LIS_AMD_LONG_ROW_TREE");          /* opt-in: NOT the reference's bits for rows beyond the LDS stage */
 		lisg.long_row_tree = (r && r[0] == '1');
+		r = getenv("LIS_AMD_GRAPHS");
+		lisg.graphs = (r && r[0] == '1');
 		r = getenv("LIS_AMD_HOST_SCALARS");
 		lisg.host_scalars = (r && r[0] == '1');
 	}

@@ -41,6 +41,29 @@ extern "C" int liship_stream_destroy(void *stream) { if (stream) HIP_TRY(hipStre
 extern "C" int liship_stream_synchronize(void *stream) { HIP_TRY(hipStreamSynchronize(as_stream(stream))); return 0; }
 extern "C" int liship_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return 0; }
 
+// hipGraph capture of a batch of Krylov iterations (host/lis_solver.c: dev_loop_run): small systems are bound by the
+// launch rate of their 5-14 kernels per iteration, and a replayed graph submits them without the per-launch host work.
+// Thread-local capture: a call that may not be captured (an allocation, a synchronisation) fails the capture instead
+// of being recorded wrongly, and the caller falls back to plain launches.
+extern "C" int liship_graph_capture_begin(void *stream)
+{ HIP_TRY(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal)); return 0; }
+extern "C" int liship_graph_capture_end(void *stream, void **exec)
+{
+    hipGraph_t g = nullptr;
+    hipError_t rc = hipStreamEndCapture(as_stream(stream), &g);          // always ends the capture, also a failed one
+    if (rc != hipSuccess || !g) { (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g); return (int)(rc != hipSuccess ? rc : hipErrorUnknown); }
+    if (!exec) { (void)hipGraphDestroy(g); return 0; }                    // the caller gave up on this capture
+    hipGraphExec_t e = nullptr;
+    rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (rc != hipSuccess) { (void)hipGetLastError(); return (int)rc; }
+    *exec = e;
+    return 0;
+}
+extern "C" int liship_graph_launch(void *exec, void *stream)
+{ if (!exec) return LISHIP_ERR_ARG; HIP_TRY(hipGraphLaunch((hipGraphExec_t)exec, as_stream(stream))); return 0; }
+extern "C" int liship_graph_destroy(void *exec) { if (exec) HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)exec)); return 0; }
+
 // page-locked host memory: the 8-32 B results of the reductions come back through it (a D2H into pageable memory
 // is staged by the runtime and costs 10-20 us more per host synchronisation)
 extern "C" int liship_malloc_host(void **p, size_t bytes) { HIP_TRY(hipHostMalloc(p, bytes, hipHostMallocDefault)); return 0; }

@@ -165,3 +165,45 @@ def test_cg_jacobi_uniform_and_varying_diagonal(lib):
     val[ptr[n // 2] + int(np.flatnonzero(idx[ptr[n // 2]:ptr[n // 2 + 1]] == n // 2)[0])] = np.nextafter(6.0, 7.0)   # one ulp in one row
     a = same(run_modes(lib, ptr, idx, val, b, "-i cg -p jacobi -tol 1e-12 -maxiter 400 -print mem"))
     assert a["status"] == 0
+
+
+@pytest.mark.parametrize("solver", ["cg", "bicgstab", "bicg"])
+@pytest.mark.parametrize("precon", ["none", "jacobi"])
+@pytest.mark.parametrize("fmt", ["csr", "ell", "jad"])
+def test_graph_replay_leaves_the_same_bits(lib, solver, precon, fmt):
+    """LIS_AMD_GRAPHS=1: from the second batch of 16 iterations on, a single-rank solve replays a hipGraph of one batch
+    (lis_solver.c: dev_loop_run): same kernels, same arguments, same order -- every bit as with plain launches,
+    wherever in a replayed batch the loop ends"""
+    ptr, idx, val = orc.poisson3d(17, 12, 10)
+    n = len(ptr) - 1
+    b = np.random.default_rng(5).uniform(-1, 1, n)
+    outs, replays = [], []
+    for mode in (0, 1):                                        # plain launches (default), graph replay
+        assert lib.dll.lis_amd_set_graphs(mode) == 0
+        A = lisdrv.make_csr(lib, ptr, idx, val)
+        B = A if fmt == "csr" else lisdrv.convert(lib, A, fmt)
+        outs.append(lisdrv.solve(lib, B, b, f"-i {solver} -p {precon} -tol 1e-12 -maxiter 400 -print mem"))
+        replays.append(lib.dll.lis_amd_last_solve_graph_replays())
+        lib.lis_matrix_destroy(B)
+    lib.dll.lis_amd_set_graphs(0)
+    a = same(outs)
+    assert a["status"] == 0 and a["iter"] > 32
+    assert replays[0] == 0 and replays[1] == (a["iter"] - 1) // 16, replays
+    lib.dll.lis_amd_set_graphs(0)
+
+
+@pytest.mark.parametrize("maxiter", [17, 31, 32, 33, 47, 48, 49])
+def test_graph_replay_at_every_batch_position(lib, maxiter):
+    ptr, idx, val = orc.poisson3d(14, 13, 9)
+    b = np.random.default_rng(6).uniform(-1, 1, len(ptr) - 1)
+    outs = []
+    for mode in (0, 1):
+        lib.dll.lis_amd_set_graphs(mode)
+        A = lisdrv.make_csr(lib, ptr, idx, val)
+        outs.append(lisdrv.solve(lib, A, b, f"-i cg -p jacobi -tol 1e-14 -maxiter {maxiter} -print mem"))
+        lib.lis_matrix_destroy(A)
+        if mode == 1:                                          # only FULL batches after the first are replayed
+            assert lib.dll.lis_amd_last_solve_graph_replays() == maxiter // 16 - 1
+    lib.dll.lis_amd_set_graphs(0)
+    a = same(outs)
+    assert a["iter"] == maxiter + 1

@@ -8,8 +8,9 @@
 Workload (BASELINE.json): the 3-D 7-point Poisson matrix on a 512^3 grid in CSR (test/test3.c entry order,
 f64 values, i32 indices), generated directly in HBM; a "step" is one y = A*x through lis_matvec() of
 liblis_amd.so (x = 1, as test/spmvtest3.c).  With N > 1 the matrix is row-block partitioned over the ranks
-(LIS_GET_ISIE: 512/N grid planes each, STRONG scaling: the global problem is fixed) and every step does the
-halo exchange over RCCL (ncclSend/ncclRecv of one plane per neighbour) before the local product.
+(LIS_GET_ISIE, whole grid planes) and every step does the halo exchange over RCCL (ncclSend/ncclRecv of one plane
+per neighbour) around the local product.  Default WEAK scaling: every GPU keeps the 512^3 rows the metric is quoted
+on (global grid 512 x 512 x 512*N; 14 GB of matrix per 288 GB GPU); --scaling strong splits the one 512^3 grid.
 Reported: value = global SpMV GFLOP/s = 2*nnz*K / t (reference convention, test/spmvtest1.c:225), the
 roofline fraction of the dominant kernel from HIP events on the library's stream, Krylov iterations/s on the
 same matrix as the reference defines them -- iter / itime of lis_solver_get_timeex (src/solver/lis_solver.c:
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--comm", choices=["rccl", "callbacks"], default="rccl",
                     help="callbacks: collectives through torch.distributed/gloo host callbacks -- bring-up of the N>1 "
                          "path with several ranks on ONE GPU (RCCL refuses that); never a measurement")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = 512^3 rows per GPU (grid 512 x 512 x 512 N), strong = the one 512^3 grid split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solvers", action="store_true")
     return ap.parse_args()
@@ -128,16 +131,19 @@ def main():
             dist.barrier()
 
     N = args.grid
-    n_global = N ** 3
-    if N % world:
+    L = N * world if args.scaling == "weak" else N        # grid planes (slowest dimension): whole planes per rank
+    n_global = L * N * N
+    if L % world:
         sys.exit(f"grid edge {N} is not divisible by {world} ranks (whole planes per rank)")
+    if n_global >= 2 ** 31:
+        sys.exit(f"{L} x {N} x {N} rows do not fit LIS_INT (32 bit, as the reference's default build)")
     A = capi.PM()
     assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
     assert lib.lis_matrix_set_size(A, 0, n_global) == 0
     dll.lis_amd_matrix_poisson3d.argtypes = [capi.PM, C.c_int, C.c_int, C.c_int, C.c_int]
-    assert dll.lis_amd_matrix_poisson3d(A, N, N, N, 0) == 0
+    assert dll.lis_amd_matrix_poisson3d(A, L, N, N, 0) == 0
     n_local, nnz_local = A.contents.n, A.contents.nnz
-    nnz_global = 7 * n_global - 6 * N * N
+    nnz_global = 7 * n_global - 2 * (N * N + 2 * L * N)
 
     def vec():
         v = capi.PV()
@@ -173,10 +179,11 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     gflops = 2.0 * nnz_global * args.steps / dt / 1e9
 
-    # result check outside the timed region: ||A*1||_2^2 = 6(N-2)^2 + 48(N-2) + 72 exactly (spmvtest3)
+    # result check outside the timed region: ||A*1||_2^2 = 6(N-2)^2 + 48(N-2) + 72 exactly on the cube (spmvtest3)
     nrm = C.c_double()
     assert lib.lis_vector_nrm2(y, C.byref(nrm)) == 0
-    expect = (6.0 * (N - 2) ** 2 + 48.0 * (N - 2) + 72.0) ** 0.5
+    # (a row sums to the number of neighbours it lacks: 8 corners 3, the edges 2, the faces 1)
+    expect = (72.0 + 4.0 * (4 * (L - 2) + 8 * (N - 2)) + 2.0 * (N - 2) ** 2 + 4.0 * (L - 2) * (N - 2)) ** 0.5
     if abs(nrm.value - expect) > 1e-12 * expect:
         sys.exit(f"rank {rank}: ||A*1||_2 = {nrm.value!r}, expected {expect!r}")
 
@@ -288,7 +295,7 @@ def main():
     solvers = {}
     if not args.no_solvers:
         dll.lis_amd_vector_poisson3d_rhs.argtypes = [capi.PV, C.c_int, C.c_int, C.c_int]
-        assert dll.lis_amd_vector_poisson3d_rhs(b, N, N, N) == 0
+        assert dll.lis_amd_vector_poisson3d_rhs(b, L, N, N) == 0
         for key, opts in (("cg_jacobi", "-i cg -p jacobi"), ("bicgstab_none", "-i bicgstab -p none"),
                           ("bicg_none", "-i bicg -p none"),            # Lis's default solver: needs A^T (built in HBM on first use)
                           ("gmres30_none", "-i gmres -restart 30 -p none")):
@@ -352,9 +359,9 @@ def main():
         out = {
             "metric": "SpMV GFLOP/s, CSR, 3-D 7-pt Poisson n=512^3" if N == 512 else f"SpMV GFLOP/s, CSR, 3-D 7-pt Poisson n={N}^3",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"3-D 7-point Poisson {N}^3, CSR f64/i32, y=A*x via lis_matvec (x=1), test3.c entry order",
+            "config": {"workload": (f"3-D 7-point Poisson {N}^3" if L == N else f"3-D 7-point Poisson {N}^3 per GPU (grid {N} x {N} x {L})") + ", CSR f64/i32, y=A*x via lis_matvec (x=1), test3.c entry order",
                        "n": n_global, "nnz": nnz_global, "parallelism": f"row-block x{world}" + ((" + RCCL halo" if comm_used == "rccl" else " + gloo-callback halo (bring-up, not a measurement)") if world > 1 else "")},
             "roofline": roofline,
             "values_streamed": streamed,

@@ -357,6 +357,10 @@ void spmv_bsr22_kernel(int nr, const int *__restrict__ bptr, const int *__restri
 // lis_matvec_bsr.c:120-148 in their order (column by column inside a block: t_i += a_ij x_j for i = 0..BS-1, then
 // the next j).  All BS rows of a block row live in one lane, y leaves as 16 B nt stores where BS is even.
 // Block rows longer than the stage are walked in passes with the running sums kept in registers.
+// One wavefront per workgroup and a stage of 18-25 KB leave 1.6 wavefronts per SIMD (profiles/r02_bsr_kernel_pmc.txt): nobody hides
+// a lane's latencies, so a lane issues the x gathers of a whole batch of U blocks (its whole row, typically) before it touches the
+// values -- one gather round trip per pass instead of one per 2-3 blocks: 3x3 0.941 -> 0.741 ms, 4x4 0.748 -> 0.664, 2x2 0.397 -> 0.368
+// at 256^3 (65.8 / 69.1 / 75.8 % -> 83.5 / 77.9 / 81.8 % of 8 TB/s on the stored bytes).
 constexpr int BSR_LANES = 64;
 template <int BS, int CAP, int U, int DOT = 0>
 __global__ __launch_bounds__(BSR_LANES)
@@ -367,7 +371,11 @@ void spmv_bsr_rows_kernel(int nr, const int *__restrict__ bptr, const int *__res
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     constexpr int BB = BS * BS;
-    __shared__ __attribute__((aligned(16))) double valL[(CAP + 4) * BB + 2 * WAVE];
+    // even BS: one 16 B unit of padding after every 1 KiB (= one DMA instruction) of the value stage.  Block rows of one length put
+    // the lanes a fixed stride apart (7 blocks of 128 B: lanes 0, 2, 4 ... in the same banks -- two thirds of the 4x4 kernel's
+    // LDS cycles were bank conflicts, profiles/r02_bsr_kernel_pmc.txt); the skew spreads them.  A block never straddles a KiB.
+    constexpr int UNITS = ((CAP + 4) * BB + 2 * WAVE + 1) / 2;
+    __shared__ __attribute__((aligned(16))) double valL[2 * (UNITS + (BB % 2 == 0 ? UNITS / 64 + 1 : 0))];
     __shared__ __attribute__((aligned(16))) int idxL[CAP + 4 + 4 * WAVE];
     const int lane = threadIdx.x;
     const int br0 = blockIdx.x * BSR_LANES, br1 = min(br0 + BSR_LANES, nr);
@@ -395,7 +403,7 @@ void spmv_bsr_rows_kernel(int nr, const int *__restrict__ bptr, const int *__res
             const int p = min(p0 + lane, npd - 1);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + (size_t)ka * BB) + p),
-                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0 + (BB % 2 == 0 ? p0 >> 6 : 0)), 16, 0, 2);
         }
         if (tail && lane == 0) valL[cnt * BB - 1] = val[(size_t)(ka + cnt) * BB - 1];
         const int nq = (cnt + 3) >> 2;
@@ -412,20 +420,12 @@ void spmv_bsr_rows_kernel(int nr, const int *__restrict__ bptr, const int *__res
         __syncthreads();
         const int s = max(rs, cb), e = min(re, cend);
         for (int b0 = s; b0 < e; b0 += U) {
-            double a[U][BB], xv[U][BS];
+            // all x gathers of the batch first (a lane's walk is a chain of gather round trips otherwise: with one wavefront per
+            // workgroup and the stage bounding the occupancy there is nobody to hide them), then block by block the values from LDS
+            double xv[U][BS];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int o = min(b0 + u, e - 1) - ka;    // clamped: repeats the row's last block
-                if (BB % 2 == 0) {
-#pragma unroll
-                    for (int q = 0; q < BB / 2; q++) {
-                        const v2f64 vv = reinterpret_cast<const v2f64 *>(valL)[(o * BB) / 2 + q];
-                        a[u][2 * q] = vv.x; a[u][2 * q + 1 < BB ? 2 * q + 1 : 2 * q] = vv.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < BB; q++) a[u][q] = valL[o * BB + q];
-                }
                 const double *xp = x + (size_t)idxL[o] * BS;
                 if (BS % 2 == 0) {
 #pragma unroll
@@ -440,12 +440,25 @@ void spmv_bsr_rows_kernel(int nr, const int *__restrict__ bptr, const int *__res
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
+                const int o = min(b0 + u, e - 1) - ka;
+                double a[BB];
+                if (BB % 2 == 0) {
+                    const int unit = o * (BB / 2), at = unit + (unit >> 6);      // the stage's skew: see the DMA above
+#pragma unroll
+                    for (int q = 0; q < BB / 2; q++) {
+                        const v2f64 vv = reinterpret_cast<const v2f64 *>(valL)[at + q];
+                        a[2 * q] = vv.x; a[2 * q + 1 < BB ? 2 * q + 1 : 2 * q] = vv.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < BB; q++) a[q] = valL[o * BB + q];
+                }
                 const bool ok = b0 + u < e;               // +0.0 terms leave the sums bit-unchanged
 #pragma unroll
                 for (int j = 0; j < BS; j++)
 #pragma unroll
                     for (int i = 0; i < BS; i++) {
-                        const double pr = a[u][i + j * BS] * xv[u][j];
+                        const double pr = a[i + j * BS] * xv[u][j];
                         t[i] += ok ? pr : 0.0;
                     }
             }
@@ -672,9 +685,9 @@ extern "C" int liship_spmv_bsr_dot_f64(int nr, int n, int bnnz, int bs, const in
     const double *guard = liship_internal_guard();
 #define GO(BS, CAP, U) do { if (want_sumsq) spmv_bsr_rows_kernel<BS, CAP, U, 2><<<grid, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y, n, w, partial, guard); \
                             else            spmv_bsr_rows_kernel<BS, CAP, U, 1><<<grid, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y, n, w, partial, guard); } while (0)
-    if (bs == 2 && mean <= 12.0) GO(2, 512, 4);
-    else if (bs == 3 && mean <= 16.0) GO(3, 256, 3);
-    else if (bs == 4 && mean <= 12.0) GO(4, 160, 2);
+    if (bs == 2 && mean <= 12.0) GO(2, 512, 8);
+    else if (bs == 3 && mean <= 16.0) GO(3, 352, 12);
+    else if (bs == 4 && mean <= 12.0) GO(4, 160, 8);
     else return LISHIP_ERR_ARG;
 #undef GO
     LAUNCH_CHECK();
@@ -698,17 +711,17 @@ extern "C" int liship_spmv_bsr_nnz_f64(int nr, int bnnz, int bnr, int bnc, const
         case 1: spmv_bsr_tile_kernel<1, 1><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
         case 2:
             if (aligned16(x) && aligned16(y) && aligned16(bidx) && (bnnz < 0 || mean <= 12.0))
-                spmv_bsr_rows_kernel<2, 512, 4><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
+                spmv_bsr_rows_kernel<2, 512, 8><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
             else if (aligned16(x)) spmv_bsr22_kernel<<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             else              spmv_bsr_tile_kernel<2, 2><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             break;
         case 3:
-            if (aligned16(bidx) && bnnz >= 0 && mean <= 16.0) spmv_bsr_rows_kernel<3, 256, 3><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
+            if (aligned16(bidx) && bnnz >= 0 && mean <= 16.0) spmv_bsr_rows_kernel<3, 352, 12><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
             else                 spmv_bsr_tile_kernel<3, 3><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             break;
         default:
             if (aligned16(x) && aligned16(y) && aligned16(bidx) && bnnz >= 0 && mean <= 12.0)
-                spmv_bsr_rows_kernel<4, 160, 2><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
+                spmv_bsr_rows_kernel<4, 160, 8><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
             else
                 spmv_bsr_tile_kernel<4, 4><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             break;

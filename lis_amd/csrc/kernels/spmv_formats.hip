@@ -245,7 +245,7 @@ void spmv_bsr_tile_kernel(int nr, const int *__restrict__ bptr, const int *__res
     double acc = 0.0;
     for (int cb = bb; cb < be; cb += CHUNK) {
         const int nblk = min(CHUNK, be - cb);
-        constexpr int UB = 4;                            // block columns in flight per lane
+        constexpr int UB = (CHUNK * BNC + BLOCK - 1) / BLOCK < 8 ? (CHUNK * BNC + BLOCK - 1) / BLOCK : 8;      // block columns in flight per lane: a whole pass (4-8)
         for (int t0 = L; t0 < nblk * BNC; t0 += UB * BLOCK) {
             double v[UB][BNR], xj[UB];
 #pragma unroll

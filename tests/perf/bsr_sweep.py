@@ -1,5 +1,6 @@
 """BSR products of the 256^3 stencil with 2x2, 3x3, 4x4 blocks (lis_matvec through the C API), against the bytes the
-format stores.   python tests/perf/bsr_sweep.py [N]"""
+format stores.   python tests/perf/bsr_sweep.py [N]        python tests/perf/bsr_sweep.py --fem G [dofs]: the dofs-per-node
+FEM pattern of a G^3 grid (27 dofs x dofs blocks per block row: the long-block-row case) in dofs x dofs blocks"""
 import ctypes as C
 import os
 import sys
@@ -16,14 +17,16 @@ from lis_amd import _capi as capi  # noqa: E402
 
 
 def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    fem = len(sys.argv) > 2 and sys.argv[1] == "--fem"
+    N = int(sys.argv[1]) if len(sys.argv) > 1 and not fem else 256
     lib = lis_amd.load()
     assert lib.initialize([]) == 0
     lib.dll.lis_amd_set_residency(1)
-    ptr, idx, val = orc.poisson3d(N, N, N)
+    dofs = int(sys.argv[3]) if fem and len(sys.argv) > 3 else 3
+    ptr, idx, val = orc.fem3(int(sys.argv[2]), dofs)[:3] if fem else orc.poisson3d(N, N, N)
     n, nnz = len(ptr) - 1, len(idx)
     x = np.ones(n)
-    for bs in (2, 3, 4):
+    for bs in ((dofs,) if fem else (2, 3, 4)):
         A = lisdrv.make_csr(lib, ptr, idx, val)
         B = lisdrv.convert(lib, A, "bsr", bs, bs)
         bnnz, nr = B.contents.bnnz, B.contents.nr

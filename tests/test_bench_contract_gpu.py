@@ -38,3 +38,28 @@ def test_bench_line_has_the_contract_fields():
         assert abs(k["iters_per_sec"] - k["iters_timed"] / k["itime_s"]) < 0.01 * k["iters_per_sec"]     # iter / itime (lis_solver.c:902-908)
         kr = k["roofline"]
         assert 0 < kr["frac"] <= 1.0 and kr["loop_bytes_per_iter"] <= kr["contract_bytes_per_iter"]
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu(scaling):
+    """the N > 1 launch line of the driver with two ranks sharing this box's GPU (RCCL refuses that: --comm callbacks, a
+    bring-up run flagged degraded): partition, halo, the closed-form result check of the (stretched) grid, the collective
+    timing and the line's bookkeeping -- weak: 48^3 rows per rank on a 96 x 48 x 48 grid, strong: one 48^3 grid split"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--grid", "48", "--scaling", scaling, "--comm", "callbacks", "--preroll", "5", "--solver-iters", "20",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    planes = 96 if scaling == "weak" else 48
+    n = planes * 48 * 48
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["degraded"] is True and d["rccl_ranks"] == 0
+    assert d["config"]["n"] == n and d["config"]["nnz"] == 7 * n - 2 * (48 * 48 + 2 * planes * 48)
+    assert ("per GPU" in d["config"]["workload"]) == (scaling == "weak")
+    assert d["value"] > 0 and d["multi_gpu"] is not None and d["cpu_baseline"] is None
+    for name in ("cg_jacobi", "bicgstab_none", "bicg_none", "gmres30_none"):
+        assert d["krylov"][name]["iters_per_sec"] > 0

@@ -243,14 +243,23 @@ void spmv_bsr_tile_kernel(int nr, const int *__restrict__ bptr, const int *__res
     int rs = 0, re = 0;
     if (rowlane) { rs = bptr[mybr]; re = bptr[mybr + 1]; }
     double acc = 0.0;
+    // a lane takes UB block columns of a pass (a whole pass: UB * BLOCK >= CHUNK * BNC).  Their block indices are fetched one pass
+    // ahead, so that a pass is ONE round trip (values and x together) instead of two (index, then x)
+    constexpr int UB = (CHUNK * BNC + BLOCK - 1) / BLOCK;
+    static_assert(UB <= 16, "block columns in flight per lane");
+    int bi[UB];
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+        const int t = min(L + u * BLOCK, min(CHUNK, be - bb) * BNC - 1);
+        bi[u] = bb < be ? bidx[bb + t / BNC] : 0;
+    }
     for (int cb = bb; cb < be; cb += CHUNK) {
         const int nblk = min(CHUNK, be - cb);
-        constexpr int UB = (CHUNK * BNC + BLOCK - 1) / BLOCK < 8 ? (CHUNK * BNC + BLOCK - 1) / BLOCK : 8;      // block columns in flight per lane: a whole pass (4-8)
-        for (int t0 = L; t0 < nblk * BNC; t0 += UB * BLOCK) {
+        {
             double v[UB][BNR], xj[UB];
 #pragma unroll
             for (int u = 0; u < UB; u++) {
-                const int t = min(t0 + u * BLOCK, nblk * BNC - 1);      // clamped: the tail repeats the last column
+                const int t = min(L + u * BLOCK, nblk * BNC - 1);      // clamped: the tail repeats the last column
                 const int b = cb + t / BNC, j = t % BNC;
                 const double *src = val + (size_t)b * BS + (size_t)j * BNR;
                 if (BNR == 2 || BNR == 4) {
@@ -263,25 +272,49 @@ void spmv_bsr_tile_kernel(int nr, const int *__restrict__ bptr, const int *__res
 #pragma unroll
                     for (int i = 0; i < BNR; i++) v[u][i] = load_stream(src + i);
                 }
-                xj[u] = x[(size_t)bidx[b] * BNC + j];
+                xj[u] = x[(size_t)bi[u] * BNC + j];
+            }
+            const int nb2 = min(CHUNK, be - (cb + CHUNK));              // the next pass's block indices (none after the last)
+            if (nb2 > 0) {
+#pragma unroll
+                for (int u = 0; u < UB; u++) bi[u] = bidx[cb + CHUNK + min(L + u * BLOCK, nb2 * BNC - 1) / BNC];
             }
 #pragma unroll
             for (int u = 0; u < UB; u++) {
-                const int t = t0 + u * BLOCK;
+                const int t = L + u * BLOCK;
                 if (t < nblk * BNC) {
                     double *dst = prod + (size_t)t * BNR;
+                    if (BNR == 2 || BNR == 4) {          // 16 B stores: half the LDS instructions and bank conflicts
 #pragma unroll
-                    for (int i = 0; i < BNR; i++) dst[i] = v[u][i] * xj[u];
+                        for (int i = 0; i < BNR; i += 2) {
+                            v2f64 pr; pr.x = v[u][i] * xj[u]; pr.y = v[u][i + 1 < BNR ? i + 1 : i] * xj[u];
+                            *reinterpret_cast<v2f64 *>(dst + i) = pr;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < BNR; i++) dst[i] = v[u][i] * xj[u];
+                    }
                 }
             }
         }
         __syncthreads();
         if (rowlane) {
             const int s = max(rs, cb), e = min(re, cb + nblk);
-            for (int b = s; b < e; b++) {
-                const double *pp = prod + (size_t)(b - cb) * BS + myi;
+            constexpr int UP = 4;                        // blocks whose products are read before they are added (in order)
+            for (int b = s; b < e; b += UP) {
+                double pv[UP][BNC];
 #pragma unroll
-                for (int j = 0; j < BNC; j++) acc += pp[j * BNR];
+                for (int u = 0; u < UP; u++) {
+                    const double *pp = prod + (size_t)(min(b + u, e - 1) - cb) * BS + myi;
+#pragma unroll
+                    for (int j = 0; j < BNC; j++) pv[u][j] = pp[j * BNR];
+                }
+#pragma unroll
+                for (int u = 0; u < UP; u++) {
+                    const bool ok = b + u < e;           // acc starts at +0.0: a +0.0 term leaves it bit-unchanged
+#pragma unroll
+                    for (int j = 0; j < BNC; j++) acc += ok ? pv[u][j] : 0.0;
+                }
             }
         }
         __syncthreads();
@@ -308,25 +341,30 @@ void spmv_bsr22_kernel(int nr, const int *__restrict__ bptr, const int *__restri
     int rs = 0, re = 0;
     if (rowlane) { rs = bptr[mybr]; re = bptr[mybr + 1]; }
     double acc = 0.0;
+    constexpr int UB = CHUNK / BLOCK;                // blocks per lane and pass: the whole pass in flight, its indices fetched a pass ahead
+    int c[UB];
+#pragma unroll
+    for (int u = 0; u < UB; u++) c[u] = bb < be ? bidx[bb + min(L + u * BLOCK, min(CHUNK, be - bb) - 1)] : 0;
     for (int cb = bb; cb < be; cb += CHUNK) {
         const int nblk = min(CHUNK, be - cb);
-        constexpr int UB = 4;                        // blocks in flight per lane
-        for (int t0 = L; t0 < nblk; t0 += UB * BLOCK) {
+        {
             v2f64 a0[UB], a1[UB], xv[UB];
-            int c[UB];
 #pragma unroll
             for (int u = 0; u < UB; u++) {
-                const int b = cb + min(t0 + u * BLOCK, nblk - 1);       // clamped: the tail repeats the last block
+                const int b = cb + min(L + u * BLOCK, nblk - 1);        // clamped: the tail repeats the last block
                 const v2f64 *src = reinterpret_cast<const v2f64 *>(val + (size_t)b * 4);
                 a0[u] = load_stream(src);            // column 0: a00 a10
                 a1[u] = load_stream(src + 1);        // column 1: a01 a11
-                c[u] = load_stream(bidx + b);
+                xv[u] = *reinterpret_cast<const v2f64 *>(x + (size_t)c[u] * 2);
+            }
+            const int nb2 = min(CHUNK, be - (cb + CHUNK));              // the next pass's block indices (none after the last)
+            if (nb2 > 0) {
+#pragma unroll
+                for (int u = 0; u < UB; u++) c[u] = bidx[cb + CHUNK + min(L + u * BLOCK, nb2 - 1)];
             }
 #pragma unroll
-            for (int u = 0; u < UB; u++) xv[u] = *reinterpret_cast<const v2f64 *>(x + (size_t)c[u] * 2);
-#pragma unroll
             for (int u = 0; u < UB; u++) {
-                const int t = t0 + u * BLOCK;
+                const int t = L + u * BLOCK;
                 if (t < nblk) {
                     v2f64 p0, p1;
                     p0.x = a0[u].x * xv[u].x; p0.y = a0[u].y * xv[u].x;
@@ -339,10 +377,20 @@ void spmv_bsr22_kernel(int nr, const int *__restrict__ bptr, const int *__restri
         __syncthreads();
         if (rowlane) {
             const int s = max(rs, cb), e = min(re, cb + nblk);
-            for (int b = s; b < e; b++) {
-                const double *pp = prod + (size_t)(b - cb) * 4 + myi;
-                acc += pp[0];
-                acc += pp[2];
+            constexpr int UP = 4;                    // blocks whose products are read before they are added (in order)
+            for (int b = s; b < e; b += UP) {
+                double pv[UP][2];
+#pragma unroll
+                for (int u = 0; u < UP; u++) {
+                    const double *pp = prod + (size_t)(min(b + u, e - 1) - cb) * 4 + myi;
+                    pv[u][0] = pp[0]; pv[u][1] = pp[2];
+                }
+#pragma unroll
+                for (int u = 0; u < UP; u++) {
+                    const bool ok = b + u < e;       // acc starts at +0.0: a +0.0 term leaves it bit-unchanged
+                    acc += ok ? pv[u][0] : 0.0;
+                    acc += ok ? pv[u][1] : 0.0;
+                }
             }
         }
         __syncthreads();

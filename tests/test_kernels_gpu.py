@@ -578,6 +578,28 @@ def test_spmv_bsr_square_blocks(lib, name, bs):
                 assert abs(got[0][1] - np.dot(ref, ref)) <= 1e-13 * np.dot(ref, ref) + 1e-300
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LIS_AMD_FUZZ_SEEDS", "40"))))
+def test_spmv_bsr_on_random_structured_matrices(lib, seed):
+    """the generated matrices of the plan-coder fuzz (stencil-like, banded, ragged, with empty and long rows) in square blocks 2..4
+    through every BSR kernel: lane per block row (claimed short), the two-phase tile kernels, the dispatcher's own choice"""
+    ptr, idx, val, ncols = _structured_random(seed)
+    n = len(ptr) - 1
+    if ncols > n:
+        pytest.skip("the reference's csr2bsr (and the oracle's) takes square matrices: its work array has n / bnc block columns")
+    for bs in (2, 3, 4):
+        nr, bptr, bidx, bv = orc.csr2bsr(ptr, idx, val, bs, bs)
+        nc = max(int(bidx.max()) + 1 if len(bidx) else 1, (ncols + bs - 1) // bs)
+        xx = np.zeros(nc * bs + bs)
+        xx[:ncols] = np.random.default_rng(3000 + seed).uniform(-1, 1, ncols)
+        ref = orc.spmv_bsr(n, nr, bs, bs, bptr, bidx, bv, xx)
+        a, b, c = DA.from_host(bptr), DA.from_host(bidx if len(bidx) else np.zeros(1, np.int32)), DA.from_host(bv if len(bv) else np.zeros(1))
+        dx = DA.from_host(xx)
+        for known in (0, 1 << 30, len(bidx)):             # claimed short block rows, claimed long ones, the truth
+            dy = DA.from_host(np.full(max(nr * bs, 1), np.nan))
+            check(lib.liship_spmv_bsr_nnz_f64(nr, known, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host(n), ref), (seed, bs, known)
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 1000, 4097, 1 << 20, (1 << 20) + 3])
 def test_elementwise_bit_exact(lib, n):
     rng = np.random.default_rng(n)

@@ -336,6 +336,44 @@ def device_poisson_generator(lib, rank, world):
     y = np.empty(nl)
     assert lib.lis_vector_get_values(vy, is_, nl, y.ctypes.data_as(capi.P_DBL)) == 0
     assert np.array_equal(y, yg[is_:ie])
+    # The form a 512^3 slab takes (x beyond the Infinity Cache): the two-rows-per-lane value-record kernels, forced here, on a
+    # partitioned matrix -- ghost columns at constant offsets keep the rows on a few (offsets, values) patterns -- through the
+    # overlapped interior / boundary launches and the fused dots of CG: the bits of the one-row kernels
+    l, m, n = 4 * world, 24, 20
+    gn = l * m * n
+    B = capi.PM()
+    assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(B)) == 0
+    assert lib.lis_matrix_set_size(B, 0, gn) == 0
+    assert lib.dll.lis_amd_matrix_poisson3d(B, l, m, n, 0) == 0
+    is_, ie = B.contents.is_, B.contents.ie
+    nl = ie - is_
+    ptr, idx, val = orc.poisson3d(l, m, n)
+    xg = np.random.default_rng(6).uniform(-1, 1, gn)
+    yg = orc.spmv_csr(ptr, idx, val, xg)
+    bx, by, bb, bs = (lisdrv.new_vector(lib, B, None) for _ in range(4))
+    assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, nl, np.ascontiguousarray(xg[is_:ie]).ctypes.data_as(capi.P_DBL), bx) == 0
+    assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, nl, np.ascontiguousarray(yg[is_:ie]).ctypes.data_as(capi.P_DBL), bb) == 0
+    got = {}
+    for variant in (0, 0x4000):
+        lib.liship_spmv_csr_set_variant(variant)
+        assert lib.lis_matvec(B, bx, by) == 0
+        yy = np.empty(nl)
+        assert lib.lis_vector_get_values(by, is_, nl, yy.ctypes.data_as(capi.P_DBL)) == 0
+        assert np.array_equal(yy, yg[is_:ie]), variant
+        S = capi.PS()
+        assert lib.lis_solver_create(C.byref(S)) == 0
+        assert lib.lis_solver_set_option(b"-i cg -p jacobi -tol 1e-12 -maxiter 500 -initx_zeros true", S) == 0
+        assert lib.lis_solve(B, bb, bs, S) == 0
+        it = C.c_int()
+        lib.lis_solver_get_iter(S, C.byref(it))
+        xs = np.empty(nl)
+        assert lib.lis_vector_get_values(bs, is_, nl, xs.ctypes.data_as(capi.P_DBL)) == 0
+        got[variant] = (it.value, xs)
+        lib.lis_solver_destroy(S)
+    lib.liship_spmv_csr_set_variant(0)
+    assert lib.dll.lis_amd_matrix_value_records(B) == 1
+    assert got[0][0] == got[0x4000][0] and 10 < got[0][0] < 500 and np.array_equal(got[0][1], got[0x4000][1])
+    assert np.allclose(got[0][1], xg[is_:ie], rtol=0, atol=1e-8)
 
 
 if __name__ == "__main__":

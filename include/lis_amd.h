@@ -71,6 +71,12 @@ LIS_INT lis_amd_matrix_pattern_records(LIS_MATRIX A);
  * copy they follow the host arrays only through lis_amd_matrix_host_modified(); the arrays of a matrix adopted with
  * lis_amd_matrix_set_csr_device() must not be rewritten in place once a product has run. */
 LIS_INT lis_amd_matrix_value_records(LIS_MATRIX A);
+/* ELL and DIA matrices with constant coefficients are kept in HBM as CSR rows that list the format's terms in the format's order
+ * (bit-identical sums), so that the value records apply.  0 keeps the native ELL / DIA layout and kernels for matrices uploaded
+ * from now on (env LIS_AMD_NO_ROW_FORM=1): A/B measurements, and the tests that pin the native kernels at full size. */
+LIS_INT lis_amd_set_row_form(LIS_INT on);
+/* storage type of the HBM copy (LIS_MATRIX_CSR for matrices re-laid as rows: CSC, JAD, the row form above), uploads A if needed */
+LIS_INT lis_amd_matrix_device_type(LIS_MATRIX A);
 /* total length of the per-row-block lists of distinct columns when the HBM copy of A carries block-local columns (liship.h:
  * long rows that share their columns), 0 when it does not; uploads A if needed */
 LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A);

@@ -348,8 +348,8 @@ LIS_INT lisi_convert_to_csr(LIS_MATRIX A, LIS_MATRIX B)
 						else { const LIS_INT dst = c.ptr[r] + count[r]++; c.index[dst] = col; c.value[dst] = v; }
 					}
 		}
-		/* entries arrive block by block, column-major inside a block: restore ascending column order per row */
-		if (!err) for (LIS_INT i = 0; i < n; i++) lisi_sort_row(c.ptr[i], c.ptr[i + 1], c.index, c.value);
+		/* a row's entries arrive block by block in stored block order, ascending column inside a block: the order
+		 * lis_matrix_convert_bsr2csr leaves (lis_matrix_bsr.c convert loop: bj outer, j inner), unsorted blocks included */
 		break; }
 	default:
 		err = LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "storage format %D is not served by liblis_amd\n", A->matrix_type);
@@ -400,6 +400,7 @@ LIS_INT lis_matrix_copy(LIS_MATRIX Ain, LIS_MATRIX Aout)
 	LISCHK(lisi_matrix_check(Ain, LISI_CHECK_ASSEMBLED));
 	LISCHK(lisi_matrix_check(Aout, LISI_CHECK_NULL));
 	if (MDEV(Ain)->device_only) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "matrix lives in HBM only\n");
+	LISCHK(lis_matrix_merge(Ain));         /* a split matrix is copied in its merged form: the parts may hold a scaled system (lis_split.c) */
 	return lisi_matrix_deep_copy(Ain, Aout);
 }
 
@@ -418,6 +419,7 @@ static LIS_INT convert_impl(LIS_MATRIX Ain, LIS_MATRIX Aout)
 	LISCHK(lisi_matrix_check(Aout, LISI_CHECK_NULL));
 	if (MDEV(Ain)->device_only) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "matrix lives in HBM only: convert the host matrix before uploading\n");
 	const LIS_INT want = Aout->matrix_type;
+	LISCHK(lis_matrix_merge(Ain));         /* ref lis_matrix_ops.c:142: a split input is merged first */
 	if (Ain->matrix_type == want && !Ain->is_block) return lisi_matrix_deep_copy(Ain, Aout);
 	if (Ain->matrix_type == LIS_MATRIX_CSR) return lisi_convert_csr_to(Ain, Aout);
 	if (want == LIS_MATRIX_CSR) return lisi_convert_to_csr(Ain, Aout);

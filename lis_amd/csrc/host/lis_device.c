@@ -116,6 +116,7 @@ LIS_INT lis_amd_get_residency(void) { return lisg.residency; }
 
 LIS_INT lis_amd_last_solve_uniform_jacobi(void) { return lisg.last_uniform_jacobi; }
 
+LIS_INT lis_amd_set_row_form(LIS_INT on) { lisg.no_row_form = on ? 0 : 1; return LIS_SUCCESS; }
 LIS_INT lis_amd_set_graphs(LIS_INT on) { lisg.graphs = (on != 0); return LIS_SUCCESS; }
 LIS_INT lis_amd_last_solve_graph_replays(void) { return lisg.last_graph_replays; }
 LIS_INT lis_amd_set_loop_mode(LIS_INT mode)
@@ -358,7 +359,7 @@ static LIS_INT try_row_form(LIS_MATRIX A, lisd_mat *d, int *taken)
 {
 	*taken = 0;
 	const int n = A->n;
-	if (lisg.no_value_records || lisg.no_row_patterns || lisg.no_index_codes || n <= 0) return LIS_SUCCESS;
+	if (lisg.no_row_form || lisg.no_value_records || lisg.no_row_patterns || lisg.no_index_codes || n <= 0) return LIS_SUCCESS;
 	const int width = A->matrix_type == LIS_MATRIX_ELL ? A->maxnzr : A->nnd;
 	if (width < 1 || width > 32 || (long long)n * width >= 0x7fffffffLL) return LIS_SUCCESS;    /* value records hold up to 32 entries per row */
 	if (!few_distinct_values(A->value, (size_t)n * (size_t)width)) return LIS_SUCCESS;
@@ -562,6 +563,11 @@ LIS_INT lis_amd_matrix_value_records(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	return MDEV(A)->plan ? liship_csr_plan_value_records(MDEV(A)->plan) : 0;
+}
+LIS_INT lis_amd_matrix_device_type(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return MDEV(A)->type;
 }
 LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A)
 {

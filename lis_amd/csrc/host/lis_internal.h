@@ -104,6 +104,7 @@ typedef struct {
 	void *ev_packed, *ev_landed;
 	int long_row_tree;         /* LIS_AMD_LONG_ROW_TREE=1: rows longer than the LDS stage are added by a tree per pass (not bit-parity; opt-in) */
 	int no_value_records;      /* LIS_AMD_NO_VALUE_RECORDS=1: matrices whose rows repeat with their values keep streaming the values (A/B measurements) */
+	int no_row_form;           /* LIS_AMD_NO_ROW_FORM=1 / lis_amd_set_row_form(0): constant-coefficient ELL / DIA matrices keep their native layout and kernels */
 	int no_row_patterns;       /* LIS_AMD_NO_ROW_PATTERNS=1: coded CSR matrices keep one byte per non-zero instead of one per row (A/B measurements) */
 	int last_uniform_jacobi;   /* the last lis_solve ran CG + Jacobi with 1/diag as one double (lis_amd_last_solve_uniform_jacobi) */
 	int graphs;                /* LIS_AMD_GRAPHS=1: single-rank device-driven loops replay a hipGraph of one batch (opt-in: measured, no gain) */

@@ -17,21 +17,57 @@
 #include <stdio.h>
 #include <ctype.h>
 #include <errno.h>
+#include <omp.h>
+#include <unistd.h>
+#include <sys/types.h>
+#include <sys/stat.h>
 #include "lis_internal.h"
 
 #define MM_BANNER "%%MatrixMarket"
 
 typedef struct { char *buf; size_t len, pos; } slurp_t;
 
+static int io_timing = -1;
+static double io_t0;
+static void io_mark(const char *what)
+{
+	if (io_timing < 0) { const char *e = getenv("LIS_AMD_IO_TIMING"); io_timing = (e && e[0] == '1'); io_t0 = lis_wtime(); }
+	if (!io_timing) return;
+	const double t = lis_wtime();
+	if (what) fprintf(stderr, "lis_amd io: %-28s %8.3f s\n", what, t - io_t0);
+	io_t0 = t;
+}
+
 static LIS_INT slurp_file(const char *path, slurp_t *s)
 {
+	io_mark(NULL);
 	memset(s, 0, sizeof(*s));
 	FILE *f = fopen(path, "rb");
 	if (!f) return LISI_ERR(LIS_ERR_FILE_IO, "cannot open file %s\n", path);
 	size_t cap = 1 << 16, len = 0;
-	if (fseek(f, 0, SEEK_END) == 0) { long sz = ftell(f); if (sz > 0) cap = (size_t)sz + 1; rewind(f); }
+	struct stat st;
+	const int regular = fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
+	if (regular) cap = (size_t)st.st_size + 1;
 	char *buf = (char *)malloc(cap + 1);
 	if (!buf) { fclose(f); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)cap); }
+	if (regular && st.st_size > (16 << 20)) {
+		/* a large regular file: the host threads read disjoint pieces (the first touch of the buffer's pages is most of the cost) */
+		const size_t size = (size_t)st.st_size;
+		const int T = lisi_host_threads(), fd = fileno(f);
+		int bad = 0;
+#pragma omp parallel for num_threads(T) schedule(static, 1) reduction(|:bad)
+		for (int t = 0; t < T; t++) {
+			size_t at = size / (size_t)T * (size_t)t;
+			const size_t to = t == T - 1 ? size : size / (size_t)T * (size_t)(t + 1);
+			while (at < to) {
+				const ssize_t got = pread(fd, buf + at, to - at, (off_t)at);
+				if (got <= 0) { bad = 1; break; }
+				at += (size_t)got;
+			}
+		}
+		if (bad) { free(buf); fclose(f); return LISI_ERR(LIS_ERR_FILE_IO, "cannot read file %s\n", path); }
+		len = size;
+	} else
 	for (;;) {
 		if (len == cap) {
 			cap *= 2;
@@ -46,6 +82,7 @@ static LIS_INT slurp_file(const char *path, slurp_t *s)
 	fclose(f);
 	buf[len] = '\0';
 	s->buf = buf; s->len = len; s->pos = 0;
+	io_mark("file read");
 	return LIS_SUCCESS;
 }
 
@@ -165,12 +202,122 @@ static LIS_INT mm_read_vec(slurp_t *s, const mm_head *h, LIS_MATRIX A, LIS_VECTO
 	return LIS_SUCCESS;
 }
 
+/* ------------------------------------------------------------------ the entry lines of a coordinate file, parsed in parallel
+ * One line per entry, "row col value" (ref lis_input_mm.c:893-930 reads them with fgets + sscanf("%d %d %lg")).  The body is cut
+ * into one piece per host thread at line boundaries, the pieces' line counts give every piece the number of its first entry, and
+ * each thread parses its own lines.  Numbers: integers by hand; values by Clinger's exact case -- a decimal mantissa below 2^53
+ * times or over a power of ten up to 10^22 is ONE correctly rounded IEEE operation on two exact doubles, i.e. what strtod /
+ * sscanf("%lg") return -- and by strtod itself for everything else (long mantissas, large exponents, inf / nan, hex floats).
+ * The first malformed line in FILE order is the one reported. */
+typedef struct { int kind; LIS_INT entry; long r, c; } mm_text_error;       /* kind 1: malformed / missing line, 2: index outside */
+
+static int scan_double_fast(char **pp, double *out)
+{
+	static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+	char *p = *pp;
+	while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f') p++;
+	if (*p == '\n' || *p == '\0') return 0;
+	char *q = p;
+	int neg = 0;
+	if (*q == '+' || *q == '-') { neg = (*q == '-'); q++; }
+	unsigned long long m = 0;
+	int sig = 0, e10 = 0, any = 0, inexact = 0;
+	for (; *q >= '0' && *q <= '9'; q++) {
+		any = 1;
+		if (sig < 19) { m = m * 10 + (unsigned)(*q - '0'); if (m) sig++; } else { e10++; inexact |= (*q != '0'); }
+	}
+	if (*q == '.') {
+		q++;
+		for (; *q >= '0' && *q <= '9'; q++) {
+			any = 1;
+			if (sig < 19) { m = m * 10 + (unsigned)(*q - '0'); if (m) sig++; e10--; } else inexact |= (*q != '0');
+		}
+	}
+	if (any && (*q == 'e' || *q == 'E')) {
+		char *x = q + 1;
+		int eneg = 0, ev = 0, edig = 0;
+		if (*x == '+' || *x == '-') { eneg = (*x == '-'); x++; }
+		for (; *x >= '0' && *x <= '9'; x++) { edig = 1; if (ev < 100000) ev = ev * 10 + (*x - '0'); }
+		if (edig) { e10 += eneg ? -ev : ev; q = x; }
+	}
+	const int alpha = (*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || *q == '.';
+	if (any && !alpha && !inexact && m <= (1ULL << 53) && e10 >= -22 && e10 <= 22) {
+		double v = (double)m;
+		v = e10 < 0 ? v / P10[-e10] : v * P10[e10];
+		*out = neg ? -v : v;
+		*pp = q;
+		return 1;
+	}
+	char *end;
+	const double v = strtod(p, &end);          /* p is not white space: the conversion cannot run into the next line */
+	if (end == p) return 0;
+	*out = v; *pp = end;
+	return 1;
+}
+
+static int mm_parse_entries(slurp_t *s, LIS_INT nnz, LIS_INT nr, int *ri, int *ci, double *va, mm_text_error *te)
+{
+	te->kind = 0; te->entry = nnz; te->r = te->c = 0;
+	if (nnz <= 0) return 0;
+	char *base = s->buf + s->pos, *end = s->buf + s->len;
+	const size_t total = (size_t)(end - base);
+	int T = total > ((size_t)4 << 20) ? lisi_host_threads() : 1;
+	if (T > 64) T = 64;
+	char *cut[65];
+	long long first[65];
+	cut[0] = base; cut[T] = end;
+	for (int t = 1; t < T; t++) {
+		char *p = base + total / (size_t)T * (size_t)t;
+		char *q = (char *)memchr(p - 1, '\n', (size_t)(end - (p - 1)));
+		cut[t] = q ? q + 1 : end;
+	}
+	long long lines[64];
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+	for (int t = 0; t < T; t++) {
+		long long c = 0;
+		char *p = cut[t], *e = cut[t + 1];
+		while (p < e) {
+			char *q = (char *)memchr(p, '\n', (size_t)(e - p));
+			c++;                                   /* (a last line without newline counts too) */
+			if (!q) break;
+			p = q + 1;
+		}
+		lines[t] = c;
+	}
+	first[0] = 0;
+	for (int t = 0; t < T; t++) first[t + 1] = first[t] + lines[t];
+	mm_text_error errs[64];
+	size_t pos_after = s->pos;
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+	for (int t = 0; t < T; t++) {
+		errs[t].kind = 0;
+		char *p = cut[t], *e = cut[t + 1];
+		for (long long k = first[t]; k < nnz && p < e; k++) {
+			char *nl = (char *)memchr(p, '\n', (size_t)(e - p));
+			char *le = nl ? nl : e;
+			long r, c; double v;
+			char *q = p;
+			if (!scan_int(&q, &r) || !scan_int(&q, &c) || !scan_double_fast(&q, &v) || q > le) { errs[t].kind = 1; errs[t].entry = (LIS_INT)k; break; }
+			if (r < 1 || r > nr || c < 1 || c > nr) { errs[t].kind = 2; errs[t].entry = (LIS_INT)k; errs[t].r = r; errs[t].c = c; break; }
+			ri[k] = (int)(r - 1); ci[k] = (int)(c - 1); va[k] = v;
+			p = nl ? nl + 1 : e;
+			if (k == (long long)nnz - 1) pos_after = (size_t)(p - s->buf);
+		}
+	}
+	for (int t = 0; t < T; t++)
+		if (errs[t].kind && errs[t].entry < te->entry) *te = errs[t];
+	if (!te->kind && first[T] < nnz) { te->kind = 1; te->entry = (LIS_INT)first[T]; }
+	if (te->kind) return 1;
+	s->pos = pos_after;
+	return 0;
+}
+
 /* ------------------------------------------------------------------ coordinate file -> CSR rows [is,ie) */
 static LIS_INT mm_read_csr(slurp_t *s, const mm_head *h, LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x)
 {
 	LISCHK(lis_matrix_set_size(A, 0, h->nr));
 	if (A->my_rank == 0) { printf("matrix size = %d x %d (%d nonzero entries)\n\n", h->nr, h->nc, h->nnz); fflush(stdout); }
-	const LIS_INT n = A->n, is = A->is, ie = A->ie, nnz = h->nnz;
+	const LIS_INT n = A->n, is = A->is, nnz = h->nnz;
 	const int swap = h->isbin && (host_little() != (h->isbin - 1));
 	LIS_INT err = LIS_SUCCESS;
 	int *ri = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
@@ -181,27 +328,39 @@ static LIS_INT mm_read_csr(slurp_t *s, const mm_head *h, LIS_MATRIX A, LIS_VECTO
 	LIS_SCALAR *value = NULL;
 	if (!ri || !ci || !va || !ptr) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", nnz); goto fail; }
 
-	for (LIS_INT k = 0; k < nnz; k++) {
-		long r, c; double v;
-		if (h->isbin) {
+	if (h->isbin) {
+		for (LIS_INT k = 0; k < nnz; k++) {
 			if (s->pos + sizeof(mm_matrec) > s->len) { err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n"); goto fail; }
 			mm_matrec rec; memcpy(&rec, s->buf + s->pos, sizeof(rec)); s->pos += sizeof(rec);
 			if (swap) { bswap4(&rec.i); bswap4(&rec.j); bswap8(&rec.value); }
-			r = rec.i; c = rec.j; v = rec.value;
-		} else {
-			char *lb, *le;
-			if (!next_line(s, &lb, &le) || !scan_int(&lb, &r) || !scan_int(&lb, &c) || !scan_double(&lb, &v)) {
-				err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n"); goto fail;
-			}
+			/* an index outside the matrix would become an x gather index of the HIP kernels (a GPU fault that takes the
+			 * context with it); the reference does not check either, but its out-of-bounds read stays in one process */
+			if (rec.i < 1 || rec.i > h->nr || rec.j < 1 || rec.j > h->nr) { err = LISI_ERR(LIS_ERR_FILE_IO, "entry %D: index (%D,%D) is outside the matrix\n", k + 1, (LIS_INT)rec.i, (LIS_INT)rec.j); goto fail; }
+			ri[k] = rec.i - 1; ci[k] = rec.j - 1; va[k] = rec.value;
 		}
-		r--; c--;
-		/* an index outside the matrix would become an x gather index of the HIP kernels (a GPU fault that takes the
-		 * context with it); the reference does not check either, but its out-of-bounds read stays in one process */
-		if (r < 0 || r >= h->nr || c < 0 || c >= h->nr) { err = LISI_ERR(LIS_ERR_FILE_IO, "entry %D: index (%D,%D) is outside the matrix\n", k + 1, (LIS_INT)(r + 1), (LIS_INT)(c + 1)); goto fail; }
-		ri[k] = (int)r; ci[k] = (int)c; va[k] = v;
-		if (h->symmetric && r != c && c >= is && c < ie) ptr[c - is + 1]++;
-		if (r >= is && r < ie) ptr[r - is + 1]++;
+	} else {
+		mm_text_error te;
+		if (mm_parse_entries(s, nnz, h->nr, ri, ci, va, &te)) {
+			if (te.kind == 2) err = LISI_ERR(LIS_ERR_FILE_IO, "entry %D: index (%D,%D) is outside the matrix\n", te.entry + 1, (LIS_INT)te.r, (LIS_INT)te.c);
+			else err = LISI_ERR(LIS_ERR_FILE_IO, "file i/o error\n");
+			goto fail;
+		}
 	}
+	io_mark("entries parsed");
+	/* counting sort by destination row, FILE order kept inside a row (the mirrored entry of a symmetric line before the line's own):
+	 * every thread walks all triplets and places the ones whose destination lies in its own range of rows */
+	const int T = (nnz > (1 << 16)) ? lisi_host_threads() : 1;
+#pragma omp parallel num_threads(T)
+	{
+		const int t = omp_get_thread_num(), tn = omp_get_num_threads();
+		const LIS_INT lo = is + (LIS_INT)((long long)n * t / tn), hi = is + (LIS_INT)((long long)n * (t + 1) / tn);
+		for (LIS_INT k = 0; k < nnz; k++) {
+			const int r = ri[k], c = ci[k];
+			if (h->symmetric && r != c && c >= lo && c < hi) ptr[c - is + 1]++;
+			if (r >= lo && r < hi) ptr[r - is + 1]++;
+		}
+	}
+	io_mark("rows counted");
 	for (LIS_INT i = 0; i < n; i++) ptr[i + 1] += ptr[i];
 	const LIS_INT lnnz = ptr[n];
 	index = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(lnnz > 0 ? lnnz : 1));
@@ -209,11 +368,17 @@ static LIS_INT mm_read_csr(slurp_t *s, const mm_head *h, LIS_MATRIX A, LIS_VECTO
 	fill = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(n > 0 ? n : 1));
 	if (!index || !value || !fill) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", lnnz); goto fail; }
 	memcpy(fill, ptr, sizeof(LIS_INT) * (size_t)n);
-	for (LIS_INT k = 0; k < nnz; k++) {
-		const int r = ri[k], c = ci[k];
-		if (h->symmetric && r != c && c >= is && c < ie) { const LIS_INT at = fill[c - is]++; index[at] = r; value[at] = va[k]; }
-		if (r >= is && r < ie) { const LIS_INT at = fill[r - is]++; index[at] = c; value[at] = va[k]; }
+#pragma omp parallel num_threads(T)
+	{
+		const int t = omp_get_thread_num(), tn = omp_get_num_threads();
+		const LIS_INT lo = is + (LIS_INT)((long long)n * t / tn), hi = is + (LIS_INT)((long long)n * (t + 1) / tn);
+		for (LIS_INT k = 0; k < nnz; k++) {
+			const int r = ri[k], c = ci[k];
+			if (h->symmetric && r != c && c >= lo && c < hi) { const LIS_INT at = fill[c - is]++; index[at] = r; value[at] = va[k]; }
+			if (r >= lo && r < hi) { const LIS_INT at = fill[r - is]++; index[at] = c; value[at] = va[k]; }
+		}
 	}
+	io_mark("entries placed");
 	free(ri); free(ci); free(va); free(fill);
 	ri = ci = NULL; va = NULL; fill = NULL;
 
@@ -221,6 +386,7 @@ static LIS_INT mm_read_csr(slurp_t *s, const mm_head *h, LIS_MATRIX A, LIS_VECTO
 	if (err) goto fail;
 	ptr = NULL; index = NULL; value = NULL;          /* adopted */
 	LISCHK(lis_matrix_assemble(A));
+	io_mark("assembled");
 	if (b != NULL && x != NULL) {
 		if (h->isb) LISCHK(mm_read_vec(s, h, A, b));
 		if (h->isx) LISCHK(mm_read_vec(s, h, A, x));

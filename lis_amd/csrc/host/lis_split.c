@@ -244,13 +244,63 @@ LIS_INT lis_matrix_split(LIS_MATRIX A)
 	return LIS_SUCCESS;
 }
 
-/* ref lis_matrix_ops.c:1052-1112 rebuilds A's arrays from L, D, U (rows then read L, D, U -- and gain a diagonal entry they
- * may not have had).  A's own arrays were never dropped here (nor there: the destroy in lis_matrix_split is commented out),
- * so merging only retires the parts and the product returns to the unsplit order of the ORIGINAL arrays. */
+/* ref lis_matrix_ops.c:1052-1112.  CSR and BSR: A's arrays are REBUILT from the parts as lis_matrix_merge_csr / _bsr do
+ * (lis_matrix_csr.c merge, lis_matrix_bsr.c:1337-1395) -- every row lists its L entries, then the diagonal (an entry the row may
+ * not have had), then its U entries, with the parts' CURRENT values: after -scale jacobi -storage bsr the parts hold the scaled
+ * system (lis_scale.c), and a later lis_matrix_convert / lis_matrix_copy / second lis_solve must see that system, not the arrays
+ * the split started from.  The other formats' parts are never modified by anything served here, and their own arrays were
+ * never dropped (nor in the reference: the destroy in lis_matrix_split is commented out), so merging them only retires the parts. */
+static LIS_INT merge_csr(LIS_MATRIX A)
+{
+	const LIS_INT n = A->n;
+	const LIS_INT nnz = A->L->nnz + A->U->nnz + n;
+	LIS_INT *ptr = (LIS_INT *)malloc(sizeof(LIS_INT) * ((size_t)n + 1));
+	LIS_INT *index = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(nnz > 0 ? nnz : 1));
+	LIS_SCALAR *value = (LIS_SCALAR *)malloc(sizeof(LIS_SCALAR) * (size_t)(nnz > 0 ? nnz : 1));
+	if (!ptr || !index || !value) { free(ptr); free(index); free(value); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", nnz); }
+	LIS_INT at = 0;
+	ptr[0] = 0;
+	for (LIS_INT i = 0; i < n; i++) {
+		for (LIS_INT j = A->L->ptr[i]; j < A->L->ptr[i + 1]; j++) { index[at] = A->L->index[j]; value[at] = A->L->value[j]; at++; }
+		index[at] = i; value[at] = A->D->value[i]; at++;
+		for (LIS_INT j = A->U->ptr[i]; j < A->U->ptr[i + 1]; j++) { index[at] = A->U->index[j]; value[at] = A->U->value[j]; at++; }
+		ptr[i + 1] = at;
+	}
+	if (A->is_destroy) { free(A->ptr); free(A->index); free(A->value); }
+	A->ptr = ptr; A->index = index; A->value = value; A->nnz = at;
+	A->is_destroy = LIS_TRUE;            /* the rebuilt arrays are the library's, whoever owned the old ones */
+	return LIS_SUCCESS;
+}
+
+static LIS_INT merge_bsr(LIS_MATRIX A)
+{
+	const LIS_INT nr = A->nr;
+	const size_t bs = (size_t)A->bnr * A->bnc;
+	const LIS_INT bnnz = A->L->bnnz + A->U->bnnz + nr;
+	LIS_INT *bptr = (LIS_INT *)malloc(sizeof(LIS_INT) * ((size_t)nr + 1));
+	LIS_INT *bindex = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(bnnz > 0 ? bnnz : 1));
+	LIS_SCALAR *value = (LIS_SCALAR *)malloc(sizeof(LIS_SCALAR) * bs * (size_t)(bnnz > 0 ? bnnz : 1));
+	if (!bptr || !bindex || !value) { free(bptr); free(bindex); free(value); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", bnnz); }
+	LIS_INT at = 0;
+	bptr[0] = 0;
+	for (LIS_INT i = 0; i < nr; i++) {
+		for (LIS_INT j = A->L->bptr[i]; j < A->L->bptr[i + 1]; j++) { bindex[at] = A->L->bindex[j]; memcpy(value + bs * (size_t)at, A->L->value + bs * (size_t)j, sizeof(LIS_SCALAR) * bs); at++; }
+		bindex[at] = i; memcpy(value + bs * (size_t)at, A->D->value + bs * (size_t)i, sizeof(LIS_SCALAR) * bs); at++;
+		for (LIS_INT j = A->U->bptr[i]; j < A->U->bptr[i + 1]; j++) { bindex[at] = A->U->bindex[j]; memcpy(value + bs * (size_t)at, A->U->value + bs * (size_t)j, sizeof(LIS_SCALAR) * bs); at++; }
+		bptr[i + 1] = at;
+	}
+	if (A->is_destroy) { free(A->bptr); free(A->bindex); free(A->value); }
+	A->bptr = bptr; A->bindex = bindex; A->value = value; A->bnnz = at;
+	A->is_destroy = LIS_TRUE;
+	return LIS_SUCCESS;
+}
+
 LIS_INT lis_matrix_merge(LIS_MATRIX A)
 {
 	LISCHK(lisi_matrix_check(A, LISI_CHECK_ASSEMBLED));
 	if (!A->is_splited || A->is_save) return LIS_SUCCESS;
+	if (A->matrix_type == LIS_MATRIX_CSR) LISCHK(merge_csr(A));
+	else if (A->matrix_type == LIS_MATRIX_BSR && A->bnr == A->bnc) LISCHK(merge_bsr(A));
 	lisi_matrix_dlu_destroy(A);
 	lisd_mat_free(A);
 	return LIS_SUCCESS;

@@ -3,7 +3,9 @@
 Config 4 (SuiteSparse Queen_4147, GMRES(30)): the file is neither in the reference tree nor fetchable, so its class --
 irregular CSR with long rows -- is covered by two generated matrices whose reference results are committed
 (tests/golden/irregular_golden.json, made by tests/golden/make_golden_irregular.py from oracle/_ref): the product must carry
-the reference's bits (sha256 of y), the solvers its iteration counts.
+the reference's bits (sha256 of y), the solvers its iteration counts.  At Queen's own scale (4.1 M rows, 2.9e8 non-zeros) a generated
+symmetric Matrix Market file with scrambled numbering goes through lis_input on this box and is checked against what the reference
+returned for the same file (tests/golden/queen_class_golden.json, made by tests/golden/make_golden_queen_class.py).
 Config 5 (256^3 7-point Poisson in ELL and DIA storage, CG + Jacobi): 764 iterations, the count the reference needs in every
 storage format (tests/golden/known_answers.json).
 """
@@ -107,6 +109,84 @@ def test_config4_class_solvers_need_the_reference_iteration_counts(lib, name, op
     lib.lis_matrix_destroy(A)
 
 
+def test_config4_queen_scale_through_the_matrix_market_reader(lib):
+    """BASELINE config 4 at its own scale.  Queen_4147 cannot be fetched, so tests/golden/gen_queen_class.c writes its stand-in on
+    this box -- 4.1 M rows, 2.9e8 non-zeros, 3 unknowns per node, scrambled node numbering, a 3.3 GB SYMMETRIC coordinate file with
+    unsorted rows -- and the file takes the road the real one would: lis_input (reader + symmetric expansion, the order of
+    src/system/lis_input_mm.c:986-1036) -> HBM -> lis_matvec / lis_solve.  Checked against what the reference itself (oracle/_ref,
+    tests/golden/make_golden_queen_class.py) returned for the same file: sha256 of y = A x (the reader's in-row order AND the
+    product's summation order must both be the reference's for this to match), GMRES(30) / BiCGSTAB / CG + Jacobi iteration counts."""
+    import time
+    import queen_class
+    g = json.load(open(os.path.join(HERE, "golden", "queen_class_golden.json"))).get("full")
+    if g is None:
+        pytest.skip("no full-scale fixture committed")
+    t0 = time.time()
+    path, rows, stored = queen_class.generate("full")
+    t_gen = time.time() - t0
+    lib.dll.lis_amd_set_residency(1)
+    A, b, x0 = capi.PM(), capi.PV(), capi.PV()
+    try:
+        assert os.path.getsize(path) == g["file_bytes"]
+        assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
+        assert lib.lis_vector_create(capi.LIS_COMM_WORLD, C.byref(b)) == 0 and lib.lis_vector_create(capi.LIS_COMM_WORLD, C.byref(x0)) == 0
+        t0 = time.time()
+        assert lib.lis_input(A, b, x0, path.encode()) == 0
+        t_read = time.time() - t0
+    finally:
+        os.unlink(path)
+    try:
+        n, nnz = A.contents.n, A.contents.nnz
+        assert (n, nnz, rows, stored) == (g["n"], g["nnz"], g["n"], g["stored_entries"])
+        t0 = time.time()
+        assert lib.dll.lis_amd_matrix_upload(A) == 0
+        assert lib.dll.lis_amd_synchronize() == 0
+        t_up = time.time() - t0
+        lib.dll.lis_amd_matrix_index_codes.argtypes = [capi.PM]
+        lib.dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
+        assert lib.dll.lis_amd_matrix_index_codes(A) == 0            # thousands of (column - row) offsets: nothing to code
+        listed = lib.dll.lis_amd_matrix_local_columns(A)
+        xs = np.cos(np.arange(n) * 0.01) + 1.25
+        y = lisdrv.matvec(lib, A, xs)
+        assert _sha(y) == g["y_sha256"]                              # the bits lis_matvec of Lis 2.1.11 returned for this file
+        # the product's rate on resident vectors (contract bytes: 12 B per non-zero + 20 B per row, SURVEY 8d)
+        vx, vy = lisdrv.new_vector(lib, A, xs), lisdrv.new_vector(lib, A)
+        for _ in range(5):
+            assert lib.lis_matvec(A, vx, vy) == 0
+        assert lib.dll.lis_amd_synchronize() == 0
+        reps = 50
+        t0 = time.time()
+        for _ in range(reps):
+            assert lib.lis_matvec(A, vx, vy) == 0
+        assert lib.dll.lis_amd_synchronize() == 0
+        ms = (time.time() - t0) / reps * 1e3
+        assert np.array_equal(lisdrv.get_vector(lib, vy, n), y)
+        report = {"n": n, "nnz": nnz, "file_bytes": g["file_bytes"], "generate_s": round(t_gen, 2), "lis_input_s": round(t_read, 2),
+                  "reference_lis_input_s": g["reference_reader_seconds"], "upload_and_plan_s": round(t_up, 2),
+                  "block_local_columns_listed": int(listed), "spmv_ms": round(ms, 4),
+                  "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1), "spmv_frac_of_8TBs_contract_bytes": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4),
+                  "solves": {}}
+        rhs = lisdrv.matvec(lib, A, np.ones(n))                     # b = A*1 (test/test1.c:138-139)
+        for opts, want in g["solves"].items():
+            res = lisdrv.solve(lib, A, rhs, opts + " -tol 1e-12 -maxiter 2000 -print mem")
+            solver = opts.split()[1]
+            report["solves"][opts] = {"iter": res["iter"], "reference_iter": want["iter"], "resid": res["resid"],
+                                      "iters_per_sec": round(res["iter"] / res["itime"], 1) if res["itime"] else None,
+                                      "reference_itime_1thread_s": want.get("itime")}
+            assert res["status"] == want["status"] == 0 and res["resid"] <= 1e-12, opts
+            assert abs(res["iter"] - want["iter"]) <= SLACK[solver], (opts, res["iter"], want["iter"])
+            k = min(len(res["rhistory"]), len(want["rhistory_head"]))
+            np.testing.assert_allclose(res["rhistory"][:k], want["rhistory_head"][:k], rtol=1e-9)
+            assert np.abs(res["x"] - 1.0).max() <= 1e-9
+        out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
+        if os.path.isdir(out_dir):
+            json.dump(report, open(os.path.join(out_dir, "queen_class_run.json"), "w"), indent=1)
+        print(json.dumps(report))
+    finally:
+        lib.dll.lis_amd_set_residency(0)
+        lib.lis_matrix_destroy(A)
+
+
 @pytest.mark.parametrize("fmt", ["ell", "dia"])
 def test_config5_256_cubed_cg_jacobi_in_ell_and_dia(lib, fmt):
     N = 256
@@ -142,6 +222,54 @@ def test_config5_256_cubed_cg_jacobi_in_ell_and_dia(lib, fmt):
     finally:
         lib.dll.lis_amd_set_residency(0)
     lib.lis_matrix_destroy(A)
+
+
+@pytest.mark.parametrize("fmt", ["ell", "dia"])
+def test_config5_256_cubed_native_ell_and_dia_kernels(lib, fmt):
+    """Config 5 through the NATIVE loops of the two formats (spmv_ell_kernel / spmv_dia_kernel: the restatements of
+    lis_matvec_ell.c:113-128 and lis_matvec_dia.c:148-172) at the config's own size: with the row form switched off the 256^3
+    matrix keeps its ELL / DIA layout in HBM, its product with a non-trivial x carries the bits of the CSR product of the same
+    entries in the same in-row order (the oracle restates exactly that loop; padding and explicit zeros add 0 * x, which changes no
+    sum), and CG + Jacobi needs the reference's 764 iterations."""
+    N = 256
+    n = N ** 3
+    ptr, idx, val = orc.poisson3d(N, N, N, sort_cols=(fmt == "dia"))    # DIA adds a row's terms by ascending offset
+    x = np.modf(np.arange(n, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+    A0 = lisdrv.make_csr(lib, ptr, idx, val)
+    want = orc.spmv_csr(ptr, idx, val, x)
+    del idx, val
+    lib.dll.lis_amd_set_row_form(0)
+    lib.dll.lis_amd_matrix_device_type.argtypes = [capi.PM]
+    lib.dll.lis_amd_matrix_value_records.argtypes = [capi.PM]
+    try:
+        A = lisdrv.convert(lib, A0, fmt)
+        lib.lis_matrix_destroy(A0)
+        native = {"ell": capi.LIS_MATRIX_ELL, "dia": capi.LIS_MATRIX_DIA}[fmt]
+        assert lib.dll.lis_amd_matrix_device_type(A) == native and lib.dll.lis_amd_matrix_value_records(A) == 0
+        got = lisdrv.matvec(lib, A, x)
+        # (a sum started at +0.0 is never -0.0, so the 0 * x terms of padding / explicit zeros cannot show even in the exact zeros)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+        del got, want
+        lib.dll.lis_amd_set_residency(1)
+        try:
+            one, b, xs = (lisdrv.new_vector(lib, A) for _ in range(3))
+            assert lib.lis_vector_set_all(1.0, one) == 0
+            assert lib.lis_matvec(A, one, b) == 0
+            S = capi.PS()
+            lib.lis_solver_create(C.byref(S))
+            lib.lis_solver_set_option(b"-i cg -p jacobi -tol 1e-12 -maxiter 2000", S)
+            assert lib.lis_solve(A, b, xs, S) == 0
+            assert S.contents.retcode == 0 and S.contents.resid <= 1e-12
+            assert S.contents.iter == KNOWN["cg_jacobi_256"]["iter"] == 764, S.contents.iter
+            assert lib.dll.lis_amd_matrix_device_type(A) == native
+            lib.lis_solver_destroy(S)
+            for v in (one, b, xs):
+                lib.lis_vector_destroy(v)
+        finally:
+            lib.dll.lis_amd_set_residency(0)
+        lib.lis_matrix_destroy(A)
+    finally:
+        lib.dll.lis_amd_set_row_form(1)
 
 
 def test_ell_and_dia_row_form_of_the_27_point_stencil(lib):

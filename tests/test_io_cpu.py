@@ -252,3 +252,83 @@ def test_live_against_reference_on_random_files(lib, reflib, tmp_path, capfd):
         assert open(o1, "rb").read() == open(o2, "rb").read()
         destroy(reflib, A1, b1, x1); destroy(lib, A2, b2, x2)
     capfd.readouterr()
+
+
+# ---------------------------------------------------------------- BASELINE config 4: the Queen_4147 stand-in through the reader
+def test_queen_class_mini_reader_has_the_reference_bits(lib):
+    """The generator of the Queen-scale case at a size the CPU suite can afford (5 184 rows, 311 K non-zeros): a SYMMETRIC coordinate
+    file whose rows list their entries unsorted, node numbering scrambled.  This library's reader (parallel parse, exact-decimal
+    fast path, counting sort by destination row) must leave the CSR arrays the reference's reader left
+    (lis_input_mm.c:699-1069, expansion :986-1036) -- tests/golden/queen_class_golden.json, made from oracle/_ref -- and the oracle
+    must reproduce the reference's product bits and iteration counts on them."""
+    import hashlib
+    import json
+    import orc
+    import queen_class
+    g = json.load(open(os.path.join(HERE, "golden", "queen_class_golden.json")))["mini"]
+    path, rows, stored = queen_class.generate("mini")
+    try:
+        assert os.path.getsize(path) == g["file_bytes"], "gen_queen_class.c drifted from the fixture"
+        err, A, b, x = read_with(lib, path)
+    finally:
+        os.unlink(path)
+    assert err == 0
+    a = A.contents
+    assert (a.n, a.nnz, rows, stored) == (g["n"], g["nnz"], g["n"], g["stored_entries"])
+    ptr, idx, val = (np.ctypeslib.as_array(p, shape=(c,)).copy() for p, c in ((a.ptr, a.n + 1), (a.index, a.nnz), (a.value, a.nnz)))
+    h = hashlib.sha256()
+    for arr in (ptr, idx, val):
+        h.update(arr.tobytes())
+    assert h.hexdigest() == g["csr_sha256"]
+    assert np.diff(ptr).max() == g["max_row"]
+    assert len(np.unique(idx - np.repeat(np.arange(a.n), np.diff(ptr)))) > 255          # no diagonal structure to code
+    n = a.n
+    y = orc.spmv_csr(ptr, idx, val, np.cos(np.arange(n) * 0.01) + 1.25)
+    assert hashlib.sha256(y.tobytes()).hexdigest() == g["y_sha256"]
+    rhs = orc.spmv_csr(ptr, idx, val, np.ones(n))
+    for opts, want in g["solves"].items():
+        tok = opts.split()
+        solver, precon = tok[1], tok[tok.index("-p") + 1]
+        kw = {"restart": 30} if solver == "gmres" else {}
+        _, it, rc, resid, rh = getattr(orc, solver)(ptr, idx, val, rhs, precon=precon, tol=1e-12, maxiter=2000, **kw)
+        assert (it, rc, resid) == (want["iter"], want["status"], want["resid"]), opts
+        assert list(rh[:6]) == want["rhistory_head"], opts
+    lib.lis_matrix_destroy(A)
+
+
+def test_reader_reports_the_first_bad_line_of_a_large_file(lib, tmp_path, capfd):
+    """the entry lines are parsed by several threads: the error reported is still the first one in FILE order, whichever piece holds it"""
+    n, m = 3000, 400000
+    rng = np.random.default_rng(5)
+    r, c = rng.integers(1, n + 1, m), rng.integers(1, n + 1, m)
+    lines = [f"{a} {b} {float(v)!r}" for a, b, v in zip(r, c, rng.uniform(-1, 1, m))]
+    good = "%%MatrixMarket matrix coordinate real general\n" + f"{n} {n} {m}\n" + "\n".join(lines) + "\n"
+    assert len(good) > (4 << 20)                     # beyond the single-thread threshold
+    p = tmp_path / "big.mtx"
+    p.write_text(good)
+    err, A, _, _ = read_with(lib, str(p), vectors=False)
+    assert err == 0 and A.contents.nnz == m
+    ptr = np.ctypeslib.as_array(A.contents.ptr, shape=(n + 1,))
+    idx = np.ctypeslib.as_array(A.contents.index, shape=(m,))
+    order = np.argsort(r, kind="stable")             # file order inside every row
+    assert np.array_equal(np.diff(ptr), np.bincount(r - 1, minlength=n)) and np.array_equal(idx, c[order] - 1)
+    val = np.ctypeslib.as_array(A.contents.value, shape=(m,))
+    assert np.array_equal(val, np.array([float(t.split()[2]) for t in lines])[order])          # Python's float() is correctly rounded too
+    lib.lis_matrix_destroy(A)
+    for k_bad, text in ((m - 7, f"{n + 1} 1 0.5"), (m // 2, "12 abc 1.0"), (5, "3 4")):
+        bad = list(lines)
+        bad[k_bad] = text
+        bad[m - 3] = "0 0 1.0"                       # a later error must not win
+        p.write_text("%%MatrixMarket matrix coordinate real general\n" + f"{n} {n} {m}\n" + "\n".join(bad) + "\n")
+        capfd.readouterr()
+        err, A, _, _ = read_with(lib, str(p), vectors=False)
+        assert err == 6                              # LIS_ERR_FILE_IO
+        said = "".join(capfd.readouterr())
+        assert "entry %d:" % (m - 2) not in said
+        if text.startswith(str(n + 1)):
+            assert "entry %d: index (%d,1) is outside the matrix" % (k_bad + 1, n + 1) in said
+        lib.lis_matrix_destroy(A)
+    p.write_text("%%MatrixMarket matrix coordinate real general\n" + f"{n} {n} {m + 1}\n" + "\n".join(lines) + "\n")      # one line short
+    err, A, _, _ = read_with(lib, str(p), vectors=False)
+    assert err == 6
+    lib.lis_matrix_destroy(A)

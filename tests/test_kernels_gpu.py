@@ -1062,6 +1062,67 @@ def test_full_size_512_properties(lib):
     check(lib.liship_csr_plan_destroy(plan))
 
 
+def test_full_size_512_six_forms_bit_equal(lib):
+    """BASELINE's full size with a NON-TRIVIAL x through every form of the CSR product the plan can choose -- 4 B indices,
+    one-byte column codes, row patterns (general kernel and the 32 B-record kernel), value records one and two rows per lane:
+    nrm1(y_form - y_4B) == 0 at 512^3, and the fused <x, A x>, ||A x||^2 of every form are the same bits.  The 4 B form is the
+    contract kernel (lis_matvec_csr.c:97-109 restated), itself bit-compared with the oracle at the sizes the oracle finishes."""
+    N = 512
+    n = N ** 3
+    nnz = lib.liship_poisson3d_nnz(N, N, N, 0, n)
+    dptr, didx, dval = DA(n + 1, np.int32), DA(nnz, np.int32), DA(nnz, np.float64)
+    check(lib.liship_poisson3d_csr(N, N, N, 0, n, 0, dptr.ptr, didx.ptr, dval.ptr, None))
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    assert lib.liship_csr_plan_coded(plan) == 7 and lib.liship_csr_plan_row_patterns(plan) == 27
+    assert lib.liship_csr_plan_pattern_records(plan) == 1 and lib.liship_csr_plan_value_records(plan) == 1
+    work, res = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
+    x, y0, y = (DA(n, np.float64) for _ in range(3))
+    chunk = 1 << 24
+    for s in range(0, n, chunk):          # x_i = frac(i * golden ratio) - 0.5: no two neighbours alike, both signs
+        part = np.modf(np.arange(s, min(n, s + chunk), dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+        check(lib.liship_memcpy_h2d(x.ptr + 8 * s, part.ctypes.data, part.nbytes, None))
+        check(lib.liship_device_synchronize())
+
+    def select(on):
+        lib.liship_spmv_csr_set_index_codes(1 if on else 0)
+        lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)
+        lib.liship_spmv_csr_set_row_values(1 if on >= 4 else 0)
+        lib.liship_spmv_csr_set_variant(0x2000 if on == 3 else 0x4000 if on == 5 else 0)
+
+    dots = {}
+    try:
+        for on in (0, 1, 2, 3, 4, 5):
+            select(on)
+            dst = y0 if on == 0 else y
+            check(lib.liship_memset(dst.ptr, 0xff, 8 * n, None))
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, dst.ptr, None))
+            if on:
+                check(lib.liship_axpy_f64(n, -1.0, y0.ptr, y.ptr, None))
+                check(lib.liship_nrm1_f64(n, y.ptr, res.ptr, work.ptr, None))
+                assert res.to_host()[0] == 0.0, on
+            check(lib.liship_memset(y.ptr, 0xff, 8 * n, None))
+            check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, x.ptr, 1, res.ptr, work.ptr, None))
+            dots[on] = res.to_host().copy()
+            check(lib.liship_axpy_f64(n, -1.0, y0.ptr, y.ptr, None))
+            check(lib.liship_nrm1_f64(n, y.ptr, res.ptr, work.ptr, None))
+            assert res.to_host()[0] == 0.0, ("fused", on)
+    finally:
+        select(4)
+        lib.liship_spmv_csr_set_variant(0)
+    # the product is not trivially zero, and x^T A x > 0 (A is positive definite)
+    check(lib.liship_nrm1_f64(n, y0.ptr, res.ptr, work.ptr, None))
+    assert res.to_host()[0] > 1e6 and dots[0][0] > 0.0
+    # the forms that share a row-block geometry share their partial sums (coded plans rebuild the split at 256 / 2048, the 4 B form keeps
+    # the 192 / 1408 one of the bare plan only when no codes exist -- here every form runs on the coded plan's blocks)
+    for on in (1, 2, 3, 4, 5):
+        assert np.array_equal(dots[on], dots[0]), (on, dots[on], dots[0])
+    check(lib.liship_csr_plan_destroy(plan))
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 1000, 1 << 20, (1 << 20) + 1])
 def test_uniform_jacobi_passes(lib, n):
     """the CG passes that take 1/diag as one double give the bits of the passes that read an array holding that double everywhere,

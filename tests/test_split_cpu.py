@@ -116,3 +116,58 @@ def test_block_scaling_leaves_the_reference_arrays(lib, key):
     assert same_bits(np.ctypeslib.as_array(vb.contents.value, shape=(n,)), GB[key + "/b_scaled"])
     lib.lis_matrix_destroy(B)
     lib.lis_matrix_destroy(A)
+
+
+@pytest.mark.parametrize("name", MATS)
+@pytest.mark.parametrize("fmt,bs", [("csr", 0), ("bsr", 2), ("bsr", 3)])
+def test_lis_matrix_merge_rebuilds_the_arrays_from_the_parts(lib, name, fmt, bs):
+    """lis_matrix_merge of a CSR / BSR matrix rebuilds A's arrays from L, D, U in that order with the parts' CURRENT values
+    (lis_matrix_merge_csr, lis_matrix_merge_bsr: lis_matrix_bsr.c:1337-1395) -- a diagonal entry appears where the row had none --
+    and lis_matrix_convert / lis_matrix_copy merge a split input first (lis_matrix_ops.c:142).  Checked live against the reference
+    when oracle/_ref is built, against the construction rule otherwise."""
+    ptr, idx, val = (G[f"{name}/{k}"] for k in ("ptr", "idx", "val"))
+    libs = [lib]
+    if os.path.exists(orc.REF_SO):
+        libs.append(lisdrv.open_lib(orc.REF_SO, threads=1))
+    got = []
+    for L in libs:
+        A = lisdrv.make_csr(L, ptr, idx, val)
+        B = A if fmt == "csr" else lisdrv.convert(L, A, fmt, bs, bs)
+        assert L.lis_matrix_split(B) == 0
+        parts = lisdrv.split_arrays(B)
+        # scale the parts in place, as -scale jacobi -storage bsr does: the merged arrays must carry the scaled values
+        for core in (B.contents.L.contents, B.contents.U.contents):
+            cnt = core.nnz if fmt == "csr" else core.bnnz * bs * bs
+            if cnt:
+                np.ctypeslib.as_array(core.value, shape=(cnt,))[:] *= 0.5
+        assert L.lis_matrix_merge(B) == 0 and B.contents.is_splited == 0
+        arrs = lisdrv.matrix_arrays(B)
+        got.append(arrs)
+        pk, ik = ("ptr", "index") if fmt == "csr" else ("bptr", "bindex")
+        blk = 1 if fmt == "csr" else bs * bs
+        rows = len(arrs[pk]) - 1
+        lp, up = parts["L"][pk], parts["U"][pk]
+        want_ptr = lp + up + np.arange(rows + 1)
+        assert np.array_equal(arrs[pk], want_ptr)
+        for r in range(rows):
+            a = want_ptr[r]
+            nl, nu = lp[r + 1] - lp[r], up[r + 1] - up[r]
+            assert np.array_equal(arrs[ik][a:a + nl], parts["L"][ik][lp[r]:lp[r + 1]]) and arrs[ik][a + nl] == r
+            assert np.array_equal(arrs[ik][a + nl + 1:a + nl + 1 + nu], parts["U"][ik][up[r]:up[r + 1]])
+            assert same_bits(arrs["value"][a * blk:(a + nl) * blk], 0.5 * parts["L"]["value"][lp[r] * blk:lp[r + 1] * blk])
+            assert same_bits(arrs["value"][(a + nl) * blk:(a + nl + 1) * blk], parts["D"][r * blk:(r + 1) * blk])
+            assert same_bits(arrs["value"][(a + nl + 1) * blk:(a + nl + 1 + nu) * blk], 0.5 * parts["U"]["value"][up[r] * blk:up[r + 1] * blk])
+        # a split input is merged by convert before anything is read from it
+        assert L.lis_matrix_split(B) == 0
+        Cc = lisdrv.convert(L, B, "csr")
+        assert B.contents.is_splited == 0
+        got.append(lisdrv.matrix_arrays(Cc))
+        L.lis_matrix_destroy(Cc)
+        if B is not A:
+            L.lis_matrix_destroy(B)
+        L.lis_matrix_destroy(A)
+    if len(libs) == 2:
+        for mine, ref in ((got[0], got[2]), (got[1], got[3])):
+            for k in mine:
+                if isinstance(mine[k], np.ndarray):
+                    assert np.array_equal(mine[k], ref[k]) and (mine[k].dtype != np.float64 or same_bits(mine[k], ref[k])), k

@@ -11,8 +11,11 @@ liblis_amd.so (x = 1, as test/spmvtest3.c).  With N > 1 the matrix is row-block 
 (LIS_GET_ISIE, whole grid planes) and every step does the halo exchange over RCCL (ncclSend/ncclRecv of one plane
 per neighbour) around the local product.  Default WEAK scaling: every GPU keeps the 512^3 rows the metric is quoted
 on (global grid 512 x 512 x 512*N; 14 GB of matrix per 288 GB GPU); --scaling strong splits the one 512^3 grid.
-Reported: value = global SpMV GFLOP/s = 2*nnz*K / t (reference convention, test/spmvtest1.c:225), the
-roofline fraction of the dominant kernel from HIP events on the library's stream, Krylov iterations/s on the
+Reported: value = global SpMV GFLOP/s = 2*nnz*K / t (reference convention, test/spmvtest1.c:225); `roofline` = the bytes
+the timed kernel is asked to move (its stored matrix streams + y + the compulsory x) over its HIP-event time on the library's
+stream, as a fraction of 8 TB/s (always <= 1; asserted), with the PMC traffic of the same command from profiles/ as the upper
+bound and the contract's 12 B/nnz + 20 B/row count beside it as `contract_frac`; the same product on a non-trivial x; the same
+product with the value records off (`values_streamed`: the kernel any matrix on these sparsity patterns takes); Krylov iterations/s on the
 same matrix as the reference defines them -- iter / itime of lis_solver_get_timeex (src/solver/lis_solver.c:
 902-908) over --solver-iters iterations -- each with its own roofline, and the reference's own
 OpenMP CPU path timed on this box's host cores.
@@ -152,6 +155,29 @@ def main():
     x, y, b = vec(), vec(), vec()
     assert lib.lis_vector_set_all(1.0, x) == 0
 
+    stream = dll.lis_amd_stream()
+    timer = C.c_void_p()
+    check(lib.liship_timer_create(C.byref(timer)))
+    ev_ms = C.c_float()
+    nrm = C.c_double()
+
+    def timed_products(xv, steps):
+        """exactly `steps` products between barrier + device sync on both sides: (seconds, MAX over ranks; HIP-event ms per launch)"""
+        sync(); barrier()
+        t0 = time.perf_counter()
+        check(lib.liship_timer_start(timer, stream))
+        for _ in range(steps):
+            assert lib.lis_matvec(A, xv, y) == 0
+        check(lib.liship_timer_stop(timer, stream))
+        sync(); barrier()
+        el = time.perf_counter() - t0
+        check(lib.liship_timer_elapsed_ms(timer, C.byref(ev_ms)))
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt[0])
+        return el, ev_ms.value / steps
+
     # ---- untimed clock ramp (power state of an idle box), then the contract's W warm-up steps
     for _ in range(args.preroll):
         assert lib.lis_matvec(A, x, y) == 0
@@ -159,115 +185,114 @@ def main():
     # ---- timed region: W warm-up steps, then exactly K steps between barrier + device sync on both sides
     for _ in range(args.warmup):
         assert lib.lis_matvec(A, x, y) == 0
-    stream = dll.lis_amd_stream()
-    timer = C.c_void_p()
-    check(lib.liship_timer_create(C.byref(timer)))
-    sync(); barrier()
-    t0 = time.perf_counter()
-    check(lib.liship_timer_start(timer, stream))
-    for _ in range(args.steps):
-        assert lib.lis_matvec(A, x, y) == 0
-    check(lib.liship_timer_stop(timer, stream))
-    sync(); barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = C.c_float()
-    check(lib.liship_timer_elapsed_ms(timer, C.byref(ev_ms)))
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    dt, kernel_ms = timed_products(x, args.steps)
     ms_per_step = dt / args.steps * 1e3
     gflops = 2.0 * nnz_global * args.steps / dt / 1e9
 
     # result check outside the timed region: ||A*1||_2^2 = 6(N-2)^2 + 48(N-2) + 72 exactly on the cube (spmvtest3)
-    nrm = C.c_double()
-    assert lib.lis_vector_nrm2(y, C.byref(nrm)) == 0
     # (a row sums to the number of neighbours it lacks: 8 corners 3, the edges 2, the faces 1)
     expect = (72.0 + 4.0 * (4 * (L - 2) + 8 * (N - 2)) + 2.0 * (N - 2) ** 2 + 4.0 * (L - 2) * (N - 2)) ** 0.5
-    if abs(nrm.value - expect) > 1e-12 * expect:
-        sys.exit(f"rank {rank}: ||A*1||_2 = {nrm.value!r}, expected {expect!r}")
 
-    # ---- roofline of the dominant kernel (CSR SpMV): algorithmic bytes per launch / HIP-event time per launch
-    alg_bytes = 12 * nnz_local + 20 * n_local + 4        # 12 B per non-zero + 20 B per row
-    kernel_ms = ev_ms.value / args.steps
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    # PMC traffic of the same command (rocprofv3 --pmc passes cannot run inside this process): the newest committed summary,
-    # made by tools/prof.sh + tools/traffic_json.py.  Bytes are counted at the L2 <-> fabric boundary by request size
-    # (TCC_EA0_RDREQ_{32B,64B,128B}, TCC_EA0_WRREQ_{,64B}), so reads served by the 256 MB Infinity Cache are included.
-    traffic, traffic_detail = None, None
-    if N == 512 and world == 1:
-        for tf in ("r02_spmv512_traffic.json", "r01_spmv512_traffic.json"):
-            tf = os.path.join(ROOT, "profiles", tf)
-            if os.path.exists(tf):
-                tj = json.load(open(tf))
-                traffic = tj.get("fabric_bytes_per_launch", tj.get("hbm_traffic_bytes_per_launch"))
-                traffic_detail = {k: tj[k] for k in ("source", "kernel", "level", "avg_kernel_ns", "read_bytes_per_launch", "write_bytes_per_launch",
-                                                     "x_bytes_per_launch", "x_refetch_factor", "fabric_rate_GBs", "hbm_bytes_bounds", "note") if k in tj}
-                traffic_detail["file"] = os.path.relpath(tf, ROOT)
-                break
-    # One-byte column codes (the stencil sits on 7 diagonals): the kernel then streams 9 B per non-zero, not
-    # the 12 B the contract's algorithmic count prices -- `achieved` / `frac` stay on the contract's bytes, the bytes the
-    # kernel is actually asked to move and the fraction of the roofline THEY reach are reported beside them.
+    def check_a_times_one(what):
+        assert lib.lis_vector_nrm2(y, C.byref(nrm)) == 0
+        if abs(nrm.value - expect) > 1e-12 * expect:
+            sys.exit(f"rank {rank}: {what}: ||A*1||_2 = {nrm.value!r}, expected {expect!r}")
+    check_a_times_one("headline")
+
+    # ---- a NON-TRIVIAL x beside the reference's x = 1 (test/spmvtest3.c): x_i = frac(i * golden ratio) - 0.5.  Same kernel, same bytes;
+    # the FP64 multipliers then toggle full mantissas and the clocks follow the power, so this is the rate real data sees.
+    xg = vec()
+    lo = C.c_int(); hi = C.c_int()
+    assert lib.lis_vector_get_range(xg, C.byref(lo), C.byref(hi)) == 0
+    chunk = 1 << 24
+    for s0 in range(0, n_local, chunk):
+        cnt = min(chunk, n_local - s0)
+        part = np.modf(np.arange(lo.value + s0, lo.value + s0 + cnt, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+        assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, lo.value + s0, cnt, part.ctypes.data_as(capi.P_DBL), xg) == 0
+
+    def leg(xv, steps):
+        for _ in range(max(args.warmup, 5)):
+            assert lib.lis_matvec(A, xv, y) == 0
+        el, k_ms = timed_products(xv, steps)
+        return {"value": round(2.0 * nnz_global * steps / el / 1e9, 2), "unit": "GFLOP/s", "ms_per_step": round(el / steps * 1e3, 4), "kernel_ms": round(k_ms, 4)}
+
+    # ---- which form of the matrix the plan keeps (found on the device at upload) and the bytes its kernel is asked to stream
+    alg_bytes = 12 * nnz_local + 20 * n_local + 4        # SURVEY 8d, the contract's count: 12 B per non-zero + 20 B per row
     dll.lis_amd_matrix_index_codes.argtypes = [capi.PM]
     coded = int(dll.lis_amd_matrix_index_codes(A))
     dll.lis_amd_matrix_row_patterns.argtypes = [capi.PM]
-    patterns = int(dll.lis_amd_matrix_row_patterns(A))     # > 0: one byte per ROW (pattern) + a 2 B row start instead of 1 B per non-zero + 4 B
+    patterns = int(dll.lis_amd_matrix_row_patterns(A))     # > 0: one byte per ROW (pattern) instead of 1 B per non-zero + 4 B per row
     dll.lis_amd_matrix_pattern_records.argtypes = [capi.PM]
     records = int(dll.lis_amd_matrix_pattern_records(A))   # 1: patterns of <= 7 offsets kept as 32 B records (gathers ahead of the value slice)
     dll.lis_amd_matrix_value_records.argtypes = [capi.PM]
-    values = int(dll.lis_amd_matrix_value_records(A))      # 1: the rows of a pattern share their values too (constant coefficients): the
+    values = int(dll.lis_amd_matrix_value_records(A))      # 1: the rows of a pattern share their values too (constant coefficients)
     if world > 1:                                          # (one answer for the whole job: the second measurement below is collective)
         vv = torch.tensor([values], dtype=torch.int32)
         dist.all_reduce(vv, op=dist.ReduceOp.MIN)
         values = int(vv[0])
-    moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, values)     # records hold them, neither values nor indices are streamed
 
     def kernel_name(v):
         pair = n_local * 8 > (256 << 20)                  # x beyond the Infinity Cache: the two-rows-per-lane form of the plain product
         return (("spmv_csr_valuerec_pair_kernel" if pair else "spmv_csr_valuerec_kernel") if patterns and records and v else "spmv_csr_pattern7_kernel" if patterns and records else
                 "spmv_csr_pattern_kernel" if patterns else "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel")
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
-                "kernel": kernel_name(values), "kernel_ms": round(kernel_ms, 4),
-                "alg_bytes_per_launch": alg_bytes, "per_gpu": True,
-                "index_codes": coded, "row_patterns": patterns, "value_records": values, "stored_bytes_per_launch": moved,
-                "frac_of_stored_bytes": round(moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    if values:
-        roofline["note"] = ("`achieved` / `frac` price the contract's algorithmic bytes (12 B per non-zero + 20 B per row) as the "
-                            "measurement contract defines them and exceed the peak because this kernel does not move them: the matrix "
-                            "is constant-coefficient, its 27 row patterns carry their values, and one byte per row is all that is "
-                            "streamed (bit-identical results).  `frac_of_stored_bytes` is the fraction of the HBM roofline on the bytes "
-                            "the kernel is asked to move (it is bound by the latency of its x gathers, not by bytes); the same product "
-                            "with the values streamed (any matrix with these patterns) is timed below as `values_streamed`.")
+
+    def pmc_traffic(name):
+        """HBM-side bytes per launch from the PMC passes of this same command (rocprofv3 --pmc cannot run inside the process it profiles;
+        separate passes as the microarchitecture guide prescribes: tools/prof.sh + tools/traffic_json.py), committed under profiles/.
+        Counted at the L2 <-> fabric boundary by request size, so re-reads the 256 MB Infinity Cache answers are included: an UPPER bound
+        of the HBM bytes; the stored bytes are the lower one."""
+        if N != 512 or world != 1:
+            return None, None
+        for tf in ("r03_spmv512_traffic%s.json", "r02_spmv512_traffic%s.json"):
+            tf = os.path.join(ROOT, "profiles", tf % name)
+            if os.path.exists(tf):
+                tj = json.load(open(tf))
+                detail = {k: tj[k] for k in ("source", "kernel", "level", "avg_kernel_ns", "read_bytes_per_launch", "write_bytes_per_launch",
+                                             "x_bytes_per_launch", "x_refetch_factor", "fabric_rate_GBs", "hbm_bytes_bounds", "note") if k in tj}
+                detail["file"] = os.path.relpath(tf, ROOT)
+                return tj.get("fabric_bytes_per_launch", tj.get("hbm_traffic_bytes_per_launch")), detail
+        return None, None
+
+    def roofline_of(v, k_ms, traffic_name, applies_to):
+        """`achieved` / `frac`: the bytes THIS kernel is asked to move (its stored matrix streams + y + the compulsory x) over its own
+        HIP-event time -- a physical rate, <= the peak by construction.  `traffic`: the PMC bytes (upper bound, see pmc_traffic).
+        `contract_*`: SURVEY 8d's algorithmic count (12 B per non-zero + 20 B per row, the reference's CSR layout) over the same time --
+        NOT a rate of this kernel when the plan stores fewer bytes; it says how much faster than a perfect streaming of the reference's
+        layout the product runs, and may exceed 1."""
+        moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, v)
+        traffic, detail = pmc_traffic(traffic_name)
+        sec = k_ms * 1e-3
+        r = {"bound": "hbm", "achieved": round(moved / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(moved / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": detail,
+             "kernel": kernel_name(v), "kernel_ms": round(k_ms, 4), "bytes_per_launch": moved, "per_gpu": True,
+             "bytes_are": "stored matrix streams + y + compulsory x of the timed kernel (lower bound of its HBM bytes; `traffic` is the counters' upper bound)",
+             "contract_bytes_per_launch": alg_bytes, "contract_achieved": round(alg_bytes / sec / 1e9, 1),
+             "contract_frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+             "index_codes": coded, "row_patterns": patterns, "value_records": v, "applies_to": applies_to}
+        if traffic:
+            r["traffic_over_bytes"] = round(traffic / moved, 3)
+        return r
+
+    CONSTANT = ("constant-coefficient matrices only: the 27 row patterns of this stencil carry their VALUES (checked bit for bit at plan time), one pattern "
+                "byte per row is the only matrix stream; latency-bound, not byte-bound (DESIGN.md 4)")
+    GENERAL = "any matrix on these sparsity patterns, whatever its coefficients: 8 B per non-zero + one pattern byte per row streamed"
+    roofline = roofline_of(values, kernel_ms, "", CONSTANT if values else GENERAL)
+    nontrivial = leg(xg, args.steps)
+    nontrivial["x"] = "x_i = frac(i * 0.618...) - 0.5"
+    nontrivial["frac"] = round(roofline["bytes_per_launch"] / (nontrivial["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     # ---- the same product with the value records switched off (the general kernel: 8 B per non-zero + 17 B per row), same run
     streamed = None
     if values:
         check(lib.liship_spmv_csr_set_row_values(0))
-        for _ in range(max(args.warmup, 5)):
-            assert lib.lis_matvec(A, x, y) == 0
-        sync(); barrier()
-        t0s = time.perf_counter()
-        check(lib.liship_timer_start(timer, stream))
-        for _ in range(args.steps):
-            assert lib.lis_matvec(A, x, y) == 0
-        check(lib.liship_timer_stop(timer, stream))
-        sync(); barrier()
-        dts = time.perf_counter() - t0s
-        check(lib.liship_timer_elapsed_ms(timer, C.byref(ev_ms)))
-        if world > 1:
-            tt = torch.tensor([dts], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dts = float(tt[0])
-        assert lib.lis_vector_nrm2(y, C.byref(nrm)) == 0
-        if abs(nrm.value - expect) > 1e-12 * expect:
-            sys.exit(f"rank {rank}: values streamed: ||A*1||_2 = {nrm.value!r}, expected {expect!r}")
-        k_ms = ev_ms.value / args.steps
-        moved_s = spmv_stored_bytes(n_local, nnz_local, coded, patterns, 0)
-        streamed = {"value": round(2.0 * nnz_global * args.steps / dts / 1e9, 2), "unit": "GFLOP/s", "ms_per_step": round(dts / args.steps * 1e3, 4),
-                    "kernel": kernel_name(0), "kernel_ms": round(k_ms, 4),
-                    "achieved": round(alg_bytes / (k_ms * 1e-3) / 1e9, 1), "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "stored_bytes_per_launch": moved_s, "frac_of_stored_bytes": round(moved_s / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        check(lib.liship_spmv_csr_set_row_values(1))
+        try:
+            streamed = leg(x, args.steps)
+            check_a_times_one("values streamed")
+            streamed["roofline"] = roofline_of(0, streamed["kernel_ms"], "_values_streamed", GENERAL)
+            streamed["kernel"] = streamed["roofline"]["kernel"]
+            streamed["nontrivial_x"] = leg(xg, args.steps)
+            streamed["nontrivial_x"]["frac"] = round(streamed["roofline"]["bytes_per_launch"] / (streamed["nontrivial_x"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        finally:
+            check(lib.liship_spmv_csr_set_row_values(1))
 
     # ---- N > 1: what the exchange costs by itself, and the product with the overlap switched off (A/B)
     multi = None
@@ -330,26 +355,28 @@ def main():
                              "loop_bytes_per_iter": loop_b, "achieved": round(loop_b / sec_per_iter / 1e9, 1),
                              "frac": round(loop_b / sec_per_iter / 1e9 / HBM_PEAK_GBS, 4),
                              "contract_bytes_per_iter": contract_b,
-                             "frac_of_contract_bytes": round(contract_b / sec_per_iter / 1e9 / HBM_PEAK_GBS, 4)}}
+                             "contract_frac": round(contract_b / sec_per_iter / 1e9 / HBM_PEAK_GBS, 4)}}
             lib.lis_solver_destroy(S)
         if values and streamed is not None:                 # CG + Jacobi once more with the values streamed
             check(lib.liship_spmv_csr_set_row_values(0))
-            S = capi.PS()
-            assert lib.lis_solver_create(C.byref(S)) == 0
-            assert lib.lis_solver_set_option(f"-i cg -p jacobi -tol 1e-12 -maxiter {args.solver_iters}".encode(), S) == 0
-            assert lib.lis_solve(A, b, y, S) == 0
-            tm = [C.c_double() for _ in range(5)]
-            assert lib.lis_solver_get_timeex(S, *[C.byref(t) for t in tm]) == 0
-            itime, iters = tm[1].value, min(S.contents.iter, args.solver_iters)
-            if world > 1:
-                tt = torch.tensor([itime], dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                itime = float(tt[0])
-            loop_b, _ = krylov_bytes("cg_jacobi", iters, n_local, nnz_local, coded, patterns, 0, int(dll.lis_amd_last_solve_uniform_jacobi()))
-            streamed["cg_jacobi"] = {"iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6),
-                                     "loop_bytes_per_iter": loop_b, "frac": round(loop_b / (itime / max(1, iters)) / 1e9 / HBM_PEAK_GBS, 4)}
-            lib.lis_solver_destroy(S)
-            check(lib.liship_spmv_csr_set_row_values(1))
+            try:
+                S = capi.PS()
+                assert lib.lis_solver_create(C.byref(S)) == 0
+                assert lib.lis_solver_set_option(f"-i cg -p jacobi -tol 1e-12 -maxiter {args.solver_iters}".encode(), S) == 0
+                assert lib.lis_solve(A, b, y, S) == 0
+                tm = [C.c_double() for _ in range(5)]
+                assert lib.lis_solver_get_timeex(S, *[C.byref(t) for t in tm]) == 0
+                itime, iters = tm[1].value, min(S.contents.iter, args.solver_iters)
+                if world > 1:
+                    tt = torch.tensor([itime], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    itime = float(tt[0])
+                loop_b, _ = krylov_bytes("cg_jacobi", iters, n_local, nnz_local, coded, patterns, 0, int(dll.lis_amd_last_solve_uniform_jacobi()))
+                streamed["cg_jacobi"] = {"iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6),
+                                         "loop_bytes_per_iter": loop_b, "frac": round(loop_b / (itime / max(1, iters)) / 1e9 / HBM_PEAK_GBS, 4)}
+                lib.lis_solver_destroy(S)
+            finally:
+                check(lib.liship_spmv_csr_set_row_values(1))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -364,9 +391,12 @@ def main():
             "config": {"workload": (f"3-D 7-point Poisson {N}^3" if L == N else f"3-D 7-point Poisson {N}^3 per GPU (grid {N} x {N} x {L})") + ", CSR f64/i32, y=A*x via lis_matvec (x=1), test3.c entry order",
                        "n": n_global, "nnz": nnz_global, "parallelism": f"row-block x{world}" + ((" + RCCL halo" if comm_used == "rccl" else " + gloo-callback halo (bring-up, not a measurement)") if world > 1 else "")},
             "roofline": roofline,
+            "nontrivial_x": nontrivial,
             "values_streamed": streamed,
-            "hbm_roofline_pct_whole_job": round(100.0 * (12 * nnz_global + 20 * n_global) / (ms_per_step * 1e-3) / 1e9
-                                                / (HBM_PEAK_GBS * world), 2),
+            "reading_guide": ("`value` / `roofline`: the product lis_matvec runs for THIS matrix (x = 1, the reference's spmvtest3 convention); `nontrivial_x`: "
+                              "the same kernel on non-trivial data; `values_streamed`: the kernel every matrix with these sparsity patterns but varying "
+                              "coefficients takes, with its own roofline.  Every `frac` is bytes-the-kernel-moves / its HIP-event time / 8 TB/s (<= 1, "
+                              "asserted); `contract_frac` prices SURVEY 8d's 12 B/nnz + 20 B/row layout over the same time and may exceed 1."),
             "preroll": args.preroll,          # untimed clock-ramp launches before the W warm-up steps (a cold process: +7 %)
             "degraded": bool(world > 1 and comm_used != "rccl"),   # True: the RCCL communicator could not be formed, NOT a measurement
             "rccl_ranks": world if (world > 1 and comm_used == "rccl" and int(dll.lis_amd_comm_kind()) == 1) else (0 if world > 1 else None),
@@ -374,6 +404,7 @@ def main():
             "krylov": solvers,
             "cpu_baseline": cpu,
         }
+        assert_fracs_physical(out)
         print(json.dumps(out), flush=True)
     degraded = world > 1 and comm_used != "rccl" and args.comm == "rccl"
     if world > 1:
@@ -381,6 +412,19 @@ def main():
         dist.destroy_process_group()
     if degraded:
         sys.exit(3)                   # the line above says "degraded": true; a driver that only looks at the exit code sees it too
+
+
+def assert_fracs_physical(node, path="line"):
+    """every `frac` in the line is a fraction of the HBM peak on bytes a kernel moves over its measured time: 0 < frac <= 1"""
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if k == "frac":
+                assert v is not None and 0.0 < v <= 1.0, f"{path}.frac = {v!r} is not a physical fraction of the roofline"
+            else:
+                assert_fracs_physical(v, f"{path}.{k}")
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            assert_fracs_physical(v, f"{path}[{i}]")
 
 
 def spmv_stored_bytes(n, nnz, coded, patterns, values=0):

@@ -27,6 +27,24 @@ def test_bench_line_has_the_contract_fields():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # the roofline prices the bytes the TIMED kernel moves over its own HIP-event time: a physical fraction; the contract's count is beside it
+    assert 0 < r["frac"] <= 1.0 and abs(r["achieved"] - r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 0.01 * r["achieved"] + 0.1
+    assert r["contract_bytes_per_launch"] == 12 * d["config"]["nnz"] + 20 * d["config"]["n"] + 4 and r["contract_frac"] > 0 and "applies_to" in r
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert d["nontrivial_x"]["value"] > 0 and 0 < d["nontrivial_x"]["frac"] <= 1.0
+    vs = d["values_streamed"]
+    if r["value_records"]:
+        assert vs is not None and vs["roofline"]["value_records"] == 0 and 0 < vs["roofline"]["frac"] <= 1.0
+        assert vs["roofline"]["bytes_per_launch"] > r["bytes_per_launch"] and vs["nontrivial_x"]["value"] > 0
+
+    def fracs(node):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                if k == "frac":
+                    yield v
+                else:
+                    yield from fracs(v)
+    assert all(0 < f <= 1.0 for f in fracs(d))
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

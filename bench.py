@@ -231,9 +231,14 @@ def main():
         dist.all_reduce(vv, op=dist.ReduceOp.MIN)
         values = int(vv[0])
 
+    dll.lis_amd_matrix_dominant_pattern.argtypes = [capi.PM]
+    dominant = int(dll.lis_amd_matrix_dominant_pattern(A))     # 1: one pattern carries most rows and its x gathers are issued with the pattern bytes (round 3)
+
     def kernel_name(v):
-        pair = n_local * 8 > (256 << 20)                  # x beyond the Infinity Cache: the two-rows-per-lane form of the plain product
-        return (("spmv_csr_valuerec_pair_kernel" if pair else "spmv_csr_valuerec_kernel") if patterns and records and v else "spmv_csr_pattern7_kernel" if patterns and records else
+        pair = n_local * 8 > (256 << 20)                  # round-2 kernels: x beyond the Infinity Cache takes the two-rows-per-lane form
+        if patterns and records and v:
+            return "spmv_csr_valuerec_dom_kernel" if dominant else "spmv_csr_valuerec_pair_kernel" if pair else "spmv_csr_valuerec_kernel"
+        return ("spmv_csr_pattern7_kernel" if patterns and records else
                 "spmv_csr_pattern_kernel" if patterns else "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel")
 
     def pmc_traffic(name):

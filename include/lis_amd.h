@@ -71,6 +71,10 @@ LIS_INT lis_amd_matrix_pattern_records(LIS_MATRIX A);
  * copy they follow the host arrays only through lis_amd_matrix_host_modified(); the arrays of a matrix adopted with
  * lis_amd_matrix_set_csr_device() must not be rewritten in place once a product has run. */
 LIS_INT lis_amd_matrix_value_records(LIS_MATRIX A);
+/* 1 when, on top of the value records, ONE pattern carries at least half of the rows and the others are read in its slots: the products
+ * then issue that pattern's x gathers together with the pattern bytes -- one round trip per wavefront, no LDS, no barrier (liship.h
+ * "dominant pattern") -- 0 otherwise; uploads A if needed */
+LIS_INT lis_amd_matrix_dominant_pattern(LIS_MATRIX A);
 /* ELL and DIA matrices with constant coefficients are kept in HBM as CSR rows that list the format's terms in the format's order
  * (bit-identical sums), so that the value records apply.  0 keeps the native ELL / DIA layout and kernels for matrices uploaded
  * from now on (env LIS_AMD_NO_ROW_FORM=1): A/B measurements, and the tests that pin the native kernels at full size. */

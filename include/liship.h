@@ -103,6 +103,15 @@ int  liship_csr_plan_pattern_records(liship_csr_plan_t plan);
  * (stream the values). */
 int  liship_csr_plan_encode_row_values(liship_csr_plan_t plan, const int *ptr, const double *value, void *stream);
 int  liship_csr_plan_value_records(liship_csr_plan_t plan);
+/* Dominant pattern (found with the value records, nothing to call): when ONE pattern carries at least half of the rows -- the interior
+ * row of a stencil: 98.8 % of the rows at 512^3 -- the plan names it, and keeps for every other pattern which of ITS slots that pattern
+ * has and the pattern's values there (a boundary row is the interior row minus the neighbours that do not exist: a subsequence).  The
+ * products then take the dominant pattern's offsets and values as kernel ARGUMENTS and issue its x gathers together with the load of
+ * the pattern bytes -- one round trip per wavefront, no records in LDS, no barrier; wavefronts that meet another pattern fetch its 64 B
+ * slot record by scalar loads, rows whose pattern is no subsequence (ghost columns of a partitioned matrix) or whose speculative
+ * addresses would leave x take their own records row by row.  Same products in the same order: bit-identical.
+ * liship_csr_plan_dominant_pattern: 1 if the plan has one. */
+int  liship_csr_plan_dominant_pattern(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_row_values(int on);
 int  liship_spmv_csr_set_row_patterns(int on);
 int  liship_spmv_csr_set_index_codes(int on);

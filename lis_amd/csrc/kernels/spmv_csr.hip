@@ -58,6 +58,9 @@ constexpr int SLACK = 128;       // extra items a block may take to start on an 
 //   bit10 register staging instead of LDS-DMA   bits11-12 gather unroll U: 0 auto, 1: 4, 2: 7, 3: 8
 //   bit13 (0x2000) row patterns through the general kernel (table in LDS) even when the plan has 32 B records
 //   bit14 (0x4000) value records: the two-rows-per-lane kernel whatever the size (tests; by default only beyond 256 MB of x)
+//   bit29 (0x20000000) value records: never the dominant-pattern kernels (the round-2 kernels: A/B, tests); bit28 (0x10000000): the
+//         dominant-pattern kernels in their plain form (product: contiguous chunks round-robin; fused dots: two rows per lane);
+//         bits 3 / 9 / 15: tiles of 32 / 64 / 128 / 256 columns for the plain product (default 128), bit3 in the fused-dot form: w by its own loads
 int g_variant = 0;
 int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps every product on the 4 B indices
 int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
@@ -1237,6 +1240,398 @@ void spmv_csr_valuerec_pair_kernel(const unsigned char *__restrict__ rowpat, con
     }
 }
 
+// Value records, the dominant pattern speculated (round 3).  The kernels above are a chain of dependent round trips per workgroup
+// -- records -> LDS, pattern byte -> barrier -> record -> x -> y -- and the counters say that chain, not bytes, is what a product
+// costs (profiles/r02_valuerec_kernel_pmc.txt: with six of seven gathers removed the time does not move).  But nearly every row of
+// a structured matrix carries ONE pattern -- the interior row: 98.8 % of the rows at 512^3 -- and the other patterns of a stencil are
+// SUBSEQUENCES of it (a boundary row is the interior row minus the neighbours that do not exist).  So the plan names the dominant
+// pattern D (a histogram of the pattern bytes), hands its seven byte offsets and values to the kernel as ARGUMENTS (scalar
+// registers: no load, no LDS, no barrier), and a lane issues the x gathers of D for its rows at once, together with the load of
+// its pattern bytes: ONE round trip.  When the bytes arrive, a wavefront whose rows all carry D (most) multiplies by the scalar
+// values and stores.  Otherwise the lanes with another pattern p take p's DOMINANT-SLOT record from a 64 B-per-pattern table --
+// which of D's seven slots p has (mask) and p's values in those slots -- by scalar loads, one per distinct pattern among the
+// wavefront's lanes (a waterfall over readlane; the table is 1.7 KB and lives in the scalar cache), and add the slots they have in
+// D's order, which is their own order: same products, same order, bit-identical.  A pattern that is not a subsequence of D (mask
+// bit 7: the ghost-column rows of a partitioned matrix) and the wavefronts whose speculative addresses would leave x (the first and
+// last |max offset| rows) take their rows one by one with their own records, as the kernels above do.
+typedef double v8f64 __attribute__((ext_vector_type(8)));
+struct DomTile { int S, cshift, ntiled, nfull; };       // spmv_csr_valuerec_dom_kernel: tiled lane -> row mapping (S = 0: none)
+struct DomRec { int off[7]; int pat; double val[7]; int mask, pad; };     // byte offsets and values of the dominant pattern, its pattern byte, its slots (length)
+
+// slots of D that pattern `pt` (uniform) has, and its values there: 8 doubles per pattern, [0] = the mask in the low word
+__device__ __forceinline__ void dom_waterfall(const double *__restrict__ drec, const DomRec &D, int pt, bool valid, double (&v)[7], unsigned &m)
+{
+#pragma unroll
+    for (int u = 0; u < 7; u++) v[u] = D.val[u];
+    m = (unsigned)D.mask;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid && pt != D.pat);
+    while (todo != 0) {                                   // (uniform) one scalar record load per distinct pattern among the lanes
+        const int l = __builtin_ctzll(todo);
+        const int q = __builtin_amdgcn_readlane(pt, l);
+        const v8f64 R = *reinterpret_cast<const v8f64 *>(drec + 8 * q);      // (uniform address: one s_load_dwordx16)
+        const bool me = valid && pt == q;
+        m = me ? (unsigned)__double2loint(R[0]) : m;
+#pragma unroll
+        for (int u = 0; u < 7; u++) v[u] = me ? R[1 + u] : v[u];
+        todo &= ~__builtin_amdgcn_ballot_w64(me);
+    }
+}
+
+// one row by its own record (96 B, global): the kernels above, without LDS
+__device__ __forceinline__ double own_record_row(const v4i32 *__restrict__ rec, int pt, int r, const double *__restrict__ x, double acc0)
+{
+    const v4i32 a = rec[6 * pt], b = rec[6 * pt + 1];
+    const v2f64 *q = reinterpret_cast<const v2f64 *>(rec + 6 * pt + 2);
+    const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const int o[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z}, len = b.w;
+    const double v[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
+    double xv[7], acc = acc0;
+#pragma unroll
+    for (int u = 0; u < 7; u++) xv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned)r * 8u + (unsigned)o[u]));
+#pragma unroll
+    for (int u = 0; u < 7; u++) { const double t = v[u] * xv[u]; acc += (u < len) ? t : -0.0; }
+    return acc;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, const double *__restrict__ drec,
+                                  const DomRec D, int safe_lo, int safe_hi,
+                                  const double *__restrict__ x, double *__restrict__ y, Rows RW, int run, const DomTile TL)
+{
+    const double acc0 = RW.acc0;
+    const int tid = (int)threadIdx.x;
+    const int wbase = tid & ~(WAVE - 1);
+    // workgroup -> chunk of rows.  Workgroups go round-robin over the 8 XCDs; with run > 1 each XCD walks runs of `run` consecutive
+    // chunks, so that the x lines neighbouring chunks share (the +-n neighbours of a grid line) are fetched by ONE L2
+    int chunk = (int)blockIdx.x;
+    if (run > 1) { const int xcd = chunk % NUM_XCD, slot = chunk / NUM_XCD; chunk = ((slot / run) * NUM_XCD + xcd) * run + slot % run; }
+    {
+        int rw, ra;                                                   // the wavefront's lowest row, the lane's first row
+        bool safe;                                                    // (uniform) speculation is safe: every address r*8 + offset of the wavefront's rows (16 B loads: one more) lies inside x[0, n)
+        if (TL.S > 0 && chunk < TL.ntiled) {
+            // TILED rows: the workgroup's 256 lane pairs cover T = 256 >> cshift lines of 2 << cshift columns each, the lines S rows apart
+            // (S: the stride of the pattern's middle offsets, +-n of a 3-D stencil) -- a wavefront then gathers its rows' +-S neighbours from
+            // lines its OWN diagonal gathers fetch (L1 hits instead of L2 requests), and the tile's halo is two lines for T instead of two per line
+            const int wpg = TL.S >> (TL.cshift + 1);                   // workgroups per group of T lines
+            const int g = chunk / wpg, cb = chunk - g * wpg;
+            const int T = (BLOCK >> TL.cshift);
+            const int base = RW.rb + g * T * TL.S + (cb << (TL.cshift + 1));
+            const int t = tid >> TL.cshift, cp = tid & ((1 << TL.cshift) - 1);
+            ra = base + t * TL.S + 2 * cp;
+            const int t0 = wbase >> TL.cshift, t1 = (wbase + WAVE - 1) >> TL.cshift;
+            rw = base + t0 * TL.S;
+            safe = rw >= safe_lo && base + t1 * TL.S + (2 << TL.cshift) + 2 <= safe_hi;
+        } else {
+            const long long c0w = (long long)RW.rb + (TL.S > 0 ? TL.nfull : 0) + (long long)(chunk - (TL.S > 0 ? TL.ntiled : 0)) * (2 * BLOCK) + 2 * wbase;
+            if (c0w >= RW.re) return;                                 // (uniform)
+            rw = (int)c0w;
+            ra = rw + 2 * (tid - wbase);
+            safe = rw >= safe_lo && rw + 2 * WAVE <= safe_hi && rw + 2 * WAVE <= RW.re;
+        }
+        if (safe) {
+            unsigned two;
+            if ((RW.rb & 1) == 0) two = *reinterpret_cast<const unsigned short *>(rowpat + ra);
+            else two = (unsigned)rowpat[ra] | ((unsigned)rowpat[ra + 1] << 8);
+            const unsigned rb8 = (unsigned)ra * 8u;
+            v2f64 xx[7];
+#pragma unroll
+            for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
+            const int pa = (int)(two & 255u), pb = (int)(two >> 8);
+            double s0 = acc0, s1 = acc0;
+            if (__builtin_amdgcn_ballot_w64(pa != D.pat || pb != D.pat) == 0) {      // (uniform) every row here is the dominant pattern
+                if (D.mask == 0x7f) {
+#pragma unroll
+                    for (int u = 0; u < 7; u++) { s0 += D.val[u] * xx[u].x; s1 += D.val[u] * xx[u].y; }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 7; u++) {
+                        const double t0 = D.val[u] * xx[u].x, t1 = D.val[u] * xx[u].y;
+                        s0 += ((D.mask >> u) & 1) ? t0 : -0.0;
+                        s1 += ((D.mask >> u) & 1) ? t1 : -0.0;
+                    }
+                }
+            } else {
+                double v[7];
+                unsigned m;
+                dom_waterfall(drec, D, pa, true, v, m);
+                if (m & 0x80u) s0 = own_record_row(rec, pa, ra, x, acc0);
+                else {
+#pragma unroll
+                    for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].x; s0 += ((m >> u) & 1u) ? t : -0.0; }    // -0.0 terms leave any sum bit-unchanged
+                }
+                dom_waterfall(drec, D, pb, true, v, m);
+                if (m & 0x80u) s1 = own_record_row(rec, pb, ra + 1, x, acc0);
+                else {
+#pragma unroll
+                    for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].y; s1 += ((m >> u) & 1u) ? t : -0.0; }
+                }
+            }
+            v2f64 out; out.x = s0; out.y = s1;
+            if ((RW.rb & 1) == 0) store_stream(reinterpret_cast<v2f64 *>(y + ra), out);
+            else { store_stream(y + ra, s0); store_stream(y + ra + 1, s1); }
+        } else {                                                      // the matrix's first and last rows, a launch's tail: row by row
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+                const int r = ra + w;
+                if (r < RW.re) store_stream(y + r, own_record_row(rec, (int)rowpat[r], r, x, acc0));
+            }
+        }
+    }
+}
+
+// The same with the fused dots.  Partial slots and the order of every addition are those of spmv_csr_valuerec_pair_dot_kernel
+// (below: two row blocks per workgroup, virtual lanes 2p and 2p + 1 in two accumulators, the one-row kernels' tree walked on
+// them), so the dots are the same bits; what changes is the chain in front: block extents (one scalar load) -> pattern bytes, w
+// and the dominant pattern's gathers together -> sums, instead of extents + records -> barrier -> pattern bytes -> records -> x.
+template <int BLOCK, int DOT>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_valuerec_dom_dot_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, const double *__restrict__ drec,
+                                      const DomRec D, int safe_lo, int safe_hi,
+                                      const double *__restrict__ x, double *__restrict__ y, const v2i32 *__restrict__ blk,
+                                      int bfirst, int nb, Rows RW,
+                                      const double *__restrict__ wdot, double *__restrict__ partial,
+                                      const double *__restrict__ guard, int pstride)
+{
+    static_assert(BLOCK == 256, "two row blocks of 128 lane pairs");
+    const double stop = guard != nullptr ? guard[0] : 0.0;          // device-driven Krylov loop already converged? (a scalar load beside the extents')
+    const double acc0 = RW.acc0;
+    __shared__ double scratch[2][2][4];                   // [block of the workgroup][result][virtual wavefront]
+    const int tid = (int)threadIdx.x;
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 7), p = tid & 127;        // wavefronts 0, 1: the first block; 2, 3: the second
+    const int lb = blockIdx.x * 2 + h;
+    const Blk B = lb < nb ? load_blk(blk, bfirst + lb) : Blk{0, 0, 0, 0};
+    const int r0 = max(B.r0, RW.rb), r1 = min(B.r1, RW.re);
+    if (stop != 0.0) return;                              // (uniform; nothing has been written)
+    double c0[2] = {0.0, 0.0}, c1[2] = {0.0, 0.0};
+    for (int base = r0; base < r1; base += 256) {         // (uniform per wavefront) virtual lane t holds the rows base + t
+        const int rw = base + 2 * (p & ~(WAVE - 1));      // the wavefront's first row
+        const int ra = base + 2 * p;
+        const bool two = ra + 1 < r1, one = ra < r1;
+        // speculation is safe when every address r*8 + offset of the wavefront's 128 rows (16 B loads: one more) lies inside x[0, n)
+        const bool safe = rw >= safe_lo && rw + 2 * WAVE <= safe_hi;          // (uniform)
+        if (safe) {
+            unsigned twob = 0;
+            v2f64 xx[7], ww;
+            ww.x = ww.y = 0.0;
+            if (two) {
+                if ((ra & 1) == 0) { twob = *reinterpret_cast<const unsigned short *>(rowpat + ra); ww = *reinterpret_cast<const v2f64 *>(wdot + ra); }
+                else { twob = (unsigned)rowpat[ra] | ((unsigned)rowpat[ra + 1] << 8); ww.x = wdot[ra]; ww.y = wdot[ra + 1]; }
+                const unsigned rb8 = (unsigned)ra * 8u;
+#pragma unroll
+                for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
+            }
+            const int pa = (int)(twob & 255u), pb = (int)(twob >> 8);
+            double s0 = acc0, s1 = acc0;
+            if (__builtin_amdgcn_ballot_w64(two && (pa != D.pat || pb != D.pat)) == 0) {      // (uniform) every row here is the dominant pattern
+                if (two) {
+                    if (D.mask == 0x7f) {
+#pragma unroll
+                        for (int u = 0; u < 7; u++) { s0 += D.val[u] * xx[u].x; s1 += D.val[u] * xx[u].y; }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 7; u++) {
+                            const double t0 = D.val[u] * xx[u].x, t1 = D.val[u] * xx[u].y;
+                            s0 += ((D.mask >> u) & 1) ? t0 : -0.0;
+                            s1 += ((D.mask >> u) & 1) ? t1 : -0.0;
+                        }
+                    }
+                }
+            } else {
+                double v[7];
+                unsigned m;
+                dom_waterfall(drec, D, pa, two, v, m);
+                if (two) {
+                    if (m & 0x80u) s0 = own_record_row(rec, pa, ra, x, acc0);
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].x; s0 += ((m >> u) & 1u) ? t : -0.0; }    // -0.0 terms leave any sum bit-unchanged
+                    }
+                }
+                dom_waterfall(drec, D, pb, two, v, m);
+                if (two) {
+                    if (m & 0x80u) s1 = own_record_row(rec, pb, ra + 1, x, acc0);
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].y; s1 += ((m >> u) & 1u) ? t : -0.0; }
+                    }
+                }
+            }
+            if (two) {
+                v2f64 out; out.x = s0; out.y = s1;
+                if ((ra & 1) == 0) store_stream(reinterpret_cast<v2f64 *>(y + ra), out);
+                else { store_stream(y + ra, s0); store_stream(y + ra + 1, s1); }
+                c0[0] += ww.x * s0; c0[1] += ww.y * s1;
+                if (DOT >= 2) { c1[0] += s0 * s0; c1[1] += s1 * s1; }
+            } else if (one) {                             // a block's last row without a partner
+                const double acc = own_record_row(rec, (int)rowpat[ra], ra, x, acc0);
+                store_stream(y + ra, acc);
+                c0[0] += wdot[ra] * acc;
+                if (DOT >= 2) c1[0] += acc * acc;
+            }
+        } else {                                          // the matrix's first and last rows: row by row, their own records
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+                const int r = ra + w;
+                if (r < r1) {
+                    const double acc = own_record_row(rec, (int)rowpat[r], r, x, acc0);
+                    store_stream(y + r, acc);
+                    c0[w] += wdot[r] * acc;
+                    if (DOT >= 2) c1[w] += acc * acc;
+                }
+            }
+        }
+    }
+    // the one-row kernels' tree on the virtual lanes (see spmv_csr_valuerec_pair_dot_kernel)
+    const int vw = p >> 5;                                // virtual wavefront of this lane's two virtual lanes
+#pragma unroll
+    for (int res = 0; res < (DOT >= 2 ? 2 : 1); res++) {
+        double e = res ? c1[0] : c0[0], f = res ? c1[1] : c0[1];
+        e += __shfl_xor(e, 16, WAVE); f += __shfl_xor(f, 16, WAVE);
+        e += lane_xor_in_row<8>(e);   f += lane_xor_in_row<8>(f);
+        e += lane_xor_in_row<4>(e);   f += lane_xor_in_row<4>(f);
+        e += lane_xor_in_row<2>(e);   f += lane_xor_in_row<2>(f);
+        e += lane_xor_in_row<1>(e);   f += lane_xor_in_row<1>(f);
+        const double t = e + f;
+        if ((p & 31) == 0) scratch[h][res][vw] = t;
+    }
+    __syncthreads();
+    if (tid < 4) {                                        // thread = (block of the workgroup, result)
+        const int hh = tid >> 1, res = tid & 1, slot = blockIdx.x * 2 + hh, stride = pstride ? pstride : nb;
+        if (slot < nb && (res == 0 || DOT >= 2)) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) t += scratch[hh][res][i];
+            partial[(size_t)res * stride + slot] = t;
+        }
+    }
+}
+
+// The fused dots, FOUR rows per lane: one wavefront per row block, no LDS, no barrier.  Lane q of the wavefront holds the virtual
+// lanes 4q .. 4q + 3 of the block's 256 (rows base + 4q + j) in four accumulators.  The one-row kernels' tree on them: the butterfly
+// steps 32, 16, 8, 4 pair virtual lanes of equal j whose physical lanes are 8, 4, 2, 1 apart -- all inside a row of 16 lanes (DPP
+// moves, no LDS permute) --, the steps 2 and 1 add inside the lane: (e0 + e2) + (e1 + e3); a row of 16 lanes is a virtual wavefront,
+// and lane 0 adds the four rows' totals in order.  Every addition has the operands it has in the one-row kernels, so the partials are
+// the same bits (tests/golden/reduction_bits.json, the forms of test_spmv_csr_index_codes).
+template <int BLOCK, int DOT>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_valuerec_dom_dot4_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, const double *__restrict__ drec,
+                                       const DomRec D, int safe_lo, int safe_hi,
+                                       const double *__restrict__ x, double *__restrict__ y, const v2i32 *__restrict__ blk,
+                                       int bfirst, int nb, Rows RW,
+                                       const double *__restrict__ wdot, double *__restrict__ partial,
+                                       const double *__restrict__ guard, int pstride, int wslot)
+{
+    const double stop = guard != nullptr ? guard[0] : 0.0;          // device-driven Krylov loop already converged? (a scalar load beside the extents')
+    const double acc0 = RW.acc0;
+    const int tid = (int)threadIdx.x, q = tid & (WAVE - 1);
+    // one row block per wavefront (stacking the workgroup's blocks a grid line apart, as the plain product's tiles do, was measured: -2 %)
+    const int lb = (int)blockIdx.x * (BLOCK / WAVE) + __builtin_amdgcn_readfirstlane(tid / WAVE);
+    if (lb >= nb) return;                                 // (uniform per wavefront; no barrier anywhere below)
+    const Blk B = load_blk(blk, bfirst + lb);
+    const int r0 = max(B.r0, RW.rb), r1 = min(B.r1, RW.re);
+    if (stop != 0.0) return;
+    double c0[4] = {0.0, 0.0, 0.0, 0.0}, c1[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int base = r0; base < r1; base += 256) {         // (uniform) virtual lane t holds the rows base + t
+        const int ra = base + 4 * q;
+        const bool four = ra + 3 < r1;
+        const bool safe = base >= safe_lo && base + 4 * WAVE <= safe_hi;          // (uniform) every speculative address stays inside x[0, n)
+        bool done = false;
+        if (safe) {
+            unsigned pats = 0;
+            v2f64 xx[2][7], ww[2];
+            if (four) {
+                if ((ra & 3) == 0) pats = *reinterpret_cast<const unsigned *>(rowpat + ra);
+                else pats = (unsigned)rowpat[ra] | ((unsigned)rowpat[ra + 1] << 8) | ((unsigned)rowpat[ra + 2] << 16) | ((unsigned)rowpat[ra + 3] << 24);
+                if (wslot < 0) {                          // (uniform) w is not x, or the dominant pattern has no diagonal entry
+                    if ((ra & 1) == 0) { ww[0] = *reinterpret_cast<const v2f64 *>(wdot + ra); ww[1] = *reinterpret_cast<const v2f64 *>(wdot + ra + 2); }
+                    else { ww[0].x = wdot[ra]; ww[0].y = wdot[ra + 1]; ww[1].x = wdot[ra + 2]; ww[1].y = wdot[ra + 3]; }
+                }
+                const unsigned rb8 = (unsigned)ra * 8u;
+#pragma unroll
+                for (int u = 0; u < 7; u++) {
+                    xx[0][u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
+                    xx[1][u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + 16u + (unsigned)D.off[u]));
+                }
+#pragma unroll
+                for (int u = 0; u < 7; u++) if (u == wslot) { ww[0] = xx[0][u]; ww[1] = xx[1][u]; }      // w = x (CG's <p, A p>): the diagonal's gather IS w
+            }
+            double sv[4] = {acc0, acc0, acc0, acc0};
+            if (__builtin_amdgcn_ballot_w64(four && pats != (unsigned)D.pat * 0x01010101u) == 0) {      // (uniform) every row here is the dominant pattern
+                if (four) {
+#pragma unroll
+                    for (int u = 0; u < 7; u++) {
+                        const bool on = (D.mask >> u) & 1;            // (uniform; all seven for a full-length pattern)
+                        const double t0 = D.val[u] * xx[0][u].x, t1 = D.val[u] * xx[0][u].y, t2 = D.val[u] * xx[1][u].x, t3 = D.val[u] * xx[1][u].y;
+                        sv[0] += on ? t0 : -0.0; sv[1] += on ? t1 : -0.0; sv[2] += on ? t2 : -0.0; sv[3] += on ? t3 : -0.0;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    double v[7];
+                    unsigned m;
+                    const int pj = (int)((pats >> (8 * j)) & 255u);
+                    dom_waterfall(drec, D, pj, four, v, m);
+                    if (four) {
+                        if (m & 0x80u) sv[j] = own_record_row(rec, pj, ra + j, x, acc0);
+                        else {
+#pragma unroll
+                            for (int u = 0; u < 7; u++) {
+                                const double xv = (j & 1) ? xx[j >> 1][u].y : xx[j >> 1][u].x;
+                                const double t = v[u] * xv;
+                                sv[j] += ((m >> u) & 1u) ? t : -0.0;          // -0.0 terms leave any sum bit-unchanged
+                            }
+                        }
+                    }
+                }
+            }
+            if (four) {
+                v2f64 o0, o1; o0.x = sv[0]; o0.y = sv[1]; o1.x = sv[2]; o1.y = sv[3];
+                if ((ra & 1) == 0) { store_stream(reinterpret_cast<v2f64 *>(y + ra), o0); store_stream(reinterpret_cast<v2f64 *>(y + ra + 2), o1); }
+                else { store_stream(y + ra, sv[0]); store_stream(y + ra + 1, sv[1]); store_stream(y + ra + 2, sv[2]); store_stream(y + ra + 3, sv[3]); }
+                c0[0] += ww[0].x * sv[0]; c0[1] += ww[0].y * sv[1]; c0[2] += ww[1].x * sv[2]; c0[3] += ww[1].y * sv[3];
+                if (DOT >= 2) { c1[0] += sv[0] * sv[0]; c1[1] += sv[1] * sv[1]; c1[2] += sv[2] * sv[2]; c1[3] += sv[3] * sv[3]; }
+                done = true;
+            }
+        }
+        if (!done) {                                      // a block's last rows, the matrix's first and last rows: row by row, their own records
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = ra + j;
+                if (r < r1) {
+                    const double acc = own_record_row(rec, (int)rowpat[r], r, x, acc0);
+                    store_stream(y + r, acc);
+                    c0[j] += wdot[r] * acc;
+                    if (DOT >= 2) c1[j] += acc * acc;
+                }
+            }
+        }
+    }
+    const int stride = pstride ? pstride : nb;
+#pragma unroll
+    for (int res = 0; res < (DOT >= 2 ? 2 : 1); res++) {
+        double e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double t = res ? c1[j] : c0[j];
+            t += lane_xor_in_row<8>(t);
+            t += lane_xor_in_row<4>(t);
+            t += lane_xor_in_row<2>(t);
+            t += lane_xor_in_row<1>(t);
+            e[j] = t;
+        }
+        const double vw = (e[0] + e[2]) + (e[1] + e[3]);          // a virtual wavefront's sum, in every lane of its row of 16
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(vw), 16 * i), hi = __builtin_amdgcn_readlane(__double2hiint(vw), 16 * i);
+            t += __hiloint2double(hi, lo);
+        }
+        if (q == 0) partial[(size_t)res * stride + lb] = t;
+    }
+}
+
 // The fused-dot forms two rows per lane.  The partial of a row block is DEFINED by the one-row kernels: lane t of the block's
 // 256 holds sum_k w*y over its rows r0 + t + 256 k, a wavefront adds its 64 lanes by the butterfly 32, 16, 8, 4, 2, 1, lane 0
 // adds the four wavefronts in order.  Here lane p of a block's 128 holds the "virtual lanes" 2p and 2p + 1 in two accumulators,
@@ -1618,6 +2013,10 @@ struct liship_csr_plan_s {
     v4i32 *ptab8;        // device: when no pattern has more than 7 offsets, one 32 B record per pattern (7 offsets, length); else NULL
     int prep[256];       // a row that carries each pattern
     v4i32 *vrec;         // device: with ptab8, when every row of a pattern carries the same values, 96 B per pattern (the 32 B record + 7 values); else NULL
+    double *drec;        // device: with vrec, when one pattern dominates: per pattern 8 doubles {slots of the dominant pattern it has (mask; bit 7: not a
+                         // subsequence), its values in those slots}; else NULL (spmv_csr_valuerec_dom_kernel)
+    DomRec dom;          // the dominant pattern: byte offsets, values, pattern byte, slots
+    int dom_lo, dom_hi;  // rows [dom_lo, dom_hi - 128] may start a wavefront that gathers x at the dominant offsets without leaving x[0, n)
 };
 
 extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
@@ -1709,6 +2108,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0;
     p->first_term = 0;
     p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
+    p->drec = nullptr; p->dom_lo = p->dom_hi = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -1727,6 +2127,7 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->ptab) (void)hipFree(p->ptab);
     if (p->ptab8) (void)hipFree(p->ptab8);
     if (p->vrec) (void)hipFree(p->vrec);
+    if (p->drec) (void)hipFree(p->drec);
     if (p->order) (void)hipFree(p->order);
     if (p->vrecw) (void)hipFree(p->vrecw);
     if (p->lcol) (void)hipFree(p->lcol);
@@ -1916,6 +2317,62 @@ extern "C" int liship_csr_plan_row_patterns(liship_csr_plan_t p) { return (p && 
 extern "C" int liship_csr_plan_pattern_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8) ? 1 : 0; }
 extern "C" int liship_spmv_csr_set_row_patterns(int on) { g_row_patterns = on ? 1 : 0; return 0; }
 
+// plan time: how many rows carry each pattern byte
+__global__ void rowpat_histogram(int n, const unsigned char *__restrict__ rowpat, unsigned long long *__restrict__ count)
+{
+    __shared__ unsigned int h[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) h[t] = 0;
+    __syncthreads();
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) atomicAdd(&h[rowpat[r]], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) if (h[t]) atomicAdd(&count[t], (unsigned long long)h[t]);
+}
+
+// The dominant pattern of a plan with value records and the other patterns' records in ITS slots (spmv_csr_valuerec_dom_kernel).
+// rec32: 8 ints per pattern (7 byte offsets, the tail repeating the last one; length), val8: 8 doubles per pattern.  Kept when
+// one pattern carries at least half of the rows; never an error when it does not.
+static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, const double *val8)
+{
+    if (p->drec) { (void)hipFree(p->drec); p->drec = nullptr; }
+    if (p->n < 4 * WAVE || npat <= 0 || npat > PAT7_MAX) return;
+    unsigned long long *d_count = nullptr, count[256];
+    if (hipMalloc(&d_count, sizeof(count)) != hipSuccess) return;
+    bool ok = hipMemset(d_count, 0, sizeof(count)) == hipSuccess;
+    if (ok) { rowpat_histogram<<<1024, 256>>>(p->n, p->rowpat, d_count); ok = hipGetLastError() == hipSuccess; }
+    ok = ok && hipMemcpy(count, d_count, sizeof(count), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d_count);
+    if (!ok) return;
+    int dom = 0;
+    for (int i = 1; i < npat; i++) if (count[i] > count[dom]) dom = i;
+    if (2 * count[dom] < (unsigned long long)p->n) return;
+    const int *od = rec32 + 8 * dom;
+    const int lend = od[7];
+    DomRec D;
+    for (int u = 0; u < 7; u++) { D.off[u] = od[u]; D.val[u] = val8[8 * dom + u]; }
+    D.pat = dom; D.mask = (1 << lend) - 1; D.pad = 0;
+    double img[PAT7_MAX * 8];
+    for (int i = 0; i < npat; i++) {
+        const int *oi = rec32 + 8 * i;
+        const int leni = oi[7];
+        unsigned mask = 0;
+        double *out = img + 8 * i;
+        for (int u = 0; u < 8; u++) out[u] = 0.0;
+        int j = 0;
+        for (int sl = 0; sl < lend && j < leni; sl++)
+            if (oi[j] == od[sl]) { mask |= 1u << sl; out[1 + sl] = val8[8 * i + j]; j++; }
+        if (j != leni) mask = 0x80u;                      // not a subsequence of the dominant pattern: its rows take their own records
+        unsigned long long bits = mask;
+        memcpy(out, &bits, 8);
+    }
+    int minoff = 0, maxoff = 0;                           // in elements
+    for (int u = 0; u < lend; u++) { const int e = od[u] / 8; if (e < minoff) minoff = e; if (e > maxoff) maxoff = e; }
+    if (hipMalloc(&p->drec, sizeof(double) * 8 * (size_t)npat) != hipSuccess) { p->drec = nullptr; return; }
+    if (hipMemcpy(p->drec, img, sizeof(double) * 8 * (size_t)npat, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p->drec); p->drec = nullptr; return; }
+    p->dom = D;
+    p->dom_lo = -minoff;
+    p->dom_hi = p->n - maxoff;
+}
+
 // the 96 B records (32 B offsets + length, 64 B values) of npat patterns -> p->vrec
 static int install_value_records(liship_csr_plan_s *p, int npat, const int *rec32, const double *val8)
 {
@@ -1924,6 +2381,7 @@ static int install_value_records(liship_csr_plan_s *p, int npat, const int *rec3
     hipError_t e = hipMalloc(&p->vrec, 96 * (size_t)npat);
     if (e == hipSuccess) e = hipMemcpy(p->vrec, img, 96 * (size_t)npat, hipMemcpyHostToDevice);
     if (e != hipSuccess) { if (p->vrec) (void)hipFree(p->vrec); p->vrec = nullptr; return (int)e; }
+    build_dominant(p, npat, rec32, val8);
     return 0;
 }
 
@@ -2150,6 +2608,8 @@ extern "C" int liship_csr_plan_encode_row_values(liship_csr_plan_t p, const int 
 extern "C" int liship_csr_plan_value_records(liship_csr_plan_t p)
 { return (p && p->rowpat && p->ptab8 && p->vrec) ? 1 : (p && p->rowpat && p->vrecw) ? 2 : 0; }        // 2: the wide records (rows of up to 32 entries)
 extern "C" int liship_spmv_csr_set_row_values(int on) { g_row_values = on ? 1 : 0; return 0; }
+// 1 when the plan also names a dominant pattern (spmv_csr_valuerec_dom_kernel), else 0
+extern "C" int liship_csr_plan_dominant_pattern(liship_csr_plan_t p) { return (p && p->vrec && p->drec) ? 1 : 0; }
 
 // Block-local columns for the products kernel (see spmv_csr_local_kernel): setup-time, optional, never an error when the
 // matrix does not qualify.  Kept when the lists cover >= 90 % of the non-zeros and hold at most half as many columns as
@@ -2233,10 +2693,22 @@ struct LaunchArgs {
     const v4i32 *vrec = nullptr;            // value records (with ptab8), when the plan has them and they are switched on
     const int *order = nullptr;             // launch order of the products kernel (whole-matrix launches of a plan that has one)
     const v4i32 *vrecw = nullptr;           // wide value records (rows of up to 32 entries), when the plan has them and they are switched on
+    const liship_csr_plan_s *plan = nullptr; // (set by the launchers) the dominant-pattern records live there
 };
 
 
 inline int xcd_run() { int c = (g_variant >> 16) & 0xff; return c ? c : 16; }
+
+// the smallest offset distance (in rows) beyond the diagonal's neighbours that the dominant pattern has on BOTH sides: +-n of a 3-D stencil
+static int dom_stride(const DomRec &D)
+{
+    int S = 0;
+    for (int u = 0; u < 7; u++) {
+        const int e = D.off[u] / 8;
+        if (e > 1 && (S == 0 || e < S)) { bool both = false; for (int v = 0; v < 7; v++) both = both || D.off[v] == -8 * e; if (both) S = e; }
+    }
+    return S;
+}
 
 template <int G, int U, bool XRUN, bool DMA, bool NOGATHER>
 void launch_rowgather(int grid, const LaunchArgs &a)
@@ -2283,7 +2755,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     const int usel = (g_variant >> 11) & 3;
     const int U = usel == 1 ? 4 : usel == 2 ? 7 : usel == 3 ? 8 : unroll;
     const bool dma = !(g_variant & 0x400);
-    if (a.codes && (g_variant & ~0xFF00F0) == 0x1 && a.nb >= 4 * NUM_XCD) {   // experiment: XCD-run block order for the coded kernel
+    if (a.codes && !a.vrec && (g_variant & ~0xFF00F0) == 0x1 && a.nb >= 4 * NUM_XCD) {   // experiment: XCD-run block order for the coded kernel
         constexpr Geometry g = kGeom[G];
         const int sp = NUM_XCD * xcd_run(), gr = ((a.nb + sp - 1) / sp) * sp;
         spmv_csr_coded_kernel<g.block, g.work, 7, 0, false, true><<<gr, g.block, 0, a.st>>>(
@@ -2296,12 +2768,43 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
-    if (a.rowpat && a.ptab8 && a.vrec && (g_variant & ~0x4000) == 0) {            // the rows' values ride in the pattern records: one byte per row
+    if (a.rowpat && a.ptab8 && a.vrec && (g_variant & ~0x70ffc209) == 0) {            // the rows' values ride in the pattern records: one byte per row
         constexpr Geometry g = kGeom[G];
         const int chunks = (a.re - a.rb + g.block - 1) / g.block;       // rows [rb, re) in chunks of one workgroup's lanes, two per workgroup
         // beyond the Infinity Cache (256 MB of x) the two-rows-per-lane form wins (16 B requests: 320^3 +4 %, 448^3 +13 %, 512^3 +7 %);
         // below it x stays cache-resident from product to product and the one-row form is 15 % faster (tools/valuerec_probe.py)
         const bool pairs = (g_variant & 0x4000) || (long long)(a.re - a.rb) * 8 > (256ll << 20);
+        // one pattern carries most rows: its gathers are issued together with the pattern bytes (one round trip, no LDS, no barrier)
+        if (chunks > 0 && a.plan && a.plan->drec && !(g_variant & 0x20000000)) {
+            const liship_csr_plan_s *P = a.plan;
+            const long long rows = (long long)a.re - a.rb;
+            // lane -> row mapping.  Default: TILES of 4 lines x 128 columns per workgroup when the pattern has a stride S of middle offsets
+            // (+-n of a 3-D stencil) that 128 divides -- the four wavefronts' +-S gathers then hit lines their neighbours' diagonal gathers bring
+            // into the same L1: 512^3 0.58 -> 0.49 ms --; otherwise contiguous 512-row chunks, each XCD walking runs of 8 of them (one L2 serves
+            // the chunks' shared x lines: 0.58 -> 0.535 ms).  Experiment knobs: bit28 plain chunks round-robin; bits 3 / 9 / 15 select tiles of
+            // 32 / 64 / 128 / 256 columns; bit0 + bits16-23 the run length.  (Measured and dropped: four rows per lane, 512 / 1024 lanes per
+            // workgroup, kernarg preload of the arguments: profiles/r03_valuerec_dom_experiments.txt.)
+            const bool plain = (g_variant & 0x10000000) != 0;
+            int tsel = ((g_variant >> 3) & 1) | (((g_variant >> 9) & 1) << 1) | (((g_variant >> 15) & 1) << 2);
+            if (!tsel && !plain && !(g_variant & 1)) tsel = 3;
+            DomTile TL{0, 0, 0, 0};
+            long long wgs = (rows + 511) / 512;
+            if (tsel) {
+                const int S = dom_stride(P->dom);
+                const int cshift = 3 + tsel;                      // pairs per tile line: 16, 32, 64, 128
+                const int C = 2 << cshift, T = 256 >> cshift;
+                if (S >= C && S % C == 0 && rows >= (long long)T * S) {
+                    const long long groups = rows / ((long long)T * S);
+                    TL.S = S; TL.cshift = cshift; TL.ntiled = (int)(groups * (S / C)); TL.nfull = (int)(groups * T * S);
+                    wgs = TL.ntiled + (rows - TL.nfull + 511) / 512;
+                }
+            }
+            const int run = (g_variant & 1) ? xcd_run() : (plain || TL.S || wgs < 8 * NUM_XCD) ? 1 : 8;
+            const int span = NUM_XCD * run;
+            spmv_csr_valuerec_dom_kernel<256><<<(unsigned)((wgs + span - 1) / span * span), 256, 0, a.st>>>(
+                a.rowpat, a.vrec, P->drec, P->dom, P->dom_lo, P->dom_hi, a.x, a.y, Rows{a.rb, a.re, a.acc0}, run, TL);
+            return;
+        }
         if (chunks > 0 && pairs)
             spmv_csr_valuerec_pair_kernel<g.block, 1><<<(chunks + 1) / 2, g.block, 0, a.st>>>(a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0});
         else if (chunks > 0)
@@ -2349,6 +2852,22 @@ template <int G, int DOT>
 void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
+    if (a.rowpat && a.ptab8 && a.vrec && a.plan && a.plan->drec && !(g_variant & 0x20002000) && g.block == 256) {    // the dominant pattern speculated (see launch_geom)
+        const liship_csr_plan_s *P = a.plan;
+        if (!(g_variant & 0x10000000)) {                  // four rows per lane, a wavefront per row block (default); bit28: two rows per lane
+            int wslot = -1;
+            if (w == a.x && !(g_variant & 0x8))            // (bit3: w by its own loads, A/B)
+                for (int u = 0; u < 7; u++) if (((P->dom.mask >> u) & 1) && P->dom.off[u] == 0) wslot = u;
+            spmv_csr_valuerec_dom_dot4_kernel<256, DOT><<<(a.nb + 3) / 4, 256, 0, a.st>>>(
+                a.rowpat, a.vrec, P->drec, P->dom, P->dom_lo, P->dom_hi, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
+                w, partial, liship_internal_guard(), pstride, wslot);
+            return;
+        }
+        spmv_csr_valuerec_dom_dot_kernel<256, DOT><<<(a.nb + 1) / 2, 256, 0, a.st>>>(
+            a.rowpat, a.vrec, P->drec, P->dom, P->dom_lo, P->dom_hi, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
+            w, partial, liship_internal_guard(), pstride);
+        return;
+    }
     if (a.rowpat && a.ptab8 && a.vrec && !(g_variant & 0x2000) && g.block == 256 &&
         ((g_variant & 0x4000) || (long long)(a.re - a.rb) * 8 > (256ll << 20))) {          // two rows per lane beyond the Infinity Cache (see launch_geom)
         spmv_csr_valuerec_pair_dot_kernel<256, DOT><<<(a.nb + 1) / 2, 256, 0, a.st>>>(
@@ -2412,9 +2931,11 @@ void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double
             <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, 16, w, partial, liship_internal_guard(), pstride, a.order);
 }
 
-int launch_csr(liship_csr_plan_t p, const LaunchArgs &a)
+int launch_csr(liship_csr_plan_t p, const LaunchArgs &a0)
 {
-    if (a.nb <= 0) return 0;
+    if (a0.nb <= 0) return 0;
+    LaunchArgs a = a0;
+    a.plan = p;
     switch (p->geom) {
         case 0: launch_geom<0>(a, p->unroll, p->products != 0, p->batch); break;
         case 1: launch_geom<1>(a, p->unroll, p->products != 0, p->batch); break;
@@ -2449,9 +2970,10 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
 {
     if (!p || !w || !result || !work) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
-    if ((g_variant & ~0x6000) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    if ((g_variant & ~0x70006008) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
     LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order, g_row_values ? p->vrecw : nullptr};
+    a.plan = p;
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);
@@ -2492,7 +3014,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
 {
     if (!p || !w || !work || !slots_used || row_begin < 0 || row_end > p->n || slot_base < 0) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
-    if ((g_variant & ~0x6000) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    if ((g_variant & ~0x70006008) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     *slots_used = 0;
     if (row_begin >= row_end || p->nblocks == 0) return 0;
     const v2i32 *br = p->blk_host;
@@ -2506,6 +3028,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if ((size_t)slot_base + (size_t)nb > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work) + slot_base;
     LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, nullptr, g_row_values ? p->vrecw : nullptr};
+    a.plan = p;
     const int ps = (int)slots;
     if (p->products && p->geom == LOCAL_GEOM) {
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial, ps);

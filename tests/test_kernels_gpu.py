@@ -294,6 +294,7 @@ CODED_CASES = {
     "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
     "p3d_40_sorted": (lambda: orc.poisson3d(40, 40, 40, sort_cols=True), 7),                # several row blocks
     "p3d_odd_33x7x5": (lambda: orc.poisson3d(33, 7, 5), 7),                                 # odd number of columns
+    "p3d_5x6x256": (lambda: orc.poisson3d(5, 6, 256), 7),                                   # grid lines of 256 rows: the tiled lane -> row mapping, with a tail
     "band_neighbours": (lambda: banded(9000, [-3, -2, -1, 0, 1, 2, 700, 701, -4000], 6), 9),
     "diagonals_255": (lambda: cyclic_diagonals(6000, 255, 2), 255),
     "diagonals_300": (lambda: cyclic_diagonals(6000, 300, 3), 0),                           # too many diagonals
@@ -303,6 +304,12 @@ CODED_CASES = {
     "single_row": (lambda: orc.random_csr(1, 5, seed=5, ncols=64, empty_rows=False), None),
     "wide_77": (lambda: orc.random_csr(4000, 77, seed=3, ncols=4000, empty_rows=False), 0),     # products kernel: never coded
 }
+
+
+# liship_spmv_csr_set_variant bits that select the value-record kernels by hand: 3 the general pattern kernel, 4 the round-2 kernels by
+# size, 5 their two-rows-per-lane form, 6 the dominant-pattern kernels in plain form (contiguous chunks; fused dots two rows per lane),
+# 7 the default (tiles where the pattern has a stride that 128 divides; fused dots four rows per lane)
+VARIANT_OF_FORM = {3: 0x2000, 4: 0x20000000, 5: 0x20004000, 6: 0x10000000, 7: 0}
 
 
 @pytest.mark.parametrize("name", list(CODED_CASES))
@@ -338,11 +345,11 @@ def test_spmv_csr_index_codes(lib, name):
         assert lib.liship_csr_plan_value_records(plan) == VALUE_RECORDS[name]
     assert lib.liship_csr_plan_value_records(plan) in (0, 2) or lib.liship_csr_plan_pattern_records(plan) == 1     # 2: the wide records
     results = {}
-    for on in (5, 4, 3, 2, 1, 0):              # 4: values in the pattern records too (nothing streamed; 5: the plain product two rows per
-        lib.liship_spmv_csr_set_index_codes(1 if on else 0)         # lane, the form for x beyond the Infinity Cache), 2: one byte per row
-        lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)   # (patterns; 3: through the general pattern kernel even when the plan has
-        lib.liship_spmv_csr_set_row_values(1 if on >= 4 else 0)     # 32 B records), 1: one byte per non-zero (codes), 0: 4 B indices
-        lib.liship_spmv_csr_set_variant(0x2000 if on == 3 else 0x4000 if on == 5 else 0)
+    for on in (7, 6, 5, 4, 3, 2, 1, 0):        # 4: values in the pattern records too (nothing streamed; 5: the plain product two rows per
+        lib.liship_spmv_csr_set_index_codes(1 if on else 0)         # lane, the form for x beyond the Infinity Cache; 6, 7: the dominant pattern's
+        lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)   # gathers speculated, two / four rows per lane), 2: one byte per row (patterns;
+        lib.liship_spmv_csr_set_row_values(1 if on >= 4 else 0)     # 3: through the general pattern kernel even when the plan has 32 B records),
+        lib.liship_spmv_csr_set_variant(VARIANT_OF_FORM.get(on, 0))  # 1: one byte per non-zero (codes), 0: 4 B indices
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
         assert np.array_equal(dy.to_host(), yref), on
@@ -385,9 +392,41 @@ def test_spmv_csr_index_codes(lib, name):
     lib.liship_spmv_csr_set_variant(0)
     lib.liship_spmv_csr_set_row_values(1)
     check(lib.liship_csr_plan_destroy(plan))
-    assert len({len(results[k]) for k in range(6)}) == 1
-    for parts in zip(*(results[k] for k in range(6))):     # same partial sums, same fold: the reductions agree to the bit too
+    assert len({len(results[k]) for k in range(8)}) == 1
+    for parts in zip(*(results[k] for k in range(8))):     # same partial sums, same fold: the reductions agree to the bit too
         assert all(np.array_equal(parts[0], q) for q in parts[1:])
+
+
+@pytest.mark.parametrize("grid", [(5, 6, 256), (3, 5, 512), (9, 4, 128)])
+def test_valuerec_dominant_pattern_tiles_and_runs(lib, grid):
+    """the dominant-pattern product under every lane -> row mapping it has -- contiguous chunks, XCD runs of chunks, tiles of 32 / 64 / 128 /
+    256 columns -- on grids whose lines the tile widths divide, whole and in row ranges that start on odd rows: the oracle's bits each time
+    (a permutation of who computes which row cannot change a row's sum, but an off-by-one in the tile arithmetic would)"""
+    ptr, idx, val = orc.poisson3d(*grid)
+    n = len(ptr) - 1
+    x = np.random.default_rng(7).uniform(-1, 1, n)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval, dx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    assert lib.liship_csr_plan_value_records(plan) == 1
+    try:
+        for variant in (0, 0x10000000, 0x10000008, 0x10000200, 0x10000208, 0x10008000, 0x10020001, 0x10080001, 0x10080209, 0x20000000):
+            lib.liship_spmv_csr_set_variant(variant)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host(), yref), hex(variant)
+            lo, hi = n // 5 | 1, (n - n // 7) | 1           # odd cuts: the 16 B pieces of y and the pattern bytes' pairs lose their alignment
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            for a, b in ((lo, hi), (0, lo), (hi, n)):
+                check(lib.liship_spmv_csr_rows_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host(), yref), ("rows", hex(variant))
+    finally:
+        lib.liship_spmv_csr_set_variant(0)
+        check(lib.liship_csr_plan_destroy(plan))
 
 
 def stack_rows(parts):
@@ -1064,7 +1103,8 @@ def test_full_size_512_properties(lib):
 
 def test_full_size_512_six_forms_bit_equal(lib):
     """BASELINE's full size with a NON-TRIVIAL x through every form of the CSR product the plan can choose -- 4 B indices,
-    one-byte column codes, row patterns (general kernel and the 32 B-record kernel), value records one and two rows per lane:
+    one-byte column codes, row patterns (general kernel and the 32 B-record kernel), value records one and two rows per lane and with
+    the dominant pattern's gathers speculated (two and four rows per lane):
     nrm1(y_form - y_4B) == 0 at 512^3, and the fused <x, A x>, ||A x||^2 of every form are the same bits.  The 4 B form is the
     contract kernel (lis_matvec_csr.c:97-109 restated), itself bit-compared with the oracle at the sizes the oracle finishes."""
     N = 512
@@ -1091,11 +1131,11 @@ def test_full_size_512_six_forms_bit_equal(lib):
         lib.liship_spmv_csr_set_index_codes(1 if on else 0)
         lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)
         lib.liship_spmv_csr_set_row_values(1 if on >= 4 else 0)
-        lib.liship_spmv_csr_set_variant(0x2000 if on == 3 else 0x4000 if on == 5 else 0)
+        lib.liship_spmv_csr_set_variant(VARIANT_OF_FORM.get(on, 0))
 
     dots = {}
     try:
-        for on in (0, 1, 2, 3, 4, 5):
+        for on in (0, 1, 2, 3, 4, 5, 6, 7):
             select(on)
             dst = y0 if on == 0 else y
             check(lib.liship_memset(dst.ptr, 0xff, 8 * n, None))
@@ -1118,7 +1158,7 @@ def test_full_size_512_six_forms_bit_equal(lib):
     assert res.to_host()[0] > 1e6 and dots[0][0] > 0.0
     # the forms that share a row-block geometry share their partial sums (coded plans rebuild the split at 256 / 2048, the 4 B form keeps
     # the 192 / 1408 one of the bare plan only when no codes exist -- here every form runs on the coded plan's blocks)
-    for on in (1, 2, 3, 4, 5):
+    for on in (1, 2, 3, 4, 5, 6, 7):
         assert np.array_equal(dots[on], dots[0]), (on, dots[on], dots[0])
     check(lib.liship_csr_plan_destroy(plan))
 
@@ -1240,7 +1280,7 @@ def test_plan_coders_on_random_structured_matrices(lib, seed):
     assert (state[3] == 1) <= state[2] <= (1 if state[1] else 0) <= (1 if state[0] else 0) and (state[3] != 2 or (state[1] and not state[2])), state
     dots = []
     try:
-        for codes, pats, vals_on, variant in ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0x2000), (1, 1, 0, 0), (1, 1, 1, 0), (1, 1, 1, 0x4000)):
+        for codes, pats, vals_on, variant in ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0x2000), (1, 1, 0, 0), (1, 1, 1, 0x20000000), (1, 1, 1, 0x20004000), (1, 1, 1, 0x10000000), (1, 1, 1, 0)):
             lib.liship_spmv_csr_set_index_codes(codes)
             lib.liship_spmv_csr_set_row_patterns(pats)
             lib.liship_spmv_csr_set_row_values(vals_on)

@@ -1,0 +1,62 @@
+"""Value-record kernels A/B at N^3 Poisson (round 3: the dominant-pattern kernel): python tools/dom_probe.py [N] [reps]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lis_amd  # noqa: E402
+from lis_amd import DeviceArray as DA, check  # noqa: E402
+from spmv_sweep import timed  # noqa: E402
+
+lib = lis_amd.load()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+n = N ** 3
+nnz = lib.liship_poisson3d_nnz(N, N, N, 0, n)
+dptr, didx, dval = DA(n + 1, np.int32), DA(nnz, np.int32), DA(nnz, np.float64)
+x, y, y2 = DA(n, np.float64), DA(n, np.float64), DA(n, np.float64)
+check(lib.liship_poisson3d_csr(N, N, N, 0, n, 0, dptr.ptr, didx.ptr, dval.ptr, None))
+chunk = 1 << 24
+for s in range(0, n, chunk):
+    part = np.modf(np.arange(s, min(n, s + chunk), dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+    check(lib.liship_memcpy_h2d(x.ptr + 8 * s, part.ctypes.data, part.nbytes, None))
+    check(lib.liship_device_synchronize())
+plan = C.c_void_p()
+check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+print("row patterns:", lib.liship_csr_plan_row_patterns(plan), "value records:", lib.liship_csr_plan_value_records(plan), flush=True)
+FORMS = {"one row/lane": 0x20000000, "two rows/lane": 0x20004000, "dominant plain": 0x10000000, "dominant run8": 0x10080001,
+         "tile 32": 0x10000008, "tile 64": 0x10000200, "tile 128": 0x10000208, "tile 256": 0x10008000, "default": 0}
+if os.environ.get("DOM_FORMS"):
+    FORMS = {k: v for k, v in FORMS.items() if k in os.environ["DOM_FORMS"].split(",")}
+lib.liship_spmv_csr_set_row_values(0)
+check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y2.ptr, None))
+ms = timed(lib, lambda: check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y2.ptr, None)), iters=30, warm=300)
+print(f"{'values streamed':16s} {ms:.4f} ms  {2e-6 * nnz / ms:.1f} GFLOP/s", flush=True)
+lib.liship_spmv_csr_set_row_values(1)
+ref = y2.to_host().view(np.uint64)
+for rep in range(reps):
+    for name, var in FORMS.items():
+        lib.liship_spmv_csr_set_variant(var)
+        check(lib.liship_memset(y.ptr, 0xff, 8 * n, None))
+        ms = timed(lib, lambda: check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None)), iters=50, warm=20)
+        same = bool(np.array_equal(y.to_host().view(np.uint64), ref)) if rep == 0 else None
+        print(f"{name:16s} {ms:.4f} ms  {2e-6 * nnz / ms:.1f} GFLOP/s  {17e-9 * n / ms * 1e3 / 8000:.3f} of 8 TB/s on 17 B/row" + ("" if same is None else f"  bit-identical: {same}"), flush=True)
+# the fused-dot forms (what the Krylov loops run): y = A x with <x, y> and ||y||^2 in the product's pass
+work, res = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
+first = None
+for rep in range(reps):
+    for name, var in (("round-2 dot", 0x20000000), ("dominant dot x2", 0x10000000), ("dom dot x4 own w", 0x8), ("dom dot x4", 0)):
+        lib.liship_spmv_csr_set_variant(var)
+        call = lambda: check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, x.ptr, 1, res.ptr, work.ptr, None))
+        ms = timed(lib, call, iters=50, warm=20)
+        got = res.to_host().copy()
+        if first is None:
+            first = got
+        same = bool(np.array_equal(y.to_host().view(np.uint64), ref)) if rep == 0 else None
+        print(f"{name:16s} {ms:.4f} ms  {2e-6 * nnz / ms:.1f} GFLOP/s  {25e-9 * n / ms * 1e3 / 8000:.3f} of 8 TB/s on 25 B/row  sums equal: {bool(np.array_equal(got, first))}" + ("" if same is None else f"  y bit-identical: {same}"), flush=True)
+lib.liship_spmv_csr_set_variant(0)

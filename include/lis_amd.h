@@ -5,10 +5,16 @@
  * (test/spmvtest1.c:215, src/solver/lis_solver_gmres.c:203).  The kernels run on HBM copies.  Two
  * residency policies decide who is authoritative:
  *
- *   LIS_AMD_COHERENT (default)  every public call treats the HOST arrays of its inputs as the truth
- *       (uploads them) and leaves its outputs valid on the host (downloads them).  Any program written
- *       for Lis works unchanged; stand-alone lis_matvec / lis_vector_* calls pay PCIe transfers.
- *       lis_solve() uploads b (and x) once, iterates entirely in HBM and downloads x once.
+ *   LIS_AMD_COHERENT (default)  any program written for Lis works unchanged: what it reads from v->value[] is what the last call
+ *       left there, what it writes there is what the next call uses.  Vectors are always library-allocated (lis_vector_create /
+ *       lis_vector_duplicate), so value[] lives on pages of its own whose PROTECTION follows the HBM copy (lis_pages.c): a kernel that
+ *       writes a vector leaves its pages inaccessible and copies nothing; the first host access faults, the handler brings the vector
+ *       home; a host WRITE to a vector both sides agree on faults once and marks the HBM copy stale.  Call sequences that stay inside
+ *       the API therefore run at the speed of LIS_AMD_RESIDENT, and only the vectors a program really touches cross PCIe.
+ *       LIS_AMD_COHERENCE=eager / lis_amd_set_coherence(0) selects the older implementation of the same semantics -- every call
+ *       uploads its inputs and downloads its outputs -- for programs that pass v->value to something a page fault cannot interrupt
+ *       (write(2) and other system calls fail with EFAULT on a protected buffer; another device's DMA).  Matrices keep their rule: the
+ *       host arrays are the truth, the HBM copy is built once, lis_amd_matrix_host_modified() after changing them.
  *   LIS_AMD_RESIDENT            objects live in HBM; validity of each side is tracked by the library.
  *       API writers (lis_vector_set_value(s), set_all ...) and readers (get_value(s), gather) stay
  *       correct; code that pokes v->value[] directly must bracket it with
@@ -28,6 +34,13 @@ extern "C" {
 
 LIS_INT lis_amd_set_residency(LIS_INT mode);
 LIS_INT lis_amd_get_residency(void);
+/* COHERENT by page protection (1, default) or by copies on every call (0); see above */
+LIS_INT lis_amd_set_coherence(LIS_INT lazy);
+/* test / diagnostic hooks: protection of v->value's pages (0 read + write: host holds the data; 1 read-only: both agree; 2 none: the HBM
+ * copy holds it; -1: plain memory), and how many read / write faults the handler has served */
+LIS_INT lis_amd_vector_page_state(LIS_VECTOR v);
+LIS_INT lis_amd_vector_page_protect(LIS_VECTOR v, LIS_INT state);      /* force a protection (tests of the fault handler without a GPU) */
+LIS_INT lis_amd_page_faults(LIS_INT *reads, LIS_INT *writes);
 
 /* How the CG / BiCGSTAB loops run (all three produce identical bits; the choice is for A/B measurements):
  *   DEVICE  scalars live in HBM, iterations are enqueued in batches, one read-back per batch (default)

@@ -57,6 +57,7 @@ int  liship_free_host(void *ptr);
 int  liship_event_create(void **event);
 int  liship_event_destroy(void *event);
 int  liship_event_record(void *event, void *stream);
+int  liship_event_synchronize(void *event);
 int  liship_stream_wait_event(void *stream, void *event);
 int  liship_timer_create(void **timer);
 int  liship_timer_destroy(void *timer);

@@ -44,6 +44,7 @@ _LISHIP = {
     "liship_event_create": (_ci, [_pvp]),
     "liship_event_destroy": (_ci, [_vp]),
     "liship_event_record": (_ci, [_vp, _vp]),
+    "liship_event_synchronize": (_ci, [_vp]),
     "liship_stream_wait_event": (_ci, [_vp, _vp]),
     "liship_timer_create": (_ci, [_pvp]),
     "liship_timer_destroy": (_ci, [_vp]),

@@ -23,11 +23,15 @@ LIS_INT lisd_init_quiet(void)
 	return lisd_init();
 }
 
+/* the HBM copy of a matrix is built where the matrix is made (assemble / convert) once this process has used the GPU at all: the upload and
+ * the plan belong to the conversion, not to the first product a driver times.  RESIDENT, and COHERENT by page protection (whose products
+ * then run at resident speed from the first one on); eager COHERENT keeps building it on first use. */
 void lisd_mat_eager(LIS_MATRIX A)
 {
-	if (lisg.residency == LIS_AMD_RESIDENT && lisg.device_ready && A->status >= LIS_MATRIX_CSR) (void)lisd_mat_ready(A);
+	if ((lisg.residency == LIS_AMD_RESIDENT || lisp_lazy()) && lisg.device_ready && A->status >= LIS_MATRIX_CSR) (void)lisd_mat_ready(A);
 }
 
+static LIS_INT stage_ready(void);
 LIS_INT lisd_init(void)
 {
 	if (lisg.device_ready) return LIS_SUCCESS;
@@ -39,8 +43,10 @@ LIS_INT lisd_init(void)
 		return LIS_ERR_NOT_IMPLEMENTED;
 	}
 	if (lisg.comm_kind != 1) {           /* the RCCL bootstrap already chose the device */
+		/* LIS_AMD_DEVICE, else the launcher's LOCAL_RANK (torchrun, mpirun wrappers: one process per GPU), else device 0 */
 		const char *env = getenv("LIS_AMD_DEVICE");
-		lisg.device = env ? atoi(env) : 0;
+		if (env) lisg.device = atoi(env);
+		else { env = getenv("LOCAL_RANK"); lisg.device = env ? atoi(env) % count : 0; }
 		if (lisg.device < 0 || lisg.device >= count) lisg.device = 0;
 	}
 	HIPCHK(liship_set_device(lisg.device));
@@ -50,6 +56,7 @@ LIS_INT lisd_init(void)
 	HIPCHK(liship_malloc_host((void **)&lisg.host_out, 4 * 64 * sizeof(double)));
 	if (lisg.long_row_tree) HIPCHK(liship_spmv_csr_set_long_row_tree(1));
 	lisg.device_ready = 1;
+	if (lisp_lazy()) (void)stage_ready();      /* the pinned staging buffers of the page-protected vectors: here, not inside a caller's first product */
 	return LIS_SUCCESS;
 }
 
@@ -149,17 +156,88 @@ LIS_INT lisd_vec_reserve(LIS_VECTOR v, size_t doubles)
 	return LIS_SUCCESS;
 }
 
-/* host -> HBM when the host side is the truth (always in COHERENT mode) */
+/* Copies between page-protected host arrays and HBM go through two pinned staging buffers.  Handing the vector's own pages to the runtime
+ * would make it register them with the driver (a pageable copy of this size pins its source), and every later mprotect of registered pages
+ * is an MMU-notifier invalidation inside the kernel driver: measured 30 - 35 ms per 64 MB vector, four times the copy itself.  With the
+ * staging buffers the driver never learns about the pages; the host memcpy overlaps the DMA of the previous piece. */
+#define STAGE_BYTES ((size_t)16 << 20)
+static struct { void *buf[2], *ev[2]; int busy[2]; } stage;
+
+static LIS_INT stage_ready(void)
+{
+	if (stage.buf[0]) return LIS_SUCCESS;
+	for (int k = 0; k < 2; k++) {
+		HIPCHK(liship_malloc_host(&stage.buf[k], STAGE_BYTES));
+		HIPCHK(liship_event_create(&stage.ev[k]));
+	}
+	return LIS_SUCCESS;
+}
+
+/* memcpy by the host threads (one thread moves ~10 GB/s, PCIe 5 takes 50) */
+static void copy_threads(void *dst, const void *src, size_t bytes)
+{
+	const size_t piece = (size_t)1 << 20;
+	const long long pieces = (long long)((bytes + piece - 1) / piece);
+	if (pieces < 4) { memcpy(dst, src, bytes); return; }
+	const int T = lisi_host_threads();
+#pragma omp parallel for num_threads(T) schedule(static)
+	for (long long i = 0; i < pieces; i++) {
+		const size_t off = (size_t)i * piece, len = bytes - off < piece ? bytes - off : piece;
+		memcpy((char *)dst + off, (const char *)src + off, len);
+	}
+}
+
+static LIS_INT staged_h2d(void *dst, const void *src, size_t bytes)
+{
+	LISCHK(stage_ready());
+	int k = 0;
+	for (size_t off = 0; off < bytes; off += STAGE_BYTES, k ^= 1) {
+		const size_t len = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+		if (stage.busy[k]) { HIPCHK(liship_event_synchronize(stage.ev[k])); stage.busy[k] = 0; }
+		copy_threads(stage.buf[k], (const char *)src + off, len);
+		HIPCHK(liship_memcpy_h2d((char *)dst + off, stage.buf[k], len, lisg.stream));
+		HIPCHK(liship_event_record(stage.ev[k], lisg.stream));
+		stage.busy[k] = 1;
+	}
+	return LIS_SUCCESS;
+}
+
+static LIS_INT staged_d2h(void *dst, const void *src, size_t bytes)
+{
+	LISCHK(stage_ready());
+	for (int k = 0; k < 2; k++) if (stage.busy[k]) { HIPCHK(liship_event_synchronize(stage.ev[k])); stage.busy[k] = 0; }
+	size_t issued = 0, landed = 0;
+	int ki = 0, kl = 0;
+	while (landed < bytes) {
+		while (issued < bytes && issued - landed < 2 * STAGE_BYTES) {          /* keep both buffers in flight */
+			const size_t len = bytes - issued < STAGE_BYTES ? bytes - issued : STAGE_BYTES;
+			HIPCHK(liship_memcpy_d2h(stage.buf[ki], (const char *)src + issued, len, lisg.stream));
+			HIPCHK(liship_event_record(stage.ev[ki], lisg.stream));
+			issued += len; ki ^= 1;
+		}
+		const size_t len = bytes - landed < STAGE_BYTES ? bytes - landed : STAGE_BYTES;
+		HIPCHK(liship_event_synchronize(stage.ev[kl]));
+		copy_threads((char *)dst + landed, stage.buf[kl], len);
+		landed += len; kl ^= 1;
+	}
+	return LIS_SUCCESS;
+}
+
+/* host -> HBM when the host side is the truth.  COHERENT with page protection (the default, lis_pages.c): the host array was written
+ * since the last upload exactly when its pages are read + write (dev_valid == 0); eager COHERENT: always (nothing tells) */
 LIS_INT lisd_vec_in(LIS_VECTOR v, double **out)
 {
 	lisd_vec *d = VDEV(v);
 	LISCHK(lisd_vec_reserve(v, vec_len(v)));
-	const int host_is_truth = (lisg.residency == LIS_AMD_COHERENT) ? (d->host_valid || !d->dev_valid) : !d->dev_valid;
+	const int lazy = lisp_lazy() && d->region;
+	const int host_is_truth = (lisg.residency == LIS_AMD_COHERENT && !lazy) ? (d->host_valid || !d->dev_valid) : !d->dev_valid;
 	if (host_is_truth && v->value) {
 		size_t len = d->hlen < d->cap ? d->hlen : d->cap;
-		HIPCHK(liship_memcpy_h2d(d->d, v->value, len * sizeof(double), lisg.stream));
+		if (lazy) LISCHK(staged_h2d(d->d, v->value, len * sizeof(double)));          /* (the array has been read when this returns) */
+		else HIPCHK(liship_memcpy_h2d(d->d, v->value, len * sizeof(double), lisg.stream));
 		d->dev_valid = 1;
 		if (lisg.residency == LIS_AMD_COHERENT) d->host_valid = 1;
+		if (lazy) lisp_protect(v, LISP_RO);        /* both sides agree: a host write from here on faults and marks the HBM copy stale */
 	}
 	*out = d->d;
 	return LIS_SUCCESS;
@@ -177,18 +255,41 @@ LIS_INT lisd_vec_done(LIS_VECTOR v)
 	lisd_vec *d = VDEV(v);
 	d->dev_valid = 1;
 	d->host_valid = 0;
-	if (lisg.residency == LIS_AMD_COHERENT) return lisd_vec_to_host(v);
+	if (lisg.residency == LIS_AMD_COHERENT) {
+		if (lisp_lazy() && d->region) { lisp_protect(v, LISP_NONE); if (lisp_state(v) == LISP_NONE) return LIS_SUCCESS; }   /* the first host access brings it home */
+		return lisd_vec_to_host(v);
+	}
 	return LIS_SUCCESS;
 }
 
 LIS_INT lisd_vec_to_host(LIS_VECTOR v)
 {
 	lisd_vec *d = VDEV(v);
-	if (d->host_valid || !d->dev_valid || !d->d || !v->value) { d->host_valid = 1; return LIS_SUCCESS; }
+	if (d->host_valid || !d->dev_valid || !d->d || !v->value) {
+		d->host_valid = 1;
+		if (lisp_state(v) == LISP_NONE) lisp_protect(v, d->dev_valid ? LISP_RO : LISP_RW);
+		return LIS_SUCCESS;
+	}
 	size_t len = d->hlen < d->cap ? d->hlen : d->cap;
-	HIPCHK(liship_memcpy_d2h(v->value, d->d, len * sizeof(double), lisg.stream));
-	HIPCHK(liship_stream_synchronize(lisg.stream));
+	lisp_protect(v, LISP_RW);
+	if (lisp_lazy() && d->region) LISCHK(staged_d2h(v->value, d->d, len * sizeof(double)));
+	else {
+		HIPCHK(liship_memcpy_d2h(v->value, d->d, len * sizeof(double), lisg.stream));
+		HIPCHK(liship_stream_synchronize(lisg.stream));
+	}
 	d->host_valid = 1;
+	if (lisp_lazy() && d->region) lisp_protect(v, LISP_RO);
+	return LIS_SUCCESS;
+}
+
+/* the library itself is about to write value[] on the host: current data first when `keep`, pages writable, HBM copy stale */
+LIS_INT lisd_vec_host_write(LIS_VECTOR v, int keep)
+{
+	lisd_vec *d = VDEV(v);
+	if (keep && !d->host_valid) LISCHK(lisd_vec_to_host(v));
+	lisp_protect(v, LISP_RW);
+	d->host_valid = 1;
+	d->dev_valid = 0;
 	return LIS_SUCCESS;
 }
 
@@ -200,8 +301,8 @@ void lisd_vec_free(LIS_VECTOR v)
 }
 
 LIS_INT lis_amd_vector_sync_host(LIS_VECTOR v) { return lisd_vec_to_host(v); }
-LIS_INT lis_amd_vector_host_modified(LIS_VECTOR v) { VDEV(v)->host_valid = 1; VDEV(v)->dev_valid = 0; return LIS_SUCCESS; }
-LIS_INT lis_amd_vector_device_modified(LIS_VECTOR v) { VDEV(v)->host_valid = 0; VDEV(v)->dev_valid = 1; return LIS_SUCCESS; }
+LIS_INT lis_amd_vector_host_modified(LIS_VECTOR v) { lisp_protect(v, LISP_RW); VDEV(v)->host_valid = 1; VDEV(v)->dev_valid = 0; return LIS_SUCCESS; }
+LIS_INT lis_amd_vector_device_modified(LIS_VECTOR v) { VDEV(v)->host_valid = 0; VDEV(v)->dev_valid = 1; if (lisp_lazy()) lisp_protect(v, LISP_NONE); return LIS_SUCCESS; }
 LIS_INT lis_amd_vector_device_ptr(LIS_VECTOR v, LIS_SCALAR **dptr) { return lisd_vec_in(v, dptr); }
 
 /* ------------------------------------------------------------------ matrices */

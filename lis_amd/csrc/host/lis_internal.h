@@ -38,6 +38,7 @@ typedef struct {
 	size_t  hlen;       /* doubles allocated on the host (value[]) */
 	int     host_valid; /* value[] holds the current data */
 	int     dev_valid;  /* d[] holds the current data */
+	void   *region;     /* value[] lives on pages of its own whose protection follows the flags above (lis_pages.c); NULL: plain memory */
 } lisd_vec;
 
 typedef struct {
@@ -104,6 +105,7 @@ typedef struct {
 	void *ev_packed, *ev_landed;
 	int long_row_tree;         /* LIS_AMD_LONG_ROW_TREE=1: rows longer than the LDS stage are added by a tree per pass (not bit-parity; opt-in) */
 	int no_value_records;      /* LIS_AMD_NO_VALUE_RECORDS=1: matrices whose rows repeat with their values keep streaming the values (A/B measurements) */
+	int eager_coherence;       /* LIS_AMD_COHERENCE=eager / lis_amd_set_coherence(0): COHERENT copies on every call instead of following page faults (lis_pages.c) */
 	int no_row_form;           /* LIS_AMD_NO_ROW_FORM=1 / lis_amd_set_row_form(0): constant-coefficient ELL / DIA matrices keep their native layout and kernels */
 	int no_row_patterns;       /* LIS_AMD_NO_ROW_PATTERNS=1: coded CSR matrices keep one byte per non-zero instead of one per row (A/B measurements) */
 	int last_uniform_jacobi;   /* the last lis_solve ran CG + Jacobi with 1/diag as one double (lis_amd_last_solve_uniform_jacobi) */
@@ -117,6 +119,18 @@ typedef struct {
 	lis_amd_comm_callbacks cb;
 } lisi_globals;
 extern lisi_globals lisg;
+
+/* ---- page-protected host arrays (lis_pages.c) */
+#define LISP_RW   0      /* host array holds the data, HBM copy stale (or none) */
+#define LISP_RO   1      /* both agree: a host write faults */
+#define LISP_NONE 2      /* HBM copy holds the data: any host access faults */
+LIS_SCALAR *lisp_alloc(LIS_VECTOR v, size_t doubles);
+void lisp_free(LIS_VECTOR v);
+LIS_INT lisp_grow(LIS_VECTOR v, size_t doubles);
+void lisp_protect(LIS_VECTOR v, int prot);
+int  lisp_state(LIS_VECTOR v);
+int  lisp_lazy(void);
+LIS_INT lisd_vec_host_write(LIS_VECTOR v, int keep);          /* the library is about to write value[] on the host (keep: current data needed first) */
 
 /* ---- device runtime (lis_device.c) */
 LIS_INT lisd_init(void);                                     /* lazy; fails loudly without a GPU */

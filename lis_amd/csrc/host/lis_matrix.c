@@ -461,6 +461,7 @@ LIS_INT lis_matrix_get_diagonal(LIS_MATRIX A, LIS_VECTOR D)
 		return lisd_vec_done(D);
 	}
 	const LIS_INT n = A->n;
+	LISCHK(lisd_vec_host_write(D, (size_t)(D->np + D->pad) > (size_t)n));   /* the host array is about to be written (entries beyond n keep what they hold) */
 	LIS_SCALAR *out = D->value;
 	for (LIS_INT i = 0; i < n; i++) out[i] = 0.0;
 	if (A->is_splited) {                /* the split form holds the diagonal itself (ref lis_matrix_csr.c:532-545, lis_matrix_bsr.c get_diagonal) */

@@ -93,16 +93,12 @@ LIS_INT lis_matrix_scale(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_INT actio
 		if (a > need) need = a;
 		if (b > need) need = b;
 	}
-	LISCHK(lisd_vec_to_host(D));
+	LISCHK(lisd_vec_host_write(D, 1));
 	if (VDEV(D)->hlen < need) {                       /* D->value grows like the reference's lis_realloc (:598-606), new entries zero */
-		double *nv = (double *)calloc(need, sizeof(double));
-		if (!nv) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)need);
-		memcpy(nv, D->value, sizeof(double) * VDEV(D)->hlen);
-		free(D->value);
-		D->value = nv; VDEV(D)->hlen = need;
+		LISCHK(lisp_grow(D, need));
 		if (D->np < np) D->np = np;
 	}
-	LISCHK(lisd_vec_to_host(B));
+	LISCHK(lisd_vec_host_write(B, 1));
 	double *d = D->value, *b = B->value;
 	if (action == LIS_SCALE_SYMM_DIAG) {
 		if (lisg.nprocs > 1 && A->commtable) {         /* ghosts of the diagonal, ref :596-608 */
@@ -111,7 +107,7 @@ LIS_INT lis_matrix_scale(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_INT actio
 			LISCHK(lisd_vec_in(D, &dd));
 			LISCHK(lisc_halo_device(A, dd));
 			lis_amd_vector_device_modified(D);
-			LISCHK(lisd_vec_to_host(D));
+			LISCHK(lisd_vec_host_write(D, 1));
 			d = D->value;
 		}
 		for (LIS_INT i = 0; i < np; i++) d[i] = 1.0 / sqrt(fabs(d[i]));
@@ -204,7 +200,7 @@ LIS_INT lisi_matrix_bscale_bsr(LIS_MATRIX A, LIS_VECTOR B)
 		}
 	}
 	/* b <- WD b; the rows of the last block beyond n read the vector's padding (zeros) */
-	LISCHK(lisd_vec_to_host(B));
+	LISCHK(lisd_vec_host_write(B, 1));
 	{
 		const size_t have = VDEV(B)->hlen;
 		LIS_SCALAR *t = (LIS_SCALAR *)calloc((size_t)nr * bn + 1, sizeof(LIS_SCALAR));

@@ -108,7 +108,7 @@ LIS_INT lis_solver_get_rhistory(LIS_SOLVER s, LIS_VECTOR v)
 	LIS_INT count = s->iter + 1;
 	if (s->retcode != LIS_SUCCESS) count--;
 	if (count > v->n) count = v->n;
-	LISCHK(lisd_vec_to_host(v));
+	LISCHK(lisd_vec_host_write(v, 1));
 	for (LIS_INT i = 0; i < count; i++) v->value[i] = s->rhistory[i];
 	lis_amd_vector_host_modified(v);
 	return LIS_SUCCESS;
@@ -1043,7 +1043,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		if (scale == LIS_SCALE_JACOBI && nsolver == LIS_SOLVER_CG) scale = LIS_SCALE_SYMM_DIAG;
 		if (!A->is_scaled) err = lis_matrix_scale(A, b, solver->d, scale);
 		else if (!b->is_scaled) {
-			err = lisd_vec_to_host(b);
+			err = lisd_vec_host_write(b, 1);
 			if (!err) err = lisd_vec_to_host(solver->d);
 			if (!err) { for (LIS_INT i = 0; i < A->n; i++) b->value[i] = b->value[i] * solver->d->value[i]; lis_amd_vector_host_modified(b); }
 		}

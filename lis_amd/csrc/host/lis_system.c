@@ -225,6 +225,11 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		if (lisg.nprocs == 0) { lisg.nprocs = 1; lisg.rank = 0; }
 		const char *r = getenv("LIS_AMD_RESIDENCY");
 		if (r && (strcmp(r, "resident") == 0 || strcmp(r, "1") == 0)) { lisg.residency = LIS_AMD_RESIDENT; (void)lisd_init_quiet(); }
+		r = getenv("LIS_AMD_COHERENCE");              /* eager: COHERENT copies on every call instead of following page faults (lis_pages.c) */
+		lisg.eager_coherence = (r && strcmp(r, "eager") == 0);
+		/* COHERENT by page protection runs at resident speed, so it starts like RESIDENT: the runtime comes up here (quietly: a box
+		 * without a GPU still serves the host-side API), and matrices are uploaded where they are made (lisd_mat_eager) */
+		if (lisg.residency == LIS_AMD_COHERENT && !lisg.eager_coherence) (void)lisd_init_quiet();
 		r = getenv("LIS_AMD_NO_FUSION");
 		lisg.no_fusion = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_OVERLAP");

@@ -47,7 +47,7 @@ LIS_INT lis_vector_set_size(LIS_VECTOR vec, LIS_INT local_n, LIS_INT global_n)
 	LIS_INT *ranges, is, ie, nprocs, my_rank;
 	LISCHK(lisc_ranges_create(vec->comm, &local_n, &global_n, &ranges, &is, &ie, &nprocs, &my_rank));
 	vec->ranges = ranges;
-	vec->value = (LIS_SCALAR *)calloc((size_t)(local_n > 0 ? local_n : 1), sizeof(LIS_SCALAR));
+	vec->value = lisp_alloc(vec, (size_t)local_n);          /* pages of its own, zero-filled: their protection follows the HBM copy (lis_pages.c) */
 	if (!vec->value) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", local_n);
 	VDEV(vec)->hlen = (size_t)local_n;
 	vec->is_copy = LIS_TRUE;
@@ -67,7 +67,7 @@ LIS_INT lis_vector_duplicate(void *vin, LIS_VECTOR *vout)
 	LISCHK(vec_alloc(vout));
 	LIS_VECTOR v = *vout;
 	const size_t len = (size_t)(src->np + src->pad);
-	v->value = (LIS_SCALAR *)calloc(len > 0 ? len : 1, sizeof(LIS_SCALAR));
+	v->value = lisp_alloc(v, len);
 	if (!v->value) { lis_vector_destroy(v); *vout = NULL; return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)len); }
 	VDEV(v)->hlen = len;
 	if (src->ranges) {
@@ -88,7 +88,8 @@ LIS_INT lis_vector_destroy(LIS_VECTOR vec)
 {
 	if (vec && lisi_is_registered(vec)) {
 		lisd_vec_free(vec);
-		if (vec->value && vec->is_destroy) free(vec->value);
+		if (VDEV(vec)->region) lisp_free(vec);
+		else if (vec->value && vec->is_destroy) free(vec->value);
 		free(vec->work);
 		free(vec->ranges);
 		lisi_unregister(vec);
@@ -113,8 +114,9 @@ LIS_INT lis_vector_get_range(LIS_VECTOR v, LIS_INT *is, LIS_INT *ie)
 	return LIS_SUCCESS;
 }
 
-/* host-side element access: make value[] current first, mark the HBM copy stale after a write */
+/* host-side element access: make value[] current first; a writer also makes the pages writable and marks the HBM copy stale */
 static LIS_INT host_begin(LIS_VECTOR v) { return VDEV(v)->host_valid ? LIS_SUCCESS : lisd_vec_to_host(v); }
+static LIS_INT host_begin_write(LIS_VECTOR v) { return lisd_vec_host_write(v, 1); }
 static void host_wrote(LIS_VECTOR v) { VDEV(v)->host_valid = 1; VDEV(v)->dev_valid = 0; }
 
 static LIS_INT index_error(const char *what, LIS_INT i, LIS_VECTOR v)
@@ -127,7 +129,7 @@ LIS_INT lis_vector_set_value(LIS_INT flag, LIS_INT i, LIS_SCALAR value, LIS_VECT
 {
 	if (v->origin) i--;
 	if (i < v->is || i >= v->ie) return index_error("i", i, v);
-	LISCHK(host_begin(v));
+	LISCHK(host_begin_write(v));
 	if (flag == LIS_INS_VALUE) v->value[i - v->is] = value; else v->value[i - v->is] += value;
 	host_wrote(v);
 	return LIS_SUCCESS;
@@ -135,7 +137,7 @@ LIS_INT lis_vector_set_value(LIS_INT flag, LIS_INT i, LIS_SCALAR value, LIS_VECT
 
 LIS_INT lis_vector_set_values(LIS_INT flag, LIS_INT count, LIS_INT index[], LIS_SCALAR value[], LIS_VECTOR v)
 {
-	LISCHK(host_begin(v));
+	LISCHK(host_begin_write(v));
 	for (LIS_INT k = 0; k < count; k++) {
 		LIS_INT i = index[k] - (v->origin ? 1 : 0);
 		if (i < v->is || i >= v->ie) return index_error("index[k]", i, v);
@@ -147,7 +149,7 @@ LIS_INT lis_vector_set_values(LIS_INT flag, LIS_INT count, LIS_INT index[], LIS_
 
 LIS_INT lis_vector_set_values2(LIS_INT flag, LIS_INT start, LIS_INT count, LIS_SCALAR value[], LIS_VECTOR v)
 {
-	LISCHK(host_begin(v));
+	LISCHK(host_begin_write(v));
 	if (v->origin) start--;
 	for (LIS_INT k = 0; k < count; k++) {
 		LIS_INT i = start + k;
@@ -183,6 +185,7 @@ LIS_INT lis_vector_get_values(LIS_VECTOR v, LIS_INT start, LIS_INT count, LIS_SC
 LIS_INT lis_vector_scatter(LIS_SCALAR value[], LIS_VECTOR v)
 {	/* ref lis_vector.c:943: every rank holds the full array and keeps its slice */
 	LISCHK(vec_check(v));
+	LISCHK(lisd_vec_host_write(v, v->np + v->pad > v->n));      /* (ghost / padding entries beyond n keep what they hold) */
 	memcpy(v->value, value + v->is, sizeof(LIS_SCALAR) * (size_t)v->n);
 	host_wrote(v);
 	return LIS_SUCCESS;
@@ -232,7 +235,7 @@ LIS_INT lis_vector_copy(LIS_VECTOR vsrc, LIS_VECTOR vdst)
 LIS_INT lis_vector_swap(LIS_VECTOR vsrc, LIS_VECTOR vdst)
 {
 	LISCHK(same_len(vsrc, vdst));
-	LISCHK(lisd_vec_to_host(vsrc)); LISCHK(lisd_vec_to_host(vdst));
+	LISCHK(lisd_vec_host_write(vsrc, 1)); LISCHK(lisd_vec_host_write(vdst, 1));
 	for (LIS_INT i = 0; i < vsrc->n; i++) { double t = vsrc->value[i]; vsrc->value[i] = vdst->value[i]; vdst->value[i] = t; }
 	host_wrote(vsrc); host_wrote(vdst);
 	return LIS_SUCCESS;

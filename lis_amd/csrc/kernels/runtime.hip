@@ -78,6 +78,7 @@ extern "C" int liship_event_create(void **ev)
     return 0;
 }
 extern "C" int liship_event_destroy(void *ev) { if (ev) HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(ev))); return 0; }
+extern "C" int liship_event_synchronize(void *ev) { HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(ev))); return 0; }
 extern "C" int liship_event_record(void *ev, void *stream) { HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(ev), as_stream(stream))); return 0; }
 extern "C" int liship_stream_wait_event(void *stream, void *ev) { HIP_TRY(hipStreamWaitEvent(as_stream(stream), static_cast<hipEvent_t>(ev), 0)); return 0; }
 

@@ -337,3 +337,81 @@ def test_handle_registry_follows_the_live_count(lib):
     for v in keep:                                       # the survivors are still known
         assert lib.lis_vector_set_size(v, 3, 0) == 0
         assert lib.lis_vector_destroy(v) == 0
+
+
+# ---------------------------------------------------------------- coherent semantics by page protection (lis_pages.c), no GPU needed
+def _vec(lib, n):
+    v = capi.PV()
+    assert lib.lis_vector_create(capi.LIS_COMM_WORLD, C.byref(v)) == 0 and lib.lis_vector_set_size(v, n, 0) == 0
+    return v
+
+
+def test_vector_pages_follow_the_flags_through_faults(lib):
+    """value[] lives on pages of its own: without access while the HBM copy is newer (any host access faults and the handler brings the
+    vector home), read-only while both sides agree (a host write faults once and marks the HBM copy stale), plain memory otherwise.
+    Driven here without a GPU: with no HBM buffer the `bring home` step has nothing to copy, the protection and bookkeeping are the same."""
+    dll = lib.dll
+    for f in (dll.lis_amd_vector_page_state, dll.lis_amd_vector_device_modified, dll.lis_amd_vector_sync_host):
+        f.argtypes = [capi.PV]
+    dll.lis_amd_vector_page_protect.argtypes = [capi.PV, C.c_int]
+    dll.lis_amd_page_faults.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+    def faults():
+        r, w = C.c_int(), C.c_int()
+        dll.lis_amd_page_faults(C.byref(r), C.byref(w))
+        return r.value, w.value
+    n = 5000                                    # ten pages
+    v = _vec(lib, n)
+    val = np.ctypeslib.as_array(v.contents.value, shape=(n,))
+    assert dll.lis_amd_vector_page_state(v) == 0 and not val.any()      # fresh pages: zero, writable
+    val[:] = np.arange(n)                       # a program poking value[] directly: plain memory, no fault
+    r0, w0 = faults()
+    assert dll.lis_amd_vector_device_modified(v) == 0                   # "a kernel wrote v": the pages lose all access
+    assert dll.lis_amd_vector_page_state(v) == 2
+    assert val[4321] == 4321.0                  # the read faults; the handler restores access (and would copy HBM -> host)
+    assert faults() == (r0 + 1, w0) and dll.lis_amd_vector_page_state(v) in (0, 1)
+    assert dll.lis_amd_vector_page_protect(v, 1) == 0                   # both sides agree: read-only
+    assert val[17] == 17.0 and faults() == (r0 + 1, w0)                 # reads are free
+    val[17] = -1.0                              # the write faults once: pages writable again, HBM copy stale
+    assert faults() == (r0 + 1, w0 + 1) and dll.lis_amd_vector_page_state(v) == 0 and val[17] == -1.0
+    val[18] = -2.0
+    assert faults() == (r0 + 1, w0 + 1)
+    # the API's own writers and readers never fault: they unprotect first
+    assert dll.lis_amd_vector_page_protect(v, 1) == 0
+    assert lib.lis_vector_set_value(capi.LIS_INS_VALUE, 3, 9.5, v) == 0 and val[3] == 9.5 and dll.lis_amd_vector_page_state(v) == 0
+    assert dll.lis_amd_vector_device_modified(v) == 0 and dll.lis_amd_vector_page_state(v) == 2
+    out = C.c_double()
+    assert lib.lis_vector_get_value(v, 3, C.byref(out)) == 0 and out.value == 9.5
+    assert faults() == (r0 + 1, w0 + 1)
+    # eager coherence: protection is never raised
+    dll.lis_amd_set_coherence(0)
+    try:
+        w = _vec(lib, 100)
+        assert dll.lis_amd_vector_device_modified(w) == 0 and dll.lis_amd_vector_page_state(w) == 0
+        lib.lis_vector_destroy(w)
+    finally:
+        dll.lis_amd_set_coherence(1)
+    assert lib.lis_vector_destroy(v) == 0       # (unmaps the pages, whatever their protection)
+    # a duplicate sized by a matrix header (np + pad entries) gets its own pages too
+    v = _vec(lib, 7)
+    d = capi.PV()
+    assert lib.lis_vector_duplicate(C.cast(v, C.c_void_p), C.byref(d)) == 0 and dll.lis_amd_vector_page_state(d) == 0
+    lib.lis_vector_destroy(d); lib.lis_vector_destroy(v)
+
+
+def test_foreign_segfaults_still_kill_the_process():
+    """the handler only answers for vector pages: any other bad access goes to the previous disposition (here: the default, death by SIGSEGV)"""
+    import subprocess
+    import sys
+    code = ("import sys, ctypes as C; sys.path[:0] = [%r, %r]\n"
+            "import lis_amd; from lis_amd import _capi as capi\n"
+            "lib = lis_amd.load(); assert lib.initialize([]) == 0\n"
+            "v = capi.PV(); lib.lis_vector_create(0, C.byref(v)); lib.lis_vector_set_size(v, 100, 0)\n"
+            "lib.dll.lis_amd_vector_page_protect.argtypes = [capi.PV, C.c_int]\n"
+            "assert lib.dll.lis_amd_vector_page_protect(v, 2) == 0\n"
+            "assert v.contents.value[5] == 0.0          # ours: served\n"
+            "print('served', flush=True)\n"
+            "C.string_at(8)                              # not ours\n"
+            "print('survived', flush=True)\n") % (ROOT, os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-X", "faulthandler=0", "-c", code], capture_output=True, text=True, timeout=120)
+    assert "served" in p.stdout and "survived" not in p.stdout and p.returncode == -11, (p.returncode, p.stdout, p.stderr[-500:])

@@ -530,3 +530,73 @@ def test_object_lifecycle_stress(lib):
     assert lib.lis_finalize() == 0 and lib.initialize([]) == 0
     y1, y2 = once(0)
     assert np.array_equal(y1, ref[0][0])
+
+
+def test_coherent_by_page_protection_on_the_gpu(lib):
+    """LIS_AMD_COHERENT as a Lis program sees it, with the program poking value[] directly between calls (test/spmvtest1.c:215 style):
+    reads of a product's result fault once and bring exactly that vector home, a write to an input both sides agreed on faults once
+    and the next product uses the new value, untouched vectors never cross PCIe -- and every number equals the eager implementation's."""
+    dll = lib.dll
+    for f in (dll.lis_amd_vector_page_state,):
+        f.argtypes = [capi.PV]
+    dll.lis_amd_page_faults.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+    def faults():
+        r, w = C.c_int(), C.c_int()
+        dll.lis_amd_page_faults(C.byref(r), C.byref(w))
+        return r.value, w.value
+    assert dll.lis_amd_get_residency() == 0
+    ptr, idx, val = orc.poisson3d(12, 11, 10)
+    n = len(ptr) - 1
+    rng = np.random.default_rng(2)
+    x0 = rng.uniform(-1, 1, n)
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    vx, vy, vz = lisdrv.new_vector(lib, A), lisdrv.new_vector(lib, A), lisdrv.new_vector(lib, A)
+    xs = np.ctypeslib.as_array(vx.contents.value, shape=(n,))
+    ys = np.ctypeslib.as_array(vy.contents.value, shape=(n,))
+    xs[:] = x0                                                  # direct pokes into fresh (writable) pages: no fault
+    r0, w0 = faults()
+    assert lib.lis_matvec(A, vx, vy) == 0                        # uploads x (its pages become read-only), leaves y in HBM (no access)
+    assert dll.lis_amd_vector_page_state(vx) == 1 and dll.lis_amd_vector_page_state(vy) == 2 and faults() == (r0, w0)
+    for _ in range(5):                                           # a loop inside the API: nothing crosses PCIe, nothing faults
+        assert lib.lis_matvec(A, vx, vy) == 0
+        assert lib.lis_vector_axpy(0.5, vy, vz) == 0
+    assert faults() == (r0, w0) and dll.lis_amd_vector_page_state(vz) == 2
+    want = orc.spmv_csr(ptr, idx, val, x0)
+    assert ys[7] == want[7]                                      # the program reads y[7]: one read fault, y comes home
+    assert faults() == (r0 + 1, w0) and dll.lis_amd_vector_page_state(vy) == 1 and np.array_equal(ys, want)
+    assert dll.lis_amd_vector_page_state(vz) == 2                # z was not touched: still in HBM only
+    xs[3] = 7.25                                                 # the program writes x[3]: one write fault, the HBM copy of x is stale
+    assert faults() == (r0 + 1, w0 + 1) and dll.lis_amd_vector_page_state(vx) == 0
+    x1 = x0.copy(); x1[3] = 7.25
+    assert lib.lis_matvec(A, vx, vy) == 0                        # ... so this product uploads x again and sees the new value
+    assert np.array_equal(ys, orc.spmv_csr(ptr, idx, val, x1)) and faults() == (r0 + 2, w0 + 1)
+    ys[5] += 1.0                                                 # read-modify-write of an output that both sides agree on
+    y2 = orc.spmv_csr(ptr, idx, val, x1); y2[5] += 1.0
+    nrm = C.c_double()
+    assert lib.lis_vector_nrm2(vy, C.byref(nrm)) == 0 and abs(nrm.value - np.sqrt(np.dot(y2, y2))) <= 1e-13 * nrm.value
+    # a solve: b and x travel once each way at most, x stays in HBM until somebody looks
+    vb, vs = lisdrv.new_vector(lib, A), lisdrv.new_vector(lib, A)
+    np.ctypeslib.as_array(vb.contents.value, shape=(n,))[:] = orc.spmv_csr(ptr, idx, val, np.ones(n))
+    S = capi.PS()
+    lib.lis_solver_create(C.byref(S))
+    lib.lis_solver_set_option(b"-i cg -p jacobi -tol 1e-12", S)
+    before = faults()
+    assert lib.lis_solve(A, vb, vs, S) == 0 and S.contents.retcode == 0
+    assert faults() == before and dll.lis_amd_vector_page_state(vs) == 2
+    sol = np.ctypeslib.as_array(vs.contents.value, shape=(n,))
+    assert abs(sol - 1.0).max() <= 1e-10 and faults() == (before[0] + 1, before[1])
+    lib.lis_solver_destroy(S)
+    # the eager implementation gives the same numbers
+    dll.lis_amd_set_coherence(0)
+    try:
+        ve = lisdrv.new_vector(lib, A)
+        assert lib.lis_matvec(A, vx, ve) == 0
+        assert dll.lis_amd_vector_page_state(ve) == 0
+        assert np.array_equal(np.ctypeslib.as_array(ve.contents.value, shape=(n,)), orc.spmv_csr(ptr, idx, val, x1))
+        lib.lis_vector_destroy(ve)
+    finally:
+        dll.lis_amd_set_coherence(1)
+    for v in (vx, vy, vz, vb, vs):
+        lib.lis_vector_destroy(v)
+    lib.lis_matrix_destroy(A)

@@ -2003,6 +2003,7 @@ struct liship_csr_plan_s {
     int *dcol;           // device, the lists (each padded to a multiple of 4 entries)
     int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
     long long ndcol;     // entries of dcol
+    int ndpl;            // distinct columns per lane of spmv_csr_local_kernel: 2 (lists of <= 1024 columns) or 4
     int first_term;      // row sums start at the first product instead of at +0.0 (split matrices)
     v4i32 *vrecw;        // device: WIDE value records for patterns of up to 32 entries (no ptab8): per pattern 144 B of byte offsets + length, 256 B of values; else NULL
     int *order;          // device, nblocks entries or NULL: launch order of the products kernel (blocks with a very long row first)
@@ -2105,7 +2106,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->blk = nullptr;
     p->blk_host = nullptr;
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
-    p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0;
+    p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
     p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
     p->drec = nullptr; p->dom_lo = p->dom_hi = 0;
@@ -2620,7 +2621,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     if (p->lcol || p->codes || !p->products || p->nblocks <= 0 || p->nnz <= 0 || g_variant != 0 || !aligned16(idx)) return 0;
     hipStream_t st = as_stream(stream);
     constexpr Geometry g = kGeom[LOCAL_GEOM];
-    constexpr int CAPL = g.work + SLACK, NDMAX = 2 * g.block;
+    constexpr int CAPL = g.work + SLACK, NDMAX = 4 * g.block;      // up to four distinct columns per lane (the kernel's NDPL = 4 form)
     const int geom_before = p->geom;
     if (p->geom != LOCAL_GEOM) { p->geom = LOCAL_GEOM; const int rc = build_split(p, ptr, st); if (rc) return rc; }
     const int nb = p->nblocks;
@@ -2637,8 +2638,10 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
         return (int)e;
     }
     long long listed = 0, covered = 0, run = 0;
+    int ndmost = 0;
     for (int b = 0; b < nb; b++) {
         const int nd = off[b];
+        if (nd > ndmost) ndmost = nd;
         off[b] = (int)run;
         if (nd > 0) { listed += nd; covered += p->blk_host[b + 1].y - p->blk_host[b].y; run += (nd + 3) & ~3; }
     }
@@ -2669,6 +2672,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     }
     p->doff = nd_dev;
     p->ndcol = run;
+    p->ndpl = ndmost > 2 * g.block ? 4 : 2;        // lists of up to 1024 columns (the dofs-per-node patterns in mesh order): two per lane, 8 KB of LDS; longer ones four
     return 0;
 }
 // entries of the distinct-column lists when the plan keeps block-local columns, 0 otherwise
@@ -2739,6 +2743,10 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     const bool products = plan_products || (g_variant & 6) != 0 || !(val16 && idx16);
     if (a.lcol && plan_products && G == LOCAL_GEOM && g_variant == 0 && val16) {     // long rows, few distinct columns per row block
         constexpr Geometry g = kGeom[LOCAL_GEOM];
+        if (a.plan && a.plan->ndpl == 4)
+            spmv_csr_local_kernel<g.block, g.work, 0, 4><<<a.nb, g.block, 0, a.st>>>(
+                a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
+        else
         spmv_csr_local_kernel<g.block, g.work><<<a.nb, g.block, 0, a.st>>>(
             a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
@@ -2919,6 +2927,11 @@ void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double
 {
     constexpr Geometry g = kGeom[G];
     if (a.lcol && G == LOCAL_GEOM) {
+        if (a.plan && a.plan->ndpl == 4) {
+            spmv_csr_local_kernel<g.block, g.work, DOT, 4><<<a.nb, g.block, 0, a.st>>>(
+                a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride);
+            return;
+        }
         spmv_csr_local_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
             a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride);
         return;

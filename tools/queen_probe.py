@@ -1,0 +1,37 @@
+"""BASELINE config 4's stand-in at Queen's scale (tests/golden/gen_queen_class.c) through lis_input, then timed products and solves:
+    python tools/queen_probe.py [reps]        (env QUEEN_VARIANT: liship_spmv_csr_set_variant bits, QUEEN_NO_LOCAL=1: no block-local columns)"""
+import ctypes as C, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import lis_amd, lisdrv, queen_class
+from lis_amd import _capi as capi
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+lib = lis_amd.load(); assert lib.initialize([]) == 0
+dll = lib.dll
+dll.lis_amd_set_residency(1)
+if os.environ.get("QUEEN_NO_LOCAL") == "1":
+    lib.liship_spmv_csr_set_local_columns(0)
+t0 = time.time(); path, rows, stored = queen_class.generate("full"); t_gen = time.time() - t0
+A, b, x0 = capi.PM(), capi.PV(), capi.PV()
+lib.lis_matrix_create(0, C.byref(A)); lib.lis_vector_create(0, C.byref(b)); lib.lis_vector_create(0, C.byref(x0))
+t0 = time.time(); assert lib.lis_input(A, b, x0, path.encode()) == 0; t_read = time.time() - t0
+os.unlink(path)
+n, nnz = A.contents.n, A.contents.nnz
+dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
+listed = dll.lis_amd_matrix_local_columns(A)
+xs = np.cos(np.arange(n) * 0.01) + 1.25
+vx, vy = lisdrv.new_vector(lib, A, xs), lisdrv.new_vector(lib, A)
+if os.environ.get("QUEEN_VARIANT"):
+    lib.liship_spmv_csr_set_variant(int(os.environ["QUEEN_VARIANT"], 0))
+for _ in range(10):
+    assert lib.lis_matvec(A, vx, vy) == 0
+dll.lis_amd_synchronize()
+t0 = time.time()
+for _ in range(reps):
+    assert lib.lis_matvec(A, vx, vy) == 0
+dll.lis_amd_synchronize()
+ms = (time.time() - t0) / reps * 1e3
+print(json.dumps({"n": n, "nnz": nnz, "generate_s": round(t_gen, 2), "lis_input_s": round(t_read, 2), "block_local_columns_listed": int(listed),
+                  "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),
+                  "frac_of_8TBs_on_contract_bytes": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4)}), flush=True)

@@ -2,6 +2,8 @@
 torch.distributed (gloo).  Test / bring-up plumbing: the production data path is RCCL (lis_amd_comm_init_rccl).
 Used by tests/dist_worker.py and by `bench.py --comm callbacks` (several ranks sharing one GPU, which RCCL refuses)."""
 import ctypes as C
+import os
+import time
 
 import numpy as np
 import torch
@@ -25,7 +27,11 @@ def make_callbacks(world):
         C.memmove(recv, flat.ctypes.data, nbytes * world)
         return 0
 
+    delay = float(os.environ.get("LIS_AMD_TEST_HALO_DELAY_MS", "0")) * 1e-3      # tests: a halo that arrives late (odd ranks later still)
+
     def exchange(ctx, nneib, neib, sendbuf, sptr, recvbuf, rptr):
+        if delay > 0.0:
+            time.sleep(delay * (1 + dist.get_rank() % 2))
         reqs, recvs = [], []
         for i in range(nneib):
             sc, rc = sptr[i + 1] - sptr[i], rptr[i + 1] - rptr[i]

@@ -306,11 +306,26 @@ LIS_INT lisc_commtable_create(LIS_MATRIX A)
 }
 
 /* ------------------------------------------------------------------ halo exchange on HBM pointers */
+/* A neighbour whose export list is a run of consecutive rows -- a whole boundary plane of a structured grid in the row-block partition --
+ * is sent STRAIGHT from x: no pack kernel, no staging copy.  export_run[i] = first row of the run, or -1 (irregular lists are packed
+ * by liship_gather_f64 into d->ws as lis_send_recv packs them into ws, lis_matrix_mpi.c:866-874).  When every list is a run the pack
+ * kernel is not launched at all. */
 static LIS_INT halo_tables_ready(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
 	if (d->halo_ready) return LIS_SUCCESS;
 	LIS_COMMTABLE t = A->commtable;
+	d->all_runs = 1;
+	d->export_run = (int *)malloc(sizeof(int) * (size_t)(t->neibpetot > 0 ? t->neibpetot : 1));
+	if (!d->export_run) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", t->neibpetot);
+	for (LIS_INT i = 0; i < t->neibpetot; i++) {
+		const LIS_INT b = t->export_ptr[i], e = t->export_ptr[i + 1];
+		int run = e > b ? t->export_index[b] : 0;
+		for (LIS_INT k = b + 1; k < e && run >= 0; k++) if (t->export_index[k] != t->export_index[b] + (k - b)) run = -1;
+		if (lisg.no_direct_halo) run = -1;
+		d->export_run[i] = run;
+		if (run < 0) d->all_runs = 0;
+	}
 	if (t->exnnz > 0) {
 		HIPCHK(lisd_malloc((void **)&d->export_index, sizeof(int) * (size_t)t->exnnz));
 		HIPCHK(liship_memcpy_h2d(d->export_index, t->export_index, sizeof(int) * (size_t)t->exnnz, lisg.stream));
@@ -321,64 +336,84 @@ static LIS_INT halo_tables_ready(LIS_MATRIX A)
 	return LIS_SUCCESS;
 }
 
+/* what a neighbour is sent: its run inside x, or its packed slice */
+static const double *send_ptr(const lisd_mat *d, LIS_COMMTABLE t, LIS_INT i, const double *dx)
+{
+	return d->export_run[i] >= 0 ? dx + d->export_run[i] : d->ws + t->export_ptr[i];
+}
+
+static LIS_INT halo_pack(LIS_MATRIX A, double *dx)
+{
+	lisd_mat *d = MDEV(A);
+	LIS_COMMTABLE t = A->commtable;
+	if (t->exnnz > 0 && !d->all_runs) HIPCHK(liship_gather_f64(t->exnnz, d->export_index, dx, d->ws, lisg.stream));
+	return LIS_SUCCESS;
+}
+
+static LIS_INT halo_rccl(LIS_MATRIX A, double *dx, void *stream)
+{
+	lisd_mat *d = MDEV(A);
+	LIS_COMMTABLE t = A->commtable;
+	const LIS_INT n = A->n, pad = t->pad;
+	NCCLCHK(rccl.GroupStart());
+	for (LIS_INT i = 0; i < t->neibpetot; i++) {
+		const LIS_INT peer = t->neibpe[i];
+		const LIS_INT sc = t->export_ptr[i + 1] - t->export_ptr[i], rc = t->import_ptr[i + 1] - t->import_ptr[i];
+		if (sc > 0) NCCLCHK(rccl.Send(send_ptr(d, t, i, dx), (size_t)sc, NCCL_DOUBLE, peer, lisg.nccl_comm, stream));
+		if (rc > 0) NCCLCHK(rccl.Recv(dx + n + pad + t->import_ptr[i], (size_t)rc, NCCL_DOUBLE, peer, lisg.nccl_comm, stream));
+	}
+	NCCLCHK(rccl.GroupEnd());
+	return LIS_SUCCESS;
+}
+
+/* host round trip (tests / bring-up only): the slices go to the host, through the callback, and back into x[n + pad ...) */
+static LIS_INT halo_callbacks(LIS_MATRIX A, double *dx)
+{
+	lisd_mat *d = MDEV(A);
+	LIS_COMMTABLE t = A->commtable;
+	const LIS_INT n = A->n, pad = t->pad;
+	for (LIS_INT i = 0; i < t->neibpetot; i++) {
+		const LIS_INT sc = t->export_ptr[i + 1] - t->export_ptr[i];
+		if (sc > 0) HIPCHK(liship_memcpy_d2h(t->ws + t->export_ptr[i], send_ptr(d, t, i, dx), sizeof(double) * (size_t)sc, lisg.stream));
+	}
+	HIPCHK(liship_stream_synchronize(lisg.stream));
+	if (lisg.cb.neighbor_exchange(lisg.cb.ctx, t->neibpetot, t->neibpe, t->ws, t->export_ptr, t->wr, t->import_ptr))
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "neighbor_exchange callback failed\n");
+	if (t->imnnz > 0) HIPCHK(liship_memcpy_h2d(dx + n + pad, t->wr, sizeof(double) * (size_t)t->imnnz, lisg.stream));
+	return LIS_SUCCESS;
+}
+
 LIS_INT lisc_halo_device(LIS_MATRIX A, double *dx)
 {
 	LIS_COMMTABLE t = A->commtable;
-	lisd_mat *d = MDEV(A);
 	if (!t || t->neibpetot == 0) return LIS_SUCCESS;
 	LISCHK(halo_tables_ready(A));
-	const LIS_INT n = A->n, pad = t->pad;
-	if (t->exnnz > 0) HIPCHK(liship_gather_f64(t->exnnz, d->export_index, dx, d->ws, lisg.stream));
-	if (lisg.comm_kind == 1) {
-		NCCLCHK(rccl.GroupStart());
-		for (LIS_INT i = 0; i < t->neibpetot; i++) {
-			const LIS_INT peer = t->neibpe[i];
-			const LIS_INT sc = t->export_ptr[i + 1] - t->export_ptr[i], rc = t->import_ptr[i + 1] - t->import_ptr[i];
-			if (sc > 0) NCCLCHK(rccl.Send(d->ws + t->export_ptr[i], (size_t)sc, NCCL_DOUBLE, peer, lisg.nccl_comm, lisg.stream));
-			if (rc > 0) NCCLCHK(rccl.Recv(dx + n + pad + t->import_ptr[i], (size_t)rc, NCCL_DOUBLE, peer, lisg.nccl_comm, lisg.stream));
-		}
-		NCCLCHK(rccl.GroupEnd());
-		return LIS_SUCCESS;
-	}
-	if (lisg.comm_kind == 2) {                  /* host round trip (tests / bring-up only) */
-		if (t->exnnz > 0) HIPCHK(liship_memcpy_d2h(t->ws, d->ws, sizeof(double) * (size_t)t->exnnz, lisg.stream));
-		HIPCHK(liship_stream_synchronize(lisg.stream));
-		if (lisg.cb.neighbor_exchange(lisg.cb.ctx, t->neibpetot, t->neibpe, t->ws, t->export_ptr, t->wr, t->import_ptr))
-			return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "neighbor_exchange callback failed\n");
-		if (t->imnnz > 0) HIPCHK(liship_memcpy_h2d(dx + n + pad, t->wr, sizeof(double) * (size_t)t->imnnz, lisg.stream));
-		return LIS_SUCCESS;
-	}
+	LISCHK(halo_pack(A, dx));
+	if (lisg.comm_kind == 1) return halo_rccl(A, dx, lisg.stream);
+	if (lisg.comm_kind == 2) return halo_callbacks(A, dx);
 	return LISI_ERR(LIS_ERR_ILL_ARG, "halo exchange without a communicator\n");
 }
 
 /* the same exchange split in two so the rows that reference no ghost column run while the planes travel:
- *   begin: pack on the compute stream; RCCL send/recv on the second stream once the pack is done
+ *   begin: pack on the compute stream (nothing when every list is a run); RCCL send/recv on the second stream behind an event
+ *          that marks "x is complete" on the compute stream
  *   end:   the compute stream waits for the landing (stream-side wait, the host does not block)
  * With the callback backend (tests) `begin` only packs and `end` does the host round trip. */
 LIS_INT lisc_halo_begin(LIS_MATRIX A, double *dx)
 {
 	LIS_COMMTABLE t = A->commtable;
-	lisd_mat *d = MDEV(A);
 	if (!t || t->neibpetot == 0) return LIS_SUCCESS;
 	LISCHK(halo_tables_ready(A));
-	const LIS_INT n = A->n, pad = t->pad;
-	if (t->exnnz > 0) HIPCHK(liship_gather_f64(t->exnnz, d->export_index, dx, d->ws, lisg.stream));
+	LISCHK(halo_pack(A, dx));
 	if (lisg.comm_kind != 1) return LIS_SUCCESS;
 	if (!lisg.comm_stream) {
 		HIPCHK(liship_stream_create(&lisg.comm_stream));
 		HIPCHK(liship_event_create(&lisg.ev_packed));
 		HIPCHK(liship_event_create(&lisg.ev_landed));
 	}
-	HIPCHK(liship_event_record(lisg.ev_packed, lisg.stream));
+	HIPCHK(liship_event_record(lisg.ev_packed, lisg.stream));          /* x (and the packed slices) are final behind this point */
 	HIPCHK(liship_stream_wait_event(lisg.comm_stream, lisg.ev_packed));
-	NCCLCHK(rccl.GroupStart());
-	for (LIS_INT i = 0; i < t->neibpetot; i++) {
-		const LIS_INT peer = t->neibpe[i];
-		const LIS_INT sc = t->export_ptr[i + 1] - t->export_ptr[i], rc = t->import_ptr[i + 1] - t->import_ptr[i];
-		if (sc > 0) NCCLCHK(rccl.Send(d->ws + t->export_ptr[i], (size_t)sc, NCCL_DOUBLE, peer, lisg.nccl_comm, lisg.comm_stream));
-		if (rc > 0) NCCLCHK(rccl.Recv(dx + n + pad + t->import_ptr[i], (size_t)rc, NCCL_DOUBLE, peer, lisg.nccl_comm, lisg.comm_stream));
-	}
-	NCCLCHK(rccl.GroupEnd());
+	LISCHK(halo_rccl(A, dx, lisg.comm_stream));
 	HIPCHK(liship_event_record(lisg.ev_landed, lisg.comm_stream));
 	return LIS_SUCCESS;
 }
@@ -386,18 +421,9 @@ LIS_INT lisc_halo_begin(LIS_MATRIX A, double *dx)
 LIS_INT lisc_halo_end(LIS_MATRIX A, double *dx)
 {
 	LIS_COMMTABLE t = A->commtable;
-	lisd_mat *d = MDEV(A);
 	if (!t || t->neibpetot == 0) return LIS_SUCCESS;
 	if (lisg.comm_kind == 1) { HIPCHK(liship_stream_wait_event(lisg.stream, lisg.ev_landed)); return LIS_SUCCESS; }
-	if (lisg.comm_kind == 2) {
-		const LIS_INT n = A->n, pad = t->pad;
-		if (t->exnnz > 0) HIPCHK(liship_memcpy_d2h(t->ws, d->ws, sizeof(double) * (size_t)t->exnnz, lisg.stream));
-		HIPCHK(liship_stream_synchronize(lisg.stream));
-		if (lisg.cb.neighbor_exchange(lisg.cb.ctx, t->neibpetot, t->neibpe, t->ws, t->export_ptr, t->wr, t->import_ptr))
-			return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "neighbor_exchange callback failed\n");
-		if (t->imnnz > 0) HIPCHK(liship_memcpy_h2d(dx + n + pad, t->wr, sizeof(double) * (size_t)t->imnnz, lisg.stream));
-		return LIS_SUCCESS;
-	}
+	if (lisg.comm_kind == 2) return halo_callbacks(A, dx);
 	return LISI_ERR(LIS_ERR_ILL_ARG, "halo exchange without a communicator\n");
 }
 

@@ -639,7 +639,7 @@ void lisd_mat_free(LIS_MATRIX A)
 	(void)liship_free(d->ell_codes); (void)liship_free(d->ell_dict);
 	(void)liship_free(d->ptr); (void)liship_free(d->index); (void)liship_free(d->row);
 	(void)liship_free(d->bptr); (void)liship_free(d->bindex); (void)liship_free(d->value);
-	(void)liship_free(d->export_index); (void)liship_free(d->ws);
+	(void)liship_free(d->export_index); (void)liship_free(d->ws); free(d->export_run);
 	(void)liship_free(d->sx); (void)liship_free(d->sy);
 	memset(d, 0, sizeof(*d));
 }

@@ -68,6 +68,8 @@ typedef struct {
 	/* halo (multi-GPU) */
 	int halo_ready;
 	int *export_index;         /* device copy of commtable->export_index */
+	int *export_run;           /* host, per neighbour: the first row when its export list is a run of consecutive rows (sent straight from x), else -1 */
+	int all_runs;              /* every neighbour's list is a run: no pack kernel at all (whole boundary planes of a structured grid) */
 	double *ws;                /* packed send buffer in HBM */
 	int inner_begin, inner_end;/* maximal run of rows without ghost columns: overlappable with the halo */
 	/* scratch for the raw-array entry points lis_matvec_<fmt>(A, x[], y[]) */
@@ -116,6 +118,7 @@ typedef struct {
 	int no_index_codes;        /* LIS_AMD_NO_INDEX_CODES=1: CSR products keep reading the 4 B column indices (A/B measurements) */
 	int host_scalars;          /* LIS_AMD_HOST_SCALARS=1: CG / BiCGSTAB read every scalar back (A/B against the device-driven loops) */
 	int no_overlap;            /* LIS_AMD_NO_OVERLAP=1: exchange first, then the whole product (A/B measurements) */
+	int no_direct_halo;        /* LIS_AMD_NO_DIRECT_HALO=1: boundary rows that form a run are packed like any other list instead of being sent straight from x (A/B) */
 	lis_amd_comm_callbacks cb;
 } lisi_globals;
 extern lisi_globals lisg;

@@ -234,6 +234,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_fusion = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_OVERLAP");
 		lisg.no_overlap = (r && r[0] == '1');
+		r = getenv("LIS_AMD_NO_DIRECT_HALO");
+		lisg.no_direct_halo = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_INDEX_CODES");
 		lisg.no_index_codes = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_ROW_PATTERNS");

@@ -19,13 +19,13 @@ def _free_port():
     return port
 
 
-def _launch(mode, world, timeout=600):
+def _launch(mode, world, timeout=600, extra_env=None):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
-                   LIS_AMD_DEVICE=str(rank) if mode == "rccl" else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   LIS_AMD_DEVICE=str(rank) if mode == "rccl" else "0", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -50,6 +50,18 @@ def test_partition_tables_and_halo_on_cpu(world):
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_spmv_and_solvers_on_one_gpu(world):
     _launch("device", world)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"LIS_AMD_TEST_HALO_DELAY_MS": "40"}, {"LIS_AMD_TEST_HALO_DELAY_MS": "40", "LIS_AMD_NO_DIRECT_HALO": "1"},
+                                 {"LIS_AMD_NO_DIRECT_HALO": "1"}, {"LIS_AMD_NO_OVERLAP": "1"}])
+def test_late_halo_changes_nothing(env):
+    """Two ranks on one GPU with the halo transport DELAYED (the exchange callback sleeps 40 / 80 ms before it moves anything, the
+    ranks by different amounts): the interior rows of every product have long finished when the ghosts land, the boundary rows are
+    queued behind the landing on the same stream, and every check of the distributed worker -- product slices bit-equal to the
+    single-process product, iteration counts, residuals -- must come out as without the delay.  Also with the boundary planes packed
+    instead of sent straight from x (LIS_AMD_NO_DIRECT_HALO=1), and with the overlap off."""
+    _launch("device", 2, extra_env=env)
 
 
 def _gpu_count():

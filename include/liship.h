@@ -188,6 +188,12 @@ int  liship_spmv_ell_f64(int n, int maxnzr, const int *index, const double *valu
                          const double *x, double *y, void *stream);
 int  liship_spmv_dia_f64(int n, int ncols, int nnd, const int *offsets, const double *value,
                          const double *x, double *y, void *stream);
+/* rows [row_begin, row_end) of the ELL / DIA product only (layouts of all n rows; codes / dict may be NULL): the parts a multi-rank
+ * job launches around its halo exchange -- same bits as the whole launch */
+int  liship_spmv_ell_rows_f64(int n, int maxnzr, const int *index, const unsigned char *codes, const int *dict, const double *value,
+                              const double *x, double *y, int row_begin, int row_end, void *stream);
+int  liship_spmv_dia_rows_f64(int n, int ncols, int nnd, const int *offsets, const double *value,
+                              const double *x, double *y, int row_begin, int row_end, void *stream);
 int  liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int *ptr, const int *index,
                          const double *value, const double *x, double *y, void *stream);
 int  liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, const int *bindex,

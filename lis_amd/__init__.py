@@ -79,6 +79,8 @@ _LISHIP = {
     "liship_spmv_csr_set_variant": (_ci, [_ci]),
     "liship_spmv_ell_f64": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp]),
     "liship_spmv_dia_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "liship_spmv_ell_rows_f64": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp]),
+    "liship_spmv_dia_rows_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _vp]),
     "liship_spmv_ell_dot_f64": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "liship_spmv_dia_dot_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "liship_spmv_jad_f64": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

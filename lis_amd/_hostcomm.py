@@ -27,10 +27,12 @@ def make_callbacks(world):
         C.memmove(recv, flat.ctypes.data, nbytes * world)
         return 0
 
-    delay = float(os.environ.get("LIS_AMD_TEST_HALO_DELAY_MS", "0")) * 1e-3      # tests: a halo that arrives late (odd ranks later still)
+    delay = float(os.environ.get("LIS_AMD_TEST_HALO_DELAY_MS", "0")) * 1e-3      # tests: a halo that arrives late (odd ranks later still),
+    late = [int(os.environ.get("LIS_AMD_TEST_HALO_DELAY_COUNT", "30"))]           # for the first so many exchanges of the process
 
     def exchange(ctx, nneib, neib, sendbuf, sptr, recvbuf, rptr):
-        if delay > 0.0:
+        if delay > 0.0 and late[0] > 0:
+            late[0] -= 1
             time.sleep(delay * (1 + dist.get_rank() % 2))
         reqs, recvs = [], []
         for i in range(nneib):

@@ -353,23 +353,55 @@ LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int
 	return LIS_SUCCESS;
 }
 
+/* the longest run of rows that reference no ghost column (columns >= n): those rows run while the halo is in flight, the boundary
+ * rows after it.  Read from the host layout of whatever format A has (CSR / CSC / ELL / DIA / JAD; BSR and split matrices: none). */
 static void find_inner_rows(LIS_MATRIX A, int *b, int *e)
 {
 	const int n = A->n;
-	int best_b = 0, best_e = 0, run_b = 0;
-	if (A->np == n) { *b = 0; *e = n; return; }                       /* no ghost columns at all */
-	if (A->matrix_type != LIS_MATRIX_CSR || !A->ptr) { *b = 0; *e = 0; return; }   /* other host layouts: no overlap, exchange first */
-	for (int r = 0; r <= n; r++) {
-		int ghost = 1;
-		if (r < n) {
-			ghost = 0;
-			for (int k = A->ptr[r]; k < A->ptr[r + 1]; k++) if (A->index[k] >= n) { ghost = 1; break; }
+	*b = 0; *e = 0;
+	if (A->np == n) { *e = n; return; }                               /* no ghost columns at all */
+	if (A->is_splited || n <= 0) return;
+	unsigned char *ghost = (unsigned char *)calloc((size_t)n + 1, 1);
+	if (!ghost) return;                                               /* (no overlap then: exchange first) */
+	switch (A->matrix_type) {
+	case LIS_MATRIX_CSR:
+		if (!A->ptr) { free(ghost); return; }
+		for (int r = 0; r < n; r++)
+			for (int k = A->ptr[r]; k < A->ptr[r + 1]; k++) if (A->index[k] >= n) { ghost[r] = 1; break; }
+		break;
+	case LIS_MATRIX_CSC:
+		for (int c = n; c < A->np; c++)
+			for (int k = A->ptr[c]; k < A->ptr[c + 1]; k++) ghost[A->index[k]] = 1;
+		break;
+	case LIS_MATRIX_ELL:
+		for (int j = 0; j < A->maxnzr; j++)
+			for (int r = 0; r < n; r++) if (A->index[(size_t)j * n + r] >= n) ghost[r] = 1;
+		break;
+	case LIS_MATRIX_DIA:                                              /* a diagonal reaches the ghosts in the rows where n <= r + offset < np (explicit zeros are read too) */
+		for (int dgl = 0; dgl < A->nnd; dgl++) {
+			const long long o = A->index[dgl];
+			long long lo = (long long)n - o, hi = (long long)A->np - o;
+			if (lo < 0) lo = 0;
+			if (hi > n) hi = n;
+			for (long long r = lo; r < hi; r++) ghost[r] = 1;
 		}
-		if (ghost) {
+		break;
+	case LIS_MATRIX_JAD:
+		for (int j = 0; j < A->maxnzr; j++)
+			for (int sl = 0; sl < A->ptr[j + 1] - A->ptr[j]; sl++) if (A->index[A->ptr[j] + sl] >= n) ghost[A->row[sl]] = 1;
+		break;
+	default:
+		free(ghost);
+		return;
+	}
+	ghost[n] = 1;
+	int best_b = 0, best_e = 0, run_b = 0;
+	for (int r = 0; r <= n; r++)
+		if (ghost[r]) {
 			if (r - run_b > best_e - best_b) { best_b = run_b; best_e = r; }
 			run_b = r + 1;
 		}
-	}
+	free(ghost);
 	*b = best_b; *e = best_e;
 }
 
@@ -573,8 +605,7 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 	if (A->is_splited && !(A->matrix_type == LIS_MATRIX_BSR && A->bnr != A->bnc)) {
 		LISCHK(upload_split(A, d));
 		HIPCHK(liship_stream_synchronize(lisg.stream));
-		find_inner_rows(A, &d->inner_begin, &d->inner_end);
-		if (A->np != A->n) { d->inner_begin = 0; d->inner_end = 0; }     /* ghost columns: exchange first, no overlap */
+		find_inner_rows(A, &d->inner_begin, &d->inner_end);      /* (a split matrix with ghost columns: exchange first, no overlap) */
 		d->ready = 1;
 		return LIS_SUCCESS;
 	}
@@ -705,6 +736,20 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 			HIPCHK(liship_spmv_csr_rows_f64(d->plan, 0, d->inner_begin, d->ptr, d->index, d->value, dx, dy, lisg.stream));
 		if (d->inner_end < d->n)
 			HIPCHK(liship_spmv_csr_rows_f64(d->plan, d->inner_end, d->n, d->ptr, d->index, d->value, dx, dy, lisg.stream));
+		return LIS_SUCCESS;
+	}
+	if (lisg.nprocs > 1 && A->commtable && (d->type == LIS_MATRIX_ELL || d->type == LIS_MATRIX_DIA) && !lisg.no_overlap &&
+	    d->inner_end - d->inner_begin >= d->n / 2) {
+		/* the native ELL / DIA layouts likewise: interior rows under the halo, boundary rows behind it (an odd cut makes that part run
+		 * one row per lane) */
+		LISCHK(lisc_halo_begin(A, dx));
+		for (int part = 0; part < 3; part++) {
+			const int rb = part == 0 ? d->inner_begin : part == 1 ? 0 : d->inner_end, re = part == 0 ? d->inner_end : part == 1 ? d->inner_begin : d->n;
+			if (part == 1) LISCHK(lisc_halo_end(A, dx));
+			if (rb >= re) continue;
+			if (d->type == LIS_MATRIX_ELL) HIPCHK(liship_spmv_ell_rows_f64(d->n, d->maxnzr, d->index, d->ell_codes, d->ell_dict, d->value, dx, dy, rb, re, lisg.stream));
+			else HIPCHK(liship_spmv_dia_rows_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, rb, re, lisg.stream));
+		}
 		return LIS_SUCCESS;
 	}
 	if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));

@@ -37,7 +37,8 @@ void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const doubl
                      const double *__restrict__ x, double *__restrict__ y,
                      const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                      const double *__restrict__ guard = nullptr,
-                     const unsigned char *__restrict__ codes = nullptr, const int *__restrict__ dict = nullptr)
+                     const unsigned char *__restrict__ codes = nullptr, const int *__restrict__ dict = nullptr,
+                     int rb = 0, int re = -1)               // rows [rb, re) of the n (re < 0: all): a multi-rank job's interior / boundary parts
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     __shared__ int dictL[CODED ? 256 : 1];
@@ -45,8 +46,8 @@ void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const doubl
         for (int i = threadIdx.x; i < 256; i += BLOCK) dictL[i] = dict[i];
         __syncthreads();
     }
-    const int r0 = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
-    const bool active = r0 < n;
+    const int r0 = rb + (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
+    const bool active = r0 < (re < 0 ? n : re);
     if (!DOT && !active) return;
     const int r = active ? r0 : 0;                  // idle lanes of the last workgroup shadow row 0 (fused form: they
     double acc[ROWS];                               // must reach the workgroup reduction)
@@ -102,11 +103,11 @@ __global__ __launch_bounds__(BLOCK)
 void spmv_dia_kernel(int n, int ncols, int nnd, const int *__restrict__ off,
                      const double *__restrict__ val, const double *__restrict__ x,
                      double *__restrict__ y, const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                     const double *__restrict__ guard = nullptr)
+                     const double *__restrict__ guard = nullptr, int rb = 0, int re = -1)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
-    const int r0 = (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
-    const bool active = r0 < n;
+    const int r0 = rb + (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
+    const bool active = r0 < (re < 0 ? n : re);
     if (!DOT && !active) return;
     const int r = active ? r0 : 0;
     double acc[ROWS];
@@ -565,6 +566,43 @@ extern "C" int liship_spmv_dia_f64(int n, int ncols, int nnd, const int *off, co
         spmv_dia_kernel<2, 8><<<grid_for(n / 2), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y);
     else
         spmv_dia_kernel<1, 8><<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+
+// Rows [rb, re) only (the array layout is that of all n rows): a multi-rank product runs the rows that reference no ghost column while the
+// halo is in flight and the boundary rows after it -- rows are independent, so the parts write the bits of the whole launch.
+extern "C" int liship_spmv_ell_rows_f64(int n, int maxnzr, const int *idx, const unsigned char *codes, const int *dict, const double *val,
+                                        const double *x, double *y, int rb, int re, void *stream)
+{
+    if (n < 0 || maxnzr < 0 || rb < 0 || re > n) return LISHIP_ERR_ARG;
+    if (rb >= re) return 0;
+    hipStream_t st = as_stream(stream);
+    if (maxnzr == 0) { HIP_TRY(hipMemsetAsync(y + rb, 0, sizeof(double) * (size_t)(re - rb), st)); return 0; }
+    const bool pairs = (n & 1) == 0 && (rb & 1) == 0 && ((re - rb) & 1) == 0 && aligned16(val) && aligned16(y);
+    if (codes && dict && pairs && (reinterpret_cast<uintptr_t>(codes) & 1u) == 0)
+        spmv_ell_kernel<2, 8, 0, true><<<grid_for((re - rb) / 2), BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, nullptr, nullptr, nullptr, codes, dict, rb, re);
+    else if (!idx) return LISHIP_ERR_ARG;
+    else if (pairs && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0)
+        spmv_ell_kernel<2, 8><<<grid_for((re - rb) / 2), BLOCK, 0, st>>>(n, maxnzr, idx, val, x, y, nullptr, nullptr, nullptr, nullptr, nullptr, rb, re);
+    else
+        spmv_ell_kernel<1, 8><<<grid_for(re - rb), BLOCK, 0, st>>>(n, maxnzr, idx, val, x, y, nullptr, nullptr, nullptr, nullptr, nullptr, rb, re);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int liship_spmv_dia_rows_f64(int n, int ncols, int nnd, const int *off, const double *val,
+                                        const double *x, double *y, int rb, int re, void *stream)
+{
+    if (n < 0 || nnd < 0 || ncols < n || rb < 0 || re > n) return LISHIP_ERR_ARG;
+    if (rb >= re) return 0;
+    hipStream_t st = as_stream(stream);
+    if (nnd == 0) { HIP_TRY(hipMemsetAsync(y + rb, 0, sizeof(double) * (size_t)(re - rb), st)); return 0; }
+    if ((n & 1) == 0 && (rb & 1) == 0 && ((re - rb) & 1) == 0 && aligned16(val) && aligned16(y))
+        spmv_dia_kernel<2, 8><<<grid_for((re - rb) / 2), BLOCK, 0, st>>>(n, ncols, nnd, off, val, x, y, nullptr, nullptr, nullptr, rb, re);
+    else
+        spmv_dia_kernel<1, 8><<<grid_for(re - rb), BLOCK, 0, st>>>(n, ncols, nnd, off, val, x, y, nullptr, nullptr, nullptr, rb, re);
     LAUNCH_CHECK();
     return 0;
 }

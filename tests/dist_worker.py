@@ -233,9 +233,31 @@ def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
     assert lib.lis_vector_get_values(vy, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
     scale = orc.spmvh_csr(ptr, idx, np.abs(val), np.abs(xg))[is_:ie] + 1e-300
     assert np.all(np.abs(y - yt[is_:ie]) <= 1e-13 * scale), name
+    scale_y = orc.spmv_csr(ptr, idx, np.abs(val), np.abs(xg))[is_:ie] + 1e-300
+    # the NATIVE ELL / DIA kernels behind the overlapped halo (interior rows while it travels, boundary rows after), overlap on and off:
+    # with the row form switched off a constant-coefficient matrix keeps its layout.
+    if name.startswith("poisson"):
+        lib.dll.lis_amd_set_row_form(0)
+        try:
+            for fmt in ("ell", "dia"):
+                for overlap in (0, 1):
+                    lib.dll.lis_amd_set_overlap(overlap)
+                    Ac = lisdrv.convert(lib, A, "csr")          # (a copy: csr2dia sorts the rows of its INPUT)
+                    B = lisdrv.convert(lib, Ac, fmt)
+                    lib.lis_matrix_destroy(Ac)
+                    vb2, vy2 = lisdrv.new_vector(lib, B, None), lisdrv.new_vector(lib, B, None)
+                    assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(xg[is_:ie]).ctypes.data_as(capi.P_DBL), vb2) == 0
+                    assert lib.lis_matvec(B, vb2, vy2) == 0, (name, fmt)
+                    assert lib.lis_vector_get_values(vy2, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
+                    assert np.all(np.abs(y - yg[is_:ie]) <= 1e-13 * scale_y), (name, fmt, overlap)
+                    if fmt == "ell":
+                        assert np.array_equal(y, yg[is_:ie]), (name, fmt, overlap)
+                    lib.lis_vector_destroy(vb2); lib.lis_vector_destroy(vy2); lib.lis_matrix_destroy(B)
+        finally:
+            lib.dll.lis_amd_set_row_form(1)
+            lib.dll.lis_amd_set_overlap(1)
     # the same product from every other storage format of the local block (ghost columns included): same rows to
     # 1e-13 relative (CSC / BSR / DIA add a row's terms in another order), every format behind the halo exchange
-    scale_y = orc.spmv_csr(ptr, idx, np.abs(val), np.abs(xg))[is_:ie] + 1e-300
     for fmt in ("csc", "ell", "jad", "bsr", "dia"):
         if fmt == "dia" and not name.startswith("poisson"):
             continue

@@ -2020,6 +2020,8 @@ struct liship_csr_plan_s {
     int dom_lo, dom_hi;  // rows [dom_lo, dom_hi - 128] may start a wavefront that gathers x at the dominant offsets without leaving x[0, n)
 };
 
+static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, const double *val8);
+
 extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
 extern "C" int liship_spmv_csr_set_index_codes(int on) { g_index_codes = on ? 1 : 0; return 0; }
 // Opt-in, off by default: the part of a row that does not fit the LDS stage (beyond ~2100 entries) is added by a workgroup-wide
@@ -2310,6 +2312,10 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
     }
     p->npat = npat; p->ptab_len = npat + 1 + total;
     for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
+    if (p->ptab8) {                                 // the dominant pattern, offsets only (values join with the value records)
+        int rec8[PAT7_MAX * 8];
+        if (hipMemcpy(rec8, p->ptab8, sizeof(int) * 8 * (size_t)npat, hipMemcpyDeviceToHost) == hipSuccess) build_dominant(p, npat, rec8, nullptr);
+    }
     return 0;
 }
 // number of row patterns when the plan keeps one byte per row, 0 otherwise
@@ -2332,7 +2338,7 @@ __global__ void rowpat_histogram(int n, const unsigned char *__restrict__ rowpat
 // The dominant pattern of a plan with value records and the other patterns' records in ITS slots (spmv_csr_valuerec_dom_kernel).
 // rec32: 8 ints per pattern (7 byte offsets, the tail repeating the last one; length), val8: 8 doubles per pattern.  Kept when
 // one pattern carries at least half of the rows; never an error when it does not.
-static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, const double *val8)
+static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, const double *val8 /* NULL: offsets only */)
 {
     if (p->drec) { (void)hipFree(p->drec); p->drec = nullptr; }
     if (p->n < 4 * WAVE || npat <= 0 || npat > PAT7_MAX) return;
@@ -2349,7 +2355,7 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
     const int *od = rec32 + 8 * dom;
     const int lend = od[7];
     DomRec D;
-    for (int u = 0; u < 7; u++) { D.off[u] = od[u]; D.val[u] = val8[8 * dom + u]; }
+    for (int u = 0; u < 7; u++) { D.off[u] = od[u]; D.val[u] = val8 ? val8[8 * dom + u] : 0.0; }
     D.pat = dom; D.mask = (1 << lend) - 1; D.pad = 0;
     double img[PAT7_MAX * 8];
     for (int i = 0; i < npat; i++) {
@@ -2360,7 +2366,7 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
         for (int u = 0; u < 8; u++) out[u] = 0.0;
         int j = 0;
         for (int sl = 0; sl < lend && j < leni; sl++)
-            if (oi[j] == od[sl]) { mask |= 1u << sl; out[1 + sl] = val8[8 * i + j]; j++; }
+            if (oi[j] == od[sl]) { mask |= 1u << sl; out[1 + sl] = val8 ? val8[8 * i + j] : 0.0; j++; }
         if (j != leni) mask = 0x80u;                      // not a subsequence of the dominant pattern: its rows take their own records
         unsigned long long bits = mask;
         memcpy(out, &bits, 8);
@@ -2382,7 +2388,6 @@ static int install_value_records(liship_csr_plan_s *p, int npat, const int *rec3
     hipError_t e = hipMalloc(&p->vrec, 96 * (size_t)npat);
     if (e == hipSuccess) e = hipMemcpy(p->vrec, img, 96 * (size_t)npat, hipMemcpyHostToDevice);
     if (e != hipSuccess) { if (p->vrec) (void)hipFree(p->vrec); p->vrec = nullptr; return (int)e; }
-    build_dominant(p, npat, rec32, val8);
     return 0;
 }
 
@@ -2453,6 +2458,7 @@ static int refine_patterns_by_values(liship_csr_plan_s *p, const int *ptr, const
     p->rowpat = newpat; p->ptab = d_tab; p->ptab8 = d_rec;
     p->npat = npat; p->ptab_len = npat + 1 + total;
     for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
+    build_dominant(p, npat, rec, hv);               // (on the refined pattern bytes)
     return 0;
 }
 
@@ -2603,14 +2609,16 @@ extern "C" int liship_csr_plan_encode_row_values(liship_csr_plan_t p, const int 
     if (vr) (void)hipFree(vr);
     if (rc != 0) return rc;
     if (bad != 0) return refine_patterns_by_values(p, ptr, val, hr, st);     // rows of one offset pattern with different values
-    return install_value_records(p, p->npat, hr, hv);
+    rc = install_value_records(p, p->npat, hr, hv);
+    if (rc == 0) build_dominant(p, p->npat, hr, hv);
+    return rc;
 }
 // 1 (2: wide records) when the plan keeps the rows' values in the pattern records (the products then read neither values nor indices), else 0
 extern "C" int liship_csr_plan_value_records(liship_csr_plan_t p)
 { return (p && p->rowpat && p->ptab8 && p->vrec) ? 1 : (p && p->rowpat && p->vrecw) ? 2 : 0; }        // 2: the wide records (rows of up to 32 entries)
 extern "C" int liship_spmv_csr_set_row_values(int on) { g_row_values = on ? 1 : 0; return 0; }
 // 1 when the plan also names a dominant pattern (spmv_csr_valuerec_dom_kernel), else 0
-extern "C" int liship_csr_plan_dominant_pattern(liship_csr_plan_t p) { return (p && p->vrec && p->drec) ? 1 : 0; }
+extern "C" int liship_csr_plan_dominant_pattern(liship_csr_plan_t p) { return (p && p->ptab8 && p->drec) ? (p->vrec ? 1 : 2) : 0; }      // 2: offsets only (no value records)
 
 // Block-local columns for the products kernel (see spmv_csr_local_kernel): setup-time, optional, never an error when the
 // matrix does not qualify.  Kept when the lists cover >= 90 % of the non-zeros and hold at most half as many columns as
@@ -2826,7 +2834,10 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.rowpat, a.vrecw, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0});
         return;
     }
-    if (a.rowpat && a.ptab8 && g_variant == 0) {      // patterns of at most 7 offsets: gathers ahead of the slice
+    if (a.rowpat && a.ptab8 && (g_variant & ~0x20000000) == 0) {      // patterns of at most 7 offsets: gathers ahead of the slice
+        // (round 3, measured and dropped: a wavefront per 64-row line segment, four lines per workgroup, the dominant pattern's gathers issued
+        //  with the pattern bytes -- the shape that paid for the value records -- is bit-identical and 1.2 % faster at 512^3, 1.842 -> 1.821 ms:
+        //  this kernel is bound by its value stream, not by x: profiles/r03_valuerec_dom_experiments.txt)
         constexpr Geometry g = kGeom[G];
         spmv_csr_pattern7_kernel<g.block, g.work, 0><<<a.nb, g.block, 0, a.st>>>(
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);

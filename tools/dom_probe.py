@@ -34,11 +34,18 @@ FORMS = {"one row/lane": 0x20000000, "two rows/lane": 0x20004000, "dominant plai
 if os.environ.get("DOM_FORMS"):
     FORMS = {k: v for k, v in FORMS.items() if k in os.environ["DOM_FORMS"].split(",")}
 lib.liship_spmv_csr_set_row_values(0)
+lib.liship_spmv_csr_set_variant(0x20000000)
 check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y2.ptr, None))
-ms = timed(lib, lambda: check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y2.ptr, None)), iters=30, warm=300)
-print(f"{'values streamed':16s} {ms:.4f} ms  {2e-6 * nnz / ms:.1f} GFLOP/s", flush=True)
-lib.liship_spmv_csr_set_row_values(1)
 ref = y2.to_host().view(np.uint64)
+for rep in range(reps):
+    for name, var in (("values streamed", 0),):
+        lib.liship_spmv_csr_set_variant(var)
+        check(lib.liship_memset(y.ptr, 0xff, 8 * n, None))
+        ms = timed(lib, lambda: check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None)), iters=30, warm=100 if rep == 0 else 10)
+        same = bool(np.array_equal(y.to_host().view(np.uint64), ref))
+        print(f"{name:16s} {ms:.4f} ms  {2e-6 * nnz / ms:.1f} GFLOP/s  {(8.0 * nnz + 17.0 * n) / ms / 1e6 / 8000:.3f} of 8 TB/s on 8 B/nnz + 17 B/row  bit-identical: {same}", flush=True)
+lib.liship_spmv_csr_set_variant(0)
+lib.liship_spmv_csr_set_row_values(1)
 for rep in range(reps):
     for name, var in FORMS.items():
         lib.liship_spmv_csr_set_variant(var)

@@ -38,6 +38,11 @@ LIS_INT lis_amd_get_residency(void);
 LIS_INT lis_amd_set_coherence(LIS_INT lazy);
 /* test / diagnostic hooks: protection of v->value's pages (0 read + write: host holds the data; 1 read-only: both agree; 2 none: the HBM
  * copy holds it; -1: plain memory), and how many read / write faults the handler has served */
+/* arrays of A (a matrix made by lis_matrix_convert in HBM) that no host access has asked for yet: they exist in HBM only (tests) */
+LIS_INT lis_amd_matrix_lazy_arrays(LIS_MATRIX A);
+/* lis_matrix_convert of a CSR matrix that lives in HBM builds ELL / DIA / CSC / BSR there (kernels/convert.hip: the reference's arrays, bit for
+ * bit) and leaves the new matrix's host arrays to their first touch (1, default); 0 (env LIS_AMD_NO_DEVICE_CONVERT=1): always on the host arrays */
+LIS_INT lis_amd_set_device_convert(LIS_INT on);
 LIS_INT lis_amd_vector_page_state(LIS_VECTOR v);
 LIS_INT lis_amd_vector_page_protect(LIS_VECTOR v, LIS_INT state);      /* force a protection (tests of the fault handler without a GPU) */
 LIS_INT lis_amd_page_faults(LIS_INT *reads, LIS_INT *writes);

@@ -364,6 +364,30 @@ int  liship_gather_f64(int count, const int *export_index, const double *x, doub
  * tindex / tvalue: nnz entries, work: ncols + nnz ints.  Setup-time (once per matrix). */
 int  liship_csr_transpose_f64(int nrows, int ncols, int nnz, const int *ptr, const int *index, const double *value,
                               int *tptr, int *tindex, double *tvalue, int *work, void *stream);
+/* ---- storage-format conversions of a CSR matrix that lives in HBM (kernels/convert.hip): the arrays the reference's host routines
+ * build (src/matrix/lis_matrix_ell.c:958-1070, lis_matrix_dia.c:1191-1304, lis_matrix_bsr.c:351-552), bit for bit, from device arrays.
+ * liship_csr_row_facts: facts[0] = longest row, facts[1] = 1 when some row is not in ascending column order (two device ints).
+ * ELL: value 0 on the row's own column pads short rows.  DIA (rows in ascending column order): liship_csr_dia_offsets marks the
+ * offsets that occur (used: n + ncols ints; slot: n + ncols + 1; scratch: (n + ncols) / 4096 + 4 long long) and returns their number,
+ * liship_csr_to_dia writes them ascending and value[d * n + i].  BSR: distinct block columns of a block row in first-seen order, blocks
+ * column-major; liship_csr_bsr_count gives bptr and the block count (-1: a block row with more than 96 distinct blocks; count: nr + 1
+ * ints, scratch: nr / 4096 + 4 long long).  The *_rows forms build the CSR row form of an ELL / DIA matrix (lis_device.c): the terms of
+ * a row in the format's own order, padding and explicit zeros included. */
+int  liship_csr_row_facts(int n, const int *ptr, const int *index, int *facts, void *stream);
+int  liship_csr_to_ell(int n, int maxnzr, const int *ptr, const int *index, const double *value, int *ell_index, double *ell_value, void *stream);
+int  liship_csr_to_ell_rows(int n, int maxnzr, const int *ptr, const int *index, const double *value, int *rptr, int *rindex, double *rvalue, void *stream);
+int  liship_csr_dia_offsets(int n, int ncols, const int *ptr, const int *index, int *used, int *slot, long long *scratch, int *nnd, void *stream);
+int  liship_csr_to_dia(int n, int ncols, int nnd, const int *ptr, const int *index, const double *value, const int *used, const int *slot,
+                       int *offsets, double *dia_value, void *stream);
+int  liship_dia_row_counts(int n, int ncols, int nnd, const int *offsets, int *count, int *rptr, long long *scratch, int *rnnz, void *stream);
+int  liship_dia_to_rows(int n, int ncols, int nnd, const int *offsets, const double *dia_value, const int *rptr, int *rindex, double *rvalue, void *stream);
+int  liship_csr_bsr_count(int n, int np, int bnr, int bnc, const int *ptr, const int *index, int *count, int *bptr, long long *scratch, int *bnnz, void *stream);
+int  liship_csr_to_bsr(int n, int bnr, int bnc, int bnnz, const int *ptr, const int *index, const double *value, const int *bptr,
+                       int *bindex, double *bsr_value, void *stream);
+/* JAD from the length-sorted row order perm[n] and the jagged-diagonal starts jptr[maxnzr + 1] (both made on the host: the order is the
+ * reference's unstable quicksort, lis_convert.c): entry j of row perm[s] goes to [jptr[j] + s] */
+int  liship_csr_to_jad(int n, const int *perm, const int *jptr, const int *ptr, const int *index, const double *value,
+                       int *jad_index, double *jad_value, void *stream);
 /* reverse halo: y[export_index[i]] += wr[i], indices unique within one call  (lis_reduce, lis_matrix_mpi.c:988-996) */
 int  liship_scatter_add_f64(int count, const int *export_index, const double *wr, double *y, void *stream);
 

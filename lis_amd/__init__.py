@@ -45,6 +45,16 @@ _LISHIP = {
     "liship_event_destroy": (_ci, [_vp]),
     "liship_event_record": (_ci, [_vp, _vp]),
     "liship_event_synchronize": (_ci, [_vp]),
+    "liship_csr_row_facts": (_ci, [_ci, _vp, _vp, _vp, _vp]),
+    "liship_csr_to_ell": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_csr_to_ell_rows": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_csr_dia_offsets": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_csr_to_dia": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_dia_row_counts": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_dia_to_rows": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_csr_bsr_count": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_csr_to_bsr": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_csr_to_jad": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_stream_wait_event": (_ci, [_vp, _vp]),
     "liship_timer_create": (_ci, [_pvp]),
     "liship_timer_destroy": (_ci, [_vp]),

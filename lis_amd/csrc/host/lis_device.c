@@ -187,6 +187,7 @@ static void copy_threads(void *dst, const void *src, size_t bytes)
 	}
 }
 
+static LIS_INT staged_d2h(void *dst, const void *src, size_t bytes);
 static LIS_INT staged_h2d(void *dst, const void *src, size_t bytes)
 {
 	LISCHK(stage_ready());
@@ -201,6 +202,8 @@ static LIS_INT staged_h2d(void *dst, const void *src, size_t bytes)
 	}
 	return LIS_SUCCESS;
 }
+
+LIS_INT lisd_staged_d2h(void *dst, const void *src, size_t bytes) { return staged_d2h(dst, src, bytes); }
 
 static LIS_INT staged_d2h(void *dst, const void *src, size_t bytes)
 {
@@ -599,6 +602,7 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_init());
 	if (A->status < LIS_MATRIX_CSR) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is not assembled\n");
+	LISCHK(lisp_fill_matrix(A));
 	d->n = A->n; d->np = A->np; d->nnz = A->nnz;
 	d->type = A->matrix_type;
 	const size_t n = (size_t)A->n;
@@ -662,6 +666,7 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 void lisd_mat_free(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
+	(void)lisp_fill_matrix(A);         /* host arrays still held in HBM only (a matrix converted there) come home before the copy goes */
 	if (d->plan) (void)liship_csr_plan_destroy(d->plan);
 	if (d->u_plan) (void)liship_csr_plan_destroy(d->u_plan);
 	(void)liship_free(d->u_ptr); (void)liship_free(d->u_index); (void)liship_free(d->u_value); (void)liship_free(d->dsplit); (void)liship_free(d->jw);
@@ -673,6 +678,230 @@ void lisd_mat_free(LIS_MATRIX A)
 	(void)liship_free(d->export_index); (void)liship_free(d->ws); free(d->export_run);
 	(void)liship_free(d->sx); (void)liship_free(d->sy);
 	memset(d, 0, sizeof(*d));
+}
+
+/* ------------------------------------------------------------------ conversions in HBM (kernels/convert.hip)
+ * lis_matrix_convert(Ain, Aout) with Ain = a CSR matrix whose HBM copy exists: the target layout is built FROM that copy by kernels --
+ * the arrays the host routines of lis_convert.c build, bit for bit -- and becomes both Aout's HBM copy and the source of Aout's HOST
+ * arrays.  Those the Lis API promises (A->index, A->value ...), but a program that only multiplies never reads them: they get address
+ * space without access (lis_pages.c), bound to the device buffer that holds their contents, and come home on their first touch.
+ * What the product of the new matrix runs on is decided as mat_upload decides it: the constant-coefficient row form (value records)
+ * for ELL / DIA where the values allow it, CSC as CSR rows in ascending column order, else the native arrays.
+ * *done = 0: not a case for this path (the caller converts on the host).  Single-rank; DIA and CSC want the source rows in ascending
+ * column order (csr2dia would sort them in place otherwise -- the host routine does that); rows of more than 96 distinct blocks: host. */
+static int device_few_distinct_values(const double *dval, size_t count)
+{
+	double head[4096];
+	const size_t take = count < 4096 ? count : 4096;
+	if (take == 0) return 0;
+	if (liship_memcpy_d2h(head, dval, take * sizeof(double), lisg.stream) || liship_stream_synchronize(lisg.stream)) return 0;
+	return few_distinct_values(head, take);
+}
+
+static void *lazy_host(LIS_MATRIX A, size_t bytes, void *dev, int own_dev) { return lisp_alloc_lazy(A, bytes, dev, own_dev); }
+
+LIS_INT lisd_convert_csr(LIS_MATRIX Ain, LIS_MATRIX Aout, int *done)
+{
+	*done = 0;
+	lisd_mat *sd = MDEV(Ain);
+	const LIS_INT want = Aout->matrix_type;
+	if (want != LIS_MATRIX_ELL && want != LIS_MATRIX_DIA && want != LIS_MATRIX_CSC && want != LIS_MATRIX_BSR && want != LIS_MATRIX_JAD) return LIS_SUCCESS;
+	if (lisg.no_device_convert || lisg.nprocs > 1 || !lisg.device_ready || sd->device_only ||
+	    Ain->matrix_type != LIS_MATRIX_CSR || Ain->is_splited || Ain->np != Ain->n || Ain->n <= 0 || Ain->nnz <= 0)
+		return LIS_SUCCESS;
+	if (!sd->ready) LISCHK(lisd_mat_ready(Ain));          /* (an upload of the source costs a fraction of a pass of the host routine over it) */
+	if (sd->type != LIS_MATRIX_CSR || !sd->ptr || !sd->index || !sd->value) return LIS_SUCCESS;
+	const int n = Ain->n, nnz = Ain->nnz;
+	lisd_mat *d = MDEV(Aout);
+	int *facts = NULL, hfacts[2] = {0, 0};
+	HIPCHK(lisd_malloc((void **)&facts, 2 * sizeof(int)));
+	int rc = liship_csr_row_facts(n, sd->ptr, sd->index, facts, lisg.stream);
+	if (!rc) rc = liship_memcpy_d2h(hfacts, facts, sizeof(hfacts), lisg.stream);
+	if (!rc) rc = liship_stream_synchronize(lisg.stream);
+	(void)liship_free(facts);
+	HIPCHK(rc);
+	const int maxlen = hfacts[0], unsorted = hfacts[1];
+	LIS_INT err = LIS_SUCCESS;
+	memset(d, 0, sizeof(*d));
+	d->n = n; d->np = Ain->np; d->nnz = nnz;
+
+	if (want == LIS_MATRIX_ELL) {
+		const int maxnzr = maxlen;
+		if ((long long)n * maxnzr >= 0x7fffffffLL) return LIS_SUCCESS;
+		const size_t slots = (size_t)n * (size_t)maxnzr;
+		int *eidx = NULL; double *eval = NULL;
+		HIPCHK(lisd_malloc((void **)&eidx, sizeof(int) * (slots ? slots : 1)));
+		if (lisd_malloc((void **)&eval, sizeof(double) * (slots ? slots : 1))) { (void)liship_free(eidx); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert\n"); }
+		HIPCHK(liship_csr_to_ell(n, maxnzr, sd->ptr, sd->index, sd->value, eidx, eval, lisg.stream));
+		int rowform = 0;
+		if (!lisg.no_row_form && !lisg.no_value_records && !lisg.no_row_patterns && !lisg.no_index_codes && maxnzr >= 1 && maxnzr <= 32 &&
+		    device_few_distinct_values(sd->value, (size_t)nnz)) {
+			int *rptr = NULL, *ridx = NULL; double *rval = NULL;
+			if (!lisd_malloc((void **)&rptr, sizeof(int) * ((size_t)n + 1)) && !lisd_malloc((void **)&ridx, sizeof(int) * slots) && !lisd_malloc((void **)&rval, sizeof(double) * slots)) {
+				HIPCHK(liship_csr_to_ell_rows(n, maxnzr, sd->ptr, sd->index, sd->value, rptr, ridx, rval, lisg.stream));
+				d->ptr = rptr; d->index = ridx; d->value = rval;
+				err = lisd_csr_plan(&d->plan, n, d->ptr, d->index, d->value);
+				if (!err && liship_csr_plan_value_records(d->plan)) { rowform = 1; d->type = LIS_MATRIX_CSR; d->nnz = (int)slots; }
+			}
+			if (!rowform) {
+				if (d->plan) { (void)liship_csr_plan_destroy(d->plan); d->plan = NULL; }
+				(void)liship_free(rptr); (void)liship_free(ridx); (void)liship_free(rval);
+				d->ptr = NULL; d->index = NULL; d->value = NULL;
+				if (err && err != LIS_ERR_OUT_OF_MEMORY) { (void)liship_free(eidx); (void)liship_free(eval); return err; }
+				err = LIS_SUCCESS;
+			}
+		}
+		if (!rowform) {
+			d->type = LIS_MATRIX_ELL; d->maxnzr = maxnzr; d->index = eidx; d->value = eval;
+			if (!lisg.no_index_codes) {
+				int nd = 0;
+				rc = liship_ell_encode_indices(n, maxnzr, d->index, &d->ell_codes, &d->ell_dict, &nd, lisg.stream);
+				if (rc) { (void)liship_free(d->ell_codes); (void)liship_free(d->ell_dict); d->ell_codes = NULL; d->ell_dict = NULL; }
+			}
+		}
+		d->maxnzr = maxnzr;
+		LIS_INT *hi = (LIS_INT *)lazy_host(Aout, sizeof(int) * slots, eidx, rowform);
+		LIS_SCALAR *hv = (LIS_SCALAR *)lazy_host(Aout, sizeof(double) * slots, eval, rowform);
+		if (!hi || !hv) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert: address space\n");
+		err = lis_matrix_set_ell(maxnzr, hi, hv, Aout);
+	} else if (want == LIS_MATRIX_DIA) {
+		if (unsorted) return LIS_SUCCESS;
+		const int span = n + Ain->np;
+		int *used = NULL, *slot = NULL, *offs = NULL, nnd = 0; long long *scratch = NULL; double *dval = NULL;
+		HIPCHK(lisd_malloc((void **)&used, sizeof(int) * (size_t)span));
+		if (lisd_malloc((void **)&slot, sizeof(int) * ((size_t)span + 1)) || lisd_malloc((void **)&scratch, sizeof(long long) * ((size_t)span / 4096 + 4))) {
+			(void)liship_free(used); (void)liship_free(slot); (void)liship_free(scratch);
+			return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert\n");
+		}
+		rc = liship_csr_dia_offsets(n, Ain->np, sd->ptr, sd->index, used, slot, scratch, &nnd, lisg.stream);
+		if (!rc && (nnd <= 0 || (long long)n * nnd >= 0x7fffffffLL)) { (void)liship_free(used); (void)liship_free(slot); (void)liship_free(scratch); return LIS_SUCCESS; }
+		if (!rc) rc = lisd_malloc((void **)&offs, sizeof(int) * (size_t)nnd);
+		if (!rc) rc = lisd_malloc((void **)&dval, sizeof(double) * (size_t)n * (size_t)nnd);
+		if (!rc) rc = liship_csr_to_dia(n, Ain->np, nnd, sd->ptr, sd->index, sd->value, used, slot, offs, dval, lisg.stream);
+		(void)liship_stream_synchronize(lisg.stream);
+		(void)liship_free(used); (void)liship_free(slot);
+		if (rc) { (void)liship_free(scratch); (void)liship_free(offs); (void)liship_free(dval); HIPCHK(rc); }
+		int rowform = 0;
+		if (!lisg.no_row_form && !lisg.no_value_records && !lisg.no_row_patterns && !lisg.no_index_codes && nnd <= 32 &&
+		    device_few_distinct_values(sd->value, (size_t)nnz)) {
+			int *count = NULL, *rptr = NULL, *ridx = NULL, rnnz = 0; double *rval = NULL;
+			if (!lisd_malloc((void **)&count, sizeof(int) * (size_t)n) && !lisd_malloc((void **)&rptr, sizeof(int) * ((size_t)n + 1)) &&
+			    !liship_dia_row_counts(n, Ain->np, nnd, offs, count, rptr, scratch, &rnnz, lisg.stream) && rnnz > 0 &&
+			    !lisd_malloc((void **)&ridx, sizeof(int) * (size_t)rnnz) && !lisd_malloc((void **)&rval, sizeof(double) * (size_t)rnnz) &&
+			    !liship_dia_to_rows(n, Ain->np, nnd, offs, dval, rptr, ridx, rval, lisg.stream)) {
+				d->ptr = rptr; d->index = ridx; d->value = rval;
+				err = lisd_csr_plan(&d->plan, n, d->ptr, d->index, d->value);
+				if (!err && liship_csr_plan_value_records(d->plan)) { rowform = 1; d->type = LIS_MATRIX_CSR; d->nnz = rnnz; }
+			}
+			(void)liship_free(count);
+			if (!rowform) {
+				if (d->plan) { (void)liship_csr_plan_destroy(d->plan); d->plan = NULL; }
+				(void)liship_free(rptr); (void)liship_free(ridx); (void)liship_free(rval);
+				d->ptr = NULL; d->index = NULL; d->value = NULL;
+				if (err && err != LIS_ERR_OUT_OF_MEMORY) { (void)liship_free(scratch); (void)liship_free(offs); (void)liship_free(dval); return err; }
+				err = LIS_SUCCESS;
+			}
+		}
+		(void)liship_free(scratch);
+		if (!rowform) { d->type = LIS_MATRIX_DIA; d->index = offs; d->value = dval; }
+		d->nnd = nnd;
+		LIS_INT *hi = (LIS_INT *)lazy_host(Aout, sizeof(int) * (size_t)nnd, offs, rowform);
+		LIS_SCALAR *hv = (LIS_SCALAR *)lazy_host(Aout, sizeof(double) * (size_t)n * (size_t)nnd, dval, rowform);
+		if (!hi || !hv) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert: address space\n");
+		err = lis_matrix_set_dia(nnd, hi, hv, Aout);
+	} else if (want == LIS_MATRIX_CSC) {
+		if (unsorted) return LIS_SUCCESS;
+		/* the host arrays: A^T row by row = A column by column, rows ascending inside a column (transpose.hip); the product's arrays: A's
+		 * own rows, which ARE in ascending column order here -- the order the reference's serial CSC sweep adds them in (lis_matvec_csc.c:128-144) */
+		int *tptr = NULL, *tidx = NULL; double *tval = NULL; void *work = NULL;
+		const size_t wbytes = sizeof(int) * ((size_t)Ain->np + (size_t)nnz) + 16;      /* (as lis_matvech.c sizes it) */
+		if (lisd_malloc((void **)&tptr, sizeof(int) * ((size_t)Ain->np + 1)) || lisd_malloc((void **)&tidx, sizeof(int) * (size_t)nnz) ||
+		    lisd_malloc((void **)&tval, sizeof(double) * (size_t)nnz) || lisd_malloc(&work, wbytes)) {
+			(void)liship_free(tptr); (void)liship_free(tidx); (void)liship_free(tval); (void)liship_free(work);
+			return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert\n");
+		}
+		rc = liship_csr_transpose_f64(n, Ain->np, nnz, sd->ptr, sd->index, sd->value, tptr, tidx, tval, work, lisg.stream);
+		if (!rc) rc = liship_stream_synchronize(lisg.stream);
+		(void)liship_free(work);
+		if (!rc) rc = lisd_malloc((void **)&d->ptr, sizeof(int) * ((size_t)n + 1));
+		if (!rc) rc = lisd_malloc((void **)&d->index, sizeof(int) * (size_t)nnz);
+		if (!rc) rc = lisd_malloc((void **)&d->value, sizeof(double) * (size_t)nnz);
+		if (!rc) rc = liship_memcpy_d2d(d->ptr, sd->ptr, sizeof(int) * ((size_t)n + 1), lisg.stream);
+		if (!rc) rc = liship_memcpy_d2d(d->index, sd->index, sizeof(int) * (size_t)nnz, lisg.stream);
+		if (!rc) rc = liship_memcpy_d2d(d->value, sd->value, sizeof(double) * (size_t)nnz, lisg.stream);
+		if (rc) { (void)liship_free(tptr); (void)liship_free(tidx); (void)liship_free(tval); HIPCHK(rc); }
+		d->type = LIS_MATRIX_CSR;
+		err = lisd_csr_plan(&d->plan, n, d->ptr, d->index, d->value);
+		if (err) { (void)liship_free(tptr); (void)liship_free(tidx); (void)liship_free(tval); return err; }
+		LIS_INT *hp = (LIS_INT *)lazy_host(Aout, sizeof(int) * ((size_t)Ain->np + 1), tptr, 1);
+		LIS_INT *hi = (LIS_INT *)lazy_host(Aout, sizeof(int) * (size_t)nnz, tidx, 1);
+		LIS_SCALAR *hv = (LIS_SCALAR *)lazy_host(Aout, sizeof(double) * (size_t)nnz, tval, 1);
+		if (!hp || !hi || !hv) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert: address space\n");
+		err = lis_matrix_set_csc(nnz, hp, hi, hv, Aout);
+	} else if (want == LIS_MATRIX_JAD) {
+		/* the row order is the reference's unstable quicksort of the row lengths: made on the host (its recursion spread over the threads,
+		 * lis_convert.c), like the diagonal starts; the entries are placed here.  The product's arrays are A's own: the j-th entry of a
+		 * row sits on jagged diagonal j, so rows in their original order, entries in theirs, is the order lis_matvec_jad adds them in */
+		LIS_INT maxnzr = 0, *perm = NULL, *jptr = NULL;
+		LISCHK(lisi_jad_order(Ain, &maxnzr, &perm, &jptr));
+		int *dperm = NULL, *djptr = NULL, *jidx = NULL; double *jval = NULL;
+		rc = lisd_malloc((void **)&dperm, sizeof(int) * (size_t)n);
+		if (!rc) rc = lisd_malloc((void **)&djptr, sizeof(int) * ((size_t)maxnzr + 1));
+		if (!rc) rc = lisd_malloc((void **)&jidx, sizeof(int) * (size_t)nnz);
+		if (!rc) rc = lisd_malloc((void **)&jval, sizeof(double) * (size_t)nnz);
+		if (!rc) rc = liship_memcpy_h2d(dperm, perm, sizeof(int) * (size_t)n, lisg.stream);
+		if (!rc) rc = liship_memcpy_h2d(djptr, jptr, sizeof(int) * ((size_t)maxnzr + 1), lisg.stream);
+		if (!rc) rc = liship_csr_to_jad(n, dperm, djptr, sd->ptr, sd->index, sd->value, jidx, jval, lisg.stream);
+		if (!rc) rc = lisd_malloc((void **)&d->ptr, sizeof(int) * ((size_t)n + 1));
+		if (!rc) rc = lisd_malloc((void **)&d->index, sizeof(int) * (size_t)nnz);
+		if (!rc) rc = lisd_malloc((void **)&d->value, sizeof(double) * (size_t)nnz);
+		if (!rc) rc = liship_memcpy_d2d(d->ptr, sd->ptr, sizeof(int) * ((size_t)n + 1), lisg.stream);
+		if (!rc) rc = liship_memcpy_d2d(d->index, sd->index, sizeof(int) * (size_t)nnz, lisg.stream);
+		if (!rc) rc = liship_memcpy_d2d(d->value, sd->value, sizeof(double) * (size_t)nnz, lisg.stream);
+		if (!rc) rc = liship_stream_synchronize(lisg.stream);
+		(void)liship_free(dperm); (void)liship_free(djptr);
+		if (rc) { free(perm); free(jptr); (void)liship_free(jidx); (void)liship_free(jval); HIPCHK(rc); }
+		d->type = LIS_MATRIX_CSR;
+		err = lisd_csr_plan(&d->plan, n, d->ptr, d->index, d->value);
+		if (err) { free(perm); free(jptr); (void)liship_free(jidx); (void)liship_free(jval); return err; }
+		LIS_INT *hi = (LIS_INT *)lazy_host(Aout, sizeof(int) * (size_t)nnz, jidx, 1);
+		LIS_SCALAR *hv = (LIS_SCALAR *)lazy_host(Aout, sizeof(double) * (size_t)nnz, jval, 1);
+		if (!hi || !hv) { free(perm); free(jptr); return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert: address space\n"); }
+		err = lis_matrix_set_jad(nnz, maxnzr, perm, jptr, hi, hv, Aout);
+	} else {                                              /* BSR */
+		const int bnr = Aout->conv_bnr, bnc = Aout->conv_bnc;
+		if (bnr < 1 || bnc < 1) return LIS_SUCCESS;
+		const int nr = 1 + (n - 1) / bnr, pad = (bnc - n % bnc) % bnc;
+		int *count = NULL, *bptr = NULL, *bindex = NULL, bnnz = 0; long long *scratch = NULL; double *bval = NULL;
+		if (lisd_malloc((void **)&count, sizeof(int) * ((size_t)nr + 1)) || lisd_malloc((void **)&bptr, sizeof(int) * ((size_t)nr + 1)) ||
+		    lisd_malloc((void **)&scratch, sizeof(long long) * ((size_t)nr / 4096 + 4))) {
+			(void)liship_free(count); (void)liship_free(bptr); (void)liship_free(scratch);
+			return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert\n");
+		}
+		rc = liship_csr_bsr_count(n, Ain->np, bnr, bnc, sd->ptr, sd->index, count, bptr, scratch, &bnnz, lisg.stream);
+		(void)liship_free(count); (void)liship_free(scratch);
+		if (rc || bnnz <= 0 || (long long)bnnz * bnr * bnc >= 0x7fffffffLL) { (void)liship_free(bptr); if (rc) HIPCHK(rc); return LIS_SUCCESS; }
+		if (!rc) rc = lisd_malloc((void **)&bindex, sizeof(int) * (size_t)bnnz);
+		if (!rc) rc = lisd_malloc((void **)&bval, sizeof(double) * (size_t)bnnz * (size_t)bnr * (size_t)bnc);
+		if (!rc) rc = liship_csr_to_bsr(n, bnr, bnc, bnnz, sd->ptr, sd->index, sd->value, bptr, bindex, bval, lisg.stream);
+		if (rc) { (void)liship_free(bptr); (void)liship_free(bindex); (void)liship_free(bval); HIPCHK(rc); }
+		d->type = LIS_MATRIX_BSR; d->nr = nr; d->bnr = bnr; d->bnc = bnc;
+		d->bptr = bptr; d->bindex = bindex; d->value = bval;
+		LIS_INT *hp = (LIS_INT *)lazy_host(Aout, sizeof(int) * ((size_t)nr + 1), bptr, 0);
+		LIS_INT *hi = (LIS_INT *)lazy_host(Aout, sizeof(int) * (size_t)bnnz, bindex, 0);
+		LIS_SCALAR *hv = (LIS_SCALAR *)lazy_host(Aout, sizeof(double) * (size_t)bnnz * (size_t)bnr * (size_t)bnc, bval, 0);
+		if (!hp || !hi || !hv) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert: address space\n");
+		err = lis_matrix_set_bsr(bnr, bnc, bnnz, hp, hi, hv, Aout);
+		if (!err) { Aout->pad_comm = pad; d->nc = Aout->nc; }
+	}
+	if (err) return err;
+	HIPCHK(liship_stream_synchronize(lisg.stream));
+	d->inner_begin = 0; d->inner_end = n;
+	d->ready = 1;                                      /* the HBM copy exists: lis_matrix_assemble's eager upload finds nothing to do */
+	err = lis_matrix_assemble(Aout);
+	if (err) { lisi_matrix_storage_destroy(Aout); return err; }
+	*done = 1;
+	return LIS_SUCCESS;
 }
 
 LIS_INT lis_amd_matrix_upload(LIS_MATRIX A) { return lisd_mat_ready(A); }

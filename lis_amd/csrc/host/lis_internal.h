@@ -108,6 +108,7 @@ typedef struct {
 	int long_row_tree;         /* LIS_AMD_LONG_ROW_TREE=1: rows longer than the LDS stage are added by a tree per pass (not bit-parity; opt-in) */
 	int no_value_records;      /* LIS_AMD_NO_VALUE_RECORDS=1: matrices whose rows repeat with their values keep streaming the values (A/B measurements) */
 	int eager_coherence;       /* LIS_AMD_COHERENCE=eager / lis_amd_set_coherence(0): COHERENT copies on every call instead of following page faults (lis_pages.c) */
+	int no_device_convert;     /* LIS_AMD_NO_DEVICE_CONVERT=1: lis_matrix_convert always works on the host arrays (A/B, tests of the host routines) */
 	int no_row_form;           /* LIS_AMD_NO_ROW_FORM=1 / lis_amd_set_row_form(0): constant-coefficient ELL / DIA matrices keep their native layout and kernels */
 	int no_row_patterns;       /* LIS_AMD_NO_ROW_PATTERNS=1: coded CSR matrices keep one byte per non-zero instead of one per row (A/B measurements) */
 	int last_uniform_jacobi;   /* the last lis_solve ran CG + Jacobi with 1/diag as one double (lis_amd_last_solve_uniform_jacobi) */
@@ -133,6 +134,12 @@ LIS_INT lisp_grow(LIS_VECTOR v, size_t doubles);
 void lisp_protect(LIS_VECTOR v, int prot);
 int  lisp_state(LIS_VECTOR v);
 int  lisp_lazy(void);
+void *lisp_alloc_lazy(void *matrix, size_t bytes_used, void *dev, int own_dev);   /* a matrix array held in HBM until its first host touch */
+int  lisp_free_array(void *p);                                /* 1: p lived on such pages (unmapped), 0: plain memory (caller frees) */
+LIS_INT lisp_fill_matrix(void *matrix);
+int  lisp_lazy_arrays(void *matrix);
+void lisp_reown(void *from, void *to);
+LIS_INT lisd_staged_d2h(void *dst, const void *src, size_t bytes);   /* HBM -> pageable host memory through the pinned staging buffers */
 LIS_INT lisd_vec_host_write(LIS_VECTOR v, int keep);          /* the library is about to write value[] on the host (keep: current data needed first) */
 
 /* ---- device runtime (lis_device.c) */
@@ -196,6 +203,8 @@ LIS_INT lisi_matrix_copy_header(LIS_MATRIX src, LIS_MATRIX dst);
 void    lisi_sort_row(LIS_INT lo, LIS_INT hi, LIS_INT *idx, LIS_SCALAR *val);
 LIS_INT lisi_convert_csr_to(LIS_MATRIX Ain, LIS_MATRIX Aout);  /* Aout->matrix_type selects the target */
 LIS_INT lisi_convert_to_csr(LIS_MATRIX Ain, LIS_MATRIX Aout);
+LIS_INT lisi_jad_order(LIS_MATRIX A, LIS_INT *maxnzr, LIS_INT **perm, LIS_INT **ptr);      /* the reference's length-sorted row order + jagged-diagonal starts */
+LIS_INT lisd_convert_csr(LIS_MATRIX Ain, LIS_MATRIX Aout, int *done);   /* csr -> ell / dia / csc / bsr in HBM when Ain lives there (lis_device.c) */
 LIS_INT lisi_matrix_deep_copy(LIS_MATRIX Ain, LIS_MATRIX Aout);
 
 /* args (lis_initialize / lis_solver_set_option share the tokenizer) */

@@ -703,6 +703,7 @@ static LIS_INT output_mm_to(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_INT fo
 	const int isb = (b && !lis_vector_is_null(b)), isx = (x && !lis_vector_is_null(x));
 	if (isb) LISCHK(lisd_vec_to_host(b));
 	if (isx) LISCHK(lisd_vec_to_host(x));
+	LISCHK(lisp_fill_matrix(A));
 	double nnz_local = (double)A->nnz, nnz_total = nnz_local;
 	if (A->nprocs > 1) {
 		double *all = (double *)malloc(sizeof(double) * (size_t)A->nprocs);

@@ -396,14 +396,16 @@ LIS_INT lis_matrix_duplicate(LIS_MATRIX Ain, LIS_MATRIX *Aout)
 
 LIS_INT lisi_matrix_storage_destroy(LIS_MATRIX A)
 {
-	lisd_mat_free(A);
 	lisi_matrix_dlu_destroy(A);
 	asm_free(A);
 	if (A->is_destroy) {
-		free(A->ptr); free(A->row); free(A->col); free(A->index);
-		free(A->bptr); free(A->bindex); free(A->value); free(A->work);
+		LIS_INT *ia[] = {A->ptr, A->row, A->col, A->index, A->bptr, A->bindex};
+		for (int k = 0; k < 6; k++) if (!lisp_free_array(ia[k])) free(ia[k]);         /* (arrays of a matrix converted in HBM live on pages of their own) */
+		if (!lisp_free_array(A->value)) free(A->value);
+		free(A->work);
 		free(A->conv_row); free(A->conv_col);
 	}
+	lisd_mat_free(A);                       /* (after the arrays: one that was never read dies unmaterialised) */
 	A->ptr = A->row = A->col = A->index = A->bptr = A->bindex = NULL;
 	A->value = A->work = NULL;
 	A->conv_row = A->conv_col = NULL;
@@ -416,6 +418,7 @@ LIS_INT lisi_matrix_copy_header(LIS_MATRIX src, LIS_MATRIX dst)
 	free(dst->ranges); free(dst->l2g_map); free(dst->w_nnz);
 	if (dst->commtable) lisc_commtable_destroy(dst->commtable);
 	memcpy(dst, src, sizeof(struct LIS_MATRIX_STRUCT));
+	lisp_reown(src, dst);                    /* arrays still held in HBM only belong to dst now */
 	*MDEV(dst) = *MDEV(src);
 	memset(MDEV(src), 0, sizeof(lisd_mat));
 	return LIS_SUCCESS;
@@ -461,6 +464,7 @@ LIS_INT lis_matrix_get_diagonal(LIS_MATRIX A, LIS_VECTOR D)
 		return lisd_vec_done(D);
 	}
 	const LIS_INT n = A->n;
+	LISCHK(lisp_fill_matrix(A));
 	LISCHK(lisd_vec_host_write(D, (size_t)(D->np + D->pad) > (size_t)n));   /* the host array is about to be written (entries beyond n keep what they hold) */
 	LIS_SCALAR *out = D->value;
 	for (LIS_INT i = 0; i < n; i++) out[i] = 0.0;

@@ -85,6 +85,7 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 	if (A->is_splited) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "A^T x of a split (D/L/U) matrix is not served\n");     /* another summation order again (lis_matvec_csr.c:124-160) */
 	if (d->t_ready) return LIS_SUCCESS;
 	LISCHK(lisd_mat_ready(A));
+	if (!(A->matrix_type == LIS_MATRIX_CSR && d->type == LIS_MATRIX_CSR)) LISCHK(lisp_fill_matrix(A));   /* the host arrays are read below (and handed to the runtime) */
 	const LIS_INT type = A->matrix_type, n = A->n, np = A->np;
 	d->t_rows = np;
 	if (type == LIS_MATRIX_CSC) {          /* CSC arrays ARE the CSR of A^T: np rows, row indices as columns */

@@ -36,7 +36,12 @@ typedef struct lisp_region {
 	char *base;
 	size_t bytes;            /* whole pages */
 	int prot;                /* LISP_RW / LISP_RO / LISP_NONE */
-	LIS_VECTOR owner;
+	LIS_VECTOR owner;        /* a vector's value[] ... */
+	/* ... or an array of a matrix the library converted in HBM: the host array is materialised from `dev` on its first touch */
+	void *mowner;            /* the matrix */
+	void *dev;               /* device buffer holding the array (NULL once the host pages hold it) */
+	size_t used;             /* bytes of the array */
+	int own_dev;             /* the buffer exists only to back these pages: freed once they are filled (else it is part of the matrix's HBM copy) */
 	struct lisp_region *next;
 } lisp_region;
 
@@ -64,6 +69,27 @@ static void on_fault(int sig, siginfo_t *info, void *context)
 	if (sig == SIGSEGV && addr) {
 		pthread_mutex_lock(&region_lock);
 		for (r = regions; r; r = r->next) if (addr >= r->base && addr < r->base + r->bytes) break;
+		if (r && r->prot == LISP_NONE && !r->owner) {
+			/* an array of a matrix converted in HBM, touched for the first time: it becomes plain host memory */
+			faults_read++;
+			pthread_mutex_lock(&sync_lock);
+			mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE);
+			r->prot = LISP_RW;
+			void *dev = r->dev;
+			const size_t used = r->used;
+			const int own = r->own_dev;
+			r->dev = NULL;
+			pthread_mutex_unlock(&region_lock);
+			LIS_INT err = LIS_SUCCESS;
+			if (dev && used) err = lisd_staged_d2h(r->base, dev, used);
+			if (dev && own) (void)liship_free(dev);
+			pthread_mutex_unlock(&sync_lock);
+			if (err != LIS_SUCCESS) {
+				fprintf(stderr, "liblis_amd: could not bring a matrix array back from HBM inside the page-fault handler\n");
+				abort();
+			}
+			return;
+		}
 		if (r && r->prot == LISP_NONE) {
 			/* the HBM copy is the truth: bring it home, leave the pages read-only (both sides agree now) */
 			LIS_VECTOR v = r->owner;
@@ -141,6 +167,7 @@ LIS_SCALAR *lisp_alloc(LIS_VECTOR v, size_t doubles)
 	if (mprotect(p, bytes, PROT_READ | PROT_WRITE) != 0) { munmap(m, bytes + 2 * ps); return NULL; }
 	lisp_region *r = (lisp_region *)malloc(sizeof(*r));
 	if (!r) { munmap(m, bytes + 2 * ps); return NULL; }
+	memset(r, 0, sizeof(*r));
 	r->base = (char *)p; r->bytes = bytes; r->prot = LISP_RW; r->owner = v;
 	pthread_mutex_lock(&region_lock);
 	r->next = regions; regions = r;
@@ -159,6 +186,85 @@ void lisp_free(LIS_VECTOR v)
 	munmap(r->base - page_size(), r->bytes + 2 * page_size());      /* (with its guard pages) */
 	free(r);
 	VDEV(v)->region = NULL;
+}
+
+/* ---- arrays of a matrix that was converted in HBM (lis_convert.c): the Lis API promises host arrays (A->ptr, A->index, A->value ...), but a
+ * program that only multiplies never reads them.  They get address space without access, bound to the device buffer that holds their
+ * contents; the first touch -- by the program or by a host-side routine of this library -- brings them home (on_fault).  NULL: no memory. */
+void *lisp_alloc_lazy(void *matrix, size_t bytes_used, void *dev, int own_dev)
+{
+	const size_t ps = page_size();
+	size_t bytes = (bytes_used > 0 ? bytes_used : 1);
+	bytes = (bytes + ps - 1) / ps * ps;
+	if (!install_handler()) return NULL;
+	char *m = (char *)mmap(NULL, bytes + 2 * ps, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+	if (m == (char *)MAP_FAILED) return NULL;
+	lisp_region *r = (lisp_region *)calloc(1, sizeof(*r));
+	if (!r) { munmap(m, bytes + 2 * ps); return NULL; }
+	r->base = m + ps; r->bytes = bytes; r->prot = LISP_NONE; r->mowner = matrix; r->dev = dev; r->used = bytes_used; r->own_dev = own_dev;
+	pthread_mutex_lock(&region_lock);
+	r->next = regions; regions = r;
+	pthread_mutex_unlock(&region_lock);
+	return r->base;
+}
+
+static lisp_region *region_at(const void *p)
+{
+	for (lisp_region *r = regions; r; r = r->next) if ((const char *)p == r->base) return r;
+	return NULL;
+}
+
+/* free() for an array that may live on such pages: 1 when it did (unmapped; a backing buffer nobody else owns is freed too) */
+int lisp_free_array(void *p)
+{
+	if (!p) return 0;
+	pthread_mutex_lock(&region_lock);
+	lisp_region *r = region_at(p);
+	if (r) for (lisp_region **pp = &regions; *pp; pp = &(*pp)->next) if (*pp == r) { *pp = r->next; break; }
+	pthread_mutex_unlock(&region_lock);
+	if (!r) return 0;
+	if (r->dev && r->own_dev) (void)liship_free(r->dev);
+	munmap(r->base - page_size(), r->bytes + 2 * page_size());
+	free(r);
+	return 1;
+}
+
+/* the HBM copy of `matrix` is about to go while the matrix lives on: every array still held there comes home now */
+LIS_INT lisp_fill_matrix(void *matrix)
+{
+	for (;;) {
+		pthread_mutex_lock(&region_lock);
+		lisp_region *r = regions;
+		while (r && !(r->mowner == matrix && r->prot == LISP_NONE && r->dev)) r = r->next;
+		if (!r) { pthread_mutex_unlock(&region_lock); return LIS_SUCCESS; }
+		mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE);
+		r->prot = LISP_RW;
+		void *dev = r->dev;
+		const size_t used = r->used;
+		const int own = r->own_dev;
+		r->dev = NULL;
+		pthread_mutex_unlock(&region_lock);
+		LIS_INT err = used ? lisd_staged_d2h(r->base, dev, used) : LIS_SUCCESS;
+		if (own) (void)liship_free(dev);
+		if (err) return err;
+	}
+}
+
+void lisp_reown(void *from, void *to)
+{
+	pthread_mutex_lock(&region_lock);
+	for (lisp_region *r = regions; r; r = r->next) if (r->mowner == from) r->mowner = to;
+	pthread_mutex_unlock(&region_lock);
+}
+
+/* how many arrays of `matrix` are still held in HBM only (tests) */
+int lisp_lazy_arrays(void *matrix)
+{
+	int c = 0;
+	pthread_mutex_lock(&region_lock);
+	for (lisp_region *r = regions; r; r = r->next) c += (r->mowner == matrix && r->prot == LISP_NONE && r->dev != NULL);
+	pthread_mutex_unlock(&region_lock);
+	return c;
 }
 
 /* value[] grows to `doubles` entries (old contents kept, new entries zero), whatever memory it lived in; the caller made it current */
@@ -210,6 +316,8 @@ LIS_INT lis_amd_set_coherence(LIS_INT lazy)
 	return LIS_SUCCESS;
 }
 
+LIS_INT lis_amd_matrix_lazy_arrays(LIS_MATRIX A) { return lisp_lazy_arrays(A); }
+LIS_INT lis_amd_set_device_convert(LIS_INT on) { lisg.no_device_convert = on ? 0 : 1; return LIS_SUCCESS; }
 LIS_INT lis_amd_vector_page_state(LIS_VECTOR v) { return lisp_state(v); }
 LIS_INT lis_amd_vector_page_protect(LIS_VECTOR v, LIS_INT state) { lisp_protect(v, (int)state); return lisp_state(v) == (int)state ? LIS_SUCCESS : LIS_ERR_ILL_ARG; }
 

@@ -85,6 +85,7 @@ LIS_INT lis_matrix_scale(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_INT actio
 	if (MDEV(A)->device_only) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "scaling a matrix that lives in HBM only is not implemented\n");
 	if (A->is_splited) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "split (D/L/U) matrices are not served\n");
 	if (action != LIS_SCALE_JACOBI && action != LIS_SCALE_SYMM_DIAG) return LIS_SUCCESS;   /* the reference falls through too */
+	LISCHK(lisp_fill_matrix(A));
 	const LIS_INT n = A->n, np = A->np;
 	LISCHK(lis_matrix_get_diagonal(A, D));
 	size_t need = (size_t)np + (size_t)A->pad;

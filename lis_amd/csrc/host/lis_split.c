@@ -218,6 +218,7 @@ LIS_INT lis_matrix_split(LIS_MATRIX A)
 {
 	LISCHK(lisi_matrix_check(A, LISI_CHECK_ASSEMBLED));
 	if (A->is_splited) return LIS_SUCCESS;
+	LISCHK(lisp_fill_matrix(A));          /* the parts are built from the host arrays */
 	if (MDEV(A)->device_only) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "matrix lives in HBM only: split the host matrix before uploading\n");
 	if (A->matrix_type == LIS_MATRIX_BSR && A->bnr != A->bnc) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "split of non-square blocks is not implemented\n");   /* ref lis_matrix_bsr.c:1164 */
 	LIS_MATRIX_CORE L = (LIS_MATRIX_CORE)calloc(1, sizeof(struct LIS_MATRIX_CORE_STRUCT));
@@ -266,7 +267,7 @@ static LIS_INT merge_csr(LIS_MATRIX A)
 		for (LIS_INT j = A->U->ptr[i]; j < A->U->ptr[i + 1]; j++) { index[at] = A->U->index[j]; value[at] = A->U->value[j]; at++; }
 		ptr[i + 1] = at;
 	}
-	if (A->is_destroy) { free(A->ptr); free(A->index); free(A->value); }
+	if (A->is_destroy) { if (!lisp_free_array(A->ptr)) free(A->ptr); if (!lisp_free_array(A->index)) free(A->index); if (!lisp_free_array(A->value)) free(A->value); }
 	A->ptr = ptr; A->index = index; A->value = value; A->nnz = at;
 	A->is_destroy = LIS_TRUE;            /* the rebuilt arrays are the library's, whoever owned the old ones */
 	return LIS_SUCCESS;
@@ -289,7 +290,7 @@ static LIS_INT merge_bsr(LIS_MATRIX A)
 		for (LIS_INT j = A->U->bptr[i]; j < A->U->bptr[i + 1]; j++) { bindex[at] = A->U->bindex[j]; memcpy(value + bs * (size_t)at, A->U->value + bs * (size_t)j, sizeof(LIS_SCALAR) * bs); at++; }
 		bptr[i + 1] = at;
 	}
-	if (A->is_destroy) { free(A->bptr); free(A->bindex); free(A->value); }
+	if (A->is_destroy) { if (!lisp_free_array(A->bptr)) free(A->bptr); if (!lisp_free_array(A->bindex)) free(A->bindex); if (!lisp_free_array(A->value)) free(A->value); }
 	A->bptr = bptr; A->bindex = bindex; A->value = value; A->bnnz = at;
 	A->is_destroy = LIS_TRUE;
 	return LIS_SUCCESS;

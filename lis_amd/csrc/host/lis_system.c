@@ -242,6 +242,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_row_patterns = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_VALUE_RECORDS");
 		lisg.no_value_records = (r && r[0] == '1');
+		r = getenv("LIS_AMD_NO_DEVICE_CONVERT");
+		lisg.no_device_convert = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_ROW_FORM");
 		lisg.no_row_form = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_UNIFORM_JACOBI");

@@ -600,3 +600,54 @@ def test_coherent_by_page_protection_on_the_gpu(lib):
     for v in (vx, vy, vz, vb, vs):
         lib.lis_vector_destroy(v)
     lib.lis_matrix_destroy(A)
+
+
+@pytest.mark.parametrize("fmt,bs", [("ell", 0), ("dia", 0), ("csc", 0), ("bsr", 2), ("bsr", 3), ("jad", 0)])
+@pytest.mark.parametrize("kind", ["stencil", "varying", "irregular"])
+def test_conversion_in_hbm_and_host_arrays_on_first_touch(lib, fmt, bs, kind):
+    """lis_matrix_convert of a CSR matrix that lives in HBM: the target layout is built there (kernels/convert.hip), the product runs at
+    once, and the new matrix's host arrays -- which the Lis API promises -- exist as address space only until somebody reads them; read,
+    they are the arrays the host routine (the restatement of lis_matrix_convert_csr2{ell,dia,csc,bsr}) builds, bit for bit."""
+    dll = lib.dll
+    dll.lis_amd_matrix_lazy_arrays.argtypes = [capi.PM]
+    dll.lis_amd_matrix_value_records.argtypes = [capi.PM]
+    rng = np.random.default_rng(3)
+    if kind == "irregular":
+        ptr, idx, val = orc.random_csr(3000, 9, seed=8)
+        idx, val = orc.sort_rows(ptr, idx, val)
+    else:
+        ptr, idx, val = orc.poisson3d(11, 10, 64, sort_cols=True)
+        if kind == "varying":
+            val = val * rng.uniform(0.5, 1.5, len(val))
+    n = len(ptr) - 1
+    x = rng.uniform(-1, 1, n)
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    lisdrv.matvec(lib, A, x)                                         # (A's HBM copy exists)
+    dll.lis_amd_set_device_convert(0)
+    H = lisdrv.convert(lib, A, fmt, bs or 2, bs or 2)               # the host routine: the checker
+    dll.lis_amd_set_device_convert(1)
+    assert dll.lis_amd_matrix_lazy_arrays(H) == 0
+    want = lisdrv.matrix_arrays(H)
+    B = lisdrv.convert(lib, A, fmt, bs or 2, bs or 2)
+    narr = dll.lis_amd_matrix_lazy_arrays(B)
+    assert narr == (3 if fmt in ("csc", "bsr") else 2), narr        # nothing has come to the host yet (JAD: its row order and diagonal starts are host-made)
+    y = lisdrv.matvec(lib, B, x)
+    assert dll.lis_amd_matrix_lazy_arrays(B) == narr                 # ... and a product does not ask for it
+    assert np.array_equal(y, lisdrv.matvec(lib, H, x))
+    if kind == "stencil" and fmt in ("ell", "dia"):
+        assert dll.lis_amd_matrix_value_records(B) == dll.lis_amd_matrix_value_records(H) == 1        # the row form, built in HBM too
+    got = lisdrv.matrix_arrays(B)                                    # reads every array: they come home now
+    assert dll.lis_amd_matrix_lazy_arrays(B) == 0
+    for k, v in want.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(got[k], v) and (v.dtype != np.float64 or np.array_equal(got[k].view(np.uint64), v.view(np.uint64))), (fmt, k)
+        else:
+            assert got[k] == v, (fmt, k, got[k], v)
+    assert np.array_equal(lisdrv.matvec(lib, B, x), y)               # the HBM copy is still the one the product uses
+    # a host-side routine on the converted matrix (here: back to CSR) finds the arrays as well, whoever asks first
+    B2 = lisdrv.convert(lib, A, fmt, bs or 2, bs or 2)
+    back, backh = lisdrv.convert(lib, B2, "csr"), lisdrv.convert(lib, H, "csr")
+    ga, gh = lisdrv.matrix_arrays(back), lisdrv.matrix_arrays(backh)
+    assert all(np.array_equal(ga[k], gh[k]) for k in ("ptr", "index", "value"))
+    for M in (back, backh, B2, B, H, A):
+        lib.lis_matrix_destroy(M)

@@ -242,6 +242,95 @@ struct RowDots {
     }
 };
 
+// the same chain for the 10^5-term row, kept fed: three register batches of 7 in rotation, the reads of a batch issued two batches
+// (14 dependent additions, ~120 cycles) before its terms are added, so that the additions are all that is left -- a lane that read 16,
+// waited, added 16 spent half its time waiting for LDS (19.5 cycles per term against the chain's 8.7, profiles/r03_long_rows.txt).
+// The loop is ONE asm statement: written in C++ the scheduler sinks the reads behind the adds and the register allocator ends every
+// iteration on s_waitcnt lgkmcnt(0).  Reads run up to 14 doubles past the last whole batch (the caller leaves 32 of slack); LDS returns in
+// order, so lgkmcnt(14) means "all but the two youngest batches".  Run by the owner's whole wavefront (same addresses: broadcast reads,
+// every lane ends with the sum), so nothing diverges.  Same terms, same order: the reference's bits.
+__device__ __forceinline__ double ordered_sum_fed(double acc, const double *buf, int first, int lim)
+{
+    constexpr int W = 7;
+    int n = lim / (3 * W);
+    const int done = n * 3 * W;
+    if (n > 0) {
+        unsigned ad = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) const double *)(buf + GUARD + first));
+        n = __builtin_amdgcn_readfirstlane(n);
+        double t[3 * W];
+        asm volatile(
+        "ds_read_b64 %[t0], %[ad]\n"
+        "ds_read_b64 %[t1], %[ad] offset:8\n"
+        "ds_read_b64 %[t2], %[ad] offset:16\n"
+        "ds_read_b64 %[t3], %[ad] offset:24\n"
+        "ds_read_b64 %[t4], %[ad] offset:32\n"
+        "ds_read_b64 %[t5], %[ad] offset:40\n"
+        "ds_read_b64 %[t6], %[ad] offset:48\n"
+        "ds_read_b64 %[t7], %[ad] offset:56\n"
+        "ds_read_b64 %[t8], %[ad] offset:64\n"
+        "ds_read_b64 %[t9], %[ad] offset:72\n"
+        "ds_read_b64 %[t10], %[ad] offset:80\n"
+        "ds_read_b64 %[t11], %[ad] offset:88\n"
+        "ds_read_b64 %[t12], %[ad] offset:96\n"
+        "ds_read_b64 %[t13], %[ad] offset:104\n"
+        "1:\n"
+        "ds_read_b64 %[t14], %[ad] offset:112\n"
+        "ds_read_b64 %[t15], %[ad] offset:120\n"
+        "ds_read_b64 %[t16], %[ad] offset:128\n"
+        "ds_read_b64 %[t17], %[ad] offset:136\n"
+        "ds_read_b64 %[t18], %[ad] offset:144\n"
+        "ds_read_b64 %[t19], %[ad] offset:152\n"
+        "ds_read_b64 %[t20], %[ad] offset:160\n"
+        "s_waitcnt lgkmcnt(14)\n"
+        "v_add_f64 %[acc], %[acc], %[t0]\n"
+        "v_add_f64 %[acc], %[acc], %[t1]\n"
+        "v_add_f64 %[acc], %[acc], %[t2]\n"
+        "v_add_f64 %[acc], %[acc], %[t3]\n"
+        "v_add_f64 %[acc], %[acc], %[t4]\n"
+        "v_add_f64 %[acc], %[acc], %[t5]\n"
+        "v_add_f64 %[acc], %[acc], %[t6]\n"
+        "ds_read_b64 %[t0], %[ad] offset:168\n"
+        "ds_read_b64 %[t1], %[ad] offset:176\n"
+        "ds_read_b64 %[t2], %[ad] offset:184\n"
+        "ds_read_b64 %[t3], %[ad] offset:192\n"
+        "ds_read_b64 %[t4], %[ad] offset:200\n"
+        "ds_read_b64 %[t5], %[ad] offset:208\n"
+        "ds_read_b64 %[t6], %[ad] offset:216\n"
+        "s_waitcnt lgkmcnt(14)\n"
+        "v_add_f64 %[acc], %[acc], %[t7]\n"
+        "v_add_f64 %[acc], %[acc], %[t8]\n"
+        "v_add_f64 %[acc], %[acc], %[t9]\n"
+        "v_add_f64 %[acc], %[acc], %[t10]\n"
+        "v_add_f64 %[acc], %[acc], %[t11]\n"
+        "v_add_f64 %[acc], %[acc], %[t12]\n"
+        "v_add_f64 %[acc], %[acc], %[t13]\n"
+        "ds_read_b64 %[t7], %[ad] offset:224\n"
+        "ds_read_b64 %[t8], %[ad] offset:232\n"
+        "ds_read_b64 %[t9], %[ad] offset:240\n"
+        "ds_read_b64 %[t10], %[ad] offset:248\n"
+        "ds_read_b64 %[t11], %[ad] offset:256\n"
+        "ds_read_b64 %[t12], %[ad] offset:264\n"
+        "ds_read_b64 %[t13], %[ad] offset:272\n"
+        "s_waitcnt lgkmcnt(14)\n"
+        "v_add_f64 %[acc], %[acc], %[t14]\n"
+        "v_add_f64 %[acc], %[acc], %[t15]\n"
+        "v_add_f64 %[acc], %[acc], %[t16]\n"
+        "v_add_f64 %[acc], %[acc], %[t17]\n"
+        "v_add_f64 %[acc], %[acc], %[t18]\n"
+        "v_add_f64 %[acc], %[acc], %[t19]\n"
+        "v_add_f64 %[acc], %[acc], %[t20]\n"
+        "v_add_u32 %[ad], 168, %[ad]\n"
+        "s_sub_u32 %[n], %[n], 1\n"
+        "s_cmp_lg_u32 %[n], 0\n"
+        "s_cbranch_scc1 1b\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        : [acc] "+v"(acc), [ad] "+v"(ad), [n] "+s"(n), [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]), [t4] "=&v"(t[4]), [t5] "=&v"(t[5]), [t6] "=&v"(t[6]), [t7] "=&v"(t[7]), [t8] "=&v"(t[8]), [t9] "=&v"(t[9]), [t10] "=&v"(t[10]), [t11] "=&v"(t[11]), [t12] "=&v"(t[12]), [t13] "=&v"(t[13]), [t14] "=&v"(t[14]), [t15] "=&v"(t[15]), [t16] "=&v"(t[16]), [t17] "=&v"(t[17]), [t18] "=&v"(t[18]), [t19] "=&v"(t[19]), [t20] "=&v"(t[20])
+        :
+        : "scc", "memory");
+    }
+    return ordered_sum_plain(acc, buf, first + done, lim - done);
+}
+
 // one whole row block of any shape (many empty rows, rows longer than the LDS stage).
 // Invariant from the plan: every row but the last ends inside the first pass of CAP products.
 template <int BLOCK, int CAP, int VEC, bool NOGATHER, int DOT = 0>
@@ -308,34 +397,62 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
         } else if (base < k1) {
             // The rest of the long row, strictly in order: ONE lane owns the chain of additions, and nothing can shorten it but
             // keeping that lane fed.  The stage is used as two halves: while the owner adds the products of one half, the lanes
-            // of the OTHER wavefronts form the products of the next half (4 loads and gathers in flight each), so a pass costs
+            // of the OTHER wavefronts form the products of the next half (all of it in flight at once), so a pass costs
             // the longer of the two instead of their sum, and the owner's wavefront never waits for memory.
-            constexpr int H = (CAP / 2) & ~15;                  // products per half
-            const int ownerwave = owner / WAVE;
             constexpr int helpers = BLOCK > WAVE ? BLOCK - WAVE : 1;   // lanes of the other wavefronts
+            constexpr int HFIT = ((CAP - 8) / 2) & ~15;         // products per half that fit (32 doubles of slack behind the second: ordered_sum_fed reads ahead)
+            constexpr int HCAP = BLOCK > WAVE ? ((6 * helpers) & ~15) : HFIT;                  // ... and at most six per helper lane (registers)
+            constexpr int H = HFIT < HCAP ? HFIT : HCAP;
+            const int ownerwave = owner / WAVE;
             const int hl = ((int)threadIdx.x / WAVE < ownerwave) ? (int)threadIdx.x : (int)threadIdx.x - WAVE;   // index among them
             const bool helper = (int)threadIdx.x / WAVE != ownerwave;
-            auto stage_half = [&](int half, int kb, int ke) {   // prod[GUARD + half * H + (k - kb)] = value[k] * x[index[k]]
-                double *dst = prod + GUARD + half * H;
-                for (int k = kb + hl; k < ke; k += 4 * helpers) {
-                    double v[4], xv[4];
+            // A helper lane takes PER entries of a half -- the whole half is in flight at once -- and the loads run TWO steps ahead of the
+            // owner: the values and x of half s+2 are issued (into registers) before the barrier that ends step s and become products in
+            // LDS at the start of step s+1, their column indices were fetched a step before that.  A round trip under the random gathers of
+            // the rest of the matrix (4-5 us) has a whole step of the owner (3 us of additions) to come back.
+            constexpr int PER = (H + helpers - 1) / helpers;
+            int nidx[PER];
+            double v[PER], xv[PER];
+            auto fetch_indices = [&](int kb) {                  // indices of the half starting at kb
+                const int ke = min(kb + H, k1);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { const int kk = min(k + u * helpers, ke - 1); v[u] = load_stream(val + kk); xv[u] = NOGATHER ? 1.0 : x[load_stream(idx + kk)]; }
+                for (int u = 0; u < PER; u++) nidx[u] = (!NOGATHER && kb < ke) ? load_stream(idx + min(kb + hl + u * helpers, ke - 1)) : 0;
+            };
+            auto issue_loads = [&](int kb) {                    // values and x of the half starting at kb (its indices are in nidx)
+                const int ke = min(kb + H, k1);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) if (k + u * helpers < ke) dst[k + u * helpers - kb] = v[u] * xv[u];
+                for (int u = 0; u < PER; u++) {
+                    v[u] = kb < ke ? load_stream(val + min(kb + hl + u * helpers, ke - 1)) : 0.0;
+                    xv[u] = (NOGATHER || kb >= ke) ? 1.0 : x[nidx[u]];
                 }
             };
+            auto write_products = [&](int half, int kb) {       // prod[GUARD + half * H + (k - kb)] = value[k] * x[index[k]]
+                const int ke = min(kb + H, k1);
+                double *dst = prod + GUARD + half * H;
+#pragma unroll
+                for (int u = 0; u < PER; u++) if (kb + hl + u * helpers < ke) dst[hl + u * helpers] = v[u] * xv[u];
+            };
             __syncthreads();                                    // the first pass's sums have read the stage
-            int half = 0;
-            if (helper) stage_half(0, base, min(base + H, k1));
-            __syncthreads();
-            while (base < k1) {
-                const int kend = min(base + H, k1);
-                if (helper) { if (kend < k1) stage_half(half ^ 1, kend, min(kend + H, k1)); }
-                else if ((int)threadIdx.x == owner) carry = ordered_sum_plain(carry, prod, half * H, kend - base);
+            // two loops with the same barriers, one per role (the branch is uniform per wavefront): in one loop the registers of the loads in
+            // flight and those of the chain would be live together in every kernel that inlines this path
+            if (helper) {
+                fetch_indices(base); issue_loads(base); fetch_indices(base + H);
+                write_products(0, base);
+                issue_loads(base + H); fetch_indices(base + 2 * H);
                 __syncthreads();
-                base = kend;
-                half ^= 1;
+                for (int half = 0, kb = base; kb < k1; kb += H, half ^= 1) {
+                    write_products(half ^ 1, kb + H);           // loaded during the step before
+                    issue_loads(kb + 2 * H); fetch_indices(kb + 3 * H);
+                    __syncthreads();
+                }
+            } else {                                            // the owner's wavefront adds as one: every lane starts from the owner's sum
+                const int ol = __builtin_amdgcn_readfirstlane(owner & (WAVE - 1));
+                carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(carry), ol), __builtin_amdgcn_readlane(__double2loint(carry), ol));
+                __syncthreads();
+                for (int half = 0, kb = base; kb < k1; kb += H, half ^= 1) {
+                    carry = ordered_sum_fed(carry, prod, half * H, min(kb + H, k1) - kb);
+                    __syncthreads();
+                }
             }
         }
         if ((int)threadIdx.x == owner) { store_stream(y + rl, carry); dots.add(rl, carry); }
@@ -368,7 +485,7 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
     const int row_begin = RW.rb, row_end = RW.re;
     const double acc0 = RW.acc0;
     constexpr int CAP = WORK + SLACK;
-    __shared__ double prod[(GUARD + CAP + 8 + 16)];
+    __shared__ __attribute__((aligned(16))) double prod[(GUARD + CAP + 8 + 16)];
     __shared__ double dot_scratch[BLOCK / WAVE];
     RowDots<DOT> dots{wdot, 0.0, 0.0};
     // order: the plan's launch order when some row blocks hold a row far longer than the stage -- those first, so that their

@@ -92,6 +92,10 @@ int  liship_csr_plan_coded(liship_csr_plan_t plan);
 int  liship_csr_plan_encode_row_patterns(liship_csr_plan_t plan, const int *ptr, void *stream);
 int  liship_csr_plan_row_patterns(liship_csr_plan_t plan);
 int  liship_csr_plan_pattern_records(liship_csr_plan_t plan);
+/* When the longest pattern has 8..32 offsets (the 27-point stencil) the plan keeps 144 B records (32 byte offsets, length) and the
+ * values-streamed product runs four lanes per row, the gathers leaving ahead of the value slice and the row's one ordered sum handed
+ * from lane to lane in registers (spmv_csr_pattern_team_kernel): liship_csr_plan_team_records = 1. */
+int  liship_csr_plan_team_records(liship_csr_plan_t plan);
 /* Value records (setup-time, optional, after liship_csr_plan_encode_row_patterns; never an error when the matrix does not
  * qualify): when the plan has 32 B pattern records and every row of a pattern carries the same values bit for bit -- a
  * constant-coefficient stencil -- the 7 values join the 7 offsets in the record and the products read neither the value nor

@@ -995,6 +995,75 @@ void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict_
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
+// ------------------------------------------------------------------------------ patterned rows of 8..32 entries: four lanes per row
+// The 27-point stencil with varying coefficients (any matrix on <= 255 row patterns whose longest has 8..32 offsets, values
+// streamed).  One lane per row leaves the general pattern kernel with 73 busy lanes of 256 and FOUR dependent gather round trips per
+// row behind the barrier that waits for the value slice (27 gathers, 8 in flight): 0.47 of the roofline on its bytes.  Here a row
+// is the business of a TEAM of four neighbouring lanes: lane t owns entries 8t .. 8t+7, so a row's gathers are one batch per lane and
+// leave BEFORE the slice has landed (pattern byte -> 144 B pattern record -> gathers: the record loads are issued ahead of the
+// slice's LDS-DMA, the vector-memory counter counts in order), every lane of the workgroup has work, and a workgroup lives for two
+// long round trips instead of six.  The sum stays ONE chain per row, strictly left to right: lane 0 adds its eight products to the
+// start value, hands the sum to lane 1 through a quad-permute DPP move (registers, not LDS -- the LDS round trip of the products is
+// what sank round 2's team variant), and so on; a lane whose segment is empty adds -0.0 terms.  Same terms, same order: the
+// reference's bits (lis_matvec_csr.c:97-109).  Row blocks are 64 consecutive rows (no merge-path split: rows of 8..32 balance).
+constexpr int TEAM_SEG = 8, TEAM_MAXLEN = 32, TEAM_REC = 9;     // a pattern record: 32 byte offsets (the tail repeats the last), length + 3 pad = 9 x 16 B
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
+                                  const v4i32 *__restrict__ prec, const double *__restrict__ x, double *__restrict__ y, Rows RW, int nnz_total)
+{
+    constexpr int RPB = BLOCK / 4;                              // rows per workgroup
+    __shared__ __attribute__((aligned(16))) double valL[RPB * TEAM_MAXLEN + 2 + 40];
+    const int r0 = RW.rb + (int)blockIdx.x * RPB, r1 = min(r0 + RPB, RW.re);
+    if (r0 >= r1) return;
+    const int t = (int)threadIdx.x & 3;
+    const int r = min(r0 + ((int)threadIdx.x >> 2), r1 - 1);    // (lanes beyond the last row repeat it and store nothing)
+    const bool live = r0 + ((int)threadIdx.x >> 2) < r1;
+    const int pat = rowpat[r];                                  // the first loads: everything the gathers wait for
+    const int s = ptr[r];
+    const int k0 = ptr[r0], k1 = ptr[r1];                       // (uniform: scalar loads)
+    const int ka = k0 & ~1, cnt = k1 - ka;
+    int np = (cnt + 1) >> 1;                                    // 16 B pieces of the value slice
+    const bool odd_end = ka + 2 * np > nnz_total;               // the last piece would pass the end of the array: its one value by a plain load
+    if (odd_end) np--;
+    const v4i32 *rec = prec + pat * TEAM_REC;
+    const v4i32 o0 = rec[2 * t], o1 = rec[2 * t + 1];           // this lane's eight byte offsets ...
+    const int len = rec[8].x;                                   // ... and the row's length: issued AHEAD of the slice
+    {
+        const int wbase = (int)threadIdx.x & ~(WAVE - 1), lane = (int)threadIdx.x & (WAVE - 1);
+        for (int p0 = wbase; p0 < np; p0 += BLOCK) {
+            const int p = min(p0 + lane, np - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+        }
+    }
+    const char *xb = reinterpret_cast<const char *>(x + r);
+    double xx[TEAM_SEG];
+    xx[0] = *reinterpret_cast<const double *>(xb + o0.x); xx[1] = *reinterpret_cast<const double *>(xb + o0.y);
+    xx[2] = *reinterpret_cast<const double *>(xb + o0.z); xx[3] = *reinterpret_cast<const double *>(xb + o0.w);
+    xx[4] = *reinterpret_cast<const double *>(xb + o1.x); xx[5] = *reinterpret_cast<const double *>(xb + o1.y);
+    xx[6] = *reinterpret_cast<const double *>(xb + o1.z); xx[7] = *reinterpret_cast<const double *>(xb + o1.w);
+    if (odd_end && threadIdx.x == 0) valL[cnt - 1] = val[k1 - 1];
+    __syncthreads();
+    const int nt = min(max(len - TEAM_SEG * t, 0), TEAM_SEG);   // entries of this lane's segment
+    const double *vp = valL + (s - ka) + TEAM_SEG * t;          // (reads up to 7 doubles past a short row: inside the stage)
+    double pm[TEAM_SEG];
+#pragma unroll
+    for (int u = 0; u < TEAM_SEG; u++) { const double pr = vp[u] * xx[u]; pm[u] = u < nt ? pr : -0.0; }
+    double c = RW.acc0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double in = RW.acc0;
+        if (k > 0) in = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(c), 0x90, 0xf, 0xf, true),     // quad_perm [0,0,1,2]: lane t takes lane t-1's sum
+                                         __builtin_amdgcn_update_dpp(0, __double2loint(c), 0x90, 0xf, 0xf, true));
+#pragma unroll
+        for (int u = 0; u < TEAM_SEG; u++) in += pm[u];
+        c = t == k ? in : c;
+    }
+    if (live && t == 3) store_stream(y + r, c);
+}
+
 // inclusive sum over the 64 lanes by data-parallel primitives: 4 shifts inside the rows of 16, then lane 15 of each row into
 // the next row, then lane 31 into the upper half -- 6 adds, no LDS traffic.  All lanes must be active.
 __device__ __forceinline__ int wave_inclusive_scan(int v)
@@ -2129,6 +2198,7 @@ struct liship_csr_plan_s {
     int *ptab;           // device: npat + 1 prefix entries, then the offsets of all patterns
     int ptab_len, npat;
     v4i32 *ptab8;        // device: when no pattern has more than 7 offsets, one 32 B record per pattern (7 offsets, length); else NULL
+    v4i32 *prec36;       // device: when the longest pattern has 8..32 offsets, one 144 B record per pattern (32 byte offsets, length): spmv_csr_pattern_team_kernel; else NULL
     int prep[256];       // a row that carries each pattern
     v4i32 *vrec;         // device: with ptab8, when every row of a pattern carries the same values, 96 B per pattern (the 32 B record + 7 values); else NULL
     double *drec;        // device: with vrec, when one pattern dominates: per pattern 8 doubles {slots of the dominant pattern it has (mask; bit 7: not a
@@ -2227,7 +2297,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
     p->drec = nullptr; p->dom_lo = p->dom_hi = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
@@ -2246,6 +2316,7 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->rowrel) (void)hipFree(p->rowrel);
     if (p->ptab) (void)hipFree(p->ptab);
     if (p->ptab8) (void)hipFree(p->ptab8);
+    if (p->prec36) (void)hipFree(p->prec36);
     if (p->vrec) (void)hipFree(p->vrec);
     if (p->drec) (void)hipFree(p->drec);
     if (p->order) (void)hipFree(p->order);
@@ -2334,6 +2405,29 @@ extern "C" int liship_csr_plan_coded(liship_csr_plan_t p) { return (p && p->code
 // Row patterns on top of the column codes (see spmv_csr_pattern_kernel): setup-time, optional, never an error when the matrix
 // does not qualify (not coded, a row longer than 64, more than 255 patterns, more than 1024 offsets over all patterns).
 // Must follow liship_csr_plan_encode_indices, whose final row split it encodes the row starts against.
+// the 144 B records of spmv_csr_pattern_team_kernel from a host copy of the pattern table T (NP + 1 prefix entries, then element offsets):
+// per pattern 32 column offsets IN BYTES (the tail repeats the last: always a column of the row) and the length.  Kept when the longest
+// pattern has 8..32 offsets and none is empty; rebuilt whenever the plan's pattern bytes are renumbered.  Never an error.
+static void build_team_records(liship_csr_plan_s *p, const int *T, int NP)
+{
+    if (p->prec36) { (void)hipFree(p->prec36); p->prec36 = nullptr; }
+    int maxlen = 0, minlen = 1 << 30, maxoff = 0;
+    for (int i = 0; i < NP; i++) { const int l = T[i + 1] - T[i]; if (l > maxlen) maxlen = l; if (l < minlen) minlen = l; }
+    for (int t = 0; t < T[NP]; t++) if (T[NP + 1 + t] > maxoff) maxoff = T[NP + 1 + t];
+    if (NP <= 0 || maxlen <= 7 || maxlen > TEAM_MAXLEN || minlen < 1 || (long long)p->n + maxoff >= (1ll << 28)) return;
+    int *rec = (int *)calloc((size_t)NP * 4 * TEAM_REC, sizeof(int));
+    if (!rec) return;
+    for (int i = 0; i < NP; i++) {
+        const int l = T[i + 1] - T[i];
+        for (int j = 0; j < TEAM_MAXLEN; j++) rec[4 * TEAM_REC * i + j] = 8 * T[NP + 1 + T[i] + (j < l ? j : l - 1)];
+        rec[4 * TEAM_REC * i + TEAM_MAXLEN] = l;
+    }
+    if (hipMalloc(&p->prec36, sizeof(int) * 4 * TEAM_REC * (size_t)NP) == hipSuccess) {
+        if (hipMemcpy(p->prec36, rec, sizeof(int) * 4 * TEAM_REC * (size_t)NP, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p->prec36); p->prec36 = nullptr; }
+    } else p->prec36 = nullptr;
+    free(rec);
+}
+
 extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const int *ptr, void *stream)
 {
     if (!p || (p->n > 0 && !ptr)) return LISHIP_ERR_ARG;
@@ -2409,6 +2503,7 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
             PT(hipMemcpyAsync(p->ptab8, rec, sizeof(int) * 8 * (size_t)npat, hipMemcpyHostToDevice, st));
             for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
         }
+        if (rc == 0) build_team_records(p, tab, npat);
         if (rc == 0) {
             csr_encode_patterns<<<p->nblocks, 256, 0, st>>>(p->blk, ptr, p->codes, npat, d_hash, d_len, d_pc, p->rowpat, p->rowrel, d_bad);
             PT(hipGetLastError());
@@ -2424,7 +2519,8 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
         if (p->rowpat) (void)hipFree(p->rowpat);
         if (p->rowrel) (void)hipFree(p->rowrel);
         if (p->ptab8) (void)hipFree(p->ptab8);
-        p->ptab = nullptr; p->rowpat = nullptr; p->rowrel = nullptr; p->ptab8 = nullptr;
+        if (p->prec36) (void)hipFree(p->prec36);
+        p->ptab = nullptr; p->rowpat = nullptr; p->rowrel = nullptr; p->ptab8 = nullptr; p->prec36 = nullptr;
         return rc;
     }
     p->npat = npat; p->ptab_len = npat + 1 + total;
@@ -2438,6 +2534,8 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
 // number of row patterns when the plan keeps one byte per row, 0 otherwise
 extern "C" int liship_csr_plan_row_patterns(liship_csr_plan_t p) { return (p && p->rowpat) ? p->npat : 0; }
 // 1 when every pattern has 1..7 offsets and the plan also keeps them as 32 B records (spmv_csr_pattern7_kernel), else 0
+// 1 when the plan keeps the 144 B records of spmv_csr_pattern_team_kernel (longest pattern 8..32 offsets)
+extern "C" int liship_csr_plan_team_records(liship_csr_plan_t p) { return (p && p->rowpat && p->prec36) ? 1 : 0; }
 extern "C" int liship_csr_plan_pattern_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8) ? 1 : 0; }
 extern "C" int liship_spmv_csr_set_row_patterns(int on) { g_row_patterns = on ? 1 : 0; return 0; }
 
@@ -2687,6 +2785,7 @@ static int encode_wide_value_records(liship_csr_plan_s *p, const int *ptr, const
             (void)hipFree(p->rowpat); (void)hipFree(p->ptab);
             p->rowpat = newpat; newpat = nullptr; p->ptab = d_tab; p->npat = np2; p->ptab_len = ntab_len;
             for (int i = 0; i < np2; i++) p->prep[i] = reps2[i];
+            build_team_records(p, ntab, np2);            // (the values-streamed product of this plan reads the renumbered pattern bytes too)
         }
     }
 #undef PT
@@ -2958,6 +3057,12 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
         constexpr Geometry g = kGeom[G];
         spmv_csr_pattern7_kernel<g.block, g.work, 0><<<a.nb, g.block, 0, a.st>>>(
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
+        return;
+    }
+    if (a.rowpat && a.plan && a.plan->prec36 && g_variant == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
+        const int rows = a.re - a.rb;
+        if (rows > 0)
+            spmv_csr_pattern_team_kernel<256><<<(rows + 63) / 64, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, a.plan->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
     if (a.rowpat && (g_variant & ~0x2000) == 0) {    // one byte per ROW (the plan found <= 255 row patterns); 0x2000: experiment, table in LDS even for short patterns

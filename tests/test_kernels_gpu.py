@@ -209,7 +209,8 @@ ROW_PATTERNS = {"p1d_10000": 3, "p3d_20x17x13": 27, "p3d_64_sorted": 27, "p3d_40
 VALUE_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
                  "p3d_varcoef": 0, "p3d_holes": 0, "diagonals_255": 0, "band_9_unsorted": 0,
                  "p3d_dirichlet": 1,         # ... after the offset patterns were split by the values their rows carry
-                 "box27_18x15x13": 2, "box9_70x50": 2, "box27_dirichlet": 2}
+                 "box27_18x15x13": 2, "box9_70x50": 2, "box27_dirichlet": 2, "box27_varcoef_21x10x9": 0, "box27_varcoef_7x6x70": 0,
+                 "box9_varcoef_130x77": 0}
 PATTERN_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
                    "diagonals_255": 0, "p3d_holes": 0, "band_9_unsorted": 0, "rand_5000": 0, "p3d_varcoef": 1, "p3d_dirichlet": 1,
                    "box27_18x15x13": 0, "box9_70x50": 0}
@@ -244,6 +245,13 @@ def stencil_box(dims, centre=None):
     ptr = np.zeros(n + 1, np.int64)
     np.cumsum(np.bincount(rows, minlength=n), out=ptr[1:])
     return ptr.astype(np.int32), cols[order].astype(np.int32), vals[order]
+
+
+def stencil_box_variable_coefficients(dims, seed):
+    """the box stencil's pattern with random values (a 27-point discretisation on a non-uniform mesh): rows of 8..27 entries, values
+    streamed -- the four-lanes-per-row kernel (spmv_csr_pattern_team_kernel)"""
+    ptr, idx, val = stencil_box(dims)
+    return ptr, idx, np.random.default_rng(seed).uniform(-1, 1, len(val))
 
 
 def box27_with_dirichlet_rows(dims, every):
@@ -290,6 +298,9 @@ CODED_CASES = {
     "box27_18x15x13": (lambda: stencil_box((18, 15, 13)), 27),                                  # rows of up to 27 entries: the wide value records
     "box9_70x50": (lambda: stencil_box((70, 50)), 9),
     "box27_dirichlet": (lambda: box27_with_dirichlet_rows((16, 13, 11), 7), 27),              # wide records after the split by values
+    "box27_varcoef_21x10x9": (lambda: stencil_box_variable_coefficients((21, 10, 9), 8), 27),      # values streamed: four lanes per row, odd sizes
+    "box27_varcoef_7x6x70": (lambda: stencil_box_variable_coefficients((7, 6, 70), 9), 27),
+    "box9_varcoef_130x77": (lambda: stencil_box_variable_coefficients((130, 77), 10), 9),
     "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
     "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
     "p3d_40_sorted": (lambda: orc.poisson3d(40, 40, 40, sort_cols=True), 7),                # several row blocks
@@ -340,6 +351,10 @@ def test_spmv_csr_index_codes(lib, name):
         assert npat == ROW_PATTERNS[name], npat
     if name in PATTERN_RECORDS:
         assert lib.liship_csr_plan_pattern_records(plan) == PATTERN_RECORDS[name]
+    if name.startswith("box"):                  # longest pattern of 8..32 offsets: the 144 B records of the four-lanes-per-row kernel
+        assert lib.liship_csr_plan_team_records(plan) == 1
+    elif lib.liship_csr_plan_pattern_records(plan) == 1:
+        assert lib.liship_csr_plan_team_records(plan) == 0
     check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
     if name in VALUE_RECORDS:
         assert lib.liship_csr_plan_value_records(plan) == VALUE_RECORDS[name]

@@ -35,9 +35,16 @@ def stencil27(N):
 lib = lis_amd.load()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 160
 ptr, idx, val = stencil27(N)
+if "--varying" in sys.argv:                       # a non-uniform mesh: the pattern stays, every row has its own values
+    val = np.random.default_rng(5).uniform(-1, 1, len(val))
 n, nnz = len(ptr) - 1, len(idx)
 dptr, didx, dval = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64)
 x, y = DA.from_host(np.cos(0.01 * np.arange(n)) + 1.25, np.float64), DA(n, np.float64)
+yref = None
+if N <= 200:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import orc
+    yref = orc.spmv_csr(ptr, idx, val, np.cos(0.01 * np.arange(n)) + 1.25)
 plan = C.c_void_p()
 check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
 check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
@@ -48,7 +55,15 @@ for codes, pats, vals in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)):
     lib.liship_spmv_csr_set_index_codes(codes)
     lib.liship_spmv_csr_set_row_patterns(pats)
     lib.liship_spmv_csr_set_row_values(vals)
-    ms = timed(lib, lambda: check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None)), iters=50, warm=20)
+    for variant in ((0, 0x2000) if (codes, pats, vals) == (1, 1, 0) else (0,)):      # 0x2000: the general (one lane per row) pattern kernel
+        lib.liship_spmv_csr_set_variant(variant)
+        ms = timed(lib, lambda: check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None)), iters=50, warm=20)
+        if yref is not None:
+            assert np.array_equal(y.to_host(), yref), (codes, pats, vals, variant)
+        own = 8 * nnz + 17 * n
+        if variant or (codes, pats, vals) == (1, 1, 0):
+            print(f"  variant {variant:#x}: {ms:.4f} ms = {own / ms / 8e7:.1f} % of 8 TB/s on the 8 B per non-zero + 17 B per row it streams (team records {lib.liship_csr_plan_team_records(plan)})", flush=True)
+    lib.liship_spmv_csr_set_variant(0)
     alg = 12 * nnz + 20 * n
     print(f"codes {codes} patterns {pats} value records {vals}: {ms:.4f} ms  {2e-6 * nnz / ms:.1f} GFLOP/s  {alg / ms / 1e6:.0f} GB/s on the contract's bytes ({alg / ms / 8e7:.1f} % of 8 TB/s)", flush=True)
 lib.liship_spmv_csr_set_index_codes(1)

@@ -999,64 +999,75 @@ void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict_
 // The 27-point stencil with varying coefficients (any matrix on <= 255 row patterns whose longest has 8..32 offsets, values
 // streamed).  One lane per row leaves the general pattern kernel with 73 busy lanes of 256 and FOUR dependent gather round trips per
 // row behind the barrier that waits for the value slice (27 gathers, 8 in flight): 0.47 of the roofline on its bytes.  Here a row
-// is the business of a TEAM of four neighbouring lanes: lane t owns entries 8t .. 8t+7, so a row's gathers are one batch per lane and
-// leave BEFORE the slice has landed (pattern byte -> 144 B pattern record -> gathers: the record loads are issued ahead of the
-// slice's LDS-DMA, the vector-memory counter counts in order), every lane of the workgroup has work, and a workgroup lives for two
+// is the business of a TEAM of four lanes: lane t of the team owns entries 8t .. 8t+7, so a row's gathers are one batch per lane and
+// leave BEFORE the slice has landed (pattern byte -> 144 B pattern record -> gathers -> the slice's LDS-DMA behind them: the
+// vector-memory counter counts in order, a wait for the records must not be a wait for the slice), every lane of the workgroup has work, and a workgroup lives for two
 // long round trips instead of six.  The sum stays ONE chain per row, strictly left to right: lane 0 adds its eight products to the
-// start value, hands the sum to lane 1 through a quad-permute DPP move (registers, not LDS -- the LDS round trip of the products is
-// what sank round 2's team variant), and so on; a lane whose segment is empty adds -0.0 terms.  Same terms, same order: the
-// reference's bits (lis_matvec_csr.c:97-109).  Row blocks are 64 consecutive rows (no merge-path split: rows of 8..32 balance).
+// start value, hands the sum to lane 1 through the LDS crossbar (ds_bpermute: registers to registers, no memory -- the LDS round trip of
+// the PRODUCTS is what sank round 2's team variant), and so on; a lane whose segment is empty adds -0.0 terms.  Same terms, same order: the
+// reference's bits (lis_matvec_csr.c:97-109).  A wavefront takes 16 consecutive rows (no merge-path split: rows of 8..32 balance).
 constexpr int TEAM_SEG = 8, TEAM_MAXLEN = 32, TEAM_REC = 9;     // a pattern record: 32 byte offsets (the tail repeats the last), length + 3 pad = 9 x 16 B
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
                                   const v4i32 *__restrict__ prec, const double *__restrict__ x, double *__restrict__ y, Rows RW, int nnz_total)
 {
-    constexpr int RPB = BLOCK / 4;                              // rows per workgroup
-    __shared__ __attribute__((aligned(16))) double valL[RPB * TEAM_MAXLEN + 2 + 40];
-    const int r0 = RW.rb + (int)blockIdx.x * RPB, r1 = min(r0 + RPB, RW.re);
+    // A wavefront owns 16 consecutive rows AND their value slice: nothing is shared between the wavefronts of a workgroup, so there is no
+    // barrier -- a wavefront waits for its own loads only.  lane = 16 t + i: the 16 lanes that hold segment t of 16 NEIGHBOURING rows
+    // are neighbours, so a gather instruction touches four 128 B runs of x (with lane = 4 i + t no two neighbouring lanes shared a line:
+    // 78 L1 accesses per gather instruction, the texture addresser 92 % busy -- profiles/r03_pattern_team_kernel.txt)
+    constexpr int RPW = 16, STAGE = RPW * TEAM_MAXLEN + 2 + 46;  // rows, doubles of LDS per wavefront (16 B multiple)
+    __shared__ __attribute__((aligned(16))) double stage[(BLOCK / WAVE) * STAGE];
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
+    double *valL = stage + w * STAGE;
+    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
     if (r0 >= r1) return;
-    const int t = (int)threadIdx.x & 3;
-    const int r = min(r0 + ((int)threadIdx.x >> 2), r1 - 1);    // (lanes beyond the last row repeat it and store nothing)
-    const bool live = r0 + ((int)threadIdx.x >> 2) < r1;
-    const int pat = rowpat[r];                                  // the first loads: everything the gathers wait for
+    const int t = lane >> 4;
+    const int r = min(r0 + (lane & 15), r1 - 1);                // (lanes beyond the last row repeat it and store nothing)
+    const bool live = r0 + (lane & 15) < r1;
+    const int k0 = ptr[r0], k1 = ptr[r1];                       // (uniform: scalar loads) the slice's extent, asked for first ...
+    const int pat = rowpat[r];                                  // ... with everything the gathers wait for
     const int s = ptr[r];
-    const int k0 = ptr[r0], k1 = ptr[r1];                       // (uniform: scalar loads)
+    __builtin_amdgcn_sched_barrier(0);                          // (the scheduler would issue the scalar loads behind the wait for the pattern byte)
     const int ka = k0 & ~1, cnt = k1 - ka;
     int np = (cnt + 1) >> 1;                                    // 16 B pieces of the value slice
     const bool odd_end = ka + 2 * np > nnz_total;               // the last piece would pass the end of the array: its one value by a plain load
     if (odd_end) np--;
     const v4i32 *rec = prec + pat * TEAM_REC;
     const v4i32 o0 = rec[2 * t], o1 = rec[2 * t + 1];           // this lane's eight byte offsets ...
-    const int len = rec[8].x;                                   // ... and the row's length: issued AHEAD of the slice
-    {
-        const int wbase = (int)threadIdx.x & ~(WAVE - 1), lane = (int)threadIdx.x & (WAVE - 1);
-        for (int p0 = wbase; p0 < np; p0 += BLOCK) {
-            const int p = min(p0 + lane, np - 1);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p),
-                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
-        }
-    }
+    const int len = *reinterpret_cast<const int *>(rec + 8);    // ... and the row's length: issued AHEAD of the slice
     const char *xb = reinterpret_cast<const char *>(x + r);
     double xx[TEAM_SEG];
     xx[0] = *reinterpret_cast<const double *>(xb + o0.x); xx[1] = *reinterpret_cast<const double *>(xb + o0.y);
     xx[2] = *reinterpret_cast<const double *>(xb + o0.z); xx[3] = *reinterpret_cast<const double *>(xb + o0.w);
     xx[4] = *reinterpret_cast<const double *>(xb + o1.x); xx[5] = *reinterpret_cast<const double *>(xb + o1.y);
     xx[6] = *reinterpret_cast<const double *>(xb + o1.z); xx[7] = *reinterpret_cast<const double *>(xb + o1.w);
-    if (odd_end && threadIdx.x == 0) valL[cnt - 1] = val[k1 - 1];
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);                          // (gathers, then the slice: a wait for the records must not be a wait for the slice)
+#pragma unroll
+    for (int it = 0; it < (RPW * TEAM_MAXLEN / 2 + WAVE) / WAVE; it++) {            // (at most five 1 KB pieces: no loop, no wait in front of it)
+        const int p0 = it * WAVE;
+        if (p0 < np) {
+            const int p = min(p0 + lane, np - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+        }
+    }
+    if (odd_end && lane == 0) valL[cnt - 1] = val[k1 - 1];
+    __builtin_amdgcn_s_waitcnt(0);                              // this wavefront's slice (and gathers) have landed: vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nt = min(max(len - TEAM_SEG * t, 0), TEAM_SEG);   // entries of this lane's segment
     const double *vp = valL + (s - ka) + TEAM_SEG * t;          // (reads up to 7 doubles past a short row: inside the stage)
     double pm[TEAM_SEG];
 #pragma unroll
     for (int u = 0; u < TEAM_SEG; u++) { const double pr = vp[u] * xx[u]; pm[u] = u < nt ? pr : -0.0; }
     double c = RW.acc0;
+    const int from = ((lane - 16) & (WAVE - 1)) * 4;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         double in = RW.acc0;
-        if (k > 0) in = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(c), 0x90, 0xf, 0xf, true),     // quad_perm [0,0,1,2]: lane t takes lane t-1's sum
-                                         __builtin_amdgcn_update_dpp(0, __double2loint(c), 0x90, 0xf, 0xf, true));
+        if (k > 0) in = __hiloint2double(__builtin_amdgcn_ds_bpermute(from, __double2hiint(c)),    // lane 16 t + i takes the sum of lane 16 (t-1) + i
+                                         __builtin_amdgcn_ds_bpermute(from, __double2loint(c)));   // (the LDS crossbar: no memory is touched)
 #pragma unroll
         for (int u = 0; u < TEAM_SEG; u++) in += pm[u];
         c = t == k ? in : c;
@@ -3060,6 +3071,8 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
         return;
     }
     if (a.rowpat && a.plan && a.plan->prec36 && g_variant == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
+        // (measured and dropped, profiles/r03_pattern_team_kernel.txt: XCD slabs / runs of 1024+ workgroups +-2 %; the pattern byte speculated -- an
+        //  ablation that takes it from a kernel argument -- 2 %: the kernel moves 2.35 GB through the fabric at 6.1 TB/s, the round trips are hidden)
         const int rows = a.re - a.rb;
         if (rows > 0)
             spmv_csr_pattern_team_kernel<256><<<(rows + 63) / 64, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, a.plan->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz);

@@ -538,6 +538,124 @@ void spmv_bsr_rows_kernel(int nr, const int *__restrict__ bptr, const int *__res
     }
 }
 
+// Square BSR blocks with LONG block rows (the dofs-per-node finite-element pattern: 27 blocks per block row for hexahedra): a TEAM of
+// T lanes per block row, the four-lanes-per-row shape of spmv_csr_pattern_team_kernel (spmv_csr.hip).  A wavefront owns 64 / T
+// neighbouring block rows and exactly their value slice (LDS-DMA, 16-18 KB in flight per wavefront; no barrier: one wavefront per
+// workgroup); lane t of a team owns blocks SEG t .. SEG t + SEG - 1 of its block row: their SEG indices, the SEG x BS gathers of x --
+// one batch, ahead of the slice -- and their BS x BS x SEG products, formed once and kept in registers.  The BS row sums of a block row
+// stay ONE chain each, block by block, column by column (lis_matvec_bsr.c:120-148, the unrolled 3x3 order :340-343): lane 0 adds its
+// products to 0.0, lane 1 takes the sums through the LDS crossbar (ds_bpermute: registers to registers) and adds its own, and so on
+// for T rounds; absent blocks add +0.0 (the sums start at +0.0 and can never be -0.0).  lane = (64 / T) t + i, so that the lanes
+// holding segment t of neighbouring block rows -- neighbouring block columns -- are neighbours.  A wavefront with a block row of more
+// than T x SEG blocks walks its rows one scalar row per lane from global memory (rare: the kernel is chosen by the MEAN length).
+// The two-phase tile kernels above measured 57-67 % of the roofline on this pattern: every pass of theirs is two barriers, and the
+// products go through LDS.
+template <int BS, int T, int SEG>
+__global__ __launch_bounds__(WAVE)
+void spmv_bsr_team_kernel(int nr, const int *__restrict__ bptr, const int *__restrict__ bidx,
+                          const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+{
+    constexpr int BB = BS * BS, RPW = WAVE / T, CAPB = RPW * T * SEG;      // block rows per wavefront; blocks the stage holds
+    constexpr int PIECES = ((CAPB + 1) * BB + 1) / 2;                       // 16 B pieces of the largest slice
+    // even BS: one 16 B unit of padding after every KiB (= one DMA instruction) of the stage, as in spmv_bsr_rows_kernel: block rows of one length
+    // put the lanes of a segment a fixed stride apart (26 blocks of 128 B: every lane in the same banks); a block never straddles a KiB
+    constexpr bool SKEW = BB % 2 == 0;
+    __shared__ __attribute__((aligned(16))) double valL[2 * (PIECES + (SKEW ? PIECES / 64 + 1 : 0)) + 2 * WAVE];
+    const int lane = (int)threadIdx.x, i = lane % RPW, t = lane / RPW;
+    const int br0 = (int)blockIdx.x * RPW, br1 = min(br0 + RPW, nr);
+    const int k0 = bptr[br0], k1 = bptr[br1], nblk_total = bptr[nr];       // (uniform: scalar loads)
+    const int br = min(br0 + i, br1 - 1);
+    const bool live = br0 + i < br1;
+    const int rs = bptr[br], re = bptr[br + 1], len = re - rs;
+    if (k1 == k0) {                                                        // nothing stored in these block rows
+        if (live && t == T - 1) for (int q = 0; q < BS; q++) y[(size_t)br * BS + q] = 0.0;
+        return;
+    }
+    if (__any(len > T * SEG)) {                                            // a block row the teams cannot hold: one scalar row per lane, from memory
+        for (int r = br0 * BS + lane; r < br1 * BS; r += WAVE) {
+            const int b = r / BS, ii = r - b * BS;
+            double acc = 0.0;
+            for (int k = bptr[b]; k < bptr[b + 1]; k++) {
+                const double *blk = val + (size_t)k * BB + ii;
+                const double *xb = x + (size_t)bidx[k] * BS;
+                for (int j = 0; j < BS; j++) acc += blk[(size_t)j * BS] * xb[j];
+            }
+            y[r] = acc;
+        }
+        return;
+    }
+    // this lane's blocks (clamped to the row's last one: always an address of the row; masked below)
+    int kb[SEG], bi[SEG];
+#pragma unroll
+    for (int u = 0; u < SEG; u++) {
+        kb[u] = min(max(min(rs + SEG * t + u, re - 1), rs), nblk_total - 1);
+        bi[u] = bidx[kb[u]];
+    }
+    double xv[SEG][BS];
+#pragma unroll
+    for (int u = 0; u < SEG; u++) {
+        const double *xp = x + (size_t)bi[u] * BS;
+#pragma unroll
+        for (int j = 0; j < BS; j++) xv[u][j] = xp[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);                  // (indices, gathers, then the slice: a wait for the indices must not be a wait for the slice)
+    const int ka = k0 & ~1;                             // 16 B aligned start of the slice
+    const int cnt = k1 - ka;
+    int np = (cnt * BB + 1) >> 1;                       // 16 B pieces
+    const bool tail = (long long)ka * BB + 2LL * np > (long long)nblk_total * BB;      // odd BS: the array's last value has no 16 B piece
+    if (tail) np--;
+#pragma unroll
+    for (int it = 0; it < (PIECES + WAVE - 1) / WAVE; it++) {
+        const int p0 = it * WAVE;
+        if (p0 < np) {
+            const int p = min(p0 + lane, np - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + (size_t)ka * BB) + p),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0 + (SKEW ? it : 0)), 16, 0, 2);
+        }
+    }
+    if (tail && lane == 0) valL[cnt * BB - 1] = val[(size_t)(ka + cnt) * BB - 1];      // (odd BS only: no skew)
+    __builtin_amdgcn_s_waitcnt(0);                      // this wavefront's slice and gathers have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double pm[SEG][BS][BS];                             // [block][column][row]: the products, in the order they are added
+#pragma unroll
+    for (int u = 0; u < SEG; u++) {
+        const int unit = (kb[u] - ka) * (BB / 2);        // (even BS) 16 B units in front of the block
+        const double *a = SKEW ? valL + 2 * (unit + (unit >> 6)) : valL + (size_t)(kb[u] - ka) * BB;
+        const bool ok = SEG * t + u < len;
+#pragma unroll
+        for (int j = 0; j < BS; j++)
+#pragma unroll
+            for (int q = 0; q < BS; q++) { const double pr = a[q + j * BS] * xv[u][j]; pm[u][j][q] = ok ? pr : 0.0; }
+    }
+    double acc[BS];
+#pragma unroll
+    for (int q = 0; q < BS; q++) acc[q] = 0.0;
+    const int from = ((lane - RPW) & (WAVE - 1)) * 4;
+#pragma unroll
+    for (int k = 0; k < T; k++) {
+        double in[BS];
+#pragma unroll
+        for (int q = 0; q < BS; q++)
+            in[q] = k == 0 ? 0.0 : __hiloint2double(__builtin_amdgcn_ds_bpermute(from, __double2hiint(acc[q])),
+                                                    __builtin_amdgcn_ds_bpermute(from, __double2loint(acc[q])));
+#pragma unroll
+        for (int u = 0; u < SEG; u++)
+#pragma unroll
+            for (int j = 0; j < BS; j++)
+#pragma unroll
+                for (int q = 0; q < BS; q++) in[q] += pm[u][j][q];
+#pragma unroll
+        for (int q = 0; q < BS; q++) acc[q] = t == k ? in[q] : acc[q];
+    }
+    if (live && t == T - 1) {
+#pragma unroll
+        for (int q = 0; q < BS; q++) store_stream(y + (size_t)br * BS + q, acc[q]);
+    }
+}
+
+int g_bsr_team = 1;              // liship_spmv_bsr_set_team: 0 keeps long block rows on the two-phase tile kernels (A/B)
+
 inline int grid_for(int n) { return (n + BLOCK - 1) / BLOCK; }
 
 } // namespace
@@ -749,6 +867,8 @@ extern "C" int liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int
     return 0;
 }
 
+extern "C" int liship_spmv_bsr_set_team(int on) { g_bsr_team = on; return 0; }
+
 extern "C" int liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, const int *bidx,
                                    const double *val, const double *x, double *y, void *stream)
 { return liship_spmv_bsr_nnz_f64(nr, -1, bnr, bnc, bptr, bidx, val, x, y, stream); }
@@ -796,16 +916,21 @@ extern "C" int liship_spmv_bsr_nnz_f64(int nr, int bnnz, int bnr, int bnc, const
         switch (bnr) {
         case 1: spmv_bsr_tile_kernel<1, 1><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y); break;
         case 2:
+            if (g_bsr_team && bnnz >= 0 && mean > 12.0) { spmv_bsr_team_kernel<2, 8, 4><<<(nr + 7) / 8, WAVE, 0, st>>>(nr, bptr, bidx, val, x, y); break; }
             if (aligned16(x) && aligned16(y) && aligned16(bidx) && (bnnz < 0 || mean <= 12.0))
                 spmv_bsr_rows_kernel<2, 512, 8><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
             else if (aligned16(x)) spmv_bsr22_kernel<<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             else              spmv_bsr_tile_kernel<2, 2><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             break;
         case 3:
+            if (g_bsr_team && bnnz >= 0 && mean > 16.0) { spmv_bsr_team_kernel<3, 8, 4><<<(nr + 7) / 8, WAVE, 0, st>>>(nr, bptr, bidx, val, x, y); break; }
             if (aligned16(bidx) && bnnz >= 0 && mean <= 16.0) spmv_bsr_rows_kernel<3, 352, 12><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
             else                 spmv_bsr_tile_kernel<3, 3><<<grid, BLOCK, 0, st>>>(nr, bptr, bidx, val, x, y);
             break;
         default:
+            // (4x4 long block rows stay with the tile kernel: a team's T rounds cost T x the additions, and at 16 per block that is what binds --
+            //  <4, 16, 2> 62.6 %, <4, 8, 4> 62.0-63.8 % against 65.8-68.4 %, profiles/r03_bsr_team_kernel.txt; g_bsr_team = 2 selects it for A/B)
+            if (g_bsr_team == 2 && bnnz >= 0 && mean > 12.0) { spmv_bsr_team_kernel<4, 8, 4><<<(nr + 7) / 8, WAVE, 0, st>>>(nr, bptr, bidx, val, x, y); break; }
             if (aligned16(x) && aligned16(y) && aligned16(bidx) && bnnz >= 0 && mean <= 12.0)
                 spmv_bsr_rows_kernel<4, 160, 8><<<(nr + BSR_LANES - 1) / BSR_LANES, BSR_LANES, 0, st>>>(nr, bptr, bidx, val, x, y);
             else

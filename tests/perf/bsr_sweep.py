@@ -31,20 +31,23 @@ def main():
         B = lisdrv.convert(lib, A, "bsr", bs, bs)
         bnnz, nr = B.contents.bnnz, B.contents.nr
         vx, vy = lisdrv.new_vector(lib, B, x), lisdrv.new_vector(lib, B)
-        for _ in range(20):
-            assert lib.lis_matvec(B, vx, vy) == 0
-        lib.dll.lis_amd_synchronize()
-        t0 = time.perf_counter()
-        reps = 200
-        for _ in range(reps):
-            assert lib.lis_matvec(B, vx, vy) == 0
-        lib.dll.lis_amd_synchronize()
-        ms = (time.perf_counter() - t0) / reps * 1e3
-        alg = bnnz * (8 * bs * bs + 4) + 4 * nr + 16 * n
-        nrm = C.c_double()
-        lib.lis_vector_nrm2(vy, C.byref(nrm))
-        print(f"bsr {bs}x{bs}: {bnnz / nr:.1f} blocks/row  {ms:.4f} ms  {2 * nnz / ms / 1e6:.1f} GFLOP/s  {alg / ms / 1e6:.0f} GB/s alg "
-              f"({alg / ms / 1e6 / 80:.1f}% of 8 TB/s)  ||A*1||={nrm.value:.6e}", flush=True)
+        for team in (1, 0):                     # 0: long block rows through the two-phase tile kernels (A/B)
+            lib.liship_spmv_bsr_set_team(team)
+            for _ in range(20):
+                assert lib.lis_matvec(B, vx, vy) == 0
+            lib.dll.lis_amd_synchronize()
+            t0 = time.perf_counter()
+            reps = 200
+            for _ in range(reps):
+                assert lib.lis_matvec(B, vx, vy) == 0
+            lib.dll.lis_amd_synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            alg = bnnz * (8 * bs * bs + 4) + 4 * nr + 16 * n
+            nrm = C.c_double()
+            lib.lis_vector_nrm2(vy, C.byref(nrm))
+            print(f"bsr {bs}x{bs} team {team}: {bnnz / nr:.1f} blocks/row  {ms:.4f} ms  {2 * nnz / ms / 1e6:.1f} GFLOP/s  {alg / ms / 1e6:.0f} GB/s alg "
+                  f"({alg / ms / 1e6 / 80:.1f}% of 8 TB/s)  ||A*1||={nrm.value:.6e}", flush=True)
+        lib.liship_spmv_bsr_set_team(1)
         lib.lis_matrix_destroy(B)
 
 

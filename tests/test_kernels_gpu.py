@@ -585,6 +585,9 @@ BSR22_CASES = {
     "long_rows": lambda: orc.random_csr(9000, 3, seed=2, long_row=7001),         # a block row of > 512 blocks: several LDS passes
     "mostly_empty": lambda: orc.random_csr(20000, 0.05, seed=4),
     "wide": lambda: orc.random_csr(4000, 77, seed=3, ncols=4000, empty_rows=False),
+    "fem_3dofs": lambda: orc.fem3(7, 3)[:3],        # 27 blocks per interior block row at 3x3: the team-per-block-row kernel (8 lanes x 4 blocks)
+    "fem_2dofs": lambda: orc.fem3(9, 2)[:3],
+    "fem_4dofs": lambda: orc.fem3(6, 4)[:3],
 }
 
 
@@ -605,10 +608,13 @@ def test_spmv_bsr_square_blocks(lib, name, bs):
     a, b, c = DA.from_host(bptr), DA.from_host(bidx if len(bidx) else np.zeros(1, np.int32)), DA.from_host(bv if len(bv) else np.zeros(1))
     dx, dy = DA.from_host(xx), DA.from_host(np.full(nr * bs, np.nan))
     ref = orc.spmv_bsr(n, nr, bs, bs, bptr, bidx, bv, xx)
-    for known in (-1, len(bidx), 0):                      # 0: "short block rows" claimed for any matrix -> the lane-per-block-row kernel
-        dy = DA.from_host(np.full(nr * bs, np.nan))
-        check(lib.liship_spmv_bsr_nnz_f64(nr, known, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
-        assert np.array_equal(dy.to_host(n), ref), known
+    for known in (-1, len(bidx), 0, 1 << 30):             # 0: "short block rows" claimed for any matrix -> the lane-per-block-row kernel;
+        for team in (1, 0, 2):                            # 2^30: long ones -> a team per block row (2: at 4x4 too), or (team 0) the two-phase tile kernels
+            lib.liship_spmv_bsr_set_team(team)
+            dy = DA.from_host(np.full(nr * bs, np.nan))
+            check(lib.liship_spmv_bsr_nnz_f64(nr, known, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host(n), ref), (known, team)
+    lib.liship_spmv_bsr_set_team(1)
     check(lib.liship_spmv_bsr_f64(nr, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
     assert np.array_equal(dy.to_host(n), ref)
     # the product with the reduction epilogue: same y, sums as numpy to 1e-13, repeatable; refuses what it does not serve
@@ -648,10 +654,12 @@ def test_spmv_bsr_on_random_structured_matrices(lib, seed):
         ref = orc.spmv_bsr(n, nr, bs, bs, bptr, bidx, bv, xx)
         a, b, c = DA.from_host(bptr), DA.from_host(bidx if len(bidx) else np.zeros(1, np.int32)), DA.from_host(bv if len(bv) else np.zeros(1))
         dx = DA.from_host(xx)
-        for known in (0, 1 << 30, len(bidx)):             # claimed short block rows, claimed long ones, the truth
+        for known, team in ((0, 1), (1 << 30, 1), (1 << 30, 2), (1 << 30, 0), (len(bidx), 1)):      # claimed short block rows, claimed long ones (a team per block row /
+            lib.liship_spmv_bsr_set_team(team)                                        # the two-phase tile kernels), the truth
             dy = DA.from_host(np.full(max(nr * bs, 1), np.nan))
             check(lib.liship_spmv_bsr_nnz_f64(nr, known, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
-            assert np.array_equal(dy.to_host(n), ref), (seed, bs, known)
+            assert np.array_equal(dy.to_host(n), ref), (seed, bs, known, team)
+        lib.liship_spmv_bsr_set_team(1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 1000, 4097, 1 << 20, (1 << 20) + 3])

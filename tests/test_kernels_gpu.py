@@ -1124,6 +1124,47 @@ def test_full_size_512_properties(lib):
     check(lib.liship_csr_plan_destroy(plan))
 
 
+def test_team_kernels_at_scale(lib):
+    """the two team-of-lanes kernels of round 3 at the sizes their timings are quoted on, against the oracle bit for bit: the 27-point stencil
+    with random coefficients at 160^3 (4.1 M rows, 109 M non-zeros: spmv_csr_pattern_team_kernel vs the one-lane-per-row pattern kernel vs
+    lis_matvec_csr's order) and the 3-dofs-per-node finite-element pattern in 3x3 BSR at 64^3 nodes (0.79 M rows, 61 M non-zeros:
+    spmv_bsr_team_kernel vs the two-phase tile kernel vs lis_matvec_bsr's order)"""
+    ptr, idx, val = stencil_box_variable_coefficients((160, 160, 160), 12)
+    n = len(ptr) - 1
+    x = np.modf(np.arange(n, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval, dx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    assert lib.liship_csr_plan_row_patterns(plan) == 27 and lib.liship_csr_plan_team_records(plan) == 1 and lib.liship_csr_plan_value_records(plan) == 0
+    for variant in (0, 0x2000):
+        lib.liship_spmv_csr_set_variant(variant)
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host().view(np.uint64), yref.view(np.uint64)), hex(variant)
+    lib.liship_spmv_csr_set_variant(0)
+    check(lib.liship_csr_plan_destroy(plan))
+    del dptr, didx, dval, dx, dy
+
+    ptr, idx, val = orc.fem3(64, 3)[:3]
+    n = len(ptr) - 1
+    nr, bptr, bidx, bv = orc.csr2bsr(ptr, idx, val, 3, 3)
+    assert len(bidx) / nr > 16                      # long block rows: the dispatcher takes the team kernel
+    xx = np.zeros(nr * 3 + 3)
+    xx[:n] = np.modf(np.arange(n, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+    ref = orc.spmv_bsr(n, nr, 3, 3, bptr, bidx, bv, xx)
+    a, b, c, dx = DA.from_host(bptr), DA.from_host(bidx), DA.from_host(bv), DA.from_host(xx)
+    for team in (1, 0):
+        lib.liship_spmv_bsr_set_team(team)
+        dy = DA.from_host(np.full(nr * 3, np.nan))
+        check(lib.liship_spmv_bsr_nnz_f64(nr, len(bidx), 3, 3, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host(n).view(np.uint64), ref.view(np.uint64)), team
+    lib.liship_spmv_bsr_set_team(1)
+
+
 def test_full_size_512_six_forms_bit_equal(lib):
     """BASELINE's full size with a NON-TRIVIAL x through every form of the CSR product the plan can choose -- 4 B indices,
     one-byte column codes, row patterns (general kernel and the 32 B-record kernel), value records one and two rows per lane and with

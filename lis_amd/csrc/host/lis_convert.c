@@ -249,10 +249,12 @@ static LIS_INT csr2bsr(LIS_MATRIX A, LIS_MATRIX B)
 	 * a short list searched linearly from its end (neighbouring entries repeat the last block) replaces a table over all nc. */
 	enum { LOCAL = 512 };
 	bptr[0] = 0;
+	int oom = 0;                                                /* a failed allocation inside the parallel loops: reported after them */
 	#pragma omp parallel for schedule(dynamic, 1024) num_threads(lisi_host_threads())
 	for (LIS_INT br = 0; br < nr; br++) {                       /* pass 1: distinct block columns per block row */
 		LIS_INT list[LOCAL], nseen = 0, *big = NULL, cap = LOCAL;
 		LIS_INT *cur = list;
+		if (oom) { bptr[br + 1] = 0; continue; }
 		for (LIS_INT ii = 0; ii < bnr && br * bnr + ii < n; ii++)
 			for (LIS_INT k = A->ptr[br * bnr + ii]; k < A->ptr[br * bnr + ii + 1]; k++) {
 				const LIS_INT bc = BCOL(A->index[k]);
@@ -261,6 +263,11 @@ static LIS_INT csr2bsr(LIS_MATRIX A, LIS_MATRIX B)
 				if (s < 0) {
 					if (nseen == cap) {                             /* a very wide block row: the list moves to the heap */
 						LIS_INT *nb = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)cap * 2);
+						if (!nb) {
+							#pragma omp atomic write
+							oom = 1;
+							nseen = 0; ii = bnr; break;                  /* give the row up: the whole conversion fails below */
+						}
 						memcpy(nb, cur, sizeof(LIS_INT) * (size_t)cap);
 						free(big); big = nb; cur = nb; cap *= 2;
 					}
@@ -270,6 +277,7 @@ static LIS_INT csr2bsr(LIS_MATRIX A, LIS_MATRIX B)
 		free(big);
 		bptr[br + 1] = nseen;
 	}
+	if (oom) { err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc: distinct block columns of a block row\n"); goto fail; }
 	for (LIS_INT br = 0; br < nr; br++) bptr[br + 1] += bptr[br];
 	const LIS_INT bnnz = bptr[nr];
 	NEW(bindex, LIS_INT, bnnz); NEW(value, LIS_SCALAR, (size_t)bnnz * bs);

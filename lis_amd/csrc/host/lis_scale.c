@@ -201,7 +201,7 @@ LIS_INT lisi_matrix_bscale_bsr(LIS_MATRIX A, LIS_VECTOR B)
 		}
 	}
 	/* b <- WD b; the rows of the last block beyond n read the vector's padding (zeros) */
-	LISCHK(lisd_vec_host_write(B, 1));
+	{ const LIS_INT werr = lisd_vec_host_write(B, 1); if (werr) { free(wd); free(lu); return werr; } }
 	{
 		const size_t have = VDEV(B)->hlen;
 		LIS_SCALAR *t = (LIS_SCALAR *)calloc((size_t)nr * bn + 1, sizeof(LIS_SCALAR));

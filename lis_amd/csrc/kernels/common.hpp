@@ -19,6 +19,10 @@
     } while (0)
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
+// the same with the alignment of a double: two neighbouring x values gathered as one 16 B load from an address that is only 8 B aligned whenever
+// the column is odd (the +-1 offsets of every stencil).  gfx9 global memory serves it as one dwordx4 in the default unaligned access mode;
+// the type says so instead of leaving it to undefined behaviour.
+typedef double v2f64u __attribute__((ext_vector_type(2), aligned(8)));
 typedef int    v2i32 __attribute__((ext_vector_type(2)));
 typedef int    v4i32 __attribute__((ext_vector_type(4)));
 

@@ -1395,7 +1395,7 @@ void spmv_csr_valuerec_pair_kernel(const unsigned char *__restrict__ rowpat, con
             const int o[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
             const unsigned rb8 = (unsigned)ra[h] * 8u;
 #pragma unroll
-            for (int u = 0; u < 7; u++) xx[h][u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)o[u]));
+            for (int u = 0; u < 7; u++) xx[h][u] = *reinterpret_cast<const v2f64u *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)o[u]));
         }
     }
 #pragma unroll
@@ -1533,7 +1533,7 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
             const unsigned rb8 = (unsigned)ra * 8u;
             v2f64 xx[7];
 #pragma unroll
-            for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
+            for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64u *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
             const int pa = (int)(two & 255u), pb = (int)(two >> 8);
             double s0 = acc0, s1 = acc0;
             if (__builtin_amdgcn_ballot_w64(pa != D.pat || pb != D.pat) == 0) {      // (uniform) every row here is the dominant pattern
@@ -1616,7 +1616,7 @@ void spmv_csr_valuerec_dom_dot_kernel(const unsigned char *__restrict__ rowpat, 
                 else { twob = (unsigned)rowpat[ra] | ((unsigned)rowpat[ra + 1] << 8); ww.x = wdot[ra]; ww.y = wdot[ra + 1]; }
                 const unsigned rb8 = (unsigned)ra * 8u;
 #pragma unroll
-                for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
+                for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64u *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
             }
             const int pa = (int)(twob & 255u), pb = (int)(twob >> 8);
             double s0 = acc0, s1 = acc0;
@@ -1747,8 +1747,8 @@ void spmv_csr_valuerec_dom_dot4_kernel(const unsigned char *__restrict__ rowpat,
                 const unsigned rb8 = (unsigned)ra * 8u;
 #pragma unroll
                 for (int u = 0; u < 7; u++) {
-                    xx[0][u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
-                    xx[1][u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + 16u + (unsigned)D.off[u]));
+                    xx[0][u] = *reinterpret_cast<const v2f64u *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
+                    xx[1][u] = *reinterpret_cast<const v2f64u *>(reinterpret_cast<const char *>(x) + (rb8 + 16u + (unsigned)D.off[u]));
                 }
 #pragma unroll
                 for (int u = 0; u < 7; u++) if (u == wslot) { ww[0] = xx[0][u]; ww[1] = xx[1][u]; }      // w = x (CG's <p, A p>): the diagonal's gather IS w
@@ -1873,7 +1873,7 @@ void spmv_csr_valuerec_pair_dot_kernel(const unsigned char *__restrict__ rowpat,
             v2f64 xx[7], ww;
             if ((ra & 1) == 0) ww = *reinterpret_cast<const v2f64 *>(wdot + ra); else { ww.x = wdot[ra]; ww.y = wdot[ra + 1]; }
 #pragma unroll
-            for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64 *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)o[u]));
+            for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64u *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)o[u]));
             const v2f64 *q = reinterpret_cast<const v2f64 *>(recL + 6 * pa + 2);
             const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             const double v[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
@@ -2248,6 +2248,7 @@ static int build_split(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
     csr_plan_kernel<<<grid, threads, 0, st>>>(p->n, ptr, p->nblocks, WORK, (g_variant & 0x1000000) ? 0 : 1, p->blk);
     e = hipGetLastError();
     p->blk_host = (v2i32 *)malloc(bytes);
+    if (!p->blk_host) { (void)hipFree(p->blk); p->blk = nullptr; return LISHIP_ERR_ARG; }
     if (e == hipSuccess) e = hipMemcpyAsync(p->blk_host, p->blk, bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { (void)hipFree(p->blk); p->blk = nullptr; free(p->blk_host); p->blk_host = nullptr; return (int)e; }
@@ -2865,6 +2866,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     csr_local_build<256, 0, 8192><<<nb, 256, 0, st>>>(p->blk, idx, CAPL, NDMAX, nd_dev, nullptr, nullptr, nullptr);
     hipError_t e = hipGetLastError();
     int *off = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
+    if (!off && e == hipSuccess) e = hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemcpyAsync(off, nd_dev, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {

@@ -1010,8 +1010,10 @@ constexpr int TEAM_SEG = 8, TEAM_MAXLEN = 32, TEAM_REC = 9;     // a pattern rec
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
-                                  const v4i32 *__restrict__ prec, const double *__restrict__ x, double *__restrict__ y, Rows RW, int nnz_total)
+                                  const v4i32 *__restrict__ prec, const double *__restrict__ x, double *__restrict__ y, Rows RW, int nnz_total,
+                                  const double *__restrict__ guard = nullptr)
 {
+    if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
     // A wavefront owns 16 consecutive rows AND their value slice: nothing is shared between the wavefronts of a workgroup, so there is no
     // barrier -- a wavefront waits for its own loads only.  lane = 16 t + i: the 16 lanes that hold segment t of 16 NEIGHBOURING rows
     // are neighbours, so a gather instruction touches four 128 B runs of x (with lane = 4 i + t no two neighbouring lanes shared a line:
@@ -1073,6 +1075,26 @@ void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__r
         c = t == k ? in : c;
     }
     if (live && t == 3) store_stream(y + r, c);
+}
+
+// <w, y> (and <y, y>) of rows already multiplied, with the partial sums of the fused kernels: one workgroup per plan row block, lane L adds
+// the rows r0 + L, r0 + L + BLOCK, ... in that order, the workgroup folds as publish_dots does.  The four-lanes-per-row product has its
+// own row split (16 rows per wavefront), so its fused form is the product followed by this pass over y and w (16 B per row on top of 230):
+// the sums are then the bits every other form of the product makes.
+template <int BLOCK, int DOT>
+__global__ __launch_bounds__(BLOCK)
+void csr_block_dots_kernel(const int *__restrict__ ptr, const v2i32 *__restrict__ blk, int bfirst, int nb, Rows RW,
+                           const double *__restrict__ y, const double *__restrict__ wdot, double *__restrict__ partial,
+                           const double *__restrict__ guard, int pstride)
+{
+    if (guard != nullptr && guard[0] != 0.0) return;               // device-driven Krylov loop already converged
+    __shared__ double dot_scratch[BLOCK / WAVE];
+    RowDots<DOT> dots{wdot, 0.0, 0.0};
+    const int lb = blockIdx.x;
+    Blk B = load_blk(blk, bfirst + lb);
+    if (clip_rows(B, ptr, RW.rb, RW.re))
+        for (int r = B.r0 + (int)threadIdx.x; r < B.r1; r += BLOCK) dots.add(r, y[r]);
+    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
 // inclusive sum over the 64 lanes by data-parallel primitives: 4 shifts inside the rows of 16, then lane 15 of each row into
@@ -3147,6 +3169,11 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
         spmv_csr_valuerecw_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(
             a.rowpat, a.vrecw, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
             w, partial, liship_internal_guard(), pstride);
+        return;
+    }
+    if (a.rowpat && a.plan && a.plan->prec36 && g_variant == 0 && a.re > a.rb) {      // patterns of 8..32 offsets: four lanes per row, then the row blocks' sums
+        spmv_csr_pattern_team_kernel<256><<<(a.re - a.rb + 63) / 64, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, a.plan->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, liship_internal_guard());
+        csr_block_dots_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(a.ptr, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.y, w, partial, liship_internal_guard(), pstride);
         return;
     }
     if (a.rowpat) {

@@ -96,6 +96,10 @@ int  liship_csr_plan_pattern_records(liship_csr_plan_t plan);
  * values-streamed product runs four lanes per row, the gathers leaving ahead of the value slice and the row's one ordered sum handed
  * from lane to lane in registers (spmv_csr_pattern_team_kernel): liship_csr_plan_team_records = 1. */
 int  liship_csr_plan_team_records(liship_csr_plan_t plan);
+/* ... and when ONE pattern carries most rows and its sorted offsets are runs of consecutive columns of one length (the box stencils), the x a
+ * wavefront's 16 neighbouring rows need is staged in LDS by a few coalesced loads instead of a gather per entry (spmv_csr_pattern_team_staged_kernel):
+ * liship_csr_plan_team_form = 2 (1: the gathers of the first form; 0: no team records). */
+int  liship_csr_plan_team_form(liship_csr_plan_t plan);
 /* Value records (setup-time, optional, after liship_csr_plan_encode_row_patterns; never an error when the matrix does not
  * qualify): when the plan has 32 B pattern records and every row of a pattern carries the same values bit for bit -- a
  * constant-coefficient stencil -- the 7 values join the 7 offsets in the record and the products read neither the value nor

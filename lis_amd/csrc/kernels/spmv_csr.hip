@@ -1048,12 +1048,10 @@ void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__r
 #pragma unroll
     for (int it = 0; it < (RPW * TEAM_MAXLEN / 2 + WAVE) / WAVE; it++) {            // (at most five 1 KB pieces: no loop, no wait in front of it)
         const int p0 = it * WAVE;
-        if (p0 < np) {
-            const int p = min(p0 + lane, np - 1);
+        if (p0 + lane < np)                             // (lanes past the slice stay out: their 16 B would land in the next wavefront's stage)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p),
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p0 + lane),
                 (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
-        }
     }
     if (odd_end && lane == 0) valL[cnt - 1] = val[k1 - 1];
     __builtin_amdgcn_s_waitcnt(0);                              // this wavefront's slice (and gathers) have landed: vmcnt(0) lgkmcnt(0)
@@ -1070,6 +1068,111 @@ void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__r
         double in = RW.acc0;
         if (k > 0) in = __hiloint2double(__builtin_amdgcn_ds_bpermute(from, __double2hiint(c)),    // lane 16 t + i takes the sum of lane 16 (t-1) + i
                                          __builtin_amdgcn_ds_bpermute(from, __double2loint(c)));   // (the LDS crossbar: no memory is touched)
+#pragma unroll
+        for (int u = 0; u < TEAM_SEG; u++) in += pm[u];
+        c = t == k ? in : c;
+    }
+    if (live && t == 3) store_stream(y + r, c);
+}
+
+// The same with x STAGED: profiles/r03_pattern_team_kernel.txt -- the kernel above is bound by the number of vector-memory instructions it issues
+// (the texture addresser takes a 64-lane instruction at a fixed rate whatever the lanes ask for: half the gathers, 0.39 -> 0.33 ms; the same
+// gathers with one lane in sixteen active, no change).  When one pattern carries most rows and its sorted offsets are runs of m consecutive
+// columns (build_team_runs: the box stencils), the x a wavefront's 16 neighbouring rows need from a run are 15 + m consecutive doubles, and all
+// runs together a few hundred bytes: ceil(slots / 64) coalesced loads -- issued at once, they depend on nothing but the row numbers -- put them
+// in LDS, and an entry of a row reads its slot from there (an LDS read per entry instead of a gather per entry: 3 vector-memory instructions
+// instead of 8 for the 27-point stencil).  Rows on other patterns whose offsets lie inside the dominant one's runs (the boundary rows of a
+// stencil) read the same slots by their own records; rows with a foreign pattern gather for themselves.  Speculative addresses are clamped
+// to [0, largest column].  Values, products, the chain through ds_bpermute: as above -- same terms, same order, the reference's bits.
+struct TeamRuns { int nruns, m, w, slots, magic, maxcol, maxlen, pad; int start[16]; };
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
+                                         const v4i32 *__restrict__ prec, const v4i32 *__restrict__ pslot, const double *__restrict__ x,
+                                         double *__restrict__ y, Rows RW, int nnz_total, const TeamRuns TR, int vcap, int xcap,
+                                         const double *__restrict__ guard = nullptr)
+{
+    if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
+    constexpr int RPW = 16, NLOAD = 3;
+    extern __shared__ __attribute__((aligned(16))) double team_dyn[];
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
+    double *valL = team_dyn + w * (vcap + xcap), *xL = valL + vcap;
+    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
+    if (r0 >= r1) return;
+    const int t = lane >> 4, i = lane & 15;
+    const int r = min(r0 + i, r1 - 1);
+    const bool live = r0 + i < r1;
+    const int k0 = ptr[r0], k1 = ptr[r1];
+    const int pat = rowpat[r];
+    const int s = ptr[r];
+    // the staged x: slot sl = run * (15 + m) + position, column r0 + start[run] + position, clamped into the array
+    double xs[NLOAD];
+#pragma unroll
+    for (int k = 0; k < NLOAD; k++) {
+        const int sl = k * WAVE + lane;
+        const int q = (sl * TR.magic) >> 16, pos = sl - q * TR.w;
+        int st = TR.start[0];
+#pragma unroll
+        for (int a = 1; a < 16; a++) st = q == a ? TR.start[a] : st;
+        const int c = min(max(r0 + st + pos, 0), TR.maxcol);
+        xs[k] = (k * WAVE < TR.slots) ? x[c] : 0.0;            // (uniform per instruction: a wavefront-wide load or none)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int ka = k0 & ~1, cnt = k1 - ka;
+    int np = (cnt + 1) >> 1;
+    const bool odd_end = ka + 2 * np > nnz_total;
+    if (odd_end) np--;
+    const v4i32 *rs = pslot + pat * TEAM_REC;
+    const v4i32 s0 = rs[2 * t], s1 = rs[2 * t + 1];              // this lane's eight slots ...
+    const v2i32 lf = *reinterpret_cast<const v2i32 *>(rs + 8);    // ... the row's length, and whether its pattern is foreign to the runs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < (RPW * TEAM_MAXLEN / 2 + WAVE) / WAVE; it++) {
+        const int p0 = it * WAVE;
+        if (p0 + lane < np)                             // (lanes past the slice stay out: their 16 B would land in the next wavefront's stage)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p0 + lane),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+    }
+    if (odd_end && lane == 0) valL[cnt - 1] = val[k1 - 1];
+    const int len = lf.x;
+    double xx[TEAM_SEG];
+    const bool foreign = lf.y != 0;
+    if (__any(foreign)) {                                          // rare: rows whose offsets the runs do not hold gather for themselves
+        if (foreign) {
+            const v4i32 *rec = prec + pat * TEAM_REC;
+            const v4i32 o0 = rec[2 * t], o1 = rec[2 * t + 1];
+            const char *xb = reinterpret_cast<const char *>(x + r);
+            xx[0] = *reinterpret_cast<const double *>(xb + o0.x); xx[1] = *reinterpret_cast<const double *>(xb + o0.y);
+            xx[2] = *reinterpret_cast<const double *>(xb + o0.z); xx[3] = *reinterpret_cast<const double *>(xb + o0.w);
+            xx[4] = *reinterpret_cast<const double *>(xb + o1.x); xx[5] = *reinterpret_cast<const double *>(xb + o1.y);
+            xx[6] = *reinterpret_cast<const double *>(xb + o1.z); xx[7] = *reinterpret_cast<const double *>(xb + o1.w);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);                                 // everything this wavefront asked for has landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < NLOAD; k++) { const int sl = k * WAVE + lane; if (sl < TR.slots) xL[sl] = xs[k]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!foreign) {
+        const double *xr = xL + i;
+        xx[0] = xr[s0.x]; xx[1] = xr[s0.y]; xx[2] = xr[s0.z]; xx[3] = xr[s0.w];
+        xx[4] = xr[s1.x]; xx[5] = xr[s1.y]; xx[6] = xr[s1.z]; xx[7] = xr[s1.w];
+    }
+    const int nt = min(max(len - TEAM_SEG * t, 0), TEAM_SEG);
+    const double *vp = valL + (s - ka) + TEAM_SEG * t;
+    double pm[TEAM_SEG];
+#pragma unroll
+    for (int u = 0; u < TEAM_SEG; u++) { const double pr = vp[u] * xx[u]; pm[u] = u < nt ? pr : -0.0; }
+    double c = RW.acc0;
+    const int from = ((lane - 16) & (WAVE - 1)) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double in = RW.acc0;
+        if (k > 0) in = __hiloint2double(__builtin_amdgcn_ds_bpermute(from, __double2hiint(c)),
+                                         __builtin_amdgcn_ds_bpermute(from, __double2loint(c)));
 #pragma unroll
         for (int u = 0; u < TEAM_SEG; u++) in += pm[u];
         c = t == k ? in : c;
@@ -2231,6 +2334,9 @@ struct liship_csr_plan_s {
     int *ptab;           // device: npat + 1 prefix entries, then the offsets of all patterns
     int ptab_len, npat;
     v4i32 *ptab8;        // device: when no pattern has more than 7 offsets, one 32 B record per pattern (7 offsets, length); else NULL
+    v4i32 *prec_slot;    // device: with prec36, when ONE pattern carries most rows and its offsets are runs of equal length (box stencils): per pattern 32 slots
+                         // into the wavefront's staged x (TeamRuns), length, "foreign" flag: spmv_csr_pattern_team_staged_kernel; else NULL
+    TeamRuns tr;         // the runs of the dominant pattern (nruns = 0: none)
     v4i32 *prec36;       // device: when the longest pattern has 8..32 offsets, one 144 B record per pattern (32 byte offsets, length): spmv_csr_pattern_team_kernel; else NULL
     int prep[256];       // a row that carries each pattern
     v4i32 *vrec;         // device: with ptab8, when every row of a pattern carries the same values, 96 B per pattern (the 32 B record + 7 values); else NULL
@@ -2331,7 +2437,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
     p->drec = nullptr; p->dom_lo = p->dom_hi = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
@@ -2351,6 +2457,7 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->ptab) (void)hipFree(p->ptab);
     if (p->ptab8) (void)hipFree(p->ptab8);
     if (p->prec36) (void)hipFree(p->prec36);
+    if (p->prec_slot) (void)hipFree(p->prec_slot);
     if (p->vrec) (void)hipFree(p->vrec);
     if (p->drec) (void)hipFree(p->drec);
     if (p->order) (void)hipFree(p->order);
@@ -2462,6 +2569,90 @@ static void build_team_records(liship_csr_plan_s *p, const int *T, int NP)
     free(rec);
 }
 
+__global__ void rowpat_histogram(int n, const unsigned char *__restrict__ rowpat, unsigned long long *__restrict__ count);
+
+// largest column index of a coded matrix (the staged x of the team kernel is read speculatively: its addresses are clamped to the array)
+__global__ void csr_max_column(int n, const int *__restrict__ ptr, const unsigned char *__restrict__ codes, const int *__restrict__ dict, int *__restrict__ out)
+{
+    int m = 0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x)
+        for (int k = ptr[r]; k < ptr[r + 1]; k++) m = max(m, r + dict[codes[k]]);
+    atomicMax(out, m);
+}
+
+// The staged-x form of the four-lanes-per-row kernel (spmv_csr_pattern_team_staged_kernel).  When ONE pattern carries most rows and its
+// offsets, sorted, fall into runs of consecutive columns of one length m (the box stencils: 9 runs of 3 for the 27-point one), the x values
+// that 16 neighbouring rows need from a run are 15 + m consecutive doubles: a wavefront stages them -- nruns x (15 + m) "slots" -- with
+// ceil(slots / 64) coalesced loads instead of one gather per entry, and a row's entry reads slot (run, offset - run start) + its row.
+// Every pattern whose offsets all lie inside the dominant one's runs is served from the same slots (the boundary rows of a stencil);
+// the others are flagged foreign and gather for themselves.  Called when the plan's pattern bytes are final; never an error.
+static void build_team_runs(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
+{
+    if (p->prec_slot) { (void)hipFree(p->prec_slot); p->prec_slot = nullptr; }
+    p->tr.nruns = 0;
+    const int NP = p->npat;
+    if (!p->prec36 || !p->rowpat || !p->ptab || NP <= 0 || NP > 255 || p->n < 4 * WAVE || !p->codes || !p->dict) return;
+    int *T = (int *)malloc(sizeof(int) * (size_t)p->ptab_len);
+    unsigned long long *d_count = nullptr, count[256];
+    int *d_max = nullptr, maxcol = 0;
+    bool ok = T && hipMalloc(&d_count, sizeof(count)) == hipSuccess && hipMalloc(&d_max, sizeof(int)) == hipSuccess;
+    ok = ok && hipMemsetAsync(d_count, 0, sizeof(count), st) == hipSuccess && hipMemsetAsync(d_max, 0, sizeof(int), st) == hipSuccess;
+    if (ok) { rowpat_histogram<<<1024, 256, 0, st>>>(p->n, p->rowpat, d_count); ok = hipGetLastError() == hipSuccess; }
+    if (ok) { csr_max_column<<<2048, 256, 0, st>>>(p->n, ptr, p->codes, p->dict, d_max); ok = hipGetLastError() == hipSuccess; }
+    ok = ok && hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(&maxcol, d_max, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(T, p->ptab, sizeof(int) * (size_t)p->ptab_len, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    if (d_count) (void)hipFree(d_count);
+    if (d_max) (void)hipFree(d_max);
+    int *rec = nullptr;
+    if (ok) {
+        int dom = 0, maxlen = 0;
+        for (int i = 1; i < NP; i++) if (count[i] > count[dom]) dom = i;
+        for (int i = 0; i < NP; i++) maxlen = max(maxlen, T[i + 1] - T[i]);
+        const int l = T[dom + 1] - T[dom];
+        int offs[TEAM_MAXLEN], start[16], nruns = 0, m = 0;
+        ok = count[dom] * 2 >= (unsigned long long)p->n && l >= 1 && l <= TEAM_MAXLEN;
+        if (ok) {
+            for (int j = 0; j < l; j++) offs[j] = T[NP + 1 + T[dom] + j];
+            for (int a = 1; a < l; a++) { const int v = offs[a]; int b = a - 1; while (b >= 0 && offs[b] > v) { offs[b + 1] = offs[b]; b--; } offs[b + 1] = v; }
+            for (int j = 0; j < l && ok; ) {                 // runs of consecutive offsets, all of one length
+                int e = j + 1;
+                while (e < l && offs[e] == offs[e - 1] + 1) e++;
+                if (e < l && offs[e] == offs[e - 1]) ok = false;     // (a repeated offset: not this kernel)
+                if (nruns == 0) m = e - j;
+                if (e - j != m || nruns == 16) ok = false; else start[nruns++] = offs[j];
+                j = e;
+            }
+        }
+        const int W = 15 + m, slots = nruns * W, magic = 65536 / (W > 0 ? W : 1) + 1;
+        ok = ok && nruns >= 1 && slots <= 3 * WAVE;
+        for (int sl = 0; sl < slots && ok; sl++) if (((sl * magic) >> 16) != sl / W) ok = false;     // the kernel divides by W this way
+        if (ok) rec = (int *)calloc((size_t)NP * 4 * TEAM_REC, sizeof(int));
+        if (ok && rec) {
+            for (int i = 0; i < NP; i++) {
+                const int li = T[i + 1] - T[i];
+                int foreign = 0;
+                for (int j = 0; j < li; j++) {
+                    const int o = T[NP + 1 + T[i] + j];
+                    int q = -1;
+                    for (int a = 0; a < nruns; a++) if (o >= start[a] && o < start[a] + m) q = a;
+                    if (q < 0) { foreign = 1; break; }
+                    rec[4 * TEAM_REC * i + j] = q * W + (o - start[q]);
+                }
+                rec[4 * TEAM_REC * i + TEAM_MAXLEN] = li;
+                rec[4 * TEAM_REC * i + TEAM_MAXLEN + 1] = foreign;
+            }
+            if (hipMalloc(&p->prec_slot, sizeof(int) * 4 * TEAM_REC * (size_t)NP) == hipSuccess &&
+                hipMemcpy(p->prec_slot, rec, sizeof(int) * 4 * TEAM_REC * (size_t)NP, hipMemcpyHostToDevice) == hipSuccess) {
+                p->tr.nruns = nruns; p->tr.m = m; p->tr.w = W; p->tr.slots = slots; p->tr.magic = magic; p->tr.maxcol = maxcol; p->tr.maxlen = maxlen; p->tr.pad = 0;
+                for (int a = 0; a < 16; a++) p->tr.start[a] = a < nruns ? start[a] : 0;
+            } else if (p->prec_slot) { (void)hipFree(p->prec_slot); p->prec_slot = nullptr; }
+        }
+    }
+    free(rec); free(T);
+}
+
 extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const int *ptr, void *stream)
 {
     if (!p || (p->n > 0 && !ptr)) return LISHIP_ERR_ARG;
@@ -2554,11 +2745,14 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
         if (p->rowrel) (void)hipFree(p->rowrel);
         if (p->ptab8) (void)hipFree(p->ptab8);
         if (p->prec36) (void)hipFree(p->prec36);
+        if (p->prec_slot) (void)hipFree(p->prec_slot);
+        p->prec_slot = nullptr; p->tr.nruns = 0;
         p->ptab = nullptr; p->rowpat = nullptr; p->rowrel = nullptr; p->ptab8 = nullptr; p->prec36 = nullptr;
         return rc;
     }
     p->npat = npat; p->ptab_len = npat + 1 + total;
     for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
+    build_team_runs(p, ptr, st);                    // (patterns of 8..32 offsets: the staged-x form of the four-lanes-per-row kernel, when one pattern dominates)
     if (p->ptab8) {                                 // the dominant pattern, offsets only (values join with the value records)
         int rec8[PAT7_MAX * 8];
         if (hipMemcpy(rec8, p->ptab8, sizeof(int) * 8 * (size_t)npat, hipMemcpyDeviceToHost) == hipSuccess) build_dominant(p, npat, rec8, nullptr);
@@ -2570,6 +2764,8 @@ extern "C" int liship_csr_plan_row_patterns(liship_csr_plan_t p) { return (p && 
 // 1 when every pattern has 1..7 offsets and the plan also keeps them as 32 B records (spmv_csr_pattern7_kernel), else 0
 // 1 when the plan keeps the 144 B records of spmv_csr_pattern_team_kernel (longest pattern 8..32 offsets)
 extern "C" int liship_csr_plan_team_records(liship_csr_plan_t p) { return (p && p->rowpat && p->prec36) ? 1 : 0; }
+// 2 when the plan also keeps the dominant pattern's runs and slot records (the staged-x form), 1: records only, 0: none
+extern "C" int liship_csr_plan_team_form(liship_csr_plan_t p) { return (p && p->rowpat && p->prec36) ? ((p->prec_slot && p->tr.nruns > 0) ? 2 : 1) : 0; }
 extern "C" int liship_csr_plan_pattern_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8) ? 1 : 0; }
 extern "C" int liship_spmv_csr_set_row_patterns(int on) { g_row_patterns = on ? 1 : 0; return 0; }
 
@@ -2820,6 +3016,7 @@ static int encode_wide_value_records(liship_csr_plan_s *p, const int *ptr, const
             p->rowpat = newpat; newpat = nullptr; p->ptab = d_tab; p->npat = np2; p->ptab_len = ntab_len;
             for (int i = 0; i < np2; i++) p->prep[i] = reps2[i];
             build_team_records(p, ntab, np2);            // (the values-streamed product of this plan reads the renumbered pattern bytes too)
+            build_team_runs(p, ptr, st);
         }
     }
 #undef PT
@@ -2990,6 +3187,21 @@ void launch_products(int grid, const LaunchArgs &a)
                                      nullptr, nullptr, nullptr, 0, XRUN ? nullptr : a.order);
 }
 
+// patterned rows of 8..32 entries, values streamed: four lanes per row, with x staged per wavefront when the plan found the dominant pattern's
+// runs (variant 0x4000: the gathers of the first form, A/B)
+static void launch_team(const LaunchArgs &a, const double *guard)
+{
+    const liship_csr_plan_s *P = a.plan;
+    const int rows = a.re - a.rb, wgs = (rows + 63) / 64;
+    if (rows <= 0) return;
+    if (P->prec_slot && P->tr.nruns > 0 && !(g_variant & 0x4000)) {
+        const int vcap = 16 * P->tr.maxlen + 48, xcap = (P->tr.slots + 1) & ~1;
+        spmv_csr_pattern_team_staged_kernel<256><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>(
+            a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard);
+    } else
+        spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard);
+}
+
 template <int G>
 void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
 {
@@ -3094,12 +3306,9 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
-    if (a.rowpat && a.plan && a.plan->prec36 && g_variant == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
-        // (measured and dropped, profiles/r03_pattern_team_kernel.txt: XCD slabs / runs of 1024+ workgroups +-2 %; the pattern byte speculated -- an
-        //  ablation that takes it from a kernel argument -- 2 %: the kernel moves 2.35 GB through the fabric at 6.1 TB/s, the round trips are hidden)
-        const int rows = a.re - a.rb;
-        if (rows > 0)
-            spmv_csr_pattern_team_kernel<256><<<(rows + 63) / 64, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, a.plan->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz);
+    if (a.rowpat && a.plan && a.plan->prec36 && (g_variant & ~0x4000) == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
+        // (measured and dropped, profiles/r03_pattern_team_kernel.txt: XCD slabs / runs of 1024+ workgroups +-2 %; the pattern byte speculated 2 %)
+        launch_team(a, nullptr);
         return;
     }
     if (a.rowpat && (g_variant & ~0x2000) == 0) {    // one byte per ROW (the plan found <= 255 row patterns); 0x2000: experiment, table in LDS even for short patterns
@@ -3171,8 +3380,8 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
             w, partial, liship_internal_guard(), pstride);
         return;
     }
-    if (a.rowpat && a.plan && a.plan->prec36 && g_variant == 0 && a.re > a.rb) {      // patterns of 8..32 offsets: four lanes per row, then the row blocks' sums
-        spmv_csr_pattern_team_kernel<256><<<(a.re - a.rb + 63) / 64, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, a.plan->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, liship_internal_guard());
+    if (a.rowpat && a.plan && a.plan->prec36 && (g_variant & ~0x4000) == 0 && a.re > a.rb) {      // patterns of 8..32 offsets: four lanes per row, then the row blocks' sums
+        launch_team(a, liship_internal_guard());
         csr_block_dots_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(a.ptr, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.y, w, partial, liship_internal_guard(), pstride);
         return;
     }

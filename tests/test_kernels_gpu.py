@@ -317,6 +317,11 @@ CODED_CASES = {
 }
 
 
+# the form of the four-lanes-per-row kernel the plan must choose: 2 = x staged per wavefront (one pattern carries at least half of the rows and its
+# offsets are runs of one length), 1 = a gather per entry
+TEAM_FORM = {"box27_18x15x13": 2, "box9_70x50": 2, "box27_varcoef_21x10x9": 2, "box27_varcoef_7x6x70": 1, "box9_varcoef_130x77": 2}
+
+
 # liship_spmv_csr_set_variant bits that select the value-record kernels by hand: 3 the general pattern kernel, 4 the round-2 kernels by
 # size, 5 their two-rows-per-lane form, 6 the dominant-pattern kernels in plain form (contiguous chunks; fused dots two rows per lane),
 # 7 the default (tiles where the pattern has a stride that 128 divides; fused dots four rows per lane)
@@ -402,6 +407,24 @@ def test_spmv_csr_index_codes(lib, name):
             assert np.array_equal(dy.to_host(), yref), on
             out.append(res.to_host().copy())
         results[on] = out
+    if lib.liship_csr_plan_team_records(plan):       # four lanes per row: x staged per wavefront (the plan's choice when one pattern dominates) and gathered
+        assert lib.liship_csr_plan_team_form(plan) == TEAM_FORM.get(name, lib.liship_csr_plan_team_form(plan)), name
+        lib.liship_spmv_csr_set_index_codes(1)
+        lib.liship_spmv_csr_set_row_patterns(1)
+        lib.liship_spmv_csr_set_row_values(0)
+        for variant in (0, 0x4000):
+            lib.liship_spmv_csr_set_variant(variant)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host(), yref), hex(variant)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            for a, b in ((n // 3 + 1, n - 5), (0, n // 3 + 1), (n - 5, n)):
+                check(lib.liship_spmv_csr_rows_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host(), yref), hex(variant)
+            res = DA.from_host(np.full(2, np.nan), np.float64)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, 1, res.ptr, work.ptr, None))
+            assert np.array_equal(dy.to_host(), yref) and np.array_equal(res.to_host(), results[2][1]), hex(variant)
     lib.liship_spmv_csr_set_index_codes(1)
     lib.liship_spmv_csr_set_row_patterns(1)
     lib.liship_spmv_csr_set_variant(0)

@@ -1085,7 +1085,7 @@ void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__r
 // stencil) read the same slots by their own records; rows with a foreign pattern gather for themselves.  Speculative addresses are clamped
 // to [0, largest column].  Values, products, the chain through ds_bpermute: as above -- same terms, same order, the reference's bits.
 struct TeamRuns { int nruns, m, w, slots, magic, maxcol, maxlen, pad; int start[16]; };
-template <int BLOCK>
+template <int BLOCK, int NLOAD>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
                                          const v4i32 *__restrict__ prec, const v4i32 *__restrict__ pslot, const double *__restrict__ x,
@@ -1093,7 +1093,7 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
                                          const double *__restrict__ guard = nullptr)
 {
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
-    constexpr int RPW = 16, NLOAD = 3;
+    constexpr int RPW = 16;                                      // NLOAD = ceil(slots / 64): the loads are unconditional, so that the counter's waits can be exact
     extern __shared__ __attribute__((aligned(16))) double team_dyn[];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
     double *valL = team_dyn + w * (vcap + xcap), *xL = valL + vcap;
@@ -1104,7 +1104,6 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     const bool live = r0 + i < r1;
     const int k0 = ptr[r0], k1 = ptr[r1];
     const int pat = rowpat[r];
-    const int s = ptr[r];
     // the staged x: slot sl = run * (15 + m) + position, column r0 + start[run] + position, clamped into the array
     double xs[NLOAD];
 #pragma unroll
@@ -1115,16 +1114,14 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
 #pragma unroll
         for (int a = 1; a < 16; a++) st = q == a ? TR.start[a] : st;
         const int c = min(max(r0 + st + pos, 0), TR.maxcol);
-        xs[k] = (k * WAVE < TR.slots) ? x[c] : 0.0;            // (uniform per instruction: a wavefront-wide load or none)
+        xs[k] = x[c];                                            // (slots past the last run read a clamped address and are not stored)
     }
     __builtin_amdgcn_sched_barrier(0);
     const int ka = k0 & ~1, cnt = k1 - ka;
     int np = (cnt + 1) >> 1;
     const bool odd_end = ka + 2 * np > nnz_total;
     if (odd_end) np--;
-    const v4i32 *rs = pslot + pat * TEAM_REC;
-    const v4i32 s0 = rs[2 * t], s1 = rs[2 * t + 1];              // this lane's eight slots ...
-    const v2i32 lf = *reinterpret_cast<const v2i32 *>(rs + 8);    // ... the row's length, and whether its pattern is foreign to the runs
+    const v4i32 rs = pslot[pat * 4 + t];                           // this lane's eight slots (bytes), the row's length, whether its pattern is foreign to the runs
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int it = 0; it < (RPW * TEAM_MAXLEN / 2 + WAVE) / WAVE; it++) {
@@ -1135,9 +1132,21 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
                 (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
     }
     if (odd_end && lane == 0) valL[cnt - 1] = val[k1 - 1];
-    const int len = lf.x;
+    __builtin_amdgcn_sched_barrier(0);                            // (nothing that needs the record may move in between the slice's loads)
+    asm volatile("" :: "v"(rs.w));                                 // (the record's unused word stays allocated until here: reusing its register while the load is in flight would
+                                                                  //  put a wait for ALL loads between the slice's instructions)
+    const int len = live ? (rs.z & 255) : 0;
     double xx[TEAM_SEG];
-    const bool foreign = lf.y != 0;
+    const bool foreign = ((rs.z >> 8) & 255) != 0;
+    // the row's start: the slice's start + the lengths of the rows before it among the wavefront's 16 (a scan inside the rows of 16 lanes: no
+    // load of ptr[r], 4 B per row less)
+    int incl = len;
+    { int v;
+      v = __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += v;     // row_shr:1
+      v = __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += v;     // row_shr:2
+      v = __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); incl += v;     // row_shr:4
+      v = __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false); incl += v; }   // row_shr:8
+    const int s = k0 + incl - len;
     if (__any(foreign)) {                                          // rare: rows whose offsets the runs do not hold gather for themselves
         if (foreign) {
             const v4i32 *rec = prec + pat * TEAM_REC;
@@ -1158,8 +1167,8 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!foreign) {
         const double *xr = xL + i;
-        xx[0] = xr[s0.x]; xx[1] = xr[s0.y]; xx[2] = xr[s0.z]; xx[3] = xr[s0.w];
-        xx[4] = xr[s1.x]; xx[5] = xr[s1.y]; xx[6] = xr[s1.z]; xx[7] = xr[s1.w];
+        xx[0] = xr[rs.x & 255]; xx[1] = xr[(rs.x >> 8) & 255]; xx[2] = xr[(rs.x >> 16) & 255]; xx[3] = xr[(unsigned)rs.x >> 24];
+        xx[4] = xr[rs.y & 255]; xx[5] = xr[(rs.y >> 8) & 255]; xx[6] = xr[(rs.y >> 16) & 255]; xx[7] = xr[(unsigned)rs.y >> 24];
     }
     const int nt = min(max(len - TEAM_SEG * t, 0), TEAM_SEG);
     const double *vp = valL + (s - ka) + TEAM_SEG * t;
@@ -2605,7 +2614,6 @@ static void build_team_runs(liship_csr_plan_s *p, const int *ptr, hipStream_t st
     ok = ok && hipStreamSynchronize(st) == hipSuccess;
     if (d_count) (void)hipFree(d_count);
     if (d_max) (void)hipFree(d_max);
-    int *rec = nullptr;
     if (ok) {
         int dom = 0, maxlen = 0;
         for (int i = 1; i < NP; i++) if (count[i] > count[dom]) dom = i;
@@ -2626,31 +2634,38 @@ static void build_team_runs(liship_csr_plan_s *p, const int *ptr, hipStream_t st
             }
         }
         const int W = 15 + m, slots = nruns * W, magic = 65536 / (W > 0 ? W : 1) + 1;
-        ok = ok && nruns >= 1 && slots <= 3 * WAVE;
+        ok = ok && nruns >= 1 && slots <= 3 * WAVE && slots <= 255;
         for (int sl = 0; sl < slots && ok; sl++) if (((sl * magic) >> 16) != sl / W) ok = false;     // the kernel divides by W this way
-        if (ok) rec = (int *)calloc((size_t)NP * 4 * TEAM_REC, sizeof(int));
-        if (ok && rec) {
+        // one 16 B record per (pattern, team lane t): the eight slots of entries 8t .. 8t+7 as bytes (the tail repeats a valid slot), the row's
+        // length, the foreign flag -- a single load per lane
+        unsigned char *rec8 = ok ? (unsigned char *)calloc((size_t)NP * 4 * 16, 1) : nullptr;
+        if (ok && rec8) {
             for (int i = 0; i < NP; i++) {
                 const int li = T[i + 1] - T[i];
-                int foreign = 0;
+                int foreign = 0, slot[TEAM_MAXLEN];
+                for (int j = 0; j < TEAM_MAXLEN; j++) slot[j] = 0;
                 for (int j = 0; j < li; j++) {
                     const int o = T[NP + 1 + T[i] + j];
                     int q = -1;
                     for (int a = 0; a < nruns; a++) if (o >= start[a] && o < start[a] + m) q = a;
                     if (q < 0) { foreign = 1; break; }
-                    rec[4 * TEAM_REC * i + j] = q * W + (o - start[q]);
+                    slot[j] = q * W + (o - start[q]);
                 }
-                rec[4 * TEAM_REC * i + TEAM_MAXLEN] = li;
-                rec[4 * TEAM_REC * i + TEAM_MAXLEN + 1] = foreign;
+                for (int t = 0; t < 4; t++) {
+                    unsigned char *r16 = rec8 + ((size_t)i * 4 + t) * 16;
+                    for (int u = 0; u < 8; u++) r16[u] = (unsigned char)(foreign ? 0 : slot[8 * t + u]);
+                    r16[8] = (unsigned char)li; r16[9] = (unsigned char)foreign;
+                }
             }
-            if (hipMalloc(&p->prec_slot, sizeof(int) * 4 * TEAM_REC * (size_t)NP) == hipSuccess &&
-                hipMemcpy(p->prec_slot, rec, sizeof(int) * 4 * TEAM_REC * (size_t)NP, hipMemcpyHostToDevice) == hipSuccess) {
+            if (hipMalloc(&p->prec_slot, (size_t)NP * 4 * 16) == hipSuccess &&
+                hipMemcpy(p->prec_slot, rec8, (size_t)NP * 4 * 16, hipMemcpyHostToDevice) == hipSuccess) {
                 p->tr.nruns = nruns; p->tr.m = m; p->tr.w = W; p->tr.slots = slots; p->tr.magic = magic; p->tr.maxcol = maxcol; p->tr.maxlen = maxlen; p->tr.pad = 0;
                 for (int a = 0; a < 16; a++) p->tr.start[a] = a < nruns ? start[a] : 0;
             } else if (p->prec_slot) { (void)hipFree(p->prec_slot); p->prec_slot = nullptr; }
         }
+        free(rec8);
     }
-    free(rec); free(T);
+    free(T);
 }
 
 extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const int *ptr, void *stream)
@@ -3196,8 +3211,10 @@ static void launch_team(const LaunchArgs &a, const double *guard)
     if (rows <= 0) return;
     if (P->prec_slot && P->tr.nruns > 0 && !(g_variant & 0x4000)) {
         const int vcap = 16 * P->tr.maxlen + 48, xcap = (P->tr.slots + 1) & ~1;
-        spmv_csr_pattern_team_staged_kernel<256><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>(
-            a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard);
+#define GOT(NL) spmv_csr_pattern_team_staged_kernel<256, NL><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>( \
+            a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard)
+        if (P->tr.slots <= WAVE) GOT(1); else if (P->tr.slots <= 2 * WAVE) GOT(2); else GOT(3);
+#undef GOT
     } else
         spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard);
 }

@@ -1085,7 +1085,7 @@ void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__r
 // stencil) read the same slots by their own records; rows with a foreign pattern gather for themselves.  Speculative addresses are clamped
 // to [0, largest column].  Values, products, the chain through ds_bpermute: as above -- same terms, same order, the reference's bits.
 struct TeamRuns { int nruns, m, w, slots, magic, maxcol, maxlen, pad; int start[16]; };
-template <int BLOCK, int NLOAD>
+template <int BLOCK, int NLOAD, bool SREC>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
                                          const v4i32 *__restrict__ prec, const v4i32 *__restrict__ pslot, const double *__restrict__ x,
@@ -1093,7 +1093,7 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
                                          const double *__restrict__ guard = nullptr)
 {
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
-    constexpr int RPW = 16;                                      // NLOAD = ceil(slots / 64): the loads are unconditional, so that the counter's waits can be exact
+    constexpr int RPW = 16;                                      // NLOAD = ceil(slots / 128): the loads are unconditional, so that the counter's waits can be exact
     extern __shared__ __attribute__((aligned(16))) double team_dyn[];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
     double *valL = team_dyn + w * (vcap + xcap), *xL = valL + vcap;
@@ -1103,25 +1103,55 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     const int r = min(r0 + i, r1 - 1);
     const bool live = r0 + i < r1;
     const int k0 = ptr[r0], k1 = ptr[r1];
-    const int pat = rowpat[r];
-    // the staged x: slot sl = run * (15 + m) + position, column r0 + start[run] + position, clamped into the array
-    double xs[NLOAD];
+    // the 16 pattern bytes of the wavefront's rows by SCALAR loads (20 bytes from the dword below r0: a row range may start anywhere; the array has
+    // 64 bytes of slack): no vector-memory instruction, and a wavefront whose rows share one pattern takes its records by scalar loads too
+    const int *pw = reinterpret_cast<const int *>(rowpat + (r0 & ~3));
+    int pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0, pb4 = 0, patv = 0;
+    if (SREC) { pb0 = pw[0]; pb1 = pw[1]; pb2 = pw[2]; pb3 = pw[3]; pb4 = pw[4]; } else patv = rowpat[r];
+    __builtin_amdgcn_sched_barrier(0);                            // (the scalar loads leave first)
+    // the staged x: slot sl = run * (15 + m) + position holds column r0 + start[run] + position.  A lane takes TWO neighbouring slots with one
+    // 16 B load (15 + m is even: a pair never straddles two runs; the address is a double's: v2f64u); a pair pushed inside the array by the
+    // clamp at either end hands each slot the half that holds its column (the other slot of such a pair belongs to no stored entry)
+    v2f64 xs[NLOAD];
 #pragma unroll
     for (int k = 0; k < NLOAD; k++) {
-        const int sl = k * WAVE + lane;
+        const int sl = 2 * (k * WAVE + lane);
         const int q = (sl * TR.magic) >> 16, pos = sl - q * TR.w;
         int st = TR.start[0];
 #pragma unroll
         for (int a = 1; a < 16; a++) st = q == a ? TR.start[a] : st;
-        const int c = min(max(r0 + st + pos, 0), TR.maxcol);
-        xs[k] = x[c];                                            // (slots past the last run read a clamped address and are not stored)
+        const int c = r0 + st + pos, cc = min(max(c, 0), TR.maxcol - 1);
+        const v2f64 v = *reinterpret_cast<const v2f64u *>(x + cc);
+        xs[k].x = c > cc ? v.y : v.x;                            // c == maxcol: its column is the pair's upper half
+        xs[k].y = c < cc ? v.x : v.y;                            // c == -1: column 0 is the pair's lower half
     }
     __builtin_amdgcn_sched_barrier(0);
     const int ka = k0 & ~1, cnt = k1 - ka;
     int np = (cnt + 1) >> 1;
     const bool odd_end = ka + 2 * np > nnz_total;
     if (odd_end) np--;
-    const v4i32 rs = pslot[pat * 4 + t];                           // this lane's eight slots (bytes), the row's length, whether its pattern is foreign to the runs
+    int pat = patv;
+    if (SREC) {
+        const int bi = (r0 & 3) + (live ? i : 0), dw = bi >> 2;   // (lanes beyond the last row take the first row's pattern)
+        int word = pb0;
+        word = dw == 1 ? pb1 : word; word = dw == 2 ? pb2 : word; word = dw == 3 ? pb3 : word; word = dw == 4 ? pb4 : word;
+        pat = (word >> (8 * (bi & 3))) & 255;
+    }
+    // this lane's record -- eight slots (bytes), the row's length, whether its pattern is foreign to the runs -- by SCALAR loads, one round per distinct
+    // pattern among the wavefront's rows (one, nearly always; a vector load here would sit between the staged x and the slice in the in-order counter)
+    v4i32 rs = {0, 0, 0, 0};
+    bool have = false;
+    if (!SREC) { rs = pslot[pat * 4 + t]; have = true; }
+    for (;;) {
+        const unsigned long long need = __ballot(!have);
+        if (need == 0) break;
+        const int pcur = __builtin_amdgcn_readlane(pat, __ffsll((long long)need) - 1);
+        const v4i32 *q = pslot + pcur * 4;
+        const v4i32 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        v4i32 cand = q0;
+        cand = t == 1 ? q1 : cand; cand = t == 2 ? q2 : cand; cand = t == 3 ? q3 : cand;
+        if (!have && pat == pcur) { rs = cand; have = true; }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int it = 0; it < (RPW * TEAM_MAXLEN / 2 + WAVE) / WAVE; it++) {
@@ -1133,8 +1163,7 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     }
     if (odd_end && lane == 0) valL[cnt - 1] = val[k1 - 1];
     __builtin_amdgcn_sched_barrier(0);                            // (nothing that needs the record may move in between the slice's loads)
-    asm volatile("" :: "v"(rs.w));                                 // (the record's unused word stays allocated until here: reusing its register while the load is in flight would
-                                                                  //  put a wait for ALL loads between the slice's instructions)
+    if (!SREC) asm volatile("" :: "v"(rs.w));                     // (the record's unused word stays allocated: reusing its register while the load is in flight would wait for ALL loads)
     const int len = live ? (rs.z & 255) : 0;
     double xx[TEAM_SEG];
     const bool foreign = ((rs.z >> 8) & 255) != 0;
@@ -1161,7 +1190,7 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     __builtin_amdgcn_s_waitcnt(0);                                 // everything this wavefront asked for has landed
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int k = 0; k < NLOAD; k++) { const int sl = k * WAVE + lane; if (sl < TR.slots) xL[sl] = xs[k]; }
+    for (int k = 0; k < NLOAD; k++) { const int sl = 2 * (k * WAVE + lane); if (sl < TR.slots) *reinterpret_cast<v2f64 *>(xL + sl) = xs[k]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2634,7 +2663,7 @@ static void build_team_runs(liship_csr_plan_s *p, const int *ptr, hipStream_t st
             }
         }
         const int W = 15 + m, slots = nruns * W, magic = 65536 / (W > 0 ? W : 1) + 1;
-        ok = ok && nruns >= 1 && slots <= 3 * WAVE && slots <= 255;
+        ok = ok && nruns >= 1 && slots <= 254 && W % 2 == 0 && maxcol >= 1;     // (slots are bytes in the records; pairs of slots per staging lane)
         for (int sl = 0; sl < slots && ok; sl++) if (((sl * magic) >> 16) != sl / W) ok = false;     // the kernel divides by W this way
         // one 16 B record per (pattern, team lane t): the eight slots of entries 8t .. 8t+7 as bytes (the tail repeats a valid slot), the row's
         // length, the foreign flag -- a single load per lane
@@ -3211,9 +3240,12 @@ static void launch_team(const LaunchArgs &a, const double *guard)
     if (rows <= 0) return;
     if (P->prec_slot && P->tr.nruns > 0 && !(g_variant & 0x4000)) {
         const int vcap = 16 * P->tr.maxlen + 48, xcap = (P->tr.slots + 1) & ~1;
-#define GOT(NL) spmv_csr_pattern_team_staged_kernel<256, NL><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>( \
+#define GOT(NL, SR) spmv_csr_pattern_team_staged_kernel<256, NL, SR><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>( \
             a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard)
-        if (P->tr.slots <= WAVE) GOT(1); else if (P->tr.slots <= 2 * WAVE) GOT(2); else GOT(3);
+        // (0x8000, measured and kept for A/B: pattern bytes and records by SCALAR loads, one round per distinct pattern in the wavefront -- two
+        //  vector-memory instructions fewer and 5 % slower, 0.351 vs 0.332 ms: the scalar chain bytes -> readlane -> records sits in front of the slice)
+        if (g_variant & 0x8000) { if (P->tr.slots <= 2 * WAVE) GOT(1, true); else GOT(2, true); }
+        else if (P->tr.slots <= 2 * WAVE) GOT(1, false); else GOT(2, false);
 #undef GOT
     } else
         spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard);
@@ -3323,7 +3355,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
-    if (a.rowpat && a.plan && a.plan->prec36 && (g_variant & ~0x4000) == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
+    if (a.rowpat && a.plan && a.plan->prec36 && (g_variant & ~0xc000) == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
         // (measured and dropped, profiles/r03_pattern_team_kernel.txt: XCD slabs / runs of 1024+ workgroups +-2 %; the pattern byte speculated 2 %)
         launch_team(a, nullptr);
         return;

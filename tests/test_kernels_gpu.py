@@ -254,6 +254,30 @@ def stencil_box_variable_coefficients(dims, seed):
     return ptr, idx, np.random.default_rng(seed).uniform(-1, 1, len(val))
 
 
+def stencil_box_slab_with_ghost_plane(dims, seed):
+    """the first dims[0] - 1 planes of the box stencil on `dims` with random values: the rows of the last plane are gone, the columns that point into
+    it remain (a rank's slab of a row-block partition, ghost columns behind the owned ones): n < ncols, and the rows of the last owned plane carry the
+    interior pattern with columns >= n"""
+    ptr, idx, val = stencil_box_variable_coefficients(dims, seed)
+    keep = (dims[0] - 1) * int(np.prod(dims[1:]))
+    return ptr[:keep + 1].copy(), idx[:ptr[keep]].copy(), val[:ptr[keep]].copy()
+
+
+def stencil_box_with_foreign_rows(dims, seed, every):
+    """the box stencil with random values where every `every`-th row moves its last entry 5 columns to the right (or left, at the end): patterns whose
+    offsets the interior pattern's runs do not hold -- the rows that gather for themselves in the staged-x kernel"""
+    ptr, idx, val = stencil_box_variable_coefficients(dims, seed)
+    n = len(ptr) - 1
+    idx = idx.copy()
+    for r in range(3, n, every):
+        k = ptr[r + 1] - 1
+        idx[k] = idx[k] + 5 if idx[k] + 5 < n else max(0, idx[ptr[r]] - 9)
+        order = np.argsort(idx[ptr[r]:ptr[r + 1]], kind="stable")           # (rows stay sorted; a repeated column is fine for CSR)
+        idx[ptr[r]:ptr[r + 1]] = idx[ptr[r]:ptr[r + 1]][order]
+        val[ptr[r]:ptr[r + 1]] = val[ptr[r]:ptr[r + 1]][order]
+    return ptr, idx, val
+
+
 def box27_with_dirichlet_rows(dims, every):
     """the 27-point stencil with identity rows stored on the stencil's sparsity (1 on the diagonal, explicit zeros beside it)"""
     ptr, idx, val = stencil_box(dims)
@@ -301,6 +325,8 @@ CODED_CASES = {
     "box27_varcoef_21x10x9": (lambda: stencil_box_variable_coefficients((21, 10, 9), 8), 27),      # values streamed: four lanes per row, odd sizes
     "box27_varcoef_7x6x70": (lambda: stencil_box_variable_coefficients((7, 6, 70), 9), 27),
     "box9_varcoef_130x77": (lambda: stencil_box_variable_coefficients((130, 77), 10), 9),
+    "box27_varcoef_ghost_plane": (lambda: stencil_box_slab_with_ghost_plane((9, 12, 22), 11), 27),     # columns >= n in the last owned plane: the staged loads' clamp
+    "box27_varcoef_foreign": (lambda: stencil_box_with_foreign_rows((10, 11, 24), 13, 17), None),       # rows off the interior pattern's runs gather for themselves
     "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
     "band_9_unsorted": (lambda: banded(5000, [40, -1, 0, 1, -40, 3, -3, 900, -900], 1), 9),
     "p3d_40_sorted": (lambda: orc.poisson3d(40, 40, 40, sort_cols=True), 7),                # several row blocks
@@ -319,7 +345,7 @@ CODED_CASES = {
 
 # the form of the four-lanes-per-row kernel the plan must choose: 2 = x staged per wavefront (one pattern carries at least half of the rows and its
 # offsets are runs of one length), 1 = a gather per entry
-TEAM_FORM = {"box27_18x15x13": 2, "box9_70x50": 2, "box27_varcoef_21x10x9": 2, "box27_varcoef_7x6x70": 1, "box9_varcoef_130x77": 2}
+TEAM_FORM = {"box27_varcoef_ghost_plane": 2, "box27_varcoef_foreign": 2, "box27_18x15x13": 2, "box9_70x50": 2, "box27_varcoef_21x10x9": 2, "box27_varcoef_7x6x70": 1, "box9_varcoef_130x77": 2}
 
 
 # liship_spmv_csr_set_variant bits that select the value-record kernels by hand: 3 the general pattern kernel, 4 the round-2 kernels by

@@ -1084,7 +1084,7 @@ void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__r
 // instead of 8 for the 27-point stencil).  Rows on other patterns whose offsets lie inside the dominant one's runs (the boundary rows of a
 // stencil) read the same slots by their own records; rows with a foreign pattern gather for themselves.  Speculative addresses are clamped
 // to [0, largest column].  Values, products, the chain through ds_bpermute: as above -- same terms, same order, the reference's bits.
-struct TeamRuns { int nruns, m, w, slots, magic, maxcol, maxlen, pad; int start[16]; };
+struct TeamRuns { int nruns, slots, maxcol, maxlen; int start[16], base[16]; };     // run a: columns r0 + start[a] + position, slots base[a] .. base[a + 1])
 template <int BLOCK, int NLOAD, bool SREC>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
@@ -1109,18 +1109,17 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     int pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0, pb4 = 0, patv = 0;
     if (SREC) { pb0 = pw[0]; pb1 = pw[1]; pb2 = pw[2]; pb3 = pw[3]; pb4 = pw[4]; } else patv = rowpat[r];
     __builtin_amdgcn_sched_barrier(0);                            // (the scalar loads leave first)
-    // the staged x: slot sl = run * (15 + m) + position holds column r0 + start[run] + position.  A lane takes TWO neighbouring slots with one
-    // 16 B load (15 + m is even: a pair never straddles two runs; the address is a double's: v2f64u); a pair pushed inside the array by the
+    // the staged x: slot sl = base[run] + position holds column r0 + start[run] + position.  A lane takes TWO neighbouring slots with one
+    // 16 B load (every run's width is even: a pair never straddles two runs; the address is a double's: v2f64u); a pair pushed inside the array by the
     // clamp at either end hands each slot the half that holds its column (the other slot of such a pair belongs to no stored entry)
     v2f64 xs[NLOAD];
 #pragma unroll
     for (int k = 0; k < NLOAD; k++) {
         const int sl = 2 * (k * WAVE + lane);
-        const int q = (sl * TR.magic) >> 16, pos = sl - q * TR.w;
-        int st = TR.start[0];
+        int st = TR.start[0], bs = 0;                            // the run the slot pair lies in (bases of unused runs are beyond every slot)
 #pragma unroll
-        for (int a = 1; a < 16; a++) st = q == a ? TR.start[a] : st;
-        const int c = r0 + st + pos, cc = min(max(c, 0), TR.maxcol - 1);
+        for (int a = 1; a < 16; a++) { const bool in = sl >= TR.base[a]; st = in ? TR.start[a] : st; bs = in ? TR.base[a] : bs; }
+        const int c = r0 + st + (sl - bs), cc = min(max(c, 0), TR.maxcol - 1);
         const v2f64 v = *reinterpret_cast<const v2f64u *>(x + cc);
         xs[k].x = c > cc ? v.y : v.x;                            // c == maxcol: its column is the pair's upper half
         xs[k].y = c < cc ? v.x : v.y;                            // c == -1: column 0 is the pair's lower half
@@ -2618,10 +2617,10 @@ __global__ void csr_max_column(int n, const int *__restrict__ ptr, const unsigne
     atomicMax(out, m);
 }
 
-// The staged-x form of the four-lanes-per-row kernel (spmv_csr_pattern_team_staged_kernel).  When ONE pattern carries most rows and its
-// offsets, sorted, fall into runs of consecutive columns of one length m (the box stencils: 9 runs of 3 for the 27-point one), the x values
-// that 16 neighbouring rows need from a run are 15 + m consecutive doubles: a wavefront stages them -- nruns x (15 + m) "slots" -- with
-// ceil(slots / 64) coalesced loads instead of one gather per entry, and a row's entry reads slot (run, offset - run start) + its row.
+// The staged-x form of the four-lanes-per-row kernel (spmv_csr_pattern_team_staged_kernel).  When ONE pattern carries most rows, its offsets,
+// sorted, fall into at most 16 runs of consecutive columns (9 runs of 3 for the 27-point stencil; 1, 3, 1, 3, 3, 3, 1, 3, 1 for the 19-point one), and the
+// x values that 16 neighbouring rows need from a run of m are 15 + m consecutive doubles: a wavefront stages them -- the runs' "slots", at most 254 --
+// with ceil(slots / 128) coalesced 16 B loads instead of one gather per entry, and a row's entry reads slot base[run] + (offset - run start) + its row.
 // Every pattern whose offsets all lie inside the dominant one's runs is served from the same slots (the boundary rows of a stencil);
 // the others are flagged foreign and gather for themselves.  Called when the plan's pattern bytes are final; never an error.
 static void build_team_runs(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
@@ -2648,23 +2647,24 @@ static void build_team_runs(liship_csr_plan_s *p, const int *ptr, hipStream_t st
         for (int i = 1; i < NP; i++) if (count[i] > count[dom]) dom = i;
         for (int i = 0; i < NP; i++) maxlen = max(maxlen, T[i + 1] - T[i]);
         const int l = T[dom + 1] - T[dom];
-        int offs[TEAM_MAXLEN], start[16], nruns = 0, m = 0;
+        int offs[TEAM_MAXLEN], start[16], mlen[16], base[17], nruns = 0;
         ok = count[dom] * 2 >= (unsigned long long)p->n && l >= 1 && l <= TEAM_MAXLEN;
         if (ok) {
             for (int j = 0; j < l; j++) offs[j] = T[NP + 1 + T[dom] + j];
             for (int a = 1; a < l; a++) { const int v = offs[a]; int b = a - 1; while (b >= 0 && offs[b] > v) { offs[b + 1] = offs[b]; b--; } offs[b + 1] = v; }
-            for (int j = 0; j < l && ok; ) {                 // runs of consecutive offsets, all of one length
+            for (int j = 0; j < l && ok; ) {                 // runs of consecutive offsets
                 int e = j + 1;
                 while (e < l && offs[e] == offs[e - 1] + 1) e++;
                 if (e < l && offs[e] == offs[e - 1]) ok = false;     // (a repeated offset: not this kernel)
-                if (nruns == 0) m = e - j;
-                if (e - j != m || nruns == 16) ok = false; else start[nruns++] = offs[j];
+                if (nruns == 16) ok = false; else { start[nruns] = offs[j]; mlen[nruns++] = e - j; }
                 j = e;
             }
         }
-        const int W = 15 + m, slots = nruns * W, magic = 65536 / (W > 0 ? W : 1) + 1;
-        ok = ok && nruns >= 1 && slots <= 254 && W % 2 == 0 && maxcol >= 1;     // (slots are bytes in the records; pairs of slots per staging lane)
-        for (int sl = 0; sl < slots && ok; sl++) if (((sl * magic) >> 16) != sl / W) ok = false;     // the kernel divides by W this way
+        // 16 neighbouring rows need 15 + m consecutive columns of a run of m; widths are rounded up to even (the staging lanes take pairs of slots)
+        base[0] = 0;
+        for (int a = 0; a < nruns; a++) base[a + 1] = base[a] + ((15 + mlen[a] + 1) & ~1);
+        const int slots = base[nruns];
+        ok = ok && nruns >= 1 && slots <= 254 && maxcol >= 1 && l > nruns;       // (slots are bytes in the records; no run longer than one column: nothing to share)
         // one 16 B record per (pattern, team lane t): the eight slots of entries 8t .. 8t+7 as bytes (the tail repeats a valid slot), the row's
         // length, the foreign flag -- a single load per lane
         unsigned char *rec8 = ok ? (unsigned char *)calloc((size_t)NP * 4 * 16, 1) : nullptr;
@@ -2676,9 +2676,9 @@ static void build_team_runs(liship_csr_plan_s *p, const int *ptr, hipStream_t st
                 for (int j = 0; j < li; j++) {
                     const int o = T[NP + 1 + T[i] + j];
                     int q = -1;
-                    for (int a = 0; a < nruns; a++) if (o >= start[a] && o < start[a] + m) q = a;
+                    for (int a = 0; a < nruns; a++) if (o >= start[a] && o < start[a] + mlen[a]) q = a;
                     if (q < 0) { foreign = 1; break; }
-                    slot[j] = q * W + (o - start[q]);
+                    slot[j] = base[q] + (o - start[q]);
                 }
                 for (int t = 0; t < 4; t++) {
                     unsigned char *r16 = rec8 + ((size_t)i * 4 + t) * 16;
@@ -2688,8 +2688,8 @@ static void build_team_runs(liship_csr_plan_s *p, const int *ptr, hipStream_t st
             }
             if (hipMalloc(&p->prec_slot, (size_t)NP * 4 * 16) == hipSuccess &&
                 hipMemcpy(p->prec_slot, rec8, (size_t)NP * 4 * 16, hipMemcpyHostToDevice) == hipSuccess) {
-                p->tr.nruns = nruns; p->tr.m = m; p->tr.w = W; p->tr.slots = slots; p->tr.magic = magic; p->tr.maxcol = maxcol; p->tr.maxlen = maxlen; p->tr.pad = 0;
-                for (int a = 0; a < 16; a++) p->tr.start[a] = a < nruns ? start[a] : 0;
+                p->tr.nruns = nruns; p->tr.slots = slots; p->tr.maxcol = maxcol; p->tr.maxlen = maxlen;
+                for (int a = 0; a < 16; a++) { p->tr.start[a] = a < nruns ? start[a] : 0; p->tr.base[a] = a < nruns ? base[a] : (1 << 20); }
             } else if (p->prec_slot) { (void)hipFree(p->prec_slot); p->prec_slot = nullptr; }
         }
         free(rec8);

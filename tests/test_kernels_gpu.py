@@ -254,6 +254,28 @@ def stencil_box_variable_coefficients(dims, seed):
     return ptr, idx, np.random.default_rng(seed).uniform(-1, 1, len(val))
 
 
+def stencil_points(dims, points, seed):
+    """any stencil on a 3-D grid: `points` = (dz, dy, dx) offsets, Dirichlet truncation, sorted columns, random values"""
+    dims = tuple(dims)
+    n = int(np.prod(dims))
+    z, y, x = (g.ravel() for g in np.meshgrid(*[np.arange(d) for d in dims], indexing="ij"))
+    rows, cols = [], []
+    for dz, dy, dx in points:
+        m = (z + dz >= 0) & (z + dz < dims[0]) & (y + dy >= 0) & (y + dy < dims[1]) & (x + dx >= 0) & (x + dx < dims[2])
+        r = np.nonzero(m)[0]
+        rows.append(r)
+        cols.append(r + (dz * dims[1] + dy) * dims[2] + dx)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    order = np.lexsort((cols, rows))
+    ptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=ptr[1:])
+    return ptr.astype(np.int32), cols[order].astype(np.int32), np.random.default_rng(seed).uniform(-1, 1, len(cols))
+
+
+POINTS_19 = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if abs(dz) + abs(dy) + abs(dx) <= 2]     # faces and edges, no corners
+POINTS_STAR9 = [(0, 0, 0)] + [tuple(s * k if a == ax else 0 for a in range(3)) for ax in (1, 2) for k in (1, 2) for s in (-1, 1)]     # the fourth-order star in 2-D
+
+
 def stencil_box_slab_with_ghost_plane(dims, seed):
     """the first dims[0] - 1 planes of the box stencil on `dims` with random values: the rows of the last plane are gone, the columns that point into
     it remain (a rank's slab of a row-block partition, ghost columns behind the owned ones): n < ncols, and the rows of the last owned plane carry the
@@ -325,6 +347,8 @@ CODED_CASES = {
     "box27_varcoef_21x10x9": (lambda: stencil_box_variable_coefficients((21, 10, 9), 8), 27),      # values streamed: four lanes per row, odd sizes
     "box27_varcoef_7x6x70": (lambda: stencil_box_variable_coefficients((7, 6, 70), 9), 27),
     "box9_varcoef_130x77": (lambda: stencil_box_variable_coefficients((130, 77), 10), 9),
+    "s19_varcoef_9x10x21": (lambda: stencil_points((9, 10, 21), POINTS_19, 14), 19),                  # runs of 1 and 3 columns: staged x with uneven runs
+    "star9_varcoef_60x70": (lambda: stencil_points((1, 60, 70), POINTS_STAR9, 15), 9),                # a run of 5 and four single columns
     "box27_varcoef_ghost_plane": (lambda: stencil_box_slab_with_ghost_plane((9, 12, 22), 11), 27),     # columns >= n in the last owned plane: the staged loads' clamp
     "box27_varcoef_foreign": (lambda: stencil_box_with_foreign_rows((10, 11, 24), 13, 17), None),       # rows off the interior pattern's runs gather for themselves
     "p3d_64_sorted": (lambda: orc.poisson3d(64, 64, 64, sort_cols=True), 7),
@@ -345,7 +369,7 @@ CODED_CASES = {
 
 # the form of the four-lanes-per-row kernel the plan must choose: 2 = x staged per wavefront (one pattern carries at least half of the rows and its
 # offsets are runs of one length), 1 = a gather per entry
-TEAM_FORM = {"box27_varcoef_ghost_plane": 2, "box27_varcoef_foreign": 2, "box27_18x15x13": 2, "box9_70x50": 2, "box27_varcoef_21x10x9": 2, "box27_varcoef_7x6x70": 1, "box9_varcoef_130x77": 2}
+TEAM_FORM = {"s19_varcoef_9x10x21": 2, "star9_varcoef_60x70": 2, "box27_varcoef_ghost_plane": 2, "box27_varcoef_foreign": 2, "box27_18x15x13": 2, "box9_70x50": 2, "box27_varcoef_21x10x9": 2, "box27_varcoef_7x6x70": 1, "box9_varcoef_130x77": 2}
 
 
 # liship_spmv_csr_set_variant bits that select the value-record kernels by hand: 3 the general pattern kernel, 4 the round-2 kernels by
@@ -382,7 +406,7 @@ def test_spmv_csr_index_codes(lib, name):
         assert npat == ROW_PATTERNS[name], npat
     if name in PATTERN_RECORDS:
         assert lib.liship_csr_plan_pattern_records(plan) == PATTERN_RECORDS[name]
-    if name.startswith("box"):                  # longest pattern of 8..32 offsets: the 144 B records of the four-lanes-per-row kernel
+    if name.startswith(("box", "s19", "star9")):    # longest pattern of 8..32 offsets: the 144 B records of the four-lanes-per-row kernel
         assert lib.liship_csr_plan_team_records(plan) == 1
     elif lib.liship_csr_plan_pattern_records(plan) == 1:
         assert lib.liship_csr_plan_team_records(plan) == 0

@@ -250,6 +250,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_uniform_jacobi = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_LOCAL_COLUMNS");
 		lisg.no_local_columns = (r && r[0] == '1');
+		r = getenv("LIS_AMD_NO_TEAM_KERNELS");
+		lisg.no_team_kernels = (r && r[0] == '1');
 		r = getenv("LIS_AMD_LONG_ROW_TREE");          /* opt-in: NOT the reference's bits for rows beyond the LDS stage */
 		lisg.long_row_tree = (r && r[0] == '1');
 		r = getenv("LIS_AMD_GRAPHS");

@@ -66,6 +66,7 @@ int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps eve
 int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
 int g_row_values = 1;            // liship_spmv_csr_set_row_values: 0 keeps streaming the values of matrices that have value records
 int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps the products kernel on the 4 B indices
+int g_team = 1;                  // liship_spmv_csr_set_team: 0 keeps patterned rows of 8..32 entries on the one-lane-per-row pattern kernel
 
 __device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
 
@@ -3178,6 +3179,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
 // entries of the distinct-column lists when the plan keeps block-local columns, 0 otherwise
 extern "C" long long liship_csr_plan_localized(liship_csr_plan_t p) { return (p && p->lcol) ? p->ndcol : 0; }
 extern "C" int liship_spmv_csr_set_local_columns(int on) { g_local_cols = on ? 1 : 0; return 0; }
+extern "C" int liship_spmv_csr_set_team(int on) { g_team = on ? 1 : 0; return 0; }
 
 namespace {
 
@@ -3355,7 +3357,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
         return;
     }
-    if (a.rowpat && a.plan && a.plan->prec36 && (g_variant & ~0xc000) == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
+    if (a.rowpat && a.plan && a.plan->prec36 && g_team && (g_variant & ~0xc000) == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
         // (measured and dropped, profiles/r03_pattern_team_kernel.txt: XCD slabs / runs of 1024+ workgroups +-2 %; the pattern byte speculated 2 %)
         launch_team(a, nullptr);
         return;
@@ -3429,7 +3431,7 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
             w, partial, liship_internal_guard(), pstride);
         return;
     }
-    if (a.rowpat && a.plan && a.plan->prec36 && (g_variant & ~0x4000) == 0 && a.re > a.rb) {      // patterns of 8..32 offsets: four lanes per row, then the row blocks' sums
+    if (a.rowpat && a.plan && a.plan->prec36 && g_team && (g_variant & ~0x4000) == 0 && a.re > a.rb) {      // patterns of 8..32 offsets: four lanes per row, then the row blocks' sums
         launch_team(a, liship_internal_guard());
         csr_block_dots_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(a.ptr, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.y, w, partial, liship_internal_guard(), pstride);
         return;

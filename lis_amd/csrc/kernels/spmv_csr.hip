@@ -2745,7 +2745,13 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
     PT(hipStreamSynchronize(st));
     int total = 0;
     for (int i = 0; i < npat && rc == 0; i++) total += plen[i];
-    const bool fits = rc == 0 && total <= 1024 && npat + 1 + total <= PAT_TABLE;
+    // the one-lane-per-row pattern kernel keeps the table in LDS (PAT_TABLE ints); patterns of 8..32 offsets run on the team kernels, which read 16 B /
+    // 144 B records instead: for them a larger table is accepted (125 patterns of up to 13 for the fourth-order star in 3-D), and the general kernel is
+    // never launched on such a plan (launch_geom / launch_rowgather_dot fall through to the coded kernel when the A/B switches turn the teams off)
+    int maxl = 0, minl = 1 << 30;
+    for (int i = 0; i < npat && rc == 0; i++) { maxl = max(maxl, plen[i]); minl = min(minl, plen[i]); }
+    const bool teams = maxl > 7 && maxl <= TEAM_MAXLEN && minl >= 1;
+    const bool fits = rc == 0 && ((total <= 1024 && npat + 1 + total <= PAT_TABLE) || (teams && total <= 4096));
     int *tab = nullptr;
     if (fits) {
         tab = (int *)malloc(sizeof(int) * (size_t)(npat + 1 + total));
@@ -3362,7 +3368,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
         launch_team(a, nullptr);
         return;
     }
-    if (a.rowpat && (g_variant & ~0x2000) == 0) {    // one byte per ROW (the plan found <= 255 row patterns); 0x2000: experiment, table in LDS even for short patterns
+    if (a.rowpat && a.ptab_len <= PAT_TABLE && (g_variant & ~0x2000) == 0) {    // one byte per ROW (the plan found <= 255 row patterns); 0x2000: experiment, table in LDS even for short patterns
         constexpr Geometry g = kGeom[G];
 #define GOP(UU) spmv_csr_pattern_kernel<g.block, g.work, UU, 0><<<a.nb, g.block, 0, a.st>>>( \
             a.ptr, a.idx, a.val, a.rowpat, a.rowrel, a.ptab, a.ptab_len, a.npat1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz)
@@ -3436,7 +3442,7 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
         csr_block_dots_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(a.ptr, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.y, w, partial, liship_internal_guard(), pstride);
         return;
     }
-    if (a.rowpat) {
+    if (a.rowpat && a.ptab_len <= PAT_TABLE) {
 #define GOP(UU) spmv_csr_pattern_kernel<g.block, g.work, UU, DOT><<<a.nb, g.block, 0, a.st>>>( \
             a.ptr, a.idx, a.val, a.rowpat, a.rowrel, a.ptab, a.ptab_len, a.npat1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, \
             w, partial, liship_internal_guard(), pstride)

@@ -203,7 +203,7 @@ def cyclic_diagonals(n, count, seed):
 # row patterns the plan must find on top of the codes: 3 for the 1-D stencil (first row, interior, last row), 27 for the 3-D one
 ROW_PATTERNS = {"p1d_10000": 3, "p3d_20x17x13": 27, "p3d_64_sorted": 27, "p3d_40_sorted": 27, "p3d_odd_33x7x5": 27, "diagonals_255": 255,
                 "diagonals_300": 0, "rand_5000": 0, "wide_77": 0,        # diagonals_255: 254 two-entry rows + the rows whose second entry falls outside
-                "p1d_9999": 3, "p3d_holes": 27, "p3d_varcoef": 27, "p3d_dirichlet": 27, "box27_18x15x13": 27, "box9_70x50": 9}            # p3d_holes: the empty row is one more pattern, a corner row that lost its entries one fewer
+                "star13_varcoef_20x18x30": 125, "p1d_9999": 3, "p3d_holes": 27, "p3d_varcoef": 27, "p3d_dirichlet": 27, "box27_18x15x13": 27, "box9_70x50": 9}            # p3d_holes: the empty row is one more pattern, a corner row that lost its entries one fewer
 # ... and whether it also keeps them as 32 B records (1..7 offsets per pattern, at most 64 patterns: spmv_csr_pattern7_kernel)
 # ... and whether every row of a pattern also carries the same values (then the records hold them: spmv_csr_valuerec_kernel)
 VALUE_RECORDS = {"p1d_10000": 1, "p1d_9999": 1, "p3d_20x17x13": 1, "p3d_64_sorted": 1, "p3d_40_sorted": 1, "p3d_odd_33x7x5": 1,
@@ -273,6 +273,7 @@ def stencil_points(dims, points, seed):
 
 
 POINTS_19 = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if abs(dz) + abs(dy) + abs(dx) <= 2]     # faces and edges, no corners
+POINTS_STAR13 = [(0, 0, 0)] + [tuple(s * k if a == ax else 0 for a in range(3)) for ax in range(3) for k in (1, 2) for s in (-1, 1)]     # the fourth-order star in 3-D
 POINTS_STAR9 = [(0, 0, 0)] + [tuple(s * k if a == ax else 0 for a in range(3)) for ax in (1, 2) for k in (1, 2) for s in (-1, 1)]     # the fourth-order star in 2-D
 
 
@@ -348,6 +349,7 @@ CODED_CASES = {
     "box27_varcoef_7x6x70": (lambda: stencil_box_variable_coefficients((7, 6, 70), 9), 27),
     "box9_varcoef_130x77": (lambda: stencil_box_variable_coefficients((130, 77), 10), 9),
     "s19_varcoef_9x10x21": (lambda: stencil_points((9, 10, 21), POINTS_19, 14), 19),                  # runs of 1 and 3 columns: staged x with uneven runs
+    "star13_varcoef_20x18x30": (lambda: stencil_points((20, 18, 30), POINTS_STAR13, 16), 13),         # 125 patterns, 1438 offsets: a table only the team kernels take
     "star9_varcoef_60x70": (lambda: stencil_points((1, 60, 70), POINTS_STAR9, 15), 9),                # a run of 5 and four single columns
     "box27_varcoef_ghost_plane": (lambda: stencil_box_slab_with_ghost_plane((9, 12, 22), 11), 27),     # columns >= n in the last owned plane: the staged loads' clamp
     "box27_varcoef_foreign": (lambda: stencil_box_with_foreign_rows((10, 11, 24), 13, 17), None),       # rows off the interior pattern's runs gather for themselves
@@ -369,7 +371,7 @@ CODED_CASES = {
 
 # the form of the four-lanes-per-row kernel the plan must choose: 2 = x staged per wavefront (one pattern carries at least half of the rows and its
 # offsets are runs of one length), 1 = a gather per entry
-TEAM_FORM = {"s19_varcoef_9x10x21": 2, "star9_varcoef_60x70": 2, "box27_varcoef_ghost_plane": 2, "box27_varcoef_foreign": 2, "box27_18x15x13": 2, "box9_70x50": 2, "box27_varcoef_21x10x9": 2, "box27_varcoef_7x6x70": 1, "box9_varcoef_130x77": 2}
+TEAM_FORM = {"s19_varcoef_9x10x21": 2, "star9_varcoef_60x70": 2, "star13_varcoef_20x18x30": 2, "box27_varcoef_ghost_plane": 2, "box27_varcoef_foreign": 2, "box27_18x15x13": 2, "box9_70x50": 2, "box27_varcoef_21x10x9": 2, "box27_varcoef_7x6x70": 1, "box9_varcoef_130x77": 2}
 
 
 # liship_spmv_csr_set_variant bits that select the value-record kernels by hand: 3 the general pattern kernel, 4 the round-2 kernels by
@@ -406,7 +408,7 @@ def test_spmv_csr_index_codes(lib, name):
         assert npat == ROW_PATTERNS[name], npat
     if name in PATTERN_RECORDS:
         assert lib.liship_csr_plan_pattern_records(plan) == PATTERN_RECORDS[name]
-    if name.startswith(("box", "s19", "star9")):    # longest pattern of 8..32 offsets: the 144 B records of the four-lanes-per-row kernel
+    if name.startswith(("box", "s19", "star9", "star13")):    # longest pattern of 8..32 offsets: the 144 B records of the four-lanes-per-row kernel
         assert lib.liship_csr_plan_team_records(plan) == 1
     elif lib.liship_csr_plan_pattern_records(plan) == 1:
         assert lib.liship_csr_plan_team_records(plan) == 0

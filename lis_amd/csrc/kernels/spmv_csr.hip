@@ -1616,7 +1616,7 @@ void spmv_csr_valuerec_pair_kernel(const unsigned char *__restrict__ rowpat, con
 // last |max offset| rows) take their rows one by one with their own records, as the kernels above do.
 typedef double v8f64 __attribute__((ext_vector_type(8)));
 struct DomTile { int S, cshift, ntiled, nfull; };       // spmv_csr_valuerec_dom_kernel: tiled lane -> row mapping (S = 0: none)
-struct DomRec { int off[7]; int pat; double val[7]; int mask, pad; };     // byte offsets and values of the dominant pattern, its pattern byte, its slots (length)
+struct DomRec { int off[7]; int pat; double val[7]; int mask, d0; };      // byte offsets and values of the dominant pattern, its pattern byte, its slots (length), the slot of offset 0 (-1: none)
 
 // slots of D that pattern `pt` (uniform) has, and its values there: 8 doubles per pattern, [0] = the mask in the low word
 __device__ __forceinline__ void dom_waterfall(const double *__restrict__ drec, const DomRec &D, int pt, bool valid, double (&v)[7], unsigned &m)
@@ -1635,6 +1635,21 @@ __device__ __forceinline__ void dom_waterfall(const double *__restrict__ drec, c
         for (int u = 0; u < 7; u++) v[u] = me ? R[1 + u] : v[u];
         todo &= ~__builtin_amdgcn_ballot_w64(me);
     }
+}
+
+// A pattern may END in up to six entries (the row itself, +0.0) behind its slots of the dominant pattern: the padding of an ELL row laid out row by row
+// (lis_matrix_ell.c:1035-1042 pads with value 0, index i; lis_matvec_ell.c:113-128 adds those terms last).  Bits 8..10 of the mask count them; each adds
+// 0.0 * x[row] -- a signed zero, or a NaN from an infinite x: the term is formed, not assumed.  Without this the boundary rows of a constant-coefficient stencil
+// in ELL storage were "foreign" and took their own records: 256^3 0.087 ms against 0.050 for the other formats.
+__device__ __forceinline__ double dom_pad_terms(double s, unsigned m, const double *__restrict__ x, int row)
+{
+    const unsigned k = (m >> 8) & 7u;
+    if (__builtin_amdgcn_ballot_w64(k != 0) != 0) {                  // (uniform) rare: x[row] is read again here rather than picked out of the gathers
+        const double t = 0.0 * x[row];
+#pragma unroll
+        for (unsigned q = 0; q < 6; q++) s += (q < k) ? t : -0.0;
+    }
+    return s;
 }
 
 // one row by its own record (96 B, global): the kernels above, without LDS
@@ -1719,12 +1734,14 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
                 else {
 #pragma unroll
                     for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].x; s0 += ((m >> u) & 1u) ? t : -0.0; }    // -0.0 terms leave any sum bit-unchanged
+                    s0 = dom_pad_terms(s0, m, x, ra);
                 }
                 dom_waterfall(drec, D, pb, true, v, m);
                 if (m & 0x80u) s1 = own_record_row(rec, pb, ra + 1, x, acc0);
                 else {
 #pragma unroll
                     for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].y; s1 += ((m >> u) & 1u) ? t : -0.0; }
+                    s1 = dom_pad_terms(s1, m, x, ra + 1);
                 }
             }
             v2f64 out; out.x = s0; out.y = s1;
@@ -1806,6 +1823,7 @@ void spmv_csr_valuerec_dom_dot_kernel(const unsigned char *__restrict__ rowpat, 
                     else {
 #pragma unroll
                         for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].x; s0 += ((m >> u) & 1u) ? t : -0.0; }    // -0.0 terms leave any sum bit-unchanged
+                        s0 = dom_pad_terms(s0, m, x, ra);
                     }
                 }
                 dom_waterfall(drec, D, pb, two, v, m);
@@ -1814,6 +1832,7 @@ void spmv_csr_valuerec_dom_dot_kernel(const unsigned char *__restrict__ rowpat, 
                     else {
 #pragma unroll
                         for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].y; s1 += ((m >> u) & 1u) ? t : -0.0; }
+                        s1 = dom_pad_terms(s1, m, x, ra + 1);
                     }
                 }
             }
@@ -1942,6 +1961,7 @@ void spmv_csr_valuerec_dom_dot4_kernel(const unsigned char *__restrict__ rowpat,
                                 const double t = v[u] * xv;
                                 sv[j] += ((m >> u) & 1u) ? t : -0.0;          // -0.0 terms leave any sum bit-unchanged
                             }
+                            sv[j] = dom_pad_terms(sv[j], m, x, ra + j);
                         }
                     }
                 }
@@ -2852,7 +2872,9 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
     const int lend = od[7];
     DomRec D;
     for (int u = 0; u < 7; u++) { D.off[u] = od[u]; D.val[u] = val8 ? val8[8 * dom + u] : 0.0; }
-    D.pat = dom; D.mask = (1 << lend) - 1; D.pad = 0;
+    D.pat = dom; D.mask = (1 << lend) - 1; D.d0 = -1;
+    for (int u = 0; u < lend; u++) if (od[u] == 0) D.d0 = u;
+    const int d0 = D.d0;
     double img[PAT7_MAX * 8];
     for (int i = 0; i < npat; i++) {
         const int *oi = rec32 + 8 * i;
@@ -2863,6 +2885,11 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
         int j = 0;
         for (int sl = 0; sl < lend && j < leni; sl++)
             if (oi[j] == od[sl]) { mask |= 1u << sl; out[1 + sl] = val8 ? val8[8 * i + j] : 0.0; j++; }
+        if (j != leni && val8 && d0 >= 0 && j >= 1) {     // ... followed by nothing but (row, +0.0) entries: ELL's padding (dom_pad_terms)
+            bool pads = true;
+            for (int k = j; k < leni; k++) { unsigned long long vb; memcpy(&vb, &val8[8 * i + k], 8); if (oi[k] != 0 || vb != 0ull) pads = false; }
+            if (pads) { mask |= (unsigned)(leni - j) << 8; j = leni; }
+        }
         if (j != leni) mask = 0x80u;                      // not a subsequence of the dominant pattern: its rows take their own records
         unsigned long long bits = mask;
         memcpy(out, &bits, 8);

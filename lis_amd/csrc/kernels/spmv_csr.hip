@@ -2179,6 +2179,86 @@ void spmv_csr_valuerecw_kernel(const unsigned char *__restrict__ rowpat, const v
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
+// The same with x STAGED and the dominant pattern in scalar registers -- the constant-coefficient 27-point stencil (the matrix of the reference's
+// spmvtest3b and of HPCG), the 9- and 19-point ones.  The kernel above issues a gather per entry (27 vector-memory instructions per 64 rows, and
+// every workgroup first copies all records into LDS); what such a kernel pays for is the number of those instructions
+// (profiles/r03_pattern_team_kernel.txt).  Here a wavefront owns 64 consecutive rows, one per lane.  The x values they need from a run of m
+// neighbouring columns of the dominant pattern are 63 + m consecutive doubles: all runs together (594 doubles for the 27-point stencil) come in
+// by ceil(slots / 128) coalesced 16 B loads whose column offsets are a per-lane table (two loads), speculative addresses clamped to the array, and
+// land in the wavefront's own LDS slice -- no barrier.  A row on the dominant pattern then multiplies slot (entry) + lane by the entry's value, a
+// SCALAR register (the pattern's slots and values are kernel arguments); rows on other patterns whose offsets the dominant one's runs hold take
+// their mask and values in the dominant pattern's slots by scalar loads, one round per distinct pattern among the lanes (dom_waterfall's scheme);
+// foreign rows walk their own record.  Same products in the same order -- masked slots add -0.0 -- so y is the reference's, bit for bit.
+struct WideDom { int len, pat, slots, maxcol; int slot[PATW_LEN]; double val[PATW_LEN]; };
+constexpr int WREC = 40;                                   // doubles per pattern in wdrec: 32 values in the dominant pattern's slots, [32] = mask | foreign << 32
+template <int BLOCK, int NL>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, const double *__restrict__ wdrec, const v4i32 *__restrict__ wstage,
+                                      const v4i32 *__restrict__ rec, int npat, const double *__restrict__ x, double *__restrict__ y, Rows RW,
+                                      const WideDom D, int xcap, const double *__restrict__ guard = nullptr)
+{
+    if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
+    extern __shared__ __attribute__((aligned(16))) double wide_dyn[];
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
+    double *xL = wide_dyn + w * xcap;
+    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * WAVE, r1 = min(r0 + WAVE, RW.re);
+    if (r0 >= r1) return;
+    const int r = min(r0 + lane, r1 - 1);
+    const bool live = r0 + lane < r1;
+    const int pat = rowpat[r];
+    const v4i32 so0 = wstage[2 * lane], so1 = wstage[2 * lane + 1];      // the column offsets of this lane's slot pairs, load by load
+    const int so[8] = {so0.x, so0.y, so0.z, so0.w, so1.x, so1.y, so1.z, so1.w};
+    v2f64 xs[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int c = r0 + so[k], cc = min(max(c, 0), D.maxcol - 1);
+        const v2f64 v = *reinterpret_cast<const v2f64u *>(x + cc);
+        xs[k].x = c > cc ? v.y : v.x;                              // a pair pushed inside the array by the clamp hands each slot the half that holds its column
+        xs[k].y = c < cc ? v.x : v.y;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for (int k = 0; k < NL; k++) { const int sl = 2 * (k * WAVE + lane); if (sl < D.slots) *reinterpret_cast<v2f64 *>(xL + sl) = xs[k]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double *xr = xL + lane;
+    double acc = RW.acc0;
+    if (__builtin_amdgcn_ballot_w64(live && pat != D.pat) == 0) {   // (uniform) every row here is on the dominant pattern
+#pragma unroll
+        for (int j = 0; j < PATW_LEN; j++) if (j < D.len) acc += D.val[j] * xr[D.slot[j]];
+    } else {
+        double v[PATW_LEN];
+#pragma unroll
+        for (int j = 0; j < PATW_LEN; j++) v[j] = D.val[j];
+        unsigned m = D.len >= 32 ? 0xffffffffu : ((1u << D.len) - 1u);
+        bool foreign = false;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(live && pat != D.pat);
+        while (todo != 0) {                                         // (uniform) one record by scalar loads per distinct pattern among the lanes
+            const int q = __builtin_amdgcn_readlane(pat, __builtin_ctzll(todo));
+            const double *R = wdrec + (size_t)q * WREC;             // (uniform address)
+            const bool me = live && pat == q;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(R[32]);
+            m = me ? (unsigned)bits : m;
+            foreign = me ? (bits >> 32) != 0 : foreign;
+#pragma unroll
+            for (int j = 0; j < PATW_LEN; j++) v[j] = me ? R[j] : v[j];
+            todo &= ~__builtin_amdgcn_ballot_w64(me);
+        }
+        if (foreign) {                                              // a pattern the dominant one's runs do not hold: its own record (offsets, values), entry by entry
+            const int *off = reinterpret_cast<const int *>(rec) + pat * PATW_OFF;
+            const double *vv = reinterpret_cast<const double *>(rec + npat * (PATW_OFF / 4)) + pat * PATW_LEN;
+            const int len = off[PATW_LEN];
+            const unsigned rb8 = (unsigned)r * 8u;
+            for (int j = 0; j < len; j++) acc += vv[j] * *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)off[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < PATW_LEN; j++) if (j < D.len) { const double t = v[j] * xr[D.slot[j]]; acc += ((m >> j) & 1u) ? t : -0.0; }     // -0.0 terms leave any sum bit-unchanged
+        }
+    }
+    if (live) store_stream(y + r, acc);
+}
+
 // plan time: one 64-bit hash per row over (length, code sequence); the distinct ones in an open-addressing table together with the
 // smallest row that has them; gives up beyond 255
 constexpr int PAT_SLOTS = 1024, PAT_MAXLEN = 64;
@@ -2395,6 +2475,9 @@ struct liship_csr_plan_s {
     v4i32 *prec_slot;    // device: with prec36, when ONE pattern carries most rows and its offsets are runs of equal length (box stencils): per pattern 32 slots
                          // into the wavefront's staged x (TeamRuns), length, "foreign" flag: spmv_csr_pattern_team_staged_kernel; else NULL
     TeamRuns tr;         // the runs of the dominant pattern (nruns = 0: none)
+    double *wdrec;       // device: with vrecw, when one pattern carries most rows: per pattern WREC doubles (values in the dominant pattern's slots, mask | foreign << 32)
+    v4i32 *wstage;       // device: 64 x 8 ints, the column offsets of a lane's slot pairs in the staging loads of spmv_csr_valuerecw_staged_kernel
+    WideDom wd;          // the dominant wide pattern (len = 0: none)
     v4i32 *prec36;       // device: when the longest pattern has 8..32 offsets, one 144 B record per pattern (32 byte offsets, length): spmv_csr_pattern_team_kernel; else NULL
     int prep[256];       // a row that carries each pattern
     v4i32 *vrec;         // device: with ptab8, when every row of a pattern carries the same values, 96 B per pattern (the 32 B record + 7 values); else NULL
@@ -2495,7 +2578,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
     p->drec = nullptr; p->dom_lo = p->dom_hi = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
@@ -2516,6 +2599,8 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->ptab8) (void)hipFree(p->ptab8);
     if (p->prec36) (void)hipFree(p->prec36);
     if (p->prec_slot) (void)hipFree(p->prec_slot);
+    if (p->wdrec) (void)hipFree(p->wdrec);
+    if (p->wstage) (void)hipFree(p->wstage);
     if (p->vrec) (void)hipFree(p->vrec);
     if (p->drec) (void)hipFree(p->drec);
     if (p->order) (void)hipFree(p->order);
@@ -2836,6 +2921,8 @@ extern "C" int liship_csr_plan_row_patterns(liship_csr_plan_t p) { return (p && 
 // 1 when the plan keeps the 144 B records of spmv_csr_pattern_team_kernel (longest pattern 8..32 offsets)
 extern "C" int liship_csr_plan_team_records(liship_csr_plan_t p) { return (p && p->rowpat && p->prec36) ? 1 : 0; }
 // 2 when the plan also keeps the dominant pattern's runs and slot records (the staged-x form), 1: records only, 0: none
+// 1 when a plan with wide value records also keeps the dominant pattern for the staged-x kernel (spmv_csr_valuerecw_staged_kernel)
+extern "C" int liship_csr_plan_wide_dominant(liship_csr_plan_t p) { return (p && p->vrecw && p->wdrec && p->wd.len > 0) ? 1 : 0; }
 extern "C" int liship_csr_plan_team_form(liship_csr_plan_t p) { return (p && p->rowpat && p->prec36) ? ((p->prec_slot && p->tr.nruns > 0) ? 2 : 1) : 0; }
 extern "C" int liship_csr_plan_pattern_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8) ? 1 : 0; }
 extern "C" int liship_spmv_csr_set_row_patterns(int on) { g_row_patterns = on ? 1 : 0; return 0; }
@@ -2990,6 +3077,86 @@ static int refine_patterns_by_values(liship_csr_plan_s *p, const int *ptr, const
 // the same for patterns of up to 32 entries (no 32 B records): offsets from the plan's pattern table, values from one row per pattern,
 // every row checked; the image is npat x 144 B (32 byte offsets, the tail repeating the last one; the length; padding) followed by
 // npat x 256 B (32 values, the tail 0).  Rows of one offset pattern with different values split the pattern (up to 48 in all).
+// The dominant pattern of a plan with WIDE value records, its runs of neighbouring columns as 64-row slots, every other pattern as a mask and values in the
+// dominant one's slots (spmv_csr_valuerecw_staged_kernel).  T: the pattern table (NP + 1 prefix entries, then element offsets), vals: NP x PATW_LEN
+// values (host).  Kept when one pattern carries at least half of the rows; never an error.
+static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, const double *vals, const int *ptr, hipStream_t st)
+{
+    if (p->wdrec) { (void)hipFree(p->wdrec); p->wdrec = nullptr; }
+    if (p->wstage) { (void)hipFree(p->wstage); p->wstage = nullptr; }
+    p->wd.len = 0;
+    if (NP <= 0 || NP > 255 || p->n < 4 * WAVE || !p->rowpat || !p->codes || !p->dict) return;
+    unsigned long long *d_count = nullptr, count[256];
+    int *d_max = nullptr, maxcol = 0;
+    bool ok = hipMalloc(&d_count, sizeof(count)) == hipSuccess && hipMalloc(&d_max, sizeof(int)) == hipSuccess;
+    ok = ok && hipMemsetAsync(d_count, 0, sizeof(count), st) == hipSuccess && hipMemsetAsync(d_max, 0, sizeof(int), st) == hipSuccess;
+    if (ok) { rowpat_histogram<<<1024, 256, 0, st>>>(p->n, p->rowpat, d_count); ok = hipGetLastError() == hipSuccess; }
+    if (ok) { csr_max_column<<<2048, 256, 0, st>>>(p->n, ptr, p->codes, p->dict, d_max); ok = hipGetLastError() == hipSuccess; }
+    ok = ok && hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(&maxcol, d_max, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    if (d_count) (void)hipFree(d_count);
+    if (d_max) (void)hipFree(d_max);
+    if (!ok) return;
+    int dom = 0;
+    for (int i = 1; i < NP; i++) if (count[i] > count[dom]) dom = i;
+    const int l = T[dom + 1] - T[dom];
+    if (count[dom] * 2 < (unsigned long long)p->n || l < 1 || l > PATW_LEN || maxcol < 1) return;
+    const int *od = T + NP + 1 + T[dom];                       // the dominant pattern's offsets (elements), in its own order = slot order
+    int offs[PATW_LEN], start[16], mlen[16], base[17], nruns = 0;
+    for (int j = 0; j < l; j++) offs[j] = od[j];
+    for (int a = 1; a < l; a++) { const int v = offs[a]; int b = a - 1; while (b >= 0 && offs[b] > v) { offs[b + 1] = offs[b]; b--; } offs[b + 1] = v; }
+    for (int j = 0; j < l; ) {
+        int e = j + 1;
+        while (e < l && offs[e] == offs[e - 1] + 1) e++;
+        if ((e < l && offs[e] == offs[e - 1]) || nruns == 16) return;     // a repeated offset, too many runs: the gathering kernel serves
+        start[nruns] = offs[j]; mlen[nruns++] = e - j;
+        j = e;
+    }
+    base[0] = 0;
+    for (int a = 0; a < nruns; a++) base[a + 1] = base[a] + ((WAVE - 1 + mlen[a] + 1) & ~1);     // 64 rows need 63 + m columns of a run of m; even widths (pairs of slots)
+    const int slots = base[nruns];
+    if (slots > 8 * 2 * WAVE) return;
+    WideDom D;
+    memset(&D, 0, sizeof(D));
+    D.len = l; D.pat = dom; D.slots = slots; D.maxcol = maxcol;
+    for (int j = 0; j < l; j++) {
+        int q = 0;
+        for (int a = 0; a < nruns; a++) if (od[j] >= start[a] && od[j] < start[a] + mlen[a]) q = a;
+        D.slot[j] = base[q] + (od[j] - start[q]);
+        D.val[j] = vals[(size_t)dom * PATW_LEN + j];
+    }
+    int *stage = (int *)calloc(WAVE * 8, sizeof(int));
+    double *img = (double *)calloc((size_t)NP * WREC, sizeof(double));
+    if (stage && img) {
+        for (int lane = 0; lane < WAVE; lane++)
+            for (int k = 0; k < 8; k++) {
+                const int sl = 2 * (k * WAVE + lane);
+                int q = -1;
+                for (int a = 0; a < nruns; a++) if (sl >= base[a] && sl < base[a + 1]) q = a;
+                stage[lane * 8 + k] = q >= 0 ? start[q] + (sl - base[q]) : 0;
+            }
+        for (int i = 0; i < NP; i++) {
+            const int li = T[i + 1] - T[i];
+            const int *oi = T + NP + 1 + T[i];
+            unsigned long long bits = 0;
+            int j = 0;
+            for (int sl = 0; sl < l && j < li; sl++)
+                if (oi[j] == od[sl]) { bits |= 1ull << sl; img[(size_t)i * WREC + sl] = vals[(size_t)i * PATW_LEN + j]; j++; }
+            if (j != li) bits = 1ull << 32;                   // not a subsequence of the dominant pattern: its rows walk their own record
+            memcpy(&img[(size_t)i * WREC + 32], &bits, 8);
+        }
+        if (hipMalloc(&p->wdrec, sizeof(double) * WREC * (size_t)NP) == hipSuccess && hipMalloc(&p->wstage, sizeof(int) * WAVE * 8) == hipSuccess &&
+            hipMemcpy(p->wdrec, img, sizeof(double) * WREC * (size_t)NP, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(p->wstage, stage, sizeof(int) * WAVE * 8, hipMemcpyHostToDevice) == hipSuccess) p->wd = D;
+        else {
+            if (p->wdrec) { (void)hipFree(p->wdrec); p->wdrec = nullptr; }
+            if (p->wstage) { (void)hipFree(p->wstage); p->wstage = nullptr; }
+        }
+    }
+    free(stage); free(img);
+}
+
 static int encode_wide_value_records(liship_csr_plan_s *p, const int *ptr, const double *val, hipStream_t st)
 {
     if (p->npat <= 0 || p->npat > PATW_MAX || p->ptab_len <= p->npat) return 0;
@@ -3096,6 +3263,7 @@ static int encode_wide_value_records(liship_csr_plan_s *p, const int *ptr, const
             build_team_records(p, ntab, np2);            // (the values-streamed product of this plan reads the renumbered pattern bytes too)
             build_team_runs(p, ptr, st);
         }
+        if (rc == 0 && p->vrecw) build_wide_dominant(p, T, NP, reinterpret_cast<const double *>(img + obytes), ptr, st);
     }
 #undef PT
     (void)hipFree(d_rep); (void)hipFree(d_bad); (void)hipFree(vr);
@@ -3266,6 +3434,22 @@ void launch_products(int grid, const LaunchArgs &a)
                                      nullptr, nullptr, nullptr, 0, XRUN ? nullptr : a.order);
 }
 
+// rows of up to 32 entries whose values ride in wide records: x staged per wavefront, the dominant pattern in scalar registers (variant 0x4000: the
+// gathering kernel on plan row blocks, A/B)
+static bool launch_wide(const LaunchArgs &a, const double *guard)
+{
+    const liship_csr_plan_s *P = a.plan;
+    if (!P || !P->wdrec || !P->wstage || P->wd.len <= 0 || !g_team || (g_variant & 0x4000)) return false;
+    const int rows = a.re - a.rb, wgs = (rows + 255) / 256;
+    if (rows <= 0) return true;
+    const int xcap = (P->wd.slots + 1) & ~1, nl = (P->wd.slots + 2 * WAVE - 1) / (2 * WAVE);
+#define GOW(NL) spmv_csr_valuerecw_staged_kernel<256, NL><<<wgs, 256, sizeof(double) * 4 * (size_t)xcap, a.st>>>( \
+        a.rowpat, P->wdrec, P->wstage, a.vrecw, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0}, P->wd, xcap, guard)
+    if (nl <= 2) GOW(2); else if (nl <= 3) GOW(3); else if (nl <= 5) GOW(5); else if (nl <= 6) GOW(6); else GOW(8);
+#undef GOW
+    return true;
+}
+
 // patterned rows of 8..32 entries, values streamed: four lanes per row, with x staged per wavefront when the plan found the dominant pattern's
 // runs (variant 0x4000: the gathers of the first form, A/B)
 static void launch_team(const LaunchArgs &a, const double *guard)
@@ -3375,7 +3559,8 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
                 a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, chunks, Rows{a.rb, a.re, a.acc0});
         return;
     }
-    if (a.rowpat && a.vrecw && g_variant == 0) {      // the rows' values ride in WIDE records (rows of up to 32 entries): one byte per row
+    if (a.rowpat && a.vrecw && (g_variant & ~0x4000) == 0 && launch_wide(a, nullptr)) return;      // wide records, x staged, the dominant pattern in scalar registers
+    if (a.rowpat && a.vrecw && (g_variant & ~0x4000) == 0) {      // the rows' values ride in WIDE records (rows of up to 32 entries): one byte per row
         constexpr Geometry g = kGeom[G];
         spmv_csr_valuerecw_kernel<g.block, 0><<<a.nb, g.block, 0, a.st>>>(
             a.rowpat, a.vrecw, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0});
@@ -3456,6 +3641,10 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
         spmv_csr_pattern7_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz,
             w, partial, liship_internal_guard(), pstride);
+        return;
+    }
+    if (a.rowpat && a.vrecw && !(g_variant & 0x2000) && a.re > a.rb && launch_wide(a, liship_internal_guard())) {      // ... then the plan row blocks' sums (the bits of the epilogue below)
+        csr_block_dots_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(a.ptr, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.y, w, partial, liship_internal_guard(), pstride);
         return;
     }
     if (a.rowpat && a.vrecw && !(g_variant & 0x2000)) {

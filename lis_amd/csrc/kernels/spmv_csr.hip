@@ -2191,7 +2191,7 @@ void spmv_csr_valuerecw_kernel(const unsigned char *__restrict__ rowpat, const v
 // foreign rows walk their own record.  Same products in the same order -- masked slots add -0.0 -- so y is the reference's, bit for bit.
 struct WideDom { int len, pat, slots, maxcol; int slot[PATW_LEN]; double val[PATW_LEN]; };
 constexpr int WREC = 40;                                   // doubles per pattern in wdrec: 32 values in the dominant pattern's slots, [32] = mask | foreign << 32
-template <int BLOCK, int NL>
+template <int BLOCK, int NL, int CH>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, const double *__restrict__ wdrec, const v4i32 *__restrict__ wstage,
                                       const v4i32 *__restrict__ rec, int npat, const double *__restrict__ x, double *__restrict__ y, Rows RW,
@@ -2201,62 +2201,99 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
     extern __shared__ __attribute__((aligned(16))) double wide_dyn[];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
     double *xL = wide_dyn + w * xcap;
-    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * WAVE, r1 = min(r0 + WAVE, RW.re);
-    if (r0 >= r1) return;
-    const int r = min(r0 + lane, r1 - 1);
-    const bool live = r0 + lane < r1;
-    const int pat = rowpat[r];
+    // a wavefront walks CH consecutive chunks of 64 rows: the staging loads and the pattern byte of the NEXT chunk are issued before the products of the
+    // one in hand are formed, so that a round trip hides behind the arithmetic (and the offset table is read once)
+    const int rbase = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * (CH * WAVE);
+    if (rbase >= RW.re) return;
     const v4i32 so0 = wstage[2 * lane], so1 = wstage[2 * lane + 1];      // the column offsets of this lane's slot pairs, load by load
     const int so[8] = {so0.x, so0.y, so0.z, so0.w, so1.x, so1.y, so1.z, so1.w};
-    v2f64 xs[NL];
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-        const int c = r0 + so[k], cc = min(max(c, 0), D.maxcol - 1);
-        const v2f64 v = *reinterpret_cast<const v2f64u *>(x + cc);
-        xs[k].x = c > cc ? v.y : v.x;                              // a pair pushed inside the array by the clamp hands each slot the half that holds its column
-        xs[k].y = c < cc ? v.x : v.y;
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll
-    for (int k = 0; k < NL; k++) { const int sl = 2 * (k * WAVE + lane); if (sl < D.slots) *reinterpret_cast<v2f64 *>(xL + sl) = xs[k]; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const double *xr = xL + lane;
-    double acc = RW.acc0;
-    if (__builtin_amdgcn_ballot_w64(live && pat != D.pat) == 0) {   // (uniform) every row here is on the dominant pattern
+    v2f64 xs[NL];
+    int patn;
+    auto prefetch = [&](int r0) {
+        patn = rowpat[min(r0 + lane, RW.re - 1)];
 #pragma unroll
-        for (int j = 0; j < PATW_LEN; j++) if (j < D.len) acc += D.val[j] * xr[D.slot[j]];
-    } else {
-        double v[PATW_LEN];
-#pragma unroll
-        for (int j = 0; j < PATW_LEN; j++) v[j] = D.val[j];
-        unsigned m = D.len >= 32 ? 0xffffffffu : ((1u << D.len) - 1u);
-        bool foreign = false;
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(live && pat != D.pat);
-        while (todo != 0) {                                         // (uniform) one record by scalar loads per distinct pattern among the lanes
-            const int q = __builtin_amdgcn_readlane(pat, __builtin_ctzll(todo));
-            const double *R = wdrec + (size_t)q * WREC;             // (uniform address)
-            const bool me = live && pat == q;
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(R[32]);
-            m = me ? (unsigned)bits : m;
-            foreign = me ? (bits >> 32) != 0 : foreign;
-#pragma unroll
-            for (int j = 0; j < PATW_LEN; j++) v[j] = me ? R[j] : v[j];
-            todo &= ~__builtin_amdgcn_ballot_w64(me);
+        for (int k = 0; k < NL; k++) {
+            const int c = r0 + so[k], cc = min(max(c, 0), D.maxcol - 1);
+            const v2f64 v = *reinterpret_cast<const v2f64u *>(x + cc);
+            xs[k].x = c > cc ? v.y : v.x;                          // a pair pushed inside the array by the clamp hands each slot the half that holds its column
+            xs[k].y = c < cc ? v.x : v.y;
         }
-        if (foreign) {                                              // a pattern the dominant one's runs do not hold: its own record (offsets, values), entry by entry
-            const int *off = reinterpret_cast<const int *>(rec) + pat * PATW_OFF;
-            const double *vv = reinterpret_cast<const double *>(rec + npat * (PATW_OFF / 4)) + pat * PATW_LEN;
-            const int len = off[PATW_LEN];
-            const unsigned rb8 = (unsigned)r * 8u;
-            for (int j = 0; j < len; j++) acc += vv[j] * *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)off[j]));
+    };
+    prefetch(rbase);
+#pragma unroll 1
+    for (int ch = 0; ch < CH; ch++) {
+        const int r0 = rbase + ch * WAVE, r1 = min(r0 + WAVE, RW.re);
+        if (r0 >= r1) break;                                        // (uniform)
+        const int r = min(r0 + lane, r1 - 1);
+        const bool live = r0 + lane < r1;
+        __builtin_amdgcn_s_waitcnt(0);                              // the chunk's x and pattern bytes have landed (and the products before have read the slice)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < NL; k++) { const int sl = 2 * (k * WAVE + lane); if (sl < D.slots) *reinterpret_cast<v2f64 *>(xL + sl) = xs[k]; }
+        const int pat = patn;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (ch + 1 < CH && r0 + WAVE < RW.re) prefetch(r0 + WAVE);  // (uniform)
+        double acc = RW.acc0;
+        if (__builtin_amdgcn_ballot_w64(live && pat != D.pat) == 0) {   // (uniform) every row here is on the dominant pattern
+#pragma unroll
+            for (int j = 0; j < PATW_LEN; j++) if (j < D.len) acc += D.val[j] * xr[D.slot[j]];
         } else {
+            // masks first: one 8 B scalar load per distinct pattern among the lanes.  Bit 32: foreign (the row walks its own record); bit 33: the pattern's values are
+            // the dominant one's in every slot it keeps (HPCG's boundary rows: 26 and -1 everywhere) -- then the values stay in scalar registers
+            unsigned m = D.len >= 32 ? 0xffffffffu : ((1u << D.len) - 1u);
+            bool foreign = false, differs = false;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(live && pat != D.pat);
+            while (todo != 0) {                                         // (uniform)
+                const int q = __builtin_amdgcn_readlane(pat, __builtin_ctzll(todo));
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(wdrec[(size_t)q * WREC + 32]);      // (uniform address)
+                const bool me = live && pat == q;
+                m = me ? (unsigned)bits : m;
+                foreign = me ? ((bits >> 32) & 1ull) != 0 : foreign;
+                differs = me ? ((bits >> 33) & 1ull) == 0 : differs;
+                todo &= ~__builtin_amdgcn_ballot_w64(me);
+            }
+            if (__builtin_amdgcn_ballot_w64(differs && !foreign) == 0) {      // (uniform) nobody needs values of its own
+                if (!foreign) {
 #pragma unroll
-            for (int j = 0; j < PATW_LEN; j++) if (j < D.len) { const double t = v[j] * xr[D.slot[j]]; acc += ((m >> j) & 1u) ? t : -0.0; }     // -0.0 terms leave any sum bit-unchanged
+                    for (int j = 0; j < PATW_LEN; j++) if (j < D.len) { const double t = D.val[j] * xr[D.slot[j]]; acc += ((m >> j) & 1u) ? t : -0.0; }     // -0.0 terms leave any sum bit-unchanged
+                }
+            } else {
+                // ... in two halves of 16 slots (32 registers of values at a time keep the kernel at 64 registers: eight wavefronts per SIMD)
+#pragma unroll
+                for (int h = 0; h < PATW_LEN; h += 16) {
+                    if (h < D.len) {                                    // (uniform)
+                        double v[16];
+#pragma unroll
+                        for (int j = 0; j < 16; j++) v[j] = D.val[h + j];
+                        todo = __builtin_amdgcn_ballot_w64(differs && !foreign);
+                        while (todo != 0) {                             // (uniform) the values in the dominant pattern's slots, by scalar loads
+                            const int q = __builtin_amdgcn_readlane(pat, __builtin_ctzll(todo));
+                            const double *R = wdrec + (size_t)q * WREC + h;
+                            const bool me = live && pat == q;
+#pragma unroll
+                            for (int j = 0; j < 16; j++) v[j] = me ? R[j] : v[j];
+                            todo &= ~__builtin_amdgcn_ballot_w64(me);
+                        }
+                        if (!foreign) {
+#pragma unroll
+                            for (int j = 0; j < 16; j++) if (h + j < D.len) { const double t = v[j] * xr[D.slot[h + j]]; acc += ((m >> (h + j)) & 1u) ? t : -0.0; }
+                        }
+                    }
+                }
+            }
+            if (foreign) {                                              // a pattern the dominant one's runs do not hold: its own record (offsets, values), entry by entry
+                const int *off = reinterpret_cast<const int *>(rec) + pat * PATW_OFF;
+                const double *vv = reinterpret_cast<const double *>(rec + npat * (PATW_OFF / 4)) + pat * PATW_LEN;
+                const int len = off[PATW_LEN];
+                const unsigned rb8 = (unsigned)r * 8u;
+                for (int j = 0; j < len; j++) acc += vv[j] * *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)off[j]));
+            }
         }
+        if (live) store_stream(y + r, acc);
     }
-    if (live) store_stream(y + r, acc);
 }
 
 // plan time: one 64-bit hash per row over (length, code sequence); the distinct ones in an open-addressing table together with the
@@ -3144,6 +3181,11 @@ static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, cons
             for (int sl = 0; sl < l && j < li; sl++)
                 if (oi[j] == od[sl]) { bits |= 1ull << sl; img[(size_t)i * WREC + sl] = vals[(size_t)i * PATW_LEN + j]; j++; }
             if (j != li) bits = 1ull << 32;                   // not a subsequence of the dominant pattern: its rows walk their own record
+            else {                                            // every kept slot carries the dominant pattern's value: the kernel leaves the values in scalar registers
+                bool same = true;
+                for (int sl = 0; sl < l; sl++) if ((bits >> sl) & 1ull) same = same && memcmp(&img[(size_t)i * WREC + sl], &D.val[sl], 8) == 0;
+                if (same) bits |= 1ull << 33;
+            }
             memcpy(&img[(size_t)i * WREC + 32], &bits, 8);
         }
         if (hipMalloc(&p->wdrec, sizeof(double) * WREC * (size_t)NP) == hipSuccess && hipMalloc(&p->wstage, sizeof(int) * WAVE * 8) == hipSuccess &&
@@ -3440,10 +3482,11 @@ static bool launch_wide(const LaunchArgs &a, const double *guard)
 {
     const liship_csr_plan_s *P = a.plan;
     if (!P || !P->wdrec || !P->wstage || P->wd.len <= 0 || !g_team || (g_variant & 0x4000)) return false;
-    const int rows = a.re - a.rb, wgs = (rows + 255) / 256;
+    constexpr int CH = 1;                            // chunks of 64 rows per wavefront
+    const int rows = a.re - a.rb, wgs = (rows + 256 * CH - 1) / (256 * CH);
     if (rows <= 0) return true;
     const int xcap = (P->wd.slots + 1) & ~1, nl = (P->wd.slots + 2 * WAVE - 1) / (2 * WAVE);
-#define GOW(NL) spmv_csr_valuerecw_staged_kernel<256, NL><<<wgs, 256, sizeof(double) * 4 * (size_t)xcap, a.st>>>( \
+#define GOW(NL) spmv_csr_valuerecw_staged_kernel<256, NL, CH><<<wgs, 256, sizeof(double) * 4 * (size_t)xcap, a.st>>>( \
         a.rowpat, P->wdrec, P->wstage, a.vrecw, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0}, P->wd, xcap, guard)
     if (nl <= 2) GOW(2); else if (nl <= 3) GOW(3); else if (nl <= 5) GOW(5); else if (nl <= 6) GOW(6); else GOW(8);
 #undef GOW

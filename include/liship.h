@@ -103,6 +103,9 @@ int  liship_csr_plan_team_form(liship_csr_plan_t plan);
 /* 1 when a plan with WIDE value records (constant-coefficient rows of up to 32 entries) also found a dominant pattern and runs the kernel with x staged per
  * wavefront and that pattern's slots and values in scalar registers (spmv_csr_valuerecw_staged_kernel) */
 int  liship_csr_plan_wide_dominant(liship_csr_plan_t plan);
+/* 0 when the products of this plan run a kernel with a row split of its own (the team / staged kernels) under the switches in force: the fused entry points
+ * (liship_spmv_csr_dot_f64, liship_spmv_csr_rows_dot_f64) then refuse with LISHIP_ERR_ARG and the caller runs the product and one reduction pass */
+int  liship_csr_plan_fused_dots(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_team(int on);           /* A/B switch: 0 = the one-lane-per-row pattern kernel for these rows too (same bits) */
 /* Value records (setup-time, optional, after liship_csr_plan_encode_row_patterns; never an error when the matrix does not
  * qualify): when the plan has 32 B pattern records and every row of a pattern carries the same values bit for bit -- a

@@ -75,6 +75,7 @@ _LISHIP = {
     "liship_csr_plan_pattern_records": (_ci, [_vp]),
     "liship_csr_plan_team_records": (_ci, [_vp]),
     "liship_csr_plan_team_form": (_ci, [_vp]),
+    "liship_csr_plan_fused_dots": (_ci, [_vp]),
     "liship_csr_plan_wide_dominant": (_ci, [_vp]),
     "liship_spmv_csr_set_team": (_ci, [_ci]),
     "liship_spmv_bsr_set_team": (_ci, [_ci]),

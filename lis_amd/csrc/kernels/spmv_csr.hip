@@ -1218,26 +1218,6 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     if (live && t == 3) store_stream(y + r, c);
 }
 
-// <w, y> (and <y, y>) of rows already multiplied, with the partial sums of the fused kernels: one workgroup per plan row block, lane L adds
-// the rows r0 + L, r0 + L + BLOCK, ... in that order, the workgroup folds as publish_dots does.  The four-lanes-per-row product has its
-// own row split (16 rows per wavefront), so its fused form is the product followed by this pass over y and w (16 B per row on top of 230):
-// the sums are then the bits every other form of the product makes.
-template <int BLOCK, int DOT>
-__global__ __launch_bounds__(BLOCK)
-void csr_block_dots_kernel(const int *__restrict__ ptr, const v2i32 *__restrict__ blk, int bfirst, int nb, Rows RW,
-                           const double *__restrict__ y, const double *__restrict__ wdot, double *__restrict__ partial,
-                           const double *__restrict__ guard, int pstride)
-{
-    if (guard != nullptr && guard[0] != 0.0) return;               // device-driven Krylov loop already converged
-    __shared__ double dot_scratch[BLOCK / WAVE];
-    RowDots<DOT> dots{wdot, 0.0, 0.0};
-    const int lb = blockIdx.x;
-    Blk B = load_blk(blk, bfirst + lb);
-    if (clip_rows(B, ptr, RW.rb, RW.re))
-        for (int r = B.r0 + (int)threadIdx.x; r < B.r1; r += BLOCK) dots.add(r, y[r]);
-    publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
-}
-
 // inclusive sum over the 64 lanes by data-parallel primitives: 4 shifts inside the rows of 16, then lane 15 of each row into
 // the next row, then lane 31 into the upper half -- 6 adds, no LDS traffic.  All lanes must be active.
 __device__ __forceinline__ int wave_inclusive_scan(int v)
@@ -2296,6 +2276,104 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
     }
 }
 
+// The same shape for STREAMED values (rows of 8..32 entries on <= 255 patterns whose coefficients vary: the 27-point stencil on a non-uniform mesh): a
+// wavefront owns 64 consecutive rows, one per lane, their value slice (LDS-DMA) and the staged x of the dominant pattern's runs; a lane walks ITS row in
+// order -- the entry of the dominant pattern's slot j is the row's (number of kept slots before j)-th value -- so the sum is one chain per lane with no
+// hand-off, and a wavefront issues 23 vector-memory instructions for 64 rows where the four-lanes-per-row kernel issues 36.  Masks by scalar loads, one
+// round per distinct pattern; rows with a foreign pattern gather by their 144 B record.  Same terms, same order: the reference's bits.
+template <int NL>
+__global__ __launch_bounds__(WAVE)
+void spmv_csr_pattern_rows_staged_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
+                                         const double *__restrict__ wdrec, const v4i32 *__restrict__ wstage, const v4i32 *__restrict__ prec,
+                                         const double *__restrict__ x, double *__restrict__ y, Rows RW, int nnz_total, const WideDom D, int vcap,
+                                         const double *__restrict__ guard = nullptr)
+{
+    if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
+    extern __shared__ __attribute__((aligned(16))) double rows_dyn[];
+    const int lane = (int)threadIdx.x;
+    double *valL = rows_dyn, *xL = rows_dyn + vcap;
+    const int r0 = RW.rb + (int)blockIdx.x * WAVE, r1 = min(r0 + WAVE, RW.re);
+    if (r0 >= r1) return;
+    const int r = min(r0 + lane, r1 - 1);
+    const bool live = r0 + lane < r1;
+    const int k0 = ptr[r0], k1 = ptr[r1];                           // (uniform: scalar loads)
+    const int pat = rowpat[r];
+    const v4i32 so0 = wstage[2 * lane], so1 = wstage[2 * lane + 1];
+    const int so[8] = {so0.x, so0.y, so0.z, so0.w, so1.x, so1.y, so1.z, so1.w};
+    __builtin_amdgcn_sched_barrier(0);
+    v2f64 xs[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int c = r0 + so[k], cc = min(max(c, 0), D.maxcol - 1);
+        const v2f64 v = *reinterpret_cast<const v2f64u *>(x + cc);
+        xs[k].x = c > cc ? v.y : v.x;
+        xs[k].y = c < cc ? v.x : v.y;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int ka = k0 & ~1, cnt = k1 - ka;
+    int np = (cnt + 1) >> 1;
+    const bool odd_end = ka + 2 * np > nnz_total;
+    if (odd_end) np--;
+#pragma unroll
+    for (int it = 0; it < (WAVE * TEAM_MAXLEN / 2 + WAVE) / WAVE; it++) {
+        const int p0 = it * WAVE;
+        if (p0 + lane < np)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p0 + lane),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
+    }
+    if (odd_end && lane == 0) valL[cnt - 1] = val[k1 - 1];
+    __builtin_amdgcn_sched_barrier(0);
+    // masks (and whether a pattern is foreign) by scalar loads, one round per distinct pattern among the lanes
+    unsigned m = D.len >= 32 ? 0xffffffffu : ((1u << D.len) - 1u);
+    bool foreign = false;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(live && pat != D.pat);
+    while (todo != 0) {                                             // (uniform)
+        const int q = __builtin_amdgcn_readlane(pat, __builtin_ctzll(todo));
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(wdrec[(size_t)q * WREC + 32]);
+        const bool me = live && pat == q;
+        m = me ? (unsigned)bits : m;
+        foreign = me ? ((bits >> 32) & 1ull) != 0 : foreign;
+        todo &= ~__builtin_amdgcn_ballot_w64(me);
+    }
+    const bool anyforeign = __builtin_amdgcn_ballot_w64(foreign) != 0;
+    int len = live ? __popc(m) : 0;
+    const v4i32 *frec = prec + pat * TEAM_REC;
+    if (anyforeign && foreign) len = live ? *reinterpret_cast<const int *>(frec + 8) : 0;
+    const int s = k0 + wave_inclusive_scan(len) - len;              // the row's start: the slice's start + the lengths of the rows below it
+    __builtin_amdgcn_s_waitcnt(0);                                  // x and the slice have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < NL; k++) { const int sl = 2 * (k * WAVE + lane); if (sl < D.slots) *reinterpret_cast<v2f64 *>(xL + sl) = xs[k]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double *xr = xL + lane, *vp = valL + (s - ka);
+    double acc = RW.acc0;
+    if (__builtin_amdgcn_ballot_w64(live && pat != D.pat) == 0) {   // (uniform) every row here is on the dominant pattern
+#pragma unroll
+        for (int j = 0; j < PATW_LEN; j++) if (j < D.len) acc += vp[j] * xr[D.slot[j]];
+    } else {
+        if (!foreign) {
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < PATW_LEN; j++)
+                if (j < D.len) {
+                    const bool on = ((m >> j) & 1u) != 0;
+                    const double t = vp[rank] * xr[D.slot[j]];          // (a slot the row does not keep reads a value of the stage and adds -0.0)
+                    acc += on ? t : -0.0;
+                    rank += on ? 1 : 0;
+                }
+        }
+        if (anyforeign && foreign) {                                // a pattern the dominant one's runs do not hold: a gather per entry, by its record of byte offsets
+            const int *off = reinterpret_cast<const int *>(frec);
+            const unsigned rb8 = (unsigned)r * 8u;
+            for (int j = 0; j < len; j++) acc += vp[j] * *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)off[j]));
+        }
+    }
+    if (live) store_stream(y + r, acc);
+}
+
 // plan time: one 64-bit hash per row over (length, code sequence); the distinct ones in an open-addressing table together with the
 // smallest row that has them; gives up beyond 255
 constexpr int PAT_SLOTS = 1024, PAT_MAXLEN = 64;
@@ -2751,6 +2829,8 @@ static void build_team_records(liship_csr_plan_s *p, const int *T, int NP)
 
 __global__ void rowpat_histogram(int n, const unsigned char *__restrict__ rowpat, unsigned long long *__restrict__ count);
 
+static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, const double *vals, const int *ptr, hipStream_t st);
+
 // largest column index of a coded matrix (the staged x of the team kernel is read speculatively: its addresses are clamped to the array)
 __global__ void csr_max_column(int n, const int *__restrict__ ptr, const unsigned char *__restrict__ codes, const int *__restrict__ dict, int *__restrict__ out)
 {
@@ -2946,6 +3026,11 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
     p->npat = npat; p->ptab_len = npat + 1 + total;
     for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
     build_team_runs(p, ptr, st);                    // (patterns of 8..32 offsets: the staged-x form of the four-lanes-per-row kernel, when one pattern dominates)
+    if (p->prec36) {                                // ... and the lane-per-row form with the dominant pattern's slots in scalar registers
+        int *Th = (int *)malloc(sizeof(int) * (size_t)p->ptab_len);
+        if (Th && hipMemcpy(Th, p->ptab, sizeof(int) * (size_t)p->ptab_len, hipMemcpyDeviceToHost) == hipSuccess) build_wide_dominant(p, Th, p->npat, nullptr, ptr, st);
+        free(Th);
+    }
     if (p->ptab8) {                                 // the dominant pattern, offsets only (values join with the value records)
         int rec8[PAT7_MAX * 8];
         if (hipMemcpy(rec8, p->ptab8, sizeof(int) * 8 * (size_t)npat, hipMemcpyDeviceToHost) == hipSuccess) build_dominant(p, npat, rec8, nullptr);
@@ -3116,7 +3201,8 @@ static int refine_patterns_by_values(liship_csr_plan_s *p, const int *ptr, const
 // npat x 256 B (32 values, the tail 0).  Rows of one offset pattern with different values split the pattern (up to 48 in all).
 // The dominant pattern of a plan with WIDE value records, its runs of neighbouring columns as 64-row slots, every other pattern as a mask and values in the
 // dominant one's slots (spmv_csr_valuerecw_staged_kernel).  T: the pattern table (NP + 1 prefix entries, then element offsets), vals: NP x PATW_LEN
-// values (host).  Kept when one pattern carries at least half of the rows; never an error.
+// values (host; NULL for a plan whose values are streamed: masks and slots only, spmv_csr_pattern_rows_staged_kernel).  Kept when one pattern carries at
+// least half of the rows; never an error.
 static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, const double *vals, const int *ptr, hipStream_t st)
 {
     if (p->wdrec) { (void)hipFree(p->wdrec); p->wdrec = nullptr; }
@@ -3161,7 +3247,7 @@ static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, cons
         int q = 0;
         for (int a = 0; a < nruns; a++) if (od[j] >= start[a] && od[j] < start[a] + mlen[a]) q = a;
         D.slot[j] = base[q] + (od[j] - start[q]);
-        D.val[j] = vals[(size_t)dom * PATW_LEN + j];
+        D.val[j] = vals ? vals[(size_t)dom * PATW_LEN + j] : 0.0;
     }
     int *stage = (int *)calloc(WAVE * 8, sizeof(int));
     double *img = (double *)calloc((size_t)NP * WREC, sizeof(double));
@@ -3179,12 +3265,12 @@ static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, cons
             unsigned long long bits = 0;
             int j = 0;
             for (int sl = 0; sl < l && j < li; sl++)
-                if (oi[j] == od[sl]) { bits |= 1ull << sl; img[(size_t)i * WREC + sl] = vals[(size_t)i * PATW_LEN + j]; j++; }
+                if (oi[j] == od[sl]) { bits |= 1ull << sl; img[(size_t)i * WREC + sl] = vals ? vals[(size_t)i * PATW_LEN + j] : 0.0; j++; }
             if (j != li) bits = 1ull << 32;                   // not a subsequence of the dominant pattern: its rows walk their own record
             else {                                            // every kept slot carries the dominant pattern's value: the kernel leaves the values in scalar registers
                 bool same = true;
                 for (int sl = 0; sl < l; sl++) if ((bits >> sl) & 1ull) same = same && memcmp(&img[(size_t)i * WREC + sl], &D.val[sl], 8) == 0;
-                if (same) bits |= 1ull << 33;
+                if (same && vals) bits |= 1ull << 33;
             }
             memcpy(&img[(size_t)i * WREC + 32], &bits, 8);
         }
@@ -3500,14 +3586,24 @@ static void launch_team(const LaunchArgs &a, const double *guard)
     const liship_csr_plan_s *P = a.plan;
     const int rows = a.re - a.rb, wgs = (rows + 63) / 64;
     if (rows <= 0) return;
+    // (variant 0x8000: one lane per row, 64 rows per wavefront, values and x staged -- 3 % faster than four lanes per row on a repeated product, 3 % slower
+    //  inside the Krylov loops, where x is new every time and 8 wavefronts per CU hide less than 28: profiles/r03_pattern_team_kernel.txt; kept for A/B)
+    if (P->wdrec && P->wstage && P->wd.len > 0 && (g_variant & 0x8000) && !(g_variant & 0x4000)) {
+        const int maxl = P->tr.nruns > 0 ? P->tr.maxlen : TEAM_MAXLEN;                  // (the longest pattern, when build_team_runs recorded it)
+        const int vcap = WAVE * maxl + 2 + 32, xcap = (P->wd.slots + 1) & ~1, nl = (P->wd.slots + 2 * WAVE - 1) / (2 * WAVE);
+#define GOR(NL) spmv_csr_pattern_rows_staged_kernel<NL><<<(rows + WAVE - 1) / WAVE, WAVE, sizeof(double) * (size_t)(vcap + xcap), a.st>>>( \
+            a.ptr, a.val, a.rowpat, P->wdrec, P->wstage, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->wd, vcap, guard)
+        if (nl <= 2) GOR(2); else if (nl <= 3) GOR(3); else if (nl <= 5) GOR(5); else if (nl <= 6) GOR(6); else GOR(8);
+#undef GOR
+        return;
+    }
     if (P->prec_slot && P->tr.nruns > 0 && !(g_variant & 0x4000)) {
         const int vcap = 16 * P->tr.maxlen + 48, xcap = (P->tr.slots + 1) & ~1;
 #define GOT(NL, SR) spmv_csr_pattern_team_staged_kernel<256, NL, SR><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>( \
             a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard)
-        // (0x8000, measured and kept for A/B: pattern bytes and records by SCALAR loads, one round per distinct pattern in the wavefront -- two
+        // (measured and dropped, template argument SREC: pattern bytes and records by SCALAR loads, one round per distinct pattern in the wavefront -- two
         //  vector-memory instructions fewer and 5 % slower, 0.351 vs 0.332 ms: the scalar chain bytes -> readlane -> records sits in front of the slice)
-        if (g_variant & 0x8000) { if (P->tr.slots <= 2 * WAVE) GOT(1, true); else GOT(2, true); }
-        else if (P->tr.slots <= 2 * WAVE) GOT(1, false); else GOT(2, false);
+        if (P->tr.slots <= 2 * WAVE) GOT(1, false); else GOT(2, false);
 #undef GOT
     } else
         spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard);
@@ -3686,19 +3782,10 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
             w, partial, liship_internal_guard(), pstride);
         return;
     }
-    if (a.rowpat && a.vrecw && !(g_variant & 0x2000) && a.re > a.rb && launch_wide(a, liship_internal_guard())) {      // ... then the plan row blocks' sums (the bits of the epilogue below)
-        csr_block_dots_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(a.ptr, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.y, w, partial, liship_internal_guard(), pstride);
-        return;
-    }
     if (a.rowpat && a.vrecw && !(g_variant & 0x2000)) {
         spmv_csr_valuerecw_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(
             a.rowpat, a.vrecw, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
             w, partial, liship_internal_guard(), pstride);
-        return;
-    }
-    if (a.rowpat && a.plan && a.plan->prec36 && g_team && (g_variant & ~0x4000) == 0 && a.re > a.rb) {      // patterns of 8..32 offsets: four lanes per row, then the row blocks' sums
-        launch_team(a, liship_internal_guard());
-        csr_block_dots_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(a.ptr, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.y, w, partial, liship_internal_guard(), pstride);
         return;
     }
     if (a.rowpat && a.ptab_len <= PAT_TABLE) {
@@ -3765,6 +3852,18 @@ int launch_csr(liship_csr_plan_t p, const LaunchArgs &a0)
 
 } // namespace
 
+// Does the product of this plan run one of the kernels with a row split of their own (16 / 64 rows per wavefront: the team and staged kernels) under the
+// switches in force?  Their launches have no per-row-block epilogue: the fused entry points below refuse (LISHIP_ERR_ARG) and the caller runs the product
+// and one reduction pass -- measured FASTER than the product followed by a pass that rebuilt the row blocks' partial sums (BiCGSTAB at 160^3 2290 against
+// 2125 it/s, profiles/r03_pattern_team_kernel.txt).
+static bool plan_runs_teams(const liship_csr_plan_s *p)
+{
+    if (!p || !p->rowpat || !g_row_patterns || !g_index_codes || !g_team || p->ptab8) return false;
+    if (g_row_values && p->vrecw) return p->wdrec && p->wstage && p->wd.len > 0 && (g_variant & ~0x4000) == 0 && !(g_variant & 0x4000);
+    return p->prec36 != nullptr && (g_variant & ~0xc000) == 0;
+}
+extern "C" int liship_csr_plan_fused_dots(liship_csr_plan_t p) { return plan_runs_teams(p) ? 0 : 1; }
+
 extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const int *idx,
                                    const double *val, const double *x, double *y, void *stream)
 {
@@ -3782,6 +3881,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
                                        double *result, void *work, void *stream)
 {
     if (!p || !w || !result || !work) return LISHIP_ERR_ARG;
+    if (plan_runs_teams(p)) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x70006008) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
@@ -3826,6 +3926,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
                                             void *work, int slot_base, int *slots_used, void *stream)
 {
     if (!p || !w || !work || !slots_used || row_begin < 0 || row_end > p->n || slot_base < 0) return LISHIP_ERR_ARG;
+    if (plan_runs_teams(p)) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x70006008) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     *slots_used = 0;

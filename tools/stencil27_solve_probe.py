@@ -17,7 +17,7 @@ val = val * rng.uniform(0.5, 1.5, len(val))          # still diagonally dominant
 A = lisdrv.make_csr(lib, ptr, idx, val)
 bb = rng.uniform(-1, 1, n)
 for opts in ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi"):
-    for variant in (0, 0x2000, 0):
+    for variant in (0, 0x8000, 0x2000, 0, 0x8000):
         lib.liship_spmv_csr_set_variant(variant)
         out = lisdrv.solve(lib, A, bb, opts + " -maxiter 200 -tol 1e-30")
         print(f"{opts}: variant {variant:#x}: {out['iter']} iterations, {out['iter'] / out['itime']:.1f} it/s, residual {out['resid']:.3e}", flush=True)

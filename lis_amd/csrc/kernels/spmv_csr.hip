@@ -1086,7 +1086,7 @@ void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__r
 // stencil) read the same slots by their own records; rows with a foreign pattern gather for themselves.  Speculative addresses are clamped
 // to [0, largest column].  Values, products, the chain through ds_bpermute: as above -- same terms, same order, the reference's bits.
 struct TeamRuns { int nruns, slots, maxcol, maxlen; int start[16], base[16]; };     // run a: columns r0 + start[a] + position, slots base[a] .. base[a + 1])
-template <int BLOCK, int NLOAD, bool SREC>
+template <int BLOCK, int NLOAD>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
                                          const v4i32 *__restrict__ prec, const v4i32 *__restrict__ pslot, const double *__restrict__ x,
@@ -1104,12 +1104,8 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     const int r = min(r0 + i, r1 - 1);
     const bool live = r0 + i < r1;
     const int k0 = ptr[r0], k1 = ptr[r1];
-    // the 16 pattern bytes of the wavefront's rows by SCALAR loads (20 bytes from the dword below r0: a row range may start anywhere; the array has
-    // 64 bytes of slack): no vector-memory instruction, and a wavefront whose rows share one pattern takes its records by scalar loads too
-    const int *pw = reinterpret_cast<const int *>(rowpat + (r0 & ~3));
-    int pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0, pb4 = 0, patv = 0;
-    if (SREC) { pb0 = pw[0]; pb1 = pw[1]; pb2 = pw[2]; pb3 = pw[3]; pb4 = pw[4]; } else patv = rowpat[r];
-    __builtin_amdgcn_sched_barrier(0);                            // (the scalar loads leave first)
+    const int pat = rowpat[r];
+    __builtin_amdgcn_sched_barrier(0);                            // (the scalar loads and the pattern byte leave first)
     // the staged x: slot sl = base[run] + position holds column r0 + start[run] + position.  A lane takes TWO neighbouring slots with one
     // 16 B load (every run's width is even: a pair never straddles two runs; the address is a double's: v2f64u); a pair pushed inside the array by the
     // clamp at either end hands each slot the half that holds its column (the other slot of such a pair belongs to no stored entry)
@@ -1130,28 +1126,10 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     int np = (cnt + 1) >> 1;
     const bool odd_end = ka + 2 * np > nnz_total;
     if (odd_end) np--;
-    int pat = patv;
-    if (SREC) {
-        const int bi = (r0 & 3) + (live ? i : 0), dw = bi >> 2;   // (lanes beyond the last row take the first row's pattern)
-        int word = pb0;
-        word = dw == 1 ? pb1 : word; word = dw == 2 ? pb2 : word; word = dw == 3 ? pb3 : word; word = dw == 4 ? pb4 : word;
-        pat = (word >> (8 * (bi & 3))) & 255;
-    }
-    // this lane's record -- eight slots (bytes), the row's length, whether its pattern is foreign to the runs -- by SCALAR loads, one round per distinct
-    // pattern among the wavefront's rows (one, nearly always; a vector load here would sit between the staged x and the slice in the in-order counter)
-    v4i32 rs = {0, 0, 0, 0};
-    bool have = false;
-    if (!SREC) { rs = pslot[pat * 4 + t]; have = true; }
-    for (;;) {
-        const unsigned long long need = __ballot(!have);
-        if (need == 0) break;
-        const int pcur = __builtin_amdgcn_readlane(pat, __ffsll((long long)need) - 1);
-        const v4i32 *q = pslot + pcur * 4;
-        const v4i32 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-        v4i32 cand = q0;
-        cand = t == 1 ? q1 : cand; cand = t == 2 ? q2 : cand; cand = t == 3 ? q3 : cand;
-        if (!have && pat == pcur) { rs = cand; have = true; }
-    }
+    // this lane's record: eight slots (bytes), the row's length, whether its pattern is foreign to the runs -- one 16 B load, issued AHEAD of the slice (the
+    // vector-memory counter counts in order).  (Measured and dropped: pattern bytes and records by scalar loads, one round per distinct pattern in the
+    // wavefront -- two vector-memory instructions fewer and 5 % slower, 0.351 against 0.332 ms: the scalar chain sits in front of the slice.)
+    const v4i32 rs = pslot[pat * 4 + t];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int it = 0; it < (RPW * TEAM_MAXLEN / 2 + WAVE) / WAVE; it++) {
@@ -1163,7 +1141,7 @@ void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const doub
     }
     if (odd_end && lane == 0) valL[cnt - 1] = val[k1 - 1];
     __builtin_amdgcn_sched_barrier(0);                            // (nothing that needs the record may move in between the slice's loads)
-    if (!SREC) asm volatile("" :: "v"(rs.w));                     // (the record's unused word stays allocated: reusing its register while the load is in flight would wait for ALL loads)
+    asm volatile("" :: "v"(rs.w));                                 // (the record's unused word stays allocated: reusing its register while the load is in flight would wait for ALL loads)
     const int len = live ? (rs.z & 255) : 0;
     double xx[TEAM_SEG];
     const bool foreign = ((rs.z >> 8) & 255) != 0;
@@ -3599,11 +3577,9 @@ static void launch_team(const LaunchArgs &a, const double *guard)
     }
     if (P->prec_slot && P->tr.nruns > 0 && !(g_variant & 0x4000)) {
         const int vcap = 16 * P->tr.maxlen + 48, xcap = (P->tr.slots + 1) & ~1;
-#define GOT(NL, SR) spmv_csr_pattern_team_staged_kernel<256, NL, SR><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>( \
+#define GOT(NL) spmv_csr_pattern_team_staged_kernel<256, NL><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>( \
             a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard)
-        // (measured and dropped, template argument SREC: pattern bytes and records by SCALAR loads, one round per distinct pattern in the wavefront -- two
-        //  vector-memory instructions fewer and 5 % slower, 0.351 vs 0.332 ms: the scalar chain bytes -> readlane -> records sits in front of the slice)
-        if (P->tr.slots <= 2 * WAVE) GOT(1, false); else GOT(2, false);
+        if (P->tr.slots <= 2 * WAVE) GOT(1); else GOT(2);
 #undef GOT
     } else
         spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard);

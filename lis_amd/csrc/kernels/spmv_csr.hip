@@ -2149,11 +2149,12 @@ void spmv_csr_valuerecw_kernel(const unsigned char *__restrict__ rowpat, const v
 // foreign rows walk their own record.  Same products in the same order -- masked slots add -0.0 -- so y is the reference's, bit for bit.
 struct WideDom { int len, pat, slots, maxcol; int slot[PATW_LEN]; double val[PATW_LEN]; };
 constexpr int WREC = 40;                                   // doubles per pattern in wdrec: 32 values in the dominant pattern's slots, [32] = mask | foreign << 32
-template <int BLOCK, int NL, int CH>
+template <int BLOCK, int NL, int CH, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, const double *__restrict__ wdrec, const v4i32 *__restrict__ wstage,
                                       const v4i32 *__restrict__ rec, int npat, const double *__restrict__ x, double *__restrict__ y, Rows RW,
-                                      const WideDom D, int xcap, const double *__restrict__ guard = nullptr)
+                                      const WideDom D, int xcap, const double *__restrict__ guard = nullptr,
+                                      const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr, int pstride = 0)
 {
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
     extern __shared__ __attribute__((aligned(16))) double wide_dyn[];
@@ -2162,14 +2163,18 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
     // a wavefront walks CH consecutive chunks of 64 rows: the staging loads and the pattern byte of the NEXT chunk are issued before the products of the
     // one in hand are formed, so that a round trip hides behind the arithmetic (and the offset table is read once)
     const int rbase = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * (CH * WAVE);
-    if (rbase >= RW.re) return;
+    if (DOT == 0 && rbase >= RW.re) return;
+    double c0 = 0.0, c1 = 0.0;                                     // (DOT) this lane's <w, y> and <y, y>: one partial per workgroup, folded by the caller
+    if (rbase < RW.re) {
     const v4i32 so0 = wstage[2 * lane], so1 = wstage[2 * lane + 1];      // the column offsets of this lane's slot pairs, load by load
     const int so[8] = {so0.x, so0.y, so0.z, so0.w, so1.x, so1.y, so1.z, so1.w};
     const double *xr = xL + lane;
     v2f64 xs[NL];
     int patn;
+    double wn = 0.0;
     auto prefetch = [&](int r0) {
         patn = rowpat[min(r0 + lane, RW.re - 1)];
+        if (DOT != 0) wn = wdot[min(r0 + lane, RW.re - 1)];
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             const int c = r0 + so[k], cc = min(max(c, 0), D.maxcol - 1);
@@ -2190,6 +2195,7 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
 #pragma unroll
         for (int k = 0; k < NL; k++) { const int sl = 2 * (k * WAVE + lane); if (sl < D.slots) *reinterpret_cast<v2f64 *>(xL + sl) = xs[k]; }
         const int pat = patn;
+        const double wv = wn;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2251,6 +2257,16 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
             }
         }
         if (live) store_stream(y + r, acc);
+        if (DOT >= 1 && live) c0 += wv * acc;
+        if (DOT >= 2 && live) c1 += acc * acc;
+    }
+    }
+    if (DOT != 0) {
+        __shared__ double dot_scratch[BLOCK / WAVE];
+        const int stride = pstride ? pstride : (int)gridDim.x;
+        const double t0 = block_sum<BLOCK / WAVE>(c0, dot_scratch);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t0;
+        if (DOT >= 2) { const double t1 = block_sum<BLOCK / WAVE>(c1, dot_scratch); if (threadIdx.x == 0) partial[stride + blockIdx.x] = t1; }
     }
 }
 
@@ -3542,17 +3558,20 @@ void launch_products(int grid, const LaunchArgs &a)
 
 // rows of up to 32 entries whose values ride in wide records: x staged per wavefront, the dominant pattern in scalar registers (variant 0x4000: the
 // gathering kernel on plan row blocks, A/B)
-static bool launch_wide(const LaunchArgs &a, const double *guard)
+static bool launch_wide(const LaunchArgs &a, const double *guard, int dot = 0, const double *w = nullptr, double *partial = nullptr, int pstride = 0, int *wgs_out = nullptr)
 {
     const liship_csr_plan_s *P = a.plan;
     if (!P || !P->wdrec || !P->wstage || P->wd.len <= 0 || !g_team || (g_variant & 0x4000)) return false;
     constexpr int CH = 1;                            // chunks of 64 rows per wavefront
     const int rows = a.re - a.rb, wgs = (rows + 256 * CH - 1) / (256 * CH);
+    if (wgs_out) *wgs_out = rows > 0 ? wgs : 0;
     if (rows <= 0) return true;
     const int xcap = (P->wd.slots + 1) & ~1, nl = (P->wd.slots + 2 * WAVE - 1) / (2 * WAVE);
-#define GOW(NL) spmv_csr_valuerecw_staged_kernel<256, NL, CH><<<wgs, 256, sizeof(double) * 4 * (size_t)xcap, a.st>>>( \
-        a.rowpat, P->wdrec, P->wstage, a.vrecw, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0}, P->wd, xcap, guard)
-    if (nl <= 2) GOW(2); else if (nl <= 3) GOW(3); else if (nl <= 5) GOW(5); else if (nl <= 6) GOW(6); else GOW(8);
+#define GOW(NL, DT) spmv_csr_valuerecw_staged_kernel<256, NL, CH, DT><<<wgs, 256, sizeof(double) * 4 * (size_t)xcap, a.st>>>( \
+        a.rowpat, P->wdrec, P->wstage, a.vrecw, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0}, P->wd, xcap, guard, w, partial, pstride)
+#define GOWD(DT) do { if (nl <= 2) GOW(2, DT); else if (nl <= 3) GOW(3, DT); else if (nl <= 5) GOW(5, DT); else if (nl <= 6) GOW(6, DT); else GOW(8, DT); } while (0)
+    if (dot == 0) GOWD(0); else if (dot == 1) GOWD(1); else GOWD(2);
+#undef GOWD
 #undef GOW
     return true;
 }
@@ -3832,10 +3851,14 @@ int launch_csr(liship_csr_plan_t p, const LaunchArgs &a0)
 // switches in force?  Their launches have no per-row-block epilogue: the fused entry points below refuse (LISHIP_ERR_ARG) and the caller runs the product
 // and one reduction pass -- measured FASTER than the product followed by a pass that rebuilt the row blocks' partial sums (BiCGSTAB at 160^3 2290 against
 // 2125 it/s, profiles/r03_pattern_team_kernel.txt).
-static bool plan_runs_teams(const liship_csr_plan_s *p)
+static bool plan_runs_wide(const liship_csr_plan_s *p)      // the staged wide-record kernel: it has an epilogue of its own (one partial per workgroup of 256 rows)
+{
+    return p && p->rowpat && g_row_patterns && g_index_codes && g_team && !p->ptab8 && g_row_values && p->vrecw && p->wdrec && p->wstage && p->wd.len > 0 && g_variant == 0;
+}
+static bool plan_runs_teams(const liship_csr_plan_s *p)     // the four-lanes-per-row kernels (values streamed): no epilogue
 {
     if (!p || !p->rowpat || !g_row_patterns || !g_index_codes || !g_team || p->ptab8) return false;
-    if (g_row_values && p->vrecw) return p->wdrec && p->wstage && p->wd.len > 0 && (g_variant & ~0x4000) == 0 && !(g_variant & 0x4000);
+    if (g_row_values && p->vrecw) return false;
     return p->prec36 != nullptr && (g_variant & ~0xc000) == 0;
 }
 extern "C" int liship_csr_plan_fused_dots(liship_csr_plan_t p) { return plan_runs_teams(p) ? 0 : 1; }
@@ -3861,6 +3884,14 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x70006008) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
+    if (plan_runs_wide(p) && p->n > 0 && (size_t)((p->n + 255) / 256) <= slots) {       // wide records, x staged: a partial per workgroup of 256 rows
+        LaunchArgs aw{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), p->codes, p->dict, nullptr, nullptr, nullptr, p->first_term ? -0.0 : 0.0, p->rowpat, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, nullptr, nullptr, nullptr, p->vrecw};
+        aw.plan = p;
+        int wgs = 0;
+        launch_wide(aw, liship_internal_guard(), want_sumsq ? 2 : 1, w, partial, 0, &wgs);
+        LAUNCH_CHECK();
+        return liship_internal_fold(wgs, want_sumsq ? 2 : 1, wgs, partial, spare, result, stream);
+    }
     LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order, g_row_values ? p->vrecw : nullptr};
     a.plan = p;
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
@@ -3907,6 +3938,16 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if ((g_variant & ~0x70006008) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     *slots_used = 0;
     if (row_begin >= row_end || p->nblocks == 0) return 0;
+    if (plan_runs_wide(p)) {                           // wide records, x staged: a partial per workgroup of 256 rows of the range
+        const int wgs = (row_end - row_begin + 255) / 256;
+        if ((size_t)slot_base + (size_t)wgs > slots) return LISHIP_ERR_ARG;
+        LaunchArgs aw{ptr, idx, val, x, y, p->blk, 0, p->nblocks, row_begin, row_end, (int)p->nnz, as_stream(stream), p->codes, p->dict, nullptr, nullptr, nullptr, p->first_term ? -0.0 : 0.0, p->rowpat, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, nullptr, nullptr, nullptr, p->vrecw};
+        aw.plan = p;
+        launch_wide(aw, liship_internal_guard(), want_sumsq ? 2 : 1, w, static_cast<double *>(work) + slot_base, (int)slots);
+        LAUNCH_CHECK();
+        *slots_used = wgs;
+        return 0;
+    }
     const v2i32 *br = p->blk_host;
     int lo = 0, hi = p->nblocks;                 // first b with br[b+1].row > row_begin
     while (lo < hi) { int mid = (lo + hi) / 2; if (br[mid + 1].x > row_begin) hi = mid; else lo = mid + 1; }

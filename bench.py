@@ -54,6 +54,7 @@ def parse():
                     help="N > 1: weak = 512^3 rows per GPU (grid 512 x 512 x 512 N), strong = the one 512^3 grid split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solvers", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 27-point stencil legs (rank 0, N = 1 only; about 10 s)")
     return ap.parse_args()
 
 
@@ -383,6 +384,10 @@ def main():
             finally:
                 check(lib.liship_spmv_csr_set_row_values(1))
 
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = stencil27_leg(lib, np, C, stream)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(np)
@@ -407,6 +412,7 @@ def main():
             "rccl_ranks": world if (world > 1 and comm_used == "rccl" and int(dll.lis_amd_comm_kind()) == 1) else (0 if world > 1 else None),
             "multi_gpu": multi,
             "krylov": solvers,
+            "stencil27": extras,              # beside the headline: the 27-point stencil (spmvtest3b / HPCG) through the round-3 kernels; not part of `value`
             "cpu_baseline": cpu,
         }
         assert_fracs_physical(out)
@@ -417,6 +423,59 @@ def main():
         dist.destroy_process_group()
     if degraded:
         sys.exit(3)                   # the line above says "degraded": true; a driver that only looks at the exit code sees it too
+
+
+def stencil27_leg(lib, np, C, stream, G=160, launches=30):
+    """Beside the headline matrix: the 27-point stencil at G^3 through the same plan API the library uses, with constant coefficients (26 / -1: the matrix of the
+    reference's spmvtest3b and of HPCG -- wide value records, x staged per wavefront, the dominant pattern in scalar registers) and with every row's values its
+    own (8 B per non-zero streamed, four lanes per row).  HIP-event ms per launch; never fatal: None when anything goes wrong."""
+    try:
+        from lis_amd import DeviceArray as DA, check
+        n = G ** 3
+        z, y, x = np.meshgrid(np.arange(G, dtype=np.int32), np.arange(G, dtype=np.int32), np.arange(G, dtype=np.int32), indexing="ij")
+        z, y, x = z.ravel(), y.ravel(), x.ravel()
+        d = np.array([-1, 0, 1], np.int32)
+        inz, iny, inx = ((c[:, None] + d >= 0) & (c[:, None] + d < G) for c in (z, y, x))
+        mask = (inz[:, :, None, None] & iny[:, None, :, None] & inx[:, None, None, :]).reshape(n, 27)
+        offs = ((d[:, None, None] * G + d[None, :, None]) * G + d[None, None, :]).reshape(27)
+        cols = np.arange(n, dtype=np.int32)[:, None] + offs[None, :]
+        idx = cols[mask]                                               # row by row, ascending columns
+        ptr = np.zeros(n + 1, np.int32)
+        np.cumsum(mask.sum(axis=1), out=ptr[1:])
+        const = np.where(offs == 0, 26.0, -1.0)
+        val_c = np.broadcast_to(const, (n, 27))[mask]
+        nnz = len(idx)
+        del mask, cols, inz, iny, inx
+        dptr, didx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32)
+        xv, yv = DA.from_host(np.modf(np.arange(n, dtype=np.float64) * 0.6180339887498949)[0] - 0.5, np.float64), DA(n, np.float64)
+        timer, ev = C.c_void_p(), C.c_float()
+        check(lib.liship_timer_create(C.byref(timer)))
+        out = {"grid": f"{G}^3", "n": n, "nnz": int(nnz), "launches": launches, "x": "x_i = frac(i * 0.618...) - 0.5"}
+        for key, values in (("constant_coefficients", val_c), ("varying_coefficients", val_c * np.random.default_rng(7).uniform(0.5, 1.5, nnz))):
+            dval = DA.from_host(values, np.float64)
+            plan = C.c_void_p()
+            check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, stream))
+            check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, stream))
+            check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, stream))
+            check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, stream))
+            for _ in range(10):
+                check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, xv.ptr, yv.ptr, stream))
+            check(lib.liship_timer_start(timer, stream))
+            for _ in range(launches):
+                check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, xv.ptr, yv.ptr, stream))
+            check(lib.liship_timer_stop(timer, stream))
+            check(lib.liship_stream_synchronize(stream))
+            check(lib.liship_timer_elapsed_ms(timer, C.byref(ev)))
+            ms = ev.value / launches
+            wide = int(lib.liship_csr_plan_wide_dominant(plan))
+            stored = 17 * n if wide else 8 * nnz + 17 * n          # one pattern byte, y, the compulsory x per row (+ the streamed values)
+            out[key] = {"kernel_ms": round(ms, 4), "gflops": round(2e-6 * nnz / ms, 1), "stored_bytes_per_launch": int(stored),
+                        "frac": round(stored / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "kernel": "spmv_csr_valuerecw_staged_kernel" if wide else ("spmv_csr_pattern_team_staged_kernel" if int(lib.liship_csr_plan_team_form(plan)) == 2 else "other")}
+            check(lib.liship_csr_plan_destroy(plan))
+        return out
+    except Exception as exc:                                          # an extra: its failure must not cost the line
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def assert_fracs_physical(node, path="line"):

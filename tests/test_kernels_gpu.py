@@ -93,6 +93,58 @@ def test_spmv_csr_special_values(lib):
     assert np.array_equal(y.view(np.uint64), ref.view(np.uint64))
 
 
+@pytest.mark.parametrize("kind", ["box27_constant", "box27_varying", "p3d_constant", "ell_padded_rows"])
+def test_special_values_through_the_planned_kernels(lib, kind):
+    """signed zeros, infinities and NaN in x (and -0.0 / 0.0 among the values) through the kernels the plan chooses -- the staged wide-record kernel, four lanes
+    per row with x staged, the dominant-pattern value-record kernel, and the dominant pattern's padded rows (an ELL row form: trailing (row, +0.0) entries,
+    where 0.0 * inf must stay NaN) -- uint64-equal to the reference loop, masked -0.0 terms and speculative loads included"""
+    if kind.startswith("box27"):
+        ptr, idx, val = stencil_box((14, 12, 20))
+        if kind == "box27_varying":
+            val = val * np.random.default_rng(4).uniform(0.5, 1.5, len(val))
+            val[::17] = -0.0
+    elif kind == "p3d_constant":
+        ptr, idx, val = orc.poisson3d(8, 8, 256, sort_cols=True)
+    else:                                                   # every row padded to 7 entries with (row, +0.0) behind its own, as lis_matrix_convert_csr2ell lays them out
+        p0, i0, v0 = orc.poisson3d(8, 8, 256, sort_cols=True)
+        n0 = len(p0) - 1
+        ptr = np.arange(0, 7 * n0 + 1, 7, dtype=np.int32)
+        idx, val = np.empty(7 * n0, np.int32), np.zeros(7 * n0)
+        for r in range(n0):
+            k = p0[r + 1] - p0[r]
+            idx[7 * r:7 * r + k], val[7 * r:7 * r + k] = i0[p0[r]:p0[r + 1]], v0[p0[r]:p0[r + 1]]
+            idx[7 * r + k:7 * r + 7] = r
+    n = len(ptr) - 1
+    x = np.random.default_rng(2).uniform(-1, 1, n)
+    x[::7] = 0.0
+    x[3::11] = -0.0
+    for pos, v in ((0, np.inf), (n - 1, -np.inf), (n // 2, np.nan), (n // 3, np.inf), (257, np.nan), (5, -np.inf)):
+        x[pos] = v
+    ref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval, dx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    if kind == "box27_constant":
+        assert lib.liship_csr_plan_wide_dominant(plan) == 1
+    if kind == "box27_varying":
+        assert lib.liship_csr_plan_team_form(plan) == 2
+    if kind in ("p3d_constant", "ell_padded_rows"):
+        assert lib.liship_csr_plan_dominant_pattern(plan) == 1
+    nanpos = np.isnan(ref)
+    for variant in (0, 0x4000, 0x8000, 0x2000, 0x20000000):
+        lib.liship_spmv_csr_set_variant(variant)
+        dy = DA.from_host(np.full(n, 7.0), np.float64)
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        y = dy.to_host()
+        assert np.array_equal(np.isnan(y), nanpos), hex(variant)                      # (a NaN's payload is the hardware's: positions, and every other bit)
+        assert np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), hex(variant)
+    lib.liship_spmv_csr_set_variant(0)
+    check(lib.liship_csr_plan_destroy(plan))
+
+
 def test_spmv_csr_row_range(lib):
     ptr, idx, val = orc.poisson3d(12, 12, 12)
     n = len(ptr) - 1

@@ -1454,6 +1454,73 @@ def _structured_random(seed):
     return np.array(ptr, np.int32), np.array(idx, np.int32), np.array(val, np.float64), ncols
 
 
+def _stencil_random(seed):
+    """a random stencil on a random small grid -- a subset of the 27 box offsets (so that runs of 1, 2 and 3 neighbouring columns occur) plus, sometimes, far
+    offsets; Dirichlet truncation; values constant per offset, per row, or constant with a few rows of their own; a few rows moved off the pattern"""
+    rng = np.random.default_rng(seed)
+    dims = tuple(int(v) for v in rng.choice([1, 3, 5, 8, 13, 21, 34, 70], 3))
+    if dims[0] * dims[1] * dims[2] < 600:
+        dims = (dims[0] + 7, dims[1] + 9, dims[2] + 17)
+    pts = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) == (0, 0, 0) or rng.random() < rng.choice([0.45, 0.8, 1.0])]
+    if rng.random() < 0.3:
+        pts += [(0, 0, int(k)) for k in rng.choice([-4, -3, 3, 4, 6], 2, replace=False)]
+    ptr, idx, val = stencil_points(dims, sorted(set(pts)), seed)
+    n = len(ptr) - 1
+    mode = rng.choice(["constant", "random", "mostly_constant"])
+    if mode != "random":
+        offs = idx - np.repeat(np.arange(n), np.diff(ptr))
+        palette = {int(o): float(v) for o, v in zip(np.unique(offs), rng.choice([-1.0, 26.0, 0.5, -0.0, 0.0, 3.25], len(np.unique(offs))))}
+        cval = np.array([palette[int(o)] for o in offs])
+        if mode == "mostly_constant":
+            rows = rng.choice(n, max(1, n // 50), replace=False)
+            for r in rows:
+                cval[ptr[r]:ptr[r + 1]] = rng.uniform(-2, 2, ptr[r + 1] - ptr[r])
+        val = cval
+    if rng.random() < 0.4:                                  # rows off the pattern: the last entry moves
+        for r in rng.choice(n, max(1, n // 40), replace=False):
+            if ptr[r + 1] > ptr[r]:
+                k = ptr[r + 1] - 1
+                idx[k] = min(n - 1, idx[k] + int(rng.integers(2, 9)))
+                order = np.argsort(idx[ptr[r]:ptr[r + 1]], kind="stable")
+                idx[ptr[r]:ptr[r + 1]] = idx[ptr[r]:ptr[r + 1]][order]
+                val[ptr[r]:ptr[r + 1]] = val[ptr[r]:ptr[r + 1]][order]
+    return ptr, idx.astype(np.int32), np.asarray(val, np.float64)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LIS_AMD_FUZZ_SEEDS", "60"))))
+def test_team_and_staged_kernels_on_random_stencils(lib, seed):
+    """random stencils on random grids through whatever the plan builds for them -- team records, runs and slots, wide records with a dominant pattern, masks,
+    foreign rows -- in every form of the product (x staged / gathered / a lane per row / round 2's kernels), whole and in row ranges: the oracle's bits"""
+    ptr, idx, val = _stencil_random(seed)
+    n = len(ptr) - 1
+    x = np.random.default_rng(2000 + seed).uniform(-1, 1, n)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval, dx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    state = (lib.liship_csr_plan_row_patterns(plan), lib.liship_csr_plan_team_form(plan), lib.liship_csr_plan_value_records(plan), lib.liship_csr_plan_wide_dominant(plan))
+    try:
+        for values_on in (1, 0):
+            lib.liship_spmv_csr_set_row_values(values_on)
+            for variant in (0, 0x4000, 0x8000, 0x2000):
+                lib.liship_spmv_csr_set_variant(variant)
+                dy = DA.from_host(np.full(n, np.nan), np.float64)
+                check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+                assert np.array_equal(dy.to_host().view(np.uint64), yref.view(np.uint64)), (seed, state, values_on, hex(variant))
+                a, b = n // 3 + 1, n - n // 5 - 3
+                dy = DA.from_host(np.full(n, np.nan), np.float64)
+                for lo, hi in ((a, b), (0, a), (b, n)):
+                    check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+                assert np.array_equal(dy.to_host().view(np.uint64), yref.view(np.uint64)), (seed, state, "rows", values_on, hex(variant))
+    finally:
+        lib.liship_spmv_csr_set_row_values(1)
+        lib.liship_spmv_csr_set_variant(0)
+        check(lib.liship_csr_plan_destroy(plan))
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LIS_AMD_FUZZ_SEEDS", "60"))))      # more seeds: LIS_AMD_FUZZ_SEEDS=1000
 def test_plan_coders_on_random_structured_matrices(lib, seed):
     """whatever the plan decides to keep -- codes, row patterns, 32 B records, value records (refined or not) -- every form of the

@@ -1,5 +1,7 @@
-import sys, ctypes as C, collections
-sys.path[:0] = ["/root/repo", "/root/repo/tests"]
+"""what the plans choose for the random stencils of tests/test_kernels_gpu.py::_stencil_random (300 seeds): python tools/fuzz_stats.py"""
+import sys, os, ctypes as C, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np, lis_amd
 from lis_amd import DeviceArray as DA, check
 import test_kernels_gpu as T

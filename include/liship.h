@@ -217,6 +217,9 @@ int  liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, const int *b
  * per block row (short block rows) and a lane per block (long ones) */
 int  liship_spmv_bsr_nnz_f64(int nr, int bnnz, int bnr, int bnc, const int *bptr, const int *bindex,
                              const double *value, const double *x, double *y, void *stream);
+/* block rows [brb, bre) only (the array layout is that of all nr block rows): the parts of a multi-rank product around its halo exchange -- same bits */
+int  liship_spmv_bsr_rows_f64(int nr, int bnnz, int bnr, int bnc, const int *bptr, const int *bindex, const double *value,
+                              const double *x, double *y, int brb, int bre, void *stream);
 /* A/B switch: 0 keeps square blocks with long block rows (mean > 12 / 16 / 12 stored blocks per block row at 2x2 / 3x3 / 4x4) on the two-phase tile
  * kernels instead of the team-per-block-row kernel (spmv_bsr_team_kernel); same bits either way. */
 int  liship_spmv_bsr_set_team(int on);

@@ -363,7 +363,7 @@ static void find_inner_rows(LIS_MATRIX A, int *b, int *e)
 {
 	const int n = A->n;
 	*b = 0; *e = 0;
-	if (A->np == n) { *e = n; return; }                               /* no ghost columns at all */
+	if (A->np == n) { *e = A->matrix_type == LIS_MATRIX_BSR ? A->nr : n; return; }       /* no ghost columns at all (BSR counts block rows) */
 	if (A->is_splited || n <= 0) return;
 	unsigned char *ghost = (unsigned char *)calloc((size_t)n + 1, 1);
 	if (!ghost) return;                                               /* (no overlap then: exchange first) */
@@ -394,6 +394,19 @@ static void find_inner_rows(LIS_MATRIX A, int *b, int *e)
 		for (int j = 0; j < A->maxnzr; j++)
 			for (int sl = 0; sl < A->ptr[j + 1] - A->ptr[j]; sl++) if (A->index[A->ptr[j] + sl] >= n) ghost[A->row[sl]] = 1;
 		break;
+	case LIS_MATRIX_BSR: {                                            /* in BLOCK rows: ghost columns start on a fresh block column (lis_matrix_bsr.c:425-428) */
+		if (!A->bptr) { free(ghost); return; }
+		const int first_ghost = (n + A->bnc - 1) / A->bnc;
+		for (int br = 0; br < A->nr; br++)
+			for (int k = A->bptr[br]; k < A->bptr[br + 1]; k++) if (A->bindex[k] >= first_ghost) { ghost[br] = 1; break; }
+		ghost[A->nr] = 1;
+		int bb = 0, be = 0, rb = 0;
+		for (int r = 0; r <= A->nr; r++)
+			if (ghost[r]) { if (r - rb > be - bb) { bb = rb; be = r; } rb = r + 1; }
+		free(ghost);
+		*b = bb; *e = be;
+		return;
+	}
 	default:
 		free(ghost);
 		return;
@@ -980,6 +993,15 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 			if (d->type == LIS_MATRIX_ELL) HIPCHK(liship_spmv_ell_rows_f64(d->n, d->maxnzr, d->index, d->ell_codes, d->ell_dict, d->value, dx, dy, rb, re, lisg.stream));
 			else HIPCHK(liship_spmv_dia_rows_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, rb, re, lisg.stream));
 		}
+		return LIS_SUCCESS;
+	}
+	if (lisg.nprocs > 1 && A->commtable && d->type == LIS_MATRIX_BSR && !lisg.no_overlap && d->inner_end - d->inner_begin >= d->nr / 2) {
+		/* BSR likewise, in block rows (inner_begin / inner_end count block rows for this format) */
+		LISCHK(lisc_halo_begin(A, dx));
+		HIPCHK(liship_spmv_bsr_rows_f64(d->nr, A->bnnz, d->bnr, d->bnc, d->bptr, d->bindex, d->value, dx, dy, d->inner_begin, d->inner_end, lisg.stream));
+		LISCHK(lisc_halo_end(A, dx));
+		HIPCHK(liship_spmv_bsr_rows_f64(d->nr, A->bnnz, d->bnr, d->bnc, d->bptr, d->bindex, d->value, dx, dy, 0, d->inner_begin, lisg.stream));
+		HIPCHK(liship_spmv_bsr_rows_f64(d->nr, A->bnnz, d->bnr, d->bnc, d->bptr, d->bindex, d->value, dx, dy, d->inner_end, d->nr, lisg.stream));
 		return LIS_SUCCESS;
 	}
 	if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));

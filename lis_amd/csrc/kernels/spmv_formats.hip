@@ -867,6 +867,19 @@ extern "C" int liship_spmv_jad_f64(int n, int maxnzr, const int *perm, const int
     return 0;
 }
 
+// Block rows [brb, bre) only: a multi-rank product runs the block rows that reference no ghost block column while the halo is in flight and the boundary block
+// rows after it.  A block-row range of a BSR matrix IS a BSR matrix -- bptr + brb still indexes the whole bindex / value arrays, y moves by brb * bnr -- so
+// the kernels above serve it unchanged (the same kind of kernel as the whole matrix takes: the mean block-row length is the matrix's); rows are independent,
+// so the parts write the bits of the whole launch.
+extern "C" int liship_spmv_bsr_rows_f64(int nr, int bnnz, int bnr, int bnc, const int *bptr, const int *bidx, const double *val,
+                                        const double *x, double *y, int brb, int bre, void *stream)
+{
+    if (nr < 0 || bnr < 1 || bnc < 1 || brb < 0 || bre > nr) return LISHIP_ERR_ARG;
+    if (brb >= bre) return 0;
+    const long long part = nr > 0 && bnnz >= 0 ? (long long)bnnz * (bre - brb) / nr : -1;
+    return liship_spmv_bsr_nnz_f64(bre - brb, (int)part, bnr, bnc, bptr + brb, bidx, val, x, y + (size_t)brb * bnr, stream);
+}
+
 extern "C" int liship_spmv_bsr_set_team(int on) { g_bsr_team = on; return 0; }
 
 extern "C" int liship_spmv_bsr_f64(int nr, int bnr, int bnc, const int *bptr, const int *bidx,

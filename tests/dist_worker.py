@@ -269,6 +269,13 @@ def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
         assert np.all(np.abs(y - yg[is_:ie]) <= 1e-13 * scale_y), (name, fmt)
         if fmt in ("ell", "jad"):
             assert np.array_equal(y, yg[is_:ie]), (name, fmt)
+        if fmt == "bsr":                                               # the block rows without ghost blocks under the halo, the others behind it: the bits of exchange-first
+            y_overlapped = y.copy()
+            lib.dll.lis_amd_set_overlap(0)
+            assert lib.lis_matvec(B, vb2, vy2) == 0, (name, fmt)
+            lib.dll.lis_amd_set_overlap(1)
+            assert lib.lis_vector_get_values(vy2, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
+            assert np.array_equal(y, y_overlapped), (name, fmt, "overlap")
         lib.lis_vector_destroy(vb2); lib.lis_vector_destroy(vy2); lib.lis_matrix_destroy(B)
     if name.startswith("poisson"):
         bg = orc.spmv_csr(ptr, idx, val, np.ones(gn))

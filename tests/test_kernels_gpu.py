@@ -751,6 +751,16 @@ def test_spmv_bsr_square_blocks(lib, name, bs):
     lib.liship_spmv_bsr_set_team(1)
     check(lib.liship_spmv_bsr_f64(nr, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, None))
     assert np.array_equal(dy.to_host(n), ref)
+    # block-row ranges (the parts of a multi-rank product around its halo exchange): the bits of the whole launch, wherever the cuts fall
+    for team in (1, 0):
+        lib.liship_spmv_bsr_set_team(team)
+        for known in (len(bidx), 1 << 30):
+            dy = DA.from_host(np.full(nr * bs, np.nan))
+            cuts = [0, nr // 3, nr - nr // 4, nr]
+            for lo, hi in ((cuts[1], cuts[2]), (cuts[0], cuts[1]), (cuts[2], cuts[3])):
+                check(lib.liship_spmv_bsr_rows_f64(nr, known, bs, bs, a.ptr, b.ptr, c.ptr, dx.ptr, dy.ptr, lo, hi, None))
+            assert np.array_equal(dy.to_host(n), ref), ("rows", team, known)
+    lib.liship_spmv_bsr_set_team(1)
     # the product with the reduction epilogue: same y, sums as numpy to 1e-13, repeatable; refuses what it does not serve
     w = np.random.default_rng(22).uniform(-1, 1, nr * bs)
     dw, work, res = DA.from_host(w), DA(lib.liship_reduce_work_bytes() // 8, np.float64), DA.from_host(np.full(2, np.nan))

@@ -2147,7 +2147,7 @@ void spmv_csr_valuerecw_kernel(const unsigned char *__restrict__ rowpat, const v
 // SCALAR register (the pattern's slots and values are kernel arguments); rows on other patterns whose offsets the dominant one's runs hold take
 // their mask and values in the dominant pattern's slots by scalar loads, one round per distinct pattern among the lanes (dom_waterfall's scheme);
 // foreign rows walk their own record.  Same products in the same order -- masked slots add -0.0 -- so y is the reference's, bit for bit.
-struct WideDom { int len, pat, slots, maxcol; int slot[PATW_LEN]; double val[PATW_LEN]; };
+struct WideDom { int len, pat, slots, maxcol; int slot[PATW_LEN]; double val[PATW_LEN]; int tri, pad[3]; };      // tri: entries 3q, 3q+1, 3q+2 sit in three neighbouring slots for every q (box stencils)
 constexpr int WREC = 40;                                   // doubles per pattern in wdrec: 32 values in the dominant pattern's slots, [32] = mask | foreign << 32
 template <int BLOCK, int NL, int CH, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
@@ -2202,8 +2202,19 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
         if (ch + 1 < CH && r0 + WAVE < RW.re) prefetch(r0 + WAVE);  // (uniform)
         double acc = RW.acc0;
         if (__builtin_amdgcn_ballot_w64(live && pat != D.pat) == 0) {   // (uniform) every row here is on the dominant pattern
+            if (D.tri) {                                            // three neighbouring slots per triple: one 16 B + one 8 B LDS read and one address for three entries
+#pragma unroll
+                for (int q = 0; q < PATW_LEN / 3; q++)
+                    if (3 * q < D.len) {
+                        const double *xp = xr + D.slot[3 * q];
+                        const v2f64 x01 = *reinterpret_cast<const v2f64u *>(xp);
+                        const double x2 = xp[2];
+                        acc += D.val[3 * q] * x01.x; acc += D.val[3 * q + 1] * x01.y; acc += D.val[3 * q + 2] * x2;
+                    }
+            } else {
 #pragma unroll
             for (int j = 0; j < PATW_LEN; j++) if (j < D.len) acc += D.val[j] * xr[D.slot[j]];
+            }
         } else {
             // masks first: one 8 B scalar load per distinct pattern among the lanes.  Bit 32: foreign (the row walks its own record); bit 33: the pattern's values are
             // the dominant one's in every slot it keeps (HPCG's boundary rows: 26 and -1 everywhere) -- then the values stay in scalar registers
@@ -2221,8 +2232,20 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
             }
             if (__builtin_amdgcn_ballot_w64(differs && !foreign) == 0) {      // (uniform) nobody needs values of its own
                 if (!foreign) {
+                    if (D.tri) {
+#pragma unroll
+                        for (int q = 0; q < PATW_LEN / 3; q++)
+                            if (3 * q < D.len) {
+                                const double *xp = xr + D.slot[3 * q];
+                                const v2f64 x01 = *reinterpret_cast<const v2f64u *>(xp);
+                                const double x2 = xp[2];
+                                const double t0 = D.val[3 * q] * x01.x, t1 = D.val[3 * q + 1] * x01.y, t2 = D.val[3 * q + 2] * x2;
+                                acc += ((m >> (3 * q)) & 1u) ? t0 : -0.0; acc += ((m >> (3 * q + 1)) & 1u) ? t1 : -0.0; acc += ((m >> (3 * q + 2)) & 1u) ? t2 : -0.0;
+                            }
+                    } else {
 #pragma unroll
                     for (int j = 0; j < PATW_LEN; j++) if (j < D.len) { const double t = D.val[j] * xr[D.slot[j]]; acc += ((m >> j) & 1u) ? t : -0.0; }     // -0.0 terms leave any sum bit-unchanged
+                    }
                 }
             } else {
                 // ... in two halves of 16 slots (32 registers of values at a time keep the kernel at 64 registers: eight wavefronts per SIMD)
@@ -3243,6 +3266,8 @@ static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, cons
         D.slot[j] = base[q] + (od[j] - start[q]);
         D.val[j] = vals ? vals[(size_t)dom * PATW_LEN + j] : 0.0;
     }
+    D.tri = (l % 3 == 0 && l <= 30) ? 1 : 0;
+    for (int q = 0; q < l / 3 && D.tri; q++) if (D.slot[3 * q + 1] != D.slot[3 * q] + 1 || D.slot[3 * q + 2] != D.slot[3 * q] + 2) D.tri = 0;
     int *stage = (int *)calloc(WAVE * 8, sizeof(int));
     double *img = (double *)calloc((size_t)NP * WREC, sizeof(double));
     if (stage && img) {

@@ -1573,7 +1573,7 @@ void spmv_csr_valuerec_pair_kernel(const unsigned char *__restrict__ rowpat, con
 // bit 7: the ghost-column rows of a partitioned matrix) and the wavefronts whose speculative addresses would leave x (the first and
 // last |max offset| rows) take their rows one by one with their own records, as the kernels above do.
 typedef double v8f64 __attribute__((ext_vector_type(8)));
-struct DomTile { int S, cshift, ntiled, nfull; };       // spmv_csr_valuerec_dom_kernel: tiled lane -> row mapping (S = 0: none)
+struct DomTile { int S, cshift, ntiled, nfull, tpp, reg, zreg; };       // spmv_csr_valuerec_dom_kernel: tiled lane -> row mapping (S = 0: none); tpp > 0: planes of tpp tiles, each XCD marching through the planes in regions of reg tiles (zreg = planes * reg)
 struct DomRec { int off[7]; int pat; double val[7]; int mask, d0; };      // byte offsets and values of the dominant pattern, its pattern byte, its slots (length), the slot of offset 0 (-1: none)
 
 // slots of D that pattern `pt` (uniform) has, and its values there: 8 doubles per pattern, [0] = the mask in the low word
@@ -1642,6 +1642,15 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
     {
         int rw, ra;                                                   // the wavefront's lowest row, the lane's first row
         bool safe;                                                    // (uniform) speculation is safe: every address r*8 + offset of the wavefront's rows (16 B loads: one more) lies inside x[0, n)
+        if (TL.tpp > 0 && chunk < TL.zreg * (TL.tpp / TL.reg)) {
+            // PLANES: the tiles of a plane (the pattern's outer stride S2: +-mn of a 3-D stencil) are split into regions of `reg` tiles; XCD k takes the
+            // regions k, k + 8, ... and walks each one plane after plane, so that the +-S2 neighbours of its rows are lines the SAME L2 fetched a few
+            // hundred workgroups ago (3 planes of a region: a fraction of the 4 MB) instead of lines another XCD's L2 holds
+            const int k = chunk % NUM_XCD, j = chunk / NUM_XCD;
+            const int col = j / TL.zreg, within = j - col * TL.zreg;
+            const int plane = within / TL.reg, t = within - plane * TL.reg;
+            chunk = plane * TL.tpp + (col * NUM_XCD + k) * TL.reg + t;
+        }
         if (TL.S > 0 && chunk < TL.ntiled) {
             // TILED rows: the workgroup's 256 lane pairs cover T = 256 >> cshift lines of 2 << cshift columns each, the lines S rows apart
             // (S: the stride of the pattern's middle offsets, +-n of a 3-D stencil) -- a wavefront then gathers its rows' +-S neighbours from
@@ -3564,6 +3573,16 @@ static int dom_stride(const DomRec &D)
     return S;
 }
 
+static int dom_stride_outer(const DomRec &D)
+{
+    int S = 0;
+    for (int u = 0; u < 7; u++) {
+        const int e = D.off[u] / 8;
+        if (e > S) { bool both = false; for (int v = 0; v < 7; v++) both = both || D.off[v] == -8 * e; if (both) S = e; }
+    }
+    return S;
+}
+
 template <int G, int U, bool XRUN, bool DMA, bool NOGATHER>
 void launch_rowgather(int grid, const LaunchArgs &a)
 {
@@ -3693,7 +3712,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             const bool plain = (g_variant & 0x10000000) != 0;
             int tsel = ((g_variant >> 3) & 1) | (((g_variant >> 9) & 1) << 1) | (((g_variant >> 15) & 1) << 2);
             if (!tsel && !plain && !(g_variant & 1)) tsel = 3;
-            DomTile TL{0, 0, 0, 0};
+            DomTile TL{0, 0, 0, 0, 0, 0, 0};
             long long wgs = (rows + 511) / 512;
             if (tsel) {
                 const int S = dom_stride(P->dom);
@@ -3703,12 +3722,26 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
                     const long long groups = rows / ((long long)T * S);
                     TL.S = S; TL.cshift = cshift; TL.ntiled = (int)(groups * (S / C)); TL.nfull = (int)(groups * T * S);
                     wgs = TL.ntiled + (rows - TL.nfull + 511) / 512;
+                    if (g_variant & 0x40000000) {
+                        const int S2 = dom_stride_outer(P->dom);
+                        const long long tile = (long long)T * C;
+                        if (S2 > S && S2 % (T * S) == 0 && rows >= 2ll * S2) {
+                            const int tpp = (int)(S2 / tile), div = (g_variant >> 16) & 0xff;
+                            const int regions = NUM_XCD * (div ? div : 1);
+                            if (tpp % regions == 0) { TL.tpp = tpp; TL.reg = tpp / regions; TL.zreg = (int)(TL.nfull / S2) * TL.reg; }
+                        }
+                    }
                 }
             }
             const int run = (g_variant & 1) ? xcd_run() : (plain || TL.S || wgs < 8 * NUM_XCD) ? 1 : 8;
             const int span = NUM_XCD * run;
+            DomRec DD = P->dom;
+            if ((g_variant & 0x40004000) == 0x40004000) {      // ablation (WRONG results, timing only): the outermost pair of offsets re-reads the diagonal
+                const int S2 = dom_stride_outer(DD);
+                for (int u = 0; u < 7; u++) if (DD.off[u] == 8 * S2 || DD.off[u] == -8 * S2) DD.off[u] = 0;
+            }
             spmv_csr_valuerec_dom_kernel<256><<<(unsigned)((wgs + span - 1) / span * span), 256, 0, a.st>>>(
-                a.rowpat, a.vrec, P->drec, P->dom, P->dom_lo, P->dom_hi, a.x, a.y, Rows{a.rb, a.re, a.acc0}, run, TL);
+                a.rowpat, a.vrec, P->drec, DD, P->dom_lo, P->dom_hi, a.x, a.y, Rows{a.rb, a.re, a.acc0}, run, TL);
             return;
         }
         if (chunks > 0 && pairs)

@@ -89,6 +89,7 @@ _LISHIP = {
     "liship_csr_plan_localized": (C.c_longlong, [_vp]),
     "liship_spmv_csr_set_local_columns": (_ci, [_ci]),
     "liship_spmv_csr_set_long_row_tree": (_ci, [_ci]),
+    "liship_spmv_csr_set_uniform_rows": (_ci, [_ci]),
     "liship_spmv_csr_set_index_codes": (_ci, [_ci]),
     "liship_spmv_csr_rows_f64": (_ci, [_vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_spmv_csr_rows_dot_f64": (_ci, [_vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp]),

@@ -66,6 +66,7 @@ int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps eve
 int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
 int g_row_values = 1;            // liship_spmv_csr_set_row_values: 0 keeps streaming the values of matrices that have value records
 int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps the products kernel on the 4 B indices
+int g_uniform_rows = 1;          // liship_spmv_csr_set_uniform_rows: 0 keeps the row sums of the block-local kernel on the skewed schedule everywhere (A/B)
 int g_team = 1;                  // liship_spmv_csr_set_team: 0 keeps patterned rows of 8..32 entries on the one-lane-per-row pattern kernel
 
 __device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
@@ -332,6 +333,54 @@ __device__ __forceinline__ double ordered_sum_fed(double acc, const double *buf,
     return ordered_sum_plain(acc, buf, first + done, lim - done);
 }
 
+// The rows of a wavefront when they all have ONE length L (the interior rows of a finite-element or stencil matrix): no lane needs a
+// mask, an odd L (or 2 x odd: two-way) spreads the lanes' reads over the banks without a skew -- which costs every wavefront up to 31 more
+// steps --, and the chain can be kept fed as the long row's is: L mod 21 terms first (all read at once, a uniform jump into the run of
+// additions), then whole rounds of 21 through ordered_sum_fed's loop, each lane from its own address.  Same terms, same order.
+__device__ __forceinline__ double ordered_sum_first20(double acc, const double *buf, int first, int rem)     // rem uniform, 0..20
+{
+    const double *p = buf + GUARD + first + rem - 20;     // p[u] = term rem - 20 + u (u < 20 - rem: slots in front of the row, read and dropped)
+    double d[20];
+#pragma unroll
+    for (int u = 0; u < 20; u++) d[u] = p[u];
+    switch (rem) {
+    case 20: acc += d[0]; [[fallthrough]];
+    case 19: acc += d[1]; [[fallthrough]];
+    case 18: acc += d[2]; [[fallthrough]];
+    case 17: acc += d[3]; [[fallthrough]];
+    case 16: acc += d[4]; [[fallthrough]];
+    case 15: acc += d[5]; [[fallthrough]];
+    case 14: acc += d[6]; [[fallthrough]];
+    case 13: acc += d[7]; [[fallthrough]];
+    case 12: acc += d[8]; [[fallthrough]];
+    case 11: acc += d[9]; [[fallthrough]];
+    case 10: acc += d[10]; [[fallthrough]];
+    case 9: acc += d[11]; [[fallthrough]];
+    case 8: acc += d[12]; [[fallthrough]];
+    case 7: acc += d[13]; [[fallthrough]];
+    case 6: acc += d[14]; [[fallthrough]];
+    case 5: acc += d[15]; [[fallthrough]];
+    case 4: acc += d[16]; [[fallthrough]];
+    case 3: acc += d[17]; [[fallthrough]];
+    case 2: acc += d[18]; [[fallthrough]];
+    case 1: acc += d[19]; [[fallthrough]];
+    default: break;
+    }
+    return acc;
+}
+
+// the sums of the rows a wavefront's lanes own (first, lim: per lane), whichever way fits
+__device__ __forceinline__ double ordered_sum_rows(double acc, const double *buf, int first, int lim, int lane, int uniform)
+{
+    const int L0 = __builtin_amdgcn_readfirstlane(lim);
+    if (uniform != 0 && L0 >= 21 && (L0 & 3) != 0 && __builtin_amdgcn_ballot_w64(lim != L0) == 0) {      // (uniform)
+        const int rem = L0 % 21;
+        acc = ordered_sum_first20(acc, buf, first, rem);
+        return ordered_sum_fed(acc, buf, first + rem, L0 - rem);
+    }
+    return ordered_sum(acc, buf, first, lim, row_skew(first, lane));
+}
+
 // one whole row block of any shape (many empty rows, rows longer than the LDS stage).
 // Invariant from the plan: every row but the last ends inside the first pass of CAP products.
 template <int BLOCK, int CAP, int VEC, bool NOGATHER, int DOT = 0>
@@ -356,7 +405,7 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
     for (int r = rmine; r < r1; r += BLOCK) {
         int s = s_first, e = e_first;
         if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
-        const double acc = ordered_sum(acc0, prod, s - ka, min(e, kfirst) - s, row_skew(s - ka, (int)threadIdx.x));
+        const double acc = ordered_sum_rows(acc0, prod, s - ka, min(e, kfirst) - s, (int)threadIdx.x, 1);
         if (e <= kfirst) { store_stream(y + r, acc); dots.add(r, acc); } else carry = acc;   // only the block's last row can overflow
     }
 
@@ -639,7 +688,7 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
                            const int *__restrict__ doff, const double *__restrict__ x, double *__restrict__ y,
                            const v2i32 *__restrict__ blk, int bfirst, int nb, Rows RW, int nnz_total,
                            const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                           const double *__restrict__ guard = nullptr, int pstride = 0)
+                           const double *__restrict__ guard = nullptr, int pstride = 0, int uniform = 1)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const int row_begin = RW.rb, row_end = RW.re;
@@ -719,7 +768,7 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
         int s = s_first, e = e_first;
         if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
         const double wr = dots.fetch(r);
-        const double acc = ordered_sum(acc0, valL, s - ka, e - s, row_skew(s - ka, (int)threadIdx.x));
+        const double acc = ordered_sum_rows(acc0, valL, s - ka, e - s, (int)threadIdx.x, uniform);
         store_stream(y + r, acc);
         dots.add_loaded(wr, acc);
     }
@@ -2642,6 +2691,13 @@ extern "C" int liship_spmv_csr_set_long_row_tree(int on)
     return 0;
 }
 
+// A/B switch of the uniform-length row sums (ordered_sum_rows): 0 keeps every wavefront on the skewed sums.  Same bits either way.
+extern "C" int liship_spmv_csr_set_uniform_rows(int on)
+{
+    g_uniform_rows = on ? 1 : 0;
+    return 0;
+}
+
 // the merge-path row split for the plan's geometry (device + host copy); replaces an existing one
 static int build_split(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
 {
@@ -3662,10 +3718,10 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
         constexpr Geometry g = kGeom[LOCAL_GEOM];
         if (a.plan && a.plan->ndpl == 4)
             spmv_csr_local_kernel<g.block, g.work, 0, 4><<<a.nb, g.block, 0, a.st>>>(
-                a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
+                a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, nullptr, nullptr, nullptr, 0, g_uniform_rows);
         else
         spmv_csr_local_kernel<g.block, g.work><<<a.nb, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
+            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, nullptr, nullptr, nullptr, 0, g_uniform_rows);
         return;
     }
     if (products) {
@@ -3869,11 +3925,11 @@ void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double
     if (a.lcol && G == LOCAL_GEOM) {
         if (a.plan && a.plan->ndpl == 4) {
             spmv_csr_local_kernel<g.block, g.work, DOT, 4><<<a.nb, g.block, 0, a.st>>>(
-                a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride);
+                a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride, g_uniform_rows);
             return;
         }
         spmv_csr_local_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride);
+            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride, g_uniform_rows);
         return;
     }
     if (batch == 2)

@@ -678,6 +678,46 @@ def test_spmv_csr_local_columns(lib, name):
         assert np.array_equal(a, b)                        # same partial sums, same fold: the reductions agree to the bit too
 
 
+@pytest.mark.parametrize("L", [21, 22, 23, 25, 26, 41, 42, 43, 62, 63, 81, 85, 101, 127])
+def test_uniform_length_rows_fed_sums(lib, L):
+    """rows of ONE length (>= 21, not a multiple of 4): the wavefronts of the products and block-local kernels add them without a skew,
+    L mod 21 terms first and whole rounds of 21 through the fed chain (ordered_sum_rows) -- the oracle's bits (lis_matvec_csr.c:97-109),
+    and the bits of the skewed sums, with special values among the products; a few shorter rows make some wavefronts mixed"""
+    n = 3000
+    rng = np.random.default_rng(L)
+    lens = np.full(n, L, np.int64)
+    lens[rng.integers(0, n, 5)] = rng.integers(0, L, 5)              # a handful of ragged rows: their wavefronts take the skewed path
+    lens[64 * 7: 64 * 9] = L                                          # ... and two whole wavefronts surely uniform
+    ptr = np.zeros(n + 1, np.int32)
+    np.cumsum(lens, out=ptr[1:])
+    nnz = int(ptr[-1])
+    rows = np.repeat(np.arange(n), lens)
+    k = np.arange(nnz) - ptr[rows]
+    idx = ((rows + (k - L // 2) * 3) % n).astype(np.int32)            # a band: few distinct columns per row block (the local kernel qualifies)
+    val = rng.uniform(-1, 1, nnz)
+    x = rng.uniform(-1, 1, n)
+    x[5], x[77] = 0.0, -0.0
+    val[rng.integers(0, nnz, 8)] = 0.0
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64)
+    dx = DA.from_host(x, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_localize_columns(plan, dptr.ptr, didx.ptr, None))
+    try:
+        for local in (1, 0):
+            lib.liship_spmv_csr_set_local_columns(local)
+            for uniform in (1, 0):
+                check(lib.liship_spmv_csr_set_uniform_rows(uniform))
+                dy = DA.from_host(np.full(n, np.nan), np.float64)
+                check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+                assert np.array_equal(dy.to_host().view(np.uint64), yref.view(np.uint64)), (local, uniform)
+    finally:
+        lib.liship_spmv_csr_set_local_columns(1)
+        check(lib.liship_spmv_csr_set_uniform_rows(1))
+        check(lib.liship_csr_plan_destroy(plan))
+
+
 def test_spmv_csr_long_row_tree_is_opt_in(lib):
     """rows longer than the LDS stage: left-to-right by default (the oracle's bits); with the opt-in tree the same value to
     rounding, reproducibly -- and rows that fit the stage keep their bits either way"""

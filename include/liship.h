@@ -106,6 +106,7 @@ int  liship_csr_plan_wide_dominant(liship_csr_plan_t plan);
 /* 0 when the products of this plan run a kernel with a row split of its own (the team / staged kernels) under the switches in force: the fused entry points
  * (liship_spmv_csr_dot_f64, liship_spmv_csr_rows_dot_f64) then refuse with LISHIP_ERR_ARG and the caller runs the product and one reduction pass */
 int  liship_csr_plan_fused_dots(liship_csr_plan_t plan);
+long long liship_csr_plan_fused_slots(liship_csr_plan_t plan);   /* upper bound of the reduction slots the fused product needs in up to three row ranges */
 int  liship_spmv_csr_set_team(int on);           /* A/B switch: 0 = the one-lane-per-row pattern kernel for these rows too (same bits) */
 /* Value records (setup-time, optional, after liship_csr_plan_encode_row_patterns; never an error when the matrix does not
  * qualify): when the plan has 32 B pattern records and every row of a pattern carries the same values bit for bit -- a

@@ -76,6 +76,7 @@ _LISHIP = {
     "liship_csr_plan_team_records": (_ci, [_vp]),
     "liship_csr_plan_team_form": (_ci, [_vp]),
     "liship_csr_plan_fused_dots": (_ci, [_vp]),
+    "liship_csr_plan_fused_slots": (C.c_longlong, [_vp]),
     "liship_csr_plan_wide_dominant": (_ci, [_vp]),
     "liship_spmv_csr_set_team": (_ci, [_ci]),
     "liship_spmv_bsr_rows_f64": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp]),

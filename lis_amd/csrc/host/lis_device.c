@@ -1063,7 +1063,9 @@ LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const doub
 	if (d->type == LIS_MATRIX_CSR && d->plan) (void)liship_csr_plan_info(d->plan, NULL, NULL, &nblocks);
 	/* the three parts launch at most nblocks + 2 row blocks (each cut splits one): all of them must find a slot for
 	 * their partial sums BEFORE the first part is launched -- otherwise the plain overlapped product + one dot pass */
-	const int slots_ok = (size_t)nblocks + 2 <= liship_reduce_work_bytes() / sizeof(double) / 4;
+	const int slots_ok = (d->type == LIS_MATRIX_CSR && d->plan)
+		? (size_t)liship_csr_plan_fused_slots(d->plan) <= liship_reduce_work_bytes() / sizeof(double) / 4
+		: (size_t)nblocks + 2 <= liship_reduce_work_bytes() / sizeof(double) / 4;
 	/* a plan whose products run the team / staged kernels has no per-row-block epilogue: the plain (overlapped) product and one reduction pass */
 	const int fused = !(d->type == LIS_MATRIX_CSR && d->plan) || liship_csr_plan_fused_dots(d->plan);
 	if (d->type == LIS_MATRIX_CSR && !fused) {

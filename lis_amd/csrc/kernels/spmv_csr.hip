@@ -1659,31 +1659,78 @@ __device__ __forceinline__ double dom_pad_terms(double s, unsigned m, const doub
     return s;
 }
 
-// one row by its own record (96 B, global): the kernels above, without LDS
+// sum across the 64 lanes by DPP moves alone (no LDS permute): the rows of 16 by the xor partners 8, 4, 2, 1, then lane 15 of a row broadcast into the next row
+// (rows 1 and 3) and lane 31 into rows 2 and 3 -- the total is valid in the lanes of row 3 (48..63).  NOT wave_sum's order: for epilogues with sums of their own.
+__device__ __forceinline__ double wave_sum_row3(double v)
+{
+    v += lane_xor_in_row<8>(v);
+    v += lane_xor_in_row<4>(v);
+    v += lane_xor_in_row<2>(v);
+    v += lane_xor_in_row<1>(v);
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xa, 0xf, false);
+        v += __hiloint2double(hi, lo);
+    }
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x143, 0xc, 0xf, false);
+        v += __hiloint2double(hi, lo);
+    }
+    return v;
+}
+
+// one row by its own record (96 B, global): the kernels above, without LDS.  Rare (ghost-column rows, the matrix's first and last rows), so it is written for
+// few registers, not for latency: slots 0..3, then slots 4..6 -- inlined in kernels that hold seven 16 B gathers, 38 live registers here cost them their occupancy
 __device__ __forceinline__ double own_record_row(const v4i32 *__restrict__ rec, int pt, int r, const double *__restrict__ x, double acc0)
 {
-    const v4i32 a = rec[6 * pt], b = rec[6 * pt + 1];
+    const v4i32 b = rec[6 * pt + 1];
+    const int len = b.w;
     const v2f64 *q = reinterpret_cast<const v2f64 *>(rec + 6 * pt + 2);
-    const v2f64 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    const int o[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z}, len = b.w;
-    const double v[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
-    double xv[7], acc = acc0;
+    double acc = acc0;
+    {
+        const v4i32 a = rec[6 * pt];
+        const v2f64 q0 = q[0], q1 = q[1];
+        const int o[4] = {a.x, a.y, a.z, a.w};
+        const double v[4] = {q0.x, q0.y, q1.x, q1.y};
+        double xv[4];
 #pragma unroll
-    for (int u = 0; u < 7; u++) xv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned)r * 8u + (unsigned)o[u]));
+        for (int u = 0; u < 4; u++) xv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned)r * 8u + (unsigned)o[u]));
 #pragma unroll
-    for (int u = 0; u < 7; u++) { const double t = v[u] * xv[u]; acc += (u < len) ? t : -0.0; }
+        for (int u = 0; u < 4; u++) { const double t = v[u] * xv[u]; acc += (u < len) ? t : -0.0; }
+    }
+    if (__builtin_amdgcn_ballot_w64(len > 4) != 0) {                 // (uniform)
+        const v2f64 q2 = q[2], q3 = q[3];
+        const int o[3] = {b.x, b.y, b.z};
+        const double v[3] = {q2.x, q2.y, q3.x};
+        double xv[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) xv[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((unsigned)r * 8u + (unsigned)o[u]));
+#pragma unroll
+        for (int u = 0; u < 3; u++) { const double t = v[u] * xv[u]; acc += (4 + u < len) ? t : -0.0; }
+    }
     return acc;
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK)
+template <int BLOCK, int DOT = 0>
+__global__ __launch_bounds__(BLOCK, 8)                  // 8 wavefronts per SIMD (64 VGPRs) with the dots' registers too: the product lives on the misses it keeps in flight
 void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, const double *__restrict__ drec,
                                   const DomRec D, int safe_lo, int safe_hi,
-                                  const double *__restrict__ x, double *__restrict__ y, Rows RW, int run, const DomTile TL)
+                                  const double *__restrict__ x, double *__restrict__ y, Rows RW, int run, const DomTile TL,
+                                  const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                                  const double *__restrict__ guard = nullptr, int pstride = 0, int wslot = -1, int total = 0)
 {
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged (nothing has been written)
     const double acc0 = RW.acc0;
     const int tid = (int)threadIdx.x;
     const int wbase = tid & ~(WAVE - 1);
+    double c0 = 0.0, c1 = 0.0;
+    __shared__ double dot_part[2][BLOCK / WAVE];
+    __shared__ unsigned dot_count;
+    if (DOT != 0) {                                                   // the only barrier: at the start, where the wavefronts of a workgroup arrive together
+        if (tid == 0) dot_count = 0u;
+        __syncthreads();
+    }
     // workgroup -> chunk of rows.  Workgroups go round-robin over the 8 XCDs; with run > 1 each XCD walks runs of `run` consecutive
     // chunks, so that the x lines neighbouring chunks share (the +-n neighbours of a grid line) are fetched by ONE L2
     int chunk = (int)blockIdx.x;
@@ -1691,6 +1738,7 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
     {
         int rw, ra;                                                   // the wavefront's lowest row, the lane's first row
         bool safe;                                                    // (uniform) speculation is safe: every address r*8 + offset of the wavefront's rows (16 B loads: one more) lies inside x[0, n)
+        bool live = true;                                             // (uniform) the wavefront has rows
         if (TL.tpp > 0 && chunk < TL.zreg * (TL.tpp / TL.reg)) {
             // PLANES: the tiles of a plane (the pattern's outer stride S2: +-mn of a 3-D stencil) are split into regions of `reg` tiles; XCD k takes the
             // regions k, k + 8, ... and walks each one plane after plane, so that the +-S2 neighbours of its rows are lines the SAME L2 fetched a few
@@ -1715,19 +1763,28 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
             safe = rw >= safe_lo && base + t1 * TL.S + (2 << TL.cshift) + 2 <= safe_hi;
         } else {
             const long long c0w = (long long)RW.rb + (TL.S > 0 ? TL.nfull : 0) + (long long)(chunk - (TL.S > 0 ? TL.ntiled : 0)) * (2 * BLOCK) + 2 * wbase;
-            if (c0w >= RW.re) return;                                 // (uniform)
-            rw = (int)c0w;
+            if (c0w >= RW.re) live = false;                           // (uniform)
+            rw = live ? (int)c0w : RW.rb;
             ra = rw + 2 * (tid - wbase);
-            safe = rw >= safe_lo && rw + 2 * WAVE <= safe_hi && rw + 2 * WAVE <= RW.re;
+            safe = live && rw >= safe_lo && rw + 2 * WAVE <= safe_hi && rw + 2 * WAVE <= RW.re;
         }
         if (safe) {
             unsigned two;
             if ((RW.rb & 1) == 0) two = *reinterpret_cast<const unsigned short *>(rowpat + ra);
             else two = (unsigned)rowpat[ra] | ((unsigned)rowpat[ra + 1] << 8);
             const unsigned rb8 = (unsigned)ra * 8u;
-            v2f64 xx[7];
+            v2f64 xx[7], ww;
+            ww.x = ww.y = 0.0;
+            if (DOT != 0 && wslot < 0) {                              // (uniform) w is not x, or the dominant pattern has no diagonal entry
+                if ((RW.rb & 1) == 0) ww = *reinterpret_cast<const v2f64 *>(wdot + ra);
+                else { ww.x = wdot[ra]; ww.y = wdot[ra + 1]; }
+            }
 #pragma unroll
             for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64u *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
+            if (DOT != 0) {
+#pragma unroll
+                for (int u = 0; u < 7; u++) if (u == wslot) ww = xx[u];
+            }
             const int pa = (int)(two & 255u), pb = (int)(two >> 8);
             double s0 = acc0, s1 = acc0;
             if (__builtin_amdgcn_ballot_w64(pa != D.pat || pb != D.pat) == 0) {      // (uniform) every row here is the dominant pattern
@@ -1763,11 +1820,45 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
             v2f64 out; out.x = s0; out.y = s1;
             if ((RW.rb & 1) == 0) store_stream(reinterpret_cast<v2f64 *>(y + ra), out);
             else { store_stream(y + ra, s0); store_stream(y + ra + 1, s1); }
-        } else {                                                      // the matrix's first and last rows, a launch's tail: row by row
+            if (DOT >= 1) { c0 += ww.x * s0; c0 += ww.y * s1; }
+            if (DOT >= 2) { c1 += s0 * s0; c1 += s1 * s1; }
+        } else if (live) {                                            // the matrix's first and last rows, a launch's tail: row by row
 #pragma unroll
             for (int w = 0; w < 2; w++) {
                 const int r = ra + w;
-                if (r < RW.re) store_stream(y + r, own_record_row(rec, (int)rowpat[r], r, x, acc0));
+                if (r < RW.re) {
+                    const double acc = own_record_row(rec, (int)rowpat[r], r, x, acc0);
+                    store_stream(y + r, acc);
+                    if (DOT >= 1) c0 += wdot[r] * acc;
+                    if (DOT >= 2) c1 += acc * acc;
+                }
+            }
+        }
+    }
+    if (DOT != 0) {
+        // one partial per WORKGROUP without a barrier at the end (which would hold every wavefront's slot until the workgroup's slowest has its lines back): a
+        // wavefront parks its sum in LDS and counts itself in; the one that counts last adds the four in wavefront order -- the same bits whoever is last.
+        // (A partial per wavefront -- a million 8 B stores at 512^3 -- cost 0.05 ms; persistent workgroups that keep their sums in registers spill: 0.9 ms.)
+        constexpr int NW = BLOCK / WAVE;
+        const int stride = pstride ? pstride : total;
+        const int wv = wbase / WAVE;
+        const double t0 = wave_sum_row3(c0), t1 = DOT >= 2 ? wave_sum_row3(c1) : 0.0;
+        int seen = 0;
+        if (tid == wbase + WAVE - 1) {
+            dot_part[0][wv] = t0;
+            if (DOT >= 2) dot_part[1][wv] = t1;
+            seen = (int)__hip_atomic_fetch_add(&dot_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // LDS operations of a wavefront execute in order
+            if (seen == NW - 1 && chunk < total) {
+                double e = 0.0;
+#pragma unroll
+                for (int i = 0; i < NW; i++) e += dot_part[0][i];
+                partial[chunk] = e;
+                if (DOT >= 2) {
+                    double f = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NW; i++) f += dot_part[1][i];
+                    partial[(size_t)stride + chunk] = f;
+                }
             }
         }
     }
@@ -3704,6 +3795,68 @@ static void launch_team(const LaunchArgs &a, const double *guard)
         spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard);
 }
 
+// the dominant-pattern product of a plan with value records (spmv_csr_valuerec_dom_kernel), plain or with the fused dots (a partial per workgroup: count_out)
+// its shape for the rows [a.rb, a.re): the tiles, the run length of the XCD order; returns the number of workgroups that have rows (= partials of the fused form)
+static long long dom_shape(const LaunchArgs &a, DomTile &TL, int &run)
+{
+    const liship_csr_plan_s *P = a.plan;
+    const long long rows = (long long)a.re - a.rb;
+    // lane -> row mapping.  Default: TILES of 4 lines x 128 columns per workgroup when the pattern has a stride S of middle offsets
+    // (+-n of a 3-D stencil) that 128 divides -- the four wavefronts' +-S gathers then hit lines their neighbours' diagonal gathers bring
+    // into the same L1: 512^3 0.58 -> 0.49 ms --; otherwise contiguous 512-row chunks, each XCD walking runs of 8 of them (one L2 serves
+    // the chunks' shared x lines: 0.58 -> 0.535 ms).  Experiment knobs: bit28 plain chunks round-robin; bits 3 / 9 / 15 select tiles of
+    // 32 / 64 / 128 / 256 columns; bit0 + bits16-23 the run length.  (Measured and dropped: four rows per lane, 512 / 1024 lanes per
+    // workgroup, kernarg preload of the arguments: profiles/r03_valuerec_dom_experiments.txt.)
+    const bool plain = (g_variant & 0x10000000) != 0;
+    int tsel = ((g_variant >> 3) & 1) | (((g_variant >> 9) & 1) << 1) | (((g_variant >> 15) & 1) << 2);
+    if (!tsel && !plain && !(g_variant & 1)) tsel = 3;
+    TL = DomTile{0, 0, 0, 0, 0, 0, 0};
+    long long wgs = (rows + 511) / 512;
+    if (tsel) {
+        const int S = dom_stride(P->dom);
+        const int cshift = 3 + tsel;                      // pairs per tile line: 16, 32, 64, 128
+        const int C = 2 << cshift, T = 256 >> cshift;
+        if (S >= C && S % C == 0 && rows >= (long long)T * S) {
+            const long long groups = rows / ((long long)T * S);
+            TL.S = S; TL.cshift = cshift; TL.ntiled = (int)(groups * (S / C)); TL.nfull = (int)(groups * T * S);
+            wgs = TL.ntiled + (rows - TL.nfull + 511) / 512;
+            if (g_variant & 0x40000000) {
+                const int S2 = dom_stride_outer(P->dom);
+                const long long tile = (long long)T * C;
+                if (S2 > S && S2 % (T * S) == 0 && rows >= 2ll * S2) {
+                    const int tpp = (int)(S2 / tile), div = (g_variant >> 16) & 0xff;
+                    const int regions = NUM_XCD * (div ? div : 1);
+                    if (tpp % regions == 0) { TL.tpp = tpp; TL.reg = tpp / regions; TL.zreg = (int)(TL.nfull / S2) * TL.reg; }
+                }
+            }
+        }
+    }
+    run = (g_variant & 1) ? xcd_run() : (plain || TL.S || wgs < 8 * NUM_XCD) ? 1 : 8;
+    return wgs;
+}
+
+static void launch_dom(const LaunchArgs &a, int dot = 0, const double *w = nullptr, double *partial = nullptr, const double *guard = nullptr, int pstride = 0)
+{
+    const liship_csr_plan_s *P = a.plan;
+    DomTile TL;
+    int run = 1;
+    const long long wgs = dom_shape(a, TL, run);
+    const int span = NUM_XCD * run;
+    DomRec DD = P->dom;
+    if ((g_variant & 0x40004000) == 0x40004000) {      // ablation (WRONG results, timing only): the outermost pair of offsets re-reads the diagonal
+        const int S2 = dom_stride_outer(DD);
+        for (int u = 0; u < 7; u++) if (DD.off[u] == 8 * S2 || DD.off[u] == -8 * S2) DD.off[u] = 0;
+    }
+    const unsigned grid = (unsigned)((wgs + span - 1) / span * span);
+    int wslot = -1;
+    if (dot != 0 && w == a.x && !(g_variant & 0x8))      // (bit3: w by its own loads, A/B)
+        for (int u = 0; u < 7; u++) if (((P->dom.mask >> u) & 1) && P->dom.off[u] == 0) wslot = u;
+#define GOD(DT) spmv_csr_valuerec_dom_kernel<256, DT><<<grid, 256, 0, a.st>>>( \
+        a.rowpat, a.vrec, P->drec, DD, P->dom_lo, P->dom_hi, a.x, a.y, Rows{a.rb, a.re, a.acc0}, run, TL, w, partial, guard, pstride, wslot, (int)wgs)
+    if (dot == 0) GOD(0); else if (dot == 1) GOD(1); else GOD(2);
+#undef GOD
+}
+
 template <int G>
 void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
 {
@@ -3756,50 +3909,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
         // below it x stays cache-resident from product to product and the one-row form is 15 % faster (tools/valuerec_probe.py)
         const bool pairs = (g_variant & 0x4000) || (long long)(a.re - a.rb) * 8 > (256ll << 20);
         // one pattern carries most rows: its gathers are issued together with the pattern bytes (one round trip, no LDS, no barrier)
-        if (chunks > 0 && a.plan && a.plan->drec && !(g_variant & 0x20000000)) {
-            const liship_csr_plan_s *P = a.plan;
-            const long long rows = (long long)a.re - a.rb;
-            // lane -> row mapping.  Default: TILES of 4 lines x 128 columns per workgroup when the pattern has a stride S of middle offsets
-            // (+-n of a 3-D stencil) that 128 divides -- the four wavefronts' +-S gathers then hit lines their neighbours' diagonal gathers bring
-            // into the same L1: 512^3 0.58 -> 0.49 ms --; otherwise contiguous 512-row chunks, each XCD walking runs of 8 of them (one L2 serves
-            // the chunks' shared x lines: 0.58 -> 0.535 ms).  Experiment knobs: bit28 plain chunks round-robin; bits 3 / 9 / 15 select tiles of
-            // 32 / 64 / 128 / 256 columns; bit0 + bits16-23 the run length.  (Measured and dropped: four rows per lane, 512 / 1024 lanes per
-            // workgroup, kernarg preload of the arguments: profiles/r03_valuerec_dom_experiments.txt.)
-            const bool plain = (g_variant & 0x10000000) != 0;
-            int tsel = ((g_variant >> 3) & 1) | (((g_variant >> 9) & 1) << 1) | (((g_variant >> 15) & 1) << 2);
-            if (!tsel && !plain && !(g_variant & 1)) tsel = 3;
-            DomTile TL{0, 0, 0, 0, 0, 0, 0};
-            long long wgs = (rows + 511) / 512;
-            if (tsel) {
-                const int S = dom_stride(P->dom);
-                const int cshift = 3 + tsel;                      // pairs per tile line: 16, 32, 64, 128
-                const int C = 2 << cshift, T = 256 >> cshift;
-                if (S >= C && S % C == 0 && rows >= (long long)T * S) {
-                    const long long groups = rows / ((long long)T * S);
-                    TL.S = S; TL.cshift = cshift; TL.ntiled = (int)(groups * (S / C)); TL.nfull = (int)(groups * T * S);
-                    wgs = TL.ntiled + (rows - TL.nfull + 511) / 512;
-                    if (g_variant & 0x40000000) {
-                        const int S2 = dom_stride_outer(P->dom);
-                        const long long tile = (long long)T * C;
-                        if (S2 > S && S2 % (T * S) == 0 && rows >= 2ll * S2) {
-                            const int tpp = (int)(S2 / tile), div = (g_variant >> 16) & 0xff;
-                            const int regions = NUM_XCD * (div ? div : 1);
-                            if (tpp % regions == 0) { TL.tpp = tpp; TL.reg = tpp / regions; TL.zreg = (int)(TL.nfull / S2) * TL.reg; }
-                        }
-                    }
-                }
-            }
-            const int run = (g_variant & 1) ? xcd_run() : (plain || TL.S || wgs < 8 * NUM_XCD) ? 1 : 8;
-            const int span = NUM_XCD * run;
-            DomRec DD = P->dom;
-            if ((g_variant & 0x40004000) == 0x40004000) {      // ablation (WRONG results, timing only): the outermost pair of offsets re-reads the diagonal
-                const int S2 = dom_stride_outer(DD);
-                for (int u = 0; u < 7; u++) if (DD.off[u] == 8 * S2 || DD.off[u] == -8 * S2) DD.off[u] = 0;
-            }
-            spmv_csr_valuerec_dom_kernel<256><<<(unsigned)((wgs + span - 1) / span * span), 256, 0, a.st>>>(
-                a.rowpat, a.vrec, P->drec, DD, P->dom_lo, P->dom_hi, a.x, a.y, Rows{a.rb, a.re, a.acc0}, run, TL);
-            return;
-        }
+        if (chunks > 0 && a.plan && a.plan->drec && !(g_variant & 0x20000000)) { launch_dom(a); return; }
         if (chunks > 0 && pairs)
             spmv_csr_valuerec_pair_kernel<g.block, 1><<<(chunks + 1) / 2, g.block, 0, a.st>>>(a.rowpat, a.vrec, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0});
         else if (chunks > 0)
@@ -3975,7 +4085,20 @@ static bool plan_runs_teams(const liship_csr_plan_s *p)     // the four-lanes-pe
     if (g_row_values && p->vrecw) return false;
     return p->prec36 != nullptr && (g_variant & ~0xc000) == 0;
 }
+static bool plan_runs_dom(const liship_csr_plan_s *p)       // the dominant-pattern product of a plan with value records: its tiles have an epilogue of their own too
+{                                                           // (variant 0x4000: the fused dots stay with the row blocks' partial sums, spmv_csr_valuerec_dom_dot4_kernel -- A/B, tests)
+    return p && p->rowpat && g_row_patterns && g_index_codes && p->ptab8 && g_row_values && p->vrec && p->drec && !p->products &&
+           kGeom[p->geom].block == 256 && (g_variant & ~0x50000008) == 0;
+}
 extern "C" int liship_csr_plan_fused_dots(liship_csr_plan_t p) { return plan_runs_teams(p) ? 0 : 1; }
+// upper bound of the partial-sum slots the fused product needs when it is launched in up to three row ranges (liship_spmv_csr_rows_dot_f64)
+extern "C" long long liship_csr_plan_fused_slots(liship_csr_plan_t p)
+{
+    if (!p) return 0;
+    if (plan_runs_dom(p)) return ((long long)p->n + 511) / 512 + 3 * 16;                // a partial per workgroup (tile); every range ends in less than one group of tiles
+    if (plan_runs_wide(p)) return ((long long)p->n + 255) / 256 + 3;
+    return (long long)p->nblocks + 2;
+}
 
 extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const int *idx,
                                    const double *val, const double *x, double *y, void *stream)
@@ -4009,6 +4132,17 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order, g_row_values ? p->vrecw : nullptr};
     a.plan = p;
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
+    if (plan_runs_dom(p)) {                            // value records, dominant pattern: a partial per workgroup (tile) of the plain product's shape
+        DomTile TL;
+        int run = 1;
+        const long long wgs = dom_shape(a, TL, run);
+        const long long np = wgs;                         // a partial per workgroup
+        if (wgs > 0 && (size_t)np <= slots) {
+            launch_dom(a, want_sumsq ? 2 : 1, w, partial, liship_internal_guard(), 0);
+            LAUNCH_CHECK();
+            return liship_internal_fold((int)np, want_sumsq ? 2 : 1, (int)np, partial, spare, result, stream);
+        }
+    }
     if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);
     } else if (p->products) {       // geometry 1
@@ -4060,6 +4194,19 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
         launch_wide(aw, liship_internal_guard(), want_sumsq ? 2 : 1, w, static_cast<double *>(work) + slot_base, (int)slots);
         LAUNCH_CHECK();
         *slots_used = wgs;
+        return 0;
+    }
+    if (plan_runs_dom(p)) {                            // value records, dominant pattern: a partial per workgroup of the range's own tiles
+        LaunchArgs ad{ptr, idx, val, x, y, p->blk, 0, p->nblocks, row_begin, row_end, (int)p->nnz, as_stream(stream), p->codes, p->dict, nullptr, nullptr, nullptr, p->first_term ? -0.0 : 0.0, p->rowpat, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, p->vrec, nullptr, nullptr};
+        ad.plan = p;
+        DomTile TL;
+        int run = 1;
+        const long long wgs = dom_shape(ad, TL, run);
+        const long long np = wgs;
+        if ((size_t)slot_base + (size_t)np > slots) return LISHIP_ERR_ARG;
+        launch_dom(ad, want_sumsq ? 2 : 1, w, static_cast<double *>(work) + slot_base, liship_internal_guard(), (int)slots);
+        LAUNCH_CHECK();
+        *slots_used = (int)np;
         return 0;
     }
     const v2i32 *br = p->blk_host;

@@ -401,7 +401,9 @@ def device_poisson_generator(lib, rank, world):
         lib.lis_solver_destroy(S)
     lib.liship_spmv_csr_set_variant(0)
     assert lib.dll.lis_amd_matrix_value_records(B) == 1
-    assert got[0][0] == got[0x4000][0] and 10 < got[0][0] < 500 and np.array_equal(got[0][1], got[0x4000][1])
+    # 0x4000: the fused dots as the row blocks' partial sums; 0: a partial per tile of the dominant-pattern product -- the same sums to rounding,
+    # so the same count (give or take one at the tolerance) and the same solution to the tolerance
+    assert abs(got[0][0] - got[0x4000][0]) <= 1 and 10 < got[0][0] < 500 and np.allclose(got[0][1], got[0x4000][1], rtol=0, atol=1e-9)
     assert np.allclose(got[0][1], xg[is_:ie], rtol=0, atol=1e-8)
 
 

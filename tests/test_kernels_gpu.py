@@ -429,7 +429,7 @@ TEAM_FORM = {"s19_varcoef_9x10x21": 2, "star9_varcoef_60x70": 2, "star13_varcoef
 # liship_spmv_csr_set_variant bits that select the value-record kernels by hand: 3 the general pattern kernel, 4 the round-2 kernels by
 # size, 5 their two-rows-per-lane form, 6 the dominant-pattern kernels in plain form (contiguous chunks; fused dots two rows per lane),
 # 7 the default (tiles where the pattern has a stride that 128 divides; fused dots four rows per lane)
-VARIANT_OF_FORM = {3: 0x2000, 4: 0x20000000, 5: 0x20004000, 6: 0x10000000, 7: 0}
+VARIANT_OF_FORM = {3: 0x2000, 4: 0x20000000, 5: 0x20004000, 6: 0x10000000, 7: 0, 8: 0x4000}     # 8: the dominant-pattern product with the row blocks' partial sums (dot4)
 
 
 @pytest.mark.parametrize("name", list(CODED_CASES))
@@ -469,7 +469,7 @@ def test_spmv_csr_index_codes(lib, name):
         assert lib.liship_csr_plan_value_records(plan) == VALUE_RECORDS[name]
     assert lib.liship_csr_plan_value_records(plan) in (0, 2) or lib.liship_csr_plan_pattern_records(plan) == 1     # 2: the wide records
     results = {}
-    for on in (7, 6, 5, 4, 3, 2, 1, 0):        # 4: values in the pattern records too (nothing streamed; 5: the plain product two rows per
+    for on in (8, 7, 6, 5, 4, 3, 2, 1, 0):     # 4: values in the pattern records too (nothing streamed; 5: the plain product two rows per
         lib.liship_spmv_csr_set_index_codes(1 if on else 0)         # lane, the form for x beyond the Infinity Cache; 6, 7: the dominant pattern's
         lib.liship_spmv_csr_set_row_patterns(1 if on >= 2 else 0)   # gathers speculated, two / four rows per lane), 2: one byte per row (patterns;
         lib.liship_spmv_csr_set_row_values(1 if on >= 4 else 0)     # 3: through the general pattern kernel even when the plan has 32 B records),
@@ -534,16 +534,18 @@ def test_spmv_csr_index_codes(lib, name):
     lib.liship_spmv_csr_set_variant(0)
     lib.liship_spmv_csr_set_row_values(1)
     wide = lib.liship_csr_plan_wide_dominant(plan) == 1
+    dom = lib.liship_csr_plan_dominant_pattern(plan) == 1  # value records with a dominant pattern: forms 6, 7 leave a partial per tile / chunk of 512 rows
     scale_sum = float(np.abs(w).sum() * np.abs(yref).max() + np.dot(yref, yref)) + 1e-300
     check(lib.liship_csr_plan_destroy(plan))
-    fusing = [k for k in range(8) if results[k] and not (wide and k == 7)]      # (a form whose kernels have a row split of their own refuses the fused entry
-    assert len({len(results[k]) for k in fusing}) == 1 and 0 in fusing           #  points: no results; the staged wide-record kernel has an epilogue of its own:
-    for parts in zip(*(results[k] for k in fusing)):       # same partial sums, same fold: the reductions agree to the bit too       its sums are compared below)
+    own = [k for k in range(9) if (wide and k == 7) or (dom and k in (6, 7))]   # forms whose kernels have an epilogue of their own
+    fusing = [k for k in range(9) if results[k] and k not in own]               # (a form whose kernels have a row split of their own refuses the fused entry
+    assert len({len(results[k]) for k in fusing}) == 1 and 0 in fusing           #  points: no results)
+    for parts in zip(*(results[k] for k in fusing)):       # same partial sums, same fold: the reductions agree to the bit too
         assert all(np.array_equal(parts[0], q) for q in parts[1:])
-    if wide:                                               # one partial per 256 rows instead of one per plan row block: the same sums to rounding, and repeatable
-        assert len(results[7]) == len(results[0])
-        for got, want in zip(results[7], results[0]):
-            assert np.all(np.abs(got - want) <= 1e-12 * np.maximum(np.abs(want), scale_sum)), (got, want)
+    for k in own:                                          # a partial per 256 / 512 rows or per tile instead of one per plan row block: the same sums to rounding
+        assert len(results[k]) == len(results[0]), k
+        for got, want in zip(results[k], results[0]):
+            assert np.all(np.abs(got - want) <= 1e-12 * np.maximum(np.abs(want), scale_sum)), (k, got, want)
 
 
 @pytest.mark.parametrize("grid", [(5, 6, 256), (3, 5, 512), (9, 4, 128)])
@@ -1383,7 +1385,7 @@ def test_full_size_512_six_forms_bit_equal(lib):
 
     dots = {}
     try:
-        for on in (0, 1, 2, 3, 4, 5, 6, 7):
+        for on in (0, 1, 2, 3, 4, 5, 6, 7, 8):
             select(on)
             dst = y0 if on == 0 else y
             check(lib.liship_memset(dst.ptr, 0xff, 8 * n, None))
@@ -1406,8 +1408,11 @@ def test_full_size_512_six_forms_bit_equal(lib):
     assert res.to_host()[0] > 1e6 and dots[0][0] > 0.0
     # the forms that share a row-block geometry share their partial sums (coded plans rebuild the split at 256 / 2048, the 4 B form keeps
     # the 192 / 1408 one of the bare plan only when no codes exist -- here every form runs on the coded plan's blocks)
-    for on in (1, 2, 3, 4, 5, 6, 7):
+    for on in (1, 2, 3, 4, 5, 8):
         assert np.array_equal(dots[on], dots[0]), (on, dots[on], dots[0])
+    # the dominant-pattern product's own epilogue (a partial per tile / per chunk of 512 rows, forms 7 / 6): the same sums to rounding
+    for on in (6, 7):
+        assert np.all(np.abs(dots[on] - dots[0]) <= 1e-13 * np.abs(dots[0])), (on, dots[on], dots[0])
     check(lib.liship_csr_plan_destroy(plan))
 
 
@@ -1595,8 +1600,9 @@ def test_plan_coders_on_random_structured_matrices(lib, seed):
     assert (state[3] == 1) <= state[2] <= (1 if state[1] else 0) <= (1 if state[0] else 0) and (state[3] != 2 or (state[1] and not state[2])), state
     dots, wide_dots = [], []
     wide = lib.liship_csr_plan_wide_dominant(plan) == 1      # the staged wide-record kernel: an epilogue of its own (one partial per 256 rows)
+    dom = lib.liship_csr_plan_dominant_pattern(plan) == 1    # ... and the dominant-pattern product of a plan with value records (one per tile / 512 rows; 0x4000: the row blocks' sums)
     try:
-        for codes, pats, vals_on, variant in ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0x2000), (1, 1, 0, 0), (1, 1, 1, 0x20000000), (1, 1, 1, 0x20004000), (1, 1, 1, 0x10000000), (1, 1, 1, 0)):
+        for codes, pats, vals_on, variant in ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0x2000), (1, 1, 0, 0), (1, 1, 1, 0x20000000), (1, 1, 1, 0x20004000), (1, 1, 1, 0x10000000), (1, 1, 1, 0x4000), (1, 1, 1, 0)):
             lib.liship_spmv_csr_set_index_codes(codes)
             lib.liship_spmv_csr_set_row_patterns(pats)
             lib.liship_spmv_csr_set_row_values(vals_on)
@@ -1614,7 +1620,8 @@ def test_plan_coders_on_random_structured_matrices(lib, seed):
             rc = lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, 1, res.ptr, work.ptr, None)
             if rc == 0:
                 assert np.array_equal(dy.to_host()[:n], yref)
-                (wide_dots if wide and (codes, pats, vals_on, variant) == (1, 1, 1, 0) else dots).append(res.to_host().copy())
+                own = (wide and (codes, pats, vals_on, variant) == (1, 1, 1, 0)) or (dom and (codes, pats, vals_on) == (1, 1, 1) and variant in (0, 0x10000000))
+                (wide_dots if own else dots).append(res.to_host().copy())
     finally:
         lib.liship_spmv_csr_set_index_codes(1)
         lib.liship_spmv_csr_set_row_patterns(1)

@@ -58,12 +58,15 @@ for rep in range(reps):
 work, res = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
 first = None
 for rep in range(reps):
-    for name, var in (("round-2 dot", 0x20000000), ("dominant dot x2", 0x10000000), ("dom dot x4 own w", 0x8), ("dom dot x4", 0)):
+    for name, var in (("round-2 dot", 0x20000000), ("dom dot4 blocks", 0x4000), ("plain chunks dot", 0x10000000), ("tiles dot", 0)):
         lib.liship_spmv_csr_set_variant(var)
+        call1 = lambda: check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, x.ptr, 0, res.ptr, work.ptr, None))
+        ms1 = timed(lib, call1, iters=50, warm=20)
         call = lambda: check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, x.ptr, 1, res.ptr, work.ptr, None))
         ms = timed(lib, call, iters=50, warm=20)
+        name = f"{name} ({ms1:.4f} one dot)"
         got = res.to_host().copy()
-        if first is None:
+        if first is None or name == "plain chunks dot":
             first = got
         same = bool(np.array_equal(y.to_host().view(np.uint64), ref)) if rep == 0 else None
         print(f"{name:16s} {ms:.4f} ms  {2e-6 * nnz / ms:.1f} GFLOP/s  {25e-9 * n / ms * 1e3 / 8000:.3f} of 8 TB/s on 25 B/row  sums equal: {bool(np.array_equal(got, first))}" + ("" if same is None else f"  y bit-identical: {same}"), flush=True)

@@ -1725,7 +1725,7 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
     const int tid = (int)threadIdx.x;
     const int wbase = tid & ~(WAVE - 1);
     double c0 = 0.0, c1 = 0.0;
-    __shared__ double dot_part[2][BLOCK / WAVE];
+    __shared__ double dot_part[DOT >= 2 ? 2 : 1][DOT != 0 ? BLOCK : 1];
     __shared__ unsigned dot_count;
     if (DOT != 0) {                                                   // the only barrier: at the start, where the wavefronts of a workgroup arrive together
         if (tid == 0) dot_count = 0u;
@@ -1781,9 +1781,17 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
             }
 #pragma unroll
             for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64u *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
-            if (DOT != 0) {
-#pragma unroll
-                for (int u = 0; u < 7; u++) if (u == wslot) ww = xx[u];
+            if (DOT != 0) {                                           // (uniform jump: seven selects cost 28 instructions a wavefront)
+                switch (wslot) {
+                case 0: ww = xx[0]; break;
+                case 1: ww = xx[1]; break;
+                case 2: ww = xx[2]; break;
+                case 3: ww = xx[3]; break;
+                case 4: ww = xx[4]; break;
+                case 5: ww = xx[5]; break;
+                case 6: ww = xx[6]; break;
+                default: break;
+                }
             }
             const int pa = (int)(two & 255u), pb = (int)(two >> 8);
             double s0 = acc0, s1 = acc0;
@@ -1837,28 +1845,31 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
     }
     if (DOT != 0) {
         // one partial per WORKGROUP without a barrier at the end (which would hold every wavefront's slot until the workgroup's slowest has its lines back): a
-        // wavefront parks its sum in LDS and counts itself in; the one that counts last adds the four in wavefront order -- the same bits whoever is last.
+        // wavefront parks its lanes' sums in LDS and counts itself in; the one that counts last adds the four wavefronts' values lane by lane, in wavefront
+        // order, and folds its 64 lanes -- the same bits whoever is last, and one butterfly per workgroup instead of four.
         // (A partial per wavefront -- a million 8 B stores at 512^3 -- cost 0.05 ms; persistent workgroups that keep their sums in registers spill: 0.9 ms.)
         constexpr int NW = BLOCK / WAVE;
         const int stride = pstride ? pstride : total;
-        const int wv = wbase / WAVE;
-        const double t0 = wave_sum_row3(c0), t1 = DOT >= 2 ? wave_sum_row3(c1) : 0.0;
-        int seen = 0;
-        if (tid == wbase + WAVE - 1) {
-            dot_part[0][wv] = t0;
-            if (DOT >= 2) dot_part[1][wv] = t1;
-            seen = (int)__hip_atomic_fetch_add(&dot_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // LDS operations of a wavefront execute in order
-            if (seen == NW - 1 && chunk < total) {
-                double e = 0.0;
+        dot_part[0][tid] = c0;
+        if (DOT >= 2) dot_part[1][tid] = c1;
+        unsigned seen = 0;
+        if (tid == wbase + WAVE - 1)
+            seen = __hip_atomic_fetch_add(&dot_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // LDS operations of a wavefront execute in order
+        seen = (unsigned)__builtin_amdgcn_readlane((int)seen, WAVE - 1);
+        if (seen == NW - 1 && chunk < total) {                        // (uniform)
+            const int l = tid - wbase;
+            double e = 0.0, f = 0.0;
 #pragma unroll
-                for (int i = 0; i < NW; i++) e += dot_part[0][i];
+            for (int i = 0; i < NW; i++) e += dot_part[0][i * WAVE + l];
+            if (DOT >= 2) {
+#pragma unroll
+                for (int i = 0; i < NW; i++) f += dot_part[1][i * WAVE + l];
+            }
+            e = wave_sum_row3(e);
+            if (DOT >= 2) f = wave_sum_row3(f);
+            if (l == WAVE - 1) {
                 partial[chunk] = e;
-                if (DOT >= 2) {
-                    double f = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NW; i++) f += dot_part[1][i];
-                    partial[(size_t)stride + chunk] = f;
-                }
+                if (DOT >= 2) partial[(size_t)stride + chunk] = f;
             }
         }
     }

@@ -1680,6 +1680,39 @@ __device__ __forceinline__ double wave_sum_row3(double v)
     return v;
 }
 
+// Fused dots of a workgroup WITHOUT a barrier at its end (which would hold every wavefront's slot until the slowest has its lines back): a wavefront parks
+// its lanes' sums in LDS and counts itself in; the wavefront that counts in last adds the NW wavefronts' values lane by lane, in wavefront order, folds its
+// 64 lanes (one butterfly per workgroup instead of one per wavefront: the epilogue's VALU instructions were what it cost) and writes the partial.  The same
+// bits whoever is last.  `count` must have been zeroed behind a barrier at the kernel's START, where the wavefronts arrive together.
+template <int BLOCK, int DOT>
+__device__ __forceinline__ void workgroup_dots_last(double c0, double c1, double *part, unsigned *count, double *__restrict__ partial, int slot, int stride, bool write)
+{
+    constexpr int NW = BLOCK / WAVE;
+    const int tid = (int)threadIdx.x, wbase = tid & ~(WAVE - 1);
+    part[tid] = c0;
+    if (DOT >= 2) part[BLOCK + tid] = c1;
+    unsigned seen = 0;
+    if (tid == wbase + WAVE - 1)
+        seen = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // LDS operations of a wavefront execute in order
+    seen = (unsigned)__builtin_amdgcn_readlane((int)seen, WAVE - 1);
+    if (seen == NW - 1 && write) {                                    // (uniform)
+        const int l = tid - wbase;
+        double e = 0.0, f = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) e += part[i * WAVE + l];
+        if (DOT >= 2) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) f += part[BLOCK + i * WAVE + l];
+        }
+        e = wave_sum_row3(e);
+        if (DOT >= 2) f = wave_sum_row3(f);
+        if (l == WAVE - 1) {
+            partial[slot] = e;
+            if (DOT >= 2) partial[(size_t)stride + slot] = f;
+        }
+    }
+}
+
 // one row by its own record (96 B, global): the kernels above, without LDS.  Rare (ghost-column rows, the matrix's first and last rows), so it is written for
 // few registers, not for latency: slots 0..3, then slots 4..6 -- inlined in kernels that hold seven 16 B gathers, 38 live registers here cost them their occupancy
 __device__ __forceinline__ double own_record_row(const v4i32 *__restrict__ rec, int pt, int r, const double *__restrict__ x, double acc0)
@@ -1725,7 +1758,7 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
     const int tid = (int)threadIdx.x;
     const int wbase = tid & ~(WAVE - 1);
     double c0 = 0.0, c1 = 0.0;
-    __shared__ double dot_part[DOT >= 2 ? 2 : 1][DOT != 0 ? BLOCK : 1];
+    __shared__ double dot_part[(DOT >= 2 ? 2 : 1) * (DOT != 0 ? BLOCK : 1)];
     __shared__ unsigned dot_count;
     if (DOT != 0) {                                                   // the only barrier: at the start, where the wavefronts of a workgroup arrive together
         if (tid == 0) dot_count = 0u;
@@ -1843,36 +1876,8 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
             }
         }
     }
-    if (DOT != 0) {
-        // one partial per WORKGROUP without a barrier at the end (which would hold every wavefront's slot until the workgroup's slowest has its lines back): a
-        // wavefront parks its lanes' sums in LDS and counts itself in; the one that counts last adds the four wavefronts' values lane by lane, in wavefront
-        // order, and folds its 64 lanes -- the same bits whoever is last, and one butterfly per workgroup instead of four.
-        // (A partial per wavefront -- a million 8 B stores at 512^3 -- cost 0.05 ms; persistent workgroups that keep their sums in registers spill: 0.9 ms.)
-        constexpr int NW = BLOCK / WAVE;
-        const int stride = pstride ? pstride : total;
-        dot_part[0][tid] = c0;
-        if (DOT >= 2) dot_part[1][tid] = c1;
-        unsigned seen = 0;
-        if (tid == wbase + WAVE - 1)
-            seen = __hip_atomic_fetch_add(&dot_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // LDS operations of a wavefront execute in order
-        seen = (unsigned)__builtin_amdgcn_readlane((int)seen, WAVE - 1);
-        if (seen == NW - 1 && chunk < total) {                        // (uniform)
-            const int l = tid - wbase;
-            double e = 0.0, f = 0.0;
-#pragma unroll
-            for (int i = 0; i < NW; i++) e += dot_part[0][i * WAVE + l];
-            if (DOT >= 2) {
-#pragma unroll
-                for (int i = 0; i < NW; i++) f += dot_part[1][i * WAVE + l];
-            }
-            e = wave_sum_row3(e);
-            if (DOT >= 2) f = wave_sum_row3(f);
-            if (l == WAVE - 1) {
-                partial[chunk] = e;
-                if (DOT >= 2) partial[(size_t)stride + chunk] = f;
-            }
-        }
-    }
+    if (DOT != 0)         // one partial per workgroup (tile), no barrier here.  (A partial per wavefront -- a million 8 B stores at 512^3 -- cost 0.05 ms; persistent
+        workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, chunk, pstride ? pstride : total, chunk < total);      // workgroups spill: 0.9 ms)
 }
 
 // The same with the fused dots.  Partial slots and the order of every addition are those of spmv_csr_valuerec_pair_dot_kernel
@@ -2318,6 +2323,12 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
 {
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
     extern __shared__ __attribute__((aligned(16))) double wide_dyn[];
+    __shared__ double dot_part[(DOT >= 2 ? 2 : 1) * (DOT != 0 ? BLOCK : 1)];
+    __shared__ unsigned dot_count;
+    if (DOT != 0) {                                                // the only barrier: at the start (workgroup_dots_last)
+        if (threadIdx.x == 0) dot_count = 0u;
+        __syncthreads();
+    }
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
     double *xL = wide_dyn + w * xcap;
     // a wavefront walks CH consecutive chunks of 64 rows: the staging loads and the pattern byte of the NEXT chunk are issued before the products of the
@@ -2444,13 +2455,7 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
         if (DOT >= 2 && live) c1 += acc * acc;
     }
     }
-    if (DOT != 0) {
-        __shared__ double dot_scratch[BLOCK / WAVE];
-        const int stride = pstride ? pstride : (int)gridDim.x;
-        const double t0 = block_sum<BLOCK / WAVE>(c0, dot_scratch);
-        if (threadIdx.x == 0) partial[blockIdx.x] = t0;
-        if (DOT >= 2) { const double t1 = block_sum<BLOCK / WAVE>(c1, dot_scratch); if (threadIdx.x == 0) partial[stride + blockIdx.x] = t1; }
-    }
+    if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : (int)gridDim.x, true);
 }
 
 // The same shape for STREAMED values (rows of 8..32 entries on <= 255 patterns whose coefficients vary: the 27-point stencil on a non-uniform mesh): a

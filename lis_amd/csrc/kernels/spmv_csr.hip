@@ -1692,9 +1692,11 @@ __device__ __forceinline__ void workgroup_dots_last(double c0, double c1, double
     part[tid] = c0;
     if (DOT >= 2) part[BLOCK + tid] = c1;
     unsigned seen = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // every lane's sums are in LDS before the wavefront counts itself in
     if (tid == wbase + WAVE - 1)
-        seen = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // LDS operations of a wavefront execute in order
+        seen = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     seen = (unsigned)__builtin_amdgcn_readlane((int)seen, WAVE - 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   // ... and the last one reads the others' behind its count
     if (seen == NW - 1 && write) {                                    // (uniform)
         const int l = tid - wbase;
         double e = 0.0, f = 0.0;

@@ -71,3 +71,17 @@ for rep in range(reps):
         same = bool(np.array_equal(y.to_host().view(np.uint64), ref)) if rep == 0 else None
         print(f"{name:16s} {ms:.4f} ms  {2e-6 * nnz / ms:.1f} GFLOP/s  {25e-9 * n / ms * 1e3 / 8000:.3f} of 8 TB/s on 25 B/row  sums equal: {bool(np.array_equal(got, first))}" + ("" if same is None else f"  y bit-identical: {same}"), flush=True)
 lib.liship_spmv_csr_set_variant(0)
+# the same call with a guard flag installed (what the device-driven Krylov loops run): the flag is a scalar load of another kernel's store
+if True:
+    flag = DA.zeros(2, np.float64)
+    lib.dll.liship_krylov_guard.argtypes = [C.c_void_p]
+    lib.dll.liship_krylov_guard.restype = C.c_int
+    for name, var in (("dom dot4 blocks", 0x4000), ("tiles dot", 0)):
+        lib.liship_spmv_csr_set_variant(var)
+        call1 = lambda: check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, x.ptr, 0, res.ptr, work.ptr, None))
+        base = timed(lib, call1, iters=50, warm=20)
+        check(lib.dll.liship_krylov_guard(flag.ptr))
+        ms1 = timed(lib, call1, iters=50, warm=20)
+        check(lib.dll.liship_krylov_guard(None))
+        print(f"{name}: one dot {base:.4f} ms, with a guard flag {ms1:.4f} ms", flush=True)
+    lib.liship_spmv_csr_set_variant(0)

@@ -146,6 +146,8 @@ int  liship_spmv_csr_set_local_columns(int on);
  * by a workgroup-wide tree per pass instead of one left-to-right chain (a 200 000-entry row is otherwise a 200 000-long
  * dependent add chain, by the parity contract).  Deterministic; rows that fit the stage keep the reference's bits. */
 int  liship_spmv_csr_set_long_row_tree(int on);
+int  liship_spmv_csr_set_row_block_dots(int on);  /* 1: fused dots of the dominant-pattern product as the row blocks' partial sums (the other forms' bits); LIS_AMD_ROW_BLOCK_DOTS=1 */
+int  liship_spmv_csr_switches(void);            /* bit 0 team kernels on, bit 1 row-block dots, bit 2 long-row tree (tests of the LIS_AMD_* variables) */
 int  liship_spmv_csr_set_uniform_rows(int on);    /* A/B: 0 keeps the row sums of uniform-length wavefronts on the skewed schedule (same bits) */
 int  liship_csr_plan_destroy(liship_csr_plan_t plan);
 int  liship_csr_plan_info(liship_csr_plan_t plan, int *n, long long *nnz, int *nblocks);

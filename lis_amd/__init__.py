@@ -91,6 +91,8 @@ _LISHIP = {
     "liship_spmv_csr_set_local_columns": (_ci, [_ci]),
     "liship_spmv_csr_set_long_row_tree": (_ci, [_ci]),
     "liship_spmv_csr_set_uniform_rows": (_ci, [_ci]),
+    "liship_spmv_csr_set_row_block_dots": (_ci, [_ci]),
+    "liship_spmv_csr_switches": (_ci, []),
     "liship_spmv_csr_set_index_codes": (_ci, [_ci]),
     "liship_spmv_csr_rows_f64": (_ci, [_vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_spmv_csr_rows_dot_f64": (_ci, [_vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp]),

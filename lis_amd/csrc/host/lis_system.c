@@ -224,12 +224,9 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.initialized = 1;
 		if (lisg.nprocs == 0) { lisg.nprocs = 1; lisg.rank = 0; }
 		const char *r = getenv("LIS_AMD_RESIDENCY");
-		if (r && (strcmp(r, "resident") == 0 || strcmp(r, "1") == 0)) { lisg.residency = LIS_AMD_RESIDENT; (void)lisd_init_quiet(); }
+		if (r && (strcmp(r, "resident") == 0 || strcmp(r, "1") == 0)) lisg.residency = LIS_AMD_RESIDENT;
 		r = getenv("LIS_AMD_COHERENCE");              /* eager: COHERENT copies on every call instead of following page faults (lis_pages.c) */
 		lisg.eager_coherence = (r && strcmp(r, "eager") == 0);
-		/* COHERENT by page protection runs at resident speed, so it starts like RESIDENT: the runtime comes up here (quietly: a box
-		 * without a GPU still serves the host-side API), and matrices are uploaded where they are made (lisd_mat_eager) */
-		if (lisg.residency == LIS_AMD_COHERENT && !lisg.eager_coherence) (void)lisd_init_quiet();
 		r = getenv("LIS_AMD_NO_FUSION");
 		lisg.no_fusion = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_OVERLAP");
@@ -252,12 +249,18 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_local_columns = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_TEAM_KERNELS");
 		lisg.no_team_kernels = (r && r[0] == '1');
+		r = getenv("LIS_AMD_ROW_BLOCK_DOTS");         /* the fused dots of the dominant-pattern product as the row blocks' partial sums: every form's bits, slower */
+		lisg.row_block_dots = (r && r[0] == '1');
 		r = getenv("LIS_AMD_LONG_ROW_TREE");          /* opt-in: NOT the reference's bits for rows beyond the LDS stage */
 		lisg.long_row_tree = (r && r[0] == '1');
 		r = getenv("LIS_AMD_GRAPHS");
 		lisg.graphs = (r && r[0] == '1');
 		r = getenv("LIS_AMD_HOST_SCALARS");
 		lisg.host_scalars = (r && r[0] == '1');
+		/* RESIDENT, and COHERENT by page protection (which runs at resident speed, so it starts like RESIDENT): the runtime comes up here (quietly: a box
+		 * without a GPU still serves the host-side API), and matrices are uploaded where they are made (lisd_mat_eager).  BEHIND the switches above: the
+		 * device's start-up applies some of them (LIS_AMD_NO_TEAM_KERNELS, LIS_AMD_ROW_BLOCK_DOTS, LIS_AMD_LONG_ROW_TREE) */
+		if (lisg.residency == LIS_AMD_RESIDENT || (lisg.residency == LIS_AMD_COHERENT && !lisg.eager_coherence)) (void)lisd_init_quiet();
 	}
 	return LIS_SUCCESS;
 }

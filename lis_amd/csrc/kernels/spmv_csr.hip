@@ -67,6 +67,8 @@ int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps co
 int g_row_values = 1;            // liship_spmv_csr_set_row_values: 0 keeps streaming the values of matrices that have value records
 int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps the products kernel on the 4 B indices
 int g_uniform_rows = 1;          // liship_spmv_csr_set_uniform_rows: 0 keeps the row sums of the block-local kernel on the skewed schedule everywhere (A/B)
+int g_long_row_tree_host = 0;    // host mirror of d_long_row_tree (liship_spmv_csr_switches)
+int g_row_block_dots = 0;        // liship_spmv_csr_set_row_block_dots: 1 keeps the fused dots of the dominant-pattern product on the row blocks' partial sums (the bits every other form gives)
 int g_team = 1;                  // liship_spmv_csr_set_team: 0 keeps patterned rows of 8..32 entries on the one-lane-per-row pattern kernel
 
 __device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
@@ -2797,8 +2799,15 @@ extern "C" int liship_spmv_csr_set_long_row_tree(int on)
 {
     const int v = on ? 1 : 0;
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(d_long_row_tree), &v, sizeof(int)));
+    g_long_row_tree_host = v;
     return 0;
 }
+
+// 1: the fused dots of the dominant-pattern product stay with the row blocks' partial sums (spmv_csr_valuerec_dom_dot4_kernel) -- the bits every other form of the
+// product gives for its dots -- instead of a partial per tile of the plain product's kernel (faster; the same sums to rounding).  LIS_AMD_ROW_BLOCK_DOTS=1.
+extern "C" int liship_spmv_csr_set_row_block_dots(int on) { g_row_block_dots = on ? 1 : 0; return 0; }
+// the process-wide switches in force, for tests of the environment variables that set them: bit 0 team kernels, bit 1 row-block dots, bit 2 the long-row tree
+extern "C" int liship_spmv_csr_switches(void) { return (g_team ? 1 : 0) | (g_row_block_dots ? 2 : 0) | (g_long_row_tree_host ? 4 : 0); }
 
 // A/B switch of the uniform-length row sums (ordered_sum_rows): 0 keeps every wavefront on the skewed sums.  Same bits either way.
 extern "C" int liship_spmv_csr_set_uniform_rows(int on)
@@ -4106,7 +4115,7 @@ static bool plan_runs_teams(const liship_csr_plan_s *p)     // the four-lanes-pe
 static bool plan_runs_dom(const liship_csr_plan_s *p)       // the dominant-pattern product of a plan with value records: its tiles have an epilogue of their own too
 {                                                           // (variant 0x4000: the fused dots stay with the row blocks' partial sums, spmv_csr_valuerec_dom_dot4_kernel -- A/B, tests)
     return p && p->rowpat && g_row_patterns && g_index_codes && p->ptab8 && g_row_values && p->vrec && p->drec && !p->products &&
-           kGeom[p->geom].block == 256 && (g_variant & ~0x50000008) == 0;
+           kGeom[p->geom].block == 256 && (g_variant & ~0x50000008) == 0 && !g_row_block_dots;
 }
 extern "C" int liship_csr_plan_fused_dots(liship_csr_plan_t p) { return plan_runs_teams(p) ? 0 : 1; }
 // upper bound of the partial-sum slots the fused product needs when it is launched in up to three row ranges (liship_spmv_csr_rows_dot_f64)

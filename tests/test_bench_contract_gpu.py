@@ -28,7 +28,7 @@ def test_bench_line_has_the_contract_fields():
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # the roofline prices the bytes the TIMED kernel moves over its own HIP-event time: a physical fraction; the contract's count is beside it
-    assert 0 < r["frac"] <= 1.0 and abs(r["achieved"] - r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 0.01 * r["achieved"] + 0.1
+    assert 0 < r["frac"] <= 1.0 and abs(r["achieved"] - r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= (0.01 + 0.00006 / r["kernel_ms"]) * r["achieved"] + 0.1     # (kernel_ms is printed to 4 decimals: 1 % of a 4 us kernel)
     assert r["contract_bytes_per_launch"] == 12 * d["config"]["nnz"] + 20 * d["config"]["n"] + 4 and r["contract_frac"] > 0 and "applies_to" in r
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.001
     assert d["nontrivial_x"]["value"] > 0 and 0 < d["nontrivial_x"]["frac"] <= 1.0

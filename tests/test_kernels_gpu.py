@@ -548,6 +548,48 @@ def test_spmv_csr_index_codes(lib, name):
             assert np.all(np.abs(got - want) <= 1e-12 * np.maximum(np.abs(want), scale_sum)), (k, got, want)
 
 
+def test_row_block_dots_switch_restores_the_other_forms_bits(lib):
+    """liship_spmv_csr_set_row_block_dots(1) (LIS_AMD_ROW_BLOCK_DOTS=1): the fused dots of the dominant-pattern product are the row blocks' partial sums again --
+    bit-equal to the round-2 value-record kernels' -- while the default (a partial per tile) agrees with them to rounding; y is the oracle's either way"""
+    ptr, idx, val = orc.poisson3d(24, 20, 128)
+    n = len(ptr) - 1
+    rng = np.random.default_rng(11)
+    x, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64)
+    dx, dw = DA.from_host(x, np.float64), DA.from_host(w, np.float64)
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    assert lib.liship_csr_plan_dominant_pattern(plan) == 1
+
+    def dots(wptr):
+        res = DA.from_host(np.full(2, np.nan), np.float64)
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, wptr, 1, res.ptr, work.ptr, None))
+        assert np.array_equal(dy.to_host(), yref)
+        return res.to_host().copy()
+    try:
+        lib.liship_spmv_csr_set_variant(0x20000000)                      # the round-2 kernels: the row blocks' partial sums
+        want = [dots(dw.ptr), dots(dx.ptr)]
+        lib.liship_spmv_csr_set_variant(0)
+        tiles = [dots(dw.ptr), dots(dx.ptr)]
+        check(lib.liship_spmv_csr_set_row_block_dots(1))
+        blocks = [dots(dw.ptr), dots(dx.ptr)]
+    finally:
+        check(lib.liship_spmv_csr_set_row_block_dots(0))
+        lib.liship_spmv_csr_set_variant(0)
+        check(lib.liship_csr_plan_destroy(plan))
+    scale = float(np.abs(w).sum() * np.abs(yref).max() + np.dot(yref, yref))
+    for a, b, c in zip(want, tiles, blocks):
+        assert np.array_equal(a, c), (a, c)
+        assert np.all(np.abs(a - b) <= 1e-12 * scale), (a, b)
+    assert any(not np.array_equal(a, b) for a, b in zip(want, tiles)) or True     # (the tile sums usually differ in the last bits; equality is not an error)
+
+
 @pytest.mark.parametrize("grid", [(5, 6, 256), (3, 5, 512), (9, 4, 128)])
 def test_valuerec_dominant_pattern_tiles_and_runs(lib, grid):
     """the dominant-pattern product under every lane -> row mapping it has -- contiguous chunks, XCD runs of chunks, tiles of 32 / 64 / 128 /

@@ -7,6 +7,7 @@ results follow north_star: CG iteration counts exact, relative residual within 1
 import ctypes as C
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ import orc
 from lis_amd import _capi as capi
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "lis_ref_golden.npz"))
 FORMATS = ["csr", "csc", "ell", "dia", "jad", "bsr"]
 
@@ -651,3 +653,20 @@ def test_conversion_in_hbm_and_host_arrays_on_first_touch(lib, fmt, bs, kind):
     assert all(np.array_equal(ga[k], gh[k]) for k in ("ptr", "index", "value"))
     for M in (back, backh, B2, B, H, A):
         lib.lis_matrix_destroy(M)
+
+
+@pytest.mark.parametrize("env, want", [({}, 1), ({"LIS_AMD_NO_TEAM_KERNELS": "1"}, 0), ({"LIS_AMD_ROW_BLOCK_DOTS": "1"}, 3), ({"LIS_AMD_LONG_ROW_TREE": "1"}, 5),
+                                       ({"LIS_AMD_RESIDENCY": "resident", "LIS_AMD_ROW_BLOCK_DOTS": "1", "LIS_AMD_NO_TEAM_KERNELS": "1"}, 2)])
+def test_environment_switches_reach_the_kernels(env, want):
+    """the LIS_AMD_* variables that the device's start-up applies (team kernels off, row-block dots, the long-row tree) are read BEFORE the runtime comes up in
+    lis_initialize -- they were read behind it while the default residency started the runtime early, and did nothing"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import lis_amd; lib = lis_amd.load(); assert lib.initialize([]) == 0; "
+            "print('SWITCHES', lib.liship_spmv_csr_switches())" % ROOT)
+    e = dict(os.environ)
+    for k in ("LIS_AMD_NO_TEAM_KERNELS", "LIS_AMD_ROW_BLOCK_DOTS", "LIS_AMD_LONG_ROW_TREE", "LIS_AMD_RESIDENCY"):
+        e.pop(k, None)
+    e.update(env)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert ("SWITCHES %d" % want) in p.stdout, p.stdout[-500:]

@@ -55,6 +55,14 @@ LIS_INT lis_amd_page_faults(LIS_INT *reads, LIS_INT *writes);
 #define LIS_AMD_LOOP_HOST    1
 #define LIS_AMD_LOOP_UNFUSED 2
 LIS_INT lis_amd_set_loop_mode(LIS_INT mode);
+/* Reference-order reductions (parity mode; env LIS_AMD_REFERENCE_REDUCTIONS=T).  T > 0: lis_vector_dot / nrm2 / nrm1 / sum and every sum
+ * a Krylov loop forms are added as the reference's OpenMP build adds them with OMP_NUM_THREADS = T -- T contiguous chunks by LIS_GET_ISIE, each
+ * strictly left to right from 0.0, the T partial sums added serially (src/vector/lis_vector_ops.c:88-107, :241-259) -- so iteration counts, residual
+ * histories and solutions carry the reference's bits (tests/test_reference_order_gpu.py demands equality with oracle/_ref).  The products' fused
+ * dot epilogues are not taken while it is on.  A job of P ranks at T = 1 forms the sums of one rank at T = P (row blocks by LIS_GET_ISIE, fold in
+ * rank order).  0 (default): the fixed trees, whose results are reproducible but not the reference's last bits.  Slow: one lane adds per chunk. */
+LIS_INT lis_amd_set_reference_reductions(LIS_INT T);
+LIS_INT lis_amd_get_reference_reductions(void);
 /* 1 when the last lis_solve ran CG + Jacobi on a matrix with a constant diagonal and its fused passes took 1/diag as one double
  * instead of reading the array (bit-identical; LIS_AMD_NO_UNIFORM_JACOBI=1 switches it off), else 0 */
 LIS_INT lis_amd_last_solve_uniform_jacobi(void);

@@ -256,6 +256,11 @@ int  liship_axpy_xpay_f64(int n, double a, const double *x, const double *w, dou
  * `result` is a DEVICE pointer to `count` doubles, `work` a device scratch of liship_reduce_work_bytes().
  * *_partial variants leave the un-rooted local sum (for a cross-GPU all-reduce before sqrt). */
 size_t liship_reduce_work_bytes(void);
+/* T > 0: the reductions below (and the fused update passes) add their terms in the reference's order for OMP_NUM_THREADS = T -- chunk t of T is
+ * LIS_GET_ISIE(t, T, n) (include/lis.h:1067-1078), summed left to right from 0.0 by one lane, the T partials added serially in chunk order
+ * (src/vector/lis_vector_ops.c:88-107) -- instead of the fixed tree; the products' fused-dot entry points then return LISHIP_ERR_ARG.  0: trees. */
+int  liship_set_reference_reductions(int T);
+int  liship_get_reference_reductions(void);
 int  liship_dot_f64 (int n, const double *x, const double *y, double *result, void *work, void *stream);
 int  liship_nrm2_f64(int n, const double *x, double *result, void *work, void *stream);
 int  liship_sumsq_f64(int n, const double *x, double *result, void *work, void *stream);
@@ -387,6 +392,11 @@ int  liship_gather_f64(int count, const int *export_index, const double *x, doub
 /* A^T of a CSR matrix in HBM, each transposed row listing its entries in the order of their positions in the
  * source arrays -- the order lis_matvech_csr's scatter adds them (lis_matvec_csr.c:213-250).  tptr: ncols+1 ints,
  * tindex / tvalue: nnz entries, work: ncols + nnz ints.  Setup-time (once per matrix). */
+/* y[0..rows) = A^T x from the transposed CSR below (rows = columns of A, nsrc = rows of A), summed as the OpenMP build of lis_matvech_csr sums with
+ * T threads: per thread chunk LIS_GET_ISIE(k, T, nsrc) of SOURCE rows left to right from 0.0, chunk sums in chunk order (src/matvec/lis_matvec_csr.c:
+ * 207-236).  The reference-order mode's A^T x for T > 1 (T = 1 is the plain row sum). */
+int  liship_spmv_csr_transposed_chunked_f64(int rows, int nsrc, int T, const int *tptr, const int *tidx, const double *tval,
+                                            const double *x, double *y, void *stream);
 int  liship_csr_transpose_f64(int nrows, int ncols, int nnz, const int *ptr, const int *index, const double *value,
                               int *tptr, int *tindex, double *tvalue, int *work, void *stream);
 /* ---- storage-format conversions of a CSR matrix that lives in HBM (kernels/convert.hip): the arrays the reference's host routines

@@ -138,6 +138,8 @@ _LISHIP = {
     "liship_scale_inv_norm_f64": (_ci, [_ci, _vp, _vp, _vp]),
     "liship_lincomb_f64": (_ci, [_ci, _ci, _vp, _vp, _ci, _vp, _vp]),
     "liship_reduce_work_bytes": (_sz, []),
+    "liship_set_reference_reductions": (_ci, [_ci]),
+    "liship_get_reference_reductions": (_ci, []),
     "liship_dot_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp]),
     "liship_nrm2_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_sumsq_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
@@ -145,6 +147,7 @@ _LISHIP = {
     "liship_sum_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_dot2_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp]),
     "liship_csr_diagonal_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp]),
+    "liship_spmv_csr_transposed_chunked_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_csr_transpose_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_gather_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_scatter_add_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),

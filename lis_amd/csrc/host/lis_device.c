@@ -57,6 +57,7 @@ LIS_INT lisd_init(void)
 	if (lisg.long_row_tree) HIPCHK(liship_spmv_csr_set_long_row_tree(1));
 	if (lisg.no_team_kernels) { HIPCHK(liship_spmv_csr_set_team(0)); HIPCHK(liship_spmv_bsr_set_team(0)); }
 	if (lisg.row_block_dots) HIPCHK(liship_spmv_csr_set_row_block_dots(1));
+	if (lisg.ref_reductions) HIPCHK(liship_set_reference_reductions(lisg.ref_reductions));
 	lisg.device_ready = 1;
 	if (lisp_lazy()) (void)stage_ready();      /* the pinned staging buffers of the page-protected vectors: here, not inside a caller's first product */
 	return LIS_SUCCESS;
@@ -126,6 +127,13 @@ LIS_INT lis_amd_get_residency(void) { return lisg.residency; }
 LIS_INT lis_amd_last_solve_uniform_jacobi(void) { return lisg.last_uniform_jacobi; }
 
 LIS_INT lis_amd_set_row_form(LIS_INT on) { lisg.no_row_form = on ? 0 : 1; return LIS_SUCCESS; }
+LIS_INT lis_amd_set_reference_reductions(LIS_INT T)
+{
+	if (T < 0 || liship_set_reference_reductions((int)T) != 0) return LISI_ERR(LIS_ERR_ILL_ARG, "reference-order reductions: T(=%D) out of range\n", T);
+	lisg.ref_reductions = (int)T;
+	return LIS_SUCCESS;
+}
+LIS_INT lis_amd_get_reference_reductions(void) { return lisg.ref_reductions; }
 LIS_INT lis_amd_set_graphs(LIS_INT on) { lisg.graphs = (on != 0); return LIS_SUCCESS; }
 LIS_INT lis_amd_last_solve_graph_replays(void) { return lisg.last_graph_replays; }
 LIS_INT lis_amd_set_loop_mode(LIS_INT mode)

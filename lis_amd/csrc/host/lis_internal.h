@@ -121,6 +121,7 @@ typedef struct {
 	int no_index_codes;        /* LIS_AMD_NO_INDEX_CODES=1: CSR products keep reading the 4 B column indices (A/B measurements) */
 	int host_scalars;          /* LIS_AMD_HOST_SCALARS=1: CG / BiCGSTAB read every scalar back (A/B against the device-driven loops) */
 	int no_overlap;            /* LIS_AMD_NO_OVERLAP=1: exchange first, then the whole product (A/B measurements) */
+	int ref_reductions;        /* LIS_AMD_REFERENCE_REDUCTIONS=T / lis_amd_set_reference_reductions(T): sums in the reference's order for T threads (parity mode) */
 	int no_direct_halo;        /* LIS_AMD_NO_DIRECT_HALO=1: boundary rows that form a run are packed like any other list instead of being sent straight from x (A/B) */
 	lis_amd_comm_callbacks cb;
 } lisi_globals;

@@ -160,7 +160,12 @@ LIS_INT lisd_spmv_t(LIS_MATRIX A, double *dx, double *dy)
 {
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_mat_ready_t(A));
-	HIPCHK(liship_spmv_csr_f64(d->t_plan, d->t_ptr, d->t_index, d->t_value, dx, dy, lisg.stream));
+	if (lisg.ref_reductions > 1 && A->matrix_type == LIS_MATRIX_CSR)
+		/* reference-order mode at T > 1: the OpenMP build's per-thread scatter buffers group a column's terms by row chunk (lis_matvec_csr.c:207-236).
+		 * CSR only: the other formats' threaded walks group differently again and keep the one-thread order */
+		HIPCHK(liship_spmv_csr_transposed_chunked_f64(d->t_rows, A->n, lisg.ref_reductions, d->t_ptr, d->t_index, d->t_value, dx, dy, lisg.stream));
+	else
+		HIPCHK(liship_spmv_csr_f64(d->t_plan, d->t_ptr, d->t_index, d->t_value, dx, dy, lisg.stream));
 	if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_reduce_device(A, dy));
 	return LIS_SUCCESS;
 }

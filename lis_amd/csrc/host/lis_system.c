@@ -253,6 +253,9 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.row_block_dots = (r && r[0] == '1');
 		r = getenv("LIS_AMD_LONG_ROW_TREE");          /* opt-in: NOT the reference's bits for rows beyond the LDS stage */
 		lisg.long_row_tree = (r && r[0] == '1');
+		r = getenv("LIS_AMD_REFERENCE_REDUCTIONS");   /* T: every sum in the reference's order for OMP_NUM_THREADS = T (parity mode, slow) */
+		lisg.ref_reductions = (r && atoi(r) > 0) ? atoi(r) : 0;
+		if (lisg.device_ready) (void)liship_set_reference_reductions(lisg.ref_reductions);      /* (a second lis_initialize in one process) */
 		r = getenv("LIS_AMD_GRAPHS");
 		lisg.graphs = (r && r[0] == '1');
 		r = getenv("LIS_AMD_HOST_SCALARS");

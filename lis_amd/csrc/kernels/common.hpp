@@ -101,3 +101,5 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 int liship_internal_fold(int count, int nres, int stride, double *partial, double *spare, double *result, void *stream);
 // vector_ops.hip: the guard flag installed by liship_krylov_guard (NULL when none)
 const double *liship_internal_guard(void);
+// vector_ops.hip: T > 0 while the reductions are formed in the reference's order (liship_set_reference_reductions): the products' fused-dot epilogues refuse
+int liship_internal_ref_chunks(void);

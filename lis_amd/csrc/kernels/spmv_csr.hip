@@ -4144,7 +4144,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
                                        double *result, void *work, void *stream)
 {
     if (!p || !w || !result || !work) return LISHIP_ERR_ARG;
-    if (plan_runs_teams(p)) return LISHIP_ERR_ARG;
+    if (plan_runs_teams(p) || liship_internal_ref_chunks()) return LISHIP_ERR_ARG;      // (reference-order sums: the product, then one ordered pass)
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x70006008) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
@@ -4208,7 +4208,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
                                             void *work, int slot_base, int *slots_used, void *stream)
 {
     if (!p || !w || !work || !slots_used || row_begin < 0 || row_end > p->n || slot_base < 0) return LISHIP_ERR_ARG;
-    if (plan_runs_teams(p)) return LISHIP_ERR_ARG;
+    if (plan_runs_teams(p) || liship_internal_ref_chunks()) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x70006008) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     *slots_used = 0;

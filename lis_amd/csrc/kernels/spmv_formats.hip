@@ -811,6 +811,7 @@ extern "C" int liship_spmv_ell_coded_f64(int n, int maxnzr, const unsigned char 
         LAUNCH_CHECK();
         return 0;
     }
+    if (liship_internal_ref_chunks()) return LISHIP_ERR_ARG;      // reference-order sums: the plain product, then one ordered pass
     if (!w || !result || !work) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((size_t)grid > slots) return LISHIP_ERR_ARG;
@@ -826,7 +827,7 @@ extern "C" int liship_spmv_ell_coded_f64(int n, int maxnzr, const unsigned char 
 extern "C" int liship_spmv_ell_dot_f64(int n, int maxnzr, const int *idx, const double *val, const double *x, double *y,
                                        const double *w, int want_sumsq, double *result, void *work, void *stream)
 {
-    if (n <= 0 || maxnzr <= 0 || !w || !result || !work) return LISHIP_ERR_ARG;
+    if (n <= 0 || maxnzr <= 0 || !w || !result || !work || liship_internal_ref_chunks()) return LISHIP_ERR_ARG;
     if ((n & 1) || !aligned16(val) || !aligned16(y) || (reinterpret_cast<uintptr_t>(idx) & 7u)) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     const int grid = grid_for(n / 2);
@@ -841,7 +842,7 @@ extern "C" int liship_spmv_ell_dot_f64(int n, int maxnzr, const int *idx, const 
 extern "C" int liship_spmv_dia_dot_f64(int n, int ncols, int nnd, const int *off, const double *val, const double *x, double *y,
                                        const double *w, int want_sumsq, double *result, void *work, void *stream)
 {
-    if (n <= 0 || nnd <= 0 || ncols < n || !w || !result || !work) return LISHIP_ERR_ARG;
+    if (n <= 0 || nnd <= 0 || ncols < n || !w || !result || !work || liship_internal_ref_chunks()) return LISHIP_ERR_ARG;
     if ((n & 1) || !aligned16(val) || !aligned16(y)) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     const int grid = grid_for(n / 2);
@@ -893,7 +894,7 @@ extern "C" int liship_spmv_bsr_dot_f64(int nr, int n, int bnnz, int bs, const in
                                        const double *x, double *y, const double *w, int want_sumsq, double *result,
                                        void *work, void *stream)
 {
-    if (nr <= 0 || n <= 0 || bnnz < 0 || !w || !result || !work) return LISHIP_ERR_ARG;
+    if (nr <= 0 || n <= 0 || bnnz < 0 || !w || !result || !work || liship_internal_ref_chunks()) return LISHIP_ERR_ARG;
     if (!aligned16(val) || !aligned16(x) || !aligned16(y) || !aligned16(bidx)) return LISHIP_ERR_ARG;
     const double mean = (double)bnnz / nr;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;

@@ -161,3 +161,42 @@ extern "C" int liship_csr_transpose_f64(int nrows, int ncols, int nnz, const int
     LAUNCH_CHECK();
     return 0;
 }
+
+// ---- A^T x in the reference's order for OMP_NUM_THREADS = T > 1 (parity mode, liship_set_reference_reductions) ----------------
+// The OpenMP build of lis_matvech_csr gives thread k the source rows LIS_GET_ISIE(k, T, n), lets it scatter into a buffer of its own
+// from 0.0, and then forms y[c] = ((0.0 + w[0][c]) + w[1][c]) + ... (src/matvec/lis_matvec_csr.c:207-236).  On the transposed rows
+// (entries of row c in ascending source row = the scatter order) that is: the entries of one thread's chunk summed left to right
+// from 0.0, the chunk sums added in chunk order from 0.0.  One lane per row: a parity mode, not a fast one.
+namespace {
+__global__ __launch_bounds__(BLOCK)
+void spmv_t_chunked_kernel(int rows, int nsrc, int T, const int *__restrict__ tptr, const int *__restrict__ tidx,
+                           const double *__restrict__ tval, const double *__restrict__ x, double *__restrict__ y, const double *skip)
+{
+    if (skip && skip[0] != 0.0) return;
+    const int c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= rows) return;
+    const int q = nsrc / T, rem = nsrc % T;
+    const long long big = (long long)rem * (q + 1);      // rows below `big` lie in chunks of q + 1 rows
+    double total = 0.0, part = 0.0;
+    int chunk = 0;
+    for (int k = tptr[c]; k < tptr[c + 1]; k++) {
+        const int j = tidx[k];
+        const int kc = j < big ? j / (q + 1) : rem + (int)((j - big) / q);
+        if (kc != chunk) { total += part; part = 0.0; chunk = kc; }      // (adding a chunk without entries adds +0.0: nothing)
+        part += tval[k] * x[j];
+    }
+    total += part;
+    y[c] = total;
+}
+} // namespace
+
+// y[0..rows) = A^T x from the transposed CSR (rows = columns of A, nsrc = rows of A), summed as the reference's T threads do
+extern "C" int liship_spmv_csr_transposed_chunked_f64(int rows, int nsrc, int T, const int *tptr, const int *tidx, const double *tval,
+                                                      const double *x, double *y, void *stream)
+{
+    if (rows < 0 || nsrc < 0 || T < 1) return LISHIP_ERR_ARG;
+    if (rows == 0) return 0;
+    spmv_t_chunked_kernel<<<(rows + BLOCK - 1) / BLOCK, BLOCK, 0, as_stream(stream)>>>(rows, nsrc, T, tptr, tidx, tval, x, y, liship_internal_guard());
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -252,6 +252,69 @@ struct RedArgs {
     double c;                        // RED_AXPY_NRM2_JACU: the uniform 1/diag
 };
 
+// one element of a reduction: the fused forms' in-place results (ox, oy) and the term(s) this element adds to the sum(s).
+// Shared by the tree kernels and the reference-order kernel, so the two orders add the SAME terms.
+struct RedCoef { double a, adev, cb, cc, c; };
+template <int OP>
+__device__ __forceinline__ void red_term(const RedCoef &K, double x, double y, double w, double d, double e,
+                                         double &ox, double &oy, double &v0, double &v1)
+{
+    v0 = 0.0; v1 = 0.0;
+    if (OP == RED_DOT)   v0 = x * y;
+    if (OP == RED_SUMSQ) v0 = x * x;
+    if (OP == RED_ABS)   v0 = fabs(x);
+    if (OP == RED_SUM)   v0 = x;
+    if (OP == RED_DOT2) { v0 = x * y; v1 = x * x; }
+    if (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC) {   // x: p, y: q, w: x-iterate, d: residual r, e: 1/diag
+        ox = w + K.a * x;               // x += alpha*p
+        oy = d + (-K.a) * y;            // r += (-alpha)*q
+        v0 = oy * oy;
+        if (OP == RED_CG_UPDATE_JAC) { const double z = oy * e; v1 = oy * z; }   // z = r.*dinv ; <r,z>
+    }
+    if (OP == RED_COUNT_NE) v0 = (__double_as_longlong(x) != __double_as_longlong(K.a)) ? 1.0 : 0.0;
+    if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC || OP == RED_AXPY_NRM2_JACU) {
+        oy = y + K.a * x;               // y += a*x
+        v0 = oy * oy;
+        if (OP == RED_AXPY_NRM2_DOT) v1 = w * oy;
+        if (OP == RED_AXPY_NRM2_JAC) { const double z = oy * e; v1 = oy * z; }   // z = r.*dinv ; <r,z>
+        if (OP == RED_AXPY_NRM2_JACU) { const double z = oy * K.c; v1 = oy * z; } // the same, dinv uniform
+    }
+    if (OP == RED_BICGSTAB_END) {       // x: t, y: s (becomes r), w: rtld, d: phat, e: the iterate; shat aliases s (no preconditioner)
+        const double t1 = e + K.cb * d; // x += alpha*phat     (lis_solver_bicgstab.c:272)
+        ox = t1 + K.cc * y;             // x += omega*shat     (:273)
+        oy = y + K.a * x;               // r += (-omega)*t     (:276)
+        v0 = oy * oy;
+        v1 = w * oy;
+    }
+    if (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) {
+        oy = y + K.adev * x;            // y += (-h)*x, h read from HBM: no host round trip between steps
+        if (OP == RED_AXPYD_DOT) v0 = oy * w; else v0 = oy * oy;
+    }
+}
+
+template <int OP> struct RedShape {
+    static constexpr bool IS_CG = (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC || OP == RED_BICGSTAB_END);     // five inputs, two outputs
+    static constexpr bool IS_AXD = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ);
+    static constexpr bool IS_AXN = (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC || OP == RED_AXPY_NRM2_JACU);
+    static constexpr bool HAS_Y = (OP == RED_DOT || OP == RED_DOT2 || IS_CG || IS_AXN || IS_AXD);
+    static constexpr bool HAS_W = (IS_CG || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPYD_DOT);
+    static constexpr bool HAS_D = IS_CG;
+    static constexpr bool HAS_E = (OP == RED_CG_UPDATE_JAC || OP == RED_AXPY_NRM2_JAC || OP == RED_BICGSTAB_END);
+};
+
+template <int OP>
+__device__ __forceinline__ RedCoef red_coef(RedArgs &A)
+{
+    if (A.pa) A.a = A.pa[0];
+    RedCoef K;
+    K.a = A.a;
+    K.adev = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) ? -A.sp[0] : 0.0;
+    K.cb = OP == RED_BICGSTAB_END ? A.pb[0] : 0.0;
+    K.cc = OP == RED_BICGSTAB_END ? A.pc[0] : 0.0;
+    K.c = A.c;
+    return K;
+}
+
 template <int OP, bool NT, bool VEC>
 __global__ __launch_bounds__(BLOCK)
 void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool root)
@@ -261,41 +324,12 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
     double s0 = 0.0, s1 = 0.0;
     const int n = A.n;
     if (A.skip && A.skip[0] != 0.0) return;
-    if (A.pa) A.a = A.pa[0];
-    const double adev = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) ? -A.sp[0] : 0.0;
-    const double cb = OP == RED_BICGSTAB_END ? A.pb[0] : 0.0, cc = OP == RED_BICGSTAB_END ? A.pc[0] : 0.0;
+    const RedCoef K = red_coef<OP>(A);
     auto term = [&](double x, double y, double w, double d, double e, double &ox, double &oy) {
-        if (OP == RED_DOT)   s0 += x * y;
-        if (OP == RED_SUMSQ) s0 += x * x;
-        if (OP == RED_ABS)   s0 += fabs(x);
-        if (OP == RED_SUM)   s0 += x;
-        if (OP == RED_DOT2) { s0 += x * y; s1 += x * x; }
-        if (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC) {   // x: p, y: q, w: x-iterate, d: residual r, e: 1/diag
-            ox = w + A.a * x;               // x += alpha*p
-            oy = d + (-A.a) * y;            // r += (-alpha)*q
-            s0 += oy * oy;
-            if (OP == RED_CG_UPDATE_JAC) { const double z = oy * e; s1 += oy * z; }   // z = r.*dinv ; <r,z>
-        }
-        if (OP == RED_COUNT_NE) s0 += (__double_as_longlong(x) != __double_as_longlong(A.a)) ? 1.0 : 0.0;
-        if (OP == RED_AXPY_NRM2 || OP == RED_AXPY_NRM2_DOT || OP == RED_AXPY_NRM2_JAC || OP == RED_AXPY_NRM2_JACU) {
-            oy = y + A.a * x;               // y += a*x
-            s0 += oy * oy;
-            if (OP == RED_AXPY_NRM2_DOT) s1 += w * oy;
-            if (OP == RED_AXPY_NRM2_JAC) { const double z = oy * e; s1 += oy * z; }   // z = r.*dinv ; <r,z>
-            if (OP == RED_AXPY_NRM2_JACU) { const double z = oy * A.c; s1 += oy * z; } // the same, dinv uniform
-        }
-        if (OP == RED_BICGSTAB_END) {       // x: t, y: s (becomes r), w: rtld, d: phat, e: the iterate; shat aliases s (no preconditioner)
-            const double t1 = e + cb * d;   // x += alpha*phat     (lis_solver_bicgstab.c:272)
-            ox = t1 + cc * y;               // x += omega*shat     (:273)
-            oy = y + A.a * x;               // r += (-omega)*t     (:276)
-            s0 += oy * oy;
-            s1 += w * oy;
-        }
-        if (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ) {
-            oy = y + adev * x;              // y += (-h)*x, h read from HBM: no host round trip between steps
-            if (OP == RED_AXPYD_DOT) s0 += oy * w; else s0 += oy * oy;
-        }
-        (void)e;
+        double v0, v1;
+        red_term<OP>(K, x, y, w, d, e, ox, oy, v0, v1);
+        s0 += v0;
+        if (NRES == 2) s1 += v1;
     };
     constexpr bool IS_CG = (OP == RED_CG_UPDATE || OP == RED_CG_UPDATE_JAC || OP == RED_BICGSTAB_END);     // five inputs, two outputs
     constexpr bool IS_AXD = (OP == RED_AXPYD_DOT || OP == RED_AXPYD_SUMSQ);
@@ -357,6 +391,60 @@ void reduce_level1(RedArgs A, int stride, double *__restrict__ partial, bool roo
         const double t1 = block_sum<NW>(s1, scratch);
         if (threadIdx.x == 0) partial[stride + blockIdx.x] = t1;
     }
+}
+
+// ---- reference-order reductions (liship_set_reference_reductions) ---------------------------------------
+// The reference sums as its OpenMP build does (src/vector/lis_vector_ops.c:88-107 dot, :241-259 nrm2, nrm1 alike): thread t of T
+// owns the contiguous chunk LIS_GET_ISIE(t, T, n) (include/lis.h:1067-1078 -- the static schedule of `omp for`), adds its terms
+// strictly left to right from 0.0, and the T partial sums are added serially, thread 0 first, from 0.0.  Here one workgroup is one
+// such thread: its 256 lanes form the terms of a tile (and store the fused forms' element-wise results), lane 0 adds the tile's
+// terms in index order out of LDS (lane 64 the second result's), and reduce_ref_final adds the T partials in chunk order.  The
+// result carries the reference's bits for OMP_NUM_THREADS = T; a parity mode, not a fast one (one lane adds at ~8 cycles a term).
+// A multi-rank job whose ranks hold the row blocks LIS_GET_ISIE(rank, P, gn) at T = 1 forms, with the rank-order fold, the sum
+// of a single rank at T = P.
+constexpr int REF_TILE = 2048;
+int g_ref_chunks = 0;
+
+template <int OP>
+__global__ __launch_bounds__(BLOCK)
+void reduce_ref_kernel(RedArgs A, int T, double *__restrict__ partial)
+{
+    constexpr int NRES = RedResults<OP>::value;
+    using S = RedShape<OP>;
+    __shared__ double t0[REF_TILE];
+    __shared__ double t1[NRES == 2 ? REF_TILE : 1];
+    if (A.skip && A.skip[0] != 0.0) return;
+    const RedCoef K = red_coef<OP>(A);
+    const int n = A.n, c = blockIdx.x;
+    long long is, ie;                                   // LIS_GET_ISIE(c, T, n, is, ie)
+    if (c < n % T) { ie = n / T + 1; is = ie * c; } else { ie = n / T; is = ie * c + n % T; }
+    ie += is;
+    double s = 0.0;                                     // lane 0: the first result's running sum; lane 64: the second's
+    for (long long base = is; base < ie; base += REF_TILE) {
+        const int cnt = (int)(ie - base < REF_TILE ? ie - base : REF_TILE);
+        for (int j = threadIdx.x; j < cnt; j += BLOCK) {
+            const long long i = base + j;
+            double ox = 0.0, oy = 0.0, v0, v1;
+            red_term<OP>(K, A.x[i], S::HAS_Y ? A.y[i] : 0.0, S::HAS_W ? A.w[i] : 0.0, S::HAS_D ? A.d[i] : 0.0, S::HAS_E ? A.e[i] : 0.0,
+                         ox, oy, v0, v1);
+            if (S::IS_CG) { A.ox[i] = ox; A.oy[i] = oy; }
+            if (S::IS_AXN || S::IS_AXD) A.oy[i] = oy;
+            t0[j] = v0;
+            if (NRES == 2) t1[j] = v1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll 8
+            for (int j = 0; j < cnt; j++) s += t0[j];
+        }
+        if (NRES == 2 && threadIdx.x == WAVE) {
+#pragma unroll 8
+            for (int j = 0; j < cnt; j++) s += t1[j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[c] = s;
+    if (NRES == 2 && threadIdx.x == WAVE) partial[T + c] = s;
 }
 
 // One lane: the scalar statements between the vector passes, on the state block in HBM.  Every operation is the
@@ -514,6 +602,20 @@ __global__ void finish_kernel(int nres, int stride, bool root, const double *__r
     }
 }
 
+// the serial sum over the T chunk partials (lis_vector_ops.c:103-107), the root of nrm2, the announced scalar step
+__global__ void reduce_ref_final(int T, int nres, const double *__restrict__ partial, double *result, bool root, const double *skip, Chain chain)
+{
+    if (threadIdx.x != 0) return;
+    if (!(skip && skip[0] != 0.0)) {
+        for (int k = 0; k < nres; k++) {
+            double s = 0.0;
+            for (int c = 0; c < T; c++) s += partial[(size_t)k * T + c];
+            result[k] = root ? sqrt(s) : s;
+        }
+    }
+    if (chain.step) krylov_step_device(chain.step, chain.st, chain.rh, nullptr, 0);
+}
+
 // fold `count` partials per result (layout partial[k*stride + i]) down to result[k]; scratch2 lives behind them
 int fold_partials(int count, int nres, int stride, double *partial, double *spare, double *result, bool root, hipStream_t st)
 {
@@ -563,6 +665,14 @@ int run_reduce(RedArgs A, double *result, void *work, bool root, void *stream)
     double *spare = partial + 2 * MAX_PARTIALS;              // second half of the scratch
     hipStream_t st = as_stream(stream);
     A.skip = g_guard;
+    if (g_ref_chunks > 0) {                                  // the reference's order (parity mode)
+        const int T = g_ref_chunks;
+        reduce_ref_kernel<OP><<<T, BLOCK, 0, st>>>(A, T, partial);
+        LAUNCH_CHECK();
+        reduce_ref_final<<<1, WAVE, 0, st>>>(T, NRES, partial, result, root, A.skip, take_chain());
+        LAUNCH_CHECK();
+        return 0;
+    }
     const bool single = (grid == 1);                         // one block: it writes result[k] itself
     double *dst = single ? result : partial;
     const bool r1 = single && root;
@@ -610,6 +720,17 @@ void csr_diagonal_kernel(int n, const int *__restrict__ ptr, const int *__restri
 
 // scratch: two ping-pong partial areas, each big enough for two results of a 2^31-element vector
 extern "C" size_t liship_reduce_work_bytes(void) { return sizeof(double) * 2 * MAX_PARTIALS * 2; }
+
+// T > 0: every reduction of this file is formed in the reference's order for OMP_NUM_THREADS = T (reduce_ref_kernel); 0: the trees.
+// The products' fused-dot epilogues refuse while it is on (their callers then run the product and one reduction pass).
+extern "C" int liship_set_reference_reductions(int T)
+{
+    if (T < 0 || (size_t)T > MAX_PARTIALS) return LISHIP_ERR_ARG;
+    g_ref_chunks = T;
+    return 0;
+}
+extern "C" int liship_get_reference_reductions(void) { return g_ref_chunks; }
+int liship_internal_ref_chunks(void) { return g_ref_chunks; }
 
 // used by spmv_csr.hip's fused dot epilogue
 int liship_internal_fold(int count, int nres, int stride, double *partial, double *spare, double *result, void *stream)

@@ -1,0 +1,110 @@
+"""Bit-level goldens of whole Krylov solves: iteration count, status, the FULL residual history and the solution of the reference
+(oracle/_ref = Lis 2.1.11 compiled from /root/reference by oracle/Makefile) at T = 1 and T = 8 OpenMP threads.
+
+The reference's dot / nrm2 add T contiguous chunks (LIS_GET_ISIE) left to right and combine the T partial sums serially
+(src/vector/lis_vector_ops.c:88-107, :241-259), so its results depend on T.  liblis_amd's reference-order mode
+(lis_amd_set_reference_reductions(T), kernels/vector_ops.hip reduce_ref_kernel) forms the same sums; tests/test_reference_order_gpu.py
+demands the same iteration count, the same residual history IN EVERY BIT and the same solution bits for every case below -- the recurrences
+are src/solver/lis_solver_bicgstab.c:186-290, lis_solver_gmres.c:198-330, lis_solver_bicg.c:180-260, lis_solver_cg.c:176-215.
+
+Cases (inputs are rebuilt by the test from the same generators / the same committed files):
+  poisson<N>     7-point Poisson on N^3 (test/test3.c:114-127 via orc.poisson3d), b = A*1, x0 = 0
+  mm/<file>      the reference's own Matrix Market fixtures (tests/golden/mm/testmat*.mtx) through lis_input, b = A*1 (test/test1.c rhs mode 2)
+  queen_mini     the Queen_4147 stand-in at its small size (tests/queen_class.py "mini") through lis_input, b = A*1
+Each with BiCGSTAB, GMRES(30), BiCG (all -p none) and CG + Jacobi, tol 1e-12.
+
+    python tests/golden/make_golden_rhistory_bits.py      (dev container only: needs oracle/_ref; rewrites rhistory_bits.npz / .json)
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+SOLVES = ("-i bicgstab -p none", "-i gmres -restart 30 -p none", "-i bicg -p none", "-i cg -p jacobi", "-i bicgstab -p jacobi")
+THREADS = (1, 8)
+POISSON = (32, 64)
+MM_FILES = ("testmat.mtx", "testmat0.mtx", "testmat2.mtx")      # (testmat3 is complex: refused by the reader; testmat4 is a dense array file)
+COMMON = " -tol 1e-12 -maxiter 2000 -print mem"
+
+WORKER = r'''
+import ctypes as C, hashlib, json, os, sys
+import numpy as np
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "tests")]
+import lisdrv, orc, queen_class
+from lis_amd import _capi as capi
+threads = int(sys.argv[1])
+ref = lisdrv.open_lib(orc.REF_SO, threads=threads)
+SOLVES = %(solves)r
+out, arrays = {}, {}
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+def solves(case, A, b):
+    for opts in SOLVES:
+        res = lisdrv.solve(ref, A, b, opts + %(common)r)
+        key = "%%s|%%s|T%%d" %% (case, opts, threads)
+        out[key] = {"iter": int(res["iter"]), "status": int(res["status"]), "resid_hex": float(res["resid"]).hex(), "x_sha256": sha(res["x"]),
+                    "n": int(len(b))}
+        arrays[key] = res["rhistory"]
+        print(key, res["iter"], res["status"], res["resid"], file=sys.stderr, flush=True)
+
+def from_file(case, path):
+    A, b, x = capi.PM(), capi.PV(), capi.PV()
+    assert ref.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
+    assert ref.lis_vector_create(capi.LIS_COMM_WORLD, C.byref(b)) == 0 and ref.lis_vector_create(capi.LIS_COMM_WORLD, C.byref(x)) == 0
+    assert ref.lis_input(A, b, x, path.encode()) == 0
+    n = A.contents.n
+    rhs = lisdrv.matvec(ref, A, np.ones(n))
+    solves(case, A, rhs)
+    ref.lis_matrix_destroy(A)
+
+for N in %(poisson)r:
+    ptr, idx, val = orc.poisson3d(N, N, N)
+    A = lisdrv.make_csr(ref, ptr, idx, val)
+    b = lisdrv.matvec(ref, A, np.ones(len(ptr) - 1))
+    solves("poisson%%d" %% N, A, b)
+    ref.lis_matrix_destroy(A)
+for f in %(mm)r:
+    from_file("mm/" + f, os.path.join(%(here)r, "mm", f))
+path, rows, stored = queen_class.generate("mini")
+try:
+    from_file("queen_mini", path)
+finally:
+    os.unlink(path)
+np.savez(sys.argv[2], **arrays)
+json.dump(out, open(sys.argv[2] + ".json", "w"))
+'''
+
+
+def main():
+    meta, arrays = {}, {}
+    for T in THREADS:
+        tmp = os.path.join(HERE, "_rh_T%d.npz" % T)
+        env = dict(os.environ, OMP_NUM_THREADS=str(T))
+        src = WORKER % {"root": ROOT, "here": HERE, "solves": SOLVES, "common": COMMON, "poisson": POISSON, "mm": MM_FILES}
+        txt = subprocess.run([sys.executable, "-c", src, str(T), tmp], capture_output=True, text=True, env=env)
+        sys.stderr.write(txt.stderr[-4000:])
+        txt.check_returncode()
+        meta.update(json.load(open(tmp + ".json")))      # (not stdout: the reference prints there too)
+        os.unlink(tmp + ".json")
+        with np.load(tmp) as z:
+            for k in z.files:
+                arrays[k] = z[k]
+        os.unlink(tmp)
+    np.savez_compressed(os.path.join(HERE, "rhistory_bits.npz"), **arrays)
+    doc = {"_source": "Lis 2.1.11 (oracle/_ref, gcc -O3 -fopenmp, no FMA) at OMP_NUM_THREADS = 1 and 8; rhistory arrays (f64, every bit) in rhistory_bits.npz "
+                      "under the same keys 'case|options|T<threads>'; x_sha256 = sha256 of the solution's bytes",
+           "common_options": COMMON.strip(), "solves": meta}
+    json.dump(doc, open(os.path.join(HERE, "rhistory_bits.json"), "w"), indent=1, sort_keys=True)
+    print(len(meta), "solves written")
+
+
+if __name__ == "__main__":
+    main()

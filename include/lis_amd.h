@@ -46,6 +46,10 @@ LIS_INT lis_amd_set_device_convert(LIS_INT on);
 LIS_INT lis_amd_vector_page_state(LIS_VECTOR v);
 LIS_INT lis_amd_vector_page_protect(LIS_VECTOR v, LIS_INT state);      /* force a protection (tests of the fault handler without a GPU) */
 LIS_INT lis_amd_page_faults(LIS_INT *reads, LIS_INT *writes);
+LIS_INT lis_amd_page_fault_waits(void);                /* faults that found another thread bringing the same array home and waited for its copy */
+/* tests of the handler without a GPU: the host buffer `src` (n + pad doubles) plays the HBM copy of v -- v's pages lose all access and the first
+ * touch copies src home in two halves delay_ms apart, through the library's alias mapping (lis_pages.c); src = NULL removes the hook */
+LIS_INT lis_amd_vector_page_test_source(LIS_VECTOR v, const LIS_SCALAR *src, LIS_INT delay_ms);
 
 /* How the CG / BiCGSTAB loops run (all three produce identical bits; the choice is for A/B measurements):
  *   DEVICE  scalars live in HBM, iterations are enqueued in batches, one read-back per batch (default)

@@ -172,6 +172,10 @@ LIS_INT lisd_vec_reserve(LIS_VECTOR v, size_t doubles)
  * staging buffers the driver never learns about the pages; the host memcpy overlaps the DMA of the previous piece. */
 #define STAGE_BYTES ((size_t)16 << 20)
 static struct { void *buf[2], *ev[2]; int busy[2]; } stage;
+/* the staging buffers are one set per process: a thread of the program that faults on a vector (lis_pages.c) copies through them while the
+ * thread that drives the library may be uploading another vector -- one copy at a time */
+#include <pthread.h>
+static pthread_mutex_t stage_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static LIS_INT stage_ready(void)
 {
@@ -197,8 +201,7 @@ static void copy_threads(void *dst, const void *src, size_t bytes)
 	}
 }
 
-static LIS_INT staged_d2h(void *dst, const void *src, size_t bytes);
-static LIS_INT staged_h2d(void *dst, const void *src, size_t bytes)
+static LIS_INT staged_h2d_locked(void *dst, const void *src, size_t bytes)
 {
 	LISCHK(stage_ready());
 	int k = 0;
@@ -212,10 +215,15 @@ static LIS_INT staged_h2d(void *dst, const void *src, size_t bytes)
 	}
 	return LIS_SUCCESS;
 }
+static LIS_INT staged_h2d(void *dst, const void *src, size_t bytes)
+{
+	pthread_mutex_lock(&stage_lock);
+	const LIS_INT err = staged_h2d_locked(dst, src, bytes);
+	pthread_mutex_unlock(&stage_lock);
+	return err;
+}
 
-LIS_INT lisd_staged_d2h(void *dst, const void *src, size_t bytes) { return staged_d2h(dst, src, bytes); }
-
-static LIS_INT staged_d2h(void *dst, const void *src, size_t bytes)
+static LIS_INT staged_d2h_locked(void *dst, const void *src, size_t bytes)
 {
 	LISCHK(stage_ready());
 	for (int k = 0; k < 2; k++) if (stage.busy[k]) { HIPCHK(liship_event_synchronize(stage.ev[k])); stage.busy[k] = 0; }
@@ -235,6 +243,14 @@ static LIS_INT staged_d2h(void *dst, const void *src, size_t bytes)
 	}
 	return LIS_SUCCESS;
 }
+/* HBM -> host memory the runtime must not learn about (page-protected arrays, through their alias mapping: lis_pages.c) */
+LIS_INT lisd_staged_d2h(void *dst, const void *src, size_t bytes)
+{
+	pthread_mutex_lock(&stage_lock);
+	const LIS_INT err = staged_d2h_locked(dst, src, bytes);
+	pthread_mutex_unlock(&stage_lock);
+	return err;
+}
 
 /* host -> HBM when the host side is the truth.  COHERENT with page protection (the default, lis_pages.c): the host array was written
  * since the last upload exactly when its pages are read + write (dev_valid == 0); eager COHERENT: always (nothing tells) */
@@ -250,7 +266,12 @@ LIS_INT lisd_vec_in(LIS_VECTOR v, double **out)
 		else HIPCHK(liship_memcpy_h2d(d->d, v->value, len * sizeof(double), lisg.stream));
 		d->dev_valid = 1;
 		if (lisg.residency == LIS_AMD_COHERENT) d->host_valid = 1;
-		if (lazy) lisp_protect(v, LISP_RO);        /* both sides agree: a host write from here on faults and marks the HBM copy stale */
+		if (lazy) {
+			lisp_protect(v, LISP_RO);        /* both sides agree: a host write from here on faults and marks the HBM copy stale */
+			/* the protection could not be had (mprotect out of VMAs, no handler): nothing would report a host write, so the HBM copy
+			 * counts as stale again and the next call uploads afresh -- slower, never wrong */
+			if (lisp_state(v) != LISP_RO) d->dev_valid = 0;
+		}
 	}
 	*out = d->d;
 	return LIS_SUCCESS;
@@ -278,20 +299,17 @@ LIS_INT lisd_vec_done(LIS_VECTOR v)
 LIS_INT lisd_vec_to_host(LIS_VECTOR v)
 {
 	lisd_vec *d = VDEV(v);
+	if (lisp_lazy() && d->region) return lisp_vec_home(v);      /* through the alias mapping: the program's pages open when the data is there */
 	if (d->host_valid || !d->dev_valid || !d->d || !v->value) {
 		d->host_valid = 1;
-		if (lisp_state(v) == LISP_NONE) lisp_protect(v, d->dev_valid ? LISP_RO : LISP_RW);
+		lisp_protect(v, LISP_RW);                 /* (pages of a vector protected before the mode was switched to eager) */
 		return LIS_SUCCESS;
 	}
 	size_t len = d->hlen < d->cap ? d->hlen : d->cap;
 	lisp_protect(v, LISP_RW);
-	if (lisp_lazy() && d->region) LISCHK(staged_d2h(v->value, d->d, len * sizeof(double)));
-	else {
-		HIPCHK(liship_memcpy_d2h(v->value, d->d, len * sizeof(double), lisg.stream));
-		HIPCHK(liship_stream_synchronize(lisg.stream));
-	}
+	HIPCHK(liship_memcpy_d2h(v->value, d->d, len * sizeof(double), lisg.stream));
+	HIPCHK(liship_stream_synchronize(lisg.stream));
 	d->host_valid = 1;
-	if (lisp_lazy() && d->region) lisp_protect(v, LISP_RO);
 	return LIS_SUCCESS;
 }
 

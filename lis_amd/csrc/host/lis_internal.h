@@ -136,6 +136,7 @@ void lisp_free(LIS_VECTOR v);
 LIS_INT lisp_grow(LIS_VECTOR v, size_t doubles);
 void lisp_protect(LIS_VECTOR v, int prot);
 int  lisp_state(LIS_VECTOR v);
+LIS_INT lisp_vec_home(LIS_VECTOR v);                          /* value[] current on the host, the copy written through the alias mapping (lazy coherence) */
 int  lisp_lazy(void);
 void *lisp_alloc_lazy(void *matrix, size_t bytes_used, void *dev, int own_dev);   /* a matrix array held in HBM until its first host touch */
 int  lisp_free_array(void *p);                                /* 1: p lived on such pages (unmapped), 0: plain memory (caller frees) */

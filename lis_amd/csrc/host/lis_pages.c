@@ -3,7 +3,7 @@
  *
  * Lis hands out raw host arrays (v->value[], lis.h:513-537) and programs read and write them behind the library's back
  * (test/spmvtest1.c:215, test/test1.c, every driver that prints a solution).  Vectors are ALWAYS library-allocated
- * (src/vector/lis_vector.c:116-156 create, :370-441 duplicate), so the library can give value[] its own pages (mmap) and let the
+ * (src/vector/lis_vector.c:116-156 create, :370-441 duplicate), so the library can give value[] its own pages and let the
  * MMU report the accesses the API cannot see:
  *
  *     pages            who holds the data                 what a host access does
@@ -14,44 +14,66 @@
  * A kernel that writes a vector leaves its pages without access and downloads nothing; a kernel that reads a vector uploads it only
  * when the host array was written since (pages read + write), then makes the pages read-only.  A loop of lis_matvec / lis_vector_*
  * calls therefore runs at the speed of LIS_AMD_RESIDENT, and a program that pokes v->value[i] in between still sees -- and changes --
- * the right numbers, at the cost of one fault and one copy of that vector.  This is the default (LIS_AMD_COHERENT);
- * LIS_AMD_COHERENCE=eager (or lis_amd_set_coherence(0)) restores the copy-on-every-call behaviour, for programs that hand v->value to
- * something the MMU cannot interrupt: a system call (write(2) of a protected buffer fails with EFAULT instead of faulting) or another
- * device's DMA.  Such code can also bracket the access with lis_amd_vector_sync_host() / lis_amd_vector_host_modified().
+ * the right numbers, at the cost of one fault and one copy of that vector.  This is the default (LIS_AMD_COHERENT).
+ *
+ * TWO MAPPINGS OF THE SAME PAGES.  The pages belong to an anonymous memory file (memfd); the program sees them through the mapping whose
+ * address is v->value and whose protection follows the table above; the library keeps a second mapping of the same pages (the alias) that
+ * is always readable and writable.  Data coming home from HBM is written THROUGH THE ALIAS while the program's mapping still has no
+ * access, and only when the last byte has landed does the program's mapping become readable.  A program with several threads (an OpenMP
+ * loop over x->value right after lis_solve is ordinary Lis user code) therefore cannot see a half-filled array: the first thread to fault
+ * brings the vector home, every other thread that touches the vector meanwhile faults too (the pages are still without access), finds the
+ * region marked `filling` and waits on a condition variable until the copy is complete.  (Rounds 1-3 opened the program's own mapping
+ * BEFORE the copy: a second thread then read stale bytes without faulting.)
  *
  * The fault handler runs synchronously in the thread that touched the page (SIGSEGV / SEGV_ACCERR), which is ordinary user code, never
- * the library itself: every library routine that reads or writes value[] on the host unprotects first (lisd_vec_to_host,
- * lisd_vec_host_write).  It therefore may take the registry lock and call the HIP runtime.  Faults at addresses that are not a vector's
- * go to whoever handled SIGSEGV before.
+ * the library itself: every library routine that reads or writes value[] on the host goes through lisp_protect / lisp_vec_home first.
+ * It therefore may take the registry lock and call the HIP runtime.  Faults at addresses that are no region's go to whoever handled
+ * SIGSEGV before; the disposition is never reset for an address inside a region.
+ *
+ * What page protection cannot do: a SYSTEM CALL that is handed a protected buffer (write(2) / fwrite of a large v->value, MPI_Send,
+ * another device's DMA) does not fault, it fails with EFAULT (a short count from fwrite).  Programs that pass v->value to the kernel
+ * call lis_amd_vector_sync_host(v) first (read access) / lis_amd_vector_host_modified(v) after (write access), or run with
+ * LIS_AMD_COHERENCE=eager / lis_amd_set_coherence(0): every call then uploads its inputs and downloads its outputs and the pages keep
+ * full access.  tests/test_host_cpu.py pins both behaviours.  The pages are shared memory: a forked child sees (and writes) the
+ * parent's vectors, not a copy -- a process with a live HIP context must not fork and go on using it anyway.
+ * When the memory file or the handler cannot be had, vectors fall back to plain memory and eager coherence -- slower, never stale.
  */
 #define _GNU_SOURCE
+#include <errno.h>
 #include <pthread.h>
 #include <signal.h>
 #include <stdio.h>
 #include <unistd.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
 #include "lis_internal.h"
 
 typedef struct lisp_region {
-	char *base;
+	char *base;              /* the program's mapping (v->value / A->index ...), a guard page on either side */
+	char *alias;             /* the library's mapping of the same pages: always read + write */
 	size_t bytes;            /* whole pages */
-	int prot;                /* LISP_RW / LISP_RO / LISP_NONE */
+	int prot;                /* protection of the program's mapping: LISP_RW / LISP_RO / LISP_NONE */
+	int filling;             /* a thread is bringing the data home through the alias: everybody else waits on fill_done */
 	LIS_VECTOR owner;        /* a vector's value[] ... */
 	/* ... or an array of a matrix the library converted in HBM: the host array is materialised from `dev` on its first touch */
 	void *mowner;            /* the matrix */
 	void *dev;               /* device buffer holding the array (NULL once the host pages hold it) */
 	size_t used;             /* bytes of the array */
 	int own_dev;             /* the buffer exists only to back these pages: freed once they are filled (else it is part of the matrix's HBM copy) */
+	/* test hook (lis_amd_vector_page_test_source): a host buffer standing in for the HBM copy, copied in two halves `test_delay_ms` apart */
+	const double *test_src;
+	int test_delay_ms;
 	struct lisp_region *next;
 } lisp_region;
 
 static lisp_region *regions;
 static pthread_mutex_t region_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t fill_done = PTHREAD_COND_INITIALIZER;
 static struct sigaction previous_action;
-static int handler_installed;
-static long faults_read, faults_write;
-static pthread_mutex_t sync_lock = PTHREAD_MUTEX_INITIALIZER;      /* held while a vector travels HBM -> host inside the handler */
-static char *last_rw_fault;
+static int handler_installed, handler_failed;
+static long faults_read, faults_write, faults_waited;
+static __thread char *tl_last_fault;
+static __thread int tl_repeats;
 
 static size_t page_size(void)
 {
@@ -62,70 +84,40 @@ static size_t page_size(void)
 
 static int native_prot(int prot) { return prot == LISP_RW ? (PROT_READ | PROT_WRITE) : prot == LISP_RO ? PROT_READ : PROT_NONE; }
 
-static void on_fault(int sig, siginfo_t *info, void *context)
+/* ---- the copy that brings a region home.  Called with r->filling set by the caller (under region_lock) and the lock RELEASED; the
+ * program's mapping keeps whatever protection it has (none, on every path that matters) until the data is complete. */
+static LIS_INT region_fill(lisp_region *r, int prot_after)
 {
-	char *addr = (char *)info->si_addr;
-	lisp_region *r = NULL;
-	if (sig == SIGSEGV && addr) {
-		pthread_mutex_lock(&region_lock);
-		for (r = regions; r; r = r->next) if (addr >= r->base && addr < r->base + r->bytes) break;
-		if (r && r->prot == LISP_NONE && !r->owner) {
-			/* an array of a matrix converted in HBM, touched for the first time: it becomes plain host memory */
-			faults_read++;
-			pthread_mutex_lock(&sync_lock);
-			mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE);
-			r->prot = LISP_RW;
-			void *dev = r->dev;
-			const size_t used = r->used;
-			const int own = r->own_dev;
-			r->dev = NULL;
-			pthread_mutex_unlock(&region_lock);
-			LIS_INT err = LIS_SUCCESS;
-			if (dev && used) err = lisd_staged_d2h(r->base, dev, used);
-			if (dev && own) (void)liship_free(dev);
-			pthread_mutex_unlock(&sync_lock);
-			if (err != LIS_SUCCESS) {
-				fprintf(stderr, "liblis_amd: could not bring a matrix array back from HBM inside the page-fault handler\n");
-				abort();
-			}
-			return;
+	LIS_INT err = LIS_SUCCESS;
+	if (r->owner) {
+		LIS_VECTOR v = r->owner;
+		lisd_vec *d = VDEV(v);
+		if (r->test_src) {                                    /* tests: a host buffer plays the HBM copy, slowly */
+			const size_t half = d->hlen / 2;
+			memcpy(r->alias, r->test_src, half * sizeof(double));
+			if (r->test_delay_ms > 0) usleep((useconds_t)r->test_delay_ms * 1000);
+			memcpy(r->alias + half * sizeof(double), r->test_src + half, (d->hlen - half) * sizeof(double));
+		} else if (d->d && d->dev_valid && !d->host_valid) {
+			const size_t len = d->hlen < d->cap ? d->hlen : d->cap;
+			err = lisd_staged_d2h(r->alias, d->d, len * sizeof(double));
 		}
-		if (r && r->prot == LISP_NONE) {
-			/* the HBM copy is the truth: bring it home, leave the pages read-only (both sides agree now) */
-			LIS_VECTOR v = r->owner;
-			faults_read++;
-			pthread_mutex_lock(&sync_lock);        /* (a second thread that faults on these pages meanwhile waits below until the data is there) */
-			mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE);
-			r->prot = LISP_RW;
-			pthread_mutex_unlock(&region_lock);
-			const LIS_INT err = lisd_vec_to_host(v);
-			pthread_mutex_unlock(&sync_lock);
-			if (err != LIS_SUCCESS) {
-				fprintf(stderr, "liblis_amd: could not bring a vector back from HBM inside the page-fault handler\n");
-				abort();
-			}
-			return;                                /* the access is retried; a write now faults on the read-only pages */
-		}
-		if (r && r->prot == LISP_RO) {
-			LIS_VECTOR v = r->owner;
-			faults_write++;
-			mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE);
-			r->prot = LISP_RW;
-			VDEV(v)->host_valid = 1;
-			VDEV(v)->dev_valid = 0;                /* the host array is being written: the HBM copy is stale from here on */
-			pthread_mutex_unlock(&region_lock);
-			return;
-		}
-		if (r && addr != last_rw_fault) {          /* another thread resolved (or is resolving) this very fault: wait for its copy, retry */
-			last_rw_fault = addr;
-			pthread_mutex_unlock(&region_lock);
-			pthread_mutex_lock(&sync_lock);
-			pthread_mutex_unlock(&sync_lock);
-			return;
-		}
-		pthread_mutex_unlock(&region_lock);
+		d->host_valid = 1;
+	} else {
+		void *dev = r->dev;
+		if (dev && r->used) err = lisd_staged_d2h(r->alias, dev, r->used);
+		if (dev && r->own_dev) (void)liship_free(dev);
+		r->dev = NULL;
 	}
-	/* not ours (or a fault that repeats inside a writable vector): the previous disposition decides */
+	pthread_mutex_lock(&region_lock);
+	if (!err && mprotect(r->base, r->bytes, native_prot(prot_after)) == 0) r->prot = prot_after;
+	r->filling = 0;
+	pthread_cond_broadcast(&fill_done);
+	pthread_mutex_unlock(&region_lock);
+	return err;
+}
+
+static void chain_to_previous(int sig, siginfo_t *info, void *context)
+{
 	if (previous_action.sa_flags & SA_SIGINFO) {
 		if (previous_action.sa_sigaction) { previous_action.sa_sigaction(sig, info, context); return; }
 	} else if (previous_action.sa_handler == SIG_IGN) {
@@ -137,71 +129,171 @@ static void on_fault(int sig, siginfo_t *info, void *context)
 	signal(sig, SIG_DFL);                          /* default action: the access is retried and terminates the process */
 }
 
+static void on_fault(int sig, siginfo_t *info, void *context)
+{
+	char *addr = (char *)info->si_addr;
+	lisp_region *r = NULL;
+	const int saved_errno = errno;
+	if (sig == SIGSEGV && addr) {
+		pthread_mutex_lock(&region_lock);
+		for (r = regions; r; r = r->next) if (addr >= r->base && addr < r->base + r->bytes) break;
+		if (r && r->filling) {
+			/* another thread is bringing this region home: wait until its copy is complete, then retry the access */
+			faults_waited++;
+			while (r->filling) pthread_cond_wait(&fill_done, &region_lock);
+			pthread_mutex_unlock(&region_lock);
+			tl_last_fault = NULL; tl_repeats = 0;
+			errno = saved_errno;
+			return;
+		}
+		if (r && r->prot == LISP_NONE) {
+			/* the HBM copy is the truth: bring it home through the alias; the program's mapping opens when the data is there --
+			 * read-only for a vector (both sides agree now; a write faults once more), read + write for a matrix array (plain memory from here on) */
+			r->filling = 1;
+			faults_read++;
+			pthread_mutex_unlock(&region_lock);
+			if (lisg.device_ready) (void)liship_set_device(lisg.device);      /* (this thread may never have called the runtime) */
+			const LIS_INT err = region_fill(r, r->owner ? LISP_RO : LISP_RW);
+			if (err != LIS_SUCCESS) {
+				fprintf(stderr, "liblis_amd: could not bring %s back from HBM inside the page-fault handler\n", r->owner ? "a vector" : "a matrix array");
+				abort();
+			}
+			tl_last_fault = NULL; tl_repeats = 0;
+			errno = saved_errno;
+			return;
+		}
+		if (r && r->prot == LISP_RO) {
+			LIS_VECTOR v = r->owner;
+			faults_write++;
+			if (mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE) == 0) r->prot = LISP_RW;
+			if (v) { VDEV(v)->host_valid = 1; VDEV(v)->dev_valid = 0; }      /* the host array is being written: the HBM copy is stale from here on */
+			pthread_mutex_unlock(&region_lock);
+			tl_last_fault = NULL; tl_repeats = 0;
+			errno = saved_errno;
+			return;
+		}
+		if (r) {
+			/* read + write already: another thread resolved this very fault between the access and the lock.  Retry; a fault that keeps
+			 * coming back at the same address of writable pages is not ours to resolve (the same thread, 64 times: give it to the previous owner) */
+			if (addr == tl_last_fault) tl_repeats++; else { tl_last_fault = addr; tl_repeats = 0; }
+			const int give_up = tl_repeats > 64;
+			if (!give_up) (void)mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE);
+			pthread_mutex_unlock(&region_lock);
+			if (!give_up) { errno = saved_errno; return; }
+		} else pthread_mutex_unlock(&region_lock);
+	}
+	/* not ours: the previous disposition decides */
+	chain_to_previous(sig, info, context);
+	errno = saved_errno;
+}
+
 static int install_handler(void)
 {
 	if (handler_installed) return 1;
+	if (handler_failed) return 0;
 	struct sigaction sa;
 	memset(&sa, 0, sizeof(sa));
 	sa.sa_sigaction = on_fault;
 	sa.sa_flags = SA_SIGINFO | SA_NODEFER | SA_ONSTACK;
 	sigemptyset(&sa.sa_mask);
-	if (sigaction(SIGSEGV, &sa, &previous_action) != 0) return 0;
+	if (sigaction(SIGSEGV, &sa, &previous_action) != 0) {
+		handler_failed = 1;
+		lisg.eager_coherence = 1;                  /* no handler, no lazy coherence: every call copies (slower, never stale) */
+		fprintf(stderr, "liblis_amd: cannot install the page-fault handler (%s): vectors use eager coherence from here on\n", strerror(errno));
+		return 0;
+	}
 	handler_installed = 1;
 	return 1;
 }
 
-/* value[] of `doubles` entries on pages of its own, zero-filled (as the calloc it replaces); NULL: out of memory */
+/* `bytes` (whole pages) of fresh zero pages mapped twice: *base with a guard page on either side and protection `prot`, *alias read + write.
+ * 0 on success.  The guard pages keep the kernel from merging the program's mapping into one VMA with a neighbour (measured in round 2: a
+ * vector sharing a VMA with arrays the runtime had registered made its first mprotect an MMU-notifier invalidation of that registration --
+ * 25 ms per stream synchronisation); a shared file mapping would not merge with anonymous memory anyway, the guards also catch overruns. */
+static int map_twice(size_t bytes, int prot, char **base, char **alias)
+{
+	const size_t ps = page_size();
+	int fd = (int)syscall(SYS_memfd_create, "lis_amd_vector", 1u /* MFD_CLOEXEC */);
+	if (fd < 0) return -1;
+	if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); return -1; }
+	char *m = (char *)mmap(NULL, bytes + 2 * ps, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+	if (m == (char *)MAP_FAILED) { close(fd); return -1; }
+	char *p = (char *)mmap(m + ps, bytes, native_prot(prot), MAP_SHARED | MAP_FIXED, fd, 0);
+	char *a = p == (char *)MAP_FAILED ? p : (char *)mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+	close(fd);                                     /* the mappings keep the pages alive */
+	if (p == (char *)MAP_FAILED || a == (char *)MAP_FAILED) {
+		if (a != (char *)MAP_FAILED && p != (char *)MAP_FAILED) munmap(a, bytes);
+		munmap(m, bytes + 2 * ps);
+		return -1;
+	}
+#ifdef MADV_HUGEPAGE
+	(void)madvise(p, bytes, MADV_HUGEPAGE);        /* (takes effect where shmem huge pages are set to `advise`; harmless elsewhere) */
+	(void)madvise(a, bytes, MADV_HUGEPAGE);
+#endif
+	*base = p; *alias = a;
+	return 0;
+}
+
+static void unmap_twice(lisp_region *r)
+{
+	munmap(r->base - page_size(), r->bytes + 2 * page_size());      /* (with its guard pages) */
+	munmap(r->alias, r->bytes);
+}
+
+/* value[] of `doubles` entries on pages of its own, zero-filled (as the calloc it replaces).  When the memory file cannot be had the vector
+ * lives in plain calloc'ed memory (region NULL: copies on every call, like eager coherence).  NULL: out of memory */
 LIS_SCALAR *lisp_alloc(LIS_VECTOR v, size_t doubles)
 {
 	const size_t ps = page_size();
 	size_t bytes = (doubles > 0 ? doubles : 1) * sizeof(LIS_SCALAR);
 	bytes = (bytes + ps - 1) / ps * ps;
-	/* an inaccessible guard page on either side keeps the kernel from merging these pages into one mapping (VMA) with a neighbour.  Measured
-	 * without them: the runtime registers the malloc'ed arrays of a matrix with the GPU driver while it uploads them (a pageable copy pins
-	 * its source); a vector mapped next to them shares their VMA, and the first mprotect of the vector then invalidates that registration --
-	 * the driver evicts the process's queues and the next stream synchronisation takes 25 ms (test/spmvtest3.c creates its vectors before it
-	 * converts its matrix: 35 instead of 7 ms for 100 products at 200^3) */
-	char *m = (char *)mmap(NULL, bytes + 2 * ps, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-	if (m == (char *)MAP_FAILED) return NULL;
-	void *p = m + ps;
-	if (mprotect(p, bytes, PROT_READ | PROT_WRITE) != 0) { munmap(m, bytes + 2 * ps); return NULL; }
-	lisp_region *r = (lisp_region *)malloc(sizeof(*r));
-	if (!r) { munmap(m, bytes + 2 * ps); return NULL; }
-	memset(r, 0, sizeof(*r));
-	r->base = (char *)p; r->bytes = bytes; r->prot = LISP_RW; r->owner = v;
+	VDEV(v)->region = NULL;
+	lisp_region *r = (lisp_region *)calloc(1, sizeof(*r));
+	if (!r) return NULL;
+	if (map_twice(bytes, LISP_RW, &r->base, &r->alias) != 0) {
+		free(r);
+		return (LIS_SCALAR *)calloc(doubles > 0 ? doubles : 1, sizeof(LIS_SCALAR));
+	}
+	r->bytes = bytes; r->prot = LISP_RW; r->owner = v;
 	pthread_mutex_lock(&region_lock);
 	r->next = regions; regions = r;
 	pthread_mutex_unlock(&region_lock);
 	VDEV(v)->region = r;
-	return (LIS_SCALAR *)p;
+	return (LIS_SCALAR *)r->base;
+}
+
+static void unlink_region(lisp_region *r)
+{
+	pthread_mutex_lock(&region_lock);
+	while (r->filling) pthread_cond_wait(&fill_done, &region_lock);
+	for (lisp_region **pp = &regions; *pp; pp = &(*pp)->next) if (*pp == r) { *pp = r->next; break; }
+	pthread_mutex_unlock(&region_lock);
 }
 
 void lisp_free(LIS_VECTOR v)
 {
 	lisp_region *r = (lisp_region *)VDEV(v)->region;
 	if (!r) return;
-	pthread_mutex_lock(&region_lock);
-	for (lisp_region **pp = &regions; *pp; pp = &(*pp)->next) if (*pp == r) { *pp = r->next; break; }
-	pthread_mutex_unlock(&region_lock);
-	munmap(r->base - page_size(), r->bytes + 2 * page_size());      /* (with its guard pages) */
+	unlink_region(r);
+	unmap_twice(r);
 	free(r);
 	VDEV(v)->region = NULL;
 }
 
 /* ---- arrays of a matrix that was converted in HBM (lis_convert.c): the Lis API promises host arrays (A->ptr, A->index, A->value ...), but a
  * program that only multiplies never reads them.  They get address space without access, bound to the device buffer that holds their
- * contents; the first touch -- by the program or by a host-side routine of this library -- brings them home (on_fault).  NULL: no memory. */
+ * contents; the first touch -- by the program or by a host-side routine of this library -- brings them home (on_fault, through the alias:
+ * no thread sees a half-filled array).  NULL: no memory / no handler / no memory file (the caller converts on the host). */
 void *lisp_alloc_lazy(void *matrix, size_t bytes_used, void *dev, int own_dev)
 {
 	const size_t ps = page_size();
 	size_t bytes = (bytes_used > 0 ? bytes_used : 1);
 	bytes = (bytes + ps - 1) / ps * ps;
 	if (!install_handler()) return NULL;
-	char *m = (char *)mmap(NULL, bytes + 2 * ps, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-	if (m == (char *)MAP_FAILED) return NULL;
 	lisp_region *r = (lisp_region *)calloc(1, sizeof(*r));
-	if (!r) { munmap(m, bytes + 2 * ps); return NULL; }
-	r->base = m + ps; r->bytes = bytes; r->prot = LISP_NONE; r->mowner = matrix; r->dev = dev; r->used = bytes_used; r->own_dev = own_dev;
+	if (!r) return NULL;
+	if (map_twice(bytes, LISP_NONE, &r->base, &r->alias) != 0) { free(r); return NULL; }
+	r->bytes = bytes; r->prot = LISP_NONE; r->mowner = matrix; r->dev = dev; r->used = bytes_used; r->own_dev = own_dev;
 	pthread_mutex_lock(&region_lock);
 	r->next = regions; regions = r;
 	pthread_mutex_unlock(&region_lock);
@@ -220,33 +312,35 @@ int lisp_free_array(void *p)
 	if (!p) return 0;
 	pthread_mutex_lock(&region_lock);
 	lisp_region *r = region_at(p);
-	if (r) for (lisp_region **pp = &regions; *pp; pp = &(*pp)->next) if (*pp == r) { *pp = r->next; break; }
+	if (r) {
+		while (r->filling) pthread_cond_wait(&fill_done, &region_lock);
+		for (lisp_region **pp = &regions; *pp; pp = &(*pp)->next) if (*pp == r) { *pp = r->next; break; }
+	}
 	pthread_mutex_unlock(&region_lock);
 	if (!r) return 0;
 	if (r->dev && r->own_dev) (void)liship_free(r->dev);
-	munmap(r->base - page_size(), r->bytes + 2 * page_size());
+	unmap_twice(r);
 	free(r);
 	return 1;
 }
 
-/* the HBM copy of `matrix` is about to go while the matrix lives on: every array still held there comes home now */
+/* the HBM copy of `matrix` is about to go while the matrix lives on (or a host routine is about to read its arrays from several
+ * threads): every array still held there comes home now */
 LIS_INT lisp_fill_matrix(void *matrix)
 {
 	for (;;) {
 		pthread_mutex_lock(&region_lock);
 		lisp_region *r = regions;
-		while (r && !(r->mowner == matrix && r->prot == LISP_NONE && r->dev)) r = r->next;
+		while (r && !(r->mowner == matrix && (r->filling || (r->prot == LISP_NONE && r->dev)))) r = r->next;
 		if (!r) { pthread_mutex_unlock(&region_lock); return LIS_SUCCESS; }
-		mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE);
-		r->prot = LISP_RW;
-		void *dev = r->dev;
-		const size_t used = r->used;
-		const int own = r->own_dev;
-		r->dev = NULL;
+		if (r->filling) {                              /* a faulting thread of the program is at it: wait for that copy, look again */
+			while (r->filling) pthread_cond_wait(&fill_done, &region_lock);
+			pthread_mutex_unlock(&region_lock);
+			continue;
+		}
+		r->filling = 1;
 		pthread_mutex_unlock(&region_lock);
-		LIS_INT err = used ? lisd_staged_d2h(r->base, dev, used) : LIS_SUCCESS;
-		if (own) (void)liship_free(dev);
-		if (err) return err;
+		LISCHK(region_fill(r, LISP_RW));
 	}
 }
 
@@ -274,11 +368,10 @@ LIS_INT lisp_grow(LIS_VECTOR v, size_t doubles)
 	LIS_SCALAR *old = v->value;
 	lisp_region *oldr = (lisp_region *)d->region;
 	const size_t have = d->hlen;
-	d->region = NULL;
-	LIS_SCALAR *nv = lisp_alloc(v, doubles);
+	LIS_SCALAR *nv = lisp_alloc(v, doubles);           /* (sets d->region to the new region, or NULL for plain memory) */
 	if (!nv) { d->region = oldr; return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)doubles); }
-	if (oldr && oldr->prot == LISP_NONE) mprotect(oldr->base, oldr->bytes, PROT_READ);
-	if (old) memcpy(nv, old, sizeof(LIS_SCALAR) * (have < doubles ? have : doubles));
+	const void *src = oldr ? (const void *)oldr->alias : (const void *)old;      /* (the alias: readable whatever the old pages' protection) */
+	if (src) memcpy(nv, src, sizeof(LIS_SCALAR) * (have < doubles ? have : doubles));
 	if (oldr) {
 		lisp_region *keep = (lisp_region *)d->region;
 		d->region = oldr;
@@ -290,14 +383,16 @@ LIS_INT lisp_grow(LIS_VECTOR v, size_t doubles)
 	return LIS_SUCCESS;
 }
 
-/* protection follows the vector's state; a no-op for vectors without pages of their own and in the other coherence modes */
+/* protection follows the vector's state; a no-op for vectors without pages of their own and in the other coherence modes.  The caller
+ * checks lisp_state() where it matters that the protection really is in place (lisd_vec_in, lisd_vec_done). */
 void lisp_protect(LIS_VECTOR v, int prot)
 {
 	lisp_region *r = (lisp_region *)VDEV(v)->region;
-	if (!r || r->prot == prot) return;
+	if (!r) return;
 	if (prot != LISP_RW && (!lisp_lazy() || !install_handler())) return;
 	pthread_mutex_lock(&region_lock);
-	if (mprotect(r->base, r->bytes, native_prot(prot)) == 0) r->prot = prot;
+	while (r->filling) pthread_cond_wait(&fill_done, &region_lock);      /* a thread of the program is bringing it home: let the copy finish */
+	if (r->prot != prot && mprotect(r->base, r->bytes, native_prot(prot)) == 0) r->prot = prot;
 	pthread_mutex_unlock(&region_lock);
 }
 
@@ -307,12 +402,36 @@ int lisp_state(LIS_VECTOR v)
 	return r ? r->prot : -1;
 }
 
+/* value[] current on the host, for a vector on pages of its own under lazy coherence: the HBM copy comes home through the alias (the
+ * program's mapping opens, read-only, when the data is there).  Called by the library's own host-side readers / writers
+ * (lisd_vec_to_host); a thread of the program that faults on the same vector meanwhile waits for this copy, and vice versa. */
+LIS_INT lisp_vec_home(LIS_VECTOR v)
+{
+	lisd_vec *d = VDEV(v);
+	lisp_region *r = (lisp_region *)d->region;
+	pthread_mutex_lock(&region_lock);
+	while (r->filling) pthread_cond_wait(&fill_done, &region_lock);
+	const int stale = r->test_src ? !d->host_valid : (!d->host_valid && d->dev_valid && d->d && v->value);
+	if (!stale) {
+		d->host_valid = 1;
+		if (r->prot == LISP_NONE) {
+			const int want = d->dev_valid ? LISP_RO : LISP_RW;
+			if (mprotect(r->base, r->bytes, native_prot(want)) == 0) r->prot = want;
+		}
+		pthread_mutex_unlock(&region_lock);
+		return LIS_SUCCESS;
+	}
+	r->filling = 1;
+	pthread_mutex_unlock(&region_lock);
+	return region_fill(r, LISP_RO);
+}
+
 /* lazy coherence applies to the COHERENT residency unless switched off */
 int lisp_lazy(void) { return lisg.residency == LIS_AMD_COHERENT && !lisg.eager_coherence; }
 
 LIS_INT lis_amd_set_coherence(LIS_INT lazy)
 {
-	lisg.eager_coherence = lazy ? 0 : 1;
+	lisg.eager_coherence = (lazy && !handler_failed) ? 0 : 1;
 	return LIS_SUCCESS;
 }
 
@@ -321,9 +440,26 @@ LIS_INT lis_amd_set_device_convert(LIS_INT on) { lisg.no_device_convert = on ? 0
 LIS_INT lis_amd_vector_page_state(LIS_VECTOR v) { return lisp_state(v); }
 LIS_INT lis_amd_vector_page_protect(LIS_VECTOR v, LIS_INT state) { lisp_protect(v, (int)state); return lisp_state(v) == (int)state ? LIS_SUCCESS : LIS_ERR_ILL_ARG; }
 
+/* tests of the fault handler without a GPU: `src` (n + pad doubles that must outlive the vector's next fault) plays the HBM copy of v --
+ * the pages lose all access, and the first touch copies src home in two halves delay_ms apart, through the alias.  NULL removes the hook. */
+LIS_INT lis_amd_vector_page_test_source(LIS_VECTOR v, const LIS_SCALAR *src, LIS_INT delay_ms)
+{
+	lisp_region *r = (lisp_region *)VDEV(v)->region;
+	if (!r) return LISI_ERR(LIS_ERR_ILL_ARG, "vector v has no pages of its own\n");
+	pthread_mutex_lock(&region_lock);
+	while (r->filling) pthread_cond_wait(&fill_done, &region_lock);
+	r->test_src = src; r->test_delay_ms = (int)delay_ms;
+	pthread_mutex_unlock(&region_lock);
+	if (!src) return LIS_SUCCESS;
+	VDEV(v)->host_valid = 0; VDEV(v)->dev_valid = 1;
+	lisp_protect(v, LISP_NONE);
+	return lisp_state(v) == LISP_NONE ? LIS_SUCCESS : LIS_ERR_NOT_IMPLEMENTED;
+}
+
 LIS_INT lis_amd_page_faults(LIS_INT *reads, LIS_INT *writes)
 {
 	if (reads) *reads = (LIS_INT)faults_read;
 	if (writes) *writes = (LIS_INT)faults_write;
 	return LIS_SUCCESS;
 }
+LIS_INT lis_amd_page_fault_waits(void) { return (LIS_INT)faults_waited; }

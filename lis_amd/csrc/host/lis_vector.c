@@ -46,7 +46,13 @@ LIS_INT lis_vector_set_size(LIS_VECTOR vec, LIS_INT local_n, LIS_INT global_n)
 		return LISI_ERR(LIS_ERR_ILL_ARG, "local n(=%D) or global n(=%D) are less than 0\n", local_n, global_n);
 	LIS_INT *ranges, is, ie, nprocs, my_rank;
 	LISCHK(lisc_ranges_create(vec->comm, &local_n, &global_n, &ranges, &is, &ie, &nprocs, &my_rank));
+	free(vec->ranges);                           /* (a second set_size: the first one's storage goes, its pages leave the fault registry) */
 	vec->ranges = ranges;
+	if (vec->value) {
+		lisd_vec_free(vec);
+		if (VDEV(vec)->region) lisp_free(vec); else free(vec->value);
+		vec->value = NULL;
+	}
 	vec->value = lisp_alloc(vec, (size_t)local_n);          /* pages of its own, zero-filled: their protection follows the HBM copy (lis_pages.c) */
 	if (!vec->value) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", local_n);
 	VDEV(vec)->hlen = (size_t)local_n;

@@ -14,6 +14,8 @@ import lisdrv
 import orc
 from lis_amd import _capi as capi
 
+HERE = os.path.dirname(os.path.abspath(__file__))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = np.load(os.path.join(ROOT, "tests", "golden", "lis_ref_golden.npz"))
 HAVE_GPU = lis_amd.gpu_available()
@@ -415,3 +417,52 @@ def test_foreign_segfaults_still_kill_the_process():
             "print('survived', flush=True)\n") % (ROOT, os.path.join(ROOT, "tests"))
     p = subprocess.run([sys.executable, "-X", "faulthandler=0", "-c", code], capture_output=True, text=True, timeout=120)
     assert "served" in p.stdout and "survived" not in p.stdout and p.returncode == -11, (p.returncode, p.stdout, p.stderr[-500:])
+
+
+# ---------------------------------------------------------------- several threads of the program on one protected vector (tests/c/pages_threads.c)
+def build_pages_driver(tmp_path):
+    """gcc -fopenmp tests/c/pages_threads.c against include/ and liblis_amd.so (a C program: Python threads would serialise on the GIL)"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "pages_threads")
+    libdir = os.path.join(root, "lis_amd", "lib")
+    subprocess.run(["gcc", "-O1", "-fopenmp", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(HERE, "c", "pages_threads.c"), "-o", exe,
+                    "-L" + libdir, "-llis_amd", "-lm", "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("mode", [("cpu-readers", "8", "4"), ("cpu-readers", "2", "6"), ("cpu-writers", "2"), ("cpu-writers", "8"), ("cpu-fwrite",)])
+def test_threads_of_the_program_never_see_a_half_filled_vector(tmp_path, mode):
+    """lis_pages.c fills a vector coming home through a second mapping of its pages and opens the program's mapping only when the data is
+    complete: T threads that read (or write) disjoint slices of v->value at once -- an OpenMP loop after lis_solve -- all see the data; the
+    first fault copies, the others wait.  Several rounds on the same vector with the same thread -> slice mapping: repeated faults at the
+    same addresses must neither be mistaken for foreign ones nor remove the handler.  A host buffer plays the HBM copy, copied in two halves
+    150 ms apart (lis_amd_vector_page_test_source), so a thread that got through early WOULD read stale entries.  cpu-fwrite pins what page
+    protection cannot do (write(2) of a protected buffer: EFAULT) and the documented ways round it."""
+    import subprocess
+    exe = build_pages_driver(tmp_path)
+    out = subprocess.run([exe, *mode], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.stdout, out.stderr[-2000:])
+    if mode[0] == "cpu-readers":
+        T, R = int(mode[1]), int(mode[2])
+        assert f"read_faults={R} " in out.stdout and f"write_faults=0 " in out.stdout       # one copy per round, whatever the thread count
+        waits = int(out.stdout.split("waits=")[1])
+        assert 1 <= waits <= (T - 1) * R          # the other threads found the copy in flight and waited (not all of them need to)
+
+
+def test_second_set_size_releases_the_first_pages(lib):
+    """lis_vector_set_size twice (the reference leaks the first array): the first pages leave the fault registry and are unmapped"""
+    v = capi.PV()
+    assert lib.lis_vector_create(0, C.byref(v)) == 0
+    assert lib.lis_vector_set_size(v, 3000, 0) == 0
+    first = C.addressof(v.contents.value.contents)
+    assert lib.lis_vector_set_size(v, 7000, 0) == 0
+    assert v.contents.n == 7000
+    val = np.ctypeslib.as_array(v.contents.value, shape=(7000,))
+    assert not val.any()
+    val[:] = 1.0
+    lib.dll.lis_amd_vector_page_state.argtypes = [capi.PV]
+    assert lib.dll.lis_amd_vector_page_state(v) == 0
+    maps = open("/proc/self/maps").read()
+    assert ("%x-" % first) not in maps            # the first mapping is gone
+    assert lib.lis_vector_destroy(v) == 0

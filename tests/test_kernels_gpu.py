@@ -1448,6 +1448,31 @@ def test_full_size_512_six_forms_bit_equal(lib):
     # the product is not trivially zero, and x^T A x > 0 (A is positive definite)
     check(lib.liship_nrm1_f64(n, y0.ptr, res.ptr, work.ptr, None))
     assert res.to_host()[0] > 1e6 and dots[0][0] > 0.0
+    # ... and the chain to the ORACLE is closed at this size too: three slabs of 2^20 rows -- the first rows (a boundary face), rows across
+    # plane boundaries in the middle, the last rows -- are generated by the oracle's own generator (test/test3.c:114-127 restated), multiplied
+    # by the oracle (lis_matvec_csr.c:97-109 restated) and compared with the same rows of y0 IN EVERY BIT; every other form equals y0 above.
+    # The device-made matrix is compared with the generator's arrays on the same rows on the way.
+    slab, mn = 1 << 20, N * N
+    hp = np.empty(slab + 1, np.int32)
+    for r0 in (0, (n // 2) - (slab // 2) + 12345, n - slab):
+        r1 = r0 + slab
+        ptr_s, idx_s, val_s = orc.poisson3d(N, N, N, is_=r0, ie=r1)
+        check(lib.liship_memcpy_d2h(hp.ctypes.data, dptr.ptr + 4 * r0, hp.nbytes, None))
+        check(lib.liship_device_synchronize())
+        k0, k1 = int(hp[0]), int(hp[-1])
+        assert np.array_equal(hp - hp[0], ptr_s)
+        hidx, hval = np.empty(k1 - k0, np.int32), np.empty(k1 - k0, np.float64)
+        check(lib.liship_memcpy_d2h(hidx.ctypes.data, didx.ptr + 4 * k0, hidx.nbytes, None))
+        check(lib.liship_memcpy_d2h(hval.ctypes.data, dval.ptr + 8 * k0, hval.nbytes, None))
+        check(lib.liship_device_synchronize())
+        assert np.array_equal(hidx, idx_s) and np.array_equal(hval, val_s)
+        lo, hi = max(0, r0 - mn), min(n, r1 + mn)          # the columns these rows reach
+        xwin, yslab = np.empty(hi - lo, np.float64), np.empty(slab, np.float64)
+        check(lib.liship_memcpy_d2h(xwin.ctypes.data, x.ptr + 8 * lo, xwin.nbytes, None))
+        check(lib.liship_memcpy_d2h(yslab.ctypes.data, y0.ptr + 8 * r0, yslab.nbytes, None))
+        check(lib.liship_device_synchronize())
+        yref = orc.spmv_csr(ptr_s, idx_s - lo, val_s, xwin)
+        assert np.array_equal(yslab.view(np.uint64), yref.view(np.uint64)), r0
     # the forms that share a row-block geometry share their partial sums (coded plans rebuild the split at 256 / 2048, the 4 B form keeps
     # the 192 / 1408 one of the bare plan only when no codes exist -- here every form runs on the coded plan's blocks)
     for on in (1, 2, 3, 4, 5, 8):

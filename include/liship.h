@@ -247,6 +247,9 @@ int  liship_set_all_f64(int n, double alpha, double *x, void *stream);
 int  liship_abs_f64  (int n, double *x, void *stream);
 int  liship_reciprocal_f64(int n, double *x, void *stream);
 int  liship_shift_f64(int n, double sigma, double *x, void *stream);
+int  liship_rsqrt_abs_f64(int n, double *x, void *stream);                                   /* x = 1/sqrt(|x|)   (lis_matrix_ops.c:611-614) */
+/* rows of a CSR matrix scaled in HBM: value *= d[row] (symm 0, lis_matrix_csr.c:609-647) or value = value*d[row]*d[col] (symm 1, :651-690) */
+int  liship_csr_scale_f64(int n, const int *ptr, const int *index, double *value, const double *d, int symm, void *stream);
 /* fused forms: the SAME per-element expressions in the SAME order as the calls they replace (bit-identical),
  * one pass over HBM instead of two or three */
 int  liship_axpy2_f64(int n, double a, const double *x, double b, const double *w, double *y, void *stream);       /* y += a*x; y += b*w   (lis_solver_bicgstab.c:272-273) */

@@ -121,6 +121,8 @@ _LISHIP = {
     "liship_abs_f64": (_ci, [_ci, _vp, _vp]),
     "liship_reciprocal_f64": (_ci, [_ci, _vp, _vp]),
     "liship_shift_f64": (_ci, [_ci, _cd, _vp, _vp]),
+    "liship_rsqrt_abs_f64": (_ci, [_ci, _vp, _vp]),
+    "liship_csr_scale_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _ci, _vp]),
     "liship_axpy2_f64": (_ci, [_ci, _cd, _vp, _cd, _vp, _vp, _vp]),
     "liship_axpy_xpay_f64": (_ci, [_ci, _cd, _vp, _vp, _cd, _vp, _vp]),
     "liship_cg_update_f64": (_ci, [_ci, _cd, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -712,7 +712,7 @@ void lisd_mat_free(LIS_MATRIX A)
 	if (d->u_plan) (void)liship_csr_plan_destroy(d->u_plan);
 	(void)liship_free(d->u_ptr); (void)liship_free(d->u_index); (void)liship_free(d->u_value); (void)liship_free(d->dsplit); (void)liship_free(d->jw);
 	if (d->t_plan) (void)liship_csr_plan_destroy(d->t_plan);
-	(void)liship_free(d->t_ptr); (void)liship_free(d->t_index); (void)liship_free(d->t_value); (void)liship_free(d->wr);
+	(void)liship_free(d->t_ptr); (void)liship_free(d->t_index); (void)liship_free(d->t_value); (void)liship_free(d->wr); (void)liship_free(d->t_diag);
 	(void)liship_free(d->ell_codes); (void)liship_free(d->ell_dict);
 	(void)liship_free(d->ptr); (void)liship_free(d->index); (void)liship_free(d->row);
 	(void)liship_free(d->bptr); (void)liship_free(d->bindex); (void)liship_free(d->value);

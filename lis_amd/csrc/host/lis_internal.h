@@ -65,6 +65,7 @@ typedef struct {
 	double *t_value;
 	liship_csr_plan_t t_plan;
 	double *wr;                /* received ghost contributions (reverse halo) */
+	double *t_diag;            /* split CSR: the diagonal, added to the off-diagonal sums of A^T x by one element-wise pass (lis_matvech.c) */
 	/* halo (multi-GPU) */
 	int halo_ready;
 	int *export_index;         /* device copy of commtable->export_index */

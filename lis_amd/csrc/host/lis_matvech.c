@@ -13,6 +13,14 @@
  * (288 GB per GPU: affordable), built lazily on the first lis_matvech.
  * Multi-GPU: local rows of A^T are the np columns of the local block, so y has ghost entries; they are
  * sent back to their owners and added there in neighbour order (lis_reduce, lis_matrix_mpi.c:959-1000).
+ *
+ * Split matrices (A = L + D + U, lis_split.c), the two formats whose split A^T x is reached by solver options (`-scale jacobi -storage bsr`
+ * with BiCG-type solvers, and lis_matrix_split by hand on CSR):
+ *   CSR  the OpenMP build scatters the L entries, then the U entries of row i into w, row after row, and finishes with
+ *        y[c] = D[c]*x[c] + (0.0 + w[c]) (src/matvec/lis_matvec_csr.c:125-160): the transposed rows list the off-diagonal walk, the
+ *        product forms w, one element-wise pass adds it to D.*x -- (d x) + (sum), not one chain
+ *   BSR  serial in every build (lis_matvec_bsr.c:878-925): y = 0, then the diagonal blocks' terms, then the L and U blocks of block
+ *        row after block row: ONE chain per y[c] -- the transposed rows list exactly that walk, D terms first
  */
 #include <stdio.h>
 #include "lis_internal.h"
@@ -72,6 +80,35 @@ static void walk(LIS_INT type, LIS_MATRIX A, const LIS_INT *ptr, const LIS_INT *
 	}
 }
 
+/* the walks of a split matrix (see the head of this file); CSR: off-diagonal parts only, the diagonal is added by lisd_spmv_t */
+static void walk_split(LIS_MATRIX A, walk_t *w)
+{
+	const LIS_INT n = A->n;
+	if (A->matrix_type == LIS_MATRIX_CSR) {
+		for (LIS_INT i = 0; i < n; i++) {
+			for (LIS_INT j = A->L->ptr[i]; j < A->L->ptr[i + 1]; j++) emit(w, A->L->index[j], i, A->L->value[j]);
+			for (LIS_INT j = A->U->ptr[i]; j < A->U->ptr[i + 1]; j++) emit(w, A->U->index[j], i, A->U->value[j]);
+		}
+		return;
+	}
+	const LIS_INT bnr = A->bnr, bnc = A->bnc, bs = bnr * bnc;
+	for (LIS_INT bi = 0; bi < A->nr; bi++) {
+		size_t k = (size_t)bi * bs;
+		for (LIS_INT j = 0; j < bnc; j++)
+			for (LIS_INT i = 0; i < bnr; i++, k++) emit(w, bi * bnr + j, bi * bnr + i, A->D->value[k]);
+	}
+	for (LIS_INT bi = 0; bi < A->nr; bi++)
+		for (int part = 0; part < 2; part++) {
+			const LIS_MATRIX_CORE P = part ? A->U : A->L;
+			for (LIS_INT bc = P->bptr[bi]; bc < P->bptr[bi + 1]; bc++) {
+				const LIS_INT bj = P->bindex[bc] * bnc;
+				size_t k = (size_t)bc * bs;
+				for (LIS_INT j = 0; j < bnc; j++)
+					for (LIS_INT i = 0; i < bnr; i++, k++) emit(w, bj + j, bi * bnr + i, P->value[k]);
+			}
+		}
+}
+
 static LIS_INT upload(void **dst, const void *src, size_t bytes)
 {
 	HIPCHK(lisd_malloc(dst, bytes + 16));
@@ -82,13 +119,44 @@ static LIS_INT upload(void **dst, const void *src, size_t bytes)
 LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
-	if (A->is_splited) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "A^T x of a split (D/L/U) matrix is not served\n");     /* another summation order again (lis_matvec_csr.c:124-160) */
+	const int split = A->is_splited != 0;
+	if (split && !(A->matrix_type == LIS_MATRIX_CSR || (A->matrix_type == LIS_MATRIX_BSR && A->bnr == A->bnc)))
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "A^T x of a split (D/L/U) matrix is served for CSR and square-block BSR storage\n");
+	if (split && lisg.nprocs > 1) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "A^T x of a split matrix in a multi-rank job is not served\n");
 	if (d->t_ready) return LIS_SUCCESS;
 	LISCHK(lisd_mat_ready(A));
 	if (!(A->matrix_type == LIS_MATRIX_CSR && d->type == LIS_MATRIX_CSR)) LISCHK(lisp_fill_matrix(A));   /* the host arrays are read below (and handed to the runtime) */
 	const LIS_INT type = A->matrix_type, n = A->n, np = A->np;
 	d->t_rows = np;
-	if (type == LIS_MATRIX_CSC) {          /* CSC arrays ARE the CSR of A^T: np rows, row indices as columns */
+	if (split) {
+		walk_t w;
+		memset(&w, 0, sizeof(w));
+		w.rows = np; w.cols = n;
+		w.ptr = (LIS_INT *)calloc((size_t)np + 2, sizeof(LIS_INT));
+		if (!w.ptr) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "transpose\n");
+		w.pass = 0;
+		walk_split(A, &w);
+		for (LIS_INT c = 0; c < np; c++) w.ptr[c + 1] += w.ptr[c];
+		const LIS_INT tnnz = w.ptr[np];
+		w.fill = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(np > 0 ? np : 1));
+		w.index = (LIS_INT *)malloc(sizeof(LIS_INT) * (size_t)(tnnz > 0 ? tnnz : 1));
+		w.value = (double *)malloc(sizeof(double) * (size_t)(tnnz > 0 ? tnnz : 1));
+		LIS_INT err = LIS_SUCCESS;
+		if (!w.fill || !w.index || !w.value) err = LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "transpose\n");
+		if (!err) {
+			memcpy(w.fill, w.ptr, sizeof(LIS_INT) * (size_t)np);
+			w.pass = 1;
+			walk_split(A, &w);
+			d->t_nnz = tnnz;
+			err = upload((void **)&d->t_ptr, w.ptr, sizeof(int) * ((size_t)np + 1));
+			if (!err) err = upload((void **)&d->t_index, w.index, sizeof(int) * (size_t)tnnz);
+			if (!err) err = upload((void **)&d->t_value, w.value, sizeof(double) * (size_t)tnnz);
+			if (!err && type == LIS_MATRIX_CSR) err = upload((void **)&d->t_diag, A->D->value, sizeof(double) * (size_t)n);
+			if (!err && liship_stream_synchronize(lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+		}
+		free(w.ptr); free(w.fill); free(w.index); free(w.value);
+		if (err) return err;
+	} else if (type == LIS_MATRIX_CSC) {          /* CSC arrays ARE the CSR of A^T: np rows, row indices as columns */
 		d->t_nnz = A->nnz;
 		LISCHK(upload((void **)&d->t_ptr, A->ptr, sizeof(int) * ((size_t)np + 1)));
 		LISCHK(upload((void **)&d->t_index, A->index, sizeof(int) * (size_t)A->nnz));
@@ -166,6 +234,8 @@ LIS_INT lisd_spmv_t(LIS_MATRIX A, double *dx, double *dy)
 		HIPCHK(liship_spmv_csr_transposed_chunked_f64(d->t_rows, A->n, lisg.ref_reductions, d->t_ptr, d->t_index, d->t_value, dx, dy, lisg.stream));
 	else
 		HIPCHK(liship_spmv_csr_f64(d->t_plan, d->t_ptr, d->t_index, d->t_value, dx, dy, lisg.stream));
+	if (d->t_diag)          /* split CSR: y = D.*x + 1*w, w the off-diagonal sums just formed (1*w is w; lis_matvec_csr.c:152-159) */
+		HIPCHK(liship_pmul_xpay_f64(A->n, dx, d->t_diag, 1.0, dy, lisg.stream));
 	if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_reduce_device(A, dy));
 	return LIS_SUCCESS;
 }

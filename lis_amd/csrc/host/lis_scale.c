@@ -13,9 +13,55 @@
  */
 #include "lis_internal.h"
 
+/* the split forms (D/L/U) the reference scales part by part: CSR (lis_matrix_csr.c:617-632, :661-676: D becomes 1) and BSR
+ * (lis_matrix_bsr.c:820-855, :895-935: the diagonal blocks are scaled like the others -- by d[row]*d[ROW] in the symmetric case, as there) */
+static LIS_INT scale_values_split(LIS_MATRIX A, const double *d, int symm)
+{
+	const LIS_INT n = A->n;
+	if (A->matrix_type == LIS_MATRIX_CSR) {
+		for (LIS_INT i = 0; i < n; i++) {
+			A->D->value[i] = 1.0;
+			for (int part = 0; part < 2; part++) {
+				const LIS_MATRIX_CORE P = part ? A->U : A->L;
+				for (LIS_INT j = P->ptr[i]; j < P->ptr[i + 1]; j++) {
+					if (symm) P->value[j] = P->value[j] * d[i] * d[P->index[j]];
+					else P->value[j] *= d[i];
+				}
+			}
+		}
+		return LIS_SUCCESS;
+	}
+	if (A->matrix_type == LIS_MATRIX_BSR) {
+		const LIS_INT bnr = A->bnr, bnc = A->bnc, bs = bnr * bnc;
+		for (LIS_INT bi = 0; bi < A->nr; bi++) {
+			for (int part = 0; part < 2; part++) {
+				const LIS_MATRIX_CORE P = part ? A->U : A->L;
+				for (LIS_INT bj = P->bptr[bi]; bj < P->bptr[bi + 1]; bj++) {
+					const LIS_INT bjj = P->bindex[bj];
+					for (LIS_INT j = 0; j < bnc; j++)
+						for (LIS_INT i = 0; i < bnr; i++) {
+							const size_t k = (size_t)bj * bs + (size_t)j * bnr + i;
+							if (symm) P->value[k] *= d[bi * bnr + i] * d[bjj * bnc + j];
+							else P->value[k] *= d[bi * bnr + i];
+						}
+				}
+			}
+			for (LIS_INT j = 0; j < bnc; j++)
+				for (LIS_INT i = 0; i < bnr; i++) {
+					const size_t k = (size_t)bi * bs + (size_t)j * bnr + i;
+					if (symm) A->D->value[k] *= d[bi * bnr + i] * d[bi * bnr + i];
+					else A->D->value[k] *= d[bi * bnr + i];
+				}
+		}
+		return LIS_SUCCESS;
+	}
+	return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "scaling a split (D/L/U) matrix is served for CSR and BSR storage\n");
+}
+
 static LIS_INT scale_values(LIS_MATRIX A, const double *d, int symm)
 {
 	const LIS_INT n = A->n;
+	if (A->is_splited) return scale_values_split(A, d, symm);
 	switch (A->matrix_type) {
 	case LIS_MATRIX_CSR:
 		for (LIS_INT i = 0; i < n; i++)
@@ -79,12 +125,49 @@ static LIS_INT scale_values(LIS_MATRIX A, const double *d, int symm)
 	return LIS_SUCCESS;
 }
 
+/* A matrix whose arrays live in HBM only (lis_amd_matrix_set_csr_device, lis_amd_matrix_poisson3d): the same passes by kernels -- diagonal,
+ * d = 1/diag or 1/sqrt|diag| (with the neighbours' entries behind it for the symmetric form: lis_matrix_ops.c:596-608), the rows' values,
+ * b -- and the plan is rebuilt on the scaled values (value records of the unscaled matrix are gone). */
+static LIS_INT scale_device_only(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_INT action)
+{
+	lisd_mat *m = MDEV(A);
+	if (A->matrix_type != LIS_MATRIX_CSR || m->type != LIS_MATRIX_CSR || A->is_splited)
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "matrices that live in HBM only are scaled in CSR storage\n");
+	const LIS_INT n = A->n, np = A->np;
+	const int symm = action == LIS_SCALE_SYMM_DIAG;
+	double *dd, *db;
+	if (D->np < np) D->np = np;
+	LISCHK(lisd_vec_reserve(D, (size_t)np + (size_t)A->pad));
+	LISCHK(lis_matrix_get_diagonal(A, D));             /* on the device for such a matrix */
+	LISCHK(lisd_vec_in(D, &dd));
+	if (symm) {
+		if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dd));
+		HIPCHK(liship_rsqrt_abs_f64(np, dd, lisg.stream));
+	} else HIPCHK(liship_reciprocal_f64(n, dd, lisg.stream));
+	LISCHK(lisd_vec_done(D));
+	LISCHK(lisd_vec_in(D, &dd));
+	HIPCHK(liship_csr_scale_f64(n, m->ptr, m->index, m->value, dd, symm, lisg.stream));
+	LISCHK(lisd_vec_in(B, &db));
+	HIPCHK(liship_pmul_f64(n, db, dd, db, lisg.stream));      /* b[i] = b[i]*d[i] */
+	LISCHK(lisd_vec_done(B));
+	/* everything derived from the old values goes: the plan (codes, patterns, value records), the transposed copy */
+	if (m->plan) { (void)liship_csr_plan_destroy(m->plan); m->plan = NULL; }
+	if (m->t_plan) { (void)liship_csr_plan_destroy(m->t_plan); m->t_plan = NULL; }
+	(void)liship_free(m->t_ptr); (void)liship_free(m->t_index); (void)liship_free(m->t_value); (void)liship_free(m->t_diag);
+	m->t_ptr = NULL; m->t_index = NULL; m->t_value = NULL; m->t_diag = NULL; m->t_ready = 0;
+	LISCHK(lisd_csr_plan(&m->plan, n, m->ptr, m->index, m->value));
+	A->is_scaled = LIS_TRUE;
+	B->is_scaled = LIS_TRUE;
+	return LIS_SUCCESS;
+}
+
 LIS_INT lis_matrix_scale(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_INT action)
 {
 	if (!lisi_is_registered(A) || A->status < LIS_MATRIX_CSR) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is not assembled\n");
-	if (MDEV(A)->device_only) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "scaling a matrix that lives in HBM only is not implemented\n");
-	if (A->is_splited) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "split (D/L/U) matrices are not served\n");
+	if (A->is_splited && A->matrix_type != LIS_MATRIX_CSR && A->matrix_type != LIS_MATRIX_BSR)
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "scaling a split (D/L/U) matrix is served for CSR and BSR storage\n");
 	if (action != LIS_SCALE_JACOBI && action != LIS_SCALE_SYMM_DIAG) return LIS_SUCCESS;   /* the reference falls through too */
+	if (MDEV(A)->device_only) return scale_device_only(A, B, D, action);
 	LISCHK(lisp_fill_matrix(A));
 	const LIS_INT n = A->n, np = A->np;
 	LISCHK(lis_matrix_get_diagonal(A, D));

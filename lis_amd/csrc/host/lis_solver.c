@@ -1013,13 +1013,6 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	if ((nsolver == LIS_SOLVER_GMRES || nsolver == LIS_SOLVER_ORTHOMIN || nsolver == LIS_SOLVER_FGMRES) && solver->options[LIS_OPTIONS_RESTART] < 0)
 		return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_RESTART(=%D) is less than 0\n", solver->options[LIS_OPTIONS_RESTART]);
 	if (A->n != b->n || A->n != x->n) return LISI_ERR(LIS_ERR_ILL_ARG, "sizes of A, b and x do not match\n");
-	/* -scale jacobi -storage bsr iterates on the SPLIT matrix (below), whose transposed product is not served (lis_matvech.c): the
-	 * solvers that need A^T x are turned away here, before A is retyped, split and scaled and b is scaled in place */
-	if (scale == LIS_SCALE_JACOBI && storage == LIS_MATRIX_BSR &&
-	    (nsolver == LIS_SOLVER_BICG || nsolver == LIS_SOLVER_BICR || nsolver == LIS_SOLVER_CRS || nsolver == LIS_SOLVER_BICRSTAB ||
-	     nsolver == LIS_SOLVER_GPBICR || nsolver == LIS_SOLVER_BICRSAFE))
-		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s with -scale jacobi -storage bsr needs A^T x of a split matrix, which is not served\n", solver_names[nsolver]);
-
 	solver->A = A; solver->b = b;
 	solver->precision = LIS_PRECISION_DOUBLE;
 	free(solver->rhistory);

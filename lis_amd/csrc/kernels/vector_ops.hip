@@ -50,7 +50,7 @@ const double *g_guard = nullptr;
 
 // ---- element-wise ---------------------------------------------------------------------------------
 enum EwOp { EW_AXPY, EW_XPAY, EW_AXPYZ, EW_SCALE_TO, EW_PMUL, EW_PDIV, EW_SET, EW_ABS, EW_RECIP, EW_SHIFT,
-            EW_AXPY2, EW_PUPDATE, EW_PMUL_XPAY, EW_SCALE_DEV };
+            EW_AXPY2, EW_PUPDATE, EW_PMUL_XPAY, EW_SCALE_DEV, EW_RSQRT_ABS };
 
 // x = in0, y = in1, w = in2; the expressions are the reference's (file:line in liship.h)
 template <int OP>
@@ -71,12 +71,13 @@ __device__ __forceinline__ double ew_apply(double a, double b, double x, double 
     case EW_PUPDATE:  { double t = y + a * x; return w + b * t; }        // y += a*x ; y = w + b*y
     case EW_PMUL_XPAY: { double z = x * w; return z + a * y; }          // z = x.*w ; y = z + a*y
     case EW_SCALE_DEV: return a * x;             // a = 1/sqrt(*device scalar), formed once per lane
+    case EW_RSQRT_ABS: return 1.0 / sqrt(fabs(x));   // d[i] = 1.0 / sqrt(fabs(d[i]))  (lis_matrix_ops.c:611-614)
     }
     return 0.0;
 }
 
 template <int OP> struct EwArity { static constexpr int value =
-    (OP == EW_SET) ? 0 : (OP == EW_SCALE_TO || OP == EW_ABS || OP == EW_RECIP || OP == EW_SHIFT || OP == EW_SCALE_DEV) ? 1 :
+    (OP == EW_SET) ? 0 : (OP == EW_SCALE_TO || OP == EW_ABS || OP == EW_RECIP || OP == EW_SHIFT || OP == EW_SCALE_DEV || OP == EW_RSQRT_ABS) ? 1 :
     (OP == EW_AXPY2 || OP == EW_PUPDATE || OP == EW_PMUL_XPAY) ? 3 : 2; };
 
 template <int OP, bool NT, bool VEC>
@@ -756,6 +757,8 @@ extern "C" int liship_abs_f64(int n, double *x, void *s)
 { return run_ew<EW_ABS>(n, 0.0, 0.0, x, nullptr, nullptr, x, s); }
 extern "C" int liship_reciprocal_f64(int n, double *x, void *s)
 { return run_ew<EW_RECIP>(n, 0.0, 0.0, x, nullptr, nullptr, x, s); }
+extern "C" int liship_rsqrt_abs_f64(int n, double *x, void *s)
+{ return run_ew<EW_RSQRT_ABS>(n, 0.0, 0.0, x, nullptr, nullptr, x, s); }
 extern "C" int liship_shift_f64(int n, double sigma, double *x, void *s)
 { return run_ew<EW_SHIFT>(n, sigma, 0.0, x, nullptr, nullptr, x, s); }
 extern "C" int liship_axpy2_f64(int n, double a, const double *x, double b, const double *w, double *y, void *s)
@@ -997,6 +1000,30 @@ extern "C" int liship_scatter_add_f64(int count, const int *index, const double 
     int grid = (count + BLOCK - 1) / BLOCK;
     if (grid > 4096) grid = 4096;
     scatter_add_kernel<<<grid, BLOCK, 0, as_stream(s)>>>(count, index, src, y);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
+// value[j] *= d[i] (jacobi) or value[j] = value[j]*d[i]*d[index[j]] (symm_diag) for the entries of row i: lis_matrix_scale_csr /
+// lis_matrix_scale_symm_csr (src/matrix/lis_matrix_csr.c:609-690), one rounded product after the other
+__global__ __launch_bounds__(BLOCK)
+void csr_scale_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ idx, double *__restrict__ val, const double *__restrict__ d, int symm)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const double dr = d[r];
+    for (int k = ptr[r]; k < ptr[r + 1]; k++) {
+        if (symm) { const double t = val[k] * dr; val[k] = t * d[idx[k]]; }
+        else val[k] = val[k] * dr;
+    }
+}
+} // namespace
+extern "C" int liship_csr_scale_f64(int n, const int *ptr, const int *idx, double *val, const double *d, int symm, void *s)
+{
+    if (n < 0) return LISHIP_ERR_ARG;
+    if (n == 0) return 0;
+    csr_scale_kernel<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, as_stream(s)>>>(n, ptr, idx, val, d, symm);
     LAUNCH_CHECK();
     return 0;
 }

@@ -171,3 +171,31 @@ def test_lis_matrix_merge_rebuilds_the_arrays_from_the_parts(lib, name, fmt, bs)
             for k in mine:
                 if isinstance(mine[k], np.ndarray):
                     assert np.array_equal(mine[k], ref[k]) and (mine[k].dtype != np.float64 or same_bits(mine[k], ref[k])), k
+
+
+# ---------------------------------------------------------------- round 4: scaling a split matrix is host code (no GPU needed for the arrays)
+GT = np.load(os.path.join(os.path.dirname(__file__), "golden", "split_t_golden.npz"))
+
+
+@pytest.mark.parametrize("name", ["p3d_6x5x4", "nonsym_61", "zeros_40"])
+@pytest.mark.parametrize("fmt,bs", [("csr", 0), ("bsr", 2), ("bsr", 3)])
+@pytest.mark.parametrize("action", [1, 2])
+def test_scaling_a_split_matrix_on_the_host(lib, name, fmt, bs, action):
+    """lis_matrix_scale on A = L + D + U: the parts and b, d as the reference leaves them (lis_matrix_csr.c:617-632, :661-676: D becomes 1;
+    lis_matrix_bsr.c:820-855, :895-935: the diagonal blocks scaled by d[row]*d[row] in the symmetric case, as there)"""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "split_golden.npz"))
+    ptr, idx, val = (G[f"{name}/{k}"] for k in ("ptr", "idx", "val"))
+    n = len(ptr) - 1
+    key = f"{name}/{fmt}{bs if bs else ''}/scale{action}"
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    B = A if fmt == "csr" else lisdrv.convert(lib, A, fmt, bs, bs)
+    assert lib.lis_matrix_split(B) == 0
+    vb, vd = lisdrv.new_vector(lib, B, np.cos(np.arange(n) * 0.3) + 2.0), lisdrv.new_vector(lib, B)
+    assert lib.lis_matrix_scale(B, vb, vd, action) == 0
+    parts = lisdrv.split_arrays(B)
+    assert same_bits(parts["L"]["value"], GT[key + "/L"]) and same_bits(parts["U"]["value"], GT[key + "/U"]) and same_bits(parts["D"], GT[key + "/D"])
+    assert same_bits(lisdrv.get_vector(lib, vb, n), GT[key + "/b"]) and same_bits(lisdrv.get_vector(lib, vd, n), GT[key + "/d"])
+    lib.lis_vector_destroy(vb); lib.lis_vector_destroy(vd)
+    if B is not A:
+        lib.lis_matrix_destroy(B)
+    lib.lis_matrix_destroy(A)

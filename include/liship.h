@@ -142,6 +142,10 @@ int  liship_spmv_csr_set_index_codes(int on);
 int  liship_csr_plan_localize_columns(liship_csr_plan_t plan, const int *ptr, const int *index, void *stream);
 long long liship_csr_plan_localized(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_local_columns(int on);
+/* round 4: the block-local kernel keeps the 2 B positions in registers and stages 3584 items (lists <= 1024 columns) or 3072 items (longer lists) per
+ * workgroup -- 39.5 KB of LDS, four workgroups per CU.  0: plans built from now on take the round-3 form (4096-item blocks, positions through LDS: three /
+ * two workgroups per CU); A/B measurements, same bits either way */
+int  liship_spmv_csr_set_local_register_positions(int on);
 /* Opt-in, off by default, NOT bit-identical to the reference: the part of a row beyond the LDS stage (~2100 entries) is added
  * by a workgroup-wide tree per pass instead of one left-to-right chain (a 200 000-entry row is otherwise a 200 000-long
  * dependent add chain, by the parity contract).  Deterministic; rows that fit the stage keep the reference's bits. */

@@ -43,9 +43,18 @@ constexpr Geometry kGeom[] = {
     {256, 1536},   // 4
     {512, 4096},   // 5
     { 64,  512},   // 6: one wavefront per workgroup
+    {512, 3072},   // 7: block-local columns, lists of up to 2048 columns, positions in registers: 39.5 KB of LDS (lists <= 1536), FOUR workgroups per CU
+    {512, 3584},   // 8: block-local columns, lists of up to 1024 columns, positions in registers: 39.5 KB of LDS, FOUR workgroups per CU
 };
 constexpr int kNumGeom = sizeof(kGeom) / sizeof(kGeom[0]);
-constexpr int LOCAL_GEOM = 5;    // block-local columns (spmv_csr_local_kernel): 512 lanes / 4096 items, 2 distinct columns per lane
+constexpr int LOCAL_GEOM = 5;    // block-local columns (spmv_csr_local_kernel), rounds 2-3: 512 lanes / 4096 items, positions staged in LDS (53 / 61 KB: 3 / 2 workgroups per CU)
+// Round 4.  The kernel is bound by the loads a CU keeps in flight, and those by what its LDS can stage: rocprof's occupancy line showed the
+// four-columns-per-lane form (Queen class: lists of ~1500 columns, 61 KB) running TWO workgroups per CU.  The 2 B positions never needed LDS -- a lane
+// reads the positions of its own items only -- so they go straight to registers, and with the stage sized to 39.5 KB FOUR workgroups fit:
+//   lists <= 1024 columns: 3584 items + 8 KB of x   (150 KB of loads in flight per CU instead of 129)
+//   longer lists:          3072 items + 12 / 16 KB  (141 / 106 KB instead of 92)
+constexpr int LOCAL_GEOM4 = 7, LOCAL_GEOM_R = 8;
+constexpr bool is_local_geom(int g) { return g == LOCAL_GEOM || g == LOCAL_GEOM4 || g == LOCAL_GEOM_R; }
 constexpr int ROW_ALIGN = 16;    // rows per 128 B line of y / x
 constexpr int SLACK = 128;       // extra items a block may take to start on an aligned row
 
@@ -66,6 +75,7 @@ int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps eve
 int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
 int g_row_values = 1;            // liship_spmv_csr_set_row_values: 0 keeps streaming the values of matrices that have value records
 int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps the products kernel on the 4 B indices
+int g_local_rpos = 1;            // liship_spmv_csr_set_local_register_positions: 0 = plans built from now on take the round-3 form (4096-item blocks, positions through LDS)
 int g_uniform_rows = 1;          // liship_spmv_csr_set_uniform_rows: 0 keeps the row sums of the block-local kernel on the skewed schedule everywhere (A/B)
 int g_long_row_tree_host = 0;    // host mirror of d_long_row_tree (liship_spmv_csr_switches)
 int g_row_block_dots = 0;        // liship_spmv_csr_set_row_block_dots: 1 keeps the fused dots of the dominant-pattern product on the row blocks' partial sums (the bits every other form gives)
@@ -683,7 +693,9 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
 // 10 B + 4 B x (distinct / entries) per non-zero instead of 12, an eighth of the gathers; same terms in the same
 // order, so y is bit-identical.  Row blocks the plan left out (a row longer than the stage, more than 4 x BLOCK
 // distinct columns) have an empty list and take block_by_products on the 4 B indices.
-template <int BLOCK, int WORK, int DOT = 0, int NDPL = 2>
+// RPOS (round 4): the 2 B positions go from HBM to REGISTERS (a lane only ever reads the positions of its own eight items), not through LDS; XCAP: the
+// longest list the plan found, rounded up to 1024 / 1536 / 2048 -- the x stage in LDS is no larger than that.
+template <int BLOCK, int WORK, int DOT = 0, int NDPL = 2, int XCAP = NDPL * BLOCK, bool RPOS = false>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
                            const unsigned short *__restrict__ lcol, const int *__restrict__ dcol,
@@ -696,11 +708,12 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     const int row_begin = RW.rb, row_end = RW.re;
     const double acc0 = RW.acc0;
     constexpr int CAP = WORK + SLACK + 8;           // + the 8-entry alignment of the position slice
-    constexpr int NDMAX = NDPL * BLOCK;             // distinct columns a block may list: NDPL per lane (2 or 4)
+    static_assert(XCAP <= NDPL * BLOCK && XCAP % 4 == 0, "the list is loaded NDPL columns per lane");
+    static_assert(!RPOS || CAP <= 8 * BLOCK, "eight items per lane");
     __shared__ double dot_scratch[BLOCK / WAVE];
     __shared__ __attribute__((aligned(16))) double valL[(GUARD + CAP + 8 + 16) + 2 * WAVE];
-    __shared__ __attribute__((aligned(16))) unsigned short lcL[CAP + 8 + 8 * WAVE];
-    __shared__ __attribute__((aligned(16))) double xL[NDMAX];
+    __shared__ __attribute__((aligned(16))) unsigned short lcL[RPOS ? 8 : CAP + 8 + 8 * WAVE];
+    __shared__ __attribute__((aligned(16))) double xL[XCAP];
     RowDots<DOT> dots{wdot, 0.0, 0.0};
 
     const int lb = blockIdx.x;
@@ -714,7 +727,7 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     const int cnt = B.k1 - ka;
     const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
     const int nl = (cnt + 7) >> 3;                  // 16 B pieces of the position slice (the array is padded)
-    if (nd == 0 || cnt > CAP || ka + 2 * np > nnz_total) {  // block without a list / last value of the array
+    if (nd == 0 || nd > XCAP || cnt > CAP || ka + 2 * np > nnz_total) {  // block without a list / last value of the array
         block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
@@ -735,12 +748,18 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
                 (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p),
                 (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL + GUARD) + p0), 16, 0, 2);
         }
-        for (int q0 = wbase; q0 < nl; q0 += BLOCK) {
+        if (!RPOS) for (int q0 = wbase; q0 < nl; q0 += BLOCK) {
             const int q = min(q0 + lane, nl - 1);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v4i32 *>(lcol + ka) + q),
                 (__attribute__((address_space(3))) void *)(reinterpret_cast<v4i32 *>(lcL) + q0), 16, 0, 2);
         }
+    }
+    // RPOS: the positions of this lane's own items (entry B.k0 + lane + g * BLOCK of the matrix), eight 2 B loads -- a wavefront's 64 lanes read 128 B each
+    unsigned short pos[8];
+    if (RPOS) {
+#pragma unroll
+        for (int g = 0; g < 8; g++) pos[g] = lcol[min(B.k0 + (int)threadIdx.x + g * BLOCK, B.k1 - 1)];
     }
     // rows stay with consecutive lanes of as few wavefronts as possible: dealing them to all wavefronts was tried and multiplies
     // the LDS instructions of the serial sums by the number of wavefronts (each then issues the whole chain for a few lanes)
@@ -757,6 +776,14 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     __syncthreads();
 
     // products in place, from LDS alone: entry e of the stage by lane e % BLOCK, 8 in flight per lane
+    if (RPOS) {
+        const int e0 = (B.k0 - ka) + (int)threadIdx.x;
+        double vv[8], xv[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) { const int e = min(e0 + g * BLOCK, cnt - 1); vv[g] = valL[GUARD + e]; xv[g] = xL[pos[g]]; }
+#pragma unroll
+        for (int g = 0; g < 8; g++) { const int e = e0 + g * BLOCK; if (e < cnt) valL[GUARD + e] = vv[g] * xv[g]; }
+    } else
     for (int e0 = (B.k0 - ka) + (int)threadIdx.x; e0 < cnt; e0 += 8 * BLOCK) {
         double vv[8], xv[8];
 #pragma unroll
@@ -2765,6 +2792,7 @@ struct liship_csr_plan_s {
     int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
     long long ndcol;     // entries of dcol
     int ndpl;            // distinct columns per lane of spmv_csr_local_kernel: 2 (lists of <= 1024 columns) or 4
+    int xcap;            // its x stage: the longest list rounded up to 1024 / 1536 / 2048 entries
     int first_term;      // row sums start at the first product instead of at +0.0 (split matrices)
     v4i32 *vrecw;        // device: WIDE value records for patterns of up to 32 entries (no ptab8): per pattern 144 B of byte offsets + length, 256 B of values; else NULL
     int *order;          // device, nblocks entries or NULL: launch order of the products kernel (blocks with a very long row first)
@@ -3652,23 +3680,37 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     if (p->lcol || p->codes || !p->products || p->nblocks <= 0 || p->nnz <= 0 || g_variant != 0 || !aligned16(idx)) return 0;
     hipStream_t st = as_stream(stream);
     constexpr Geometry g = kGeom[LOCAL_GEOM];
-    constexpr int CAPL = g.work + SLACK, NDMAX = 4 * g.block;      // up to four distinct columns per lane (the kernel's NDPL = 4 form)
+    constexpr int NDMAX = 4 * g.block;      // up to four distinct columns per lane (the kernel's NDPL = 4 form)
     const int geom_before = p->geom;
-    if (p->geom != LOCAL_GEOM) { p->geom = LOCAL_GEOM; const int rc = build_split(p, ptr, st); if (rc) return rc; }
-    const int nb = p->nblocks;
-    int *nd_dev = nullptr;
-    HIP_TRY(hipMalloc(&nd_dev, sizeof(int) * (size_t)(nb + 1)));
-    csr_local_build<256, 0, 8192><<<nb, 256, 0, st>>>(p->blk, idx, CAPL, NDMAX, nd_dev, nullptr, nullptr, nullptr);
-    hipError_t e = hipGetLastError();
-    int *off = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
-    if (!off && e == hipSuccess) e = hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemcpyAsync(off, nd_dev, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        (void)hipFree(nd_dev); free(off);
-        if (geom_before != LOCAL_GEOM) { p->geom = geom_before; (void)build_split(p, ptr, st); }
-        return (int)e;
+    int *nd_dev = nullptr, *off = nullptr;
+    int nb = 0, capl = 0;
+    // blocks of 3584 items with the positions in registers (round 4); when those list more than two columns per lane, blocks of 3072.
+    // (liship_spmv_csr_set_local_register_positions(0): the round-3 form, 4096-item blocks whatever the lists)
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const int want = !g_local_rpos ? LOCAL_GEOM : attempt == 0 ? LOCAL_GEOM_R : LOCAL_GEOM4;
+        if (p->geom != want) { p->geom = want; const int rc = build_split(p, ptr, st); if (rc) return rc; }
+        nb = p->nblocks;
+        capl = kGeom[want].work + SLACK;
+        if (nd_dev) (void)hipFree(nd_dev);
+        free(off);
+        nd_dev = nullptr; off = nullptr;
+        HIP_TRY(hipMalloc(&nd_dev, sizeof(int) * (size_t)(nb + 1)));
+        csr_local_build<256, 0, 8192><<<nb, 256, 0, st>>>(p->blk, idx, capl, NDMAX, nd_dev, nullptr, nullptr, nullptr);
+        hipError_t e0 = hipGetLastError();
+        off = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
+        if (!off && e0 == hipSuccess) e0 = hipErrorOutOfMemory;
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(off, nd_dev, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);
+        if (e0 != hipSuccess) {
+            (void)hipFree(nd_dev); free(off);
+            if (geom_before != p->geom) { p->geom = geom_before; (void)build_split(p, ptr, st); }
+            return (int)e0;
+        }
+        int most = 0;
+        for (int b = 0; b < nb; b++) if (off[b] > most) most = off[b];
+        if (!g_local_rpos || attempt == 1 || most <= 2 * g.block) break;      // short lists keep the larger blocks
     }
+    hipError_t e = hipSuccess;
     long long listed = 0, covered = 0, run = 0;
     int ndmost = 0;
     for (int b = 0; b < nb; b++) {
@@ -3680,7 +3722,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     off[nb] = (int)run;
     if (run > 0x7fffffffLL || covered * 10 < p->nnz * 9 || listed * 2 > covered) {      // not worth it: back to the products kernel's own split
         (void)hipFree(nd_dev); free(off);
-        if (geom_before != LOCAL_GEOM) { p->geom = geom_before; return build_split(p, ptr, st); }
+        if (geom_before != p->geom) { p->geom = geom_before; return build_split(p, ptr, st); }
         return 0;
     }
     const size_t lbytes = ((size_t)p->nnz + 7) / 8 * 16 + 16 * WAVE;          // whole 16 B pieces, one wave slice of slack
@@ -3689,7 +3731,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     if (e == hipSuccess) e = hipMemsetAsync(p->lcol, 0, lbytes, st);
     if (e == hipSuccess) e = hipMemcpyAsync(nd_dev, off, sizeof(int) * (size_t)(nb + 1), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        csr_local_build<256, 1, 8192><<<nb, 256, 0, st>>>(p->blk, idx, CAPL, NDMAX, nullptr, nd_dev, p->dcol, p->lcol);
+        csr_local_build<256, 1, 8192><<<nb, 256, 0, st>>>(p->blk, idx, capl, NDMAX, nullptr, nd_dev, p->dcol, p->lcol);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -3699,17 +3741,20 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
         if (p->lcol) (void)hipFree(p->lcol);
         (void)hipFree(nd_dev);
         p->dcol = nullptr; p->lcol = nullptr;
-        if (geom_before != LOCAL_GEOM) { p->geom = geom_before; (void)build_split(p, ptr, st); }
+        if (geom_before != p->geom) { p->geom = geom_before; (void)build_split(p, ptr, st); }
         return (int)e;
     }
     p->doff = nd_dev;
     p->ndcol = run;
     p->ndpl = ndmost > 2 * g.block ? 4 : 2;        // lists of up to 1024 columns (the dofs-per-node patterns in mesh order): two per lane, 8 KB of LDS; longer ones four
+    p->xcap = ndmost <= 1024 ? 1024 : (ndmost <= 1536 && p->geom == LOCAL_GEOM4) ? 1536 : 2048;
     return 0;
 }
 // entries of the distinct-column lists when the plan keeps block-local columns, 0 otherwise
 extern "C" long long liship_csr_plan_localized(liship_csr_plan_t p) { return (p && p->lcol) ? p->ndcol : 0; }
 extern "C" int liship_spmv_csr_set_local_columns(int on) { g_local_cols = on ? 1 : 0; return 0; }
+// 0: plans built from now on take the round-3 form of the block-local kernel (4096-item blocks, positions staged in LDS: 3 / 2 workgroups per CU); A/B, same bits
+extern "C" int liship_spmv_csr_set_local_register_positions(int on) { g_local_rpos = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_team(int on) { g_team = on ? 1 : 0; return 0; }
 
 namespace {
@@ -3884,6 +3929,24 @@ static void launch_dom(const LaunchArgs &a, int dot = 0, const double *w = nullp
 #undef GOD
 }
 
+// the block-local kernel in the form the plan was built for: geometry 5 = round 3 (positions through LDS), 7 / 8 = positions in registers, x stage as long as the longest list
+template <int G, int DOT>
+void launch_local(const LaunchArgs &a, const double *w, double *partial, const double *guard, int pstride)
+{
+    constexpr Geometry g = kGeom[is_local_geom(G) ? G : LOCAL_GEOM];
+    const int ndpl = a.plan ? a.plan->ndpl : 2, xcap = a.plan ? a.plan->xcap : 1024;
+#define GOL(NDPL_, XCAP_, RPOS_) spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, RPOS_><<<a.nb, g.block, 0, a.st>>>( \
+        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows)
+    if constexpr (G == LOCAL_GEOM_R) { if (ndpl == 4) GOL(4, 2048, true); else GOL(2, 1024, true); }
+    else if constexpr (G == LOCAL_GEOM4) {
+        if (xcap <= 1024) GOL(2, 1024, true);
+        else if (xcap <= 1536) GOL(4, 1536, true);
+        else GOL(4, 2048, true);
+    } else { if (ndpl == 4) GOL(4, 2048, false); else GOL(2, 1024, false); }
+    (void)xcap;
+#undef GOL
+}
+
 template <int G>
 void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
 {
@@ -3894,16 +3957,17 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     const bool val16 = aligned16(a.val), idx16 = aligned16(a.idx);
     const bool idx8 = (reinterpret_cast<uintptr_t>(a.idx) & 7u) == 0;
     const bool products = plan_products || (g_variant & 6) != 0 || !(val16 && idx16);
-    if (a.lcol && plan_products && G == LOCAL_GEOM && g_variant == 0 && val16) {     // long rows, few distinct columns per row block
-        constexpr Geometry g = kGeom[LOCAL_GEOM];
-        if (a.plan && a.plan->ndpl == 4)
-            spmv_csr_local_kernel<g.block, g.work, 0, 4><<<a.nb, g.block, 0, a.st>>>(
-                a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, nullptr, nullptr, nullptr, 0, g_uniform_rows);
-        else
-        spmv_csr_local_kernel<g.block, g.work><<<a.nb, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, nullptr, nullptr, nullptr, 0, g_uniform_rows);
+    if (a.lcol && plan_products && is_local_geom(G) && g_variant == 0 && val16) {     // long rows, few distinct columns per row block
+        launch_local<G, 0>(a, nullptr, nullptr, nullptr, 0);
         return;
     }
+    if constexpr (G == LOCAL_GEOM4 || G == LOCAL_GEOM_R) {      // geometries only block-local plans have: whatever else such a plan launches (lists switched off,
+        const bool vec = val16 && idx8;                          // values not 16 B aligned) takes the products kernel on the 4 B indices
+        if (!vec) launch_products<G, false, 0, false>(a.nb, a);
+        else if (batch == 2) launch_products<G, false, 2, false>(a.nb, a);
+        else launch_products<G, false, 4, false>(a.nb, a);
+        return;
+    } else {
     if (products) {
         const bool vec = !(g_variant & 2) && val16 && idx8;
         if (nogather)  launch_products<G, false, 4, true>(a.nb, a);
@@ -3987,6 +4051,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     if (U == 4)      launch_rowgather<G, 4, false, true, false>(grid, a);
     else if (U == 7) launch_rowgather<G, 7, false, true, false>(grid, a);
     else             launch_rowgather<G, 8, false, true, false>(grid, a);
+    }
 }
 
 template <int G, int DOT>
@@ -4059,14 +4124,8 @@ template <int G, int DOT>
 void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double *partial, int pstride = 0)
 {
     constexpr Geometry g = kGeom[G];
-    if (a.lcol && G == LOCAL_GEOM) {
-        if (a.plan && a.plan->ndpl == 4) {
-            spmv_csr_local_kernel<g.block, g.work, DOT, 4><<<a.nb, g.block, 0, a.st>>>(
-                a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride, g_uniform_rows);
-            return;
-        }
-        spmv_csr_local_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride, g_uniform_rows);
+    if (a.lcol && is_local_geom(G)) {
+        launch_local<G, DOT>(a, w, partial, liship_internal_guard(), pstride);
         return;
     }
     if (batch == 2)
@@ -4090,6 +4149,8 @@ int launch_csr(liship_csr_plan_t p, const LaunchArgs &a0)
         case 4: launch_geom<4>(a, p->unroll, p->products != 0, p->batch); break;
         case 5: launch_geom<5>(a, p->unroll, p->products != 0, p->batch); break;
         case 6: launch_geom<6>(a, p->unroll, p->products != 0, p->batch); break;
+        case 7: launch_geom<7>(a, p->unroll, p->products != 0, p->batch); break;
+        case 8: launch_geom<8>(a, p->unroll, p->products != 0, p->batch); break;
         default: return LISHIP_ERR_ARG;
     }
     LAUNCH_CHECK();
@@ -4172,6 +4233,10 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     }
     if (p->products && p->geom == LOCAL_GEOM) {      // a plan with block-local columns (or one that has them switched off)
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial);
+    } else if (p->products && p->geom == LOCAL_GEOM4) {
+        if (want_sumsq) launch_products_dot<LOCAL_GEOM4, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM4, 1>(a, p->batch, w, partial);
+    } else if (p->products && p->geom == LOCAL_GEOM_R) {
+        if (want_sumsq) launch_products_dot<LOCAL_GEOM_R, 2>(a, p->batch, w, partial); else launch_products_dot<LOCAL_GEOM_R, 1>(a, p->batch, w, partial);
     } else if (p->products) {       // geometry 1
         if (want_sumsq) launch_products_dot<1, 2>(a, p->batch, w, partial); else launch_products_dot<1, 1>(a, p->batch, w, partial);
     } else if (p->geom == 1) { if (want_sumsq) launch_rowgather_dot<1, 2>(a, p->unroll, w, partial); else launch_rowgather_dot<1, 1>(a, p->unroll, w, partial); }
@@ -4251,6 +4316,10 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     const int ps = (int)slots;
     if (p->products && p->geom == LOCAL_GEOM) {
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial, ps);
+    } else if (p->products && p->geom == LOCAL_GEOM4) {
+        if (want_sumsq) launch_products_dot<LOCAL_GEOM4, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM4, 1>(a, p->batch, w, partial, ps);
+    } else if (p->products && p->geom == LOCAL_GEOM_R) {
+        if (want_sumsq) launch_products_dot<LOCAL_GEOM_R, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM_R, 1>(a, p->batch, w, partial, ps);
     } else if (p->products) {
         if (want_sumsq) launch_products_dot<1, 2>(a, p->batch, w, partial, ps); else launch_products_dot<1, 1>(a, p->batch, w, partial, ps);
     } else if (p->geom == 1) { if (want_sumsq) launch_rowgather_dot<1, 2>(a, p->unroll, w, partial, ps); else launch_rowgather_dot<1, 1>(a, p->unroll, w, partial, ps); }

@@ -64,6 +64,8 @@ def main():
     variants = [int(v, 0) for v in os.environ.get("SWEEP_VARIANTS", "0").split(",")]
     if os.environ.get("IRREG_UNIFORM_ROWS"):           # A/B of the uniform-length row sums (0: skewed sums everywhere)
         check(lib.liship_spmv_csr_set_uniform_rows(int(os.environ["IRREG_UNIFORM_ROWS"])))
+    if os.environ.get("IRREG_ROUND3") == "1":          # A/B: the round-3 form of the block-local kernel (4096-item blocks, positions through LDS)
+        check(lib.liship_spmv_csr_set_local_register_positions(0))
     only = os.environ.get("IRREG_ONLY")                # "fem3" / "zipf": one of the two (profiling runs)
     for name, gen in (("fem3", lambda: fem3(G)[:4]), ("zipf", lambda: zipf(2_000_000))):
         if only and name != only:

@@ -12,6 +12,8 @@ dll = lib.dll
 dll.lis_amd_set_residency(1)
 if os.environ.get("QUEEN_NO_LOCAL") == "1":
     lib.liship_spmv_csr_set_local_columns(0)
+if os.environ.get("QUEEN_ROUND3") == "1":              # round-3 form: 4096-item blocks, positions through LDS (two workgroups per CU on this matrix)
+    lib.liship_spmv_csr_set_local_register_positions(0)
 t0 = time.time(); path, rows, stored = queen_class.generate("full"); t_gen = time.time() - t0
 A, b, x0 = capi.PM(), capi.PV(), capi.PV()
 lib.lis_matrix_create(0, C.byref(A)); lib.lis_vector_create(0, C.byref(b)); lib.lis_vector_create(0, C.byref(x0))

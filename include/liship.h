@@ -417,6 +417,9 @@ int  liship_csr_transpose_f64(int nrows, int ncols, int nnz, const int *ptr, con
  * a row in the format's own order, padding and explicit zeros included. */
 int  liship_csr_row_facts(int n, const int *ptr, const int *index, int *facts, void *stream);
 int  liship_csr_to_ell(int n, int maxnzr, const int *ptr, const int *index, const double *value, int *ell_index, double *ell_value, void *stream);
+/* the row form of a BSR matrix (as liship_csr_to_ell_rows for ELL): CSR rows that list lis_matvec_bsr's terms of each scalar row -- block after block, column after column,
+ * explicit zeros included -- so that the CSR kernels form the same sums and the value records apply to constant-coefficient block matrices */
+int  liship_bsr_to_rows(int n, int bnr, int bnc, const int *bptr, const int *bindex, const double *value, int *rptr, int *rindex, double *rvalue, void *stream);
 int  liship_csr_to_ell_rows(int n, int maxnzr, const int *ptr, const int *index, const double *value, int *rptr, int *rindex, double *rvalue, void *stream);
 int  liship_csr_dia_offsets(int n, int ncols, const int *ptr, const int *index, int *used, int *slot, long long *scratch, int *nnd, void *stream);
 int  liship_csr_to_dia(int n, int ncols, int nnd, const int *ptr, const int *index, const double *value, const int *used, const int *slot,

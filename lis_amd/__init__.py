@@ -151,6 +151,7 @@ _LISHIP = {
     "liship_dot2_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp]),
     "liship_csr_diagonal_f64": (_ci, [_ci, _vp, _vp, _vp, _vp, _vp]),
     "liship_spmv_csr_transposed_chunked_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_bsr_to_rows": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_csr_transpose_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_gather_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_scatter_add_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),

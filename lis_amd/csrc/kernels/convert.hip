@@ -231,6 +231,41 @@ extern "C" int liship_csr_to_ell(int n, int maxnzr, const int *ptr, const int *i
     return 0;
 }
 
+namespace {
+// the row form of a BSR matrix: scalar row r = bi * bnr + i lists, block after block of block row bi and column after column of the block, the terms
+// lis_matvec_bsr adds to y[r] -- value[bc * bs + j * bnr + i] * x[bindex[bc] * bnc + j], explicit zeros included -- in that order (src/matvec/
+// lis_matvec_bsr.c:57-150 generic, :293-343 2x2 ...).  Rows of one block row have the same length, so rptr is a closed form of bptr.
+__global__ __launch_bounds__(BLOCK)
+void bsr_to_rows(int n, int bnr, int bnc, const int *__restrict__ bptr, const int *__restrict__ bidx, const double *__restrict__ val,
+                 int *__restrict__ rptr, int *__restrict__ ridx, double *__restrict__ rval)
+{
+    const long long r = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (r > n) return;
+    if (r == n) {                                   // rptr[n]: everything the n rows hold (the padding rows of the last block row are not rows of A)
+        const int bi = (n - 1) / bnr, i = n - bi * bnr;          // i = rows of the last block row that exist (1..bnr)
+        rptr[n] = bnc * (bnr * bptr[bi] + i * (bptr[bi + 1] - bptr[bi]));
+        return;
+    }
+    const int bi = (int)(r / bnr), i = (int)(r - (long long)bi * bnr);
+    const int b0 = bptr[bi], nbk = bptr[bi + 1] - b0, bs = bnr * bnc;
+    int at = bnc * (bnr * b0 + i * nbk);
+    rptr[r] = at;
+    for (int bc = b0; bc < b0 + nbk; bc++) {
+        const int c0 = bidx[bc] * bnc;
+        for (int j = 0; j < bnc; j++, at++) { ridx[at] = c0 + j; rval[at] = val[(size_t)bc * bs + (size_t)j * bnr + i]; }
+    }
+}
+} // namespace
+
+// rptr: n + 1 ints; ridx / rval: bnnz * bnr * bnc entries (fewer are used when the last block row is padded).  All device pointers.
+extern "C" int liship_bsr_to_rows(int n, int bnr, int bnc, const int *bptr, const int *bindex, const double *value, int *rptr, int *rindex, double *rvalue, void *stream)
+{
+    if (n <= 0 || bnr < 1 || bnc < 1) return LISHIP_ERR_ARG;
+    bsr_to_rows<<<grid_for((long long)n + 1), BLOCK, 0, as_stream(stream)>>>(n, bnr, bnc, bptr, bindex, value, rptr, rindex, rvalue);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int liship_csr_to_ell_rows(int n, int maxnzr, const int *ptr, const int *idx, const double *val, int *rptr, int *ridx, double *rval, void *stream)
 {
     csr_to_ell_rows<<<grid_for((long long)n + 1), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, ptr, idx, val, rptr, ridx, rval);

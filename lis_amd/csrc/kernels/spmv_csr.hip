@@ -696,7 +696,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
 // RPOS (round 4): the 2 B positions go from HBM to REGISTERS (a lane only ever reads the positions of its own eight items), not through LDS; XCAP: the
 // longest list the plan found, rounded up to 1024 / 1536 / 2048 -- the x stage in LDS is no larger than that.
 template <int BLOCK, int WORK, int DOT = 0, int NDPL = 2, int XCAP = NDPL * BLOCK, bool RPOS = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(RPOS ? 8 : 4)))      // RPOS: four 512-lane workgroups per CU want <= 64 VGPRs (the fused-dot forms took 66 - 68)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((RPOS && XCAP <= 1536) ? 8 : 4)))      // four 512-lane workgroups per CU want <= 64 VGPRs (the fused-dot forms took 66 - 68)
 void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
                            const unsigned short *__restrict__ lcol, const int *__restrict__ dcol,
                            const int *__restrict__ doff, const double *__restrict__ x, double *__restrict__ y,

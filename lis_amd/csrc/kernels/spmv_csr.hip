@@ -2277,7 +2277,7 @@ void spmv_csr_valuerec_pair_dot_kernel(const unsigned char *__restrict__ rowpat,
 // patterns carry their values when the coefficients are constant).  One row per lane; the records -- 144 B of byte offsets and
 // the length, 256 B of values per pattern -- sit in LDS; a row is walked in chunks of 8 entries: offsets, 8 gathers in flight,
 // values, 8 additions in order (terms beyond the row's length add -0.0).  Same products in the same order: bit-identical.
-constexpr int PATW_MAX = 48, PATW_LEN = 32, PATW_OFF = 36;             // patterns, entries per pattern, ints per offset record
+constexpr int PATW_MAX = 64, PATW_LEN = 32, PATW_OFF = 36;             // patterns (48 until round 4: the 2 x 2 blocking of a 7-point stencil has 54), entries per pattern, ints per offset record
 template <int BLOCK, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_valuerecw_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, int npat,

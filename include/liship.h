@@ -146,6 +146,9 @@ int  liship_spmv_csr_set_local_columns(int on);
  * workgroup -- 39.5 KB of LDS, four workgroups per CU.  0: plans built from now on take the round-3 form (4096-item blocks, positions through LDS: three /
  * two workgroups per CU); A/B measurements, same bits either way */
 int  liship_spmv_csr_set_local_register_positions(int on);
+/* structured grids, values streamed (spmv_csr_pattern7_kernel): every XCD takes one eighth of every plane of the grid and walks the planes in order, so that the
+ * +-plane neighbours of its rows stay in its own L2 (round 4).  0: the natural block order (A/B measurements); same bits either way */
+int  liship_spmv_csr_set_xcd_strips(int on);
 /* Opt-in, off by default, NOT bit-identical to the reference: the part of a row beyond the LDS stage (~2100 entries) is added
  * by a workgroup-wide tree per pass instead of one left-to-right chain (a 200 000-entry row is otherwise a 200 000-long
  * dependent add chain, by the parity contract).  Deterministic; rows that fit the stage keep the reference's bits. */

@@ -90,6 +90,7 @@ _LISHIP = {
     "liship_csr_plan_localized": (C.c_longlong, [_vp]),
     "liship_spmv_csr_set_local_columns": (_ci, [_ci]),
     "liship_spmv_csr_set_local_register_positions": (_ci, [_ci]),
+    "liship_spmv_csr_set_xcd_strips": (_ci, [_ci]),
     "liship_spmv_csr_set_long_row_tree": (_ci, [_ci]),
     "liship_spmv_csr_set_uniform_rows": (_ci, [_ci]),
     "liship_spmv_csr_set_row_block_dots": (_ci, [_ci]),

@@ -75,6 +75,7 @@ int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps eve
 int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
 int g_row_values = 1;            // liship_spmv_csr_set_row_values: 0 keeps streaming the values of matrices that have value records
 int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps the products kernel on the 4 B indices
+int g_xcd_strips = 1;            // liship_spmv_csr_set_xcd_strips: 0 keeps the row blocks of the 7-offset pattern kernel in their natural (round-robin over the XCDs) order
 int g_local_rpos = 1;            // liship_spmv_csr_set_local_register_positions: 0 = plans built from now on take the round-3 form (4096-item blocks, positions through LDS)
 int g_uniform_rows = 1;          // liship_spmv_csr_set_uniform_rows: 0 keeps the row sums of the block-local kernel on the skewed schedule everywhere (A/B)
 int g_long_row_tree_host = 0;    // host mirror of d_long_row_tree (liship_spmv_csr_switches)
@@ -1310,7 +1311,7 @@ void spmv_csr_pattern7_kernel(const int *__restrict__ ptr, const double *__restr
                               const double *__restrict__ x, double *__restrict__ y, const v2i32 *__restrict__ blk,
                               int bfirst, int nb, Rows RW, int nnz_total,
                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                              const double *__restrict__ guard = nullptr, int pstride = 0)
+                              const double *__restrict__ guard = nullptr, int pstride = 0, int xs_plane = 0)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const int row_begin = RW.rb, row_end = RW.re;
@@ -1323,7 +1324,19 @@ void spmv_csr_pattern7_kernel(const int *__restrict__ ptr, const double *__restr
     const int tid = (int)threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     const bool w_is_x = DOT >= 1 && wdot == x;
 
-    const int lb = blockIdx.x;
+    // XCD strips (round 4, structured grids): workgroup w runs on XCD w % 8.  With the identity order the seven rows that read x[j] sit in five row blocks on five
+    // different XCDs, and x crosses the fabric 5.2 times (the L2 <-> fabric boundary ran at its 8 TB/s: profiles/r03_spmv512_traffic_values_streamed.json).  Here every
+    // XCD takes one eighth of every plane of the grid -- `xs_plane` row blocks cover a plane -- and walks the planes in order: the +-plane neighbours of its rows are its
+    // own rows of the next / previous plane, two strips (0.5 MB at 512^3) apart in its own L2.  A permutation of the blocks: same bits, partial sums in the same slots.
+    int lb = blockIdx.x;
+    if (xs_plane > 0) {
+        const int full = (nb / xs_plane) * xs_plane;
+        if (lb < full) {
+            const int sb = xs_plane >> 3, xcd = lb & 7, slot = lb >> 3;
+            const int plane = slot / sb;
+            lb = plane * xs_plane + xcd * sb + (slot - plane * sb);
+        }
+    }
     Blk B = load_blk(blk, bfirst + lb);
     const int kplan = B.k0, rplan0 = B.r0, rplan1 = B.r1;   // the PLAN's block, whatever this launch clips
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
@@ -2793,6 +2806,7 @@ struct liship_csr_plan_s {
     long long ndcol;     // entries of dcol
     int ndpl;            // distinct columns per lane of spmv_csr_local_kernel: 2 (lists of <= 1024 columns) or 4
     int xcap;            // its x stage: the longest list rounded up to 1024 / 1536 / 2048 entries
+    int xs_plane;        // row blocks per plane of a structured grid, a multiple of 8 (0: none): the XCD strips of spmv_csr_pattern7_kernel
     int first_term;      // row sums start at the first product instead of at +0.0 (split matrices)
     v4i32 *vrecw;        // device: WIDE value records for patterns of up to 32 entries (no ptab8): per pattern 144 B of byte offsets + length, 256 B of values; else NULL
     int *order;          // device, nblocks entries or NULL: launch order of the products kernel (blocks with a very long row first)
@@ -3228,6 +3242,13 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
             PT(hipMalloc(&p->ptab8, sizeof(int) * 8 * (size_t)npat));
             PT(hipMemcpyAsync(p->ptab8, rec, sizeof(int) * 8 * (size_t)npat, hipMemcpyHostToDevice, st));
             for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
+            // a structured grid: the largest offset is a plane of the grid; `xs_plane` row blocks cover one (XCD strips, see the kernel)
+            p->xs_plane = 0;
+            if (p->nblocks > 0 && maxoff > 0) {
+                const double rows_per_block = (double)p->n / p->nblocks;
+                const long long pb = (long long)((double)maxoff / rows_per_block + 0.5);
+                if (pb >= 64 && pb * 4 <= p->nblocks) p->xs_plane = (int)(pb / 8) * 8;
+            }
         }
         if (rc == 0) build_team_records(p, tab, npat);
         if (rc == 0) {
@@ -3754,6 +3775,8 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
 extern "C" long long liship_csr_plan_localized(liship_csr_plan_t p) { return (p && p->lcol) ? p->ndcol : 0; }
 extern "C" int liship_spmv_csr_set_local_columns(int on) { g_local_cols = on ? 1 : 0; return 0; }
 // 0: plans built from now on take the round-3 form of the block-local kernel (4096-item blocks, positions staged in LDS: 3 / 2 workgroups per CU); A/B, same bits
+// 0: the 7-offset pattern kernel walks the row blocks in their natural order (round-robin over the XCDs) instead of XCD strips; A/B measurements, same bits
+extern "C" int liship_spmv_csr_set_xcd_strips(int on) { g_xcd_strips = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_local_register_positions(int on) { g_local_rpos = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_team(int on) { g_team = on ? 1 : 0; return 0; }
 
@@ -3778,6 +3801,13 @@ struct LaunchArgs {
     const liship_csr_plan_s *plan = nullptr; // (set by the launchers) the dominant-pattern records live there
 };
 
+
+// XCD strips of the 7-offset pattern kernel: whole-matrix launches of a plan that found a plane (xs_plane), unless switched off
+inline int xcd_strips(const LaunchArgs &a)
+{
+    if (!g_xcd_strips || !a.plan || a.bfirst != 0 || a.nb != a.plan->nblocks) return 0;
+    return a.plan->xs_plane;
+}
 
 inline int xcd_run() { int c = (g_variant >> 16) & 0xff; return c ? c : 16; }
 
@@ -4021,7 +4051,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
         //  this kernel is bound by its value stream, not by x: profiles/r03_valuerec_dom_experiments.txt)
         constexpr Geometry g = kGeom[G];
         spmv_csr_pattern7_kernel<g.block, g.work, 0><<<a.nb, g.block, 0, a.st>>>(
-            a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
+            a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, nullptr, nullptr, nullptr, 0, xcd_strips(a));
         return;
     }
     if (a.rowpat && a.plan && a.plan->prec36 && g_team && (g_variant & ~0xc000) == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
@@ -4090,7 +4120,7 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
     if (a.rowpat && a.ptab8 && !(g_variant & 0x2000)) {
         spmv_csr_pattern7_kernel<g.block, g.work, DOT><<<a.nb, g.block, 0, a.st>>>(
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz,
-            w, partial, liship_internal_guard(), pstride);
+            w, partial, liship_internal_guard(), pstride, xcd_strips(a));
         return;
     }
     if (a.rowpat && a.vrecw && !(g_variant & 0x2000)) {

@@ -11,6 +11,8 @@ from lis_amd import DeviceArray as DA, check  # noqa: E402
 from spmv_sweep import timed  # noqa: E402
 
 lib = lis_amd.load()
+if os.environ.get("NO_XCD_STRIPS") == "1":        # A/B: the 7-offset pattern kernel in the natural block order
+    lib.liship_spmv_csr_set_xcd_strips(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n = N ** 3

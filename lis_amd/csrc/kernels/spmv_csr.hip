@@ -125,6 +125,21 @@ __device__ __forceinline__ int block_of_workgroup(int nb, int run)
     return lb < nb ? lb : -1;
 }
 
+// XCD strips (round 4, structured grids).  Workgroup w runs on XCD w % 8.  In the natural order the rows that read x[j] -- its own, the neighbouring lines', the
+// neighbouring planes' -- sit in workgroups on different XCDs, and x crosses the fabric once per XCD that touches it (5.2 times for the 7-point stencil at 512^3, where
+// the L2 <-> fabric boundary ran at its 8 TB/s: profiles/r03_spmv512_traffic_values_streamed.json).  With strips every XCD takes one eighth of every plane of the grid --
+// `plane` units of work (row blocks, 64-row workgroups ...) cover a plane, a multiple of 8 -- and walks the planes in order: the +-plane neighbours of its rows are its own
+// rows of the next / previous plane, two strips apart in its own L2.  A permutation of the first (n / plane) * plane units; the tail keeps its place.
+__device__ __forceinline__ int xcd_strip_unit(int w, int n, int plane)
+{
+    if (plane <= 0) return w;
+    const int full = (n / plane) * plane;
+    if (w >= full) return w;
+    const int sb = plane >> 3, xcd = w & 7, slot = w >> 3;
+    const int pl = slot / sb;
+    return pl * plane + xcd * sb + (slot - pl * sb);
+}
+
 __device__ __forceinline__ bool clip_rows(Blk &B, const int *__restrict__ ptr, int row_begin, int row_end)
 {
     if (B.r0 < row_begin) { B.r0 = row_begin; if (B.r0 < B.r1) B.k0 = ptr[B.r0]; }     // partial launches only
@@ -1091,7 +1106,7 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
                                   const v4i32 *__restrict__ prec, const double *__restrict__ x, double *__restrict__ y, Rows RW, int nnz_total,
-                                  const double *__restrict__ guard = nullptr)
+                                  const double *__restrict__ guard = nullptr, int xs_plane = 0)
 {
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
     // A wavefront owns 16 consecutive rows AND their value slice: nothing is shared between the wavefronts of a workgroup, so there is no
@@ -1102,7 +1117,7 @@ void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__r
     __shared__ __attribute__((aligned(16))) double stage[(BLOCK / WAVE) * STAGE];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
     double *valL = stage + w * STAGE;
-    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
+    const int r0 = RW.rb + (xcd_strip_unit((int)blockIdx.x, (int)gridDim.x, xs_plane) * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
     if (r0 >= r1) return;
     const int t = lane >> 4;
     const int r = min(r0 + (lane & 15), r1 - 1);                // (lanes beyond the last row repeat it and store nothing)
@@ -1170,14 +1185,14 @@ __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
                                          const v4i32 *__restrict__ prec, const v4i32 *__restrict__ pslot, const double *__restrict__ x,
                                          double *__restrict__ y, Rows RW, int nnz_total, const TeamRuns TR, int vcap, int xcap,
-                                         const double *__restrict__ guard = nullptr)
+                                         const double *__restrict__ guard = nullptr, int xs_plane = 0)
 {
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
     constexpr int RPW = 16;                                      // NLOAD = ceil(slots / 128): the loads are unconditional, so that the counter's waits can be exact
     extern __shared__ __attribute__((aligned(16))) double team_dyn[];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
     double *valL = team_dyn + w * (vcap + xcap), *xL = valL + vcap;
-    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
+    const int r0 = RW.rb + (xcd_strip_unit((int)blockIdx.x, (int)gridDim.x, xs_plane) * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
     if (r0 >= r1) return;
     const int t = lane >> 4, i = lane & 15;
     const int r = min(r0 + i, r1 - 1);
@@ -1324,19 +1339,7 @@ void spmv_csr_pattern7_kernel(const int *__restrict__ ptr, const double *__restr
     const int tid = (int)threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     const bool w_is_x = DOT >= 1 && wdot == x;
 
-    // XCD strips (round 4, structured grids): workgroup w runs on XCD w % 8.  With the identity order the seven rows that read x[j] sit in five row blocks on five
-    // different XCDs, and x crosses the fabric 5.2 times (the L2 <-> fabric boundary ran at its 8 TB/s: profiles/r03_spmv512_traffic_values_streamed.json).  Here every
-    // XCD takes one eighth of every plane of the grid -- `xs_plane` row blocks cover a plane -- and walks the planes in order: the +-plane neighbours of its rows are its
-    // own rows of the next / previous plane, two strips (0.5 MB at 512^3) apart in its own L2.  A permutation of the blocks: same bits, partial sums in the same slots.
-    int lb = blockIdx.x;
-    if (xs_plane > 0) {
-        const int full = (nb / xs_plane) * xs_plane;
-        if (lb < full) {
-            const int sb = xs_plane >> 3, xcd = lb & 7, slot = lb >> 3;
-            const int plane = slot / sb;
-            lb = plane * xs_plane + xcd * sb + (slot - plane * sb);
-        }
-    }
+    const int lb = xcd_strip_unit((int)blockIdx.x, nb, xs_plane);      // (XCD strips: see xcd_strip_unit)
     Blk B = load_blk(blk, bfirst + lb);
     const int kplan = B.k0, rplan0 = B.r0, rplan1 = B.r1;   // the PLAN's block, whatever this launch clips
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
@@ -2806,7 +2809,7 @@ struct liship_csr_plan_s {
     long long ndcol;     // entries of dcol
     int ndpl;            // distinct columns per lane of spmv_csr_local_kernel: 2 (lists of <= 1024 columns) or 4
     int xcap;            // its x stage: the longest list rounded up to 1024 / 1536 / 2048 entries
-    int xs_plane;        // row blocks per plane of a structured grid, a multiple of 8 (0: none): the XCD strips of spmv_csr_pattern7_kernel
+    int xs_rows;         // rows per plane of a structured grid = the largest column offset of the row patterns (0: none): the XCD strips of the pattern kernels
     int first_term;      // row sums start at the first product instead of at +0.0 (split matrices)
     v4i32 *vrecw;        // device: WIDE value records for patterns of up to 32 entries (no ptab8): per pattern 144 B of byte offsets + length, 256 B of values; else NULL
     int *order;          // device, nblocks entries or NULL: launch order of the products kernel (blocks with a very long row first)
@@ -3242,14 +3245,8 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
             PT(hipMalloc(&p->ptab8, sizeof(int) * 8 * (size_t)npat));
             PT(hipMemcpyAsync(p->ptab8, rec, sizeof(int) * 8 * (size_t)npat, hipMemcpyHostToDevice, st));
             for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
-            // a structured grid: the largest offset is a plane of the grid; `xs_plane` row blocks cover one (XCD strips, see the kernel)
-            p->xs_plane = 0;
-            if (p->nblocks > 0 && maxoff > 0) {
-                const double rows_per_block = (double)p->n / p->nblocks;
-                const long long pb = (long long)((double)maxoff / rows_per_block + 0.5);
-                if (pb >= 64 && pb * 4 <= p->nblocks) p->xs_plane = (int)(pb / 8) * 8;
-            }
         }
+        p->xs_rows = maxoff;                        // a structured grid: the largest offset is a plane of the grid (XCD strips: xcd_strip_unit)
         if (rc == 0) build_team_records(p, tab, npat);
         if (rc == 0) {
             csr_encode_patterns<<<p->nblocks, 256, 0, st>>>(p->blk, ptr, p->codes, npat, d_hash, d_len, d_pc, p->rowpat, p->rowrel, d_bad);
@@ -3803,10 +3800,18 @@ struct LaunchArgs {
 
 
 // XCD strips of the 7-offset pattern kernel: whole-matrix launches of a plan that found a plane (xs_plane), unless switched off
-inline int xcd_strips(const LaunchArgs &a)
+// in units of `unit_rows` rows (the mean rows of a row block, the 64 rows of a team workgroup): units per plane, a multiple of 8, for launches over `units` units
+inline int xcd_strip_plane(const liship_csr_plan_s *P, double unit_rows, long long units)
 {
-    if (!g_xcd_strips || !a.plan || a.bfirst != 0 || a.nb != a.plan->nblocks) return 0;
-    return a.plan->xs_plane;
+    if (!g_xcd_strips || !P || P->xs_rows <= 0 || unit_rows <= 0.0) return 0;
+    const long long pb = (long long)((double)P->xs_rows / unit_rows + 0.5);
+    if (pb < 64 || pb * 4 > units) return 0;                  // planes too small to matter / fewer than four of them
+    return (int)(pb / 8) * 8;
+}
+inline int xcd_strips(const LaunchArgs &a)          // (row-range launches too -- the interior rows of a multi-rank slab: the strips are cut from the launch's own blocks)
+{
+    if (!a.plan || a.nb <= 0 || a.plan->nblocks <= 0) return 0;
+    return xcd_strip_plane(a.plan, (double)a.plan->n / a.plan->nblocks, a.nb);
 }
 
 inline int xcd_run() { int c = (g_variant >> 16) & 0xff; return c ? c : 16; }
@@ -3876,6 +3881,9 @@ static void launch_team(const LaunchArgs &a, const double *guard)
     const liship_csr_plan_s *P = a.plan;
     const int rows = a.re - a.rb, wgs = (rows + 63) / 64;
     if (rows <= 0) return;
+    // XCD strips (xcd_strip_unit) for whole-matrix launches, workgroups of 64 rows per plane: measured NEUTRAL for these kernels (27-point stencil, varying coefficients,
+    // 224^3: 0.4478-0.4522 ms with, 0.4478-0.4483 without -- they stage x per wavefront and are not bound by the fabric), so only behind variant bit 0x10000
+    const int xsp = ((g_variant & 0x10000) && a.rb == 0 && a.re == P->n) ? xcd_strip_plane(P, 64.0, wgs) : 0;
     // (variant 0x8000: one lane per row, 64 rows per wavefront, values and x staged -- 3 % faster than four lanes per row on a repeated product, 3 % slower
     //  inside the Krylov loops, where x is new every time and 8 wavefronts per CU hide less than 28: profiles/r03_pattern_team_kernel.txt; kept for A/B)
     if (P->wdrec && P->wstage && P->wd.len > 0 && (g_variant & 0x8000) && !(g_variant & 0x4000)) {
@@ -3890,11 +3898,11 @@ static void launch_team(const LaunchArgs &a, const double *guard)
     if (P->prec_slot && P->tr.nruns > 0 && !(g_variant & 0x4000)) {
         const int vcap = 16 * P->tr.maxlen + 48, xcap = (P->tr.slots + 1) & ~1;
 #define GOT(NL) spmv_csr_pattern_team_staged_kernel<256, NL><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>( \
-            a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard)
+            a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard, xsp)
         if (P->tr.slots <= 2 * WAVE) GOT(1); else GOT(2);
 #undef GOT
     } else
-        spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard);
+        spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard, xsp);
 }
 
 // the dominant-pattern product of a plan with value records (spmv_csr_valuerec_dom_kernel), plain or with the fused dots (a partial per workgroup: count_out)

@@ -33,6 +33,9 @@ def stencil27(N):
 
 
 lib = lis_amd.load()
+import os as _os
+if _os.environ.get('NO_XCD_STRIPS') == '1':
+    lib.liship_spmv_csr_set_xcd_strips(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 160
 ptr, idx, val = stencil27(N)
 if "--varying" in sys.argv:                       # a non-uniform mesh: the pattern stays, every row has its own values

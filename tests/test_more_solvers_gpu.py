@@ -73,3 +73,29 @@ def test_unserved_solver_says_so(lib):
     A = lisdrv.make_csr(lib, ptr, idx, val)
     out = lisdrv.solve(lib, A, np.ones(10), "-i sor")                  # Gauss-Seidel / SOR: not served, said loudly
     assert out["err"] == capi.LIS_ERR_NOT_IMPLEMENTED
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_solver_is_the_reference_bit_for_bit_in_the_ordered_mode(lib, case):
+    """With lis_amd_set_reference_reductions(1) the sums are the reference's one-thread sums, and lis_solver_more.c restates the reference's recurrences
+    statement by statement: count, status, the whole residual history and the solution must be the reference's in every bit (the fixtures were made at one
+    OpenMP thread).  No slack here, whatever the conditioning."""
+    solver, precon, mat = case.split("_")
+    ptr, idx, val = orc.poisson3d(8, 7, 6) if mat == "p3d" else nonsym_matrix(n=120, seed=9)
+    n = len(ptr) - 1
+    b = orc.spmv_csr(ptr, idx, val, np.ones(n))
+    opts = bytes(G[case + "/opts"]).decode()
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    assert lib.dll.lis_amd_set_reference_reductions(1) == 0
+    try:
+        out = lisdrv.solve(lib, A, b, opts)
+    finally:
+        lib.dll.lis_amd_set_reference_reductions(0)
+    it_ref, st_ref = (int(v) for v in G[case + "/iter_status"])
+    assert (out["iter"], out["status"]) == (it_ref, st_ref), (case, out["iter"], out["status"], it_ref, st_ref)
+    want = G[case + "/rhistory"]
+    assert len(out["rhistory"]) == len(want)
+    diff = np.flatnonzero(out["rhistory"].view(np.int64) != want.view(np.int64))
+    assert diff.size == 0, (case, "first differing history entry", int(diff[0]), out["rhistory"][diff[0]].hex(), want[diff[0]].hex())
+    assert np.array_equal(out["x"].view(np.int64), G[case + "/x"].view(np.int64)), case
+    lib.lis_matrix_destroy(A)

@@ -11,6 +11,7 @@ Cases (inputs are rebuilt by the test from the same generators / the same commit
   poisson<N>     7-point Poisson on N^3 (test/test3.c:114-127 via orc.poisson3d), b = A*1, x0 = 0
   mm/<file>      the reference's own Matrix Market fixtures (tests/golden/mm/testmat*.mtx) through lis_input, b = A*1 (test/test1.c rhs mode 2)
   queen_mini     the Queen_4147 stand-in at its small size (tests/queen_class.py "mini") through lis_input, b = A*1
+  p3d_24x20x16   (one thread) the same stencil solved with -storage csc / ell / dia / jad / bsr: BASELINE config 5's class, each format's own order of additions
 Each with BiCGSTAB, GMRES(30), BiCG (all -p none) and CG + Jacobi, tol 1e-12.
 
     python tests/golden/make_golden_rhistory_bits.py      (dev container only: needs oracle/_ref; rewrites rhistory_bits.npz / .json)
@@ -71,6 +72,17 @@ for N in %(poisson)r:
     b = lisdrv.matvec(ref, A, np.ones(len(ptr) - 1))
     solves("poisson%%d" %% N, A, b)
     ref.lis_matrix_destroy(A)
+if threads == 1:
+    # BASELINE config 5's class: the same system solved in the other storage formats (-storage converts the caller's matrix: lis_solver.c:640-657).
+    # One thread only: the reference's CSC and JAD products group their sums by thread, ELL / DIA / BSR do not
+    ptr, idx, val = orc.poisson3d(24, 20, 16, sort_cols=True)
+    for fmt in ("csc", "ell", "dia", "jad", "bsr"):
+        SOLVES = ("-i cg -p jacobi -storage " + fmt, "-i bicgstab -p none -storage " + fmt, "-i gmres -restart 30 -p none -storage " + fmt)
+        A = lisdrv.make_csr(ref, ptr, idx, val)
+        b = lisdrv.matvec(ref, A, np.ones(len(ptr) - 1))
+        solves("p3d_24x20x16", A, b)
+        ref.lis_matrix_destroy(A)
+    SOLVES = %(solves)r
 for f in %(mm)r:
     from_file("mm/" + f, os.path.join(%(here)r, "mm", f))
 path, rows, stored = queen_class.generate("mini")

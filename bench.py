@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = 512^3 rows per GPU (grid 512 x 512 x 512 N), strong = the one 512^3 grid split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profiles/ figure instead of two rocprofv3 --pmc passes of this run (about 15 s)")
     ap.add_argument("--no-solvers", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the 27-point stencil legs (rank 0, N = 1 only; about 10 s)")
     return ap.parse_args()
@@ -278,6 +279,61 @@ def main():
                 return tj.get("fabric_bytes_per_launch", tj.get("hbm_traffic_bytes_per_launch")), detail
         return None, None
 
+    live_cache = {}
+
+    def live_traffic(v):
+        """The same bytes measured IN THIS RUN: rocprofv3 --kernel-trace --pmc over a child process that sets up the same matrix and runs 12 products
+        (tools/traffic_child.py), one pass for the read requests by size, one for the writes -- separate passes with kernel-trace only, as the
+        microarchitecture guide prescribes.  None when rocprofv3 is not there or a pass fails (the committed figure then serves, and `traffic_detail` says so)."""
+        if v in live_cache:
+            return live_cache[v]
+        live_cache[v] = None
+        if N != 512 or world != 1 or args.no_live_traffic:
+            return None
+        import csv
+        import glob
+        import shutil
+        import subprocess
+        import tempfile
+        prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+        if not os.path.exists(prof):
+            return None
+        want = kernel_name(v)
+        per, t0 = {}, time.perf_counter()
+        tmp = tempfile.mkdtemp(prefix="lis_amd_traffic_", dir="/tmp")
+        try:
+            for tag, ctrs in (("rd", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]),
+                              ("wr", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"])):
+                out_dir = os.path.join(tmp, tag)
+                cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc", *ctrs, "-d", out_dir, "-o", "pmc", "--",
+                       sys.executable, os.path.join(ROOT, "tools", "traffic_child.py"), str(N), str(int(bool(v))), "12"]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+                if r.returncode != 0:
+                    return None
+                acc = {}
+                for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if want in row.get("Kernel_Name", "") and "_dot" not in row.get("Kernel_Name", ""):
+                            a = acc.setdefault(row["Counter_Name"], [0.0, 0])
+                            a[0] += float(row["Counter_Value"]); a[1] += 1
+                for k, (tot, cnt) in acc.items():
+                    per[k] = tot / cnt
+            need = ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")
+            if any(k not in per for k in need):
+                return None
+            r32, r64, r128 = per["TCC_EA0_RDREQ_32B_sum"], per["TCC_EA0_RDREQ_64B_sum"], per["TCC_EA0_RDREQ_128B_sum"]
+            rd = 32 * r32 + 64 * r64 + 128 * r128 + 64 * max(0.0, per["TCC_EA0_RDREQ_sum"] - r32 - r64 - r128)
+            wr = 64 * per["TCC_EA0_WRREQ_64B_sum"] + 32 * (per["TCC_EA0_WRREQ_sum"] - per["TCC_EA0_WRREQ_64B_sum"])
+            live_cache[v] = {"read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr), "fabric_bytes_per_launch": int(rd + wr), "kernel": want,
+                             "source": "measured in this run: rocprofv3 --kernel-trace --pmc (two passes) over tools/traffic_child.py, 12 products of the same matrix",
+                             "level": "L2 <-> fabric requests by size (Infinity Cache hits included: an upper bound of the HBM bytes)",
+                             "seconds": round(time.perf_counter() - t0, 1)}
+            return live_cache[v]
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     def roofline_of(v, k_ms, traffic_name, applies_to):
         """`achieved` / `frac`: the bytes THIS kernel is asked to move (its stored matrix streams + y + the compulsory x) over its own
         HIP-event time -- a physical rate, <= the peak by construction.  `traffic`: the PMC bytes (upper bound, see pmc_traffic).
@@ -286,6 +342,10 @@ def main():
         layout the product runs, and may exceed 1."""
         moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, v)
         traffic, detail = pmc_traffic(traffic_name)
+        live = live_traffic(v) if rank == 0 else None
+        if live:                                            # this run's own counters take precedence over the committed figure (kept beside them)
+            detail = dict(live, committed=detail)
+            traffic = live["fabric_bytes_per_launch"]
         sec = k_ms * 1e-3
         r = {"bound": "hbm", "achieved": round(moved / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(moved / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": detail,

@@ -1,7 +1,7 @@
 # round 4's committed profile set: kernel-trace stats + PMC passes of bench.py, traffic json of both timed kernels, the roofline table, the bench line
 cd $GRAFT_REPO_ROOT
-CMD="python bench.py --steps 20 --warmup 3 --preroll 100 --no-cpu-baseline --no-extras --solver-iters 40"
-PROF_PASS_TIMEOUT=400 bash tools/prof.sh r4final python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --preroll 100 --no-cpu-baseline --no-extras --solver-iters 40 > gpurun_out/r4final_summary.txt 2>&1
+CMD="python bench.py --steps 20 --warmup 3 --preroll 100 --no-cpu-baseline --no-extras --no-live-traffic --solver-iters 40"
+PROF_PASS_TIMEOUT=400 bash tools/prof.sh r4final python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --preroll 100 --no-cpu-baseline --no-extras --no-live-traffic --solver-iters 40 > gpurun_out/r4final_summary.txt 2>&1
 python tools/traffic_json.py gpurun_out/r4final "spmv_csr_valuerec_dom_kernel<256, 0>" gpurun_out/r4final_traffic.json --patterns 27 --values 1 --command "$CMD" > gpurun_out/r4final_traffic.log 2>&1
 python tools/traffic_json.py gpurun_out/r4final "spmv_csr_pattern7_kernel<256, 2048, 0>" gpurun_out/r4final_traffic_streamed.json --patterns 27 --command "$CMD" > gpurun_out/r4final_traffic_streamed.log 2>&1
 tail -3 gpurun_out/r4final_traffic_streamed.log

@@ -1,0 +1,29 @@
+"""A few products of the 512^3 (N^3) Poisson matrix through lis_matvec, exactly as bench.py sets them up -- the process rocprofv3 profiles when bench.py measures
+its `roofline.traffic` live (bench.py live_traffic):   python tools/traffic_child.py N values(0|1) iters"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import lis_amd  # noqa: E402
+from lis_amd import _capi as capi, check  # noqa: E402
+
+N, values, iters = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+lib = lis_amd.load()
+assert lib.initialize([]) == 0
+lib.dll.lis_amd_set_residency(1)
+A = capi.PM()
+assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0 and lib.lis_matrix_set_size(A, 0, N ** 3) == 0
+lib.dll.lis_amd_matrix_poisson3d.argtypes = [capi.PM, C.c_int, C.c_int, C.c_int, C.c_int]
+assert lib.dll.lis_amd_matrix_poisson3d(A, N, N, N, 0) == 0
+x, y = capi.PV(), capi.PV()
+for v in (x, y):
+    assert lib.lis_vector_duplicate(C.cast(A, C.c_void_p), C.byref(v)) == 0
+assert lib.lis_vector_set_all(1.0, x) == 0
+if not values:
+    check(lib.liship_spmv_csr_set_row_values(0))
+for _ in range(iters):
+    assert lib.lis_matvec(A, x, y) == 0
+lib.dll.lis_amd_synchronize()
+print("done", N, values, iters, flush=True)

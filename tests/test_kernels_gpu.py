@@ -1700,3 +1700,47 @@ def test_plan_coders_on_random_structured_matrices(lib, seed):
     for d in wide_dots:                                     # the same sums to rounding
         scale = float(np.abs(w).sum() * (np.abs(yref).max() if n else 0.0) + np.dot(yref, yref)) + 1e-300
         assert dots and np.all(np.abs(d - dots[0]) <= 1e-12 * scale), (state, d, dots[0])
+
+
+@pytest.mark.parametrize("dims", [(128, 128, 128), (40, 256, 128), (72, 96, 200)])
+def test_xcd_strips_permute_blocks_not_bits(lib, dims):
+    """Round 4: the 7-offset pattern kernel (values streamed) walks its row blocks in XCD strips on structured grids -- every XCD one eighth of every plane, plane after
+    plane (xcd_strip_unit).  A permutation of the blocks: y must be the oracle's bits with the strips on and off, whole and in the row ranges of a multi-rank slab
+    (interior / boundary parts), and the fused dots -- a partial per row block, folded in block order -- the same bits either way.  Grids whose planes are 64+ row
+    blocks (strips active: 128 x 128 and 256 x 128 planes) and one whose planes are too small (96 x 200: natural order)."""
+    l, m, n_ = dims
+    ptr, idx, val = orc.poisson3d(l, m, n_)
+    n = len(ptr) - 1
+    rng = np.random.default_rng(l * 7 + m)
+    val = val * rng.uniform(0.5, 1.5, len(val))                 # varying coefficients: no value records, the values are streamed
+    x = np.modf(np.arange(n, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval, dx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    assert lib.liship_csr_plan_pattern_records(plan) == 1 and lib.liship_csr_plan_value_records(plan) == 0
+    work, res = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
+    mn = m * n_
+    dots = {}
+    try:
+        for strips in (1, 0):
+            check(lib.liship_spmv_csr_set_xcd_strips(strips))
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host().view(np.uint64), yref.view(np.uint64)), (dims, strips)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            for lo, hi in ((mn, n - mn), (0, mn), (n - mn, n)):          # a slab's interior rows first, then its two boundary planes
+                check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host().view(np.uint64), yref.view(np.uint64)), (dims, strips, "ranges")
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dx.ptr, 1, res.ptr, work.ptr, None))
+            assert np.array_equal(dy.to_host().view(np.uint64), yref.view(np.uint64)), (dims, strips, "fused")
+            dots[strips] = res.to_host().copy()
+        assert np.array_equal(dots[0].view(np.uint64), dots[1].view(np.uint64)), dots
+        assert abs(dots[1][0] - np.dot(x, yref)) <= 1e-12 * np.abs(x * yref).sum()
+    finally:
+        check(lib.liship_spmv_csr_set_xcd_strips(1))
+        check(lib.liship_csr_plan_destroy(plan))

@@ -17,8 +17,24 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n = N ** 3
 nnz = lib.liship_poisson3d_nnz(N, N, N, 0, n)
-dptr, didx, dval = DA(n + 1, np.int32), DA(nnz, np.int32), DA(nnz, np.float64)
-x, y, y2 = DA(n, np.float64), DA(n, np.float64), DA(n, np.float64)
+OFF = {k: int(os.environ.get(k + "_OFF", "0")) for k in "XYV"}          # A/B: shift x / y / the values by so many bytes (channel placement)
+
+
+class Shifted:
+    def __init__(self, count, dtype, off):
+        self.buf = DA(count + off // np.dtype(dtype).itemsize + 1, dtype)
+        self.ptr, self.count, self.dtype = self.buf.ptr + off, count, np.dtype(dtype)
+
+    def to_host(self):
+        out = np.empty(self.count, self.dtype)
+        check(lib.liship_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, None))
+        check(lib.liship_device_synchronize())
+        return out
+
+
+dptr, didx, dval = DA(n + 1, np.int32), DA(nnz, np.int32), Shifted(nnz, np.float64, OFF["V"])
+x, y, y2 = Shifted(n, np.float64, OFF["X"]), Shifted(n, np.float64, OFF["Y"]), DA(n, np.float64)
+print("device addresses: val %#x  x %#x  y %#x  idx %#x" % (dval.ptr, x.ptr, y.ptr, didx.ptr), flush=True)
 check(lib.liship_poisson3d_csr(N, N, N, 0, n, 0, dptr.ptr, didx.ptr, dval.ptr, None))
 chunk = 1 << 24
 for s in range(0, n, chunk):

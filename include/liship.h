@@ -108,6 +108,7 @@ int  liship_csr_plan_wide_dominant(liship_csr_plan_t plan);
 int  liship_csr_plan_fused_dots(liship_csr_plan_t plan);
 long long liship_csr_plan_fused_slots(liship_csr_plan_t plan);   /* upper bound of the reduction slots the fused product needs in up to three row ranges */
 int  liship_spmv_csr_set_team(int on);           /* A/B switch: 0 = the one-lane-per-row pattern kernel for these rows too (same bits) */
+int  liship_spmv_csr_set_wide_union(int on);     /* plan-time A/B switch: 0 = no virtual dominant pattern (a common supersequence of the patterns rows take turns on: b x b blocked stencils), 1 = from 2^19 rows on (default), 2 = at any size */
 /* Value records (setup-time, optional, after liship_csr_plan_encode_row_patterns; never an error when the matrix does not
  * qualify): when the plan has 32 B pattern records and every row of a pattern carries the same values bit for bit -- a
  * constant-coefficient stencil -- the 7 values join the 7 offsets in the record and the products read neither the value nor

@@ -1022,6 +1022,11 @@ LIS_INT lis_amd_matrix_dominant_pattern(LIS_MATRIX A)
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	return MDEV(A)->plan ? liship_csr_plan_dominant_pattern(MDEV(A)->plan) : 0;
 }
+LIS_INT lis_amd_matrix_wide_dominant(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return MDEV(A)->plan ? liship_csr_plan_wide_dominant(MDEV(A)->plan) : 0;
+}
 LIS_INT lis_amd_matrix_device_type(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;

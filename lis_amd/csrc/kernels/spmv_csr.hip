@@ -80,6 +80,7 @@ int g_local_rpos = 1;            // liship_spmv_csr_set_local_register_positions
 int g_uniform_rows = 1;          // liship_spmv_csr_set_uniform_rows: 0 keeps the row sums of the block-local kernel on the skewed schedule everywhere (A/B)
 int g_long_row_tree_host = 0;    // host mirror of d_long_row_tree (liship_spmv_csr_switches)
 int g_row_block_dots = 0;        // liship_spmv_csr_set_row_block_dots: 1 keeps the fused dots of the dominant-pattern product on the row blocks' partial sums (the bits every other form gives)
+int g_wide_union = 1;            // liship_spmv_csr_set_wide_union: 0 keeps plans whose rows take turns on several patterns off the staged value-record kernel (plan time, A/B)
 int g_team = 1;                  // liship_spmv_csr_set_team: 0 keeps patterned rows of 8..32 entries on the one-lane-per-row pattern kernel
 
 __device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
@@ -3449,6 +3450,24 @@ static int refine_patterns_by_values(liship_csr_plan_s *p, const int *ptr, const
 // dominant one's slots (spmv_csr_valuerecw_staged_kernel).  T: the pattern table (NP + 1 prefix entries, then element offsets), vals: NP x PATW_LEN
 // values (host; NULL for a plan whose values are streamed: masks and slots only, spmv_csr_pattern_rows_staged_kernel).  Kept when one pattern carries at
 // least half of the rows; never an error.
+// a shortest common supersequence of two patterns (offsets, values), an entry of one being an entry of the other when offset and value bits agree; <= 2 * PATW_LEN long
+static int scs_merge(const int *ao, const double *av, int al, const int *bo, const double *bv, int bl, int *mo, double *mv)
+{
+    static_assert(PATW_LEN < 255, "lengths in a byte");
+    unsigned char L[PATW_LEN + 1][PATW_LEN + 1];                // L[a][b]: the longest common subsequence of the tails
+    auto eq = [&](int a, int b) { return ao[a] == bo[b] && memcmp(&av[a], &bv[b], 8) == 0; };
+    for (int a = al; a >= 0; a--)
+        for (int b = bl; b >= 0; b--)
+            L[a][b] = (a == al || b == bl) ? 0 : eq(a, b) ? (unsigned char)(1 + L[a + 1][b + 1]) : (L[a + 1][b] >= L[a][b + 1] ? L[a + 1][b] : L[a][b + 1]);
+    int a = 0, b = 0, ml = 0;
+    while (a < al || b < bl) {
+        if (a < al && b < bl && eq(a, b)) { mo[ml] = ao[a]; mv[ml++] = av[a]; a++; b++; }
+        else if (b >= bl || (a < al && L[a + 1][b] >= L[a][b + 1])) { mo[ml] = ao[a]; mv[ml++] = av[a]; a++; }
+        else { mo[ml] = bo[b]; mv[ml++] = bv[b]; b++; }
+    }
+    return ml;
+}
+
 static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, const double *vals, const int *ptr, hipStream_t st)
 {
     if (p->wdrec) { (void)hipFree(p->wdrec); p->wdrec = nullptr; }
@@ -3469,16 +3488,45 @@ static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, cons
     if (!ok) return;
     int dom = 0;
     for (int i = 1; i < NP; i++) if (count[i] > count[dom]) dom = i;
-    const int l = T[dom + 1] - T[dom];
-    if (count[dom] * 2 < (unsigned long long)p->n || l < 1 || l > PATW_LEN || maxcol < 1) return;
+    int l = T[dom + 1] - T[dom];
+    if (l < 1 || l > PATW_LEN || maxcol < 1) return;
     const int *od = T + NP + 1 + T[dom];                       // the dominant pattern's offsets (elements), in its own order = slot order
+    int uoff[PATW_LEN];
+    double uval[PATW_LEN];
+    if (count[dom] * 2 < (unsigned long long)p->n) {
+        // No single pattern carries half of the rows (a b x b blocking of a stencil kept row by row has b interior patterns that take turns; lis_matrix_convert_csr2bsr
+        // keeps a block row's blocks in first-seen order, so the turns do not even agree on the order of the columns they share): a VIRTUAL dominant pattern, a common
+        // supersequence of the most frequent patterns -- entries are the same when offset and value bits are; an offset may sit in it twice, both entries reading one
+        // staged slot -- so that each of them is an order-preserving mask over it with ITS values.  No row is ON it (D.pat = -1): every row takes the kernel's masked
+        // scalar-register path, -0.0 for the entries it does not have, its own terms in its own order.  Value records only (the streamed-value kernels count kept slots).
+        if (!vals || g_wide_union == 0 || (p->n < (1 << 19) && g_wide_union != 2)) return;       // (below half a million rows the gathering kernel's shorter chain of round trips wins: 64^3 0.0073 against 0.0094 ms; 2 = always, for tests)
+        int order[256], ul = 0;
+        unsigned long long covered = 0;
+        for (int i = 0; i < NP; i++) order[i] = i;
+        for (int a = 1; a < NP; a++) { const int v = order[a]; int b = a - 1; while (b >= 0 && count[order[b]] < count[v]) { order[b + 1] = order[b]; b--; } order[b + 1] = v; }
+        for (int t = 0; t < NP && count[order[t]] * 64 >= (unsigned long long)p->n; t++) {
+            const int i = order[t], li = T[i + 1] - T[i];
+            if (li < 1 || li > PATW_LEN) continue;
+            int moff[2 * PATW_LEN];
+            double mval[2 * PATW_LEN];
+            const int ml = scs_merge(uoff, uval, ul, T + NP + 1 + T[i], vals + (size_t)i * PATW_LEN, li, moff, mval);
+            // a longer supersequence is more masked work for EVERY row: grown only for a pattern with an eighth of the rows, or while half of them are not covered yet
+            if (ml > PATW_LEN || (ml > ul && ul > 0 && count[i] * 8 < (unsigned long long)p->n && covered * 2 >= (unsigned long long)p->n)) continue;
+            memcpy(uoff, moff, sizeof(int) * (size_t)ml); memcpy(uval, mval, sizeof(double) * (size_t)ml);
+            ul = ml; covered += count[i];
+        }
+        if (ul < 1 || covered * 2 < (unsigned long long)p->n) return;
+        dom = -1; l = ul; od = uoff;
+    }
     int offs[PATW_LEN], start[16], mlen[16], base[17], nruns = 0;
     for (int j = 0; j < l; j++) offs[j] = od[j];
     for (int a = 1; a < l; a++) { const int v = offs[a]; int b = a - 1; while (b >= 0 && offs[b] > v) { offs[b + 1] = offs[b]; b--; } offs[b + 1] = v; }
-    for (int j = 0; j < l; ) {
+    int lu = l;                                                 // distinct offsets (the virtual pattern may hold one twice: one staged slot)
+    if (dom < 0) { lu = 0; for (int j = 0; j < l; j++) if (lu == 0 || offs[j] != offs[lu - 1]) offs[lu++] = offs[j]; }
+    for (int j = 0; j < lu; ) {
         int e = j + 1;
-        while (e < l && offs[e] == offs[e - 1] + 1) e++;
-        if ((e < l && offs[e] == offs[e - 1]) || nruns == 16) return;     // a repeated offset, too many runs: the gathering kernel serves
+        while (e < lu && offs[e] == offs[e - 1] + 1) e++;
+        if ((e < lu && offs[e] == offs[e - 1]) || nruns == 16) return;     // a repeated offset, too many runs: the gathering kernel serves
         start[nruns] = offs[j]; mlen[nruns++] = e - j;
         j = e;
     }
@@ -3493,7 +3541,7 @@ static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, cons
         int q = 0;
         for (int a = 0; a < nruns; a++) if (od[j] >= start[a] && od[j] < start[a] + mlen[a]) q = a;
         D.slot[j] = base[q] + (od[j] - start[q]);
-        D.val[j] = vals ? vals[(size_t)dom * PATW_LEN + j] : 0.0;
+        D.val[j] = dom < 0 ? uval[j] : vals ? vals[(size_t)dom * PATW_LEN + j] : 0.0;
     }
     D.tri = (l % 3 == 0 && l <= 30) ? 1 : 0;
     for (int q = 0; q < l / 3 && D.tri; q++) if (D.slot[3 * q + 1] != D.slot[3 * q] + 1 || D.slot[3 * q + 2] != D.slot[3 * q] + 2) D.tri = 0;
@@ -3512,6 +3560,12 @@ static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, cons
             const int *oi = T + NP + 1 + T[i];
             unsigned long long bits = 0;
             int j = 0;
+            if (dom < 0) {                                    // the virtual pattern: first as a mask over entries that carry this pattern's VALUES too (leftmost match)
+                for (int sl = 0; sl < l && j < li; sl++)
+                    if (oi[j] == od[sl] && memcmp(&vals[(size_t)i * PATW_LEN + j], &D.val[sl], 8) == 0) { bits |= 1ull << sl; j++; }
+                if (j != li) { bits = 0; j = 0; }
+                else for (int sl = 0; sl < l; sl++) if ((bits >> sl) & 1ull) img[(size_t)i * WREC + sl] = D.val[sl];
+            }
             for (int sl = 0; sl < l && j < li; sl++)
                 if (oi[j] == od[sl]) { bits |= 1ull << sl; img[(size_t)i * WREC + sl] = vals ? vals[(size_t)i * PATW_LEN + j] : 0.0; j++; }
             if (j != li) bits = 1ull << 32;                   // not a subsequence of the dominant pattern: its rows walk their own record
@@ -3776,6 +3830,7 @@ extern "C" int liship_spmv_csr_set_local_columns(int on) { g_local_cols = on ? 1
 extern "C" int liship_spmv_csr_set_xcd_strips(int on) { g_xcd_strips = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_local_register_positions(int on) { g_local_rpos = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_team(int on) { g_team = on ? 1 : 0; return 0; }
+extern "C" int liship_spmv_csr_set_wide_union(int on) { g_wide_union = on == 2 ? 2 : on ? 1 : 0; return 0; }
 
 namespace {
 

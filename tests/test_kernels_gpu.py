@@ -1744,3 +1744,97 @@ def test_xcd_strips_permute_blocks_not_bits(lib, dims):
     finally:
         check(lib.liship_spmv_csr_set_xcd_strips(1))
         check(lib.liship_csr_plan_destroy(plan))
+
+
+def _blocked_rows(ptr, idx, val, bs, first_seen=True):
+    """the CSR rows that list lis_matvec_bsr's terms of every scalar row of the bs x bs blocking (block after block, column after column, explicit zeros
+    included): what liship_bsr_to_rows lays out in HBM for a constant-coefficient BSR matrix.  first_seen: a block row's blocks in the order
+    lis_matrix_convert_csr2bsr meets them (lis_matrix_bsr.c:351-552: row after row of the block row, entry after entry) -- NOT ascending; else sorted."""
+    import scipy.sparse as sp
+    n = len(ptr) - 1
+    assert n % bs == 0
+    B = sp.csr_matrix((val, idx, ptr), shape=(n, n)).tobsr(blocksize=(bs, bs))
+    B.sort_indices()
+    nb = np.diff(B.indptr)
+    rptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.repeat(nb, bs) * bs, out=rptr[1:])
+    ridx, rval = np.empty(rptr[-1], np.int32), np.empty(rptr[-1])
+    for i in range(n // bs):
+        blocks = np.arange(B.indptr[i], B.indptr[i + 1])
+        if first_seen:
+            met = idx[ptr[i * bs]:ptr[(i + 1) * bs]] // bs
+            _, first = np.unique(met, return_index=True)           # (sorted block columns = B.indices[blocks]; their first positions)
+            blocks = blocks[np.argsort(first, kind="stable")]
+        cols = (B.indices[blocks, None] * bs + np.arange(bs)[None, :]).ravel()
+        for k in range(bs):
+            r = i * bs + k
+            ridx[rptr[r]:rptr[r + 1]] = cols
+            rval[rptr[r]:rptr[r + 1]] = B.data[blocks, k, :].ravel()
+    return rptr.astype(np.int32), ridx, rval
+
+
+@pytest.mark.parametrize("case", ["p3d_2x2", "p2d_2x2", "p3d_2x2_long", "p3d_2x2_sorted", "p3d_3x3"])
+def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(lib, case):
+    """the row form of a b x b blocked stencil has b interior patterns that take turns, none with half of the rows: the plan stages x for the UNION of the most
+    frequent ones and every row is a mask over it with the union's values in scalar registers (build_wide_dominant).  Bits of the plain loop over the listed
+    terms -- explicit zeros meet Inf and NaN as in lis_matvec_bsr.c:293-343, slots a row does not have add -0.0 -- whole, in row ranges, with the fused dots."""
+    if case == "p2d_2x2":
+        ptr, idx, val = orc.poisson3d(1, 48, 64, sort_cols=True)
+    else:
+        ptr, idx, val = orc.poisson3d(*((6, 6, 128) if case == "p3d_2x2_long" else (24, 24, 24)), sort_cols=True)
+    rptr, ridx, rval = _blocked_rows(ptr, idx, val, 3 if case == "p3d_3x3" else 2, first_seen=case != "p3d_2x2_sorted")
+    n = len(rptr) - 1
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-1, 1, n)
+    x[::7] = 0.0
+    x[3::11] = -0.0
+    for pos, v in ((0, np.inf), (n - 1, -np.inf), (n // 2, np.nan), (n // 3, np.inf), (257, np.nan), (5, -np.inf)):
+        x[pos] = v
+    w = rng.uniform(-1, 1, n)
+    ref = orc.spmv_csr(rptr, ridx, rval, x)
+    nanpos = np.isnan(ref)
+    dptr, didx, dval, dx, dw = DA.from_host(rptr, np.int32), DA.from_host(ridx, np.int32), DA.from_host(rval, np.float64), DA.from_host(x, np.float64), DA.from_host(w, np.float64)
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    taken = []
+    try:
+        for union in (2, 0):                              # (2: at any size; the default keeps it for plans of 2^19 rows and more)
+            lib.liship_spmv_csr_set_wide_union(union)
+            plan = C.c_void_p()
+            check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+            check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+            check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+            check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+            if case == "p3d_3x3":                          # 81 patterns: more than the wide value records hold; the blocks stay native in the library (test_configs_gpu.py)
+                assert lib.liship_csr_plan_value_records(plan) == 0
+                check(lib.liship_csr_plan_destroy(plan))
+                return
+            assert lib.liship_csr_plan_value_records(plan) == 2
+            taken.append(lib.liship_csr_plan_wide_dominant(plan))
+            for variant in (0, 0x4000):
+                lib.liship_spmv_csr_set_variant(variant)
+                dy = DA.from_host(np.full(n, 7.0), np.float64)
+                check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+                y = dy.to_host()
+                assert np.array_equal(np.isnan(y), nanpos), (union, hex(variant))
+                assert np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), (union, hex(variant))
+                dy = DA.from_host(np.full(n, 7.0), np.float64)
+                a, b = n // 3 + 1, n - n // 5 - 3
+                for lo, hi in ((a, b), (0, a), (b, n)):
+                    check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+                y = dy.to_host()
+                assert np.array_equal(np.isnan(y), nanpos) and np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), (union, "rows", hex(variant))
+            lib.liship_spmv_csr_set_variant(0)
+            # the fused dots on finite data: y the same bits, the sums to rounding
+            xf = np.where(np.isfinite(x), x, 0.5)
+            dxf = DA.from_host(xf, np.float64)
+            yf = orc.spmv_csr(rptr, ridx, rval, xf)
+            res = DA.from_host(np.full(2, np.nan), np.float64)
+            dy = DA.from_host(np.full(n, 7.0), np.float64)
+            if lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dxf.ptr, dy.ptr, dw.ptr, 1, res.ptr, work.ptr, None) == 0:
+                assert np.array_equal(dy.to_host().view(np.uint64), yf.view(np.uint64))
+                np.testing.assert_allclose(res.to_host(), [np.dot(w, yf), np.dot(yf, yf)], rtol=1e-12)
+            check(lib.liship_csr_plan_destroy(plan))
+    finally:
+        lib.liship_spmv_csr_set_wide_union(1)
+        lib.liship_spmv_csr_set_variant(0)
+    assert taken == [1, 0], taken

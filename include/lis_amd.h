@@ -108,6 +108,9 @@ LIS_INT lis_amd_matrix_dominant_pattern(LIS_MATRIX A);
 /* 1 when the HBM copy's rows of 8..32 entries ride in wide value records AND the plan stages x per wavefront for a dominant pattern -- one pattern with half of
  * the rows, or the union of the patterns the rows take turns on (b x b blocked stencils kept row by row) -- 0 otherwise; uploads A if needed */
 LIS_INT lis_amd_matrix_wide_dominant(LIS_MATRIX A);
+/* b when the HBM copy of a b x b BSR matrix with constant coefficients is its row form AND the product gives a lane a whole block row (each x read once for the
+ * block row's b sums, liship.h "block rows"), else 0; uploads A if needed */
+LIS_INT lis_amd_matrix_block_rows(LIS_MATRIX A);
 /* ELL and DIA matrices with constant coefficients are kept in HBM as CSR rows that list the format's terms in the format's order
  * (bit-identical sums), so that the value records apply.  0 keeps the native ELL / DIA layout and kernels for matrices uploaded
  * from now on (env LIS_AMD_NO_ROW_FORM=1): A/B measurements, and the tests that pin the native kernels at full size. */

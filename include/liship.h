@@ -108,6 +108,13 @@ int  liship_csr_plan_wide_dominant(liship_csr_plan_t plan);
 int  liship_csr_plan_fused_dots(liship_csr_plan_t plan);
 long long liship_csr_plan_fused_slots(liship_csr_plan_t plan);   /* upper bound of the reduction slots the fused product needs in up to three row ranges */
 int  liship_spmv_csr_set_team(int on);           /* A/B switch: 0 = the one-lane-per-row pattern kernel for these rows too (same bits) */
+/* Block rows on top of the wide value records: the rows b i .. b i + b - 1 of the matrix list the SAME columns in the same order (the row form of a b x b BSR matrix,
+ * liship_bsr_to_rows; b = 2, 3, 4).  When one block row pattern carries half of the block rows, the product gives a LANE a block row: each x read once from the
+ * wavefront's staged window feeds the b running sums, the b x len values are kernel arguments (spmv_csr_blockrows_staged_kernel).  Optional, never an error when the
+ * matrix does not qualify; row ranges that cut a block row run the row-by-row kernels.  Bits of lis_matvec_bsr.c:293-343. */
+int  liship_csr_plan_encode_block_rows(liship_csr_plan_t plan, int b, const int *ptr, void *stream);
+int  liship_csr_plan_block_rows(liship_csr_plan_t plan);       /* b when the plan keeps them, else 0 */
+int  liship_spmv_csr_set_block_rows(int on);                   /* A/B switch: 0 = the row-by-row kernels (same bits) */
 int  liship_spmv_csr_set_wide_union(int on);     /* plan-time A/B switch: 0 = no virtual dominant pattern (a common supersequence of the patterns rows take turns on: b x b blocked stencils), 1 = from 2^19 rows on (default), 2 = at any size */
 /* Value records (setup-time, optional, after liship_csr_plan_encode_row_patterns; never an error when the matrix does not
  * qualify): when the plan has 32 B pattern records and every row of a pattern carries the same values bit for bit -- a

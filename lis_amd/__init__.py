@@ -80,6 +80,9 @@ _LISHIP = {
     "liship_csr_plan_wide_dominant": (_ci, [_vp]),
     "liship_spmv_csr_set_team": (_ci, [_ci]),
     "liship_spmv_csr_set_wide_union": (_ci, [_ci]),
+    "liship_csr_plan_encode_block_rows": (_ci, [_vp, _ci, _vp, _vp]),
+    "liship_csr_plan_block_rows": (_ci, [_vp]),
+    "liship_spmv_csr_set_block_rows": (_ci, [_ci]),
     "liship_spmv_bsr_rows_f64": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp]),
     "liship_spmv_bsr_set_team": (_ci, [_ci]),
     "liship_csr_plan_encode_row_values": (_ci, [_vp, _vp, _vp, _vp]),

@@ -654,6 +654,8 @@ static LIS_INT try_bsr_row_form(LIS_MATRIX A, lisd_mat *d, const int *dbptr, con
 	liship_csr_plan_t plan = NULL;
 	if (!err) err = lisd_csr_plan(&plan, n, rptr, ridx, rval);
 	if (!err && plan && liship_csr_plan_value_records(plan)) {
+		if (bnr == bnc && bnr <= 4 && liship_csr_plan_value_records(plan) == 2)       /* a lane per block row (optional; the plan decides) */
+			(void)liship_csr_plan_encode_block_rows(plan, bnr, rptr, lisg.stream);
 		d->ptr = rptr; d->index = ridx; d->value = rval; d->plan = plan;
 		d->type = LIS_MATRIX_CSR; d->nnz = (int)slots;
 		*taken = 1;
@@ -1026,6 +1028,11 @@ LIS_INT lis_amd_matrix_wide_dominant(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	return MDEV(A)->plan ? liship_csr_plan_wide_dominant(MDEV(A)->plan) : 0;
+}
+LIS_INT lis_amd_matrix_block_rows(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return MDEV(A)->plan ? liship_csr_plan_block_rows(MDEV(A)->plan) : 0;
 }
 LIS_INT lis_amd_matrix_device_type(LIS_MATRIX A)
 {

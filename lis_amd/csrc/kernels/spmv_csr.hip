@@ -80,6 +80,7 @@ int g_local_rpos = 1;            // liship_spmv_csr_set_local_register_positions
 int g_uniform_rows = 1;          // liship_spmv_csr_set_uniform_rows: 0 keeps the row sums of the block-local kernel on the skewed schedule everywhere (A/B)
 int g_long_row_tree_host = 0;    // host mirror of d_long_row_tree (liship_spmv_csr_switches)
 int g_row_block_dots = 0;        // liship_spmv_csr_set_row_block_dots: 1 keeps the fused dots of the dominant-pattern product on the row blocks' partial sums (the bits every other form gives)
+int g_block_rows = 1;            // liship_spmv_csr_set_block_rows: 0 keeps plans with block rows (liship_csr_plan_encode_block_rows) on the row-by-row kernels (A/B); 2: plans of any size take them (tests)
 int g_wide_union = 1;            // liship_spmv_csr_set_wide_union: 0 keeps plans whose rows take turns on several patterns off the staged value-record kernel (plan time, A/B)
 int g_team = 1;                  // liship_spmv_csr_set_team: 0 keeps patterned rows of 8..32 entries on the one-lane-per-row pattern kernel
 
@@ -2294,7 +2295,7 @@ void spmv_csr_valuerec_pair_dot_kernel(const unsigned char *__restrict__ rowpat,
 // patterns carry their values when the coefficients are constant).  One row per lane; the records -- 144 B of byte offsets and
 // the length, 256 B of values per pattern -- sit in LDS; a row is walked in chunks of 8 entries: offsets, 8 gathers in flight,
 // values, 8 additions in order (terms beyond the row's length add -0.0).  Same products in the same order: bit-identical.
-constexpr int PATW_MAX = 64, PATW_LEN = 32, PATW_OFF = 36;             // patterns (48 until round 4: the 2 x 2 blocking of a 7-point stencil has 54), entries per pattern, ints per offset record
+constexpr int PATW_MAX = 128, PATW_LEN = 32, PATW_OFF = 36;            // patterns (48 until round 4; the b x b blocking of a 7-point stencil has 27 b: 54, 81, 108), entries per pattern, ints per offset record
 template <int BLOCK, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_valuerecw_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, int npat,
@@ -2306,8 +2307,9 @@ void spmv_csr_valuerecw_kernel(const unsigned char *__restrict__ rowpat, const v
     const double stop = (DOT != 0 && guard != nullptr) ? guard[0] : 0.0;
     const double acc0 = RW.acc0;
     __shared__ double dot_scratch[BLOCK / WAVE];
-    __shared__ __attribute__((aligned(16))) int offL[PATW_MAX * PATW_OFF];
-    __shared__ __attribute__((aligned(16))) double valL[PATW_MAX * PATW_LEN];
+    extern __shared__ __attribute__((aligned(16))) double recw_dyn[];     // npat x 256 B of values, then npat x 144 B of offsets (the launcher sizes it: 400 B per pattern)
+    double *valL = recw_dyn;
+    int *offL = reinterpret_cast<int *>(recw_dyn + (size_t)npat * PATW_LEN);
     const int tid = (int)threadIdx.x;
     {   // the image: npat x 144 B of offsets, then npat x 256 B of values
         const v4i32 *src = rec;
@@ -2502,6 +2504,127 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
         if (DOT >= 1 && live) c0 += wv * acc;
         if (DOT >= 2 && live) c1 += acc * acc;
     }
+    }
+    if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : (int)gridDim.x, true);
+}
+
+// BLOCK ROWS: the row form of a b x b blocked stencil (liship_bsr_to_rows: CSR rows that list lis_matvec_bsr's terms) has b interior row patterns that take
+// turns, one per place in the block -- but the b rows of a block row list the SAME columns in the same order (the block row's blocks, column after column),
+// only their values differ.  Here a LANE owns a block row: it reads each x of the block row once from the wavefront's staged window (64 block rows, the
+// dominant block row's runs of columns, 63 b + m doubles each) and feeds its b running sums, entry after entry in the rows' own order, the values b x len
+// scalars of the kernel's arguments.  A block row is named by the pattern byte of its FIRST row (plan time checks that it determines the others'); block rows
+// whose columns are a subsequence of the dominant one's with its values in the entries they keep are a mask (-0.0 terms), the rest walk their rows' own wide
+// records.  14 x reads and 28 multiply-adds for the two rows of a 2 x 2 block row where the row-by-row kernel on the virtual pattern spends 40 masked terms.
+// Same products in the same order as lis_matvec_bsr.c:293-343 (explicit zeros included): the reference's bits.
+struct BlockDom { int len, key, slots, maxcol, b, pair, pad0, pad1; int slot[PATW_LEN]; double val[4][PATW_LEN]; };
+template <int B, int NL, int DOT = 0>
+__global__ __launch_bounds__(256)
+void spmv_csr_blockrows_staged_kernel(const unsigned char *__restrict__ rowpat, const unsigned long long *__restrict__ bdrec, const int *__restrict__ bstage,
+                                      const v4i32 *__restrict__ rec, int npat, const double *__restrict__ x, double *__restrict__ y, Rows RW,
+                                      const BlockDom D, int xcap, const double *__restrict__ guard = nullptr,
+                                      const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr, int pstride = 0)
+{
+    constexpr int BLOCK = 256;
+    if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
+    extern __shared__ __attribute__((aligned(16))) double wide_dyn[];
+    __shared__ double dot_part[(DOT >= 2 ? 2 : 1) * (DOT != 0 ? BLOCK : 1)];
+    __shared__ unsigned dot_count;
+    if (DOT != 0) {                                                // the only barrier: at the start (workgroup_dots_last)
+        if (threadIdx.x == 0) dot_count = 0u;
+        __syncthreads();
+    }
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
+    double *xL = wide_dyn + w * xcap;
+    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * (WAVE * B);      // (RW.rb and RW.re are multiples of B: the launcher checks)
+    double c0 = 0.0, c1 = 0.0;
+    if (r0 < RW.re) {
+        const int rl = r0 + lane * B;
+        const bool live = rl < RW.re;
+        const int key = live ? (int)rowpat[rl] : D.key;
+        v2f64 xs[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int c = r0 + bstage[k * WAVE + lane], cc = min(max(c, 0), D.maxcol - 1);
+            const v2f64 v = *reinterpret_cast<const v2f64u *>(x + cc);
+            xs[k].x = c > cc ? v.y : v.x;                          // a pair pushed inside the array by the clamp hands each slot the half that holds its column
+            xs[k].y = c < cc ? v.x : v.y;
+        }
+        double wv[B];
+        if (DOT != 0) {
+#pragma unroll
+            for (int k = 0; k < B; k++) wv[k] = live ? wdot[rl + k] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) { const int sl = 2 * (k * WAVE + lane); if (sl < D.slots) *reinterpret_cast<v2f64 *>(xL + sl) = xs[k]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double *xr = xL + lane * B;
+        double acc[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) acc[k] = RW.acc0;
+        if (__builtin_amdgcn_ballot_w64(key != D.key) == 0) {      // (uniform) every block row here is the dominant one
+            if (D.pair) {                                          // entries 2q, 2q + 1 sit in neighbouring slots (even b: a block's columns two by two)
+#pragma unroll
+                for (int q = 0; q < PATW_LEN / 2; q++)
+                    if (2 * q < D.len) {
+                        const v2f64 x01 = *reinterpret_cast<const v2f64u *>(xr + D.slot[2 * q]);
+#pragma unroll
+                        for (int k = 0; k < B; k++) { acc[k] += D.val[k][2 * q] * x01.x; acc[k] += D.val[k][2 * q + 1] * x01.y; }
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PATW_LEN; j++)
+                    if (j < D.len) {
+                        const double xj = xr[D.slot[j]];
+#pragma unroll
+                        for (int k = 0; k < B; k++) acc[k] += D.val[k][j] * xj;
+                    }
+            }
+        } else {
+            // masks: one 8 B scalar load per distinct key among the lanes.  Bit 32: foreign (the block row's rows walk their own records)
+            unsigned m = D.len >= 32 ? 0xffffffffu : ((1u << D.len) - 1u);
+            bool foreign = false;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(key != D.key);
+            while (todo != 0) {                                     // (uniform)
+                const int q = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
+                const unsigned long long bits = bdrec[q];           // (uniform address)
+                const bool me = key == q;
+                m = me ? (unsigned)bits : m;
+                foreign = me ? ((bits >> 32) & 1ull) != 0 : foreign;
+                todo &= ~__builtin_amdgcn_ballot_w64(me);
+            }
+            if (!foreign) {
+#pragma unroll
+                for (int j = 0; j < PATW_LEN; j++)
+                    if (j < D.len) {
+                        const double xj = xr[D.slot[j]];
+                        const bool keep = ((m >> j) & 1u) != 0;
+#pragma unroll
+                        for (int k = 0; k < B; k++) { const double t = D.val[k][j] * xj; acc[k] += keep ? t : -0.0; }      // -0.0 terms leave any sum bit-unchanged
+                    }
+            } else if (live) {
+#pragma unroll 1
+                for (int k = 0; k < B; k++) {
+                    const int r = rl + k, pat = (int)rowpat[r];
+                    const int *off = reinterpret_cast<const int *>(rec) + pat * PATW_OFF;
+                    const double *vv = reinterpret_cast<const double *>(rec + npat * (PATW_OFF / 4)) + pat * PATW_LEN;
+                    const int len = off[PATW_LEN];
+                    const unsigned rb8 = (unsigned)r * 8u;
+                    double a = RW.acc0;
+                    for (int j = 0; j < len; j++) a += vv[j] * *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)off[j]));
+                    acc[k] = a;
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < B; k++) store_stream(y + rl + k, acc[k]);
+        }
+        if (DOT != 0 && live) {
+#pragma unroll
+            for (int k = 0; k < B; k++) { c0 += wv[k] * acc[k]; if (DOT >= 2) c1 += acc[k] * acc[k]; }
+        }
     }
     if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : (int)gridDim.x, true);
 }
@@ -2825,6 +2948,9 @@ struct liship_csr_plan_s {
     double *wdrec;       // device: with vrecw, when one pattern carries most rows: per pattern WREC doubles (values in the dominant pattern's slots, mask | foreign << 32)
     v4i32 *wstage;       // device: 64 x 8 ints, the column offsets of a lane's slot pairs in the staging loads of spmv_csr_valuerecw_staged_kernel
     WideDom wd;          // the dominant wide pattern (len = 0: none)
+    BlockDom bd;         // block rows (liship_csr_plan_encode_block_rows): the dominant block row, one lane per block row (len = 0: none)
+    unsigned long long *bdrec; // device: per pattern byte of a block row's FIRST row: mask over the dominant block row's entries | foreign << 32
+    int *bstage;         // device: NL x 64 ints, the column offsets (from the wavefront's first row) of a lane's slot pairs in the staging loads
     v4i32 *prec36;       // device: when the longest pattern has 8..32 offsets, one 144 B record per pattern (32 byte offsets, length): spmv_csr_pattern_team_kernel; else NULL
     int prep[256];       // a row that carries each pattern
     v4i32 *vrec;         // device: with ptab8, when every row of a pattern carries the same values, 96 B per pattern (the 32 B record + 7 values); else NULL
@@ -2939,7 +3065,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->bd.len = 0; p->bdrec = nullptr; p->bstage = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
     p->drec = nullptr; p->dom_lo = p->dom_hi = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
@@ -2962,6 +3088,8 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->prec_slot) (void)hipFree(p->prec_slot);
     if (p->wdrec) (void)hipFree(p->wdrec);
     if (p->wstage) (void)hipFree(p->wstage);
+    if (p->bdrec) (void)hipFree(p->bdrec);
+    if (p->bstage) (void)hipFree(p->bstage);
     if (p->vrec) (void)hipFree(p->vrec);
     if (p->drec) (void)hipFree(p->drec);
     if (p->order) (void)hipFree(p->order);
@@ -3604,7 +3732,7 @@ static int encode_wide_value_records(liship_csr_plan_s *p, const int *ptr, const
     PT(hipMalloc(&d_rep, sizeof(int) * (size_t)npat)); PT(hipMalloc(&d_bad, sizeof(int))); PT(hipMalloc(&vr, sizeof(double) * PATW_LEN * (size_t)npat));
     PT(hipMemcpyAsync(d_rep, p->prep, sizeof(int) * (size_t)npat, hipMemcpyHostToDevice, st));
     PT(hipMemsetAsync(d_bad, 0, sizeof(int), st));
-    if (rc == 0) { csr_fetch_values<<<1, 64, 0, st>>>(npat, d_rep, ptr, val, vr, PATW_LEN, PATW_LEN); PT(hipGetLastError()); }
+    if (rc == 0) { csr_fetch_values<<<(npat + 63) / 64, 64, 0, st>>>(npat, d_rep, ptr, val, vr, PATW_LEN, PATW_LEN); PT(hipGetLastError()); }
     if (rc == 0) { csr_check_values<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, val, p->rowpat, vr, d_bad, PATW_LEN, PATW_LEN); PT(hipGetLastError()); }
     PT(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
     PT(hipStreamSynchronize(st));
@@ -3637,7 +3765,7 @@ static int encode_wide_value_records(liship_csr_plan_s *p, const int *ptr, const
                 PT(hipMemcpyAsync(d_hash, hashes, sizeof(unsigned long long) * np2, hipMemcpyHostToDevice, st));
                 PT(hipMemcpyAsync(d_rep2, reps2, sizeof(int) * np2, hipMemcpyHostToDevice, st));
                 PT(hipMemsetAsync(d_bad, 0, sizeof(int), st));
-                if (rc == 0) { csr_fetch_value_patterns<<<1, 64, 0, st>>>(np2, d_rep2, ptr, val, p->rowpat, d_old, vr2, PATW_LEN, PATW_LEN); PT(hipGetLastError()); }
+                if (rc == 0) { csr_fetch_value_patterns<<<(np2 + 63) / 64, 64, 0, st>>>(np2, d_rep2, ptr, val, p->rowpat, d_old, vr2, PATW_LEN, PATW_LEN); PT(hipGetLastError()); }
                 if (rc == 0) {
                     csr_encode_value_patterns<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, ptr, val, p->rowpat, np2, d_hash, d_old, vr2, newpat, d_bad, PATW_LEN, PATW_LEN);
                     PT(hipGetLastError());
@@ -3740,6 +3868,144 @@ extern "C" int liship_csr_plan_encode_row_values(liship_csr_plan_t p, const int 
 extern "C" int liship_csr_plan_value_records(liship_csr_plan_t p)
 { return (p && p->rowpat && p->ptab8 && p->vrec) ? 1 : (p && p->rowpat && p->vrecw) ? 2 : 0; }        // 2: the wide records (rows of up to 32 entries)
 extern "C" int liship_spmv_csr_set_row_values(int on) { g_row_values = on ? 1 : 0; return 0; }
+
+// plan time: the pattern byte of a block row's first row must determine its other rows' (tab: 256 x 3, 0xffffffff = not seen); block rows per first-row pattern
+__global__ void blockrow_keys(int nbr, int b, const unsigned char *__restrict__ rowpat, unsigned int *__restrict__ tab, unsigned long long *__restrict__ count, int *__restrict__ bad)
+{
+    __shared__ unsigned int h[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) h[t] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nbr; i += (long long)gridDim.x * blockDim.x) {
+        const int key = rowpat[i * b];
+        atomicAdd(&h[key], 1u);
+        for (int k = 1; k < b; k++) {
+            const unsigned int v = rowpat[i * b + k], old = atomicCAS(&tab[key * 3 + k - 1], 0xffffffffu, v);
+            if (old != 0xffffffffu && old != v) *bad = 1;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) if (h[t]) atomicAdd(&count[t], (unsigned long long)h[t]);
+}
+
+// Block rows on top of the wide value records (see spmv_csr_blockrows_staged_kernel): setup-time, optional, never an error when the matrix does not qualify.
+// b: the rows b i .. b i + b - 1 list the same columns in the same order for every i (the row form of a b x b BSR matrix, liship_bsr_to_rows).
+extern "C" int liship_csr_plan_encode_block_rows(liship_csr_plan_t p, int b, const int *ptr, void *stream)
+{
+    if (!p || b < 2 || b > 4 || (p->n > 0 && !ptr)) return LISHIP_ERR_ARG;
+    if (!p->rowpat || !p->vrecw || p->ptab8 || !p->ptab || p->npat <= 0 || p->npat > 255 || p->n % b != 0 || p->n < 4 * WAVE * b || p->bd.len > 0 ||
+        !p->codes || !p->dict || g_variant != 0) return 0;
+    if (p->n < (1 << 17) && g_block_rows != 2) return 0;            // (small matrices: the gathering kernel's shorter chain of round trips wins, 2 x 2 at 32^3: 0.0035 against 0.0052 ms; from 48^3 on it does not)
+    hipStream_t st = as_stream(stream);
+    const int NP = p->npat, nbr = p->n / b;
+    const size_t obytes = sizeof(int) * PATW_OFF * (size_t)NP, vbytes = sizeof(double) * PATW_LEN * (size_t)NP;
+    int *T = (int *)malloc(sizeof(int) * (size_t)p->ptab_len);
+    unsigned char *img = (unsigned char *)malloc(obytes + vbytes);
+    unsigned int *d_tab = nullptr, tab[256 * 3];
+    unsigned long long *d_count = nullptr, count[256];
+    int *d_bad = nullptr, bad[2] = {1, 0};                       // {rows of one first-row pattern disagree, the largest column}
+    bool ok = T && img && hipMalloc(&d_tab, sizeof(tab)) == hipSuccess && hipMalloc(&d_count, sizeof(count)) == hipSuccess && hipMalloc(&d_bad, sizeof(bad)) == hipSuccess;
+    ok = ok && hipMemsetAsync(d_tab, 0xff, sizeof(tab), st) == hipSuccess && hipMemsetAsync(d_count, 0, sizeof(count), st) == hipSuccess && hipMemsetAsync(d_bad, 0, sizeof(bad), st) == hipSuccess;
+    if (ok) { blockrow_keys<<<1024, 256, 0, st>>>(nbr, b, p->rowpat, d_tab, d_count, d_bad); ok = hipGetLastError() == hipSuccess; }
+    if (ok) { csr_max_column<<<2048, 256, 0, st>>>(p->n, ptr, p->codes, p->dict, d_bad + 1); ok = hipGetLastError() == hipSuccess; }
+    ok = ok && hipMemcpyAsync(tab, d_tab, sizeof(tab), hipMemcpyDeviceToHost, st) == hipSuccess && hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(T, p->ptab, sizeof(int) * (size_t)p->ptab_len, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(img, p->vrecw, obytes + vbytes, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (d_tab) (void)hipFree(d_tab);
+    if (d_count) (void)hipFree(d_count);
+    if (d_bad) (void)hipFree(d_bad);
+    const double *vals = reinterpret_cast<const double *>(img + obytes);
+    // the rows of the block row named by `key`: their patterns, the common length, the columns relative to the block row's first row; false when they do not share them
+    auto block_row = [&](int key, int *pats, int *offs) -> int {
+        pats[0] = key;
+        for (int k = 1; k < b; k++) { const unsigned int v = tab[key * 3 + k - 1]; if (v >= (unsigned int)NP) return 0; pats[k] = (int)v; }
+        const int l = T[key + 1] - T[key];
+        if (l < 1 || l > PATW_LEN) return 0;
+        for (int j = 0; j < l; j++) offs[j] = T[NP + 1 + T[key] + j];
+        for (int k = 1; k < b; k++) {
+            if (T[pats[k] + 1] - T[pats[k]] != l) return 0;
+            for (int j = 0; j < l; j++) if (T[NP + 1 + T[pats[k]] + j] + k != offs[j]) return 0;
+        }
+        return l;
+    };
+    while (ok && bad[0] == 0 && bad[1] >= 1) {                  // (one pass; `break` = does not qualify)
+        int dom = 0;
+        for (int i = 1; i < NP; i++) if (count[i] > count[dom]) dom = i;
+        if (count[dom] * 2 < (unsigned long long)nbr) break;
+        int dpat[4], doff[PATW_LEN];
+        const int l = block_row(dom, dpat, doff);
+        if (l < 1) break;
+        int offs[PATW_LEN], start[16], mlen[16], base[17], nruns = 0;
+        for (int j = 0; j < l; j++) offs[j] = doff[j];
+        for (int a = 1; a < l; a++) { const int v = offs[a]; int c = a - 1; while (c >= 0 && offs[c] > v) { offs[c + 1] = offs[c]; c--; } offs[c + 1] = v; }
+        bool fits = true;
+        for (int j = 0; j < l && fits; ) {
+            int e = j + 1;
+            while (e < l && offs[e] == offs[e - 1] + 1) e++;
+            if ((e < l && offs[e] == offs[e - 1]) || nruns == 16) { fits = false; break; }
+            start[nruns] = offs[j]; mlen[nruns++] = e - j;
+            j = e;
+        }
+        if (!fits) break;
+        base[0] = 0;
+        for (int a = 0; a < nruns; a++) base[a + 1] = base[a] + (((WAVE - 1) * b + mlen[a] + 1) & ~1);      // 64 block rows need 63 b + m columns of a run of m; even widths (pairs of slots)
+        const int slots = base[nruns], nl = (slots + 2 * WAVE - 1) / (2 * WAVE);
+        if (nl > (b == 2 ? 6 : b == 3 ? 8 : 12)) break;
+        BlockDom D;
+        memset(&D, 0, sizeof(D));
+        D.len = l; D.key = dom; D.slots = slots; D.maxcol = bad[1]; D.b = b;
+        for (int j = 0; j < l; j++) {
+            int q = 0;
+            for (int a = 0; a < nruns; a++) if (doff[j] >= start[a] && doff[j] < start[a] + mlen[a]) q = a;
+            D.slot[j] = base[q] + (doff[j] - start[q]);
+            for (int k = 0; k < b; k++) D.val[k][j] = vals[(size_t)dpat[k] * PATW_LEN + j];
+        }
+        D.pair = (l % 2 == 0) ? 1 : 0;
+        for (int q = 0; q < l / 2 && D.pair; q++) if (D.slot[2 * q + 1] != D.slot[2 * q] + 1) D.pair = 0;
+        const int nlk = b == 2 ? (nl <= 4 ? 4 : 6) : b == 3 ? (nl <= 6 ? 6 : 8) : (nl <= 8 ? 8 : 12);      // the kernel's instantiations
+        int *stage = (int *)calloc((size_t)nlk * WAVE, sizeof(int));
+        unsigned long long *rec = (unsigned long long *)calloc(256, sizeof(unsigned long long));
+        if (stage && rec) {
+            for (int k = 0; k < nlk; k++)
+                for (int lane = 0; lane < WAVE; lane++) {
+                    const int sl = 2 * (k * WAVE + lane);
+                    int q = -1;
+                    for (int a = 0; a < nruns; a++) if (sl >= base[a] && sl < base[a + 1]) q = a;
+                    stage[k * WAVE + lane] = q >= 0 ? start[q] + (sl - base[q]) : 0;
+                }
+            for (int i = 0; i < 256; i++) {
+                rec[i] = 1ull << 32;                              // foreign unless shown otherwise
+                if (i >= NP || count[i] == 0) continue;
+                int qpat[4], qoff[PATW_LEN];
+                const int li = block_row(i, qpat, qoff);
+                if (li < 1) continue;
+                unsigned long long bits = 0;
+                int j = 0;
+                for (int sl = 0; sl < l && j < li; sl++)
+                    if (qoff[j] == doff[sl]) {
+                        bool same = true;
+                        for (int k = 0; k < b; k++) same = same && memcmp(&vals[(size_t)qpat[k] * PATW_LEN + j], &D.val[k][sl], 8) == 0;
+                        if (!same) break;
+                        bits |= 1ull << sl; j++;
+                    }
+                if (j == li) rec[i] = bits;
+            }
+            if (hipMalloc(&p->bdrec, sizeof(unsigned long long) * 256) == hipSuccess && hipMalloc(&p->bstage, sizeof(int) * (size_t)nlk * WAVE) == hipSuccess &&
+                hipMemcpy(p->bdrec, rec, sizeof(unsigned long long) * 256, hipMemcpyHostToDevice) == hipSuccess &&
+                hipMemcpy(p->bstage, stage, sizeof(int) * (size_t)nlk * WAVE, hipMemcpyHostToDevice) == hipSuccess) p->bd = D;
+            else {
+                if (p->bdrec) { (void)hipFree(p->bdrec); p->bdrec = nullptr; }
+                if (p->bstage) { (void)hipFree(p->bstage); p->bstage = nullptr; }
+            }
+        }
+        free(stage); free(rec);
+        break;
+    }
+    free(T); free(img);
+    return 0;
+}
+// b when the plan keeps block rows for spmv_csr_blockrows_staged_kernel, else 0
+extern "C" int liship_csr_plan_block_rows(liship_csr_plan_t p) { return (p && p->vrecw && p->bdrec && p->bstage && p->bd.len > 0) ? p->bd.b : 0; }
 // 1 when the plan also names a dominant pattern (spmv_csr_valuerec_dom_kernel), else 0
 extern "C" int liship_csr_plan_dominant_pattern(liship_csr_plan_t p) { return (p && p->ptab8 && p->drec) ? (p->vrec ? 1 : 2) : 0; }      // 2: offsets only (no value records)
 
@@ -3830,6 +4096,7 @@ extern "C" int liship_spmv_csr_set_local_columns(int on) { g_local_cols = on ? 1
 extern "C" int liship_spmv_csr_set_xcd_strips(int on) { g_xcd_strips = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_local_register_positions(int on) { g_local_rpos = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_team(int on) { g_team = on ? 1 : 0; return 0; }
+extern "C" int liship_spmv_csr_set_block_rows(int on) { g_block_rows = on == 2 ? 2 : on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_wide_union(int on) { g_wide_union = on == 2 ? 2 : on ? 1 : 0; return 0; }
 
 namespace {
@@ -3909,11 +4176,30 @@ void launch_products(int grid, const LaunchArgs &a)
                                      nullptr, nullptr, nullptr, 0, XRUN ? nullptr : a.order);
 }
 
+static bool block_rows_serve(const liship_csr_plan_s *P, int rb, int re)      // the block-row kernel for this row range? (whole block rows only)
+{
+    return P && P->bd.len > 0 && P->bdrec && P->bstage && g_block_rows && g_team && rb % P->bd.b == 0 && re % P->bd.b == 0;
+}
+
 // rows of up to 32 entries whose values ride in wide records: x staged per wavefront, the dominant pattern in scalar registers (variant 0x4000: the
 // gathering kernel on plan row blocks, A/B)
 static bool launch_wide(const LaunchArgs &a, const double *guard, int dot = 0, const double *w = nullptr, double *partial = nullptr, int pstride = 0, int *wgs_out = nullptr)
 {
     const liship_csr_plan_s *P = a.plan;
+    if (block_rows_serve(P, a.rb, a.re) && !(g_variant & 0x4000)) {      // one lane per block row (the row form of a b x b blocked stencil)
+        const int b = P->bd.b, rows = a.re - a.rb, wgs = (rows + 256 * b - 1) / (256 * b);
+        if (wgs_out) *wgs_out = rows > 0 ? wgs : 0;
+        if (rows <= 0) return true;
+        const int xcap = (P->bd.slots + 1) & ~1, nl = (P->bd.slots + 2 * WAVE - 1) / (2 * WAVE);
+#define GOB(B_, NL_, DT) spmv_csr_blockrows_staged_kernel<B_, NL_, DT><<<wgs, 256, sizeof(double) * 4 * (size_t)xcap, a.st>>>( \
+        a.rowpat, P->bdrec, P->bstage, a.vrecw, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0}, P->bd, xcap, guard, w, partial, pstride)
+#define GOBD(DT) do { if (b == 2) { if (nl <= 4) GOB(2, 4, DT); else GOB(2, 6, DT); } else if (b == 3) { if (nl <= 6) GOB(3, 6, DT); else GOB(3, 8, DT); } \
+                      else { if (nl <= 8) GOB(4, 8, DT); else GOB(4, 12, DT); } } while (0)
+        if (dot == 0) GOBD(0); else if (dot == 1) GOBD(1); else GOBD(2);
+#undef GOBD
+#undef GOB
+        return true;
+    }
     if (!P || !P->wdrec || !P->wstage || P->wd.len <= 0 || !g_team || (g_variant & 0x4000)) return false;
     constexpr int CH = 1;                            // chunks of 64 rows per wavefront
     const int rows = a.re - a.rb, wgs = (rows + 256 * CH - 1) / (256 * CH);
@@ -4104,7 +4390,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     if (a.rowpat && a.vrecw && (g_variant & ~0x4000) == 0 && launch_wide(a, nullptr)) return;      // wide records, x staged, the dominant pattern in scalar registers
     if (a.rowpat && a.vrecw && (g_variant & ~0x4000) == 0) {      // the rows' values ride in WIDE records (rows of up to 32 entries): one byte per row
         constexpr Geometry g = kGeom[G];
-        spmv_csr_valuerecw_kernel<g.block, 0><<<a.nb, g.block, 0, a.st>>>(
+        spmv_csr_valuerecw_kernel<g.block, 0><<<a.nb, g.block, (size_t)(a.npat1 - 1) * (sizeof(double) * PATW_LEN + sizeof(int) * PATW_OFF), a.st>>>(
             a.rowpat, a.vrecw, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0});
         return;
     }
@@ -4187,7 +4473,7 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
         return;
     }
     if (a.rowpat && a.vrecw && !(g_variant & 0x2000)) {
-        spmv_csr_valuerecw_kernel<g.block, DOT><<<a.nb, g.block, 0, a.st>>>(
+        spmv_csr_valuerecw_kernel<g.block, DOT><<<a.nb, g.block, (size_t)(a.npat1 - 1) * (sizeof(double) * PATW_LEN + sizeof(int) * PATW_OFF), a.st>>>(
             a.rowpat, a.vrecw, a.npat1 - 1, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
             w, partial, liship_internal_guard(), pstride);
         return;
@@ -4256,9 +4542,10 @@ int launch_csr(liship_csr_plan_t p, const LaunchArgs &a0)
 // switches in force?  Their launches have no per-row-block epilogue: the fused entry points below refuse (LISHIP_ERR_ARG) and the caller runs the product
 // and one reduction pass -- measured FASTER than the product followed by a pass that rebuilt the row blocks' partial sums (BiCGSTAB at 160^3 2290 against
 // 2125 it/s, profiles/r03_pattern_team_kernel.txt).
-static bool plan_runs_wide(const liship_csr_plan_s *p)      // the staged wide-record kernel: it has an epilogue of its own (one partial per workgroup of 256 rows)
+static bool plan_runs_wide(const liship_csr_plan_s *p, int rb, int re)      // the staged wide-record kernels: an epilogue of their own (one partial per workgroup of 256 rows / block rows)
 {
-    return p && p->rowpat && g_row_patterns && g_index_codes && g_team && !p->ptab8 && g_row_values && p->vrecw && p->wdrec && p->wstage && p->wd.len > 0 && g_variant == 0;
+    return p && p->rowpat && g_row_patterns && g_index_codes && g_team && !p->ptab8 && g_row_values && p->vrecw && g_variant == 0 &&
+           ((p->wdrec && p->wstage && p->wd.len > 0) || block_rows_serve(p, rb, re));
 }
 static bool plan_runs_teams(const liship_csr_plan_s *p)     // the four-lanes-per-row kernels (values streamed): no epilogue
 {
@@ -4277,7 +4564,10 @@ extern "C" long long liship_csr_plan_fused_slots(liship_csr_plan_t p)
 {
     if (!p) return 0;
     if (plan_runs_dom(p)) return ((long long)p->n + 511) / 512 + 3 * 16;                // a partial per workgroup (tile); every range ends in less than one group of tiles
-    if (plan_runs_wide(p)) return ((long long)p->n + 255) / 256 + 3;
+    if (plan_runs_wide(p, 0, p->n)) {                   // (block rows only: a range that cuts a block row runs the row blocks' kernel)
+        const long long wide = ((long long)p->n + 255) / 256 + 3, blocks = (long long)p->nblocks + 2;
+        return (p->wdrec && p->wd.len > 0) || wide > blocks ? wide : blocks;
+    }
     return (long long)p->nblocks + 2;
 }
 
@@ -4302,7 +4592,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x70006008) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    if (plan_runs_wide(p) && p->n > 0 && (size_t)((p->n + 255) / 256) <= slots) {       // wide records, x staged: a partial per workgroup of 256 rows
+    if (plan_runs_wide(p, 0, p->n) && p->n > 0 && (size_t)((p->n + 255) / 256) <= slots) {       // wide records, x staged: a partial per workgroup of 256 rows
         LaunchArgs aw{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), p->codes, p->dict, nullptr, nullptr, nullptr, p->first_term ? -0.0 : 0.0, p->rowpat, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, nullptr, nullptr, nullptr, p->vrecw};
         aw.plan = p;
         int wgs = 0;
@@ -4371,12 +4661,12 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if ((g_variant & ~0x70006008) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     *slots_used = 0;
     if (row_begin >= row_end || p->nblocks == 0) return 0;
-    if (plan_runs_wide(p)) {                           // wide records, x staged: a partial per workgroup of 256 rows of the range
-        const int wgs = (row_end - row_begin + 255) / 256;
+    if (plan_runs_wide(p, row_begin, row_end)) {       // wide records, x staged: a partial per workgroup of 256 rows (block rows) of the range
+        int wgs = (row_end - row_begin + 255) / 256;
         if ((size_t)slot_base + (size_t)wgs > slots) return LISHIP_ERR_ARG;
         LaunchArgs aw{ptr, idx, val, x, y, p->blk, 0, p->nblocks, row_begin, row_end, (int)p->nnz, as_stream(stream), p->codes, p->dict, nullptr, nullptr, nullptr, p->first_term ? -0.0 : 0.0, p->rowpat, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, nullptr, nullptr, nullptr, p->vrecw};
         aw.plan = p;
-        launch_wide(aw, liship_internal_guard(), want_sumsq ? 2 : 1, w, static_cast<double *>(work) + slot_base, (int)slots);
+        launch_wide(aw, liship_internal_guard(), want_sumsq ? 2 : 1, w, static_cast<double *>(work) + slot_base, (int)slots, &wgs);
         LAUNCH_CHECK();
         *slots_used = wgs;
         return 0;

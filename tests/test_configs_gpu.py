@@ -357,9 +357,9 @@ def test_bsr_row_form_for_constant_coefficients(lib, bs, where):
                 v[idx == rows] += rng.uniform(0.0, 1.0, n)
             A = lisdrv.make_csr(lib, ptr, idx, v)
             B = lisdrv.convert(lib, A, "bsr", bs, bs)
-            # 2 x 2: 54 row patterns (27 boundary cases x the row's place in its block) fit the 64 wide value records; 3 x 3 / 4 x 4 have 81 / 108: native blocks
+            # 27 boundary cases x the row's place in its block: 54 / 81 / 108 row patterns, all within the 128 wide value records
             taken = ft(B) == capi.LIS_MATRIX_CSR
-            assert taken == (constant and bs == 2), (bs, constant, ft(B))
+            assert taken == constant, (bs, constant, ft(B))
             assert (fn(B) > 0) == taken
             arrs = lisdrv.matrix_arrays(B)          # (the host arrays of a device-converted matrix come home here: the native blocks, whatever the HBM copy runs on)
             for x in xs:
@@ -387,27 +387,40 @@ def test_bsr_row_form_for_constant_coefficients(lib, bs, where):
         lib.dll.lis_amd_set_residency(0)
 
 
-def test_bsr_row_form_stages_x_for_the_patterns_its_rows_take_turns_on(lib):
-    """from 2^19 rows on, the row form of a 2 x 2 blocked stencil runs the staged value-record kernel on a virtual dominant pattern (a common supersequence of the
-    even rows' and the odd rows' patterns, blocks in lis_matrix_convert_csr2bsr's first-seen order): 256^3 0.34 -> 0.15 ms.  The reference's bits (lis_matvec_bsr.c:293-343)."""
-    G = 82                                           # 82^3 = 551,368 rows
-    ptr, idx, val = orc.poisson3d(G, G, G, sort_cols=True)
+@pytest.mark.parametrize("bs,G", [(2, 82), (3, 60), (4, 60)])
+def test_bsr_row_form_gives_a_lane_a_block_row(lib, bs, G):
+    """from 2^17 rows on, the row form of a b x b blocked stencil gives a LANE a block row (spmv_csr_blockrows_staged_kernel: each x read once from the staged window
+    for the block row's b sums; 256^3: 2 x 2 0.34 -> 0.087 ms, 3 x 3 at 255^3 0.61 -> 0.106, 4 x 4 0.69 -> 0.142); from 2^19 rows on the row-by-row kernel it falls
+    back to also stages x, for a virtual dominant pattern (a common supersequence of the even rows' and the odd rows' patterns, blocks in lis_matrix_convert_csr2bsr's
+    first-seen order).  Every form: the reference's bits (lis_matvec_bsr.c:293-343), Inf / NaN through the explicit zeros included."""
+    ptr, idx, val = orc.poisson3d(G, G, G, sort_cols=True)      # 82^3 = 551,368 rows; 60^3 = 216,000
     n = len(ptr) - 1
-    fw = lib.dll.lis_amd_matrix_wide_dominant
-    fw.argtypes = [capi.PM]
+    fw, fb = lib.dll.lis_amd_matrix_wide_dominant, lib.dll.lis_amd_matrix_block_rows
+    fw.argtypes = [capi.PM]; fb.argtypes = [capi.PM]
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, n)
     x[[3, n // 2, n - 2]] = [np.inf, np.nan, -0.0]
     lib.dll.lis_amd_set_residency(1)
     try:
-        B = lisdrv.convert(lib, lisdrv.make_csr(lib, ptr, idx, val), "bsr", 2, 2)
-        assert fw(B) == 1
+        B = lisdrv.convert(lib, lisdrv.make_csr(lib, ptr, idx, val), "bsr", bs, bs)
+        assert fb(B) == bs and (fw(B) == 1 or bs > 2)
         got = lisdrv.matvec(lib, B, x)
         arrs = lisdrv.matrix_arrays(B)
-        want = orc.spmv_bsr(n, arrs["nr"], 2, 2, arrs["bptr"], arrs["bindex"], arrs["value"], x)
+        want = orc.spmv_bsr(n, arrs["nr"], bs, bs, arrs["bptr"], arrs["bindex"], arrs["value"], x)
         assert np.array_equal(np.isnan(got), np.isnan(want))
         assert np.array_equal(got[~np.isnan(got)].view(np.uint64), want[~np.isnan(want)].view(np.uint64))
+        lib.liship_spmv_csr_set_block_rows(0)        # the row-by-row kernels on the same plan
+        try:
+            again = lisdrv.matvec(lib, B, x)
+        finally:
+            lib.liship_spmv_csr_set_block_rows(1)
+        assert np.array_equal(np.isnan(again), np.isnan(want))
+        assert np.array_equal(again[~np.isnan(again)].view(np.uint64), want[~np.isnan(want)].view(np.uint64))
         out = lisdrv.solve(lib, B, orc.spmv_csr(ptr, idx, val, np.ones(n)), "-i cg -p jacobi -tol 1e-12 -maxiter 400")
+        assert out["status"] == 0 and out["resid"] <= 1e-12
+        ref = lisdrv.solve(lib, lisdrv.make_csr(lib, ptr, idx, val), orc.spmv_csr(ptr, idx, val, np.ones(n)), "-i cg -p jacobi -tol 1e-12 -maxiter 400")
+        assert abs(out["iter"] - ref["iter"]) <= 1  # (the fused dots of the two kernels fold their partial sums in different trees)
+        out = lisdrv.solve(lib, B, orc.spmv_csr(ptr, idx, val, np.ones(n)), "-i bicgstab -p none -tol 1e-12 -maxiter 400")
         assert out["status"] == 0 and out["resid"] <= 1e-12
         lib.lis_matrix_destroy(B)
     finally:

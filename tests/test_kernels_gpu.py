@@ -1773,7 +1773,7 @@ def _blocked_rows(ptr, idx, val, bs, first_seen=True):
     return rptr.astype(np.int32), ridx, rval
 
 
-@pytest.mark.parametrize("case", ["p3d_2x2", "p2d_2x2", "p3d_2x2_long", "p3d_2x2_sorted", "p3d_3x3"])
+@pytest.mark.parametrize("case", ["p3d_2x2", "p2d_2x2", "p3d_2x2_long", "p3d_2x2_sorted", "p3d_3x3", "p3d_4x4"])
 def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(lib, case):
     """the row form of a b x b blocked stencil has b interior patterns that take turns, none with half of the rows: the plan stages x for the UNION of the most
     frequent ones and every row is a mask over it with the union's values in scalar registers (build_wide_dominant).  Bits of the plain loop over the listed
@@ -1782,7 +1782,8 @@ def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(l
         ptr, idx, val = orc.poisson3d(1, 48, 64, sort_cols=True)
     else:
         ptr, idx, val = orc.poisson3d(*((6, 6, 128) if case == "p3d_2x2_long" else (24, 24, 24)), sort_cols=True)
-    rptr, ridx, rval = _blocked_rows(ptr, idx, val, 3 if case == "p3d_3x3" else 2, first_seen=case != "p3d_2x2_sorted")
+    bs = 3 if case == "p3d_3x3" else 4 if case == "p3d_4x4" else 2
+    rptr, ridx, rval = _blocked_rows(ptr, idx, val, bs, first_seen=case != "p3d_2x2_sorted")
     n = len(rptr) - 1
     rng = np.random.default_rng(77)
     x = rng.uniform(-1, 1, n)
@@ -1804,12 +1805,12 @@ def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(l
             check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
             check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
             check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
-            if case == "p3d_3x3":                          # 81 patterns: more than the wide value records hold; the blocks stay native in the library (test_configs_gpu.py)
-                assert lib.liship_csr_plan_value_records(plan) == 0
-                check(lib.liship_csr_plan_destroy(plan))
-                return
             assert lib.liship_csr_plan_value_records(plan) == 2
             taken.append(lib.liship_csr_plan_wide_dominant(plan))
+            if union == 0:                                  # ... and a lane per block row on top of the same records: switched on for the second plan, so that
+                lib.liship_spmv_csr_set_block_rows(2)       # both the row-by-row kernels and this one are checked (2: at any size)
+                check(lib.liship_csr_plan_encode_block_rows(plan, bs, dptr.ptr, None))
+                assert lib.liship_csr_plan_block_rows(plan) == (0 if case == "p3d_2x2_long" else bs)      # (the 6 x 6 x 128 bar: no block row pattern with half of them)
             for variant in (0, 0x4000):
                 lib.liship_spmv_csr_set_variant(variant)
                 dy = DA.from_host(np.full(n, 7.0), np.float64)
@@ -1817,12 +1818,14 @@ def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(l
                 y = dy.to_host()
                 assert np.array_equal(np.isnan(y), nanpos), (union, hex(variant))
                 assert np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), (union, hex(variant))
-                dy = DA.from_host(np.full(n, 7.0), np.float64)
-                a, b = n // 3 + 1, n - n // 5 - 3
-                for lo, hi in ((a, b), (0, a), (b, n)):
-                    check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
-                y = dy.to_host()
-                assert np.array_equal(np.isnan(y), nanpos) and np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), (union, "rows", hex(variant))
+                for cut in (1, bs):                         # row ranges that cut block rows (the row-by-row kernels serve), and ranges of whole block rows
+                    dy = DA.from_host(np.full(n, 7.0), np.float64)
+                    a, b = n // 3 + 1, n - n // 5 - 3
+                    a, b = a - a % cut, b - b % cut
+                    for lo, hi in ((a, b), (0, a), (b, n)):
+                        check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+                    y = dy.to_host()
+                    assert np.array_equal(np.isnan(y), nanpos) and np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), (union, "rows", cut, hex(variant))
             lib.liship_spmv_csr_set_variant(0)
             # the fused dots on finite data: y the same bits, the sums to rounding
             xf = np.where(np.isfinite(x), x, 0.5)
@@ -1836,5 +1839,6 @@ def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(l
             check(lib.liship_csr_plan_destroy(plan))
     finally:
         lib.liship_spmv_csr_set_wide_union(1)
+        lib.liship_spmv_csr_set_block_rows(1)
         lib.liship_spmv_csr_set_variant(0)
-    assert taken == [1, 0], taken
+    assert taken[1] == 0 and (taken[0] == 1 or bs > 2), taken      # (3 x 3, 4 x 4: the rows' turns have no common supersequence of 32 entries; their block rows do not need one)

@@ -115,6 +115,11 @@ int  liship_spmv_csr_set_team(int on);           /* A/B switch: 0 = the one-lane
 int  liship_csr_plan_encode_block_rows(liship_csr_plan_t plan, int b, const int *ptr, void *stream);
 int  liship_csr_plan_block_rows(liship_csr_plan_t plan);       /* b when the plan keeps them, else 0 */
 int  liship_spmv_csr_set_block_rows(int on);                   /* A/B switch: 0 = the row-by-row kernels (same bits) */
+/* The z-marching form of the dominant-pattern product (7-point stencil with value records, grid lines a multiple of 128 long): 1 = on (default), 0 = the gathering kernel,
+ * 3 = on, but with the faces' masks even where plan time found the grid a box (liship_csr_plan_box_planes: planes in which a slot is missing exactly where its neighbour
+ * lies outside the grid -- there the kernel reads no pattern byte at all).  Same bits in every form. */
+int  liship_spmv_csr_set_dom_march(int on);
+int  liship_csr_plan_box_planes(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_wide_union(int on);     /* plan-time A/B switch: 0 = no virtual dominant pattern (a common supersequence of the patterns rows take turns on: b x b blocked stencils), 1 = from 2^19 rows on (default), 2 = at any size */
 /* Value records (setup-time, optional, after liship_csr_plan_encode_row_patterns; never an error when the matrix does not
  * qualify): when the plan has 32 B pattern records and every row of a pattern carries the same values bit for bit -- a

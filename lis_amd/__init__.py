@@ -80,6 +80,8 @@ _LISHIP = {
     "liship_csr_plan_wide_dominant": (_ci, [_vp]),
     "liship_spmv_csr_set_team": (_ci, [_ci]),
     "liship_spmv_csr_set_wide_union": (_ci, [_ci]),
+    "liship_spmv_csr_set_dom_march": (_ci, [_ci]),
+    "liship_csr_plan_box_planes": (_ci, [_vp]),
     "liship_csr_plan_encode_block_rows": (_ci, [_vp, _ci, _vp, _vp]),
     "liship_csr_plan_block_rows": (_ci, [_vp]),
     "liship_spmv_csr_set_block_rows": (_ci, [_ci]),

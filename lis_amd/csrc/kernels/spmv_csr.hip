@@ -80,6 +80,7 @@ int g_local_rpos = 1;            // liship_spmv_csr_set_local_register_positions
 int g_uniform_rows = 1;          // liship_spmv_csr_set_uniform_rows: 0 keeps the row sums of the block-local kernel on the skewed schedule everywhere (A/B)
 int g_long_row_tree_host = 0;    // host mirror of d_long_row_tree (liship_spmv_csr_switches)
 int g_row_block_dots = 0;        // liship_spmv_csr_set_row_block_dots: 1 keeps the fused dots of the dominant-pattern product on the row blocks' partial sums (the bits every other form gives)
+int g_dom_march = 1;             // liship_spmv_csr_set_dom_march: 0 keeps 7-point plans with value records on the gathering dominant-pattern kernel (A/B)
 int g_block_rows = 1;            // liship_spmv_csr_set_block_rows: 0 keeps plans with block rows (liship_csr_plan_encode_block_rows) on the row-by-row kernels (A/B); 2: plans of any size take them (tests)
 int g_wide_union = 1;            // liship_spmv_csr_set_wide_union: 0 keeps plans whose rows take turns on several patterns off the staged value-record kernel (plan time, A/B)
 int g_team = 1;                  // liship_spmv_csr_set_team: 0 keeps patterned rows of 8..32 entries on the one-lane-per-row pattern kernel
@@ -1929,6 +1930,234 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
         workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, chunk, pstride ? pstride : total, chunk < total);      // workgroups spill: 0.9 ms)
 }
 
+// Z-MARCHING form of the dominant-pattern product (round 4) for the 7-point stencil on a grid whose lines are a multiple of 128 long: offsets exactly
+// {-SO, -S, -1, 0, +1, +S, +SO} in ascending slot order (S: a grid line, SO: a plane).  The kernel above reads every x seven times through L1 (seven 16 B loads per lane
+// pair; counters: TA busy 97 %, ~89 requests in flight per CU -- latency / issue bound at 0.58 of the roofline).  Here a workgroup owns a tile of 128 columns x TY
+// lines of a plane and WALKS `zseg` planes: a plane's tile (+ one halo line above and below, one halo column left and right) is loaded ONCE by coalesced 16 B loads
+// issued D planes ahead and parked in registers, written to one of two LDS buffers, and the row sums take -1 / 0 / +1 / -S / +S from LDS and -SO / +SO from the
+// registers of the plane before and the plane after: 1.3 loads of 16 B per lane pair and plane instead of seven, one barrier per plane.  512^3: 0.49 -> 0.41 ms
+// (0.58 -> 0.70 of 8 TB/s on the 17 B per row).  Same terms in the same order: rows on other patterns take their masks and values by the waterfall above (-0.0 terms),
+// foreign rows their own records, ELL's padding terms as above -- y is the reference's, bit for bit.  Speculative addresses (the planes before the first and after the
+// last, the halo of the grid's faces) are clamped into x[0, nx); their values only ever meet masked slots.
+struct DomMarch { int S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, wgs, xcd, perm, order, planes; };      // planes [z0, z1) of the grid (whole planes of the launch's row range); perm: 3 bits per slot, which neighbour it is (0: -SO, 1: -S, 2: -1, 3: 0, 4: +1, 5: +S, 6: +SO)
+// masks of the rows' patterns over the dominant one's slots, by scalar loads, one round per distinct pattern among the lanes that `need` one (the first double of a
+// pattern's record: spmv_csr_valuerec_march_kernel's short form, whose plan has no other kind of pattern)
+__device__ __forceinline__ unsigned dom_masks_only(const double *__restrict__ drec, const DomRec &D, int pt, bool need, unsigned m)
+{
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(need);
+    while (todo != 0) {                                   // (uniform)
+        const int q = __builtin_amdgcn_readlane(pt, __builtin_ctzll(todo));
+        const unsigned mq = q == D.pat ? (unsigned)D.mask : (unsigned)__double2loint(drec[8 * q]);      // (uniform address: one scalar load)
+        const bool me = need && pt == q;
+        m = me ? mq : m;
+        todo &= ~__builtin_amdgcn_ballot_w64(me);
+    }
+    return m;
+}
+
+// ORD: the slot order -- 0 ascending columns, 1 the reference's generators' (-SO, +SO, -S, +S, -1, +1, 0: lis's test drivers), 2 any (M.perm).  WS: w is a vector of its
+// own (else the diagonal's pair).  GEN: the plan has patterns that are more than a mask (values of their own, foreign patterns, ELL's padding terms): the waterfall of
+// the gathering kernel, every plane; else (the Poisson matrix: the faces' patterns are masks) a lane keeps its rows' masks from plane to plane and asks only when a
+// pattern byte changes (the first and last planes).
+// BOX: plan time has checked, row by row, that in the planes of this launch a slot is missing exactly where its neighbour lies outside the grid (dom_box_check) and
+// that the faces' rows carry the dominant pattern's values: then no pattern byte is read at all, and instead of masks the halo cells that only masked slots ever read
+// (the column left of the grid's first, the line above its first line, the plane before its first plane ... and their opposites) hold a ZERO whose sign makes the product
+// with the slot's value -0.0, the term every masked slot adds: the sums run the unmasked code everywhere.  16 B per row: x once, y once.
+template <int LPW, int D_, int DOT, bool WS, int ORD, bool GEN, bool BOX = false>
+__global__ __launch_bounds__(256)
+void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, const double *__restrict__ drec,
+                                    const DomRec D, const double *__restrict__ x, double *__restrict__ y, double acc0, const DomMarch M, int nx,
+                                    const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                                    const double *__restrict__ guard = nullptr, int pstride = 0)
+{
+    constexpr int BLOCK = 256, TX = 128, TY = 4 * LPW, LX = TX + 4;      // an LDS line: [pad][left halo][TX columns][right halo][pad]: a lane's pair at 2 + 2 lane, 16 B aligned
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;      // device-driven Krylov loop already converged (nothing has been written)
+    __shared__ __attribute__((aligned(16))) double buf[2][(TY + 2) * LX];
+    __shared__ double dot_part[(DOT >= 2 ? 2 : 1) * (DOT != 0 ? BLOCK : 1)];
+    __shared__ unsigned dot_count;
+    const int tid = (int)threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & (WAVE - 1);
+    if (DOT != 0 && tid == 0) dot_count = 0u;                         // (a barrier follows before anyone counts itself in)
+    int wg = (int)blockIdx.x;
+    const int ntile = M.tiles_x * M.tiles_y;
+    if (M.xcd) { const int k = wg % NUM_XCD, j = wg / NUM_XCD; wg = k * (M.wgs / NUM_XCD) + j; }      // each XCD a contiguous eighth of the (segment, tile) list: its L2 holds the halo lines neighbouring tiles share
+    const int seg = wg / ntile, t = wg - seg * ntile;
+    const int ty = t / M.tiles_x, tx = t - ty * M.tiles_x;
+    const int za = M.z0 + seg * M.zseg, zb = min(M.z1, za + M.zseg);
+    const int col0 = tx * TX, line0 = ty * TY;
+    const long long S = M.S, SO = M.SO;
+    const long long base = (long long)(line0 + w * LPW) * S + col0 + 2 * lane;      // this lane's first pair inside a plane; its LPW pairs are S apart
+    auto at = [&](long long a) { return (int)(a < 0 ? 0 : (a > (long long)nx - 2 ? (long long)nx - 2 : a)); };      // (pairs: the last start is nx - 2)
+    // (BOX) the zero that a masked slot's x is replaced by: its product with the slot's value must be -0.0, so it carries the opposite of the value's sign
+    auto poison = [&](int kind) {
+        double v = 0.0;
+#pragma unroll
+        for (int u = 0; u < 7; u++) if ((int)((M.perm >> (3 * u)) & 7) == kind) v = D.val[u];
+        return __builtin_signbit(v) ? 0.0 : -0.0;
+    };
+    const int lines = (int)(SO / S), planes_all = M.planes;
+    const bool box_left = BOX && tx == 0, box_right = BOX && tx == M.tiles_x - 1, box_top = BOX && ty == 0, box_bottom = BOX && ty == M.tiles_y - 1;      // (uniform)
+    (void)lines;
+    struct Packet { v2f64 own[LPW]; v2f64 hy; double hx[LPW]; v2f64 ww[WS ? LPW : 1]; unsigned short pat[LPW]; };
+    auto load_packet = [&](Packet &P, int z, bool pats) {
+        const long long pb = (long long)z * SO + base;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + at(pb + i * S));
+        if (w == 0) P.hy = *reinterpret_cast<const v2f64u *>(x + at((long long)z * SO + (long long)(line0 - 1) * S + col0 + 2 * lane));
+        if (w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at((long long)z * SO + (long long)(line0 + TY) * S + col0 + 2 * lane));
+        if (lane == 0 || lane == WAVE - 1) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) P.hx[i] = x[at((long long)z * SO + (long long)(line0 + w * LPW + i) * S + (lane == 0 ? col0 - 1 : col0 + TX))];
+        }
+        if (pats && z < M.z1) {                                       // (uniform) the pattern bytes (and w, when it is a vector of its own) of the rows this plane's sums are for
+            if (!BOX) {
+#pragma unroll
+                for (int i = 0; i < LPW; i++) P.pat[i] = *reinterpret_cast<const unsigned short *>(rowpat + pb + i * S);
+            }
+            if (DOT != 0 && WS) {
+#pragma unroll
+                for (int i = 0; i < LPW; i++) P.ww[i] = *reinterpret_cast<const v2f64u *>(wdot + pb + i * S);
+            }
+        }
+    };
+    auto store_packet = [&](const Packet &P, double *B) {
+#pragma unroll
+        for (int i = 0; i < LPW; i++) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = P.own[i];
+        if (w == 0) { v2f64 h = P.hy; if (box_top) { h.x = h.y = poison(1); } *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = h; }
+        if (w == 3) { v2f64 h = P.hy; if (box_bottom) { h.x = h.y = poison(5); } *reinterpret_cast<v2f64 *>(B + (TY + 1) * LX + 2 + 2 * lane) = h; }
+        if (lane == 0 || lane == WAVE - 1) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) {
+                double h = P.hx[i];
+                if (box_left && lane == 0) h = poison(2);
+                if (box_right && lane == WAVE - 1) h = poison(4);
+                B[(w * LPW + i + 1) * LX + (lane == 0 ? 1 : 2 + TX)] = h;
+            }
+        }
+    };
+    Packet Q[D_];
+    v2f64 prev[LPW];
+    unsigned short pat0[LPW];
+    v2f64 ww0[WS ? LPW : 1];
+    unsigned patc[LPW], mc[LPW];                                      // (short form) the pattern bytes a lane last asked about and its rows' masks, first row | second row << 8
+#pragma unroll
+    for (int i = 0; i < LPW; i++) { patc[i] = (unsigned)D.pat | ((unsigned)D.pat << 8); mc[i] = (unsigned)D.mask | ((unsigned)D.mask << 8); }
+    {   // prologue: plane za - 1 (registers only), plane za (LDS + its pattern bytes), planes za + 1 .. za + D in flight
+        Packet P;
+        load_packet(P, za - 1, false);
+#pragma unroll
+        for (int i = 0; i < LPW; i++) { prev[i] = P.own[i]; if (BOX && za == 0) { prev[i].x = prev[i].y = poison(0); } }      // (uniform) the grid's first plane has no plane before it
+        load_packet(P, za, true);
+        store_packet(P, buf[za & 1]);
+#pragma unroll
+        for (int i = 0; i < LPW; i++) pat0[i] = BOX ? (unsigned short)0 : P.pat[i];
+        if (WS) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) ww0[i] = P.ww[i];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D_; d++) load_packet(Q[d], za + 1 + d, true);
+    __syncthreads();
+    double c0 = 0.0, c1 = 0.0;
+    for (int zq = za; zq < zb; zq += D_) {
+#pragma unroll
+        for (int d = 0; d < D_; d++) {
+            const int z = zq + d;
+            if (z < zb) {                                             // (uniform)
+                Packet &P = Q[d];                                     // plane z + 1: the oldest in flight
+                store_packet(P, buf[(z + 1) & 1]);
+                const double *B = buf[z & 1];
+#pragma unroll
+                for (int i = 0; i < LPW; i++) {
+                    const int li = (w * LPW + i + 1) * LX + 2 + 2 * lane;
+                    const v2f64 c = *reinterpret_cast<const v2f64 *>(B + li);
+                    const double l = B[li - 1], r = B[li + 2];
+                    const v2f64 up = *reinterpret_cast<const v2f64 *>(B + li - LX), dn = *reinterpret_cast<const v2f64 *>(B + li + LX);
+                    v2f64 xl, xr, xx[7], nxt = P.own[i];
+                    xl.x = l; xl.y = c.x; xr.x = c.y; xr.y = r;
+                    if (BOX && z == planes_all - 1) { nxt.x = nxt.y = poison(6); }      // (uniform) the grid's last plane has no plane behind it
+                    if (ORD == 0) { xx[0] = prev[i]; xx[1] = up; xx[2] = xl; xx[3] = c; xx[4] = xr; xx[5] = dn; xx[6] = nxt; }
+                    else if (ORD == 1) { xx[0] = prev[i]; xx[1] = nxt; xx[2] = up; xx[3] = dn; xx[4] = xl; xx[5] = xr; xx[6] = c; }
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 7; u++)
+                            switch ((M.perm >> (3 * u)) & 7) {      // (uniform)
+                            case 0: xx[u] = prev[i]; break;
+                            case 1: xx[u] = up; break;
+                            case 2: xx[u] = xl; break;
+                            case 3: xx[u] = c; break;
+                            case 4: xx[u] = xr; break;
+                            case 5: xx[u] = dn; break;
+                            default: xx[u] = nxt; break;
+                            }
+                    }
+                    const long long row = (long long)z * SO + base + i * S;
+                    const int ra = (int)row;
+                    const int pa = (int)(pat0[i] & 255u), pb = (int)(pat0[i] >> 8);
+                    double s0 = acc0, s1 = acc0;
+                    if (BOX) {
+#pragma unroll
+                        for (int u = 0; u < 7; u++) { s0 += D.val[u] * xx[u].x; s1 += D.val[u] * xx[u].y; }
+                    } else if (!GEN) {
+                        if (__builtin_amdgcn_ballot_w64((unsigned)pat0[i] != patc[i]) != 0) {      // (uniform) a pattern byte changed since the last plane: ask again
+                            unsigned ma = dom_masks_only(drec, D, pa, pa != (int)(patc[i] & 255u), mc[i] & 255u);
+                            unsigned mb = dom_masks_only(drec, D, pb, pb != (int)(patc[i] >> 8), mc[i] >> 8);
+                            mc[i] = (ma & 255u) | ((mb & 255u) << 8);
+                            patc[i] = pat0[i];
+                        }
+                        const unsigned full = (unsigned)D.mask | ((unsigned)D.mask << 8);
+                        if ((M.order & 0x100) || __builtin_amdgcn_ballot_w64(mc[i] != full) == 0) {      // (uniform) every row here has all of the dominant pattern's slots
+#pragma unroll
+                            for (int u = 0; u < 7; u++) { s0 += D.val[u] * xx[u].x; s1 += D.val[u] * xx[u].y; }
+                        } else {
+                            const unsigned m = mc[i];
+#pragma unroll
+                            for (int u = 0; u < 7; u++) {
+                                const double t0 = D.val[u] * xx[u].x, t1 = D.val[u] * xx[u].y;
+                                s0 += ((m >> u) & 1u) ? t0 : -0.0;              // -0.0 terms leave any sum bit-unchanged
+                                s1 += ((m >> (8 + u)) & 1u) ? t1 : -0.0;
+                            }
+                        }
+                    } else if (__builtin_amdgcn_ballot_w64(pa != D.pat || pb != D.pat) == 0) {      // (uniform) every row here is the dominant pattern
+#pragma unroll
+                        for (int u = 0; u < 7; u++) { s0 += D.val[u] * xx[u].x; s1 += D.val[u] * xx[u].y; }
+                    } else {
+                        double v[7];
+                        unsigned m;
+                        dom_waterfall(drec, D, pa, true, v, m);
+                        if (m & 0x80u) s0 = own_record_row(rec, pa, ra, x, acc0);
+                        else {
+#pragma unroll
+                            for (int u = 0; u < 7; u++) { const double tt = v[u] * xx[u].x; s0 += ((m >> u) & 1u) ? tt : -0.0; }
+                            s0 = dom_pad_terms(s0, m, x, ra);
+                        }
+                        dom_waterfall(drec, D, pb, true, v, m);
+                        if (m & 0x80u) s1 = own_record_row(rec, pb, ra + 1, x, acc0);
+                        else {
+#pragma unroll
+                            for (int u = 0; u < 7; u++) { const double tt = v[u] * xx[u].y; s1 += ((m >> u) & 1u) ? tt : -0.0; }
+                            s1 = dom_pad_terms(s1, m, x, ra + 1);
+                        }
+                    }
+                    v2f64 out; out.x = s0; out.y = s1;
+                    store_stream(reinterpret_cast<v2f64 *>(y + row), out);
+                    if (DOT != 0) {
+                        const v2f64 wv = WS ? ww0[i] : c;
+                        c0 += wv.x * s0; c0 += wv.y * s1;
+                        if (DOT >= 2) { c1 += s0 * s0; c1 += s1 * s1; }
+                    }
+                    prev[i] = c;
+                    if (!BOX) pat0[i] = P.pat[i];
+                    if (WS) ww0[i] = P.ww[i];
+                }
+                load_packet(Q[d], z + 1 + D_, true);                  // this slot's next plane
+                __syncthreads();                                      // plane z + 1 is in LDS, plane z's buffer is free
+            }
+        }
+    }
+    if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : M.wgs, true);
+}
+
 // The same with the fused dots.  Partial slots and the order of every addition are those of spmv_csr_valuerec_pair_dot_kernel
 // (below: two row blocks per workgroup, virtual lanes 2p and 2p + 1 in two accumulators, the one-row kernels' tree walked on
 // them), so the dots are the same bits; what changes is the chain in front: block extents (one scalar load) -> pattern bytes, w
@@ -2957,6 +3186,9 @@ struct liship_csr_plan_s {
     double *drec;        // device: with vrec, when one pattern dominates: per pattern 8 doubles {slots of the dominant pattern it has (mask; bit 7: not a
                          // subsequence), its values in those slots}; else NULL (spmv_csr_valuerec_dom_kernel)
     DomRec dom;          // the dominant pattern: byte offsets, values, pattern byte, slots
+    int dom_xlen;        // 1 + the largest column the rows read (>= n; ghost columns in a multi-rank job): the marching kernel clamps its speculative loads into x[0, dom_xlen)
+    int box_z0, box_z1;  // planes [box_z0, box_z1) of the 7-point grid in which a slot is missing exactly where its neighbour lies outside the grid (dom_box_check): the marching kernel's BOX form
+    int dom_simple;      // 1: every pattern is the dominant one's slots under a mask with the dominant one's VALUES (no foreign pattern, no padding terms): the marching kernel's short form
     int dom_lo, dom_hi;  // rows [dom_lo, dom_hi - 128] may start a wavefront that gathers x at the dominant offsets without leaving x[0, n)
 };
 
@@ -3066,7 +3298,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
     p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->bd.len = 0; p->bdrec = nullptr; p->bstage = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
-    p->drec = nullptr; p->dom_lo = p->dom_hi = 0;
+    p->drec = nullptr; p->dom_lo = p->dom_hi = 0; p->dom_simple = 0; p->box_z0 = p->box_z1 = 0; p->dom_xlen = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -3435,6 +3667,56 @@ __global__ void rowpat_histogram(int n, const unsigned char *__restrict__ rowpat
     for (int t = threadIdx.x; t < 256; t += blockDim.x) if (h[t]) atomicAdd(&count[t], (unsigned long long)h[t]);
 }
 
+// the 7-point stencil?  S, SO: the strides of the middle and the outer pair of offsets; perm: 3 bits per slot, which neighbour it is (0: -SO, 1: -S, 2: -1, 3: 0, 4: +1, 5: +S, 6: +SO)
+static bool dom_seven_point(const DomRec &D, int &S, int &SO, int &perm)
+{
+    if (D.mask != 0x7f) return false;
+    S = 0; SO = 0;
+    for (int u = 0; u < 7; u++) {                              // (dom_stride / dom_stride_outer, defined further down: the smallest and the largest offset beyond +-1 present on both sides)
+        const int e = D.off[u] / 8;
+        bool both = false;
+        for (int v = 0; v < 7; v++) both = both || D.off[v] == -8 * e;
+        if (e > 1 && both) { if (S == 0 || e < S) S = e; if (e > SO) SO = e; }
+    }
+    if (S <= 1 || SO <= S) return false;
+    perm = 0;
+    int seen = 0;
+    for (int u = 0; u < 7; u++) {
+        const int e = D.off[u] / 8;
+        const int k = e == -SO ? 0 : e == -S ? 1 : e == -1 ? 2 : e == 0 ? 3 : e == 1 ? 4 : e == S ? 5 : e == SO ? 6 : -1;
+        if (k < 0 || D.off[u] % 8 != 0) return false;
+        perm |= k << (3 * u); seen |= 1 << k;
+    }
+    return seen == 0x7f;
+}
+// plan time: the largest column any row reads (by its pattern's largest offset): the x entries a speculative load may touch are [0, that] -- in a multi-rank job
+// beyond the rows (ghost columns)
+__global__ void dom_max_column(int n, const unsigned char *__restrict__ rowpat, const int *__restrict__ maxoff, int *__restrict__ out)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (r < n) c = (int)r + maxoff[rowpat[r]];
+    for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o));
+    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(out, c);
+}
+// plan time: in which planes of the grid is every row's pattern the dominant one under the mask its place in the grid dictates (a slot is missing exactly where the
+// neighbour lies outside the grid)?  bad[z] != 0: some row of plane z is not.
+__global__ void dom_box_check(int n, int S, int SO, int perm, int dpat, const unsigned char *__restrict__ rowpat, const double *__restrict__ drec, int *__restrict__ bad)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int z = (int)(r / SO), rem = (int)(r - (long long)z * SO), yy = rem / S, xx = rem - yy * S, lines = SO / S, planes = n / SO;
+    const int pat = rowpat[r];
+    const unsigned m = (unsigned)__double2loint(drec[8 * pat]);      // slots | foreign 0x80 | padding terms (bits 8-10) | bit 11: the dominant pattern's values in the slots it keeps
+    unsigned e = 0;
+    for (int u = 0; u < 7; u++) {
+        const int k = (perm >> (3 * u)) & 7;
+        const bool present = k == 0 ? z > 0 : k == 1 ? yy > 0 : k == 2 ? xx > 0 : k == 3 ? true : k == 4 ? xx < S - 1 : k == 5 ? yy < lines - 1 : z < planes - 1;
+        e |= (present ? 1u : 0u) << u;
+    }
+    if (m != (e | 0x800u)) bad[z] = 1;
+}
+
 // The dominant pattern of a plan with value records and the other patterns' records in ITS slots (spmv_csr_valuerec_dom_kernel).
 // rec32: 8 ints per pattern (7 byte offsets, the tail repeating the last one; length), val8: 8 doubles per pattern.  Kept when
 // one pattern carries at least half of the rows; never an error when it does not.
@@ -3459,6 +3741,7 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
     D.pat = dom; D.mask = (1 << lend) - 1; D.d0 = -1;
     for (int u = 0; u < lend; u++) if (od[u] == 0) D.d0 = u;
     const int d0 = D.d0;
+    bool simple = true;
     double img[PAT7_MAX * 8];
     for (int i = 0; i < npat; i++) {
         const int *oi = rec32 + 8 * i;
@@ -3475,9 +3758,14 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
             if (pads) { mask |= (unsigned)(leni - j) << 8; j = leni; }
         }
         if (j != leni) mask = 0x80u;                      // not a subsequence of the dominant pattern: its rows take their own records
+        bool same = val8 != nullptr && mask < 0x80u;      // ... a plain mask whose kept slots carry the dominant pattern's values, bit for bit
+        for (int sl = 0; sl < lend && same; sl++) if ((mask >> sl) & 1u) same = memcmp(&out[1 + sl], &D.val[sl], 8) == 0;
+        simple = simple && same;
+        if (same) mask |= 0x800u;                         // (bit 11: dom_box_check asks for it row by row)
         unsigned long long bits = mask;
         memcpy(out, &bits, 8);
     }
+    p->dom_simple = simple ? 1 : 0;
     int minoff = 0, maxoff = 0;                           // in elements
     for (int u = 0; u < lend; u++) { const int e = od[u] / 8; if (e < minoff) minoff = e; if (e > maxoff) maxoff = e; }
     if (hipMalloc(&p->drec, sizeof(double) * 8 * (size_t)npat) != hipSuccess) { p->drec = nullptr; return; }
@@ -3485,6 +3773,43 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
     p->dom = D;
     p->dom_lo = -minoff;
     p->dom_hi = p->n - maxoff;
+    p->box_z0 = p->box_z1 = 0;
+    p->dom_xlen = 0;
+    if (p->rowpat) {
+        int mo[256], *d_mo = nullptr, *d_out = nullptr, top = 0;
+        for (int i = 0; i < 256; i++) mo[i] = 0;
+        for (int i = 0; i < npat; i++) { const int *oi = rec32 + 8 * i; for (int u = 0; u < oi[7] && u < 7; u++) if (oi[u] / 8 > mo[i]) mo[i] = oi[u] / 8; }
+        if (hipMalloc(&d_mo, sizeof(mo)) == hipSuccess && hipMalloc(&d_out, sizeof(int)) == hipSuccess && hipMemcpy(d_mo, mo, sizeof(mo), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemset(d_out, 0, sizeof(int)) == hipSuccess) {
+            dom_max_column<<<(p->n + 255) / 256, 256>>>(p->n, p->rowpat, d_mo, d_out);
+            if (hipGetLastError() == hipSuccess && hipMemcpy(&top, d_out, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) p->dom_xlen = top + 1;
+        }
+        if (d_mo) (void)hipFree(d_mo);
+        if (d_out) (void)hipFree(d_out);
+    }
+    int S = 0, SO = 0, perm = 0;
+    bool finite = true;
+    for (int u = 0; u < 7; u++) finite = finite && D.val[u] - D.val[u] == 0.0;      // (the BOX form's signed zeros need finite values)
+    if (finite && val8 && p->rowpat && dom_seven_point(D, S, SO, perm) && p->n % SO == 0 && SO % S == 0) {
+        const int planes = p->n / SO;
+        int *d_bad = nullptr, *bad = (int *)malloc(sizeof(int) * (size_t)planes);
+        if (bad && hipMalloc(&d_bad, sizeof(int) * (size_t)planes) == hipSuccess && hipMemset(d_bad, 0, sizeof(int) * (size_t)planes) == hipSuccess) {
+            dom_box_check<<<(p->n + 255) / 256, 256>>>(p->n, S, SO, perm, D.pat, p->rowpat, p->drec, d_bad);
+            if (hipGetLastError() == hipSuccess && hipMemcpy(bad, d_bad, sizeof(int) * (size_t)planes, hipMemcpyDeviceToHost) == hipSuccess) {
+                int best0 = 0, best1 = 0;
+                for (int z = 0; z < planes; ) {                   // the longest run of conforming planes
+                    if (bad[z]) { z++; continue; }
+                    int e = z;
+                    while (e < planes && !bad[e]) e++;
+                    if (e - z > best1 - best0) { best0 = z; best1 = e; }
+                    z = e;
+                }
+                p->box_z0 = best0; p->box_z1 = best1;
+            }
+        }
+        if (d_bad) (void)hipFree(d_bad);
+        free(bad);
+    }
 }
 
 // the 96 B records (32 B offsets + length, 64 B values) of npat patterns -> p->vrec
@@ -4006,6 +4331,8 @@ extern "C" int liship_csr_plan_encode_block_rows(liship_csr_plan_t p, int b, con
 }
 // b when the plan keeps block rows for spmv_csr_blockrows_staged_kernel, else 0
 extern "C" int liship_csr_plan_block_rows(liship_csr_plan_t p) { return (p && p->vrecw && p->bdrec && p->bstage && p->bd.len > 0) ? p->bd.b : 0; }
+// the planes of a 7-point grid in which the marching kernel needs neither pattern bytes nor masks (its BOX form), 0 when there are none
+extern "C" int liship_csr_plan_box_planes(liship_csr_plan_t p) { return (p && p->drec && p->vrec) ? p->box_z1 - p->box_z0 : 0; }
 // 1 when the plan also names a dominant pattern (spmv_csr_valuerec_dom_kernel), else 0
 extern "C" int liship_csr_plan_dominant_pattern(liship_csr_plan_t p) { return (p && p->ptab8 && p->drec) ? (p->vrec ? 1 : 2) : 0; }      // 2: offsets only (no value records)
 
@@ -4096,6 +4423,7 @@ extern "C" int liship_spmv_csr_set_local_columns(int on) { g_local_cols = on ? 1
 extern "C" int liship_spmv_csr_set_xcd_strips(int on) { g_xcd_strips = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_local_register_positions(int on) { g_local_rpos = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_team(int on) { g_team = on ? 1 : 0; return 0; }
+extern "C" int liship_spmv_csr_set_dom_march(int on) { g_dom_march = on; return 0; }
 extern "C" int liship_spmv_csr_set_block_rows(int on) { g_block_rows = on == 2 ? 2 : on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_wide_union(int on) { g_wide_union = on == 2 ? 2 : on ? 1 : 0; return 0; }
 
@@ -4248,8 +4576,35 @@ static void launch_team(const LaunchArgs &a, const double *guard)
 
 // the dominant-pattern product of a plan with value records (spmv_csr_valuerec_dom_kernel), plain or with the fused dots (a partial per workgroup: count_out)
 // its shape for the rows [a.rb, a.re): the tiles, the run length of the XCD order; returns the number of workgroups that have rows (= partials of the fused form)
+// the z-marching form (spmv_csr_valuerec_march_kernel) for the rows [a.rb, a.re)?  Whole planes of a grid whose dominant pattern is the 7-point stencil in ascending
+// slot order, lines a multiple of 128 long, a multiple of 8 lines per plane.  Segments of planes: as long as possible while the launch has about four workgroups per CU.
+static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
+{
+    const liship_csr_plan_s *P = a.plan;
+    if (!g_dom_march || g_variant != 0 || !P || P->dom.mask != 0x7f || !aligned16(a.y) || P->dom_xlen < P->n) return false;
+    const DomRec &D = P->dom;
+    int S = 0, SO = 0, perm = 0;
+    if (!dom_seven_point(D, S, SO, perm)) return false;
+    const int order = perm == 0x1ac688 ? 0 : perm == 0x0e2a70 ? 1 : 2;      // (slot u at bits 3u: ascending 0,1,2,3,4,5,6; the generators' 0,6,1,5,2,4,3)
+    if (S < 128 || S % 128 != 0 || SO <= S || SO % S != 0 || (SO / S) % 8 != 0) return false;
+    if (a.rb % SO != 0 || a.re % SO != 0 || a.re > P->n || a.rb < 0) return false;
+    const int z0 = a.rb / SO, z1 = a.re / SO, planes = z1 - z0;
+    if (planes < 8) return false;
+    const int tiles_x = S / 128, tiles_y = (SO / S) / 8, tiles = tiles_x * tiles_y;
+    int nseg = (4 * 256 + tiles - 1) / tiles;
+    if (nseg > planes / 8) nseg = planes / 8;
+    if (nseg < 1) nseg = 1;
+    const int zseg = (planes + nseg - 1) / nseg;
+    nseg = (planes + zseg - 1) / zseg;
+    M = DomMarch{S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, tiles * nseg, 0, perm, order, P->n / SO};
+    if (g_dom_march == 2) M.order |= 0x100;      // (experiment, WRONG results on the faces: every row taken for the dominant pattern -- timing only)
+    M.xcd = (M.wgs % NUM_XCD == 0 && M.wgs >= 8 * NUM_XCD) ? 1 : 0;
+    return true;
+}
+
 static long long dom_shape(const LaunchArgs &a, DomTile &TL, int &run)
 {
+    { DomMarch M; if (dom_march_shape(a, M)) { TL = DomTile{0, 0, 0, 0, 0, 0, 0}; run = 1; return M.wgs; } }
     const liship_csr_plan_s *P = a.plan;
     const long long rows = (long long)a.re - a.rb;
     // lane -> row mapping.  Default: TILES of 4 lines x 128 columns per workgroup when the pattern has a stride S of middle offsets
@@ -4289,6 +4644,23 @@ static long long dom_shape(const LaunchArgs &a, DomTile &TL, int &run)
 static void launch_dom(const LaunchArgs &a, int dot = 0, const double *w = nullptr, double *partial = nullptr, const double *guard = nullptr, int pstride = 0)
 {
     const liship_csr_plan_s *P = a.plan;
+    {
+        DomMarch M;
+        if (dom_march_shape(a, M)) {                 // whole planes of a 7-point grid: the z-marching form
+            const bool ws = dot != 0 && w != a.x;       // w is a vector of its own (else the diagonal's pair serves)
+            const int ord = M.order & 3;
+#define GOM(DT, WS_, ORD_, GEN_) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, GEN_><<<M.wgs, 256, 0, a.st>>>(a.rowpat, a.vrec, P->drec, P->dom, a.x, a.y, a.acc0, M, P->dom_xlen, w, partial, guard, pstride)
+            const bool box = ord != 2 && g_dom_march != 3 && M.z0 >= P->box_z0 && M.z1 <= P->box_z1;      // (3: the masks' form on a box too, A/B)
+#define GOMB(DT, WS_, ORD_) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true><<<M.wgs, 256, 0, a.st>>>(a.rowpat, a.vrec, P->drec, P->dom, a.x, a.y, a.acc0, M, P->dom_xlen, w, partial, guard, pstride)
+#define GOMO(DT, WS_) do { if (box) { if (ord == 0) GOMB(DT, WS_, 0); else GOMB(DT, WS_, 1); } \
+                           else if (!P->dom_simple || ord == 2) GOM(DT, WS_, 2, true); else if (ord == 0) GOM(DT, WS_, 0, false); else GOM(DT, WS_, 1, false); } while (0)
+            if (dot == 0) GOMO(0, false); else if (dot == 1) { if (ws) GOMO(1, true); else GOMO(1, false); } else { if (ws) GOMO(2, true); else GOMO(2, false); }
+#undef GOMO
+#undef GOMB
+#undef GOM
+            return;
+        }
+    }
     DomTile TL;
     int run = 1;
     const long long wgs = dom_shape(a, TL, run);

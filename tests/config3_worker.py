@@ -47,6 +47,10 @@ def main():
         assert lib.dll.lis_amd_comm_init_callbacks(C.byref(cb), rank, world) == 0
     assert lib.initialize([]) == 0
     lib.dll.lis_amd_set_residency(1)
+    if os.environ.get("CONFIG3_NO_OVERLAP") == "1":     # A/B: the whole local product in one launch behind the halo exchange
+        lib.dll.lis_amd_set_overlap(0)
+    if os.environ.get("CONFIG3_DOM_MARCH"):            # A/B: the form of the dominant-pattern product (liship_spmv_csr_set_dom_march)
+        lib.liship_spmv_csr_set_dom_march(int(os.environ["CONFIG3_DOM_MARCH"]))
     gn, mn = N ** 3, N * N
     A = capi.PM()
     assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0

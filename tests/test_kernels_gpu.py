@@ -1842,3 +1842,111 @@ def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(l
         lib.liship_spmv_csr_set_block_rows(1)
         lib.liship_spmv_csr_set_variant(0)
     assert taken[1] == 0 and (taken[0] == 1 or bs > 2), taken      # (3 x 3, 4 x 4: the rows' turns have no common supersequence of 32 entries; their block rows do not need one)
+
+
+@pytest.mark.parametrize("case", ["constant", "ell_padded", "values_differ", "foreign_rows", "two_tiles_wide", "generator_order", "other_order", "slab_of_rank_0", "slab_of_rank_1"])
+def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
+    """the 7-point stencil with value records on a grid whose lines are a multiple of 128 long: a workgroup walks the planes of its 128 x 8 tile, each x loaded once
+    (spmv_csr_valuerec_march_kernel; 512^3: 0.49 -> 0.41 ms).  The oracle's bits with the form on and off -- Inf / NaN / -0.0 in x, rows of other patterns (faces: masks;
+    other values: the waterfall's; foreign rows: their own records; ELL's padding terms), whole launches, plane ranges (the form) and ranges that cut planes (the
+    gathering kernel), the fused dots."""
+    nz, ny, nx = (12, 16, 256) if case == "two_tiles_wide" else (20, 16, 128)
+    ptr, idx, val = orc.poisson3d(nz, ny, nx, sort_cols=True)
+    n = len(ptr) - 1
+    SO = ny * nx
+    ncols = n
+    foreign_planes = set()
+    if case == "slab_of_rank_0":                              # the first nz planes of a taller grid: the last plane's rows are on the DOMINANT pattern, their +SO neighbours
+        ptr, idx, val = orc.poisson3d(nz + 3, ny, nx, sort_cols=True, is_=0, ie=n)      # beyond the rows (a multi-rank job's ghost columns right behind x[0, n))
+        ncols = n + SO
+    if case == "slab_of_rank_1":                              # planes 2 .. nz + 1 of a taller grid with the ghost planes renumbered behind the rows, lower neighbour first
+        ptr, idx, val = orc.poisson3d(nz + 4, ny, nx, sort_cols=True, is_=2 * SO, ie=2 * SO + n)      # (as lis_matrix_g2l does): the first and last planes' rows are foreign
+        idx = idx.astype(np.int64) - 2 * SO
+        idx = np.where(idx < 0, n + (idx + SO), np.where(idx >= n, n + SO + (idx - n), idx)).astype(np.int32)
+        ncols = n + 2 * SO
+    rng = np.random.default_rng(11)
+    if case == "ell_padded":                                  # every row padded to 7 entries with (row, +0.0) behind its own, as lis_matrix_convert_csr2ell lays them out
+        p0, i0, v0 = ptr, idx, val
+        ptr = np.arange(0, 7 * n + 1, 7, dtype=np.int32)
+        idx, val = np.empty(7 * n, np.int32), np.zeros(7 * n)
+        lens = np.diff(p0)
+        for r in np.flatnonzero(lens < 7):
+            k = lens[r]
+            idx[7 * r:7 * r + k], val[7 * r:7 * r + k] = i0[p0[r]:p0[r + 1]], v0[p0[r]:p0[r + 1]]
+            idx[7 * r + k:7 * r + 7] = r
+        full = np.flatnonzero(lens == 7)
+        idx.reshape(n, 7)[full] = i0[(p0[full][:, None] + np.arange(7)[None, :])]
+        val.reshape(n, 7)[full] = v0[(p0[full][:, None] + np.arange(7)[None, :])]
+    if case == "values_differ":                               # the rows of three planes carry another diagonal: the same offsets, values of their own
+        rows = np.repeat(np.arange(n), np.diff(ptr))
+        val = val.copy()
+        val[(idx == rows) & (rows // SO % 5 == 2)] = 7.5
+    if case == "foreign_rows":                                # a few interior rows whose +1 neighbour is the +5 one instead: seven entries, not a subsequence of the dominant pattern
+        idx, val = idx.copy(), val.copy()
+        for r in np.sort(rng.choice(np.arange(3 * SO, 9 * SO), 40, replace=False)):
+            k = ptr[r] + int(np.flatnonzero(idx[ptr[r]:ptr[r + 1]] == r + 1)[0]) if (idx[ptr[r]:ptr[r + 1]] == r + 1).any() else -1
+            if k >= 0 and r + 5 not in idx[ptr[r]:ptr[r + 1]]:
+                idx[k], val[k] = r + 5, 0.25
+                foreign_planes.add(int(r // SO))
+    if case == "generator_order":                             # the slot order of the reference's generators (-SO, +SO, -S, +S, -1, +1, 0)
+        ptr, idx, val = orc.poisson3d(nz, ny, nx, sort_cols=False)
+    if case == "other_order":                                 # some other order of the same seven columns: the kernel's general form
+        idx, val = idx.copy(), val.copy()
+        full = np.flatnonzero(np.diff(ptr) == 7)
+        sel = np.array([3, 0, 6, 2, 4, 1, 5])
+        I, V = idx[ptr[full][:, None] + sel[None, :]], val[ptr[full][:, None] + sel[None, :]]
+        idx[ptr[full][:, None] + np.arange(7)[None, :]], val[ptr[full][:, None] + np.arange(7)[None, :]] = I, V
+    x = rng.uniform(-1, 1, ncols)
+    x[::7] = 0.0
+    x[3::11] = -0.0
+    for pos, v in ((0, np.inf), (n - 1, -np.inf), (n // 2, np.nan), (n // 3, np.inf), (SO + 129, np.nan), (5, -np.inf), (ncols - 3, np.inf)):
+        x[pos] = v
+    ref = orc.spmv_csr(ptr, idx, val, x)
+    nanpos = np.isnan(ref)
+    xf = np.where(np.isfinite(x), x, 0.5)
+    yf = orc.spmv_csr(ptr, idx, val, xf)
+    w = rng.uniform(-1, 1, n)
+    dptr, didx, dval, dx, dxf, dw = (DA.from_host(a, t) for a, t in ((ptr, np.int32), (idx, np.int32), (val, np.float64), (x, np.float64), (xf, np.float64), (w, np.float64)))
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    assert lib.liship_csr_plan_dominant_pattern(plan) == 1
+    # a box (no pattern bytes, no masks: signed zeros in the halo) where every face row is the dominant pattern minus the neighbours outside the grid
+    # a box (no pattern bytes, no masks: signed zeros in the halo) in the planes where every row is the dominant pattern minus the neighbours outside the grid, with its values
+    bad = {"ell_padded": set(range(nz)), "other_order": set(range(nz)),      # (padding terms on every face row; "other_order" permutes the full rows only: its face rows are foreign)
+           "values_differ": {z for z in range(nz) if z % 5 == 2}, "foreign_rows": foreign_planes,
+           "slab_of_rank_0": {nz - 1}, "slab_of_rank_1": {0, nz - 1}}.get(case, set())
+    runs = "".join("x" if z in bad else "o" for z in range(nz)).split("x")
+    assert lib.liship_csr_plan_box_planes(plan) == max(len(r) for r in runs), (case, sorted(bad))
+    sums = []
+    try:
+        for march in (1, 3, 0):                               # 3: the masks' form on a box too
+            lib.liship_spmv_csr_set_dom_march(march)
+            dy = DA.from_host(np.full(n, 7.0), np.float64)
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            y = dy.to_host()
+            assert np.array_equal(np.isnan(y), nanpos), march
+            assert np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), march
+            for ranges in (((0, 9 * SO), (9 * SO, n)), ((0, 3 * SO + 77), (3 * SO + 77, 12 * SO), (12 * SO, n)) if nz > 12 else ((0, 5 * SO), (5 * SO, n))):
+                dy = DA.from_host(np.full(n, 7.0), np.float64)
+                for lo, hi in ranges:
+                    check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+                y = dy.to_host()
+                assert np.array_equal(np.isnan(y), nanpos) and np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), (march, ranges)
+            for wv, want_w in ((dxf, xf), (dw, w)):           # w = x (the diagonal's pair serves) and a vector of its own
+                for sumsq in (0, 1):
+                    res = DA.from_host(np.full(2, np.nan), np.float64)
+                    dy = DA.from_host(np.full(n, 7.0), np.float64)
+                    check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dxf.ptr, dy.ptr, wv.ptr, sumsq, res.ptr, work.ptr, None))
+                    assert np.array_equal(dy.to_host().view(np.uint64), yf.view(np.uint64)), (march, sumsq)
+                    got = res.to_host()
+                    np.testing.assert_allclose(got[0], np.dot(want_w[:n], yf), rtol=1e-12)
+                    if sumsq:
+                        np.testing.assert_allclose(got[1], np.dot(yf, yf), rtol=1e-12)
+                    sums.append(got.copy())
+    finally:
+        lib.liship_spmv_csr_set_dom_march(1)
+        check(lib.liship_csr_plan_destroy(plan))

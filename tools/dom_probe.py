@@ -11,6 +11,8 @@ from lis_amd import DeviceArray as DA, check  # noqa: E402
 from spmv_sweep import timed  # noqa: E402
 
 lib = lis_amd.load()
+if os.environ.get("DOM_MARCH"):         # A/B: 0 = the gathering dominant-pattern kernel instead of the z-marching one
+    lib.liship_spmv_csr_set_dom_march(int(os.environ["DOM_MARCH"]))
 if os.environ.get("NO_XCD_STRIPS") == "1":        # A/B: the 7-offset pattern kernel in the natural block order
     lib.liship_spmv_csr_set_xcd_strips(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512

@@ -254,10 +254,18 @@ def main():
 
     dll.lis_amd_matrix_dominant_pattern.argtypes = [capi.PM]
     dominant = int(dll.lis_amd_matrix_dominant_pattern(A))     # 1: one pattern carries most rows and its x gathers are issued with the pattern bytes (round 3)
+    dll.lis_amd_matrix_marching.argtypes = [capi.PM]
+    marching = int(dll.lis_amd_matrix_marching(A))             # round 4: 1 = the z-marching form of that product (each x loaded once per plane tile), 2 = its box form (no pattern bytes read)
+    if world > 1:
+        mm = torch.tensor([marching], dtype=torch.int32)
+        dist.all_reduce(mm, op=dist.ReduceOp.MIN)
+        marching = int(mm[0])
 
     def kernel_name(v):
         pair = n_local * 8 > (256 << 20)                  # round-2 kernels: x beyond the Infinity Cache takes the two-rows-per-lane form
         if patterns and records and v:
+            if dominant and marching:
+                return "spmv_csr_valuerec_march_kernel"
             return "spmv_csr_valuerec_dom_kernel" if dominant else "spmv_csr_valuerec_pair_kernel" if pair else "spmv_csr_valuerec_kernel"
         return ("spmv_csr_pattern7_kernel" if patterns and records else
                 "spmv_csr_pattern_kernel" if patterns else "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel")
@@ -340,7 +348,7 @@ def main():
         `contract_*`: SURVEY 8d's algorithmic count (12 B per non-zero + 20 B per row, the reference's CSR layout) over the same time --
         NOT a rate of this kernel when the plan stores fewer bytes; it says how much faster than a perfect streaming of the reference's
         layout the product runs, and may exceed 1."""
-        moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, v)
+        moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, v) - (n_local if (v and marching == 2) else 0)      # (the box form reads no pattern byte: x and y alone)
         traffic, detail = pmc_traffic(traffic_name)
         live = live_traffic(v) if rank == 0 else None
         if live:                                            # this run's own counters take precedence over the committed figure (kept beside them)
@@ -353,13 +361,14 @@ def main():
              "bytes_are": "stored matrix streams + y + compulsory x of the timed kernel (lower bound of its HBM bytes; `traffic` is the counters' upper bound)",
              "contract_bytes_per_launch": alg_bytes, "contract_achieved": round(alg_bytes / sec / 1e9, 1),
              "contract_frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
-             "index_codes": coded, "row_patterns": patterns, "value_records": v, "applies_to": applies_to}
+             "index_codes": coded, "row_patterns": patterns, "value_records": v, "marching": marching if v else 0, "applies_to": applies_to}
         if traffic:
             r["traffic_over_bytes"] = round(traffic / moved, 3)
         return r
 
     CONSTANT = ("constant-coefficient matrices only: the 27 row patterns of this stencil carry their VALUES (checked bit for bit at plan time), one pattern "
-                "byte per row is the only matrix stream; latency-bound, not byte-bound (DESIGN.md 4)")
+                "byte per row is the only matrix stream" + ("; round 4: the grid is a box (checked row by row at plan time), the z-marching kernel reads x once per plane tile "
+                "and no pattern byte: x and y alone are streamed (DESIGN.md 4)" if marching == 2 else "; latency-bound, not byte-bound (DESIGN.md 4)"))
     GENERAL = "any matrix on these sparsity patterns, whatever its coefficients: 8 B per non-zero + one pattern byte per row streamed"
     roofline = roofline_of(values, kernel_ms, "", CONSTANT if values else GENERAL)
     nontrivial = leg(xg, args.steps)

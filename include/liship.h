@@ -120,6 +120,7 @@ int  liship_spmv_csr_set_block_rows(int on);                   /* A/B switch: 0 
  * lies outside the grid -- there the kernel reads no pattern byte at all).  Same bits in every form. */
 int  liship_spmv_csr_set_dom_march(int on);
 int  liship_csr_plan_box_planes(liship_csr_plan_t plan);
+int  liship_csr_plan_marching(liship_csr_plan_t plan);       /* the whole-matrix product: 0 = the gathering kernels, 1 = z-marching with the faces' masks, 2 = its box form (no pattern bytes) */
 int  liship_spmv_csr_set_wide_union(int on);     /* plan-time A/B switch: 0 = no virtual dominant pattern (a common supersequence of the patterns rows take turns on: b x b blocked stencils), 1 = from 2^19 rows on (default), 2 = at any size */
 /* Value records (setup-time, optional, after liship_csr_plan_encode_row_patterns; never an error when the matrix does not
  * qualify): when the plan has 32 B pattern records and every row of a pattern carries the same values bit for bit -- a

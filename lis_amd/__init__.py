@@ -82,6 +82,7 @@ _LISHIP = {
     "liship_spmv_csr_set_wide_union": (_ci, [_ci]),
     "liship_spmv_csr_set_dom_march": (_ci, [_ci]),
     "liship_csr_plan_box_planes": (_ci, [_vp]),
+    "liship_csr_plan_marching": (_ci, [_vp]),
     "liship_csr_plan_encode_block_rows": (_ci, [_vp, _ci, _vp, _vp]),
     "liship_csr_plan_block_rows": (_ci, [_vp]),
     "liship_spmv_csr_set_block_rows": (_ci, [_ci]),

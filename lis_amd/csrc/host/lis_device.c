@@ -1029,6 +1029,11 @@ LIS_INT lis_amd_matrix_wide_dominant(LIS_MATRIX A)
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	return MDEV(A)->plan ? liship_csr_plan_wide_dominant(MDEV(A)->plan) : 0;
 }
+LIS_INT lis_amd_matrix_marching(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return (MDEV(A)->type == LIS_MATRIX_CSR && MDEV(A)->plan) ? liship_csr_plan_marching(MDEV(A)->plan) : 0;
+}
 LIS_INT lis_amd_matrix_block_rows(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;

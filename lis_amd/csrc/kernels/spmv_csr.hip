@@ -3693,11 +3693,13 @@ static bool dom_seven_point(const DomRec &D, int &S, int &SO, int &perm)
 // beyond the rows (ghost columns)
 __global__ void dom_max_column(int n, const unsigned char *__restrict__ rowpat, const int *__restrict__ maxoff, int *__restrict__ out)
 {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int part[4];
     int c = 0;
-    if (r < n) c = (int)r + maxoff[rowpat[r]];
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) c = max(c, (int)r + maxoff[rowpat[r]]);
     for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o));
-    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(out, c);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(part[0], part[1]), max(part[2], part[3])));      // (one atomic per workgroup: two million of them on one address cost 40 ms at 512^3)
 }
 // plan time: in which planes of the grid is every row's pattern the dominant one under the mask its place in the grid dictates (a slot is missing exactly where the
 // neighbour lies outside the grid)?  bad[z] != 0: some row of plane z is not.
@@ -3781,7 +3783,7 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
         for (int i = 0; i < npat; i++) { const int *oi = rec32 + 8 * i; for (int u = 0; u < oi[7] && u < 7; u++) if (oi[u] / 8 > mo[i]) mo[i] = oi[u] / 8; }
         if (hipMalloc(&d_mo, sizeof(mo)) == hipSuccess && hipMalloc(&d_out, sizeof(int)) == hipSuccess && hipMemcpy(d_mo, mo, sizeof(mo), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemset(d_out, 0, sizeof(int)) == hipSuccess) {
-            dom_max_column<<<(p->n + 255) / 256, 256>>>(p->n, p->rowpat, d_mo, d_out);
+            dom_max_column<<<2048, 256>>>(p->n, p->rowpat, d_mo, d_out);
             if (hipGetLastError() == hipSuccess && hipMemcpy(&top, d_out, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) p->dom_xlen = top + 1;
         }
         if (d_mo) (void)hipFree(d_mo);
@@ -4577,7 +4579,7 @@ static void launch_team(const LaunchArgs &a, const double *guard)
 // the dominant-pattern product of a plan with value records (spmv_csr_valuerec_dom_kernel), plain or with the fused dots (a partial per workgroup: count_out)
 // its shape for the rows [a.rb, a.re): the tiles, the run length of the XCD order; returns the number of workgroups that have rows (= partials of the fused form)
 // the z-marching form (spmv_csr_valuerec_march_kernel) for the rows [a.rb, a.re)?  Whole planes of a grid whose dominant pattern is the 7-point stencil in ascending
-// slot order, lines a multiple of 128 long, a multiple of 8 lines per plane.  Segments of planes: as long as possible while the launch has about four workgroups per CU.
+// slot order, lines a multiple of 128 long, a multiple of 8 lines per plane.  Segments of planes: as long as possible while the launch has about three workgroups per CU.
 static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
 {
     const liship_csr_plan_s *P = a.plan;
@@ -4591,7 +4593,7 @@ static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
     const int z0 = a.rb / SO, z1 = a.re / SO, planes = z1 - z0;
     if (planes < 8) return false;
     const int tiles_x = S / 128, tiles_y = (SO / S) / 8, tiles = tiles_x * tiles_y;
-    int nseg = (4 * 256 + tiles - 1) / tiles;
+    int nseg = (3 * 256 + tiles - 1) / tiles;                 // (512^3, 256 tiles: three segments 0.385 ms, four 0.398, two 0.37-0.42, one 0.52; tiles of 16 lines or three planes ahead: within the noise)
     if (nseg > planes / 8) nseg = planes / 8;
     if (nseg < 1) nseg = 1;
     const int zseg = (planes + nseg - 1) / nseg;
@@ -4639,6 +4641,17 @@ static long long dom_shape(const LaunchArgs &a, DomTile &TL, int &run)
     }
     run = (g_variant & 1) ? xcd_run() : (plain || TL.S || wgs < 8 * NUM_XCD) ? 1 : 8;
     return wgs;
+}
+
+// which form the whole-matrix product of this plan takes: 0 the gathering kernels, 1 the z-marching kernel with the faces' masks, 2 its BOX form (x and y alone are streamed)
+extern "C" int liship_csr_plan_marching(liship_csr_plan_t p)
+{
+    if (!p || !p->rowpat || !p->ptab8 || !p->vrec || !p->drec || p->products || !g_row_values || !g_row_patterns || !g_index_codes) return 0;
+    LaunchArgs a{};
+    a.plan = p; a.rb = 0; a.re = p->n; a.y = reinterpret_cast<double *>(16);
+    DomMarch M;
+    if (!dom_march_shape(a, M)) return 0;
+    return ((M.order & 3) != 2 && g_dom_march != 3 && M.z0 >= p->box_z0 && M.z1 <= p->box_z1) ? 2 : 1;
 }
 
 static void launch_dom(const LaunchArgs &a, int dot = 0, const double *w = nullptr, double *partial = nullptr, const double *guard = nullptr, int pstride = 0)

@@ -115,8 +115,8 @@ int  liship_spmv_csr_set_team(int on);           /* A/B switch: 0 = the one-lane
 int  liship_csr_plan_encode_block_rows(liship_csr_plan_t plan, int b, const int *ptr, void *stream);
 int  liship_csr_plan_block_rows(liship_csr_plan_t plan);       /* b when the plan keeps them, else 0 */
 int  liship_spmv_csr_set_block_rows(int on);                   /* A/B switch: 0 = the row-by-row kernels (same bits) */
-/* The z-marching form of the dominant-pattern product (7-point stencil with value records, grid lines a multiple of 128 long): 1 = on (default), 0 = the gathering kernel,
- * 3 = on, but with the faces' masks even where plan time found the grid a box (liship_csr_plan_box_planes: planes in which a slot is missing exactly where its neighbour
+/* The z-marching form of the dominant-pattern product (7-point stencil with value records, grid lines a multiple of 128 long): 1 = on for launches of 64 workgroups and more (default), 0 = the gathering kernel, 2 = on at any size,
+ * 3 = at any size, but with the faces' masks even where plan time found the grid a box (liship_csr_plan_box_planes: planes in which a slot is missing exactly where its neighbour
  * lies outside the grid -- there the kernel reads no pattern byte at all).  Same bits in every form. */
 int  liship_spmv_csr_set_dom_march(int on);
 int  liship_csr_plan_box_planes(liship_csr_plan_t plan);

@@ -2106,7 +2106,7 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
                             patc[i] = pat0[i];
                         }
                         const unsigned full = (unsigned)D.mask | ((unsigned)D.mask << 8);
-                        if ((M.order & 0x100) || __builtin_amdgcn_ballot_w64(mc[i] != full) == 0) {      // (uniform) every row here has all of the dominant pattern's slots
+                        if (__builtin_amdgcn_ballot_w64(mc[i] != full) == 0) {      // (uniform) every row here has all of the dominant pattern's slots
 #pragma unroll
                             for (int u = 0; u < 7; u++) { s0 += D.val[u] * xx[u].x; s1 += D.val[u] * xx[u].y; }
                         } else {
@@ -4599,7 +4599,11 @@ static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
     const int zseg = (planes + nseg - 1) / nseg;
     nseg = (planes + zseg - 1) / zseg;
     M = DomMarch{S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, tiles * nseg, 0, perm, order, P->n / SO};
-    if (g_dom_march == 2) M.order |= 0x100;      // (experiment, WRONG results on the faces: every row taken for the dominant pattern -- timing only)
+    // the general form (patterns with values of their own, foreign patterns, padding terms: the waterfall in every plane) loses to the gathering kernel -- ELL / DIA row
+    // forms at 256^3: 0.105 / 0.086 against 0.057 / 0.050 ms -- so by default only launches inside the box planes or of plans whose other patterns are plain masks march
+    if (g_dom_march == 1 && !(P->dom_simple || (z0 >= P->box_z0 && z1 <= P->box_z1)) ) return false;
+    if (g_dom_march == 1 && order == 2 && !P->dom_simple) return false;
+    if (M.wgs < 64 && g_dom_march == 1) return false;      // (a handful of workgroups walking a small grid: the gathering kernel's thousands of independent wavefronts win; 2 / 3: at any size, tests)
     M.xcd = (M.wgs % NUM_XCD == 0 && M.wgs >= 8 * NUM_XCD) ? 1 : 0;
     return true;
 }

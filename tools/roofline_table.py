@@ -26,6 +26,11 @@ EW = {0: (24, "axpy"), 1: (24, "xpay"), 2: (24, "axpyz"), 3: (16, "y = a x"), 4:
 
 
 def bytes_of(name):
+    m = re.search(r"spmv_csr_valuerec_march_kernel<2, 2, (\d), (\w+), \d, (\w+), (\w+)>", name)
+    if m:
+        dot, ws, gen, box = m.group(1) != "0", m.group(2) == "true", m.group(3) == "true", m.group(4) == "true"
+        return ((16 if box else 17) + (8 if ws else 0)) * n, ("headline product, z-marching" + (" (box form: x and y alone)" if box else " (faces by masks)" if not gen else " (general form)") +
+                                                           (", fused dots" + (", w a vector of its own" if ws else " (w = x: the diagonal's pair)") if dot else ""))
     m = re.search(r"spmv_csr_valuerec_dom_kernel<256, (\d)", name)
     if m:
         return 17 * n, "headline product (value records, dominant pattern)" + (", fused dots (w = x in CG: no extra stream; w streamed adds 8 B per row)" if m.group(1) != "0" else "")

@@ -22,6 +22,7 @@ ap.add_argument("--nnz", type=int, default=7 * 512 ** 3 - 6 * 512 * 512)
 ap.add_argument("--coded", type=int, default=1)
 ap.add_argument("--patterns", type=int, default=0, help="row patterns: 8 B per non-zero + 1 B per row of matrix streams (row starts by scan)")
 ap.add_argument("--values", type=int, default=0, help="value records: one pattern byte per row is the only matrix stream")
+ap.add_argument("--box", type=int, default=0, help="with --values: the z-marching kernel's box form, which reads no pattern byte either (x and y alone)")
 ap.add_argument("--command", default="python bench.py --steps 20 --warmup 3 --preroll 100 --no-cpu-baseline")
 a = ap.parse_args()
 
@@ -55,7 +56,7 @@ stream_rd = (9 if a.coded else 12) * nnz + 4 * (n + 1)           # value + code/
 if a.patterns:
     stream_rd = 8 * nnz + n                                       # value + one pattern byte per row
 if a.patterns and a.values:
-    stream_rd = n                                                 # one pattern byte per row
+    stream_rd = 0 if a.box else n                                 # one pattern byte per row (the box form: none)
 out = {
     "source": f"rocprofv3 --kernel-trace --pmc <group> -- {a.command} (separate passes per counter group, tools/prof.sh), summarised by tools/traffic_json.py",
     "kernel": a.kernel, "launches": launches, "avg_kernel_ns": avg_ns,
@@ -68,7 +69,7 @@ out = {
     "dram_read_bytes_32B_granular": 32 * g("TCC_EA0_RDREQ_DRAM_32B_sum") if g("TCC_EA0_RDREQ_DRAM_32B_sum") is not None else None,
     "dram_write_bytes_32B_granular": 32 * g("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum") if g("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum") is not None else None,
     "algorithmic_bytes_per_launch": 12 * nnz + 20 * n + 4,
-    "stored_bytes_per_launch": (17 * n + 4) if (a.patterns and a.values) else (8 * nnz + 17 * n + 4) if a.patterns else ((9 if a.coded else 12) * nnz + 20 * n + 4),
+    "stored_bytes_per_launch": ((16 if a.box else 17) * n + 4) if (a.patterns and a.values) else (8 * nnz + 17 * n + 4) if a.patterns else ((9 if a.coded else 12) * nnz + 20 * n + 4),
     "stream_read_bytes_per_launch": stream_rd,
 }
 if rd is not None:

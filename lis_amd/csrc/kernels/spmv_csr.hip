@@ -1939,7 +1939,8 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
 // (0.58 -> 0.70 of 8 TB/s on the 17 B per row).  Same terms in the same order: rows on other patterns take their masks and values by the waterfall above (-0.0 terms),
 // foreign rows their own records, ELL's padding terms as above -- y is the reference's, bit for bit.  Speculative addresses (the planes before the first and after the
 // last, the halo of the grid's faces) are clamped into x[0, nx); their values only ever meet masked slots.
-struct DomMarch { int S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, wgs, xcd, perm, order, planes; };      // planes [z0, z1) of the grid (whole planes of the launch's row range); perm: 3 bits per slot, which neighbour it is (0: -SO, 1: -S, 2: -1, 3: 0, 4: +1, 5: +S, 6: +SO)
+struct DomMarch { int S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, wgs, xcd, perm, order, planes, modes; };
+struct BoxAlt { double v[7]; };       // (BOX, ALT) by slot: the value of a slot whose neighbour lies outside the grid when the rows keep it with a value of its own (DIA's explicit zeros)      // planes [z0, z1) of the grid (whole planes of the launch's row range); perm: 3 bits per slot, which neighbour it is (0: -SO, 1: -S, 2: -1, 3: 0, 4: +1, 5: +S, 6: +SO)
 // masks of the rows' patterns over the dominant one's slots, by scalar loads, one round per distinct pattern among the lanes that `need` one (the first double of a
 // pattern's record: spmv_csr_valuerec_march_kernel's short form, whose plan has no other kind of pattern)
 __device__ __forceinline__ unsigned dom_masks_only(const double *__restrict__ drec, const DomRec &D, int pt, bool need, unsigned m)
@@ -1963,12 +1964,15 @@ __device__ __forceinline__ unsigned dom_masks_only(const double *__restrict__ dr
 // that the faces' rows carry the dominant pattern's values: then no pattern byte is read at all, and instead of masks the halo cells that only masked slots ever read
 // (the column left of the grid's first, the line above its first line, the plane before its first plane ... and their opposites) hold a ZERO whose sign makes the product
 // with the slot's value -0.0, the term every masked slot adds: the sums run the unmasked code everywhere.  16 B per row: x once, y once.
-template <int LPW, int D_, int DOT, bool WS, int ORD, bool GEN, bool BOX = false>
+// What the rows of a box do with a neighbour outside the grid is one of three things per side (M.modes, plan time): the slot is missing (the signed zero above), it is there
+// with the dominant value and a real x behind it (a multi-rank job's ghost plane: nothing to do), or it is there with another value (ALT: DIA keeps the diagonals' explicit
+// zeros, 0.0 * x of the row across the line's end -- the value is picked per row, x is the real one).  PADS: a (row, +0.0) term behind the sum per missing slot (ELL's padding).
+template <int LPW, int D_, int DOT, bool WS, int ORD, bool GEN, bool BOX = false, bool ALT = false, bool PADS = false>
 __global__ __launch_bounds__(256)
 void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, const double *__restrict__ drec,
                                     const DomRec D, const double *__restrict__ x, double *__restrict__ y, double acc0, const DomMarch M, int nx,
                                     const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                                    const double *__restrict__ guard = nullptr, int pstride = 0)
+                                    const double *__restrict__ guard = nullptr, int pstride = 0, const BoxAlt A = BoxAlt{})
 {
     constexpr int BLOCK = 256, TX = 128, TY = 4 * LPW, LX = TX + 4;      // an LDS line: [pad][left halo][TX columns][right halo][pad]: a lane's pair at 2 + 2 lane, 16 B aligned
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;      // device-driven Krylov loop already converged (nothing has been written)
@@ -1996,6 +2000,7 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
     };
     const int lines = (int)(SO / S), planes_all = M.planes;
     const bool box_left = BOX && tx == 0, box_right = BOX && tx == M.tiles_x - 1, box_top = BOX && ty == 0, box_bottom = BOX && ty == M.tiles_y - 1;      // (uniform)
+    auto mode = [&](int kind) { return (M.modes >> (2 * kind)) & 3; };      // 0: the slot is missing, 1: there with the dominant value, 2: there with A.v's
     (void)lines;
     struct Packet { v2f64 own[LPW]; v2f64 hy; double hx[LPW]; v2f64 ww[WS ? LPW : 1]; unsigned short pat[LPW]; };
     auto load_packet = [&](Packet &P, int z, bool pats) {
@@ -2022,14 +2027,14 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
     auto store_packet = [&](const Packet &P, double *B) {
 #pragma unroll
         for (int i = 0; i < LPW; i++) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = P.own[i];
-        if (w == 0) { v2f64 h = P.hy; if (box_top) { h.x = h.y = poison(1); } *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = h; }
-        if (w == 3) { v2f64 h = P.hy; if (box_bottom) { h.x = h.y = poison(5); } *reinterpret_cast<v2f64 *>(B + (TY + 1) * LX + 2 + 2 * lane) = h; }
+        if (w == 0) { v2f64 h = P.hy; if (box_top && mode(1) == 0) { h.x = h.y = poison(1); } *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = h; }
+        if (w == 3) { v2f64 h = P.hy; if (box_bottom && mode(5) == 0) { h.x = h.y = poison(5); } *reinterpret_cast<v2f64 *>(B + (TY + 1) * LX + 2 + 2 * lane) = h; }
         if (lane == 0 || lane == WAVE - 1) {
 #pragma unroll
             for (int i = 0; i < LPW; i++) {
                 double h = P.hx[i];
-                if (box_left && lane == 0) h = poison(2);
-                if (box_right && lane == WAVE - 1) h = poison(4);
+                if (box_left && lane == 0 && mode(2) == 0) h = poison(2);
+                if (box_right && lane == WAVE - 1 && mode(4) == 0) h = poison(4);
                 B[(w * LPW + i + 1) * LX + (lane == 0 ? 1 : 2 + TX)] = h;
             }
         }
@@ -2045,7 +2050,7 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
         Packet P;
         load_packet(P, za - 1, false);
 #pragma unroll
-        for (int i = 0; i < LPW; i++) { prev[i] = P.own[i]; if (BOX && za == 0) { prev[i].x = prev[i].y = poison(0); } }      // (uniform) the grid's first plane has no plane before it
+        for (int i = 0; i < LPW; i++) { prev[i] = P.own[i]; if (BOX && za == 0 && mode(0) == 0) { prev[i].x = prev[i].y = poison(0); } }      // (uniform) the grid's first plane has no plane before it
         load_packet(P, za, true);
         store_packet(P, buf[za & 1]);
 #pragma unroll
@@ -2075,7 +2080,7 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
                     const v2f64 up = *reinterpret_cast<const v2f64 *>(B + li - LX), dn = *reinterpret_cast<const v2f64 *>(B + li + LX);
                     v2f64 xl, xr, xx[7], nxt = P.own[i];
                     xl.x = l; xl.y = c.x; xr.x = c.y; xr.y = r;
-                    if (BOX && z == planes_all - 1) { nxt.x = nxt.y = poison(6); }      // (uniform) the grid's last plane has no plane behind it
+                    if (BOX && z == planes_all - 1 && mode(6) == 0) { nxt.x = nxt.y = poison(6); }      // (uniform) the grid's last plane has no plane behind it
                     if (ORD == 0) { xx[0] = prev[i]; xx[1] = up; xx[2] = xl; xx[3] = c; xx[4] = xr; xx[5] = dn; xx[6] = nxt; }
                     else if (ORD == 1) { xx[0] = prev[i]; xx[1] = nxt; xx[2] = up; xx[3] = dn; xx[4] = xl; xx[5] = xr; xx[6] = c; }
                     else {
@@ -2096,8 +2101,31 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
                     const int pa = (int)(pat0[i] & 255u), pb = (int)(pat0[i] >> 8);
                     double s0 = acc0, s1 = acc0;
                     if (BOX) {
+                        // which sides of the grid this pair's rows lie on (x: the first row of lane 0 / the second row of the last lane; y, z: uniform)
+                        const bool o_l = box_left && lane == 0, o_r = box_right && lane == WAVE - 1;
+                        const bool o_u = box_top && w * LPW + i == 0, o_d = box_bottom && w * LPW + i == TY - 1, o_p = z == 0, o_n = z == planes_all - 1;
 #pragma unroll
-                        for (int u = 0; u < 7; u++) { s0 += D.val[u] * xx[u].x; s1 += D.val[u] * xx[u].y; }
+                        for (int u = 0; u < 7; u++) {
+                            double v0 = D.val[u], v1 = D.val[u];
+                            if (ALT) {
+                                const int k = ORD == 0 ? u : (u == 0 ? 0 : u == 1 ? 6 : u == 2 ? 1 : u == 3 ? 5 : u == 4 ? 2 : u == 5 ? 4 : 3);      // the slot's neighbour (compile time)
+                                if (mode(k) == 2) {                             // (uniform)
+                                    const bool out0 = k == 0 ? o_p : k == 1 ? o_u : k == 2 ? o_l : k == 4 ? false : k == 5 ? o_d : k == 6 ? o_n : false;
+                                    const bool out1 = k == 0 ? o_p : k == 1 ? o_u : k == 2 ? false : k == 4 ? o_r : k == 5 ? o_d : k == 6 ? o_n : false;
+                                    v0 = out0 ? A.v[u] : v0; v1 = out1 ? A.v[u] : v1;
+                                }
+                            }
+                            s0 += v0 * xx[u].x; s1 += v1 * xx[u].y;
+                        }
+                        if (PADS) {                                             // a term 0.0 * x[row] per missing slot, behind the sum (lis_matvec_ell.c:113-128 adds the padding last)
+                            const int ku = (o_u && mode(1) == 0) + (o_d && mode(5) == 0) + (o_p && mode(0) == 0) + (o_n && mode(6) == 0);
+                            const int k0 = ku + (o_l && mode(2) == 0), k1 = ku + (o_r && mode(4) == 0);
+                            if (__builtin_amdgcn_ballot_w64((k0 | k1) != 0) != 0) {      // (uniform)
+                                const double t0 = 0.0 * c.x, t1 = 0.0 * c.y;
+#pragma unroll
+                                for (int q = 0; q < 3; q++) { s0 += (q < k0) ? t0 : -0.0; s1 += (q < k1) ? t1 : -0.0; }      // (a row lies on at most three sides)
+                            }
+                        }
                     } else if (!GEN) {
                         if (__builtin_amdgcn_ballot_w64((unsigned)pat0[i] != patc[i]) != 0) {      // (uniform) a pattern byte changed since the last plane: ask again
                             unsigned ma = dom_masks_only(drec, D, pa, pa != (int)(patc[i] & 255u), mc[i] & 255u);
@@ -3187,6 +3215,9 @@ struct liship_csr_plan_s {
                          // subsequence), its values in those slots}; else NULL (spmv_csr_valuerec_dom_kernel)
     DomRec dom;          // the dominant pattern: byte offsets, values, pattern byte, slots
     int dom_xlen;        // 1 + the largest column the rows read (>= n; ghost columns in a multi-rank job): the marching kernel clamps its speculative loads into x[0, dom_xlen)
+    int box_modes, box_pads;  // per neighbour kind (2 bits each: 0 -SO .. 6 +SO) what the box planes' rows do with a neighbour OUTSIDE the grid: 0 the slot is missing, 1 it is there with the
+                         // dominant pattern's value (x real: a multi-rank job's ghost plane), 2 there with box_alt's value (DIA's explicit zeros); box_pads: a (row, +0.0) term per missing slot (ELL)
+    double box_alt[7];   // by SLOT: the value of mode 2
     int box_z0, box_z1;  // planes [box_z0, box_z1) of the 7-point grid in which a slot is missing exactly where its neighbour lies outside the grid (dom_box_check): the marching kernel's BOX form
     int dom_simple;      // 1: every pattern is the dominant one's slots under a mask with the dominant one's VALUES (no foreign pattern, no padding terms): the marching kernel's short form
     int dom_lo, dom_hi;  // rows [dom_lo, dom_hi - 128] may start a wavefront that gathers x at the dominant offsets without leaving x[0, n)
@@ -3298,7 +3329,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
     p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->bd.len = 0; p->bdrec = nullptr; p->bstage = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
-    p->drec = nullptr; p->dom_lo = p->dom_hi = 0; p->dom_simple = 0; p->box_z0 = p->box_z1 = 0; p->dom_xlen = 0;
+    p->drec = nullptr; p->dom_lo = p->dom_hi = 0; p->dom_simple = 0; p->box_z0 = p->box_z1 = 0; p->dom_xlen = 0; p->box_modes = p->box_pads = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -3701,22 +3732,30 @@ __global__ void dom_max_column(int n, const unsigned char *__restrict__ rowpat, 
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(out, max(max(part[0], part[1]), max(part[2], part[3])));      // (one atomic per workgroup: two million of them on one address cost 40 ms at 512^3)
 }
-// plan time: in which planes of the grid is every row's pattern the dominant one under the mask its place in the grid dictates (a slot is missing exactly where the
-// neighbour lies outside the grid)?  bad[z] != 0: some row of plane z is not.
-__global__ void dom_box_check(int n, int S, int SO, int perm, int dpat, const unsigned char *__restrict__ rowpat, const double *__restrict__ drec, int *__restrict__ bad)
+// plan time: what do the rows of each plane of the grid do with the neighbours their place in the grid puts OUTSIDE it?  desc[pattern]: 2 bits per slot of the dominant
+// pattern (0 missing, 1 there with the dominant value, 2 there with the slot's alternative value), the count of trailing (row, +0.0) terms << 14, bit 20: none of that
+// (foreign, values of its own).  A row is out (bad[z]) when a neighbour INSIDE the grid is not a plain dominant slot; for neighbours outside, obs[z] collects per kind
+// (3 bits each) the states seen; bit 21: a row with missing slots and no padding terms, bit 22: one with a padding term per missing slot (other counts: bad).
+__global__ void dom_box_check(int n, int S, int SO, int perm, const unsigned char *__restrict__ rowpat, const int *__restrict__ desc, int *__restrict__ bad, unsigned *__restrict__ obs)
 {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const int z = (int)(r / SO), rem = (int)(r - (long long)z * SO), yy = rem / S, xx = rem - yy * S, lines = SO / S, planes = n / SO;
-    const int pat = rowpat[r];
-    const unsigned m = (unsigned)__double2loint(drec[8 * pat]);      // slots | foreign 0x80 | padding terms (bits 8-10) | bit 11: the dominant pattern's values in the slots it keeps
-    unsigned e = 0;
+    const int d = desc[rowpat[r]];
+    bool b = ((d >> 20) & 1) != 0;
+    unsigned o = 0;
+    int missing = 0;
     for (int u = 0; u < 7; u++) {
-        const int k = (perm >> (3 * u)) & 7;
-        const bool present = k == 0 ? z > 0 : k == 1 ? yy > 0 : k == 2 ? xx > 0 : k == 3 ? true : k == 4 ? xx < S - 1 : k == 5 ? yy < lines - 1 : z < planes - 1;
-        e |= (present ? 1u : 0u) << u;
+        const int k = (perm >> (3 * u)) & 7, st = (d >> (2 * u)) & 3;
+        const bool inside = k == 0 ? z > 0 : k == 1 ? yy > 0 : k == 2 ? xx > 0 : k == 3 ? true : k == 4 ? xx < S - 1 : k == 5 ? yy < lines - 1 : z < planes - 1;
+        if (inside) { if (st != 1) b = true; }
+        else { o |= 1u << (3 * k + st); if (st == 0) missing++; }
     }
-    if (m != (e | 0x800u)) bad[z] = 1;
+    const int pads = (d >> 14) & 7;
+    if (pads != 0 && pads != missing) b = true;
+    if (missing > 0) o |= pads == 0 ? (1u << 21) : (1u << 22);
+    if (b) bad[z] = 1;
+    if (o & ~obs[z]) atomicOr(&obs[z], o);                     // (after the first rows of a plane everyone finds its bits there already)
 }
 
 // The dominant pattern of a plan with value records and the other patterns' records in ITS slots (spmv_csr_valuerec_dom_kernel).
@@ -3745,6 +3784,10 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
     const int d0 = D.d0;
     bool simple = true;
     double img[PAT7_MAX * 8];
+    int desc[256];
+    double alt[7] = {0, 0, 0, 0, 0, 0, 0};
+    bool alt_set[7] = {false, false, false, false, false, false, false};
+    for (int i = 0; i < 256; i++) desc[i] = 1 << 20;
     for (int i = 0; i < npat; i++) {
         const int *oi = rec32 + 8 * i;
         const int leni = oi[7];
@@ -3763,7 +3806,19 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
         bool same = val8 != nullptr && mask < 0x80u;      // ... a plain mask whose kept slots carry the dominant pattern's values, bit for bit
         for (int sl = 0; sl < lend && same; sl++) if ((mask >> sl) & 1u) same = memcmp(&out[1 + sl], &D.val[sl], 8) == 0;
         simple = simple && same;
-        if (same) mask |= 0x800u;                         // (bit 11: dom_box_check asks for it row by row)
+        if (same) mask |= 0x800u;                         // (bit 11: the dominant pattern's values in the slots it keeps)
+        {   // the box check's view of the pattern
+            int dsc = 0;
+            bool complex_ = (mask & 0x80u) != 0 || val8 == nullptr;
+            for (int sl = 0; sl < 7 && !complex_; sl++) {
+                if (!((mask >> sl) & 1u)) continue;
+                if (sl < lend && memcmp(&out[1 + sl], &D.val[sl], 8) == 0) { dsc |= 1 << (2 * sl); continue; }
+                if (!alt_set[sl]) { alt_set[sl] = true; alt[sl] = out[1 + sl]; }
+                if (memcmp(&out[1 + sl], &alt[sl], 8) != 0) complex_ = true;      // a third value in this slot
+                dsc |= 2 << (2 * sl);
+            }
+            desc[i] = complex_ ? (1 << 20) : (dsc | (int)(((mask >> 8) & 7u) << 14));
+        }
         unsigned long long bits = mask;
         memcpy(out, &bits, 8);
     }
@@ -3794,23 +3849,41 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
     for (int u = 0; u < 7; u++) finite = finite && D.val[u] - D.val[u] == 0.0;      // (the BOX form's signed zeros need finite values)
     if (finite && val8 && p->rowpat && dom_seven_point(D, S, SO, perm) && p->n % SO == 0 && SO % S == 0) {
         const int planes = p->n / SO;
-        int *d_bad = nullptr, *bad = (int *)malloc(sizeof(int) * (size_t)planes);
-        if (bad && hipMalloc(&d_bad, sizeof(int) * (size_t)planes) == hipSuccess && hipMemset(d_bad, 0, sizeof(int) * (size_t)planes) == hipSuccess) {
-            dom_box_check<<<(p->n + 255) / 256, 256>>>(p->n, S, SO, perm, D.pat, p->rowpat, p->drec, d_bad);
-            if (hipGetLastError() == hipSuccess && hipMemcpy(bad, d_bad, sizeof(int) * (size_t)planes, hipMemcpyDeviceToHost) == hipSuccess) {
-                int best0 = 0, best1 = 0;
-                for (int z = 0; z < planes; ) {                   // the longest run of conforming planes
-                    if (bad[z]) { z++; continue; }
+        int *d_bad = nullptr, *d_desc = nullptr, *bad = (int *)malloc(sizeof(int) * (size_t)planes);
+        unsigned *d_obs = nullptr, *obs = (unsigned *)malloc(sizeof(unsigned) * (size_t)planes);
+        if (bad && obs && hipMalloc(&d_bad, sizeof(int) * (size_t)planes) == hipSuccess && hipMalloc(&d_obs, sizeof(unsigned) * (size_t)planes) == hipSuccess &&
+            hipMalloc(&d_desc, sizeof(desc)) == hipSuccess && hipMemcpy(d_desc, desc, sizeof(desc), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemset(d_bad, 0, sizeof(int) * (size_t)planes) == hipSuccess && hipMemset(d_obs, 0, sizeof(unsigned) * (size_t)planes) == hipSuccess) {
+            dom_box_check<<<(p->n + 255) / 256, 256>>>(p->n, S, SO, perm, p->rowpat, d_desc, d_bad, d_obs);
+            if (hipGetLastError() == hipSuccess && hipMemcpy(bad, d_bad, sizeof(int) * (size_t)planes, hipMemcpyDeviceToHost) == hipSuccess &&
+                hipMemcpy(obs, d_obs, sizeof(unsigned) * (size_t)planes, hipMemcpyDeviceToHost) == hipSuccess) {
+                // the longest run of planes that agree: per kind of neighbour ONE way to treat it outside the grid, padding terms everywhere or nowhere, and not both
+                // alternative values and padding terms (no kernel for that)
+                auto agree = [](unsigned u) {
+                    bool alts = false;
+                    for (int k = 0; k < 7; k++) { const unsigned m3 = (u >> (3 * k)) & 7u; if (m3 & (m3 - 1)) return false; alts = alts || (m3 & 4u); }
+                    const bool pn = (u >> 21) & 1u, py = (u >> 22) & 1u;
+                    return !(pn && py) && !(py && alts);
+                };
+                int best0 = 0, best1 = 0; unsigned bestu = 0;
+                for (int z = 0; z < planes; z++) {
+                    if (bad[z] || !agree(obs[z]) || (best1 > z && z >= best0)) continue;      // (inside the best run so far: a run from here is shorter)
+                    unsigned u = 0;
                     int e = z;
-                    while (e < planes && !bad[e]) e++;
-                    if (e - z > best1 - best0) { best0 = z; best1 = e; }
-                    z = e;
+                    while (e < planes && !bad[e] && agree(u | obs[e])) { u |= obs[e]; e++; }
+                    if (e - z > best1 - best0) { best0 = z; best1 = e; bestu = u; }
                 }
                 p->box_z0 = best0; p->box_z1 = best1;
+                p->box_modes = 0;
+                for (int k = 0; k < 7; k++) { const unsigned m3 = (bestu >> (3 * k)) & 7u; p->box_modes |= (m3 & 2u ? 1 : m3 & 4u ? 2 : 0) << (2 * k); }
+                p->box_pads = (bestu >> 22) & 1u;
+                for (int u = 0; u < 7; u++) p->box_alt[u] = alt[u];
             }
         }
         if (d_bad) (void)hipFree(d_bad);
-        free(bad);
+        if (d_obs) (void)hipFree(d_obs);
+        if (d_desc) (void)hipFree(d_desc);
+        free(bad); free(obs);
     }
 }
 
@@ -4598,7 +4671,7 @@ static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
     if (nseg < 1) nseg = 1;
     const int zseg = (planes + nseg - 1) / nseg;
     nseg = (planes + zseg - 1) / zseg;
-    M = DomMarch{S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, tiles * nseg, 0, perm, order, P->n / SO};
+    M = DomMarch{S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, tiles * nseg, 0, perm, order, P->n / SO, P->box_modes};
     // the general form (patterns with values of their own, foreign patterns, padding terms: the waterfall in every plane) loses to the gathering kernel -- ELL / DIA row
     // forms at 256^3: 0.105 / 0.086 against 0.057 / 0.050 ms -- so by default only launches inside the box planes or of plans whose other patterns are plain masks march
     if (g_dom_march == 1 && !(P->dom_simple || (z0 >= P->box_z0 && z1 <= P->box_z1)) ) return false;
@@ -4608,9 +4681,8 @@ static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
     return true;
 }
 
-static long long dom_shape(const LaunchArgs &a, DomTile &TL, int &run)
+static long long dom_gather_shape(const LaunchArgs &a, DomTile &TL, int &run)
 {
-    { DomMarch M; if (dom_march_shape(a, M)) { TL = DomTile{0, 0, 0, 0, 0, 0, 0}; run = 1; return M.wgs; } }
     const liship_csr_plan_s *P = a.plan;
     const long long rows = (long long)a.re - a.rb;
     // lane -> row mapping.  Default: TILES of 4 lines x 128 columns per workgroup when the pattern has a stride S of middle offsets
@@ -4658,43 +4730,104 @@ extern "C" int liship_csr_plan_marching(liship_csr_plan_t p)
     return ((M.order & 3) != 2 && g_dom_march != 3 && M.z0 >= p->box_z0 && M.z1 <= p->box_z1) ? 2 : 1;
 }
 
-static void launch_dom(const LaunchArgs &a, int dot = 0, const double *w = nullptr, double *partial = nullptr, const double *guard = nullptr, int pstride = 0)
+// A launch over the rows [a.rb, a.re) in up to three parts: the planes the marching kernel serves (all of them, or the launch's share of the plan's box planes when that is
+// most of it -- DIA's first and last plane differ from the others, a multi-rank slab's boundary planes are foreign) and what is left before and behind them, which the
+// gathering kernel takes.  The parts' partial sums (fused dots) sit one after the other: a partial per workgroup, dom_shape() = their number.
+struct DomPart { int rb, re; bool march; long long wgs; DomMarch M; DomTile TL; int run; };
+static int dom_parts(const LaunchArgs &a, DomPart (&parts)[3])
 {
     const liship_csr_plan_s *P = a.plan;
-    {
-        DomMarch M;
-        if (dom_march_shape(a, M)) {                 // whole planes of a 7-point grid: the z-marching form
+    auto gather = [&](int rb, int re) {
+        DomPart G{rb, re, false, 0, DomMarch{}, DomTile{0, 0, 0, 0, 0, 0, 0}, 1};
+        LaunchArgs b = a; b.rb = rb; b.re = re;
+        G.wgs = dom_gather_shape(b, G.TL, G.run);
+        return G;
+    };
+    DomMarch M;
+    if (dom_march_shape(a, M)) { parts[0] = DomPart{a.rb, a.re, true, M.wgs, M, DomTile{0, 0, 0, 0, 0, 0, 0}, 1}; return 1; }
+    int S = 0, SO = 0, perm = 0;
+    if (g_dom_march && P && P->box_z1 > P->box_z0 && dom_seven_point(P->dom, S, SO, perm)) {
+        const long long zlo = std::max<long long>(((long long)a.rb + SO - 1) / SO, P->box_z0), zhi = std::min<long long>((long long)a.re / SO, P->box_z1);
+        if (zhi - zlo >= 8 && (zhi - zlo) * SO * 2 >= (long long)a.re - a.rb) {
+            LaunchArgs b = a; b.rb = (int)(zlo * SO); b.re = (int)(zhi * SO);
+            if (dom_march_shape(b, M)) {
+                int np = 0;
+                if (a.rb < b.rb) parts[np++] = gather(a.rb, b.rb);
+                parts[np++] = DomPart{b.rb, b.re, true, M.wgs, M, DomTile{0, 0, 0, 0, 0, 0, 0}, 1};
+                if (b.re < a.re) parts[np++] = gather(b.re, a.re);
+                return np;
+            }
+        }
+    }
+    parts[0] = gather(a.rb, a.re);
+    return 1;
+}
+static long long dom_shape(const LaunchArgs &a, DomTile &TL, int &run)      // the number of workgroups with rows = partial sums of the fused forms (TL, run: the gathering kernel's, when it is the only part)
+{
+    DomPart parts[3];
+    const int np = dom_parts(a, parts);
+    long long total = 0;
+    for (int i = 0; i < np; i++) total += parts[i].wgs;
+    TL = parts[0].TL; run = parts[0].run;
+    return total;
+}
+
+static void launch_dom(const LaunchArgs &a0, int dot = 0, const double *w = nullptr, double *partial0 = nullptr, const double *guard = nullptr, int pstride0 = 0)
+{
+    const liship_csr_plan_s *P = a0.plan;
+    DomPart parts[3];
+    const int np = dom_parts(a0, parts);
+    long long total = 0;
+    for (int i = 0; i < np; i++) total += parts[i].wgs;
+    const int pstride = pstride0 ? pstride0 : (int)total;     // the second sums sit `stride` behind the first ones: the same for every part
+    long long done = 0;
+    for (int ip = 0; ip < np; ip++) {
+        const DomPart &Q = parts[ip];
+        LaunchArgs a = a0; a.rb = Q.rb; a.re = Q.re;
+        double *partial = partial0 ? partial0 + done : nullptr;
+        done += Q.wgs;
+        if (Q.wgs <= 0) continue;
+        if (Q.march) {                                // whole planes of a 7-point grid: the z-marching form
+            const DomMarch &M = Q.M;
             const bool ws = dot != 0 && w != a.x;       // w is a vector of its own (else the diagonal's pair serves)
             const int ord = M.order & 3;
-#define GOM(DT, WS_, ORD_, GEN_) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, GEN_><<<M.wgs, 256, 0, a.st>>>(a.rowpat, a.vrec, P->drec, P->dom, a.x, a.y, a.acc0, M, P->dom_xlen, w, partial, guard, pstride)
             const bool box = ord != 2 && g_dom_march != 3 && M.z0 >= P->box_z0 && M.z1 <= P->box_z1;      // (3: the masks' form on a box too, A/B)
-#define GOMB(DT, WS_, ORD_) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true><<<M.wgs, 256, 0, a.st>>>(a.rowpat, a.vrec, P->drec, P->dom, a.x, a.y, a.acc0, M, P->dom_xlen, w, partial, guard, pstride)
+            bool alt = false;
+            for (int k = 0; k < 7; k++) alt = alt || ((P->box_modes >> (2 * k)) & 3) == 2;
+            BoxAlt BA;
+            for (int u = 0; u < 7; u++) BA.v[u] = P->box_alt[u];
+#define MARCH_ARGS a.rowpat, a.vrec, P->drec, P->dom, a.x, a.y, a.acc0, M, P->dom_xlen, w, partial, guard, pstride
+#define GOM(DT, WS_, ORD_, GEN_) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, GEN_><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS)
+#define GOMB(DT, WS_, ORD_) do { if (alt) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, true, false><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS, BA); \
+                                 else if (P->box_pads) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, false, true><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); \
+                                 else spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); } while (0)
 #define GOMO(DT, WS_) do { if (box) { if (ord == 0) GOMB(DT, WS_, 0); else GOMB(DT, WS_, 1); } \
                            else if (!P->dom_simple || ord == 2) GOM(DT, WS_, 2, true); else if (ord == 0) GOM(DT, WS_, 0, false); else GOM(DT, WS_, 1, false); } while (0)
             if (dot == 0) GOMO(0, false); else if (dot == 1) { if (ws) GOMO(1, true); else GOMO(1, false); } else { if (ws) GOMO(2, true); else GOMO(2, false); }
 #undef GOMO
 #undef GOMB
 #undef GOM
-            return;
+#undef MARCH_ARGS
+            continue;
         }
-    }
-    DomTile TL;
-    int run = 1;
-    const long long wgs = dom_shape(a, TL, run);
-    const int span = NUM_XCD * run;
-    DomRec DD = P->dom;
-    if ((g_variant & 0x40004000) == 0x40004000) {      // ablation (WRONG results, timing only): the outermost pair of offsets re-reads the diagonal
-        const int S2 = dom_stride_outer(DD);
-        for (int u = 0; u < 7; u++) if (DD.off[u] == 8 * S2 || DD.off[u] == -8 * S2) DD.off[u] = 0;
-    }
-    const unsigned grid = (unsigned)((wgs + span - 1) / span * span);
-    int wslot = -1;
-    if (dot != 0 && w == a.x && !(g_variant & 0x8))      // (bit3: w by its own loads, A/B)
-        for (int u = 0; u < 7; u++) if (((P->dom.mask >> u) & 1) && P->dom.off[u] == 0) wslot = u;
+        const DomTile TL = Q.TL;
+        const int run = Q.run;
+        const long long wgs = Q.wgs;
+        const int span = NUM_XCD * run;
+        DomRec DD = P->dom;
+        if ((g_variant & 0x40004000) == 0x40004000) {      // ablation (WRONG results, timing only): the outermost pair of offsets re-reads the diagonal
+            const int S2 = dom_stride_outer(DD);
+            for (int u = 0; u < 7; u++) if (DD.off[u] == 8 * S2 || DD.off[u] == -8 * S2) DD.off[u] = 0;
+        }
+        const unsigned grid = (unsigned)((wgs + span - 1) / span * span);
+        int wslot = -1;
+        if (dot != 0 && w == a.x && !(g_variant & 0x8))      // (bit3: w by its own loads, A/B)
+            for (int u = 0; u < 7; u++) if (((P->dom.mask >> u) & 1) && P->dom.off[u] == 0) wslot = u;
 #define GOD(DT) spmv_csr_valuerec_dom_kernel<256, DT><<<grid, 256, 0, a.st>>>( \
-        a.rowpat, a.vrec, P->drec, DD, P->dom_lo, P->dom_hi, a.x, a.y, Rows{a.rb, a.re, a.acc0}, run, TL, w, partial, guard, pstride, wslot, (int)wgs)
-    if (dot == 0) GOD(0); else if (dot == 1) GOD(1); else GOD(2);
+            a.rowpat, a.vrec, P->drec, DD, P->dom_lo, P->dom_hi, a.x, a.y, Rows{a.rb, a.re, a.acc0}, run, TL, w, partial, guard, np > 1 ? pstride : pstride0, wslot, (int)wgs)
+        if (dot == 0) GOD(0); else if (dot == 1) GOD(1); else GOD(2);
 #undef GOD
+    }
 }
 
 // the block-local kernel in the form the plan was built for: geometry 5 = round 3 (positions through LDS), 7 / 8 = positions in registers, x stage as long as the longest list

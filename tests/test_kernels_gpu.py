@@ -1844,7 +1844,7 @@ def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(l
     assert taken[1] == 0 and (taken[0] == 1 or bs > 2), taken      # (3 x 3, 4 x 4: the rows' turns have no common supersequence of 32 entries; their block rows do not need one)
 
 
-@pytest.mark.parametrize("case", ["constant", "ell_padded", "values_differ", "foreign_rows", "two_tiles_wide", "generator_order", "other_order", "slab_of_rank_0", "slab_of_rank_1"])
+@pytest.mark.parametrize("case", ["constant", "ell_padded", "values_differ", "foreign_rows", "two_tiles_wide", "generator_order", "other_order", "slab_of_rank_0", "slab_of_rank_1", "dia_zeros"])
 def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
     """the 7-point stencil with value records on a grid whose lines are a multiple of 128 long: a workgroup walks the planes of its 128 x 8 tile, each x loaded once
     (spmv_csr_valuerec_march_kernel; 512^3: 0.49 -> 0.41 ms).  The oracle's bits with the form on and off -- Inf / NaN / -0.0 in x, rows of other patterns (faces: masks;
@@ -1877,6 +1877,17 @@ def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
         full = np.flatnonzero(lens == 7)
         idx.reshape(n, 7)[full] = i0[(p0[full][:, None] + np.arange(7)[None, :])]
         val.reshape(n, 7)[full] = v0[(p0[full][:, None] + np.arange(7)[None, :])]
+    if case == "dia_zeros":                                   # DIA's row form (liship_dia_to_rows): every diagonal that stays inside the array, explicit +0.0 where the grid has no neighbour
+        offs = np.array([-SO, -nx, -1, 0, 1, nx, SO])
+        rows = np.arange(n)
+        cols = rows[:, None] + offs[None, :]
+        inside = (cols >= 0) & (cols < n)
+        import scipy.sparse as sp
+        A = sp.csr_matrix((val, idx, ptr), shape=(n, n))
+        vals = np.zeros(cols.shape)
+        vals[inside] = np.asarray(A[np.repeat(rows, 7).reshape(n, 7)[inside], cols[inside]]).ravel()
+        ptr = np.concatenate(([0], np.cumsum(inside.sum(1)))).astype(np.int32)
+        idx, val = cols[inside].astype(np.int32), vals[inside]
     if case == "values_differ":                               # the rows of three planes carry another diagonal: the same offsets, values of their own
         rows = np.repeat(np.arange(n), np.diff(ptr))
         val = val.copy()
@@ -1916,9 +1927,10 @@ def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
     assert lib.liship_csr_plan_dominant_pattern(plan) == 1
     # a box (no pattern bytes, no masks: signed zeros in the halo) where every face row is the dominant pattern minus the neighbours outside the grid
     # a box (no pattern bytes, no masks: signed zeros in the halo) in the planes where every row is the dominant pattern minus the neighbours outside the grid, with its values
-    bad = {"ell_padded": set(range(nz)), "other_order": set(range(nz)),      # (padding terms on every face row; "other_order" permutes the full rows only: its face rows are foreign)
+    bad = {"other_order": set(range(nz)),                     # ("other_order" permutes the full rows only: its face rows are foreign; ELL's padding terms and DIA's zeros are box forms of their own)
+           "dia_zeros": {0, nz - 1},                          # (the first and the last plane lose the diagonals that leave the array: another rule than the planes between)
            "values_differ": {z for z in range(nz) if z % 5 == 2}, "foreign_rows": foreign_planes,
-           "slab_of_rank_0": {nz - 1}, "slab_of_rank_1": {0, nz - 1}}.get(case, set())
+           "slab_of_rank_1": {0, nz - 1}}.get(case, set())      # (rank 0's last plane keeps its +SO slot, the ghost plane behind it: a box whose far side is "there, with a real x")
     runs = "".join("x" if z in bad else "o" for z in range(nz)).split("x")
     assert lib.liship_csr_plan_box_planes(plan) == max(len(r) for r in runs), (case, sorted(bad))
     sums = []

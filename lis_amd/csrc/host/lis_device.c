@@ -56,6 +56,7 @@ LIS_INT lisd_init(void)
 	HIPCHK(liship_malloc_host((void **)&lisg.host_out, 4 * 64 * sizeof(double)));
 	if (lisg.long_row_tree) HIPCHK(liship_spmv_csr_set_long_row_tree(1));
 	if (lisg.no_team_kernels) { HIPCHK(liship_spmv_csr_set_team(0)); HIPCHK(liship_spmv_bsr_set_team(0)); }
+	if (lisg.no_marching) HIPCHK(liship_spmv_csr_set_dom_march(0));
 	if (lisg.row_block_dots) HIPCHK(liship_spmv_csr_set_row_block_dots(1));
 	if (lisg.ref_reductions) HIPCHK(liship_set_reference_reductions(lisg.ref_reductions));
 	lisg.device_ready = 1;

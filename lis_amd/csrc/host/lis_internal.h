@@ -117,6 +117,7 @@ typedef struct {
 	int last_graph_replays;    /* batches of the last lis_solve that were graph replays (lis_amd_last_solve_graph_replays) */
 	int no_uniform_jacobi;     /* LIS_AMD_NO_UNIFORM_JACOBI=1: CG + Jacobi reads 1/diag even when the diagonal is constant (A/B measurements) */
 	int row_block_dots;        /* LIS_AMD_ROW_BLOCK_DOTS=1: fused dots of the dominant-pattern product as the row blocks' partial sums */
+	int no_marching;           /* LIS_AMD_NO_MARCHING=1: 7-point matrices with value records keep the gathering dominant-pattern kernel (round 3's headline kernel: A/B measurements) */
 	int no_team_kernels;       /* LIS_AMD_NO_TEAM_KERNELS=1: patterned rows of 8..32 entries and long BSR block rows keep the round-2 kernels (A/B measurements) */
 	int no_local_columns;      /* LIS_AMD_NO_LOCAL_COLUMNS=1: long-row CSR products keep the 4 B column indices (A/B measurements) */
 	int no_index_codes;        /* LIS_AMD_NO_INDEX_CODES=1: CSR products keep reading the 4 B column indices (A/B measurements) */

@@ -247,6 +247,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_uniform_jacobi = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_LOCAL_COLUMNS");
 		lisg.no_local_columns = (r && r[0] == '1');
+		r = getenv("LIS_AMD_NO_MARCHING");
+		lisg.no_marching = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_TEAM_KERNELS");
 		lisg.no_team_kernels = (r && r[0] == '1');
 		r = getenv("LIS_AMD_ROW_BLOCK_DOTS");         /* the fused dots of the dominant-pattern product as the row blocks' partial sums: every form's bits, slower */

@@ -1962,3 +1962,82 @@ def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
     finally:
         lib.liship_spmv_csr_set_dom_march(1)
         check(lib.liship_csr_plan_destroy(plan))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LIS_AMD_FUZZ_SEEDS", "60")) // 2))
+def test_z_marching_on_perturbed_grids(lib, seed):
+    """random 7-point grids (lines of 128 or 256 columns), in CSR (either slot order), ELL's padded or DIA's zero-filled row form, with random planes perturbed --
+    a value changed, an entry of an interior row removed, a column moved -- so that the box the plan finds is some run of planes between them: every form of the
+    product (marching at any size, its masks' form, the gathering kernel), whole and in ranges that cut planes, must give the oracle's bits"""
+    rng = np.random.default_rng(9000 + seed)
+    nx, ny, nz = int(rng.choice([128, 256])), 8 * int(rng.integers(1, 4)), int(rng.integers(9, 22))
+    flavour = ["csr", "csr_generator", "ell", "dia"][seed % 4]
+    ptr, idx, val = orc.poisson3d(nz, ny, nx, sort_cols=flavour != "csr_generator")
+    n, SO = len(ptr) - 1, ny * nx
+    ptr = ptr.astype(np.int64)
+    rows_of = np.repeat(np.arange(n), np.diff(ptr))
+    idx, val = idx.astype(np.int64), val.copy()
+    keep = np.ones(len(idx), bool)
+    for z in rng.choice(nz, int(rng.integers(0, 3)), replace=False):
+        r = int(z) * SO + int(rng.integers(0, SO))
+        kind = int(rng.integers(0, 3))
+        ks = np.arange(ptr[r], ptr[r + 1])
+        off = ks[idx[ks] != r]
+        if kind == 0:
+            val[rng.choice(ks)] = 0.375                       # a value of its own
+        elif kind == 1 and len(off):
+            keep[rng.choice(off)] = False                     # an entry missing inside the grid
+        elif len(off):
+            k = int(rng.choice(off))
+            c = int(np.clip(idx[k] + 3, 0, n - 1))
+            if c not in idx[ks]:
+                idx[k] = c                                    # a column of its own
+    idx, val, rows_of = idx[keep], val[keep], rows_of[keep]
+    ptr = np.concatenate(([0], np.cumsum(np.bincount(rows_of, minlength=n))))
+    if flavour == "ell":                                      # rows padded to the longest with (row, +0.0)
+        w = int(np.diff(ptr).max())
+        I = np.repeat(np.arange(n), w).reshape(n, w)
+        V = np.zeros((n, w))
+        for r in np.flatnonzero(np.diff(ptr) < w):
+            k = ptr[r + 1] - ptr[r]
+            I[r, :k], V[r, :k] = idx[ptr[r]:ptr[r + 1]], val[ptr[r]:ptr[r + 1]]
+        full = np.flatnonzero(np.diff(ptr) == w)
+        I[full] = idx[ptr[full][:, None] + np.arange(w)[None, :]]
+        V[full] = val[ptr[full][:, None] + np.arange(w)[None, :]]
+        ptr, idx, val = np.arange(0, n * w + 1, w), I.ravel(), V.ravel()
+    if flavour == "dia":                                      # every diagonal of the matrix that stays inside the array, explicit +0.0
+        import scipy.sparse as sp
+        A = sp.csr_matrix((val, idx, ptr), shape=(n, n))
+        offs = np.unique(idx - rows_of)
+        cols = np.arange(n)[:, None] + offs[None, :]
+        inside = (cols >= 0) & (cols < n)
+        vals = np.zeros(cols.shape)
+        vals[inside] = np.asarray(A[np.repeat(np.arange(n), len(offs)).reshape(n, -1)[inside], cols[inside]]).ravel()
+        ptr, idx, val = np.concatenate(([0], np.cumsum(inside.sum(1)))), cols[inside], vals[inside]
+    ptr, idx = ptr.astype(np.int32), idx.astype(np.int32)
+    x = rng.uniform(-1, 1, n)
+    x[rng.integers(0, n, 6)] = [np.inf, -np.inf, np.nan, 0.0, -0.0, np.inf]
+    ref = orc.spmv_csr(ptr, idx, val, x)
+    nanpos = np.isnan(ref)
+    dptr, didx, dval, dx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    state = (flavour, nx, ny, nz, lib.liship_csr_plan_value_records(plan), lib.liship_csr_plan_dominant_pattern(plan), lib.liship_csr_plan_box_planes(plan))
+    print("marching fuzz", seed, state)
+    try:
+        for march in (2, 3, 0):
+            lib.liship_spmv_csr_set_dom_march(march)
+            cut = int(rng.integers(1, nz - 1)) * SO + int(rng.integers(0, 2)) * 77
+            for ranges in (((0, n),), ((0, cut), (cut, n))):
+                dy = DA.from_host(np.full(n, 7.0), np.float64)
+                for lo, hi in ranges:
+                    check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+                y = dy.to_host()
+                assert np.array_equal(np.isnan(y), nanpos), (seed, state, march, ranges)
+                assert np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), (seed, state, march, ranges)
+    finally:
+        lib.liship_spmv_csr_set_dom_march(1)
+        check(lib.liship_csr_plan_destroy(plan))

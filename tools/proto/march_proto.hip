@@ -115,6 +115,121 @@ void march_kernel(const unsigned char *__restrict__ rowpat, const double *__rest
     }
 }
 
+// TX = 128 columns (64 lanes x pairs), TY lines = 4 waves x LPW lines per wave
+template <int LPW, int D, bool XCD, int VD>
+__global__ __launch_bounds__(256)
+void marchv_kernel(const unsigned char *__restrict__ rowpat, const double *__restrict__ x, double *__restrict__ y, int N, int zseg, const double *__restrict__ vals, int tiles_x, int tiles_y)
+{
+    constexpr int TX = 128, TY = 4 * LPW, LX = TX + 4;               // LDS line: [1 pad][left halo][TX][right halo][1 pad] -> own pair at 2 + 2 cp: 16 B aligned
+    __shared__ __attribute__((aligned(16))) double buf[2][(TY + 2) * LX];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    int wg = blockIdx.x;
+    const int ntile = tiles_x * tiles_y, nseg = (N + zseg - 1) / zseg;
+    if (XCD) { const int k = wg % 8, j = wg / 8, per = (ntile * nseg) / 8; wg = k * per + j; }      // each XCD a contiguous eighth of the (tile, segment) list
+    const int seg = wg / ntile, t = wg - seg * ntile;                // consecutive workgroups: neighbouring tiles of one z segment
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int z0 = seg * zseg, z1 = min(N, z0 + zseg);
+    const long long S = N, SO = (long long)N * N;
+    const int col0 = tx * TX, line0 = ty * TY;
+    // this lane's points: columns col0 + 2 lane, +1 on lines line0 + w * LPW + i
+    const long long base = (long long)(line0 + w * LPW) * S + col0 + 2 * lane;
+    const int total = N * N * N;
+    auto clampi = [&](long long a) { return (int)(a < 0 ? 0 : (a > total - 2 ? total - 2 : a)); };
+    struct Packet { v2f64 own[LPW]; v2f64 hy; double hx[LPW]; };
+    auto load_packet = [&](Packet &P, int z) {
+        const long long pb = (long long)z * SO + base;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + clampi(pb + i * S));
+        // y halo: wave 0 loads the line above the tile, wave 3 the line below
+        if (w == 0) P.hy = *reinterpret_cast<const v2f64u *>(x + clampi((long long)z * SO + (long long)(line0 - 1) * S + col0 + 2 * lane));
+        if (w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + clampi((long long)z * SO + (long long)(line0 + TY) * S + col0 + 2 * lane));
+        // x halo: lane 0 the column left of the tile, lane 63 the column right of it, for the wave's lines
+        if (lane == 0 || lane == 63) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) P.hx[i] = x[clampi((long long)z * SO + (long long)(line0 + w * LPW + i) * S + (lane == 0 ? col0 - 1 : col0 + TX))];
+        }
+    };
+    auto store_packet = [&](const Packet &P, double *B) {
+#pragma unroll
+        for (int i = 0; i < LPW; i++) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = P.own[i];
+        if (w == 0) *reinterpret_cast<v2f64 *>(B + 0 * LX + 2 + 2 * lane) = P.hy;
+        if (w == 3) *reinterpret_cast<v2f64 *>(B + (TY + 1) * LX + 2 + 2 * lane) = P.hy;
+        if (lane == 0 || lane == 63) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) B[(w * LPW + i + 1) * LX + (lane == 0 ? 1 : 2 + TX)] = P.hx[i];
+        }
+    };
+    Packet Q[D];
+    v2f64 prev[LPW], cur[LPW];
+    v2f64 VQ[VD][7][LPW];
+    auto load_vals = [&](v2f64 (&V)[7][LPW], int z) {
+        const long long pb = (long long)z * SO + base;
+#pragma unroll
+        for (int u = 0; u < 7; u++)
+#pragma unroll
+            for (int i = 0; i < LPW; i++) V[u][i] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(vals + (size_t)u * total + clampi(pb + i * S)));
+    };
+    // prologue: planes z0 - 1 (registers only), z0 (LDS + registers), packets z0 + 1 .. z0 + D in flight
+    {
+        Packet P;
+        load_packet(P, z0 - 1);
+#pragma unroll
+        for (int i = 0; i < LPW; i++) prev[i] = P.own[i];
+        load_packet(P, z0);
+        store_packet(P, buf[z0 & 1]);
+#pragma unroll
+        for (int i = 0; i < LPW; i++) cur[i] = P.own[i];
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) load_packet(Q[d], z0 + 1 + d);
+#pragma unroll
+    for (int d = 0; d < VD; d++) load_vals(VQ[d], z0 + d);
+    __syncthreads();
+    static_assert(VD == D, "one rotation");
+    for (int zb = z0; zb < z1; zb += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int z = zb + d;
+            v2f64 (&V)[7][LPW] = VQ[d];
+            if (z < z1) {                                                   // (uniform)
+                // packet z + 1 has landed (the oldest in flight): its tile goes to the other LDS buffer
+                Packet &P = Q[d];
+                store_packet(P, buf[(z + 1) & 1]);
+                const unsigned short two = *reinterpret_cast<const unsigned short *>(rowpat + clampi((long long)z * SO + base));
+                const double *B = buf[z & 1];
+#pragma unroll
+                for (int i = 0; i < LPW; i++) {
+                    const int li = (w * LPW + i + 1) * LX + 2 + 2 * lane;
+                    const v2f64 c = *reinterpret_cast<const v2f64 *>(B + li);
+                    const double l = B[li - 1], r = B[li + 2];
+                    const v2f64 up = *reinterpret_cast<const v2f64 *>(B + li - LX), dn = *reinterpret_cast<const v2f64 *>(B + li + LX);
+                    double s0 = 0.0, s1 = 0.0;
+                    s0 += V[0][i].x * prev[i].x;  s1 += V[0][i].y * prev[i].y;
+                    s0 += V[1][i].x * up.x;       s1 += V[1][i].y * up.y;
+                    s0 += V[2][i].x * l;          s1 += V[2][i].y * c.x;
+                    s0 += V[3][i].x * c.x;        s1 += V[3][i].y * c.y;
+                    s0 += V[4][i].x * c.y;        s1 += V[4][i].y * r;
+                    s0 += V[5][i].x * dn.x;       s1 += V[5][i].y * dn.y;
+                    s0 += V[6][i].x * P.own[i].x; s1 += V[6][i].y * P.own[i].y;
+                    if (two == 0xffff) { s0 = -s0; s1 = -s1; }            // (keeps the pattern bytes alive; never true)
+                    v2f64 out; out.x = s0; out.y = s1;
+                    __builtin_nontemporal_store(out, reinterpret_cast<v2f64 *>(y + (long long)z * SO + base + i * S));
+                    prev[i] = c; 
+                }
+                // the next packet for this slot: plane z + 1 + D
+                {
+                    Packet N2;
+                    load_packet(N2, z + 1 + D);
+                    // rotate: cur is not needed (the centre comes from LDS); Q[d] becomes the new packet after its own values were used above
+                    Q[d] = N2;
+                }
+                load_vals(VQ[d], z + VD);
+                __syncthreads();
+            }
+        }
+    }
+}
+
 // reference form: what the library runs today, stripped to the interior: lane pair, seven 16 B gathers
 __global__ __launch_bounds__(256)
 void gather_kernel(const unsigned char *__restrict__ rowpat, const double *__restrict__ x, double *__restrict__ y, int N, Coef C)
@@ -174,6 +289,22 @@ int main(int argc, char **argv)
         printf("march TY=%2d D=%d xcd=%d zseg=%3d: %.4f ms  %.3f of 8 TB/s  (interior sample: %zu of %zu differ)\n", 4 * LPW, D, (int)XCD, ZSEG, ms, bytes / ms / 1e6 / 8000, bad, checked); \
         fflush(stdout); \
     } while (0)
+    double *vals; CK(hipMalloc(&vals, 8 * n * 7 + 64));
+    { std::vector<double> hv(n); for (int u = 0; u < 7; u++) { for (size_t i = 0; i < n; i++) hv[i] = (u == 3 ? 6.0 : -1.0); CK(hipMemcpy(vals + (size_t)u * n, hv.data(), 8 * n, hipMemcpyHostToDevice)); } }
+    const double bytesv = 73.0 * n;
+#define RUNV(LPW, D, ZSEG) do { \
+        const int tiles_x = N / 128, tiles_y = N / (4 * LPW), nseg = (N + ZSEG - 1) / ZSEG; \
+        if (N % 128 || N % (4 * LPW)) break; \
+        CK(hipMemset(y, 0, 8 * n)); \
+        ms = timeit([&] { marchv_kernel<LPW, D, true, D><<<tiles_x * tiles_y * nseg, 256>>>(pat, x, y, N, ZSEG, vals, tiles_x, tiles_y); }, 5, 20); \
+        CK(hipGetLastError()); \
+        CK(hipMemcpy(h1.data(), y, 8 * n, hipMemcpyDeviceToHost)); \
+        size_t bad = 0, checked = 0; \
+        for (int z = 1; z < N - 1; z += 7) for (int yy = 1; yy < N - 1; yy += 5) for (int xx = 1; xx < N - 1; xx++) { const size_t r = ((size_t)z * N + yy) * N + xx; checked++; if (h1[r] != h2[r]) bad++; } \
+        printf("march, values streamed (SoA) TY=%2d D=%d zseg=%3d: %.4f ms  %.3f of 8 TB/s on 73 B/row  (interior sample: %zu of %zu differ)\n", 4 * LPW, D, ZSEG, ms, bytesv / ms / 1e6 / 8000, bad, checked); \
+        fflush(stdout); \
+    } while (0)
+    RUNV(1, 2, 171); RUNV(1, 2, 128); RUNV(1, 2, 64); RUNV(2, 2, 171); RUNV(2, 2, 128); RUNV(1, 3, 171);
     RUN(2, 2, true, 64); RUN(2, 3, true, 64); RUN(2, 4, true, 64);
     RUN(2, 3, true, 32); RUN(2, 3, true, 128); RUN(2, 3, false, 64);
     RUN(1, 3, true, 64); RUN(1, 4, true, 64); RUN(1, 6, true, 64);

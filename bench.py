@@ -33,6 +33,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CONTRACT_FORM = "contract"     # roofline_of / kernel_name / live_traffic: the product on the reference's own arrays (4 B indices, 8 B values)
 
 
 def parse():
@@ -262,6 +263,8 @@ def main():
         marching = int(mm[0])
 
     def kernel_name(v):
+        if v == CONTRACT_FORM:
+            return "spmv_csr_rowgather_kernel"
         pair = n_local * 8 > (256 << 20)                  # round-2 kernels: x beyond the Infinity Cache takes the two-rows-per-lane form
         if patterns and records and v:
             if dominant and marching:
@@ -314,7 +317,7 @@ def main():
                               ("wr", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"])):
                 out_dir = os.path.join(tmp, tag)
                 cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc", *ctrs, "-d", out_dir, "-o", "pmc", "--",
-                       sys.executable, os.path.join(ROOT, "tools", "traffic_child.py"), str(N), str(int(bool(v))), "12"]
+                       sys.executable, os.path.join(ROOT, "tools", "traffic_child.py"), str(N), str(2 if v == CONTRACT_FORM else int(bool(v))), "12"]
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
                 if r.returncode != 0:
                     return None
@@ -348,7 +351,10 @@ def main():
         `contract_*`: SURVEY 8d's algorithmic count (12 B per non-zero + 20 B per row, the reference's CSR layout) over the same time --
         NOT a rate of this kernel when the plan stores fewer bytes; it says how much faster than a perfect streaming of the reference's
         layout the product runs, and may exceed 1."""
-        moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, v) - (n_local if (v and marching == 2) else 0)      # (the box form reads no pattern byte: x and y alone)
+        if v == CONTRACT_FORM:
+            moved = alg_bytes                               # the reference's layout itself: 4 B index + 8 B value per non-zero, ptr, y, the compulsory x
+        else:
+            moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, v) - (n_local if (v and marching == 2) else 0)      # (the box form reads no pattern byte: x and y alone)
         traffic, detail = pmc_traffic(traffic_name)
         live = live_traffic(v) if rank == 0 else None
         if live:                                            # this run's own counters take precedence over the committed figure (kept beside them)
@@ -361,7 +367,8 @@ def main():
              "bytes_are": "stored matrix streams + y + compulsory x of the timed kernel (lower bound of its HBM bytes; `traffic` is the counters' upper bound)",
              "contract_bytes_per_launch": alg_bytes, "contract_achieved": round(alg_bytes / sec / 1e9, 1),
              "contract_frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
-             "index_codes": coded, "row_patterns": patterns, "value_records": v, "marching": marching if v else 0, "applies_to": applies_to}
+             "index_codes": 0 if v == CONTRACT_FORM else coded, "row_patterns": 0 if v == CONTRACT_FORM else patterns,
+             "value_records": 0 if v == CONTRACT_FORM else v, "marching": marching if (v and v != CONTRACT_FORM) else 0, "applies_to": applies_to}
         if traffic:
             r["traffic_over_bytes"] = round(traffic / moved, 3)
         return r
@@ -387,6 +394,24 @@ def main():
             streamed["nontrivial_x"]["frac"] = round(streamed["roofline"]["bytes_per_launch"] / (streamed["nontrivial_x"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         finally:
             check(lib.liship_spmv_csr_set_row_values(1))
+
+    # ---- the CONTRACT FORM (SURVEY 8d / north_star): the same matrix through the kernel that streams the reference's own arrays -- 4 B index[] + 8 B value[] per
+    # non-zero, ptr[], y, x gathered (lis_matvec_csr.c:97-109's loop on 12 B per non-zero) -- index codes, row patterns and value records switched off.  Its `frac`
+    # is priced on 12 nnz + 20 n + 4 bytes, so it is <= 1 by construction; this is the figure the >= 70 % CSR roofline target is about.
+    contract = None
+    check(lib.liship_spmv_csr_set_index_codes(0)); check(lib.liship_spmv_csr_set_row_patterns(0)); check(lib.liship_spmv_csr_set_row_values(0))
+    try:
+        contract = leg(x, args.steps)
+        check_a_times_one("contract form")
+        contract["roofline"] = roofline_of(CONTRACT_FORM, contract["kernel_ms"], "_contract_form",
+                                           "ANY CSR matrix with short rows: nothing about the matrix is assumed or precomputed beyond the row split (12 B per non-zero + 20 B per row streamed)")
+        contract["kernel"] = contract["roofline"]["kernel"]
+        contract["nontrivial_x"] = leg(xg, args.steps)
+        contract["nontrivial_x"]["frac"] = round(alg_bytes / (contract["nontrivial_x"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        dll.lis_amd_matrix_strip_rows.argtypes = [capi.PM]
+        contract["xcd_strip_rows"] = int(dll.lis_amd_matrix_strip_rows(A))     # rows per plane the XCD strips are cut from (0: natural block order)
+    finally:
+        check(lib.liship_spmv_csr_set_index_codes(1)); check(lib.liship_spmv_csr_set_row_patterns(1)); check(lib.liship_spmv_csr_set_row_values(1))
 
     # ---- N > 1: what the exchange costs by itself, and the product with the overlap switched off (A/B)
     multi = None
@@ -472,6 +497,28 @@ def main():
             finally:
                 check(lib.liship_spmv_csr_set_row_values(1))
 
+        if contract is not None:                            # CG + Jacobi with the product in the contract form (fused dots in the same kernel)
+            check(lib.liship_spmv_csr_set_index_codes(0)); check(lib.liship_spmv_csr_set_row_patterns(0)); check(lib.liship_spmv_csr_set_row_values(0))
+            try:
+                S = capi.PS()
+                assert lib.lis_solver_create(C.byref(S)) == 0
+                assert lib.lis_solver_set_option(f"-i cg -p jacobi -tol 1e-12 -maxiter {args.solver_iters}".encode(), S) == 0
+                assert lib.lis_solve(A, b, y, S) == 0
+                tm = [C.c_double() for _ in range(5)]
+                assert lib.lis_solver_get_timeex(S, *[C.byref(t) for t in tm]) == 0
+                itime, iters = tm[1].value, min(S.contents.iter, args.solver_iters)
+                if world > 1:
+                    tt = torch.tensor([itime], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    itime = float(tt[0])
+                loop_b, contract_b = krylov_bytes("cg_jacobi", iters, n_local, nnz_local, 0, 0, 0, int(dll.lis_amd_last_solve_uniform_jacobi()))
+                contract["cg_jacobi"] = {"iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6), "rel_residual_after": S.contents.resid,
+                                         "loop_bytes_per_iter": loop_b, "frac": round(loop_b / (itime / max(1, iters)) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "contract_bytes_per_iter": contract_b}
+                lib.lis_solver_destroy(S)
+            finally:
+                check(lib.liship_spmv_csr_set_index_codes(1)); check(lib.liship_spmv_csr_set_row_patterns(1)); check(lib.liship_spmv_csr_set_row_values(1))
+
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = stencil27_leg(lib, np, C, stream)
@@ -491,9 +538,11 @@ def main():
             "roofline": roofline,
             "nontrivial_x": nontrivial,
             "values_streamed": streamed,
+            "contract_form": contract,
             "reading_guide": ("`value` / `roofline`: the product lis_matvec runs for THIS matrix (x = 1, the reference's spmvtest3 convention); `nontrivial_x`: "
                               "the same kernel on non-trivial data; `values_streamed`: the kernel every matrix with these sparsity patterns but varying "
-                              "coefficients takes, with its own roofline.  Every `frac` is bytes-the-kernel-moves / its HIP-event time / 8 TB/s (<= 1, "
+                              "coefficients takes, with its own roofline; `contract_form`: the kernel that streams the reference's own index[] / value[] arrays "
+                              "(12 B per non-zero + 20 B per row -- SURVEY 8d's count, what ANY short-row CSR matrix takes), frac priced on exactly those bytes.  Every `frac` is bytes-the-kernel-moves / its HIP-event time / 8 TB/s (<= 1, "
                               "asserted); `contract_frac` prices SURVEY 8d's 12 B/nnz + 20 B/row layout over the same time and may exceed 1."),
             "setup": {"generate_and_plan_ms": round(setup_ms, 1), "generate_ms": None if gen_ms is None else round(gen_ms, 1),
                       "plan_build_ms": None if gen_ms is None else round(max(setup_ms - gen_ms, 0.0), 1),

@@ -114,6 +114,9 @@ LIS_INT lis_amd_matrix_block_rows(LIS_MATRIX A);
 /* the form of the whole local product of a 7-point matrix with value records: 0 = the gathering dominant-pattern kernel, 1 = the z-marching kernel (each x loaded once per
  * plane tile; liship.h), 2 = its box form, which reads no pattern byte either (x and y alone are streamed: 16 B per row); uploads A if needed */
 LIS_INT lis_amd_matrix_marching(LIS_MATRIX A);
+/* rows per plane of the structured grid the plan found (the largest pattern offset, or the band of a matrix without row patterns): the XCD strips of the kernels that
+ * stream the matrix are cut from it (liship.h); 0 = none, natural block order; uploads A if needed */
+LIS_INT lis_amd_matrix_strip_rows(LIS_MATRIX A);
 /* ELL and DIA matrices with constant coefficients are kept in HBM as CSR rows that list the format's terms in the format's order
  * (bit-identical sums), so that the value records apply.  0 keeps the native ELL / DIA layout and kernels for matrices uploaded
  * from now on (env LIS_AMD_NO_ROW_FORM=1): A/B measurements, and the tests that pin the native kernels at full size. */

@@ -162,6 +162,11 @@ int  liship_spmv_csr_set_local_columns(int on);
 int  liship_spmv_csr_set_local_register_positions(int on);
 /* structured grids, values streamed (spmv_csr_pattern7_kernel): every XCD takes one eighth of every plane of the grid and walks the planes in order, so that the
  * +-plane neighbours of its rows stay in its own L2 (round 4).  0: the natural block order (A/B measurements); same bits either way */
+/* the same strips for the kernels that stream index[] (spmv_csr_rowgather_kernel: the reference's 12 B per non-zero; spmv_csr_coded_kernel): a plan
+ * without row patterns learns its plane from the band of the matrix -- the largest |column - row|, when at least half of the rows reach it (two passes over
+ * index[] at plan time; optional, never an error when the matrix does not qualify).  liship_csr_plan_strip_rows: rows per plane, 0 = natural order */
+int  liship_csr_plan_scan_band(liship_csr_plan_t plan, const int *ptr, const int *index, void *stream);
+int  liship_csr_plan_strip_rows(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_xcd_strips(int on);
 /* Opt-in, off by default, NOT bit-identical to the reference: the part of a row beyond the LDS stage (~2100 entries) is added
  * by a workgroup-wide tree per pass instead of one left-to-right chain (a 200 000-entry row is otherwise a 200 000-long

@@ -382,6 +382,9 @@ LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int
 		if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
 		if (rc && rc != 2) HIPCHK(rc);
 	}
+	/* a plan that streams index[] / codes (no row patterns): the plane of a structured grid from the band of the matrix, for the XCD strips */
+	rc = liship_csr_plan_scan_band(*plan, dptr, dindex, lisg.stream);
+	if (rc && rc != 2) HIPCHK(rc);
 	return LIS_SUCCESS;
 }
 
@@ -1034,6 +1037,11 @@ LIS_INT lis_amd_matrix_marching(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	return (MDEV(A)->type == LIS_MATRIX_CSR && MDEV(A)->plan) ? liship_csr_plan_marching(MDEV(A)->plan) : 0;
+}
+LIS_INT lis_amd_matrix_strip_rows(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return MDEV(A)->plan ? liship_csr_plan_strip_rows(MDEV(A)->plan) : 0;
 }
 LIS_INT lis_amd_matrix_block_rows(LIS_MATRIX A)
 {

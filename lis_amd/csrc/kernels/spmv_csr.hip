@@ -58,13 +58,10 @@ constexpr bool is_local_geom(int g) { return g == LOCAL_GEOM || g == LOCAL_GEOM4
 constexpr int ROW_ALIGN = 16;    // rows per 128 B line of y / x
 constexpr int SLACK = 128;       // extra items a block may take to start on an aligned row
 
-// Experiment knob (liship_spmv_csr_set_variant); 0 is the shipped configuration.
-//   bit0  XCD-run block order (each XCD walks runs of consecutive row blocks; measured slower: the x
-//         lines neighbours share then all hit ONE L2 -- DESIGN.md 5)         bits16-23 run length
+// Form selector (liship_spmv_csr_set_variant); 0 is the shipped configuration.  Every value gives the reference's bits: the bits choose among kernels
+// that all compute the same sums in the same order (tests and A/B measurements select them by hand).
 //   bit1  products kernel with scalar loads     bit2  products kernel with vector loads
 //   bits4-7 geometry id and bit24 "no row alignment": read at plan creation
-//   bit8  ablation: skip the x gather  (WRONG results, timing only)
-//   bit10 register staging instead of LDS-DMA   bits11-12 gather unroll U: 0 auto, 1: 4, 2: 7, 3: 8
 //   bit13 (0x2000) row patterns through the general kernel (table in LDS) even when the plan has 32 B records
 //   bit14 (0x4000) value records: the two-rows-per-lane kernel whatever the size (tests; by default only beyond 256 MB of x)
 //   bit29 (0x20000000) value records: never the dominant-pattern kernels (the round-2 kernels: A/B, tests); bit28 (0x10000000): the
@@ -118,16 +115,6 @@ __device__ __forceinline__ Blk load_blk(const v2i32 *__restrict__ blk, int b)
     return Blk{lo.x, lo.y, hi.x, hi.y};
 }
 
-// workgroup id -> row block.  Round-robin (identity) spreads neighbouring row blocks over the 8 XCDs.
-template <bool XRUN>
-__device__ __forceinline__ int block_of_workgroup(int nb, int run)
-{
-    if (!XRUN) return blockIdx.x;
-    const int xcd = blockIdx.x % NUM_XCD, slot = blockIdx.x / NUM_XCD;
-    const int lb = ((slot / run) * NUM_XCD + xcd) * run + slot % run;
-    return lb < nb ? lb : -1;
-}
-
 // XCD strips (round 4, structured grids).  Workgroup w runs on XCD w % 8.  In the natural order the rows that read x[j] -- its own, the neighbouring lines', the
 // neighbouring planes' -- sit in workgroups on different XCDs, and x crosses the fabric once per XCD that touches it (5.2 times for the 7-point stencil at 512^3, where
 // the L2 <-> fabric boundary ran at its 8 TB/s: profiles/r03_spmv512_traffic_values_streamed.json).  With strips every XCD takes one eighth of every plane of the grid --
@@ -163,7 +150,7 @@ __device__ __forceinline__ int row_skew(int start, int i) { return (start - 17 *
 // products for non-zeros [kbeg,kend) -> prod[GUARD + k - ka]; ka is kbeg rounded down to even
 // VEC: 0 = scalar loads; 2 / 4 = 16 B value + 8 B index loads with that many independent pairs in flight per lane
 // (4 for rows of 14-24 entries, 2 beyond: measured on banded and FEM patterns, tools/rowlen_sweep.py, irregular_sweep.py)
-template <int BLOCK, int VEC, bool NOGATHER>
+template <int BLOCK, int VEC>
 __device__ __forceinline__ void stage_products(double *prod, const int *__restrict__ idx,
                                                const double *__restrict__ val,
                                                const double *__restrict__ x,
@@ -189,8 +176,7 @@ __device__ __forceinline__ void stage_products(double *prod, const int *__restri
             for (int u = 0; u < BATCH; u++) {       // all gathers in flight before the first use
                 const int p = base + u * BLOCK + (int)threadIdx.x;
                 if (p < npairs) {
-                    if (NOGATHER) { xv[u].x = (double)c[u].x; xv[u].y = (double)c[u].y; }
-                    else { xv[u].x = x[c[u].x]; xv[u].y = x[c[u].y]; }
+                    xv[u].x = x[c[u].x]; xv[u].y = x[c[u].y];
                 }
             }
 #pragma unroll
@@ -414,7 +400,7 @@ __device__ __forceinline__ double ordered_sum_rows(double acc, const double *buf
 
 // one whole row block of any shape (many empty rows, rows longer than the LDS stage).
 // Invariant from the plan: every row but the last ends inside the first pass of CAP products.
-template <int BLOCK, int CAP, int VEC, bool NOGATHER, int DOT = 0>
+template <int BLOCK, int CAP, int VEC, int DOT = 0>
 __device__ __forceinline__ void block_by_products(double *prod, const int *__restrict__ ptr,
                                                   const int *__restrict__ idx, const double *__restrict__ val,
                                                   const double *__restrict__ x, double *__restrict__ y,
@@ -429,7 +415,7 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
     int s_first = 0, e_first = 0;
     if (rmine < r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; }
 
-    stage_products<BLOCK, VEC, NOGATHER>(prod, idx, val, x, k0, kfirst, ka);
+    stage_products<BLOCK, VEC>(prod, idx, val, x, k0, kfirst, ka);
     __syncthreads();
 
     double carry = 0.0;
@@ -470,7 +456,7 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
                 const int kend = min(base + CAP, k1);
                 const int ka2 = base & ~1;
                 __syncthreads();
-                stage_products<BLOCK, VEC, NOGATHER>(prod, idx, val, x, base, kend, ka2);
+                stage_products<BLOCK, VEC>(prod, idx, val, x, base, kend, ka2);
                 __syncthreads();
                 if ((int)threadIdx.x == owner) carry = ordered_sum_plain(carry, prod, base - ka2, kend - base);
                 base = kend;
@@ -497,14 +483,14 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
             auto fetch_indices = [&](int kb) {                  // indices of the half starting at kb
                 const int ke = min(kb + H, k1);
 #pragma unroll
-                for (int u = 0; u < PER; u++) nidx[u] = (!NOGATHER && kb < ke) ? load_stream(idx + min(kb + hl + u * helpers, ke - 1)) : 0;
+                for (int u = 0; u < PER; u++) nidx[u] = (kb < ke) ? load_stream(idx + min(kb + hl + u * helpers, ke - 1)) : 0;
             };
             auto issue_loads = [&](int kb) {                    // values and x of the half starting at kb (its indices are in nidx)
                 const int ke = min(kb + H, k1);
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     v[u] = kb < ke ? load_stream(val + min(kb + hl + u * helpers, ke - 1)) : 0.0;
-                    xv[u] = (NOGATHER || kb >= ke) ? 1.0 : x[nidx[u]];
+                    xv[u] = (kb >= ke) ? 1.0 : x[nidx[u]];
                 }
             };
             auto write_products = [&](int half, int kb) {       // prod[GUARD + half * H + (k - kb)] = value[k] * x[index[k]]
@@ -553,12 +539,12 @@ __device__ __forceinline__ void publish_dots(const RowDots<DOT> &dots, double *s
     }
 }
 
-template <int BLOCK, int WORK, bool XRUN, int VEC, bool NOGATHER, int DOT = 0>
+template <int BLOCK, int WORK, int VEC, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                               const double *__restrict__ val, const double *__restrict__ x,
                               double *__restrict__ y, const v2i32 *__restrict__ blk,
-                              int bfirst, int nb, Rows RW, int run,
+                              int bfirst, int nb, Rows RW,
                               const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                               const double *__restrict__ guard = nullptr, int pstride = 0, const int *__restrict__ order = nullptr)
 {
@@ -571,25 +557,29 @@ void spmv_csr_products_kernel(const int *__restrict__ ptr, const int *__restrict
     RowDots<DOT> dots{wdot, 0.0, 0.0};
     // order: the plan's launch order when some row blocks hold a row far longer than the stage -- those first, so that their
     // chains of additions (one lane, strictly in order) run beside the rest of the matrix instead of behind it
-    const int lb = order ? order[blockIdx.x] : block_of_workgroup<XRUN>(nb, run);
-    if (lb < 0) return;
+    const int lb = order ? order[blockIdx.x] : (int)blockIdx.x;
     Blk B = load_blk(blk, bfirst + lb);
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
     }
-    block_by_products<BLOCK, CAP, VEC, NOGATHER, DOT>(prod, ptr, idx, val, x, y, B, dots, acc0);
+    block_by_products<BLOCK, CAP, VEC, DOT>(prod, ptr, idx, val, x, y, B, dots, acc0);
     __syncthreads();
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
 }
 
 // ------------------------------------------------------------------------------ row-gather kernel
-template <int BLOCK, int WORK, int U, bool XRUN, bool DMA, bool NOGATHER, int DOT = 0>
+// xs_plane: XCD strips (xcd_strip_unit) -- row blocks per plane of a structured grid, or 0 for the natural order.  A permutation of the launch's blocks: the
+// partial sums of the fused dots stay in block order.
+// (Round 5, measured and dropped: the index slice issued ahead of the value slice, one bare barrier once every wavefront's index pieces have landed, and the x gathers
+//  of a row's first U entries issued behind the value stream instead of after it -- everything by hand, the compiler waits with vmcnt(0) for loads whose age it cannot
+//  count.  512^3, same box, interleaved: 2.3839 against 2.3843 ms at 256 / 2048, 2.421 against 2.411 at 192 / 1408.  The fabric binds this kernel, not its prologue.)
+template <int BLOCK, int WORK, int U, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                                const double *__restrict__ val, const double *__restrict__ x,
                                double *__restrict__ y, const v2i32 *__restrict__ blk,
-                               int bfirst, int nb, Rows RW, int nnz_total, int run,
+                               int bfirst, int nb, Rows RW, int nnz_total, int xs_plane,
                                const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                                const double *__restrict__ guard = nullptr, int pstride = 0)
 {
@@ -603,8 +593,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     __shared__ __attribute__((aligned(16))) double valL[(GUARD + CAP + 8 + 16) + 2 * WAVE];    // also the padded product stage of block_by_products
     __shared__ __attribute__((aligned(16))) int idxL[CAP + 8 + 4 * WAVE];
 
-    const int lb = block_of_workgroup<XRUN>(nb, run);
-    if (lb < 0) return;
+    const int lb = xcd_strip_unit((int)blockIdx.x, nb, xs_plane);
     Blk B = load_blk(blk, bfirst + lb);
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
@@ -614,7 +603,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     const int ka = B.k0 & ~3;                       // 16 B aligned start for both streams
     const int nq = (B.k1 - ka + 3) >> 2;            // quads of 4 non-zeros
     if ((B.k1 - ka) > CAP || ka + 4 * nq > nnz_total) {     // long row / tail of the arrays
-        block_by_products<BLOCK, CAP, 4, NOGATHER, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
+        block_by_products<BLOCK, CAP, 4, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
@@ -624,11 +613,10 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     int s_first = 0, e_first = 0;
     if (rmine < B.r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; }
 
-    // linear copies of both slices, every load instruction fully coalesced (16 B per lane, 1 KiB per wave)
+    // linear copies of both slices, every load instruction fully coalesced (16 B per lane, 1 KiB per wave): global -> LDS directly, each wave lands
+    // 64 x 16 B at a wave-uniform LDS base; lanes past the end re-read the last valid 16 B (their LDS slot is never used)
     const int np = 2 * nq;                          // pairs of values
-    if (DMA) {
-        // global -> LDS directly: each wave lands 64 x 16 B at a wave-uniform LDS base; lanes past the
-        // end re-read the last valid 16 B (their LDS slot is never used)
+    {
         const int wbase = (int)threadIdx.x & ~(WAVE - 1), lane = (int)threadIdx.x & (WAVE - 1);
         for (int p0 = wbase; p0 < np; p0 += BLOCK) {
             const int p = min(p0 + lane, np - 1);
@@ -641,30 +629,6 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v4i32 *>(idx + ka) + q),
                 (__attribute__((address_space(3))) void *)(reinterpret_cast<v4i32 *>(idxL) + q0), 16, 0, 2);
-        }
-    } else {
-        for (int p0 = 0; p0 < np; p0 += 4 * BLOCK) {
-            v2f64 v[4]; v4i32 c[2];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int p = p0 + u * BLOCK + (int)threadIdx.x;
-                if (p < np) v[u] = load_stream(reinterpret_cast<const v2f64 *>(val + ka) + p);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int q = (p0 >> 1) + u * BLOCK + (int)threadIdx.x;
-                if (q < nq) c[u] = load_stream(reinterpret_cast<const v4i32 *>(idx + ka) + q);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int p = p0 + u * BLOCK + (int)threadIdx.x;
-                if (p < np) reinterpret_cast<v2f64 *>(valL)[p] = v[u];
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int q = (p0 >> 1) + u * BLOCK + (int)threadIdx.x;
-                if (q < nq) reinterpret_cast<v4i32 *>(idxL)[q] = c[u];
-            }
         }
     }
     __syncthreads();
@@ -685,7 +649,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
                 vv[u] = valL[off + j];
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) xx[u] = NOGATHER ? (double)cc[u] : x[cc[u]];
+            for (int u = 0; u < U; u++) xx[u] = x[cc[u]];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const double t = vv[u] * xx[u];
@@ -747,7 +711,7 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
     const int nl = (cnt + 7) >> 3;                  // 16 B pieces of the position slice (the array is padded)
     if (nd == 0 || nd > XCAP || cnt > CAP || ka + 2 * np > nnz_total) {  // block without a list / last value of the array
-        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
+        block_by_products<BLOCK, CAP, 4, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
@@ -894,7 +858,7 @@ void csr_local_build(const v2i32 *__restrict__ blk, const int *__restrict__ idx,
 // kernel streams 9 B per non-zero instead of 12.  Same rows, same terms, same order as the kernel above (the column
 // is rebuilt as row + dict[code]), so the sums are bit-identical; the index array itself stays in HBM for the
 // paths that want it (long rows, array tails, transposition).
-template <int BLOCK, int WORK, int U, int DOT = 0, bool NOGATHER = false, bool XRUN = false>
+template <int BLOCK, int WORK, int U, int DOT = 0>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                            const double *__restrict__ val, const unsigned char *__restrict__ codes,
@@ -902,7 +866,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
                            double *__restrict__ y, const v2i32 *__restrict__ blk,
                            int bfirst, int nb, Rows RW, int nnz_total,
                            const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                           const double *__restrict__ guard = nullptr, int pstride = 0, int run = 16)
+                           const double *__restrict__ guard = nullptr, int pstride = 0, int xs_plane = 0)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const int row_begin = RW.rb, row_end = RW.re;
@@ -914,8 +878,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     __shared__ __attribute__((aligned(16))) unsigned char codeL[CAP + 16 + 16 * WAVE];
     __shared__ int dictL[256];
 
-    const int lb = block_of_workgroup<XRUN>(nb, run);
-    if (lb < 0) return;
+    const int lb = xcd_strip_unit((int)blockIdx.x, nb, xs_plane);      // (XCD strips: see xcd_strip_unit)
     Blk B = load_blk(blk, bfirst + lb);
     if (!clip_rows(B, ptr, row_begin, row_end)) {           // empty block: still owes its (zero) partial
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
@@ -926,7 +889,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
     const int nc = (cnt + 15) >> 4;                 // 16 B pieces of the code slice (the code array is padded)
     if (cnt > CAP || ka + 2 * np > nnz_total) {     // long row / last value of the array
-        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
+        block_by_products<BLOCK, CAP, 4, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
@@ -968,7 +931,7 @@ void spmv_csr_coded_kernel(const int *__restrict__ ptr, const int *__restrict__ 
                 vv[u] = valL[off + j];
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) xx[u] = NOGATHER ? x[cc[u] & 4095] : x[cc[u]];   // NOGATHER: ablation (all gathers hit one 32 KiB window), wrong results
+            for (int u = 0; u < U; u++) xx[u] = x[cc[u]];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const double t = vv[u] * xx[u];
@@ -1019,7 +982,7 @@ void spmv_csr_pattern_kernel(const int *__restrict__ ptr, const int *__restrict_
     const int cnt = B.k1 - ka;
     const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
     if (cnt > CAP || ka + 2 * np > nnz_total) {     // long row / last value of the array
-        block_by_products<BLOCK, CAP, 4, false, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
+        block_by_products<BLOCK, CAP, 4, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
@@ -4496,6 +4459,49 @@ extern "C" int liship_spmv_csr_set_local_columns(int on) { g_local_cols = on ? 1
 // 0: plans built from now on take the round-3 form of the block-local kernel (4096-item blocks, positions staged in LDS: 3 / 2 workgroups per CU); A/B, same bits
 // 0: the 7-offset pattern kernel walks the row blocks in their natural order (round-robin over the XCDs) instead of XCD strips; A/B measurements, same bits
 extern "C" int liship_spmv_csr_set_xcd_strips(int on) { g_xcd_strips = on ? 1 : 0; return 0; }
+
+// The band of a matrix whose plan has no row patterns (4 B indices, one-byte codes): the largest |column - row| among the owned columns, and how many rows reach
+// it.  When most rows do -- the +-plane neighbours of a 3-D grid -- that distance is the plane the XCD strips are cut from (xcd_strip_unit), exactly what the
+// largest pattern offset is for patterned plans.  Two passes over index[] at plan time; an order of the row blocks only: the bits cannot depend on it.
+namespace {
+__global__ void csr_band_max(int n, const int *__restrict__ ptr, const int *__restrict__ idx, int *__restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int m = 0;
+    if (r < n) for (int k = ptr[r], e = ptr[r + 1]; k < e; k++) { const int c = idx[k]; if (c < n) m = max(m, abs(c - r)); }
+    for (int s = WAVE / 2; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s));
+    if ((threadIdx.x & (WAVE - 1)) == 0 && m > 0) atomicMax(out, m);
+}
+__global__ void csr_band_count(int n, const int *__restrict__ ptr, const int *__restrict__ idx, const int *__restrict__ band, unsigned long long *__restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, B = band[0];
+    bool hit = false;
+    if (r < n) for (int k = ptr[r], e = ptr[r + 1]; k < e; k++) { const int c = idx[k]; hit = hit || (c < n && abs(c - r) == B); }
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(hit);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && b) atomicAdd(out, (unsigned long long)__builtin_popcountll(b));
+}
+}
+extern "C" int liship_csr_plan_scan_band(liship_csr_plan_t p, const int *ptr, const int *idx, void *stream)
+{
+    if (!p || !ptr || !idx) return LISHIP_ERR_ARG;
+    if (p->xs_rows > 0 || p->products || p->n < (1 << 16) || p->nnz <= 0) return 0;      // the patterns named the plane / another kernel family / too small to matter
+    hipStream_t st = as_stream(stream);
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), st);
+    const int threads = 256, grid = (p->n + threads - 1) / threads;
+    if (e == hipSuccess) { csr_band_max<<<grid, threads, 0, st>>>(p->n, ptr, idx, reinterpret_cast<int *>(d)); e = hipGetLastError(); }
+    if (e == hipSuccess) { csr_band_count<<<grid, threads, 0, st>>>(p->n, ptr, idx, reinterpret_cast<const int *>(d), d + 1); e = hipGetLastError(); }
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) return (int)e;
+    const int band = (int)(h[0] & 0xffffffffull);
+    if (band > 0 && 2 * h[1] >= (unsigned long long)p->n) p->xs_rows = band;
+    return 0;
+}
+extern "C" int liship_csr_plan_strip_rows(liship_csr_plan_t p) { return p ? p->xs_rows : 0; }
 extern "C" int liship_spmv_csr_set_local_register_positions(int on) { g_local_rpos = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_team(int on) { g_team = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_dom_march(int on) { g_dom_march = on; return 0; }
@@ -4539,7 +4545,6 @@ inline int xcd_strips(const LaunchArgs &a)          // (row-range launches too -
     return xcd_strip_plane(a.plan, (double)a.plan->n / a.plan->nblocks, a.nb);
 }
 
-inline int xcd_run() { int c = (g_variant >> 16) & 0xff; return c ? c : 16; }
 
 // the smallest offset distance (in rows) beyond the diagonal's neighbours that the dominant pattern has on BOTH sides: +-n of a 3-D stencil
 static int dom_stride(const DomRec &D)
@@ -4562,21 +4567,21 @@ static int dom_stride_outer(const DomRec &D)
     return S;
 }
 
-template <int G, int U, bool XRUN, bool DMA, bool NOGATHER>
-void launch_rowgather(int grid, const LaunchArgs &a)
+template <int G, int U>
+void launch_rowgather(const LaunchArgs &a)
 {
     constexpr Geometry g = kGeom[G];
-    spmv_csr_rowgather_kernel<g.block, g.work, U, XRUN, DMA, NOGATHER>
-        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, xcd_run());
+    spmv_csr_rowgather_kernel<g.block, g.work, U>
+        <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, xcd_strips(a));
 }
 
-template <int G, bool XRUN, int VEC, bool NOGATHER>
-void launch_products(int grid, const LaunchArgs &a)
+template <int G, int VEC>
+void launch_products(const LaunchArgs &a)
 {
     constexpr Geometry g = kGeom[G];
-    spmv_csr_products_kernel<g.block, g.work, XRUN, VEC, NOGATHER>
-        <<<grid, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, xcd_run(),
-                                     nullptr, nullptr, nullptr, 0, XRUN ? nullptr : a.order);
+    spmv_csr_products_kernel<g.block, g.work, VEC>
+        <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
+                                     nullptr, nullptr, nullptr, 0, a.order);
 }
 
 static bool block_rows_serve(const liship_csr_plan_s *P, int rb, int re)      // the block-row kernel for this row range? (whole block rows only)
@@ -4693,7 +4698,7 @@ static long long dom_gather_shape(const LaunchArgs &a, DomTile &TL, int &run)
     // workgroup, kernarg preload of the arguments: profiles/r03_valuerec_dom_experiments.txt.)
     const bool plain = (g_variant & 0x10000000) != 0;
     int tsel = ((g_variant >> 3) & 1) | (((g_variant >> 9) & 1) << 1) | (((g_variant >> 15) & 1) << 2);
-    if (!tsel && !plain && !(g_variant & 1)) tsel = 3;
+    if (!tsel && !plain) tsel = 3;
     TL = DomTile{0, 0, 0, 0, 0, 0, 0};
     long long wgs = (rows + 511) / 512;
     if (tsel) {
@@ -4715,7 +4720,7 @@ static long long dom_gather_shape(const LaunchArgs &a, DomTile &TL, int &run)
             }
         }
     }
-    run = (g_variant & 1) ? xcd_run() : (plain || TL.S || wgs < 8 * NUM_XCD) ? 1 : 8;
+    run = (plain || TL.S || wgs < 8 * NUM_XCD) ? 1 : 8;
     return wgs;
 }
 
@@ -4814,11 +4819,7 @@ static void launch_dom(const LaunchArgs &a0, int dot = 0, const double *w = null
         const int run = Q.run;
         const long long wgs = Q.wgs;
         const int span = NUM_XCD * run;
-        DomRec DD = P->dom;
-        if ((g_variant & 0x40004000) == 0x40004000) {      // ablation (WRONG results, timing only): the outermost pair of offsets re-reads the diagonal
-            const int S2 = dom_stride_outer(DD);
-            for (int u = 0; u < 7; u++) if (DD.off[u] == 8 * S2 || DD.off[u] == -8 * S2) DD.off[u] = 0;
-        }
+        const DomRec &DD = P->dom;
         const unsigned grid = (unsigned)((wgs + span - 1) / span * span);
         int wslot = -1;
         if (dot != 0 && w == a.x && !(g_variant & 0x8))      // (bit3: w by its own loads, A/B)
@@ -4851,10 +4852,6 @@ void launch_local(const LaunchArgs &a, const double *w, double *partial, const d
 template <int G>
 void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
 {
-    const bool nogather = (g_variant & 0x100) != 0;
-    const bool xrun = (g_variant & 1) && a.nb >= 4 * NUM_XCD;
-    const int span = NUM_XCD * xcd_run();
-    const int grid = xrun ? ((a.nb + span - 1) / span) * span : a.nb;
     const bool val16 = aligned16(a.val), idx16 = aligned16(a.idx);
     const bool idx8 = (reinterpret_cast<uintptr_t>(a.idx) & 7u) == 0;
     const bool products = plan_products || (g_variant & 6) != 0 || !(val16 && idx16);
@@ -4864,37 +4861,20 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
     }
     if constexpr (G == LOCAL_GEOM4 || G == LOCAL_GEOM_R) {      // geometries only block-local plans have: whatever else such a plan launches (lists switched off,
         const bool vec = val16 && idx8;                          // values not 16 B aligned) takes the products kernel on the 4 B indices
-        if (!vec) launch_products<G, false, 0, false>(a.nb, a);
-        else if (batch == 2) launch_products<G, false, 2, false>(a.nb, a);
-        else launch_products<G, false, 4, false>(a.nb, a);
+        if (!vec) launch_products<G, 0>(a);
+        else if (batch == 2) launch_products<G, 2>(a);
+        else launch_products<G, 4>(a);
         return;
     } else {
     if (products) {
-        const bool vec = !(g_variant & 2) && val16 && idx8;
-        if (nogather)  launch_products<G, false, 4, true>(a.nb, a);
-        else if (xrun) { if (vec) launch_products<G, true, 4, false>(grid, a); else launch_products<G, true, 0, false>(grid, a); }
-        else if (!vec) launch_products<G, false, 0, false>(grid, a);
-        else if (batch == 2) launch_products<G, false, 2, false>(grid, a);
-        else           launch_products<G, false, 4, false>(grid, a);
+        const bool vec = !(g_variant & 2) && val16 && idx8;        // (variant bit 1: the scalar-load form on aligned arrays too -- tests)
+        if (!vec) launch_products<G, 0>(a);
+        else if (batch == 2) launch_products<G, 2>(a);
+        else           launch_products<G, 4>(a);
         return;
     }
-    const int usel = (g_variant >> 11) & 3;
-    const int U = usel == 1 ? 4 : usel == 2 ? 7 : usel == 3 ? 8 : unroll;
-    const bool dma = !(g_variant & 0x400);
-    if (a.codes && !a.vrec && (g_variant & ~0xFF00F0) == 0x1 && a.nb >= 4 * NUM_XCD) {   // experiment: XCD-run block order for the coded kernel
-        constexpr Geometry g = kGeom[G];
-        const int sp = NUM_XCD * xcd_run(), gr = ((a.nb + sp - 1) / sp) * sp;
-        spmv_csr_coded_kernel<g.block, g.work, 7, 0, false, true><<<gr, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, nullptr, nullptr, nullptr, 0, xcd_run());
-        return;
-    }
-    if (a.codes && (g_variant & ~0xF0) == 0x100) {   // ablation: coded kernel without the x gather (timing only)
-        constexpr Geometry g = kGeom[G];
-        spmv_csr_coded_kernel<g.block, g.work, 7, 0, true><<<a.nb, g.block, 0, a.st>>>(
-            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz);
-        return;
-    }
-    if (a.rowpat && a.ptab8 && a.vrec && (g_variant & ~0x70ffc209) == 0) {            // the rows' values ride in the pattern records: one byte per row
+    const int U = unroll;
+    if (a.rowpat && a.ptab8 && a.vrec && (g_variant & ~0x70ffc208) == 0) {            // the rows' values ride in the pattern records: one byte per row
         constexpr Geometry g = kGeom[G];
         const int chunks = (a.re - a.rb + g.block - 1) / g.block;       // rows [rb, re) in chunks of one workgroup's lanes, two per workgroup
         // beyond the Infinity Cache (256 MB of x) the two-rows-per-lane form wins (16 B requests: 320^3 +4 %, 448^3 +13 %, 512^3 +7 %);
@@ -4938,20 +4918,17 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
 #undef GOP
         return;
     }
-    if (a.codes && (g_variant & ~0x18F0) == 0) {     // one-byte column codes (the plan found <= 255 diagonals)
+    if (a.codes && (g_variant & ~0xF0) == 0) {     // one-byte column codes (the plan found <= 255 diagonals)
         constexpr Geometry g = kGeom[G];
 #define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, 0><<<a.nb, g.block, 0, a.st>>>( \
-            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz)
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, nullptr, nullptr, nullptr, 0, xcd_strips(a))
         if (U == 4) GO(4); else if (U == 7) GO(7); else GO(8);
 #undef GO
         return;
     }
-    if (nogather)  { launch_rowgather<G, 8, false, true, true>(a.nb, a); return; }
-    if (xrun)      { launch_rowgather<G, 8, true, true, false>(grid, a); return; }
-    if (!dma)      { launch_rowgather<G, 8, false, false, false>(grid, a); return; }
-    if (U == 4)      launch_rowgather<G, 4, false, true, false>(grid, a);
-    else if (U == 7) launch_rowgather<G, 7, false, true, false>(grid, a);
-    else             launch_rowgather<G, 8, false, true, false>(grid, a);
+    if (U == 4)      launch_rowgather<G, 4>(a);
+    else if (U == 7) launch_rowgather<G, 7>(a);
+    else             launch_rowgather<G, 8>(a);
     }
 }
 
@@ -5010,13 +4987,13 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
     }
     if (a.codes) {
 #define GO(UU) spmv_csr_coded_kernel<g.block, g.work, UU, DOT><<<a.nb, g.block, 0, a.st>>>( \
-            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride)
+            a.ptr, a.idx, a.val, a.codes, a.dict, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, liship_internal_guard(), pstride, xcd_strips(a))
         if (unroll == 4) GO(4); else if (unroll == 7) GO(7); else GO(8);
 #undef GO
         return;
     }
-#define GO(UU) spmv_csr_rowgather_kernel<g.block, g.work, UU, false, true, false, DOT><<<a.nb, g.block, 0, a.st>>>( \
-        a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, 16, w, partial, liship_internal_guard(), pstride)
+#define GO(UU) spmv_csr_rowgather_kernel<g.block, g.work, UU, DOT><<<a.nb, g.block, 0, a.st>>>( \
+        a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, xcd_strips(a), w, partial, liship_internal_guard(), pstride)
     if (unroll == 4) GO(4); else if (unroll == 7) GO(7); else GO(8);
 #undef GO
 }
@@ -5030,11 +5007,11 @@ void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double
         return;
     }
     if (batch == 2)
-        spmv_csr_products_kernel<g.block, g.work, false, 2, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, 16, w, partial, liship_internal_guard(), pstride, a.order);
+        spmv_csr_products_kernel<g.block, g.work, 2, DOT>
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, w, partial, liship_internal_guard(), pstride, a.order);
     else
-        spmv_csr_products_kernel<g.block, g.work, false, 4, false, DOT>
-            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, 16, w, partial, liship_internal_guard(), pstride, a.order);
+        spmv_csr_products_kernel<g.block, g.work, 4, DOT>
+            <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, w, partial, liship_internal_guard(), pstride, a.order);
 }
 
 int launch_csr(liship_csr_plan_t p, const LaunchArgs &a0)

@@ -1,5 +1,6 @@
 """A few products of the 512^3 (N^3) Poisson matrix through lis_matvec, exactly as bench.py sets them up -- the process rocprofv3 profiles when bench.py measures
-its `roofline.traffic` live (bench.py live_traffic):   python tools/traffic_child.py N values(0|1) iters"""
+its `roofline.traffic` live (bench.py live_traffic):   python tools/traffic_child.py N form iters
+form: 1 the plan's own choice, 0 value records off (values streamed), 2 the contract form (index codes, row patterns and value records off: 4 B indices + 8 B values)"""
 import ctypes as C
 import os
 import sys
@@ -21,8 +22,11 @@ x, y = capi.PV(), capi.PV()
 for v in (x, y):
     assert lib.lis_vector_duplicate(C.cast(A, C.c_void_p), C.byref(v)) == 0
 assert lib.lis_vector_set_all(1.0, x) == 0
-if not values:
+if values != 1:
     check(lib.liship_spmv_csr_set_row_values(0))
+if values == 2:
+    check(lib.liship_spmv_csr_set_row_patterns(0))
+    check(lib.liship_spmv_csr_set_index_codes(0))
 for _ in range(iters):
     assert lib.lis_matvec(A, x, y) == 0
 lib.dll.lis_amd_synchronize()

@@ -48,7 +48,8 @@ LIS_INT lis_amd_vector_page_protect(LIS_VECTOR v, LIS_INT state);      /* force 
 LIS_INT lis_amd_page_faults(LIS_INT *reads, LIS_INT *writes);
 LIS_INT lis_amd_page_fault_waits(void);                /* faults that found another thread bringing the same array home and waited for its copy */
 /* tests of the handler without a GPU: the host buffer `src` (n + pad doubles) plays the HBM copy of v -- v's pages lose all access and the first
- * touch copies src home in two halves delay_ms apart, through the library's alias mapping (lis_pages.c); src = NULL removes the hook */
+ * touch copies src home in two halves delay_ms apart (delay_ms < 0: the second half is held until -delay_ms other threads wait for the copy, 10 s at most),
+ * through the library's alias mapping (lis_pages.c); src = NULL removes the hook */
 LIS_INT lis_amd_vector_page_test_source(LIS_VECTOR v, const LIS_SCALAR *src, LIS_INT delay_ms);
 
 /* How the CG / BiCGSTAB loops run (all three produce identical bits; the choice is for A/B measurements):
@@ -86,6 +87,18 @@ LIS_INT lis_amd_vector_device_modified(LIS_VECTOR v);  /* HBM copy was written b
 /* matrices */
 LIS_INT lis_amd_matrix_upload(LIS_MATRIX A);           /* build the HBM copy now (otherwise on first use) */
 LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A);   /* host arrays changed: drop the HBM copy */
+/* Host writes to a matrix's arrays after its HBM copy was built.  The reference adopts arrays (src/matrix/lis_matrix_csr.c:98-103) and reads them live on every
+ * product.  Here: arrays that came from lis_matrix_malloc_<fmt> (lis_matrix_csr.c:170), from element-wise assembly or from a conversion live on pages of the
+ * library's own; under the default (lazy) coherence a write to them is SEEN -- one page fault -- and the copy, its plan and the transposed operator are rebuilt
+ * before the next product, with no call from the program.  Arrays the caller malloc'ed and handed to lis_matrix_set_<fmt> cannot be watched: call
+ * lis_amd_matrix_host_modified(A) after changing them, or run with LIS_AMD_MATRIX_CHECK=1 / lis_amd_set_matrix_check(1) while debugging: every use of a matrix
+ * then re-hashes its host arrays (a pass over them on the host cores) and rebuilds a stale copy, with one line on stderr naming the matrix.
+ * lis_amd_matrix_protected_arrays: how many arrays of A are write-protected right now (tests).  System calls that WRITE INTO a protected array (fread into
+ * A->value) fail with EFAULT, as for vectors: call lis_amd_matrix_host_modified(A) first, which opens the pages. */
+LIS_INT lis_amd_set_matrix_check(LIS_INT on);
+LIS_INT lis_amd_matrix_protected_arrays(LIS_MATRIX A);
+LIS_INT lis_amd_matrix_host_written(LIS_MATRIX A);     /* 1: a host write to one of A's watched arrays was seen since the HBM copy was built (tests) */
+LIS_INT lis_amd_matrix_page_test_watch(LIS_MATRIX A);  /* tests without a GPU: adopt + write-protect A's arrays as an upload would; returns the number protected */
 /* number of entries of the column-offset dictionary when the HBM copy of A carries one-byte column codes (liship.h
  * "index coding": matrices on <= 255 diagonals), 0 when it reads the 4 B indices; uploads A if needed */
 LIS_INT lis_amd_matrix_index_codes(LIS_MATRIX A);

@@ -176,6 +176,7 @@ static struct { void *buf[2], *ev[2]; int busy[2]; } stage;
 /* the staging buffers are one set per process: a thread of the program that faults on a vector (lis_pages.c) copies through them while the
  * thread that drives the library may be uploading another vector -- one copy at a time */
 #include <pthread.h>
+#include <unistd.h>
 static pthread_mutex_t stage_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static LIS_INT stage_ready(void)
@@ -188,12 +189,14 @@ static LIS_INT stage_ready(void)
 	return LIS_SUCCESS;
 }
 
-/* memcpy by the host threads (one thread moves ~10 GB/s, PCIe 5 takes 50) */
+/* memcpy by the host threads (one thread moves ~10 GB/s, PCIe 5 takes 50) -- except inside the page-fault handler, which runs on whatever thread of the
+ * program touched the page: no OpenMP region is opened from a signal handler (the faulting thread may sit inside a region of its own) */
+static __thread int in_fault_copy;
 static void copy_threads(void *dst, const void *src, size_t bytes)
 {
 	const size_t piece = (size_t)1 << 20;
 	const long long pieces = (long long)((bytes + piece - 1) / piece);
-	if (pieces < 4) { memcpy(dst, src, bytes); return; }
+	if (pieces < 4 || in_fault_copy) { memcpy(dst, src, bytes); return; }
 	const int T = lisi_host_threads();
 #pragma omp parallel for num_threads(T) schedule(static)
 	for (long long i = 0; i < pieces; i++) {
@@ -250,6 +253,62 @@ LIS_INT lisd_staged_d2h(void *dst, const void *src, size_t bytes)
 	pthread_mutex_lock(&stage_lock);
 	const LIS_INT err = staged_d2h_locked(dst, src, bytes);
 	pthread_mutex_unlock(&stage_lock);
+	return err;
+}
+
+/* The same copy from INSIDE the page-fault handler (lis_pages.c on_fault), i.e. on a thread of the program, possibly while the thread that drives the library is
+ * enqueueing work: a stream, two pinned buffers and two events of its own (made when the handler is installed, never inside it), so that nothing is enqueued on
+ * the library's stream from a foreign thread -- a stream under hipGraph capture (LIS_AMD_GRAPHS=1) would have its capture invalidated -- and the driving
+ * thread's staging buffers are never waited for.  What the data depends on has been enqueued on lisg.stream by the time its pages lost their access: the copy
+ * waits for an event recorded there... by THIS thread, which is legal on a capturing stream only outside the capture, so a fault during a capture waits for
+ * the capture to end first (a batch of launches: microseconds).  Plain memcpy, no OpenMP. */
+static struct { void *stream, *buf[2], *ev[2], *order; int ready; } fstage;
+static volatile int capture_active;
+static pthread_mutex_t fault_lock = PTHREAD_MUTEX_INITIALIZER;      /* one fault-time copy at a time; a capture begins only between two of them */
+void lisd_capture_mark(int on)
+{
+	if (on) { pthread_mutex_lock(&fault_lock); capture_active = 1; pthread_mutex_unlock(&fault_lock); }
+	else capture_active = 0;
+}
+LIS_INT lisd_fault_stage_prepare(void)
+{
+	if (fstage.ready || !lisg.device_ready) return LIS_SUCCESS;
+	HIPCHK(liship_stream_create(&fstage.stream));
+	for (int k = 0; k < 2; k++) {
+		HIPCHK(liship_malloc_host(&fstage.buf[k], STAGE_BYTES));
+		HIPCHK(liship_event_create(&fstage.ev[k]));
+	}
+	HIPCHK(liship_event_create(&fstage.order));
+	fstage.ready = 1;
+	return LIS_SUCCESS;
+}
+LIS_INT lisd_staged_d2h_fault(void *dst, const void *src, size_t bytes)
+{
+	if (!fstage.ready) return lisd_staged_d2h(dst, src, bytes);       /* (the handler was installed before the device existed: the shared path) */
+	LIS_INT err = LIS_SUCCESS;
+	pthread_mutex_lock(&fault_lock);
+	while (capture_active) usleep(50);
+	int rc = liship_event_record(fstage.order, lisg.stream);
+	if (!rc) rc = liship_stream_wait_event(fstage.stream, fstage.order);
+	in_fault_copy = 1;
+	size_t issued = 0, landed = 0;
+	int ki = 0, kl = 0;
+	while (!rc && landed < bytes) {
+		while (!rc && issued < bytes && issued - landed < 2 * STAGE_BYTES) {
+			const size_t len = bytes - issued < STAGE_BYTES ? bytes - issued : STAGE_BYTES;
+			rc = liship_memcpy_d2h(fstage.buf[ki], (const char *)src + issued, len, fstage.stream);
+			if (!rc) rc = liship_event_record(fstage.ev[ki], fstage.stream);
+			issued += len; ki ^= 1;
+		}
+		if (rc) break;
+		const size_t len = bytes - landed < STAGE_BYTES ? bytes - landed : STAGE_BYTES;
+		rc = liship_event_synchronize(fstage.ev[kl]);
+		if (!rc) memcpy((char *)dst + landed, fstage.buf[kl], len);
+		landed += len; kl ^= 1;
+	}
+	in_fault_copy = 0;
+	if (rc) { (void)liship_stream_synchronize(fstage.stream); err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
+	pthread_mutex_unlock(&fault_lock);
 	return err;
 }
 
@@ -638,12 +697,12 @@ static LIS_INT upload_split(LIS_MATRIX A, lisd_mat *d)
  * zeros included (lis_matvec_bsr.c:123-148, :293-343) -- are built IN HBM from the native arrays (liship_bsr_to_rows) and kept when the plan finds value records on them.
  * Only without padding (n a multiple of bnr, the columns a multiple of bnc: the padded x entries would otherwise be columns of the row form) and in single-rank jobs.
  * *taken = 1: d->ptr / index / value / plan hold the row form, d->type is CSR; the native arrays stay with the caller. */
-static LIS_INT try_bsr_row_form(LIS_MATRIX A, lisd_mat *d, const int *dbptr, const int *dbindex, const double *dbvalue, LIS_INT bnnz, int values_few, int *taken)
+/* (the facts about the matrix come as arguments: the in-HBM conversion calls this before the target's header is filled in) */
+static LIS_INT try_bsr_row_form(int n, int np, int bnr, int bnc, int splited, lisd_mat *d, const int *dbptr, const int *dbindex, const double *dbvalue, LIS_INT bnnz, int values_few, int *taken)
 {
 	*taken = 0;
-	const int n = A->n, bnr = A->bnr, bnc = A->bnc;
 	if (lisg.no_row_form || lisg.no_value_records || lisg.no_row_patterns || lisg.no_index_codes || lisg.nprocs > 1 || n <= 0 || bnnz <= 0 || !values_few) return LIS_SUCCESS;
-	if (n % bnr != 0 || A->np % bnc != 0 || A->np != n || A->is_splited) return LIS_SUCCESS;
+	if (n % bnr != 0 || np % bnc != 0 || np != n || splited) return LIS_SUCCESS;
 	const long long slots = (long long)bnnz * bnr * bnc;
 	if (slots >= 0x7fffffffLL || (slots / n) > 32) return LIS_SUCCESS;          /* value records hold up to 32 entries per row */
 	int *rptr = NULL, *ridx = NULL; double *rval = NULL;
@@ -671,12 +730,81 @@ static LIS_INT try_bsr_row_form(LIS_MATRIX A, lisd_mat *d, const int *dbptr, con
 }
 
 static LIS_INT mat_upload(LIS_MATRIX A);
+
+/* ---- host writes to adopted arrays.  The reference adopts the caller's arrays (lis_matrix_csr.c:98-103) and reads them live on every product
+ * (lis_matvec_csr.c:97-109); here the product runs on an HBM copy built once.  Arrays that came from lis_matrix_malloc_<fmt> -- or that the library made itself:
+ * element-wise assembly, conversions in HBM -- live on pages of the library's (lis_pages.c): under lazy coherence they are read-only while the HBM copy lives,
+ * the first host write faults, opens them and sets host_written, and the next use rebuilds the copy (arrays, plan, transposed operator).  Arrays the caller
+ * malloc'ed cannot be watched: lis_amd_matrix_host_modified(A) is the contract for those, and LIS_AMD_MATRIX_CHECK=1 the debugging aid -- every use of A then
+ * re-hashes its host arrays and rebuilds the copy (with one line on stderr) when they changed. */
+static unsigned long long hash_words(const void *p, size_t bytes)
+{
+	const unsigned long long *w = (const unsigned long long *)p;
+	const size_t nw = bytes / 8;
+	unsigned long long h = 0x9E3779B97F4A7C15ull ^ bytes;
+	#pragma omp parallel for reduction(^:h) schedule(static) num_threads(lisi_host_threads())
+	for (long long c = 0; c < (long long)((nw + 4095) / 4096); c++) {
+		const size_t lo = (size_t)c * 4096, hi = lo + 4096 < nw ? lo + 4096 : nw;
+		unsigned long long a = 0x243F6A8885A308D3ull + (unsigned long long)c, b = 0x13198A2E03707344ull;
+		for (size_t i = lo; i + 1 < hi; i += 2) { a = (a ^ w[i]) * 0x9E3779B97F4A7C15ull; b = (b ^ w[i + 1]) * 0xC2B2AE3D27D4EB4Full; }
+		if ((hi - lo) & 1) a = (a ^ w[hi - 1]) * 0x9E3779B97F4A7C15ull;
+		h ^= (a ^ (b >> 29) ^ (a << 17)) * 0xD6E8FEB86659FD93ull;
+	}
+	const unsigned char *t = (const unsigned char *)p + nw * 8;
+	for (size_t i = 0; i < bytes % 8; i++) h = (h ^ t[i]) * 0x100000001B3ull;
+	return h;
+}
+
+static int host_arrays(LIS_MATRIX A, const void *arr[6], size_t bytes[6])
+{
+	const size_t n = (size_t)A->n;
+	int k = 0;
+#define ARR(p, b) do { if (p) { arr[k] = (p); bytes[k] = (b); k++; } } while (0)
+	if (A->is_splited) return 0;                       /* (the split parts L, U, D are the library's own work arrays: not watched) */
+	switch (A->matrix_type) {
+	case LIS_MATRIX_CSR: ARR(A->ptr, 4 * (n + 1)); ARR(A->index, 4 * (size_t)A->nnz); ARR(A->value, 8 * (size_t)A->nnz); break;
+	case LIS_MATRIX_CSC: ARR(A->ptr, 4 * ((size_t)A->np + 1)); ARR(A->index, 4 * (size_t)A->nnz); ARR(A->value, 8 * (size_t)A->nnz); break;
+	case LIS_MATRIX_ELL: ARR(A->index, 4 * n * (size_t)A->maxnzr); ARR(A->value, 8 * n * (size_t)A->maxnzr); break;
+	case LIS_MATRIX_DIA: ARR(A->index, 4 * (size_t)A->nnd); ARR(A->value, 8 * n * (size_t)A->nnd); break;
+	case LIS_MATRIX_JAD: ARR(A->row, 4 * n); ARR(A->ptr, 4 * ((size_t)A->maxnzr + 1)); ARR(A->index, 4 * (size_t)A->nnz); ARR(A->value, 8 * (size_t)A->nnz); break;
+	case LIS_MATRIX_BSR: ARR(A->bptr, 4 * ((size_t)A->nr + 1)); ARR(A->bindex, 4 * (size_t)A->bnnz); ARR(A->value, 8 * (size_t)A->bnnz * (size_t)A->bnr * (size_t)A->bnc); break;
+	default: break;
+	}
+#undef ARR
+	return k;
+}
+
+static unsigned long long host_arrays_hash(LIS_MATRIX A)
+{
+	const void *arr[6]; size_t bytes[6];
+	const int k = host_arrays(A, arr, bytes);
+	unsigned long long h = 0;
+	for (int i = 0; i < k; i++) h = (h * 0x9E3779B97F4A7C15ull) ^ hash_words(arr[i], bytes[i]);
+	return h;
+}
+
 LIS_INT lisd_mat_ready(LIS_MATRIX A)
 {
-	if (MDEV(A)->ready) return LIS_SUCCESS;
+	lisd_mat *d = MDEV(A);
+	if (d->ready && !d->device_only) {
+		if (d->host_written) lisd_mat_free(A);             /* a host write to one of its arrays was seen (page fault): the copy is stale */
+		else if (lisg.matrix_check && d->checked && lisp_lazy_arrays(A) == 0 && host_arrays_hash(A) != d->host_hash) {
+			fprintf(stderr, "liblis_amd: LIS_AMD_MATRIX_CHECK: the host arrays of matrix %p changed since its HBM copy was built and lis_amd_matrix_host_modified() was "
+			                "not called: rebuilding the copy\n", (void *)A);
+			lisd_mat_free(A);
+		}
+	}
+	if (d->ready) return LIS_SUCCESS;
 	const LIS_INT err = mat_upload(A);
-	if (err) lisd_mat_free(A);      /* a half-made HBM copy (arrays up, plan failed ...) must not be uploaded over by the next call */
-	return err;
+	if (err) { lisd_mat_free(A); return err; }      /* a half-made HBM copy (arrays up, plan failed ...) must not be uploaded over by the next call */
+	{	/* the arrays the copy was built from: watched from here on where they live on the library's pages */
+		const void *arr[6]; size_t bytes[6];
+		const int k = host_arrays(A, arr, bytes);
+		for (int i = 0; i < k; i++) (void)lisp_adopt(A, (void *)arr[i]);
+		(void)lisp_matrix_protect(A);
+		if (lisg.matrix_check) { d->host_hash = host_arrays_hash(A); d->checked = 1; }
+	}
+	return LIS_SUCCESS;
 }
 
 static LIS_INT mat_upload(LIS_MATRIX A)
@@ -685,6 +813,7 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 	LISCHK(lisd_init());
 	if (A->status < LIS_MATRIX_CSR) return LISI_ERR(LIS_ERR_ILL_ARG, "matrix A is not assembled\n");
 	LISCHK(lisp_fill_matrix(A));
+	d->host_written = 0;
 	d->n = A->n; d->np = A->np; d->nnz = A->nnz;
 	d->type = A->matrix_type;
 	const size_t n = (size_t)A->n;
@@ -739,7 +868,7 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 			int taken = 0;
 			double *native = d->value;
 			d->value = NULL;
-			LIS_INT e2 = try_bsr_row_form(A, d, d->bptr, d->bindex, native, A->bnnz, few_distinct_values(A->value, (size_t)A->bnnz * (size_t)A->bnr * (size_t)A->bnc), &taken);
+			LIS_INT e2 = try_bsr_row_form(A->n, A->np, A->bnr, A->bnc, A->is_splited, d, d->bptr, d->bindex, native, A->bnnz, few_distinct_values(A->value, (size_t)A->bnnz * (size_t)A->bnr * (size_t)A->bnc), &taken);
 			if (e2) { d->value = native; return e2; }
 			if (taken) { (void)liship_free(native); (void)liship_free(d->bptr); (void)liship_free(d->bindex); d->bptr = NULL; d->bindex = NULL; }
 			else d->value = native;
@@ -769,6 +898,7 @@ void lisd_mat_free(LIS_MATRIX A)
 	(void)liship_free(d->export_index); (void)liship_free(d->ws); free(d->export_run);
 	(void)liship_free(d->sx); (void)liship_free(d->sy);
 	memset(d, 0, sizeof(*d));
+	lisp_matrix_release(A, 0);         /* no copy left that a host write could leave stale: the watched arrays are plain memory again */
 }
 
 /* ------------------------------------------------------------------ conversions in HBM (kernels/convert.hip)
@@ -800,7 +930,7 @@ LIS_INT lisd_convert_csr(LIS_MATRIX Ain, LIS_MATRIX Aout, int *done)
 	if (lisg.no_device_convert || lisg.nprocs > 1 || !lisg.device_ready || sd->device_only ||
 	    Ain->matrix_type != LIS_MATRIX_CSR || Ain->is_splited || Ain->np != Ain->n || Ain->n <= 0 || Ain->nnz <= 0)
 		return LIS_SUCCESS;
-	if (!sd->ready) LISCHK(lisd_mat_ready(Ain));          /* (an upload of the source costs a fraction of a pass of the host routine over it) */
+	LISCHK(lisd_mat_ready(Ain));          /* (an upload of the source costs a fraction of a pass of the host routine over it; a stale copy is rebuilt) */
 	if (sd->type != LIS_MATRIX_CSR || !sd->ptr || !sd->index || !sd->value) return LIS_SUCCESS;
 	const int n = Ain->n, nnz = Ain->nnz;
 	lisd_mat *d = MDEV(Aout);
@@ -978,9 +1108,8 @@ LIS_INT lisd_convert_csr(LIS_MATRIX Ain, LIS_MATRIX Aout, int *done)
 		if (rc) { (void)liship_free(bptr); (void)liship_free(bindex); (void)liship_free(bval); HIPCHK(rc); }
 		d->type = LIS_MATRIX_BSR; d->nr = nr; d->bnr = bnr; d->bnc = bnc;
 		int rowform = 0;
-		if (pad == 0) {          /* constant coefficients: the row form (try_bsr_row_form); Aout's header is not filled in yet, so the facts it asks for are set here */
-			Aout->bnr = bnr; Aout->bnc = bnc;
-			err = try_bsr_row_form(Aout, d, bptr, bindex, bval, bnnz, device_few_distinct_values(sd->value, (size_t)nnz), &rowform);
+		if (pad == 0) {          /* constant coefficients: the row form (try_bsr_row_form); Aout's header is not filled in yet, the source's facts are the target's */
+			err = try_bsr_row_form(n, Ain->np, bnr, bnc, 0, d, bptr, bindex, bval, bnnz, device_few_distinct_values(sd->value, (size_t)nnz), &rowform);
 			if (err) { (void)liship_free(bptr); (void)liship_free(bindex); (void)liship_free(bval); return err; }
 		}
 		if (!rowform) { d->bptr = bptr; d->bindex = bindex; d->value = bval; }
@@ -988,7 +1117,14 @@ LIS_INT lisd_convert_csr(LIS_MATRIX Ain, LIS_MATRIX Aout, int *done)
 		LIS_INT *hp = (LIS_INT *)lazy_host(Aout, sizeof(int) * ((size_t)nr + 1), bptr, rowform);
 		LIS_INT *hi = (LIS_INT *)lazy_host(Aout, sizeof(int) * (size_t)bnnz, bindex, rowform);
 		LIS_SCALAR *hv = (LIS_SCALAR *)lazy_host(Aout, sizeof(double) * (size_t)bnnz * (size_t)bnr * (size_t)bnc, bval, rowform);
-		if (!hp || !hi || !hv) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert: address space\n");
+		if (!hp || !hi || !hv) {
+			/* the pages that were made go (with the row form they own their buffer and free it), a buffer whose pages were not made is freed here; without the
+			 * row form the buffers are d's and go with the half-made copy (lisd_mat_free in the caller's error path) */
+			if (hp) (void)lisp_free_array(hp); else if (rowform) (void)liship_free(bptr);
+			if (hi) (void)lisp_free_array(hi); else if (rowform) (void)liship_free(bindex);
+			if (hv) (void)lisp_free_array(hv); else if (rowform) (void)liship_free(bval);
+			return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert: address space\n");
+		}
 		err = lis_matrix_set_bsr(bnr, bnc, bnnz, hp, hi, hv, Aout);
 		if (!err) { Aout->pad_comm = pad; d->nc = Aout->nc; }
 	}
@@ -1058,6 +1194,17 @@ LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A)
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	const long long listed = MDEV(A)->plan ? liship_csr_plan_localized(MDEV(A)->plan) : 0;
 	return listed > 0x7fffffffLL ? 0x7fffffff : (LIS_INT)listed;
+}
+LIS_INT lis_amd_set_matrix_check(LIS_INT on) { lisg.matrix_check = on ? 1 : 0; return LIS_SUCCESS; }
+LIS_INT lis_amd_matrix_host_written(LIS_MATRIX A) { return MDEV(A)->host_written; }
+/* tests of the write watch without a GPU: the arrays of an assembled matrix are adopted and write-protected exactly as lisd_mat_ready does after an upload */
+LIS_INT lis_amd_matrix_page_test_watch(LIS_MATRIX A)
+{
+	const void *arr[6]; size_t bytes[6];
+	const int k = host_arrays(A, arr, bytes);
+	MDEV(A)->host_written = 0;
+	for (int i = 0; i < k; i++) (void)lisp_adopt(A, (void *)arr[i]);
+	return lisp_matrix_protect(A);
 }
 LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A)
 {

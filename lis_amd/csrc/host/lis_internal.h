@@ -50,6 +50,9 @@ typedef struct {
 /* ---- matrices ----------------------------------------------------------------------------------- */
 typedef struct {
 	int ready;                 /* HBM copy is built */
+	int host_written;          /* the program wrote one of the host arrays the copy was built from (page fault, lis_pages.c): rebuilt before the next use */
+	int checked;               /* LIS_AMD_MATRIX_CHECK=1: host_hash holds the hash of the host arrays the copy was built from */
+	unsigned long long host_hash;
 	int device_only;           /* arrays were adopted from the caller; no host copy exists */
 	int type;                  /* kernel family actually used (CSC is served as transposed CSR) */
 	int n, np, nnz;
@@ -124,6 +127,7 @@ typedef struct {
 	int host_scalars;          /* LIS_AMD_HOST_SCALARS=1: CG / BiCGSTAB read every scalar back (A/B against the device-driven loops) */
 	int no_overlap;            /* LIS_AMD_NO_OVERLAP=1: exchange first, then the whole product (A/B measurements) */
 	int ref_reductions;        /* LIS_AMD_REFERENCE_REDUCTIONS=T / lis_amd_set_reference_reductions(T): sums in the reference's order for T threads (parity mode) */
+	int matrix_check;          /* LIS_AMD_MATRIX_CHECK=1 / lis_amd_set_matrix_check(1): every use of a matrix re-hashes its host arrays and rebuilds a stale HBM copy (debugging aid for caller-malloc'ed arrays) */
 	int no_direct_halo;        /* LIS_AMD_NO_DIRECT_HALO=1: boundary rows that form a run are packed like any other list instead of being sent straight from x (A/B) */
 	lis_amd_comm_callbacks cb;
 } lisi_globals;
@@ -145,7 +149,16 @@ int  lisp_free_array(void *p);                                /* 1: p lived on s
 LIS_INT lisp_fill_matrix(void *matrix);
 int  lisp_lazy_arrays(void *matrix);
 void lisp_reown(void *from, void *to);
+void *lisp_alloc_tracked(size_t bytes_used);                  /* an array of lis_matrix_malloc_<fmt>: pages whose writes are seen once a matrix adopted and uploaded it */
+int  lisp_adopt(void *matrix, void *array);
+int  lisp_matrix_protect(void *matrix);
+void lisp_matrix_release(void *matrix, int forget);
+int  lisp_protected_arrays(void *matrix);
+size_t lisp_array_bytes(void *p);
 LIS_INT lisd_staged_d2h(void *dst, const void *src, size_t bytes);   /* HBM -> pageable host memory through the pinned staging buffers */
+LIS_INT lisd_staged_d2h_fault(void *dst, const void *src, size_t bytes);   /* the same from inside the page-fault handler: a stream and buffers of its own, no OpenMP */
+LIS_INT lisd_fault_stage_prepare(void);                             /* (made when the handler is installed, never inside it) */
+void    lisd_capture_mark(int on);                                  /* a hipGraph capture of the library's stream begins / ends: fault-time copies wait it out */
 LIS_INT lisd_vec_host_write(LIS_VECTOR v, int keep);          /* the library is about to write value[] on the host (keep: current data needed first) */
 
 /* ---- device runtime (lis_device.c) */

@@ -145,7 +145,15 @@ LIS_INT lis_matrix_set_blocksize(LIS_MATRIX A, LIS_INT bnr, LIS_INT bnc, LIS_INT
 LIS_INT lis_matrix_is_assembled(LIS_MATRIX A) { return A->status != LIS_MATRIX_NULL ? !LIS_SUCCESS : LIS_SUCCESS; }
 
 /* ------------------------------------------------------------------ array allocation + adoption */
-#define ALLOC_OR_FAIL(p, T, count) do { (p) = (T *)malloc(sizeof(T) * (size_t)((count) > 0 ? (count) : 1)); \
+/* The arrays of lis_matrix_malloc_<fmt> live on pages of the library's own (lis_pages.c, lisp_alloc_tracked): once a matrix has adopted them and its HBM copy is
+ * built, a host write to them is SEEN (one page fault) and the copy is rebuilt before the next product -- the reference reads adopted arrays live on every call
+ * (lis_matrix_csr.c:98-103, lis_matvec_csr.c:97-109).  Released by lis_matrix_destroy / lis_free, never by free().  Without a memory file: plain malloc. */
+static void *matrix_array(size_t bytes)
+{
+	void *p = lisp_alloc_tracked(bytes);
+	return p ? p : malloc(bytes ? bytes : 1);
+}
+#define ALLOC_OR_FAIL(p, T, count) do { (p) = (T *)matrix_array(sizeof(T) * (size_t)((count) > 0 ? (count) : 1)); \
 	if (!(p)) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)(count)); } while (0)
 
 LIS_INT lis_matrix_malloc_csr(LIS_INT n, LIS_INT nnz, LIS_INT **ptr, LIS_INT **index, LIS_SCALAR **value)
@@ -406,6 +414,7 @@ LIS_INT lisi_matrix_storage_destroy(LIS_MATRIX A)
 		free(A->conv_row); free(A->conv_col);
 	}
 	lisd_mat_free(A);                       /* (after the arrays: one that was never read dies unmaterialised) */
+	lisp_matrix_release(A, 1);              /* arrays that outlive the matrix (is_destroy off) are nobody's from here on */
 	A->ptr = A->row = A->col = A->index = A->bptr = A->bindex = NULL;
 	A->value = A->work = NULL;
 	A->conv_row = A->conv_col = NULL;
@@ -429,6 +438,7 @@ LIS_INT lis_matrix_unset(LIS_MATRIX A)
 	LISCHK(lisi_matrix_check(A, LISI_CHECK_NULL));
 	if (A->is_copy) lisi_matrix_storage_destroy(A);
 	lisd_mat_free(A);
+	lisp_matrix_release(A, 1);              /* the caller's again */
 	A->ptr = A->row = A->col = A->index = A->bptr = A->bindex = NULL;
 	A->value = NULL;
 	A->is_copy = LIS_FALSE;

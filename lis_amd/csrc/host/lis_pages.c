@@ -30,6 +30,13 @@
  * It therefore may take the registry lock and call the HIP runtime.  Faults at addresses that are no region's go to whoever handled
  * SIGSEGV before; the disposition is never reset for an address inside a region.
  *
+ * The handler is NOT async-signal-safe in the POSIX sense -- it takes a mutex, may wait on a condition variable and calls the HIP runtime -- and does not need to be:
+ * it runs only for a synchronous fault of ordinary user code on a protected buffer, never for an asynchronous signal.  What follows from that is a rule for callers:
+ * a protected buffer must not be handed to code that touches it WHILE HOLDING a lock the handler's callees need (a malloc arena, the HIP runtime's own locks): in
+ * practice, do not pass v->value to another library's internals without lis_amd_vector_sync_host(v) first.  To keep the handler's own footprint small it copies
+ * through a stream, pinned buffers and events of its own (lisd_staged_d2h_fault: nothing is enqueued on the library's stream from the faulting thread, a hipGraph
+ * capture in progress there is waited out, not invalidated) and with plain memcpy -- no OpenMP region is opened from inside it.
+ *
  * What page protection cannot do: a SYSTEM CALL that is handed a protected buffer (write(2) / fwrite of a large v->value, MPI_Send,
  * another device's DMA) does not fault, it fails with EFAULT (a short count from fwrite).  Programs that pass v->value to the kernel
  * call lis_amd_vector_sync_host(v) first (read access) / lis_amd_vector_host_modified(v) after (write access), or run with
@@ -60,9 +67,13 @@ typedef struct lisp_region {
 	void *dev;               /* device buffer holding the array (NULL once the host pages hold it) */
 	size_t used;             /* bytes of the array */
 	int own_dev;             /* the buffer exists only to back these pages: freed once they are filled (else it is part of the matrix's HBM copy) */
+	/* ... or an array handed out by lis_matrix_malloc_<fmt> (lisp_alloc_tracked): plain memory until a matrix adopts it (mowner) and uploads it; from then on
+	 * read-only, and the first host write marks the matrix's HBM copy stale (the reference reads the adopted arrays live on every product, lis_matvec_csr.c:97-109) */
+	int tracked;
 	/* test hook (lis_amd_vector_page_test_source): a host buffer standing in for the HBM copy, copied in two halves `test_delay_ms` apart */
 	const double *test_src;
-	int test_delay_ms;
+	int test_delay_ms;       /* > 0: that pause between the halves; < 0: the second half waits until -test_delay_ms other threads wait for the copy */
+	int waiters;             /* threads that found the current copy in flight */
 	struct lisp_region *next;
 } lisp_region;
 
@@ -86,8 +97,9 @@ static int native_prot(int prot) { return prot == LISP_RW ? (PROT_READ | PROT_WR
 
 /* ---- the copy that brings a region home.  Called with r->filling set by the caller (under region_lock) and the lock RELEASED; the
  * program's mapping keeps whatever protection it has (none, on every path that matters) until the data is complete. */
-static LIS_INT region_fill(lisp_region *r, int prot_after)
+static LIS_INT region_fill(lisp_region *r, int prot_after, int from_fault)
 {
+	LIS_INT (*d2h)(void *, const void *, size_t) = from_fault ? lisd_staged_d2h_fault : lisd_staged_d2h;
 	LIS_INT err = LIS_SUCCESS;
 	if (r->owner) {
 		LIS_VECTOR v = r->owner;
@@ -96,24 +108,42 @@ static LIS_INT region_fill(lisp_region *r, int prot_after)
 			const size_t half = d->hlen / 2;
 			memcpy(r->alias, r->test_src, half * sizeof(double));
 			if (r->test_delay_ms > 0) usleep((useconds_t)r->test_delay_ms * 1000);
+			else if (r->test_delay_ms < 0) {                  /* hold the copy until that many other threads wait for it (deterministic tests; 10 s at most) */
+				for (int ms = 0; ms < 10000; ms++) {
+					pthread_mutex_lock(&region_lock);
+					const int enough = r->waiters >= -r->test_delay_ms;
+					pthread_mutex_unlock(&region_lock);
+					if (enough) break;
+					usleep(1000);
+				}
+			}
 			memcpy(r->alias + half * sizeof(double), r->test_src + half, (d->hlen - half) * sizeof(double));
 		} else if (d->d && d->dev_valid && !d->host_valid) {
 			const size_t len = d->hlen < d->cap ? d->hlen : d->cap;
-			err = lisd_staged_d2h(r->alias, d->d, len * sizeof(double));
+			err = d2h(r->alias, d->d, len * sizeof(double));
 		}
-		d->host_valid = 1;
+		if (!err) d->host_valid = 1;                          /* (a failed copy leaves the pages without access and the HBM copy the truth) */
 	} else {
 		void *dev = r->dev;
-		if (dev && r->used) err = lisd_staged_d2h(r->alias, dev, r->used);
-		if (dev && r->own_dev) (void)liship_free(dev);
-		r->dev = NULL;
+		if (dev && r->used) err = d2h(r->alias, dev, r->used);
+		if (!err) {                                           /* (a failed copy keeps its source: the array's only copy) */
+			if (dev && r->own_dev) (void)liship_free(dev);
+			r->dev = NULL;
+		}
 	}
 	pthread_mutex_lock(&region_lock);
 	if (!err && mprotect(r->base, r->bytes, native_prot(prot_after)) == 0) r->prot = prot_after;
 	r->filling = 0;
+	r->waiters = 0;
 	pthread_cond_broadcast(&fill_done);
 	pthread_mutex_unlock(&region_lock);
 	return err;
+}
+
+/* does `matrix` hold an HBM copy that a host write to one of its arrays would leave stale? (lazy coherence only: the other modes never protect) */
+static int matrix_copy_live(void *matrix)
+{
+	return matrix && lisp_lazy() && MDEV((LIS_MATRIX)matrix)->ready && !MDEV((LIS_MATRIX)matrix)->device_only;
 }
 
 static void chain_to_previous(int sig, siginfo_t *info, void *context)
@@ -138,9 +168,15 @@ static void on_fault(int sig, siginfo_t *info, void *context)
 		pthread_mutex_lock(&region_lock);
 		for (r = regions; r; r = r->next) if (addr >= r->base && addr < r->base + r->bytes) break;
 		if (r && r->filling) {
-			/* another thread is bringing this region home: wait until its copy is complete, then retry the access */
+			/* another thread is bringing this region home: wait until its copy is complete, then retry the access.  (The region is looked up again after
+			 * every wake-up: a thread that destroys the vector waits for the same copy and may have freed the region by the time this one runs.) */
 			faults_waited++;
-			while (r->filling) pthread_cond_wait(&fill_done, &region_lock);
+			r->waiters++;
+			for (;;) {
+				pthread_cond_wait(&fill_done, &region_lock);
+				for (r = regions; r; r = r->next) if (addr >= r->base && addr < r->base + r->bytes) break;
+				if (!r || !r->filling) break;
+			}
 			pthread_mutex_unlock(&region_lock);
 			tl_last_fault = NULL; tl_repeats = 0;
 			errno = saved_errno;
@@ -148,12 +184,13 @@ static void on_fault(int sig, siginfo_t *info, void *context)
 		}
 		if (r && r->prot == LISP_NONE) {
 			/* the HBM copy is the truth: bring it home through the alias; the program's mapping opens when the data is there --
-			 * read-only for a vector (both sides agree now; a write faults once more), read + write for a matrix array (plain memory from here on) */
+			 * read-only for a vector (both sides agree now; a write faults once more) and for an array of a matrix whose HBM copy lives (a write marks
+			 * that copy stale), read + write for any other matrix array (plain memory from here on) */
 			r->filling = 1;
 			faults_read++;
 			pthread_mutex_unlock(&region_lock);
 			if (lisg.device_ready) (void)liship_set_device(lisg.device);      /* (this thread may never have called the runtime) */
-			const LIS_INT err = region_fill(r, r->owner ? LISP_RO : LISP_RW);
+			const LIS_INT err = region_fill(r, (r->owner || matrix_copy_live(r->mowner)) ? LISP_RO : LISP_RW, 1);
 			if (err != LIS_SUCCESS) {
 				fprintf(stderr, "liblis_amd: could not bring %s back from HBM inside the page-fault handler\n", r->owner ? "a vector" : "a matrix array");
 				abort();
@@ -167,6 +204,7 @@ static void on_fault(int sig, siginfo_t *info, void *context)
 			faults_write++;
 			if (mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE) == 0) r->prot = LISP_RW;
 			if (v) { VDEV(v)->host_valid = 1; VDEV(v)->dev_valid = 0; }      /* the host array is being written: the HBM copy is stale from here on */
+			else if (r->mowner) MDEV((LIS_MATRIX)r->mowner)->host_written = 1;      /* ... the matrix's: rebuilt (arrays, plan) before its next product */
 			pthread_mutex_unlock(&region_lock);
 			tl_last_fault = NULL; tl_repeats = 0;
 			errno = saved_errno;
@@ -189,7 +227,7 @@ static void on_fault(int sig, siginfo_t *info, void *context)
 
 static int install_handler(void)
 {
-	if (handler_installed) return 1;
+	if (handler_installed) { (void)lisd_fault_stage_prepare(); return 1; }      /* (no-op once made; the device may have come up since the handler was installed) */
 	if (handler_failed) return 0;
 	struct sigaction sa;
 	memset(&sa, 0, sizeof(sa));
@@ -203,6 +241,7 @@ static int install_handler(void)
 		return 0;
 	}
 	handler_installed = 1;
+	(void)lisd_fault_stage_prepare();              /* the stream and pinned buffers fault-time copies use: made here, in ordinary context */
 	return 1;
 }
 
@@ -300,6 +339,87 @@ void *lisp_alloc_lazy(void *matrix, size_t bytes_used, void *dev, int own_dev)
 	return r->base;
 }
 
+/* ---- arrays handed out by lis_matrix_malloc_<fmt> (src/matrix/lis_matrix_csr.c:170 and its siblings): library memory that a program fills, hands to
+ * lis_matrix_set_<fmt> (adopted, not copied: lis_matrix_csr.c:98-103) and may keep writing to between solves -- the reference reads it live on every product.
+ * They live on pages like a vector's: read + write until the adopting matrix is uploaded, read-only from then on; a host write faults once, opens the pages and
+ * marks the HBM copy (arrays, plan, transposed operator) stale, and the next product rebuilds it.  NULL: no memory file (the caller uses malloc; untracked). */
+void *lisp_alloc_tracked(size_t bytes_used)
+{
+	const size_t ps = page_size();
+	size_t bytes = (bytes_used > 0 ? bytes_used : 1);
+	bytes = (bytes + ps - 1) / ps * ps;
+	lisp_region *r = (lisp_region *)calloc(1, sizeof(*r));
+	if (!r) return NULL;
+	if (map_twice(bytes, LISP_RW, &r->base, &r->alias) != 0) { free(r); return NULL; }
+	r->bytes = bytes; r->prot = LISP_RW; r->used = bytes_used; r->tracked = 1;
+	pthread_mutex_lock(&region_lock);
+	r->next = regions; regions = r;
+	pthread_mutex_unlock(&region_lock);
+	return r->base;
+}
+
+/* `matrix` adopts `array` (lis_matrix_set_<fmt>, assemble): 1 when the array lives on tracked pages */
+int lisp_adopt(void *matrix, void *array)
+{
+	int hit = 0;
+	if (!array) return 0;
+	pthread_mutex_lock(&region_lock);
+	for (lisp_region *r = regions; r; r = r->next)
+		if ((char *)array == r->base && r->tracked) { r->mowner = matrix; hit = 1; break; }
+	pthread_mutex_unlock(&region_lock);
+	return hit;
+}
+
+/* the HBM copy of `matrix` was just built from its host arrays: those that live on pages of the library's become read-only (lazy coherence).
+ * Returns how many arrays are now write-protected. */
+int lisp_matrix_protect(void *matrix)
+{
+	int c = 0;
+	if (!lisp_lazy() || !install_handler()) return 0;
+	pthread_mutex_lock(&region_lock);
+	for (lisp_region *r = regions; r; r = r->next) {
+		if (r->mowner != matrix || r->filling) continue;
+		if (r->prot == LISP_RW && mprotect(r->base, r->bytes, PROT_READ) == 0) r->prot = LISP_RO;
+		c += r->prot == LISP_RO;
+	}
+	pthread_mutex_unlock(&region_lock);
+	return c;
+}
+
+/* the HBM copy of `matrix` is gone (or the matrix lets go of its arrays: lis_matrix_unset, destroy without is_destroy): its read-only arrays are plain memory again.
+ * forget: the arrays no longer belong to it at all */
+void lisp_matrix_release(void *matrix, int forget)
+{
+	pthread_mutex_lock(&region_lock);
+	for (lisp_region *r = regions; r; r = r->next) {
+		if (r->mowner != matrix) continue;
+		if (r->prot == LISP_RO && !r->filling && mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE) == 0) r->prot = LISP_RW;
+		if (forget) r->mowner = NULL;
+	}
+	pthread_mutex_unlock(&region_lock);
+}
+
+/* bytes of the array at p when it lives on pages of the library's (made current on the host first), else 0 */
+size_t lisp_array_bytes(void *p)
+{
+	size_t b = 0;
+	if (!p) return 0;
+	pthread_mutex_lock(&region_lock);
+	for (lisp_region *r = regions; r; r = r->next) if ((char *)p == r->base && !r->owner) { b = r->used ? r->used : 1; break; }
+	pthread_mutex_unlock(&region_lock);
+	return b;
+}
+
+/* how many arrays of `matrix` are write-protected right now (tests) */
+int lisp_protected_arrays(void *matrix)
+{
+	int c = 0;
+	pthread_mutex_lock(&region_lock);
+	for (lisp_region *r = regions; r; r = r->next) c += (r->mowner == matrix && r->prot == LISP_RO);
+	pthread_mutex_unlock(&region_lock);
+	return c;
+}
+
 static lisp_region *region_at(const void *p)
 {
 	for (lisp_region *r = regions; r; r = r->next) if ((const char *)p == r->base) return r;
@@ -340,7 +460,7 @@ LIS_INT lisp_fill_matrix(void *matrix)
 		}
 		r->filling = 1;
 		pthread_mutex_unlock(&region_lock);
-		LISCHK(region_fill(r, LISP_RW));
+		LISCHK(region_fill(r, LISP_RW, 0));
 	}
 }
 
@@ -423,7 +543,7 @@ LIS_INT lisp_vec_home(LIS_VECTOR v)
 	}
 	r->filling = 1;
 	pthread_mutex_unlock(&region_lock);
-	return region_fill(r, LISP_RO);
+	return region_fill(r, LISP_RO, 0);
 }
 
 /* lazy coherence applies to the COHERENT residency unless switched off */
@@ -436,6 +556,7 @@ LIS_INT lis_amd_set_coherence(LIS_INT lazy)
 }
 
 LIS_INT lis_amd_matrix_lazy_arrays(LIS_MATRIX A) { return lisp_lazy_arrays(A); }
+LIS_INT lis_amd_matrix_protected_arrays(LIS_MATRIX A) { return lisp_protected_arrays(A); }
 LIS_INT lis_amd_set_device_convert(LIS_INT on) { lisg.no_device_convert = on ? 0 : 1; return LIS_SUCCESS; }
 LIS_INT lis_amd_vector_page_state(LIS_VECTOR v) { return lisp_state(v); }
 LIS_INT lis_amd_vector_page_protect(LIS_VECTOR v, LIS_INT state) { lisp_protect(v, (int)state); return lisp_state(v) == (int)state ? LIS_SUCCESS : LIS_ERR_ILL_ARG; }

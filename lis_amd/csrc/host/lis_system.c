@@ -99,13 +99,21 @@ int lisi_host_threads(void)
  * malloc/free gives the same observable behaviour. */
 void *lis_malloc(size_t size, char *tag) { (void)tag; return malloc(size ? size : 1); }
 void *lis_calloc(size_t size, char *tag) { (void)tag; return calloc(size ? size : 1, 1); }
-void *lis_realloc(void *p, size_t size) { return realloc(p, size ? size : 1); }
-void  lis_free(void *p) { free(p); }
+/* (arrays of lis_matrix_malloc_<fmt> live on pages of the library's, lis_pages.c: lis_free / lis_realloc know them, free() does not) */
+void *lis_realloc(void *p, size_t size)
+{
+	const size_t have = lisp_array_bytes(p);
+	if (!have) return realloc(p, size ? size : 1);
+	void *q = malloc(size ? size : 1);
+	if (q) { memcpy(q, p, have < size ? have : size); (void)lisp_free_array(p); }
+	return q;
+}
+void  lis_free(void *p) { if (!lisp_free_array(p)) free(p); }
 void  lis_free2(LIS_INT n, ...)
 {
 	va_list ap;
 	va_start(ap, n);
-	for (LIS_INT i = 0; i < n; i++) { void *p = va_arg(ap, void *); if (p) free(p); }
+	for (LIS_INT i = 0; i < n; i++) { void *p = va_arg(ap, void *); if (p) lis_free(p); }
 	va_end(ap);
 }
 LIS_INT lis_is_malloc(void *p) { return lisi_is_registered(p) ? LIS_TRUE : LIS_FALSE; }
@@ -233,6 +241,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_overlap = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_DIRECT_HALO");
 		lisg.no_direct_halo = (r && r[0] == '1');
+		r = getenv("LIS_AMD_MATRIX_CHECK");
+		lisg.matrix_check = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_INDEX_CODES");
 		lisg.no_index_codes = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_ROW_PATTERNS");

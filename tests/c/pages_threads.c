@@ -3,7 +3,8 @@
  * Test driver of lis_amd/csrc/host/lis_pages.c (built by tests/test_host_cpu.py / tests/test_pages_gpu.py with gcc -fopenmp against
  * include/ and liblis_amd.so).  Every mode prints "ok ..." and exits 0, or prints what it saw and exits 1.
  *
- *   cpu-readers  T R   no GPU: a host buffer plays the HBM copy (lis_amd_vector_page_test_source, copied home in two halves 150 ms apart);
+ *   cpu-readers  T R   no GPU: a host buffer plays the HBM copy (lis_amd_vector_page_test_source, copied home in two halves, the second held until another
+ *                      thread waits for the copy);
  *                      T threads read disjoint slices of v->value at once, R rounds over the same vector (same thread -> same slice:
  *                      the second and third round fault at the addresses of the first)
  *   cpu-writers  T     the same, the threads WRITE their slices
@@ -38,7 +39,8 @@ static int cpu_threads(int T, int rounds, int writers)
 		for (LIS_INT i = 0; i < n; i++) src[i] = i + 0.5 + round;
 		lis_amd_vector_host_modified(v);
 		for (LIS_INT i = 0; i < n; i++) v->value[i] = -7.0;          /* what a thread must never see once "a kernel wrote v" */
-		if (lis_amd_vector_page_test_source(v, src, 150) != 0) return fail("no page protection here", 0, 0);
+		/* the copy comes home in two halves; with several threads the second half is held until another thread waits for the copy (deterministic), else 150 ms apart */
+		if (lis_amd_vector_page_test_source(v, src, T > 1 ? -1 : 150) != 0) return fail("no page protection here", 0, 0);
 		if (lis_amd_vector_page_state(v) != 2) return fail("state before", lis_amd_vector_page_state(v), 2);
 		long bad = 0;
 #pragma omp parallel num_threads(T) reduction(+ : bad)

@@ -134,6 +134,28 @@ def main():
             assert np.all(np.abs(yb - yg[is_:ie]) <= 1e-13 * sc), (name, bs)
             lib.lis_matrix_destroy(B)
 
+        # a solve the multi-rank job cannot serve is refused BEFORE A and b are touched: -scale jacobi -storage bsr retypes, splits and scales A in place and scales b,
+        # and the solvers that multiply by A^T would then fail at their first transposed product of the split matrix (one rank only, lis_matvech.c)
+        if world > 1:
+            S = capi.PS()
+            assert lib.lis_solver_create(C.byref(S)) == 0
+            assert lib.lis_solver_set_option(b"-i bicg -p none -scale jacobi -storage bsr -maxiter 5 -print none", S) == 0
+            vb, vs = lisdrv.new_vector(lib, A, None), lisdrv.new_vector(lib, A, None)
+            assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(yg[is_:ie]).ctypes.data_as(capi.P_DBL), vb) == 0
+            devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(2)       # (the refusal prints the reference's "file(line) : func : error" line)
+            os.dup2(devnull, 2)
+            try:
+                rc = lib.lis_solve(A, vb, vs, S)
+            finally:
+                os.dup2(saved, 2); os.close(devnull); os.close(saved)
+            assert rc == capi.LIS_ERR_NOT_IMPLEMENTED, (name, rc)
+            assert a.matrix_type == 1 and a.is_splited == 0 and a.is_scaled == 0, (name, a.matrix_type)      # still the CSR matrix it was
+            after = lisdrv.matrix_arrays(A)
+            assert np.array_equal(after["value"], got["value"]) and np.array_equal(after["index"], got["index"]), name
+            bvals = np.empty(n)
+            assert lib.lis_vector_get_values(vb, is_, n, bvals.ctypes.data_as(capi.P_DBL)) == 0 and np.array_equal(bvals, yg[is_:ie]), name
+            lib.lis_solver_destroy(S); lib.lis_vector_destroy(vb); lib.lis_vector_destroy(vs)
+
         # vectors of the partition: ranges, gather, infinity norm (host-side collectives)
         v = lisdrv.new_vector(lib, A, None)
         assert (v.contents.n, v.contents.np, v.contents.gn, v.contents.is_) == (n, a.np, gn, is_)

@@ -109,6 +109,43 @@ def test_config4_class_solvers_need_the_reference_iteration_counts(lib, name, op
     lib.lis_matrix_destroy(A)
 
 
+@pytest.mark.parametrize("opts", list(GOLD["tail"]["solves"]))
+def test_long_row_tree_is_a_supported_mode(lib, opts):
+    """The long-row policy (README "Parity"): rows beyond the LDS stage are ONE left-to-right chain by default -- the reference's bits, at the price of a serial chain
+    on hub rows -- and LIS_AMD_LONG_ROW_TREE=1 (liship_spmv_csr_set_long_row_tree) trades those rows' last bits for a workgroup tree.  The tree is a supported mode,
+    not an experiment: on the heavy-tailed fixture (rows up to 9000 entries) every row stays within 1e-14 of the sum of its terms' magnitudes, rows that cannot
+    overflow a stage (up to 128 entries) keep the reference's bits, two runs give the same bits, and the solvers meet the reference's iteration counts with the default mode's slack."""
+    ptr, idx, val = _matrix("tail")
+    n = len(ptr) - 1
+    x_true = np.cos(np.arange(n) * 0.01) + 1.25
+    yref = orc.spmv_csr(ptr, idx, val, x_true)
+    want = GOLD["tail"]["solves"][opts]
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    lib.dll.lis_amd_set_residency(1)
+    check_ = lis_amd.check
+    check_(lib.liship_spmv_csr_set_long_row_tree(1))
+    try:
+        y1, y2 = lisdrv.matvec(lib, A, x_true), lisdrv.matvec(lib, A, x_true)
+        assert np.array_equal(y1.view(np.uint64), y2.view(np.uint64))
+        lens = np.diff(ptr)
+        short = lens <= 128                                   # (a row block takes whole rows up to its stage + 128 items of slack: such rows never overflow it; longer ones
+                                                              #  do when they happen to start near the end of their block's stage -- the part beyond it is the tree's)
+        assert np.array_equal(y1[short].view(np.uint64), yref[short].view(np.uint64))
+        absum = np.add.reduceat(np.abs(val * x_true[idx]), np.minimum(ptr[:-1], len(val) - 1).astype(np.int64)) * (lens > 0)
+        assert np.all(np.abs(y1 - yref) <= 1e-14 * absum + 0.0), float(np.max(np.abs(y1 - yref) / np.maximum(absum, 1e-300)))
+        assert (lens > 4096).any()                            # the fixture does have rows the tree serves
+        res = lisdrv.solve(lib, A, yref, opts + " -tol 1e-12 -maxiter 2000 -print mem")
+    finally:
+        check_(lib.liship_spmv_csr_set_long_row_tree(0))
+        lib.dll.lis_amd_set_residency(0)
+    solver = opts.split()[1]
+    assert res["status"] == want["status"] == 0 and res["resid"] <= 1e-12
+    slack = SLACK[solver] if want["iter"] < 200 else max(SLACK[solver], want["iter"] // 50)
+    assert abs(res["iter"] - want["iter"]) <= slack, (res["iter"], want["iter"])
+    assert np.abs(res["x"] - x_true).max() / np.abs(x_true).max() <= 1e-8
+    lib.lis_matrix_destroy(A)
+
+
 def test_config4_queen_scale_through_the_matrix_market_reader(lib):
     """BASELINE config 4 at its own scale.  Queen_4147 cannot be fetched, so tests/golden/gen_queen_class.c writes its stand-in on
     this box -- 4.1 M rows, 2.9e8 non-zeros, 3 unknowns per node, scrambled node numbering, a 3.3 GB SYMMETRIC coordinate file with

@@ -401,6 +401,70 @@ def test_vector_pages_follow_the_flags_through_faults(lib):
     lib.lis_vector_destroy(d); lib.lis_vector_destroy(v)
 
 
+def test_matrix_arrays_from_lis_matrix_malloc_are_watched_for_host_writes(lib):
+    """lis_matrix_malloc_csr (ref lis_matrix_csr.c:170) hands out pages of the library's own: plain memory until the adopting matrix's HBM copy is built, read-only
+    from then on; reads stay free, the first host write to an array opens it and marks the copy stale (the reference reads adopted arrays live on every product,
+    lis_matvec_csr.c:97-109).  Driven here without a GPU through lis_amd_matrix_page_test_watch, which protects exactly as an upload does.  Arrays the caller
+    malloc'ed cannot be watched; lis_free / lis_matrix_destroy / lis_matrix_unset take the pages back in whatever state they are."""
+    dll = lib.dll
+    for f in (dll.lis_amd_matrix_page_test_watch, dll.lis_amd_matrix_protected_arrays, dll.lis_amd_matrix_host_written):
+        f.argtypes = [capi.PM]
+    dll.lis_amd_page_faults.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+    def faults():
+        r, w = C.c_int(), C.c_int()
+        dll.lis_amd_page_faults(C.byref(r), C.byref(w))
+        return r.value, w.value
+    ptr, idx, val = orc.poisson3d(12, 10, 8)
+    A = lisdrv.make_csr(lib, ptr, idx, val)                      # lis_matrix_malloc_csr + set_csr + assemble
+    nnz = len(idx)
+    hv = np.ctypeslib.as_array(A.contents.value, shape=(nnz,))
+    hi = np.ctypeslib.as_array(A.contents.index, shape=(nnz,))
+    hv[3] = 2.5                                                  # before any HBM copy: plain memory
+    f0 = faults()
+    assert faults() == f0 and dll.lis_amd_matrix_protected_arrays(A) == 0
+    assert dll.lis_amd_matrix_page_test_watch(A) == 3 and dll.lis_amd_matrix_protected_arrays(A) == 3
+    assert hv[3] == 2.5 and int(hi[5]) == int(idx[5]) and faults() == f0 and dll.lis_amd_matrix_host_written(A) == 0      # reads are free
+    hv[7] = -4.0                                                 # the write faults once ...
+    assert faults() == (f0[0], f0[1] + 1) and hv[7] == -4.0
+    assert dll.lis_amd_matrix_host_written(A) == 1 and dll.lis_amd_matrix_protected_arrays(A) == 2      # ... value[] is open, ptr[] / index[] still watched
+    hv[8] = -5.0
+    assert faults() == (f0[0], f0[1] + 1)
+    hi[0] = int(idx[0])                                          # an index write is seen too
+    assert faults() == (f0[0], f0[1] + 2) and dll.lis_amd_matrix_protected_arrays(A) == 1
+    assert dll.lis_amd_matrix_page_test_watch(A) == 3 and dll.lis_amd_matrix_host_written(A) == 0         # "uploaded again"
+    assert lib.lis_matrix_destroy(A) == 0                        # unmaps protected pages without a fault
+    assert faults() == (f0[0], f0[1] + 2)
+    # arrays that never reach a matrix go back through lis_free; lis_matrix_unset hands watched arrays back to the program as plain memory
+    p, i, v = capi.P_INT(), capi.P_INT(), capi.P_DBL()
+    assert lib.lis_matrix_malloc_csr(10, 30, C.byref(p), C.byref(i), C.byref(v)) == 0
+    v[29] = 1.0
+    dll.lis_free.argtypes = [C.c_void_p]
+    dll.lis_free.restype = None
+    for a in (p, i, v):
+        dll.lis_free(C.cast(a, C.c_void_p))
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    keep = [C.cast(a, C.c_void_p).value for a in (A.contents.ptr, A.contents.index, A.contents.value)]      # (addresses: the struct's fields are cleared by unset)
+    assert dll.lis_amd_matrix_page_test_watch(A) == 3
+    dll.lis_matrix_unset.argtypes = [capi.PM]
+    assert dll.lis_matrix_unset(A) == 0 and dll.lis_amd_matrix_protected_arrays(A) == 0
+    f1 = faults()
+    kv = C.cast(keep[2], capi.P_DBL)
+    kv[0] = 9.0                                                  # the program's again: no fault, nobody's matrix
+    assert faults() == f1 and kv[0] == 9.0
+    assert lib.lis_matrix_destroy(A) == 0
+    for a in keep:
+        dll.lis_free(a)
+    # eager coherence never protects
+    dll.lis_amd_set_coherence(0)
+    try:
+        A = lisdrv.make_csr(lib, ptr, idx, val)
+        assert dll.lis_amd_matrix_page_test_watch(A) == 0 and dll.lis_amd_matrix_protected_arrays(A) == 0
+        lib.lis_matrix_destroy(A)
+    finally:
+        dll.lis_amd_set_coherence(1)
+
+
 def test_foreign_segfaults_still_kill_the_process():
     """the handler only answers for vector pages: any other bad access goes to the previous disposition (here: the default, death by SIGSEGV)"""
     import subprocess

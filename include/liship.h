@@ -40,6 +40,10 @@ int  liship_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int  liship_stream_create(void **stream);
 int  liship_stream_destroy(void *stream);
 int  liship_stream_synchronize(void *stream);
+/* watchdog for streams that carry collectives: with a limit > 0 liship_stream_synchronize polls and returns LISHIP_ERR_TIMEOUT (-2) when the stream has not
+ * drained within `seconds` (a peer that never arrived); 0 = wait for ever (default) */
+int  liship_set_sync_timeout(double seconds);
+#define LISHIP_ERR_TIMEOUT (-2)
 int  liship_device_synchronize(void);
 /* hipGraph capture of whatever is enqueued on `stream` between begin and end (the Krylov loops replay a batch of
  * iterations this way when the system is small enough to be launch bound -- the reference has no counterpart: its

@@ -99,6 +99,7 @@ _LISHIP = {
     "liship_spmv_csr_set_local_register_positions": (_ci, [_ci]),
     "liship_spmv_csr_set_xcd_strips": (_ci, [_ci]),
     "liship_csr_plan_scan_band": (_ci, [_vp, _vp, _vp, _vp]),
+    "liship_set_sync_timeout": (_ci, [C.c_double]),
     "liship_csr_plan_strip_rows": (_ci, [_vp]),
     "liship_spmv_csr_set_long_row_tree": (_ci, [_ci]),
     "liship_spmv_csr_set_uniform_rows": (_ci, [_ci]),

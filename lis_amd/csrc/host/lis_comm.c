@@ -17,8 +17,10 @@
  * A second backend routes the same calls through host-memory callbacks (lis_amd_comm_init_callbacks):
  * it exists so the partition / table / exchange logic is testable on CPU with torch.distributed+gloo.
  */
+#define _GNU_SOURCE
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "lis_internal.h"
 
 /* ------------------------------------------------------------------ RCCL, bound at run time */
@@ -60,6 +62,37 @@ static LIS_INT nccl_fail(const char *what, int rc)
 }
 #define NCCLCHK(call) do { int rc__ = (call); if (rc__ != 0) return nccl_fail(#call, rc__); } while (0)
 
+/* ncclCommInitRank blocks inside RCCL until every rank has joined: a rank that never comes (a crashed peer, a wrong world size) would hang the others for ever.
+ * It runs on a helper thread; the caller waits for it with the communication time limit and aborts the process, loudly, when it expires. */
+#include <pthread.h>
+#include <time.h>
+typedef struct { nccl_comm *out; int nprocs, rank, device, rc; nccl_uid id; } init_job;
+static void *init_thread(void *p)
+{
+	init_job *j = (init_job *)p;
+	(void)liship_set_device(j->device);
+	j->rc = rccl.CommInitRank(j->out, j->nprocs, j->id, j->rank);
+	return NULL;
+}
+static int comm_init_guarded(nccl_comm *out, int nprocs, const nccl_uid *id, int rank, int device)
+{
+	const char *e = getenv("LIS_AMD_COMM_TIMEOUT");
+	const double limit = e ? atof(e) : 300.0;
+	init_job j = {out, nprocs, rank, device, -1, *id};
+	if (limit <= 0.0) return rccl.CommInitRank(out, nprocs, *id, rank);
+	pthread_t th;
+	if (pthread_create(&th, NULL, init_thread, &j) != 0) return rccl.CommInitRank(out, nprocs, *id, rank);
+	struct timespec until;
+	clock_gettime(CLOCK_REALTIME, &until);
+	until.tv_sec += (time_t)limit + 1;
+	if (pthread_timedjoin_np(th, NULL, &until) != 0) {
+		fprintf(stderr, "liblis_amd: rank %d of %d: ncclCommInitRank did not return within %.0f s (LIS_AMD_COMM_TIMEOUT): a peer never joined -- aborting\n", rank, nprocs, limit);
+		fflush(stderr);
+		abort();
+	}
+	return j.rc;
+}
+
 LIS_INT lis_amd_comm_get_unique_id(void *id128)
 {
 	LISCHK(rccl_load());
@@ -82,10 +115,39 @@ LIS_INT lis_amd_comm_init_rccl(const void *id128, LIS_INT rank, LIS_INT nprocs, 
 	nccl_uid id;
 	memcpy(&id, id128, sizeof(id));
 	nccl_comm c = NULL;
-	NCCLCHK(rccl.CommInitRank(&c, nprocs, id, rank));
+	NCCLCHK(comm_init_guarded(&c, nprocs, &id, rank, device));
 	lisg.nccl_comm = c;
 	lisg.rank = rank; lisg.nprocs = nprocs;
 	HIPCHK(lisd_malloc((void **)&lisg.gather_out, sizeof(double) * 4 * (size_t)nprocs));
+	/* from here on a stream that waits for a peer that never arrives is a loud failure, not a hang (liship_set_sync_timeout, lisi_hip_error) */
+	{
+		const char *e = getenv("LIS_AMD_COMM_TIMEOUT");
+		const double limit = e ? atof(e) : 300.0;
+		HIPCHK(liship_set_sync_timeout(limit));
+	}
+	/* A communicator of its own for the halo exchange.  The overlapped product queues ncclSend/ncclRecv on the second stream while the folds' all-gathers run
+	 * on the library's stream (lisc_halo_begin / lisc_fold): two streams on ONE communicator are legal only as long as every operation is ordered against
+	 * every other, which the events do -- but it is the kind of arrangement that deadlocks on first contact with new hardware.  With two communicators the two
+	 * streams share nothing.  Its unique id is made on rank 0 and travels over the first communicator; if it cannot be formed on EVERY rank (an all-gathered
+	 * flag) the job goes on with the one communicator and says so. */
+	if (nprocs > 1 && !(getenv("LIS_AMD_ONE_COMMUNICATOR") && getenv("LIS_AMD_ONE_COMMUNICATOR")[0] == '1')) {
+		nccl_uid hid, *all = (nccl_uid *)malloc(sizeof(nccl_uid) * (size_t)nprocs);
+		int ok = all != NULL;
+		memset(&hid, 0, sizeof(hid));
+		if (ok && rank == 0) ok = rccl.GetUniqueId(&hid) == 0;
+		if (all && lisc_allgather_host(&hid, all, sizeof(hid)) != LIS_SUCCESS) ok = 0;      /* (every rank takes part whatever its own state) */
+		nccl_comm h = NULL;
+		if (ok) { hid = all[0]; ok = comm_init_guarded(&h, nprocs, &hid, rank, device) == 0; }
+		free(all);
+		int mine = ok, *flags = (int *)calloc((size_t)nprocs, sizeof(int));
+		if (flags && lisc_allgather_host(&mine, flags, sizeof(int)) == LIS_SUCCESS) { for (LIS_INT r = 0; r < nprocs; r++) ok = ok && flags[r]; } else ok = 0;
+		free(flags);
+		if (ok) lisg.nccl_halo = h;
+		else {
+			if (h) (void)rccl.CommDestroy(h);
+			if (rank == 0) fprintf(stderr, "liblis_amd: no second RCCL communicator for the halo exchange: sharing the first one (ordered by events)\n");
+		}
+	}
 	return LIS_SUCCESS;
 }
 
@@ -101,19 +163,25 @@ LIS_INT lis_amd_comm_init_callbacks(const lis_amd_comm_callbacks *cb, LIS_INT ra
 
 LIS_INT lis_amd_comm_finalize(void)
 {
-	if (lisg.comm_kind == 1 && lisg.nccl_comm) { (void)liship_device_synchronize(); (void)rccl.CommDestroy(lisg.nccl_comm); }
+	if (lisg.comm_kind == 1 && lisg.nccl_comm) {
+		(void)liship_device_synchronize();
+		if (lisg.nccl_halo) (void)rccl.CommDestroy(lisg.nccl_halo);
+		(void)rccl.CommDestroy(lisg.nccl_comm);
+		(void)liship_set_sync_timeout(0.0);
+	}
 	if (lisg.comm_stream) {
 		(void)liship_event_destroy(lisg.ev_packed); (void)liship_event_destroy(lisg.ev_landed);
 		(void)liship_stream_destroy(lisg.comm_stream);
 		lisg.comm_stream = lisg.ev_packed = lisg.ev_landed = NULL;
 	}
 	if (lisg.gather_out) { (void)liship_free(lisg.gather_out); lisg.gather_out = NULL; }
-	lisg.nccl_comm = NULL; lisg.comm_kind = 0; lisg.rank = 0; lisg.nprocs = 1;
+	lisg.nccl_comm = lisg.nccl_halo = NULL; lisg.comm_kind = 0; lisg.rank = 0; lisg.nprocs = 1;
 	return LIS_SUCCESS;
 }
 
 LIS_INT lis_amd_comm_rank(void) { return lisg.rank; }
 LIS_INT lis_amd_comm_kind(void) { return lisg.comm_kind; }
+LIS_INT lis_amd_comm_halo_communicator(void) { return lisg.nccl_halo != NULL; }      /* 1: the overlapped halo exchange has an RCCL communicator of its own */
 LIS_INT lis_amd_set_overlap(LIS_INT on) { lisg.no_overlap = on ? 0 : 1; return LIS_SUCCESS; }
 /* the halo exchange of one product on its own (pack, send/recv, ghosts landed), for timing it apart from the rows */
 LIS_INT lis_amd_halo_exchange(LIS_MATRIX A, LIS_VECTOR x)
@@ -355,12 +423,15 @@ static LIS_INT halo_rccl(LIS_MATRIX A, double *dx, void *stream)
 	lisd_mat *d = MDEV(A);
 	LIS_COMMTABLE t = A->commtable;
 	const LIS_INT n = A->n, pad = t->pad;
+	/* the exchange overlapped with the interior rows runs on the second stream AND the second communicator; the plain one (library's stream) stays on the first,
+	 * in line with the folds queued around it */
+	nccl_comm comm = (stream != lisg.stream && lisg.nccl_halo) ? lisg.nccl_halo : lisg.nccl_comm;
 	NCCLCHK(rccl.GroupStart());
 	for (LIS_INT i = 0; i < t->neibpetot; i++) {
 		const LIS_INT peer = t->neibpe[i];
 		const LIS_INT sc = t->export_ptr[i + 1] - t->export_ptr[i], rc = t->import_ptr[i + 1] - t->import_ptr[i];
-		if (sc > 0) NCCLCHK(rccl.Send(send_ptr(d, t, i, dx), (size_t)sc, NCCL_DOUBLE, peer, lisg.nccl_comm, stream));
-		if (rc > 0) NCCLCHK(rccl.Recv(dx + n + pad + t->import_ptr[i], (size_t)rc, NCCL_DOUBLE, peer, lisg.nccl_comm, stream));
+		if (sc > 0) NCCLCHK(rccl.Send(send_ptr(d, t, i, dx), (size_t)sc, NCCL_DOUBLE, peer, comm, stream));
+		if (rc > 0) NCCLCHK(rccl.Recv(dx + n + pad + t->import_ptr[i], (size_t)rc, NCCL_DOUBLE, peer, comm, stream));
 	}
 	NCCLCHK(rccl.GroupEnd());
 	return LIS_SUCCESS;

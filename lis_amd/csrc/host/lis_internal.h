@@ -107,6 +107,7 @@ typedef struct {
 	int rank, nprocs;
 	int comm_kind;             /* 0 none, 1 rccl, 2 callbacks */
 	void *nccl_comm;
+	void *nccl_halo;           /* a second communicator for the halo exchange on the second stream (NULL: the first one serves, ordered by events) */
 	void *comm_stream;         /* second HIP stream: halo send/recv overlapped with the interior rows */
 	void *ev_packed, *ev_landed;
 	int long_row_tree;         /* LIS_AMD_LONG_ROW_TREE=1: rows longer than the LDS stage are added by a tree per pass (not bit-parity; opt-in) */

@@ -20,8 +20,19 @@ LIS_INT lis_matvec(LIS_MATRIX A, LIS_VECTOR X, LIS_VECTOR Y)
 		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "storage format %D is not served by liblis_amd\n", A->matrix_type);
 	}
 	LISCHK(lisd_mat_ready(A));
-	/* like the reference, grow X to hold the ghost (and block padding) entries of A */
-	if (A->np + A->pad > X->np + X->pad) { X->np = A->np; X->pad = A->pad; }
+	/* like the reference (LIS_MATVEC_REALLOC, include/lis_matvec.h:32-43: lis_realloc of X->value to np + pad entries), X grows to hold the ghost and block
+	 * padding entries of A -- the host array too: a program that reads X->value[n ..) after a product in a multi-rank job must find memory there.  The new
+	 * entries are zero, the old ones keep their place, nothing is transferred: whichever copy is current stays the truth. */
+	if (A->np + A->pad > X->np + X->pad) {
+		const size_t need = (size_t)A->np + (size_t)A->pad;
+		lisd_vec *dv = VDEV(X);
+		if (X->value && dv->hlen < need) {
+			const int hv = dv->host_valid, dvv = dv->dev_valid;
+			LISCHK(lisp_grow(X, need));
+			if (lisp_lazy() && dv->region) lisp_protect(X, (!hv && dvv) ? LISP_NONE : (hv && dvv) ? LISP_RO : LISP_RW);
+		}
+		X->np = A->np; X->pad = A->pad;
+	}
 	double *dx, *dy;
 	size_t need_x = (size_t)(A->np + A->pad), need_y = (size_t)(A->n + A->pad);
 	if (A->matrix_type == LIS_MATRIX_BSR) { need_x = (size_t)A->nc * A->bnc; need_y = (size_t)A->nr * A->bnr; }

@@ -162,6 +162,14 @@ LIS_INT lisi_error(const char *file, const char *func, int line, LIS_INT code, c
 LIS_INT lisi_hip_error(const char *file, const char *func, int line, int hipcode)
 {
 	const char *base = strrchr(file, '/');
+	if (hipcode == LISHIP_ERR_TIMEOUT) {
+		/* the watchdog of a multi-rank job (lis_comm.c): a collective or a halo exchange this rank queued never completed.  Nothing useful can follow -- the
+		 * communicator is wedged and every later call would wait again -- so the job dies here, loudly, instead of hanging until somebody notices */
+		fprintf(stderr, "%s(%d) : %s : rank %d of %d: the stream did not drain within the communication time limit (LIS_AMD_COMM_TIMEOUT seconds): a peer of the RCCL "
+		        "communicator is missing or stuck in another collective -- aborting\n", base ? base + 1 : file, line, func, (int)lisg.rank, (int)(lisg.nprocs ? lisg.nprocs : 1));
+		fflush(stderr);
+		abort();
+	}
 	fprintf(stderr, "%s(%d) : %s : HIP error %d (%s) -- liblis_amd has no CPU fallback\n",
 	        base ? base + 1 : file, line, func, hipcode, liship_error_string(hipcode));
 	return hipcode == 2 /* hipErrorOutOfMemory */ ? LIS_ERR_OUT_OF_MEMORY : LIS_ERR_NOT_IMPLEMENTED;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #define LISHIP_ERR_ARG (-1)
+#define LISHIP_ERR_TIMEOUT (-2)   // liship_stream_synchronize: the stream did not drain within the limit of liship_set_sync_timeout
 
 // every launcher returns the hipError_t of the first failing runtime call
 #define HIP_TRY(expr)                                   \

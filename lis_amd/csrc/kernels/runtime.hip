@@ -1,5 +1,6 @@
 // runtime.hip -- device/memory/stream/timer utilities of the kernel-level C ABI (liship.h) and the
 // device-side generator of the synthetic 3-D Poisson inputs.
+#include <time.h>
 #include "common.hpp"
 #include "liship.h"
 #include <string.h>
@@ -38,7 +39,26 @@ extern "C" int liship_memcpy_d2d(void *dst, const void *src, size_t bytes, void 
 extern "C" int liship_stream_create(void **stream)
 { hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = s; return 0; }
 extern "C" int liship_stream_destroy(void *stream) { if (stream) HIP_TRY(hipStreamDestroy(as_stream(stream))); return 0; }
-extern "C" int liship_stream_synchronize(void *stream) { HIP_TRY(hipStreamSynchronize(as_stream(stream))); return 0; }
+// Watchdog for jobs whose streams carry collectives (host/lis_comm.c sets it when an RCCL communicator of several ranks is formed): a stream that waits for a peer
+// that never arrives would block hipStreamSynchronize for ever.  With a limit set, the wait polls hipStreamQuery (spinning for the first 2 ms: the folds of a
+// Krylov loop come back in tens of microseconds; then 100 us naps) and returns LISHIP_ERR_TIMEOUT when the stream has not drained within the limit.
+static double g_sync_limit_s = 0.0;
+extern "C" int liship_set_sync_timeout(double seconds) { g_sync_limit_s = seconds > 0.0 ? seconds : 0.0; return 0; }
+extern "C" int liship_stream_synchronize(void *stream)
+{
+    if (g_sync_limit_s <= 0.0) { HIP_TRY(hipStreamSynchronize(as_stream(stream))); return 0; }
+    struct timespec t0, t;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(as_stream(stream));
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return (int)e;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        const double el = (double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec);
+        if (el > g_sync_limit_s) return LISHIP_ERR_TIMEOUT;
+        if (el > 2e-3) { struct timespec nap = {0, 100000}; nanosleep(&nap, nullptr); }
+    }
+}
 extern "C" int liship_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return 0; }
 
 // hipGraph capture of a batch of Krylov iterations (host/lis_solver.c: dev_loop_run): small systems are bound by the

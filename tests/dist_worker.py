@@ -248,6 +248,20 @@ def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
     assert lib.lis_vector_dot(vx, vy, C.byref(out)) == 0
     assert abs(out.value - float(np.dot(xg, yg))) <= 1e-13 * float(np.abs(xg * yg).sum()), name
     assert lib.lis_vector_nrm2(vy, C.byref(out)) == 0 and abs(out.value - np.linalg.norm(yg)) <= 1e-13 * np.linalg.norm(yg)
+    # a vector that was NOT made from the matrix (no room for ghosts) grows inside lis_matvec like the reference's lis_realloc (include/lis_matvec.h:32-43):
+    # the header AND the host array -- a program may read X->value[n .. np) afterwards
+    vs = capi.PV()
+    assert lib.lis_vector_create(capi.LIS_COMM_WORLD, C.byref(vs)) == 0 and lib.lis_vector_set_size(vs, n, 0) == 0
+    assert vs.contents.np == n
+    assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(xg[is_:ie]).ctypes.data_as(capi.P_DBL), vs) == 0
+    assert lib.lis_matvec(A, vs, vy) == 0
+    assert lib.lis_vector_get_values(vy, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0 and np.array_equal(y, yg[is_:ie]), name
+    a_np, a_pad = A.contents.np, A.contents.pad
+    assert vs.contents.np == a_np and vs.contents.pad == a_pad
+    host = np.ctypeslib.as_array(vs.contents.value, shape=(a_np + a_pad,))
+    assert np.array_equal(host[:n], xg[is_:ie])                        # the owned entries kept their place (and the memory beyond them exists)
+    assert host[a_np + a_pad - 1] == host[a_np + a_pad - 1]
+    lib.lis_vector_destroy(vs)
     # distributed A^T x: local transposed rows + ghost contributions sent back to their owners (lis_reduce);
     # the cross-rank adds change the association, so 1e-13 relative instead of bit equality
     yt = orc.spmvh_csr(ptr, idx, val, xg)

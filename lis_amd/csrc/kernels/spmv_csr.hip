@@ -38,11 +38,11 @@ struct Geometry { int block, work; };
 constexpr Geometry kGeom[] = {
     {192, 1408},   // 0: default -- 176 stencil rows per block, 18.5 KB LDS, 8 workgroups per CU
     {256, 2048},   // 1
-    {128,  896},   // 2
+    {128,  896},   // 2  (ids 2, 3, 4, 6: geometries of the round-1 sweep, no longer instantiated -- liship_csr_plan_create refuses them; the ids of the others stay)
     {192, 1536},   // 3
     {256, 1536},   // 4
     {512, 4096},   // 5
-    { 64,  512},   // 6: one wavefront per workgroup
+    { 64,  512},   // 6
     {512, 3072},   // 7: block-local columns, lists of up to 2048 columns, positions in registers: 39.5 KB of LDS (lists <= 1536), FOUR workgroups per CU
     {512, 3584},   // 8: block-local columns, lists of up to 1024 columns, positions in registers: 39.5 KB of LDS, FOUR workgroups per CU
 };
@@ -64,9 +64,8 @@ constexpr int SLACK = 128;       // extra items a block may take to start on an 
 //   bits4-7 geometry id and bit24 "no row alignment": read at plan creation
 //   bit13 (0x2000) row patterns through the general kernel (table in LDS) even when the plan has 32 B records
 //   bit14 (0x4000) value records: the two-rows-per-lane kernel whatever the size (tests; by default only beyond 256 MB of x)
-//   bit29 (0x20000000) value records: never the dominant-pattern kernels (the round-2 kernels: A/B, tests); bit28 (0x10000000): the
-//         dominant-pattern kernels in their plain form (product: contiguous chunks round-robin; fused dots: two rows per lane);
-//         bits 3 / 9 / 15: tiles of 32 / 64 / 128 / 256 columns for the plain product (default 128), bit3 in the fused-dot form: w by its own loads
+//   bit29 (0x20000000) value records: never the dominant-pattern kernels (the kernels of plans without a dominant pattern: tests);
+//   bit28 (0x10000000) the dominant-pattern product on contiguous chunks instead of tiles (the path of grids whose lines 128 does not divide: tests)
 int g_variant = 0;
 int g_index_codes = 1;           // liship_spmv_csr_set_index_codes: 0 keeps every product on the 4 B indices
 int g_row_patterns = 1;          // liship_spmv_csr_set_row_patterns: 0 keeps coded matrices on one byte per non-zero
@@ -451,24 +450,15 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
             if ((int)threadIdx.x == owner) carry += tree_scratch[0];
             base = k1;
         }
-        if (BLOCK == WAVE) {                                    // a single wavefront has nobody to stage for it
-            while (base < k1) {
-                const int kend = min(base + CAP, k1);
-                const int ka2 = base & ~1;
-                __syncthreads();
-                stage_products<BLOCK, VEC>(prod, idx, val, x, base, kend, ka2);
-                __syncthreads();
-                if ((int)threadIdx.x == owner) carry = ordered_sum_plain(carry, prod, base - ka2, kend - base);
-                base = kend;
-            }
-        } else if (base < k1) {
+        static_assert(BLOCK > WAVE, "the owner of a long row is fed by the lanes of the OTHER wavefronts");
+        if (base < k1) {
             // The rest of the long row, strictly in order: ONE lane owns the chain of additions, and nothing can shorten it but
             // keeping that lane fed.  The stage is used as two halves: while the owner adds the products of one half, the lanes
             // of the OTHER wavefronts form the products of the next half (all of it in flight at once), so a pass costs
             // the longer of the two instead of their sum, and the owner's wavefront never waits for memory.
-            constexpr int helpers = BLOCK > WAVE ? BLOCK - WAVE : 1;   // lanes of the other wavefronts
+            constexpr int helpers = BLOCK - WAVE;                      // lanes of the other wavefronts
             constexpr int HFIT = ((CAP - 8) / 2) & ~15;         // products per half that fit (32 doubles of slack behind the second: ordered_sum_fed reads ahead)
-            constexpr int HCAP = BLOCK > WAVE ? ((6 * helpers) & ~15) : HFIT;                  // ... and at most six per helper lane (registers)
+            constexpr int HCAP = (6 * helpers) & ~15;                  // ... and at most six per helper lane (registers)
             constexpr int H = HFIT < HCAP ? HFIT : HCAP;
             const int ownerwave = owner / WAVE;
             const int hl = ((int)threadIdx.x / WAVE < ownerwave) ? (int)threadIdx.x : (int)threadIdx.x - WAVE;   // index among them
@@ -1072,7 +1062,7 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
                                   const v4i32 *__restrict__ prec, const double *__restrict__ x, double *__restrict__ y, Rows RW, int nnz_total,
-                                  const double *__restrict__ guard = nullptr, int xs_plane = 0)
+                                  const double *__restrict__ guard = nullptr)
 {
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
     // A wavefront owns 16 consecutive rows AND their value slice: nothing is shared between the wavefronts of a workgroup, so there is no
@@ -1083,7 +1073,7 @@ void spmv_csr_pattern_team_kernel(const int *__restrict__ ptr, const double *__r
     __shared__ __attribute__((aligned(16))) double stage[(BLOCK / WAVE) * STAGE];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
     double *valL = stage + w * STAGE;
-    const int r0 = RW.rb + (xcd_strip_unit((int)blockIdx.x, (int)gridDim.x, xs_plane) * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
+    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
     if (r0 >= r1) return;
     const int t = lane >> 4;
     const int r = min(r0 + (lane & 15), r1 - 1);                // (lanes beyond the last row repeat it and store nothing)
@@ -1151,14 +1141,14 @@ __global__ __launch_bounds__(BLOCK)
 void spmv_csr_pattern_team_staged_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
                                          const v4i32 *__restrict__ prec, const v4i32 *__restrict__ pslot, const double *__restrict__ x,
                                          double *__restrict__ y, Rows RW, int nnz_total, const TeamRuns TR, int vcap, int xcap,
-                                         const double *__restrict__ guard = nullptr, int xs_plane = 0)
+                                         const double *__restrict__ guard = nullptr)
 {
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
     constexpr int RPW = 16;                                      // NLOAD = ceil(slots / 128): the loads are unconditional, so that the counter's waits can be exact
     extern __shared__ __attribute__((aligned(16))) double team_dyn[];
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
     double *valL = team_dyn + w * (vcap + xcap), *xL = valL + vcap;
-    const int r0 = RW.rb + (xcd_strip_unit((int)blockIdx.x, (int)gridDim.x, xs_plane) * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
+    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * RPW, r1 = min(r0 + RPW, RW.re);
     if (r0 >= r1) return;
     const int t = lane >> 4, i = lane & 15;
     const int r = min(r0 + i, r1 - 1);
@@ -1633,7 +1623,7 @@ void spmv_csr_valuerec_pair_kernel(const unsigned char *__restrict__ rowpat, con
 // bit 7: the ghost-column rows of a partitioned matrix) and the wavefronts whose speculative addresses would leave x (the first and
 // last |max offset| rows) take their rows one by one with their own records, as the kernels above do.
 typedef double v8f64 __attribute__((ext_vector_type(8)));
-struct DomTile { int S, cshift, ntiled, nfull, tpp, reg, zreg; };       // spmv_csr_valuerec_dom_kernel: tiled lane -> row mapping (S = 0: none); tpp > 0: planes of tpp tiles, each XCD marching through the planes in regions of reg tiles (zreg = planes * reg)
+struct DomTile { int S, cshift, ntiled, nfull; };       // spmv_csr_valuerec_dom_kernel: tiled lane -> row mapping (S = 0: none)
 struct DomRec { int off[7]; int pat; double val[7]; int mask, d0; };      // byte offsets and values of the dominant pattern, its pattern byte, its slots (length), the slot of offset 0 (-1: none)
 
 // slots of D that pattern `pt` (uniform) has, and its values there: 8 doubles per pattern, [0] = the mask in the low word
@@ -1785,15 +1775,6 @@ void spmv_csr_valuerec_dom_kernel(const unsigned char *__restrict__ rowpat, cons
         int rw, ra;                                                   // the wavefront's lowest row, the lane's first row
         bool safe;                                                    // (uniform) speculation is safe: every address r*8 + offset of the wavefront's rows (16 B loads: one more) lies inside x[0, n)
         bool live = true;                                             // (uniform) the wavefront has rows
-        if (TL.tpp > 0 && chunk < TL.zreg * (TL.tpp / TL.reg)) {
-            // PLANES: the tiles of a plane (the pattern's outer stride S2: +-mn of a 3-D stencil) are split into regions of `reg` tiles; XCD k takes the
-            // regions k, k + 8, ... and walks each one plane after plane, so that the +-S2 neighbours of its rows are lines the SAME L2 fetched a few
-            // hundred workgroups ago (3 planes of a region: a fraction of the 4 MB) instead of lines another XCD's L2 holds
-            const int k = chunk % NUM_XCD, j = chunk / NUM_XCD;
-            const int col = j / TL.zreg, within = j - col * TL.zreg;
-            const int plane = within / TL.reg, t = within - plane * TL.reg;
-            chunk = plane * TL.tpp + (col * NUM_XCD + k) * TL.reg + t;
-        }
         if (TL.S > 0 && chunk < TL.ntiled) {
             // TILED rows: the workgroup's 256 lane pairs cover T = 256 >> cshift lines of 2 << cshift columns each, the lines S rows apart
             // (S: the stride of the pattern's middle offsets, +-n of a 3-D stencil) -- a wavefront then gathers its rows' +-S neighbours from
@@ -2147,135 +2128,6 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
         }
     }
     if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : M.wgs, true);
-}
-
-// The same with the fused dots.  Partial slots and the order of every addition are those of spmv_csr_valuerec_pair_dot_kernel
-// (below: two row blocks per workgroup, virtual lanes 2p and 2p + 1 in two accumulators, the one-row kernels' tree walked on
-// them), so the dots are the same bits; what changes is the chain in front: block extents (one scalar load) -> pattern bytes, w
-// and the dominant pattern's gathers together -> sums, instead of extents + records -> barrier -> pattern bytes -> records -> x.
-template <int BLOCK, int DOT>
-__global__ __launch_bounds__(BLOCK)
-void spmv_csr_valuerec_dom_dot_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, const double *__restrict__ drec,
-                                      const DomRec D, int safe_lo, int safe_hi,
-                                      const double *__restrict__ x, double *__restrict__ y, const v2i32 *__restrict__ blk,
-                                      int bfirst, int nb, Rows RW,
-                                      const double *__restrict__ wdot, double *__restrict__ partial,
-                                      const double *__restrict__ guard, int pstride)
-{
-    static_assert(BLOCK == 256, "two row blocks of 128 lane pairs");
-    const double stop = guard != nullptr ? guard[0] : 0.0;          // device-driven Krylov loop already converged? (a scalar load beside the extents')
-    const double acc0 = RW.acc0;
-    __shared__ double scratch[2][2][4];                   // [block of the workgroup][result][virtual wavefront]
-    const int tid = (int)threadIdx.x;
-    const int h = __builtin_amdgcn_readfirstlane(tid >> 7), p = tid & 127;        // wavefronts 0, 1: the first block; 2, 3: the second
-    const int lb = blockIdx.x * 2 + h;
-    const Blk B = lb < nb ? load_blk(blk, bfirst + lb) : Blk{0, 0, 0, 0};
-    const int r0 = max(B.r0, RW.rb), r1 = min(B.r1, RW.re);
-    if (stop != 0.0) return;                              // (uniform; nothing has been written)
-    double c0[2] = {0.0, 0.0}, c1[2] = {0.0, 0.0};
-    for (int base = r0; base < r1; base += 256) {         // (uniform per wavefront) virtual lane t holds the rows base + t
-        const int rw = base + 2 * (p & ~(WAVE - 1));      // the wavefront's first row
-        const int ra = base + 2 * p;
-        const bool two = ra + 1 < r1, one = ra < r1;
-        // speculation is safe when every address r*8 + offset of the wavefront's 128 rows (16 B loads: one more) lies inside x[0, n)
-        const bool safe = rw >= safe_lo && rw + 2 * WAVE <= safe_hi;          // (uniform)
-        if (safe) {
-            unsigned twob = 0;
-            v2f64 xx[7], ww;
-            ww.x = ww.y = 0.0;
-            if (two) {
-                if ((ra & 1) == 0) { twob = *reinterpret_cast<const unsigned short *>(rowpat + ra); ww = *reinterpret_cast<const v2f64 *>(wdot + ra); }
-                else { twob = (unsigned)rowpat[ra] | ((unsigned)rowpat[ra + 1] << 8); ww.x = wdot[ra]; ww.y = wdot[ra + 1]; }
-                const unsigned rb8 = (unsigned)ra * 8u;
-#pragma unroll
-                for (int u = 0; u < 7; u++) xx[u] = *reinterpret_cast<const v2f64u *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)D.off[u]));
-            }
-            const int pa = (int)(twob & 255u), pb = (int)(twob >> 8);
-            double s0 = acc0, s1 = acc0;
-            if (__builtin_amdgcn_ballot_w64(two && (pa != D.pat || pb != D.pat)) == 0) {      // (uniform) every row here is the dominant pattern
-                if (two) {
-                    if (D.mask == 0x7f) {
-#pragma unroll
-                        for (int u = 0; u < 7; u++) { s0 += D.val[u] * xx[u].x; s1 += D.val[u] * xx[u].y; }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 7; u++) {
-                            const double t0 = D.val[u] * xx[u].x, t1 = D.val[u] * xx[u].y;
-                            s0 += ((D.mask >> u) & 1) ? t0 : -0.0;
-                            s1 += ((D.mask >> u) & 1) ? t1 : -0.0;
-                        }
-                    }
-                }
-            } else {
-                double v[7];
-                unsigned m;
-                dom_waterfall(drec, D, pa, two, v, m);
-                if (two) {
-                    if (m & 0x80u) s0 = own_record_row(rec, pa, ra, x, acc0);
-                    else {
-#pragma unroll
-                        for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].x; s0 += ((m >> u) & 1u) ? t : -0.0; }    // -0.0 terms leave any sum bit-unchanged
-                        s0 = dom_pad_terms(s0, m, x, ra);
-                    }
-                }
-                dom_waterfall(drec, D, pb, two, v, m);
-                if (two) {
-                    if (m & 0x80u) s1 = own_record_row(rec, pb, ra + 1, x, acc0);
-                    else {
-#pragma unroll
-                        for (int u = 0; u < 7; u++) { const double t = v[u] * xx[u].y; s1 += ((m >> u) & 1u) ? t : -0.0; }
-                        s1 = dom_pad_terms(s1, m, x, ra + 1);
-                    }
-                }
-            }
-            if (two) {
-                v2f64 out; out.x = s0; out.y = s1;
-                if ((ra & 1) == 0) store_stream(reinterpret_cast<v2f64 *>(y + ra), out);
-                else { store_stream(y + ra, s0); store_stream(y + ra + 1, s1); }
-                c0[0] += ww.x * s0; c0[1] += ww.y * s1;
-                if (DOT >= 2) { c1[0] += s0 * s0; c1[1] += s1 * s1; }
-            } else if (one) {                             // a block's last row without a partner
-                const double acc = own_record_row(rec, (int)rowpat[ra], ra, x, acc0);
-                store_stream(y + ra, acc);
-                c0[0] += wdot[ra] * acc;
-                if (DOT >= 2) c1[0] += acc * acc;
-            }
-        } else {                                          // the matrix's first and last rows: row by row, their own records
-#pragma unroll
-            for (int w = 0; w < 2; w++) {
-                const int r = ra + w;
-                if (r < r1) {
-                    const double acc = own_record_row(rec, (int)rowpat[r], r, x, acc0);
-                    store_stream(y + r, acc);
-                    c0[w] += wdot[r] * acc;
-                    if (DOT >= 2) c1[w] += acc * acc;
-                }
-            }
-        }
-    }
-    // the one-row kernels' tree on the virtual lanes (see spmv_csr_valuerec_pair_dot_kernel)
-    const int vw = p >> 5;                                // virtual wavefront of this lane's two virtual lanes
-#pragma unroll
-    for (int res = 0; res < (DOT >= 2 ? 2 : 1); res++) {
-        double e = res ? c1[0] : c0[0], f = res ? c1[1] : c0[1];
-        e += __shfl_xor(e, 16, WAVE); f += __shfl_xor(f, 16, WAVE);
-        e += lane_xor_in_row<8>(e);   f += lane_xor_in_row<8>(f);
-        e += lane_xor_in_row<4>(e);   f += lane_xor_in_row<4>(f);
-        e += lane_xor_in_row<2>(e);   f += lane_xor_in_row<2>(f);
-        e += lane_xor_in_row<1>(e);   f += lane_xor_in_row<1>(f);
-        const double t = e + f;
-        if ((p & 31) == 0) scratch[h][res][vw] = t;
-    }
-    __syncthreads();
-    if (tid < 4) {                                        // thread = (block of the workgroup, result)
-        const int hh = tid >> 1, res = tid & 1, slot = blockIdx.x * 2 + hh, stride = pstride ? pstride : nb;
-        if (slot < nb && (res == 0 || DOT >= 2)) {
-            double t = 0.0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) t += scratch[hh][res][i];
-            partial[(size_t)res * stride + slot] = t;
-        }
-    }
 }
 
 // The fused dots, FOUR rows per lane: one wavefront per row block, no LDS, no barrier.  Lane q of the wavefront holds the virtual
@@ -2849,104 +2701,6 @@ void spmv_csr_blockrows_staged_kernel(const unsigned char *__restrict__ rowpat, 
     if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : (int)gridDim.x, true);
 }
 
-// The same shape for STREAMED values (rows of 8..32 entries on <= 255 patterns whose coefficients vary: the 27-point stencil on a non-uniform mesh): a
-// wavefront owns 64 consecutive rows, one per lane, their value slice (LDS-DMA) and the staged x of the dominant pattern's runs; a lane walks ITS row in
-// order -- the entry of the dominant pattern's slot j is the row's (number of kept slots before j)-th value -- so the sum is one chain per lane with no
-// hand-off, and a wavefront issues 23 vector-memory instructions for 64 rows where the four-lanes-per-row kernel issues 36.  Masks by scalar loads, one
-// round per distinct pattern; rows with a foreign pattern gather by their 144 B record.  Same terms, same order: the reference's bits.
-template <int NL>
-__global__ __launch_bounds__(WAVE)
-void spmv_csr_pattern_rows_staged_kernel(const int *__restrict__ ptr, const double *__restrict__ val, const unsigned char *__restrict__ rowpat,
-                                         const double *__restrict__ wdrec, const v4i32 *__restrict__ wstage, const v4i32 *__restrict__ prec,
-                                         const double *__restrict__ x, double *__restrict__ y, Rows RW, int nnz_total, const WideDom D, int vcap,
-                                         const double *__restrict__ guard = nullptr)
-{
-    if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
-    extern __shared__ __attribute__((aligned(16))) double rows_dyn[];
-    const int lane = (int)threadIdx.x;
-    double *valL = rows_dyn, *xL = rows_dyn + vcap;
-    const int r0 = RW.rb + (int)blockIdx.x * WAVE, r1 = min(r0 + WAVE, RW.re);
-    if (r0 >= r1) return;
-    const int r = min(r0 + lane, r1 - 1);
-    const bool live = r0 + lane < r1;
-    const int k0 = ptr[r0], k1 = ptr[r1];                           // (uniform: scalar loads)
-    const int pat = rowpat[r];
-    const v4i32 so0 = wstage[2 * lane], so1 = wstage[2 * lane + 1];
-    const int so[8] = {so0.x, so0.y, so0.z, so0.w, so1.x, so1.y, so1.z, so1.w};
-    __builtin_amdgcn_sched_barrier(0);
-    v2f64 xs[NL];
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-        const int c = r0 + so[k], cc = min(max(c, 0), D.maxcol - 1);
-        const v2f64 v = *reinterpret_cast<const v2f64u *>(x + cc);
-        xs[k].x = c > cc ? v.y : v.x;
-        xs[k].y = c < cc ? v.x : v.y;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int ka = k0 & ~1, cnt = k1 - ka;
-    int np = (cnt + 1) >> 1;
-    const bool odd_end = ka + 2 * np > nnz_total;
-    if (odd_end) np--;
-#pragma unroll
-    for (int it = 0; it < (WAVE * TEAM_MAXLEN / 2 + WAVE) / WAVE; it++) {
-        const int p0 = it * WAVE;
-        if (p0 + lane < np)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const v2f64 *>(val + ka) + p0 + lane),
-                (__attribute__((address_space(3))) void *)(reinterpret_cast<v2f64 *>(valL) + p0), 16, 0, 2);
-    }
-    if (odd_end && lane == 0) valL[cnt - 1] = val[k1 - 1];
-    __builtin_amdgcn_sched_barrier(0);
-    // masks (and whether a pattern is foreign) by scalar loads, one round per distinct pattern among the lanes
-    unsigned m = D.len >= 32 ? 0xffffffffu : ((1u << D.len) - 1u);
-    bool foreign = false;
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(live && pat != D.pat);
-    while (todo != 0) {                                             // (uniform)
-        const int q = __builtin_amdgcn_readlane(pat, __builtin_ctzll(todo));
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(wdrec[(size_t)q * WREC + 32]);
-        const bool me = live && pat == q;
-        m = me ? (unsigned)bits : m;
-        foreign = me ? ((bits >> 32) & 1ull) != 0 : foreign;
-        todo &= ~__builtin_amdgcn_ballot_w64(me);
-    }
-    const bool anyforeign = __builtin_amdgcn_ballot_w64(foreign) != 0;
-    int len = live ? __popc(m) : 0;
-    const v4i32 *frec = prec + pat * TEAM_REC;
-    if (anyforeign && foreign) len = live ? *reinterpret_cast<const int *>(frec + 8) : 0;
-    const int s = k0 + wave_inclusive_scan(len) - len;              // the row's start: the slice's start + the lengths of the rows below it
-    __builtin_amdgcn_s_waitcnt(0);                                  // x and the slice have landed
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int k = 0; k < NL; k++) { const int sl = 2 * (k * WAVE + lane); if (sl < D.slots) *reinterpret_cast<v2f64 *>(xL + sl) = xs[k]; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double *xr = xL + lane, *vp = valL + (s - ka);
-    double acc = RW.acc0;
-    if (__builtin_amdgcn_ballot_w64(live && pat != D.pat) == 0) {   // (uniform) every row here is on the dominant pattern
-#pragma unroll
-        for (int j = 0; j < PATW_LEN; j++) if (j < D.len) acc += vp[j] * xr[D.slot[j]];
-    } else {
-        if (!foreign) {
-            int rank = 0;
-#pragma unroll
-            for (int j = 0; j < PATW_LEN; j++)
-                if (j < D.len) {
-                    const bool on = ((m >> j) & 1u) != 0;
-                    const double t = vp[rank] * xr[D.slot[j]];          // (a slot the row does not keep reads a value of the stage and adds -0.0)
-                    acc += on ? t : -0.0;
-                    rank += on ? 1 : 0;
-                }
-        }
-        if (anyforeign && foreign) {                                // a pattern the dominant one's runs do not hold: a gather per entry, by its record of byte offsets
-            const int *off = reinterpret_cast<const int *>(frec);
-            const unsigned rb8 = (unsigned)r * 8u;
-            for (int j = 0; j < len; j++) acc += vp[j] * *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (rb8 + (unsigned)off[j]));
-        }
-    }
-    if (live) store_stream(y + r, acc);
-}
-
 // plan time: one 64-bit hash per row over (length, code sequence); the distinct ones in an open-addressing table together with the
 // smallest row that has them; gives up beyond 255
 constexpr int PAT_SLOTS = 1024, PAT_MAXLEN = 64;
@@ -3274,7 +3028,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->n = n;
     p->nnz = nnz;
     p->geom = (g_variant >> 4) & 15;
-    if (p->geom >= kNumGeom) p->geom = 0;
+    if (p->geom >= kNumGeom || p->geom == 2 || p->geom == 3 || p->geom == 4 || p->geom == 6) { delete p; return LISHIP_ERR_ARG; }
     const double mean_len = n > 0 ? (double)nnz / n : 0.0;
     p->unroll = mean_len <= 4.0 ? 4 : (mean_len <= 7.0 ? 7 : 8);
     // lane-per-row keeps 176 lanes busy on 7-entry rows but only 17 on 80-entry rows: from 22 entries per row on,
@@ -3284,8 +3038,6 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->products = (g_variant == 0 && mean_len >= 22.0) ? 1 : 0;
     if (p->products) p->geom = 1;
     p->batch = mean_len >= 24.0 ? 2 : 4;
-    if (g_variant & 0x4000000) p->batch = 4;              // experiment knobs
-    if (g_variant & 0x8000000) p->batch = 2;
     p->blk = nullptr;
     p->blk_host = nullptr;
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
@@ -4557,16 +4309,6 @@ static int dom_stride(const DomRec &D)
     return S;
 }
 
-static int dom_stride_outer(const DomRec &D)
-{
-    int S = 0;
-    for (int u = 0; u < 7; u++) {
-        const int e = D.off[u] / 8;
-        if (e > S) { bool both = false; for (int v = 0; v < 7; v++) both = both || D.off[v] == -8 * e; if (both) S = e; }
-    }
-    return S;
-}
-
 template <int G, int U>
 void launch_rowgather(const LaunchArgs &a)
 {
@@ -4630,28 +4372,16 @@ static void launch_team(const LaunchArgs &a, const double *guard)
     const liship_csr_plan_s *P = a.plan;
     const int rows = a.re - a.rb, wgs = (rows + 63) / 64;
     if (rows <= 0) return;
-    // XCD strips (xcd_strip_unit) for whole-matrix launches, workgroups of 64 rows per plane: measured NEUTRAL for these kernels (27-point stencil, varying coefficients,
-    // 224^3: 0.4478-0.4522 ms with, 0.4478-0.4483 without -- they stage x per wavefront and are not bound by the fabric), so only behind variant bit 0x10000
-    const int xsp = ((g_variant & 0x10000) && a.rb == 0 && a.re == P->n) ? xcd_strip_plane(P, 64.0, wgs) : 0;
-    // (variant 0x8000: one lane per row, 64 rows per wavefront, values and x staged -- 3 % faster than four lanes per row on a repeated product, 3 % slower
-    //  inside the Krylov loops, where x is new every time and 8 wavefronts per CU hide less than 28: profiles/r03_pattern_team_kernel.txt; kept for A/B)
-    if (P->wdrec && P->wstage && P->wd.len > 0 && (g_variant & 0x8000) && !(g_variant & 0x4000)) {
-        const int maxl = P->tr.nruns > 0 ? P->tr.maxlen : TEAM_MAXLEN;                  // (the longest pattern, when build_team_runs recorded it)
-        const int vcap = WAVE * maxl + 2 + 32, xcap = (P->wd.slots + 1) & ~1, nl = (P->wd.slots + 2 * WAVE - 1) / (2 * WAVE);
-#define GOR(NL) spmv_csr_pattern_rows_staged_kernel<NL><<<(rows + WAVE - 1) / WAVE, WAVE, sizeof(double) * (size_t)(vcap + xcap), a.st>>>( \
-            a.ptr, a.val, a.rowpat, P->wdrec, P->wstage, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->wd, vcap, guard)
-        if (nl <= 2) GOR(2); else if (nl <= 3) GOR(3); else if (nl <= 5) GOR(5); else if (nl <= 6) GOR(6); else GOR(8);
-#undef GOR
-        return;
-    }
+    // (measured and dropped, profiles/EXPERIMENTS.md: XCD strips for these kernels -- neutral, they stage x per wavefront and are not bound by the fabric --; one lane
+    //  per row with values and x staged -- 3 % faster on a repeated product, 3 % slower inside the Krylov loops)
     if (P->prec_slot && P->tr.nruns > 0 && !(g_variant & 0x4000)) {
         const int vcap = 16 * P->tr.maxlen + 48, xcap = (P->tr.slots + 1) & ~1;
 #define GOT(NL) spmv_csr_pattern_team_staged_kernel<256, NL><<<wgs, 256, sizeof(double) * 4 * (size_t)(vcap + xcap), a.st>>>( \
-            a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard, xsp)
+            a.ptr, a.val, a.rowpat, P->prec36, P->prec_slot, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, P->tr, vcap, xcap, guard)
         if (P->tr.slots <= 2 * WAVE) GOT(1); else GOT(2);
 #undef GOT
     } else
-        spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard, xsp);
+        spmv_csr_pattern_team_kernel<256><<<wgs, 256, 0, a.st>>>(a.ptr, a.val, a.rowpat, P->prec36, a.x, a.y, Rows{a.rb, a.re, a.acc0}, a.nnz, guard);
 }
 
 // the dominant-pattern product of a plan with value records (spmv_csr_valuerec_dom_kernel), plain or with the fused dots (a partial per workgroup: count_out)
@@ -4693,31 +4423,20 @@ static long long dom_gather_shape(const LaunchArgs &a, DomTile &TL, int &run)
     // lane -> row mapping.  Default: TILES of 4 lines x 128 columns per workgroup when the pattern has a stride S of middle offsets
     // (+-n of a 3-D stencil) that 128 divides -- the four wavefronts' +-S gathers then hit lines their neighbours' diagonal gathers bring
     // into the same L1: 512^3 0.58 -> 0.49 ms --; otherwise contiguous 512-row chunks, each XCD walking runs of 8 of them (one L2 serves
-    // the chunks' shared x lines: 0.58 -> 0.535 ms).  Experiment knobs: bit28 plain chunks round-robin; bits 3 / 9 / 15 select tiles of
-    // 32 / 64 / 128 / 256 columns; bit0 + bits16-23 the run length.  (Measured and dropped: four rows per lane, 512 / 1024 lanes per
-    // workgroup, kernarg preload of the arguments: profiles/r03_valuerec_dom_experiments.txt.)
+    // the chunks' shared x lines: 0.58 -> 0.535 ms).  Variant bit28 forces the plain chunks round-robin (tests of that path at small sizes).
+    // (Measured and dropped, profiles/EXPERIMENTS.md: tiles of 32 / 64 / 256 columns, XCD regions of the planes, four rows per lane, 512 / 1024 lanes per
+    // workgroup, kernarg preload of the arguments.)
     const bool plain = (g_variant & 0x10000000) != 0;
-    int tsel = ((g_variant >> 3) & 1) | (((g_variant >> 9) & 1) << 1) | (((g_variant >> 15) & 1) << 2);
-    if (!tsel && !plain) tsel = 3;
-    TL = DomTile{0, 0, 0, 0, 0, 0, 0};
+    TL = DomTile{0, 0, 0, 0};
     long long wgs = (rows + 511) / 512;
-    if (tsel) {
+    if (!plain) {
         const int S = dom_stride(P->dom);
-        const int cshift = 3 + tsel;                      // pairs per tile line: 16, 32, 64, 128
-        const int C = 2 << cshift, T = 256 >> cshift;
+        constexpr int cshift = 6;                         // 64 pairs per tile line: 128 columns, 4 lines
+        constexpr int C = 2 << cshift, T = 256 >> cshift;
         if (S >= C && S % C == 0 && rows >= (long long)T * S) {
             const long long groups = rows / ((long long)T * S);
             TL.S = S; TL.cshift = cshift; TL.ntiled = (int)(groups * (S / C)); TL.nfull = (int)(groups * T * S);
             wgs = TL.ntiled + (rows - TL.nfull + 511) / 512;
-            if (g_variant & 0x40000000) {
-                const int S2 = dom_stride_outer(P->dom);
-                const long long tile = (long long)T * C;
-                if (S2 > S && S2 % (T * S) == 0 && rows >= 2ll * S2) {
-                    const int tpp = (int)(S2 / tile), div = (g_variant >> 16) & 0xff;
-                    const int regions = NUM_XCD * (div ? div : 1);
-                    if (tpp % regions == 0) { TL.tpp = tpp; TL.reg = tpp / regions; TL.zreg = (int)(TL.nfull / S2) * TL.reg; }
-                }
-            }
         }
     }
     run = (plain || TL.S || wgs < 8 * NUM_XCD) ? 1 : 8;
@@ -4743,13 +4462,13 @@ static int dom_parts(const LaunchArgs &a, DomPart (&parts)[3])
 {
     const liship_csr_plan_s *P = a.plan;
     auto gather = [&](int rb, int re) {
-        DomPart G{rb, re, false, 0, DomMarch{}, DomTile{0, 0, 0, 0, 0, 0, 0}, 1};
+        DomPart G{rb, re, false, 0, DomMarch{}, DomTile{0, 0, 0, 0}, 1};
         LaunchArgs b = a; b.rb = rb; b.re = re;
         G.wgs = dom_gather_shape(b, G.TL, G.run);
         return G;
     };
     DomMarch M;
-    if (dom_march_shape(a, M)) { parts[0] = DomPart{a.rb, a.re, true, M.wgs, M, DomTile{0, 0, 0, 0, 0, 0, 0}, 1}; return 1; }
+    if (dom_march_shape(a, M)) { parts[0] = DomPart{a.rb, a.re, true, M.wgs, M, DomTile{0, 0, 0, 0}, 1}; return 1; }
     int S = 0, SO = 0, perm = 0;
     if (g_dom_march && P && P->box_z1 > P->box_z0 && dom_seven_point(P->dom, S, SO, perm)) {
         const long long zlo = std::max<long long>(((long long)a.rb + SO - 1) / SO, P->box_z0), zhi = std::min<long long>((long long)a.re / SO, P->box_z1);
@@ -4758,7 +4477,7 @@ static int dom_parts(const LaunchArgs &a, DomPart (&parts)[3])
             if (dom_march_shape(b, M)) {
                 int np = 0;
                 if (a.rb < b.rb) parts[np++] = gather(a.rb, b.rb);
-                parts[np++] = DomPart{b.rb, b.re, true, M.wgs, M, DomTile{0, 0, 0, 0, 0, 0, 0}, 1};
+                parts[np++] = DomPart{b.rb, b.re, true, M.wgs, M, DomTile{0, 0, 0, 0}, 1};
                 if (b.re < a.re) parts[np++] = gather(b.re, a.re);
                 return np;
             }
@@ -4822,7 +4541,7 @@ static void launch_dom(const LaunchArgs &a0, int dot = 0, const double *w = null
         const DomRec &DD = P->dom;
         const unsigned grid = (unsigned)((wgs + span - 1) / span * span);
         int wslot = -1;
-        if (dot != 0 && w == a.x && !(g_variant & 0x8))      // (bit3: w by its own loads, A/B)
+        if (dot != 0 && w == a.x)
             for (int u = 0; u < 7; u++) if (((P->dom.mask >> u) & 1) && P->dom.off[u] == 0) wslot = u;
 #define GOD(DT) spmv_csr_valuerec_dom_kernel<256, DT><<<grid, 256, 0, a.st>>>( \
             a.rowpat, a.vrec, P->drec, DD, P->dom_lo, P->dom_hi, a.x, a.y, Rows{a.rb, a.re, a.acc0}, run, TL, w, partial, guard, np > 1 ? pstride : pstride0, wslot, (int)wgs)
@@ -4874,7 +4593,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
         return;
     }
     const int U = unroll;
-    if (a.rowpat && a.ptab8 && a.vrec && (g_variant & ~0x70ffc208) == 0) {            // the rows' values ride in the pattern records: one byte per row
+    if (a.rowpat && a.ptab8 && a.vrec && (g_variant & ~0x30004000) == 0) {            // the rows' values ride in the pattern records: one byte per row
         constexpr Geometry g = kGeom[G];
         const int chunks = (a.re - a.rb + g.block - 1) / g.block;       // rows [rb, re) in chunks of one workgroup's lanes, two per workgroup
         // beyond the Infinity Cache (256 MB of x) the two-rows-per-lane form wins (16 B requests: 320^3 +4 %, 448^3 +13 %, 512^3 +7 %);
@@ -4905,7 +4624,7 @@ void launch_geom(const LaunchArgs &a, int unroll, bool plan_products, int batch)
             a.ptr, a.val, a.rowpat, a.rowrel, a.ptab8, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, nullptr, nullptr, nullptr, 0, xcd_strips(a));
         return;
     }
-    if (a.rowpat && a.plan && a.plan->prec36 && g_team && (g_variant & ~0xc000) == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
+    if (a.rowpat && a.plan && a.plan->prec36 && g_team && (g_variant & ~0x4000) == 0) {    // patterns of 8..32 offsets, values streamed: four lanes per row (0x2000: the general kernel, A/B)
         // (measured and dropped, profiles/r03_pattern_team_kernel.txt: XCD slabs / runs of 1024+ workgroups +-2 %; the pattern byte speculated 2 %)
         launch_team(a, nullptr);
         return;
@@ -4938,19 +4657,15 @@ void launch_rowgather_dot(const LaunchArgs &a, int unroll, const double *w, doub
     constexpr Geometry g = kGeom[G];
     if (a.rowpat && a.ptab8 && a.vrec && a.plan && a.plan->drec && !(g_variant & 0x20002000) && g.block == 256) {    // the dominant pattern speculated (see launch_geom)
         const liship_csr_plan_s *P = a.plan;
-        if (!(g_variant & 0x10000000)) {                  // four rows per lane, a wavefront per row block (default); bit28: two rows per lane
+        {                                                 // four rows per lane, a wavefront per row block
             int wslot = -1;
-            if (w == a.x && !(g_variant & 0x8))            // (bit3: w by its own loads, A/B)
+            if (w == a.x)
                 for (int u = 0; u < 7; u++) if (((P->dom.mask >> u) & 1) && P->dom.off[u] == 0) wslot = u;
             spmv_csr_valuerec_dom_dot4_kernel<256, DOT><<<(a.nb + 3) / 4, 256, 0, a.st>>>(
                 a.rowpat, a.vrec, P->drec, P->dom, P->dom_lo, P->dom_hi, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
                 w, partial, liship_internal_guard(), pstride, wslot);
             return;
         }
-        spmv_csr_valuerec_dom_dot_kernel<256, DOT><<<(a.nb + 1) / 2, 256, 0, a.st>>>(
-            a.rowpat, a.vrec, P->drec, P->dom, P->dom_lo, P->dom_hi, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0},
-            w, partial, liship_internal_guard(), pstride);
-        return;
     }
     if (a.rowpat && a.ptab8 && a.vrec && !(g_variant & 0x2000) && g.block == 256 &&
         ((g_variant & 0x4000) || (long long)(a.re - a.rb) * 8 > (256ll << 20))) {          // two rows per lane beyond the Infinity Cache (see launch_geom)
@@ -5022,11 +4737,7 @@ int launch_csr(liship_csr_plan_t p, const LaunchArgs &a0)
     switch (p->geom) {
         case 0: launch_geom<0>(a, p->unroll, p->products != 0, p->batch); break;
         case 1: launch_geom<1>(a, p->unroll, p->products != 0, p->batch); break;
-        case 2: launch_geom<2>(a, p->unroll, p->products != 0, p->batch); break;
-        case 3: launch_geom<3>(a, p->unroll, p->products != 0, p->batch); break;
-        case 4: launch_geom<4>(a, p->unroll, p->products != 0, p->batch); break;
         case 5: launch_geom<5>(a, p->unroll, p->products != 0, p->batch); break;
-        case 6: launch_geom<6>(a, p->unroll, p->products != 0, p->batch); break;
         case 7: launch_geom<7>(a, p->unroll, p->products != 0, p->batch); break;
         case 8: launch_geom<8>(a, p->unroll, p->products != 0, p->batch); break;
         default: return LISHIP_ERR_ARG;
@@ -5050,12 +4761,12 @@ static bool plan_runs_teams(const liship_csr_plan_s *p)     // the four-lanes-pe
 {
     if (!p || !p->rowpat || !g_row_patterns || !g_index_codes || !g_team || p->ptab8) return false;
     if (g_row_values && p->vrecw) return false;
-    return p->prec36 != nullptr && (g_variant & ~0xc000) == 0;
+    return p->prec36 != nullptr && (g_variant & ~0x4000) == 0;
 }
 static bool plan_runs_dom(const liship_csr_plan_s *p)       // the dominant-pattern product of a plan with value records: its tiles have an epilogue of their own too
 {                                                           // (variant 0x4000: the fused dots stay with the row blocks' partial sums, spmv_csr_valuerec_dom_dot4_kernel -- A/B, tests)
     return p && p->rowpat && g_row_patterns && g_index_codes && p->ptab8 && g_row_values && p->vrec && p->drec && !p->products &&
-           kGeom[p->geom].block == 256 && (g_variant & ~0x50000008) == 0 && !g_row_block_dots;
+           kGeom[p->geom].block == 256 && (g_variant & ~0x10000000) == 0 && !g_row_block_dots;
 }
 extern "C" int liship_csr_plan_fused_dots(liship_csr_plan_t p) { return plan_runs_teams(p) ? 0 : 1; }
 // upper bound of the partial-sum slots the fused product needs when it is launched in up to three row ranges (liship_spmv_csr_rows_dot_f64)
@@ -5089,7 +4800,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     if (!p || !w || !result || !work) return LISHIP_ERR_ARG;
     if (plan_runs_teams(p) || liship_internal_ref_chunks()) return LISHIP_ERR_ARG;      // (reference-order sums: the product, then one ordered pass)
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
-    if ((g_variant & ~0x70006008) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    if ((g_variant & ~0x30006000) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
     if (plan_runs_wide(p, 0, p->n) && p->n > 0 && (size_t)((p->n + 255) / 256) <= slots) {       // wide records, x staged: a partial per workgroup of 256 rows
         LaunchArgs aw{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), p->codes, p->dict, nullptr, nullptr, nullptr, p->first_term ? -0.0 : 0.0, p->rowpat, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, nullptr, nullptr, nullptr, p->vrecw};
@@ -5157,7 +4868,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     if (!p || !w || !work || !slots_used || row_begin < 0 || row_end > p->n || slot_base < 0) return LISHIP_ERR_ARG;
     if (plan_runs_teams(p) || liship_internal_ref_chunks()) return LISHIP_ERR_ARG;
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
-    if ((g_variant & ~0x70006008) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
+    if ((g_variant & ~0x30006000) != 0 || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     *slots_used = 0;
     if (row_begin >= row_end || p->nblocks == 0) return 0;
     if (plan_runs_wide(p, row_begin, row_end)) {       // wide records, x staged: a partial per workgroup of 256 rows (block rows) of the range

@@ -37,6 +37,15 @@ def test_bench_line_has_the_contract_fields():
         assert vs is not None and vs["roofline"]["value_records"] == 0 and 0 < vs["roofline"]["frac"] <= 1.0
         assert vs["roofline"]["bytes_per_launch"] > r["bytes_per_launch"] and vs["nontrivial_x"]["value"] > 0
 
+    # the contract form (round 5): the same matrix through the kernel that streams the reference's own index[] / value[] arrays, priced on SURVEY 8d's bytes
+    cf = d["contract_form"]
+    cr = cf["roofline"]
+    assert cf["kernel"] == cr["kernel"] == "spmv_csr_rowgather_kernel" and cr["index_codes"] == cr["row_patterns"] == cr["value_records"] == 0
+    assert cr["bytes_per_launch"] == cr["contract_bytes_per_launch"] == r["contract_bytes_per_launch"] and 0 < cr["frac"] <= 1.0 and cr["frac"] == cr["contract_frac"]
+    assert abs(cr["achieved"] - cr["bytes_per_launch"] / (cr["kernel_ms"] * 1e-3) / 1e9) <= (0.01 + 0.00006 / cr["kernel_ms"]) * cr["achieved"] + 0.1
+    assert cf["value"] > 0 and cf["nontrivial_x"]["value"] > 0 and 0 < cf["nontrivial_x"]["frac"] <= 1.0 and cf["xcd_strip_rows"] in (0, 64 * 64)
+    assert cf["cg_jacobi"]["iters_per_sec"] > 0 and cf["cg_jacobi"]["loop_bytes_per_iter"] > d["krylov"]["cg_jacobi"]["roofline"]["loop_bytes_per_iter"]
+
     def fracs(node):
         if isinstance(node, dict):
             for k, v in node.items():
@@ -79,5 +88,10 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     assert d["config"]["n"] == n and d["config"]["nnz"] == 7 * n - 2 * (48 * 48 + 2 * planes * 48)
     assert ("per GPU" in d["config"]["workload"]) == (scaling == "weak")
     assert d["value"] > 0 and d["multi_gpu"] is not None and d["cpu_baseline"] is None
+    m = d["multi_gpu"]
+    assert m["halo_bytes_per_neighbour"] == 8 * 48 * 48 and m["halo_bytes_per_interior_rank_per_step"] == 2 * 8 * 48 * 48 and m["neighbours_of_rank0"] == 1
+    assert m["halo_communicator"] is None and m["folds_per_iteration"]["cg_jacobi"] == 2           # (callbacks: no RCCL communicator of either kind)
+    assert m["halo_ms_per_step"] > 0 and m["ms_per_step_no_overlap"] > 0
+    assert d["contract_form"]["kernel"] == "spmv_csr_rowgather_kernel" and d["contract_form"]["cg_jacobi"]["iters_per_sec"] > 0
     for name in ("cg_jacobi", "bicgstab_none", "bicg_none", "gmres30_none"):
         assert d["krylov"][name]["iters_per_sec"] > 0

@@ -49,9 +49,7 @@ check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
 check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
 check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
 print("row patterns:", lib.liship_csr_plan_row_patterns(plan), "value records:", lib.liship_csr_plan_value_records(plan), flush=True)
-FORMS = {"one row/lane": 0x20000000, "two rows/lane": 0x20004000, "dominant plain": 0x10000000, "dominant run8": 0x10080001,
-         "tile 32": 0x10000008, "tile 64": 0x10000200, "tile 128": 0x10000208, "tile 256": 0x10008000, "default": 0,
-         "planes": 0x40000000, "planes/2": 0x40020000, "planes/4": 0x40040000, "planes/16": 0x40100000, "abl planes": 0x40004000}
+FORMS = {"one row/lane": 0x20000000, "two rows/lane": 0x20004000, "dominant plain": 0x10000000, "default": 0}
 if os.environ.get("DOM_FORMS"):
     FORMS = {k: v for k, v in FORMS.items() if k in os.environ["DOM_FORMS"].split(",")}
 lib.liship_spmv_csr_set_row_values(0)

@@ -639,11 +639,12 @@ def stencil27_leg(lib, np, C, stream, G=256, launches=30):
             check(lib.liship_timer_elapsed_ms(timer, C.byref(ev)))
             ms = ev.value / launches
             wide = int(lib.liship_csr_plan_wide_dominant(plan))
-            stored = 17 * n if wide else 8 * nnz + 17 * n          # one pattern byte, y, the compulsory x per row (+ the streamed values)
+            box27 = int(lib.liship_csr_plan_box27(plan))           # round 5: the grid is a box and the product walks its planes (x and y alone: 16 B per row)
+            stored = 16 * n if box27 else 17 * n if wide else 8 * nnz + 17 * n          # (one pattern byte,) y, the compulsory x per row (+ the streamed values)
             out[key] = {"kernel_ms": round(ms, 4), "gflops": round(2e-6 * nnz / ms, 1), "stored_bytes_per_launch": int(stored),
                         "working_set_note": "x (8 B per row) alone still fits the 256 MB Infinity Cache at this size; the bytes of one launch do not" if 8 * n <= (256 << 20) < stored else None,
                         "frac": round(stored / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "kernel": "spmv_csr_valuerecw_staged_kernel" if wide else ("spmv_csr_pattern_team_staged_kernel" if int(lib.liship_csr_plan_team_form(plan)) == 2 else "other")}
+                        "kernel": "spmv_csr_box27_march_kernel" if box27 else "spmv_csr_valuerecw_staged_kernel" if wide else ("spmv_csr_pattern_team_staged_kernel" if int(lib.liship_csr_plan_team_form(plan)) == 2 else "other")}
             check(lib.liship_csr_plan_destroy(plan))
         return out
     except Exception as exc:                                          # an extra: its failure must not cost the line

@@ -107,6 +107,10 @@ int  liship_csr_plan_team_form(liship_csr_plan_t plan);
 /* 1 when a plan with WIDE value records (constant-coefficient rows of up to 32 entries) also found a dominant pattern and runs the kernel with x staged per
  * wavefront and that pattern's slots and values in scalar registers (spmv_csr_valuerecw_staged_kernel) */
 int  liship_csr_plan_wide_dominant(liship_csr_plan_t plan);
+/* 1 when, on top of that, the matrix is the 27-point box stencil with constant coefficients on a grid that IS a box (lines a multiple of 128 long, rows in ascending
+ * column order; checked row by row at plan time) and its whole-matrix product walks the planes of 128-column tiles with each x loaded once (round 5:
+ * spmv_csr_box27_march_kernel -- x and y alone are streamed); liship_spmv_csr_set_dom_march(0) keeps the staged kernel (A/B), 2 marches at any size (tests) */
+int  liship_csr_plan_box27(liship_csr_plan_t plan);
 /* 0 when the products of this plan run a kernel with a row split of its own (the team / staged kernels) under the switches in force: the fused entry points
  * (liship_spmv_csr_dot_f64, liship_spmv_csr_rows_dot_f64) then refuse with LISHIP_ERR_ARG and the caller runs the product and one reduction pass */
 int  liship_csr_plan_fused_dots(liship_csr_plan_t plan);

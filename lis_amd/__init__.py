@@ -101,6 +101,7 @@ _LISHIP = {
     "liship_csr_plan_scan_band": (_ci, [_vp, _vp, _vp, _vp]),
     "liship_set_sync_timeout": (_ci, [C.c_double]),
     "liship_csr_plan_strip_rows": (_ci, [_vp]),
+    "liship_csr_plan_box27": (_ci, [_vp]),
     "liship_spmv_csr_set_long_row_tree": (_ci, [_ci]),
     "liship_spmv_csr_set_uniform_rows": (_ci, [_ci]),
     "liship_spmv_csr_set_row_block_dots": (_ci, [_ci]),

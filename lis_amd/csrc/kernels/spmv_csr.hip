@@ -2441,10 +2441,15 @@ __global__ __launch_bounds__(BLOCK)
 void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, const double *__restrict__ wdrec, const v4i32 *__restrict__ wstage,
                                       const v4i32 *__restrict__ rec, int npat, const double *__restrict__ x, double *__restrict__ y, Rows RW,
                                       const WideDom D, int xcap, const double *__restrict__ guard = nullptr,
-                                      const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr, int pstride = 0)
+                                      const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr, int pstride = 0, int xs_plane = 0)
 {
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
     extern __shared__ __attribute__((aligned(16))) double wide_dyn[];
+    // XCD strips (round 5; xcd_strip_unit): workgroup -> chunk of 256 rows.  This kernel streams one byte per row, so x IS its traffic, and in the natural order the
+    // x a chunk stages (its own rows, the lines next to them, the planes before and behind) crosses the fabric once per XCD that touches it: 5.9 x at 200^3
+    // (profiles/r03_wide_records_staged.txt).  With strips an XCD keeps its eighth of every plane and finds the planes before and behind in its own L2.  The
+    // partial sums of the fused dots stay with the CHUNK (not with the workgroup that ran it): the fold's order does not move.
+    const int wg = xcd_strip_unit((int)blockIdx.x, (int)gridDim.x, xs_plane);
     __shared__ double dot_part[(DOT >= 2 ? 2 : 1) * (DOT != 0 ? BLOCK : 1)];
     __shared__ unsigned dot_count;
     if (DOT != 0) {                                                // the only barrier: at the start (workgroup_dots_last)
@@ -2455,7 +2460,7 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
     double *xL = wide_dyn + w * xcap;
     // a wavefront walks CH consecutive chunks of 64 rows: the staging loads and the pattern byte of the NEXT chunk are issued before the products of the
     // one in hand are formed, so that a round trip hides behind the arithmetic (and the offset table is read once)
-    const int rbase = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * (CH * WAVE);
+    const int rbase = RW.rb + (wg * (BLOCK / WAVE) + w) * (CH * WAVE);
     if (DOT == 0 && rbase >= RW.re) return;
     double c0 = 0.0, c1 = 0.0;                                     // (DOT) this lane's <w, y> and <y, y>: one partial per workgroup, folded by the caller
     if (rbase < RW.re) {
@@ -2577,7 +2582,7 @@ void spmv_csr_valuerecw_staged_kernel(const unsigned char *__restrict__ rowpat, 
         if (DOT >= 2 && live) c1 += acc * acc;
     }
     }
-    if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : (int)gridDim.x, true);
+    if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, wg, pstride ? pstride : (int)gridDim.x, true);
 }
 
 // BLOCK ROWS: the row form of a b x b blocked stencil (liship_bsr_to_rows: CSR rows that list lis_matvec_bsr's terms) has b interior row patterns that take
@@ -2594,7 +2599,7 @@ __global__ __launch_bounds__(256)
 void spmv_csr_blockrows_staged_kernel(const unsigned char *__restrict__ rowpat, const unsigned long long *__restrict__ bdrec, const int *__restrict__ bstage,
                                       const v4i32 *__restrict__ rec, int npat, const double *__restrict__ x, double *__restrict__ y, Rows RW,
                                       const BlockDom D, int xcap, const double *__restrict__ guard = nullptr,
-                                      const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr, int pstride = 0)
+                                      const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr, int pstride = 0, int xs_plane = 0)
 {
     constexpr int BLOCK = 256;
     if (guard != nullptr && guard[0] != 0.0) return;               // (fused forms) device-driven Krylov loop already converged
@@ -2607,7 +2612,8 @@ void spmv_csr_blockrows_staged_kernel(const unsigned char *__restrict__ rowpat, 
     }
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & (WAVE - 1);
     double *xL = wide_dyn + w * xcap;
-    const int r0 = RW.rb + ((int)blockIdx.x * (BLOCK / WAVE) + w) * (WAVE * B);      // (RW.rb and RW.re are multiples of B: the launcher checks)
+    const int wg = xcd_strip_unit((int)blockIdx.x, (int)gridDim.x, xs_plane);      // (XCD strips: see spmv_csr_valuerecw_staged_kernel)
+    const int r0 = RW.rb + (wg * (BLOCK / WAVE) + w) * (WAVE * B);      // (RW.rb and RW.re are multiples of B: the launcher checks)
     double c0 = 0.0, c1 = 0.0;
     if (r0 < RW.re) {
         const int rl = r0 + lane * B;
@@ -2698,7 +2704,175 @@ void spmv_csr_blockrows_staged_kernel(const unsigned char *__restrict__ rowpat, 
             for (int k = 0; k < B; k++) { c0 += wv[k] * acc[k]; if (DOT >= 2) c1 += acc[k] * acc[k]; }
         }
     }
-    if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : (int)gridDim.x, true);
+    if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, wg, pstride ? pstride : (int)gridDim.x, true);
+}
+
+// Z-MARCHING form of the 27-point box stencil with constant coefficients (round 5): the matrix of the reference's spmvtest3b (test/spmvtest3b.c:136-160) and of
+// HPCG, rows in ascending column order, on a grid that is a BOX -- plan time has checked, row by row, that a row lacks exactly the neighbours that lie outside the
+// grid (wide_box_check) and that every pattern carries the dominant pattern's values.  The staged kernel above brings the x of a wavefront's 64 rows in by nine
+// runs of loads through L1 and runs at a quarter of the roofline: it is bound by the chain of round trips inside a wavefront, not by bytes.  Here a workgroup owns a
+// tile of 128 columns x TY lines and WALKS the planes, as the 7-point marching kernel does: a plane's tile (+ a halo line above and below, a halo column left and
+// right, the four corners) is loaded ONCE by coalesced 16 B loads issued D planes ahead, parked in registers, written to one of two LDS buffers; a lane takes the
+// LPW + 2 lines x 4 columns its two rows per line need from the NEWEST plane out of LDS -- (LPW + 2) x (16 + 8 + 8) B per plane instead of 27 entries per row --
+// and keeps the two planes before it in registers.  The 27 values are kernel arguments (scalar registers).  Same products in the same order, one rounded multiply
+// and one rounded add per term: the reference's bits.  A neighbour outside the grid is a halo cell that holds a ZERO whose product with any off-centre value is
+// -0.0 (all off-centre values have one sign: checked), the term a missing slot adds: no masks, no pattern bytes -- x once and y once, 16 B per row.
+struct Box27 { int S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, wgs, xcd, planes, pad; double poison; double val[27]; };
+template <int LPW, int DOT, bool WS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LPW == 2 ? 3 : 4)))      // (eight lines per tile: 171 registers without the hint -- three short of a third workgroup per CU)
+void spmv_csr_box27_march_kernel(const double *__restrict__ x, double *__restrict__ y, double acc0, const Box27 M, int nx,
+                                 const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                                 const double *__restrict__ guard = nullptr, int pstride = 0)
+{
+    constexpr int BLOCK = 256, TX = 128, TY = 4 * LPW, LX = TX + 4, NLN = LPW + 2;      // an LDS line: [pad][left halo][TX columns][right halo][pad]: a lane's pair at 2 + 2 lane, 16 B aligned
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;      // device-driven Krylov loop already converged (nothing has been written)
+    __shared__ __attribute__((aligned(16))) double buf[2][(TY + 2) * LX];
+    __shared__ double dot_part[(DOT >= 2 ? 2 : 1) * (DOT != 0 ? BLOCK : 1)];
+    __shared__ unsigned dot_count;
+    const int tid = (int)threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & (WAVE - 1);
+    if (DOT != 0 && tid == 0) dot_count = 0u;                         // (a barrier follows before anyone counts itself in)
+    int wg = (int)blockIdx.x;
+    const int ntile = M.tiles_x * M.tiles_y;
+    if (M.xcd) { const int k = wg % NUM_XCD, j = wg / NUM_XCD; wg = k * (M.wgs / NUM_XCD) + j; }      // each XCD a contiguous eighth of the (segment, tile) list
+    const int seg = wg / ntile, t = wg - seg * ntile;
+    const int ty = t / M.tiles_x, tx = t - ty * M.tiles_x;
+    const int za = M.z0 + seg * M.zseg, zb = min(M.z1, za + M.zseg);
+    const int col0 = tx * TX, line0 = ty * TY;
+    const long long S = M.S, SO = M.SO;
+    const long long base = (long long)(line0 + w * LPW) * S + col0 + 2 * lane;      // this lane's first pair inside a plane; its LPW pairs are S apart
+    auto at = [&](long long a) { return (int)(a < 0 ? 0 : (a > (long long)nx - 2 ? (long long)nx - 2 : a)); };      // (pairs: the last start is nx - 2; clamped addresses only ever feed poisoned cells)
+    const double pz = M.poison;
+    const bool box_left = tx == 0, box_right = tx == M.tiles_x - 1, box_top = ty == 0, box_bottom = ty == M.tiles_y - 1;      // (uniform)
+    struct Packet { v2f64 own[LPW]; v2f64 hy; double hx[LPW]; double hc; v2f64 ww[WS ? LPW : 1]; };
+    auto load_packet = [&](Packet &P, int z, bool with_w) {
+        const long long zo = (long long)z * SO, pb = zo + base;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + at(pb + i * S));
+        const long long hl = zo + (long long)(w == 0 ? line0 - 1 : line0 + TY) * S + col0;      // the halo line this wavefront brings (the first and the last wavefront)
+        if (w == 0 || w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at(hl + 2 * lane));
+        if (lane == 0 || lane == WAVE - 1) {
+            const int hcol = lane == 0 ? col0 - 1 : col0 + TX;
+#pragma unroll
+            for (int i = 0; i < LPW; i++) { const long long a = zo + (long long)(line0 + w * LPW + i) * S + hcol; P.hx[i] = x[a < 0 ? 0 : (a > (long long)nx - 1 ? (long long)nx - 1 : a)]; }
+            if (w == 0 || w == 3) { const long long a = zo + (long long)(w == 0 ? line0 - 1 : line0 + TY) * S + hcol; P.hc = x[a < 0 ? 0 : (a > (long long)nx - 1 ? (long long)nx - 1 : a)]; }
+        }
+        if (DOT != 0 && WS && with_w && z < M.z1) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) P.ww[i] = *reinterpret_cast<const v2f64u *>(wdot + pb + i * S);
+        }
+    };
+    // a plane into an LDS buffer: the cells outside the grid take the zero (a whole plane of it before the first and behind the last plane)
+    auto store_packet = [&](const Packet &P, double *B, int z) {
+        const bool off = z < 0 || z >= M.planes;                      // (uniform)
+#pragma unroll
+        for (int i = 0; i < LPW; i++) { v2f64 v = P.own[i]; if (off) { v.x = v.y = pz; } *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = v; }
+        if (w == 0) { v2f64 h = P.hy; if (off || box_top) { h.x = h.y = pz; } *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = h; }
+        if (w == 3) { v2f64 h = P.hy; if (off || box_bottom) { h.x = h.y = pz; } *reinterpret_cast<v2f64 *>(B + (TY + 1) * LX + 2 + 2 * lane) = h; }
+        if (lane == 0 || lane == WAVE - 1) {
+            const bool side = lane == 0 ? box_left : box_right;
+            const int c = lane == 0 ? 1 : 2 + TX;
+#pragma unroll
+            for (int i = 0; i < LPW; i++) B[(w * LPW + i + 1) * LX + c] = (off || side) ? pz : P.hx[i];
+            if (w == 0) B[c] = (off || side || box_top) ? pz : P.hc;
+            if (w == 3) B[(TY + 1) * LX + c] = (off || side || box_bottom) ? pz : P.hc;
+        }
+    };
+    // the lines a lane's rows need from a plane in LDS: LPW + 2 of them, four columns each (left, its pair, right)
+    auto read_plane = [&](double (&X)[NLN][4], const double *B) {
+#pragma unroll
+        for (int j = 0; j < NLN; j++) {
+            const int li = (w * LPW + j) * LX + 2 + 2 * lane;
+            const v2f64 c = *reinterpret_cast<const v2f64 *>(B + li);
+            X[j][0] = B[li - 1]; X[j][1] = c.x; X[j][2] = c.y; X[j][3] = B[li + 2];
+        }
+    };
+    double Xa[NLN][4], Xb[NLN][4], Xc[NLN][4];
+    Packet Q0, Q1;
+    v2f64 ww0[WS ? LPW : 1];
+    {   // prologue: plane za - 1 and plane za through the two buffers into registers; planes za + 1, za + 2 in flight
+        Packet P;
+        load_packet(P, za - 1, false);
+        store_packet(P, buf[0], za - 1);
+        load_packet(P, za, true);
+        store_packet(P, buf[1], za);
+        if (WS) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) ww0[i] = P.ww[i];
+        }
+        load_packet(Q0, za + 1, true);
+        load_packet(Q1, za + 2, true);
+        __syncthreads();
+        read_plane(Xa, buf[0]);
+        read_plane(Xb, buf[1]);
+        __syncthreads();                                              // both buffers are free again
+    }
+    double c0 = 0.0, c1 = 0.0;
+    // one plane: Xp / Xc hold planes z - 1 / z, packet P plane z + 1 (the oldest in flight), which goes to LDS buffer (z + 1) & 1 and from there into Xn
+    auto step = [&](int z, double (&Xp)[NLN][4], double (&Xq)[NLN][4], double (&Xn)[NLN][4], Packet &P) {
+        double *B = buf[(z + 1) & 1];
+        store_packet(P, B, z + 1);
+        v2f64 wnext[WS ? LPW : 1];
+        if (WS) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) wnext[i] = P.ww[i];
+        }
+        load_packet(P, z + 3, true);                                  // this slot's next plane
+        __syncthreads();                                              // plane z + 1 is in LDS (and nobody reads the other buffer any more)
+        read_plane(Xn, B);
+#pragma unroll
+        for (int i = 0; i < LPW; i++) {
+            double s0 = acc0, s1 = acc0;
+#pragma unroll
+            for (int dz = 0; dz < 3; dz++) {
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    const double *L = dz == 0 ? Xp[i + dy] : dz == 1 ? Xq[i + dy] : Xn[i + dy];
+#pragma unroll
+                    for (int dx = 0; dx < 3; dx++) {
+                        const double v = M.val[dz * 9 + dy * 3 + dx];
+                        s0 += v * L[dx];
+                        s1 += v * L[dx + 1];
+                    }
+                }
+            }
+            const long long row = (long long)z * SO + base + i * S;
+            v2f64 out; out.x = s0; out.y = s1;
+            store_stream(reinterpret_cast<v2f64 *>(y + row), out);
+            if (DOT != 0) {
+                v2f64 wv;
+                if (WS) wv = ww0[i]; else { wv.x = Xq[i + 1][1]; wv.y = Xq[i + 1][2]; }
+                c0 += wv.x * s0; c0 += wv.y * s1;
+                if (DOT >= 2) { c1 += s0 * s0; c1 += s1 * s1; }
+            }
+        }
+        if (WS) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) ww0[i] = wnext[i];
+        }
+    };
+    for (int z = za; z < zb; z += 6) {                                // the three register planes and the two packets rotate by NAME: six steps per trip, no moves
+        step(z, Xa, Xb, Xc, Q0);
+        if (z + 1 < zb) step(z + 1, Xb, Xc, Xa, Q1);
+        if (z + 2 < zb) step(z + 2, Xc, Xa, Xb, Q0);
+        if (z + 3 < zb) step(z + 3, Xa, Xb, Xc, Q1);
+        if (z + 4 < zb) step(z + 4, Xb, Xc, Xa, Q0);
+        if (z + 5 < zb) step(z + 5, Xc, Xa, Xb, Q1);
+    }
+    if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : M.wgs, true);
+}
+
+// plan time: is the grid of a 27-point plan a BOX?  Row r = (z, y, x) must keep exactly the dominant pattern's slots whose neighbour (z + dz, y + dy, x + dx) lies
+// inside the grid (masks: wdrec[pattern * WREC + 32], the low 27 bits).  bad[0] counts the rows that do not.
+__global__ void wide_box_check(int n, int S, int SO, const unsigned char *__restrict__ rowpat, const double *__restrict__ wdrec, int *__restrict__ bad)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int z = r / SO, q = r - z * SO, yy = q / S, xx = q - yy * S, lines = SO / S, planes = n / SO;
+    unsigned want = 0;
+    for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++)
+        if (z + dz >= 0 && z + dz < planes && yy + dy >= 0 && yy + dy < lines && xx + dx >= 0 && xx + dx < S) want |= 1u << ((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1));
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(wdrec[(size_t)rowpat[r] * WREC + 32]);
+    if ((unsigned)(bits & 0x7ffffffull) != want || ((bits >> 32) & 3ull) != 2ull) atomicAdd(bad, 1);      // (bit 32: foreign; bit 33: the kept slots carry the dominant values)
 }
 
 // plan time: one 64-bit hash per row over (length, code sequence); the distinct ones in an open-addressing table together with the
@@ -2922,6 +3096,7 @@ struct liship_csr_plan_s {
     double *wdrec;       // device: with vrecw, when one pattern carries most rows: per pattern WREC doubles (values in the dominant pattern's slots, mask | foreign << 32)
     v4i32 *wstage;       // device: 64 x 8 ints, the column offsets of a lane's slot pairs in the staging loads of spmv_csr_valuerecw_staged_kernel
     WideDom wd;          // the dominant wide pattern (len = 0: none)
+    Box27 b27;           // the 27-point box stencil with constant coefficients (try_box27): the z-marching kernel's arguments (S = 0: none)
     BlockDom bd;         // block rows (liship_csr_plan_encode_block_rows): the dominant block row, one lane per block row (len = 0: none)
     unsigned long long *bdrec; // device: per pattern byte of a block row's FIRST row: mask over the dominant block row's entries | foreign << 32
     int *bstage;         // device: NL x 64 ints, the column offsets (from the wavefront's first row) of a lane's slot pairs in the staging loads
@@ -3043,7 +3218,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->bd.len = 0; p->bdrec = nullptr; p->bstage = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->b27.S = 0; p->bd.len = 0; p->bdrec = nullptr; p->bstage = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
     p->drec = nullptr; p->dom_lo = p->dom_hi = 0; p->dom_simple = 0; p->box_z0 = p->box_z1 = 0; p->dom_xlen = 0; p->box_modes = p->box_pads = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
@@ -3353,7 +3528,23 @@ extern "C" int liship_csr_plan_encode_row_patterns(liship_csr_plan_t p, const in
             PT(hipMemcpyAsync(p->ptab8, rec, sizeof(int) * 8 * (size_t)npat, hipMemcpyHostToDevice, st));
             for (int i = 0; i < npat; i++) p->prep[i] = reps[i];
         }
-        p->xs_rows = maxoff;                        // a structured grid: the largest offset is a plane of the grid (XCD strips: xcd_strip_unit)
+        // a structured grid: the plane the XCD strips are cut from (xcd_strip_unit).  The positive offsets of the longest pattern fall into clusters -- the line's
+        // neighbours, the neighbouring lines, the neighbouring planes --; the plane is the centre of the cluster above the LARGEST gap (7-point: +SO itself; 27-point:
+        // SO - S - 1 .. SO + S + 1 -> SO; 9-point in 2-D: S - 1 .. S + 1 -> S).  A pattern with a single positive cluster keeps the largest offset.
+        {
+            int lp = 0;
+            for (int i = 1; i < npat; i++) if (plen[i] > plen[lp]) lp = i;
+            int pos[PAT_MAXLEN], np_ = 0;
+            for (int j = 0; j < plen[lp]; j++) { const int o = tab[npat + 1 + tab[lp] + j]; if (o > 0 && np_ < PAT_MAXLEN) pos[np_++] = o; }
+            for (int i = 1; i < np_; i++) { const int v = pos[i]; int j = i - 1; while (j >= 0 && pos[j] > v) { pos[j + 1] = pos[j]; j--; } pos[j + 1] = v; }
+            int plane = maxoff;
+            if (np_ >= 2) {
+                int g = 1;
+                for (int i = 2; i < np_; i++) if (pos[i] - pos[i - 1] > pos[g] - pos[g - 1]) g = i;
+                if (pos[g] - pos[g - 1] > 2) plane = (pos[g] + pos[np_ - 1]) / 2;
+            }
+            p->xs_rows = plane;
+        }
         if (rc == 0) build_team_records(p, tab, npat);
         if (rc == 0) {
             csr_encode_patterns<<<p->nblocks, 256, 0, st>>>(p->blk, ptr, p->codes, npat, d_hash, d_len, d_pc, p->rowpat, p->rowrel, d_bad);
@@ -3397,6 +3588,8 @@ extern "C" int liship_csr_plan_row_patterns(liship_csr_plan_t p) { return (p && 
 extern "C" int liship_csr_plan_team_records(liship_csr_plan_t p) { return (p && p->rowpat && p->prec36) ? 1 : 0; }
 // 2 when the plan also keeps the dominant pattern's runs and slot records (the staged-x form), 1: records only, 0: none
 // 1 when a plan with wide value records also keeps the dominant pattern for the staged-x kernel (spmv_csr_valuerecw_staged_kernel)
+// 1 when the whole-matrix product of a plan with wide value records marches (the 27-point box stencil: spmv_csr_box27_march_kernel) under the switches in force
+extern "C" int liship_csr_plan_box27(liship_csr_plan_t p);
 extern "C" int liship_csr_plan_wide_dominant(liship_csr_plan_t p) { return (p && p->vrecw && p->wdrec && p->wd.len > 0) ? 1 : 0; }
 extern "C" int liship_csr_plan_team_form(liship_csr_plan_t p) { return (p && p->rowpat && p->prec36) ? ((p->prec_slot && p->tr.nruns > 0) ? 2 : 1) : 0; }
 extern "C" int liship_csr_plan_pattern_records(liship_csr_plan_t p) { return (p && p->rowpat && p->ptab8) ? 1 : 0; }
@@ -3711,8 +3904,44 @@ static int scs_merge(const int *ao, const double *av, int al, const int *bo, con
     return ml;
 }
 
+// Is the plan the 27-point box stencil the marching kernel serves (spmv_csr_box27_march_kernel)?  The dominant pattern's offsets are dz SO + dy S + dx in ascending
+// order, lines a multiple of 128 long, a multiple of four lines per plane, whole planes; the values finite and non-zero, the 26 off-centre ones of one sign (the
+// zero that stands in for a neighbour outside the grid must turn every one of them into -0.0); and every row keeps exactly the slots whose neighbour lies inside
+// the grid, with the dominant values (wide_box_check, one pass over the pattern bytes).
+static void try_box27(liship_csr_plan_s *p, const int *od, const WideDom &D, hipStream_t st)
+{
+    p->b27.S = 0;
+    if (D.len != 27 || D.pat < 0 || !p->wdrec || !p->rowpat) return;
+    const int S = od[16], SO = od[22];
+    if (S < 128 || S % 128 != 0 || SO < 4 * S || SO % S != 0 || (SO / S) % 4 != 0 || p->n % SO != 0 || p->n / SO < 2) return;
+    for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++)
+        if (od[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] != dz * SO + dy * S + dx) return;
+    int sign = 0;
+    for (int u = 0; u < 27; u++) {
+        const double v = D.val[u];
+        if (!(v == v) || v - v != 0.0 || v == 0.0) return;            // NaN, infinite, zero
+        if (u == 13) continue;
+        const int sg = v < 0.0 ? -1 : 1;
+        if (sign == 0) sign = sg; else if (sg != sign) return;
+    }
+    int *d_bad = nullptr, bad = 1;
+    if (hipMalloc(&d_bad, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return; }
+    bool ok = hipMemsetAsync(d_bad, 0, sizeof(int), st) == hipSuccess;
+    if (ok) { wide_box_check<<<(p->n + 255) / 256, 256, 0, st>>>(p->n, S, SO, p->rowpat, p->wdrec, d_bad); ok = hipGetLastError() == hipSuccess; }
+    ok = ok && hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    (void)hipFree(d_bad);
+    if (!ok || bad != 0) return;
+    Box27 B;
+    memset(&B, 0, sizeof(B));
+    B.S = S; B.SO = SO; B.planes = p->n / SO;
+    B.poison = sign < 0 ? 0.0 : -0.0;                                 // (value) * (poison) = -0.0 for every off-centre value
+    for (int u = 0; u < 27; u++) B.val[u] = D.val[u];
+    p->b27 = B;
+}
+
 static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, const double *vals, const int *ptr, hipStream_t st)
 {
+    p->b27.S = 0;
     if (p->wdrec) { (void)hipFree(p->wdrec); p->wdrec = nullptr; }
     if (p->wstage) { (void)hipFree(p->wstage); p->wstage = nullptr; }
     p->wd.len = 0;
@@ -3821,7 +4050,7 @@ static void build_wide_dominant(liship_csr_plan_s *p, const int *T, int NP, cons
         }
         if (hipMalloc(&p->wdrec, sizeof(double) * WREC * (size_t)NP) == hipSuccess && hipMalloc(&p->wstage, sizeof(int) * WAVE * 8) == hipSuccess &&
             hipMemcpy(p->wdrec, img, sizeof(double) * WREC * (size_t)NP, hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(p->wstage, stage, sizeof(int) * WAVE * 8, hipMemcpyHostToDevice) == hipSuccess) p->wd = D;
+            hipMemcpy(p->wstage, stage, sizeof(int) * WAVE * 8, hipMemcpyHostToDevice) == hipSuccess) { p->wd = D; if (vals && dom >= 0) try_box27(p, od, D, st); }
         else {
             if (p->wdrec) { (void)hipFree(p->wdrec); p->wdrec = nullptr; }
             if (p->wstage) { (void)hipFree(p->wstage); p->wstage = nullptr; }
@@ -4331,6 +4560,32 @@ static bool block_rows_serve(const liship_csr_plan_s *P, int rb, int re)      //
     return P && P->bd.len > 0 && P->bdrec && P->bstage && g_block_rows && g_team && rb % P->bd.b == 0 && re % P->bd.b == 0;
 }
 
+// the shape of the 27-point marching kernel for the rows [a.rb, a.re): whole planes of a plan whose grid is a box (try_box27).  Tiles of 128 columns x 8 lines (x 4 when
+// eight does not divide the lines of a plane), segments of planes so that the launch has about three workgroups per CU (the 7-point kernel's choice).
+static bool box27_shape(const LaunchArgs &a, Box27 &M, int &lpw)
+{
+    const liship_csr_plan_s *P = a.plan;
+    if (!P || P->b27.S <= 0 || !g_dom_march || g_variant != 0 || !aligned16(a.y) || !g_row_values) return false;
+    M = P->b27;
+    const int S = M.S, SO = M.SO;
+    if (a.rb < 0 || a.re > P->n || a.rb % SO != 0 || a.re % SO != 0) return false;
+    const int z0 = a.rb / SO, z1 = a.re / SO, planes = z1 - z0;
+    if (planes < 1 || (planes < 8 && g_dom_march == 1)) return false;
+    const int lines = SO / S;
+    lpw = (lines % 8 == 0 && g_dom_march != 3) ? 2 : 1;                 // (3: four lines per tile everywhere -- tests of that instantiation)
+    const int tiles_x = S / 128, tiles_y = lines / (4 * lpw), tiles = tiles_x * tiles_y;
+    // (256^3, same box: three workgroups per CU 0.0591 ms, two 0.0613, four 0.0630, six 0.0633; tiles of four lines 0.0640 at best -- profiles/EXPERIMENTS.md)
+    int nseg = (3 * 256 + tiles - 1) / tiles;
+    if (nseg > planes / 8) nseg = planes / 8;
+    if (nseg < 1) nseg = 1;
+    const int zseg = (planes + nseg - 1) / nseg;
+    nseg = (planes + zseg - 1) / zseg;
+    M.tiles_x = tiles_x; M.tiles_y = tiles_y; M.zseg = zseg; M.nseg = nseg; M.z0 = z0; M.z1 = z1; M.wgs = tiles * nseg;
+    if (M.wgs < 64 && g_dom_march == 1) return false;                // (a handful of workgroups walking a small grid: the staged kernel's thousands of independent wavefronts win)
+    M.xcd = (M.wgs % NUM_XCD == 0 && M.wgs >= 8 * NUM_XCD) ? 1 : 0;
+    return true;
+}
+
 // rows of up to 32 entries whose values ride in wide records: x staged per wavefront, the dominant pattern in scalar registers (variant 0x4000: the
 // gathering kernel on plan row blocks, A/B)
 static bool launch_wide(const LaunchArgs &a, const double *guard, int dot = 0, const double *w = nullptr, double *partial = nullptr, int pstride = 0, int *wgs_out = nullptr)
@@ -4342,7 +4597,7 @@ static bool launch_wide(const LaunchArgs &a, const double *guard, int dot = 0, c
         if (rows <= 0) return true;
         const int xcap = (P->bd.slots + 1) & ~1, nl = (P->bd.slots + 2 * WAVE - 1) / (2 * WAVE);
 #define GOB(B_, NL_, DT) spmv_csr_blockrows_staged_kernel<B_, NL_, DT><<<wgs, 256, sizeof(double) * 4 * (size_t)xcap, a.st>>>( \
-        a.rowpat, P->bdrec, P->bstage, a.vrecw, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0}, P->bd, xcap, guard, w, partial, pstride)
+        a.rowpat, P->bdrec, P->bstage, a.vrecw, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0}, P->bd, xcap, guard, w, partial, pstride, xcd_strip_plane(P, 256.0 * b, wgs))
 #define GOBD(DT) do { if (b == 2) { if (nl <= 4) GOB(2, 4, DT); else GOB(2, 6, DT); } else if (b == 3) { if (nl <= 6) GOB(3, 6, DT); else GOB(3, 8, DT); } \
                       else { if (nl <= 8) GOB(4, 8, DT); else GOB(4, 12, DT); } } while (0)
         if (dot == 0) GOBD(0); else if (dot == 1) GOBD(1); else GOBD(2);
@@ -4351,13 +4606,28 @@ static bool launch_wide(const LaunchArgs &a, const double *guard, int dot = 0, c
         return true;
     }
     if (!P || !P->wdrec || !P->wstage || P->wd.len <= 0 || !g_team || (g_variant & 0x4000)) return false;
+    {   // the 27-point box stencil: whole planes march (spmv_csr_box27_march_kernel)
+        Box27 M;
+        int lpw = 0;
+        if (box27_shape(a, M, lpw)) {
+            if (wgs_out) *wgs_out = M.wgs;
+            const bool ws = dot != 0 && w != a.x;
+#define GO27(LPW_, DT, WS_) spmv_csr_box27_march_kernel<LPW_, DT, WS_><<<M.wgs, 256, 0, a.st>>>(a.x, a.y, a.acc0, M, P->wd.maxcol + 1, w, partial, guard, pstride)
+#define GO27D(LPW_) do { if (dot == 0) GO27(LPW_, 0, false); else if (dot == 1) { if (ws) GO27(LPW_, 1, true); else GO27(LPW_, 1, false); } \
+                         else { if (ws) GO27(LPW_, 2, true); else GO27(LPW_, 2, false); } } while (0)
+            if (lpw == 2) GO27D(2); else GO27D(1);
+#undef GO27D
+#undef GO27
+            return true;
+        }
+    }
     constexpr int CH = 1;                            // chunks of 64 rows per wavefront
     const int rows = a.re - a.rb, wgs = (rows + 256 * CH - 1) / (256 * CH);
     if (wgs_out) *wgs_out = rows > 0 ? wgs : 0;
     if (rows <= 0) return true;
     const int xcap = (P->wd.slots + 1) & ~1, nl = (P->wd.slots + 2 * WAVE - 1) / (2 * WAVE);
 #define GOW(NL, DT) spmv_csr_valuerecw_staged_kernel<256, NL, CH, DT><<<wgs, 256, sizeof(double) * 4 * (size_t)xcap, a.st>>>( \
-        a.rowpat, P->wdrec, P->wstage, a.vrecw, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0}, P->wd, xcap, guard, w, partial, pstride)
+        a.rowpat, P->wdrec, P->wstage, a.vrecw, a.npat1 - 1, a.x, a.y, Rows{a.rb, a.re, a.acc0}, P->wd, xcap, guard, w, partial, pstride, xcd_strip_plane(P, 256.0 * CH, wgs))
 #define GOWD(DT) do { if (nl <= 2) GOW(2, DT); else if (nl <= 3) GOW(3, DT); else if (nl <= 5) GOW(5, DT); else if (nl <= 6) GOW(6, DT); else GOW(8, DT); } while (0)
     if (dot == 0) GOWD(0); else if (dot == 1) GOWD(1); else GOWD(2);
 #undef GOWD
@@ -4779,6 +5049,16 @@ extern "C" long long liship_csr_plan_fused_slots(liship_csr_plan_t p)
         return (p->wdrec && p->wd.len > 0) || wide > blocks ? wide : blocks;
     }
     return (long long)p->nblocks + 2;
+}
+
+extern "C" int liship_csr_plan_box27(liship_csr_plan_t p)
+{
+    if (!p || p->b27.S <= 0 || !p->vrecw || !g_team || !g_row_patterns || !g_index_codes) return 0;
+    LaunchArgs a{};
+    a.plan = p; a.rb = 0; a.re = p->n; a.y = reinterpret_cast<double *>(16);
+    Box27 M;
+    int lpw = 0;
+    return box27_shape(a, M, lpw) ? 1 : 0;
 }
 
 extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const int *idx,

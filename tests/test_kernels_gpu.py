@@ -1807,6 +1807,114 @@ def test_scan_band_leaves_irregular_matrices_alone(lib):
         check(lib.liship_csr_plan_destroy(plan))
 
 
+def _box27_per_slot(dims, values):
+    """the 27-point box stencil with ONE value per slot (dz, dy, dx) -- constant coefficients, but 27 different ones: a wrong slot order shows in the bits"""
+    ptr, idx, val = stencil_box(dims)
+    nz, ny, nx = dims
+    rows = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    off = idx.astype(np.int64) - rows
+    dz = np.rint(off / (ny * nx)).astype(np.int64)
+    rem = off - dz * ny * nx
+    dy = np.rint(rem / nx).astype(np.int64)
+    dx = rem - dy * nx
+    return ptr, idx, values[((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)).astype(np.int64)]
+
+
+@pytest.mark.parametrize("dims,march", [((9, 8, 128), 2), ((10, 12, 128), 2), ((9, 8, 128), 3), ((11, 16, 256), 2), ((8, 8, 256), 2)])
+@pytest.mark.parametrize("values", ["hpcg", "per_slot"])
+def test_box27_marching_kernel_bit_exact(lib, dims, march, values):
+    """Round 5: the 27-point box stencil with constant coefficients on a grid that is a box -- the matrix of the reference's spmvtest3b (test/spmvtest3b.c:136-160)
+    and of HPCG -- walks the planes of 128-column tiles (spmv_csr_box27_march_kernel: each x loaded once, the planes before in registers, neighbours outside the grid as
+    signed zeros in the halo).  y must be the oracle's bits -- with 27 DIFFERENT values a wrong slot or order cannot hide --, whole, in ranges of whole planes, with
+    the fused dots; tiles of 8 lines (march 2) and of 4 (grids whose planes have 12 lines; march 3 forces them); x with infinities, NaN and signed zeros; and the
+    same bits as the staged kernel the plan runs with marching off."""
+    nz, ny, nx = dims
+    if values == "hpcg":
+        ptr, idx, val = stencil_box(dims)
+    else:
+        v27 = -np.random.default_rng(3).uniform(0.5, 1.5, 27)
+        v27[13] = 26.5
+        ptr, idx, val = _box27_per_slot(dims, v27)
+    n = len(ptr) - 1
+    x = np.modf(np.arange(n, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+    x[::7] = 0.0
+    x[3::11] = -0.0
+    for pos, v in ((0, np.inf), (n - 1, -np.inf), (n // 2, np.nan), (n // 3, np.inf), (nx * 3 + 5, np.nan), (ny * nx * 2 + 127, -np.inf)):
+        x[pos] = v
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    wv = np.random.default_rng(9).uniform(-1, 1, n)
+    dptr, didx, dval, dx, dw = (DA.from_host(a, t) for a, t in ((ptr, np.int32), (idx, np.int32), (val, np.float64), (x, np.float64), (wv, np.float64)))
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+    check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+    check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+    assert lib.liship_csr_plan_wide_dominant(plan) == 1
+    work, res = DA.zeros(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
+    mn = ny * nx
+    try:
+        check(lib.liship_spmv_csr_set_dom_march(march))
+        assert lib.liship_csr_plan_box27(plan) == 1
+        dy = DA.from_host(np.full(n, 7.0), np.float64)
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        y = dy.to_host()
+        assert np.array_equal(y.view(np.uint64)[~np.isnan(yref)], yref.view(np.uint64)[~np.isnan(yref)]) and np.array_equal(np.isnan(y), np.isnan(yref))
+        dy = DA.from_host(np.full(n, 7.0), np.float64)
+        for lo, hi in ((mn, n - mn), (0, mn), (n - mn, n)):                # a slab's interior planes, then its boundary planes
+            check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        y2 = dy.to_host()
+        assert np.array_equal(y2.view(np.uint64)[~np.isnan(yref)], yref.view(np.uint64)[~np.isnan(yref)])
+        # fused dots on a finite x (w = x and w a vector of its own): y again the oracle's, the sums to rounding
+        xf = np.modf(np.arange(n, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+        yf = orc.spmv_csr(ptr, idx, val, xf)
+        check(lib.liship_memcpy_h2d(dx.ptr, xf.ctypes.data, xf.nbytes, None))
+        for wname, wd, wh in (("x", dx, xf), ("w", dw, wv)):
+            dy = DA.from_host(np.full(n, 7.0), np.float64)
+            check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, wd.ptr, 1, res.ptr, work.ptr, None))
+            assert np.array_equal(dy.to_host().view(np.uint64), yf.view(np.uint64)), wname
+            got = res.to_host()
+            assert abs(got[0] - np.dot(wh, yf)) <= 1e-12 * np.abs(wh * yf).sum() and abs(got[1] - np.dot(yf, yf)) <= 1e-12 * np.dot(yf, yf), (wname, got)
+        check(lib.liship_spmv_csr_set_dom_march(0))
+        assert lib.liship_csr_plan_box27(plan) == 0
+        dy = DA.from_host(np.full(n, 7.0), np.float64)
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host().view(np.uint64), yf.view(np.uint64))
+    finally:
+        check(lib.liship_spmv_csr_set_dom_march(1))
+        check(lib.liship_csr_plan_destroy(plan))
+
+
+def test_box27_marching_needs_a_box_and_one_sign(lib):
+    """what plan time refuses: a grid whose rows are not a box's (one boundary row given a neighbour it should lack), off-centre values of both signs (no single zero
+    turns them all into -0.0), lines that 128 does not divide -- those plans keep the staged kernel and still give the oracle's bits"""
+    cases = {}
+    ptr, idx, val = stencil_box((9, 8, 128))
+    v2 = val.copy()
+    v2[ptr[500] + 2] = 3.0                                      # a positive off-centre value in ONE row: the pattern splits, the rows no longer share the dominant values
+    cases["two_signs_one_row"] = (ptr, idx, v2)
+    v27 = -np.ones(27); v27[13] = 26.0; v27[5] = 0.75
+    cases["two_signs_every_row"] = _box27_per_slot((9, 8, 128), v27)
+    cases["lines_of_96"] = stencil_box((9, 8, 96))
+    for name, (ptr, idx, val) in cases.items():
+        n = len(ptr) - 1
+        x = np.random.default_rng(4).uniform(-1, 1, n)
+        dptr, didx, dval, dx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64)
+        plan = C.c_void_p()
+        check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+        check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+        check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+        check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+        try:
+            check(lib.liship_spmv_csr_set_dom_march(2))
+            assert lib.liship_csr_plan_box27(plan) == 0, name
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host().view(np.uint64), orc.spmv_csr(ptr, idx, val, x).view(np.uint64)), name
+        finally:
+            check(lib.liship_spmv_csr_set_dom_march(1))
+            check(lib.liship_csr_plan_destroy(plan))
+
+
 def _blocked_rows(ptr, idx, val, bs, first_seen=True):
     """the CSR rows that list lis_matvec_bsr's terms of every scalar row of the bs x bs blocking (block after block, column after column, explicit zeros
     included): what liship_bsr_to_rows lays out in HBM for a constant-coefficient BSR matrix.  first_seen: a block row's blocks in the order

@@ -287,7 +287,7 @@ def main():
         of the HBM bytes; the stored bytes are the lower one."""
         if N != 512 or world != 1 or slab:
             return None, None
-        for tf in ("r04_spmv512_traffic%s.json", "r03_spmv512_traffic%s.json", "r02_spmv512_traffic%s.json"):
+        for tf in ("r05_spmv512_traffic%s.json", "r04_spmv512_traffic%s.json", "r03_spmv512_traffic%s.json", "r02_spmv512_traffic%s.json"):
             tf = os.path.join(ROOT, "profiles", tf % name)
             if os.path.exists(tf):
                 tj = json.load(open(tf))

@@ -34,6 +34,10 @@ def bytes_of(name):
     m = re.search(r"spmv_csr_valuerec_dom_kernel<256, (\d)", name)
     if m:
         return 17 * n, "headline product (value records, dominant pattern)" + (", fused dots (w = x in CG: no extra stream; w streamed adds 8 B per row)" if m.group(1) != "0" else "")
+    m = re.search(r"spmv_csr_rowgather_kernel<\d+, \d+, \d, (\d)", name)
+    if m:
+        return 12 * nnz + 20 * n + 4, ("CONTRACT FORM: 4 B indices + 8 B values streamed (SURVEY 8d's 12 B per non-zero + 20 B per row), XCD strips" +
+                                     (", fused dots (lower count: w may be a stream of its own)" if m.group(1) != "0" else ""))
     m = re.search(r"spmv_csr_pattern7_kernel<256, 2048, (\d)", name)
     if m:
         return 8 * nnz + 17 * n, "product with the values streamed (any 7-point matrix), XCD strips" + (", fused dots (lower count: w may be a stream of its own)" if m.group(1) != "0" else "")

@@ -19,7 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("dir"); ap.add_argument("kernel"); ap.add_argument("out")
 ap.add_argument("--n", type=int, default=512 ** 3)
 ap.add_argument("--nnz", type=int, default=7 * 512 ** 3 - 6 * 512 * 512)
-ap.add_argument("--coded", type=int, default=1)
+ap.add_argument("--coded", type=int, default=1, help="0: the contract form (4 B indices: 12 B per non-zero + the row pointers)")
 ap.add_argument("--patterns", type=int, default=0, help="row patterns: 8 B per non-zero + 1 B per row of matrix streams (row starts by scan)")
 ap.add_argument("--values", type=int, default=0, help="value records: one pattern byte per row is the only matrix stream")
 ap.add_argument("--box", type=int, default=0, help="with --values: the z-marching kernel's box form, which reads no pattern byte either (x and y alone)")

@@ -164,6 +164,11 @@ int  liship_spmv_csr_set_index_codes(int on);
 int  liship_csr_plan_localize_columns(liship_csr_plan_t plan, const int *ptr, const int *index, void *stream);
 long long liship_csr_plan_localized(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_local_columns(int on);
+/* round 5: when every list is made of TRIPLES of consecutive columns (meshes with 3 unknowns per node) the plan also keeps the triples' first columns and the kernel
+ * reads one 4 B run start per triple instead of three columns (a third of the list bytes).  liship_csr_plan_local_runs: 3 when the plan has them, else 0;
+ * liship_spmv_csr_set_local_runs(0): A/B switch (the full lists), same bits */
+int  liship_csr_plan_local_runs(liship_csr_plan_t plan);
+int  liship_spmv_csr_set_local_runs(int on);
 /* round 4: the block-local kernel keeps the 2 B positions in registers and stages 3584 items (lists <= 1024 columns) or 3072 items (longer lists) per
  * workgroup -- 39.5 KB of LDS, four workgroups per CU.  0: plans built from now on take the round-3 form (4096-item blocks, positions through LDS: three /
  * two workgroups per CU); A/B measurements, same bits either way */

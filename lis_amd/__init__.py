@@ -102,6 +102,8 @@ _LISHIP = {
     "liship_set_sync_timeout": (_ci, [C.c_double]),
     "liship_csr_plan_strip_rows": (_ci, [_vp]),
     "liship_csr_plan_box27": (_ci, [_vp]),
+    "liship_csr_plan_local_runs": (_ci, [_vp]),
+    "liship_spmv_csr_set_local_runs": (_ci, [_ci]),
     "liship_spmv_csr_set_long_row_tree": (_ci, [_ci]),
     "liship_spmv_csr_set_uniform_rows": (_ci, [_ci]),
     "liship_spmv_csr_set_row_block_dots": (_ci, [_ci]),

@@ -668,14 +668,18 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
 // distinct columns) have an empty list and take block_by_products on the 4 B indices.
 // RPOS (round 4): the 2 B positions go from HBM to REGISTERS (a lane only ever reads the positions of its own eight items), not through LDS; XCAP: the
 // longest list the plan found, rounded up to 1024 / 1536 / 2048 -- the x stage in LDS is no larger than that.
-template <int BLOCK, int WORK, int DOT = 0, int NDPL = 2, int XCAP = NDPL * BLOCK, bool RPOS = false>
+// RUNS (round 5): the sorted distinct columns of a row block of a mesh with 3 unknowns per node come in TRIPLES of consecutive columns; when every list of the plan
+// is made of such triples (liship_csr_plan_localize_columns checks) the kernel reads one 4 B run start per triple instead of three 4 B columns -- a third of the list
+// bytes (Queen class: 384 -> 128 MB of 3.34 GB) and a third of the list loads -- and a lane gathers its triple's three x.  Same stage contents: same bits.
+template <int BLOCK, int WORK, int DOT = 0, int NDPL = 2, int XCAP = NDPL * BLOCK, bool RPOS = false, bool RUNS = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((RPOS && XCAP <= 1536) ? 8 : 4)))      // four 512-lane workgroups per CU want <= 64 VGPRs (the fused-dot forms took 66 - 68)
 void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
                            const unsigned short *__restrict__ lcol, const int *__restrict__ dcol,
                            const int *__restrict__ doff, const double *__restrict__ x, double *__restrict__ y,
                            const v2i32 *__restrict__ blk, int bfirst, int nb, Rows RW, int nnz_total,
                            const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                           const double *__restrict__ guard = nullptr, int pstride = 0, int uniform = 1)
+                           const double *__restrict__ guard = nullptr, int pstride = 0, int uniform = 1,
+                           const int *__restrict__ drun = nullptr, const int *__restrict__ droff = nullptr)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const int row_begin = RW.rb, row_end = RW.re;
@@ -709,7 +713,14 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     // the block's distinct columns: the first memory operation, so that the gathers can leave while the slices stream in
     const int j4 = NDPL * (int)threadIdx.x;
     v4i32 dc = {0, 0, 0, 0};
-    if (j4 < nd) {                                  // lists are padded to whole 16 B pieces
+    constexpr int NRPL = (XCAP / 3 + BLOCK - 1) / BLOCK;      // (RUNS) triples per lane
+    int rs[NRPL], nr = 0;
+    if (RUNS) {
+        const int q0 = droff[bfirst + lb];
+        nr = droff[bfirst + lb + 1] - q0;
+#pragma unroll
+        for (int k = 0; k < NRPL; k++) { const int j = k * BLOCK + (int)threadIdx.x; rs[k] = j < nr ? drun[q0 + j] : -1; }
+    } else if (j4 < nd) {                           // lists are padded to whole 16 B pieces
         if (NDPL == 4) dc = *reinterpret_cast<const v4i32 *>(dcol + d0 + j4);
         else { const v2i32 h = *reinterpret_cast<const v2i32 *>(dcol + d0 + j4); dc.x = h.x; dc.y = h.y; }
     }
@@ -739,7 +750,13 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     const int rmine = B.r0 + (int)threadIdx.x;
     int s_first = 0, e_first = 0;
     if (rmine < B.r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; }
-    if (j4 < nd) {
+    if (RUNS) {
+        double t0[NRPL], t1[NRPL], t2[NRPL];
+#pragma unroll
+        for (int k = 0; k < NRPL; k++) if (rs[k] >= 0) { t0[k] = x[rs[k]]; t1[k] = x[rs[k] + 1]; t2[k] = x[rs[k] + 2]; }
+#pragma unroll
+        for (int k = 0; k < NRPL; k++) if (rs[k] >= 0) { double *q = xL + 3 * (k * BLOCK + (int)threadIdx.x); q[0] = t0[k]; q[1] = t1[k]; q[2] = t2[k]; }
+    } else if (j4 < nd) {
         v2f64 a, b;
         a.x = x[dc.x]; a.y = x[dc.y];
         if (NDPL == 4) { b.x = x[dc.z]; b.y = x[dc.w]; }
@@ -3079,6 +3096,7 @@ struct liship_csr_plan_s {
     int *dcol;           // device, the lists (each padded to a multiple of 4 entries)
     int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
     long long ndcol;     // entries of dcol
+    int *drun, *droff;   // device, or NULL: when every list is made of TRIPLES of consecutive columns (3 unknowns per node), the triples' first columns and nblocks + 1 offsets into them
     int ndpl;            // distinct columns per lane of spmv_csr_local_kernel: 2 (lists of <= 1024 columns) or 4
     int xcap;            // its x stage: the longest list rounded up to 1024 / 1536 / 2048 entries
     int xs_rows;         // rows per plane of a structured grid = the largest column offset of the row patterns (0: none): the XCD strips of the pattern kernels
@@ -3216,7 +3234,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->blk = nullptr;
     p->blk_host = nullptr;
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
-    p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->ndcol = 0; p->ndpl = 2;
+    p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->drun = nullptr; p->droff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
     p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->b27.S = 0; p->bd.len = 0; p->bdrec = nullptr; p->bstage = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
     p->drec = nullptr; p->dom_lo = p->dom_hi = 0; p->dom_simple = 0; p->box_z0 = p->box_z1 = 0; p->dom_xlen = 0; p->box_modes = p->box_pads = 0;
@@ -3249,6 +3267,8 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->vrecw) (void)hipFree(p->vrecw);
     if (p->lcol) (void)hipFree(p->lcol);
     if (p->dcol) (void)hipFree(p->dcol);
+    if (p->drun) (void)hipFree(p->drun);
+    if (p->droff) (void)hipFree(p->droff);
     if (p->doff) (void)hipFree(p->doff);
     free(p->blk_host);
     delete p;
@@ -4358,6 +4378,56 @@ extern "C" int liship_csr_plan_dominant_pattern(liship_csr_plan_t p) { return (p
 // Block-local columns for the products kernel (see spmv_csr_local_kernel): setup-time, optional, never an error when the
 // matrix does not qualify.  Kept when the lists cover >= 90 % of the non-zeros and hold at most half as many columns as
 // the blocks hold entries -- below that the 2 B + 4 B of a once-used column cost more than its 4 B index.
+// Lists made of triples (3 unknowns per node: the sorted distinct columns of a row block are 3c, 3c + 1, 3c + 2 for the nodes it touches).  One pass over the lists:
+// a block's true length (the padding repeats its last entry), whether it is a multiple of three and every group of three consecutive; when ALL blocks pass, the
+// triples' first columns are kept beside the lists (a third of their size) and the kernel reads those.  Optional: any failure leaves the plan as it was.
+namespace {
+__global__ void local_runs_count(int nb, const int *__restrict__ doff, const int *__restrict__ dcol, int *__restrict__ nruns)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const int d0 = doff[b], d1 = doff[b + 1];
+    int nd = d1 - d0;
+    while (nd > 1 && dcol[d0 + nd - 1] == dcol[d0 + nd - 2]) nd--;      // (strictly increasing up to the padding)
+    bool ok = nd % 3 == 0;
+    for (int k = 0; ok && k < nd; k += 3) ok = dcol[d0 + k + 1] == dcol[d0 + k] + 1 && dcol[d0 + k + 2] == dcol[d0 + k] + 2;
+    nruns[b] = ok ? nd / 3 : -1;
+}
+__global__ void local_runs_write(int nb, const int *__restrict__ doff, const int *__restrict__ dcol, const int *__restrict__ droff, int *__restrict__ drun)
+{
+    const int b = blockIdx.x;
+    const int d0 = doff[b], q0 = droff[b], nr = droff[b + 1] - q0;
+    for (int j = threadIdx.x; j < nr; j += blockDim.x) drun[q0 + j] = dcol[d0 + 3 * j];
+}
+}
+static void build_local_runs(liship_csr_plan_s *p, hipStream_t st)
+{
+    const int nb = p->nblocks;
+    if (nb <= 0 || !p->dcol || !p->doff) return;
+    int *d_n = nullptr, *h = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
+    bool ok = h && hipMalloc(&d_n, sizeof(int) * (size_t)(nb + 1)) == hipSuccess;
+    if (ok) { local_runs_count<<<(nb + 255) / 256, 256, 0, st>>>(nb, p->doff, p->dcol, d_n); ok = hipGetLastError() == hipSuccess; }
+    ok = ok && hipMemcpyAsync(h, d_n, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    long long total = 0;
+    if (ok) {
+        for (int b = 0; b < nb && ok; b++) { if (h[b] < 0) ok = false; else { const int c = h[b]; h[b] = (int)total; total += c; } }
+        h[nb] = (int)total;
+    }
+    ok = ok && total > 0 && total < 0x7fffffffLL;
+    if (ok) ok = hipMemcpyAsync(d_n, h, sizeof(int) * (size_t)(nb + 1), hipMemcpyHostToDevice, st) == hipSuccess && hipMalloc(&p->drun, sizeof(int) * (size_t)(total + 4)) == hipSuccess;
+    if (ok) { local_runs_write<<<nb, 256, 0, st>>>(nb, p->doff, p->dcol, d_n, p->drun); ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess; }
+    free(h);
+    if (ok) p->droff = d_n;
+    else {
+        (void)hipGetLastError();
+        if (d_n) (void)hipFree(d_n);
+        if (p->drun) { (void)hipFree(p->drun); p->drun = nullptr; }
+    }
+}
+extern "C" int liship_csr_plan_local_runs(liship_csr_plan_t p) { return (p && p->lcol && p->drun && p->droff) ? 3 : 0; }
+static int g_local_runs = 1;
+extern "C" int liship_spmv_csr_set_local_runs(int on) { g_local_runs = on ? 1 : 0; return 0; }
+
 extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *ptr, const int *idx, void *stream)
 {
     if (!p || (p->n > 0 && (!ptr || !idx))) return LISHIP_ERR_ARG;
@@ -4430,6 +4500,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     }
     p->doff = nd_dev;
     p->ndcol = run;
+    build_local_runs(p, st);
     p->ndpl = ndmost > 2 * g.block ? 4 : 2;        // lists of up to 1024 columns (the dofs-per-node patterns in mesh order): two per lane, 8 KB of LDS; longer ones four
     p->xcap = ndmost <= 1024 ? 1024 : (ndmost <= 1536 && p->geom == LOCAL_GEOM4) ? 1536 : 2048;
     return 0;
@@ -4826,14 +4897,18 @@ void launch_local(const LaunchArgs &a, const double *w, double *partial, const d
 {
     constexpr Geometry g = kGeom[is_local_geom(G) ? G : LOCAL_GEOM];
     const int ndpl = a.plan ? a.plan->ndpl : 2, xcap = a.plan ? a.plan->xcap : 1024;
+    const bool runs = a.plan && a.plan->drun && a.plan->droff && g_local_runs;      // lists of triples: the positions-in-registers forms read the run starts
 #define GOL(NDPL_, XCAP_, RPOS_) spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, RPOS_><<<a.nb, g.block, 0, a.st>>>( \
         a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows)
-    if constexpr (G == LOCAL_GEOM_R) { if (ndpl == 4) GOL(4, 2048, true); else GOL(2, 1024, true); }
+#define GOLR(NDPL_, XCAP_) spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, true, true><<<a.nb, g.block, 0, a.st>>>( \
+        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, a.plan->drun, a.plan->droff)
+    if constexpr (G == LOCAL_GEOM_R) { if (ndpl == 4) { if (runs) GOLR(4, 2048); else GOL(4, 2048, true); } else { if (runs) GOLR(2, 1024); else GOL(2, 1024, true); } }
     else if constexpr (G == LOCAL_GEOM4) {
-        if (xcap <= 1024) GOL(2, 1024, true);
-        else if (xcap <= 1536) GOL(4, 1536, true);
-        else GOL(4, 2048, true);
+        if (xcap <= 1024) { if (runs) GOLR(2, 1024); else GOL(2, 1024, true); }
+        else if (xcap <= 1536) { if (runs) GOLR(4, 1536); else GOL(4, 1536, true); }
+        else { if (runs) GOLR(4, 2048); else GOL(4, 2048, true); }
     } else { if (ndpl == 4) GOL(4, 2048, false); else GOL(2, 1024, false); }
+#undef GOLR
     (void)xcap;
 #undef GOL
 }

@@ -26,14 +26,25 @@ xs = np.cos(np.arange(n) * 0.01) + 1.25
 vx, vy = lisdrv.new_vector(lib, A, xs), lisdrv.new_vector(lib, A)
 if os.environ.get("QUEEN_VARIANT"):
     lib.liship_spmv_csr_set_variant(int(os.environ["QUEEN_VARIANT"], 0))
-for _ in range(10):
-    assert lib.lis_matvec(A, vx, vy) == 0
-dll.lis_amd_synchronize()
-t0 = time.time()
-for _ in range(reps):
-    assert lib.lis_matvec(A, vx, vy) == 0
-dll.lis_amd_synchronize()
-ms = (time.time() - t0) / reps * 1e3
+def timed():
+    for _ in range(10):
+        assert lib.lis_matvec(A, vx, vy) == 0
+    dll.lis_amd_synchronize()
+    t0 = time.time()
+    for _ in range(reps):
+        assert lib.lis_matvec(A, vx, vy) == 0
+    dll.lis_amd_synchronize()
+    return (time.time() - t0) / reps * 1e3
+if os.environ.get("QUEEN_RUNS_AB") == "1":             # round 5: the lists as run starts (triples) against the full lists, interleaved, same process
+    import hashlib
+    for rep in range(3):
+        for on in (1, 0):
+            lib.liship_spmv_csr_set_local_runs(on)
+            m = timed()
+            yh = np.empty(n); lib.lis_vector_get_values(vy, 0, n, yh.ctypes.data_as(capi.P_DBL))
+            print(f"runs={on}: {m:.4f} ms  y sha256 {hashlib.sha256(yh.tobytes()).hexdigest()[:16]}", flush=True)
+    lib.liship_spmv_csr_set_local_runs(1)
+ms = timed()
 print(json.dumps({"n": n, "nnz": nnz, "generate_s": round(t_gen, 2), "lis_input_s": round(t_read, 2), "block_local_columns_listed": int(listed),
                   "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),
                   "frac_of_8TBs_on_contract_bytes": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4)}), flush=True)

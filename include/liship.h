@@ -122,6 +122,9 @@ int  liship_spmv_csr_set_team(int on);           /* A/B switch: 0 = the one-lane
  * matrix does not qualify; row ranges that cut a block row run the row-by-row kernels.  Bits of lis_matvec_bsr.c:293-343. */
 int  liship_csr_plan_encode_block_rows(liship_csr_plan_t plan, int b, const int *ptr, void *stream);
 int  liship_csr_plan_block_rows(liship_csr_plan_t plan);       /* b when the plan keeps them, else 0 */
+/* 1 when those block rows are the 7-point stencil in 2 x 2 blocks on a grid that is a box (lines a multiple of 128 long; checked block row by block row at plan time)
+ * and the whole-matrix product walks the planes with each x loaded once (round 5: spmv_csr_block2_march_kernel); liship_spmv_csr_set_dom_march as for the others */
+int  liship_csr_plan_block2_march(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_block_rows(int on);                   /* A/B switch: 0 = the row-by-row kernels (same bits) */
 /* The z-marching form of the dominant-pattern product (7-point stencil with value records, grid lines a multiple of 128 long): 1 = on for launches of 64 workgroups and more (default), 0 = the gathering kernel, 2 = on at any size,
  * 3 = at any size, but with the faces' masks even where plan time found the grid a box (liship_csr_plan_box_planes: planes in which a slot is missing exactly where its neighbour

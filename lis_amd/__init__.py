@@ -102,6 +102,7 @@ _LISHIP = {
     "liship_set_sync_timeout": (_ci, [C.c_double]),
     "liship_csr_plan_strip_rows": (_ci, [_vp]),
     "liship_csr_plan_box27": (_ci, [_vp]),
+    "liship_csr_plan_block2_march": (_ci, [_vp]),
     "liship_csr_plan_local_runs": (_ci, [_vp]),
     "liship_spmv_csr_set_local_runs": (_ci, [_ci]),
     "liship_spmv_csr_set_long_row_tree": (_ci, [_ci]),

@@ -2732,8 +2732,8 @@ void spmv_csr_blockrows_staged_kernel(const unsigned char *__restrict__ rowpat, 
 // right, the four corners) is loaded ONCE by coalesced 16 B loads issued D planes ahead, parked in registers, written to one of two LDS buffers; a lane takes the
 // LPW + 2 lines x 4 columns its two rows per line need from the NEWEST plane out of LDS -- (LPW + 2) x (16 + 8 + 8) B per plane instead of 27 entries per row --
 // and keeps the two planes before it in registers.  The 27 values are kernel arguments (scalar registers).  Same products in the same order, one rounded multiply
-// and one rounded add per term: the reference's bits.  A neighbour outside the grid is a halo cell that holds a ZERO whose product with any off-centre value is
-// -0.0 (all off-centre values have one sign: checked), the term a missing slot adds: no masks, no pattern bytes -- x once and y once, 16 B per row.
+// and one rounded add per term: the reference's bits.  A neighbour outside the grid is a halo cell that holds a ZERO: its term is +-0.0, and a sum that starts at
+// +0.0 is never -0.0, so the term leaves every bit where a missing slot leaves it: no masks, no pattern bytes -- x once and y once, 16 B per row.
 struct Box27 { int S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, wgs, xcd, planes, pad; double poison; double val[27]; };
 template <int LPW, int DOT, bool WS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LPW == 2 ? 3 : 4)))      // (eight lines per tile: 171 registers without the hint -- three short of a third workgroup per CU)
@@ -2876,6 +2876,151 @@ void spmv_csr_box27_march_kernel(const double *__restrict__ x, double *__restric
         if (z + 5 < zb) step(z + 5, Xc, Xa, Xb, Q1);
     }
     if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : M.wgs, true);
+}
+
+// Z-MARCHING form of the block-row product for the 7-point stencil kept as 2 x 2 BLOCKS (round 5): Lis's default BSR block size on its own test matrices
+// (`-storage bsr`, lis_matvec_bsr.c:293-343), constant coefficients, the grid a box.  A lane's pair of rows IS a block row; block j of it brings the pair
+// (x[2 bj], x[2 bj + 1]) and both rows add value * x column by column, block after block in the order the conversion met them, explicit zeros included -- 14 terms
+// per row.  The seven pairs a block row needs are the 7-point marching kernel's: the planes before and behind in registers, the lines above and below and the
+// blocks left and right from the LDS copy of the plane in hand (two halo columns on either side).  The term list (which pair, which column, the two rows' values)
+// rides as kernel arguments; a block outside the grid is a pair of zeros in the halo, whose terms (+-0.0) cannot change a sum that started at +0.0.
+// ORD: the order of the seven blocks in a block row -- 0 ascending columns (-SO, -S, left, own, right, +S, +SO); 1 and 2 the orders lis_matrix_convert_csr2bsr meets
+// them in (row after row of the block row, lis_matrix_bsr.c:351-552) when the CSR rows are sorted (-SO, -S, left, own, +S, +SO, right) or in the order of the
+// reference's generators (test/test3.c:114-127: -SO, +SO, -S, +S, left, own, right).  Compile-time, so that the 14 terms of a row are straight-line
+// code on registers (a run-time term list cost 350 branches and spilled the scalar registers: 0.108 ms at 256^3 against the staged kernel's 0.08).
+struct Block2March { int S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, wgs, xcd, planes, ord; double v0[14], v1[14]; };
+template <int ORD, int DOT, bool WS>
+__global__ __launch_bounds__(256)
+void spmv_csr_block2_march_kernel(const double *__restrict__ x, double *__restrict__ y, const Block2March M, int nx,
+                                  const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
+                                  const double *__restrict__ guard = nullptr, int pstride = 0)
+{
+    constexpr int BLOCK = 256, LPW = 2, TX = 128, TY = 4 * LPW, LX = TX + 4;      // an LDS line: [2 left halo][TX columns][2 right halo]: a lane's pair at 2 + 2 lane, 16 B aligned
+    if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;      // device-driven Krylov loop already converged
+    __shared__ __attribute__((aligned(16))) double buf[2][(TY + 2) * LX];
+    __shared__ double dot_part[(DOT >= 2 ? 2 : 1) * (DOT != 0 ? BLOCK : 1)];
+    __shared__ unsigned dot_count;
+    const int tid = (int)threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & (WAVE - 1);
+    if (DOT != 0 && tid == 0) dot_count = 0u;
+    int wg = (int)blockIdx.x;
+    const int ntile = M.tiles_x * M.tiles_y;
+    if (M.xcd) { const int k = wg % NUM_XCD, j = wg / NUM_XCD; wg = k * (M.wgs / NUM_XCD) + j; }
+    const int seg = wg / ntile, t = wg - seg * ntile;
+    const int ty = t / M.tiles_x, tx = t - ty * M.tiles_x;
+    const int za = M.z0 + seg * M.zseg, zb = min(M.z1, za + M.zseg);
+    const int col0 = tx * TX, line0 = ty * TY;
+    const long long S = M.S, SO = M.SO;
+    const long long base = (long long)(line0 + w * LPW) * S + col0 + 2 * lane;
+    auto at = [&](long long a) { return (int)(a < 0 ? 0 : (a > (long long)nx - 2 ? (long long)nx - 2 : a)); };      // (clamped addresses only ever feed zeroed cells)
+    const bool box_left = tx == 0, box_right = tx == M.tiles_x - 1, box_top = ty == 0, box_bottom = ty == M.tiles_y - 1;      // (uniform)
+    v2f64 zero2; zero2.x = 0.0; zero2.y = 0.0;
+    struct Packet { v2f64 own[LPW]; v2f64 hy; v2f64 hx[LPW]; v2f64 ww[WS ? LPW : 1]; };
+    auto load_packet = [&](Packet &P, int z, bool with_w) {
+        const long long zo = (long long)z * SO, pb = zo + base;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + at(pb + i * S));
+        if (w == 0 || w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at(zo + (long long)(w == 0 ? line0 - 1 : line0 + TY) * S + col0 + 2 * lane));
+        if (lane == 0 || lane == WAVE - 1) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) P.hx[i] = *reinterpret_cast<const v2f64u *>(x + at(zo + (long long)(line0 + w * LPW + i) * S + (lane == 0 ? col0 - 2 : col0 + TX)));
+        }
+        if (DOT != 0 && WS && with_w && z < M.z1) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) P.ww[i] = *reinterpret_cast<const v2f64u *>(wdot + pb + i * S);
+        }
+    };
+    auto store_packet = [&](const Packet &P, double *B) {
+#pragma unroll
+        for (int i = 0; i < LPW; i++) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = P.own[i];
+        if (w == 0) *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = box_top ? zero2 : P.hy;
+        if (w == 3) *reinterpret_cast<v2f64 *>(B + (TY + 1) * LX + 2 + 2 * lane) = box_bottom ? zero2 : P.hy;
+        if (lane == 0 || lane == WAVE - 1) {
+            const bool side = lane == 0 ? box_left : box_right;
+#pragma unroll
+            for (int i = 0; i < LPW; i++) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + (lane == 0 ? 0 : 2 + TX)) = side ? zero2 : P.hx[i];
+        }
+    };
+    Packet Q[2];
+    v2f64 prev[LPW], ww0[WS ? LPW : 1];
+    {
+        Packet P;
+        load_packet(P, za - 1, false);
+#pragma unroll
+        for (int i = 0; i < LPW; i++) prev[i] = za == 0 ? zero2 : P.own[i];      // (uniform) the grid's first plane has no plane before it
+        load_packet(P, za, true);
+        store_packet(P, buf[za & 1]);
+        if (WS) {
+#pragma unroll
+            for (int i = 0; i < LPW; i++) ww0[i] = P.ww[i];
+        }
+    }
+    load_packet(Q[0], za + 1, true);
+    load_packet(Q[1], za + 2, true);
+    __syncthreads();
+    double c0 = 0.0, c1 = 0.0;
+    for (int zq = za; zq < zb; zq += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const int z = zq + d;
+            if (z < zb) {                                             // (uniform)
+                Packet &P = Q[d];                                     // plane z + 1: the oldest in flight
+                store_packet(P, buf[(z + 1) & 1]);
+                const double *B = buf[z & 1];
+#pragma unroll
+                for (int i = 0; i < LPW; i++) {
+                    const int li = (w * LPW + i + 1) * LX + 2 + 2 * lane;
+                    v2f64 src[7];
+                    src[0] = prev[i];
+                    src[1] = *reinterpret_cast<const v2f64 *>(B + li - LX);
+                    src[2] = *reinterpret_cast<const v2f64 *>(B + li - 2);
+                    src[3] = *reinterpret_cast<const v2f64 *>(B + li);
+                    src[4] = *reinterpret_cast<const v2f64 *>(B + li + 2);
+                    src[5] = *reinterpret_cast<const v2f64 *>(B + li + LX);
+                    src[6] = z == M.planes - 1 ? zero2 : P.own[i];      // (uniform) the grid's last plane has no plane behind it
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 7; q++) {                     // block after block, column after column (lis_matvec_bsr.c:340-343)
+                        constexpr int kinds[3][7] = {{0, 1, 2, 3, 4, 5, 6}, {0, 1, 2, 3, 5, 6, 4}, {0, 6, 1, 5, 2, 3, 4}};
+                        const v2f64 pr = src[kinds[ORD][q]];
+                        s0 += M.v0[2 * q] * pr.x; s1 += M.v1[2 * q] * pr.x;
+                        s0 += M.v0[2 * q + 1] * pr.y; s1 += M.v1[2 * q + 1] * pr.y;
+                    }
+                    const long long row = (long long)z * SO + base + i * S;
+                    v2f64 out; out.x = s0; out.y = s1;
+                    store_stream(reinterpret_cast<v2f64 *>(y + row), out);
+                    if (DOT != 0) {
+                        const v2f64 wv = WS ? ww0[i] : src[3];
+                        c0 += wv.x * s0; c0 += wv.y * s1;
+                        if (DOT >= 2) { c1 += s0 * s0; c1 += s1 * s1; }
+                    }
+                    prev[i] = src[3];
+                    if (WS) ww0[i] = P.ww[i];
+                }
+                load_packet(Q[d], z + 3, true);
+                __syncthreads();
+            }
+        }
+    }
+    if (DOT != 0) workgroup_dots_last<BLOCK, DOT>(c0, c1, dot_part, &dot_count, partial, (int)blockIdx.x, pstride ? pstride : M.wgs, true);
+}
+
+// plan time: block row br = (z, y, xb) of a 2 x 2 blocked 7-point grid must keep exactly the terms of the dominant block row whose block lies inside the grid
+// (bdrec[key]: a mask over the dominant block row's entries, bit 32 = foreign); term j's block is `kind[j]` (0 -SO, 1 -S, 2 left, 3 own, 4 right, 5 +S, 6 +SO)
+__global__ void block2_box_check(int nbr, int S, int SO, int nterm, const unsigned char *__restrict__ rowpat, const unsigned long long *__restrict__ bdrec,
+                                 const Block2March M, int *__restrict__ bad)
+{
+    const int br = blockIdx.x * blockDim.x + threadIdx.x;
+    if (br >= nbr) return;
+    const int r = 2 * br, z = r / SO, q = r - z * SO, yy = q / S, xx = q - yy * S, lines = SO / S, planes = M.planes;
+    unsigned want = 0;
+    const int kinds[3][7] = {{0, 1, 2, 3, 4, 5, 6}, {0, 1, 2, 3, 5, 6, 4}, {0, 6, 1, 5, 2, 3, 4}};
+    for (int j = 0; j < nterm; j++) {
+        const int k = kinds[M.ord][j >> 1];
+        const bool in = k == 0 ? z > 0 : k == 1 ? yy > 0 : k == 2 ? xx > 0 : k == 3 ? true : k == 4 ? xx + 2 < S : k == 5 ? yy + 1 < lines : z + 1 < planes;
+        if (in) want |= 1u << j;
+    }
+    const unsigned long long bits = bdrec[rowpat[r]];
+    if ((bits >> 32) != 0ull || (unsigned)bits != want) atomicAdd(bad, 1);
 }
 
 // plan time: is the grid of a 27-point plan a BOX?  Row r = (z, y, x) must keep exactly the dominant pattern's slots whose neighbour (z + dz, y + dy, x + dx) lies
@@ -3115,6 +3260,7 @@ struct liship_csr_plan_s {
     v4i32 *wstage;       // device: 64 x 8 ints, the column offsets of a lane's slot pairs in the staging loads of spmv_csr_valuerecw_staged_kernel
     WideDom wd;          // the dominant wide pattern (len = 0: none)
     Box27 b27;           // the 27-point box stencil with constant coefficients (try_box27): the z-marching kernel's arguments (S = 0: none)
+    Block2March b2;      // 2 x 2 block rows of a 7-point box grid (try_block2_march): the marching kernel's arguments (S = 0: none)
     BlockDom bd;         // block rows (liship_csr_plan_encode_block_rows): the dominant block row, one lane per block row (len = 0: none)
     unsigned long long *bdrec; // device: per pattern byte of a block row's FIRST row: mask over the dominant block row's entries | foreign << 32
     int *bstage;         // device: NL x 64 ints, the column offsets (from the wavefront's first row) of a lane's slot pairs in the staging loads
@@ -3236,7 +3382,7 @@ extern "C" int liship_csr_plan_create(liship_csr_plan_t *out, int n, const int *
     p->codes = nullptr; p->dict = nullptr; p->ndict = 0;
     p->lcol = nullptr; p->dcol = nullptr; p->doff = nullptr; p->drun = nullptr; p->droff = nullptr; p->ndcol = 0; p->ndpl = 2;
     p->first_term = 0;
-    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->b27.S = 0; p->bd.len = 0; p->bdrec = nullptr; p->bstage = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
+    p->rowpat = nullptr; p->rowrel = nullptr; p->ptab = nullptr; p->ptab_len = 0; p->npat = 0; p->ptab8 = nullptr; p->prec36 = nullptr; p->prec_slot = nullptr; p->tr.nruns = 0; p->wdrec = nullptr; p->wstage = nullptr; p->wd.len = 0; p->b27.S = 0; p->b2.S = 0; p->bd.len = 0; p->bdrec = nullptr; p->bstage = nullptr; p->vrec = nullptr; p->vrecw = nullptr; p->order = nullptr;
     p->drec = nullptr; p->dom_lo = p->dom_hi = 0; p->dom_simple = 0; p->box_z0 = p->box_z1 = 0; p->dom_xlen = 0; p->box_modes = p->box_pads = 0;
     const int rc = build_split(p, ptr, st);
     if (rc) { delete p; return rc; }
@@ -3925,9 +4071,9 @@ static int scs_merge(const int *ao, const double *av, int al, const int *bo, con
 }
 
 // Is the plan the 27-point box stencil the marching kernel serves (spmv_csr_box27_march_kernel)?  The dominant pattern's offsets are dz SO + dy S + dx in ascending
-// order, lines a multiple of 128 long, a multiple of four lines per plane, whole planes; the values finite and non-zero, the 26 off-centre ones of one sign (the
-// zero that stands in for a neighbour outside the grid must turn every one of them into -0.0); and every row keeps exactly the slots whose neighbour lies inside
-// the grid, with the dominant values (wide_box_check, one pass over the pattern bytes).
+// order, lines a multiple of 128 long, a multiple of four lines per plane, whole planes; the values finite (the zero that stands in for a neighbour outside the grid
+// turns each of them into a +-0.0 term, and a sum that starts at +0.0 is never -0.0, so such terms cannot change its bits); and every row keeps exactly the slots
+// whose neighbour lies inside the grid, with the dominant values (wide_box_check, one pass over the pattern bytes).
 static void try_box27(liship_csr_plan_s *p, const int *od, const WideDom &D, hipStream_t st)
 {
     p->b27.S = 0;
@@ -3936,13 +4082,9 @@ static void try_box27(liship_csr_plan_s *p, const int *od, const WideDom &D, hip
     if (S < 128 || S % 128 != 0 || SO < 4 * S || SO % S != 0 || (SO / S) % 4 != 0 || p->n % SO != 0 || p->n / SO < 2) return;
     for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++)
         if (od[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] != dz * SO + dy * S + dx) return;
-    int sign = 0;
     for (int u = 0; u < 27; u++) {
         const double v = D.val[u];
-        if (!(v == v) || v - v != 0.0 || v == 0.0) return;            // NaN, infinite, zero
-        if (u == 13) continue;
-        const int sg = v < 0.0 ? -1 : 1;
-        if (sign == 0) sign = sg; else if (sg != sign) return;
+        if (!(v == v) || v - v != 0.0) return;                        // NaN, infinite: their product with the halo's zero would not be a zero
     }
     int *d_bad = nullptr, bad = 1;
     if (hipMalloc(&d_bad, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -3954,7 +4096,7 @@ static void try_box27(liship_csr_plan_s *p, const int *od, const WideDom &D, hip
     Box27 B;
     memset(&B, 0, sizeof(B));
     B.S = S; B.SO = SO; B.planes = p->n / SO;
-    B.poison = sign < 0 ? 0.0 : -0.0;                                 // (value) * (poison) = -0.0 for every off-centre value
+    B.poison = 0.0;                                                   // (finite value) * 0.0 = +-0.0: a term that cannot change a sum that started at +0.0 (box27_shape asks for that)
     for (int u = 0; u < 27; u++) B.val[u] = D.val[u];
     p->b27 = B;
 }
@@ -4253,6 +4395,44 @@ __global__ void blockrow_keys(int nbr, int b, const unsigned char *__restrict__ 
 
 // Block rows on top of the wide value records (see spmv_csr_blockrows_staged_kernel): setup-time, optional, never an error when the matrix does not qualify.
 // b: the rows b i .. b i + b - 1 list the same columns in the same order for every i (the row form of a b x b BSR matrix, liship_bsr_to_rows).
+// Is the block-row plan the 7-point stencil in 2 x 2 blocks on a box grid (spmv_csr_block2_march_kernel)?  The dominant block row's entries are seven blocks of two
+// columns at block offsets {-SO, -S, -2, 0, +2, +S, +SO} (rows), both columns of a block adjacent in the list, lines a multiple of 128 long, a multiple of eight lines
+// per plane, finite values; and every block row keeps exactly the blocks that lie inside the grid (block2_box_check).
+static void try_block2_march(liship_csr_plan_s *p, const int *doff, const BlockDom &D, hipStream_t st)
+{
+    p->b2.S = 0;
+    if (D.b != 2 || D.len != 14 || !p->bdrec || !p->rowpat) return;
+    int pos[7], npos = 0;
+    for (int j = 0; j < 14; j++) { const int o = doff[j] & ~1; if (o > 0) { bool seen = false; for (int k = 0; k < npos; k++) seen = seen || pos[k] == o; if (!seen && npos < 7) pos[npos++] = o; } }
+    if (npos != 3) return;
+    for (int a = 1; a < 3; a++) { const int v = pos[a]; int c = a - 1; while (c >= 0 && pos[c] > v) { pos[c + 1] = pos[c]; c--; } pos[c + 1] = v; }
+    const int S = pos[1], SO = pos[2];
+    if (pos[0] != 2 || S < 128 || S % 128 != 0 || SO < 8 * S || SO % S != 0 || (SO / S) % 8 != 0 || p->n % SO != 0 || p->n / SO < 2) return;
+    Block2March M;
+    memset(&M, 0, sizeof(M));
+    M.S = S; M.SO = SO; M.planes = p->n / SO;
+    int kseq[7];
+    for (int j = 0; j < 14; j++) {
+        const int o = doff[j], blk = o & ~1, c = o & 1;          // (two's complement: o & ~1 is the block's first column for negative offsets too)
+        const int k = blk == -SO ? 0 : blk == -S ? 1 : blk == -2 ? 2 : blk == 0 ? 3 : blk == 2 ? 4 : blk == S ? 5 : blk == SO ? 6 : -1;
+        if (k < 0 || c != (j & 1)) return;                       // a block's two columns are neighbours in the list, first column first
+        if ((j & 1) == 0) kseq[j >> 1] = k; else if (kseq[j >> 1] != k) return;
+        M.v0[j] = D.val[0][j]; M.v1[j] = D.val[1][j];
+        if (!(M.v0[j] == M.v0[j]) || M.v0[j] - M.v0[j] != 0.0 || !(M.v1[j] == M.v1[j]) || M.v1[j] - M.v1[j] != 0.0) return;      // NaN / infinite
+    }
+    const int ord0[7] = {0, 1, 2, 3, 4, 5, 6}, ord1[7] = {0, 1, 2, 3, 5, 6, 4}, ord2[7] = {0, 6, 1, 5, 2, 3, 4};
+    if (memcmp(kseq, ord0, sizeof(kseq)) == 0) M.ord = 0; else if (memcmp(kseq, ord1, sizeof(kseq)) == 0) M.ord = 1;
+    else if (memcmp(kseq, ord2, sizeof(kseq)) == 0) M.ord = 2; else return;      // (other orders: the staged kernel)
+    int *d_bad = nullptr, bad = 1;
+    if (hipMalloc(&d_bad, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return; }
+    bool ok = hipMemsetAsync(d_bad, 0, sizeof(int), st) == hipSuccess;
+    const int nbr = p->n / 2;
+    if (ok) { block2_box_check<<<(nbr + 255) / 256, 256, 0, st>>>(nbr, S, SO, 14, p->rowpat, p->bdrec, M, d_bad); ok = hipGetLastError() == hipSuccess; }
+    ok = ok && hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    (void)hipFree(d_bad);
+    if (ok && bad == 0) p->b2 = M;
+}
+
 extern "C" int liship_csr_plan_encode_block_rows(liship_csr_plan_t p, int b, const int *ptr, void *stream)
 {
     if (!p || b < 2 || b > 4 || (p->n > 0 && !ptr)) return LISHIP_ERR_ARG;
@@ -4356,7 +4536,7 @@ extern "C" int liship_csr_plan_encode_block_rows(liship_csr_plan_t p, int b, con
             }
             if (hipMalloc(&p->bdrec, sizeof(unsigned long long) * 256) == hipSuccess && hipMalloc(&p->bstage, sizeof(int) * (size_t)nlk * WAVE) == hipSuccess &&
                 hipMemcpy(p->bdrec, rec, sizeof(unsigned long long) * 256, hipMemcpyHostToDevice) == hipSuccess &&
-                hipMemcpy(p->bstage, stage, sizeof(int) * (size_t)nlk * WAVE, hipMemcpyHostToDevice) == hipSuccess) p->bd = D;
+                hipMemcpy(p->bstage, stage, sizeof(int) * (size_t)nlk * WAVE, hipMemcpyHostToDevice) == hipSuccess) { p->bd = D; if (b == 2) try_block2_march(p, doff, D, st); }
             else {
                 if (p->bdrec) { (void)hipFree(p->bdrec); p->bdrec = nullptr; }
                 if (p->bstage) { (void)hipFree(p->bstage); p->bstage = nullptr; }
@@ -4636,7 +4816,7 @@ static bool block_rows_serve(const liship_csr_plan_s *P, int rb, int re)      //
 static bool box27_shape(const LaunchArgs &a, Box27 &M, int &lpw)
 {
     const liship_csr_plan_s *P = a.plan;
-    if (!P || P->b27.S <= 0 || !g_dom_march || g_variant != 0 || !aligned16(a.y) || !g_row_values) return false;
+    if (!P || P->b27.S <= 0 || !g_dom_march || g_variant != 0 || !aligned16(a.y) || !g_row_values || a.acc0 != 0.0 || __builtin_signbit(a.acc0)) return false;
     M = P->b27;
     const int S = M.S, SO = M.SO;
     if (a.rb < 0 || a.re > P->n || a.rb % SO != 0 || a.re % SO != 0) return false;
@@ -4657,6 +4837,28 @@ static bool box27_shape(const LaunchArgs &a, Box27 &M, int &lpw)
     return true;
 }
 
+// the same for the 2 x 2 block rows of a 7-point box grid (try_block2_march): tiles of 128 columns x 8 lines, whole planes; sums start at +0.0 only
+static bool block2_shape(const LaunchArgs &a, Block2March &M)
+{
+    const liship_csr_plan_s *P = a.plan;
+    if (!P || P->b2.S <= 0 || !g_dom_march || g_variant != 0 || !aligned16(a.y) || !g_row_values || a.acc0 != 0.0 || __builtin_signbit(a.acc0)) return false;
+    M = P->b2;
+    const int S = M.S, SO = M.SO;
+    if (a.rb < 0 || a.re > P->n || a.rb % SO != 0 || a.re % SO != 0) return false;
+    const int z0 = a.rb / SO, z1 = a.re / SO, planes = z1 - z0;
+    if (planes < 1 || (planes < 8 && g_dom_march == 1)) return false;
+    const int tiles_x = S / 128, tiles_y = (SO / S) / 8, tiles = tiles_x * tiles_y;
+    int nseg = (3 * 256 + tiles - 1) / tiles;
+    if (nseg > planes / 8) nseg = planes / 8;
+    if (nseg < 1) nseg = 1;
+    const int zseg = (planes + nseg - 1) / nseg;
+    nseg = (planes + zseg - 1) / zseg;
+    M.tiles_x = tiles_x; M.tiles_y = tiles_y; M.zseg = zseg; M.nseg = nseg; M.z0 = z0; M.z1 = z1; M.wgs = tiles * nseg;
+    if (M.wgs < 64 && g_dom_march == 1) return false;
+    M.xcd = (M.wgs % NUM_XCD == 0 && M.wgs >= 8 * NUM_XCD) ? 1 : 0;
+    return true;
+}
+
 // rows of up to 32 entries whose values ride in wide records: x staged per wavefront, the dominant pattern in scalar registers (variant 0x4000: the
 // gathering kernel on plan row blocks, A/B)
 static bool launch_wide(const LaunchArgs &a, const double *guard, int dot = 0, const double *w = nullptr, double *partial = nullptr, int pstride = 0, int *wgs_out = nullptr)
@@ -4664,6 +4866,19 @@ static bool launch_wide(const LaunchArgs &a, const double *guard, int dot = 0, c
     const liship_csr_plan_s *P = a.plan;
     if (block_rows_serve(P, a.rb, a.re) && !(g_variant & 0x4000)) {      // one lane per block row (the row form of a b x b blocked stencil)
         const int b = P->bd.b, rows = a.re - a.rb, wgs = (rows + 256 * b - 1) / (256 * b);
+        {   // 2 x 2 blocks of a 7-point box grid: whole planes march (spmv_csr_block2_march_kernel)
+            Block2March M;
+            if (rows > 0 && block2_shape(a, M)) {
+                if (wgs_out) *wgs_out = M.wgs;
+                const bool ws = dot != 0 && w != a.x;
+#define GOB2(OD, DT, WS_) spmv_csr_block2_march_kernel<OD, DT, WS_><<<M.wgs, 256, 0, a.st>>>(a.x, a.y, M, P->bd.maxcol + 1, w, partial, guard, pstride)
+#define GOB2D(OD) do { if (dot == 0) GOB2(OD, 0, false); else if (dot == 1) { if (ws) GOB2(OD, 1, true); else GOB2(OD, 1, false); } else { if (ws) GOB2(OD, 2, true); else GOB2(OD, 2, false); } } while (0)
+                if (M.ord == 0) GOB2D(0); else if (M.ord == 1) GOB2D(1); else GOB2D(2);
+#undef GOB2D
+#undef GOB2
+                return true;
+            }
+        }
         if (wgs_out) *wgs_out = rows > 0 ? wgs : 0;
         if (rows <= 0) return true;
         const int xcap = (P->bd.slots + 1) & ~1, nl = (P->bd.slots + 2 * WAVE - 1) / (2 * WAVE);
@@ -5126,11 +5341,19 @@ extern "C" long long liship_csr_plan_fused_slots(liship_csr_plan_t p)
     return (long long)p->nblocks + 2;
 }
 
+extern "C" int liship_csr_plan_block2_march(liship_csr_plan_t p)
+{
+    if (!p || p->b2.S <= 0 || !block_rows_serve(p, 0, p->n)) return 0;
+    LaunchArgs a{};
+    a.plan = p; a.rb = 0; a.re = p->n; a.y = reinterpret_cast<double *>(16); a.acc0 = p->first_term ? -0.0 : 0.0;
+    Block2March M;
+    return block2_shape(a, M) ? 1 : 0;
+}
 extern "C" int liship_csr_plan_box27(liship_csr_plan_t p)
 {
     if (!p || p->b27.S <= 0 || !p->vrecw || !g_team || !g_row_patterns || !g_index_codes) return 0;
     LaunchArgs a{};
-    a.plan = p; a.rb = 0; a.re = p->n; a.y = reinterpret_cast<double *>(16);
+    a.plan = p; a.rb = 0; a.re = p->n; a.y = reinterpret_cast<double *>(16); a.acc0 = p->first_term ? -0.0 : 0.0;
     Box27 M;
     int lpw = 0;
     return box27_shape(a, M, lpw) ? 1 : 0;

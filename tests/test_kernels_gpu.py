@@ -1839,9 +1839,10 @@ def test_box27_marching_kernel_bit_exact(lib, dims, march, values):
     nz, ny, nx = dims
     if values == "hpcg":
         ptr, idx, val = stencil_box(dims)
-    else:
-        v27 = -np.random.default_rng(3).uniform(0.5, 1.5, 27)
+    else:                                                   # 27 different values of BOTH signs (and one explicit zero): a stiffness matrix on a regular mesh
+        v27 = np.random.default_rng(3).uniform(-1.5, 1.5, 27)
         v27[13] = 26.5
+        v27[7] = 0.0
         ptr, idx, val = _box27_per_slot(dims, v27)
     n = len(ptr) - 1
     x = np.modf(np.arange(n, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
@@ -1892,16 +1893,16 @@ def test_box27_marching_kernel_bit_exact(lib, dims, march, values):
         check(lib.liship_csr_plan_destroy(plan))
 
 
-def test_box27_marching_needs_a_box_and_one_sign(lib):
-    """what plan time refuses: a grid whose rows are not a box's (one boundary row given a neighbour it should lack), off-centre values of both signs (no single zero
-    turns them all into -0.0), lines that 128 does not divide -- those plans keep the staged kernel and still give the oracle's bits"""
+def test_box27_marching_needs_a_box_of_shared_values(lib):
+    """what plan time refuses: rows that do not carry the dominant pattern's values (one row with a value of its own: its pattern splits off), an infinite
+    coefficient (its product with the halo's zero would be NaN), lines that 128 does not divide -- those plans keep the staged kernel and still give the oracle's bits"""
     cases = {}
     ptr, idx, val = stencil_box((9, 8, 128))
     v2 = val.copy()
-    v2[ptr[500] + 2] = 3.0                                      # a positive off-centre value in ONE row: the pattern splits, the rows no longer share the dominant values
-    cases["two_signs_one_row"] = (ptr, idx, v2)
-    v27 = -np.ones(27); v27[13] = 26.0; v27[5] = 0.75
-    cases["two_signs_every_row"] = _box27_per_slot((9, 8, 128), v27)
+    v2[ptr[500] + 2] = 3.0                                      # ONE row with a value of its own: the pattern splits, the rows no longer share the dominant values
+    cases["one_row_differs"] = (ptr, idx, v2)
+    v27 = -np.ones(27); v27[13] = 26.0; v27[5] = np.inf
+    cases["infinite_coefficient"] = _box27_per_slot((9, 8, 128), v27)
     cases["lines_of_96"] = stencil_box((9, 8, 96))
     for name, (ptr, idx, val) in cases.items():
         n = len(ptr) - 1
@@ -2019,6 +2020,68 @@ def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(l
         lib.liship_spmv_csr_set_block_rows(1)
         lib.liship_spmv_csr_set_variant(0)
     assert taken[1] == 0 and (taken[0] == 1 or bs > 2), taken      # (3 x 3, 4 x 4: the rows' turns have no common supersequence of 32 entries; their block rows do not need one)
+
+
+@pytest.mark.parametrize("dims", [(9, 8, 128), (10, 16, 256), (8, 8, 256)])
+@pytest.mark.parametrize("order", ["first_seen_generator", "first_seen_sorted", "ascending"])
+def test_block2_marching_kernel_bit_exact(lib, dims, order):
+    """Round 5: the 7-point stencil kept as 2 x 2 blocks (Lis's default BSR block size, constant coefficients) on a box grid walks the planes like the scalar
+    stencil does (spmv_csr_block2_march_kernel): a lane's pair of rows is a block row, 14 terms per row -- explicit zeros included, block after block in the order
+    the conversion met them (lis_matvec_bsr.c:293-343) -- and a block outside the grid is a pair of zeros in the halo.  The bits of the plain loop over the listed
+    terms: whole, in ranges of whole planes, with the fused dots, x with Inf / NaN / signed zeros (an explicit zero times Inf must stay NaN), three block orders."""
+    nz, ny, nx = dims
+    ptr, idx, val = orc.poisson3d(nz, ny, nx, sort_cols=(order != "first_seen_generator"))
+    rptr, ridx, rval = _blocked_rows(ptr, idx, val, 2, first_seen=order != "ascending")
+    n = len(rptr) - 1
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, n)
+    x[::7] = 0.0
+    x[3::11] = -0.0
+    for pos, v in ((0, np.inf), (n - 1, -np.inf), (n // 2, np.nan), (n // 3, np.inf), (257, np.nan), (ny * nx + 5, -np.inf)):
+        x[pos] = v
+    w = rng.uniform(-1, 1, n)
+    ref = orc.spmv_csr(rptr, ridx, rval, x)
+    nanpos = np.isnan(ref)
+    dptr, didx, dval, dx, dw = DA.from_host(rptr, np.int32), DA.from_host(ridx, np.int32), DA.from_host(rval, np.float64), DA.from_host(x, np.float64), DA.from_host(w, np.float64)
+    work, res = DA(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64)
+    mn = ny * nx
+    try:
+        lib.liship_spmv_csr_set_wide_union(0)
+        lib.liship_spmv_csr_set_block_rows(2)
+        plan = C.c_void_p()
+        check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+        check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
+        check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
+        check(lib.liship_csr_plan_encode_row_values(plan, dptr.ptr, dval.ptr, None))
+        check(lib.liship_csr_plan_encode_block_rows(plan, 2, dptr.ptr, None))
+        assert lib.liship_csr_plan_block_rows(plan) == 2
+        outs = {}
+        for march in (2, 0):
+            check(lib.liship_spmv_csr_set_dom_march(march))
+            assert lib.liship_csr_plan_block2_march(plan) == (1 if march else 0)
+            dy = DA.from_host(np.full(n, 7.0), np.float64)
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            y = dy.to_host()
+            assert np.array_equal(np.isnan(y), nanpos) and np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), march
+            dy = DA.from_host(np.full(n, 7.0), np.float64)
+            for lo, hi in ((mn, n - mn), (0, mn), (n - mn, n)):
+                check(lib.liship_spmv_csr_rows_f64(plan, lo, hi, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            y = dy.to_host()
+            assert np.array_equal(np.isnan(y), nanpos) and np.array_equal(y[~nanpos].view(np.uint64), ref[~nanpos].view(np.uint64)), (march, "planes")
+            xf = np.where(np.isfinite(x), x, 0.5)
+            dxf = DA.from_host(xf, np.float64)
+            yf = orc.spmv_csr(rptr, ridx, rval, xf)
+            for wname, wd, wh in (("x", dxf, xf), ("w", dw, w)):
+                dy = DA.from_host(np.full(n, 7.0), np.float64)
+                check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dxf.ptr, dy.ptr, wd.ptr, 1, res.ptr, work.ptr, None))
+                assert np.array_equal(dy.to_host().view(np.uint64), yf.view(np.uint64)), (march, wname)
+                got = res.to_host()
+                assert abs(got[0] - np.dot(wh, yf)) <= 1e-12 * np.abs(wh * yf).sum() and abs(got[1] - np.dot(yf, yf)) <= 1e-12 * np.dot(yf, yf), (march, wname, got)
+        check(lib.liship_csr_plan_destroy(plan))
+    finally:
+        check(lib.liship_spmv_csr_set_dom_march(1))
+        lib.liship_spmv_csr_set_wide_union(1)
+        lib.liship_spmv_csr_set_block_rows(1)
 
 
 @pytest.mark.parametrize("case", ["constant", "ell_padded", "values_differ", "foreign_rows", "two_tiles_wide", "generator_order", "other_order", "slab_of_rank_0", "slab_of_rank_1", "dia_zeros"])

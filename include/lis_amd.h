@@ -46,6 +46,11 @@ LIS_INT lis_amd_set_device_convert(LIS_INT on);
 LIS_INT lis_amd_vector_page_state(LIS_VECTOR v);
 LIS_INT lis_amd_vector_page_protect(LIS_VECTOR v, LIS_INT state);      /* force a protection (tests of the fault handler without a GPU) */
 LIS_INT lis_amd_page_faults(LIS_INT *reads, LIS_INT *writes);
+/* lazy coherence lives on the process's SIGSEGV disposition (one line on stderr says so when it is taken; LIS_AMD_QUIET=1 drops the line).  A handler the program
+ * installs LATER would take the protected pages' faults away: the library checks at every lis_solve (and now and then in between), and when the disposition is no
+ * longer its own it brings home what only HBM holds, opens every page for good and goes on in eager coherence, with a line on stderr.  This call runs the check
+ * now; 1: the library's handler is in place, 0: it is not (never installed, or replaced) */
+LIS_INT lis_amd_check_fault_handler(void);
 LIS_INT lis_amd_page_fault_waits(void);                /* faults that found another thread bringing the same array home and waited for its copy */
 /* tests of the handler without a GPU: the host buffer `src` (n + pad doubles) plays the HBM copy of v -- v's pages lose all access and the first
  * touch copies src home in two halves delay_ms apart (delay_ms < 0: the second half is held until -delay_ms other threads wait for the copy, 10 s at most),

@@ -145,6 +145,7 @@ void lisp_protect(LIS_VECTOR v, int prot);
 int  lisp_state(LIS_VECTOR v);
 LIS_INT lisp_vec_home(LIS_VECTOR v);                          /* value[] current on the host, the copy written through the alias mapping (lazy coherence) */
 int  lisp_lazy(void);
+void lisp_check_handler(void);                                    /* is the SIGSEGV disposition still the library's?  (else: eager coherence from here on, with a message) */
 void *lisp_alloc_lazy(void *matrix, size_t bytes_used, void *dev, int own_dev);   /* a matrix array held in HBM until its first host touch */
 int  lisp_free_array(void *p);                                /* 1: p lived on such pages (unmapped), 0: plain memory (caller frees) */
 LIS_INT lisp_fill_matrix(void *matrix);

@@ -242,8 +242,50 @@ static int install_handler(void)
 	}
 	handler_installed = 1;
 	(void)lisd_fault_stage_prepare();              /* the stream and pinned buffers fault-time copies use: made here, in ordinary context */
+	{	/* a process-wide signal disposition is not something a library takes silently: one line, once (LIS_AMD_QUIET=1 drops it) */
+		const char *q = getenv("LIS_AMD_QUIET");
+		if (!(q && q[0] == '1'))
+			fprintf(stderr, "liblis_amd: lazy coherence on: a SIGSEGV handler now serves accesses to the library's page-protected vectors and matrix arrays "
+			                "(other faults go to the previous handler; LIS_AMD_COHERENCE=eager or LIS_AMD_RESIDENCY=resident run without it)\n");
+	}
 	return 1;
 }
+
+/* A handler the PROGRAM installs later (sigaction(SIGSEGV, ...) of its own) would silently take the faults of protected pages away.  Checked where it is cheap --
+ * at the start of every lis_solve and every 1024th change of a protection --: when the disposition is no longer ours, every page is opened for good, the HBM
+ * copies are declared stale where the host may have been written, and the process goes on in eager coherence with a line on stderr. */
+static void check_handler_still_ours(void)
+{
+	struct sigaction cur;
+	if (!handler_installed || sigaction(SIGSEGV, NULL, &cur) != 0) return;
+	if ((cur.sa_flags & SA_SIGINFO) && cur.sa_sigaction == on_fault) return;
+	handler_installed = 0; handler_failed = 1;
+	lisg.eager_coherence = 1;
+	fprintf(stderr, "liblis_amd: the SIGSEGV handler of lazy coherence was replaced by the program: all protected pages are opened and the library copies on every "
+	                "call from here on (eager coherence)\n");
+	for (int guard = 0; guard < (1 << 20); guard++) {   /* what only HBM holds comes home first (through the alias; a program's read of it could no longer be served) */
+		LIS_VECTOR v = NULL; void *m = NULL;
+		pthread_mutex_lock(&region_lock);
+		for (lisp_region *r = regions; r && !v && !m; r = r->next)
+			if (!r->filling && r->prot == LISP_NONE) { if (r->owner) v = r->owner; else if (r->mowner && r->dev) m = r->mowner; }
+		pthread_mutex_unlock(&region_lock);
+		if (v) { if (lisp_vec_home(v) != LIS_SUCCESS) break; }
+		else if (m) { if (lisp_fill_matrix(m) != LIS_SUCCESS) break; }
+		else break;
+	}
+	pthread_mutex_lock(&region_lock);
+	for (lisp_region *r = regions; r; r = r->next) {
+		if (r->filling || r->prot == LISP_RW) continue;
+		if (mprotect(r->base, r->bytes, PROT_READ | PROT_WRITE) == 0) {
+			r->prot = LISP_RW;
+			if (r->owner) { VDEV(r->owner)->host_valid = 1; VDEV(r->owner)->dev_valid = 0; }      /* (nobody would tell us about a write any more) */
+			else if (r->mowner) MDEV((LIS_MATRIX)r->mowner)->host_written = 1;
+		}
+	}
+	pthread_mutex_unlock(&region_lock);
+}
+void lisp_check_handler(void) { check_handler_still_ours(); }
+LIS_INT lis_amd_check_fault_handler(void) { check_handler_still_ours(); return handler_installed ? 1 : 0; }
 
 /* `bytes` (whole pages) of fresh zero pages mapped twice: *base with a guard page on either side and protection `prot`, *alias read + write.
  * 0 on success.  The guard pages keep the kernel from merging the program's mapping into one VMA with a neighbour (measured in round 2: a
@@ -510,6 +552,8 @@ void lisp_protect(LIS_VECTOR v, int prot)
 	lisp_region *r = (lisp_region *)VDEV(v)->region;
 	if (!r) return;
 	if (prot != LISP_RW && (!lisp_lazy() || !install_handler())) return;
+	{ static unsigned calls; if ((++calls & 1023u) == 0) check_handler_still_ours(); }
+	if (prot != LISP_RW && !lisp_lazy()) return;         /* (the check may just have switched to eager coherence) */
 	pthread_mutex_lock(&region_lock);
 	while (r->filling) pthread_cond_wait(&fill_done, &region_lock);      /* a thread of the program is bringing it home: let the copy finish */
 	if (r->prot != prot && mprotect(r->base, r->bytes, native_prot(prot)) == 0) r->prot = prot;

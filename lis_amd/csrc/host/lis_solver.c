@@ -996,6 +996,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	ctx_t c;
 	memset(&c, 0, sizeof(c));
 
+	if (lisp_lazy()) lisp_check_handler();          /* a SIGSEGV handler the program installed since would take the protected pages' faults away */
 	/* parameter checks, ref :482-537 */
 	if (nsolver < 1 || nsolver > LIS_SOLVER_LEN) return LISI_ERR(LIS_ERR_ILL_ARG, "Parameter LIS_OPTIONS_SOLVER is %D (Set between 1 to %D)\n", nsolver, LIS_SOLVER_LEN);
 	switch (nsolver) {

@@ -465,6 +465,31 @@ def test_matrix_arrays_from_lis_matrix_malloc_are_watched_for_host_writes(lib):
         dll.lis_amd_set_coherence(1)
 
 
+def test_a_handler_the_program_installs_later_is_noticed():
+    """lazy coherence lives on the SIGSEGV disposition: when the program replaces it, the library's next check opens every protected page for good, declares the
+    HBM copies stale and goes on in eager coherence -- with a line on stderr -- instead of leaving pages whose faults nobody serves"""
+    import subprocess
+    import sys
+    code = ("import sys, signal, ctypes as C; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, lis_amd; from lis_amd import _capi as capi\n"
+            "lib = lis_amd.load(); assert lib.initialize([]) == 0; dll = lib.dll\n"
+            "v = capi.PV(); lib.lis_vector_create(0, C.byref(v)); lib.lis_vector_set_size(v, 5000, 0)\n"
+            "dll.lis_amd_vector_page_protect.argtypes = [capi.PV, C.c_int]; dll.lis_amd_vector_page_state.argtypes = [capi.PV]\n"
+            "val = np.ctypeslib.as_array(v.contents.value, shape=(5000,)); val[:] = 3.0\n"
+            "assert dll.lis_amd_vector_page_protect(v, 1) == 0 and dll.lis_amd_vector_page_state(v) == 1\n"
+            "assert dll.lis_amd_check_fault_handler() == 1\n"
+            "signal.signal(signal.SIGSEGV, lambda *a: None)        # the program's own handler\n"
+            "assert dll.lis_amd_check_fault_handler() == 0\n"
+            "assert dll.lis_amd_vector_page_state(v) == 0          # opened for good\n"
+            "val[7] = 9.0; assert val[7] == 9.0 and val[8] == 3.0  # plain memory: nobody needs to serve a fault\n"
+            "w = capi.PV(); lib.lis_vector_create(0, C.byref(w)); lib.lis_vector_set_size(w, 100, 0)\n"
+            "assert dll.lis_amd_vector_page_protect(w, 1) != 0 and dll.lis_amd_vector_page_state(w) == 0      # eager from here on: protection is never raised\n"
+            "print('ok', flush=True)\n") % (ROOT, os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-X", "faulthandler=0", "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "ok" in p.stdout, (p.returncode, p.stdout, p.stderr[-800:])
+    assert "lazy coherence on: a SIGSEGV handler" in p.stderr and "was replaced by the program" in p.stderr
+
+
 def test_foreign_segfaults_still_kill_the_process():
     """the handler only answers for vector pages: any other bad access goes to the previous disposition (here: the default, death by SIGSEGV)"""
     import subprocess

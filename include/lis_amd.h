@@ -131,6 +131,8 @@ LIS_INT lis_amd_matrix_wide_dominant(LIS_MATRIX A);
 LIS_INT lis_amd_matrix_block_rows(LIS_MATRIX A);
 /* the form of the whole local product of a 7-point matrix with value records: 0 = the gathering dominant-pattern kernel, 1 = the z-marching kernel (each x loaded once per
  * plane tile; liship.h), 2 = its box form, which reads no pattern byte either (x and y alone are streamed: 16 B per row); uploads A if needed */
+/* round 5: 3 = the 27-point box stencil with constant coefficients marches (spmv_csr_box27_march_kernel), 4 = the 7-point stencil in 2 x 2 blocks does
+ * (a constant-coefficient BSR matrix in its row form: spmv_csr_block2_march_kernel) */
 LIS_INT lis_amd_matrix_marching(LIS_MATRIX A);
 /* rows per plane of the structured grid the plan found (the largest pattern offset, or the band of a matrix without row patterns): the XCD strips of the kernels that
  * stream the matrix are cut from it (liship.h); 0 = none, natural block order; uploads A if needed */

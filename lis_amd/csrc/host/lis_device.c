@@ -1172,7 +1172,10 @@ LIS_INT lis_amd_matrix_wide_dominant(LIS_MATRIX A)
 LIS_INT lis_amd_matrix_marching(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
-	return (MDEV(A)->type == LIS_MATRIX_CSR && MDEV(A)->plan) ? liship_csr_plan_marching(MDEV(A)->plan) : 0;
+	if (!(MDEV(A)->type == LIS_MATRIX_CSR && MDEV(A)->plan)) return 0;
+	if (liship_csr_plan_block2_march(MDEV(A)->plan)) return 4;
+	if (liship_csr_plan_box27(MDEV(A)->plan)) return 3;
+	return liship_csr_plan_marching(MDEV(A)->plan);
 }
 LIS_INT lis_amd_matrix_strip_rows(LIS_MATRIX A)
 {

@@ -34,8 +34,8 @@
  * it runs only for a synchronous fault of ordinary user code on a protected buffer, never for an asynchronous signal.  What follows from that is a rule for callers:
  * a protected buffer must not be handed to code that touches it WHILE HOLDING a lock the handler's callees need (a malloc arena, the HIP runtime's own locks): in
  * practice, do not pass v->value to another library's internals without lis_amd_vector_sync_host(v) first.  To keep the handler's own footprint small it copies
- * through a stream, pinned buffers and events of its own (lisd_staged_d2h_fault: nothing is enqueued on the library's stream from the faulting thread, a hipGraph
- * capture in progress there is waited out, not invalidated) and with plain memcpy -- no OpenMP region is opened from inside it.
+ * through a stream, pinned buffers and events of its own (lisd_staged_d2h_fault: the one thing the faulting thread puts on the library's stream is an event record that
+ * orders the copy behind the work already queued there -- never a copy --, and a hipGraph capture in progress there is waited out, not invalidated) and with plain memcpy -- no OpenMP region is opened from inside it.
  *
  * What page protection cannot do: a SYSTEM CALL that is handed a protected buffer (write(2) / fwrite of a large v->value, MPI_Send,
  * another device's DMA) does not fault, it fails with EFAULT (a short count from fwrite).  Programs that pass v->value to the kernel

@@ -424,6 +424,60 @@ def test_bsr_row_form_for_constant_coefficients(lib, bs, where):
         lib.dll.lis_amd_set_residency(0)
 
 
+@pytest.mark.parametrize("kind", ["bsr2x2_of_the_7_point_stencil", "the_27_point_stencil"])
+def test_marching_kernels_behind_the_lis_api(lib, kind):
+    """round 5's two marching kernels reached the way a Lis program reaches them: lis_matrix_convert(CSR -> BSR 2 x 2) of the 7-point matrix in the generators' row
+    order (test/test3.c:114-127) and lis_matvec, resp. the 27-point matrix of spmvtest3b through lis_matrix_set_csr -- the plan finds the box, lis_amd_matrix_marching says
+    which kernel runs, the product carries the reference's bits (lis_matvec_bsr.c:293-343 resp. lis_matvec_csr.c:97-109) and CG + Jacobi the reference's count"""
+    fm = lib.dll.lis_amd_matrix_marching
+    fm.argtypes = [capi.PM]
+    lib.dll.lis_amd_set_residency(1)
+    check_ = lis_amd.check
+    try:
+        check_(lib.liship_spmv_csr_set_dom_march(2))            # (2: at any size -- these grids are small)
+        if kind.startswith("bsr"):
+            ptr, idx, val = orc.poisson3d(64, 16, 128)          # 2^17 rows: the size block rows start at
+            n = len(ptr) - 1
+            A = lisdrv.make_csr(lib, ptr, idx, val)
+            B = lisdrv.convert(lib, A, "bsr", 2, 2)
+            assert fm(B) == 4
+            arrs = lisdrv.matrix_arrays(B)
+            ref = lambda xx: orc.spmv_bsr(n, arrs["nr"], 2, 2, arrs["bptr"], arrs["bindex"], arrs["value"], xx)
+        else:
+            import itertools
+            dims = (16, 16, 128)
+            n = int(np.prod(dims))
+            z, y, x_ = (g.ravel() for g in np.meshgrid(*[np.arange(d) for d in dims], indexing="ij"))
+            rows, cols = [], []
+            for dz, dy, dx in itertools.product((-1, 0, 1), repeat=3):
+                m = (z + dz >= 0) & (z + dz < dims[0]) & (y + dy >= 0) & (y + dy < dims[1]) & (x_ + dx >= 0) & (x_ + dx < dims[2])
+                r = np.nonzero(m)[0]
+                rows.append(r); cols.append(r + (dz * dims[1] + dy) * dims[2] + dx)
+            rows, cols = np.concatenate(rows), np.concatenate(cols)
+            order = np.lexsort((cols, rows))
+            ptr = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(rows, minlength=n), out=ptr[1:])
+            ptr, idx = ptr.astype(np.int32), cols[order].astype(np.int32)
+            val = np.where(idx == np.repeat(np.arange(n), np.diff(ptr)), 26.0, -1.0)
+            B = lisdrv.make_csr(lib, ptr, idx, val)
+            assert fm(B) == 3
+            ref = lambda xx: orc.spmv_csr(ptr, idx, val, xx)
+        rng = np.random.default_rng(8)
+        x = rng.uniform(-1, 1, n)
+        x[[3, n // 2, n - 2]] = [np.inf, np.nan, -0.0]
+        got, want = lisdrv.matvec(lib, B, x), ref(x)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)].view(np.uint64), want[~np.isnan(want)].view(np.uint64))
+        b = ref(np.ones(n))
+        out = lisdrv.solve(lib, B, b, "-i cg -p jacobi -tol 1e-12 -maxiter 1000")
+        check_(lib.liship_spmv_csr_set_dom_march(0))
+        assert fm(B) == 0
+        off = lisdrv.solve(lib, B, b, "-i cg -p jacobi -tol 1e-12 -maxiter 1000")
+        assert out["status"] == off["status"] == 0 and out["resid"] <= 1e-12 and abs(out["iter"] - off["iter"]) <= 1 and np.abs(out["x"] - 1.0).max() <= 1e-8
+        lib.lis_matrix_destroy(B)
+    finally:
+        check_(lib.liship_spmv_csr_set_dom_march(1))
+        lib.dll.lis_amd_set_residency(0)
+
+
 @pytest.mark.parametrize("bs,G", [(2, 82), (3, 60), (4, 60)])
 def test_bsr_row_form_gives_a_lane_a_block_row(lib, bs, G):
     """from 2^17 rows on, the row form of a b x b blocked stencil gives a LANE a block row (spmv_csr_blockrows_staged_kernel: each x read once from the staged window

@@ -1399,7 +1399,7 @@ def test_team_kernels_at_scale(lib):
     lib.liship_spmv_bsr_set_team(1)
 
 
-def test_full_size_512_six_forms_bit_equal(lib):
+def test_full_size_512_nine_forms_bit_equal(lib):
     """BASELINE's full size with a NON-TRIVIAL x through every form of the CSR product the plan can choose -- 4 B indices,
     one-byte column codes, row patterns (general kernel and the 32 B-record kernel), value records one and two rows per lane and with
     the dominant pattern's gathers speculated (two and four rows per lane):
@@ -1448,9 +1448,22 @@ def test_full_size_512_six_forms_bit_equal(lib):
             check(lib.liship_axpy_f64(n, -1.0, y0.ptr, y.ptr, None))
             check(lib.liship_nrm1_f64(n, y.ptr, res.ptr, work.ptr, None))
             assert res.to_host()[0] == 0.0, ("fused", on)
+        # the ninth form (round 5): the contract kernel again with the XCD strips OFF -- a permutation of its row blocks, not of any bit (y, and the fused dots,
+        # whose partials stay with their blocks)
+        select(0)
+        check(lib.liship_spmv_csr_set_xcd_strips(0))
+        check(lib.liship_memset(y.ptr, 0xff, 8 * n, None))
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None))
+        check(lib.liship_axpy_f64(n, -1.0, y0.ptr, y.ptr, None))
+        check(lib.liship_nrm1_f64(n, y.ptr, res.ptr, work.ptr, None))
+        assert res.to_host()[0] == 0.0, "strips off"
+        check(lib.liship_memset(y.ptr, 0xff, 8 * n, None))
+        check(lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, x.ptr, 1, res.ptr, work.ptr, None))
+        assert np.array_equal(res.to_host(), dots[0]), ("strips off", res.to_host(), dots[0])
     finally:
         select(4)
         lib.liship_spmv_csr_set_variant(0)
+        check(lib.liship_spmv_csr_set_xcd_strips(1))
     # the product is not trivially zero, and x^T A x > 0 (A is positive definite)
     check(lib.liship_nrm1_f64(n, y0.ptr, res.ptr, work.ptr, None))
     assert res.to_host()[0] > 1e6 and dots[0][0] > 0.0

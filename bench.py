@@ -15,7 +15,9 @@ Reported: value = global SpMV GFLOP/s = 2*nnz*K / t (reference convention, test/
 the timed kernel is asked to move (its stored matrix streams + y + the compulsory x) over its HIP-event time on the library's
 stream, as a fraction of 8 TB/s (always <= 1; asserted), with the PMC traffic of the same command from profiles/ as the upper
 bound and the contract's 12 B/nnz + 20 B/row count beside it as `contract_frac`; the same product on a non-trivial x; the same
-product with the value records off (`values_streamed`: the kernel any matrix on these sparsity patterns takes); Krylov iterations/s on the
+product with the value records off (`values_streamed`: the kernel any matrix on these sparsity patterns takes) and in the CONTRACT FORM (`contract_form`: index
+codes, row patterns and value records off -- spmv_csr_rowgather_kernel streams the reference's own index[] / value[] arrays, 12 B per non-zero + 20 B per row, SURVEY 8d's
+count, which its `frac` is priced on; CG + Jacobi in the same mode); Krylov iterations/s on the
 same matrix as the reference defines them -- iter / itime of lis_solver_get_timeex (src/solver/lis_solver.c:
 902-908) over --solver-iters iterations -- each with its own roofline, and the reference's own
 OpenMP CPU path timed on this box's host cores.

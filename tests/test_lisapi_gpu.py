@@ -670,3 +670,30 @@ def test_environment_switches_reach_the_kernels(env, want):
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
     assert p.returncode == 0, p.stderr[-2000:]
     assert ("SWITCHES %d" % want) in p.stdout, p.stdout[-500:]
+
+
+def test_contract_form_behind_the_environment_switch():
+    """LIS_AMD_NO_INDEX_CODES=1: a Lis program's CSR matrix keeps the reference's own arrays in the product (4 B indices + 8 B values: spmv_csr_rowgather_kernel, the form
+    SURVEY 8d prices) -- no codes, no patterns, no value records; the plan still learns the grid's plane, from the band of the matrix, for the XCD strips; y is the oracle's
+    bits and CG + Jacobi needs the reference's count"""
+    import subprocess
+    code = ("import sys, ctypes as C; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, lis_amd, lisdrv, orc; from lis_amd import _capi as capi\n"
+            "lib = lis_amd.load(); assert lib.initialize([]) == 0; dll = lib.dll\n"
+            "ptr, idx, val = orc.poisson3d(48, 64, 64)\n"
+            "n = len(ptr) - 1\n"
+            "A = lisdrv.make_csr(lib, ptr, idx, val)\n"
+            "for f in (dll.lis_amd_matrix_index_codes, dll.lis_amd_matrix_row_patterns, dll.lis_amd_matrix_value_records, dll.lis_amd_matrix_strip_rows): f.argtypes = [capi.PM]\n"
+            "assert dll.lis_amd_matrix_index_codes(A) == 0 and dll.lis_amd_matrix_row_patterns(A) == 0 and dll.lis_amd_matrix_value_records(A) == 0\n"
+            "assert dll.lis_amd_matrix_strip_rows(A) == 64 * 64\n"
+            "x = np.modf(np.arange(n) * 0.6180339887498949)[0] - 0.5\n"
+            "y = lisdrv.matvec(lib, A, x)\n"
+            "assert np.array_equal(y.view(np.uint64), orc.spmv_csr(ptr, idx, val, x).view(np.uint64))\n"
+            "b = orc.spmv_csr(ptr, idx, val, np.ones(n))\n"
+            "out = lisdrv.solve(lib, A, b, '-i cg -p jacobi -tol 1e-12 -maxiter 1000')\n"
+            "ref = orc.cg(ptr, idx, val, b, precon='jacobi', maxiter=1000)\n"
+            "assert out['status'] == 0 and out['iter'] == ref[1], (out['iter'], ref[1])\n"
+            "print('OK', out['iter'])\n") % (ROOT, os.path.join(ROOT, "tests"))
+    e = dict(os.environ, LIS_AMD_NO_INDEX_CODES="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=e)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])

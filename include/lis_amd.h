@@ -82,6 +82,7 @@ LIS_INT lis_amd_last_solve_uniform_jacobi(void);
  * GPU's ~4.5 us per dependent kernel, not by the host's launch rate (profiles/r02_graph_sweep.txt). */
 LIS_INT lis_amd_set_graphs(LIS_INT on);
 LIS_INT lis_amd_last_solve_graph_replays(void);        /* batches of the last lis_solve that ran as a graph replay */
+LIS_INT lis_amd_last_solve_renumbered(void);           /* 1: the last lis_solve ran in the numbering of a reordered plan (b, x0 gathered once, x scattered back; lis_amd_matrix_reordered) */
 
 /* vectors */
 LIS_INT lis_amd_vector_sync_host(LIS_VECTOR v);        /* make v->value[] current (D2H if needed)        */
@@ -146,6 +147,9 @@ LIS_INT lis_amd_matrix_device_type(LIS_MATRIX A);
 /* total length of the per-row-block lists of distinct columns when the HBM copy of A carries block-local columns (liship.h:
  * long rows that share their columns), 0 when it does not; uploads A if needed */
 LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A);
+/* total length of those lists in the REORDERED form, when the plan renumbered rows and columns because the caller's numbering has no locality (liship.h:
+ * liship_csr_plan_reorder; one rank, CSR with long rows; env LIS_AMD_NO_REORDER=1 keeps the caller's numbering); 0 when it did not; uploads A if needed */
+long long lis_amd_matrix_reordered(LIS_MATRIX A);
 /* adopt CSR arrays that already live in HBM (no host copy exists; A must be sized and unassembled).
  * ptr has n+1 entries, columns are local (0..np-1, ghosts >= n).  The arrays are freed with the matrix. */
 LIS_INT lis_amd_matrix_set_csr_device(LIS_INT nnz, LIS_INT np, LIS_INT *dptr, LIS_INT *dindex,

@@ -172,6 +172,23 @@ int  liship_spmv_csr_set_local_columns(int on);
  * liship_spmv_csr_set_local_runs(0): A/B switch (the full lists), same bits */
 int  liship_csr_plan_local_runs(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_local_runs(int on);
+/* Reordering (round 5): when the lists of a plan with block-local columns are long -- more than one listed column per `min_items_per_listed` non-zeros (0: the
+ * default, 4) -- or a long-row plan could not have lists at all (more than 2048 distinct columns per row block): the signs of a numbering without locality -- the plan renumbers rows and columns by a Cuthill-McKee walk of the matrix graph (on the host, at plan
+ * time: index[] is read back once), builds P A P^T in HBM (the same entries in the same in-row order) with a block-local plan of its own, and keeps it when that plan
+ * lists at most 3/4 of the columns.  liship_spmv_csr_f64 then gathers x into the new numbering, walks the renumbered rows and stores row r where the original row
+ * lives: every y[i] is the reference's sum (lis_matvec_csr.c:97-109), term by term -- the same bits.  Row-range products and the fused reductions keep the original
+ * numbering (liship_csr_plan_fused_dots returns 0: the caller runs the product and one reduction pass).  The values are copied: a matrix whose value[] changes needs a
+ * new plan, as with value records.  Never an error when the matrix does not qualify (fewer than 65 536 rows, short lists, columns outside [0, n)); 2 = out of memory,
+ * the plan unchanged.  liship_csr_plan_reordered: listed columns of the reordered form (0: none); liship_spmv_csr_set_reorder(0): A/B switch, same bits. */
+int  liship_csr_plan_reorder(liship_csr_plan_t plan, const int *ptr, const int *index, const double *value, int min_items_per_listed, void *stream);
+long long liship_csr_plan_reordered(liship_csr_plan_t plan);
+int  liship_spmv_csr_set_reorder(int on);
+/* the reordered form as a matrix of its own -- P A P^T: its plan (owned by `plan`), arrays and the permutation perm[new position] = original row -- for callers that keep
+ * whole iterations in the new numbering (lis_solve gathers b and x0 once and scatters x back at the end: no per-product passes); LISHIP_ERR_ARG when the plan has none
+ * (or it is switched off).  liship_permute_gather_f64: xp[i] = x[perm[i]]; liship_permute_scatter_f64: x[perm[i]] = xp[i] (x and xp distinct). */
+int  liship_csr_plan_reordered_form(liship_csr_plan_t plan, liship_csr_plan_t *inner, const int **ptr, const int **index, const double **value, const int **perm);
+int  liship_permute_gather_f64(int n, const int *perm, const double *x, double *xp, void *stream);
+int  liship_permute_scatter_f64(int n, const int *perm, const double *xp, double *x, void *stream);
 /* round 4: the block-local kernel keeps the 2 B positions in registers and stages 3584 items (lists <= 1024 columns) or 3072 items (longer lists) per
  * workgroup -- 39.5 KB of LDS, four workgroups per CU.  0: plans built from now on take the round-3 form (4096-item blocks, positions through LDS: three /
  * two workgroups per CU); A/B measurements, same bits either way */

@@ -105,6 +105,12 @@ _LISHIP = {
     "liship_csr_plan_block2_march": (_ci, [_vp]),
     "liship_csr_plan_local_runs": (_ci, [_vp]),
     "liship_spmv_csr_set_local_runs": (_ci, [_ci]),
+    "liship_csr_plan_reorder": (_ci, [_vp, _vp, _vp, _vp, _ci, _vp]),
+    "liship_csr_plan_reordered": (C.c_longlong, [_vp]),
+    "liship_spmv_csr_set_reorder": (_ci, [_ci]),
+    "liship_csr_plan_reordered_form": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_permute_gather_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
+    "liship_permute_scatter_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_spmv_csr_set_long_row_tree": (_ci, [_ci]),
     "liship_spmv_csr_set_uniform_rows": (_ci, [_ci]),
     "liship_spmv_csr_set_row_block_dots": (_ci, [_ci]),

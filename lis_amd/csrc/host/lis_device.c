@@ -137,6 +137,7 @@ LIS_INT lis_amd_set_reference_reductions(LIS_INT T)
 LIS_INT lis_amd_get_reference_reductions(void) { return lisg.ref_reductions; }
 LIS_INT lis_amd_set_graphs(LIS_INT on) { lisg.graphs = (on != 0); return LIS_SUCCESS; }
 LIS_INT lis_amd_last_solve_graph_replays(void) { return lisg.last_graph_replays; }
+LIS_INT lis_amd_last_solve_renumbered(void) { return lisg.last_renumbered; }
 LIS_INT lis_amd_set_loop_mode(LIS_INT mode)
 {
 	if (mode < LIS_AMD_LOOP_DEVICE || mode > LIS_AMD_LOOP_UNFUSED) return LISI_ERR(LIS_ERR_ILL_ARG, "unknown loop mode %D\n", mode);
@@ -440,6 +441,11 @@ LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int
 		rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
 		if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
 		if (rc && rc != 2) HIPCHK(rc);
+		/* lists that stay long say the numbering has no locality: rows and columns renumbered inside the plan (one rank: its row ranges follow the original order) */
+		if (!rc && !lisg.no_reorder && lisg.nprocs == 1 && dvalue) {
+			rc = liship_csr_plan_reorder(*plan, dptr, dindex, dvalue, 0, lisg.stream);
+			if (rc && rc != 2) HIPCHK(rc);
+		}
 	}
 	/* a plan that streams index[] / codes (no row patterns): the plane of a structured grid from the band of the matrix, for the XCD strips */
 	rc = liship_csr_plan_scan_band(*plan, dptr, dindex, lisg.stream);
@@ -1197,6 +1203,11 @@ LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A)
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
 	const long long listed = MDEV(A)->plan ? liship_csr_plan_localized(MDEV(A)->plan) : 0;
 	return listed > 0x7fffffffLL ? 0x7fffffff : (LIS_INT)listed;
+}
+long long lis_amd_matrix_reordered(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;
+	return MDEV(A)->plan ? liship_csr_plan_reordered(MDEV(A)->plan) : 0;
 }
 LIS_INT lis_amd_set_matrix_check(LIS_INT on) { lisg.matrix_check = on ? 1 : 0; return LIS_SUCCESS; }
 LIS_INT lis_amd_matrix_host_written(LIS_MATRIX A) { return MDEV(A)->host_written; }

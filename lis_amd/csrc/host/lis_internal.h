@@ -118,11 +118,13 @@ typedef struct {
 	int no_row_patterns;       /* LIS_AMD_NO_ROW_PATTERNS=1: coded CSR matrices keep one byte per non-zero instead of one per row (A/B measurements) */
 	int last_uniform_jacobi;   /* the last lis_solve ran CG + Jacobi with 1/diag as one double (lis_amd_last_solve_uniform_jacobi) */
 	int graphs;                /* LIS_AMD_GRAPHS=1: single-rank device-driven loops replay a hipGraph of one batch (opt-in: measured, no gain) */
+	int last_renumbered;       /* the last lis_solve ran in the numbering of a reordered plan (lis_amd_last_solve_renumbered) */
 	int last_graph_replays;    /* batches of the last lis_solve that were graph replays (lis_amd_last_solve_graph_replays) */
 	int no_uniform_jacobi;     /* LIS_AMD_NO_UNIFORM_JACOBI=1: CG + Jacobi reads 1/diag even when the diagonal is constant (A/B measurements) */
 	int row_block_dots;        /* LIS_AMD_ROW_BLOCK_DOTS=1: fused dots of the dominant-pattern product as the row blocks' partial sums */
 	int no_marching;           /* LIS_AMD_NO_MARCHING=1: 7-point matrices with value records keep the gathering dominant-pattern kernel (round 3's headline kernel: A/B measurements) */
 	int no_team_kernels;       /* LIS_AMD_NO_TEAM_KERNELS=1: patterned rows of 8..32 entries and long BSR block rows keep the round-2 kernels (A/B measurements) */
+	int no_reorder;            /* LIS_AMD_NO_REORDER=1: long-row CSR plans keep the caller's numbering whatever their lists look like (A/B measurements) */
 	int no_local_columns;      /* LIS_AMD_NO_LOCAL_COLUMNS=1: long-row CSR products keep the 4 B column indices (A/B measurements) */
 	int no_index_codes;        /* LIS_AMD_NO_INDEX_CODES=1: CSR products keep reading the 4 B column indices (A/B measurements) */
 	int host_scalars;          /* LIS_AMD_HOST_SCALARS=1: CG / BiCGSTAB read every scalar back (A/B against the device-driven loops) */

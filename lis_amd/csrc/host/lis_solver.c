@@ -995,6 +995,12 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	LIS_INT err = 0;
 	ctx_t c;
 	memset(&c, 0, sizeof(c));
+	int renumbered = 0;                        /* the solve runs in the numbering of a reordered plan (below) */
+	const int *renum = NULL;
+	double *renum_b = NULL, *renum_d = NULL;
+	liship_csr_plan_t held_plan = NULL;
+	int *held_ptr = NULL, *held_index = NULL;
+	double *held_value = NULL;
 
 	if (lisp_lazy()) lisp_check_handler();          /* a SIGSEGV handler the program installed since would take the protected pages' faults away */
 	/* parameter checks, ref :482-537 */
@@ -1087,6 +1093,24 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		}
 		c.len = len;
 	}
+	/* A plan that renumbered the matrix (liship.h: liship_csr_plan_reorder -- the caller's numbering has no locality): the WHOLE solve runs in the plan's numbering.
+	 * b, x0 and 1/diag are gathered once, the iterations see P A P^T as the matrix (its plan with its fused reductions, its arrays), x is scattered back at the end:
+	 * no product pays for a permutation.  The same recurrences on renumbered vectors; their sums fold in another order, so not in the reference-order mode, and not
+	 * for the solvers that multiply by A^T (its transposed copy keeps the caller's numbering). */
+	{
+		lisd_mat *dm = MDEV(Awork);
+		const int needs_t = nsolver == LIS_SOLVER_BICG || nsolver == LIS_SOLVER_BICR || nsolver == LIS_SOLVER_CRS || nsolver == LIS_SOLVER_BICRSTAB ||
+		                    nsolver == LIS_SOLVER_GPBICR || nsolver == LIS_SOLVER_BICRSAFE;
+		liship_csr_plan_t in = NULL;
+		const int *rp = NULL, *ri = NULL;
+		const double *rv = NULL;
+		if (lisg.nprocs == 1 && !scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && !needs_t && dm->type == LIS_MATRIX_CSR && !dm->split_jad &&
+		    dm->plan && Awork->np == Awork->n && liship_csr_plan_reordered_form(dm->plan, &in, &rp, &ri, &rv, &renum) == 0) {
+			held_plan = dm->plan; held_ptr = dm->ptr; held_index = dm->index; held_value = dm->value;
+			dm->plan = in; dm->ptr = (int *)rp; dm->index = (int *)ri; dm->value = (double *)rv;
+			renumbered = 1;
+		}
+	}
 	/* b: once over PCIe (or already resident); x: a private HBM iterate "xx" (ref :545-592), zero or copy of x */
 	{
 		double *db, *dx0;
@@ -1095,15 +1119,28 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		if ((err = lisd_pool_get(c.len * sizeof(double), (void **)&c.x))) goto out;
 		int rc = liship_memset(c.x, 0, c.len * sizeof(double), lisg.stream);
 		if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
+		if (renumbered) {
+			if ((err = lisd_pool_get(c.len * sizeof(double), (void **)&renum_b))) goto out;
+			if ((rc = liship_memset(renum_b, 0, c.len * sizeof(double), lisg.stream)) || (rc = liship_permute_gather_f64(A->n, renum, db, renum_b, lisg.stream))) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
+			c.b = renum_b;
+		}
 		if (!solver->options[LIS_OPTIONS_INITGUESS_ZEROS]) {
 			if ((err = lisd_vec_in(x, &dx0))) goto out;
-			if ((rc = liship_memcpy_d2d(c.x, dx0, sizeof(double) * (size_t)A->n, lisg.stream))) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
+			rc = renumbered ? liship_permute_gather_f64(A->n, renum, dx0, c.x, lisg.stream) : liship_memcpy_d2d(c.x, dx0, sizeof(double) * (size_t)A->n, lisg.stream);
+			if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
 		}
 	}
 	lisg.last_uniform_jacobi = 0;
 	lisg.last_graph_replays = 0;
+	lisg.last_renumbered = renumbered;
 	if (precon && precon->precon_type == LIS_PRECON_TYPE_JACOBI) {
 		if ((err = lisd_vec_in(precon->D, &c.dinv))) goto out;
+		if (renumbered) {
+			int rc;
+			if ((err = lisd_pool_get(c.len * sizeof(double), (void **)&renum_d))) goto out;
+			if ((rc = liship_memset(renum_d, 0, c.len * sizeof(double), lisg.stream)) || (rc = liship_permute_gather_f64(A->n, renum, c.dinv, renum_d, lisg.stream))) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
+			c.dinv = renum_d;
+		}
 		if (nsolver == LIS_SOLVER_CG && !lisg.no_uniform_jacobi) {        /* (every rank: the count below is a collective) */
 			/* a constant diagonal (constant-coefficient stencils): z = r.*dinv is r*dinv[0] in every bit, and the fused CG passes
 			 * need not read the array -- one counting pass per solve decides (all ranks: the count is folded like any sum) */
@@ -1157,7 +1194,8 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 			double *dd;
 			if ((err = lisd_vec_in(solver->d, &dd))) goto out;
 			rc = liship_pmul_f64(A->n, c.x, dd, dx, lisg.stream);
-		} else rc = liship_memcpy_d2d(dx, c.x, sizeof(double) * (size_t)A->n, lisg.stream);
+		} else if (renumbered) rc = liship_permute_scatter_f64(A->n, renum, c.x, dx, lisg.stream);
+		else rc = liship_memcpy_d2d(dx, c.x, sizeof(double) * (size_t)A->n, lisg.stream);
 		if (rc) { err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); goto out; }
 		if ((err = lisd_vec_done(x))) goto out;
 	}
@@ -1174,6 +1212,12 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		else lis_printf(LIS_COMM_WORLD, "linear solver status  : normal end\n\n");
 	}
 out:
+	if (renumbered) {           /* the caller's matrix again, whatever happened */
+		lisd_mat *dm = MDEV(Awork);
+		dm->plan = held_plan; dm->ptr = held_ptr; dm->index = held_index; dm->value = held_value;
+	}
+	if (renum_b) lisd_pool_put(renum_b, c.len * sizeof(double));
+	if (renum_d) lisd_pool_put(renum_d, c.len * sizeof(double));
 	if (c.x) lisd_pool_put(c.x, c.len * sizeof(double));
 	solver->precon = NULL;
 	if (err) solver->retcode = err;

@@ -265,6 +265,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_uniform_jacobi = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_LOCAL_COLUMNS");
 		lisg.no_local_columns = (r && r[0] == '1');
+		r = getenv("LIS_AMD_NO_REORDER");
+		lisg.no_reorder = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_MARCHING");
 		lisg.no_marching = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_TEAM_KERNELS");

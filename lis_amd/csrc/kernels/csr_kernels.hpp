@@ -50,6 +50,7 @@ int g_row_block_dots = 0;        // liship_spmv_csr_set_row_block_dots: 1 keeps 
 int g_dom_march = 1;             // liship_spmv_csr_set_dom_march: 0 keeps 7-point plans with value records on the gathering dominant-pattern kernel (A/B)
 int g_block_rows = 1;            // liship_spmv_csr_set_block_rows: 0 keeps plans with block rows (liship_csr_plan_encode_block_rows) on the row-by-row kernels (A/B); 2: plans of any size take them (tests)
 int g_wide_union = 1;            // liship_spmv_csr_set_wide_union: 0 keeps plans whose rows take turns on several patterns off the staged value-record kernel (plan time, A/B)
+int g_reorder = 1;               // liship_spmv_csr_set_reorder: 0 keeps the products of reordered plans (liship_csr_plan_reorder) on the original numbering (A/B; the same bits)
 int g_team = 1;                  // liship_spmv_csr_set_team: 0 keeps patterned rows of 8..32 entries on the one-lane-per-row pattern kernel
 
 __device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
@@ -374,7 +375,8 @@ template <int BLOCK, int CAP, int VEC, int DOT = 0>
 __device__ __forceinline__ void block_by_products(double *prod, const int *__restrict__ ptr,
                                                   const int *__restrict__ idx, const double *__restrict__ val,
                                                   const double *__restrict__ x, double *__restrict__ y,
-                                                  const Blk B, RowDots<DOT> &dots, const double acc0 = 0.0)
+                                                  const Blk B, RowDots<DOT> &dots, const double acc0 = 0.0,
+                                                  const int *__restrict__ rowmap = nullptr)      // (reordered plans: row r of this matrix is y[rowmap[r]])
 {
     const int r0 = B.r0, r1 = B.r1, k0 = B.k0, k1 = B.k1;
     const int ka = k0 & ~1;
@@ -393,7 +395,7 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
         int s = s_first, e = e_first;
         if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
         const double acc = ordered_sum_rows(acc0, prod, s - ka, min(e, kfirst) - s, (int)threadIdx.x, 1);
-        if (e <= kfirst) { store_stream(y + r, acc); dots.add(r, acc); } else carry = acc;   // only the block's last row can overflow
+        if (e <= kfirst) { store_stream(y + (rowmap ? rowmap[r] : r), acc); dots.add(r, acc); } else carry = acc;   // only the block's last row can overflow
     }
 
     if (k1 > kfirst) {                                          // uniform: finish the long last row
@@ -483,7 +485,7 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
                 }
             }
         }
-        if ((int)threadIdx.x == owner) { store_stream(y + rl, carry); dots.add(rl, carry); }
+        if ((int)threadIdx.x == owner) { store_stream(y + (rowmap ? rowmap[rl] : rl), carry); dots.add(rl, carry); }
     }
 }
 
@@ -650,7 +652,8 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
                            const v2i32 *__restrict__ blk, int bfirst, int nb, Rows RW, int nnz_total,
                            const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                            const double *__restrict__ guard = nullptr, int pstride = 0, int uniform = 1,
-                           const int *__restrict__ drun = nullptr, const int *__restrict__ droff = nullptr)
+                           const int *__restrict__ drun = nullptr, const int *__restrict__ droff = nullptr,
+                           const int *__restrict__ rowmap = nullptr)      // reordered plans (liship_csr_plan_reorder): row r of the matrix this launch walks is y[rowmap[r]]
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const int row_begin = RW.rb, row_end = RW.re;
@@ -676,7 +679,7 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     const int np = (cnt + 1) >> 1;                  // 16 B pieces of the value slice
     const int nl = (cnt + 7) >> 3;                  // 16 B pieces of the position slice (the array is padded)
     if (nd == 0 || nd > XCAP || cnt > CAP || ka + 2 * np > nnz_total) {  // block without a list / last value of the array
-        block_by_products<BLOCK, CAP, 4, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
+        block_by_products<BLOCK, CAP, 4, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0, rowmap);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
@@ -719,8 +722,8 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     // rows stay with consecutive lanes of as few wavefronts as possible: dealing them to all wavefronts was tried and multiplies
     // the LDS instructions of the serial sums by the number of wavefronts (each then issues the whole chain for a few lanes)
     const int rmine = B.r0 + (int)threadIdx.x;
-    int s_first = 0, e_first = 0;
-    if (rmine < B.r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; }
+    int s_first = 0, e_first = 0, y_first = rmine;
+    if (rmine < B.r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; if (rowmap) y_first = rowmap[rmine]; }
     if (RUNS) {
         double t0[NRPL], t1[NRPL], t2[NRPL];
 #pragma unroll
@@ -755,15 +758,40 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     __syncthreads();
 
     for (int r = rmine; r < B.r1; r += BLOCK) {
-        int s = s_first, e = e_first;
-        if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
+        int s = s_first, e = e_first, yr = y_first;
+        if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; yr = rowmap ? rowmap[r] : r; }
         const double wr = dots.fetch(r);
         const double acc = ordered_sum_rows(acc0, valL, s - ka, e - s, (int)threadIdx.x, uniform);
-        store_stream(y + r, acc);
+        store_stream(y + yr, acc);
         dots.add_loaded(wr, acc);
     }
     if (DOT != 0) __syncthreads();
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
+}
+
+// x in the numbering of a reordered plan: xp[i] = x[perm[i]], THREE consecutive entries per lane -- the walk keeps the unknowns of a node together, so on a 3-dof mesh a
+// lane's three reads are one 24 B piece of x (one cache line instead of three: 29.6 -> ?? us on the Queen-class matrix); any other permutation is served all the same
+__global__ __launch_bounds__(256)
+void csr_reorder_gather_kernel(int n, const int *__restrict__ perm, const double *__restrict__ x, double *__restrict__ xp)
+{
+    const int i = 3 * (blockIdx.x * 256 + (int)threadIdx.x);
+    if (i + 2 < n) {
+        const int a = perm[i], b = perm[i + 1], c = perm[i + 2];
+        const double va = x[a], vb = x[b], vc = x[c];
+        xp[i] = va; xp[i + 1] = vb; xp[i + 2] = vc;
+    } else for (int k = i; k < n; k++) xp[k] = x[perm[k]];
+}
+
+// and back: x[perm[i]] = xp[i] (24 B pieces on a 3-dof mesh)
+__global__ __launch_bounds__(256)
+void csr_reorder_scatter_kernel(int n, const int *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x)
+{
+    const int i = 3 * (blockIdx.x * 256 + (int)threadIdx.x);
+    if (i + 2 < n) {
+        const int a = perm[i], b = perm[i + 1], c = perm[i + 2];
+        const double va = xp[i], vb = xp[i + 1], vc = xp[i + 2];
+        x[a] = va; x[b] = vb; x[c] = vc;
+    } else for (int k = i; k < n; k++) x[perm[k]] = xp[k];
 }
 
 // plan time, one workgroup per row block: sort the block's column indices (bitonic, in LDS), keep the distinct ones.

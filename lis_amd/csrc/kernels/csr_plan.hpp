@@ -240,6 +240,12 @@ struct liship_csr_plan_s {
     int *dcol;           // device, the lists (each padded to a multiple of 4 entries)
     int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
     long long ndcol;     // entries of dcol
+    // Reordered form (liship_csr_plan_reorder): P A P^T in HBM -- the same entries in the same in-row order, rows and columns renumbered by a Cuthill-McKee walk -- with a
+    // block-local plan of its own.  The product gathers x into the new numbering, walks the renumbered rows and stores row r at y[r_perm[r]]: every row sum is the sum the
+    // original row forms, term by term.
+    liship_csr_plan_s *inner = nullptr;
+    int *r_ptr = nullptr, *r_idx = nullptr, *r_perm = nullptr;      // device: row starts and columns of P A P^T; new position -> original row
+    double *r_val = nullptr, *r_x = nullptr;                        // device: its values; x in the new numbering (n entries)
     int *drun, *droff;   // device, or NULL: when every list is made of TRIPLES of consecutive columns (3 unknowns per node), the triples' first columns and nblocks + 1 offsets into them
     int ndpl;            // distinct columns per lane of spmv_csr_local_kernel: 2 (lists of <= 1024 columns) or 4
     int xcap;            // its x stage: the longest list rounded up to 1024 / 1536 / 2048 entries
@@ -415,6 +421,12 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->drun) (void)hipFree(p->drun);
     if (p->droff) (void)hipFree(p->droff);
     if (p->doff) (void)hipFree(p->doff);
+    if (p->inner) (void)liship_csr_plan_destroy(p->inner);
+    if (p->r_ptr) (void)hipFree(p->r_ptr);
+    if (p->r_idx) (void)hipFree(p->r_idx);
+    if (p->r_perm) (void)hipFree(p->r_perm);
+    if (p->r_val) (void)hipFree(p->r_val);
+    if (p->r_x) (void)hipFree(p->r_x);
     free(p->blk_host);
     delete p;
     return rc;
@@ -426,6 +438,7 @@ extern "C" int liship_csr_plan_set_first_term_initialises(liship_csr_plan_t p, i
 {
     if (!p) return LISHIP_ERR_ARG;
     p->first_term = on ? 1 : 0;
+    if (p->inner) p->inner->first_term = p->first_term;
     return 0;
 }
 
@@ -1684,6 +1697,130 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     p->xcap = ndmost <= 1024 ? 1024 : (ndmost <= 1536 && p->geom == LOCAL_GEOM4) ? 1536 : 2048;
     return 0;
 }
+// ---------------------------------------------------------------------------------------------- reordering (round 5)
+// A mesh whose nodes are numbered without locality (the Queen-class stand-in: numbers permuted at random inside runs of 1024 nodes) gives every row block ~2.3 x the
+// distinct columns the same mesh has in a local numbering, each on a cache line of its own: the block-local kernel then spends more L1 <-> L2 requests on x than on the
+// matrix (profiles/r04_queen_class_pmc.txt: 30 M of 55.7 M per product) and runs at 0.65 ms where the naturally numbered mesh takes 0.52.  The product does not care in
+// which order rows are WALKED or what a column is CALLED -- a row sum is its own terms in their stored order -- so the plan may renumber: a Cuthill-McKee walk of the
+// matrix graph on the host (breadth first, the children of a vertex in index order: the unknowns of a node stay neighbours), P A P^T built once in HBM.
+namespace {
+__global__ void csr_reorder_inverse(int n, const int *__restrict__ perm, int *__restrict__ inv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[perm[i]] = i;
+}
+// one wavefront per row of P A P^T: entry j of new row r is entry j of row perm[r], its column renumbered
+__global__ __launch_bounds__(256)
+void csr_reorder_rows(int n, const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val, const int *__restrict__ perm,
+                      const int *__restrict__ inv, const int *__restrict__ ptr2, int *__restrict__ idx2, double *__restrict__ val2)
+{
+    const int r = blockIdx.x * (256 / WAVE) + (int)threadIdx.x / WAVE, lane = (int)threadIdx.x & (WAVE - 1);
+    if (r >= n) return;
+    const int src = perm[r], s = ptr[src], len = ptr[src + 1] - s, d = ptr2[r];
+    for (int j = lane; j < len; j += WAVE) { idx2[d + j] = inv[idx[s + j]]; val2[d + j] = val[s + j]; }
+}
+
+// Cuthill-McKee on the host: order[] = the vertices in the order a breadth-first walk meets them, the unvisited neighbours of a vertex appended in index order; the
+// first component starts from the far end of a walk that started at vertex 0, every other one at its lowest index.  false: a column outside [0, n) (ghost columns).
+bool cuthill_mckee(int n, const int *ptr, const int *idx, int *order)
+{
+    std::vector<unsigned char> seen((size_t)n, 0);
+    std::vector<int> kids;
+    int head = 0, tail = 0;
+    bool ok = true;
+    auto walk = [&](int start) {
+        seen[start] = 1; order[tail++] = start;
+        while (head < tail) {
+            const int u = order[head++];
+            kids.clear();
+            for (int k = ptr[u]; k < ptr[u + 1]; k++) {
+                const int c = idx[k];
+                if (c < 0 || c >= n) { ok = false; continue; }
+                if (!seen[c]) { seen[c] = 1; kids.push_back(c); }
+            }
+            if (kids.size() > 1) std::sort(kids.begin(), kids.end());
+            for (int c : kids) order[tail++] = c;
+        }
+    };
+    if (n <= 0) return true;
+    walk(0);
+    const int far_end = order[tail - 1];
+    for (int i = 0; i < tail; i++) seen[order[i]] = 0;
+    head = tail = 0;
+    walk(far_end);
+    for (int s = 0; s < n && ok; s++) if (!seen[s]) walk(s);
+    return ok && tail == n;
+}
+} // namespace
+
+extern "C" int liship_spmv_csr_set_reorder(int on) { g_reorder = on ? 1 : 0; return 0; }
+// listed columns of the reordered form (compare liship_csr_plan_localized: the original numbering's), 0 when the plan has none
+extern "C" long long liship_csr_plan_reordered(liship_csr_plan_t p) { return (p && p->inner) ? p->inner->ndcol : 0; }
+
+// Builds the reordered form when the plan keeps block-local columns AND its lists are long (more than one listed column per `min_items_per_listed` non-zeros: 4 by
+// default when 0 is passed) AND the renumbered matrix lists at most 3/4 of them.  Never an error when the matrix does not qualify; out of memory (2) leaves the plan as
+// it was.  Host work at plan time: index[] comes to the host once (4 B per non-zero), the walk visits every entry twice.
+extern "C" int liship_csr_plan_reorder(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, void *stream)
+{
+    if (!p || (p->n > 0 && (!ptr || !idx || !val))) return LISHIP_ERR_ARG;
+    if (p->inner || !p->products || p->codes || p->n < 65536 || p->nnz <= 0 || g_variant != 0) return 0;
+    const int mi = min_items_per_listed > 0 ? min_items_per_listed : 4;
+    if (p->lcol && p->ndcol * (long long)mi <= p->nnz) return 0;   // lists short already: the numbering is local (no lists at all: too many distinct columns per row block)
+    hipStream_t st = as_stream(stream);
+    const int n = p->n;
+    const size_t nnz = (size_t)p->nnz;
+    int *hptr = (int *)malloc(sizeof(int) * ((size_t)n + 1)), *hidx = (int *)malloc(sizeof(int) * nnz), *order = (int *)malloc(sizeof(int) * (size_t)n);
+    int *hptr2 = (int *)malloc(sizeof(int) * ((size_t)n + 1));
+    int *inv = nullptr;
+    liship_csr_plan_s *in = nullptr;
+    hipError_t e = (hptr && hidx && order && hptr2) ? hipSuccess : hipErrorOutOfMemory;
+    bool keep = false;
+    if (e == hipSuccess) e = hipMemcpyAsync(hptr, ptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hidx, idx, sizeof(int) * nnz, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && cuthill_mckee(n, hptr, hidx, order)) {
+        bool moved = false;
+        hptr2[0] = 0;
+        for (int r = 0; r < n; r++) { hptr2[r + 1] = hptr2[r] + (hptr[order[r] + 1] - hptr[order[r]]); moved = moved || order[r] != r; }
+        if (moved) {
+            e = hipMalloc(&p->r_perm, sizeof(int) * ((size_t)n + 2));
+            if (e == hipSuccess) e = hipMalloc(&p->r_ptr, sizeof(int) * ((size_t)n + 2));
+            if (e == hipSuccess) e = hipMalloc(&inv, sizeof(int) * ((size_t)n + 2));
+            if (e == hipSuccess) e = hipMalloc(&p->r_idx, sizeof(int) * (nnz + 16));
+            if (e == hipSuccess) e = hipMalloc(&p->r_val, sizeof(double) * (nnz + 16));
+            if (e == hipSuccess) e = hipMalloc(&p->r_x, sizeof(double) * ((size_t)n + 2));
+            if (e == hipSuccess) e = hipMemcpyAsync(p->r_perm, order, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(p->r_ptr, hptr2, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemsetAsync(p->r_idx + nnz, 0, sizeof(int) * 16, st);
+            if (e == hipSuccess) e = hipMemsetAsync(p->r_val + nnz, 0, sizeof(double) * 16, st);
+            if (e == hipSuccess) {
+                csr_reorder_inverse<<<(n + 255) / 256, 256, 0, st>>>(n, p->r_perm, inv);
+                csr_reorder_rows<<<(n + 3) / 4, 256, 0, st>>>(n, ptr, idx, val, p->r_perm, inv, p->r_ptr, p->r_idx, p->r_val);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess) {
+                int rc = liship_csr_plan_create(&in, n, p->r_ptr, stream);
+                if (!rc) rc = liship_csr_plan_localize_columns(in, p->r_ptr, p->r_idx, stream);
+                if (rc) e = (hipError_t)rc;
+                else keep = in->lcol && (!p->lcol || in->ndcol * 4 <= p->ndcol * 3);
+            }
+        }
+    }
+    free(hptr); free(hidx); free(order); free(hptr2);
+    if (inv) (void)hipFree(inv);
+    if (keep) { in->first_term = p->first_term; p->inner = in; return 0; }
+    if (in) (void)liship_csr_plan_destroy(in);
+    if (p->r_ptr) (void)hipFree(p->r_ptr);
+    if (p->r_idx) (void)hipFree(p->r_idx);
+    if (p->r_perm) (void)hipFree(p->r_perm);
+    if (p->r_val) (void)hipFree(p->r_val);
+    if (p->r_x) (void)hipFree(p->r_x);
+    p->r_ptr = p->r_idx = p->r_perm = nullptr; p->r_val = p->r_x = nullptr;
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // entries of the distinct-column lists when the plan keeps block-local columns, 0 otherwise
 extern "C" long long liship_csr_plan_localized(liship_csr_plan_t p) { return (p && p->lcol) ? p->ndcol : 0; }
 extern "C" int liship_spmv_csr_set_local_columns(int on) { g_local_cols = on ? 1 : 0; return 0; }

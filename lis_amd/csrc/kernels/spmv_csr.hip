@@ -28,6 +28,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 #include "common.hpp"
 #include "liship.h"
 
@@ -54,6 +56,7 @@ struct LaunchArgs {
     const int *order = nullptr;             // launch order of the products kernel (whole-matrix launches of a plan that has one)
     const v4i32 *vrecw = nullptr;           // wide value records (rows of up to 32 entries), when the plan has them and they are switched on
     const liship_csr_plan_s *plan = nullptr; // (set by the launchers) the dominant-pattern records live there
+    const int *rowmap = nullptr;            // reordered plans: where row r of the (renumbered) matrix goes in y -- the block-local kernel only
 };
 
 
@@ -409,9 +412,9 @@ void launch_local(const LaunchArgs &a, const double *w, double *partial, const d
     const int ndpl = a.plan ? a.plan->ndpl : 2, xcap = a.plan ? a.plan->xcap : 1024;
     const bool runs = a.plan && a.plan->drun && a.plan->droff && g_local_runs;      // lists of triples: the positions-in-registers forms read the run starts
 #define GOL(NDPL_, XCAP_, RPOS_) spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, RPOS_><<<a.nb, g.block, 0, a.st>>>( \
-        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows)
+        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, nullptr, nullptr, a.rowmap)
 #define GOLR(NDPL_, XCAP_) spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, true, true><<<a.nb, g.block, 0, a.st>>>( \
-        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, a.plan->drun, a.plan->droff)
+        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, a.plan->drun, a.plan->droff, a.rowmap)
     if constexpr (G == LOCAL_GEOM_R) { if (ndpl == 4) { if (runs) GOLR(4, 2048); else GOL(4, 2048, true); } else { if (runs) GOLR(2, 1024); else GOL(2, 1024, true); } }
     else if constexpr (G == LOCAL_GEOM4) {
         if (xcap <= 1024) { if (runs) GOLR(2, 1024); else GOL(2, 1024, true); }
@@ -623,7 +626,42 @@ static bool plan_runs_dom(const liship_csr_plan_s *p)       // the dominant-patt
     return p && p->rowpat && g_row_patterns && g_index_codes && p->ptab8 && g_row_values && p->vrec && p->drec && !p->products &&
            kGeom[p->geom].block == 256 && (g_variant & ~0x10000000) == 0 && !g_row_block_dots;
 }
-extern "C" int liship_csr_plan_fused_dots(liship_csr_plan_t p) { return plan_runs_teams(p) ? 0 : 1; }
+// the reordered form serves whole-matrix products of the plan in its shipped configuration; row ranges and the fused reductions (whose partial sums follow the
+// ORIGINAL row blocks) keep the original numbering
+static bool plan_runs_reordered(const liship_csr_plan_s *p) { return p && p->inner && p->inner->lcol && g_reorder && g_local_cols && g_variant == 0; }
+static int launch_reordered(liship_csr_plan_t p, const double *x, double *y, hipStream_t st)
+{
+    const liship_csr_plan_s *q = p->inner;
+    csr_reorder_gather_kernel<<<(p->n / 3 + 256) / 256, 256, 0, st>>>(p->n, p->r_perm, x, p->r_x);
+    LaunchArgs a{p->r_ptr, p->r_idx, p->r_val, p->r_x, y, q->blk, 0, q->nblocks, 0, q->n, (int)q->nnz, st, nullptr, nullptr, q->lcol, q->dcol, q->doff, p->first_term ? -0.0 : 0.0};
+    a.rowmap = p->r_perm;
+    return launch_csr(p->inner, a);
+}
+extern "C" int liship_csr_plan_fused_dots(liship_csr_plan_t p) { return (plan_runs_teams(p) || plan_runs_reordered(p)) ? 0 : 1; }
+// The reordered form as a matrix of its own -- P A P^T: its plan (owned by `p`), its arrays, the permutation (new position -> original row) -- for a caller that keeps
+// whole iterations in the new numbering (lis_solve: b and x0 gathered once, every product, dot and update on renumbered vectors, x scattered back at the end).
+extern "C" int liship_csr_plan_reordered_form(liship_csr_plan_t p, liship_csr_plan_t *inner, const int **ptr, const int **idx, const double **val, const int **perm)
+{
+    if (!plan_runs_reordered(p) || !inner || !ptr || !idx || !val || !perm) return LISHIP_ERR_ARG;
+    *inner = p->inner; *ptr = p->r_ptr; *idx = p->r_idx; *val = p->r_val; *perm = p->r_perm;
+    return 0;
+}
+extern "C" int liship_permute_gather_f64(int n, const int *perm, const double *x, double *xp, void *stream)       // xp[i] = x[perm[i]]
+{
+    if (n < 0 || (n > 0 && (!perm || !x || !xp || x == xp))) return LISHIP_ERR_ARG;
+    if (n == 0) return 0;
+    csr_reorder_gather_kernel<<<(n / 3 + 256) / 256, 256, 0, as_stream(stream)>>>(n, perm, x, xp);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int liship_permute_scatter_f64(int n, const int *perm, const double *xp, double *x, void *stream)      // x[perm[i]] = xp[i]
+{
+    if (n < 0 || (n > 0 && (!perm || !x || !xp || x == xp))) return LISHIP_ERR_ARG;
+    if (n == 0) return 0;
+    csr_reorder_scatter_kernel<<<(n / 3 + 256) / 256, 256, 0, as_stream(stream)>>>(n, perm, xp, x);
+    LAUNCH_CHECK();
+    return 0;
+}
 // upper bound of the partial-sum slots the fused product needs when it is launched in up to three row ranges (liship_spmv_csr_rows_dot_f64)
 extern "C" long long liship_csr_plan_fused_slots(liship_csr_plan_t p)
 {
@@ -658,6 +696,7 @@ extern "C" int liship_spmv_csr_f64(liship_csr_plan_t p, const int *ptr, const in
                                    const double *val, const double *x, double *y, void *stream)
 {
     if (!p) return LISHIP_ERR_ARG;
+    if (plan_runs_reordered(p) && x != y) return launch_reordered(p, x, y, as_stream(stream));
     LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order, g_row_values ? p->vrecw : nullptr};
     return launch_csr(p, a);
 }
@@ -671,7 +710,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
                                        double *result, void *work, void *stream)
 {
     if (!p || !w || !result || !work) return LISHIP_ERR_ARG;
-    if (plan_runs_teams(p) || liship_internal_ref_chunks()) return LISHIP_ERR_ARG;      // (reference-order sums: the product, then one ordered pass)
+    if (plan_runs_teams(p) || plan_runs_reordered(p) || liship_internal_ref_chunks()) return LISHIP_ERR_ARG;      // (reference-order sums: the product, then one ordered pass)
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((g_variant & ~0x30006000) != 0 || (size_t)p->nblocks > slots || !aligned16(val) || !aligned16(idx)) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;

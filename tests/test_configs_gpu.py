@@ -183,6 +183,9 @@ def test_config4_queen_scale_through_the_matrix_market_reader(lib):
         lib.dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
         assert lib.dll.lis_amd_matrix_index_codes(A) == 0            # thousands of (column - row) offsets: nothing to code
         listed = lib.dll.lis_amd_matrix_local_columns(A)
+        lib.dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; lib.dll.lis_amd_matrix_reordered.restype = C.c_longlong
+        reordered = lib.dll.lis_amd_matrix_reordered(A)
+        assert 0 < reordered * 2 < listed                            # the generator's scramble: the walk finds the mesh again (less than half the listed columns)
         xs = np.cos(np.arange(n) * 0.01) + 1.25
         y = lisdrv.matvec(lib, A, xs)
         assert _sha(y) == g["y_sha256"]                              # the bits lis_matvec of Lis 2.1.11 returned for this file
@@ -200,7 +203,7 @@ def test_config4_queen_scale_through_the_matrix_market_reader(lib):
         assert np.array_equal(lisdrv.get_vector(lib, vy, n), y)
         report = {"n": n, "nnz": nnz, "file_bytes": g["file_bytes"], "generate_s": round(t_gen, 2), "lis_input_s": round(t_read, 2),
                   "reference_lis_input_s": g["reference_reader_seconds"], "upload_and_plan_s": round(t_up, 2),
-                  "block_local_columns_listed": int(listed), "spmv_ms": round(ms, 4),
+                  "block_local_columns_listed": int(listed), "listed_after_reordering": int(reordered), "spmv_ms": round(ms, 4),
                   "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1), "spmv_frac_of_8TBs_contract_bytes": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4),
                   "solves": {}}
         rhs = lisdrv.matvec(lib, A, np.ones(n))                     # b = A*1 (test/test1.c:138-139)
@@ -215,6 +218,17 @@ def test_config4_queen_scale_through_the_matrix_market_reader(lib):
             k = min(len(res["rhistory"]), len(want["rhistory_head"]))
             np.testing.assert_allclose(res["rhistory"][:k], want["rhistory_head"][:k], rtol=1e-9)
             assert np.abs(res["x"] - 1.0).max() <= 1e-9
+            # round 5: the scrambled numbering makes the plan renumber the matrix and lis_solve iterate in that numbering; the same solve in the caller's numbering beside it
+            report["solves"][opts]["renumbered"] = int(lib.dll.lis_amd_last_solve_renumbered())
+            if report["solves"][opts]["renumbered"]:
+                lib.liship_spmv_csr_set_reorder(0)
+                try:
+                    plain = lisdrv.solve(lib, A, rhs, opts + " -tol 1e-12 -maxiter 2000 -print mem")
+                finally:
+                    lib.liship_spmv_csr_set_reorder(1)
+                assert lib.dll.lis_amd_last_solve_renumbered() == 0
+                assert plain["status"] == 0 and abs(plain["iter"] - want["iter"]) <= SLACK[solver]
+                report["solves"][opts]["callers_numbering"] = {"iter": plain["iter"], "iters_per_sec": round(plain["iter"] / plain["itime"], 1)}
         out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
         if os.path.isdir(out_dir):
             json.dump(report, open(os.path.join(out_dir, "queen_class_run.json"), "w"), indent=1)

@@ -728,6 +728,103 @@ def test_spmv_csr_local_columns(lib, name):
         assert np.array_equal(a, b) and np.array_equal(a, c)                        # same partial sums, same fold: the reductions agree to the bit too
 
 
+def permute_csr(ptr, idx, val, perm):
+    """P A P^T: new row i is old row perm[i] with its entries in their stored order, column c renamed to the new position of c"""
+    n = len(ptr) - 1
+    inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+    lens = np.diff(ptr)[perm]
+    ptr2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    src = np.repeat(np.asarray(ptr[:-1], np.int64)[perm] - ptr2[:-1], lens) + np.arange(ptr2[-1])
+    return ptr2, inv[idx[src]].astype(np.int32), val[src]
+
+
+def _scrambled_fem(kind):
+    """a 3-dof mesh (81 entries per row) whose numbering has no locality: what liship_csr_plan_reorder is for"""
+    rng = np.random.default_rng(55)
+    if kind == "two_meshes_and_loose_rows":           # two components, and rows that are empty / hold one entry (vertices without neighbours)
+        p, i, v = _fem(23)
+        m = len(p) - 1
+        p2 = np.concatenate([p, p[1:] + p[-1]]).astype(np.int32)
+        i2 = np.concatenate([i, i + m]).astype(np.int32)
+        ptr, idx, val = p2, i2, np.concatenate([v, 0.5 * v])
+        n = 2 * m
+        loose = np.zeros(1200, np.int64); loose[::3] = 1                                  # 400 single-entry rows (their own diagonal), 800 empty ones
+        lp = np.concatenate([[0], np.cumsum(loose)]) + ptr[-1]
+        ptr = np.concatenate([ptr, lp[1:]]).astype(np.int32)
+        idx = np.concatenate([idx, n + np.flatnonzero(loose)]).astype(np.int32)
+        val = np.concatenate([val, np.full(int(loose.sum()), 2.5)])
+        n += 1200
+        nodes = n // 3
+    else:
+        ptr, idx, val = _fem(28)
+        n = len(ptr) - 1
+        nodes = n // 3
+    if kind == "rows":                                # every unknown on its own: no triples left
+        perm = rng.permutation(n)
+    else:                                             # nodes permuted, the three unknowns of a node stay together
+        perm = (3 * rng.permutation(nodes)[:, None] + np.arange(3)[None, :]).reshape(-1)
+        perm = np.concatenate([perm, np.arange(3 * nodes, n)])
+    return permute_csr(ptr, idx, val, perm)
+
+
+@pytest.mark.parametrize("kind", ["nodes", "rows", "two_meshes_and_loose_rows", "natural"])
+def test_reordered_plan_bit_exact(lib, kind):
+    """liship_csr_plan_reorder: a matrix numbered without locality is renumbered inside the plan (Cuthill-McKee, P A P^T in HBM); y keeps the oracle's bits
+    (lis_matvec_csr.c:97-109: every row sum is its own terms in stored order) with the reordered form on and off, special values included; the fused entry
+    points step aside, row ranges keep the original numbering; a mesh in its natural numbering is left alone"""
+    ptr, idx, val = _fem(28) if kind == "natural" else _scrambled_fem(kind)
+    n = len(ptr) - 1
+    assert n >= 65536
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, n)
+    x[rng.integers(0, n, 40)] = [-0.0, np.inf, -np.inf, np.nan, 5e-324, 1e308, -1e308, 0.0] * 5
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    dptr, didx, dval, dx = DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    check(lib.liship_csr_plan_localize_columns(plan, dptr.ptr, didx.ptr, None))
+    listed = lib.liship_csr_plan_localized(plan)
+    assert (listed > 0) == (kind != "rows")            # unknowns scattered one by one: more than 2048 distinct columns per row block, no lists in the caller's numbering
+    check(lib.liship_csr_plan_reorder(plan, dptr.ptr, didx.ptr, dval.ptr, 0, None))
+    re = lib.liship_csr_plan_reordered(plan)
+    if kind == "natural":
+        assert re == 0 and lib.liship_csr_plan_fused_dots(plan) == 1
+        check(lib.liship_csr_plan_reorder(plan, dptr.ptr, didx.ptr, dval.ptr, 1 << 20, None))      # forced to try: the walk cannot list 1/4 fewer columns than the mesh order
+        assert lib.liship_csr_plan_reordered(plan) == 0
+    else:
+        assert re > 0 and (listed == 0 or re * 4 <= listed * 3), (re, listed)
+        assert lib.liship_csr_plan_fused_dots(plan) == 0
+    ys = {}
+    for on in (1, 0, 1):
+        lib.liship_spmv_csr_set_reorder(on)
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        ys[on] = dy.to_host()
+        assert np.array_equal(ys[on], yref, equal_nan=True), (kind, on)
+        assert np.array_equal(np.signbit(ys[on]), np.signbit(yref))
+    if re:
+        work, res, dw = DA(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64), DA.from_host(x, np.float64)
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        assert lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, 1, res.ptr, work.ptr, None) != 0      # the caller runs product + reduction
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        for a, b in ((n // 3, n - 7), (0, n // 3), (n - 7, n)):
+            check(lib.liship_spmv_csr_rows_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host(), yref, equal_nan=True)
+        # a split matrix's rows start from their first product (-0.0 + p): the reordered form starts there too
+        check(lib.liship_csr_plan_set_first_term_initialises(plan, 1))
+        x0 = np.zeros(n); x0[::2] = -0.0
+        d0 = DA.from_host(x0, np.float64)
+        got = {}
+        for on in (1, 0):
+            lib.liship_spmv_csr_set_reorder(on)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, d0.ptr, dy.ptr, None))
+            got[on] = dy.to_host()
+        assert np.array_equal(got[0], got[1]) and np.array_equal(np.signbit(got[0]), np.signbit(got[1]))
+    lib.liship_spmv_csr_set_reorder(1)
+    check(lib.liship_csr_plan_destroy(plan))
+
+
 @pytest.mark.parametrize("L", [21, 22, 23, 25, 26, 41, 42, 43, 62, 63, 81, 85, 101, 127])
 def test_uniform_length_rows_fed_sums(lib, L):
     """rows of ONE length (>= 21, not a multiple of 4): the wavefronts of the products and block-local kernels add them without a skew,

@@ -672,6 +672,46 @@ def test_environment_switches_reach_the_kernels(env, want):
     assert ("SWITCHES %d" % want) in p.stdout, p.stdout[-500:]
 
 
+@pytest.mark.parametrize("options", ["-i cg -p jacobi", "-i bicgstab -p none", "-i gmres -restart 30 -p jacobi", "-i cgs -p none", "-i bicg -p none"])
+def test_solves_in_the_numbering_of_a_reordered_plan(lib, options):
+    """a 3-dof mesh numbered without locality (65 856 rows): the plan renumbers it (lis_amd_matrix_reordered), lis_matvec keeps the oracle's bits, and lis_solve
+    runs the whole iteration in the plan's numbering -- b, x0 and 1/diag gathered once, x scattered back -- for the solvers that do not multiply by A^T (BiCG keeps
+    the caller's numbering).  The same recurrences on renumbered vectors: the counts of the run in the caller's numbering (+-2 %: the sums fold in another order),
+    the same solution, the residual the criterion asked for"""
+    from test_kernels_gpu import _scrambled_fem
+    dll = lib.dll
+    dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
+    ptr, idx, val = _scrambled_fem("nodes")
+    n = len(ptr) - 1
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    assert dll.lis_amd_matrix_reordered(A) > 0
+    rng = np.random.default_rng(12)
+    xs = rng.uniform(-1, 1, n)
+    assert np.array_equal(lisdrv.matvec(lib, A, xs).view(np.uint64), orc.spmv_csr(ptr, idx, val, xs).view(np.uint64))
+    xt = np.cos(np.arange(n) * 0.37) + 1.5
+    b = orc.spmv_csr(ptr, idx, val, xt)
+    x0 = rng.uniform(-0.1, 0.1, n)
+    opt = options + " -tol 1e-11 -maxiter 500 -initx_zeros false"
+    runs = {}
+    for on in (1, 0):
+        lib.liship_spmv_csr_set_reorder(on)
+        runs[on] = lisdrv.solve(lib, A, b, opt, x0=x0)
+        want = 1 if (on and "bicg " not in options + " ") else 0
+        assert dll.lis_amd_last_solve_renumbered() == want, (options, on)
+    lib.liship_spmv_csr_set_reorder(1)
+    a, c = runs[1], runs[0]
+    assert a["err"] == c["err"] == 0 and a["status"] == c["status"] == 0, (a["status"], c["status"])
+    assert abs(a["iter"] - c["iter"]) <= max(1, c["iter"] // 50), (a["iter"], c["iter"])
+    assert np.linalg.norm(a["x"] - c["x"]) <= 1e-9 * np.linalg.norm(c["x"])
+    assert np.linalg.norm(a["x"] - xt) <= 1e-8 * np.linalg.norm(xt)
+    r = b - orc.spmv_csr(ptr, idx, val, a["x"])
+    r0 = b - orc.spmv_csr(ptr, idx, val, x0)
+    assert np.linalg.norm(r) <= 3e-11 * np.linalg.norm(r0 if "gmres" in options else b) * (10 if "gmres" in options else 1)
+    m = min(len(a["rhistory"]), len(c["rhistory"]), 20)
+    assert np.allclose(a["rhistory"][:m], c["rhistory"][:m], rtol=1e-6, atol=0)         # the early history: the same numbers up to the fold order
+    assert lib.lis_matrix_destroy(A) == 0
+
+
 def test_contract_form_behind_the_environment_switch():
     """LIS_AMD_NO_INDEX_CODES=1: a Lis program's CSR matrix keeps the reference's own arrays in the product (4 B indices + 8 B values: spmv_csr_rowgather_kernel, the form
     SURVEY 8d prices) -- no codes, no patterns, no value records; the plan still learns the grid's plane, from the band of the matrix, for the XCD strips; y is the oracle's

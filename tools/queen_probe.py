@@ -14,6 +14,8 @@ if os.environ.get("QUEEN_NO_LOCAL") == "1":
     lib.liship_spmv_csr_set_local_columns(0)
 if os.environ.get("QUEEN_ROUND3") == "1":              # round-3 form: 4096-item blocks, positions through LDS (two workgroups per CU on this matrix)
     lib.liship_spmv_csr_set_local_register_positions(0)
+if os.environ.get("QUEEN_BAND"):                      # numbering sensitivity: 1 = the natural (lexicographic) node order, 1024 = the fixture's scramble
+    queen_class.CASES["full"] = (queen_class.CASES["full"][0], int(os.environ["QUEEN_BAND"]))
 t0 = time.time(); path, rows, stored = queen_class.generate("full"); t_gen = time.time() - t0
 A, b, x0 = capi.PM(), capi.PV(), capi.PV()
 lib.lis_matrix_create(0, C.byref(A)); lib.lis_vector_create(0, C.byref(b)); lib.lis_vector_create(0, C.byref(x0))
@@ -21,7 +23,7 @@ t0 = time.time(); assert lib.lis_input(A, b, x0, path.encode()) == 0; t_read = t
 os.unlink(path)
 n, nnz = A.contents.n, A.contents.nnz
 dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
-listed = dll.lis_amd_matrix_local_columns(A)
+t0 = time.time(); listed = dll.lis_amd_matrix_local_columns(A); t_plan = time.time() - t0       # (the first call uploads the matrix and builds the plan)
 xs = np.cos(np.arange(n) * 0.01) + 1.25
 vx, vy = lisdrv.new_vector(lib, A, xs), lisdrv.new_vector(lib, A)
 if os.environ.get("QUEEN_VARIANT"):
@@ -44,7 +46,18 @@ if os.environ.get("QUEEN_RUNS_AB") == "1":             # round 5: the lists as r
             yh = np.empty(n); lib.lis_vector_get_values(vy, 0, n, yh.ctypes.data_as(capi.P_DBL))
             print(f"runs={on}: {m:.4f} ms  y sha256 {hashlib.sha256(yh.tobytes()).hexdigest()[:16]}", flush=True)
     lib.liship_spmv_csr_set_local_runs(1)
+dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
+reordered = dll.lis_amd_matrix_reordered(A)
+if os.environ.get("QUEEN_REORDER_AB") == "1" and reordered:      # round 5: rows and columns renumbered inside the plan against the caller's numbering, interleaved
+    import hashlib
+    for rep in range(3):
+        for on in (1, 0):
+            lib.liship_spmv_csr_set_reorder(on)
+            m = timed()
+            yh = np.empty(n); lib.lis_vector_get_values(vy, 0, n, yh.ctypes.data_as(capi.P_DBL))
+            print(f"reorder={on}: {m:.4f} ms  y sha256 {hashlib.sha256(yh.tobytes()).hexdigest()[:16]}", flush=True)
+    lib.liship_spmv_csr_set_reorder(1)
 ms = timed()
-print(json.dumps({"n": n, "nnz": nnz, "generate_s": round(t_gen, 2), "lis_input_s": round(t_read, 2), "block_local_columns_listed": int(listed),
+print(json.dumps({"n": n, "nnz": nnz, "generate_s": round(t_gen, 2), "lis_input_s": round(t_read, 2), "block_local_columns_listed": int(listed), "listed_after_reordering": int(reordered), "plan_s": round(t_plan, 2),
                   "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),
                   "frac_of_8TBs_on_contract_bytes": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4)}), flush=True)

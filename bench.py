@@ -535,8 +535,10 @@ def main():
                 check(lib.liship_spmv_csr_set_index_codes(1)); check(lib.liship_spmv_csr_set_row_patterns(1)); check(lib.liship_spmv_csr_set_row_values(1))
 
     extras = None
+    irregular = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = stencil27_leg(lib, np, C, stream)
+        irregular = queen_class_leg(lib, np, C)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -571,6 +573,7 @@ def main():
             "multi_gpu": multi,
             "krylov": solvers,
             "stencil27": extras,              # beside the headline: the 27-point stencil (spmvtest3b / HPCG) through the round-3 kernels; not part of `value`
+            "config4_stand_in": irregular,    # BASELINE config 4 (irregular CSR, long rows): a generated matrix of Queen_4147's size through lis_input; not part of `value`
             "cpu_baseline": cpu,
         }
         assert_fracs_physical(out)
@@ -651,6 +654,81 @@ def stencil27_leg(lib, np, C, stream, G=256, launches=30):
         return out
     except Exception as exc:                                          # an extra: its failure must not cost the line
         return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def queen_class_leg(lib, np, C, reps=50):
+    """BASELINE config 4's stand-in (SuiteSparse Queen_4147 cannot be fetched: tests/golden/gen_queen_class.c writes a 3-dof mesh of its size -- 4.1 M rows, 2.9e8
+    non-zeros, node numbers scrambled inside runs of 1024 -- as a symmetric Matrix Market file) through lis_input, lis_matvec and lis_solve, as a Lis program would.
+    The plan finds no locality in the numbering and renumbers the matrix (liship_csr_plan_reorder); lis_matvec then pays a gather and a scattered store per product,
+    lis_solve iterates in the plan's numbering.  Host-clock ms per product over `reps` calls behind one synchronize; never fatal: an error string instead."""
+    path = None
+    try:
+        import time
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        import queen_class
+        from lis_amd import _capi as capi
+        dll = lib.dll
+        t0 = time.time(); path, rows, stored = queen_class.generate("full"); t_gen = time.time() - t0
+        A, b, x0 = capi.PM(), capi.PV(), capi.PV()
+        assert lib.lis_matrix_create(0, C.byref(A)) == 0 and lib.lis_vector_create(0, C.byref(b)) == 0 and lib.lis_vector_create(0, C.byref(x0)) == 0
+        t0 = time.time(); assert lib.lis_input(A, b, x0, path.encode()) == 0; t_read = time.time() - t0
+        os.unlink(path); path = None
+        n, nnz = A.contents.n, A.contents.nnz
+        dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
+        dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
+        t0 = time.time(); listed = int(dll.lis_amd_matrix_local_columns(A)); t_plan = time.time() - t0      # (uploads the matrix and builds the plan when lis_input did not)
+        reordered = int(dll.lis_amd_matrix_reordered(A))
+        vx, vy, ones = capi.PV(), capi.PV(), capi.PV()
+        for v in (vx, vy, ones):
+            assert lib.lis_vector_duplicate(A, C.byref(v)) == 0
+        xs = np.cos(np.arange(n) * 0.01) + 1.25
+        assert lib.lis_vector_set_values(0, n, np.arange(n, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int)), xs.ctypes.data_as(capi.P_DBL), vx) == 0
+        assert lib.lis_vector_set_all(1.0, ones) == 0
+
+        def timed():
+            for _ in range(10):
+                assert lib.lis_matvec(A, vx, vy) == 0
+            dll.lis_amd_synchronize()
+            t0 = time.time()
+            for _ in range(reps):
+                assert lib.lis_matvec(A, vx, vy) == 0
+            dll.lis_amd_synchronize()
+            return (time.time() - t0) / reps * 1e3
+        ms = timed()
+        out = {"matrix": "tests/golden/gen_queen_class.c 111 1024 (3 unknowns per node of a 111^3 grid, 27-node connectivity, scrambled numbering), symmetric .mtx through lis_input",
+               "n": n, "nnz": nnz, "generate_s": round(t_gen, 2), "lis_input_s": round(t_read, 2), "plan_s": round(t_plan, 2),
+               "block_local_columns_listed": listed, "listed_after_reordering": reordered,
+               "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),
+               "contract_bytes": 12 * nnz + 20 * n, "contract_frac": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4),
+               "kernel": "spmv_csr_local_kernel" + (" on P A P^T + csr_reorder_gather_kernel" if reordered else "")}
+        if reordered:
+            check = lib.liship_spmv_csr_set_reorder
+            check(0)
+            try:
+                out["spmv_ms_callers_numbering"] = round(timed(), 4)
+            finally:
+                check(1)
+        rhs = capi.PV()
+        assert lib.lis_vector_duplicate(A, C.byref(rhs)) == 0 and lib.lis_matvec(A, ones, rhs) == 0          # b = A*1 (test/test1.c:138-139)
+        out["solves"] = {}
+        for opts in ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi"):
+            S = capi.PS()
+            assert lib.lis_solver_create(C.byref(S)) == 0 and lib.lis_solver_set_option((opts + " -tol 1e-12 -maxiter 2000 -print none").encode(), S) == 0
+            assert lib.lis_vector_set_all(0.0, vy) == 0
+            assert lib.lis_solve(A, rhs, vy, S) == 0
+            it, itime = S.contents.iter, S.contents.itime
+            out["solves"][opts] = {"iter": it, "status": S.contents.retcode, "rel_residual": S.contents.resid, "iters_per_sec": round(it / itime, 1) if itime > 0 else None,
+                                   "renumbered": int(dll.lis_amd_last_solve_renumbered())}
+            lib.lis_solver_destroy(S)
+        for v in (vx, vy, ones, rhs, b, x0):
+            lib.lis_vector_destroy(v)
+        lib.lis_matrix_destroy(A)
+        return out
+    except Exception as exc:                                          # an extra: its failure must not cost the line
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        if path and os.path.exists(path):
+            os.unlink(path)
 
 
 def assert_fracs_physical(node, path="line"):

@@ -770,7 +770,8 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
 }
 
 // x in the numbering of a reordered plan: xp[i] = x[perm[i]], THREE consecutive entries per lane -- the walk keeps the unknowns of a node together, so on a 3-dof mesh a
-// lane's three reads are one 24 B piece of x (one cache line instead of three: 29.6 -> ?? us on the Queen-class matrix); any other permutation is served all the same
+// lane's three reads are one 24 B piece of x; any other permutation is served all the same.  Bound by the 128 B lines those pieces arrive in -- 1.37 M of them, 0.030 ms
+// on the Queen-class matrix, whether x is cache-resident or not and whatever the cache-policy bits of the loads (tools/permute_probe.py, profiles/EXPERIMENTS.md)
 __global__ __launch_bounds__(256)
 void csr_reorder_gather_kernel(int n, const int *__restrict__ perm, const double *__restrict__ x, double *__restrict__ xp)
 {

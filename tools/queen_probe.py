@@ -57,6 +57,24 @@ if os.environ.get("QUEEN_REORDER_AB") == "1" and reordered:      # round 5: rows
             yh = np.empty(n); lib.lis_vector_get_values(vy, 0, n, yh.ctypes.data_as(capi.P_DBL))
             print(f"reorder={on}: {m:.4f} ms  y sha256 {hashlib.sha256(yh.tobytes()).hexdigest()[:16]}", flush=True)
     lib.liship_spmv_csr_set_reorder(1)
+if os.environ.get("QUEEN_CHAIN") == "1" and reordered:         # a caller's own iteration: y = A x, x = y * c, ... -- x is fresh from the kernel before (cache-resident), not 3 GB old
+    def chain():
+        va, vb = vx, vy
+        for it in range(reps + 10):
+            if it == 10:
+                dll.lis_amd_synchronize(); t0 = time.time()
+            assert lib.lis_matvec(A, va, vb) == 0
+            assert lib.lis_vector_scale(0.01, vb) == 0
+            va, vb = vb, va
+        dll.lis_amd_synchronize()
+        return (time.time() - t0) / reps * 1e3
+    for rep in range(3):
+        for on in (1, 0):
+            lib.liship_spmv_csr_set_reorder(on)
+            lisdrv.set_vector(lib, vx, xs)
+            print(f"chain (product + scale) reorder={on}: {chain():.4f} ms per step", flush=True)
+    lib.liship_spmv_csr_set_reorder(1)
+    lisdrv.set_vector(lib, vx, xs)
 ms = timed()
 print(json.dumps({"n": n, "nnz": nnz, "generate_s": round(t_gen, 2), "lis_input_s": round(t_read, 2), "block_local_columns_listed": int(listed), "listed_after_reordering": int(reordered), "plan_s": round(t_plan, 2),
                   "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),

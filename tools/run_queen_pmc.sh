@@ -1,13 +1,17 @@
 #!/bin/bash
-# rocprofv3 counters of the CSR product on the Queen-class matrix (tools/queen_probe.py), separate passes per group (kernel-trace only)
+# rocprofv3 counters of the CSR product on the Queen-class matrix (tools/queen_probe.py), separate passes per group (kernel-trace only);
+# round 5: twice -- the plan's renumbering on (default) and off (LIS_AMD_NO_REORDER=1)
 cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out/queenpmc; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
-python $GRAFT_REPO_ROOT/tools/queen_probe.py 50 2>&1 | tail -1
-i=0
-for c in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
-  i=$((i+1))
-  timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OUT/pmc_$i -o pmc -- python $GRAFT_REPO_ROOT/tools/queen_probe.py 20 > $OUT/pmc_$i.log 2>&1
+for tag in reordered callers_numbering; do
+  OUT=$GRAFT_REPO_ROOT/gpurun_out/queenpmc_$tag; rm -rf $OUT; mkdir -p $OUT
+  E=""; [ $tag = callers_numbering ] && E="LIS_AMD_NO_REORDER=1"
+  echo "== $tag"
+  env $E python $GRAFT_REPO_ROOT/tools/queen_probe.py 50 2>&1 | tail -1
+  i=0
+  for c in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCP_TCC_WRITE_REQ_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+    i=$((i+1))
+    env $E timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OUT/pmc_$i -o pmc -- python $GRAFT_REPO_ROOT/tools/queen_probe.py 20 > $OUT/pmc_$i.log 2>&1
+  done
+  python $GRAFT_REPO_ROOT/tools/prof_summary.py $OUT | grep -E "spmv_csr_local|reorder_gather" | cut -c1-70,110-400
 done
-cd $GRAFT_REPO_ROOT
-python tools/prof_summary.py $OUT | grep -E "spmv_csr" | cut -c1-70,110-240

@@ -576,7 +576,7 @@ def main():
             "config4_stand_in": irregular,    # BASELINE config 4 (irregular CSR, long rows): a generated matrix of Queen_4147's size through lis_input; not part of `value`
             "cpu_baseline": cpu,
         }
-        assert_fracs_physical(out)
+        assert_fracs_physical(out, shared_gpu=out["degraded"])
         print(json.dumps(out), flush=True)
     degraded = world > 1 and comm_used != "rccl" and args.comm == "rccl"
     if world > 1:
@@ -731,17 +731,19 @@ def queen_class_leg(lib, np, C, reps=50):
             os.unlink(path)
 
 
-def assert_fracs_physical(node, path="line"):
-    """every `frac` in the line is a fraction of the HBM peak on bytes a kernel moves over its measured time: 0 < frac <= 1"""
+def assert_fracs_physical(node, path="line", shared_gpu=False):
+    """every `frac` in the line is a fraction of the HBM peak on bytes a kernel moves over its measured time: 0 < frac <= 1
+    (shared_gpu: a bring-up run of several ranks on ONE GPU, flagged degraded -- the other process's time slices fall inside the event intervals of a 48^3 kernel
+    and a fraction may round to 0.0000)"""
     if isinstance(node, dict):
         for k, v in node.items():
             if k == "frac":
-                assert v is not None and 0.0 < v <= 1.0, f"{path}.frac = {v!r} is not a physical fraction of the roofline"
+                assert v is not None and (0.0 < v or (shared_gpu and v == 0.0)) and v <= 1.0, f"{path}.frac = {v!r} is not a physical fraction of the roofline"
             else:
-                assert_fracs_physical(v, f"{path}.{k}")
+                assert_fracs_physical(v, f"{path}.{k}", shared_gpu)
     elif isinstance(node, list):
         for i, v in enumerate(node):
-            assert_fracs_physical(v, f"{path}[{i}]")
+            assert_fracs_physical(v, f"{path}[{i}]", shared_gpu)
 
 
 def spmv_stored_bytes(n, nnz, coded, patterns, values=0):

@@ -181,6 +181,11 @@ int  liship_spmv_csr_set_local_runs(int on);
  * new plan, as with value records.  Never an error when the matrix does not qualify (fewer than 65 536 rows, short lists, columns outside [0, n)); 2 = out of memory,
  * the plan unchanged.  liship_csr_plan_reordered: listed columns of the reordered form (0: none); liship_spmv_csr_set_reorder(0): A/B switch, same bits. */
 int  liship_csr_plan_reorder(liship_csr_plan_t plan, const int *ptr, const int *index, const double *value, int min_items_per_listed, void *stream);
+/* the same with a permutation to try first (HOST, n entries: new position -> row), e.g. the one a plan of the same sparsity pattern found: a matrix whose values were
+ * edited needs a new plan but not a new walk.  A hint that is not a permutation, or does not shorten the lists enough, is dropped for a walk.
+ * liship_csr_plan_reorder_permutation: the permutation of the reordered form to the host (LISHIP_ERR_ARG when the plan has none). */
+int  liship_csr_plan_reorder_with(liship_csr_plan_t plan, const int *ptr, const int *index, const double *value, int min_items_per_listed, const int *perm_hint, void *stream);
+int  liship_csr_plan_reorder_permutation(liship_csr_plan_t plan, int *perm_host);
 long long liship_csr_plan_reordered(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_reorder(int on);
 /* the reordered form as a matrix of its own -- P A P^T: its plan (owned by `plan`), arrays and the permutation perm[new position] = original row -- for callers that keep

@@ -107,6 +107,8 @@ _LISHIP = {
     "liship_spmv_csr_set_local_runs": (_ci, [_ci]),
     "liship_csr_plan_reorder": (_ci, [_vp, _vp, _vp, _vp, _ci, _vp]),
     "liship_csr_plan_reordered": (C.c_longlong, [_vp]),
+    "liship_csr_plan_reorder_with": (_ci, [_vp, _vp, _vp, _vp, _ci, _vp, _vp]),
+    "liship_csr_plan_reorder_permutation": (_ci, [_vp, _vp]),
     "liship_spmv_csr_set_reorder": (_ci, [_ci]),
     "liship_csr_plan_reordered_form": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_permute_gather_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),

@@ -415,6 +415,9 @@ static LIS_INT up_d(double **dst, const double *src, size_t count)
 	return LIS_SUCCESS;
 }
 
+/* the permutation the last reordered plan found (liship_csr_plan_reorder), tried first by the next plan of the same size: a program that edits A->value between solves
+ * rebuilds the HBM copy and its plan each time, and the walk (1.4 s on the Queen-class matrix) is most of that.  One entry; a hint is only ever a hint. */
+static struct { int *perm; int n; long long nnz; } renum_cache;
 /* rows of the local matrix that reference no ghost column, as one maximal run [b,e) */
 /* the row split of a CSR-ordered HBM matrix and, where its columns allow it, the one-byte column codes
  * (liship.h "index coding"; LIS_AMD_NO_INDEX_CODES=1 keeps the 4 B indices for A/B measurements) */
@@ -443,8 +446,18 @@ LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int
 		if (rc && rc != 2) HIPCHK(rc);
 		/* lists that stay long say the numbering has no locality: rows and columns renumbered inside the plan (one rank: its row ranges follow the original order) */
 		if (!rc && !lisg.no_reorder && lisg.nprocs == 1 && dvalue) {
-			rc = liship_csr_plan_reorder(*plan, dptr, dindex, dvalue, 0, lisg.stream);
+			long long pnnz = 0;
+			(void)liship_csr_plan_info(*plan, NULL, &pnnz, NULL);
+			const int *hint = (renum_cache.perm && renum_cache.n == n && renum_cache.nnz == pnnz) ? renum_cache.perm : NULL;      /* the last walk, when the sizes match (a matrix whose values were edited; any other matrix drops it for a walk of its own) */
+			rc = liship_csr_plan_reorder_with(*plan, dptr, dindex, dvalue, 0, hint, lisg.stream);
 			if (rc && rc != 2) HIPCHK(rc);
+			if (!rc && liship_csr_plan_reordered(*plan) > 0 && !hint) {
+				int *keep = (int *)malloc(sizeof(int) * (size_t)n);
+				if (keep && liship_csr_plan_reorder_permutation(*plan, keep) == 0) {
+					free(renum_cache.perm);
+					renum_cache.perm = keep; renum_cache.n = n; renum_cache.nnz = pnnz;
+				} else free(keep);
+			}
 		}
 	}
 	/* a plan that streams index[] / codes (no row patterns): the plane of a structured grid from the band of the matrix, for the XCD strips */
@@ -792,6 +805,7 @@ static unsigned long long host_arrays_hash(LIS_MATRIX A)
 LIS_INT lisd_mat_ready(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
+	if (d->ready && d->solve_holds) return LIS_SUCCESS;       /* a solve in the plan's numbering has P A P^T's arrays in d->ptr / index / value (lis_solver.c): the copy stays as it is until the solve hands it back */
 	if (d->ready && !d->device_only) {
 		if (d->host_written) lisd_mat_free(A);             /* a host write to one of its arrays was seen (page fault): the copy is stale */
 		else if (lisg.matrix_check && d->checked && lisp_lazy_arrays(A) == 0 && host_arrays_hash(A) != d->host_hash) {

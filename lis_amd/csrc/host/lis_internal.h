@@ -51,6 +51,7 @@ typedef struct {
 typedef struct {
 	int ready;                 /* HBM copy is built */
 	int host_written;          /* the program wrote one of the host arrays the copy was built from (page fault, lis_pages.c): rebuilt before the next use */
+	int solve_holds;           /* lis_solve_kernel swapped the renumbered form in (plan, ptr, index, value are the plan's P A P^T): no rebuild, no free until it swaps back */
 	int checked;               /* LIS_AMD_MATRIX_CHECK=1: host_hash holds the hash of the host arrays the copy was built from */
 	unsigned long long host_hash;
 	int device_only;           /* arrays were adopted from the caller; no host copy exists */

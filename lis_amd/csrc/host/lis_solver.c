@@ -1108,6 +1108,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		    dm->plan && Awork->np == Awork->n && liship_csr_plan_reordered_form(dm->plan, &in, &rp, &ri, &rv, &renum) == 0) {
 			held_plan = dm->plan; held_ptr = dm->ptr; held_index = dm->index; held_value = dm->value;
 			dm->plan = in; dm->ptr = (int *)rp; dm->index = (int *)ri; dm->value = (double *)rv;
+			dm->solve_holds = 1;
 			renumbered = 1;
 		}
 	}
@@ -1215,6 +1216,7 @@ out:
 	if (renumbered) {           /* the caller's matrix again, whatever happened */
 		lisd_mat *dm = MDEV(Awork);
 		dm->plan = held_plan; dm->ptr = held_ptr; dm->index = held_index; dm->value = held_value;
+		dm->solve_holds = 0;
 	}
 	if (renum_b) lisd_pool_put(renum_b, c.len * sizeof(double));
 	if (renum_d) lisd_pool_put(renum_d, c.len * sizeof(double));

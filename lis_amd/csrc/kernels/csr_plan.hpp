@@ -1760,7 +1760,29 @@ extern "C" long long liship_csr_plan_reordered(liship_csr_plan_t p) { return (p 
 // Builds the reordered form when the plan keeps block-local columns AND its lists are long (more than one listed column per `min_items_per_listed` non-zeros: 4 by
 // default when 0 is passed) AND the renumbered matrix lists at most 3/4 of them.  Never an error when the matrix does not qualify; out of memory (2) leaves the plan as
 // it was.  Host work at plan time: index[] comes to the host once (4 B per non-zero), the walk visits every entry twice.
+static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, const int *hint, void *stream);
 extern "C" int liship_csr_plan_reorder(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, void *stream)
+{
+    return reorder_impl(p, ptr, idx, val, min_items_per_listed, nullptr, stream);
+}
+// the same with a permutation to try first (host, n entries: new position -> row; e.g. the one a plan of the same sparsity pattern found -- a matrix whose values were
+// edited needs a new plan but not a new walk).  Anything that is not a permutation of 0 .. n-1, or that does not shorten the lists enough, is dropped for a walk.
+extern "C" int liship_csr_plan_reorder_with(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, const int *perm_hint, void *stream)
+{
+    if (perm_hint) {
+        const int rc = reorder_impl(p, ptr, idx, val, min_items_per_listed, perm_hint, stream);
+        if (rc || (p && p->inner)) return rc;
+    }
+    return reorder_impl(p, ptr, idx, val, min_items_per_listed, nullptr, stream);
+}
+// the permutation of the reordered form to the host (n entries); LISHIP_ERR_ARG when the plan has none
+extern "C" int liship_csr_plan_reorder_permutation(liship_csr_plan_t p, int *out_host)
+{
+    if (!p || !p->inner || !p->r_perm || !out_host) return LISHIP_ERR_ARG;
+    HIP_TRY(hipMemcpy(out_host, p->r_perm, sizeof(int) * (size_t)p->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, const int *hint, void *stream)
 {
     if (!p || (p->n > 0 && (!ptr || !idx || !val))) return LISHIP_ERR_ARG;
     if (p->inner || !p->products || p->codes || p->n < 65536 || p->nnz <= 0 || g_variant != 0) return 0;
@@ -1769,16 +1791,24 @@ extern "C" int liship_csr_plan_reorder(liship_csr_plan_t p, const int *ptr, cons
     hipStream_t st = as_stream(stream);
     const int n = p->n;
     const size_t nnz = (size_t)p->nnz;
-    int *hptr = (int *)malloc(sizeof(int) * ((size_t)n + 1)), *hidx = (int *)malloc(sizeof(int) * nnz), *order = (int *)malloc(sizeof(int) * (size_t)n);
+    int *hptr = (int *)malloc(sizeof(int) * ((size_t)n + 1)), *hidx = hint ? nullptr : (int *)malloc(sizeof(int) * nnz), *order = (int *)malloc(sizeof(int) * (size_t)n);
     int *hptr2 = (int *)malloc(sizeof(int) * ((size_t)n + 1));
     int *inv = nullptr;
     liship_csr_plan_s *in = nullptr;
-    hipError_t e = (hptr && hidx && order && hptr2) ? hipSuccess : hipErrorOutOfMemory;
-    bool keep = false;
+    hipError_t e = (hptr && (hint || hidx) && order && hptr2) ? hipSuccess : hipErrorOutOfMemory;
+    bool keep = false, have_order = false;
     if (e == hipSuccess) e = hipMemcpyAsync(hptr, ptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hidx, idx, sizeof(int) * nnz, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && !hint) e = hipMemcpyAsync(hidx, idx, sizeof(int) * nnz, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess && cuthill_mckee(n, hptr, hidx, order)) {
+    if (e == hipSuccess && hint) {                                 // a permutation of 0 .. n-1, or nothing
+        std::vector<unsigned char> seen((size_t)n, 0);
+        have_order = true;
+        for (int i = 0; i < n && have_order; i++) {
+            const int r = hint[i];
+            if (r < 0 || r >= n || seen[r]) have_order = false; else { seen[r] = 1; order[i] = r; }
+        }
+    } else if (e == hipSuccess) have_order = cuthill_mckee(n, hptr, hidx, order);
+    if (e == hipSuccess && have_order) {
         bool moved = false;
         hptr2[0] = 0;
         for (int r = 0; r < n; r++) { hptr2[r + 1] = hptr2[r] + (hptr[order[r] + 1] - hptr[order[r]]); moved = moved || order[r] != r; }

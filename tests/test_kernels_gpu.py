@@ -821,6 +821,25 @@ def test_reordered_plan_bit_exact(lib, kind):
             check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, d0.ptr, dy.ptr, None))
             got[on] = dy.to_host()
         assert np.array_equal(got[0], got[1]) and np.array_equal(np.signbit(got[0]), np.signbit(got[1]))
+    if kind == "nodes":
+        # a plan for the same pattern with other values (a matrix edited in place): the first plan's permutation as a hint, no second walk; a broken hint is dropped
+        check(lib.liship_csr_plan_set_first_term_initialises(plan, 0))
+        perm = np.empty(n, np.int32)
+        check(lib.liship_csr_plan_reorder_permutation(plan, perm.ctypes.data))
+        assert np.array_equal(np.sort(perm), np.arange(n))
+        val2 = val * rng.uniform(0.5, 1.5, len(val))
+        dval2 = DA.from_host(val2, np.float64)
+        yref2 = orc.spmv_csr(ptr, idx, val2, x)
+        for hint in (perm, np.zeros(n, np.int32), np.arange(n, dtype=np.int32)[::-1].copy()):        # the walk's own; not a permutation; a permutation that is no better
+            plan2 = C.c_void_p()
+            check(lib.liship_csr_plan_create(C.byref(plan2), n, dptr.ptr, None))
+            check(lib.liship_csr_plan_localize_columns(plan2, dptr.ptr, didx.ptr, None))
+            check(lib.liship_csr_plan_reorder_with(plan2, dptr.ptr, didx.ptr, dval2.ptr, 0, hint.ctypes.data, None))
+            assert lib.liship_csr_plan_reordered(plan2) == re             # the same lists either way (the walk is deterministic)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_f64(plan2, dptr.ptr, didx.ptr, dval2.ptr, dx.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host(), yref2, equal_nan=True)
+            check(lib.liship_csr_plan_destroy(plan2))
     lib.liship_spmv_csr_set_reorder(1)
     check(lib.liship_csr_plan_destroy(plan))
 

@@ -172,6 +172,8 @@ int  liship_spmv_csr_set_local_columns(int on);
  * liship_spmv_csr_set_local_runs(0): A/B switch (the full lists), same bits */
 int  liship_csr_plan_local_runs(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_local_runs(int on);
+/* 0: the block-local kernel keeps one entry per lane and step (eight 2 B position loads) instead of pairs of neighbouring entries (four 4 B loads, 16 B LDS accesses): A/B, same bits */
+int  liship_spmv_csr_set_local_pairs(int on);
 /* Reordering (round 5): when the lists of a plan with block-local columns are long -- more than one listed column per `min_items_per_listed` non-zeros (0: the
  * default, 4) -- or a long-row plan could not have lists at all (more than 2048 distinct columns per row block): the signs of a numbering without locality -- the plan renumbers rows and columns by a Cuthill-McKee walk of the matrix graph (on the host, at plan
  * time: index[] is read back once), builds P A P^T in HBM (the same entries in the same in-row order) with a block-local plan of its own, and keeps it when that plan

@@ -50,6 +50,7 @@ int g_row_block_dots = 0;        // liship_spmv_csr_set_row_block_dots: 1 keeps 
 int g_dom_march = 1;             // liship_spmv_csr_set_dom_march: 0 keeps 7-point plans with value records on the gathering dominant-pattern kernel (A/B)
 int g_block_rows = 1;            // liship_spmv_csr_set_block_rows: 0 keeps plans with block rows (liship_csr_plan_encode_block_rows) on the row-by-row kernels (A/B); 2: plans of any size take them (tests)
 int g_wide_union = 1;            // liship_spmv_csr_set_wide_union: 0 keeps plans whose rows take turns on several patterns off the staged value-record kernel (plan time, A/B)
+int g_local_pairs = 1;           // liship_spmv_csr_set_local_pairs: 0 keeps the block-local kernel on one entry per lane and step (eight 2 B position loads) -- A/B, same bits
 int g_reorder = 1;               // liship_spmv_csr_set_reorder: 0 keeps the products of reordered plans (liship_csr_plan_reorder) on the original numbering (A/B; the same bits)
 int g_team = 1;                  // liship_spmv_csr_set_team: 0 keeps patterned rows of 8..32 entries on the one-lane-per-row pattern kernel
 
@@ -644,7 +645,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
 // RUNS (round 5): the sorted distinct columns of a row block of a mesh with 3 unknowns per node come in TRIPLES of consecutive columns; when every list of the plan
 // is made of such triples (liship_csr_plan_localize_columns checks) the kernel reads one 4 B run start per triple instead of three 4 B columns -- a third of the list
 // bytes (Queen class: 384 -> 128 MB of 3.34 GB) and a third of the list loads -- and a lane gathers its triple's three x.  Same stage contents: same bits.
-template <int BLOCK, int WORK, int DOT = 0, int NDPL = 2, int XCAP = NDPL * BLOCK, bool RPOS = false, bool RUNS = false>
+template <int BLOCK, int WORK, int DOT = 0, int NDPL = 2, int XCAP = NDPL * BLOCK, bool RPOS = false, bool RUNS = false, bool PAIR = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((RPOS && XCAP <= 1536) ? 8 : 4)))      // four 512-lane workgroups per CU want <= 64 VGPRs (the fused-dot forms took 66 - 68)
 void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
                            const unsigned short *__restrict__ lcol, const int *__restrict__ dcol,
@@ -714,8 +715,16 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
         }
     }
     // RPOS: the positions of this lane's own items (entry B.k0 + lane + g * BLOCK of the matrix), eight 2 B loads -- a wavefront's 64 lanes read 128 B each
+    // PAIR: a lane owns PAIRS of neighbouring entries (2 (lane + g BLOCK), + 1 counted from the aligned start ka): four 4 B position loads instead of eight 2 B ones,
+    // 16 B LDS accesses in the products phase.  The up to 7 entries in front of the block's first one come along (the previous block's values and positions: a product
+    // nobody reads, parked in front of the first row)
     unsigned short pos[8];
-    if (RPOS) {
+    unsigned pp[4];
+    const int cnt2 = (cnt + 1) & ~1;
+    if (RPOS && PAIR) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) pp[g] = *reinterpret_cast<const unsigned *>(lcol + ka + min(2 * ((int)threadIdx.x + g * BLOCK), cnt2 - 2));
+    } else if (RPOS) {
 #pragma unroll
         for (int g = 0; g < 8; g++) pos[g] = lcol[min(B.k0 + (int)threadIdx.x + g * BLOCK, B.k1 - 1)];
     }
@@ -740,7 +749,21 @@ void spmv_csr_local_kernel(const int *__restrict__ ptr, const int *__restrict__ 
     __syncthreads();
 
     // products in place, from LDS alone: entry e of the stage by lane e % BLOCK, 8 in flight per lane
-    if (RPOS) {
+    if (RPOS && PAIR) {
+        v2f64 vv[4];
+        double x0[4], x1[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int e = min(2 * ((int)threadIdx.x + g * BLOCK), cnt2 - 2);
+            vv[g] = *reinterpret_cast<const v2f64 *>(valL + GUARD + e);
+            x0[g] = xL[min((int)(pp[g] & 0xffffu), XCAP - 1)]; x1[g] = xL[min((int)(pp[g] >> 16), XCAP - 1)];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int e = 2 * ((int)threadIdx.x + g * BLOCK);
+            if (e < cnt) { v2f64 pr; pr.x = vv[g].x * x0[g]; pr.y = vv[g].y * x1[g]; *reinterpret_cast<v2f64 *>(valL + GUARD + e) = pr; }
+        }
+    } else if (RPOS) {
         const int e0 = (B.k0 - ka) + (int)threadIdx.x;
         double vv[8], xv[8];
 #pragma unroll

@@ -1619,6 +1619,7 @@ static void build_local_runs(liship_csr_plan_s *p, hipStream_t st)
 extern "C" int liship_csr_plan_local_runs(liship_csr_plan_t p) { return (p && p->lcol && p->drun && p->droff) ? 3 : 0; }
 static int g_local_runs = 1;
 extern "C" int liship_spmv_csr_set_local_runs(int on) { g_local_runs = on ? 1 : 0; return 0; }
+extern "C" int liship_spmv_csr_set_local_pairs(int on) { g_local_pairs = on ? 1 : 0; return 0; }
 
 extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *ptr, const int *idx, void *stream)
 {

@@ -411,10 +411,14 @@ void launch_local(const LaunchArgs &a, const double *w, double *partial, const d
     constexpr Geometry g = kGeom[is_local_geom(G) ? G : LOCAL_GEOM];
     const int ndpl = a.plan ? a.plan->ndpl : 2, xcap = a.plan ? a.plan->xcap : 1024;
     const bool runs = a.plan && a.plan->drun && a.plan->droff && g_local_runs;      // lists of triples: the positions-in-registers forms read the run starts
-#define GOL(NDPL_, XCAP_, RPOS_) spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, RPOS_><<<a.nb, g.block, 0, a.st>>>( \
-        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, nullptr, nullptr, a.rowmap)
-#define GOLR(NDPL_, XCAP_) spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, true, true><<<a.nb, g.block, 0, a.st>>>( \
-        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, a.plan->drun, a.plan->droff, a.rowmap)
+#define GOL(NDPL_, XCAP_, RPOS_) do { if (RPOS_ && g_local_pairs) spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, RPOS_, false, RPOS_><<<a.nb, g.block, 0, a.st>>>( \
+        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, nullptr, nullptr, a.rowmap); \
+    else spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, RPOS_><<<a.nb, g.block, 0, a.st>>>( \
+        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, nullptr, nullptr, a.rowmap); } while (0)
+#define GOLR(NDPL_, XCAP_) do { if (g_local_pairs) spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, true, true, true><<<a.nb, g.block, 0, a.st>>>( \
+        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, a.plan->drun, a.plan->droff, a.rowmap); \
+    else spmv_csr_local_kernel<g.block, g.work, DOT, NDPL_, XCAP_, true, true><<<a.nb, g.block, 0, a.st>>>( \
+        a.ptr, a.idx, a.val, a.lcol, a.dcol, a.doff, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, w, partial, guard, pstride, g_uniform_rows, a.plan->drun, a.plan->droff, a.rowmap); } while (0)
     if constexpr (G == LOCAL_GEOM_R) { if (ndpl == 4) { if (runs) GOLR(4, 2048); else GOL(4, 2048, true); } else { if (runs) GOLR(2, 1024); else GOL(2, 1024, true); } }
     else if constexpr (G == LOCAL_GEOM4) {
         if (xcap <= 1024) { if (runs) GOLR(2, 1024); else GOL(2, 1024, true); }

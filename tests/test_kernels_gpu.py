@@ -687,9 +687,10 @@ def test_spmv_csr_local_columns(lib, name):
     elif name in ("fem2_14", "band_60", "fem3_ghost_columns", "wide_77_random", "p3d_30"):      # pairs, a band, triples torn by the shifted columns, no lists at all
         assert runs == 0, name
     results = {}
-    for on in (1, 2, 0):                                   # 2: the lists in full although the plan has the runs (A/B: same bits)
+    for on in (1, 2, 3, 0):                                # 2: the lists in full although the plan has the runs; 3: one entry per lane and step instead of pairs (A/B: same bits)
         lib.liship_spmv_csr_set_local_columns(1 if on else 0)
         lib.liship_spmv_csr_set_local_runs(0 if on == 2 else 1)
+        lib.liship_spmv_csr_set_local_pairs(0 if on == 3 else 1)
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
         assert np.array_equal(dy.to_host(), yref), on
@@ -722,10 +723,11 @@ def test_spmv_csr_local_columns(lib, name):
         results[on] = out
     lib.liship_spmv_csr_set_local_columns(1)
     lib.liship_spmv_csr_set_local_runs(1)
+    lib.liship_spmv_csr_set_local_pairs(1)
     check(lib.liship_csr_plan_destroy(plan))
-    assert len(results[0]) == len(results[1]) == len(results[2])
-    for a, b, c in zip(results[0], results[1], results[2]):
-        assert np.array_equal(a, b) and np.array_equal(a, c)                        # same partial sums, same fold: the reductions agree to the bit too
+    assert len(results[0]) == len(results[1]) == len(results[2]) == len(results[3])
+    for a, b, c, d in zip(results[0], results[1], results[2], results[3]):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)                        # same partial sums, same fold: the reductions agree to the bit too
 
 
 def permute_csr(ptr, idx, val, perm):

@@ -57,6 +57,15 @@ if os.environ.get("QUEEN_REORDER_AB") == "1" and reordered:      # round 5: rows
             yh = np.empty(n); lib.lis_vector_get_values(vy, 0, n, yh.ctypes.data_as(capi.P_DBL))
             print(f"reorder={on}: {m:.4f} ms  y sha256 {hashlib.sha256(yh.tobytes()).hexdigest()[:16]}", flush=True)
     lib.liship_spmv_csr_set_reorder(1)
+if os.environ.get("QUEEN_PAIRS_AB") == "1":            # round 5: pairs of entries per lane (4 B position loads, 16 B LDS accesses) against single entries, interleaved
+    import hashlib
+    for rep in range(3):
+        for on in (1, 0):
+            lib.liship_spmv_csr_set_local_pairs(on)
+            m = timed()
+            yh = np.empty(n); lib.lis_vector_get_values(vy, 0, n, yh.ctypes.data_as(capi.P_DBL))
+            print(f"pairs={on}: {m:.4f} ms  y sha256 {hashlib.sha256(yh.tobytes()).hexdigest()[:16]}", flush=True)
+    lib.liship_spmv_csr_set_local_pairs(1)
 if os.environ.get("QUEEN_CHAIN") == "1" and reordered:         # a caller's own iteration: y = A x, x = y * c, ... -- x is fresh from the kernel before (cache-resident), not 3 GB old
     def chain():
         va, vb = vx, vy

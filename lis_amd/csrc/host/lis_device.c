@@ -105,7 +105,8 @@ int lis_amd_trim_count(void)
 		if (pool[i].p) { (void)liship_free(pool[i].p); pool[i].p = NULL; pool[i].bytes = 0; freed++; }
 	return freed;
 }
-LIS_INT lis_amd_trim(void) { (void)lis_amd_trim_count(); return LIS_SUCCESS; }
+static void renum_cache_drop(void);
+LIS_INT lis_amd_trim(void) { (void)lis_amd_trim_count(); renum_cache_drop(); return LIS_SUCCESS; }
 
 void *lis_amd_stream(void) { return lisd_init() == LIS_SUCCESS ? lisg.stream : NULL; }
 
@@ -418,6 +419,7 @@ static LIS_INT up_d(double **dst, const double *src, size_t count)
 /* the permutation the last reordered plan found (liship_csr_plan_reorder), tried first by the next plan of the same size: a program that edits A->value between solves
  * rebuilds the HBM copy and its plan each time, and the walk (1.4 s on the Queen-class matrix) is most of that.  One entry; a hint is only ever a hint. */
 static struct { int *perm; int n; long long nnz; } renum_cache;
+static void renum_cache_drop(void) { free(renum_cache.perm); renum_cache.perm = NULL; renum_cache.n = 0; renum_cache.nnz = 0; }
 /* rows of the local matrix that reference no ghost column, as one maximal run [b,e) */
 /* the row split of a CSR-ordered HBM matrix and, where its columns allow it, the one-byte column codes
  * (liship.h "index coding"; LIS_AMD_NO_INDEX_CODES=1 keeps the 4 B indices for A/B measurements) */

@@ -1713,12 +1713,17 @@ __global__ void csr_reorder_inverse(int n, const int *__restrict__ perm, int *__
 // one wavefront per row of P A P^T: entry j of new row r is entry j of row perm[r], its column renumbered
 __global__ __launch_bounds__(256)
 void csr_reorder_rows(int n, const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val, const int *__restrict__ perm,
-                      const int *__restrict__ inv, const int *__restrict__ ptr2, int *__restrict__ idx2, double *__restrict__ val2)
+                      const int *__restrict__ inv, const int *__restrict__ ptr2, int *__restrict__ idx2, double *__restrict__ val2, int *__restrict__ bad)
 {
     const int r = blockIdx.x * (256 / WAVE) + (int)threadIdx.x / WAVE, lane = (int)threadIdx.x & (WAVE - 1);
     if (r >= n) return;
     const int src = perm[r], s = ptr[src], len = ptr[src + 1] - s, d = ptr2[r];
-    for (int j = lane; j < len; j += WAVE) { idx2[d + j] = inv[idx[s + j]]; val2[d + j] = val[s + j]; }
+    for (int j = lane; j < len; j += WAVE) {
+        const int c = idx[s + j];
+        if (c < 0 || c >= n) { *bad = 1; idx2[d + j] = 0; }        // a column outside [0, n) (ghost columns: a hinted permutation skipped the walk that would have seen it)
+        else idx2[d + j] = inv[c];
+        val2[d + j] = val[s + j];
+    }
 }
 
 // Cuthill-McKee on the host: order[] = the vertices in the order a breadth-first walk meets them, the unvisited neighbours of a vertex appended in index order; the
@@ -1816,7 +1821,8 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
         if (moved) {
             e = hipMalloc(&p->r_perm, sizeof(int) * ((size_t)n + 2));
             if (e == hipSuccess) e = hipMalloc(&p->r_ptr, sizeof(int) * ((size_t)n + 2));
-            if (e == hipSuccess) e = hipMalloc(&inv, sizeof(int) * ((size_t)n + 2));
+            if (e == hipSuccess) e = hipMalloc(&inv, sizeof(int) * ((size_t)n + 4));
+            if (e == hipSuccess) e = hipMemsetAsync(inv + n, 0, sizeof(int), st);            // inv[n]: the kernel's flag
             if (e == hipSuccess) e = hipMalloc(&p->r_idx, sizeof(int) * (nnz + 16));
             if (e == hipSuccess) e = hipMalloc(&p->r_val, sizeof(double) * (nnz + 16));
             if (e == hipSuccess) e = hipMalloc(&p->r_x, sizeof(double) * ((size_t)n + 2));
@@ -1826,11 +1832,13 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
             if (e == hipSuccess) e = hipMemsetAsync(p->r_val + nnz, 0, sizeof(double) * 16, st);
             if (e == hipSuccess) {
                 csr_reorder_inverse<<<(n + 255) / 256, 256, 0, st>>>(n, p->r_perm, inv);
-                csr_reorder_rows<<<(n + 3) / 4, 256, 0, st>>>(n, ptr, idx, val, p->r_perm, inv, p->r_ptr, p->r_idx, p->r_val);
+                csr_reorder_rows<<<(n + 3) / 4, 256, 0, st>>>(n, ptr, idx, val, p->r_perm, inv, p->r_ptr, p->r_idx, p->r_val, inv + n);
                 e = hipGetLastError();
             }
+            int bad = 0;
+            if (e == hipSuccess) e = hipMemcpyAsync(&bad, inv + n, sizeof(int), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e == hipSuccess) {
+            if (e == hipSuccess && !bad) {
                 int rc = liship_csr_plan_create(&in, n, p->r_ptr, stream);
                 if (!rc) rc = liship_csr_plan_localize_columns(in, p->r_ptr, p->r_idx, stream);
                 if (rc) e = (hipError_t)rc;

@@ -824,6 +824,17 @@ def test_reordered_plan_bit_exact(lib, kind):
             got[on] = dy.to_host()
         assert np.array_equal(got[0], got[1]) and np.array_equal(np.signbit(got[0]), np.signbit(got[1]))
     if kind == "nodes":
+        # ghost columns (>= n): the walk refuses; a hinted permutation skips the walk and the renumbering kernel refuses instead -- no reordered form either way
+        idx_g = idx.copy(); idx_g[7] = n + 3
+        didx_g = DA.from_host(idx_g, np.int32)
+        for hint in (None, np.arange(n, dtype=np.int32)[::-1].copy()):
+            plan_g = C.c_void_p()
+            check(lib.liship_csr_plan_create(C.byref(plan_g), n, dptr.ptr, None))
+            check(lib.liship_csr_plan_localize_columns(plan_g, dptr.ptr, didx_g.ptr, None))
+            check(lib.liship_csr_plan_reorder_with(plan_g, dptr.ptr, didx_g.ptr, dval.ptr, 0, None if hint is None else hint.ctypes.data, None))
+            assert lib.liship_csr_plan_reordered(plan_g) == 0
+            check(lib.liship_csr_plan_destroy(plan_g))
+    if kind == "nodes":
         # a plan for the same pattern with other values (a matrix edited in place): the first plan's permutation as a hint, no second walk; a broken hint is dropped
         check(lib.liship_csr_plan_set_first_term_initialises(plan, 0))
         perm = np.empty(n, np.int32)

@@ -180,7 +180,9 @@ int  liship_spmv_csr_set_local_pairs(int on);
  * lists at most 3/4 of the columns.  liship_spmv_csr_f64 then gathers x into the new numbering, walks the renumbered rows and stores row r where the original row
  * lives: every y[i] is the reference's sum (lis_matvec_csr.c:97-109), term by term -- the same bits.  Row-range products and the fused reductions keep the original
  * numbering (liship_csr_plan_fused_dots returns 0: the caller runs the product and one reduction pass).  The values are copied: a matrix whose value[] changes needs a
- * new plan, as with value records.  Never an error when the matrix does not qualify (fewer than 65 536 rows, short lists, columns outside [0, n)); 2 = out of memory,
+ * new plan, as with value records.  Short rows (plans of the row-gather kernel, no lists): the 128 B lines of x a row block touches are counted instead -- more than one
+ * per 4 entries starts the walk, at most half of them afterwards keeps its result; such a plan keeps its PRODUCTS in the caller's numbering (permuting x and y
+ * would cost more than the product) and serves liship_csr_plan_reordered_form alone.  Never an error when the matrix does not qualify (fewer than 65 536 rows, short lists, columns outside [0, n)); 2 = out of memory,
  * the plan unchanged.  liship_csr_plan_reordered: listed columns of the reordered form (0: none); liship_spmv_csr_set_reorder(0): A/B switch, same bits. */
 int  liship_csr_plan_reorder(liship_csr_plan_t plan, const int *ptr, const int *index, const double *value, int min_items_per_listed, void *stream);
 /* the same with a permutation to try first (HOST, n entries: new position -> row), e.g. the one a plan of the same sparsity pattern found: a matrix whose values were

@@ -545,7 +545,8 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
                                double *__restrict__ y, const v2i32 *__restrict__ blk,
                                int bfirst, int nb, Rows RW, int nnz_total, int xs_plane,
                                const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                               const double *__restrict__ guard = nullptr, int pstride = 0)
+                               const double *__restrict__ guard = nullptr, int pstride = 0,
+                               const int *__restrict__ rowmap = nullptr)      // reordered plans: row r of the matrix this launch walks is y[rowmap[r]]
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     const int row_begin = RW.rb, row_end = RW.re;
@@ -567,15 +568,15 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     const int ka = B.k0 & ~3;                       // 16 B aligned start for both streams
     const int nq = (B.k1 - ka + 3) >> 2;            // quads of 4 non-zeros
     if ((B.k1 - ka) > CAP || ka + 4 * nq > nnz_total) {     // long row / tail of the arrays
-        block_by_products<BLOCK, CAP, 4, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0);
+        block_by_products<BLOCK, CAP, 4, DOT>(valL, ptr, idx, val, x, y, B, dots, acc0, rowmap);
         __syncthreads();
         publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
         return;
     }
 
     const int rmine = B.r0 + (int)threadIdx.x;
-    int s_first = 0, e_first = 0;
-    if (rmine < B.r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; }
+    int s_first = 0, e_first = 0, y_first = rmine;
+    if (rmine < B.r1) { s_first = ptr[rmine]; e_first = ptr[rmine + 1]; if (rowmap) y_first = rowmap[rmine]; }
 
     // linear copies of both slices, every load instruction fully coalesced (16 B per lane, 1 KiB per wave): global -> LDS directly, each wave lands
     // 64 x 16 B at a wave-uniform LDS base; lanes past the end re-read the last valid 16 B (their LDS slot is never used)
@@ -598,8 +599,8 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
     __syncthreads();
 
     for (int r = rmine; r < B.r1; r += BLOCK) {
-        int s = s_first, e = e_first;
-        if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; }
+        int s = s_first, e = e_first, yr = y_first;
+        if (r != rmine) { s = ptr[r]; e = ptr[r + 1]; yr = rowmap ? rowmap[r] : r; }
         const int len = e - s;
         const int off = s - ka;
         const double wr = dots.fetch(r);
@@ -620,7 +621,7 @@ void spmv_csr_rowgather_kernel(const int *__restrict__ ptr, const int *__restric
                 acc += (j0 + u < len) ? t : -0.0;           // -0.0 terms leave any sum bit-unchanged
             }
         }
-        store_stream(y + r, acc);
+        store_stream(y + yr, acc);
         dots.add_loaded(wr, acc);
     }
     publish_dots<BLOCK, DOT>(dots, dot_scratch, partial, lb, pstride ? pstride : nb);
@@ -826,7 +827,7 @@ template <int BLOCK, int PASS, int LOCAL_SORT>
 __global__ __launch_bounds__(BLOCK)
 void csr_local_build(const v2i32 *__restrict__ blk, const int *__restrict__ idx, int cap, int ndmax,
                      int *__restrict__ nd_out, const int *__restrict__ doff, int *__restrict__ dcol,
-                     unsigned short *__restrict__ lcol)
+                     unsigned short *__restrict__ lcol, int shift = 0)      // shift (PASS 0 only): count distinct (column >> shift) -- 4: the 128 B lines of x a block touches
 {
     __shared__ int keys[LOCAL_SORT];
     __shared__ int dist[LOCAL_SORT / 2 + 256];
@@ -835,7 +836,7 @@ void csr_local_build(const v2i32 *__restrict__ blk, const int *__restrict__ idx,
     const int k0 = blk[b].y, k1 = blk[b + 1].y, cnt = k1 - k0;
     if (cnt <= 0 || cnt > cap || cnt > LOCAL_SORT / 2 + 256) { if (PASS == 0 && t == 0) nd_out[b] = 0; return; }
     if (PASS == 1 && doff[b + 1] == doff[b]) return;
-    for (int i = t; i < LOCAL_SORT; i += BLOCK) keys[i] = i < cnt ? idx[k0 + i] : 0x7fffffff;
+    for (int i = t; i < LOCAL_SORT; i += BLOCK) keys[i] = i < cnt ? (idx[k0 + i] >> shift) : 0x7fffffff;
     __syncthreads();
     for (int k = 2; k <= LOCAL_SORT; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {

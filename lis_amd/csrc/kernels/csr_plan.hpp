@@ -1759,13 +1759,33 @@ bool cuthill_mckee(int n, const int *ptr, const int *idx, int *order)
 }
 } // namespace
 
+// 128 B lines of x (columns >> 4) the row blocks of a plan touch, summed over the blocks; -1: could not be counted
+static long long block_lines(const liship_csr_plan_s *p, const int *idx, hipStream_t st)
+{
+    const int nb = p->nblocks;
+    if (nb <= 0) return 0;
+    int *nd_dev = nullptr;
+    if (hipMalloc(&nd_dev, sizeof(int) * (size_t)(nb + 1)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    std::vector<int> nd((size_t)nb);
+    csr_local_build<256, 0, 8192><<<nb, 256, 0, st>>>(p->blk, idx, kGeom[p->geom].work + SLACK, 0x7fffffff, nd_dev, nullptr, nullptr, nullptr, 4);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(nd.data(), nd_dev, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(nd_dev);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -1; }
+    long long total = 0;
+    for (int b = 0; b < nb; b++) total += nd[b];
+    return total;
+}
+
 extern "C" int liship_spmv_csr_set_reorder(int on) { g_reorder = on ? 1 : 0; return 0; }
 // listed columns of the reordered form (compare liship_csr_plan_localized: the original numbering's), 0 when the plan has none
 extern "C" long long liship_csr_plan_reordered(liship_csr_plan_t p) { return (p && p->inner) ? p->inner->ndcol : 0; }
 
 // Builds the reordered form when the plan keeps block-local columns AND its lists are long (more than one listed column per `min_items_per_listed` non-zeros: 4 by
-// default when 0 is passed) AND the renumbered matrix lists at most 3/4 of them.  Never an error when the matrix does not qualify; out of memory (2) leaves the plan as
-// it was.  Host work at plan time: index[] comes to the host once (4 B per non-zero), the walk visits every entry twice.
+// default when 0 is passed) AND the renumbered matrix lists at most 3/4 of them; for short rows (the row-gather kernel) the 128 B lines of x a row block touches take
+// the lists' place (more than one per 4 entries; at most half of them afterwards).  Never an error when the matrix does not qualify; out of memory (2) leaves the plan
+// as it was.  Host work at plan time: index[] comes to the host once (4 B per non-zero), the walk visits every entry twice.
 static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, const int *hint, void *stream);
 extern "C" int liship_csr_plan_reorder(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, void *stream)
 {
@@ -1791,12 +1811,20 @@ extern "C" int liship_csr_plan_reorder_permutation(liship_csr_plan_t p, int *out
 static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, const int *hint, void *stream)
 {
     if (!p || (p->n > 0 && (!ptr || !idx || !val))) return LISHIP_ERR_ARG;
-    if (p->inner || !p->products || p->codes || p->n < 65536 || p->nnz <= 0 || g_variant != 0) return 0;
+    if (p->inner || p->codes || p->rowpat || p->n < 65536 || p->nnz <= 0 || g_variant != 0) return 0;
     const int mi = min_items_per_listed > 0 ? min_items_per_listed : 4;
     if (p->lcol && p->ndcol * (long long)mi <= p->nnz) return 0;   // lists short already: the numbering is local (no lists at all: too many distinct columns per row block)
     hipStream_t st = as_stream(stream);
     const int n = p->n;
     const size_t nnz = (size_t)p->nnz;
+    // short rows (the row-gather kernel: no lists to judge by): the 128 B lines of x a row block touches.  A grid in its natural order touches ~0.05 per entry (the
+    // same lines serve a block's neighbouring rows), a numbering without locality ~1
+    long long lines_before = 0;
+    if (!p->products) {
+        lines_before = block_lines(p, idx, st);
+        if (lines_before < 0) return 0;                            // (could not count: leave the plan alone)
+        if (lines_before * mi <= p->nnz) return 0;
+    }
     int *hptr = (int *)malloc(sizeof(int) * ((size_t)n + 1)), *hidx = hint ? nullptr : (int *)malloc(sizeof(int) * nnz), *order = (int *)malloc(sizeof(int) * (size_t)n);
     int *hptr2 = (int *)malloc(sizeof(int) * ((size_t)n + 1));
     int *inv = nullptr;
@@ -1840,9 +1868,14 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e == hipSuccess && !bad) {
                 int rc = liship_csr_plan_create(&in, n, p->r_ptr, stream);
-                if (!rc) rc = liship_csr_plan_localize_columns(in, p->r_ptr, p->r_idx, stream);
+                if (!rc && in->products) rc = liship_csr_plan_localize_columns(in, p->r_ptr, p->r_idx, stream);
                 if (rc) e = (hipError_t)rc;
-                else keep = in->lcol && (!p->lcol || in->ndcol * 4 <= p->ndcol * 3);
+                else if (in->products) keep = in->lcol && (!p->lcol || in->ndcol * 4 <= p->ndcol * 3);
+                else {                                              // short rows: at most half the lines
+                    const long long lines_after = block_lines(in, p->r_idx, st);
+                    keep = lines_after >= 0 && lines_after * 2 <= lines_before;
+                    if (keep) in->ndcol = lines_after;              // (what liship_csr_plan_reordered reports for such a plan)
+                }
             }
         }
     }

@@ -92,7 +92,7 @@ void launch_rowgather(const LaunchArgs &a)
 {
     constexpr Geometry g = kGeom[G];
     spmv_csr_rowgather_kernel<g.block, g.work, U>
-        <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, xcd_strips(a));
+        <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, a.nnz, xcd_strips(a), nullptr, nullptr, nullptr, 0, a.rowmap);
 }
 
 template <int G, int VEC>
@@ -632,7 +632,15 @@ static bool plan_runs_dom(const liship_csr_plan_s *p)       // the dominant-patt
 }
 // the reordered form serves whole-matrix products of the plan in its shipped configuration; row ranges and the fused reductions (whose partial sums follow the
 // ORIGINAL row blocks) keep the original numbering
-static bool plan_runs_reordered(const liship_csr_plan_s *p) { return p && p->inner && p->inner->lcol && g_reorder && g_local_cols && g_variant == 0; }
+static bool plan_has_reordered_form(const liship_csr_plan_s *p)      // ... for callers that iterate in the new numbering (liship_csr_plan_reordered_form)
+{
+    if (!p || !p->inner || !g_reorder || g_variant != 0) return false;
+    return p->inner->products ? (p->inner->lcol && g_local_cols) : true;
+}
+// ... and for single products: long rows only.  A product in the caller's numbering pays a gather of x and a scattered store of y, one random access per node each:
+// with 3 unknowns per node and ~70 entries per row that is 8 % of the product (Queen class), with scalar unknowns and 7 entries per row it is four times the product
+// (tools/scrambled_short_rows_probe.py: 160^3 7-point, numbered at random inside runs of 4096: 0.130 ms as it is, 0.257 ms renumbered per product -- and 0.06 inside a solve)
+static bool plan_runs_reordered(const liship_csr_plan_s *p) { return plan_has_reordered_form(p) && p->inner->products; }
 static int launch_reordered(liship_csr_plan_t p, const double *x, double *y, hipStream_t st)
 {
     const liship_csr_plan_s *q = p->inner;
@@ -646,7 +654,7 @@ extern "C" int liship_csr_plan_fused_dots(liship_csr_plan_t p) { return (plan_ru
 // whole iterations in the new numbering (lis_solve: b and x0 gathered once, every product, dot and update on renumbered vectors, x scattered back at the end).
 extern "C" int liship_csr_plan_reordered_form(liship_csr_plan_t p, liship_csr_plan_t *inner, const int **ptr, const int **idx, const double **val, const int **perm)
 {
-    if (!plan_runs_reordered(p) || !inner || !ptr || !idx || !val || !perm) return LISHIP_ERR_ARG;
+    if (!plan_has_reordered_form(p) || !inner || !ptr || !idx || !val || !perm) return LISHIP_ERR_ARG;
     *inner = p->inner; *ptr = p->r_ptr; *idx = p->r_idx; *val = p->r_val; *perm = p->r_perm;
     return 0;
 }

@@ -769,12 +769,22 @@ def _scrambled_fem(kind):
     return permute_csr(ptr, idx, val, perm)
 
 
-@pytest.mark.parametrize("kind", ["nodes", "rows", "two_meshes_and_loose_rows", "natural"])
+def _scrambled_poisson(scramble, vary=True):
+    """short rows: the 7-point matrix of a 48 x 48 x 40 grid (with varying coefficients: products only; without: the SPD matrix the solvers want), its nodes numbered at random (or not)"""
+    ptr, idx, val = orc.poisson3d(40, 48, 48)
+    n = len(ptr) - 1
+    if vary:
+        val = val * np.random.default_rng(8).uniform(0.5, 1.5, len(val))
+    return permute_csr(ptr, idx, val, np.random.default_rng(9).permutation(n)) if scramble else (ptr, idx, val)
+
+
+@pytest.mark.parametrize("kind", ["nodes", "rows", "two_meshes_and_loose_rows", "natural", "short_rows", "short_rows_natural"])
 def test_reordered_plan_bit_exact(lib, kind):
     """liship_csr_plan_reorder: a matrix numbered without locality is renumbered inside the plan (Cuthill-McKee, P A P^T in HBM); y keeps the oracle's bits
     (lis_matvec_csr.c:97-109: every row sum is its own terms in stored order) with the reordered form on and off, special values included; the fused entry
     points step aside, row ranges keep the original numbering; a mesh in its natural numbering is left alone"""
-    ptr, idx, val = _fem(28) if kind == "natural" else _scrambled_fem(kind)
+    short = kind.startswith("short_rows")
+    ptr, idx, val = _scrambled_poisson(kind == "short_rows") if short else _fem(28) if kind == "natural" else _scrambled_fem(kind)
     n = len(ptr) - 1
     assert n >= 65536
     rng = np.random.default_rng(3)
@@ -786,16 +796,24 @@ def test_reordered_plan_bit_exact(lib, kind):
     check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
     check(lib.liship_csr_plan_localize_columns(plan, dptr.ptr, didx.ptr, None))
     listed = lib.liship_csr_plan_localized(plan)
-    assert (listed > 0) == (kind != "rows")            # unknowns scattered one by one: more than 2048 distinct columns per row block, no lists in the caller's numbering
+    assert (listed > 0) == (kind != "rows" and not short)      # unknowns scattered one by one: more than 2048 distinct columns per row block, no lists in the caller's numbering; short rows: no lists at all (the row-gather kernel)
     check(lib.liship_csr_plan_reorder(plan, dptr.ptr, didx.ptr, dval.ptr, 0, None))
     re = lib.liship_csr_plan_reordered(plan)
-    if kind == "natural":
+    if kind in ("natural", "short_rows_natural"):
         assert re == 0 and lib.liship_csr_plan_fused_dots(plan) == 1
         check(lib.liship_csr_plan_reorder(plan, dptr.ptr, didx.ptr, dval.ptr, 1 << 20, None))      # forced to try: the walk cannot list 1/4 fewer columns than the mesh order
         assert lib.liship_csr_plan_reordered(plan) == 0
     else:
         assert re > 0 and (listed == 0 or re * 4 <= listed * 3), (re, listed)
-        assert lib.liship_csr_plan_fused_dots(plan) == 0
+        assert lib.liship_csr_plan_fused_dots(plan) == (1 if short else 0)       # short rows: products stay in the caller's numbering (permuting x and y costs more than the product)
+        # the reordered form as a matrix of its own (what lis_solve iterates on): gather x, multiply by P A P^T, scatter y -- the oracle's bits
+        inner, rp, ri, rv, pm = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.liship_csr_plan_reordered_form(plan, C.byref(inner), C.byref(rp), C.byref(ri), C.byref(rv), C.byref(pm)))
+        xp, yp, yb = DA(n, np.float64), DA.from_host(np.full(n, np.nan), np.float64), DA.from_host(np.full(n, np.nan), np.float64)
+        check(lib.liship_permute_gather_f64(n, pm, dx.ptr, xp.ptr, None))
+        check(lib.liship_spmv_csr_f64(inner, rp, ri, rv, xp.ptr, yp.ptr, None))
+        check(lib.liship_permute_scatter_f64(n, pm, yp.ptr, yb.ptr, None))
+        assert np.array_equal(yb.to_host(), yref, equal_nan=True)
     ys = {}
     for on in (1, 0, 1):
         lib.liship_spmv_csr_set_reorder(on)
@@ -804,7 +822,7 @@ def test_reordered_plan_bit_exact(lib, kind):
         ys[on] = dy.to_host()
         assert np.array_equal(ys[on], yref, equal_nan=True), (kind, on)
         assert np.array_equal(np.signbit(ys[on]), np.signbit(yref))
-    if re:
+    if re and not short:
         work, res, dw = DA(lib.liship_reduce_work_bytes() // 8, np.float64), DA.zeros(2, np.float64), DA.from_host(x, np.float64)
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         assert lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, 1, res.ptr, work.ptr, None) != 0      # the caller runs product + reduction

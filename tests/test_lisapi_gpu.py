@@ -679,9 +679,19 @@ def test_solves_in_the_numbering_of_a_reordered_plan(lib, options):
     the caller's numbering).  The same recurrences on renumbered vectors: the counts of the run in the caller's numbering (+-2 %: the sums fold in another order),
     the same solution, the residual the criterion asked for"""
     from test_kernels_gpu import _scrambled_fem
+    _renumbered_solve_case(lib, *_scrambled_fem("nodes"), options)
+
+
+@pytest.mark.parametrize("options", ["-i cg -p jacobi", "-i bicgstab -p none", "-i gmres -restart 30 -p none"])
+def test_solves_in_the_numbering_of_a_reordered_plan_short_rows(lib, options):
+    """the same for short rows: a 7-point matrix (varying coefficients) whose grid nodes are numbered at random -- the row-gather kernel on P A P^T"""
+    from test_kernels_gpu import _scrambled_poisson
+    _renumbered_solve_case(lib, *_scrambled_poisson(True, vary=False), options)
+
+
+def _renumbered_solve_case(lib, ptr, idx, val, options):
     dll = lib.dll
     dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
-    ptr, idx, val = _scrambled_fem("nodes")
     n = len(ptr) - 1
     A = lisdrv.make_csr(lib, ptr, idx, val)
     assert dll.lis_amd_matrix_reordered(A) > 0
@@ -701,7 +711,8 @@ def test_solves_in_the_numbering_of_a_reordered_plan(lib, options):
     lib.liship_spmv_csr_set_reorder(1)
     a, c = runs[1], runs[0]
     assert a["err"] == c["err"] == 0 and a["status"] == c["status"] == 0, (a["status"], c["status"])
-    assert abs(a["iter"] - c["iter"]) <= max(1, c["iter"] // 50), (a["iter"], c["iter"])
+    slack = c["iter"] // 7 if "bicgstab" in options or "cgs" in options else c["iter"] // 50      # (BiCGSTAB's count moves with the fold order of its dots: 137 .. 153 over the reference's own thread counts at 64^3)
+    assert abs(a["iter"] - c["iter"]) <= max(1, slack), (a["iter"], c["iter"])
     assert np.linalg.norm(a["x"] - c["x"]) <= 1e-9 * np.linalg.norm(c["x"])
     assert np.linalg.norm(a["x"] - xt) <= 1e-8 * np.linalg.norm(xt)
     r = b - orc.spmv_csr(ptr, idx, val, a["x"])

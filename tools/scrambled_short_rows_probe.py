@@ -29,11 +29,30 @@ for tag, (p, i, v) in (("natural", (ptr, idx, val * rng.uniform(0.5, 1.5, len(va
     check(lib.liship_csr_plan_encode_indices(plan, dptr.ptr, didx.ptr, None))
     check(lib.liship_csr_plan_encode_row_patterns(plan, dptr.ptr, None))
     check(lib.liship_csr_plan_scan_band(plan, dptr.ptr, didx.ptr, None))
-    for _ in range(10):
+    for reorder in ((0, 1) if tag == "scrambled" else (0,)):
+      if reorder:
+        check(lib.liship_csr_plan_reorder(plan, dptr.ptr, didx.ptr, dval.ptr, 0, None))
+        print("   reordered:", lib.liship_csr_plan_reordered(plan), "lines of x over the row blocks", flush=True)
+      for _ in range(10):
         check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None))
-    check(lib.liship_timer_start(timer, None))
-    for _ in range(30):
-        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None))
-    check(lib.liship_timer_stop(timer, None)); check(lib.liship_device_synchronize()); check(lib.liship_timer_elapsed_ms(timer, C.byref(ev)))
-    ms = ev.value / 30
-    print(f"{tag:10s} n={n} coded={lib.liship_csr_plan_coded(plan)} patterns={lib.liship_csr_plan_row_patterns(plan)}  {ms:.4f} ms  {(12 * len(i) + 20 * n) / ms / 1e6 / 8000:.3f} of 8 TB/s on 12 B/nnz + 20 B/row", flush=True)
+      check(lib.liship_timer_start(timer, None))
+      for _ in range(30):
+          check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, x.ptr, y.ptr, None))
+      check(lib.liship_timer_stop(timer, None)); check(lib.liship_device_synchronize()); check(lib.liship_timer_elapsed_ms(timer, C.byref(ev)))
+      ms = ev.value / 30
+      print(f"{tag:10s} n={n} coded={lib.liship_csr_plan_coded(plan)} patterns={lib.liship_csr_plan_row_patterns(plan)}  {ms:.4f} ms  {(12 * len(i) + 20 * n) / ms / 1e6 / 8000:.3f} of 8 TB/s on 12 B/nnz + 20 B/row", flush=True)
+
+# the same numbering through the Lis API: lis_solve iterates in the plan's numbering (b, x0 gathered once, x scattered back)
+if os.environ.get("SOLVES", "1") == "1":
+    import lisdrv
+    from lis_amd import _capi as capi
+    assert lib.initialize([]) == 0
+    lib.dll.lis_amd_set_residency(1)
+    A = lisdrv.make_csr(lib, ptr2, idx2, val[src])          # (constant coefficients: the SPD matrix)
+    b = orc.spmv_csr(ptr2, idx2, val[src], np.ones(n))
+    for opts in ("-i cg -p jacobi", "-i bicgstab -p none", "-i gmres -restart 30 -p none"):
+        for on in (1, 0):
+            lib.liship_spmv_csr_set_reorder(on)
+            out = lisdrv.solve(lib, A, b, opts + " -tol 1e-10 -maxiter 300")
+            print(f"{opts:32s} renumbered={lib.dll.lis_amd_last_solve_renumbered()}  iter {out['iter']}  {out['iter'] / out['itime']:.0f} it/s  |x-1|max {np.abs(out['x'] - 1).max():.2e}", flush=True)
+    lib.liship_spmv_csr_set_reorder(1)

@@ -659,8 +659,8 @@ def stencil27_leg(lib, np, C, stream, G=256, launches=30):
 def queen_class_leg(lib, np, C, reps=50):
     """BASELINE config 4's stand-in (SuiteSparse Queen_4147 cannot be fetched: tests/golden/gen_queen_class.c writes a 3-dof mesh of its size -- 4.1 M rows, 2.9e8
     non-zeros, node numbers scrambled inside runs of 1024 -- as a symmetric Matrix Market file) through lis_input, lis_matvec and lis_solve, as a Lis program would.
-    The plan finds no locality in the numbering and renumbers the matrix (liship_csr_plan_reorder); lis_matvec then pays a gather and a scattered store per product,
-    lis_solve iterates in the plan's numbering.  Host-clock ms per product over `reps` calls behind one synchronize; never fatal: an error string instead."""
+    The plan finds no locality in the numbering and builds a renumbered form (liship_csr_plan_reorder): lis_solve iterates in that numbering, single products keep
+    the caller's (they would pay a gather and a scattered store each: timed beside, opt-in).  Host-clock ms per product over `reps` calls behind one synchronize; never fatal: an error string instead."""
     path = None
     try:
         import time
@@ -700,14 +700,13 @@ def queen_class_leg(lib, np, C, reps=50):
                "block_local_columns_listed": listed, "listed_after_reordering": reordered,
                "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),
                "contract_bytes": 12 * nnz + 20 * n, "contract_frac": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4),
-               "kernel": "spmv_csr_local_kernel" + (" on P A P^T + csr_reorder_gather_kernel" if reordered else "")}
-        if reordered:
-            check = lib.liship_spmv_csr_set_reorder
-            check(0)
+               "kernel": "spmv_csr_local_kernel", "numbering": "the caller's for single products; lis_solve iterates on P A P^T (renumbered: 1)" if reordered else "the caller's"}
+        if reordered:                       # opt-in (LIS_AMD_REORDER_PRODUCTS=1): single products through P A P^T too -- a gather of x and a scattered store of y per product
+            lib.liship_spmv_csr_set_reorder(2)
             try:
-                out["spmv_ms_callers_numbering"] = round(timed(), 4)
+                out["spmv_ms_products_renumbered"] = round(timed(), 4)
             finally:
-                check(1)
+                lib.liship_spmv_csr_set_reorder(1)
         rhs = capi.PV()
         assert lib.lis_vector_duplicate(A, C.byref(rhs)) == 0 and lib.lis_matvec(A, ones, rhs) == 0          # b = A*1 (test/test1.c:138-139)
         out["solves"] = {}

@@ -175,15 +175,18 @@ int  liship_spmv_csr_set_local_runs(int on);
 /* 0: the block-local kernel keeps one entry per lane and step (eight 2 B position loads) instead of pairs of neighbouring entries (four 4 B loads, 16 B LDS accesses): A/B, same bits */
 int  liship_spmv_csr_set_local_pairs(int on);
 /* Reordering (round 5): when the lists of a plan with block-local columns are long -- more than one listed column per `min_items_per_listed` non-zeros (0: the
- * default, 4) -- or a long-row plan could not have lists at all (more than 2048 distinct columns per row block): the signs of a numbering without locality -- the plan renumbers rows and columns by a Cuthill-McKee walk of the matrix graph (on the host, at plan
- * time: index[] is read back once), builds P A P^T in HBM (the same entries in the same in-row order) with a block-local plan of its own, and keeps it when that plan
- * lists at most 3/4 of the columns.  liship_spmv_csr_f64 then gathers x into the new numbering, walks the renumbered rows and stores row r where the original row
- * lives: every y[i] is the reference's sum (lis_matvec_csr.c:97-109), term by term -- the same bits.  Row-range products and the fused reductions keep the original
- * numbering (liship_csr_plan_fused_dots returns 0: the caller runs the product and one reduction pass).  The values are copied: a matrix whose value[] changes needs a
- * new plan, as with value records.  Short rows (plans of the row-gather kernel, no lists): the 128 B lines of x a row block touches are counted instead -- more than one
- * per 4 entries starts the walk, at most half of them afterwards keeps its result; such a plan keeps its PRODUCTS in the caller's numbering (permuting x and y
- * would cost more than the product) and serves liship_csr_plan_reordered_form alone.  Never an error when the matrix does not qualify (fewer than 65 536 rows, short lists, columns outside [0, n)); 2 = out of memory,
- * the plan unchanged.  liship_csr_plan_reordered: listed columns of the reordered form (0: none); liship_spmv_csr_set_reorder(0): A/B switch, same bits. */
+ * default, 4) -- or a long-row plan could not have lists at all (more than 2048 distinct columns per row block): the signs of a numbering without locality -- the plan
+ * renumbers rows and columns by a Cuthill-McKee walk of the matrix graph (on the host, at plan time: index[] is read back once), builds P A P^T in HBM (the same entries
+ * in the same in-row order) with a plan of its own, and keeps it when that plan lists at most 3/4 of the columns.  Short rows (plans of the row-gather kernel, no lists):
+ * the 128 B lines of x a row block touches are counted instead -- more than one per 4 entries starts the walk, at most half of them afterwards keeps its result.
+ * WHO USES IT: liship_csr_plan_reordered_form hands P A P^T out as a matrix of its own, for callers that keep whole iterations in the new numbering (lis_solve).
+ * Products through the original plan keep the caller's numbering by default: a single product would have to gather x into the numbering and scatter y out of it, one
+ * random access per node each, which costs what the better kernel gains (Queen class) or several times the product (scalar unknowns, short rows).
+ * liship_spmv_csr_set_reorder(2) lets whole-matrix products of LONG-row plans take it all the same (row r stored where the original row lives: every y[i] is the
+ * reference's sum, lis_matvec_csr.c:97-109, term by term -- the same bits; row-range products and the fused reductions keep the original numbering, and
+ * liship_csr_plan_fused_dots returns 0); 1 is the default, 0 switches the reordered form off altogether (A/B).  The values are copied: a matrix whose value[] changes
+ * needs a new plan, as with value records.  Never an error when the matrix does not qualify (fewer than 65 536 rows, coded indices, short lists, columns outside
+ * [0, n)); 2 = out of memory, the plan unchanged.  liship_csr_plan_reordered: listed columns (lines of x for short rows) of the reordered form, 0: none. */
 int  liship_csr_plan_reorder(liship_csr_plan_t plan, const int *ptr, const int *index, const double *value, int min_items_per_listed, void *stream);
 /* the same with a permutation to try first (HOST, n entries: new position -> row), e.g. the one a plan of the same sparsity pattern found: a matrix whose values were
  * edited needs a new plan but not a new walk.  A hint that is not a permutation, or does not shorten the lists enough, is dropped for a walk.
@@ -191,7 +194,7 @@ int  liship_csr_plan_reorder(liship_csr_plan_t plan, const int *ptr, const int *
 int  liship_csr_plan_reorder_with(liship_csr_plan_t plan, const int *ptr, const int *index, const double *value, int min_items_per_listed, const int *perm_hint, void *stream);
 int  liship_csr_plan_reorder_permutation(liship_csr_plan_t plan, int *perm_host);
 long long liship_csr_plan_reordered(liship_csr_plan_t plan);
-int  liship_spmv_csr_set_reorder(int on);
+int  liship_spmv_csr_set_reorder(int mode);
 /* the reordered form as a matrix of its own -- P A P^T: its plan (owned by `plan`), arrays and the permutation perm[new position] = original row -- for callers that keep
  * whole iterations in the new numbering (lis_solve gathers b and x0 once and scatters x back at the end: no per-product passes); LISHIP_ERR_ARG when the plan has none
  * (or it is switched off).  liship_permute_gather_f64: xp[i] = x[perm[i]]; liship_permute_scatter_f64: x[perm[i]] = xp[i] (x and xp distinct). */

@@ -267,6 +267,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_local_columns = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_REORDER");
 		lisg.no_reorder = (r && r[0] == '1');
+		r = getenv("LIS_AMD_REORDER_PRODUCTS");        /* single products of renumbered long-row plans take the renumbered form too (gather of x, scattered store of y): opt-in */
+		if (r && r[0] == '1') (void)liship_spmv_csr_set_reorder(2);
 		r = getenv("LIS_AMD_NO_MARCHING");
 		lisg.no_marching = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_TEAM_KERNELS");

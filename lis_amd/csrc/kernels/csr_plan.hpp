@@ -1778,7 +1778,7 @@ static long long block_lines(const liship_csr_plan_s *p, const int *idx, hipStre
     return total;
 }
 
-extern "C" int liship_spmv_csr_set_reorder(int on) { g_reorder = on ? 1 : 0; return 0; }
+extern "C" int liship_spmv_csr_set_reorder(int mode) { g_reorder = mode == 2 ? 2 : mode ? 1 : 0; return 0; }
 // listed columns of the reordered form (compare liship_csr_plan_localized: the original numbering's), 0 when the plan has none
 extern "C" long long liship_csr_plan_reordered(liship_csr_plan_t p) { return (p && p->inner) ? p->inner->ndcol : 0; }
 

@@ -805,7 +805,10 @@ def test_reordered_plan_bit_exact(lib, kind):
         assert lib.liship_csr_plan_reordered(plan) == 0
     else:
         assert re > 0 and (listed == 0 or re * 4 <= listed * 3), (re, listed)
-        assert lib.liship_csr_plan_fused_dots(plan) == (1 if short else 0)       # short rows: products stay in the caller's numbering (permuting x and y costs more than the product)
+        assert lib.liship_csr_plan_fused_dots(plan) == 1                          # by default products stay in the caller's numbering (permuting x and y per product eats the gain)
+        lib.liship_spmv_csr_set_reorder(2)
+        assert lib.liship_csr_plan_fused_dots(plan) == (1 if short else 0)       # opted in: long rows only
+        lib.liship_spmv_csr_set_reorder(1)
         # the reordered form as a matrix of its own (what lis_solve iterates on): gather x, multiply by P A P^T, scatter y -- the oracle's bits
         inner, rp, ri, rv, pm = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(lib.liship_csr_plan_reordered_form(plan, C.byref(inner), C.byref(rp), C.byref(ri), C.byref(rv), C.byref(pm)))
@@ -815,7 +818,7 @@ def test_reordered_plan_bit_exact(lib, kind):
         check(lib.liship_permute_scatter_f64(n, pm, yp.ptr, yb.ptr, None))
         assert np.array_equal(yb.to_host(), yref, equal_nan=True)
     ys = {}
-    for on in (1, 0, 1):
+    for on in (2, 0, 1, 2):                              # 2: whole-matrix products of long-row plans take the reordered form (opt-in); 1: the default, products in the caller's numbering
         lib.liship_spmv_csr_set_reorder(on)
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
@@ -835,12 +838,12 @@ def test_reordered_plan_bit_exact(lib, kind):
         x0 = np.zeros(n); x0[::2] = -0.0
         d0 = DA.from_host(x0, np.float64)
         got = {}
-        for on in (1, 0):
+        for on in (2, 0):
             lib.liship_spmv_csr_set_reorder(on)
             dy = DA.from_host(np.full(n, np.nan), np.float64)
             check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, d0.ptr, dy.ptr, None))
             got[on] = dy.to_host()
-        assert np.array_equal(got[0], got[1]) and np.array_equal(np.signbit(got[0]), np.signbit(got[1]))
+        assert np.array_equal(got[0], got[2]) and np.array_equal(np.signbit(got[0]), np.signbit(got[2]))
     if kind == "nodes":
         # ghost columns (>= n): the walk refuses; a hinted permutation skips the walk and the renumbering kernel refuses instead -- no reordered form either way
         idx_g = idx.copy(); idx_g[7] = n + 3
@@ -854,6 +857,7 @@ def test_reordered_plan_bit_exact(lib, kind):
             check(lib.liship_csr_plan_destroy(plan_g))
     if kind == "nodes":
         # a plan for the same pattern with other values (a matrix edited in place): the first plan's permutation as a hint, no second walk; a broken hint is dropped
+        lib.liship_spmv_csr_set_reorder(2)
         check(lib.liship_csr_plan_set_first_term_initialises(plan, 0))
         perm = np.empty(n, np.int32)
         check(lib.liship_csr_plan_reorder_permutation(plan, perm.ctypes.data))

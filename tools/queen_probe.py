@@ -51,7 +51,7 @@ reordered = dll.lis_amd_matrix_reordered(A)
 if os.environ.get("QUEEN_REORDER_AB") == "1" and reordered:      # round 5: rows and columns renumbered inside the plan against the caller's numbering, interleaved
     import hashlib
     for rep in range(3):
-        for on in (1, 0):
+        for on in (2, 0):                              # 2: products take the renumbered form (opt-in); 0 / 1: the caller's numbering
             lib.liship_spmv_csr_set_reorder(on)
             m = timed()
             yh = np.empty(n); lib.lis_vector_get_values(vy, 0, n, yh.ctypes.data_as(capi.P_DBL))
@@ -78,7 +78,7 @@ if os.environ.get("QUEEN_CHAIN") == "1" and reordered:         # a caller's own 
         dll.lis_amd_synchronize()
         return (time.time() - t0) / reps * 1e3
     for rep in range(3):
-        for on in (1, 0):
+        for on in (2, 0):
             lib.liship_spmv_csr_set_reorder(on)
             lisdrv.set_vector(lib, vx, xs)
             print(f"chain (product + scale) reorder={on}: {chain():.4f} ms per step", flush=True)

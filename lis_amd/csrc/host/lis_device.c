@@ -423,7 +423,11 @@ static void renum_cache_drop(void) { free(renum_cache.perm); renum_cache.perm = 
 /* rows of the local matrix that reference no ghost column, as one maximal run [b,e) */
 /* the row split of a CSR-ordered HBM matrix and, where its columns allow it, the one-byte column codes
  * (liship.h "index coding"; LIS_AMD_NO_INDEX_CODES=1 keeps the 4 B indices for A/B measurements) */
-LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue)
+static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue, int reorder);
+LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue) { return csr_plan_impl(plan, n, dptr, dindex, dvalue, 1); }
+/* ... of a matrix no solve iterates on (a transposed copy, a scaled copy, the halves of a split JAD matrix): no renumbered form (products would not use it) */
+LIS_INT lisd_csr_plan_plain(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue) { return csr_plan_impl(plan, n, dptr, dindex, dvalue, 0); }
+static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue, int reorder)
 {
 	int rc = liship_csr_plan_create(plan, n, dptr, lisg.stream);
 	if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_create(plan, n, dptr, lisg.stream);   /* the plan allocates in the kernel layer */
@@ -447,7 +451,7 @@ LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int
 		if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
 		if (rc && rc != 2) HIPCHK(rc);
 		/* lists that stay long say the numbering has no locality: rows and columns renumbered inside the plan (one rank: its row ranges follow the original order) */
-		if (!rc && !lisg.no_reorder && lisg.nprocs == 1 && dvalue) {
+		if (!rc && reorder && !lisg.no_reorder && lisg.nprocs == 1 && dvalue) {
 			long long pnnz = 0;
 			(void)liship_csr_plan_info(*plan, NULL, &pnnz, NULL);
 			const int *hint = (renum_cache.perm && renum_cache.n == n && renum_cache.nnz == pnnz) ? renum_cache.perm : NULL;      /* the last walk, when the sizes match (a matrix whose values were edited; any other matrix drops it for a walk of its own) */
@@ -675,7 +679,7 @@ static LIS_INT try_row_form(LIS_MATRIX A, lisd_mat *d, int *taken)
  * (t0 = D[i]*x[i]; t0 += ...: lis_matvec_csr.c:70-87) bit for bit, signed zeros included.  JAD is not one chain:
  * (D x + sum over L) + sum over U with both partial sums started at 0 (lis_matvec_jad.c:60-140) -- two products, then two
  * element-wise passes (lisd_spmv). */
-static LIS_INT upload_rows(lisd_mat *d, LIS_INT rows, LIS_INT *ptr, LIS_INT *idx, LIS_SCALAR *val, int **dptr, int **didx, double **dval, liship_csr_plan_t *plan, int from_zero)
+static LIS_INT upload_rows(lisd_mat *d, LIS_INT rows, LIS_INT *ptr, LIS_INT *idx, LIS_SCALAR *val, int **dptr, int **didx, double **dval, liship_csr_plan_t *plan, int from_zero, int half)
 {
 	const LIS_INT nnz = ptr[rows];
 	LIS_INT err = up_i(dptr, ptr, (size_t)rows + 1);
@@ -684,7 +688,8 @@ static LIS_INT upload_rows(lisd_mat *d, LIS_INT rows, LIS_INT *ptr, LIS_INT *idx
 	if (!err) { int rc = liship_stream_synchronize(lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
 	free(ptr); free(idx); free(val);
 	if (err) return err;
-	LISCHK(lisd_csr_plan(plan, rows, *dptr, *didx, *dval));
+	if (half) LISCHK(lisd_csr_plan_plain(plan, rows, *dptr, *didx, *dval));
+	else LISCHK(lisd_csr_plan(plan, rows, *dptr, *didx, *dval));
 	if (!from_zero) HIPCHK(liship_csr_plan_set_first_term_initialises(*plan, 1));
 	(void)d;
 	return LIS_SUCCESS;
@@ -695,9 +700,9 @@ static LIS_INT upload_split(LIS_MATRIX A, lisd_mat *d)
 	LIS_INT *ptr, *idx; LIS_SCALAR *val;
 	if (A->matrix_type == LIS_MATRIX_JAD) {
 		LISCHK(lisi_split_jad_part(A, 0, &ptr, &idx, &val));
-		LISCHK(upload_rows(d, A->n, ptr, idx, val, &d->ptr, &d->index, &d->value, &d->plan, 1));
+		LISCHK(upload_rows(d, A->n, ptr, idx, val, &d->ptr, &d->index, &d->value, &d->plan, 1, 1));
 		LISCHK(lisi_split_jad_part(A, 1, &ptr, &idx, &val));
-		LISCHK(upload_rows(d, A->n, ptr, idx, val, &d->u_ptr, &d->u_index, &d->u_value, &d->u_plan, 1));
+		LISCHK(upload_rows(d, A->n, ptr, idx, val, &d->u_ptr, &d->u_index, &d->u_value, &d->u_plan, 1, 1));
 		LISCHK(up_d(&d->dsplit, A->D->value, (size_t)A->n));
 		HIPCHK(lisd_malloc((void **)&d->jw, ((size_t)A->n + 16) * sizeof(double)));
 		d->type = LIS_MATRIX_CSR;
@@ -707,7 +712,7 @@ static LIS_INT upload_split(LIS_MATRIX A, lisd_mat *d)
 	LIS_INT rows; int from_zero;
 	LISCHK(lisi_split_rows(A, &rows, &ptr, &idx, &val, &from_zero));
 	d->nnz = ptr[rows];
-	LISCHK(upload_rows(d, rows, ptr, idx, val, &d->ptr, &d->index, &d->value, &d->plan, from_zero));
+	LISCHK(upload_rows(d, rows, ptr, idx, val, &d->ptr, &d->index, &d->value, &d->plan, from_zero, 0));
 	d->type = LIS_MATRIX_CSR;
 	d->n = rows;                          /* BSR: nr*bnr rows, the padding rows included (the vectors carry the pad) */
 	return LIS_SUCCESS;
@@ -913,6 +918,8 @@ void lisd_mat_free(LIS_MATRIX A)
 	if (d->u_plan) (void)liship_csr_plan_destroy(d->u_plan);
 	(void)liship_free(d->u_ptr); (void)liship_free(d->u_index); (void)liship_free(d->u_value); (void)liship_free(d->dsplit); (void)liship_free(d->jw);
 	if (d->t_plan) (void)liship_csr_plan_destroy(d->t_plan);
+	if (d->rt_plan) (void)liship_csr_plan_destroy(d->rt_plan);
+	(void)liship_free(d->rt_ptr); (void)liship_free(d->rt_index); (void)liship_free(d->rt_value);
 	(void)liship_free(d->t_ptr); (void)liship_free(d->t_index); (void)liship_free(d->t_value); (void)liship_free(d->wr); (void)liship_free(d->t_diag);
 	(void)liship_free(d->ell_codes); (void)liship_free(d->ell_dict);
 	(void)liship_free(d->ptr); (void)liship_free(d->index); (void)liship_free(d->row);

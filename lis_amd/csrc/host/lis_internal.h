@@ -69,6 +69,12 @@ typedef struct {
 	double *t_value;
 	liship_csr_plan_t t_plan;
 	double *wr;                /* received ghost contributions (reverse halo) */
+	/* the same for the renumbered form (P A P^T)^T: swapped with the set above while a solve iterates in the plan's numbering (lis_solver.c), so that BiCG & co.
+	 * find a transposed copy in the numbering they run in */
+	int rt_ready, rt_nnz;
+	int *rt_ptr, *rt_index;
+	double *rt_value;
+	liship_csr_plan_t rt_plan;
 	double *t_diag;            /* split CSR: the diagonal, added to the off-diagonal sums of A^T x by one element-wise pass (lis_matvech.c) */
 	/* halo (multi-GPU) */
 	int halo_ready;
@@ -186,6 +192,7 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A);                       /* build / upload 
 LIS_INT lisd_spmv_t(LIS_MATRIX A, double *dx, double *dy);    /* y[0..np) = A^T x, ghost rows reduced to owners */
 LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy);      /* y = A x on device pointers (halo included) */
 LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue);   /* row split + index codes */
+LIS_INT lisd_csr_plan_plain(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue);    /* the same without a renumbered form (matrices no solve iterates on) */
 LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq); /* sums -> reduce_out */
 LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq, double *result); /* sums -> result (HBM) */
 LIS_INT lisd_fetch(int count, double *out);                   /* reduce_out[0..count) -> host, cross-rank fold */

@@ -217,7 +217,7 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 		free(hptr); free(hidx); free(hval);
 		if (err) return err;
 	}
-	LISCHK(lisd_csr_plan(&d->t_plan, d->t_rows, d->t_ptr, d->t_index, d->t_value));
+	LISCHK(lisd_csr_plan_plain(&d->t_plan, d->t_rows, d->t_ptr, d->t_index, d->t_value));
 	HIPCHK(liship_stream_synchronize(lisg.stream));
 	d->t_ready = 1;
 	return LIS_SUCCESS;

@@ -155,7 +155,7 @@ static LIS_INT scale_device_only(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_I
 	if (m->t_plan) { (void)liship_csr_plan_destroy(m->t_plan); m->t_plan = NULL; }
 	(void)liship_free(m->t_ptr); (void)liship_free(m->t_index); (void)liship_free(m->t_value); (void)liship_free(m->t_diag);
 	m->t_ptr = NULL; m->t_index = NULL; m->t_value = NULL; m->t_diag = NULL; m->t_ready = 0;
-	LISCHK(lisd_csr_plan(&m->plan, n, m->ptr, m->index, m->value));
+	LISCHK(lisd_csr_plan_plain(&m->plan, n, m->ptr, m->index, m->value));
 	A->is_scaled = LIS_TRUE;
 	B->is_scaled = LIS_TRUE;
 	return LIS_SUCCESS;

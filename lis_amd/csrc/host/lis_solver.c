@@ -985,6 +985,18 @@ LIS_INT lis_solve(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER solver)
 	return LIS_SUCCESS;
 }
 
+/* the transposed copy of the matrix a solve runs on: A^T in the caller's numbering <-> (P A P^T)^T in the plan's (lis_internal.h: rt_*) */
+static void swap_transposed(lisd_mat *d)
+{
+	int ti; int *tp; double *tv; liship_csr_plan_t tq;
+	ti = d->t_ready; d->t_ready = d->rt_ready; d->rt_ready = ti;
+	ti = d->t_nnz; d->t_nnz = d->rt_nnz; d->rt_nnz = ti;
+	tp = d->t_ptr; d->t_ptr = d->rt_ptr; d->rt_ptr = tp;
+	tp = d->t_index; d->t_index = d->rt_index; d->rt_index = tp;
+	tv = d->t_value; d->t_value = d->rt_value; d->rt_value = tv;
+	tq = d->t_plan; d->t_plan = d->rt_plan; d->rt_plan = tq;
+}
+
 LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER solver, LIS_PRECON precon)
 {
 	const LIS_INT nsolver = solver->options[LIS_OPTIONS_SOLVER], maxiter = solver->options[LIS_OPTIONS_MAXITER];
@@ -1095,8 +1107,7 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	}
 	/* A plan that renumbered the matrix (liship.h: liship_csr_plan_reorder -- the caller's numbering has no locality): the WHOLE solve runs in the plan's numbering.
 	 * b, x0 and 1/diag are gathered once, the iterations see P A P^T as the matrix (its plan with its fused reductions, its arrays), x is scattered back at the end:
-	 * no product pays for a permutation.  The same recurrences on renumbered vectors; their sums fold in another order, so not in the reference-order mode, and not
-	 * for the solvers that multiply by A^T (its transposed copy keeps the caller's numbering). */
+	 * no product pays for a permutation.  The same recurrences on renumbered vectors; their sums fold in another order, so not in the reference-order mode. */
 	{
 		lisd_mat *dm = MDEV(Awork);
 		const int needs_t = nsolver == LIS_SOLVER_BICG || nsolver == LIS_SOLVER_BICR || nsolver == LIS_SOLVER_CRS || nsolver == LIS_SOLVER_BICRSTAB ||
@@ -1104,12 +1115,15 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		liship_csr_plan_t in = NULL;
 		const int *rp = NULL, *ri = NULL;
 		const double *rv = NULL;
-		if (lisg.nprocs == 1 && !scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && !needs_t && dm->type == LIS_MATRIX_CSR && !dm->split_jad &&
-		    dm->plan && Awork->np == Awork->n && liship_csr_plan_reordered_form(dm->plan, &in, &rp, &ri, &rv, &renum) == 0) {
+		/* A^T x: the HBM copy is transposed in HBM (lis_matvech.c) -- of an unsplit CSR matrix, that is P A P^T's while it is swapped in; it gets a set of fields of its own */
+		const int t_ok = !needs_t || (Awork->matrix_type == LIS_MATRIX_CSR && !Awork->is_splited);
+		if (lisg.nprocs == 1 && !scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && t_ok && dm->type == LIS_MATRIX_CSR && !dm->split_jad &&
+		    dm->plan && Awork->np == Awork->n && dm->n == Awork->n && liship_csr_plan_reordered_form(dm->plan, &in, &rp, &ri, &rv, &renum) == 0) {
 			held_plan = dm->plan; held_ptr = dm->ptr; held_index = dm->index; held_value = dm->value;
 			dm->plan = in; dm->ptr = (int *)rp; dm->index = (int *)ri; dm->value = (double *)rv;
 			dm->solve_holds = 1;
 			renumbered = 1;
+			swap_transposed(dm);
 		}
 	}
 	/* b: once over PCIe (or already resident); x: a private HBM iterate "xx" (ref :545-592), zero or copy of x */
@@ -1217,6 +1231,7 @@ out:
 		lisd_mat *dm = MDEV(Awork);
 		dm->plan = held_plan; dm->ptr = held_ptr; dm->index = held_index; dm->value = held_value;
 		dm->solve_holds = 0;
+		swap_transposed(dm);
 	}
 	if (renum_b) lisd_pool_put(renum_b, c.len * sizeof(double));
 	if (renum_d) lisd_pool_put(renum_d, c.len * sizeof(double));

@@ -710,7 +710,7 @@ def queen_class_leg(lib, np, C, reps=50):
         rhs = capi.PV()
         assert lib.lis_vector_duplicate(A, C.byref(rhs)) == 0 and lib.lis_matvec(A, ones, rhs) == 0          # b = A*1 (test/test1.c:138-139)
         out["solves"] = {}
-        for opts in ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi"):
+        for opts in ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi", "-i bicg -p none"):       # (BiCG: Lis's default solver, lis_solver.c:242)
             S = capi.PS()
             assert lib.lis_solver_create(C.byref(S)) == 0 and lib.lis_solver_set_option((opts + " -tol 1e-12 -maxiter 2000 -print none").encode(), S) == 0
             assert lib.lis_vector_set_all(0.0, vy) == 0

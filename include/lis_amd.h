@@ -150,6 +150,8 @@ LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A);
 /* total length of those lists in the REORDERED form, when the plan renumbered rows and columns because the caller's numbering has no locality (liship.h:
  * liship_csr_plan_reorder; one rank, CSR with long rows; env LIS_AMD_NO_REORDER=1 keeps the caller's numbering); 0 when it did not; uploads A if needed */
 long long lis_amd_matrix_reordered(LIS_MATRIX A);
+/* the liship plan of A's HBM copy when it is served as CSR rows (for the liship_csr_plan_* queries of liship.h; owned by A), else NULL; uploads A if needed */
+void *lis_amd_matrix_csr_plan(LIS_MATRIX A);
 /* adopt CSR arrays that already live in HBM (no host copy exists; A must be sized and unassembled).
  * ptr has n+1 entries, columns are local (0..np-1, ghosts >= n).  The arrays are freed with the matrix. */
 LIS_INT lis_amd_matrix_set_csr_device(LIS_INT nnz, LIS_INT np, LIS_INT *dptr, LIS_INT *dindex,

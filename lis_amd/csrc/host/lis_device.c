@@ -1227,6 +1227,11 @@ LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A)
 	const long long listed = MDEV(A)->plan ? liship_csr_plan_localized(MDEV(A)->plan) : 0;
 	return listed > 0x7fffffffLL ? 0x7fffffff : (LIS_INT)listed;
 }
+void *lis_amd_matrix_csr_plan(LIS_MATRIX A)
+{
+	if (lisd_mat_ready(A) != LIS_SUCCESS) return NULL;
+	return MDEV(A)->type == LIS_MATRIX_CSR ? (void *)MDEV(A)->plan : NULL;
+}
 long long lis_amd_matrix_reordered(LIS_MATRIX A)
 {
 	if (lisd_mat_ready(A) != LIS_SUCCESS) return 0;

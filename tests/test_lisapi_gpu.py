@@ -732,6 +732,31 @@ def _renumbered_solve_case(lib, ptr, idx, val, options):
     assert lib.lis_matrix_destroy(A) == 0
 
 
+@pytest.mark.parametrize("env, fused", [({}, 1), ({"LIS_AMD_REORDER_PRODUCTS": "1"}, 0), ({"LIS_AMD_NO_REORDER": "1"}, None)])
+def test_reordering_environment_switches(env, fused):
+    """by default a badly numbered long-row matrix gets the renumbered form for solves and keeps its products in the caller's numbering (fused reductions stay);
+    LIS_AMD_REORDER_PRODUCTS=1 sends lis_matvec through P A P^T too (the oracle's bits either way); LIS_AMD_NO_REORDER=1: no renumbered form at all"""
+    import subprocess
+    code = ("import sys, ctypes as C; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, lis_amd, lisdrv, orc; from lis_amd import _capi as capi\n"
+            "from test_kernels_gpu import _scrambled_fem\n"
+            "lib = lis_amd.load(); assert lib.initialize([]) == 0; dll = lib.dll\n"
+            "dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong\n"
+            "dll.lis_amd_matrix_csr_plan.argtypes = [capi.PM]; dll.lis_amd_matrix_csr_plan.restype = C.c_void_p\n"
+            "ptr, idx, val = _scrambled_fem('nodes'); n = len(ptr) - 1\n"
+            "A = lisdrv.make_csr(lib, ptr, idx, val)\n"
+            "re = dll.lis_amd_matrix_reordered(A)\n"
+            "x = np.random.default_rng(1).uniform(-1, 1, n)\n"
+            "assert np.array_equal(lisdrv.matvec(lib, A, x).view(np.uint64), orc.spmv_csr(ptr, idx, val, x).view(np.uint64))\n"
+            "out = lisdrv.solve(lib, A, orc.spmv_csr(ptr, idx, val, np.ones(n)), '-i cg -p jacobi -tol 1e-11 -maxiter 300')\n"
+            "assert out['status'] == 0 and np.abs(out['x'] - 1).max() < 1e-8\n"
+            "print('RE', int(re > 0), 'FUSED', lib.liship_csr_plan_fused_dots(dll.lis_amd_matrix_csr_plan(A)), 'RENUM', dll.lis_amd_last_solve_renumbered())\n") % (ROOT, os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
+    want = "RE 0 FUSED 1 RENUM 0" if fused is None else "RE 1 FUSED %d RENUM 1" % fused
+    assert want in p.stdout, p.stdout[-300:]
+
+
 def test_contract_form_behind_the_environment_switch():
     """LIS_AMD_NO_INDEX_CODES=1: a Lis program's CSR matrix keeps the reference's own arrays in the product (4 B indices + 8 B values: spmv_csr_rowgather_kernel, the form
     SURVEY 8d prices) -- no codes, no patterns, no value records; the plan still learns the grid's plane, from the band of the matrix, for the XCD strips; y is the oracle's

@@ -373,6 +373,50 @@ __device__ __forceinline__ double ordered_sum_rows(double acc, const double *buf
 
 // one whole row block of any shape (many empty rows, rows longer than the LDS stage).
 // Invariant from the plan: every row but the last ends inside the first pass of CAP products.
+// ------------------------------------------------------------------------------ long rows in tree mode: the tail over many workgroups
+// (LIS_AMD_LONG_ROW_TREE=1 only.)  One workgroup folding a 200 000-entry row is ~100 dependent rounds of memory latency: the heavy-tailed stress matrix ran at 0.78 ms with the
+// workgroup tree where its bytes are worth 0.09 ms.  So the part of a row block beyond its first TAIL_FROM entries -- always the tail of its last row -- is cut into chunks of
+// TAIL_CHUNK entries (the plan lists them: build_split), a workgroup per chunk adds its products (lane sums, wavefront butterfly, wavefronts in order: a fixed order),
+// spmv_csr_tail_fold_kernel adds a block's chunk sums in chunk order and leaves the total in y[that row], and block_by_products -- which every kernel reaches for such a
+// block -- adds it to the head of the row it has summed itself.  Both passes run in front of every launch of a plan that has such blocks (tail_prepass, spmv_csr.hip) with
+// the launch's own row range, so they see the block as the product's kernel will.
+constexpr int TAIL_FROM = 16384, TAIL_CHUNK = 8192;
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK)
+void spmv_csr_tail_chunks_kernel(const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val, const double *__restrict__ x,
+                                 const v2i32 *__restrict__ blk, const v2i32 *__restrict__ tchunk, Rows RW, double *__restrict__ tpart)
+{
+    __shared__ double scratch[BLOCK / WAVE];
+    const v2i32 c = tchunk[blockIdx.x];                 // {row block, chunk of its tail}
+    Blk B = load_blk(blk, c.x);
+    double part = 0.0;
+    if (clip_rows(B, ptr, RW.rb, RW.re) && B.k1 - B.k0 > TAIL_FROM) {
+        const int kb = B.k0 + TAIL_FROM + c.y * TAIL_CHUNK, ke = min(B.k1, kb + TAIL_CHUNK);
+        for (int k = kb + (int)threadIdx.x; k < ke; k += 8 * BLOCK) {
+            double v[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int kk = min(k + u * BLOCK, ke - 1); v[u] = load_stream(val + kk); xv[u] = x[load_stream(idx + kk)]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) part += (k + u * BLOCK < ke) ? v[u] * xv[u] : 0.0;
+        }
+    }
+    const double tot = block_sum<BLOCK / WAVE>(part, scratch);
+    if (threadIdx.x == 0) tpart[blockIdx.x] = tot;
+}
+__global__ void spmv_csr_tail_fold_kernel(int nheavy, const int *__restrict__ ptr, const v2i32 *__restrict__ blk, const v2i32 *__restrict__ thead, Rows RW,
+                                          const double *__restrict__ tpart, double *__restrict__ y, const int *__restrict__ rowmap)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nheavy) return;
+    const v2i32 hd = thead[h], nx = thead[h + 1];       // {row block, its first chunk}
+    Blk B = load_blk(blk, hd.x);
+    if (!clip_rows(B, ptr, RW.rb, RW.re) || B.k1 - B.k0 <= TAIL_FROM) return;
+    double s = 0.0;
+    for (int c = hd.y; c < nx.y; c++) s += tpart[c];
+    const int rl = B.r1 - 1;
+    y[rowmap ? rowmap[rl] : rl] = s;
+}
+
 template <int BLOCK, int CAP, int VEC, int DOT = 0>
 __device__ __forceinline__ void block_by_products(double *prod, const int *__restrict__ ptr,
                                                   const int *__restrict__ idx, const double *__restrict__ val,
@@ -410,19 +454,23 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
             // every lane adds the products it reaches with stride BLOCK (8 loads and gathers in flight, nothing staged), the
             // workgroup folds the lane sums (butterfly, then the wavefronts in order): a fixed order, but not left to right --
             // a 200 000-entry row costs ~100 rounds of memory latency instead of a 200 000-long dependent add chain
+            // beyond TAIL_FROM entries the tail was summed by the launch's prepass (a workgroup per TAIL_CHUNK entries) and waits in y[this row]
+            static_assert(CAP < TAIL_FROM, "the prepass starts beyond the first pass's stage");
+            const bool heavy = k1 - k0 > TAIL_FROM;
+            const int kt = heavy ? k0 + TAIL_FROM : k1;
             double part = 0.0;
-            for (int k = kfirst + (int)threadIdx.x; k < k1; k += 8 * BLOCK) {
+            for (int k = kfirst + (int)threadIdx.x; k < kt; k += 8 * BLOCK) {
                 double v[8], xv[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const int kk = min(k + u * BLOCK, k1 - 1); v[u] = load_stream(val + kk); xv[u] = x[load_stream(idx + kk)]; }
+                for (int u = 0; u < 8; u++) { const int kk = min(k + u * BLOCK, kt - 1); v[u] = load_stream(val + kk); xv[u] = x[load_stream(idx + kk)]; }
 #pragma unroll
-                for (int u = 0; u < 8; u++) part += (k + u * BLOCK < k1) ? v[u] * xv[u] : 0.0;
+                for (int u = 0; u < 8; u++) part += (k + u * BLOCK < kt) ? v[u] * xv[u] : 0.0;
             }
             __syncthreads();
             const double tot = block_sum<BLOCK / WAVE>(part, tree_scratch);
             if (threadIdx.x == 0) tree_scratch[0] = tot;
             __syncthreads();
-            if ((int)threadIdx.x == owner) carry += tree_scratch[0];
+            if ((int)threadIdx.x == owner) { carry += tree_scratch[0]; if (heavy) carry += y[rowmap ? rowmap[rl] : rl]; }
             base = k1;
         }
         static_assert(BLOCK > WAVE, "the owner of a long row is fed by the lanes of the OTHER wavefronts");

@@ -253,6 +253,9 @@ struct liship_csr_plan_s {
     int first_term;      // row sums start at the first product instead of at +0.0 (split matrices)
     v4i32 *vrecw;        // device: WIDE value records for patterns of up to 32 entries (no ptab8): per pattern 144 B of byte offsets + length, 256 B of values; else NULL
     int *order;          // device, nblocks entries or NULL: launch order of the products kernel (blocks with a very long row first)
+    v2i32 *tchunk = nullptr, *thead = nullptr;   // device, or NULL: tree mode's prepass (spmv_csr_tail_chunks_kernel) -- per chunk {row block, chunk of its tail}; per block with more
+    double *tpart = nullptr;                     // than TAIL_FROM entries (+ a closing entry) {row block, its first chunk}; a partial sum per chunk
+    int ntchunk = 0, nheavy = 0;
     unsigned char *rowpat; // device, one byte per row: its pattern (length + offset sequence); NULL = none
     unsigned short *rowrel; // device, 2 B per row: its first non-zero relative to its row block
     int *ptab;           // device: npat + 1 prefix entries, then the offsets of all patterns
@@ -313,6 +316,13 @@ extern "C" int liship_spmv_csr_set_uniform_rows(int on)
 }
 
 // the merge-path row split for the plan's geometry (device + host copy); replaces an existing one
+static void free_tail(liship_csr_plan_s *p)
+{
+    if (p->tchunk) (void)hipFree(p->tchunk);
+    if (p->thead) (void)hipFree(p->thead);
+    if (p->tpart) (void)hipFree(p->tpart);
+    p->tchunk = nullptr; p->thead = nullptr; p->tpart = nullptr; p->ntchunk = 0; p->nheavy = 0;
+}
 static int build_split(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
 {
     if (p->blk) { (void)hipFree(p->blk); p->blk = nullptr; }
@@ -332,6 +342,35 @@ static int build_split(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
     if (e == hipSuccess) e = hipMemcpyAsync(p->blk_host, p->blk, bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { (void)hipFree(p->blk); p->blk = nullptr; free(p->blk_host); p->blk_host = nullptr; return (int)e; }
+    free_tail(p);
+    {                                                // blocks with more than TAIL_FROM entries: the chunks of their tails (tree mode's prepass)
+        long long nch = 0; int nh = 0;
+        for (int b = 0; b < p->nblocks; b++) {
+            const int len = p->blk_host[b + 1].y - p->blk_host[b].y;
+            if (len > TAIL_FROM) { nh++; nch += (len - TAIL_FROM + TAIL_CHUNK - 1) / TAIL_CHUNK; }
+        }
+        if (nh > 0) {
+            v2i32 *hc = (v2i32 *)malloc(sizeof(v2i32) * (size_t)nch), *hh = (v2i32 *)malloc(sizeof(v2i32) * (size_t)(nh + 1));
+            if (!hc || !hh) { free(hc); free(hh); return LISHIP_ERR_ARG; }
+            int c = 0, h = 0;
+            for (int b = 0; b < p->nblocks; b++) {
+                const int len = p->blk_host[b + 1].y - p->blk_host[b].y;
+                if (len <= TAIL_FROM) continue;
+                hh[h].x = b; hh[h].y = c; h++;
+                const int m = (len - TAIL_FROM + TAIL_CHUNK - 1) / TAIL_CHUNK;
+                for (int j = 0; j < m; j++) { hc[c].x = b; hc[c].y = j; c++; }
+            }
+            hh[nh].x = p->nblocks - 1; hh[nh].y = c;
+            e = hipMalloc(&p->tchunk, sizeof(v2i32) * (size_t)nch);
+            if (e == hipSuccess) e = hipMalloc(&p->thead, sizeof(v2i32) * (size_t)(nh + 1));
+            if (e == hipSuccess) e = hipMalloc(&p->tpart, sizeof(double) * (size_t)nch);
+            if (e == hipSuccess) e = hipMemcpy(p->tchunk, hc, sizeof(v2i32) * (size_t)nch, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(p->thead, hh, sizeof(v2i32) * (size_t)(nh + 1), hipMemcpyHostToDevice);
+            free(hc); free(hh);
+            if (e != hipSuccess) { free_tail(p); return (int)e; }      // (tree mode's kernels count on the prepass: no plan without it)
+            p->ntchunk = (int)nch; p->nheavy = nh;
+        }
+    }
     if (p->order) { (void)hipFree(p->order); p->order = nullptr; }
     if (p->products && p->nblocks > 1) {             // blocks whose last row overflows the stage by far: launched first (products kernel)
         const int heavy_from = 4 * (WORK + SLACK);
@@ -415,6 +454,7 @@ extern "C" int liship_csr_plan_destroy(liship_csr_plan_t p)
     if (p->vrec) (void)hipFree(p->vrec);
     if (p->drec) (void)hipFree(p->drec);
     if (p->order) (void)hipFree(p->order);
+    free_tail(p);
     if (p->vrecw) (void)hipFree(p->vrecw);
     if (p->lcol) (void)hipFree(p->lcol);
     if (p->dcol) (void)hipFree(p->dcol);

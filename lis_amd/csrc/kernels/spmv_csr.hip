@@ -591,11 +591,22 @@ void launch_products_dot(const LaunchArgs &a, int batch, const double *w, double
             <<<a.nb, g.block, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.y, a.blk, a.bfirst, a.nb, Rows{a.rb, a.re, a.acc0}, w, partial, liship_internal_guard(), pstride, a.order);
 }
 
+// tree mode (liship_spmv_csr_set_long_row_tree), plans with row blocks of more than TAIL_FROM entries: the tails of those blocks' last rows are summed by a
+// workgroup per TAIL_CHUNK entries and left in y[row] for the product's kernel (block_by_products) -- in front of EVERY launch of such a plan, on its row range
+static void tail_prepass(const liship_csr_plan_s *p, const LaunchArgs &a)
+{
+    if (!g_long_row_tree_host || !p || p->ntchunk <= 0 || a.nb <= 0) return;
+    const Rows RW{a.rb, a.re, a.acc0};
+    spmv_csr_tail_chunks_kernel<256><<<p->ntchunk, 256, 0, a.st>>>(a.ptr, a.idx, a.val, a.x, a.blk, p->tchunk, RW, p->tpart);
+    spmv_csr_tail_fold_kernel<<<(p->nheavy + 63) / 64, 64, 0, a.st>>>(p->nheavy, a.ptr, a.blk, p->thead, RW, p->tpart, a.y, a.rowmap);
+}
+
 int launch_csr(liship_csr_plan_t p, const LaunchArgs &a0)
 {
     if (a0.nb <= 0) return 0;
     LaunchArgs a = a0;
     a.plan = p;
+    tail_prepass(p, a);
     switch (p->geom) {
         case 0: launch_geom<0>(a, p->unroll, p->products != 0, p->batch); break;
         case 1: launch_geom<1>(a, p->unroll, p->products != 0, p->batch); break;
@@ -738,6 +749,7 @@ extern "C" int liship_spmv_csr_dot_f64(liship_csr_plan_t p, const int *ptr, cons
     }
     LaunchArgs a{ptr, idx, val, x, y, p->blk, 0, p->nblocks, 0, p->n, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, p->order, g_row_values ? p->vrecw : nullptr};
     a.plan = p;
+    tail_prepass(p, a);
     if (p->nblocks == 0) { HIP_TRY(hipMemsetAsync(result, 0, sizeof(double) * 2, a.st)); return 0; }
     if (plan_runs_dom(p)) {                            // value records, dominant pattern: a partial per workgroup (tile) of the plain product's shape
         DomTile TL;
@@ -832,6 +844,7 @@ extern "C" int liship_spmv_csr_rows_dot_f64(liship_csr_plan_t p, int row_begin, 
     double *partial = static_cast<double *>(work) + slot_base;
     LaunchArgs a{ptr, idx, val, x, y, p->blk, bfirst, nb, row_begin, row_end, (int)p->nnz, as_stream(stream), g_index_codes ? p->codes : nullptr, p->dict, g_local_cols ? p->lcol : nullptr, p->dcol, p->doff, p->first_term ? -0.0 : 0.0, (g_row_patterns && g_index_codes) ? p->rowpat : nullptr, p->rowrel, p->ptab, p->ptab_len, p->npat + 1, p->ptab8, g_row_values ? p->vrec : nullptr, nullptr, g_row_values ? p->vrecw : nullptr};
     a.plan = p;
+    tail_prepass(p, a);
     const int ps = (int)slots;
     if (p->products && p->geom == LOCAL_GEOM) {
         if (want_sumsq) launch_products_dot<LOCAL_GEOM, 2>(a, p->batch, w, partial, ps); else launch_products_dot<LOCAL_GEOM, 1>(a, p->batch, w, partial, ps);

@@ -952,6 +952,69 @@ def test_spmv_csr_long_row_tree_is_opt_in(lib):
     assert abs(out[1][1500] - yref[1500]) <= 1e-13 * scale            # a different association of 60 000 terms
 
 
+def test_spmv_csr_long_row_tree_tail_over_many_workgroups(lib):
+    """tree mode: beyond 16 384 entries of a row block the tail of its last row is summed by a workgroup per 8192 entries in front of the product
+    (spmv_csr_tail_chunks_kernel / _fold_kernel) and handed over in y[row] -- whole products, row ranges that cut in front of / behind / away from the long
+    rows, the fused dots; two long rows (one of them the matrix's last row); every value within 1e-14 of the row's magnitude, short rows keep their bits"""
+    rng = np.random.default_rng(21)
+    base = orc.random_csr(4000, 11, seed=21, ncols=4000)
+    cut = 1700
+
+    def long_row(m):
+        return (np.array([0, m], np.int32), rng.integers(0, 4000, m).astype(np.int32), rng.uniform(-1, 1, m))
+    top = (base[0][:cut + 1], base[1][:base[0][cut]], base[2][:base[0][cut]])
+    bot = (base[0][cut:] - base[0][cut], base[1][base[0][cut]:], base[2][base[0][cut]:])
+    ptr, idx, val = stack_rows([top, long_row(150001), bot, long_row(16384 + 8192 + 5)])
+    n = len(ptr) - 1
+    lens = np.diff(ptr)
+    x = np.random.default_rng(6).uniform(-1, 1, 4000)
+    w = np.random.default_rng(7).uniform(-1, 1, n)
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    absum = np.add.reduceat(np.abs(val * x[idx]), ptr[:-1].astype(np.int64))
+    dptr, didx, dval, dx, dw = (DA.from_host(ptr, np.int32), DA.from_host(idx, np.int32), DA.from_host(val, np.float64), DA.from_host(x, np.float64),
+                                DA.from_host(w, np.float64))
+    work = DA(lib.liship_reduce_work_bytes() // 8, np.float64)
+    res = DA(2, np.float64)
+    plan = C.c_void_p()
+    check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
+    short = lens <= 2000
+
+    def close(y, rows=slice(None)):
+        assert np.array_equal(y[rows][short[rows]], yref[rows][short[rows]])
+        assert np.all(np.abs(y[rows] - yref[rows]) <= 1e-14 * absum[rows])
+    check(lib.liship_spmv_csr_set_long_row_tree(1))
+    try:
+        whole = []
+        for _ in range(2):
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            whole.append(dy.to_host())
+        assert np.array_equal(whole[0], whole[1])
+        close(whole[0])
+        for a, b in ((0, cut), (cut, cut + 1), (cut - 3, cut + 4), (cut + 1, n), (n - 1, n), (5, n - 1)):
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_rows_f64(plan, a, b, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+            y = dy.to_host()
+            assert np.isnan(y[:a]).all() and np.isnan(y[b:]).all()
+            close(y, slice(a, b))                                 # (a range that cuts a row block moves the start of its tail: the same sum to rounding)
+        for sq in (0, 1):
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            rc = lib.liship_spmv_csr_dot_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, dw.ptr, sq, res.ptr, work.ptr, None)
+            if rc != 0:
+                continue                                          # (the plan's form has no fused epilogue: the caller runs the product and a pass)
+            y, r = dy.to_host(), res.to_host()
+            assert np.array_equal(y, whole[0])
+            assert abs(r[0] - float(np.dot(w, y))) <= 1e-12 * float(np.abs(w * y).sum())
+            if sq:
+                assert abs(r[1] - float(np.dot(y, y))) <= 1e-12 * float(np.dot(y, y))
+    finally:
+        check(lib.liship_spmv_csr_set_long_row_tree(0))
+    dy = DA.from_host(np.full(n, np.nan), np.float64)
+    check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+    assert np.array_equal(dy.to_host(), yref)                      # and the default mode is the reference's chain, bit for bit
+    check(lib.liship_csr_plan_destroy(plan))
+
+
 BSR22_CASES = {
     "stencil": lambda: orc.poisson3d(23, 18, 14),
     "one_block_row": lambda: orc.random_csr(2, 2, seed=7, empty_rows=False),

@@ -711,14 +711,20 @@ def queen_class_leg(lib, np, C, reps=50):
         assert lib.lis_vector_duplicate(A, C.byref(rhs)) == 0 and lib.lis_matvec(A, ones, rhs) == 0          # b = A*1 (test/test1.c:138-139)
         out["solves"] = {}
         for opts in ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi", "-i bicg -p none"):       # (BiCG: Lis's default solver, lis_solver.c:242)
-            S = capi.PS()
-            assert lib.lis_solver_create(C.byref(S)) == 0 and lib.lis_solver_set_option((opts + " -tol 1e-12 -maxiter 2000 -print none").encode(), S) == 0
-            assert lib.lis_vector_set_all(0.0, vy) == 0
-            assert lib.lis_solve(A, rhs, vy, S) == 0
-            it, itime = S.contents.iter, S.contents.itime
-            out["solves"][opts] = {"iter": it, "status": S.contents.retcode, "rel_residual": S.contents.resid, "iters_per_sec": round(it / itime, 1) if itime > 0 else None,
-                                   "renumbered": int(dll.lis_amd_last_solve_renumbered())}
-            lib.lis_solver_destroy(S)
+            first = None
+            for attempt in (0, 1):          # twice: the first solve that multiplies by A^T builds the transposed copy in HBM inside its itime (one-off per matrix; the reference pays none)
+                S = capi.PS()
+                assert lib.lis_solver_create(C.byref(S)) == 0 and lib.lis_solver_set_option((opts + " -tol 1e-12 -maxiter 2000 -print none").encode(), S) == 0
+                assert lib.lis_vector_set_all(0.0, vy) == 0
+                assert lib.lis_solve(A, rhs, vy, S) == 0
+                it, itime = S.contents.iter, S.contents.itime
+                rate = round(it / itime, 1) if itime > 0 else None
+                if attempt == 0:
+                    first = rate
+                else:
+                    out["solves"][opts] = {"iter": it, "status": S.contents.retcode, "rel_residual": S.contents.resid, "iters_per_sec": rate,
+                                           "first_solve_iters_per_sec": first, "renumbered": int(dll.lis_amd_last_solve_renumbered())}
+                lib.lis_solver_destroy(S)
         for v in (vx, vy, ones, rhs, b, x0):
             lib.lis_vector_destroy(v)
         lib.lis_matrix_destroy(A)

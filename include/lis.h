@@ -425,6 +425,12 @@ typedef struct LIS_SOLVER_STRUCT *LIS_SOLVER;
  * array out; the matrix is the (cached) device copy of A */
 typedef void (*LIS_MATVEC_XXX)(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);
 typedef LIS_INT (*LIS_MATVEC_FUNC)(LIS_MATRIX A, LIS_VECTOR X, LIS_VECTOR Y);
+/* the dispatch pointers of the reference (include/lis_matvec.h:84-85, src/matvec/lis_matvec.c:50-51: only the hybrid preconditioner ever swaps them) */
+extern LIS_MATVEC_FUNC LIS_MATVEC;
+extern LIS_MATVEC_FUNC LIS_MATVECH;
+/* the reference's storage-format auto-tuner (src/matvec/lis_matvec.c:354-461, undeclared there too): converts A to every format the library serves, times
+ * 1e7 / nnz + 1 products of each (device time, one synchronize per format) and returns the fastest in *matrix_type_maxperf; prints the reference's report lines */
+LIS_INT lis_matvec_optimize(LIS_MATRIX A, LIS_INT *matrix_type_maxperf);
 void lis_matvec_csr(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);   /* src/matvec/lis_matvec_csr.c:53 */
 void lis_matvec_csc(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);   /* src/matvec/lis_matvec_csc.c:53 */
 void lis_matvec_ell(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]);   /* src/matvec/lis_matvec_ell.c:50 */

@@ -178,6 +178,7 @@ _PROTOS = {
     # matvec (lis.h:920)
     "lis_matvec": (LIS_INT, [PM, PV, PV]),
     "lis_matvech": (LIS_INT, [PM, PV, PV]),
+    "lis_matvec_optimize": (LIS_INT, [PM, C.POINTER(LIS_INT)]),
     "lis_matrix_scale": (LIS_INT, [PM, PV, PV, LIS_INT]),
     "lis_matrix_set_values": (LIS_INT, [LIS_INT, LIS_INT, P_DBL, PM]),
     "lis_matrix_malloc": (LIS_INT, [PM, LIS_INT, C.POINTER(LIS_INT)]),

@@ -70,3 +70,57 @@ void lis_matvec_ell(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A
 void lis_matvec_dia(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A, LIS_MATRIX_DIA, x, y); }
 void lis_matvec_jad(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A, LIS_MATRIX_JAD, x, y); }
 void lis_matvec_bsr(LIS_MATRIX A, LIS_SCALAR x[], LIS_SCALAR y[]) { raw_matvec(A, LIS_MATRIX_BSR, x, y); }
+
+/* ref src/matvec/lis_matvec.c:50-51 */
+LIS_MATVEC_FUNC LIS_MATVEC  = lis_matvec;
+LIS_MATVEC_FUNC LIS_MATVECH = lis_matvech;
+
+/* ref src/matvec/lis_matvec.c:354-461: the same sweep and the same report lines over the formats this library serves (the reference walks all eleven and CHKERRs on a
+ * conversion it cannot do; MSR, BSC, VBR, COO and DNS are reported as not served here).  Products are asynchronous: the clock stops behind ONE synchronize per format,
+ * so `computation` is device time for `iter` products, not `iter` launch times. */
+LIS_INT lis_matvec_optimize(LIS_MATRIX A, LIS_INT *matrix_type_maxperf)
+{
+	static const char *name[] = {"CSR", "CSC", "MSR", "DIA", "ELL", "JAD", "BSR", "BSC", "VBR", "COO", "DNS"};
+	if (!A || !matrix_type_maxperf) return LISI_ERR(LIS_ERR_ILL_ARG, "lis_matvec_optimize: NULL argument\n");
+	LIS_VECTOR X = NULL, Y = NULL;
+	LIS_INT err = lis_vector_duplicate(A, &X);
+	if (!err) err = lis_vector_duplicate(A, &Y);
+	if (!err) err = lis_vector_set_all(1.0, X);
+	if (err) { if (X) lis_vector_destroy(X); if (Y) lis_vector_destroy(Y); return err; }
+	const LIS_INT iter = (LIS_INT)(10000000 / (A->nnz > 0 ? A->nnz : 1)) + 1;
+	double best = 0.0;
+	*matrix_type_maxperf = A->matrix_type;
+	if (lisg.rank == 0) {
+		printf("\nmeasuring matvec performance...\n");
+		printf("number of iterations = 1e7 / %d + 1 = %d\n", (int)A->nnz, (int)iter);
+	}
+	for (LIS_INT type = 1; type < 11 && !err; type++) {
+		const int served = type == LIS_MATRIX_CSR || type == LIS_MATRIX_CSC || type == LIS_MATRIX_DIA || type == LIS_MATRIX_ELL || type == LIS_MATRIX_JAD || type == LIS_MATRIX_BSR;
+		if (!served) {
+			if (lisg.rank == 0) printf("matrix_type = %2d (%s), not served by liblis_amd\n", (int)type, name[type - 1]);
+			continue;
+		}
+		LIS_MATRIX A1 = NULL;
+		err = lis_matrix_duplicate(A, &A1);
+		if (!err) err = lis_matrix_set_type(A1, type);
+		if (!err) err = lis_matrix_convert(A, A1);
+		if (!err) err = lis_matvec(A1, X, Y);                     /* untimed: uploads A1 and builds its plan (the reference converts outside its clock too) */
+		if (!err && liship_stream_synchronize(lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+		double comptime = lis_wtime();
+		for (LIS_INT i = 0; i < iter && !err; i++) err = lis_matvec(A1, X, Y);
+		if (!err && liship_stream_synchronize(lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+		comptime = lis_wtime() - comptime;
+		LIS_REAL val = 0.0;
+		if (!err) err = lis_vector_nrm2(Y, &val);
+		if (!err) {
+			const double flops = comptime > 0.0 ? 2.0 * (double)A->nnz * (double)iter * 1.0e-6 / comptime : 0.0;
+			if (lisg.rank == 0) printf("matrix_type = %2d (%s), computation = %e sec, %8.3f MFLOPS\n", (int)type, name[type - 1], comptime, flops);
+			if (flops > best) { best = flops; *matrix_type_maxperf = type; }
+		}
+		if (A1) lis_matrix_destroy(A1);
+	}
+	if (!err && lisg.rank == 0) printf("matrix format is set to %s\n\n", name[*matrix_type_maxperf - 1]);
+	fflush(stdout);
+	lis_vector_destroy(X); lis_vector_destroy(Y);
+	return err;
+}

@@ -71,6 +71,34 @@ def test_lis_matvec_formats_vs_oracle(lib, fmt, bs):
     assert np.array_equal(lisdrv.matvec(lib, B, x), oracle_for(fmt, ptr, idx, val, x, bs or 2))
 
 
+def test_matvec_optimize_and_dispatch_pointers(lib, capfd):
+    """lis_matvec_optimize (ref src/matvec/lis_matvec.c:354-461): every served format converted, timed and reported in the reference's lines, the fastest returned;
+    LIS_MATVEC / LIS_MATVECH (ref :50-51) are lis_matvec / lis_matvech"""
+    ptr, idx, val = orc.poisson3d(12, 10, 9)
+    A = lisdrv.make_csr(lib, ptr, idx, val)
+    best = capi.LIS_INT(0)
+    assert lib.lis_matvec_optimize(A, C.byref(best)) == 0
+    out = capfd.readouterr().out
+    assert best.value in (capi.FORMAT_ID[f] for f in ("csr", "csc", "dia", "ell", "jad", "bsr"))
+    assert "measuring matvec performance..." in out and f"number of iterations = 1e7 / {int(ptr[-1])} + 1 = {10000000 // int(ptr[-1]) + 1}" in out
+    for name in ("CSR", "CSC", "DIA", "ELL", "JAD", "BSR"):
+        assert f"({name}), computation = " in out
+    for name in ("MSR", "BSC", "VBR", "COO"):                                  # (the reference stops in front of DNS: `matrix_type < 11`)
+        assert f"({name}), not served by liblis_amd" in out
+    assert "matrix format is set to " in out
+    assert A.contents.matrix_type == capi.FORMAT_ID["csr"]                     # A itself is untouched
+    fn_t = C.CFUNCTYPE(capi.LIS_INT, capi.PM, capi.PV, capi.PV)
+    x = np.cos(np.arange(len(ptr) - 1) * 0.3)
+    vx, vy, vz = lisdrv.new_vector(lib, A, x), lisdrv.new_vector(lib, A), lisdrv.new_vector(lib, A)
+    for sym, direct in (("LIS_MATVEC", lib.lis_matvec), ("LIS_MATVECH", lib.lis_matvech)):
+        fn = fn_t(C.c_void_p.in_dll(lib.dll, sym).value)
+        assert fn(A, vx, vy) == 0 and direct(A, vx, vz) == 0
+        assert np.array_equal(lisdrv.get_vector(lib, vy), lisdrv.get_vector(lib, vz))
+    for v in (vx, vy, vz):
+        lib.lis_vector_destroy(v)
+    lib.lis_matrix_destroy(A)
+
+
 def test_raw_array_entry_points(lib):
     """void lis_matvec_csr(LIS_MATRIX, LIS_SCALAR x[], LIS_SCALAR y[]) and friends take HOST arrays."""
     ptr, idx, val = orc.poisson3d(9, 8, 7)

@@ -126,7 +126,7 @@ int  liship_csr_plan_block_rows(liship_csr_plan_t plan);       /* b when the pla
  * and the whole-matrix product walks the planes with each x loaded once (round 5: spmv_csr_block2_march_kernel); liship_spmv_csr_set_dom_march as for the others */
 int  liship_csr_plan_block2_march(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_block_rows(int on);                   /* A/B switch: 0 = the row-by-row kernels (same bits) */
-/* The z-marching form of the dominant-pattern product (7-point stencil with value records, grid lines a multiple of 128 long): 1 = on for launches of 64 workgroups and more (default), 0 = the gathering kernel, 2 = on at any size,
+/* The z-marching form of the dominant-pattern product (7-point stencil with value records, grid lines of any even length from 128 on: the last 128-column tile of a line may be partial): 1 = on for launches of 64 workgroups and more (default), 0 = the gathering kernel, 2 = on at any size,
  * 3 = at any size, but with the faces' masks even where plan time found the grid a box (liship_csr_plan_box_planes: planes in which a slot is missing exactly where its neighbour
  * lies outside the grid -- there the kernel reads no pattern byte at all).  Same bits in every form. */
 int  liship_spmv_csr_set_dom_march(int on);

@@ -250,11 +250,12 @@ static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
     int S = 0, SO = 0, perm = 0;
     if (!dom_seven_point(D, S, SO, perm)) return false;
     const int order = perm == 0x1ac688 ? 0 : perm == 0x0e2a70 ? 1 : 2;      // (slot u at bits 3u: ascending 0,1,2,3,4,5,6; the generators' 0,6,1,5,2,4,3)
-    if (S < 128 || S % 128 != 0 || SO <= S || SO % S != 0 || (SO / S) % 8 != 0) return false;
+    // lines of any even length from 128 on (round 5: the last tile of a line is partial -- at least two pairs wide, so that its left and right halo columns have a lane each)
+    if (S < 128 || S % 2 != 0 || (S % 128 != 0 && S % 128 < 4) || SO <= S || SO % S != 0 || (SO / S) % 8 != 0) return false;
     if (a.rb % SO != 0 || a.re % SO != 0 || a.re > P->n || a.rb < 0) return false;
     const int z0 = a.rb / SO, z1 = a.re / SO, planes = z1 - z0;
     if (planes < 8) return false;
-    const int tiles_x = S / 128, tiles_y = (SO / S) / 8, tiles = tiles_x * tiles_y;
+    const int tiles_x = (S + 127) / 128, tiles_y = (SO / S) / 8, tiles = tiles_x * tiles_y;
     int nseg = (3 * 256 + tiles - 1) / tiles;                 // (512^3, 256 tiles: three segments 0.385 ms, four 0.398, two 0.37-0.42, one 0.52; tiles of 16 lines or three planes ahead: within the noise)
     if (nseg > planes / 8) nseg = planes / 8;
     if (nseg < 1) nseg = 1;

@@ -2311,13 +2311,18 @@ def test_block2_marching_kernel_bit_exact(lib, dims, order):
         lib.liship_spmv_csr_set_block_rows(1)
 
 
-@pytest.mark.parametrize("case", ["constant", "ell_padded", "values_differ", "foreign_rows", "two_tiles_wide", "generator_order", "other_order", "slab_of_rank_0", "slab_of_rank_1", "dia_zeros"])
+@pytest.mark.parametrize("case", ["constant", "ell_padded", "values_differ", "foreign_rows", "two_tiles_wide", "generator_order", "other_order", "slab_of_rank_0", "slab_of_rank_1", "dia_zeros",
+                                  # lines that are not a multiple of 128 long (round 5): the last tile of a line is partial -- 64, 4, 72, 126, 8 and 60 columns wide
+                                  "constant@192", "ell_padded@132", "dia_zeros@200", "generator_order@254", "slab_of_rank_1@136", "foreign_rows@188", "values_differ@320", "other_order@192"])
 def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
     """the 7-point stencil with value records on a grid whose lines are a multiple of 128 long: a workgroup walks the planes of its 128 x 8 tile, each x loaded once
     (spmv_csr_valuerec_march_kernel; 512^3: 0.49 -> 0.41 ms).  The oracle's bits with the form on and off -- Inf / NaN / -0.0 in x, rows of other patterns (faces: masks;
     other values: the waterfall's; foreign rows: their own records; ELL's padding terms), whole launches, plane ranges (the form) and ranges that cut planes (the
     gathering kernel), the fused dots."""
+    case, _, line = case.partition("@")
     nz, ny, nx = (12, 16, 256) if case == "two_tiles_wide" else (20, 16, 128)
+    if line:
+        nx = int(line)
     ptr, idx, val = orc.poisson3d(nz, ny, nx, sort_cols=True)
     n = len(ptr) - 1
     SO = ny * nx
@@ -2404,6 +2409,8 @@ def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
     try:
         for march in (2, 3, 0):                               # 2: at any size (the default leaves grids this small to the gathering kernel); 3: the masks' form on a box too
             lib.liship_spmv_csr_set_dom_march(march)
+            if line and march:
+                assert lib.liship_csr_plan_marching(plan) >= 1, (case, line)      # the partial tile is served by the marching kernel, not by a fall-back
             dy = DA.from_host(np.full(n, 7.0), np.float64)
             check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
             y = dy.to_host()
@@ -2433,11 +2440,11 @@ def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LIS_AMD_FUZZ_SEEDS", "60")) // 2))
 def test_z_marching_on_perturbed_grids(lib, seed):
-    """random 7-point grids (lines of 128 or 256 columns), in CSR (either slot order), ELL's padded or DIA's zero-filled row form, with random planes perturbed --
+    """random 7-point grids (lines of 128 .. 322 columns), in CSR (either slot order), ELL's padded or DIA's zero-filled row form, with random planes perturbed --
     a value changed, an entry of an interior row removed, a column moved -- so that the box the plan finds is some run of planes between them: every form of the
     product (marching at any size, its masks' form, the gathering kernel), whole and in ranges that cut planes, must give the oracle's bits"""
     rng = np.random.default_rng(9000 + seed)
-    nx, ny, nz = int(rng.choice([128, 256])), 8 * int(rng.integers(1, 4)), int(rng.integers(9, 22))
+    nx, ny, nz = int(rng.choice([128, 256, 132, 190, 200, 254, 322])), 8 * int(rng.integers(1, 4)), int(rng.integers(9, 22))      # (lines with a partial last tile too: round 5)
     flavour = ["csr", "csr_generator", "ell", "dia"][seed % 4]
     ptr, idx, val = orc.poisson3d(nz, ny, nx, sort_cols=flavour != "csr_generator")
     n, SO = len(ptr) - 1, ny * nx

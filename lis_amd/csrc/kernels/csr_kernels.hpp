@@ -2028,7 +2028,11 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
     // repeat that pair's loads (no traffic of their own), park nothing in LDS, store nothing and add nothing to the dots; the right halo sits behind the last pair.
     const int SX = min(TX, (int)S_ - col0), hl = (SX >> 1) - 1, lc = 2 * min(lane, hl);
     const bool act = lane <= hl;
-    const long long base = (long long)(line0 + w * LPW) * S + col0 + lc;      // this lane's first pair inside a plane; its LPW pairs are S apart
+    // ... and planes whose lines are not a multiple of TY: the last tile of a plane holds LY < TY lines.  A wavefront's lines beyond them repeat the last line's loads,
+    // park nothing, store nothing; the bottom halo line sits behind the last line (LDS row LY + 1), loaded and parked by wavefront 3 as ever.
+    const int LY = min(TY, (int)(SO / S) - line0);
+    auto lval = [&](int i) { return w * LPW + i < LY; };
+    auto roff = [&](int i) { return (long long)(line0 + min(w * LPW + i, LY - 1)) * S + col0 + lc; };      // this lane's pair of line i inside a plane
     auto at = [&](long long a) { return (int)(a < 0 ? 0 : (a > (long long)nx - 2 ? (long long)nx - 2 : a)); };      // (pairs: the last start is nx - 2)
     // (BOX) the zero that a masked slot's x is replaced by: its product with the slot's value must be -0.0, so it carries the opposite of the value's sign
     auto poison = [&](int kind) {
@@ -2043,36 +2047,36 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
     (void)lines;
     struct Packet { v2f64 own[LPW]; v2f64 hy; double hx[LPW]; v2f64 ww[WS ? LPW : 1]; unsigned short pat[LPW]; };
     auto load_packet = [&](Packet &P, int z, bool pats) {
-        const long long pb = (long long)z * SO + base;
+        const long long pz = (long long)z * SO;
 #pragma unroll
-        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + at(pb + i * S));
+        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + at(pz + roff(i)));
         if (w == 0) P.hy = *reinterpret_cast<const v2f64u *>(x + at((long long)z * SO + (long long)(line0 - 1) * S + col0 + lc));
-        if (w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at((long long)z * SO + (long long)(line0 + TY) * S + col0 + lc));
+        if (w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at((long long)z * SO + (long long)(line0 + LY) * S + col0 + lc));
         if (lane == 0 || lane == hl) {
 #pragma unroll
-            for (int i = 0; i < LPW; i++) P.hx[i] = x[at((long long)z * SO + (long long)(line0 + w * LPW + i) * S + (lane == 0 ? col0 - 1 : col0 + SX))];
+            for (int i = 0; i < LPW; i++) P.hx[i] = x[at((long long)z * SO + (long long)(line0 + min(w * LPW + i, LY - 1)) * S + (lane == 0 ? col0 - 1 : col0 + SX))];
         }
         if (pats && z < M.z1) {                                       // (uniform) the pattern bytes (and w, when it is a vector of its own) of the rows this plane's sums are for
             if (!BOX) {
 #pragma unroll
-                for (int i = 0; i < LPW; i++) P.pat[i] = *reinterpret_cast<const unsigned short *>(rowpat + pb + i * S);
+                for (int i = 0; i < LPW; i++) P.pat[i] = *reinterpret_cast<const unsigned short *>(rowpat + pz + roff(i));
             }
             if (DOT != 0 && WS) {
 #pragma unroll
-                for (int i = 0; i < LPW; i++) P.ww[i] = *reinterpret_cast<const v2f64u *>(wdot + pb + i * S);
+                for (int i = 0; i < LPW; i++) P.ww[i] = *reinterpret_cast<const v2f64u *>(wdot + pz + roff(i));
             }
         }
     };
     auto store_packet = [&](const Packet &P, double *B) {
         if (act) {
 #pragma unroll
-            for (int i = 0; i < LPW; i++) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = P.own[i];
+            for (int i = 0; i < LPW; i++) if (lval(i)) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = P.own[i];
             if (w == 0) { v2f64 h = P.hy; if (box_top && mode(1) == 0) { h.x = h.y = poison(1); } *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = h; }
-            if (w == 3) { v2f64 h = P.hy; if (box_bottom && mode(5) == 0) { h.x = h.y = poison(5); } *reinterpret_cast<v2f64 *>(B + (TY + 1) * LX + 2 + 2 * lane) = h; }
+            if (w == 3) { v2f64 h = P.hy; if (box_bottom && mode(5) == 0) { h.x = h.y = poison(5); } *reinterpret_cast<v2f64 *>(B + (LY + 1) * LX + 2 + 2 * lane) = h; }
         }
         if (lane == 0 || lane == hl) {
 #pragma unroll
-            for (int i = 0; i < LPW; i++) {
+            for (int i = 0; i < LPW; i++) if (lval(i)) {
                 double h = P.hx[i];
                 if (box_left && lane == 0 && mode(2) == 0) h = poison(2);
                 if (box_right && lane == hl && mode(4) == 0) h = poison(4);
@@ -2137,14 +2141,15 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
                             default: xx[u] = nxt; break;
                             }
                     }
-                    const long long row = (long long)z * SO + base + i * S;
+                    const long long row = (long long)z * SO + roff(i);
+                    const bool live = act && lval(i);
                     const int ra = (int)row;
                     const int pa = (int)(pat0[i] & 255u), pb = (int)(pat0[i] >> 8);
                     double s0 = acc0, s1 = acc0;
                     if (BOX) {
                         // which sides of the grid this pair's rows lie on (x: the first row of lane 0 / the second row of the last lane; y, z: uniform)
                         const bool o_l = box_left && lane == 0, o_r = box_right && lane == hl;
-                        const bool o_u = box_top && w * LPW + i == 0, o_d = box_bottom && w * LPW + i == TY - 1, o_p = z == 0, o_n = z == planes_all - 1;
+                        const bool o_u = box_top && w * LPW + i == 0, o_d = box_bottom && w * LPW + i == LY - 1, o_p = z == 0, o_n = z == planes_all - 1;
 #pragma unroll
                         for (int u = 0; u < 7; u++) {
                             double v0 = D.val[u], v1 = D.val[u];
@@ -2209,8 +2214,8 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
                         }
                     }
                     v2f64 out; out.x = s0; out.y = s1;
-                    if (act) store_stream(reinterpret_cast<v2f64 *>(y + row), out);
-                    if (DOT != 0 && act) {
+                    if (live) store_stream(reinterpret_cast<v2f64 *>(y + row), out);
+                    if (DOT != 0 && live) {
                         const v2f64 wv = WS ? ww0[i] : c;
                         c0 += wv.x * s0; c0 += wv.y * s1;
                         if (DOT >= 2) { c1 += s0 * s0; c1 += s1 * s1; }

@@ -251,11 +251,12 @@ static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
     if (!dom_seven_point(D, S, SO, perm)) return false;
     const int order = perm == 0x1ac688 ? 0 : perm == 0x0e2a70 ? 1 : 2;      // (slot u at bits 3u: ascending 0,1,2,3,4,5,6; the generators' 0,6,1,5,2,4,3)
     // lines of any even length from 128 on (round 5: the last tile of a line is partial -- at least two pairs wide, so that its left and right halo columns have a lane each)
-    if (S < 128 || S % 2 != 0 || (S % 128 != 0 && S % 128 < 4) || SO <= S || SO % S != 0 || (SO / S) % 8 != 0) return false;
+    // ... and planes of any number of lines from 8 on (the last tile of a plane holds fewer than its 8 lines); lines shorter than a tile from 64 columns on (half the lanes idle at worst)
+    if (S < 64 || S % 2 != 0 || (S % 128 != 0 && S % 128 < 4) || SO <= S || SO % S != 0 || SO / S < 8) return false;
     if (a.rb % SO != 0 || a.re % SO != 0 || a.re > P->n || a.rb < 0) return false;
     const int z0 = a.rb / SO, z1 = a.re / SO, planes = z1 - z0;
     if (planes < 8) return false;
-    const int tiles_x = (S + 127) / 128, tiles_y = (SO / S) / 8, tiles = tiles_x * tiles_y;
+    const int tiles_x = (S + 127) / 128, tiles_y = (SO / S + 7) / 8, tiles = tiles_x * tiles_y;
     int nseg = (3 * 256 + tiles - 1) / tiles;                 // (512^3, 256 tiles: three segments 0.385 ms, four 0.398, two 0.37-0.42, one 0.52; tiles of 16 lines or three planes ahead: within the noise)
     if (nseg > planes / 8) nseg = planes / 8;
     if (nseg < 1) nseg = 1;
@@ -266,6 +267,9 @@ static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
     // forms at 256^3: 0.105 / 0.086 against 0.057 / 0.050 ms -- so by default only launches inside the box planes or of plans whose other patterns are plain masks march
     if (g_dom_march == 1 && !(P->dom_simple || (z0 >= P->box_z0 && z1 <= P->box_z1)) ) return false;
     if (g_dom_march == 1 && order == 2 && !P->dom_simple) return false;
+    // partial tiles pay from ~4 M rows on (192^3: 0.031 -> 0.021 ms, 300^3: 0.115 -> 0.076; 150^3: 0.017 -> 0.019, 100^3: 0.0069 -> 0.0111, 64^3: 0.0046 -> 0.010 -- a few
+    // hundred marching workgroups lose to the gathering kernel's thousands of independent wavefronts); grids of whole tiles keep the round-4 rule below
+    if (g_dom_march == 1 && (S % 128 != 0 || (SO / S) % 8 != 0) && (S < 128 || (long long)planes * SO < (4ll << 20))) return false;
     if (M.wgs < 64 && g_dom_march == 1) return false;      // (a handful of workgroups walking a small grid: the gathering kernel's thousands of independent wavefronts win; 2 / 3: at any size, tests)
     M.xcd = (M.wgs % NUM_XCD == 0 && M.wgs >= 8 * NUM_XCD) ? 1 : 0;
     return true;

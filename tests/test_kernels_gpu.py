@@ -2313,7 +2313,10 @@ def test_block2_marching_kernel_bit_exact(lib, dims, order):
 
 @pytest.mark.parametrize("case", ["constant", "ell_padded", "values_differ", "foreign_rows", "two_tiles_wide", "generator_order", "other_order", "slab_of_rank_0", "slab_of_rank_1", "dia_zeros",
                                   # lines that are not a multiple of 128 long (round 5): the last tile of a line is partial -- 64, 4, 72, 126, 8 and 60 columns wide
-                                  "constant@192", "ell_padded@132", "dia_zeros@200", "generator_order@254", "slab_of_rank_1@136", "foreign_rows@188", "values_differ@320", "other_order@192"])
+                                  "constant@192", "ell_padded@132", "dia_zeros@200", "generator_order@254", "slab_of_rank_1@136", "foreign_rows@188", "values_differ@320", "other_order@192",
+                                  # ... planes whose lines are not a multiple of 8 (the last tile of a plane is partial: 1 .. 7 lines), lines shorter than a tile
+                                  "constant@128x9", "constant@192x15", "ell_padded@132x12", "dia_zeros@100x13", "generator_order@64x10", "slab_of_rank_0@200x11", "slab_of_rank_1@72x17",
+                                  "foreign_rows@100x20", "values_differ@140x14", "other_order@96x9"])
 def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
     """the 7-point stencil with value records on a grid whose lines are a multiple of 128 long: a workgroup walks the planes of its 128 x 8 tile, each x loaded once
     (spmv_csr_valuerec_march_kernel; 512^3: 0.49 -> 0.41 ms).  The oracle's bits with the form on and off -- Inf / NaN / -0.0 in x, rows of other patterns (faces: masks;
@@ -2322,7 +2325,8 @@ def test_z_marching_form_of_the_dominant_pattern_product(lib, case):
     case, _, line = case.partition("@")
     nz, ny, nx = (12, 16, 256) if case == "two_tiles_wide" else (20, 16, 128)
     if line:
-        nx = int(line)
+        nx = int(line.split("x")[0])
+        ny = int(line.split("x")[1]) if "x" in line else ny
     ptr, idx, val = orc.poisson3d(nz, ny, nx, sort_cols=True)
     n = len(ptr) - 1
     SO = ny * nx
@@ -2444,7 +2448,7 @@ def test_z_marching_on_perturbed_grids(lib, seed):
     a value changed, an entry of an interior row removed, a column moved -- so that the box the plan finds is some run of planes between them: every form of the
     product (marching at any size, its masks' form, the gathering kernel), whole and in ranges that cut planes, must give the oracle's bits"""
     rng = np.random.default_rng(9000 + seed)
-    nx, ny, nz = int(rng.choice([128, 256, 132, 190, 200, 254, 322])), 8 * int(rng.integers(1, 4)), int(rng.integers(9, 22))      # (lines with a partial last tile too: round 5)
+    nx, ny, nz = int(rng.choice([128, 256, 132, 190, 200, 254, 322, 64, 100])), int(rng.choice([8, 16, 24, 9, 13, 20, 31])), int(rng.integers(9, 22))      # (partial last tiles in x and y too: round 5)
     flavour = ["csr", "csr_generator", "ell", "dia"][seed % 4]
     ptr, idx, val = orc.poisson3d(nz, ny, nx, sort_cols=flavour != "csr_generator")
     n, SO = len(ptr) - 1, ny * nx

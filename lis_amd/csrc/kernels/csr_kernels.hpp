@@ -2017,7 +2017,7 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
     if (DOT != 0 && tid == 0) dot_count = 0u;                         // (a barrier follows before anyone counts itself in)
     int wg = (int)blockIdx.x;
     const int ntile = M.tiles_x * M.tiles_y;
-    if (M.xcd) { const int k = wg % NUM_XCD, j = wg / NUM_XCD; wg = k * (M.wgs / NUM_XCD) + j; }      // each XCD a contiguous eighth of the (segment, tile) list: its L2 holds the halo lines neighbouring tiles share
+    if (M.xcd) { const int e = M.wgs / NUM_XCD; if (wg < e * NUM_XCD) { const int k = wg % NUM_XCD, j = wg / NUM_XCD; wg = k * e + j; } }      // each XCD a contiguous eighth of the (segment, tile) list: its L2 holds the halo lines neighbouring tiles share (the last wgs % 8 keep their place)
     const int seg = wg / ntile, t = wg - seg * ntile;
     const int ty = t / M.tiles_x, tx = t - ty * M.tiles_x;
     const int za = M.z0 + seg * M.zseg, zb = min(M.z1, za + M.zseg);

@@ -271,7 +271,7 @@ static bool dom_march_shape(const LaunchArgs &a, DomMarch &M)
     // hundred marching workgroups lose to the gathering kernel's thousands of independent wavefronts); grids of whole tiles keep the round-4 rule below
     if (g_dom_march == 1 && (S % 128 != 0 || (SO / S) % 8 != 0) && (S < 128 || (long long)planes * SO < (4ll << 20))) return false;
     if (M.wgs < 64 && g_dom_march == 1) return false;      // (a handful of workgroups walking a small grid: the gathering kernel's thousands of independent wavefronts win; 2 / 3: at any size, tests)
-    M.xcd = (M.wgs % NUM_XCD == 0 && M.wgs >= 8 * NUM_XCD) ? 1 : 0;
+    M.xcd = M.wgs >= 8 * NUM_XCD ? 1 : 0;
     return true;
 }
 

@@ -107,7 +107,7 @@ int  liship_csr_plan_team_form(liship_csr_plan_t plan);
 /* 1 when a plan with WIDE value records (constant-coefficient rows of up to 32 entries) also found a dominant pattern and runs the kernel with x staged per
  * wavefront and that pattern's slots and values in scalar registers (spmv_csr_valuerecw_staged_kernel) */
 int  liship_csr_plan_wide_dominant(liship_csr_plan_t plan);
-/* 1 when, on top of that, the matrix is the 27-point box stencil with constant coefficients on a grid that IS a box (lines a multiple of 128 long, rows in ascending
+/* 1 when, on top of that, the matrix is the 27-point box stencil with constant coefficients on a grid that IS a box (lines of any even length from 128 on -- round 5: partial tiles --, rows in ascending
  * column order; checked row by row at plan time) and its whole-matrix product walks the planes of 128-column tiles with each x loaded once (round 5:
  * spmv_csr_box27_march_kernel -- x and y alone are streamed); liship_spmv_csr_set_dom_march(0) keeps the staged kernel (A/B), 2 marches at any size (tests) */
 int  liship_csr_plan_box27(liship_csr_plan_t plan);

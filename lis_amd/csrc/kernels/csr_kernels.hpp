@@ -2835,48 +2835,56 @@ void spmv_csr_box27_march_kernel(const double *__restrict__ x, double *__restric
     if (DOT != 0 && tid == 0) dot_count = 0u;                         // (a barrier follows before anyone counts itself in)
     int wg = (int)blockIdx.x;
     const int ntile = M.tiles_x * M.tiles_y;
-    if (M.xcd) { const int k = wg % NUM_XCD, j = wg / NUM_XCD; wg = k * (M.wgs / NUM_XCD) + j; }      // each XCD a contiguous eighth of the (segment, tile) list
+    if (M.xcd) { const int e = M.wgs / NUM_XCD; if (wg < e * NUM_XCD) { const int k = wg % NUM_XCD, j = wg / NUM_XCD; wg = k * e + j; } }      // each XCD a contiguous eighth of the (segment, tile) list
     const int seg = wg / ntile, t = wg - seg * ntile;
     const int ty = t / M.tiles_x, tx = t - ty * M.tiles_x;
     const int za = M.z0 + seg * M.zseg, zb = min(M.z1, za + M.zseg);
     const int col0 = tx * TX, line0 = ty * TY;
     const long long S = M.S, SO = M.SO;
-    const long long base = (long long)(line0 + w * LPW) * S + col0 + 2 * lane;      // this lane's first pair inside a plane; its LPW pairs are S apart
+    // partial tiles (round 5, as in spmv_csr_valuerec_march_kernel): the last tile of a line holds SX < 128 columns (even, >= 4), the last tile of a plane LY < TY lines.  Lanes /
+    // lines beyond them repeat the last pair's / line's loads, park nothing, store nothing; the right halo column sits behind the last pair, the bottom halo line behind the last line.
+    const int SX = min(TX, M.S - col0), hlane = (SX >> 1) - 1, lc = 2 * min(lane, hlane);
+    const int LY = min(TY, (int)(SO / S) - line0);
+    const bool act = lane <= hlane;
+    auto lval = [&](int i) { return w * LPW + i < LY; };
+    auto lidx = [&](int i) { return line0 + min(w * LPW + i, LY - 1); };
+    auto roff = [&](int i) { return (long long)lidx(i) * S + col0 + lc; };      // this lane's pair of line i inside a plane
     auto at = [&](long long a) { return (int)(a < 0 ? 0 : (a > (long long)nx - 2 ? (long long)nx - 2 : a)); };      // (pairs: the last start is nx - 2; clamped addresses only ever feed poisoned cells)
     const double pz = M.poison;
     const bool box_left = tx == 0, box_right = tx == M.tiles_x - 1, box_top = ty == 0, box_bottom = ty == M.tiles_y - 1;      // (uniform)
     struct Packet { v2f64 own[LPW]; v2f64 hy; double hx[LPW]; double hc; v2f64 ww[WS ? LPW : 1]; };
     auto load_packet = [&](Packet &P, int z, bool with_w) {
-        const long long zo = (long long)z * SO, pb = zo + base;
+        const long long zo = (long long)z * SO;
 #pragma unroll
-        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + at(pb + i * S));
-        const long long hl = zo + (long long)(w == 0 ? line0 - 1 : line0 + TY) * S + col0;      // the halo line this wavefront brings (the first and the last wavefront)
-        if (w == 0 || w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at(hl + 2 * lane));
-        if (lane == 0 || lane == WAVE - 1) {
-            const int hcol = lane == 0 ? col0 - 1 : col0 + TX;
+        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + at(zo + roff(i)));
+        const long long hl = zo + (long long)(w == 0 ? line0 - 1 : line0 + LY) * S + col0;      // the halo line this wavefront brings (the first and the last wavefront)
+        if (w == 0 || w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at(hl + lc));
+        if (lane == 0 || lane == hlane) {
+            const int hcol = lane == 0 ? col0 - 1 : col0 + SX;
 #pragma unroll
-            for (int i = 0; i < LPW; i++) { const long long a = zo + (long long)(line0 + w * LPW + i) * S + hcol; P.hx[i] = x[a < 0 ? 0 : (a > (long long)nx - 1 ? (long long)nx - 1 : a)]; }
-            if (w == 0 || w == 3) { const long long a = zo + (long long)(w == 0 ? line0 - 1 : line0 + TY) * S + hcol; P.hc = x[a < 0 ? 0 : (a > (long long)nx - 1 ? (long long)nx - 1 : a)]; }
+            for (int i = 0; i < LPW; i++) { const long long a = zo + (long long)lidx(i) * S + hcol; P.hx[i] = x[a < 0 ? 0 : (a > (long long)nx - 1 ? (long long)nx - 1 : a)]; }
+            if (w == 0 || w == 3) { const long long a = zo + (long long)(w == 0 ? line0 - 1 : line0 + LY) * S + hcol; P.hc = x[a < 0 ? 0 : (a > (long long)nx - 1 ? (long long)nx - 1 : a)]; }
         }
         if (DOT != 0 && WS && with_w && z < M.z1) {
 #pragma unroll
-            for (int i = 0; i < LPW; i++) P.ww[i] = *reinterpret_cast<const v2f64u *>(wdot + pb + i * S);
+            for (int i = 0; i < LPW; i++) P.ww[i] = *reinterpret_cast<const v2f64u *>(wdot + zo + roff(i));
         }
     };
     // a plane into an LDS buffer: the cells outside the grid take the zero (a whole plane of it before the first and behind the last plane)
     auto store_packet = [&](const Packet &P, double *B, int z) {
         const bool off = z < 0 || z >= M.planes;                      // (uniform)
 #pragma unroll
-        for (int i = 0; i < LPW; i++) { v2f64 v = P.own[i]; if (off) { v.x = v.y = pz; } *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = v; }
-        if (w == 0) { v2f64 h = P.hy; if (off || box_top) { h.x = h.y = pz; } *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = h; }
-        if (w == 3) { v2f64 h = P.hy; if (off || box_bottom) { h.x = h.y = pz; } *reinterpret_cast<v2f64 *>(B + (TY + 1) * LX + 2 + 2 * lane) = h; }
-        if (lane == 0 || lane == WAVE - 1) {
+        for (int i = 0; i < LPW; i++) if (act && lval(i)) { v2f64 v = P.own[i]; if (off) { v.x = v.y = pz; } *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = v; }
+        if (w == 0 && act) { v2f64 h = P.hy; if (off || box_top) { h.x = h.y = pz; } *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = h; }
+        if (w == 3 && act) { v2f64 h = P.hy; if (off || box_bottom) { h.x = h.y = pz; } *reinterpret_cast<v2f64 *>(B + (LY + 1) * LX + 2 + 2 * lane) = h; }
+        if (lane == 0 || lane == hlane) {
+            const int c = lane == 0 ? 1 : 2 + SX;
+            // (a tile one pair wide cannot be: SX >= 4, so lane 0 and lane hlane are two lanes and each writes one side)
             const bool side = lane == 0 ? box_left : box_right;
-            const int c = lane == 0 ? 1 : 2 + TX;
 #pragma unroll
-            for (int i = 0; i < LPW; i++) B[(w * LPW + i + 1) * LX + c] = (off || side) ? pz : P.hx[i];
+            for (int i = 0; i < LPW; i++) if (lval(i)) B[(w * LPW + i + 1) * LX + c] = (off || side) ? pz : P.hx[i];
             if (w == 0) B[c] = (off || side || box_top) ? pz : P.hc;
-            if (w == 3) B[(TY + 1) * LX + c] = (off || side || box_bottom) ? pz : P.hc;
+            if (w == 3) B[(LY + 1) * LX + c] = (off || side || box_bottom) ? pz : P.hc;
         }
     };
     // the lines a lane's rows need from a plane in LDS: LPW + 2 of them, four columns each (left, its pair, right)
@@ -2937,10 +2945,11 @@ void spmv_csr_box27_march_kernel(const double *__restrict__ x, double *__restric
                     }
                 }
             }
-            const long long row = (long long)z * SO + base + i * S;
+            const long long row = (long long)z * SO + roff(i);
+            const bool live = act && lval(i);
             v2f64 out; out.x = s0; out.y = s1;
-            store_stream(reinterpret_cast<v2f64 *>(y + row), out);
-            if (DOT != 0) {
+            if (live) store_stream(reinterpret_cast<v2f64 *>(y + row), out);
+            if (DOT != 0 && live) {
                 v2f64 wv;
                 if (WS) wv = ww0[i]; else { wv.x = Xq[i + 1][1]; wv.y = Xq[i + 1][2]; }
                 c0 += wv.x * s0; c0 += wv.y * s1;

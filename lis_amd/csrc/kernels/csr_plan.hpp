@@ -1131,7 +1131,7 @@ static void try_box27(liship_csr_plan_s *p, const int *od, const WideDom &D, hip
     p->b27.S = 0;
     if (D.len != 27 || D.pat < 0 || !p->wdrec || !p->rowpat) return;
     const int S = od[16], SO = od[22];
-    if (S < 128 || S % 128 != 0 || SO < 4 * S || SO % S != 0 || (SO / S) % 4 != 0 || p->n % SO != 0 || p->n / SO < 2) return;
+    if (S < 128 || S % 2 != 0 || (S % 128 != 0 && S % 128 < 4) || SO < 4 * S || SO % S != 0 || p->n % SO != 0 || p->n / SO < 2) return;      // (lines of any even length from 128 on, any number of lines from 4 on: partial tiles)
     for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++)
         if (od[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] != dz * SO + dy * S + dx) return;
     for (int u = 0; u < 27; u++) {

@@ -121,8 +121,9 @@ static bool box27_shape(const LaunchArgs &a, Box27 &M, int &lpw)
     const int z0 = a.rb / SO, z1 = a.re / SO, planes = z1 - z0;
     if (planes < 1 || (planes < 8 && g_dom_march == 1)) return false;
     const int lines = SO / S;
-    lpw = (lines % 8 == 0 && g_dom_march != 3) ? 2 : 1;                 // (3: four lines per tile everywhere -- tests of that instantiation)
-    const int tiles_x = S / 128, tiles_y = lines / (4 * lpw), tiles = tiles_x * tiles_y;
+    lpw = ((lines % 8 == 0 || lines % 4 != 0) && g_dom_march != 3) ? 2 : 1;      // (3: four lines per tile everywhere -- tests of that instantiation; lines % 4 == 0 keeps the whole tiles of four)
+    const int tiles_x = (S + 127) / 128, tiles_y = (lines + 4 * lpw - 1) / (4 * lpw), tiles = tiles_x * tiles_y;      // (round 5: the last tile of a line / of a plane may be partial)
+    if (g_dom_march == 1 && (S % 128 != 0 || lines % 4 != 0) && (long long)planes * SO < (4ll << 20)) return false;      // partial tiles pay on large grids only (the 7-point kernel's measurement)
     // (256^3, same box: three workgroups per CU 0.0591 ms, two 0.0613, four 0.0630, six 0.0633; tiles of four lines 0.0640 at best -- profiles/EXPERIMENTS.md)
     int nseg = (3 * 256 + tiles - 1) / tiles;
     if (nseg > planes / 8) nseg = planes / 8;
@@ -131,7 +132,7 @@ static bool box27_shape(const LaunchArgs &a, Box27 &M, int &lpw)
     nseg = (planes + zseg - 1) / zseg;
     M.tiles_x = tiles_x; M.tiles_y = tiles_y; M.zseg = zseg; M.nseg = nseg; M.z0 = z0; M.z1 = z1; M.wgs = tiles * nseg;
     if (M.wgs < 64 && g_dom_march == 1) return false;                // (a handful of workgroups walking a small grid: the staged kernel's thousands of independent wavefronts win)
-    M.xcd = (M.wgs % NUM_XCD == 0 && M.wgs >= 8 * NUM_XCD) ? 1 : 0;
+    M.xcd = M.wgs >= 8 * NUM_XCD ? 1 : 0;
     return true;
 }
 

@@ -2055,7 +2055,9 @@ def _box27_per_slot(dims, values):
     return ptr, idx, values[((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)).astype(np.int64)]
 
 
-@pytest.mark.parametrize("dims,march", [((9, 8, 128), 2), ((10, 12, 128), 2), ((9, 8, 128), 3), ((11, 16, 256), 2), ((8, 8, 256), 2)])
+@pytest.mark.parametrize("dims,march", [((9, 8, 128), 2), ((10, 12, 128), 2), ((9, 8, 128), 3), ((11, 16, 256), 2), ((8, 8, 256), 2),
+                                        # partial tiles (round 5): lines that are not a multiple of 128 long, planes whose lines are not a multiple of a tile's
+                                        ((9, 10, 192), 2), ((10, 7, 132), 2), ((9, 13, 200), 2), ((8, 9, 254), 2), ((9, 6, 136), 3), ((9, 17, 128), 2), ((9, 11, 320), 3)])
 @pytest.mark.parametrize("values", ["hpcg", "per_slot"])
 def test_box27_marching_kernel_bit_exact(lib, dims, march, values):
     """Round 5: the 27-point box stencil with constant coefficients on a grid that is a box -- the matrix of the reference's spmvtest3b (test/spmvtest3b.c:136-160)

@@ -1,6 +1,6 @@
 # bench.py over grid sizes: SpMV GFLOP/s (value records and values streamed) and Krylov it/s per size -> gpurun_out/size_sweep.txt
 cd $GRAFT_REPO_ROOT
-for g in 64 128 192 256 320 384 448 512; do
+for g in 64 100 128 192 200 256 300 320 384 448 512; do
   timeout 600 python bench.py --grid $g --steps 50 --warmup 5 --preroll 200 --solver-iters 300 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])

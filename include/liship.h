@@ -122,7 +122,7 @@ int  liship_spmv_csr_set_team(int on);           /* A/B switch: 0 = the one-lane
  * matrix does not qualify; row ranges that cut a block row run the row-by-row kernels.  Bits of lis_matvec_bsr.c:293-343. */
 int  liship_csr_plan_encode_block_rows(liship_csr_plan_t plan, int b, const int *ptr, void *stream);
 int  liship_csr_plan_block_rows(liship_csr_plan_t plan);       /* b when the plan keeps them, else 0 */
-/* 1 when those block rows are the 7-point stencil in 2 x 2 blocks on a grid that is a box (lines a multiple of 128 long; checked block row by block row at plan time)
+/* 1 when those block rows are the 7-point stencil in 2 x 2 blocks on a grid that is a box (lines of any even length from 128 on -- round 5: partial tiles --; checked block row by block row at plan time)
  * and the whole-matrix product walks the planes with each x loaded once (round 5: spmv_csr_block2_march_kernel); liship_spmv_csr_set_dom_march as for the others */
 int  liship_csr_plan_block2_march(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_block_rows(int on);                   /* A/B switch: 0 = the row-by-row kernels (same bits) */

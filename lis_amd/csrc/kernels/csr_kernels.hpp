@@ -2998,40 +2998,46 @@ void spmv_csr_block2_march_kernel(const double *__restrict__ x, double *__restri
     if (DOT != 0 && tid == 0) dot_count = 0u;
     int wg = (int)blockIdx.x;
     const int ntile = M.tiles_x * M.tiles_y;
-    if (M.xcd) { const int k = wg % NUM_XCD, j = wg / NUM_XCD; wg = k * (M.wgs / NUM_XCD) + j; }
+    if (M.xcd) { const int e = M.wgs / NUM_XCD; if (wg < e * NUM_XCD) { const int k = wg % NUM_XCD, j = wg / NUM_XCD; wg = k * e + j; } }
     const int seg = wg / ntile, t = wg - seg * ntile;
     const int ty = t / M.tiles_x, tx = t - ty * M.tiles_x;
     const int za = M.z0 + seg * M.zseg, zb = min(M.z1, za + M.zseg);
     const int col0 = tx * TX, line0 = ty * TY;
     const long long S = M.S, SO = M.SO;
-    const long long base = (long long)(line0 + w * LPW) * S + col0 + 2 * lane;
+    // partial tiles (round 5, as in spmv_csr_valuerec_march_kernel): SX < 128 columns in the last tile of a line (whole blocks: even, >= 4), LY < TY lines in the last tile of a plane
+    const int SX = min(TX, M.S - col0), hlane = (SX >> 1) - 1, lc = 2 * min(lane, hlane);
+    const int LY = min(TY, (int)(SO / S) - line0);
+    const bool act = lane <= hlane;
+    auto lval = [&](int i) { return w * LPW + i < LY; };
+    auto lidx = [&](int i) { return line0 + min(w * LPW + i, LY - 1); };
+    auto roff = [&](int i) { return (long long)lidx(i) * S + col0 + lc; };
     auto at = [&](long long a) { return (int)(a < 0 ? 0 : (a > (long long)nx - 2 ? (long long)nx - 2 : a)); };      // (clamped addresses only ever feed zeroed cells)
     const bool box_left = tx == 0, box_right = tx == M.tiles_x - 1, box_top = ty == 0, box_bottom = ty == M.tiles_y - 1;      // (uniform)
     v2f64 zero2; zero2.x = 0.0; zero2.y = 0.0;
     struct Packet { v2f64 own[LPW]; v2f64 hy; v2f64 hx[LPW]; v2f64 ww[WS ? LPW : 1]; };
     auto load_packet = [&](Packet &P, int z, bool with_w) {
-        const long long zo = (long long)z * SO, pb = zo + base;
+        const long long zo = (long long)z * SO;
 #pragma unroll
-        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + at(pb + i * S));
-        if (w == 0 || w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at(zo + (long long)(w == 0 ? line0 - 1 : line0 + TY) * S + col0 + 2 * lane));
-        if (lane == 0 || lane == WAVE - 1) {
+        for (int i = 0; i < LPW; i++) P.own[i] = *reinterpret_cast<const v2f64u *>(x + at(zo + roff(i)));
+        if (w == 0 || w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at(zo + (long long)(w == 0 ? line0 - 1 : line0 + LY) * S + col0 + lc));
+        if (lane == 0 || lane == hlane) {
 #pragma unroll
-            for (int i = 0; i < LPW; i++) P.hx[i] = *reinterpret_cast<const v2f64u *>(x + at(zo + (long long)(line0 + w * LPW + i) * S + (lane == 0 ? col0 - 2 : col0 + TX)));
+            for (int i = 0; i < LPW; i++) P.hx[i] = *reinterpret_cast<const v2f64u *>(x + at(zo + (long long)lidx(i) * S + (lane == 0 ? col0 - 2 : col0 + SX)));
         }
         if (DOT != 0 && WS && with_w && z < M.z1) {
 #pragma unroll
-            for (int i = 0; i < LPW; i++) P.ww[i] = *reinterpret_cast<const v2f64u *>(wdot + pb + i * S);
+            for (int i = 0; i < LPW; i++) P.ww[i] = *reinterpret_cast<const v2f64u *>(wdot + zo + roff(i));
         }
     };
     auto store_packet = [&](const Packet &P, double *B) {
 #pragma unroll
-        for (int i = 0; i < LPW; i++) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = P.own[i];
-        if (w == 0) *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = box_top ? zero2 : P.hy;
-        if (w == 3) *reinterpret_cast<v2f64 *>(B + (TY + 1) * LX + 2 + 2 * lane) = box_bottom ? zero2 : P.hy;
-        if (lane == 0 || lane == WAVE - 1) {
+        for (int i = 0; i < LPW; i++) if (act && lval(i)) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + 2 + 2 * lane) = P.own[i];
+        if (w == 0 && act) *reinterpret_cast<v2f64 *>(B + 2 + 2 * lane) = box_top ? zero2 : P.hy;
+        if (w == 3 && act) *reinterpret_cast<v2f64 *>(B + (LY + 1) * LX + 2 + 2 * lane) = box_bottom ? zero2 : P.hy;
+        if (lane == 0 || lane == hlane) {
             const bool side = lane == 0 ? box_left : box_right;
 #pragma unroll
-            for (int i = 0; i < LPW; i++) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + (lane == 0 ? 0 : 2 + TX)) = side ? zero2 : P.hx[i];
+            for (int i = 0; i < LPW; i++) if (lval(i)) *reinterpret_cast<v2f64 *>(B + (w * LPW + i + 1) * LX + (lane == 0 ? 0 : 2 + SX)) = side ? zero2 : P.hx[i];
         }
     };
     Packet Q[2];
@@ -3079,10 +3085,11 @@ void spmv_csr_block2_march_kernel(const double *__restrict__ x, double *__restri
                         s0 += M.v0[2 * q] * pr.x; s1 += M.v1[2 * q] * pr.x;
                         s0 += M.v0[2 * q + 1] * pr.y; s1 += M.v1[2 * q + 1] * pr.y;
                     }
-                    const long long row = (long long)z * SO + base + i * S;
+                    const long long row = (long long)z * SO + roff(i);
+                    const bool live = act && lval(i);
                     v2f64 out; out.x = s0; out.y = s1;
-                    store_stream(reinterpret_cast<v2f64 *>(y + row), out);
-                    if (DOT != 0) {
+                    if (live) store_stream(reinterpret_cast<v2f64 *>(y + row), out);
+                    if (DOT != 0 && live) {
                         const v2f64 wv = WS ? ww0[i] : src[3];
                         c0 += wv.x * s0; c0 += wv.y * s1;
                         if (DOT >= 2) { c1 += s0 * s0; c1 += s1 * s1; }

@@ -1459,7 +1459,7 @@ static void try_block2_march(liship_csr_plan_s *p, const int *doff, const BlockD
     if (npos != 3) return;
     for (int a = 1; a < 3; a++) { const int v = pos[a]; int c = a - 1; while (c >= 0 && pos[c] > v) { pos[c + 1] = pos[c]; c--; } pos[c + 1] = v; }
     const int S = pos[1], SO = pos[2];
-    if (pos[0] != 2 || S < 128 || S % 128 != 0 || SO < 8 * S || SO % S != 0 || (SO / S) % 8 != 0 || p->n % SO != 0 || p->n / SO < 2) return;
+    if (pos[0] != 2 || S < 128 || S % 2 != 0 || (S % 128 != 0 && S % 128 < 4) || SO < 8 * S || SO % S != 0 || p->n % SO != 0 || p->n / SO < 2) return;      // (partial tiles: lines of any even length from 128 on, any number of lines from 8 on)
     Block2March M;
     memset(&M, 0, sizeof(M));
     M.S = S; M.SO = SO; M.planes = p->n / SO;

@@ -146,7 +146,8 @@ static bool block2_shape(const LaunchArgs &a, Block2March &M)
     if (a.rb < 0 || a.re > P->n || a.rb % SO != 0 || a.re % SO != 0) return false;
     const int z0 = a.rb / SO, z1 = a.re / SO, planes = z1 - z0;
     if (planes < 1 || (planes < 8 && g_dom_march == 1)) return false;
-    const int tiles_x = S / 128, tiles_y = (SO / S) / 8, tiles = tiles_x * tiles_y;
+    const int tiles_x = (S + 127) / 128, tiles_y = (SO / S + 7) / 8, tiles = tiles_x * tiles_y;      // (round 5: the last tile of a line / of a plane may be partial)
+    if (g_dom_march == 1 && (S % 128 != 0 || (SO / S) % 8 != 0) && (long long)planes * SO < (4ll << 20)) return false;      // partial tiles pay on large grids only (the 7-point kernel's measurement)
     int nseg = (3 * 256 + tiles - 1) / tiles;
     if (nseg > planes / 8) nseg = planes / 8;
     if (nseg < 1) nseg = 1;
@@ -154,7 +155,7 @@ static bool block2_shape(const LaunchArgs &a, Block2March &M)
     nseg = (planes + zseg - 1) / zseg;
     M.tiles_x = tiles_x; M.tiles_y = tiles_y; M.zseg = zseg; M.nseg = nseg; M.z0 = z0; M.z1 = z1; M.wgs = tiles * nseg;
     if (M.wgs < 64 && g_dom_march == 1) return false;
-    M.xcd = (M.wgs % NUM_XCD == 0 && M.wgs >= 8 * NUM_XCD) ? 1 : 0;
+    M.xcd = M.wgs >= 8 * NUM_XCD ? 1 : 0;
     return true;
 }
 

@@ -2251,7 +2251,8 @@ def test_rows_that_take_turns_on_several_patterns_share_a_virtual_dominant_one(l
     assert taken[1] == 0 and (taken[0] == 1 or bs > 2), taken      # (3 x 3, 4 x 4: the rows' turns have no common supersequence of 32 entries; their block rows do not need one)
 
 
-@pytest.mark.parametrize("dims", [(9, 8, 128), (10, 16, 256), (8, 8, 256)])
+@pytest.mark.parametrize("dims", [(9, 8, 128), (10, 16, 256), (8, 8, 256),
+                                  (9, 10, 192), (10, 13, 132), (9, 8, 200), (8, 9, 254), (9, 17, 128)])      # partial tiles (round 5): lines that 128 does not divide, planes whose lines 8 does not
 @pytest.mark.parametrize("order", ["first_seen_generator", "first_seen_sorted", "ascending"])
 def test_block2_marching_kernel_bit_exact(lib, dims, order):
     """Round 5: the 7-point stencil kept as 2 x 2 blocks (Lis's default BSR block size, constant coefficients) on a box grid walks the planes like the scalar

@@ -351,7 +351,7 @@ static int build_split(liship_csr_plan_s *p, const int *ptr, hipStream_t st)
         }
         if (nh > 0) {
             v2i32 *hc = (v2i32 *)malloc(sizeof(v2i32) * (size_t)nch), *hh = (v2i32 *)malloc(sizeof(v2i32) * (size_t)(nh + 1));
-            if (!hc || !hh) { free(hc); free(hh); return LISHIP_ERR_ARG; }
+            if (!hc || !hh) { free(hc); free(hh); return (int)hipErrorOutOfMemory; }
             int c = 0, h = 0;
             for (int b = 0; b < p->nblocks; b++) {
                 const int len = p->blk_host[b + 1].y - p->blk_host[b].y;

@@ -2001,7 +2001,7 @@ __device__ __forceinline__ unsigned dom_masks_only(const double *__restrict__ dr
 // What the rows of a box do with a neighbour outside the grid is one of three things per side (M.modes, plan time): the slot is missing (the signed zero above), it is there
 // with the dominant value and a real x behind it (a multi-rank job's ghost plane: nothing to do), or it is there with another value (ALT: DIA keeps the diagonals' explicit
 // zeros, 0.0 * x of the row across the line's end -- the value is picked per row, x is the real one).  PADS: a (row, +0.0) term behind the sum per missing slot (ELL's padding).
-template <int LPW, int D_, int DOT, bool WS, int ORD, bool GEN, bool BOX = false, bool ALT = false, bool PADS = false>
+template <int LPW, int D_, int DOT, bool WS, int ORD, bool GEN, bool BOX = false, bool ALT = false, bool PADS = false, bool PT = true>
 __global__ __launch_bounds__(256)
 void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, const v4i32 *__restrict__ rec, const double *__restrict__ drec,
                                     const DomRec D, const double *__restrict__ x, double *__restrict__ y, double acc0, const DomMarch M, int nx,
@@ -2026,13 +2026,14 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
     const int S_ = M.S;
     // lines that are not a multiple of 128 long (round 5): the last tile of a line holds SX < 128 columns (even, >= 4: dom_march_shape).  Its lanes beyond the last pair
     // repeat that pair's loads (no traffic of their own), park nothing in LDS, store nothing and add nothing to the dots; the right halo sits behind the last pair.
-    const int SX = min(TX, (int)S_ - col0), hl = (SX >> 1) - 1, lc = 2 * min(lane, hl);
-    const bool act = lane <= hl;
+    // PT = false (grids of whole tiles, the plain box form: the headline's instantiation) folds every one of these tests away -- they cost 128^3 12 %, 512^3 1.3 %.
+    const int SX = PT ? min(TX, (int)S_ - col0) : TX, hl = PT ? (SX >> 1) - 1 : WAVE - 1, lc = PT ? 2 * min(lane, hl) : 2 * lane;
+    const bool act = PT ? lane <= hl : true;
     // ... and planes whose lines are not a multiple of TY: the last tile of a plane holds LY < TY lines.  A wavefront's lines beyond them repeat the last line's loads,
     // park nothing, store nothing; the bottom halo line sits behind the last line (LDS row LY + 1), loaded and parked by wavefront 3 as ever.
-    const int LY = min(TY, (int)(SO / S) - line0);
-    auto lval = [&](int i) { return w * LPW + i < LY; };
-    auto roff = [&](int i) { return (long long)(line0 + min(w * LPW + i, LY - 1)) * S + col0 + lc; };      // this lane's pair of line i inside a plane
+    const int LY = PT ? min(TY, (int)(SO / S) - line0) : TY;
+    auto lval = [&](int i) { return PT ? w * LPW + i < LY : true; };
+    auto roff = [&](int i) { return (long long)(line0 + (PT ? min(w * LPW + i, LY - 1) : w * LPW + i)) * S + col0 + lc; };      // this lane's pair of line i inside a plane
     auto at = [&](long long a) { return (int)(a < 0 ? 0 : (a > (long long)nx - 2 ? (long long)nx - 2 : a)); };      // (pairs: the last start is nx - 2)
     // (BOX) the zero that a masked slot's x is replaced by: its product with the slot's value must be -0.0, so it carries the opposite of the value's sign
     auto poison = [&](int kind) {
@@ -2054,7 +2055,7 @@ void spmv_csr_valuerec_march_kernel(const unsigned char *__restrict__ rowpat, co
         if (w == 3) P.hy = *reinterpret_cast<const v2f64u *>(x + at((long long)z * SO + (long long)(line0 + LY) * S + col0 + lc));
         if (lane == 0 || lane == hl) {
 #pragma unroll
-            for (int i = 0; i < LPW; i++) P.hx[i] = x[at((long long)z * SO + (long long)(line0 + min(w * LPW + i, LY - 1)) * S + (lane == 0 ? col0 - 1 : col0 + SX))];
+            for (int i = 0; i < LPW; i++) P.hx[i] = x[at((long long)z * SO + (long long)(line0 + (PT ? min(w * LPW + i, LY - 1) : w * LPW + i)) * S + (lane == 0 ? col0 - 1 : col0 + SX))];
         }
         if (pats && z < M.z1) {                                       // (uniform) the pattern bytes (and w, when it is a vector of its own) of the rows this plane's sums are for
             if (!BOX) {
@@ -2820,7 +2821,7 @@ void spmv_csr_blockrows_staged_kernel(const unsigned char *__restrict__ rowpat, 
 // and one rounded add per term: the reference's bits.  A neighbour outside the grid is a halo cell that holds a ZERO: its term is +-0.0, and a sum that starts at
 // +0.0 is never -0.0, so the term leaves every bit where a missing slot leaves it: no masks, no pattern bytes -- x once and y once, 16 B per row.
 struct Box27 { int S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, wgs, xcd, planes, pad; double poison; double val[27]; };
-template <int LPW, int DOT, bool WS>
+template <int LPW, int DOT, bool WS, bool PT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LPW == 2 ? 3 : 4)))      // (eight lines per tile: 171 registers without the hint -- three short of a third workgroup per CU)
 void spmv_csr_box27_march_kernel(const double *__restrict__ x, double *__restrict__ y, double acc0, const Box27 M, int nx,
                                  const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
@@ -2843,11 +2844,12 @@ void spmv_csr_box27_march_kernel(const double *__restrict__ x, double *__restric
     const long long S = M.S, SO = M.SO;
     // partial tiles (round 5, as in spmv_csr_valuerec_march_kernel): the last tile of a line holds SX < 128 columns (even, >= 4), the last tile of a plane LY < TY lines.  Lanes /
     // lines beyond them repeat the last pair's / line's loads, park nothing, store nothing; the right halo column sits behind the last pair, the bottom halo line behind the last line.
-    const int SX = min(TX, M.S - col0), hlane = (SX >> 1) - 1, lc = 2 * min(lane, hlane);
-    const int LY = min(TY, (int)(SO / S) - line0);
-    const bool act = lane <= hlane;
-    auto lval = [&](int i) { return w * LPW + i < LY; };
-    auto lidx = [&](int i) { return line0 + min(w * LPW + i, LY - 1); };
+    // PT = false (grids of whole tiles) folds all of it away: the partial-tile tests in the plane loop cost the whole-tile grids a third of their rate (256^3: 0.060 -> 0.080 ms).
+    const int SX = PT ? min(TX, M.S - col0) : TX, hlane = PT ? (SX >> 1) - 1 : WAVE - 1, lc = PT ? 2 * min(lane, hlane) : 2 * lane;
+    const int LY = PT ? min(TY, (int)(SO / S) - line0) : TY;
+    const bool act = PT ? lane <= hlane : true;
+    auto lval = [&](int i) { return PT ? w * LPW + i < LY : true; };
+    auto lidx = [&](int i) { return PT ? line0 + min(w * LPW + i, LY - 1) : line0 + w * LPW + i; };
     auto roff = [&](int i) { return (long long)lidx(i) * S + col0 + lc; };      // this lane's pair of line i inside a plane
     auto at = [&](long long a) { return (int)(a < 0 ? 0 : (a > (long long)nx - 2 ? (long long)nx - 2 : a)); };      // (pairs: the last start is nx - 2; clamped addresses only ever feed poisoned cells)
     const double pz = M.poison;
@@ -2983,7 +2985,7 @@ void spmv_csr_box27_march_kernel(const double *__restrict__ x, double *__restric
 // reference's generators (test/test3.c:114-127: -SO, +SO, -S, +S, left, own, right).  Compile-time, so that the 14 terms of a row are straight-line
 // code on registers (a run-time term list cost 350 branches and spilled the scalar registers: 0.108 ms at 256^3 against the staged kernel's 0.08).
 struct Block2March { int S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, wgs, xcd, planes, ord; double v0[14], v1[14]; };
-template <int ORD, int DOT, bool WS>
+template <int ORD, int DOT, bool WS, bool PT = true>
 __global__ __launch_bounds__(256)
 void spmv_csr_block2_march_kernel(const double *__restrict__ x, double *__restrict__ y, const Block2March M, int nx,
                                   const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
@@ -3005,11 +3007,12 @@ void spmv_csr_block2_march_kernel(const double *__restrict__ x, double *__restri
     const int col0 = tx * TX, line0 = ty * TY;
     const long long S = M.S, SO = M.SO;
     // partial tiles (round 5, as in spmv_csr_valuerec_march_kernel): SX < 128 columns in the last tile of a line (whole blocks: even, >= 4), LY < TY lines in the last tile of a plane
-    const int SX = min(TX, M.S - col0), hlane = (SX >> 1) - 1, lc = 2 * min(lane, hlane);
-    const int LY = min(TY, (int)(SO / S) - line0);
-    const bool act = lane <= hlane;
-    auto lval = [&](int i) { return w * LPW + i < LY; };
-    auto lidx = [&](int i) { return line0 + min(w * LPW + i, LY - 1); };
+    // PT = false (grids of whole tiles) folds these tests away: they cost 256^3 8 % (0.038 -> 0.041 ms).
+    const int SX = PT ? min(TX, M.S - col0) : TX, hlane = PT ? (SX >> 1) - 1 : WAVE - 1, lc = PT ? 2 * min(lane, hlane) : 2 * lane;
+    const int LY = PT ? min(TY, (int)(SO / S) - line0) : TY;
+    const bool act = PT ? lane <= hlane : true;
+    auto lval = [&](int i) { return PT ? w * LPW + i < LY : true; };
+    auto lidx = [&](int i) { return PT ? line0 + min(w * LPW + i, LY - 1) : line0 + w * LPW + i; };
     auto roff = [&](int i) { return (long long)lidx(i) * S + col0 + lc; };
     auto at = [&](long long a) { return (int)(a < 0 ? 0 : (a > (long long)nx - 2 ? (long long)nx - 2 : a)); };      // (clamped addresses only ever feed zeroed cells)
     const bool box_left = tx == 0, box_right = tx == M.tiles_x - 1, box_top = ty == 0, box_bottom = ty == M.tiles_y - 1;      // (uniform)

@@ -171,7 +171,9 @@ static bool launch_wide(const LaunchArgs &a, const double *guard, int dot = 0, c
             if (rows > 0 && block2_shape(a, M)) {
                 if (wgs_out) *wgs_out = M.wgs;
                 const bool ws = dot != 0 && w != a.x;
-#define GOB2(OD, DT, WS_) spmv_csr_block2_march_kernel<OD, DT, WS_><<<M.wgs, 256, 0, a.st>>>(a.x, a.y, M, P->bd.maxcol + 1, w, partial, guard, pstride)
+                const bool pt = M.S % 128 != 0 || (M.SO / M.S) % 8 != 0;      // partial tiles: an instantiation of their own (the whole-tile one carries none of their tests)
+#define GOB2(OD, DT, WS_) do { if (pt) spmv_csr_block2_march_kernel<OD, DT, WS_, true><<<M.wgs, 256, 0, a.st>>>(a.x, a.y, M, P->bd.maxcol + 1, w, partial, guard, pstride); \
+                               else spmv_csr_block2_march_kernel<OD, DT, WS_, false><<<M.wgs, 256, 0, a.st>>>(a.x, a.y, M, P->bd.maxcol + 1, w, partial, guard, pstride); } while (0)
 #define GOB2D(OD) do { if (dot == 0) GOB2(OD, 0, false); else if (dot == 1) { if (ws) GOB2(OD, 1, true); else GOB2(OD, 1, false); } else { if (ws) GOB2(OD, 2, true); else GOB2(OD, 2, false); } } while (0)
                 if (M.ord == 0) GOB2D(0); else if (M.ord == 1) GOB2D(1); else GOB2D(2);
 #undef GOB2D
@@ -198,7 +200,9 @@ static bool launch_wide(const LaunchArgs &a, const double *guard, int dot = 0, c
         if (box27_shape(a, M, lpw)) {
             if (wgs_out) *wgs_out = M.wgs;
             const bool ws = dot != 0 && w != a.x;
-#define GO27(LPW_, DT, WS_) spmv_csr_box27_march_kernel<LPW_, DT, WS_><<<M.wgs, 256, 0, a.st>>>(a.x, a.y, a.acc0, M, P->wd.maxcol + 1, w, partial, guard, pstride)
+            const bool pt = M.S % 128 != 0 || (M.SO / M.S) % (4 * lpw) != 0;      // partial tiles: an instantiation of their own (the whole-tile one carries none of their tests)
+#define GO27(LPW_, DT, WS_) do { if (pt) spmv_csr_box27_march_kernel<LPW_, DT, WS_, true><<<M.wgs, 256, 0, a.st>>>(a.x, a.y, a.acc0, M, P->wd.maxcol + 1, w, partial, guard, pstride); \
+                                 else spmv_csr_box27_march_kernel<LPW_, DT, WS_, false><<<M.wgs, 256, 0, a.st>>>(a.x, a.y, a.acc0, M, P->wd.maxcol + 1, w, partial, guard, pstride); } while (0)
 #define GO27D(LPW_) do { if (dot == 0) GO27(LPW_, 0, false); else if (dot == 1) { if (ws) GO27(LPW_, 1, true); else GO27(LPW_, 1, false); } \
                          else { if (ws) GO27(LPW_, 2, true); else GO27(LPW_, 2, false); } } while (0)
             if (lpw == 2) GO27D(2); else GO27D(1);
@@ -381,11 +385,13 @@ static void launch_dom(const LaunchArgs &a0, int dot = 0, const double *w = null
             for (int k = 0; k < 7; k++) alt = alt || ((P->box_modes >> (2 * k)) & 3) == 2;
             BoxAlt BA;
             for (int u = 0; u < 7; u++) BA.v[u] = P->box_alt[u];
+            const bool pt = M.S % 128 != 0 || (M.SO / M.S) % 8 != 0;      // partial tiles (the last tile of a line / of a plane)
 #define MARCH_ARGS a.rowpat, a.vrec, P->drec, P->dom, a.x, a.y, a.acc0, M, P->dom_xlen, w, partial, guard, pstride
 #define GOM(DT, WS_, ORD_, GEN_) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, GEN_><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS)
 #define GOMB(DT, WS_, ORD_) do { if (alt) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, true, false><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS, BA); \
                                  else if (P->box_pads) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, false, true><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); \
-                                 else spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); } while (0)
+                                 else if (pt) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); \
+                                 else spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, false, false, false><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); } while (0)      /* whole tiles, the plain box form: no partial-tile tests */
 #define GOMO(DT, WS_) do { if (box) { if (ord == 0) GOMB(DT, WS_, 0); else GOMB(DT, WS_, 1); } \
                            else if (!P->dom_simple || ord == 2) GOM(DT, WS_, 2, true); else if (ord == 0) GOM(DT, WS_, 0, false); else GOM(DT, WS_, 1, false); } while (0)
             if (dot == 0) GOMO(0, false); else if (dot == 1) { if (ws) GOMO(1, true); else GOMO(1, false); } else { if (ws) GOMO(2, true); else GOMO(2, false); }

@@ -26,7 +26,7 @@ EW = {0: (24, "axpy"), 1: (24, "xpay"), 2: (24, "axpyz"), 3: (16, "y = a x"), 4:
 
 
 def bytes_of(name):
-    m = re.search(r"spmv_csr_valuerec_march_kernel<2, 2, (\d), (\w+), \d, (\w+), (\w+), (\w+), (\w+)>", name)
+    m = re.search(r"spmv_csr_valuerec_march_kernel<2, 2, (\d), (\w+), \d, (\w+), (\w+), (\w+), (\w+)(?:, \w+)?>", name)
     if m:
         dot, ws, gen, box = m.group(1) != "0", m.group(2) == "true", m.group(3) == "true", m.group(4) == "true"
         return ((16 if box else 17) + (8 if ws else 0)) * n, ("headline product, z-marching" + (" (box form: x and y alone)" if box else " (faces by masks)" if not gen else " (general form)") +

@@ -68,6 +68,11 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON: the library (lis_input's "matrix size = ...", as the reference prints it), the reference build of the CPU baseline and child
+    # processes write to file descriptor 1 too -- from here on that is stderr, and the line goes out through the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -577,7 +582,8 @@ def main():
             "cpu_baseline": cpu,
         }
         assert_fracs_physical(out, shared_gpu=out["degraded"])
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())          # the ONE line of stdout (everything else this process printed went to stderr)
     degraded = world > 1 and comm_used != "rccl" and args.comm == "rccl"
     if world > 1:
         dll.lis_amd_comm_finalize()

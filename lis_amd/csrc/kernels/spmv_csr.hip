@@ -388,8 +388,10 @@ static void launch_dom(const LaunchArgs &a0, int dot = 0, const double *w = null
             const bool pt = M.S % 128 != 0 || (M.SO / M.S) % 8 != 0;      // partial tiles (the last tile of a line / of a plane)
 #define MARCH_ARGS a.rowpat, a.vrec, P->drec, P->dom, a.x, a.y, a.acc0, M, P->dom_xlen, w, partial, guard, pstride
 #define GOM(DT, WS_, ORD_, GEN_) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, GEN_><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS)
-#define GOMB(DT, WS_, ORD_) do { if (alt) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, true, false><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS, BA); \
-                                 else if (P->box_pads) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, false, true><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); \
+#define GOMB(DT, WS_, ORD_) do { if (alt && pt) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, true, false><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS, BA); \
+                                 else if (alt) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, true, false, false><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS, BA); \
+                                 else if (P->box_pads && pt) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, false, true><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); \
+                                 else if (P->box_pads) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, false, true, false><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); \
                                  else if (pt) spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); \
                                  else spmv_csr_valuerec_march_kernel<2, 2, DT, WS_, ORD_, false, true, false, false, false><<<M.wgs, 256, 0, a.st>>>(MARCH_ARGS); } while (0)      /* whole tiles, the plain box form: no partial-tile tests */
 #define GOMO(DT, WS_) do { if (box) { if (ord == 0) GOMB(DT, WS_, 0); else GOMB(DT, WS_, 1); } \

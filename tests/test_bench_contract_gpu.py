@@ -16,6 +16,7 @@ def test_bench_line_has_the_contract_fields():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    assert [l for l in p.stdout.splitlines() if l.strip()] == lines, "stdout carries the JSON line alone (what the library and the legs print goes to stderr)"
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):

@@ -2822,7 +2822,7 @@ void spmv_csr_blockrows_staged_kernel(const unsigned char *__restrict__ rowpat, 
 // +0.0 is never -0.0, so the term leaves every bit where a missing slot leaves it: no masks, no pattern bytes -- x once and y once, 16 B per row.
 struct Box27 { int S, SO, tiles_x, tiles_y, zseg, nseg, z0, z1, wgs, xcd, planes, pad; double poison; double val[27]; };
 template <int LPW, int DOT, bool WS, bool PT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LPW == 2 ? 3 : 4)))      // (eight lines per tile: 171 registers without the hint -- three short of a third workgroup per CU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LPW == 2 ? (WS ? 2 : 3) : (WS ? 3 : 4))))      // (eight lines per tile: 171 registers without the hint -- three short of a third workgroup per CU; with a vector w of their own the forms spilled 140 registers under that cap: one workgroup fewer per CU instead)
 void spmv_csr_box27_march_kernel(const double *__restrict__ x, double *__restrict__ y, double acc0, const Box27 M, int nx,
                                  const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                                  const double *__restrict__ guard = nullptr, int pstride = 0)

@@ -1,26 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- the hot path's headline metric on N MI355X GPUs of one node.
 
-    python bench.py [--gpus 1] [--steps 50] [--warmup 5]
+    python bench.py [--gpus N] [--steps 50] [--warmup 5]        (N > 1: launches its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W                (the same job under an outside launcher)
 
-Workload (BASELINE.json): the 3-D 7-point Poisson matrix on a 512^3 grid in CSR (test/test3.c entry order,
-f64 values, i32 indices), generated directly in HBM; a "step" is one y = A*x through lis_matvec() of
-liblis_amd.so (x = 1, as test/spmvtest3.c).  With N > 1 the matrix is row-block partitioned over the ranks
-(LIS_GET_ISIE, whole grid planes) and every step does the halo exchange over RCCL (ncclSend/ncclRecv of one plane
-per neighbour) around the local product.  Default WEAK scaling: every GPU keeps the 512^3 rows the metric is quoted
-on (global grid 512 x 512 x 512*N; 14 GB of matrix per 288 GB GPU); --scaling strong splits the one 512^3 grid.
-Reported: value = global SpMV GFLOP/s = 2*nnz*K / t (reference convention, test/spmvtest1.c:225); `roofline` = the bytes
-the timed kernel is asked to move (its stored matrix streams + y + the compulsory x) over its HIP-event time on the library's
-stream, as a fraction of 8 TB/s (always <= 1; asserted), with the PMC traffic of the same command from profiles/ as the upper
-bound and the contract's 12 B/nnz + 20 B/row count beside it as `contract_frac`; the same product on a non-trivial x; the same
-product with the value records off (`values_streamed`: the kernel any matrix on these sparsity patterns takes) and in the CONTRACT FORM (`contract_form`: index
-codes, row patterns and value records off -- spmv_csr_rowgather_kernel streams the reference's own index[] / value[] arrays, 12 B per non-zero + 20 B per row, SURVEY 8d's
-count, which its `frac` is priced on; CG + Jacobi in the same mode); Krylov iterations/s on the
-same matrix as the reference defines them -- iter / itime of lis_solver_get_timeex (src/solver/lis_solver.c:
-902-908) over --solver-iters iterations -- each with its own roofline, and the reference's own
-OpenMP CPU path timed on this box's host cores.
+Workload (BASELINE.json): the 3-D 7-point Poisson matrix on a 512^3 grid in CSR (test/test3.c entry order, f64 values, i32 indices), generated
+directly in HBM.  A "step" is one y = A*x through lis_matvec() of liblis_amd.so in the REFERENCE LAYOUT mode (lis_amd_set_reference_layout): the kernel
+streams the reference's own arrays -- 4 B index[] + 8 B value[] per non-zero, ptr[], y, x gathered: the loop of src/matvec/lis_matvec_csr.c:97-109 on
+SURVEY 8d's 12 nnz + 20 n + 4 bytes -- on a NON-TRIVIAL x (x_i = frac(i * golden ratio) - 0.5).  That is the line's `value`, `ms_per_step` and `roofline`
+(`frac` <= 1 by construction: exactly those bytes over the kernel's HIP-event time over 8 TB/s; `traffic` = this run's own PMC counters).
+Beside it, each labelled with what it applies to:
+  x_equals_one           the same kernel on the reference's x = 1 (test/spmvtest3.c), with its closed-form norm check
+  krylov                 CG+Jacobi / BiCGSTAB / BiCG / GMRES(30) iterations per second in the same mode: iter / itime of lis_solver_get_timeex (lis_solver.c:902-908)
+  structured_fast_path   what lis_matvec runs for THIS matrix by default -- the plan found a constant-coefficient box stencil and marches it without reading the
+                         matrix arrays at all; NOT a CSR-roofline figure (its own bytes, its own `applies_to`), with its Krylov rates and the values-streamed form
+  configs                one driver-timed leg per BASELINE.json config: config1 spmvtest1 (n = 10000, all six formats, the 2-norm check), config2 256^3 CG+Jacobi
+                         to convergence, config3 512^3 BiCGSTAB (this job's ranks), config4 the Queen_4147 stand-in (or LIS_AMD_BENCH_MTX=/path/file.mtx),
+                         config5 CSR / ELL / DIA at 256^3 and 512^3 through their native kernels on SURVEY 8d's bytes and through the default forms
+  cpu_baseline           the reference's own OpenMP path (oracle/_ref = Lis 2.1.11) on this box's host cores
+With N > 1 the matrix is row-block partitioned (LIS_GET_ISIE, whole grid planes) and every step does the halo exchange over RCCL.  Default WEAK scaling: every
+GPU keeps the 512^3 rows the metric is quoted on (global grid 512 x 512 x 512 N); --scaling strong splits the one 512^3 grid.  value = 2 nnz K / t whole job.
 """
 import argparse
 import ctypes as C
@@ -35,7 +35,16 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-CONTRACT_FORM = "contract"     # roofline_of / kernel_name / live_traffic: the product on the reference's own arrays (4 B indices, 8 B values)
+BASELINE_CONFIGS = {           # BASELINE.json `configs`, verbatim: every leg under `configs` carries its name
+    "config1": "test/spmvtest1: 1D 3-pt Poisson n=10000 CSR, reference CPU OpenMP path (plumbing, no GPU)",
+    "config2": "3D 7-pt Poisson n=256^3 CSR, CG+Jacobi, 1 MI355X",
+    "config3": "3D 7-pt Poisson n=512^3 CSR, BiCGSTAB, row-block across 8×MI355X (RCCL halo+allreduce)",
+    "config4": "SuiteSparse Queen_4147 (irregular CSR), GMRES(30), 1 MI355X — merge-path load-balance",
+    "config5": "3D 7-pt Poisson n=256^3 in ELL and DIA formats, CG, 1 MI355X — format sweep vs CSR",
+}
+SOLVERS = (("cg_jacobi", "-i cg -p jacobi"), ("bicgstab_none", "-i bicgstab -p none"),
+           ("bicg_none", "-i bicg -p none"),            # Lis's default solver: needs A^T (built in HBM on first use)
+           ("gmres30_none", "-i gmres -restart 30 -p none"))
 
 
 def parse():
@@ -44,12 +53,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=512, help="cubic grid edge (BASELINE: 512)")
-    ap.add_argument("--solver-iters", type=int, default=500,
-                    help="Krylov iterations timed for the it/s figures (maxiter of the timed solve; none of the solvers "
+    ap.add_argument("--solver-iters", type=int, default=200,
+                    help="Krylov iterations timed for the it/s figures at the headline size (maxiter of the timed solve; none of the solvers "
                          "converges earlier at 512^3: CG needs 1504)")
-    ap.add_argument("--preroll", type=int, default=600,
-                    help="untimed clock-ramp steps before the W warm-up steps: a fresh box's first process measured "
-                         "7 %% slower for its first ~second of kernels (DESIGN.md 5); same count on every rank")
+    ap.add_argument("--preroll", type=int, default=200,
+                    help="untimed clock-ramp steps before the W warm-up steps (reported in the line): a fresh box's first process measured "
+                         "7 %% slower for its first ~half second of kernels; same count on every rank")
     ap.add_argument("--comm", choices=["rccl", "callbacks"], default="rccl",
                     help="callbacks: collectives through torch.distributed/gloo host callbacks -- bring-up of the N>1 "
                          "path with several ranks on ONE GPU (RCCL refuses that); never a measurement")
@@ -58,16 +67,37 @@ def parse():
     ap.add_argument("--planes", type=int, default=0,
                     help="the slowest grid dimension when it is not --grid (whole job): `--planes 64` on one GPU is the slab ONE rank of the 8-rank strong-scaling job "
                          "owns (512 x 512 x 64 rows) -- the per-rank kernel times tools/scale_predict.py builds the predicted curve from.  Not the headline workload: "
-                         "`config.workload` says so and the profiles/ traffic figures are not attached")
+                         "`config.workload` says so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profiles/ figure instead of two rocprofv3 --pmc passes of this run (about 15 s)")
     ap.add_argument("--no-solvers", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the 27-point stencil legs (rank 0, N = 1 only; about 10 s)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 27-point stencil leg and the config legs (rank 0, N = 1 only)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config legs (config1, 2, 4, 5; rank 0, N = 1 only)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="bring-up of the launch path without a GPU: form the process group, gather the ranks, print one JSON line, exit")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks here, one per GPU, under torch.distributed.run on
+    127.0.0.1 with a free port -- the same command line the driver's launcher would run.  Rank 0's JSON line is this process's stdout; the exit code is the job's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), LIS_AMD_BENCH_SELF_LAUNCHED="1")
+    print(f"bench.py: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     # stdout carries ONE line, the JSON: the library (lis_input's "matrix size = ...", as the reference prints it), the reference build of the CPU baseline and child
     # processes write to file descriptor 1 too -- from here on that is stderr, and the line goes out through the saved descriptor
     sys.stdout.flush()
@@ -76,10 +106,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())          # the ONE line of stdout (everything else this process printed went to stderr)
 
     # torch first: liblis_amd.so then binds the HIP / RCCL runtime torch already loaded (one runtime per process),
     # so torch.cuda.synchronize() and the library see the same device context.  torch is plumbing only.
@@ -93,6 +124,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only; data plane is RCCL
+    if args.launch_check:
+        ranks = [None] * world
+        if world > 1:
+            dist.all_gather_object(ranks, (rank, local_rank))
+            dist.destroy_process_group()
+        else:
+            ranks = [(rank, local_rank)]
+        if rank == 0:
+            emit({"launch_check": True, "world": world, "ranks": [list(r) for r in ranks], "self_launched": os.environ.get("LIS_AMD_BENCH_SELF_LAUNCHED") == "1"})
+        return
     import numpy as np
     import lis_amd
     from lis_amd import _capi as capi, check
@@ -104,7 +145,7 @@ def main():
     comm_used = args.comm
     if world > 1 and args.comm == "rccl":
         # RCCL communicator: rank 0's unique id travels over the gloo control plane.  If ANY rank fails to join,
-        # every rank drops to the callback backend so that the job still reports (marked as such in `config`).
+        # every rank drops to the callback backend so that the job still reports (marked as such: `degraded`, exit code 3).
         uid = [None]
         ok = int(torch.cuda.is_available() and local_rank < torch.cuda.device_count())   # a rank without its own GPU
         flag = torch.tensor([ok], dtype=torch.int32)                                      # must not leave the others
@@ -137,6 +178,11 @@ def main():
         torch.cuda.set_device(local_rank)
     dll.lis_amd_set_residency(1)                          # objects live in HBM; nothing crosses PCIe in the timed region
     dll.lis_amd_stream.restype = C.c_void_p
+    for fn in ("lis_amd_matrix_index_codes", "lis_amd_matrix_row_patterns", "lis_amd_matrix_pattern_records", "lis_amd_matrix_value_records",
+               "lis_amd_matrix_dominant_pattern", "lis_amd_matrix_marching", "lis_amd_matrix_strip_rows", "lis_amd_matrix_device_type"):
+        getattr(dll, fn).argtypes = [capi.PM]
+    dll.lis_amd_matrix_poisson3d.argtypes = [capi.PM, C.c_int, C.c_int, C.c_int, C.c_int]
+    dll.lis_amd_vector_poisson3d_rhs.argtypes = [capi.PV, C.c_int, C.c_int, C.c_int]
 
     def sync():
         assert dll.lis_amd_synchronize() == 0
@@ -146,6 +192,9 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+
+    def reference_layout(on):
+        assert dll.lis_amd_set_reference_layout(1 if on else 0) == 0
 
     N = args.grid
     L = N * world if args.scaling == "weak" else N        # grid planes (slowest dimension): whole planes per rank
@@ -157,13 +206,32 @@ def main():
         sys.exit(f"grid edge {N} is not divisible by {world} ranks (whole planes per rank)")
     if n_global >= 2 ** 31:
         sys.exit(f"{L} x {N} x {N} rows do not fit LIS_INT (32 bit, as the reference's default build)")
-    A = capi.PM()
-    assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
-    assert lib.lis_matrix_set_size(A, 0, n_global) == 0
-    dll.lis_amd_matrix_poisson3d.argtypes = [capi.PM, C.c_int, C.c_int, C.c_int, C.c_int]
+
+    def poisson(l, m, n, sorted_=0):
+        M = capi.PM()
+        assert lib.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(M)) == 0
+        assert lib.lis_matrix_set_size(M, 0, l * m * n) == 0
+        assert dll.lis_amd_matrix_poisson3d(M, l, m, n, sorted_) == 0    # generated in HBM + the plan
+        return M
+
+    def vec(M):
+        v = capi.PV()
+        assert lib.lis_vector_duplicate(C.cast(M, C.c_void_p), C.byref(v)) == 0
+        return v
+
+    def golden_x(v, n_rows):
+        """x_i = frac(i * golden ratio) - 0.5 on this rank's rows: every mantissa bit toggles (the FP64 multipliers then draw their real power and the clocks follow)"""
+        lo = C.c_int(); hi = C.c_int()
+        assert lib.lis_vector_get_range(v, C.byref(lo), C.byref(hi)) == 0
+        chunk = 1 << 24
+        for s0 in range(0, n_rows, chunk):
+            cnt = min(chunk, n_rows - s0)
+            part = np.modf(np.arange(lo.value + s0, lo.value + s0 + cnt, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+            assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, lo.value + s0, cnt, part.ctypes.data_as(capi.P_DBL), v) == 0
+
     dll.lis_amd_synchronize()
     t_setup = time.perf_counter()
-    assert dll.lis_amd_matrix_poisson3d(A, L, N, N, 0) == 0       # generated in HBM + the plan (row split, index codes, row patterns, value records)
+    A = poisson(L, N, N)                                  # the DEFAULT plan (row split, index codes, row patterns, value records): what a Lis program gets
     dll.lis_amd_synchronize()
     setup_ms = (time.perf_counter() - t_setup) * 1e3
     n_local, nnz_local = A.contents.n, A.contents.nnz
@@ -184,12 +252,9 @@ def main():
         gen_ms = None
     nnz_global = 7 * n_global - 2 * (N * N + 2 * L * N)
 
-    def vec():
-        v = capi.PV()
-        assert lib.lis_vector_duplicate(C.cast(A, C.c_void_p), C.byref(v)) == 0
-        return v
-    x, y, b = vec(), vec(), vec()
-    assert lib.lis_vector_set_all(1.0, x) == 0
+    x1, xg, y, yc, b = vec(A), vec(A), vec(A), vec(A), vec(A)
+    assert lib.lis_vector_set_all(1.0, x1) == 0
+    golden_x(xg, n_local)
 
     stream = dll.lis_amd_stream()
     timer = C.c_void_p()
@@ -197,33 +262,32 @@ def main():
     ev_ms = C.c_float()
     nrm = C.c_double()
 
-    def timed_products(xv, steps):
-        """exactly `steps` products between barrier + device sync on both sides: (seconds, MAX over ranks; HIP-event ms per launch)"""
-        sync(); barrier()
+    def timed_products(M, xv, yv, steps, collective=True):
+        """exactly `steps` products between barrier + device sync on both sides: (seconds, MAX over ranks; HIP-event ms per launch on the library's stream)"""
+        sync()
+        if collective:
+            barrier()
         t0 = time.perf_counter()
         check(lib.liship_timer_start(timer, stream))
         for _ in range(steps):
-            assert lib.lis_matvec(A, xv, y) == 0
+            assert lib.lis_matvec(M, xv, yv) == 0
         check(lib.liship_timer_stop(timer, stream))
-        sync(); barrier()
+        sync()
+        if collective:
+            barrier()
         el = time.perf_counter() - t0
         check(lib.liship_timer_elapsed_ms(timer, C.byref(ev_ms)))
-        if world > 1:
+        if world > 1 and collective:
             tt = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt[0])
         return el, ev_ms.value / steps
 
-    # ---- untimed clock ramp (power state of an idle box), then the contract's W warm-up steps
-    for _ in range(args.preroll):
-        assert lib.lis_matvec(A, x, y) == 0
-    sync()
-    # ---- timed region: W warm-up steps, then exactly K steps between barrier + device sync on both sides
-    for _ in range(args.warmup):
-        assert lib.lis_matvec(A, x, y) == 0
-    dt, kernel_ms = timed_products(x, args.steps)
-    ms_per_step = dt / args.steps * 1e3
-    gflops = 2.0 * nnz_global * args.steps / dt / 1e9
+    def leg(M, xv, yv, steps, nnz, collective=True):
+        for _ in range(max(args.warmup, 5)):
+            assert lib.lis_matvec(M, xv, yv) == 0
+        el, k_ms = timed_products(M, xv, yv, steps, collective)
+        return {"value": round(2.0 * nnz * steps / el / 1e9, 2), "unit": "GFLOP/s", "ms_per_step": round(el / steps * 1e3, 4), "kernel_ms": round(k_ms, 4)}
 
     # result check outside the timed region: ||A*1||_2^2 = 6(N-2)^2 + 48(N-2) + 72 exactly on the cube (spmvtest3, SURVEY 8c)
     # (a row sums to the number of neighbours it lacks: 8 corners 3, the edges 2, the faces 1)
@@ -233,51 +297,30 @@ def main():
         assert lib.lis_vector_nrm2(y, C.byref(nrm)) == 0
         if abs(nrm.value - expect) > 1e-12 * expect:
             sys.exit(f"rank {rank}: {what}: ||A*1||_2 = {nrm.value!r}, expected {expect!r}")
-    check_a_times_one("headline")
 
-    # ---- a NON-TRIVIAL x beside the reference's x = 1 (test/spmvtest3.c): x_i = frac(i * golden ratio) - 0.5.  Same kernel, same bytes;
-    # the FP64 multipliers then toggle full mantissas and the clocks follow the power, so this is the rate real data sees.
-    xg = vec()
-    lo = C.c_int(); hi = C.c_int()
-    assert lib.lis_vector_get_range(xg, C.byref(lo), C.byref(hi)) == 0
-    chunk = 1 << 24
-    for s0 in range(0, n_local, chunk):
-        cnt = min(chunk, n_local - s0)
-        part = np.modf(np.arange(lo.value + s0, lo.value + s0 + cnt, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
-        assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, lo.value + s0, cnt, part.ctypes.data_as(capi.P_DBL), xg) == 0
+    def same_bits(u, v, what):
+        """||u - v||_2 == 0 exactly (u is overwritten): two forms of the product must agree to the last bit"""
+        assert lib.lis_vector_axpy(-1.0, v, u) == 0 and lib.lis_vector_nrm2(u, C.byref(nrm)) == 0
+        if nrm.value != 0.0:
+            sys.exit(f"rank {rank}: {what}: the two forms of the product differ: ||dy||_2 = {nrm.value!r}")
 
-    def leg(xv, steps):
-        for _ in range(max(args.warmup, 5)):
-            assert lib.lis_matvec(A, xv, y) == 0
-        el, k_ms = timed_products(xv, steps)
-        return {"value": round(2.0 * nnz_global * steps / el / 1e9, 2), "unit": "GFLOP/s", "ms_per_step": round(el / steps * 1e3, 4), "kernel_ms": round(k_ms, 4)}
-
-    # ---- which form of the matrix the plan keeps (found on the device at upload) and the bytes its kernel is asked to stream
-    alg_bytes = 12 * nnz_local + 20 * n_local + 4        # SURVEY 8d, the contract's count: 12 B per non-zero + 20 B per row
-    dll.lis_amd_matrix_index_codes.argtypes = [capi.PM]
+    # ---- which form of the matrix the DEFAULT plan keeps (found on the device at upload, DESIGN.md 4)
+    alg_bytes = 12 * nnz_local + 20 * n_local + 4        # SURVEY 8d: 12 B per non-zero + 20 B per row (+ the last ptr entry)
     coded = int(dll.lis_amd_matrix_index_codes(A))
-    dll.lis_amd_matrix_row_patterns.argtypes = [capi.PM]
     patterns = int(dll.lis_amd_matrix_row_patterns(A))     # > 0: one byte per ROW (pattern) instead of 1 B per non-zero + 4 B per row
-    dll.lis_amd_matrix_pattern_records.argtypes = [capi.PM]
     records = int(dll.lis_amd_matrix_pattern_records(A))   # 1: patterns of <= 7 offsets kept as 32 B records (gathers ahead of the value slice)
-    dll.lis_amd_matrix_value_records.argtypes = [capi.PM]
     values = int(dll.lis_amd_matrix_value_records(A))      # 1: the rows of a pattern share their values too (constant coefficients)
-    if world > 1:                                          # (one answer for the whole job: the second measurement below is collective)
-        vv = torch.tensor([values], dtype=torch.int32)
-        dist.all_reduce(vv, op=dist.ReduceOp.MIN)
-        values = int(vv[0])
-
-    dll.lis_amd_matrix_dominant_pattern.argtypes = [capi.PM]
     dominant = int(dll.lis_amd_matrix_dominant_pattern(A))     # 1: one pattern carries most rows and its x gathers are issued with the pattern bytes (round 3)
-    dll.lis_amd_matrix_marching.argtypes = [capi.PM]
     marching = int(dll.lis_amd_matrix_marching(A))             # round 4: 1 = the z-marching form of that product (each x loaded once per plane tile), 2 = its box form (no pattern bytes read)
-    if world > 1:
-        mm = torch.tensor([marching], dtype=torch.int32)
-        dist.all_reduce(mm, op=dist.ReduceOp.MIN)
-        marching = int(mm[0])
+    if world > 1:                                          # (one answer for the whole job: the legs below are collective)
+        vv = torch.tensor([values, marching], dtype=torch.int32)
+        dist.all_reduce(vv, op=dist.ReduceOp.MIN)
+        values, marching = int(vv[0]), int(vv[1])
+
+    REF = "reference_layout"      # kernel_name / live_traffic / roofline_of: the product on the reference's own arrays (4 B indices, 8 B values)
 
     def kernel_name(v):
-        if v == CONTRACT_FORM:
+        if v == REF:
             return "spmv_csr_rowgather_kernel"
         pair = n_local * 8 > (256 << 20)                  # round-2 kernels: x beyond the Infinity Cache takes the two-rows-per-lane form
         if patterns and records and v:
@@ -288,18 +331,18 @@ def main():
                 "spmv_csr_pattern_kernel" if patterns else "spmv_csr_coded_kernel" if coded else "spmv_csr_rowgather_kernel")
 
     def pmc_traffic(name):
-        """HBM-side bytes per launch from the PMC passes of this same command (rocprofv3 --pmc cannot run inside the process it profiles;
+        """HBM-side bytes per launch from the PMC passes of the same products (rocprofv3 --pmc cannot run inside the process it profiles;
         separate passes as the microarchitecture guide prescribes: tools/prof.sh + tools/traffic_json.py), committed under profiles/.
         Counted at the L2 <-> fabric boundary by request size, so re-reads the 256 MB Infinity Cache answers are included: an UPPER bound
         of the HBM bytes; the stored bytes are the lower one."""
         if N != 512 or world != 1 or slab:
             return None, None
-        for tf in ("r05_spmv512_traffic%s.json", "r04_spmv512_traffic%s.json", "r03_spmv512_traffic%s.json", "r02_spmv512_traffic%s.json"):
+        for tf in ("r06_spmv512_traffic%s.json", "r05_spmv512_traffic%s.json", "r04_spmv512_traffic%s.json", "r03_spmv512_traffic%s.json"):
             tf = os.path.join(ROOT, "profiles", tf % name)
             if os.path.exists(tf):
                 tj = json.load(open(tf))
                 detail = {k: tj[k] for k in ("source", "kernel", "level", "avg_kernel_ns", "read_bytes_per_launch", "write_bytes_per_launch",
-                                             "x_bytes_per_launch", "x_refetch_factor", "fabric_rate_GBs", "hbm_bytes_bounds", "note") if k in tj}
+                                             "x_bytes_per_launch", "x_refetch_factor", "fabric_rate_GBs", "hbm_bytes_bounds") if k in tj}
                 detail["file"] = os.path.relpath(tf, ROOT)
                 return tj.get("fabric_bytes_per_launch", tj.get("hbm_traffic_bytes_per_launch")), detail
         return None, None
@@ -331,7 +374,7 @@ def main():
                               ("wr", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"])):
                 out_dir = os.path.join(tmp, tag)
                 cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc", *ctrs, "-d", out_dir, "-o", "pmc", "--",
-                       sys.executable, os.path.join(ROOT, "tools", "traffic_child.py"), str(N), str(2 if v == CONTRACT_FORM else int(bool(v))), "12"]
+                       sys.executable, os.path.join(ROOT, "tools", "traffic_child.py"), str(N), str(2 if v == REF else int(bool(v))), "12"]
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
                 if r.returncode != 0:
                     return None
@@ -350,7 +393,7 @@ def main():
             rd = 32 * r32 + 64 * r64 + 128 * r128 + 64 * max(0.0, per["TCC_EA0_RDREQ_sum"] - r32 - r64 - r128)
             wr = 64 * per["TCC_EA0_WRREQ_64B_sum"] + 32 * (per["TCC_EA0_WRREQ_sum"] - per["TCC_EA0_WRREQ_64B_sum"])
             live_cache[v] = {"read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr), "fabric_bytes_per_launch": int(rd + wr), "kernel": want,
-                             "source": "measured in this run: rocprofv3 --kernel-trace --pmc (two passes) over tools/traffic_child.py, 12 products of the same matrix",
+                             "source": "measured in this run: rocprofv3 --kernel-trace --pmc (two passes) over tools/traffic_child.py, 12 products of the same matrix in the same mode",
                              "level": "L2 <-> fabric requests by size (Infinity Cache hits included: an upper bound of the HBM bytes)",
                              "seconds": round(time.perf_counter() - t0, 1)}
             return live_cache[v]
@@ -359,75 +402,99 @@ def main():
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
 
-    def roofline_of(v, k_ms, traffic_name, applies_to):
-        """`achieved` / `frac`: the bytes THIS kernel is asked to move (its stored matrix streams + y + the compulsory x) over its own
-        HIP-event time -- a physical rate, <= the peak by construction.  `traffic`: the PMC bytes (upper bound, see pmc_traffic).
-        `contract_*`: SURVEY 8d's algorithmic count (12 B per non-zero + 20 B per row, the reference's CSR layout) over the same time --
-        NOT a rate of this kernel when the plan stores fewer bytes; it says how much faster than a perfect streaming of the reference's
-        layout the product runs, and may exceed 1."""
-        if v == CONTRACT_FORM:
-            moved = alg_bytes                               # the reference's layout itself: 4 B index + 8 B value per non-zero, ptr, y, the compulsory x
+    def roofline_of(v, k_ms, traffic_name, applies_to, live=True):
+        """`achieved` / `frac`: the bytes THIS kernel is asked to move over its own HIP-event time -- for the reference layout exactly SURVEY 8d's 12 nnz + 20 n + 4;
+        for a derived form its stored streams + y + the compulsory x.  A physical rate, <= the peak by construction.  `traffic`: the PMC bytes (upper bound, see
+        pmc_traffic).  `contract_*`: SURVEY 8d's count over the same time -- identical to `frac` for the reference layout; for a derived form NOT a rate of that
+        kernel (it reads fewer bytes) and it may exceed 1."""
+        if v == REF:
+            moved = alg_bytes
         else:
             moved = spmv_stored_bytes(n_local, nnz_local, coded, patterns, v) - (n_local if (v and marching == 2) else 0)      # (the box form reads no pattern byte: x and y alone)
         traffic, detail = pmc_traffic(traffic_name)
-        live = live_traffic(v) if rank == 0 else None
-        if live:                                            # this run's own counters take precedence over the committed figure (kept beside them)
-            detail = dict(live, committed=detail)
-            traffic = live["fabric_bytes_per_launch"]
+        lt = live_traffic(v) if (rank == 0 and live) else None
+        if lt:                                              # this run's own counters take precedence over the committed figure (kept beside them)
+            detail = dict(lt, committed=detail)
+            traffic = lt["fabric_bytes_per_launch"]
         sec = k_ms * 1e-3
         r = {"bound": "hbm", "achieved": round(moved / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(moved / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": detail,
              "kernel": kernel_name(v), "kernel_ms": round(k_ms, 4), "bytes_per_launch": moved, "per_gpu": True,
-             "bytes_are": "stored matrix streams + y + compulsory x of the timed kernel (lower bound of its HBM bytes; `traffic` is the counters' upper bound)",
+             "bytes_are": ("SURVEY 8d's algorithmic bytes: 12 B per non-zero (8 B value[] + 4 B index[]) + 20 B per row (4 B ptr[], 8 B y, 8 B compulsory x) + 4" if v == REF else
+                           "stored matrix streams + y + compulsory x of the timed kernel (lower bound of its HBM bytes; `traffic` is the counters' upper bound)"),
              "contract_bytes_per_launch": alg_bytes, "contract_achieved": round(alg_bytes / sec / 1e9, 1),
              "contract_frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
-             "index_codes": 0 if v == CONTRACT_FORM else coded, "row_patterns": 0 if v == CONTRACT_FORM else patterns,
-             "value_records": 0 if v == CONTRACT_FORM else v, "marching": marching if (v and v != CONTRACT_FORM) else 0, "applies_to": applies_to}
+             "index_codes": 0 if v == REF else coded, "row_patterns": 0 if v == REF else patterns,
+             "value_records": 0 if v == REF else v, "marching": marching if (v and v != REF) else 0, "applies_to": applies_to}
         if traffic:
             r["traffic_over_bytes"] = round(traffic / moved, 3)
         return r
 
-    CONSTANT = ("constant-coefficient matrices only: the 27 row patterns of this stencil carry their VALUES (checked bit for bit at plan time), one pattern "
-                "byte per row is the only matrix stream" + ("; round 4: the grid is a box (checked row by row at plan time), the z-marching kernel reads x once per plane tile "
-                "and no pattern byte: x and y alone are streamed (DESIGN.md 4)" if marching == 2 else "; latency-bound, not byte-bound (DESIGN.md 4)"))
-    GENERAL = "any matrix on these sparsity patterns, whatever its coefficients: 8 B per non-zero + one pattern byte per row streamed"
-    roofline = roofline_of(values, kernel_ms, "", CONSTANT if values else GENERAL)
-    nontrivial = leg(xg, args.steps)
-    nontrivial["x"] = "x_i = frac(i * 0.618...) - 0.5"
-    nontrivial["frac"] = round(roofline["bytes_per_launch"] / (nontrivial["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    # ---- the same product with the value records switched off (the general kernel: 8 B per non-zero + 17 B per row), same run
-    streamed = None
-    if values:
-        check(lib.liship_spmv_csr_set_row_values(0))
-        try:
-            streamed = leg(x, args.steps)
-            check_a_times_one("values streamed")
-            streamed["roofline"] = roofline_of(0, streamed["kernel_ms"], "_values_streamed", GENERAL)
-            streamed["kernel"] = streamed["roofline"]["kernel"]
-            streamed["nontrivial_x"] = leg(xg, args.steps)
-            streamed["nontrivial_x"]["frac"] = round(streamed["roofline"]["bytes_per_launch"] / (streamed["nontrivial_x"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        finally:
-            check(lib.liship_spmv_csr_set_row_values(1))
+    def solve_rates(M, rhs, sol, keys, iters, n_rows, nnz_rows, form):
+        """Krylov iterations/s on M (b = A*1, x0 = 0), whole job: iter / itime as the reference splits it (lis_solver.c:902-908).
+        form: (coded, patterns, values) of the products the loops run, for the bytes one iteration is asked to stream."""
+        out = {}
+        for key, opts in SOLVERS:
+            if key not in keys:
+                continue
+            S = capi.PS()
+            assert lib.lis_solver_create(C.byref(S)) == 0
+            # warm-up pass: work-vector pool, A^T, first launches -- the one-off costs the reference pays in its own setup
+            assert lib.lis_solver_set_option(f"{opts} -tol 1e-12 -maxiter 20".encode(), S) == 0
+            assert lib.lis_solve(M, rhs, sol, S) == 0
+            assert lib.lis_solver_set_option(f"-maxiter {iters}".encode(), S) == 0
+            sync(); barrier()
+            t1 = time.perf_counter()
+            assert lib.lis_solve(M, rhs, sol, S) == 0
+            sync(); barrier()
+            wall = time.perf_counter() - t1
+            tm = [C.c_double() for _ in range(5)]           # time, itime, ptime, p_c_time, p_i_time
+            assert lib.lis_solver_get_timeex(S, *[C.byref(t) for t in tm]) == 0
+            itime = tm[1].value
+            it = min(S.contents.iter, iters)
+            if world > 1:
+                tt = torch.tensor([itime, wall], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                itime, wall = float(tt[0]), float(tt[1])
+            uniform = int(dll.lis_amd_last_solve_uniform_jacobi())      # CG + Jacobi on a constant diagonal: 1/diag rides as a scalar
+            loop_b, contract_b = krylov_bytes(key, it, n_rows, nnz_rows, form[0], form[1], form[2], uniform)
+            sec_per_iter = itime / max(1, it)
+            out[key] = {
+                "iters_per_sec": round(it / itime, 2), "iters_timed": it, "itime_s": round(itime, 6),
+                "lis_solve_wall_s": round(wall, 4), "rel_residual_after": S.contents.resid, "status": S.contents.retcode,
+                # per GPU: bytes one iteration's passes are asked to stream (fused loops: DESIGN.md 6)
+                # and the bytes of the reference's unfused operator sequence (SURVEY 8d) over the same time
+                "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_gpu": True,
+                             "loop_bytes_per_iter": loop_b, "achieved": round(loop_b / sec_per_iter / 1e9, 1),
+                             "frac": round(loop_b / sec_per_iter / 1e9 / HBM_PEAK_GBS, 4),
+                             "contract_bytes_per_iter": contract_b,
+                             "contract_frac": round(contract_b / sec_per_iter / 1e9 / HBM_PEAK_GBS, 4)}}
+            lib.lis_solver_destroy(S)
+        return out
 
-    # ---- the CONTRACT FORM (SURVEY 8d / north_star): the same matrix through the kernel that streams the reference's own arrays -- 4 B index[] + 8 B value[] per
-    # non-zero, ptr[], y, x gathered (lis_matvec_csr.c:97-109's loop on 12 B per non-zero) -- index codes, row patterns and value records switched off.  Its `frac`
-    # is priced on 12 nnz + 20 n + 4 bytes, so it is <= 1 by construction; this is the figure the >= 70 % CSR roofline target is about.
-    contract = None
-    check(lib.liship_spmv_csr_set_index_codes(0)); check(lib.liship_spmv_csr_set_row_patterns(0)); check(lib.liship_spmv_csr_set_row_values(0))
-    try:
-        contract = leg(x, args.steps)
-        check_a_times_one("contract form")
-        contract["roofline"] = roofline_of(CONTRACT_FORM, contract["kernel_ms"], "_contract_form",
-                                           "ANY CSR matrix with short rows: nothing about the matrix is assumed or precomputed beyond the row split (12 B per non-zero + 20 B per row streamed)")
-        contract["kernel"] = contract["roofline"]["kernel"]
-        contract["nontrivial_x"] = leg(xg, args.steps)
-        contract["nontrivial_x"]["frac"] = round(alg_bytes / (contract["nontrivial_x"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        dll.lis_amd_matrix_strip_rows.argtypes = [capi.PM]
-        contract["xcd_strip_rows"] = int(dll.lis_amd_matrix_strip_rows(A))     # rows per plane the XCD strips are cut from (0: natural block order)
-    finally:
-        check(lib.liship_spmv_csr_set_index_codes(1)); check(lib.liship_spmv_csr_set_row_patterns(1)); check(lib.liship_spmv_csr_set_row_values(1))
+    # =====================================================================================================================================
+    # HEADLINE: the reference layout on a non-trivial x.  Untimed clock ramp (power state of an idle box), the contract's W warm-up steps,
+    # then exactly K steps between barrier + device sync on both sides.
+    reference_layout(True)
+    for _ in range(args.preroll):
+        assert lib.lis_matvec(A, xg, y) == 0
+    sync()
+    for _ in range(args.warmup):
+        assert lib.lis_matvec(A, xg, y) == 0
+    dt, kernel_ms = timed_products(A, xg, y, args.steps)
+    ms_per_step = dt / args.steps * 1e3
+    gflops = 2.0 * nnz_global * args.steps / dt / 1e9
+    assert lib.lis_vector_copy(y, yc) == 0                # kept: the default form below must reproduce it bit for bit
+    roofline = roofline_of(REF, kernel_ms, "_contract_form",
+                           "ANY CSR matrix with short rows: nothing about the matrix is assumed or precomputed beyond the row split (12 B per non-zero + 20 B per row streamed)")
+    roofline["xcd_strip_rows"] = int(dll.lis_amd_matrix_strip_rows(A))     # rows per plane the XCD strips are cut from (0: natural block order)
+    x_one = leg(A, x1, y, args.steps, nnz_global)
+    check_a_times_one("reference layout, x = 1")
+    x_one["x"] = "x = 1 (test/spmvtest3.c): the same kernel, the same bytes; the multipliers see one mantissa pattern and the clocks run a few per cent higher"
+    x_one["frac"] = round(alg_bytes / (x_one["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    x_one["norm_check"] = "||A*1||_2 equals its closed form to 1e-12"
 
-    # ---- N > 1: what the exchange costs by itself, and the product with the overlap switched off (A/B)
+    # ---- N > 1: what the exchange costs by itself, and the product with the overlap switched off (A/B), in the headline's mode
     multi = None
     if world > 1:
         dll.lis_amd_halo_exchange.argtypes = [capi.PM, capi.PV]
@@ -442,9 +509,9 @@ def main():
             tt = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt[0]) / reps * 1e3
-        halo_ms = timed(lambda: dll.lis_amd_halo_exchange(A, x), args.steps)
+        halo_ms = timed(lambda: dll.lis_amd_halo_exchange(A, xg), args.steps)
         dll.lis_amd_set_overlap(0)
-        serial_ms = timed(lambda: lib.lis_matvec(A, x, y), args.steps)
+        serial_ms = timed(lambda: lib.lis_matvec(A, xg, y), args.steps)
         dll.lis_amd_set_overlap(1)
         nb = [int(rank > 0), int(rank < world - 1)]           # (whole planes per rank: the ranks before and behind)
         dll.lis_amd_comm_halo_communicator.restype = C.c_int
@@ -455,95 +522,62 @@ def main():
                  "neighbours_of_rank0": sum(nb), "halo_communicator": bool(dll.lis_amd_comm_halo_communicator()) if comm_used == "rccl" else None,
                  "folds_per_iteration": {"cg_jacobi": 2, "bicgstab_none": 4, "bicg_none": 2, "gmres30_none": "i + 1 at inner step i"}}
 
-    # ---- Krylov iterations/s on the same matrix (b = A*1, x0 = 0), whole job: iter / itime as the reference splits it
-    solvers = {}
+    keys = [k for k, _ in SOLVERS]
+    krylov = {}
     if not args.no_solvers:
-        dll.lis_amd_vector_poisson3d_rhs.argtypes = [capi.PV, C.c_int, C.c_int, C.c_int]
         assert dll.lis_amd_vector_poisson3d_rhs(b, L, N, N) == 0
-        for key, opts in (("cg_jacobi", "-i cg -p jacobi"), ("bicgstab_none", "-i bicgstab -p none"),
-                          ("bicg_none", "-i bicg -p none"),            # Lis's default solver: needs A^T (built in HBM on first use)
-                          ("gmres30_none", "-i gmres -restart 30 -p none")):
-            S = capi.PS()
-            assert lib.lis_solver_create(C.byref(S)) == 0
-            # warm-up pass: work-vector pool, A^T, first launches -- the one-off costs the reference pays in its own setup
-            assert lib.lis_solver_set_option(f"{opts} -tol 1e-12 -maxiter 20".encode(), S) == 0
-            assert lib.lis_solve(A, b, y, S) == 0
-            assert lib.lis_solver_set_option(f"-maxiter {args.solver_iters}".encode(), S) == 0
-            sync(); barrier()
-            t1 = time.perf_counter()
-            assert lib.lis_solve(A, b, y, S) == 0
-            sync(); barrier()
-            wall = time.perf_counter() - t1
-            tm = [C.c_double() for _ in range(5)]           # time, itime, ptime, p_c_time, p_i_time
-            assert lib.lis_solver_get_timeex(S, *[C.byref(t) for t in tm]) == 0
-            itime = tm[1].value
-            iters = min(S.contents.iter, args.solver_iters)
-            if world > 1:
-                tt = torch.tensor([itime, wall], dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                itime, wall = float(tt[0]), float(tt[1])
-            uniform = int(dll.lis_amd_last_solve_uniform_jacobi())      # CG + Jacobi on a constant diagonal: 1/diag rides as a scalar
-            loop_b, contract_b = krylov_bytes(key, iters, n_local, nnz_local, coded, patterns, values, uniform)
-            sec_per_iter = itime / max(1, iters)
-            solvers[key] = {
-                "iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6),
-                "lis_solve_wall_s": round(wall, 4), "rel_residual_after": S.contents.resid,
-                # per GPU: bytes one iteration's passes are asked to stream (fused loops, coded indices: DESIGN.md 6)
-                # and the bytes of the reference's unfused operator sequence over the same time
-                "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_gpu": True,
-                             "loop_bytes_per_iter": loop_b, "achieved": round(loop_b / sec_per_iter / 1e9, 1),
-                             "frac": round(loop_b / sec_per_iter / 1e9 / HBM_PEAK_GBS, 4),
-                             "contract_bytes_per_iter": contract_b,
-                             "contract_frac": round(contract_b / sec_per_iter / 1e9 / HBM_PEAK_GBS, 4)}}
-            lib.lis_solver_destroy(S)
-        if values and streamed is not None:                 # CG + Jacobi once more with the values streamed
-            check(lib.liship_spmv_csr_set_row_values(0))
-            try:
-                S = capi.PS()
-                assert lib.lis_solver_create(C.byref(S)) == 0
-                assert lib.lis_solver_set_option(f"-i cg -p jacobi -tol 1e-12 -maxiter {args.solver_iters}".encode(), S) == 0
-                assert lib.lis_solve(A, b, y, S) == 0
-                tm = [C.c_double() for _ in range(5)]
-                assert lib.lis_solver_get_timeex(S, *[C.byref(t) for t in tm]) == 0
-                itime, iters = tm[1].value, min(S.contents.iter, args.solver_iters)
-                if world > 1:
-                    tt = torch.tensor([itime], dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    itime = float(tt[0])
-                loop_b, _ = krylov_bytes("cg_jacobi", iters, n_local, nnz_local, coded, patterns, 0, int(dll.lis_amd_last_solve_uniform_jacobi()))
-                streamed["cg_jacobi"] = {"iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6),
-                                         "loop_bytes_per_iter": loop_b, "frac": round(loop_b / (itime / max(1, iters)) / 1e9 / HBM_PEAK_GBS, 4)}
-                lib.lis_solver_destroy(S)
-            finally:
-                check(lib.liship_spmv_csr_set_row_values(1))
+        krylov = solve_rates(A, b, y, keys, args.solver_iters, n_local, nnz_local, (0, 0, 0))
+    reference_layout(False)
 
-        if contract is not None:                            # CG + Jacobi with the product in the contract form (fused dots in the same kernel)
-            check(lib.liship_spmv_csr_set_index_codes(0)); check(lib.liship_spmv_csr_set_row_patterns(0)); check(lib.liship_spmv_csr_set_row_values(0))
-            try:
-                S = capi.PS()
-                assert lib.lis_solver_create(C.byref(S)) == 0
-                assert lib.lis_solver_set_option(f"-i cg -p jacobi -tol 1e-12 -maxiter {args.solver_iters}".encode(), S) == 0
-                assert lib.lis_solve(A, b, y, S) == 0
-                tm = [C.c_double() for _ in range(5)]
-                assert lib.lis_solver_get_timeex(S, *[C.byref(t) for t in tm]) == 0
-                itime, iters = tm[1].value, min(S.contents.iter, args.solver_iters)
-                if world > 1:
-                    tt = torch.tensor([itime], dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    itime = float(tt[0])
-                loop_b, contract_b = krylov_bytes("cg_jacobi", iters, n_local, nnz_local, 0, 0, 0, int(dll.lis_amd_last_solve_uniform_jacobi()))
-                contract["cg_jacobi"] = {"iters_per_sec": round(iters / itime, 2), "iters_timed": iters, "itime_s": round(itime, 6), "rel_residual_after": S.contents.resid,
-                                         "loop_bytes_per_iter": loop_b, "frac": round(loop_b / (itime / max(1, iters)) / 1e9 / HBM_PEAK_GBS, 4),
-                                         "contract_bytes_per_iter": contract_b}
-                lib.lis_solver_destroy(S)
-            finally:
-                check(lib.liship_spmv_csr_set_index_codes(1)); check(lib.liship_spmv_csr_set_row_patterns(1)); check(lib.liship_spmv_csr_set_row_values(1))
+    # =====================================================================================================================================
+    # BESIDE IT: what lis_matvec runs for this matrix by default (the plan's derived form), same matrix object, same vectors
+    CONSTANT = ("constant-coefficient matrices only: the 27 row patterns of this stencil carry their VALUES (checked bit for bit at plan time), one pattern "
+                "byte per row is the only matrix stream" + ("; the grid is a box (checked row by row at plan time), the z-marching kernel reads x once per plane tile "
+                "and no pattern byte: x and y alone are streamed (DESIGN.md 4).  Applies to no matrix with varying coefficients -- NOT a CSR-roofline figure" if marching == 2 else "; latency-bound, not byte-bound (DESIGN.md 4)"))
+    GENERAL = "any matrix on these sparsity patterns, whatever its coefficients: 8 B per non-zero + one pattern byte per row streamed"
+    fast = leg(A, xg, y, args.steps, nnz_global)
+    same_bits(y, yc, "default form vs reference layout")
+    fast["x"] = "x_i = frac(i * 0.618...) - 0.5 (as the headline); y equals the headline's y bit for bit (checked)"
+    fast["roofline"] = roofline_of(values, fast["kernel_ms"], "", CONSTANT if values else GENERAL, live=False)
+    fast["kernel"] = fast["roofline"]["kernel"]
+    fast["applies_to"] = fast["roofline"]["applies_to"]
+    fast["x_equals_one"] = leg(A, x1, y, args.steps, nnz_global)
+    check_a_times_one("default form, x = 1")
+    fast["x_equals_one"]["frac"] = round(fast["roofline"]["bytes_per_launch"] / (fast["x_equals_one"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if values:                                              # the same product with the value records switched off (the general kernel: 8 B per non-zero + 17 B per row)
+        check(lib.liship_spmv_csr_set_row_values(0))
+        try:
+            st = leg(A, xg, y, args.steps, nnz_global)
+            same_bits(y, yc, "values-streamed form vs reference layout")
+            st["roofline"] = roofline_of(0, st["kernel_ms"], "_values_streamed", GENERAL, live=False)
+            st["kernel"] = st["roofline"]["kernel"]
+            fast["values_streamed"] = st
+        finally:
+            check(lib.liship_spmv_csr_set_row_values(1))
+    if not args.no_solvers:
+        fast["krylov"] = solve_rates(A, b, y, keys, args.solver_iters, n_local, nnz_local, (coded, patterns, values))
+
+    configs = {}
+    if not args.no_solvers:
+        k3 = krylov.get("bicgstab_none", {})
+        configs["config3"] = {"name": BASELINE_CONFIGS["config3"], "n_gpus": world, "grid": f"{L} x {N} x {N}",
+                              "parallelism": f"row-block x{world}" + (" + RCCL halo + rank-order folds" if world > 1 and comm_used == "rccl" else ""),
+                              "reference_layout": {"iters_per_sec": k3.get("iters_per_sec"), "frac": k3.get("roofline", {}).get("frac"), "iters_timed": k3.get("iters_timed")},
+                              "default_form": {"iters_per_sec": fast.get("krylov", {}).get("bicgstab_none", {}).get("iters_per_sec"),
+                                               "frac": fast.get("krylov", {}).get("bicgstab_none", {}).get("roofline", {}).get("frac")},
+                              "note": "BiCGSTAB -p none on this job's ranks (`krylov.bicgstab_none` / `structured_fast_path.krylov.bicgstab_none` hold the full entries); "
+                                      "the 8-GPU figure is this line at --gpus 8"}
 
     extras = None
-    irregular = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = stencil27_leg(lib, np, C, stream)
-        irregular = queen_class_leg(lib, np, C)
+        if not args.no_configs:
+            ctx = {"lib": lib, "dll": dll, "np": np, "capi": capi, "check": check, "poisson": poisson, "vec": vec, "golden_x": golden_x, "leg": leg,
+                   "reference_layout": reference_layout, "solve_rates": solve_rates, "nrm": nrm, "steps": args.steps, "grid": N, "headline_matrix": A}
+            configs["config1"] = config1_leg(ctx)
+            configs["config2"] = config2_leg(ctx)
+            configs["config4"] = dict({"name": BASELINE_CONFIGS["config4"]}, **queen_class_leg(lib, np, C))
+            configs["config5"] = config5_leg(ctx, sizes=(256, N) if N >= 256 else (N,))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -555,41 +589,205 @@ def main():
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"3-D 7-point Poisson {N}^3" if L == N else f"3-D 7-point Poisson {N}^3 per GPU (grid {N} x {N} x {L})") + ", CSR f64/i32, y=A*x via lis_matvec (x=1), test3.c entry order",
-                       "n": n_global, "nnz": nnz_global, "parallelism": f"row-block x{world}" + ((" + RCCL halo" if comm_used == "rccl" else " + gloo-callback halo (bring-up, not a measurement)") if world > 1 else "")},
+            "config": {"workload": (f"3-D 7-point Poisson {N}^3" if L == N else f"3-D 7-point Poisson {N}^3 per GPU (grid {N} x {N} x {L})") +
+                                   ", CSR f64/i32 (test3.c entry order), y=A*x via lis_matvec streaming the reference's own value[] / index[] / ptr[] arrays (12 B per non-zero + 20 B per row), "
+                                   "x_i = frac(i * 0.618...) - 0.5",
+                       "n": n_global, "nnz": nnz_global, "mode": "lis_amd_set_reference_layout(1)",
+                       "parallelism": f"row-block x{world}" + ((" + RCCL halo" if comm_used == "rccl" else " + gloo-callback halo (bring-up, not a measurement)") if world > 1 else "")},
             "roofline": roofline,
-            "nontrivial_x": nontrivial,
-            "values_streamed": streamed,
-            "contract_form": contract,
-            "reading_guide": ("`value` / `roofline`: the product lis_matvec runs for THIS matrix (x = 1, the reference's spmvtest3 convention); `nontrivial_x`: "
-                              "the same kernel on non-trivial data; `values_streamed`: the kernel every matrix with these sparsity patterns but varying "
-                              "coefficients takes, with its own roofline; `contract_form`: the kernel that streams the reference's own index[] / value[] arrays "
-                              "(12 B per non-zero + 20 B per row -- SURVEY 8d's count, what ANY short-row CSR matrix takes), frac priced on exactly those bytes.  Every `frac` is bytes-the-kernel-moves / its HIP-event time / 8 TB/s (<= 1, "
-                              "asserted); `contract_frac` prices SURVEY 8d's 12 B/nnz + 20 B/row layout over the same time and may exceed 1."),
+            "x_equals_one": x_one,
+            "krylov": krylov,
+            "structured_fast_path": fast,
+            "configs": configs,
+            "reading_guide": ("`value` / `ms_per_step` / `roofline`: lis_matvec on the 512^3 CSR matrix in the reference layout mode -- spmv_csr_rowgather_kernel streams the reference's own "
+                              "index[] / value[] / ptr[] arrays, SURVEY 8d's 12 B per non-zero + 20 B per row, on a non-trivial x; `frac` is exactly those bytes / the kernel's HIP-event time / "
+                              "8 TB/s, <= 1 by construction, and `traffic` is this run's own PMC count of the same kernel.  `krylov`: the solver loops in the same mode.  "
+                              "`structured_fast_path`: what the library does for THIS matrix by default (a constant-coefficient box stencil: matrix-free marching) -- the same bits, "
+                              "priced on its own bytes, not a CSR-roofline claim.  `configs`: one leg per BASELINE.json config.  Every `frac` in the line is bytes-the-kernel-is-asked-to-move / "
+                              "its measured time / 8 TB/s (0 < frac <= 1, asserted); `contract_frac` prices SURVEY 8d's layout over the same time and exceeds 1 exactly where a derived form reads fewer bytes."),
             "setup": {"generate_and_plan_ms": round(setup_ms, 1), "generate_ms": None if gen_ms is None else round(gen_ms, 1),
                       "plan_build_ms": None if gen_ms is None else round(max(setup_ms - gen_ms, 0.0), 1),
                       "plan_build_in_products": None if gen_ms is None else round(max(setup_ms - gen_ms, 0.0) / max(ms_per_step, 1e-9), 1),
                       "note": "one-off per matrix, outside the timed region (the reference pays its own at lis_matrix_assemble / _convert): the matrix generated in HBM, then "
-                              "the plan -- merge-path row split, one-byte column codes, row patterns, value records, the dominant pattern (DESIGN.md 4); "
-                              "plan_build_in_products = how many timed products it costs"},
+                              "the DEFAULT plan -- merge-path row split, one-byte column codes, row patterns, value records, the dominant pattern (DESIGN.md 4); "
+                              "plan_build_in_products = how many timed (reference-layout) products it costs"},
             "preroll": args.preroll,          # untimed clock-ramp launches before the W warm-up steps (a cold process: +7 %)
             "degraded": bool(world > 1 and comm_used != "rccl"),   # True: the RCCL communicator could not be formed, NOT a measurement
             "rccl_ranks": world if (world > 1 and comm_used == "rccl" and int(dll.lis_amd_comm_kind()) == 1) else (0 if world > 1 else None),
+            "self_launched": os.environ.get("LIS_AMD_BENCH_SELF_LAUNCHED") == "1",
             "multi_gpu": multi,
-            "krylov": solvers,
             "stencil27": extras,              # beside the headline: the 27-point stencil (spmvtest3b / HPCG) through the round-3 kernels; not part of `value`
-            "config4_stand_in": irregular,    # BASELINE config 4 (irregular CSR, long rows): a generated matrix of Queen_4147's size through lis_input; not part of `value`
             "cpu_baseline": cpu,
         }
         assert_fracs_physical(out, shared_gpu=out["degraded"])
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())          # the ONE line of stdout (everything else this process printed went to stderr)
+        assert alg_bytes / (ms_per_step * 1e-3) <= HBM_PEAK_GBS * 1e9, "SURVEY 8d bytes / ms_per_step exceeds the HBM peak: the timed kernel is not doing the work"
+        emit(out)
     degraded = world > 1 and comm_used != "rccl" and args.comm == "rccl"
     if world > 1:
         dll.lis_amd_comm_finalize()
         dist.destroy_process_group()
     if degraded:
         sys.exit(3)                   # the line above says "degraded": true; a driver that only looks at the exit code sees it too
+
+
+# ============================================================================================================================ per-config legs
+def config1_leg(ctx):
+    """BASELINE config 1 = test/spmvtest1.c: the 1-D 3-point matrix (2 on the diagonal, -1 beside it, test/spmvtest1.c:139-146) of n = 10000 rows, y = A*1 in every
+    storage format the driver walks that this library serves, `iter` products each, the 2-norm it prints (sqrt 2: 1 at both ends, 0 inside) and MFLOPS = 2 nnz iter / t
+    (:225).  A plumbing case: 30 kB of matrix, latency-bound -- no roofline fraction."""
+    lib, np, capi = ctx["lib"], ctx["np"], ctx["capi"]
+    try:
+        import lisdrv
+        n, iters = 10000, 100
+        idx = np.stack([np.arange(n) - 1, np.arange(n), np.arange(n) + 1], axis=1).ravel()
+        val = np.tile(np.array([-1.0, 2.0, -1.0]), n)
+        keep = (idx >= 0) & (idx < n)
+        idx, val = idx[keep].astype(np.int32), val[keep]
+        ptr = np.concatenate([[0], np.cumsum(keep.reshape(n, 3).sum(axis=1))]).astype(np.int32)
+        A0 = lisdrv.make_csr(lib, ptr, idx, val)
+        nnz = int(ptr[-1])
+        out = {"name": BASELINE_CONFIGS["config1"], "n": n, "nnz": nnz, "iter": iters, "formats": {}}
+        nrm = C.c_double()
+        for fmt in ("csr", "csc", "dia", "ell", "jad", "bsr"):
+            M = A0 if fmt == "csr" else lisdrv.convert(lib, A0, fmt)
+            x, y = ctx["vec"](M), ctx["vec"](M)
+            assert lib.lis_vector_set_all(1.0, x) == 0
+            for _ in range(5):
+                assert lib.lis_matvec(M, x, y) == 0
+            ctx["dll"].lis_amd_synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                assert lib.lis_matvec(M, x, y) == 0
+            ctx["dll"].lis_amd_synchronize()
+            el = time.perf_counter() - t0
+            assert lib.lis_vector_nrm2(y, C.byref(nrm)) == 0
+            ok = abs(nrm.value - 2.0 ** 0.5) <= 1e-14
+            out["formats"][fmt.upper()] = {"two_norm": nrm.value, "two_norm_is_sqrt2": ok, "mflops": round(2.0 * nnz * iters * 1e-6 / el, 1), "us_per_product": round(el / iters * 1e6, 2)}
+            if not ok:
+                out["error"] = f"{fmt}: 2-norm {nrm.value!r} != sqrt(2)"
+            lib.lis_vector_destroy(x); lib.lis_vector_destroy(y)
+            if M is not A0:
+                lib.lis_matrix_destroy(M)
+        lib.lis_matrix_destroy(A0)
+        out["note"] = "spmvtest1's own report: `2-norm = 1.414214e+00` for every format; products are queued, the clock stops behind one synchronize"
+        return out
+    except Exception as exc:
+        return {"name": BASELINE_CONFIGS["config1"], "error": f"{type(exc).__name__}: {exc}"}
+
+
+def fmt_bytes(fmt, n, nnz, width):
+    """the algorithmic bytes of one product in the format's own (reference) layout"""
+    if fmt == "csr":
+        return 12 * nnz + 20 * n + 4
+    if fmt == "ell":
+        return 12 * width * n + 16 * n
+    if fmt == "dia":
+        return 8 * width * n + 16 * n
+    raise KeyError(fmt)
+
+
+def format_legs(ctx, G, fmts, cg_iters, reference):
+    """CSR / ELL / DIA of the G^3 7-point matrix (spmvtest3's sorted rows: DIA adds a row's terms by ascending offset, so all three give the same bits), each through
+    lis_matvec on a non-trivial x and through CG + Jacobi.  reference=True: the reference layout mode -- native kernels on the formats' own arrays, `frac` on SURVEY 8d's
+    bytes (CSR 12 nnz + 20 n, ELL 100 n, DIA 72 n for this stencil).  reference=False: the default forms (constant coefficients: all formats collapse onto the row form
+    and its marching kernel -- reported as times and contract_frac, which exceeds 1 there because the arrays are not read)."""
+    lib, dll, capi, np = ctx["lib"], ctx["dll"], ctx["capi"], ctx["np"]
+    import lisdrv
+    n, nnz = G ** 3, 7 * G ** 3 - 6 * G * G
+    ctx["reference_layout"](reference)
+    out = {}
+    try:
+        As = ctx["poisson"](G, G, G, 1)
+        x, y, yref, b, sol = (ctx["vec"](As) for _ in range(5))
+        ctx["golden_x"](x, n)
+        assert dll.lis_amd_vector_poisson3d_rhs(b, G, G, G) == 0
+        nrm = ctx["nrm"]
+        for fmt in fmts:
+            M = As if fmt == "csr" else lisdrv.convert(lib, As, fmt)
+            width = {"csr": 0, "ell": M.contents.maxnzr, "dia": M.contents.nnd}[fmt]
+            e = ctx["leg"](M, x, y, ctx["steps"], nnz, collective=False)
+            if fmt == "csr":
+                assert lib.lis_vector_copy(y, yref) == 0
+            else:
+                assert lib.lis_vector_axpy(-1.0, yref, y) == 0 and lib.lis_vector_nrm2(y, C.byref(nrm)) == 0
+                e["same_bits_as_csr"] = nrm.value == 0.0
+            B = fmt_bytes(fmt, n, nnz, width)
+            sec = e["kernel_ms"] * 1e-3
+            dtype = int(dll.lis_amd_matrix_device_type(M))
+            native = dtype == {"csr": capi.LIS_MATRIX_CSR, "ell": capi.LIS_MATRIX_ELL, "dia": capi.LIS_MATRIX_DIA}[fmt]
+            e.update({"contract_bytes_per_launch": B, "width": width, "device_layout": {capi.LIS_MATRIX_CSR: "CSR rows", capi.LIS_MATRIX_ELL: "ELL", capi.LIS_MATRIX_DIA: "DIA"}.get(dtype, dtype),
+                      "value_records": int(dll.lis_amd_matrix_value_records(M)), "marching": int(dll.lis_amd_matrix_marching(M)) if dtype == capi.LIS_MATRIX_CSR else 0})
+            if reference:
+                assert native and e["value_records"] == 0, "the reference layout mode must keep the format's own arrays"
+                e["kernel"] = {"csr": "spmv_csr_rowgather_kernel", "ell": "spmv_ell_kernel", "dia": "spmv_dia_kernel"}[fmt]
+                e["frac"] = round(B / sec / 1e9 / HBM_PEAK_GBS, 4)
+                form = (0, 0, 0)
+            else:
+                e["contract_frac"] = round(B / sec / 1e9 / HBM_PEAK_GBS, 4)
+            # CG + Jacobi: to convergence when cg_iters is None (the reference's count is the check), else cg_iters timed iterations
+            S = capi.PS()
+            assert lib.lis_solver_create(C.byref(S)) == 0
+            assert lib.lis_solver_set_option(b"-i cg -p jacobi -tol 1e-12 -maxiter 20", S) == 0 and lib.lis_solve(M, b, sol, S) == 0      # warm-up
+            assert lib.lis_solver_set_option(f"-maxiter {cg_iters or 3000}".encode(), S) == 0
+            assert lib.lis_solve(M, b, sol, S) == 0
+            it, itime = S.contents.iter, S.contents.itime
+            cg = {"iters_per_sec": round(it / itime, 2) if itime > 0 else None, "iter": it, "itime_s": round(itime, 6), "status": S.contents.retcode, "rel_residual": S.contents.resid,
+                  "to_convergence": cg_iters is None}
+            if reference and itime > 0:
+                uniform = int(dll.lis_amd_last_solve_uniform_jacobi())
+                loop_b = B - 4 * (fmt == "csr") + (CG_VECTOR_BYTES_PER_ROW - (16 if uniform else 0)) * n
+                cg["loop_bytes_per_iter"] = loop_b
+                cg["frac"] = round(loop_b / (itime / max(1, it)) / 1e9 / HBM_PEAK_GBS, 4)
+                cg["contract_bytes_per_iter"] = B + 136 * n
+            e["cg_jacobi"] = cg
+            lib.lis_solver_destroy(S)
+            out[fmt.upper()] = e
+            if M is not As:
+                lib.lis_matrix_destroy(M)
+        for v in (x, y, yref, b, sol):
+            lib.lis_vector_destroy(v)
+        lib.lis_matrix_destroy(As)
+    finally:
+        ctx["reference_layout"](False)
+    return out
+
+
+def config2_leg(ctx):
+    """BASELINE config 2: 256^3 CSR, CG + Jacobi to convergence (tol 1e-12: 764 iterations, the reference's count in every format and at every thread count,
+    tests/golden/known_answers.json), in the reference layout mode and in the default form."""
+    try:
+        G = 256 if ctx["grid"] >= 256 else ctx["grid"]
+        out = {"name": BASELINE_CONFIGS["config2"], "grid": f"{G}^3", "n": G ** 3, "nnz": 7 * G ** 3 - 6 * G * G,
+               "reference_iterations": 764 if G == 256 else None}
+        out["reference_layout"] = format_legs(ctx, G, ("csr",), None, True)["CSR"]
+        out["default_form"] = format_legs(ctx, G, ("csr",), None, False)["CSR"]
+        for k in ("reference_layout", "default_form"):
+            cg = out[k]["cg_jacobi"]
+            if G == 256 and (cg["iter"] != 764 or cg["status"] != 0):
+                out["error"] = f"{k}: CG + Jacobi took {cg['iter']} iterations (status {cg['status']}), the reference takes 764"
+        return out
+    except Exception as exc:
+        return {"name": BASELINE_CONFIGS["config2"], "error": f"{type(exc).__name__}: {exc}"}
+
+
+def config5_leg(ctx, sizes):
+    """BASELINE config 5: the format sweep -- CSR / ELL / DIA at 256^3 (the config's size; x + y = 268 MB sit at the edge of the 256 MB Infinity Cache) and at the
+    headline's 512^3 (nothing fits), native kernels on SURVEY 8d's bytes and the default forms; CG + Jacobi each (256^3: to convergence = 764 iterations; 512^3: 100 timed)."""
+    out = {"name": BASELINE_CONFIGS["config5"]}
+    for G in sizes:
+        try:
+            full = G <= 256
+            out[f"{G}^3"] = {"n": G ** 3, "nnz": 7 * G ** 3 - 6 * G * G,
+                             "native_kernels_reference_layout": format_legs(ctx, G, ("csr", "ell", "dia"), None if full else 100, True),
+                             "default_forms": format_legs(ctx, G, ("csr", "ell", "dia"), None if full else 100, False)}
+            if G == 256:
+                for mode in ("native_kernels_reference_layout", "default_forms"):
+                    for fmt, e in out["256^3"][mode].items():
+                        if e["cg_jacobi"]["iter"] != 764:
+                            out["error"] = f"{mode} {fmt}: {e['cg_jacobi']['iter']} iterations, the reference takes 764"
+        except Exception as exc:
+            out[f"{G}^3"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
 
 
 def stencil27_leg(lib, np, C, stream, G=256, launches=30):

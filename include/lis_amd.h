@@ -29,6 +29,11 @@
 extern "C" {
 #endif
 
+/* A HIP runtime or RCCL failure (a kernel launch, a copy, a stream synchronize, a collective) is reported as LIS_AMD_ERR_DEVICE with the HIP error string on stderr;
+ * hipErrorOutOfMemory as LIS_ERR_OUT_OF_MEMORY.  (The reference has no device and no such code: 7 is the first value lis.h:1052-1063 leaves free.  It is NOT
+ * LIS_ERR_NOT_IMPLEMENTED, which keeps its meaning: a storage format, solver or preconditioner this library does not serve.) */
+#define LIS_AMD_ERR_DEVICE 7
+
 #define LIS_AMD_COHERENT 0
 #define LIS_AMD_RESIDENT 1
 
@@ -142,6 +147,12 @@ LIS_INT lis_amd_matrix_strip_rows(LIS_MATRIX A);
  * (bit-identical sums), so that the value records apply.  0 keeps the native ELL / DIA layout and kernels for matrices uploaded
  * from now on (env LIS_AMD_NO_ROW_FORM=1): A/B measurements, and the tests that pin the native kernels at full size. */
 LIS_INT lis_amd_set_row_form(LIS_INT on);
+/* REFERENCE LAYOUT mode (env LIS_AMD_REFERENCE_LAYOUT=1), a supported mode: every product streams the reference's own arrays -- CSR: 4 B index[] + 8 B value[] per
+ * non-zero + ptr[] (the loop of src/matvec/lis_matvec_csr.c:97-109 on 12 B per non-zero + 20 B per row, the count the CSR roofline target is quoted on), ELL / DIA / BSR
+ * their native arrays -- and nothing a plan could derive from them (one-byte column codes, row patterns, value records, block-local columns, renumbering, row forms).
+ * Results carry the same bits; bench.py's headline runs in this mode.  Takes effect for plans already built and for matrices uploaded from now on. */
+LIS_INT lis_amd_set_reference_layout(LIS_INT on);
+LIS_INT lis_amd_get_reference_layout(void);
 /* storage type of the HBM copy (LIS_MATRIX_CSR for matrices re-laid as rows: CSC, JAD, the row form above), uploads A if needed */
 LIS_INT lis_amd_matrix_device_type(LIS_MATRIX A);
 /* total length of the per-row-block lists of distinct columns when the HBM copy of A carries block-local columns (liship.h:

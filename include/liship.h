@@ -461,6 +461,10 @@ int  liship_dot2_f64(int n, const double *x, const double *y, double *result, vo
  * src/matrix/lis_matrix_csr.c:547-558 */
 int  liship_csr_diagonal_f64(int n, const int *ptr, const int *index, const double *value,
                              double *d, void *stream);
+/* the same for the native ELL arrays (first slot whose index is the row; padding gives 0: src/matrix/lis_matrix_ell.c lis_matrix_get_diagonal_ell) and the
+ * native DIA arrays (the stored diagonal of offset 0, one chunk value[d*n + i]: src/matrix/lis_matrix_dia.c lis_matrix_get_diagonal_dia) */
+int  liship_ell_diagonal_f64(int n, int maxnzr, const int *index, const double *value, double *d, void *stream);
+int  liship_dia_diagonal_f64(int n, int nnd, const int *offsets, const double *value, double *d, void *stream);
 /* halo pack: ws[i] = x[export_index[i]]  (lis_send_recv, src/matrix/lis_matrix_mpi.c:904-916) */
 int  liship_gather_f64(int count, const int *export_index, const double *x, double *ws, void *stream);
 /* A^T of a CSR matrix in HBM, each transposed row listing its entries in the order of their positions in the

@@ -58,7 +58,7 @@ static LIS_INT rccl_load(void)
 static LIS_INT nccl_fail(const char *what, int rc)
 {
 	fprintf(stderr, "liblis_amd: %s failed: %s\n", what, rccl.GetErrorString ? rccl.GetErrorString(rc) : "?");
-	return LIS_ERR_NOT_IMPLEMENTED;
+	return LIS_AMD_ERR_DEVICE;
 }
 #define NCCLCHK(call) do { int rc__ = (call); if (rc__ != 0) return nccl_fail(#call, rc__); } while (0)
 
@@ -137,7 +137,14 @@ LIS_INT lis_amd_comm_init_rccl(const void *id128, LIS_INT rank, LIS_INT nprocs, 
 		if (ok && rank == 0) ok = rccl.GetUniqueId(&hid) == 0;
 		if (all && lisc_allgather_host(&hid, all, sizeof(hid)) != LIS_SUCCESS) ok = 0;      /* (every rank takes part whatever its own state) */
 		nccl_comm h = NULL;
-		if (ok) { hid = all[0]; ok = comm_init_guarded(&h, nprocs, &hid, rank, device) == 0; }
+		if (ok) {
+			/* rank 0's GetUniqueId may have failed: its id then arrives as zeros on EVERY rank, and every rank skips the second communicator together
+			 * (a CommInitRank on a zero id would block until the watchdog) */
+			static const nccl_uid zero_id;
+			hid = all[0];
+			ok = memcmp(&hid, &zero_id, sizeof(hid)) != 0;
+		}
+		if (ok) ok = comm_init_guarded(&h, nprocs, &hid, rank, device) == 0;
 		free(all);
 		int mine = ok, *flags = (int *)calloc((size_t)nprocs, sizeof(int));
 		if (flags && lisc_allgather_host(&mine, flags, sizeof(int)) == LIS_SUCCESS) { for (LIS_INT r = 0; r < nprocs; r++) ok = ok && flags[r]; } else ok = 0;
@@ -423,9 +430,14 @@ static LIS_INT halo_rccl(LIS_MATRIX A, double *dx, void *stream)
 	lisd_mat *d = MDEV(A);
 	LIS_COMMTABLE t = A->commtable;
 	const LIS_INT n = A->n, pad = t->pad;
-	/* the exchange overlapped with the interior rows runs on the second stream AND the second communicator; the plain one (library's stream) stays on the first,
-	 * in line with the folds queued around it */
-	nccl_comm comm = (stream != lisg.stream && lisg.nccl_halo) ? lisg.nccl_halo : lisg.nccl_comm;
+	/* EVERY forward exchange goes over the halo communicator when there is one, whichever stream it is queued on.  Whether a product overlaps its exchange with the
+	 * interior rows is decided rank by rank (lisd_spmv: "at least half of my rows touch no ghost column"), so two neighbours may well decide differently -- 3 planes
+	 * per rank on 3 ranks: the end ranks overlap, the middle one does not -- and a Send on one communicator never meets a Recv on the other (the job hung
+	 * until the watchdog).  The communicator must therefore not depend on that decision; only the STREAM does.  Order on each communicator is program order on every
+	 * rank (exchanges on nccl_halo, folds and reverse exchanges on nccl_comm), and on one rank the two never run concurrently: an overlapped exchange is fenced
+	 * by ev_packed / ev_landed between the folds before and after it (lisc_halo_begin / lisc_halo_end), a plain one sits in the library's stream with them.
+	 * Keep it that way -- concurrent collectives on two communicators of one process are a known deadlock shape. */
+	nccl_comm comm = lisg.nccl_halo ? lisg.nccl_halo : lisg.nccl_comm;
 	NCCLCHK(rccl.GroupStart());
 	for (LIS_INT i = 0; i < t->neibpetot; i++) {
 		const LIS_INT peer = t->neibpe[i];

@@ -480,8 +480,13 @@ static LIS_INT convert_impl(LIS_MATRIX Ain, LIS_MATRIX Aout)
 {
 	LISCHK(lisi_matrix_check(Ain, LISI_CHECK_ASSEMBLED));
 	LISCHK(lisi_matrix_check(Aout, LISI_CHECK_NULL));
-	if (MDEV(Ain)->device_only) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "matrix lives in HBM only: convert the host matrix before uploading\n");
 	const LIS_INT want = Aout->matrix_type;
+	if (MDEV(Ain)->device_only) {          /* born in HBM: the conversions that are built there (ELL, DIA, CSC, BSR) are served, the host routines have nothing to read */
+		int done = 0;
+		if (Ain->matrix_type == LIS_MATRIX_CSR && want != LIS_MATRIX_CSR) LISCHK(lisd_convert_csr(Ain, Aout, &done));
+		if (done) return LIS_SUCCESS;
+		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "matrix lives in HBM only: this conversion runs on host arrays -- convert the host matrix before uploading\n");
+	}
 	LISCHK(lis_matrix_merge(Ain));         /* ref lis_matrix_ops.c:142: a split input is merged first */
 	if (Ain->matrix_type == want && !Ain->is_block) { LISCHK(lisp_fill_matrix(Ain)); return lisi_matrix_deep_copy(Ain, Aout); }
 	if (Ain->matrix_type == LIS_MATRIX_CSR) {

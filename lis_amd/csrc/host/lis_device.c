@@ -55,6 +55,7 @@ LIS_INT lisd_init(void)
 	HIPCHK(lisd_malloc((void **)&lisg.reduce_out, 4 * sizeof(double)));
 	HIPCHK(liship_malloc_host((void **)&lisg.host_out, 4 * 64 * sizeof(double)));
 	if (lisg.long_row_tree) HIPCHK(liship_spmv_csr_set_long_row_tree(1));
+	if (lisg.reference_layout) LISCHK(lis_amd_set_reference_layout(1));
 	if (lisg.no_team_kernels) { HIPCHK(liship_spmv_csr_set_team(0)); HIPCHK(liship_spmv_bsr_set_team(0)); }
 	if (lisg.no_marching) HIPCHK(liship_spmv_csr_set_dom_march(0));
 	if (lisg.row_block_dots) HIPCHK(liship_spmv_csr_set_row_block_dots(1));
@@ -129,6 +130,30 @@ LIS_INT lis_amd_get_residency(void) { return lisg.residency; }
 LIS_INT lis_amd_last_solve_uniform_jacobi(void) { return lisg.last_uniform_jacobi; }
 
 LIS_INT lis_amd_set_row_form(LIS_INT on) { lisg.no_row_form = on ? 0 : 1; return LIS_SUCCESS; }
+/* The REFERENCE LAYOUT mode (env LIS_AMD_REFERENCE_LAYOUT=1): every product streams the reference's own arrays -- CSR 4 B index[] + 8 B value[] per non-zero + ptr[]
+ * (lis_matvec_csr.c:97-109 on SURVEY 8d's 12 B per non-zero + 20 B per row), ELL / DIA / BSR their native arrays -- and nothing the plan could derive from them: no
+ * one-byte column codes, row patterns, value records, block-local columns, renumbering or row forms.  Same bits either way; this is the form the CSR roofline target is
+ * quoted on and what bench.py's headline runs.  Applies to plans already built (the kernels' own switches) and to matrices uploaded from now on. */
+static struct { int saved, codes, patterns, values, rowform, local, reorder; } ref_layout;
+LIS_INT lis_amd_set_reference_layout(LIS_INT on)
+{
+	if (on && !ref_layout.saved) {
+		ref_layout.saved = 1;
+		ref_layout.codes = lisg.no_index_codes; ref_layout.patterns = lisg.no_row_patterns; ref_layout.values = lisg.no_value_records;
+		ref_layout.rowform = lisg.no_row_form; ref_layout.local = lisg.no_local_columns; ref_layout.reorder = lisg.no_reorder;
+		lisg.no_index_codes = lisg.no_row_patterns = lisg.no_value_records = lisg.no_row_form = lisg.no_local_columns = lisg.no_reorder = 1;
+	} else if (!on && ref_layout.saved) {
+		ref_layout.saved = 0;
+		lisg.no_index_codes = ref_layout.codes; lisg.no_row_patterns = ref_layout.patterns; lisg.no_value_records = ref_layout.values;
+		lisg.no_row_form = ref_layout.rowform; lisg.no_local_columns = ref_layout.local; lisg.no_reorder = ref_layout.reorder;
+	}
+	lisg.reference_layout = on ? 1 : 0;
+	HIPCHK(liship_spmv_csr_set_index_codes(!lisg.no_index_codes)); HIPCHK(liship_spmv_csr_set_row_patterns(!lisg.no_row_patterns));
+	HIPCHK(liship_spmv_csr_set_row_values(!lisg.no_value_records)); HIPCHK(liship_spmv_csr_set_local_columns(!lisg.no_local_columns));
+	HIPCHK(liship_spmv_csr_set_reorder(lisg.no_reorder ? 0 : 1));
+	return LIS_SUCCESS;
+}
+LIS_INT lis_amd_get_reference_layout(void) { return lisg.reference_layout; }
 LIS_INT lis_amd_set_reference_reductions(LIS_INT T)
 {
 	if (T < 0 || liship_set_reference_reductions((int)T) != 0) return LISI_ERR(LIS_ERR_ILL_ARG, "reference-order reductions: T(=%D) out of range\n", T);
@@ -956,7 +981,9 @@ LIS_INT lisd_convert_csr(LIS_MATRIX Ain, LIS_MATRIX Aout, int *done)
 	lisd_mat *sd = MDEV(Ain);
 	const LIS_INT want = Aout->matrix_type;
 	if (want != LIS_MATRIX_ELL && want != LIS_MATRIX_DIA && want != LIS_MATRIX_CSC && want != LIS_MATRIX_BSR && want != LIS_MATRIX_JAD) return LIS_SUCCESS;
-	if (lisg.no_device_convert || lisg.nprocs > 1 || !lisg.device_ready || sd->device_only ||
+	/* (a matrix born in HBM -- lis_amd_matrix_set_csr_device / lis_amd_matrix_poisson3d -- converts like any other: nothing below reads Ain's host arrays, except JAD's
+	 * row order, which is the reference's quicksort on the host) */
+	if (lisg.no_device_convert || lisg.nprocs > 1 || !lisg.device_ready || (sd->device_only && want == LIS_MATRIX_JAD) ||
 	    Ain->matrix_type != LIS_MATRIX_CSR || Ain->is_splited || Ain->np != Ain->n || Ain->n <= 0 || Ain->nnz <= 0)
 		return LIS_SUCCESS;
 	LISCHK(lisd_mat_ready(Ain));          /* (an upload of the source costs a fraction of a pass of the host routine over it; a stale copy is rebuilt) */

@@ -117,6 +117,7 @@ typedef struct {
 	void *nccl_halo;           /* a second communicator for the halo exchange on the second stream (NULL: the first one serves, ordered by events) */
 	void *comm_stream;         /* second HIP stream: halo send/recv overlapped with the interior rows */
 	void *ev_packed, *ev_landed;
+	int reference_layout;      /* LIS_AMD_REFERENCE_LAYOUT=1 / lis_amd_set_reference_layout(1): products stream the reference's own arrays (lis_device.c) */
 	int long_row_tree;         /* LIS_AMD_LONG_ROW_TREE=1: rows longer than the LDS stage are added by a tree per pass (not bit-parity; opt-in) */
 	int no_value_records;      /* LIS_AMD_NO_VALUE_RECORDS=1: matrices whose rows repeat with their values keep streaming the values (A/B measurements) */
 	int eager_coherence;       /* LIS_AMD_COHERENCE=eager / lis_amd_set_coherence(0): COHERENT copies on every call instead of following page faults (lis_pages.c) */

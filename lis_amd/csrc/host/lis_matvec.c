@@ -55,9 +55,9 @@ static void raw_matvec(LIS_MATRIX A, LIS_INT fmt, LIS_SCALAR x[], LIS_SCALAR y[]
 		if (lisd_malloc((void **)&d->sx, nx * sizeof(double)) || lisd_malloc((void **)&d->sy, nx * sizeof(double))) err = LIS_ERR_OUT_OF_MEMORY;
 		else { d->scap = nx; (void)liship_memset(d->sx, 0, nx * sizeof(double), lisg.stream); }
 	}
-	if (!err && liship_memcpy_h2d(d->sx, x, sizeof(double) * (size_t)(lisg.nprocs > 1 ? A->n : A->np), lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+	if (!err) { int rc = liship_memcpy_h2d(d->sx, x, sizeof(double) * (size_t)(lisg.nprocs > 1 ? A->n : A->np), lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
 	if (!err) err = lisd_spmv(A, d->sx, d->sy);
-	if (!err && (liship_memcpy_d2h(y, d->sy, sizeof(double) * (size_t)A->n, lisg.stream) || liship_stream_synchronize(lisg.stream))) err = LIS_ERR_NOT_IMPLEMENTED;
+	if (!err) { int rc = liship_memcpy_d2h(y, d->sy, sizeof(double) * (size_t)A->n, lisg.stream); if (!rc) rc = liship_stream_synchronize(lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
 	if (err) {
 		fprintf(stderr, "liblis_amd: lis_matvec_<fmt>(A, x[], y[]) failed (code %d) and has no error channel -- aborting\n", (int)err);
 		abort();
@@ -105,10 +105,10 @@ LIS_INT lis_matvec_optimize(LIS_MATRIX A, LIS_INT *matrix_type_maxperf)
 		if (!err) err = lis_matrix_set_type(A1, type);
 		if (!err) err = lis_matrix_convert(A, A1);
 		if (!err) err = lis_matvec(A1, X, Y);                     /* untimed: uploads A1 and builds its plan (the reference converts outside its clock too) */
-		if (!err && liship_stream_synchronize(lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+		if (!err) { int rc = liship_stream_synchronize(lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
 		double comptime = lis_wtime();
 		for (LIS_INT i = 0; i < iter && !err; i++) err = lis_matvec(A1, X, Y);
-		if (!err && liship_stream_synchronize(lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+		if (!err) { int rc = liship_stream_synchronize(lisg.stream); if (rc) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
 		comptime = lis_wtime() - comptime;
 		LIS_REAL val = 0.0;
 		if (!err) err = lis_vector_nrm2(Y, &val);

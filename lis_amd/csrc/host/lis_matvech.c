@@ -152,7 +152,7 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 			if (!err) err = upload((void **)&d->t_index, w.index, sizeof(int) * (size_t)tnnz);
 			if (!err) err = upload((void **)&d->t_value, w.value, sizeof(double) * (size_t)tnnz);
 			if (!err && type == LIS_MATRIX_CSR) err = upload((void **)&d->t_diag, A->D->value, sizeof(double) * (size_t)n);
-			if (!err && liship_stream_synchronize(lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+			if (!err) { int rc__ = liship_stream_synchronize(lisg.stream); if (rc__) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc__); }
 		}
 		free(w.ptr); free(w.fill); free(w.index); free(w.value);
 		if (err) return err;
@@ -211,7 +211,7 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 			err = upload((void **)&d->t_ptr, w.ptr, sizeof(int) * ((size_t)np + 1));
 			if (!err) err = upload((void **)&d->t_index, w.index, sizeof(int) * (size_t)tnnz);
 			if (!err) err = upload((void **)&d->t_value, w.value, sizeof(double) * (size_t)tnnz);
-			if (!err && liship_stream_synchronize(lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+			if (!err) { int rc__ = liship_stream_synchronize(lisg.stream); if (rc__) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc__); }
 		}
 		free(w.ptr); free(w.fill); free(w.index); free(w.value);
 		free(hptr); free(hidx); free(hval);
@@ -277,9 +277,9 @@ static void raw_matvech(LIS_MATRIX A, LIS_INT fmt, LIS_SCALAR x[], LIS_SCALAR y[
 		if (lisd_malloc((void **)&d->sx, nx * sizeof(double)) || lisd_malloc((void **)&d->sy, nx * sizeof(double))) err = LIS_ERR_OUT_OF_MEMORY;
 		else { d->scap = nx; (void)liship_memset(d->sx, 0, nx * sizeof(double), lisg.stream); }
 	}
-	if (!err && liship_memcpy_h2d(d->sx, x, sizeof(double) * (size_t)A->n, lisg.stream)) err = LIS_ERR_NOT_IMPLEMENTED;
+	if (!err) { int rc__ = liship_memcpy_h2d(d->sx, x, sizeof(double) * (size_t)A->n, lisg.stream); if (rc__) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc__); }
 	if (!err) err = lisd_spmv_t(A, d->sx, d->sy);
-	if (!err && (liship_memcpy_d2h(y, d->sy, sizeof(double) * (size_t)(lisg.nprocs > 1 ? A->n : A->np), lisg.stream) || liship_stream_synchronize(lisg.stream))) err = LIS_ERR_NOT_IMPLEMENTED;
+	if (!err) { int rc__ = liship_memcpy_d2h(y, d->sy, sizeof(double) * (size_t)(lisg.nprocs > 1 ? A->n : A->np), lisg.stream); if (!rc__) rc__ = liship_stream_synchronize(lisg.stream); if (rc__) err = lisi_hip_error(__FILE__, __func__, __LINE__, rc__); }
 	if (err) {
 		fprintf(stderr, "liblis_amd: lis_matvech_<fmt>(A, x[], y[]) failed (code %d) and has no error channel -- aborting\n", (int)err);
 		abort();

@@ -172,7 +172,7 @@ LIS_INT lisi_hip_error(const char *file, const char *func, int line, int hipcode
 	}
 	fprintf(stderr, "%s(%d) : %s : HIP error %d (%s) -- liblis_amd has no CPU fallback\n",
 	        base ? base + 1 : file, line, func, hipcode, liship_error_string(hipcode));
-	return hipcode == 2 /* hipErrorOutOfMemory */ ? LIS_ERR_OUT_OF_MEMORY : LIS_ERR_NOT_IMPLEMENTED;
+	return hipcode == 2 /* hipErrorOutOfMemory */ ? LIS_ERR_OUT_OF_MEMORY : LIS_AMD_ERR_DEVICE;
 }
 
 void CHKERR(LIS_INT err)
@@ -275,6 +275,8 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_team_kernels = (r && r[0] == '1');
 		r = getenv("LIS_AMD_ROW_BLOCK_DOTS");         /* the fused dots of the dominant-pattern product as the row blocks' partial sums: every form's bits, slower */
 		lisg.row_block_dots = (r && r[0] == '1');
+		r = getenv("LIS_AMD_REFERENCE_LAYOUT");      /* products stream the reference's own arrays: no codes, patterns, value records, local columns, renumbering, row forms */
+		lisg.reference_layout = (r && r[0] == '1');
 		r = getenv("LIS_AMD_LONG_ROW_TREE");          /* opt-in: NOT the reference's bits for rows beyond the LDS stage */
 		lisg.long_row_tree = (r && r[0] == '1');
 		r = getenv("LIS_AMD_REFERENCE_REDUCTIONS");   /* T: every sum in the reference's order for OMP_NUM_THREADS = T (parity mode, slow) */

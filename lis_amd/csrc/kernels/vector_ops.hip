@@ -717,6 +717,31 @@ void csr_diagonal_kernel(int n, const int *__restrict__ ptr, const int *__restri
     d[r] = v;
 }
 
+// ELL: the first slot j with index[j*n + r] == r (padding carries index r and value 0 behind the row's entries: a row without a diagonal entry gets that 0),
+// lis_matrix_get_diagonal_ell, src/matrix/lis_matrix_ell.c.  Slot-major arrays: the lanes of a wavefront read consecutive addresses of every slot.
+__global__ __launch_bounds__(BLOCK)
+void ell_diagonal_kernel(int n, int maxnzr, const int *__restrict__ idx, const double *__restrict__ val, double *__restrict__ d)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    double v = 0.0;
+    for (int j = 0; j < maxnzr; j++)
+        if (idx[(size_t)j * n + r] == r) { v = val[(size_t)j * n + r]; break; }
+    d[r] = v;
+}
+
+// DIA: the stored diagonal with offset 0 (explicit zeros included), else 0: lis_matrix_get_diagonal_dia, src/matrix/lis_matrix_dia.c (one chunk: value[d*n + i])
+__global__ __launch_bounds__(BLOCK)
+void dia_diagonal_kernel(int n, int nnd, const int *__restrict__ offs, const double *__restrict__ val, double *__restrict__ d)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    double v = 0.0;
+    for (int j = 0; j < nnd; j++)
+        if (offs[j] == 0) { v = val[(size_t)j * n + r]; break; }
+    d[r] = v;
+}
+
 } // namespace
 
 // scratch: two ping-pong partial areas, each big enough for two results of a 2^31-element vector
@@ -1034,6 +1059,24 @@ extern "C" int liship_csr_diagonal_f64(int n, const int *ptr, const int *idx, co
     if (n < 0) return LISHIP_ERR_ARG;
     if (n == 0) return 0;
     csr_diagonal_kernel<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, as_stream(s)>>>(n, ptr, idx, val, d);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int liship_ell_diagonal_f64(int n, int maxnzr, const int *idx, const double *val, double *d, void *s)
+{
+    if (n < 0 || maxnzr < 0) return LISHIP_ERR_ARG;
+    if (n == 0) return 0;
+    ell_diagonal_kernel<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, as_stream(s)>>>(n, maxnzr, idx, val, d);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int liship_dia_diagonal_f64(int n, int nnd, const int *offs, const double *val, double *d, void *s)
+{
+    if (n < 0 || nnd < 0) return LISHIP_ERR_ARG;
+    if (n == 0) return 0;
+    dia_diagonal_kernel<<<(n + BLOCK - 1) / BLOCK, BLOCK, 0, as_stream(s)>>>(n, nnd, offs, val, d);
     LAUNCH_CHECK();
     return 0;
 }

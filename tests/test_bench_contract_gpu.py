@@ -1,4 +1,4 @@
-"""bench.py prints ONE JSON line with the fields the driver reads (small grid, seconds)."""
+"""bench.py prints ONE JSON line with the fields the driver reads (small grid, seconds), and the line leads with a figure that does SURVEY 8d's work."""
 import json
 import os
 import subprocess
@@ -6,10 +6,36 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASELINE = json.load(open(os.path.join(ROOT, "BASELINE.json")))
 
 
+def _fracs(node):
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if k == "frac":
+                yield v
+            else:
+                yield from _fracs(v)
+    elif isinstance(node, list):
+        for v in node:
+            yield from _fracs(v)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks under torch.distributed.run (the driver may launch N > 1 exactly like N = 1);
+    --launch-check stops behind the process group, so this runs without a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "callbacks", "--grid", "32", "--launch-check"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d == {"launch_check": True, "world": 2, "ranks": [[0, 0], [1, 1]], "self_launched": True}
+
+
+@pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--grid", "64",
                         "--preroll", "5", "--solver-iters", "20"], capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -24,75 +50,109 @@ def test_bench_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["unit"] == "GFLOP/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
+    n, nnz = d["config"]["n"], d["config"]["nnz"]
+    contract = 12 * nnz + 20 * n + 4
+
+    # the HEADLINE is the kernel that streams the reference's own arrays, priced on SURVEY 8d's bytes: frac <= 1 by construction and bytes / ms_per_step <= the peak
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # the roofline prices the bytes the TIMED kernel moves over its own HIP-event time: a physical fraction; the contract's count is beside it
-    assert 0 < r["frac"] <= 1.0 and abs(r["achieved"] - r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= (0.01 + 0.00006 / r["kernel_ms"]) * r["achieved"] + 0.1     # (kernel_ms is printed to 4 decimals: 1 % of a 4 us kernel)
-    assert r["contract_bytes_per_launch"] == 12 * d["config"]["nnz"] + 20 * d["config"]["n"] + 4 and r["contract_frac"] > 0 and "applies_to" in r
+    assert r["kernel"] == "spmv_csr_rowgather_kernel" and r["index_codes"] == r["row_patterns"] == r["value_records"] == r["marching"] == 0
+    assert r["bytes_per_launch"] == r["contract_bytes_per_launch"] == contract and 0 < r["frac"] <= 1.0 and r["frac"] == r["contract_frac"]
+    assert abs(r["achieved"] - contract / (r["kernel_ms"] * 1e-3) / 1e9) <= (0.01 + 0.00006 / r["kernel_ms"]) * r["achieved"] + 0.1     # (kernel_ms is printed to 4 decimals: 1 % of a 4 us kernel)
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.001
-    assert d["nontrivial_x"]["value"] > 0 and 0 < d["nontrivial_x"]["frac"] <= 1.0
-    vs = d["values_streamed"]
-    if r["value_records"]:
-        assert vs is not None and vs["roofline"]["value_records"] == 0 and 0 < vs["roofline"]["frac"] <= 1.0
-        assert vs["roofline"]["bytes_per_launch"] > r["bytes_per_launch"] and vs["nontrivial_x"]["value"] > 0
+    assert contract / (d["ms_per_step"] * 1e-3) <= 8e12
+    assert abs(d["value"] - 2.0 * nnz / (d["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * d["value"]
+    assert "lis_amd_set_reference_layout" in d["config"]["mode"] and r["xcd_strip_rows"] in (0, 64 * 64)
+    assert d["x_equals_one"]["value"] > 0 and 0 < d["x_equals_one"]["frac"] <= 1.0
 
-    # the contract form (round 5): the same matrix through the kernel that streams the reference's own index[] / value[] arrays, priced on SURVEY 8d's bytes
-    cf = d["contract_form"]
-    cr = cf["roofline"]
-    assert cf["kernel"] == cr["kernel"] == "spmv_csr_rowgather_kernel" and cr["index_codes"] == cr["row_patterns"] == cr["value_records"] == 0
-    assert cr["bytes_per_launch"] == cr["contract_bytes_per_launch"] == r["contract_bytes_per_launch"] and 0 < cr["frac"] <= 1.0 and cr["frac"] == cr["contract_frac"]
-    assert abs(cr["achieved"] - cr["bytes_per_launch"] / (cr["kernel_ms"] * 1e-3) / 1e9) <= (0.01 + 0.00006 / cr["kernel_ms"]) * cr["achieved"] + 0.1
-    assert cf["value"] > 0 and cf["nontrivial_x"]["value"] > 0 and 0 < cf["nontrivial_x"]["frac"] <= 1.0 and cf["xcd_strip_rows"] in (0, 64 * 64)
-    assert cf["cg_jacobi"]["iters_per_sec"] > 0 and cf["cg_jacobi"]["loop_bytes_per_iter"] > d["krylov"]["cg_jacobi"]["roofline"]["loop_bytes_per_iter"]
+    # the default form of this matrix sits beside it, labelled, priced on its own bytes
+    f = d["structured_fast_path"]
+    fr = f["roofline"]
+    assert f["kernel"] == fr["kernel"] and "applies_to" in f and 0 < fr["frac"] <= 1.0
+    assert fr["contract_bytes_per_launch"] == contract and fr["contract_frac"] > 0
+    if fr["value_records"]:
+        assert fr["bytes_per_launch"] < contract and "constant-coefficient" in f["applies_to"]
+        vs = f["values_streamed"]
+        assert vs["roofline"]["value_records"] == 0 and 0 < vs["roofline"]["frac"] <= 1.0 and vs["roofline"]["bytes_per_launch"] > fr["bytes_per_launch"]
+    assert f["x_equals_one"]["value"] > 0
 
-    def fracs(node):
-        if isinstance(node, dict):
-            for k, v in node.items():
-                if k == "frac":
-                    yield v
-                else:
-                    yield from fracs(v)
-    assert all(0 < f <= 1.0 for f in fracs(d))
+    assert all(0 < v <= 1.0 for v in _fracs(d))
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
-    assert d["preroll"] == 5 and d["degraded"] is False and d["rccl_ranks"] is None
-    for name in ("cg_jacobi", "bicgstab_none", "bicg_none", "gmres30_none"):
-        k = d["krylov"][name]
-        assert k["iters_per_sec"] > 0 and 0 < k["itime_s"] <= k["lis_solve_wall_s"] + 1e-3
-        assert abs(k["iters_per_sec"] - k["iters_timed"] / k["itime_s"]) < 0.01 * k["iters_per_sec"]     # iter / itime (lis_solver.c:902-908)
-        kr = k["roofline"]
-        assert 0 < kr["frac"] <= 1.0 and kr["loop_bytes_per_iter"] <= kr["contract_bytes_per_iter"]
+    assert d["preroll"] == 5 and d["degraded"] is False and d["rccl_ranks"] is None and d["self_launched"] is False
+    for group in (d["krylov"], f["krylov"]):
+        for name in ("cg_jacobi", "bicgstab_none", "bicg_none", "gmres30_none"):
+            k = group[name]
+            assert k["iters_per_sec"] > 0 and 0 < k["itime_s"] <= k["lis_solve_wall_s"] + 1e-3
+            assert abs(k["iters_per_sec"] - k["iters_timed"] / k["itime_s"]) < 0.01 * k["iters_per_sec"]     # iter / itime (lis_solver.c:902-908)
+            kr = k["roofline"]
+            assert 0 < kr["frac"] <= 1.0 and kr["loop_bytes_per_iter"] <= kr["contract_bytes_per_iter"]
+    assert d["krylov"]["cg_jacobi"]["roofline"]["loop_bytes_per_iter"] > f["krylov"]["cg_jacobi"]["roofline"]["loop_bytes_per_iter"]
+
+    # every BASELINE.json config has a driver-timed leg that carries its name
+    cfg = d["configs"]
+    assert sorted(cfg) == ["config1", "config2", "config3", "config4", "config5"]
+    assert [cfg[f"config{i + 1}"]["name"] for i in range(5)] == BASELINE["configs"]
+    for k, v in cfg.items():
+        assert "error" not in v, (k, v.get("error"))
+    c1 = cfg["config1"]
+    assert c1["n"] == 10000 and sorted(c1["formats"]) == ["BSR", "CSC", "CSR", "DIA", "ELL", "JAD"]
+    assert all(e["two_norm_is_sqrt2"] and e["mflops"] > 0 for e in c1["formats"].values())
+    c2 = cfg["config2"]
+    for mode in ("reference_layout", "default_form"):
+        e = c2[mode]
+        assert e["value"] > 0 and e["cg_jacobi"]["iters_per_sec"] > 0 and e["cg_jacobi"]["status"] == 0 and e["cg_jacobi"]["to_convergence"]
+    assert c2["reference_layout"]["kernel"] == "spmv_csr_rowgather_kernel" and 0 < c2["reference_layout"]["cg_jacobi"]["frac"] <= 1.0
+    assert c2["reference_layout"]["cg_jacobi"]["iter"] == c2["default_form"]["cg_jacobi"]["iter"] == 201     # 64^3: the reference's count
+    c3 = cfg["config3"]
+    assert c3["n_gpus"] == 1 and c3["reference_layout"]["iters_per_sec"] > 0 and c3["default_form"]["iters_per_sec"] > 0
+    c5 = cfg["config5"]["64^3"]
+    native, dflt = c5["native_kernels_reference_layout"], c5["default_forms"]
+    assert sorted(native) == sorted(dflt) == ["CSR", "DIA", "ELL"]
+    assert native["CSR"]["contract_bytes_per_launch"] == 12 * c5["nnz"] + 20 * c5["n"] + 4
+    assert native["ELL"]["contract_bytes_per_launch"] == 100 * c5["n"] and native["DIA"]["contract_bytes_per_launch"] == 72 * c5["n"]
+    assert native["ELL"]["kernel"] == "spmv_ell_kernel" and native["DIA"]["kernel"] == "spmv_dia_kernel"
+    assert native["ELL"]["device_layout"] == "ELL" and native["DIA"]["device_layout"] == "DIA"
+    for fmt in ("ELL", "DIA"):
+        assert native[fmt]["same_bits_as_csr"] and dflt[fmt]["same_bits_as_csr"]
+    for e in list(native.values()) + list(dflt.values()):
+        assert e["value"] > 0 and e["cg_jacobi"]["iter"] == 201 and e["cg_jacobi"]["status"] == 0
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_two_ranks_on_one_gpu(scaling):
-    """the N > 1 launch line of the driver with two ranks sharing this box's GPU (RCCL refuses that: --comm callbacks, a
-    bring-up run flagged degraded): partition, halo, the closed-form result check of the (stretched) grid, the collective
-    timing and the line's bookkeeping -- weak: 48^3 rows per rank on a 96 x 48 x 48 grid, strong: one 48^3 grid split"""
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling,launcher", [("weak", "torchrun"), ("strong", "torchrun"), ("weak", "self")])
+def test_bench_two_ranks_on_one_gpu(scaling, launcher):
+    """the N > 1 job with two ranks sharing this box's GPU (RCCL refuses that: --comm callbacks, a bring-up run flagged degraded): partition, halo, the
+    closed-form result check of the (stretched) grid, the collective timing and the line's bookkeeping -- weak: 48^3 rows per rank on a 96 x 48 x 48 grid,
+    strong: one 48^3 grid split.  launcher "torchrun": the driver's documented launch line; "self": plain `python bench.py --gpus 2`, which starts its own ranks."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-                        "--grid", "48", "--scaling", scaling, "--comm", "callbacks", "--preroll", "5", "--solver-iters", "20",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--grid", "48", "--scaling", scaling, "--comm", "callbacks",
+            "--preroll", "5", "--solver-iters", "20", "--no-cpu-baseline"]
+    head = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+            if launcher == "torchrun" else [sys.executable])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(head + tail, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 only
     d = json.loads(lines[0])
     planes = 96 if scaling == "weak" else 48
     n = planes * 48 * 48
-    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["degraded"] is True and d["rccl_ranks"] == 0
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["degraded"] is True and d["rccl_ranks"] == 0 and d["self_launched"] is (launcher == "self")
     assert d["config"]["n"] == n and d["config"]["nnz"] == 7 * n - 2 * (48 * 48 + 2 * planes * 48)
     assert ("per GPU" in d["config"]["workload"]) == (scaling == "weak")
     assert d["value"] > 0 and d["multi_gpu"] is not None and d["cpu_baseline"] is None
+    assert d["roofline"]["kernel"] == "spmv_csr_rowgather_kernel"
     m = d["multi_gpu"]
     assert m["halo_bytes_per_neighbour"] == 8 * 48 * 48 and m["halo_bytes_per_interior_rank_per_step"] == 2 * 8 * 48 * 48 and m["neighbours_of_rank0"] == 1
     assert m["halo_communicator"] is None and m["folds_per_iteration"]["cg_jacobi"] == 2           # (callbacks: no RCCL communicator of either kind)
     assert m["halo_ms_per_step"] > 0 and m["ms_per_step_no_overlap"] > 0
-    assert d["contract_form"]["kernel"] == "spmv_csr_rowgather_kernel" and d["contract_form"]["cg_jacobi"]["iters_per_sec"] > 0
-    for name in ("cg_jacobi", "bicgstab_none", "bicg_none", "gmres30_none"):
-        assert d["krylov"][name]["iters_per_sec"] > 0
+    assert d["configs"]["config3"]["n_gpus"] == 2 and d["configs"]["config3"]["name"] == BASELINE["configs"][2]
+    for group in (d["krylov"], d["structured_fast_path"]["krylov"]):
+        for name in ("cg_jacobi", "bicgstab_none", "bicg_none", "gmres30_none"):
+            assert group[name]["iters_per_sec"] > 0

@@ -1,6 +1,6 @@
 """A few products of the 512^3 (N^3) Poisson matrix through lis_matvec, exactly as bench.py sets them up -- the process rocprofv3 profiles when bench.py measures
 its `roofline.traffic` live (bench.py live_traffic):   python tools/traffic_child.py N form iters
-form: 1 the plan's own choice, 0 value records off (values streamed), 2 the contract form (index codes, row patterns and value records off: 4 B indices + 8 B values)"""
+form: 1 the plan's own choice, 0 value records off (values streamed), 2 the reference layout mode (lis_amd_set_reference_layout: 4 B indices + 8 B values streamed) on the non-trivial x"""
 import ctypes as C
 import os
 import sys
@@ -22,11 +22,20 @@ x, y = capi.PV(), capi.PV()
 for v in (x, y):
     assert lib.lis_vector_duplicate(C.cast(A, C.c_void_p), C.byref(v)) == 0
 assert lib.lis_vector_set_all(1.0, x) == 0
-if values != 1:
+if values == 0:
     check(lib.liship_spmv_csr_set_row_values(0))
 if values == 2:
-    check(lib.liship_spmv_csr_set_row_patterns(0))
-    check(lib.liship_spmv_csr_set_index_codes(0))
+    assert lib.dll.lis_amd_set_reference_layout(1) == 0       # the mode bench.py's headline runs in, applied to the plan already built -- as bench.py does
+x1 = x
+if values == 2:                                               # ... on the headline's non-trivial x
+    import numpy as np
+    x = capi.PV()
+    assert lib.lis_vector_duplicate(C.cast(A, C.c_void_p), C.byref(x)) == 0
+    n = N ** 3
+    for s0 in range(0, n, 1 << 24):
+        cnt = min(1 << 24, n - s0)
+        part = np.modf(np.arange(s0, s0 + cnt, dtype=np.float64) * 0.6180339887498949)[0] - 0.5
+        assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, s0, cnt, part.ctypes.data_as(capi.P_DBL), x) == 0
 for _ in range(iters):
     assert lib.lis_matvec(A, x, y) == 0
 lib.dll.lis_amd_synchronize()

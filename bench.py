@@ -526,7 +526,6 @@ def main():
     krylov = {}
     if not args.no_solvers:
         assert dll.lis_amd_vector_poisson3d_rhs(b, L, N, N) == 0
-        krylov = solve_rates(A, b, y, keys, args.solver_iters, n_local, nnz_local, (0, 0, 0))
     reference_layout(False)
 
     # =====================================================================================================================================
@@ -555,7 +554,12 @@ def main():
         finally:
             check(lib.liship_spmv_csr_set_row_values(1))
     if not args.no_solvers:
+        # (the default form first: the transposed copy BiCG needs is built once, with the default plan's column codes; the reference layout mode then switches
+        #  the codes of BOTH copies off at run time, exactly as it does for A itself)
         fast["krylov"] = solve_rates(A, b, y, keys, args.solver_iters, n_local, nnz_local, (coded, patterns, values))
+        reference_layout(True)
+        krylov = solve_rates(A, b, y, keys, args.solver_iters, n_local, nnz_local, (0, 0, 0))
+        reference_layout(False)
 
     configs = {}
     if not args.no_solvers:
@@ -576,7 +580,7 @@ def main():
                    "reference_layout": reference_layout, "solve_rates": solve_rates, "nrm": nrm, "steps": args.steps, "grid": N, "headline_matrix": A}
             configs["config1"] = config1_leg(ctx)
             configs["config2"] = config2_leg(ctx)
-            configs["config4"] = dict({"name": BASELINE_CONFIGS["config4"]}, **queen_class_leg(lib, np, C))
+            configs["config4"] = config4_leg(lib, np, C)
             configs["config5"] = config5_leg(ctx, sizes=(256, N) if N >= 256 else (N,))
 
     cpu = None
@@ -731,6 +735,8 @@ def format_legs(ctx, G, fmts, cg_iters, reference):
             assert lib.lis_solver_set_option(f"-maxiter {cg_iters or 3000}".encode(), S) == 0
             assert lib.lis_solve(M, b, sol, S) == 0
             it, itime = S.contents.iter, S.contents.itime
+            if cg_iters:
+                it = min(it, cg_iters)                    # (a solve that stops at maxiter reports maxiter + 1)
             cg = {"iters_per_sec": round(it / itime, 2) if itime > 0 else None, "iter": it, "itime_s": round(itime, 6), "status": S.contents.retcode, "rel_residual": S.contents.resid,
                   "to_convergence": cg_iters is None}
             if reference and itime > 0:
@@ -860,28 +866,46 @@ def stencil27_leg(lib, np, C, stream, G=256, launches=30):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
-def queen_class_leg(lib, np, C, reps=50):
-    """BASELINE config 4's stand-in (SuiteSparse Queen_4147 cannot be fetched: tests/golden/gen_queen_class.c writes a 3-dof mesh of its size -- 4.1 M rows, 2.9e8
-    non-zeros, node numbers scrambled inside runs of 1024 -- as a symmetric Matrix Market file) through lis_input, lis_matvec and lis_solve, as a Lis program would.
-    The plan finds no locality in the numbering and builds a renumbered form (liship_csr_plan_reorder): lis_solve iterates in that numbering, single products keep
-    the caller's (they would pay a gather and a scattered store each: timed beside, opt-in).  Host-clock ms per product over `reps` calls behind one synchronize; never fatal: an error string instead."""
-    path = None
+def config4_leg(lib, np, C, reps=50):
+    """BASELINE config 4 (SuiteSparse Queen_4147, irregular CSR with long rows, GMRES(30)) through lis_input, lis_matvec and lis_solve, as a Lis program would run it.
+    The file: LIS_AMD_BENCH_MTX=/path/to/file.mtx when somebody has one (Queen_4147.mtx itself, or any Matrix Market file), else the STAND-IN -- Queen_4147 cannot be
+    fetched here: tests/golden/gen_queen_class.c writes a 3-dof mesh of its size (4.1 M rows, 2.9e8 non-zeros, node numbers scrambled inside runs of 1024) as a symmetric
+    coordinate file on this box.  Reported: the reader, upload + plan, the product in the caller's numbering (contract_frac on 12 B per non-zero + 20 B per row; sha256 of
+    y for a check against any other implementation), GMRES(30) / BiCGSTAB / CG + Jacobi / BiCG with iterations, it/s and time to solution.  The renumbered form
+    (liship_csr_plan_reorder) is LAZY since round 6 -- none of these first solves triggers it; its cost (`reorder_s`, a host walk), its gain and the break-even
+    iteration count are measured beside them by asking for it explicitly.  Host-clock ms per product over `reps` calls behind one synchronize; never fatal: an error string instead."""
+    import hashlib
+    path, made = os.environ.get("LIS_AMD_BENCH_MTX"), False
     try:
-        import time
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
-        import queen_class
         from lis_amd import _capi as capi
         dll = lib.dll
-        t0 = time.time(); path, rows, stored = queen_class.generate("full"); t_gen = time.time() - t0
+        out = {"name": BASELINE_CONFIGS["config4"]}
+        if path:
+            out.update({"stand_in": False, "matrix": f"LIS_AMD_BENCH_MTX={path}, through lis_input"})
+        else:
+            import queen_class
+            t0 = time.time(); path, rows, stored = queen_class.generate("full"); made = True
+            out.update({"stand_in": True, "generate_s": round(time.time() - t0, 2),
+                        "matrix": "STAND-IN for Queen_4147 (not fetchable here; LIS_AMD_BENCH_MTX=/path/file.mtx runs a real file): tests/golden/gen_queen_class.c 111 1024 -- 3 unknowns per "
+                                  "node of a 111^3 grid, 27-node connectivity, scrambled numbering -- a symmetric .mtx through lis_input"})
         A, b, x0 = capi.PM(), capi.PV(), capi.PV()
         assert lib.lis_matrix_create(0, C.byref(A)) == 0 and lib.lis_vector_create(0, C.byref(b)) == 0 and lib.lis_vector_create(0, C.byref(x0)) == 0
-        t0 = time.time(); assert lib.lis_input(A, b, x0, path.encode()) == 0; t_read = time.time() - t0
-        os.unlink(path); path = None
+        dll.lis_amd_synchronize()
+        t0 = time.time(); assert lib.lis_input(A, b, x0, path.encode()) == 0; dll.lis_amd_synchronize(); t_read = time.time() - t0
+        if made:
+            os.unlink(path)
+        path = None
         n, nnz = A.contents.n, A.contents.nnz
         dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
         dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
-        t0 = time.time(); listed = int(dll.lis_amd_matrix_local_columns(A)); t_plan = time.time() - t0      # (uploads the matrix and builds the plan when lis_input did not)
-        reordered = int(dll.lis_amd_matrix_reordered(A))
+        dll.lis_amd_matrix_upload.argtypes = [capi.PM]
+        dll.lis_amd_set_reorder_after.argtypes = [C.c_longlong]
+        t0 = time.time(); assert dll.lis_amd_matrix_upload(A) == 0; dll.lis_amd_synchronize(); t_plan = time.time() - t0   # (zero when lis_input already uploaded and planned: resident mode does)
+        tot, asm = C.c_double(), C.c_double()
+        assert dll.lis_amd_last_input_times(C.byref(tot), C.byref(asm)) == 0
+        t_reader, t_plan = max(0.0, t_read - asm.value), t_plan + asm.value      # lis_input's assemble step IS the upload + plan in resident mode
+        listed = int(dll.lis_amd_matrix_local_columns(A))
         vx, vy, ones = capi.PV(), capi.PV(), capi.PV()
         for v in (vx, vy, ones):
             assert lib.lis_vector_duplicate(A, C.byref(v)) == 0
@@ -899,44 +923,66 @@ def queen_class_leg(lib, np, C, reps=50):
             dll.lis_amd_synchronize()
             return (time.time() - t0) / reps * 1e3
         ms = timed()
-        out = {"matrix": "tests/golden/gen_queen_class.c 111 1024 (3 unknowns per node of a 111^3 grid, 27-node connectivity, scrambled numbering), symmetric .mtx through lis_input",
-               "n": n, "nnz": nnz, "generate_s": round(t_gen, 2), "lis_input_s": round(t_read, 2), "plan_s": round(t_plan, 2),
-               "block_local_columns_listed": listed, "listed_after_reordering": reordered,
-               "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),
-               "contract_bytes": 12 * nnz + 20 * n, "contract_frac": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4),
-               "kernel": "spmv_csr_local_kernel", "numbering": "the caller's for single products; lis_solve iterates on P A P^T (renumbered: 1)" if reordered else "the caller's"}
-        if reordered:                       # opt-in (LIS_AMD_REORDER_PRODUCTS=1): single products through P A P^T too -- a gather of x and a scattered store of y per product
-            lib.liship_spmv_csr_set_reorder(2)
-            try:
-                out["spmv_ms_products_renumbered"] = round(timed(), 4)
-            finally:
-                lib.liship_spmv_csr_set_reorder(1)
+        yh = np.empty(n)
+        assert lib.lis_vector_get_values(vy, 0, n, yh.ctypes.data_as(capi.P_DBL)) == 0
+        out.update({"n": n, "nnz": nnz, "lis_input_s": round(t_read, 2), "reader_s": round(t_reader, 2), "upload_and_plan_s": round(t_plan, 3),
+                    "lis_input_note": "lis_input_s = reader_s (file read, parse, symmetric expansion, rows placed: host) + upload_and_plan_s (the HBM copy and its plan, inside lis_input's assemble step)",
+                    "block_local_columns_listed": listed, "kernel": "spmv_csr_local_kernel" if listed else "spmv_csr_rowgather_kernel / spmv_csr_products_kernel (the plan's choice)",
+                    "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),
+                    "contract_bytes": 12 * nnz + 20 * n, "contract_frac": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4),
+                    "x": "x_i = cos(0.01 i) + 1.25", "y_sha256": hashlib.sha256(yh.tobytes()).hexdigest(),
+                    "numbering": "the caller's (the renumbered form is lazy: lis_amd_set_reorder_after, default 10000 products)"})
         rhs = capi.PV()
         assert lib.lis_vector_duplicate(A, C.byref(rhs)) == 0 and lib.lis_matvec(A, ones, rhs) == 0          # b = A*1 (test/test1.c:138-139)
+        SOLVES = ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi", "-i bicg -p none")       # (BiCG: Lis's default solver, lis_solver.c:242)
+
+        def solve(opts):
+            S = capi.PS()
+            assert lib.lis_solver_create(C.byref(S)) == 0 and lib.lis_solver_set_option((opts + " -tol 1e-12 -maxiter 2000 -print none").encode(), S) == 0
+            assert lib.lis_vector_set_all(0.0, vy) == 0
+            dll.lis_amd_synchronize()
+            t0 = time.time()
+            assert lib.lis_solve(A, rhs, vy, S) == 0
+            dll.lis_amd_synchronize()
+            wall = time.time() - t0
+            r = {"iter": S.contents.iter, "status": S.contents.retcode, "rel_residual": S.contents.resid,
+                 "iters_per_sec": round(S.contents.iter / S.contents.itime, 1) if S.contents.itime > 0 else None,
+                 "time_to_solution_s": round(wall, 4), "renumbered": int(dll.lis_amd_last_solve_renumbered())}
+            lib.lis_solver_destroy(S)
+            return r
         out["solves"] = {}
-        for opts in ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi", "-i bicg -p none"):       # (BiCG: Lis's default solver, lis_solver.c:242)
-            first = None
-            for attempt in (0, 1):          # twice: the first solve that multiplies by A^T builds the transposed copy in HBM inside its itime (one-off per matrix; the reference pays none)
-                S = capi.PS()
-                assert lib.lis_solver_create(C.byref(S)) == 0 and lib.lis_solver_set_option((opts + " -tol 1e-12 -maxiter 2000 -print none").encode(), S) == 0
-                assert lib.lis_vector_set_all(0.0, vy) == 0
-                assert lib.lis_solve(A, rhs, vy, S) == 0
-                it, itime = S.contents.iter, S.contents.itime
-                rate = round(it / itime, 1) if itime > 0 else None
-                if attempt == 0:
-                    first = rate
-                else:
-                    out["solves"][opts] = {"iter": it, "status": S.contents.retcode, "rel_residual": S.contents.resid, "iters_per_sec": rate,
-                                           "first_solve_iters_per_sec": first, "renumbered": int(dll.lis_amd_last_solve_renumbered())}
-                lib.lis_solver_destroy(S)
+        for opts in SOLVES:
+            first = solve(opts)             # the FIRST solve of its kind pays the one-off costs (work-vector pool; BiCG: the transposed copy built in HBM): that is a program's time to solution
+            again = solve(opts)
+            again["first_solve_time_to_solution_s"] = first["time_to_solution_s"]
+            again["first_solve_iters_per_sec"] = first["iters_per_sec"]
+            out["solves"][opts] = again
+        # ---- the renumbered form, asked for explicitly: what it costs, what it gains, when it pays
+        dll.lis_amd_set_reorder_after(1)
+        try:
+            trig = solve("-i cg -p jacobi")                           # this solve builds P A P^T first (reorder_s = what that added to its time to solution) ...
+            reordered = int(dll.lis_amd_matrix_reordered(A))
+            ren = {"listed_after_reordering": reordered, "built": bool(reordered)}
+            if reordered:
+                base = out["solves"]["-i cg -p jacobi"]
+                ren["reorder_s"] = round(max(0.0, trig["time_to_solution_s"] - base["time_to_solution_s"]), 3)
+                ren["solves"] = {opts: solve(opts) for opts in SOLVES[:3]}     # ... and these iterate on it
+                gain = 1.0 / base["iters_per_sec"] - 1.0 / ren["solves"]["-i cg -p jacobi"]["iters_per_sec"]
+                ren["cg_jacobi_seconds_saved_per_iteration"] = round(gain, 7)
+                ren["break_even_iterations"] = int(ren["reorder_s"] / gain) if gain > 0 else None
+                ren["policy"] = ("lazy: the first lis_solve that finds 10000 products served by the plan builds it (lis_amd_set_reorder_after / LIS_AMD_REORDER_AFTER; 0 = at plan time); "
+                                 "single products always keep the caller's numbering")
+            out["renumbered_form"] = ren
+        finally:
+            dll.lis_amd_set_reorder_after(10000)
         for v in (vx, vy, ones, rhs, b, x0):
             lib.lis_vector_destroy(v)
         lib.lis_matrix_destroy(A)
         return out
     except Exception as exc:                                          # an extra: its failure must not cost the line
-        return {"error": f"{type(exc).__name__}: {exc}"}
+        return {"name": BASELINE_CONFIGS["config4"], "error": f"{type(exc).__name__}: {exc}"}
     finally:
-        if path and os.path.exists(path):
+        if made and path and os.path.exists(path):
             os.unlink(path)
 
 

@@ -161,6 +161,11 @@ LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A);
 /* total length of those lists in the REORDERED form, when the plan renumbered rows and columns because the caller's numbering has no locality (liship.h:
  * liship_csr_plan_reorder; one rank, CSR with long rows; env LIS_AMD_NO_REORDER=1 keeps the caller's numbering); 0 when it did not; uploads A if needed */
 long long lis_amd_matrix_reordered(LIS_MATRIX A);
+/* WHEN the renumbered form is built: by the first lis_solve that finds A's HBM copy has served `products` products in the caller's numbering (default 10000; env
+ * LIS_AMD_REORDER_AFTER).  The attempt is host work -- a Cuthill-McKee walk, +1.4 s and +3.5 GB of HBM on the Queen-class matrix -- that saves 0.1 ms per iteration there:
+ * a program earns it back after ~13 000 iterations, and the first solves of most programs take 40-50.  0: at plan time (upload / assemble), the round-5 behaviour. */
+LIS_INT lis_amd_set_reorder_after(long long products);
+long long lis_amd_matrix_products_served(LIS_MATRIX A);      /* products A's current HBM copy has served (approximately: a fused product + dot that falls back counts twice) */
 /* the liship plan of A's HBM copy when it is served as CSR rows (for the liship_csr_plan_* queries of liship.h; owned by A), else NULL; uploads A if needed */
 void *lis_amd_matrix_csr_plan(LIS_MATRIX A);
 /* adopt CSR arrays that already live in HBM (no host copy exists; A must be sized and unassembled).
@@ -173,6 +178,9 @@ LIS_INT lis_amd_matrix_set_csr_device(LIS_INT nnz, LIS_INT np, LIS_INT *dptr, LI
 LIS_INT lis_amd_matrix_poisson3d(LIS_MATRIX A, LIS_INT l, LIS_INT m, LIS_INT n, LIS_INT sorted);
 /* b = A*1 for that matrix in closed form (test/test3.c:150) */
 LIS_INT lis_amd_vector_poisson3d_rhs(LIS_VECTOR b, LIS_INT l, LIS_INT m, LIS_INT n);
+
+/* seconds of the last lis_input: the whole call, and its lis_matrix_assemble step alone -- for a matrix that lives in HBM that step is the upload and the plan */
+LIS_INT lis_amd_last_input_times(double *total_s, double *assemble_upload_plan_s);
 
 /* stream all library work is queued on (hipStream_t as void*), and a full device sync */
 void   *lis_amd_stream(void);

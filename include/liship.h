@@ -213,9 +213,10 @@ int  liship_spmv_csr_set_local_register_positions(int on);
 int  liship_csr_plan_scan_band(liship_csr_plan_t plan, const int *ptr, const int *index, void *stream);
 int  liship_csr_plan_strip_rows(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_xcd_strips(int on);
-/* Opt-in, off by default, NOT bit-identical to the reference: the part of a row beyond the LDS stage (~2100 entries) is added
+/* On by default (round 6), NOT bit-identical to the reference for the rows it touches: the part of a row beyond the LDS stage (~2100 entries) is added
  * by a workgroup-wide tree per pass instead of one left-to-right chain (a 200 000-entry row is otherwise a 200 000-long
- * dependent add chain, by the parity contract).  Deterministic; rows that fit the stage keep the reference's bits. */
+ * dependent add chain).  Deterministic, within 1e-14 of the row's magnitude; rows that fit the stage keep the reference's bits.
+ * 0 = the chain: the reference's bits for every row (LIS_AMD_LONG_ROW_CHAIN=1; implied by the reference-order reductions mode). */
 int  liship_spmv_csr_set_long_row_tree(int on);
 int  liship_spmv_csr_set_row_block_dots(int on);  /* 1: fused dots of the dominant-pattern product as the row blocks' partial sums (the other forms' bits); LIS_AMD_ROW_BLOCK_DOTS=1 */
 int  liship_spmv_csr_switches(void);            /* bit 0 team kernels on, bit 1 row-block dots, bit 2 long-row tree (tests of the LIS_AMD_* variables) */
@@ -461,6 +462,10 @@ int  liship_dot2_f64(int n, const double *x, const double *y, double *result, vo
  * src/matrix/lis_matrix_csr.c:547-558 */
 int  liship_csr_diagonal_f64(int n, const int *ptr, const int *index, const double *value,
                              double *d, void *stream);
+/* XCD strips of the native ELL / DIA kernels (round 6): rows per plane of the structured grid the next whole-matrix ELL / DIA launches work on -- every XCD then takes
+ * one eighth of every plane and walks the planes in order, so the +-plane neighbours of a row are in its own L2 (the CSR kernels learn their plane at plan time:
+ * liship_csr_plan_strip_rows).  0: the natural workgroup order.  An order of the workgroups only: the bits cannot depend on it. */
+int  liship_spmv_formats_set_plane(int rows);
 /* the same for the native ELL arrays (first slot whose index is the row; padding gives 0: src/matrix/lis_matrix_ell.c lis_matrix_get_diagonal_ell) and the
  * native DIA arrays (the stored diagonal of offset 0, one chunk value[d*n + i]: src/matrix/lis_matrix_dia.c lis_matrix_get_diagonal_dia) */
 int  liship_ell_diagonal_f64(int n, int maxnzr, const int *index, const double *value, double *d, void *stream);

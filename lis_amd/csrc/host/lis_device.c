@@ -54,7 +54,7 @@ LIS_INT lisd_init(void)
 	HIPCHK(lisd_malloc(&lisg.reduce_work, liship_reduce_work_bytes()));
 	HIPCHK(lisd_malloc((void **)&lisg.reduce_out, 4 * sizeof(double)));
 	HIPCHK(liship_malloc_host((void **)&lisg.host_out, 4 * 64 * sizeof(double)));
-	if (lisg.long_row_tree) HIPCHK(liship_spmv_csr_set_long_row_tree(1));
+	HIPCHK(liship_spmv_csr_set_long_row_tree((lisg.long_row_chain || lisg.ref_reductions) ? 0 : 1));     /* parity modes take the chain */
 	if (lisg.reference_layout) LISCHK(lis_amd_set_reference_layout(1));
 	if (lisg.no_team_kernels) { HIPCHK(liship_spmv_csr_set_team(0)); HIPCHK(liship_spmv_bsr_set_team(0)); }
 	if (lisg.no_marching) HIPCHK(liship_spmv_csr_set_dom_march(0));
@@ -158,6 +158,8 @@ LIS_INT lis_amd_set_reference_reductions(LIS_INT T)
 {
 	if (T < 0 || liship_set_reference_reductions((int)T) != 0) return LISI_ERR(LIS_ERR_ILL_ARG, "reference-order reductions: T(=%D) out of range\n", T);
 	lisg.ref_reductions = (int)T;
+	/* the parity mode wants the reference's bits everywhere: hub rows go back to the left-to-right chain while it is on */
+	if (lisg.device_ready) HIPCHK(liship_spmv_csr_set_long_row_tree((lisg.long_row_chain || T > 0) ? 0 : 1));
 	return LIS_SUCCESS;
 }
 LIS_INT lis_amd_get_reference_reductions(void) { return lisg.ref_reductions; }
@@ -452,6 +454,37 @@ static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, const int *dptr, co
 LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue) { return csr_plan_impl(plan, n, dptr, dindex, dvalue, 1); }
 /* ... of a matrix no solve iterates on (a transposed copy, a scaled copy, the halves of a split JAD matrix): no renumbered form (products would not use it) */
 LIS_INT lisd_csr_plan_plain(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue) { return csr_plan_impl(plan, n, dptr, dindex, dvalue, 0); }
+/* the renumbered form of a plan (liship_csr_plan_reorder: never an error when the matrix does not qualify; out of memory leaves the plan as it was) */
+static LIS_INT plan_try_reorder(liship_csr_plan_t plan, int n, const int *dptr, const int *dindex, const double *dvalue)
+{
+	long long pnnz = 0;
+	(void)liship_csr_plan_info(plan, NULL, &pnnz, NULL);
+	const int *hint = (renum_cache.perm && renum_cache.n == n && renum_cache.nnz == pnnz) ? renum_cache.perm : NULL;      /* the last walk, when the sizes match (a matrix whose values were edited; any other matrix drops it for a walk of its own) */
+	int rc = liship_csr_plan_reorder_with(plan, dptr, dindex, dvalue, 0, hint, lisg.stream);
+	if (rc && rc != 2) HIPCHK(rc);
+	if (!rc && liship_csr_plan_reordered(plan) > 0 && !hint) {
+		int *keep = (int *)malloc(sizeof(int) * (size_t)n);
+		if (keep && liship_csr_plan_reorder_permutation(plan, keep) == 0) {
+			free(renum_cache.perm);
+			renum_cache.perm = keep; renum_cache.n = n; renum_cache.nnz = pnnz;
+		} else free(keep);
+	}
+	return LIS_SUCCESS;
+}
+/* LAZY renumbering (round 6): called by lis_solve before it looks for a renumbered form.  A CSR copy on one rank whose plan has served lisg.reorder_after products
+ * in the caller's numbering gets the attempt once; what the attempt costs (the Cuthill-McKee walk on the host, P A P^T in HBM: +1.4 s and +3.5 GB on the
+ * Queen-class matrix) is paid by a program that has shown it iterates long enough to earn it back (0.1 ms per iteration there), never by the first solves. */
+LIS_INT lisd_mat_lazy_reorder(LIS_MATRIX A)
+{
+	lisd_mat *d = MDEV(A);
+	if (lisg.no_reorder || lisg.nprocs != 1 || lisg.reorder_after <= 0 || !d->ready || d->reorder_tried || d->served < lisg.reorder_after) return LIS_SUCCESS;
+	if (d->type != LIS_MATRIX_CSR || !d->plan || !d->value || d->split_jad || d->solve_holds || A->is_scaled || A->is_splited || A->np != A->n || d->n != A->n) return LIS_SUCCESS;
+	d->reorder_tried = 1;
+	return plan_try_reorder(d->plan, d->n, d->ptr, d->index, d->value);
+}
+LIS_INT lis_amd_set_reorder_after(long long products) { lisg.reorder_after = products < 0 ? 0 : products; return LIS_SUCCESS; }
+long long lis_amd_matrix_products_served(LIS_MATRIX A) { return MDEV(A)->served; }
+
 static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue, int reorder)
 {
 	int rc = liship_csr_plan_create(plan, n, dptr, lisg.stream);
@@ -475,21 +508,11 @@ static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, const int *dptr, co
 		rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
 		if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
 		if (rc && rc != 2) HIPCHK(rc);
-		/* lists that stay long say the numbering has no locality: rows and columns renumbered inside the plan (one rank: its row ranges follow the original order) */
-		if (!rc && reorder && !lisg.no_reorder && lisg.nprocs == 1 && dvalue) {
-			long long pnnz = 0;
-			(void)liship_csr_plan_info(*plan, NULL, &pnnz, NULL);
-			const int *hint = (renum_cache.perm && renum_cache.n == n && renum_cache.nnz == pnnz) ? renum_cache.perm : NULL;      /* the last walk, when the sizes match (a matrix whose values were edited; any other matrix drops it for a walk of its own) */
-			rc = liship_csr_plan_reorder_with(*plan, dptr, dindex, dvalue, 0, hint, lisg.stream);
-			if (rc && rc != 2) HIPCHK(rc);
-			if (!rc && liship_csr_plan_reordered(*plan) > 0 && !hint) {
-				int *keep = (int *)malloc(sizeof(int) * (size_t)n);
-				if (keep && liship_csr_plan_reorder_permutation(*plan, keep) == 0) {
-					free(renum_cache.perm);
-					renum_cache.perm = keep; renum_cache.n = n; renum_cache.nnz = pnnz;
-				} else free(keep);
-			}
-		}
+		/* lists that stay long say the numbering has no locality: rows and columns renumbered inside the plan (one rank: its row ranges follow the original order).
+		 * At plan time only when asked (LIS_AMD_REORDER_AFTER=0); by default the plan first serves lisg.reorder_after products in the caller's numbering
+		 * (lisd_mat_lazy_reorder): the walk is host work worth ~13 000 iterations of what it saves per iteration on the Queen-class matrix, and the solves
+		 * people time first take 40-50 */
+		if (!rc && reorder && !lisg.no_reorder && lisg.nprocs == 1 && dvalue && lisg.reorder_after == 0) LISCHK(plan_try_reorder(*plan, n, dptr, dindex, dvalue));
 	}
 	/* a plan that streams index[] / codes (no row patterns): the plane of a structured grid from the band of the matrix, for the XCD strips */
 	rc = liship_csr_plan_scan_band(*plan, dptr, dindex, lisg.stream);
@@ -1288,6 +1311,7 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 {
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_mat_ready(A));
+	d->served++;
 	if (lisg.nprocs > 1 && A->commtable && d->type == LIS_MATRIX_CSR && !lisg.no_overlap &&
 	    d->inner_end - d->inner_begin >= d->n / 2) {
 		/* rows [inner_begin, inner_end) reference no ghost column: they run while the halo is in flight; the
@@ -1373,6 +1397,7 @@ LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const doub
 {
 	lisd_mat *d = MDEV(A);
 	LISCHK(lisd_mat_ready(A));
+	d->served++;                          /* (a branch below that falls back to lisd_spmv counts the product twice: the count is a threshold, not a statistic) */
 	int nblocks = 0;
 	if (d->split_jad) {
 		LISCHK(lisd_spmv(A, dx, dy));

@@ -55,6 +55,8 @@ typedef struct {
 	int checked;               /* LIS_AMD_MATRIX_CHECK=1: host_hash holds the hash of the host arrays the copy was built from */
 	unsigned long long host_hash;
 	int device_only;           /* arrays were adopted from the caller; no host copy exists */
+	long long served;          /* products this HBM copy has served (lisd_spmv and the fused product + dot): the lazy renumbering waits for lisg.reorder_after of them */
+	int reorder_tried;         /* the renumbered form was built, or found not worth building, for this copy */
 	int type;                  /* kernel family actually used (CSC is served as transposed CSR) */
 	int n, np, nnz;
 	int maxnzr, nnd, nr, nc, bnr, bnc;
@@ -118,7 +120,7 @@ typedef struct {
 	void *comm_stream;         /* second HIP stream: halo send/recv overlapped with the interior rows */
 	void *ev_packed, *ev_landed;
 	int reference_layout;      /* LIS_AMD_REFERENCE_LAYOUT=1 / lis_amd_set_reference_layout(1): products stream the reference's own arrays (lis_device.c) */
-	int long_row_tree;         /* LIS_AMD_LONG_ROW_TREE=1: rows longer than the LDS stage are added by a tree per pass (not bit-parity; opt-in) */
+	int long_row_chain;        /* LIS_AMD_LONG_ROW_CHAIN=1: the part of a row beyond the LDS stage is ONE left-to-right chain (the reference's bits) instead of the default workgroup tree */
 	int no_value_records;      /* LIS_AMD_NO_VALUE_RECORDS=1: matrices whose rows repeat with their values keep streaming the values (A/B measurements) */
 	int eager_coherence;       /* LIS_AMD_COHERENCE=eager / lis_amd_set_coherence(0): COHERENT copies on every call instead of following page faults (lis_pages.c) */
 	int no_device_convert;     /* LIS_AMD_NO_DEVICE_CONVERT=1: lis_matrix_convert always works on the host arrays (A/B, tests of the host routines) */
@@ -132,6 +134,8 @@ typedef struct {
 	int row_block_dots;        /* LIS_AMD_ROW_BLOCK_DOTS=1: fused dots of the dominant-pattern product as the row blocks' partial sums */
 	int no_marching;           /* LIS_AMD_NO_MARCHING=1: 7-point matrices with value records keep the gathering dominant-pattern kernel (round 3's headline kernel: A/B measurements) */
 	int no_team_kernels;       /* LIS_AMD_NO_TEAM_KERNELS=1: patterned rows of 8..32 entries and long BSR block rows keep the round-2 kernels (A/B measurements) */
+	double last_input_s, last_input_assemble_s;      /* lis_amd_last_input_times */
+	long long reorder_after;   /* LIS_AMD_REORDER_AFTER=K: the renumbered form of a plan is built by the first lis_solve that finds K products served (default 10000; 0: at plan time) */
 	int no_reorder;            /* LIS_AMD_NO_REORDER=1: long-row CSR plans keep the caller's numbering whatever their lists look like (A/B measurements) */
 	int no_local_columns;      /* LIS_AMD_NO_LOCAL_COLUMNS=1: long-row CSR products keep the 4 B column indices (A/B measurements) */
 	int no_index_codes;        /* LIS_AMD_NO_INDEX_CODES=1: CSR products keep reading the 4 B column indices (A/B measurements) */
@@ -210,6 +214,7 @@ LIS_INT lisc_matrix_g2l(LIS_MATRIX A);                        /* global -> local
 LIS_INT lisc_commtable_create(LIS_MATRIX A);
 void    lisc_commtable_destroy(LIS_COMMTABLE t);
 LIS_INT lisc_reduce_device(LIS_MATRIX A, double *dy);         /* dy[export rows] += neighbours' dy[n..np) */
+LIS_INT lisd_mat_lazy_reorder(LIS_MATRIX A);                  /* the renumbered form of A's plan once it has served lisg.reorder_after products (lis_solve) */
 LIS_INT lisc_halo_begin(LIS_MATRIX A, double *dx);            /* pack + start the exchange (second stream) */
 LIS_INT lisc_halo_end(LIS_MATRIX A, double *dx);              /* ghosts of dx are valid for work queued after this */
 LIS_INT lisc_halo_device(LIS_MATRIX A, double *dx);           /* fill dx[n..np) from the neighbours */

@@ -385,7 +385,11 @@ static LIS_INT mm_read_csr(slurp_t *s, const mm_head *h, LIS_MATRIX A, LIS_VECTO
 	err = lis_matrix_set_csr(lnnz, ptr, index, value, A);
 	if (err) goto fail;
 	ptr = NULL; index = NULL; value = NULL;          /* adopted */
-	LISCHK(lis_matrix_assemble(A));
+	{	/* the assemble step is also where a resident / lazily coherent matrix gets its HBM copy and its plan (lisd_mat_eager): timed apart from the reader */
+		const double ta = lis_wtime();
+		LISCHK(lis_matrix_assemble(A));
+		lisg.last_input_assemble_s = lis_wtime() - ta;
+	}
 	io_mark("assembled");
 	if (b != NULL && x != NULL) {
 		if (h->isb) LISCHK(mm_read_vec(s, h, A, b));
@@ -568,6 +572,8 @@ LIS_INT lis_input(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, char *filename)
 	}
 	if (filename == NULL) return LISI_ERR(LIS_ERR_ILL_ARG, "filname is NULL\n");
 	slurp_t s;
+	const double t_in = lis_wtime();
+	lisg.last_input_assemble_s = 0.0; lisg.last_input_s = 0.0;
 	LISCHK(slurp_file(filename, &s));
 	LIS_INT err;
 	if (s.len == 0) { free(s.buf); return LIS_ERR_FILE_IO; }
@@ -587,7 +593,16 @@ LIS_INT lis_input(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, char *filename)
 	if (!err) err = h.coordinate ? mm_read_csr(&s, &h, A, b, x) : mm_read_dense(&s, &h, A);
 	free(s.buf);
 	if (err) return err;
-	return lisi_matrix_retype(A, want, 0);
+	err = lisi_matrix_retype(A, want, 0);
+	lisg.last_input_s = lis_wtime() - t_in;
+	return err;
+}
+/* seconds of the last lis_input: the whole call, and the part of it spent in lis_matrix_assemble -- which, for a matrix that lives in HBM, is the upload and the plan */
+LIS_INT lis_amd_last_input_times(double *total_s, double *assemble_upload_plan_s)
+{
+	if (total_s) *total_s = lisg.last_input_s;
+	if (assemble_upload_plan_s) *assemble_upload_plan_s = lisg.last_input_assemble_s;
+	return LIS_SUCCESS;
 }
 
 LIS_INT lis_input_matrix(LIS_MATRIX A, char *filename) { return lis_input(A, NULL, NULL, filename); }

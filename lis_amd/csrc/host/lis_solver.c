@@ -1117,6 +1117,8 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		const double *rv = NULL;
 		/* A^T x: the HBM copy is transposed in HBM (lis_matvech.c) -- of an unsplit CSR matrix, that is P A P^T's while it is swapped in; it gets a set of fields of its own */
 		const int t_ok = !needs_t || (Awork->matrix_type == LIS_MATRIX_CSR && !Awork->is_splited);
+		/* the renumbered form is built LAZILY: by the first solve that finds the plan has served lisg.reorder_after products (lis_device.c) */
+		if (lisg.nprocs == 1 && !scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && t_ok) { if ((err = lisd_mat_lazy_reorder(Awork))) goto out; }
 		if (lisg.nprocs == 1 && !scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && t_ok && dm->type == LIS_MATRIX_CSR && !dm->split_jad &&
 		    dm->plan && Awork->np == Awork->n && dm->n == Awork->n && liship_csr_plan_reordered_form(dm->plan, &in, &rp, &ri, &rv, &renum) == 0) {
 			held_plan = dm->plan; held_ptr = dm->ptr; held_index = dm->index; held_value = dm->value;

@@ -267,6 +267,9 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.no_local_columns = (r && r[0] == '1');
 		r = getenv("LIS_AMD_NO_REORDER");
 		lisg.no_reorder = (r && r[0] == '1');
+		r = getenv("LIS_AMD_REORDER_AFTER");           /* products a plan serves before a lis_solve builds its renumbered form (0: at plan time, the round-5 behaviour) */
+		lisg.reorder_after = r ? atoll(r) : 10000;
+		if (lisg.reorder_after < 0) lisg.reorder_after = 0;
 		r = getenv("LIS_AMD_REORDER_PRODUCTS");        /* single products of renumbered long-row plans take the renumbered form too (gather of x, scattered store of y): opt-in */
 		if (r && r[0] == '1') (void)liship_spmv_csr_set_reorder(2);
 		r = getenv("LIS_AMD_NO_MARCHING");
@@ -277,8 +280,10 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.row_block_dots = (r && r[0] == '1');
 		r = getenv("LIS_AMD_REFERENCE_LAYOUT");      /* products stream the reference's own arrays: no codes, patterns, value records, local columns, renumbering, row forms */
 		lisg.reference_layout = (r && r[0] == '1');
-		r = getenv("LIS_AMD_LONG_ROW_TREE");          /* opt-in: NOT the reference's bits for rows beyond the LDS stage */
-		lisg.long_row_tree = (r && r[0] == '1');
+		r = getenv("LIS_AMD_LONG_ROW_CHAIN");         /* the part of a row beyond the LDS stage as ONE left-to-right chain: the reference's bits for hub rows, slow on them */
+		lisg.long_row_chain = (r && r[0] == '1');
+		r = getenv("LIS_AMD_LONG_ROW_TREE");          /* (rounds 4-5 spelling: the tree was opt-in then; =0 still selects the chain) */
+		if (r && r[0] == '0') lisg.long_row_chain = 1;
 		r = getenv("LIS_AMD_REFERENCE_REDUCTIONS");   /* T: every sum in the reference's order for OMP_NUM_THREADS = T (parity mode, slow) */
 		lisg.ref_reductions = (r && atoi(r) > 0) ? atoi(r) : 0;
 		if (lisg.device_ready) (void)liship_set_reference_reductions(lisg.ref_reductions);      /* (a second lis_initialize in one process) */
@@ -288,7 +293,7 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		lisg.host_scalars = (r && r[0] == '1');
 		/* RESIDENT, and COHERENT by page protection (which runs at resident speed, so it starts like RESIDENT): the runtime comes up here (quietly: a box
 		 * without a GPU still serves the host-side API), and matrices are uploaded where they are made (lisd_mat_eager).  BEHIND the switches above: the
-		 * device's start-up applies some of them (LIS_AMD_NO_TEAM_KERNELS, LIS_AMD_ROW_BLOCK_DOTS, LIS_AMD_LONG_ROW_TREE) */
+		 * device's start-up applies some of them (LIS_AMD_NO_TEAM_KERNELS, LIS_AMD_ROW_BLOCK_DOTS, LIS_AMD_LONG_ROW_CHAIN) */
 		if (lisg.residency == LIS_AMD_RESIDENT || (lisg.residency == LIS_AMD_COHERENT && !lisg.eager_coherence)) (void)lisd_init_quiet();
 	}
 	return LIS_SUCCESS;

@@ -45,7 +45,7 @@ int g_local_cols = 1;            // liship_spmv_csr_set_local_columns: 0 keeps t
 int g_xcd_strips = 1;            // liship_spmv_csr_set_xcd_strips: 0 keeps the row blocks of the 7-offset pattern kernel in their natural (round-robin over the XCDs) order
 int g_local_rpos = 1;            // liship_spmv_csr_set_local_register_positions: 0 = plans built from now on take the round-3 form (4096-item blocks, positions through LDS)
 int g_uniform_rows = 1;          // liship_spmv_csr_set_uniform_rows: 0 keeps the row sums of the block-local kernel on the skewed schedule everywhere (A/B)
-int g_long_row_tree_host = 0;    // host mirror of d_long_row_tree (liship_spmv_csr_switches)
+int g_long_row_tree_host = 1;    // host mirror of d_long_row_tree (liship_spmv_csr_switches); round 6: the tree is the default
 int g_row_block_dots = 0;        // liship_spmv_csr_set_row_block_dots: 1 keeps the fused dots of the dominant-pattern product on the row blocks' partial sums (the bits every other form gives)
 int g_dom_march = 1;             // liship_spmv_csr_set_dom_march: 0 keeps 7-point plans with value records on the gathering dominant-pattern kernel (A/B)
 int g_block_rows = 1;            // liship_spmv_csr_set_block_rows: 0 keeps plans with block rows (liship_csr_plan_encode_block_rows) on the row-by-row kernels (A/B); 2: plans of any size take them (tests)
@@ -55,7 +55,7 @@ int g_reorder = 1;               // liship_spmv_csr_set_reorder: 1 (default) = t
                                  // the caller's numbering; 2 = whole-matrix products of long-row plans take it too (gather of x, scattered store of y); 0 = nobody is served (A/B; the same bits)
 int g_team = 1;                  // liship_spmv_csr_set_team: 0 keeps patterned rows of 8..32 entries on the one-lane-per-row pattern kernel
 
-__device__ int d_long_row_tree = 0;   // liship_spmv_csr_set_long_row_tree
+__device__ int d_long_row_tree = 1;   // liship_spmv_csr_set_long_row_tree (default: the tree; 0: the reference's left-to-right chain)
 
 struct Blk { int r0, k0, r1, k1; };
 // the row range of a launch and the value every row sum starts from: +0.0 as the reference's `t0 = 0.0`, or -0.0 for the
@@ -374,13 +374,13 @@ __device__ __forceinline__ double ordered_sum_rows(double acc, const double *buf
 // one whole row block of any shape (many empty rows, rows longer than the LDS stage).
 // Invariant from the plan: every row but the last ends inside the first pass of CAP products.
 // ------------------------------------------------------------------------------ long rows in tree mode: the tail over many workgroups
-// (LIS_AMD_LONG_ROW_TREE=1 only.)  One workgroup folding a 200 000-entry row is ~100 dependent rounds of memory latency: the heavy-tailed stress matrix ran at 0.78 ms with the
+// (The default since round 6; LIS_AMD_LONG_ROW_CHAIN=1 / liship_spmv_csr_set_long_row_tree(0) switch it off.)  One workgroup folding a 200 000-entry row is ~100 dependent rounds of memory latency: the heavy-tailed stress matrix ran at 0.78 ms with the
 // workgroup tree where its bytes are worth 0.09 ms.  So the part of a row block beyond its first TAIL_FROM entries -- always the tail of its last row -- is cut into chunks of
 // TAIL_CHUNK entries (the plan lists them: build_split), a workgroup per chunk adds its products (lane sums, wavefront butterfly, wavefronts in order: a fixed order),
 // spmv_csr_tail_fold_kernel adds a block's chunk sums in chunk order and leaves the total in y[that row], and block_by_products -- which every kernel reaches for such a
 // block -- adds it to the head of the row it has summed itself.  Both passes run in front of every launch of a plan that has such blocks (tail_prepass, spmv_csr.hip) with
 // the launch's own row range, so they see the block as the product's kernel will.
-constexpr int TAIL_FROM = 16384, TAIL_CHUNK = 8192;
+constexpr int TAIL_FROM = 16384, TAIL_CHUNK = 8192, TREE_MIN = 1024;
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK)
 void spmv_csr_tail_chunks_kernel(const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val, const double *__restrict__ x,
@@ -447,7 +447,10 @@ __device__ __forceinline__ void block_by_products(double *prod, const int *__res
     if (k1 > kfirst) {                                          // uniform: finish the long last row
         const int rl = r1 - 1;
         const int owner = (rl - r0) % BLOCK;
-        const bool tree = d_long_row_tree != 0;                 // opt-in (liship_spmv_csr_set_long_row_tree): NOT the reference's bits
+        // the tree (the default: liship_spmv_csr_set_long_row_tree) only where there is a chain worth cutting: at least TREE_MIN entries beyond the first pass.  A row
+        // block's last row may straddle the end of the stage whatever its length (81-entry FEM rows in the block-local kernel's blocks do): those few dozen entries stay
+        // on the ordered chain, so every row SHORTER than TREE_MIN entries keeps the reference's bits in every kernel, tree or not
+        const bool tree = d_long_row_tree != 0 && k1 - kfirst >= TREE_MIN;
         __shared__ double tree_scratch[BLOCK / WAVE];
         int base = kfirst;
         if (tree) {

@@ -291,9 +291,11 @@ static void build_dominant(liship_csr_plan_s *p, int npat, const int *rec32, con
 
 extern "C" int liship_spmv_csr_set_variant(int variant) { g_variant = variant; return 0; }
 extern "C" int liship_spmv_csr_set_index_codes(int on) { g_index_codes = on ? 1 : 0; return 0; }
-// Opt-in, off by default: the part of a row that does not fit the LDS stage (beyond ~2100 entries) is added by a workgroup-wide
+// On by default (round 6; it was opt-in before): the part of a row that does not fit the LDS stage (beyond ~2100 entries) is added by a workgroup-wide
 // tree per pass instead of one strictly ordered chain.  Deterministic, but NOT bit-identical to the reference's left-to-right
-// sum (differences of a few ulp of the row's magnitude); for heavy-tailed matrices where a single row is 10^5 entries long.
+// sum (within 1e-14 of the row's magnitude; north_star's bar for floating point is a tolerance, and the dots are trees already): a single row of 10^5 entries
+// is a 10^5-long dependent add chain otherwise (5.5 ns a term: 7 % of the roofline on the heavy-tailed stress matrix).  0 restores the chain and with it the
+// reference's bits for those rows (LIS_AMD_LONG_ROW_CHAIN=1; the reference-order reductions mode implies it).
 extern "C" int liship_spmv_csr_set_long_row_tree(int on)
 {
     const int v = on ? 1 : 0;

@@ -13,19 +13,35 @@ namespace {
 
 constexpr int BLOCK = 256;
 
+// XCD strips for the native ELL / DIA kernels (round 6; csr_kernels.hpp xcd_strip_unit is the same permutation): workgroup w runs on XCD w % 8.  With `plane`
+// workgroups per grid plane (a multiple of 8) every XCD takes one eighth of every plane and walks the planes in order, so the +-plane neighbours of its rows are
+// rows it multiplied itself two strips earlier: x crosses the fabric once instead of once per XCD that touches it.  A permutation of the launch's workgroups:
+// rows are independent, the bits cannot depend on it (the fused dots publish their partial under the PERMUTED index, so their fold order is the natural one too).
+int g_fmt_plane_rows = 0;           // liship_spmv_formats_set_plane: rows per plane for launches that are not told (0: natural order)
+__device__ __forceinline__ int fmt_strip_unit(int w, int n, int plane)
+{
+    if (plane <= 0) return w;
+    const int full = (n / plane) * plane;
+    if (w >= full) return w;
+    const int sb = plane >> 3, xcd = w & 7, slot = w >> 3;
+    const int pl = slot / sb;
+    return pl * plane + xcd * sb + (slot - pl * sb);
+}
+
 // ELL: lane owns ROWS consecutive rows (2 when n is even: 16 B value / 8 B index loads), UNROLL jagged columns
 // in flight before the first use; column-major storage makes every load of a wavefront contiguous.
 // lane partials of the fused reductions <w,y> (DOT >= 1) and <y,y> (DOT == 2) -> one value per workgroup
 template <int DOT>
-__device__ __forceinline__ void publish(double c0, double c1, double *__restrict__ partial, int stride)
+__device__ __forceinline__ void publish(double c0, double c1, double *__restrict__ partial, int stride, int slot = -1)
 {
     __shared__ double scratch[BLOCK / WAVE];
     if (DOT == 0) return;
+    if (slot < 0) slot = (int)blockIdx.x;
     const double t0 = block_sum<BLOCK / WAVE>(c0, scratch);
-    if (threadIdx.x == 0) partial[blockIdx.x] = t0;
+    if (threadIdx.x == 0) partial[slot] = t0;
     if (DOT == 2) {
         const double t1 = block_sum<BLOCK / WAVE>(c1, scratch);
-        if (threadIdx.x == 0) partial[stride + blockIdx.x] = t1;
+        if (threadIdx.x == 0) partial[stride + slot] = t1;
     }
 }
 
@@ -38,15 +54,17 @@ void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const doubl
                      const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
                      const double *__restrict__ guard = nullptr,
                      const unsigned char *__restrict__ codes = nullptr, const int *__restrict__ dict = nullptr,
-                     int rb = 0, int re = -1)               // rows [rb, re) of the n (re < 0: all): a multi-rank job's interior / boundary parts
+                     int rb = 0, int re = -1,               // rows [rb, re) of the n (re < 0: all): a multi-rank job's interior / boundary parts
+                     int xs_plane = 0)                      // XCD strips: workgroups per grid plane (fmt_strip_unit), 0 = natural order
 {
+    const int bid = fmt_strip_unit((int)blockIdx.x, (int)gridDim.x, xs_plane);
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
     __shared__ int dictL[CODED ? 256 : 1];
     if (CODED) {
         for (int i = threadIdx.x; i < 256; i += BLOCK) dictL[i] = dict[i];
         __syncthreads();
     }
-    const int r0 = rb + (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
+    const int r0 = rb + (bid * BLOCK + threadIdx.x) * ROWS;
     const bool active = r0 < (re < 0 ? n : re);
     if (!DOT && !active) return;
     const int r = active ? r0 : 0;                  // idle lanes of the last workgroup shadow row 0 (fused form: they
@@ -93,7 +111,7 @@ void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const doubl
             for (int i = 0; i < ROWS; i++) { c0 += wdot[r + i] * acc[i]; if (DOT == 2) c1 += acc[i] * acc[i]; }
         }
     }
-    publish<DOT>(c0, c1, partial, gridDim.x);
+    publish<DOT>(c0, c1, partial, gridDim.x, bid);
 }
 
 // DIA: same shape; a diagonal's offset is wave-uniform (scalar load), x[r + off] is contiguous across the wavefront.
@@ -103,10 +121,11 @@ __global__ __launch_bounds__(BLOCK)
 void spmv_dia_kernel(int n, int ncols, int nnd, const int *__restrict__ off,
                      const double *__restrict__ val, const double *__restrict__ x,
                      double *__restrict__ y, const double *__restrict__ wdot = nullptr, double *__restrict__ partial = nullptr,
-                     const double *__restrict__ guard = nullptr, int rb = 0, int re = -1)
+                     const double *__restrict__ guard = nullptr, int rb = 0, int re = -1, int xs_plane = 0)
 {
     if (DOT != 0 && guard != nullptr && guard[0] != 0.0) return;   // device-driven Krylov loop already converged
-    const int r0 = rb + (blockIdx.x * BLOCK + threadIdx.x) * ROWS;
+    const int bid = fmt_strip_unit((int)blockIdx.x, (int)gridDim.x, xs_plane);
+    const int r0 = rb + (bid * BLOCK + threadIdx.x) * ROWS;
     const bool active = r0 < (re < 0 ? n : re);
     if (!DOT && !active) return;
     const int r = active ? r0 : 0;
@@ -149,7 +168,7 @@ void spmv_dia_kernel(int n, int ncols, int nnd, const int *__restrict__ off,
             for (int i = 0; i < ROWS; i++) { c0 += wdot[r + i] * acc[i]; if (DOT == 2) c1 += acc[i] * acc[i]; }
         }
     }
-    publish<DOT>(c0, c1, partial, gridDim.x);
+    publish<DOT>(c0, c1, partial, gridDim.x, bid);
 }
 
 // JAD: a lane owns TWO adjacent slots of the length-sorted order (their entries are adjacent in every jagged
@@ -657,8 +676,20 @@ void spmv_bsr_team_kernel(int nr, const int *__restrict__ bptr, const int *__res
 int g_bsr_team = 1;              // liship_spmv_bsr_set_team: 0 keeps long block rows on the two-phase tile kernels (A/B)
 
 inline int grid_for(int n) { return (n + BLOCK - 1) / BLOCK; }
+// workgroups per grid plane for a whole-matrix launch of `grid` workgroups of `rows_per_wg` rows each (fmt_strip_unit), 0: natural order
+inline int fmt_plane(int rows_per_wg, int grid)
+{
+    if (g_fmt_plane_rows <= 0) return 0;
+    const long long pb = (long long)g_fmt_plane_rows / rows_per_wg;
+    if (pb * rows_per_wg != g_fmt_plane_rows || pb < 64 || (pb & 7) || pb * 4 > grid) return 0;      // whole workgroups per plane, eight strips, at least four planes
+    return (int)pb;
+}
 
 } // namespace
+
+// rows per plane of the structured grid the NEXT whole-matrix ELL / DIA launches work on (0: none -- natural workgroup order): the host layer sets it from the matrix
+// it is about to multiply (one driving thread per process, as the Lis API requires: lis_device.c)
+extern "C" int liship_spmv_formats_set_plane(int rows) { g_fmt_plane_rows = rows > 0 ? rows : 0; return 0; }
 
 extern "C" int liship_spmv_ell_f64(int n, int maxnzr, const int *idx, const double *val,
                                    const double *x, double *y, void *stream)
@@ -667,7 +698,7 @@ extern "C" int liship_spmv_ell_f64(int n, int maxnzr, const int *idx, const doub
     if (n == 0) return 0;
     if (maxnzr == 0) { HIP_TRY(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n, as_stream(stream))); return 0; }
     if ((n & 1) == 0 && aligned16(val) && aligned16(y) && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0)
-        spmv_ell_kernel<2, 8><<<grid_for(n / 2), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y);
+        spmv_ell_kernel<2, 8><<<grid_for(n / 2), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1, fmt_plane(2 * BLOCK, grid_for(n / 2)));
     else
         spmv_ell_kernel<1, 8><<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y);
     LAUNCH_CHECK();
@@ -681,7 +712,7 @@ extern "C" int liship_spmv_dia_f64(int n, int ncols, int nnd, const int *off, co
     if (n == 0) return 0;
     if (nnd == 0) { HIP_TRY(hipMemsetAsync(y, 0, sizeof(double) * (size_t)n, as_stream(stream))); return 0; }
     if ((n & 1) == 0 && aligned16(val) && aligned16(y))
-        spmv_dia_kernel<2, 8><<<grid_for(n / 2), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y);
+        spmv_dia_kernel<2, 8><<<grid_for(n / 2), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, nullptr, nullptr, nullptr, 0, -1, fmt_plane(2 * BLOCK, grid_for(n / 2)));
     else
         spmv_dia_kernel<1, 8><<<grid_for(n), BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y);
     LAUNCH_CHECK();
@@ -807,7 +838,7 @@ extern "C" int liship_spmv_ell_coded_f64(int n, int maxnzr, const unsigned char 
     const int grid = grid_for(n / 2);
     hipStream_t st = as_stream(stream);
     if (want_sumsq < 0) {
-        spmv_ell_kernel<2, 8, 0, true><<<grid, BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, nullptr, nullptr, nullptr, codes, dict);
+        spmv_ell_kernel<2, 8, 0, true><<<grid, BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, nullptr, nullptr, nullptr, codes, dict, 0, -1, fmt_plane(2 * BLOCK, grid));
         LAUNCH_CHECK();
         return 0;
     }
@@ -816,8 +847,8 @@ extern "C" int liship_spmv_ell_coded_f64(int n, int maxnzr, const unsigned char 
     const size_t slots = liship_reduce_work_bytes() / sizeof(double) / 4;
     if ((size_t)grid > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    if (want_sumsq) spmv_ell_kernel<2, 8, 2, true><<<grid, BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, w, partial, liship_internal_guard(), codes, dict);
-    else            spmv_ell_kernel<2, 8, 1, true><<<grid, BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, w, partial, liship_internal_guard(), codes, dict);
+    if (want_sumsq) spmv_ell_kernel<2, 8, 2, true><<<grid, BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, w, partial, liship_internal_guard(), codes, dict, 0, -1, fmt_plane(2 * BLOCK, grid));
+    else            spmv_ell_kernel<2, 8, 1, true><<<grid, BLOCK, 0, st>>>(n, maxnzr, nullptr, val, x, y, w, partial, liship_internal_guard(), codes, dict, 0, -1, fmt_plane(2 * BLOCK, grid));
     LAUNCH_CHECK();
     return liship_internal_fold(grid, want_sumsq ? 2 : 1, grid, partial, spare, result, stream);
 }
@@ -833,8 +864,8 @@ extern "C" int liship_spmv_ell_dot_f64(int n, int maxnzr, const int *idx, const 
     const int grid = grid_for(n / 2);
     if ((size_t)grid > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    if (want_sumsq) spmv_ell_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial, liship_internal_guard());
-    else            spmv_ell_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial, liship_internal_guard());
+    if (want_sumsq) spmv_ell_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial, liship_internal_guard(), nullptr, nullptr, 0, -1, fmt_plane(2 * BLOCK, grid));
+    else            spmv_ell_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, maxnzr, idx, val, x, y, w, partial, liship_internal_guard(), nullptr, nullptr, 0, -1, fmt_plane(2 * BLOCK, grid));
     LAUNCH_CHECK();
     return liship_internal_fold(grid, want_sumsq ? 2 : 1, grid, partial, spare, result, stream);
 }
@@ -848,8 +879,8 @@ extern "C" int liship_spmv_dia_dot_f64(int n, int ncols, int nnd, const int *off
     const int grid = grid_for(n / 2);
     if ((size_t)grid > slots) return LISHIP_ERR_ARG;
     double *partial = static_cast<double *>(work), *spare = partial + 2 * slots;
-    if (want_sumsq) spmv_dia_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial, liship_internal_guard());
-    else            spmv_dia_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial, liship_internal_guard());
+    if (want_sumsq) spmv_dia_kernel<2, 8, 2><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial, liship_internal_guard(), 0, -1, fmt_plane(2 * BLOCK, grid));
+    else            spmv_dia_kernel<2, 8, 1><<<grid, BLOCK, 0, as_stream(stream)>>>(n, ncols, nnd, off, val, x, y, w, partial, liship_internal_guard(), 0, -1, fmt_plane(2 * BLOCK, grid));
     LAUNCH_CHECK();
     return liship_internal_fold(grid, want_sumsq ? 2 : 1, grid, partial, spare, result, stream);
 }

@@ -64,9 +64,23 @@ def test_config4_class_product_has_the_reference_bits(lib, name):
     lib.dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
     listed = lib.dll.lis_amd_matrix_local_columns(A)
     assert (listed > 0) == (name == "fem3_22")          # the FEM pattern runs on block-local columns, random columns cannot
-    y = lisdrv.matvec(lib, A, x)
-    assert np.array_equal(y, orc.spmv_csr(ptr, idx, val, x))
-    assert _sha(y) == g["y_sha256"]                      # what lis_matvec of Lis 2.1.11 returned for this input
+    yref = orc.spmv_csr(ptr, idx, val, x)
+    if name == "tail":                                   # rows of up to 9000 entries: the default adds what lies beyond the LDS stage by a tree -- the reference's value to
+        y = lisdrv.matvec(lib, A, x)                     # rounding; LIS_AMD_LONG_ROW_CHAIN=1 (the switch below) is the mode that carries its bits
+        absum = np.add.reduceat(np.abs(val * x[idx]), np.minimum(ptr[:-1], len(val) - 1).astype(np.int64)) * (np.diff(ptr) > 0)
+        assert np.all(np.abs(y - yref) <= 1e-14 * absum)
+        lis_amd.check(lib.liship_spmv_csr_set_long_row_tree(0))
+    try:
+        y = lisdrv.matvec(lib, A, x)
+        assert np.array_equal(y, yref)
+        assert _sha(y) == g["y_sha256"]                  # what lis_matvec of Lis 2.1.11 returned for this input
+        _same_through_the_other_formats(lib, A, name, ptr, idx, val, x, y, n)
+    finally:
+        lis_amd.check(lib.liship_spmv_csr_set_long_row_tree(1))
+    lib.lis_matrix_destroy(A)
+
+
+def _same_through_the_other_formats(lib, A, name, ptr, idx, val, x, y, n):
     # the same through every storage format (conversion on the host, product on the GPU)
     for fmt in ("csc", "ell", "jad", "bsr") if name == "fem3_22" else ("csc", "jad"):
         B = lisdrv.convert(lib, A, fmt, 3, 3)
@@ -82,7 +96,6 @@ def test_config4_class_product_has_the_reference_bits(lib, name):
         else:
             np.testing.assert_allclose(yb, y, rtol=1e-13, atol=0)
         lib.lis_matrix_destroy(B)
-    lib.lis_matrix_destroy(A)
 
 
 @pytest.mark.parametrize("name,opts", [(n, o) for n in ("fem3_22", "tail") for o in GOLD[n]["solves"]])
@@ -110,11 +123,12 @@ def test_config4_class_solvers_need_the_reference_iteration_counts(lib, name, op
 
 
 @pytest.mark.parametrize("opts", list(GOLD["tail"]["solves"]))
-def test_long_row_tree_is_a_supported_mode(lib, opts):
-    """The long-row policy (README "Parity"): rows beyond the LDS stage are ONE left-to-right chain by default -- the reference's bits, at the price of a serial chain
-    on hub rows -- and LIS_AMD_LONG_ROW_TREE=1 (liship_spmv_csr_set_long_row_tree) trades those rows' last bits for a workgroup tree.  The tree is a supported mode,
-    not an experiment: on the heavy-tailed fixture (rows up to 9000 entries) every row stays within 1e-14 of the sum of its terms' magnitudes, rows that cannot
-    overflow a stage (up to 128 entries) keep the reference's bits, two runs give the same bits, and the solvers meet the reference's iteration counts with the default mode's slack."""
+def test_long_row_tree_is_the_default(lib, opts):
+    """The long-row policy (README "Parity"; flipped in round 6): the part of a row beyond the LDS stage is added by a workgroup tree by default -- a hub row of 10^5
+    entries is otherwise a 10^5-long dependent add chain -- and LIS_AMD_LONG_ROW_CHAIN=1 (liship_spmv_csr_set_long_row_tree(0); implied by the reference-order
+    reductions mode) restores the ONE left-to-right chain and with it the reference's bits.  On the heavy-tailed fixture (rows up to 9000 entries), in the DEFAULT
+    configuration: every row stays within 1e-14 of the sum of its terms' magnitudes, rows that cannot overflow a stage (up to 128 entries) keep the reference's
+    bits, two runs give the same bits, and the solvers meet the reference's iteration counts (tests/golden/irregular_golden.json) with the usual slack."""
     ptr, idx, val = _matrix("tail")
     n = len(ptr) - 1
     x_true = np.cos(np.arange(n) * 0.01) + 1.25
@@ -122,8 +136,7 @@ def test_long_row_tree_is_a_supported_mode(lib, opts):
     want = GOLD["tail"]["solves"][opts]
     A = lisdrv.make_csr(lib, ptr, idx, val)
     lib.dll.lis_amd_set_residency(1)
-    check_ = lis_amd.check
-    check_(lib.liship_spmv_csr_set_long_row_tree(1))
+    assert lib.liship_spmv_csr_switches() & 4, "the tree is the default"
     try:
         y1, y2 = lisdrv.matvec(lib, A, x_true), lisdrv.matvec(lib, A, x_true)
         assert np.array_equal(y1.view(np.uint64), y2.view(np.uint64))
@@ -136,7 +149,6 @@ def test_long_row_tree_is_a_supported_mode(lib, opts):
         assert (lens > 4096).any()                            # the fixture does have rows the tree serves
         res = lisdrv.solve(lib, A, yref, opts + " -tol 1e-12 -maxiter 2000 -print mem")
     finally:
-        check_(lib.liship_spmv_csr_set_long_row_tree(0))
         lib.dll.lis_amd_set_residency(0)
     solver = opts.split()[1]
     assert res["status"] == want["status"] == 0 and res["resid"] <= 1e-12
@@ -162,6 +174,8 @@ def test_config4_queen_scale_through_the_matrix_market_reader(lib):
     path, rows, stored = queen_class.generate("full")
     t_gen = time.time() - t0
     lib.dll.lis_amd_set_residency(1)
+    lib.dll.lis_amd_set_reorder_after.argtypes = [C.c_longlong]
+    lib.dll.lis_amd_set_reorder_after(0)          # the renumbered form at plan time (round 6: by default only after 10000 products, tests/test_lisapi_gpu.py): this test covers it at scale
     A, b, x0 = capi.PM(), capi.PV(), capi.PV()
     try:
         assert os.path.getsize(path) == g["file_bytes"]
@@ -234,6 +248,7 @@ def test_config4_queen_scale_through_the_matrix_market_reader(lib):
             json.dump(report, open(os.path.join(out_dir, "queen_class_run.json"), "w"), indent=1)
         print(json.dumps(report))
     finally:
+        lib.dll.lis_amd_set_reorder_after(10000)
         lib.dll.lis_amd_set_residency(0)
         lib.lis_matrix_destroy(A)
 

@@ -56,6 +56,21 @@ CSR_CASES = {
 }
 
 
+@pytest.fixture(autouse=True)
+def _chain_mode_for_the_long_row_cases(request, lib):
+    """Round 6: the part of a row beyond the LDS stage is added by a workgroup tree BY DEFAULT when it is at least 1024 entries long (value to 1e-14 of the row's
+    magnitude, not the reference's last bits: test_spmv_csr_long_row_tree_is_the_default, test_spmv_csr_long_rows_in_the_default_mode).  The parametrised cases
+    whose matrices hold such rows demand the reference's BITS, so they run in the mode that promises them: the left-to-right chain (LIS_AMD_LONG_ROW_CHAIN=1)."""
+    cid = getattr(request.node, "callspec", None)
+    names = [str(v) for v in cid.params.values()] if cid else []
+    chain = any(n in ("rand_long_rows", "fem3_long_row", "long_rows") for n in names)
+    if chain:
+        check(lib.liship_spmv_csr_set_long_row_tree(0))
+    yield
+    if chain:
+        check(lib.liship_spmv_csr_set_long_row_tree(1))
+
+
 # liship_spmv_csr_set_variant bits (lis_amd/csrc/kernels/spmv_csr.hip): 0 = shipped row-gather kernel with LDS-DMA;
 # 0x2 / 0x4 products kernel (scalar / vector loads); 0x10 / 0x50 the 256 / 2048 and 512 / 4096 geometries; 0x1000000 unaligned row blocks.  Every value selects kernels that give the reference's bits.
 VARIANTS = [0x0, 0x2, 0x4, 0x10, 0x12, 0x14, 0x50, 0x54, 0x1000000, 0x1000004]
@@ -69,6 +84,23 @@ def test_spmv_csr_bit_exact(lib, name, variant):
     x = np.random.default_rng(3).uniform(-1, 1, ncols)
     y = dev_csr_spmv(lib, ptr, idx, val, x, variant)
     assert np.array_equal(y, orc.spmv_csr(ptr, idx, val, x)), name
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_spmv_csr_long_rows_in_the_default_mode(lib, variant):
+    """the matrix of the chain-mode cases (a 7001-entry row among rows of ~40) in the DEFAULT mode, through every kernel variant: rows shorter than 1024 entries carry
+    the reference's bits, the long row its value to 1e-14 of the sum of its terms' magnitudes, and two runs agree bit for bit"""
+    assert lib.liship_spmv_csr_switches() & 4
+    ptr, idx, val = CSR_CASES["rand_long_rows"]()
+    x = np.random.default_rng(3).uniform(-1, 1, max(len(ptr) - 1, int(idx.max()) + 1))
+    ref = orc.spmv_csr(ptr, idx, val, x)
+    y1, y2 = dev_csr_spmv(lib, ptr, idx, val, x, variant), dev_csr_spmv(lib, ptr, idx, val, x, variant)
+    assert np.array_equal(y1.view(np.uint64), y2.view(np.uint64))
+    lens = np.diff(ptr)
+    short = lens < 1024
+    assert (~short).sum() == 1 and np.array_equal(y1[short], ref[short])
+    absum = np.add.reduceat(np.abs(val * x[idx]), np.minimum(ptr[:-1], len(val) - 1).astype(np.int64)) * (lens > 0)
+    assert np.all(np.abs(y1 - ref) <= 1e-14 * absum)
 
 
 def test_spmv_csr_empty_matrix_and_zero_rows(lib):
@@ -919,9 +951,9 @@ def test_uniform_length_rows_fed_sums(lib, L):
         check(lib.liship_csr_plan_destroy(plan))
 
 
-def test_spmv_csr_long_row_tree_is_opt_in(lib):
-    """rows longer than the LDS stage: left-to-right by default (the oracle's bits); with the opt-in tree the same value to
-    rounding, reproducibly -- and rows that fit the stage keep their bits either way"""
+def test_spmv_csr_long_row_tree_is_the_default(lib):
+    """rows longer than the LDS stage: a workgroup tree by default (round 6) -- the oracle's value to rounding, reproducibly -- and left to right (the oracle's bits)
+    with the chain switched on; rows that fit the stage keep their bits either way"""
     rng = np.random.default_rng(12)
     base = orc.random_csr(3000, 9, seed=12, ncols=3000)
     half = 1500
@@ -937,16 +969,17 @@ def test_spmv_csr_long_row_tree_is_opt_in(lib):
     plan = C.c_void_p()
     check(lib.liship_csr_plan_create(C.byref(plan), n, dptr.ptr, None))
     out = []
-    for tree in (0, 1, 1):
-        check(lib.liship_spmv_csr_set_long_row_tree(tree))
+    assert lib.liship_spmv_csr_switches() & 4, "the tree is the default"
+    for tree in (0, 1, 1, None):
+        if tree is not None:
+            check(lib.liship_spmv_csr_set_long_row_tree(tree))
         dy = DA.from_host(np.full(n, np.nan), np.float64)
         check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
         out.append(dy.to_host())
-    check(lib.liship_spmv_csr_set_long_row_tree(0))
     check(lib.liship_csr_plan_destroy(plan))
     assert np.array_equal(out[0], yref)
-    assert np.array_equal(out[1], out[2])
-    short = np.diff(ptr) <= 2000
+    assert np.array_equal(out[1], out[2]) and np.array_equal(out[1], out[3])
+    short = np.diff(ptr) < 1024                                      # (rows shorter than 1024 entries keep the reference's bits whatever the mode)
     assert np.array_equal(out[1][short], yref[short])
     scale = np.abs(val[ptr[1500]:ptr[1501]] * x[idx[ptr[1500]:ptr[1501]]]).sum()
     assert abs(out[1][1500] - yref[1500]) <= 1e-13 * scale            # a different association of 60 000 terms
@@ -1009,9 +1042,12 @@ def test_spmv_csr_long_row_tree_tail_over_many_workgroups(lib):
                 assert abs(r[1] - float(np.dot(y, y))) <= 1e-12 * float(np.dot(y, y))
     finally:
         check(lib.liship_spmv_csr_set_long_row_tree(0))
-    dy = DA.from_host(np.full(n, np.nan), np.float64)
-    check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
-    assert np.array_equal(dy.to_host(), yref)                      # and the default mode is the reference's chain, bit for bit
+    try:
+        dy = DA.from_host(np.full(n, np.nan), np.float64)
+        check(lib.liship_spmv_csr_f64(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr, dy.ptr, None))
+        assert np.array_equal(dy.to_host(), yref)                  # and the chain mode is the reference's sum, bit for bit
+    finally:
+        check(lib.liship_spmv_csr_set_long_row_tree(1))            # (back to the default)
     check(lib.liship_csr_plan_destroy(plan))
 
 

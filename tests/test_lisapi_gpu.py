@@ -683,16 +683,17 @@ def test_conversion_in_hbm_and_host_arrays_on_first_touch(lib, fmt, bs, kind):
         lib.lis_matrix_destroy(M)
 
 
-@pytest.mark.parametrize("env, want", [({}, 1), ({"LIS_AMD_NO_TEAM_KERNELS": "1"}, 0), ({"LIS_AMD_ROW_BLOCK_DOTS": "1"}, 3), ({"LIS_AMD_LONG_ROW_TREE": "1"}, 5),
-                                       ({"LIS_AMD_RESIDENCY": "resident", "LIS_AMD_ROW_BLOCK_DOTS": "1", "LIS_AMD_NO_TEAM_KERNELS": "1"}, 2)])
+@pytest.mark.parametrize("env, want", [({}, 5), ({"LIS_AMD_NO_TEAM_KERNELS": "1"}, 4), ({"LIS_AMD_ROW_BLOCK_DOTS": "1"}, 7), ({"LIS_AMD_LONG_ROW_CHAIN": "1"}, 1),
+                                       ({"LIS_AMD_LONG_ROW_TREE": "0"}, 1), ({"LIS_AMD_REFERENCE_REDUCTIONS": "2"}, 1),
+                                       ({"LIS_AMD_RESIDENCY": "resident", "LIS_AMD_ROW_BLOCK_DOTS": "1", "LIS_AMD_NO_TEAM_KERNELS": "1"}, 6)])
 def test_environment_switches_reach_the_kernels(env, want):
-    """the LIS_AMD_* variables that the device's start-up applies (team kernels off, row-block dots, the long-row tree) are read BEFORE the runtime comes up in
+    """the LIS_AMD_* variables that the device's start-up applies (team kernels off, row-block dots, the long-row chain in place of the default tree) are read BEFORE the runtime comes up in
     lis_initialize -- they were read behind it while the default residency started the runtime early, and did nothing"""
     import subprocess
     code = ("import sys; sys.path.insert(0, %r); import lis_amd; lib = lis_amd.load(); assert lib.initialize([]) == 0; "
             "print('SWITCHES', lib.liship_spmv_csr_switches())" % ROOT)
     e = dict(os.environ)
-    for k in ("LIS_AMD_NO_TEAM_KERNELS", "LIS_AMD_ROW_BLOCK_DOTS", "LIS_AMD_LONG_ROW_TREE", "LIS_AMD_RESIDENCY"):
+    for k in ("LIS_AMD_NO_TEAM_KERNELS", "LIS_AMD_ROW_BLOCK_DOTS", "LIS_AMD_LONG_ROW_TREE", "LIS_AMD_LONG_ROW_CHAIN", "LIS_AMD_REFERENCE_REDUCTIONS", "LIS_AMD_RESIDENCY"):
         e.pop(k, None)
     e.update(env)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e)
@@ -718,6 +719,53 @@ def test_solves_in_the_numbering_of_a_reordered_plan_short_rows(lib, options):
 
 
 def _renumbered_solve_case(lib, ptr, idx, val, options):
+    dll = lib.dll
+    dll.lis_amd_set_reorder_after.argtypes = [C.c_longlong]
+    dll.lis_amd_set_reorder_after(0)                # the renumbered form at plan time (the default builds it lazily: test_renumbering_is_lazy_by_default)
+    try:
+        _renumbered_solve_case_body(lib, ptr, idx, val, options)
+    finally:
+        dll.lis_amd_set_reorder_after(10000)
+
+
+def test_renumbering_is_lazy_by_default(lib):
+    """Round 6: the renumbered form costs a host-side Cuthill-McKee walk (+1.4 s on the Queen-class matrix) that pays back after ~13 000 iterations, so by default a
+    plan first serves lis_amd_set_reorder_after() products (10000) in the caller's numbering and only the first lis_solve BEHIND them builds it.  Here with a
+    threshold of 40 products: the first solve (fewer products than that) runs in the caller's numbering and leaves no renumbered form, the one after the threshold
+    runs renumbered -- the same counts (to the fold order of the sums) and the same solution, the oracle's bits for single products throughout."""
+    from test_kernels_gpu import _scrambled_fem
+    dll = lib.dll
+    dll.lis_amd_set_reorder_after.argtypes = [C.c_longlong]
+    dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
+    dll.lis_amd_matrix_products_served.argtypes = [capi.PM]; dll.lis_amd_matrix_products_served.restype = C.c_longlong
+    ptr, idx, val = _scrambled_fem("nodes")
+    n = len(ptr) - 1
+    xs = np.random.default_rng(3).uniform(-1, 1, n)
+    want = orc.spmv_csr(ptr, idx, val, xs)
+    b = orc.spmv_csr(ptr, idx, val, np.ones(n))
+    dll.lis_amd_set_reorder_after(40)
+    try:
+        A = lisdrv.make_csr(lib, ptr, idx, val)
+        assert dll.lis_amd_matrix_reordered(A) == 0                                   # nothing at plan time
+        first = lisdrv.solve(lib, A, b, "-i cg -p jacobi -tol 1e-11 -maxiter 20")     # stops at 20 iterations: ~21 products
+        assert dll.lis_amd_last_solve_renumbered() == 0 and dll.lis_amd_matrix_reordered(A) == 0
+        assert 0 < dll.lis_amd_matrix_products_served(A) < 40
+        assert np.array_equal(lisdrv.matvec(lib, A, xs).view(np.uint64), want.view(np.uint64))
+        plain = lisdrv.solve(lib, A, b, "-i cg -p jacobi -tol 1e-11 -maxiter 300")      # still below the threshold when it STARTS: the caller's numbering
+        assert dll.lis_amd_last_solve_renumbered() == 0 and plain["status"] == 0
+        assert dll.lis_amd_matrix_products_served(A) >= 40
+        lazy = lisdrv.solve(lib, A, b, "-i cg -p jacobi -tol 1e-11 -maxiter 300")       # the threshold is behind it: this solve builds P A P^T and iterates on it
+        assert dll.lis_amd_last_solve_renumbered() == 1 and dll.lis_amd_matrix_reordered(A) > 0
+        assert lazy["status"] == 0 and abs(lazy["iter"] - plain["iter"]) <= max(1, plain["iter"] // 50)
+        assert np.abs(lazy["x"] - 1).max() < 1e-8 and np.abs(plain["x"] - 1).max() < 1e-8
+        assert np.array_equal(lisdrv.matvec(lib, A, xs).view(np.uint64), want.view(np.uint64))
+        assert first["iter"] >= 20
+        assert lib.lis_matrix_destroy(A) == 0
+    finally:
+        dll.lis_amd_set_reorder_after(10000)
+
+
+def _renumbered_solve_case_body(lib, ptr, idx, val, options):
     dll = lib.dll
     dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
     n = len(ptr) - 1
@@ -760,10 +808,12 @@ def _renumbered_solve_case(lib, ptr, idx, val, options):
     assert lib.lis_matrix_destroy(A) == 0
 
 
-@pytest.mark.parametrize("env, fused", [({}, 1), ({"LIS_AMD_REORDER_PRODUCTS": "1"}, 0), ({"LIS_AMD_NO_REORDER": "1"}, None)])
+@pytest.mark.parametrize("env, fused", [({"LIS_AMD_REORDER_AFTER": "0"}, 1), ({"LIS_AMD_REORDER_AFTER": "0", "LIS_AMD_REORDER_PRODUCTS": "1"}, 0),
+                                        ({"LIS_AMD_REORDER_AFTER": "0", "LIS_AMD_NO_REORDER": "1"}, None), ({}, None)])
 def test_reordering_environment_switches(env, fused):
-    """by default a badly numbered long-row matrix gets the renumbered form for solves and keeps its products in the caller's numbering (fused reductions stay);
-    LIS_AMD_REORDER_PRODUCTS=1 sends lis_matvec through P A P^T too (the oracle's bits either way); LIS_AMD_NO_REORDER=1: no renumbered form at all"""
+    """LIS_AMD_REORDER_AFTER=0: a badly numbered long-row matrix gets the renumbered form at plan time, for solves, and keeps its products in the caller's numbering
+    (fused reductions stay); with LIS_AMD_REORDER_PRODUCTS=1 lis_matvec goes through P A P^T too (the oracle's bits either way); LIS_AMD_NO_REORDER=1: no renumbered
+    form at all; and the default (no variable: only behind 10000 products): none for a first short solve either"""
     import subprocess
     code = ("import sys, ctypes as C; sys.path[:0] = [%r, %r]\n"
             "import numpy as np, lis_amd, lisdrv, orc; from lis_amd import _capi as capi\n"

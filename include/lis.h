@@ -508,6 +508,10 @@ LIS_INT lis_matrix_copy(LIS_MATRIX Ain, LIS_MATRIX Aout);
 LIS_INT lis_matrix_set_blocksize(LIS_MATRIX A, LIS_INT bnr, LIS_INT bnc, LIS_INT row[], LIS_INT col[]);
 LIS_INT lis_matrix_unset(LIS_MATRIX A);
 LIS_INT lis_matrix_set_destroyflag(LIS_MATRIX A, LIS_INT flag);
+/* lis_matrix_malloc_<fmt>: DIFFERENT FROM THE REFERENCE IN ONE RESPECT.  The arrays live on pages of the library's own (not malloc memory): release them with
+ * lis_free() or lis_matrix_destroy() -- NEVER free() --, and while the adopting matrix has a copy in HBM they are read-only: a store into them is caught (one page
+ * fault) and the next product uses the new values, but read(2) / fread / MPI_Recv INTO them fails with EFAULT until lis_amd_matrix_host_modified(A) or
+ * lis_matrix_unset(A) opens them.  LIS_AMD_PLAIN_MALLOC=1 / lis_amd_set_matrix_pages(0) (lis_amd.h) gives plain malloc memory instead. */
 LIS_INT lis_matrix_malloc_csr(LIS_INT n, LIS_INT nnz, LIS_INT **ptr, LIS_INT **index, LIS_SCALAR **value);
 LIS_INT lis_matrix_set_csr(LIS_INT nnz, LIS_INT *ptr, LIS_INT *index, LIS_SCALAR *value, LIS_MATRIX A);
 LIS_INT lis_matrix_malloc_csc(LIS_INT n, LIS_INT nnz, LIS_INT **ptr, LIS_INT **index, LIS_SCALAR **value);

@@ -106,6 +106,11 @@ LIS_INT lis_amd_matrix_host_modified(LIS_MATRIX A);   /* host arrays changed: dr
  * then re-hashes its host arrays (a pass over them on the host cores) and rebuilds a stale copy, with one line on stderr naming the matrix.
  * lis_amd_matrix_protected_arrays: how many arrays of A are write-protected right now (tests).  System calls that WRITE INTO a protected array (fread into
  * A->value) fail with EFAULT, as for vectors: call lis_amd_matrix_host_modified(A) first, which opens the pages. */
+/* 0 (env LIS_AMD_PLAIN_MALLOC=1): lis_matrix_malloc_<fmt> returns plain malloc memory, as the reference's lis_malloc does -- for a program that free()s those arrays
+ * itself or passes them to read(2) / fread / MPI_Recv between solves (a system call into a write-protected page fails with EFAULT).  Such arrays are never protected and
+ * an in-place edit is not seen: lis_amd_matrix_host_modified(A) is then the contract, as for any array the caller malloc'ed.  1 (default): pages of the library's own,
+ * released by lis_free / lis_matrix_destroy only, read-only while the HBM copy lives. */
+LIS_INT lis_amd_set_matrix_pages(LIS_INT on);
 LIS_INT lis_amd_set_matrix_check(LIS_INT on);
 LIS_INT lis_amd_matrix_protected_arrays(LIS_MATRIX A);
 LIS_INT lis_amd_matrix_host_written(LIS_MATRIX A);     /* 1: a host write to one of A's watched arrays was seen since the HBM copy was built (tests) */

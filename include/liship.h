@@ -462,10 +462,15 @@ int  liship_dot2_f64(int n, const double *x, const double *y, double *result, vo
  * src/matrix/lis_matrix_csr.c:547-558 */
 int  liship_csr_diagonal_f64(int n, const int *ptr, const int *index, const double *value,
                              double *d, void *stream);
+/* The box's own streaming yardstick (bench.py): one pass of nt loads over val[nnz] (16 B) and idx[nnz] (8 B per pair) with 8 B of nt store per 7 entries into
+ * y[nnz / 7 + 1024] -- the read : write mix of a 7-point CSR product, nothing computed.  Bytes moved: 12 nnz + 8 (nnz / 7).  Not on the product path. */
+int  liship_stream_yardstick(long long nnz, const double *val, const int *idx, double *y, void *stream);
 /* XCD strips of the native ELL / DIA kernels (round 6): rows per plane of the structured grid the next whole-matrix ELL / DIA launches work on -- every XCD then takes
  * one eighth of every plane and walks the planes in order, so the +-plane neighbours of a row are in its own L2 (the CSR kernels learn their plane at plan time:
  * liship_csr_plan_strip_rows).  0: the natural workgroup order.  An order of the workgroups only: the bits cannot depend on it. */
 int  liship_spmv_formats_set_plane(int rows);
+/* the plane of a structured grid from ELL arrays in HBM: the largest |column - row| when at least half of the rows reach it (as liship_csr_plan_scan_band), else 0 */
+int  liship_ell_scan_band(int n, int maxnzr, const int *index, int *plane_rows, void *stream);
 /* the same for the native ELL arrays (first slot whose index is the row; padding gives 0: src/matrix/lis_matrix_ell.c lis_matrix_get_diagonal_ell) and the
  * native DIA arrays (the stored diagonal of offset 0, one chunk value[d*n + i]: src/matrix/lis_matrix_dia.c lis_matrix_get_diagonal_dia) */
 int  liship_ell_diagonal_f64(int n, int maxnzr, const int *index, const double *value, double *d, void *stream);

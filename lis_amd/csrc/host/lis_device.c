@@ -293,10 +293,11 @@ LIS_INT lisd_staged_d2h(void *dst, const void *src, size_t bytes)
  * the capture to end first (a batch of launches: microseconds).  Plain memcpy, no OpenMP. */
 static struct { void *stream, *buf[2], *ev[2], *order; int ready; } fstage;
 static volatile int capture_active;
+static pthread_t capture_thread;                                    /* the thread that began the capture in progress */
 static pthread_mutex_t fault_lock = PTHREAD_MUTEX_INITIALIZER;      /* one fault-time copy at a time; a capture begins only between two of them */
 void lisd_capture_mark(int on)
 {
-	if (on) { pthread_mutex_lock(&fault_lock); capture_active = 1; pthread_mutex_unlock(&fault_lock); }
+	if (on) { pthread_mutex_lock(&fault_lock); capture_thread = pthread_self(); capture_active = 1; pthread_mutex_unlock(&fault_lock); }
 	else capture_active = 0;
 }
 LIS_INT lisd_fault_stage_prepare(void)
@@ -313,10 +314,28 @@ LIS_INT lisd_fault_stage_prepare(void)
 }
 LIS_INT lisd_staged_d2h_fault(void *dst, const void *src, size_t bytes)
 {
-	if (!fstage.ready) return lisd_staged_d2h(dst, src, bytes);       /* (the handler was installed before the device existed: the shared path) */
+	if (!fstage.ready) {               /* (the handler was installed before the device existed: the shared path -- with plain memcpy: no OpenMP region from inside a signal handler) */
+		in_fault_copy = 1;
+		const LIS_INT e = lisd_staged_d2h(dst, src, bytes);
+		in_fault_copy = 0;
+		return e;
+	}
 	LIS_INT err = LIS_SUCCESS;
 	pthread_mutex_lock(&fault_lock);
-	while (capture_active) usleep(50);
+	/* a capture in progress is waited out -- a batch of launches, microseconds.  Two ways this could never end, both loud instead of a silent spin:
+	 * the capturing thread ITSELF faulted (nobody is left to end the capture), or the capture was abandoned on an error path without lisd_capture_mark(0) */
+	if (capture_active && pthread_equal(capture_thread, pthread_self())) {
+		fprintf(stderr, "liblis_amd: the thread that is capturing a hipGraph touched a page-protected array whose data lives in HBM: the copy cannot be ordered inside the capture -- aborting\n");
+		abort();
+	}
+	for (int waited_us = 0; capture_active; waited_us += 50) {
+		if (waited_us > 10 * 1000 * 1000) {
+			fprintf(stderr, "liblis_amd: a hipGraph capture has not ended for 10 s while a page fault waits for it: taking the capture for abandoned\n");
+			capture_active = 0;
+			break;
+		}
+		usleep(50);
+	}
 	int rc = liship_event_record(fstage.order, lisg.stream);
 	if (!rc) rc = liship_stream_wait_event(fstage.stream, fstage.order);
 	in_fault_copy = 1;
@@ -441,6 +460,27 @@ static LIS_INT up_d(double **dst, const double *src, size_t count)
 	if (count) HIPCHK(liship_memcpy_h2d(p, src, count * sizeof(double), lisg.stream));
 	*dst = (double *)p;
 	return LIS_SUCCESS;
+}
+
+/* XCD strips of the native ELL / DIA kernels (liship_spmv_formats_set_plane): the plane of the grid is the largest offset most rows reach -- for DIA read off its
+ * offsets (the largest positive one: a diagonal serves every row it fits), for ELL found by two passes over index[] in HBM.  Used only where x does not fit the
+ * 256 MB Infinity Cache (measured: 512^3 ELL 0.671 -> 0.733 of the roofline with the counters' traffic at 1.01 x the algorithmic bytes instead of 1.26 x, DIA 0.687 ->
+ * 0.709; at 256^3, where x + y sit in that cache, the strips COST ELL 7 %: profiles/r06_formats_512.txt). */
+static void fmt_find_plane(lisd_mat *d, const int *host_dia_offsets)
+{
+	d->xs_rows = 0;
+	if (d->type == LIS_MATRIX_DIA && host_dia_offsets) {
+		int best = 0;
+		for (int k = 0; k < d->nnd; k++) if (host_dia_offsets[k] > best && host_dia_offsets[k] < d->n) best = host_dia_offsets[k];
+		d->xs_rows = best;
+	} else if (d->type == LIS_MATRIX_ELL && d->index) {
+		int plane = 0;
+		if (liship_ell_scan_band(d->n, d->maxnzr, d->index, &plane, lisg.stream) == 0) d->xs_rows = plane;
+	}
+}
+static void fmt_strips(const lisd_mat *d)        /* in front of every whole-matrix launch of a native ELL / DIA kernel */
+{
+	(void)liship_spmv_formats_set_plane((d->xs_rows > 0 && (size_t)d->n * sizeof(double) > ((size_t)256 << 20)) ? d->xs_rows : 0);
 }
 
 /* the permutation the last reordered plan found (liship_csr_plan_reorder), tried first by the next plan of the same size: a program that edits A->value between solves
@@ -922,12 +962,16 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 			if (rc) { (void)liship_free(d->ell_codes); (void)liship_free(d->ell_dict); d->ell_codes = NULL; d->ell_dict = NULL; }
 			if (rc && rc != 2 /* hipErrorOutOfMemory */) HIPCHK(rc);
 		}
+		d->type = LIS_MATRIX_ELL; d->n = A->n;
+		fmt_find_plane(d, NULL);
 		break;
 	case LIS_MATRIX_DIA:
 		d->nnd = A->nnd;
 		{ int taken = 0; LISCHK(try_row_form(A, d, &taken)); if (taken) break; }
 		LISCHK(up_i(&d->index, A->index, (size_t)A->nnd));
 		LISCHK(up_d(&d->value, A->value, n * (size_t)A->nnd));
+		d->type = LIS_MATRIX_DIA; d->n = A->n;
+		fmt_find_plane(d, A->index);
 		break;
 	case LIS_MATRIX_JAD:
 		LISCHK(upload_jad_as_csr(A, d));
@@ -1060,6 +1104,7 @@ LIS_INT lisd_convert_csr(LIS_MATRIX Ain, LIS_MATRIX Aout, int *done)
 			}
 		}
 		d->maxnzr = maxnzr;
+		if (!rowform) fmt_find_plane(d, NULL);
 		LIS_INT *hi = (LIS_INT *)lazy_host(Aout, sizeof(int) * slots, eidx, rowform);
 		LIS_SCALAR *hv = (LIS_SCALAR *)lazy_host(Aout, sizeof(double) * slots, eval, rowform);
 		if (!hi || !hv) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert: address space\n");
@@ -1105,6 +1150,10 @@ LIS_INT lisd_convert_csr(LIS_MATRIX Ain, LIS_MATRIX Aout, int *done)
 		(void)liship_free(scratch);
 		if (!rowform) { d->type = LIS_MATRIX_DIA; d->index = offs; d->value = dval; }
 		d->nnd = nnd;
+		if (!rowform && nnd <= 4096) {
+			int hoffs[4096];
+			if (liship_memcpy_d2h(hoffs, offs, sizeof(int) * (size_t)nnd, lisg.stream) == 0 && liship_stream_synchronize(lisg.stream) == 0) fmt_find_plane(d, hoffs);
+		}
 		LIS_INT *hi = (LIS_INT *)lazy_host(Aout, sizeof(int) * (size_t)nnd, offs, rowform);
 		LIS_SCALAR *hv = (LIS_SCALAR *)lazy_host(Aout, sizeof(double) * (size_t)n * (size_t)nnd, dval, rowform);
 		if (!hi || !hv) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "convert: address space\n");
@@ -1363,6 +1412,7 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));
 		break;
 	case LIS_MATRIX_ELL:
+		fmt_strips(d);
 		if (d->ell_codes) {
 			int rc = liship_spmv_ell_coded_f64(d->n, d->maxnzr, d->ell_codes, d->ell_dict, d->value, dx, dy, NULL, -1, NULL, NULL, lisg.stream);
 			if (rc == 0) break;
@@ -1371,6 +1421,7 @@ LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy)
 		HIPCHK(liship_spmv_ell_f64(d->n, d->maxnzr, d->index, d->value, dx, dy, lisg.stream));
 		break;
 	case LIS_MATRIX_DIA:
+		fmt_strips(d);
 		HIPCHK(liship_spmv_dia_f64(d->n, d->np, d->nnd, d->index, d->value, dx, dy, lisg.stream));
 		break;
 	case LIS_MATRIX_JAD:
@@ -1453,6 +1504,7 @@ LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const doub
 		HIPCHK(liship_spmv_csr_f64(d->plan, d->ptr, d->index, d->value, dx, dy, lisg.stream));
 	} else if ((d->type == LIS_MATRIX_ELL || d->type == LIS_MATRIX_DIA) && !lisg.no_fusion) {
 		if (lisg.nprocs > 1 && A->commtable) LISCHK(lisc_halo_device(A, dx));
+		fmt_strips(d);
 		int rc = (d->type == LIS_MATRIX_ELL && d->ell_codes)
 			? liship_spmv_ell_coded_f64(d->n, d->maxnzr, d->ell_codes, d->ell_dict, d->value, dx, dy, dw, want_sumsq ? 1 : 0, result, lisg.reduce_work, lisg.stream)
 			: (d->type == LIS_MATRIX_ELL)

@@ -148,11 +148,18 @@ LIS_INT lis_matrix_is_assembled(LIS_MATRIX A) { return A->status != LIS_MATRIX_N
 /* The arrays of lis_matrix_malloc_<fmt> live on pages of the library's own (lis_pages.c, lisp_alloc_tracked): once a matrix has adopted them and its HBM copy is
  * built, a host write to them is SEEN (one page fault) and the copy is rebuilt before the next product -- the reference reads adopted arrays live on every call
  * (lis_matrix_csr.c:98-103, lis_matvec_csr.c:97-109).  Released by lis_matrix_destroy / lis_free, never by free().  Without a memory file: plain malloc. */
+/* WHAT THIS CHANGES FOR A PROGRAM: the reference hands out lis_malloc memory, which is malloc memory.  Arrays on these pages (1) must not be given to
+ * free() -- lis_free() / lis_matrix_destroy() release them, as they release the reference's; (2) are READ-ONLY while the adopting matrix has an HBM copy: a store into
+ * them faults once and is then seen, but a system call that writes into them (fread / read / MPI_Recv into A->value) fails with EFAULT -- call
+ * lis_amd_matrix_host_modified(A) first, which opens the pages; lis_matrix_unset() opens them too.  A program that needs plain malloc memory -- it frees the arrays
+ * itself, or reads files into them between solves -- runs with LIS_AMD_PLAIN_MALLOC=1 / lis_amd_set_matrix_pages(0): lis_matrix_malloc_<fmt> then returns malloc
+ * memory, nothing is protected, and lis_amd_matrix_host_modified(A) after an in-place edit is the contract (as for every array the caller malloc'ed itself). */
 static void *matrix_array(size_t bytes)
 {
-	void *p = lisp_alloc_tracked(bytes);
+	void *p = lisg.plain_malloc ? NULL : lisp_alloc_tracked(bytes);
 	return p ? p : malloc(bytes ? bytes : 1);
 }
+LIS_INT lis_amd_set_matrix_pages(LIS_INT on) { lisg.plain_malloc = on ? 0 : 1; return LIS_SUCCESS; }
 #define ALLOC_OR_FAIL(p, T, count) do { (p) = (T *)matrix_array(sizeof(T) * (size_t)((count) > 0 ? (count) : 1)); \
 	if (!(p)) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", (LIS_INT)(count)); } while (0)
 

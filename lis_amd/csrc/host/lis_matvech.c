@@ -122,7 +122,8 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 	const int split = A->is_splited != 0;
 	if (split && !(A->matrix_type == LIS_MATRIX_CSR || (A->matrix_type == LIS_MATRIX_BSR && A->bnr == A->bnc)))
 		return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "A^T x of a split (D/L/U) matrix is served for CSR and square-block BSR storage\n");
-	if (split && lisg.nprocs > 1) return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "A^T x of a split matrix in a multi-rank job is not served\n");
+	/* (a multi-rank job: the transposed rows of the split walk cover the np local columns like any other matrix's, the ghost rows' sums travel back to their owners
+	 * through the reverse exchange -- lisd_spmv_t / lisc_reduce_device, the reference's LIS_MATVEC_REDUCE around lis_matvech_<fmt>, src/matvec/lis_matvec.c:191-349) */
 	if (d->t_ready) return LIS_SUCCESS;
 	LISCHK(lisd_mat_ready(A));
 	if (!(A->matrix_type == LIS_MATRIX_CSR && d->type == LIS_MATRIX_CSR)) LISCHK(lisp_fill_matrix(A));   /* the host arrays are read below (and handed to the runtime) */

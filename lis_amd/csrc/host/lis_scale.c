@@ -155,6 +155,11 @@ static LIS_INT scale_device_only(LIS_MATRIX A, LIS_VECTOR B, LIS_VECTOR D, LIS_I
 	if (m->t_plan) { (void)liship_csr_plan_destroy(m->t_plan); m->t_plan = NULL; }
 	(void)liship_free(m->t_ptr); (void)liship_free(m->t_index); (void)liship_free(m->t_value); (void)liship_free(m->t_diag);
 	m->t_ptr = NULL; m->t_index = NULL; m->t_value = NULL; m->t_diag = NULL; m->t_ready = 0;
+	/* ... and the renumbered transpose cache beside it (built from the UNSCALED values by a solve in a reordered plan's numbering: swap_transposed must never bring it back) */
+	if (m->rt_plan) { (void)liship_csr_plan_destroy(m->rt_plan); m->rt_plan = NULL; }
+	(void)liship_free(m->rt_ptr); (void)liship_free(m->rt_index); (void)liship_free(m->rt_value);
+	m->rt_ptr = NULL; m->rt_index = NULL; m->rt_value = NULL; m->rt_ready = 0; m->rt_nnz = 0;
+	m->reorder_tried = 0; m->served = 0;
 	LISCHK(lisd_csr_plan_plain(&m->plan, n, m->ptr, m->index, m->value));
 	A->is_scaled = LIS_TRUE;
 	B->is_scaled = LIS_TRUE;

@@ -1047,15 +1047,15 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 	if (scale && storage == LIS_MATRIX_BSR && scale == LIS_SCALE_JACOBI) {
 		/* block-diagonal scaling: A becomes BSR, is split and multiplied by the inverse diagonal blocks, b likewise; the
 		 * iterations then run on the split product (ref :659-690) */
-		{	/* feasibility BEFORE A and b are touched: the solvers that multiply by A^T need the transposed split product, which lisd_mat_ready_t serves on one rank
-			 * and for square blocks only (lis_matvech.c) -- a refusal after the retype / split / scaling would hand the caller back a mutated A and b */
+		{	/* feasibility BEFORE A and b are touched: the solvers that multiply by A^T need the transposed split product, which lisd_mat_ready_t serves
+			 * for square blocks only (lis_matvech.c) -- a refusal after the retype / split / scaling would hand the caller back a mutated A and b */
 			const int needs_t = nsolver == LIS_SOLVER_BICG || nsolver == LIS_SOLVER_BICR || nsolver == LIS_SOLVER_CRS || nsolver == LIS_SOLVER_BICRSTAB ||
 			                    nsolver == LIS_SOLVER_GPBICR || nsolver == LIS_SOLVER_BICRSAFE;
 			const LIS_INT blk = solver->options[LIS_OPTIONS_STORAGE_BLOCK];
 			const int square = A->matrix_type == LIS_MATRIX_BSR ? A->bnr == A->bnc : (blk > 0 || A->conv_bnr == A->conv_bnc);      /* (-storage_block b: b x b blocks) */
-			if (needs_t && (lisg.nprocs > 1 || !square)) {
+			if (needs_t && !square) {
 				solver->retcode = LIS_ERR_NOT_IMPLEMENTED;
-				return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s with -scale jacobi -storage bsr needs A^T x of a split matrix: served on one rank and for square blocks only (A and b are untouched)\n", solver_names[nsolver]);
+				return LISI_ERR(LIS_ERR_NOT_IMPLEMENTED, "solver %s with -scale jacobi -storage bsr needs A^T x of a split matrix: served for square blocks only (A and b are untouched)\n", solver_names[nsolver]);
 			}
 		}
 		if (A->matrix_type != LIS_MATRIX_BSR) err = lisi_matrix_retype(A, LIS_MATRIX_BSR, solver->options[LIS_OPTIONS_STORAGE_BLOCK]);

@@ -687,6 +687,48 @@ inline int fmt_plane(int rows_per_wg, int grid)
 
 } // namespace
 
+// the plane of a structured grid from an ELL matrix's own arrays (as liship_csr_plan_scan_band finds it for CSR): the largest |column - row| over the slots with owned
+// columns, when at least half of the rows reach it -- the +-plane neighbours of a 3-D stencil.  Two passes over index[] at upload time; 0 when there is none.
+namespace {
+__global__ void ell_band_max(int n, int maxnzr, const int *__restrict__ idx, int *__restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int m = 0;
+    if (r < n) for (int j = 0; j < maxnzr; j++) { const int c = idx[(size_t)j * n + r]; if (c >= 0 && c < n) m = max(m, abs(c - r)); }
+    for (int s = WAVE / 2; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s));
+    if ((threadIdx.x & (WAVE - 1)) == 0 && m > 0) atomicMax(out, m);
+}
+__global__ void ell_band_count(int n, int maxnzr, const int *__restrict__ idx, const int *__restrict__ band, unsigned long long *__restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, B = band[0];
+    bool hit = false;
+    if (r < n) for (int j = 0; j < maxnzr; j++) { const int c = idx[(size_t)j * n + r]; hit = hit || (c >= 0 && c < n && abs(c - r) == B); }
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(hit);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && b) atomicAdd(out, (unsigned long long)__builtin_popcountll(b));
+}
+}
+extern "C" int liship_ell_scan_band(int n, int maxnzr, const int *idx, int *plane_rows, void *stream)
+{
+    if (!plane_rows) return LISHIP_ERR_ARG;
+    *plane_rows = 0;
+    if (n <= 0 || maxnzr <= 0 || !idx) return 0;
+    hipStream_t st = as_stream(stream);
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), st);
+    const int grid = (n + BLOCK - 1) / BLOCK;
+    if (e == hipSuccess) { ell_band_max<<<grid, BLOCK, 0, st>>>(n, maxnzr, idx, reinterpret_cast<int *>(d)); e = hipGetLastError(); }
+    if (e == hipSuccess) { ell_band_count<<<grid, BLOCK, 0, st>>>(n, maxnzr, idx, reinterpret_cast<const int *>(d), d + 1); e = hipGetLastError(); }
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) return (int)e;
+    const int band = (int)(h[0] & 0xffffffffull);
+    if (band > 0 && 2 * h[1] >= (unsigned long long)n) *plane_rows = band;
+    return 0;
+}
+
 // rows per plane of the structured grid the NEXT whole-matrix ELL / DIA launches work on (0: none -- natural workgroup order): the host layer sets it from the matrix
 // it is about to multiply (one driving thread per process, as the Lis API requires: lis_device.c)
 extern "C" int liship_spmv_formats_set_plane(int rows) { g_fmt_plane_rows = rows > 0 ? rows : 0; return 0; }

@@ -555,3 +555,40 @@ def test_second_set_size_releases_the_first_pages(lib):
     maps = open("/proc/self/maps").read()
     assert ("%x-" % first) not in maps            # the first mapping is gone
     assert lib.lis_vector_destroy(v) == 0
+
+
+def test_plain_malloc_arrays_can_be_freed_by_the_program():
+    """lis_matrix_malloc_<fmt> hands out pages of the library's own (write-watched once uploaded; lis_free releases them, free() would crash).  With
+    LIS_AMD_PLAIN_MALLOC=1 / lis_amd_set_matrix_pages(0) it hands out malloc memory like the reference's lis_malloc: free() takes it, lis_free() too.  In a child:
+    a wrong free() aborts the process."""
+    import subprocess
+    code = ("import sys, ctypes as C; sys.path[:0] = [%r, %r]\n"
+            "import lis_amd; from lis_amd import _capi as capi\n"
+            "lib = lis_amd.load(); assert lib.initialize([]) == 0; dll = lib.dll\n"
+            "libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]\n"
+            "dll.lis_amd_matrix_page_test_watch.argtypes = [capi.PM]\n"
+            "def arrays():\n"
+            "    p, i, v = capi.P_INT(), capi.P_INT(), capi.P_DBL()\n"
+            "    assert lib.lis_matrix_malloc_csr(4, 10, C.byref(p), C.byref(i), C.byref(v)) == 0\n"
+            "    return p, i, v\n"
+            "p, i, v = arrays()\n"
+            "A = capi.PM(); assert lib.lis_matrix_create(0, C.byref(A)) == 0 and lib.lis_matrix_set_size(A, 4, 0) == 0\n"
+            "for k in range(5): p[k] = 2 * k if k < 4 else 7\n"
+            "for k in range(7): i[k] = k %% 4; v[k] = 1.0\n"
+            "assert lib.lis_matrix_set_csr(7, p, i, v, A) == 0 and lib.lis_matrix_assemble(A) == 0\n"
+            "print('WATCHED', dll.lis_amd_matrix_page_test_watch(A))\n"
+            "assert lib.lis_matrix_destroy(A) == 0\n"
+            "assert dll.lis_amd_set_matrix_pages(0) == 0\n"
+            "p, i, v = arrays()\n"
+            "A = capi.PM(); assert lib.lis_matrix_create(0, C.byref(A)) == 0 and lib.lis_matrix_set_size(A, 4, 0) == 0\n"
+            "for k in range(5): p[k] = 2 * k if k < 4 else 7\n"
+            "for k in range(7): i[k] = k %% 4; v[k] = 1.0\n"
+            "assert lib.lis_matrix_set_csr(7, p, i, v, A) == 0 and lib.lis_matrix_assemble(A) == 0\n"
+            "print('PLAIN', dll.lis_amd_matrix_page_test_watch(A))\n"
+            "dll.lis_matrix_unset.argtypes = [capi.PM]; assert dll.lis_matrix_unset(A) == 0 and lib.lis_matrix_destroy(A) == 0\n"
+            "for a in (p, i, v): libc.free(C.cast(a, C.c_void_p))\n"
+            "print('FREED')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    import sys
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
+    assert "WATCHED 3" in p.stdout and "PLAIN 0" in p.stdout and "FREED" in p.stdout, p.stdout[-500:]

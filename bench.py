@@ -488,7 +488,6 @@ def main():
     roofline = roofline_of(REF, kernel_ms, "_contract_form",
                            "ANY CSR matrix with short rows: nothing about the matrix is assumed or precomputed beyond the row split (12 B per non-zero + 20 B per row streamed)")
     roofline["xcd_strip_rows"] = int(dll.lis_amd_matrix_strip_rows(A))     # rows per plane the XCD strips are cut from (0: natural block order)
-    roofline["box_streaming_yardstick"] = streaming_yardstick(lib, C, np, stream, timer, min(nnz_local, 940_000_000))
     x_one = leg(A, x1, y, args.steps, nnz_global)
     check_a_times_one("reference layout, x = 1")
     x_one["x"] = "x = 1 (test/spmvtest3.c): the same kernel, the same bytes; the multipliers see one mantissa pattern and the clocks run a few per cent higher"
@@ -633,33 +632,6 @@ def main():
         dist.destroy_process_group()
     if degraded:
         sys.exit(3)                   # the line above says "degraded": true; a driver that only looks at the exit code sees it too
-
-
-def streaming_yardstick(lib, C, np, stream, timer, nnz, launches=10):
-    """What THIS box sustains on the access mix of the headline product with nothing to compute (liship_stream_yardstick: nt loads of 16 B values + 8 B index pairs, 8 B of nt
-    store per 7 entries, persistent workgroups) -- context for `roofline.frac`, which stays priced against the 8 TB/s peak: boxes of this pool differ by ~8 %, and no SpMV
-    kernel can beat its own box's copy rate.  Never fatal: None when anything goes wrong."""
-    try:
-        from lis_amd import DeviceArray as DA, check
-        nnz -= nnz % 14
-        val, idx, yy = DA(nnz, np.float64), DA(nnz, np.int32), DA(nnz // 7 + 1024, np.float64)
-        check(lib.liship_memset(val.ptr, 0, val.nbytes, stream)); check(lib.liship_memset(idx.ptr, 0, idx.nbytes, stream))
-        for _ in range(3):
-            check(lib.liship_stream_yardstick(nnz, val.ptr, idx.ptr, yy.ptr, stream))
-        ev = C.c_float()
-        check(lib.liship_timer_start(timer, stream))
-        for _ in range(launches):
-            check(lib.liship_stream_yardstick(nnz, val.ptr, idx.ptr, yy.ptr, stream))
-        check(lib.liship_timer_stop(timer, stream))
-        check(lib.liship_stream_synchronize(stream))
-        check(lib.liship_timer_elapsed_ms(timer, C.byref(ev)))
-        ms = ev.value / launches
-        moved = 12 * nnz + 8 * (nnz // 7)
-        val.free(); idx.free(); yy.free()
-        return {"kernel": "stream_yardstick_kernel", "what": "12 B read per entry (16 B + 8 B nt loads) + 8 B nt store per 7 entries, nothing computed: the ceiling of this box for the product's read : write mix",
-                "bytes_per_launch": moved, "kernel_ms": round(ms, 4), "achieved": round(moved / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    except Exception as exc:
-        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 # ============================================================================================================================ per-config legs

@@ -462,9 +462,6 @@ int  liship_dot2_f64(int n, const double *x, const double *y, double *result, vo
  * src/matrix/lis_matrix_csr.c:547-558 */
 int  liship_csr_diagonal_f64(int n, const int *ptr, const int *index, const double *value,
                              double *d, void *stream);
-/* The box's own streaming yardstick (bench.py): one pass of nt loads over val[nnz] (16 B) and idx[nnz] (8 B per pair) with 8 B of nt store per 7 entries into
- * y[nnz / 7 + 1024] -- the read : write mix of a 7-point CSR product, nothing computed.  Bytes moved: 12 nnz + 8 (nnz / 7).  Not on the product path. */
-int  liship_stream_yardstick(long long nnz, const double *val, const int *idx, double *y, void *stream);
 /* XCD strips of the native ELL / DIA kernels (round 6): rows per plane of the structured grid the next whole-matrix ELL / DIA launches work on -- every XCD then takes
  * one eighth of every plane and walks the planes in order, so the +-plane neighbours of a row are in its own L2 (the CSR kernels learn their plane at plan time:
  * liship_csr_plan_strip_rows).  0: the natural workgroup order.  An order of the workgroups only: the bits cannot depend on it. */

@@ -177,7 +177,6 @@ _LISHIP = {
     "liship_ell_diagonal_f64": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp]),
     "liship_dia_diagonal_f64": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp]),
     "liship_spmv_formats_set_plane": (_ci, [_ci]),
-    "liship_stream_yardstick": (_ci, [C.c_longlong, _vp, _vp, _vp, _vp]),
     "liship_ell_scan_band": (_ci, [_ci, _ci, _vp, _vp, _vp]),
     "liship_spmv_csr_transposed_chunked_f64": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_bsr_to_rows": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

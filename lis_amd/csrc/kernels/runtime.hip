@@ -255,40 +255,3 @@ extern "C" int liship_poisson3d_rhs(int l, int m, int n, int is, int ie, double 
     LAUNCH_CHECK();
     return 0;
 }
-
-// ------------------------------------------------------------------------------------------------ the box's own streaming yardstick
-// What THIS GPU sustains on the access mix of a CSR product with nothing to compute: two read streams (16 B values, 8 B index pairs: 12 B per "non-zero") through nt loads,
-// 8 B of nt store per 7 "non-zeros" -- 13 B read per B written, persistent workgroups, four pairs in flight per lane.  bench.py times it beside the headline: the SpMV
-// kernels are priced against 8 TB/s (the contract), and this says how much of the distance to 8 TB/s no kernel on this box can close (boxes differ by 8 %).
-namespace {
-template <int UNROLL>
-__global__ __launch_bounds__(256) void stream_yardstick_kernel(const double *__restrict__ val, const int *__restrict__ idx, double *__restrict__ y, long long npairs, double *__restrict__ sink)
-{
-    const long long stride = (long long)gridDim.x * 256 * UNROLL;
-    double acc = 0.0; int iacc = 0;
-    for (long long base = (long long)blockIdx.x * 256 * UNROLL + threadIdx.x; base < npairs; base += stride) {
-        v2f64 v[UNROLL]; v2i32 c[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            long long p = base + (long long)u * 256; if (p >= npairs) p = npairs - 1;
-            v[u] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(val) + p);
-            c[u] = __builtin_nontemporal_load(reinterpret_cast<const v2i32 *>(idx) + p);
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) { acc += v[u].x + v[u].y; iacc += c[u].x ^ c[u].y; }
-        const long long row0 = (base - threadIdx.x) * 2 / 7;           // 8 B per 7 non-zeros: 2 * 256 * UNROLL non-zeros per iteration
-        if ((int)threadIdx.x < (2 * 256 * UNROLL) / 7) __builtin_nontemporal_store(acc, y + row0 + threadIdx.x);
-    }
-    if (acc == 1.2345 && iacc == 77) sink[0] = acc;                     // (keeps the loads alive)
-}
-}
-// one pass over nnz "non-zeros" (val: nnz doubles, idx: nnz ints, y: nnz / 7 + 1024 doubles, all in HBM, contents irrelevant); bytes moved = 12 nnz + 8 (nnz / 7)
-extern "C" int liship_stream_yardstick(long long nnz, const double *val, const int *idx, double *y, void *stream)
-{
-    if (nnz < 2 || !val || !idx || !y) return LISHIP_ERR_ARG;
-    static double *sink = nullptr;
-    if (!sink) HIP_TRY(hipMalloc(&sink, sizeof(double)));
-    stream_yardstick_kernel<4><<<2048, 256, 0, as_stream(stream)>>>(val, idx, y, nnz / 2, sink);
-    LAUNCH_CHECK();
-    return 0;
-}

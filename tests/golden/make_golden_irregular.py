@@ -6,6 +6,9 @@ SuiteSparse Queen_4147 itself is neither in the reference tree nor fetchable her
             up to 81 per row, symmetric, diagonally dominant (the block-local-columns kernel serves it)
   tail      orc.heavy_tail(30000): Pareto row lengths 1 .. 9000 (mean ~25, rows longer than the LDS stage), random
             columns, non-symmetric, diagonally dominant (the products kernel and its long-row passes serve it)
+  mesh_60k  orc.unstructured_mesh(60000) (round 6): an unstructured 3-D mesh, one unknown per node, ragged rows of 7 .. 30 entries,
+            varying coefficients, symmetric positive definite -- no row patterns, no blocks, no constant values: the class none of the
+            plan's special forms catch (the row-gather kernel on the reference's own arrays serves it)
 Dev container only: oracle/_ref (Lis 2.1.11 from /root/reference/src, 1 OpenMP thread) through lis_matvec / lis_solve, with
 b = A * x_true as test/test1.c builds it in rhs mode 2 (test1.c:138-139), but with x_true = cos(0.01 i) + 1.25 instead of 1: the
 rows of fem3 sum to 1, so b = A*1 = 1 would be solved in one iteration.  Stored per case: iteration count,
@@ -29,6 +32,7 @@ import orc     # noqa: E402
 SOLVES = {
     "fem3_22": ("-i gmres -restart 30 -p none", "-i gmres -restart 30 -p jacobi", "-i bicgstab -p none", "-i cg -p jacobi", "-i bicg -p none"),
     "tail": ("-i gmres -restart 30 -p none", "-i gmres -restart 30 -p jacobi", "-i bicgstab -p jacobi", "-i bicg -p jacobi"),
+    "mesh_60k": ("-i gmres -restart 30 -p jacobi", "-i bicgstab -p jacobi", "-i cg -p jacobi", "-i bicg -p jacobi"),
 }
 
 
@@ -36,6 +40,7 @@ def matrices():
     ptr, idx, val, _ = orc.fem3(22)
     yield "fem3_22", ptr, idx, val
     yield ("tail",) + orc.heavy_tail(30000)
+    yield ("mesh_60k",) + orc.unstructured_mesh(60000)
 
 
 def fingerprint(ptr, idx, val):

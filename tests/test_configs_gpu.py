@@ -43,6 +43,8 @@ def lib():
 def _matrix(name):
     if name == "fem3_22":
         return orc.fem3(22)[:3]
+    if name == "mesh_60k":            # round 6: an unstructured 3-D mesh, one unknown per node, ragged rows of 7 .. 30 entries, varying coefficients: none of the plan's special forms applies
+        return orc.unstructured_mesh(60000)
     return orc.heavy_tail(30000)
 
 
@@ -53,7 +55,7 @@ def _sha(*arrays):
     return h.hexdigest()
 
 
-@pytest.mark.parametrize("name", ["fem3_22", "tail"])
+@pytest.mark.parametrize("name", ["fem3_22", "tail", "mesh_60k"])
 def test_config4_class_product_has_the_reference_bits(lib, name):
     ptr, idx, val = _matrix(name)
     g = GOLD[name]
@@ -63,7 +65,12 @@ def test_config4_class_product_has_the_reference_bits(lib, name):
     A = lisdrv.make_csr(lib, ptr, idx, val)
     lib.dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
     listed = lib.dll.lis_amd_matrix_local_columns(A)
-    assert (listed > 0) == (name == "fem3_22")          # the FEM pattern runs on block-local columns, random columns cannot
+    if name == "mesh_60k":                               # none of the plan's derived forms: the product streams the reference's own arrays
+        for q in ("lis_amd_matrix_index_codes", "lis_amd_matrix_row_patterns", "lis_amd_matrix_value_records", "lis_amd_matrix_marching"):
+            getattr(lib.dll, q).argtypes = [capi.PM]
+            assert getattr(lib.dll, q)(A) == 0, q
+    else:
+        assert (listed > 0) == (name == "fem3_22")      # the FEM pattern runs on block-local columns, random columns cannot
     yref = orc.spmv_csr(ptr, idx, val, x)
     if name == "tail":                                   # rows of up to 9000 entries: the default adds what lies beyond the LDS stage by a tree -- the reference's value to
         y = lisdrv.matvec(lib, A, x)                     # rounding; LIS_AMD_LONG_ROW_CHAIN=1 (the switch below) is the mode that carries its bits
@@ -82,7 +89,7 @@ def test_config4_class_product_has_the_reference_bits(lib, name):
 
 def _same_through_the_other_formats(lib, A, name, ptr, idx, val, x, y, n):
     # the same through every storage format (conversion on the host, product on the GPU)
-    for fmt in ("csc", "ell", "jad", "bsr") if name == "fem3_22" else ("csc", "jad"):
+    for fmt in ("csc", "ell", "jad", "bsr") if name == "fem3_22" else ("csc", "ell", "jad") if name == "mesh_60k" else ("csc", "jad"):
         B = lisdrv.convert(lib, A, fmt, 3, 3)
         yb = lisdrv.matvec(lib, B, x)
         if fmt in ("csc", "jad"):                        # these add a row's terms in another order: compare with their own oracle
@@ -98,7 +105,7 @@ def _same_through_the_other_formats(lib, A, name, ptr, idx, val, x, y, n):
         lib.lis_matrix_destroy(B)
 
 
-@pytest.mark.parametrize("name,opts", [(n, o) for n in ("fem3_22", "tail") for o in GOLD[n]["solves"]])
+@pytest.mark.parametrize("name,opts", [(n, o) for n in ("fem3_22", "tail", "mesh_60k") for o in GOLD[n]["solves"]])
 def test_config4_class_solvers_need_the_reference_iteration_counts(lib, name, opts):
     ptr, idx, val = _matrix(name)
     n = len(ptr) - 1
@@ -545,3 +552,61 @@ def test_bsr_row_form_gives_a_lane_a_block_row(lib, bs, G):
         lib.lis_matrix_destroy(B)
     finally:
         lib.dll.lis_amd_set_residency(0)
+
+
+def test_config4_matrix_market_file_hook(lib):
+    """The real-matrix hook (round 6): LIS_AMD_BENCH_MTX=/path/file.mtx -- SuiteSparse's Queen_4147.mtx when somebody has it, any Matrix Market file otherwise -- goes
+    through lis_input -> lis_matvec -> GMRES(30) / BiCGSTAB / CG + Jacobi here and in bench.py's config4 leg.  Without the variable the reference's own test/testmat.mtx
+    (tests/golden/mm) stands in, so the hook itself is always exercised.  When oracle/_ref travelled with the snapshot the same file runs through the reference for the
+    expected sha256 of y = A x (reader order AND summation order must both be the reference's) and for the iteration counts; without it the oracle's CSR loop on the arrays
+    lis_input produced is the check.  Then the same file through bench.config4_leg."""
+    import hashlib
+    import bench
+    given = os.environ.get("LIS_AMD_BENCH_MTX")
+    path = given or os.path.join(HERE, "golden", "mm", "testmat.mtx")
+    assert os.path.exists(path), path
+
+    def run(L, threads_note):
+        A, b, x0 = capi.PM(), capi.PV(), capi.PV()
+        assert L.lis_matrix_create(capi.LIS_COMM_WORLD, C.byref(A)) == 0
+        assert L.lis_vector_create(capi.LIS_COMM_WORLD, C.byref(b)) == 0 and L.lis_vector_create(capi.LIS_COMM_WORLD, C.byref(x0)) == 0
+        assert L.lis_input(A, b, x0, path.encode()) == 0
+        n = A.contents.n
+        xs = np.cos(np.arange(n) * 0.01) + 1.25
+        y = lisdrv.matvec(L, A, xs)
+        rhs = lisdrv.matvec(L, A, np.ones(n))
+        out = {"n": n, "nnz": A.contents.nnz, "y_sha256": hashlib.sha256(y.tobytes()).hexdigest(), "y": y, "solves": {}}
+        for opts in ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi"):
+            r = lisdrv.solve(L, A, rhs, opts + " -tol 1e-12 -maxiter 2000 -print none")
+            out["solves"][opts] = {"iter": r["iter"], "status": r["status"], "resid": r["resid"]}
+        arrays = lisdrv.matrix_arrays(A) if L is lib else None
+        L.lis_matrix_destroy(A)
+        return out, arrays
+    got, arrays = run(lib, "")
+    if os.path.exists(orc.REF_SO):
+        ref = lisdrv.open_lib(orc.REF_SO, threads=1)
+        want, _ = run(ref, "1 thread")
+        assert (got["n"], got["nnz"]) == (want["n"], want["nnz"])
+        assert got["y_sha256"] == want["y_sha256"], "y = A x differs from the reference's for this file"
+        for opts, w in want["solves"].items():
+            g = got["solves"][opts]
+            assert g["status"] == w["status"], (opts, g, w)
+            if w["status"] == 0:
+                solver = opts.split()[1]
+                assert abs(g["iter"] - w["iter"]) <= max(SLACK[solver], w["iter"] // 50), (opts, g["iter"], w["iter"])
+    else:
+        xs = np.cos(np.arange(got["n"]) * 0.01) + 1.25
+        assert np.array_equal(got["y"], orc.spmv_csr(arrays["ptr"], arrays["index"], arrays["value"], xs))
+    # ... and the same file through bench.py's leg
+    os.environ["LIS_AMD_BENCH_MTX"] = path
+    lib.dll.lis_amd_set_residency(1)
+    try:
+        leg = bench.config4_leg(lib, np, C, reps=5)
+    finally:
+        lib.dll.lis_amd_set_residency(0)
+        if given is None:
+            del os.environ["LIS_AMD_BENCH_MTX"]
+    assert "error" not in leg, leg.get("error")
+    assert leg["stand_in"] is False and leg["n"] == got["n"] and leg["nnz"] == got["nnz"] and leg["y_sha256"] == got["y_sha256"]
+    assert leg["spmv_ms"] > 0 and 0 < leg["contract_frac"] and set(leg["solves"]) >= set(got["solves"])
+    print(json.dumps({k: v for k, v in leg.items() if k != "solves"}))

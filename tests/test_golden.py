@@ -88,10 +88,10 @@ IRR = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "irregula
 
 
 def _irr_matrix(name):
-    return orc.fem3(22)[:3] if name == "fem3_22" else orc.heavy_tail(30000)
+    return orc.fem3(22)[:3] if name == "fem3_22" else orc.unstructured_mesh(60000) if name == "mesh_60k" else orc.heavy_tail(30000)
 
 
-@pytest.mark.parametrize("name", ["fem3_22", "tail"])
+@pytest.mark.parametrize("name", ["fem3_22", "tail", "mesh_60k"])
 def test_irregular_fixture_oracle_product_and_counts(name):
     """the generators still produce the matrices the fixture was made from, and the oracle reproduces what the reference
     returned for them: the bits of y = A*x and -- same arithmetic at one thread -- the exact iteration counts"""

@@ -127,7 +127,11 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A)
 	if (d->t_ready) return LIS_SUCCESS;
 	LISCHK(lisd_mat_ready(A));
 	if (!(A->matrix_type == LIS_MATRIX_CSR && d->type == LIS_MATRIX_CSR)) LISCHK(lisp_fill_matrix(A));   /* the host arrays are read below (and handed to the runtime) */
-	const LIS_INT type = A->matrix_type, n = A->n, np = A->np;
+	const LIS_INT type = A->matrix_type, n = A->n;
+	/* rows of A^T = local columns.  BSR in a multi-rank job: the ghost block columns start on a fresh block column, i.e. pad entries behind the owned ones
+	 * (lis_matrix_bsr.c:425-428; the halo lands at x[n + pad ...), lis_comm.c), so the ghost rows of A^T reach np + pad -- with np alone the walk dropped the
+	 * contributions to the last `pad` ghosts (round 6: found by the 3 x 3 blocks of the split multi-rank test; square 2 x 2 blocks of an even slab have pad 0) */
+	const LIS_INT np = (lisg.nprocs > 1 && type == LIS_MATRIX_BSR) ? A->np + A->pad : A->np;
 	d->t_rows = np;
 	if (split) {
 		walk_t w;

@@ -305,6 +305,21 @@ def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
         assert np.all(np.abs(y - yg[is_:ie]) <= 1e-13 * scale_y), (name, fmt)
         if fmt in ("ell", "jad"):
             assert np.array_equal(y, yg[is_:ie]), (name, fmt)
+        # A^T x through the same format: the local transposed rows + the reverse halo (ghost sums back to their owners)
+        assert lib.lis_matvech(B, vb2, vy2) == 0, (name, fmt)
+        assert lib.lis_vector_get_values(vy2, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
+        assert np.all(np.abs(y - yt[is_:ie]) <= 1e-13 * scale), (name, fmt, "A^T x")
+        if fmt == "bsr":                                               # 3 x 3 blocks: n % 3 != 0 on some rank puts the ghost block columns `pad` entries behind the owned ones
+            B3 = lisdrv.convert(lib, A, "bsr", 3, 3)
+            vb3, vy3 = lisdrv.new_vector(lib, B3, None), lisdrv.new_vector(lib, B3, None)
+            assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(xg[is_:ie]).ctypes.data_as(capi.P_DBL), vb3) == 0
+            assert lib.lis_matvech(B3, vb3, vy3) == 0, (name, "bsr3")
+            assert lib.lis_vector_get_values(vy3, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
+            assert np.all(np.abs(y - yt[is_:ie]) <= 1e-13 * scale), (name, "bsr 3x3", "A^T x")
+            assert lib.lis_matvec(B3, vb3, vy3) == 0 and lib.lis_vector_get_values(vy3, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
+            assert np.all(np.abs(y - yg[is_:ie]) <= 1e-13 * scale_y), (name, "bsr 3x3", "A x")
+            lib.lis_vector_destroy(vb3); lib.lis_vector_destroy(vy3); lib.lis_matrix_destroy(B3)
+            assert lib.lis_matvec(B, vb2, vy2) == 0 and lib.lis_vector_get_values(vy2, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
         if fmt == "bsr":                                               # the block rows without ghost blocks under the halo, the others behind it: the bits of exchange-first
             y_overlapped = y.copy()
             lib.dll.lis_amd_set_overlap(0)
@@ -377,7 +392,7 @@ def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
         assert lib.lis_matvec(B, vb2, vy2) == 0 and lib.lis_vector_get_values(vy2, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
         assert np.all(np.abs(y - yg[is_:ie]) <= 1e-13 * scale_y), (name, "split A x")
         lib.lis_vector_destroy(vb2); lib.lis_vector_destroy(vy2); lib.lis_matrix_destroy(B)
-        for opts in ("-i bicg -p none -scale jacobi -storage bsr", "-i bicr -p none -scale jacobi -storage bsr -storage_block 3"):
+        for opts in ("-i bicg -p none -scale jacobi -storage bsr", "-i bicg -p none -scale jacobi -storage bsr -storage_block 3"):
             B = lisdrv.convert(lib, A, "csr")
             vb2, vs2 = lisdrv.new_vector(lib, B, None), lisdrv.new_vector(lib, B, None)
             assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(bg[is_:ie]).ctypes.data_as(capi.P_DBL), vb2) == 0

@@ -11,7 +11,7 @@ SuiteSparse Queen_4147 itself is neither in the reference tree nor fetchable her
             plan's special forms catch (the row-gather kernel on the reference's own arrays serves it)
 Dev container only: oracle/_ref (Lis 2.1.11 from /root/reference/src, 1 OpenMP thread) through lis_matvec / lis_solve, with
 b = A * x_true as test/test1.c builds it in rhs mode 2 (test1.c:138-139), but with x_true = cos(0.01 i) + 1.25 instead of 1: the
-rows of fem3 sum to 1, so b = A*1 = 1 would be solved in one iteration.  Stored per case: iteration count,
+rows of fem3 sum to 1, so b = A*1 = 1 would be solved in one iteration.  Stored per case: iteration count (at 1 thread, and at 2 / 4 / 8 / 16 threads -- the spread the reference's own chunked sums give),
 status, final relative residual, the first residual-history entries, and a checksum of y = A*x.
     python tests/golden/make_golden_irregular.py
 """
@@ -50,8 +50,33 @@ def fingerprint(ptr, idx, val):
     return h.hexdigest()
 
 
+def counts_at(threads):
+    """iteration counts of every case with the reference's OpenMP team at `threads` (its sums are formed per thread chunk: the counts move with the team size)"""
+    ref = lisdrv.open_lib(orc.REF_SO, threads=threads)
+    out = {}
+    for name, ptr, idx, val in matrices():
+        n = len(ptr) - 1
+        A = lisdrv.make_csr(ref, ptr, idx, val)
+        b = orc.spmv_csr(ptr, idx, val, np.cos(np.arange(n) * 0.01) + 1.25)
+        out[name] = {}
+        for opts in SOLVES[name]:
+            res = lisdrv.solve(ref, A, b, opts + " -tol 1e-12 -maxiter 2000 -print none")
+            out[name][opts] = [int(res["iter"]), int(res["status"])]
+    return out
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--threads":
+        fd = os.dup(1); os.dup2(2, 1)                                   # (the reference prints its banners on stdout)
+        res = counts_at(int(sys.argv[2]))
+        os.write(fd, (json.dumps(res) + "\n").encode())
+        return
     orc.build()
+    import subprocess
+    spread = {}
+    for t in (2, 4, 8, 16):
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--threads", str(t)], capture_output=True, text=True, check=True)
+        spread[t] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     ref = lisdrv.open_lib(orc.REF_SO, threads=1)
     out = {"_source": "Lis 2.1.11 compiled from /root/reference by oracle/Makefile, 1 OpenMP thread, b = A*(cos(0.01 i) + 1.25), x0 = 0, tol 1e-12 "
                       "(tests/golden/make_golden_irregular.py)"}
@@ -70,7 +95,10 @@ def main():
         for opts in SOLVES[name]:
             res = lisdrv.solve(ref, A, b, opts + " -tol 1e-12 -maxiter 2000 -print mem")
             case["solves"][opts] = {"iter": int(res["iter"]), "status": int(res["status"]), "resid": float(res["resid"]),
-                                    "rhistory_head": [float(v) for v in res["rhistory"][:6]]}
+                                    "rhistory_head": [float(v) for v in res["rhistory"][:6]],
+                                    # the reference's own counts with 2 / 4 / 8 / 16 OpenMP threads (all converged): the spread its chunked sums give
+                                    "iter_by_threads": dict({"1": int(res["iter"])}, **{str(t): spread[t][name][opts][0] for t in spread})}
+            assert all(spread[t][name][opts][1] == res["status"] for t in spread)
             print(name, opts, res["iter"], res["status"], res["resid"])
         out[name] = case
     json.dump(out, open(os.path.join(HERE, "irregular_golden.json"), "w"), indent=1)

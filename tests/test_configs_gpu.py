@@ -121,7 +121,10 @@ def test_config4_class_solvers_need_the_reference_iteration_counts(lib, name, op
     solver = opts.split()[1]
     assert res["status"] == want["status"] == 0 and res["resid"] <= 1e-12
     slack = SLACK[solver] if want["iter"] < 200 else max(SLACK[solver], want["iter"] // 50)    # 2 % on the 1225-iteration GMRES run
-    assert abs(res["iter"] - want["iter"]) <= slack, (res["iter"], want["iter"])
+    # the reference's own count moves with its OpenMP team size where the residual crosses the tolerance flatly (mesh_60k: BiCGSTAB 73 / 76 / 79 / 75 / 78 and CG 119 / 120 /
+    # 118 / 118 / 118 at 1 / 2 / 4 / 8 / 16 threads): the fixture holds that spread, and a count is right when it lies inside it (widened by the solver's usual slack)
+    spread = list(want.get("iter_by_threads", {"1": want["iter"]}).values())
+    assert min(spread) - slack <= res["iter"] <= max(spread) + slack, (res["iter"], want["iter"], spread)
     k = min(len(res["rhistory"]), len(want["rhistory_head"]))
     np.testing.assert_allclose(res["rhistory"][:k], want["rhistory_head"][:k], rtol=1e-9)
     err = np.abs(res["x"] - x_true).max() / np.abs(x_true).max()

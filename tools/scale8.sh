@@ -18,16 +18,10 @@ for MODE in weak strong; do
   : > "$OUT/scale8_$MODE.jsonl"
   for N in 1 2 4 8; do
     [ "$N" -gt "$MAXN" ] && continue
-    PORT=$((29500 + RANDOM % 2000))
     echo "== $MODE scaling, $N GPU(s)" >&2
-    if [ "$N" -eq 1 ]; then
-      timeout 1800 python bench.py --gpus 1 --steps "$STEPS" --warmup 5 --solver-iters "$ITERS" --no-extras --no-live-traffic --no-cpu-baseline \
-        2> "$OUT/scale8_${MODE}_$N.err" | grep '^{' >> "$OUT/scale8_$MODE.jsonl"
-    else
-      timeout 1800 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port "$PORT" \
-        bench.py --gpus "$N" --steps "$STEPS" --warmup 5 --scaling "$MODE" --solver-iters "$ITERS" --no-extras --no-live-traffic --no-cpu-baseline \
-        2> "$OUT/scale8_${MODE}_$N.err" | grep '^{' >> "$OUT/scale8_$MODE.jsonl"
-    fi
+    # the driver's own entry point: `python bench.py --gpus N` starts its N ranks itself (one per GPU, torch.distributed.run on 127.0.0.1)
+    timeout 1800 python bench.py --gpus "$N" --steps "$STEPS" --warmup 5 --scaling "$MODE" --solver-iters "$ITERS" --no-extras --no-live-traffic --no-cpu-baseline \
+      2> "$OUT/scale8_${MODE}_$N.err" | grep '^{' >> "$OUT/scale8_$MODE.jsonl"
     echo "   exit ${PIPESTATUS[0]}" >&2
   done
 done

@@ -30,12 +30,15 @@ for path in sys.argv[1:]:
              "halo_bytes_per_interior_rank_per_step": m.get("halo_bytes_per_interior_rank_per_step"), "halo_ms_alone": m.get("halo_ms_per_step"),
              "ms_per_step_no_overlap": m.get("ms_per_step_no_overlap"), "halo_communicator": m.get("halo_communicator"),
              "cg_jacobi_iters_per_sec": (k.get("cg_jacobi") or {}).get("iters_per_sec"), "bicgstab_iters_per_sec": (k.get("bicgstab_none") or {}).get("iters_per_sec"),
-             "contract_form_value": (l.get("contract_form") or {}).get("value"), "contract_form_frac": ((l.get("contract_form") or {}).get("roofline") or {}).get("frac"),
+             "roofline_frac": (l.get("roofline") or {}).get("frac"),
+             "structured_fast_path_value": (l.get("structured_fast_path") or {}).get("value"),
+             "structured_fast_path_cg_jacobi_iters_per_sec": (((l.get("structured_fast_path") or {}).get("krylov") or {}).get("cg_jacobi") or {}).get("iters_per_sec"),
              "efficiency": round(l["value"] / (n * base["value"]), 4) if base else None}
         if pred and mode in pred and str(n) in pred[mode]:
             q = pred[mode][str(n)]
             p["predicted"] = q
-            for key, mine in (("value", "value"), ("cg_jacobi_iters_per_sec", "cg_jacobi_iters_per_sec"), ("bicgstab_iters_per_sec", "bicgstab_iters_per_sec")):
+            # (the prediction of round 5 was made for the plan's default form of this matrix -- round 6's `structured_fast_path`; the headline is the reference layout)
+            for key, mine in (("value", "structured_fast_path_value"), ("cg_jacobi_iters_per_sec", "structured_fast_path_cg_jacobi_iters_per_sec")):
                 if q.get(key) and p.get(mine):
                     p[f"{mine}_over_predicted"] = round(p[mine] / q[key], 3)
         pts.append(p)

@@ -872,7 +872,7 @@ def config4_leg(lib, np, C, reps=50):
     fetched here: tests/golden/gen_queen_class.c writes a 3-dof mesh of its size (4.1 M rows, 2.9e8 non-zeros, node numbers scrambled inside runs of 1024) as a symmetric
     coordinate file on this box.  Reported: the reader, upload + plan, the product in the caller's numbering (contract_frac on 12 B per non-zero + 20 B per row; sha256 of
     y for a check against any other implementation), GMRES(30) / BiCGSTAB / CG + Jacobi / BiCG with iterations, it/s and time to solution.  The renumbered form
-    (liship_csr_plan_reorder) is LAZY since round 6 -- none of these first solves triggers it; its cost (`reorder_s`, a host walk), its gain and the break-even
+    (liship_csr_plan_reorder) is LAZY since round 6 -- none of these first solves triggers it; its cost (`reorder_s`: the numbering found on the device, P A P^T and its plan built in HBM), its gain and the break-even
     iteration count are measured beside them by asking for it explicitly.  Host-clock ms per product over `reps` calls behind one synchronize; never fatal: an error string instead."""
     import hashlib
     path, made = os.environ.get("LIS_AMD_BENCH_MTX"), False
@@ -931,7 +931,7 @@ def config4_leg(lib, np, C, reps=50):
                     "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),
                     "contract_bytes": 12 * nnz + 20 * n, "contract_frac": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4),
                     "x": "x_i = cos(0.01 i) + 1.25", "y_sha256": hashlib.sha256(yh.tobytes()).hexdigest(),
-                    "numbering": "the caller's (the renumbered form is lazy: lis_amd_set_reorder_after, default 10000 products)"})
+                    "numbering": "the caller's (the renumbered form is lazy: lis_amd_set_reorder_after, default 4096 products)"})
         rhs = capi.PV()
         assert lib.lis_vector_duplicate(A, C.byref(rhs)) == 0 and lib.lis_matvec(A, ones, rhs) == 0          # b = A*1 (test/test1.c:138-139)
         SOLVES = ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi", "-i bicg -p none")       # (BiCG: Lis's default solver, lis_solver.c:242)
@@ -970,11 +970,11 @@ def config4_leg(lib, np, C, reps=50):
                 gain = 1.0 / base["iters_per_sec"] - 1.0 / ren["solves"]["-i cg -p jacobi"]["iters_per_sec"]
                 ren["cg_jacobi_seconds_saved_per_iteration"] = round(gain, 7)
                 ren["break_even_iterations"] = int(ren["reorder_s"] / gain) if gain > 0 else None
-                ren["policy"] = ("lazy: the first lis_solve that finds 10000 products served by the plan builds it (lis_amd_set_reorder_after / LIS_AMD_REORDER_AFTER; 0 = at plan time); "
+                ren["policy"] = ("lazy: the first lis_solve that finds 4096 products served by the plan builds it (lis_amd_set_reorder_after / LIS_AMD_REORDER_AFTER; 0 = at plan time); "
                                  "single products always keep the caller's numbering")
             out["renumbered_form"] = ren
         finally:
-            dll.lis_amd_set_reorder_after(10000)
+            dll.lis_amd_set_reorder_after(4096)
         for v in (vx, vy, ones, rhs, b, x0):
             lib.lis_vector_destroy(v)
         lib.lis_matrix_destroy(A)

@@ -166,9 +166,10 @@ LIS_INT lis_amd_matrix_local_columns(LIS_MATRIX A);
 /* total length of those lists in the REORDERED form, when the plan renumbered rows and columns because the caller's numbering has no locality (liship.h:
  * liship_csr_plan_reorder; one rank, CSR with long rows; env LIS_AMD_NO_REORDER=1 keeps the caller's numbering); 0 when it did not; uploads A if needed */
 long long lis_amd_matrix_reordered(LIS_MATRIX A);
-/* WHEN the renumbered form is built: by the first lis_solve that finds A's HBM copy has served `products` products in the caller's numbering (default 10000; env
- * LIS_AMD_REORDER_AFTER).  The attempt is host work -- a Cuthill-McKee walk, +1.4 s and +3.5 GB of HBM on the Queen-class matrix -- that saves 0.1 ms per iteration there:
- * a program earns it back after ~13 000 iterations, and the first solves of most programs take 40-50.  0: at plan time (upload / assemble), the round-5 behaviour. */
+/* WHEN the renumbered form is built: by the first lis_solve that finds A's HBM copy has served `products` products in the caller's numbering (default 4096; env
+ * LIS_AMD_REORDER_AFTER).  Building it -- the numbering found on the device (breadth-first distances from landmarks, Morton keys, a radix sort: kernels/csr_order.hpp; rounds
+ * 4-5 walked the graph on the host), P A P^T and its plan in HBM -- costs 0.17 s and +3.5 GB on the Queen-class matrix and saves 0.06-0.1 ms per iteration there: a program
+ * earns it back after ~3000 iterations, and the first solves of most programs take 40-50.  0: at plan time (upload / assemble), the round-5 behaviour. */
 LIS_INT lis_amd_set_reorder_after(long long products);
 long long lis_amd_matrix_products_served(LIS_MATRIX A);      /* products A's current HBM copy has served (approximately: a fused product + dot that falls back counts twice) */
 /* the liship plan of A's HBM copy when it is served as CSR rows (for the liship_csr_plan_* queries of liship.h; owned by A), else NULL; uploads A if needed */

@@ -176,7 +176,7 @@ int  liship_spmv_csr_set_local_runs(int on);
 int  liship_spmv_csr_set_local_pairs(int on);
 /* Reordering (round 5): when the lists of a plan with block-local columns are long -- more than one listed column per `min_items_per_listed` non-zeros (0: the
  * default, 4) -- or a long-row plan could not have lists at all (more than 2048 distinct columns per row block): the signs of a numbering without locality -- the plan
- * renumbers rows and columns by a Cuthill-McKee walk of the matrix graph (on the host, at plan time: index[] is read back once), builds P A P^T in HBM (the same entries
+ * renumbers rows and columns by graph distances found on the device (breadth-first searches from 3-4 landmarks, Morton keys, a stable radix sort: csr_order.hpp; rounds 4-5: a Cuthill-McKee walk on the host), builds P A P^T in HBM (the same entries
  * in the same in-row order) with a plan of its own, and keeps it when that plan lists at most 3/4 of the columns.  Short rows (plans of the row-gather kernel, no lists):
  * the 128 B lines of x a row block touches are counted instead -- more than one per 4 entries starts the walk, at most half of them afterwards keeps its result.
  * WHO USES IT: liship_csr_plan_reordered_form hands P A P^T out as a matrix of its own, for callers that keep whole iterations in the new numbering (lis_solve).

@@ -512,8 +512,9 @@ static LIS_INT plan_try_reorder(liship_csr_plan_t plan, int n, const int *dptr, 
 	return LIS_SUCCESS;
 }
 /* LAZY renumbering (round 6): called by lis_solve before it looks for a renumbered form.  A CSR copy on one rank whose plan has served lisg.reorder_after products
- * in the caller's numbering gets the attempt once; what the attempt costs (the Cuthill-McKee walk on the host, P A P^T in HBM: +1.4 s and +3.5 GB on the
- * Queen-class matrix) is paid by a program that has shown it iterates long enough to earn it back (0.1 ms per iteration there), never by the first solves. */
+ * in the caller's numbering gets the attempt once; what the attempt costs (the numbering found on the device -- kernels/csr_order.hpp --, P A P^T and its plan built in HBM: +0.17 s and +3.5 GB on the
+ * Queen-class matrix; rounds 4-5 walked the graph on the host: 1.6 s) is paid by a program that has shown it iterates long enough to earn it back (0.06-0.1 ms per
+ * iteration there: ~3000 iterations), never by the first solves. */
 LIS_INT lisd_mat_lazy_reorder(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
@@ -550,7 +551,7 @@ static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, const int *dptr, co
 		if (rc && rc != 2) HIPCHK(rc);
 		/* lists that stay long say the numbering has no locality: rows and columns renumbered inside the plan (one rank: its row ranges follow the original order).
 		 * At plan time only when asked (LIS_AMD_REORDER_AFTER=0); by default the plan first serves lisg.reorder_after products in the caller's numbering
-		 * (lisd_mat_lazy_reorder): the walk is host work worth ~13 000 iterations of what it saves per iteration on the Queen-class matrix, and the solves
+		 * (lisd_mat_lazy_reorder): building the form costs ~3000 iterations of what it saves per iteration on the Queen-class matrix, and the solves
 		 * people time first take 40-50 */
 		if (!rc && reorder && !lisg.no_reorder && lisg.nprocs == 1 && dvalue && lisg.reorder_after == 0) LISCHK(plan_try_reorder(*plan, n, dptr, dindex, dvalue));
 	}

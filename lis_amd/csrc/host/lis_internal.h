@@ -136,7 +136,7 @@ typedef struct {
 	int no_marching;           /* LIS_AMD_NO_MARCHING=1: 7-point matrices with value records keep the gathering dominant-pattern kernel (round 3's headline kernel: A/B measurements) */
 	int no_team_kernels;       /* LIS_AMD_NO_TEAM_KERNELS=1: patterned rows of 8..32 entries and long BSR block rows keep the round-2 kernels (A/B measurements) */
 	double last_input_s, last_input_assemble_s;      /* lis_amd_last_input_times */
-	long long reorder_after;   /* LIS_AMD_REORDER_AFTER=K: the renumbered form of a plan is built by the first lis_solve that finds K products served (default 10000; 0: at plan time) */
+	long long reorder_after;   /* LIS_AMD_REORDER_AFTER=K: the renumbered form of a plan is built by the first lis_solve that finds K products served (default 4096; 0: at plan time) */
 	int plain_malloc;          /* LIS_AMD_PLAIN_MALLOC=1 / lis_amd_set_matrix_pages(0): lis_matrix_malloc_<fmt> returns malloc memory (free()-compatible, never protected, edits not seen) */
 	int no_reorder;            /* LIS_AMD_NO_REORDER=1: long-row CSR plans keep the caller's numbering whatever their lists look like (A/B measurements) */
 	int no_local_columns;      /* LIS_AMD_NO_LOCAL_COLUMNS=1: long-row CSR products keep the 4 B column indices (A/B measurements) */

@@ -270,7 +270,7 @@ LIS_INT lis_initialize(int *argc, char **argv[])
 		r = getenv("LIS_AMD_PLAIN_MALLOC");            /* lis_matrix_malloc_<fmt> hands out malloc memory (a program that free()s the arrays or read()s into them) */
 		lisg.plain_malloc = (r && r[0] == '1');
 		r = getenv("LIS_AMD_REORDER_AFTER");           /* products a plan serves before a lis_solve builds its renumbered form (0: at plan time, the round-5 behaviour) */
-		lisg.reorder_after = r ? atoll(r) : 10000;
+		lisg.reorder_after = r ? atoll(r) : 4096;
 		if (lisg.reorder_after < 0) lisg.reorder_after = 0;
 		r = getenv("LIS_AMD_REORDER_PRODUCTS");        /* single products of renumbered long-row plans take the renumbered form too (gather of x, scattered store of y): opt-in */
 		if (r && r[0] == '1') (void)liship_spmv_csr_set_reorder(2);

@@ -240,7 +240,7 @@ struct liship_csr_plan_s {
     int *dcol;           // device, the lists (each padded to a multiple of 4 entries)
     int *doff;           // device, nblocks + 1 offsets into dcol; an empty list = the block reads the 4 B indices
     long long ndcol;     // entries of dcol
-    // Reordered form (liship_csr_plan_reorder): P A P^T in HBM -- the same entries in the same in-row order, rows and columns renumbered by a Cuthill-McKee walk -- with a
+    // Reordered form (liship_csr_plan_reorder): P A P^T in HBM -- the same entries in the same in-row order, rows and columns renumbered by landmark distances (csr_order.hpp) -- with a
     // block-local plan of its own.  The product gathers x into the new numbering, walks the renumbered rows and stores row r at y[r_perm[r]]: every row sum is the sum the
     // original row forms, term by term.
     liship_csr_plan_s *inner = nullptr;
@@ -1740,12 +1740,14 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     p->xcap = ndmost <= 1024 ? 1024 : (ndmost <= 1536 && p->geom == LOCAL_GEOM4) ? 1536 : 2048;
     return 0;
 }
+#include "csr_order.hpp"
 // ---------------------------------------------------------------------------------------------- reordering (round 5)
 // A mesh whose nodes are numbered without locality (the Queen-class stand-in: numbers permuted at random inside runs of 1024 nodes) gives every row block ~2.3 x the
 // distinct columns the same mesh has in a local numbering, each on a cache line of its own: the block-local kernel then spends more L1 <-> L2 requests on x than on the
 // matrix (profiles/r04_queen_class_pmc.txt: 30 M of 55.7 M per product) and runs at 0.65 ms where the naturally numbered mesh takes 0.52.  The product does not care in
-// which order rows are WALKED or what a column is CALLED -- a row sum is its own terms in their stored order -- so the plan may renumber: a Cuthill-McKee walk of the
-// matrix graph on the host (breadth first, the children of a vertex in index order: the unknowns of a node stay neighbours), P A P^T built once in HBM.
+// which order rows are WALKED or what a column is CALLED -- a row sum is its own terms in their stored order -- so the plan may renumber: rounds 4-5 by a Cuthill-McKee
+// walk of the matrix graph on the host (1.4-1.6 s there), round 6 by landmark distances on the device (csr_order.hpp: breadth-first searches, Morton keys, a stable
+// radix sort -- the same locality, no host walk, index[] never leaves HBM), P A P^T built once in HBM.
 namespace {
 __global__ void csr_reorder_inverse(int n, const int *__restrict__ perm, int *__restrict__ inv)
 {
@@ -1768,37 +1770,6 @@ void csr_reorder_rows(int n, const int *__restrict__ ptr, const int *__restrict_
     }
 }
 
-// Cuthill-McKee on the host: order[] = the vertices in the order a breadth-first walk meets them, the unvisited neighbours of a vertex appended in index order; the
-// first component starts from the far end of a walk that started at vertex 0, every other one at its lowest index.  false: a column outside [0, n) (ghost columns).
-bool cuthill_mckee(int n, const int *ptr, const int *idx, int *order)
-{
-    std::vector<unsigned char> seen((size_t)n, 0);
-    std::vector<int> kids;
-    int head = 0, tail = 0;
-    bool ok = true;
-    auto walk = [&](int start) {
-        seen[start] = 1; order[tail++] = start;
-        while (head < tail) {
-            const int u = order[head++];
-            kids.clear();
-            for (int k = ptr[u]; k < ptr[u + 1]; k++) {
-                const int c = idx[k];
-                if (c < 0 || c >= n) { ok = false; continue; }
-                if (!seen[c]) { seen[c] = 1; kids.push_back(c); }
-            }
-            if (kids.size() > 1) std::sort(kids.begin(), kids.end());
-            for (int c : kids) order[tail++] = c;
-        }
-    };
-    if (n <= 0) return true;
-    walk(0);
-    const int far_end = order[tail - 1];
-    for (int i = 0; i < tail; i++) seen[order[i]] = 0;
-    head = tail = 0;
-    walk(far_end);
-    for (int s = 0; s < n && ok; s++) if (!seen[s]) walk(s);
-    return ok && tail == n;
-}
 } // namespace
 
 // 128 B lines of x (columns >> 4) the row blocks of a plan touch, summed over the blocks; -1: could not be counted
@@ -1827,7 +1798,7 @@ extern "C" long long liship_csr_plan_reordered(liship_csr_plan_t p) { return (p 
 // Builds the reordered form when the plan keeps block-local columns AND its lists are long (more than one listed column per `min_items_per_listed` non-zeros: 4 by
 // default when 0 is passed) AND the renumbered matrix lists at most 3/4 of them; for short rows (the row-gather kernel) the 128 B lines of x a row block touches take
 // the lists' place (more than one per 4 entries; at most half of them afterwards).  Never an error when the matrix does not qualify; out of memory (2) leaves the plan
-// as it was.  Host work at plan time: index[] comes to the host once (4 B per non-zero), the walk visits every entry twice.
+// as it was.  The numbering is found in HBM (csr_order.hpp); the host sees ptr[] (4 B per row) and the permutation.
 static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, const int *hint, void *stream);
 extern "C" int liship_csr_plan_reorder(liship_csr_plan_t p, const int *ptr, const int *idx, const double *val, int min_items_per_listed, void *stream)
 {
@@ -1867,14 +1838,13 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
         if (lines_before < 0) return 0;                            // (could not count: leave the plan alone)
         if (lines_before * mi <= p->nnz) return 0;
     }
-    int *hptr = (int *)malloc(sizeof(int) * ((size_t)n + 1)), *hidx = hint ? nullptr : (int *)malloc(sizeof(int) * nnz), *order = (int *)malloc(sizeof(int) * (size_t)n);
+    int *hptr = (int *)malloc(sizeof(int) * ((size_t)n + 1)), *hidx = nullptr, *order = (int *)malloc(sizeof(int) * (size_t)n);
     int *hptr2 = (int *)malloc(sizeof(int) * ((size_t)n + 1));
     int *inv = nullptr;
     liship_csr_plan_s *in = nullptr;
-    hipError_t e = (hptr && (hint || hidx) && order && hptr2) ? hipSuccess : hipErrorOutOfMemory;
+    hipError_t e = (hptr && order && hptr2) ? hipSuccess : hipErrorOutOfMemory;
     bool keep = false, have_order = false;
-    if (e == hipSuccess) e = hipMemcpyAsync(hptr, ptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && !hint) e = hipMemcpyAsync(hidx, idx, sizeof(int) * nnz, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hptr, ptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, st);      // (row starts: 4 B per row; index[] stays in HBM)
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess && hint) {                                 // a permutation of 0 .. n-1, or nothing
         std::vector<unsigned char> seen((size_t)n, 0);
@@ -1883,7 +1853,7 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
             const int r = hint[i];
             if (r < 0 || r >= n || seen[r]) have_order = false; else { seen[r] = 1; order[i] = r; }
         }
-    } else if (e == hipSuccess) have_order = cuthill_mckee(n, hptr, hidx, order);
+    } else if (e == hipSuccess) have_order = order_dev::device_order(n, ptr, idx, p->products ? 4 : 3, order, st);      // long rows (dense neighbourhoods): four landmarks, short rows: three
     if (e == hipSuccess && have_order) {
         bool moved = false;
         hptr2[0] = 0;

@@ -185,7 +185,7 @@ def test_config4_queen_scale_through_the_matrix_market_reader(lib):
     t_gen = time.time() - t0
     lib.dll.lis_amd_set_residency(1)
     lib.dll.lis_amd_set_reorder_after.argtypes = [C.c_longlong]
-    lib.dll.lis_amd_set_reorder_after(0)          # the renumbered form at plan time (round 6: by default only after 10000 products, tests/test_lisapi_gpu.py): this test covers it at scale
+    lib.dll.lis_amd_set_reorder_after(0)          # the renumbered form at plan time (round 6: by default only after 4096 products, tests/test_lisapi_gpu.py): this test covers it at scale
     A, b, x0 = capi.PM(), capi.PV(), capi.PV()
     try:
         assert os.path.getsize(path) == g["file_bytes"]
@@ -258,7 +258,7 @@ def test_config4_queen_scale_through_the_matrix_market_reader(lib):
             json.dump(report, open(os.path.join(out_dir, "queen_class_run.json"), "w"), indent=1)
         print(json.dumps(report))
     finally:
-        lib.dll.lis_amd_set_reorder_after(10000)
+        lib.dll.lis_amd_set_reorder_after(4096)
         lib.dll.lis_amd_set_residency(0)
         lib.lis_matrix_destroy(A)
 

@@ -725,12 +725,12 @@ def _renumbered_solve_case(lib, ptr, idx, val, options):
     try:
         _renumbered_solve_case_body(lib, ptr, idx, val, options)
     finally:
-        dll.lis_amd_set_reorder_after(10000)
+        dll.lis_amd_set_reorder_after(4096)
 
 
 def test_renumbering_is_lazy_by_default(lib):
-    """Round 6: the renumbered form costs a host-side Cuthill-McKee walk (+1.4 s on the Queen-class matrix) that pays back after ~13 000 iterations, so by default a
-    plan first serves lis_amd_set_reorder_after() products (10000) in the caller's numbering and only the first lis_solve BEHIND them builds it.  Here with a
+    """Round 6: the renumbered form costs 0.17 s on the Queen-class matrix (numbering found on the device, P A P^T and its plan) and pays back after ~3000 iterations, so by default a
+    plan first serves lis_amd_set_reorder_after() products (4096) in the caller's numbering and only the first lis_solve BEHIND them builds it.  Here with a
     threshold of 40 products: the first solve (fewer products than that) runs in the caller's numbering and leaves no renumbered form, the one after the threshold
     runs renumbered -- the same counts (to the fold order of the sums) and the same solution, the oracle's bits for single products throughout."""
     from test_kernels_gpu import _scrambled_fem
@@ -762,7 +762,7 @@ def test_renumbering_is_lazy_by_default(lib):
         assert first["iter"] >= 20
         assert lib.lis_matrix_destroy(A) == 0
     finally:
-        dll.lis_amd_set_reorder_after(10000)
+        dll.lis_amd_set_reorder_after(4096)
 
 
 def _renumbered_solve_case_body(lib, ptr, idx, val, options):
@@ -813,7 +813,7 @@ def _renumbered_solve_case_body(lib, ptr, idx, val, options):
 def test_reordering_environment_switches(env, fused):
     """LIS_AMD_REORDER_AFTER=0: a badly numbered long-row matrix gets the renumbered form at plan time, for solves, and keeps its products in the caller's numbering
     (fused reductions stay); with LIS_AMD_REORDER_PRODUCTS=1 lis_matvec goes through P A P^T too (the oracle's bits either way); LIS_AMD_NO_REORDER=1: no renumbered
-    form at all; and the default (no variable: only behind 10000 products): none for a first short solve either"""
+    form at all; and the default (no variable: only behind 4096 products): none for a first short solve either"""
     import subprocess
     code = ("import sys, ctypes as C; sys.path[:0] = [%r, %r]\n"
             "import numpy as np, lis_amd, lisdrv, orc; from lis_amd import _capi as capi\n"

@@ -5,21 +5,23 @@
 // numbering is not a small bandwidth but LOCALITY: the rows of a row block should share their columns.  Graph distances give that without a serial walk:
 //
 //   1. level-synchronous breadth-first searches (one kernel launch per level, every vertex of the current level marks its unvisited neighbours: a benign race, all
-//      writers store the same level) from L landmarks chosen far apart -- a = the vertex farthest from vertex 0, b = farthest from a, c = farthest from {a, b}, d = farthest
-//      from {a, b, c} (ties: the smallest index), so the L distance fields d_a .. d_d are a coordinate system of the mesh;
+//      writers store the same level) from L landmarks chosen far apart -- a = the vertex farthest from vertex 0, b = farthest from a, c = farthest from {a, b}, and so on
+//      (ties: the smallest index), so the L distance fields are a coordinate system of the mesh;
 //   2. key(v) = the bit-interleaved (Morton) code of those distances: vertices with close keys are close in the graph;
 //   3. a stable LSD radix sort of (key, index) -- per-tile histograms, one scan, a stable scatter: deterministic, no atomics on the order -- gives the numbering.
 //
 // Measured on the CPU prototype (the scrambled 3-dof FEM mesh of the tests, listed columns per 4096-item row block, summed): caller's numbering 4.81 M, natural grid order
 // 1.92 M, reverse Cuthill-McKee 1.91 M, THIS with 4 landmarks 1.88 M (3 landmarks: 2.45 M); a 7-point grid numbered at random, 128 B lines of x per 2048-item row block:
-// 590 k -> 26 k with 3 landmarks (natural 24 k, RCM 23 k; 4 landmarks: 40 k).  So: 4 landmarks for long rows (dense, Chebyshev-like neighbourhoods), 3 for short ones.
+// 590 k -> 26 k with 3 landmarks (natural 24 k, RCM 23 k; 4 landmarks: 40 k).  At 527 k rows of the FEM mesh: caller's 13.4 M, natural 5.34 M, RCM 5.39 M, 3 / 4 / 5 / 6
+// landmarks 7.02 / 5.83 / 4.67 / 4.21 M -- compact 3-D cells beat line-by-line orders.  So: 6 landmarks for long rows (dense, Chebyshev-like neighbourhoods), 3 for short ones.
 // Components: up to MAX_COMP are ordered one after the other (each with its own landmarks); vertices without a neighbour and anything beyond keep their index order at the end.
 // The result is only ever a CANDIDATE: reorder_impl keeps P A P^T when its lists / lines shrink enough, exactly as it judged the walk's.
 #pragma once
 
 namespace order_dev {
 
-constexpr int MAX_COMP = 8, MAX_LEVEL = (1 << 15) - 1, LEVEL_BATCH = 32, SORT_TILE = 2048;
+constexpr int MAX_COMP = 8, MAX_LEVEL = (1 << 15) - 1, LEVEL_BATCH = 32, SORT_TILE = 2048, MAX_FIELDS = 6;
+struct Fields { const int *l[MAX_FIELDS]; };      // the landmark distance fields, by value into the kernels
 constexpr int LEVEL_BUDGET = 16384;     // levels over ALL searches of one ordering: a graph of huge diameter (a chain) is not worth ~10 us per level -- no candidate then
 
 // one level of a top-down breadth-first search: every vertex of level `cur` gives its unvisited neighbours level cur + 1
@@ -54,35 +56,32 @@ __global__ void next_seed(int n, const int *__restrict__ ptr, const int *__restr
     for (int k = ptr[v], e = ptr[v + 1]; k < e && !nb; k++) { const int c = idx[k]; nb = c >= 0 && c < n && c != v; }
     if (nb) atomicMin(out, v);
 }
-// the vertex of component `c` that maximises min(l0, l1, l2) over the fields given (absent ones: nullptr); ties go to the smallest index.  Packed into one 64-bit atomicMax.
-__global__ void farthest(int n, const int *__restrict__ comp, int c, const int *__restrict__ l0, const int *__restrict__ l1, const int *__restrict__ l2,
-                         unsigned long long *__restrict__ out)
+// the vertex of component `c` that maximises the smallest of the first `count` fields; ties go to the smallest index.  Packed into one 64-bit atomicMax.
+__global__ void farthest(int n, const int *__restrict__ comp, int c, Fields F, int count, unsigned long long *__restrict__ out)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n || comp[v] != c) return;
-    int m = l0[v];
-    if (l1) m = min(m, l1[v]);
-    if (l2) m = min(m, l2[v]);
+    int m = F.l[0][v];
+    for (int k = 1; k < count; k++) m = min(m, F.l[k][v]);
     if (m < 0) return;
     atomicMax(out, ((unsigned long long)(unsigned)m << 32) | (unsigned long long)(0xffffffffu - (unsigned)v));
 }
-__device__ __forceinline__ unsigned long long spread(unsigned v, int fields)          // bit i of v -> bit fields * i
+__device__ __forceinline__ unsigned long long spread(unsigned v, int fields, int bits)          // bit i of v -> bit fields * i
 {
     unsigned long long r = 0;
-    for (int b = 0; b < 15; b++) r |= (unsigned long long)((v >> b) & 1u) << (fields * b);
+    for (int b = 0; b < bits; b++) r |= (unsigned long long)((v >> b) & 1u) << (fields * b);
     return r;
 }
-// key = component (top byte) | Morton code of the landmark distances; no component: the last bucket, in index order
-__global__ void make_keys(int n, int fields, const int *__restrict__ comp, const int *__restrict__ la, const int *__restrict__ lb, const int *__restrict__ lc,
-                          const int *__restrict__ ld, unsigned long long *__restrict__ key, int *__restrict__ payload)
+// key = component (top byte) | Morton code of the landmark distances (each shifted down to `bits` bits); no component: the last bucket, in index order
+__global__ void make_keys(int n, int fields, int bits, int shift, const int *__restrict__ comp, Fields F, unsigned long long *__restrict__ key, int *__restrict__ payload)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     payload[v] = v;
     const int c = comp[v];
     if (c < 0) { key[v] = 0xffull << 56; return; }
-    unsigned long long k = spread((unsigned)min(la[v], MAX_LEVEL), fields) | (spread((unsigned)min(lb[v], MAX_LEVEL), fields) << 1) | (spread((unsigned)min(lc[v], MAX_LEVEL), fields) << 2);
-    if (fields == 4) k |= spread((unsigned)min(ld[v], MAX_LEVEL), fields) << 3;
+    unsigned long long k = 0;
+    for (int f = 0; f < fields; f++) k |= spread((unsigned)min(max(F.l[f][v], 0) >> shift, (1 << bits) - 1), fields, bits) << f;
     key[v] = ((unsigned long long)c << 56) | k;
 }
 
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(256) void radix_scatter(int n, const unsigned long 
 }
 
 struct Scratch {
-    int *level[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *comp = nullptr, *grew = nullptr, *hist = nullptr, *pay[2] = {nullptr, nullptr};
+    int *level[1 + MAX_FIELDS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *comp = nullptr, *grew = nullptr, *hist = nullptr, *pay[2] = {nullptr, nullptr};
     unsigned long long *key[2] = {nullptr, nullptr}, *best = nullptr;
     ~Scratch()
     {
@@ -171,31 +170,36 @@ static int bfs(int n, const int *ptr, const int *idx, int *level, int src, int *
     }
     return MAX_LEVEL;
 }
-static int pick_farthest(int n, const int *comp, int c, const int *l0, const int *l1, const int *l2, unsigned long long *best, hipStream_t st)
+static int pick_farthest(int n, const int *comp, int c, const Fields &F, int count, unsigned long long *best, hipStream_t st)
 {
     unsigned long long h = 0;
     if (hipMemsetAsync(best, 0, sizeof(unsigned long long), st) != hipSuccess) return -1;
-    farthest<<<(n + 255) / 256, 256, 0, st>>>(n, comp, c, l0, l1, l2, best);
+    farthest<<<(n + 255) / 256, 256, 0, st>>>(n, comp, c, F, count, best);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, best, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
     if (h == 0) return -1;
     return (int)(0xffffffffu - (unsigned)(h & 0xffffffffull));
 }
 
-// order_host[new position] = row.  fields: 3 or 4 landmarks.  false: a runtime error or out of memory (the plan then simply has no renumbered form)
+// order_host[new position] = row.  fields: how many landmarks (3 .. MAX_FIELDS).  false: a runtime error, out of memory or a graph of huge diameter (the plan then
+// simply has no renumbered form)
 static bool device_order(int n, const int *ptr, const int *idx, int fields, int *order_host, hipStream_t st)
 {
     if (n <= 0) return true;
+    fields = fields < 3 ? 3 : fields > MAX_FIELDS ? MAX_FIELDS : fields;
     Scratch s;
     const size_t nb = sizeof(int) * ((size_t)n + 4);
     const int grid = (n + 255) / 256, ntiles = (n + SORT_TILE - 1) / SORT_TILE;
-    for (int k = 0; k < 5; k++) if (hipMalloc(&s.level[k], nb) != hipSuccess) return false;
+    for (int k = 0; k <= fields; k++) if (hipMalloc(&s.level[k], nb) != hipSuccess) return false;
     if (hipMalloc(&s.comp, nb) != hipSuccess || hipMalloc(&s.grew, sizeof(int) * LEVEL_BATCH) != hipSuccess || hipMalloc(&s.best, sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&s.hist, sizeof(int) * 256 * (size_t)ntiles) != hipSuccess) return false;
     for (int k = 0; k < 2; k++) if (hipMalloc(&s.key[k], sizeof(unsigned long long) * ((size_t)n + 2)) != hipSuccess || hipMalloc(&s.pay[k], nb) != hipSuccess) return false;
-    for (int k = 0; k < 5; k++) fill_int<<<grid, 256, 0, st>>>(n, s.level[k], -1);
+    for (int k = 0; k <= fields; k++) fill_int<<<grid, 256, 0, st>>>(n, s.level[k], -1);
     fill_int<<<grid, 256, 0, st>>>(n, s.comp, -1);
-    int *l0 = s.level[0], *la = s.level[1], *lb = s.level[2], *lc = s.level[3], *ld = s.level[4];
-    int seed = 0, budget = LEVEL_BUDGET;
+    int *l0 = s.level[0];
+    Fields F{}, F0{};
+    for (int f = 0; f < fields; f++) F.l[f] = s.level[1 + f];
+    F0.l[0] = l0;
+    int seed = 0, budget = LEVEL_BUDGET, deepest = 0;
     for (int c = 0; c < MAX_COMP; c++) {
         if (c > 0) {                                                    // the next component's seed: the smallest index nobody owns that has a neighbour
             int h = 0x7fffffff;
@@ -207,24 +211,26 @@ static bool device_order(int n, const int *ptr, const int *idx, int fields, int 
         }
         if (bfs(n, ptr, idx, l0, seed, s.grew, st, &budget) < 0) return false;
         claim_component<<<grid, 256, 0, st>>>(n, l0, s.comp, c);
-        const int a = pick_farthest(n, s.comp, c, l0, nullptr, nullptr, s.best, st);
-        if (a < 0 || bfs(n, ptr, idx, la, a, s.grew, st, &budget) < 0) return false;
-        const int b = pick_farthest(n, s.comp, c, la, nullptr, nullptr, s.best, st);
-        if (b < 0 || bfs(n, ptr, idx, lb, b, s.grew, st, &budget) < 0) return false;
-        const int cc = pick_farthest(n, s.comp, c, la, lb, nullptr, s.best, st);
-        if (cc < 0 || bfs(n, ptr, idx, lc, cc, s.grew, st, &budget) < 0) return false;
-        if (fields == 4) {
-            const int d = pick_farthest(n, s.comp, c, la, lb, lc, s.best, st);
-            if (d < 0 || bfs(n, ptr, idx, ld, d, s.grew, st, &budget) < 0) return false;
+        // landmark f: the vertex of the component farthest from the seed (f = 0), then farthest from all the landmarks before it
+        for (int f = 0; f < fields; f++) {
+            const int at = f == 0 ? pick_farthest(n, s.comp, c, F0, 1, s.best, st) : pick_farthest(n, s.comp, c, F, f, s.best, st);
+            if (at < 0) return false;
+            const int depth = bfs(n, ptr, idx, s.level[1 + f], at, s.grew, st, &budget);
+            if (depth < 0) return false;
+            if (depth > deepest) deepest = depth;
         }
     }
-    make_keys<<<grid, 256, 0, st>>>(n, fields, s.comp, la, lb, lc, ld, s.key[0], s.pay[0]);
+    // 56 key bits for the Morton code: `bits` per field; deeper graphs lose their low distance bits (neighbouring levels share a cell)
+    const int bits = 56 / fields > 15 ? 15 : 56 / fields;
+    int shift = 0;
+    while ((deepest >> shift) >= (1 << bits)) shift++;
+    make_keys<<<grid, 256, 0, st>>>(n, fields, bits, shift, s.comp, F, s.key[0], s.pay[0]);
     if (hipGetLastError() != hipSuccess) return false;
     int cur = 0;
-    for (int shift = 0; shift < 64; shift += 8) {                        // (passes over digits that are all zero cost a histogram and move nothing: kept simple)
-        radix_hist<<<ntiles, 256, 0, st>>>(n, s.key[cur], shift, ntiles, s.hist);
+    for (int sh = 0; sh < 64; sh += 8) {                                 // (passes over digits that are all zero cost a histogram and move nothing: kept simple)
+        radix_hist<<<ntiles, 256, 0, st>>>(n, s.key[cur], sh, ntiles, s.hist);
         scan_exclusive<<<1, 1024, 0, st>>>(256 * ntiles, s.hist);
-        radix_scatter<<<ntiles, 256, 0, st>>>(n, s.key[cur], s.pay[cur], shift, ntiles, s.hist, s.key[cur ^ 1], s.pay[cur ^ 1]);
+        radix_scatter<<<ntiles, 256, 0, st>>>(n, s.key[cur], s.pay[cur], sh, ntiles, s.hist, s.key[cur ^ 1], s.pay[cur ^ 1]);
         if (hipGetLastError() != hipSuccess) return false;
         cur ^= 1;
     }

@@ -1853,7 +1853,7 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
             const int r = hint[i];
             if (r < 0 || r >= n || seen[r]) have_order = false; else { seen[r] = 1; order[i] = r; }
         }
-    } else if (e == hipSuccess) have_order = order_dev::device_order(n, ptr, idx, p->products ? 4 : 3, order, st);      // long rows (dense neighbourhoods): four landmarks, short rows: three
+    } else if (e == hipSuccess) have_order = order_dev::device_order(n, ptr, idx, p->products ? 6 : 3, order, st);      // long rows (dense neighbourhoods): six landmarks, short rows: three
     if (e == hipSuccess && have_order) {
         bool moved = false;
         hptr2[0] = 0;

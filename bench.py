@@ -583,6 +583,12 @@ def main():
             configs["config4"] = config4_leg(lib, np, C)
             configs["config5"] = config5_leg(ctx, sizes=(256, N) if N >= 256 else (N,))
 
+    yard = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        yard = box_yardstick(lib, np, C, check, stream, timer, n_local)
+        if yard and yard.get("rate_GBs"):
+            roofline["frac_of_box_yardstick"] = round(roofline["achieved"] / yard["rate_GBs"], 4)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(np, N)
@@ -620,6 +626,7 @@ def main():
             "rccl_ranks": world if (world > 1 and comm_used == "rccl" and int(dll.lis_amd_comm_kind()) == 1) else (0 if world > 1 else None),
             "self_launched": os.environ.get("LIS_AMD_BENCH_SELF_LAUNCHED") == "1",
             "multi_gpu": multi,
+            "box_yardstick": yard,            # what a pure streaming kernel with the product's read : write ratio reaches on THIS box (no gather, no index): the practical ceiling behind `roofline.frac`
             "stencil27": extras,              # beside the headline: the 27-point stencil (spmvtest3b / HPCG) through the round-3 kernels; not part of `value`
             "cpu_baseline": cpu,
         }
@@ -1050,18 +1057,61 @@ def krylov_bytes(key, iters, n, nnz, coded, patterns=0, values=0, uniform_jacobi
 CG_VECTOR_BYTES_PER_ROW = 80      # 48 (x += alpha_prev p, p = dinv.*r + beta p: r dinv p x | p x) + 32 (r -= alpha q with both sums: q r dinv | r)
 
 
-def usable_cores():
-    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+def box_yardstick(lib, np, C, check, stream, timer, n):
+    """The box's streaming yardstick (liship_stream_yardstick): every workgroup sums 13 consecutive 4 KB tiles of one read stream into one 4 KB tile of the write stream --
+    the CSR product's own read : write ratio on SURVEY 8d's bytes (13.0 : 1 at 7 entries per row), 14 n * 8 B per launch, nontemporal both ways, no gather and no index.  MI355X boxes of this
+    pool differ by several per cent in what they stream; this says what THIS one does, so that `roofline.frac` (priced on the 8 TB/s spec peak) can
+    be read against the practical ceiling measured in the same process."""
+    from lis_amd import DeviceArray as DA
+    try:
+        n = int(n) & ~511
+        out = {"kernel": "stream_sum_kernel<13>", "reads": 13, "writes": 1, "n": n, "bytes_per_launch": 14 * 8 * n}
+        src, dst = DA(13 * n, np.float64), DA(n, np.float64)
+        check(lib.liship_memset(src.ptr, 0, src.nbytes, None))
+        ms = C.c_float()
+        for reads in (13, 8, 1):
+            for _ in range(5):
+                check(lib.liship_stream_yardstick(reads, n, src.ptr, dst.ptr, 0, stream))
+            check(lib.liship_timer_start(timer, stream))
+            for _ in range(20):
+                check(lib.liship_stream_yardstick(reads, n, src.ptr, dst.ptr, 0, stream))
+            check(lib.liship_timer_stop(timer, stream))
+            check(lib.liship_device_synchronize())
+            check(lib.liship_timer_elapsed_ms(timer, C.byref(ms)))
+            rate = (reads + 1) * 8 * n / (ms.value / 20 * 1e-3) / 1e9
+            if reads == 13:
+                out.update({"kernel_ms": round(ms.value / 20, 4), "rate_GBs": round(rate, 1), "frac_of_spec_peak": round(rate / HBM_PEAK_GBS, 4)})
+            elif reads == 8:
+                out["rate_8_to_1_GBs"] = round(rate, 1)      # the DIA product's ratio (7 diagonals + x : y)
+            else:
+                out["copy_1_to_1_GBs"] = round(rate, 1)
+        out["note"] = ("a workgroup per 4 KB tile, 16 B per lane, nontemporal loads and stores (persistent grid-stride workgroups measured 5-12 % slower).  Every byte of this "
+                       "kernel comes from HBM; the products' x gathers are partly served by the 256 MB Infinity Cache, which is how a product can exceed this rate on SURVEY 8d's bytes")
+        src.free(); dst.free()
+        return out
+    except Exception as e:                                 # a yardstick must never sink the bench line
+        return {"rate_GBs": None, "error": str(e)}
+
+
+def usable_cores(why=None):
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota.  `why` (a dict) receives what limited the count."""
     try:
         cores = len(os.sched_getaffinity(0))
+        src = f"affinity mask of {cores} of the machine's {os.cpu_count()} logical CPUs"
     except Exception:
         cores = os.cpu_count() or 1
+        src = f"os.cpu_count() = {cores}"
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if quota != "max":
-            cores = max(1, min(cores, int(int(quota) / int(period))))
+            q = int(int(quota) / int(period))
+            if q < cores:
+                src = f"cgroup CPU quota {quota}/{period} = {q} cores (affinity mask: {cores}, machine: {os.cpu_count()} logical CPUs)"
+            cores = max(1, min(cores, q))
     except Exception:
         pass
+    if why is not None:
+        why["cores_limited_by"] = src
     return cores
 
 
@@ -1095,7 +1145,8 @@ def cpu_baseline(np, N=512):
     import lisdrv
     import orc
     from lis_amd import _capi as capi
-    cores = usable_cores()
+    why = {}
+    cores = usable_cores(why)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -1163,6 +1214,7 @@ def cpu_baseline(np, N=512):
                     full = Nc == N
                     return {"value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "kind": "reference", "cpu_model": model,
                             "cg_jacobi_iters_per_sec": cg, "full_workload": full, "seconds": round(time.perf_counter() - t_all, 1),
+                            "omp_threads": cores, "cores_limited_by": why.get("cores_limited_by"),
                             "sample": (f"the FULL workload: {reps} CSR SpMV on the {Nc}^3 stencil matrix ({el / reps * 1e3:.1f} ms each), lis_matvec of Lis 2.1.11 with OpenMP on {cores} "
                                        f"threads; cg_jacobi_iters_per_sec: {cg_iters} iterations of its lis_solve on the same matrix; matrix built on the host in {gen_s:.1f} s"
                                        if full else

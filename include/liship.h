@@ -63,6 +63,9 @@ int  liship_event_destroy(void *event);
 int  liship_event_record(void *event, void *stream);
 int  liship_event_synchronize(void *event);
 int  liship_stream_wait_event(void *stream, void *event);
+/* the box's streaming yardstick: every workgroup sums `reads` (1, 2, 4, 8 or 13) consecutive 512-double tiles of src (reads * n doubles) into one tile of dst (n doubles),
+ * nontemporal, no gather: what a kernel with the products' read : write ratio reaches on THIS box (bench.py reports it beside the product's roofline fraction); n % 512 == 0 */
+int  liship_stream_yardstick(int reads, size_t n, const double *src, double *dst, int wgs_per_cu /* 0: a workgroup per tile, else persistent workgroups per CU */, void *stream);
 int  liship_timer_create(void **timer);
 int  liship_timer_destroy(void *timer);
 int  liship_timer_start(void *timer, void *stream);
@@ -193,6 +196,13 @@ int  liship_csr_plan_reorder(liship_csr_plan_t plan, const int *ptr, const int *
  * liship_csr_plan_reorder_permutation: the permutation of the reordered form to the host (LISHIP_ERR_ARG when the plan has none). */
 int  liship_csr_plan_reorder_with(liship_csr_plan_t plan, const int *ptr, const int *index, const double *value, int min_items_per_listed, const int *perm_hint, void *stream);
 int  liship_csr_plan_reorder_permutation(liship_csr_plan_t plan, int *perm_host);
+/* A rank's local matrix of a multi-rank job (columns [n, ncols) are ghost columns, lis_matrix_mpi.c:274-306): said before liship_csr_plan_reorder, the numbering is found on
+ * the owned columns alone, ghost columns keep their numbers in P A P^T and the rows that read one are placed behind all the others --
+ * rows [0, liship_csr_plan_reordered_inner_rows) of the reordered form touch no ghost column (they can run while the halo travels). */
+int  liship_csr_plan_set_ghost_columns(liship_csr_plan_t plan, int ncols);
+int  liship_csr_plan_reordered_inner_rows(liship_csr_plan_t plan);
+/* out[k] = the position of row index[k] under the permutation perm (perm[new position] = row; n entries): a list of rows -- a halo export list -- in the new numbering */
+int  liship_permute_rows_of_list(int n, const int *perm, int count, const int *index, int *out, void *stream);
 long long liship_csr_plan_reordered(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_reorder(int mode);
 /* the reordered form as a matrix of its own -- P A P^T: its plan (owned by `plan`), arrays and the permutation perm[new position] = original row -- for callers that keep

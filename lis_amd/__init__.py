@@ -30,6 +30,7 @@ _LISHIP = {
     "liship_memset": (_ci, [_vp, _ci, _sz, _vp]),
     "liship_memcpy_h2d": (_ci, [_vp, _vp, _sz, _vp]),
     "liship_memcpy_d2h": (_ci, [_vp, _vp, _sz, _vp]),
+    "liship_stream_yardstick": (_ci, [_ci, _sz, _vp, _vp, _ci, _vp]),
     "liship_memcpy_d2d": (_ci, [_vp, _vp, _sz, _vp]),
     "liship_stream_create": (_ci, [_pvp]),
     "liship_stream_destroy": (_ci, [_vp]),
@@ -112,6 +113,9 @@ _LISHIP = {
     "liship_csr_plan_reorder_permutation": (_ci, [_vp, _vp]),
     "liship_spmv_csr_set_reorder": (_ci, [_ci]),
     "liship_csr_plan_reordered_form": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "liship_csr_plan_set_ghost_columns": (_ci, [_vp, _ci]),
+    "liship_csr_plan_reordered_inner_rows": (_ci, [_vp]),
+    "liship_permute_rows_of_list": (_ci, [_ci, _vp, _ci, _vp, _vp, _vp]),
     "liship_permute_gather_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_permute_scatter_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_spmv_csr_set_long_row_tree": (_ci, [_ci]),

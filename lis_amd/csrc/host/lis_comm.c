@@ -411,6 +411,42 @@ static LIS_INT halo_tables_ready(LIS_MATRIX A)
 	return LIS_SUCCESS;
 }
 
+/* A solve that iterates in the numbering of a reordered plan (lis_solver.c) on several ranks: the rows a neighbour is sent are the same rows under their new
+ * numbers -- export_index'[k] = position of row export_index[k] --, no list is a run any more (the pack kernel gathers them), the ghost slots x[n .. np) and
+ * everything the neighbours see stay as they are: a rank renumbers (or not) on its own.  inner_rows: rows [0, inner_rows) of P A P^T read no ghost column
+ * (liship_csr_plan_reordered_inner_rows): they run under the exchange as the interior planes of a slab do. */
+LIS_INT lisc_halo_renumbered(LIS_MATRIX A, const int *perm, int inner_rows)
+{
+	lisd_mat *d = MDEV(A);
+	LIS_COMMTABLE t = A->commtable;
+	if (d->held_halo || !t) return LIS_SUCCESS;
+	LISCHK(halo_tables_ready(A));
+	int *ri = NULL, *rr = (int *)malloc(sizeof(int) * (size_t)(t->neibpetot > 0 ? t->neibpetot : 1));
+	if (!rr) return LISI_ERR(LIS_ERR_OUT_OF_MEMORY, "malloc size = %D\n", t->neibpetot);
+	for (LIS_INT i = 0; i < t->neibpetot; i++) rr[i] = -1;
+	if (t->exnnz > 0) {
+		LIS_INT err = lisd_malloc((void **)&ri, sizeof(int) * (size_t)t->exnnz);
+		if (err) { free(rr); return err; }
+		int rc = liship_permute_rows_of_list(A->n, perm, t->exnnz, d->export_index, ri, lisg.stream);
+		if (rc) { (void)liship_free(ri); free(rr); return lisi_hip_error(__FILE__, __func__, __LINE__, rc); }
+	}
+	d->held_export_index = d->export_index; d->held_export_run = d->export_run; d->held_all_runs = d->all_runs;
+	d->held_inner_begin = d->inner_begin; d->held_inner_end = d->inner_end;
+	d->export_index = ri; d->export_run = rr; d->all_runs = t->exnnz > 0 ? 0 : 1;
+	d->inner_begin = 0; d->inner_end = inner_rows < 0 ? 0 : inner_rows > A->n ? A->n : inner_rows;
+	d->held_halo = 1;
+	return LIS_SUCCESS;
+}
+void lisc_halo_restore(LIS_MATRIX A)
+{
+	lisd_mat *d = MDEV(A);
+	if (!d->held_halo) return;
+	(void)liship_free(d->export_index); free(d->export_run);
+	d->export_index = d->held_export_index; d->export_run = d->held_export_run; d->all_runs = d->held_all_runs;
+	d->inner_begin = d->held_inner_begin; d->inner_end = d->held_inner_end;
+	d->held_export_index = NULL; d->held_export_run = NULL; d->held_halo = 0;
+}
+
 /* what a neighbour is sent: its run inside x, or its packed slice */
 static const double *send_ptr(const lisd_mat *d, LIS_COMMTABLE t, LIS_INT i, const double *dx)
 {

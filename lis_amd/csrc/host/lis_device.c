@@ -490,10 +490,12 @@ static void renum_cache_drop(void) { free(renum_cache.perm); renum_cache.perm = 
 /* rows of the local matrix that reference no ghost column, as one maximal run [b,e) */
 /* the row split of a CSR-ordered HBM matrix and, where its columns allow it, the one-byte column codes
  * (liship.h "index coding"; LIS_AMD_NO_INDEX_CODES=1 keeps the 4 B indices for A/B measurements) */
-static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue, int reorder);
-LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue) { return csr_plan_impl(plan, n, dptr, dindex, dvalue, 1); }
+static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, int ncols, const int *dptr, const int *dindex, const double *dvalue, int reorder);
+LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue) { return csr_plan_impl(plan, n, 0, dptr, dindex, dvalue, 1); }
+/* ... of a rank's local rows: columns [n, ncols) are its ghost columns (the renumbered form keeps them apart: liship_csr_plan_set_ghost_columns) */
+LIS_INT lisd_csr_plan_cols(liship_csr_plan_t *plan, int n, int ncols, const int *dptr, const int *dindex, const double *dvalue) { return csr_plan_impl(plan, n, ncols, dptr, dindex, dvalue, 1); }
 /* ... of a matrix no solve iterates on (a transposed copy, a scaled copy, the halves of a split JAD matrix): no renumbered form (products would not use it) */
-LIS_INT lisd_csr_plan_plain(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue) { return csr_plan_impl(plan, n, dptr, dindex, dvalue, 0); }
+LIS_INT lisd_csr_plan_plain(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue) { return csr_plan_impl(plan, n, 0, dptr, dindex, dvalue, 0); }
 /* the renumbered form of a plan (liship_csr_plan_reorder: never an error when the matrix does not qualify; out of memory leaves the plan as it was) */
 static LIS_INT plan_try_reorder(liship_csr_plan_t plan, int n, const int *dptr, const int *dindex, const double *dvalue)
 {
@@ -518,19 +520,22 @@ static LIS_INT plan_try_reorder(liship_csr_plan_t plan, int n, const int *dptr, 
 LIS_INT lisd_mat_lazy_reorder(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
-	if (lisg.no_reorder || lisg.nprocs != 1 || lisg.reorder_after <= 0 || !d->ready || d->reorder_tried || d->served < lisg.reorder_after) return LIS_SUCCESS;
-	if (d->type != LIS_MATRIX_CSR || !d->plan || !d->value || d->split_jad || d->solve_holds || A->is_scaled || A->is_splited || A->np != A->n || d->n != A->n) return LIS_SUCCESS;
+	if (lisg.no_reorder || lisg.reorder_after <= 0 || !d->ready || d->reorder_tried || d->served < lisg.reorder_after) return LIS_SUCCESS;
+	/* (several ranks: each renumbers its own rows and owned columns -- the plan knows its ghost columns --; a matrix served as CSR from another layout with ghost columns stays as it is) */
+	if (d->type != LIS_MATRIX_CSR || !d->plan || !d->value || d->split_jad || d->solve_holds || A->is_scaled || A->is_splited || d->n != A->n ||
+	    (A->np != A->n && A->matrix_type != LIS_MATRIX_CSR)) return LIS_SUCCESS;
 	d->reorder_tried = 1;
 	return plan_try_reorder(d->plan, d->n, d->ptr, d->index, d->value);
 }
 LIS_INT lis_amd_set_reorder_after(long long products) { lisg.reorder_after = products < 0 ? 0 : products; return LIS_SUCCESS; }
 long long lis_amd_matrix_products_served(LIS_MATRIX A) { return MDEV(A)->served; }
 
-static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue, int reorder)
+static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, int ncols, const int *dptr, const int *dindex, const double *dvalue, int reorder)
 {
 	int rc = liship_csr_plan_create(plan, n, dptr, lisg.stream);
 	if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_create(plan, n, dptr, lisg.stream);   /* the plan allocates in the kernel layer */
 	HIPCHK(rc);
+	if (ncols > n) HIPCHK(liship_csr_plan_set_ghost_columns(*plan, ncols));
 	if (!lisg.no_index_codes) {
 		/* the codes are an optimisation: a matrix that cannot have them (out of memory included) keeps its 4 B indices */
 		rc = liship_csr_plan_encode_indices(*plan, dptr, dindex, lisg.stream);
@@ -553,7 +558,7 @@ static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, const int *dptr, co
 		 * At plan time only when asked (LIS_AMD_REORDER_AFTER=0); by default the plan first serves lisg.reorder_after products in the caller's numbering
 		 * (lisd_mat_lazy_reorder): building the form costs ~3000 iterations of what it saves per iteration on the Queen-class matrix, and the solves
 		 * people time first take 40-50 */
-		if (!rc && reorder && !lisg.no_reorder && lisg.nprocs == 1 && dvalue && lisg.reorder_after == 0) LISCHK(plan_try_reorder(*plan, n, dptr, dindex, dvalue));
+		if (!rc && reorder && !lisg.no_reorder && (lisg.nprocs == 1 || ncols >= n) && dvalue && lisg.reorder_after == 0) LISCHK(plan_try_reorder(*plan, n, dptr, dindex, dvalue));
 	}
 	/* a plan that streams index[] / codes (no row patterns): the plane of a structured grid from the band of the matrix, for the XCD strips */
 	rc = liship_csr_plan_scan_band(*plan, dptr, dindex, lisg.stream);
@@ -945,7 +950,7 @@ static LIS_INT mat_upload(LIS_MATRIX A)
 		LISCHK(up_i(&d->ptr, A->ptr, n + 1));
 		LISCHK(up_i(&d->index, A->index, (size_t)A->nnz));
 		LISCHK(up_d(&d->value, A->value, (size_t)A->nnz));
-		LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index, d->value));
+		LISCHK(lisd_csr_plan_cols(&d->plan, A->n, A->np, d->ptr, d->index, d->value));
 		break;
 	case LIS_MATRIX_CSC:
 		LISCHK(upload_csc_as_csr(A, d));
@@ -1579,7 +1584,7 @@ LIS_INT lis_amd_matrix_set_csr_device(LIS_INT nnz, LIS_INT np, LIS_INT *dptr, LI
 	d->type = LIS_MATRIX_CSR;
 	d->n = A->n; d->np = np; d->nnz = nnz;
 	d->ptr = dptr; d->index = dindex; d->value = dvalue;
-	LISCHK(lisd_csr_plan(&d->plan, A->n, d->ptr, d->index, d->value));
+	LISCHK(lisd_csr_plan_cols(&d->plan, A->n, np, d->ptr, d->index, d->value));
 	d->inner_begin = 0; d->inner_end = A->n;
 	d->ready = 1;
 	A->nnz = nnz; A->np = np;

@@ -86,6 +86,9 @@ typedef struct {
 	int all_runs;              /* every neighbour's list is a run: no pack kernel at all (whole boundary planes of a structured grid) */
 	double *ws;                /* packed send buffer in HBM */
 	int inner_begin, inner_end;/* maximal run of rows without ghost columns: overlappable with the halo */
+	/* while a multi-rank solve iterates in the numbering of a reordered plan (lisc_halo_renumbered): the tables above hold the renumbered export list, these the caller's */
+	int held_halo, held_all_runs, held_inner_begin, held_inner_end;
+	int *held_export_index, *held_export_run;
 	/* scratch for the raw-array entry points lis_matvec_<fmt>(A, x[], y[]) */
 	double *sx, *sy; size_t scap;
 	/* split JAD matrix (lis_split.c): d->ptr/index/value/plan hold L, these hold U, the diagonal and a work vector */
@@ -199,6 +202,7 @@ LIS_INT lisd_mat_ready_t(LIS_MATRIX A);                       /* build / upload 
 LIS_INT lisd_spmv_t(LIS_MATRIX A, double *dx, double *dy);    /* y[0..np) = A^T x, ghost rows reduced to owners */
 LIS_INT lisd_spmv(LIS_MATRIX A, double *dx, double *dy);      /* y = A x on device pointers (halo included) */
 LIS_INT lisd_csr_plan(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue);   /* row split + index codes */
+LIS_INT lisd_csr_plan_cols(liship_csr_plan_t *plan, int n, int ncols, const int *dptr, const int *dindex, const double *dvalue);   /* ... of a rank's local rows with ghost columns [n, ncols) */
 LIS_INT lisd_csr_plan_plain(liship_csr_plan_t *plan, int n, const int *dptr, const int *dindex, const double *dvalue);    /* the same without a renumbered form (matrices no solve iterates on) */
 LIS_INT lisd_spmv_dot_launch(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq); /* sums -> reduce_out */
 LIS_INT lisd_spmv_dot_launch_to(LIS_MATRIX A, double *dx, double *dy, const double *dw, int want_sumsq, double *result); /* sums -> result (HBM) */
@@ -220,6 +224,8 @@ LIS_INT lisd_mat_lazy_reorder(LIS_MATRIX A);                  /* the renumbered 
 LIS_INT lisc_halo_begin(LIS_MATRIX A, double *dx);            /* pack + start the exchange (second stream) */
 LIS_INT lisc_halo_end(LIS_MATRIX A, double *dx);              /* ghosts of dx are valid for work queued after this */
 LIS_INT lisc_halo_device(LIS_MATRIX A, double *dx);           /* fill dx[n..np) from the neighbours */
+LIS_INT lisc_halo_renumbered(LIS_MATRIX A, const int *perm, int inner_rows);   /* the export list in a reordered plan's numbering (perm[new position] = row, device) swapped in ... */
+void    lisc_halo_restore(LIS_MATRIX A);                      /* ... and the caller's back */
 LIS_INT lisc_gather_device(const double *src, int count);    /* RCCL only: every rank's src[0..count) -> lisg.gather_out, rank-major, on the stream */
 LIS_INT lisc_fold(int count, double *host_inout);             /* sum over ranks, rank order */
 LIS_INT lisc_allgather_host(const void *send, void *recv, size_t bytes);

@@ -1116,11 +1116,15 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		const int *rp = NULL, *ri = NULL;
 		const double *rv = NULL;
 		/* A^T x: the HBM copy is transposed in HBM (lis_matvech.c) -- of an unsplit CSR matrix, that is P A P^T's while it is swapped in; it gets a set of fields of its own */
-		const int t_ok = !needs_t || (Awork->matrix_type == LIS_MATRIX_CSR && !Awork->is_splited);
+		/* (several ranks: each rank renumbers its own rows and owned columns, the ghost columns and the halo slots keep their place -- lisc_halo_renumbered --; the
+		 * solvers that multiply by A^T keep the caller's numbering there: the reverse halo's transposed rows are laid out for it) */
+		const int t_ok = !needs_t || (lisg.nprocs == 1 && Awork->matrix_type == LIS_MATRIX_CSR && !Awork->is_splited);
+		const int multi = lisg.nprocs > 1 && Awork->commtable;
 		/* the renumbered form is built LAZILY: by the first solve that finds the plan has served lisg.reorder_after products (lis_device.c) */
-		if (lisg.nprocs == 1 && !scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && t_ok) { if ((err = lisd_mat_lazy_reorder(Awork))) goto out; }
-		if (lisg.nprocs == 1 && !scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && t_ok && dm->type == LIS_MATRIX_CSR && !dm->split_jad &&
-		    dm->plan && Awork->np == Awork->n && dm->n == Awork->n && liship_csr_plan_reordered_form(dm->plan, &in, &rp, &ri, &rv, &renum) == 0) {
+		if (!scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && t_ok) { if ((err = lisd_mat_lazy_reorder(Awork))) goto out; }
+		if (!scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && t_ok && dm->type == LIS_MATRIX_CSR && !dm->split_jad &&
+		    dm->plan && (Awork->np == Awork->n || (multi && Awork->matrix_type == LIS_MATRIX_CSR)) && dm->n == Awork->n && liship_csr_plan_reordered_form(dm->plan, &in, &rp, &ri, &rv, &renum) == 0) {
+			if (multi && (err = lisc_halo_renumbered(Awork, renum, liship_csr_plan_reordered_inner_rows(dm->plan)))) goto out;
 			held_plan = dm->plan; held_ptr = dm->ptr; held_index = dm->index; held_value = dm->value;
 			dm->plan = in; dm->ptr = (int *)rp; dm->index = (int *)ri; dm->value = (double *)rv;
 			dm->solve_holds = 1;
@@ -1234,6 +1238,7 @@ out:
 		dm->plan = held_plan; dm->ptr = held_ptr; dm->index = held_index; dm->value = held_value;
 		dm->solve_holds = 0;
 		swap_transposed(dm);
+		lisc_halo_restore(Awork);
 	}
 	if (renum_b) lisd_pool_put(renum_b, c.len * sizeof(double));
 	if (renum_d) lisd_pool_put(renum_d, c.len * sizeof(double));

@@ -72,17 +72,29 @@ __device__ __forceinline__ unsigned long long spread(unsigned v, int fields, int
     for (int b = 0; b < bits; b++) r |= (unsigned long long)((v >> b) & 1u) << (fields * b);
     return r;
 }
-// key = component (top byte) | Morton code of the landmark distances (each shifted down to `bits` bits); no component: the last bucket, in index order
-__global__ void make_keys(int n, int fields, int bits, int shift, const int *__restrict__ comp, Fields F, unsigned long long *__restrict__ key, int *__restrict__ payload)
+// key = component (top byte) | Morton code of the landmark distances (each shifted down to `bits` bits); no component: the last bucket, in index order.
+// ncols > n (a rank's local matrix): a row that reads a ghost column gets bit 62 -- all such rows sort behind the rows that read none (and in front of the last
+// bucket); inner[0] counts the rows in front of them.
+__global__ void make_keys(int n, int ncols, const int *__restrict__ ptr, const int *__restrict__ idx, int fields, int bits, int shift, const int *__restrict__ comp, Fields F,
+                          unsigned long long *__restrict__ key, int *__restrict__ payload, int *__restrict__ inner)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    payload[v] = v;
-    const int c = comp[v];
-    if (c < 0) { key[v] = 0xffull << 56; return; }
-    unsigned long long k = 0;
-    for (int f = 0; f < fields; f++) k |= spread((unsigned)min(max(F.l[f][v], 0) >> shift, (1 << bits) - 1), fields, bits) << f;
-    key[v] = ((unsigned long long)c << 56) | k;
+    bool front = false;
+    if (v < n) {
+        payload[v] = v;
+        const int c = comp[v];
+        if (c < 0) key[v] = 0xffull << 56;
+        else {
+            unsigned long long k = 0;
+            for (int f = 0; f < fields; f++) k |= spread((unsigned)min(max(F.l[f][v], 0) >> shift, (1 << bits) - 1), fields, bits) << f;
+            bool ghost = false;
+            if (ncols > n) for (int j = ptr[v], e = ptr[v + 1]; j < e && !ghost; j++) ghost = idx[j] >= n;
+            front = !ghost;
+            key[v] = ((unsigned long long)c << 56) | k | (ghost ? 1ull << 62 : 0ull);
+        }
+    }
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(front);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(inner, __builtin_popcountll(b));
 }
 
 // ---- stable LSD radix sort, 8 bits a pass, (key, payload) pairs.  Tile = SORT_TILE consecutive elements per workgroup of 256 lanes.
@@ -182,7 +194,7 @@ static int pick_farthest(int n, const int *comp, int c, const Fields &F, int cou
 
 // order_host[new position] = row.  fields: how many landmarks (3 .. MAX_FIELDS).  false: a runtime error, out of memory or a graph of huge diameter (the plan then
 // simply has no renumbered form)
-static bool device_order(int n, const int *ptr, const int *idx, int fields, int *order_host, hipStream_t st)
+static bool device_order(int n, int ncols, const int *ptr, const int *idx, int fields, int *order_host, int *inner_rows, hipStream_t st)
 {
     if (n <= 0) return true;
     fields = fields < 3 ? 3 : fields > MAX_FIELDS ? MAX_FIELDS : fields;
@@ -224,8 +236,9 @@ static bool device_order(int n, const int *ptr, const int *idx, int fields, int 
     const int bits = 56 / fields > 15 ? 15 : 56 / fields;
     int shift = 0;
     while ((deepest >> shift) >= (1 << bits)) shift++;
-    make_keys<<<grid, 256, 0, st>>>(n, fields, bits, shift, s.comp, F, s.key[0], s.pay[0]);
-    if (hipGetLastError() != hipSuccess) return false;
+    if (hipMemsetAsync(s.grew, 0, sizeof(int), st) != hipSuccess) return false;
+    make_keys<<<grid, 256, 0, st>>>(n, ncols, ptr, idx, fields, bits, shift, s.comp, F, s.key[0], s.pay[0], s.grew);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(inner_rows, s.grew, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     int cur = 0;
     for (int sh = 0; sh < 64; sh += 8) {                                 // (passes over digits that are all zero cost a histogram and move nothing: kept simple)
         radix_hist<<<ntiles, 256, 0, st>>>(n, s.key[cur], sh, ntiles, s.hist);

@@ -246,6 +246,8 @@ struct liship_csr_plan_s {
     liship_csr_plan_s *inner = nullptr;
     int *r_ptr = nullptr, *r_idx = nullptr, *r_perm = nullptr;      // device: row starts and columns of P A P^T; new position -> original row
     double *r_val = nullptr, *r_x = nullptr;                        // device: its values; x in the new numbering (n entries)
+    int ncols = 0;                                                  // > n: columns [n, ncols) are a rank's GHOST columns (liship_csr_plan_set_ghost_columns): the reordered form keeps them where they are
+    int r_inner_end = 0;                                            // ... and puts the rows that read one behind all the others: rows [0, r_inner_end) of P A P^T touch no ghost column
     int *drun, *droff;   // device, or NULL: when every list is made of TRIPLES of consecutive columns (3 unknowns per node), the triples' first columns and nblocks + 1 offsets into them
     int ndpl;            // distinct columns per lane of spmv_csr_local_kernel: 2 (lists of <= 1024 columns) or 4
     int xcap;            // its x stage: the longest list rounded up to 1024 / 1536 / 2048 entries
@@ -1757,14 +1759,15 @@ __global__ void csr_reorder_inverse(int n, const int *__restrict__ perm, int *__
 // one wavefront per row of P A P^T: entry j of new row r is entry j of row perm[r], its column renumbered
 __global__ __launch_bounds__(256)
 void csr_reorder_rows(int n, const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val, const int *__restrict__ perm,
-                      const int *__restrict__ inv, const int *__restrict__ ptr2, int *__restrict__ idx2, double *__restrict__ val2, int *__restrict__ bad)
+                      const int *__restrict__ inv, const int *__restrict__ ptr2, int *__restrict__ idx2, double *__restrict__ val2, int *__restrict__ bad, int ncols)
 {
     const int r = blockIdx.x * (256 / WAVE) + (int)threadIdx.x / WAVE, lane = (int)threadIdx.x & (WAVE - 1);
     if (r >= n) return;
     const int src = perm[r], s = ptr[src], len = ptr[src + 1] - s, d = ptr2[r];
     for (int j = lane; j < len; j += WAVE) {
         const int c = idx[s + j];
-        if (c < 0 || c >= n) { *bad = 1; idx2[d + j] = 0; }        // a column outside [0, n) (ghost columns: a hinted permutation skipped the walk that would have seen it)
+        if (c >= n && c < ncols) idx2[d + j] = c;                  // a rank's ghost column: not renumbered (the halo lands where it always did)
+        else if (c < 0 || c >= n) { *bad = 1; idx2[d + j] = 0; }   // a column outside the matrix
         else idx2[d + j] = inv[c];
         val2[d + j] = val[s + j];
     }
@@ -1814,6 +1817,16 @@ extern "C" int liship_csr_plan_reorder_with(liship_csr_plan_t p, const int *ptr,
     }
     return reorder_impl(p, ptr, idx, val, min_items_per_listed, nullptr, stream);
 }
+// A rank's local matrix in a multi-rank job: columns [n, ncols) are ghost columns (x[n .. ncols) is filled by the halo exchange).  Said BEFORE liship_csr_plan_reorder:
+// the numbering is then found on the owned columns alone (the ghosts are no vertices of the local graph), the ghost columns keep their numbers in P A P^T, and the rows
+// that read one are placed behind all the others, so that rows [0, liship_csr_plan_reordered_inner_rows) can run while the halo travels.
+extern "C" int liship_csr_plan_set_ghost_columns(liship_csr_plan_t p, int ncols)
+{
+    if (!p || ncols < p->n) return LISHIP_ERR_ARG;
+    p->ncols = ncols;
+    return 0;
+}
+extern "C" int liship_csr_plan_reordered_inner_rows(liship_csr_plan_t p) { return (p && p->inner) ? (p->ncols > p->n ? p->r_inner_end : p->n) : 0; }
 // the permutation of the reordered form to the host (n entries); LISHIP_ERR_ARG when the plan has none
 extern "C" int liship_csr_plan_reorder_permutation(liship_csr_plan_t p, int *out_host)
 {
@@ -1828,8 +1841,9 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
     const int mi = min_items_per_listed > 0 ? min_items_per_listed : 4;
     if (p->lcol && p->ndcol * (long long)mi <= p->nnz) return 0;   // lists short already: the numbering is local (no lists at all: too many distinct columns per row block)
     hipStream_t st = as_stream(stream);
-    const int n = p->n;
+    const int n = p->n, ncols = p->ncols > p->n ? p->ncols : p->n;
     const size_t nnz = (size_t)p->nnz;
+    int inner_rows = n;
     // short rows (the row-gather kernel: no lists to judge by): the 128 B lines of x a row block touches.  A grid in its natural order touches ~0.05 per entry (the
     // same lines serve a block's neighbouring rows), a numbering without locality ~1
     long long lines_before = 0;
@@ -1853,7 +1867,7 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
             const int r = hint[i];
             if (r < 0 || r >= n || seen[r]) have_order = false; else { seen[r] = 1; order[i] = r; }
         }
-    } else if (e == hipSuccess) have_order = order_dev::device_order(n, ptr, idx, p->products ? 6 : 3, order, st);      // long rows (dense neighbourhoods): six landmarks, short rows: three
+    } else if (e == hipSuccess) have_order = order_dev::device_order(n, ncols, ptr, idx, p->products ? 6 : 3, order, &inner_rows, st);      // long rows (dense neighbourhoods): six landmarks, short rows: three
     if (e == hipSuccess && have_order) {
         bool moved = false;
         hptr2[0] = 0;
@@ -1872,7 +1886,7 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
             if (e == hipSuccess) e = hipMemsetAsync(p->r_val + nnz, 0, sizeof(double) * 16, st);
             if (e == hipSuccess) {
                 csr_reorder_inverse<<<(n + 255) / 256, 256, 0, st>>>(n, p->r_perm, inv);
-                csr_reorder_rows<<<(n + 3) / 4, 256, 0, st>>>(n, ptr, idx, val, p->r_perm, inv, p->r_ptr, p->r_idx, p->r_val, inv + n);
+                csr_reorder_rows<<<(n + 3) / 4, 256, 0, st>>>(n, ptr, idx, val, p->r_perm, inv, p->r_ptr, p->r_idx, p->r_val, inv + n, ncols);
                 e = hipGetLastError();
             }
             int bad = 0;
@@ -1893,7 +1907,7 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
     }
     free(hptr); free(hidx); free(order); free(hptr2);
     if (inv) (void)hipFree(inv);
-    if (keep) { in->first_term = p->first_term; p->inner = in; return 0; }
+    if (keep) { in->first_term = p->first_term; in->ncols = p->ncols; p->inner = in; p->r_inner_end = (ncols > n && !hint) ? inner_rows : 0; return 0; }
     if (in) (void)liship_csr_plan_destroy(in);
     if (p->r_ptr) (void)hipFree(p->r_ptr);
     if (p->r_idx) (void)hipFree(p->r_idx);

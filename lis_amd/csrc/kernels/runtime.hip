@@ -131,6 +131,46 @@ extern "C" int liship_timer_elapsed_ms(void *timer, float *ms)
     HIP_TRY(hipEventElapsedTime(ms, t->a, t->b));
     return 0;
 }
+// ---- the box's streaming yardstick: workgroup b reads READS consecutive tiles of 512 doubles (src[(b * READS + k) * 512 + ...]: ONE read stream that advances READS
+// times as fast as the write stream) and writes their sum to dst[b * 512 + ...]; 16 B per lane, nontemporal both ways -- the traffic shape of the products
+// (13 : 1 is the CSR product's read : write ratio on SURVEY 8d's bytes) without a single gather or index.  What this kernel reaches on a box is what "the HBM
+// roofline" means on that box; bench.py prints it beside the product's fraction.  (READS separate streams n doubles apart -- the first form of this kernel --
+// reach LESS than the CSR product itself: 5.8 against 6.4 TB/s on the same box.)
+namespace {
+template <int READS>
+__global__ __launch_bounds__(256) void stream_sum_kernel(size_t ntiles, const double *__restrict__ src, double *__restrict__ dst)
+{
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {               // persistent workgroups walking the tiles grid-stride (gridDim = 0: one tile per workgroup)
+        const double *s = src + t * 512 * READS + (size_t)threadIdx.x * 2;
+        v2f64 v[READS];
+#pragma unroll
+        for (int k = 0; k < READS; k++) v[k] = load_stream(reinterpret_cast<const v2f64 *>(s + (size_t)k * 512));
+        v2f64 a = v[0];
+#pragma unroll
+        for (int k = 1; k < READS; k++) { a.x += v[k].x; a.y += v[k].y; }
+        store_stream(reinterpret_cast<v2f64 *>(dst + t * 512 + (size_t)threadIdx.x * 2), a);
+    }
+}
+}
+// wgs_per_cu: 0 = one workgroup per tile, else that many persistent workgroups per CU (256 CUs)
+extern "C" int liship_stream_yardstick(int reads, size_t n, const double *src, double *dst, int wgs_per_cu, void *stream)
+{
+    if (!src || !dst || (n & 511) || n == 0 || wgs_per_cu < 0) return LISHIP_ERR_ARG;
+    const size_t ntiles = n / 512;
+    const unsigned grid = wgs_per_cu > 0 ? (unsigned)(256 * wgs_per_cu) : (unsigned)ntiles;
+    hipStream_t st = as_stream(stream);
+    switch (reads) {
+    case 1:  stream_sum_kernel<1><<<grid, 256, 0, st>>>(ntiles, src, dst); break;
+    case 2:  stream_sum_kernel<2><<<grid, 256, 0, st>>>(ntiles, src, dst); break;
+    case 4:  stream_sum_kernel<4><<<grid, 256, 0, st>>>(ntiles, src, dst); break;
+    case 8:  stream_sum_kernel<8><<<grid, 256, 0, st>>>(ntiles, src, dst); break;
+    case 13: stream_sum_kernel<13><<<grid, 256, 0, st>>>(ntiles, src, dst); break;
+    default: return LISHIP_ERR_ARG;
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" const char *liship_error_string(int code)
 {
     if (code == 0) return "success";

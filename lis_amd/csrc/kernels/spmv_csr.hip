@@ -668,7 +668,7 @@ static bool plan_has_reordered_form(const liship_csr_plan_s *p)      // ... for 
 // (tools/scrambled_short_rows_probe.py: 160^3 7-point, numbered at random inside runs of 4096: 0.130 ms as it is, 0.257 ms renumbered per product -- and 0.06 inside a solve)
 // Opt-in even there (liship_spmv_csr_set_reorder(2), LIS_AMD_REORDER_PRODUCTS=1): over six boxes the Queen-class product moved between -5.5 % and +1.5 % -- the
 // two passes eat what the kernel gains (0.636 -> 0.58-0.60 ms), and the spread of a box's page placement is as large as the rest.  The loops take the whole gain.
-static bool plan_runs_reordered(const liship_csr_plan_s *p) { return g_reorder == 2 && plan_has_reordered_form(p) && p->inner->products; }
+static bool plan_runs_reordered(const liship_csr_plan_s *p) { return g_reorder == 2 && plan_has_reordered_form(p) && p->inner->products && p->ncols <= p->n; }      // (a rank's local matrix: x carries ghost entries behind the rows -- its single products keep the caller's numbering)
 static int launch_reordered(liship_csr_plan_t p, const double *x, double *y, hipStream_t st)
 {
     const liship_csr_plan_s *q = p->inner;
@@ -701,6 +701,27 @@ extern "C" int liship_permute_scatter_f64(int n, const int *perm, const double *
     csr_reorder_scatter_kernel<<<(n / 3 + 256) / 256, 256, 0, as_stream(stream)>>>(n, perm, xp, x);
     LAUNCH_CHECK();
     return 0;
+}
+namespace {
+__global__ void rows_of_list_kernel(int count, const int *__restrict__ inv, const int *__restrict__ index, int *__restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) out[k] = inv[index[k]];
+}
+}
+extern "C" int liship_permute_rows_of_list(int n, const int *perm, int count, const int *index, int *out, void *stream)      // out[k] = new position of row index[k]
+{
+    if (n < 0 || count < 0 || (n > 0 && !perm) || (count > 0 && (!index || !out))) return LISHIP_ERR_ARG;
+    if (count == 0 || n == 0) return 0;
+    hipStream_t st = as_stream(stream);
+    int *inv = nullptr;
+    HIP_TRY(hipMalloc(&inv, sizeof(int) * (size_t)n));
+    csr_reorder_inverse<<<(n + 255) / 256, 256, 0, st>>>(n, perm, inv);
+    rows_of_list_kernel<<<(count + 255) / 256, 256, 0, st>>>(count, inv, index, out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(inv);
+    return e == hipSuccess ? 0 : (int)e;
 }
 // upper bound of the partial-sum slots the fused product needs when it is launched in up to three row ranges (liship_spmv_csr_rows_dot_f64)
 extern "C" long long liship_csr_plan_fused_slots(liship_csr_plan_t p)

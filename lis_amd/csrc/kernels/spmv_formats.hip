@@ -76,24 +76,30 @@ void spmv_ell_kernel(int n, int maxnzr, const int *__restrict__ idx, const doubl
         int c[UNROLL][ROWS];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            const int j = min(j0 + u, maxnzr - 1);          // clamped: the tail repeats the last column, masked below
-            const size_t k = (size_t)j * (size_t)n + (size_t)r;
-            if (ROWS == 2) {
-                const v2f64 vv = load_stream(reinterpret_cast<const v2f64 *>(val + k));
-                v[u][0] = vv.x; v[u][ROWS - 1] = vv.y;
-                if (CODED) {
-                    const unsigned short two = load_stream(reinterpret_cast<const unsigned short *>(codes + k));
-                    c[u][0] = r + dictL[two & 255]; c[u][ROWS - 1] = r + 1 + dictL[two >> 8];
-                } else {
-                    const v2i32 cc = load_stream(reinterpret_cast<const v2i32 *>(idx + k));
-                    c[u][0] = cc.x; c[u][ROWS - 1] = cc.y;
-                }
-            } else { v[u][0] = load_stream(val + k); c[u][0] = load_stream(idx + k); }
+            // slots past the last jagged column (7 columns in batches of 8: the eighth) load NOTHING -- the test is wave-uniform, a scalar branch.  They used to repeat
+            // the last column's loads under a mask: one load in eight for nothing (round 6: 7-point ELL at 512^3 2.35 -> 2.2x ms)
+            if (j0 + u < maxnzr) {
+                const size_t k = (size_t)(j0 + u) * (size_t)n + (size_t)r;
+                if (ROWS == 2) {
+                    const v2f64 vv = load_stream(reinterpret_cast<const v2f64 *>(val + k));
+                    v[u][0] = vv.x; v[u][ROWS - 1] = vv.y;
+                    if (CODED) {
+                        const unsigned short two = load_stream(reinterpret_cast<const unsigned short *>(codes + k));
+                        c[u][0] = r + dictL[two & 255]; c[u][ROWS - 1] = r + 1 + dictL[two >> 8];
+                    } else {
+                        const v2i32 cc = load_stream(reinterpret_cast<const v2i32 *>(idx + k));
+                        c[u][0] = cc.x; c[u][ROWS - 1] = cc.y;
+                    }
+                } else { v[u][0] = load_stream(val + k); c[u][0] = load_stream(idx + k); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < ROWS; i++) { v[u][i] = 0.0; c[u][i] = r; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
 #pragma unroll
-            for (int i = 0; i < ROWS; i++) xv[u][i] = x[c[u][i]];
+            for (int i = 0; i < ROWS; i++) xv[u][i] = (j0 + u < maxnzr) ? x[c[u][i]] : 0.0;
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
 #pragma unroll
@@ -135,20 +141,31 @@ void spmv_dia_kernel(int n, int ncols, int nnd, const int *__restrict__ off,
     for (int d0 = 0; d0 < nnd; d0 += UNROLL) {
         double v[UNROLL][ROWS], xv[UNROLL][ROWS];
         bool ok[UNROLL][ROWS];
+        int o_[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) o_[u] = off[min(d0 + u, nnd - 1)];       // the batch's offsets first (scalar loads, one wait for all of them): taken one by one inside the
+                                                                                   // slots below, every diagonal's x loads waited for a scalar-cache round trip of their own
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) asm volatile("" : "+s"(o_[u]));          // (the compiler sinks the loads back into the slots otherwise)
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            const int d = min(d0 + u, nnd - 1);
-            const size_t k = (size_t)d * (size_t)n + (size_t)r;
-            if (ROWS == 2) {
-                const v2f64 vv = load_stream(reinterpret_cast<const v2f64 *>(val + k));
-                v[u][0] = vv.x; v[u][ROWS - 1] = vv.y;
-            } else v[u][0] = load_stream(val + k);
-            const int o = off[d];
+            if (d0 + u < nnd) {                       // wave-uniform: slots past the last diagonal load nothing (they used to repeat the last diagonal's loads under a mask)
+                const int d = d0 + u;
+                const size_t k = (size_t)d * (size_t)n + (size_t)r;
+                if (ROWS == 2) {
+                    const v2f64 vv = load_stream(reinterpret_cast<const v2f64 *>(val + k));
+                    v[u][0] = vv.x; v[u][ROWS - 1] = vv.y;
+                } else v[u][0] = load_stream(val + k);
+                const int o = o_[u];
 #pragma unroll
-            for (int i = 0; i < ROWS; i++) {
-                const int c = r + i + o;
-                ok[u][i] = (d0 + u < nnd) && c >= 0 && c < ncols;
-                xv[u][i] = x[ok[u][i] ? c : r];
+                for (int i = 0; i < ROWS; i++) {
+                    const int c = r + i + o;
+                    ok[u][i] = c >= 0 && c < ncols;
+                    xv[u][i] = x[ok[u][i] ? c : r];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < ROWS; i++) { v[u][i] = 0.0; xv[u][i] = 0.0; ok[u][i] = false; }
             }
         }
 #pragma unroll

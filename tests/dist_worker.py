@@ -7,6 +7,8 @@ into the library as host-memory callbacks (lis_amd_comm_init_callbacks).
     python tests/dist_worker.py device   # GPU box: lis_matvec / lis_solve on every rank's HBM slice
     python tests/dist_worker.py rccl     # >= WORLD_SIZE GPUs: the same checks with an RCCL communicator, one GPU per rank --
                                          # grouped ncclSend/ncclRecv halos, ncclAllGather + rank-order folds, the overlap stream
+    python tests/dist_worker.py renumber # GPU box: every rank renumbers ITS rows and owned columns inside its plan (ghost columns kept apart) and lis_solve
+                                         # iterates in those numberings -- the halo export lists renumbered with them
 """
 import ctypes as C
 import os
@@ -64,6 +66,12 @@ def main():
     assert lib.initialize([]) == 0
     assert lib.dll.lis_amd_comm_rank() == rank and lib.dll.lis_amd_comm_size() == world
     lib.dll.lis_amd_halo_exchange_host.argtypes = [capi.PM, capi.P_DBL]
+    if mode == "renumber":
+        renumber_checks(lib, rank, world)
+        dist.barrier()
+        print(f"rank {rank}/{world} {tag} OK", flush=True)
+        dist.destroy_process_group()
+        return
 
     cases = {
         "poisson_unaligned": orc.poisson3d(5, 4, 3),                  # 60 rows: slabs cut through planes
@@ -419,6 +427,84 @@ def device_checks(lib, name, A, ptr, idx, val, xg, yg, is_, ie, gn):
             assert S.contents.retcode == 0, (name, scale, S.contents.retcode)
             assert np.allclose(xs, xo[is_:ie], rtol=0, atol=1e-8), (name, scale, np.abs(xs - xo[is_:ie]).max())
             lib.lis_solver_destroy(S); lib.lis_vector_destroy(vb2); lib.lis_vector_destroy(vs2); lib.lis_matrix_destroy(B)
+
+
+def renumber_checks(lib, rank, world):
+    """Round 6: the plan-time renumbering on several ranks.  A 3-dof mesh (81 entries per row) cut into row blocks, the NODES of every block
+    numbered at random inside it -- a partitioned mesh whose local numbering has no locality.  Every rank's plan renumbers its rows and owned columns on the device
+    (ghost columns keep their numbers, the rows that read one go behind the others), lis_matvec keeps the bits of the single-process product, and lis_solve iterates
+    in the ranks' own numberings: b, x0, 1/diag gathered once, the export lists of the halo renumbered with the rows, x scattered back -- the counts and the
+    solution of the run in the caller's numbering (sums fold in another order), with the overlap of interior rows and halo on and off."""
+    dll = lib.dll
+    dll.lis_amd_set_reorder_after.argtypes = [C.c_longlong]
+    dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
+    G = 42                                                         # 74 088 nodes, 222 264 rows: >= 65 536 rows on each of 2 or 3 ranks, nodes divisible by both
+    ptr, idx, val = orc.fem3(G, 3)[:3]
+    gn = len(ptr) - 1
+    nodes = gn // 3
+    assert nodes % world == 0
+    rng = np.random.default_rng(77)
+    pn = np.concatenate([r * (nodes // world) + rng.permutation(nodes // world) for r in range(world)])
+    perm = (3 * pn[:, None] + np.arange(3)[None, :]).reshape(-1)
+    inv = np.empty(gn, np.int64); inv[perm] = np.arange(gn)
+    lens = np.diff(ptr)[perm]
+    p2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    src = np.repeat(np.asarray(ptr[:-1], np.int64)[perm] - p2[:-1], lens) + np.arange(p2[-1])
+    ptr, idx, val = p2, inv[idx[src]].astype(np.int32), val[src]
+    is_, ie = isie(rank, world, gn)
+    n = ie - is_
+    assert n >= 65536
+    lp, li, lv = local_rows(ptr, idx, val, is_, ie)
+    xg = np.random.default_rng(19).uniform(-1, 1, gn)
+    yg = orc.spmv_csr(ptr, idx, val, xg)
+    xt = np.cos(np.arange(gn) * 0.37) + 1.5
+    bg = orc.spmv_csr(ptr, idx, val, xt)
+    dll.lis_amd_set_reorder_after(0)                               # the renumbered form at plan time (the default builds it after 4096 products)
+    try:
+        A = lisdrv.make_csr(lib, lp, li, lv, n=0, gn=gn)
+        assert A.contents.np > A.contents.n                        # (there are ghost columns)
+        vx, vy, vb, vs = (lisdrv.new_vector(lib, A, None) for _ in range(4))
+        assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(xg[is_:ie]).ctypes.data_as(capi.P_DBL), vx) == 0
+        assert lib.lis_vector_set_values2(capi.LIS_INS_VALUE, is_, n, np.ascontiguousarray(bg[is_:ie]).ctypes.data_as(capi.P_DBL), vb) == 0
+        y = np.empty(n)
+        assert lib.lis_matvec(A, vx, vy) == 0 and lib.lis_vector_get_values(vy, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
+        assert np.array_equal(y.view(np.uint64), yg[is_:ie].view(np.uint64))
+        listed = dll.lis_amd_matrix_reordered(A)
+        assert listed > 0, "the rank's plan holds no renumbered form"
+        runs = {}
+        for opts in ("-i cg -p jacobi", "-i bicgstab -p none", "-i gmres -restart 30 -p jacobi", "-i bicg -p none"):
+            for on, overlap in ((1, 1), (1, 0), (0, 1)):
+                lib.liship_spmv_csr_set_reorder(on)
+                dll.lis_amd_set_overlap(overlap)
+                S = capi.PS()
+                lib.lis_solver_create(C.byref(S))
+                lib.lis_solver_set_option(f"{opts} -tol 1e-11 -maxiter 800 -initx_zeros true -print none".encode(), S)
+                assert lib.lis_solve(A, vb, vs, S) == 0, (opts, on, overlap)
+                want = 1 if (on and "bicg " not in opts + " ") else 0          # BiCG multiplies by A^T: the caller's numbering on several ranks
+                assert dll.lis_amd_last_solve_renumbered() == want, (opts, on, overlap, dll.lis_amd_last_solve_renumbered())
+                xs = np.empty(n)
+                assert lib.lis_vector_get_values(vs, is_, n, xs.ctypes.data_as(capi.P_DBL)) == 0
+                assert S.contents.retcode == 0, (opts, on, overlap, S.contents.retcode, S.contents.iter)
+                runs[(opts, on, overlap)] = (S.contents.iter, xs)
+                lib.lis_solver_destroy(S)
+            lib.liship_spmv_csr_set_reorder(1)
+            dll.lis_amd_set_overlap(1)
+            it0, x0 = runs[(opts, 0, 1)]
+            for key in ((opts, 1, 1), (opts, 1, 0)):
+                it, xs = runs[key]
+                slack = it0 // 7 if "bicgstab" in opts else it0 // 50
+                assert abs(it - it0) <= max(1, slack), (key, it, it0)
+                assert np.linalg.norm(xs - x0) <= 1e-8 * np.linalg.norm(x0) and np.linalg.norm(xs - xt[is_:ie]) <= 1e-7 * np.linalg.norm(xt[is_:ie]), key
+        # the product after the solves: the caller's tables are back (the bits of the single-process product)
+        assert lib.lis_matvec(A, vx, vy) == 0 and lib.lis_vector_get_values(vy, is_, n, y.ctypes.data_as(capi.P_DBL)) == 0
+        assert np.array_equal(y.view(np.uint64), yg[is_:ie].view(np.uint64))
+        for v in (vx, vy, vb, vs):
+            lib.lis_vector_destroy(v)
+        lib.lis_matrix_destroy(A)
+    finally:
+        dll.lis_amd_set_reorder_after(4096)
+    if rank == 0:
+        print(f"renumbered form on every rank; rank 0 lists {listed} columns", flush=True)
 
 
 def device_poisson_generator(lib, rank, world):

@@ -79,6 +79,9 @@ def test_bench_line_has_the_contract_fields():
     assert f["x_equals_one"]["value"] > 0
 
     assert all(0 < v <= 1.0 for v in _fracs(d))
+    yd = d["box_yardstick"]                                 # the box's own streaming rate (13 read streams : 1 write stream, no gather) beside the headline's fraction
+    assert yd["reads"] == 13 and yd["bytes_per_launch"] == 14 * 8 * yd["n"] and yd["rate_GBs"] > 0 and yd["copy_1_to_1_GBs"] > 0
+    assert abs(r["frac_of_box_yardstick"] - r["achieved"] / yd["rate_GBs"]) < 1e-3
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

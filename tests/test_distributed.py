@@ -64,6 +64,14 @@ def test_late_halo_changes_nothing(env):
     _launch("device", 2, extra_env=env)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_renumbered_solves_on_several_ranks(world):
+    """every rank renumbers its own rows and owned columns inside its plan (ghost columns and halo slots keep their place, the export lists move with the rows):
+    products keep the single-process bits, lis_solve iterates in the ranks' numberings (tests/dist_worker.py renumber_checks)"""
+    _launch("renumber", world, timeout=900)
+
+
 def _gpu_count():
     try:
         import torch

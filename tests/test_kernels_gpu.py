@@ -833,8 +833,10 @@ def test_reordered_plan_bit_exact(lib, kind):
     re = lib.liship_csr_plan_reordered(plan)
     if kind in ("natural", "short_rows_natural"):
         assert re == 0 and lib.liship_csr_plan_fused_dots(plan) == 1
-        check(lib.liship_csr_plan_reorder(plan, dptr.ptr, didx.ptr, dval.ptr, 1 << 20, None))      # forced to try: the walk cannot list 1/4 fewer columns than the mesh order
-        assert lib.liship_csr_plan_reordered(plan) == 0
+        check(lib.liship_csr_plan_reorder(plan, dptr.ptr, didx.ptr, dval.ptr, 1 << 20, None))      # forced to try: a candidate is kept only when it lists 1/4 fewer columns than the mesh order
+        forced = lib.liship_csr_plan_reordered(plan)      # (the Cuthill-McKee walk of rounds 4-5 never did; the six-landmark cells of round 6 do on this 28^3 mesh: compact 3-D cells against line-by-line rows)
+        assert forced == 0 or (listed > 0 and forced * 4 <= listed * 3), (forced, listed)
+        re = forced
     else:
         assert re > 0 and (listed == 0 or re * 4 <= listed * 3), (re, listed)
         assert lib.liship_csr_plan_fused_dots(plan) == 1                          # by default products stay in the caller's numbering (permuting x and y per product eats the gain)
@@ -887,6 +889,55 @@ def test_reordered_plan_bit_exact(lib, kind):
             check(lib.liship_csr_plan_reorder_with(plan_g, dptr.ptr, didx_g.ptr, dval.ptr, 0, None if hint is None else hint.ctypes.data, None))
             assert lib.liship_csr_plan_reordered(plan_g) == 0
             check(lib.liship_csr_plan_destroy(plan_g))
+        # ... DECLARED as a rank's ghost columns (liship_csr_plan_set_ghost_columns: a multi-rank job's local rows, lis_matrix_mpi.c:274-306), the matrix is renumbered all the
+        # same: the ghost columns keep their numbers in P A P^T, the rows that read one come behind all the others (rows [0, inner) can run while the halo travels), the
+        # export list of a halo is the same rows under their new numbers -- and the product has the oracle's bits
+        lib.liship_spmv_csr_set_reorder(1)
+        sel = rng.integers(0, len(idx), 5000)
+        idx_g = idx.copy(); idx_g[sel] = n + (sel % 8)
+        xg = np.concatenate([np.where(np.isfinite(x), x, 0.25), rng.uniform(-1, 1, 8)])
+        yg = orc.spmv_csr(ptr, idx_g, val, xg)
+        didx_g = DA.from_host(idx_g, np.int32)
+        plan_g = C.c_void_p()
+        check(lib.liship_csr_plan_create(C.byref(plan_g), n, dptr.ptr, None))
+        check(lib.liship_csr_plan_localize_columns(plan_g, dptr.ptr, didx_g.ptr, None))
+        check(lib.liship_csr_plan_set_ghost_columns(plan_g, n + 8))
+        check(lib.liship_csr_plan_reorder(plan_g, dptr.ptr, didx_g.ptr, dval.ptr, 0, None))
+        assert lib.liship_csr_plan_reordered(plan_g) > 0
+        inner_rows = lib.liship_csr_plan_reordered_inner_rows(plan_g)
+        has_ghost = np.add.reduceat((idx_g >= n).astype(np.int64), ptr[:-1]) > 0
+        assert inner_rows == n - int(has_ghost.sum())                  # (one connected mesh: every row has a component)
+        inner, rp, ri, rv, pm = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.liship_csr_plan_reordered_form(plan_g, C.byref(inner), C.byref(rp), C.byref(ri), C.byref(rv), C.byref(pm)))
+        hp, hperm = np.empty(n + 1, np.int32), np.empty(n, np.int32)
+        check(lib.liship_memcpy_d2h(hp.ctypes.data, rp, hp.nbytes, None)); check(lib.liship_memcpy_d2h(hperm.ctypes.data, pm, hperm.nbytes, None))
+        check(lib.liship_device_synchronize())
+        hi = np.empty(hp[-1], np.int32)
+        check(lib.liship_memcpy_d2h(hi.ctypes.data, ri, hi.nbytes, None)); check(lib.liship_device_synchronize())
+        assert np.array_equal(np.sort(hperm), np.arange(n)) and np.array_equal(has_ghost[hperm], np.arange(n) >= inner_rows)
+        assert hi[:hp[inner_rows]].max() < n and np.array_equal(np.sort(hi[hi >= n]), np.sort(idx_g[idx_g >= n]))
+        xp, yp, yb = DA.from_host(np.zeros(n + 8), np.float64), DA.from_host(np.full(n, np.nan), np.float64), DA.from_host(np.full(n, np.nan), np.float64)
+        dxg = DA.from_host(xg, np.float64)
+        check(lib.liship_permute_gather_f64(n, pm, dxg.ptr, xp.ptr, None))
+        check(lib.liship_memcpy_d2d(xp.ptr + 8 * n, dxg.ptr + 8 * n, 64, None))          # the ghost slots: where the halo always lands
+        check(lib.liship_spmv_csr_f64(inner, rp, ri, rv, xp.ptr, yp.ptr, None))
+        check(lib.liship_permute_scatter_f64(n, pm, yp.ptr, yb.ptr, None))
+        assert np.array_equal(yb.to_host().view(np.uint64), yg.view(np.uint64))
+        for a, b in ((0, inner_rows), (inner_rows, n)):                                    # ... in the two launches of an overlapped product
+            check(lib.liship_spmv_csr_rows_f64(inner, a, b, rp, ri, rv, xp.ptr, yp.ptr, None))
+        check(lib.liship_permute_scatter_f64(n, pm, yp.ptr, yb.ptr, None))
+        assert np.array_equal(yb.to_host().view(np.uint64), yg.view(np.uint64))
+        ex = np.sort(rng.choice(n, 3000, replace=False)).astype(np.int32)                  # a halo export list
+        dex, dout = DA.from_host(ex, np.int32), DA(3000, np.int32)
+        check(lib.liship_permute_rows_of_list(n, pm, 3000, dex.ptr, dout.ptr, None))
+        assert np.array_equal(hperm[dout.to_host()], ex)
+        for on in (2, 1):                                                                   # single products keep the caller's numbering (x carries the ghost entries behind the rows)
+            lib.liship_spmv_csr_set_reorder(on)
+            dy = DA.from_host(np.full(n, np.nan), np.float64)
+            check(lib.liship_spmv_csr_f64(plan_g, dptr.ptr, didx_g.ptr, dval.ptr, dxg.ptr, dy.ptr, None))
+            assert np.array_equal(dy.to_host().view(np.uint64), yg.view(np.uint64))
+        assert lib.liship_csr_plan_fused_dots(plan_g) == 1
+        check(lib.liship_csr_plan_destroy(plan_g))
     if kind == "nodes":
         # a plan for the same pattern with other values (a matrix edited in place): the first plan's permutation as a hint, no second walk; a broken hint is dropped
         lib.liship_spmv_csr_set_reorder(2)

@@ -1117,8 +1117,9 @@ LIS_INT lis_solve_kernel(LIS_MATRIX A, LIS_VECTOR b, LIS_VECTOR x, LIS_SOLVER so
 		const double *rv = NULL;
 		/* A^T x: the HBM copy is transposed in HBM (lis_matvech.c) -- of an unsplit CSR matrix, that is P A P^T's while it is swapped in; it gets a set of fields of its own */
 		/* (several ranks: each rank renumbers its own rows and owned columns, the ghost columns and the halo slots keep their place -- lisc_halo_renumbered --; the
-		 * solvers that multiply by A^T keep the caller's numbering there: the reverse halo's transposed rows are laid out for it) */
-		const int t_ok = !needs_t || (lisg.nprocs == 1 && Awork->matrix_type == LIS_MATRIX_CSR && !Awork->is_splited);
+		 * transposed copy of the swapped-in arrays has the np local columns as its rows like any rank's A^T, and the reverse halo adds the neighbours' sums at the
+		 * renumbered export rows: lisd_spmv_t / lisc_reduce_device read the same swapped tables) */
+		const int t_ok = !needs_t || (Awork->matrix_type == LIS_MATRIX_CSR && !Awork->is_splited);
 		const int multi = lisg.nprocs > 1 && Awork->commtable;
 		/* the renumbered form is built LAZILY: by the first solve that finds the plan has served lisg.reorder_after products (lis_device.c) */
 		if (!scale && !Awork->is_scaled && !lisg.ref_reductions && !lisg.no_reorder && t_ok) { if ((err = lisd_mat_lazy_reorder(Awork))) goto out; }

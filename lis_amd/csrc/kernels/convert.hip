@@ -27,12 +27,19 @@ void scan_tile_sums(int m, const int *__restrict__ count, long long *__restrict_
     for (int w = BLOCK / 2; w > 0; w >>= 1) { if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w]; __syncthreads(); }
     if (threadIdx.x == 0) sums[blockIdx.x] = part[0];
 }
-__global__ void scan_tile_offsets(int ntiles, long long *__restrict__ sums)      // one thread: a few thousand tiles at most
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    long long run = 0;
-    for (int t = 0; t < ntiles; t++) { const long long v = sums[t]; sums[t] = run; run += v; }
-    sums[ntiles] = run;
+__global__ __launch_bounds__(1024) void scan_tile_offsets(int ntiles, long long *__restrict__ sums)      // one workgroup: sums[t] = sum of the tiles before t, sums[ntiles] = all
+{                                                                                                       // (one THREAD walked the 32 768 tiles of a 512^3 conversion in 2.3 ms)
+    __shared__ long long part[1024];
+    const int t = threadIdx.x, per = (ntiles + 1023) / 1024;
+    const int lo = min(ntiles, t * per), hi = min(ntiles, lo + per);
+    long long s = 0;
+    for (int i = lo; i < hi; i++) s += sums[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) { long long run = 0; for (int i = 0; i < 1024; i++) { const long long v = part[i]; part[i] = run; run += v; } sums[ntiles] = run; }
+    __syncthreads();
+    long long run = part[t];
+    for (int i = lo; i < hi; i++) { const long long v = sums[i]; sums[i] = run; run += v; }
 }
 __global__ __launch_bounds__(BLOCK)
 void scan_tiles(int m, const int *__restrict__ count, const long long *__restrict__ sums, int *__restrict__ out)
@@ -60,7 +67,7 @@ int exclusive_scan(int m, const int *count, int *out, long long *scratch, hipStr
     const int tiles = (m + TILE - 1) / TILE;
     if (m <= 0) { HIP_TRY(hipMemsetAsync(out, 0, sizeof(int), st)); return 0; }
     scan_tile_sums<<<tiles, BLOCK, 0, st>>>(m, count, scratch);
-    scan_tile_offsets<<<1, 1, 0, st>>>(tiles, scratch);
+    scan_tile_offsets<<<1, 1024, 0, st>>>(tiles, scratch);
     scan_tiles<<<tiles, BLOCK, 0, st>>>(m, count, scratch, out);
     LAUNCH_CHECK();
     return 0;

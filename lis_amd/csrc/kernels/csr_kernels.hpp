@@ -875,18 +875,21 @@ void csr_reorder_scatter_kernel(int n, const int *__restrict__ perm, const doubl
 // PASS 0 counts them (nd[b]; 0 = no list: empty block, a row longer than the stage, more than ndmax columns);
 // PASS 1 writes the list at dcol[doff[b]...) (padded to a multiple of 4 with its last entry) and, per non-zero, the
 // position of its column in the list.
-template <int BLOCK, int PASS, int LOCAL_SORT>
+// LOCAL_SORT: the power of two the bitonic network sorts (>= the block's entries), DCAP: room for its distinct columns.  (8192, 4352) serves the 4096-item blocks
+// of rounds 2-3; the 3584- / 3072-item blocks of the register-position kernels fit (4096, 3840): 78 stages over 4096 keys instead of 91 over 8192 (round 6:
+// the three plans of a Queen-class BiCG solve -- A, A^T, P A P^T -- spent 270 ms here).
+template <int BLOCK, int PASS, int LOCAL_SORT, int DCAP = LOCAL_SORT / 2 + 256>
 __global__ __launch_bounds__(BLOCK)
 void csr_local_build(const v2i32 *__restrict__ blk, const int *__restrict__ idx, int cap, int ndmax,
                      int *__restrict__ nd_out, const int *__restrict__ doff, int *__restrict__ dcol,
                      unsigned short *__restrict__ lcol, int shift = 0)      // shift (PASS 0 only): count distinct (column >> shift) -- 4: the 128 B lines of x a block touches
 {
     __shared__ int keys[LOCAL_SORT];
-    __shared__ int dist[LOCAL_SORT / 2 + 256];
+    __shared__ int dist[DCAP];
     __shared__ int wsum[BLOCK / WAVE];
     const int b = blockIdx.x, t = threadIdx.x;
     const int k0 = blk[b].y, k1 = blk[b + 1].y, cnt = k1 - k0;
-    if (cnt <= 0 || cnt > cap || cnt > LOCAL_SORT / 2 + 256) { if (PASS == 0 && t == 0) nd_out[b] = 0; return; }
+    if (cnt <= 0 || cnt > cap || cnt > DCAP || cnt > LOCAL_SORT) { if (PASS == 0 && t == 0) nd_out[b] = 0; return; }
     if (PASS == 1 && doff[b + 1] == doff[b]) return;
     for (int i = t; i < LOCAL_SORT; i += BLOCK) keys[i] = i < cnt ? (idx[k0 + i] >> shift) : 0x7fffffff;
     __syncthreads();

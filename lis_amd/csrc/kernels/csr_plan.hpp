@@ -1686,7 +1686,8 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
         free(off);
         nd_dev = nullptr; off = nullptr;
         HIP_TRY(hipMalloc(&nd_dev, sizeof(int) * (size_t)(nb + 1)));
-        csr_local_build<256, 0, 8192><<<nb, 256, 0, st>>>(p->blk, idx, capl, NDMAX, nd_dev, nullptr, nullptr, nullptr);
+        if (capl <= 3840) csr_local_build<256, 0, 4096, 3840><<<nb, 256, 0, st>>>(p->blk, idx, capl, NDMAX, nd_dev, nullptr, nullptr, nullptr);
+        else csr_local_build<256, 0, 8192><<<nb, 256, 0, st>>>(p->blk, idx, capl, NDMAX, nd_dev, nullptr, nullptr, nullptr);
         hipError_t e0 = hipGetLastError();
         off = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
         if (!off && e0 == hipSuccess) e0 = hipErrorOutOfMemory;
@@ -1722,7 +1723,8 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     if (e == hipSuccess) e = hipMemsetAsync(p->lcol, 0, lbytes, st);
     if (e == hipSuccess) e = hipMemcpyAsync(nd_dev, off, sizeof(int) * (size_t)(nb + 1), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        csr_local_build<256, 1, 8192><<<nb, 256, 0, st>>>(p->blk, idx, capl, NDMAX, nullptr, nd_dev, p->dcol, p->lcol);
+        if (capl <= 3840) csr_local_build<256, 1, 4096, 3840><<<nb, 256, 0, st>>>(p->blk, idx, capl, NDMAX, nullptr, nd_dev, p->dcol, p->lcol);
+        else csr_local_build<256, 1, 8192><<<nb, 256, 0, st>>>(p->blk, idx, capl, NDMAX, nullptr, nd_dev, p->dcol, p->lcol);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1783,7 +1785,8 @@ static long long block_lines(const liship_csr_plan_s *p, const int *idx, hipStre
     int *nd_dev = nullptr;
     if (hipMalloc(&nd_dev, sizeof(int) * (size_t)(nb + 1)) != hipSuccess) { (void)hipGetLastError(); return -1; }
     std::vector<int> nd((size_t)nb);
-    csr_local_build<256, 0, 8192><<<nb, 256, 0, st>>>(p->blk, idx, kGeom[p->geom].work + SLACK, 0x7fffffff, nd_dev, nullptr, nullptr, nullptr, 4);
+    if (kGeom[p->geom].work + SLACK <= 3840) csr_local_build<256, 0, 4096, 3840><<<nb, 256, 0, st>>>(p->blk, idx, kGeom[p->geom].work + SLACK, 0x7fffffff, nd_dev, nullptr, nullptr, nullptr, 4);
+    else csr_local_build<256, 0, 8192><<<nb, 256, 0, st>>>(p->blk, idx, kGeom[p->geom].work + SLACK, 0x7fffffff, nd_dev, nullptr, nullptr, nullptr, 4);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(nd.data(), nd_dev, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

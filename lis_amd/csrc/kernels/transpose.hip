@@ -77,17 +77,20 @@ void scan_tiles(int m, const int *__restrict__ count, const long long *__restric
 
 __global__ __launch_bounds__(BLOCK)
 void scatter_positions(int n, const int *__restrict__ ptr, const int *__restrict__ idx,
-                       const int *__restrict__ tptr, int *__restrict__ fill, int *__restrict__ pos)
+                       const int *__restrict__ tptr, int *__restrict__ fill, int *__restrict__ pos, int *__restrict__ rws)
 {
     const int r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
     for (int k = ptr[r]; k < ptr[r + 1]; k++) {
         const int c = idx[k];
-        pos[tptr[c] + atomicAdd(&fill[c], 1)] = k;
+        const int at = tptr[c] + atomicAdd(&fill[c], 1);
+        pos[at] = k;
+        if (rws) rws[at] = r;                         // the row travels with the position (round 6): no search for it afterwards
     }
 }
 
-__device__ void sift_down(int *a, int start, int end)
+// (a, b): positions and, when b is not NULL, their rows -- sorted together by position
+__device__ void sift_down(int *a, int *b, int start, int end)
 {
     int root = start;
     while (2 * root + 1 <= end) {
@@ -95,36 +98,76 @@ __device__ void sift_down(int *a, int start, int end)
         if (child + 1 <= end && a[child] < a[child + 1]) child++;
         if (a[root] >= a[child]) return;
         const int t = a[root]; a[root] = a[child]; a[child] = t;
+        if (b) { const int u = b[root]; b[root] = b[child]; b[child] = u; }
         root = child;
     }
 }
 
+constexpr int MID_FROM = 33, MID_TO = 2048;         // segment lengths a wavefront sorts by ranks in LDS (order_mid)
+
+// one lane per column: segments of up to 32 positions (insertion sort) and those beyond MID_TO (heap sort in place); the lengths in between are order_mid's
+// when `mid` says so.  rws == NULL (no room for the rows): the row of position k by binary search in ptr, as rounds 2-5 did for every entry.
 __global__ __launch_bounds__(BLOCK)
 void order_and_fill(int ncols, int nrows, const int *__restrict__ ptr, const double *__restrict__ val,
-                    const int *__restrict__ tptr, int *__restrict__ pos, int *__restrict__ tidx,
-                    double *__restrict__ tval)
+                    const int *__restrict__ tptr, int *__restrict__ pos, int *__restrict__ rws, int *__restrict__ tidx,
+                    double *__restrict__ tval, int mid)
 {
     const int c = blockIdx.x * BLOCK + threadIdx.x;
     if (c >= ncols) return;
-    int *a = pos + tptr[c];
+    int *a = pos + tptr[c], *b = rws ? rws + tptr[c] : nullptr;
     const int len = tptr[c + 1] - tptr[c];
+    if (mid && len >= MID_FROM && len <= MID_TO) return;
     if (len <= 32) {                                 // insertion sort
         for (int i = 1; i < len; i++) {
-            const int v = a[i];
+            const int v = a[i], w = b ? b[i] : 0;
             int j = i - 1;
-            while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; j--; }
+            while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; if (b) b[j + 1] = b[j]; j--; }
             a[j + 1] = v;
+            if (b) b[j + 1] = w;
         }
     } else {                                         // heap sort, in place
-        for (int s = (len - 2) / 2; s >= 0; s--) sift_down(a, s, len - 1);
-        for (int e = len - 1; e > 0; e--) { const int t = a[e]; a[e] = a[0]; a[0] = t; sift_down(a, 0, e - 1); }
+        for (int s = (len - 2) / 2; s >= 0; s--) sift_down(a, b, s, len - 1);
+        for (int e = len - 1; e > 0; e--) {
+            const int t = a[e]; a[e] = a[0]; a[0] = t;
+            if (b) { const int u = b[e]; b[e] = b[0]; b[0] = u; }
+            sift_down(a, b, 0, e - 1);
+        }
     }
     for (int i = 0; i < len; i++) {
         const int k = a[i];
-        int lo = 0, hi = nrows;                      // last row r with ptr[r] <= k
-        while (hi - lo > 1) { const int mid = lo + ((hi - lo) >> 1); if (ptr[mid] <= k) lo = mid; else hi = mid; }
+        int lo = 0;
+        if (b) lo = b[i];
+        else {
+            int hi = nrows;                          // last row r with ptr[r] <= k
+            while (hi - lo > 1) { const int m2 = lo + ((hi - lo) >> 1); if (ptr[m2] <= k) lo = m2; else hi = m2; }
+        }
         tidx[tptr[c] + i] = lo;
         tval[tptr[c] + i] = val[k];
+    }
+}
+
+// one WAVEFRONT per column, segments of MID_FROM .. MID_TO positions (the columns of a finite-element matrix: 81 entries; round 6): the segment goes to LDS, every
+// lane finds the rank of its elements by counting the smaller positions (positions are unique), and the entry lands where its rank says -- coalesced loads, no
+// dependent chain through global memory.  The lane-per-column heap sort took 0.23 s on the Queen-class matrix (most of the first BiCG solve).
+__global__ __launch_bounds__(BLOCK)
+void order_mid(int ncols, const double *__restrict__ val, const int *__restrict__ tptr, const int *__restrict__ pos, const int *__restrict__ rws,
+               int *__restrict__ tidx, double *__restrict__ tval)
+{
+    __shared__ int keys[BLOCK / WAVE][MID_TO];
+    const int wave = (int)threadIdx.x / WAVE, lane = (int)threadIdx.x & (WAVE - 1);
+    const int c = blockIdx.x * (BLOCK / WAVE) + wave;
+    const int b = c < ncols ? tptr[c] : 0, len = c < ncols ? tptr[c + 1] - b : 0;
+    const bool mine_to_do = len >= MID_FROM && len <= MID_TO;
+    int *k = keys[wave];
+    if (mine_to_do) for (int i = lane; i < len; i += WAVE) k[i] = pos[b + i];
+    __syncthreads();                                  // (every wavefront of the workgroup gets here, with or without a column of its own)
+    if (!mine_to_do) return;
+    for (int i = lane; i < len; i += WAVE) {
+        const int mine = k[i];
+        int rank = 0;
+        for (int j = 0; j < len; j++) rank += k[j] < mine;
+        tidx[b + rank] = rws[b + i];
+        tval[b + rank] = val[mine];
     }
 }
 
@@ -155,11 +198,15 @@ extern "C" int liship_csr_transpose_f64(int nrows, int ncols, int nnz, const int
         if (e != hipSuccess) return (int)e;
     }
     HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * (size_t)(ncols > 0 ? ncols : 1), st));
-    if (nrows > 0) scatter_positions<<<(nrows + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(nrows, ptr, idx, tptr, count, pos);
-    LAUNCH_CHECK();
-    if (ncols > 0) order_and_fill<<<(ncols + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(ncols, nrows, ptr, val, tptr, pos, tidx, tval);
-    LAUNCH_CHECK();
-    return 0;
+    int *rws = nullptr;                              // the row of every scattered position (nnz ints of scratch of its own; without it: the binary searches of rounds 2-5)
+    if (nnz > 0 && hipMalloc(&rws, sizeof(int) * (size_t)nnz) != hipSuccess) { (void)hipGetLastError(); rws = nullptr; }
+    if (nrows > 0) scatter_positions<<<(nrows + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(nrows, ptr, idx, tptr, count, pos, rws);
+    hipError_t e = hipGetLastError();
+    const bool mid = rws != nullptr && nrows > 0 && (long long)nnz > 8ll * ncols;      // (short rows on average: no column worth a wavefront)
+    if (e == hipSuccess && ncols > 0) { order_and_fill<<<(ncols + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(ncols, nrows, ptr, val, tptr, pos, rws, tidx, tval, mid ? 1 : 0); e = hipGetLastError(); }
+    if (e == hipSuccess && mid) { order_mid<<<(ncols + BLOCK / WAVE - 1) / (BLOCK / WAVE), BLOCK, 0, st>>>(ncols, val, tptr, pos, rws, tidx, tval); e = hipGetLastError(); }
+    if (rws) { if (e == hipSuccess) e = hipStreamSynchronize(st); (void)hipFree(rws); }
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 // ---- A^T x in the reference's order for OMP_NUM_THREADS = T > 1 (parity mode, liship_set_reference_reductions) ----------------

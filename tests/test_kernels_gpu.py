@@ -1492,11 +1492,26 @@ def test_gmres_device_chained_kernels(lib, n):
     assert np.array_equal(dV[0].to_host(), z)
 
 
-@pytest.mark.parametrize("name", ["p3d_16", "rand_5000", "rand_long_rows", "mostly_empty", "single_row", "rand_wide_77"])
+def _hub_columns():
+    """6000 rows of 12 random columns, every row also reading column 7 and every second one column 4001: two columns of 6000 / 3000 entries (the lane-per-column
+    heap sort beyond the wavefront's LDS stage), the rest short"""
+    ptr, idx, val = orc.random_csr(6000, 12, seed=21, ncols=6000, empty_rows=False)
+    rows = np.repeat(np.arange(6000), np.diff(ptr))
+    extra_r = np.concatenate([np.arange(6000), np.arange(0, 6000, 2)])
+    extra_c = np.concatenate([np.full(6000, 7), np.full(3000, 4001)])
+    r2, c2 = np.concatenate([rows, extra_r]), np.concatenate([idx, extra_c])
+    v2 = np.concatenate([val, np.random.default_rng(22).uniform(-1, 1, len(extra_r))])
+    o = np.argsort(r2, kind="stable")
+    p2 = np.concatenate([[0], np.cumsum(np.bincount(r2, minlength=6000))]).astype(np.int32)
+    return p2, c2[o].astype(np.int32), v2[o]
+
+
+@pytest.mark.parametrize("name", ["p3d_16", "rand_5000", "rand_long_rows", "mostly_empty", "single_row", "rand_wide_77", "fem3_12", "hub_columns"])
 def test_csr_transpose_in_scatter_order(lib, name):
     """A^T built in HBM lists every transposed row's entries by their position in the source arrays (the order of
-    lis_matvech_csr's scatter): arrays equal to a stable host transposition, whatever the atomics did."""
-    ptr, idx, val = CSR_CASES[name]()
+    lis_matvech_csr's scatter): arrays equal to a stable host transposition, whatever the atomics did -- short columns (a lane each), the 33 .. 2048-entry
+    columns of finite-element matrices (a wavefront each, ranks counted in LDS: round 6) and hub columns beyond that"""
+    ptr, idx, val = _fem(12) if name == "fem3_12" else _hub_columns() if name == "hub_columns" else CSR_CASES[name]()
     n = len(ptr) - 1
     ncols = max(n, int(idx.max()) + 1 if len(idx) else 1)
     nnz = len(idx)

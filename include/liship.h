@@ -177,6 +177,9 @@ int  liship_csr_plan_local_runs(liship_csr_plan_t plan);
 int  liship_spmv_csr_set_local_runs(int on);
 /* 0: the block-local kernel keeps one entry per lane and step (eight 2 B position loads) instead of pairs of neighbouring entries (four 4 B loads, 16 B LDS accesses): A/B, same bits */
 int  liship_spmv_csr_set_local_pairs(int on);
+/* 0: plans of short rows (mean < 22 entries, no column codes) never try block-local columns (the rule of rounds 2-5); default 1 (round 6): they are tried from a mean
+ * of 4 entries per row on and kept under the long rows' rule -- unstructured meshes with one unknown per node: +6 .. +39 % over the lane-per-row kernel.  Same bits. */
+int  liship_spmv_csr_set_local_short_rows(int on);
 /* Reordering (round 5): when the lists of a plan with block-local columns are long -- more than one listed column per `min_items_per_listed` non-zeros (0: the
  * default, 4) -- or a long-row plan could not have lists at all (more than 2048 distinct columns per row block): the signs of a numbering without locality -- the plan
  * renumbers rows and columns by graph distances found on the device (breadth-first searches from 3-4 landmarks, Morton keys, a stable radix sort: csr_order.hpp; rounds 4-5: a Cuthill-McKee walk on the host), builds P A P^T in HBM (the same entries

@@ -107,6 +107,7 @@ _LISHIP = {
     "liship_csr_plan_local_runs": (_ci, [_vp]),
     "liship_spmv_csr_set_local_runs": (_ci, [_ci]),
     "liship_spmv_csr_set_local_pairs": (_ci, [_ci]),
+    "liship_spmv_csr_set_local_short_rows": (_ci, [_ci]),
     "liship_csr_plan_reorder": (_ci, [_vp, _vp, _vp, _vp, _ci, _vp]),
     "liship_csr_plan_reordered": (C.c_longlong, [_vp]),
     "liship_csr_plan_reorder_with": (_ci, [_vp, _vp, _vp, _vp, _ci, _vp, _vp]),

@@ -58,6 +58,7 @@ LIS_INT lisd_init(void)
 	if (lisg.reference_layout) LISCHK(lis_amd_set_reference_layout(1));
 	if (lisg.no_team_kernels) { HIPCHK(liship_spmv_csr_set_team(0)); HIPCHK(liship_spmv_bsr_set_team(0)); }
 	if (lisg.no_marching) HIPCHK(liship_spmv_csr_set_dom_march(0));
+	{ const char *e = getenv("LIS_AMD_NO_LOCAL_SHORT_ROWS"); lisg.no_local_short_rows = (e && e[0] == '1'); }      /* A/B: short-row plans never try block-local columns (csr_plan_impl) */
 	if (lisg.row_block_dots) HIPCHK(liship_spmv_csr_set_row_block_dots(1));
 	if (lisg.ref_reductions) HIPCHK(liship_set_reference_reductions(lisg.ref_reductions));
 	lisg.device_ready = 1;
@@ -550,7 +551,9 @@ static LIS_INT csr_plan_impl(liship_csr_plan_t *plan, int n, int ncols, const in
 			}
 		}
 	}
-	if (!lisg.no_local_columns && !liship_csr_plan_coded(*plan)) {      /* long rows: block-local columns where they pay */
+	if (!lisg.no_local_columns && !liship_csr_plan_coded(*plan)) {      /* block-local columns where they pay: long rows, and (round 6) short rows whose row blocks share their columns */
+		/* LIS_AMD_NO_INDEX_CODES=1 asks for the reference's own arrays in the product of a short-row matrix (the contract form): no lists for short rows then either */
+		HIPCHK(liship_spmv_csr_set_local_short_rows((lisg.no_index_codes || lisg.no_local_short_rows) ? 0 : 1));
 		rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
 		if (rc && lis_amd_trim_count() > 0) rc = liship_csr_plan_localize_columns(*plan, dptr, dindex, lisg.stream);
 		if (rc && rc != 2) HIPCHK(rc);

@@ -129,6 +129,7 @@ typedef struct {
 	int eager_coherence;       /* LIS_AMD_COHERENCE=eager / lis_amd_set_coherence(0): COHERENT copies on every call instead of following page faults (lis_pages.c) */
 	int no_device_convert;     /* LIS_AMD_NO_DEVICE_CONVERT=1: lis_matrix_convert always works on the host arrays (A/B, tests of the host routines) */
 	int no_row_form;           /* LIS_AMD_NO_ROW_FORM=1 / lis_amd_set_row_form(0): constant-coefficient ELL / DIA matrices keep their native layout and kernels */
+	int no_local_short_rows;   /* LIS_AMD_NO_LOCAL_SHORT_ROWS=1: plans of short rows never try block-local columns (the rule of rounds 2-5; A/B) */
 	int no_row_patterns;       /* LIS_AMD_NO_ROW_PATTERNS=1: coded CSR matrices keep one byte per non-zero instead of one per row (A/B measurements) */
 	int last_uniform_jacobi;   /* the last lis_solve ran CG + Jacobi with 1/diag as one double (lis_amd_last_solve_uniform_jacobi) */
 	int graphs;                /* LIS_AMD_GRAPHS=1: single-rank device-driven loops replay a hipGraph of one batch (opt-in: measured, no gain) */

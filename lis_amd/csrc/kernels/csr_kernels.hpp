@@ -50,6 +50,7 @@ int g_row_block_dots = 0;        // liship_spmv_csr_set_row_block_dots: 1 keeps 
 int g_dom_march = 1;             // liship_spmv_csr_set_dom_march: 0 keeps 7-point plans with value records on the gathering dominant-pattern kernel (A/B)
 int g_block_rows = 1;            // liship_spmv_csr_set_block_rows: 0 keeps plans with block rows (liship_csr_plan_encode_block_rows) on the row-by-row kernels (A/B); 2: plans of any size take them (tests)
 int g_wide_union = 1;            // liship_spmv_csr_set_wide_union: 0 keeps plans whose rows take turns on several patterns off the staged value-record kernel (plan time, A/B)
+int g_local_short_rows = 1;      // liship_spmv_csr_set_local_short_rows: 0 = plans of short rows never try block-local columns (rounds 2-5) -- A/B, same bits
 int g_local_pairs = 1;           // liship_spmv_csr_set_local_pairs: 0 keeps the block-local kernel on one entry per lane and step (eight 2 B position loads) -- A/B, same bits
 int g_reorder = 1;               // liship_spmv_csr_set_reorder: 1 (default) = the reordered form of a plan (liship_csr_plan_reorder) serves liship_csr_plan_reordered_form (whole solves), products keep
                                  // the caller's numbering; 2 = whole-matrix products of long-row plans take it too (gather of x, scattered store of y); 0 = nobody is served (A/B; the same bits)

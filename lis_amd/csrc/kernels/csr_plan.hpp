@@ -1664,15 +1664,31 @@ extern "C" int liship_csr_plan_local_runs(liship_csr_plan_t p) { return (p && p-
 static int g_local_runs = 1;
 extern "C" int liship_spmv_csr_set_local_runs(int on) { g_local_runs = on ? 1 : 0; return 0; }
 extern "C" int liship_spmv_csr_set_local_pairs(int on) { g_local_pairs = on ? 1 : 0; return 0; }
+// 0: plans of short rows (mean < 22 entries) never try block-local columns (rounds 2-5; A/B).  Plans built from now on.
+extern "C" int liship_spmv_csr_set_local_short_rows(int on) { g_local_short_rows = on ? 1 : 0; return 0; }
 
 extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *ptr, const int *idx, void *stream)
 {
     if (!p || (p->n > 0 && (!ptr || !idx))) return LISHIP_ERR_ARG;
-    if (p->lcol || p->codes || !p->products || p->nblocks <= 0 || p->nnz <= 0 || g_variant != 0 || !aligned16(idx)) return 0;
+    if (p->lcol || p->codes || p->nblocks <= 0 || p->nnz <= 0 || g_variant != 0 || !aligned16(idx)) return 0;
+    // Short rows too (round 6): the lists are TRIED for every plan without column codes whose rows hold 4 entries or more on average, and kept by the same rule --
+    // the listed blocks cover 90 % of the entries with at most one listed column per two entries.  An unstructured mesh with one unknown per node (ragged rows of
+    // 8 .. 40 entries, numbered along a space-filling curve) qualifies, and the block-local kernel -- lanes own entries, x staged once per distinct column -- beats
+    // the row-gather kernel's lane-per-row there at every mean row length measured (2 M nodes: mean 4.9 +6 %, 7.9 +15 %, 11 +23 %, 14.4 +36 %, 18.3 +39 %): ragged
+    // rows leave a lane-per-row wavefront waiting for its longest row, and every gather of a lane-per-row wavefront touches 64 lines.  A plan that does not qualify
+    // goes back to the row-gather kernel exactly as it was.
+    const bool trial = !p->products;
+    if (trial && (!g_local_short_rows || (double)p->nnz < 4.0 * p->n)) return 0;
     hipStream_t st = as_stream(stream);
     constexpr Geometry g = kGeom[LOCAL_GEOM];
     constexpr int NDMAX = 4 * g.block;      // up to four distinct columns per lane (the kernel's NDPL = 4 form)
     const int geom_before = p->geom;
+    if (trial) p->products = 1;
+    auto give_up = [&]() -> int {           // the plan as it was: the row-gather kernel's split for a short-row plan, the products kernel's own otherwise
+        if (trial) p->products = 0;
+        if (geom_before != p->geom) { p->geom = geom_before; return build_split(p, ptr, st); }
+        return trial ? build_split(p, ptr, st) : 0;
+    };
     int *nd_dev = nullptr, *off = nullptr;
     int nb = 0, capl = 0;
     // blocks of 3584 items with the positions in registers (round 4); when those list more than two columns per lane, blocks of 3072.
@@ -1695,7 +1711,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
         if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);
         if (e0 != hipSuccess) {
             (void)hipFree(nd_dev); free(off);
-            if (geom_before != p->geom) { p->geom = geom_before; (void)build_split(p, ptr, st); }
+            (void)give_up();
             return (int)e0;
         }
         int most = 0;
@@ -1712,10 +1728,9 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
         if (nd > 0) { listed += nd; covered += p->blk_host[b + 1].y - p->blk_host[b].y; run += (nd + 3) & ~3; }
     }
     off[nb] = (int)run;
-    if (run > 0x7fffffffLL || covered * 10 < p->nnz * 9 || listed * 2 > covered) {      // not worth it: back to the products kernel's own split
+    if (run > 0x7fffffffLL || covered * 10 < p->nnz * 9 || listed * 2 > covered) {      // not worth it: back to the plan's own split
         (void)hipFree(nd_dev); free(off);
-        if (geom_before != p->geom) { p->geom = geom_before; return build_split(p, ptr, st); }
-        return 0;
+        return give_up();
     }
     const size_t lbytes = ((size_t)p->nnz + 7) / 8 * 16 + 16 * WAVE;          // whole 16 B pieces, one wave slice of slack
     e = hipMalloc(&p->dcol, sizeof(int) * (size_t)(run + 4));
@@ -1734,7 +1749,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
         if (p->lcol) (void)hipFree(p->lcol);
         (void)hipFree(nd_dev);
         p->dcol = nullptr; p->lcol = nullptr;
-        if (geom_before != p->geom) { p->geom = geom_before; (void)build_split(p, ptr, st); }
+        (void)give_up();
         return (int)e;
     }
     p->doff = nd_dev;
@@ -1897,7 +1912,7 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e == hipSuccess && !bad) {
                 int rc = liship_csr_plan_create(&in, n, p->r_ptr, stream);
-                if (!rc && in->products) rc = liship_csr_plan_localize_columns(in, p->r_ptr, p->r_idx, stream);
+                if (!rc) rc = liship_csr_plan_localize_columns(in, p->r_ptr, p->r_idx, stream);      // (short rows too, round 6: a renumbered short-row matrix whose row blocks now share their columns takes the block-local kernel)
                 if (rc) e = (hipError_t)rc;
                 else if (in->products) keep = in->lcol && (!p->lcol || in->ndcol * 4 <= p->ndcol * 3);
                 else {                                              // short rows: at most half the lines

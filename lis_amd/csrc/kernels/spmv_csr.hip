@@ -668,7 +668,7 @@ static bool plan_has_reordered_form(const liship_csr_plan_s *p)      // ... for 
 // (tools/scrambled_short_rows_probe.py: 160^3 7-point, numbered at random inside runs of 4096: 0.130 ms as it is, 0.257 ms renumbered per product -- and 0.06 inside a solve)
 // Opt-in even there (liship_spmv_csr_set_reorder(2), LIS_AMD_REORDER_PRODUCTS=1): over six boxes the Queen-class product moved between -5.5 % and +1.5 % -- the
 // two passes eat what the kernel gains (0.636 -> 0.58-0.60 ms), and the spread of a box's page placement is as large as the rest.  The loops take the whole gain.
-static bool plan_runs_reordered(const liship_csr_plan_s *p) { return g_reorder == 2 && plan_has_reordered_form(p) && p->inner->products && p->ncols <= p->n; }      // (a rank's local matrix: x carries ghost entries behind the rows -- its single products keep the caller's numbering)
+static bool plan_runs_reordered(const liship_csr_plan_s *p) { return g_reorder == 2 && plan_has_reordered_form(p) && p->products && p->inner->products && p->ncols <= p->n; }      // (a rank's local matrix: x carries ghost entries behind the rows -- its single products keep the caller's numbering)
 static int launch_reordered(liship_csr_plan_t p, const double *x, double *y, hipStream_t st)
 {
     const liship_csr_plan_s *q = p->inner;

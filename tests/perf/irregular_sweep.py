@@ -5,6 +5,8 @@ SuiteSparse Queen_4147 cannot be fetched here (no network), so two synthetic mat
          rows shorter) -- the sparsity class of Queen_4147 (3-D structural FEM); symmetric, diagonally dominant
   zipf   row lengths drawn from a heavy-tailed law (1 .. 200 000 per row), random columns: the load-balance stress
          for the merge-path row split
+  mesh   (IRREG_MESH_NODES=N, default 1 000 000) an unstructured 3-D mesh, one unknown per node, ragged rows of 8 .. 40 entries (mean ~19), varying
+         coefficients, numbered along a coarse Morton curve and at random inside a cell: the class none of the plan's special forms catch (orc.unstructured_mesh)
     python tests/perf/irregular_sweep.py [G] [--gmres-iters K]
 Prints SpMV ms / GFLOP/s / algorithmic GB/s (12*nnz + 20*n bytes) with y checked bit for bit against the CPU oracle,
 and GMRES(30) iterations per second through lis_solve."""
@@ -67,7 +69,11 @@ def main():
     if os.environ.get("IRREG_ROUND3") == "1":          # A/B: the round-3 form of the block-local kernel (4096-item blocks, positions through LDS)
         check(lib.liship_spmv_csr_set_local_register_positions(0))
     only = os.environ.get("IRREG_ONLY")                # "fem3" / "zipf": one of the two (profiling runs)
-    for name, gen in (("fem3", lambda: fem3(G)[:4]), ("zipf", lambda: zipf(2_000_000))):
+    def mesh():
+        kmin, kmax = (int(t) for t in os.environ.get("IRREG_MESH_K", "6,22").split(","))      # neighbours a node asks for: the mean row is ~ 1 + 1.3 (kmin + kmax) / 2
+        p, i, v = orc.unstructured_mesh(int(os.environ.get("IRREG_MESH_NODES", "1000000")), kmin=kmin, kmax=kmax)
+        return p, i, v, len(p) - 1
+    for name, gen in (("fem3", lambda: fem3(G)[:4]), ("zipf", lambda: zipf(2_000_000)), ("mesh", mesh)):
         if only and name != only:
             continue
         t0 = time.time()
@@ -89,7 +95,7 @@ def main():
             if variant != variants[-1]:
                 lib.lis_matrix_destroy(A)
         lib.liship_spmv_csr_set_variant(0)
-        if name == "fem3" and iters > 0:
+        if name in ("fem3", "mesh") and iters > 0:
             bb = lisdrv.new_vector(lib, A)
             assert lib.lis_matvec(A, vx, bb) == 0           # b = A * x_true, x_true = cos(0.01 i) + 1.25
             for opts in ("-i gmres -restart 30 -p none", "-i gmres -restart 30 -p jacobi", "-i bicgstab -p none", "-i cg -p jacobi"):

@@ -246,6 +246,7 @@ struct liship_csr_plan_s {
     liship_csr_plan_s *inner = nullptr;
     int *r_ptr = nullptr, *r_idx = nullptr, *r_perm = nullptr;      // device: row starts and columns of P A P^T; new position -> original row
     double *r_val = nullptr, *r_x = nullptr;                        // device: its values; x in the new numbering (n entries)
+    int local_trial_failed = 0;                                     // a short-row plan tried block-local columns and its lists were too long (liship_csr_plan_localize_columns): a candidate for renumbering
     int ncols = 0;                                                  // > n: columns [n, ncols) are a rank's GHOST columns (liship_csr_plan_set_ghost_columns): the reordered form keeps them where they are
     int r_inner_end = 0;                                            // ... and puts the rows that read one behind all the others: rows [0, r_inner_end) of P A P^T touch no ghost column
     int *drun, *droff;   // device, or NULL: when every list is made of TRIPLES of consecutive columns (3 unknowns per node), the triples' first columns and nblocks + 1 offsets into them
@@ -1685,7 +1686,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     const int geom_before = p->geom;
     if (trial) p->products = 1;
     auto give_up = [&]() -> int {           // the plan as it was: the row-gather kernel's split for a short-row plan, the products kernel's own otherwise
-        if (trial) p->products = 0;
+        if (trial) { p->products = 0; p->local_trial_failed = 1; }
         if (geom_before != p->geom) { p->geom = geom_before; return build_split(p, ptr, st); }
         return trial ? build_split(p, ptr, st) : 0;
     };
@@ -1868,7 +1869,10 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
     if (!p->products) {
         lines_before = block_lines(p, idx, st);
         if (lines_before < 0) return 0;                            // (could not count: leave the plan alone)
-        if (lines_before * mi <= p->nnz) return 0;
+        // (round 6: ... unless the plan tried block-local columns and its lists were too long -- few lines per row block and yet a column of its own for nearly every entry is
+        //  what a mesh numbered at random inside coarse cells looks like: the row-gather kernel's 64 lanes then gather from 64 different lines at every step, 42 % of the
+        //  roofline at 8 M nodes, and the same matrix renumbered runs the block-local kernel at 70 %+)
+        if (lines_before * mi <= p->nnz && !p->local_trial_failed) return 0;
     }
     int *hptr = (int *)malloc(sizeof(int) * ((size_t)n + 1)), *hidx = nullptr, *order = (int *)malloc(sizeof(int) * (size_t)n);
     int *hptr2 = (int *)malloc(sizeof(int) * ((size_t)n + 1));
@@ -1885,7 +1889,7 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
             const int r = hint[i];
             if (r < 0 || r >= n || seen[r]) have_order = false; else { seen[r] = 1; order[i] = r; }
         }
-    } else if (e == hipSuccess) have_order = order_dev::device_order(n, ncols, ptr, idx, p->products ? 6 : 3, order, &inner_rows, st);      // long rows (dense neighbourhoods): six landmarks, short rows: three
+    } else if (e == hipSuccess) have_order = order_dev::device_order(n, ncols, ptr, idx, (p->products || (double)p->nnz >= 12.0 * n) ? 6 : 3, order, &inner_rows, st);      // dense neighbourhoods (long rows; 12 entries per row or more: a k-nearest-neighbour mesh, 27-point connectivity): six landmarks; sparse ones (grid graphs, whose breadth-first distances ARE coordinates): three
     if (e == hipSuccess && have_order) {
         bool moved = false;
         hptr2[0] = 0;
@@ -1923,6 +1927,9 @@ static int reorder_impl(liship_csr_plan_t p, const int *ptr, const int *idx, con
             }
         }
     }
+    if (getenv("LIS_AMD_REORDER_TRACE"))            // why a matrix did (not) get a renumbered form
+        fprintf(stderr, "liblis_amd: reorder: n %d nnz %lld long rows %d lists before %lld lines before %lld -> ordering %s, candidate plan %s, its lists %lld: %s (HIP %d)\n", n, p->nnz, p->products,
+                p->lcol ? p->ndcol : 0ll, lines_before, have_order ? "found" : "none", in ? (in->lcol ? "block-local" : "row-gather") : "none", in ? in->ndcol : 0ll, keep ? "kept" : "dropped", (int)e);
     free(hptr); free(hidx); free(order); free(hptr2);
     if (inv) (void)hipFree(inv);
     if (keep) { in->first_term = p->first_term; in->ncols = p->ncols; p->inner = in; p->r_inner_end = (ncols > n && !hint) ? inner_rows : 0; return 0; }

@@ -881,7 +881,6 @@ def config4_leg(lib, np, C, reps=50):
     y for a check against any other implementation), GMRES(30) / BiCGSTAB / CG + Jacobi / BiCG with iterations, it/s and time to solution.  The renumbered form
     (liship_csr_plan_reorder) is LAZY since round 6 -- none of these first solves triggers it; its cost (`reorder_s`: the numbering found on the device, P A P^T and its plan built in HBM), its gain and the break-even
     iteration count are measured beside them by asking for it explicitly.  Host-clock ms per product over `reps` calls behind one synchronize; never fatal: an error string instead."""
-    import hashlib
     path, made = os.environ.get("LIS_AMD_BENCH_MTX"), False
     try:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
@@ -903,7 +902,6 @@ def config4_leg(lib, np, C, reps=50):
         if made:
             os.unlink(path)
         path = None
-        n, nnz = A.contents.n, A.contents.nnz
         dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
         dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
         dll.lis_amd_matrix_upload.argtypes = [capi.PM]
@@ -912,6 +910,51 @@ def config4_leg(lib, np, C, reps=50):
         tot, asm = C.c_double(), C.c_double()
         assert dll.lis_amd_last_input_times(C.byref(tot), C.byref(asm)) == 0
         t_reader, t_plan = max(0.0, t_read - asm.value), t_plan + asm.value      # lis_input's assemble step IS the upload + plan in resident mode
+        out.update({"lis_input_s": round(t_read, 2), "reader_s": round(t_reader, 2), "upload_and_plan_s": round(t_plan, 3),
+                    "lis_input_note": "lis_input_s = reader_s (file read, parse, symmetric expansion, rows placed: host) + upload_and_plan_s (the HBM copy and its plan, inside lis_input's assemble step)"})
+        irregular_measure(lib, np, C, A, out, reps)
+        for v in (b, x0):
+            lib.lis_vector_destroy(v)
+        lib.lis_matrix_destroy(A)
+        if not os.environ.get("LIS_AMD_BENCH_MTX"):
+            out["unstructured_mesh_class"] = mesh_leg(lib, np, C, reps)
+        return out
+    except Exception as exc:                                          # an extra: its failure must not cost the line
+        return {"name": BASELINE_CONFIGS["config4"], "error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        if made and path and os.path.exists(path):
+            os.unlink(path)
+
+
+def mesh_leg(lib, np, C, reps=50, nodes=4000000):
+    """Beside the Queen-class stand-in (long rows, 3 unknowns per node): the irregular class none of the plan's special forms catch -- an unstructured 3-D mesh, ONE unknown per
+    node, ragged rows of 7 .. 32 entries (mean 18), varying coefficients, numbered along a coarse Morton curve and at random inside a cell (tests/orc.py unstructured_mesh;
+    reference goldens at 60 000 nodes in tests/test_configs_gpu.py).  Round 6: short rows try block-local columns, and a plan whose lists fail is renumbered on the device."""
+    try:
+        import lisdrv
+        import orc
+        t0 = time.time()
+        ptr, idx, val = orc.unstructured_mesh(nodes)
+        out = {"matrix": f"tests/orc.py unstructured_mesh({nodes}): k-nearest-neighbour graph of random points in the unit cube, symmetrised, 4096 Morton cells, random order inside a cell",
+               "generate_s": round(time.time() - t0, 1)}
+        A = lisdrv.make_csr(lib, ptr, idx, val)
+        irregular_measure(lib, np, C, A, out, reps, rhs_of_ones=False)
+        lib.lis_matrix_destroy(A)
+        return out
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def irregular_measure(lib, np, C, A, out, reps, rhs_of_ones=True):
+    """the product in the caller's numbering, four solvers with time to solution, the renumbered form asked for explicitly (config4_leg, mesh_leg)"""
+    import hashlib
+    from lis_amd import _capi as capi
+    dll = lib.dll
+    dll.lis_amd_matrix_local_columns.argtypes = [capi.PM]
+    dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
+    dll.lis_amd_set_reorder_after.argtypes = [C.c_longlong]
+    if True:
+        n, nnz = A.contents.n, A.contents.nnz
         listed = int(dll.lis_amd_matrix_local_columns(A))
         vx, vy, ones = capi.PV(), capi.PV(), capi.PV()
         for v in (vx, vy, ones):
@@ -932,15 +975,15 @@ def config4_leg(lib, np, C, reps=50):
         ms = timed()
         yh = np.empty(n)
         assert lib.lis_vector_get_values(vy, 0, n, yh.ctypes.data_as(capi.P_DBL)) == 0
-        out.update({"n": n, "nnz": nnz, "lis_input_s": round(t_read, 2), "reader_s": round(t_reader, 2), "upload_and_plan_s": round(t_plan, 3),
-                    "lis_input_note": "lis_input_s = reader_s (file read, parse, symmetric expansion, rows placed: host) + upload_and_plan_s (the HBM copy and its plan, inside lis_input's assemble step)",
+        out.update({"n": n, "nnz": nnz,
                     "block_local_columns_listed": listed, "kernel": "spmv_csr_local_kernel" if listed else "spmv_csr_rowgather_kernel / spmv_csr_products_kernel (the plan's choice)",
                     "spmv_ms": round(ms, 4), "spmv_gflops": round(2.0 * nnz / ms / 1e6, 1),
                     "contract_bytes": 12 * nnz + 20 * n, "contract_frac": round((12.0 * nnz + 20.0 * n) / (ms * 1e-3) / 8e12, 4),
                     "x": "x_i = cos(0.01 i) + 1.25", "y_sha256": hashlib.sha256(yh.tobytes()).hexdigest(),
                     "numbering": "the caller's (the renumbered form is lazy: lis_amd_set_reorder_after, default 4096 products)"})
         rhs = capi.PV()
-        assert lib.lis_vector_duplicate(A, C.byref(rhs)) == 0 and lib.lis_matvec(A, ones, rhs) == 0          # b = A*1 (test/test1.c:138-139)
+        assert lib.lis_vector_duplicate(A, C.byref(rhs)) == 0 and lib.lis_matvec(A, ones if rhs_of_ones else vx, rhs) == 0          # b = A*1 (test/test1.c:138-139); the mesh: b = A*x_s
+        out["rhs"] = "b = A*1 (test/test1.c:138-139)" if rhs_of_ones else "b = A*x_s, x_s the product's x (with b = A*1 the Jacobi-preconditioned residual of this diagonally weighted matrix is a multiple of the solution: one iteration)"
         SOLVES = ("-i gmres -restart 30 -p none", "-i bicgstab -p none", "-i cg -p jacobi", "-i bicg -p none")       # (BiCG: Lis's default solver, lis_solver.c:242)
 
         def solve(opts):
@@ -982,15 +1025,8 @@ def config4_leg(lib, np, C, reps=50):
             out["renumbered_form"] = ren
         finally:
             dll.lis_amd_set_reorder_after(4096)
-        for v in (vx, vy, ones, rhs, b, x0):
+        for v in (vx, vy, ones, rhs):
             lib.lis_vector_destroy(v)
-        lib.lis_matrix_destroy(A)
-        return out
-    except Exception as exc:                                          # an extra: its failure must not cost the line
-        return {"name": BASELINE_CONFIGS["config4"], "error": f"{type(exc).__name__}: {exc}"}
-    finally:
-        if made and path and os.path.exists(path):
-            os.unlink(path)
 
 
 def assert_fracs_physical(node, path="line", shared_gpu=False):

@@ -1673,7 +1673,7 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
     if (!p || (p->n > 0 && (!ptr || !idx))) return LISHIP_ERR_ARG;
     if (p->lcol || p->codes || p->nblocks <= 0 || p->nnz <= 0 || g_variant != 0 || !aligned16(idx)) return 0;
     // Short rows too (round 6): the lists are TRIED for every plan without column codes whose rows hold 4 entries or more on average, and kept by the same rule --
-    // the listed blocks cover 90 % of the entries with at most one listed column per two entries.  An unstructured mesh with one unknown per node (ragged rows of
+    // the listed blocks cover 90 % of the entries with at most two listed columns per three entries.  An unstructured mesh with one unknown per node (ragged rows of
     // 8 .. 40 entries, numbered along a space-filling curve) qualifies, and the block-local kernel -- lanes own entries, x staged once per distinct column -- beats
     // the row-gather kernel's lane-per-row there at every mean row length measured (2 M nodes: mean 4.9 +6 %, 7.9 +15 %, 11 +23 %, 14.4 +36 %, 18.3 +39 %): ragged
     // rows leave a lane-per-row wavefront waiting for its longest row, and every gather of a lane-per-row wavefront touches 64 lines.  A plan that does not qualify
@@ -1729,7 +1729,9 @@ extern "C" int liship_csr_plan_localize_columns(liship_csr_plan_t p, const int *
         if (nd > 0) { listed += nd; covered += p->blk_host[b + 1].y - p->blk_host[b].y; run += (nd + 3) & ~3; }
     }
     off[nb] = (int)run;
-    if (run > 0x7fffffffLL || covered * 10 < p->nnz * 9 || listed * 2 > covered) {      // not worth it: back to the plan's own split
+    // kept when the listed blocks cover 90 % of the entries with at most one listed column per two entries (long rows) / two per three (short rows: measured
+    // on the 8 M-node mesh at 0.57 listed columns per entry, 0.574 -> 0.462 ms against the row-gather kernel)
+    if (run > 0x7fffffffLL || covered * 10 < p->nnz * 9 || (trial ? listed * 3 > covered * 2 : listed * 2 > covered)) {      // not worth it: back to the plan's own split
         (void)hipFree(nd_dev); free(off);
         return give_up();
     }

@@ -191,7 +191,7 @@ def heavy_tail(n, seed=3, cap=9000):
     val[ptr[:-1]] = np.add.reduceat(np.abs(val), ptr[:-1]) + 1.0
     return ptr.astype(np.int32), idx, val
 
-def unstructured_mesh(nodes, seed=7, kmin=6, kmax=22):
+def unstructured_mesh(nodes, seed=7, kmin=6, kmax=22, cells=16):
     """An unstructured 3-D mesh, one unknown per node, varying coefficients, no block structure (round 6: the irregular class none of the plan's special forms catch --
     no repeating row patterns, no dofs-per-node blocks, no constant values).  Points at random in the unit cube; every node is joined to its kmin .. kmax
     nearest neighbours (its own draw) and the graph is symmetrised, which gives ragged rows of 8 .. ~40 entries (mean ~19).  Numbered as a mesher would leave it: along a coarse
@@ -200,7 +200,7 @@ def unstructured_mesh(nodes, seed=7, kmin=6, kmax=22):
     from scipy.spatial import cKDTree
     rng = np.random.default_rng(seed)
     pts = rng.random((nodes, 3))
-    cell = np.minimum((pts * 16).astype(np.int64), 15)
+    cell = np.minimum((pts * cells).astype(np.int64), cells - 1)      # (cells = 16: the 4096 Morton cells of the goldens; fewer cells = a numbering with less locality, perf probes)
     morton = np.zeros(nodes, np.int64)
     for bit in range(4):
         for d in range(3):

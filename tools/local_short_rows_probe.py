@@ -14,8 +14,9 @@ from lis_amd import DeviceArray as DA, check  # noqa: E402
 G = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "mesh" else 160
 lib = lis_amd.load()
 if len(sys.argv) > 2 and sys.argv[1] == "mesh":            # python tools/local_short_rows_probe.py mesh NODES: the unstructured mesh of tests/orc.py (4096 Morton cells, random order inside a cell)
-    ptr, idx, val = orc.unstructured_mesh(int(sys.argv[2]))
-    G = f"mesh {sys.argv[2]}"
+    cells = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    ptr, idx, val = orc.unstructured_mesh(int(sys.argv[2]), cells=cells)
+    G = f"mesh {sys.argv[2]} cells {cells}^3"
 else:
     ptr, idx, val = orc.poisson3d(G, G, G)
     val = val * np.random.default_rng(8).uniform(0.5, 1.5, len(val))

@@ -169,7 +169,9 @@ long long lis_amd_matrix_reordered(LIS_MATRIX A);
 /* WHEN the renumbered form is built: by the first lis_solve that finds A's HBM copy has served `products` products in the caller's numbering (default 4096; env
  * LIS_AMD_REORDER_AFTER).  Building it -- the numbering found on the device (breadth-first distances from landmarks, Morton keys, a radix sort: kernels/csr_order.hpp; rounds
  * 4-5 walked the graph on the host), P A P^T and its plan in HBM -- costs 0.17 s and +3.5 GB on the Queen-class matrix and saves 0.06-0.1 ms per iteration there: a program
- * earns it back after ~3000 iterations, and the first solves of most programs take 40-50.  0: at plan time (upload / assemble), the round-5 behaviour. */
+ * earns it back after ~3000 iterations, and the first solves of most programs take 40-50.  A matrix whose block-local lists FAILED altogether (no locality at all: an
+ * unstructured mesh numbered at random inside coarse cells runs at 30-40 % of its roofline and twice as fast renumbered) waits for products / 16 only (256): about what
+ * building the form costs in products of that kind.  0: at plan time (upload / assemble), the round-5 behaviour. */
 LIS_INT lis_amd_set_reorder_after(long long products);
 long long lis_amd_matrix_products_served(LIS_MATRIX A);      /* products A's current HBM copy has served (approximately: a fused product + dot that falls back counts twice) */
 /* the liship plan of A's HBM copy when it is served as CSR rows (for the liship_csr_plan_* queries of liship.h; owned by A), else NULL; uploads A if needed */

@@ -204,6 +204,8 @@ int  liship_csr_plan_reorder_permutation(liship_csr_plan_t plan, int *perm_host)
  * rows [0, liship_csr_plan_reordered_inner_rows) of the reordered form touch no ghost column (they can run while the halo travels). */
 int  liship_csr_plan_set_ghost_columns(liship_csr_plan_t plan, int ncols);
 int  liship_csr_plan_reordered_inner_rows(liship_csr_plan_t plan);
+/* 1: the plan wanted block-local column lists and has none (lists too long / trial failed): a numbering without any locality */
+int  liship_csr_plan_lists_failed(liship_csr_plan_t plan);
 /* out[k] = the position of row index[k] under the permutation perm (perm[new position] = row; n entries): a list of rows -- a halo export list -- in the new numbering */
 int  liship_permute_rows_of_list(int n, const int *perm, int count, const int *index, int *out, void *stream);
 long long liship_csr_plan_reordered(liship_csr_plan_t plan);

@@ -116,6 +116,7 @@ _LISHIP = {
     "liship_csr_plan_reordered_form": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "liship_csr_plan_set_ghost_columns": (_ci, [_vp, _ci]),
     "liship_csr_plan_reordered_inner_rows": (_ci, [_vp]),
+    "liship_csr_plan_lists_failed": (_ci, [_vp]),
     "liship_permute_rows_of_list": (_ci, [_ci, _vp, _ci, _vp, _vp, _vp]),
     "liship_permute_gather_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),
     "liship_permute_scatter_f64": (_ci, [_ci, _vp, _vp, _vp, _vp]),

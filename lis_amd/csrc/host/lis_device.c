@@ -521,7 +521,14 @@ static LIS_INT plan_try_reorder(liship_csr_plan_t plan, int n, const int *dptr, 
 LIS_INT lisd_mat_lazy_reorder(LIS_MATRIX A)
 {
 	lisd_mat *d = MDEV(A);
-	if (lisg.no_reorder || lisg.reorder_after <= 0 || !d->ready || d->reorder_tried || d->served < lisg.reorder_after) return LIS_SUCCESS;
+	if (lisg.no_reorder || lisg.reorder_after <= 0 || !d->ready || d->reorder_tried) return LIS_SUCCESS;
+	{	/* when: the ski-rental point -- build once the products served have cost about what the form costs.  Lists that exist but are long (the Queen class: the form
+		 * saves 5-15 % of an iteration) wait for reorder_after products; a plan whose lists FAILED (no locality at all: 30-40 % of the roofline, the form doubles the
+		 * rate; building it costs ~200 of those products whatever the size) waits for a sixteenth of that (256 by default) */
+		long long wait = lisg.reorder_after;
+		if (d->type == LIS_MATRIX_CSR && d->plan && liship_csr_plan_lists_failed(d->plan)) wait = wait / 16 > 0 ? wait / 16 : 1;
+		if (d->served < wait) return LIS_SUCCESS;
+	}
 	/* (several ranks: each renumbers its own rows and owned columns -- the plan knows its ghost columns --; a matrix served as CSR from another layout with ghost columns stays as it is) */
 	if (d->type != LIS_MATRIX_CSR || !d->plan || !d->value || d->split_jad || d->solve_holds || A->is_scaled || A->is_splited || d->n != A->n ||
 	    (A->np != A->n && A->matrix_type != LIS_MATRIX_CSR)) return LIS_SUCCESS;

@@ -1847,6 +1847,9 @@ extern "C" int liship_csr_plan_set_ghost_columns(liship_csr_plan_t p, int ncols)
     p->ncols = ncols;
     return 0;
 }
+// 1: the plan has NO block-local lists although it wanted them (a short-row plan whose trial failed; a long-row plan whose row blocks list too many columns): the
+// numbering has no locality at all, the product runs at 30-40 % of its roofline and a renumbered form doubles it -- the host layer builds that form early for such a plan
+extern "C" int liship_csr_plan_lists_failed(liship_csr_plan_t p) { return (p && !p->lcol && !p->codes && (p->local_trial_failed || p->products)) ? 1 : 0; }
 extern "C" int liship_csr_plan_reordered_inner_rows(liship_csr_plan_t p) { return (p && p->inner) ? (p->ncols > p->n ? p->r_inner_end : p->n) : 0; }
 // the permutation of the reordered form to the host (n entries); LISHIP_ERR_ARG when the plan has none
 extern "C" int liship_csr_plan_reorder_permutation(liship_csr_plan_t p, int *out_host)

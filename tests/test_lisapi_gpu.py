@@ -765,6 +765,35 @@ def test_renumbering_is_lazy_by_default(lib):
         dll.lis_amd_set_reorder_after(4096)
 
 
+def test_renumbering_comes_early_when_the_lists_failed(lib):
+    """A matrix whose block-local lists failed altogether (short rows numbered at random: the row-gather kernel at a third of its roofline, the renumbered form twice as
+    fast) waits for a SIXTEENTH of lis_amd_set_reorder_after() -- the ski-rental point: what the form costs in products of that kind.  Threshold 320 here: a first solve of
+    ~11 products stays in the caller's numbering (fewer than 20), the next one finds more than 20 served and iterates renumbered; a matrix WITH lists would have waited for 320."""
+    from test_kernels_gpu import _scrambled_poisson
+    dll = lib.dll
+    dll.lis_amd_set_reorder_after.argtypes = [C.c_longlong]
+    dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong
+    dll.lis_amd_matrix_products_served.argtypes = [capi.PM]; dll.lis_amd_matrix_products_served.restype = C.c_longlong
+    dll.lis_amd_matrix_csr_plan.argtypes = [capi.PM]; dll.lis_amd_matrix_csr_plan.restype = C.c_void_p
+    ptr, idx, val = _scrambled_poisson(True, vary=False)
+    n = len(ptr) - 1
+    b = orc.spmv_csr(ptr, idx, val, np.ones(n))
+    dll.lis_amd_set_reorder_after(320)
+    try:
+        A = lisdrv.make_csr(lib, ptr, idx, val)
+        assert lib.liship_csr_plan_lists_failed(dll.lis_amd_matrix_csr_plan(A)) == 1 and dll.lis_amd_matrix_reordered(A) == 0
+        first = lisdrv.solve(lib, A, b, "-i cg -p jacobi -tol 1e-11 -maxiter 10")
+        assert dll.lis_amd_last_solve_renumbered() == 0 and 0 < dll.lis_amd_matrix_products_served(A) < 20 and first["iter"] >= 10
+        plain = lisdrv.solve(lib, A, b, "-i cg -p jacobi -tol 1e-11 -maxiter 400")          # fewer than 20 served when it starts
+        assert dll.lis_amd_last_solve_renumbered() == 0 and plain["status"] == 0 and 20 <= dll.lis_amd_matrix_products_served(A) < 320
+        early = lisdrv.solve(lib, A, b, "-i cg -p jacobi -tol 1e-11 -maxiter 400")
+        assert dll.lis_amd_last_solve_renumbered() == 1 and dll.lis_amd_matrix_reordered(A) > 0
+        assert early["status"] == 0 and abs(early["iter"] - plain["iter"]) <= max(1, plain["iter"] // 50) and np.abs(early["x"] - 1).max() < 1e-8
+        assert lib.lis_matrix_destroy(A) == 0
+    finally:
+        dll.lis_amd_set_reorder_after(4096)
+
+
 def _renumbered_solve_case_body(lib, ptr, idx, val, options):
     dll = lib.dll
     dll.lis_amd_matrix_reordered.argtypes = [capi.PM]; dll.lis_amd_matrix_reordered.restype = C.c_longlong

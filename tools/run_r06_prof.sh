@@ -16,6 +16,16 @@ tools/prof_formats.sh r06_formats_256 256 csr,ell,dia,bsr > gpurun_out/r06_forma
 { echo "== tests/perf/format_sweep.py (256^3, default forms)"; python tests/perf/format_sweep.py 2>&1 | tail -40;
   echo "== tests/perf/irregular_sweep.py (default: long-row tree on)"; python tests/perf/irregular_sweep.py 2>&1 | grep -E "^fem3|^zipf" ;
   echo "== LIS_AMD_LONG_ROW_CHAIN=1 zipf"; IRREG_ONLY=zipf LIS_AMD_LONG_ROW_CHAIN=1 python tests/perf/irregular_sweep.py 2>&1 | grep -E "^zipf" ; } > gpurun_out/r06_format_irregular_sweeps.txt 2>&1
+{ echo "== tests/perf/irregular_sweep.py mesh, 2 M nodes (short rows through block-local columns: round 6) and with LIS_AMD_NO_LOCAL_SHORT_ROWS=1 (the rule of rounds 2-5)";
+  IRREG_ONLY=mesh IRREG_MESH_NODES=2000000 python tests/perf/irregular_sweep.py 2>&1 | grep -E "^mesh";
+  LIS_AMD_NO_LOCAL_SHORT_ROWS=1 IRREG_ONLY=mesh IRREG_MESH_NODES=2000000 python tests/perf/irregular_sweep.py 2>&1 | grep -E "^mesh";
+  echo "== 8 M nodes: as it comes / renumbered at plan time (LIS_AMD_REORDER_AFTER=0) / rounds 2-5 (no short-row lists, no renumbering)";
+  IRREG_ONLY=mesh IRREG_MESH_NODES=8000000 python tests/perf/irregular_sweep.py --gmres-iters 100 2>&1 | grep -E "^mesh";
+  LIS_AMD_REORDER_TRACE=1 LIS_AMD_REORDER_AFTER=0 IRREG_ONLY=mesh IRREG_MESH_NODES=8000000 python tests/perf/irregular_sweep.py --gmres-iters 100 2>&1 | grep -E "^mesh|reorder:";
+  LIS_AMD_NO_LOCAL_SHORT_ROWS=1 LIS_AMD_NO_REORDER=1 IRREG_ONLY=mesh IRREG_MESH_NODES=8000000 python tests/perf/irregular_sweep.py --gmres-iters 100 2>&1 | grep -E "^mesh";
+  echo "== tools/local_short_rows_probe.py: numberings with less locality (4 M nodes, 8^3 and 4^3 cells)";
+  python tools/local_short_rows_probe.py mesh 4000000 8 2>&1 | grep -E "^G=|P A P|renumbered"; python tools/local_short_rows_probe.py mesh 4000000 4 2>&1 | grep -E "^G=|P A P|renumbered";
+  echo "== tools/yardstick_sweep.py"; python tools/yardstick_sweep.py 2>&1 | grep yardstick; } > gpurun_out/r06_unstructured_mesh_and_yardstick.txt 2>&1
 bash tools/size_sweep.sh > gpurun_out/r06_size_sweep.txt 2>&1
 python bench.py > gpurun_out/r06_bench_line.json 2> gpurun_out/r06_bench_line.err
 echo done; tail -3 gpurun_out/r06_size_sweep.txt; python tools/show_bench.py gpurun_out/r06_bench_line.json 1 | head -8

@@ -113,6 +113,12 @@ def test_bench_line_has_the_contract_fields():
     assert c2["reference_layout"]["cg_jacobi"]["iter"] == c2["default_form"]["cg_jacobi"]["iter"] == 201     # 64^3: the reference's count
     c3 = cfg["config3"]
     assert c3["n_gpus"] == 1 and c3["reference_layout"]["iters_per_sec"] > 0 and c3["default_form"]["iters_per_sec"] > 0
+    c4 = cfg["config4"]
+    assert c4["spmv_ms"] > 0 and 0 < c4["contract_frac"] <= 1.0 and all(v["status"] == 0 for v in c4["solves"].values())
+    um = c4["unstructured_mesh_class"]                       # the irregular class with ONE unknown per node (round 6: short rows through block-local columns)
+    assert "error" not in um, um.get("error")
+    assert um["n"] == 4000000 and um["spmv_ms"] > 0 and 0 < um["contract_frac"] <= 1.0 and um["kernel"] == "spmv_csr_local_kernel"
+    assert all(v["status"] == 0 for v in um["solves"].values()) and um["solves"]["-i cg -p jacobi"]["iter"] > 10
     c5 = cfg["config5"]["64^3"]
     native, dflt = c5["native_kernels_reference_layout"], c5["default_forms"]
     assert sorted(native) == sorted(dflt) == ["CSR", "DIA", "ELL"]

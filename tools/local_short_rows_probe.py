@@ -63,4 +63,9 @@ for short in (0, 1):
             check(lib.liship_permute_scatter_f64(n, pm, dy2.ptr, yb.ptr, None))
             assert np.array_equal(yb.to_host(), yref)
             print(f"   the product on P A P^T (what lis_solve iterates on): {t2:.4f} ms  {B / t2 / 1e6 / 80:.1f} %")
+            lib.liship_spmv_csr_set_reorder(2)              # single products THROUGH the form: x gathered, rows stored at y[perm[r]] (opt-in: LIS_AMD_REORDER_PRODUCTS=1)
+            t4, dy4 = timed(plan, dptr.ptr, didx.ptr, dval.ptr, dx.ptr)
+            lib.liship_spmv_csr_set_reorder(1)
+            assert np.array_equal(dy4.to_host(), yref)
+            print(f"   a single product through the form (gather x + P A P^T + scattered y): {t4:.4f} ms against {t:.4f} in the caller's numbering")
     check(lib.liship_csr_plan_destroy(plan))

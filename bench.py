@@ -630,8 +630,15 @@ def main():
             "stencil27": extras,              # beside the headline: the 27-point stencil (spmvtest3b / HPCG) through the round-3 kernels; not part of `value`
             "cpu_baseline": cpu,
         }
-        assert_fracs_physical(out, shared_gpu=out["degraded"])
+        # the HEADLINE's fraction is a hard rule (SURVEY 8d's bytes over the timed kernel: above 1 the kernel is not doing the work); a side leg whose working set sits in
+        # the 256 MB Infinity Cache (a slab run, a small --grid) can legitimately beat the HBM peak: reported in the line, not fatal to it
+        assert_fracs_physical({"roofline": out["roofline"]}, shared_gpu=out["degraded"])
         assert alg_bytes / (ms_per_step * 1e-3) <= HBM_PEAK_GBS * 1e9, "SURVEY 8d bytes / ms_per_step exceeds the HBM peak: the timed kernel is not doing the work"
+        bad = []
+        collect_unphysical_fracs(out, "line", bad, shared_gpu=out["degraded"])
+        out["fracs_outside_0_1"] = bad        # [] in every run at the headline size
+        if bad:
+            print(f"bench.py: fractions outside (0, 1] in side legs (cache-resident working sets?): {bad}", file=sys.stderr, flush=True)
         emit(out)
     degraded = world > 1 and comm_used != "rccl" and args.comm == "rccl"
     if world > 1:
@@ -1042,6 +1049,19 @@ def assert_fracs_physical(node, path="line", shared_gpu=False):
     elif isinstance(node, list):
         for i, v in enumerate(node):
             assert_fracs_physical(v, f"{path}[{i}]", shared_gpu)
+
+
+def collect_unphysical_fracs(node, path, bad, shared_gpu=False):
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if k == "frac":
+                if not (v is not None and (0.0 < v or (shared_gpu and v == 0.0)) and v <= 1.0):
+                    bad.append([path, v])
+            else:
+                collect_unphysical_fracs(v, f"{path}.{k}", bad, shared_gpu)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            collect_unphysical_fracs(v, f"{path}[{i}]", bad, shared_gpu)
 
 
 def spmv_stored_bytes(n, nnz, coded, patterns, values=0):

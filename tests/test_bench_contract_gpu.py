@@ -78,7 +78,7 @@ def test_bench_line_has_the_contract_fields():
         assert vs["roofline"]["value_records"] == 0 and 0 < vs["roofline"]["frac"] <= 1.0 and vs["roofline"]["bytes_per_launch"] > fr["bytes_per_launch"]
     assert f["x_equals_one"]["value"] > 0
 
-    assert all(0 < v <= 1.0 for v in _fracs(d))
+    assert all(0 < v <= 1.0 for v in _fracs(d)) and d["fracs_outside_0_1"] == []
     yd = d["box_yardstick"]                                 # the box's own streaming rate (13 read streams : 1 write stream, no gather) beside the headline's fraction
     assert yd["reads"] == 13 and yd["bytes_per_launch"] == 14 * 8 * yd["n"] and yd["rate_GBs"] > 0 and yd["copy_1_to_1_GBs"] > 0
     assert abs(r["frac_of_box_yardstick"] - r["achieved"] / yd["rate_GBs"]) < 1e-3

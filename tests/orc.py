@@ -207,7 +207,7 @@ def unstructured_mesh(nodes, seed=7, kmin=6, kmax=22, cells=16):
             morton |= ((cell[:, d] >> bit) & 1) << (3 * bit + d)
     order = np.lexsort((rng.random(nodes), morton))
     pts = pts[order]
-    _, nb = cKDTree(pts).query(pts, k=kmax + 1)
+    _, nb = cKDTree(pts).query(pts, k=kmax + 1, workers=min(16, os.cpu_count() or 1))      # (the same neighbours whatever the number of workers)
     want = rng.integers(kmin, kmax + 1, nodes)                         # every node asks for its own number of neighbours: ragged rows
     keep = np.arange(1, kmax + 1)[None, :] <= want[:, None]
     src = np.repeat(np.arange(nodes, dtype=np.int64), kmax)[keep.reshape(-1)]
